@@ -1,0 +1,317 @@
+/*
+ * ssgpu.h -- C ABI of the MI355X-native column-block pipeline (libssgpu.so).
+ *
+ * This is the drop-in boundary for Supersonic's Filter -> Project/Compute ->
+ * Aggregate (+Sort) hot path.  The reference has no FFI of its own; its
+ * extension seams are C++ virtual interfaces.  Each entry point below names
+ * the reference interface it stands in for (paths relative to the reference
+ * tree):
+ *
+ *   ssgpu_plan_create      Operation::CreateCursor() + Expression::Bind()
+ *                            supersonic/cursor/base/operation.h:62
+ *                            supersonic/expression/base/expression.cc:84-94
+ *                          (all binding, type promotion, naming and the
+ *                           400-range bind errors happen here)
+ *   ssgpu_plan_attr        Cursor::schema()            cursor/base/cursor.h:135
+ *   ssgpu_plan_run         the Cursor::Next() pull loop drained to the end
+ *                            cursor/base/cursor.h:148
+ *                            cursor/core/aggregate_scalar.cc:53-68
+ *                            cursor/core/filter.cc:96-128
+ *                            cursor/core/aggregate_groups.cc:332-433
+ *                            cursor/core/sort.cc:590-650
+ *                          and BoundExpressionTree::Evaluate over a View
+ *                            expression/base/expression.cc:57-76
+ *   ssgpu_result_*         ResultView / View        cursor/base/cursor.h:42-122
+ *                            base/infrastructure/block.h:288-402
+ *   ssgpu_interrupt        Cursor::Interrupt()   cursor/base/cursor.h:150-186
+ *   ssgpu_block_*          Block / Table (owning column storage)
+ *                            base/infrastructure/block.h:412
+ *                            cursor/infrastructure/table.h:49
+ *   ssgpu_host_alloc/free  BufferAllocator::Allocate / Buffer dtor
+ *                            base/memory/memory.h:100-233
+ *
+ * Conventions
+ *   - plain C, no exceptions cross this boundary, no torch types;
+ *   - every function that can fail returns a reference ReturnCode integer
+ *     (supersonic/proto/supersonic.proto:40-82): 0 = OK, 102 = MEMORY_EXCEEDED,
+ *     103 = NOT_IMPLEMENTED, 104 = EVALUATION_ERROR, 4xx = schema/bind errors,
+ *     1000 = INTERRUPTED.  ssgpu_last_error() returns the message;
+ *   - DataType / Aggregation / ColumnOrder / OperatorId integers are the
+ *     reference's proto enum values (supersonic.proto:15-36,86-101;
+ *     expression/proto/operators.proto);
+ *   - null masks are one byte per row (0 = value present, non-zero = NULL),
+ *     exactly as the reference's bool* is_null (bit_pointers.h:529-533);
+ *   - every *_create has a *_destroy; one ctx/plan is driven by one host
+ *     thread at a time (as the reference); only ssgpu_interrupt is callable
+ *     concurrently;
+ *   - there is NO CPU execution path behind this ABI: running a plan without
+ *     a usable gfx950 device fails with SSGPU_ERROR_NO_DEVICE.
+ */
+#ifndef SSGPU_H_
+#define SSGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSGPU_ABI_VERSION 1
+
+/* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
+enum {
+  SSGPU_INT32 = 1, SSGPU_INT64 = 2, SSGPU_UINT64 = 3, SSGPU_DATETIME = 4,
+  SSGPU_DOUBLE = 5, SSGPU_BOOL = 6, SSGPU_UINT32 = 8, SSGPU_FLOAT = 9,
+  SSGPU_DATE = 10, SSGPU_STRING = 0, SSGPU_BINARY = 7
+};
+enum { SSGPU_NOT_NULLABLE = 0, SSGPU_NULLABLE = 1 };
+enum {
+  SSGPU_SUM = 0, SSGPU_MIN = 1, SSGPU_MAX = 2, SSGPU_COUNT = 3,
+  SSGPU_CONCAT = 4, SSGPU_FIRST = 5, SSGPU_LAST = 6
+};
+enum { SSGPU_ASCENDING = 0, SSGPU_DESCENDING = 1 };
+enum {
+  SSGPU_OK = 0,
+  SSGPU_ERROR_UNKNOWN = 100,
+  SSGPU_ERROR_MEMORY_EXCEEDED = 102,
+  SSGPU_ERROR_NOT_IMPLEMENTED = 103,
+  SSGPU_ERROR_EVALUATION_ERROR = 104,
+  SSGPU_ERROR_TOO_MANY_ROWS = 302,
+  SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH = 401,
+  SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH = 402,
+  SSGPU_ERROR_ATTRIBUTE_MISSING = 403,
+  SSGPU_ERROR_ATTRIBUTE_EXISTS = 404,
+  SSGPU_ERROR_INVALID_ARGUMENT_TYPE = 405,
+  SSGPU_ERROR_INVALID_ARGUMENT_VALUE = 407,
+  SSGPU_ERROR_ATTRIBUTE_AMBIGUOUS = 408,
+  SSGPU_INTERRUPTED = 1000,
+  /* not a reference code: no gfx950 device / HIP runtime failure */
+  SSGPU_ERROR_NO_DEVICE = 2000,
+  SSGPU_ERROR_HIP = 2001
+};
+
+/* ---- opaque handles ----------------------------------------------------- */
+typedef struct ssgpu_ctx ssgpu_ctx;
+typedef struct ssgpu_plan ssgpu_plan;
+typedef struct ssgpu_block ssgpu_block;
+typedef struct ssgpu_result ssgpu_result;
+
+/* ---- schema (TupleSchema / Attribute, tuple_schema.h:77,126) ------------ */
+typedef struct ssgpu_attr {
+  const char* name;
+  int32_t dtype;    /* DataType value */
+  int32_t nullable; /* Nullability value */
+} ssgpu_attr;
+
+/* ---- symbolic expression tree (Expression, expression/base/expression.h) --
+ * Nodes are stored in one array; children are referenced by index and must
+ * precede their parent.  Variable-length child lists live in `expr_args`. */
+enum {
+  SSGPU_EXPR_ATTR_NAMED = 1, /* NamedAttribute(name)  projecting_expressions.h */
+  SSGPU_EXPR_ATTR_AT = 2,    /* AttributeAt(i64)                                */
+  SSGPU_EXPR_CONST = 3,      /* ConstInt64(..) etc: dtype + i64/f64 payload     */
+  SSGPU_EXPR_NULL = 4,       /* Null(dtype)                                     */
+  SSGPU_EXPR_OP = 5,         /* operator `op` (OperatorId) over children        */
+  SSGPU_EXPR_ALIAS = 6,      /* Alias(name, child)                              */
+  SSGPU_EXPR_COMPOUND = 7,   /* CompoundExpression: children (+ALIAS children)  */
+  SSGPU_EXPR_CAST = 8        /* CastTo(dtype, child) (explicit, quiet)          */
+};
+/* Operators that are not a single OperatorId in the reference but are public
+ * factory functions (comparison_expressions.h): expressed with these pseudo
+ * ids; the binder rewrites them exactly as the reference does
+ * (comparison_bound_expressions.cc:832-848: a > b  ==  Less(b, a)). */
+enum { SSGPU_OP_GREATER = 100001, SSGPU_OP_GREATER_OR_EQUAL = 100002 };
+
+typedef struct ssgpu_expr {
+  int32_t kind;      /* SSGPU_EXPR_* */
+  int32_t op;        /* OperatorId for SSGPU_EXPR_OP */
+  int32_t dtype;     /* CONST / NULL / CAST target type */
+  int32_t first_arg; /* index into expr_args */
+  int32_t nargs;
+  int32_t reserved;
+  int64_t i64;       /* integer / bool / date payload, or attribute position */
+  double f64;        /* FLOAT / DOUBLE payload */
+  const char* name;  /* attribute name or alias */
+} ssgpu_expr;
+
+/* ---- projector (SingleSourceProjector, base/infrastructure/projector.h) - */
+enum {
+  SSGPU_PROJ_ALL = 1,      /* ProjectAllAttributes()            */
+  SSGPU_PROJ_NAMED = 2,    /* ProjectNamedAttribute(name)       */
+  SSGPU_PROJ_AT = 3,       /* ProjectAttributeAt(position)      */
+  SSGPU_PROJ_NAMED_AS = 4  /* ProjectNamedAttributeAs(name,alias) */
+};
+typedef struct ssgpu_proj {
+  int32_t kind;
+  int32_t position;
+  const char* name;
+  const char* alias;
+} ssgpu_proj;
+
+/* ---- AggregationSpecification::Element (cursor/core/aggregate.h:28-80) -- */
+typedef struct ssgpu_agg {
+  int32_t aggregation; /* Aggregation value */
+  int32_t distinct;    /* 0/1 */
+  int32_t output_type; /* DataType, or -1 when not specified */
+  int32_t reserved;
+  const char* input;   /* "" for COUNT(*) */
+  const char* output;
+} ssgpu_agg;
+
+/* ---- SortOrder element (cursor/infrastructure/ordering.h:48-101) -------- */
+typedef struct ssgpu_sortkey {
+  const char* name;
+  int32_t order; /* ColumnOrder value */
+  int32_t reserved;
+} ssgpu_sortkey;
+
+/* ---- operation tree (Operation factories, supersonic/supersonic.h) ------ */
+enum {
+  SSGPU_OP_SCAN = 1,               /* ScanView(view)            scan_view.h   */
+  SSGPU_OP_COMPUTE = 2,            /* Compute(expr, child)      compute.h     */
+  SSGPU_OP_FILTER = 3,             /* Filter(pred, proj, child) filter.h      */
+  SSGPU_OP_PROJECT = 4,            /* Project(proj, child)      project.h     */
+  SSGPU_OP_SCALAR_AGGREGATE = 5,   /* ScalarAggregate(spec, child) aggregate.h:341 */
+  SSGPU_OP_GROUP_AGGREGATE = 6,    /* GroupAggregate(keys, spec, opts, child) aggregate.h:224 */
+  SSGPU_OP_AGGREGATE_CLUSTERS = 7, /* AggregateClusters(keys, spec, child) aggregate.h:285 */
+  SSGPU_OP_SORT = 8                /* Sort(order, proj, mem_limit, child) sort.h:83 */
+};
+typedef struct ssgpu_op {
+  int32_t kind;       /* SSGPU_OP_* */
+  int32_t child;      /* index of the child op (must precede), -1 for SCAN */
+  int32_t expr;       /* COMPUTE: expression root; FILTER: predicate; else -1 */
+  int32_t proj_first; /* FILTER/PROJECT/SORT: result projector;               */
+  int32_t proj_n;     /*   GROUP_AGGREGATE/AGGREGATE_CLUSTERS: key projector   */
+  int32_t agg_first;
+  int32_t agg_n;
+  int32_t sort_first;
+  int32_t sort_n;
+  int32_t reserved;
+  int64_t option0;    /* GROUP: max_unique_keys_in_result (0 = unlimited);
+                         SORT: memory limit (ignored: no spill path)          */
+} ssgpu_op;
+
+typedef struct ssgpu_plan_desc {
+  const ssgpu_attr* input_schema; /* schema of the scanned View/Block */
+  int32_t n_attrs;
+  const ssgpu_op* ops;
+  int32_t n_ops;                  /* root = ops[n_ops-1] */
+  const ssgpu_expr* exprs;
+  int32_t n_exprs;
+  const int32_t* expr_args;
+  int32_t n_expr_args;
+  const ssgpu_proj* projs;
+  int32_t n_projs;
+  const ssgpu_agg* aggs;
+  int32_t n_aggs;
+  const ssgpu_sortkey* sortkeys;
+  int32_t n_sortkeys;
+} ssgpu_plan_desc;
+
+/* ---- a column of a View (base/infrastructure/block.h:55-192) ------------ */
+typedef struct ssgpu_column {
+  const void* data;       /* DEVICE pointer to rows * sizeof(type) bytes     */
+  const uint8_t* is_null; /* DEVICE pointer to `rows` bytes, or NULL          */
+} ssgpu_column;
+
+/* ---- context ------------------------------------------------------------ */
+/* device_id >= 0: bind that HIP device.  device_id == -1: bind-only context
+ * (plans can be created/inspected, running fails with SSGPU_ERROR_NO_DEVICE);
+ * this is what lets schema/bind errors be tested on a machine without a GPU. */
+int ssgpu_ctx_create(int device_id, ssgpu_ctx** out);
+void ssgpu_ctx_destroy(ssgpu_ctx* ctx);
+const char* ssgpu_last_error(const ssgpu_ctx* ctx);
+int ssgpu_abi_version(void);
+/* The HIP stream (hipStream_t) all kernels of this ctx are launched on, and
+ * the side stream used for host<->device staging of blocks. */
+void* ssgpu_ctx_stream(ssgpu_ctx* ctx);
+void* ssgpu_ctx_copy_stream(ssgpu_ctx* ctx);
+/* Use a caller-owned stream (e.g. torch's current stream) for kernels. */
+int ssgpu_ctx_set_stream(ssgpu_ctx* ctx, void* hip_stream);
+int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
+/* Tuning knobs (0 = library default).  tile_rows must be a multiple of 512. */
+int ssgpu_ctx_set_option(ssgpu_ctx* ctx, const char* key, int64_t value);
+
+/* ---- pinned host memory (BufferAllocator seam, memory.h:100-233) -------- */
+int ssgpu_host_alloc(ssgpu_ctx* ctx, size_t bytes, void** out);
+void ssgpu_host_free(ssgpu_ctx* ctx, void* p);
+
+/* ---- device-resident Block ----------------------------------------------- */
+int ssgpu_block_create(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs,
+                       int64_t row_capacity, ssgpu_block** out);
+void ssgpu_block_destroy(ssgpu_block* b);
+/* Async H2D on the copy stream; `is_null` may be NULL for NOT_NULLABLE columns.
+ * Source should be pinned (ssgpu_host_alloc) for the copy to overlap. */
+int ssgpu_block_upload(ssgpu_block* b, int32_t col, const void* host_data,
+                       const uint8_t* host_is_null, int64_t row_offset, int64_t rows);
+int ssgpu_block_set_row_count(ssgpu_block* b, int64_t rows);
+int64_t ssgpu_block_row_count(const ssgpu_block* b);
+/* Device pointers of column `col` (valid while the block lives). */
+int ssgpu_block_column(const ssgpu_block* b, int32_t col, ssgpu_column* out);
+
+/* ---- plan: bind + lower --------------------------------------------------- */
+int ssgpu_plan_create(ssgpu_ctx* ctx, const ssgpu_plan_desc* desc, ssgpu_plan** out);
+void ssgpu_plan_destroy(ssgpu_plan* plan);
+int32_t ssgpu_plan_attr_count(const ssgpu_plan* plan);
+int ssgpu_plan_attr(const ssgpu_plan* plan, int32_t i, ssgpu_attr* out);
+/* Human-readable bound tree + lowered pipeline stages + VM disassembly. */
+const char* ssgpu_plan_describe(ssgpu_plan* plan);
+/* Debug/test hook: raw VM program of pipeline stage `stage` (see csrc/vm.h). */
+int ssgpu_plan_program(const ssgpu_plan* plan, int32_t stage, const void** instrs,
+                       int32_t* n_instrs, int32_t* instr_bytes);
+
+/* ---- run ------------------------------------------------------------------ */
+/* cols: one entry per attribute of the plan's input schema, DEVICE pointers. */
+int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
+                   int64_t rows, ssgpu_result** out);
+int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);
+/* Thread-safe, non-blocking; the running/next run returns SSGPU_INTERRUPTED. */
+void ssgpu_interrupt(ssgpu_plan* plan);
+
+/* Multi-GPU partial aggregates (row-range shards).  For plans
+ * whose root is a ScalarAggregate (or a dense-slot GroupAggregate) the run can
+ * stop before finalisation and expose element-wise reducible partial buffers.
+ * Segment `i` is `count` elements of `dtype` to be combined across ranks with
+ * `reduce` (0 = sum, 1 = min, 2 = max); the caller all-reduces each segment in
+ * place (RCCL) and then calls ssgpu_plan_finalize. */
+typedef struct ssgpu_partial_segment {
+  void* device_ptr;
+  int64_t count;
+  int32_t dtype;  /* SSGPU_INT64 / SSGPU_UINT64 / SSGPU_DOUBLE */
+  int32_t reduce; /* 0 sum, 1 min, 2 max */
+} ssgpu_partial_segment;
+int ssgpu_plan_run_partial(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
+                           int64_t rows, int64_t global_row_offset);
+int32_t ssgpu_plan_partial_segments(ssgpu_plan* plan, ssgpu_partial_segment* out,
+                                    int32_t max_segments);
+int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
+
+/* ---- result (ResultView / View) ------------------------------------------- */
+void ssgpu_result_destroy(ssgpu_result* r);
+int64_t ssgpu_result_row_count(ssgpu_result* r);
+int32_t ssgpu_result_column_count(const ssgpu_result* r);
+/* Host view of column i (pinned memory owned by the result; D2H on first use). */
+int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data,
+                        const uint8_t** is_null);
+/* Device view of column i (no copy). */
+int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out);
+
+/* ---- counters (profiling seam: CursorStatistics, benchmark/) -------------- */
+typedef struct ssgpu_counters {
+  double kernel_ms;        /* HIP-event time of all kernels of the last run   */
+  double dominant_ms;      /* HIP-event time of the dominant (pipeline) kernel */
+  int64_t rows_in;
+  int64_t rows_out;
+  int64_t algorithmic_bytes; /* bytes the plan must move through HBM once     */
+  int32_t n_launches;
+  int32_t tile_rows;
+  int32_t grid;
+  int32_t lds_bytes;
+} ssgpu_counters;
+int ssgpu_plan_counters(ssgpu_plan* plan, ssgpu_counters* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSGPU_H_ */

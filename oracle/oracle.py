@@ -1,0 +1,188 @@
+"""ctypes driver of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() as the checker.  It duck-types the plain description
+objects of supersonic_amd.api (Expression / Operation trees) so one tree can be
+evaluated by the HIP path and by the oracle; it shares no execution code with
+the product.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_NP = {1: np.int32, 2: np.int64, 8: np.uint32, 3: np.uint64, 9: np.float32, 5: np.float64, 6: np.bool_,
+       10: np.int32, 4: np.int64}
+
+KIND = {"ScanView": 1, "Compute": 2, "Filter": 3, "Project": 4, "ScalarAggregate": 5, "GroupAggregate": 6,
+        "AggregateClusters": 7, "Sort": 8}
+
+
+class OracleError(Exception):
+    def __init__(self, return_code, message):
+        Exception.__init__(self, "[%d] %s" % (return_code, message))
+        self.return_code = return_code
+        self.message = message
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        P = C.c_void_p
+        L.orc_expr_new.restype = P
+        L.orc_expr_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_char_p]
+        L.orc_expr_add_arg.argtypes = [P, P]
+        L.orc_op_new.restype = P
+        L.orc_op_new.argtypes = [C.c_int, P, P]
+        L.orc_op_add_proj.argtypes = [P, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        L.orc_op_add_agg.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        L.orc_op_add_sortkey.argtypes = [P, C.c_char_p, C.c_int]
+        L.orc_scan_add_column.argtypes = [P, C.c_char_p, C.c_int, C.c_int, P, P]
+        L.orc_scan_set_rows.argtypes = [P, C.c_int64]
+        L.orc_create_cursor.restype = P
+        L.orc_create_cursor.argtypes = [P]
+        L.orc_cursor_error.restype = C.c_int
+        L.orc_cursor_error.argtypes = [P, C.c_char_p, C.c_int]
+        L.orc_cursor_ncols.restype = C.c_int
+        L.orc_cursor_ncols.argtypes = [P]
+        L.orc_cursor_col_name.restype = C.c_char_p
+        L.orc_cursor_col_name.argtypes = [P, C.c_int]
+        L.orc_cursor_col_type.restype = C.c_int
+        L.orc_cursor_col_type.argtypes = [P, C.c_int]
+        L.orc_cursor_col_nullable.restype = C.c_int
+        L.orc_cursor_col_nullable.argtypes = [P, C.c_int]
+        L.orc_next.restype = C.c_int
+        L.orc_next.argtypes = [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(P), C.POINTER(P)]
+        L.orc_drain.restype = C.c_int64
+        L.orc_drain.argtypes = [P]
+        _LIB = L
+    return _LIB
+
+
+def _enc(s):
+    return None if s is None else (s.encode() if isinstance(s, str) else s)
+
+
+class _Tree(object):
+    def __init__(self):
+        self.keep = []
+
+    def expr(self, e):
+        L = lib()
+        h = L.orc_expr_new(e.kind, e.op, e.dtype, int(e.i64), float(e.f64), _enc(e.name))
+        for a in e.args:
+            L.orc_expr_add_arg(h, self.expr(a))
+        return h
+
+    def op(self, o):
+        L = lib()
+        kind = KIND[type(o).__name__]
+        if kind == 1:
+            h = L.orc_op_new(1, None, None)
+            v = o.view
+            schema = v.schema()
+            for i in range(schema.attribute_count()):
+                a = schema.attribute(i)
+                col = v.column(i)
+                data = np.ascontiguousarray(col.data)
+                nulls = None if col.is_null is None else np.ascontiguousarray(col.is_null).view(np.uint8)
+                self.keep += [data, nulls]
+                L.orc_scan_add_column(h, _enc(a.name()), a.type(), a.nullability(), data.ctypes.data_as(C.c_void_p),
+                                      None if nulls is None else nulls.ctypes.data_as(C.c_void_p))
+            L.orc_scan_set_rows(h, v.row_count())
+            return h
+        child = self.op(o.child)
+        expr = None
+        if kind == 2:
+            expr = self.expr(o.expression)
+        elif kind == 3:
+            expr = self.expr(o.predicate)
+        h = L.orc_op_new(kind, child, expr)
+        proj = getattr(o, "projector", None) if kind in (3, 4, 8) else getattr(o, "group_by", None)
+        if kind == 8 and proj is None:
+            L.orc_op_add_proj(h, 1, 0, None, None)
+        elif proj is not None:
+            for (k, pos, name, alias) in proj.entries:
+                L.orc_op_add_proj(h, k, pos, _enc(name), _enc(alias))
+        spec = getattr(o, "spec", None)
+        if spec is not None:
+            for (agg, distinct, otype, inp, outp) in spec.elements:
+                L.orc_op_add_agg(h, agg, distinct, otype, _enc(inp), _enc(outp))
+        if kind == 8:
+            for (name, order) in o.order.keys:
+                L.orc_op_add_sortkey(h, _enc(name), order)
+        return h
+
+
+class Cursor(object):
+    def __init__(self, operation):
+        self.tree = _Tree()
+        self.handle = lib().orc_create_cursor(self.tree.op(operation))
+        buf = C.create_string_buffer(600)
+        code = lib().orc_cursor_error(self.handle, buf, 600)
+        if code:
+            raise OracleError(code, buf.value.decode())
+        L = lib()
+        n = L.orc_cursor_ncols(self.handle)
+        self.schema = [(L.orc_cursor_col_name(self.handle, i).decode(), L.orc_cursor_col_type(self.handle, i),
+                        L.orc_cursor_col_nullable(self.handle, i)) for i in range(n)]
+
+    def next(self, max_rows=1024):
+        """-> list of (data, is_null|None) per column, or None at end of stream."""
+        L = lib()
+        n = len(self.schema)
+        rows = C.c_int64()
+        data = (C.c_void_p * max(n, 1))()
+        nulls = (C.c_void_p * max(n, 1))()
+        r = L.orc_next(self.handle, max_rows, C.byref(rows), data, nulls)
+        if r < 0:
+            buf = C.create_string_buffer(600)
+            code = L.orc_cursor_error(self.handle, buf, 600)
+            raise OracleError(code, buf.value.decode())
+        if r == 0:
+            return None
+        out = []
+        for i, (_name, t, _nullable) in enumerate(self.schema):
+            dt = np.dtype(_NP[t])
+            d = np.frombuffer(C.string_at(data[i], rows.value * dt.itemsize), dtype=dt).copy()
+            z = None
+            if nulls[i]:
+                z = np.frombuffer(C.string_at(nulls[i], rows.value), dtype=np.uint8).copy() != 0
+            out.append((d, z))
+        return out
+
+    def drain_discard(self):
+        return lib().orc_drain(self.handle)
+
+
+def run(operation, max_rows=1024):
+    """Evaluate an operation tree on the CPU: (schema, [(data, is_null|None), ...])."""
+    cur = Cursor(operation)
+    parts = []
+    while True:
+        p = cur.next(max_rows)
+        if p is None:
+            break
+        parts.append(p)
+    cols = []
+    for i, (_n, t, nullable) in enumerate(cur.schema):
+        dt = np.dtype(_NP[t])
+        d = np.concatenate([p[i][0] for p in parts]) if parts else np.zeros(0, dt)
+        z = None
+        if nullable:
+            z = np.concatenate([(p[i][1] if p[i][1] is not None else np.zeros(len(p[i][0]), bool)) for p in parts]) \
+                if parts else np.zeros(0, bool)
+        cols.append((d, z))
+    return cur.schema, cols

@@ -1,0 +1,1122 @@
+/*
+ * ss_oracle.c -- CPU restatement of Supersonic's Filter -> Project/Compute ->
+ * Aggregate (+Sort) path, in plain C.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it; the product path
+ * (libssgpu.so) never links, calls or falls back to anything in oracle/.
+ *
+ * It restates the reference's algorithms the way the reference executes them
+ * ("reference mode"): a pull model over <=1024-row blocks, materialised
+ * intermediate columns per expression node, an int64 row-id list + gather for
+ * Filter, one pass per aggregate column, a chained-bucket hash set for
+ * GroupAggregate that emits groups in first-seen order, and a comparison sort
+ * of an int64 permutation for Sort.  Every function cites the reference
+ * file:line it follows (paths relative to the reference tree).
+ *
+ * Pinning: the reference itself cannot be built in this image without writing
+ * stand-ins for glog/gflags/protobuf/boost, so the oracle is
+ * pinned against the golden vectors of the reference's own tests, transcribed
+ * as data under tests/golden/ (tests/test_oracle_golden.py).
+ *
+ * Build: gcc -O3 -msse2 -funsigned-char -shared -fPIC (the reference's flags,
+ * configure.ac:36-40).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_BLOCK 1024 /* Cursor::kDefaultRowCount, cursor/base/cursor.h:133 */
+
+/* DataType values, supersonic/proto/supersonic.proto:15-36 */
+enum { T_INT32 = 1, T_INT64 = 2, T_UINT64 = 3, T_DATETIME = 4, T_DOUBLE = 5, T_BOOL = 6,
+       T_UINT32 = 8, T_FLOAT = 9, T_DATE = 10, T_STRING = 0, T_BINARY = 7 };
+/* Aggregation values, supersonic.proto:86-94 */
+enum { A_SUM = 0, A_MIN = 1, A_MAX = 2, A_COUNT = 3, A_CONCAT = 4, A_FIRST = 5, A_LAST = 6 };
+/* ReturnCode values, supersonic.proto:40-82 */
+enum { RC_OK = 0, RC_NOT_IMPLEMENTED = 103, RC_EVALUATION_ERROR = 104, RC_COUNT_MISMATCH = 401,
+       RC_TYPE_MISMATCH = 402, RC_ATTRIBUTE_MISSING = 403, RC_ATTRIBUTE_EXISTS = 404,
+       RC_INVALID_ARGUMENT_TYPE = 405 };
+/* OperatorId values, supersonic/expression/proto/operators.proto */
+enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DIVIDE_NULLING = 14,
+       OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
+       OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36, OP_AND = 40, OP_OR = 44,
+       OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116,
+       OP_LESS_OR_EQUAL = 120, OP_IF = 204, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
+       OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002 };
+
+typedef struct { int code; char msg[512]; } orc_error;
+static void set_err(orc_error* e, int code, const char* fmt, const char* a, const char* b) {
+  if (!e || e->code) return;
+  e->code = code;
+  snprintf(e->msg, sizeof(e->msg), fmt, a ? a : "", b ? b : "");
+}
+
+static const char* type_name(int t) {
+  switch (t) {
+    case T_INT32: return "INT32"; case T_INT64: return "INT64"; case T_UINT32: return "UINT32";
+    case T_UINT64: return "UINT64"; case T_FLOAT: return "FLOAT"; case T_DOUBLE: return "DOUBLE";
+    case T_BOOL: return "BOOL"; case T_DATE: return "DATE"; case T_DATETIME: return "DATETIME";
+    case T_STRING: return "STRING"; case T_BINARY: return "BINARY";
+  }
+  return "?";
+}
+static int type_width(int t) {
+  switch (t) {
+    case T_INT32: case T_UINT32: case T_FLOAT: case T_DATE: return 4;
+    case T_INT64: case T_UINT64: case T_DOUBLE: case T_DATETIME: return 8;
+    case T_BOOL: return 1;
+  }
+  return 0;
+}
+static int is_integer(int t) { return t == T_INT32 || t == T_INT64 || t == T_UINT32 || t == T_UINT64; }
+static int is_float(int t) { return t == T_FLOAT || t == T_DOUBLE; }
+static int is_numeric(int t) { return is_integer(t) || is_float(t); }
+
+/* ---- schema / views (base/infrastructure/tuple_schema.h:77,126; block.h:288) ---- */
+#define ORC_MAX_COLS 64
+typedef struct { char name[256]; int type; int nullable; } orc_attr;
+typedef struct { int n; orc_attr a[ORC_MAX_COLS]; } orc_schema;
+typedef struct { const void* data; const uint8_t* is_null; } orc_col; /* is_null NULL => no NULLs */
+typedef struct { int n; int64_t rows; orc_col c[ORC_MAX_COLS]; } orc_view;
+
+static int schema_lookup(const orc_schema* s, const char* name) {
+  for (int i = 0; i < s->n; ++i) if (strcmp(s->a[i].name, name) == 0) return i;
+  return -1;
+}
+static int schema_add(orc_schema* s, const char* name, int type, int nullable) {
+  if (schema_lookup(s, name) >= 0 || s->n >= ORC_MAX_COLS) return 0;
+  snprintf(s->a[s->n].name, sizeof(s->a[s->n].name), "%s", name);
+  s->a[s->n].type = type; s->a[s->n].nullable = nullable; s->n++;
+  return 1;
+}
+
+/* =========================== expressions ====================================== */
+enum { E_NAMED = 1, E_AT = 2, E_CONST = 3, E_NULL = 4, E_OP = 5, E_ALIAS = 6, E_COMPOUND = 7, E_CAST = 8 };
+typedef struct orc_expr {
+  int kind, op, dtype, nargs;
+  struct orc_expr* args[16];
+  int64_t i64; double f64;
+  char name[256];
+} orc_expr;
+
+orc_expr* orc_expr_new(int kind, int op, int dtype, int64_t i64, double f64, const char* name) {
+  orc_expr* e = (orc_expr*)calloc(1, sizeof(orc_expr));
+  e->kind = kind; e->op = op; e->dtype = dtype; e->i64 = i64; e->f64 = f64;
+  if (name) snprintf(e->name, sizeof(e->name), "%s", name);
+  return e;
+}
+void orc_expr_add_arg(orc_expr* e, orc_expr* a) { if (e->nargs < 16) e->args[e->nargs++] = a; }
+
+/* bound node: typed, owns a 1024-row result block
+ * (BasicBoundExpression, expression/infrastructure/basic_bound_expression.h:49) */
+enum { B_INPUT, B_CONST, B_NULLCONST, B_OP, B_CAST };
+typedef struct bnode {
+  int kind, op, dtype, nullable, input_col, nargs;
+  struct bnode* args[3];
+  uint64_t bits;
+  char name[256];
+  void* buf;          /* result data, ORC_BLOCK rows */
+  uint8_t* nullbuf;   /* result is_null, ORC_BLOCK rows */
+  const void* data;   /* evaluation result for the current block */
+  const uint8_t* nulls;
+} bnode;
+
+static bnode* bnode_new(int kind, int op, int dtype, int nullable, const char* name) {
+  bnode* b = (bnode*)calloc(1, sizeof(bnode));
+  b->kind = kind; b->op = op; b->dtype = dtype; b->nullable = nullable;
+  snprintf(b->name, sizeof(b->name), "%s", name ? name : "");
+  b->buf = calloc(ORC_BLOCK, 8);
+  b->nullbuf = (uint8_t*)calloc(ORC_BLOCK, 1);
+  return b;
+}
+
+static uint64_t const_bits(int dtype, int64_t i64, double f64) {
+  uint64_t b = 0;
+  switch (dtype) {
+    case T_INT32: case T_DATE: { int32_t v = (int32_t)i64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
+    case T_UINT32: b = (uint32_t)i64; break;
+    case T_INT64: case T_DATETIME: case T_UINT64: memcpy(&b, &i64, 8); break;
+    case T_FLOAT: { float v = (float)f64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
+    case T_DOUBLE: memcpy(&b, &f64, 8); break;
+    case T_BOOL: b = i64 != 0; break;
+  }
+  return b;
+}
+
+/* BoundConstExpression names "CONST_<TYPE>", NOT_NULLABLE
+ * (expression/infrastructure/elementary_bound_const_expressions.h:36-41);
+ * BoundNullExpression is named "NULL", NULLABLE (terminal_bound_expressions.cc:142) */
+static bnode* make_const(int dtype, uint64_t bits) {
+  char nm[64]; snprintf(nm, sizeof(nm), "CONST_%s", type_name(dtype));
+  bnode* b = bnode_new(B_CONST, 0, dtype, 0, nm); b->bits = bits; return b;
+}
+static bnode* make_null(int dtype) { return bnode_new(B_NULLCONST, 0, dtype, 1, "NULL"); }
+
+/* ---- vector primitives: the inner loops
+ * (expression/vector/vector_primitives.h:99-105,393-412; functors operators.h:68-296) ---- */
+#define LOOP2(TA, TB, TD, EXPR) { const TA* pa = (const TA*)A; const TB* pb = (const TB*)B; TD* pd = (TD*)D; \
+  for (int64_t i = 0; i < n; ++i) { TA a = pa[i]; TB b = pb[i]; pd[i] = (TD)(EXPR); } }
+#define LOOP1(TA, TD, EXPR) { const TA* pa = (const TA*)A; TD* pd = (TD*)D; \
+  for (int64_t i = 0; i < n; ++i) { TA a = pa[i]; pd[i] = (TD)(EXPR); } }
+
+static int arith_kind(int t) { /* 0:i32 1:u32 2:i64 3:u64 4:f32 5:f64 6:bool */
+  switch (t) { case T_INT32: case T_DATE: return 0; case T_UINT32: return 1; case T_INT64: case T_DATETIME: return 2;
+               case T_UINT64: return 3; case T_FLOAT: return 4; case T_DOUBLE: return 5; case T_BOOL: return 6; }
+  return -1;
+}
+
+/* D = A op B, both operands already of type t (after promotion) */
+static int eval_binary(int op, int t, const void* A, const void* B, void* D, int64_t n) {
+  const int k = arith_kind(t);
+  switch (op) {
+#define ARITH(OPID, EXPR) case OPID: switch (k) { \
+      case 0: case 1: LOOP2(uint32_t, uint32_t, uint32_t, EXPR) return 1; \
+      case 2: case 3: LOOP2(uint64_t, uint64_t, uint64_t, EXPR) return 1; \
+      case 4: LOOP2(float, float, float, EXPR) return 1; \
+      case 5: LOOP2(double, double, double, EXPR) return 1; } return 0;
+    ARITH(OP_ADD, a + b)       /* integer + - * wrap (operators.h:68-81) */
+    ARITH(OP_SUBTRACT, a - b)
+    ARITH(OP_MULTIPLY, a * b)
+    case OP_DIVIDE_QUIET: case OP_DIVIDE_NULLING: case OP_DIVIDE_SIGNALING:
+      if (k == 5) { LOOP2(double, double, double, a / b) return 1; }
+      if (k == 4) { LOOP2(float, float, float, a / b) return 1; }
+      return 0;
+    case OP_CPP_DIVIDE_NULLING: case OP_CPP_DIVIDE_SIGNALING:
+      switch (k) {
+        case 0: LOOP2(int32_t, int32_t, int32_t, (b == 0 ? 0 : (b == -1 ? (int32_t)(0u - (uint32_t)a) : a / b))) return 1;
+        case 1: LOOP2(uint32_t, uint32_t, uint32_t, (b == 0 ? 0 : a / b)) return 1;
+        case 2: LOOP2(int64_t, int64_t, int64_t, (b == 0 ? 0 : (b == -1 ? (int64_t)(0ull - (uint64_t)a) : a / b))) return 1;
+        case 3: LOOP2(uint64_t, uint64_t, uint64_t, (b == 0 ? 0 : a / b)) return 1;
+        case 4: LOOP2(float, float, float, a / b) return 1;
+        case 5: LOOP2(double, double, double, a / b) return 1;
+      } return 0;
+    case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING:
+      switch (k) {
+        case 0: LOOP2(int32_t, int32_t, int32_t, (b == 0 || b == -1 ? 0 : a % b)) return 1;
+        case 1: LOOP2(uint32_t, uint32_t, uint32_t, (b == 0 ? 0 : a % b)) return 1;
+        case 2: LOOP2(int64_t, int64_t, int64_t, (b == 0 || b == -1 ? 0 : a % b)) return 1;
+        case 3: LOOP2(uint64_t, uint64_t, uint64_t, (b == 0 ? 0 : a % b)) return 1;
+      } return 0;
+#define CMP(OPID, EXPR) case OPID: switch (k) { \
+      case 0: LOOP2(int32_t, int32_t, uint8_t, EXPR) return 1; case 1: LOOP2(uint32_t, uint32_t, uint8_t, EXPR) return 1; \
+      case 2: LOOP2(int64_t, int64_t, uint8_t, EXPR) return 1; case 3: LOOP2(uint64_t, uint64_t, uint8_t, EXPR) return 1; \
+      case 4: LOOP2(float, float, uint8_t, EXPR) return 1; case 5: LOOP2(double, double, uint8_t, EXPR) return 1; \
+      case 6: LOOP2(uint8_t, uint8_t, uint8_t, EXPR) return 1; } return 0;
+    CMP(OP_LESS, a < b)
+    CMP(OP_LESS_OR_EQUAL, a <= b)
+    CMP(OP_EQUAL, a == b)
+    CMP(OP_NOT_EQUAL, a != b)
+    case OP_XOR: LOOP2(uint8_t, uint8_t, uint8_t, ((a != 0) != (b != 0))) return 1;
+  }
+  return 0;
+}
+
+/* comparisons of two DIFFERENT integer types are not cast: the functors are
+ * value-correct for mixed signedness (operators.h:189-214,243-268) */
+static int64_t load_signed(int t, const void* p, int64_t i, int* is_big_unsigned, uint64_t* u) {
+  *is_big_unsigned = 0;
+  switch (arith_kind(t)) {
+    case 0: return ((const int32_t*)p)[i];
+    case 1: return ((const uint32_t*)p)[i];
+    case 2: return ((const int64_t*)p)[i];
+    case 3: *u = ((const uint64_t*)p)[i]; if (*u > (uint64_t)INT64_MAX) { *is_big_unsigned = 1; return 0; } return (int64_t)*u;
+  }
+  return 0;
+}
+static void eval_mixed_int_compare(int op, int ta, const void* A, int tb, const void* B, uint8_t* D, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    int ba, bb; uint64_t ua = 0, ub = 0;
+    int64_t a = load_signed(ta, A, i, &ba, &ua), b = load_signed(tb, B, i, &bb, &ub);
+    int lt, eq;
+    if (ba && bb) { lt = ua < ub; eq = ua == ub; }
+    else if (ba) { lt = 0; eq = 0; }      /* a > INT64_MAX >= b */
+    else if (bb) { lt = 1; eq = 0; }
+    else { lt = a < b; eq = a == b; }
+    D[i] = op == OP_LESS ? lt : op == OP_LESS_OR_EQUAL ? (lt || eq) : op == OP_EQUAL ? eq : !eq;
+  }
+}
+
+static int eval_cast(int from, int to, const void* A, void* D, int64_t n) {
+  const int kf = arith_kind(from), kt = arith_kind(to);
+  if (kf < 0 || kt < 0) return 0;
+#define CASTROW(TA) switch (kt) { \
+    case 0: LOOP1(TA, int32_t, a) return 1; case 1: LOOP1(TA, uint32_t, a) return 1; \
+    case 2: LOOP1(TA, int64_t, a) return 1; case 3: LOOP1(TA, uint64_t, a) return 1; \
+    case 4: LOOP1(TA, float, a) return 1; case 5: LOOP1(TA, double, a) return 1; } return 0;
+  switch (kf) {
+    case 0: CASTROW(int32_t) case 1: CASTROW(uint32_t) case 2: CASTROW(int64_t)
+    case 3: CASTROW(uint64_t) case 4: CASTROW(float) case 5: CASTROW(double)
+  }
+  return 0;
+}
+
+/* ---- binding ---------------------------------------------------------------------- */
+/* CommonTypeCalculator, expression/templated/bound_expression_factory.cc:67-107 */
+static int common_type(int t1, int t2, orc_error* err) {
+  if (t1 == t2) return t1;
+  static const int tab[][3] = {
+      {T_DOUBLE, T_INT32, T_DOUBLE}, {T_DOUBLE, T_INT64, T_DOUBLE}, {T_DOUBLE, T_UINT32, T_DOUBLE},
+      {T_DOUBLE, T_UINT64, T_DOUBLE}, {T_DOUBLE, T_FLOAT, T_DOUBLE}, {T_FLOAT, T_INT32, T_FLOAT},
+      {T_FLOAT, T_UINT32, T_FLOAT}, {T_FLOAT, T_UINT64, T_DOUBLE}, {T_FLOAT, T_INT64, T_DOUBLE},
+      {T_INT64, T_INT32, T_INT64}, {T_INT64, T_UINT32, T_INT64}, {T_INT64, T_UINT64, T_INT64},
+      {T_UINT64, T_INT32, T_INT64}, {T_UINT64, T_UINT32, T_UINT64}, {T_UINT32, T_INT32, T_INT64},
+      {T_DATE, T_DATETIME, T_DATETIME}};
+  for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); ++i)
+    if ((tab[i][0] == t1 && tab[i][1] == t2) || (tab[i][0] == t2 && tab[i][1] == t1)) return tab[i][2];
+  set_err(err, RC_TYPE_MISMATCH, "Cannot reconcile types: %s and %s.", type_name(t1), type_name(t2));
+  return -1;
+}
+
+static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err);
+static int all_const(bnode* b) {
+  for (int i = 0; i < b->nargs; ++i) if (b->args[i]->kind != B_CONST && b->args[i]->kind != B_NULLCONST) return 0;
+  return b->nargs > 0;
+}
+/* InitBasicExpression: an expression with only constant children is evaluated once
+ * (for one row) and replaced by the constant
+ * (expression/infrastructure/basic_bound_expression.cc:57-92) */
+static bnode* fold(bnode* b, orc_error* err) {
+  if ((b->kind != B_OP && b->kind != B_CAST) || !all_const(b)) return b;
+  orc_view dummy; memset(&dummy, 0, sizeof(dummy)); dummy.rows = 1;
+  orc_error local; memset(&local, 0, sizeof(local));
+  eval_node(b, &dummy, 1, &local);
+  if (local.code) { if (err && !err->code) *err = local; return b; }
+  if (b->nulls && b->nulls[0]) return make_null(b->dtype);
+  uint64_t bits = 0; memcpy(&bits, b->data, (size_t)type_width(b->dtype));
+  return make_const(b->dtype, bits);
+}
+
+/* BoundInternalCast (expression/templated/cast_bound_expression.cc:285-470):
+ * result name "CAST_<FROM>_TO_<TO>(child)"; implicit downcasts and float->int are
+ * bind errors (ERROR_ATTRIBUTE_TYPE_MISMATCH). */
+static bnode* make_cast(bnode* child, int to, int is_implicit, orc_error* err) {
+  const int from = child->dtype;
+  if (from == to) return child;
+  if (!is_numeric(from) || !is_numeric(to)) { set_err(err, RC_TYPE_MISMATCH, "Cannot cast %s to %s.", type_name(from), type_name(to)); return child; }
+  if (is_float(from) && is_integer(to)) { set_err(err, RC_TYPE_MISMATCH, "Cannot cast %s to %s (floating to integer).", type_name(from), type_name(to)); return child; }
+  int down = ((from == T_INT64 || from == T_UINT64) && (to == T_INT32 || to == T_UINT32 || to == T_FLOAT)) || (from == T_DOUBLE && to == T_FLOAT);
+  if (down && is_implicit) { set_err(err, RC_TYPE_MISMATCH, "Cannot cast %s to %s. Implicit downcasts are disallowed.", type_name(from), type_name(to)); return child; }
+  char nm[256]; snprintf(nm, sizeof(nm), "CAST_%s_TO_%s(%s)", type_name(from), type_name(to), child->name);
+  bnode* b = bnode_new(B_CAST, OP_CAST, to, child->nullable, nm);
+  b->args[0] = child; b->nargs = 1;
+  return fold(b, err);
+}
+
+/* FormatDescription strings, expression/vector/expression_traits.h:1204-1570 */
+static void fmt_binary(char* out, size_t cap, int op, const char* l, const char* r) {
+  const char* s = "?";
+  switch (op) {
+    case OP_ADD: s = "+"; break; case OP_SUBTRACT: s = "-"; break; case OP_MULTIPLY: s = "*"; break;
+    case OP_DIVIDE_QUIET: case OP_DIVIDE_NULLING: case OP_DIVIDE_SIGNALING: s = "/."; break;
+    case OP_CPP_DIVIDE_NULLING: case OP_CPP_DIVIDE_SIGNALING: s = "/"; break;
+    case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING: s = "%"; break;
+    case OP_EQUAL: s = "=="; break; case OP_NOT_EQUAL: s = "<>"; break; case OP_LESS: s = "<"; break;
+    case OP_LESS_OR_EQUAL: s = "<="; break; case OP_AND: s = "AND"; break; case OP_OR: s = "OR"; break;
+    case OP_AND_NOT: s = "!&&"; break; case OP_XOR: s = "XOR"; break;
+  }
+  if (op == OP_IF_NULL) snprintf(out, cap, "IFNULL(%s, %s)", l, r);
+  else snprintf(out, cap, "(%s %s %s)", l, s, r);
+}
+
+static bnode* make_op2(int op, int dtype, int nullable, bnode* l, bnode* r, orc_error* err) {
+  char nm[256]; fmt_binary(nm, sizeof(nm), op, l->name, r->name);
+  bnode* b = bnode_new(B_OP, op, dtype, nullable, nm);
+  b->args[0] = l; b->args[1] = r; b->nargs = 2;
+  return fold(b, err);
+}
+
+static bnode* bind_expr(const orc_expr* e, const orc_schema* s, bnode** multi, int* nmulti, orc_error* err);
+
+static bnode* bind_single(const orc_expr* e, const orc_schema* s, orc_error* err) {
+  bnode* m[ORC_MAX_COLS]; int nm = 0;
+  bnode* b = bind_expr(e, s, m, &nm, err);
+  if (err->code) return NULL;
+  if (nm != 1) { set_err(err, RC_COUNT_MISMATCH, "expression argument must have exactly one attribute%s%s", "", ""); return NULL; }
+  (void)b;
+  return m[0];
+}
+
+/* GenerateComparison, expression/core/comparison_bound_expressions.cc:587-638 */
+static bnode* bind_compare(int op, bnode* l, bnode* r, orc_error* err) {
+  int lt = l->dtype, rt = r->dtype;
+  if (lt != rt) {
+    if (!is_numeric(lt) || !is_numeric(rt)) { set_err(err, RC_TYPE_MISMATCH, "Cannot compare expressions of different, non-numeric types%s%s", "", ""); return NULL; }
+    if (lt == T_DOUBLE || rt == T_DOUBLE) { l = make_cast(l, T_DOUBLE, 1, err); r = make_cast(r, T_DOUBLE, 1, err); }
+    else if (lt == T_FLOAT || rt == T_FLOAT) { l = make_cast(l, T_FLOAT, 0, err); r = make_cast(r, T_FLOAT, 0, err); }
+  }
+  if (err->code) return NULL;
+  return make_op2(op, T_BOOL, l->nullable || r->nullable, l, r, err);
+}
+
+static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
+  bnode* a[3] = {0, 0, 0};
+  for (int i = 0; i < e->nargs && i < 3; ++i) { a[i] = bind_single(e->args[i], s, err); if (err->code) return NULL; }
+  const int op = e->op;
+  switch (op) {
+    case OP_ADD: case OP_SUBTRACT: case OP_MULTIPLY: case OP_CPP_DIVIDE_NULLING: case OP_CPP_DIVIDE_SIGNALING:
+    case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING: {
+      /* CreateBinaryNumericExpression, bound_expression_factory.h:506-535 */
+      int t = common_type(a[0]->dtype, a[1]->dtype, err);
+      if (err->code) return NULL;
+      int integer_only = op == OP_MODULUS_NULLING || op == OP_MODULUS_SIGNALING;
+      if (!is_numeric(t) || (integer_only && !is_integer(t))) { set_err(err, RC_TYPE_MISMATCH, "Operator not defined for type %s%s", type_name(t), ""); return NULL; }
+      bnode* l = make_cast(a[0], t, 1, err); bnode* r = make_cast(a[1], t, 1, err);
+      if (err->code) return NULL;
+      int can_null = op == OP_CPP_DIVIDE_NULLING || op == OP_MODULUS_NULLING;
+      return make_op2(op, t, l->nullable || r->nullable || can_null, l, r, err);
+    }
+    case OP_DIVIDE_QUIET: case OP_DIVIDE_NULLING: case OP_DIVIDE_SIGNALING: {
+      /* always DOUBLE, arithmetic_bound_expressions.cc:47-72 */
+      bnode* l = make_cast(a[0], T_DOUBLE, 1, err); bnode* r = make_cast(a[1], T_DOUBLE, 1, err);
+      if (err->code) return NULL;
+      return make_op2(op, T_DOUBLE, l->nullable || r->nullable || op == OP_DIVIDE_NULLING, l, r, err);
+    }
+    case OP_EQUAL: case OP_NOT_EQUAL: case OP_LESS: case OP_LESS_OR_EQUAL: return bind_compare(op, a[0], a[1], err);
+    /* a > b is bound as Less(b, a): comparison_bound_expressions.cc:832-848 */
+    case OP_GREATER: return bind_compare(OP_LESS, a[1], a[0], err);
+    case OP_GREATER_OR_EQUAL: return bind_compare(OP_LESS_OR_EQUAL, a[1], a[0], err);
+    case OP_AND: case OP_OR: case OP_AND_NOT: case OP_XOR:
+      /* BoundBooleanBinary: no promotions, both BOOL (elementary_bound_expressions.cc:1122-1148) */
+      if (a[0]->dtype != T_BOOL || a[1]->dtype != T_BOOL) { set_err(err, RC_TYPE_MISMATCH, "Expected BOOL in %s%s", a[0]->name, ""); return NULL; }
+      return make_op2(op, T_BOOL, a[0]->nullable || a[1]->nullable, a[0], a[1], err);
+    case OP_NOT: {
+      if (a[0]->dtype != T_BOOL) { set_err(err, RC_TYPE_MISMATCH, "Expected BOOL in %s%s", a[0]->name, ""); return NULL; }
+      char nm[256]; snprintf(nm, sizeof(nm), "(NOT %s)", a[0]->name);
+      bnode* b = bnode_new(B_OP, op, T_BOOL, a[0]->nullable, nm); b->args[0] = a[0]; b->nargs = 1;
+      return fold(b, err);
+    }
+    case OP_NEGATE: {
+      int t = a[0]->dtype;
+      if (!is_numeric(t)) { set_err(err, RC_TYPE_MISMATCH, "NEGATE needs a numeric argument%s%s", "", ""); return NULL; }
+      int st = t == T_UINT32 ? T_INT32 : t == T_UINT64 ? T_INT64 : t;
+      bnode* c = a[0];
+      if (st != t) {  /* projecting cast to the signed type of the same width */
+        char cn[256]; snprintf(cn, sizeof(cn), "CAST_%s_TO_%s(%s)", type_name(t), type_name(st), c->name);
+        bnode* k = bnode_new(B_CAST, OP_CAST, st, c->nullable, cn); k->args[0] = c; k->nargs = 1; c = fold(k, err);
+      }
+      char nm[256]; snprintf(nm, sizeof(nm), "(-%s)", c->name);
+      bnode* b = bnode_new(B_OP, op, st, c->nullable, nm); b->args[0] = c; b->nargs = 1;
+      return fold(b, err);
+    }
+    case OP_IS_NULL: {
+      /* non-nullable argument binds to ConstBool(false): elementary_bound_expressions.cc:1419-1424 */
+      if (!a[0]->nullable) return make_const(T_BOOL, 0);
+      char nm[256]; snprintf(nm, sizeof(nm), "ISNULL(%s)", a[0]->name);
+      bnode* b = bnode_new(B_OP, op, T_BOOL, 0, nm); b->args[0] = a[0]; b->nargs = 1;
+      return fold(b, err);
+    }
+    case OP_IF_NULL: {
+      int t = common_type(a[0]->dtype, a[1]->dtype, err); if (err->code) return NULL;
+      bnode* l = make_cast(a[0], t, 1, err); bnode* r = make_cast(a[1], t, 1, err); if (err->code) return NULL;
+      if (!l->nullable) return l;
+      char nm[256]; fmt_binary(nm, sizeof(nm), op, l->name, r->name);
+      bnode* b = bnode_new(B_OP, op, t, r->nullable, nm); b->args[0] = l; b->args[1] = r; b->nargs = 2;
+      return b;
+    }
+    case OP_IF: {
+      /* BoundIfInternal, elementary_bound_expressions.cc:1084-1120 */
+      if (a[0]->dtype != T_BOOL) { set_err(err, RC_TYPE_MISMATCH, "Expected BOOL in %s%s", a[0]->name, ""); return NULL; }
+      int t = common_type(a[1]->dtype, a[2]->dtype, err); if (err->code) return NULL;
+      bnode* x = make_cast(a[1], t, 1, err); bnode* y = make_cast(a[2], t, 1, err); if (err->code) return NULL;
+      char nm[256]; snprintf(nm, sizeof(nm), "IF %s THEN %s ELSE %s", a[0]->name, x->name, y->name);
+      bnode* b = bnode_new(B_OP, op, t, a[0]->nullable || x->nullable || y->nullable, nm);
+      b->args[0] = a[0]; b->args[1] = x; b->args[2] = y; b->nargs = 3;
+      return b;
+    }
+  }
+  set_err(err, RC_NOT_IMPLEMENTED, "operator outside the restated path%s%s", "", "");
+  return NULL;
+}
+
+static bnode* bind_expr(const orc_expr* e, const orc_schema* s, bnode** multi, int* nmulti, orc_error* err) {
+  bnode* b = NULL;
+  switch (e->kind) {
+    case E_NAMED: {
+      /* BoundInputProjectionExpression: zero-copy column reference
+       * (expression/core/projecting_bound_expressions.cc:54-82) */
+      int pos = schema_lookup(s, e->name);
+      if (pos < 0) { set_err(err, RC_ATTRIBUTE_MISSING, "No attribute '%s' in the schema%s", e->name, ""); return NULL; }
+      b = bnode_new(B_INPUT, 0, s->a[pos].type, s->a[pos].nullable, s->a[pos].name); b->input_col = pos;
+    } break;
+    case E_AT:
+      if (e->i64 < 0 || e->i64 >= s->n) { set_err(err, RC_COUNT_MISMATCH, "source schema has too few attributes%s%s", "", ""); return NULL; }
+      b = bnode_new(B_INPUT, 0, s->a[e->i64].type, s->a[e->i64].nullable, s->a[e->i64].name); b->input_col = (int)e->i64;
+      break;
+    case E_CONST: b = make_const(e->dtype, const_bits(e->dtype, e->i64, e->f64)); break;
+    case E_NULL: b = make_null(e->dtype); break;
+    case E_ALIAS: {
+      bnode* c = bind_single(e->args[0], s, err); if (err->code) return NULL;
+      b = (bnode*)malloc(sizeof(bnode)); *b = *c;   /* same computation, new name */
+      snprintf(b->name, sizeof(b->name), "%s", e->name);
+    } break;
+    case E_COMPOUND:
+      for (int i = 0; i < e->nargs; ++i) {
+        bnode* m[ORC_MAX_COLS]; int nm = 0;
+        bind_expr(e->args[i], s, m, &nm, err); if (err->code) return NULL;
+        for (int j = 0; j < nm; ++j) {
+          for (int q = 0; q < *nmulti; ++q)
+            if (strcmp(multi[q]->name, m[j]->name) == 0) { set_err(err, RC_ATTRIBUTE_EXISTS, "Duplicate attribute name \"%s\" in result schema%s", m[j]->name, ""); return NULL; }
+          multi[(*nmulti)++] = m[j];
+        }
+      }
+      return NULL;
+    case E_CAST: { bnode* c = bind_single(e->args[0], s, err); if (err->code) return NULL; b = make_cast(c, e->dtype, 0, err); } break;
+    case E_OP: b = bind_op(e, s, err); break;
+  }
+  if (err->code || !b) return NULL;
+  multi[(*nmulti)++] = b;
+  return b;
+}
+
+/* ---- evaluation: BoundExpression::DoEvaluate over one <=1024-row view
+ * (expression/templated/abstract_bound_expressions.h:129-147; NULL flow
+ *  projecting_bound_expressions.cc:66-82) ---------------------------------------------- */
+static void or_nulls(uint8_t* dst, const uint8_t* a, const uint8_t* b, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) dst[i] = (a ? a[i] : 0) | (b ? b[i] : 0);
+}
+static void fill_const(bnode* b, int64_t n) {
+  const int w = type_width(b->dtype);
+  for (int64_t i = 0; i < n; ++i) memcpy((char*)b->buf + i * w, &b->bits, (size_t)w);
+}
+
+static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
+  switch (b->kind) {
+    case B_INPUT: b->data = in->c[b->input_col].data; b->nulls = in->c[b->input_col].is_null; return;
+    case B_CONST: fill_const(b, n); b->data = b->buf; b->nulls = NULL; return;  /* PostInit pre-fill */
+    case B_NULLCONST: memset(b->buf, 0, (size_t)n * 8); memset(b->nullbuf, 1, (size_t)n); b->data = b->buf; b->nulls = b->nullbuf; return;
+    default: break;
+  }
+  for (int i = 0; i < b->nargs; ++i) { eval_node(b->args[i], in, n, err); if (err->code) return; }
+  bnode* x = b->args[0]; bnode* y = b->nargs > 1 ? b->args[1] : NULL;
+  b->data = b->buf; b->nulls = NULL;
+  if (b->kind == B_CAST) {
+    const int same_width_int = is_integer(x->dtype) && is_integer(b->dtype) && type_width(x->dtype) == type_width(b->dtype);
+    if (same_width_int) b->data = x->data;  /* projecting cast */
+    else if (!eval_cast(x->dtype, b->dtype, x->data, b->buf, n)) set_err(err, RC_NOT_IMPLEMENTED, "cast%s%s", "", "");
+    b->nulls = x->nulls;
+    return;
+  }
+  switch (b->op) {
+    case OP_AND: case OP_OR: case OP_AND_NOT: {
+      /* three-valued logic, elementary_bound_expressions.cc:343-404: FALSE AND NULL = FALSE,
+       * TRUE OR NULL = TRUE; AND_NOT(a,b) = (NOT a) AND b */
+      const uint8_t* av = (const uint8_t*)x->data; const uint8_t* bv = (const uint8_t*)y->data;
+      uint8_t* d = (uint8_t*)b->buf; int any_null = x->nulls || y->nulls;
+      for (int64_t i = 0; i < n; ++i) {
+        int A = av[i] != 0, B = bv[i] != 0, NA = x->nulls ? x->nulls[i] : 0, NB = y->nulls ? y->nulls[i] : 0;
+        if (b->op == OP_AND_NOT) A = !A;
+        if (b->op == OP_OR) { int dec = (!NA && A) || (!NB && B); b->nullbuf[i] = (NA || NB) && !dec; d[i] = dec || A || B; }
+        else { int dec = (!NA && !A) || (!NB && !B); b->nullbuf[i] = (NA || NB) && !dec; d[i] = !dec && A && B; }
+      }
+      b->nulls = any_null ? b->nullbuf : NULL;
+      return;
+    }
+    case OP_NOT: { const uint8_t* A = (const uint8_t*)x->data; uint8_t* D = (uint8_t*)b->buf; for (int64_t i = 0; i < n; ++i) D[i] = !A[i]; b->nulls = x->nulls; return; }
+    case OP_NEGATE: {
+      const void* A = x->data; void* D = b->buf;
+      switch (arith_kind(b->dtype)) {
+        case 0: case 1: LOOP1(uint32_t, uint32_t, 0u - a) break;
+        case 2: case 3: LOOP1(uint64_t, uint64_t, 0ull - a) break;
+        case 4: LOOP1(float, float, -a) break;
+        case 5: LOOP1(double, double, -a) break;
+      }
+      b->nulls = x->nulls; return;
+    }
+    case OP_IS_NULL: { uint8_t* D = (uint8_t*)b->buf; for (int64_t i = 0; i < n; ++i) D[i] = x->nulls ? x->nulls[i] : 0; return; }
+    case OP_IF_NULL: {
+      const int w = type_width(b->dtype);
+      for (int64_t i = 0; i < n; ++i) {
+        int an = x->nulls ? x->nulls[i] : 0;
+        memcpy((char*)b->buf + i * w, (const char*)(an ? y->data : x->data) + i * w, (size_t)w);
+        b->nullbuf[i] = an && (y->nulls ? y->nulls[i] : 0);
+      }
+      b->nulls = y->nulls ? b->nullbuf : NULL; return;
+    }
+    case OP_IF: {
+      bnode* z = b->args[2]; const int w = type_width(b->dtype); const uint8_t* cv = (const uint8_t*)x->data;
+      int any = x->nulls || y->nulls || z->nulls;
+      for (int64_t i = 0; i < n; ++i) {
+        int c = cv[i] != 0; bnode* src = c ? y : z;
+        memcpy((char*)b->buf + i * w, (const char*)src->data + i * w, (size_t)w);
+        b->nullbuf[i] = (x->nulls ? x->nulls[i] : 0) || (src->nulls ? src->nulls[i] : 0);
+      }
+      b->nulls = any ? b->nullbuf : NULL; return;
+    }
+  }
+  /* standard binary operators: NULL in -> NULL out */
+  if (x->nulls || y->nulls) { or_nulls(b->nullbuf, x->nulls, y->nulls, n); b->nulls = b->nullbuf; }
+  const int is_cmp = b->op == OP_LESS || b->op == OP_LESS_OR_EQUAL || b->op == OP_EQUAL || b->op == OP_NOT_EQUAL;
+  if (is_cmp && x->dtype != y->dtype) { eval_mixed_int_compare(b->op, x->dtype, x->data, y->dtype, y->data, (uint8_t*)b->buf, n); return; }
+  if (!eval_binary(b->op, x->dtype, x->data, y->data, b->buf, n)) { set_err(err, RC_NOT_IMPLEMENTED, "operator/type not restated%s%s", "", ""); return; }
+  /* failers / nullers (expression/vector/column_validity_checkers.h): zero divisor */
+  const int nulling = b->op == OP_DIVIDE_NULLING || b->op == OP_CPP_DIVIDE_NULLING || b->op == OP_MODULUS_NULLING;
+  const int signaling = b->op == OP_DIVIDE_SIGNALING || b->op == OP_CPP_DIVIDE_SIGNALING || b->op == OP_MODULUS_SIGNALING;
+  if (nulling || signaling) {
+    const int w = type_width(y->dtype); const int k = arith_kind(y->dtype);
+    for (int64_t i = 0; i < n; ++i) {
+      int zero;
+      if (k == 5) zero = ((const double*)y->data)[i] == 0.0; else if (k == 4) zero = ((const float*)y->data)[i] == 0.0f;
+      else if (w == 8) zero = ((const uint64_t*)y->data)[i] == 0; else zero = ((const uint32_t*)y->data)[i] == 0;
+      if (!zero) continue;
+      int already_null = b->nulls ? b->nulls[i] : 0;
+      if (nulling) { if (!b->nulls) { memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; } b->nullbuf[i] = 1; }
+      else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: division by zero in %s%s", b->name, ""); return; }
+    }
+  }
+}
+
+/* =========================== cursors ============================================ */
+enum { C_SCAN = 1, C_COMPUTE, C_FILTER, C_PROJECT, C_SCALAR_AGG, C_GROUP_AGG, C_CLUSTERS, C_SORT };
+enum { P_ALL = 1, P_NAMED = 2, P_AT = 3, P_NAMED_AS = 4 };
+typedef struct { int kind, position; char name[256], alias[256]; } orc_proj;
+typedef struct { int aggregation, distinct, output_type; char input[256], output[256]; } orc_agg;
+typedef struct { char name[256]; int order; } orc_sortkey;
+
+typedef struct orc_op {
+  int kind; struct orc_op* child; orc_expr* expr;
+  orc_proj projs[ORC_MAX_COLS]; int nproj;
+  orc_agg aggs[ORC_MAX_COLS]; int nagg;
+  orc_sortkey sortkeys[16]; int nsort;
+  orc_schema scan_schema; orc_view scan_view;
+} orc_op;
+
+orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
+  orc_op* o = (orc_op*)calloc(1, sizeof(orc_op)); o->kind = kind; o->child = child; o->expr = expr; return o;
+}
+void orc_op_add_proj(orc_op* o, int kind, int position, const char* name, const char* alias) {
+  orc_proj* p = &o->projs[o->nproj++]; p->kind = kind; p->position = position;
+  snprintf(p->name, sizeof(p->name), "%s", name ? name : ""); snprintf(p->alias, sizeof(p->alias), "%s", alias ? alias : "");
+}
+void orc_op_add_agg(orc_op* o, int aggregation, int distinct, int output_type, const char* input, const char* output) {
+  orc_agg* a = &o->aggs[o->nagg++]; a->aggregation = aggregation; a->distinct = distinct; a->output_type = output_type;
+  snprintf(a->input, sizeof(a->input), "%s", input ? input : ""); snprintf(a->output, sizeof(a->output), "%s", output ? output : "");
+}
+void orc_op_add_sortkey(orc_op* o, const char* name, int order) {
+  orc_sortkey* k = &o->sortkeys[o->nsort++]; snprintf(k->name, sizeof(k->name), "%s", name); k->order = order;
+}
+void orc_scan_add_column(orc_op* o, const char* name, int type, int nullable, const void* data, const uint8_t* is_null) {
+  int i = o->scan_schema.n;
+  schema_add(&o->scan_schema, name, type, nullable);
+  o->scan_view.c[i].data = data; o->scan_view.c[i].is_null = is_null; o->scan_view.n = i + 1;
+}
+void orc_scan_set_rows(orc_op* o, int64_t rows) { o->scan_view.rows = rows; }
+
+/* owned result block of a cursor */
+typedef struct { int n; int64_t cap; void* data[ORC_MAX_COLS]; uint8_t* nulls[ORC_MAX_COLS]; int width[ORC_MAX_COLS]; } orc_block;
+static void block_init(orc_block* b, const orc_schema* s, int64_t cap) {
+  b->n = s->n; b->cap = cap;
+  for (int i = 0; i < s->n; ++i) {
+    b->width[i] = type_width(s->a[i].type);
+    b->data[i] = calloc((size_t)(cap > 0 ? cap : 1), (size_t)(b->width[i] ? b->width[i] : 1));
+    b->nulls[i] = (uint8_t*)calloc((size_t)(cap > 0 ? cap : 1), 1);
+  }
+}
+static void block_grow(orc_block* b, int64_t cap) {
+  if (cap <= b->cap) return;
+  for (int i = 0; i < b->n; ++i) {
+    b->data[i] = realloc(b->data[i], (size_t)cap * (size_t)b->width[i]);
+    b->nulls[i] = (uint8_t*)realloc(b->nulls[i], (size_t)cap);
+    memset((char*)b->data[i] + b->cap * b->width[i], 0, (size_t)(cap - b->cap) * (size_t)b->width[i]);
+    memset(b->nulls[i] + b->cap, 0, (size_t)(cap - b->cap));
+  }
+  b->cap = cap;
+}
+
+typedef struct agg_col { int aggregation, in_pos, in_type, out_type; } agg_col;
+
+typedef struct orc_cursor {
+  int kind; struct orc_cursor* child; orc_schema schema; orc_error err;
+  /* scan */ orc_view scan; int64_t pos;
+  /* compute */ bnode* outs[ORC_MAX_COLS]; int nouts;
+  /* filter / project / group keys */ bnode* pred; int proj_pos[ORC_MAX_COLS]; int nproj;
+  int64_t* ids; int64_t nids, read_ptr; orc_view cur; int have_cur, eos;
+  orc_block block;                  /* result block (filter / aggregates / sort) */
+  /* aggregates */ agg_col aggs[ORC_MAX_COLS]; int nagg; int done; int64_t out_rows, emit_pos;
+  /* group */ int64_t* bucket_head; int64_t* chain_next; uint64_t* row_hash; int64_t nbuckets;
+  /* sort */ int sort_pos[16], sort_order[16], nsort; int64_t* perm; void* table;
+  orc_view outv;
+} orc_cursor;
+
+static int bind_projector(const orc_proj* p, int np, const orc_schema* in, int* pos, char names[][256], int* nout, orc_error* err) {
+  int k = 0;
+  for (int i = 0; i < np; ++i) {
+    switch (p[i].kind) {
+      case P_ALL: for (int c = 0; c < in->n; ++c) { pos[k] = c; snprintf(names[k], 256, "%s", in->a[c].name); ++k; } break;
+      case P_NAMED: case P_NAMED_AS: {
+        int c = schema_lookup(in, p[i].name);
+        /* projector.cc:99-105 */
+        if (c < 0) { set_err(err, RC_ATTRIBUTE_MISSING, "No attribute '%s' in the schema%s", p[i].name, ""); return 0; }
+        pos[k] = c; snprintf(names[k], 256, "%s", p[i].kind == P_NAMED_AS ? p[i].alias : in->a[c].name); ++k;
+      } break;
+      case P_AT:
+        /* projector.cc:185-190 */
+        if (p[i].position < 0 || p[i].position >= in->n) { set_err(err, RC_COUNT_MISMATCH, "source schema has too few attributes%s%s", "", ""); return 0; }
+        pos[k] = p[i].position; snprintf(names[k], 256, "%s", in->a[p[i].position].name); ++k; break;
+    }
+  }
+  for (int i = 0; i < k; ++i) for (int j = i + 1; j < k; ++j)
+    if (strcmp(names[i], names[j]) == 0) { set_err(err, RC_ATTRIBUTE_EXISTS, "Duplicate attribute name \"%s\" in result schema%s", names[i], ""); return 0; }
+  *nout = k;
+  return 1;
+}
+
+/* Aggregator::Init, cursor/core/aggregator.cc:116-186; output type rule :63-78;
+ * supported matrix column_aggregator.cc:484-532 */
+static int bind_aggs(orc_cursor* c, const orc_op* op, const orc_schema* in) {
+  for (int i = 0; i < op->nagg; ++i) {
+    const orc_agg* a = &op->aggs[i]; agg_col* g = &c->aggs[i];
+    g->aggregation = a->aggregation;
+    if (a->aggregation == A_COUNT && !a->distinct && a->input[0] == 0) g->in_pos = -1;
+    else {
+      g->in_pos = schema_lookup(in, a->input);
+      if (g->in_pos < 0) { set_err(&c->err, RC_ATTRIBUTE_MISSING, "Incorrect aggregation specification. Aggregation input column does not exist: %s.%s", a->input, ""); return 0; }
+    }
+    g->in_type = g->in_pos >= 0 ? in->a[g->in_pos].type : T_UINT64;
+    g->out_type = a->output_type >= 0 ? a->output_type : (a->aggregation == A_COUNT ? T_UINT64 : g->in_type);
+    if (a->distinct || a->aggregation == A_CONCAT) { set_err(&c->err, RC_NOT_IMPLEMENTED, "DISTINCT/CONCAT not restated%s%s", "", ""); return 0; }
+    if (a->aggregation == A_COUNT) { if (!is_integer(g->out_type)) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "COUNT output must be integer%s%s", "", ""); return 0; } }
+    else {
+      int ok = (is_numeric(g->in_type) && is_numeric(g->out_type)) ||
+               (g->in_type == g->out_type && a->aggregation != A_SUM && (g->in_type == T_BOOL || g->in_type == T_DATE || g->in_type == T_DATETIME));
+      if (!ok) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "Aggregation not supported for types %s and %s.", type_name(g->in_type), type_name(g->out_type)); return 0; }
+    }
+    if (!schema_add(&c->schema, a->output, g->out_type, a->aggregation != A_COUNT)) {
+      set_err(&c->err, RC_ATTRIBUTE_EXISTS, "Incorrect aggregation specification. Aggregation output column name is non-unique: '%s'.%s", a->output, ""); return 0;
+    }
+  }
+  c->nagg = op->nagg;
+  return 1;
+}
+
+orc_cursor* orc_create_cursor(const orc_op* op);
+
+static orc_cursor* cursor_fail(orc_cursor* c) { return c; }
+
+orc_cursor* orc_create_cursor(const orc_op* op) {
+  orc_cursor* c = (orc_cursor*)calloc(1, sizeof(orc_cursor));
+  c->kind = op->kind;
+  if (op->child) {
+    c->child = orc_create_cursor(op->child);
+    if (c->child->err.code) { c->err = c->child->err; return cursor_fail(c); }
+  }
+  const orc_schema* in = c->child ? &c->child->schema : NULL;
+  switch (op->kind) {
+    case C_SCAN: c->schema = op->scan_schema; c->scan = op->scan_view; break;
+    case C_COMPUTE: {
+      /* ComputeOperation::CreateCursor binds the expression to the child schema
+       * (cursor/core/compute.cc:69-79) */
+      bnode* m[ORC_MAX_COLS]; int nm = 0;
+      bind_expr(op->expr, in, m, &nm, &c->err);
+      if (c->err.code) return cursor_fail(c);
+      for (int i = 0; i < nm; ++i) {
+        c->outs[i] = m[i];
+        if (!schema_add(&c->schema, m[i]->name, m[i]->dtype, m[i]->nullable)) { set_err(&c->err, RC_ATTRIBUTE_EXISTS, "Duplicate attribute name \"%s\" in result schema%s", m[i]->name, ""); return cursor_fail(c); }
+      }
+      c->nouts = nm;
+    } break;
+    case C_PROJECT: case C_FILTER: {
+      if (op->kind == C_FILTER) {
+        bnode* m[ORC_MAX_COLS]; int nm = 0;
+        bind_expr(op->expr, in, m, &nm, &c->err);
+        if (c->err.code) return cursor_fail(c);
+        /* filter.cc:84-92 */
+        if (nm != 1) { set_err(&c->err, RC_COUNT_MISMATCH, "Predicate has to return exactly one column of type BOOL%s%s", "", ""); return cursor_fail(c); }
+        if (m[0]->dtype != T_BOOL) { set_err(&c->err, RC_TYPE_MISMATCH, "Predicate has to return exactly one column of type BOOL%s%s", "", ""); return cursor_fail(c); }
+        c->pred = m[0];
+      }
+      char names[ORC_MAX_COLS][256];
+      if (!bind_projector(op->projs, op->nproj, in, c->proj_pos, names, &c->nproj, &c->err)) return cursor_fail(c);
+      for (int i = 0; i < c->nproj; ++i) schema_add(&c->schema, names[i], in->a[c->proj_pos[i]].type, in->a[c->proj_pos[i]].nullable);
+      if (op->kind == C_FILTER) { block_init(&c->block, &c->schema, ORC_BLOCK); c->ids = (int64_t*)malloc(sizeof(int64_t) * ORC_BLOCK); }
+    } break;
+    case C_SCALAR_AGG:
+      if (!bind_aggs(c, op, in)) return cursor_fail(c);
+      block_init(&c->block, &c->schema, 1);
+      break;
+    case C_GROUP_AGG: case C_CLUSTERS: {
+      char names[ORC_MAX_COLS][256];
+      if (!bind_projector(op->projs, op->nproj, in, c->proj_pos, names, &c->nproj, &c->err)) return cursor_fail(c);
+      for (int i = 0; i < c->nproj; ++i) schema_add(&c->schema, names[i], in->a[c->proj_pos[i]].type, in->a[c->proj_pos[i]].nullable);
+      if (!bind_aggs(c, op, in)) return cursor_fail(c);
+      block_init(&c->block, &c->schema, 16);  /* kDefaultResultEstimatedGroupCount, aggregate.h:162 */
+    } break;
+    case C_SORT: {
+      for (int i = 0; i < op->nsort; ++i) {
+        int p = schema_lookup(in, op->sortkeys[i].name);
+        if (p < 0) { set_err(&c->err, RC_ATTRIBUTE_MISSING, "No attribute '%s' in the schema%s", op->sortkeys[i].name, ""); return cursor_fail(c); }
+        c->sort_pos[i] = p; c->sort_order[i] = op->sortkeys[i].order;
+      }
+      c->nsort = op->nsort;
+      char names[ORC_MAX_COLS][256];
+      if (!bind_projector(op->projs, op->nproj, in, c->proj_pos, names, &c->nproj, &c->err)) return cursor_fail(c);
+      for (int i = 0; i < c->nproj; ++i) schema_add(&c->schema, names[i], in->a[c->proj_pos[i]].type, in->a[c->proj_pos[i]].nullable);
+    } break;
+  }
+  return c;
+}
+
+int orc_cursor_error(const orc_cursor* c, char* buf, int cap) { if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", c->err.msg); return c->err.code; }
+int orc_cursor_ncols(const orc_cursor* c) { return c->schema.n; }
+const char* orc_cursor_col_name(const orc_cursor* c, int i) { return c->schema.a[i].name; }
+int orc_cursor_col_type(const orc_cursor* c, int i) { return c->schema.a[i].type; }
+int orc_cursor_col_nullable(const orc_cursor* c, int i) { return c->schema.a[i].nullable; }
+
+/* returns 1 = data, 0 = end of stream, -1 = failure */
+static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out);
+
+/* ---- aggregation operators: AssignmentOperator / AggregationOperator
+ * (base/infrastructure/aggregation_operators.h:57-71,173-228); first non-NULL value is
+ * ASSIGNED (clears is_null), later ones AGGREGATED; NULL inputs skipped
+ * (cursor/core/column_aggregator.cc:108-124,154-166); COUNT :213-226 ------------------ */
+static double load_as_double(int t, const void* p, int64_t i) {
+  switch (arith_kind(t)) {
+    case 0: return ((const int32_t*)p)[i]; case 1: return ((const uint32_t*)p)[i];
+    case 2: return (double)((const int64_t*)p)[i]; case 3: return (double)((const uint64_t*)p)[i];
+    case 4: return ((const float*)p)[i]; case 5: return ((const double*)p)[i]; case 6: return ((const uint8_t*)p)[i];
+  }
+  return 0;
+}
+static int64_t load_as_i64(int t, const void* p, int64_t i) {
+  switch (arith_kind(t)) {
+    case 0: return ((const int32_t*)p)[i]; case 1: return ((const uint32_t*)p)[i];
+    case 2: return ((const int64_t*)p)[i]; case 3: return (int64_t)((const uint64_t*)p)[i];
+    case 4: return (int64_t)((const float*)p)[i]; case 5: return (int64_t)((const double*)p)[i]; case 6: return ((const uint8_t*)p)[i];
+  }
+  return 0;
+}
+
+/* one aggregate column over one view: acc[map[i]] op= v[i] */
+static void update_aggregation(const agg_col* g, const orc_view* v, const int64_t* map, void* res, uint8_t* res_null) {
+  const int64_t n = v->rows;
+  if (g->aggregation == A_COUNT) {
+    const uint8_t* nl = g->in_pos >= 0 ? v->c[g->in_pos].is_null : NULL;
+    for (int64_t i = 0; i < n; ++i) {
+      if (nl && nl[i]) continue;
+      if (type_width(g->out_type) == 8) ((uint64_t*)res)[map[i]] += 1; else ((uint32_t*)res)[map[i]] += 1;
+    }
+    return;
+  }
+  const void* in = v->c[g->in_pos].data; const uint8_t* nl = v->c[g->in_pos].is_null;
+  const int ko = arith_kind(g->out_type);
+  for (int64_t i = 0; i < n; ++i) {
+    if (nl && nl[i]) continue;
+    const int64_t r = map[i];
+    const int first = res_null[r];
+    if (first) res_null[r] = 0;
+#define AGG_TYPED(TO, LOADER) { TO val = (TO)LOADER(g->in_type, in, i); TO* acc = (TO*)res + r; \
+      if (first) *acc = val; \
+      else switch (g->aggregation) { \
+        case A_SUM: *acc += val; break; \
+        case A_MIN: if (val < *acc) *acc = val; break;    /* "val < result" replaces; NaN never does */ \
+        case A_MAX: if (*acc < val) *acc = val; break; \
+        case A_FIRST: break; \
+        case A_LAST: *acc = val; break; } }
+    switch (ko) {
+      case 0: AGG_TYPED(int32_t, load_as_i64) break;
+      case 1: AGG_TYPED(uint32_t, load_as_i64) break;
+      case 2: AGG_TYPED(int64_t, load_as_i64) break;
+      case 3: AGG_TYPED(uint64_t, load_as_i64) break;
+      case 4: AGG_TYPED(float, load_as_double) break;
+      case 5: AGG_TYPED(double, load_as_double) break;
+      case 6: AGG_TYPED(uint8_t, load_as_i64) break;
+    }
+  }
+}
+
+static void reset_agg_rows(orc_cursor* c, int key_cols, int64_t from, int64_t to) {
+  for (int j = 0; j < c->nagg; ++j) {
+    const int col = key_cols + j;
+    /* COUNT starts at 0 and is NOT NULL; the others start NULL (column_aggregator.cc:240-252,170-175) */
+    memset((char*)c->block.data[col] + from * c->block.width[col], 0, (size_t)(to - from) * (size_t)c->block.width[col]);
+    memset(c->block.nulls[col] + from, c->aggs[j].aggregation == A_COUNT ? 0 : 1, (size_t)(to - from));
+  }
+}
+
+/* ---- RowHashSet semantics (cursor/infrastructure/row_hash_set.cc:458-517): key -> dense
+ * group id in insertion order; NULL keys equal each other (:81-93); chained buckets, 75%
+ * load, power-of-two growth (:305-319,375). ------------------------------------------- */
+static uint64_t mix64(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
+static uint64_t hash_row(const orc_cursor* c, const orc_view* v, int64_t i) {
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+  for (int k = 0; k < c->nproj; ++k) {
+    const orc_col* col = &v->c[c->proj_pos[k]]; const int w = type_width(c->child->schema.a[c->proj_pos[k]].type);
+    uint64_t x = 0;
+    if (col->is_null && col->is_null[i]) x = 0xdeadbeefcafef00dull; else memcpy(&x, (const char*)col->data + i * w, (size_t)w);
+    h = mix64(h ^ x) + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1);
+  }
+  return h;
+}
+static int key_equal(const orc_cursor* c, const orc_view* v, int64_t i, int64_t group) {
+  for (int k = 0; k < c->nproj; ++k) {
+    const orc_col* col = &v->c[c->proj_pos[k]]; const int w = c->block.width[k];
+    const int an = col->is_null ? col->is_null[i] : 0, bn = c->block.nulls[k][group];
+    if (an != bn) return 0;
+    if (an) continue;
+    if (memcmp((const char*)col->data + i * w, (const char*)c->block.data[k] + group * w, (size_t)w) != 0) return 0;
+  }
+  return 1;
+}
+static void group_rehash(orc_cursor* c, int64_t nb) {
+  free(c->bucket_head); c->bucket_head = (int64_t*)malloc(sizeof(int64_t) * (size_t)nb); c->nbuckets = nb;
+  for (int64_t i = 0; i < nb; ++i) c->bucket_head[i] = -1;
+  for (int64_t g = 0; g < c->out_rows; ++g) { int64_t b = (int64_t)(c->row_hash[g] & (uint64_t)(nb - 1)); c->chain_next[g] = c->bucket_head[b]; c->bucket_head[b] = g; }
+}
+static int64_t group_insert(orc_cursor* c, const orc_view* v, int64_t i) {
+  const uint64_t h = hash_row(c, v, i);
+  for (int64_t g = c->bucket_head[h & (uint64_t)(c->nbuckets - 1)]; g >= 0; g = c->chain_next[g])
+    if (c->row_hash[g] == h && key_equal(c, v, i, g)) return g;
+  const int64_t g = c->out_rows;
+  if (g >= c->block.cap) {  /* Aggregator grows x2 (aggregate_groups.cc:372-402) */
+    const int64_t old = c->block.cap; block_grow(&c->block, old * 2);
+    c->chain_next = (int64_t*)realloc(c->chain_next, sizeof(int64_t) * (size_t)c->block.cap);
+    c->row_hash = (uint64_t*)realloc(c->row_hash, sizeof(uint64_t) * (size_t)c->block.cap);
+    reset_agg_rows(c, c->nproj, old, c->block.cap);
+  }
+  for (int k = 0; k < c->nproj; ++k) {
+    const orc_col* col = &v->c[c->proj_pos[k]]; const int w = c->block.width[k];
+    memcpy((char*)c->block.data[k] + g * w, (const char*)col->data + i * w, (size_t)w);
+    c->block.nulls[k][g] = col->is_null ? col->is_null[i] : 0;
+  }
+  c->row_hash[g] = h; c->out_rows = g + 1;
+  if (c->out_rows * 4 > c->nbuckets * 3) group_rehash(c, c->nbuckets * 2);
+  else { int64_t b = (int64_t)(h & (uint64_t)(c->nbuckets - 1)); c->chain_next[g] = c->bucket_head[b]; c->bucket_head[b] = g; }
+  return g;
+}
+
+/* ---- Sort: SortPermutation over all key columns (cursor/core/sort.cc:781-805,182-238):
+ * NULLs first for ASCENDING, last for DESCENDING; not stable (sort.h:42). ------------- */
+typedef struct { const orc_cursor* c; const orc_block* t; } sort_ctx;
+static int three_way(int t, const void* p, int64_t a, int64_t b) {
+  switch (arith_kind(t)) {
+    case 0: { int32_t x = ((const int32_t*)p)[a], y = ((const int32_t*)p)[b]; return x < y ? -1 : y < x; }
+    case 1: { uint32_t x = ((const uint32_t*)p)[a], y = ((const uint32_t*)p)[b]; return x < y ? -1 : y < x; }
+    case 2: { int64_t x = ((const int64_t*)p)[a], y = ((const int64_t*)p)[b]; return x < y ? -1 : y < x; }
+    case 3: { uint64_t x = ((const uint64_t*)p)[a], y = ((const uint64_t*)p)[b]; return x < y ? -1 : y < x; }
+    case 4: { float x = ((const float*)p)[a], y = ((const float*)p)[b]; return x < y ? -1 : y < x; }
+    case 5: { double x = ((const double*)p)[a], y = ((const double*)p)[b]; return x < y ? -1 : y < x; }
+    case 6: { uint8_t x = ((const uint8_t*)p)[a], y = ((const uint8_t*)p)[b]; return x < y ? -1 : y < x; }
+  }
+  return 0;
+}
+static int sort_cmp(const void* pa, const void* pb, void* vctx) {
+  const sort_ctx* s = (const sort_ctx*)vctx; const int64_t a = *(const int64_t*)pa, b = *(const int64_t*)pb;
+  for (int k = 0; k < s->c->nsort; ++k) {
+    const int col = s->c->sort_pos[k]; const int desc = s->c->sort_order[k] == 1;
+    const int an = s->t->nulls[col][a], bn = s->t->nulls[col][b];
+    int r;
+    if (an || bn) r = an == bn ? 0 : (an ? -1 : 1);           /* NULL sorts before every value */
+    else r = three_way(s->c->child->schema.a[col].type, s->t->data[col], a, b);
+    if (r) return desc ? -r : r;
+  }
+  return 0;
+}
+
+static void view_from_block(const orc_cursor* c, const orc_block* b, int64_t off, int64_t rows, orc_view* out) {
+  out->n = c->schema.n; out->rows = rows;
+  for (int i = 0; i < out->n; ++i) {
+    out->c[i].data = (const char*)b->data[i] + off * b->width[i];
+    out->c[i].is_null = c->schema.a[i].nullable ? b->nulls[i] + off : NULL;
+  }
+}
+
+static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
+  if (c->err.code) return -1;
+  if (max_rows > ORC_BLOCK) max_rows = ORC_BLOCK;
+  switch (c->kind) {
+    case C_SCAN: {
+      /* ViewCursor::Next -> ViewIterator::next: pointer bump (view_cursor.cc:51-55) */
+      if (c->pos >= c->scan.rows) return 0;
+      int64_t n = c->scan.rows - c->pos; if (n > max_rows) n = max_rows;
+      out->n = c->scan.n; out->rows = n;
+      for (int i = 0; i < c->scan.n; ++i) {
+        const int w = type_width(c->schema.a[i].type);
+        out->c[i].data = (const char*)c->scan.c[i].data + c->pos * w;
+        out->c[i].is_null = c->scan.c[i].is_null ? c->scan.c[i].is_null + c->pos : NULL;
+      }
+      c->pos += n; return 1;
+    }
+    case C_COMPUTE: {
+      /* ComputeCursor::Next, cursor/core/compute.cc:49-56 */
+      orc_view in; int r = cursor_next(c->child, max_rows, &in);
+      if (r <= 0) { if (r < 0) c->err = c->child->err; return r; }
+      out->n = c->nouts; out->rows = in.rows;
+      for (int i = 0; i < c->nouts; ++i) {
+        eval_node(c->outs[i], &in, in.rows, &c->err);
+        if (c->err.code) return -1;
+        out->c[i].data = c->outs[i]->data; out->c[i].is_null = c->outs[i]->nulls;
+      }
+      return 1;
+    }
+    case C_PROJECT: {
+      /* ProjectCursor::Next: pointer re-mapping (cursor/core/project.cc:49-59) */
+      orc_view in; int r = cursor_next(c->child, max_rows, &in);
+      if (r <= 0) { if (r < 0) c->err = c->child->err; return r; }
+      out->n = c->nproj; out->rows = in.rows;
+      for (int i = 0; i < c->nproj; ++i) out->c[i] = in.c[c->proj_pos[i]];
+      return 1;
+    }
+    case C_FILTER: {
+      /* FilterCursor::Next, cursor/core/filter.cc:96-128: fill the result block until it is
+       * >= 25% full (kMinimumFillPercent, :51,215-217) or the input ends */
+      int64_t write_ptr = 0;
+      for (;;) {
+        if (c->have_cur && c->read_ptr < c->nids) {
+          int64_t n = c->nids - c->read_ptr; if (n > max_rows - write_ptr) n = max_rows - write_ptr;
+          const int final = 100 * (n + write_ptr) >= 25 * max_rows;
+          /* gather: dst[w+i] = src[ids[i]] per projected column (copy_column.cc:199-217) */
+          for (int k = 0; k < c->nproj; ++k) {
+            const orc_col* src = &c->cur.c[c->proj_pos[k]]; const int w = c->block.width[k];
+            const int64_t* ids = c->ids + c->read_ptr;
+            if (w == 8) { const uint64_t* s = (const uint64_t*)src->data; uint64_t* d = (uint64_t*)c->block.data[k] + write_ptr; for (int64_t i = 0; i < n; ++i) d[i] = s[ids[i]]; }
+            else if (w == 4) { const uint32_t* s = (const uint32_t*)src->data; uint32_t* d = (uint32_t*)c->block.data[k] + write_ptr; for (int64_t i = 0; i < n; ++i) d[i] = s[ids[i]]; }
+            else { const uint8_t* s = (const uint8_t*)src->data; uint8_t* d = (uint8_t*)c->block.data[k] + write_ptr; for (int64_t i = 0; i < n; ++i) d[i] = s[ids[i]]; }
+            uint8_t* dn = c->block.nulls[k] + write_ptr;
+            if (src->is_null) for (int64_t i = 0; i < n; ++i) dn[i] = src->is_null[ids[i]]; else memset(dn, 0, (size_t)n);
+          }
+          c->read_ptr += n; write_ptr += n;
+          if (final) break;
+        } else {
+          if (c->eos) { if (write_ptr) break; return 0; }
+          int r = cursor_next(c->child, max_rows < ORC_BLOCK ? max_rows : ORC_BLOCK, &c->cur);
+          if (r < 0) { c->err = c->child->err; return -1; }
+          if (r == 0) { c->eos = 1; c->have_cur = 0; if (write_ptr) break; return 0; }
+          /* PrepareInputRowIds, filter.cc:170-199: ids of rows whose predicate is non-NULL TRUE */
+          eval_node(c->pred, &c->cur, c->cur.rows, &c->err);
+          if (c->err.code) return -1;
+          const uint8_t* pv = (const uint8_t*)c->pred->data; const uint8_t* pn = c->pred->nulls;
+          int64_t k = 0;
+          if (pn) { for (int64_t i = 0; i < c->cur.rows; ++i) if (!pn[i] && pv[i]) c->ids[k++] = i; }
+          else { for (int64_t i = 0; i < c->cur.rows; ++i) if (pv[i]) c->ids[k++] = i; }
+          c->nids = k; c->read_ptr = 0; c->have_cur = 1;
+        }
+      }
+      view_from_block(c, &c->block, 0, write_ptr, out);
+      return 1;
+    }
+    case C_SCALAR_AGG: {
+      /* ScalarAggregateCursor::Next, cursor/core/aggregate_scalar.cc:53-68: drain the child,
+       * UpdateAggregations(view, zeros); exactly one output row even on empty input */
+      if (c->done) return 0;
+      static const int64_t zeros[ORC_BLOCK] = {0};
+      reset_agg_rows(c, 0, 0, 1);
+      orc_view in; int r;
+      while ((r = cursor_next(c->child, ORC_BLOCK, &in)) > 0)
+        for (int j = 0; j < c->nagg; ++j) update_aggregation(&c->aggs[j], &in, zeros, c->block.data[j], c->block.nulls[j]);
+      if (r < 0) { c->err = c->child->err; return -1; }
+      c->done = 1;
+      view_from_block(c, &c->block, 0, 1, out);
+      return 1;
+    }
+    case C_GROUP_AGG: {
+      /* GroupAggregateCursor::ProcessInput, cursor/core/aggregate_groups.cc:332-433: consume
+       * ALL input, then iterate the result (keys || aggregates, first-seen order) */
+      if (!c->done) {
+        c->nbuckets = 32; c->bucket_head = NULL; c->out_rows = 0;
+        c->chain_next = (int64_t*)malloc(sizeof(int64_t) * (size_t)c->block.cap);
+        c->row_hash = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)c->block.cap);
+        group_rehash(c, c->nbuckets);
+        reset_agg_rows(c, c->nproj, 0, c->block.cap);
+        int64_t map[ORC_BLOCK]; orc_view in; int r;
+        while ((r = cursor_next(c->child, ORC_BLOCK, &in)) > 0) {
+          for (int64_t i = 0; i < in.rows; ++i) map[i] = group_insert(c, &in, i);
+          for (int j = 0; j < c->nagg; ++j) update_aggregation(&c->aggs[j], &in, map, c->block.data[c->nproj + j], c->block.nulls[c->nproj + j]);
+        }
+        if (r < 0) { c->err = c->child->err; return -1; }
+        c->done = 1; c->emit_pos = 0;
+      }
+      if (c->emit_pos >= c->out_rows) return 0;
+      int64_t n = c->out_rows - c->emit_pos; if (n > max_rows) n = max_rows;
+      view_from_block(c, &c->block, c->emit_pos, n, out);
+      c->emit_pos += n; return 1;
+    }
+    case C_CLUSTERS: {
+      /* AggregateClustersCursor, cursor/core/aggregate_clusters.cc:338-520: a new output row
+       * starts whenever any key column differs from the previous input row (ColumnEqual
+       * :97-122, NULL == NULL); streaming in the reference, materialised here (same rows) */
+      if (!c->done) {
+        c->out_rows = 0; reset_agg_rows(c, c->nproj, 0, c->block.cap);
+        int64_t map[ORC_BLOCK]; orc_view in; int r;
+        while ((r = cursor_next(c->child, ORC_BLOCK, &in)) > 0) {
+          for (int64_t i = 0; i < in.rows; ++i) {
+            int same = c->out_rows > 0 && key_equal(c, &in, i, c->out_rows - 1);
+            if (!same) {
+              if (c->out_rows >= c->block.cap) { int64_t old = c->block.cap; block_grow(&c->block, old * 2); reset_agg_rows(c, c->nproj, old, c->block.cap); }
+              for (int k = 0; k < c->nproj; ++k) {
+                const orc_col* col = &in.c[c->proj_pos[k]]; const int w = c->block.width[k];
+                memcpy((char*)c->block.data[k] + c->out_rows * w, (const char*)col->data + i * w, (size_t)w);
+                c->block.nulls[k][c->out_rows] = col->is_null ? col->is_null[i] : 0;
+              }
+              c->out_rows++;
+            }
+            map[i] = c->out_rows - 1;
+          }
+          for (int j = 0; j < c->nagg; ++j) update_aggregation(&c->aggs[j], &in, map, c->block.data[c->nproj + j], c->block.nulls[c->nproj + j]);
+        }
+        if (r < 0) { c->err = c->child->err; return -1; }
+        c->done = 1; c->emit_pos = 0;
+      }
+      if (c->emit_pos >= c->out_rows) return 0;
+      int64_t n = c->out_rows - c->emit_pos; if (n > max_rows) n = max_rows;
+      view_from_block(c, &c->block, c->emit_pos, n, out);
+      c->emit_pos += n; return 1;
+    }
+    case C_SORT: {
+      /* SortCursor::ProcessData, cursor/core/sort.cc:636-650: deep-copy the input into a Table,
+       * sort an int64 permutation, then gather 1024 rows per Next (view_cursor.cc:97-118) */
+      if (!c->done) {
+        orc_block* t = (orc_block*)calloc(1, sizeof(orc_block));
+        block_init(t, &c->child->schema, ORC_BLOCK);
+        int64_t rows = 0; orc_view in; int r;
+        while ((r = cursor_next(c->child, ORC_BLOCK, &in)) > 0) {
+          if (rows + in.rows > t->cap) block_grow(t, (rows + in.rows) * 2);
+          for (int k = 0; k < t->n; ++k) {
+            memcpy((char*)t->data[k] + rows * t->width[k], in.c[k].data, (size_t)in.rows * (size_t)t->width[k]);
+            if (in.c[k].is_null) memcpy(t->nulls[k] + rows, in.c[k].is_null, (size_t)in.rows); else memset(t->nulls[k] + rows, 0, (size_t)in.rows);
+          }
+          rows += in.rows;
+        }
+        if (r < 0) { c->err = c->child->err; return -1; }
+        c->perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)(rows > 0 ? rows : 1));
+        for (int64_t i = 0; i < rows; ++i) c->perm[i] = i;
+        sort_ctx s; s.c = c; s.t = t;
+        qsort_r(c->perm, (size_t)rows, sizeof(int64_t), sort_cmp, &s);
+        c->out_rows = rows; c->emit_pos = 0; c->done = 1;
+        block_init(&c->block, &c->schema, ORC_BLOCK);
+        c->table = t;
+      }
+      if (c->emit_pos >= c->out_rows) return 0;
+      int64_t n = c->out_rows - c->emit_pos; if (n > max_rows) n = max_rows;
+      const orc_block* t = (const orc_block*)c->table;
+      for (int k = 0; k < c->nproj; ++k) {
+        const int col = c->proj_pos[k]; const int w = t->width[col]; const int64_t* ids = c->perm + c->emit_pos;
+        for (int64_t i = 0; i < n; ++i) memcpy((char*)c->block.data[k] + i * w, (const char*)t->data[col] + ids[i] * w, (size_t)w);
+        for (int64_t i = 0; i < n; ++i) c->block.nulls[k][i] = t->nulls[col][ids[i]];
+      }
+      view_from_block(c, &c->block, 0, n, out);
+      c->emit_pos += n; return 1;
+    }
+  }
+  return -1;
+}
+
+/* ---- public pull API --------------------------------------------------------------- */
+int orc_next(orc_cursor* c, int64_t max_rows, int64_t* rows, const void** data, const uint8_t** is_null) {
+  orc_view v; memset(&v, 0, sizeof(v));
+  int r = cursor_next(c, max_rows, &v);
+  if (r <= 0) return r;
+  *rows = v.rows;
+  for (int i = 0; i < c->schema.n; ++i) { data[i] = v.c[i].data; is_null[i] = v.c[i].is_null; }
+  return 1;
+}
+
+/* drain a cursor completely, discarding rows: used by bench.py's cpu_baseline leg
+ * (returns the number of result rows, or -1 on failure) */
+int64_t orc_drain(orc_cursor* c) {
+  orc_view v; int r; int64_t total = 0;
+  while ((r = cursor_next(c, ORC_BLOCK, &v)) > 0) total += v.rows;
+  return r < 0 ? -1 : total;
+}

@@ -1,0 +1,150 @@
+"""ctypes binding of the C ABI in include/ssgpu.h (libssgpu.so).
+
+This is the reference-side stub a maintainer would write for a Python host: plain
+pointers and sizes, no torch types.  The library is built in-tree by
+``__graft_entry__.build()`` (``make -C supersonic_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libssgpu.so")
+
+# reference enum values (supersonic/proto/supersonic.proto:15-36,86-101)
+INT32, INT64, UINT64, DATETIME, DOUBLE, BOOL, UINT32, FLOAT, DATE, STRING, BINARY = 1, 2, 3, 4, 5, 6, 8, 9, 10, 0, 7
+NOT_NULLABLE, NULLABLE = 0, 1
+SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6
+ASCENDING, DESCENDING = 0, 1
+
+OK = 0
+ERROR_MEMORY_EXCEEDED = 102
+ERROR_NOT_IMPLEMENTED = 103
+ERROR_EVALUATION_ERROR = 104
+ERROR_TOO_MANY_ROWS = 302
+ERROR_ATTRIBUTE_COUNT_MISMATCH = 401
+ERROR_ATTRIBUTE_TYPE_MISMATCH = 402
+ERROR_ATTRIBUTE_MISSING = 403
+ERROR_ATTRIBUTE_EXISTS = 404
+ERROR_INVALID_ARGUMENT_TYPE = 405
+ERROR_INVALID_ARGUMENT_VALUE = 407
+INTERRUPTED = 1000
+ERROR_NO_DEVICE = 2000
+ERROR_HIP = 2001
+
+EXPR_ATTR_NAMED, EXPR_ATTR_AT, EXPR_CONST, EXPR_NULL, EXPR_OP, EXPR_ALIAS, EXPR_COMPOUND, EXPR_CAST = 1, 2, 3, 4, 5, 6, 7, 8
+OP_GREATER, OP_GREATER_OR_EQUAL = 100001, 100002
+PROJ_ALL, PROJ_NAMED, PROJ_AT, PROJ_NAMED_AS = 1, 2, 3, 4
+OP_SCAN, OP_COMPUTE, OP_FILTER, OP_PROJECT, OP_SCALAR_AGGREGATE, OP_GROUP_AGGREGATE, OP_AGGREGATE_CLUSTERS, OP_SORT = 1, 2, 3, 4, 5, 6, 7, 8
+
+
+class Attr(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("nullable", C.c_int32)]
+
+
+class Expr(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("dtype", C.c_int32), ("first_arg", C.c_int32),
+                ("nargs", C.c_int32), ("reserved", C.c_int32), ("i64", C.c_int64), ("f64", C.c_double),
+                ("name", C.c_char_p)]
+
+
+class Proj(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("position", C.c_int32), ("name", C.c_char_p), ("alias", C.c_char_p)]
+
+
+class Agg(C.Structure):
+    _fields_ = [("aggregation", C.c_int32), ("distinct", C.c_int32), ("output_type", C.c_int32),
+                ("reserved", C.c_int32), ("input", C.c_char_p), ("output", C.c_char_p)]
+
+
+class SortKey(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("order", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("child", C.c_int32), ("expr", C.c_int32), ("proj_first", C.c_int32),
+                ("proj_n", C.c_int32), ("agg_first", C.c_int32), ("agg_n", C.c_int32), ("sort_first", C.c_int32),
+                ("sort_n", C.c_int32), ("reserved", C.c_int32), ("option0", C.c_int64)]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("input_schema", C.POINTER(Attr)), ("n_attrs", C.c_int32),
+                ("ops", C.POINTER(Op)), ("n_ops", C.c_int32),
+                ("exprs", C.POINTER(Expr)), ("n_exprs", C.c_int32),
+                ("expr_args", C.POINTER(C.c_int32)), ("n_expr_args", C.c_int32),
+                ("projs", C.POINTER(Proj)), ("n_projs", C.c_int32),
+                ("aggs", C.POINTER(Agg)), ("n_aggs", C.c_int32),
+                ("sortkeys", C.POINTER(SortKey)), ("n_sortkeys", C.c_int32)]
+
+
+class Column(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("is_null", C.c_void_p)]
+
+
+class PartialSegment(C.Structure):
+    _fields_ = [("device_ptr", C.c_void_p), ("count", C.c_int64), ("dtype", C.c_int32), ("reduce", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("dominant_ms", C.c_double), ("rows_in", C.c_int64),
+                ("rows_out", C.c_int64), ("algorithmic_bytes", C.c_int64), ("n_launches", C.c_int32),
+                ("tile_rows", C.c_int32), ("grid", C.c_int32), ("lds_bytes", C.c_int32)]
+
+
+# every symbol include/ssgpu.h declares: (name, restype, argtypes)
+P = C.c_void_p
+SYMBOLS = [
+    ("ssgpu_abi_version", C.c_int, []),
+    ("ssgpu_ctx_create", C.c_int, [C.c_int, C.POINTER(P)]),
+    ("ssgpu_ctx_destroy", None, [P]),
+    ("ssgpu_last_error", C.c_char_p, [P]),
+    ("ssgpu_ctx_stream", P, [P]),
+    ("ssgpu_ctx_copy_stream", P, [P]),
+    ("ssgpu_ctx_set_stream", C.c_int, [P, P]),
+    ("ssgpu_ctx_synchronize", C.c_int, [P]),
+    ("ssgpu_ctx_set_option", C.c_int, [P, C.c_char_p, C.c_int64]),
+    ("ssgpu_host_alloc", C.c_int, [P, C.c_size_t, C.POINTER(P)]),
+    ("ssgpu_host_free", None, [P, P]),
+    ("ssgpu_block_create", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.c_int64, C.POINTER(P)]),
+    ("ssgpu_block_destroy", None, [P]),
+    ("ssgpu_block_upload", C.c_int, [P, C.c_int32, P, P, C.c_int64, C.c_int64]),
+    ("ssgpu_block_set_row_count", C.c_int, [P, C.c_int64]),
+    ("ssgpu_block_row_count", C.c_int64, [P]),
+    ("ssgpu_block_column", C.c_int, [P, C.c_int32, C.POINTER(Column)]),
+    ("ssgpu_plan_create", C.c_int, [P, C.POINTER(PlanDesc), C.POINTER(P)]),
+    ("ssgpu_plan_destroy", None, [P]),
+    ("ssgpu_plan_attr_count", C.c_int32, [P]),
+    ("ssgpu_plan_attr", C.c_int, [P, C.c_int32, C.POINTER(Attr)]),
+    ("ssgpu_plan_describe", C.c_char_p, [P]),
+    ("ssgpu_plan_program", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("ssgpu_plan_run", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(P)]),
+    ("ssgpu_plan_run_block", C.c_int, [P, P, C.POINTER(P)]),
+    ("ssgpu_interrupt", None, [P]),
+    ("ssgpu_plan_run_partial", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64]),
+    ("ssgpu_plan_partial_segments", C.c_int32, [P, C.POINTER(PartialSegment), C.c_int32]),
+    ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
+    ("ssgpu_result_destroy", None, [P]),
+    ("ssgpu_result_row_count", C.c_int64, [P]),
+    ("ssgpu_result_column_count", C.c_int32, [P]),
+    ("ssgpu_result_column", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(P)]),
+    ("ssgpu_result_device_column", C.c_int, [P, C.c_int32, C.POINTER(Column)]),
+    ("ssgpu_plan_counters", C.c_int, [P, C.POINTER(Counters)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libssgpu.so; fails loudly if the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libssgpu.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` -- "
+                "there is no CPU fallback for the product path" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the library does not export the ABI
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,729 @@
+"""Host-side mirror of Supersonic's Expression / Operation / Cursor builder API
+(supersonic/supersonic.h) over the C ABI of libssgpu.so.
+
+Names, argument meaning and error behaviour follow the reference so that the
+parity tests read like the reference's own tests:
+
+    schema = TupleSchema([Attribute("a", INT64, NOT_NULLABLE), ...])
+    op = ScalarAggregate(AggregationSpecification().AddAggregation(SUM, "s", "sum_s"),
+             Filter(Greater(NamedAttribute("a"), ConstInt64(499)), ProjectAllAttributes(),
+                 Compute(CompoundExpression().Add(NamedAttribute("a"))
+                                             .AddAs("s", Plus(NamedAttribute("a"), NamedAttribute("b"))),
+                         ScanView(view))))
+    cursor = op.CreateCursor()          # binds: raises SupersonicException(return_code, message)
+    result = cursor.Next(1024)          # ResultView: has_data() / is_eos() / view()
+
+Execution is whole-shard on the GPU; Next() only slices the
+finished result, as ViewIterator does (cursor/infrastructure/iterators.h:64).
+There is no CPU execution path here: without libssgpu.so or without a device,
+running a plan raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import (INT32, INT64, UINT32, UINT64, FLOAT, DOUBLE, BOOL, DATE, DATETIME, STRING, BINARY,  # noqa: F401
+                   NOT_NULLABLE, NULLABLE, SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST, ASCENDING, DESCENDING)
+
+kDefaultRowCount = 1024  # Cursor::kDefaultRowCount, cursor/base/cursor.h:133
+
+_NP = {INT32: np.int32, INT64: np.int64, UINT32: np.uint32, UINT64: np.uint64, FLOAT: np.float32,
+       DOUBLE: np.float64, BOOL: np.bool_, DATE: np.int32, DATETIME: np.int64}
+_TYPE_NAMES = {INT32: "INT32", INT64: "INT64", UINT32: "UINT32", UINT64: "UINT64", FLOAT: "FLOAT",
+               DOUBLE: "DOUBLE", BOOL: "BOOL", DATE: "DATE", DATETIME: "DATETIME", STRING: "STRING",
+               BINARY: "BINARY"}
+
+
+def numpy_dtype(data_type):
+    return _NP[data_type]
+
+
+class SupersonicException(Exception):
+    """Exception{return_code, message} (supersonic/base/exception/exception.h:53)."""
+
+    def __init__(self, return_code, message):
+        Exception.__init__(self, "[%d] %s" % (return_code, message))
+        self.return_code = return_code
+        self.message = message
+
+
+# --------------------------------------------------------------------------- context
+class Context(object):
+    _default = None
+
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.ssgpu_ctx_create(device, C.byref(h))
+        if rc != L.OK:
+            raise SupersonicException(rc, "cannot create a context on device %d" % device)
+        self.handle = h
+        self.device = device
+
+    @classmethod
+    def default(cls):
+        """Device 0 if there is a GPU, else a bind-only context (plans bind, runs fail)."""
+        if cls._default is None:
+            try:
+                cls._default = Context(0)
+            except SupersonicException:
+                cls._default = Context(-1)
+        return cls._default
+
+    def set_option(self, key, value):
+        rc = self.lib.ssgpu_ctx_set_option(self.handle, key.encode(), int(value))
+        self.check(rc)
+
+    def stream(self):
+        return self.lib.ssgpu_ctx_stream(self.handle)
+
+    def set_stream(self, hip_stream):
+        self.check(self.lib.ssgpu_ctx_set_stream(self.handle, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        self.check(self.lib.ssgpu_ctx_synchronize(self.handle))
+
+    def last_error(self):
+        return (self.lib.ssgpu_last_error(self.handle) or b"").decode()
+
+    def check(self, rc):
+        if rc != L.OK:
+            raise SupersonicException(rc, self.last_error())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ssgpu_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------- schema
+class Attribute(object):
+    def __init__(self, name, data_type, nullability=NOT_NULLABLE):
+        self._name, self._type, self._nullability = name, data_type, nullability
+
+    def name(self):
+        return self._name
+
+    def type(self):
+        return self._type
+
+    def nullability(self):
+        return self._nullability
+
+    def is_nullable(self):
+        return self._nullability == NULLABLE
+
+    def __eq__(self, o):
+        return (self._name, self._type, self._nullability) == (o._name, o._type, o._nullability)
+
+    def __repr__(self):
+        return "%s: %s%s" % (self._name, _TYPE_NAMES.get(self._type, "?"), "" if self.is_nullable() else " NOT NULL")
+
+
+class TupleSchema(object):
+    def __init__(self, attributes=()):
+        self._attrs = []
+        for a in attributes:
+            if not self.add_attribute(a):
+                raise SupersonicException(L.ERROR_ATTRIBUTE_EXISTS, "duplicate attribute %s" % a.name())
+
+    @staticmethod
+    def Singleton(name, data_type, nullability):
+        return TupleSchema([Attribute(name, data_type, nullability)])
+
+    def add_attribute(self, attribute):
+        if self.LookupAttributePosition(attribute.name()) >= 0:
+            return False
+        self._attrs.append(attribute)
+        return True
+
+    def attribute_count(self):
+        return len(self._attrs)
+
+    def attribute(self, i):
+        return self._attrs[i]
+
+    def LookupAttributePosition(self, name):
+        for i, a in enumerate(self._attrs):
+            if a.name() == name:
+                return i
+        return -1
+
+    def __eq__(self, o):
+        return self._attrs == o._attrs
+
+    def __repr__(self):
+        return ", ".join(repr(a) for a in self._attrs)
+
+
+class Column(object):
+    """One column of a host View: typed data + optional bool is_null (block.h:55-192)."""
+
+    def __init__(self, data, is_null=None):
+        self.data = data
+        self.is_null = is_null
+
+
+class View(object):
+    """Host-side View: N (data, is_null) pairs + row_count (block.h:288-402)."""
+
+    def __init__(self, schema, columns, row_count=None):
+        self._schema = schema
+        cols = []
+        for i, c in enumerate(columns):
+            if not isinstance(c, Column):
+                c = Column(*c) if isinstance(c, tuple) else Column(c)
+            dt = _NP[schema.attribute(i).type()]
+            data = np.ascontiguousarray(c.data, dtype=dt)
+            nulls = None if c.is_null is None else np.ascontiguousarray(c.is_null, dtype=np.bool_)
+            cols.append(Column(data, nulls))
+        self._cols = cols
+        self._rows = int(row_count if row_count is not None else (len(cols[0].data) if cols else 0))
+
+    def schema(self):
+        return self._schema
+
+    def row_count(self):
+        return self._rows
+
+    def column_count(self):
+        return len(self._cols)
+
+    def column(self, i):
+        return self._cols[i]
+
+
+class DeviceView(object):
+    """Columns already resident in HBM: (data_ptr, is_null_ptr or 0) integers."""
+
+    def __init__(self, schema, pointers, row_count):
+        self._schema, self._ptrs, self._rows = schema, list(pointers), int(row_count)
+
+    def schema(self):
+        return self._schema
+
+    def row_count(self):
+        return self._rows
+
+
+# ------------------------------------------------------------------------ expressions
+class Expression(object):
+    def __init__(self, kind, op=0, dtype=0, args=(), i64=0, f64=0.0, name=None):
+        self.kind, self.op, self.dtype, self.args, self.i64, self.f64, self.name = kind, op, dtype, list(args), i64, f64, name
+
+
+def NamedAttribute(name):
+    return Expression(L.EXPR_ATTR_NAMED, name=name)
+
+
+def AttributeAt(position):
+    return Expression(L.EXPR_ATTR_AT, i64=position)
+
+
+def _const(dtype, i64=0, f64=0.0):
+    return Expression(L.EXPR_CONST, dtype=dtype, i64=int(i64), f64=float(f64))
+
+
+def ConstInt32(v): return _const(INT32, i64=v)
+def ConstInt64(v): return _const(INT64, i64=v)
+def ConstUint32(v): return _const(UINT32, i64=v)
+def ConstUint64(v): return _const(UINT64, i64=np.array(v, dtype=np.uint64).astype(np.int64))
+def ConstFloat(v): return _const(FLOAT, f64=v)
+def ConstDouble(v): return _const(DOUBLE, f64=v)
+def ConstBool(v): return _const(BOOL, i64=1 if v else 0)
+def ConstDate(v): return _const(DATE, i64=v)
+def ConstDateTime(v): return _const(DATETIME, i64=v)
+def Null(data_type): return Expression(L.EXPR_NULL, dtype=data_type)
+
+
+def _op(op, *args):
+    return Expression(L.EXPR_OP, op=op, args=args)
+
+
+# OperatorId values: supersonic/expression/proto/operators.proto
+def Plus(a, b): return _op(0, a, b)
+def Multiply(a, b): return _op(4, a, b)
+def Minus(a, b): return _op(8, a, b)
+def DivideQuiet(a, b): return _op(13, a, b)
+def DivideNulling(a, b): return _op(14, a, b)
+def DivideSignaling(a, b): return _op(15, a, b)
+def Divide(a, b): return DivideSignaling(a, b)  # arithmetic_expressions.cc:104-107
+def CppDivideNulling(a, b): return _op(18, a, b)
+def CppDivideSignaling(a, b): return _op(19, a, b)
+def CppDivide(a, b): return CppDivideSignaling(a, b)
+def ModulusNulling(a, b): return _op(26, a, b)
+def ModulusSignaling(a, b): return _op(27, a, b)
+def Modulus(a, b): return ModulusSignaling(a, b)
+def Negate(a): return _op(36, a)
+def And(a, b): return _op(40, a, b)
+def Or(a, b): return _op(44, a, b)
+def AndNot(a, b): return _op(48, a, b)
+def Not(a): return _op(52, a)
+def Xor(a, b): return _op(56, a, b)
+def BitwiseAnd(a, b): return _op(60, a, b)
+def BitwiseOr(a, b): return _op(64, a, b)
+def BitwiseNot(a): return _op(68, a)
+def BitwiseXor(a, b): return _op(72, a, b)
+def ShiftLeft(a, b): return _op(76, a, b)
+def ShiftRight(a, b): return _op(80, a, b)
+def BitwiseAndNot(a, b): return _op(84, a, b)
+def Equal(a, b): return _op(100, a, b)
+def NotEqual(a, b): return _op(104, a, b)
+def Less(a, b): return _op(116, a, b)
+def LessOrEqual(a, b): return _op(120, a, b)
+def Greater(a, b): return _op(L.OP_GREATER, a, b)
+def GreaterOrEqual(a, b): return _op(L.OP_GREATER_OR_EQUAL, a, b)
+def If(c, t, e): return _op(204, c, t, e)
+def IfNull(a, b): return _op(220, a, b)
+def IsNull(a): return _op(224, a)
+def CastTo(data_type, a): return Expression(L.EXPR_CAST, dtype=data_type, args=[a])
+def Alias(new_name, a): return Expression(L.EXPR_ALIAS, name=new_name, args=[a])
+
+
+class CompoundExpression(Expression):
+    def __init__(self):
+        Expression.__init__(self, L.EXPR_COMPOUND)
+
+    def Add(self, argument):
+        self.args.append(argument)
+        return self
+
+    def AddAs(self, alias, argument):
+        self.args.append(Alias(alias, argument))
+        return self
+
+
+# ------------------------------------------------------------------------- projectors
+class SingleSourceProjector(object):
+    def __init__(self, entries):
+        self.entries = list(entries)  # (kind, position, name, alias)
+
+
+def ProjectAllAttributes(): return SingleSourceProjector([(L.PROJ_ALL, 0, None, None)])
+def ProjectNamedAttribute(name): return SingleSourceProjector([(L.PROJ_NAMED, 0, name, None)])
+def ProjectNamedAttributeAs(name, alias): return SingleSourceProjector([(L.PROJ_NAMED_AS, 0, name, alias)])
+def ProjectAttributeAt(position): return SingleSourceProjector([(L.PROJ_AT, position, None, None)])
+def ProjectNamedAttributes(names): return SingleSourceProjector([(L.PROJ_NAMED, 0, n, None) for n in names])
+
+
+class CompoundSingleSourceProjector(SingleSourceProjector):
+    def __init__(self):
+        SingleSourceProjector.__init__(self, [])
+
+    def add(self, projector):
+        self.entries.extend(projector.entries)
+        return self
+
+
+class AggregationSpecification(object):
+    """cursor/core/aggregate.h:28-130."""
+
+    def __init__(self):
+        self.elements = []
+
+    def AddAggregation(self, aggregation, input_name, output_name):
+        self.elements.append((aggregation, 0, -1, input_name, output_name))
+        return self
+
+    def AddDistinctAggregation(self, aggregation, input_name, output_name):
+        self.elements.append((aggregation, 1, -1, input_name, output_name))
+        return self
+
+    def AddAggregationWithDefinedOutputType(self, aggregation, input_name, output_name, output_type):
+        self.elements.append((aggregation, 0, output_type, input_name, output_name))
+        return self
+
+
+class GroupAggregateOptions(object):
+    def __init__(self):
+        self.max_unique_keys_in_result = 0
+
+
+class SortOrder(object):
+    """cursor/infrastructure/ordering.h:48-101."""
+
+    def __init__(self):
+        self.keys = []
+
+    def add(self, projector_or_name, column_order):
+        if isinstance(projector_or_name, SingleSourceProjector):
+            for (_k, _p, name, _a) in projector_or_name.entries:
+                self.keys.append((name, column_order))
+        else:
+            self.keys.append((projector_or_name, column_order))
+        return self
+
+
+# ------------------------------------------------------------------------- operations
+class _Builder(object):
+    """Flattens an operation tree into the ssgpu_plan_desc arrays."""
+
+    def __init__(self):
+        self.exprs, self.expr_args, self.projs, self.aggs, self.sortkeys, self.ops = [], [], [], [], [], []
+        self.keep = []
+        self.scan = None
+
+    def s(self, text):
+        if text is None:
+            return None
+        b = text.encode() if isinstance(text, str) else text
+        self.keep.append(b)
+        return b
+
+    def expr(self, e):
+        child = [self.expr(a) for a in e.args]
+        first = len(self.expr_args)
+        self.expr_args.extend(child)
+        x = L.Expr(e.kind, e.op, e.dtype, first, len(child), 0, int(e.i64), float(e.f64), self.s(e.name))
+        self.exprs.append(x)
+        return len(self.exprs) - 1
+
+    def proj(self, p):
+        first = len(self.projs)
+        for (k, pos, name, alias) in p.entries:
+            self.projs.append(L.Proj(k, pos, self.s(name), self.s(alias)))
+        return first, len(p.entries)
+
+    def aggspec(self, spec):
+        first = len(self.aggs)
+        for (agg, distinct, otype, inp, outp) in spec.elements:
+            self.aggs.append(L.Agg(agg, distinct, otype, 0, self.s(inp), self.s(outp)))
+        return first, len(spec.elements)
+
+    def sort(self, order):
+        first = len(self.sortkeys)
+        for (name, o) in order.keys:
+            self.sortkeys.append(L.SortKey(self.s(name), o, 0))
+        return first, len(order.keys)
+
+    def op(self, **kw):
+        o = L.Op(kw.get("kind"), kw.get("child", -1), kw.get("expr", -1), kw.get("proj_first", 0), kw.get("proj_n", 0),
+                 kw.get("agg_first", 0), kw.get("agg_n", 0), kw.get("sort_first", 0), kw.get("sort_n", 0), 0,
+                 kw.get("option0", 0))
+        self.ops.append(o)
+        return len(self.ops) - 1
+
+
+class Operation(object):
+    def _emit(self, b):
+        raise NotImplementedError
+
+    def CreateCursor(self, context=None):
+        """Operation::CreateCursor (cursor/base/operation.h:62): binds the whole tree."""
+        return Cursor(self, context or Context.default())
+
+
+class ScanView(Operation):
+    def __init__(self, view):
+        self.view = view
+
+    def _emit(self, b):
+        b.scan = self.view
+        return b.op(kind=L.OP_SCAN)
+
+
+class Compute(Operation):
+    def __init__(self, expression, child):
+        self.expression, self.child = expression, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        return b.op(kind=L.OP_COMPUTE, child=c, expr=b.expr(self.expression))
+
+
+class Project(Operation):
+    def __init__(self, projector, child):
+        self.projector, self.child = projector, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        pf, pn = b.proj(self.projector)
+        return b.op(kind=L.OP_PROJECT, child=c, proj_first=pf, proj_n=pn)
+
+
+class Filter(Operation):
+    def __init__(self, predicate, projector, child):
+        self.predicate, self.projector, self.child = predicate, projector, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        pf, pn = b.proj(self.projector)
+        return b.op(kind=L.OP_FILTER, child=c, expr=b.expr(self.predicate), proj_first=pf, proj_n=pn)
+
+
+class ScalarAggregate(Operation):
+    def __init__(self, aggregation_specification, child):
+        self.spec, self.child = aggregation_specification, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        af, an = b.aggspec(self.spec)
+        return b.op(kind=L.OP_SCALAR_AGGREGATE, child=c, agg_first=af, agg_n=an)
+
+
+class GroupAggregate(Operation):
+    def __init__(self, group_by, aggregation, options, child):
+        self.group_by, self.spec, self.options, self.child = group_by, aggregation, options, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        pf, pn = b.proj(self.group_by)
+        af, an = b.aggspec(self.spec)
+        return b.op(kind=L.OP_GROUP_AGGREGATE, child=c, proj_first=pf, proj_n=pn, agg_first=af, agg_n=an,
+                    option0=(self.options.max_unique_keys_in_result if self.options else 0))
+
+
+class AggregateClusters(Operation):
+    def __init__(self, clustered_by_columns, aggregation, child):
+        self.group_by, self.spec, self.child = clustered_by_columns, aggregation, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        pf, pn = b.proj(self.group_by)
+        af, an = b.aggspec(self.spec)
+        return b.op(kind=L.OP_AGGREGATE_CLUSTERS, child=c, proj_first=pf, proj_n=pn, agg_first=af, agg_n=an)
+
+
+class Sort(Operation):
+    def __init__(self, sort_order, result_projector, memory_limit, child):
+        self.order, self.projector, self.memory_limit, self.child = sort_order, result_projector, memory_limit, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        pf, pn = b.proj(self.projector if self.projector is not None else ProjectAllAttributes())
+        sf, sn = b.sort(self.order)
+        return b.op(kind=L.OP_SORT, child=c, proj_first=pf, proj_n=pn, sort_first=sf, sort_n=sn,
+                    option0=int(self.memory_limit or 0))
+
+
+def _array(ctype, items):
+    arr = (ctype * max(len(items), 1))()
+    for i, it in enumerate(items):
+        arr[i] = it
+    return arr
+
+
+class Plan(object):
+    """A bound plan (ssgpu_plan): owns the device programs and result buffers."""
+
+    def __init__(self, operation, context):
+        self.ctx = context
+        self.lib = context.lib
+        b = _Builder()
+        operation._emit(b)
+        if b.scan is None:
+            raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "plan has no ScanView")
+        self.input = b.scan
+        schema = b.scan.schema()
+        attrs = [L.Attr(b.s(schema.attribute(i).name()), schema.attribute(i).type(), schema.attribute(i).nullability())
+                 for i in range(schema.attribute_count())]
+        self._keep = b
+        d = L.PlanDesc()
+        self._arrays = [_array(L.Attr, attrs), _array(L.Op, b.ops), _array(L.Expr, b.exprs),
+                        _array(C.c_int32, b.expr_args), _array(L.Proj, b.projs), _array(L.Agg, b.aggs),
+                        _array(L.SortKey, b.sortkeys)]
+        d.input_schema, d.n_attrs = self._arrays[0], len(attrs)
+        d.ops, d.n_ops = self._arrays[1], len(b.ops)
+        d.exprs, d.n_exprs = self._arrays[2], len(b.exprs)
+        d.expr_args, d.n_expr_args = self._arrays[3], len(b.expr_args)
+        d.projs, d.n_projs = self._arrays[4], len(b.projs)
+        d.aggs, d.n_aggs = self._arrays[5], len(b.aggs)
+        d.sortkeys, d.n_sortkeys = self._arrays[6], len(b.sortkeys)
+        h = C.c_void_p()
+        rc = self.lib.ssgpu_plan_create(context.handle, C.byref(d), C.byref(h))
+        context.check(rc)
+        self.handle = h
+        n = self.lib.ssgpu_plan_attr_count(h)
+        out = []
+        for i in range(n):
+            a = L.Attr()
+            self.lib.ssgpu_plan_attr(h, i, C.byref(a))
+            out.append(Attribute(a.name.decode(), a.dtype, a.nullable))
+        self.result_schema = TupleSchema(out)
+        self._block = None
+        self._block_key = None
+
+    def describe(self):
+        return self.lib.ssgpu_plan_describe(self.handle).decode()
+
+    def program(self, stage=0):
+        """Raw VM instructions of a stage (debug hook used by tests/vm_emulator.py)."""
+        ptr, n, nb = C.c_void_p(), C.c_int32(), C.c_int32()
+        self.ctx.check(self.lib.ssgpu_plan_program(self.handle, stage, C.byref(ptr), C.byref(n), C.byref(nb)))
+        return C.string_at(ptr, n.value * nb.value), n.value, nb.value
+
+    # -- input staging ------------------------------------------------------------
+    def _columns_for(self, view):
+        if isinstance(view, DeviceView):
+            cols = (L.Column * max(len(view._ptrs), 1))()
+            for i, (dp, npn) in enumerate(view._ptrs):
+                cols[i].data = dp
+                cols[i].is_null = npn or None
+            return cols, len(view._ptrs), view.row_count()
+        # host View: stage into a device Block on the copy stream (pinned staging is the
+        # caller's choice; numpy memory is pageable, which only makes the copy synchronous)
+        key = id(view)
+        if self._block is None or self._block_key != key:
+            if self._block is not None:
+                self.lib.ssgpu_block_destroy(self._block)
+                self._block = None
+            schema = view.schema()
+            attrs = _array(L.Attr, [L.Attr(schema.attribute(i).name().encode(), schema.attribute(i).type(),
+                                           schema.attribute(i).nullability()) for i in range(schema.attribute_count())])
+            blk = C.c_void_p()
+            self.ctx.check(self.lib.ssgpu_block_create(self.ctx.handle, attrs, schema.attribute_count(),
+                                                       max(view.row_count(), 1), C.byref(blk)))
+            for i in range(view.column_count()):
+                col = view.column(i)
+                nulls = col.is_null
+                if view.row_count():
+                    self.ctx.check(self.lib.ssgpu_block_upload(
+                        blk, i, col.data.ctypes.data_as(C.c_void_p),
+                        None if nulls is None else nulls.ctypes.data_as(C.c_void_p), 0, view.row_count()))
+            self.lib.ssgpu_block_set_row_count(blk, view.row_count())
+            self.ctx.synchronize()
+            self._block, self._block_key = blk, key
+        n = view.schema().attribute_count()
+        cols = (L.Column * max(n, 1))()
+        for i in range(n):
+            self.lib.ssgpu_block_column(self._block, i, C.byref(cols[i]))
+        return cols, n, view.row_count()
+
+    # -- execution ------------------------------------------------------------------
+    def run(self, view=None):
+        cols, n, rows = self._columns_for(view if view is not None else self.input)
+        res = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_plan_run(self.handle, cols, n, rows, C.byref(res)))
+        self._result = res
+        return res
+
+    def run_partial(self, view, global_row_offset=0):
+        cols, n, rows = self._columns_for(view)
+        self.ctx.check(self.lib.ssgpu_plan_run_partial(self.handle, cols, n, rows, global_row_offset))
+        segs = (L.PartialSegment * 16)()
+        k = self.lib.ssgpu_plan_partial_segments(self.handle, segs, 16)
+        return [(segs[i].device_ptr, segs[i].count, segs[i].dtype, segs[i].reduce) for i in range(k)]
+
+    def finalize(self):
+        res = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_plan_finalize(self.handle, C.byref(res)))
+        self._result = res
+        return res
+
+    def fetch(self, res=None):
+        """Copy the result to host: a View over numpy arrays."""
+        res = res or self._result
+        rows = self.lib.ssgpu_result_row_count(res)
+        if rows < 0:
+            raise SupersonicException(L.ERROR_HIP, self.ctx.last_error())
+        cols = []
+        for i in range(self.result_schema.attribute_count()):
+            a = self.result_schema.attribute(i)
+            dp, npn = C.c_void_p(), C.c_void_p()
+            self.ctx.check(self.lib.ssgpu_result_column(res, i, C.byref(dp), C.byref(npn)))
+            dt = np.dtype(_NP[a.type()])
+            data = np.frombuffer(C.string_at(dp, rows * dt.itemsize), dtype=dt).copy() if rows else np.zeros(0, dt)
+            nulls = None
+            if a.is_nullable():
+                nulls = (np.frombuffer(C.string_at(npn, rows), dtype=np.uint8).copy() != 0) if rows else np.zeros(0, bool)
+            cols.append(Column(data, nulls))
+        return View(self.result_schema, cols, rows)
+
+    def counters(self):
+        c = L.Counters()
+        self.ctx.check(self.lib.ssgpu_plan_counters(self.handle, C.byref(c)))
+        return c
+
+    def interrupt(self):
+        self.lib.ssgpu_interrupt(self.handle)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_block", None):
+                self.lib.ssgpu_block_destroy(self._block)
+            if getattr(self, "handle", None):
+                self.lib.ssgpu_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ResultView(object):
+    """cursor/base/cursor.h:42-122."""
+
+    def __init__(self, view=None, eos=False, exception=None):
+        self._view, self._eos, self._exc = view, eos, exception
+
+    def has_data(self):
+        return self._view is not None
+
+    def is_eos(self):
+        return self._eos
+
+    def is_failure(self):
+        return self._exc is not None
+
+    def view(self):
+        return self._view
+
+    def exception(self):
+        return self._exc
+
+
+class Cursor(object):
+    """cursor/base/cursor.h:131-226.  The pipeline runs on the first Next()."""
+
+    def __init__(self, operation, context):
+        self.plan = Plan(operation, context)
+        self._result = None
+        self._pos = 0
+        self._interrupted = False
+
+    def schema(self):
+        return self.plan.result_schema
+
+    def Interrupt(self):
+        self._interrupted = True
+        self.plan.interrupt()
+
+    def Next(self, max_row_count=kDefaultRowCount):
+        if self._result is None:
+            try:
+                self.plan.run()
+                self._result = self.plan.fetch()
+            except SupersonicException as e:
+                return ResultView(exception=e)
+        total = self._result.row_count()
+        if self._pos >= total:
+            return ResultView(eos=True)
+        n = min(int(max_row_count), total - self._pos)
+        lo, hi = self._pos, self._pos + n
+        self._pos = hi
+        cols = [Column(c.data[lo:hi], None if c.is_null is None else c.is_null[lo:hi]) for c in self._result._cols]
+        return ResultView(view=View(self._result.schema(), cols, n))
+
+
+def drain(cursor, max_row_count=kDefaultRowCount):
+    """Pull a cursor to EOS and concatenate the views (test helper, cf. ViewCopier)."""
+    parts = []
+    while True:
+        r = cursor.Next(max_row_count)
+        if r.is_failure():
+            raise r.exception()
+        if r.is_eos():
+            break
+        parts.append(r.view())
+    schema = cursor.schema()
+    cols = []
+    for i in range(schema.attribute_count()):
+        dt = _NP[schema.attribute(i).type()]
+        data = np.concatenate([p.column(i).data for p in parts]) if parts else np.zeros(0, dt)
+        nulls = None
+        if schema.attribute(i).is_nullable():
+            nulls = np.concatenate([p.column(i).is_null for p in parts]) if parts else np.zeros(0, bool)
+        cols.append(Column(data, nulls))
+    return View(schema, cols, sum(p.row_count() for p in parts))

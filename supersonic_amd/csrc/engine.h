@@ -1,0 +1,159 @@
+// engine.h -- host-side plan model: schema, bound expressions, lowered stages.
+//
+// The binder restates Supersonic's bind-time behaviour (type promotion, result
+// names, nullability, bind errors); the lowering pass turns a chain of
+// Scan/Compute/Project/Filter operations ending in a blocking operator into one
+// tile-VM program (vm.h).  Host code only: nothing here touches row data.
+#ifndef SSGPU_ENGINE_H_
+#define SSGPU_ENGINE_H_
+
+#include <stdint.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ssgpu.h"
+#include "vm.h"
+#include "launch.h"
+
+namespace ssgpu {
+
+struct Status {
+  int code = SSGPU_OK;
+  std::string msg;
+  bool ok() const { return code == SSGPU_OK; }
+  static Status OK() { return Status(); }
+  static Status Error(int c, const std::string& m) { Status s; s.code = c; s.msg = m; return s; }
+};
+#define SS_RETURN_IF_ERROR(expr) do { ::ssgpu::Status _s = (expr); if (!_s.ok()) return _s; } while (0)
+
+struct Attr {
+  std::string name;
+  int dtype = SSGPU_INT64;
+  bool nullable = false;
+};
+typedef std::vector<Attr> Schema;
+
+const char* dtype_name(int dtype);
+int dtype_width(int dtype);          // bytes per row on device; 0 = unsupported (STRING/BINARY)
+bool dtype_is_integer(int dtype);
+bool dtype_is_numeric(int dtype);
+bool dtype_is_float(int dtype);
+bool dtype_is_signed_int(int dtype);
+std::string schema_to_string(const Schema& s);
+
+// ---- bound expression (single attribute) ------------------------------------
+struct BExpr;
+typedef std::shared_ptr<BExpr> BExprP;
+struct BExpr {
+  enum Kind { INPUT, CONST, NULLCONST, OP, CAST } kind = INPUT;
+  int op = 0;          // reference OperatorId for OP
+  int dtype = SSGPU_INT64;
+  bool nullable = false;
+  std::string name;
+  int input_col = -1;  // INPUT: column of the stage input
+  uint64_t bits = 0;   // CONST: raw value bits in the column's device width
+  int filter_depth = 0;  // number of Filter operations below this expression
+  std::vector<BExprP> args;
+};
+
+// ---- lowered pipeline stage ---------------------------------------------------
+enum StageKind {
+  STAGE_SCALAR_AGG = 1,   // pipeline -> scalar aggregate slots -> 1 row
+  STAGE_MATERIALIZE = 2,  // pipeline -> output columns (1:1 or compacted by a filter)
+  STAGE_GROUP_AGG = 3,    // pipeline -> device hash table -> group rows
+  STAGE_SORT = 4,         // radix sort of the stage input by key columns
+  STAGE_CLUSTERS = 5      // segmented aggregate over pre-clustered keys
+};
+
+struct AggOut {        // one aggregate result column
+  int slot;            // accumulator slot (scalar) / index in the per-group record (group)
+  int slot_kind;       // SlotKind
+  int emit_kind;       // EmitKind
+  bool has_cnt;        // group: contribution count tracked (nullable input)
+  bool result_nullable;
+};
+
+struct GroupKeyField { int out_col; uint32_t shift, bits, nullbit, width; };
+
+struct SortKey { int col; int order; };
+
+// Lowered instruction over virtual registers.  A register is an LDS array of
+// tile_rows elements; its LDS byte offset is row_off * tile_rows, fixed when the
+// tile size is chosen (finalize_program).
+struct LReg { uint32_t width; uint32_t row_off; };
+struct LInstr {
+  uint16_t op = 0;
+  bool a_imm = false, b_imm = false;
+  bool dst_is_reg = true;   // false: dst is a slot / output-column index
+  int dst = -1;
+  int a = -1, b = -1, c = -1, d = -1, e = -1;  // register ids, -1 = none
+  uint64_t imm = 0;
+};
+struct StagedInput { int col; bool is_null_mask; int reg; };
+
+struct Program {
+  std::vector<LInstr> code;
+  std::vector<LReg> regs;
+  std::vector<StagedInput> staged;
+  uint32_t bytes_per_row = 0;   // LDS bytes per tile row (peak of live registers)
+  int n_slots = 0;
+  int n_outputs = 0;
+  bool empty() const { return code.empty(); }
+};
+
+struct Stage {
+  StageKind kind = STAGE_MATERIALIZE;
+  Schema in_schema;     // schema of the stage input (plan input or previous stage's result)
+  Schema out_schema;
+  Program main;         // the pipeline program
+  Program count_pass;   // STAGE_MATERIALIZE with a filter: predicate + SEL_COUNT
+  bool has_filter = false;
+  std::vector<AggOut> aggs;               // SCALAR_AGG / GROUP_AGG (out_schema order, after keys)
+  std::vector<GroupKeyField> group_keys;  // GROUP_AGG
+  std::vector<uint64_t> group_acc_init;   // per-group accumulator identities
+  int n_gaggs = 0;
+  std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
+  std::vector<int> sort_out_cols;         // SORT: projected input columns
+  int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row
+  int64_t output_bytes_per_row = 0;       // materialised output bytes per output row
+};
+
+// ---- plan description (host copy of ssgpu_plan_desc with owned strings) --------
+struct PlanDesc {
+  Schema input_schema;
+  std::vector<ssgpu_op> ops;
+  std::vector<ssgpu_expr> exprs;
+  std::vector<int32_t> expr_args;
+  std::vector<ssgpu_proj> projs;
+  std::vector<ssgpu_agg> aggs;
+  std::vector<ssgpu_sortkey> sortkeys;
+  std::vector<std::string> strings;  // storage for all names (stable addresses)
+};
+Status copy_plan_desc(const ssgpu_plan_desc* d, PlanDesc* out);
+
+// bind.cpp: expression binding against a schema.  Results are expressions over
+// the schema's columns (INPUT nodes index `schema`).
+Status bind_expression(const PlanDesc& d, int expr_index, const Schema& schema, int filter_depth,
+                       std::vector<BExprP>* out);
+// projector binding: positions into `schema` + result names
+Status bind_projector(const PlanDesc& d, int first, int n, const Schema& schema,
+                      std::vector<int>* positions, std::vector<std::string>* names);
+std::string bexpr_to_string(const BExprP& e);
+
+// lower.cpp: operation chain -> stages
+struct LowerOptions {
+  int lds_target_bytes = 48 * 1024;
+  int tile_rows = 0;  // 0 = choose by lds_target_bytes
+};
+Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe);
+// choose the tile size (K = tile_rows / 512) and fix LDS offsets for a program
+struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; };
+ProgramLayout layout_program(const Program& p, const LowerOptions& opt);
+// final device instructions for a tile of `tile_rows`
+void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out);
+std::string disassemble(const Program& p);
+
+}  // namespace ssgpu
+#endif  // SSGPU_ENGINE_H_

@@ -1,0 +1,57 @@
+// launch.h -- host-visible launchers and parameter blocks of the HIP kernels.
+#ifndef SSGPU_LAUNCH_H_
+#define SSGPU_LAUNCH_H_
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "vm.h"
+
+// scalar-aggregate slot combine rules (finish kernel) ------------------------
+enum SlotKind {
+  SLOT_SUM_INT = 0, SLOT_SUM_DD = 1, SLOT_MIN_U64 = 2, SLOT_MAX_U64 = 3, SLOT_MIN_F64 = 4,
+  SLOT_MAX_F64 = 5, SLOT_FIRST = 6, SLOT_LAST = 7, SLOT_COUNT = 8
+};
+// accumulator-domain -> column-type conversions (emit kernels) ----------------
+enum EmitKind {
+  EMIT_U64 = 0, EMIT_I64KEY = 1, EMIT_U32 = 2, EMIT_I32KEY = 3, EMIT_F64 = 4, EMIT_F32 = 5,
+  EMIT_DD_F64 = 6, EMIT_DD_F32 = 7, EMIT_U8 = 8,
+  EMIT_FKEY_F64 = 100, EMIT_FKEY_F32 = 101 /* group table: ordered-double key */
+};
+#define SSGPU_STATE_ARRAYS 8 /* reducible state: 8 u64 arrays of n_slots */
+
+struct EmitDesc { void* data; uint8_t* is_null; int slot; int out_kind; };
+
+struct GroupKeyOut { void* data; uint8_t* is_null; uint32_t shift, bits, nullbit, width; };
+struct GroupAggOut { void* data; uint8_t* is_null; int s; int out_kind; int has_cnt; int pad; };
+struct GroupExtractParams {
+  const unsigned long long* keys;
+  const unsigned long long* first_row;
+  const unsigned long long* acc;
+  const unsigned int* cnt;
+  uint32_t capacity;      /* slots 0..capacity-1 + the special slot `capacity` */
+  uint32_t n_gaggs;
+  uint32_t n_keys;
+  uint32_t n_aggs_out;
+  const unsigned int* tile_offsets;
+  unsigned long long* out_first_row;
+  GroupKeyOut keys_out[16];
+  GroupAggOut aggs_out[VM_MAX_AGG_SLOTS];
+};
+
+hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream);
+hipError_t ssgpu_pipeline_set_max_lds(int bytes);
+hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
+                                     VmAccRec* out, hipStream_t stream);
+hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state,
+                                       hipStream_t stream);
+hipError_t ssgpu_launch_state_to_slots(const uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs,
+                                       hipStream_t stream);
+hipError_t ssgpu_launch_emit_scalar(const VmAccRec* recs, const EmitDesc* descs, int n_out, hipStream_t stream);
+hipError_t ssgpu_launch_scan_counts(const uint32_t* in, uint32_t* out, int n, uint64_t* total, hipStream_t stream);
+hipError_t ssgpu_launch_group_count(const GroupExtractParams& P, uint32_t* tile_counts, hipStream_t stream);
+hipError_t ssgpu_launch_group_extract(const GroupExtractParams& P, hipStream_t stream);
+hipError_t ssgpu_launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t stream);
+hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, uint32_t plen, size_t n,
+                                         hipStream_t stream);
+
+#endif  // SSGPU_LAUNCH_H_

@@ -1,0 +1,942 @@
+// lower.cpp -- operation chain -> pipeline stages -> tile-VM programs.
+//
+// Restates the cursor layer's composition rules:
+//   Compute   = replace the row's columns by the expression's result columns
+//               supersonic/cursor/core/compute.cc:49-79
+//   Project   = pointer re-mapping                       cursor/core/project.cc:49-59
+//   Filter    = keep rows whose predicate is non-NULL TRUE, then project
+//               cursor/core/filter.cc:84-92,170-199,287-303
+//   ScalarAggregate / GroupAggregate binding of the AggregationSpecification
+//               cursor/core/aggregator.cc:63-186, column_aggregator.cc:484-560
+// Everything between the Scan and the first blocking operator is fused into ONE
+// program: expressions compose by substitution, filters become a selection byte
+// vector, no intermediate column or row-id list is ever written to HBM.
+#include "engine.h"
+
+#include <algorithm>
+#include <functional>
+#include <sstream>
+#include <string.h>
+
+namespace ssgpu {
+
+enum {
+  OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DIVIDE_NULLING = 14,
+  OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
+  OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36, OP_AND = 40, OP_OR = 44,
+  OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_BITWISE_AND = 60, OP_BITWISE_OR = 64,
+  OP_BITWISE_NOT = 68, OP_BITWISE_XOR = 72, OP_SHIFT_LEFT = 76, OP_SHIFT_RIGHT = 80,
+  OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116, OP_LESS_OR_EQUAL = 120,
+  OP_IF = 204, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST_QUIET = 265
+};
+
+// machine type classes
+enum MT { M_I32, M_U32, M_I64, M_U64, M_F32, M_F64, M_B8, M_BAD };
+static MT mtype(int dtype) {
+  switch (dtype) {
+    case SSGPU_INT32: case SSGPU_DATE: return M_I32;
+    case SSGPU_UINT32: return M_U32;
+    case SSGPU_INT64: case SSGPU_DATETIME: return M_I64;
+    case SSGPU_UINT64: return M_U64;
+    case SSGPU_FLOAT: return M_F32;
+    case SSGPU_DOUBLE: return M_F64;
+    case SSGPU_BOOL: return M_B8;
+  }
+  return M_BAD;
+}
+static uint32_t mwidth(MT m) { return (m == M_I32 || m == M_U32 || m == M_F32) ? 4 : (m == M_B8 ? 1 : 8); }
+
+struct Val {
+  int reg = -1;       // value register (when !imm)
+  bool imm = false;
+  uint64_t bits = 0;
+  int null = -1;      // null-mask register, -1 = never NULL
+  uint32_t width = 8;
+};
+
+class Emitter {
+ public:
+  explicit Emitter(Program* p) : P(p) {}
+
+  int new_reg(uint32_t width) { LReg r; r.width = width; r.row_off = 0; P->regs.push_back(r); return (int)P->regs.size() - 1; }
+  LInstr& emit(uint16_t op) { LInstr i; i.op = op; P->code.push_back(i); return P->code.back(); }
+
+  int staged(int col, bool is_null, uint32_t width) {
+    auto key = std::make_pair(col, is_null);
+    auto it = staged_.find(key);
+    if (it != staged_.end()) return it->second;
+    int r = new_reg(width);
+    StagedInput s; s.col = col; s.is_null_mask = is_null; s.reg = r;
+    P->staged.push_back(s);
+    staged_[key] = r;
+    return r;
+  }
+
+  int materialize(const Val& v) {
+    if (!v.imm) return v.reg;
+    int r = new_reg(v.width);
+    LInstr& i = emit(v.width == 8 ? VM_FILL_64 : v.width == 4 ? VM_FILL_32 : VM_FILL_8);
+    i.dst = r; i.a_imm = true; i.imm = v.bits;
+    return r;
+  }
+  int const_null_reg() {
+    if (all_null_ < 0) {
+      all_null_ = new_reg(1);
+      LInstr& i = emit(VM_FILL_8); i.dst = all_null_; i.a_imm = true; i.imm = 1;
+    }
+    return all_null_;
+  }
+  int or_null(int a, int b) {
+    if (a < 0) return b;
+    if (b < 0) return a;
+    if (a == b) return a;
+    int r = new_reg(1);
+    LInstr& i = emit(VM_NULL_OR); i.dst = r; i.a = a; i.b = b;
+    return r;
+  }
+  // dst = op(a, b) with immediates folded into the instruction
+  int binop(uint16_t op, Val a, Val b, uint32_t out_width) {
+    if (a.imm && b.imm) { a.reg = materialize(a); a.imm = false; }
+    int r = new_reg(out_width);
+    LInstr& i = emit(op);
+    i.dst = r;
+    if (a.imm) { i.a_imm = true; i.imm = a.bits; } else i.a = a.reg;
+    if (b.imm) { i.b_imm = true; i.imm = b.bits; } else i.b = b.reg;
+    return r;
+  }
+  int unop(uint16_t op, Val a, uint32_t out_width) {
+    int r = new_reg(out_width);
+    LInstr& i = emit(op);
+    i.dst = r;
+    if (a.imm) { i.a_imm = true; i.imm = a.bits; } else i.a = a.reg;
+    return r;
+  }
+
+  Status value(const BExprP& e, Val* out);
+  Status cast_val(const Val& v, MT from, MT to, Val* out);
+
+  // selection registers: sel_by_depth[d] = rows passing the first d filters (-1 = all)
+  std::vector<int> sel_by_depth{-1};
+  int sel_at(int depth) const { return sel_by_depth[std::min<size_t>(depth, sel_by_depth.size() - 1)]; }
+
+  Program* P;
+
+ private:
+  std::string key_of(const BExprP& e);
+  std::map<std::pair<int, bool>, int> staged_;
+  std::map<std::string, Val> memo_;
+  int all_null_ = -1;
+};
+
+std::string Emitter::key_of(const BExprP& e) {
+  std::ostringstream s;
+  switch (e->kind) {
+    case BExpr::INPUT: s << "I" << e->input_col; break;
+    case BExpr::CONST: s << "C" << e->dtype << ":" << e->bits; break;
+    case BExpr::NULLCONST: s << "N" << e->dtype; break;
+    default:
+      s << (e->kind == BExpr::CAST ? "K" : "O") << e->op << ":" << e->dtype << ":" << e->filter_depth << "(";
+      for (auto& a : e->args) s << key_of(a) << ",";
+      s << ")";
+  }
+  return s.str();
+}
+
+Status Emitter::cast_val(const Val& v, MT from, MT to, Val* out) {
+  *out = v;
+  out->width = mwidth(to);
+  if (from == to) return Status::OK();
+  auto same_bits = [&](MT a, MT b) { return (a == M_I32 && b == M_U32) || (a == M_U32 && b == M_I32) || (a == M_I64 && b == M_U64) || (a == M_U64 && b == M_I64); };
+  if (same_bits(from, to)) return Status::OK();
+  uint16_t op = VM_NOP;
+  const bool to64 = to == M_I64 || to == M_U64, to32 = to == M_I32 || to == M_U32;
+  if (from == M_I32 && to64) op = VM_CAST_I32_I64;
+  else if (from == M_U32 && to64) op = VM_CAST_U32_I64;
+  else if ((from == M_I64 || from == M_U64) && to32) op = VM_CAST_I64_I32;
+  else if (from == M_I32 && to == M_F32) op = VM_CAST_I32_F32;
+  else if (from == M_I32 && to == M_F64) op = VM_CAST_I32_F64;
+  else if (from == M_U32 && to == M_F32) op = VM_CAST_U32_F32;
+  else if (from == M_U32 && to == M_F64) op = VM_CAST_U32_F64;
+  else if (from == M_I64 && to == M_F32) op = VM_CAST_I64_F32;
+  else if (from == M_I64 && to == M_F64) op = VM_CAST_I64_F64;
+  else if (from == M_U64 && to == M_F32) op = VM_CAST_U64_F32;
+  else if (from == M_U64 && to == M_F64) op = VM_CAST_U64_F64;
+  else if (from == M_F32 && to == M_F64) op = VM_CAST_F32_F64;
+  else if (from == M_F64 && to == M_F32) op = VM_CAST_F64_F32;
+  else return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "cast not available on device");
+  Val src = v;
+  out->reg = unop(op, src, mwidth(to));
+  out->imm = false;
+  return Status::OK();
+}
+
+static uint16_t pick(MT m, uint16_t i32, uint16_t u32, uint16_t i64, uint16_t u64, uint16_t f32, uint16_t f64, uint16_t b8 = VM_NOP) {
+  switch (m) {
+    case M_I32: return i32; case M_U32: return u32; case M_I64: return i64; case M_U64: return u64;
+    case M_F32: return f32; case M_F64: return f64; case M_B8: return b8; default: return VM_NOP;
+  }
+}
+
+Status Emitter::value(const BExprP& e, Val* out) {
+  const std::string key = key_of(e);
+  auto it = memo_.find(key);
+  if (it != memo_.end()) { *out = it->second; return Status::OK(); }
+  const MT mt = mtype(e->dtype);
+  if (mt == M_BAD)
+    return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED,
+                         std::string("type ") + dtype_name(e->dtype) + " is outside the device hot path (SURVEY 8f)");
+  Val v; v.width = mwidth(mt);
+  switch (e->kind) {
+    case BExpr::INPUT:
+      v.reg = staged(e->input_col, false, v.width);
+      if (e->nullable) v.null = staged(e->input_col, true, 1);
+      break;
+    case BExpr::CONST: v.imm = true; v.bits = e->bits; break;
+    case BExpr::NULLCONST: v.imm = true; v.bits = 0; v.null = const_null_reg(); break;
+    case BExpr::CAST: {
+      Val a; SS_RETURN_IF_ERROR(value(e->args[0], &a));
+      SS_RETURN_IF_ERROR(cast_val(a, mtype(e->args[0]->dtype), mt, &v));
+    } break;
+    case BExpr::OP: {
+      std::vector<Val> a(e->args.size());
+      for (size_t i = 0; i < a.size(); ++i) SS_RETURN_IF_ERROR(value(e->args[i], &a[i]));
+      const MT at = mtype(e->args[0]->dtype);
+      const int sel = sel_at(e->filter_depth);
+      switch (e->op) {
+        case OP_ADD: v.reg = binop(pick(mt, VM_ADD_I32, VM_ADD_I32, VM_ADD_I64, VM_ADD_I64, VM_ADD_F32, VM_ADD_F64), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_SUBTRACT: v.reg = binop(pick(mt, VM_SUB_I32, VM_SUB_I32, VM_SUB_I64, VM_SUB_I64, VM_SUB_F32, VM_SUB_F64), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_MULTIPLY: v.reg = binop(pick(mt, VM_MUL_I32, VM_MUL_I32, VM_MUL_I64, VM_MUL_I64, VM_MUL_F32, VM_MUL_F64), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_DIVIDE_QUIET: case OP_DIVIDE_NULLING: case OP_DIVIDE_SIGNALING:
+        case OP_CPP_DIVIDE_NULLING: case OP_CPP_DIVIDE_SIGNALING:
+        case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING: {
+          const bool is_mod = e->op == OP_MODULUS_NULLING || e->op == OP_MODULUS_SIGNALING;
+          const bool nulling = e->op == OP_DIVIDE_NULLING || e->op == OP_CPP_DIVIDE_NULLING || e->op == OP_MODULUS_NULLING;
+          const bool signaling = e->op == OP_DIVIDE_SIGNALING || e->op == OP_CPP_DIVIDE_SIGNALING || e->op == OP_MODULUS_SIGNALING;
+          uint16_t op = is_mod ? pick(mt, VM_MOD_I32, VM_MOD_U32, VM_MOD_I64, VM_MOD_U64, VM_NOP, VM_NOP)
+                               : pick(mt, VM_CDIV_I32, VM_CDIV_U32, VM_CDIV_I64, VM_CDIV_U64, VM_DIV_F32, VM_DIV_F64);
+          if (op == VM_NOP) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "division variant not available on device");
+          int base_null = or_null(a[0].null, a[1].null);
+          const uint16_t zop_null = pick(mt, VM_NULL_DIVZERO_32, VM_NULL_DIVZERO_32, VM_NULL_DIVZERO_64, VM_NULL_DIVZERO_64, VM_NULL_DIVZERO_F32, VM_NULL_DIVZERO_F64);
+          const uint16_t zop_fail = pick(mt, VM_FAIL_DIVZERO_32, VM_FAIL_DIVZERO_32, VM_FAIL_DIVZERO_64, VM_FAIL_DIVZERO_64, VM_FAIL_DIVZERO_F32, VM_FAIL_DIVZERO_F64);
+          // DIVIDE_SIGNALING on DOUBLE: "double division cannot fail at runtime" is the
+          // reference's comment, but its CheckFailure still flags a zero divisor
+          // (expression_traits.h:1229-1242); mirror the failer.
+          if (nulling) {
+            int r = new_reg(1);
+            LInstr& i = emit(zop_null); i.dst = r; i.a = base_null;
+            if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; } else i.b = a[1].reg;
+            base_null = r;
+          } else if (signaling) {
+            LInstr& i = emit(zop_fail); i.dst_is_reg = false; i.dst = 0; i.a = base_null; i.c = sel;
+            if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; } else i.b = a[1].reg;
+          }
+          v.reg = binop(op, a[0], a[1], v.width);
+          v.null = base_null;
+        } break;
+        case OP_NEGATE: v.reg = unop(pick(mt, VM_NEG_I32, VM_NEG_I32, VM_NEG_I64, VM_NEG_I64, VM_NEG_F32, VM_NEG_F64), a[0], v.width); v.null = a[0].null; break;
+        case OP_BITWISE_AND: v.reg = binop(v.width == 4 ? VM_BAND_32 : VM_BAND_64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_BITWISE_OR: v.reg = binop(v.width == 4 ? VM_BOR_32 : VM_BOR_64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_BITWISE_XOR: v.reg = binop(v.width == 4 ? VM_BXOR_32 : VM_BXOR_64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_BITWISE_ANDNOT: v.reg = binop(v.width == 4 ? VM_BANDNOT_32 : VM_BANDNOT_64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_BITWISE_NOT: v.reg = unop(v.width == 4 ? VM_BNOT_32 : VM_BNOT_64, a[0], v.width); v.null = a[0].null; break;
+        case OP_SHIFT_LEFT: v.reg = binop(v.width == 4 ? VM_SHL_I32 : VM_SHL_I64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_SHIFT_RIGHT: v.reg = binop(pick(mt, VM_SHR_I32, VM_SHR_U32, VM_SHR_I64, VM_SHR_U64, VM_NOP, VM_NOP), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_EQUAL: case OP_NOT_EQUAL: case OP_LESS: case OP_LESS_OR_EQUAL: {
+          MT lt = at, rt = mtype(e->args[1]->dtype);
+          Val l = a[0], r = a[1];
+          uint16_t op = VM_NOP;
+          const int c = e->op == OP_LESS ? 0 : e->op == OP_LESS_OR_EQUAL ? 1 : e->op == OP_EQUAL ? 2 : 3;
+          if (lt == rt) {
+            static const uint16_t T[4][7] = {
+                {VM_LT_I32, VM_LT_U32, VM_LT_I64, VM_LT_U64, VM_LT_F32, VM_LT_F64, VM_LT_B8},
+                {VM_LE_I32, VM_LE_U32, VM_LE_I64, VM_LE_U64, VM_LE_F32, VM_LE_F64, VM_LE_B8},
+                {VM_EQ_32, VM_EQ_32, VM_EQ_64, VM_EQ_64, VM_EQ_F32, VM_EQ_F64, VM_EQ_B8},
+                {VM_NE_32, VM_NE_32, VM_NE_64, VM_NE_64, VM_NE_F32, VM_NE_F64, VM_NE_B8}};
+            op = T[c][lt];
+          } else {
+            // two different integer types: widen to 64 bits, pick the sign-correct compare
+            auto is_int = [](MT m) { return m == M_I32 || m == M_U32 || m == M_I64 || m == M_U64; };
+            if (!is_int(lt) || !is_int(rt)) return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, "cannot compare these types");
+            const bool l_u = lt == M_U64 || (lt == M_U32 && rt == M_U64);
+            const bool r_u = rt == M_U64 || (rt == M_U32 && lt == M_U64);
+            Val lw, rw;
+            SS_RETURN_IF_ERROR(cast_val(l, lt, l_u ? M_U64 : M_I64, &lw));
+            SS_RETURN_IF_ERROR(cast_val(r, rt, r_u ? M_U64 : M_I64, &rw));
+            l = lw; r = rw;
+            if (!l_u && !r_u) op = c == 0 ? VM_LT_I64 : c == 1 ? VM_LE_I64 : c == 2 ? VM_EQ_64 : VM_NE_64;
+            else if (l_u && r_u) op = c == 0 ? VM_LT_U64 : c == 1 ? VM_LE_U64 : c == 2 ? VM_EQ_64 : VM_NE_64;
+            else if (!l_u && r_u) op = c == 0 ? VM_LT_I64_U64 : c == 1 ? VM_LE_I64_U64 : c == 2 ? VM_EQ_I64_U64 : VM_NE_I64_U64;
+            else {
+              if (c >= 2) { std::swap(l, r); op = c == 2 ? VM_EQ_I64_U64 : VM_NE_I64_U64; }
+              else op = c == 0 ? VM_LT_U64_I64 : VM_LE_U64_I64;
+            }
+          }
+          v.width = 1;
+          v.reg = binop(op, l, r, 1);
+          v.null = or_null(a[0].null, a[1].null);
+        } break;
+        case OP_AND: case OP_OR: case OP_AND_NOT: {
+          Val l = a[0], r = a[1];
+          if (e->op == OP_AND_NOT) { l.reg = unop(VM_NOT_B8, l, 1); l.imm = false; }  // andnot(a,b) = (!a) && b
+          const bool is_or = e->op == OP_OR;
+          if (l.null < 0 && r.null < 0) {
+            v.reg = binop(is_or ? VM_OR_B8 : VM_AND_B8, l, r, 1);
+          } else {
+            int lr = materialize(l), rr = materialize(r);
+            v.reg = new_reg(1); v.null = new_reg(1);
+            LInstr& i = emit(is_or ? VM_OR3 : VM_AND3);
+            i.dst = v.reg; i.c = v.null; i.a = lr; i.b = rr; i.d = l.null; i.e = r.null;
+          }
+        } break;
+        case OP_XOR: v.reg = binop(VM_XOR_B8, a[0], a[1], 1); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_NOT: v.reg = unop(VM_NOT_B8, a[0], 1); v.null = a[0].null; break;
+        case OP_IS_NULL:
+          if (a[0].null < 0) { v.imm = true; v.bits = 0; } else { v.reg = a[0].null; }
+          break;
+        case OP_IF_NULL: {  // a NULL ? b : a
+          const uint16_t sop = v.width == 8 ? VM_SELECT_64 : v.width == 4 ? VM_SELECT_32 : VM_SELECT_8;
+          Val x = a[1], y = a[0];
+          if (x.imm && y.imm) { x.reg = materialize(x); x.imm = false; }
+          v.reg = new_reg(v.width);
+          LInstr& i = emit(sop); i.dst = v.reg; i.c = a[0].null;
+          if (x.imm) { i.a_imm = true; i.imm = x.bits; } else i.a = x.reg;
+          if (y.imm) { i.b_imm = true; i.imm = y.bits; } else i.b = y.reg;
+          if (a[1].null >= 0) {
+            v.null = new_reg(1);
+            LInstr& j = emit(VM_SELECT_8); j.dst = v.null; j.a = a[1].null; j.b_imm = true; j.imm = 0; j.c = a[0].null;
+          }
+        } break;
+        case OP_IF: {
+          const uint16_t sop = v.width == 8 ? VM_SELECT_64 : v.width == 4 ? VM_SELECT_32 : VM_SELECT_8;
+          int cond = materialize(a[0]);
+          Val x = a[1], y = a[2];
+          if (x.imm && y.imm) { x.reg = materialize(x); x.imm = false; }
+          v.reg = new_reg(v.width);
+          LInstr& i = emit(sop); i.dst = v.reg; i.c = cond;
+          if (x.imm) { i.a_imm = true; i.imm = x.bits; } else i.a = x.reg;
+          if (y.imm) { i.b_imm = true; i.imm = y.bits; } else i.b = y.reg;
+          int branch_null = -1;
+          if (a[1].null >= 0 || a[2].null >= 0) {
+            branch_null = new_reg(1);
+            LInstr& j = emit(VM_SELECT_8); j.dst = branch_null; j.c = cond;
+            if (a[1].null >= 0) j.a = a[1].null; else { j.a_imm = true; j.imm = 0; }
+            if (a[2].null >= 0) j.b = a[2].null; else { j.b_imm = true; j.imm = 0; }
+            if (j.a_imm && j.b_imm) { /* unreachable: one side has a mask */ }
+          }
+          v.null = or_null(a[0].null, branch_null);
+        } break;
+        default:
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "operator has no device lowering: " + e->name);
+      }
+    } break;
+  }
+  memo_[key] = v;
+  *out = v;
+  return Status::OK();
+}
+
+// ---- register allocation: linear scan over LDS row offsets ---------------------
+static void for_each_use(const LInstr& i, const std::function<void(int)>& f) {
+  if (!i.a_imm && i.a >= 0) f(i.a);
+  if (!i.b_imm && i.b >= 0) f(i.b);
+  if (i.d >= 0) f(i.d);
+  if (i.e >= 0) f(i.e);
+  const bool c_is_def = i.op == VM_AND3 || i.op == VM_OR3;
+  if (i.c >= 0 && !c_is_def) f(i.c);
+  const bool dst_is_use = i.op == VM_KEY_APPEND_8 || i.op == VM_KEY_APPEND_32 || i.op == VM_KEY_APPEND_64;
+  if (i.dst_is_reg && dst_is_use && i.dst >= 0) f(i.dst);
+}
+static void for_each_def(const LInstr& i, const std::function<void(int)>& f) {
+  if (i.dst_is_reg && i.dst >= 0) f(i.dst);
+  if ((i.op == VM_AND3 || i.op == VM_OR3) && i.c >= 0) f(i.c);
+}
+
+static void allocate_registers(Program* p) {
+  const int n = (int)p->regs.size();
+  std::vector<int> first(n, 1 << 30), last(n, -1);
+  for (auto& s : p->staged) first[s.reg] = -1;
+  for (int pc = 0; pc < (int)p->code.size(); ++pc) {
+    for_each_def(p->code[pc], [&](int r) { first[r] = std::min(first[r], pc); last[r] = std::max(last[r], pc); });
+    for_each_use(p->code[pc], [&](int r) { last[r] = std::max(last[r], pc); first[r] = std::min(first[r], pc); });
+  }
+  // free list of (row_off, width) holes; bump pointer `top`
+  struct Hole { uint32_t off, width; };
+  std::vector<Hole> holes;
+  uint32_t top = 0, peak = 0;
+  std::vector<bool> placed(n, false);
+  auto place = [&](int r) {
+    if (placed[r]) return;
+    placed[r] = true;
+    const uint32_t w = p->regs[r].width;
+    for (size_t h = 0; h < holes.size(); ++h) {
+      if (holes[h].width >= w) {
+        p->regs[r].row_off = holes[h].off;
+        if (holes[h].width > w) { holes[h].off += w; holes[h].width -= w; } else holes.erase(holes.begin() + h);
+        return;
+      }
+    }
+    p->regs[r].row_off = top; top += w; peak = std::max(peak, top);
+  };
+  auto release = [&](int r) {
+    Hole h; h.off = p->regs[r].row_off; h.width = p->regs[r].width;
+    // merge with neighbours / the bump pointer
+    holes.push_back(h);
+    std::sort(holes.begin(), holes.end(), [](const Hole& x, const Hole& y) { return x.off < y.off; });
+    for (size_t i = 0; i + 1 < holes.size();) {
+      if (holes[i].off + holes[i].width == holes[i + 1].off) { holes[i].width += holes[i + 1].width; holes.erase(holes.begin() + i + 1); }
+      else ++i;
+    }
+    if (!holes.empty() && holes.back().off + holes.back().width == top) { top = holes.back().off; holes.pop_back(); }
+  };
+  // staged registers live from the start (wide ones first for alignment-friendly packing)
+  std::vector<int> st;
+  for (auto& s : p->staged) st.push_back(s.reg);
+  std::sort(st.begin(), st.end(), [&](int a, int b) { return p->regs[a].width > p->regs[b].width; });
+  for (int r : st) place(r);
+  for (int r : st) if (last[r] < 0) last[r] = -1;
+  for (int pc = 0; pc < (int)p->code.size(); ++pc) {
+    for_each_def(p->code[pc], [&](int r) { place(r); });
+    // a register whose last use is this instruction is released AFTER the definition was
+    // placed: an instruction never writes a slot it is still reading at another width
+    std::vector<int> dead;
+    for_each_use(p->code[pc], [&](int r) { if (last[r] == pc) dead.push_back(r); });
+    for_each_def(p->code[pc], [&](int r) { if (last[r] == pc) dead.push_back(r); });
+    std::sort(dead.begin(), dead.end()); dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
+    for (int r : dead) release(r);
+  }
+  p->bytes_per_row = peak;
+}
+
+ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
+  ProgramLayout L;
+  auto lds_for = [&](int K, uint32_t* acc, uint32_t* scr) {
+    uint32_t regs = p.bytes_per_row * 512u * (uint32_t)K;
+    uint32_t a = (regs + 15u) & ~15u;
+    uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
+    if (acc) *acc = a;
+    if (scr) *scr = s;
+    return s + 256u;
+  };
+  int K = 1;
+  if (opt.tile_rows > 0) {
+    K = std::max(1, opt.tile_rows / 512);
+    if (K >= 4) K = 4; else if (K >= 2) K = 2; else K = 1;
+  } else {
+    for (int cand : {4, 2, 1}) { K = cand; if ((int)lds_for(cand, nullptr, nullptr) <= opt.lds_target_bytes) break; }
+  }
+  L.K = K;
+  L.lds_bytes = lds_for(K, &L.acc_off, &L.scratch_off);
+  return L;
+}
+
+void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out) {
+  out->clear();
+  auto off = [&](int r) -> uint32_t { return r < 0 ? VM_NONE : p.regs[r].row_off * (uint32_t)tile_rows; };
+  for (const LInstr& i : p.code) {
+    VmInstr v; memset(&v, 0, sizeof(v));
+    v.op = i.op; v.a_imm = i.a_imm; v.b_imm = i.b_imm;
+    v.dst = i.dst_is_reg ? off(i.dst) : (uint32_t)i.dst;
+    v.a = i.a_imm ? VM_NONE : off(i.a);
+    v.b = i.b_imm ? VM_NONE : off(i.b);
+    v.c = off(i.c); v.d = off(i.d);
+    v.imm = i.imm;
+    if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
+    out->push_back(v);
+  }
+}
+
+std::string disassemble(const Program& p) {
+  std::ostringstream s;
+  s << "  staged:";
+  for (auto& st : p.staged) s << " r" << st.reg << "<-col" << st.col << (st.is_null_mask ? ".null" : "") << "(w" << p.regs[st.reg].width << ")";
+  s << "\n  lds bytes/row: " << p.bytes_per_row << ", slots: " << p.n_slots << ", outputs: " << p.n_outputs << "\n";
+  auto R = [&](int r) { return r < 0 ? std::string("-") : "r" + std::to_string(r) + "@" + std::to_string(p.regs[r].row_off); };
+  for (size_t pc = 0; pc < p.code.size(); ++pc) {
+    const LInstr& i = p.code[pc];
+    s << "  " << pc << ": " << vm_op_name(i.op) << " dst=" << (i.dst_is_reg ? R(i.dst) : "#" + std::to_string(i.dst))
+      << " a=" << (i.a_imm ? "imm" : R(i.a)) << " b=" << (i.b_imm ? "imm" : R(i.b)) << " c=" << R(i.c) << " d=" << R(i.d);
+    if (i.e >= 0) s << " e=" << R(i.e);
+    if (i.a_imm || i.b_imm || i.imm) s << " imm=0x" << std::hex << i.imm << std::dec;
+    s << "\n";
+  }
+  return s.str();
+}
+
+// ---- expression composition -------------------------------------------------------
+struct VCol { BExprP expr; std::string name; };
+
+static BExprP substitute(const BExprP& e, const std::vector<VCol>& cols, std::map<const BExpr*, BExprP>* memo) {
+  auto it = memo->find(e.get());
+  if (it != memo->end()) return it->second;
+  BExprP r;
+  if (e->kind == BExpr::INPUT) {
+    r = cols[e->input_col].expr;
+  } else if (e->args.empty()) {
+    r = e;
+  } else {
+    r.reset(new BExpr(*e));
+    for (auto& a : r->args) a = substitute(a, cols, memo);
+  }
+  (*memo)[e.get()] = r;
+  return r;
+}
+
+static Schema schema_of(const std::vector<VCol>& cols) {
+  Schema s;
+  for (auto& c : cols) { Attr a; a.name = c.name; a.dtype = c.expr->dtype; a.nullable = c.expr->nullable; s.push_back(a); }
+  return s;
+}
+
+static int lookup_pos(const Schema& s, const std::string& name) {
+  for (size_t i = 0; i < s.size(); ++i) if (s[i].name == name) return (int)i;
+  return -1;
+}
+
+// ---- aggregate specification binding (aggregator.cc:63-186) --------------------------
+struct AggPlan {
+  int aggregation = 0;
+  int input_pos = -1;  // -1 for COUNT(*)
+  int out_type = 0;
+  std::string out_name;
+  bool result_nullable = true;
+};
+
+static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schema& in, std::vector<AggPlan>* out) {
+  for (int i = 0; i < n; ++i) {
+    const ssgpu_agg& a = d.aggs[first + i];
+    AggPlan p;
+    p.aggregation = a.aggregation;
+    p.out_name = a.output;
+    if (a.aggregation == SSGPU_COUNT && !a.distinct && a.input[0] == 0) {
+      p.input_pos = -1;
+    } else {
+      p.input_pos = lookup_pos(in, a.input);
+      if (p.input_pos < 0)
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_MISSING,
+                             std::string("Incorrect aggregation specification. Aggregation input column does not exist: ") + a.input + ".");
+    }
+    if (a.output_type >= 0) p.out_type = a.output_type;
+    else if (a.aggregation == SSGPU_COUNT) p.out_type = SSGPU_UINT64;
+    else p.out_type = in[p.input_pos].dtype;
+    p.result_nullable = a.aggregation != SSGPU_COUNT;
+    for (auto& q : *out)
+      if (q.out_name == p.out_name)
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS,
+                             "Incorrect aggregation specification. Aggregation output column name is non-unique: '" + p.out_name + "'.");
+    if (a.distinct)
+      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "DISTINCT aggregations are outside the device hot path");
+    if (a.aggregation == SSGPU_CONCAT)
+      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT (STRING) is outside the device hot path");
+    // supported matrix (column_aggregator.cc:484-532)
+    if (a.aggregation == SSGPU_COUNT) {
+      if (!dtype_is_integer(p.out_type))
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, std::string("COUNT output type must be an integer, got ") + dtype_name(p.out_type));
+    } else {
+      const int it = in[p.input_pos].dtype;
+      bool ok = (dtype_is_numeric(it) && dtype_is_numeric(p.out_type)) ||
+                (it == p.out_type && a.aggregation != SSGPU_SUM && (it == SSGPU_BOOL || it == SSGPU_DATE || it == SSGPU_DATETIME));
+      if (!ok)
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE,
+                             std::string("Aggregation not supported. Aggregation function not defined for types ") +
+                                 dtype_name(it) + " and " + dtype_name(p.out_type) + ".");
+      if (dtype_is_float(it) && dtype_is_integer(p.out_type))
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "floating input aggregated into an integer output is order-dependent; not on device");
+    }
+    out->push_back(p);
+  }
+  return Status::OK();
+}
+
+// scalar-aggregate instruction selection
+struct AggSel { uint16_t op; int slot_kind; int emit_kind; };
+static bool select_scalar_agg(int aggregation, int out_type, AggSel* s) {
+  const MT m = mtype(out_type);
+  switch (aggregation) {
+    case SSGPU_SUM:
+      switch (m) {
+        case M_I32: *s = {VM_AGG_SUM_I32, SLOT_SUM_INT, EMIT_U32}; return true;
+        case M_U32: *s = {VM_AGG_SUM_U32, SLOT_SUM_INT, EMIT_U32}; return true;
+        case M_I64: case M_U64: *s = {VM_AGG_SUM_I64, SLOT_SUM_INT, EMIT_U64}; return true;
+        case M_F32: *s = {VM_AGG_SUM_F32, SLOT_SUM_DD, EMIT_DD_F32}; return true;
+        case M_F64: *s = {VM_AGG_SUM_F64, SLOT_SUM_DD, EMIT_DD_F64}; return true;
+        default: return false;
+      }
+    case SSGPU_MIN: case SSGPU_MAX: {
+      const bool mn = aggregation == SSGPU_MIN;
+      switch (m) {
+        case M_I32: *s = {mn ? VM_AGG_MIN_I32 : VM_AGG_MAX_I32, mn ? SLOT_MIN_U64 : SLOT_MAX_U64, EMIT_I32KEY}; return true;
+        case M_U32: *s = {mn ? VM_AGG_MIN_U32 : VM_AGG_MAX_U32, mn ? SLOT_MIN_U64 : SLOT_MAX_U64, EMIT_U32}; return true;
+        case M_I64: *s = {mn ? VM_AGG_MIN_I64 : VM_AGG_MAX_I64, mn ? SLOT_MIN_U64 : SLOT_MAX_U64, EMIT_I64KEY}; return true;
+        case M_U64: *s = {mn ? VM_AGG_MIN_U64 : VM_AGG_MAX_U64, mn ? SLOT_MIN_U64 : SLOT_MAX_U64, EMIT_U64}; return true;
+        case M_F32: *s = {mn ? VM_AGG_MIN_F32 : VM_AGG_MAX_F32, mn ? SLOT_MIN_F64 : SLOT_MAX_F64, EMIT_F32}; return true;
+        case M_F64: *s = {mn ? VM_AGG_MIN_F64 : VM_AGG_MAX_F64, mn ? SLOT_MIN_F64 : SLOT_MAX_F64, EMIT_F64}; return true;
+        case M_B8: *s = {mn ? VM_AGG_MIN_B8 : VM_AGG_MAX_B8, mn ? SLOT_MIN_U64 : SLOT_MAX_U64, EMIT_U8}; return true;
+        default: return false;
+      }
+    }
+    case SSGPU_FIRST: case SSGPU_LAST: {
+      const bool f = aggregation == SSGPU_FIRST;
+      const uint32_t w = mwidth(m);
+      *s = {(uint16_t)(w == 8 ? (f ? VM_AGG_FIRST_64 : VM_AGG_LAST_64) : w == 4 ? (f ? VM_AGG_FIRST_32 : VM_AGG_LAST_32)
+                                                                              : (f ? VM_AGG_FIRST_8 : VM_AGG_LAST_8)),
+            f ? SLOT_FIRST : SLOT_LAST, w == 8 ? EMIT_U64 : w == 4 ? EMIT_U32 : EMIT_U8};
+      return m != M_BAD;
+    }
+  }
+  return false;
+}
+static bool select_group_agg(int aggregation, int out_type, AggSel* s, uint64_t* init) {
+  const MT m = mtype(out_type);
+  *init = 0;
+  switch (aggregation) {
+    case SSGPU_SUM:
+      switch (m) {
+        case M_I32: *s = {VM_GAGG_SUM_I32, 0, EMIT_U32}; return true;
+        case M_U32: *s = {VM_GAGG_SUM_U32, 0, EMIT_U32}; return true;
+        case M_I64: case M_U64: *s = {VM_GAGG_SUM_I64, 0, EMIT_U64}; return true;
+        case M_F32: *s = {VM_GAGG_SUM_F32, 0, EMIT_F32}; return true;
+        case M_F64: *s = {VM_GAGG_SUM_F64, 0, EMIT_F64}; return true;
+        default: return false;
+      }
+    case SSGPU_MIN: case SSGPU_MAX: {
+      const bool mn = aggregation == SSGPU_MIN;
+      *init = mn ? ~0ull : 0ull;
+      switch (m) {
+        case M_I32: *s = {mn ? VM_GAGG_MIN_I32 : VM_GAGG_MAX_I32, 0, EMIT_I32KEY}; return true;
+        case M_U32: *s = {mn ? VM_GAGG_MIN_U32 : VM_GAGG_MAX_U32, 0, EMIT_U32}; return true;
+        case M_I64: *s = {mn ? VM_GAGG_MIN_I64 : VM_GAGG_MAX_I64, 0, EMIT_I64KEY}; return true;
+        case M_U64: *s = {mn ? VM_GAGG_MIN_U64 : VM_GAGG_MAX_U64, 0, EMIT_U64}; return true;
+        case M_F32: *s = {mn ? VM_GAGG_MIN_F32 : VM_GAGG_MAX_F32, 0, EMIT_FKEY_F32}; return true;
+        case M_F64: *s = {mn ? VM_GAGG_MIN_F64 : VM_GAGG_MAX_F64, 0, EMIT_FKEY_F64}; return true;
+        case M_B8: *s = {mn ? VM_GAGG_MIN_B8 : VM_GAGG_MAX_B8, 0, EMIT_U8}; return true;
+        default: return false;
+      }
+    }
+  }
+  return false;
+}
+
+// ---- one pipeline being assembled -----------------------------------------------------
+struct Pipe {
+  Schema in_schema;                // stage input
+  std::vector<VCol> cols;          // current virtual schema over the stage input
+  std::vector<BExprP> filters;     // predicates in order; filter i was bound at depth i
+  int depth() const { return (int)filters.size(); }
+};
+
+static void reset_pipe(Pipe* p, const Schema& in) {
+  p->in_schema = in; p->cols.clear(); p->filters.clear();
+  for (size_t i = 0; i < in.size(); ++i) {
+    BExprP e(new BExpr);
+    e->kind = BExpr::INPUT; e->input_col = (int)i; e->dtype = in[i].dtype; e->nullable = in[i].nullable; e->name = in[i].name;
+    VCol c; c.expr = e; c.name = in[i].name;
+    p->cols.push_back(c);
+  }
+}
+
+// emit the filter chain; fills em.sel_by_depth
+static Status emit_filters(Emitter& em, const Pipe& pipe) {
+  for (size_t f = 0; f < pipe.filters.size(); ++f) {
+    Val pv;
+    SS_RETURN_IF_ERROR(em.value(pipe.filters[f], &pv));
+    int r = em.new_reg(1);
+    LInstr& i = em.emit(VM_SEL_FROM_PRED);
+    i.dst = r;
+    if (pv.imm) { i.a_imm = true; i.imm = pv.bits; } else i.a = pv.reg;
+    i.b = pv.null;
+    i.c = em.sel_by_depth.back();
+    em.sel_by_depth.push_back(r);
+  }
+  return Status::OK();
+}
+
+static int64_t staged_bytes(const Program& p) {
+  int64_t b = 0;
+  for (auto& s : p.staged) b += p.regs[s.reg].width;
+  return b;
+}
+
+static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st) {
+  st->kind = STAGE_SCALAR_AGG;
+  st->in_schema = pipe.in_schema;
+  const Schema vs = schema_of(pipe.cols);
+  std::vector<AggPlan> plans;
+  SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, vs, &plans));
+  if ((int)plans.size() > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
+  Emitter em(&st->main);
+  SS_RETURN_IF_ERROR(emit_filters(em, pipe));
+  const int sel = em.sel_by_depth.back();
+  for (size_t j = 0; j < plans.size(); ++j) {
+    const AggPlan& ap = plans[j];
+    AggOut ao; ao.slot = (int)j; ao.has_cnt = true; ao.result_nullable = ap.result_nullable;
+    if (ap.aggregation == SSGPU_COUNT) {
+      int nullreg = -1;
+      if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
+      LInstr& i = em.emit(VM_AGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = sel;
+      ao.slot_kind = SLOT_COUNT;
+      ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
+    } else {
+      const BExprP& src = pipe.cols[ap.input_pos].expr;
+      Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
+      Val c;
+      SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+      AggSel s;
+      if (!select_scalar_agg(ap.aggregation, ap.out_type, &s))
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
+      int vr = em.materialize(c);
+      LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = sel;
+      ao.slot_kind = s.slot_kind; ao.emit_kind = s.emit_kind;
+    }
+    st->aggs.push_back(ao);
+    Attr a; a.name = ap.out_name; a.dtype = ap.out_type; a.nullable = ap.result_nullable;
+    st->out_schema.push_back(a);
+  }
+  st->main.n_slots = (int)plans.size();
+  allocate_registers(&st->main);
+  st->algorithmic_bytes_per_row = staged_bytes(st->main);
+  st->has_filter = !pipe.filters.empty();
+  return Status::OK();
+}
+
+static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st) {
+  st->kind = STAGE_GROUP_AGG;
+  st->in_schema = pipe.in_schema;
+  const Schema vs = schema_of(pipe.cols);
+  std::vector<int> kpos; std::vector<std::string> knames;
+  SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, vs, &kpos, &knames));
+  std::vector<AggPlan> plans;
+  SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, vs, &plans));
+  for (auto& ap : plans)
+    for (auto& kn : knames)
+      if (kn == ap.out_name)
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS, "Duplicate attribute name \"" + kn + "\" in result schema");
+  if ((int)plans.size() > VM_MAX_AGG_SLOTS || kpos.size() > 16)
+    return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many keys/aggregations for one pipeline");
+  Emitter em(&st->main);
+  SS_RETURN_IF_ERROR(emit_filters(em, pipe));
+  const int sel = em.sel_by_depth.back();
+  // pack the key columns into one 64-bit word (value bits + one NULL flag bit per nullable key)
+  int keyreg = em.new_reg(8);
+  { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; }
+  uint32_t shift = 0;
+  for (size_t k = 0; k < kpos.size(); ++k) {
+    const BExprP& ke = pipe.cols[kpos[k]].expr;
+    const MT m = mtype(ke->dtype);
+    if (m == M_BAD) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, std::string("group key type ") + dtype_name(ke->dtype) + " is outside the device hot path (SURVEY 8f.2)");
+    Val v; SS_RETURN_IF_ERROR(em.value(ke, &v));
+    const uint32_t w = mwidth(m), bits = w * 8;
+    GroupKeyField f; f.out_col = (int)k; f.shift = shift; f.bits = bits; f.width = w;
+    f.nullbit = v.null >= 0 ? shift + bits : 0xFF;
+    const uint32_t used = bits + (v.null >= 0 ? 1 : 0);
+    if (shift + used > 64)
+      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "group keys wider than 64 packed bits are not on device yet");
+    int vr = em.materialize(v);
+    LInstr& i = em.emit(w == 8 ? VM_KEY_APPEND_64 : w == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
+    i.dst = keyreg; i.a = vr; i.b = v.null;
+    i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
+    st->group_keys.push_back(f);
+    shift += used;
+    Attr a; a.name = knames[k]; a.dtype = ke->dtype; a.nullable = ke->nullable;
+    st->out_schema.push_back(a);
+  }
+  int slotreg = em.new_reg(4);
+  { LInstr& i = em.emit(VM_GRP_INSERT); i.dst = slotreg; i.a = keyreg; i.c = sel; }
+  const uint64_t ng = plans.size();
+  for (size_t j = 0; j < plans.size(); ++j) {
+    const AggPlan& ap = plans[j];
+    AggOut ao; ao.slot = (int)j; ao.slot_kind = 0; ao.result_nullable = ap.result_nullable; ao.has_cnt = false;
+    uint64_t init = 0;
+    if (ap.aggregation == SSGPU_COUNT) {
+      int nullreg = -1;
+      if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
+      LInstr& i = em.emit(VM_GAGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = slotreg;
+      i.imm = (ng << 32) | j;
+      ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
+    } else {
+      const BExprP& src = pipe.cols[ap.input_pos].expr;
+      Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
+      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+      AggSel s;
+      if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST)
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST/LAST inside GroupAggregate are not on device yet");
+      if (!select_group_agg(ap.aggregation, ap.out_type, &s, &init))
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
+      int vr = em.materialize(c);
+      ao.has_cnt = v.null >= 0;
+      LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = slotreg;
+      i.imm = ((uint64_t)(ao.has_cnt ? 1 : 0) << 63) | (ng << 32) | j;
+      ao.emit_kind = s.emit_kind;
+    }
+    st->group_acc_init.push_back(init);
+    st->aggs.push_back(ao);
+    Attr a; a.name = ap.out_name; a.dtype = ap.out_type; a.nullable = ap.result_nullable;
+    st->out_schema.push_back(a);
+  }
+  st->n_gaggs = (int)plans.size();
+  allocate_registers(&st->main);
+  st->algorithmic_bytes_per_row = staged_bytes(st->main);
+  st->has_filter = !pipe.filters.empty();
+  return Status::OK();
+}
+
+static Status finish_materialize(const Pipe& pipe, Stage* st) {
+  st->kind = STAGE_MATERIALIZE;
+  st->in_schema = pipe.in_schema;
+  st->out_schema = schema_of(pipe.cols);
+  st->has_filter = !pipe.filters.empty();
+  if (st->has_filter) {
+    Emitter ec(&st->count_pass);
+    SS_RETURN_IF_ERROR(emit_filters(ec, pipe));
+    LInstr& i = ec.emit(VM_SEL_COUNT); i.dst_is_reg = false; i.dst = 0; i.a = ec.sel_by_depth.back();
+    allocate_registers(&st->count_pass);
+  }
+  Emitter em(&st->main);
+  SS_RETURN_IF_ERROR(emit_filters(em, pipe));
+  const int sel = em.sel_by_depth.back();
+  int rank = -1;
+  if (st->has_filter) {
+    rank = em.new_reg(4);
+    LInstr& i = em.emit(VM_SEL_RANK); i.dst = rank; i.a = sel;
+  }
+  int out_index = 0;
+  for (size_t c = 0; c < pipe.cols.size(); ++c) {
+    const BExprP& e = pipe.cols[c].expr;
+    Val v; SS_RETURN_IF_ERROR(em.value(e, &v));
+    auto store = [&](const Val& x, uint32_t w) {
+      const uint16_t op = st->has_filter ? (w == 8 ? VM_STOREC_64 : w == 4 ? VM_STOREC_32 : VM_STOREC_8)
+                                         : (w == 8 ? VM_STORE_64 : w == 4 ? VM_STORE_32 : VM_STORE_8);
+      LInstr& i = em.emit(op); i.dst_is_reg = false; i.dst = out_index++;
+      if (x.imm) { i.a_imm = true; i.imm = x.bits; } else i.a = x.reg;
+      if (st->has_filter) { i.b = rank; i.c = sel; }
+    };
+    store(v, v.width);
+    if (e->nullable) {
+      Val nv; nv.width = 1;
+      if (v.null >= 0) nv.reg = v.null; else { nv.imm = true; nv.bits = 0; }
+      store(nv, 1);
+    }
+    st->output_bytes_per_row += v.width + (e->nullable ? 1 : 0);
+  }
+  if (out_index > VM_MAX_OUTPUTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many output columns for one pipeline");
+  st->main.n_outputs = out_index;
+  allocate_registers(&st->main);
+  st->algorithmic_bytes_per_row = staged_bytes(st->main);
+  return Status::OK();
+}
+
+Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe) {
+  if (d.ops.empty()) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "empty plan");
+  // chain from the root down to the scan
+  std::vector<int> chain;
+  for (int i = (int)d.ops.size() - 1; i >= 0;) {
+    chain.push_back(i);
+    const int c = d.ops[i].child;
+    if (d.ops[i].kind == SSGPU_OP_SCAN) break;
+    if (c < 0 || c >= i) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "operation child must precede its parent");
+    i = c;
+  }
+  std::reverse(chain.begin(), chain.end());
+  if (d.ops[chain[0]].kind != SSGPU_OP_SCAN) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "plan must start with a scan");
+  for (auto& a : d.input_schema)
+    if (dtype_width(a.dtype) == 0)
+      ;  // STRING/BINARY columns may exist in the input as long as no expression touches them
+  std::ostringstream desc;
+  Pipe pipe;
+  reset_pipe(&pipe, d.input_schema);
+  bool pending = true;  // pipe has operations not yet flushed into a stage
+  for (size_t ci = 1; ci < chain.size(); ++ci) {
+    const ssgpu_op& op = d.ops[chain[ci]];
+    const Schema vs = schema_of(pipe.cols);
+    switch (op.kind) {
+      case SSGPU_OP_COMPUTE: {
+        std::vector<BExprP> bound;
+        SS_RETURN_IF_ERROR(bind_expression(d, op.expr, vs, pipe.depth(), &bound));
+        std::map<const BExpr*, BExprP> memo;
+        std::vector<VCol> nc;
+        for (auto& b : bound) { VCol c; c.name = b->name; c.expr = substitute(b, pipe.cols, &memo); nc.push_back(c); }
+        // substitution keeps the bound node's name/type; INPUT leaves adopt the child's name, restore it
+        for (size_t i = 0; i < nc.size(); ++i) if (nc[i].expr->name != nc[i].name) { BExprP r(new BExpr(*nc[i].expr)); r->name = nc[i].name; nc[i].expr = r; }
+        pipe.cols = nc; pending = true;
+        desc << "Compute -> [" << schema_to_string(schema_of(pipe.cols)) << "]\n";
+      } break;
+      case SSGPU_OP_PROJECT: {
+        std::vector<int> pos; std::vector<std::string> names;
+        SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, vs, &pos, &names));
+        std::vector<VCol> nc;
+        for (size_t i = 0; i < pos.size(); ++i) { VCol c = pipe.cols[pos[i]]; c.name = names[i]; nc.push_back(c); }
+        pipe.cols = nc; pending = true;
+        desc << "Project -> [" << schema_to_string(schema_of(pipe.cols)) << "]\n";
+      } break;
+      case SSGPU_OP_FILTER: {
+        std::vector<BExprP> bound;
+        SS_RETURN_IF_ERROR(bind_expression(d, op.expr, vs, pipe.depth(), &bound));
+        if (bound.size() != 1)
+          return Status::Error(SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH, "Predicate has to return exactly one column of type BOOL");
+        if (bound[0]->dtype != SSGPU_BOOL)
+          return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, "Predicate has to return exactly one column of type BOOL");
+        std::vector<int> pos; std::vector<std::string> names;
+        SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, vs, &pos, &names));
+        std::map<const BExpr*, BExprP> memo;
+        pipe.filters.push_back(substitute(bound[0], pipe.cols, &memo));
+        std::vector<VCol> nc;
+        for (size_t i = 0; i < pos.size(); ++i) { VCol c = pipe.cols[pos[i]]; c.name = names[i]; nc.push_back(c); }
+        pipe.cols = nc; pending = true;
+        desc << "Filter " << bound[0]->name << " -> [" << schema_to_string(schema_of(pipe.cols)) << "]\n";
+      } break;
+      case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: {
+        Stage st;
+        if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
+        else SS_RETURN_IF_ERROR(finish_group_agg(d, op, pipe, &st));
+        desc << (op.kind == SSGPU_OP_SCALAR_AGGREGATE ? "ScalarAggregate" : "GroupAggregate") << " -> [" << schema_to_string(st.out_schema) << "]\n";
+        stages->push_back(st);
+        reset_pipe(&pipe, st.out_schema);
+        pending = false;
+      } break;
+      case SSGPU_OP_SORT: case SSGPU_OP_AGGREGATE_CLUSTERS: {
+        // blocking operators over materialised rows: flush the pipeline first
+        if (pending || stages->empty()) {
+          Stage m; SS_RETURN_IF_ERROR(finish_materialize(pipe, &m));
+          stages->push_back(m);
+          reset_pipe(&pipe, m.out_schema);
+        }
+        Stage st;
+        st.in_schema = pipe.in_schema;
+        if (op.kind == SSGPU_OP_SORT) {
+          st.kind = STAGE_SORT;
+          for (int k = 0; k < op.sort_n; ++k) {
+            const ssgpu_sortkey& sk = d.sortkeys[op.sort_first + k];
+            int pos = lookup_pos(st.in_schema, sk.name);
+            if (pos < 0) return Status::Error(SSGPU_ERROR_ATTRIBUTE_MISSING, std::string("No attribute '") + sk.name + "' in the schema:\n '" + schema_to_string(st.in_schema) + "'");
+            if (dtype_width(st.in_schema[pos].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length sort keys are outside the device hot path");
+            SortKey s; s.col = pos; s.order = sk.order; st.sort_keys.push_back(s);
+          }
+          std::vector<int> pos; std::vector<std::string> names;
+          SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, st.in_schema, &pos, &names));
+          st.sort_out_cols = pos;
+          for (size_t i = 0; i < pos.size(); ++i) { Attr a = st.in_schema[pos[i]]; a.name = names[i]; st.out_schema.push_back(a); }
+          desc << "Sort -> [" << schema_to_string(st.out_schema) << "]\n";
+        } else {
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "AggregateClusters is not lowered yet");
+        }
+        stages->push_back(st);
+        reset_pipe(&pipe, st.out_schema);
+        pending = false;
+      } break;
+      default:
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "operation kind " + std::to_string(op.kind) + " is outside the device hot path");
+    }
+  }
+  if (pending) {
+    Stage m; SS_RETURN_IF_ERROR(finish_materialize(pipe, &m));
+    stages->push_back(m);
+  }
+  *result_schema = stages->back().out_schema;
+  for (size_t i = 0; i < stages->size(); ++i) {
+    desc << "stage " << i << " kind=" << (*stages)[i].kind << "\n" << disassemble((*stages)[i].main);
+    if (!(*stages)[i].count_pass.empty()) desc << " count pass:\n" << disassemble((*stages)[i].count_pass);
+  }
+  *describe = desc.str();
+  return Status::OK();
+}
+
+}  // namespace ssgpu

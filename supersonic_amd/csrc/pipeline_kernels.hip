@@ -1,0 +1,1069 @@
+// pipeline_kernels.hip -- hand-written gfx950 kernels for the fused
+// Scan -> Compute/Project -> Filter -> {ScalarAggregate | GroupAggregate |
+// materialise} pipeline.  See vm.h for the execution model.
+//
+// Reference loops restated here (paths relative to the reference tree):
+//   K1/K2 VectorBinaryPrimitive / VectorUnaryPrimitive
+//         supersonic/expression/vector/vector_primitives.h:99-105,393-412
+//   K3    null propagation  expression/core/projecting_bound_expressions.cc:66-82,
+//         vector_logic.h:30-50, elementary_bound_expressions.cc:343-404
+//   K4    FilterCursor::PrepareInputRowIds  cursor/core/filter.cc:170-199
+//   K5    DataCopier<...SELECTION>  base/infrastructure/copy_column.cc:199-217
+//   K6    ColumnAggregatorImpl::UpdateAggregation  cursor/core/column_aggregator.cc:108-124
+//         + AggregationOperator  base/infrastructure/aggregation_operators.h:173-228
+//   K7    RowHashSetImpl::InsertUnique  cursor/infrastructure/row_hash_set.cc:458-517
+//
+// Compile with -ffp-contract=off: the reference's IEEE + - * / are correctly
+// rounded single operations; FMA contraction would change results.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vm.h"
+#include "launch.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int u32;
+typedef int i32;
+typedef unsigned char u8;
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+template <typename T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2))); };
+
+template <typename T>
+__device__ __forceinline__ typename Vec2<T>::type lds_load2(u32 off, int p) {
+  return *reinterpret_cast<const typename Vec2<T>::type*>(smem + off + (u32)p * (2u * sizeof(T)));
+}
+template <typename T>
+__device__ __forceinline__ void lds_store2(u32 off, int p, T x, T y) {
+  typename Vec2<T>::type v; v.x = x; v.y = y;
+  *reinterpret_cast<typename Vec2<T>::type*>(smem + off + (u32)p * (2u * sizeof(T))) = v;
+}
+template <typename T> __device__ __forceinline__ T imm_as(u64 imm) {
+  T v; __builtin_memcpy(&v, &imm, sizeof(T)); return v;
+}
+// Operand fetch: register pair from LDS, or the broadcast immediate.
+template <typename T>
+__device__ __forceinline__ typename Vec2<T>::type fetch2(u32 off, bool is_imm, u64 imm, int p) {
+  if (is_imm) { typename Vec2<T>::type v; T c = imm_as<T>(imm); v.x = c; v.y = c; return v; }
+  return lds_load2<T>(off, p);
+}
+
+// ---------------------------------------------------------------------------
+// wave-level reductions: DPP inside each 16-lane row, v_readlane across rows.
+// Result is wave-uniform.  EXEC must be full (handlers run in uniform flow).
+// ---------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ u32 dpp32(u32 v) {
+  return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ u64 dpp64(u64 v) {
+  u32 lo = dpp32<CTRL>((u32)v), hi = dpp32<CTRL>((u32)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+  u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
+  u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
+  return ((u64)hi << 32) | lo;
+}
+#define DPP_QUAD_XOR1 0xB1  /* quad_perm:[1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E  /* quad_perm:[2,3,0,1] */
+#define DPP_ROW_ROR4 0x124
+#define DPP_ROW_ROR8 0x128
+
+template <typename Op> __device__ __forceinline__ u64 wave_reduce_u64(u64 v, Op op) {
+  v = op(v, dpp64<DPP_QUAD_XOR1>(v));
+  v = op(v, dpp64<DPP_QUAD_XOR2>(v));
+  v = op(v, dpp64<DPP_ROW_ROR4>(v));
+  v = op(v, dpp64<DPP_ROW_ROR8>(v));
+  u64 r0 = readlane64(v, 0), r1 = readlane64(v, 16), r2 = readlane64(v, 32), r3 = readlane64(v, 48);
+  return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ double u2d(u64 v) { return __longlong_as_double((i64)v); }
+__device__ __forceinline__ u64 d2u(double v) { return (u64)__double_as_longlong(v); }
+
+// double-double (hi, lo) helpers; every operation is a plain IEEE add/sub so
+// the error terms are exact (Knuth TwoSum).  No FMA, no reassociation.
+struct DD { double hi, lo; };
+__device__ __forceinline__ DD dd_add_d(DD a, double v) {
+  double t = a.hi + v;
+  double bp = t - a.hi;
+  double err = (a.hi - (t - bp)) + (v - bp);
+  DD r; r.hi = t; r.lo = a.lo + err; return r;
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+  DD r = dd_add_d(a, b.hi);
+  r.lo = r.lo + b.lo;
+  return r;
+}
+template <int CTRL> __device__ __forceinline__ DD dd_dpp(DD v) {
+  DD r; r.hi = u2d(dpp64<CTRL>(d2u(v.hi))); r.lo = u2d(dpp64<CTRL>(d2u(v.lo))); return r;
+}
+__device__ __forceinline__ DD dd_readlane(DD v, int lane) {
+  DD r; r.hi = u2d(readlane64(d2u(v.hi), lane)); r.lo = u2d(readlane64(d2u(v.lo), lane)); return r;
+}
+__device__ __forceinline__ DD wave_reduce_dd(DD v) {
+  v = dd_add(v, dd_dpp<DPP_QUAD_XOR1>(v));
+  v = dd_add(v, dd_dpp<DPP_QUAD_XOR2>(v));
+  v = dd_add(v, dd_dpp<DPP_ROW_ROR4>(v));
+  v = dd_add(v, dd_dpp<DPP_ROW_ROR8>(v));
+  DD r0 = dd_readlane(v, 0), r1 = dd_readlane(v, 16), r2 = dd_readlane(v, 32), r3 = dd_readlane(v, 48);
+  return dd_add(dd_add(r0, r1), dd_add(r2, r3));
+}
+
+// order-preserving maps so that every MIN/MAX runs on u64 keys
+__device__ __forceinline__ u64 key_i64(i64 v) { return (u64)v ^ 0x8000000000000000ull; }
+__device__ __forceinline__ i64 unkey_i64(u64 k) { return (i64)(k ^ 0x8000000000000000ull); }
+
+// ---------------------------------------------------------------------------
+// row validity for sinks: row exists, passes the selection, value not NULL.
+// ---------------------------------------------------------------------------
+struct Valid2 { bool x, y; };
+__device__ __forceinline__ Valid2 valid_pair(const VmInstr& I, int p, i64 tile_base, i64 n_rows,
+                                             u32 null_off, u32 sel_off) {
+  i64 r0 = tile_base + 2 * (i64)p;
+  Valid2 v; v.x = r0 < n_rows; v.y = (r0 + 1) < n_rows;
+  if (sel_off != VM_NONE) { auto s = lds_load2<u8>(sel_off, p); v.x = v.x && s.x; v.y = v.y && s.y; }
+  if (null_off != VM_NONE) { auto z = lds_load2<u8>(null_off, p); v.x = v.x && !z.x; v.y = v.y && !z.y; }
+  return v;
+}
+
+__device__ __forceinline__ VmAccRec* acc_rec(const VmParams& P, u32 slot, int wave) {
+  return reinterpret_cast<VmAccRec*>(smem + P.acc_lds_off + slot * VM_ACC_STRIDE + wave * 32);
+}
+
+// ---------------------------------------------------------------------------
+// group table helpers (open addressing, linear probing, 64-bit packed keys)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 hash64(u64 k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return (u32)k;
+}
+__device__ __forceinline__ u32 group_insert(const VmGroupTable& G, u64 key) {
+  const u32 mask = G.capacity_mask;
+  if (key == VM_KEY_EMPTY) {           // the one key equal to the sentinel owns slot `capacity`
+    __hip_atomic_store(&G.keys[mask + 1], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return mask + 1;
+  }
+  u32 slot = hash64(key) & mask;
+  for (u32 probe = 0; probe <= mask; ++probe) {
+    u64 cur = __hip_atomic_load(&G.keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return slot;
+    if (cur == VM_KEY_EMPTY) {
+      u64 old = atomicCAS(&G.keys[slot], VM_KEY_EMPTY, key);
+      if (old == VM_KEY_EMPTY || old == key) return slot;
+    }
+    slot = (slot + 1) & mask;
+    if (probe >= 4096) break;          // table (nearly) full: host regrows and reruns
+  }
+  atomicExch(G.overflow, 1u);
+  return 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------
+// input staging: global -> LDS.  Fast path = LDS-DMA, 16 B per lane, 1 KiB per
+// wave instruction, destination wave-uniform base + lane*16 (linear layout).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int tile_rows, int t) {
+  const bool full = tile_base + tile_rows <= P.n_rows;
+  for (int s = 0; s < P.n_staged; ++s) {
+    const VmStagedCol C = P.staged[s];
+    if (C.src == nullptr) {  // nullable attribute whose View carries no is_null vector
+      for (u32 c = (u32)t * 4u; c < (u32)tile_rows * C.width; c += VM_WG_THREADS * 4u)
+        *reinterpret_cast<u32*>(smem + C.lds_off + c) = 0u;
+      continue;
+    }
+    const char* src = reinterpret_cast<const char*>(C.src) + tile_base * (i64)C.width;
+    const u32 bytes = (u32)tile_rows * C.width;
+    if (full && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+      for (u32 c = (u32)t * 16u; c < bytes; c += VM_WG_THREADS * 16u) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + c),
+            (__attribute__((address_space(3))) void*)(smem + C.lds_off + c), 16, 0, 0);
+      }
+    } else {
+      // tail tile or unaligned view: element-wise, rows past the end read as 0
+      const i64 remain = P.n_rows - tile_base;
+      if (C.width == 8) {
+        for (int r = t; r < tile_rows; r += VM_WG_THREADS)
+          reinterpret_cast<u64*>(smem + C.lds_off)[r] = r < remain ? reinterpret_cast<const u64*>(src)[r] : 0ull;
+      } else if (C.width == 4) {
+        for (int r = t; r < tile_rows; r += VM_WG_THREADS)
+          reinterpret_cast<u32*>(smem + C.lds_off)[r] = r < remain ? reinterpret_cast<const u32*>(src)[r] : 0u;
+      } else {
+        for (int r = t; r < tile_rows; r += VM_WG_THREADS)
+          reinterpret_cast<u8*>(smem + C.lds_off)[r] = r < remain ? reinterpret_cast<const u8*>(src)[r] : (u8)0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// handler generators
+// ---------------------------------------------------------------------------
+// Keeps LLVM's speculative-execution / hoisting passes from lifting every case's
+// LDS loads above the switch (which costs >250 VGPRs and all the occupancy).
+#define CASE_FENCE asm volatile("" ::: "memory")
+#define FOR_PAIRS for (int k = 0, p = tp; k < K; ++k, p += VM_WG_THREADS)
+
+#define BINOP(OPNAME, TA, TB, TD, EXPR)                                        \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      auto va = fetch2<TA>(I.a, I.a_imm, I.imm, p);                            \
+      auto vb = fetch2<TB>(I.b, I.b_imm, I.imm, p);                            \
+      TD r0, r1;                                                               \
+      { TA a = va.x; TB b = vb.x; r0 = (TD)(EXPR); }                           \
+      { TA a = va.y; TB b = vb.y; r1 = (TD)(EXPR); }                           \
+      lds_store2<TD>(I.dst, p, r0, r1);                                        \
+    }                                                                          \
+  } break;
+
+#define UNOP(OPNAME, TA, TD, EXPR)                                             \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      auto va = fetch2<TA>(I.a, I.a_imm, I.imm, p);                            \
+      TD r0, r1;                                                               \
+      { TA a = va.x; r0 = (TD)(EXPR); }                                        \
+      { TA a = va.y; r1 = (TD)(EXPR); }                                        \
+      lds_store2<TD>(I.dst, p, r0, r1);                                        \
+    }                                                                          \
+  } break;
+
+// integer aggregate (sum / min / max) on u64 accumulators.
+//   LOADT: register element type, CONV: element -> u64 accumulator domain,
+//   IDENT: identity, COMB(x, y): combine.
+#define AGG_INT(OPNAME, LOADT, CONV, IDENT, COMB)                              \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    u64 local = (IDENT); u32 cnt = 0;                                          \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);              \
+      auto vv = lds_load2<LOADT>(I.a, p);                                      \
+      { LOADT e = vv.x; u64 x = local, y = m.x ? (u64)(CONV) : (u64)(IDENT); local = (COMB); } \
+      { LOADT e = vv.y; u64 x = local, y = m.y ? (u64)(CONV) : (u64)(IDENT); local = (COMB); } \
+      cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));      \
+    }                                                                          \
+    u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(COMB); });\
+    if (lane == 0 && cnt) {                                                    \
+      VmAccRec* A = acc_rec(P, I.dst, wave);                                   \
+      u64 x = A->cnt ? A->v0 : (u64)(IDENT), y = tot;                          \
+      A->v0 = (COMB); A->cnt += cnt;                                           \
+    }                                                                          \
+  } break;
+
+// floating MIN / MAX: "val < result" / "result < val" replaces, so NaN never
+// replaces (aggregation_operators.h:189-228).  Accumulate as doubles.
+#define AGG_FLT(OPNAME, LOADT, IDENT, BETTER)                                  \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    double local = (IDENT); u32 cnt = 0;                                       \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);              \
+      auto vv = lds_load2<LOADT>(I.a, p);                                      \
+      { double x = local, y = (double)vv.x; if (m.x && (BETTER)) local = y; }  \
+      { double x = local, y = (double)vv.y; if (m.y && (BETTER)) local = y; }  \
+      cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));      \
+    }                                                                          \
+    u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {                 \
+      double x = u2d(xa), y = u2d(ya); return (BETTER) ? ya : xa; });          \
+    if (lane == 0 && cnt) {                                                    \
+      VmAccRec* A = acc_rec(P, I.dst, wave);                                   \
+      double x = A->cnt ? u2d(A->v0) : (double)(IDENT), y = u2d(tot);          \
+      A->v0 = d2u((BETTER) ? y : x); A->cnt += cnt;                            \
+    }                                                                          \
+  } break;
+
+// FIRST / LAST: value at the smallest / largest contributing global row id.
+#define AGG_POS(OPNAME, LOADT, IDENTROW, BETTERROW)                            \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    u64 brow = (IDENTROW), bval = 0; u32 cnt = 0;                              \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);              \
+      auto vv = lds_load2<LOADT>(I.a, p);                                      \
+      u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);                  \
+      { u64 x = brow, y = r0;     if (m.x && (BETTERROW)) { brow = y; bval = (u64)vv.x; } } \
+      { u64 x = brow, y = r0 + 1; if (m.y && (BETTERROW)) { brow = y; bval = (u64)vv.y; } } \
+      cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));      \
+    }                                                                          \
+    u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return (BETTERROW) ? y : x; }); \
+    u64 owner = __ballot(brow == trow && cnt != 0);                            \
+    if (cnt) {                                                                 \
+      int src = __ffsll((long long)owner) - 1;                                 \
+      u64 tval = readlane64(bval, src);                                        \
+      if (lane == 0) {                                                         \
+        VmAccRec* A = acc_rec(P, I.dst, wave);                                 \
+        u64 x = A->cnt ? A->v1 : (u64)(IDENTROW), y = trow;                    \
+        if (BETTERROW) { A->v1 = trow; A->v0 = tval; }                         \
+        A->cnt += cnt;                                                         \
+      }                                                                        \
+    }                                                                          \
+  } break;
+
+#define STORE_OP(OPNAME, T)                                                    \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      i64 r0 = tile_base + 2 * (i64)p;                                         \
+      auto vv = fetch2<T>(I.a, I.a_imm, I.imm, p);                             \
+      if (r0 + 1 < P.n_rows) {                                                 \
+        *reinterpret_cast<typename Vec2<T>::type*>(out + r0) = vv;             \
+      } else if (r0 < P.n_rows) {                                              \
+        out[r0] = vv.x;                                                        \
+      }                                                                        \
+    }                                                                          \
+  } break;
+
+#define STOREC_OP(OPNAME, T)                                                   \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.c);          \
+      auto vv = fetch2<T>(I.a, I.a_imm, I.imm, p);                             \
+      auto rk = lds_load2<u32>(I.b, p);                                        \
+      if (m.x) out[rk.x] = vv.x;                                               \
+      if (m.y) out[rk.y] = vv.y;                                               \
+    }                                                                          \
+  } break;
+
+#define KEY_APPEND_OP(OPNAME, T, UT)                                           \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    const u32 shift = (u32)(I.imm & 0xFF), bits = (u32)((I.imm >> 8) & 0xFF);  \
+    const u32 nullbit = (u32)((I.imm >> 16) & 0xFF);                           \
+    const u64 vmask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);            \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      auto kk = lds_load2<u64>(I.dst, p);                                      \
+      auto vv = lds_load2<T>(I.a, p);                                          \
+      u64 a0 = ((u64)(UT)vv.x) & vmask, a1 = ((u64)(UT)vv.y) & vmask;          \
+      if (I.b != VM_NONE) {                                                    \
+        auto z = lds_load2<u8>(I.b, p);                                        \
+        if (z.x) a0 = 1ull << (nullbit - shift);                               \
+        if (z.y) a1 = 1ull << (nullbit - shift);                               \
+      }                                                                        \
+      lds_store2<u64>(I.dst, p, kk.x | (a0 << shift), kk.y | (a1 << shift));   \
+    }                                                                          \
+  } break;
+
+// group aggregate by global atomics on acc[slot * n_gaggs + s]
+#define GAGG_PROLOGUE(LOADT)                                                   \
+      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, VM_NONE);          \
+      auto sl = lds_load2<u32>(I.c, p);                                        \
+      m.x = m.x && sl.x != 0xFFFFFFFFu; m.y = m.y && sl.y != 0xFFFFFFFFu;      \
+      auto vv = lds_load2<LOADT>(I.a, p);
+
+#define GAGG_ATOMIC(OPNAME, LOADT, ATOM)                                       \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    const u32 ng = (u32)(I.imm >> 32) & 0x7FFFFFFFu, s = (u32)I.imm;           \
+    const bool has_cnt = (I.imm >> 63) != 0;                                   \
+    _Pragma("unroll") FOR_PAIRS {                                              \
+      GAGG_PROLOGUE(LOADT)                                                     \
+      if (m.x) { u64* A = &P.group.acc[(u64)sl.x * ng + s]; LOADT e = vv.x; ATOM; \
+                 if (has_cnt) atomicAdd(&P.group.cnt[(u64)sl.x * ng + s], 1u); } \
+      if (m.y) { u64* A = &P.group.acc[(u64)sl.y * ng + s]; LOADT e = vv.y; ATOM; \
+                 if (has_cnt) atomicAdd(&P.group.cnt[(u64)sl.y * ng + s], 1u); } \
+    }                                                                          \
+  } break;
+
+// ---------------------------------------------------------------------------
+// the pipeline kernel: persistent workgroups stride over tiles
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const VmParams P) {
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int tile_rows = 512 * K;
+
+  // zero this workgroup's aggregate accumulators
+  for (u32 o = (u32)t * 8u; o < (u32)P.n_slots * VM_ACC_STRIDE; o += VM_WG_THREADS * 8u)
+    *reinterpret_cast<u64*>(smem + P.acc_lds_off + o) = 0ull;
+
+  for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const i64 tile_base = (i64)tile * tile_rows;
+    __syncthreads();  // previous tile's readers are done with LDS
+    stage_tile(P, tile_base, tile_rows, t);
+    __syncthreads();  // carries vmcnt(0): DMA'd data visible to the whole workgroup
+
+    for (int pc = 0; pc < P.n_instr; ++pc) {
+      const VmInstr I = P.prog[pc];
+      // launder the thread id once per instruction: without this LICM hoists every
+      // case's (t * width) address chain into the prologue (255 VGPRs, occupancy 1)
+      int tp = t;
+      asm volatile("" : "+v"(tp));
+      switch (I.op) {
+        case VM_NOP: break;
+        // ---- arithmetic ---------------------------------------------------
+        BINOP(ADD_I32, u32, u32, u32, a + b)
+        BINOP(ADD_I64, u64, u64, u64, a + b)
+        BINOP(ADD_F32, float, float, float, a + b)
+        BINOP(ADD_F64, double, double, double, a + b)
+        BINOP(SUB_I32, u32, u32, u32, a - b)
+        BINOP(SUB_I64, u64, u64, u64, a - b)
+        BINOP(SUB_F32, float, float, float, a - b)
+        BINOP(SUB_F64, double, double, double, a - b)
+        BINOP(MUL_I32, u32, u32, u32, a * b)
+        BINOP(MUL_I64, u64, u64, u64, a * b)
+        BINOP(MUL_F32, float, float, float, a * b)
+        BINOP(MUL_F64, double, double, double, a * b)
+        BINOP(DIV_F32, float, float, float, a / b)
+        BINOP(DIV_F64, double, double, double, a / b)
+        // integer division / modulus: rows with a zero divisor are NULL (nulling)
+        // or flagged (signaling) by a preceding *_DIVZERO_* instruction; compute 0
+        // there so no trap-like behaviour exists on device.
+        BINOP(CDIV_I32, i32, i32, i32, (b == 0 ? 0 : (b == -1 ? (i32)(0u - (u32)a) : a / b)))
+        BINOP(CDIV_I64, i64, i64, i64, (b == 0 ? 0 : (b == -1 ? (i64)(0ull - (u64)a) : a / b)))
+        BINOP(CDIV_U32, u32, u32, u32, (b == 0 ? 0u : a / b))
+        BINOP(CDIV_U64, u64, u64, u64, (b == 0 ? 0ull : a / b))
+        BINOP(MOD_I32, i32, i32, i32, (b == 0 || b == -1 ? 0 : a % b))
+        BINOP(MOD_I64, i64, i64, i64, (b == 0 || b == -1 ? 0 : a % b))
+        BINOP(MOD_U32, u32, u32, u32, (b == 0 ? 0u : a % b))
+        BINOP(MOD_U64, u64, u64, u64, (b == 0 ? 0ull : a % b))
+        UNOP(NEG_I32, u32, u32, 0u - a)
+        UNOP(NEG_I64, u64, u64, 0ull - a)
+        UNOP(NEG_F32, float, float, -a)
+        UNOP(NEG_F64, double, double, -a)
+        // ---- bitwise --------------------------------------------------------
+        BINOP(BAND_32, u32, u32, u32, a & b)
+        BINOP(BAND_64, u64, u64, u64, a & b)
+        BINOP(BOR_32, u32, u32, u32, a | b)
+        BINOP(BOR_64, u64, u64, u64, a | b)
+        BINOP(BXOR_32, u32, u32, u32, a ^ b)
+        BINOP(BXOR_64, u64, u64, u64, a ^ b)
+        BINOP(BANDNOT_32, u32, u32, u32, (~a) & b)
+        BINOP(BANDNOT_64, u64, u64, u64, (~a) & b)
+        UNOP(BNOT_32, u32, u32, ~a)
+        UNOP(BNOT_64, u64, u64, ~a)
+        BINOP(SHL_I32, u32, u32, u32, a << (b & 31))
+        BINOP(SHL_I64, u64, u64, u64, a << (b & 63))
+        BINOP(SHR_I32, i32, u32, i32, a >> (b & 31))
+        BINOP(SHR_I64, i64, u64, i64, a >> (b & 63))
+        BINOP(SHR_U32, u32, u32, u32, a >> (b & 31))
+        BINOP(SHR_U64, u64, u64, u64, a >> (b & 63))
+        // ---- comparisons ----------------------------------------------------
+        BINOP(LT_I32, i32, i32, u8, a < b)
+        BINOP(LT_I64, i64, i64, u8, a < b)
+        BINOP(LT_U32, u32, u32, u8, a < b)
+        BINOP(LT_U64, u64, u64, u8, a < b)
+        BINOP(LT_F32, float, float, u8, a < b)
+        BINOP(LT_F64, double, double, u8, a < b)
+        BINOP(LT_B8, u8, u8, u8, a < b)
+        BINOP(LE_I32, i32, i32, u8, a <= b)
+        BINOP(LE_I64, i64, i64, u8, a <= b)
+        BINOP(LE_U32, u32, u32, u8, a <= b)
+        BINOP(LE_U64, u64, u64, u8, a <= b)
+        BINOP(LE_F32, float, float, u8, a <= b)
+        BINOP(LE_F64, double, double, u8, a <= b)
+        BINOP(LE_B8, u8, u8, u8, a <= b)
+        BINOP(EQ_32, u32, u32, u8, a == b)
+        BINOP(EQ_64, u64, u64, u8, a == b)
+        BINOP(EQ_F32, float, float, u8, a == b)
+        BINOP(EQ_F64, double, double, u8, a == b)
+        BINOP(EQ_B8, u8, u8, u8, a == b)
+        BINOP(NE_32, u32, u32, u8, a != b)
+        BINOP(NE_64, u64, u64, u8, a != b)
+        BINOP(NE_F32, float, float, u8, a != b)
+        BINOP(NE_F64, double, double, u8, a != b)
+        BINOP(NE_B8, u8, u8, u8, a != b)
+        BINOP(LT_I64_U64, i64, u64, u8, (a < 0) || ((u64)a < b))
+        BINOP(LT_U64_I64, u64, i64, u8, (b >= 0) && (a < (u64)b))
+        BINOP(LE_I64_U64, i64, u64, u8, (a < 0) || ((u64)a <= b))
+        BINOP(LE_U64_I64, u64, i64, u8, (b >= 0) && (a <= (u64)b))
+        BINOP(EQ_I64_U64, i64, u64, u8, (a >= 0) && ((u64)a == b))
+        BINOP(NE_I64_U64, i64, u64, u8, (a < 0) || ((u64)a != b))
+        // ---- casts -----------------------------------------------------------
+        UNOP(CAST_I32_I64, i32, i64, a)
+        UNOP(CAST_U32_I64, u32, i64, a)
+        UNOP(CAST_I64_I32, u64, u32, a)
+        UNOP(CAST_I32_F32, i32, float, a)
+        UNOP(CAST_I32_F64, i32, double, a)
+        UNOP(CAST_U32_F32, u32, float, a)
+        UNOP(CAST_U32_F64, u32, double, a)
+        UNOP(CAST_I64_F32, i64, float, a)
+        UNOP(CAST_I64_F64, i64, double, a)
+        UNOP(CAST_U64_F32, u64, float, a)
+        UNOP(CAST_U64_F64, u64, double, a)
+        UNOP(CAST_F32_F64, float, double, a)
+        UNOP(CAST_F64_F32, double, float, a)
+        UNOP(CAST_F32_I32, float, i32, a)
+        UNOP(CAST_F32_I64, float, i64, a)
+        UNOP(CAST_F32_U32, float, u32, a)
+        UNOP(CAST_F32_U64, float, u64, a)
+        UNOP(CAST_F64_I32, double, i32, a)
+        UNOP(CAST_F64_I64, double, i64, a)
+        UNOP(CAST_F64_U32, double, u32, a)
+        UNOP(CAST_F64_U64, double, u64, a)
+        UNOP(CAST_B8_I32, u8, i32, (a != 0))
+        UNOP(CAST_B8_I64, u8, i64, (a != 0))
+        UNOP(CAST_B8_F32, u8, float, (a != 0))
+        UNOP(CAST_B8_F64, u8, double, (a != 0))
+        UNOP(CAST_32_B8, u32, u8, (a != 0))
+        UNOP(CAST_64_B8, u64, u8, (a != 0))
+        UNOP(CAST_F32_B8, float, u8, (a != 0.0f))
+        UNOP(CAST_F64_B8, double, u8, (a != 0.0))
+        UNOP(COPY_8, u8, u8, a)
+        UNOP(COPY_32, u32, u32, a)
+        UNOP(COPY_64, u64, u64, a)
+        UNOP(FILL_8, u8, u8, a)
+        UNOP(FILL_32, u32, u32, a)
+        UNOP(FILL_64, u64, u64, a)
+        // ---- logic ------------------------------------------------------------
+        BINOP(AND_B8, u8, u8, u8, (a && b))
+        BINOP(OR_B8, u8, u8, u8, (a || b))
+        BINOP(XOR_B8, u8, u8, u8, ((a != 0) != (b != 0)))
+        BINOP(ANDNOT_B8, u8, u8, u8, (!a && b))
+        UNOP(NOT_B8, u8, u8, !a)
+        BINOP(NULL_OR, u8, u8, u8, (a || b))
+        // SQL three-valued AND / OR (elementary_bound_expressions.cc:343-404):
+        // operands a,b values; null masks at (imm & 0xFFFFFFFF) and (imm >> 32),
+        // VM_NONE when the side is not nullable.  dst = value, c = null out.
+        case VM_AND3:
+        case VM_OR3: { CASE_FENCE;
+          const u32 an_off = (u32)I.imm, bn_off = (u32)(I.imm >> 32);
+          const bool is_and = I.op == VM_AND3;
+          _Pragma("unroll") FOR_PAIRS {
+            auto va = lds_load2<u8>(I.a, p); auto vb = lds_load2<u8>(I.b, p);
+            Vec2<u8>::type an, bn; an.x = an.y = 0; bn.x = bn.y = 0;
+            if (an_off != VM_NONE) an = lds_load2<u8>(an_off, p);
+            if (bn_off != VM_NONE) bn = lds_load2<u8>(bn_off, p);
+            u8 v[2], z[2];
+            u8 aa[2] = {va.x, va.y}, bb[2] = {vb.x, vb.y}, na[2] = {an.x, an.y}, nb[2] = {bn.x, bn.y};
+            for (int j = 0; j < 2; ++j) {
+              bool A = aa[j] != 0, B = bb[j] != 0, NA = na[j] != 0, NB = nb[j] != 0;
+              if (is_and) {
+                bool decided_false = (!NA && !A) || (!NB && !B);
+                z[j] = (NA || NB) && !decided_false;
+                v[j] = !decided_false && A && B;
+              } else {
+                bool decided_true = (!NA && A) || (!NB && B);
+                z[j] = (NA || NB) && !decided_true;
+                v[j] = decided_true || (A || B);
+              }
+            }
+            lds_store2<u8>(I.dst, p, v[0], v[1]);
+            lds_store2<u8>(I.c, p, z[0], z[1]);
+          }
+        } break;
+        // dst(null mask) = a(null mask or NONE) | (b == 0)
+#define NULL_DIVZERO(OPNAME, T)                                                \
+        case VM_##OPNAME: { CASE_FENCE;                                        \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
+            Vec2<u8>::type z; z.x = z.y = 0;                                   \
+            if (I.a != VM_NONE) z = lds_load2<u8>(I.a, p);                     \
+            lds_store2<u8>(I.dst, p, (u8)(z.x || vb.x == (T)0), (u8)(z.y || vb.y == (T)0)); \
+          }                                                                    \
+        } break;
+        NULL_DIVZERO(NULL_DIVZERO_32, u32)
+        NULL_DIVZERO(NULL_DIVZERO_64, u64)
+        NULL_DIVZERO(NULL_DIVZERO_F32, float)
+        NULL_DIVZERO(NULL_DIVZERO_F64, double)
+        // signaling: a = null mask (or NONE), b = divisor, c = selection (or NONE)
+#define FAIL_DIVZERO(OPNAME, T)                                                \
+        case VM_##OPNAME: { CASE_FENCE;                                        \
+          bool bad = false;                                                    \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.a, I.c);        \
+            auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
+            bad = bad || (m.x && vb.x == (T)0) || (m.y && vb.y == (T)0);       \
+          }                                                                    \
+          if (bad) atomicExch(P.error_flag, (u32)SSGPU_EVAL_ERROR_DIVZERO);    \
+        } break;
+#define SSGPU_EVAL_ERROR_DIVZERO 1
+        FAIL_DIVZERO(FAIL_DIVZERO_32, u32)
+        FAIL_DIVZERO(FAIL_DIVZERO_64, u64)
+        FAIL_DIVZERO(FAIL_DIVZERO_F32, float)
+        FAIL_DIVZERO(FAIL_DIVZERO_F64, double)
+#define SELECT_OP(OPNAME, T)                                                   \
+        case VM_##OPNAME: { CASE_FENCE;                                        \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            auto va = fetch2<T>(I.a, I.a_imm, I.imm, p);                       \
+            auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
+            auto vc = lds_load2<u8>(I.c, p);                                   \
+            lds_store2<T>(I.dst, p, vc.x ? va.x : vb.x, vc.y ? va.y : vb.y);   \
+          }                                                                    \
+        } break;
+        SELECT_OP(SELECT_8, u8)
+        SELECT_OP(SELECT_32, u32)
+        SELECT_OP(SELECT_64, u64)
+        case VM_SEL_FROM_PRED: { CASE_FENCE;  // keep iff predicate is non-NULL and TRUE (filter.cc:180-196)
+          _Pragma("unroll") FOR_PAIRS {
+            auto va = fetch2<u8>(I.a, I.a_imm, I.imm, p);
+            u8 s0 = va.x != 0, s1 = va.y != 0;
+            if (I.b != VM_NONE) { auto z = lds_load2<u8>(I.b, p); s0 = s0 && !z.x; s1 = s1 && !z.y; }
+            if (I.c != VM_NONE) { auto q = lds_load2<u8>(I.c, p); s0 = s0 && q.x; s1 = s1 && q.y; }
+            lds_store2<u8>(I.dst, p, s0, s1);
+          }
+        } break;
+
+        // ---- scalar aggregate sinks -------------------------------------------
+        case VM_AGG_COUNT: { CASE_FENCE;
+          u32 cnt = 0;
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+          }
+          if (lane == 0) { VmAccRec* A = acc_rec(P, I.dst, wave); A->v0 += cnt; A->cnt += cnt; }
+        } break;
+        AGG_INT(AGG_SUM_I32, i32, (i64)e, 0ull, x + y)
+        AGG_INT(AGG_SUM_U32, u32, e, 0ull, x + y)
+        AGG_INT(AGG_SUM_I64, u64, e, 0ull, x + y)
+        AGG_INT(AGG_MIN_I32, i32, key_i64((i64)e), ~0ull, (x < y ? x : y))
+        AGG_INT(AGG_MIN_U32, u32, e, ~0ull, (x < y ? x : y))
+        AGG_INT(AGG_MIN_I64, i64, key_i64(e), ~0ull, (x < y ? x : y))
+        AGG_INT(AGG_MIN_U64, u64, e, ~0ull, (x < y ? x : y))
+        AGG_INT(AGG_MIN_B8, u8, (e != 0), ~0ull, (x < y ? x : y))
+        AGG_INT(AGG_MAX_I32, i32, key_i64((i64)e), 0ull, (x > y ? x : y))
+        AGG_INT(AGG_MAX_U32, u32, e, 0ull, (x > y ? x : y))
+        AGG_INT(AGG_MAX_I64, i64, key_i64(e), 0ull, (x > y ? x : y))
+        AGG_INT(AGG_MAX_U64, u64, e, 0ull, (x > y ? x : y))
+        AGG_INT(AGG_MAX_B8, u8, (e != 0), 0ull, (x > y ? x : y))
+        AGG_FLT(AGG_MIN_F32, float, __builtin_inf(), (y < x))
+        AGG_FLT(AGG_MIN_F64, double, __builtin_inf(), (y < x))
+        AGG_FLT(AGG_MAX_F32, float, -__builtin_inf(), (x < y))
+        AGG_FLT(AGG_MAX_F64, double, -__builtin_inf(), (x < y))
+        case VM_AGG_SUM_F32:
+        case VM_AGG_SUM_F64: { CASE_FENCE;
+          // compensated (double-double) sum: bit-identical to the reference's
+          // sequential fold whenever every partial sum is exact, and within 1 ULP of
+          // the exact sum otherwise (the sequential fold itself is not).
+          DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;
+          const bool f32 = I.op == VM_AGG_SUM_F32;
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);
+            double e0, e1;
+            if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; }
+            else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
+            if (m.x) local = dd_add_d(local, e0);
+            if (m.y) local = dd_add_d(local, e1);
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+          }
+          DD tot = wave_reduce_dd(local);
+          if (lane == 0 && cnt) {
+            VmAccRec* A = acc_rec(P, I.dst, wave);
+            DD cur; cur.hi = A->cnt ? u2d(A->v0) : -0.0; cur.lo = A->cnt ? u2d(A->v1) : 0.0;
+            cur = dd_add(cur, tot);
+            A->v0 = d2u(cur.hi); A->v1 = d2u(cur.lo); A->cnt += cnt;
+          }
+        } break;
+        AGG_POS(AGG_FIRST_8, u8, ~0ull, (y < x))
+        AGG_POS(AGG_FIRST_32, u32, ~0ull, (y < x))
+        AGG_POS(AGG_FIRST_64, u64, ~0ull, (y < x))
+        AGG_POS(AGG_LAST_8, u8, 0ull, (y >= x))
+        AGG_POS(AGG_LAST_32, u32, 0ull, (y >= x))
+        AGG_POS(AGG_LAST_64, u64, 0ull, (y >= x))
+
+        // ---- materialising sinks ----------------------------------------------
+        case VM_SEL_COUNT: { CASE_FENCE;
+          u32 cnt = 0;
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.a);
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+          }
+          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
+          if (lane == 0) scratch[wave] = cnt;
+          __syncthreads();
+          if (t == 0) P.tile_counts[tile] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+          __syncthreads();
+        } break;
+        case VM_SEL_RANK: { CASE_FENCE;
+          // order-preserving ranks: rows are ordered (k, wave, lane, j)
+          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.a);
+            u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            if (lane == 0) scratch[k * VM_WAVES + wave] = c;
+          }
+          __syncthreads();
+          u32 base = P.tile_offsets[tile];
+          const u64 lt = (1ull << lane) - 1ull;
+          _Pragma("unroll") FOR_PAIRS {
+            u32 mine = base;
+            for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
+            for (int w = 0; w < VM_WAVES; ++w) base += scratch[k * VM_WAVES + w];
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.a);
+            u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
+            u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
+            lds_store2<u32>(I.dst, p, r0, r0 + (m.x ? 1u : 0u));
+          }
+          __syncthreads();
+        } break;
+        STORE_OP(STORE_8, u8)
+        STORE_OP(STORE_32, u32)
+        STORE_OP(STORE_64, u64)
+        STOREC_OP(STOREC_8, u8)
+        STOREC_OP(STOREC_32, u32)
+        STOREC_OP(STOREC_64, u64)
+        case VM_STORE_ROWID: { CASE_FENCE;
+          i64* out = reinterpret_cast<i64*>(P.outputs[I.dst].dst);
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.c);
+            auto rk = lds_load2<u32>(I.b, p);
+            i64 r0 = P.row_id_base + tile_base + 2 * (i64)p;
+            if (m.x) out[rk.x] = r0;
+            if (m.y) out[rk.y] = r0 + 1;
+          }
+        } break;
+
+        // ---- group aggregate sinks ----------------------------------------------
+        UNOP(KEY_ZERO, u64, u64, (a & 0ull))
+        KEY_APPEND_OP(KEY_APPEND_8, u8, u8)
+        KEY_APPEND_OP(KEY_APPEND_32, u32, u32)
+        KEY_APPEND_OP(KEY_APPEND_64, u64, u64)
+        case VM_GRP_INSERT: { CASE_FENCE;
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.c);
+            auto kk = lds_load2<u64>(I.a, p);
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+            u32 s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;
+            if (m.x) { s0 = group_insert(P.group, kk.x); if (s0 != 0xFFFFFFFFu) atomicMin(&P.group.first_row[s0], r0); }
+            if (m.y) { s1 = group_insert(P.group, kk.y); if (s1 != 0xFFFFFFFFu) atomicMin(&P.group.first_row[s1], r0 + 1); }
+            lds_store2<u32>(I.dst, p, s0, s1);
+          }
+        } break;
+        case VM_GAGG_COUNT: { CASE_FENCE;
+          const u32 ng = (u32)(I.imm >> 32), s = (u32)I.imm;
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, VM_NONE);
+            auto sl = lds_load2<u32>(I.c, p);
+            if (m.x && sl.x != 0xFFFFFFFFu) atomicAdd(&P.group.acc[(u64)sl.x * ng + s], 1ull);
+            if (m.y && sl.y != 0xFFFFFFFFu) atomicAdd(&P.group.acc[(u64)sl.y * ng + s], 1ull);
+          }
+        } break;
+        GAGG_ATOMIC(GAGG_SUM_I32, i32, atomicAdd(A, (u64)(i64)e))
+        GAGG_ATOMIC(GAGG_SUM_U32, u32, atomicAdd(A, (u64)e))
+        GAGG_ATOMIC(GAGG_SUM_I64, u64, atomicAdd(A, e))
+        GAGG_ATOMIC(GAGG_SUM_F32, float, unsafeAtomicAdd(reinterpret_cast<double*>(A), (double)e))
+        GAGG_ATOMIC(GAGG_SUM_F64, double, unsafeAtomicAdd(reinterpret_cast<double*>(A), e))
+        GAGG_ATOMIC(GAGG_MIN_I32, i32, atomicMin(A, key_i64((i64)e)))
+        GAGG_ATOMIC(GAGG_MIN_U32, u32, atomicMin(A, (u64)e))
+        GAGG_ATOMIC(GAGG_MIN_I64, i64, atomicMin(A, key_i64(e)))
+        GAGG_ATOMIC(GAGG_MIN_U64, u64, atomicMin(A, e))
+        GAGG_ATOMIC(GAGG_MIN_B8, u8, atomicMin(A, (u64)(e != 0)))
+        GAGG_ATOMIC(GAGG_MAX_I32, i32, atomicMax(A, key_i64((i64)e)))
+        GAGG_ATOMIC(GAGG_MAX_U32, u32, atomicMax(A, (u64)e))
+        GAGG_ATOMIC(GAGG_MAX_I64, i64, atomicMax(A, key_i64(e)))
+        GAGG_ATOMIC(GAGG_MAX_U64, u64, atomicMax(A, e))
+        GAGG_ATOMIC(GAGG_MAX_B8, u8, atomicMax(A, (u64)(e != 0)))
+        // floating MIN/MAX through the total-order key of the double (NaN rows skipped:
+        // "val < result" is false for NaN, aggregation_operators.h:200,221)
+#define FKEY(d) ({ u64 b_ = d2u((double)(d)); (b_ & 0x8000000000000000ull) ? ~b_ : (b_ | 0x8000000000000000ull); })
+        GAGG_ATOMIC(GAGG_MIN_F32, float, if (e == e) atomicMin(A, FKEY(e)))
+        GAGG_ATOMIC(GAGG_MIN_F64, double, if (e == e) atomicMin(A, FKEY(e)))
+        GAGG_ATOMIC(GAGG_MAX_F32, float, if (e == e) atomicMax(A, FKEY(e)))
+        GAGG_ATOMIC(GAGG_MAX_F64, double, if (e == e) atomicMax(A, FKEY(e)))
+        default: break;
+      }
+    }
+  }
+
+  // publish this workgroup's partial aggregates (wave order, deterministic)
+  if (P.n_slots > 0) {
+    __syncthreads();
+    for (int s = t; s < P.n_slots; s += VM_WG_THREADS) {
+      VmAccRec out; out.v0 = 0; out.v1 = 0; out.cnt = 0; out.pad = 0;
+      // the combine rule is applied by the finish kernel; here we only forward
+      // the four wave records in wave order
+      for (int w = 0; w < VM_WAVES; ++w)
+        P.wg_partials[((size_t)blockIdx.x * P.n_slots + s) * VM_WAVES + w] = *acc_rec(P, (u32)s, w);
+      (void)out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finish kernel: combine [grid][n_slots][4 waves] partial records per slot, in
+// (workgroup, wave) order, by the slot's rule.  One thread per slot.
+// ---------------------------------------------------------------------------
+
+__global__ void ssgpu_finish_slots_kernel(const VmAccRec* __restrict__ partials, int n_records_per_slot_stride,
+                                          int n_slots, int n_parts, const int* __restrict__ slot_kind,
+                                          VmAccRec* __restrict__ out) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int kind = slot_kind[s];
+  VmAccRec acc; acc.v0 = 0; acc.v1 = 0; acc.cnt = 0; acc.pad = 0;
+  if (kind == SLOT_SUM_DD) { acc.v0 = d2u(-0.0); acc.v1 = d2u(0.0); }
+  for (int i = 0; i < n_parts; ++i) {
+    const VmAccRec r = partials[((size_t)(i / VM_WAVES) * n_slots + s) * VM_WAVES + (i % VM_WAVES)];
+    if (r.cnt == 0) continue;
+    switch (kind) {
+      case SLOT_COUNT:
+      case SLOT_SUM_INT: acc.v0 += r.v0; break;
+      case SLOT_SUM_DD: {
+        DD a; a.hi = u2d(acc.v0); a.lo = u2d(acc.v1);
+        DD b; b.hi = u2d(r.v0); b.lo = u2d(r.v1);
+        a = dd_add(a, b); acc.v0 = d2u(a.hi); acc.v1 = d2u(a.lo);
+      } break;
+      case SLOT_MIN_U64: acc.v0 = acc.cnt ? (r.v0 < acc.v0 ? r.v0 : acc.v0) : r.v0; break;
+      case SLOT_MAX_U64: acc.v0 = acc.cnt ? (r.v0 > acc.v0 ? r.v0 : acc.v0) : r.v0; break;
+      case SLOT_MIN_F64: acc.v0 = acc.cnt ? (u2d(r.v0) < u2d(acc.v0) ? r.v0 : acc.v0) : r.v0; break;
+      case SLOT_MAX_F64: acc.v0 = acc.cnt ? (u2d(acc.v0) < u2d(r.v0) ? r.v0 : acc.v0) : r.v0; break;
+      case SLOT_FIRST: if (!acc.cnt || r.v1 < acc.v1) { acc.v0 = r.v0; acc.v1 = r.v1; } break;
+      case SLOT_LAST: if (!acc.cnt || r.v1 >= acc.v1) { acc.v0 = r.v0; acc.v1 = r.v1; } break;
+    }
+    acc.cnt += r.cnt;
+  }
+  (void)n_records_per_slot_stride;
+  out[s] = acc;
+}
+
+// Reducible-state <-> slot records for the multi-GPU exchange.  The state is
+// eight u64 arrays of n_slots elements: [sum_i64 | cnt | dd_hi | dd_lo | min_u64 |
+// max_u64 | min_f64 | max_f64], each combined across ranks by one element-wise
+// all-reduce (sum / sum / sum / sum / min / max / min / max).
+__global__ void ssgpu_slots_to_state_kernel(const VmAccRec* __restrict__ recs, int n_slots,
+                                            const int* __restrict__ slot_kind, u64* __restrict__ state) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const VmAccRec r = recs[s];
+  const int kind = slot_kind[s];
+  u64* sum_i = state; u64* cnt = state + n_slots; u64* hi = state + 2 * n_slots; u64* lo = state + 3 * n_slots;
+  u64* mn = state + 4 * n_slots; u64* mx = state + 5 * n_slots;
+  u64* mnf = state + 6 * n_slots; u64* mxf = state + 7 * n_slots;
+  sum_i[s] = (kind == SLOT_SUM_INT || kind == SLOT_COUNT) ? r.v0 : 0;
+  cnt[s] = r.cnt;
+  hi[s] = kind == SLOT_SUM_DD ? r.v0 : d2u(0.0);
+  lo[s] = kind == SLOT_SUM_DD ? r.v1 : d2u(0.0);
+  // signed-order view so that an int64 all-reduce min/max is order-correct for u64 keys
+  mn[s] = (kind == SLOT_MIN_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : 0x7FFFFFFFFFFFFFFFull;
+  mx[s] = (kind == SLOT_MAX_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : 0x8000000000000000ull;
+  mnf[s] = (kind == SLOT_MIN_F64 && r.cnt) ? r.v0 : d2u(__builtin_inf());
+  mxf[s] = (kind == SLOT_MAX_F64 && r.cnt) ? r.v0 : d2u(-__builtin_inf());
+}
+__global__ void ssgpu_state_to_slots_kernel(const u64* __restrict__ state, int n_slots,
+                                            const int* __restrict__ slot_kind, VmAccRec* __restrict__ recs) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int kind = slot_kind[s];
+  VmAccRec r; r.v0 = 0; r.v1 = 0; r.pad = 0;
+  r.cnt = state[n_slots + s];
+  switch (kind) {
+    case SLOT_COUNT: case SLOT_SUM_INT: r.v0 = state[s]; break;
+    case SLOT_SUM_DD: {
+      // the all-reduce summed hi and lo parts independently; renormalise
+      DD a; a.hi = u2d(state[2 * n_slots + s]); a.lo = 0.0;
+      a = dd_add_d(a, u2d(state[3 * n_slots + s]));
+      r.v0 = d2u(a.hi); r.v1 = d2u(a.lo);
+    } break;
+    case SLOT_MIN_U64: r.v0 = state[4 * n_slots + s] ^ 0x8000000000000000ull; break;
+    case SLOT_MAX_U64: r.v0 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
+    case SLOT_MIN_F64: r.v0 = state[6 * n_slots + s]; break;
+    case SLOT_MAX_F64: r.v0 = state[7 * n_slots + s]; break;
+    default: break;
+  }
+  recs[s] = r;
+}
+
+// Emit one aggregate result column element from its final slot record.
+// out_kind encodes the conversion from the accumulator domain to the column type.
+
+__device__ __forceinline__ void emit_value(void* dst, size_t idx, int out_kind, u64 v0, u64 v1) {
+  switch (out_kind) {
+    case EMIT_U64: reinterpret_cast<u64*>(dst)[idx] = v0; break;
+    case EMIT_I64KEY: reinterpret_cast<i64*>(dst)[idx] = unkey_i64(v0); break;
+    case EMIT_U32: reinterpret_cast<u32*>(dst)[idx] = (u32)v0; break;
+    case EMIT_I32KEY: reinterpret_cast<i32*>(dst)[idx] = (i32)unkey_i64(v0); break;
+    case EMIT_F64: reinterpret_cast<double*>(dst)[idx] = u2d(v0); break;
+    case EMIT_F32: reinterpret_cast<float*>(dst)[idx] = (float)u2d(v0); break;
+    case EMIT_DD_F64: { double hi = u2d(v0), lo = u2d(v1);
+      reinterpret_cast<double*>(dst)[idx] = (lo == 0.0) ? hi : hi + lo; } break;
+    case EMIT_DD_F32: { double hi = u2d(v0), lo = u2d(v1);
+      reinterpret_cast<float*>(dst)[idx] = (float)((lo == 0.0) ? hi : hi + lo); } break;
+    case EMIT_U8: reinterpret_cast<u8*>(dst)[idx] = (u8)(v0 != 0); break;
+    default: break;
+  }
+}
+
+
+__global__ void ssgpu_emit_scalar_kernel(const VmAccRec* __restrict__ recs, const EmitDesc* __restrict__ descs,
+                                         int n_out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const EmitDesc d = descs[i];
+  const VmAccRec r = recs[d.slot];
+  emit_value(d.data, 0, d.out_kind, r.v0, r.v1);
+  if (d.is_null) d.is_null[0] = r.cnt == 0;
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of per-tile counts (single workgroup; n is #tiles, small)
+// out[i] = sum_{j<i} in[j]; total written to *total.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ssgpu_scan_counts_kernel(const u32* __restrict__ in, u32* __restrict__ out,
+                                                                  int n, u64* __restrict__ total) {
+  __shared__ u64 wave_sums[16];
+  __shared__ u64 carry_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024 * 8) {
+    // each thread owns 8 consecutive elements
+    u32 v[8]; u64 sum = 0;
+    int i0 = base + t * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0u; sum += v[j]; }
+    // inclusive scan of `sum` across the wave by shuffles
+    u64 inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u64 o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    u64 wpre = 0;
+    for (int w = 0; w < wave; ++w) wpre += wave_sums[w];
+    u64 run = carry_s + wpre + (inc - sum);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (i0 + j < n) out[i0 + j] = (u32)run; run += v[j]; }
+    __syncthreads();
+    if (t == 1023) carry_s = run;
+    __syncthreads();
+  }
+  if (t == 0) *total = carry_s;
+}
+
+// ---------------------------------------------------------------------------
+// group table extraction: occupied slots -> dense result rows (slot order made
+// deterministic by a count / scan / scatter over 512-slot tiles).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool group_slot_occupied(const GroupExtractParams& P, u32 slot) {
+  if (slot > P.capacity) return false;
+  // the special slot `capacity` owns the key whose value equals the EMPTY sentinel
+  if (slot == P.capacity) return P.first_row[slot] != ~0ull;
+  return P.keys[slot] != VM_KEY_EMPTY;
+}
+
+__global__ __launch_bounds__(256) void ssgpu_group_count_kernel(const GroupExtractParams P, u32* __restrict__ tile_counts) {
+  __shared__ u32 wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  u32 s0 = blockIdx.x * 512u + t * 2u;
+  bool o0 = group_slot_occupied(P, s0);
+  bool o1 = group_slot_occupied(P, s0 + 1);
+  u32 c = (u32)__popcll(__ballot(o0)) + (u32)__popcll(__ballot(o1));
+  if (lane == 0) wsum[wave] = c;
+  __syncthreads();
+  if (t == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExtractParams P) {
+  __shared__ u32 wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  u32 s0 = blockIdx.x * 512u + t * 2u;
+  bool o0 = group_slot_occupied(P, s0);
+  bool o1 = group_slot_occupied(P, s0 + 1);
+  u64 b0 = __ballot(o0), b1 = __ballot(o1);
+  if (lane == 0) wsum[wave] = (u32)__popcll(b0) + (u32)__popcll(b1);
+  __syncthreads();
+  u32 base = P.tile_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const u64 lt = (1ull << lane) - 1ull;
+  u32 r0 = base + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
+  u32 rr[2] = {r0, r0 + (o0 ? 1u : 0u)};
+  bool oo[2] = {o0, o1};
+  for (int j = 0; j < 2; ++j) {
+    if (!oo[j]) continue;
+    const u32 slot = s0 + j; const u32 row = rr[j];
+    const u64 key = P.keys[slot];
+    P.out_first_row[row] = P.first_row[slot];
+    for (u32 q = 0; q < P.n_keys; ++q) {
+      const GroupKeyOut ko = P.keys_out[q];
+      u64 field = key >> ko.shift;
+      bool isnull = ko.nullbit != 0xFF && ((key >> ko.nullbit) & 1ull);
+      u64 vmask = ko.bits >= 64 ? ~0ull : ((1ull << ko.bits) - 1ull);
+      u64 v = isnull ? 0ull : (field & vmask);
+      if (ko.width == 8) reinterpret_cast<u64*>(ko.data)[row] = v;
+      else if (ko.width == 4) reinterpret_cast<u32*>(ko.data)[row] = (u32)v;
+      else reinterpret_cast<u8*>(ko.data)[row] = (u8)v;
+      if (ko.is_null) ko.is_null[row] = isnull;
+    }
+    for (u32 q = 0; q < P.n_aggs_out; ++q) {
+      const GroupAggOut ao = P.aggs_out[q];
+      u64 v0 = P.acc[(u64)slot * P.n_gaggs + ao.s];
+      u32 c = ao.has_cnt ? P.cnt[(u64)slot * P.n_gaggs + ao.s] : 1u;
+      if (ao.out_kind == EMIT_FKEY_F64) {  // ordered-double key back to double bits
+        v0 = (v0 & 0x8000000000000000ull) ? (v0 & 0x7FFFFFFFFFFFFFFFull) : ~v0;
+        emit_value(ao.data, row, EMIT_F64, v0, 0);
+      } else if (ao.out_kind == EMIT_FKEY_F32) {
+        v0 = (v0 & 0x8000000000000000ull) ? (v0 & 0x7FFFFFFFFFFFFFFFull) : ~v0;
+        emit_value(ao.data, row, EMIT_F32, v0, 0);
+      } else {
+        emit_value(ao.data, row, ao.out_kind, v0, 0);
+      }
+      if (ao.is_null) ao.is_null[row] = c == 0;
+    }
+  }
+}
+
+// fill helpers (table initialisation without a host round trip)
+__global__ void ssgpu_fill_u64_kernel(u64* __restrict__ p, u64 v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+// acc init: per-slot pattern of n_gaggs identities
+__global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __restrict__ pattern, u32 plen, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = pattern[i % plen];
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers (C++ linkage inside the library)
+// ---------------------------------------------------------------------------
+hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream) {
+  dim3 g(grid), b(VM_WG_THREADS);
+  size_t lds = P.lds_bytes;
+  switch (K) {
+    case 1: hipLaunchKernelGGL(ssgpu_pipeline_kernel<1>, g, b, lds, stream, P); break;
+    case 2: hipLaunchKernelGGL(ssgpu_pipeline_kernel<2>, g, b, lds, stream, P); break;
+    case 4: hipLaunchKernelGGL(ssgpu_pipeline_kernel<4>, g, b, lds, stream, P); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
+  hipError_t e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e;
+}
+hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
+                                     VmAccRec* out, hipStream_t stream) {
+  int blocks = (n_slots + 63) / 64;
+  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(blocks), dim3(64), 0, stream, partials, 0, n_slots, n_parts, slot_kind, out);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state, hipStream_t stream) {
+  int blocks = (n_slots + 63) / 64;
+  hipLaunchKernelGGL(ssgpu_slots_to_state_kernel, dim3(blocks), dim3(64), 0, stream, recs, n_slots, slot_kind, (u64*)state);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_state_to_slots(const uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs, hipStream_t stream) {
+  int blocks = (n_slots + 63) / 64;
+  hipLaunchKernelGGL(ssgpu_state_to_slots_kernel, dim3(blocks), dim3(64), 0, stream, (const u64*)state, n_slots, slot_kind, recs);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_emit_scalar(const VmAccRec* recs, const EmitDesc* descs, int n_out, hipStream_t stream) {
+  int blocks = (n_out + 63) / 64;
+  hipLaunchKernelGGL(ssgpu_emit_scalar_kernel, dim3(blocks), dim3(64), 0, stream, recs, descs, n_out);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_scan_counts(const uint32_t* in, uint32_t* out, int n, uint64_t* total, hipStream_t stream) {
+  hipLaunchKernelGGL(ssgpu_scan_counts_kernel, dim3(1), dim3(1024), 0, stream, in, out, n, (u64*)total);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_group_count(const GroupExtractParams& P, uint32_t* tile_counts, hipStream_t stream) {
+  int blocks = (int)(((size_t)P.capacity + 1 + 511) / 512);
+  hipLaunchKernelGGL(ssgpu_group_count_kernel, dim3(blocks), dim3(256), 0, stream, P, tile_counts);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_group_extract(const GroupExtractParams& P, hipStream_t stream) {
+  int blocks = (int)(((size_t)P.capacity + 1 + 511) / 512);
+  hipLaunchKernelGGL(ssgpu_group_extract_kernel, dim3(blocks), dim3(256), 0, stream, P);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t stream) {
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ssgpu_fill_u64_kernel, dim3(blocks), dim3(256), 0, stream, (u64*)p, (u64)v, n);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, uint32_t plen, size_t n, hipStream_t stream) {
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ssgpu_fill_pattern_u64_kernel, dim3(blocks), dim3(256), 0, stream, (u64*)p, (const u64*)pattern, plen, n);
+  return hipGetLastError();
+}

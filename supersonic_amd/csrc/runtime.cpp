@@ -1,0 +1,769 @@
+// runtime.cpp -- the C ABI (include/ssgpu.h): contexts, blocks, plans, execution.
+//
+// Execution is push-style and whole-shard: one ssgpu_plan_run drains the whole
+// input through the fused pipeline kernel(s) of each stage, where the reference
+// would pull 1024-row views through Cursor::Next (cursor/base/cursor.h:131-148).
+// There is no CPU data path in this file: without a device every run fails.
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using namespace ssgpu;
+
+#define HIP_TRY(ctx, expr)                                                          \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                \
+      return _e == hipErrorOutOfMemory ? SSGPU_ERROR_MEMORY_EXCEEDED : SSGPU_ERROR_HIP; \
+    }                                                                                \
+  } while (0)
+
+struct ssgpu_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  bool own_stream = false;
+  int cu_count = 0;
+  std::string err;
+  LowerOptions opt;
+  int64_t grid_limit = 0;        // 0 = CUs * residency
+  int64_t group_capacity = 1 << 18;
+  int64_t profile = 1;           // record HIP events around kernels
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want; else p = nullptr;
+    return e;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want; else p = nullptr;
+    return e;
+  }
+};
+
+struct OutCol { DevBuf data, nulls; bool nullable = false; uint32_t width = 8; };
+
+struct StageExec {
+  // device copies of the programs, finalised for tile_rows
+  DevBuf prog_main, prog_count;
+  ProgramLayout lay{};
+  ProgramLayout lay_count{};
+  int n_instr_main = 0, n_instr_count = 0;
+  int grid = 0;
+  // scalar aggregates
+  DevBuf wg_partials, slot_recs, slot_kind, emit_descs, state;
+  // filter compaction
+  DevBuf tile_counts, tile_offsets, total;
+  // group table
+  DevBuf gkeys, gfirst, gacc, gcnt, goverflow, gpattern, gout_first;
+  uint32_t capacity = 0;
+  DevBuf error_flag;
+  bool emit_ready = false;
+  bool pattern_ready = false;
+  // outputs
+  std::vector<OutCol> out;
+  int64_t out_rows = -1;     // -1: read lazily from `total`
+  int64_t out_capacity = 0;
+};
+
+struct ssgpu_result {
+  ssgpu_plan* plan = nullptr;
+  std::vector<PinnedBuf> host_data, host_nulls;
+  std::vector<bool> fetched;
+};
+
+struct ssgpu_plan {
+  ssgpu_ctx* ctx = nullptr;
+  PlanDesc desc;
+  std::vector<Stage> stages;
+  std::vector<StageExec> exec;
+  Schema result_schema;
+  std::vector<std::string> attr_names;  // stable c_str for ssgpu_plan_attr
+  std::string describe, describe_full;
+  std::atomic<int> interrupted{0};
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
+  bool events_valid = false;
+  ssgpu_counters counters{};
+  std::vector<VmInstr> host_prog_scratch;
+  bool partial_pending = false;
+  int64_t last_rows = 0;
+  ssgpu_result result;
+};
+
+struct ssgpu_block {
+  ssgpu_ctx* ctx = nullptr;
+  Schema schema;
+  int64_t capacity = 0, rows = 0;
+  std::vector<DevBuf> data, nulls;
+};
+
+static int fail(ssgpu_ctx* ctx, const Status& s) { if (ctx) ctx->err = s.msg; return s.code; }
+
+extern "C" {
+
+int ssgpu_abi_version(void) { return SSGPU_ABI_VERSION; }
+
+int ssgpu_ctx_create(int device_id, ssgpu_ctx** out) {
+  if (!out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = new ssgpu_ctx;
+  c->device = device_id;
+  if (device_id >= 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device_id >= n) { delete c; return SSGPU_ERROR_NO_DEVICE; }
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return SSGPU_ERROR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return SSGPU_ERROR_NO_DEVICE; }
+    c->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SSGPU_ERROR_HIP; }
+    c->own_stream = true;
+    (void)ssgpu_pipeline_set_max_lds(160 * 1024);
+  }
+  *out = c;
+  return SSGPU_OK;
+}
+
+void ssgpu_ctx_destroy(ssgpu_ctx* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  }
+  delete c;
+}
+
+const char* ssgpu_last_error(const ssgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void* ssgpu_ctx_stream(ssgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* ssgpu_ctx_copy_stream(ssgpu_ctx* c) { return c ? (void*)c->copy_stream : nullptr; }
+
+int ssgpu_ctx_set_stream(ssgpu_ctx* c, void* s) {
+  if (!c || c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)s; c->own_stream = false;
+  return SSGPU_OK;
+}
+
+int ssgpu_ctx_synchronize(ssgpu_ctx* c) {
+  if (!c || c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  return SSGPU_OK;
+}
+
+int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  std::string k(key);
+  if (k == "tile_rows") {
+    if (value != 0 && (value % 512 != 0 || value > 2048)) { c->err = "tile_rows must be 0, 512, 1024 or 2048"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+    c->opt.tile_rows = (int)value;
+  } else if (k == "lds_target_bytes") c->opt.lds_target_bytes = (int)value;
+  else if (k == "grid_limit") c->grid_limit = value;
+  else if (k == "group_capacity") {
+    int64_t cap = 1; while (cap < value) cap <<= 1;
+    c->group_capacity = cap;
+  } else if (k == "profile") c->profile = value;
+  else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  return SSGPU_OK;
+}
+
+int ssgpu_host_alloc(ssgpu_ctx* c, size_t bytes, void** out) {
+  if (!c || c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  HIP_TRY(c, hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+  return SSGPU_OK;
+}
+void ssgpu_host_free(ssgpu_ctx* c, void* p) { (void)c; if (p) (void)hipHostFree(p); }
+
+// ---- blocks ---------------------------------------------------------------------
+int ssgpu_block_create(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n, int64_t cap, ssgpu_block** out) {
+  if (!c || c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  ssgpu_block* b = new ssgpu_block;
+  b->ctx = c; b->capacity = cap; b->rows = 0;
+  b->data.resize(n); b->nulls.resize(n);
+  for (int i = 0; i < n; ++i) {
+    Attr a; a.name = schema[i].name ? schema[i].name : ""; a.dtype = schema[i].dtype; a.nullable = schema[i].nullable != 0;
+    int w = dtype_width(a.dtype);
+    if (w == 0) { delete b; c->err = "variable-length columns are outside the device hot path"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    b->schema.push_back(a);
+    // rows << log2(size) bytes per column + rows bytes of null mask (block.cc:20-36)
+    if (b->data[i].ensure((size_t)cap * w) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+    if (a.nullable && b->nulls[i].ensure((size_t)cap) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+  }
+  *out = b;
+  return SSGPU_OK;
+}
+void ssgpu_block_destroy(ssgpu_block* b) { delete b; }
+
+int ssgpu_block_upload(ssgpu_block* b, int32_t col, const void* hd, const uint8_t* hn, int64_t off, int64_t rows) {
+  if (!b) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = b->ctx;
+  if (col < 0 || col >= (int)b->schema.size() || off < 0 || off + rows > b->capacity) { c->err = "upload out of range"; return SSGPU_ERROR_TOO_MANY_ROWS; }
+  const int w = dtype_width(b->schema[col].dtype);
+  HIP_TRY(c, hipMemcpyAsync((char*)b->data[col].p + off * w, hd, (size_t)rows * w, hipMemcpyHostToDevice, c->copy_stream));
+  if (b->schema[col].nullable) {
+    if (hn) HIP_TRY(c, hipMemcpyAsync((char*)b->nulls[col].p + off, hn, (size_t)rows, hipMemcpyHostToDevice, c->copy_stream));
+    else HIP_TRY(c, hipMemsetAsync((char*)b->nulls[col].p + off, 0, (size_t)rows, c->copy_stream));
+  }
+  if (off + rows > b->rows) b->rows = off + rows;
+  return SSGPU_OK;
+}
+int ssgpu_block_set_row_count(ssgpu_block* b, int64_t rows) {
+  if (!b || rows < 0 || rows > b->capacity) return SSGPU_ERROR_TOO_MANY_ROWS;
+  b->rows = rows; return SSGPU_OK;
+}
+int64_t ssgpu_block_row_count(const ssgpu_block* b) { return b ? b->rows : 0; }
+int ssgpu_block_column(const ssgpu_block* b, int32_t col, ssgpu_column* out) {
+  if (!b || col < 0 || col >= (int)b->schema.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  out->data = b->data[col].p;
+  out->is_null = b->schema[col].nullable ? (const uint8_t*)b->nulls[col].p : nullptr;
+  return SSGPU_OK;
+}
+
+// ---- plans ------------------------------------------------------------------------
+int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) {
+  if (!c || !d || !out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_plan* p = new ssgpu_plan;
+  p->ctx = c;
+  Status s = copy_plan_desc(d, &p->desc);
+  if (s.ok()) s = lower_plan(p->desc, &p->stages, &p->result_schema, &p->describe);
+  if (!s.ok()) { delete p; return fail(c, s); }
+  for (auto& st : p->stages) {
+    // every program must fit the CU's LDS at the smallest tile
+    LowerOptions o = c->opt; o.tile_rows = 512;
+    if (!st.main.empty() && layout_program(st.main, o).lds_bytes > 160u * 1024u) {
+      delete p; c->err = "expression needs more than 160 KiB of LDS per 512-row tile"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+    }
+  }
+  p->exec.resize(p->stages.size());
+  for (auto& a : p->result_schema) p->attr_names.push_back(a.name);
+  p->result.plan = p;
+  if (c->device >= 0) {
+    (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end);
+    (void)hipEventCreate(&p->ev_dom0); (void)hipEventCreate(&p->ev_dom1);
+  }
+  *out = p;
+  return SSGPU_OK;
+}
+
+void ssgpu_plan_destroy(ssgpu_plan* p) {
+  if (!p) return;
+  if (p->ctx && p->ctx->device >= 0) {
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
+    if (p->ev_end) (void)hipEventDestroy(p->ev_end);
+    if (p->ev_dom0) (void)hipEventDestroy(p->ev_dom0);
+    if (p->ev_dom1) (void)hipEventDestroy(p->ev_dom1);
+  }
+  delete p;
+}
+
+int32_t ssgpu_plan_attr_count(const ssgpu_plan* p) { return p ? (int32_t)p->result_schema.size() : 0; }
+int ssgpu_plan_attr(const ssgpu_plan* p, int32_t i, ssgpu_attr* out) {
+  if (!p || i < 0 || i >= (int)p->result_schema.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  out->name = p->attr_names[i].c_str();
+  out->dtype = p->result_schema[i].dtype;
+  out->nullable = p->result_schema[i].nullable ? 1 : 0;
+  return SSGPU_OK;
+}
+const char* ssgpu_plan_describe(ssgpu_plan* p) { return p ? p->describe.c_str() : ""; }
+
+int ssgpu_plan_program(const ssgpu_plan* cp, int32_t stage, const void** instrs, int32_t* n, int32_t* bytes) {
+  ssgpu_plan* p = const_cast<ssgpu_plan*>(cp);
+  if (!p || stage < 0 || stage >= (int)p->stages.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ProgramLayout L = layout_program(p->stages[stage].main, p->ctx->opt);
+  finalize_program(p->stages[stage].main, 512 * L.K, &p->host_prog_scratch);
+  *instrs = p->host_prog_scratch.data(); *n = (int32_t)p->host_prog_scratch.size(); *bytes = (int32_t)sizeof(VmInstr);
+  return SSGPU_OK;
+}
+
+void ssgpu_interrupt(ssgpu_plan* p) { if (p) p->interrupted.store(1, std::memory_order_relaxed); }
+
+}  // extern "C"
+
+// ---- execution helpers -------------------------------------------------------------
+namespace {
+
+struct InCols { std::vector<ssgpu_column> cols; int64_t rows = 0; };
+
+int upload_program(ssgpu_ctx* c, const Program& prog, int tile_rows, DevBuf* dev, int* n_instr, std::vector<VmInstr>* scratch) {
+  finalize_program(prog, tile_rows, scratch);
+  *n_instr = (int)scratch->size();
+  HIP_TRY(c, dev->ensure(std::max<size_t>(1, scratch->size()) * sizeof(VmInstr)));
+  if (!scratch->empty())
+    HIP_TRY(c, hipMemcpyAsync(dev->p, scratch->data(), scratch->size() * sizeof(VmInstr), hipMemcpyHostToDevice, c->stream));
+  // the scratch vector is reused by the next upload: wait for this copy (pageable source is staged
+  // synchronously by the runtime, so this is a formality and only happens on (re)layout)
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SSGPU_OK;
+}
+
+int prepare_stage(ssgpu_plan* p, size_t si) {
+  ssgpu_ctx* c = p->ctx;
+  Stage& st = p->stages[si];
+  StageExec& ex = p->exec[si];
+  if (st.main.empty()) return SSGPU_OK;
+  ProgramLayout L = layout_program(st.main, c->opt);
+  if (ex.prog_main.p && L.K == ex.lay.K) return SSGPU_OK;  // already prepared for this tile size
+  ex.lay = L;
+  int rc = upload_program(c, st.main, 512 * L.K, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
+  if (rc != SSGPU_OK) return rc;
+  if (!st.count_pass.empty()) {
+    LowerOptions o = c->opt; o.tile_rows = 512 * L.K;
+    ex.lay_count = layout_program(st.count_pass, o);
+    rc = upload_program(c, st.count_pass, 512 * L.K, &ex.prog_count, &ex.n_instr_count, &p->host_prog_scratch);
+    if (rc != SSGPU_OK) return rc;
+  }
+  HIP_TRY(c, ex.error_flag.ensure(sizeof(uint32_t)));
+  // slot kinds / emit descriptors are uploaded per run (they hold output pointers)
+  return SSGPU_OK;
+}
+
+int grid_for(ssgpu_ctx* c, const ProgramLayout& L, int n_tiles) {
+  int per_cu = (int)std::min<uint32_t>(8, (160u * 1024u) / std::max<uint32_t>(L.lds_bytes, 1));
+  if (per_cu < 1) per_cu = 1;
+  int64_t g = (int64_t)c->cu_count * per_cu;
+  if (c->grid_limit > 0) g = std::min<int64_t>(g, c->grid_limit);
+  g = std::min<int64_t>(g, std::max(1, n_tiles));
+  return (int)std::max<int64_t>(g, 1);
+}
+
+void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const DevBuf& dev_prog, int n_instr,
+                 const InCols& in, int64_t row_id_base) {
+  memset(P, 0, sizeof(*P));
+  P->prog = dev_prog.as<const VmInstr>();
+  P->n_instr = n_instr;
+  P->n_staged = (int)prog.staged.size();
+  P->n_outputs = prog.n_outputs;
+  P->n_slots = prog.n_slots;
+  P->n_rows = in.rows;
+  P->row_id_base = row_id_base;
+  P->tile_rows = 512 * L.K;
+  P->n_tiles = (int)((in.rows + P->tile_rows - 1) / P->tile_rows);
+  P->acc_lds_off = L.acc_off;
+  P->scratch_lds_off = L.scratch_off;
+  P->lds_bytes = L.lds_bytes;
+  for (size_t i = 0; i < prog.staged.size(); ++i) {
+    const StagedInput& s = prog.staged[i];
+    P->staged[i].src = s.is_null_mask ? (const void*)in.cols[s.col].is_null : in.cols[s.col].data;
+    P->staged[i].lds_off = prog.regs[s.reg].row_off * (uint32_t)P->tile_rows;
+    P->staged[i].width = prog.regs[s.reg].width;
+  }
+}
+
+int ensure_out_cols(ssgpu_ctx* c, const Stage& st, StageExec& ex, int64_t rows) {
+  ex.out.resize(st.out_schema.size());
+  for (size_t i = 0; i < st.out_schema.size(); ++i) {
+    OutCol& oc = ex.out[i];
+    oc.width = (uint32_t)dtype_width(st.out_schema[i].dtype);
+    oc.nullable = st.out_schema[i].nullable;
+    HIP_TRY(c, oc.data.ensure((size_t)std::max<int64_t>(rows, 1) * oc.width + 16));
+    if (oc.nullable) HIP_TRY(c, oc.nulls.ensure((size_t)std::max<int64_t>(rows, 1) + 16));
+  }
+  ex.out_capacity = rows;
+  return SSGPU_OK;
+}
+
+int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base, bool stop_at_partial) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  VmParams P;
+  fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+  const int grid = grid_for(c, ex.lay, P.n_tiles);
+  ex.grid = grid;
+  const int ns = st.main.n_slots;
+  HIP_TRY(c, ex.wg_partials.ensure((size_t)grid * ns * VM_WAVES * sizeof(VmAccRec)));
+  HIP_TRY(c, ex.slot_recs.ensure((size_t)ns * sizeof(VmAccRec)));
+  HIP_TRY(c, ex.state.ensure((size_t)ns * SSGPU_STATE_ARRAYS * sizeof(uint64_t)));
+  if (!ex.slot_kind.p) {
+    std::vector<int> kinds; for (auto& a : st.aggs) kinds.push_back(a.slot_kind);
+    HIP_TRY(c, ex.slot_kind.ensure(kinds.size() * sizeof(int)));
+    HIP_TRY(c, hipMemcpy(ex.slot_kind.p, kinds.data(), kinds.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  P.wg_partials = ex.wg_partials.as<VmAccRec>();
+  P.error_flag = ex.error_flag.as<unsigned int>();
+  HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  HIP_TRY(c, ssgpu_launch_finish_slots(ex.wg_partials.as<VmAccRec>(), ns, grid * VM_WAVES, ex.slot_kind.as<int>(),
+                                       ex.slot_recs.as<VmAccRec>(), c->stream));
+  p->counters.n_launches += 2;
+  p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
+  if (stop_at_partial) {
+    HIP_TRY(c, ssgpu_launch_slots_to_state(ex.slot_recs.as<VmAccRec>(), ns, ex.slot_kind.as<int>(), ex.state.as<uint64_t>(), c->stream));
+    p->counters.n_launches += 1;
+  }
+  return SSGPU_OK;
+}
+
+int emit_scalar_agg(ssgpu_plan* p, size_t si) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  int rc = ensure_out_cols(c, st, ex, 1);
+  if (rc != SSGPU_OK) return rc;
+  std::vector<EmitDesc> descs;
+  for (size_t i = 0; i < st.aggs.size(); ++i) {
+    EmitDesc d; d.data = ex.out[i].data.p; d.is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
+    d.slot = st.aggs[i].slot; d.out_kind = st.aggs[i].emit_kind;
+    descs.push_back(d);
+  }
+  if (!ex.emit_ready) {  // output buffers of a 1-row result never move: upload once
+    HIP_TRY(c, ex.emit_descs.ensure(descs.size() * sizeof(EmitDesc)));
+    HIP_TRY(c, hipMemcpy(ex.emit_descs.p, descs.data(), descs.size() * sizeof(EmitDesc), hipMemcpyHostToDevice));
+    ex.emit_ready = true;
+  }
+  HIP_TRY(c, ssgpu_launch_emit_scalar(ex.slot_recs.as<VmAccRec>(), ex.emit_descs.as<EmitDesc>(), (int)descs.size(), c->stream));
+  p->counters.n_launches += 1;
+  ex.out_rows = 1;
+  return SSGPU_OK;
+}
+
+int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  int rc = ensure_out_cols(c, st, ex, in.rows);
+  if (rc != SSGPU_OK) return rc;
+  VmParams P;
+  fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+  P.error_flag = ex.error_flag.as<unsigned int>();
+  HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
+  // output table: data column then (if nullable) its null mask, in out_schema order
+  int oi = 0;
+  for (size_t i = 0; i < ex.out.size(); ++i) {
+    P.outputs[oi].dst = ex.out[i].data.p; P.outputs[oi].width = ex.out[i].width; ++oi;
+    if (ex.out[i].nullable) { P.outputs[oi].dst = ex.out[i].nulls.p; P.outputs[oi].width = 1; ++oi; }
+  }
+  const int grid = grid_for(c, ex.lay, P.n_tiles);
+  ex.grid = grid;
+  p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
+  if (st.has_filter) {
+    const int nt = std::max(P.n_tiles, 1);
+    HIP_TRY(c, ex.tile_counts.ensure((size_t)nt * sizeof(uint32_t)));
+    HIP_TRY(c, ex.tile_offsets.ensure((size_t)nt * sizeof(uint32_t)));
+    HIP_TRY(c, ex.total.ensure(sizeof(uint64_t)));
+    VmParams C;
+    fill_params(&C, st.count_pass, ex.lay_count, ex.prog_count, ex.n_instr_count, in, row_id_base);
+    C.tile_counts = ex.tile_counts.as<unsigned int>();
+    C.error_flag = P.error_flag;
+    const int cgrid = grid_for(c, ex.lay_count, C.n_tiles);
+    HIP_TRY(c, ssgpu_launch_pipeline(C, ex.lay.K, cgrid, c->stream));
+    HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), P.n_tiles,
+                                        ex.total.as<uint64_t>(), c->stream));
+    P.tile_offsets = ex.tile_offsets.as<unsigned int>();
+    p->counters.n_launches += 2;
+    ex.out_rows = -1;
+  } else {
+    ex.out_rows = in.rows;
+  }
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  p->counters.n_launches += 1;
+  return SSGPU_OK;
+}
+
+int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    const size_t slots = (size_t)ex.capacity + 1;
+    HIP_TRY(c, ex.gkeys.ensure(slots * 8));
+    HIP_TRY(c, ex.gfirst.ensure(slots * 8));
+    HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
+    HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
+    HIP_TRY(c, ex.goverflow.ensure(4));
+    HIP_TRY(c, ex.gpattern.ensure(ng * 8));
+    if (!ex.pattern_ready) {
+      std::vector<uint64_t> pattern(ng, 0);
+      for (size_t i = 0; i < st.group_acc_init.size(); ++i) pattern[i] = st.group_acc_init[i];
+      HIP_TRY(c, hipMemcpy(ex.gpattern.p, pattern.data(), ng * 8, hipMemcpyHostToDevice));
+      ex.pattern_ready = true;
+    }
+    HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>(), VM_KEY_EMPTY, slots, c->stream));
+    HIP_TRY(c, ssgpu_launch_fill_u64(ex.gfirst.as<uint64_t>(), ~0ull, slots, c->stream));
+    HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>(), ex.gpattern.as<uint64_t>(), ng, slots * ng, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.gcnt.p, 0, slots * ng * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
+    VmParams P;
+    fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+    P.error_flag = ex.error_flag.as<unsigned int>();
+    P.group.keys = ex.gkeys.as<unsigned long long>();
+    P.group.first_row = ex.gfirst.as<unsigned long long>();
+    P.group.acc = ex.gacc.as<unsigned long long>();
+    P.group.cnt = ex.gcnt.as<unsigned int>();
+    P.group.overflow = ex.goverflow.as<unsigned int>();
+    P.group.capacity_mask = ex.capacity - 1;
+    const int grid = grid_for(c, ex.lay, P.n_tiles);
+    ex.grid = grid;
+    p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+    HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+    p->counters.n_launches += 5;
+    uint32_t overflow = 0;
+    HIP_TRY(c, hipMemcpyAsync(&overflow, ex.goverflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!overflow) break;
+    // table too small for this input: regrow x4 and run again (the reference grows its
+    // Aggregator x2 on demand, aggregate_groups.cc:372-402)
+    if ((uint64_t)ex.capacity >= (1ull << 30)) { c->err = "group table overflow"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+    ex.capacity *= 4;
+  }
+  // extraction: occupied slots -> dense rows in slot order
+  const size_t slots = (size_t)ex.capacity + 1;
+  const int ntile = (int)((slots + 511) / 512);
+  int rc = ensure_out_cols(c, st, ex, (int64_t)slots);
+  if (rc != SSGPU_OK) return rc;
+  HIP_TRY(c, ex.tile_counts.ensure((size_t)ntile * 4));
+  HIP_TRY(c, ex.tile_offsets.ensure((size_t)ntile * 4));
+  HIP_TRY(c, ex.total.ensure(8));
+  HIP_TRY(c, ex.gout_first.ensure(slots * 8));
+  GroupExtractParams G;
+  memset(&G, 0, sizeof(G));
+  G.keys = ex.gkeys.as<unsigned long long>(); G.first_row = ex.gfirst.as<unsigned long long>();
+  G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
+  G.capacity = ex.capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size();
+  G.tile_offsets = ex.tile_offsets.as<unsigned int>();
+  G.out_first_row = ex.gout_first.as<unsigned long long>();
+  for (size_t k = 0; k < st.group_keys.size(); ++k) {
+    const GroupKeyField& f = st.group_keys[k];
+    G.keys_out[k].data = ex.out[k].data.p;
+    G.keys_out[k].is_null = ex.out[k].nullable ? ex.out[k].nulls.as<uint8_t>() : nullptr;
+    G.keys_out[k].shift = f.shift; G.keys_out[k].bits = f.bits; G.keys_out[k].nullbit = f.nullbit; G.keys_out[k].width = f.width;
+  }
+  const size_t nk = st.group_keys.size();
+  for (size_t j = 0; j < st.aggs.size(); ++j) {
+    G.aggs_out[j].data = ex.out[nk + j].data.p;
+    G.aggs_out[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
+    G.aggs_out[j].s = st.aggs[j].slot; G.aggs_out[j].out_kind = st.aggs[j].emit_kind; G.aggs_out[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
+  }
+  HIP_TRY(c, ssgpu_launch_group_count(G, ex.tile_counts.as<uint32_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), ntile, ex.total.as<uint64_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_group_extract(G, c->stream));
+  p->counters.n_launches += 3;
+  ex.out_rows = -1;
+  return SSGPU_OK;
+}
+
+int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
+  ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[si];
+  if (ex.out_rows < 0) {
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, ex.total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ex.out_rows = (int64_t)total;
+  }
+  *rows = ex.out_rows;
+  return SSGPU_OK;
+}
+
+int check_error_flags(ssgpu_plan* p) {
+  ssgpu_ctx* c = p->ctx;
+  for (auto& ex : p->exec) {
+    if (!ex.error_flag.p) continue;
+    uint32_t f = 0;
+    HIP_TRY(c, hipMemcpy(&f, ex.error_flag.p, 4, hipMemcpyDeviceToHost));
+    if (f) { c->err = "Evaluation error: division by zero in a signaling expression"; return SSGPU_ERROR_EVALUATION_ERROR; }
+  }
+  return SSGPU_OK;
+}
+
+int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial) {
+  ssgpu_ctx* c = p->ctx;
+  if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  if (n_cols != (int)p->desc.input_schema.size()) { c->err = "column count does not match the plan's input schema"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
+  if (rows < 0) { c->err = "negative row count"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // blocks are staged on the copy stream: kernels must wait for those copies
+  memset(&p->counters, 0, sizeof(p->counters));
+  p->counters.rows_in = rows;
+  p->result.fetched.assign(p->result.fetched.size(), false);
+  InCols in; in.cols.assign(cols, cols + n_cols); in.rows = rows;
+  if (partial && !(p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG)) {
+    c->err = "partial runs need a plan whose only stage is a ScalarAggregate"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+  }
+  for (size_t si = 0; si < p->stages.size(); ++si) {
+    int rc = prepare_stage(p, si);
+    if (rc != SSGPU_OK) return rc;
+  }
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_begin, c->stream));
+  int64_t alg_bytes = 0;
+  for (size_t si = 0; si < p->stages.size(); ++si) {
+    if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
+    Stage& st = p->stages[si];
+    int rc = SSGPU_OK;
+    alg_bytes += st.algorithmic_bytes_per_row * in.rows;
+    switch (st.kind) {
+      case STAGE_SCALAR_AGG:
+        rc = run_scalar_agg(p, si, in, row_id_base, partial);
+        if (rc == SSGPU_OK && !partial) rc = emit_scalar_agg(p, si);
+        break;
+      case STAGE_MATERIALIZE: rc = run_materialize(p, si, in, row_id_base); break;
+      case STAGE_GROUP_AGG: rc = run_group_agg(p, si, in, row_id_base); break;
+      default: c->err = "stage kind not executable yet"; rc = SSGPU_ERROR_NOT_IMPLEMENTED; break;
+    }
+    if (rc != SSGPU_OK) return rc;
+    if (si + 1 < p->stages.size()) {
+      // next stage reads this stage's materialised result
+      int64_t r = 0;
+      rc = stage_rows(p, si, &r);
+      if (rc != SSGPU_OK) return rc;
+      StageExec& ex = p->exec[si];
+      in.cols.clear();
+      for (auto& oc : ex.out) { ssgpu_column col; col.data = oc.data.p; col.is_null = oc.nullable ? oc.nulls.as<uint8_t>() : nullptr; in.cols.push_back(col); }
+      in.rows = r;
+      row_id_base = 0;
+    }
+  }
+  if (c->profile) { HIP_TRY(c, hipEventRecord(p->ev_end, c->stream)); p->events_valid = true; }
+  p->counters.algorithmic_bytes = alg_bytes;
+  p->last_rows = rows;
+  p->partial_pending = partial;
+  return SSGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, ssgpu_result** out) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  int rc = run_plan(p, cols, n_cols, rows, 0, false);
+  if (rc != SSGPU_OK) return rc;
+  if (out) *out = &p->result;
+  return SSGPU_OK;
+}
+
+int ssgpu_plan_run_block(ssgpu_plan* p, const ssgpu_block* b, ssgpu_result** out) {
+  if (!p || !b) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (!c || c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  // uploads were issued on the copy stream; order the compute stream after them
+  hipEvent_t ev;
+  HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(ev, c->copy_stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
+  (void)hipEventDestroy(ev);
+  std::vector<ssgpu_column> cols(b->schema.size());
+  for (size_t i = 0; i < cols.size(); ++i) ssgpu_block_column(b, (int32_t)i, &cols[i]);
+  return ssgpu_plan_run(p, cols.data(), (int32_t)cols.size(), b->rows, out);
+}
+
+int ssgpu_plan_run_partial(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t base) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  return run_plan(p, cols, n_cols, rows, base, true);
+}
+
+int32_t ssgpu_plan_partial_segments(ssgpu_plan* p, ssgpu_partial_segment* out, int32_t max_segments) {
+  if (!p || !p->partial_pending || p->stages.empty()) return 0;
+  StageExec& ex = p->exec[0];
+  const int ns = p->stages[0].main.n_slots;
+  static const int reduce[SSGPU_STATE_ARRAYS] = {0, 0, 0, 0, 1, 2, 1, 2};
+  static const int dtype[SSGPU_STATE_ARRAYS] = {SSGPU_INT64, SSGPU_INT64, SSGPU_DOUBLE, SSGPU_DOUBLE, SSGPU_INT64, SSGPU_INT64, SSGPU_DOUBLE, SSGPU_DOUBLE};
+  int n = 0;
+  for (int i = 0; i < SSGPU_STATE_ARRAYS && n < max_segments; ++i, ++n) {
+    out[n].device_ptr = ex.state.as<uint64_t>() + (size_t)i * ns;
+    out[n].count = ns; out[n].dtype = dtype[i]; out[n].reduce = reduce[i];
+  }
+  return n;
+}
+
+int ssgpu_plan_finalize(ssgpu_plan* p, ssgpu_result** out) {
+  if (!p || !p->partial_pending) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  StageExec& ex = p->exec[0];
+  const int ns = p->stages[0].main.n_slots;
+  HIP_TRY(c, ssgpu_launch_state_to_slots(ex.state.as<uint64_t>(), ns, ex.slot_kind.as<int>(), ex.slot_recs.as<VmAccRec>(), c->stream));
+  int rc = emit_scalar_agg(p, 0);
+  if (rc != SSGPU_OK) return rc;
+  p->partial_pending = false;
+  if (out) *out = &p->result;
+  return SSGPU_OK;
+}
+
+void ssgpu_result_destroy(ssgpu_result* r) { (void)r; /* owned by the plan: valid until the next run */ }
+
+int64_t ssgpu_result_row_count(ssgpu_result* r) {
+  if (!r || !r->plan || r->plan->exec.empty()) return -1;
+  int64_t rows = -1;
+  if (stage_rows(r->plan, r->plan->exec.size() - 1, &rows) != SSGPU_OK) return -1;
+  r->plan->counters.rows_out = rows;
+  return rows;
+}
+int32_t ssgpu_result_column_count(const ssgpu_result* r) { return r && r->plan ? (int32_t)r->plan->result_schema.size() : 0; }
+
+int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
+  if (!r || !r->plan) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  StageExec& ex = r->plan->exec.back();
+  if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  out->data = ex.out[i].data.p;
+  out->is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
+  return SSGPU_OK;
+}
+
+int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data, const uint8_t** is_null) {
+  if (!r || !r->plan) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
+  StageExec& ex = p->exec.back();
+  if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  int rc = check_error_flags(p);
+  if (rc != SSGPU_OK) return rc;
+  int64_t rows = ssgpu_result_row_count(r);
+  if (rows < 0) return SSGPU_ERROR_HIP;
+  const size_t n = ex.out.size();
+  if (r->host_data.size() != n) { r->host_data = std::vector<PinnedBuf>(n); r->host_nulls = std::vector<PinnedBuf>(n); r->fetched.assign(n, false); }
+  if (!r->fetched[i]) {
+    const size_t bytes = (size_t)rows * ex.out[i].width;
+    HIP_TRY(c, r->host_data[i].ensure(bytes));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(r->host_data[i].p, ex.out[i].data.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (ex.out[i].nullable) {
+      HIP_TRY(c, r->host_nulls[i].ensure((size_t)rows));
+      if (rows) HIP_TRY(c, hipMemcpyAsync(r->host_nulls[i].p, ex.out[i].nulls.p, (size_t)rows, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    r->fetched[i] = true;
+  }
+  if (data) *data = r->host_data[i].p;
+  if (is_null) *is_null = ex.out[i].nullable ? (const uint8_t*)r->host_nulls[i].p : nullptr;
+  return SSGPU_OK;
+}
+
+int ssgpu_plan_counters(ssgpu_plan* p, ssgpu_counters* out) {
+  if (!p || !out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (c->device >= 0 && p->events_valid && c->profile) {
+    HIP_TRY(c, hipEventSynchronize(p->ev_end));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p->ev_begin, p->ev_end) == hipSuccess) p->counters.kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, p->ev_dom0, p->ev_dom1) == hipSuccess) p->counters.dominant_ms = ms;
+  }
+  *out = p->counters;
+  return SSGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// vm.h -- the column-tile VM shared by the host lowering pass and the HIP kernels.
+//
+// Execution model (MI355X-first restatement of Supersonic's block-at-a-time
+// evaluation, supersonic/expression/base/expression.cc:57-76 and
+// supersonic/expression/vector/vector_primitives.h:99-105): where the reference
+// keeps a 1024-row block hot in the CPU's L1 and walks a tree of virtual
+// DoEvaluate() calls, we keep a TILE of rows resident in a workgroup's LDS and
+// run a flat, wave-uniform instruction list over it.  Every VM "register" is a
+// typed array of TILE rows in LDS; input columns are staged into their
+// registers by LDS-DMA (global_load_lds_dwordx4), intermediates never leave the
+// CU, and only sink instructions (aggregate / store / group) touch HBM again.
+//
+// Thread <-> row mapping inside a tile (256 threads, K = tile_rows / 512):
+//   thread t, step k owns the row PAIR  p = k*256 + t  ->  rows 2p, 2p+1.
+//   8-byte registers: one ds_read_b128 at p*16;  4-byte: ds_read_b64 at p*8;
+//   1-byte (BOOL / null masks): ds_read_u16 at p*2.  Lanes are contiguous, so
+//   every LDS access is conflict-free and no barrier is needed between
+//   elementwise instructions (a thread only ever touches its own pairs).
+#ifndef SSGPU_VM_H_
+#define SSGPU_VM_H_
+
+#include <stdint.h>
+
+#define VM_NONE 0xFFFFFFFFu
+#define VM_WG_THREADS 256
+#define VM_WAVES 4
+#define VM_MAX_STAGED 64
+#define VM_MAX_OUTPUTS 64
+#define VM_MAX_AGG_SLOTS 64
+#define VM_ACC_STRIDE 128 /* bytes of LDS per aggregate slot: 4 waves x 32 B */
+
+// type suffixes: I32 I64 U32 U64 F32 F64 (B8 = BOOL byte)
+#define VM_OPS(X)                                                              \
+  X(NOP)                                                                       \
+  /* ---- arithmetic: dst = a op b (supersonic operators.h:68-86) ---------- */\
+  X(ADD_I32) X(ADD_I64) X(ADD_F32) X(ADD_F64)                                  \
+  X(SUB_I32) X(SUB_I64) X(SUB_F32) X(SUB_F64)                                  \
+  X(MUL_I32) X(MUL_I64) X(MUL_F32) X(MUL_F64)                                  \
+  X(DIV_F32) X(DIV_F64)                                                        \
+  X(CDIV_I32) X(CDIV_I64) X(CDIV_U32) X(CDIV_U64)                              \
+  X(MOD_I32) X(MOD_I64) X(MOD_U32) X(MOD_U64)                                  \
+  X(NEG_I32) X(NEG_I64) X(NEG_F32) X(NEG_F64)                                  \
+  /* ---- bitwise ---------------------------------------------------------- */\
+  X(BAND_32) X(BAND_64) X(BOR_32) X(BOR_64) X(BXOR_32) X(BXOR_64)              \
+  X(BANDNOT_32) X(BANDNOT_64) X(BNOT_32) X(BNOT_64)                            \
+  X(SHL_I32) X(SHL_I64) X(SHR_I32) X(SHR_I64) X(SHR_U32) X(SHR_U64)            \
+  /* ---- comparisons: dst(B8) = a op b (operators.h:185-296) --------------- */\
+  X(LT_I32) X(LT_I64) X(LT_U32) X(LT_U64) X(LT_F32) X(LT_F64) X(LT_B8)         \
+  X(LE_I32) X(LE_I64) X(LE_U32) X(LE_U64) X(LE_F32) X(LE_F64) X(LE_B8)         \
+  X(EQ_32) X(EQ_64) X(EQ_F32) X(EQ_F64) X(EQ_B8)                               \
+  X(NE_32) X(NE_64) X(NE_F32) X(NE_F64) X(NE_B8)                               \
+  /* mixed-sign 64-bit compares (value-correct, operators.h:189-214) */        \
+  X(LT_I64_U64) X(LT_U64_I64) X(LE_I64_U64) X(LE_U64_I64)                      \
+  X(EQ_I64_U64) X(NE_I64_U64)                                                  \
+  /* ---- casts (cast_bound_expression.cc) ---------------------------------- */\
+  X(CAST_I32_I64) X(CAST_U32_I64) X(CAST_I64_I32) /* I64->32 = truncation */   \
+  X(CAST_I32_F32) X(CAST_I32_F64) X(CAST_U32_F32) X(CAST_U32_F64)              \
+  X(CAST_I64_F32) X(CAST_I64_F64) X(CAST_U64_F32) X(CAST_U64_F64)              \
+  X(CAST_F32_F64) X(CAST_F64_F32)                                              \
+  X(CAST_F32_I32) X(CAST_F32_I64) X(CAST_F32_U32) X(CAST_F32_U64)              \
+  X(CAST_F64_I32) X(CAST_F64_I64) X(CAST_F64_U32) X(CAST_F64_U64)              \
+  X(CAST_B8_I32) X(CAST_B8_I64) X(CAST_B8_F32) X(CAST_B8_F64)                  \
+  X(CAST_32_B8) X(CAST_64_B8) X(CAST_F32_B8) X(CAST_F64_B8)                    \
+  X(COPY_8) X(COPY_32) X(COPY_64)                                              \
+  /* ---- boolean logic on byte vectors (vector_logic.h:30-50) -------------- */\
+  X(AND_B8) X(OR_B8) X(XOR_B8) X(ANDNOT_B8) X(NOT_B8)                          \
+  /* 3-valued: dst,c = value,null out; a,b values; imm packs null offsets    */\
+  X(AND3) X(OR3)                                                               \
+  X(NULL_OR)   /* dst = a | b  on null masks */                                \
+  X(NULL_DIVZERO_32) X(NULL_DIVZERO_64) X(NULL_DIVZERO_F32) X(NULL_DIVZERO_F64)\
+  X(FAIL_DIVZERO_32) X(FAIL_DIVZERO_64) X(FAIL_DIVZERO_F32) X(FAIL_DIVZERO_F64)\
+  X(FILL_8) X(FILL_32) X(FILL_64)                                              \
+  X(SELECT_8) X(SELECT_32) X(SELECT_64) /* dst = c ? a : b  (IF / IFNULL) */   \
+  X(SEL_FROM_PRED) /* dst = a(value) & !b(null)        filter.cc:180-196 */    \
+  /* ---- scalar-aggregate sinks: dst = slot, a = value, b = null, c = sel -- */\
+  X(AGG_COUNT)                                                                 \
+  X(AGG_SUM_I32) X(AGG_SUM_U32) X(AGG_SUM_I64) X(AGG_SUM_F32) X(AGG_SUM_F64)   \
+  X(AGG_MIN_I32) X(AGG_MIN_U32) X(AGG_MIN_I64) X(AGG_MIN_U64)                  \
+  X(AGG_MIN_F32) X(AGG_MIN_F64) X(AGG_MIN_B8)                                  \
+  X(AGG_MAX_I32) X(AGG_MAX_U32) X(AGG_MAX_I64) X(AGG_MAX_U64)                  \
+  X(AGG_MAX_F32) X(AGG_MAX_F64) X(AGG_MAX_B8)                                  \
+  X(AGG_FIRST_8) X(AGG_FIRST_32) X(AGG_FIRST_64)                               \
+  X(AGG_LAST_8) X(AGG_LAST_32) X(AGG_LAST_64)                                  \
+  /* ---- materialising sinks ---------------------------------------------- */\
+  X(SEL_COUNT)   /* a = sel: tile_counts[tile] = #selected        */           \
+  X(SEL_RANK)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
+  X(STORE_8) X(STORE_32) X(STORE_64)     /* dst = out col, a = reg, rows 1:1 */\
+  X(STOREC_8) X(STOREC_32) X(STOREC_64)  /* + b = rank reg, c = sel (compact)*/\
+  X(STORE_ROWID) /* dst = out col: int64 global row id of survivors, b,c */    \
+  /* ---- group-aggregate sinks --------------------------------------------- */\
+  X(KEY_ZERO)    /* dst(64) = 0 */                                             \
+  X(KEY_APPEND_8) X(KEY_APPEND_32) X(KEY_APPEND_64)                            \
+                 /* dst |= (a & mask) << shift, null b sets flag bit; imm =   */\
+                 /* shift | bits<<8 | nullbit<<16 (nullbit 0xFF = none)        */\
+  X(GRP_INSERT)  /* a = key(64), c = sel -> dst = u32 slot reg */              \
+  X(GAGG_COUNT)                                                                \
+  X(GAGG_SUM_I32) X(GAGG_SUM_U32) X(GAGG_SUM_I64) X(GAGG_SUM_F32) X(GAGG_SUM_F64)\
+  X(GAGG_MIN_I32) X(GAGG_MIN_U32) X(GAGG_MIN_I64) X(GAGG_MIN_U64)              \
+  X(GAGG_MIN_F32) X(GAGG_MIN_F64) X(GAGG_MIN_B8)                               \
+  X(GAGG_MAX_I32) X(GAGG_MAX_U32) X(GAGG_MAX_I64) X(GAGG_MAX_U64)              \
+  X(GAGG_MAX_F32) X(GAGG_MAX_F64) X(GAGG_MAX_B8)                               \
+  X(GAGG_FIRST) X(GAGG_LAST)                                                   \
+  X(OP_COUNT_)
+
+enum VmOp : uint16_t {
+#define X(n) VM_##n,
+  VM_OPS(X)
+#undef X
+};
+
+struct VmInstr {
+  uint16_t op;
+  uint8_t a_imm; /* operand a is `imm` */
+  uint8_t b_imm; /* operand b is `imm` */
+  uint32_t dst;  /* LDS byte offset | aggregate slot | output column index */
+  uint32_t a, b, c, d; /* LDS byte offsets, VM_NONE when absent */
+  uint64_t imm;
+};
+static_assert(sizeof(VmInstr) == 32, "VmInstr must be 32 bytes");
+
+struct VmStagedCol {
+  const void* src;   /* device pointer of the column (data or null mask) */
+  uint32_t lds_off;  /* destination register */
+  uint32_t width;    /* 1, 4 or 8 bytes per row */
+};
+
+struct VmOutCol {
+  void* dst;         /* device pointer of the output column */
+  uint32_t width;
+  uint32_t pad;
+};
+
+/* One partial-aggregate record (per workgroup per slot, then per slot). */
+struct VmAccRec {
+  uint64_t v0;  /* value bits (sum hi / min / max / first|last value) */
+  uint64_t v1;  /* double-double low part, or row id for FIRST/LAST   */
+  uint64_t cnt; /* number of contributing (non-NULL, selected) rows    */
+  uint64_t pad;
+};
+
+/* Group table (open addressing, 64-bit packed keys). */
+struct VmGroupTable {
+  unsigned long long* keys;      /* capacity + 1 entries (last = EMPTY-valued key) */
+  unsigned long long* first_row; /* min global row id per slot                    */
+  unsigned long long* acc;       /* [n_gaggs][capacity+1] value bits              */
+  unsigned int* cnt;             /* [n_gaggs][capacity+1] contribution counts      */
+  unsigned int* overflow;        /* set to 1 when probing exhausted the table      */
+  uint32_t capacity_mask;        /* capacity - 1                                   */
+  uint32_t pad;
+};
+#define VM_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct VmParams {
+  const VmInstr* prog;
+  int32_t n_instr;
+  int32_t n_staged;
+  int32_t n_outputs;
+  int32_t n_slots;        /* scalar aggregate slots */
+  int64_t n_rows;
+  int64_t row_id_base;    /* global row id of row 0 (multi-GPU shards) */
+  int32_t tile_rows;      /* 512 * K */
+  int32_t n_tiles;
+  uint32_t acc_lds_off;   /* LDS offset of the aggregate accumulators */
+  uint32_t scratch_lds_off; /* LDS offset of 256 B of scan scratch */
+  uint32_t lds_bytes;
+  uint32_t flags;
+  VmAccRec* wg_partials;        /* [grid][n_slots] */
+  unsigned int* tile_counts;    /* SEL_COUNT output / scanned offsets input */
+  const unsigned int* tile_offsets;
+  unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
+  VmGroupTable group;
+  VmStagedCol staged[VM_MAX_STAGED];
+  VmOutCol outputs[VM_MAX_OUTPUTS];
+};
+
+#ifndef __HIPCC__
+static inline const char* vm_op_name(uint16_t op) {
+  static const char* names[] = {
+#define X(n) #n,
+      VM_OPS(X)
+#undef X
+  };
+  return op < VM_OP_COUNT_ ? names[op] : "?";
+}
+#endif
+
+#endif  // SSGPU_VM_H_

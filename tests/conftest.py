@@ -1,0 +1,24 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # build the in-tree artefacts if they are missing (no-op when already built)
+    if not os.path.exists(os.path.join(ROOT, "supersonic_amd", "lib", "libssgpu.so")):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "supersonic_amd", "csrc")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import supersonic_amd as ss
+    return ss.Context(0)  # fails loudly without a device: GPU tests never fall back

@@ -1,0 +1,60 @@
+"""Shared helpers for the parity tests: run one operation tree through the HIP path
+(C ABI) and through the CPU oracle and compare, masking values at NULL rows (values at
+NULL result rows are unspecified in the reference: binary_column_computers.h:204-218)."""
+import numpy as np
+
+import supersonic_amd as ss
+from oracle import oracle
+
+
+def to_cols(view):
+    return [(view.column(i).data, view.column(i).is_null) for i in range(view.column_count())]
+
+
+def schema_list(schema):
+    return [(schema.attribute(i).name(), schema.attribute(i).type(), schema.attribute(i).nullability())
+            for i in range(schema.attribute_count())]
+
+
+def sort_rows(cols):
+    """Order-insensitive comparison support: sort rows lexicographically (NULLs first)."""
+    if not cols or len(cols[0][0]) == 0:
+        return cols
+    keys = []
+    for d, z in reversed(cols):
+        keys.append(np.where(z, 0, d) if z is not None else d)
+        if z is not None:
+            keys.append(~z)
+    order = np.lexsort(keys)
+    return [(d[order], None if z is None else z[order]) for d, z in cols]
+
+
+def assert_cols_equal(got, want, float_exact=True, context=""):
+    assert len(got) == len(want), (context, len(got), len(want))
+    for i, ((gd, gz), (wd, wz)) in enumerate(zip(got, want)):
+        assert len(gd) == len(wd), "%s column %d: %d rows vs %d" % (context, i, len(gd), len(wd))
+        gz_ = np.zeros(len(gd), bool) if gz is None else gz
+        wz_ = np.zeros(len(wd), bool) if wz is None else wz
+        assert np.array_equal(gz_, wz_), "%s column %d: NULL masks differ at %s" % (
+            context, i, np.nonzero(gz_ != wz_)[0][:10])
+        live = ~wz_
+        g, w = gd[live], wd[live]
+        if float_exact or g.dtype.kind != "f":
+            same = g.view(np.uint8).reshape(len(g), -1) == w.view(np.uint8).reshape(len(w), -1) if len(g) else np.ones((0, 1), bool)
+            bad = np.nonzero(~same.all(axis=1))[0] if len(g) else []
+            assert len(bad) == 0, "%s column %d: %d rows differ, first %s: got %s want %s" % (
+                context, i, len(bad), bad[:5], g[bad[:5]], w[bad[:5]])
+        else:
+            assert np.allclose(g, w, rtol=0, atol=0, equal_nan=True)
+
+
+def run_both(op, ctx, ignore_order=False, max_rows=1024):
+    cur = op.CreateCursor(ctx)
+    got_view = ss.drain(cur, max_rows)
+    oschema, want = oracle.run(op, max_rows)
+    assert schema_list(cur.schema()) == oschema, (schema_list(cur.schema()), oschema)
+    got = to_cols(got_view)
+    if ignore_order:
+        got, want = sort_rows(got), sort_rows(want)
+    assert_cols_equal(got, want, context=str(cur.schema()))
+    return got_view

@@ -1,0 +1,193 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact for integer / index / BOOL columns; DOUBLE data is chosen so that
+every partial sum is exact, which makes DOUBLE aggregates bit-exact too.
+
+Row counts follow the reference's block-size cross product idea
+(supersonic/testing/operation_testing.cc:350-352), restated as launch-geometry / tile-boundary
+cases: around one wave (64), one tile (512/1024/2048) and many tiles.
+"""
+import numpy as np
+import pytest
+
+import supersonic_amd as ss
+from helpers import run_both
+
+pytestmark = pytest.mark.gpu
+
+ROWS = [0, 1, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 10001, 100003]
+NA = ss.NamedAttribute
+
+
+def make_view(n, seed=42, nullable=False):
+    rng = np.random.default_rng(seed)
+    N = ss.NULLABLE if nullable else ss.NOT_NULLABLE
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64, N), ss.Attribute("b", ss.INT64), ss.Attribute("c", ss.INT64),
+                             ss.Attribute("d", ss.INT64, N), ss.Attribute("k1", ss.INT32, N), ss.Attribute("k2", ss.INT32),
+                             ss.Attribute("d0", ss.DOUBLE, N), ss.Attribute("d1", ss.DOUBLE),
+                             ss.Attribute("d2", ss.DOUBLE), ss.Attribute("d3", ss.DOUBLE),
+                             ss.Attribute("u", ss.UINT32), ss.Attribute("f", ss.FLOAT), ss.Attribute("t", ss.BOOL, N)])
+    g = rng.integers(0, 1000, n)
+
+    def nl():
+        return (rng.random(n) < 0.1) if nullable else None
+    cols = [ss.Column(rng.integers(0, 1000, n), nl()), rng.integers(0, 1000, n), np.arange(n) % 100000,
+            ss.Column(rng.integers(-(1 << 62), 1 << 62, n), nl()), ss.Column(g // 31, nl()), g % 31,
+            ss.Column(rng.integers(-1000000, 1000001, n).astype(np.float64), nl()), rng.integers(0, 4000, n) * 0.25,
+            rng.integers(0, 64, n).astype(np.float64), rng.integers(0, 64, n).astype(np.float64),
+            rng.integers(0, 1 << 32, n).astype(np.uint32), (rng.integers(0, 2048, n) * 0.5).astype(np.float32),
+            ss.Column(rng.integers(0, 2, n).astype(bool), nl())]
+    return ss.View(schema, cols)
+
+
+def fpa_narrow(view):
+    return ss.ScalarAggregate(
+        ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.COUNT, "a", "cnt"),
+        ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(),
+                  ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))), ss.ScanView(view))))
+
+
+def fpa_wide(view):
+    compute = (ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))).Add(NA("c")).Add(NA("d"))
+               .Add(NA("d0")).Add(NA("d1")).AddAs("p", ss.Multiply(NA("d2"), NA("d3"))))
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.COUNT, "", "cnt")
+            .AddAggregation(ss.SUM, "c", "sum_c").AddAggregation(ss.MIN, "d", "min_d").AddAggregation(ss.MAX, "d0", "max_d0")
+            .AddAggregation(ss.SUM, "d1", "sum_d1").AddAggregation(ss.SUM, "p", "sum_p"))
+    return ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(),
+                                              ss.Compute(compute, ss.ScanView(view))))
+
+
+@pytest.mark.parametrize("n", ROWS)
+def test_fpa_narrow(gpu_ctx, n):
+    run_both(fpa_narrow(make_view(n)), gpu_ctx)
+
+
+@pytest.mark.parametrize("n", ROWS)
+def test_fpa_wide(gpu_ctx, n):
+    run_both(fpa_wide(make_view(n)), gpu_ctx)
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
+def test_fpa_wide_nullable(gpu_ctx, n):
+    run_both(fpa_wide(make_view(n, nullable=True)), gpu_ctx)
+
+
+@pytest.mark.parametrize("tile", [512, 1024, 2048])
+def test_fpa_tile_sizes(tile, n=100003):
+    ctx = ss.Context(0)
+    ctx.set_option("tile_rows", tile)
+    run_both(fpa_wide(make_view(n)), ctx)
+    run_both(fpa_narrow(make_view(n)), ctx)
+
+
+def all_aggs(view):
+    spec = ss.AggregationSpecification()
+    for col in ["a", "d", "k1", "d0", "u", "f", "t"]:
+        for agg, nm in [(ss.MIN, "min"), (ss.MAX, "max"), (ss.FIRST, "first"), (ss.LAST, "last")]:
+            spec.AddAggregation(agg, col, "%s_%s" % (nm, col))
+        if col != "t":
+            spec.AddAggregation(ss.SUM, col, "sum_%s" % col)
+        spec.AddAggregation(ss.COUNT, col, "cnt_%s" % col)
+    spec.AddAggregationWithDefinedOutputType(ss.SUM, "k1", "sum_k1_64", ss.INT64)
+    spec.AddAggregationWithDefinedOutputType(ss.SUM, "k1", "sum_k1_f64", ss.DOUBLE)
+    spec.AddAggregationWithDefinedOutputType(ss.COUNT, "", "cnt32", ss.INT32)
+    return ss.ScalarAggregate(spec, ss.ScanView(view))
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 1000, 100003])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_scalar_aggregate_matrix(gpu_ctx, n, nullable):
+    run_both(all_aggs(make_view(n, nullable=nullable)), gpu_ctx)
+
+
+def compute_exprs(view):
+    e = (ss.CompoundExpression()
+         .AddAs("sum", ss.Plus(NA("a"), NA("b")))
+         .AddAs("mixed", ss.Plus(NA("a"), NA("k1")))            # INT64 + INT32 -> cast
+         .AddAs("dbl", ss.Multiply(NA("d0"), NA("k2")))         # DOUBLE * INT32
+         .AddAs("neg", ss.Negate(NA("u")))                      # UINT32 -> INT32
+         .AddAs("div", ss.DivideNulling(NA("d1"), NA("k2")))
+         .AddAs("cmp", ss.LessOrEqual(NA("k1"), NA("d")))       # INT32 vs INT64, no cast
+         .AddAs("ucmp", ss.Less(NA("u"), NA("k2")))             # UINT32 vs INT32
+         .AddAs("logic", ss.Or(ss.And(NA("t"), ss.Greater(NA("a"), ss.ConstInt64(300))), ss.Less(NA("f"), ss.ConstDouble(100.0))))
+         .AddAs("isnull", ss.IsNull(NA("d0")))
+         .AddAs("ifnull", ss.IfNull(NA("a"), NA("c")))
+         .AddAs("iff", ss.If(NA("t"), NA("a"), NA("k1")))
+         .AddAs("sub", ss.Minus(NA("f"), NA("u")))
+         .AddAs("c5", ss.Plus(ss.ConstInt32(2), ss.ConstInt32(3)))
+         .Add(NA("d")))
+    return ss.Compute(e, ss.ScanView(view))
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 513, 2049, 100003])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_compute_materialize(gpu_ctx, n, nullable):
+    run_both(compute_exprs(make_view(n, nullable=nullable)), gpu_ctx)
+
+
+@pytest.mark.parametrize("n", ROWS)
+@pytest.mark.parametrize("k", [-1, 499, 989, 1000])   # all / half / 1% / none pass
+def test_filter_materialize(gpu_ctx, n, k):
+    op = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(k)), ss.ProjectAllAttributes(), ss.ScanView(make_view(n)))
+    run_both(op, gpu_ctx)
+
+
+@pytest.mark.parametrize("n", [0, 65, 1025, 100003])
+def test_filter_nullable_predicate_and_project(gpu_ctx, n):
+    view = make_view(n, nullable=True)
+    pred = ss.And(ss.Greater(NA("a"), ss.ConstInt64(300)), NA("t"))
+    op = ss.Filter(pred, ss.ProjectNamedAttributes(["d", "k1", "a", "d0"]), ss.ScanView(view))
+    run_both(op, gpu_ctx)
+
+
+def group_query(view, with_filter, keys=("k1", "k2")):
+    spec = ss.AggregationSpecification()
+    for col in ["d0", "d1", "d2", "d3"]:
+        spec.AddAggregation(ss.SUM, col, "sum_" + col).AddAggregation(ss.MIN, col, "min_" + col).AddAggregation(ss.MAX, col, "max_" + col)
+    spec.AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.SUM, "a", "sum_a").AddAggregation(ss.MAX, "k2", "max_k2")
+    child = ss.ScanView(view)
+    if with_filter:
+        child = ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), child)
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(list(keys)), spec, None, child)
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
+@pytest.mark.parametrize("with_filter", [False, True])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_group_aggregate(gpu_ctx, n, with_filter, nullable):
+    # packed group keys are limited to 64 bits: a NULLABLE INT32 key takes 33 of them
+    keys = ("k1",) if nullable else ("k1", "k2")
+    run_both(group_query(make_view(n, nullable=nullable), with_filter, keys), gpu_ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("n", [0, 1000, 100003])
+def test_group_aggregate_int64_key(gpu_ctx, n):
+    view = make_view(n)
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "s").AddAggregation(ss.MIN, "d", "mn").AddAggregation(ss.MAX, "d", "mx")
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["c"]), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+
+
+def test_group_table_regrow():
+    ctx = ss.Context(0)
+    ctx.set_option("group_capacity", 64)   # 1000 groups do not fit: forces the regrow + rerun path
+    run_both(group_query(make_view(50000), False), ctx, ignore_order=True)
+
+
+def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
+    n = 5000
+    view = make_view(n)
+    # k2 == 0 exists; dividing over all rows must fail ...
+    op = ss.Compute(ss.DivideSignaling(NA("d1"), NA("k2")), ss.ScanView(view))
+    r = op.CreateCursor(gpu_ctx).Next(1024)
+    assert r.is_failure() and r.exception().return_code == 104
+    # ... but not when the zero divisors are filtered out first
+    op = ss.Compute(ss.DivideSignaling(NA("d1"), NA("k2")),
+                    ss.Filter(ss.Greater(NA("k2"), ss.ConstInt32(0)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    run_both(op, gpu_ctx)
+
+
+def test_chained_stages(gpu_ctx):
+    # Compute over a GroupAggregate result: two pipeline stages
+    view = make_view(20000)
+    grouped = group_query(view, True)
+    op = ss.Compute(ss.CompoundExpression().Add(NA("k1")).Add(NA("k2")).AddAs("range", ss.Minus(NA("max_d0"), NA("min_d0"))), grouped)
+    run_both(op, gpu_ctx, ignore_order=True)
