@@ -443,6 +443,10 @@ void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out
     if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
     out->push_back(v);
   }
+  // one trailing NOP: the kernel prefetches instruction pc + 1
+  VmInstr nop; memset(&nop, 0, sizeof(nop)); nop.op = VM_NOP;
+  nop.dst = nop.a = nop.b = nop.c = nop.d = VM_NONE;
+  out->push_back(nop);
 }
 
 std::string disassemble(const Program& p) {

@@ -380,8 +380,18 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     stage_tile(P, tile_base, tile_rows, t);
     __syncthreads();  // carries vmcnt(0): DMA'd data visible to the whole workgroup
 
+    // The program is immutable for the launch: fetch it through the constant address
+    // space so every instruction is ONE scalar s_load_dwordx8 (a vector global_load +
+    // v_readfirstlane round trip per instruction cost ~35% of the kernel), and fetch the
+    // next instruction while the current one executes.
+    typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) u64x4* ProgPtr;
+    const ProgPtr prog = (ProgPtr)(P.prog);
+    u64x4 raw_next = prog[0];
     for (int pc = 0; pc < P.n_instr; ++pc) {
-      const VmInstr I = P.prog[pc];
+      VmInstr I;
+      __builtin_memcpy(&I, &raw_next, sizeof(I));
+      raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
       // launder the thread id once per instruction: without this LICM hoists every
       // case's (t * width) address chain into the prologue (255 VGPRs, occupancy 1)
       int tp = t;
@@ -771,36 +781,48 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
 // (workgroup, wave) order, by the slot's rule.  One thread per slot.
 // ---------------------------------------------------------------------------
 
-__global__ void ssgpu_finish_slots_kernel(const VmAccRec* __restrict__ partials, int n_records_per_slot_stride,
-                                          int n_slots, int n_parts, const int* __restrict__ slot_kind,
-                                          VmAccRec* __restrict__ out) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
+__device__ __forceinline__ void combine_rec(int kind, VmAccRec& acc, const VmAccRec& r) {
+  if (r.cnt == 0) return;
+  switch (kind) {
+    case SLOT_COUNT:
+    case SLOT_SUM_INT: acc.v0 += r.v0; break;
+    case SLOT_SUM_DD: {
+      DD a; a.hi = u2d(acc.v0); a.lo = u2d(acc.v1);
+      DD b; b.hi = u2d(r.v0); b.lo = u2d(r.v1);
+      a = dd_add(a, b); acc.v0 = d2u(a.hi); acc.v1 = d2u(a.lo);
+    } break;
+    case SLOT_MIN_U64: acc.v0 = acc.cnt ? (r.v0 < acc.v0 ? r.v0 : acc.v0) : r.v0; break;
+    case SLOT_MAX_U64: acc.v0 = acc.cnt ? (r.v0 > acc.v0 ? r.v0 : acc.v0) : r.v0; break;
+    case SLOT_MIN_F64: acc.v0 = acc.cnt ? (u2d(r.v0) < u2d(acc.v0) ? r.v0 : acc.v0) : r.v0; break;
+    case SLOT_MAX_F64: acc.v0 = acc.cnt ? (u2d(acc.v0) < u2d(r.v0) ? r.v0 : acc.v0) : r.v0; break;
+    case SLOT_FIRST: if (!acc.cnt || r.v1 < acc.v1) { acc.v0 = r.v0; acc.v1 = r.v1; } break;
+    case SLOT_LAST: if (!acc.cnt || r.v1 >= acc.v1) { acc.v0 = r.v0; acc.v1 = r.v1; } break;
+  }
+  acc.cnt += r.cnt;
+}
+
+// One workgroup per slot: thread t folds records t, t+256, ... in order, then a fixed
+// LDS tree folds the 256 thread results.  The shape is fixed, so results are reproducible
+// run to run (and exact whenever the partial sums are exact).
+__global__ __launch_bounds__(256) void ssgpu_finish_slots_kernel(const VmAccRec* __restrict__ partials, int n_slots,
+                                                                 int n_parts, const int* __restrict__ slot_kind,
+                                                                 VmAccRec* __restrict__ out) {
+  __shared__ VmAccRec tree[256];
+  const int s = blockIdx.x, t = threadIdx.x;
   const int kind = slot_kind[s];
   VmAccRec acc; acc.v0 = 0; acc.v1 = 0; acc.cnt = 0; acc.pad = 0;
   if (kind == SLOT_SUM_DD) { acc.v0 = d2u(-0.0); acc.v1 = d2u(0.0); }
-  for (int i = 0; i < n_parts; ++i) {
+  for (int i = t; i < n_parts; i += 256) {
     const VmAccRec r = partials[((size_t)(i / VM_WAVES) * n_slots + s) * VM_WAVES + (i % VM_WAVES)];
-    if (r.cnt == 0) continue;
-    switch (kind) {
-      case SLOT_COUNT:
-      case SLOT_SUM_INT: acc.v0 += r.v0; break;
-      case SLOT_SUM_DD: {
-        DD a; a.hi = u2d(acc.v0); a.lo = u2d(acc.v1);
-        DD b; b.hi = u2d(r.v0); b.lo = u2d(r.v1);
-        a = dd_add(a, b); acc.v0 = d2u(a.hi); acc.v1 = d2u(a.lo);
-      } break;
-      case SLOT_MIN_U64: acc.v0 = acc.cnt ? (r.v0 < acc.v0 ? r.v0 : acc.v0) : r.v0; break;
-      case SLOT_MAX_U64: acc.v0 = acc.cnt ? (r.v0 > acc.v0 ? r.v0 : acc.v0) : r.v0; break;
-      case SLOT_MIN_F64: acc.v0 = acc.cnt ? (u2d(r.v0) < u2d(acc.v0) ? r.v0 : acc.v0) : r.v0; break;
-      case SLOT_MAX_F64: acc.v0 = acc.cnt ? (u2d(acc.v0) < u2d(r.v0) ? r.v0 : acc.v0) : r.v0; break;
-      case SLOT_FIRST: if (!acc.cnt || r.v1 < acc.v1) { acc.v0 = r.v0; acc.v1 = r.v1; } break;
-      case SLOT_LAST: if (!acc.cnt || r.v1 >= acc.v1) { acc.v0 = r.v0; acc.v1 = r.v1; } break;
-    }
-    acc.cnt += r.cnt;
+    combine_rec(kind, acc, r);
   }
-  (void)n_records_per_slot_stride;
-  out[s] = acc;
+  tree[t] = acc;
+  __syncthreads();
+  for (int stride = 128; stride > 0; stride >>= 1) {
+    if (t < stride) { VmAccRec a = tree[t]; combine_rec(kind, a, tree[t + stride]); tree[t] = a; }
+    __syncthreads();
+  }
+  if (t == 0) out[s] = tree[0];
 }
 
 // Reducible-state <-> slot records for the multi-GPU exchange.  The state is
@@ -1024,8 +1046,7 @@ hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
 }
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
                                      VmAccRec* out, hipStream_t stream) {
-  int blocks = (n_slots + 63) / 64;
-  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(blocks), dim3(64), 0, stream, partials, 0, n_slots, n_parts, slot_kind, out);
+  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(n_slots), dim3(256), 0, stream, partials, n_slots, n_parts, slot_kind, out);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state, hipStream_t stream) {

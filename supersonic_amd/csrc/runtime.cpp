@@ -312,7 +312,7 @@ struct InCols { std::vector<ssgpu_column> cols; int64_t rows = 0; };
 
 int upload_program(ssgpu_ctx* c, const Program& prog, int tile_rows, DevBuf* dev, int* n_instr, std::vector<VmInstr>* scratch) {
   finalize_program(prog, tile_rows, scratch);
-  *n_instr = (int)scratch->size();
+  *n_instr = (int)scratch->size() - 1;  // without the trailing prefetch pad
   HIP_TRY(c, dev->ensure(std::max<size_t>(1, scratch->size()) * sizeof(VmInstr)));
   if (!scratch->empty())
     HIP_TRY(c, hipMemcpyAsync(dev->p, scratch->data(), scratch->size() * sizeof(VmInstr), hipMemcpyHostToDevice, c->stream));

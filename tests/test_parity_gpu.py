@@ -34,7 +34,7 @@ def make_view(n, seed=42, nullable=False):
             ss.Column(rng.integers(-(1 << 62), 1 << 62, n), nl()), ss.Column(g // 31, nl()), g % 31,
             ss.Column(rng.integers(-1000000, 1000001, n).astype(np.float64), nl()), rng.integers(0, 4000, n) * 0.25,
             rng.integers(0, 64, n).astype(np.float64), rng.integers(0, 64, n).astype(np.float64),
-            rng.integers(0, 1 << 32, n).astype(np.uint32), (rng.integers(0, 2048, n) * 0.5).astype(np.float32),
+            rng.integers(0, 1 << 32, n).astype(np.uint32), (rng.integers(0, 64, n) * 0.5).astype(np.float32),
             ss.Column(rng.integers(0, 2, n).astype(bool), nl())]
     return ss.View(schema, cols)
 
@@ -108,7 +108,7 @@ def compute_exprs(view):
          .AddAs("div", ss.DivideNulling(NA("d1"), NA("k2")))
          .AddAs("cmp", ss.LessOrEqual(NA("k1"), NA("d")))       # INT32 vs INT64, no cast
          .AddAs("ucmp", ss.Less(NA("u"), NA("k2")))             # UINT32 vs INT32
-         .AddAs("logic", ss.Or(ss.And(NA("t"), ss.Greater(NA("a"), ss.ConstInt64(300))), ss.Less(NA("f"), ss.ConstDouble(100.0))))
+         .AddAs("logic", ss.Or(ss.And(NA("t"), ss.Greater(NA("a"), ss.ConstInt64(300))), ss.Less(NA("f"), ss.ConstDouble(10.0))))
          .AddAs("isnull", ss.IsNull(NA("d0")))
          .AddAs("ifnull", ss.IfNull(NA("a"), NA("c")))
          .AddAs("iff", ss.If(NA("t"), NA("a"), NA("k1")))

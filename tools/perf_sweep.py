@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Development aid: time the pipeline kernel for several plan shapes and tile/grid settings
+on device-resident synthetic blocks (prints one line per configuration)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import supersonic_amd as ss  # noqa: E402
+import bench  # noqa: E402
+
+NA = ss.NamedAttribute
+
+
+def q_wide(v):
+    return bench.build_plan(ss, v)
+
+
+def q_narrow(v):
+    return ss.ScalarAggregate(
+        ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.COUNT, "a", "cnt"),
+        ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(),
+                  ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))), ss.ScanView(v))))
+
+
+def q_stage8(v):
+    # all 8 columns staged, little work: 2 aggregates over sums of columns
+    e = (ss.CompoundExpression().AddAs("i", ss.Plus(ss.Plus(NA("a"), NA("b")), ss.Plus(NA("c"), NA("d"))))
+         .AddAs("f", ss.Plus(ss.Plus(NA("d0"), NA("d1")), ss.Plus(NA("d2"), NA("d3")))))
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "i", "si").AddAggregation(ss.MAX, "f", "mf")
+    return ss.ScalarAggregate(spec, ss.Compute(e, ss.ScanView(v)))
+
+
+def q_min8(v):
+    spec = ss.AggregationSpecification()
+    for c in ["a", "b", "c", "d", "d0", "d1", "d2", "d3"]:
+        spec.AddAggregation(ss.MIN, c, "m" + c)
+    return ss.ScalarAggregate(spec, ss.ScanView(v))
+
+
+def q_sum1(v):
+    return ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "sa"), ss.ScanView(v))
+
+
+def q_filter_mat(v):
+    return ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(v))
+
+
+def q_group(v):
+    spec = ss.AggregationSpecification()
+    for c in ["d0", "d1", "d2", "d3"]:
+        spec.AddAggregation(ss.SUM, c, "s" + c).AddAggregation(ss.MIN, c, "n" + c).AddAggregation(ss.MAX, c, "x" + c)
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(["c"]), spec, None, ss.ScanView(v))
+
+
+QUERIES = {"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
+           "filter_mat": q_filter_mat, "group": q_group}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000_000)
+    ap.add_argument("--queries", default="wide,narrow,stage8,min8,sum1")
+    ap.add_argument("--tiles", default="0,512,1024,2048")
+    ap.add_argument("--lds", default="49152")
+    ap.add_argument("--grids", default="0")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cols = bench.gen_device_columns(torch, args.rows, 42, dev)
+    torch.cuda.synchronize()
+    view = ss.DeviceView(bench.bench_schema(ss), [(t.data_ptr(), 0) for t in cols], args.rows)
+    for qn in args.queries.split(","):
+        for tile in [int(x) for x in args.tiles.split(",")]:
+            for lds in [int(x) for x in args.lds.split(",")]:
+                for grid in [int(x) for x in args.grids.split(",")]:
+                    ctx = ss.Context(0)
+                    ctx.set_option("tile_rows", tile)
+                    ctx.set_option("lds_target_bytes", lds)
+                    ctx.set_option("grid_limit", grid)
+                    try:
+                        plan = ss.Plan(QUERIES[qn](view), ctx)
+                        ms = []
+                        for _ in range(args.reps):
+                            plan.run(view)
+                            ctx.synchronize()
+                            c = plan.counters()
+                            ms.append((c.dominant_ms, c.kernel_ms))
+                        ms.sort()
+                        dom, tot = ms[len(ms) // 2]
+                        gbs = c.algorithmic_bytes / (dom / 1e3) / 1e9
+                        print("%-10s tile=%-5d lds_target=%-6d grid=%-5d lds=%-6d dom=%.3f ms total=%.3f ms  %.0f GB/s (%.1f%% of 8TB/s)  %.1f Grows/s" % (
+                            qn, c.tile_rows, lds, c.grid, c.lds_bytes, dom, tot, gbs, gbs / 80.0, args.rows / dom / 1e6), flush=True)
+                    except ss.SupersonicException as e:
+                        print("%-10s tile=%d: %s" % (qn, tile, e), flush=True)
+
+
+if __name__ == "__main__":
+    main()
