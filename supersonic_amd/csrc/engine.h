@@ -98,6 +98,8 @@ struct Program {
   std::vector<LReg> regs;
   std::vector<StagedInput> staged;
   uint32_t bytes_per_row = 0;   // LDS bytes per tile row (peak of live registers)
+  uint32_t in_bytes_per_row = 0;  // of which: the (double-buffered) input region
+  int n_sync_per_tile = 0;      // workgroup barriers executed inside the program per tile
   int n_slots = 0;
   int n_outputs = 0;
   bool empty() const { return code.empty(); }
@@ -149,7 +151,7 @@ struct LowerOptions {
 };
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe);
 // choose the tile size (K = tile_rows / 512) and fix LDS offsets for a program
-struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; };
+struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t in_lds_bytes; };
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt);
 // final device instructions for a tile of `tile_rows`
 void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out);

@@ -377,23 +377,24 @@ static void allocate_registers(Program* p) {
     }
     p->regs[r].row_off = top; top += w; peak = std::max(peak, top);
   };
+  uint32_t in_bpr = 0;  // end of the input region: registers never straddle it
   auto release = [&](int r) {
     Hole h; h.off = p->regs[r].row_off; h.width = p->regs[r].width;
-    // merge with neighbours / the bump pointer
+    // merge with neighbours / the bump pointer, but never across the input-region boundary
     holes.push_back(h);
     std::sort(holes.begin(), holes.end(), [](const Hole& x, const Hole& y) { return x.off < y.off; });
     for (size_t i = 0; i + 1 < holes.size();) {
-      if (holes[i].off + holes[i].width == holes[i + 1].off) { holes[i].width += holes[i + 1].width; holes.erase(holes.begin() + i + 1); }
+      if (holes[i].off + holes[i].width == holes[i + 1].off && holes[i + 1].off != in_bpr) { holes[i].width += holes[i + 1].width; holes.erase(holes.begin() + i + 1); }
       else ++i;
     }
-    if (!holes.empty() && holes.back().off + holes.back().width == top) { top = holes.back().off; holes.pop_back(); }
+    if (!holes.empty() && holes.back().off + holes.back().width == top && holes.back().off >= in_bpr) { top = holes.back().off; holes.pop_back(); }
   };
   // staged registers live from the start (wide ones first for alignment-friendly packing)
   std::vector<int> st;
   for (auto& s : p->staged) st.push_back(s.reg);
   std::sort(st.begin(), st.end(), [&](int a, int b) { return p->regs[a].width > p->regs[b].width; });
   for (int r : st) place(r);
-  for (int r : st) if (last[r] < 0) last[r] = -1;
+  in_bpr = top;
   for (int pc = 0; pc < (int)p->code.size(); ++pc) {
     for_each_def(p->code[pc], [&](int r) { place(r); });
     // a register whose last use is this instruction is released AFTER the definition was
@@ -404,13 +405,17 @@ static void allocate_registers(Program* p) {
     std::sort(dead.begin(), dead.end()); dead.erase(std::unique(dead.begin(), dead.end()), dead.end());
     for (int r : dead) release(r);
   }
-  p->bytes_per_row = peak;
+  p->bytes_per_row = std::max(peak, in_bpr);
+  p->in_bytes_per_row = in_bpr;
+  p->n_sync_per_tile = 0;
+  for (auto& i : p->code) if (i.op == VM_SEL_COUNT || i.op == VM_SEL_RANK) p->n_sync_per_tile += 2;
 }
 
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   ProgramLayout L;
   auto lds_for = [&](int K, uint32_t* acc, uint32_t* scr) {
-    uint32_t regs = p.bytes_per_row * 512u * (uint32_t)K;
+    // two input buffers (the loader wave fills one while the other is consumed) + temporaries
+    uint32_t regs = (p.bytes_per_row + p.in_bytes_per_row) * 512u * (uint32_t)K;
     uint32_t a = (regs + 15u) & ~15u;
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
     if (acc) *acc = a;
@@ -421,17 +426,26 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   if (opt.tile_rows > 0) {
     K = std::max(1, opt.tile_rows / 512);
     if (K >= 4) K = 4; else if (K >= 2) K = 2; else K = 1;
+    while (K > 1 && lds_for(K, nullptr, nullptr) > 160u * 1024u) K /= 2;  // must fit one CU
   } else {
     for (int cand : {4, 2, 1}) { K = cand; if ((int)lds_for(cand, nullptr, nullptr) <= opt.lds_target_bytes) break; }
   }
   L.K = K;
   L.lds_bytes = lds_for(K, &L.acc_off, &L.scratch_off);
+  L.in_lds_bytes = p.in_bytes_per_row * 512u * (uint32_t)K;
   return L;
 }
 
 void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out) {
   out->clear();
-  auto off = [&](int r) -> uint32_t { return r < 0 ? VM_NONE : p.regs[r].row_off * (uint32_t)tile_rows; };
+  // input-region registers: offset inside ONE input buffer, bit 31 = "add the current buffer
+  // base"; temporaries live behind both input buffers
+  auto off = [&](int r) -> uint32_t {
+    if (r < 0) return VM_NONE;
+    const uint32_t ro = p.regs[r].row_off;
+    if (ro < p.in_bytes_per_row) return (ro * (uint32_t)tile_rows) | 0x80000000u;
+    return (ro + p.in_bytes_per_row) * (uint32_t)tile_rows;
+  };
   for (const LInstr& i : p.code) {
     VmInstr v; memset(&v, 0, sizeof(v));
     v.op = i.op; v.a_imm = i.a_imm; v.b_imm = i.b_imm;

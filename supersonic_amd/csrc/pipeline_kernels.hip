@@ -127,6 +127,11 @@ __device__ __forceinline__ Valid2 valid_pair(const VmInstr& I, int p, i64 tile_b
   return v;
 }
 
+// LDS operand offsets: bit 31 marks a register in the (double-buffered) input region
+__device__ __forceinline__ u32 vm_resolve(u32 o, u32 bufbase) {
+  return o == VM_NONE ? o : ((o & 0x7FFFFFFFu) + ((o >> 31) ? bufbase : 0u));
+}
+
 __device__ __forceinline__ VmAccRec* acc_rec(const VmParams& P, u32 slot, int wave) {
   return reinterpret_cast<VmAccRec*>(smem + P.acc_lds_off + slot * VM_ACC_STRIDE + wave * 32);
 }
@@ -163,35 +168,37 @@ __device__ __forceinline__ u32 group_insert(const VmGroupTable& G, u64 key) {
 // input staging: global -> LDS.  Fast path = LDS-DMA, 16 B per lane, 1 KiB per
 // wave instruction, destination wave-uniform base + lane*16 (linear layout).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int tile_rows, int t) {
+__device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int tile_rows, int lane, u32 bufbase) {
   const bool full = tile_base + tile_rows <= P.n_rows;
   for (int s = 0; s < P.n_staged; ++s) {
     const VmStagedCol C = P.staged[s];
+    char* dst = smem + C.lds_off + bufbase;
     if (C.src == nullptr) {  // nullable attribute whose View carries no is_null vector
-      for (u32 c = (u32)t * 4u; c < (u32)tile_rows * C.width; c += VM_WG_THREADS * 4u)
-        *reinterpret_cast<u32*>(smem + C.lds_off + c) = 0u;
+      for (u32 c = (u32)lane * 4u; c < (u32)tile_rows * C.width; c += 64u * 4u)
+        *reinterpret_cast<u32*>(dst + c) = 0u;
       continue;
     }
     const char* src = reinterpret_cast<const char*>(C.src) + tile_base * (i64)C.width;
     const u32 bytes = (u32)tile_rows * C.width;
     if (full && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-      for (u32 c = (u32)t * 16u; c < bytes; c += VM_WG_THREADS * 16u) {
+      // 1 KiB per wave instruction, LDS destination = wave-uniform base + lane * 16
+      for (u32 c = (u32)lane * 16u; c < bytes; c += 64u * 16u) {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + c),
-            (__attribute__((address_space(3))) void*)(smem + C.lds_off + c), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(dst + c), 16, 0, 0);
       }
     } else {
       // tail tile or unaligned view: element-wise, rows past the end read as 0
       const i64 remain = P.n_rows - tile_base;
       if (C.width == 8) {
-        for (int r = t; r < tile_rows; r += VM_WG_THREADS)
-          reinterpret_cast<u64*>(smem + C.lds_off)[r] = r < remain ? reinterpret_cast<const u64*>(src)[r] : 0ull;
+        for (int r = lane; r < tile_rows; r += 64)
+          reinterpret_cast<u64*>(dst)[r] = r < remain ? reinterpret_cast<const u64*>(src)[r] : 0ull;
       } else if (C.width == 4) {
-        for (int r = t; r < tile_rows; r += VM_WG_THREADS)
-          reinterpret_cast<u32*>(smem + C.lds_off)[r] = r < remain ? reinterpret_cast<const u32*>(src)[r] : 0u;
+        for (int r = lane; r < tile_rows; r += 64)
+          reinterpret_cast<u32*>(dst)[r] = r < remain ? reinterpret_cast<const u32*>(src)[r] : 0u;
       } else {
-        for (int r = t; r < tile_rows; r += VM_WG_THREADS)
-          reinterpret_cast<u8*>(smem + C.lds_off)[r] = r < remain ? reinterpret_cast<const u8*>(src)[r] : (u8)0;
+        for (int r = lane; r < tile_rows; r += 64)
+          reinterpret_cast<u8*>(dst)[r] = r < remain ? reinterpret_cast<const u8*>(src)[r] : (u8)0;
       }
     }
   }
@@ -203,7 +210,10 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
 // Keeps LLVM's speculative-execution / hoisting passes from lifting every case's
 // LDS loads above the switch (which costs >250 VGPRs and all the occupancy).
 #define CASE_FENCE asm volatile("" ::: "memory")
-#define FOR_PAIRS for (int k = 0, p = tp; k < K; ++k, p += VM_WG_THREADS)
+// Workgroup barrier used INSIDE handlers.  The loader wave executes one bare s_barrier for
+// each of these (VmParams.n_sync_per_tile), so the counts must stay in step.
+#define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define FOR_PAIRS for (int k = 0, p = tp; k < K; ++k, p += VM_COMPUTE_THREADS)
 
 #define BINOP(OPNAME, TA, TB, TD, EXPR)                                        \
   case VM_##OPNAME: { CASE_FENCE;                                              \
@@ -228,73 +238,21 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
     }                                                                          \
   } break;
 
-// integer aggregate (sum / min / max) on u64 accumulators.
-//   LOADT: register element type, CONV: element -> u64 accumulator domain,
-//   IDENT: identity, COMB(x, y): combine.
-#define AGG_INT(OPNAME, LOADT, CONV, IDENT, COMB)                              \
-  case VM_##OPNAME: { CASE_FENCE;                                              \
-    u64 local = (IDENT); u32 cnt = 0;                                          \
-    _Pragma("unroll") FOR_PAIRS {                                              \
-      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);              \
-      auto vv = lds_load2<LOADT>(I.a, p);                                      \
-      { LOADT e = vv.x; u64 x = local, y = m.x ? (u64)(CONV) : (u64)(IDENT); local = (COMB); } \
-      { LOADT e = vv.y; u64 x = local, y = m.y ? (u64)(CONV) : (u64)(IDENT); local = (COMB); } \
-      cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));      \
-    }                                                                          \
-    u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(COMB); });\
-    if (lane == 0 && cnt) {                                                    \
-      VmAccRec* A = acc_rec(P, I.dst, wave);                                   \
-      u64 x = A->cnt ? A->v0 : (u64)(IDENT), y = tot;                          \
-      A->v0 = (COMB); A->cnt += cnt;                                           \
-    }                                                                          \
-  } break;
-
-// floating MIN / MAX: "val < result" / "result < val" replaces, so NaN never
-// replaces (aggregation_operators.h:189-228).  Accumulate as doubles.
-#define AGG_FLT(OPNAME, LOADT, IDENT, BETTER)                                  \
-  case VM_##OPNAME: { CASE_FENCE;                                              \
-    double local = (IDENT); u32 cnt = 0;                                       \
-    _Pragma("unroll") FOR_PAIRS {                                              \
-      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);              \
-      auto vv = lds_load2<LOADT>(I.a, p);                                      \
-      { double x = local, y = (double)vv.x; if (m.x && (BETTER)) local = y; }  \
-      { double x = local, y = (double)vv.y; if (m.y && (BETTER)) local = y; }  \
-      cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));      \
-    }                                                                          \
-    u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {                 \
-      double x = u2d(xa), y = u2d(ya); return (BETTER) ? ya : xa; });          \
-    if (lane == 0 && cnt) {                                                    \
-      VmAccRec* A = acc_rec(P, I.dst, wave);                                   \
-      double x = A->cnt ? u2d(A->v0) : (double)(IDENT), y = u2d(tot);          \
-      A->v0 = d2u((BETTER) ? y : x); A->cnt += cnt;                            \
-    }                                                                          \
-  } break;
-
-// FIRST / LAST: value at the smallest / largest contributing global row id.
-#define AGG_POS(OPNAME, LOADT, IDENTROW, BETTERROW)                            \
-  case VM_##OPNAME: { CASE_FENCE;                                              \
-    u64 brow = (IDENTROW), bval = 0; u32 cnt = 0;                              \
-    _Pragma("unroll") FOR_PAIRS {                                              \
-      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);              \
-      auto vv = lds_load2<LOADT>(I.a, p);                                      \
-      u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);                  \
-      { u64 x = brow, y = r0;     if (m.x && (BETTERROW)) { brow = y; bval = (u64)vv.x; } } \
-      { u64 x = brow, y = r0 + 1; if (m.y && (BETTERROW)) { brow = y; bval = (u64)vv.y; } } \
-      cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));      \
-    }                                                                          \
-    u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return (BETTERROW) ? y : x; }); \
-    u64 owner = __ballot(brow == trow && cnt != 0);                            \
-    if (cnt) {                                                                 \
-      int src = __ffsll((long long)owner) - 1;                                 \
-      u64 tval = readlane64(bval, src);                                        \
-      if (lane == 0) {                                                         \
-        VmAccRec* A = acc_rec(P, I.dst, wave);                                 \
-        u64 x = A->cnt ? A->v1 : (u64)(IDENTROW), y = trow;                    \
-        if (BETTERROW) { A->v1 = trow; A->v0 = tval; }                         \
-        A->cnt += cnt;                                                         \
-      }                                                                        \
-    }                                                                          \
-  } break;
+// ---------------------------------------------------------------------------
+// scalar aggregates.  The first VM_FAST_SLOTS slots keep PER-LANE accumulators in
+// registers for the whole kernel (f0/f1/fc, statically indexed through a uniform switch on
+// the slot): per tile an aggregate costs a compare-select-combine per row and no cross-lane
+// traffic; the wave reduction happens once, at the end of the kernel.  Further slots fall
+// back to a per-tile wave reduction into LDS records.
+// ---------------------------------------------------------------------------
+#define SLOT_SWITCH(FAST, SLOW)                                                \
+  switch (I.dst) {                                                             \
+    case 0: { FAST(0) } break; case 1: { FAST(1) } break;                      \
+    case 2: { FAST(2) } break; case 3: { FAST(3) } break;                      \
+    case 4: { FAST(4) } break; case 5: { FAST(5) } break;                      \
+    case 6: { FAST(6) } break; case 7: { FAST(7) } break;                      \
+    default: { SLOW } break;                                                   \
+  }
 
 #define STORE_OP(OPNAME, T)                                                    \
   case VM_##OPNAME: { CASE_FENCE;                                              \
@@ -363,35 +321,72 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
 // ---------------------------------------------------------------------------
 // the pipeline kernel: persistent workgroups stride over tiles
 // ---------------------------------------------------------------------------
+// Execution shape: VM_WAVES (4) compute waves + ONE loader wave per workgroup.  The loader
+// issues the LDS-DMA for tile i+1 into the other input buffer while the compute waves run
+// the program over tile i, so HBM requests are in flight continuously (a single-buffered
+// load -> wait -> compute cycle leaves the DMA latency exposed on every tile).  Only the
+// loader ever has VMEM loads outstanding, which also keeps the compiler's conservative
+// "LDS-DMA may alias this ds_read" vmcnt(0) waits out of the compute waves.
+// One s_barrier per tile: the loader arrives after its DMA for the NEXT tile has landed
+// (s_waitcnt vmcnt(0)), the compute waves arrive when they are done with the CURRENT one.
 template <int K>
-__global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const VmParams P) {
+__global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmParams P) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int tile_rows = 512 * K;
+  const int n_my_tiles = P.n_tiles > (int)blockIdx.x ? (P.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
 
-  // zero this workgroup's aggregate accumulators
-  for (u32 o = (u32)t * 8u; o < (u32)P.n_slots * VM_ACC_STRIDE; o += VM_WG_THREADS * 8u)
+  if (wave == VM_WAVES) {
+    // ------------------------------ loader wave ------------------------------
+    if (n_my_tiles > 0) stage_tile(P, (i64)blockIdx.x * tile_rows, tile_rows, lane, 0u);
+    for (int it = 0; it < n_my_tiles; ++it) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile `it` is in LDS
+      if (it + 1 < n_my_tiles) {
+        const int tile = (int)blockIdx.x + (it + 1) * (int)gridDim.x;
+        stage_tile(P, (i64)tile * tile_rows, tile_rows, lane, ((it + 1) & 1) ? P.in_lds_bytes : 0u);
+      }
+      for (int i = 0; i < P.n_sync_per_tile; ++i) asm volatile("s_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // final rendezvous
+    return;
+  }
+
+  // ------------------------------ compute waves ------------------------------
+  // zero this workgroup's LDS aggregate records (slow slots; fast slots are written once)
+  for (u32 o = (u32)t * 8u; o < (u32)P.n_slots * VM_ACC_STRIDE; o += VM_COMPUTE_THREADS * 8u)
     *reinterpret_cast<u64*>(smem + P.acc_lds_off + o) = 0ull;
+  // per-lane register accumulators of the first VM_FAST_SLOTS aggregate slots
+  u64 f0[VM_FAST_SLOTS], f1[VM_FAST_SLOTS]; u32 fc[VM_FAST_SLOTS];
+#pragma unroll
+  for (int s = 0; s < VM_FAST_SLOTS; ++s) { f0[s] = P.slot_init0[s]; f1[s] = P.slot_init1[s]; fc[s] = 0; }
 
-  for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+  typedef u64 u64x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) u64x4* ProgPtr;
+  const ProgPtr prog = (ProgPtr)(P.prog);
+
+  u64 dbg_wait = 0;
+  const u64 dbg_t0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
+  for (int it = 0; it < n_my_tiles; ++it) {
+    const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const i64 tile_base = (i64)tile * tile_rows;
-    __syncthreads();  // previous tile's readers are done with LDS
-    stage_tile(P, tile_base, tile_rows, t);
-    __syncthreads();  // carries vmcnt(0): DMA'd data visible to the whole workgroup
+    const u32 bufbase = (it & 1) ? P.in_lds_bytes : 0u;
+    const u64 tw0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile landed; previous tile fully consumed
+    if (P.debug) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
 
     // The program is immutable for the launch: fetch it through the constant address
-    // space so every instruction is ONE scalar s_load_dwordx8 (a vector global_load +
-    // v_readfirstlane round trip per instruction cost ~35% of the kernel), and fetch the
-    // next instruction while the current one executes.
-    typedef u64 u64x4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(4))) u64x4* ProgPtr;
-    const ProgPtr prog = (ProgPtr)(P.prog);
+    // space so every instruction is ONE scalar s_load_dwordx8, and fetch the next
+    // instruction while the current one executes.
     u64x4 raw_next = prog[0];
     for (int pc = 0; pc < P.n_instr; ++pc) {
       VmInstr I;
+      if (P.flags & 1u) raw_next = prog[pc];   // experiment: no prefetch
       __builtin_memcpy(&I, &raw_next, sizeof(I));
-      raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
+      if (!(P.flags & 1u)) raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
+      // operands in the input region are relative to the current input buffer (bit 31)
+      I.dst = vm_resolve(I.dst, bufbase); I.a = vm_resolve(I.a, bufbase); I.b = vm_resolve(I.b, bufbase);
+      I.c = vm_resolve(I.c, bufbase); I.d = vm_resolve(I.d, bufbase);
       // launder the thread id once per instruction: without this LICM hoists every
       // case's (t * width) address chain into the prologue (255 VGPRs, occupancy 1)
       int tp = t;
@@ -524,7 +519,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
         // VM_NONE when the side is not nullable.  dst = value, c = null out.
         case VM_AND3:
         case VM_OR3: { CASE_FENCE;
-          const u32 an_off = (u32)I.imm, bn_off = (u32)(I.imm >> 32);
+          const u32 an_off = vm_resolve((u32)I.imm, bufbase), bn_off = vm_resolve((u32)(I.imm >> 32), bufbase);
           const bool is_and = I.op == VM_AND3;
           _Pragma("unroll") FOR_PAIRS {
             auto va = lds_load2<u8>(I.a, p); auto vb = lds_load2<u8>(I.b, p);
@@ -603,60 +598,759 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
 
         // ---- scalar aggregate sinks -------------------------------------------
         case VM_AGG_COUNT: { CASE_FENCE;
-          u32 cnt = 0;
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
           }
+#define SLOW_                                                                  \
+          u32 cnt = 0;                                                         \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
           if (lane == 0) { VmAccRec* A = acc_rec(P, I.dst, wave); A->v0 += cnt; A->cnt += cnt; }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
         } break;
-        AGG_INT(AGG_SUM_I32, i32, (i64)e, 0ull, x + y)
-        AGG_INT(AGG_SUM_U32, u32, e, 0ull, x + y)
-        AGG_INT(AGG_SUM_I64, u64, e, 0ull, x + y)
-        AGG_INT(AGG_MIN_I32, i32, key_i64((i64)e), ~0ull, (x < y ? x : y))
-        AGG_INT(AGG_MIN_U32, u32, e, ~0ull, (x < y ? x : y))
-        AGG_INT(AGG_MIN_I64, i64, key_i64(e), ~0ull, (x < y ? x : y))
-        AGG_INT(AGG_MIN_U64, u64, e, ~0ull, (x < y ? x : y))
-        AGG_INT(AGG_MIN_B8, u8, (e != 0), ~0ull, (x < y ? x : y))
-        AGG_INT(AGG_MAX_I32, i32, key_i64((i64)e), 0ull, (x > y ? x : y))
-        AGG_INT(AGG_MAX_U32, u32, e, 0ull, (x > y ? x : y))
-        AGG_INT(AGG_MAX_I64, i64, key_i64(e), 0ull, (x > y ? x : y))
-        AGG_INT(AGG_MAX_U64, u64, e, 0ull, (x > y ? x : y))
-        AGG_INT(AGG_MAX_B8, u8, (e != 0), 0ull, (x > y ? x : y))
-        AGG_FLT(AGG_MIN_F32, float, __builtin_inf(), (y < x))
-        AGG_FLT(AGG_MIN_F64, double, __builtin_inf(), (y < x))
-        AGG_FLT(AGG_MAX_F32, float, -__builtin_inf(), (x < y))
-        AGG_FLT(AGG_MAX_F64, double, -__builtin_inf(), (x < y))
+        case VM_AGG_SUM_I32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i32>(I.a, p);                              \
+            { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((i64)e) : (u64)(0ull); f0[S] = (x + y); } \
+            { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((i64)e) : (u64)(0ull); f0[S] = (x + y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i32>(I.a, p);                              \
+            { i32 e = vv.x; u64 x = local, y = m.x ? (u64)((i64)e) : (u64)(0ull); local = (x + y); } \
+            { i32 e = vv.y; u64 x = local, y = m.y ? (u64)((i64)e) : (u64)(0ull); local = (x + y); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = (x + y); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_SUM_U32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
+            { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); } \
+            { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = (x + y); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_SUM_I64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
+            { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); } \
+            { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = (x + y); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_I32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i32>(I.a, p);                              \
+            { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (~0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i32>(I.a, p);                              \
+            { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
+            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_U32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (~0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
+            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_I64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i64>(I.a, p);                              \
+            { i64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            { i64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (~0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i64>(I.a, p);                              \
+            { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
+            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_U64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (~0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
+            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_B8: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            { u8 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((e != 0)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            { u8 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((e != 0)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (~0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
+            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_I32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i32>(I.a, p);                              \
+            { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i32>(I.a, p);                              \
+            { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_U32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_I64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i64>(I.a, p);                              \
+            { i64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            { i64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<i64>(I.a, p);                              \
+            { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_U64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_B8: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            { u8 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((e != 0)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            { u8 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((e != 0)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 local = (0ull); u32 cnt = 0;                                  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
+            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_F32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<float>(I.a, p);                              \
+            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((y < x))) f0[S] = d2u(y); } \
+            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((y < x))) f0[S] = d2u(y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          double local = (__builtin_inf()); u32 cnt = 0;                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<float>(I.a, p);                              \
+            { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; } \
+            { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
+            double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });  \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);  \
+            A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;                    \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MIN_F64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<double>(I.a, p);                              \
+            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((y < x))) f0[S] = d2u(y); } \
+            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((y < x))) f0[S] = d2u(y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          double local = (__builtin_inf()); u32 cnt = 0;                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<double>(I.a, p);                              \
+            { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; } \
+            { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
+            double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });  \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);  \
+            A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;                    \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_F32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<float>(I.a, p);                              \
+            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((x < y))) f0[S] = d2u(y); } \
+            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((x < y))) f0[S] = d2u(y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          double local = (-__builtin_inf()); u32 cnt = 0;                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<float>(I.a, p);                              \
+            { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; } \
+            { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
+            double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });  \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);  \
+            A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;                    \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_MAX_F64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<double>(I.a, p);                              \
+            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((x < y))) f0[S] = d2u(y); } \
+            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((x < y))) f0[S] = d2u(y); } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          double local = (-__builtin_inf()); u32 cnt = 0;                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<double>(I.a, p);                              \
+            { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; } \
+            { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
+            double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });  \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);  \
+            A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;                    \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
         case VM_AGG_SUM_F32:
         case VM_AGG_SUM_F64: { CASE_FENCE;
           // compensated (double-double) sum: bit-identical to the reference's
           // sequential fold whenever every partial sum is exact, and within 1 ULP of
           // the exact sum otherwise (the sequential fold itself is not).
-          DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;
           const bool f32 = I.op == VM_AGG_SUM_F32;
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);
-            double e0, e1;
-            if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; }
+#define LOAD_E_                                                                \
+            double e0, e1;                                                     \
+            if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; } \
             else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
-            if (m.x) local = dd_add_d(local, e0);
-            if (m.y) local = dd_add_d(local, e1);
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+#define FAST_(S)                                                               \
+          DD local; local.hi = u2d(f0[S]); local.lo = u2d(f1[S]);              \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            LOAD_E_                                                            \
+            if (m.x) local = dd_add_d(local, e0);                              \
+            if (m.y) local = dd_add_d(local, e1);                              \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }                                                                    \
+          f0[S] = d2u(local.hi); f1[S] = d2u(local.lo);
+#define SLOW_                                                                  \
+          DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;              \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            LOAD_E_                                                            \
+            if (m.x) local = dd_add_d(local, e0);                              \
+            if (m.y) local = dd_add_d(local, e1);                              \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          DD tot = wave_reduce_dd(local);                                      \
+          if (lane == 0 && cnt) {                                              \
+            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
+            DD cur; cur.hi = A->cnt ? u2d(A->v0) : -0.0; cur.lo = A->cnt ? u2d(A->v1) : 0.0; \
+            cur = dd_add(cur, tot);                                            \
+            A->v0 = d2u(cur.hi); A->v1 = d2u(cur.lo); A->cnt += cnt;           \
           }
-          DD tot = wave_reduce_dd(local);
-          if (lane == 0 && cnt) {
-            VmAccRec* A = acc_rec(P, I.dst, wave);
-            DD cur; cur.hi = A->cnt ? u2d(A->v0) : -0.0; cur.lo = A->cnt ? u2d(A->v1) : 0.0;
-            cur = dd_add(cur, tot);
-            A->v0 = d2u(cur.hi); A->v1 = d2u(cur.lo); A->cnt += cnt;
-          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+#undef LOAD_E_
         } break;
-        AGG_POS(AGG_FIRST_8, u8, ~0ull, (y < x))
-        AGG_POS(AGG_FIRST_32, u32, ~0ull, (y < x))
-        AGG_POS(AGG_FIRST_64, u64, ~0ull, (y < x))
-        AGG_POS(AGG_LAST_8, u8, 0ull, (y >= x))
-        AGG_POS(AGG_LAST_32, u32, 0ull, (y >= x))
-        AGG_POS(AGG_LAST_64, u64, 0ull, (y >= x))
+        case VM_AGG_FIRST_8: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
+            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
+            { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; }); \
+          u64 owner = __ballot(brow == trow);                                  \
+          if (cnt) {                                                           \
+            int src = __ffsll((long long)owner) - 1;                           \
+            u64 tval = readlane64(bval, src);                                  \
+            if (lane == 0) {                                                   \
+              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
+              u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;            \
+              if ((y < x)) { A->v1 = trow; A->v0 = tval; }                   \
+              A->cnt += cnt;                                                   \
+            }                                                                  \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_FIRST_32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
+            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
+            { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; }); \
+          u64 owner = __ballot(brow == trow);                                  \
+          if (cnt) {                                                           \
+            int src = __ffsll((long long)owner) - 1;                           \
+            u64 tval = readlane64(bval, src);                                  \
+            if (lane == 0) {                                                   \
+              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
+              u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;            \
+              if ((y < x)) { A->v1 = trow; A->v0 = tval; }                   \
+              A->cnt += cnt;                                                   \
+            }                                                                  \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_FIRST_64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
+            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
+            { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; }); \
+          u64 owner = __ballot(brow == trow);                                  \
+          if (cnt) {                                                           \
+            int src = __ffsll((long long)owner) - 1;                           \
+            u64 tval = readlane64(bval, src);                                  \
+            if (lane == 0) {                                                   \
+              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
+              u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;            \
+              if ((y < x)) { A->v1 = trow; A->v0 = tval; }                   \
+              A->cnt += cnt;                                                   \
+            }                                                                  \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_LAST_8: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
+            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u8>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
+            { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; }); \
+          u64 owner = __ballot(brow == trow);                                  \
+          if (cnt) {                                                           \
+            int src = __ffsll((long long)owner) - 1;                           \
+            u64 tval = readlane64(bval, src);                                  \
+            if (lane == 0) {                                                   \
+              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
+              u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;            \
+              if ((y >= x)) { A->v1 = trow; A->v0 = tval; }                   \
+              A->cnt += cnt;                                                   \
+            }                                                                  \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_LAST_32: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
+            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u32>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
+            { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; }); \
+          u64 owner = __ballot(brow == trow);                                  \
+          if (cnt) {                                                           \
+            int src = __ffsll((long long)owner) - 1;                           \
+            u64 tval = readlane64(bval, src);                                  \
+            if (lane == 0) {                                                   \
+              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
+              u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;            \
+              if ((y >= x)) { A->v1 = trow; A->v0 = tval; }                   \
+              A->cnt += cnt;                                                   \
+            }                                                                  \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
+        case VM_AGG_LAST_64: { CASE_FENCE;
+#define FAST_(S)                                                               \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
+            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
+            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          }
+#define SLOW_                                                                  \
+          u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            auto vv = lds_load2<u64>(I.a, p);                              \
+            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
+            { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
+            { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } } \
+            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
+          }                                                                    \
+          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; }); \
+          u64 owner = __ballot(brow == trow);                                  \
+          if (cnt) {                                                           \
+            int src = __ffsll((long long)owner) - 1;                           \
+            u64 tval = readlane64(bval, src);                                  \
+            if (lane == 0) {                                                   \
+              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
+              u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;            \
+              if ((y >= x)) { A->v1 = trow; A->v0 = tval; }                   \
+              A->cnt += cnt;                                                   \
+            }                                                                  \
+          }
+          SLOT_SWITCH(FAST_, SLOW_)
+#undef FAST_
+#undef SLOW_
+        } break;
 
         // ---- materialising sinks ----------------------------------------------
         case VM_SEL_COUNT: { CASE_FENCE;
@@ -667,9 +1361,9 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           }
           u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
           if (lane == 0) scratch[wave] = cnt;
-          __syncthreads();
+          WG_BARRIER();
           if (t == 0) P.tile_counts[tile] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-          __syncthreads();
+          WG_BARRIER();
         } break;
         case VM_SEL_RANK: { CASE_FENCE;
           // order-preserving ranks: rows are ordered (k, wave, lane, j)
@@ -679,7 +1373,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
             u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
             if (lane == 0) scratch[k * VM_WAVES + wave] = c;
           }
-          __syncthreads();
+          WG_BARRIER();
           u32 base = P.tile_offsets[tile];
           const u64 lt = (1ull << lane) - 1ull;
           _Pragma("unroll") FOR_PAIRS {
@@ -691,7 +1385,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
             u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
             lds_store2<u32>(I.dst, p, r0, r0 + (m.x ? 1u : 0u));
           }
-          __syncthreads();
+          WG_BARRIER();
         } break;
         STORE_OP(STORE_8, u8)
         STORE_OP(STORE_32, u32)
@@ -762,18 +1456,51 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     }
   }
 
-  // publish this workgroup's partial aggregates (wave order, deterministic)
-  if (P.n_slots > 0) {
-    __syncthreads();
-    for (int s = t; s < P.n_slots; s += VM_WG_THREADS) {
-      VmAccRec out; out.v0 = 0; out.v1 = 0; out.cnt = 0; out.pad = 0;
-      // the combine rule is applied by the finish kernel; here we only forward
-      // the four wave records in wave order
-      for (int w = 0; w < VM_WAVES; ++w)
-        P.wg_partials[((size_t)blockIdx.x * P.n_slots + s) * VM_WAVES + w] = *acc_rec(P, (u32)s, w);
-      (void)out;
+  if (P.debug && t == 0) {
+    P.debug[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    P.debug[blockIdx.x * 4 + 1] = dbg_wait;
+    P.debug[blockIdx.x * 4 + 2] = (u64)n_my_tiles;
+  }
+  // fold the per-lane register accumulators of the fast slots: one wave reduction per slot
+  // for the whole kernel, written to the wave's LDS record
+#pragma unroll
+  for (int s = 0; s < VM_FAST_SLOTS; ++s) {
+    if (s < P.n_slots) {
+      const int kind = P.slot_kind[s];
+      const u64 cnt = wave_reduce_u64((u64)fc[s], [](u64 x, u64 y) { return x + y; });
+      u64 v0 = 0, v1 = 0;
+      switch (kind) {
+        case SLOT_COUNT: v0 = cnt; break;
+        case SLOT_SUM_INT: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return x + y; }); break;
+        case SLOT_MIN_U64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return x < y ? x : y; }); break;
+        case SLOT_MAX_U64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return x > y ? x : y; }); break;
+        case SLOT_MIN_F64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return u2d(y) < u2d(x) ? y : x; }); break;
+        case SLOT_MAX_F64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return u2d(x) < u2d(y) ? y : x; }); break;
+        case SLOT_SUM_DD: {
+          DD d; d.hi = u2d(f0[s]); d.lo = u2d(f1[s]);
+          d = wave_reduce_dd(d); v0 = d2u(d.hi); v1 = d2u(d.lo);
+        } break;
+        case SLOT_FIRST: case SLOT_LAST: {
+          // lanes without a contribution hold the identity row, which never wins
+          const bool first = kind == SLOT_FIRST;
+          const u64 trow = first ? wave_reduce_u64(f1[s], [](u64 x, u64 y) { return x < y ? x : y; })
+                                 : wave_reduce_u64(fc[s] ? f1[s] : 0ull, [](u64 x, u64 y) { return x > y ? x : y; });
+          const u64 owner = __ballot(fc[s] != 0 && f1[s] == trow);
+          const int src = owner ? __ffsll((long long)owner) - 1 : 0;
+          v0 = readlane64(f0[s], src); v1 = trow;
+        } break;
+        default: break;
+      }
+      if (lane == 0) { VmAccRec* A = acc_rec(P, (u32)s, wave); A->v0 = v0; A->v1 = v1; A->cnt = cnt; A->pad = 0; }
     }
   }
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // final rendezvous (with the loader)
+  // publish this workgroup's partial aggregates: the four wave records in wave order; the
+  // combine rule is applied by the finish kernel (fixed shape -> reproducible)
+  for (int s = t; s < P.n_slots; s += VM_COMPUTE_THREADS)
+    for (int w = 0; w < VM_WAVES; ++w)
+      P.wg_partials[((size_t)blockIdx.x * P.n_slots + s) * VM_WAVES + w] = *acc_rec(P, (u32)s, w);
 }
 
 // ---------------------------------------------------------------------------
@@ -1027,7 +1754,7 @@ __global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __
 // host-callable launchers (C++ linkage inside the library)
 // ---------------------------------------------------------------------------
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream) {
-  dim3 g(grid), b(VM_WG_THREADS);
+  dim3 g(grid), b(VM_WG_THREADS);  // 4 compute waves + 1 loader wave
   size_t lds = P.lds_bytes;
   switch (K) {
     case 1: hipLaunchKernelGGL(ssgpu_pipeline_kernel<1>, g, b, lds, stream, P); break;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <stdio.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -35,6 +36,8 @@ struct ssgpu_ctx {
   int64_t grid_limit = 0;        // 0 = CUs * residency
   int64_t group_capacity = 1 << 18;
   int64_t profile = 1;           // record HIP events around kernels
+  int64_t debug_timing = 0;
+  int64_t kernel_flags = 0;      // in-kernel cycle counters (development aid)
 };
 
 struct DevBuf {
@@ -83,6 +86,7 @@ struct StageExec {
   DevBuf gkeys, gfirst, gacc, gcnt, goverflow, gpattern, gout_first;
   uint32_t capacity = 0;
   DevBuf error_flag;
+  DevBuf debug;
   bool emit_ready = false;
   bool pattern_ready = false;
   // outputs
@@ -188,6 +192,8 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
   } else if (k == "profile") c->profile = value;
+  else if (k == "debug_timing") c->debug_timing = value;
+  else if (k == "kernel_flags") c->kernel_flags = value;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
 }
@@ -367,6 +373,8 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->acc_lds_off = L.acc_off;
   P->scratch_lds_off = L.scratch_off;
   P->lds_bytes = L.lds_bytes;
+  P->in_lds_bytes = L.in_lds_bytes;
+  P->n_sync_per_tile = prog.n_sync_per_tile;
   for (size_t i = 0; i < prog.staged.size(); ++i) {
     const StagedInput& s = prog.staged[i];
     P->staged[i].src = s.is_null_mask ? (const void*)in.cols[s.col].is_null : in.cols[s.col].data;
@@ -388,10 +396,30 @@ int ensure_out_cols(ssgpu_ctx* c, const Stage& st, StageExec& ex, int64_t rows) 
   return SSGPU_OK;
 }
 
+// per-lane identities of the register-resident (fast) aggregate slots
+void fill_fast_slots(VmParams* P, const Stage& st) {
+  for (size_t i = 0; i < st.aggs.size() && i < VM_FAST_SLOTS; ++i) {
+    const int kind = st.aggs[i].slot_kind;
+    uint64_t i0 = 0, i1 = 0;
+    const double pinf = __builtin_inf(), ninf = -__builtin_inf(), nzero = -0.0;
+    switch (kind) {
+      case SLOT_SUM_DD: memcpy(&i0, &nzero, 8); break;            // -0.0 is the identity of IEEE +
+      case SLOT_MIN_U64: i0 = ~0ull; break;
+      case SLOT_MIN_F64: memcpy(&i0, &pinf, 8); break;
+      case SLOT_MAX_F64: memcpy(&i0, &ninf, 8); break;
+      case SLOT_FIRST: i1 = ~0ull; break;
+      default: break;
+    }
+    P->slot_init0[i] = i0; P->slot_init1[i] = i1; P->slot_kind[i] = kind;
+  }
+}
+
 int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base, bool stop_at_partial) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+  fill_fast_slots(&P, st);
+  P.flags = (uint32_t)c->kernel_flags;
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   ex.grid = grid;
   const int ns = st.main.n_slots;
@@ -405,6 +433,10 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
   }
   P.wg_partials = ex.wg_partials.as<VmAccRec>();
   P.error_flag = ex.error_flag.as<unsigned int>();
+  if (c->debug_timing) {
+    HIP_TRY(c, ex.debug.ensure((size_t)grid * 4 * 8));
+    P.debug = ex.debug.as<unsigned long long>();
+  }
   HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
   HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
@@ -413,6 +445,14 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
                                        ex.slot_recs.as<VmAccRec>(), c->stream));
   p->counters.n_launches += 2;
   p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
+  if (c->debug_timing) {
+    std::vector<unsigned long long> dbg((size_t)grid * 4);
+    HIP_TRY(c, hipMemcpy(dbg.data(), ex.debug.p, dbg.size() * 8, hipMemcpyDeviceToHost));
+    double tot = 0, wait = 0, tiles = 0;
+    for (int g = 0; g < grid; ++g) { tot += (double)dbg[g * 4]; wait += (double)dbg[g * 4 + 1]; tiles += (double)dbg[g * 4 + 2]; }
+    fprintf(stderr, "[ssgpu debug] grid=%d tiles/wg=%.1f cycles/wg=%.0f wait=%.1f%% cycles/tile=%.0f (wait %.0f)\n", grid, tiles / grid,
+            tot / grid, 100.0 * wait / tot, tot / tiles, wait / tiles);
+  }
   if (stop_at_partial) {
     HIP_TRY(c, ssgpu_launch_slots_to_state(ex.slot_recs.as<VmAccRec>(), ns, ex.slot_kind.as<int>(), ex.state.as<uint64_t>(), c->stream));
     p->counters.n_launches += 1;

@@ -22,9 +22,11 @@
 #include <stdint.h>
 
 #define VM_NONE 0xFFFFFFFFu
-#define VM_WG_THREADS 256
-#define VM_WAVES 4
-#define VM_MAX_STAGED 64
+#define VM_COMPUTE_THREADS 256
+#define VM_WAVES 4          /* compute waves per workgroup */
+#define VM_WG_THREADS 320   /* + one loader wave */
+#define VM_FAST_SLOTS 8     /* aggregate slots with per-lane register accumulators */
+#define VM_MAX_STAGED 48
 #define VM_MAX_OUTPUTS 64
 #define VM_MAX_AGG_SLOTS 64
 #define VM_ACC_STRIDE 128 /* bytes of LDS per aggregate slot: 4 waves x 32 B */
@@ -163,11 +165,17 @@ struct VmParams {
   uint32_t acc_lds_off;   /* LDS offset of the aggregate accumulators */
   uint32_t scratch_lds_off; /* LDS offset of 256 B of scan scratch */
   uint32_t lds_bytes;
-  uint32_t flags;
+  uint32_t in_lds_bytes;      /* bytes of ONE input buffer (two are resident) */
+  int32_t n_sync_per_tile;    /* s_barriers executed inside the program per tile */
+  uint32_t flags;             /* experiments */
+  uint64_t slot_init0[VM_FAST_SLOTS]; /* per-lane identities of the fast slots */
+  uint64_t slot_init1[VM_FAST_SLOTS];
+  int32_t slot_kind[VM_FAST_SLOTS];   /* SlotKind of the fast slots */
   VmAccRec* wg_partials;        /* [grid][n_slots] */
   unsigned int* tile_counts;    /* SEL_COUNT output / scanned offsets input */
   const unsigned int* tile_offsets;
   unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
+  unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */
   VmGroupTable group;
   VmStagedCol staged[VM_MAX_STAGED];
   VmOutCol outputs[VM_MAX_OUTPUTS];

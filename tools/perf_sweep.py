@@ -55,7 +55,26 @@ def q_group(v):
     return ss.GroupAggregate(ss.ProjectNamedAttributes(["c"]), spec, None, ss.ScanView(v))
 
 
-QUERIES = {"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
+def q_addn(n):
+    def q(v):
+        e = NA("a")
+        for i in range(n):
+            e = ss.Plus(e, ss.ConstInt64(i + 1))
+        return ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "x", "sx"),
+                                  ss.Compute(ss.CompoundExpression().AddAs("x", e), ss.ScanView(v)))
+    return q
+
+
+def q_sumn(n):
+    def q(v):
+        spec = ss.AggregationSpecification()
+        for i in range(n):
+            spec.AddAggregation(ss.SUM, "a", "s%d" % i)
+        return ss.ScalarAggregate(spec, ss.ScanView(v))
+    return q
+
+
+QUERIES = {"add4": q_addn(4), "add16": q_addn(16), "sum4": q_sumn(4), "sum8": q_sumn(8),"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
            "filter_mat": q_filter_mat, "group": q_group}
 
 
@@ -67,6 +86,8 @@ def main():
     ap.add_argument("--lds", default="49152")
     ap.add_argument("--grids", default="0")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--debug", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cols = bench.gen_device_columns(torch, args.rows, 42, dev)
@@ -80,6 +101,8 @@ def main():
                     ctx.set_option("tile_rows", tile)
                     ctx.set_option("lds_target_bytes", lds)
                     ctx.set_option("grid_limit", grid)
+                    ctx.set_option("debug_timing", args.debug)
+                    ctx.set_option("kernel_flags", args.flags)
                     try:
                         plan = ss.Plan(QUERIES[qn](view), ctx)
                         ms = []
