@@ -86,6 +86,7 @@ struct LReg { uint32_t width; uint32_t row_off; };
 struct LInstr {
   uint16_t op = 0;
   bool a_imm = false, b_imm = false;
+  uint8_t imm_width = 8;    // device width of the immediate operand (1 / 4 / 8)
   bool dst_is_reg = true;   // false: dst is a slot / output-column index
   int dst = -1;
   int a = -1, b = -1, c = -1, d = -1, e = -1;  // register ids, -1 = none
@@ -151,10 +152,11 @@ struct LowerOptions {
 };
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe);
 // choose the tile size (K = tile_rows / 512) and fix LDS offsets for a program
-struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t in_lds_bytes; };
+struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t in_lds_bytes; uint32_t imm_pool_off; };
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt);
-// final device instructions for a tile of `tile_rows`
-void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out);
+// final device instructions for a tile of `tile_rows`: two variants (one per input buffer),
+// each n + 1 instructions (trailing NOP for the prefetch)
+void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmInstr>* out);
 std::string disassemble(const Program& p);
 
 }  // namespace ssgpu

@@ -76,13 +76,13 @@ class Emitter {
     if (!v.imm) return v.reg;
     int r = new_reg(v.width);
     LInstr& i = emit(v.width == 8 ? VM_FILL_64 : v.width == 4 ? VM_FILL_32 : VM_FILL_8);
-    i.dst = r; i.a_imm = true; i.imm = v.bits;
+    i.dst = r; i.a_imm = true; i.imm = v.bits; i.imm_width = (uint8_t)v.width;
     return r;
   }
   int const_null_reg() {
     if (all_null_ < 0) {
       all_null_ = new_reg(1);
-      LInstr& i = emit(VM_FILL_8); i.dst = all_null_; i.a_imm = true; i.imm = 1;
+      LInstr& i = emit(VM_FILL_8); i.dst = all_null_; i.a_imm = true; i.imm = 1; i.imm_width = 1;
     }
     return all_null_;
   }
@@ -100,15 +100,15 @@ class Emitter {
     int r = new_reg(out_width);
     LInstr& i = emit(op);
     i.dst = r;
-    if (a.imm) { i.a_imm = true; i.imm = a.bits; } else i.a = a.reg;
-    if (b.imm) { i.b_imm = true; i.imm = b.bits; } else i.b = b.reg;
+    if (a.imm) { i.a_imm = true; i.imm = a.bits; i.imm_width = (uint8_t)a.width; } else i.a = a.reg;
+    if (b.imm) { i.b_imm = true; i.imm = b.bits; i.imm_width = (uint8_t)b.width; } else i.b = b.reg;
     return r;
   }
   int unop(uint16_t op, Val a, uint32_t out_width) {
     int r = new_reg(out_width);
     LInstr& i = emit(op);
     i.dst = r;
-    if (a.imm) { i.a_imm = true; i.imm = a.bits; } else i.a = a.reg;
+    if (a.imm) { i.a_imm = true; i.imm = a.bits; i.imm_width = (uint8_t)a.width; } else i.a = a.reg;
     return r;
   }
 
@@ -224,11 +224,11 @@ Status Emitter::value(const BExprP& e, Val* out) {
           if (nulling) {
             int r = new_reg(1);
             LInstr& i = emit(zop_null); i.dst = r; i.a = base_null;
-            if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; } else i.b = a[1].reg;
+            if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; i.imm_width = (uint8_t)a[1].width; } else i.b = a[1].reg;
             base_null = r;
           } else if (signaling) {
             LInstr& i = emit(zop_fail); i.dst_is_reg = false; i.dst = 0; i.a = base_null; i.c = sel;
-            if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; } else i.b = a[1].reg;
+            if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; i.imm_width = (uint8_t)a[1].width; } else i.b = a[1].reg;
           }
           v.reg = binop(op, a[0], a[1], v.width);
           v.null = base_null;
@@ -299,11 +299,11 @@ Status Emitter::value(const BExprP& e, Val* out) {
           if (x.imm && y.imm) { x.reg = materialize(x); x.imm = false; }
           v.reg = new_reg(v.width);
           LInstr& i = emit(sop); i.dst = v.reg; i.c = a[0].null;
-          if (x.imm) { i.a_imm = true; i.imm = x.bits; } else i.a = x.reg;
-          if (y.imm) { i.b_imm = true; i.imm = y.bits; } else i.b = y.reg;
+          if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = (uint8_t)x.width; } else i.a = x.reg;
+          if (y.imm) { i.b_imm = true; i.imm = y.bits; i.imm_width = (uint8_t)y.width; } else i.b = y.reg;
           if (a[1].null >= 0) {
             v.null = new_reg(1);
-            LInstr& j = emit(VM_SELECT_8); j.dst = v.null; j.a = a[1].null; j.b_imm = true; j.imm = 0; j.c = a[0].null;
+            LInstr& j = emit(VM_SELECT_8); j.dst = v.null; j.a = a[1].null; j.b_imm = true; j.imm = 0; j.imm_width = 1; j.c = a[0].null;
           }
         } break;
         case OP_IF: {
@@ -313,14 +313,14 @@ Status Emitter::value(const BExprP& e, Val* out) {
           if (x.imm && y.imm) { x.reg = materialize(x); x.imm = false; }
           v.reg = new_reg(v.width);
           LInstr& i = emit(sop); i.dst = v.reg; i.c = cond;
-          if (x.imm) { i.a_imm = true; i.imm = x.bits; } else i.a = x.reg;
-          if (y.imm) { i.b_imm = true; i.imm = y.bits; } else i.b = y.reg;
+          if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = (uint8_t)x.width; } else i.a = x.reg;
+          if (y.imm) { i.b_imm = true; i.imm = y.bits; i.imm_width = (uint8_t)y.width; } else i.b = y.reg;
           int branch_null = -1;
           if (a[1].null >= 0 || a[2].null >= 0) {
             branch_null = new_reg(1);
             LInstr& j = emit(VM_SELECT_8); j.dst = branch_null; j.c = cond;
-            if (a[1].null >= 0) j.a = a[1].null; else { j.a_imm = true; j.imm = 0; }
-            if (a[2].null >= 0) j.b = a[2].null; else { j.b_imm = true; j.imm = 0; }
+            if (a[1].null >= 0) j.a = a[1].null; else { j.a_imm = true; j.imm = 0; j.imm_width = 1; }
+            if (a[2].null >= 0) j.b = a[2].null; else { j.b_imm = true; j.imm = 0; j.imm_width = 1; }
             if (j.a_imm && j.b_imm) { /* unreachable: one side has a mask */ }
           }
           v.null = or_null(a[0].null, branch_null);
@@ -359,46 +359,32 @@ static void allocate_registers(Program* p) {
     for_each_def(p->code[pc], [&](int r) { first[r] = std::min(first[r], pc); last[r] = std::max(last[r], pc); });
     for_each_use(p->code[pc], [&](int r) { last[r] = std::max(last[r], pc); first[r] = std::min(first[r], pc); });
   }
-  // free list of (row_off, width) holes; bump pointer `top`
-  struct Hole { uint32_t off, width; };
-  std::vector<Hole> holes;
-  uint32_t top = 0, peak = 0;
+  // Free lists PER WIDTH CLASS.  Elementwise instructions need no barrier because a thread
+  // only ever touches the bytes of its own row pairs -- which bytes those are depends on the
+  // register width, so a slot may only be recycled by a register of the SAME width (waves are
+  // not in lockstep between instructions: a recycled slot of another width would let one wave
+  // overwrite bytes another wave still has to read).
+  std::map<uint32_t, std::vector<uint32_t>> free_slots;
+  uint32_t top = 0, peak = 0, in_bpr = 0;
   std::vector<bool> placed(n, false);
   auto place = [&](int r) {
     if (placed[r]) return;
     placed[r] = true;
     const uint32_t w = p->regs[r].width;
-    for (size_t h = 0; h < holes.size(); ++h) {
-      if (holes[h].width >= w) {
-        p->regs[r].row_off = holes[h].off;
-        if (holes[h].width > w) { holes[h].off += w; holes[h].width -= w; } else holes.erase(holes.begin() + h);
-        return;
-      }
-    }
+    auto& fl = free_slots[w];
+    if (!fl.empty()) { p->regs[r].row_off = fl.back(); fl.pop_back(); return; }
     p->regs[r].row_off = top; top += w; peak = std::max(peak, top);
   };
-  uint32_t in_bpr = 0;  // end of the input region: registers never straddle it
-  auto release = [&](int r) {
-    Hole h; h.off = p->regs[r].row_off; h.width = p->regs[r].width;
-    // merge with neighbours / the bump pointer, but never across the input-region boundary
-    holes.push_back(h);
-    std::sort(holes.begin(), holes.end(), [](const Hole& x, const Hole& y) { return x.off < y.off; });
-    for (size_t i = 0; i + 1 < holes.size();) {
-      if (holes[i].off + holes[i].width == holes[i + 1].off && holes[i + 1].off != in_bpr) { holes[i].width += holes[i + 1].width; holes.erase(holes.begin() + i + 1); }
-      else ++i;
-    }
-    if (!holes.empty() && holes.back().off + holes.back().width == top && holes.back().off >= in_bpr) { top = holes.back().off; holes.pop_back(); }
-  };
-  // staged registers live from the start (wide ones first for alignment-friendly packing)
+  auto release = [&](int r) { free_slots[p->regs[r].width].push_back(p->regs[r].row_off); };
+  // staged registers live from the start (wide ones first)
   std::vector<int> st;
   for (auto& s : p->staged) st.push_back(s.reg);
-  std::sort(st.begin(), st.end(), [&](int a, int b) { return p->regs[a].width > p->regs[b].width; });
+  std::stable_sort(st.begin(), st.end(), [&](int a, int b) { return p->regs[a].width > p->regs[b].width; });
   for (int r : st) place(r);
   in_bpr = top;
   for (int pc = 0; pc < (int)p->code.size(); ++pc) {
     for_each_def(p->code[pc], [&](int r) { place(r); });
-    // a register whose last use is this instruction is released AFTER the definition was
-    // placed: an instruction never writes a slot it is still reading at another width
+    // a register whose last use is this instruction is released AFTER the definition was placed
     std::vector<int> dead;
     for_each_use(p->code[pc], [&](int r) { if (last[r] == pc) dead.push_back(r); });
     for_each_def(p->code[pc], [&](int r) { if (last[r] == pc) dead.push_back(r); });
@@ -420,7 +406,7 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
     if (acc) *acc = a;
     if (scr) *scr = s;
-    return s + 256u;
+    return s + 256u + 16u * (uint32_t)p.code.size();  // + the immediates' constant pool
   };
   int K = 1;
   if (opt.tile_rows > 0) {
@@ -433,34 +419,41 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   L.K = K;
   L.lds_bytes = lds_for(K, &L.acc_off, &L.scratch_off);
   L.in_lds_bytes = p.in_bytes_per_row * 512u * (uint32_t)K;
+  L.imm_pool_off = L.scratch_off + 256u;
   return L;
 }
 
-void finalize_program(const Program& p, int tile_rows, std::vector<VmInstr>* out) {
+void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmInstr>* out) {
   out->clear();
-  // input-region registers: offset inside ONE input buffer, bit 31 = "add the current buffer
-  // base"; temporaries live behind both input buffers
-  auto off = [&](int r) -> uint32_t {
-    if (r < 0) return VM_NONE;
-    const uint32_t ro = p.regs[r].row_off;
-    if (ro < p.in_bytes_per_row) return (ro * (uint32_t)tile_rows) | 0x80000000u;
-    return (ro + p.in_bytes_per_row) * (uint32_t)tile_rows;
-  };
-  for (const LInstr& i : p.code) {
-    VmInstr v; memset(&v, 0, sizeof(v));
-    v.op = i.op; v.a_imm = i.a_imm; v.b_imm = i.b_imm;
-    v.dst = i.dst_is_reg ? off(i.dst) : (uint32_t)i.dst;
-    v.a = i.a_imm ? VM_NONE : off(i.a);
-    v.b = i.b_imm ? VM_NONE : off(i.b);
-    v.c = off(i.c); v.d = off(i.d);
-    v.imm = i.imm;
-    if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
-    out->push_back(v);
+  const uint32_t T = 512u * (uint32_t)L.K;
+  for (int buf = 0; buf < 2; ++buf) {
+    // input-region registers live in input buffer `buf`; temporaries behind both buffers
+    auto off = [&](int r) -> uint32_t {
+      if (r < 0) return VM_NONE;
+      const uint32_t ro = p.regs[r].row_off;
+      if (ro < p.in_bytes_per_row) return ro * T + (uint32_t)buf * L.in_lds_bytes;
+      return (ro + p.in_bytes_per_row) * T;
+    };
+    for (size_t pc = 0; pc < p.code.size(); ++pc) {
+      const LInstr& i = p.code[pc];
+      VmInstr v; memset(&v, 0, sizeof(v));
+      v.op = i.op;
+      v.a_imm = i.a_imm ? i.imm_width : 0;
+      v.b_imm = i.b_imm ? i.imm_width : 0;
+      v.dst = i.dst_is_reg ? off(i.dst) : (uint32_t)i.dst;
+      const uint32_t pool = L.imm_pool_off + 16u * (uint32_t)pc;  // this instruction's constant
+      v.a = i.a_imm ? pool : off(i.a);
+      v.b = i.b_imm ? pool : off(i.b);
+      v.c = off(i.c); v.d = off(i.d);
+      v.imm = i.imm;
+      if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
+      out->push_back(v);
+    }
+    // one trailing NOP: the kernel prefetches instruction pc + 1
+    VmInstr nop; memset(&nop, 0, sizeof(nop)); nop.op = VM_NOP;
+    nop.dst = nop.a = nop.b = nop.c = nop.d = VM_NONE;
+    out->push_back(nop);
   }
-  // one trailing NOP: the kernel prefetches instruction pc + 1
-  VmInstr nop; memset(&nop, 0, sizeof(nop)); nop.op = VM_NOP;
-  nop.dst = nop.a = nop.b = nop.c = nop.d = VM_NONE;
-  out->push_back(nop);
 }
 
 std::string disassemble(const Program& p) {
@@ -657,10 +650,15 @@ static Status emit_filters(Emitter& em, const Pipe& pipe) {
   for (size_t f = 0; f < pipe.filters.size(); ++f) {
     Val pv;
     SS_RETURN_IF_ERROR(em.value(pipe.filters[f], &pv));
+    if (!pv.imm && pv.null < 0 && em.sel_by_depth.back() < 0) {
+      // first filter, never-NULL predicate: its 0/1 byte vector IS the selection
+      em.sel_by_depth.push_back(pv.reg);
+      continue;
+    }
     int r = em.new_reg(1);
     LInstr& i = em.emit(VM_SEL_FROM_PRED);
     i.dst = r;
-    if (pv.imm) { i.a_imm = true; i.imm = pv.bits; } else i.a = pv.reg;
+    if (pv.imm) { i.a_imm = true; i.imm = pv.bits; i.imm_width = 1; } else i.a = pv.reg;
     i.b = pv.null;
     i.c = em.sel_by_depth.back();
     em.sel_by_depth.push_back(r);
@@ -735,7 +733,7 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
   const int sel = em.sel_by_depth.back();
   // pack the key columns into one 64-bit word (value bits + one NULL flag bit per nullable key)
   int keyreg = em.new_reg(8);
-  { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; }
+  { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
   uint32_t shift = 0;
   for (size_t k = 0; k < kpos.size(); ++k) {
     const BExprP& ke = pipe.cols[kpos[k]].expr;
@@ -824,7 +822,7 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
       const uint16_t op = st->has_filter ? (w == 8 ? VM_STOREC_64 : w == 4 ? VM_STOREC_32 : VM_STOREC_8)
                                          : (w == 8 ? VM_STORE_64 : w == 4 ? VM_STORE_32 : VM_STORE_8);
       LInstr& i = em.emit(op); i.dst_is_reg = false; i.dst = out_index++;
-      if (x.imm) { i.a_imm = true; i.imm = x.bits; } else i.a = x.reg;
+      if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = (uint8_t)x.width; } else i.a = x.reg;
       if (st->has_filter) { i.b = rank; i.c = sel; }
     };
     store(v, v.width);

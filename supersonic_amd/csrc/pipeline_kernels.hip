@@ -43,10 +43,14 @@ template <typename T> __device__ __forceinline__ T imm_as(u64 imm) {
   T v; __builtin_memcpy(&v, &imm, sizeof(T)); return v;
 }
 // Operand fetch: register pair from LDS, or the broadcast immediate.
+// Immediates live in an LDS constant pool (one 16-byte replicated entry per instruction,
+// written once per kernel): an immediate operand is the same pair load with stride 0, so
+// handlers are branch-free and their K loads issue back to back.
 template <typename T>
-__device__ __forceinline__ typename Vec2<T>::type fetch2(u32 off, bool is_imm, u64 imm, int p) {
-  if (is_imm) { typename Vec2<T>::type v; T c = imm_as<T>(imm); v.x = c; v.y = c; return v; }
-  return lds_load2<T>(off, p);
+__device__ __forceinline__ typename Vec2<T>::type fetch2(u32 off, u32 is_imm, u64 imm, int p) {
+  (void)imm;
+  const u32 stride = is_imm ? 0u : (u32)(2u * sizeof(T));
+  return *reinterpret_cast<const typename Vec2<T>::type*>(smem + off + (u32)p * stride);
 }
 
 // ---------------------------------------------------------------------------
@@ -118,10 +122,9 @@ __device__ __forceinline__ i64 unkey_i64(u64 k) { return (i64)(k ^ 0x80000000000
 // row validity for sinks: row exists, passes the selection, value not NULL.
 // ---------------------------------------------------------------------------
 struct Valid2 { bool x, y; };
-__device__ __forceinline__ Valid2 valid_pair(const VmInstr& I, int p, i64 tile_base, i64 n_rows,
-                                             u32 null_off, u32 sel_off) {
-  i64 r0 = tile_base + 2 * (i64)p;
-  Valid2 v; v.x = r0 < n_rows; v.y = (r0 + 1) < n_rows;
+__device__ __forceinline__ Valid2 valid_pair_(int p, u32 tile_valid, u32 null_off, u32 sel_off) {
+  const u32 r0 = 2u * (u32)p;
+  Valid2 v; v.x = r0 < tile_valid; v.y = (r0 + 1u) < tile_valid;
   if (sel_off != VM_NONE) { auto s = lds_load2<u8>(sel_off, p); v.x = v.x && s.x; v.y = v.y && s.y; }
   if (null_off != VM_NONE) { auto z = lds_load2<u8>(null_off, p); v.x = v.x && !z.x; v.y = v.y && !z.y; }
   return v;
@@ -272,7 +275,7 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
   case VM_##OPNAME: { CASE_FENCE;                                              \
     T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
     _Pragma("unroll") FOR_PAIRS {                                              \
-      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.c);          \
+      Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);          \
       auto vv = fetch2<T>(I.a, I.a_imm, I.imm, p);                             \
       auto rk = lds_load2<u32>(I.b, p);                                        \
       if (m.x) out[rk.x] = vv.x;                                               \
@@ -300,7 +303,7 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
 
 // group aggregate by global atomics on acc[slot * n_gaggs + s]
 #define GAGG_PROLOGUE(LOADT)                                                   \
-      Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, VM_NONE);          \
+      Valid2 m = valid_pair_(p, tile_valid, I.b, VM_NONE);          \
       auto sl = lds_load2<u32>(I.c, p);                                        \
       m.x = m.x && sl.x != 0xFFFFFFFFu; m.y = m.y && sl.y != 0xFFFFFFFFu;      \
       auto vv = lds_load2<LOADT>(I.a, p);
@@ -361,16 +364,31 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #pragma unroll
   for (int s = 0; s < VM_FAST_SLOTS; ++s) { f0[s] = P.slot_init0[s]; f1[s] = P.slot_init1[s]; fc[s] = 0; }
 
-  typedef u64 u64x4 __attribute__((ext_vector_type(4)));
-  typedef const __attribute__((address_space(4))) u64x4* ProgPtr;
-  const ProgPtr prog = (ProgPtr)(P.prog);
+  typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+  typedef const __attribute__((address_space(4))) u32x8* ProgPtr;
+  const ProgPtr prog0 = (ProgPtr)(P.prog);
+
+  // immediates -> LDS constant pool (entry pc: the value replicated to 16 bytes by width)
+  for (int pc = t; pc < P.n_instr; pc += VM_COMPUTE_THREADS) {
+    const VmInstr J = P.prog[pc];
+    const u32 w = J.a_imm ? J.a_imm : J.b_imm;
+    if (w) {
+      u64 lo = J.imm;
+      if (w == 4) lo = (lo & 0xFFFFFFFFull) * 0x100000001ull;
+      else if (w == 1) lo = (lo & 0xFFull) * 0x0101010101010101ull;
+      u64* e = reinterpret_cast<u64*>(smem + P.imm_pool_lds_off + (u32)pc * 16u);
+      e[0] = lo; e[1] = lo;
+    }
+  }
 
   u64 dbg_wait = 0;
   const u64 dbg_t0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
   for (int it = 0; it < n_my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const i64 tile_base = (i64)tile * tile_rows;
-    const u32 bufbase = (it & 1) ? P.in_lds_bytes : 0u;
+    const u32 tile_valid = (u32)((P.n_rows - tile_base) < (i64)tile_rows ? (P.n_rows - tile_base) : (i64)tile_rows);
+    // the host finalises the program twice, once per input buffer: no address fix-ups here
+    const ProgPtr prog = prog0 + ((it & 1) ? (P.n_instr + 1) : 0);
     const u64 tw0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile landed; previous tile fully consumed
     if (P.debug) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
@@ -378,15 +396,14 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
     // The program is immutable for the launch: fetch it through the constant address
     // space so every instruction is ONE scalar s_load_dwordx8, and fetch the next
     // instruction while the current one executes.
-    u64x4 raw_next = prog[0];
+    u32x8 raw_next = prog[0];
     for (int pc = 0; pc < P.n_instr; ++pc) {
-      VmInstr I;
-      if (P.flags & 1u) raw_next = prog[pc];   // experiment: no prefetch
-      __builtin_memcpy(&I, &raw_next, sizeof(I));
-      if (!(P.flags & 1u)) raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
-      // operands in the input region are relative to the current input buffer (bit 31)
-      I.dst = vm_resolve(I.dst, bufbase); I.a = vm_resolve(I.a, bufbase); I.b = vm_resolve(I.b, bufbase);
-      I.c = vm_resolve(I.c, bufbase); I.d = vm_resolve(I.d, bufbase);
+      // decode by dwords (a struct memcpy makes the compiler shuffle SGPR bytes)
+      struct { u32 op, a_imm, b_imm, dst, a, b, c, d; u64 imm; } I;
+      I.op = raw_next[0] & 0xFFFFu; I.a_imm = (raw_next[0] >> 16) & 0xFFu; I.b_imm = raw_next[0] >> 24;
+      I.dst = raw_next[1]; I.a = raw_next[2]; I.b = raw_next[3]; I.c = raw_next[4]; I.d = raw_next[5];
+      I.imm = (u64)raw_next[6] | ((u64)raw_next[7] << 32);
+      raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
       // launder the thread id once per instruction: without this LICM hoists every
       // case's (t * width) address chain into the prologue (255 VGPRs, occupancy 1)
       int tp = t;
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         // VM_NONE when the side is not nullable.  dst = value, c = null out.
         case VM_AND3:
         case VM_OR3: { CASE_FENCE;
-          const u32 an_off = vm_resolve((u32)I.imm, bufbase), bn_off = vm_resolve((u32)(I.imm >> 32), bufbase);
+          const u32 an_off = (u32)I.imm, bn_off = (u32)(I.imm >> 32);
           const bool is_and = I.op == VM_AND3;
           _Pragma("unroll") FOR_PAIRS {
             auto va = lds_load2<u8>(I.a, p); auto vb = lds_load2<u8>(I.b, p);
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_##OPNAME: { CASE_FENCE;                                        \
           bool bad = false;                                                    \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.a, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.a, I.c);        \
             auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
             bad = bad || (m.x && vb.x == (T)0) || (m.y && vb.y == (T)0);       \
           }                                                                    \
@@ -600,13 +617,13 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_COUNT: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             fc[S] += (u32)m.x + (u32)m.y;                                      \
           }
 #define SLOW_                                                                  \
           u32 cnt = 0;                                                         \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
           }                                                                    \
           if (lane == 0) { VmAccRec* A = acc_rec(P, I.dst, wave); A->v0 += cnt; A->cnt += cnt; }
@@ -617,7 +634,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_SUM_I32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i32>(I.a, p);                              \
             { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((i64)e) : (u64)(0ull); f0[S] = (x + y); } \
             { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((i64)e) : (u64)(0ull); f0[S] = (x + y); } \
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i32>(I.a, p);                              \
             { i32 e = vv.x; u64 x = local, y = m.x ? (u64)((i64)e) : (u64)(0ull); local = (x + y); } \
             { i32 e = vv.y; u64 x = local, y = m.y ? (u64)((i64)e) : (u64)(0ull); local = (x + y); } \
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_SUM_U32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
             { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); } \
             { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); } \
@@ -673,7 +690,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_SUM_I64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
             { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); } \
             { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); } \
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_I32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i32>(I.a, p);                              \
             { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
             { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
@@ -710,7 +727,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (~0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i32>(I.a, p);                              \
             { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
             { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
@@ -729,7 +746,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_U32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
             { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
@@ -738,7 +755,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (~0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
             { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
@@ -757,7 +774,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_I64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i64>(I.a, p);                              \
             { i64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
             { i64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (~0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i64>(I.a, p);                              \
             { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
             { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
@@ -785,7 +802,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_U64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
             { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
@@ -794,7 +811,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (~0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
             { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_B8: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             { u8 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((e != 0)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
             { u8 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((e != 0)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
@@ -822,7 +839,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (~0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
             { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
@@ -841,7 +858,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_I32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i32>(I.a, p);                              \
             { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
             { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
@@ -850,7 +867,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i32>(I.a, p);                              \
             { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
             { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
@@ -869,7 +886,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_U32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
             { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
@@ -878,7 +895,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
             { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
@@ -897,7 +914,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_I64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i64>(I.a, p);                              \
             { i64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
             { i64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
@@ -906,7 +923,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<i64>(I.a, p);                              \
             { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
             { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
@@ -925,7 +942,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_U64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
             { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
@@ -934,7 +951,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
             { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
@@ -953,7 +970,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_B8: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             { u8 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((e != 0)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
             { u8 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((e != 0)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
@@ -962,7 +979,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 local = (0ull); u32 cnt = 0;                                  \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); } \
             { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); } \
@@ -981,7 +998,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_F32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<float>(I.a, p);                              \
             { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((y < x))) f0[S] = d2u(y); } \
             { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((y < x))) f0[S] = d2u(y); } \
@@ -990,7 +1007,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           double local = (__builtin_inf()); u32 cnt = 0;                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<float>(I.a, p);                              \
             { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; } \
             { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; } \
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MIN_F64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<double>(I.a, p);                              \
             { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((y < x))) f0[S] = d2u(y); } \
             { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((y < x))) f0[S] = d2u(y); } \
@@ -1019,7 +1036,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           double local = (__builtin_inf()); u32 cnt = 0;                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<double>(I.a, p);                              \
             { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; } \
             { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; } \
@@ -1039,7 +1056,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_F32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<float>(I.a, p);                              \
             { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((x < y))) f0[S] = d2u(y); } \
             { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((x < y))) f0[S] = d2u(y); } \
@@ -1048,7 +1065,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           double local = (-__builtin_inf()); u32 cnt = 0;                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<float>(I.a, p);                              \
             { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; } \
             { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; } \
@@ -1068,7 +1085,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_MAX_F64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<double>(I.a, p);                              \
             { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((x < y))) f0[S] = d2u(y); } \
             { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((x < y))) f0[S] = d2u(y); } \
@@ -1077,7 +1094,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           double local = (-__builtin_inf()); u32 cnt = 0;                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<double>(I.a, p);                              \
             { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; } \
             { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; } \
@@ -1107,7 +1124,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define FAST_(S)                                                               \
           DD local; local.hi = u2d(f0[S]); local.lo = u2d(f1[S]);              \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             LOAD_E_                                                            \
             if (m.x) local = dd_add_d(local, e0);                              \
             if (m.y) local = dd_add_d(local, e1);                              \
@@ -1117,7 +1134,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;              \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             LOAD_E_                                                            \
             if (m.x) local = dd_add_d(local, e0);                              \
             if (m.y) local = dd_add_d(local, e1);                              \
@@ -1138,7 +1155,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_FIRST_8: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
@@ -1148,7 +1165,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
@@ -1174,7 +1191,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_FIRST_32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
@@ -1184,7 +1201,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
@@ -1210,7 +1227,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_FIRST_64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
@@ -1220,7 +1237,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
@@ -1246,7 +1263,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_LAST_8: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
@@ -1256,7 +1273,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u8>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
@@ -1282,7 +1299,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_LAST_32: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
@@ -1292,7 +1309,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u32>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
@@ -1318,7 +1335,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_AGG_LAST_64: { CASE_FENCE;
 #define FAST_(S)                                                               \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
@@ -1328,7 +1345,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 #define SLOW_                                                                  \
           u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, I.c);        \
+            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
             auto vv = lds_load2<u64>(I.a, p);                              \
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
             { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
@@ -1356,7 +1373,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_SEL_COUNT: { CASE_FENCE;
           u32 cnt = 0;
           _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.a);
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
             cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
           }
           u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
@@ -1369,7 +1386,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
           // order-preserving ranks: rows are ordered (k, wave, lane, j)
           u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
           _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.a);
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
             u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
             if (lane == 0) scratch[k * VM_WAVES + wave] = c;
           }
@@ -1380,7 +1397,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
             u32 mine = base;
             for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
             for (int w = 0; w < VM_WAVES; ++w) base += scratch[k * VM_WAVES + w];
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.a);
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
             u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
             u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
             lds_store2<u32>(I.dst, p, r0, r0 + (m.x ? 1u : 0u));
@@ -1396,7 +1413,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_STORE_ROWID: { CASE_FENCE;
           i64* out = reinterpret_cast<i64*>(P.outputs[I.dst].dst);
           _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.c);
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
             auto rk = lds_load2<u32>(I.b, p);
             i64 r0 = P.row_id_base + tile_base + 2 * (i64)p;
             if (m.x) out[rk.x] = r0;
@@ -1411,7 +1428,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         KEY_APPEND_OP(KEY_APPEND_64, u64, u64)
         case VM_GRP_INSERT: { CASE_FENCE;
           _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, VM_NONE, I.c);
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
             auto kk = lds_load2<u64>(I.a, p);
             u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
             u32 s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;
@@ -1423,7 +1440,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         case VM_GAGG_COUNT: { CASE_FENCE;
           const u32 ng = (u32)(I.imm >> 32), s = (u32)I.imm;
           _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair(I, p, tile_base, P.n_rows, I.b, VM_NONE);
+            Valid2 m = valid_pair_(p, tile_valid, I.b, VM_NONE);
             auto sl = lds_load2<u32>(I.c, p);
             if (m.x && sl.x != 0xFFFFFFFFu) atomicAdd(&P.group.acc[(u64)sl.x * ng + s], 1ull);
             if (m.y && sl.y != 0xFFFFFFFFu) atomicAdd(&P.group.acc[(u64)sl.y * ng + s], 1ull);

@@ -302,7 +302,7 @@ int ssgpu_plan_program(const ssgpu_plan* cp, int32_t stage, const void** instrs,
   ssgpu_plan* p = const_cast<ssgpu_plan*>(cp);
   if (!p || stage < 0 || stage >= (int)p->stages.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ProgramLayout L = layout_program(p->stages[stage].main, p->ctx->opt);
-  finalize_program(p->stages[stage].main, 512 * L.K, &p->host_prog_scratch);
+  finalize_program(p->stages[stage].main, L, &p->host_prog_scratch);
   *instrs = p->host_prog_scratch.data(); *n = (int32_t)p->host_prog_scratch.size(); *bytes = (int32_t)sizeof(VmInstr);
   return SSGPU_OK;
 }
@@ -316,9 +316,9 @@ namespace {
 
 struct InCols { std::vector<ssgpu_column> cols; int64_t rows = 0; };
 
-int upload_program(ssgpu_ctx* c, const Program& prog, int tile_rows, DevBuf* dev, int* n_instr, std::vector<VmInstr>* scratch) {
-  finalize_program(prog, tile_rows, scratch);
-  *n_instr = (int)scratch->size() - 1;  // without the trailing prefetch pad
+int upload_program(ssgpu_ctx* c, const Program& prog, const ProgramLayout& L, DevBuf* dev, int* n_instr, std::vector<VmInstr>* scratch) {
+  finalize_program(prog, L, scratch);
+  *n_instr = (int)prog.code.size();  // per variant, without the trailing prefetch pad
   HIP_TRY(c, dev->ensure(std::max<size_t>(1, scratch->size()) * sizeof(VmInstr)));
   if (!scratch->empty())
     HIP_TRY(c, hipMemcpyAsync(dev->p, scratch->data(), scratch->size() * sizeof(VmInstr), hipMemcpyHostToDevice, c->stream));
@@ -336,12 +336,12 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   ProgramLayout L = layout_program(st.main, c->opt);
   if (ex.prog_main.p && L.K == ex.lay.K) return SSGPU_OK;  // already prepared for this tile size
   ex.lay = L;
-  int rc = upload_program(c, st.main, 512 * L.K, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
+  int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
   if (!st.count_pass.empty()) {
     LowerOptions o = c->opt; o.tile_rows = 512 * L.K;
     ex.lay_count = layout_program(st.count_pass, o);
-    rc = upload_program(c, st.count_pass, 512 * L.K, &ex.prog_count, &ex.n_instr_count, &p->host_prog_scratch);
+    rc = upload_program(c, st.count_pass, ex.lay_count, &ex.prog_count, &ex.n_instr_count, &p->host_prog_scratch);
     if (rc != SSGPU_OK) return rc;
   }
   HIP_TRY(c, ex.error_flag.ensure(sizeof(uint32_t)));
@@ -372,6 +372,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->n_tiles = (int)((in.rows + P->tile_rows - 1) / P->tile_rows);
   P->acc_lds_off = L.acc_off;
   P->scratch_lds_off = L.scratch_off;
+  P->imm_pool_lds_off = L.imm_pool_off;
   P->lds_bytes = L.lds_bytes;
   P->in_lds_bytes = L.in_lds_bytes;
   P->n_sync_per_tile = prog.n_sync_per_tile;

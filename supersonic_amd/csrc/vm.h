@@ -112,8 +112,8 @@ enum VmOp : uint16_t {
 
 struct VmInstr {
   uint16_t op;
-  uint8_t a_imm; /* operand a is `imm` */
-  uint8_t b_imm; /* operand b is `imm` */
+  uint8_t a_imm; /* != 0: operand a is the immediate; value = its width in bytes (1/4/8) */
+  uint8_t b_imm; /* != 0: operand b is the immediate; `a`/`b` then point at the LDS constant pool */
   uint32_t dst;  /* LDS byte offset | aggregate slot | output column index */
   uint32_t a, b, c, d; /* LDS byte offsets, VM_NONE when absent */
   uint64_t imm;
@@ -164,6 +164,7 @@ struct VmParams {
   int32_t n_tiles;
   uint32_t acc_lds_off;   /* LDS offset of the aggregate accumulators */
   uint32_t scratch_lds_off; /* LDS offset of 256 B of scan scratch */
+  uint32_t imm_pool_lds_off; /* LDS offset of the constant pool: 16 B per instruction */
   uint32_t lds_bytes;
   uint32_t in_lds_bytes;      /* bytes of ONE input buffer (two are resident) */
   int32_t n_sync_per_tile;    /* s_barriers executed inside the program per tile */
