@@ -149,10 +149,11 @@ std::string bexpr_to_string(const BExprP& e);
 struct LowerOptions {
   int lds_target_bytes = 48 * 1024;
   int tile_rows = 0;  // 0 = choose by lds_target_bytes
+  bool double_buffer = true;  // two input buffers per workgroup (loader prefetches the next tile)
 };
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe);
 // choose the tile size (K = tile_rows / 512) and fix LDS offsets for a program
-struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t in_lds_bytes; uint32_t imm_pool_off; };
+struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t in_lds_bytes; uint32_t imm_pool_off; bool double_buffer; };
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt);
 // final device instructions for a tile of `tile_rows`: two variants (one per input buffer),
 // each n + 1 instructions (trailing NOP for the prefetch)

@@ -401,7 +401,7 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   ProgramLayout L;
   auto lds_for = [&](int K, uint32_t* acc, uint32_t* scr) {
     // two input buffers (the loader wave fills one while the other is consumed) + temporaries
-    uint32_t regs = (p.bytes_per_row + p.in_bytes_per_row) * 512u * (uint32_t)K;
+    uint32_t regs = (p.bytes_per_row + (opt.double_buffer ? p.in_bytes_per_row : 0u)) * 512u * (uint32_t)K;
     uint32_t a = (regs + 15u) & ~15u;
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
     if (acc) *acc = a;
@@ -420,6 +420,7 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   L.lds_bytes = lds_for(K, &L.acc_off, &L.scratch_off);
   L.in_lds_bytes = p.in_bytes_per_row * 512u * (uint32_t)K;
   L.imm_pool_off = L.scratch_off + 256u;
+  L.double_buffer = opt.double_buffer;
   return L;
 }
 
@@ -431,6 +432,7 @@ void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmIn
     auto off = [&](int r) -> uint32_t {
       if (r < 0) return VM_NONE;
       const uint32_t ro = p.regs[r].row_off;
+      if (!L.double_buffer) return ro * T;
       if (ro < p.in_bytes_per_row) return ro * T + (uint32_t)buf * L.in_lds_bytes;
       return (ro + p.in_bytes_per_row) * T;
     };

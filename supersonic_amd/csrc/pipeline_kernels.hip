@@ -333,7 +333,7 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
 // One s_barrier per tile: the loader arrives after its DMA for the NEXT tile has landed
 // (s_waitcnt vmcnt(0)), the compute waves arrive when they are done with the CURRENT one.
 template <int K>
-__global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmParams P) {
+__global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const VmParams P) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
@@ -342,14 +342,24 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
 
   if (wave == VM_WAVES) {
     // ------------------------------ loader wave ------------------------------
+    const bool single = (P.flags & VM_FLAG_SINGLE_BUFFER) != 0;
     if (n_my_tiles > 0) stage_tile(P, (i64)blockIdx.x * tile_rows, tile_rows, lane, 0u);
     for (int it = 0; it < n_my_tiles; ++it) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile `it` is in LDS
-      if (it + 1 < n_my_tiles) {
+      if (!single && it + 1 < n_my_tiles) {
         const int tile = (int)blockIdx.x + (it + 1) * (int)gridDim.x;
         stage_tile(P, (i64)tile * tile_rows, tile_rows, lane, ((it + 1) & 1) ? P.in_lds_bytes : 0u);
       }
       for (int i = 0; i < P.n_sync_per_tile; ++i) asm volatile("s_barrier" ::: "memory");
+      if (single) {
+        // one input buffer: the next tile may only be fetched once this one is consumed; the
+        // other resident workgroups of the CU cover the DMA latency
+        asm volatile("s_barrier" ::: "memory");
+        if (it + 1 < n_my_tiles) {
+          const int tile = (int)blockIdx.x + (it + 1) * (int)gridDim.x;
+          stage_tile(P, (i64)tile * tile_rows, tile_rows, lane, 0u);
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // final rendezvous
     return;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
     const i64 tile_base = (i64)tile * tile_rows;
     const u32 tile_valid = (u32)((P.n_rows - tile_base) < (i64)tile_rows ? (P.n_rows - tile_base) : (i64)tile_rows);
     // the host finalises the program twice, once per input buffer: no address fix-ups here
-    const ProgPtr prog = prog0 + ((it & 1) ? (P.n_instr + 1) : 0);
+    const ProgPtr prog = prog0 + (((it & 1) && !(P.flags & VM_FLAG_SINGLE_BUFFER)) ? (P.n_instr + 1) : 0);
     const u64 tw0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile landed; previous tile fully consumed
     if (P.debug) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
@@ -1471,6 +1481,7 @@ __global__ __launch_bounds__(VM_WG_THREADS) void ssgpu_pipeline_kernel(const VmP
         default: break;
       }
     }
+    if (P.flags & VM_FLAG_SINGLE_BUFFER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile consumed
   }
 
   if (P.debug && t == 0) {

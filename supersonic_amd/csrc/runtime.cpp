@@ -194,6 +194,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   } else if (k == "profile") c->profile = value;
   else if (k == "debug_timing") c->debug_timing = value;
   else if (k == "kernel_flags") c->kernel_flags = value;
+  else if (k == "double_buffer") c->opt.double_buffer = value != 0;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
 }
@@ -334,7 +335,7 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   StageExec& ex = p->exec[si];
   if (st.main.empty()) return SSGPU_OK;
   ProgramLayout L = layout_program(st.main, c->opt);
-  if (ex.prog_main.p && L.K == ex.lay.K) return SSGPU_OK;  // already prepared for this tile size
+  if (ex.prog_main.p && L.K == ex.lay.K && L.double_buffer == ex.lay.double_buffer) return SSGPU_OK;  // already prepared
   ex.lay = L;
   int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
@@ -376,6 +377,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->lds_bytes = L.lds_bytes;
   P->in_lds_bytes = L.in_lds_bytes;
   P->n_sync_per_tile = prog.n_sync_per_tile;
+  P->flags = L.double_buffer ? 0u : VM_FLAG_SINGLE_BUFFER;
   for (size_t i = 0; i < prog.staged.size(); ++i) {
     const StagedInput& s = prog.staged[i];
     P->staged[i].src = s.is_null_mask ? (const void*)in.cols[s.col].is_null : in.cols[s.col].data;
@@ -420,7 +422,7 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   fill_fast_slots(&P, st);
-  P.flags = (uint32_t)c->kernel_flags;
+  P.flags |= (uint32_t)c->kernel_flags;
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   ex.grid = grid;
   const int ns = st.main.n_slots;
