@@ -15,6 +15,7 @@ enum SlotKind {
 enum EmitKind {
   EMIT_U64 = 0, EMIT_I64KEY = 1, EMIT_U32 = 2, EMIT_I32KEY = 3, EMIT_F64 = 4, EMIT_F32 = 5,
   EMIT_DD_F64 = 6, EMIT_DD_F32 = 7, EMIT_U8 = 8,
+  EMIT_CNT_U64 = 20, EMIT_CNT_U32 = 21, /* COUNT(*) = contribution count of another slot */
   EMIT_FKEY_F64 = 100, EMIT_FKEY_F32 = 101 /* group table: ordered-double key */
 };
 #define SSGPU_STATE_ARRAYS 8 /* reducible state: 8 u64 arrays of n_slots */

@@ -113,6 +113,7 @@ class Emitter {
   }
 
   Status value(const BExprP& e, Val* out);
+  bool has_value(const BExprP& e) { return memo_.count(key_of(e)) != 0; }
   Status cast_val(const Val& v, MT from, MT to, Val* out);
 
   // selection registers: sel_by_depth[d] = rows passing the first d filters (-1 = all)
@@ -338,7 +339,8 @@ Status Emitter::value(const BExprP& e, Val* out) {
 // ---- register allocation: linear scan over LDS row offsets ---------------------
 static void for_each_use(const LInstr& i, const std::function<void(int)>& f) {
   if (!i.a_imm && i.a >= 0) f(i.a);
-  if (!i.b_imm && i.b >= 0) f(i.b);
+  const bool fused_agg = i.op >= VM_AGG_SUM_I64_ADD && i.op <= VM_AGG_SUM_F64_MUL;
+  if ((!i.b_imm || fused_agg) && i.b >= 0) f(i.b);
   if (i.d >= 0) f(i.d);
   if (i.e >= 0) f(i.e);
   const bool c_is_def = i.op == VM_AND3 || i.op == VM_OR3;
@@ -447,6 +449,11 @@ void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmIn
       v.a = i.a_imm ? pool : off(i.a);
       v.b = i.b_imm ? pool : off(i.b);
       v.c = off(i.c); v.d = off(i.d);
+      const bool fused_agg = i.op >= VM_AGG_SUM_I64_ADD && i.op <= VM_AGG_SUM_F64_MUL;
+      if (fused_agg) {  // operands a and d; b is the null mask; b_imm flags operand d
+        v.b = off(i.b);
+        if (i.b_imm) v.d = pool;
+      }
       v.imm = i.imm;
       if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
       out->push_back(v);
@@ -684,10 +691,24 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
   Emitter em(&st->main);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
+  // COUNT(*) (or COUNT of a never-NULL column) under the same selection equals the contribution
+  // count every non-COUNT aggregate of a never-NULL input already keeps: share it, no instruction
+  int count_donor = -1;
+  for (size_t j = 0; j < plans.size(); ++j)
+    if (plans[j].aggregation != SSGPU_COUNT && !pipe.cols[plans[j].input_pos].expr->nullable) { count_donor = (int)j; break; }
   for (size_t j = 0; j < plans.size(); ++j) {
     const AggPlan& ap = plans[j];
     AggOut ao; ao.slot = (int)j; ao.has_cnt = true; ao.result_nullable = ap.result_nullable;
     if (ap.aggregation == SSGPU_COUNT) {
+      const bool never_null = ap.input_pos < 0 || !pipe.cols[ap.input_pos].expr->nullable;
+      if (never_null && count_donor >= 0) {
+        ao.slot = count_donor; ao.slot_kind = SLOT_COUNT;
+        ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_CNT_U32 : EMIT_CNT_U64;
+        st->aggs.push_back(ao);
+        Attr a; a.name = ap.out_name; a.dtype = ap.out_type; a.nullable = ap.result_nullable;
+        st->out_schema.push_back(a);
+        continue;
+      }
       int nullreg = -1;
       if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
       LInstr& i = em.emit(VM_AGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = sel;
@@ -695,14 +716,34 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
       ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
     } else {
       const BExprP& src = pipe.cols[ap.input_pos].expr;
-      Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
-      Val c;
-      SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
       AggSel s;
       if (!select_scalar_agg(ap.aggregation, ap.out_type, &s))
         return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
-      int vr = em.materialize(c);
-      LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = sel;
+      // fused SUM(x op y): the binary node feeds only this aggregate -> no LDS round trip
+      const MT smt = mtype(src->dtype);
+      const bool fusable = ap.aggregation == SSGPU_SUM && (int)j < VM_FAST_SLOTS && src->kind == BExpr::OP &&
+                           src->dtype == ap.out_type && (smt == M_I64 || smt == M_U64 || smt == M_F64) &&
+                           (src->op == OP_ADD || src->op == OP_SUBTRACT || src->op == OP_MULTIPLY) && !em.has_value(src);
+      if (fusable) {
+        Val x, y;
+        SS_RETURN_IF_ERROR(em.value(src->args[0], &x));
+        SS_RETURN_IF_ERROR(em.value(src->args[1], &y));
+        if (x.imm && y.imm) { x.reg = em.materialize(x); x.imm = false; }
+        const int nullreg = em.or_null(x.null, y.null);
+        const bool f = smt == M_F64;
+        const uint16_t op = src->op == OP_ADD ? (f ? VM_AGG_SUM_F64_ADD : VM_AGG_SUM_I64_ADD)
+                          : src->op == OP_SUBTRACT ? (f ? VM_AGG_SUM_F64_SUB : VM_AGG_SUM_I64_SUB)
+                                                   : (f ? VM_AGG_SUM_F64_MUL : VM_AGG_SUM_I64_MUL);
+        LInstr& i = em.emit(op); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = sel;
+        if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = 8; } else i.a = x.reg;
+        if (y.imm) { i.b_imm = true; i.imm = y.bits; i.imm_width = 8; } else i.d = y.reg;
+      } else {
+        Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
+        Val c;
+        SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+        int vr = em.materialize(c);
+        LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = sel;
+      }
       ao.slot_kind = s.slot_kind; ao.emit_kind = s.emit_kind;
     }
     st->aggs.push_back(ao);

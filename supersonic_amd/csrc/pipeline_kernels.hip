@@ -122,13 +122,20 @@ __device__ __forceinline__ i64 unkey_i64(u64 k) { return (i64)(k ^ 0x80000000000
 // row validity for sinks: row exists, passes the selection, value not NULL.
 // ---------------------------------------------------------------------------
 struct Valid2 { bool x, y; };
-__device__ __forceinline__ Valid2 valid_pair_(int p, u32 tile_valid, u32 null_off, u32 sel_off) {
+// Absent selection / NULL masks read a constant LDS slot with stride 0 (all-ones / all-zeros),
+// so the three LDS reads of a sink (selection, NULL mask, value) issue back to back.
+__device__ __forceinline__ Valid2 valid_pair_c(int p, u32 tile_valid, u32 null_off, u32 sel_off, u32 const_off) {
   const u32 r0 = 2u * (u32)p;
-  Valid2 v; v.x = r0 < tile_valid; v.y = (r0 + 1u) < tile_valid;
-  if (sel_off != VM_NONE) { auto s = lds_load2<u8>(sel_off, p); v.x = v.x && s.x; v.y = v.y && s.y; }
-  if (null_off != VM_NONE) { auto z = lds_load2<u8>(null_off, p); v.x = v.x && !z.x; v.y = v.y && !z.y; }
+  const u32 so = sel_off == VM_NONE ? const_off : sel_off, ss = sel_off == VM_NONE ? 0u : 2u;
+  const u32 no = null_off == VM_NONE ? const_off + 16u : null_off, ns = null_off == VM_NONE ? 0u : 2u;
+  const auto s = *reinterpret_cast<const Vec2<u8>::type*>(smem + so + (u32)p * ss);
+  const auto z = *reinterpret_cast<const Vec2<u8>::type*>(smem + no + (u32)p * ns);
+  Valid2 v;
+  v.x = (r0 < tile_valid) && s.x && !z.x;
+  v.y = ((r0 + 1u) < tile_valid) && s.y && !z.y;
   return v;
 }
+#define valid_pair_(p, tile_valid, null_off, sel_off) valid_pair_c(p, tile_valid, null_off, sel_off, P.const_lds_off)
 
 // LDS operand offsets: bit 31 marks a register in the (double-buffered) input region
 __device__ __forceinline__ u32 vm_resolve(u32 o, u32 bufbase) {
@@ -241,21 +248,11 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
     }                                                                          \
   } break;
 
-// ---------------------------------------------------------------------------
-// scalar aggregates.  The first VM_FAST_SLOTS slots keep PER-LANE accumulators in
-// registers for the whole kernel (f0/f1/fc, statically indexed through a uniform switch on
-// the slot): per tile an aggregate costs a compare-select-combine per row and no cross-lane
-// traffic; the wave reduction happens once, at the end of the kernel.  Further slots fall
-// back to a per-tile wave reduction into LDS records.
-// ---------------------------------------------------------------------------
-#define SLOT_SWITCH(FAST, SLOW)                                                \
-  switch (I.dst) {                                                             \
-    case 0: { FAST(0) } break; case 1: { FAST(1) } break;                      \
-    case 2: { FAST(2) } break; case 3: { FAST(3) } break;                      \
-    case 4: { FAST(4) } break; case 5: { FAST(5) } break;                      \
-    case 6: { FAST(6) } break; case 7: { FAST(7) } break;                      \
-    default: { SLOW } break;                                                   \
-  }
+// Scalar aggregates: the first VM_FAST_SLOTS slots keep PER-LANE accumulators in registers
+// for the whole kernel (vectors F0/F1/FC indexed by the wave-uniform slot -> v_movrel, no
+// switch): per tile an aggregate costs a select-combine per row and no cross-lane traffic;
+// the wave reduction happens once, at the end of the kernel.  Further slots fall back to a
+// per-tile wave reduction into LDS records.
 
 #define STORE_OP(OPNAME, T)                                                    \
   case VM_##OPNAME: { CASE_FENCE;                                              \
@@ -370,9 +367,13 @@ __global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const 
   for (u32 o = (u32)t * 8u; o < (u32)P.n_slots * VM_ACC_STRIDE; o += VM_COMPUTE_THREADS * 8u)
     *reinterpret_cast<u64*>(smem + P.acc_lds_off + o) = 0ull;
   // per-lane register accumulators of the first VM_FAST_SLOTS aggregate slots
-  u64 f0[VM_FAST_SLOTS], f1[VM_FAST_SLOTS]; u32 fc[VM_FAST_SLOTS];
+  typedef u64 u64xS __attribute__((ext_vector_type(VM_FAST_SLOTS)));
+  typedef u32 u32xS __attribute__((ext_vector_type(VM_FAST_SLOTS)));
+  u64xS F0, F1; u32xS FC;
 #pragma unroll
-  for (int s = 0; s < VM_FAST_SLOTS; ++s) { f0[s] = P.slot_init0[s]; f1[s] = P.slot_init1[s]; fc[s] = 0; }
+  for (int s = 0; s < VM_FAST_SLOTS; ++s) { F0[s] = P.slot_init0[s]; F1[s] = P.slot_init1[s]; FC[s] = 0; }
+  // constant LDS slots: 16 x 0x01 (absent selection) then 16 x 0x00 (absent NULL mask)
+  if (t < 4) reinterpret_cast<u64*>(smem + P.const_lds_off)[t] = t < 2 ? 0x0101010101010101ull : 0ull;
 
   typedef u32 u32x8 __attribute__((ext_vector_type(8)));
   typedef const __attribute__((address_space(4))) u32x8* ProgPtr;
@@ -625,758 +626,834 @@ __global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const 
 
         // ---- scalar aggregate sinks -------------------------------------------
         case VM_AGG_COUNT: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              ac += (u32)m.x + (u32)m.y;
+            }
+            FC[I.dst] = ac;
+          } else {
+            u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            if (lane == 0) { VmAccRec* A = acc_rec(P, I.dst, wave); A->v0 += cnt; A->cnt += cnt; }
           }
-#define SLOW_                                                                  \
-          u32 cnt = 0;                                                         \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          if (lane == 0) { VmAccRec* A = acc_rec(P, I.dst, wave); A->v0 += cnt; A->cnt += cnt; }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_SUM_I32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i32>(I.a, p);                              \
-            { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((i64)e) : (u64)(0ull); f0[S] = (x + y); } \
-            { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((i64)e) : (u64)(0ull); f0[S] = (x + y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i32 e = vv.x; u64 x = acc, y = m.x ? (u64)((i64)e) : (u64)(0ull); acc = (x + y); }
+              { i32 e = vv.y; u64 x = acc, y = m.y ? (u64)((i64)e) : (u64)(0ull); acc = (x + y); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i32 e = vv.x; u64 x = local, y = m.x ? (u64)((i64)e) : (u64)(0ull); local = (x + y); }
+              { i32 e = vv.y; u64 x = local, y = m.y ? (u64)((i64)e) : (u64)(0ull); local = (x + y); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = (x + y); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i32>(I.a, p);                              \
-            { i32 e = vv.x; u64 x = local, y = m.x ? (u64)((i64)e) : (u64)(0ull); local = (x + y); } \
-            { i32 e = vv.y; u64 x = local, y = m.y ? (u64)((i64)e) : (u64)(0ull); local = (x + y); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = (x + y); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_SUM_U32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
-            { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u32 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = (x + y); }
+              { u32 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = (x + y); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); }
+              { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = (x + y); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); } \
-            { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = (x + y); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_SUM_I64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
-            { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = (x + y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = (x + y); }
+              { u64 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = (x + y); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); }
+              { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = (x + y); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); } \
-            { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = (x + y); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_I32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i32>(I.a, p);                              \
-            { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i32 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              { i32 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (~0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
+              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (~0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i32>(I.a, p);                              \
-            { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
-            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_U32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u32 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              { u32 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (~0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
+              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (~0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
-            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_I64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i64>(I.a, p);                              \
-            { i64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            { i64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i64 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              { i64 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (~0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
+              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (~0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i64>(I.a, p);                              \
-            { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
-            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_U64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              { u64 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (~0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
+              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (~0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
-            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_B8: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            { u8 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((e != 0)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            { u8 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((e != 0)) : (u64)(~0ull); f0[S] = ((x < y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u8 e = vv.x; u64 x = acc, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              { u8 e = vv.y; u64 x = acc, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (~0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
+              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (~0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;                  \
-            A->v0 = ((x < y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_I32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i32>(I.a, p);                              \
-            { i32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            { i32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i32 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              { i32 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); }
+              { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i32>(I.a, p);                              \
-            { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_U32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            { u32 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            { u32 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u32 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              { u32 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
+              { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_I64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i64>(I.a, p);                              \
-            { i64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            { i64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i64 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              { i64 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<i64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); }
+              { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<i64>(I.a, p);                              \
-            { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_U64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            { u64 e = vv.x; u64 x = f0[S], y = m.x ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            { u64 e = vv.y; u64 x = f0[S], y = m.y ? (u64)(e) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              { u64 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
+              { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_B8: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            { u8 e = vv.x; u64 x = f0[S], y = m.x ? (u64)((e != 0)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            { u8 e = vv.y; u64 x = f0[S], y = m.y ? (u64)((e != 0)) : (u64)(0ull); f0[S] = ((x > y ? x : y)); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u8 e = vv.x; u64 x = acc, y = m.x ? (u64)((e != 0)) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              { u8 e = vv.y; u64 x = acc, y = m.y ? (u64)((e != 0)) : (u64)(0ull); acc = ((x > y ? x : y)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          } else {
+            u64 local = (0ull); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); }
+              { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
+              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          u64 local = (0ull); u32 cnt = 0;                                  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); }); \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;                  \
-            A->v0 = ((x > y ? x : y)); A->cnt += cnt;                                   \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_F32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<float>(I.a, p);                              \
-            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((y < x))) f0[S] = d2u(y); } \
-            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((y < x))) f0[S] = d2u(y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<float>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = acc, y = (double)vv.x; if (m.x && ((y < x))) acc = y; }
+              { double x = acc, y = (double)vv.y; if (m.y && ((y < x))) acc = y; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
+          } else {
+            double local = (__builtin_inf()); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<float>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; }
+              { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);
+              A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          double local = (__builtin_inf()); u32 cnt = 0;                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<float>(I.a, p);                              \
-            { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; } \
-            { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
-            double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });  \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);  \
-            A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;                    \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MIN_F64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<double>(I.a, p);                              \
-            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((y < x))) f0[S] = d2u(y); } \
-            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((y < x))) f0[S] = d2u(y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<double>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = acc, y = (double)vv.x; if (m.x && ((y < x))) acc = y; }
+              { double x = acc, y = (double)vv.y; if (m.y && ((y < x))) acc = y; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
+          } else {
+            double local = (__builtin_inf()); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<double>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; }
+              { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);
+              A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          double local = (__builtin_inf()); u32 cnt = 0;                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<double>(I.a, p);                              \
-            { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; } \
-            { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
-            double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });  \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);  \
-            A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;                    \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_F32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<float>(I.a, p);                              \
-            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((x < y))) f0[S] = d2u(y); } \
-            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((x < y))) f0[S] = d2u(y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<float>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = acc, y = (double)vv.x; if (m.x && ((x < y))) acc = y; }
+              { double x = acc, y = (double)vv.y; if (m.y && ((x < y))) acc = y; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
+          } else {
+            double local = (-__builtin_inf()); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<float>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; }
+              { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);
+              A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          double local = (-__builtin_inf()); u32 cnt = 0;                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<float>(I.a, p);                              \
-            { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; } \
-            { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
-            double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });  \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);  \
-            A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;                    \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_MAX_F64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<double>(I.a, p);                              \
-            { double x = u2d(f0[S]), y = (double)vv.x; if (m.x && ((x < y))) f0[S] = d2u(y); } \
-            { double x = u2d(f0[S]), y = (double)vv.y; if (m.y && ((x < y))) f0[S] = d2u(y); } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<double>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = acc, y = (double)vv.x; if (m.x && ((x < y))) acc = y; }
+              { double x = acc, y = (double)vv.y; if (m.y && ((x < y))) acc = y; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
+          } else {
+            double local = (-__builtin_inf()); u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<double>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; }
+              { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);
+              A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;
+            }
           }
-#define SLOW_                                                                  \
-          double local = (-__builtin_inf()); u32 cnt = 0;                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<double>(I.a, p);                              \
-            { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; } \
-            { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) {           \
-            double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });  \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);  \
-            A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;                    \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_SUM_F32:
         case VM_AGG_SUM_F64: { CASE_FENCE;
-          // compensated (double-double) sum: bit-identical to the reference's
-          // sequential fold whenever every partial sum is exact, and within 1 ULP of
-          // the exact sum otherwise (the sequential fold itself is not).
+          // compensated (double-double) sum: bit-identical to the reference's sequential fold
+          // whenever every partial sum is exact, and within 1 ULP of the exact sum otherwise
           const bool f32 = I.op == VM_AGG_SUM_F32;
-#define LOAD_E_                                                                \
-            double e0, e1;                                                     \
-            if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; } \
-            else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
-#define FAST_(S)                                                               \
-          DD local; local.hi = u2d(f0[S]); local.lo = u2d(f1[S]);              \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            LOAD_E_                                                            \
-            if (m.x) local = dd_add_d(local, e0);                              \
-            if (m.y) local = dd_add_d(local, e1);                              \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
-          }                                                                    \
-          f0[S] = d2u(local.hi); f1[S] = d2u(local.lo);
-#define SLOW_                                                                  \
-          DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;              \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            LOAD_E_                                                            \
-            if (m.x) local = dd_add_d(local, e0);                              \
-            if (m.y) local = dd_add_d(local, e1);                              \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          DD tot = wave_reduce_dd(local);                                      \
-          if (lane == 0 && cnt) {                                              \
-            VmAccRec* A = acc_rec(P, I.dst, wave);                             \
-            DD cur; cur.hi = A->cnt ? u2d(A->v0) : -0.0; cur.lo = A->cnt ? u2d(A->v1) : 0.0; \
-            cur = dd_add(cur, tot);                                            \
-            A->v0 = d2u(cur.hi); A->v1 = d2u(cur.lo); A->cnt += cnt;           \
+          if (I.dst < VM_FAST_SLOTS) {
+            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              double e0, e1;
+              if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; }
+              else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              if (m.x) local = dd_add_d(local, e0);
+              if (m.y) local = dd_add_d(local, e1);
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
+          } else {
+            DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              double e0, e1;
+              if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; }
+              else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              if (m.x) local = dd_add_d(local, e0);
+              if (m.y) local = dd_add_d(local, e1);
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            DD tot = wave_reduce_dd(local);
+            if (lane == 0 && cnt) {
+              VmAccRec* A = acc_rec(P, I.dst, wave);
+              DD cur; cur.hi = A->cnt ? u2d(A->v0) : -0.0; cur.lo = A->cnt ? u2d(A->v1) : 0.0;
+              cur = dd_add(cur, tot);
+              A->v0 = d2u(cur.hi); A->v1 = d2u(cur.lo); A->cnt += cnt;
+            }
           }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
-#undef LOAD_E_
         } break;
         case VM_AGG_FIRST_8: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
-            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = ar, y = r0;     if (m.x && ((y < x))) { ar = y; av = (u64)vv.x; } }
+              { u64 x = ar, y = r0 + 1; if (m.y && ((y < x))) { ar = y; av = (u64)vv.y; } }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
+          } else {
+            u64 brow = (~0ull), bval = 0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } }
+              { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; });
+            u64 owner = __ballot(brow == trow);
+            if (cnt) {
+              int src = __ffsll((long long)owner) - 1;
+              u64 tval = readlane64(bval, src);
+              if (lane == 0) {
+                VmAccRec* A = acc_rec(P, I.dst, wave);
+                u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;
+                if ((y < x)) { A->v1 = trow; A->v0 = tval; }
+                A->cnt += cnt;
+              }
+            }
           }
-#define SLOW_                                                                  \
-          u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
-            { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; }); \
-          u64 owner = __ballot(brow == trow);                                  \
-          if (cnt) {                                                           \
-            int src = __ffsll((long long)owner) - 1;                           \
-            u64 tval = readlane64(bval, src);                                  \
-            if (lane == 0) {                                                   \
-              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
-              u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;            \
-              if ((y < x)) { A->v1 = trow; A->v0 = tval; }                   \
-              A->cnt += cnt;                                                   \
-            }                                                                  \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_FIRST_32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
-            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = ar, y = r0;     if (m.x && ((y < x))) { ar = y; av = (u64)vv.x; } }
+              { u64 x = ar, y = r0 + 1; if (m.y && ((y < x))) { ar = y; av = (u64)vv.y; } }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
+          } else {
+            u64 brow = (~0ull), bval = 0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } }
+              { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; });
+            u64 owner = __ballot(brow == trow);
+            if (cnt) {
+              int src = __ffsll((long long)owner) - 1;
+              u64 tval = readlane64(bval, src);
+              if (lane == 0) {
+                VmAccRec* A = acc_rec(P, I.dst, wave);
+                u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;
+                if ((y < x)) { A->v1 = trow; A->v0 = tval; }
+                A->cnt += cnt;
+              }
+            }
           }
-#define SLOW_                                                                  \
-          u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
-            { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; }); \
-          u64 owner = __ballot(brow == trow);                                  \
-          if (cnt) {                                                           \
-            int src = __ffsll((long long)owner) - 1;                           \
-            u64 tval = readlane64(bval, src);                                  \
-            if (lane == 0) {                                                   \
-              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
-              u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;            \
-              if ((y < x)) { A->v1 = trow; A->v0 = tval; }                   \
-              A->cnt += cnt;                                                   \
-            }                                                                  \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_FIRST_64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = f1[S], y = r0;     if (m.x && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
-            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y < x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = ar, y = r0;     if (m.x && ((y < x))) { ar = y; av = (u64)vv.x; } }
+              { u64 x = ar, y = r0 + 1; if (m.y && ((y < x))) { ar = y; av = (u64)vv.y; } }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
+          } else {
+            u64 brow = (~0ull), bval = 0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } }
+              { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; });
+            u64 owner = __ballot(brow == trow);
+            if (cnt) {
+              int src = __ffsll((long long)owner) - 1;
+              u64 tval = readlane64(bval, src);
+              if (lane == 0) {
+                VmAccRec* A = acc_rec(P, I.dst, wave);
+                u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;
+                if ((y < x)) { A->v1 = trow; A->v0 = tval; }
+                A->cnt += cnt;
+              }
+            }
           }
-#define SLOW_                                                                  \
-          u64 brow = (~0ull), bval = 0; u32 cnt = 0;                      \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } } \
-            { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; }); \
-          u64 owner = __ballot(brow == trow);                                  \
-          if (cnt) {                                                           \
-            int src = __ffsll((long long)owner) - 1;                           \
-            u64 tval = readlane64(bval, src);                                  \
-            if (lane == 0) {                                                   \
-              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
-              u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;            \
-              if ((y < x)) { A->v1 = trow; A->v0 = tval; }                   \
-              A->cnt += cnt;                                                   \
-            }                                                                  \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_LAST_8: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
-            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = ar, y = r0;     if (m.x && ((y >= x))) { ar = y; av = (u64)vv.x; } }
+              { u64 x = ar, y = r0 + 1; if (m.y && ((y >= x))) { ar = y; av = (u64)vv.y; } }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
+          } else {
+            u64 brow = (0ull), bval = 0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u8>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } }
+              { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; });
+            u64 owner = __ballot(brow == trow);
+            if (cnt) {
+              int src = __ffsll((long long)owner) - 1;
+              u64 tval = readlane64(bval, src);
+              if (lane == 0) {
+                VmAccRec* A = acc_rec(P, I.dst, wave);
+                u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;
+                if ((y >= x)) { A->v1 = trow; A->v0 = tval; }
+                A->cnt += cnt;
+              }
+            }
           }
-#define SLOW_                                                                  \
-          u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u8>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
-            { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; }); \
-          u64 owner = __ballot(brow == trow);                                  \
-          if (cnt) {                                                           \
-            int src = __ffsll((long long)owner) - 1;                           \
-            u64 tval = readlane64(bval, src);                                  \
-            if (lane == 0) {                                                   \
-              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
-              u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;            \
-              if ((y >= x)) { A->v1 = trow; A->v0 = tval; }                   \
-              A->cnt += cnt;                                                   \
-            }                                                                  \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_LAST_32: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
-            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = ar, y = r0;     if (m.x && ((y >= x))) { ar = y; av = (u64)vv.x; } }
+              { u64 x = ar, y = r0 + 1; if (m.y && ((y >= x))) { ar = y; av = (u64)vv.y; } }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
+          } else {
+            u64 brow = (0ull), bval = 0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u32>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } }
+              { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; });
+            u64 owner = __ballot(brow == trow);
+            if (cnt) {
+              int src = __ffsll((long long)owner) - 1;
+              u64 tval = readlane64(bval, src);
+              if (lane == 0) {
+                VmAccRec* A = acc_rec(P, I.dst, wave);
+                u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;
+                if ((y >= x)) { A->v1 = trow; A->v0 = tval; }
+                A->cnt += cnt;
+              }
+            }
           }
-#define SLOW_                                                                  \
-          u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u32>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
-            { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; }); \
-          u64 owner = __ballot(brow == trow);                                  \
-          if (cnt) {                                                           \
-            int src = __ffsll((long long)owner) - 1;                           \
-            u64 tval = readlane64(bval, src);                                  \
-            if (lane == 0) {                                                   \
-              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
-              u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;            \
-              if ((y >= x)) { A->v1 = trow; A->v0 = tval; }                   \
-              A->cnt += cnt;                                                   \
-            }                                                                  \
-          }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
         } break;
         case VM_AGG_LAST_64: { CASE_FENCE;
-#define FAST_(S)                                                               \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = f1[S], y = r0;     if (m.x && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.x; } } \
-            { u64 x = f1[S], y = r0 + 1; if (m.y && ((y >= x))) { f1[S] = y; f0[S] = (u64)vv.y; } } \
-            fc[S] += (u32)m.x + (u32)m.y;                                      \
+          if (I.dst < VM_FAST_SLOTS) {
+            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = ar, y = r0;     if (m.x && ((y >= x))) { ar = y; av = (u64)vv.x; } }
+              { u64 x = ar, y = r0 + 1; if (m.y && ((y >= x))) { ar = y; av = (u64)vv.y; } }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
+          } else {
+            u64 brow = (0ull), bval = 0; u32 cnt = 0;
+            _Pragma("unroll") FOR_PAIRS {
+              auto vv = lds_load2<u64>(I.a, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+              { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } }
+              { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } }
+              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            }
+            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; });
+            u64 owner = __ballot(brow == trow);
+            if (cnt) {
+              int src = __ffsll((long long)owner) - 1;
+              u64 tval = readlane64(bval, src);
+              if (lane == 0) {
+                VmAccRec* A = acc_rec(P, I.dst, wave);
+                u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;
+                if ((y >= x)) { A->v1 = trow; A->v0 = tval; }
+                A->cnt += cnt;
+              }
+            }
           }
-#define SLOW_                                                                  \
-          u64 brow = (0ull), bval = 0; u32 cnt = 0;                      \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);        \
-            auto vv = lds_load2<u64>(I.a, p);                              \
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);            \
-            { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } } \
-            { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } } \
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y)); \
-          }                                                                    \
-          u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; }); \
-          u64 owner = __ballot(brow == trow);                                  \
-          if (cnt) {                                                           \
-            int src = __ffsll((long long)owner) - 1;                           \
-            u64 tval = readlane64(bval, src);                                  \
-            if (lane == 0) {                                                   \
-              VmAccRec* A = acc_rec(P, I.dst, wave);                           \
-              u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;            \
-              if ((y >= x)) { A->v1 = trow; A->v0 = tval; }                   \
-              A->cnt += cnt;                                                   \
-            }                                                                  \
+        } break;
+        case VM_AGG_SUM_I64_ADD: { CASE_FENCE;
+          if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto va = fetch2<u64>(I.a, I.a_imm, I.imm, p);
+              auto vd = fetch2<u64>(I.d, I.b_imm, I.imm, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 a = va.x, b = vd.x; acc += m.x ? (a + b) : 0ull; }
+              { u64 a = va.y, b = vd.y; acc += m.y ? (a + b) : 0ull; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
           }
-          SLOT_SWITCH(FAST_, SLOW_)
-#undef FAST_
-#undef SLOW_
+        } break;
+        case VM_AGG_SUM_I64_SUB: { CASE_FENCE;
+          if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto va = fetch2<u64>(I.a, I.a_imm, I.imm, p);
+              auto vd = fetch2<u64>(I.d, I.b_imm, I.imm, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 a = va.x, b = vd.x; acc += m.x ? (a - b) : 0ull; }
+              { u64 a = va.y, b = vd.y; acc += m.y ? (a - b) : 0ull; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          }
+        } break;
+        case VM_AGG_SUM_I64_MUL: { CASE_FENCE;
+          if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
+            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto va = fetch2<u64>(I.a, I.a_imm, I.imm, p);
+              auto vd = fetch2<u64>(I.d, I.b_imm, I.imm, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { u64 a = va.x, b = vd.x; acc += m.x ? (a * b) : 0ull; }
+              { u64 a = va.y, b = vd.y; acc += m.y ? (a * b) : 0ull; }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = acc; FC[I.dst] = ac;
+          }
+        } break;
+        case VM_AGG_SUM_F64_ADD: { CASE_FENCE;
+          if (I.dst < VM_FAST_SLOTS) {
+            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto va = fetch2<double>(I.a, I.a_imm, I.imm, p);
+              auto vd = fetch2<double>(I.d, I.b_imm, I.imm, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a + b)); }
+              { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a + b)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
+          }
+        } break;
+        case VM_AGG_SUM_F64_SUB: { CASE_FENCE;
+          if (I.dst < VM_FAST_SLOTS) {
+            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto va = fetch2<double>(I.a, I.a_imm, I.imm, p);
+              auto vd = fetch2<double>(I.d, I.b_imm, I.imm, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a - b)); }
+              { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a - b)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
+          }
+        } break;
+        case VM_AGG_SUM_F64_MUL: { CASE_FENCE;
+          if (I.dst < VM_FAST_SLOTS) {
+            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
+            _Pragma("unroll") FOR_PAIRS {
+              auto va = fetch2<double>(I.a, I.a_imm, I.imm, p);
+              auto vd = fetch2<double>(I.d, I.b_imm, I.imm, p);
+              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
+              { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a * b)); }
+              { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a * b)); }
+              ac += (u32)m.x + (u32)m.y;
+            }
+            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
+          }
         } break;
 
         // ---- materialising sinks ----------------------------------------------
@@ -1495,27 +1572,27 @@ __global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const 
   for (int s = 0; s < VM_FAST_SLOTS; ++s) {
     if (s < P.n_slots) {
       const int kind = P.slot_kind[s];
-      const u64 cnt = wave_reduce_u64((u64)fc[s], [](u64 x, u64 y) { return x + y; });
+      const u64 cnt = wave_reduce_u64((u64)FC[s], [](u64 x, u64 y) { return x + y; });
       u64 v0 = 0, v1 = 0;
       switch (kind) {
         case SLOT_COUNT: v0 = cnt; break;
-        case SLOT_SUM_INT: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return x + y; }); break;
-        case SLOT_MIN_U64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return x < y ? x : y; }); break;
-        case SLOT_MAX_U64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return x > y ? x : y; }); break;
-        case SLOT_MIN_F64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return u2d(y) < u2d(x) ? y : x; }); break;
-        case SLOT_MAX_F64: v0 = wave_reduce_u64(f0[s], [](u64 x, u64 y) { return u2d(x) < u2d(y) ? y : x; }); break;
+        case SLOT_SUM_INT: v0 = wave_reduce_u64(F0[s], [](u64 x, u64 y) { return x + y; }); break;
+        case SLOT_MIN_U64: v0 = wave_reduce_u64(F0[s], [](u64 x, u64 y) { return x < y ? x : y; }); break;
+        case SLOT_MAX_U64: v0 = wave_reduce_u64(F0[s], [](u64 x, u64 y) { return x > y ? x : y; }); break;
+        case SLOT_MIN_F64: v0 = wave_reduce_u64(F0[s], [](u64 x, u64 y) { return u2d(y) < u2d(x) ? y : x; }); break;
+        case SLOT_MAX_F64: v0 = wave_reduce_u64(F0[s], [](u64 x, u64 y) { return u2d(x) < u2d(y) ? y : x; }); break;
         case SLOT_SUM_DD: {
-          DD d; d.hi = u2d(f0[s]); d.lo = u2d(f1[s]);
+          DD d; d.hi = u2d(F0[s]); d.lo = u2d(F1[s]);
           d = wave_reduce_dd(d); v0 = d2u(d.hi); v1 = d2u(d.lo);
         } break;
         case SLOT_FIRST: case SLOT_LAST: {
           // lanes without a contribution hold the identity row, which never wins
           const bool first = kind == SLOT_FIRST;
-          const u64 trow = first ? wave_reduce_u64(f1[s], [](u64 x, u64 y) { return x < y ? x : y; })
-                                 : wave_reduce_u64(fc[s] ? f1[s] : 0ull, [](u64 x, u64 y) { return x > y ? x : y; });
-          const u64 owner = __ballot(fc[s] != 0 && f1[s] == trow);
+          const u64 trow = first ? wave_reduce_u64(F1[s], [](u64 x, u64 y) { return x < y ? x : y; })
+                                 : wave_reduce_u64(FC[s] ? F1[s] : 0ull, [](u64 x, u64 y) { return x > y ? x : y; });
+          const u64 owner = __ballot(FC[s] != 0 && F1[s] == trow);
           const int src = owner ? __ffsll((long long)owner) - 1 : 0;
-          v0 = readlane64(f0[s], src); v1 = trow;
+          v0 = readlane64(F0[s], src); v1 = trow;
         } break;
         default: break;
       }
@@ -1654,7 +1731,10 @@ __global__ void ssgpu_emit_scalar_kernel(const VmAccRec* __restrict__ recs, cons
   if (i >= n_out) return;
   const EmitDesc d = descs[i];
   const VmAccRec r = recs[d.slot];
-  emit_value(d.data, 0, d.out_kind, r.v0, r.v1);
+  if (d.out_kind == EMIT_CNT_U64 || d.out_kind == EMIT_CNT_U32)   // COUNT(*) sharing another slot's row count
+    emit_value(d.data, 0, d.out_kind == EMIT_CNT_U64 ? EMIT_U64 : EMIT_U32, r.cnt, 0);
+  else
+    emit_value(d.data, 0, d.out_kind, r.v0, r.v1);
   if (d.is_null) d.is_null[0] = r.cnt == 0;
 }
 

@@ -374,6 +374,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->acc_lds_off = L.acc_off;
   P->scratch_lds_off = L.scratch_off;
   P->imm_pool_lds_off = L.imm_pool_off;
+  P->const_lds_off = L.scratch_off + 192u;  // tail of the 256-byte scratch area (scans use <= 128 B)
   P->lds_bytes = L.lds_bytes;
   P->in_lds_bytes = L.in_lds_bytes;
   P->n_sync_per_tile = prog.n_sync_per_tile;
@@ -402,7 +403,7 @@ int ensure_out_cols(ssgpu_ctx* c, const Stage& st, StageExec& ex, int64_t rows) 
 // per-lane identities of the register-resident (fast) aggregate slots
 void fill_fast_slots(VmParams* P, const Stage& st) {
   for (size_t i = 0; i < st.aggs.size() && i < VM_FAST_SLOTS; ++i) {
-    const int kind = st.aggs[i].slot_kind;
+    const int kind = st.aggs[i].slot == (int)i ? st.aggs[i].slot_kind : SLOT_COUNT;
     uint64_t i0 = 0, i1 = 0;
     const double pinf = __builtin_inf(), ninf = -__builtin_inf(), nzero = -0.0;
     switch (kind) {
@@ -430,7 +431,9 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
   HIP_TRY(c, ex.slot_recs.ensure((size_t)ns * sizeof(VmAccRec)));
   HIP_TRY(c, ex.state.ensure((size_t)ns * SSGPU_STATE_ARRAYS * sizeof(uint64_t)));
   if (!ex.slot_kind.p) {
-    std::vector<int> kinds; for (auto& a : st.aggs) kinds.push_back(a.slot_kind);
+    std::vector<int> kinds((size_t)ns, SLOT_COUNT);   // per SLOT (an aliased COUNT owns no slot)
+    for (size_t i = 0; i < st.aggs.size(); ++i)
+      if (st.aggs[i].slot == (int)i) kinds[i] = st.aggs[i].slot_kind;
     HIP_TRY(c, ex.slot_kind.ensure(kinds.size() * sizeof(int)));
     HIP_TRY(c, hipMemcpy(ex.slot_kind.p, kinds.data(), kinds.size() * sizeof(int), hipMemcpyHostToDevice));
   }

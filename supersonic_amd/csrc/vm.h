@@ -83,6 +83,9 @@
   X(AGG_MAX_F32) X(AGG_MAX_F64) X(AGG_MAX_B8)                                  \
   X(AGG_FIRST_8) X(AGG_FIRST_32) X(AGG_FIRST_64)                               \
   X(AGG_LAST_8) X(AGG_LAST_32) X(AGG_LAST_64)                                  \
+  /* fused SUM(a op d) for register-resident slots: a, d operands (b_imm flags d) */\
+  X(AGG_SUM_I64_ADD) X(AGG_SUM_I64_SUB) X(AGG_SUM_I64_MUL)                     \
+  X(AGG_SUM_F64_ADD) X(AGG_SUM_F64_SUB) X(AGG_SUM_F64_MUL)                     \
   /* ---- materialising sinks ---------------------------------------------- */\
   X(SEL_COUNT)   /* a = sel: tile_counts[tile] = #selected        */           \
   X(SEL_RANK)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
@@ -166,6 +169,7 @@ struct VmParams {
   uint32_t acc_lds_off;   /* LDS offset of the aggregate accumulators */
   uint32_t scratch_lds_off; /* LDS offset of 256 B of scan scratch */
   uint32_t imm_pool_lds_off; /* LDS offset of the constant pool: 16 B per instruction */
+  uint32_t const_lds_off;    /* LDS offset of 32 B: 16 x 0x01 then 16 x 0x00 */
   uint32_t lds_bytes;
   uint32_t in_lds_bytes;      /* bytes of ONE input buffer (two are resident) */
   int32_t n_sync_per_tile;    /* s_barriers executed inside the program per tile */
