@@ -85,7 +85,7 @@ def cpu_baseline(ss, sample_rows):
     view = ss.View(bench_schema(ss), cols)
     op = build_plan(ss, view)
     reps, elapsed = 0, 0.0
-    while elapsed < 10.0 and reps < 20:
+    while elapsed < 12.0 and reps < 200:
         cur = oracle.Cursor(op)
         t0 = time.perf_counter()
         out_rows = cur.drain_discard()

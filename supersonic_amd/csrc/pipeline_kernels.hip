@@ -193,9 +193,13 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
     if (full && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
       // 1 KiB per wave instruction, LDS destination = wave-uniform base + lane * 16
       for (u32 c = (u32)lane * 16u; c < bytes; c += 64u * 16u) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + c),
-            (__attribute__((address_space(3))) void*)(dst + c), 16, 0, 0);
+        // aux = 2 (nt): every byte is streamed exactly once, keep it out of the way in L2/MALL
+        if (P.flags & VM_FLAG_NT_LOADS)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                           (__attribute__((address_space(3))) void*)(dst + c), 16, 0, 2);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
+                                           (__attribute__((address_space(3))) void*)(dst + c), 16, 0, 0);
       }
     } else {
       // tail tile or unaligned view: element-wise, rows past the end read as 0

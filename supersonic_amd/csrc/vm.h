@@ -153,6 +153,7 @@ struct VmGroupTable {
   uint32_t capacity_mask;        /* capacity - 1                                   */
   uint32_t pad;
 };
+#define VM_FLAG_NT_LOADS 4u      /* non-temporal LDS-DMA */
 #define VM_FLAG_SINGLE_BUFFER 2u /* one input buffer per workgroup (more workgroups per CU) */
 #define VM_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 
