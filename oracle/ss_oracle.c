@@ -423,7 +423,8 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       int t = common_type(a[1]->dtype, a[2]->dtype, err); if (err->code) return NULL;
       bnode* x = make_cast(a[1], t, 1, err); bnode* y = make_cast(a[2], t, 1, err); if (err->code) return NULL;
       char nm[256]; snprintf(nm, sizeof(nm), "IF %s THEN %s ELSE %s", a[0]->name, x->name, y->name);
-      bnode* b = bnode_new(B_OP, op, t, a[0]->nullable || x->nullable || y->nullable, nm);
+      /* plain IF: nullable iff THEN or OTHERWISE is (CreateIfSchema :1010-1025) */
+      bnode* b = bnode_new(B_OP, op, t, x->nullable || y->nullable, nm);
       b->args[0] = a[0]; b->args[1] = x; b->args[2] = y; b->nargs = 3;
       return b;
     }
@@ -538,11 +539,13 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
     }
     case OP_IF: {
       bnode* z = b->args[2]; const int w = type_width(b->dtype); const uint8_t* cv = (const uint8_t*)x->data;
-      int any = x->nulls || y->nulls || z->nulls;
+      /* non-nulling IF: THEN iff the condition is non-NULL TRUE, otherwise OTHERWISE; NULLs come
+       * from the chosen branch only (elementary_bound_expressions.cc:893-1008) */
+      int any = y->nulls || z->nulls;
       for (int64_t i = 0; i < n; ++i) {
-        int c = cv[i] != 0; bnode* src = c ? y : z;
+        int c = cv[i] != 0 && !(x->nulls && x->nulls[i]); bnode* src = c ? y : z;
         memcpy((char*)b->buf + i * w, (const char*)src->data + i * w, (size_t)w);
-        b->nullbuf[i] = (x->nulls ? x->nulls[i] : 0) || (src->nulls ? src->nulls[i] : 0);
+        b->nullbuf[i] = src->nulls ? src->nulls[i] : 0;
       }
       b->nulls = any ? b->nullbuf : NULL; return;
     }

@@ -506,7 +506,9 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
       BExprP tc, ec;
       SS_RETURN_IF_ERROR(make_cast(args[1], t, true, &tc));
       SS_RETURN_IF_ERROR(make_cast(args[2], t, true, &ec));
-      *out = make_op(op, t, args[0]->nullable || tc->nullable || ec->nullable,
+      // plain (non-nulling) IF: a NULL condition takes the ELSE branch and does not make the
+      // result NULL (elementary_bound_expressions.cc:893-904,1010-1025)
+      *out = make_op(op, t, tc->nullable || ec->nullable,
                      "IF " + args[0]->name + " THEN " + tc->name + " ELSE " + ec->name, {args[0], tc, ec}, depth);
       return Status::OK();
     }

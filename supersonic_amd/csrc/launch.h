@@ -55,4 +55,22 @@ hipError_t ssgpu_launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t 
 hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, uint32_t plen, size_t n,
                                          hipStream_t stream);
 
+// sort / clusters (sort_kernels.hip)
+hipError_t ssgpu_launch_sort_iota(uint32_t* idx, uint64_t n, hipStream_t s);
+hipError_t ssgpu_launch_sort_load_keys(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width,
+                                       int kind, int descending, int null_pass, uint64_t n, hipStream_t s);
+uint32_t ssgpu_sort_tiles(uint64_t n);
+hipError_t ssgpu_launch_sort_hist(const uint64_t* keys, uint32_t shift, uint64_t n, uint32_t* hist, hipStream_t s);
+hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out,
+                                     uint32_t shift, uint64_t n, const uint32_t* offsets, hipStream_t s);
+hipError_t ssgpu_launch_sort_gather(void* out, uint8_t* out_nulls, const void* col, const uint8_t* nulls, uint32_t width,
+                                    const uint32_t* idx, uint64_t n, hipStream_t s);
+hipError_t ssgpu_launch_cluster_count(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
+                                      uint64_t n, uint32_t* tile_counts, hipStream_t s);
+hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
+                                       void* const* out_data, uint8_t* const* out_nulls, uint64_t n, const uint32_t* tile_offsets,
+                                       uint32_t* seg_id, hipStream_t s);
+hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
+                                      const GroupAggOut* outs, uint32_t n_out, hipStream_t s);
+
 #endif  // SSGPU_LAUNCH_H_

@@ -309,22 +309,25 @@ Status Emitter::value(const BExprP& e, Val* out) {
         } break;
         case OP_IF: {
           const uint16_t sop = v.width == 8 ? VM_SELECT_64 : v.width == 4 ? VM_SELECT_32 : VM_SELECT_8;
+          // choice = condition is non-NULL TRUE; a NULL condition takes the ELSE branch
           int cond = materialize(a[0]);
+          if (a[0].null >= 0) {
+            int ch = new_reg(1);
+            LInstr& c = emit(VM_SEL_FROM_PRED); c.dst = ch; c.a = cond; c.b = a[0].null;
+            cond = ch;
+          }
           Val x = a[1], y = a[2];
           if (x.imm && y.imm) { x.reg = materialize(x); x.imm = false; }
           v.reg = new_reg(v.width);
           LInstr& i = emit(sop); i.dst = v.reg; i.c = cond;
           if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = (uint8_t)x.width; } else i.a = x.reg;
           if (y.imm) { i.b_imm = true; i.imm = y.bits; i.imm_width = (uint8_t)y.width; } else i.b = y.reg;
-          int branch_null = -1;
           if (a[1].null >= 0 || a[2].null >= 0) {
-            branch_null = new_reg(1);
-            LInstr& j = emit(VM_SELECT_8); j.dst = branch_null; j.c = cond;
+            v.null = new_reg(1);
+            LInstr& j = emit(VM_SELECT_8); j.dst = v.null; j.c = cond;
             if (a[1].null >= 0) j.a = a[1].null; else { j.a_imm = true; j.imm = 0; j.imm_width = 1; }
             if (a[2].null >= 0) j.b = a[2].null; else { j.b_imm = true; j.imm = 0; j.imm_width = 1; }
-            if (j.a_imm && j.b_imm) { /* unreachable: one side has a mask */ }
           }
-          v.null = or_null(a[0].null, branch_null);
         } break;
         default:
           return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "operator has no device lowering: " + e->name);
@@ -757,8 +760,11 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
   return Status::OK();
 }
 
-static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st) {
-  st->kind = STAGE_GROUP_AGG;
+// clustered = AggregateClusters (aggregate_clusters.cc:338-520): the group id of a row is the
+// number of key changes before it, computed by a flag + scan pre-pass over the materialised
+// input (segment ids arrive as an extra staged UINT32 column) -- no hash table.
+static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st, bool clustered = false) {
+  st->kind = clustered ? STAGE_CLUSTERS : STAGE_GROUP_AGG;
   st->in_schema = pipe.in_schema;
   const Schema vs = schema_of(pipe.cols);
   std::vector<int> kpos; std::vector<std::string> knames;
@@ -774,6 +780,18 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
   Emitter em(&st->main);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
+  int slotreg = -1;
+  if (clustered) {
+    for (size_t k = 0; k < kpos.size(); ++k) {
+      const BExprP& ke = pipe.cols[kpos[k]].expr;
+      if (ke->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "clustered keys must be plain input columns");
+      if (mtype(ke->dtype) == M_BAD) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "cluster key type is outside the device hot path");
+      SortKey sk; sk.col = ke->input_col; sk.order = 0; st->sort_keys.push_back(sk);
+      Attr a; a.name = knames[k]; a.dtype = ke->dtype; a.nullable = ke->nullable;
+      st->out_schema.push_back(a);
+    }
+    slotreg = em.staged((int)pipe.in_schema.size(), false, 4);   // segment ids: synthetic last input column
+  } else {
   // pack the key columns into one 64-bit word (value bits + one NULL flag bit per nullable key)
   int keyreg = em.new_reg(8);
   { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
@@ -798,8 +816,9 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
     Attr a; a.name = knames[k]; a.dtype = ke->dtype; a.nullable = ke->nullable;
     st->out_schema.push_back(a);
   }
-  int slotreg = em.new_reg(4);
+  slotreg = em.new_reg(4);
   { LInstr& i = em.emit(VM_GRP_INSERT); i.dst = slotreg; i.a = keyreg; i.c = sel; }
+  }
   const uint64_t ng = plans.size();
   for (size_t j = 0; j < plans.size(); ++j) {
     const AggPlan& ap = plans[j];
@@ -952,8 +971,13 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         pending = false;
       } break;
       case SSGPU_OP_SORT: case SSGPU_OP_AGGREGATE_CLUSTERS: {
-        // blocking operators over materialised rows: flush the pipeline first
-        if (pending || stages->empty()) {
+        // blocking operators over materialised rows: flush the pipeline first (a pipe that is
+        // still the identity over its input needs no copy)
+        bool identity = pipe.filters.empty() && pipe.cols.size() == pipe.in_schema.size();
+        for (size_t i = 0; identity && i < pipe.cols.size(); ++i)
+          identity = pipe.cols[i].expr->kind == BExpr::INPUT && pipe.cols[i].expr->input_col == (int)i &&
+                     pipe.cols[i].name == pipe.in_schema[i].name;
+        if (!identity) {
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pipe, &m));
           stages->push_back(m);
           reset_pipe(&pipe, m.out_schema);
@@ -975,7 +999,8 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           for (size_t i = 0; i < pos.size(); ++i) { Attr a = st.in_schema[pos[i]]; a.name = names[i]; st.out_schema.push_back(a); }
           desc << "Sort -> [" << schema_to_string(st.out_schema) << "]\n";
         } else {
-          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "AggregateClusters is not lowered yet");
+          SS_RETURN_IF_ERROR(finish_group_agg(d, op, pipe, &st, true));
+          desc << "AggregateClusters -> [" << schema_to_string(st.out_schema) << "]\n";
         }
         stages->push_back(st);
         reset_pipe(&pipe, st.out_schema);

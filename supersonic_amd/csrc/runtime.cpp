@@ -87,6 +87,8 @@ struct StageExec {
   uint32_t capacity = 0;
   DevBuf error_flag;
   DevBuf debug;
+  // sort / clusters
+  DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id;
   bool emit_ready = false;
   bool pattern_ready = false;
   // outputs
@@ -615,6 +617,120 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
   return SSGPU_OK;
 }
 
+int sort_kind_of(int dtype) {   // 0 unsigned, 1 signed, 2 float32, 3 float64
+  switch (dtype) {
+    case SSGPU_INT32: case SSGPU_INT64: case SSGPU_DATE: case SSGPU_DATETIME: return 1;
+    case SSGPU_FLOAT: return 2;
+    case SSGPU_DOUBLE: return 3;
+    default: return 0;
+  }
+}
+
+int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  const uint64_t n = (uint64_t)in.rows;
+  if (n >= (1ull << 32)) { c->err = "Sort: more than 2^32 rows per GPU is not supported yet"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  int rc = ensure_out_cols(c, st, ex, in.rows);
+  if (rc != SSGPU_OK) return rc;
+  const uint32_t nt = ssgpu_sort_tiles(n);
+  HIP_TRY(c, ex.skeys_a.ensure(std::max<uint64_t>(n, 1) * 8)); HIP_TRY(c, ex.skeys_b.ensure(std::max<uint64_t>(n, 1) * 8));
+  HIP_TRY(c, ex.sidx_a.ensure(std::max<uint64_t>(n, 1) * 4)); HIP_TRY(c, ex.sidx_b.ensure(std::max<uint64_t>(n, 1) * 4));
+  HIP_TRY(c, ex.shist.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4)); HIP_TRY(c, ex.soffs.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4));
+  HIP_TRY(c, ex.total.ensure(8));
+  uint64_t* ka = ex.skeys_a.as<uint64_t>(); uint64_t* kb = ex.skeys_b.as<uint64_t>();
+  uint32_t* ia = ex.sidx_a.as<uint32_t>(); uint32_t* ib = ex.sidx_b.as<uint32_t>();
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+  auto one_pass = [&](uint32_t shift) -> int {
+    HIP_TRY(c, ssgpu_launch_sort_hist(ka, shift, n, ex.shist.as<uint32_t>(), c->stream));
+    HIP_TRY(c, ssgpu_launch_scan_counts(ex.shist.as<uint32_t>(), ex.soffs.as<uint32_t>(), (int)(nt * 256), ex.total.as<uint64_t>(), c->stream));
+    HIP_TRY(c, ssgpu_launch_sort_scatter(ka, ia, kb, ib, shift, n, ex.soffs.as<uint32_t>(), c->stream));
+    std::swap(ka, kb); std::swap(ia, ib);
+    p->counters.n_launches += 3;
+    return SSGPU_OK;
+  };
+  // least significant key first; each key: value digits, then the NULL-order bit on top
+  for (int k = (int)st.sort_keys.size() - 1; k >= 0 && n > 0; --k) {
+    const SortKey& sk = st.sort_keys[k];
+    const int dtype = st.in_schema[sk.col].dtype;
+    const uint32_t w = (uint32_t)dtype_width(dtype);
+    const uint8_t* nulls = in.cols[sk.col].is_null;
+    HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, in.cols[sk.col].data, nulls, w, sort_kind_of(dtype), sk.order == SSGPU_DESCENDING, 0, n, c->stream));
+    for (uint32_t pass = 0; pass < w; ++pass) { rc = one_pass(pass * 8); if (rc != SSGPU_OK) return rc; }
+    if (nulls && st.in_schema[sk.col].nullable) {
+      HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, in.cols[sk.col].data, nulls, w, 0, sk.order == SSGPU_DESCENDING, 1, n, c->stream));
+      rc = one_pass(0); if (rc != SSGPU_OK) return rc;
+    }
+  }
+  for (size_t i = 0; i < st.sort_out_cols.size(); ++i) {
+    const int col = st.sort_out_cols[i];
+    HIP_TRY(c, ssgpu_launch_sort_gather(ex.out[i].data.p, ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr,
+                                        in.cols[col].data, in.cols[col].is_null, ex.out[i].width, ia, n, c->stream));
+  }
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  ex.out_rows = in.rows;
+  return SSGPU_OK;
+}
+
+int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  const uint64_t n = (uint64_t)in.rows;
+  const uint32_t nk = (uint32_t)st.sort_keys.size();
+  const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  const void* kdata[16] = {nullptr}; const uint8_t* knulls[16] = {nullptr}; uint32_t kwidth[16] = {0};
+  for (uint32_t k = 0; k < nk; ++k) {
+    const int col = st.sort_keys[k].col;
+    kdata[k] = in.cols[col].data; knulls[k] = in.cols[col].is_null; kwidth[k] = (uint32_t)dtype_width(st.in_schema[col].dtype);
+  }
+  const int ntile = (int)((n + 511) / 512);
+  HIP_TRY(c, ex.tile_counts.ensure((size_t)std::max(ntile, 1) * 4)); HIP_TRY(c, ex.tile_offsets.ensure((size_t)std::max(ntile, 1) * 4));
+  HIP_TRY(c, ex.total.ensure(8)); HIP_TRY(c, ex.seg_id.ensure(std::max<uint64_t>(n, 1) * 4));
+  HIP_TRY(c, hipMemsetAsync(ex.total.p, 0, 8, c->stream));
+  HIP_TRY(c, ssgpu_launch_cluster_count(kdata, knulls, kwidth, nk, n, ex.tile_counts.as<uint32_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), ntile, ex.total.as<uint64_t>(), c->stream));
+  uint64_t nseg = 0;
+  HIP_TRY(c, hipMemcpyAsync(&nseg, ex.total.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = ensure_out_cols(c, st, ex, (int64_t)nseg);
+  if (rc != SSGPU_OK) return rc;
+  void* okdata[16] = {nullptr}; uint8_t* oknulls[16] = {nullptr};
+  for (uint32_t k = 0; k < nk; ++k) { okdata[k] = ex.out[k].data.p; oknulls[k] = ex.out[k].nullable ? ex.out[k].nulls.as<uint8_t>() : nullptr; }
+  HIP_TRY(c, ssgpu_launch_cluster_assign(kdata, knulls, kwidth, nk, okdata, oknulls, n, ex.tile_offsets.as<uint32_t>(), ex.seg_id.as<uint32_t>(), c->stream));
+  const size_t slots = (size_t)std::max<uint64_t>(nseg, 1);
+  HIP_TRY(c, ex.gacc.ensure(slots * ng * 8)); HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4)); HIP_TRY(c, ex.gpattern.ensure(ng * 8));
+  if (!ex.pattern_ready) {
+    std::vector<uint64_t> pattern(ng, 0);
+    for (size_t i = 0; i < st.group_acc_init.size(); ++i) pattern[i] = st.group_acc_init[i];
+    HIP_TRY(c, hipMemcpy(ex.gpattern.p, pattern.data(), ng * 8, hipMemcpyHostToDevice));
+    ex.pattern_ready = true;
+  }
+  HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>(), ex.gpattern.as<uint64_t>(), ng, slots * ng, c->stream));
+  HIP_TRY(c, hipMemsetAsync(ex.gcnt.p, 0, slots * ng * 4, c->stream));
+  HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
+  InCols ext = in;
+  ssgpu_column segcol; segcol.data = ex.seg_id.p; segcol.is_null = nullptr;
+  ext.cols.push_back(segcol);
+  VmParams P;
+  fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, ext, row_id_base);
+  P.error_flag = ex.error_flag.as<unsigned int>();
+  P.group.acc = ex.gacc.as<unsigned long long>();
+  P.group.cnt = ex.gcnt.as<unsigned int>();
+  const int grid = grid_for(c, ex.lay, P.n_tiles);
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  std::vector<GroupAggOut> outs(st.aggs.size());
+  for (size_t j = 0; j < st.aggs.size(); ++j) {
+    outs[j].data = ex.out[nk + j].data.p;
+    outs[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
+    outs[j].s = st.aggs[j].slot; outs[j].out_kind = st.aggs[j].emit_kind; outs[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
+  }
+  HIP_TRY(c, ssgpu_launch_dense_extract(ex.gacc.as<uint64_t>(), ex.gcnt.as<uint32_t>(), ng, nseg, outs.data(), (uint32_t)outs.size(), c->stream));
+  p->counters.n_launches += 6;
+  ex.out_rows = (int64_t)nseg;
+  return SSGPU_OK;
+}
+
 int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
   ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[si];
   if (ex.out_rows < 0) {
@@ -671,6 +787,8 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
         break;
       case STAGE_MATERIALIZE: rc = run_materialize(p, si, in, row_id_base); break;
       case STAGE_GROUP_AGG: rc = run_group_agg(p, si, in, row_id_base); break;
+      case STAGE_SORT: rc = run_sort(p, si, in); break;
+      case STAGE_CLUSTERS: rc = run_clusters(p, si, in, row_id_base); break;
       default: c->err = "stage kind not executable yet"; rc = SSGPU_ERROR_NOT_IMPLEMENTED; break;
     }
     if (rc != SSGPU_OK) return rc;

@@ -1,3 +1,303 @@
-// sort_kernels.hip -- device radix sort for the Sort operator (placeholder TU,
-// filled in by the sort milestone).
+// sort_kernels.hip -- device kernels of the Sort and AggregateClusters operators.
+//
+// Sort (supersonic/cursor/core/sort.cc:781-805 SortPermutation + :182-238, gather through
+// ViewCursorWithSelectionVector, cursor/infrastructure/view_cursor.cc:97-118): the reference
+// sorts an int64 permutation with std::sort and gathers rows 1024 at a time.  Here: an LSD
+// radix sort of (64-bit order-preserving key, row id) pairs, 8 bits per pass, stable, one
+// pass sequence per key column from the least to the most significant key; NULL ordering
+// (first for ASCENDING, last for DESCENDING) is one extra 1-bit pass per nullable key.
+// Every pass is HBM-bound: histogram reads the keys once, scatter reads and writes
+// (key, id) once; payload columns are gathered exactly once at the end.
+//
+// AggregateClusters (cursor/core/aggregate_clusters.cc:97-122,286-315): cluster boundary
+// flags + exclusive scan give every row its output row ("segment id").
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "launch.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int u32;
+typedef unsigned char u8;
+
+#define SORT_THREADS 256
+#define SORT_ITEMS 16                       /* keys per thread */
+#define SORT_TILE (SORT_THREADS * SORT_ITEMS) /* 4096 keys per workgroup */
+
+// ---- key construction -------------------------------------------------------------------
+// kind: 0 unsigned, 1 signed, 2 float32, 3 float64, 4 bool
+__device__ __forceinline__ u64 order_key(const void* col, u32 width, int kind, u64 row) {
+  u64 k;
+  if (width == 8) k = reinterpret_cast<const u64*>(col)[row];
+  else if (width == 4) k = reinterpret_cast<const u32*>(col)[row];
+  else k = reinterpret_cast<const u8*>(col)[row];
+  switch (kind) {
+    case 1: k = width == 8 ? (k ^ 0x8000000000000000ull) : (u64)((u32)k ^ 0x80000000u); break;
+    case 2: { u32 b = (u32)k; b = (b & 0x80000000u) ? ~b : (b | 0x80000000u); k = b; } break;
+    case 3: k = (k & 0x8000000000000000ull) ? ~k : (k | 0x8000000000000000ull); break;
+    default: break;
+  }
+  return k;
+}
+
+__global__ void ssgpu_sort_iota_kernel(u32* __restrict__ idx, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = (u32)i;
+}
+
+// keys[i] = transform(col[idx[i]]) (descending: complemented), or the NULL-order bit
+__global__ void ssgpu_sort_load_keys_kernel(u64* __restrict__ keys, const u32* __restrict__ idx, const void* __restrict__ col,
+                                            const u8* __restrict__ nulls, u32 width, int kind, int descending,
+                                            int null_pass, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 row = idx[i];
+  u64 k;
+  if (null_pass) {
+    const bool isnull = nulls && nulls[row];
+    k = descending ? (isnull ? 1ull : 0ull) : (isnull ? 0ull : 1ull);   // NULLs first ASC, last DESC
+  } else {
+    k = order_key(col, width, kind, row);
+    if (descending) k = ~k;
+    if (nulls && nulls[row]) k = 0;   // value of a NULL row is unspecified: make ties deterministic
+  }
+  keys[i] = k;
+}
+
+// per-tile digit histogram -> hist[digit * n_tiles + tile]
+__global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_hist_kernel(const u64* __restrict__ keys, u32 shift, u64 n,
+                                                                       u32 n_tiles, u32* __restrict__ hist) {
+  __shared__ u32 h[256];
+  const int t = threadIdx.x;
+  h[t] = 0;
+  __syncthreads();
+  const u64 base = (u64)blockIdx.x * SORT_TILE;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u64 i = base + (u64)j * SORT_THREADS + t;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  hist[(u64)t * n_tiles + blockIdx.x] = h[t];
+}
+
+// stable scatter: element order inside a tile is (wave, step, lane); ranks of equal digits by
+// wave-level match (8 ballots) on top of running per-wave digit counters in LDS
+__global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
+    const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
+    u32 shift, u64 n, u32 n_tiles, const u32* __restrict__ offsets) {
+  __shared__ u32 wave_cnt[4][256];   // running offsets per wave and digit
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u64 tile_base = (u64)blockIdx.x * SORT_TILE;
+  const u64 wave_base = tile_base + (u64)wave * (SORT_TILE / 4);
+  // phase 1: per-wave histograms
+  for (int d = lane; d < 256; d += 64) wave_cnt[wave][d] = 0;
+  __syncthreads();
+  u64 k[SORT_ITEMS]; u32 id[SORT_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u64 i = wave_base + (u64)j * 64 + lane;
+    const bool ok = i < n;
+    k[j] = ok ? keys_in[i] : ~0ull;
+    id[j] = ok ? idx_in[i] : 0u;
+    if (ok) atomicAdd(&wave_cnt[wave][(k[j] >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  // wave bases: global offset of (digit, tile) + counts of the earlier waves of this tile
+  for (int d = t; d < 256; d += SORT_THREADS) {
+    u32 run = offsets[(u64)d * n_tiles + blockIdx.x];
+    for (int w = 0; w < 4; ++w) { const u32 c = wave_cnt[w][d]; wave_cnt[w][d] = run; run += c; }
+  }
+  __syncthreads();
+  // phase 2: rank and scatter, 64 consecutive elements per step
+  const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u64 i = wave_base + (u64)j * 64 + lane;
+    const bool ok = i < n;
+    const u32 d = (u32)(k[j] >> shift) & 0xFF;
+    u64 peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const u64 bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    if (ok) {
+      const u32 rank = (u32)__popcll(peers & lt);
+      const u32 pos = wave_cnt[wave][d] + rank;
+      keys_out[pos] = k[j];
+      idx_out[pos] = id[j];
+    }
+    // one lane per digit group advances the running counter (after every lane has read it)
+    __builtin_amdgcn_wave_barrier();
+    if (ok && (peers & lt) == 0) wave_cnt[wave][d] += (u32)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// out[i] = col[idx[i]] for one column (and its NULL mask)
+__global__ void ssgpu_sort_gather_kernel(void* __restrict__ out, u8* __restrict__ out_nulls, const void* __restrict__ col,
+                                         const u8* __restrict__ nulls, u32 width, const u32* __restrict__ idx, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 r = idx[i];
+  if (width == 8) reinterpret_cast<u64*>(out)[i] = reinterpret_cast<const u64*>(col)[r];
+  else if (width == 4) reinterpret_cast<u32*>(out)[i] = reinterpret_cast<const u32*>(col)[r];
+  else reinterpret_cast<u8*>(out)[i] = reinterpret_cast<const u8*>(col)[r];
+  if (out_nulls) out_nulls[i] = nulls ? nulls[r] : (u8)0;
+}
+
+// ---- AggregateClusters: boundary flags --------------------------------------------------
+struct ClusterKeys { const void* data[16]; const u8* nulls[16]; u32 width[16]; u32 n; };
+
+__device__ __forceinline__ bool cluster_boundary(const ClusterKeys& K, u64 i) {
+  if (i == 0) return true;
+  for (u32 k = 0; k < K.n; ++k) {
+    const bool an = K.nulls[k] && K.nulls[k][i], bn = K.nulls[k] && K.nulls[k][i - 1];
+    if (an != bn) return true;
+    if (an) continue;   // NULL == NULL (aggregate_clusters.cc:97-122)
+    const u32 w = K.width[k];
+    if (w == 8) { if (reinterpret_cast<const u64*>(K.data[k])[i] != reinterpret_cast<const u64*>(K.data[k])[i - 1]) return true; }
+    else if (w == 4) { if (reinterpret_cast<const u32*>(K.data[k])[i] != reinterpret_cast<const u32*>(K.data[k])[i - 1]) return true; }
+    else { if (reinterpret_cast<const u8*>(K.data[k])[i] != reinterpret_cast<const u8*>(K.data[k])[i - 1]) return true; }
+  }
+  return false;
+}
+
+// pass 1: per-tile (512 rows) boundary counts
+__global__ __launch_bounds__(256) void ssgpu_cluster_count_kernel(const ClusterKeys K, u64 n, u32* __restrict__ tile_counts) {
+  __shared__ u32 wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u64 r0 = (u64)blockIdx.x * 512 + 2 * t;
+  const bool f0 = r0 < n && cluster_boundary(K, r0), f1 = (r0 + 1) < n && cluster_boundary(K, r0 + 1);
+  const u32 c = (u32)__popcll(__ballot(f0)) + (u32)__popcll(__ballot(f1));
+  if (lane == 0) wsum[wave] = c;
+  __syncthreads();
+  if (t == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: seg_id[i] = (#boundaries in [0, i]) - 1; key columns of each new segment are emitted
+struct ClusterKeyOut { void* data[16]; u8* nulls[16]; };
+__global__ __launch_bounds__(256) void ssgpu_cluster_assign_kernel(const ClusterKeys K, const ClusterKeyOut O, u64 n,
+                                                                    const u32* __restrict__ tile_offsets, u32* __restrict__ seg_id) {
+  __shared__ u32 wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u64 r0 = (u64)blockIdx.x * 512 + 2 * t;
+  const bool f0 = r0 < n && cluster_boundary(K, r0), f1 = (r0 + 1) < n && cluster_boundary(K, r0 + 1);
+  const u64 b0 = __ballot(f0), b1 = __ballot(f1);
+  if (lane == 0) wsum[wave] = (u32)__popcll(b0) + (u32)__popcll(b1);
+  __syncthreads();
+  u32 base = tile_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const u64 lt = (1ull << lane) - 1ull;
+  const u32 before = base + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);   // boundaries before row r0
+  const u32 s0 = before + (f0 ? 1u : 0u) - 1u, s1 = s0 + (f1 ? 1u : 0u);
+  const bool ff[2] = {f0, f1}; const u32 ss[2] = {s0, s1};
+  for (int j = 0; j < 2; ++j) {
+    const u64 r = r0 + j;
+    if (r >= n) continue;
+    seg_id[r] = ss[j];
+    if (!ff[j]) continue;
+    for (u32 k = 0; k < K.n; ++k) {
+      const bool isnull = K.nulls[k] && K.nulls[k][r];
+      const u32 w = K.width[k];
+      if (w == 8) reinterpret_cast<u64*>(O.data[k])[ss[j]] = isnull ? 0ull : reinterpret_cast<const u64*>(K.data[k])[r];
+      else if (w == 4) reinterpret_cast<u32*>(O.data[k])[ss[j]] = isnull ? 0u : reinterpret_cast<const u32*>(K.data[k])[r];
+      else reinterpret_cast<u8*>(O.data[k])[ss[j]] = isnull ? (u8)0 : reinterpret_cast<const u8*>(K.data[k])[r];
+      if (O.nulls[k]) O.nulls[k][ss[j]] = isnull;
+    }
+  }
+}
+
+// dense extraction of per-segment aggregates (same record layout as the group table)
+struct DenseAggOut { void* data; u8* is_null; int s; int out_kind; int has_cnt; int pad; };
+struct DenseExtractParams { const u64* acc; const u32* cnt; u32 n_gaggs; u32 n_out; u64 n_rows; DenseAggOut out[VM_MAX_AGG_SLOTS]; };
+
+__device__ __forceinline__ void dense_emit(void* dst, u64 idx, int kind, u64 v0) {
+  switch (kind) {
+    case EMIT_U64: reinterpret_cast<u64*>(dst)[idx] = v0; break;
+    case EMIT_I64KEY: reinterpret_cast<i64*>(dst)[idx] = (i64)(v0 ^ 0x8000000000000000ull); break;
+    case EMIT_U32: reinterpret_cast<u32*>(dst)[idx] = (u32)v0; break;
+    case EMIT_I32KEY: reinterpret_cast<int*>(dst)[idx] = (int)(i64)(v0 ^ 0x8000000000000000ull); break;
+    case EMIT_F64: reinterpret_cast<u64*>(dst)[idx] = v0; break;
+    case EMIT_F32: { double d = __longlong_as_double((i64)v0); reinterpret_cast<float*>(dst)[idx] = (float)d; } break;
+    case EMIT_U8: reinterpret_cast<u8*>(dst)[idx] = (u8)(v0 != 0); break;
+    case EMIT_FKEY_F64: { u64 b = (v0 & 0x8000000000000000ull) ? (v0 & 0x7FFFFFFFFFFFFFFFull) : ~v0; reinterpret_cast<u64*>(dst)[idx] = b; } break;
+    case EMIT_FKEY_F32: { u64 b = (v0 & 0x8000000000000000ull) ? (v0 & 0x7FFFFFFFFFFFFFFFull) : ~v0;
+                          reinterpret_cast<float*>(dst)[idx] = (float)__longlong_as_double((i64)b); } break;
+    default: break;
+  }
+}
+__global__ void ssgpu_dense_extract_kernel(const DenseExtractParams P) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_rows) return;
+  for (u32 q = 0; q < P.n_out; ++q) {
+    const DenseAggOut o = P.out[q];
+    dense_emit(o.data, i, o.out_kind, P.acc[i * P.n_gaggs + o.s]);
+    if (o.is_null) o.is_null[i] = o.has_cnt ? (P.cnt[i * P.n_gaggs + o.s] == 0) : 0;
+  }
+}
+
+// ---- launchers ------------------------------------------------------------------------------
+static inline int blocks_for(uint64_t n, int per) { return (int)((n + per - 1) / per); }
+
+hipError_t ssgpu_launch_sort_iota(uint32_t* idx, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, idx, (u64)n);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_load_keys(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width,
+                                       int kind, int descending, int null_pass, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_load_keys_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)keys, idx, col, nulls, width,
+                            kind, descending, null_pass, (u64)n);
+  return hipGetLastError();
+}
+uint32_t ssgpu_sort_tiles(uint64_t n) { return (uint32_t)((n + SORT_TILE - 1) / SORT_TILE); }
+hipError_t ssgpu_launch_sort_hist(const uint64_t* keys, uint32_t shift, uint64_t n, uint32_t* hist, hipStream_t s) {
+  const uint32_t nt = ssgpu_sort_tiles(n);
+  if (nt) hipLaunchKernelGGL(ssgpu_sort_hist_kernel, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys, shift, (u64)n, nt, hist);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out,
+                                     uint32_t shift, uint64_t n, const uint32_t* offsets, hipStream_t s) {
+  const uint32_t nt = ssgpu_sort_tiles(n);
+  if (nt) hipLaunchKernelGGL(ssgpu_sort_scatter_kernel, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out,
+                             idx_out, shift, (u64)n, nt, offsets);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_gather(void* out, uint8_t* out_nulls, const void* col, const uint8_t* nulls, uint32_t width,
+                                    const uint32_t* idx, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_gather_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, out, out_nulls, col, nulls, width, idx, (u64)n);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_cluster_count(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
+                                      uint64_t n, uint32_t* tile_counts, hipStream_t s) {
+  ClusterKeys K; K.n = nkeys;
+  for (uint32_t k = 0; k < 16; ++k) { K.data[k] = k < nkeys ? data[k] : nullptr; K.nulls[k] = k < nkeys ? nulls[k] : nullptr; K.width[k] = k < nkeys ? width[k] : 0; }
+  const int nt = blocks_for(n, 512);
+  if (nt) hipLaunchKernelGGL(ssgpu_cluster_count_kernel, dim3(nt), dim3(256), 0, s, K, (u64)n, tile_counts);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
+                                       void* const* out_data, uint8_t* const* out_nulls, uint64_t n, const uint32_t* tile_offsets,
+                                       uint32_t* seg_id, hipStream_t s) {
+  ClusterKeys K; K.n = nkeys; ClusterKeyOut O;
+  for (uint32_t k = 0; k < 16; ++k) {
+    K.data[k] = k < nkeys ? data[k] : nullptr; K.nulls[k] = k < nkeys ? nulls[k] : nullptr; K.width[k] = k < nkeys ? width[k] : 0;
+    O.data[k] = k < nkeys ? out_data[k] : nullptr; O.nulls[k] = k < nkeys ? out_nulls[k] : nullptr;
+  }
+  const int nt = blocks_for(n, 512);
+  if (nt) hipLaunchKernelGGL(ssgpu_cluster_assign_kernel, dim3(nt), dim3(256), 0, s, K, O, (u64)n, tile_offsets, seg_id);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
+                                      const GroupAggOut* outs, uint32_t n_out, hipStream_t s) {
+  DenseExtractParams P; memset(&P, 0, sizeof(P));
+  P.acc = (const u64*)acc; P.cnt = cnt; P.n_gaggs = n_gaggs; P.n_out = n_out; P.n_rows = n_rows;
+  for (uint32_t q = 0; q < n_out; ++q) {
+    P.out[q].data = outs[q].data; P.out[q].is_null = outs[q].is_null; P.out[q].s = outs[q].s;
+    P.out[q].out_kind = outs[q].out_kind; P.out[q].has_cnt = outs[q].has_cnt;
+  }
+  if (n_rows) hipLaunchKernelGGL(ssgpu_dense_extract_kernel, dim3(blocks_for(n_rows, 256)), dim3(256), 0, s, P);
+  return hipGetLastError();
+}

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Golden vectors transcribed (as DATA: inputs and expected outputs) from the reference's own
+tests for the Filter -> Project/Compute -> Aggregate (+Sort) path.  Running this script rewrites
+tests/golden/reference_tests.json.  Every case cites the reference test it restates.
+
+Conventions
+  * None is the NULL literal (`__` in supersonic/testing/block_builder.h).
+  * Expression tests of the reference are `BlockBuilder<In..., Out>` tables whose LAST column is
+    the expected result of `Factory(AttributeAt(0), AttributeAt(1), ...)`
+    (supersonic/testing/expression_test_helper.h:89-95): here "plan" = Compute(expr, Scan).
+  * Operation tests use TestDataBuilder: columns are named col0, col1, ... and are NULLABLE
+    (supersonic/testing/block_builder.h); here likewise.
+  * STRING payload columns of the reference's operation tests are outside the device hot path
+    (SURVEY 8f.2); they are substituted by INT64 codes with the same ordering ("a" < "b" < ...),
+    which keeps which-rows-pass / which-group / sort-order semantics intact.  Cases whose POINT
+    is a STRING feature are not transcribed.
+  * FakePredicate(values, nulls) of filter_test.cc:52-135 is restated as an input BOOL column
+    "p" that the filter reads with NamedAttribute("p") and then projects away.
+"""
+import json
+import os
+
+I32, I64, U32, U64, F32, F64, BOOL, DATE = "INT32", "INT64", "UINT32", "UINT64", "FLOAT", "DOUBLE", "BOOL", "DATE"
+INF, NAN = "inf", "nan"
+CASES = []
+
+
+def expr_case(name, source, types, rows, factory, nullable=True, expect_name=None, expect_type=None,
+              expect_nullable=None, expect_error=None):
+    """types: input types + output type (last); rows: input values + expected (last)."""
+    n_in = len(types) - 1
+    CASES.append({
+        "name": name, "source": source, "kind": "expression",
+        "input": {"schema": [["col%d" % i, types[i], nullable] for i in range(n_in)],
+                  "rows": [r[:n_in] for r in rows]},
+        "plan": ["Compute", [factory] + [["AttributeAt", i] for i in range(n_in)], "INPUT"],
+        "expected": {"types": [types[-1]], "rows": [[r[-1]] for r in rows],
+                     "names": [expect_name] if expect_name else None,
+                     "nullable": [expect_nullable] if expect_nullable is not None else None},
+        "ordered": True, "expect_error": expect_error})
+
+
+def bind_case(name, source, factory, in_types, in_nullable, out_name, out_type, out_nullable, expect_error=None):
+    n_in = len(in_types)
+    CASES.append({
+        "name": name, "source": source, "kind": "binding",
+        "input": {"schema": [["$%d" % i, in_types[i], in_nullable[i]] for i in range(n_in)], "rows": []},
+        "plan": ["Compute", [factory] + [["AttributeAt", i] for i in range(n_in)], "INPUT"],
+        "expected": {"types": [out_type] if out_type else None, "rows": [], "names": [out_name] if out_name else None,
+                     "nullable": [out_nullable] if out_nullable is not None else None},
+        "ordered": True, "expect_error": expect_error})
+
+
+def op_case(name, source, schema, rows, plan, exp_types, exp_rows, ordered=True, exp_names=None, exp_nullable=None,
+            expect_error=None):
+    CASES.append({
+        "name": name, "source": source, "kind": "operation",
+        "input": {"schema": schema, "rows": rows}, "plan": plan,
+        "expected": {"types": exp_types, "rows": exp_rows, "names": exp_names, "nullable": exp_nullable},
+        "ordered": ordered, "expect_error": expect_error})
+
+
+def cols(types, nullable=True):
+    return [["col%d" % i, t, nullable] for i, t in enumerate(types)]
+
+
+A = "supersonic/expression/core/arithmetic_expressions_test.cc"
+E = "supersonic/expression/core/elementary_expressions_test.cc"
+
+# ---- arithmetic (arithmetic_expressions_test.cc) ---------------------------------------------
+bind_case("NegateBinding_double", A + ":25-27", "Negate", [F64], [False], "(-$0)", F64, False)
+bind_case("NegateBinding_int32", A + ":25-28", "Negate", [I32], [False], "(-$0)", I32, False)
+bind_case("NegateBinding_uint32", A + ":25-29", "Negate", [U32], [False], "(-CAST_UINT32_TO_INT32($0))", I32, False)
+expr_case("Negate_float", A + ":34-40", [F32, F32], [[3., -3.], [0., -0.], [-3., 3.], [11.2, -11.2]], "Negate")
+expr_case("Negate_uint64", A + ":42-46", [U64, I64], [[0, 0], [4, -4], [12314, -12314]], "Negate")
+expr_case("Negate_uint32_null", A + ":48-52", [U32, I32], [[13, -13], [None, None], [0, 0]], "Negate")
+bind_case("PlusBinding_int64", A + ":60-61", "Plus", [I64, I64], [False, False], "($0 + $1)", I64, False)
+bind_case("PlusBinding_nullable", A + ":62-63", "Plus", [I64, I64], [False, True], "($0 + $1)", I64, True)
+bind_case("PlusBinding_uint64_float", A + ":64-65", "Plus", [U64, F32], [False, False],
+          "(CAST_UINT64_TO_DOUBLE($0) + CAST_FLOAT_TO_DOUBLE($1))", F64, False)
+expr_case("Plus", A + ":68-75", [I64, I64, I64], [[-1, 1, 0], [-2, 2, 0], [2, 2, 4], [13, 1, 14]], "Plus")
+expr_case("PlusNullable", A + ":77-83", [I64, I64, I64], [[1, None, None], [-1, 2, 1], [None, 2, None]], "Plus")
+expr_case("PlusLeftColumnNullable", A + ":85-91", [I64, I64, I64], [[-1, 2, 1], [-1, -2, -3], [None, 2, None]], "Plus")
+expr_case("PlusDifferentTypes", A + ":93-100", [I64, I32, I64], [[-1, 1, 0], [-2, 2, 0], [2, 2, 4], [3, 1, 4]], "Plus")
+bind_case("Binding_Minus", A + ":103-104", "Minus", [I64, I64], [False, False], "($0 - $1)", I64, False)
+bind_case("Binding_Multiply", A + ":105-106", "Multiply", [I64, I64], [False, False], "($0 * $1)", I64, False)
+bind_case("Binding_DivideSignaling", A + ":107-108", "DivideSignaling", [F64, F64], [False, False], "($0 /. $1)", F64, False)
+bind_case("Binding_DivideQuiet", A + ":109-110", "DivideQuiet", [F64, F64], [False, False], "($0 /. $1)", F64, False)
+bind_case("Binding_CppDivideSignaling", A + ":111-112", "CppDivideSignaling", [I32, I32], [False, False], "($0 / $1)", I32, False)
+bind_case("Binding_ModulusSignaling", A + ":113-114", "ModulusSignaling", [U32, U32], [False, False], "($0 % $1)", U32, False)
+bind_case("Binding_CppDivideNulling", A + ":116-117", "CppDivideNulling", [I64, I64], [False, False], "($0 / $1)", I64, True)
+bind_case("Binding_ModulusNulling", A + ":118-119", "ModulusNulling", [I32, I32], [False, False], "($0 % $1)", I32, True)
+bind_case("Binding_DivideNulling", A + ":120-121", "DivideNulling", [F64, F64], [False, False], "($0 /. $1)", F64, True)
+bind_case("Binding_ModulusNulling_cast", A + ":123-124", "ModulusNulling", [I64, I32], [False, False],
+          "($0 % CAST_INT32_TO_INT64($1))", I64, True)
+expr_case("Minus", A + ":126-133", [I64, I32, I64], [[1, None, None], [2, -1, 3], [-1, 2, -3], [None, 2, None]], "Minus")
+expr_case("Multiply", A + ":135-143", [I64, I32, I64], [[1, None, None], [2, 2, 4], [2, 0, 0], [20, 20, 400], [None, 2, None]], "Multiply")
+expr_case("DivideQuiet", A + ":145-153", [I64, I32, F64], [[2, 2, 1.], [3, 1, 3.], [1, 2, 0.5], [1, 0, INF], [0, 0, NAN]], "DivideQuiet")
+expr_case("DivideNulling", A + ":155-163", [I64, F32, F64], [[2, 2, 1.], [3, 1, 3.], [1, 2, 0.5], [1, 0, None], [0, 0, None]], "DivideNulling")
+expr_case("DivideSignaling_fails", A + ":172-175", [F64, I32, F64], [[1, 0, None], [0, 0, None]], "DivideSignaling", expect_error=104)
+expr_case("CppDivideNulling", A + ":178-186", [I64, I32, I64], [[5, 2, 2], [2, 2, 1], [-3, 1, -3], [3, 0, None], [0, 3, 0]], "CppDivideNulling")
+expr_case("CppDivideSignaling", A + ":188-197", [I32, I32, I32],
+          [[5, 2, 2], [2, 2, 1], [-3, 1, -3], [0, 3, 0], [None, 0, None], [0, None, None]], "CppDivideSignaling")
+expr_case("CppDivideSignaling_fails", A + ":199-203", [I32, I32, I32], [[3, 0, None], [0, 0, None], [-1, 0, None]],
+          "CppDivideSignaling", expect_error=104)
+expr_case("ModulusNulling", A + ":206-216", [I32, I32, I32],
+          [[5, 2, 1], [-1, 5, -1], [0, 3, 0], [7, 5, 2], [None, 4, None], [4, 0, None], [4, -3, 1]], "ModulusNulling")
+expr_case("ModulusSignaling", A + ":218-227", [I32, I32, I32],
+          [[5, 2, 1], [-1, 5, -1], [0, 3, 0], [7, 5, 2], [None, 4, None], [-4, -3, -1]], "ModulusSignaling")
+expr_case("ModulusSignaling_fails", A + ":229-232", [I64, I64, I64], [[1, 0, None], [0, 0, None]], "ModulusSignaling", expect_error=104)
+
+# ---- logic / IS NULL / IF (elementary_expressions_test.cc) -----------------------------------
+bind_case("NotBinding", E + ":256-257", "Not", [BOOL], [False], "(NOT $0)", BOOL, False)
+bind_case("NotBinding_int32_fails", E + ":261", "Not", [I32], [False], None, None, None, expect_error=402)
+expr_case("Not", E + ":264-270", [BOOL, BOOL], [[False, True], [True, False], [None, None]], "Not")
+expr_case("IsNull", E + ":272-281", [I32, BOOL], [[1, False], [None, True], [4, False], [1, False], [0, False], [None, True]], "IsNull")
+bind_case("Binding_And", E + ":323-324", "And", [BOOL, BOOL], [False, False], "($0 AND $1)", BOOL, False)
+bind_case("Binding_AndNot", E + ":325", "AndNot", [BOOL, BOOL], [False, False], "($0 !&& $1)", BOOL, False)
+bind_case("Binding_Or", E + ":326", "Or", [BOOL, BOOL], [False, False], "($0 OR $1)", BOOL, False)
+bind_case("Binding_Xor", E + ":327", "Xor", [BOOL, BOOL], [False, False], "($0 XOR $1)", BOOL, False)
+bind_case("BindingIfNull_notnull_left", E + ":331", "IfNull", [I32, I32], [False, False], "$0", I32, False)
+bind_case("BindingIfNull_nullable_left", E + ":332-333", "IfNull", [I32, I32], [True, False], "IFNULL($0, $1)", I32, False)
+bind_case("BindingIfNull_both_nullable", E + ":335-336", "IfNull", [I32, I32], [True, True], "IFNULL($0, $1)", I32, True)
+bind_case("BindingIfNull_cast_left", E + ":342-343", "IfNull", [I32, I64], [False, False], "CAST_INT32_TO_INT64($0)", I64, False)
+bind_case("BindingIfNull_bool_int_fails", E + ":347", "IfNull", [BOOL, I32], [False, False], None, None, None, expect_error=402)
+bind_case("BindingIfNullWithCast", E + ":350-353", "IfNull", [I32, F32], [True, False], "IFNULL(CAST_INT32_TO_FLOAT($0), $1)", F32, False)
+expr_case("IfNull", E + ":355-364", [I64, I64, I64],
+          [[1, 20, 1], [10, 20, 10], [None, 20, 20], [None, 15, 15], [7, None, 7], [None, None, None]], "IfNull")
+expr_case("IfNullWithCast", E + ":366-375", [I64, I32, I64],
+          [[1, 20, 1], [10, 20, 10], [None, 20, 20], [None, 15, 15], [7, None, 7], [None, None, None]], "IfNull")
+T, F, N = True, False, None
+expr_case("Xor", E + ":396-410", [BOOL, BOOL, BOOL],
+          [[T, T, F], [T, F, T], [T, N, N], [F, T, T], [F, F, F], [F, N, N], [N, T, N], [N, F, N], [N, N, N]], "Xor")
+bind_case("Xor_bool_int_fails", E + ":398", "Xor", [BOOL, I32], [False, False], None, None, None, expect_error=402)
+expr_case("And", E + ":421-433", [BOOL, BOOL, BOOL],
+          [[F, F, F], [F, T, F], [F, N, F], [T, F, F], [T, T, T], [T, N, N], [N, F, F], [N, T, N], [N, N, N]], "And")
+expr_case("AndWithoutNulls", E + ":435-442", [BOOL, BOOL, BOOL], [[F, F, F], [F, T, F], [T, F, F], [T, T, T]], "And", nullable=False)
+expr_case("Or", E + ":462-474", [BOOL, BOOL, BOOL],
+          [[F, F, F], [F, T, T], [F, N, N], [T, F, T], [T, T, T], [T, N, T], [N, F, N], [N, T, T], [N, N, N]], "Or")
+expr_case("OrNotNullable", E + ":495-502", [BOOL, BOOL, BOOL], [[F, F, F], [T, F, T], [F, T, T], [T, T, T]], "Or", nullable=False)
+expr_case("AndNot", E + ":504-516", [BOOL, BOOL, BOOL],
+          [[F, F, F], [F, T, T], [F, N, N], [T, F, F], [T, T, F], [T, N, F], [N, F, F], [N, T, N], [N, N, N]], "AndNot")
+bind_case("BasicIf_binding", E + ":622-623", "If", [BOOL, I32, I32], [False, False, False], "IF $0 THEN $1 ELSE $2", I32, False)
+expr_case("BasicIf", E + ":625-629", [BOOL, I32, I32, I32], [[T, 1, 2, 1], [F, 3, 4, 4], [T, 1, 1, 1]], "If")
+expr_case("IfWithNullCondition", E + ":645-649", [BOOL, I32, I32, I32], [[F, 1, 2, 2], [N, 1, 2, 2], [T, 1, 2, 1]], "If")
+expr_case("IfWithNullThen", E + ":659-663", [BOOL, DATE, DATE, DATE], [[T, 1, 2, 1], [T, N, 2, N], [F, N, 2, 2]], "If")
+expr_case("IfWithNullOtherwise", E + ":673-677", [BOOL, BOOL, BOOL, BOOL], [[T, T, F, T], [T, T, N, T], [F, T, N, N]], "If")
+expr_case("IfWithAllNullable", E + ":687-701", [BOOL, I32, I32, I32],
+          [[T, 1, 2, 1], [F, 1, 2, 2], [N, 1, 2, 2], [T, N, 2, N], [F, N, 2, 2], [N, N, 2, 2], [T, 1, N, 1], [F, 1, N, N],
+           [N, 1, N, N], [T, N, N, N], [F, N, N, N], [N, N, N, N]], "If")
+
+# ---- the Primer's column add (test/guide/primer.cc:205-221) -----------------------------------
+expr_case("Primer_ColumnAdd", "test/guide/primer.cc:205-221", [I32, I32, I32],
+          [[a, b, c] for a, b, c in zip(range(8), [3, 4, 6, 8, 1, 2, 2, 9], [3, 5, 8, 11, 5, 7, 8, 16])], "Plus", nullable=False)
+
+# ---- Compute (supersonic/cursor/core/compute_test.cc:30-81; STRING col0 dropped) ---------------
+CT = "supersonic/cursor/core/compute_test.cc"
+compute_schema = [["col1", I32, True], ["col2", F64, True], ["col3", I64, True]]
+compute_rows = [[12, 5.0, 5], [13, 6.0, 6], [None, None, None]]
+op_case("Compute_NamedAttribute", CT + ":51-62", compute_schema, compute_rows,
+        ["Compute", ["CompoundExpression", ["AddAs", "col0", ["NamedAttribute", "col1"]]], "INPUT"],
+        [I32], [[12], [13], [None]], exp_names=["col0"])
+op_case("Compute_CompoundWithArithmetics", CT + ":64-81", compute_schema, compute_rows,
+        ["Compute", ["CompoundExpression", ["AddAs", "col0", ["NamedAttribute", "col1"]],
+                     ["AddAs", "col1", ["Plus", ["NamedAttribute", "col1"], ["NamedAttribute", "col3"]]]], "INPUT"],
+        [I32, I64], [[12, 17], [13, 19], [None, None]], exp_names=["col0", "col1"])
+
+# ---- Filter (supersonic/cursor/core/filter_test.cc:151-351) ------------------------------------
+FT = "supersonic/cursor/core/filter_test.cc"
+
+
+def filter_case(name, src, rows, pvals, pnulls, expected, n_payload=2):
+    schema = [["col0", I32, True], ["col1", I64, True], ["p", BOOL, pnulls is not None]]
+    data = [[r[0], r[1], (None if (pnulls and pnulls[i]) else pvals[i])] for i, r in enumerate(rows)]
+    op_case(name, src, schema, data,
+            ["Filter", ["NamedAttribute", "p"], ["ProjectNamedAttributes", ["col0", "col1"]], "INPUT"],
+            [I32, I64], expected)
+
+
+two = [[1, 65], [3, 66]]   # (1,"A"), (3,"B")
+filter_case("Filter_AllPassing", FT + ":151-163", two, [True, True], None, [[1, 65], [3, 66]])
+filter_case("Filter_NonePassing", FT + ":165-175", two, [False, False], None, [])
+filter_case("Filter_OnePassing", FT + ":177-191", two, [False, True], None, [[3, 66]])
+K2 = 2048  # Cursor::kDefaultRowCount * 2
+filter_case("Filter_ResultsAcrossBlocks", FT + ":206-226", [[i, 65] for i in range(K2)], [bool(i % 2) for i in range(K2)], None,
+            [[i, 65] for i in range(K2) if i % 2])
+filter_case("Filter_NoResultsFromFirstBlock", FT + ":228-247", [[i, 65] for i in range(K2)], [i >= 1024 for i in range(K2)], None,
+            [[i, 65] for i in range(1024, K2)])
+filter_case("Filter_NoResultsFromSecondBlock", FT + ":249-267", [[i, 65] for i in range(K2)], [i < 1024 for i in range(K2)], None,
+            [[i, 65] for i in range(1024)])
+filter_case("Filter_NullableAllPassing", FT + ":269-283", two, [True, True], [False, False], [[1, 65], [3, 66]])
+filter_case("Filter_NullableOnePassing", FT + ":285-300", two, [True, True], [True, False], [[3, 66]])
+op_case("Filter_FilterOnProjected", FT + ":302-316", cols([I32, I64]), two,
+        ["Filter", ["Equal", ["NamedAttribute", "col0"], ["ConstInt32", 1]], ["ProjectNamedAttribute", "col0"], "INPUT"],
+        [I32], [[1]], exp_names=["col0"])
+op_case("Filter_FilterOnDropped", FT + ":318-332", cols([I32, I64]), two,
+        ["Filter", ["Equal", ["NamedAttribute", "col1"], ["ConstInt64", 65]], ["ProjectNamedAttribute", "col0"], "INPUT"],
+        [I32], [[1]], exp_names=["col0"])
+
+# ---- ScalarAggregate (supersonic/cursor/core/aggregate_scalar_test.cc:53-90; DISTINCT dropped) --
+ST = "supersonic/cursor/core/aggregate_scalar_test.cc"
+spec4 = [["MAX", "col0", "max"], ["SUM", "col0", "sum"], ["COUNT", "", "count(*)"], ["COUNT", "col0", "count"]]
+op_case("ScalarAggregate_Integers", ST + ":53-70", cols([I32]), [[13], [3], [3], [None], [7]],
+        ["ScalarAggregate", spec4, "INPUT"], [I32, I32, U64, U64], [[13, 26, 5, 4]],
+        exp_names=["max", "sum", "count(*)", "count"], exp_nullable=[True, True, False, False])
+op_case("ScalarAggregate_EmptyInput", ST + ":72-86", cols([I32]), [],
+        ["ScalarAggregate", spec4, "INPUT"], [I32, I32, U64, U64], [[None, None, 0, 0]])
+
+# ---- GroupAggregate (supersonic/cursor/core/aggregate_groups_test.cc) --------------------------
+GT = "supersonic/cursor/core/aggregate_groups_test.cc"
+op_case("Group_SimpleAggregation", GT + ":102-117", cols([I32]), [[1], [3]],
+        ["GroupAggregate", ["CompoundSingleSourceProjector"], [["SUM", "col0", "sum"]], "INPUT"],
+        [I32], [[4]], exp_names=["sum"], exp_nullable=[True])
+op_case("Group_CountWithInputColumn", GT + ":119-133", cols([I32]), [[1], [3]],
+        ["GroupAggregate", ["CompoundSingleSourceProjector"], [["COUNT", "col0", "count"]], "INPUT"],
+        [U64], [[2]], exp_nullable=[False])
+op_case("Group_AggregationWithGroupBy", GT + ":272-295", cols([I32, I32], nullable=False), [[1, 3], [3, -3], [1, 4], [3, -5]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"],
+        [I32, I32], [[1, 7], [3, -8]], ordered=False, exp_names=["col0", "sum"], exp_nullable=[False, True])
+op_case("Group_GroupByNullableColumn", GT + ":330-354", cols([I32, I32]), [[3, -3], [None, 4], [3, -5], [None, 1]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"],
+        [I32, I32], [[3, -8], [None, 5]], ordered=False, exp_names=["col0", "sum"], exp_nullable=[True, True])
+# (a NULLABLE 64-bit key needs 65 packed key bits, beyond the device table's 64: INT32 codes here)
+op_case("Group_GroupBySecondColumn", GT + ":356-377", cols([I32, I32]), [[-3, 2], [2, 1], [3, 1], [-2, 2]],   # foo=2, bar=1
+        ["GroupAggregate", ["ProjectNamedAttribute", "col1"], [["SUM", "col0", "sum"]], "INPUT"],
+        [I32, I32], [[2, -5], [1, 5]], ordered=False, exp_names=["col1", "sum"])
+two_key_rows = [[2, 1, 3], [1, 2, -3], [2, 1, 4], [1, 3, -5]]                                                  # foo=2, bar=1
+op_case("Group_GroupByTwoColumns", GT + ":379-401", cols([I32, I32, I32], nullable=False), two_key_rows,
+        ["GroupAggregate", ["ProjectNamedAttributes", ["col0", "col1"]], [["SUM", "col2", "sum"]], "INPUT"],
+        [I32, I32, I32], [[2, 1, 7], [1, 2, -3], [1, 3, -5]], ordered=False)
+op_case("Group_TwoColumnsMultipleAggregations", GT + ":403-429", cols([I32, I32, I32], nullable=False), two_key_rows,
+        ["GroupAggregate", ["ProjectNamedAttributes", ["col0", "col1"]],
+         [["SUM", "col2", "sum"], ["MIN", "col2", "min"], ["COUNT", "", "count"]], "INPUT"],
+        [I32, I32, I32, I32, U64], [[2, 1, 7, 3, 2], [1, 2, -3, -3, 1], [1, 3, -5, -5, 1]], ordered=False)
+
+# ---- AggregateClusters (supersonic/cursor/core/aggregate_clusters_test.cc:28-150) ---------------
+CL = "supersonic/cursor/core/aggregate_clusters_test.cc"
+cl_rows = [[0, 13], [2, 4], [2, 5], [2, -4], [2, -6], [1, 3], [1, 4], [1, -3]]
+op_case("Clusters_AggregateClusters", CL + ":33-45,70-82", cols([I32, I32]), cl_rows,
+        ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"],
+        [I32, I32], [[0, 13], [2, -1], [1, 4]])
+op_case("Clusters_WithoutClusteredColumn", CL + ":105-121", cols([I32]), [[13], [3], [7]],
+        ["AggregateClusters", ["CompoundSingleSourceProjector"], [["SUM", "col0", "sum"]], "INPUT"], [I32], [[23]])
+op_case("Clusters_EmptyInputWithClusteredColumn", CL + ":123-134", cols([I64, I32]), [],
+        ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"], [I64, I32], [])
+
+# ---- Sort (supersonic/cursor/core/sort_test.cc:121-330; letters -> INT64 codes a=1, b=2, ...) ---
+SO = "supersonic/cursor/core/sort_test.cc"
+
+
+def L(ch):
+    return None if ch is None else ord(ch) - ord("a") + 1
+
+
+def srows(pairs):
+    return [[k, L(v)] for k, v in pairs]
+
+
+op_case("Sort_OneIntegerColumnNoDuplicatesNoNulls", SO + ":121-145", cols([I32, I64]),
+        srows([(2, "b"), (3, "c"), (1, "a"), (7, "g"), (4, "d"), (6, "f"), (5, "e")]),
+        ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(1, "a"), (2, "b"), (3, "c"), (4, "d"), (5, "e"), (6, "f"), (7, "g")]))
+op_case("Sort_OneIntegerColumnNoDuplicatesWithNulls", SO + ":76-89,147-156", cols([I32, I64]),
+        srows([(None, "a"), (3, "c"), (None, "a"), (7, "g"), (4, "d"), (6, "f"), (5, "e")]),
+        ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(None, "a"), (None, "a"), (3, "c"), (4, "d"), (5, "e"), (6, "f"), (7, "g")]))
+op_case("Sort_OneColumnWithDuplicatesAndNulls", SO + ":189-215", cols([I64]),
+        [[L("a")], [L("c")], [L("a")], [None], [L("d")], [None], [L("e")]],
+        ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [I64],
+        [[None], [None], [L("a")], [L("a")], [L("c")], [L("d")], [L("e")]])
+op_case("Sort_OneIntegerColumnMostlyNullsDescending", SO + ":217-241", cols([I32, I64]),
+        srows([(None, "a"), (None, "a"), (None, "a"), (7, "g"), (None, "a"), (None, "a"), (None, "a")]),
+        ["Sort", [["col0", "DESCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(7, "g")] + [(None, "a")] * 6))
+op_case("Sort_TwoColumnsFirstUnique", SO + ":243-269", cols([I32, I64]),
+        srows([(2, "x"), (3, "v"), (1, "z"), (7, "x"), (4, "w"), (6, "x"), (5, "y")]),
+        ["Sort", [["col0", "ASCENDING"], ["col1", "DESCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(1, "z"), (2, "x"), (3, "v"), (4, "w"), (5, "y"), (6, "x"), (7, "x")]))
+op_case("Sort_TwoColumnsFirstConst", SO + ":271-297", cols([I32, I64]),
+        srows([(1, "x"), (1, "v"), (1, "z"), (1, "x"), (1, "w"), (1, "x"), (1, "y")]),
+        ["Sort", [["col0", "ASCENDING"], ["col1", "ASCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(1, "v"), (1, "w"), (1, "x"), (1, "x"), (1, "x"), (1, "y"), (1, "z")]))
+op_case("Sort_TwoColumnsFirstMixed", SO + ":299-328", cols([I32, I64]),
+        srows([(3, "z"), (None, "v"), (2, "z"), (3, None), (None, "w"), (3, "x"), (1, "x"), (None, "y")]),
+        ["Sort", [["col0", "ASCENDING"], ["col1", "ASCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(None, "v"), (None, "w"), (None, "y"), (1, "x"), (2, "z"), (3, None), (3, "x"), (3, "z")]))
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
+    with open(out, "w") as f:
+        json.dump(CASES, f, indent=0, separators=(",", ":"))
+    print("wrote %d cases to %s" % (len(CASES), out))

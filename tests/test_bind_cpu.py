@@ -1,0 +1,74 @@
+"""Host logic on CPU: the product's binder (libssgpu.so, bind-only context -- no device, no data
+path) must give every golden case the reference's result names, types, nullability and bind
+errors, and must agree with the oracle's independent binder on the parity-test plans."""
+import pytest
+
+import supersonic_amd as ss
+from golden_runner import TYPES, build_plan, build_view, load_cases
+from helpers import schema_list
+from oracle import oracle
+
+CASES = load_cases()
+EVAL_ERRORS = (104,)
+
+
+@pytest.fixture(scope="module")
+def bind_ctx():
+    return ss.Context(-1)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_binder_matches_reference(bind_ctx, case):
+    view = build_view(case["input"])
+    op = build_plan(case["plan"], view)
+    if case["expect_error"] and case["expect_error"] not in EVAL_ERRORS:
+        with pytest.raises(ss.SupersonicException) as e:
+            ss.Plan(op, bind_ctx)
+        assert e.value.return_code == case["expect_error"]
+        return
+    plan = ss.Plan(op, bind_ctx)
+    schema = schema_list(plan.result_schema)
+    exp = case["expected"]
+    if exp.get("names"):
+        assert [s[0] for s in schema] == exp["names"]
+    if exp.get("types"):
+        assert [s[1] for s in schema] == [TYPES[t] for t in exp["types"]]
+    if exp.get("nullable"):
+        assert [bool(s[2]) for s in schema] == exp["nullable"]
+    # and the oracle's independent binder agrees on the whole schema
+    assert schema == oracle.Cursor(op).schema
+
+
+def test_running_without_a_device_fails_loudly(bind_ctx):
+    import numpy as np
+    view = ss.View(ss.TupleSchema([ss.Attribute("a", ss.INT64)]), [np.arange(4)])
+    cur = ss.Compute(ss.Plus(ss.NamedAttribute("a"), ss.ConstInt64(1)), ss.ScanView(view)).CreateCursor(bind_ctx)
+    assert cur.schema().attribute(0).name() == "(a + CONST_INT64)"
+    r = cur.Next(1024)
+    assert r.is_failure() and r.exception().return_code == 2000   # no CPU fallback behind the ABI
+
+
+def test_bind_errors(bind_ctx):
+    import numpy as np
+    view = ss.View(ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("t", ss.BOOL)]), [np.arange(4), np.zeros(4, bool)])
+    NA = ss.NamedAttribute
+
+    def code(op):
+        with pytest.raises(ss.SupersonicException) as e:
+            ss.Plan(op, bind_ctx)
+        return e.value.return_code
+
+    scan = lambda: ss.ScanView(view)  # noqa: E731
+    assert code(ss.Compute(NA("zz"), scan())) == 403                                   # ERROR_ATTRIBUTE_MISSING
+    assert code(ss.Compute(ss.AttributeAt(7), scan())) == 401                          # ERROR_ATTRIBUTE_COUNT_MISMATCH
+    assert code(ss.Compute(ss.And(NA("a"), NA("t")), scan())) == 402                   # ERROR_ATTRIBUTE_TYPE_MISMATCH
+    assert code(ss.Filter(NA("a"), ss.ProjectAllAttributes(), scan())) == 402          # predicate must be BOOL (filter.cc:84-92)
+    assert code(ss.Filter(ss.CompoundExpression().Add(NA("t")).Add(NA("a")), ss.ProjectAllAttributes(), scan())) == 401
+    assert code(ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("a", NA("t")), scan())) == 404   # duplicate name
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "nope", "s")
+    assert code(ss.ScalarAggregate(spec, scan())) == 403                                # aggregator.cc:134-140
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "s").AddAggregation(ss.MAX, "a", "s")
+    assert code(ss.ScalarAggregate(spec, scan())) == 404                                # aggregator.cc:153-158
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "t", "s")
+    assert code(ss.ScalarAggregate(spec, scan())) == 405                                # column_aggregator.cc:549-556
+    assert code(ss.Compute(ss.CastTo(ss.INT32, ss.Plus(NA("a"), ss.ConstDouble(1.0))), scan())) == 402   # float -> int cast

@@ -1,0 +1,23 @@
+"""Pins the CPU oracle: every golden vector transcribed from the reference's own tests
+(tests/golden/reference_tests.json, see transcribe_reference_tests.py for the citations) must be
+reproduced by oracle/ss_oracle.c -- values, NULLs, result names, types, nullability and the
+reference's bind / evaluation error codes.  Runs on CPU."""
+import pytest
+
+from golden_runner import build_plan, build_view, check, load_cases
+from oracle import oracle
+
+CASES = load_cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_reproduces_reference_golden_vector(case):
+    view = build_view(case["input"])
+    op = build_plan(case["plan"], view)
+    if case["expect_error"]:
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.run(op)
+        assert e.value.return_code == case["expect_error"]
+        return
+    schema, cols = oracle.run(op)
+    check(case, schema, cols)

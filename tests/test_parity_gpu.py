@@ -191,3 +191,72 @@ def test_chained_stages(gpu_ctx):
     grouped = group_query(view, True)
     op = ss.Compute(ss.CompoundExpression().Add(NA("k1")).Add(NA("k2")).AddAs("range", ss.Minus(NA("max_d0"), NA("min_d0"))), grouped)
     run_both(op, gpu_ctx, ignore_order=True)
+
+
+# ---- Sort (cursor/core/sort.cc): unique trailing key -> the order is fully determined ----------
+def sort_view(n, nullable):
+    rng = np.random.default_rng(7)
+    N = ss.NULLABLE if nullable else ss.NOT_NULLABLE
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64, N), ss.Attribute("g", ss.INT32, N), ss.Attribute("x", ss.DOUBLE, N),
+                             ss.Attribute("f", ss.FLOAT), ss.Attribute("u", ss.UINT32), ss.Attribute("t", ss.BOOL),
+                             ss.Attribute("id", ss.INT64)])
+
+    def nl():
+        return (rng.random(n) < 0.1) if nullable else None
+    cols = [ss.Column(rng.integers(-(1 << 62), 1 << 62, n), nl()), ss.Column(rng.integers(-50, 50, n), nl()),
+            ss.Column(rng.integers(-1000, 1000, n) * 0.5, nl()), (rng.integers(-100, 100, n) * 0.25).astype(np.float32),
+            rng.integers(0, 1 << 32, n).astype(np.uint32), rng.integers(0, 2, n).astype(bool), rng.permutation(n)]
+    return ss.View(schema, cols)
+
+
+SORT_ORDERS = [
+    [("k", ss.ASCENDING), ("id", ss.ASCENDING)],
+    [("g", ss.DESCENDING), ("id", ss.ASCENDING)],
+    [("g", ss.ASCENDING), ("x", ss.DESCENDING), ("id", ss.DESCENDING)],
+    [("f", ss.ASCENDING), ("t", ss.DESCENDING), ("u", ss.ASCENDING), ("id", ss.ASCENDING)],
+]
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 4095, 4096, 4097, 100003])
+@pytest.mark.parametrize("order", range(len(SORT_ORDERS)))
+@pytest.mark.parametrize("nullable", [False, True])
+def test_sort(gpu_ctx, n, order, nullable):
+    so = ss.SortOrder()
+    for name, o in SORT_ORDERS[order]:
+        so.add(name, o)
+    run_both(ss.Sort(so, ss.ProjectAllAttributes(), 0, ss.ScanView(sort_view(n, nullable))), gpu_ctx)
+
+
+def test_sort_after_filter_with_projection(gpu_ctx):
+    view = sort_view(50000, True)
+    so = ss.SortOrder().add("k", ss.DESCENDING).add("id", ss.ASCENDING)
+    child = ss.Filter(ss.Greater(NA("g"), ss.ConstInt32(0)), ss.ProjectAllAttributes(), ss.ScanView(view))
+    run_both(ss.Sort(so, ss.ProjectNamedAttributes(["id", "k", "x"]), 0, child), gpu_ctx)
+
+
+def test_sort_then_group(gpu_ctx):
+    # Sort over a GroupAggregate result (the reference's group_sort guide example shape)
+    view = make_view(30000)
+    grouped = group_query(view, False)
+    so = ss.SortOrder().add("k1", ss.ASCENDING).add("k2", ss.DESCENDING)
+    run_both(ss.Sort(so, ss.ProjectAllAttributes(), 0, grouped), gpu_ctx)
+
+
+# ---- AggregateClusters (cursor/core/aggregate_clusters.cc) ---------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 513, 10001, 100003])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_aggregate_clusters(gpu_ctx, n, nullable):
+    rng = np.random.default_rng(11)
+    N = ss.NULLABLE if nullable else ss.NOT_NULLABLE
+    # runs of random length 1..9 with a key that changes at every run boundary (keys may repeat later)
+    key = np.cumsum(rng.integers(0, 9, n) == 0) % 13 if n else np.zeros(0, np.int64)
+    key2 = (np.arange(n) // 1000).astype(np.int32)
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64, N), ss.Attribute("k2", ss.INT32), ss.Attribute("v", ss.INT64, N),
+                             ss.Attribute("d", ss.DOUBLE)])
+    knull = (key % 5 == 0) if nullable else None      # whole runs NULL: NULL keys cluster together
+    vnull = (rng.random(n) < 0.2) if nullable else None
+    view = ss.View(schema, [ss.Column(key, knull), key2, ss.Column(rng.integers(-100, 100, n), vnull), rng.integers(0, 64, n) * 0.5])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "sv").AddAggregation(ss.MIN, "v", "mn")
+            .AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.COUNT, "v", "cv")
+            .AddAggregation(ss.COUNT, "", "n"))
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttributes(["k", "k2"]), spec, ss.ScanView(view)), gpu_ctx)
