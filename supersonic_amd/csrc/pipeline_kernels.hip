@@ -1903,8 +1903,57 @@ hipError_t ssgpu_launch_emit_scalar(const VmAccRec* recs, const EmitDesc* descs,
   hipLaunchKernelGGL(ssgpu_emit_scalar_kernel, dim3(blocks), dim3(64), 0, stream, recs, descs, n_out);
   return hipGetLastError();
 }
+// large inputs: chunk totals (one workgroup per 8192-entry chunk) -> scan of the totals ->
+// per-chunk exclusive scans seeded with their base; small inputs: one workgroup does it all
+__global__ __launch_bounds__(1024) void ssgpu_scan_chunk_totals_kernel(const u32* __restrict__ in, int n, u32* __restrict__ totals) {
+  __shared__ u64 wave_sums[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i0 = blockIdx.x * 8192 + t * 8;
+  u64 sum = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sum += (i0 + j < n) ? in[i0 + j] : 0u;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+  if (lane == 0) wave_sums[wave] = sum;
+  __syncthreads();
+  if (t == 0) { u64 s = 0; for (int w = 0; w < 16; ++w) s += wave_sums[w]; totals[blockIdx.x] = (u32)s; }
+}
+__global__ __launch_bounds__(1024) void ssgpu_scan_chunks_kernel(const u32* __restrict__ in, u32* __restrict__ out, int n,
+                                                                  const u32* __restrict__ chunk_base) {
+  __shared__ u64 wave_sums[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i0 = blockIdx.x * 8192 + t * 8;
+  u32 v[8]; u64 sum = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0u; sum += v[j]; }
+  u64 inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { u64 o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  u64 run = chunk_base[blockIdx.x] + (inc - sum);
+  for (int w = 0; w < wave; ++w) run += wave_sums[w];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { if (i0 + j < n) out[i0 + j] = (u32)run; run += v[j]; }
+}
+
 hipError_t ssgpu_launch_scan_counts(const uint32_t* in, uint32_t* out, int n, uint64_t* total, hipStream_t stream) {
-  hipLaunchKernelGGL(ssgpu_scan_counts_kernel, dim3(1), dim3(1024), 0, stream, in, out, n, (u64*)total);
+  if (n <= 65536) {
+    hipLaunchKernelGGL(ssgpu_scan_counts_kernel, dim3(1), dim3(1024), 0, stream, in, out, n, (u64*)total);
+    return hipGetLastError();
+  }
+  // scratch for the chunk totals / bases lives behind the output array's last element? no: own static buffers
+  static thread_local u32* d_totals = nullptr; static thread_local u32* d_bases = nullptr; static thread_local int cap = 0;
+  const int chunks = (n + 8191) / 8192;
+  if (chunks > cap) {
+    if (d_totals) { (void)hipFree(d_totals); (void)hipFree(d_bases); }
+    hipError_t e = hipMalloc((void**)&d_totals, (size_t)chunks * 4); if (e != hipSuccess) return e;
+    e = hipMalloc((void**)&d_bases, (size_t)chunks * 4); if (e != hipSuccess) return e;
+    cap = chunks;
+  }
+  hipLaunchKernelGGL(ssgpu_scan_chunk_totals_kernel, dim3(chunks), dim3(1024), 0, stream, in, n, d_totals);
+  hipLaunchKernelGGL(ssgpu_scan_counts_kernel, dim3(1), dim3(1024), 0, stream, d_totals, d_bases, chunks, (u64*)total);
+  hipLaunchKernelGGL(ssgpu_scan_chunks_kernel, dim3(chunks), dim3(1024), 0, stream, in, out, n, d_bases);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_group_count(const GroupExtractParams& P, uint32_t* tile_counts, hipStream_t stream) {

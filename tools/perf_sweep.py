@@ -74,7 +74,25 @@ def q_sumn(n):
     return q
 
 
-QUERIES = {"add4": q_addn(4), "add16": q_addn(16), "sum4": q_sumn(4), "sum8": q_sumn(8),"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
+def q_sort(v):
+    return ss.Sort(ss.SortOrder().add("d", ss.ASCENDING), ss.ProjectAllAttributes(), 0, ss.ScanView(v))
+
+
+def q_sort_keyonly(v):
+    return ss.Sort(ss.SortOrder().add("d", ss.ASCENDING), ss.ProjectNamedAttributes(["d"]), 0, ss.ScanView(v))
+
+
+def q_group2(v):
+    # BASELINE config #3 shape: 2 x INT32 keys (1e5 distinct pairs) + SUM/MIN/MAX over 4 DOUBLE columns
+    e = (ss.CompoundExpression().AddAs("k1", ss.CastTo(ss.INT32, ss.CppDivideSignaling(NA("c"), ss.ConstInt64(317))))
+         .AddAs("k2", ss.CastTo(ss.INT32, ss.ModulusSignaling(NA("c"), ss.ConstInt64(317)))).Add(NA("d0")).Add(NA("d1")).Add(NA("d2")).Add(NA("d3")))
+    spec = ss.AggregationSpecification()
+    for c in ["d0", "d1", "d2", "d3"]:
+        spec.AddAggregation(ss.SUM, c, "s" + c).AddAggregation(ss.MIN, c, "n" + c).AddAggregation(ss.MAX, c, "x" + c)
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, None, ss.Compute(e, ss.ScanView(v)))
+
+
+QUERIES = {"sort": q_sort, "sort_key": q_sort_keyonly, "group2": q_group2, "add4": q_addn(4), "add16": q_addn(16), "sum4": q_sumn(4), "sum8": q_sumn(8),"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
            "filter_mat": q_filter_mat, "group": q_group}
 
 
@@ -116,6 +134,8 @@ def main():
                         ms.sort()
                         dom, tot = ms[len(ms) // 2]
                         gbs = c.algorithmic_bytes / (dom / 1e3) / 1e9
+                        if qn.startswith("sort") or qn in ("filter_mat", "group", "group2"):
+                            print("   [%s] total kernel time %.3f ms -> %.2f Grows/s, launches %d" % (qn, tot, args.rows / tot / 1e6, c.n_launches))
                         print("%-10s tile=%-5d lds_target=%-6d grid=%-5d lds=%-6d dom=%.3f ms total=%.3f ms  %.0f GB/s (%.1f%% of 8TB/s)  %.1f Grows/s" % (
                             qn, c.tile_rows, lds, c.grid, c.lds_bytes, dom, tot, gbs, gbs / 80.0, args.rows / dom / 1e6), flush=True)
                     except ss.SupersonicException as e:
