@@ -1,0 +1,454 @@
+// supersonic_amd/supersonic.h -- C++ host-side mirror of the builder API of
+// supersonic/supersonic.h for the Filter -> Project/Compute -> Aggregate (+Sort) path,
+// implemented over the C ABI of include/ssgpu.h (libssgpu.so).  Header-only.
+//
+// Same names, argument meaning, ownership and error behaviour as the reference:
+//   * factories take OWNERSHIP of the raw pointers they are given
+//     (cursor/core/compute.h, filter.h, aggregate.h:224-342, sort.h:83-86);
+//   * Operation::CreateCursor() binds the whole tree and returns FailureOrOwned<Cursor>
+//     (cursor/base/operation.h:62) -- bind errors carry the reference's ReturnCode;
+//   * Cursor::Next(max_row_count) returns a ResultView whose View stays valid until the
+//     next call (cursor/base/cursor.h:131-148); Interrupt() may come from another thread.
+// Execution differs by design: the first Next() runs the whole fused pipeline on the GPU,
+// later calls slice the finished result.  There is no CPU execution path.
+#ifndef SUPERSONIC_AMD_SUPERSONIC_H_
+#define SUPERSONIC_AMD_SUPERSONIC_H_
+
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../ssgpu.h"
+
+namespace supersonic {
+
+typedef int64_t rowcount_t;
+typedef int64_t rowid_t;
+
+// ---- enums: numeric values of supersonic/proto/supersonic.proto ------------------------
+enum DataType { INT32 = 1, INT64 = 2, UINT64 = 3, DATETIME = 4, DOUBLE = 5, BOOL = 6, UINT32 = 8, FLOAT = 9, DATE = 10, STRING = 0, BINARY = 7 };
+enum Nullability { NOT_NULLABLE = 0, NULLABLE = 1 };
+enum Aggregation { SUM = 0, MIN = 1, MAX = 2, COUNT = 3, CONCAT = 4, FIRST = 5, LAST = 6 };
+enum ColumnOrder { ASCENDING = 0, DESCENDING = 1 };
+enum ReturnCode {
+  OK = 0, ERROR_UNKNOWN_ERROR = 100, ERROR_MEMORY_EXCEEDED = 102, ERROR_NOT_IMPLEMENTED = 103,
+  ERROR_EVALUATION_ERROR = 104, ERROR_TOO_MANY_ROWS = 302, ERROR_ATTRIBUTE_COUNT_MISMATCH = 401,
+  ERROR_ATTRIBUTE_TYPE_MISMATCH = 402, ERROR_ATTRIBUTE_MISSING = 403, ERROR_ATTRIBUTE_EXISTS = 404,
+  ERROR_INVALID_ARGUMENT_TYPE = 405, ERROR_INVALID_ARGUMENT_VALUE = 407, INTERRUPTED = 1000
+};
+
+// ---- errors (base/exception/exception.h:53, result.h:43-130) ----------------------------
+class Exception {
+ public:
+  Exception(int code, const std::string& message) : code_(code), message_(message) {}
+  ReturnCode return_code() const { return static_cast<ReturnCode>(code_); }
+  const std::string& message() const { return message_; }
+ private:
+  int code_;
+  std::string message_;
+};
+
+template <typename T>
+class FailureOrOwned {
+ public:
+  explicit FailureOrOwned(T* value) : value_(value) {}
+  explicit FailureOrOwned(Exception* e) : exception_(e) {}
+  FailureOrOwned(FailureOrOwned&& o) = default;
+  bool is_failure() const { return exception_ != nullptr; }
+  bool is_success() const { return !is_failure(); }
+  const Exception& exception() const { return *exception_; }
+  T* get() const { return value_.get(); }
+  T* release() { return value_.release(); }
+  T* operator->() const { return value_.get(); }
+ private:
+  std::unique_ptr<T> value_;
+  std::unique_ptr<Exception> exception_;
+};
+
+// ---- schema (base/infrastructure/tuple_schema.h:77,126) ---------------------------------
+class Attribute {
+ public:
+  Attribute(const std::string& name, DataType type, Nullability nullability) : name_(name), type_(type), nullability_(nullability) {}
+  const std::string& name() const { return name_; }
+  DataType type() const { return type_; }
+  Nullability nullability() const { return nullability_; }
+  bool is_nullable() const { return nullability_ == NULLABLE; }
+ private:
+  std::string name_;
+  DataType type_;
+  Nullability nullability_;
+};
+
+class TupleSchema {
+ public:
+  TupleSchema() {}
+  static TupleSchema Singleton(const std::string& name, DataType type, Nullability n) { TupleSchema s; s.add_attribute(Attribute(name, type, n)); return s; }
+  bool add_attribute(const Attribute& a) { if (LookupAttributePosition(a.name()) >= 0) return false; attrs_.push_back(a); return true; }
+  int attribute_count() const { return static_cast<int>(attrs_.size()); }
+  const Attribute& attribute(int i) const { return attrs_[i]; }
+  int LookupAttributePosition(const std::string& name) const {
+    for (size_t i = 0; i < attrs_.size(); ++i) if (attrs_[i].name() == name) return static_cast<int>(i);
+    return -1;
+  }
+ private:
+  std::vector<Attribute> attrs_;
+};
+
+inline size_t SizeOfDataType(DataType t) {
+  switch (t) { case INT32: case UINT32: case FLOAT: case DATE: return 4; case INT64: case UINT64: case DOUBLE: case DATETIME: return 8; case BOOL: return 1; default: return 0; }
+}
+
+// ---- View (base/infrastructure/block.h:55-402): N (data, is_null) pairs + row count -----
+class Column {
+ public:
+  Column() : data_(nullptr), is_null_(nullptr) {}
+  void Reset(const void* data, const bool* is_null) { data_ = data; is_null_ = is_null; }
+  const void* data() const { return data_; }
+  const bool* is_null() const { return is_null_; }   // nullptr => no NULLs
+  template <typename T> const T* typed_data() const { return static_cast<const T*>(data_); }
+ private:
+  const void* data_;
+  const bool* is_null_;
+};
+
+class View {
+ public:
+  explicit View(const TupleSchema& schema) : schema_(schema), columns_(schema.attribute_count()), row_count_(0) {}
+  const TupleSchema& schema() const { return schema_; }
+  int column_count() const { return schema_.attribute_count(); }
+  const Column& column(int i) const { return columns_[i]; }
+  Column* mutable_column(int i) { return &columns_[i]; }
+  rowcount_t row_count() const { return row_count_; }
+  void set_row_count(rowcount_t n) { row_count_ = n; }
+ private:
+  TupleSchema schema_;
+  std::vector<Column> columns_;
+  rowcount_t row_count_;
+};
+
+// ---- expressions (expression/base/expression.h, core/*_expressions.h) --------------------
+class Expression {
+ public:
+  Expression(int kind, int op, int dtype, int64_t i64, double f64, const std::string& name) : kind(kind), op(op), dtype(dtype), i64(i64), f64(f64), name(name) {}
+  virtual ~Expression() {}
+  int kind, op, dtype;
+  int64_t i64;
+  double f64;
+  std::string name;
+  std::vector<std::unique_ptr<const Expression>> args;
+};
+namespace internal {
+inline Expression* Node(int kind, int op = 0, int dtype = 0, int64_t i64 = 0, double f64 = 0, const std::string& name = "") { return new Expression(kind, op, dtype, i64, f64, name); }
+inline const Expression* Op(int op, const Expression* a, const Expression* b = nullptr, const Expression* c = nullptr) {
+  Expression* e = Node(SSGPU_EXPR_OP, op);
+  e->args.emplace_back(a); if (b) e->args.emplace_back(b); if (c) e->args.emplace_back(c);
+  return e;
+}
+}  // namespace internal
+inline const Expression* NamedAttribute(const std::string& name) { return internal::Node(SSGPU_EXPR_ATTR_NAMED, 0, 0, 0, 0, name); }
+inline const Expression* AttributeAt(size_t position) { return internal::Node(SSGPU_EXPR_ATTR_AT, 0, 0, static_cast<int64_t>(position)); }
+inline const Expression* ConstInt32(int32_t v) { return internal::Node(SSGPU_EXPR_CONST, 0, INT32, v); }
+inline const Expression* ConstInt64(int64_t v) { return internal::Node(SSGPU_EXPR_CONST, 0, INT64, v); }
+inline const Expression* ConstUint32(uint32_t v) { return internal::Node(SSGPU_EXPR_CONST, 0, UINT32, v); }
+inline const Expression* ConstUint64(uint64_t v) { return internal::Node(SSGPU_EXPR_CONST, 0, UINT64, static_cast<int64_t>(v)); }
+inline const Expression* ConstFloat(float v) { return internal::Node(SSGPU_EXPR_CONST, 0, FLOAT, 0, v); }
+inline const Expression* ConstDouble(double v) { return internal::Node(SSGPU_EXPR_CONST, 0, DOUBLE, 0, v); }
+inline const Expression* ConstBool(bool v) { return internal::Node(SSGPU_EXPR_CONST, 0, BOOL, v ? 1 : 0); }
+inline const Expression* Null(DataType t) { return internal::Node(SSGPU_EXPR_NULL, 0, t); }
+inline const Expression* Plus(const Expression* a, const Expression* b) { return internal::Op(0, a, b); }
+inline const Expression* Multiply(const Expression* a, const Expression* b) { return internal::Op(4, a, b); }
+inline const Expression* Minus(const Expression* a, const Expression* b) { return internal::Op(8, a, b); }
+inline const Expression* DivideQuiet(const Expression* a, const Expression* b) { return internal::Op(13, a, b); }
+inline const Expression* DivideNulling(const Expression* a, const Expression* b) { return internal::Op(14, a, b); }
+inline const Expression* DivideSignaling(const Expression* a, const Expression* b) { return internal::Op(15, a, b); }
+inline const Expression* Divide(const Expression* a, const Expression* b) { return DivideSignaling(a, b); }
+inline const Expression* CppDivideNulling(const Expression* a, const Expression* b) { return internal::Op(18, a, b); }
+inline const Expression* CppDivideSignaling(const Expression* a, const Expression* b) { return internal::Op(19, a, b); }
+inline const Expression* CppDivide(const Expression* a, const Expression* b) { return CppDivideSignaling(a, b); }
+inline const Expression* ModulusNulling(const Expression* a, const Expression* b) { return internal::Op(26, a, b); }
+inline const Expression* ModulusSignaling(const Expression* a, const Expression* b) { return internal::Op(27, a, b); }
+inline const Expression* Modulus(const Expression* a, const Expression* b) { return ModulusSignaling(a, b); }
+inline const Expression* Negate(const Expression* a) { return internal::Op(36, a); }
+inline const Expression* And(const Expression* a, const Expression* b) { return internal::Op(40, a, b); }
+inline const Expression* Or(const Expression* a, const Expression* b) { return internal::Op(44, a, b); }
+inline const Expression* AndNot(const Expression* a, const Expression* b) { return internal::Op(48, a, b); }
+inline const Expression* Not(const Expression* a) { return internal::Op(52, a); }
+inline const Expression* Xor(const Expression* a, const Expression* b) { return internal::Op(56, a, b); }
+inline const Expression* BitwiseAnd(const Expression* a, const Expression* b) { return internal::Op(60, a, b); }
+inline const Expression* BitwiseOr(const Expression* a, const Expression* b) { return internal::Op(64, a, b); }
+inline const Expression* BitwiseNot(const Expression* a) { return internal::Op(68, a); }
+inline const Expression* BitwiseXor(const Expression* a, const Expression* b) { return internal::Op(72, a, b); }
+inline const Expression* ShiftLeft(const Expression* a, const Expression* b) { return internal::Op(76, a, b); }
+inline const Expression* ShiftRight(const Expression* a, const Expression* b) { return internal::Op(80, a, b); }
+inline const Expression* BitwiseAndNot(const Expression* a, const Expression* b) { return internal::Op(84, a, b); }
+inline const Expression* Equal(const Expression* a, const Expression* b) { return internal::Op(100, a, b); }
+inline const Expression* NotEqual(const Expression* a, const Expression* b) { return internal::Op(104, a, b); }
+inline const Expression* Less(const Expression* a, const Expression* b) { return internal::Op(116, a, b); }
+inline const Expression* LessOrEqual(const Expression* a, const Expression* b) { return internal::Op(120, a, b); }
+inline const Expression* Greater(const Expression* a, const Expression* b) { return internal::Op(SSGPU_OP_GREATER, a, b); }
+inline const Expression* GreaterOrEqual(const Expression* a, const Expression* b) { return internal::Op(SSGPU_OP_GREATER_OR_EQUAL, a, b); }
+inline const Expression* If(const Expression* c, const Expression* t, const Expression* e) { return internal::Op(204, c, t, e); }
+inline const Expression* IfNull(const Expression* a, const Expression* b) { return internal::Op(220, a, b); }
+inline const Expression* IsNull(const Expression* a) { return internal::Op(224, a); }
+inline const Expression* CastTo(DataType t, const Expression* a) { Expression* e = internal::Node(SSGPU_EXPR_CAST, 0, t); e->args.emplace_back(a); return e; }
+inline const Expression* Alias(const std::string& new_name, const Expression* a) { Expression* e = internal::Node(SSGPU_EXPR_ALIAS, 0, 0, 0, 0, new_name); e->args.emplace_back(a); return e; }
+
+class CompoundExpression : public Expression {
+ public:
+  CompoundExpression() : Expression(SSGPU_EXPR_COMPOUND, 0, 0, 0, 0, "") {}
+  CompoundExpression* Add(const Expression* argument) { args.emplace_back(argument); return this; }
+  CompoundExpression* AddAs(const std::string& alias, const Expression* argument) { args.emplace_back(Alias(alias, argument)); return this; }
+};
+
+// ---- projectors (base/infrastructure/projector.h) ------------------------------------------
+class SingleSourceProjector {
+ public:
+  virtual ~SingleSourceProjector() {}
+  struct Entry { int kind; int position; std::string name, alias; };
+  std::vector<Entry> entries;
+};
+inline const SingleSourceProjector* ProjectAllAttributes() { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_ALL, 0, "", ""}); return p; }
+inline const SingleSourceProjector* ProjectNamedAttribute(const std::string& name) { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_NAMED, 0, name, ""}); return p; }
+inline const SingleSourceProjector* ProjectNamedAttributeAs(const std::string& name, const std::string& alias) { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_NAMED_AS, 0, name, alias}); return p; }
+inline const SingleSourceProjector* ProjectAttributeAt(int position) { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_AT, position, "", ""}); return p; }
+inline const SingleSourceProjector* ProjectNamedAttributes(const std::vector<std::string>& names) { auto* p = new SingleSourceProjector; for (auto& n : names) p->entries.push_back({SSGPU_PROJ_NAMED, 0, n, ""}); return p; }
+class CompoundSingleSourceProjector : public SingleSourceProjector {
+ public:
+  CompoundSingleSourceProjector* add(const SingleSourceProjector* p) { std::unique_ptr<const SingleSourceProjector> own(p); for (auto& e : p->entries) entries.push_back(e); return this; }
+};
+
+// ---- specifications (cursor/core/aggregate.h:28-205, infrastructure/ordering.h:48-101) -----
+class AggregationSpecification {
+ public:
+  struct Element { Aggregation aggregation; std::string input, output; int output_type; bool distinct; };
+  AggregationSpecification* AddAggregation(Aggregation a, const std::string& in, const std::string& out) { elements.push_back({a, in, out, -1, false}); return this; }
+  AggregationSpecification* AddDistinctAggregation(Aggregation a, const std::string& in, const std::string& out) { elements.push_back({a, in, out, -1, true}); return this; }
+  AggregationSpecification* AddAggregationWithDefinedOutputType(Aggregation a, const std::string& in, const std::string& out, DataType t) { elements.push_back({a, in, out, t, false}); return this; }
+  std::vector<Element> elements;
+};
+class GroupAggregateOptions {
+ public:
+  GroupAggregateOptions() : max_unique_keys_in_result(0) {}
+  int64_t max_unique_keys_in_result;
+};
+class SortOrder {
+ public:
+  SortOrder* add(const SingleSourceProjector* projector, ColumnOrder order) {
+    std::unique_ptr<const SingleSourceProjector> own(projector);
+    for (auto& e : projector->entries) keys.push_back(std::make_pair(e.name, order));
+    return this;
+  }
+  std::vector<std::pair<std::string, ColumnOrder>> keys;
+};
+
+// ---- process-wide device context -------------------------------------------------------------
+namespace internal {
+struct Context {
+  ssgpu_ctx* ctx = nullptr;
+  Context() { if (ssgpu_ctx_create(0, &ctx) != SSGPU_OK) ssgpu_ctx_create(-1, &ctx); }  // bind-only without a GPU
+  ~Context() { ssgpu_ctx_destroy(ctx); }
+  static Context& Get() { static Context c; return c; }
+};
+}  // namespace internal
+
+// ---- cursors (cursor/base/cursor.h:42-226) -----------------------------------------------------
+class ResultView {
+ public:
+  static ResultView Success(const View* v) { ResultView r; r.view_ = v; return r; }
+  static ResultView EOS() { ResultView r; r.eos_ = true; return r; }
+  static ResultView Failure(Exception* e) { ResultView r; r.exception_.reset(e); return r; }
+  bool has_data() const { return view_ != nullptr; }
+  bool is_eos() const { return eos_; }
+  bool is_failure() const { return exception_ != nullptr; }
+  const View& view() const { return *view_; }
+  const Exception& exception() const { return *exception_; }
+ private:
+  ResultView() : view_(nullptr), eos_(false) {}
+  const View* view_;
+  bool eos_;
+  std::shared_ptr<Exception> exception_;
+};
+
+class Operation;
+
+class Cursor {
+ public:
+  static const rowcount_t kDefaultRowCount = 1024;  // cursor.h:133
+  ~Cursor() { if (res_) ssgpu_result_destroy(res_); if (block_) ssgpu_block_destroy(block_); if (plan_) ssgpu_plan_destroy(plan_); }
+  const TupleSchema& schema() const { return schema_; }
+  void Interrupt() { ssgpu_interrupt(plan_); }   // thread-safe, non-blocking (cursor.h:150-186)
+
+  ResultView Next(rowcount_t max_row_count) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    if (!ran_) {
+      ran_ = true;
+      int rc = Stage(ctx);
+      if (rc == SSGPU_OK) rc = ssgpu_plan_run_block(plan_, block_, &res_);
+      ssgpu_result* res = res_;
+      if (rc == SSGPU_OK) {
+        total_ = ssgpu_result_row_count(res);
+        if (total_ < 0) rc = SSGPU_ERROR_HIP;
+      }
+      for (int i = 0; rc == SSGPU_OK && i < schema_.attribute_count(); ++i) {
+        const void* d = nullptr; const uint8_t* z = nullptr;
+        rc = ssgpu_result_column(res, i, &d, &z);
+        host_data_.push_back(d); host_null_.push_back(z);
+      }
+      if (rc != SSGPU_OK) { failed_ = true; return ResultView::Failure(new Exception(rc, ssgpu_last_error(ctx))); }
+    }
+    if (failed_) return ResultView::Failure(new Exception(ERROR_UNKNOWN_ERROR, "cursor already failed"));
+    if (pos_ >= total_) return ResultView::EOS();
+    const rowcount_t n = std::min<rowcount_t>(max_row_count, total_ - pos_);
+    for (int i = 0; i < schema_.attribute_count(); ++i) {
+      const size_t w = SizeOfDataType(schema_.attribute(i).type());
+      view_->mutable_column(i)->Reset(static_cast<const char*>(host_data_[i]) + pos_ * w,
+                                      host_null_[i] ? reinterpret_cast<const bool*>(host_null_[i]) + pos_ : nullptr);
+    }
+    view_->set_row_count(n);
+    pos_ += n;
+    return ResultView::Success(view_.get());
+  }
+
+ private:
+  friend class Operation;
+  Cursor() {}
+  int Stage(ssgpu_ctx* ctx) {  // host View -> device block on the copy stream
+    const TupleSchema& s = input_->schema();
+    std::vector<ssgpu_attr> attrs;
+    for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
+    int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), std::max<rowcount_t>(input_->row_count(), 1), &block_);
+    for (int i = 0; rc == SSGPU_OK && i < s.attribute_count() && input_->row_count() > 0; ++i)
+      rc = ssgpu_block_upload(block_, i, input_->column(i).data(), reinterpret_cast<const uint8_t*>(input_->column(i).is_null()), 0, input_->row_count());
+    if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(block_, input_->row_count());
+    return rc;
+  }
+  ssgpu_plan* plan_ = nullptr;
+  ssgpu_block* block_ = nullptr;
+  ssgpu_result* res_ = nullptr;
+  const View* input_ = nullptr;
+  TupleSchema schema_;
+  std::unique_ptr<View> view_;
+  std::vector<const void*> host_data_;
+  std::vector<const uint8_t*> host_null_;
+  rowcount_t total_ = 0, pos_ = 0;
+  bool ran_ = false, failed_ = false;
+};
+
+// ---- operations (cursor/base/operation.h:35-83 and the factories of supersonic.h) -------------
+class Operation {
+ public:
+  virtual ~Operation() {}
+  // Binds the whole tree (Expression::Bind, projector/aggregation binding) and lowers it.
+  FailureOrOwned<Cursor> CreateCursor() const {
+    Builder b;
+    Emit(&b);
+    std::vector<ssgpu_attr> attrs;
+    const TupleSchema& in = b.scan->schema();
+    for (int i = 0; i < in.attribute_count(); ++i) attrs.push_back({in.attribute(i).name().c_str(), in.attribute(i).type(), in.attribute(i).nullability()});
+    ssgpu_plan_desc d; memset(&d, 0, sizeof(d));
+    d.input_schema = attrs.data(); d.n_attrs = static_cast<int32_t>(attrs.size());
+    d.ops = b.ops.data(); d.n_ops = static_cast<int32_t>(b.ops.size());
+    d.exprs = b.exprs.data(); d.n_exprs = static_cast<int32_t>(b.exprs.size());
+    d.expr_args = b.expr_args.data(); d.n_expr_args = static_cast<int32_t>(b.expr_args.size());
+    d.projs = b.projs.data(); d.n_projs = static_cast<int32_t>(b.projs.size());
+    d.aggs = b.aggs.data(); d.n_aggs = static_cast<int32_t>(b.aggs.size());
+    d.sortkeys = b.sortkeys.data(); d.n_sortkeys = static_cast<int32_t>(b.sortkeys.size());
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    ssgpu_plan* plan = nullptr;
+    const int rc = ssgpu_plan_create(ctx, &d, &plan);
+    if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, ssgpu_last_error(ctx)));
+    std::unique_ptr<Cursor> c(new Cursor);
+    c->plan_ = plan; c->input_ = b.scan;
+    for (int i = 0; i < ssgpu_plan_attr_count(plan); ++i) {
+      ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
+      c->schema_.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
+    }
+    c->view_.reset(new View(c->schema_));
+    return FailureOrOwned<Cursor>(c.release());
+  }
+  // The reference's allocator seam (operation.h:66-76): device buffers are owned by the plan.
+  void SetBufferAllocator(void* /*allocator*/, bool /*cascade*/) {}
+
+  struct Builder {
+    std::vector<ssgpu_op> ops; std::vector<ssgpu_expr> exprs; std::vector<int32_t> expr_args;
+    std::vector<ssgpu_proj> projs; std::vector<ssgpu_agg> aggs; std::vector<ssgpu_sortkey> sortkeys;
+    const View* scan = nullptr;
+    int Expr(const Expression* e) {
+      std::vector<int32_t> kids;
+      for (auto& a : e->args) kids.push_back(Expr(a.get()));
+      ssgpu_expr x; memset(&x, 0, sizeof(x));
+      x.kind = e->kind; x.op = e->op; x.dtype = e->dtype; x.first_arg = static_cast<int32_t>(expr_args.size()); x.nargs = static_cast<int32_t>(kids.size());
+      x.i64 = e->i64; x.f64 = e->f64; x.name = e->name.c_str();
+      expr_args.insert(expr_args.end(), kids.begin(), kids.end());
+      exprs.push_back(x);
+      return static_cast<int>(exprs.size()) - 1;
+    }
+    void Proj(const SingleSourceProjector* p, ssgpu_op* o) {
+      o->proj_first = static_cast<int32_t>(projs.size()); o->proj_n = static_cast<int32_t>(p->entries.size());
+      for (auto& e : p->entries) projs.push_back({e.kind, e.position, e.name.c_str(), e.alias.c_str()});
+    }
+    void Aggs(const AggregationSpecification* s, ssgpu_op* o) {
+      o->agg_first = static_cast<int32_t>(aggs.size()); o->agg_n = static_cast<int32_t>(s->elements.size());
+      for (auto& e : s->elements) aggs.push_back({e.aggregation, e.distinct ? 1 : 0, e.output_type, 0, e.input.c_str(), e.output.c_str()});
+    }
+    int Op(ssgpu_op o) { ops.push_back(o); return static_cast<int>(ops.size()) - 1; }
+  };
+  virtual int Emit(Builder* b) const = 0;
+ protected:
+  static ssgpu_op Blank(int kind, int child) { ssgpu_op o; memset(&o, 0, sizeof(o)); o.kind = kind; o.child = child; o.expr = -1; return o; }
+};
+
+namespace internal {
+class ScanViewOp : public Operation {
+ public:
+  explicit ScanViewOp(const View& v) : view_(v) {}
+  int Emit(Builder* b) const override { b->scan = &view_; return b->Op(Blank(SSGPU_OP_SCAN, -1)); }
+ private:
+  const View& view_;  // must outlive the operation (scan_view.h)
+};
+class UnaryOp : public Operation {
+ public:
+  UnaryOp(int kind, Operation* child, const Expression* e, const SingleSourceProjector* p, const AggregationSpecification* a, const SortOrder* s, int64_t opt = 0)
+      : kind_(kind), child_(child), expr_(e), proj_(p), aggs_(a), sort_(s), opt_(opt) {}
+  int Emit(Builder* b) const override {
+    ssgpu_op o = Blank(kind_, child_->Emit(b));
+    if (expr_) o.expr = b->Expr(expr_.get());
+    if (proj_) b->Proj(proj_.get(), &o);
+    if (aggs_) b->Aggs(aggs_.get(), &o);
+    if (sort_) { o.sort_first = static_cast<int32_t>(b->sortkeys.size()); o.sort_n = static_cast<int32_t>(sort_->keys.size());
+                 for (auto& k : sort_->keys) b->sortkeys.push_back({k.first.c_str(), k.second, 0}); }
+    o.option0 = opt_;
+    return b->Op(o);
+  }
+ private:
+  int kind_;
+  std::unique_ptr<Operation> child_;
+  std::unique_ptr<const Expression> expr_;
+  std::unique_ptr<const SingleSourceProjector> proj_;
+  std::unique_ptr<const AggregationSpecification> aggs_;
+  std::unique_ptr<const SortOrder> sort_;
+  int64_t opt_;
+};
+}  // namespace internal
+
+inline Operation* ScanView(const View& view) { return new internal::ScanViewOp(view); }
+inline Operation* Compute(const Expression* computation, Operation* child) { return new internal::UnaryOp(SSGPU_OP_COMPUTE, child, computation, nullptr, nullptr, nullptr); }
+inline Operation* Project(const SingleSourceProjector* projector, Operation* child) { return new internal::UnaryOp(SSGPU_OP_PROJECT, child, nullptr, projector, nullptr, nullptr); }
+inline Operation* Filter(const Expression* predicate, const SingleSourceProjector* projector, Operation* child) { return new internal::UnaryOp(SSGPU_OP_FILTER, child, predicate, projector, nullptr, nullptr); }
+inline Operation* ScalarAggregate(AggregationSpecification* spec, Operation* child) { return new internal::UnaryOp(SSGPU_OP_SCALAR_AGGREGATE, child, nullptr, nullptr, spec, nullptr); }
+inline Operation* GroupAggregate(const SingleSourceProjector* group_by, const AggregationSpecification* spec, GroupAggregateOptions* options, Operation* child) {
+  std::unique_ptr<GroupAggregateOptions> own(options);
+  return new internal::UnaryOp(SSGPU_OP_GROUP_AGGREGATE, child, nullptr, group_by, spec, nullptr, options ? options->max_unique_keys_in_result : 0);
+}
+inline Operation* AggregateClusters(const SingleSourceProjector* clustered_by, const AggregationSpecification* spec, Operation* child) { return new internal::UnaryOp(SSGPU_OP_AGGREGATE_CLUSTERS, child, nullptr, clustered_by, spec, nullptr); }
+inline Operation* Sort(const SortOrder* order, const SingleSourceProjector* result_projector, size_t memory_limit, Operation* child) {
+  return new internal::UnaryOp(SSGPU_OP_SORT, child, nullptr, result_projector ? result_projector : ProjectAllAttributes(), nullptr, order, static_cast<int64_t>(memory_limit));
+}
+
+}  // namespace supersonic
+#endif  // SUPERSONIC_AMD_SUPERSONIC_H_

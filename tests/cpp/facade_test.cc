@@ -1,0 +1,179 @@
+// Exercises include/supersonic_amd/supersonic.h the way the reference's own guide/tests use
+// supersonic/supersonic.h (test/guide/*.cc, cursor/core/*_test.cc): build an Operation tree
+// with the public factories, CreateCursor(), pull with Next().
+//
+//   facade_test bind   -- binding, naming and bind-error checks only (no GPU needed)
+//   facade_test run    -- also executes the pipelines on the GPU and checks the values
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <memory>
+#include <vector>
+
+#include "supersonic_amd/supersonic.h"
+
+using namespace supersonic;  // NOLINT
+
+static int g_fail = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+#define CHECK_EQ(a, b) do { auto va = (a); auto vb = (b); if (!(va == vb)) { printf("FAIL %s:%d: %s == %s\n", __FILE__, __LINE__, #a, #b); ++g_fail; } } while (0)
+
+struct Input {
+  static const int N = 5000;
+  std::vector<int64_t> a, b;
+  std::vector<int32_t> k;
+  std::vector<double> d;
+  std::vector<char> d_null;
+  TupleSchema schema;
+  std::unique_ptr<View> view;
+  Input() : a(N), b(N), k(N), d(N), d_null(N) {
+    uint64_t s = 12345;
+    for (int i = 0; i < N; ++i) {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      a[i] = static_cast<int64_t>((s >> 33) % 1000) - 300;
+      b[i] = static_cast<int64_t>((s >> 20) % 77);
+      k[i] = static_cast<int32_t>((s >> 45) % 7);
+      d[i] = static_cast<double>((s >> 11) % 64) * 0.25;
+      d_null[i] = ((s >> 5) % 9) == 0;
+    }
+    schema.add_attribute(Attribute("a", INT64, NOT_NULLABLE));
+    schema.add_attribute(Attribute("b", INT64, NOT_NULLABLE));
+    schema.add_attribute(Attribute("k", INT32, NOT_NULLABLE));
+    schema.add_attribute(Attribute("d", DOUBLE, NULLABLE));
+    view.reset(new View(schema));
+    view->mutable_column(0)->Reset(a.data(), nullptr);
+    view->mutable_column(1)->Reset(b.data(), nullptr);
+    view->mutable_column(2)->Reset(k.data(), nullptr);
+    view->mutable_column(3)->Reset(d.data(), reinterpret_cast<const bool*>(d_null.data()));
+    view->set_row_count(N);
+  }
+};
+
+// Filter -> Compute -> ScalarAggregate, the Q-FPA shape.
+static Operation* Fpa(const Input& in) {
+  return ScalarAggregate(
+      (new AggregationSpecification)->AddAggregation(SUM, "s", "sum_s")->AddAggregation(COUNT, "", "cnt")->AddAggregation(MIN, "d", "min_d"),
+      Compute((new CompoundExpression)->AddAs("s", Plus(NamedAttribute("a"), Multiply(NamedAttribute("b"), ConstInt64(3))))->Add(NamedAttribute("d")),
+              Filter(Greater(NamedAttribute("a"), ConstInt64(0)), ProjectAllAttributes(), ScanView(*in.view))));
+}
+
+static void TestBind(const Input& in) {
+  {
+    std::unique_ptr<Operation> op(Fpa(in));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) {
+      CHECK_EQ(c->schema().attribute_count(), 3);
+      CHECK_EQ(c->schema().attribute(0).name(), std::string("sum_s"));
+      CHECK_EQ(c->schema().attribute(0).type(), INT64);
+      CHECK_EQ(c->schema().attribute(1).type(), UINT64);
+      CHECK(!c->schema().attribute(1).is_nullable());
+      CHECK_EQ(c->schema().attribute(2).type(), DOUBLE);
+    }
+  }
+  {  // result naming of expressions (expression tests: "(a + b)", CAST_..)
+    std::unique_ptr<Operation> op(Compute((new CompoundExpression)->Add(Plus(NamedAttribute("a"), NamedAttribute("k")))->Add(Less(NamedAttribute("d"), NamedAttribute("a"))), ScanView(*in.view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) {
+      CHECK_EQ(c->schema().attribute(0).name(), std::string("(a + CAST_INT32_TO_INT64(k))"));
+      CHECK_EQ(c->schema().attribute(1).type(), BOOL);
+      CHECK(c->schema().attribute(1).is_nullable());
+    }
+  }
+  {  // missing attribute -> ERROR_ATTRIBUTE_MISSING at CreateCursor
+    std::unique_ptr<Operation> op(Filter(Less(NamedAttribute("nope"), ConstInt64(1)), ProjectAllAttributes(), ScanView(*in.view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_failure());
+    if (c.is_failure()) CHECK_EQ(c.exception().return_code(), ERROR_ATTRIBUTE_MISSING);
+  }
+  {  // non-BOOL predicate
+    std::unique_ptr<Operation> op(Filter(NamedAttribute("a"), ProjectAllAttributes(), ScanView(*in.view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_failure());
+  }
+  {  // duplicate output name
+    std::unique_ptr<Operation> op(ScalarAggregate((new AggregationSpecification)->AddAggregation(SUM, "a", "x")->AddAggregation(MIN, "b", "x"), ScanView(*in.view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_failure());
+    if (c.is_failure()) CHECK_EQ(c.exception().return_code(), ERROR_ATTRIBUTE_EXISTS);
+  }
+}
+
+static void TestRun(const Input& in) {
+  {
+    std::unique_ptr<Operation> op(Fpa(in));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    ResultView r = c->Next(Cursor::kDefaultRowCount);
+    if (r.is_failure()) { printf("run failed: %s\n", r.exception().message().c_str()); ++g_fail; return; }
+    CHECK(r.has_data());
+    int64_t sum = 0; uint64_t cnt = 0; double mn = INFINITY; bool any = false;
+    for (int i = 0; i < Input::N; ++i) if (in.a[i] > 0) {
+      sum += in.a[i] + in.b[i] * 3; ++cnt;
+      if (!in.d_null[i]) { any = true; mn = fmin(mn, in.d[i]); }
+    }
+    CHECK_EQ(r.view().row_count(), 1);
+    CHECK_EQ(r.view().column(0).typed_data<int64_t>()[0], sum);
+    CHECK_EQ(r.view().column(1).typed_data<uint64_t>()[0], cnt);
+    CHECK(any && r.view().column(2).typed_data<double>()[0] == mn);
+    CHECK(c->Next(Cursor::kDefaultRowCount).is_eos());
+  }
+  {  // Filter materialisation pulled in 1024-row views, order preserved
+    std::unique_ptr<Operation> op(Filter(Less(NamedAttribute("d"), ConstDouble(4.0)), ProjectNamedAttributes({"a", "d"}), ScanView(*in.view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    int i = 0; rowcount_t total = 0;
+    for (;;) {
+      ResultView r = c->Next(1024);
+      if (r.is_failure()) { printf("run failed: %s\n", r.exception().message().c_str()); ++g_fail; break; }
+      if (r.is_eos()) break;
+      CHECK(r.view().row_count() <= 1024);
+      for (rowcount_t j = 0; j < r.view().row_count(); ++j) {
+        while (i < Input::N && (in.d_null[i] || !(in.d[i] < 4.0))) ++i;
+        CHECK(i < Input::N);
+        if (i >= Input::N) break;
+        if (r.view().column(0).typed_data<int64_t>()[j] != in.a[i] || r.view().column(1).typed_data<double>()[j] != in.d[i]) { CHECK(false); break; }
+        ++i;
+      }
+      total += r.view().row_count();
+    }
+    rowcount_t expect = 0;
+    for (int j = 0; j < Input::N; ++j) expect += (!in.d_null[j] && in.d[j] < 4.0);
+    CHECK_EQ(total, expect);
+  }
+  {  // GroupAggregate then Sort by key
+    std::unique_ptr<Operation> op(Sort((new SortOrder)->add(ProjectNamedAttribute("k"), ASCENDING), nullptr, 1 << 20,
+        GroupAggregate(ProjectNamedAttribute("k"), (new AggregationSpecification)->AddAggregation(SUM, "a", "sa")->AddAggregation(COUNT, "d", "cd"), nullptr, ScanView(*in.view))));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    ResultView r = c->Next(Cursor::kDefaultRowCount);
+    if (r.is_failure()) { printf("run failed: %s\n", r.exception().message().c_str()); ++g_fail; return; }
+    int64_t sa[7] = {0}; uint64_t cd[7] = {0};
+    for (int i = 0; i < Input::N; ++i) { sa[in.k[i]] += in.a[i]; cd[in.k[i]] += !in.d_null[i]; }
+    CHECK_EQ(r.view().row_count(), 7);
+    for (int g = 0; g < 7 && g < r.view().row_count(); ++g) {
+      CHECK_EQ(r.view().column(0).typed_data<int32_t>()[g], g);
+      CHECK_EQ(r.view().column(1).typed_data<int64_t>()[g], sa[g]);
+      CHECK_EQ(r.view().column(2).typed_data<uint64_t>()[g], cd[g]);
+    }
+  }
+  {  // signaling division by zero surfaces as ERROR_EVALUATION_ERROR from Next()
+    std::unique_ptr<Operation> op(Compute(DivideSignaling(NamedAttribute("a"), Minus(NamedAttribute("b"), NamedAttribute("b"))), ScanView(*in.view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    ResultView r = c->Next(Cursor::kDefaultRowCount);
+    CHECK(r.is_failure());
+    if (r.is_failure()) CHECK_EQ(r.exception().return_code(), ERROR_EVALUATION_ERROR);
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool run = argc > 1 && !strcmp(argv[1], "run");
+  Input in;
+  TestBind(in);
+  if (run) TestRun(in);
+  printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
+  return g_fail ? 1 : 0;
+}
