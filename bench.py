@@ -71,6 +71,23 @@ class _DevPtr(object):
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+def pmc_traffic(alg_bytes):
+    """HBM bytes per launch of the pipeline kernel from the committed PMC pass
+    (profiles/rNN_pmc.json, collected with rocprofv3 --pmc on this same command); PMC
+    counters cannot be read from inside the timed process, so the value is only reported
+    when the committed pass measured the same workload (same algorithmic bytes)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            if int(j.get("algorithmic_bytes_per_launch", -1)) == int(alg_bytes):
+                return float(j["traffic_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def cpu_baseline(ss, sample_rows):
     """The oracle (CPU restatement of the reference's 1024-row pull model) on a bounded sample of
     the same workload, 1 thread (the reference is single-threaded per plan)."""
@@ -210,7 +227,7 @@ def main():
                        if distributed else "single GPU",
                        "tile_rows": counters.tile_rows, "grid": counters.grid, "lds_bytes": counters.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(alg_bytes),
                          "kernel": "ssgpu_pipeline_kernel", "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_row": alg_bytes / max(rows, 1)},
             "result_row": [result.column(i).data[0].item() for i in range(result.column_count())],
