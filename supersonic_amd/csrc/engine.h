@@ -149,7 +149,7 @@ std::string bexpr_to_string(const BExprP& e);
 struct LowerOptions {
   int lds_target_bytes = 48 * 1024;
   int tile_rows = 0;  // 0 = choose by lds_target_bytes
-  bool double_buffer = true;  // two input buffers per workgroup (loader prefetches the next tile)
+  bool double_buffer = false; // legacy layout with two LDS input buffers (the kernel prefetches into registers)
 };
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe);
 // choose the tile size (K = tile_rows / 512) and fix LDS offsets for a program

@@ -405,7 +405,7 @@ static void allocate_registers(Program* p) {
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   ProgramLayout L;
   auto lds_for = [&](int K, uint32_t* acc, uint32_t* scr) {
-    // two input buffers (the loader wave fills one while the other is consumed) + temporaries
+    // input registers (+ a second copy in the legacy double-buffered layout) + temporaries
     uint32_t regs = (p.bytes_per_row + (opt.double_buffer ? p.in_bytes_per_row : 0u)) * 512u * (uint32_t)K;
     uint32_t a = (regs + 15u) & ~15u;
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
@@ -419,7 +419,12 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
     if (K >= 4) K = 4; else if (K >= 2) K = 2; else K = 1;
     while (K > 1 && lds_for(K, nullptr, nullptr) > 160u * 1024u) K /= 2;  // must fit one CU
   } else {
-    for (int cand : {4, 2, 1}) { K = cand; if ((int)lds_for(cand, nullptr, nullptr) <= opt.lds_target_bytes) break; }
+    // the largest tile that fits the LDS target AND whose staged units fit the kernel's
+    // register prefetch file (units beyond it are fetched with their latency exposed)
+    for (int cand : {4, 2, 1}) {
+      K = cand;
+      if ((int)lds_for(cand, nullptr, nullptr) <= opt.lds_target_bytes && (int)p.staged.size() * cand <= VM_PF_UNITS) break;
+    }
   }
   L.K = K;
   L.lds_bytes = lds_for(K, &L.acc_off, &L.scratch_off);

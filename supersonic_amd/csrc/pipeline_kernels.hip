@@ -175,47 +175,63 @@ __device__ __forceinline__ u32 group_insert(const VmGroupTable& G, u64 key) {
 }
 
 // ---------------------------------------------------------------------------
-// input staging: global -> LDS.  Fast path = LDS-DMA, 16 B per lane, 1 KiB per
-// wave instruction, destination wave-uniform base + lane*16 (linear layout).
+// input staging: global -> registers -> LDS.
+// Every compute lane owns the row pairs p = k*256 + t of a tile, so one "unit" (staged
+// column s, sub-tile k) is 2 rows = 16 / 8 / 2 bytes per lane: a fully coalesced 1 KiB
+// (512 B, 128 B) wave load.  The units of tile i+1 are loaded into a register file
+// (VM_PF_UNITS x 16 B per lane) right after tile i has been committed to LDS, and stay in
+// flight while the program runs over tile i: HBM requests are outstanding continuously
+// without spending LDS on a second input buffer (in-flight bytes live in VGPRs, 8 KiB per
+// wave), and no lane ever reads another lane's rows, so staging needs no barrier at all.
+// Loads are non-temporal: every input byte is streamed exactly once.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int tile_rows, int lane, u32 bufbase) {
-  const bool full = tile_base + tile_rows <= P.n_rows;
-  for (int s = 0; s < P.n_staged; ++s) {
-    const VmStagedCol C = P.staged[s];
-    char* dst = smem + C.lds_off + bufbase;
-    if (C.src == nullptr) {  // nullable attribute whose View carries no is_null vector
-      for (u32 c = (u32)lane * 4u; c < (u32)tile_rows * C.width; c += 64u * 4u)
-        *reinterpret_cast<u32*>(dst + c) = 0u;
-      continue;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+
+template <int K>
+__device__ __forceinline__ u32x4 load_unit(const VmParams& P, int u, i64 tile_base, u32 tile_valid, bool full, int t) {
+  const int s = u / K, k = u % K;
+  const VmStagedCol C = P.staged[s];
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (C.src == nullptr) return v;  // nullable attribute whose View carries no is_null vector
+  const u32 r0 = 2u * (u32)(k * VM_COMPUTE_THREADS + t);
+  const char* src = reinterpret_cast<const char*>(C.src) + (tile_base + (i64)r0) * (i64)C.width;
+  if (C.width == 8) {
+    if (full) {
+      v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+    } else if (r0 + 1u < tile_valid) {
+      v = *reinterpret_cast<const u32x4*>(src);
+    } else if (r0 < tile_valid) {
+      const u32x2 x = *reinterpret_cast<const u32x2*>(src); v[0] = x[0]; v[1] = x[1];
     }
-    const char* src = reinterpret_cast<const char*>(C.src) + tile_base * (i64)C.width;
-    const u32 bytes = (u32)tile_rows * C.width;
-    if (full && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-      // 1 KiB per wave instruction, LDS destination = wave-uniform base + lane * 16
-      for (u32 c = (u32)lane * 16u; c < bytes; c += 64u * 16u) {
-        // aux = 2 (nt): every byte is streamed exactly once, keep it out of the way in L2/MALL
-        if (P.flags & VM_FLAG_NT_LOADS)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
-                                           (__attribute__((address_space(3))) void*)(dst + c), 16, 0, 2);
-        else
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c),
-                                           (__attribute__((address_space(3))) void*)(dst + c), 16, 0, 0);
-      }
+  } else if (C.width == 4) {
+    if (full) {
+      const u32x2 x = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src)); v[0] = x[0]; v[1] = x[1];
+    } else if (r0 + 1u < tile_valid) {
+      const u32x2 x = *reinterpret_cast<const u32x2*>(src); v[0] = x[0]; v[1] = x[1];
+    } else if (r0 < tile_valid) {
+      v[0] = *reinterpret_cast<const u32*>(src);
+    }
+  } else {
+    const bool even = (reinterpret_cast<uintptr_t>(C.src) & 1) == 0;  // uniform
+    if (even && (full || r0 + 1u < tile_valid)) {
+      v[0] = (u32)__builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(src));
     } else {
-      // tail tile or unaligned view: element-wise, rows past the end read as 0
-      const i64 remain = P.n_rows - tile_base;
-      if (C.width == 8) {
-        for (int r = lane; r < tile_rows; r += 64)
-          reinterpret_cast<u64*>(dst)[r] = r < remain ? reinterpret_cast<const u64*>(src)[r] : 0ull;
-      } else if (C.width == 4) {
-        for (int r = lane; r < tile_rows; r += 64)
-          reinterpret_cast<u32*>(dst)[r] = r < remain ? reinterpret_cast<const u32*>(src)[r] : 0u;
-      } else {
-        for (int r = lane; r < tile_rows; r += 64)
-          reinterpret_cast<u8*>(dst)[r] = r < remain ? reinterpret_cast<const u8*>(src)[r] : (u8)0;
-      }
+      if (r0 < tile_valid) v[0] = (u32)*reinterpret_cast<const u8*>(src);
+      if (r0 + 1u < tile_valid) v[0] |= (u32)*reinterpret_cast<const u8*>(src + 1) << 8;
     }
   }
+  return v;
+}
+
+template <int K>
+__device__ __forceinline__ void commit_unit(const VmParams& P, int u, u32x4 v, int t) {
+  const int s = u / K, k = u % K;
+  const u32 w = P.staged[s].width;
+  char* dst = smem + P.staged[s].lds_off + (u32)(k * VM_COMPUTE_THREADS + t) * 2u * w;
+  if (w == 8) *reinterpret_cast<u32x4*>(dst) = v;
+  else if (w == 4) { u32x2 x = {v[0], v[1]}; *reinterpret_cast<u32x2*>(dst) = x; }
+  else *reinterpret_cast<unsigned short*>(dst) = (unsigned short)v[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -224,8 +240,7 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
 // Keeps LLVM's speculative-execution / hoisting passes from lifting every case's
 // LDS loads above the switch (which costs >250 VGPRs and all the occupancy).
 #define CASE_FENCE asm volatile("" ::: "memory")
-// Workgroup barrier used INSIDE handlers.  The loader wave executes one bare s_barrier for
-// each of these (VmParams.n_sync_per_tile), so the counts must stay in step.
+// Workgroup barrier used INSIDE handlers (cross-wave scratch of the selection sinks).
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define FOR_PAIRS for (int k = 0, p = tp; k < K; ++k, p += VM_COMPUTE_THREADS)
 
@@ -325,48 +340,17 @@ __device__ __forceinline__ void stage_tile(const VmParams& P, i64 tile_base, int
 // ---------------------------------------------------------------------------
 // the pipeline kernel: persistent workgroups stride over tiles
 // ---------------------------------------------------------------------------
-// Execution shape: VM_WAVES (4) compute waves + ONE loader wave per workgroup.  The loader
-// issues the LDS-DMA for tile i+1 into the other input buffer while the compute waves run
-// the program over tile i, so HBM requests are in flight continuously (a single-buffered
-// load -> wait -> compute cycle leaves the DMA latency exposed on every tile).  Only the
-// loader ever has VMEM loads outstanding, which also keeps the compiler's conservative
-// "LDS-DMA may alias this ds_read" vmcnt(0) waits out of the compute waves.
-// One s_barrier per tile: the loader arrives after its DMA for the NEXT tile has landed
-// (s_waitcnt vmcnt(0)), the compute waves arrive when they are done with the CURRENT one.
+// One persistent 4-wave workgroup strides over the tiles.  Per tile: commit the prefetched
+// units to the LDS input registers, issue the loads of the next tile, run the program.
 template <int K>
-__global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const VmParams P) {
+__global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const VmParams P) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int tile_rows = 512 * K;
   const int n_my_tiles = P.n_tiles > (int)blockIdx.x ? (P.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int n_units = P.n_staged * K;
 
-  if (wave == VM_WAVES) {
-    // ------------------------------ loader wave ------------------------------
-    const bool single = (P.flags & VM_FLAG_SINGLE_BUFFER) != 0;
-    if (n_my_tiles > 0) stage_tile(P, (i64)blockIdx.x * tile_rows, tile_rows, lane, 0u);
-    for (int it = 0; it < n_my_tiles; ++it) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile `it` is in LDS
-      if (!single && it + 1 < n_my_tiles) {
-        const int tile = (int)blockIdx.x + (it + 1) * (int)gridDim.x;
-        stage_tile(P, (i64)tile * tile_rows, tile_rows, lane, ((it + 1) & 1) ? P.in_lds_bytes : 0u);
-      }
-      for (int i = 0; i < P.n_sync_per_tile; ++i) asm volatile("s_barrier" ::: "memory");
-      if (single) {
-        // one input buffer: the next tile may only be fetched once this one is consumed; the
-        // other resident workgroups of the CU cover the DMA latency
-        asm volatile("s_barrier" ::: "memory");
-        if (it + 1 < n_my_tiles) {
-          const int tile = (int)blockIdx.x + (it + 1) * (int)gridDim.x;
-          stage_tile(P, (i64)tile * tile_rows, tile_rows, lane, 0u);
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // final rendezvous
-    return;
-  }
-
-  // ------------------------------ compute waves ------------------------------
   // zero this workgroup's LDS aggregate records (slow slots; fast slots are written once)
   for (u32 o = (u32)t * 8u; o < (u32)P.n_slots * VM_ACC_STRIDE; o += VM_COMPUTE_THREADS * 8u)
     *reinterpret_cast<u64*>(smem + P.acc_lds_off + o) = 0ull;
@@ -396,17 +380,50 @@ __global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const 
     }
   }
 
+  __syncthreads();  // constant pool and accumulator records visible to all waves
+
+  // register prefetch file: the first VM_PF_UNITS units of the NEXT tile
+  u32x4 pf[VM_PF_UNITS];
+  if (n_my_tiles > 0) {
+    const i64 tb = (i64)blockIdx.x * tile_rows;
+    const u32 tv = (u32)((P.n_rows - tb) < (i64)tile_rows ? (P.n_rows - tb) : (i64)tile_rows);
+#pragma unroll
+    for (int u = 0; u < VM_PF_UNITS; ++u)
+      if (u < n_units) pf[u] = load_unit<K>(P, u, tb, tv, tv == (u32)tile_rows, t);
+  }
+
   u64 dbg_wait = 0;
   const u64 dbg_t0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
+  const ProgPtr prog = prog0;
   for (int it = 0; it < n_my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const i64 tile_base = (i64)tile * tile_rows;
     const u32 tile_valid = (u32)((P.n_rows - tile_base) < (i64)tile_rows ? (P.n_rows - tile_base) : (i64)tile_rows);
-    // the host finalises the program twice, once per input buffer: no address fix-ups here
-    const ProgPtr prog = prog0 + (((it & 1) && !(P.flags & VM_FLAG_SINGLE_BUFFER)) ? (P.n_instr + 1) : 0);
     const u64 tw0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile landed; previous tile fully consumed
+    // commit the prefetched units (this is where a wave waits for HBM) ...
+#pragma unroll
+    for (int u = 0; u < VM_PF_UNITS; ++u)
+      if (u < n_units) commit_unit<K>(P, u, pf[u], t);
     if (P.debug) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
+    // ... units beyond the register file are fetched in place (latency exposed; wide schemas
+    // still stream their first VM_PF_UNITS units ahead)
+    for (int u = VM_PF_UNITS; u < n_units; u += 4) {
+      u32x4 late[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (u + j < n_units) late[j] = load_unit<K>(P, u + j, tile_base, tile_valid, tile_valid == (u32)tile_rows, t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (u + j < n_units) commit_unit<K>(P, u + j, late[j], t);
+    }
+    // ... and put the next tile's loads in flight before the program runs over this one
+    if (it + 1 < n_my_tiles) {
+      const i64 tb = tile_base + (i64)gridDim.x * tile_rows;
+      const u32 tv = (u32)((P.n_rows - tb) < (i64)tile_rows ? (P.n_rows - tb) : (i64)tile_rows);
+#pragma unroll
+      for (int u = 0; u < VM_PF_UNITS; ++u)
+        if (u < n_units) pf[u] = load_unit<K>(P, u, tb, tv, tv == (u32)tile_rows, t);
+    }
 
     // The program is immutable for the launch: fetch it through the constant address
     // space so every instruction is ONE scalar s_load_dwordx8, and fetch the next
@@ -1562,7 +1579,6 @@ __global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const 
         default: break;
       }
     }
-    if (P.flags & VM_FLAG_SINGLE_BUFFER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile consumed
   }
 
   if (P.debug && t == 0) {
@@ -1604,7 +1620,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 5) void ssgpu_pipeline_kernel(const 
     }
   }
 
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // final rendezvous (with the loader)
+  __syncthreads();
   // publish this workgroup's partial aggregates: the four wave records in wave order; the
   // combine rule is applied by the finish kernel (fixed shape -> reproducible)
   for (int s = t; s < P.n_slots; s += VM_COMPUTE_THREADS)
@@ -1866,7 +1882,7 @@ __global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __
 // host-callable launchers (C++ linkage inside the library)
 // ---------------------------------------------------------------------------
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream) {
-  dim3 g(grid), b(VM_WG_THREADS);  // 4 compute waves + 1 loader wave
+  dim3 g(grid), b(VM_WG_THREADS);  // 4 waves
   size_t lds = P.lds_bytes;
   switch (K) {
     case 1: hipLaunchKernelGGL(ssgpu_pipeline_kernel<1>, g, b, lds, stream, P); break;

@@ -34,6 +34,7 @@ struct ssgpu_ctx {
   std::string err;
   LowerOptions opt;
   int64_t grid_limit = 0;        // 0 = CUs * residency
+  int64_t wgs_per_cu = 4;        // resident 4-wave workgroups per CU (<= 4 at the kernel's 128-VGPR budget)
   int64_t group_capacity = 1 << 18;
   int64_t profile = 1;           // record HIP events around kernels
   int64_t debug_timing = 0;
@@ -190,6 +191,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
     c->opt.tile_rows = (int)value;
   } else if (k == "lds_target_bytes") c->opt.lds_target_bytes = (int)value;
   else if (k == "grid_limit") c->grid_limit = value;
+  else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 4;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -353,7 +355,7 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
 }
 
 int grid_for(ssgpu_ctx* c, const ProgramLayout& L, int n_tiles) {
-  int per_cu = (int)std::min<uint32_t>(8, (160u * 1024u) / std::max<uint32_t>(L.lds_bytes, 1));
+  int per_cu = (int)std::min<uint32_t>((uint32_t)c->wgs_per_cu, (160u * 1024u) / std::max<uint32_t>(L.lds_bytes, 1));
   if (per_cu < 1) per_cu = 1;
   int64_t g = (int64_t)c->cu_count * per_cu;
   if (c->grid_limit > 0) g = std::min<int64_t>(g, c->grid_limit);
@@ -380,7 +382,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->lds_bytes = L.lds_bytes;
   P->in_lds_bytes = L.in_lds_bytes;
   P->n_sync_per_tile = prog.n_sync_per_tile;
-  P->flags = L.double_buffer ? 0u : VM_FLAG_SINGLE_BUFFER;
+  P->flags = 0u;
   for (size_t i = 0; i < prog.staged.size(); ++i) {
     const StagedInput& s = prog.staged[i];
     P->staged[i].src = s.is_null_mask ? (const void*)in.cols[s.col].is_null : in.cols[s.col].data;

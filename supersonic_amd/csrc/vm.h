@@ -23,8 +23,9 @@
 
 #define VM_NONE 0xFFFFFFFFu
 #define VM_COMPUTE_THREADS 256
-#define VM_WAVES 4          /* compute waves per workgroup */
-#define VM_WG_THREADS 320   /* + one loader wave */
+#define VM_WAVES 4          /* waves per workgroup */
+#define VM_WG_THREADS 256
+#define VM_PF_UNITS 8       /* 16-byte-per-lane units of the register prefetch file */
 #define VM_FAST_SLOTS 8     /* aggregate slots with per-lane register accumulators */
 #define VM_MAX_STAGED 48
 #define VM_MAX_OUTPUTS 64
@@ -153,8 +154,6 @@ struct VmGroupTable {
   uint32_t capacity_mask;        /* capacity - 1                                   */
   uint32_t pad;
 };
-#define VM_FLAG_NT_LOADS 4u      /* non-temporal LDS-DMA */
-#define VM_FLAG_SINGLE_BUFFER 2u /* one input buffer per workgroup (more workgroups per CU) */
 #define VM_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 struct VmParams {
