@@ -411,7 +411,8 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
     if (acc) *acc = a;
     if (scr) *scr = s;
-    return s + 256u + 16u * (uint32_t)p.code.size();  // + the immediates' constant pool
+    return s + 256u + 16u * (uint32_t)p.code.size()   // + the immediates' constant pool
+           + 2u * 512u * (uint32_t)K;                   // + all-ones / all-zeros mask arrays of one tile
   };
   int K = 1;
   if (opt.tile_rows > 0) {

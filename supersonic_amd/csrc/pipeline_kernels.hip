@@ -49,8 +49,9 @@ template <typename T> __device__ __forceinline__ T imm_as(u64 imm) {
 template <typename T>
 __device__ __forceinline__ typename Vec2<T>::type fetch2(u32 off, u32 is_imm, u64 imm, int p) {
   (void)imm;
-  const u32 stride = is_imm ? 0u : (u32)(2u * sizeof(T));
-  return *reinterpret_cast<const typename Vec2<T>::type*>(smem + off + (u32)p * stride);
+  // (pair offset) & mask instead of pair * stride: v_mul_lo_u32 is a quarter-rate instruction
+  const u32 mask = is_imm ? 0u : ~0u;
+  return *reinterpret_cast<const typename Vec2<T>::type*>(smem + off + (((u32)p * (u32)(2u * sizeof(T))) & mask));
 }
 
 // ---------------------------------------------------------------------------
@@ -122,20 +123,22 @@ __device__ __forceinline__ i64 unkey_i64(u64 k) { return (i64)(k ^ 0x80000000000
 // row validity for sinks: row exists, passes the selection, value not NULL.
 // ---------------------------------------------------------------------------
 struct Valid2 { bool x, y; };
-// Absent selection / NULL masks read a constant LDS slot with stride 0 (all-ones / all-zeros),
-// so the three LDS reads of a sink (selection, NULL mask, value) issue back to back.
-__device__ __forceinline__ Valid2 valid_pair_c(int p, u32 tile_valid, u32 null_off, u32 sel_off, u32 const_off) {
+// Absent selection / NULL masks read constant all-ones / all-zeros LDS arrays of one tile
+// (2 x tile_rows bytes at const_off) exactly like real masks, so a sink's three LDS reads
+// (selection, NULL mask, value) need no special case and issue back to back; both rows'
+// mask bytes come in ONE 16-bit read each.
+__device__ __forceinline__ Valid2 valid_pair_c(int p, u32 tile_valid, u32 null_off, u32 sel_off, u32 const_off, u32 tile_rows) {
   const u32 r0 = 2u * (u32)p;
-  const u32 so = sel_off == VM_NONE ? const_off : sel_off, ss = sel_off == VM_NONE ? 0u : 2u;
-  const u32 no = null_off == VM_NONE ? const_off + 16u : null_off, ns = null_off == VM_NONE ? 0u : 2u;
-  const auto s = *reinterpret_cast<const Vec2<u8>::type*>(smem + so + (u32)p * ss);
-  const auto z = *reinterpret_cast<const Vec2<u8>::type*>(smem + no + (u32)p * ns);
+  const u32 so = sel_off == VM_NONE ? const_off : sel_off;
+  const u32 no = null_off == VM_NONE ? const_off + tile_rows : null_off;
+  const u32 s = *reinterpret_cast<const unsigned short*>(smem + so + r0);
+  const u32 z = *reinterpret_cast<const unsigned short*>(smem + no + r0);
   Valid2 v;
-  v.x = (r0 < tile_valid) && s.x && !z.x;
-  v.y = ((r0 + 1u) < tile_valid) && s.y && !z.y;
+  v.x = (r0 < tile_valid) && (s & 0xFFu) && !(z & 0xFFu);
+  v.y = ((r0 + 1u) < tile_valid) && (s >> 8) && !(z >> 8);
   return v;
 }
-#define valid_pair_(p, tile_valid, null_off, sel_off) valid_pair_c(p, tile_valid, null_off, sel_off, P.const_lds_off)
+#define valid_pair_(p, tile_valid, null_off, sel_off) valid_pair_c(p, tile_valid, null_off, sel_off, P.const_lds_off, (u32)(512 * K))
 
 // LDS operand offsets: bit 31 marks a register in the (double-buffered) input region
 __device__ __forceinline__ u32 vm_resolve(u32 o, u32 bufbase) {
@@ -360,8 +363,9 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
   u64xS F0, F1; u32xS FC;
 #pragma unroll
   for (int s = 0; s < VM_FAST_SLOTS; ++s) { F0[s] = P.slot_init0[s]; F1[s] = P.slot_init1[s]; FC[s] = 0; }
-  // constant LDS slots: 16 x 0x01 (absent selection) then 16 x 0x00 (absent NULL mask)
-  if (t < 4) reinterpret_cast<u64*>(smem + P.const_lds_off)[t] = t < 2 ? 0x0101010101010101ull : 0ull;
+  // constant LDS arrays: tile_rows x 0x01 (absent selection) then tile_rows x 0x00 (absent NULL mask)
+  for (u32 o = (u32)t * 8u; o < 2u * (u32)tile_rows; o += VM_COMPUTE_THREADS * 8u)
+    *reinterpret_cast<u64*>(smem + P.const_lds_off + o) = o < (u32)tile_rows ? 0x0101010101010101ull : 0ull;
 
   typedef u32 u32x8 __attribute__((ext_vector_type(8)));
   typedef const __attribute__((address_space(4))) u32x8* ProgPtr;

@@ -378,7 +378,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->acc_lds_off = L.acc_off;
   P->scratch_lds_off = L.scratch_off;
   P->imm_pool_lds_off = L.imm_pool_off;
-  P->const_lds_off = L.scratch_off + 192u;  // tail of the 256-byte scratch area (scans use <= 128 B)
+  P->const_lds_off = L.imm_pool_off + 16u * (uint32_t)prog.code.size();  // behind the constant pool
   P->lds_bytes = L.lds_bytes;
   P->in_lds_bytes = L.in_lds_bytes;
   P->n_sync_per_tile = prog.n_sync_per_tile;

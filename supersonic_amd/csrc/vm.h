@@ -169,7 +169,7 @@ struct VmParams {
   uint32_t acc_lds_off;   /* LDS offset of the aggregate accumulators */
   uint32_t scratch_lds_off; /* LDS offset of 256 B of scan scratch */
   uint32_t imm_pool_lds_off; /* LDS offset of the constant pool: 16 B per instruction */
-  uint32_t const_lds_off;    /* LDS offset of 32 B: 16 x 0x01 then 16 x 0x00 */
+  uint32_t const_lds_off;    /* LDS offset of 2 x tile_rows bytes: all 0x01, then all 0x00 */
   uint32_t lds_bytes;
   uint32_t in_lds_bytes;      /* bytes of ONE input buffer (two are resident) */
   int32_t n_sync_per_tile;    /* s_barriers executed inside the program per tile */
