@@ -191,50 +191,64 @@ __device__ __forceinline__ u32 group_insert(const VmGroupTable& G, u64 key) {
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
+// Only FULL tiles go through the register file; the (single) partial tile at the end of the
+// input is staged in place by stage_partial_tile().
 template <int K>
-__device__ __forceinline__ u32x4 load_unit(const VmParams& P, int u, i64 tile_base, u32 tile_valid, bool full, int t) {
+__device__ __forceinline__ void load_unit(const VmParams& P, int u, i64 tile_base, int t, u32x4& v) {
   const int s = u / K, k = u % K;
-  const VmStagedCol C = P.staged[s];
-  u32x4 v = {0u, 0u, 0u, 0u};
-  if (C.src == nullptr) return v;  // nullable attribute whose View carries no is_null vector
-  const u32 r0 = 2u * (u32)(k * VM_COMPUTE_THREADS + t);
-  const char* src = reinterpret_cast<const char*>(C.src) + (tile_base + (i64)r0) * (i64)C.width;
-  if (C.width == 8) {
-    if (full) {
-      v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-    } else if (r0 + 1u < tile_valid) {
-      v = *reinterpret_cast<const u32x4*>(src);
-    } else if (r0 < tile_valid) {
-      const u32x2 x = *reinterpret_cast<const u32x2*>(src); v[0] = x[0]; v[1] = x[1];
-    }
-  } else if (C.width == 4) {
-    if (full) {
-      const u32x2 x = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src)); v[0] = x[0]; v[1] = x[1];
-    } else if (r0 + 1u < tile_valid) {
-      const u32x2 x = *reinterpret_cast<const u32x2*>(src); v[0] = x[0]; v[1] = x[1];
-    } else if (r0 < tile_valid) {
-      v[0] = *reinterpret_cast<const u32*>(src);
-    }
+  const char* const src0 = reinterpret_cast<const char*>(P.staged[s].src);
+  const u32 w = P.staged[s].width;
+  if (src0 == nullptr) return;  // nullable attribute whose View carries no is_null vector: stays 0
+  const u32 p = (u32)(k * VM_COMPUTE_THREADS + t);
+  if (w == 8) {
+    v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src0 + (tile_base << 3) + (size_t)(p * 16u)));
+  } else if (w == 4) {
+    const u32x2 x = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src0 + (tile_base << 2) + (size_t)(p * 8u)));
+    v[0] = x[0]; v[1] = x[1];
+  } else if ((reinterpret_cast<uintptr_t>(src0) & 1) == 0) {
+    v[0] = (u32)__builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(src0 + tile_base + (size_t)(p * 2u)));
   } else {
-    const bool even = (reinterpret_cast<uintptr_t>(C.src) & 1) == 0;  // uniform
-    if (even && (full || r0 + 1u < tile_valid)) {
-      v[0] = (u32)__builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(src));
-    } else {
-      if (r0 < tile_valid) v[0] = (u32)*reinterpret_cast<const u8*>(src);
-      if (r0 + 1u < tile_valid) v[0] |= (u32)*reinterpret_cast<const u8*>(src + 1) << 8;
-    }
+    const u8* b = reinterpret_cast<const u8*>(src0 + tile_base + (size_t)(p * 2u));
+    v[0] = (u32)b[0] | ((u32)b[1] << 8);
   }
-  return v;
 }
 
 template <int K>
 __device__ __forceinline__ void commit_unit(const VmParams& P, int u, u32x4 v, int t) {
   const int s = u / K, k = u % K;
   const u32 w = P.staged[s].width;
-  char* dst = smem + P.staged[s].lds_off + (u32)(k * VM_COMPUTE_THREADS + t) * 2u * w;
-  if (w == 8) *reinterpret_cast<u32x4*>(dst) = v;
-  else if (w == 4) { u32x2 x = {v[0], v[1]}; *reinterpret_cast<u32x2*>(dst) = x; }
-  else *reinterpret_cast<unsigned short*>(dst) = (unsigned short)v[0];
+  const u32 p = (u32)(k * VM_COMPUTE_THREADS + t);
+  char* const dst = smem + P.staged[s].lds_off;
+  if (w == 8) *reinterpret_cast<u32x4*>(dst + p * 16u) = v;
+  else if (w == 4) { u32x2 x = {v[0], v[1]}; *reinterpret_cast<u32x2*>(dst + p * 8u) = x; }
+  else *reinterpret_cast<unsigned short*>(dst + p * 2u) = (unsigned short)v[0];
+}
+
+// In-place staging (global -> LDS, latency exposed): the partial last tile, and the units of
+// wide schemas that do not fit the register file.  Rows past the end of the input read as 0.
+template <int K>
+__device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begin, int u_end, i64 tile_base, u32 tile_valid, int t) {
+  for (int u = u_begin; u < u_end; ++u) {
+    const int s = u / K, k = u % K;
+    const char* const src0 = reinterpret_cast<const char*>(P.staged[s].src);
+    const u32 w = P.staged[s].width;
+    const u32 p = (u32)(k * VM_COMPUTE_THREADS + t), r0 = 2u * p;
+    char* const dst = smem + P.staged[s].lds_off;
+    const bool v0 = src0 != nullptr && r0 < tile_valid, v1 = src0 != nullptr && r0 + 1u < tile_valid;
+    if (w == 8) {
+      const u64* src = reinterpret_cast<const u64*>(src0) + tile_base + r0;
+      u64 a = v0 ? src[0] : 0ull, b = v1 ? src[1] : 0ull;
+      reinterpret_cast<u64*>(dst)[r0] = a; reinterpret_cast<u64*>(dst)[r0 + 1u] = b;
+    } else if (w == 4) {
+      const u32* src = reinterpret_cast<const u32*>(src0) + tile_base + r0;
+      u32 a = v0 ? src[0] : 0u, b = v1 ? src[1] : 0u;
+      reinterpret_cast<u32*>(dst)[r0] = a; reinterpret_cast<u32*>(dst)[r0 + 1u] = b;
+    } else {
+      const u8* src = reinterpret_cast<const u8*>(src0) + tile_base + r0;
+      u8 a = v0 ? src[0] : (u8)0, b = v1 ? src[1] : (u8)0;
+      reinterpret_cast<u8*>(dst)[r0] = a; reinterpret_cast<u8*>(dst)[r0 + 1u] = b;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -386,14 +400,18 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
 
   __syncthreads();  // constant pool and accumulator records visible to all waves
 
-  // register prefetch file: the first VM_PF_UNITS units of the NEXT tile
+  // register prefetch file: the first VM_PF_UNITS units of the NEXT (full) tile
   u32x4 pf[VM_PF_UNITS];
-  if (n_my_tiles > 0) {
-    const i64 tb = (i64)blockIdx.x * tile_rows;
-    const u32 tv = (u32)((P.n_rows - tb) < (i64)tile_rows ? (P.n_rows - tb) : (i64)tile_rows);
 #pragma unroll
-    for (int u = 0; u < VM_PF_UNITS; ++u)
-      if (u < n_units) pf[u] = load_unit<K>(P, u, tb, tv, tv == (u32)tile_rows, t);
+  for (int u = 0; u < VM_PF_UNITS; ++u) pf[u] = u32x4{0u, 0u, 0u, 0u};
+  const int n_pf = n_units < VM_PF_UNITS ? n_units : VM_PF_UNITS;
+  {
+    const i64 tb = (i64)blockIdx.x * tile_rows;
+    if (n_my_tiles > 0 && tb + tile_rows <= P.n_rows) {
+#pragma unroll
+      for (int u = 0; u < VM_PF_UNITS; ++u)
+        if (u < n_pf) load_unit<K>(P, u, tb, t, pf[u]);
+    }
   }
 
   u64 dbg_wait = 0;
@@ -404,29 +422,32 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     const i64 tile_base = (i64)tile * tile_rows;
     const u32 tile_valid = (u32)((P.n_rows - tile_base) < (i64)tile_rows ? (P.n_rows - tile_base) : (i64)tile_rows);
     const u64 tw0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
-    // commit the prefetched units (this is where a wave waits for HBM) ...
-#pragma unroll
-    for (int u = 0; u < VM_PF_UNITS; ++u)
-      if (u < n_units) commit_unit<K>(P, u, pf[u], t);
-    if (P.debug) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
-    // ... units beyond the register file are fetched in place (latency exposed; wide schemas
-    // still stream their first VM_PF_UNITS units ahead)
-    for (int u = VM_PF_UNITS; u < n_units; u += 4) {
-      u32x4 late[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (u + j < n_units) late[j] = load_unit<K>(P, u + j, tile_base, tile_valid, tile_valid == (u32)tile_rows, t);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (u + j < n_units) commit_unit<K>(P, u + j, late[j], t);
-    }
-    // ... and put the next tile's loads in flight before the program runs over this one
-    if (it + 1 < n_my_tiles) {
-      const i64 tb = tile_base + (i64)gridDim.x * tile_rows;
-      const u32 tv = (u32)((P.n_rows - tb) < (i64)tile_rows ? (P.n_rows - tb) : (i64)tile_rows);
+    if (tile_valid == (u32)tile_rows) {
+      // commit the prefetched units (this is where a wave waits for HBM) ...
+      int tc = t;
+      asm volatile("" : "+v"(tc));
 #pragma unroll
       for (int u = 0; u < VM_PF_UNITS; ++u)
-        if (u < n_units) pf[u] = load_unit<K>(P, u, tb, tv, tv == (u32)tile_rows, t);
+        if (u < n_pf) commit_unit<K>(P, u, pf[u], tc);
+      if (P.debug) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
+      // ... units beyond the register file are fetched in place (wide schemas still stream
+      // their first VM_PF_UNITS units ahead)
+      if (n_units > VM_PF_UNITS) stage_units_direct<K>(P, VM_PF_UNITS, n_units, tile_base, tile_valid, t);
+    } else {
+      stage_units_direct<K>(P, 0, n_units, tile_base, tile_valid, t);
+    }
+    // ... and put the next tile's loads in flight before the program runs over this one
+    {
+      const i64 tb = tile_base + (i64)gridDim.x * tile_rows;
+      if (it + 1 < n_my_tiles && tb + tile_rows <= P.n_rows) {
+        // launder the thread id: otherwise the per-unit lane offsets are hoisted out of the
+        // tile loop as 64-bit VGPR pairs and spilled (scratch reloads between the loads)
+        int tl = t;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int u = 0; u < VM_PF_UNITS; ++u)
+          if (u < n_pf) load_unit<K>(P, u, tb, tl, pf[u]);
+      }
     }
 
     // The program is immutable for the launch: fetch it through the constant address
