@@ -116,6 +116,7 @@ struct Stage {
   std::vector<AggOut> aggs;               // SCALAR_AGG / GROUP_AGG (out_schema order, after keys)
   std::vector<GroupKeyField> group_keys;  // GROUP_AGG
   std::vector<uint64_t> group_acc_init;   // per-group accumulator identities
+  std::vector<uint32_t> group_merge_op;   // VM_MERGE_* of every group accumulator
   int n_gaggs = 0;
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns

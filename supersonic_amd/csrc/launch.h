@@ -26,7 +26,6 @@ struct GroupKeyOut { void* data; uint8_t* is_null; uint32_t shift, bits, nullbit
 struct GroupAggOut { void* data; uint8_t* is_null; int s; int out_kind; int has_cnt; int pad; };
 struct GroupExtractParams {
   const unsigned long long* keys;
-  const unsigned long long* first_row;
   const unsigned long long* acc;
   const unsigned int* cnt;
   uint32_t capacity;      /* slots 0..capacity-1 + the special slot `capacity` */
@@ -34,7 +33,6 @@ struct GroupExtractParams {
   uint32_t n_keys;
   uint32_t n_aggs_out;
   const unsigned int* tile_offsets;
-  unsigned long long* out_first_row;
   GroupKeyOut keys_out[16];
   GroupAggOut aggs_out[VM_MAX_AGG_SLOTS];
 };

@@ -451,8 +451,8 @@ void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmIn
       const LInstr& i = p.code[pc];
       VmInstr v; memset(&v, 0, sizeof(v));
       v.op = i.op;
-      v.a_imm = i.a_imm ? i.imm_width : 0;
-      v.b_imm = i.b_imm ? i.imm_width : 0;
+      v.reg_ops = (uint8_t)((i.a_imm ? 0 : 1) | (i.b_imm ? 0 : 2));
+      v.imm_width = (i.a_imm || i.b_imm) ? i.imm_width : 0;
       v.dst = i.dst_is_reg ? off(i.dst) : (uint32_t)i.dst;
       const uint32_t pool = L.imm_pool_off + 16u * (uint32_t)pc;  // this instruction's constant
       v.a = i.a_imm ? pool : off(i.a);
@@ -852,6 +852,13 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
       ao.emit_kind = s.emit_kind;
     }
     st->group_acc_init.push_back(init);
+    {
+      uint32_t mop = VM_MERGE_ADD_U64;
+      if (ap.aggregation == SSGPU_MIN) mop = VM_MERGE_MIN_U64;
+      else if (ap.aggregation == SSGPU_MAX) mop = VM_MERGE_MAX_U64;
+      else if (ap.aggregation == SSGPU_SUM && (mtype(ap.out_type) == M_F32 || mtype(ap.out_type) == M_F64)) mop = VM_MERGE_ADD_F64;
+      st->group_merge_op.push_back(mop);
+    }
     st->aggs.push_back(ao);
     Attr a; a.name = ap.out_name; a.dtype = ap.out_type; a.nullable = ap.result_nullable;
     st->out_schema.push_back(a);

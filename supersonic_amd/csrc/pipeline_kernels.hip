@@ -26,7 +26,20 @@ typedef unsigned int u32;
 typedef int i32;
 typedef unsigned char u8;
 
-extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SSGPU_PC_PROFILE   // per-instruction cycle profile: development builds only (make PCPROF=1)
+#define PC_PROF(...) __VA_ARGS__
+#else
+#define PC_PROF(...)
+#endif
+// The kernel's LDS is all dynamic and starts at LDS address 0 (no static __shared__ in this
+// kernel), so VM register offsets ARE LDS addresses: `smem + off` is a plain integer-to-LDS-
+// pointer cast, with no per-use "add the symbol's base" scalar instruction.
+struct LdsBase {
+  __device__ __forceinline__ char* operator+(u32 off) const {
+    return (char*)(__attribute__((address_space(3))) char*)off;
+  }
+};
+static constexpr LdsBase smem{};
 
 template <typename T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2))); };
 
@@ -47,10 +60,8 @@ template <typename T> __device__ __forceinline__ T imm_as(u64 imm) {
 // written once per kernel): an immediate operand is the same pair load with stride 0, so
 // handlers are branch-free and their K loads issue back to back.
 template <typename T>
-__device__ __forceinline__ typename Vec2<T>::type fetch2(u32 off, u32 is_imm, u64 imm, int p) {
-  (void)imm;
-  // (pair offset) & mask instead of pair * stride: v_mul_lo_u32 is a quarter-rate instruction
-  const u32 mask = is_imm ? 0u : ~0u;
+__device__ __forceinline__ typename Vec2<T>::type fetch2(u32 off, u32 mask, int p) {
+  // (pair offset) & mask: a row register has mask ~0, the immediate mask 0 (stride-0 read)
   return *reinterpret_cast<const typename Vec2<T>::type*>(smem + off + (((u32)p * (u32)(2u * sizeof(T))) & mask));
 }
 
@@ -159,7 +170,7 @@ __device__ __forceinline__ u32 hash64(u64 k) {
 __device__ __forceinline__ u32 group_insert(const VmGroupTable& G, u64 key) {
   const u32 mask = G.capacity_mask;
   if (key == VM_KEY_EMPTY) {           // the one key equal to the sentinel owns slot `capacity`
-    __hip_atomic_store(&G.keys[mask + 1], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&G.keys[mask + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // != EMPTY: present
     return mask + 1;
   }
   u32 slot = hash64(key) & mask;
@@ -174,6 +185,32 @@ __device__ __forceinline__ u32 group_insert(const VmGroupTable& G, u64 key) {
     if (probe >= 4096) break;          // table (nearly) full: host regrows and reruns
   }
   atomicExch(G.overflow, 1u);
+  return 0xFFFFFFFFu;
+}
+
+// Workgroup-private table in LDS: the same open addressing with a short probe limit.  Returns
+// VM_SLOT_LOCAL | index, or 0xFFFFFFFF when the key has no place here (table full around its
+// home slot, or the EMPTY-valued key): that row then goes straight to the global table.
+// The table is split into local_sub independent sub-tables (local_sub_capacity entries each,
+// home slot = mulhi(hash, capacity)) and a lane uses sub-table (lane % local_sub): with few
+// groups, rows of one group in different lanes then hit different LDS words instead of
+// serialising on one.
+__device__ __forceinline__ u32 hash_local(u64 key) {   // two 32-bit multiplies (the 64-bit mixer costs ten)
+  u32 h = (u32)key ^ ((u32)(key >> 32) * 0x9E3779B1u);
+  h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+  return h;
+}
+__device__ __forceinline__ u32 group_probe_local(u64* keys, u32 cap, u32 tag, u64 key, u32 i, u64 cur) {
+  // `cur` = keys[i] already read by the caller (the common case is a hit on the home slot)
+  for (int probe = 0; probe < 16; ++probe) {
+    if (cur == key) return tag + i;
+    if (cur == VM_KEY_EMPTY) {
+      const u64 old = atomicCAS(&keys[i], VM_KEY_EMPTY, key);
+      if (old == VM_KEY_EMPTY || old == key) return tag + i;
+    }
+    i = i + 1u == cap ? 0u : i + 1u;
+    cur = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   return 0xFFFFFFFFu;
 }
 
@@ -264,8 +301,8 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
 #define BINOP(OPNAME, TA, TB, TD, EXPR)                                        \
   case VM_##OPNAME: { CASE_FENCE;                                              \
     _Pragma("unroll") FOR_PAIRS {                                              \
-      auto va = fetch2<TA>(I.a, I.a_imm, I.imm, p);                            \
-      auto vb = fetch2<TB>(I.b, I.b_imm, I.imm, p);                            \
+      auto va = fetch2<TA>(I.a, I.a_mask, p);                            \
+      auto vb = fetch2<TB>(I.b, I.b_mask, p);                            \
       TD r0, r1;                                                               \
       { TA a = va.x; TB b = vb.x; r0 = (TD)(EXPR); }                           \
       { TA a = va.y; TB b = vb.y; r1 = (TD)(EXPR); }                           \
@@ -276,7 +313,7 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
 #define UNOP(OPNAME, TA, TD, EXPR)                                             \
   case VM_##OPNAME: { CASE_FENCE;                                              \
     _Pragma("unroll") FOR_PAIRS {                                              \
-      auto va = fetch2<TA>(I.a, I.a_imm, I.imm, p);                            \
+      auto va = fetch2<TA>(I.a, I.a_mask, p);                            \
       TD r0, r1;                                                               \
       { TA a = va.x; r0 = (TD)(EXPR); }                                        \
       { TA a = va.y; r1 = (TD)(EXPR); }                                        \
@@ -295,7 +332,7 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
     _Pragma("unroll") FOR_PAIRS {                                              \
       i64 r0 = tile_base + 2 * (i64)p;                                         \
-      auto vv = fetch2<T>(I.a, I.a_imm, I.imm, p);                             \
+      auto vv = fetch2<T>(I.a, I.a_mask, p);                             \
       if (r0 + 1 < P.n_rows) {                                                 \
         *reinterpret_cast<typename Vec2<T>::type*>(out + r0) = vv;             \
       } else if (r0 < P.n_rows) {                                              \
@@ -309,7 +346,7 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
     _Pragma("unroll") FOR_PAIRS {                                              \
       Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);          \
-      auto vv = fetch2<T>(I.a, I.a_imm, I.imm, p);                             \
+      auto vv = fetch2<T>(I.a, I.a_mask, p);                             \
       auto rk = lds_load2<u32>(I.b, p);                                        \
       if (m.x) out[rk.x] = vv.x;                                               \
       if (m.y) out[rk.y] = vv.y;                                               \
@@ -334,12 +371,23 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     }                                                                          \
   } break;
 
-// group aggregate by global atomics on acc[slot * n_gaggs + s]
+// group aggregate: atomics on acc[slot * n_gaggs + s] of the workgroup's LDS table (slot ids
+// tagged VM_SLOT_LOCAL) or of the global table
 #define GAGG_PROLOGUE(LOADT)                                                   \
       Valid2 m = valid_pair_(p, tile_valid, I.b, VM_NONE);          \
       auto sl = lds_load2<u32>(I.c, p);                                        \
       m.x = m.x && sl.x != 0xFFFFFFFFu; m.y = m.y && sl.y != 0xFFFFFFFFu;      \
       auto vv = lds_load2<LOADT>(I.a, p);
+
+#define GAGG_APPLY(LOADT, SL, E, ATOM)                                         \
+      if ((SL) & VM_SLOT_LOCAL) {                                              \
+        const u32 li = ((SL) & ~VM_SLOT_LOCAL) * ng + s;                       \
+        u64* A = reinterpret_cast<u64*>(smem + P.group.local_acc_off) + li; LOADT e = (E); ATOM; \
+        if (has_cnt) atomicAdd(reinterpret_cast<u32*>(smem + P.group.local_cnt_off) + li, 1u); \
+      } else {                                                                 \
+        u64* A = &P.group.acc[(u64)(SL) * ng + s]; LOADT e = (E); ATOM;        \
+        if (has_cnt) atomicAdd(&P.group.cnt[(u64)(SL) * ng + s], 1u);          \
+      }
 
 #define GAGG_ATOMIC(OPNAME, LOADT, ATOM)                                       \
   case VM_##OPNAME: { CASE_FENCE;                                              \
@@ -347,10 +395,8 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     const bool has_cnt = (I.imm >> 63) != 0;                                   \
     _Pragma("unroll") FOR_PAIRS {                                              \
       GAGG_PROLOGUE(LOADT)                                                     \
-      if (m.x) { u64* A = &P.group.acc[(u64)sl.x * ng + s]; LOADT e = vv.x; ATOM; \
-                 if (has_cnt) atomicAdd(&P.group.cnt[(u64)sl.x * ng + s], 1u); } \
-      if (m.y) { u64* A = &P.group.acc[(u64)sl.y * ng + s]; LOADT e = vv.y; ATOM; \
-                 if (has_cnt) atomicAdd(&P.group.cnt[(u64)sl.y * ng + s], 1u); } \
+      if (m.x) { GAGG_APPLY(LOADT, sl.x, vv.x, ATOM) }                         \
+      if (m.y) { GAGG_APPLY(LOADT, sl.y, vv.y, ATOM) }                         \
     }                                                                          \
   } break;
 
@@ -388,7 +434,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
   // immediates -> LDS constant pool (entry pc: the value replicated to 16 bytes by width)
   for (int pc = t; pc < P.n_instr; pc += VM_COMPUTE_THREADS) {
     const VmInstr J = P.prog[pc];
-    const u32 w = J.a_imm ? J.a_imm : J.b_imm;
+    const u32 w = J.imm_width;
     if (w) {
       u64 lo = J.imm;
       if (w == 4) lo = (lo & 0xFFFFFFFFull) * 0x100000001ull;
@@ -398,7 +444,18 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     }
   }
 
-  __syncthreads();  // constant pool and accumulator records visible to all waves
+  if (P.group.local_capacity) {  // workgroup-private group table: empty keys, identity accumulators
+    const VmGroupTable& G = P.group;
+    for (u32 e = (u32)t; e < G.local_capacity; e += VM_COMPUTE_THREADS)
+      reinterpret_cast<u64*>(smem + G.local_keys_off)[e] = VM_KEY_EMPTY;
+    for (u32 i = (u32)t; i < G.local_capacity * G.n_gaggs; i += VM_COMPUTE_THREADS) {
+      reinterpret_cast<u64*>(smem + G.local_acc_off)[i] = G.acc_init[i % G.n_gaggs];
+      if (G.local_cnt_off != VM_NONE) reinterpret_cast<u32*>(smem + G.local_cnt_off)[i] = 0u;
+    }
+    if (t < 2) reinterpret_cast<u32*>(smem + P.scratch_lds_off + 128u)[t] = 0u;
+  }
+  PC_PROF(if (P.debug_pc) for (int i = t; i <= P.n_instr; i += VM_COMPUTE_THREADS) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[i] = 0ull;)
+  __syncthreads();  // constant pool, accumulator records and group table visible to all waves
 
   // register prefetch file: the first VM_PF_UNITS units of the NEXT (full) tile
   u32x4 pf[VM_PF_UNITS];
@@ -421,7 +478,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const i64 tile_base = (i64)tile * tile_rows;
     const u32 tile_valid = (u32)((P.n_rows - tile_base) < (i64)tile_rows ? (P.n_rows - tile_base) : (i64)tile_rows);
-    const u64 tw0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
+    const u64 tw0 = (P.debug || P.debug_pc) ? __builtin_amdgcn_s_memtime() : 0;
     if (tile_valid == (u32)tile_rows) {
       // commit the prefetched units (this is where a wave waits for HBM) ...
       int tc = t;
@@ -454,10 +511,19 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     // space so every instruction is ONE scalar s_load_dwordx8, and fetch the next
     // instruction while the current one executes.
     u32x8 raw_next = prog[0];
+    PC_PROF(u64 dbg_pc_last = 0;
+    if (P.debug_pc) { dbg_pc_last = __builtin_amdgcn_s_memtime(); if (t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr] += dbg_pc_last - tw0; })
     for (int pc = 0; pc < P.n_instr; ++pc) {
+      PC_PROF(if (P.debug_pc && pc > 0) {
+        const u64 now = __builtin_amdgcn_s_memtime();
+        if (t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[pc - 1] += now - dbg_pc_last;
+        dbg_pc_last = now;
+      })
       // decode by dwords (a struct memcpy makes the compiler shuffle SGPR bytes)
-      struct { u32 op, a_imm, b_imm, dst, a, b, c, d; u64 imm; } I;
-      I.op = raw_next[0] & 0xFFFFu; I.a_imm = (raw_next[0] >> 16) & 0xFFu; I.b_imm = raw_next[0] >> 24;
+      // a_mask / b_mask: all-ones for a row register, 0 for the (stride-0) immediate
+      struct { u32 op, a_mask, b_mask, dst, a, b, c, d; u64 imm; } I;
+      I.op = raw_next[0] & 0xFFFFu;
+      I.a_mask = (u32)((int)(raw_next[0] << 15) >> 31); I.b_mask = (u32)((int)(raw_next[0] << 14) >> 31);
       I.dst = raw_next[1]; I.a = raw_next[2]; I.b = raw_next[3]; I.c = raw_next[4]; I.d = raw_next[5];
       I.imm = (u64)raw_next[6] | ((u64)raw_next[7] << 32);
       raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
@@ -622,7 +688,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
 #define NULL_DIVZERO(OPNAME, T)                                                \
         case VM_##OPNAME: { CASE_FENCE;                                        \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
+            auto vb = fetch2<T>(I.b, I.b_mask, p);                       \
             Vec2<u8>::type z; z.x = z.y = 0;                                   \
             if (I.a != VM_NONE) z = lds_load2<u8>(I.a, p);                     \
             lds_store2<u8>(I.dst, p, (u8)(z.x || vb.x == (T)0), (u8)(z.y || vb.y == (T)0)); \
@@ -638,7 +704,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           bool bad = false;                                                    \
           _Pragma("unroll") FOR_PAIRS {                                        \
             Valid2 m = valid_pair_(p, tile_valid, I.a, I.c);        \
-            auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
+            auto vb = fetch2<T>(I.b, I.b_mask, p);                       \
             bad = bad || (m.x && vb.x == (T)0) || (m.y && vb.y == (T)0);       \
           }                                                                    \
           if (bad) atomicExch(P.error_flag, (u32)SSGPU_EVAL_ERROR_DIVZERO);    \
@@ -651,8 +717,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
 #define SELECT_OP(OPNAME, T)                                                   \
         case VM_##OPNAME: { CASE_FENCE;                                        \
           _Pragma("unroll") FOR_PAIRS {                                        \
-            auto va = fetch2<T>(I.a, I.a_imm, I.imm, p);                       \
-            auto vb = fetch2<T>(I.b, I.b_imm, I.imm, p);                       \
+            auto va = fetch2<T>(I.a, I.a_mask, p);                       \
+            auto vb = fetch2<T>(I.b, I.b_mask, p);                       \
             auto vc = lds_load2<u8>(I.c, p);                                   \
             lds_store2<T>(I.dst, p, vc.x ? va.x : vb.x, vc.y ? va.y : vb.y);   \
           }                                                                    \
@@ -662,7 +728,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
         SELECT_OP(SELECT_64, u64)
         case VM_SEL_FROM_PRED: { CASE_FENCE;  // keep iff predicate is non-NULL and TRUE (filter.cc:180-196)
           _Pragma("unroll") FOR_PAIRS {
-            auto va = fetch2<u8>(I.a, I.a_imm, I.imm, p);
+            auto va = fetch2<u8>(I.a, I.a_mask, p);
             u8 s0 = va.x != 0, s1 = va.y != 0;
             if (I.b != VM_NONE) { auto z = lds_load2<u8>(I.b, p); s0 = s0 && !z.x; s1 = s1 && !z.y; }
             if (I.c != VM_NONE) { auto q = lds_load2<u8>(I.c, p); s0 = s0 && q.x; s1 = s1 && q.y; }
@@ -1421,8 +1487,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
             u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
             _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<u64>(I.a, I.a_imm, I.imm, p);
-              auto vd = fetch2<u64>(I.d, I.b_imm, I.imm, p);
+              auto va = fetch2<u64>(I.a, I.a_mask, p);
+              auto vd = fetch2<u64>(I.d, I.b_mask, p);
               Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
               { u64 a = va.x, b = vd.x; acc += m.x ? (a + b) : 0ull; }
               { u64 a = va.y, b = vd.y; acc += m.y ? (a + b) : 0ull; }
@@ -1435,8 +1501,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
             u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
             _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<u64>(I.a, I.a_imm, I.imm, p);
-              auto vd = fetch2<u64>(I.d, I.b_imm, I.imm, p);
+              auto va = fetch2<u64>(I.a, I.a_mask, p);
+              auto vd = fetch2<u64>(I.d, I.b_mask, p);
               Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
               { u64 a = va.x, b = vd.x; acc += m.x ? (a - b) : 0ull; }
               { u64 a = va.y, b = vd.y; acc += m.y ? (a - b) : 0ull; }
@@ -1449,8 +1515,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
             u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
             _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<u64>(I.a, I.a_imm, I.imm, p);
-              auto vd = fetch2<u64>(I.d, I.b_imm, I.imm, p);
+              auto va = fetch2<u64>(I.a, I.a_mask, p);
+              auto vd = fetch2<u64>(I.d, I.b_mask, p);
               Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
               { u64 a = va.x, b = vd.x; acc += m.x ? (a * b) : 0ull; }
               { u64 a = va.y, b = vd.y; acc += m.y ? (a * b) : 0ull; }
@@ -1463,8 +1529,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           if (I.dst < VM_FAST_SLOTS) {
             DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
             _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<double>(I.a, I.a_imm, I.imm, p);
-              auto vd = fetch2<double>(I.d, I.b_imm, I.imm, p);
+              auto va = fetch2<double>(I.a, I.a_mask, p);
+              auto vd = fetch2<double>(I.d, I.b_mask, p);
               Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
               { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a + b)); }
               { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a + b)); }
@@ -1477,8 +1543,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           if (I.dst < VM_FAST_SLOTS) {
             DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
             _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<double>(I.a, I.a_imm, I.imm, p);
-              auto vd = fetch2<double>(I.d, I.b_imm, I.imm, p);
+              auto va = fetch2<double>(I.a, I.a_mask, p);
+              auto vd = fetch2<double>(I.d, I.b_mask, p);
               Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
               { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a - b)); }
               { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a - b)); }
@@ -1491,8 +1557,8 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           if (I.dst < VM_FAST_SLOTS) {
             DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
             _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<double>(I.a, I.a_imm, I.imm, p);
-              auto vd = fetch2<double>(I.d, I.b_imm, I.imm, p);
+              auto va = fetch2<double>(I.a, I.a_mask, p);
+              auto vd = fetch2<double>(I.d, I.b_mask, p);
               Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
               { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a * b)); }
               { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a * b)); }
@@ -1560,14 +1626,31 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
         KEY_APPEND_OP(KEY_APPEND_32, u32, u32)
         KEY_APPEND_OP(KEY_APPEND_64, u64, u64)
         case VM_GRP_INSERT: { CASE_FENCE;
+          const VmGroupTable& G = P.group;
+          const bool local = G.local_capacity != 0;
+          const u32 cap = G.local_sub_capacity, sub = ((u32)lane & (G.local_sub - 1u)) * cap;
+          u64* lkeys = reinterpret_cast<u64*>(smem + G.local_keys_off) + sub;
+          const u32 tag = VM_SLOT_LOCAL | sub;
+          u32 bypass = 0;
           _Pragma("unroll") FOR_PAIRS {
             Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
             auto kk = lds_load2<u64>(I.a, p);
-            u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
             u32 s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;
-            if (m.x) { s0 = group_insert(P.group, kk.x); if (s0 != 0xFFFFFFFFu) atomicMin(&P.group.first_row[s0], r0); }
-            if (m.y) { s1 = group_insert(P.group, kk.y); if (s1 != 0xFFFFFFFFu) atomicMin(&P.group.first_row[s1], r0 + 1); }
+            if (local) {
+              // both rows' home slots are read back to back, then resolved
+              const u32 i0 = __umulhi(hash_local(kk.x), cap), i1 = __umulhi(hash_local(kk.y), cap);
+              const u64 c0 = __hip_atomic_load(&lkeys[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const u64 c1 = __hip_atomic_load(&lkeys[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (m.x && kk.x != VM_KEY_EMPTY) s0 = group_probe_local(lkeys, cap, tag, kk.x, i0, c0);
+              if (m.y && kk.y != VM_KEY_EMPTY) s1 = group_probe_local(lkeys, cap, tag, kk.y, i1, c1);
+            }
+            if (m.x && s0 == 0xFFFFFFFFu) { s0 = group_insert(G, kk.x); ++bypass; }
+            if (m.y && s1 == 0xFFFFFFFFu) { s1 = group_insert(G, kk.y); ++bypass; }
             lds_store2<u32>(I.dst, p, s0, s1);
+          }
+          if (local && __ballot(bypass != 0)) {   // feedback for the host's table sizing
+            const u32 nb = (u32)wave_reduce_u64((u64)bypass, [](u64 x, u64 y) { return x + y; });
+            if (lane == 0) atomicAdd(reinterpret_cast<u32*>(smem + P.scratch_lds_off + 128u), nb);
           }
         } break;
         case VM_GAGG_COUNT: { CASE_FENCE;
@@ -1575,8 +1658,14 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           _Pragma("unroll") FOR_PAIRS {
             Valid2 m = valid_pair_(p, tile_valid, I.b, VM_NONE);
             auto sl = lds_load2<u32>(I.c, p);
-            if (m.x && sl.x != 0xFFFFFFFFu) atomicAdd(&P.group.acc[(u64)sl.x * ng + s], 1ull);
-            if (m.y && sl.y != 0xFFFFFFFFu) atomicAdd(&P.group.acc[(u64)sl.y * ng + s], 1ull);
+            if (m.x && sl.x != 0xFFFFFFFFu) {
+              if (sl.x & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.x & ~VM_SLOT_LOCAL) * ng + s, 1ull);
+              else atomicAdd(&P.group.acc[(u64)sl.x * ng + s], 1ull);
+            }
+            if (m.y && sl.y != 0xFFFFFFFFu) {
+              if (sl.y & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.y & ~VM_SLOT_LOCAL) * ng + s, 1ull);
+              else atomicAdd(&P.group.acc[(u64)sl.y * ng + s], 1ull);
+            }
           }
         } break;
         GAGG_ATOMIC(GAGG_SUM_I32, i32, atomicAdd(A, (u64)(i64)e))
@@ -1604,8 +1693,43 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
         default: break;
       }
     }
+    PC_PROF(if (P.debug_pc && P.n_instr > 0 && t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr - 1] += __builtin_amdgcn_s_memtime() - dbg_pc_last;)
   }
 
+  if (P.group.local_capacity) {
+    // merge the workgroup's table into the global one: one atomic per (group, aggregate)
+    // per workgroup instead of one per row
+    const VmGroupTable& G = P.group;
+    __syncthreads();
+    const u32 ng = G.n_gaggs;
+    u32 occupied = 0;
+    for (u32 e = (u32)t; e < G.local_capacity; e += VM_COMPUTE_THREADS) {
+      const u64 key = reinterpret_cast<const u64*>(smem + G.local_keys_off)[e];
+      if (key == VM_KEY_EMPTY) continue;
+      ++occupied;
+      const u32 gs = group_insert(G, key);
+      if (gs == 0xFFFFFFFFu) continue;  // global table full: the host regrows and reruns
+      for (u32 s = 0; s < ng; ++s) {
+        const u64 v = reinterpret_cast<const u64*>(smem + G.local_acc_off)[e * ng + s];
+        u64* A = &G.acc[(u64)gs * ng + s];
+        const u32 op = G.merge_op[s];
+        if (op == VM_MERGE_ADD_U64) { if (v) atomicAdd(A, v); }
+        else if (op == VM_MERGE_MIN_U64) atomicMin(A, v);
+        else if (op == VM_MERGE_MAX_U64) atomicMax(A, v);
+        else unsafeAtomicAdd(reinterpret_cast<double*>(A), u2d(v));
+        if (G.local_cnt_off != VM_NONE) {
+          const u32 c = reinterpret_cast<const u32*>(smem + G.local_cnt_off)[e * ng + s];
+          if (c) atomicAdd(&G.cnt[(u64)gs * ng + s], c);
+        }
+      }
+    }
+    u32* st = reinterpret_cast<u32*>(smem + P.scratch_lds_off + 128u);
+    if (occupied) atomicAdd(&st[1], occupied);
+    __syncthreads();
+    if (t == 0) { if (st[0]) atomicAdd(&G.stats[0], st[0]); atomicMax(&G.stats[1], st[1]); }
+  }
+
+  PC_PROF(if (P.debug_pc && t == 0) for (int i = 0; i <= P.n_instr; ++i) atomicAdd(&P.debug_pc[i], reinterpret_cast<const u64*>(smem + P.debug_pc_lds_off)[i]);)
   if (P.debug && t == 0) {
     P.debug[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - dbg_t0;
     P.debug[blockIdx.x * 4 + 1] = dbg_wait;
@@ -1825,8 +1949,7 @@ __global__ __launch_bounds__(1024) void ssgpu_scan_counts_kernel(const u32* __re
 __device__ __forceinline__ bool group_slot_occupied(const GroupExtractParams& P, u32 slot) {
   if (slot > P.capacity) return false;
   // the special slot `capacity` owns the key whose value equals the EMPTY sentinel
-  if (slot == P.capacity) return P.first_row[slot] != ~0ull;
-  return P.keys[slot] != VM_KEY_EMPTY;
+  return P.keys[slot] != VM_KEY_EMPTY;  // the special slot holds 0 once its key was seen
 }
 
 __global__ __launch_bounds__(256) void ssgpu_group_count_kernel(const GroupExtractParams P, u32* __restrict__ tile_counts) {
@@ -1859,8 +1982,7 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
   for (int j = 0; j < 2; ++j) {
     if (!oo[j]) continue;
     const u32 slot = s0 + j; const u32 row = rr[j];
-    const u64 key = P.keys[slot];
-    P.out_first_row[row] = P.first_row[slot];
+    const u64 key = slot == P.capacity ? VM_KEY_EMPTY : P.keys[slot];
     for (u32 q = 0; q < P.n_keys; ++q) {
       const GroupKeyOut ko = P.keys_out[q];
       u64 field = key >> ko.shift;

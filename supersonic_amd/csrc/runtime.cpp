@@ -34,8 +34,9 @@ struct ssgpu_ctx {
   std::string err;
   LowerOptions opt;
   int64_t grid_limit = 0;        // 0 = CUs * residency
-  int64_t wgs_per_cu = 4;        // resident 4-wave workgroups per CU (<= 4 at the kernel's 128-VGPR budget)
+  int64_t wgs_per_cu = 3;        // resident 4-wave workgroups per CU (<= 4 at the kernel's 128-VGPR budget; 3 streams best)
   int64_t group_capacity = 1 << 18;
+  int64_t group_local = 1;       // 0: never use the LDS pre-aggregation table
   int64_t profile = 1;           // record HIP events around kernels
   int64_t debug_timing = 0;
   int64_t kernel_flags = 0;      // in-kernel cycle counters (development aid)
@@ -84,10 +85,13 @@ struct StageExec {
   // filter compaction
   DevBuf tile_counts, tile_offsets, total;
   // group table
-  DevBuf gkeys, gfirst, gacc, gcnt, goverflow, gpattern, gout_first;
+  DevBuf gkeys, gacc, gcnt, goverflow, gpattern, gmergeop;
+  int group_wgs = 3;            // resident workgroups per CU of the group stage (adapted from run feedback)
+  bool group_local = true;      // workgroup-private LDS pre-aggregation table in use
+  int group_sub = 1;            // sub-tables of the LDS table (spreads same-group rows of a wave)
   uint32_t capacity = 0;
   DevBuf error_flag;
-  DevBuf debug;
+  DevBuf debug, debug_pc;
   // sort / clusters
   DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id;
   bool emit_ready = false;
@@ -191,7 +195,8 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
     c->opt.tile_rows = (int)value;
   } else if (k == "lds_target_bytes") c->opt.lds_target_bytes = (int)value;
   else if (k == "grid_limit") c->grid_limit = value;
-  else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 4;
+  else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 3;
+  else if (k == "group_local") c->group_local = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -354,6 +359,28 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   return SSGPU_OK;
 }
 
+// debug_timing >= 2: per-instruction cycle profile of a stage program (development aid)
+int attach_pc_profile(ssgpu_ctx* c, StageExec& ex, VmParams* P) {
+  if (c->debug_timing < 2) return SSGPU_OK;
+  HIP_TRY(c, ex.debug_pc.ensure((size_t)(P->n_instr + 1) * 8));
+  HIP_TRY(c, hipMemsetAsync(ex.debug_pc.p, 0, (size_t)(P->n_instr + 1) * 8, c->stream));
+  P->debug_pc = ex.debug_pc.as<unsigned long long>();
+  P->debug_pc_lds_off = (P->lds_bytes + 7u) & ~7u;
+  P->lds_bytes = P->debug_pc_lds_off + (uint32_t)(P->n_instr + 1) * 8u;
+  return SSGPU_OK;
+}
+int print_pc_profile(ssgpu_ctx* c, StageExec& ex, const Program& prog, int n_instr) {
+  if (c->debug_timing < 2) return SSGPU_OK;
+  std::vector<unsigned long long> cyc((size_t)n_instr + 1);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(cyc.data(), ex.debug_pc.p, cyc.size() * 8, hipMemcpyDeviceToHost));
+  double tot = 0; for (auto v : cyc) tot += (double)v;
+  fprintf(stderr, "[ssgpu pc-profile] staging+wait %5.1f%%\n", 100.0 * (double)cyc[n_instr] / tot);
+  for (int pc = 0; pc < n_instr && pc < (int)prog.code.size(); ++pc)
+    fprintf(stderr, "[ssgpu pc-profile] %3d %-22s %5.1f%%\n", pc, vm_op_name(prog.code[pc].op), 100.0 * (double)cyc[pc] / tot);
+  return SSGPU_OK;
+}
+
 int grid_for(ssgpu_ctx* c, const ProgramLayout& L, int n_tiles) {
   int per_cu = (int)std::min<uint32_t>((uint32_t)c->wgs_per_cu, (160u * 1024u) / std::max<uint32_t>(L.lds_bytes, 1));
   if (per_cu < 1) per_cu = 1;
@@ -448,9 +475,11 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
     P.debug = ex.debug.as<unsigned long long>();
   }
   HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
+  { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
   HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
   HIP_TRY(c, ssgpu_launch_finish_slots(ex.wg_partials.as<VmAccRec>(), ns, grid * VM_WAVES, ex.slot_kind.as<int>(),
                                        ex.slot_recs.as<VmAccRec>(), c->stream));
   p->counters.n_launches += 2;
@@ -541,42 +570,101 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
   for (int attempt = 0; attempt < 8; ++attempt) {
     const size_t slots = (size_t)ex.capacity + 1;
     HIP_TRY(c, ex.gkeys.ensure(slots * 8));
-    HIP_TRY(c, ex.gfirst.ensure(slots * 8));
     HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
     HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
-    HIP_TRY(c, ex.goverflow.ensure(4));
+    HIP_TRY(c, ex.goverflow.ensure(16));
     HIP_TRY(c, ex.gpattern.ensure(ng * 8));
+    HIP_TRY(c, ex.gmergeop.ensure(ng * 4));
     if (!ex.pattern_ready) {
       std::vector<uint64_t> pattern(ng, 0);
+      std::vector<uint32_t> mop(ng, VM_MERGE_ADD_U64);
       for (size_t i = 0; i < st.group_acc_init.size(); ++i) pattern[i] = st.group_acc_init[i];
+      for (size_t i = 0; i < st.group_merge_op.size(); ++i) mop[i] = st.group_merge_op[i];
       HIP_TRY(c, hipMemcpy(ex.gpattern.p, pattern.data(), ng * 8, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(ex.gmergeop.p, mop.data(), ng * 4, hipMemcpyHostToDevice));
       ex.pattern_ready = true;
     }
     HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>(), VM_KEY_EMPTY, slots, c->stream));
-    HIP_TRY(c, ssgpu_launch_fill_u64(ex.gfirst.as<uint64_t>(), ~0ull, slots, c->stream));
     HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>(), ex.gpattern.as<uint64_t>(), ng, slots * ng, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.gcnt.p, 0, slots * ng * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
     VmParams P;
     fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
     P.error_flag = ex.error_flag.as<unsigned int>();
     P.group.keys = ex.gkeys.as<unsigned long long>();
-    P.group.first_row = ex.gfirst.as<unsigned long long>();
     P.group.acc = ex.gacc.as<unsigned long long>();
     P.group.cnt = ex.gcnt.as<unsigned int>();
     P.group.overflow = ex.goverflow.as<unsigned int>();
+    P.group.stats = ex.goverflow.as<unsigned int>() + 1;
     P.group.capacity_mask = ex.capacity - 1;
-    const int grid = grid_for(c, ex.lay, P.n_tiles);
+    P.group.n_gaggs = ng;
+    P.group.acc_init = ex.gpattern.as<unsigned long long>();
+    P.group.merge_op = ex.gmergeop.as<unsigned int>();
+    // workgroup-private pre-aggregation table behind the program's LDS registers: as many
+    // entries as the LDS share of `group_wgs` resident workgroups per CU leaves room for
+    bool any_cnt = false;
+    for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
+    const uint32_t entry = 8u + ng * 8u + (any_cnt ? ng * 4u : 0u);
+    const uint32_t base = (ex.lay.lds_bytes + 15u) & ~15u;
+    auto local_capacity_for = [&](int wgs) -> uint32_t {
+      const uint32_t share = (160u * 1024u) / (uint32_t)wgs;
+      if (share < base + 64u + 16u * entry) return 0u;
+      return std::min<uint32_t>((share - base - 64u) / entry, 8192u);
+    };
+    uint32_t lcap = (c->group_local && ex.group_local) ? local_capacity_for(ex.group_wgs) : 0u;
+    const uint32_t lsub = (uint32_t)std::max(ex.group_sub, 1);
+    lcap = lcap / lsub * lsub;
+    P.group.local_capacity = lcap;
+    P.group.local_sub = lsub;
+    P.group.local_sub_capacity = lcap / lsub;
+    if (lcap) {
+      P.group.local_keys_off = base;
+      P.group.local_acc_off = base + lcap * 8u;
+      P.group.local_cnt_off = any_cnt ? base + lcap * 8u + lcap * ng * 8u : VM_NONE;
+      P.lds_bytes = base + lcap * entry;
+    }
+    int grid;
+    {
+      ProgramLayout Lg = ex.lay; Lg.lds_bytes = P.lds_bytes;
+      const int64_t saved = c->wgs_per_cu;
+      if (lcap) c->wgs_per_cu = std::min<int64_t>(saved, ex.group_wgs);
+      grid = grid_for(c, Lg, P.n_tiles);
+      c->wgs_per_cu = saved;
+    }
     ex.grid = grid;
-    p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
+    p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)P.lds_bytes;
+    { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
     HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+    { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
+    if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: wgs/CU=%d local entries=%u sub-tables=%u grid=%d lds=%u\n", ex.group_wgs, lcap, lsub, grid, P.lds_bytes);
     p->counters.n_launches += 5;
-    uint32_t overflow = 0;
-    HIP_TRY(c, hipMemcpyAsync(&overflow, ex.goverflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t fb[4] = {0, 0, 0, 0};   // overflow flag, rows that bypassed the local table, max local occupancy
+    HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t overflow = fb[0];
+    if (lcap && !overflow) {
+      // feedback for the next run of this plan: the largest residency whose table still holds
+      // every group of a workgroup at <= 75% load; a table most rows bypass is switched off
+      if (fb[1] == 0) {
+        const uint32_t groups = std::max<uint32_t>((fb[2] + lsub - 1u) / lsub, 1u);  // per workgroup
+        int best = 1;
+        for (int w = 4; w >= 1; --w) if (local_capacity_for(w) * 3u >= 4u * groups) { best = w; break; }
+        ex.group_wgs = best;
+        // (splitting the table into per-lane-group sub-tables was measured: 1.5 -> 2.1 ms on an
+        //  8-group query; same-address LDS atomics are not the bottleneck, so group_sub stays 1)
+      } else if ((uint64_t)fb[1] * 2u >= (uint64_t)std::max<int64_t>(in.rows, 1) && local_capacity_for(1) <= lcap) {
+        ex.group_local = false;
+      } else if (ex.group_sub > 1) {
+        ex.group_sub = 1;
+      } else if (ex.group_wgs > 1) {
+        ex.group_wgs -= 1;
+      } else if ((uint64_t)fb[1] * 2u >= (uint64_t)std::max<int64_t>(in.rows, 1)) {
+        ex.group_local = false;
+      }
+    }
     if (!overflow) break;
     // table too small for this input: regrow x4 and run again (the reference grows its
     // Aggregator x2 on demand, aggregate_groups.cc:372-402)
@@ -591,14 +679,12 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
   HIP_TRY(c, ex.tile_counts.ensure((size_t)ntile * 4));
   HIP_TRY(c, ex.tile_offsets.ensure((size_t)ntile * 4));
   HIP_TRY(c, ex.total.ensure(8));
-  HIP_TRY(c, ex.gout_first.ensure(slots * 8));
   GroupExtractParams G;
   memset(&G, 0, sizeof(G));
-  G.keys = ex.gkeys.as<unsigned long long>(); G.first_row = ex.gfirst.as<unsigned long long>();
+  G.keys = ex.gkeys.as<unsigned long long>();
   G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
   G.capacity = ex.capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size();
   G.tile_offsets = ex.tile_offsets.as<unsigned int>();
-  G.out_first_row = ex.gout_first.as<unsigned long long>();
   for (size_t k = 0; k < st.group_keys.size(); ++k) {
     const GroupKeyField& f = st.group_keys[k];
     G.keys_out[k].data = ex.out[k].data.p;

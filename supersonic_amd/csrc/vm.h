@@ -84,7 +84,7 @@
   X(AGG_MAX_F32) X(AGG_MAX_F64) X(AGG_MAX_B8)                                  \
   X(AGG_FIRST_8) X(AGG_FIRST_32) X(AGG_FIRST_64)                               \
   X(AGG_LAST_8) X(AGG_LAST_32) X(AGG_LAST_64)                                  \
-  /* fused SUM(a op d) for register-resident slots: a, d operands (b_imm flags d) */\
+  /* fused SUM(a op d) for register-resident slots: a, d operands (reg_ops bit 1 describes d) */\
   X(AGG_SUM_I64_ADD) X(AGG_SUM_I64_SUB) X(AGG_SUM_I64_MUL)                     \
   X(AGG_SUM_F64_ADD) X(AGG_SUM_F64_SUB) X(AGG_SUM_F64_MUL)                     \
   /* ---- materialising sinks ---------------------------------------------- */\
@@ -116,8 +116,9 @@ enum VmOp : uint16_t {
 
 struct VmInstr {
   uint16_t op;
-  uint8_t a_imm; /* != 0: operand a is the immediate; value = its width in bytes (1/4/8) */
-  uint8_t b_imm; /* != 0: operand b is the immediate; `a`/`b` then point at the LDS constant pool */
+  uint8_t reg_ops;   /* bit 0: operand a is a row register, bit 1: operand b (fused aggregates: d) is;
+                        a clear bit = the immediate, whose operand field points at the LDS constant pool */
+  uint8_t imm_width; /* width in bytes (1/4/8) of the immediate, 0 = none */
   uint32_t dst;  /* LDS byte offset | aggregate slot | output column index */
   uint32_t a, b, c, d; /* LDS byte offsets, VM_NONE when absent */
   uint64_t imm;
@@ -146,14 +147,30 @@ struct VmAccRec {
 
 /* Group table (open addressing, 64-bit packed keys). */
 struct VmGroupTable {
-  unsigned long long* keys;      /* capacity + 1 entries (last = EMPTY-valued key) */
-  unsigned long long* first_row; /* min global row id per slot                    */
-  unsigned long long* acc;       /* [n_gaggs][capacity+1] value bits              */
-  unsigned int* cnt;             /* [n_gaggs][capacity+1] contribution counts      */
+  unsigned long long* keys;      /* capacity + 1 entries; [capacity] != EMPTY marks the EMPTY-valued key present */
+  unsigned long long* acc;       /* [capacity+1][n_gaggs] value bits              */
+  unsigned int* cnt;             /* [capacity+1][n_gaggs] contribution counts      */
   unsigned int* overflow;        /* set to 1 when probing exhausted the table      */
   uint32_t capacity_mask;        /* capacity - 1                                   */
-  uint32_t pad;
+  /* workgroup-private pre-aggregation table in LDS (local_capacity == 0: disabled).  Rows
+   * whose key does not fit go straight to the global table; the local entries are merged
+   * into the global table once, at the end of the kernel. */
+  uint32_t local_capacity;       /* entries (a multiple of local_sub)              */
+  uint32_t local_sub;            /* independent sub-tables, lane % local_sub picks one (power of two) */
+  uint32_t local_sub_capacity;   /* local_capacity / local_sub                     */
+  uint32_t local_keys_off;       /* LDS offsets: u64 keys[C], u64 acc[C][n], u32 cnt[C][n] */
+  uint32_t local_acc_off;
+  uint32_t local_cnt_off;        /* VM_NONE: no aggregate needs a contribution count */
+  uint32_t n_gaggs;
+  const unsigned long long* acc_init;  /* [n_gaggs] identities                      */
+  const unsigned int* merge_op;        /* [n_gaggs] VM_MERGE_*                       */
+  unsigned int* stats;           /* [0] rows that bypassed the local table, [1] max local occupancy */
 };
+#define VM_MERGE_ADD_U64 0u
+#define VM_MERGE_MIN_U64 1u
+#define VM_MERGE_MAX_U64 2u
+#define VM_MERGE_ADD_F64 3u
+#define VM_SLOT_LOCAL 0x80000000u /* GRP_INSERT result: index into the LDS table */
 #define VM_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 
 struct VmParams {
@@ -182,6 +199,9 @@ struct VmParams {
   const unsigned int* tile_offsets;
   unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */
+  unsigned long long* debug_pc; /* optional [n_instr + 1]: cycles per instruction (wave 0 of every workgroup); last = staging */
+  uint32_t debug_pc_lds_off;    /* LDS scratch of the same shape (accumulated there, flushed once) */
+  uint32_t pad_dbg;
   VmGroupTable group;
   VmStagedCol staged[VM_MAX_STAGED];
   VmOutCol outputs[VM_MAX_OUTPUTS];

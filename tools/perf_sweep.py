@@ -55,6 +55,22 @@ def q_group(v):
     return ss.GroupAggregate(ss.ProjectNamedAttributes(["c"]), spec, None, ss.ScanView(v))
 
 
+def q_group_small(v):
+    # 1000 groups (key a), SUM/MIN/MAX over 4 DOUBLE columns
+    spec = ss.AggregationSpecification()
+    for c in ["d0", "d1", "d2", "d3"]:
+        spec.AddAggregation(ss.SUM, c, "s" + c).AddAggregation(ss.MIN, c, "n" + c).AddAggregation(ss.MAX, c, "x" + c)
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(["a"]), spec, None, ss.ScanView(v))
+
+
+def q_group_tiny(v):
+    # 8 groups, 3 aggregates (TPC-H Q1 shape)
+    e = ss.CompoundExpression().AddAs("k", ss.ModulusSignaling(NA("a"), ss.ConstInt64(8))).Add(NA("d0")).Add(NA("d1"))
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "d0", "s0").AddAggregation(ss.SUM, "d1", "s1")
+            .AddAggregation(ss.COUNT, "", "n"))
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.Compute(e, ss.ScanView(v)))
+
+
 def q_addn(n):
     def q(v):
         e = NA("a")
@@ -93,7 +109,7 @@ def q_group2(v):
 
 
 QUERIES = {"sort": q_sort, "sort_key": q_sort_keyonly, "group2": q_group2, "add4": q_addn(4), "add16": q_addn(16), "sum4": q_sumn(4), "sum8": q_sumn(8),"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
-           "filter_mat": q_filter_mat, "group": q_group}
+           "filter_mat": q_filter_mat, "group": q_group, "group_small": q_group_small, "group_tiny": q_group_tiny}
 
 
 def main():
@@ -136,7 +152,7 @@ def main():
                         ms.sort()
                         dom, tot = ms[len(ms) // 2]
                         gbs = c.algorithmic_bytes / (dom / 1e3) / 1e9
-                        if qn.startswith("sort") or qn in ("filter_mat", "group", "group2"):
+                        if qn.startswith("sort") or qn in ("filter_mat", "group", "group2", "group_small", "group_tiny"):
                             print("   [%s] total kernel time %.3f ms -> %.2f Grows/s, launches %d" % (qn, tot, args.rows / tot / 1e6, c.n_launches))
                         print("%-10s tile=%-5d lds_target=%-6d grid=%-5d lds=%-6d dom=%.3f ms total=%.3f ms  %.0f GB/s (%.1f%% of 8TB/s)  %.1f Grows/s" % (
                             qn, c.tile_rows, lds, c.grid, c.lds_bytes, dom, tot, gbs, gbs / 80.0, args.rows / dom / 1e6), flush=True)
