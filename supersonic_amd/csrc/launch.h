@@ -56,7 +56,7 @@ hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, u
 // sort / clusters (sort_kernels.hip)
 hipError_t ssgpu_launch_sort_iota(uint32_t* idx, uint64_t n, hipStream_t s);
 hipError_t ssgpu_launch_sort_load_keys(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width,
-                                       int kind, int descending, int null_pass, uint64_t n, hipStream_t s);
+                                       int kind, int descending, int null_pass, uint64_t n, unsigned long long* bits, hipStream_t s);
 uint32_t ssgpu_sort_tiles(uint64_t n);
 hipError_t ssgpu_launch_sort_hist(const uint64_t* keys, uint32_t shift, uint64_t n, uint32_t* hist, hipStream_t s);
 hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out,

@@ -91,7 +91,7 @@ struct StageExec {
   int group_sub = 1;            // sub-tables of the LDS table (spreads same-group rows of a wave)
   uint32_t capacity = 0;
   DevBuf error_flag;
-  DevBuf debug, debug_pc;
+  DevBuf debug, debug_pc, total2;
   // sort / clusters
   DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id;
   bool emit_ready = false;
@@ -724,7 +724,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   HIP_TRY(c, ex.skeys_a.ensure(std::max<uint64_t>(n, 1) * 8)); HIP_TRY(c, ex.skeys_b.ensure(std::max<uint64_t>(n, 1) * 8));
   HIP_TRY(c, ex.sidx_a.ensure(std::max<uint64_t>(n, 1) * 4)); HIP_TRY(c, ex.sidx_b.ensure(std::max<uint64_t>(n, 1) * 4));
   HIP_TRY(c, ex.shist.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4)); HIP_TRY(c, ex.soffs.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4));
-  HIP_TRY(c, ex.total.ensure(8));
+  HIP_TRY(c, ex.total.ensure(8)); HIP_TRY(c, ex.total2.ensure(16));
   uint64_t* ka = ex.skeys_a.as<uint64_t>(); uint64_t* kb = ex.skeys_b.as<uint64_t>();
   uint32_t* ia = ex.sidx_a.as<uint32_t>(); uint32_t* ib = ex.sidx_b.as<uint32_t>();
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
@@ -743,11 +743,25 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     const int dtype = st.in_schema[sk.col].dtype;
     const uint32_t w = (uint32_t)dtype_width(dtype);
     const uint8_t* nulls = in.cols[sk.col].is_null;
-    HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, in.cols[sk.col].data, nulls, w, sort_kind_of(dtype), sk.order == SSGPU_DESCENDING, 0, n, c->stream));
-    for (uint32_t pass = 0; pass < w; ++pass) { rc = one_pass(pass * 8); if (rc != SSGPU_OK) return rc; }
+    // OR / AND of all transformed keys: digits on which every key agrees are skipped
+    auto load_and_profile = [&](int kind, int null_pass, uint64_t* varying) -> int {
+      const unsigned long long init[2] = {0ull, ~0ull};
+      HIP_TRY(c, hipMemcpyAsync(ex.total2.p, init, 16, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, in.cols[sk.col].data, nulls, w, kind, sk.order == SSGPU_DESCENDING, null_pass, n,
+                                             ex.total2.as<unsigned long long>(), c->stream));
+      unsigned long long bits[2];
+      HIP_TRY(c, hipMemcpyAsync(bits, ex.total2.p, 16, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      *varying = bits[0] ^ bits[1];
+      return SSGPU_OK;
+    };
+    uint64_t varying = 0;
+    rc = load_and_profile(sort_kind_of(dtype), 0, &varying); if (rc != SSGPU_OK) return rc;
+    for (uint32_t pass = 0; pass < w; ++pass)
+      if ((varying >> (pass * 8)) & 0xFFull) { rc = one_pass(pass * 8); if (rc != SSGPU_OK) return rc; }
     if (nulls && st.in_schema[sk.col].nullable) {
-      HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, in.cols[sk.col].data, nulls, w, 0, sk.order == SSGPU_DESCENDING, 1, n, c->stream));
-      rc = one_pass(0); if (rc != SSGPU_OK) return rc;
+      rc = load_and_profile(0, 1, &varying); if (rc != SSGPU_OK) return rc;
+      if (varying & 1ull) { rc = one_pass(0); if (rc != SSGPU_OK) return rc; }
     }
   }
   for (size_t i = 0; i < st.sort_out_cols.size(); ++i) {

@@ -46,23 +46,42 @@ __global__ void ssgpu_sort_iota_kernel(u32* __restrict__ idx, u64 n) {
   if (i < n) idx[i] = (u32)i;
 }
 
-// keys[i] = transform(col[idx[i]]) (descending: complemented), or the NULL-order bit
-__global__ void ssgpu_sort_load_keys_kernel(u64* __restrict__ keys, const u32* __restrict__ idx, const void* __restrict__ col,
+// keys[i] = transform(col[idx[i]]) (descending: complemented), or the NULL-order bit.
+// Also folds OR / AND of all keys into bits[0] / bits[1]: a radix digit whose bits agree in
+// every key (OR == AND there) needs no pass at all -- real keys (dates, small integers, ids)
+// rarely use all 64 bits.
+#define LOAD_KEYS_PER_THREAD 8
+__global__ __launch_bounds__(256) void ssgpu_sort_load_keys_kernel(u64* __restrict__ keys, const u32* __restrict__ idx, const void* __restrict__ col,
                                             const u8* __restrict__ nulls, u32 width, int kind, int descending,
-                                            int null_pass, u64 n) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 row = idx[i];
-  u64 k;
-  if (null_pass) {
-    const bool isnull = nulls && nulls[row];
-    k = descending ? (isnull ? 1ull : 0ull) : (isnull ? 0ull : 1ull);   // NULLs first ASC, last DESC
-  } else {
-    k = order_key(col, width, kind, row);
-    if (descending) k = ~k;
-    if (nulls && nulls[row]) k = 0;   // value of a NULL row is unspecified: make ties deterministic
+                                            int null_pass, u64 n, unsigned long long* __restrict__ bits) {
+  __shared__ u64 red[2][4];
+  u64 vor = 0, vand = ~0ull;
+  const u64 base = (u64)blockIdx.x * (256u * LOAD_KEYS_PER_THREAD) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < LOAD_KEYS_PER_THREAD; ++j) {
+    const u64 i = base + (u64)j * 256u;
+    if (i >= n) break;
+    const u64 row = idx[i];
+    u64 k;
+    if (null_pass) {
+      const bool isnull = nulls && nulls[row];
+      k = descending ? (isnull ? 1ull : 0ull) : (isnull ? 0ull : 1ull);   // NULLs first ASC, last DESC
+    } else {
+      k = order_key(col, width, kind, row);
+      if (descending) k = ~k;
+      if (nulls && nulls[row]) k = 0;   // value of a NULL row is unspecified: make ties deterministic
+    }
+    keys[i] = k;
+    vor |= k; vand &= k;
   }
-  keys[i] = k;
+  for (int o = 32; o; o >>= 1) { vor |= __shfl_xor(vor, o); vand &= __shfl_xor(vand, o); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = vor; red[1][wave] = vand; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicOr(&bits[0], red[0][0] | red[0][1] | red[0][2] | red[0][3]);
+    atomicAnd(&bits[1], red[1][0] & red[1][1] & red[1][2] & red[1][3]);
+  }
 }
 
 // per-tile digit histogram -> hist[digit * n_tiles + tile]
@@ -83,11 +102,18 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_hist_kernel(const u64
 }
 
 // stable scatter: element order inside a tile is (wave, step, lane); ranks of equal digits by
-// wave-level match (8 ballots) on top of running per-wave digit counters in LDS
+// wave-level match (8 ballots) on top of running per-wave digit counters in LDS.  The tile is
+// first reordered by digit INSIDE LDS, then written out: a digit's keys of this tile form one
+// contiguous run in the output (4096 / 256 = 16 keys = 128 B on average), so the global writes
+// are coalesced instead of 64 random 8-byte stores per wave step.
 __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
     const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
     u32 shift, u64 n, u32 n_tiles, const u32* __restrict__ offsets) {
-  __shared__ u32 wave_cnt[4][256];   // running offsets per wave and digit
+  __shared__ u32 wave_cnt[4][256];   // running tile-local positions per wave and digit
+  __shared__ u32 scanbuf[256];
+  __shared__ u32 goff[256];          // global offset of digit d minus its tile-local start
+  __shared__ u64 lk[SORT_TILE];
+  __shared__ u32 li[SORT_TILE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const u64 tile_base = (u64)blockIdx.x * SORT_TILE;
   const u64 wave_base = tile_base + (u64)wave * (SORT_TILE / 4);
@@ -104,13 +130,25 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
     if (ok) atomicAdd(&wave_cnt[wave][(k[j] >> shift) & 0xFF], 1u);
   }
   __syncthreads();
-  // wave bases: global offset of (digit, tile) + counts of the earlier waves of this tile
-  for (int d = t; d < 256; d += SORT_THREADS) {
-    u32 run = offsets[(u64)d * n_tiles + blockIdx.x];
-    for (int w = 0; w < 4; ++w) { const u32 c = wave_cnt[w][d]; wave_cnt[w][d] = run; run += c; }
-  }
+  // exclusive scan of the tile's digit totals (thread t = digit t) -> tile-local run starts
+  const u32 tot = wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
+  scanbuf[t] = tot;
   __syncthreads();
-  // phase 2: rank and scatter, 64 consecutive elements per step
+  for (int o = 1; o < 256; o <<= 1) {
+    const u32 v = t >= o ? scanbuf[t - o] : 0u;
+    __syncthreads();
+    scanbuf[t] += v;
+    __syncthreads();
+  }
+  {
+    const u32 excl = scanbuf[t] - tot;
+    goff[t] = offsets[(u64)t * n_tiles + blockIdx.x] - excl;
+    u32 run = excl;
+    for (int w = 0; w < 4; ++w) { const u32 c = wave_cnt[w][t]; wave_cnt[w][t] = run; run += c; }
+  }
+  const u32 valid = scanbuf[255];
+  __syncthreads();
+  // phase 2: rank and place into LDS, 64 consecutive elements per step
   const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; ++j) {
@@ -126,13 +164,25 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
     if (ok) {
       const u32 rank = (u32)__popcll(peers & lt);
       const u32 pos = wave_cnt[wave][d] + rank;
-      keys_out[pos] = k[j];
-      idx_out[pos] = id[j];
+      lk[pos] = k[j];
+      li[pos] = id[j];
     }
     // one lane per digit group advances the running counter (after every lane has read it)
     __builtin_amdgcn_wave_barrier();
     if (ok && (peers & lt) == 0) wave_cnt[wave][d] += (u32)__popcll(peers);
     __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // phase 3: coalesced write-out of the digit-ordered tile
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u32 e = (u32)j * SORT_THREADS + (u32)t;
+    if (e < valid) {
+      const u64 key = lk[e];
+      const u32 pos = goff[(u32)(key >> shift) & 0xFF] + e;
+      keys_out[pos] = key;
+      idx_out[pos] = li[e];
+    }
   }
 }
 
@@ -247,9 +297,9 @@ hipError_t ssgpu_launch_sort_iota(uint32_t* idx, uint64_t n, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_load_keys(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width,
-                                       int kind, int descending, int null_pass, uint64_t n, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(ssgpu_sort_load_keys_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)keys, idx, col, nulls, width,
-                            kind, descending, null_pass, (u64)n);
+                                       int kind, int descending, int null_pass, uint64_t n, unsigned long long* bits, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_load_keys_kernel, dim3(blocks_for(n, 256 * LOAD_KEYS_PER_THREAD)), dim3(256), 0, s, (u64*)keys, idx, col, nulls, width,
+                            kind, descending, null_pass, (u64)n, bits);
   return hipGetLastError();
 }
 uint32_t ssgpu_sort_tiles(uint64_t n) { return (uint32_t)((n + SORT_TILE - 1) / SORT_TILE); }
