@@ -118,6 +118,13 @@ struct Stage {
   std::vector<uint64_t> group_acc_init;   // per-group accumulator identities
   std::vector<uint32_t> group_merge_op;   // VM_MERGE_* of every group accumulator
   int n_gaggs = 0;
+  // GROUP_AGG, partitioned execution (many groups): rows are first scattered into hash partitions
+  // (key + the distinct aggregate inputs), then one workgroup aggregates each partition in LDS
+  Program part_count;    // filters + key packing + PART_COUNT
+  Program part_scatter;  // filters + key packing + PART_RANK + one STOREC per partition column
+  std::vector<uint32_t> part_col_width;   // partition buffer columns: [0] = packed key (8), then values / NULL masks
+  struct PartAgg { int op; int val_col; int null_col; int has_cnt; };
+  std::vector<PartAgg> part_aggs;         // one per aggregate: GAGG opcode + its partition columns (-1 = none)
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns
   int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row

@@ -37,6 +37,28 @@ struct GroupExtractParams {
   GroupAggOut aggs_out[VM_MAX_AGG_SLOTS];
 };
 
+// Partitioned GroupAggregate, second phase: one workgroup aggregates one hash partition in LDS
+// and dumps its table into slots [part * local_capacity, (part + 1) * local_capacity) of the
+// global table (no global atomics; the usual extraction kernels run on the result).
+#define SSGPU_PART_THREADS 1024
+struct PartAggParams {
+  const void* cols[VM_MAX_OUTPUTS];   // partition columns; [0] = packed 64-bit keys
+  const unsigned int* offsets;        // scanned [partition][workgroup of the scatter pass] row offsets
+  const unsigned long long* total;    // selected rows in total
+  unsigned int n_tiles, n_parts;      // n_tiles = workgroups of the scatter pass
+  unsigned int local_capacity;        // LDS table entries per partition
+  unsigned int n_gaggs;
+  unsigned int any_cnt;
+  unsigned int pad;
+  VmGroupTable G;                     // global table: capacity_mask + 1 == n_parts * local_capacity (any number)
+  int agg_op[VM_MAX_AGG_SLOTS];       // GAGG opcode per aggregate
+  int val_col[VM_MAX_AGG_SLOTS];      // partition column of the value (-1: COUNT)
+  int null_col[VM_MAX_AGG_SLOTS];     // partition column of the NULL mask (-1: never NULL)
+  int has_cnt[VM_MAX_AGG_SLOTS];
+};
+hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
+hipError_t ssgpu_part_agg_set_max_lds(int bytes);
+
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream);
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,

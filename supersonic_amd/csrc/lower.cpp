@@ -766,6 +766,9 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
   return Status::OK();
 }
 
+struct AggPlan;
+static Status build_partition_programs(const struct Pipe& pipe, const std::vector<int>& kpos, const std::vector<AggPlan>& plans, Stage* st);
+
 // clustered = AggregateClusters (aggregate_clusters.cc:338-520): the group id of a row is the
 // number of key changes before it, computed by a flag + scan pre-pass over the materialised
 // input (segment ids arrive as an extra staged UINT32 column) -- no hash table.
@@ -867,6 +870,79 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
   allocate_registers(&st->main);
   st->algorithmic_bytes_per_row = staged_bytes(st->main);
   st->has_filter = !pipe.filters.empty();
+  if (!clustered) SS_RETURN_IF_ERROR(build_partition_programs(pipe, kpos, plans, st));
+  return Status::OK();
+}
+
+// Partitioned execution of a hash GroupAggregate (many groups): two more programs over the same
+// pipe.  Both pack the key exactly like the direct program; the scatter program writes the key
+// and every distinct aggregate input (after its cast) to the row's slot of its hash partition.
+static Status build_partition_programs(const Pipe& pipe, const std::vector<int>& kpos, const std::vector<AggPlan>& plans, Stage* st) {
+  auto pack_key = [&](Emitter& em, int* keyreg_out) -> Status {
+    int keyreg = em.new_reg(8);
+    { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
+    for (size_t k = 0; k < kpos.size(); ++k) {
+      const BExprP& ke = pipe.cols[kpos[k]].expr;
+      Val v; SS_RETURN_IF_ERROR(em.value(ke, &v));
+      const GroupKeyField& f = st->group_keys[k];
+      int vr = em.materialize(v);
+      LInstr& i = em.emit(f.width == 8 ? VM_KEY_APPEND_64 : f.width == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
+      i.dst = keyreg; i.a = vr; i.b = v.null;
+      i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
+    }
+    *keyreg_out = keyreg;
+    return Status::OK();
+  };
+  {
+    Emitter em(&st->part_count);
+    SS_RETURN_IF_ERROR(emit_filters(em, pipe));
+    int keyreg; SS_RETURN_IF_ERROR(pack_key(em, &keyreg));
+    LInstr& i = em.emit(VM_PART_COUNT); i.dst_is_reg = false; i.dst = 0; i.a = keyreg; i.c = em.sel_by_depth.back();
+    allocate_registers(&st->part_count);
+  }
+  Emitter em(&st->part_scatter);
+  SS_RETURN_IF_ERROR(emit_filters(em, pipe));
+  const int sel = em.sel_by_depth.back();
+  int keyreg; SS_RETURN_IF_ERROR(pack_key(em, &keyreg));
+  const int rank = em.new_reg(4);
+  { LInstr& i = em.emit(VM_PART_RANK); i.dst = rank; i.a = keyreg; i.c = sel; }
+  st->part_col_width.clear(); st->part_aggs.clear();
+  std::map<int, int> col_of_reg;   // value / mask register -> partition column
+  auto store_reg = [&](int reg, uint32_t w) -> int {
+    auto it = col_of_reg.find(reg);
+    if (it != col_of_reg.end()) return it->second;
+    const int col = (int)st->part_col_width.size();
+    st->part_col_width.push_back(w);
+    LInstr& i = em.emit(w == 8 ? VM_STOREC_64 : w == 4 ? VM_STOREC_32 : VM_STOREC_8);
+    i.dst_is_reg = false; i.dst = col; i.a = reg; i.b = rank; i.c = sel;
+    col_of_reg[reg] = col;
+    return col;
+  };
+  store_reg(keyreg, 8);
+  for (size_t j = 0; j < plans.size(); ++j) {
+    const AggPlan& ap = plans[j];
+    Stage::PartAgg pa; pa.op = VM_GAGG_COUNT; pa.val_col = -1; pa.null_col = -1; pa.has_cnt = 0;
+    if (ap.aggregation == SSGPU_COUNT) {
+      if (ap.input_pos >= 0) {
+        Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v));
+        if (v.null >= 0) pa.null_col = store_reg(v.null, 1);
+      }
+    } else {
+      const BExprP& src = pipe.cols[ap.input_pos].expr;
+      Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
+      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+      AggSel sl; uint64_t init = 0;
+      if (!select_group_agg(ap.aggregation, ap.out_type, &sl, &init))
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
+      pa.op = sl.op;
+      pa.val_col = store_reg(em.materialize(c), c.width);
+      if (v.null >= 0) { pa.null_col = store_reg(v.null, 1); pa.has_cnt = 1; }
+    }
+    st->part_aggs.push_back(pa);
+  }
+  if ((int)st->part_col_width.size() > VM_MAX_OUTPUTS) { st->part_count = Program(); st->part_scatter = Program(); return Status::OK(); }
+  st->part_scatter.n_outputs = (int)st->part_col_width.size();
+  allocate_registers(&st->part_scatter);
   return Status::OK();
 }
 
@@ -1031,6 +1107,8 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
   for (size_t i = 0; i < stages->size(); ++i) {
     desc << "stage " << i << " kind=" << (*stages)[i].kind << "\n" << disassemble((*stages)[i].main);
     if (!(*stages)[i].count_pass.empty()) desc << " count pass:\n" << disassemble((*stages)[i].count_pass);
+    if (!(*stages)[i].part_count.empty()) desc << " partition count pass:\n" << disassemble((*stages)[i].part_count);
+    if (!(*stages)[i].part_scatter.empty()) desc << " partition scatter pass:\n" << disassemble((*stages)[i].part_scatter);
   }
   *describe = desc.str();
   return Status::OK();

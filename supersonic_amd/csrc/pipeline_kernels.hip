@@ -200,6 +200,12 @@ __device__ __forceinline__ u32 hash_local(u64 key) {   // two 32-bit multiplies 
   h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
   return h;
 }
+// hash partition of a key: decorrelated from the in-table home slot (both use the HIGH bits of
+// their hash through mulhi)
+__device__ __forceinline__ u32 part_of(u64 key, u32 n_parts) {
+  u32 h = hash_local(key) * 0x2C1B3C6Du; h ^= h >> 16;
+  return __umulhi(h * 0x297A2D39u, n_parts);
+}
 __device__ __forceinline__ u32 group_probe_local(u64* keys, u32 cap, u32 tag, u64 key, u32 i, u64 cur) {
   // `cur` = keys[i] already read by the caller (the common case is a hit on the home slot)
   for (int probe = 0; probe < 16; ++probe) {
@@ -453,6 +459,11 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
       if (G.local_cnt_off != VM_NONE) reinterpret_cast<u32*>(smem + G.local_cnt_off)[i] = 0u;
     }
     if (t < 2) reinterpret_cast<u32*>(smem + P.scratch_lds_off + 128u)[t] = 0u;
+  }
+  if (P.part_n) {  // partition passes: this workgroup's counters / scanned start offsets, [partition][workgroup]
+    u32* h = reinterpret_cast<u32*>(smem + P.part_lds_off);
+    for (u32 i = (u32)t; i < P.part_n; i += VM_COMPUTE_THREADS)
+      h[i] = P.tile_offsets ? P.tile_offsets[(u64)i * gridDim.x + blockIdx.x] : 0u;
   }
   PC_PROF(if (P.debug_pc) for (int i = t; i <= P.n_instr; i += VM_COMPUTE_THREADS) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[i] = 0ull;)
   __syncthreads();  // constant pool, accumulator records and group table visible to all waves
@@ -1603,6 +1614,30 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           }
           WG_BARRIER();
         } break;
+        // ---- hash partitioning of the rows of a GroupAggregate with many groups ----------
+        // The partition counters live in LDS for the whole kernel (per WORKGROUP, not per tile: the
+        // persistent workgroup sees the same tiles in the count pass and in the scatter pass, so
+        // its scanned per-partition start offsets simply keep running) -- no barrier needed.
+        case VM_PART_COUNT: { CASE_FENCE;
+          u32* h = reinterpret_cast<u32*>(smem + P.part_lds_off);
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
+            auto kk = lds_load2<u64>(I.a, p);
+            if (m.x) atomicAdd(&h[part_of(kk.x, P.part_n)], 1u);
+            if (m.y) atomicAdd(&h[part_of(kk.y, P.part_n)], 1u);
+          }
+        } break;
+        case VM_PART_RANK: { CASE_FENCE;    // destination row of every selected row inside its partition
+          u32* h = reinterpret_cast<u32*>(smem + P.part_lds_off);
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
+            auto kk = lds_load2<u64>(I.a, p);
+            u32 r0 = 0, r1 = 0;
+            if (m.x) r0 = atomicAdd(&h[part_of(kk.x, P.part_n)], 1u);
+            if (m.y) r1 = atomicAdd(&h[part_of(kk.y, P.part_n)], 1u);
+            lds_store2<u32>(I.dst, p, r0, r1);
+          }
+        } break;
         STORE_OP(STORE_8, u8)
         STORE_OP(STORE_32, u32)
         STORE_OP(STORE_64, u64)
@@ -1696,6 +1731,11 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
     PC_PROF(if (P.debug_pc && P.n_instr > 0 && t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr - 1] += __builtin_amdgcn_s_memtime() - dbg_pc_last;)
   }
 
+  if (P.part_n && P.tile_counts && !P.tile_offsets) {  // count pass: publish this workgroup's partition histogram
+    __syncthreads();
+    const u32* h = reinterpret_cast<const u32*>(smem + P.part_lds_off);
+    for (u32 i = (u32)t; i < P.part_n; i += VM_COMPUTE_THREADS) P.tile_counts[(u64)i * gridDim.x + blockIdx.x] = h[i];
+  }
   if (P.group.local_capacity) {
     // merge the workgroup's table into the global one: one atomic per (group, aggregate)
     // per workgroup instead of one per row
@@ -2012,6 +2052,102 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// partitioned GroupAggregate, phase 2 (see PartAggParams in launch.h)
+// ---------------------------------------------------------------------------
+#define PART_ROWS 4   /* rows per thread per step: amortises the per-aggregate dispatch */
+#define PART_APPLY(OPNAME, LOADT, ATOM)                                               \
+  case VM_##OPNAME: {                                                                 \
+    const LOADT* col = reinterpret_cast<const LOADT*>(P.cols[vc]);                    \
+    LOADT ev[PART_ROWS];                                                              \
+    _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) ev[j] = live[j] ? col[rr[j]] : (LOADT)0; \
+    _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) if (live[j]) { u64* A = AP[j]; LOADT e = ev[j]; ATOM; } \
+  } break;
+
+__global__ __launch_bounds__(SSGPU_PART_THREADS) void ssgpu_part_agg_kernel(const PartAggParams P) {
+  const u32 t = threadIdx.x, part = blockIdx.x;
+  const u32 C = P.local_capacity, ng = P.n_gaggs;
+  u64* lkeys = reinterpret_cast<u64*>(smem + 0u);
+  u64* lacc = lkeys + C;
+  u32* lcnt = reinterpret_cast<u32*>(lacc + (size_t)C * ng);
+  for (u32 e = t; e < C; e += SSGPU_PART_THREADS) lkeys[e] = VM_KEY_EMPTY;
+  for (u32 i = t; i < C * ng; i += SSGPU_PART_THREADS) { lacc[i] = P.G.acc_init[i % ng]; if (P.any_cnt) lcnt[i] = 0u; }
+  __syncthreads();
+  const u64 begin = P.offsets[(u64)part * P.n_tiles];
+  const u64 end = part + 1u < P.n_parts ? (u64)P.offsets[(u64)(part + 1u) * P.n_tiles] : *P.total;
+  const u64* keys = reinterpret_cast<const u64*>(P.cols[0]);
+  const u32 special = P.G.capacity_mask + 1u;   // global slot of the EMPTY-valued key
+  for (u64 r0 = begin; r0 < end; r0 += (u64)SSGPU_PART_THREADS * PART_ROWS) {
+    u64 rr[PART_ROWS]; bool live[PART_ROWS], spec[PART_ROWS]; u32 li[PART_ROWS]; u64 kk[PART_ROWS];
+#pragma unroll
+    for (int j = 0; j < PART_ROWS; ++j) {
+      rr[j] = r0 + (u64)j * SSGPU_PART_THREADS + t;
+      live[j] = rr[j] < end;
+      kk[j] = live[j] ? keys[rr[j]] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < PART_ROWS; ++j) {
+      spec[j] = live[j] && kk[j] == VM_KEY_EMPTY;
+      li[j] = 0;
+      if (spec[j]) {
+        __hip_atomic_store(&P.G.keys[special], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (live[j]) {
+        const u32 i0 = __umulhi(hash_local(kk[j]), C);
+        const u64 c0 = __hip_atomic_load(&lkeys[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 sl = group_probe_local(lkeys, C, 0u, kk[j], i0, c0);
+        if (sl == 0xFFFFFFFFu) { atomicExch(P.G.overflow, 1u); live[j] = false; }  // partition too large: the host re-partitions finer
+        li[j] = sl * ng;
+      }
+    }
+    for (u32 s = 0; s < ng; ++s) {
+      const int vc = P.val_col[s], nc = P.null_col[s];
+      const bool has_cnt = P.has_cnt[s] != 0;
+      bool lv[PART_ROWS]; u64* AP[PART_ROWS];
+#pragma unroll
+      for (int j = 0; j < PART_ROWS; ++j) {
+        lv[j] = live[j] && !(nc >= 0 && reinterpret_cast<const u8*>(P.cols[nc])[rr[j]]);   // NULL input: skipped
+        // the EMPTY-valued key aggregates straight into its reserved global slot (at most one group)
+        AP[j] = spec[j] ? &P.G.acc[(u64)special * ng + s] : &lacc[li[j] + s];
+        if (has_cnt && lv[j]) { if (spec[j]) atomicAdd(&P.G.cnt[(u64)special * ng + s], 1u); else atomicAdd(&lcnt[li[j] + s], 1u); }
+      }
+      {
+        bool* live = lv;   // PART_APPLY works on the rows whose input is not NULL
+        switch (P.agg_op[s]) {
+          case VM_GAGG_COUNT: { _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) if (live[j]) atomicAdd(AP[j], 1ull); } break;
+          PART_APPLY(GAGG_SUM_I32, i32, atomicAdd(A, (u64)(i64)e))
+          PART_APPLY(GAGG_SUM_U32, u32, atomicAdd(A, (u64)e))
+          PART_APPLY(GAGG_SUM_I64, u64, atomicAdd(A, e))
+          PART_APPLY(GAGG_SUM_F32, float, unsafeAtomicAdd(reinterpret_cast<double*>(A), (double)e))
+          PART_APPLY(GAGG_SUM_F64, double, unsafeAtomicAdd(reinterpret_cast<double*>(A), e))
+          PART_APPLY(GAGG_MIN_I32, i32, atomicMin(A, key_i64((i64)e)))
+          PART_APPLY(GAGG_MIN_U32, u32, atomicMin(A, (u64)e))
+          PART_APPLY(GAGG_MIN_I64, i64, atomicMin(A, key_i64(e)))
+          PART_APPLY(GAGG_MIN_U64, u64, atomicMin(A, e))
+          PART_APPLY(GAGG_MIN_B8, u8, atomicMin(A, (u64)(e != 0)))
+          PART_APPLY(GAGG_MAX_I32, i32, atomicMax(A, key_i64((i64)e)))
+          PART_APPLY(GAGG_MAX_U32, u32, atomicMax(A, (u64)e))
+          PART_APPLY(GAGG_MAX_I64, i64, atomicMax(A, key_i64(e)))
+          PART_APPLY(GAGG_MAX_U64, u64, atomicMax(A, e))
+          PART_APPLY(GAGG_MAX_B8, u8, atomicMax(A, (u64)(e != 0)))
+          PART_APPLY(GAGG_MIN_F32, float, if (e == e) atomicMin(A, FKEY(e)))
+          PART_APPLY(GAGG_MIN_F64, double, if (e == e) atomicMin(A, FKEY(e)))
+          PART_APPLY(GAGG_MAX_F32, float, if (e == e) atomicMax(A, FKEY(e)))
+          PART_APPLY(GAGG_MAX_F64, double, if (e == e) atomicMax(A, FKEY(e)))
+          default: break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // dump: local entry e of partition `part` = global slot part * C + e (empty entries stay empty)
+  for (u32 e = t; e < C; e += SSGPU_PART_THREADS) P.G.keys[(u64)part * C + e] = lkeys[e];
+  for (u32 i = t; i < C * ng; i += SSGPU_PART_THREADS) {
+    P.G.acc[(u64)part * C * ng + i] = lacc[i];
+    if (P.any_cnt) P.G.cnt[(u64)part * C * ng + i] = lcnt[i];
+  }
+}
+
 // fill helpers (table initialisation without a host round trip)
 __global__ void ssgpu_fill_u64_kernel(u64* __restrict__ p, u64 v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2038,6 +2174,13 @@ hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(ssgpu_part_agg_kernel, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
+  return hipGetLastError();
+}
+hipError_t ssgpu_part_agg_set_max_lds(int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
   hipError_t e;

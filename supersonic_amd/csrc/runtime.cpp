@@ -37,6 +37,7 @@ struct ssgpu_ctx {
   int64_t wgs_per_cu = 3;        // resident 4-wave workgroups per CU (<= 4 at the kernel's 128-VGPR budget; 3 streams best)
   int64_t group_capacity = 1 << 18;
   int64_t group_local = 1;       // 0: never use the LDS pre-aggregation table
+  int64_t group_partition = 1;   // 0: never switch to the partitioned GroupAggregate; 2: always use it
   int64_t profile = 1;           // record HIP events around kernels
   int64_t debug_timing = 0;
   int64_t kernel_flags = 0;      // in-kernel cycle counters (development aid)
@@ -89,6 +90,13 @@ struct StageExec {
   int group_wgs = 3;            // resident workgroups per CU of the group stage (adapted from run feedback)
   bool group_local = true;      // workgroup-private LDS pre-aggregation table in use
   int group_sub = 1;            // sub-tables of the LDS table (spreads same-group rows of a wave)
+  // partitioned execution (many groups)
+  bool group_partitioned = false;
+  uint32_t part_n = 512;        // hash partitions (doubled when a partition overflows its LDS table)
+  DevBuf prog_pcount, prog_pscatter, part_hist, part_offs;
+  ProgramLayout lay_pcount{}, lay_pscatter{};
+  int n_instr_pcount = 0, n_instr_pscatter = 0;
+  std::vector<DevBuf> part_cols;
   uint32_t capacity = 0;
   DevBuf error_flag;
   DevBuf debug, debug_pc, total2;
@@ -155,6 +163,7 @@ int ssgpu_ctx_create(int device_id, ssgpu_ctx** out) {
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SSGPU_ERROR_HIP; }
     c->own_stream = true;
     (void)ssgpu_pipeline_set_max_lds(160 * 1024);
+    (void)ssgpu_part_agg_set_max_lds(160 * 1024);
   }
   *out = c;
   return SSGPU_OK;
@@ -197,6 +206,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "grid_limit") c->grid_limit = value;
   else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 3;
   else if (k == "group_local") c->group_local = value;
+  else if (k == "group_partition") c->group_partition = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -563,9 +573,151 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
   return SSGPU_OK;
 }
 
+// occupied slots of the global group table -> dense result rows in slot order
+int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, uint32_t ng) {
+  ssgpu_ctx* c = p->ctx;
+  const size_t slots = (size_t)capacity + 1;
+  const int ntile = (int)((slots + 511) / 512);
+  int rc = ensure_out_cols(c, st, ex, (int64_t)slots);
+  if (rc != SSGPU_OK) return rc;
+  HIP_TRY(c, ex.tile_counts.ensure((size_t)ntile * 4));
+  HIP_TRY(c, ex.tile_offsets.ensure((size_t)ntile * 4));
+  HIP_TRY(c, ex.total.ensure(8));
+  GroupExtractParams G;
+  memset(&G, 0, sizeof(G));
+  G.keys = ex.gkeys.as<unsigned long long>();
+  G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
+  G.capacity = capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size();
+  G.tile_offsets = ex.tile_offsets.as<unsigned int>();
+  for (size_t k = 0; k < st.group_keys.size(); ++k) {
+    const GroupKeyField& f = st.group_keys[k];
+    G.keys_out[k].data = ex.out[k].data.p;
+    G.keys_out[k].is_null = ex.out[k].nullable ? ex.out[k].nulls.as<uint8_t>() : nullptr;
+    G.keys_out[k].shift = f.shift; G.keys_out[k].bits = f.bits; G.keys_out[k].nullbit = f.nullbit; G.keys_out[k].width = f.width;
+  }
+  const size_t nk = st.group_keys.size();
+  for (size_t j = 0; j < st.aggs.size(); ++j) {
+    G.aggs_out[j].data = ex.out[nk + j].data.p;
+    G.aggs_out[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
+    G.aggs_out[j].s = st.aggs[j].slot; G.aggs_out[j].out_kind = st.aggs[j].emit_kind; G.aggs_out[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
+  }
+  HIP_TRY(c, ssgpu_launch_group_count(G, ex.tile_counts.as<uint32_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), ntile, ex.total.as<uint64_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_group_extract(G, c->stream));
+  p->counters.n_launches += 3;
+  ex.out_rows = -1;
+  return SSGPU_OK;
+}
+
+// GroupAggregate with many groups (run feedback: the workgroup-private LDS table of the direct
+// path is bypassed by most rows, i.e. the 24 G/s global atomic rate would bound the stage):
+//   1. PART_COUNT pass   per-tile histogram of hash partitions            (reads the key columns)
+//   2. scan              [partition][tile] offsets
+//   3. PART_RANK pass    key + distinct aggregate inputs scattered into their partition
+//   4. ssgpu_part_agg    one workgroup per partition aggregates it in LDS, no global atomics
+//   5. the usual extraction over the dumped tables
+int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  if (!ex.prog_pscatter.p) {
+    LowerOptions o = c->opt;
+    ex.lay_pscatter = layout_program(st.part_scatter, o);
+    o.tile_rows = 512 * ex.lay_pscatter.K;
+    ex.lay_pcount = layout_program(st.part_count, o);
+    if (ex.lay_pcount.K != ex.lay_pscatter.K) { c->err = "partition passes disagree on the tile size"; return SSGPU_ERROR_UNKNOWN; }
+    int rc = upload_program(c, st.part_scatter, ex.lay_pscatter, &ex.prog_pscatter, &ex.n_instr_pscatter, &p->host_prog_scratch);
+    if (rc != SSGPU_OK) return rc;
+    rc = upload_program(c, st.part_count, ex.lay_pcount, &ex.prog_pcount, &ex.n_instr_pcount, &p->host_prog_scratch);
+    if (rc != SSGPU_OK) return rc;
+  }
+  bool any_cnt = false;
+  for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
+  const uint32_t entry = 8u + ng * 8u + (any_cnt ? ng * 4u : 0u);
+  const uint32_t C = std::max<uint32_t>(16u, (80u * 1024u) / entry);   // two 1024-thread workgroups per CU
+  HIP_TRY(c, ex.gpattern.ensure(ng * 8));
+  if (!ex.pattern_ready) {
+    std::vector<uint64_t> pattern(ng, 0);
+    for (size_t i = 0; i < st.group_acc_init.size(); ++i) pattern[i] = st.group_acc_init[i];
+    HIP_TRY(c, hipMemcpy(ex.gpattern.p, pattern.data(), ng * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, ex.gmergeop.ensure(ng * 4));
+    std::vector<uint32_t> mop(ng, VM_MERGE_ADD_U64);
+    for (size_t i = 0; i < st.group_merge_op.size(); ++i) mop[i] = st.group_merge_op[i];
+    HIP_TRY(c, hipMemcpy(ex.gmergeop.p, mop.data(), ng * 4, hipMemcpyHostToDevice));
+    ex.pattern_ready = true;
+  }
+  HIP_TRY(c, ex.goverflow.ensure(16));
+  HIP_TRY(c, ex.total.ensure(8));
+  ex.part_cols.resize(st.part_col_width.size());
+  for (size_t i = 0; i < ex.part_cols.size(); ++i)
+    HIP_TRY(c, ex.part_cols[i].ensure((size_t)std::max<int64_t>(in.rows, 1) * st.part_col_width[i] + 16));
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    const uint32_t NP = ex.part_n;
+    const uint32_t capacity = NP * C;
+    const size_t slots = (size_t)capacity + 1;
+    HIP_TRY(c, ex.gkeys.ensure(slots * 8));
+    HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
+    HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
+    // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
+    HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>() + capacity, VM_KEY_EMPTY, 1, c->stream));
+    HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>() + (size_t)capacity * ng, ex.gpattern.as<uint64_t>(), ng, ng, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.gcnt.as<uint32_t>() + (size_t)capacity * ng, 0, ng * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
+    VmParams Pc, Ps;
+    fill_params(&Pc, st.part_count, ex.lay_pcount, ex.prog_pcount, ex.n_instr_pcount, in, row_id_base);
+    fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
+    Pc.part_n = Ps.part_n = NP;
+    Pc.part_lds_off = (Pc.lds_bytes + 15u) & ~15u; Pc.lds_bytes = Pc.part_lds_off + NP * 4u;
+    Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u; Ps.lds_bytes = Ps.part_lds_off + NP * 4u;
+    // both passes MUST run the same grid: the counters are per (partition, workgroup) and a
+    // persistent workgroup has to meet the same tiles in both
+    ProgramLayout Ls = ex.lay_pscatter; Ls.lds_bytes = std::max(Ps.lds_bytes, Pc.lds_bytes);
+    const int grid = grid_for(c, Ls, Ps.n_tiles);
+    const size_t cells = (size_t)NP * (size_t)grid;
+    HIP_TRY(c, ex.part_hist.ensure(cells * 4));
+    HIP_TRY(c, ex.part_offs.ensure(cells * 4));
+    Pc.error_flag = ex.error_flag.as<unsigned int>();
+    Pc.tile_counts = ex.part_hist.as<unsigned int>();
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+    HIP_TRY(c, ssgpu_launch_pipeline(Pc, ex.lay_pcount.K, grid, c->stream));
+    HIP_TRY(c, ssgpu_launch_scan_counts(ex.part_hist.as<uint32_t>(), ex.part_offs.as<uint32_t>(), (int)cells, ex.total.as<uint64_t>(), c->stream));
+    Ps.error_flag = ex.error_flag.as<unsigned int>();
+    Ps.tile_offsets = ex.part_offs.as<unsigned int>();
+    for (size_t i = 0; i < ex.part_cols.size(); ++i) { Ps.outputs[i].dst = ex.part_cols[i].p; Ps.outputs[i].width = st.part_col_width[i]; }
+    HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
+    PartAggParams A;
+    memset(&A, 0, sizeof(A));
+    for (size_t i = 0; i < ex.part_cols.size(); ++i) A.cols[i] = ex.part_cols[i].p;
+    A.offsets = ex.part_offs.as<unsigned int>();
+    A.total = ex.total.as<unsigned long long>();
+    A.n_tiles = (unsigned int)grid; A.n_parts = NP; A.local_capacity = C; A.n_gaggs = ng; A.any_cnt = any_cnt ? 1u : 0u;
+    A.G.keys = ex.gkeys.as<unsigned long long>(); A.G.acc = ex.gacc.as<unsigned long long>(); A.G.cnt = ex.gcnt.as<unsigned int>();
+    A.G.overflow = ex.goverflow.as<unsigned int>(); A.G.capacity_mask = capacity - 1u; A.G.n_gaggs = ng;
+    A.G.acc_init = ex.gpattern.as<unsigned long long>(); A.G.merge_op = ex.gmergeop.as<unsigned int>();
+    for (size_t j = 0; j < st.part_aggs.size(); ++j) {
+      A.agg_op[j] = st.part_aggs[j].op; A.val_col[j] = st.part_aggs[j].val_col;
+      A.null_col[j] = st.part_aggs[j].null_col; A.has_cnt[j] = st.part_aggs[j].has_cnt;
+    }
+    HIP_TRY(c, ssgpu_launch_part_agg(A, C * entry, c->stream));
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+    p->counters.n_launches += 8;
+    p->counters.tile_rows = Ps.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)Ps.lds_bytes;
+    uint32_t fb[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, overflow=%u\n", NP, C, fb[0]);
+    if (!fb[0]) return extract_groups(p, st, ex, capacity, ng);
+    if (ex.part_n >= 8192) break;
+    ex.part_n *= 2;   // a partition held more groups than its LDS table: partition finer and rerun
+  }
+  c->err = "GroupAggregate: a hash partition does not fit the on-chip group table";
+  return SSGPU_ERROR_MEMORY_EXCEEDED;
+}
+
 int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  if ((ex.group_partitioned || c->group_partition == 2) && !st.part_scatter.empty()) return run_group_agg_partitioned(p, si, in, row_id_base);
   if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
   for (int attempt = 0; attempt < 8; ++attempt) {
     const size_t slots = (size_t)ex.capacity + 1;
@@ -655,14 +807,21 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         ex.group_wgs = best;
         // (splitting the table into per-lane-group sub-tables was measured: 1.5 -> 2.1 ms on an
         //  8-group query; same-address LDS atomics are not the bottleneck, so group_sub stays 1)
-      } else if ((uint64_t)fb[1] * 2u >= (uint64_t)std::max<int64_t>(in.rows, 1) && local_capacity_for(1) <= lcap) {
-        ex.group_local = false;
-      } else if (ex.group_sub > 1) {
-        ex.group_sub = 1;
-      } else if (ex.group_wgs > 1) {
-        ex.group_wgs -= 1;
-      } else if ((uint64_t)fb[1] * 2u >= (uint64_t)std::max<int64_t>(in.rows, 1)) {
-        ex.group_local = false;
+      } else {
+        // some rows missed the (full) table.  With G >> C uniformly hit groups a fraction C/G of
+        // the rows finds its group in the table, so G ~= C * rows / (rows - bypassed): size the
+        // next run for that estimate in one step -- a bigger table at a lower residency if the
+        // groups fit on chip, hash partitioning of the rows if not.
+        const double rows = (double)std::max<int64_t>(in.rows, 1);
+        const double hit = std::max(rows - (double)fb[1], 1.0);
+        const double groups = std::max<double>((double)std::max(fb[2], lcap) * rows / hit, (double)fb[2]);
+        int best = 0;
+        for (int w = 4; w >= 1; --w) if ((double)local_capacity_for(w) * 0.9 >= groups) { best = w; break; }
+        if (best > 0 && best != ex.group_wgs) ex.group_wgs = best;
+        else if (best == 0 || (best == ex.group_wgs && (double)fb[1] * 4.0 >= rows)) {
+          if (c->group_partition && !st.part_scatter.empty() && in.rows >= (1 << 20)) ex.group_partitioned = true;
+          else if ((double)fb[1] * 2.0 >= rows) ex.group_local = false;
+        }
       }
     }
     if (!overflow) break;
@@ -671,38 +830,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     if ((uint64_t)ex.capacity >= (1ull << 30)) { c->err = "group table overflow"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
     ex.capacity *= 4;
   }
-  // extraction: occupied slots -> dense rows in slot order
-  const size_t slots = (size_t)ex.capacity + 1;
-  const int ntile = (int)((slots + 511) / 512);
-  int rc = ensure_out_cols(c, st, ex, (int64_t)slots);
-  if (rc != SSGPU_OK) return rc;
-  HIP_TRY(c, ex.tile_counts.ensure((size_t)ntile * 4));
-  HIP_TRY(c, ex.tile_offsets.ensure((size_t)ntile * 4));
-  HIP_TRY(c, ex.total.ensure(8));
-  GroupExtractParams G;
-  memset(&G, 0, sizeof(G));
-  G.keys = ex.gkeys.as<unsigned long long>();
-  G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
-  G.capacity = ex.capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size();
-  G.tile_offsets = ex.tile_offsets.as<unsigned int>();
-  for (size_t k = 0; k < st.group_keys.size(); ++k) {
-    const GroupKeyField& f = st.group_keys[k];
-    G.keys_out[k].data = ex.out[k].data.p;
-    G.keys_out[k].is_null = ex.out[k].nullable ? ex.out[k].nulls.as<uint8_t>() : nullptr;
-    G.keys_out[k].shift = f.shift; G.keys_out[k].bits = f.bits; G.keys_out[k].nullbit = f.nullbit; G.keys_out[k].width = f.width;
-  }
-  const size_t nk = st.group_keys.size();
-  for (size_t j = 0; j < st.aggs.size(); ++j) {
-    G.aggs_out[j].data = ex.out[nk + j].data.p;
-    G.aggs_out[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
-    G.aggs_out[j].s = st.aggs[j].slot; G.aggs_out[j].out_kind = st.aggs[j].emit_kind; G.aggs_out[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
-  }
-  HIP_TRY(c, ssgpu_launch_group_count(G, ex.tile_counts.as<uint32_t>(), c->stream));
-  HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), ntile, ex.total.as<uint64_t>(), c->stream));
-  HIP_TRY(c, ssgpu_launch_group_extract(G, c->stream));
-  p->counters.n_launches += 3;
-  ex.out_rows = -1;
-  return SSGPU_OK;
+  return extract_groups(p, st, ex, ex.capacity, ng);
 }
 
 int sort_kind_of(int dtype) {   // 0 unsigned, 1 signed, 2 float32, 3 float64

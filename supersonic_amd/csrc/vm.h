@@ -89,7 +89,7 @@
   X(AGG_SUM_F64_ADD) X(AGG_SUM_F64_SUB) X(AGG_SUM_F64_MUL)                     \
   /* ---- materialising sinks ---------------------------------------------- */\
   X(SEL_COUNT)   /* a = sel: tile_counts[tile] = #selected        */           \
-  X(SEL_RANK)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
+  X(SEL_RANK) X(PART_COUNT) X(PART_RANK)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
   X(STORE_8) X(STORE_32) X(STORE_64)     /* dst = out col, a = reg, rows 1:1 */\
   X(STOREC_8) X(STOREC_32) X(STOREC_64)  /* + b = rank reg, c = sel (compact)*/\
   X(STORE_ROWID) /* dst = out col: int64 global row id of survivors, b,c */    \
@@ -195,7 +195,9 @@ struct VmParams {
   uint64_t slot_init1[VM_FAST_SLOTS];
   int32_t slot_kind[VM_FAST_SLOTS];   /* SlotKind of the fast slots */
   VmAccRec* wg_partials;        /* [grid][n_slots] */
-  unsigned int* tile_counts;    /* SEL_COUNT output / scanned offsets input */
+  unsigned int* tile_counts;    /* SEL_COUNT output / scanned offsets input; PART_*: [partition][workgroup] */
+  uint32_t part_n;              /* PART_COUNT / PART_RANK: number of hash partitions */
+  uint32_t part_lds_off;        /* LDS offset of part_n u32 counters */
   const unsigned int* tile_offsets;
   unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */

@@ -172,6 +172,43 @@ def test_group_table_regrow():
     run_both(group_query(make_view(50000), False), ctx, ignore_order=True)
 
 
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
+@pytest.mark.parametrize("with_filter", [False, True])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_group_aggregate_partitioned(n, with_filter, nullable):
+    # the hash-partitioned execution (normally chosen by run feedback when the group count is large)
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", 2)
+    keys = ("k1",) if nullable else ("k1", "k2")
+    run_both(group_query(make_view(n, nullable=nullable), with_filter, keys), ctx, ignore_order=True)
+
+
+def test_group_aggregate_partitioned_many_groups():
+    # more groups than one partition's on-chip table holds at 512 partitions x 100 k groups:
+    # exercises the "partition finer and rerun" path as well as the EMPTY-valued key
+    n = 300000
+    rng = np.random.default_rng(7)
+    key = rng.integers(0, 120000, n).astype(np.int64)
+    key[::1000] = -1          # packed key 0xFFFF...: the table's EMPTY sentinel value
+    val = rng.integers(-1000, 1000, n).astype(np.int64)
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64)])
+    view = ss.View(schema, [ss.Column(key), ss.Column(val)], n)
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "c").AddAggregation(ss.MIN, "v", "mn")
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view))
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", 2)
+    run_both(op, ctx, ignore_order=True)
+    # adaptive: repeated runs of ONE plan walk through the fed-back configurations (smaller
+    # residency / larger LDS table, then hash partitioning); every one must give the same rows
+    from helpers import to_cols, sort_rows, assert_cols_equal
+    from oracle import oracle
+    _, want = oracle.run(op, 1024)
+    plan = ss.Plan(op, ss.Context(0))
+    for _ in range(6):
+        plan.run()
+        assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="adaptive group run")
+
+
 def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     n = 5000
     view = make_view(n)
