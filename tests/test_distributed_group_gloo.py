@@ -1,0 +1,95 @@
+"""N > 1 GroupAggregate on CPU processes (gloo, world_size 2): SURVEY 8(e) / BASELINE config #4.
+
+supersonic_amd.distributed.sharded_group_aggregate = per-shard GroupAggregate -> all-gather of the
+partial group tables -> local merge GroupAggregate.  No kernel can run here, so the executor handed
+to it is the CPU oracle; what is under test is the exchange (variable-size all-gather of typed
+columns and NULL masks, empty shards) and the merge plan (SUM of sums, MIN of mins, MAX of maxes,
+SUM of counts, COUNT kept NOT NULL), which must reproduce the oracle's answer for the WHOLE input.
+The same function runs over RCCL with the device executor (tests/test_parity_gpu.py covers the
+merge plan on the GPU with world_size 1)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import supersonic_amd as ss
+from supersonic_amd.distributed import sharded_group_aggregate
+from oracle import oracle
+from helpers import sort_rows, assert_cols_equal
+
+NA = ss.NamedAttribute
+
+
+def make_view(n, seed=11):
+    rng = np.random.default_rng(seed)
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("k1", ss.INT32), ss.Attribute("k2", ss.INT32, ss.NULLABLE),
+                             ss.Attribute("v", ss.INT64, ss.NULLABLE), ss.Attribute("d", ss.DOUBLE)])
+    return ss.View(schema, [rng.integers(0, 1000, n), rng.integers(0, 40, n).astype(np.int32),
+                            ss.Column(rng.integers(0, 5, n).astype(np.int32), rng.random(n) < 0.1),
+                            ss.Column(rng.integers(-1000, 1000, n), rng.random(n) < 0.3),
+                            rng.integers(-4000, 4000, n) * 0.25])
+
+
+def spec():
+    return (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "sv").AddAggregation(ss.MIN, "v", "mnv")
+            .AddAggregation(ss.MAX, "d", "mxd").AddAggregation(ss.SUM, "d", "sd")
+            .AddAggregation(ss.COUNT, "v", "cv").AddAggregation(ss.COUNT, "", "n"))
+
+
+def child(view, with_filter):
+    op = ss.ScanView(view)
+    if with_filter:
+        op = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), op)
+    return op
+
+
+def oracle_executor(op):
+    schema, cols = oracle.run(op)
+    ts = ss.TupleSchema([ss.Attribute(n, t, ss.NULLABLE if nullable else ss.NOT_NULLABLE) for (n, t, nullable) in schema])
+    return ss.View(ts, [ss.Column(d, z) for (d, z) in cols])
+
+
+def shard_of(full, lo, hi):
+    return ss.View(full.schema(), [ss.Column(full.column(i).data[lo:hi], None if full.column(i).is_null is None else full.column(i).is_null[lo:hi])
+                                   for i in range(full.column_count())])
+
+
+def worker(rank, world, port, n, with_filter, empty_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = make_view(n)
+    bounds = [0, n, n] if empty_rank == 1 else ([0, 0, n] if empty_rank == 0 else [0, n // 3, n])
+    shard = shard_of(full, bounds[rank], bounds[rank + 1])
+    out = sharded_group_aggregate(["k1", "k2"], spec(), child(shard, with_filter), oracle_executor)
+    cols = [(out.column(i).data, out.column(i).is_null) for i in range(out.column_count())]
+    schema = [(out.schema().attribute(i).name(), out.schema().attribute(i).type(), out.schema().attribute(i).is_nullable())
+              for i in range(out.schema().attribute_count())]
+    q.put((rank, schema, cols))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("n,with_filter,empty_rank", [(20001, False, None), (20001, True, None), (3000, True, 1), (3000, False, 0), (0, False, None)])
+def test_sharded_group_aggregate_over_gloo(n, with_filter, empty_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, n, with_filter, empty_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want_schema, want = oracle.run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec(), None, child(make_view(n), with_filter)))
+    for _rank, schema, cols in results:           # every rank holds the full answer
+        assert [tuple(x) for x in schema] == [tuple(x) for x in want_schema]
+        assert_cols_equal(sort_rows(cols), sort_rows(want), context="sharded group aggregate")

@@ -209,6 +209,28 @@ def test_group_aggregate_partitioned_many_groups():
         assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="adaptive group run")
 
 
+def test_sharded_group_aggregate_merge_plan_on_device(gpu_ctx):
+    # the multi-GPU GroupAggregate (per-shard aggregate -> all-gather -> merge aggregate) with the
+    # device executor; one rank here, the world_size-2 exchange is covered on CPU (gloo)
+    import socket
+    import torch.distributed as dist
+    from supersonic_amd.distributed import sharded_group_aggregate, device_executor
+    from helpers import to_cols, sort_rows, assert_cols_equal
+    from oracle import oracle
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        view = make_view(50000)
+        spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "d0", "s0").AddAggregation(ss.MIN, "d1", "mn1")
+                .AddAggregation(ss.MAX, "d2", "mx2").AddAggregation(ss.COUNT, "", "n"))
+        child = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))
+        out = sharded_group_aggregate(["k1", "k2"], spec, child, device_executor(gpu_ctx))
+        _schema, want = oracle.run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, None, child))
+        assert_cols_equal(sort_rows(to_cols(out)), sort_rows(want), context="sharded group aggregate on device")
+    finally:
+        dist.destroy_process_group()
+
+
 def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     n = 5000
     view = make_view(n)
