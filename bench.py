@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="take the N > 1 code path (run_partial + RCCL all-reduce + finalize) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -133,7 +135,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -141,7 +143,11 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if "RANK" in os.environ:
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
 
     ctx = ss.Context(local_rank)
     # launch on torch's current stream so that RCCL collectives and our kernels are ordered
@@ -170,15 +176,25 @@ def main():
             return
         segs = plan.run_partial(view, row_offset)
         if seg_tensors is None:
-            seg_tensors = []
-            for (ptr, count, dtype, reduce) in segs:
-                t = torch.as_tensor(_DevPtr(ptr, count, "<f8" if dtype == ss.DOUBLE else "<i8"), device=device)
-                seg_tensors.append((t, reduce))
-        # one grouped exchange of the (tiny) partial-aggregate state over RCCL / xGMI
-        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}
-        works = [dist.all_reduce(t, op=ops[r], async_op=True) for (t, r) in seg_tensors]
-        for w in works:
-            w.wait()
+            # the partial-aggregate state is ONE contiguous device buffer of 8 arrays x n_slots
+            # 64-bit words (a few hundred bytes): view it as int64 words without a copy
+            total = sum(count for (_p, count, _d, _r) in segs)
+            assert all(segs[i][0] + segs[i][1] * 8 == segs[i + 1][0] for i in range(len(segs) - 1))
+            state = torch.as_tensor(_DevPtr(segs[0][0], total, "<i8"), device=device)
+            gathered = torch.empty((world, total), dtype=torch.int64, device=device)
+            seg_tensors = (state, gathered, [(count, dtype == ss.DOUBLE, reduce) for (_p, count, dtype, reduce) in segs])
+        state, gathered, layout = seg_tensors
+        # ONE collective over RCCL / xGMI (all-gather of the tiny state), then each segment is
+        # folded locally with its own operator (sum / min / max over int64 or float64)
+        dist.all_gather_into_tensor(gathered, state)
+        off = 0
+        for (count, is_f64, reduce) in layout:
+            part = gathered[:, off:off + count]
+            if is_f64:
+                part = part.view(torch.float64)
+            red = part.sum(dim=0) if reduce == 0 else (part.amin(dim=0) if reduce == 1 else part.amax(dim=0))
+            state[off:off + count] = red.view(torch.int64) if is_f64 else red
+            off += count
         plan.finalize()
 
     def barrier():
