@@ -250,7 +250,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ss, args.cpu_sample_rows)
-        print(json.dumps(line))
+        # RCCL prints its version banner through C stdio (still buffered when stdout is a file):
+        # drain it first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
