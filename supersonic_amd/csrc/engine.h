@@ -99,8 +99,7 @@ struct Program {
   std::vector<LReg> regs;
   std::vector<StagedInput> staged;
   uint32_t bytes_per_row = 0;   // LDS bytes per tile row (peak of live registers)
-  uint32_t in_bytes_per_row = 0;  // of which: the (double-buffered) input region
-  int n_sync_per_tile = 0;      // workgroup barriers executed inside the program per tile
+  uint32_t in_bytes_per_row = 0;  // of which: the staged input registers
   int n_slots = 0;
   int n_outputs = 0;
   bool empty() const { return code.empty(); }
@@ -157,11 +156,10 @@ std::string bexpr_to_string(const BExprP& e);
 struct LowerOptions {
   int lds_target_bytes = 48 * 1024;
   int tile_rows = 0;  // 0 = choose by lds_target_bytes
-  bool double_buffer = false; // legacy layout with two LDS input buffers (the kernel prefetches into registers)
 };
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe);
 // choose the tile size (K = tile_rows / 512) and fix LDS offsets for a program
-struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t in_lds_bytes; uint32_t imm_pool_off; bool double_buffer; };
+struct ProgramLayout { int K; uint32_t lds_bytes; uint32_t acc_off; uint32_t scratch_off; uint32_t imm_pool_off; };
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt);
 // final device instructions for a tile of `tile_rows`: two variants (one per input buffer),
 // each n + 1 instructions (trailing NOP for the prefetch)

@@ -398,15 +398,13 @@ static void allocate_registers(Program* p) {
   }
   p->bytes_per_row = std::max(peak, in_bpr);
   p->in_bytes_per_row = in_bpr;
-  p->n_sync_per_tile = 0;
-  for (auto& i : p->code) if (i.op == VM_SEL_COUNT || i.op == VM_SEL_RANK) p->n_sync_per_tile += 2;
 }
 
 ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   ProgramLayout L;
   auto lds_for = [&](int K, uint32_t* acc, uint32_t* scr) {
-    // input registers (+ a second copy in the legacy double-buffered layout) + temporaries
-    uint32_t regs = (p.bytes_per_row + (opt.double_buffer ? p.in_bytes_per_row : 0u)) * 512u * (uint32_t)K;
+    // input registers + temporaries
+    uint32_t regs = p.bytes_per_row * 512u * (uint32_t)K;
     uint32_t a = (regs + 15u) & ~15u;
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
     if (acc) *acc = a;
@@ -429,49 +427,39 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   }
   L.K = K;
   L.lds_bytes = lds_for(K, &L.acc_off, &L.scratch_off);
-  L.in_lds_bytes = p.in_bytes_per_row * 512u * (uint32_t)K;
   L.imm_pool_off = L.scratch_off + 256u;
-  L.double_buffer = opt.double_buffer;
   return L;
 }
 
 void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmInstr>* out) {
   out->clear();
   const uint32_t T = 512u * (uint32_t)L.K;
-  for (int buf = 0; buf < 2; ++buf) {
-    // input-region registers live in input buffer `buf`; temporaries behind both buffers
-    auto off = [&](int r) -> uint32_t {
-      if (r < 0) return VM_NONE;
-      const uint32_t ro = p.regs[r].row_off;
-      if (!L.double_buffer) return ro * T;
-      if (ro < p.in_bytes_per_row) return ro * T + (uint32_t)buf * L.in_lds_bytes;
-      return (ro + p.in_bytes_per_row) * T;
-    };
-    for (size_t pc = 0; pc < p.code.size(); ++pc) {
-      const LInstr& i = p.code[pc];
-      VmInstr v; memset(&v, 0, sizeof(v));
-      v.op = i.op;
-      v.reg_ops = (uint8_t)((i.a_imm ? 0 : 1) | (i.b_imm ? 0 : 2));
-      v.imm_width = (i.a_imm || i.b_imm) ? i.imm_width : 0;
-      v.dst = i.dst_is_reg ? off(i.dst) : (uint32_t)i.dst;
-      const uint32_t pool = L.imm_pool_off + 16u * (uint32_t)pc;  // this instruction's constant
-      v.a = i.a_imm ? pool : off(i.a);
-      v.b = i.b_imm ? pool : off(i.b);
-      v.c = off(i.c); v.d = off(i.d);
-      const bool fused_agg = i.op >= VM_AGG_SUM_I64_ADD && i.op <= VM_AGG_SUM_F64_MUL;
-      if (fused_agg) {  // operands a and d; b is the null mask; b_imm flags operand d
-        v.b = off(i.b);
-        if (i.b_imm) v.d = pool;
-      }
-      v.imm = i.imm;
-      if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
-      out->push_back(v);
+  // VM register -> LDS byte offset: a register is `row_off` bytes per row, i.e. an array at row_off * T
+  auto off = [&](int r) -> uint32_t { return r < 0 ? VM_NONE : p.regs[r].row_off * T; };
+  for (size_t pc = 0; pc < p.code.size(); ++pc) {
+    const LInstr& i = p.code[pc];
+    VmInstr v; memset(&v, 0, sizeof(v));
+    v.op = i.op;
+    v.reg_ops = (uint8_t)((i.a_imm ? 0 : 1) | (i.b_imm ? 0 : 2));
+    v.imm_width = (i.a_imm || i.b_imm) ? i.imm_width : 0;
+    v.dst = i.dst_is_reg ? off(i.dst) : (uint32_t)i.dst;
+    const uint32_t pool = L.imm_pool_off + 16u * (uint32_t)pc;  // this instruction's constant
+    v.a = i.a_imm ? pool : off(i.a);
+    v.b = i.b_imm ? pool : off(i.b);
+    v.c = off(i.c); v.d = off(i.d);
+    const bool fused_agg = i.op >= VM_AGG_SUM_I64_ADD && i.op <= VM_AGG_SUM_F64_MUL;
+    if (fused_agg) {  // operands a and d; b is the null mask; b_imm flags operand d
+      v.b = off(i.b);
+      if (i.b_imm) v.d = pool;
     }
-    // one trailing NOP: the kernel prefetches instruction pc + 1
-    VmInstr nop; memset(&nop, 0, sizeof(nop)); nop.op = VM_NOP;
-    nop.dst = nop.a = nop.b = nop.c = nop.d = VM_NONE;
-    out->push_back(nop);
+    v.imm = i.imm;
+    if (i.op == VM_AND3 || i.op == VM_OR3) v.imm = (uint64_t)off(i.d) | ((uint64_t)off(i.e) << 32);
+    out->push_back(v);
   }
+  // one trailing NOP: the kernel prefetches instruction pc + 1
+  VmInstr nop; memset(&nop, 0, sizeof(nop)); nop.op = VM_NOP;
+  nop.dst = nop.a = nop.b = nop.c = nop.d = VM_NONE;
+  out->push_back(nop);
 }
 
 std::string disassemble(const Program& p) {

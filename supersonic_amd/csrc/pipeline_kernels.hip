@@ -151,11 +151,6 @@ __device__ __forceinline__ Valid2 valid_pair_c(int p, u32 tile_valid, u32 null_o
 }
 #define valid_pair_(p, tile_valid, null_off, sel_off) valid_pair_c(p, tile_valid, null_off, sel_off, P.const_lds_off, (u32)(512 * K))
 
-// LDS operand offsets: bit 31 marks a register in the (double-buffered) input region
-__device__ __forceinline__ u32 vm_resolve(u32 o, u32 bufbase) {
-  return o == VM_NONE ? o : ((o & 0x7FFFFFFFu) + ((o >> 31) ? bufbase : 0u));
-}
-
 __device__ __forceinline__ VmAccRec* acc_rec(const VmParams& P, u32 slot, int wave) {
   return reinterpret_cast<VmAccRec*>(smem + P.acc_lds_off + slot * VM_ACC_STRIDE + wave * 32);
 }

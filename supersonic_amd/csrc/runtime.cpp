@@ -40,7 +40,6 @@ struct ssgpu_ctx {
   int64_t group_partition = 1;   // 0: never switch to the partitioned GroupAggregate; 2: always use it
   int64_t profile = 1;           // record HIP events around kernels
   int64_t debug_timing = 0;
-  int64_t kernel_flags = 0;      // in-kernel cycle counters (development aid)
 };
 
 struct DevBuf {
@@ -212,8 +211,6 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
     c->group_capacity = cap;
   } else if (k == "profile") c->profile = value;
   else if (k == "debug_timing") c->debug_timing = value;
-  else if (k == "kernel_flags") c->kernel_flags = value;
-  else if (k == "double_buffer") c->opt.double_buffer = value != 0;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
 }
@@ -338,7 +335,7 @@ struct InCols { std::vector<ssgpu_column> cols; int64_t rows = 0; };
 
 int upload_program(ssgpu_ctx* c, const Program& prog, const ProgramLayout& L, DevBuf* dev, int* n_instr, std::vector<VmInstr>* scratch) {
   finalize_program(prog, L, scratch);
-  *n_instr = (int)prog.code.size();  // per variant, without the trailing prefetch pad
+  *n_instr = (int)prog.code.size();  // without the trailing prefetch pad
   HIP_TRY(c, dev->ensure(std::max<size_t>(1, scratch->size()) * sizeof(VmInstr)));
   if (!scratch->empty())
     HIP_TRY(c, hipMemcpyAsync(dev->p, scratch->data(), scratch->size() * sizeof(VmInstr), hipMemcpyHostToDevice, c->stream));
@@ -354,7 +351,7 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   StageExec& ex = p->exec[si];
   if (st.main.empty()) return SSGPU_OK;
   ProgramLayout L = layout_program(st.main, c->opt);
-  if (ex.prog_main.p && L.K == ex.lay.K && L.double_buffer == ex.lay.double_buffer) return SSGPU_OK;  // already prepared
+  if (ex.prog_main.p && L.K == ex.lay.K) return SSGPU_OK;  // already prepared
   ex.lay = L;
   int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
@@ -417,9 +414,6 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->imm_pool_lds_off = L.imm_pool_off;
   P->const_lds_off = L.imm_pool_off + 16u * (uint32_t)prog.code.size();  // behind the constant pool
   P->lds_bytes = L.lds_bytes;
-  P->in_lds_bytes = L.in_lds_bytes;
-  P->n_sync_per_tile = prog.n_sync_per_tile;
-  P->flags = 0u;
   for (size_t i = 0; i < prog.staged.size(); ++i) {
     const StagedInput& s = prog.staged[i];
     P->staged[i].src = s.is_null_mask ? (const void*)in.cols[s.col].is_null : in.cols[s.col].data;
@@ -464,7 +458,6 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   fill_fast_slots(&P, st);
-  P.flags |= (uint32_t)c->kernel_flags;
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   ex.grid = grid;
   const int ns = st.main.n_slots;

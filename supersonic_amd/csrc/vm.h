@@ -6,9 +6,10 @@
 // keeps a 1024-row block hot in the CPU's L1 and walks a tree of virtual
 // DoEvaluate() calls, we keep a TILE of rows resident in a workgroup's LDS and
 // run a flat, wave-uniform instruction list over it.  Every VM "register" is a
-// typed array of TILE rows in LDS; input columns are staged into their
-// registers by LDS-DMA (global_load_lds_dwordx4), intermediates never leave the
-// CU, and only sink instructions (aggregate / store / group) touch HBM again.
+// typed array of TILE rows in LDS; input columns reach their registers through
+// a per-lane register prefetch file (the next tile's loads are in flight while
+// the program runs over this one), intermediates never leave the CU, and only
+// sink instructions (aggregate / store / group) touch HBM again.
 //
 // Thread <-> row mapping inside a tile (256 threads, K = tile_rows / 512):
 //   thread t, step k owns the row PAIR  p = k*256 + t  ->  rows 2p, 2p+1.
@@ -188,9 +189,8 @@ struct VmParams {
   uint32_t imm_pool_lds_off; /* LDS offset of the constant pool: 16 B per instruction */
   uint32_t const_lds_off;    /* LDS offset of 2 x tile_rows bytes: all 0x01, then all 0x00 */
   uint32_t lds_bytes;
-  uint32_t in_lds_bytes;      /* bytes of ONE input buffer (two are resident) */
-  int32_t n_sync_per_tile;    /* s_barriers executed inside the program per tile */
-  uint32_t flags;             /* experiments */
+  int32_t reserved1;
+  uint32_t reserved0;
   uint64_t slot_init0[VM_FAST_SLOTS]; /* per-lane identities of the fast slots */
   uint64_t slot_init1[VM_FAST_SLOTS];
   int32_t slot_kind[VM_FAST_SLOTS];   /* SlotKind of the fast slots */

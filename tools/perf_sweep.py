@@ -121,8 +121,6 @@ def main():
     ap.add_argument("--grids", default="0")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--debug", type=int, default=0)
-    ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--dbuf", type=int, default=0)
     ap.add_argument("--wgs", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -138,8 +136,6 @@ def main():
                     ctx.set_option("lds_target_bytes", lds)
                     ctx.set_option("grid_limit", grid)
                     ctx.set_option("debug_timing", args.debug)
-                    ctx.set_option("kernel_flags", args.flags)
-                    ctx.set_option("double_buffer", args.dbuf)
                     ctx.set_option("wgs_per_cu", args.wgs)
                     try:
                         plan = ss.Plan(QUERIES[qn](view), ctx)
