@@ -192,6 +192,27 @@ inline const Expression* Less(const Expression* a, const Expression* b) { return
 inline const Expression* LessOrEqual(const Expression* a, const Expression* b) { return internal::Op(120, a, b); }
 inline const Expression* Greater(const Expression* a, const Expression* b) { return internal::Op(SSGPU_OP_GREATER, a, b); }
 inline const Expression* GreaterOrEqual(const Expression* a, const Expression* b) { return internal::Op(SSGPU_OP_GREATER_OR_EQUAL, a, b); }
+// owning list of expressions (expression/base/expression.h): the arguments of Case / In
+class ExpressionList {
+ public:
+  ExpressionList* add(const Expression* e) { items.emplace_back(e); return this; }
+  std::vector<std::unique_ptr<const Expression>> items;
+};
+// CASE arg0 WHEN arg2 THEN arg3 [...] ELSE arg1 (elementary_expressions.h:91-93); takes ownership
+inline const Expression* Case(ExpressionList* arguments) {
+  std::unique_ptr<ExpressionList> own(arguments);
+  Expression* e = internal::Node(SSGPU_EXPR_OP, 200);
+  for (auto& a : own->items) e->args.emplace_back(a.release());
+  return e;
+}
+// needle IN (haystack...) with SQL NULL semantics (comparison_expressions.h:75-89); takes ownership
+inline const Expression* In(const Expression* needle, ExpressionList* haystack) {
+  std::unique_ptr<ExpressionList> own(haystack);
+  Expression* e = internal::Node(SSGPU_EXPR_OP, 208);
+  e->args.emplace_back(needle);
+  for (auto& a : own->items) e->args.emplace_back(a.release());
+  return e;
+}
 inline const Expression* If(const Expression* c, const Expression* t, const Expression* e) { return internal::Op(204, c, t, e); }
 inline const Expression* IfNull(const Expression* a, const Expression* b) { return internal::Op(220, a, b); }
 inline const Expression* IsNull(const Expression* a) { return internal::Op(224, a); }

@@ -39,13 +39,13 @@ enum { A_SUM = 0, A_MIN = 1, A_MAX = 2, A_COUNT = 3, A_CONCAT = 4, A_FIRST = 5, 
 /* ReturnCode values, supersonic.proto:40-82 */
 enum { RC_OK = 0, RC_NOT_IMPLEMENTED = 103, RC_EVALUATION_ERROR = 104, RC_COUNT_MISMATCH = 401,
        RC_TYPE_MISMATCH = 402, RC_ATTRIBUTE_MISSING = 403, RC_ATTRIBUTE_EXISTS = 404,
-       RC_INVALID_ARGUMENT_TYPE = 405 };
+       RC_INVALID_ARGUMENT_TYPE = 405, RC_INVALID_ARGUMENT_VALUE = 407 };
 /* OperatorId values, supersonic/expression/proto/operators.proto */
 enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DIVIDE_NULLING = 14,
        OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
        OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36, OP_AND = 40, OP_OR = 44,
        OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116,
-       OP_LESS_OR_EQUAL = 120, OP_IF = 204, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
+       OP_LESS_OR_EQUAL = 120, OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
        OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002 };
 
 typedef struct { int code; char msg[512]; } orc_error;
@@ -116,7 +116,7 @@ void orc_expr_add_arg(orc_expr* e, orc_expr* a) { if (e->nargs < 16) e->args[e->
 enum { B_INPUT, B_CONST, B_NULLCONST, B_OP, B_CAST };
 typedef struct bnode {
   int kind, op, dtype, nullable, input_col, nargs;
-  struct bnode* args[3];
+  struct bnode* args[16];
   uint64_t bits;
   char name[256];
   void* buf;          /* result data, ORC_BLOCK rows */
@@ -352,7 +352,59 @@ static bnode* bind_compare(int op, bnode* l, bnode* r, orc_error* err) {
   return make_op2(op, T_BOOL, l->nullable || r->nullable, l, r, err);
 }
 
+/* CASE arg0 WHEN arg2 THEN arg3 ... ELSE arg1: BoundCase, elementary_bound_expressions.cc:1297-1356 */
+static bnode* bind_case(const orc_expr* e, const orc_schema* s, orc_error* err) {
+  bnode* a[16];
+  const int n = e->nargs;
+  if (n < 2) { set_err(err, RC_INVALID_ARGUMENT_VALUE, "Case expects at least 2 arguments (make sense from 4 arguments).%s%s", "", ""); return NULL; }
+  if (n % 2 != 0) { set_err(err, RC_INVALID_ARGUMENT_VALUE, "Case expects odd number of arguments.%s%s", "", ""); return NULL; }
+  for (int i = 0; i < n; ++i) { a[i] = bind_single(e->args[i], s, err); if (err->code) return NULL; }
+  int test_type = a[0]->dtype, out_type = a[1]->dtype;
+  for (int i = 2; i < n; ++i) {
+    int* expected = (i % 2 == 0) ? &test_type : &out_type;
+    if (a[i]->dtype != *expected) {
+      if (!is_numeric(a[i]->dtype) || !is_numeric(*expected)) {
+        set_err(err, RC_TYPE_MISMATCH, "Bind failed: Case: Cannot cast attribute (%s to %s)", type_name(a[i]->dtype), type_name(*expected)); return NULL;
+      }
+      *expected = common_type(a[i]->dtype, *expected, err); if (err->code) return NULL;
+    }
+  }
+  char nm[256]; size_t len = (size_t)snprintf(nm, sizeof(nm), "CASE(");
+  int nullable = 0;
+  for (int i = 0; i < n; ++i) {
+    a[i] = make_cast(a[i], i % 2 == 0 ? test_type : out_type, 1, err); if (err->code) return NULL;
+    if (i % 2 == 1 && a[i]->nullable) nullable = 1;   /* DetermineNullability :773-780 */
+    if (len < sizeof(nm)) len += (size_t)snprintf(nm + len, sizeof(nm) - len, "%s%s", i ? ", " : "", a[i]->name);
+  }
+  if (len < sizeof(nm)) snprintf(nm + len, sizeof(nm) - len, ")");
+  bnode* b = bnode_new(B_OP, OP_CASE, out_type, nullable, nm);
+  for (int i = 0; i < n; ++i) b->args[i] = a[i];
+  b->nargs = n;
+  return fold(b, err);
+}
+
+/* expr IN (value, ...): BoundInSet, comparison_bound_expressions.cc:759-813 (+ :642-700, :150-156) */
+static bnode* bind_in(const orc_expr* e, const orc_schema* s, orc_error* err) {
+  bnode* a[16];
+  const int n = e->nargs;
+  if (n < 1) { set_err(err, RC_INVALID_ARGUMENT_VALUE, "IN needs a needle%s%s", "", ""); return NULL; }
+  for (int i = 0; i < n; ++i) { a[i] = bind_single(e->args[i], s, err); if (err->code) return NULL; }
+  int t = a[0]->dtype;
+  for (int i = 1; i < n; ++i) { t = common_type(t, a[i]->dtype, err); if (err->code) return NULL; }
+  int nullable = 0;
+  for (int i = 0; i < n; ++i) { a[i] = make_cast(a[i], t, 1, err); if (err->code) return NULL; if (a[i]->nullable) nullable = 1; }
+  char nm[256]; size_t len = (size_t)snprintf(nm, sizeof(nm), "%s IN (", a[0]->name);
+  for (int i = 1; i < n; ++i) if (len < sizeof(nm)) len += (size_t)snprintf(nm + len, sizeof(nm) - len, "%s%s", i > 1 ? ", " : "", a[i]->name);
+  if (len < sizeof(nm)) snprintf(nm + len, sizeof(nm) - len, ")");
+  bnode* b = bnode_new(B_OP, OP_IN, T_BOOL, nullable, nm);
+  for (int i = 0; i < n; ++i) b->args[i] = a[i];
+  b->nargs = n;
+  return fold(b, err);
+}
+
 static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
+  if (e->op == OP_CASE) return bind_case(e, s, err);
+  if (e->op == OP_IN) return bind_in(e, s, err);
   bnode* a[3] = {0, 0, 0};
   for (int i = 0; i < e->nargs && i < 3; ++i) { a[i] = bind_single(e->args[i], s, err); if (err->code) return NULL; }
   const int op = e->op;
@@ -528,6 +580,53 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
       b->nulls = x->nulls; return;
     }
     case OP_IS_NULL: { uint8_t* D = (uint8_t*)b->buf; for (int64_t i = 0; i < n; ++i) D[i] = x->nulls ? x->nulls[i] : 0; return; }
+    case OP_CASE: {
+      /* BoundCaseExpression::DoEvaluate (elementary_bound_expressions.cc:595-760): the first WHEN
+       * that is non-NULL and equal to a non-NULL CASE value selects its THEN; otherwise (no match,
+       * or CASE value NULL) the OTHERWISE argument; the result is NULL iff the selected one is.
+       * (All arguments are evaluated on all rows here; the reference skips unselected rows, which
+       * only matters for failing sub-expressions.) */
+      const int w = type_width(b->dtype), tw = type_width(x->dtype);
+      int any = 0;
+      for (int a = 1; a < b->nargs; a += 2) if (b->args[a]->nulls) any = 1;
+      for (int64_t i = 0; i < n; ++i) {
+        bnode* src = b->args[1];
+        if (!(x->nulls && x->nulls[i])) {
+          for (int a = 2; a + 1 < b->nargs; a += 2) {
+            bnode* wn = b->args[a];
+            if (wn->nulls && wn->nulls[i]) continue;
+            int eq;
+            if (x->dtype == T_DOUBLE) eq = ((const double*)x->data)[i] == ((const double*)wn->data)[i];
+            else if (x->dtype == T_FLOAT) eq = ((const float*)x->data)[i] == ((const float*)wn->data)[i];
+            else eq = memcmp((const char*)x->data + i * tw, (const char*)wn->data + i * tw, (size_t)tw) == 0;
+            if (eq) { src = b->args[a + 1]; break; }
+          }
+        }
+        memcpy((char*)b->buf + i * w, (const char*)src->data + i * w, (size_t)w);
+        b->nullbuf[i] = src->nulls ? src->nulls[i] : 0;
+      }
+      b->nulls = any ? b->nullbuf : NULL; return;
+    }
+    case OP_IN: {
+      /* SQL IN (comparison_expressions.h:75-84): TRUE on a match; else NULL if the needle or any
+       * list element is NULL; else FALSE */
+      const int tw = type_width(x->dtype);
+      uint8_t* D = (uint8_t*)b->buf; int any = 0;
+      for (int a = 0; a < b->nargs; ++a) if (b->args[a]->nulls) any = 1;
+      for (int64_t i = 0; i < n; ++i) {
+        int found = 0, saw_null = x->nulls && x->nulls[i];
+        for (int a = 1; a < b->nargs && !found; ++a) {
+          bnode* h = b->args[a];
+          if (h->nulls && h->nulls[i]) { saw_null = 1; continue; }
+          if (x->nulls && x->nulls[i]) continue;
+          if (x->dtype == T_DOUBLE) found = ((const double*)x->data)[i] == ((const double*)h->data)[i];
+          else if (x->dtype == T_FLOAT) found = ((const float*)x->data)[i] == ((const float*)h->data)[i];
+          else found = memcmp((const char*)x->data + i * tw, (const char*)h->data + i * tw, (size_t)tw) == 0;
+        }
+        D[i] = (uint8_t)found; b->nullbuf[i] = (uint8_t)(!found && saw_null);
+      }
+      b->nulls = any ? b->nullbuf : NULL; return;
+    }
     case OP_IF_NULL: {
       const int w = type_width(b->dtype);
       for (int64_t i = 0; i < n; ++i) {

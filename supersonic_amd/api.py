@@ -277,6 +277,31 @@ def Less(a, b): return _op(116, a, b)
 def LessOrEqual(a, b): return _op(120, a, b)
 def Greater(a, b): return _op(L.OP_GREATER, a, b)
 def GreaterOrEqual(a, b): return _op(L.OP_GREATER_OR_EQUAL, a, b)
+class ExpressionList(object):
+    """expression/base/expression.h: owning list of expressions (Case / In arguments)."""
+
+    def __init__(self, *expressions):
+        self.expressions = list(expressions)
+
+    def add(self, e):
+        self.expressions.append(e)
+        return self
+
+
+def _list(arguments):
+    return list(arguments.expressions) if isinstance(arguments, ExpressionList) else list(arguments)
+
+
+def Case(arguments):
+    """CASE arg0 WHEN arg2 THEN arg3 [...] ELSE arg1 (elementary_expressions.h:91-93)."""
+    return Expression(L.EXPR_OP, op=200, args=_list(arguments))
+
+
+def In(needle, haystack):
+    """needle IN (haystack...) with SQL NULL semantics (comparison_expressions.h:75-89)."""
+    return Expression(L.EXPR_OP, op=208, args=[needle] + _list(haystack))
+
+
 def If(c, t, e): return _op(204, c, t, e)
 def IfNull(a, b): return _op(220, a, b)
 def IsNull(a): return _op(224, a)

@@ -22,7 +22,7 @@ enum {
   OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_BITWISE_AND = 60, OP_BITWISE_OR = 64,
   OP_BITWISE_NOT = 68, OP_BITWISE_XOR = 72, OP_SHIFT_LEFT = 76, OP_SHIFT_RIGHT = 80,
   OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116, OP_LESS_OR_EQUAL = 120,
-  OP_IF = 204, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST_QUIET = 265
+  OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST_QUIET = 265
 };
 
 const char* dtype_name(int t) {
@@ -497,6 +497,85 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
       SS_RETURN_IF_ERROR(make_cast(args[1], t, true, &rc));
       if (!lc->nullable) { *out = lc; return Status::OK(); }
       *out = make_op(op, t, rc->nullable, fmt_binary(op, lc->name, rc->name), {lc, rc}, depth);
+      return Status::OK();
+    }
+    case OP_CASE: {
+      // CASE arg0 WHEN arg2 THEN arg3 ... ELSE arg1 (BoundCase, elementary_bound_expressions.cc:1297-1356).
+      // Bound as a chain of plain IFs over equality tests, which has exactly the reference's
+      // semantics (:556-600): a NULL CASE value or a NULL WHEN never matches, the first match
+      // wins, and the result is NULL iff the selected THEN / OTHERWISE is.
+      const size_t n = args.size();
+      if (n < 2) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "Case expects at least 2 arguments (make sense from 4 arguments).");
+      if (n % 2 != 0) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "Case expects odd number of arguments.");
+      int test_type = args[0]->dtype, out_type = args[1]->dtype;
+      for (size_t i = 2; i < n; ++i) {
+        int* expected = (i % 2 == 0) ? &test_type : &out_type;
+        if (args[i]->dtype == *expected) continue;
+        if (!dtype_is_numeric(args[i]->dtype) || !dtype_is_numeric(*expected))
+          return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("Bind failed: Case: Cannot cast attribute ") + std::to_string(i) +
+                               " (" + dtype_name(args[i]->dtype) + " to " + dtype_name(*expected) + ")");
+        int t; SS_RETURN_IF_ERROR(common_type(args[i]->dtype, *expected, &t));
+        *expected = t;
+      }
+      std::vector<BExprP> c(n);
+      std::string name = "CASE(";
+      bool nullable = false, all_const = true;
+      for (size_t i = 0; i < n; ++i) {
+        SS_RETURN_IF_ERROR(make_cast(args[i], i % 2 == 0 ? test_type : out_type, true, &c[i]));
+        if (i % 2 == 1 && c[i]->nullable) nullable = true;
+        if (c[i]->kind != BExpr::CONST && c[i]->kind != BExpr::NULLCONST) all_const = false;
+        name += (i ? ", " : "") + c[i]->name;
+      }
+      name += ")";
+      BExprP result = c[1];
+      for (size_t i = n; i >= 4; i -= 2) {   // last WHEN/THEN pair innermost
+        BExprP cond;
+        SS_RETURN_IF_ERROR(bind_compare(OP_EQUAL, c[0], c[i - 2], depth, &cond));
+        if (cond->kind == BExpr::NULLCONST || (cond->kind == BExpr::CONST && !cond->bits)) continue;   // can never match
+        if (cond->kind == BExpr::CONST) { result = c[i - 1]; continue; }                                 // always matches
+        result = make_op(OP_IF, out_type, c[i - 1]->nullable || result->nullable, "", {cond, c[i - 1], result}, depth);
+      }
+      (void)all_const;
+      BExprP named(new BExpr(*result));
+      named->name = name;
+      if (named->kind == BExpr::CONST) named->name = result->name;   // folded to a constant, as InitBasicExpression does
+      *out = named;
+      return Status::OK();
+    }
+    case OP_IN: {
+      // expr IN (value, ...): BoundInSet, comparison_bound_expressions.cc:759-813.  Bound as the
+      // three-valued OR of equality tests: TRUE on a match, else NULL if the needle or a list
+      // element is NULL, else FALSE (comparison_expressions.h:75-84).
+      const size_t n = args.size();
+      if (n < 1) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "IN needs a needle expression");
+      int t = args[0]->dtype;
+      for (size_t i = 1; i < n; ++i) { int u; SS_RETURN_IF_ERROR(common_type(t, args[i]->dtype, &u)); t = u; }
+      std::vector<BExprP> c(n);
+      bool nullable = false;
+      for (size_t i = 0; i < n; ++i) {
+        SS_RETURN_IF_ERROR(make_cast(args[i], t, true, &c[i]));
+        nullable = nullable || c[i]->nullable;
+      }
+      std::string name = c[0]->name + " IN (";
+      for (size_t i = 1; i < n; ++i) name += (i > 1 ? ", " : "") + c[i]->name;
+      name += ")";
+      BExprP result;
+      if (n == 1) {
+        // "$0 IN ()": FALSE, or NULL for a NULL needle -- (x == x) XOR (x == x) has exactly that
+        // value for every x, NaN included, and keeps the node non-constant like the reference's
+        BExprP eq;
+        SS_RETURN_IF_ERROR(bind_compare(OP_EQUAL, c[0], c[0], depth, &eq));
+        result = make_op(OP_XOR, SSGPU_BOOL, eq->nullable, "", {eq, eq}, depth);
+      }
+      for (size_t i = 1; i < n; ++i) {
+        BExprP eq;
+        SS_RETURN_IF_ERROR(bind_compare(OP_EQUAL, c[0], c[i], depth, &eq));
+        if (i == 1) { result = eq; continue; }
+        result = fold(make_op(OP_OR, SSGPU_BOOL, result->nullable || eq->nullable, "", {result, eq}, depth));
+      }
+      BExprP named(new BExpr(*result));
+      if (named->kind != BExpr::CONST && named->kind != BExpr::NULLCONST) { named->name = name; named->nullable = nullable; }
+      *out = named;
       return Status::OK();
     }
     case OP_IF: {

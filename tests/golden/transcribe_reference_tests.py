@@ -64,6 +64,17 @@ def cols(types, nullable=True):
     return [["col%d" % i, t, nullable] for i, t in enumerate(types)]
 
 
+def expr_plan_case(name, source, in_types, expr, out_type, rows, nullable=True):
+    """An expression over AttributeAt(i) inputs given as a DSL tree; rows: inputs + expected (last)."""
+    n_in = len(in_types)
+    CASES.append({
+        "name": name, "source": source, "kind": "expression",
+        "input": {"schema": [["col%d" % i, in_types[i], nullable] for i in range(n_in)], "rows": [r[:n_in] for r in rows]},
+        "plan": ["Compute", expr, "INPUT"],
+        "expected": {"types": [out_type], "rows": [[r[-1]] for r in rows], "names": None, "nullable": None},
+        "ordered": True, "expect_error": None})
+
+
 A = "supersonic/expression/core/arithmetic_expressions_test.cc"
 E = "supersonic/expression/core/elementary_expressions_test.cc"
 
@@ -284,6 +295,51 @@ op_case("Sort_TwoColumnsFirstMixed", SO + ":299-328", cols([I32, I64]),
         srows([(3, "z"), (None, "v"), (2, "z"), (3, None), (None, "w"), (3, "x"), (1, "x"), (None, "y")]),
         ["Sort", [["col0", "ASCENDING"], ["col1", "ASCENDING"]], None, "INPUT"], [I32, I64],
         srows([(None, "v"), (None, "w"), (None, "y"), (1, "x"), (2, "z"), (3, None), (3, "x"), (3, "z")]))
+
+def bind_plan_case(name, source, expr, in_types, in_nullable, out_name, out_type, out_nullable, expect_error=None):
+    n_in = len(in_types)
+    CASES.append({
+        "name": name, "source": source, "kind": "binding",
+        "input": {"schema": [["$%d" % i, in_types[i], in_nullable[i]] for i in range(n_in)], "rows": []},
+        "plan": ["Compute", expr, "INPUT"],
+        "expected": {"types": [out_type] if out_type else None, "rows": [], "names": [out_name] if out_name else None,
+                     "nullable": [out_nullable] if out_nullable is not None else None},
+        "ordered": True, "expect_error": expect_error})
+
+
+# ---- IN (comparison_bound_expressions_test.cc: binding names; the reference has no evaluation
+# ---- table for IN, its SQL NULL rule is restated from comparison_expressions.h:75-84) -----------
+CB = "supersonic/expression/core/comparison_bound_expressions_test.cc"
+IN4 = ["InList", ["AttributeAt", 0], ["AttributeAt", 1], ["AttributeAt", 2], ["AttributeAt", 3]]
+bind_plan_case("InSet_int32", CB + ":120-121", IN4, [I32, I32, I32, I32], [False] * 4, "$0 IN ($1, $2, $3)", BOOL, False)
+bind_plan_case("InSet_empty", CB + ":122", ["InList", ["AttributeAt", 0]], [I64], [False], "$0 IN ()", BOOL, False)
+bind_plan_case("InSet_multi_1", CB + ":126-127", IN4, [I32, I64, I64, I64], [False] * 4, "CAST_INT32_TO_INT64($0) IN ($1, $2, $3)", BOOL, False)
+bind_plan_case("InSet_multi_2", CB + ":128-129", IN4, [I64, I32, I64, I64], [False] * 4, "$0 IN (CAST_INT32_TO_INT64($1), $2, $3)", BOOL, False)
+bind_plan_case("InSet_multi_3", CB + ":130-132", IN4, [F64, I32, U32, U64], [False] * 4,
+               "$0 IN (CAST_INT32_TO_DOUBLE($1), CAST_UINT32_TO_DOUBLE($2), CAST_UINT64_TO_DOUBLE($3))", BOOL, False)
+bind_plan_case("InSet_multi_4", CB + ":133-135", IN4, [I32, I32, F64, U64], [False] * 4,
+               "CAST_INT32_TO_DOUBLE($0) IN (CAST_INT32_TO_DOUBLE($1), $2, CAST_UINT64_TO_DOUBLE($3))", BOOL, False)
+
+# ---- CASE (case_expression_test.cc) ------------------------------------------------------------
+# STRING THEN/OTHERWISE payloads are substituted by INT64 codes ("A" -> 65 ...), see the header.
+C = "supersonic/expression/core/case_expression_test.cc"
+AT = lambda i: ["AttributeAt", i]  # noqa: E731
+expr_plan_case("Case_BasicInt32", C + ":33-50",
+               [I32], ["CaseList", AT(0), ["ConstInt64", 0], ["ConstInt32", 1], ["ConstInt64", 1], ["ConstInt32", 2], ["ConstInt64", 2]], I64,
+               [[1, 1], [2, 2], [3, 0], [4, 0], [5, 0], [None, 0]])
+expr_plan_case("Case_NullThen", C + ":52-70 (selector INT32 instead of STRING)",
+               [I32, U32], ["CaseList", AT(0), AT(1), ["ConstInt32", 1], ["ConstUint32", 1], ["ConstInt32", 5], ["NullOf", "UINT32"]], U32,
+               [[0, 10, 10], [9, 9, 9], [1, 8, 1], [4, 7, 7], [5, 6, None], [None, None, None]])
+expr_plan_case("Case_ForceCast", C + ":72-93",
+               [I32, U32], ["CaseList", AT(0), AT(1), ["ConstInt64", 3], ["ConstUint64", 4], ["ConstFloat", 5.0], ["ConstDouble", 10.0]], F64,
+               [[1, 10, 10.0], [2, 9, 9.0], [3, 8, 4.0], [4, 7, 7.0], [5, 6, 10.0], [None, None, None]])
+IFCASE = ["CaseList", AT(0), AT(2), ["ConstBool", True], AT(1)]
+expr_plan_case("Case_IfCaseWithNullCondition", C + ":112-118", [BOOL, I64, I64], IFCASE, I64,
+               [[False, 65, 66, 66], [None, 67, 68, 68], [True, 69, 70, 69]])
+expr_plan_case("Case_IfCaseAllNullable", C + ":178-195", [BOOL, I64, I64], IFCASE, I64,
+               [[True, 65, 66, 65], [False, 67, 68, 68], [True, None, 70, None], [False, None, 72, 72], [True, 73, None, 73],
+                [False, 75, None, None], [True, None, None, None], [False, None, None, None], [None, 77, 78, 78], [None, None, 80, 80],
+                [None, 82, None, None], [None, None, None, None], [False, 87, 89, 89]])
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")

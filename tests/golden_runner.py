@@ -55,6 +55,12 @@ def build_expr(e):
             else:
                 c.Add(build_expr(a[1] if a[0] == "Add" else a))
         return c
+    if head == "CaseList":     # CASE arg0 WHEN arg2 THEN arg3 ... ELSE arg1
+        return ss.Case([build_expr(a) for a in args])
+    if head == "InList":       # needle IN (rest...)
+        return ss.In(build_expr(args[0]), [build_expr(a) for a in args[1:]])
+    if head == "NullOf":
+        return ss.Null(TYPES[args[0]])
     if head in ("AttributeAt", "NamedAttribute") or head.startswith("Const"):
         return getattr(ss, head)(*args)
     return getattr(ss, head)(*[build_expr(a) for a in args])

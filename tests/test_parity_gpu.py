@@ -231,6 +231,25 @@ def test_sharded_group_aggregate_merge_plan_on_device(gpu_ctx):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("n", [0, 1, 1025, 20011])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_case_and_in_expressions(gpu_ctx, n, nullable):
+    # CASE (elementary_bound_expressions.cc:542-760) and IN (comparison_expressions.h:75-89) over
+    # columns, constants and NULL literals, with type promotion of the WHEN / THEN / list elements
+    view = make_view(n, nullable=nullable)
+    case1 = ss.Case([NA("k2"), NA("d0"), ss.ConstInt32(1), NA("d1"), NA("k1"), ss.ConstDouble(-1.5), ss.ConstInt64(7), ss.Null(ss.DOUBLE)])
+    case2 = ss.Case([NA("t"), NA("a"), ss.ConstBool(True), NA("b")])
+    in1 = ss.In(NA("k2"), [ss.ConstInt32(3), NA("k1"), ss.ConstInt64(11)])
+    in2 = ss.In(NA("a"), [ss.ConstInt64(5), ss.Null(ss.INT64), NA("b")])
+    in3 = ss.In(NA("d2"), [ss.ConstDouble(3.0), NA("d3")])
+    e = (ss.CompoundExpression().AddAs("c1", case1).AddAs("c2", case2).AddAs("i1", in1).AddAs("i2", in2).AddAs("i3", in3)
+         .AddAs("i0", ss.In(NA("a"), [])))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
+    # as a filter predicate and inside an aggregate
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "c1", "s").AddAggregation(ss.COUNT, "c2", "n")
+    run_both(ss.ScalarAggregate(spec, ss.Compute(e, ss.Filter(in1, ss.ProjectAllAttributes(), ss.ScanView(view)))), gpu_ctx)
+
+
 def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     n = 5000
     view = make_view(n)
