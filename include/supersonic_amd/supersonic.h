@@ -192,6 +192,24 @@ inline const Expression* Less(const Expression* a, const Expression* b) { return
 inline const Expression* LessOrEqual(const Expression* a, const Expression* b) { return internal::Op(120, a, b); }
 inline const Expression* Greater(const Expression* a, const Expression* b) { return internal::Op(SSGPU_OP_GREATER, a, b); }
 inline const Expression* GreaterOrEqual(const Expression* a, const Expression* b) { return internal::Op(SSGPU_OP_GREATER_OR_EQUAL, a, b); }
+// exact math family (expression/core/math_expressions.h:78-126; IsOdd/IsEven: comparison_expressions.h)
+inline const Expression* Abs(const Expression* a) { return internal::Op(360, a); }
+inline const Expression* Round(const Expression* a) { return internal::Op(300, a); }
+inline const Expression* Ceil(const Expression* a) { return internal::Op(342, a); }
+inline const Expression* Floor(const Expression* a) { return internal::Op(346, a); }
+inline const Expression* Trunc(const Expression* a) { return internal::Op(304, a); }
+inline const Expression* RoundToInt(const Expression* a) { return internal::Op(316, a); }
+inline const Expression* CeilToInt(const Expression* a) { return internal::Op(308, a); }
+inline const Expression* FloorToInt(const Expression* a) { return internal::Op(312, a); }
+inline const Expression* SqrtQuiet(const Expression* a) { return internal::Op(333, a); }
+inline const Expression* SqrtNulling(const Expression* a) { return internal::Op(334, a); }
+inline const Expression* SqrtSignaling(const Expression* a) { return internal::Op(335, a); }
+inline const Expression* IsFinite(const Expression* a) { return internal::Op(148, a); }
+inline const Expression* IsInf(const Expression* a) { return internal::Op(152, a); }
+inline const Expression* IsNaN(const Expression* a) { return internal::Op(156, a); }
+inline const Expression* IsNormal(const Expression* a) { return internal::Op(160, a); }
+inline const Expression* IsOdd(const Expression* a) { return internal::Op(140, a); }
+inline const Expression* IsEven(const Expression* a) { return internal::Op(144, a); }
 // owning list of expressions (expression/base/expression.h): the arguments of Case / In
 class ExpressionList {
  public:

@@ -45,7 +45,10 @@ enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DI
        OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
        OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36, OP_AND = 40, OP_OR = 44,
        OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116,
-       OP_LESS_OR_EQUAL = 120, OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
+       OP_LESS_OR_EQUAL = 120, OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
+       OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
+       OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
+       OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
        OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002 };
 
 typedef struct { int code; char msg[512]; } orc_error;
@@ -454,6 +457,48 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       bnode* b = bnode_new(B_OP, op, st, c->nullable, nm); b->args[0] = c; b->nargs = 1;
       return fold(b, err);
     }
+    /* ---- exact math family (expression/core/math_bound_expressions.cc:150-170,318-456,473-486) ---- */
+    case OP_ABS: {
+      int t = a[0]->dtype;
+      if (t == T_UINT32 || t == T_UINT64) return a[0];
+      int ot = t == T_INT32 ? T_UINT32 : t == T_INT64 ? T_UINT64 : (t == T_FLOAT || t == T_DOUBLE) ? t : -1;
+      if (ot < 0) { set_err(err, RC_TYPE_MISMATCH, "ABS is not defined for %s%s", type_name(t), ""); return NULL; }
+      char nm[256]; snprintf(nm, sizeof(nm), "ABS(%s)", a[0]->name);
+      bnode* b = bnode_new(B_OP, op, ot, a[0]->nullable, nm); b->args[0] = a[0]; b->nargs = 1;
+      return fold(b, err);
+    }
+    case OP_ROUND: case OP_CEIL: case OP_FLOOR: case OP_TRUNC: case OP_CEIL_TO_INT: case OP_FLOOR_TO_INT: case OP_ROUND_TO_INT: {
+      int t = a[0]->dtype;
+      if (is_integer(t)) return a[0];
+      if (!is_float(t)) { set_err(err, RC_TYPE_MISMATCH, "rounding is not defined for %s%s", type_name(t), ""); return NULL; }
+      bnode* child = a[0];
+      int ops[2] = {op, -1};
+      if (op == OP_ROUND_TO_INT) { ops[0] = OP_ROUND; ops[1] = OP_CEIL_TO_INT; }   /* BoundRoundToInt :327-339 */
+      for (int k = 0; k < 2 && ops[k] >= 0; ++k) {
+        const int o = ops[k];
+        const char* n = o == OP_ROUND ? "ROUND" : o == OP_CEIL ? "CEIL" : o == OP_FLOOR ? "FLOOR" : o == OP_TRUNC ? "TRUNC" : o == OP_CEIL_TO_INT ? "CEIL_TO_INT" : "FLOOR_TO_INT";
+        const int ot = (o == OP_CEIL_TO_INT || o == OP_FLOOR_TO_INT) ? T_INT64 : child->dtype;
+        char nm[256]; snprintf(nm, sizeof(nm), "%s(%s)", n, child->name);
+        bnode* b = bnode_new(B_OP, o, ot, child->nullable, nm); b->args[0] = child; b->nargs = 1;
+        child = fold(b, err);
+      }
+      return child;
+    }
+    case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING:
+    case OP_IS_FINITE: case OP_IS_INF: case OP_IS_NAN: case OP_IS_NORMAL: {
+      bnode* c = make_cast(a[0], T_DOUBLE, 1, err); if (err->code) return NULL;
+      const int is_sqrt = op == OP_SQRT_QUIET || op == OP_SQRT_NULLING || op == OP_SQRT_SIGNALING;
+      const char* n = is_sqrt ? "SQRT" : op == OP_IS_FINITE ? "IS_FINITE" : op == OP_IS_INF ? "IS_INF" : op == OP_IS_NAN ? "IS_NAN" : "IS_NORMAL";
+      char nm[256]; snprintf(nm, sizeof(nm), "%s(%s)", n, c->name);
+      bnode* b = bnode_new(B_OP, op, is_sqrt ? T_DOUBLE : T_BOOL, c->nullable || op == OP_SQRT_NULLING, nm); b->args[0] = c; b->nargs = 1;
+      return op == OP_SQRT_SIGNALING ? b : fold(b, err);
+    }
+    case OP_IS_ODD: case OP_IS_EVEN: {
+      if (!is_integer(a[0]->dtype)) { set_err(err, RC_TYPE_MISMATCH, "IS_ODD / IS_EVEN need an integer argument%s%s", "", ""); return NULL; }
+      char nm[256]; snprintf(nm, sizeof(nm), "%s(%s)", op == OP_IS_ODD ? "IS_ODD" : "IS_EVEN", a[0]->name);
+      bnode* b = bnode_new(B_OP, op, T_BOOL, a[0]->nullable, nm); b->args[0] = a[0]; b->nargs = 1;
+      return fold(b, err);
+    }
     case OP_IS_NULL: {
       /* non-nullable argument binds to ConstBool(false): elementary_bound_expressions.cc:1419-1424 */
       if (!a[0]->nullable) return make_const(T_BOOL, 0);
@@ -580,6 +625,72 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
       b->nulls = x->nulls; return;
     }
     case OP_IS_NULL: { uint8_t* D = (uint8_t*)b->buf; for (int64_t i = 0; i < n; ++i) D[i] = x->nulls ? x->nulls[i] : 0; return; }
+    /* ---- exact math family: the functors of expression/core/math_evaluators.h:82-146,206-220 ---- */
+    case OP_ABS: {
+      const void* A = x->data; void* D = b->buf;
+      switch (x->dtype) {
+        case T_INT32: LOOP1(int32_t, uint32_t, (a < 0) ? 0u - (uint32_t)a : (uint32_t)a) break;
+        case T_INT64: LOOP1(int64_t, uint64_t, (a < 0) ? 0ull - (uint64_t)a : (uint64_t)a) break;
+        case T_FLOAT: LOOP1(float, float, (a < 0) ? -a : a) break;
+        default: LOOP1(double, double, (a < 0) ? -a : a) break;
+      }
+      b->nulls = x->nulls; return;
+    }
+    case OP_ROUND: case OP_CEIL: case OP_FLOOR: case OP_TRUNC: {
+      const void* A = x->data; void* D = b->buf; const int o = b->op;
+      if (x->dtype == T_FLOAT) {
+        if (o == OP_ROUND) LOOP1(float, float, roundf(a))
+        else if (o == OP_CEIL) LOOP1(float, float, (float)ceil((double)a))
+        else if (o == OP_FLOOR) LOOP1(float, float, (float)floor((double)a))
+        else LOOP1(float, float, (float)trunc((double)a))
+      } else {
+        if (o == OP_ROUND) LOOP1(double, double, round(a))
+        else if (o == OP_CEIL) LOOP1(double, double, ceil(a))
+        else if (o == OP_FLOOR) LOOP1(double, double, floor(a))
+        else LOOP1(double, double, trunc(a))
+      }
+      b->nulls = x->nulls; return;
+    }
+    case OP_CEIL_TO_INT: case OP_FLOOR_TO_INT: {
+      const void* A = x->data; void* D = b->buf; const int up = b->op == OP_CEIL_TO_INT;
+      if (x->dtype == T_FLOAT) { if (up) LOOP1(float, int64_t, (int64_t)ceil((double)a)) else LOOP1(float, int64_t, (int64_t)floor((double)a)) }
+      else { if (up) LOOP1(double, int64_t, (int64_t)ceil(a)) else LOOP1(double, int64_t, (int64_t)floor(a)) }
+      b->nulls = x->nulls; return;
+    }
+    case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING: {
+      const double* A = (const double*)x->data; double* D = (double*)b->buf;
+      for (int64_t i = 0; i < n; ++i) D[i] = sqrt(A[i]);
+      b->nulls = x->nulls;
+      if (b->op != OP_SQRT_QUIET)   /* IsNegativeNuller / IsNegativeFailer, expression_traits.h:922-947 */
+        for (int64_t i = 0; i < n; ++i) {
+          if (!(A[i] < 0)) continue;
+          const int already_null = x->nulls ? x->nulls[i] : 0;
+          if (b->op == OP_SQRT_NULLING) {
+            if (b->nulls != b->nullbuf) { if (x->nulls) memcpy(b->nullbuf, x->nulls, (size_t)n); else memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; }
+            b->nullbuf[i] = 1;
+          } else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative argument in %s%s", b->name, ""); return; }
+        }
+      return;
+    }
+    case OP_IS_FINITE: case OP_IS_INF: case OP_IS_NAN: case OP_IS_NORMAL: {
+      const double* A = (const double*)x->data; uint8_t* D = (uint8_t*)b->buf;
+      for (int64_t i = 0; i < n; ++i)
+        D[i] = (uint8_t)(b->op == OP_IS_FINITE ? isfinite(A[i]) != 0 : b->op == OP_IS_INF ? isinf(A[i]) != 0 : b->op == OP_IS_NAN ? isnan(A[i]) != 0 : isnormal(A[i]) != 0);
+      b->nulls = x->nulls; return;
+    }
+    case OP_IS_ODD: case OP_IS_EVEN: {
+      /* operators::IsOdd: arg % 2 (operators.h:101-120) */
+      uint8_t* D = (uint8_t*)b->buf; const int w = type_width(x->dtype);
+      for (int64_t i = 0; i < n; ++i) {
+        int odd;
+        if (x->dtype == T_INT32) odd = (((const int32_t*)x->data)[i] % 2) != 0;
+        else if (x->dtype == T_UINT32) odd = (((const uint32_t*)x->data)[i] % 2) != 0;
+        else if (x->dtype == T_INT64) odd = (((const int64_t*)x->data)[i] % 2) != 0;
+        else odd = (((const uint64_t*)x->data)[i] % 2) != 0;
+        D[i] = (uint8_t)(b->op == OP_IS_ODD ? odd : !odd);
+      }
+      (void)w; b->nulls = x->nulls; return;
+    }
     case OP_CASE: {
       /* BoundCaseExpression::DoEvaluate (elementary_bound_expressions.cc:595-760): the first WHEN
        * that is non-NULL and equal to a non-NULL CASE value selects its THEN; otherwise (no match,

@@ -277,6 +277,26 @@ def Less(a, b): return _op(116, a, b)
 def LessOrEqual(a, b): return _op(120, a, b)
 def Greater(a, b): return _op(L.OP_GREATER, a, b)
 def GreaterOrEqual(a, b): return _op(L.OP_GREATER_OR_EQUAL, a, b)
+# exact math family (expression/core/math_expressions.h:78-126, comparison_expressions.h IsOdd/IsEven)
+def Abs(a): return _op(360, a)
+def Round(a): return _op(300, a)
+def Ceil(a): return _op(342, a)
+def Floor(a): return _op(346, a)
+def Trunc(a): return _op(304, a)
+def RoundToInt(a): return _op(316, a)
+def CeilToInt(a): return _op(308, a)
+def FloorToInt(a): return _op(312, a)
+def SqrtQuiet(a): return _op(333, a)
+def SqrtNulling(a): return _op(334, a)
+def SqrtSignaling(a): return _op(335, a)
+def IsFinite(a): return _op(148, a)
+def IsInf(a): return _op(152, a)
+def IsNaN(a): return _op(156, a)
+def IsNormal(a): return _op(160, a)
+def IsOdd(a): return _op(140, a)
+def IsEven(a): return _op(144, a)
+
+
 class ExpressionList(object):
     """expression/base/expression.h: owning list of expressions (Case / In arguments)."""
 

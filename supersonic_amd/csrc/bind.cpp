@@ -22,6 +22,9 @@ enum {
   OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_BITWISE_AND = 60, OP_BITWISE_OR = 64,
   OP_BITWISE_NOT = 68, OP_BITWISE_XOR = 72, OP_SHIFT_LEFT = 76, OP_SHIFT_RIGHT = 80,
   OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116, OP_LESS_OR_EQUAL = 120,
+  OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
+  OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
+  OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
   OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST_QUIET = 265
 };
 
@@ -347,6 +350,36 @@ static bool try_fold(const BExprP& e, BExprP* out) {
   if (e->args.size() == 1) {
     const BExprP& x = e->args[0];
     if (e->op == OP_NOT) { *out = make_const(SSGPU_BOOL, !x->bits); return true; }
+    {  // exact math family on a constant (same libm calls as math_evaluators.h:82-146,206-220)
+      const bool f32 = x->dtype == SSGPU_FLOAT;
+      const double d = x->dtype == SSGPU_DOUBLE ? from_bits<double>(x->bits) : f32 ? (double)from_bits<float>(x->bits) : 0.0;
+      auto flt = [&](double r) { return f32 ? to_bits((float)r) : to_bits(r); };
+      switch (e->op) {
+        case OP_ROUND: *out = make_const(e->dtype, f32 ? to_bits(roundf((float)d)) : to_bits(round(d))); return true;
+        case OP_CEIL: *out = make_const(e->dtype, flt(ceil(d))); return true;
+        case OP_FLOOR: *out = make_const(e->dtype, flt(floor(d))); return true;
+        case OP_TRUNC: *out = make_const(e->dtype, flt(trunc(d))); return true;
+        case OP_CEIL_TO_INT: *out = make_const(e->dtype, (uint64_t)(int64_t)ceil(d)); return true;
+        case OP_FLOOR_TO_INT: *out = make_const(e->dtype, (uint64_t)(int64_t)floor(d)); return true;
+        case OP_IS_FINITE: *out = make_const(SSGPU_BOOL, std::isfinite(d)); return true;
+        case OP_IS_NAN: *out = make_const(SSGPU_BOOL, std::isnan(d)); return true;
+        case OP_IS_INF: *out = make_const(SSGPU_BOOL, std::isinf(d)); return true;
+        case OP_IS_NORMAL: *out = make_const(SSGPU_BOOL, std::isnormal(d)); return true;
+        case OP_SQRT_QUIET: *out = make_const(e->dtype, to_bits(sqrt(d))); return true;
+        case OP_SQRT_NULLING: *out = d < 0 ? make_null(e->dtype) : make_const(e->dtype, to_bits(sqrt(d))); return true;
+        case OP_IS_ODD: case OP_IS_EVEN: {
+          const int64_t v = dtype_width(x->dtype) == 4 ? (x->dtype == SSGPU_UINT32 ? (int64_t)(uint32_t)x->bits : (int64_t)(int32_t)(uint32_t)x->bits) : (int64_t)x->bits;
+          const bool odd = x->dtype == SSGPU_UINT64 ? (x->bits & 1) : (v % 2) != 0;
+          *out = make_const(SSGPU_BOOL, e->op == OP_IS_ODD ? odd : !odd); return true;
+        }
+        case OP_ABS:
+          if (x->dtype == SSGPU_DOUBLE || f32) { *out = make_const(e->dtype, flt(d < 0 ? -d : d)); return true; }
+          if (x->dtype == SSGPU_INT32) { const int32_t v = (int32_t)(uint32_t)x->bits; *out = make_const(e->dtype, v < 0 ? (uint32_t)(0u - (uint32_t)v) : (uint32_t)v); return true; }
+          if (x->dtype == SSGPU_INT64) { const int64_t v = (int64_t)x->bits; *out = make_const(e->dtype, v < 0 ? 0ull - (uint64_t)v : (uint64_t)v); return true; }
+          break;
+        default: break;
+      }
+    }
     if (e->op == OP_NEGATE) {
       uint64_t b;
       if (x->dtype == SSGPU_DOUBLE) b = to_bits(-from_bits<double>(x->bits));
@@ -497,6 +530,59 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
       SS_RETURN_IF_ERROR(make_cast(args[1], t, true, &rc));
       if (!lc->nullable) { *out = lc; return Status::OK(); }
       *out = make_op(op, t, rc->nullable, fmt_binary(op, lc->name, rc->name), {lc, rc}, depth);
+      return Status::OK();
+    }
+    // ---- exact math family: math_bound_expressions.cc:150-170,318-456,473-486 (names "OP(child)") ----
+    case OP_ABS: {
+      SS_RETURN_IF_ERROR(need(1));
+      const int t = args[0]->dtype;
+      if (t == SSGPU_UINT32 || t == SSGPU_UINT64) { *out = args[0]; return Status::OK(); }
+      int ot = t == SSGPU_INT32 ? SSGPU_UINT32 : t == SSGPU_INT64 ? SSGPU_UINT64 : (t == SSGPU_FLOAT || t == SSGPU_DOUBLE) ? t : -1;
+      if (ot < 0) return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("ABS is not defined for ") + dtype_name(t));
+      *out = fold(make_op(op, ot, args[0]->nullable, "ABS(" + args[0]->name + ")", {args[0]}, depth));
+      return Status::OK();
+    }
+    case OP_ROUND: case OP_CEIL: case OP_FLOOR: case OP_TRUNC: case OP_CEIL_TO_INT: case OP_FLOOR_TO_INT: case OP_ROUND_TO_INT: {
+      SS_RETURN_IF_ERROR(need(1));
+      const int t = args[0]->dtype;
+      if (dtype_is_integer(t)) { *out = args[0]; return Status::OK(); }   // integers are already rounded
+      if (t != SSGPU_FLOAT && t != SSGPU_DOUBLE)
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("rounding is not defined for ") + dtype_name(t));
+      auto unary = [&](int o, const char* nm, int ot, BExprP child) {
+        return fold(make_op(o, ot, child->nullable, std::string(nm) + "(" + child->name + ")", {child}, depth));
+      };
+      switch (op) {
+        case OP_ROUND: *out = unary(op, "ROUND", t, args[0]); break;
+        case OP_CEIL: *out = unary(op, "CEIL", t, args[0]); break;
+        case OP_FLOOR: *out = unary(op, "FLOOR", t, args[0]); break;
+        case OP_TRUNC: *out = unary(op, "TRUNC", t, args[0]); break;
+        case OP_CEIL_TO_INT: *out = unary(op, "CEIL_TO_INT", SSGPU_INT64, args[0]); break;
+        case OP_FLOOR_TO_INT: *out = unary(op, "FLOOR_TO_INT", SSGPU_INT64, args[0]); break;
+        default:  // RoundToInt binds as CEIL_TO_INT(ROUND(x)) (math_bound_expressions.cc:327-339)
+          *out = unary(OP_CEIL_TO_INT, "CEIL_TO_INT", SSGPU_INT64, unary(OP_ROUND, "ROUND", t, args[0])); break;
+      }
+      return Status::OK();
+    }
+    case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING:
+    case OP_IS_FINITE: case OP_IS_INF: case OP_IS_NAN: case OP_IS_NORMAL: {
+      SS_RETURN_IF_ERROR(need(1));
+      if (!dtype_is_numeric(args[0]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("Cannot cast ") + dtype_name(args[0]->dtype) + " to DOUBLE");
+      BExprP c;
+      SS_RETURN_IF_ERROR(make_cast(args[0], SSGPU_DOUBLE, true, &c));   // promoting unary expressions
+      const bool is_sqrt = op == OP_SQRT_QUIET || op == OP_SQRT_NULLING || op == OP_SQRT_SIGNALING;
+      const char* nm = is_sqrt ? "SQRT" : op == OP_IS_FINITE ? "IS_FINITE" : op == OP_IS_INF ? "IS_INF" : op == OP_IS_NAN ? "IS_NAN" : "IS_NORMAL";
+      BExprP e = make_op(op, is_sqrt ? SSGPU_DOUBLE : SSGPU_BOOL, c->nullable || op == OP_SQRT_NULLING, std::string(nm) + "(" + c->name + ")", {c}, depth);
+      // a constant negative SQRT_SIGNALING must still fail at evaluation time: never folded
+      *out = op == OP_SQRT_SIGNALING ? e : fold(e);
+      if (op == OP_SQRT_NULLING && (*out)->kind == BExpr::OP) (*out)->nullable = true;
+      return Status::OK();
+    }
+    case OP_IS_ODD: case OP_IS_EVEN: {
+      SS_RETURN_IF_ERROR(need(1));
+      if (!dtype_is_integer(args[0]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string(op == OP_IS_ODD ? "IS_ODD" : "IS_EVEN") + " needs an integer argument");
+      *out = fold(make_op(op, SSGPU_BOOL, args[0]->nullable, std::string(op == OP_IS_ODD ? "IS_ODD(" : "IS_EVEN(") + args[0]->name + ")", {args[0]}, depth));
       return Status::OK();
     }
     case OP_CASE: {

@@ -23,7 +23,10 @@ namespace ssgpu {
 enum {
   OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DIVIDE_NULLING = 14,
   OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
-  OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36, OP_AND = 40, OP_OR = 44,
+  OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36,
+  OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
+  OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334,
+  OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360, OP_AND = 40, OP_OR = 44,
   OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_BITWISE_AND = 60, OP_BITWISE_OR = 64,
   OP_BITWISE_NOT = 68, OP_BITWISE_XOR = 72, OP_SHIFT_LEFT = 76, OP_SHIFT_RIGHT = 80,
   OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116, OP_LESS_OR_EQUAL = 120,
@@ -232,6 +235,39 @@ Status Emitter::value(const BExprP& e, Val* out) {
             if (a[1].imm) { i.b_imm = true; i.imm = a[1].bits; i.imm_width = (uint8_t)a[1].width; } else i.b = a[1].reg;
           }
           v.reg = binop(op, a[0], a[1], v.width);
+          v.null = base_null;
+        } break;
+        // exact math family (math_bound_expressions.cc:150-170,318-456,473-486)
+        case OP_ABS: v.reg = unop(pick(at, VM_ABS_I32, VM_NOP, VM_ABS_I64, VM_NOP, VM_ABS_F32, VM_ABS_F64), a[0], v.width); v.null = a[0].null; break;
+        case OP_ROUND: v.reg = unop(at == M_F32 ? VM_ROUND_F32 : VM_ROUND_F64, a[0], v.width); v.null = a[0].null; break;
+        case OP_CEIL: v.reg = unop(at == M_F32 ? VM_CEIL_F32 : VM_CEIL_F64, a[0], v.width); v.null = a[0].null; break;
+        case OP_FLOOR: v.reg = unop(at == M_F32 ? VM_FLOOR_F32 : VM_FLOOR_F64, a[0], v.width); v.null = a[0].null; break;
+        case OP_TRUNC: v.reg = unop(at == M_F32 ? VM_TRUNC_F32 : VM_TRUNC_F64, a[0], v.width); v.null = a[0].null; break;
+        case OP_CEIL_TO_INT: v.reg = unop(at == M_F32 ? VM_CEIL2I_F32 : VM_CEIL2I_F64, a[0], v.width); v.null = a[0].null; break;
+        case OP_FLOOR_TO_INT: v.reg = unop(at == M_F32 ? VM_FLOOR2I_F32 : VM_FLOOR2I_F64, a[0], v.width); v.null = a[0].null; break;
+        case OP_IS_FINITE: v.reg = unop(VM_ISFINITE_F64, a[0], 1); v.null = a[0].null; break;
+        case OP_IS_NAN: v.reg = unop(VM_ISNAN_F64, a[0], 1); v.null = a[0].null; break;
+        case OP_IS_INF: v.reg = unop(VM_ISINF_F64, a[0], 1); v.null = a[0].null; break;
+        case OP_IS_NORMAL: v.reg = unop(VM_ISNORMAL_F64, a[0], 1); v.null = a[0].null; break;
+        case OP_IS_ODD: case OP_IS_EVEN: {
+          Val odd; odd.width = 1; odd.reg = unop(mwidth(at) == 4 ? VM_ISODD_32 : VM_ISODD_64, a[0], 1);
+          v.reg = e->op == OP_IS_ODD ? odd.reg : unop(VM_NOT_B8, odd, 1);
+          v.null = a[0].null;
+        } break;
+        case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING: {
+          int base_null = a[0].null;
+          if (e->op != OP_SQRT_QUIET) {
+            // IsNegativeNuller / IsNegativeFailer (expression_traits.h:922-947): x < 0
+            Val zero; zero.imm = true; zero.bits = 0; zero.width = 8;
+            Val neg; neg.width = 1; neg.reg = binop(VM_LT_F64, a[0], zero, 1);
+            if (e->op == OP_SQRT_NULLING) {
+              if (base_null >= 0) { int r = new_reg(1); LInstr& i = emit(VM_NULL_OR); i.dst = r; i.a = base_null; i.b = neg.reg; base_null = r; }
+              else base_null = neg.reg;
+            } else {
+              LInstr& i = emit(VM_FAIL_TRUE_8); i.dst_is_reg = false; i.dst = 0; i.a = base_null; i.b = neg.reg; i.c = sel;
+            }
+          }
+          v.reg = unop(VM_SQRT_F64, a[0], v.width);
           v.null = base_null;
         } break;
         case OP_NEGATE: v.reg = unop(pick(mt, VM_NEG_I32, VM_NEG_I32, VM_NEG_I64, VM_NEG_I64, VM_NEG_F32, VM_NEG_F64), a[0], v.width); v.null = a[0].null; break;

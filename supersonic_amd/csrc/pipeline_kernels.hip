@@ -569,6 +569,43 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
         UNOP(NEG_I64, u64, u64, 0ull - a)
         UNOP(NEG_F32, float, float, -a)
         UNOP(NEG_F64, double, double, -a)
+        // ---- exact math: every one of these is a correctly rounded / exact IEEE operation, so the
+        // device result is bit-identical to the reference's libm call (math_evaluators.h:82-146)
+        UNOP(ABS_I32, i32, u32, (a < 0 ? 0u - (u32)a : (u32)a))
+        UNOP(ABS_I64, i64, u64, (a < 0 ? 0ull - (u64)a : (u64)a))
+        UNOP(ABS_F32, float, float, (a < 0 ? -a : a))
+        UNOP(ABS_F64, double, double, (a < 0 ? -a : a))
+        UNOP(ROUND_F32, float, float, roundf(a))
+        UNOP(ROUND_F64, double, double, round(a))
+        UNOP(CEIL_F32, float, float, ceilf(a))
+        UNOP(CEIL_F64, double, double, ceil(a))
+        UNOP(FLOOR_F32, float, float, floorf(a))
+        UNOP(FLOOR_F64, double, double, floor(a))
+        UNOP(TRUNC_F32, float, float, truncf(a))
+        UNOP(TRUNC_F64, double, double, trunc(a))
+        // static_cast<int64>(double) is undefined out of range; the reference runs on x86-64, whose
+        // cvttsd2si returns the "integer indefinite" value INT64_MIN for NaN and out-of-range inputs
+#define CVT_I64_X86(v) ({ const double v_ = (v); (v_ >= -9223372036854775808.0 && v_ < 9223372036854775808.0) ? (i64)v_ : (i64)0x8000000000000000ull; })
+        UNOP(CEIL2I_F32, float, i64, CVT_I64_X86(ceilf(a)))
+        UNOP(CEIL2I_F64, double, i64, CVT_I64_X86(ceil(a)))
+        UNOP(FLOOR2I_F32, float, i64, CVT_I64_X86(floorf(a)))
+        UNOP(FLOOR2I_F64, double, i64, CVT_I64_X86(floor(a)))
+        UNOP(SQRT_F64, double, double, __builtin_sqrt(a))
+        UNOP(ISFINITE_F64, double, u8, (__builtin_isfinite(a) ? 1 : 0))
+        UNOP(ISNAN_F64, double, u8, (a != a ? 1 : 0))
+        UNOP(ISINF_F64, double, u8, (__builtin_isinf(a) ? 1 : 0))
+        UNOP(ISNORMAL_F64, double, u8, (__builtin_isnormal(a) ? 1 : 0))
+        UNOP(ISODD_32, i32, u8, ((a % 2) != 0 ? 1 : 0))
+        UNOP(ISODD_64, i64, u8, ((a % 2) != 0 ? 1 : 0))
+        case VM_FAIL_TRUE_8: { CASE_FENCE;   // signaling math: flagged rows that are selected and not NULL
+          bool bad = false;
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair_(p, tile_valid, I.a, I.c);
+            auto vb = lds_load2<u8>(I.b, p);
+            bad = bad || (m.x && vb.x) || (m.y && vb.y);
+          }
+          if (bad) atomicExch(P.error_flag, 2u);
+        } break;
         // ---- bitwise --------------------------------------------------------
         BINOP(BAND_32, u32, u32, u32, a & b)
         BINOP(BAND_64, u64, u64, u64, a & b)

@@ -972,7 +972,11 @@ int check_error_flags(ssgpu_plan* p) {
     if (!ex.error_flag.p) continue;
     uint32_t f = 0;
     HIP_TRY(c, hipMemcpy(&f, ex.error_flag.p, 4, hipMemcpyDeviceToHost));
-    if (f) { c->err = "Evaluation error: division by zero in a signaling expression"; return SSGPU_ERROR_EVALUATION_ERROR; }
+    if (f) {
+      c->err = f == 2 ? "Evaluation error: invalid argument of a signaling math expression (negative input of SQRT)"
+                      : "Evaluation error: division by zero in a signaling expression";
+      return SSGPU_ERROR_EVALUATION_ERROR;
+    }
   }
   return SSGPU_OK;
 }

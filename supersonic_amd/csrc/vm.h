@@ -44,6 +44,15 @@
   X(CDIV_I32) X(CDIV_I64) X(CDIV_U32) X(CDIV_U64)                              \
   X(MOD_I32) X(MOD_I64) X(MOD_U32) X(MOD_U64)                                  \
   X(NEG_I32) X(NEG_I64) X(NEG_F32) X(NEG_F64)                                  \
+  /* ---- exact math (expression/core/math_evaluators.h:82-146,206-220) ----- */\
+  X(ABS_I32) X(ABS_I64) X(ABS_F32) X(ABS_F64)                                  \
+  X(ROUND_F32) X(ROUND_F64) X(CEIL_F32) X(CEIL_F64) X(FLOOR_F32) X(FLOOR_F64)  \
+  X(TRUNC_F32) X(TRUNC_F64)                                                    \
+  X(CEIL2I_F32) X(CEIL2I_F64) X(FLOOR2I_F32) X(FLOOR2I_F64) /* -> I64 */       \
+  X(SQRT_F64)                                                                  \
+  X(ISFINITE_F64) X(ISNAN_F64) X(ISINF_F64) X(ISNORMAL_F64) /* -> B8 */        \
+  X(ISODD_32) X(ISODD_64) /* -> B8; IS_EVEN = NOT */                           \
+  X(FAIL_TRUE_8) /* a = null mask, b = BOOL flags, c = selection: evaluation error where set */ \
   /* ---- bitwise ---------------------------------------------------------- */\
   X(BAND_32) X(BAND_64) X(BOR_32) X(BOR_64) X(BXOR_32) X(BXOR_64)              \
   X(BANDNOT_32) X(BANDNOT_64) X(BNOT_32) X(BNOT_64)                            \

@@ -341,6 +341,53 @@ expr_plan_case("Case_IfCaseAllNullable", C + ":178-195", [BOOL, I64, I64], IFCAS
                 [False, 75, None, None], [True, None, None, None], [False, None, None, None], [None, 77, 78, 78], [None, None, 80, 80],
                 [None, 82, None, None], [None, None, None, None], [False, 87, 89, 89]])
 
+# ---- exact math family (math_expressions_test.cc) -------------------------------------------------
+M = "supersonic/expression/core/math_expressions_test.cc"
+bind_case("Math_Ceil_double", M + ":34", "Ceil", [F64], [False], "CEIL($0)", F64, False)
+bind_case("Math_Ceil_uint32", M + ":35", "Ceil", [U32], [False], "$0", U32, False)
+bind_case("Math_CeilToInt_double", M + ":36", "CeilToInt", [F64], [False], "CEIL_TO_INT($0)", I64, False)
+bind_case("Math_CeilToInt_uint64", M + ":37", "CeilToInt", [U64], [False], "$0", U64, False)
+bind_case("Math_Floor_float", M + ":40", "Floor", [F32], [False], "FLOOR($0)", F32, False)
+bind_case("Math_FloorToInt_float", M + ":41", "FloorToInt", [F32], [False], "FLOOR_TO_INT($0)", I64, False)
+bind_case("Math_Round_float", M + ":50", "Round", [F32], [False], "ROUND($0)", F32, False)
+bind_case("Math_Round_int32", M + ":51", "Round", [I32], [False], "$0", I32, False)
+bind_case("Math_RoundToInt_double", M + ":53", "RoundToInt", [F64], [False], "CEIL_TO_INT(ROUND($0))", I64, False)
+bind_case("Math_SqrtQuiet", M + ":55", "SqrtQuiet", [F64], [False], "SQRT($0)", F64, False)
+bind_case("Math_SqrtNulling", M + ":56", "SqrtNulling", [F64], [False], "SQRT($0)", F64, True)
+bind_case("Math_SqrtSignaling", M + ":57", "SqrtSignaling", [F64], [False], "SQRT($0)", F64, False)
+bind_case("Math_Trunc", M + ":58", "Trunc", [F64], [False], "TRUNC($0)", F64, False)
+bind_case("Math_Abs_int32", M + ":137", "Abs", [I32], [False], "ABS($0)", U32, False)
+bind_case("Math_Abs_uint32", M + ":138", "Abs", [U32], [False], "$0", U32, False)
+bind_case("Math_Abs_int64", M + ":139", "Abs", [I64], [False], "ABS($0)", U64, False)
+bind_case("Math_Abs_float", M + ":141", "Abs", [F32], [False], "ABS($0)", F32, False)
+expr_case("Math_Round", M + ":147-156", [F64, F64], [[4., 4.], [0.5, 1.], [-0.5, -1.], [0.49, 0.], [-0.49, -0.], [2345., 2345.]], "Round")
+expr_case("Math_RoundFloat", M + ":158-167", [F32, F32], [[4., 4.], [0.5, 1.], [-0.5, -1.], [0.49, 0.], [-0.49, -0.], [2345., 2345.]], "Round")
+expr_case("Math_RoundToIntOnDouble", M + ":169-180", [F64, I64],
+          [[4., 4], [0.5, 1], [-0.5, -1], [0.49, 0], [None, None], [-0.49, 0], [2345., 2345], [-3.65309740835E17, -365309740835000000]], "RoundToInt")
+expr_case("Math_RoundToIntOnFloat", M + ":182-193", [F32, I64],
+          [[4., 4], [0.5, 1], [-0.5, -1], [0.49, 0], [None, None], [-0.49, 0], [2345., 2345], [-3.65309E5, -365309]], "RoundToInt")
+expr_case("Math_Ceil", M + ":211-219", [F64, F64], [[3., 3.], [-3., -3.], [-2.9, -2.], [1.9, 2.], [-2.1, -2.], [1.001, 2.]], "Ceil")
+expr_case("Math_Ceil_float", M + ":221-224", [F32, F32], [[0.1, 1.], [-0.9, -0.]], "Ceil")
+expr_case("Math_Ceil_int32", M + ":226-229", [I32, I32], [[7, 7], [-1, -1]], "Ceil")
+expr_case("Math_CeilToInt", M + ":232-240", [F64, I64], [[3., 3], [-3., -3], [-2.9, -2], [1.9, 2], [-2.1, -2], [1.001, 2]], "CeilToInt")
+expr_case("Math_CeilToInt_float", M + ":242-245", [F32, I64], [[0.1, 1], [-0.9, 0]], "CeilToInt")
+expr_case("Math_Floor", M + ":253-261", [F64, F64], [[3., 3.], [-3., -3.], [-2.9, -3.], [1.9, 1.], [-2.1, -3.], [1.001, 1.]], "Floor")
+expr_case("Math_Floor_float", M + ":263-266", [F32, F32], [[0.1, 0.], [-0.9, -1.]], "Floor")
+expr_case("Math_FloorToInt", M + ":274-282", [F64, I64], [[3., 3], [-3., -3], [-2.9, -3], [1.9, 1], [-2.1, -3], [1.001, 1]], "FloorToInt")
+expr_case("Math_FloorToInt_float", M + ":284-287", [F32, I64], [[0.1, 0], [-0.9, -1]], "FloorToInt")
+expr_case("Math_Trunc", M + ":295-303", [F64, F64], [[3., 3.], [-3., -3.], [-2.9, -2.], [1.9, 1.], [-2.1, -2.], [1.001, 1.]], "Trunc")
+expr_case("Math_Trunc_float", M + ":305-308", [F32, F32], [[0.1, 0.], [None, None]], "Trunc")
+expr_case("Math_Trunc_uint32", M + ":310-313", [U32, U32], [[7, 7], [0, 0]], "Trunc")
+expr_case("Math_Abs", M + ":316-324", [I32, U32], [[0, 0], [1, 1], [-3, 3], [-2147483648, 2147483648]], "Abs")
+expr_case("Math_SqrtNulling", M + ":326-334", [F64, F64], [[0.25, 0.5], [1., 1.], [40000., 200.], [0., 0.], [-1, None]], "SqrtNulling")
+expr_case("Math_SqrtSignaling", M + ":336-343", [F64, F64], [[0.25, 0.5], [1., 1.], [None, None], [0., 0.]], "SqrtSignaling")
+expr_case("Math_SqrtSignaling_failure", M + ":344-348", [F64, F64], [[-1., None], [-123321., None]], "SqrtSignaling", expect_error=104)
+expr_case("Math_SqrtQuiet", M + ":350-360", [F64, F64], [[0.25, 0.5], [1., 1.], [-123., NAN], [40000., 200.], [0., 0.], [-1, NAN]], "SqrtQuiet")
+expr_case("Math_IsFinite", M + ":712-722", [F32, BOOL], [[0., True], [1234., True], [INF, False], [NAN, False], [None, None]], "IsFinite")
+expr_case("Math_IsInf", M + ":724-734", [F64, BOOL], [[0., False], [1234., False], [INF, True], [NAN, False], [None, None]], "IsInf")
+expr_case("Math_IsNaN", M + ":736-746", [F32, BOOL], [[0., False], [1234., False], [INF, False], [NAN, True], [None, None]], "IsNaN")
+expr_case("Math_IsNormal", M + ":748-758", [F64, BOOL], [[0., False], [1234., True], [INF, False], [NAN, False], [None, None]], "IsNormal")
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
     with open(out, "w") as f:

@@ -250,6 +250,49 @@ def test_case_and_in_expressions(gpu_ctx, n, nullable):
     run_both(ss.ScalarAggregate(spec, ss.Compute(e, ss.Filter(in1, ss.ProjectAllAttributes(), ss.ScanView(view)))), gpu_ctx)
 
 
+@pytest.mark.parametrize("n", [0, 3, 1025, 40013])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_exact_math_family(gpu_ctx, n, nullable):
+    # ABS / ROUND / CEIL / FLOOR / TRUNC / *_TO_INT / SQRT / IS_* : every one is an exact or
+    # correctly rounded IEEE operation, so the device must match libm bit for bit
+    rng = np.random.default_rng(3)
+    N = ss.NULLABLE if nullable else ss.NOT_NULLABLE
+    schema = ss.TupleSchema([ss.Attribute("x", ss.DOUBLE, N), ss.Attribute("f", ss.FLOAT, N), ss.Attribute("i", ss.INT32, N),
+                             ss.Attribute("l", ss.INT64), ss.Attribute("u", ss.UINT64), ss.Attribute("p", ss.DOUBLE)])
+    x = rng.standard_normal(n) * np.exp(rng.integers(-20, 20, n))
+    special = np.array([0.0, -0.0, 0.5, -0.5, 1.5, 2.5, -2.5, np.inf, -np.inf, np.nan, 4.9e-324, 1e308, -1e-310])
+    x[: min(n, len(special))] = special[: min(n, len(special))]
+
+    def nl():
+        return (rng.random(n) < 0.15) if nullable else None
+    view = ss.View(schema, [ss.Column(x, nl()), ss.Column((rng.standard_normal(n) * 1000).astype(np.float32), nl()),
+                            ss.Column(rng.integers(-2**31, 2**31, n).astype(np.int32), nl()), rng.integers(-2**63, 2**63 - 1, n),
+                            rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2) + np.uint64(1), np.where(np.isfinite(x), np.abs(x), np.nan)])
+    small = ss.Multiply(NA("p"), ss.ConstDouble(1e-280))    # keeps *_TO_INT inside the int64 range
+    e = (ss.CompoundExpression()
+         .AddAs("abs_x", ss.Abs(NA("x"))).AddAs("abs_f", ss.Abs(NA("f"))).AddAs("abs_i", ss.Abs(NA("i"))).AddAs("abs_l", ss.Abs(NA("l"))).AddAs("abs_u", ss.Abs(NA("u")))
+         .AddAs("round_x", ss.Round(NA("x"))).AddAs("round_f", ss.Round(NA("f"))).AddAs("ceil_x", ss.Ceil(NA("x"))).AddAs("ceil_f", ss.Ceil(NA("f")))
+         .AddAs("floor_x", ss.Floor(NA("x"))).AddAs("floor_f", ss.Floor(NA("f"))).AddAs("trunc_x", ss.Trunc(NA("x"))).AddAs("trunc_f", ss.Trunc(NA("f")))
+         .AddAs("ceil_i", ss.Ceil(NA("i"))))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
+    e = (ss.CompoundExpression()     # (the oracle's expression lists hold 16 entries)
+         .AddAs("c2i", ss.CeilToInt(small)).AddAs("f2i", ss.FloorToInt(small)).AddAs("r2i", ss.RoundToInt(small)).AddAs("f2i_f", ss.FloorToInt(NA("f")))
+         .AddAs("sqrt_q", ss.SqrtQuiet(NA("x"))).AddAs("sqrt_n", ss.SqrtNulling(NA("x"))).AddAs("sqrt_p", ss.SqrtSignaling(NA("p"))).AddAs("sqrt_i", ss.SqrtNulling(NA("i")))
+         .AddAs("fin", ss.IsFinite(NA("x"))).AddAs("inf", ss.IsInf(NA("x"))).AddAs("nan", ss.IsNaN(NA("x"))).AddAs("nrm", ss.IsNormal(NA("x"))).AddAs("fin_f", ss.IsFinite(NA("f")))
+         .AddAs("odd_i", ss.IsOdd(NA("i"))).AddAs("even_l", ss.IsEven(NA("l"))).AddAs("odd_u", ss.IsOdd(NA("u"))))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
+
+
+def test_sqrt_signaling_fails_on_selected_negative_rows(gpu_ctx):
+    view = make_view(5000)
+    op = ss.Compute(ss.SqrtSignaling(NA("d0")), ss.ScanView(view))      # d0 has negative values
+    r = op.CreateCursor(gpu_ctx).Next(1024)
+    assert r.is_failure() and r.exception().return_code == 104
+    op = ss.Compute(ss.SqrtSignaling(NA("d0")),
+                    ss.Filter(ss.GreaterOrEqual(NA("d0"), ss.ConstDouble(0.0)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    run_both(op, gpu_ctx)
+
+
 def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     n = 5000
     view = make_view(n)
