@@ -250,6 +250,19 @@ int64_t ssgpu_block_row_count(const ssgpu_block* b);
 /* Device pointers of column `col` (valid while the block lives). */
 int ssgpu_block_column(const ssgpu_block* b, int32_t col, ssgpu_column* out);
 
+/* ---- View file format (cursor/infrastructure/file_io.cc:176-193,377-440) ------
+ * The reference's only on-disk block format: a sequence of chunks (<= 8192 rows, :70), each
+ *   uint64 row_count, then per column  [row_count bytes of bool is_null, if the attribute is
+ *   NULLABLE]  [row_count * sizeof(type) bytes of data]   (fixed-width types; the schema is
+ * not stored).  ssgpu_block_create_from_file = FileInput(schema, file, ...) drained into a
+ * device Block: chunks are read into pinned staging buffers and copied on the copy stream
+ * while the next chunk is being read.  ssgpu_result_write_file = FileOutput(file)->Write(view)
+ * for a finished result (or any block via ssgpu_block_write_file). */
+int ssgpu_block_create_from_file(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs,
+                                 const char* path, ssgpu_block** out);
+int ssgpu_block_write_file(ssgpu_block* b, const char* path);
+int ssgpu_result_write_file(ssgpu_result* r, const char* path);
+
 /* ---- plan: bind + lower --------------------------------------------------- */
 int ssgpu_plan_create(ssgpu_ctx* ctx, const ssgpu_plan_desc* desc, ssgpu_plan** out);
 void ssgpu_plan_destroy(ssgpu_plan* plan);

@@ -17,6 +17,7 @@ SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6
 ASCENDING, DESCENDING = 0, 1
 
 OK = 0
+ERROR_UNKNOWN = 100
 ERROR_MEMORY_EXCEEDED = 102
 ERROR_NOT_IMPLEMENTED = 103
 ERROR_EVALUATION_ERROR = 104
@@ -110,6 +111,9 @@ SYMBOLS = [
     ("ssgpu_block_set_row_count", C.c_int, [P, C.c_int64]),
     ("ssgpu_block_row_count", C.c_int64, [P]),
     ("ssgpu_block_column", C.c_int, [P, C.c_int32, C.POINTER(Column)]),
+    ("ssgpu_block_create_from_file", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.c_char_p, C.POINTER(P)]),
+    ("ssgpu_block_write_file", C.c_int, [P, C.c_char_p]),
+    ("ssgpu_result_write_file", C.c_int, [P, C.c_char_p]),
     ("ssgpu_plan_create", C.c_int, [P, C.POINTER(PlanDesc), C.POINTER(P)]),
     ("ssgpu_plan_destroy", None, [P]),
     ("ssgpu_plan_attr_count", C.c_int32, [P]),

@@ -210,6 +210,108 @@ class DeviceView(object):
         return self._rows
 
 
+class BlockView(DeviceView):
+    """A DeviceView over an owned device Block (kept alive with the view)."""
+
+    def __init__(self, schema, ctx, block):
+        self._ctx, self._block = ctx, block
+        lib = ctx.lib
+        ptrs = []
+        for i in range(schema.attribute_count()):
+            col = L.Column()
+            ctx.check(lib.ssgpu_block_column(block, i, C.byref(col)))
+            ptrs.append((col.data or 0, col.is_null or 0))
+        DeviceView.__init__(self, schema, ptrs, lib.ssgpu_block_row_count(block))
+
+    def write_file(self, path):
+        self._ctx.check(self._ctx.lib.ssgpu_block_write_file(self._block, path.encode()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_block", None):
+                self._ctx.lib.ssgpu_block_destroy(self._block)
+                self._block = None
+        except Exception:
+            pass
+
+
+# ---- the reference's View file format (cursor/infrastructure/file_io.cc:176-193,377-440) ----------
+FILE_CHUNK_ROWS = 8192   # kMaxChunkRowCount, file_io.cc:70
+
+
+class FileOutput(object):
+    """Sink that appends host Views to a file: per chunk (<= 8192 rows) a uint64 row count, then
+    per column [row_count bool bytes of is_null if the attribute is NULLABLE][raw data]."""
+
+    def __init__(self, path):
+        self._f = open(path, "wb")
+
+    def Write(self, view):
+        schema = view.schema()
+        for off in range(0, view.row_count(), FILE_CHUNK_ROWS):
+            rc = min(FILE_CHUNK_ROWS, view.row_count() - off)
+            self._f.write(np.uint64(rc).tobytes())
+            for i in range(view.column_count()):
+                col = view.column(i)
+                if schema.attribute(i).is_nullable():
+                    nulls = col.is_null[off:off + rc] if col.is_null is not None else np.zeros(rc, np.bool_)
+                    self._f.write(np.ascontiguousarray(nulls, dtype=np.bool_).tobytes())
+                self._f.write(np.ascontiguousarray(col.data[off:off + rc]).tobytes())
+        return view.row_count()
+
+    def Finalize(self):
+        self._f.close()
+
+
+def read_view_file(schema, path):
+    """FileInput drained on the host (numpy): the whole file as one View."""
+    data = [[] for _ in range(schema.attribute_count())]
+    nulls = [[] for _ in range(schema.attribute_count())]
+    with open(path, "rb") as f:
+        while True:
+            head = f.read(8)
+            if not head:
+                break
+            if len(head) != 8:
+                raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+            rc = int(np.frombuffer(head, np.uint64)[0])
+            for i in range(schema.attribute_count()):
+                a = schema.attribute(i)
+                dt = np.dtype(_NP[a.type()])
+                if a.is_nullable():
+                    raw = f.read(rc)
+                    if len(raw) != rc:
+                        raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                    nulls[i].append(np.frombuffer(raw, np.bool_))
+                raw = f.read(rc * dt.itemsize)
+                if len(raw) != rc * dt.itemsize:
+                    raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                data[i].append(np.frombuffer(raw, dt))
+    cols = []
+    for i in range(schema.attribute_count()):
+        dt = np.dtype(_NP[schema.attribute(i).type()])
+        d = np.concatenate(data[i]) if data[i] else np.zeros(0, dt)
+        z = (np.concatenate(nulls[i]) if nulls[i] else np.zeros(0, np.bool_)) if schema.attribute(i).is_nullable() else None
+        cols.append(Column(d, z))
+    return View(schema, cols)
+
+
+def FileInput(schema, path, context=None):
+    """FileInput(schema, file) drained straight into a device Block: chunks go through pinned
+    staging buffers on the copy stream while the next chunk is read (ssgpu_block_create_from_file).
+    Returns a device-resident view usable with ScanView."""
+    ctx = context or Context.default()
+    attrs = (L.Attr * schema.attribute_count())()
+    keep = []
+    for i in range(schema.attribute_count()):
+        a = schema.attribute(i)
+        name = a.name().encode(); keep.append(name)
+        attrs[i] = L.Attr(name, a.type(), 1 if a.is_nullable() else 0)
+    block = C.c_void_p()
+    ctx.check(ctx.lib.ssgpu_block_create_from_file(ctx.handle, attrs, schema.attribute_count(), path.encode(), C.byref(block)))
+    return BlockView(schema, ctx, block)
+
+
 # ------------------------------------------------------------------------ expressions
 class Expression(object):
     def __init__(self, kind, op=0, dtype=0, args=(), i64=0, f64=0.0, name=None):
@@ -658,6 +760,10 @@ class Plan(object):
         self.ctx.check(self.lib.ssgpu_plan_finalize(self.handle, C.byref(res)))
         self._result = res
         return res
+
+    def write_file(self, path, res=None):
+        """FileOutput(path)->Write(result view): the finished result in the reference's file format."""
+        self.ctx.check(self.lib.ssgpu_result_write_file(res or self._result, path.encode()))
 
     def fetch(self, res=None):
         """Copy the result to host: a View over numpy arrays."""

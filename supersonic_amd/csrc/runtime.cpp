@@ -242,6 +242,94 @@ int ssgpu_block_create(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n, int64_
 }
 void ssgpu_block_destroy(ssgpu_block* b) { delete b; }
 
+// ---- View file format: cursor/infrastructure/file_io.cc ---------------------------------------
+static const int64_t kFileChunkRows = 8192;   // kMaxChunkRowCount, file_io.cc:70
+
+int ssgpu_block_create_from_file(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n, const char* path, ssgpu_block** out) {
+  if (!c || c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  FILE* f = path ? fopen(path, "rb") : nullptr;
+  if (!f) { c->err = std::string("cannot open ") + (path ? path : "(null)"); return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  std::vector<int> width(n); std::vector<bool> nullable(n);
+  int64_t row_bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    width[i] = dtype_width(schema[i].dtype); nullable[i] = schema[i].nullable != 0;
+    if (width[i] == 0) { fclose(f); c->err = "variable-length columns are outside the device hot path"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    row_bytes += width[i] + (nullable[i] ? 1 : 0);
+  }
+  // pass 1: chunk headers only (the payload size follows from the row count and the schema)
+  int64_t total = 0; uint64_t rc = 0; int64_t max_chunk = 0;
+  while (fread(&rc, 8, 1, f) == 1) {
+    if (fseek(f, (long)((int64_t)rc * row_bytes), SEEK_CUR) != 0) break;
+    total += (int64_t)rc; max_chunk = std::max<int64_t>(max_chunk, (int64_t)rc);
+  }
+  { const long end = ftell(f); fseek(f, 0, SEEK_END); if (ftell(f) < end) { fclose(f); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; } }
+  rewind(f);
+  ssgpu_block* b = nullptr;
+  int rcode = ssgpu_block_create(c, schema, n, std::max<int64_t>(total, 1), &b);
+  if (rcode != SSGPU_OK) { fclose(f); return rcode; }
+  // pass 2: two pinned staging buffers; chunk k+1 is read from the file while chunk k crosses PCIe
+  const size_t stage_bytes = (size_t)std::max<int64_t>(max_chunk, 1) * (size_t)row_bytes;
+  PinnedBuf stage[2]; hipEvent_t done[2] = {nullptr, nullptr};
+  int64_t off = 0; int k = 0; bool ok = true;
+  for (int i = 0; i < 2 && ok; ++i) ok = stage[i].ensure(stage_bytes) == hipSuccess && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+  while (ok && fread(&rc, 8, 1, f) == 1) {
+    if (hipEventSynchronize(done[k]) != hipSuccess) { ok = false; break; }   // staging buffer k free again
+    char* p = reinterpret_cast<char*>(stage[k].p);
+    const size_t bytes = (size_t)rc * (size_t)row_bytes;
+    if (bytes && fread(p, 1, bytes, f) != bytes) { ok = false; break; }
+    for (int i = 0; i < n && ok; ++i) {
+      const uint8_t* nulls = nullptr;
+      if (nullable[i]) { nulls = reinterpret_cast<const uint8_t*>(p); p += rc; }
+      ok = ssgpu_block_upload(b, i, p, nulls, off, (int64_t)rc) == SSGPU_OK;
+      p += (size_t)rc * width[i];
+    }
+    if (ok) ok = hipEventRecord(done[k], c->copy_stream) == hipSuccess;
+    off += (int64_t)rc; k ^= 1;
+  }
+  fclose(f);
+  if (ok) ok = hipStreamSynchronize(c->copy_stream) == hipSuccess;
+  for (int i = 0; i < 2; ++i) if (done[i]) (void)hipEventDestroy(done[i]);
+  if (!ok || off != total) { ssgpu_block_destroy(b); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; }
+  b->rows = total;
+  *out = b;
+  return SSGPU_OK;
+}
+
+static int write_view_file(ssgpu_ctx* c, const char* path, int n, int64_t rows, const std::vector<const void*>& dev_data,
+                           const std::vector<const uint8_t*>& dev_nulls, const std::vector<int>& width, const std::vector<bool>& nullable) {
+  FILE* f = path ? fopen(path, "wb") : nullptr;
+  if (!f) { c->err = "Writing view to the output file failed."; return SSGPU_ERROR_UNKNOWN; }
+  std::vector<char> host;
+  bool ok = true;
+  for (int64_t off = 0; off < rows && ok; off += kFileChunkRows) {
+    const uint64_t rc = (uint64_t)std::min<int64_t>(kFileChunkRows, rows - off);
+    ok = fwrite(&rc, 8, 1, f) == 1;
+    for (int i = 0; i < n && ok; ++i) {
+      if (nullable[i]) {
+        host.assign((size_t)rc, 0);
+        if (dev_nulls[i]) ok = hipMemcpy(host.data(), dev_nulls[i] + off, (size_t)rc, hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && fwrite(host.data(), 1, (size_t)rc, f) == (size_t)rc;
+      }
+      host.resize((size_t)rc * width[i]);
+      ok = ok && hipMemcpy(host.data(), reinterpret_cast<const char*>(dev_data[i]) + off * width[i], host.size(), hipMemcpyDeviceToHost) == hipSuccess;
+      ok = ok && fwrite(host.data(), 1, host.size(), f) == host.size();
+    }
+  }
+  ok = fclose(f) == 0 && ok;
+  if (!ok) { c->err = "Writing view to the output file failed."; return SSGPU_ERROR_UNKNOWN; }
+  return SSGPU_OK;
+}
+
+int ssgpu_block_write_file(ssgpu_block* b, const char* path) {
+  if (!b) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = b->ctx;
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  const int n = (int)b->schema.size();
+  std::vector<const void*> d(n); std::vector<const uint8_t*> z(n); std::vector<int> w(n); std::vector<bool> nl(n);
+  for (int i = 0; i < n; ++i) { d[i] = b->data[i].p; z[i] = b->schema[i].nullable ? b->nulls[i].as<uint8_t>() : nullptr; w[i] = dtype_width(b->schema[i].dtype); nl[i] = b->schema[i].nullable; }
+  return write_view_file(c, path, n, b->rows, d, z, w, nl);
+}
+
 int ssgpu_block_upload(ssgpu_block* b, int32_t col, const void* hd, const uint8_t* hn, int64_t off, int64_t rows) {
   if (!b) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_ctx* c = b->ctx;
@@ -1098,6 +1186,21 @@ int ssgpu_plan_finalize(ssgpu_plan* p, ssgpu_result** out) {
 }
 
 void ssgpu_result_destroy(ssgpu_result* r) { (void)r; /* owned by the plan: valid until the next run */ }
+
+int ssgpu_result_write_file(ssgpu_result* r, const char* path) {
+  if (!r || !r->plan || r->plan->exec.empty()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
+  int rc = check_error_flags(p);
+  if (rc != SSGPU_OK) return rc;
+  const int64_t rows = ssgpu_result_row_count(r);
+  if (rows < 0) return SSGPU_ERROR_HIP;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  StageExec& ex = p->exec.back();
+  const int n = (int)ex.out.size();
+  std::vector<const void*> d(n); std::vector<const uint8_t*> z(n); std::vector<int> w(n); std::vector<bool> nl(n);
+  for (int i = 0; i < n; ++i) { d[i] = ex.out[i].data.p; z[i] = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr; w[i] = (int)ex.out[i].width; nl[i] = ex.out[i].nullable; }
+  return write_view_file(c, path, n, rows, d, z, w, nl);
+}
 
 int64_t ssgpu_result_row_count(ssgpu_result* r) {
   if (!r || !r->plan || r->plan->exec.empty()) return -1;
