@@ -41,6 +41,15 @@
  *     expression/proto/operators.proto);
  *   - null masks are one byte per row (0 = value present, non-zero = NULL),
  *     exactly as the reference's bool* is_null (bit_pointers.h:529-533);
+ *   - STRING columns cross this boundary as INT32 codes (4 bytes per row) of ONE order-
+ *     preserving dictionary per plan, built by the caller over every STRING column it scans
+ *     and every STRING constant of the plan (SSGPU_EXPR_CONST with dtype SSGPU_STRING carries
+ *     the code in i64).  Code order == the reference's StringPiece order (memcmp, then
+ *     length), so comparisons, IN / CASE, MIN / MAX / FIRST / LAST, group keys and sort order
+ *     on the codes are bit-exact restatements of the same operations on the strings
+ *     (types_infrastructure.h:238-246); the bytes themselves never reach the device.
+ *     Arithmetic, casts and SUM on STRING are bind errors exactly as in the reference.  The
+ *     host mirrors own the dictionary (supersonic_amd/api.py: StringDictionary);
  *   - every *_create has a *_destroy; one ctx/plan is driven by one host
  *     thread at a time (as the reference); only ssgpu_interrupt is callable
  *     concurrently;

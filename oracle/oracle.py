@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 _NP = {1: np.int32, 2: np.int64, 8: np.uint32, 3: np.uint64, 9: np.float32, 5: np.float64, 6: np.bool_,
-       10: np.int32, 4: np.int64}
+       10: np.int32, 4: np.int64, 0: np.int32}   # 0 = STRING: dictionary codes inside the C restatement
+T_STRING = 0
 
 KIND = {"ScanView": 1, "Compute": 2, "Filter": 3, "Project": 4, "ScalarAggregate": 5, "GroupAggregate": 6,
         "AggregateClusters": 7, "Sort": 8}
@@ -75,13 +76,46 @@ def _enc(s):
     return None if s is None else (s.encode() if isinstance(s, str) else s)
 
 
+def _bytes(v):
+    return v.encode() if isinstance(v, str) else bytes(v)
+
+
+def _collect_strings(o, found):
+    """STRING constants and STRING column values of a tree (own walk: no code shared with the product)."""
+    def walk(e):
+        if e is None:
+            return
+        if getattr(e, "sval", None) is not None:
+            found.add(_bytes(e.sval))
+        for a in getattr(e, "args", ()):
+            walk(a)
+    while o is not None:
+        walk(getattr(o, "expression", None))
+        walk(getattr(o, "predicate", None))
+        v = getattr(o, "view", None)
+        if v is not None:
+            schema = v.schema()
+            for i in range(schema.attribute_count()):
+                if schema.attribute(i).type() == T_STRING:
+                    col = v.column(i)
+                    for j, s in enumerate(col.data):
+                        if col.is_null is None or not col.is_null[j]:
+                            found.add(_bytes(s))
+        o = getattr(o, "child", None)
+
+
 class _Tree(object):
     def __init__(self):
         self.keep = []
+        self.values = []     # order-preserving dictionary: sorted byte strings; code = index
+        self.code = {}
 
     def expr(self, e):
         L = lib()
-        h = L.orc_expr_new(e.kind, e.op, e.dtype, int(e.i64), float(e.f64), _enc(e.name))
+        i64 = int(e.i64)
+        if e.kind == 3 and e.dtype == T_STRING:      # ConstString -> its code
+            i64 = self.code[_bytes(e.sval)]
+        h = L.orc_expr_new(e.kind, e.op, e.dtype, i64, float(e.f64), _enc(e.name))
         for a in e.args:
             L.orc_expr_add_arg(h, self.expr(a))
         return h
@@ -96,7 +130,11 @@ class _Tree(object):
             for i in range(schema.attribute_count()):
                 a = schema.attribute(i)
                 col = v.column(i)
-                data = np.ascontiguousarray(col.data)
+                if a.type() == T_STRING:
+                    data = np.array([0 if (col.is_null is not None and col.is_null[j]) else self.code[_bytes(sv)]
+                                     for j, sv in enumerate(col.data)], dtype=np.int32)
+                else:
+                    data = np.ascontiguousarray(col.data)
                 nulls = None if col.is_null is None else np.ascontiguousarray(col.is_null).view(np.uint8)
                 self.keep += [data, nulls]
                 L.orc_scan_add_column(h, _enc(a.name()), a.type(), a.nullability(), data.ctypes.data_as(C.c_void_p),
@@ -129,6 +167,10 @@ class _Tree(object):
 class Cursor(object):
     def __init__(self, operation):
         self.tree = _Tree()
+        found = set()
+        _collect_strings(operation, found)
+        self.tree.values = sorted(found)
+        self.tree.code = {v: i for i, v in enumerate(self.tree.values)}
         self.handle = lib().orc_create_cursor(self.tree.op(operation))
         buf = C.create_string_buffer(600)
         code = lib().orc_cursor_error(self.handle, buf, 600)
@@ -184,5 +226,10 @@ def run(operation, max_rows=1024):
         if nullable:
             z = np.concatenate([(p[i][1] if p[i][1] is not None else np.zeros(len(p[i][0]), bool)) for p in parts]) \
                 if parts else np.zeros(0, bool)
+        if t == T_STRING:       # codes -> byte strings
+            dec = np.empty(len(d), dtype=object)
+            for j, c in enumerate(d):
+                dec[j] = b"" if (z is not None and z[j]) else cur.tree.values[int(c)]
+            d = dec
         cols.append((d, z))
     return cur.schema, cols

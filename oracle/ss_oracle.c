@@ -72,6 +72,10 @@ static int type_width(int t) {
     case T_INT32: case T_UINT32: case T_FLOAT: case T_DATE: return 4;
     case T_INT64: case T_UINT64: case T_DOUBLE: case T_DATETIME: return 8;
     case T_BOOL: return 1;
+    /* STRING columns reach this restatement as INT32 codes of an order-preserving dictionary
+     * (oracle.py encodes them): comparisons, MIN/MAX, keys and sort order of the codes are those
+     * of the strings (StringPiece compare = memcmp then length) */
+    case T_STRING: return 4;
   }
   return 0;
 }
@@ -140,7 +144,7 @@ static bnode* bnode_new(int kind, int op, int dtype, int nullable, const char* n
 static uint64_t const_bits(int dtype, int64_t i64, double f64) {
   uint64_t b = 0;
   switch (dtype) {
-    case T_INT32: case T_DATE: { int32_t v = (int32_t)i64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
+    case T_INT32: case T_DATE: case T_STRING: { int32_t v = (int32_t)i64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
     case T_UINT32: b = (uint32_t)i64; break;
     case T_INT64: case T_DATETIME: case T_UINT64: memcpy(&b, &i64, 8); break;
     case T_FLOAT: { float v = (float)f64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
@@ -167,7 +171,7 @@ static bnode* make_null(int dtype) { return bnode_new(B_NULLCONST, 0, dtype, 1, 
   for (int64_t i = 0; i < n; ++i) { TA a = pa[i]; pd[i] = (TD)(EXPR); } }
 
 static int arith_kind(int t) { /* 0:i32 1:u32 2:i64 3:u64 4:f32 5:f64 6:bool */
-  switch (t) { case T_INT32: case T_DATE: return 0; case T_UINT32: return 1; case T_INT64: case T_DATETIME: return 2;
+  switch (t) { case T_INT32: case T_DATE: case T_STRING: return 0; case T_UINT32: return 1; case T_INT64: case T_DATETIME: return 2;
                case T_UINT64: return 3; case T_FLOAT: return 4; case T_DOUBLE: return 5; case T_BOOL: return 6; }
   return -1;
 }
@@ -894,7 +898,7 @@ static int bind_aggs(orc_cursor* c, const orc_op* op, const orc_schema* in) {
     if (a->aggregation == A_COUNT) { if (!is_integer(g->out_type)) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "COUNT output must be integer%s%s", "", ""); return 0; } }
     else {
       int ok = (is_numeric(g->in_type) && is_numeric(g->out_type)) ||
-               (g->in_type == g->out_type && a->aggregation != A_SUM && (g->in_type == T_BOOL || g->in_type == T_DATE || g->in_type == T_DATETIME));
+               (g->in_type == g->out_type && a->aggregation != A_SUM && (g->in_type == T_BOOL || g->in_type == T_DATE || g->in_type == T_DATETIME || g->in_type == T_STRING));
       if (!ok) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "Aggregation not supported for types %s and %s.", type_name(g->in_type), type_name(g->out_type)); return 0; }
     }
     if (!schema_add(&c->schema, a->output, g->out_type, a->aggregation != A_COUNT)) {

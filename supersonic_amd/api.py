@@ -36,7 +36,40 @@ _TYPE_NAMES = {INT32: "INT32", INT64: "INT64", UINT32: "UINT32", UINT64: "UINT64
 
 
 def numpy_dtype(data_type):
-    return _NP[data_type]
+    return np.dtype(object) if data_type == STRING else _NP[data_type]
+
+
+def _as_bytes(v):
+    return v.encode() if isinstance(v, str) else bytes(v)
+
+
+class StringDictionary(object):
+    """STRING columns cross the C ABI as INT32 codes of ONE order-preserving dictionary per plan
+    (include/ssgpu.h, "STRING columns"): sorted unique byte strings of every STRING column of the
+    scanned View and of every ConstString of the plan.  Python's bytes order is the reference's
+    StringPiece order (memcmp, then length), so comparisons, MIN/MAX, group keys and sort order of
+    the codes are those of the strings."""
+
+    def __init__(self, strings):
+        self.values = sorted(set(strings))
+        self.code = {v: i for i, v in enumerate(self.values)}
+
+    def encode(self, data, nulls):
+        out = np.zeros(len(data), np.int32)
+        for i, v in enumerate(data):
+            if nulls is not None and nulls[i]:
+                continue
+            try:
+                out[i] = self.code[_as_bytes(v)]
+            except KeyError:
+                raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "STRING value not in the plan's dictionary: the plan was created over another View")
+        return out
+
+    def decode(self, codes, nulls):
+        out = np.empty(len(codes), dtype=object)
+        for i, c in enumerate(codes):
+            out[i] = b"" if (nulls is not None and nulls[i]) else self.values[int(c)]
+        return out
 
 
 class SupersonicException(Exception):
@@ -177,9 +210,13 @@ class View(object):
         for i, c in enumerate(columns):
             if not isinstance(c, Column):
                 c = Column(*c) if isinstance(c, tuple) else Column(c)
-            dt = _NP[schema.attribute(i).type()]
-            data = np.ascontiguousarray(c.data, dtype=dt)
             nulls = None if c.is_null is None else np.ascontiguousarray(c.is_null, dtype=np.bool_)
+            if schema.attribute(i).type() == STRING:
+                data = np.empty(len(c.data), dtype=object)
+                for j, v in enumerate(c.data):
+                    data[j] = b"" if v is None else _as_bytes(v)
+            else:
+                data = np.ascontiguousarray(c.data, dtype=_NP[schema.attribute(i).type()])
             cols.append(Column(data, nulls))
         self._cols = cols
         self._rows = int(row_count if row_count is not None else (len(cols[0].data) if cols else 0))
@@ -335,6 +372,12 @@ def ConstInt64(v): return _const(INT64, i64=v)
 def ConstUint32(v): return _const(UINT32, i64=v)
 def ConstUint64(v): return _const(UINT64, i64=np.array(v, dtype=np.uint64).astype(np.int64))
 def ConstFloat(v): return _const(FLOAT, f64=v)
+
+
+def ConstString(v):
+    e = _const(STRING)
+    e.sval = _as_bytes(v)
+    return e
 def ConstDouble(v): return _const(DOUBLE, f64=v)
 def ConstBool(v): return _const(BOOL, i64=1 if v else 0)
 def ConstDate(v): return _const(DATE, i64=v)
@@ -513,6 +556,7 @@ class _Builder(object):
         self.exprs, self.expr_args, self.projs, self.aggs, self.sortkeys, self.ops = [], [], [], [], [], []
         self.keep = []
         self.scan = None
+        self.strings = StringDictionary([])
 
     def s(self, text):
         if text is None:
@@ -525,7 +569,10 @@ class _Builder(object):
         child = [self.expr(a) for a in e.args]
         first = len(self.expr_args)
         self.expr_args.extend(child)
-        x = L.Expr(e.kind, e.op, e.dtype, first, len(child), 0, int(e.i64), float(e.f64), self.s(e.name))
+        i64 = int(e.i64)
+        if e.kind == L.EXPR_CONST and e.dtype == STRING:
+            i64 = self.strings.code[e.sval]          # dictionary code of the constant
+        x = L.Expr(e.kind, e.op, e.dtype, first, len(child), 0, i64, float(e.f64), self.s(e.name))
         self.exprs.append(x)
         return len(self.exprs) - 1
 
@@ -654,6 +701,38 @@ def _array(ctype, items):
     return arr
 
 
+def collect_strings(operation):
+    """Every STRING value a plan can meet: ConstString payloads and the STRING columns of the host
+    Views it scans."""
+    found = []
+
+    def walk_expr(e):
+        if e is None:
+            return
+        if getattr(e, "sval", None) is not None:
+            found.append(e.sval)
+        for a in getattr(e, "args", ()):
+            walk_expr(a)
+
+    def walk_op(o):
+        if o is None:
+            return
+        for attr in ("expression", "predicate"):
+            walk_expr(getattr(o, attr, None))
+        view = getattr(o, "view", None)
+        if isinstance(view, View):
+            schema = view.schema()
+            for i in range(schema.attribute_count()):
+                if schema.attribute(i).type() == STRING:
+                    col = view.column(i)
+                    for j, v in enumerate(col.data):
+                        if col.is_null is None or not col.is_null[j]:
+                            found.append(v)
+        walk_op(getattr(o, "child", None))
+    walk_op(operation)
+    return found
+
+
 class Plan(object):
     """A bound plan (ssgpu_plan): owns the device programs and result buffers."""
 
@@ -661,6 +740,7 @@ class Plan(object):
         self.ctx = context
         self.lib = context.lib
         b = _Builder()
+        b.strings = self.strings = StringDictionary(collect_strings(operation))
         operation._emit(b)
         if b.scan is None:
             raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "plan has no ScanView")
@@ -727,6 +807,8 @@ class Plan(object):
             for i in range(view.column_count()):
                 col = view.column(i)
                 nulls = col.is_null
+                if schema.attribute(i).type() == STRING:
+                    col = Column(self.strings.encode(col.data, nulls), nulls)
                 if view.row_count():
                     self.ctx.check(self.lib.ssgpu_block_upload(
                         blk, i, col.data.ctypes.data_as(C.c_void_p),
@@ -776,11 +858,13 @@ class Plan(object):
             a = self.result_schema.attribute(i)
             dp, npn = C.c_void_p(), C.c_void_p()
             self.ctx.check(self.lib.ssgpu_result_column(res, i, C.byref(dp), C.byref(npn)))
-            dt = np.dtype(_NP[a.type()])
+            dt = np.dtype(np.int32 if a.type() == STRING else _NP[a.type()])
             data = np.frombuffer(C.string_at(dp, rows * dt.itemsize), dtype=dt).copy() if rows else np.zeros(0, dt)
             nulls = None
             if a.is_nullable():
                 nulls = (np.frombuffer(C.string_at(npn, rows), dtype=np.uint8).copy() != 0) if rows else np.zeros(0, bool)
+            if a.type() == STRING:
+                data = self.strings.decode(data, nulls)
             cols.append(Column(data, nulls))
         return View(self.result_schema, cols, rows)
 
@@ -871,7 +955,7 @@ def drain(cursor, max_row_count=kDefaultRowCount):
     schema = cursor.schema()
     cols = []
     for i in range(schema.attribute_count()):
-        dt = _NP[schema.attribute(i).type()]
+        dt = numpy_dtype(schema.attribute(i).type())
         data = np.concatenate([p.column(i).data for p in parts]) if parts else np.zeros(0, dt)
         nulls = None
         if schema.attribute(i).is_nullable():

@@ -42,6 +42,7 @@ int dtype_width(int t) {
     case SSGPU_INT32: case SSGPU_UINT32: case SSGPU_FLOAT: case SSGPU_DATE: return 4;
     case SSGPU_INT64: case SSGPU_UINT64: case SSGPU_DOUBLE: case SSGPU_DATETIME: return 8;
     case SSGPU_BOOL: return 1;
+    case SSGPU_STRING: return 4;   // dictionary code (see ssgpu.h: STRING columns)
   }
   return 0;
 }
@@ -134,7 +135,7 @@ Status bind_projector(const PlanDesc& d, int first, int n, const Schema& schema,
 static uint64_t const_bits(int dtype, int64_t i64, double f64) {
   uint64_t b = 0;
   switch (dtype) {
-    case SSGPU_INT32: case SSGPU_DATE: { int32_t v = (int32_t)i64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
+    case SSGPU_INT32: case SSGPU_DATE: case SSGPU_STRING: { int32_t v = (int32_t)i64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
     case SSGPU_UINT32: b = (uint32_t)i64; break;
     case SSGPU_INT64: case SSGPU_DATETIME: case SSGPU_UINT64: memcpy(&b, &i64, 8); break;
     case SSGPU_FLOAT: { float v = (float)f64; uint32_t u; memcpy(&u, &v, 4); b = u; } break;
@@ -160,7 +161,7 @@ static bool is_constant(const BExprP& e) { return e->kind == BExpr::CONST || e->
 // typed scalar views of constant bits (bind-time constant folding only)
 static double bits_to_double(int dtype, uint64_t b) {
   switch (dtype) {
-    case SSGPU_INT32: case SSGPU_DATE: return (double)(int32_t)(uint32_t)b;
+    case SSGPU_INT32: case SSGPU_DATE: case SSGPU_STRING: return (double)(int32_t)(uint32_t)b;
     case SSGPU_UINT32: return (double)(uint32_t)b;
     case SSGPU_INT64: case SSGPU_DATETIME: return (double)(int64_t)b;
     case SSGPU_UINT64: return (double)b;
@@ -172,7 +173,7 @@ static double bits_to_double(int dtype, uint64_t b) {
 }
 static int64_t bits_to_i64(int dtype, uint64_t b) {
   switch (dtype) {
-    case SSGPU_INT32: case SSGPU_DATE: return (int32_t)(uint32_t)b;
+    case SSGPU_INT32: case SSGPU_DATE: case SSGPU_STRING: return (int32_t)(uint32_t)b;
     case SSGPU_UINT32: return (uint32_t)b;
     case SSGPU_BOOL: return b != 0;
     default: return (int64_t)b;

@@ -37,7 +37,7 @@ enum {
 enum MT { M_I32, M_U32, M_I64, M_U64, M_F32, M_F64, M_B8, M_BAD };
 static MT mtype(int dtype) {
   switch (dtype) {
-    case SSGPU_INT32: case SSGPU_DATE: return M_I32;
+    case SSGPU_INT32: case SSGPU_DATE: case SSGPU_STRING: return M_I32;   // STRING = order-preserving dictionary code
     case SSGPU_UINT32: return M_U32;
     case SSGPU_INT64: case SSGPU_DATETIME: return M_I64;
     case SSGPU_UINT64: return M_U64;
@@ -587,7 +587,7 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
     } else {
       const int it = in[p.input_pos].dtype;
       bool ok = (dtype_is_numeric(it) && dtype_is_numeric(p.out_type)) ||
-                (it == p.out_type && a.aggregation != SSGPU_SUM && (it == SSGPU_BOOL || it == SSGPU_DATE || it == SSGPU_DATETIME));
+                (it == p.out_type && a.aggregation != SSGPU_SUM && (it == SSGPU_BOOL || it == SSGPU_DATE || it == SSGPU_DATETIME || it == SSGPU_STRING));
       if (!ok)
         return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE,
                              std::string("Aggregation not supported. Aggregation function not defined for types ") +

@@ -253,7 +253,7 @@ int ssgpu_block_create_from_file(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t
   int64_t row_bytes = 0;
   for (int i = 0; i < n; ++i) {
     width[i] = dtype_width(schema[i].dtype); nullable[i] = schema[i].nullable != 0;
-    if (width[i] == 0) { fclose(f); c->err = "variable-length columns are outside the device hot path"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    if (width[i] == 0 || schema[i].dtype == SSGPU_STRING) { fclose(f); c->err = "variable-length columns of the file format are outside the device hot path"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
     row_bytes += width[i] + (nullable[i] ? 1 : 0);
   }
   // pass 1: chunk headers only (the payload size follows from the row count and the schema)

@@ -20,7 +20,7 @@ Conventions
 import json
 import os
 
-I32, I64, U32, U64, F32, F64, BOOL, DATE = "INT32", "INT64", "UINT32", "UINT64", "FLOAT", "DOUBLE", "BOOL", "DATE"
+I32, I64, U32, U64, F32, F64, BOOL, DATE, STR = "INT32", "INT64", "UINT32", "UINT64", "FLOAT", "DOUBLE", "BOOL", "DATE", "STRING"
 INF, NAN = "inf", "nan"
 CASES = []
 
@@ -387,6 +387,36 @@ expr_case("Math_IsFinite", M + ":712-722", [F32, BOOL], [[0., True], [1234., Tru
 expr_case("Math_IsInf", M + ":724-734", [F64, BOOL], [[0., False], [1234., False], [INF, True], [NAN, False], [None, None]], "IsInf")
 expr_case("Math_IsNaN", M + ":736-746", [F32, BOOL], [[0., False], [1234., False], [INF, False], [NAN, True], [None, None]], "IsNaN")
 expr_case("Math_IsNormal", M + ":748-758", [F64, BOOL], [[0., False], [1234., True], [INF, False], [NAN, False], [None, None]], "IsNormal")
+
+# ---- real STRING columns (dictionary codes on the device, see include/ssgpu.h) ---------------------
+expr_plan_case("Case_BasicInt32ToString", C + ":33-50",
+               [I32], ["CaseList", AT(0), ["ConstString", "other"], ["ConstInt32", 1], ["ConstString", "one"], ["ConstInt32", 2], ["ConstString", "two"]], STR,
+               [[1, "one"], [2, "two"], [3, "other"], [4, "other"], [5, "other"], [None, "other"]])
+expr_plan_case("Case_StringToUInt32", C + ":52-70",
+               [STR, U32], ["CaseList", AT(0), AT(1), ["ConstString", "one"], ["ConstUint32", 1], ["ConstString", "null"], ["NullOf", "UINT32"]], U32,
+               [["zero", 10, 10], ["nine", 9, 9], ["one", 8, 1], ["NULL", 7, 7], ["null", 6, None], [None, None, None]])
+expr_plan_case("Case_IfCaseAllNullable_strings", C + ":178-195", [BOOL, STR, STR], IFCASE, STR,
+               [[True, "A", "B", "A"], [False, "C", "D", "D"], [True, None, "F", None], [False, None, "H", "H"], [True, "I", None, "I"],
+                [False, "K", None, None], [True, None, None, None], [False, None, None, None], [None, "M", "N", "N"], [None, None, "P", "P"],
+                [None, "R", None, None], [None, None, None, None], [False, "W", "Y", "Y"]])
+bind_plan_case("InSet_string", CB + ":118-119", IN4, [STR, STR, STR, STR], [False] * 4, "$0 IN ($1, $2, $3)", BOOL, False)
+bind_plan_case("InSet_string_int_mismatch", CB + ":136", ["InList", ["AttributeAt", 0], ["AttributeAt", 1], ["AttributeAt", 2]],
+               [I32, STR, I32], [False] * 3, None, None, None, expect_error=402)
+
+# ---- operation tests with their original STRING columns ------------------------------------------------
+op_case("Group_GroupBySecondColumn_string", GT + ":356-377", cols([I32, STR]), [[-3, "foo"], [2, "bar"], [3, "bar"], [-2, "foo"]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col1"], [["SUM", "col0", "sum"]], "INPUT"],
+        [STR, I32], [["foo", -5], ["bar", 5]], ordered=False, exp_names=["col1", "sum"])
+op_case("Group_GroupByWithoutAggregateFunctions_string", GT + ":430-447", cols([STR]), [["foo"], ["bar"], ["foo"], ["bar"]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [], "INPUT"], [STR], [["foo"], ["bar"]], ordered=False)
+op_case("Sort_OneIntegerColumnNoDuplicatesNoNulls_string", SO + ":121-145", cols([I32, STR]),
+        [[2, "b"], [3, "c"], [1, "a"], [7, "g"], [4, "d"], [6, "f"], [5, "e"]],
+        ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [I32, STR],
+        [[1, "a"], [2, "b"], [3, "c"], [4, "d"], [5, "e"], [6, "f"], [7, "g"]])
+op_case("Sort_OneStringColumnWithDuplicatesAndNulls_string", SO + ":190-215", cols([STR]),
+        [["a"], ["c"], ["a"], [None], ["d"], [None], ["e"]],
+        ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [STR], [[None], [None], ["a"], ["a"], ["c"], ["d"], ["e"]])
+op_case("Sort_OneEmptyStringColumn_string", SO + ":180-188", cols([STR]), [], ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [STR], [])
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")

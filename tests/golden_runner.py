@@ -10,7 +10,7 @@ import supersonic_amd as ss
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TYPES = {"INT32": ss.INT32, "INT64": ss.INT64, "UINT32": ss.UINT32, "UINT64": ss.UINT64, "FLOAT": ss.FLOAT,
-         "DOUBLE": ss.DOUBLE, "BOOL": ss.BOOL, "DATE": ss.DATE, "DATETIME": ss.DATETIME}
+         "DOUBLE": ss.DOUBLE, "BOOL": ss.BOOL, "DATE": ss.DATE, "DATETIME": ss.DATETIME, "STRING": ss.STRING}
 AGGS = {"SUM": ss.SUM, "MIN": ss.MIN, "MAX": ss.MAX, "COUNT": ss.COUNT, "FIRST": ss.FIRST, "LAST": ss.LAST}
 ORDERS = {"ASCENDING": ss.ASCENDING, "DESCENDING": ss.DESCENDING}
 
@@ -36,7 +36,10 @@ def build_view(inp):
         vals = [r[i] for r in inp["rows"]]
         nulls = np.array([v is None for v in vals], dtype=bool)
         dt = ss.numpy_dtype(TYPES[t])
-        data = np.array([0 if v is None else _value(v) for v in vals]).astype(dt) if vals else np.zeros(0, dt)
+        if t == "STRING":
+            data = ["" if v is None else v for v in vals]
+        else:
+            data = np.array([0 if v is None else _value(v) for v in vals]).astype(dt) if vals else np.zeros(0, dt)
         cols.append(ss.Column(data, nulls if nullable else None))
         if not nullable:
             assert not nulls.any()
@@ -130,7 +133,7 @@ def check(case, schema, cols):
             if z is not None and z[r]:
                 row.append(None)
             else:
-                v = d[r].item()
+                v = d[r].decode() if isinstance(d[r], bytes) else d[r].item()
                 row.append(v)
         got.append(row)
     want = [[_value(v) for v in r] for r in exp["rows"]]

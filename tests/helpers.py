@@ -22,6 +22,9 @@ def sort_rows(cols):
         return cols
     keys = []
     for d, z in reversed(cols):
+        if d.dtype == object:   # STRING column: rank of the byte strings
+            uniq = {v: i for i, v in enumerate(sorted(set(d.tolist())))}
+            d = np.array([uniq[v] for v in d.tolist()], dtype=np.int64)
         keys.append(np.where(z, 0, d) if z is not None else d)
         if z is not None:
             keys.append(~z)
@@ -39,7 +42,11 @@ def assert_cols_equal(got, want, float_exact=True, context=""):
             context, i, np.nonzero(gz_ != wz_)[0][:10])
         live = ~wz_
         g, w = gd[live], wd[live]
-        if float_exact or g.dtype.kind != "f":
+        if g.dtype == object or w.dtype == object:
+            bad = [j for j in range(len(g)) if g[j] != w[j]]
+            assert not bad, "%s column %d: %d rows differ, first %s: got %s want %s" % (
+                context, i, len(bad), bad[:5], [g[j] for j in bad[:5]], [w[j] for j in bad[:5]])
+        elif float_exact or g.dtype.kind != "f":
             same = g.view(np.uint8).reshape(len(g), -1) == w.view(np.uint8).reshape(len(w), -1) if len(g) else np.ones((0, 1), bool)
             bad = np.nonzero(~same.all(axis=1))[0] if len(g) else []
             assert len(bad) == 0, "%s column %d: %d rows differ, first %s: got %s want %s" % (
