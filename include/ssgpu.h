@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 1
+#define SSGPU_ABI_VERSION 2
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -155,7 +155,9 @@ typedef struct ssgpu_proj {
   int32_t kind;
   int32_t position;
   const char* name;
-  const char* alias;
+  const char* alias;   /* NAMED_AS: new name; ALL: optional name prefix (ProjectAllAttributes("L.")) */
+  int32_t source;      /* MultiSourceProjector entries (HASH_JOIN result): 0 = lhs, 1 = rhs */
+  int32_t reserved;
 } ssgpu_proj;
 
 /* ---- AggregationSpecification::Element (cursor/core/aggregate.h:28-80) -- */
@@ -184,8 +186,15 @@ enum {
   SSGPU_OP_SCALAR_AGGREGATE = 5,   /* ScalarAggregate(spec, child) aggregate.h:341 */
   SSGPU_OP_GROUP_AGGREGATE = 6,    /* GroupAggregate(keys, spec, opts, child) aggregate.h:224 */
   SSGPU_OP_AGGREGATE_CLUSTERS = 7, /* AggregateClusters(keys, spec, child) aggregate.h:285 */
-  SSGPU_OP_SORT = 8                /* Sort(order, proj, mem_limit, child) sort.h:83 */
+  SSGPU_OP_SORT = 8,               /* Sort(order, proj, mem_limit, child) sort.h:83 */
+  SSGPU_OP_HASH_JOIN = 9           /* HashJoinOperation(type, lhs keys, rhs keys, result projector,
+                                      uniqueness, lhs, rhs) hash_join.h:37-56.  `child` = lhs chain,
+                                      `child2` = the rhs op, which must be a SCAN of the auxiliary
+                                      input (a device-resident dimension table); the probe and the
+                                      gathers of the rhs columns are fused into the lhs pipeline */
 };
+enum { SSGPU_JOIN_INNER = 0, SSGPU_JOIN_LEFT_OUTER = 1 };           /* JoinType, supersonic.proto:108-113 */
+enum { SSGPU_KEYS_NOT_UNIQUE = 0, SSGPU_KEYS_UNIQUE = 1 };            /* KeyUniqueness, :115-118 */
 typedef struct ssgpu_op {
   int32_t kind;       /* SSGPU_OP_* */
   int32_t child;      /* index of the child op (must precede), -1 for SCAN */
@@ -196,9 +205,15 @@ typedef struct ssgpu_op {
   int32_t agg_n;
   int32_t sort_first;
   int32_t sort_n;
-  int32_t reserved;
+  int32_t child2;     /* HASH_JOIN: index of the rhs op (must precede); else unused */
   int64_t option0;    /* GROUP: max_unique_keys_in_result (0 = unlimited);
-                         SORT: memory limit (ignored: no spill path)          */
+                         SORT: memory limit (ignored: no spill path);
+                         SCAN: input index (0 = the plan input, 1 = the auxiliary input);
+                         HASH_JOIN: JoinType | KeyUniqueness << 8             */
+  int32_t proj2_first; /* HASH_JOIN: rhs key selector (proj_first/proj_n = lhs key selector) */
+  int32_t proj2_n;
+  int32_t proj3_first; /* HASH_JOIN: result projector (entries tagged with `source`) */
+  int32_t proj3_n;
 } ssgpu_op;
 
 typedef struct ssgpu_plan_desc {
@@ -216,6 +231,8 @@ typedef struct ssgpu_plan_desc {
   int32_t n_aggs;
   const ssgpu_sortkey* sortkeys;
   int32_t n_sortkeys;
+  const ssgpu_attr* aux_schema;   /* schema of the auxiliary input (rhs of a HASH_JOIN), or NULL */
+  int32_t n_aux_attrs;
 } ssgpu_plan_desc;
 
 /* ---- a column of a View (base/infrastructure/block.h:55-192) ------------ */
@@ -288,6 +305,9 @@ int ssgpu_plan_program(const ssgpu_plan* plan, int32_t stage, const void** instr
 int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
                    int64_t rows, ssgpu_result** out);
 int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);
+/* The auxiliary input of a HASH_JOIN plan (rhs: DEVICE columns of the dimension table).  Stays
+ * bound until replaced; the join index is rebuilt from it at the start of every run. */
+int ssgpu_plan_set_aux_input(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows);
 /* Thread-safe, non-blocking; the running/next run returns SSGPU_INTERRUPTED. */
 void ssgpu_interrupt(ssgpu_plan* plan);
 

@@ -20,7 +20,7 @@ _NP = {1: np.int32, 2: np.int64, 8: np.uint32, 3: np.uint64, 9: np.float32, 5: n
 T_STRING = 0
 
 KIND = {"ScanView": 1, "Compute": 2, "Filter": 3, "Project": 4, "ScalarAggregate": 5, "GroupAggregate": 6,
-        "AggregateClusters": 7, "Sort": 8}
+        "AggregateClusters": 7, "Sort": 8, "HashJoinOperation": 9}
 
 
 class OracleError(Exception):
@@ -50,6 +50,8 @@ def lib():
         L.orc_op_add_proj.argtypes = [P, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_op_add_agg.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_op_add_sortkey.argtypes = [P, C.c_char_p, C.c_int]
+        L.orc_op_set_join.argtypes = [P, P, C.c_int]
+        L.orc_op_add_proj_to.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_scan_add_column.argtypes = [P, C.c_char_p, C.c_int, C.c_int, P, P]
         L.orc_scan_set_rows.argtypes = [P, C.c_int64]
         L.orc_create_cursor.restype = P
@@ -90,6 +92,8 @@ def _collect_strings(o, found):
         for a in getattr(e, "args", ()):
             walk(a)
     while o is not None:
+        if getattr(o, "rhs_child", None) is not None:
+            _collect_strings(o.rhs_child, found)
         walk(getattr(o, "expression", None))
         walk(getattr(o, "predicate", None))
         v = getattr(o, "view", None)
@@ -142,6 +146,19 @@ class _Tree(object):
             L.orc_scan_set_rows(h, v.row_count())
             return h
         child = self.op(o.child)
+        if kind == 9:   # HashJoinOperation(type, lhs keys, rhs keys, result projector, uniqueness, lhs, rhs)
+            if o.uniqueness != 1:
+                raise OracleError(103, "only UNIQUE rhs keys are restated")
+            rhs = self.op(o.rhs_child)
+            h = L.orc_op_new(9, child, None)
+            L.orc_op_set_join(h, rhs, int(o.join_type))
+            for (k, pos, name, alias) in o.lhs_keys.entries:
+                L.orc_op_add_proj(h, k, pos, _enc(name), _enc(alias))
+            for (k, pos, name, alias) in o.rhs_keys.entries:
+                L.orc_op_add_proj_to(h, 2, 0, k, pos, _enc(name), _enc(alias))
+            for (source, k, pos, name, alias) in o.result_projector.entries:
+                L.orc_op_add_proj_to(h, 3, source, k, pos, _enc(name), _enc(alias))
+            return h
         expr = None
         if kind == 2:
             expr = self.expr(o.expression)

@@ -787,9 +787,9 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
 }
 
 /* =========================== cursors ============================================ */
-enum { C_SCAN = 1, C_COMPUTE, C_FILTER, C_PROJECT, C_SCALAR_AGG, C_GROUP_AGG, C_CLUSTERS, C_SORT };
+enum { C_SCAN = 1, C_COMPUTE, C_FILTER, C_PROJECT, C_SCALAR_AGG, C_GROUP_AGG, C_CLUSTERS, C_SORT, C_HASH_JOIN };
 enum { P_ALL = 1, P_NAMED = 2, P_AT = 3, P_NAMED_AS = 4 };
-typedef struct { int kind, position; char name[256], alias[256]; } orc_proj;
+typedef struct { int kind, position; char name[256], alias[256]; int source; } orc_proj;
 typedef struct { int aggregation, distinct, output_type; char input[256], output[256]; } orc_agg;
 typedef struct { char name[256]; int order; } orc_sortkey;
 
@@ -799,6 +799,9 @@ typedef struct orc_op {
   orc_agg aggs[ORC_MAX_COLS]; int nagg;
   orc_sortkey sortkeys[16]; int nsort;
   orc_schema scan_schema; orc_view scan_view;
+  /* hash join (cursor/core/hash_join.h:37-56): projs = lhs key selector */
+  struct orc_op* child2; orc_proj projs2[ORC_MAX_COLS]; int nproj2; orc_proj projs3[ORC_MAX_COLS]; int nproj3;
+  int join_type;
 } orc_op;
 
 orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
@@ -807,6 +810,15 @@ orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
 void orc_op_add_proj(orc_op* o, int kind, int position, const char* name, const char* alias) {
   orc_proj* p = &o->projs[o->nproj++]; p->kind = kind; p->position = position;
   snprintf(p->name, sizeof(p->name), "%s", name ? name : ""); snprintf(p->alias, sizeof(p->alias), "%s", alias ? alias : "");
+}
+void orc_op_set_join(orc_op* o, orc_op* rhs, int join_type) { o->child2 = rhs; o->join_type = join_type; }
+void orc_op_add_proj_to(orc_op* o, int which, int source, int kind, int position, const char* name, const char* alias) {
+  orc_proj* list = which == 2 ? o->projs2 : o->projs3; int* n = which == 2 ? &o->nproj2 : &o->nproj3;
+  if (*n >= ORC_MAX_COLS) return;
+  orc_proj* p = &list[(*n)++]; memset(p, 0, sizeof(*p));
+  p->kind = kind; p->position = position; p->source = source;
+  if (name) snprintf(p->name, sizeof(p->name), "%s", name);
+  if (alias) snprintf(p->alias, sizeof(p->alias), "%s", alias);
 }
 void orc_op_add_agg(orc_op* o, int aggregation, int distinct, int output_type, const char* input, const char* output) {
   orc_agg* a = &o->aggs[o->nagg++]; a->aggregation = aggregation; a->distinct = distinct; a->output_type = output_type;
@@ -856,13 +868,18 @@ typedef struct orc_cursor {
   /* group */ int64_t* bucket_head; int64_t* chain_next; uint64_t* row_hash; int64_t nbuckets;
   /* sort */ int sort_pos[16], sort_order[16], nsort; int64_t* perm; void* table;
   orc_view outv;
+  /* hash join: rhs fully materialised, lhs streamed (hash_join.cc: LookupIndex + HashJoinCursor) */
+  struct orc_cursor* rhs; orc_block rhs_rows; int64_t rhs_n;
+  int jl_pos[16], jr_pos[16], nkeys, join_type;
+  int out_src[ORC_MAX_COLS], out_pos[ORC_MAX_COLS], nout_cols;
+  int64_t* match;
 } orc_cursor;
 
 static int bind_projector(const orc_proj* p, int np, const orc_schema* in, int* pos, char names[][256], int* nout, orc_error* err) {
   int k = 0;
   for (int i = 0; i < np; ++i) {
     switch (p[i].kind) {
-      case P_ALL: for (int c = 0; c < in->n; ++c) { pos[k] = c; snprintf(names[k], 256, "%s", in->a[c].name); ++k; } break;
+      case P_ALL: for (int c = 0; c < in->n; ++c) { pos[k] = c; snprintf(names[k], 256, "%s%s", p[i].alias, in->a[c].name); ++k; } break;  /* ProjectAllAttributes(prefix) */
       case P_NAMED: case P_NAMED_AS: {
         int c = schema_lookup(in, p[i].name);
         /* projector.cc:99-105 */
@@ -960,6 +977,32 @@ orc_cursor* orc_create_cursor(const orc_op* op) {
       for (int i = 0; i < c->nproj; ++i) schema_add(&c->schema, names[i], in->a[c->proj_pos[i]].type, in->a[c->proj_pos[i]].nullable);
       if (!bind_aggs(c, op, in)) return cursor_fail(c);
       block_init(&c->block, &c->schema, 16);  /* kDefaultResultEstimatedGroupCount, aggregate.h:162 */
+    } break;
+    case C_HASH_JOIN: {
+      c->rhs = orc_create_cursor(op->child2);
+      if (c->rhs->err.code) { c->err = c->rhs->err; return cursor_fail(c); }
+      const orc_schema* rs = &c->rhs->schema;
+      char names[ORC_MAX_COLS][256]; int nl = 0, nr = 0;
+      if (!bind_projector(op->projs, op->nproj, in, c->jl_pos, names, &nl, &c->err)) return cursor_fail(c);
+      if (!bind_projector(op->projs2, op->nproj2, rs, c->jr_pos, names, &nr, &c->err)) return cursor_fail(c);
+      if (nl != nr || nl == 0) { set_err(&c->err, RC_COUNT_MISMATCH, "hash join key selectors must pick the same number of columns%s%s", "", ""); return cursor_fail(c); }
+      for (int k = 0; k < nl; ++k)
+        if (in->a[c->jl_pos[k]].type != rs->a[c->jr_pos[k]].type) { set_err(&c->err, RC_TYPE_MISMATCH, "hash join key types differ%s%s", "", ""); return cursor_fail(c); }
+      c->nkeys = nl; c->join_type = op->join_type;
+      /* BoundMultiSourceProjector: entries in order, each bound against its source schema */
+      for (int q = 0; q < op->nproj3; ++q) {
+        const orc_schema* src = op->projs3[q].source == 0 ? in : rs;
+        int pos[ORC_MAX_COLS], n1 = 0; char nm[ORC_MAX_COLS][256];
+        if (!bind_projector(&op->projs3[q], 1, src, pos, nm, &n1, &c->err)) return cursor_fail(c);
+        for (int i = 0; i < n1; ++i) {
+          const int nullable = src->a[pos[i]].nullable || (op->projs3[q].source == 1 && op->join_type == 1);  /* LEFT_OUTER: rhs columns nullable */
+          if (!schema_add(&c->schema, nm[i], src->a[pos[i]].type, nullable)) { set_err(&c->err, RC_ATTRIBUTE_EXISTS, "Duplicate attribute name \"%s\" in result schema%s", nm[i], ""); return cursor_fail(c); }
+          c->out_src[c->nout_cols] = op->projs3[q].source; c->out_pos[c->nout_cols] = pos[i]; ++c->nout_cols;
+        }
+      }
+      block_init(&c->block, &c->schema, ORC_BLOCK);
+      c->match = (int64_t*)malloc(sizeof(int64_t) * ORC_BLOCK);
+      c->rhs_n = -1;
     } break;
     case C_SORT: {
       for (int i = 0; i < op->nsort; ++i) {
@@ -1167,6 +1210,72 @@ static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
         out->c[i].data = c->outs[i]->data; out->c[i].is_null = c->outs[i]->nulls;
       }
       return 1;
+    }
+    case C_HASH_JOIN: {
+      /* rhs: drained once into a table; then every lhs row looks its key up (NULL keys never
+       * match); INNER keeps matched rows, LEFT_OUTER keeps all with NULL rhs columns; output in
+       * lhs order (hash_join.cc HashJoinCursor, UNIQUE rhs keys) */
+      if (c->rhs_n < 0) {
+        block_init(&c->rhs_rows, &c->rhs->schema, ORC_BLOCK);
+        c->rhs_n = 0;
+        for (;;) {
+          orc_view rv; int r = cursor_next(c->rhs, ORC_BLOCK, &rv);
+          if (r < 0) { c->err = c->rhs->err; return -1; }
+          if (r == 0) break;
+          if (c->rhs_n + rv.rows > c->rhs_rows.cap) block_grow(&c->rhs_rows, (c->rhs_n + rv.rows) * 2);
+          for (int k = 0; k < c->rhs->schema.n; ++k) {
+            const int w = c->rhs_rows.width[k];
+            memcpy((char*)c->rhs_rows.data[k] + c->rhs_n * w, rv.c[k].data, (size_t)rv.rows * w);
+            if (rv.c[k].is_null) memcpy(c->rhs_rows.nulls[k] + c->rhs_n, rv.c[k].is_null, (size_t)rv.rows);
+            else memset(c->rhs_rows.nulls[k] + c->rhs_n, 0, (size_t)rv.rows);
+          }
+          c->rhs_n += rv.rows;
+        }
+        /* the device path requires UNIQUE keys: a repeated non-NULL key is an error here too */
+        for (int64_t a = 0; a < c->rhs_n; ++a) for (int64_t b = a + 1; b < c->rhs_n && c->rhs_n <= 4096; ++b) {
+          int same = 1;
+          for (int k = 0; k < c->nkeys && same; ++k) {
+            const int col = c->jr_pos[k]; const int w = c->rhs_rows.width[col];
+            if (c->rhs_rows.nulls[col][a] || c->rhs_rows.nulls[col][b]) same = 0;
+            else same = memcmp((char*)c->rhs_rows.data[col] + a * w, (char*)c->rhs_rows.data[col] + b * w, (size_t)w) == 0;
+          }
+          if (same) { set_err(&c->err, 407, "hash join: rhs keys declared UNIQUE but a key repeats%s%s", "", ""); return -1; }
+        }
+      }
+      for (;;) {
+        orc_view in; int r = cursor_next(c->child, max_rows, &in);
+        if (r <= 0) { if (r < 0) c->err = c->child->err; return r; }
+        int64_t nout = 0;
+        for (int64_t i = 0; i < in.rows; ++i) {
+          int64_t found = -1; int null_key = 0;
+          for (int k = 0; k < c->nkeys; ++k) if (in.c[c->jl_pos[k]].is_null && in.c[c->jl_pos[k]].is_null[i]) null_key = 1;
+          for (int64_t j = 0; j < c->rhs_n && !null_key && found < 0; ++j) {
+            int same = 1;
+            for (int k = 0; k < c->nkeys && same; ++k) {
+              const int col = c->jr_pos[k]; const int w = c->rhs_rows.width[col];
+              if (c->rhs_rows.nulls[col][j]) same = 0;
+              else same = memcmp((const char*)in.c[c->jl_pos[k]].data + i * w, (char*)c->rhs_rows.data[col] + j * w, (size_t)w) == 0;
+            }
+            if (same) found = j;
+          }
+          if (found < 0 && c->join_type == 0) continue;
+          for (int q = 0; q < c->nout_cols; ++q) {
+            const int w = c->block.width[q];
+            if (c->out_src[q] == 0) {
+              const orc_col* src = &in.c[c->out_pos[q]];
+              memcpy((char*)c->block.data[q] + nout * w, (const char*)src->data + i * w, (size_t)w);
+              c->block.nulls[q][nout] = src->is_null ? src->is_null[i] : 0;
+            } else if (found >= 0) {
+              memcpy((char*)c->block.data[q] + nout * w, (char*)c->rhs_rows.data[c->out_pos[q]] + found * w, (size_t)w);
+              c->block.nulls[q][nout] = c->rhs_rows.nulls[c->out_pos[q]][found];
+            } else { memset((char*)c->block.data[q] + nout * w, 0, (size_t)w); c->block.nulls[q][nout] = 1; }
+          }
+          ++nout;
+        }
+        if (nout == 0) continue;   /* nothing survived this input view: pull the next one */
+        view_from_block(c, &c->block, 0, nout, out);
+        return 1;
+      }
     }
     case C_PROJECT: {
       /* ProjectCursor::Next: pointer re-mapping (cursor/core/project.cc:49-59) */

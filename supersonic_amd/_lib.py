@@ -35,7 +35,10 @@ ERROR_HIP = 2001
 EXPR_ATTR_NAMED, EXPR_ATTR_AT, EXPR_CONST, EXPR_NULL, EXPR_OP, EXPR_ALIAS, EXPR_COMPOUND, EXPR_CAST = 1, 2, 3, 4, 5, 6, 7, 8
 OP_GREATER, OP_GREATER_OR_EQUAL = 100001, 100002
 PROJ_ALL, PROJ_NAMED, PROJ_AT, PROJ_NAMED_AS = 1, 2, 3, 4
+JOIN_INNER, JOIN_LEFT_OUTER = 0, 1
+KEYS_NOT_UNIQUE, KEYS_UNIQUE = 0, 1
 OP_SCAN, OP_COMPUTE, OP_FILTER, OP_PROJECT, OP_SCALAR_AGGREGATE, OP_GROUP_AGGREGATE, OP_AGGREGATE_CLUSTERS, OP_SORT = 1, 2, 3, 4, 5, 6, 7, 8
+OP_HASH_JOIN = 9
 
 
 class Attr(C.Structure):
@@ -49,7 +52,8 @@ class Expr(C.Structure):
 
 
 class Proj(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("position", C.c_int32), ("name", C.c_char_p), ("alias", C.c_char_p)]
+    _fields_ = [("kind", C.c_int32), ("position", C.c_int32), ("name", C.c_char_p), ("alias", C.c_char_p),
+                ("source", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Agg(C.Structure):
@@ -64,7 +68,8 @@ class SortKey(C.Structure):
 class Op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("child", C.c_int32), ("expr", C.c_int32), ("proj_first", C.c_int32),
                 ("proj_n", C.c_int32), ("agg_first", C.c_int32), ("agg_n", C.c_int32), ("sort_first", C.c_int32),
-                ("sort_n", C.c_int32), ("reserved", C.c_int32), ("option0", C.c_int64)]
+                ("sort_n", C.c_int32), ("child2", C.c_int32), ("option0", C.c_int64),
+                ("proj2_first", C.c_int32), ("proj2_n", C.c_int32), ("proj3_first", C.c_int32), ("proj3_n", C.c_int32)]
 
 
 class PlanDesc(C.Structure):
@@ -74,7 +79,8 @@ class PlanDesc(C.Structure):
                 ("expr_args", C.POINTER(C.c_int32)), ("n_expr_args", C.c_int32),
                 ("projs", C.POINTER(Proj)), ("n_projs", C.c_int32),
                 ("aggs", C.POINTER(Agg)), ("n_aggs", C.c_int32),
-                ("sortkeys", C.POINTER(SortKey)), ("n_sortkeys", C.c_int32)]
+                ("sortkeys", C.POINTER(SortKey)), ("n_sortkeys", C.c_int32),
+                ("aux_schema", C.POINTER(Attr)), ("n_aux_attrs", C.c_int32)]
 
 
 class Column(C.Structure):
@@ -122,6 +128,7 @@ SYMBOLS = [
     ("ssgpu_plan_program", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("ssgpu_plan_run", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_plan_run_block", C.c_int, [P, P, C.POINTER(P)]),
+    ("ssgpu_plan_set_aux_input", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64]),
     ("ssgpu_interrupt", None, [P]),
     ("ssgpu_plan_run_partial", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64]),
     ("ssgpu_plan_partial_segments", C.c_int32, [P, C.POINTER(PartialSegment), C.c_int32]),

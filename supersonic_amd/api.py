@@ -493,7 +493,7 @@ class SingleSourceProjector(object):
         self.entries = list(entries)  # (kind, position, name, alias)
 
 
-def ProjectAllAttributes(): return SingleSourceProjector([(L.PROJ_ALL, 0, None, None)])
+def ProjectAllAttributes(prefix=None): return SingleSourceProjector([(L.PROJ_ALL, 0, None, prefix)])
 def ProjectNamedAttribute(name): return SingleSourceProjector([(L.PROJ_NAMED, 0, name, None)])
 def ProjectNamedAttributeAs(name, alias): return SingleSourceProjector([(L.PROJ_NAMED_AS, 0, name, alias)])
 def ProjectAttributeAt(position): return SingleSourceProjector([(L.PROJ_AT, position, None, None)])
@@ -507,6 +507,22 @@ class CompoundSingleSourceProjector(SingleSourceProjector):
     def add(self, projector):
         self.entries.extend(projector.entries)
         return self
+
+
+class CompoundMultiSourceProjector(object):
+    """base/infrastructure/projector.h:422-441: (source index, SingleSourceProjector) pairs."""
+
+    def __init__(self):
+        self.entries = []      # (source, kind, position, name, alias)
+
+    def add(self, source_index, projector):
+        for (k, pos, name, alias) in projector.entries:
+            self.entries.append((int(source_index), k, pos, name, alias))
+        return self
+
+
+INNER, LEFT_OUTER = L.JOIN_INNER, L.JOIN_LEFT_OUTER
+NOT_UNIQUE, UNIQUE = L.KEYS_NOT_UNIQUE, L.KEYS_UNIQUE
 
 
 class AggregationSpecification(object):
@@ -556,6 +572,8 @@ class _Builder(object):
         self.exprs, self.expr_args, self.projs, self.aggs, self.sortkeys, self.ops = [], [], [], [], [], []
         self.keep = []
         self.scan = None
+        self.scan_aux = None         # rhs table of a HashJoin (auxiliary input)
+        self.aux = False             # emitting the rhs subtree
         self.strings = StringDictionary([])
 
     def s(self, text):
@@ -578,8 +596,12 @@ class _Builder(object):
 
     def proj(self, p):
         first = len(self.projs)
-        for (k, pos, name, alias) in p.entries:
-            self.projs.append(L.Proj(k, pos, self.s(name), self.s(alias)))
+        for entry in p.entries:
+            source = 0
+            if len(entry) == 5:
+                source, entry = entry[0], entry[1:]
+            (k, pos, name, alias) = entry
+            self.projs.append(L.Proj(k, pos, self.s(name), self.s(alias), source, 0))
         return first, len(p.entries)
 
     def aggspec(self, spec):
@@ -596,8 +618,9 @@ class _Builder(object):
 
     def op(self, **kw):
         o = L.Op(kw.get("kind"), kw.get("child", -1), kw.get("expr", -1), kw.get("proj_first", 0), kw.get("proj_n", 0),
-                 kw.get("agg_first", 0), kw.get("agg_n", 0), kw.get("sort_first", 0), kw.get("sort_n", 0), 0,
-                 kw.get("option0", 0))
+                 kw.get("agg_first", 0), kw.get("agg_n", 0), kw.get("sort_first", 0), kw.get("sort_n", 0),
+                 kw.get("child2", -1), kw.get("option0", 0), kw.get("proj2_first", 0), kw.get("proj2_n", 0),
+                 kw.get("proj3_first", 0), kw.get("proj3_n", 0))
         self.ops.append(o)
         return len(self.ops) - 1
 
@@ -616,6 +639,9 @@ class ScanView(Operation):
         self.view = view
 
     def _emit(self, b):
+        if b.aux:
+            b.scan_aux = self.view
+            return b.op(kind=L.OP_SCAN, option0=1)
         b.scan = self.view
         return b.op(kind=L.OP_SCAN)
 
@@ -694,6 +720,31 @@ class Sort(Operation):
                     option0=int(self.memory_limit or 0))
 
 
+class HashJoinOperation(Operation):
+    """cursor/core/hash_join.h:37-56.  On the device the rhs must be ScanView(table) -- a resident
+    dimension table -- and its keys UNIQUE; the probe is fused into the lhs pipeline."""
+
+    def __init__(self, join_type, lhs_key_selector, rhs_key_selector, result_projector, rhs_key_uniqueness, lhs_child, rhs_child):
+        self.join_type, self.lhs_keys, self.rhs_keys = join_type, lhs_key_selector, rhs_key_selector
+        self.result_projector, self.uniqueness = result_projector, rhs_key_uniqueness
+        self.child, self.rhs_child = lhs_child, rhs_child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        b.aux = True
+        r = self.rhs_child._emit(b)
+        b.aux = False
+        pf, pn = b.proj(self.lhs_keys)
+        p2f, p2n = b.proj(self.rhs_keys)
+        p3f, p3n = b.proj(self.result_projector)
+        return b.op(kind=L.OP_HASH_JOIN, child=c, child2=r, proj_first=pf, proj_n=pn, proj2_first=p2f, proj2_n=p2n,
+                    proj3_first=p3f, proj3_n=p3n, option0=int(self.join_type) | (int(self.uniqueness) << 8))
+
+
+def HashJoin(join_type, lhs_key_selector, rhs_key_selector, result_projector, rhs_key_uniqueness, lhs_child, rhs_child):
+    return HashJoinOperation(join_type, lhs_key_selector, rhs_key_selector, result_projector, rhs_key_uniqueness, lhs_child, rhs_child)
+
+
 def _array(ctype, items):
     arr = (ctype * max(len(items), 1))()
     for i, it in enumerate(items):
@@ -729,6 +780,7 @@ def collect_strings(operation):
                         if col.is_null is None or not col.is_null[j]:
                             found.append(v)
         walk_op(getattr(o, "child", None))
+        walk_op(getattr(o, "rhs_child", None))
     walk_op(operation)
     return found
 
@@ -760,6 +812,13 @@ class Plan(object):
         d.projs, d.n_projs = self._arrays[4], len(b.projs)
         d.aggs, d.n_aggs = self._arrays[5], len(b.aggs)
         d.sortkeys, d.n_sortkeys = self._arrays[6], len(b.sortkeys)
+        self.aux_input = b.scan_aux
+        if b.scan_aux is not None:
+            asch = b.scan_aux.schema()
+            aux_attrs = [L.Attr(b.s(asch.attribute(i).name()), asch.attribute(i).type(), asch.attribute(i).nullability())
+                         for i in range(asch.attribute_count())]
+            self._arrays.append(_array(L.Attr, aux_attrs))
+            d.aux_schema, d.n_aux_attrs = self._arrays[-1], len(aux_attrs)
         h = C.c_void_p()
         rc = self.lib.ssgpu_plan_create(context.handle, C.byref(d), C.byref(h))
         context.check(rc)
@@ -773,6 +832,8 @@ class Plan(object):
         self.result_schema = TupleSchema(out)
         self._block = None
         self._block_key = None
+        self._aux_block = None
+        self._aux_block_key = None
 
     def describe(self):
         return self.lib.ssgpu_plan_describe(self.handle).decode()
@@ -784,7 +845,7 @@ class Plan(object):
         return C.string_at(ptr, n.value * nb.value), n.value, nb.value
 
     # -- input staging ------------------------------------------------------------
-    def _columns_for(self, view):
+    def _columns_for(self, view, slot="_block"):
         if isinstance(view, DeviceView):
             cols = (L.Column * max(len(view._ptrs), 1))()
             for i, (dp, npn) in enumerate(view._ptrs):
@@ -794,10 +855,10 @@ class Plan(object):
         # host View: stage into a device Block on the copy stream (pinned staging is the
         # caller's choice; numpy memory is pageable, which only makes the copy synchronous)
         key = id(view)
-        if self._block is None or self._block_key != key:
-            if self._block is not None:
-                self.lib.ssgpu_block_destroy(self._block)
-                self._block = None
+        if getattr(self, slot) is None or getattr(self, slot + "_key") != key:
+            if getattr(self, slot) is not None:
+                self.lib.ssgpu_block_destroy(getattr(self, slot))
+                setattr(self, slot, None)
             schema = view.schema()
             attrs = _array(L.Attr, [L.Attr(schema.attribute(i).name().encode(), schema.attribute(i).type(),
                                            schema.attribute(i).nullability()) for i in range(schema.attribute_count())])
@@ -815,15 +876,22 @@ class Plan(object):
                         None if nulls is None else nulls.ctypes.data_as(C.c_void_p), 0, view.row_count()))
             self.lib.ssgpu_block_set_row_count(blk, view.row_count())
             self.ctx.synchronize()
-            self._block, self._block_key = blk, key
+            setattr(self, slot, blk); setattr(self, slot + "_key", key)
         n = view.schema().attribute_count()
         cols = (L.Column * max(n, 1))()
         for i in range(n):
-            self.lib.ssgpu_block_column(self._block, i, C.byref(cols[i]))
+            self.lib.ssgpu_block_column(getattr(self, slot), i, C.byref(cols[i]))
         return cols, n, view.row_count()
 
     # -- execution ------------------------------------------------------------------
+    def _bind_aux(self):
+        if self.aux_input is not None:
+            cols, n, rows = self._columns_for(self.aux_input, "_aux_block")
+            self._aux_cols = cols    # keep the ctypes array alive
+            self.ctx.check(self.lib.ssgpu_plan_set_aux_input(self.handle, cols, n, rows))
+
     def run(self, view=None):
+        self._bind_aux()
         cols, n, rows = self._columns_for(view if view is not None else self.input)
         res = C.c_void_p()
         self.ctx.check(self.lib.ssgpu_plan_run(self.handle, cols, n, rows, C.byref(res)))
@@ -878,6 +946,8 @@ class Plan(object):
 
     def __del__(self):
         try:
+            if getattr(self, "_aux_block", None):
+                self.lib.ssgpu_block_destroy(self._aux_block)
             if getattr(self, "_block", None):
                 self.lib.ssgpu_block_destroy(self._block)
             if getattr(self, "handle", None):

@@ -74,6 +74,11 @@ Status copy_plan_desc(const ssgpu_plan_desc* d, PlanDesc* out) {
     a.dtype = d->input_schema[i].dtype; a.nullable = d->input_schema[i].nullable != 0;
     out->input_schema.push_back(a);
   }
+  for (int i = 0; i < d->n_aux_attrs && d->aux_schema; ++i) {
+    Attr a; a.name = d->aux_schema[i].name ? d->aux_schema[i].name : "";
+    a.dtype = d->aux_schema[i].dtype; a.nullable = d->aux_schema[i].nullable != 0;
+    out->aux_schema.push_back(a);
+  }
   out->ops.assign(d->ops, d->ops + d->n_ops);
   out->exprs.assign(d->exprs, d->exprs + d->n_exprs);
   for (auto& e : out->exprs) e.name = keep(e.name);
@@ -98,8 +103,8 @@ Status bind_projector(const PlanDesc& d, int first, int n, const Schema& schema,
   for (int i = 0; i < n; ++i) {
     const ssgpu_proj& p = d.projs[first + i];
     switch (p.kind) {
-      case SSGPU_PROJ_ALL:
-        for (size_t c = 0; c < schema.size(); ++c) { positions->push_back((int)c); names->push_back(schema[c].name); }
+      case SSGPU_PROJ_ALL:   // ProjectAllAttributes(prefix): the optional prefix travels in `alias`
+        for (size_t c = 0; c < schema.size(); ++c) { positions->push_back((int)c); names->push_back(std::string(p.alias ? p.alias : "") + schema[c].name); }
         break;
       case SSGPU_PROJ_NAMED:
       case SSGPU_PROJ_NAMED_AS: {

@@ -47,12 +47,13 @@ std::string schema_to_string(const Schema& s);
 struct BExpr;
 typedef std::shared_ptr<BExpr> BExprP;
 struct BExpr {
-  enum Kind { INPUT, CONST, NULLCONST, OP, CAST } kind = INPUT;
+  enum Kind { INPUT, CONST, NULLCONST, OP, CAST, JOINCOL, JOINMATCH } kind = INPUT;
   int op = 0;          // reference OperatorId for OP
   int dtype = SSGPU_INT64;
   bool nullable = false;
   std::string name;
-  int input_col = -1;  // INPUT: column of the stage input
+  int input_col = -1;  // INPUT: column of the stage input; JOINCOL: column of the join's rhs table
+  int join_id = -1;    // JOINCOL / JOINMATCH: index into the stage's joins
   uint64_t bits = 0;   // CONST: raw value bits in the column's device width
   int filter_depth = 0;  // number of Filter operations below this expression
   std::vector<BExprP> args;
@@ -79,6 +80,17 @@ struct GroupKeyField { int out_col; uint32_t shift, bits, nullbit, width; };
 
 struct SortKey { int col; int order; };
 
+// HashJoin fused into a pipeline (hash_join.h:37-56, UNIQUE rhs keys): lhs key expressions are
+// packed like group keys, probed against an index built over the rhs table (the plan's auxiliary
+// input) and the referenced rhs columns are gathered by the matched row.
+struct JoinSpec {
+  int type = 0;                          // SSGPU_JOIN_INNER / SSGPU_JOIN_LEFT_OUTER
+  std::vector<BExprP> lhs_keys;          // over the stage input
+  std::vector<int> rhs_key_cols;         // columns of the auxiliary input
+  std::vector<GroupKeyField> fields;     // packing of the 64-bit key (nullbit only for nullable lhs keys)
+};
+struct JoinGather { int join_id; int rhs_col; bool is_null_mask; };  // slot i of VmParams.join_cols
+
 // Lowered instruction over virtual registers.  A register is an LDS array of
 // tile_rows elements; its LDS byte offset is row_off * tile_rows, fixed when the
 // tile size is chosen (finalize_program).
@@ -98,6 +110,7 @@ struct Program {
   std::vector<LInstr> code;
   std::vector<LReg> regs;
   std::vector<StagedInput> staged;
+  std::vector<JoinGather> gathers;   // rhs columns (and NULL masks) read by GATHER_* instructions
   uint32_t bytes_per_row = 0;   // LDS bytes per tile row (peak of live registers)
   uint32_t in_bytes_per_row = 0;  // of which: the staged input registers
   int n_slots = 0;
@@ -124,6 +137,7 @@ struct Stage {
   std::vector<uint32_t> part_col_width;   // partition buffer columns: [0] = packed key (8), then values / NULL masks
   struct PartAgg { int op; int val_col; int null_col; int has_cnt; };
   std::vector<PartAgg> part_aggs;         // one per aggregate: GAGG opcode + its partition columns (-1 = none)
+  std::vector<JoinSpec> joins;            // HashJoins fused into this stage's programs
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns
   int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row
@@ -133,6 +147,7 @@ struct Stage {
 // ---- plan description (host copy of ssgpu_plan_desc with owned strings) --------
 struct PlanDesc {
   Schema input_schema;
+  Schema aux_schema;                 // auxiliary input (rhs of a HASH_JOIN)
   std::vector<ssgpu_op> ops;
   std::vector<ssgpu_expr> exprs;
   std::vector<int32_t> expr_args;

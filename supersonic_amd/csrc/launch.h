@@ -59,6 +59,24 @@ struct PartAggParams {
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
 hipError_t ssgpu_part_agg_set_max_lds(int bytes);
 
+// HashJoin index over the rhs table: packed 64-bit key (same packing as the lhs KEY_APPEND
+// instructions) -> rhs row.  Rows with a NULL key are not indexed (they can never match);
+// a second row with an already indexed key raises flags[0] (the join was declared UNIQUE).
+struct JoinBuildParams {
+  const void* key_data[8];
+  const unsigned char* key_nulls[8];
+  unsigned int width[8], shift[8], bits[8];
+  unsigned int n_keys;
+  unsigned int capacity_mask;
+  unsigned long long n_rows;
+  unsigned long long* keys;     // capacity entries, pre-filled with VM_KEY_EMPTY
+  unsigned int* rows;
+  unsigned int* special;        // pre-filled with VM_NONE
+  unsigned int* flags;          // pre-zeroed
+};
+hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream);
+hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream);
+
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream);
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,

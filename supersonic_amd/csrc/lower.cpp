@@ -59,7 +59,7 @@ struct Val {
 
 class Emitter {
  public:
-  explicit Emitter(Program* p) : P(p) {}
+  explicit Emitter(Program* p, const std::vector<JoinSpec>* joins = nullptr) : P(p), joins_(joins) {}
 
   int new_reg(uint32_t width) { LReg r; r.width = width; r.row_off = 0; P->regs.push_back(r); return (int)P->regs.size() - 1; }
   LInstr& emit(uint16_t op) { LInstr i; i.op = op; P->code.push_back(i); return P->code.back(); }
@@ -125,7 +125,19 @@ class Emitter {
 
   Program* P;
 
+  // HashJoin: matched rhs row of every lhs row (u32 register, VM_NONE = no match); emitted once
+  Status join_index(int join_id, int* reg);
+  int gather_slot(int join_id, int rhs_col, bool is_null) {
+    for (size_t i = 0; i < P->gathers.size(); ++i)
+      if (P->gathers[i].join_id == join_id && P->gathers[i].rhs_col == rhs_col && P->gathers[i].is_null_mask == is_null) return (int)i;
+    JoinGather g; g.join_id = join_id; g.rhs_col = rhs_col; g.is_null_mask = is_null;
+    P->gathers.push_back(g);
+    return (int)P->gathers.size() - 1;
+  }
+
  private:
+  const std::vector<JoinSpec>* joins_;
+  std::map<int, int> join_idx_;
   std::string key_of(const BExprP& e);
   std::map<std::pair<int, bool>, int> staged_;
   std::map<std::string, Val> memo_;
@@ -138,6 +150,8 @@ std::string Emitter::key_of(const BExprP& e) {
     case BExpr::INPUT: s << "I" << e->input_col; break;
     case BExpr::CONST: s << "C" << e->dtype << ":" << e->bits; break;
     case BExpr::NULLCONST: s << "N" << e->dtype; break;
+    case BExpr::JOINCOL: s << "J" << e->join_id << ":" << e->input_col; break;
+    case BExpr::JOINMATCH: s << "M" << e->join_id; break;
     default:
       s << (e->kind == BExpr::CAST ? "K" : "O") << e->op << ":" << e->dtype << ":" << e->filter_depth << "(";
       for (auto& a : e->args) s << key_of(a) << ",";
@@ -181,6 +195,31 @@ static uint16_t pick(MT m, uint16_t i32, uint16_t u32, uint16_t i64, uint16_t u6
   }
 }
 
+Status Emitter::join_index(int join_id, int* reg) {
+  auto it = join_idx_.find(join_id);
+  if (it != join_idx_.end()) { *reg = it->second; return Status::OK(); }
+  if (!joins_ || join_id < 0 || join_id >= (int)joins_->size()) return Status::Error(SSGPU_ERROR_UNKNOWN, "join reference outside its stage");
+  const JoinSpec& js = (*joins_)[join_id];
+  // pack the lhs key exactly as the index build packs the rhs key (JoinBuildParams)
+  int keyreg = new_reg(8);
+  { LInstr& i = emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
+  int any_null = -1;   // a NULL in any key column: the row matches nothing
+  for (size_t k = 0; k < js.lhs_keys.size(); ++k) {
+    Val v; SS_RETURN_IF_ERROR(value(js.lhs_keys[k], &v));
+    const GroupKeyField& f = js.fields[k];
+    int vr = materialize(v);
+    LInstr& i = emit(f.width == 8 ? VM_KEY_APPEND_64 : f.width == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
+    i.dst = keyreg; i.a = vr; i.b = -1;
+    i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
+    any_null = or_null(any_null, v.null);
+  }
+  const int idx = new_reg(4);
+  { LInstr& i = emit(VM_JOIN_PROBE); i.dst = idx; i.a = keyreg; i.b = any_null; i.imm = (uint64_t)join_id; }
+  join_idx_[join_id] = idx;
+  *reg = idx;
+  return Status::OK();
+}
+
 Status Emitter::value(const BExprP& e, Val* out) {
   const std::string key = key_of(e);
   auto it = memo_.find(key);
@@ -197,6 +236,21 @@ Status Emitter::value(const BExprP& e, Val* out) {
       break;
     case BExpr::CONST: v.imm = true; v.bits = e->bits; break;
     case BExpr::NULLCONST: v.imm = true; v.bits = 0; v.null = const_null_reg(); break;
+    case BExpr::JOINMATCH: {
+      int idx; SS_RETURN_IF_ERROR(join_index(e->join_id, &idx));
+      v.reg = new_reg(1);
+      LInstr& i = emit(VM_IDX_VALID); i.dst = v.reg; i.a = idx;
+    } break;
+    case BExpr::JOINCOL: {
+      int idx; SS_RETURN_IF_ERROR(join_index(e->join_id, &idx));
+      v.reg = new_reg(v.width);
+      { LInstr& i = emit(v.width == 8 ? VM_GATHER_64 : v.width == 4 ? VM_GATHER_32 : VM_GATHER_8);
+        i.dst = v.reg; i.a = idx; i.imm = (uint64_t)gather_slot(e->join_id, e->input_col, false); }
+      if (e->nullable) {
+        v.null = new_reg(1);
+        LInstr& i = emit(VM_GATHER_NULL); i.dst = v.null; i.a = idx; i.imm = (uint64_t)gather_slot(e->join_id, e->input_col, true);
+      }
+    } break;
     case BExpr::CAST: {
       Val a; SS_RETURN_IF_ERROR(value(e->args[0], &a));
       SS_RETURN_IF_ERROR(cast_val(a, mtype(e->args[0]->dtype), mt, &v));
@@ -674,11 +728,12 @@ struct Pipe {
   Schema in_schema;                // stage input
   std::vector<VCol> cols;          // current virtual schema over the stage input
   std::vector<BExprP> filters;     // predicates in order; filter i was bound at depth i
+  std::vector<JoinSpec> joins;     // HashJoins fused into this pipeline
   int depth() const { return (int)filters.size(); }
 };
 
 static void reset_pipe(Pipe* p, const Schema& in) {
-  p->in_schema = in; p->cols.clear(); p->filters.clear();
+  p->in_schema = in; p->cols.clear(); p->filters.clear(); p->joins.clear();
   for (size_t i = 0; i < in.size(); ++i) {
     BExprP e(new BExpr);
     e->kind = BExpr::INPUT; e->input_col = (int)i; e->dtype = in[i].dtype; e->nullable = in[i].nullable; e->name = in[i].name;
@@ -721,7 +776,8 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
   std::vector<AggPlan> plans;
   SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, vs, &plans));
   if ((int)plans.size() > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
-  Emitter em(&st->main);
+  st->joins = pipe.joins;
+  Emitter em(&st->main, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
   // COUNT(*) (or COUNT of a never-NULL column) under the same selection equals the contribution
@@ -810,7 +866,8 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
         return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS, "Duplicate attribute name \"" + kn + "\" in result schema");
   if ((int)plans.size() > VM_MAX_AGG_SLOTS || kpos.size() > 16)
     return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many keys/aggregations for one pipeline");
-  Emitter em(&st->main);
+  st->joins = pipe.joins;
+  Emitter em(&st->main, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
   int slotreg = -1;
@@ -918,13 +975,13 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     return Status::OK();
   };
   {
-    Emitter em(&st->part_count);
+    Emitter em(&st->part_count, &pipe.joins);
     SS_RETURN_IF_ERROR(emit_filters(em, pipe));
     int keyreg; SS_RETURN_IF_ERROR(pack_key(em, &keyreg));
     LInstr& i = em.emit(VM_PART_COUNT); i.dst_is_reg = false; i.dst = 0; i.a = keyreg; i.c = em.sel_by_depth.back();
     allocate_registers(&st->part_count);
   }
-  Emitter em(&st->part_scatter);
+  Emitter em(&st->part_scatter, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
   int keyreg; SS_RETURN_IF_ERROR(pack_key(em, &keyreg));
@@ -976,12 +1033,13 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
   st->out_schema = schema_of(pipe.cols);
   st->has_filter = !pipe.filters.empty();
   if (st->has_filter) {
-    Emitter ec(&st->count_pass);
+    Emitter ec(&st->count_pass, &pipe.joins);
     SS_RETURN_IF_ERROR(emit_filters(ec, pipe));
     LInstr& i = ec.emit(VM_SEL_COUNT); i.dst_is_reg = false; i.dst = 0; i.a = ec.sel_by_depth.back();
     allocate_registers(&st->count_pass);
   }
-  Emitter em(&st->main);
+  st->joins = pipe.joins;
+  Emitter em(&st->main, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
   int rank = -1;
@@ -1074,6 +1132,69 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         pipe.cols = nc; pending = true;
         desc << "Filter " << bound[0]->name << " -> [" << schema_to_string(schema_of(pipe.cols)) << "]\n";
       } break;
+      case SSGPU_OP_HASH_JOIN: {
+        // HashJoinOperation (hash_join.h:37-56): the probe and the rhs gathers join the lhs pipeline
+        const int jtype = (int)(op.option0 & 0xFF), uniq = (int)((op.option0 >> 8) & 0xFF);
+        if (jtype != SSGPU_JOIN_INNER && jtype != SSGPU_JOIN_LEFT_OUTER)
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "only INNER and LEFT_OUTER hash joins are on device");
+        if (uniq != SSGPU_KEYS_UNIQUE)
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join with NOT_UNIQUE rhs keys (row multiplication) is not on device yet");
+        if (op.child2 < 0 || op.child2 >= (int)d.ops.size() || d.ops[op.child2].kind != SSGPU_OP_SCAN || d.ops[op.child2].option0 != 1)
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "the rhs of a device hash join must be a scan of the auxiliary input (a resident table)");
+        if ((int)pipe.joins.size() >= VM_MAX_JOINS)
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many hash joins in one pipeline");
+        const Schema& rs = d.aux_schema;
+        std::vector<int> lpos, rpos; std::vector<std::string> lnames, rnames;
+        SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, vs, &lpos, &lnames));
+        SS_RETURN_IF_ERROR(bind_projector(d, op.proj2_first, op.proj2_n, rs, &rpos, &rnames));
+        if (lpos.size() != rpos.size() || lpos.empty())
+          return Status::Error(SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH, "hash join key selectors must pick the same, non-zero number of columns");
+        JoinSpec js; js.type = jtype;
+        uint32_t shift = 0;
+        for (size_t k = 0; k < lpos.size(); ++k) {
+          const BExprP& le = pipe.cols[lpos[k]].expr;
+          if (le->dtype != rs[rpos[k]].dtype)
+            return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("hash join key types differ: ") + dtype_name(le->dtype) + " vs " + dtype_name(rs[rpos[k]].dtype));
+          const uint32_t w = (uint32_t)dtype_width(le->dtype);
+          if (w == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join key type is outside the device hot path");
+          GroupKeyField f; f.out_col = (int)k; f.shift = shift; f.bits = w * 8; f.width = w;
+          f.nullbit = 0xFF;   // NULL keys never match: lhs NULLs are masked after the probe, rhs NULL rows are not indexed
+          shift += f.bits;
+          if (shift > 64) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join keys wider than 64 packed bits are not on device yet");
+          js.lhs_keys.push_back(le); js.rhs_key_cols.push_back(rpos[k]); js.fields.push_back(f);
+        }
+        const int join_id = (int)pipe.joins.size();
+        std::vector<VCol> nc;
+        for (int q = 0; q < op.proj3_n; ++q) {
+          const ssgpu_proj& pr = d.projs[op.proj3_first + q];
+          std::vector<int> pos; std::vector<std::string> names;
+          SS_RETURN_IF_ERROR(bind_projector(d, op.proj3_first + q, 1, pr.source == 0 ? vs : rs, &pos, &names));
+          for (size_t i = 0; i < pos.size(); ++i) {
+            VCol c;
+            if (pr.source == 0) { c = pipe.cols[pos[i]]; }
+            else if (pr.source == 1) {
+              BExprP e(new BExpr);
+              e->kind = BExpr::JOINCOL; e->join_id = join_id; e->input_col = pos[i]; e->dtype = rs[pos[i]].dtype;
+              e->nullable = rs[pos[i]].nullable || jtype == SSGPU_JOIN_LEFT_OUTER;   // hash_join.h:39-40
+              e->name = names[i]; e->filter_depth = pipe.depth();
+              if (dtype_width(e->dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "rhs column type is outside the device hot path");
+              c.expr = e;
+            } else return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "hash join result projector: source index must be 0 or 1");
+            c.name = names[i];
+            for (auto& o : nc) if (o.name == c.name) return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS, "Duplicate attribute name \"" + c.name + "\" in result schema");
+            nc.push_back(c);
+          }
+        }
+        if (jtype == SSGPU_JOIN_INNER) {   // rows without a match are dropped: one more (never-NULL) filter
+          BExprP m(new BExpr);
+          m->kind = BExpr::JOINMATCH; m->join_id = join_id; m->dtype = SSGPU_BOOL; m->nullable = false;
+          m->name = "JOIN_MATCH"; m->filter_depth = pipe.depth();
+          pipe.filters.push_back(m);
+        }
+        pipe.joins.push_back(js);
+        pipe.cols = nc; pending = true;
+        desc << (jtype == SSGPU_JOIN_INNER ? "HashJoin INNER" : "HashJoin LEFT_OUTER") << " -> [" << schema_to_string(schema_of(pipe.cols)) << "]\n";
+      } break;
       case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: {
         Stage st;
         if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
@@ -1127,6 +1248,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
     Stage m; SS_RETURN_IF_ERROR(finish_materialize(pipe, &m));
     stages->push_back(m);
   }
+  for (auto& st : *stages)
+    for (const Program* pr : {&st.main, &st.count_pass, &st.part_count, &st.part_scatter})
+      if (pr->gathers.size() > VM_MAX_JOIN_COLS)
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many rhs columns gathered by the hash joins of one pipeline");
   *result_schema = stages->back().out_schema;
   for (size_t i = 0; i < stages->size(); ++i) {
     desc << "stage " << i << " kind=" << (*stages)[i].kind << "\n" << disassemble((*stages)[i].main);

@@ -1646,6 +1646,65 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           }
           WG_BARRIER();
         } break;
+        // ---- HashJoin probe + gathers (see VmJoin in vm.h) -------------------------------------
+        case VM_JOIN_PROBE: { CASE_FENCE;
+          const VmJoin J = P.join[I.imm & (VM_MAX_JOINS - 1)];
+          _Pragma("unroll") FOR_PAIRS {
+            auto kk = lds_load2<u64>(I.a, p);
+            u32 r[2];
+            const u64 key2[2] = {kk.x, kk.y};
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {
+              const u64 key = key2[j];
+              u32 found = VM_NONE;
+              if (key == VM_KEY_EMPTY) {
+                found = J.special[0];
+              } else {
+                u32 slot = hash64(key) & J.capacity_mask;
+                for (u32 probe = 0; probe <= J.capacity_mask; ++probe) {
+                  const u64 cur = J.keys[slot];
+                  if (cur == key) { found = J.rows[slot]; break; }
+                  if (cur == VM_KEY_EMPTY) break;
+                  slot = (slot + 1) & J.capacity_mask;
+                }
+              }
+              r[j] = found;
+            }
+            if (I.b != VM_NONE) {   // NULL key: no match
+              auto z = lds_load2<u8>(I.b, p);
+              if (z.x) r[0] = VM_NONE;
+              if (z.y) r[1] = VM_NONE;
+            }
+            lds_store2<u32>(I.dst, p, r[0], r[1]);
+          }
+        } break;
+        case VM_IDX_VALID: { CASE_FENCE;
+          _Pragma("unroll") FOR_PAIRS {
+            auto ix = lds_load2<u32>(I.a, p);
+            lds_store2<u8>(I.dst, p, (u8)(ix.x != VM_NONE), (u8)(ix.y != VM_NONE));
+          }
+        } break;
+#define GATHER_OP(OPNAME, T)                                                   \
+        case VM_##OPNAME: { CASE_FENCE;                                        \
+          const T* col = reinterpret_cast<const T*>(P.join_cols[I.imm].data);  \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            auto ix = lds_load2<u32>(I.a, p);                                  \
+            const T v0 = ix.x != VM_NONE ? col[ix.x] : (T)0;                   \
+            const T v1 = ix.y != VM_NONE ? col[ix.y] : (T)0;                   \
+            lds_store2<T>(I.dst, p, v0, v1);                                   \
+          }                                                                    \
+        } break;
+        GATHER_OP(GATHER_64, u64)
+        GATHER_OP(GATHER_32, u32)
+        GATHER_OP(GATHER_8, u8)
+        case VM_GATHER_NULL: { CASE_FENCE;   // NULL where nothing matched or the rhs value is NULL
+          const u8* nl = P.join_cols[I.imm].is_null;
+          _Pragma("unroll") FOR_PAIRS {
+            auto ix = lds_load2<u32>(I.a, p);
+            const u8 z0 = ix.x == VM_NONE ? (u8)1 : (nl ? (u8)(nl[ix.x] != 0) : (u8)0);
+            const u8 z1 = ix.y == VM_NONE ? (u8)1 : (nl ? (u8)(nl[ix.y] != 0) : (u8)0);
+            lds_store2<u8>(I.dst, p, z0, z1);
+          }
+        } break;
         // ---- hash partitioning of the rows of a GroupAggregate with many groups ----------
         // The partition counters live in LDS for the whole kernel (per WORKGROUP, not per tile: the
         // persistent workgroup sees the same tiles in the count pass and in the scatter pass, so
@@ -2180,6 +2239,41 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS) void ssgpu_part_agg_kernel(cons
   }
 }
 
+// ---------------------------------------------------------------------------
+// HashJoin index build (see JoinBuildParams in launch.h)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ssgpu_join_build_kernel(const JoinBuildParams P) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.n_rows) return;
+  u64 key = 0;
+  for (u32 k = 0; k < P.n_keys; ++k) {
+    if (P.key_nulls[k] && P.key_nulls[k][i]) return;   // NULL never equals anything: not indexed
+    u64 v;
+    if (P.width[k] == 8) v = reinterpret_cast<const u64*>(P.key_data[k])[i];
+    else if (P.width[k] == 4) v = reinterpret_cast<const u32*>(P.key_data[k])[i];
+    else v = reinterpret_cast<const u8*>(P.key_data[k])[i];
+    const u64 vmask = P.bits[k] >= 64 ? ~0ull : ((1ull << P.bits[k]) - 1ull);
+    key |= (v & vmask) << P.shift[k];
+  }
+  if (key == VM_KEY_EMPTY) {
+    if (atomicCAS(P.special, VM_NONE, (u32)i) != VM_NONE) atomicExch(&P.flags[0], 1u);
+    return;
+  }
+  u32 slot = hash64(key) & P.capacity_mask;
+  for (u32 probe = 0; probe <= P.capacity_mask; ++probe) {
+    const u64 old = atomicCAS(&P.keys[slot], VM_KEY_EMPTY, key);
+    if (old == VM_KEY_EMPTY) { P.rows[slot] = (u32)i; return; }
+    if (old == key) { atomicExch(&P.flags[0], 1u); return; }     // duplicate key in a UNIQUE rhs
+    slot = (slot + 1) & P.capacity_mask;
+  }
+  atomicExch(&P.flags[0], 2u);
+}
+__global__ void ssgpu_fill_u32_kernel(u32* __restrict__ p, u32 v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
 // fill helpers (table initialisation without a host round trip)
 __global__ void ssgpu_fill_u64_kernel(u64* __restrict__ p, u64 v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2205,6 +2299,14 @@ hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t
     case 4: hipLaunchKernelGGL(ssgpu_pipeline_kernel<4>, g, b, lds, stream, P); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream) {
+  if (P.n_rows) hipLaunchKernelGGL(ssgpu_join_build_kernel, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, stream, P);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(ssgpu_fill_u32_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, p, v, n);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream) {

@@ -96,6 +96,9 @@ struct StageExec {
   ProgramLayout lay_pcount{}, lay_pscatter{};
   int n_instr_pcount = 0, n_instr_pscatter = 0;
   std::vector<DevBuf> part_cols;
+  // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
+  std::vector<DevBuf> jkeys, jrows, jmisc;
+  std::vector<VmJoin> vm_joins;
   uint32_t capacity = 0;
   DevBuf error_flag;
   DevBuf debug, debug_pc, total2;
@@ -122,6 +125,8 @@ struct ssgpu_plan {
   std::vector<StageExec> exec;
   Schema result_schema;
   std::vector<std::string> attr_names;  // stable c_str for ssgpu_plan_attr
+  std::vector<ssgpu_column> aux_cols;   // auxiliary input (rhs table of a HASH_JOIN), device pointers
+  int64_t aux_rows = -1;
   std::string describe, describe_full;
   std::atomic<int> interrupted{0};
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
@@ -454,6 +459,54 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   return SSGPU_OK;
 }
 
+// ---- hash joins fused into a stage -------------------------------------------------------------
+// The index over the rhs table is rebuilt at the start of every run of the stage (dimension
+// tables are small next to the probing side; the build is one launch of ssgpu_join_build_kernel).
+int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
+  ssgpu_ctx* c = p->ctx;
+  if (st.joins.empty()) return SSGPU_OK;
+  if (p->aux_rows < 0) { c->err = "this plan joins against an auxiliary input: call ssgpu_plan_set_aux_input first"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  const size_t nj = st.joins.size();
+  ex.jkeys.resize(nj); ex.jrows.resize(nj); ex.jmisc.resize(nj); ex.vm_joins.resize(nj);
+  for (size_t j = 0; j < nj; ++j) {
+    const JoinSpec& js = st.joins[j];
+    uint64_t cap = 16; while (cap < (uint64_t)std::max<int64_t>(p->aux_rows, 1) * 2) cap <<= 1;
+    if (cap > (1ull << 31)) { c->err = "hash join rhs table too large"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+    HIP_TRY(c, ex.jkeys[j].ensure(cap * 8)); HIP_TRY(c, ex.jrows[j].ensure(cap * 4)); HIP_TRY(c, ex.jmisc[j].ensure(16));
+    HIP_TRY(c, ssgpu_launch_fill_u64(ex.jkeys[j].as<uint64_t>(), VM_KEY_EMPTY, cap, c->stream));
+    const uint32_t misc_init[4] = {VM_NONE, 0u, 0u, 0u};   // [0] special row, [1] flags
+    HIP_TRY(c, hipMemcpyAsync(ex.jmisc[j].p, misc_init, 16, hipMemcpyHostToDevice, c->stream));
+    JoinBuildParams B; memset(&B, 0, sizeof(B));
+    B.n_keys = (unsigned)js.rhs_key_cols.size();
+    for (size_t k = 0; k < js.rhs_key_cols.size(); ++k) {
+      const ssgpu_column& col = p->aux_cols[js.rhs_key_cols[k]];
+      B.key_data[k] = col.data; B.key_nulls[k] = p->desc.aux_schema[js.rhs_key_cols[k]].nullable ? col.is_null : nullptr;
+      B.width[k] = js.fields[k].width; B.shift[k] = js.fields[k].shift; B.bits[k] = js.fields[k].bits;
+    }
+    B.capacity_mask = (uint32_t)(cap - 1); B.n_rows = (unsigned long long)p->aux_rows;
+    B.keys = ex.jkeys[j].as<unsigned long long>(); B.rows = ex.jrows[j].as<unsigned int>();
+    B.special = ex.jmisc[j].as<unsigned int>(); B.flags = ex.jmisc[j].as<unsigned int>() + 1;
+    HIP_TRY(c, ssgpu_launch_join_build(B, c->stream));
+    uint32_t misc[4];
+    HIP_TRY(c, hipMemcpyAsync(misc, ex.jmisc[j].p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (misc[1]) { c->err = "hash join: the rhs keys were declared UNIQUE but a key occurs more than once"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+    VmJoin& J = ex.vm_joins[j];
+    J.keys = ex.jkeys[j].as<unsigned long long>(); J.rows = ex.jrows[j].as<unsigned int>();
+    J.special = ex.jmisc[j].as<unsigned int>(); J.capacity_mask = (uint32_t)(cap - 1); J.pad = 0;
+    p->counters.n_launches += 2;
+  }
+  return SSGPU_OK;
+}
+void apply_joins(const ssgpu_plan* p, const StageExec& ex, const Program& prog, VmParams* P) {
+  for (size_t j = 0; j < ex.vm_joins.size() && j < VM_MAX_JOINS; ++j) P->join[j] = ex.vm_joins[j];
+  for (size_t g = 0; g < prog.gathers.size() && g < VM_MAX_JOIN_COLS; ++g) {
+    const ssgpu_column& col = p->aux_cols[prog.gathers[g].rhs_col];
+    P->join_cols[g].data = col.data;
+    P->join_cols[g].is_null = p->desc.aux_schema[prog.gathers[g].rhs_col].nullable ? col.is_null : nullptr;
+  }
+}
+
 // debug_timing >= 2: per-instruction cycle profile of a stage program (development aid)
 int attach_pc_profile(ssgpu_ctx* c, StageExec& ex, VmParams* P) {
   if (c->debug_timing < 2) return SSGPU_OK;
@@ -545,6 +598,7 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_ba
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+  apply_joins(p, ex, st.main, &P);
   fill_fast_slots(&P, st);
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   ex.grid = grid;
@@ -617,6 +671,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
   if (rc != SSGPU_OK) return rc;
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+  apply_joins(p, ex, st.main, &P);
   P.error_flag = ex.error_flag.as<unsigned int>();
   HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
   // output table: data column then (if nullable) its null mask, in out_schema order
@@ -635,6 +690,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
     HIP_TRY(c, ex.total.ensure(sizeof(uint64_t)));
     VmParams C;
     fill_params(&C, st.count_pass, ex.lay_count, ex.prog_count, ex.n_instr_count, in, row_id_base);
+    apply_joins(p, ex, st.count_pass, &C);
     C.tile_counts = ex.tile_counts.as<unsigned int>();
     C.error_flag = P.error_flag;
     const int cgrid = grid_for(c, ex.lay_count, C.n_tiles);
@@ -746,7 +802,9 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
     VmParams Pc, Ps;
     fill_params(&Pc, st.part_count, ex.lay_pcount, ex.prog_pcount, ex.n_instr_pcount, in, row_id_base);
+    apply_joins(p, ex, st.part_count, &Pc);
     fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
+    apply_joins(p, ex, st.part_scatter, &Ps);
     Pc.part_n = Ps.part_n = NP;
     Pc.part_lds_off = (Pc.lds_bytes + 15u) & ~15u; Pc.lds_bytes = Pc.part_lds_off + NP * 4u;
     Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u; Ps.lds_bytes = Ps.part_lds_off + NP * 4u;
@@ -824,6 +882,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
     VmParams P;
     fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
+    apply_joins(p, ex, st.main, &P);
     P.error_flag = ex.error_flag.as<unsigned int>();
     P.group.keys = ex.gkeys.as<unsigned long long>();
     P.group.acc = ex.gacc.as<unsigned long long>();
@@ -1023,6 +1082,7 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   ext.cols.push_back(segcol);
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, ext, row_id_base);
+  apply_joins(p, ex, st.main, &P);
   P.error_flag = ex.error_flag.as<unsigned int>();
   P.group.acc = ex.gacc.as<unsigned long long>();
   P.group.cnt = ex.gcnt.as<unsigned int>();
@@ -1095,6 +1155,8 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
     Stage& st = p->stages[si];
     int rc = SSGPU_OK;
     alg_bytes += st.algorithmic_bytes_per_row * in.rows;
+    rc = build_joins(p, st, p->exec[si]);
+    if (rc != SSGPU_OK) return rc;
     switch (st.kind) {
       case STAGE_SCALAR_AGG:
         rc = run_scalar_agg(p, si, in, row_id_base, partial);
@@ -1151,6 +1213,15 @@ int ssgpu_plan_run_block(ssgpu_plan* p, const ssgpu_block* b, ssgpu_result** out
   std::vector<ssgpu_column> cols(b->schema.size());
   for (size_t i = 0; i < cols.size(); ++i) ssgpu_block_column(b, (int32_t)i, &cols[i]);
   return ssgpu_plan_run(p, cols.data(), (int32_t)cols.size(), b->rows, out);
+}
+
+int ssgpu_plan_set_aux_input(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  if (n_cols != (int)p->desc.aux_schema.size()) { p->ctx->err = "column count does not match the plan's auxiliary schema"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
+  if (rows < 0 || rows >= (int64_t)VM_NONE) { p->ctx->err = "auxiliary input: bad row count"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  p->aux_cols.assign(cols, cols + n_cols);
+  p->aux_rows = rows;
+  return SSGPU_OK;
 }
 
 int ssgpu_plan_run_partial(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t base) {

@@ -99,7 +99,7 @@
   X(AGG_SUM_F64_ADD) X(AGG_SUM_F64_SUB) X(AGG_SUM_F64_MUL)                     \
   /* ---- materialising sinks ---------------------------------------------- */\
   X(SEL_COUNT)   /* a = sel: tile_counts[tile] = #selected        */           \
-  X(SEL_RANK) X(PART_COUNT) X(PART_RANK)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
+  X(SEL_RANK) X(PART_COUNT) X(PART_RANK) X(JOIN_PROBE) X(IDX_VALID) X(GATHER_64) X(GATHER_32) X(GATHER_8) X(GATHER_NULL)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
   X(STORE_8) X(STORE_32) X(STORE_64)     /* dst = out col, a = reg, rows 1:1 */\
   X(STOREC_8) X(STOREC_32) X(STOREC_64)  /* + b = rank reg, c = sel (compact)*/\
   X(STORE_ROWID) /* dst = out col: int64 global row id of survivors, b,c */    \
@@ -183,6 +183,20 @@ struct VmGroupTable {
 #define VM_SLOT_LOCAL 0x80000000u /* GRP_INSERT result: index into the LDS table */
 #define VM_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 
+/* HashJoin (UNIQUE rhs keys) fused into the pipeline: JOIN_PROBE looks a packed 64-bit lhs key up
+ * in an open-addressing index over the rhs table (imm = join number) and leaves the matched rhs
+ * row (or VM_NONE) in a u32 register; GATHER_* (imm = slot of join_cols) fetch rhs values by it. */
+struct VmJoin {
+  const unsigned long long* keys;   /* capacity entries, VM_KEY_EMPTY = free */
+  const unsigned int* rows;         /* rhs row of every entry */
+  const unsigned int* special;      /* [0]: rhs row whose packed key equals VM_KEY_EMPTY, or VM_NONE */
+  uint32_t capacity_mask;
+  uint32_t pad;
+};
+struct VmJoinCol { const void* data; const unsigned char* is_null; };
+#define VM_MAX_JOINS 2
+#define VM_MAX_JOIN_COLS 24
+
 struct VmParams {
   const VmInstr* prog;
   int32_t n_instr;
@@ -214,6 +228,8 @@ struct VmParams {
   uint32_t debug_pc_lds_off;    /* LDS scratch of the same shape (accumulated there, flushed once) */
   uint32_t pad_dbg;
   VmGroupTable group;
+  VmJoin join[VM_MAX_JOINS];
+  VmJoinCol join_cols[VM_MAX_JOIN_COLS];
   VmStagedCol staged[VM_MAX_STAGED];
   VmOutCol outputs[VM_MAX_OUTPUTS];
 };

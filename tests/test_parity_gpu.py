@@ -331,6 +331,65 @@ def test_string_columns_through_the_pipeline(gpu_ctx, n):
         ss.Compute(ss.Plus(NA("s"), ss.ConstInt32(1)), ss.ScanView(view)).CreateCursor(gpu_ctx)
 
 
+def _join_views(n, m, seed=23):
+    rng = np.random.default_rng(seed)
+    ls = ss.TupleSchema([ss.Attribute("fk", ss.INT64, ss.NULLABLE), ss.Attribute("fk2", ss.INT32), ss.Attribute("v", ss.DOUBLE), ss.Attribute("a", ss.INT64)])
+    rs = ss.TupleSchema([ss.Attribute("id", ss.INT64, ss.NULLABLE), ss.Attribute("id2", ss.INT32), ss.Attribute("name", ss.STRING),
+                         ss.Attribute("w", ss.DOUBLE, ss.NULLABLE), ss.Attribute("g", ss.INT32)])
+    ids = rng.permutation(4 * m)[:m].astype(np.int64) - m          # unique, includes negatives and -1 (the EMPTY sentinel value)
+    if m > 3:
+        ids[3] = -1
+    rview = ss.View(rs, [ss.Column(ids, np.arange(m) % 17 == 5), (np.arange(m) % 3).astype(np.int32), ["n%d" % (i % 37) for i in range(m)],
+                         ss.Column(rng.integers(-100, 100, m) * 0.5, rng.random(m) < 0.2), rng.integers(0, 9, m).astype(np.int32)])
+    lview = ss.View(ls, [ss.Column(rng.integers(-m, 3 * m + 1, n), rng.random(n) < 0.1), rng.integers(0, 3, n).astype(np.int32),
+                         rng.integers(-4000, 4000, n) * 0.25, rng.integers(0, 1000, n)])
+    return lview, rview
+
+
+@pytest.mark.parametrize("n,m", [(0, 5), (7, 0), (1025, 40), (30011, 300)])
+@pytest.mark.parametrize("join_type", [ss.INNER, ss.LEFT_OUTER])
+def test_hash_join_fused_into_the_pipeline(gpu_ctx, n, m, join_type):
+    # HashJoinOperation (hash_join.h:37-56), UNIQUE rhs keys: probe + rhs gathers inside the lhs program
+    lview, rview = _join_views(n, m)
+    proj = (ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes("L."))
+            .add(1, ss.ProjectNamedAttributes(["name", "w", "g"])).add(1, ss.ProjectNamedAttributeAs("id", "rid")))
+
+    def join(lhs_op):
+        return ss.HashJoin(join_type, ss.ProjectNamedAttribute("fk"), ss.ProjectNamedAttribute("id"), proj, ss.UNIQUE, lhs_op, ss.ScanView(rview))
+    run_both(join(ss.ScanView(lview)), gpu_ctx)                                     # materialised join, lhs order
+    flt = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(lview))
+    run_both(join(flt), gpu_ctx)                                                    # under a filter
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "w", "sw").AddAggregation(ss.COUNT, "name", "c")
+            .AddAggregation(ss.MIN, "name", "mn").AddAggregation(ss.SUM, "L.v", "sv"))
+    run_both(ss.ScalarAggregate(spec, join(flt)), gpu_ctx)                          # join -> aggregate, one kernel
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), spec, None,
+                               ss.Filter(ss.IsNull(NA("w")), ss.ProjectAllAttributes(), join(ss.ScanView(lview)))), gpu_ctx, ignore_order=True)
+    expr = ss.CompoundExpression().AddAs("x", ss.Plus(NA("L.v"), ss.IfNull(NA("w"), ss.ConstDouble(0.0)))).Add(NA("name"))
+    run_both(ss.Compute(expr, join(ss.ScanView(lview))), gpu_ctx)                    # expressions over joined columns
+
+
+def test_hash_join_two_key_columns_and_errors(gpu_ctx):
+    rng = np.random.default_rng(4)
+    m, n = 200, 7000
+    rs = ss.TupleSchema([ss.Attribute("x", ss.INT32), ss.Attribute("y", ss.INT32, ss.NULLABLE), ss.Attribute("name", ss.STRING)])
+    ls = ss.TupleSchema([ss.Attribute("p", ss.INT32, ss.NULLABLE), ss.Attribute("q", ss.INT32), ss.Attribute("big", ss.INT64)])
+    rview = ss.View(rs, [(np.arange(m) // 10).astype(np.int32), ss.Column((np.arange(m) % 10).astype(np.int32), np.arange(m) % 41 == 7), ["r%d" % i for i in range(m)]])
+    lview = ss.View(ls, [ss.Column(rng.integers(-2, 24, n).astype(np.int32), rng.random(n) < 0.1), rng.integers(-1, 11, n).astype(np.int32), rng.integers(0, 5, n)])
+    proj = ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes()).add(1, ss.ProjectNamedAttributes(["name"]))
+    for jt in (ss.INNER, ss.LEFT_OUTER):     # (x, y) is unique; NULL y rows can never match
+        op = ss.HashJoin(jt, ss.ProjectNamedAttributes(["p", "q"]), ss.ProjectNamedAttributes(["x", "y"]), proj, ss.UNIQUE,
+                         ss.ScanView(lview), ss.ScanView(rview))
+        run_both(op, gpu_ctx)
+    # key type mismatch is a bind error
+    bad = ss.HashJoin(ss.INNER, ss.ProjectNamedAttribute("big"), ss.ProjectNamedAttribute("x"), proj, ss.UNIQUE, ss.ScanView(lview), ss.ScanView(rview))
+    with pytest.raises(ss.SupersonicException):
+        bad.CreateCursor(gpu_ctx)
+    # duplicate rhs keys under a UNIQUE declaration are reported, not silently resolved
+    dup = ss.HashJoin(ss.INNER, ss.ProjectNamedAttribute("q"), ss.ProjectNamedAttribute("x"), proj, ss.UNIQUE, ss.ScanView(lview), ss.ScanView(rview))
+    r = dup.CreateCursor(gpu_ctx).Next(1024)
+    assert r.is_failure()
+
+
 def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     n = 5000
     view = make_view(n)
