@@ -35,6 +35,8 @@ enum DataType { INT32 = 1, INT64 = 2, UINT64 = 3, DATETIME = 4, DOUBLE = 5, BOOL
 enum Nullability { NOT_NULLABLE = 0, NULLABLE = 1 };
 enum Aggregation { SUM = 0, MIN = 1, MAX = 2, COUNT = 3, CONCAT = 4, FIRST = 5, LAST = 6 };
 enum ColumnOrder { ASCENDING = 0, DESCENDING = 1 };
+enum JoinType { INNER = 0, LEFT_OUTER = 1 };          // supersonic.proto:108-113 (RIGHT/FULL_OUTER: not on device)
+enum KeyUniqueness { NOT_UNIQUE = 0, UNIQUE = 1 };    // supersonic.proto:115-118
 enum ReturnCode {
   OK = 0, ERROR_UNKNOWN_ERROR = 100, ERROR_MEMORY_EXCEEDED = 102, ERROR_NOT_IMPLEMENTED = 103,
   ERROR_EVALUATION_ERROR = 104, ERROR_TOO_MANY_ROWS = 302, ERROR_ATTRIBUTE_COUNT_MISMATCH = 401,
@@ -248,10 +250,10 @@ class CompoundExpression : public Expression {
 class SingleSourceProjector {
  public:
   virtual ~SingleSourceProjector() {}
-  struct Entry { int kind; int position; std::string name, alias; };
+  struct Entry { int kind; int position; std::string name, alias; int source = 0; };
   std::vector<Entry> entries;
 };
-inline const SingleSourceProjector* ProjectAllAttributes() { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_ALL, 0, "", ""}); return p; }
+inline const SingleSourceProjector* ProjectAllAttributes(const std::string& prefix = "") { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_ALL, 0, "", prefix}); return p; }
 inline const SingleSourceProjector* ProjectNamedAttribute(const std::string& name) { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_NAMED, 0, name, ""}); return p; }
 inline const SingleSourceProjector* ProjectNamedAttributeAs(const std::string& name, const std::string& alias) { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_NAMED_AS, 0, name, alias}); return p; }
 inline const SingleSourceProjector* ProjectAttributeAt(int position) { auto* p = new SingleSourceProjector; p->entries.push_back({SSGPU_PROJ_AT, position, "", ""}); return p; }
@@ -259,6 +261,21 @@ inline const SingleSourceProjector* ProjectNamedAttributes(const std::vector<std
 class CompoundSingleSourceProjector : public SingleSourceProjector {
  public:
   CompoundSingleSourceProjector* add(const SingleSourceProjector* p) { std::unique_ptr<const SingleSourceProjector> own(p); for (auto& e : p->entries) entries.push_back(e); return this; }
+};
+
+// (source index, projector) pairs over the inputs of a join (base/infrastructure/projector.h:405-441)
+class MultiSourceProjector {
+ public:
+  virtual ~MultiSourceProjector() {}
+  std::vector<SingleSourceProjector::Entry> entries;
+};
+class CompoundMultiSourceProjector : public MultiSourceProjector {
+ public:
+  CompoundMultiSourceProjector* add(int source_index, const SingleSourceProjector* p) {
+    std::unique_ptr<const SingleSourceProjector> own(p);
+    for (auto e : p->entries) { e.source = source_index; entries.push_back(e); }
+    return this;
+  }
 };
 
 // ---- specifications (cursor/core/aggregate.h:28-205, infrastructure/ordering.h:48-101) -----
@@ -318,7 +335,7 @@ class Operation;
 class Cursor {
  public:
   static const rowcount_t kDefaultRowCount = 1024;  // cursor.h:133
-  ~Cursor() { if (res_) ssgpu_result_destroy(res_); if (block_) ssgpu_block_destroy(block_); if (plan_) ssgpu_plan_destroy(plan_); }
+  ~Cursor() { if (res_) ssgpu_result_destroy(res_); if (aux_block_) ssgpu_block_destroy(aux_block_); if (block_) ssgpu_block_destroy(block_); if (plan_) ssgpu_plan_destroy(plan_); }
   const TupleSchema& schema() const { return schema_; }
   void Interrupt() { ssgpu_interrupt(plan_); }   // thread-safe, non-blocking (cursor.h:150-186)
 
@@ -356,7 +373,24 @@ class Cursor {
  private:
   friend class Operation;
   Cursor() {}
+  static int Upload(ssgpu_ctx* ctx, const View* v, ssgpu_block** out) {
+    const TupleSchema& s = v->schema();
+    std::vector<ssgpu_attr> attrs;
+    for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
+    int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), std::max<rowcount_t>(v->row_count(), 1), out);
+    for (int i = 0; rc == SSGPU_OK && i < s.attribute_count() && v->row_count() > 0; ++i)
+      rc = ssgpu_block_upload(*out, i, v->column(i).data(), reinterpret_cast<const uint8_t*>(v->column(i).is_null()), 0, v->row_count());
+    if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(*out, v->row_count());
+    return rc;
+  }
   int Stage(ssgpu_ctx* ctx) {  // host View -> device block on the copy stream
+    if (aux_) {                // rhs table of a HashJoin: the plan's auxiliary input
+      int rc = Upload(ctx, aux_, &aux_block_);
+      std::vector<ssgpu_column> cols(aux_->schema().attribute_count());
+      for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(aux_block_, static_cast<int32_t>(i), &cols[i]);
+      if (rc == SSGPU_OK) rc = ssgpu_plan_set_aux_input(plan_, cols.data(), static_cast<int32_t>(cols.size()), aux_->row_count());
+      if (rc != SSGPU_OK) return rc;
+    }
     const TupleSchema& s = input_->schema();
     std::vector<ssgpu_attr> attrs;
     for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
@@ -370,6 +404,8 @@ class Cursor {
   ssgpu_block* block_ = nullptr;
   ssgpu_result* res_ = nullptr;
   const View* input_ = nullptr;
+  const View* aux_ = nullptr;
+  ssgpu_block* aux_block_ = nullptr;
   TupleSchema schema_;
   std::unique_ptr<View> view_;
   std::vector<const void*> host_data_;
@@ -397,12 +433,18 @@ class Operation {
     d.projs = b.projs.data(); d.n_projs = static_cast<int32_t>(b.projs.size());
     d.aggs = b.aggs.data(); d.n_aggs = static_cast<int32_t>(b.aggs.size());
     d.sortkeys = b.sortkeys.data(); d.n_sortkeys = static_cast<int32_t>(b.sortkeys.size());
+    std::vector<ssgpu_attr> aux_attrs;
+    if (b.scan_aux) {
+      const TupleSchema& as = b.scan_aux->schema();
+      for (int i = 0; i < as.attribute_count(); ++i) aux_attrs.push_back({as.attribute(i).name().c_str(), as.attribute(i).type(), as.attribute(i).nullability()});
+      d.aux_schema = aux_attrs.data(); d.n_aux_attrs = static_cast<int32_t>(aux_attrs.size());
+    }
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
     ssgpu_plan* plan = nullptr;
     const int rc = ssgpu_plan_create(ctx, &d, &plan);
     if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, ssgpu_last_error(ctx)));
     std::unique_ptr<Cursor> c(new Cursor);
-    c->plan_ = plan; c->input_ = b.scan;
+    c->plan_ = plan; c->input_ = b.scan; c->aux_ = b.scan_aux;
     for (int i = 0; i < ssgpu_plan_attr_count(plan); ++i) {
       ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
       c->schema_.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
@@ -417,6 +459,12 @@ class Operation {
     std::vector<ssgpu_op> ops; std::vector<ssgpu_expr> exprs; std::vector<int32_t> expr_args;
     std::vector<ssgpu_proj> projs; std::vector<ssgpu_agg> aggs; std::vector<ssgpu_sortkey> sortkeys;
     const View* scan = nullptr;
+    const View* scan_aux = nullptr;   // rhs table of a HashJoin (the plan's auxiliary input)
+    bool aux = false;
+    void ProjRange(const std::vector<SingleSourceProjector::Entry>& es, int32_t* first, int32_t* n) {
+      *first = static_cast<int32_t>(projs.size()); *n = static_cast<int32_t>(es.size());
+      for (auto& e : es) projs.push_back({e.kind, e.position, e.name.c_str(), e.alias.c_str(), e.source, 0});
+    }
     int Expr(const Expression* e) {
       std::vector<int32_t> kids;
       for (auto& a : e->args) kids.push_back(Expr(a.get()));
@@ -429,7 +477,7 @@ class Operation {
     }
     void Proj(const SingleSourceProjector* p, ssgpu_op* o) {
       o->proj_first = static_cast<int32_t>(projs.size()); o->proj_n = static_cast<int32_t>(p->entries.size());
-      for (auto& e : p->entries) projs.push_back({e.kind, e.position, e.name.c_str(), e.alias.c_str()});
+      for (auto& e : p->entries) projs.push_back({e.kind, e.position, e.name.c_str(), e.alias.c_str(), e.source, 0});
     }
     void Aggs(const AggregationSpecification* s, ssgpu_op* o) {
       o->agg_first = static_cast<int32_t>(aggs.size()); o->agg_n = static_cast<int32_t>(s->elements.size());
@@ -446,7 +494,11 @@ namespace internal {
 class ScanViewOp : public Operation {
  public:
   explicit ScanViewOp(const View& v) : view_(v) {}
-  int Emit(Builder* b) const override { b->scan = &view_; return b->Op(Blank(SSGPU_OP_SCAN, -1)); }
+  int Emit(Builder* b) const override {
+    ssgpu_op o = Blank(SSGPU_OP_SCAN, -1);
+    if (b->aux) { b->scan_aux = &view_; o.option0 = 1; } else { b->scan = &view_; }
+    return b->Op(o);
+  }
  private:
   const View& view_;  // must outlive the operation (scan_view.h)
 };
@@ -473,7 +525,34 @@ class UnaryOp : public Operation {
   std::unique_ptr<const SortOrder> sort_;
   int64_t opt_;
 };
+// HashJoinOperation (cursor/core/hash_join.h:37-56): INNER / LEFT_OUTER, UNIQUE rhs keys, rhs = ScanView(table)
+class HashJoinOp : public Operation {
+ public:
+  HashJoinOp(JoinType t, const SingleSourceProjector* lk, const SingleSourceProjector* rk, const MultiSourceProjector* rp,
+             KeyUniqueness u, Operation* lhs, Operation* rhs) : type_(t), uniq_(u), lk_(lk), rk_(rk), rp_(rp), lhs_(lhs), rhs_(rhs) {}
+  int Emit(Builder* b) const override {
+    const int l = lhs_->Emit(b);
+    b->aux = true; const int r = rhs_->Emit(b); b->aux = false;
+    ssgpu_op o = Blank(SSGPU_OP_HASH_JOIN, l);
+    o.child2 = r; o.option0 = static_cast<int64_t>(type_) | (static_cast<int64_t>(uniq_) << 8);
+    b->ProjRange(lk_->entries, &o.proj_first, &o.proj_n);
+    b->ProjRange(rk_->entries, &o.proj2_first, &o.proj2_n);
+    b->ProjRange(rp_->entries, &o.proj3_first, &o.proj3_n);
+    return b->Op(o);
+  }
+ private:
+  JoinType type_; KeyUniqueness uniq_;
+  std::unique_ptr<const SingleSourceProjector> lk_, rk_;
+  std::unique_ptr<const MultiSourceProjector> rp_;
+  std::unique_ptr<Operation> lhs_, rhs_;
+};
 }  // namespace internal
+
+// Takes ownership of all projectors and both children (hash_join.h:48-56).
+inline Operation* HashJoin(JoinType join_type, const SingleSourceProjector* lhs_key_selector, const SingleSourceProjector* rhs_key_selector,
+                           const MultiSourceProjector* result_projector, KeyUniqueness rhs_key_uniqueness, Operation* lhs_child, Operation* rhs_child) {
+  return new internal::HashJoinOp(join_type, lhs_key_selector, rhs_key_selector, result_projector, rhs_key_uniqueness, lhs_child, rhs_child);
+}
 
 inline Operation* ScanView(const View& view) { return new internal::ScanViewOp(view); }
 inline Operation* Compute(const Expression* computation, Operation* child) { return new internal::UnaryOp(SSGPU_OP_COMPUTE, child, computation, nullptr, nullptr, nullptr); }

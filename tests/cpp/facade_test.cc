@@ -159,6 +159,36 @@ static void TestRun(const Input& in) {
       CHECK_EQ(r.view().column(2).typed_data<uint64_t>()[g], cd[g]);
     }
   }
+  {  // HashJoin(LEFT_OUTER) against a small dimension table, aggregated in the same pipeline
+    std::vector<int32_t> id = {0, 1, 2, 3, 5};
+    std::vector<int64_t> w = {100, 10, 20, 30, 50};
+    TupleSchema ds;
+    ds.add_attribute(Attribute("id", INT32, NOT_NULLABLE));
+    ds.add_attribute(Attribute("w", INT64, NOT_NULLABLE));
+    View dim(ds);
+    dim.mutable_column(0)->Reset(id.data(), nullptr);
+    dim.mutable_column(1)->Reset(w.data(), nullptr);
+    dim.set_row_count(5);
+    std::unique_ptr<Operation> op(ScalarAggregate(
+        (new AggregationSpecification)->AddAggregation(SUM, "w", "sw")->AddAggregation(COUNT, "w", "cw")->AddAggregation(COUNT, "", "n"),
+        HashJoin(LEFT_OUTER, ProjectNamedAttribute("k"), ProjectNamedAttribute("id"),
+                 (new CompoundMultiSourceProjector)->add(0, ProjectNamedAttribute("a"))->add(1, ProjectNamedAttribute("w")), UNIQUE,
+                 ScanView(*in.view), ScanView(dim))));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) {
+      ResultView r = c->Next(Cursor::kDefaultRowCount);
+      if (r.is_failure()) { printf("join failed: %s\n", r.exception().message().c_str()); ++g_fail; }
+      else {
+        const int64_t wt[7] = {100, 10, 20, 30, 0, 50, 0};
+        int64_t sw = 0; uint64_t cw = 0;
+        for (int i = 0; i < Input::N; ++i) { sw += wt[in.k[i]]; cw += (in.k[i] != 4 && in.k[i] != 6); }
+        CHECK_EQ(r.view().column(0).typed_data<int64_t>()[0], sw);
+        CHECK_EQ(r.view().column(1).typed_data<uint64_t>()[0], cw);
+        CHECK_EQ(r.view().column(2).typed_data<uint64_t>()[0], static_cast<uint64_t>(Input::N));
+      }
+    }
+  }
   {  // signaling division by zero surfaces as ERROR_EVALUATION_ERROR from Next()
     std::unique_ptr<Operation> op(Compute(DivideSignaling(NamedAttribute("a"), Minus(NamedAttribute("b"), NamedAttribute("b"))), ScanView(*in.view)));
     FailureOrOwned<Cursor> c = op->CreateCursor();

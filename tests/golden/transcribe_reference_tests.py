@@ -418,6 +418,34 @@ op_case("Sort_OneStringColumnWithDuplicatesAndNulls_string", SO + ":190-215", co
         ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [STR], [[None], [None], ["a"], ["a"], ["c"], ["d"], ["e"]])
 op_case("Sort_OneEmptyStringColumn_string", SO + ":180-188", cols([STR]), [], ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [STR], [])
 
+# ---- HashJoin (hash_join_test.cc), UNIQUE rhs keys, with the tests' own STRING payloads ------------------
+HJ = "supersonic/cursor/core/hash_join_test.cc"
+ALLP = [[0, ["ProjectAllAttributes", "L."]], [1, ["ProjectAllAttributes", "R."]]]
+JT = [I64, STR, I64, STR]
+JN = ["L.col0", "L.col1", "R.col0", "R.col1"]
+R1, R2 = [[1, "a"]], [[2, "b"]]
+R12345 = [[1, "a"], [2, "b"], [3, "c"], [4, "d"], [5, "e"]]
+R654321 = [[6, "f"], [5, "e"], [4, "d"], [3, "c"], [2, "b"], [1, "a"]]
+
+
+def join_case(name, src, jtype, lrows, rrows, expected):
+    CASES.append({
+        "name": name, "source": src, "kind": "operation",
+        "input": {"schema": cols([I64, STR]), "rows": lrows}, "input2": {"schema": cols([I64, STR]), "rows": rrows},
+        "plan": ["HashJoin", jtype, [0], [0], ALLP, "UNIQUE", "INPUT", "INPUT2"],
+        "expected": {"types": JT, "rows": expected, "names": JN, "nullable": None},
+        "ordered": True, "expect_error": None})
+
+
+join_case("HashJoin_1_InnerJoin_1", HJ + ":140-150", "INNER", R1, R1, [[1, "a", 1, "a"]])
+join_case("HashJoin_1_LeftOuterJoin_1", HJ + ":152-163", "LEFT_OUTER", R1, R1, [[1, "a", 1, "a"]])
+join_case("HashJoin_1_InnerJoin_2", HJ + ":165-174", "INNER", R1, R2, [])
+join_case("HashJoin_1_LeftOuterJoin_2", HJ + ":176-187", "LEFT_OUTER", R1, R2, [[1, "a", None, None]])
+join_case("HashJoin_12345_InnerJoin_654321", HJ + ":189-203", "INNER", R12345, R654321, [[k, v, k, v] for k, v in R12345])
+join_case("HashJoin_654321_InnerJoin_12345", HJ + ":205-219", "INNER", R654321, R12345, [[k, v, k, v] for k, v in R654321[1:]])
+join_case("HashJoin_654321_LeftOuterJoin_12345", HJ + ":222-238", "LEFT_OUTER", R654321, R12345,
+          [[6, "f", None, None]] + [[k, v, k, v] for k, v in R654321[1:]])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
     with open(out, "w") as f:

@@ -87,9 +87,23 @@ def build_spec(spec):
 
 
 def build_plan(plan, view):
+    """view: the case's input View, or a (view, second_view) pair for two-input plans."""
     if plan == "INPUT":
-        return ss.ScanView(view)
+        return ss.ScanView(view[0] if isinstance(view, tuple) else view)
+    if plan == "INPUT2":
+        return ss.ScanView(view[1])
     head = plan[0]
+    if head == "HashJoin":   # [HashJoin, type, lhs key positions, rhs key positions, [[source, projector], ...], uniqueness, lhs, rhs]
+        def selector(positions):
+            c = ss.CompoundSingleSourceProjector()
+            for q in positions:
+                c.add(ss.ProjectAttributeAt(q))
+            return c
+        mp = ss.CompoundMultiSourceProjector()
+        for source, pr in plan[4]:
+            mp.add(source, build_projector(pr))
+        return ss.HashJoin({"INNER": ss.INNER, "LEFT_OUTER": ss.LEFT_OUTER}[plan[1]], selector(plan[2]), selector(plan[3]), mp,
+                           {"UNIQUE": ss.UNIQUE, "NOT_UNIQUE": ss.NOT_UNIQUE}[plan[5]], build_plan(plan[6], view), build_plan(plan[7], view))
     if head == "Compute":
         return ss.Compute(build_expr(plan[1]), build_plan(plan[2], view))
     if head == "Filter":

@@ -20,6 +20,8 @@ def bind_ctx():
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_binder_matches_reference(bind_ctx, case):
     view = build_view(case["input"])
+    if case.get("input2"):
+        view = (view, build_view(case["input2"]))
     op = build_plan(case["plan"], view)
     if case["expect_error"] and case["expect_error"] not in EVAL_ERRORS:
         with pytest.raises(ss.SupersonicException) as e:

@@ -12,6 +12,8 @@ CASES = [c for c in load_cases() if c["kind"] != "binding"]
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_hip_path_reproduces_reference_golden_vector(gpu_ctx, case):
     view = build_view(case["input"])
+    if case.get("input2"):
+        view = (view, build_view(case["input2"]))
     op = build_plan(case["plan"], view)
     if case["expect_error"]:
         with pytest.raises(ss.SupersonicException) as e:

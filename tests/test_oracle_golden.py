@@ -13,6 +13,8 @@ CASES = load_cases()
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_oracle_reproduces_reference_golden_vector(case):
     view = build_view(case["input"])
+    if case.get("input2"):
+        view = (view, build_view(case["input2"]))
     op = build_plan(case["plan"], view)
     if case["expect_error"]:
         with pytest.raises(oracle.OracleError) as e:

@@ -71,6 +71,26 @@ def q_group_tiny(v):
     return ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.Compute(e, ss.ScanView(v)))
 
 
+_DIM = {}
+
+
+def q_join(v):
+    # star-join shape: 100 M-row fact table (key c, 1e5 distinct) INNER JOIN a 1e5-row dimension table, then aggregate
+    if "view" not in _DIM:
+        dev = torch.device("cuda", 0)
+        m = 100000
+        ids = torch.randperm(m, device=dev, dtype=torch.int64)
+        w = torch.arange(m, device=dev, dtype=torch.float64) * 0.5
+        g = (torch.arange(m, device=dev, dtype=torch.int64) % 7).to(torch.int32)
+        _DIM["cols"] = [ids, w, g]
+        schema = ss.TupleSchema([ss.Attribute("id", ss.INT64), ss.Attribute("w", ss.DOUBLE), ss.Attribute("g", ss.INT32)])
+        _DIM["view"] = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in _DIM["cols"]], m)
+    proj = ss.CompoundMultiSourceProjector().add(0, ss.ProjectNamedAttributes(["a", "d0"])).add(1, ss.ProjectNamedAttributes(["w", "g"]))
+    join = ss.HashJoin(ss.INNER, ss.ProjectNamedAttribute("c"), ss.ProjectNamedAttribute("id"), proj, ss.UNIQUE, ss.ScanView(v), ss.ScanView(_DIM["view"]))
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "w", "sw").AddAggregation(ss.SUM, "d0", "sd").AddAggregation(ss.COUNT, "", "n")
+    return ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), join))
+
+
 def q_addn(n):
     def q(v):
         e = NA("a")
@@ -109,7 +129,7 @@ def q_group2(v):
 
 
 QUERIES = {"sort": q_sort, "sort_key": q_sort_keyonly, "group2": q_group2, "add4": q_addn(4), "add16": q_addn(16), "sum4": q_sumn(4), "sum8": q_sumn(8),"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
-           "filter_mat": q_filter_mat, "group": q_group, "group_small": q_group_small, "group_tiny": q_group_tiny}
+           "filter_mat": q_filter_mat, "group": q_group, "group_small": q_group_small, "group_tiny": q_group_tiny, "join": q_join}
 
 
 def main():
