@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libssgpu.so")
+LIB_PATH = os.environ.get("SSGPU_LIB") or os.path.join(_HERE, "lib", "libssgpu.so")   # SSGPU_LIB: build-variant experiments (tools/)
 
 # reference enum values (supersonic/proto/supersonic.proto:15-36,86-101)
 INT32, INT64, UINT64, DATETIME, DOUBLE, BOOL, UINT32, FLOAT, DATE, STRING, BINARY = 1, 2, 3, 4, 5, 6, 8, 9, 10, 0, 7

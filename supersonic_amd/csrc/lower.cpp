@@ -494,17 +494,17 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
   ProgramLayout L;
   auto lds_for = [&](int K, uint32_t* acc, uint32_t* scr) {
     // input registers + temporaries
-    uint32_t regs = p.bytes_per_row * 512u * (uint32_t)K;
+    uint32_t regs = p.bytes_per_row * (uint32_t)VM_TILE_UNIT * (uint32_t)K;
     uint32_t a = (regs + 15u) & ~15u;
     uint32_t s = a + (uint32_t)p.n_slots * VM_ACC_STRIDE;
     if (acc) *acc = a;
     if (scr) *scr = s;
     return s + 256u + 16u * (uint32_t)p.code.size()   // + the immediates' constant pool
-           + 2u * 512u * (uint32_t)K;                   // + all-ones / all-zeros mask arrays of one tile
+           + 2u * (uint32_t)VM_TILE_UNIT * (uint32_t)K;                   // + all-ones / all-zeros mask arrays of one tile
   };
   int K = 1;
   if (opt.tile_rows > 0) {
-    K = std::max(1, opt.tile_rows / 512);
+    K = std::max(1, opt.tile_rows / VM_TILE_UNIT);
     if (K >= 4) K = 4; else if (K >= 2) K = 2; else K = 1;
     while (K > 1 && lds_for(K, nullptr, nullptr) > 160u * 1024u) K /= 2;  // must fit one CU
   } else {
@@ -523,7 +523,7 @@ ProgramLayout layout_program(const Program& p, const LowerOptions& opt) {
 
 void finalize_program(const Program& p, const ProgramLayout& L, std::vector<VmInstr>* out) {
   out->clear();
-  const uint32_t T = 512u * (uint32_t)L.K;
+  const uint32_t T = (uint32_t)VM_TILE_UNIT * (uint32_t)L.K;
   // VM register -> LDS byte offset: a register is `row_off` bytes per row, i.e. an array at row_off * T
   auto off = [&](int r) -> uint32_t { return r < 0 ? VM_NONE : p.regs[r].row_off * T; };
   for (size_t pc = 0; pc < p.code.size(); ++pc) {

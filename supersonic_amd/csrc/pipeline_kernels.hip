@@ -149,7 +149,7 @@ __device__ __forceinline__ Valid2 valid_pair_c(int p, u32 tile_valid, u32 null_o
   v.y = ((r0 + 1u) < tile_valid) && (s >> 8) && !(z >> 8);
   return v;
 }
-#define valid_pair_(p, tile_valid, null_off, sel_off) valid_pair_c(p, tile_valid, null_off, sel_off, P.const_lds_off, (u32)(512 * K))
+#define valid_pair_(p, tile_valid, null_off, sel_off) valid_pair_c(p, tile_valid, null_off, sel_off, P.const_lds_off, (u32)(VM_TILE_UNIT * K))
 
 __device__ __forceinline__ VmAccRec* acc_rec(const VmParams& P, u32 slot, int wave) {
   return reinterpret_cast<VmAccRec*>(smem + P.acc_lds_off + slot * VM_ACC_STRIDE + wave * 32);
@@ -407,11 +407,11 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
 // One persistent 4-wave workgroup strides over the tiles.  Per tile: commit the prefetched
 // units to the LDS input registers, issue the loads of the next tile, run the program.
 template <int K>
-__global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const VmParams P) {
+__global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline_kernel(const VmParams P) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  const int tile_rows = 512 * K;
+  const int tile_rows = VM_TILE_UNIT * K;
   const int n_my_tiles = P.n_tiles > (int)blockIdx.x ? (P.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int n_units = P.n_staged * K;
 
@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, 4) void ssgpu_pipeline_kernel(const 
           u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
           if (lane == 0) scratch[wave] = cnt;
           WG_BARRIER();
-          if (t == 0) P.tile_counts[tile] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+          if (t == 0) { u32 sum = 0; for (int w = 0; w < VM_WAVES; ++w) sum += scratch[w]; P.tile_counts[tile] = sum; }
           WG_BARRIER();
         } break;
         case VM_SEL_RANK: { CASE_FENCE;

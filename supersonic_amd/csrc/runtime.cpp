@@ -204,7 +204,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   std::string k(key);
   if (k == "tile_rows") {
-    if (value != 0 && (value % 512 != 0 || value > 2048)) { c->err = "tile_rows must be 0, 512, 1024 or 2048"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+    if (value != 0 && (value % VM_TILE_UNIT != 0 || value > 4 * VM_TILE_UNIT)) { c->err = "tile_rows must be 0 or 1, 2, 4 times the workgroup's row-pair count"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
     c->opt.tile_rows = (int)value;
   } else if (k == "lds_target_bytes") c->opt.lds_target_bytes = (int)value;
   else if (k == "grid_limit") c->grid_limit = value;
@@ -370,9 +370,9 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   if (!s.ok()) { delete p; return fail(c, s); }
   for (auto& st : p->stages) {
     // every program must fit the CU's LDS at the smallest tile
-    LowerOptions o = c->opt; o.tile_rows = 512;
+    LowerOptions o = c->opt; o.tile_rows = VM_TILE_UNIT;
     if (!st.main.empty() && layout_program(st.main, o).lds_bytes > 160u * 1024u) {
-      delete p; c->err = "expression needs more than 160 KiB of LDS per 512-row tile"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+      delete p; c->err = "expression needs more than 160 KiB of LDS per tile"; return SSGPU_ERROR_NOT_IMPLEMENTED;
     }
   }
   p->exec.resize(p->stages.size());
@@ -449,7 +449,7 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
   if (!st.count_pass.empty()) {
-    LowerOptions o = c->opt; o.tile_rows = 512 * L.K;
+    LowerOptions o = c->opt; o.tile_rows = VM_TILE_UNIT * L.K;
     ex.lay_count = layout_program(st.count_pass, o);
     rc = upload_program(c, st.count_pass, ex.lay_count, &ex.prog_count, &ex.n_instr_count, &p->host_prog_scratch);
     if (rc != SSGPU_OK) return rc;
@@ -548,7 +548,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->n_slots = prog.n_slots;
   P->n_rows = in.rows;
   P->row_id_base = row_id_base;
-  P->tile_rows = 512 * L.K;
+  P->tile_rows = VM_TILE_UNIT * L.K;
   P->n_tiles = (int)((in.rows + P->tile_rows - 1) / P->tile_rows);
   P->acc_lds_off = L.acc_off;
   P->scratch_lds_off = L.scratch_off;
@@ -759,7 +759,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
   if (!ex.prog_pscatter.p) {
     LowerOptions o = c->opt;
     ex.lay_pscatter = layout_program(st.part_scatter, o);
-    o.tile_rows = 512 * ex.lay_pscatter.K;
+    o.tile_rows = VM_TILE_UNIT * ex.lay_pscatter.K;
     ex.lay_pcount = layout_program(st.part_count, o);
     if (ex.lay_pcount.K != ex.lay_pscatter.K) { c->err = "partition passes disagree on the tile size"; return SSGPU_ERROR_UNKNOWN; }
     int rc = upload_program(c, st.part_scatter, ex.lay_pscatter, &ex.prog_pscatter, &ex.n_instr_pscatter, &p->host_prog_scratch);

@@ -23,15 +23,24 @@
 #include <stdint.h>
 
 #define VM_NONE 0xFFFFFFFFu
-#define VM_COMPUTE_THREADS 256
-#define VM_WAVES 4          /* waves per workgroup */
-#define VM_WG_THREADS 256
+#ifndef VM_THREADS
+#define VM_THREADS 256      /* threads per workgroup */
+#endif
+#ifndef VM_PF_UNITS
 #define VM_PF_UNITS 8       /* 16-byte-per-lane units of the register prefetch file */
+#endif
+#ifndef VM_WAVES_PER_EU
+#define VM_WAVES_PER_EU 4   /* occupancy target of the pipeline kernel (sets its VGPR budget) */
+#endif
+#define VM_COMPUTE_THREADS VM_THREADS
+#define VM_WG_THREADS VM_THREADS
+#define VM_WAVES (VM_THREADS / 64)       /* waves per workgroup */
+#define VM_TILE_UNIT (2 * VM_THREADS)    /* rows of a K = 1 tile: one row pair per thread */
 #define VM_FAST_SLOTS 8     /* aggregate slots with per-lane register accumulators */
 #define VM_MAX_STAGED 48
 #define VM_MAX_OUTPUTS 64
 #define VM_MAX_AGG_SLOTS 64
-#define VM_ACC_STRIDE 128 /* bytes of LDS per aggregate slot: 4 waves x 32 B */
+#define VM_ACC_STRIDE (VM_WAVES * 32) /* bytes of LDS per aggregate slot: one 32 B record per wave */
 
 // type suffixes: I32 I64 U32 U64 F32 F64 (B8 = BOOL byte)
 #define VM_OPS(X)                                                              \
