@@ -74,6 +74,7 @@ struct AggOut {        // one aggregate result column
   int emit_kind;       // EmitKind
   bool has_cnt;        // group: contribution count tracked (nullable input)
   bool result_nullable;
+  int gather_col = -1; // group FIRST/LAST: the slot holds a row id; the result is this stage-input column at that row
 };
 
 struct GroupKeyField { int out_col; uint32_t shift, bits, nullbit, width; };

@@ -852,20 +852,32 @@ static Status build_partition_programs(const struct Pipe& pipe, const std::vecto
 // clustered = AggregateClusters (aggregate_clusters.cc:338-520): the group id of a row is the
 // number of key changes before it, computed by a flag + scan pre-pass over the materialised
 // input (segment ids arrive as an extra staged UINT32 column) -- no hash table.
-static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st, bool clustered = false) {
-  st->kind = clustered ? STAGE_CLUSTERS : STAGE_GROUP_AGG;
-  st->in_schema = pipe.in_schema;
-  const Schema vs = schema_of(pipe.cols);
+struct GroupBinding {   // keys and aggregations of a Group/Clusters aggregate, bound against a pipe's virtual schema
   std::vector<int> kpos; std::vector<std::string> knames;
-  SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, vs, &kpos, &knames));
   std::vector<AggPlan> plans;
-  SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, vs, &plans));
-  for (auto& ap : plans)
-    for (auto& kn : knames)
+};
+
+static Status bind_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, GroupBinding* g) {
+  const Schema vs = schema_of(pipe.cols);
+  SS_RETURN_IF_ERROR(bind_projector(d, op.proj_first, op.proj_n, vs, &g->kpos, &g->knames));
+  SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, vs, &g->plans));
+  for (auto& ap : g->plans)
+    for (auto& kn : g->knames)
       if (kn == ap.out_name)
         return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS, "Duplicate attribute name \"" + kn + "\" in result schema");
-  if ((int)plans.size() > VM_MAX_AGG_SLOTS || kpos.size() > 16)
+  if ((int)g->plans.size() > VM_MAX_AGG_SLOTS || g->kpos.size() > 16)
     return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many keys/aggregations for one pipeline");
+  return Status::OK();
+}
+
+// *too_wide is set (with an error status) when the hash aggregate cannot run as one fused pipeline
+// -- the packed key needs more than 64 bits, or FIRST/LAST reads a computed expression --
+// and lower_plan falls back to materialise + sort + clustered aggregation.
+static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* st, bool clustered = false, bool* too_wide = nullptr) {
+  st->kind = clustered ? STAGE_CLUSTERS : STAGE_GROUP_AGG;
+  st->in_schema = pipe.in_schema;
+  const std::vector<int>& kpos = g.kpos; const std::vector<std::string>& knames = g.knames;
+  const std::vector<AggPlan>& plans = g.plans;
   st->joins = pipe.joins;
   Emitter em(&st->main, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
@@ -895,8 +907,10 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
     GroupKeyField f; f.out_col = (int)k; f.shift = shift; f.bits = bits; f.width = w;
     f.nullbit = v.null >= 0 ? shift + bits : 0xFF;
     const uint32_t used = bits + (v.null >= 0 ? 1 : 0);
-    if (shift + used > 64)
-      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "group keys wider than 64 packed bits are not on device yet");
+    if (shift + used > 64) {
+      if (too_wide) *too_wide = true;
+      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "group keys wider than 64 packed bits");
+    }
     int vr = em.materialize(v);
     LInstr& i = em.emit(w == 8 ? VM_KEY_APPEND_64 : w == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
     i.dst = keyreg; i.a = vr; i.b = v.null;
@@ -910,6 +924,7 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
   { LInstr& i = em.emit(VM_GRP_INSERT); i.dst = slotreg; i.a = keyreg; i.c = sel; }
   }
   const uint64_t ng = plans.size();
+  int rowid_reg = -1;
   for (size_t j = 0; j < plans.size(); ++j) {
     const AggPlan& ap = plans[j];
     AggOut ao; ao.slot = (int)j; ao.slot_kind = 0; ao.result_nullable = ap.result_nullable; ao.has_cnt = false;
@@ -925,11 +940,23 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
       Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
       Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
       AggSel s;
-      if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST)
-        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST/LAST inside GroupAggregate are not on device yet");
-      if (!select_group_agg(ap.aggregation, ap.out_type, &s, &init))
-        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
-      int vr = em.materialize(c);
+      int vr;
+      if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
+        // FIRST / LAST (aggregation_operators.h:290-320): MIN / MAX of the contributing row ids;
+        // the value is fetched from the input column after extraction (runtime: gather_rowid)
+        if (src->kind != BExpr::INPUT || dtype_width(src->dtype) == 0) {
+          if (too_wide && dtype_width(src->dtype) != 0) *too_wide = true;   // computed input: materialise it first
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST/LAST inside GroupAggregate need a plain input column on device");
+        }
+        select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &s, &init);
+        if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
+        vr = rowid_reg;
+        ao.gather_col = src->input_col;
+      } else {
+        if (!select_group_agg(ap.aggregation, ap.out_type, &s, &init))
+          return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
+        vr = em.materialize(c);
+      }
       ao.has_cnt = v.null >= 0;
       LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = slotreg;
       i.imm = ((uint64_t)(ao.has_cnt ? 1 : 0) << 63) | (ng << 32) | j;
@@ -938,8 +965,8 @@ static Status finish_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe
     st->group_acc_init.push_back(init);
     {
       uint32_t mop = VM_MERGE_ADD_U64;
-      if (ap.aggregation == SSGPU_MIN) mop = VM_MERGE_MIN_U64;
-      else if (ap.aggregation == SSGPU_MAX) mop = VM_MERGE_MAX_U64;
+      if (ap.aggregation == SSGPU_MIN || ap.aggregation == SSGPU_FIRST) mop = VM_MERGE_MIN_U64;
+      else if (ap.aggregation == SSGPU_MAX || ap.aggregation == SSGPU_LAST) mop = VM_MERGE_MAX_U64;
       else if (ap.aggregation == SSGPU_SUM && (mtype(ap.out_type) == M_F32 || mtype(ap.out_type) == M_F64)) mop = VM_MERGE_ADD_F64;
       st->group_merge_op.push_back(mop);
     }
@@ -1000,6 +1027,7 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     return col;
   };
   store_reg(keyreg, 8);
+  int rowid_reg = -1;
   for (size_t j = 0; j < plans.size(); ++j) {
     const AggPlan& ap = plans[j];
     Stage::PartAgg pa; pa.op = VM_GAGG_COUNT; pa.val_col = -1; pa.null_col = -1; pa.has_cnt = 0;
@@ -1013,10 +1041,17 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
       Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
       Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
       AggSel sl; uint64_t init = 0;
-      if (!select_group_agg(ap.aggregation, ap.out_type, &sl, &init))
-        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
-      pa.op = sl.op;
-      pa.val_col = store_reg(em.materialize(c), c.width);
+      if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
+        select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &sl, &init);
+        if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
+        pa.op = sl.op;
+        pa.val_col = store_reg(rowid_reg, 8);
+      } else {
+        if (!select_group_agg(ap.aggregation, ap.out_type, &sl, &init))
+          return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
+        pa.op = sl.op;
+        pa.val_col = store_reg(em.materialize(c), c.width);
+      }
       if (v.null >= 0) { pa.null_col = store_reg(v.null, 1); pa.has_cnt = 1; }
     }
     st->part_aggs.push_back(pa);
@@ -1198,7 +1233,39 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
       case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: {
         Stage st;
         if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
-        else SS_RETURN_IF_ERROR(finish_group_agg(d, op, pipe, &st));
+        else {
+          GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          bool too_wide = false;
+          Status s = finish_group_agg(g, pipe, &st, false, &too_wide);
+          if (!s.ok() && !too_wide) return s;
+          if (too_wide) {
+            // Keys that do not pack into one 64-bit word (e.g. a NULLABLE INT64 key, three INT32
+            // keys), or FIRST/LAST of a computed expression (the value is fetched by row id from a
+            // stored column): materialise the keys and the aggregated columns, radix-sort the rows by the
+            // keys and aggregate the now contiguous groups with the clustered kernel.  Group order
+            // is unspecified in the reference (hash order, aggregate_groups.cc:332-433).
+            std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
+            auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
+            GroupBinding gm = g;
+            for (auto& k : gm.kpos) k = slot_of(k);
+            for (auto& ap : gm.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+            Pipe pruned = pipe; pruned.cols.clear();
+            for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+            Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
+            stages->push_back(m);
+            Stage so; so.kind = STAGE_SORT; so.in_schema = m.out_schema; so.out_schema = m.out_schema;
+            for (int k : gm.kpos) {
+              if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length group keys are outside the device hot path");
+              SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+            }
+            for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+            stages->push_back(so);
+            reset_pipe(&pipe, so.out_schema);
+            st = Stage();
+            SS_RETURN_IF_ERROR(finish_group_agg(gm, pipe, &st, true));
+            desc << "(materialise + sort + clustered aggregation) ";
+          }
+        }
         desc << (op.kind == SSGPU_OP_SCALAR_AGGREGATE ? "ScalarAggregate" : "GroupAggregate") << " -> [" << schema_to_string(st.out_schema) << "]\n";
         stages->push_back(st);
         reset_pipe(&pipe, st.out_schema);
@@ -1233,7 +1300,8 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           for (size_t i = 0; i < pos.size(); ++i) { Attr a = st.in_schema[pos[i]]; a.name = names[i]; st.out_schema.push_back(a); }
           desc << "Sort -> [" << schema_to_string(st.out_schema) << "]\n";
         } else {
-          SS_RETURN_IF_ERROR(finish_group_agg(d, op, pipe, &st, true));
+          GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
           desc << "AggregateClusters -> [" << schema_to_string(st.out_schema) << "]\n";
         }
         stages->push_back(st);

@@ -1677,6 +1677,12 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
             lds_store2<u32>(I.dst, p, r[0], r[1]);
           }
         } break;
+        case VM_ROWID_64: { CASE_FENCE;      // global row id of every row of the tile
+          _Pragma("unroll") FOR_PAIRS {
+            const u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
+            lds_store2<u64>(I.dst, p, r0, r0 + 1ull);
+          }
+        } break;
         case VM_IDX_VALID: { CASE_FENCE;
           _Pragma("unroll") FOR_PAIRS {
             auto ix = lds_load2<u32>(I.a, p);
@@ -2303,6 +2309,26 @@ hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t
 }
 hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream) {
   if (P.n_rows) hipLaunchKernelGGL(ssgpu_join_build_kernel, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, stream, P);
+  return hipGetLastError();
+}
+// GroupAggregate FIRST / LAST: the group's accumulator holds the smallest / largest contributing
+// row id; the result is the input column's value at that row.
+__global__ __launch_bounds__(256) void ssgpu_gather_rowid_kernel(void* __restrict__ dst, const u8* __restrict__ dst_null, const void* __restrict__ src,
+                                                                 u32 width, const u64* __restrict__ rowids, i64 row_id_base,
+                                                                 const u64* __restrict__ n_rows_dev, u64 n_rows_max) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 n = n_rows_dev ? *n_rows_dev : n_rows_max;
+  if (i >= n || i >= n_rows_max) return;
+  const bool isnull = dst_null && dst_null[i];
+  const u64 r = isnull ? 0ull : (u64)((i64)rowids[i] - row_id_base);
+  if (width == 8) reinterpret_cast<u64*>(dst)[i] = isnull ? 0ull : reinterpret_cast<const u64*>(src)[r];
+  else if (width == 4) reinterpret_cast<u32*>(dst)[i] = isnull ? 0u : reinterpret_cast<const u32*>(src)[r];
+  else reinterpret_cast<u8*>(dst)[i] = isnull ? (u8)0 : reinterpret_cast<const u8*>(src)[r];
+}
+hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, const uint64_t* rowids,
+                                     int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream) {
+  if (n_rows_max) hipLaunchKernelGGL(ssgpu_gather_rowid_kernel, dim3((unsigned)((n_rows_max + 255) / 256)), dim3(256), 0, stream,
+                                     dst, dst_null, src, width, (const u64*)rowids, (i64)row_id_base, (const u64*)n_rows_dev, (u64)n_rows_max);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream) {

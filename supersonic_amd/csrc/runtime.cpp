@@ -96,6 +96,7 @@ struct StageExec {
   ProgramLayout lay_pcount{}, lay_pscatter{};
   int n_instr_pcount = 0, n_instr_pscatter = 0;
   std::vector<DevBuf> part_cols;
+  std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jrows, jmisc;
   std::vector<VmJoin> vm_joins;
@@ -711,7 +712,29 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
 }
 
 // occupied slots of the global group table -> dense result rows in slot order
-int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, uint32_t ng) {
+// FIRST / LAST inside Group/Clusters aggregates: the extracted column holds row ids (written to
+// ex.rowid_tmp[j]); fetch the input column's values at those rows into the real output column.
+static int gather_first_last(ssgpu_plan* p, Stage& st, StageExec& ex, size_t nk, const InCols& in, int64_t row_id_base,
+                             const uint64_t* n_rows_dev, uint64_t n_rows_max) {
+  ssgpu_ctx* c = p->ctx;
+  for (size_t j = 0; j < st.aggs.size(); ++j) {
+    const int col = st.aggs[j].gather_col;
+    if (col < 0) continue;
+    HIP_TRY(c, ssgpu_launch_gather_rowid(ex.out[nk + j].data.p, ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr,
+                                         in.cols[col].data, ex.out[nk + j].width, ex.rowid_tmp[j].as<uint64_t>(), row_id_base,
+                                         n_rows_dev, n_rows_max, c->stream));
+    p->counters.n_launches += 1;
+  }
+  return SSGPU_OK;
+}
+static int ensure_rowid_tmp(ssgpu_ctx* c, Stage& st, StageExec& ex, uint64_t rows) {
+  ex.rowid_tmp.resize(st.aggs.size());
+  for (size_t j = 0; j < st.aggs.size(); ++j)
+    if (st.aggs[j].gather_col >= 0) HIP_TRY(c, ex.rowid_tmp[j].ensure(std::max<uint64_t>(rows, 1) * 8));
+  return SSGPU_OK;
+}
+
+int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, uint32_t ng, const InCols& in, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx;
   const size_t slots = (size_t)capacity + 1;
   const int ntile = (int)((slots + 511) / 512);
@@ -733,8 +756,10 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
     G.keys_out[k].shift = f.shift; G.keys_out[k].bits = f.bits; G.keys_out[k].nullbit = f.nullbit; G.keys_out[k].width = f.width;
   }
   const size_t nk = st.group_keys.size();
+  rc = ensure_rowid_tmp(c, st, ex, slots);
+  if (rc != SSGPU_OK) return rc;
   for (size_t j = 0; j < st.aggs.size(); ++j) {
-    G.aggs_out[j].data = ex.out[nk + j].data.p;
+    G.aggs_out[j].data = st.aggs[j].gather_col >= 0 ? ex.rowid_tmp[j].p : ex.out[nk + j].data.p;
     G.aggs_out[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
     G.aggs_out[j].s = st.aggs[j].slot; G.aggs_out[j].out_kind = st.aggs[j].emit_kind; G.aggs_out[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
   }
@@ -742,6 +767,8 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
   HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), ntile, ex.total.as<uint64_t>(), c->stream));
   HIP_TRY(c, ssgpu_launch_group_extract(G, c->stream));
   p->counters.n_launches += 3;
+  rc = gather_first_last(p, st, ex, nk, in, row_id_base, ex.total.as<uint64_t>(), slots);
+  if (rc != SSGPU_OK) return rc;
   ex.out_rows = -1;
   return SSGPU_OK;
 }
@@ -845,7 +872,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, overflow=%u\n", NP, C, fb[0]);
-    if (!fb[0]) return extract_groups(p, st, ex, capacity, ng);
+    if (!fb[0]) return extract_groups(p, st, ex, capacity, ng, in, row_id_base);
     if (ex.part_n >= 8192) break;
     ex.part_n *= 2;   // a partition held more groups than its LDS table: partition finer and rerun
   }
@@ -970,7 +997,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     if ((uint64_t)ex.capacity >= (1ull << 30)) { c->err = "group table overflow"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
     ex.capacity *= 4;
   }
-  return extract_groups(p, st, ex, ex.capacity, ng);
+  return extract_groups(p, st, ex, ex.capacity, ng, in, row_id_base);
 }
 
 int sort_kind_of(int dtype) {   // 0 unsigned, 1 signed, 2 float32, 3 float64
@@ -1090,13 +1117,17 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
   HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  rc = ensure_rowid_tmp(c, st, ex, nseg);
+  if (rc != SSGPU_OK) return rc;
   std::vector<GroupAggOut> outs(st.aggs.size());
   for (size_t j = 0; j < st.aggs.size(); ++j) {
-    outs[j].data = ex.out[nk + j].data.p;
+    outs[j].data = st.aggs[j].gather_col >= 0 ? ex.rowid_tmp[j].p : ex.out[nk + j].data.p;
     outs[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
     outs[j].s = st.aggs[j].slot; outs[j].out_kind = st.aggs[j].emit_kind; outs[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
   }
   HIP_TRY(c, ssgpu_launch_dense_extract(ex.gacc.as<uint64_t>(), ex.gcnt.as<uint32_t>(), ng, nseg, outs.data(), (uint32_t)outs.size(), c->stream));
+  rc = gather_first_last(p, st, ex, nk, in, row_id_base, nullptr, nseg);
+  if (rc != SSGPU_OK) return rc;
   p->counters.n_launches += 6;
   ex.out_rows = (int64_t)nseg;
   return SSGPU_OK;

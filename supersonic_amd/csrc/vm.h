@@ -91,7 +91,7 @@
   X(NULL_OR)   /* dst = a | b  on null masks */                                \
   X(NULL_DIVZERO_32) X(NULL_DIVZERO_64) X(NULL_DIVZERO_F32) X(NULL_DIVZERO_F64)\
   X(FAIL_DIVZERO_32) X(FAIL_DIVZERO_64) X(FAIL_DIVZERO_F32) X(FAIL_DIVZERO_F64)\
-  X(FILL_8) X(FILL_32) X(FILL_64)                                              \
+  X(FILL_8) X(FILL_32) X(FILL_64) X(ROWID_64)                                  \
   X(SELECT_8) X(SELECT_32) X(SELECT_64) /* dst = c ? a : b  (IF / IFNULL) */   \
   X(SEL_FROM_PRED) /* dst = a(value) & !b(null)        filter.cc:180-196 */    \
   /* ---- scalar-aggregate sinks: dst = slot, a = value, b = null, c = sel -- */\

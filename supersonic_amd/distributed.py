@@ -28,7 +28,7 @@ def _merge_spec(spec):
     merged = ss.AggregationSpecification()
     counts = []
     for (aggregation, distinct, out_type, _input_name, output_name) in spec.elements:
-        if distinct or aggregation in (ss.FIRST, ss.LAST, ss.CONCAT):
+        if distinct or aggregation == ss.CONCAT:   # FIRST / LAST merge as themselves: partial tables are gathered in rank (= row) order
             raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "aggregation cannot be merged across shards")
         if aggregation == ss.COUNT:
             merged.AddAggregation(ss.SUM, output_name, output_name)   # COUNT merges as SUM of the partial counts

@@ -36,7 +36,8 @@ def make_view(n, seed=11):
 def spec():
     return (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "sv").AddAggregation(ss.MIN, "v", "mnv")
             .AddAggregation(ss.MAX, "d", "mxd").AddAggregation(ss.SUM, "d", "sd")
-            .AddAggregation(ss.COUNT, "v", "cv").AddAggregation(ss.COUNT, "", "n"))
+            .AddAggregation(ss.COUNT, "v", "cv").AddAggregation(ss.COUNT, "", "n")
+            .AddAggregation(ss.FIRST, "v", "fv").AddAggregation(ss.LAST, "d", "ld"))
 
 
 def child(view, with_filter):

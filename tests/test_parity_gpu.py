@@ -159,7 +159,7 @@ def group_query(view, with_filter, keys=("k1", "k2")):
 @pytest.mark.parametrize("with_filter", [False, True])
 @pytest.mark.parametrize("nullable", [False, True])
 def test_group_aggregate(gpu_ctx, n, with_filter, nullable):
-    # packed group keys are limited to 64 bits: a NULLABLE INT32 key takes 33 of them
+    # one packed 64-bit key word here (a NULLABLE INT32 key takes 33 bits); wider keys: test_group_aggregate_wide_keys
     keys = ("k1",) if nullable else ("k1", "k2")
     run_both(group_query(make_view(n, nullable=nullable), with_filter, keys), gpu_ctx, ignore_order=True)
 
@@ -169,6 +169,57 @@ def test_group_aggregate_int64_key(gpu_ctx, n):
     view = make_view(n)
     spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "s").AddAggregation(ss.MIN, "d", "mn").AddAggregation(ss.MAX, "d", "mx")
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["c"]), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_group_aggregate_wide_keys(gpu_ctx, n, with_filter):
+    # keys that do not pack into 64 bits run as materialise -> radix sort -> clustered aggregation:
+    # two NULLABLE INT32 keys (66 bits), a NULLABLE INT64 key (65 bits), INT64 + INT32 + BOOL (104 bits)
+    view = make_view(n, nullable=True)
+    run_both(group_query(view, with_filter, ("k1", "k2")), gpu_ctx, ignore_order=True)
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "s").AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.COUNT, "d0", "c").AddAggregation(ss.COUNT, "", "n")
+    child = ss.ScanView(view)
+    if with_filter:
+        child = ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), child)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["a"]), spec, None, child), gpu_ctx, ignore_order=True)
+    child = ss.Compute(ss.CompoundExpression().AddAs("k64", ss.Plus(NA("a"), NA("k1"))).Add(NA("k2")).Add(NA("t")).Add(NA("b")).Add(NA("d0")), child)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k64", "k2", "t"]), spec, None, child), gpu_ctx, ignore_order=True)
+
+
+def first_last_spec():
+    return (ss.AggregationSpecification().AddAggregation(ss.FIRST, "d0", "f_d0").AddAggregation(ss.LAST, "d0", "l_d0")
+            .AddAggregation(ss.FIRST, "c", "f_c").AddAggregation(ss.LAST, "u", "l_u").AddAggregation(ss.LAST, "t", "l_t")
+            .AddAggregation(ss.SUM, "b", "s").AddAggregation(ss.COUNT, "", "n"))
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
+@pytest.mark.parametrize("with_filter", [False, True])
+@pytest.mark.parametrize("partition", [0, 2])
+def test_group_aggregate_first_last(n, with_filter, partition):
+    # FIRST / LAST per group (aggregation_operators.h:290-320): first / last non-NULL value in input order
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", partition)
+    view = make_view(n, nullable=True)
+    child = ss.ScanView(view)
+    if with_filter:
+        child = ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), child)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), None, child), ctx, ignore_order=True)
+    # wide keys and a computed FIRST input: materialise + sort + clustered aggregation
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), first_last_spec(), None, child), ctx, ignore_order=True)
+    spec = ss.AggregationSpecification().AddAggregation(ss.FIRST, "x", "fx").AddAggregation(ss.LAST, "x", "lx").AddAggregation(ss.MAX, "x", "mx")
+    computed = ss.Compute(ss.CompoundExpression().Add(NA("k2")).AddAs("x", ss.Plus(NA("a"), NA("c"))), child)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, None, computed), ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("n", [0, 1, 1025, 100003])
+def test_aggregate_clusters_first_last(gpu_ctx, n):
+    view = make_view(n, nullable=True)
+    order = np.argsort(view.column(5).data, kind="stable")      # rows clustered by k2
+    cols = [ss.Column(view.column(i).data[order], None if view.column(i).is_null is None else view.column(i).is_null[order])
+            for i in range(view.column_count())]
+    clustered = ss.View(view.schema(), cols)
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), ss.ScanView(clustered)), gpu_ctx)
 
 
 def test_group_table_regrow():
