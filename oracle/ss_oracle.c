@@ -248,6 +248,8 @@ static void eval_mixed_int_compare(int op, int ta, const void* A, int tb, const 
 }
 
 static int eval_cast(int from, int to, const void* A, void* D, int64_t n) {
+  /* OPERATOR_DATE_TO_DATETIME (templated/cast_bound_expression.cc:129-136): days * microseconds per day */
+  if (from == T_DATE && to == T_DATETIME) { LOOP1(int32_t, int64_t, (int64_t)a * 86400000000LL) return 1; }
   const int kf = arith_kind(from), kt = arith_kind(to);
   if (kf < 0 || kt < 0) return 0;
 #define CASTROW(TA) switch (kt) { \
@@ -303,6 +305,12 @@ static bnode* fold(bnode* b, orc_error* err) {
 static bnode* make_cast(bnode* child, int to, int is_implicit, orc_error* err) {
   const int from = child->dtype;
   if (from == to) return child;
+  if (from == T_DATE && to == T_DATETIME) {
+    char nm[256]; snprintf(nm, sizeof(nm), "CAST_DATE_TO_DATETIME(%s)", child->name);
+    bnode* b = bnode_new(B_CAST, OP_CAST, to, child->nullable, nm);
+    b->args[0] = child; b->nargs = 1;
+    return fold(b, err);
+  }
   if (!is_numeric(from) || !is_numeric(to)) { set_err(err, RC_TYPE_MISMATCH, "Cannot cast %s to %s.", type_name(from), type_name(to)); return child; }
   if (is_float(from) && is_integer(to)) { set_err(err, RC_TYPE_MISMATCH, "Cannot cast %s to %s (floating to integer).", type_name(from), type_name(to)); return child; }
   int down = ((from == T_INT64 || from == T_UINT64) && (to == T_INT32 || to == T_UINT32 || to == T_FLOAT)) || (from == T_DOUBLE && to == T_FLOAT);

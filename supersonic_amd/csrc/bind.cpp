@@ -209,8 +209,23 @@ static Status make_cast(BExprP child, int to, bool is_implicit, BExprP* out) {
     return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH,
                          std::string("Cannot cast ") + dtype_name(from) + " to " + dtype_name(to) + " in " + child->name + ". " + why);
   };
-  if (from == SSGPU_DATE && to == SSGPU_DATETIME)
-    return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "DATE -> DATETIME cast is outside the device hot path");
+  if (from == SSGPU_DATE && to == SSGPU_DATETIME) {
+    // OPERATOR_DATE_TO_DATETIME (cast_bound_expression.cc:129-136, expression_traits.h:417-425):
+    // days since the epoch times the microseconds of a day
+    const int64_t micros_per_day = 86400000000LL;
+    if (child->kind == BExpr::NULLCONST) { *out = make_null(to); return Status::OK(); }
+    if (child->kind == BExpr::CONST) { *out = make_const(to, const_bits(to, bits_to_i64(from, child->bits) * micros_per_day, 0)); return Status::OK(); }
+    BExprP wide(new BExpr);
+    wide->kind = BExpr::CAST; wide->op = OP_CAST_QUIET; wide->dtype = to; wide->nullable = child->nullable;
+    wide->filter_depth = child->filter_depth; wide->name = child->name; wide->args.push_back(child);
+    BExprP e(new BExpr);
+    e->kind = BExpr::OP; e->op = OP_MULTIPLY; e->dtype = to; e->nullable = child->nullable;
+    e->filter_depth = child->filter_depth;
+    e->name = "CAST_DATE_TO_DATETIME(" + child->name + ")";
+    e->args.push_back(wide); e->args.push_back(make_const(to, const_bits(to, micros_per_day, 0)));
+    *out = e;
+    return Status::OK();
+  }
   if (!dtype_is_numeric(from) || !dtype_is_numeric(to)) return bad("Only numeric casts are supported.");
   if (dtype_is_float(from) && dtype_is_integer(to)) return bad("Casts from floating point to integer types are not allowed.");
   bool down = ((from == SSGPU_INT64 || from == SSGPU_UINT64) && (to == SSGPU_INT32 || to == SSGPU_UINT32 || to == SSGPU_FLOAT)) ||

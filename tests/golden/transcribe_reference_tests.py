@@ -78,6 +78,17 @@ def expr_plan_case(name, source, in_types, expr, out_type, rows, nullable=True):
 A = "supersonic/expression/core/arithmetic_expressions_test.cc"
 E = "supersonic/expression/core/elementary_expressions_test.cc"
 
+# ---- casts (templated/cast_expression_test.cc) ------------------------------------------------
+expr_plan_case("DateToDatetimeCast", "supersonic/expression/templated/cast_expression_test.cc:335-341", [DATE],
+               ["CastToType", "DATETIME", ["AttributeAt", 0]], "DATETIME",
+               [[1, 86400000000], [100, 8640000000000], [14600, 1261440000000000]], nullable=False)
+expr_plan_case("StandardCast_int32_to_int64", "supersonic/expression/templated/cast_expression_test.cc:318-327", [I32],
+               ["CastToType", "INT64", ["AttributeAt", 0]], "INT64",
+               [[476, 476], [1054, 1054], [1453, 1453], [1517, 1517], [1914, 1914], [1939, 1939], [2011, 2011]], nullable=False)
+expr_plan_case("StandardCast_uint64_to_uint32", "supersonic/expression/templated/cast_expression_test.cc:329-333", [U64],
+               ["CastToType", "UINT32", ["AttributeAt", 0]], "UINT32",
+               [[1234, 1234], [18446744073709551615, 4294967295], [0, 0]], nullable=False)
+
 # ---- arithmetic (arithmetic_expressions_test.cc) ---------------------------------------------
 bind_case("NegateBinding_double", A + ":25-27", "Negate", [F64], [False], "(-$0)", F64, False)
 bind_case("NegateBinding_int32", A + ":25-28", "Negate", [I32], [False], "(-$0)", I32, False)

@@ -39,7 +39,11 @@ def build_view(inp):
         if t == "STRING":
             data = ["" if v is None else v for v in vals]
         else:
-            data = np.array([0 if v is None else _value(v) for v in vals]).astype(dt) if vals else np.zeros(0, dt)
+            py = [0 if v is None else _value(v) for v in vals]
+            if np.issubdtype(dt, np.integer) and all(isinstance(v, int) and not isinstance(v, bool) for v in py):
+                data = np.array(py, dtype=dt)      # exact for UINT64 values above 2^63
+            else:
+                data = np.array(py).astype(dt) if vals else np.zeros(0, dt)
         cols.append(ss.Column(data, nulls if nullable else None))
         if not nullable:
             assert not nulls.any()
@@ -64,6 +68,8 @@ def build_expr(e):
         return ss.In(build_expr(args[0]), [build_expr(a) for a in args[1:]])
     if head == "NullOf":
         return ss.Null(TYPES[args[0]])
+    if head == "CastToType":   # CastTo(type, expr)
+        return ss.CastTo(TYPES[args[0]], build_expr(args[1]))
     if head in ("AttributeAt", "NamedAttribute") or head.startswith("Const"):
         return getattr(ss, head)(*args)
     return getattr(ss, head)(*[build_expr(a) for a in args])

@@ -529,3 +529,22 @@ def test_aggregate_clusters(gpu_ctx, n, nullable):
             .AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.COUNT, "v", "cv")
             .AddAggregation(ss.COUNT, "", "n"))
     run_both(ss.AggregateClusters(ss.ProjectNamedAttributes(["k", "k2"]), spec, ss.ScanView(view)), gpu_ctx)
+
+
+@pytest.mark.parametrize("n", [0, 1, 1025, 100003])
+def test_date_and_datetime(gpu_ctx, n):
+    # DATE (days, INT32) / DATETIME (microseconds, INT64): the DATE -> DATETIME cast multiplies by the
+    # microseconds of a day (cast_bound_expression.cc:129-136); IFNULL / IF / CASE promote DATE to DATETIME through it,
+    # comparisons of the two need the explicit cast (comparison_bound_expressions.cc:613)
+    rng = np.random.default_rng(3)
+    schema = ss.TupleSchema([ss.Attribute("day", ss.DATE, ss.NULLABLE), ss.Attribute("ts", ss.DATETIME), ss.Attribute("v", ss.INT64)])
+    view = ss.View(schema, [ss.Column(rng.integers(-20000, 20000, n).astype(np.int32), rng.random(n) < 0.1),
+                            rng.integers(-20000, 20000, n) * 86400000000 + rng.integers(0, 86400000000, n), rng.integers(0, 1000, n)])
+    e = (ss.CompoundExpression().AddAs("dt", ss.CastTo(ss.DATETIME, NA("day"))).AddAs("before", ss.Less(ss.CastTo(ss.DATETIME, NA("day")), NA("ts")))
+         .AddAs("filled", ss.IfNull(NA("day"), NA("ts"))).AddAs("c", ss.CastTo(ss.DATETIME, ss.ConstDate(14600))).Add(NA("v")))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
+    spec = ss.AggregationSpecification().AddAggregation(ss.MIN, "ts", "first_ts").AddAggregation(ss.MAX, "dt", "last_day").AddAggregation(ss.SUM, "v", "s")
+    q = ss.GroupAggregate(ss.ProjectNamedAttributes(["before"]), spec, None,
+                          ss.Compute(ss.CompoundExpression().AddAs("dt", ss.CastTo(ss.DATETIME, NA("day"))).AddAs("before", ss.Less(ss.CastTo(ss.DATETIME, NA("day")), NA("ts"))).Add(NA("ts")).Add(NA("v")),
+                                     ss.ScanView(view)))
+    run_both(q, gpu_ctx, ignore_order=True)
