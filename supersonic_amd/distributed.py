@@ -94,3 +94,127 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
                 e.Add(ss.NamedAttribute(a.name()))
         merged = ss.Compute(e, merged)
     return executor(merged)
+
+
+# ---------------------------------------------------------------------------------------------
+# Sort across shards: sample sort with ONE all-to-all (BASELINE config #5 scaled out)
+# ---------------------------------------------------------------------------------------------
+_CONST_OF = {ss.INT32: ss.ConstInt32, ss.INT64: ss.ConstInt64, ss.UINT32: ss.ConstUint32, ss.UINT64: ss.ConstUint64,
+             ss.FLOAT: ss.ConstFloat, ss.DOUBLE: ss.ConstDouble, ss.DATE: ss.ConstDate, ss.DATETIME: ss.ConstDateTime}
+
+
+def _choose_splitters(samples, world):
+    """world - 1 ascending splitters from the gathered, sorted sample of first-key values."""
+    if len(samples) == 0:
+        return []
+    return [samples[min(len(samples) - 1, (i + 1) * len(samples) // world)] for i in range(world - 1)]
+
+
+def _range_predicate(key, dtype, nullable, splitters, d, world, descending):
+    """Rows whose first sort key belongs to destination rank d.  Ascending: rank 0 takes the
+    smallest values and the NULLs (NULLs sort first, sort.cc:205-238); descending: mirrored, NULLs
+    last.  All rows with equal first-key values land on the same rank, so the remaining keys and
+    the stable tie order are settled by the destination's local sort."""
+    const = _CONST_OF[dtype]
+    b = (world - 1 - d) if descending else d          # bucket index in ascending value order
+    pred = None
+    if splitters:
+        if b > 0:
+            pred = ss.Greater(ss.NamedAttribute(key), const(splitters[b - 1]))
+        if b < world - 1:
+            hi = ss.LessOrEqual(ss.NamedAttribute(key), const(splitters[b]))
+            pred = hi if pred is None else ss.And(pred, hi)
+    elif b != 0:
+        pred = ss.ConstBool(False)                      # no non-NULL value anywhere: one bucket holds everything
+    if pred is None:
+        pred = ss.ConstBool(True)
+    if nullable:
+        null_rank = world - 1 if descending else 0
+        isnull = ss.IsNull(ss.NamedAttribute(key))
+        pred = ss.Or(isnull, pred) if d == null_rank else ss.And(ss.Not(isnull), pred)
+    return pred
+
+
+def _all_to_all_views(parts, schema, group, device):
+    """parts[d] = this rank's rows for rank d (same schema).  Returns the rows every rank sent to
+    this one, concatenated in source-rank order.  One all-gather of the count matrix, then one
+    all_to_all_single per column buffer (values, NULL mask)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    send = torch.tensor([p.row_count() for p in parts], dtype=torch.int64, device=device)
+    matrix = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(matrix, send, group=group)
+    recv = [int(matrix[src][rank].item()) for src in range(world)]
+    sent = [int(x) for x in send.tolist()]
+    cols = []
+    for i in range(schema.attribute_count()):
+        np_dtype = parts[0].column(i).data.dtype
+        if np_dtype == object:
+            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
+        bufs = []
+        for which in (0, 1):
+            if which == 1 and not schema.attribute(i).is_nullable():
+                bufs.append(None)
+                continue
+            dt = np_dtype if which == 0 else np.dtype(np.bool_)
+            pieces = []
+            for p in parts:
+                arr = p.column(i).data if which == 0 else p.column(i).is_null
+                if arr is None:
+                    arr = np.zeros(p.row_count(), dtype=np.bool_)
+                pieces.append(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+            out_bytes = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+            t_in = torch.from_numpy(out_bytes.copy()).to(device)
+            t_out = torch.empty(sum(recv) * dt.itemsize, dtype=torch.uint8, device=device)
+            dist.all_to_all_single(t_out, t_in, [r * dt.itemsize for r in recv], [s * dt.itemsize for s in sent], group=group)
+            bufs.append(t_out.cpu().numpy().view(dt))
+        cols.append(ss.Column(bufs[0], bufs[1]))
+    return ss.View(schema, cols, sum(recv))
+
+
+def sharded_sort(sort_order, local_child, executor, group=None, device="cpu", samples_per_rank=256):
+    """Sort(sort_order, <all shards of local_child>) as a sample sort: local sort, splitters from a
+    regular sample of the first key, ONE all-to-all of the rows, local sort of what arrived.
+
+    Returns this rank's slice of the globally sorted rows: the concatenation of the results in
+    rank order equals the single-process Sort (same stable order of ties when the shards are
+    contiguous row ranges in rank order).  Rows are partitioned by the first key only, so a first
+    key with few distinct values balances poorly (but stays correct)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    local = executor(ss.Sort(sort_order, None, 0, local_child))
+    if world == 1:
+        return local
+    schema = local.schema()
+    key, order = sort_order.keys[0]
+    pos = [schema.attribute(i).name() for i in range(schema.attribute_count())].index(key)
+    attr = schema.attribute(pos)
+    if attr.type() not in _CONST_OF:
+        raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "first sort key type cannot be range-partitioned across shards yet")
+    descending = order == ss.DESCENDING
+    # regular sample of the non-NULL first-key values of the (already sorted) shard
+    col = local.column(pos)
+    vals = col.data if col.is_null is None else col.data[~col.is_null]
+    take = min(samples_per_rank, len(vals))
+    sample = np.zeros(samples_per_rank, dtype=vals.dtype)
+    if take:
+        sample[:take] = vals[(np.arange(take) * len(vals)) // take]
+    raw = torch.from_numpy(np.concatenate([np.array([take], dtype=np.int64).view(np.uint8), sample.view(np.uint8)]).copy()).to(device)
+    gathered = [torch.empty_like(raw) for _ in range(world)]
+    dist.all_gather(gathered, raw, group=group)
+    everyone = []
+    for g in gathered:
+        b = g.cpu().numpy()
+        n = int(b[:8].view(np.int64)[0])
+        everyone.append(b[8:].view(vals.dtype)[:n])
+    allv = np.sort(np.concatenate(everyone)) if everyone else np.zeros(0, vals.dtype)
+    splitters = [v.item() for v in _choose_splitters(allv, world)]
+    parts = [executor(ss.Filter(_range_predicate(key, attr.type(), attr.is_nullable(), splitters, d, world, descending),
+                                ss.ProjectAllAttributes(), ss.ScanView(local))) for d in range(world)]
+    arrived = _all_to_all_views(parts, schema, group, device)
+    return executor(ss.Sort(sort_order, None, 0, ss.ScanView(arrived)))

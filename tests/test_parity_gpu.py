@@ -548,3 +548,18 @@ def test_date_and_datetime(gpu_ctx, n):
                           ss.Compute(ss.CompoundExpression().AddAs("dt", ss.CastTo(ss.DATETIME, NA("day"))).AddAs("before", ss.Less(ss.CastTo(ss.DATETIME, NA("day")), NA("ts"))).Add(NA("ts")).Add(NA("v")),
                                      ss.ScanView(view)))
     run_both(q, gpu_ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_sample_sort_range_filters(gpu_ctx, descending):
+    # the per-destination range Filters of supersonic_amd.distributed.sharded_sort (the N > 1 Sort) on the device:
+    # parity with the oracle, and every row lands on exactly one of 4 ranks
+    from supersonic_amd.distributed import _range_predicate
+    view = make_view(100003, nullable=True)
+    total = 0
+    for d in range(4):
+        pred = _range_predicate("a", ss.INT64, True, [120, 500, 500], d, 4, descending)
+        op = ss.Filter(pred, ss.ProjectNamedAttributes(["a", "d", "d0"]), ss.ScanView(view))
+        run_both(op, gpu_ctx)
+        total += ss.drain(op.CreateCursor(gpu_ctx), 1 << 20).row_count()
+    assert total == 100003
