@@ -144,6 +144,29 @@ SYMBOLS = [
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and finds it by file name,
+    so a process that loads libssgpu.so first (which binds /opt/rocm's copy by SONAME) and torch later
+    ends up with TWO HIP runtimes, and the second one sees no GPU.  Loading torch's copy first makes
+    both resolve to the same runtime in either import order (torch itself is not imported here)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libssgpu.so; fails loudly if the HIP extension was not built."""
     global _lib
@@ -152,6 +175,7 @@ def load():
             raise RuntimeError(
                 "libssgpu.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` -- "
                 "there is no CPU fallback for the product path" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the library does not export the ABI

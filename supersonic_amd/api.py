@@ -936,6 +936,20 @@ class Plan(object):
             cols.append(Column(data, nulls))
         return View(self.result_schema, cols, rows)
 
+    def result_device_view(self, res=None):
+        """The result as a DeviceView over the plan's own output buffers (no copy): valid until the
+        plan runs again or is destroyed -- keep the Plan alive while the view is in use."""
+        res = res or self._result
+        rows = self.lib.ssgpu_result_row_count(res)
+        if rows < 0:
+            raise SupersonicException(L.ERROR_HIP, self.ctx.last_error())
+        ptrs = []
+        for i in range(self.result_schema.attribute_count()):
+            col = L.Column()
+            self.ctx.check(self.lib.ssgpu_result_device_column(res, i, C.byref(col)))
+            ptrs.append((col.data or 0, col.is_null or 0))
+        return DeviceView(self.result_schema, ptrs, rows)
+
     def counters(self):
         c = L.Counters()
         self.ctx.check(self.lib.ssgpu_plan_counters(self.handle, C.byref(c)))

@@ -218,3 +218,107 @@ def sharded_sort(sort_order, local_child, executor, group=None, device="cpu", sa
                                 ss.ProjectAllAttributes(), ss.ScanView(local))) for d in range(world)]
     arrived = _all_to_all_views(parts, schema, group, device)
     return executor(ss.Sort(sort_order, None, 0, ss.ScanView(arrived)))
+
+
+class _DevPtr(object):
+    """A raw device pointer as something torch.as_tensor can wrap without a copy."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _bytes_over(torch, device, ptr, nbytes):
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DevPtr(ptr, nbytes, "|u1"), device=device)
+
+
+def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_rank=256, always_exchange=False):
+    """sharded_sort with every row staying in HBM: the local sorts and the range Filters run as device
+    plans, their result buffers are wrapped as torch tensors (no copy) and exchanged with ONE RCCL
+    all_to_all_single per column buffer, and the arrivals are sorted where they land.
+
+    local_view: this rank's shard (host View or DeviceView).  Returns (plan, DeviceView): the rank's
+    slice of the global order as device columns owned by `plan` (fetch with plan.fetch())."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = torch.device("cuda", torch.cuda.current_device())
+    schema = local_view.schema()
+    n_attrs = schema.attribute_count()
+    widths = []
+    for i in range(n_attrs):
+        if schema.attribute(i).type() == ss.STRING:
+            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
+        widths.append(np.dtype(ss.numpy_dtype(schema.attribute(i).type())).itemsize)
+    first = ss.Plan(ss.Sort(sort_order, None, 0, ss.ScanView(local_view)), ctx)
+    first.run()
+    ctx.synchronize()
+    local = first.result_device_view()
+    if world == 1 and not always_exchange:
+        return first, local
+    key, order = sort_order.keys[0]
+    pos = [schema.attribute(i).name() for i in range(n_attrs)].index(key)
+    attr = schema.attribute(pos)
+    if attr.type() not in _CONST_OF:
+        raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "first sort key type cannot be range-partitioned across shards yet")
+    descending = order == ss.DESCENDING
+    np_dt = np.dtype(ss.numpy_dtype(attr.type()))
+    rows = local.row_count()
+    # the NULLs of the first key are one contiguous run of the sorted shard (front for ASCENDING, back for DESCENDING)
+    n_null = 0
+    if attr.is_nullable() and rows and local._ptrs[pos][1]:
+        n_null = int(_bytes_over(torch, device, local._ptrs[pos][1], rows).sum(dtype=torch.int64).item())
+    lo = 0 if descending else n_null
+    n_val = rows - n_null
+    take = min(samples_per_rank, n_val)
+    sample = torch.zeros(samples_per_rank * np_dt.itemsize + 8, dtype=torch.uint8, device=device)
+    sample[:8] = torch.tensor([take], dtype=torch.int64, device=device).view(torch.uint8)
+    if take:
+        keys = _bytes_over(torch, device, local._ptrs[pos][0], rows * np_dt.itemsize).view(-1, np_dt.itemsize)
+        idx = lo + (torch.arange(take, device=device, dtype=torch.int64) * n_val) // take
+        sample[8:8 + take * np_dt.itemsize] = keys[idx].reshape(-1)
+    gathered = [torch.empty_like(sample) for _ in range(world)]
+    dist.all_gather(gathered, sample, group=group)
+    everyone = []
+    for g in gathered:
+        b = g.cpu().numpy()
+        everyone.append(b[8:].view(np_dt)[: int(b[:8].view(np.int64)[0])])
+    allv = np.sort(np.concatenate(everyone))
+    splitters = [v.item() for v in _choose_splitters(allv, world)]
+    # one range Filter per destination, straight over the sorted shard's device columns
+    parts = []
+    for d in range(world):
+        pl = ss.Plan(ss.Filter(_range_predicate(key, attr.type(), attr.is_nullable(), splitters, d, world, descending),
+                               ss.ProjectAllAttributes(), ss.ScanView(local)), ctx)
+        pl.run()
+        parts.append((pl, pl.result_device_view()))
+    ctx.synchronize()
+    send = torch.tensor([v.row_count() for (_p, v) in parts], dtype=torch.int64, device=device)
+    matrix = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(matrix, send, group=group)
+    recv = [int(matrix[src][rank].item()) for src in range(world)]
+    sent = [int(x) for x in send.tolist()]
+    arrived, keep = [], []
+    for i in range(n_attrs):
+        ptrs = []
+        for which, w in ((0, widths[i]), (1, 1)):
+            if which == 1 and not schema.attribute(i).is_nullable():
+                ptrs.append(0)
+                continue
+            pieces = [_bytes_over(torch, device, v._ptrs[i][which], v.row_count() * w) if v._ptrs[i][which]
+                      else torch.zeros(v.row_count() * w, dtype=torch.uint8, device=device) for (_p, v) in parts]
+            t_in = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=device)
+            t_out = torch.empty(max(sum(recv) * w, 1), dtype=torch.uint8, device=device)
+            dist.all_to_all_single(t_out[: sum(recv) * w], t_in, [r * w for r in recv], [s * w for s in sent], group=group)
+            keep.append(t_out)
+            ptrs.append(t_out.data_ptr())
+        arrived.append((ptrs[0], ptrs[1]))
+    torch.cuda.synchronize()
+    final = ss.Plan(ss.Sort(sort_order, None, 0, ss.ScanView(ss.DeviceView(schema, arrived, sum(recv)))), ctx)
+    final.run()
+    ctx.synchronize()
+    del keep, parts
+    return final, final.result_device_view()

@@ -6,6 +6,8 @@ Row counts follow the reference's block-size cross product idea
 (supersonic/testing/operation_testing.cc:350-352), restated as launch-geometry / tile-boundary
 cases: around one wave (64), one tile (512/1024/2048) and many tiles.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -563,3 +565,27 @@ def test_sample_sort_range_filters(gpu_ctx, descending):
         run_both(op, gpu_ctx)
         total += ss.drain(op.CreateCursor(gpu_ctx), 1 << 20).row_count()
     assert total == 100003
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_device_sharded_sort_single_rank_exchange(descending):
+    # the device-resident sample sort (local sort -> range Filters -> RCCL all_to_all_single over the plans' own
+    # result buffers -> local sort) with the exchange forced on a 1-rank process group
+    import socket
+    import torch
+    import torch.distributed as dist
+    from supersonic_amd.distributed import device_sharded_sort
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = ss.Context(0)
+        view = make_view(100003, nullable=True)
+        so = ss.SortOrder().add("a", ss.DESCENDING if descending else ss.ASCENDING).add("k2", ss.ASCENDING)
+        plan, _dv = device_sharded_sort(ctx, so, view, always_exchange=True)
+        got = plan.fetch()
+        _schema, want = oracle_run(ss.Sort(so, None, 0, ss.ScanView(view)))
+        assert_cols_equal([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())], want, context="device sharded sort")
+    finally:
+        dist.destroy_process_group()
