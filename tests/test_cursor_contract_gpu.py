@@ -1,0 +1,95 @@
+"""Cursor-contract tests modelled on the reference's OperationTest fixture
+(supersonic/testing/operation_testing.cc:350-352,452-520): every operator is pulled with the output
+block sizes {1, 2, 5, 20, 10001, "everything"}, Interrupt() is best-effort and leaves the plan
+usable (cursor.h:150-186), and repeated runs of a plan do not grow device memory
+(expression_test_helper.cc:213-245, the "memory stability" run)."""
+import threading
+
+import numpy as np
+import pytest
+
+import supersonic_amd as ss
+from helpers import run_both
+from test_parity_gpu import make_view, fpa_narrow, group_query
+
+pytestmark = pytest.mark.gpu
+NA = ss.NamedAttribute
+
+
+def operators(view):
+    flt = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectNamedAttributes(["a", "d0", "k1"]), ss.ScanView(view))
+    return {
+        "scalar": fpa_narrow(view),
+        "compute": ss.Compute(ss.CompoundExpression().AddAs("s", ss.Plus(NA("a"), NA("b"))).Add(NA("t")), ss.ScanView(view)),
+        "filter": flt,
+        "group": group_query(view, True, ("k2",)),
+        "sort": ss.Sort(ss.SortOrder().add("k1", ss.DESCENDING).add("a", ss.ASCENDING), None, 0, flt),
+    }
+
+
+@pytest.mark.parametrize("max_rows", [1, 2, 5, 20, 10001, 1 << 40])
+@pytest.mark.parametrize("name", ["scalar", "compute", "filter", "group", "sort"])
+def test_output_block_sizes(gpu_ctx, name, max_rows):
+    n = 137 if max_rows < 20 else 30011
+    op = operators(make_view(n, nullable=True))[name]
+    cur = op.CreateCursor(gpu_ctx)
+    seen = 0
+    while True:
+        r = cur.Next(max_rows)
+        assert not r.is_failure(), r.exception()
+        if r.is_eos():
+            break
+        assert 1 <= r.view().row_count() <= max_rows          # cursor.h:131-148
+        seen += r.view().row_count()
+    assert cur.Next(max_rows).is_eos()                          # EOS is sticky
+    got = run_both(op, gpu_ctx, ignore_order=(name == "group"), max_rows=max_rows)
+    assert got.row_count() == seen
+
+
+def test_interrupt_before_next_and_reuse(gpu_ctx):
+    op = operators(make_view(30011))["sort"]
+    cur = op.CreateCursor(gpu_ctx)
+    cur.Interrupt()
+    r = cur.Next(1024)
+    assert r.is_failure() and r.exception().return_code == ss.INTERRUPTED
+    run_both(op, gpu_ctx)                                       # a fresh cursor over the same operation is unaffected
+
+
+def test_interrupt_from_another_thread_is_best_effort(gpu_ctx):
+    # multi-stage plan (count pass, compaction, radix sort passes, gathers): the flag is checked between stages
+    view = make_view(2000003)
+    op = ss.Sort(ss.SortOrder().add("d", ss.ASCENDING), None, 0,
+                 ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(99)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    outcomes = set()
+    for delay in (0.0, 0.0005, 0.002, 0.01):
+        cur = op.CreateCursor(gpu_ctx)
+        timer = threading.Timer(delay, cur.Interrupt)
+        timer.start()
+        r = cur.Next(1 << 30)
+        timer.join()
+        if r.is_failure():
+            assert r.exception().return_code == ss.INTERRUPTED
+            outcomes.add("interrupted")
+        else:
+            assert r.view().row_count() > 0
+            outcomes.add("completed")
+    assert outcomes                                             # either outcome is legal; no crash, no other error
+    cur = op.CreateCursor(gpu_ctx)
+    r = cur.Next(1 << 30)
+    assert not r.is_failure() and r.view().row_count() == int((view.column(0).data > 99).sum())
+
+
+def test_repeated_runs_do_not_grow_device_memory(gpu_ctx):
+    import torch
+    view = make_view(200003, nullable=True)
+    for name, op in operators(view).items():
+        plan = ss.Plan(op, gpu_ctx)
+        for _ in range(3):                                      # warm-up: buffers are sized on the first runs
+            plan.run(); plan.fetch()
+        gpu_ctx.synchronize()
+        free_before, _total = torch.cuda.mem_get_info(0)
+        for _ in range(7):
+            plan.run(); plan.fetch()
+        gpu_ctx.synchronize()
+        free_after, _total = torch.cuda.mem_get_info(0)
+        assert free_after >= free_before, (name, free_before, free_after)
