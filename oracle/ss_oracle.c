@@ -44,7 +44,8 @@ enum { RC_OK = 0, RC_NOT_IMPLEMENTED = 103, RC_EVALUATION_ERROR = 104, RC_COUNT_
 enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DIVIDE_NULLING = 14,
        OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
        OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36, OP_AND = 40, OP_OR = 44,
-       OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116,
+       OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_BITWISE_AND = 60, OP_BITWISE_OR = 64, OP_BITWISE_NOT = 68,
+       OP_BITWISE_XOR = 72, OP_SHIFT_LEFT = 76, OP_SHIFT_RIGHT = 80, OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116,
        OP_LESS_OR_EQUAL = 120, OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
        OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
        OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
@@ -201,6 +202,11 @@ static int eval_binary(int op, int t, const void* A, const void* B, void* D, int
         case 4: LOOP2(float, float, float, a / b) return 1;
         case 5: LOOP2(double, double, double, a / b) return 1;
       } return 0;
+/* operators.h:145-173: & | ^ and (~a) & b on the common integer type */
+#define BITOP(OPID, EXPR) case OPID: switch (k) { \
+      case 0: case 1: LOOP2(uint32_t, uint32_t, uint32_t, EXPR) return 1; \
+      case 2: case 3: LOOP2(uint64_t, uint64_t, uint64_t, EXPR) return 1; } return 0;
+    BITOP(OP_BITWISE_AND, a & b) BITOP(OP_BITWISE_OR, a | b) BITOP(OP_BITWISE_XOR, a ^ b) BITOP(OP_BITWISE_ANDNOT, (~a) & b)
     case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING:
       switch (k) {
         case 0: LOOP2(int32_t, int32_t, int32_t, (b == 0 || b == -1 ? 0 : a % b)) return 1;
@@ -332,7 +338,10 @@ static void fmt_binary(char* out, size_t cap, int op, const char* l, const char*
     case OP_EQUAL: s = "=="; break; case OP_NOT_EQUAL: s = "<>"; break; case OP_LESS: s = "<"; break;
     case OP_LESS_OR_EQUAL: s = "<="; break; case OP_AND: s = "AND"; break; case OP_OR: s = "OR"; break;
     case OP_AND_NOT: s = "!&&"; break; case OP_XOR: s = "XOR"; break;
+    case OP_BITWISE_AND: s = "&"; break; case OP_BITWISE_OR: s = "|"; break; case OP_BITWISE_XOR: s = "^"; break;
+    case OP_SHIFT_LEFT: s = "<<"; break; case OP_SHIFT_RIGHT: s = ">>"; break;
   }
+  if (op == OP_BITWISE_ANDNOT) { snprintf(out, cap, "(~%s & %s)", l, r); return; }   /* expression_traits.h:1527-1536 */
   if (op == OP_IF_NULL) snprintf(out, cap, "IFNULL(%s, %s)", l, r);
   else snprintf(out, cap, "(%s %s %s)", l, s, r);
 }
@@ -435,6 +444,28 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       if (err->code) return NULL;
       int can_null = op == OP_CPP_DIVIDE_NULLING || op == OP_MODULUS_NULLING;
       return make_op2(op, t, l->nullable || r->nullable || can_null, l, r, err);
+    }
+    case OP_BITWISE_AND: case OP_BITWISE_OR: case OP_BITWISE_XOR: case OP_BITWISE_ANDNOT: {
+      /* CreateBinaryIntegerExpression, bound_expression_factory.h:520-535: common type, integers only */
+      int t = common_type(a[0]->dtype, a[1]->dtype, err);
+      if (err->code) return NULL;
+      if (!is_integer(t)) { set_err(err, RC_TYPE_MISMATCH, "Operator not defined for type %s%s", type_name(t), ""); return NULL; }
+      bnode* l = make_cast(a[0], t, 1, err); bnode* r = make_cast(a[1], t, 1, err);
+      if (err->code) return NULL;
+      return make_op2(op, t, l->nullable || r->nullable, l, r, err);
+    }
+    case OP_SHIFT_LEFT: case OP_SHIFT_RIGHT: {
+      /* CreateShiftExpression, elementary_bound_expressions.cc:1446-1489: the result inherits the LEFT
+       * type, the shift count is any integer type and is not promoted */
+      if (!is_integer(a[0]->dtype) || !is_integer(a[1]->dtype)) { set_err(err, RC_TYPE_MISMATCH, "Shift needs integer arguments%s%s", "", ""); return NULL; }
+      return make_op2(op, a[0]->dtype, a[0]->nullable || a[1]->nullable, a[0], a[1], err);
+    }
+    case OP_BITWISE_NOT: {
+      /* CreateIntegerUnaryFactory, elementary_bound_expressions.cc:1433-1443,1490-1503 */
+      if (!is_integer(a[0]->dtype)) { set_err(err, RC_TYPE_MISMATCH, "BITWISE NOT needs an integer argument%s%s", "", ""); return NULL; }
+      char nm[256]; snprintf(nm, sizeof(nm), "(~%s)", a[0]->name);
+      bnode* b = bnode_new(B_OP, op, a[0]->dtype, a[0]->nullable, nm); b->args[0] = a[0]; b->nargs = 1;
+      return fold(b, err);
     }
     case OP_DIVIDE_QUIET: case OP_DIVIDE_NULLING: case OP_DIVIDE_SIGNALING: {
       /* always DOUBLE, arithmetic_bound_expressions.cc:47-72 */
@@ -635,6 +666,29 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
         case 5: LOOP1(double, double, -a) break;
       }
       b->nulls = x->nulls; return;
+    }
+    case OP_BITWISE_NOT: {
+      const void* A = x->data; void* D = b->buf;
+      if (type_width(b->dtype) == 4) LOOP1(uint32_t, uint32_t, ~a) else LOOP1(uint64_t, uint64_t, ~a)
+      b->nulls = x->nulls; return;
+    }
+    case OP_SHIFT_LEFT: case OP_SHIFT_RIGHT: {
+      /* operators.h:175-183: T1(a << b) / T1(a >> b); >> of a signed left operand is arithmetic (gcc / x86).
+       * Counts outside [0, width) are undefined in the reference and are not exercised. */
+      const int left = b->op == OP_SHIFT_LEFT, kx = arith_kind(x->dtype), ky = arith_kind(y->dtype);
+      if (x->nulls || y->nulls) { or_nulls(b->nullbuf, x->nulls, y->nulls, n); b->nulls = b->nullbuf; }
+      for (int64_t i = 0; i < n; ++i) {
+        uint64_t c;
+        switch (ky) { case 0: c = (uint64_t)(int64_t)((const int32_t*)y->data)[i]; break; case 1: c = ((const uint32_t*)y->data)[i]; break;
+                      default: c = ((const uint64_t*)y->data)[i]; break; }
+        switch (kx) {
+          case 0: { int32_t v = ((const int32_t*)x->data)[i]; c &= 31; ((int32_t*)b->buf)[i] = left ? (int32_t)((uint32_t)v << c) : (v >> c); } break;
+          case 1: { uint32_t v = ((const uint32_t*)x->data)[i]; c &= 31; ((uint32_t*)b->buf)[i] = left ? (v << c) : (v >> c); } break;
+          case 2: { int64_t v = ((const int64_t*)x->data)[i]; c &= 63; ((int64_t*)b->buf)[i] = left ? (int64_t)((uint64_t)v << c) : (v >> c); } break;
+          default: { uint64_t v = ((const uint64_t*)x->data)[i]; c &= 63; ((uint64_t*)b->buf)[i] = left ? (v << c) : (v >> c); } break;
+        }
+      }
+      return;
     }
     case OP_IS_NULL: { uint8_t* D = (uint8_t*)b->buf; for (int64_t i = 0; i < n; ++i) D[i] = x->nulls ? x->nulls[i] : 0; return; }
     /* ---- exact math family: the functors of expression/core/math_evaluators.h:82-146,206-220 ---- */

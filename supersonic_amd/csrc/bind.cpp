@@ -305,7 +305,25 @@ static bool fold_binary(int op, int t, uint64_t a, uint64_t b, int* out_type, ui
   if (dtype_is_integer(t)) {
     const bool w32 = dtype_width(t) == 4;
     uint64_t x = w32 ? (uint32_t)a : a, y = w32 ? (uint32_t)b : b, r;
-    switch (op) { case OP_ADD: r = x + y; break; case OP_SUBTRACT: r = x - y; break; case OP_MULTIPLY: r = x * y; break; default: return false; }
+    const bool is_signed = t == SSGPU_INT32 || t == SSGPU_INT64;
+    const int64_t sx = w32 ? (int64_t)(int32_t)(uint32_t)a : (int64_t)a, sy = w32 ? (int64_t)(int32_t)(uint32_t)b : (int64_t)b;
+    switch (op) {
+      case OP_ADD: r = x + y; break; case OP_SUBTRACT: r = x - y; break; case OP_MULTIPLY: r = x * y; break;
+      case OP_BITWISE_AND: r = x & y; break; case OP_BITWISE_OR: r = x | y; break; case OP_BITWISE_XOR: r = x ^ y; break;
+      case OP_BITWISE_ANDNOT: r = (~x) & y; break;
+      case OP_SHIFT_LEFT: r = x << (y & (w32 ? 31 : 63)); break;
+      case OP_SHIFT_RIGHT: r = is_signed ? (uint64_t)(sx >> (y & (w32 ? 31 : 63))) : x >> (y & (w32 ? 31 : 63)); break;
+      case OP_CPP_DIVIDE_NULLING: case OP_CPP_DIVIDE_SIGNALING: case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING: {
+        const bool div = op == OP_CPP_DIVIDE_NULLING || op == OP_CPP_DIVIDE_SIGNALING;
+        if (y == 0) {
+          if (op == OP_CPP_DIVIDE_SIGNALING || op == OP_MODULUS_SIGNALING) return false;   // fails when evaluated, not when bound
+          *out_null = true; *out = 0; return true;
+        }
+        if (is_signed) r = sy == -1 ? (div ? 0ull - (uint64_t)sx : 0ull) : (uint64_t)(div ? sx / sy : sx % sy);
+        else r = div ? x / y : x % y;
+      } break;
+      default: return false;
+    }
     *out = w32 ? (uint32_t)r : r; return true;
   }
   return false;
@@ -331,7 +349,7 @@ static std::string fmt_binary(int op, const std::string& l, const std::string& r
     case OP_BITWISE_AND: return "(" + l + " & " + r + ")";
     case OP_BITWISE_OR: return "(" + l + " | " + r + ")";
     case OP_BITWISE_XOR: return "(" + l + " ^ " + r + ")";
-    case OP_BITWISE_ANDNOT: return "(~" + l + " & " + r + ")";
+    case OP_BITWISE_ANDNOT: return "(~" + l + " & " + r + ")";   // expression_traits.h:1527-1536
     case OP_SHIFT_LEFT: return "(" + l + " << " + r + ")";
     case OP_SHIFT_RIGHT: return "(" + l + " >> " + r + ")";
     case OP_IF_NULL: return "IFNULL(" + l + ", " + r + ")";
@@ -371,6 +389,7 @@ static bool try_fold(const BExprP& e, BExprP* out) {
   if (e->args.size() == 1) {
     const BExprP& x = e->args[0];
     if (e->op == OP_NOT) { *out = make_const(SSGPU_BOOL, !x->bits); return true; }
+    if (e->op == OP_BITWISE_NOT) { *out = make_const(e->dtype, dtype_width(x->dtype) == 4 ? (uint64_t)(uint32_t)~(uint32_t)x->bits : ~x->bits); return true; }
     {  // exact math family on a constant (same libm calls as math_evaluators.h:82-146,206-220)
       const bool f32 = x->dtype == SSGPU_FLOAT;
       const double d = x->dtype == SSGPU_DOUBLE ? from_bits<double>(x->bits) : f32 ? (double)from_bits<float>(x->bits) : 0.0;
@@ -489,8 +508,16 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
     case OP_MODULUS_NULLING: case OP_MODULUS_SIGNALING:
       SS_RETURN_IF_ERROR(need(2)); return bind_arith(op, args[0], args[1], depth, true, out);
     case OP_BITWISE_AND: case OP_BITWISE_OR: case OP_BITWISE_XOR: case OP_BITWISE_ANDNOT:
-    case OP_SHIFT_LEFT: case OP_SHIFT_RIGHT:
       SS_RETURN_IF_ERROR(need(2)); return bind_arith(op, args[0], args[1], depth, true, out);
+    case OP_SHIFT_LEFT: case OP_SHIFT_RIGHT:
+      // CreateShiftExpression (elementary_bound_expressions.cc:1446-1489): the result inherits the LEFT
+      // type; the shift count may be any integer type and is not promoted
+      SS_RETURN_IF_ERROR(need(2));
+      if (!dtype_is_integer(args[0]->dtype) || !dtype_is_integer(args[1]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, "Shift needs integer arguments");
+      *out = fold(make_op(op, args[0]->dtype, args[0]->nullable || args[1]->nullable,
+                          fmt_binary(op, args[0]->name, args[1]->name), {args[0], args[1]}, depth));
+      return Status::OK();
     case OP_DIVIDE_QUIET: case OP_DIVIDE_NULLING: case OP_DIVIDE_SIGNALING:
       SS_RETURN_IF_ERROR(need(2)); return bind_divide(op, args[0], args[1], depth, out);
     case OP_EQUAL: case OP_NOT_EQUAL: case OP_LESS: case OP_LESS_OR_EQUAL:
@@ -535,7 +562,7 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
     case OP_BITWISE_NOT: {
       SS_RETURN_IF_ERROR(need(1));
       if (!dtype_is_integer(args[0]->dtype)) return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, "BITWISE NOT needs an integer argument");
-      *out = make_op(op, args[0]->dtype, args[0]->nullable, "(~" + args[0]->name + ")", {args[0]}, depth);
+      *out = fold(make_op(op, args[0]->dtype, args[0]->nullable, "(~" + args[0]->name + ")", {args[0]}, depth));
       return Status::OK();
     }
     case OP_IS_NULL:
@@ -642,10 +669,18 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
         if (cond->kind == BExpr::CONST) { result = c[i - 1]; continue; }                                 // always matches
         result = make_op(OP_IF, out_type, c[i - 1]->nullable || result->nullable, "", {cond, c[i - 1], result}, depth);
       }
-      (void)all_const;
+      if (all_const) { *out = result; return Status::OK(); }   // every argument constant: folded, as InitBasicExpression does
+      // Otherwise the schema is the unfolded BoundCase's -- its name, and NULLABLE iff any THEN / OTHERWISE
+      // is -- also when WHENs that can never (or always) match were dropped from the chain.  A chain that
+      // collapsed to one of its arguments stays an expression node of its own, so that nothing above folds
+      // through it and its schema entry is not mistaken for the argument's.
+      bool collapsed = false;   // the chain is one of the (cast) arguments itself: a constant, a column, ...
+      for (size_t i = 1; i < n; i += 2) collapsed = collapsed || result == c[i];
+      if (collapsed)
+        result = make_op(OP_IF, out_type, nullable, "", {make_const(SSGPU_BOOL, 1), result, result}, depth);
       BExprP named(new BExpr(*result));
       named->name = name;
-      if (named->kind == BExpr::CONST) named->name = result->name;   // folded to a constant, as InitBasicExpression does
+      named->nullable = nullable;
       *out = named;
       return Status::OK();
     }

@@ -330,8 +330,16 @@ Status Emitter::value(const BExprP& e, Val* out) {
         case OP_BITWISE_XOR: v.reg = binop(v.width == 4 ? VM_BXOR_32 : VM_BXOR_64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
         case OP_BITWISE_ANDNOT: v.reg = binop(v.width == 4 ? VM_BANDNOT_32 : VM_BANDNOT_64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
         case OP_BITWISE_NOT: v.reg = unop(v.width == 4 ? VM_BNOT_32 : VM_BNOT_64, a[0], v.width); v.null = a[0].null; break;
-        case OP_SHIFT_LEFT: v.reg = binop(v.width == 4 ? VM_SHL_I32 : VM_SHL_I64, a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
-        case OP_SHIFT_RIGHT: v.reg = binop(pick(mt, VM_SHR_I32, VM_SHR_U32, VM_SHR_I64, VM_SHR_U64, VM_NOP, VM_NOP), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
+        case OP_SHIFT_LEFT: case OP_SHIFT_RIGHT: {
+          // the count keeps its own integer type in the bound tree (the result inherits the left type):
+          // bring it to the left operand's width; valid counts (< width) survive any such conversion
+          Val cnt = a[1];
+          const MT ct = mtype(e->args[1]->dtype);
+          if (cnt.width != v.width) SS_RETURN_IF_ERROR(cast_val(a[1], ct, v.width == 8 ? M_I64 : M_I32, &cnt));
+          const uint16_t vop = e->op == OP_SHIFT_LEFT ? (v.width == 4 ? VM_SHL_I32 : VM_SHL_I64)
+                                                      : pick(mt, VM_SHR_I32, VM_SHR_U32, VM_SHR_I64, VM_SHR_U64, VM_NOP, VM_NOP);
+          v.reg = binop(vop, a[0], cnt, v.width); v.null = or_null(a[0].null, a[1].null);
+        } break;
         case OP_EQUAL: case OP_NOT_EQUAL: case OP_LESS: case OP_LESS_OR_EQUAL: {
           MT lt = at, rt = mtype(e->args[1]->dtype);
           Val l = a[0], r = a[1];

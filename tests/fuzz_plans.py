@@ -1,0 +1,189 @@
+"""Random plan generator for the fuzz parity tests (test_fuzz_cpu.py, test_fuzz_gpu.py).
+
+Seeded and deterministic.  Expressions are drawn from the operator families on the device path with
+random types and nullability, so most trees bind and a fraction do not (implicit downcasts,
+irreconcilable types ...): the binder must agree with the oracle on BOTH outcomes.  Operators whose
+results are not bit-defined across CPUs and GPUs are left out on purpose: quiet division / square root
+(they produce NaNs whose sign and payload differ), variable shift counts, SUM over floating point
+(order-dependent rounding)."""
+import numpy as np
+
+import supersonic_amd as ss
+
+NA = ss.NamedAttribute
+
+COLUMNS = [("a", ss.INT64, True), ("b", ss.INT64, False), ("k1", ss.INT32, True), ("k2", ss.INT32, False),
+           ("u", ss.UINT32, False), ("w", ss.UINT64, True), ("d0", ss.DOUBLE, True), ("d1", ss.DOUBLE, False),
+           ("f", ss.FLOAT, False), ("t", ss.BOOL, True), ("s", ss.BOOL, False)]
+INTS = [c for c in COLUMNS if c[1] in (ss.INT64, ss.INT32, ss.UINT32, ss.UINT64)]
+FLOATS = [c for c in COLUMNS if c[1] in (ss.DOUBLE, ss.FLOAT)]
+BOOLS = [c for c in COLUMNS if c[1] == ss.BOOL]
+
+
+def make_view(n, seed):
+    rng = np.random.default_rng(seed)
+
+    def nulls(flag):
+        return (rng.random(n) < 0.15) if flag else None
+    data = {
+        "a": rng.integers(-1000, 1000, n), "b": rng.integers(-50, 50, n),
+        "k1": rng.integers(-100, 100, n).astype(np.int32), "k2": rng.integers(0, 7, n).astype(np.int32),
+        "u": rng.integers(0, 1 << 32, n).astype(np.uint32), "w": rng.integers(0, 1 << 63, n).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64),
+        "d0": rng.integers(-4000, 4000, n) * 0.25, "d1": rng.integers(-64, 64, n).astype(np.float64),
+        "f": (rng.integers(-64, 64, n) * 0.5).astype(np.float32), "t": rng.integers(0, 2, n).astype(bool), "s": rng.integers(0, 2, n).astype(bool)}
+    schema = ss.TupleSchema([ss.Attribute(name, t, ss.NULLABLE if nl else ss.NOT_NULLABLE) for (name, t, nl) in COLUMNS])
+    return ss.View(schema, [ss.Column(data[name], nulls(nl)) for (name, _t, nl) in COLUMNS])
+
+
+class Gen(object):
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+
+    def pick(self, xs):
+        return xs[int(self.rng.integers(0, len(xs)))]
+
+    def const_int(self):
+        v = int(self.rng.integers(-20, 20))
+        return self.pick([ss.ConstInt32, ss.ConstInt64, ss.ConstInt64])(v)
+
+    def const_float(self):
+        return self.pick([ss.ConstDouble, ss.ConstDouble, ss.ConstFloat])(float(self.rng.integers(-16, 16)) * 0.5)
+
+    def integer(self, depth):
+        r = self.rng.random()
+        if depth <= 0 or r < 0.25:
+            return NA(self.pick(INTS)[0]) if self.rng.random() < 0.8 else self.const_int()
+        x, y = self.integer(depth - 1), self.integer(depth - 1)
+        if self.rng.random() < 0.04:     # ill-typed on purpose: both binders must refuse it with the same code
+            bad = int(self.rng.integers(0, 5))
+            if bad == 0:
+                return ss.Plus(x, self.boolean(0))
+            if bad == 1:
+                return ss.BitwiseAnd(x, self.floating(0))
+            if bad == 2:
+                return ss.If(y, x, y)
+            if bad == 3:
+                return ss.ShiftLeft(x, self.floating(0))
+            return ss.ModulusNulling(self.floating(0), x)
+        choice = int(self.rng.integers(0, 15))
+        if choice < 3:
+            return self.pick([ss.Plus, ss.Minus, ss.Multiply])(x, y)
+        if choice == 3:
+            return ss.Negate(x)
+        if choice == 4:
+            return self.pick([ss.CppDivideNulling, ss.ModulusNulling])(x, y)
+        if choice == 5:
+            return ss.If(self.boolean(depth - 1), x, y)
+        if choice == 6:
+            return ss.IfNull(x, y)
+        if choice == 7:
+            return ss.CastTo(self.pick([ss.INT64, ss.INT32, ss.UINT32, ss.UINT64]), x)
+        if choice == 8:
+            return self.pick([ss.BitwiseAnd, ss.BitwiseOr, ss.BitwiseXor, ss.BitwiseAndNot])(x, y)
+        if choice == 9:
+            return ss.BitwiseNot(x)
+        if choice == 10:
+            return self.pick([ss.ShiftLeft, ss.ShiftRight])(x, ss.ConstInt32(int(self.rng.integers(0, 9))))
+        if choice == 11:
+            return self.pick([ss.RoundToInt, ss.CeilToInt, ss.FloorToInt])(self.floating(depth - 1))
+        if choice == 12:
+            return ss.Abs(x)
+        if choice == 13:
+            return ss.Case([self.integer(depth - 1), x, self.const_int(), y, self.const_int(), self.integer(0)])
+        return x
+
+    def floating(self, depth):
+        r = self.rng.random()
+        if depth <= 0 or r < 0.25:
+            return NA(self.pick(FLOATS)[0]) if self.rng.random() < 0.8 else self.const_float()
+        x = self.floating(depth - 1)
+        y = self.floating(depth - 1) if self.rng.random() < 0.7 else self.integer(depth - 1)
+        choice = int(self.rng.integers(0, 10))
+        if choice < 3:
+            return self.pick([ss.Plus, ss.Minus, ss.Multiply])(x, y)
+        if choice == 3:
+            return ss.DivideNulling(x, y)
+        if choice == 4:
+            return self.pick([ss.Round, ss.Ceil, ss.Floor, ss.Trunc, ss.Abs, ss.Negate])(x)
+        if choice == 5:
+            return ss.SqrtNulling(x)
+        if choice == 6:
+            return ss.If(self.boolean(depth - 1), x, y)
+        if choice == 7:
+            return ss.IfNull(x, y)
+        if choice == 8:
+            return ss.CastTo(self.pick([ss.DOUBLE, ss.FLOAT]), y)
+        return x
+
+    def numeric(self, depth):
+        return self.integer(depth) if self.rng.random() < 0.6 else self.floating(depth)
+
+    def boolean(self, depth):
+        r = self.rng.random()
+        if depth <= 0 or r < 0.15:
+            return NA(self.pick(BOOLS)[0])
+        choice = int(self.rng.integers(0, 9))
+        if choice < 3:
+            cmp = self.pick([ss.Less, ss.LessOrEqual, ss.Greater, ss.GreaterOrEqual, ss.Equal, ss.NotEqual])
+            return cmp(self.numeric(depth - 1), self.numeric(depth - 1))
+        if choice == 3:
+            return self.pick([ss.And, ss.Or, ss.Xor, ss.AndNot])(self.boolean(depth - 1), self.boolean(depth - 1))
+        if choice == 4:
+            return ss.Not(self.boolean(depth - 1))
+        if choice == 5:
+            return ss.IsNull(self.numeric(depth - 1))
+        if choice == 6:
+            return self.pick([ss.IsOdd, ss.IsEven])(self.integer(depth - 1))
+        if choice == 7:
+            return ss.In(self.integer(depth - 1), [self.const_int() for _ in range(int(self.rng.integers(1, 5)))])
+        return ss.If(self.boolean(depth - 1), self.boolean(depth - 1), self.boolean(depth - 1))
+
+    def any_expr(self, depth):
+        r = self.rng.random()
+        return self.integer(depth) if r < 0.45 else self.floating(depth) if r < 0.75 else self.boolean(depth)
+
+    # ---- plans ------------------------------------------------------------------------------
+    def compute_plan(self, view):
+        e = ss.CompoundExpression()
+        for i in range(int(self.rng.integers(1, 6))):
+            e.AddAs("e%d" % i, self.any_expr(int(self.rng.integers(1, 5))))
+        child = ss.ScanView(view)
+        if self.rng.random() < 0.5:
+            child = ss.Filter(self.boolean(int(self.rng.integers(1, 4))), ss.ProjectAllAttributes(), child)
+        return ss.Compute(e, child)
+
+    def aggregate_plan(self, view, grouped):
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s"))
+        spec = ss.AggregationSpecification()
+        for i in range(int(self.rng.integers(1, 7))):
+            name = "x%d" % i
+            kind = int(self.rng.integers(0, 4))
+            if kind == 0:
+                e.AddAs(name, self.integer(int(self.rng.integers(0, 4))))
+                spec.AddAggregation(self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT]), name, "r%d" % i)
+            elif kind == 1:
+                # MIN / MAX of -0.0 and +0.0 depends on the visiting order in the reference;
+                # x + 0.0 turns -0.0 into +0.0 and leaves every other value alone
+                e.AddAs(name, ss.Plus(self.floating(int(self.rng.integers(0, 4))), ss.ConstDouble(0.0)))
+                spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT]), name, "r%d" % i)
+            elif kind == 2:
+                e.AddAs(name, self.boolean(int(self.rng.integers(0, 3))))
+                spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT]), name, "r%d" % i)
+            else:
+                e.AddAs(name, self.integer(0))
+                spec.AddAggregation(ss.COUNT, "", "r%d" % i)
+        child = ss.ScanView(view)
+        if self.rng.random() < 0.6:
+            child = ss.Filter(self.boolean(int(self.rng.integers(1, 4))), ss.ProjectAllAttributes(), child)
+        child = ss.Compute(e, child)
+        if grouped:
+            return ss.GroupAggregate(ss.ProjectNamedAttributes(self.pick([["k2"], ["k2", "s"], ["s"]])), spec, None, child)
+        return ss.ScalarAggregate(spec, child)
+
+    def plan(self, view):
+        r = self.rng.random()
+        if r < 0.5:
+            return self.compute_plan(view), True
+        if r < 0.75:
+            return self.aggregate_plan(view, False), True
+        return self.aggregate_plan(view, True), False      # group order is unspecified

@@ -78,6 +78,35 @@ def expr_plan_case(name, source, in_types, expr, out_type, rows, nullable=True):
 A = "supersonic/expression/core/arithmetic_expressions_test.cc"
 E = "supersonic/expression/core/elementary_expressions_test.cc"
 
+# ---- bitwise and shift operators (elementary_expressions_test.cc:304-319,537-617) ---------------
+EB = "supersonic/expression/core/elementary_expressions_test.cc"
+bind_case("BitwiseNotBinding", EB + ":305", "BitwiseNot", [I32], [False], "(~$0)", I32, False)
+bind_case("BitwiseNot_bool_fails", EB + ":306", "BitwiseNot", [BOOL], [False], None, None, None, expect_error=402)
+bind_case("BitwiseNot_date_fails", EB + ":307", "BitwiseNot", [DATE], [False], None, None, None, expect_error=402)
+expr_case("BitwiseNot_int32", EB + ":309-313", [I32, I32], [[None, None], [0, -1], [1234567, -1234568]], "BitwiseNot")
+expr_case("BitwiseNot_uint64", EB + ":315-318", [U64, U64], [[0, 18446744073709551615], [123456789, 18446744073586094826]], "BitwiseNot")
+bind_case("BitwiseAndBinding", EB + ":538-540", "BitwiseAnd", [I32, U64], [False, False],
+          "(CAST_INT32_TO_INT64($0) & CAST_UINT64_TO_INT64($1))", I64, False)
+bind_case("BitwiseAnd_bool_int_fails", EB + ":541", "BitwiseAnd", [BOOL, I32], [False, False], None, None, None, expect_error=402)
+bind_case("BitwiseAnd_bool_bool_fails", EB + ":542", "BitwiseAnd", [BOOL, BOOL], [False, False], None, None, None, expect_error=402)
+expr_case("BitwiseAnd", EB + ":544-548", [I32, I64, I64], [[12, 12, 12], [12, 1000000000000, 0], [-1, 12345, 12345]], "BitwiseAnd")
+bind_case("BitwiseAndNotBinding", EB + ":552-553", "BitwiseAndNot", [I32, I32], [False, False], "(~$0 & $1)", I32, False)
+expr_case("BitwiseAndNot", EB + ":555-560", [I32, I32, I32], [[1, 1, 0], [3, 7, 4], [10, 7, 5], [None, 8, None]], "BitwiseAndNot")
+bind_case("BitwiseOrBinding", EB + ":564-566", "BitwiseOr", [I32, U64], [False, False],
+          "(CAST_INT32_TO_INT64($0) | CAST_UINT64_TO_INT64($1))", I64, False)
+expr_case("BitwiseOr", EB + ":568-572", [I64, I64, I64], [[1, 0, 1], [1099511627776, 549755813888, 1649267441664], [3, 5, 7]], "BitwiseOr")
+bind_case("BitwiseXorBinding", EB + ":576-577", "BitwiseXor", [U32, U64], [False, False], "(CAST_UINT32_TO_UINT64($0) ^ $1)", U64, False)
+expr_case("BitwiseXor", EB + ":579-588", [U32, U32, U32],
+          [[1, 1, 0], [2, 1, 3], [3, 1, 2], [5, 10, 15], [19, 39, 52], [None, 1, None], [1, None, None], [None, None, None]], "BitwiseXor")
+bind_case("ShiftLeftBinding_uint32_int64", EB + ":592-593", "ShiftLeft", [U32, I64], [False, False], "($0 << $1)", U32, False)
+bind_case("ShiftLeftBinding_int64_uint32", EB + ":594", "ShiftLeft", [I64, U32], [False, False], "($0 << $1)", I64, False)
+bind_case("ShiftLeft_uint32_bool_fails", EB + ":595", "ShiftLeft", [U32, BOOL], [False, False], None, None, None, expect_error=402)
+bind_case("ShiftLeft_bool_int64_fails", EB + ":596", "ShiftLeft", [BOOL, I64], [False, False], None, None, None, expect_error=402)
+bind_case("ShiftLeft_date_int32_fails", EB + ":597", "ShiftLeft", [DATE, I32], [False, False], None, None, None, expect_error=402)
+expr_case("ShiftLeft", EB + ":600-604", [U32, I32, U32], [[1, 4, 16], [3, 2, 12], [5, 31, 2147483648]], "ShiftLeft")
+bind_case("ShiftRightBinding_int32_uint64", EB + ":608", "ShiftRight", [I32, U64], [False, False], "($0 >> $1)", I32, False)
+expr_case("ShiftRight", EB + ":610-616", [I32, I32, I32], [[1, 1, 0], [2, 1, 1], [-1, 1, -1], [-4, 1, -2], [None, 1, None]], "ShiftRight")
+
 # ---- casts (templated/cast_expression_test.cc) ------------------------------------------------
 expr_plan_case("DateToDatetimeCast", "supersonic/expression/templated/cast_expression_test.cc:335-341", [DATE],
                ["CastToType", "DATETIME", ["AttributeAt", 0]], "DATETIME",

@@ -1,0 +1,25 @@
+"""Parity fuzz (GPU): seeded random plans -- expression trees over every operator family on the device
+path, under Compute / Filter / ScalarAggregate / GroupAggregate -- must produce the oracle's result
+bit for bit (fuzz_plans.py keeps to operators whose results are bit-defined).  1537 rows = three full
+512-row tiles and a partial one."""
+import pytest
+
+import supersonic_amd as ss
+from oracle import oracle
+from helpers import run_both
+from fuzz_plans import Gen, make_view
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(2000))
+def test_random_plan_matches_oracle(gpu_ctx, seed):
+    view = make_view(1537, 1000 + seed)
+    op, ordered = Gen(seed).plan(view)
+    try:
+        oracle.run(op)
+    except oracle.OracleError:
+        with pytest.raises(ss.SupersonicException):
+            ss.Plan(op, gpu_ctx)
+        return
+    run_both(op, gpu_ctx, ignore_order=not ordered)
