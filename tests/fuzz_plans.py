@@ -177,13 +177,46 @@ class Gen(object):
             child = ss.Filter(self.boolean(int(self.rng.integers(1, 4))), ss.ProjectAllAttributes(), child)
         child = ss.Compute(e, child)
         if grouped:
-            return ss.GroupAggregate(ss.ProjectNamedAttributes(self.pick([["k2"], ["k2", "s"], ["s"]])), spec, None, child)
+            # [k1], [a], [k1, k2] ... do not pack into one 64-bit key word: the sort-based fallback
+            keys = self.pick([["k2"], ["k2", "s"], ["s"], ["k1"], ["k1", "k2"], ["a"], ["a", "k1", "s"]])
+            return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child)
         return ss.ScalarAggregate(spec, child)
+
+    def sort_plan(self, view):
+        e = ss.CompoundExpression().Add(NA("b")).Add(NA("k1")).Add(NA("d0")).Add(NA("t")).Add(NA("u"))
+        for i in range(int(self.rng.integers(0, 3))):
+            e.AddAs("e%d" % i, self.any_expr(int(self.rng.integers(1, 4))))
+        child = ss.ScanView(view)
+        if self.rng.random() < 0.5:
+            child = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), child)
+        names = ["b", "k1", "d0", "t", "u"]
+        order = ss.SortOrder()
+        for k in self.rng.permutation(len(names))[: int(self.rng.integers(1, 4))]:
+            order.add(names[int(k)], self.pick([ss.ASCENDING, ss.DESCENDING]))
+        return ss.Sort(order, None, 0, ss.Compute(e, child))
+
+    def join_plan(self, view):
+        # star join against a 7-row dimension keyed by k2 (one key missing for LEFT_OUTER / INNER to differ)
+        dim_schema = ss.TupleSchema([ss.Attribute("id", ss.INT32), ss.Attribute("weight", ss.INT64, ss.NULLABLE), ss.Attribute("rate", ss.DOUBLE)])
+        ids = np.array([0, 1, 2, 3, 5, 6], dtype=np.int32)
+        dim = ss.View(dim_schema, [ids, ss.Column(ids.astype(np.int64) * 100 - 250, ids == 3), ids * 0.25])
+        joined = ss.HashJoin(self.pick([ss.INNER, ss.LEFT_OUTER]), ss.ProjectNamedAttribute("k2"), ss.ProjectNamedAttribute("id"),
+                             ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes()).add(1, ss.ProjectNamedAttributes(["weight", "rate"])),
+                             ss.UNIQUE, ss.ScanView(view), ss.ScanView(dim))
+        e = ss.CompoundExpression().AddAs("j0", ss.Plus(NA("weight"), self.integer(int(self.rng.integers(0, 3))))) \
+            .AddAs("j1", ss.Multiply(NA("rate"), self.floating(int(self.rng.integers(0, 3))))).AddAs("j2", self.any_expr(2))
+        if self.rng.random() < 0.5:
+            joined = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), joined)
+        return ss.Compute(e, joined)
 
     def plan(self, view):
         r = self.rng.random()
-        if r < 0.5:
+        if r < 0.4:
             return self.compute_plan(view), True
-        if r < 0.75:
+        if r < 0.55:
             return self.aggregate_plan(view, False), True
-        return self.aggregate_plan(view, True), False      # group order is unspecified
+        if r < 0.75:
+            return self.aggregate_plan(view, True), False      # group order is unspecified
+        if r < 0.9:
+            return self.sort_plan(view), True
+        return self.join_plan(view), True
