@@ -23,3 +23,15 @@ def test_random_plan_matches_oracle(gpu_ctx, seed):
             ss.Plan(op, gpu_ctx)
         return
     run_both(op, gpu_ctx, ignore_order=not ordered)
+
+
+@pytest.mark.parametrize("seed", range(2000, 2200))
+def test_random_plan_matches_oracle_many_tiles(gpu_ctx, seed):
+    # 70001 rows: more tiles than one workgroup round, several workgroups per CU, a ragged last tile
+    view = make_view(70001, seed)
+    op, ordered = Gen(seed).plan(view)
+    try:
+        oracle.run(op)
+    except oracle.OracleError:
+        return
+    run_both(op, gpu_ctx, ignore_order=not ordered)
