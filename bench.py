@@ -182,19 +182,12 @@ def main():
             assert all(segs[i][0] + segs[i][1] * 8 == segs[i + 1][0] for i in range(len(segs) - 1))
             state = torch.as_tensor(_DevPtr(segs[0][0], total, "<i8"), device=device)
             gathered = torch.empty((world, total), dtype=torch.int64, device=device)
-            seg_tensors = (state, gathered, [(count, dtype == ss.DOUBLE, reduce) for (_p, count, dtype, reduce) in segs])
-        state, gathered, layout = seg_tensors
-        # ONE collective over RCCL / xGMI (all-gather of the tiny state), then each segment is
-        # folded locally with its own operator (sum / min / max over int64 or float64)
+            seg_tensors = (state, gathered)
+        state, gathered = seg_tensors
+        # ONE collective over RCCL / xGMI (all-gather of the tiny state), then ONE kernel folds the
+        # `world` images segment by segment with each segment's operator (ssgpu_plan_fold_partials)
         dist.all_gather_into_tensor(gathered, state)
-        off = 0
-        for (count, is_f64, reduce) in layout:
-            part = gathered[:, off:off + count]
-            if is_f64:
-                part = part.view(torch.float64)
-            red = part.sum(dim=0) if reduce == 0 else (part.amin(dim=0) if reduce == 1 else part.amax(dim=0))
-            state[off:off + count] = red.view(torch.int64) if is_f64 else red
-            off += count
+        plan.fold_partials(gathered.data_ptr(), world)
         plan.finalize()
 
     def barrier():

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 2
+#define SSGPU_ABI_VERSION 3
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -327,6 +327,14 @@ int ssgpu_plan_run_partial(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n
                            int64_t rows, int64_t global_row_offset);
 int32_t ssgpu_plan_partial_segments(ssgpu_plan* plan, ssgpu_partial_segment* out,
                                     int32_t max_segments);
+/* Folds `n_images` images of the partial state into the plan's own state with ONE kernel on the
+ * plan's stream: `images` is device memory holding n_images consecutive copies of the buffer the
+ * segments describe (all segments are contiguous, in segment order) -- exactly what an all-gather
+ * of that buffer across ranks produces.  Equivalent to reducing each segment with its `reduce`
+ * operator; the alternative to one all-reduce per segment, and the only way to merge FIRST / LAST
+ * aggregates (their value travels with the smallest / largest contributing global row id, which
+ * an element-wise all-reduce cannot express). */
+int ssgpu_plan_fold_partials(ssgpu_plan* plan, const void* images, int32_t n_images);
 int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
 
 /* ---- result (ResultView / View) ------------------------------------------- */

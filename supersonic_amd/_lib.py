@@ -132,6 +132,7 @@ SYMBOLS = [
     ("ssgpu_interrupt", None, [P]),
     ("ssgpu_plan_run_partial", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64]),
     ("ssgpu_plan_partial_segments", C.c_int32, [P, C.POINTER(PartialSegment), C.c_int32]),
+    ("ssgpu_plan_fold_partials", C.c_int, [P, P, C.c_int32]),
     ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
     ("ssgpu_result_destroy", None, [P]),
     ("ssgpu_result_row_count", C.c_int64, [P]),

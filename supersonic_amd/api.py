@@ -909,6 +909,10 @@ class Plan(object):
         k = self.lib.ssgpu_plan_partial_segments(self.handle, segs, 16)
         return [(segs[i].device_ptr, segs[i].count, segs[i].dtype, segs[i].reduce) for i in range(k)]
 
+    def fold_partials(self, images_ptr, n_images):
+        """Fold n_images all-gathered images of the partial state (device pointer) into this plan's state."""
+        self.ctx.check(self.lib.ssgpu_plan_fold_partials(self.handle, C.c_void_p(images_ptr), n_images))
+
     def finalize(self):
         res = C.c_void_p()
         self.ctx.check(self.lib.ssgpu_plan_finalize(self.handle, C.byref(res)))

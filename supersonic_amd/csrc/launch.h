@@ -83,6 +83,7 @@ hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int 
                                      VmAccRec* out, hipStream_t stream);
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state,
                                        hipStream_t stream);
+hipError_t ssgpu_launch_fold_state(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, hipStream_t stream);
 hipError_t ssgpu_launch_state_to_slots(const uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs,
                                        hipStream_t stream);
 hipError_t ssgpu_launch_emit_scalar(const VmAccRec* recs, const EmitDesc* descs, int n_out, hipStream_t stream);

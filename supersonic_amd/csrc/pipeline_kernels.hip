@@ -1976,13 +1976,14 @@ __global__ void ssgpu_slots_to_state_kernel(const VmAccRec* __restrict__ recs, i
   u64* sum_i = state; u64* cnt = state + n_slots; u64* hi = state + 2 * n_slots; u64* lo = state + 3 * n_slots;
   u64* mn = state + 4 * n_slots; u64* mx = state + 5 * n_slots;
   u64* mnf = state + 6 * n_slots; u64* mxf = state + 7 * n_slots;
-  sum_i[s] = (kind == SLOT_SUM_INT || kind == SLOT_COUNT) ? r.v0 : 0;
+  const bool fl = kind == SLOT_FIRST || kind == SLOT_LAST;   // value in the sum array, row id in the min / max array
+  sum_i[s] = (kind == SLOT_SUM_INT || kind == SLOT_COUNT || fl) ? r.v0 : 0;
   cnt[s] = r.cnt;
   hi[s] = kind == SLOT_SUM_DD ? r.v0 : d2u(0.0);
   lo[s] = kind == SLOT_SUM_DD ? r.v1 : d2u(0.0);
   // signed-order view so that an int64 all-reduce min/max is order-correct for u64 keys
-  mn[s] = (kind == SLOT_MIN_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : 0x7FFFFFFFFFFFFFFFull;
-  mx[s] = (kind == SLOT_MAX_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : 0x8000000000000000ull;
+  mn[s] = (kind == SLOT_MIN_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : (kind == SLOT_FIRST && r.cnt) ? (r.v1 ^ 0x8000000000000000ull) : 0x7FFFFFFFFFFFFFFFull;
+  mx[s] = (kind == SLOT_MAX_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : (kind == SLOT_LAST && r.cnt) ? (r.v1 ^ 0x8000000000000000ull) : 0x8000000000000000ull;
   mnf[s] = (kind == SLOT_MIN_F64 && r.cnt) ? r.v0 : d2u(__builtin_inf());
   mxf[s] = (kind == SLOT_MAX_F64 && r.cnt) ? r.v0 : d2u(-__builtin_inf());
 }
@@ -2005,6 +2006,8 @@ __global__ void ssgpu_state_to_slots_kernel(const u64* __restrict__ state, int n
     case SLOT_MAX_U64: r.v0 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
     case SLOT_MIN_F64: r.v0 = state[6 * n_slots + s]; break;
     case SLOT_MAX_F64: r.v0 = state[7 * n_slots + s]; break;
+    case SLOT_FIRST: r.v0 = state[s]; r.v1 = state[4 * n_slots + s] ^ 0x8000000000000000ull; break;
+    case SLOT_LAST: r.v0 = state[s]; r.v1 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
     default: break;
   }
   recs[s] = r;
@@ -2357,6 +2360,39 @@ hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int 
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state, hipStream_t stream) {
   int blocks = (n_slots + 63) / 64;
   hipLaunchKernelGGL(ssgpu_slots_to_state_kernel, dim3(blocks), dim3(64), 0, stream, recs, n_slots, slot_kind, (u64*)state);
+  return hipGetLastError();
+}
+// Cross-rank fold of the partial-aggregate state (ssgpu_plan_fold_partials): one thread per slot
+// combines the images array by array with the array's operator -- wrapping integer sum (sums,
+// counts), double sum (double-double hi / lo), signed min / max (integer extrema and row ids in
+// their sign-corrected domain), double min / max.  FIRST / LAST slots take the value of the image
+// that holds the smallest / largest contributing row id.
+__global__ __launch_bounds__(64) void ssgpu_fold_state_kernel(const u64* __restrict__ images, int n_images, u64* __restrict__ state,
+                                                              int n_slots, const int* __restrict__ slot_kind) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_slots) return;
+  const size_t total = (size_t)SSGPU_STATE_ARRAYS * n_slots;
+  const int kind = slot_kind[s];
+  u64 a[SSGPU_STATE_ARRAYS];
+  for (int k = 0; k < SSGPU_STATE_ARRAYS; ++k) a[k] = images[(size_t)k * n_slots + s];
+  for (int r = 1; r < n_images; ++r) {
+    u64 v[SSGPU_STATE_ARRAYS];
+    for (int k = 0; k < SSGPU_STATE_ARRAYS; ++k) v[k] = images[(size_t)r * total + (size_t)k * n_slots + s];
+    if (kind == SLOT_FIRST) { if ((i64)v[4] < (i64)a[4]) a[0] = v[0]; }
+    else if (kind == SLOT_LAST) { if ((i64)v[5] > (i64)a[5]) a[0] = v[0]; }
+    else a[0] += v[0];
+    a[1] += v[1];
+    a[2] = d2u(u2d(a[2]) + u2d(v[2]));
+    a[3] = d2u(u2d(a[3]) + u2d(v[3]));
+    a[4] = (i64)v[4] < (i64)a[4] ? v[4] : a[4];
+    a[5] = (i64)v[5] > (i64)a[5] ? v[5] : a[5];
+    a[6] = u2d(v[6]) < u2d(a[6]) ? v[6] : a[6];
+    a[7] = u2d(v[7]) > u2d(a[7]) ? v[7] : a[7];
+  }
+  for (int k = 0; k < SSGPU_STATE_ARRAYS; ++k) state[(size_t)k * n_slots + s] = a[k];
+}
+hipError_t ssgpu_launch_fold_state(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, hipStream_t stream) {
+  if (n_slots > 0) hipLaunchKernelGGL(ssgpu_fold_state_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, stream, (const u64*)images, n_images, (u64*)state, n_slots, slot_kind);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_state_to_slots(const uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs, hipStream_t stream) {

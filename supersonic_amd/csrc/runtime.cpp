@@ -1274,6 +1274,15 @@ int32_t ssgpu_plan_partial_segments(ssgpu_plan* p, ssgpu_partial_segment* out, i
   return n;
 }
 
+int ssgpu_plan_fold_partials(ssgpu_plan* p, const void* images, int32_t n_images) {
+  if (!p || !p->partial_pending || p->stages.empty() || !images || n_images < 1) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  StageExec& ex = p->exec[0];
+  const int ns = p->stages[0].main.n_slots;
+  HIP_TRY(c, ssgpu_launch_fold_state(static_cast<const uint64_t*>(images), n_images, ex.state.as<uint64_t>(), ns, ex.slot_kind.as<int>(), c->stream));
+  return SSGPU_OK;
+}
+
 int ssgpu_plan_finalize(ssgpu_plan* p, ssgpu_result** out) {
   if (!p || !p->partial_pending) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_ctx* c = p->ctx;

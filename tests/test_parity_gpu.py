@@ -589,3 +589,40 @@ def test_device_sharded_sort_single_rank_exchange(descending):
         assert_cols_equal([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())], want, context="device sharded sort")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,shards", [(100003, 3), (2000, 4), (5, 3)])
+def test_partial_state_fold_across_shards(gpu_ctx, n, shards):
+    # the N > 1 ScalarAggregate protocol on one GPU: every shard runs ssgpu_plan_run_partial with its global row
+    # offset, the shards' partial states are laid out as an all-gather would (consecutive images), folded with
+    # ssgpu_plan_fold_partials and finalised -- the result must be the single-plan answer (FIRST / LAST included)
+    import torch
+    from supersonic_amd.distributed import _bytes_over
+    view = make_view(n, nullable=True)
+    bounds = [n * i // shards for i in range(shards + 1)]
+    bounds[1] = bounds[0]                                   # an empty shard
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "sa").AddAggregation(ss.SUM, "d0", "sd").AddAggregation(ss.MIN, "d", "mn")
+            .AddAggregation(ss.MAX, "d0", "mx").AddAggregation(ss.MIN, "f", "mf").AddAggregation(ss.COUNT, "k1", "c").AddAggregation(ss.COUNT, "", "n")
+            .AddAggregation(ss.FIRST, "d", "fd").AddAggregation(ss.LAST, "k1", "lk"))
+
+    def query(v):
+        return ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(300)), ss.ProjectAllAttributes(), ss.ScanView(v)))
+    device = torch.device("cuda", 0)
+    plans, images = [], []
+    for i in range(shards):
+        lo, hi = bounds[i], bounds[i + 1]
+        shard = ss.View(view.schema(), [ss.Column(view.column(c).data[lo:hi], None if view.column(c).is_null is None else view.column(c).is_null[lo:hi])
+                                        for c in range(view.column_count())])
+        plan = ss.Plan(query(shard), gpu_ctx)
+        segs = plan.run_partial(shard, lo)
+        gpu_ctx.synchronize()
+        total = sum(count for (_p, count, _d, _r) in segs)
+        images.append(_bytes_over(torch, device, segs[0][0], total * 8).clone())
+        plans.append(plan)
+    gathered = torch.cat(images)
+    torch.cuda.synchronize()
+    plans[0].fold_partials(gathered.data_ptr(), shards)
+    plans[0].finalize()
+    got = plans[0].fetch()
+    _schema, want = oracle_run(query(view))
+    assert_cols_equal([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())], want, context="folded partial state")
