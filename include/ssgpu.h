@@ -190,8 +190,11 @@ enum {
   SSGPU_OP_HASH_JOIN = 9           /* HashJoinOperation(type, lhs keys, rhs keys, result projector,
                                       uniqueness, lhs, rhs) hash_join.h:37-56.  `child` = lhs chain,
                                       `child2` = the rhs op, which must be a SCAN of the auxiliary
-                                      input (a device-resident dimension table); the probe and the
-                                      gathers of the rhs columns are fused into the lhs pipeline */
+                                      input (a device-resident table).  UNIQUE rhs keys: the probe
+                                      and the gathers of the rhs columns are fused into the lhs
+                                      pipeline (a repeated key is reported at run time); NOT_UNIQUE:
+                                      rows multiply -- the lhs pipeline materialises its side and an
+                                      expand stage emits one row per match (lhs order, rhs order) */
 };
 enum { SSGPU_JOIN_INNER = 0, SSGPU_JOIN_LEFT_OUTER = 1 };           /* JoinType, supersonic.proto:108-113 */
 enum { SSGPU_KEYS_NOT_UNIQUE = 0, SSGPU_KEYS_UNIQUE = 1 };            /* KeyUniqueness, :115-118 */

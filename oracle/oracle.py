@@ -147,11 +147,9 @@ class _Tree(object):
             return h
         child = self.op(o.child)
         if kind == 9:   # HashJoinOperation(type, lhs keys, rhs keys, result projector, uniqueness, lhs, rhs)
-            if o.uniqueness != 1:
-                raise OracleError(103, "only UNIQUE rhs keys are restated")
             rhs = self.op(o.rhs_child)
             h = L.orc_op_new(9, child, None)
-            L.orc_op_set_join(h, rhs, int(o.join_type))
+            L.orc_op_set_join(h, rhs, int(o.join_type) | (int(o.uniqueness) << 8))
             for (k, pos, name, alias) in o.lhs_keys.entries:
                 L.orc_op_add_proj(h, k, pos, _enc(name), _enc(alias))
             for (k, pos, name, alias) in o.rhs_keys.entries:

@@ -873,6 +873,7 @@ void orc_op_add_proj(orc_op* o, int kind, int position, const char* name, const 
   orc_proj* p = &o->projs[o->nproj++]; p->kind = kind; p->position = position;
   snprintf(p->name, sizeof(p->name), "%s", name ? name : ""); snprintf(p->alias, sizeof(p->alias), "%s", alias ? alias : "");
 }
+/* join_type: 0 INNER, 1 LEFT_OUTER; bit 8 set = rhs keys declared UNIQUE (hash_join.h:37-56) */
 void orc_op_set_join(orc_op* o, orc_op* rhs, int join_type) { o->child2 = rhs; o->join_type = join_type; }
 void orc_op_add_proj_to(orc_op* o, int which, int source, int kind, int position, const char* name, const char* alias) {
   orc_proj* list = which == 2 ? o->projs2 : o->projs3; int* n = which == 2 ? &o->nproj2 : &o->nproj3;
@@ -932,7 +933,8 @@ typedef struct orc_cursor {
   orc_view outv;
   /* hash join: rhs fully materialised, lhs streamed (hash_join.cc: LookupIndex + HashJoinCursor) */
   struct orc_cursor* rhs; orc_block rhs_rows; int64_t rhs_n;
-  int jl_pos[16], jr_pos[16], nkeys, join_type;
+  int jl_pos[16], jr_pos[16], nkeys, join_type, join_unique;
+  int64_t join_pending, join_served;   /* joined rows of the current input view: produced / already returned */
   int out_src[ORC_MAX_COLS], out_pos[ORC_MAX_COLS], nout_cols;
   int64_t* match;
 } orc_cursor;
@@ -1050,14 +1052,14 @@ orc_cursor* orc_create_cursor(const orc_op* op) {
       if (nl != nr || nl == 0) { set_err(&c->err, RC_COUNT_MISMATCH, "hash join key selectors must pick the same number of columns%s%s", "", ""); return cursor_fail(c); }
       for (int k = 0; k < nl; ++k)
         if (in->a[c->jl_pos[k]].type != rs->a[c->jr_pos[k]].type) { set_err(&c->err, RC_TYPE_MISMATCH, "hash join key types differ%s%s", "", ""); return cursor_fail(c); }
-      c->nkeys = nl; c->join_type = op->join_type;
+      c->nkeys = nl; c->join_type = op->join_type & 0xFF; c->join_unique = (op->join_type >> 8) & 1;
       /* BoundMultiSourceProjector: entries in order, each bound against its source schema */
       for (int q = 0; q < op->nproj3; ++q) {
         const orc_schema* src = op->projs3[q].source == 0 ? in : rs;
         int pos[ORC_MAX_COLS], n1 = 0; char nm[ORC_MAX_COLS][256];
         if (!bind_projector(&op->projs3[q], 1, src, pos, nm, &n1, &c->err)) return cursor_fail(c);
         for (int i = 0; i < n1; ++i) {
-          const int nullable = src->a[pos[i]].nullable || (op->projs3[q].source == 1 && op->join_type == 1);  /* LEFT_OUTER: rhs columns nullable */
+          const int nullable = src->a[pos[i]].nullable || (op->projs3[q].source == 1 && (op->join_type & 0xFF) == 1);  /* LEFT_OUTER: rhs columns nullable */
           if (!schema_add(&c->schema, nm[i], src->a[pos[i]].type, nullable)) { set_err(&c->err, RC_ATTRIBUTE_EXISTS, "Duplicate attribute name \"%s\" in result schema%s", nm[i], ""); return cursor_fail(c); }
           c->out_src[c->nout_cols] = op->projs3[q].source; c->out_pos[c->nout_cols] = pos[i]; ++c->nout_cols;
         }
@@ -1293,8 +1295,9 @@ static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
           }
           c->rhs_n += rv.rows;
         }
-        /* the device path requires UNIQUE keys: a repeated non-NULL key is an error here too */
-        for (int64_t a = 0; a < c->rhs_n; ++a) for (int64_t b = a + 1; b < c->rhs_n && c->rhs_n <= 4096; ++b) {
+        /* rhs keys declared UNIQUE: a repeated non-NULL key is an error (the reference's unique index would
+         * keep only one of the rows; the device reports it) */
+        for (int64_t a = 0; a < c->rhs_n && c->join_unique; ++a) for (int64_t b = a + 1; b < c->rhs_n && c->rhs_n <= 4096; ++b) {
           int same = 1;
           for (int k = 0; k < c->nkeys && same; ++k) {
             const int col = c->jr_pos[k]; const int w = c->rhs_rows.width[col];
@@ -1304,38 +1307,54 @@ static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
           if (same) { set_err(&c->err, 407, "hash join: rhs keys declared UNIQUE but a key repeats%s%s", "", ""); return -1; }
         }
       }
-      for (;;) {
+      while (c->join_served >= c->join_pending) {
         orc_view in; int r = cursor_next(c->child, max_rows, &in);
         if (r <= 0) { if (r < 0) c->err = c->child->err; return r; }
         int64_t nout = 0;
         for (int64_t i = 0; i < in.rows; ++i) {
-          int64_t found = -1; int null_key = 0;
+          int null_key = 0; int64_t n_found = 0;
           for (int k = 0; k < c->nkeys; ++k) if (in.c[c->jl_pos[k]].is_null && in.c[c->jl_pos[k]].is_null[i]) null_key = 1;
-          for (int64_t j = 0; j < c->rhs_n && !null_key && found < 0; ++j) {
-            int same = 1;
-            for (int k = 0; k < c->nkeys && same; ++k) {
-              const int col = c->jr_pos[k]; const int w = c->rhs_rows.width[col];
-              if (c->rhs_rows.nulls[col][j]) same = 0;
-              else same = memcmp((const char*)in.c[c->jl_pos[k]].data + i * w, (char*)c->rhs_rows.data[col] + j * w, (size_t)w) == 0;
+          /* every matching rhs row, in rhs order (RowIdSetIterator walks the equal-row list in insertion
+           * order, row_hash_set.cc:581-600,650-652); one NULL-extended row for an unmatched LEFT_OUTER lhs row */
+          for (int64_t j = 0; j <= c->rhs_n; ++j) {
+            int64_t found = -1;
+            if (j < c->rhs_n) {
+              if (null_key) continue;
+              int same = 1;
+              for (int k = 0; k < c->nkeys && same; ++k) {
+                const int col = c->jr_pos[k]; const int w = c->rhs_rows.width[col];
+                if (c->rhs_rows.nulls[col][j]) same = 0;
+                else same = memcmp((const char*)in.c[c->jl_pos[k]].data + i * w, (char*)c->rhs_rows.data[col] + j * w, (size_t)w) == 0;
+              }
+              if (!same) continue;
+              found = j; ++n_found;
+            } else if (n_found > 0 || c->join_type == 0) {
+              break;
             }
-            if (same) found = j;
+            if (nout >= c->block.cap) block_grow(&c->block, c->block.cap * 2);
+            for (int q = 0; q < c->nout_cols; ++q) {
+              const int w = c->block.width[q];
+              if (c->out_src[q] == 0) {
+                const orc_col* src = &in.c[c->out_pos[q]];
+                memcpy((char*)c->block.data[q] + nout * w, (const char*)src->data + i * w, (size_t)w);
+                c->block.nulls[q][nout] = src->is_null ? src->is_null[i] : 0;
+              } else if (found >= 0) {
+                memcpy((char*)c->block.data[q] + nout * w, (char*)c->rhs_rows.data[c->out_pos[q]] + found * w, (size_t)w);
+                c->block.nulls[q][nout] = c->rhs_rows.nulls[c->out_pos[q]][found];
+              } else { memset((char*)c->block.data[q] + nout * w, 0, (size_t)w); c->block.nulls[q][nout] = 1; }
+            }
+            ++nout;
           }
-          if (found < 0 && c->join_type == 0) continue;
-          for (int q = 0; q < c->nout_cols; ++q) {
-            const int w = c->block.width[q];
-            if (c->out_src[q] == 0) {
-              const orc_col* src = &in.c[c->out_pos[q]];
-              memcpy((char*)c->block.data[q] + nout * w, (const char*)src->data + i * w, (size_t)w);
-              c->block.nulls[q][nout] = src->is_null ? src->is_null[i] : 0;
-            } else if (found >= 0) {
-              memcpy((char*)c->block.data[q] + nout * w, (char*)c->rhs_rows.data[c->out_pos[q]] + found * w, (size_t)w);
-              c->block.nulls[q][nout] = c->rhs_rows.nulls[c->out_pos[q]][found];
-            } else { memset((char*)c->block.data[q] + nout * w, 0, (size_t)w); c->block.nulls[q][nout] = 1; }
-          }
-          ++nout;
         }
         if (nout == 0) continue;   /* nothing survived this input view: pull the next one */
-        view_from_block(c, &c->block, 0, nout, out);
+        c->join_pending = nout; c->join_served = 0;
+        break;
+      }
+      /* NOT_UNIQUE keys can multiply an input view past max_rows: serve the joined rows in slices */
+      {
+        int64_t take = c->join_pending - c->join_served; if (take > max_rows) take = max_rows;
+        view_from_block(c, &c->block, c->join_served, take, out);
+        c->join_served += take;
         return 1;
       }
     }

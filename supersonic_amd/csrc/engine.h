@@ -47,13 +47,13 @@ std::string schema_to_string(const Schema& s);
 struct BExpr;
 typedef std::shared_ptr<BExpr> BExprP;
 struct BExpr {
-  enum Kind { INPUT, CONST, NULLCONST, OP, CAST, JOINCOL, JOINMATCH } kind = INPUT;
+  enum Kind { INPUT, CONST, NULLCONST, OP, CAST, JOINCOL, JOINMATCH, JOINSTART, JOINCNT } kind = INPUT;
   int op = 0;          // reference OperatorId for OP
   int dtype = SSGPU_INT64;
   bool nullable = false;
   std::string name;
   int input_col = -1;  // INPUT: column of the stage input; JOINCOL: column of the join's rhs table
-  int join_id = -1;    // JOINCOL / JOINMATCH: index into the stage's joins
+  int join_id = -1;    // JOINCOL / JOINMATCH / JOINSTART / JOINCNT: index into the stage's joins
   uint64_t bits = 0;   // CONST: raw value bits in the column's device width
   int filter_depth = 0;  // number of Filter operations below this expression
   std::vector<BExprP> args;
@@ -65,7 +65,8 @@ enum StageKind {
   STAGE_MATERIALIZE = 2,  // pipeline -> output columns (1:1 or compacted by a filter)
   STAGE_GROUP_AGG = 3,    // pipeline -> device hash table -> group rows
   STAGE_SORT = 4,         // radix sort of the stage input by key columns
-  STAGE_CLUSTERS = 5      // segmented aggregate over pre-clustered keys
+  STAGE_CLUSTERS = 5,     // segmented aggregate over pre-clustered keys
+  STAGE_JOIN_EXPAND = 6   // NOT_UNIQUE hash join: (lhs row, matching rhs row) pairs -> gathered columns
 };
 
 struct AggOut {        // one aggregate result column
@@ -89,8 +90,10 @@ struct JoinSpec {
   std::vector<BExprP> lhs_keys;          // over the stage input
   std::vector<int> rhs_key_cols;         // columns of the auxiliary input
   std::vector<GroupKeyField> fields;     // packing of the 64-bit key (nullbit only for nullable lhs keys)
+  bool multi = false;                    // NOT_UNIQUE rhs keys: the index maps a key to a run of rhs rows
 };
 struct JoinGather { int join_id; int rhs_col; bool is_null_mask; };  // slot i of VmParams.join_cols
+enum { JOIN_GATHER_RUN_START = -1, JOIN_GATHER_RUN_COUNT = -2 };   // rhs_col of a multi join's per-key run arrays
 
 // Lowered instruction over virtual registers.  A register is an LDS array of
 // tile_rows elements; its LDS byte offset is row_off * tile_rows, fixed when the
@@ -141,6 +144,10 @@ struct Stage {
   std::vector<JoinSpec> joins;            // HashJoins fused into this stage's programs
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns
+  // JOIN_EXPAND: the previous stage materialised [lhs fields..., run start, run count]; every output
+  // column is lhs field `col` (from_rhs = false) or column `col` of the auxiliary input
+  struct JoinOut { bool from_rhs; int col; };
+  std::vector<JoinOut> join_out;
   int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row
   int64_t output_bytes_per_row = 0;       // materialised output bytes per output row
 };

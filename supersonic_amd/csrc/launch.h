@@ -73,7 +73,14 @@ struct JoinBuildParams {
   unsigned int* rows;
   unsigned int* special;        // pre-filled with VM_NONE
   unsigned int* flags;          // pre-zeroed
+  // NOT_UNIQUE keys (both null for a UNIQUE index): the table maps a key to its own slot, counts[slot]
+  // (capacity + 1 entries, pre-zeroed; entry `capacity` belongs to the EMPTY-valued key) counts the key's
+  // rows and slot_of_row[i] is row i's slot (VM_NONE for a NULL key)
+  unsigned int* counts;
+  unsigned int* slot_of_row;
 };
+hipError_t ssgpu_launch_join_expand(const unsigned int* offsets, const unsigned int* run_start, const unsigned int* rows_sorted,
+                                    unsigned long long n_lhs, unsigned long long n_out, unsigned int* lhs_idx, unsigned int* rhs_row, hipStream_t stream);
 hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream);
 hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream);
 

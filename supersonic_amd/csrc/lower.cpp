@@ -152,6 +152,8 @@ std::string Emitter::key_of(const BExprP& e) {
     case BExpr::NULLCONST: s << "N" << e->dtype; break;
     case BExpr::JOINCOL: s << "J" << e->join_id << ":" << e->input_col; break;
     case BExpr::JOINMATCH: s << "M" << e->join_id; break;
+    case BExpr::JOINSTART: s << "JS" << e->join_id; break;
+    case BExpr::JOINCNT: s << "JC" << e->join_id; break;
     default:
       s << (e->kind == BExpr::CAST ? "K" : "O") << e->op << ":" << e->dtype << ":" << e->filter_depth << "(";
       for (auto& a : e->args) s << key_of(a) << ",";
@@ -240,6 +242,13 @@ Status Emitter::value(const BExprP& e, Val* out) {
       int idx; SS_RETURN_IF_ERROR(join_index(e->join_id, &idx));
       v.reg = new_reg(1);
       LInstr& i = emit(VM_IDX_VALID); i.dst = v.reg; i.a = idx;
+    } break;
+    case BExpr::JOINSTART: case BExpr::JOINCNT: {
+      // multi join: the probe yields the key's slot; its run of rhs rows is [start, start + count)
+      int idx; SS_RETURN_IF_ERROR(join_index(e->join_id, &idx));
+      v.reg = new_reg(4);
+      LInstr& i = emit(VM_GATHER_32); i.dst = v.reg; i.a = idx;
+      i.imm = (uint64_t)gather_slot(e->join_id, e->kind == BExpr::JOINSTART ? JOIN_GATHER_RUN_START : JOIN_GATHER_RUN_COUNT, false);
     } break;
     case BExpr::JOINCOL: {
       int idx; SS_RETURN_IF_ERROR(join_index(e->join_id, &idx));
@@ -1180,8 +1189,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         const int jtype = (int)(op.option0 & 0xFF), uniq = (int)((op.option0 >> 8) & 0xFF);
         if (jtype != SSGPU_JOIN_INNER && jtype != SSGPU_JOIN_LEFT_OUTER)
           return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "only INNER and LEFT_OUTER hash joins are on device");
-        if (uniq != SSGPU_KEYS_UNIQUE)
-          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join with NOT_UNIQUE rhs keys (row multiplication) is not on device yet");
+        const bool multi = uniq != SSGPU_KEYS_UNIQUE;
         if (op.child2 < 0 || op.child2 >= (int)d.ops.size() || d.ops[op.child2].kind != SSGPU_OP_SCAN || d.ops[op.child2].option0 != 1)
           return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "the rhs of a device hash join must be a scan of the auxiliary input (a resident table)");
         if ((int)pipe.joins.size() >= VM_MAX_JOINS)
@@ -1192,7 +1200,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         SS_RETURN_IF_ERROR(bind_projector(d, op.proj2_first, op.proj2_n, rs, &rpos, &rnames));
         if (lpos.size() != rpos.size() || lpos.empty())
           return Status::Error(SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH, "hash join key selectors must pick the same, non-zero number of columns");
-        JoinSpec js; js.type = jtype;
+        JoinSpec js; js.type = jtype; js.multi = multi;
         uint32_t shift = 0;
         for (size_t k = 0; k < lpos.size(); ++k) {
           const BExprP& le = pipe.cols[lpos[k]].expr;
@@ -1208,6 +1216,9 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         }
         const int join_id = (int)pipe.joins.size();
         std::vector<VCol> nc;
+        std::vector<Stage::JoinOut> jout;   // multi join: where every result column comes from
+        std::vector<VCol> lhs_fields;       // multi join: the lhs columns the result keeps
+        Schema joined_schema;
         for (int q = 0; q < op.proj3_n; ++q) {
           const ssgpu_proj& pr = d.projs[op.proj3_first + q];
           std::vector<int> pos; std::vector<std::string> names;
@@ -1226,7 +1237,51 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             c.name = names[i];
             for (auto& o : nc) if (o.name == c.name) return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS, "Duplicate attribute name \"" + c.name + "\" in result schema");
             nc.push_back(c);
+            Attr a; a.name = c.name; a.dtype = c.expr->dtype; a.nullable = c.expr->nullable;
+            joined_schema.push_back(a);
+            if (pr.source == 0) { jout.push_back({false, (int)lhs_fields.size()}); VCol f = c; f.name = "l" + std::to_string(lhs_fields.size()); lhs_fields.push_back(f); }
+            else jout.push_back({true, pos[i]});
           }
+        }
+        if (multi) {
+          // NOT_UNIQUE rhs keys multiply rows, which no per-row pipeline can do: the lhs pipeline ends here.
+          // It materialises the lhs columns the result keeps plus, per row, the run [start, start + count) of
+          // matching rhs rows (LEFT_OUTER: a run of one "no row" for an unmatched lhs row); the expand stage
+          // turns the runs into (lhs row, rhs row) pairs and gathers every result column.  Output order is
+          // the reference's: lhs order, matches in rhs order (hash_join.cc:361-470, row_hash_set.cc:581-600).
+          auto join_expr = [&](BExpr::Kind k, int dtype, const char* name) {
+            BExprP e(new BExpr);
+            e->kind = k; e->join_id = join_id; e->dtype = dtype; e->nullable = false; e->name = name; e->filter_depth = pipe.depth();
+            return e;
+          };
+          BExprP start = join_expr(BExpr::JOINSTART, SSGPU_UINT32, "JOIN_RUN_START");
+          BExprP cnt = join_expr(BExpr::JOINCNT, SSGPU_UINT32, "JOIN_RUN_COUNT");
+          BExprP match = join_expr(BExpr::JOINMATCH, SSGPU_BOOL, "JOIN_MATCH");
+          Pipe pp = pipe;
+          pp.joins.push_back(js);
+          if (jtype == SSGPU_JOIN_INNER) pp.filters.push_back(match);
+          else {
+            auto pick = [&](const BExprP& matched, uint32_t otherwise, const char* name) {
+              BExprP k(new BExpr); k->kind = BExpr::CONST; k->dtype = SSGPU_UINT32; k->bits = otherwise; k->name = "CONST_UINT32"; k->filter_depth = pipe.depth();
+              BExprP e(new BExpr);
+              e->kind = BExpr::OP; e->op = OP_IF; e->dtype = SSGPU_UINT32; e->nullable = false; e->name = name; e->filter_depth = pipe.depth();
+              e->args = {match, matched, k};
+              return e;
+            };
+            start = pick(start, VM_NONE, "JOIN_RUN_START_OR_NONE");
+            cnt = pick(cnt, 1u, "JOIN_RUN_COUNT_OR_ONE");
+          }
+          pp.cols = lhs_fields;
+          VCol cs; cs.expr = start; cs.name = "__join_run_start"; pp.cols.push_back(cs);
+          VCol cc; cc.expr = cnt; cc.name = "__join_run_count"; pp.cols.push_back(cc);
+          Stage m; SS_RETURN_IF_ERROR(finish_materialize(pp, &m));
+          stages->push_back(m);
+          Stage x; x.kind = STAGE_JOIN_EXPAND; x.in_schema = m.out_schema; x.out_schema = joined_schema; x.join_out = jout;
+          stages->push_back(x);
+          reset_pipe(&pipe, x.out_schema);
+          pending = false;
+          desc << (jtype == SSGPU_JOIN_INNER ? "HashJoin INNER" : "HashJoin LEFT_OUTER") << " (NOT_UNIQUE: materialise + expand) -> [" << schema_to_string(x.out_schema) << "]\n";
+          break;
         }
         if (jtype == SSGPU_JOIN_INNER) {   // rows without a match are dropped: one more (never-NULL) filter
           BExprP m(new BExpr);

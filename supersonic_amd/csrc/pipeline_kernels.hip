@@ -2256,7 +2256,7 @@ __global__ __launch_bounds__(256) void ssgpu_join_build_kernel(const JoinBuildPa
   if (i >= P.n_rows) return;
   u64 key = 0;
   for (u32 k = 0; k < P.n_keys; ++k) {
-    if (P.key_nulls[k] && P.key_nulls[k][i]) return;   // NULL never equals anything: not indexed
+    if (P.key_nulls[k] && P.key_nulls[k][i]) { if (P.slot_of_row) P.slot_of_row[i] = VM_NONE; return; }   // NULL never equals anything: not indexed
     u64 v;
     if (P.width[k] == 8) v = reinterpret_cast<const u64*>(P.key_data[k])[i];
     else if (P.width[k] == 4) v = reinterpret_cast<const u32*>(P.key_data[k])[i];
@@ -2264,15 +2264,27 @@ __global__ __launch_bounds__(256) void ssgpu_join_build_kernel(const JoinBuildPa
     const u64 vmask = P.bits[k] >= 64 ? ~0ull : ((1ull << P.bits[k]) - 1ull);
     key |= (v & vmask) << P.shift[k];
   }
+  const bool multi = P.counts != nullptr;
   if (key == VM_KEY_EMPTY) {
-    if (atomicCAS(P.special, VM_NONE, (u32)i) != VM_NONE) atomicExch(&P.flags[0], 1u);
+    if (multi) {
+      const u32 cap = P.capacity_mask + 1u;
+      atomicExch(P.special, cap); atomicAdd(&P.counts[cap], 1u); P.slot_of_row[i] = cap;
+    } else if (atomicCAS(P.special, VM_NONE, (u32)i) != VM_NONE) atomicExch(&P.flags[0], 1u);
     return;
   }
   u32 slot = hash64(key) & P.capacity_mask;
   for (u32 probe = 0; probe <= P.capacity_mask; ++probe) {
     const u64 old = atomicCAS(&P.keys[slot], VM_KEY_EMPTY, key);
-    if (old == VM_KEY_EMPTY) { P.rows[slot] = (u32)i; return; }
-    if (old == key) { atomicExch(&P.flags[0], 1u); return; }     // duplicate key in a UNIQUE rhs
+    if (multi) {
+      if (old == VM_KEY_EMPTY || old == key) {
+        if (old == VM_KEY_EMPTY) P.rows[slot] = slot;   // the probe answers with the key's slot, not a row
+        atomicAdd(&P.counts[slot], 1u); P.slot_of_row[i] = slot;
+        return;
+      }
+    } else {
+      if (old == VM_KEY_EMPTY) { P.rows[slot] = (u32)i; return; }
+      if (old == key) { atomicExch(&P.flags[0], 1u); return; }     // duplicate key in a UNIQUE rhs
+    }
     slot = (slot + 1) & P.capacity_mask;
   }
   atomicExch(&P.flags[0], 2u);
@@ -2308,6 +2320,29 @@ hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t
     case 4: hipLaunchKernelGGL(ssgpu_pipeline_kernel<4>, g, b, lds, stream, P); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+// NOT_UNIQUE hash join, expansion: output row o belongs to the lhs row i whose run [offsets[i],
+// offsets[i] + count[i]) contains it (binary search over the exclusive scan of the run counts) and to
+// rhs row rows_sorted[run_start[i] + (o - offsets[i])] -- or to no rhs row (LEFT_OUTER, unmatched).
+__global__ __launch_bounds__(256) void ssgpu_join_expand_kernel(const u32* __restrict__ offsets, const u32* __restrict__ run_start,
+                                                                const u32* __restrict__ rows_sorted, u64 n_lhs, u64 n_out,
+                                                                u32* __restrict__ lhs_idx, u32* __restrict__ rhs_row) {
+  const u64 o = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_out) return;
+  u64 lo = 0, hi = n_lhs - 1;
+  while (lo < hi) {                       // the largest i with offsets[i] <= o (rows with an empty run share
+    const u64 mid = (lo + hi + 1) >> 1;   // their successor's offset and are skipped by "largest")
+    if ((u64)offsets[mid] <= o) lo = mid; else hi = mid - 1;
+  }
+  const u32 s = run_start[lo];
+  lhs_idx[o] = (u32)lo;
+  rhs_row[o] = s == VM_NONE ? VM_NONE : rows_sorted[(u64)s + (o - (u64)offsets[lo])];
+}
+hipError_t ssgpu_launch_join_expand(const unsigned int* offsets, const unsigned int* run_start, const unsigned int* rows_sorted,
+                                    unsigned long long n_lhs, unsigned long long n_out, unsigned int* lhs_idx, unsigned int* rhs_row, hipStream_t stream) {
+  if (n_out) hipLaunchKernelGGL(ssgpu_join_expand_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, stream,
+                                offsets, run_start, rows_sorted, (u64)n_lhs, (u64)n_out, lhs_idx, rhs_row);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream) {

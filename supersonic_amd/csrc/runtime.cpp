@@ -99,6 +99,8 @@ struct StageExec {
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jrows, jmisc;
+  std::vector<DevBuf> jcounts, jstarts, jslot_of_row, jrows_sorted;   // NOT_UNIQUE joins: key -> run of rhs rows
+  DevBuf jx_offsets, jx_lhs_idx, jx_rhs_row;                           // JOIN_EXPAND scratch
   std::vector<VmJoin> vm_joins;
   uint32_t capacity = 0;
   DevBuf error_flag;
@@ -463,6 +465,39 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
 // ---- hash joins fused into a stage -------------------------------------------------------------
 // The index over the rhs table is rebuilt at the start of every run of the stage (dimension
 // tables are small next to the probing side; the build is one launch of ssgpu_join_build_kernel).
+// Stable LSD radix sort of the row ids 0..n-1 by a device array of 32-bit keys (the sort stage's
+// kernels and scratch buffers); *sorted points into the stage's index buffers.
+int sort_rows_by_u32(ssgpu_plan* p, StageExec& ex, const uint32_t* keys32, uint64_t n, uint32_t** sorted) {
+  ssgpu_ctx* c = p->ctx;
+  const uint32_t nt = ssgpu_sort_tiles(n);
+  HIP_TRY(c, ex.skeys_a.ensure(std::max<uint64_t>(n, 1) * 8)); HIP_TRY(c, ex.skeys_b.ensure(std::max<uint64_t>(n, 1) * 8));
+  HIP_TRY(c, ex.sidx_a.ensure(std::max<uint64_t>(n, 1) * 4)); HIP_TRY(c, ex.sidx_b.ensure(std::max<uint64_t>(n, 1) * 4));
+  HIP_TRY(c, ex.shist.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4)); HIP_TRY(c, ex.soffs.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4));
+  HIP_TRY(c, ex.total.ensure(8)); HIP_TRY(c, ex.total2.ensure(16));
+  uint64_t* ka = ex.skeys_a.as<uint64_t>(); uint64_t* kb = ex.skeys_b.as<uint64_t>();
+  uint32_t* ia = ex.sidx_a.as<uint32_t>(); uint32_t* ib = ex.sidx_b.as<uint32_t>();
+  HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+  if (n > 0) {
+    const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(c, hipMemcpyAsync(ex.total2.p, init, 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, keys32, nullptr, 4, 0, 0, 0, n, ex.total2.as<unsigned long long>(), c->stream));
+    unsigned long long bits[2];
+    HIP_TRY(c, hipMemcpyAsync(bits, ex.total2.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t varying = bits[0] ^ bits[1];
+    for (uint32_t pass = 0; pass < 4; ++pass) {
+      if (!((varying >> (pass * 8)) & 0xFFull)) continue;
+      HIP_TRY(c, ssgpu_launch_sort_hist(ka, pass * 8, n, ex.shist.as<uint32_t>(), c->stream));
+      HIP_TRY(c, ssgpu_launch_scan_counts(ex.shist.as<uint32_t>(), ex.soffs.as<uint32_t>(), (int)(nt * 256), ex.total.as<uint64_t>(), c->stream));
+      HIP_TRY(c, ssgpu_launch_sort_scatter(ka, ia, kb, ib, pass * 8, n, ex.soffs.as<uint32_t>(), c->stream));
+      std::swap(ka, kb); std::swap(ia, ib);
+      p->counters.n_launches += 3;
+    }
+  }
+  *sorted = ia;
+  return SSGPU_OK;
+}
+
 int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
   ssgpu_ctx* c = p->ctx;
   if (st.joins.empty()) return SSGPU_OK;
@@ -487,10 +522,29 @@ int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
     B.capacity_mask = (uint32_t)(cap - 1); B.n_rows = (unsigned long long)p->aux_rows;
     B.keys = ex.jkeys[j].as<unsigned long long>(); B.rows = ex.jrows[j].as<unsigned int>();
     B.special = ex.jmisc[j].as<unsigned int>(); B.flags = ex.jmisc[j].as<unsigned int>() + 1;
+    if (js.multi) {
+      const uint64_t nr = (uint64_t)std::max<int64_t>(p->aux_rows, 1);
+      ex.jcounts.resize(nj); ex.jstarts.resize(nj); ex.jslot_of_row.resize(nj); ex.jrows_sorted.resize(nj);
+      HIP_TRY(c, ex.jcounts[j].ensure((cap + 1) * 4)); HIP_TRY(c, ex.jstarts[j].ensure((cap + 1) * 4));
+      HIP_TRY(c, ex.jslot_of_row[j].ensure(nr * 4)); HIP_TRY(c, ex.jrows_sorted[j].ensure(nr * 4));
+      HIP_TRY(c, hipMemsetAsync(ex.jcounts[j].p, 0, (cap + 1) * 4, c->stream));
+      B.counts = ex.jcounts[j].as<unsigned int>(); B.slot_of_row = ex.jslot_of_row[j].as<unsigned int>();
+    }
     HIP_TRY(c, ssgpu_launch_join_build(B, c->stream));
+    if (js.multi) {
+      // run starts = exclusive scan of the per-key counts in slot order; the rhs row ids, stably sorted by
+      // their slot, list every key's rows contiguously in that same order and in ascending row order
+      HIP_TRY(c, ex.total.ensure(8));
+      HIP_TRY(c, ssgpu_launch_scan_counts(ex.jcounts[j].as<uint32_t>(), ex.jstarts[j].as<uint32_t>(), (int)(cap + 1), ex.total.as<uint64_t>(), c->stream));
+      uint32_t* sorted = nullptr;
+      int rc = sort_rows_by_u32(p, ex, ex.jslot_of_row[j].as<uint32_t>(), (uint64_t)p->aux_rows, &sorted);
+      if (rc != SSGPU_OK) return rc;
+      if (p->aux_rows > 0) HIP_TRY(c, hipMemcpyAsync(ex.jrows_sorted[j].p, sorted, (size_t)p->aux_rows * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     uint32_t misc[4];
     HIP_TRY(c, hipMemcpyAsync(misc, ex.jmisc[j].p, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (misc[1] == 2) { c->err = "hash join: index table overflow"; return SSGPU_ERROR_UNKNOWN; }
     if (misc[1]) { c->err = "hash join: the rhs keys were declared UNIQUE but a key occurs more than once"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
     VmJoin& J = ex.vm_joins[j];
     J.keys = ex.jkeys[j].as<unsigned long long>(); J.rows = ex.jrows[j].as<unsigned int>();
@@ -502,6 +556,12 @@ int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
 void apply_joins(const ssgpu_plan* p, const StageExec& ex, const Program& prog, VmParams* P) {
   for (size_t j = 0; j < ex.vm_joins.size() && j < VM_MAX_JOINS; ++j) P->join[j] = ex.vm_joins[j];
   for (size_t g = 0; g < prog.gathers.size() && g < VM_MAX_JOIN_COLS; ++g) {
+    const JoinGather& jg = prog.gathers[g];
+    if (jg.rhs_col < 0) {   // the per-key run arrays of a NOT_UNIQUE join, indexed by the probed slot
+      const DevBuf& b = jg.rhs_col == JOIN_GATHER_RUN_START ? ex.jstarts[jg.join_id] : ex.jcounts[jg.join_id];
+      P->join_cols[g].data = b.p; P->join_cols[g].is_null = nullptr;
+      continue;
+    }
     const ssgpu_column& col = p->aux_cols[prog.gathers[g].rhs_col];
     P->join_cols[g].data = col.data;
     P->join_cols[g].is_null = p->desc.aux_schema[prog.gathers[g].rhs_col].nullable ? col.is_null : nullptr;
@@ -1133,6 +1193,51 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   return SSGPU_OK;
 }
 
+// NOT_UNIQUE hash join, second half (the previous stage materialised the kept lhs columns plus every
+// row's run of matching rhs rows): scan the run counts, expand to (lhs row, rhs row) pairs, gather.
+int run_join_expand(ssgpu_plan* p, size_t si, const InCols& in) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  if (si == 0 || p->exec[si - 1].jrows_sorted.empty()) { c->err = "join expansion without its index"; return SSGPU_ERROR_UNKNOWN; }
+  StageExec& bx = p->exec[si - 1];
+  const size_t join_id = bx.jrows_sorted.size() - 1;   // the multi join is the last join of the lhs pipeline
+  const uint64_t n = (uint64_t)in.rows;
+  const size_t n_in = in.cols.size();
+  const uint32_t* run_start = static_cast<const uint32_t*>(in.cols[n_in - 2].data);
+  const uint32_t* run_count = static_cast<const uint32_t*>(in.cols[n_in - 1].data);
+  HIP_TRY(c, ex.jx_offsets.ensure(std::max<uint64_t>(n, 1) * 4)); HIP_TRY(c, ex.total.ensure(8));
+  HIP_TRY(c, hipMemsetAsync(ex.total.p, 0, 8, c->stream));
+  uint64_t n_out = 0;
+  if (n > 0) {
+    if (n >= (1ull << 31)) { c->err = "hash join: more than 2^31 lhs rows per GPU is not supported yet"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    HIP_TRY(c, ssgpu_launch_scan_counts(run_count, ex.jx_offsets.as<uint32_t>(), (int)n, ex.total.as<uint64_t>(), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&n_out, ex.total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (n_out >= (uint64_t)VM_NONE) { c->err = "hash join: the result has more than 2^32 rows"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+  int rc = ensure_out_cols(c, st, ex, (int64_t)n_out);
+  if (rc != SSGPU_OK) return rc;
+  HIP_TRY(c, ex.jx_lhs_idx.ensure(std::max<uint64_t>(n_out, 1) * 4)); HIP_TRY(c, ex.jx_rhs_row.ensure(std::max<uint64_t>(n_out, 1) * 4));
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  HIP_TRY(c, ssgpu_launch_join_expand(ex.jx_offsets.as<uint32_t>(), run_start, bx.jrows_sorted[join_id].as<uint32_t>(), n, n_out,
+                                      ex.jx_lhs_idx.as<uint32_t>(), ex.jx_rhs_row.as<uint32_t>(), c->stream));
+  for (size_t q = 0; q < st.join_out.size(); ++q) {
+    const Stage::JoinOut& f = st.join_out[q];
+    const void* src; const uint8_t* src_null; const uint32_t* idx;
+    if (f.from_rhs) {
+      src = p->aux_cols[f.col].data; src_null = p->desc.aux_schema[f.col].nullable ? p->aux_cols[f.col].is_null : nullptr;
+      idx = ex.jx_rhs_row.as<uint32_t>();
+    } else {
+      src = in.cols[f.col].data; src_null = in.cols[f.col].is_null; idx = ex.jx_lhs_idx.as<uint32_t>();
+    }
+    HIP_TRY(c, ssgpu_launch_sort_gather(ex.out[q].data.p, ex.out[q].nullable ? ex.out[q].nulls.as<uint8_t>() : nullptr, src, src_null,
+                                        ex.out[q].width, idx, n_out, c->stream));
+  }
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  p->counters.n_launches += 2 + (int)st.join_out.size();
+  ex.out_rows = (int64_t)n_out;
+  return SSGPU_OK;
+}
+
 int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
   ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[si];
   if (ex.out_rows < 0) {
@@ -1197,6 +1302,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       case STAGE_GROUP_AGG: rc = run_group_agg(p, si, in, row_id_base); break;
       case STAGE_SORT: rc = run_sort(p, si, in); break;
       case STAGE_CLUSTERS: rc = run_clusters(p, si, in, row_id_base); break;
+      case STAGE_JOIN_EXPAND: rc = run_join_expand(p, si, in); break;
       default: c->err = "stage kind not executable yet"; rc = SSGPU_ERROR_NOT_IMPLEMENTED; break;
     }
     if (rc != SSGPU_OK) return rc;

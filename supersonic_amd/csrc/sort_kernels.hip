@@ -192,6 +192,13 @@ __global__ void ssgpu_sort_gather_kernel(void* __restrict__ out, u8* __restrict_
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 r = idx[i];
+  if (r == 0xFFFFFFFFull) {   // "no row" (the rhs side of an unmatched LEFT_OUTER row): a NULL
+    if (width == 8) reinterpret_cast<u64*>(out)[i] = 0ull;
+    else if (width == 4) reinterpret_cast<u32*>(out)[i] = 0u;
+    else reinterpret_cast<u8*>(out)[i] = (u8)0;
+    if (out_nulls) out_nulls[i] = (u8)1;
+    return;
+  }
   if (width == 8) reinterpret_cast<u64*>(out)[i] = reinterpret_cast<const u64*>(col)[r];
   else if (width == 4) reinterpret_cast<u32*>(out)[i] = reinterpret_cast<const u32*>(col)[r];
   else reinterpret_cast<u8*>(out)[i] = reinterpret_cast<const u8*>(col)[r];

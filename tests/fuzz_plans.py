@@ -198,11 +198,13 @@ class Gen(object):
     def join_plan(self, view):
         # star join against a 7-row dimension keyed by k2 (one key missing for LEFT_OUTER / INNER to differ)
         dim_schema = ss.TupleSchema([ss.Attribute("id", ss.INT32), ss.Attribute("weight", ss.INT64, ss.NULLABLE), ss.Attribute("rate", ss.DOUBLE)])
-        ids = np.array([0, 1, 2, 3, 5, 6], dtype=np.int32)
-        dim = ss.View(dim_schema, [ids, ss.Column(ids.astype(np.int64) * 100 - 250, ids == 3), ids * 0.25])
+        unique = self.rng.random() < 0.5
+        ids = np.array([0, 1, 2, 3, 5, 6] if unique else [0, 1, 5, 1, 3, 5, 5, 2], dtype=np.int32)   # NOT_UNIQUE: keys repeat, rows multiply
+        seq = np.arange(len(ids), dtype=np.int64)
+        dim = ss.View(dim_schema, [ids, ss.Column(seq * 100 - 250, seq == 3), seq * 0.25])
         joined = ss.HashJoin(self.pick([ss.INNER, ss.LEFT_OUTER]), ss.ProjectNamedAttribute("k2"), ss.ProjectNamedAttribute("id"),
                              ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes()).add(1, ss.ProjectNamedAttributes(["weight", "rate"])),
-                             ss.UNIQUE, ss.ScanView(view), ss.ScanView(dim))
+                             ss.UNIQUE if unique else ss.NOT_UNIQUE, ss.ScanView(view), ss.ScanView(dim))
         e = ss.CompoundExpression().AddAs("j0", ss.Plus(NA("weight"), self.integer(int(self.rng.integers(0, 3))))) \
             .AddAs("j1", ss.Multiply(NA("rate"), self.floating(int(self.rng.integers(0, 3))))).AddAs("j2", self.any_expr(2))
         if self.rng.random() < 0.5:

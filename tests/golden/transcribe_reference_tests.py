@@ -458,7 +458,7 @@ op_case("Sort_OneStringColumnWithDuplicatesAndNulls_string", SO + ":190-215", co
         ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [STR], [[None], [None], ["a"], ["a"], ["c"], ["d"], ["e"]])
 op_case("Sort_OneEmptyStringColumn_string", SO + ":180-188", cols([STR]), [], ["Sort", [["col0", "ASCENDING"]], None, "INPUT"], [STR], [])
 
-# ---- HashJoin (hash_join_test.cc), UNIQUE rhs keys, with the tests' own STRING payloads ------------------
+# ---- HashJoin (hash_join_test.cc) with the tests' own STRING payloads ---------------------------------
 HJ = "supersonic/cursor/core/hash_join_test.cc"
 ALLP = [[0, ["ProjectAllAttributes", "L."]], [1, ["ProjectAllAttributes", "R."]]]
 JT = [I64, STR, I64, STR]
@@ -468,11 +468,11 @@ R12345 = [[1, "a"], [2, "b"], [3, "c"], [4, "d"], [5, "e"]]
 R654321 = [[6, "f"], [5, "e"], [4, "d"], [3, "c"], [2, "b"], [1, "a"]]
 
 
-def join_case(name, src, jtype, lrows, rrows, expected):
+def join_case(name, src, jtype, lrows, rrows, expected, uniqueness="UNIQUE"):
     CASES.append({
         "name": name, "source": src, "kind": "operation",
         "input": {"schema": cols([I64, STR]), "rows": lrows}, "input2": {"schema": cols([I64, STR]), "rows": rrows},
-        "plan": ["HashJoin", jtype, [0], [0], ALLP, "UNIQUE", "INPUT", "INPUT2"],
+        "plan": ["HashJoin", jtype, [0], [0], ALLP, uniqueness, "INPUT", "INPUT2"],
         "expected": {"types": JT, "rows": expected, "names": JN, "nullable": None},
         "ordered": True, "expect_error": None})
 
@@ -485,6 +485,27 @@ join_case("HashJoin_12345_InnerJoin_654321", HJ + ":189-203", "INNER", R12345, R
 join_case("HashJoin_654321_InnerJoin_12345", HJ + ":205-219", "INNER", R654321, R12345, [[k, v, k, v] for k, v in R654321[1:]])
 join_case("HashJoin_654321_LeftOuterJoin_12345", HJ + ":222-238", "LEFT_OUTER", R654321, R12345,
           [[6, "f", None, None]] + [[k, v, k, v] for k, v in R654321[1:]])
+
+# the same TEST_P cases with rhs_key_uniqueness() == NOT_UNIQUE (hash_join_test.cc:136-138), then the tests
+# whose rhs keys really repeat: matches of one lhs row come out in rhs order
+NU = "NOT_UNIQUE"
+join_case("HashJoin_1_InnerJoin_1_not_unique", HJ + ":140-150", "INNER", R1, R1, [[1, "a", 1, "a"]], NU)
+join_case("HashJoin_1_LeftOuterJoin_2_not_unique", HJ + ":176-187", "LEFT_OUTER", R1, R2, [[1, "a", None, None]], NU)
+join_case("HashJoin_12345_InnerJoin_654321_not_unique", HJ + ":189-203", "INNER", R12345, R654321, [[k, v, k, v] for k, v in R12345], NU)
+join_case("HashJoin_654321_LeftOuterJoin_12345_not_unique", HJ + ":222-238", "LEFT_OUTER", R654321, R12345,
+          [[6, "f", None, None]] + [[k, v, k, v] for k, v in R654321[1:]], NU)
+R2b2b2c = [[2, "b"], [2, "b"], [2, "c"]]
+join_case("HashJoin_12345_InnerJoin_2b2b2c", HJ + ":240-252", "INNER", R12345, R2b2b2c,
+          [[2, "b", 2, "b"], [2, "b", 2, "b"], [2, "b", 2, "c"]], NU)
+join_case("HashJoin_12345_LeftOuterJoin_2b2b2c", HJ + ":254-271", "LEFT_OUTER", R12345, R2b2b2c,
+          [[1, "a", None, None], [2, "b", 2, "b"], [2, "b", 2, "b"], [2, "b", 2, "c"], [3, "c", None, None], [4, "d", None, None], [5, "e", None, None]], NU)
+join_case("HashJoin_2b2b2c_InnerJoin_2b2b2c", HJ + ":112-121,273-281", "INNER", R2b2b2c, R2b2b2c,
+          [[2, "b", 2, "b"], [2, "b", 2, "b"], [2, "b", 2, "c"], [2, "b", 2, "b"], [2, "b", 2, "b"], [2, "b", 2, "c"],
+           [2, "c", 2, "b"], [2, "c", 2, "b"], [2, "c", 2, "c"]], NU)
+# every lhs row matches 1100 rhs rows: more than one 1024-row result view per lhs row
+R5k = [[k, v] for _ in range(1100) for k, v in R12345]
+join_case("HashJoin_12345_InnerJoin_5k_Rows", HJ + ":321-353", "INNER", R12345, R5k,
+          [[k, v, k, v] for k, v in R12345 for _ in range(1100)], NU)
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")

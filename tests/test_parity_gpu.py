@@ -421,6 +421,38 @@ def test_hash_join_fused_into_the_pipeline(gpu_ctx, n, m, join_type):
     run_both(ss.Compute(expr, join(ss.ScanView(lview))), gpu_ctx)                    # expressions over joined columns
 
 
+@pytest.mark.parametrize("n,m", [(0, 5), (7, 0), (1025, 40), (30011, 300)])
+@pytest.mark.parametrize("join_type", [ss.INNER, ss.LEFT_OUTER])
+def test_hash_join_not_unique(gpu_ctx, n, m, join_type):
+    # NOT_UNIQUE rhs keys multiply rows (hash_join_test.cc:240-300): rhs keys repeat (id2 has 3 values, id // 4
+    # runs of up to 4), lhs order is kept and the matches of one lhs row come in rhs order
+    lview, rview = _join_views(n, m)
+    proj = (ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes("L."))
+            .add(1, ss.ProjectNamedAttributes(["name", "w", "g"])).add(1, ss.ProjectNamedAttributeAs("id", "rid")))
+    narrow = ss.Filter(ss.Less(NA("a"), ss.ConstInt64(40)), ss.ProjectAllAttributes(), ss.ScanView(lview))   # ~4 % of the lhs: fk2 fans out m / 3 ways
+
+    def join(lhs_op, lk="fk2", rk="id2"):
+        return ss.HashJoin(join_type, ss.ProjectNamedAttribute(lk), ss.ProjectNamedAttribute(rk), proj, ss.NOT_UNIQUE, lhs_op, ss.ScanView(rview))
+    run_both(join(narrow), gpu_ctx)
+    # a NULLABLE INT64 key with NULLs on both sides and the EMPTY-sentinel value (-1); keys made to repeat
+    rdup = ss.View(rview.schema(), [ss.Column(rview.column(0).data // 4, rview.column(0).is_null)] + [rview.column(i) for i in range(1, 5)])
+    ldup = ss.View(lview.schema(), [ss.Column(lview.column(0).data // 4, lview.column(0).is_null)] + [lview.column(i) for i in range(1, 4)])
+    op = ss.HashJoin(join_type, ss.ProjectNamedAttribute("fk"), ss.ProjectNamedAttribute("id"), proj, ss.NOT_UNIQUE, ss.ScanView(ldup), ss.ScanView(rdup))
+    run_both(op, gpu_ctx)
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "w", "sw").AddAggregation(ss.COUNT, "name", "c")
+            .AddAggregation(ss.MIN, "name", "mn").AddAggregation(ss.SUM, "L.v", "sv").AddAggregation(ss.COUNT, "", "n"))
+    run_both(ss.ScalarAggregate(spec, op), gpu_ctx)                                   # the joined rows feed a new pipeline
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), spec, None, join(narrow)), gpu_ctx, ignore_order=True)
+    # a UNIQUE-declared join below a NOT_UNIQUE one: the first stays fused in the lhs pipeline of the second
+    inner = ss.HashJoin(ss.LEFT_OUTER, ss.ProjectNamedAttribute("fk"), ss.ProjectNamedAttribute("id"),
+                        ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes()).add(1, ss.ProjectNamedAttributeAs("g", "g1")),
+                        ss.UNIQUE, narrow, ss.ScanView(rview))
+    outer = ss.HashJoin(join_type, ss.ProjectNamedAttribute("fk2"), ss.ProjectNamedAttribute("id2"),
+                        ss.CompoundMultiSourceProjector().add(0, ss.ProjectNamedAttributes(["fk", "g1", "v"])).add(1, ss.ProjectNamedAttributes(["w"])),
+                        ss.NOT_UNIQUE, inner, ss.ScanView(rview))
+    run_both(outer, gpu_ctx)
+
+
 def test_hash_join_two_key_columns_and_errors(gpu_ctx):
     rng = np.random.default_rng(4)
     m, n = 200, 7000
