@@ -34,4 +34,4 @@ json.dump(j, open(out + "/pmc.json", "w"), indent=1)
 print(json.dumps(j))
 PY
 cat $OUT/bench_line.json | tail -1 | cut -c1-900
-f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); head -5 $f | cut -c1-200
+f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -5 "$f" | cut -c1-200 < /dev/null
