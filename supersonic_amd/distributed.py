@@ -80,10 +80,14 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
     merged_spec, counts = _merge_spec(spec)
     partial = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), spec, None, local_child))
     everyone = _all_gather_view(partial, group, device)
+    return executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), everyone))
+
+
+def _merge_plan(group_by, merged_spec, counts, schema, everyone):
+    """The second, local GroupAggregate over the gathered partial tables (+ COUNT columns back to NOT NULL)."""
     merged = ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), merged_spec, None, ss.ScanView(everyone))
     if counts:
         # SUM(...) is NULLABLE, COUNT is not: restore the schema of the single-process result
-        schema = partial.schema()
         e = ss.CompoundExpression()
         for i in range(schema.attribute_count()):
             a = schema.attribute(i)
@@ -93,7 +97,7 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
             else:
                 e.Add(ss.NamedAttribute(a.name()))
         merged = ss.Compute(e, merged)
-    return executor(merged)
+    return merged
 
 
 # ---------------------------------------------------------------------------------------------
@@ -321,4 +325,61 @@ def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_ran
     final.run()
     ctx.synchronize()
     del keep, parts
+    return final, final.result_device_view()
+
+
+def device_sharded_group_aggregate(ctx, group_by, spec, local_child, group=None):
+    """sharded_group_aggregate with the partial group tables staying in HBM: the per-shard aggregate runs as a
+    device plan, its result buffers are wrapped as torch tensors (no copy), padded to the largest table and
+    exchanged with ONE RCCL all_gather per column buffer; the merge plan reads the gathered tables in place
+    (the padding rows are cut out by a compacting copy on the device).  BASELINE config #4.
+
+    Returns (plan, DeviceView): the full result on every rank, as device columns owned by `plan`."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    device = torch.device("cuda", torch.cuda.current_device())
+    merged_spec, counts = _merge_spec(spec)
+    first = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), spec, None, local_child), ctx)
+    first.run()
+    ctx.synchronize()
+    partial = first.result_device_view()
+    schema = partial.schema()
+    n_attrs = schema.attribute_count()
+    for i in range(n_attrs):
+        if schema.attribute(i).type() == ss.STRING:
+            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
+    rows = torch.tensor([partial.row_count()], dtype=torch.int64, device=device)
+    all_rows = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_rows, rows, group=group)
+    table_rows = [int(t.item()) for t in all_rows]
+    cap = max(max(table_rows), 1)
+    gathered, keep = [], []
+    for i in range(n_attrs):
+        w = np.dtype(ss.numpy_dtype(schema.attribute(i).type())).itemsize
+        ptrs = []
+        for which, width in ((0, w), (1, 1)):
+            if which == 1 and not schema.attribute(i).is_nullable():
+                ptrs.append(0)
+                continue
+            mine = torch.zeros(cap * width, dtype=torch.uint8, device=device)
+            src = partial._ptrs[i][which]
+            if src and partial.row_count():
+                mine[: partial.row_count() * width] = _bytes_over(torch, device, src, partial.row_count() * width)
+            everyone = torch.empty(world * cap * width, dtype=torch.uint8, device=device)
+            dist.all_gather_into_tensor(everyone, mine, group=group)
+            # drop the padding: the tables of all ranks back to back
+            packed = torch.cat([everyone[r * cap * width: r * cap * width + table_rows[r] * width] for r in range(world)]) if sum(table_rows) else everyone[:0]
+            if packed.numel() == 0:
+                packed = torch.zeros(max(width, 1), dtype=torch.uint8, device=device)
+            keep.append(packed)
+            ptrs.append(packed.data_ptr())
+        gathered.append((ptrs[0], ptrs[1]))
+    torch.cuda.synchronize()
+    everyone_view = ss.DeviceView(schema, gathered, sum(table_rows))
+    final = ss.Plan(_merge_plan(group_by, merged_spec, counts, schema, everyone_view), ctx)
+    final.run()
+    ctx.synchronize()
+    del keep
     return final, final.result_device_view()

@@ -658,3 +658,34 @@ def test_partial_state_fold_across_shards(gpu_ctx, n, shards):
     got = plans[0].fetch()
     _schema, want = oracle_run(query(view))
     assert_cols_equal([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())], want, context="folded partial state")
+
+
+@pytest.mark.parametrize("n,with_filter", [(100003, True), (2000, False), (0, False)])
+def test_device_sharded_group_aggregate_single_rank(n, with_filter):
+    # BASELINE config #4's protocol with the tables staying in HBM (per-shard GroupAggregate -> RCCL all-gather of the
+    # plan's own result buffers -> merge plan), on a 1-rank process group
+    import socket
+    import torch
+    import torch.distributed as dist
+    from supersonic_amd.distributed import device_sharded_group_aggregate
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = ss.Context(0)
+        view = make_view(n, nullable=True)
+        spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "sa").AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.MAX, "d1", "mx")
+                .AddAggregation(ss.COUNT, "d0", "c").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.FIRST, "d", "fd"))
+        child = ss.ScanView(view)
+        if with_filter:
+            child = ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), child)
+        plan, _dv = device_sharded_group_aggregate(ctx, ["k2", "t"], spec, child)
+        got = plan.fetch()
+        schema, want = oracle_run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2", "t"]), spec, None, child))
+        gs = plan.result_schema
+        assert [(gs.attribute(i).name(), gs.attribute(i).type(), gs.attribute(i).is_nullable()) for i in range(gs.attribute_count())] == [tuple(x) for x in schema]
+        assert_cols_equal(sort_rows([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())]), sort_rows(want),
+                          context="device sharded group aggregate")
+    finally:
+        dist.destroy_process_group()
