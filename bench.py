@@ -117,14 +117,15 @@ def cpu_baseline(ss, sample_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
+    ap.add_argument("--events-in-loop", action="store_true", help="keep the per-kernel HIP event records in the timed steps")
     ap.add_argument("--force-distributed", action="store_true",
                     help="take the N > 1 code path (run_partial + RCCL all-reduce + finalize) even with one rank")
     args = ap.parse_args()
@@ -195,6 +196,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # the library's per-kernel HIP events (4 event records per run) are instrumentation: off for the
+    # timed steps, on again for the dedicated kernel-time loop below
+    ctx.set_option("profile", 1 if args.events_in_loop else 0)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -207,6 +211,7 @@ def main():
     # the per-kernel clock: HIP events recorded by the library around the pipeline kernel of
     # the LAST step (every step is identical); plus a dedicated loop for an average
     kernel_ms = []
+    ctx.set_option("profile", 1)
     for _ in range(min(args.steps, 10)):
         step()
         torch.cuda.synchronize(device)
