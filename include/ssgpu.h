@@ -362,6 +362,11 @@ typedef struct ssgpu_counters {
   int32_t grid;
   int32_t lds_bytes;
 } ssgpu_counters;
+/* Durations (ms) of the dominant kernel of the most recent runs of the plan, oldest first (HIP events
+ * recorded on the plan's stream around that kernel, kept for the last 256 runs): lets a caller time many
+ * asynchronous runs and read every kernel duration afterwards.  Waits for the stream; returns the
+ * number of values written (<= max). */
+int32_t ssgpu_plan_recent_kernel_ms(ssgpu_plan* plan, double* out_ms, int32_t max);
 int ssgpu_plan_counters(ssgpu_plan* plan, ssgpu_counters* out);
 
 #ifdef __cplusplus

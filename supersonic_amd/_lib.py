@@ -140,6 +140,7 @@ SYMBOLS = [
     ("ssgpu_result_column", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(P)]),
     ("ssgpu_result_device_column", C.c_int, [P, C.c_int32, C.POINTER(Column)]),
     ("ssgpu_plan_counters", C.c_int, [P, C.POINTER(Counters)]),
+    ("ssgpu_plan_recent_kernel_ms", C.c_int32, [P, C.POINTER(C.c_double), C.c_int32]),
 ]
 
 _lib = None

@@ -963,6 +963,12 @@ class Plan(object):
         self.ctx.check(self.lib.ssgpu_plan_counters(self.handle, C.byref(c)))
         return c
 
+    def recent_kernel_ms(self, max_runs=256):
+        """Dominant-kernel durations (ms) of the most recent runs, oldest first (waits for the stream)."""
+        buf = (C.c_double * max_runs)()
+        n = self.lib.ssgpu_plan_recent_kernel_ms(self.handle, buf, max_runs)
+        return [buf[i] for i in range(n)]
+
     def interrupt(self):
         self.lib.ssgpu_interrupt(self.handle)
 

@@ -39,6 +39,7 @@ struct ssgpu_ctx {
   int64_t group_local = 1;       // 0: never use the LDS pre-aggregation table
   int64_t group_partition = 1;   // 0: never switch to the partitioned GroupAggregate; 2: always use it
   int64_t profile = 1;           // record HIP events around kernels
+  int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
 };
 
@@ -133,6 +134,11 @@ struct ssgpu_plan {
   std::string describe, describe_full;
   std::atomic<int> interrupted{0};
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
+  // the (dom0, dom1) pairs of the most recent profiled runs: ev_dom0 / ev_dom1 alias the current pair, so
+  // a caller can time many asynchronous runs and read every kernel duration afterwards, without a sync in between
+  static const int kEventRing = 256;
+  hipEvent_t ring0[kEventRing] = {nullptr}, ring1[kEventRing] = {nullptr};
+  uint64_t profiled_runs = 0;
   bool events_valid = false;
   ssgpu_counters counters{};
   std::vector<VmInstr> host_prog_scratch;
@@ -218,6 +224,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
   } else if (k == "profile") c->profile = value;
+  else if (k == "profile_total") c->profile_total = value;
   else if (k == "debug_timing") c->debug_timing = value;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
@@ -383,7 +390,6 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   p->result.plan = p;
   if (c->device >= 0) {
     (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end);
-    (void)hipEventCreate(&p->ev_dom0); (void)hipEventCreate(&p->ev_dom1);
   }
   *out = p;
   return SSGPU_OK;
@@ -395,8 +401,10 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
     if (p->ev_end) (void)hipEventDestroy(p->ev_end);
-    if (p->ev_dom0) (void)hipEventDestroy(p->ev_dom0);
-    if (p->ev_dom1) (void)hipEventDestroy(p->ev_dom1);
+    for (int i = 0; i < ssgpu_plan::kEventRing; ++i) {
+      if (p->ring0[i]) (void)hipEventDestroy(p->ring0[i]);
+      if (p->ring1[i]) (void)hipEventDestroy(p->ring1[i]);
+    }
   }
   delete p;
 }
@@ -1284,7 +1292,14 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
     int rc = prepare_stage(p, si);
     if (rc != SSGPU_OK) return rc;
   }
-  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_begin, c->stream));
+  if (c->profile) {
+    const int slot = (int)(p->profiled_runs % ssgpu_plan::kEventRing);
+    if (!p->ring0[slot]) { HIP_TRY(c, hipEventCreate(&p->ring0[slot])); HIP_TRY(c, hipEventCreate(&p->ring1[slot])); }
+    p->ev_dom0 = p->ring0[slot]; p->ev_dom1 = p->ring1[slot];
+    ++p->profiled_runs;
+    p->events_valid = false;
+    if (c->profile_total) HIP_TRY(c, hipEventRecord(p->ev_begin, c->stream));
+  }
   int64_t alg_bytes = 0;
   for (size_t si = 0; si < p->stages.size(); ++si) {
     if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
@@ -1318,7 +1333,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       row_id_base = 0;
     }
   }
-  if (c->profile) { HIP_TRY(c, hipEventRecord(p->ev_end, c->stream)); p->events_valid = true; }
+  if (c->profile && c->profile_total) { HIP_TRY(c, hipEventRecord(p->ev_end, c->stream)); p->events_valid = true; }
   p->counters.algorithmic_bytes = alg_bytes;
   p->last_rows = rows;
   p->partial_pending = partial;
@@ -1378,6 +1393,21 @@ int32_t ssgpu_plan_partial_segments(ssgpu_plan* p, ssgpu_partial_segment* out, i
     out[n].count = ns; out[n].dtype = dtype[i]; out[n].reduce = reduce[i];
   }
   return n;
+}
+
+int32_t ssgpu_plan_recent_kernel_ms(ssgpu_plan* p, double* out_ms, int32_t max) {
+  if (!p || !out_ms || max <= 0 || !p->ctx || p->ctx->device < 0) return 0;
+  ssgpu_ctx* c = p->ctx;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+  const uint64_t have = std::min<uint64_t>(p->profiled_runs, (uint64_t)ssgpu_plan::kEventRing);
+  const uint64_t n = std::min<uint64_t>(have, (uint64_t)max);
+  int32_t written = 0;
+  for (uint64_t i = p->profiled_runs - n; i < p->profiled_runs; ++i) {
+    const int slot = (int)(i % ssgpu_plan::kEventRing);
+    float ms = 0.f;
+    if (p->ring0[slot] && hipEventElapsedTime(&ms, p->ring0[slot], p->ring1[slot]) == hipSuccess) out_ms[written++] = ms;
+  }
+  return written;
 }
 
 int ssgpu_plan_fold_partials(ssgpu_plan* p, const void* images, int32_t n_images) {
@@ -1467,11 +1497,15 @@ int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data, const uin
 int ssgpu_plan_counters(ssgpu_plan* p, ssgpu_counters* out) {
   if (!p || !out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_ctx* c = p->ctx;
-  if (c->device >= 0 && p->events_valid && c->profile) {
-    HIP_TRY(c, hipEventSynchronize(p->ev_end));
+  if (c->device >= 0 && c->profile && p->profiled_runs > 0) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p->ev_begin, p->ev_end) == hipSuccess) p->counters.kernel_ms = ms;
-    if (hipEventElapsedTime(&ms, p->ev_dom0, p->ev_dom1) == hipSuccess) p->counters.dominant_ms = ms;
+    if (p->events_valid) {
+      HIP_TRY(c, hipEventSynchronize(p->ev_end));
+      if (hipEventElapsedTime(&ms, p->ev_begin, p->ev_end) == hipSuccess) p->counters.kernel_ms = ms;
+    } else if (p->ev_dom1) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (p->ev_dom0 && hipEventElapsedTime(&ms, p->ev_dom0, p->ev_dom1) == hipSuccess) p->counters.dominant_ms = ms;
   }
   *out = p->counters;
   return SSGPU_OK;
