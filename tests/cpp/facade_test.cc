@@ -189,6 +189,38 @@ static void TestRun(const Input& in) {
       }
     }
   }
+  {  // HashJoin(INNER, NOT_UNIQUE): rhs keys repeat, rows multiply (lhs order, matches in rhs order)
+    std::vector<int32_t> id = {1, 3, 1, 5, 1};
+    std::vector<int64_t> w = {10, 30, 11, 50, 12};
+    TupleSchema ds;
+    ds.add_attribute(Attribute("id", INT32, NOT_NULLABLE));
+    ds.add_attribute(Attribute("w", INT64, NOT_NULLABLE));
+    View dim(ds);
+    dim.mutable_column(0)->Reset(id.data(), nullptr);
+    dim.mutable_column(1)->Reset(w.data(), nullptr);
+    dim.set_row_count(5);
+    std::unique_ptr<Operation> op(
+        HashJoin(INNER, ProjectNamedAttribute("k"), ProjectNamedAttribute("id"),
+                 (new CompoundMultiSourceProjector)->add(0, ProjectNamedAttribute("a"))->add(1, ProjectNamedAttribute("w")), NOT_UNIQUE,
+                 ScanView(*in.view), ScanView(dim)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) {
+      std::vector<int64_t> want_a, want_w;
+      for (int i = 0; i < Input::N; ++i)
+        for (int j = 0; j < 5; ++j) if (id[j] == in.k[i]) { want_a.push_back(in.a[i]); want_w.push_back(w[j]); }
+      size_t at = 0; bool ok = true;
+      for (;;) {
+        ResultView r = c->Next(1024);
+        if (r.is_failure()) { printf("multi join failed: %s\n", r.exception().message().c_str()); ++g_fail; break; }
+        if (r.is_eos()) break;
+        for (rowcount_t j = 0; j < r.view().row_count() && ok; ++j, ++at)
+          ok = at < want_a.size() && r.view().column(0).typed_data<int64_t>()[j] == want_a[at] && r.view().column(1).typed_data<int64_t>()[j] == want_w[at];
+      }
+      CHECK(ok);
+      CHECK_EQ(at, want_a.size());
+    }
+  }
   {  // signaling division by zero surfaces as ERROR_EVALUATION_ERROR from Next()
     std::unique_ptr<Operation> op(Compute(DivideSignaling(NamedAttribute("a"), Minus(NamedAttribute("b"), NamedAttribute("b"))), ScanView(*in.view)));
     FailureOrOwned<Cursor> c = op->CreateCursor();
