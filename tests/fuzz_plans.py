@@ -160,7 +160,7 @@ class Gen(object):
             kind = int(self.rng.integers(0, 4))
             if kind == 0:
                 e.AddAs(name, self.integer(int(self.rng.integers(0, 4))))
-                spec.AddAggregation(self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT]), name, "r%d" % i)
+                spec.AddAggregation(self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST]), name, "r%d" % i)
             elif kind == 1:
                 # MIN / MAX of -0.0 and +0.0 depends on the visiting order in the reference;
                 # x + 0.0 turns -0.0 into +0.0 and leaves every other value alone
@@ -168,7 +168,7 @@ class Gen(object):
                 spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT]), name, "r%d" % i)
             elif kind == 2:
                 e.AddAs(name, self.boolean(int(self.rng.integers(0, 3))))
-                spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT]), name, "r%d" % i)
+                spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST]), name, "r%d" % i)
             else:
                 e.AddAs(name, self.integer(0))
                 spec.AddAggregation(ss.COUNT, "", "r%d" % i)
