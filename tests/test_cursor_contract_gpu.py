@@ -24,11 +24,25 @@ def operators(view):
         "filter": flt,
         "group": group_query(view, True, ("k2",)),
         "sort": ss.Sort(ss.SortOrder().add("k1", ss.DESCENDING).add("a", ss.ASCENDING), None, 0, flt),
+        "group_wide": group_query(view, False, ("k1", "k2")),       # > 64 key bits: materialise + sort + clustered aggregation
+        "group_first_last": ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification()
+                                              .AddAggregation(ss.FIRST, "d0", "f").AddAggregation(ss.LAST, "a", "l").AddAggregation(ss.COUNT, "", "n"), None, flt_all(view)),
+        "join_not_unique": ss.HashJoin(ss.LEFT_OUTER, ss.ProjectNamedAttribute("k2"), ss.ProjectNamedAttribute("id"),
+                                       ss.CompoundMultiSourceProjector().add(0, ss.ProjectNamedAttributes(["a", "k2"])).add(1, ss.ProjectNamedAttributes(["w"])),
+                                       ss.NOT_UNIQUE, flt_all(view), ss.ScanView(DIM)),
     }
 
 
+DIM = ss.View(ss.TupleSchema([ss.Attribute("id", ss.INT32), ss.Attribute("w", ss.INT64, ss.NULLABLE)]),
+              [np.array([0, 3, 3, 7, 30, 3, 7], dtype=np.int32), ss.Column(np.arange(7) * 11, np.arange(7) == 2)])
+
+
+def flt_all(view):
+    return ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))
+
+
 @pytest.mark.parametrize("max_rows", [1, 2, 5, 20, 10001, 1 << 40])
-@pytest.mark.parametrize("name", ["scalar", "compute", "filter", "group", "sort"])
+@pytest.mark.parametrize("name", ["scalar", "compute", "filter", "group", "sort", "group_wide", "group_first_last", "join_not_unique"])
 def test_output_block_sizes(gpu_ctx, name, max_rows):
     n = 137 if max_rows < 20 else 30011
     op = operators(make_view(n, nullable=True))[name]
@@ -42,7 +56,7 @@ def test_output_block_sizes(gpu_ctx, name, max_rows):
         assert 1 <= r.view().row_count() <= max_rows          # cursor.h:131-148
         seen += r.view().row_count()
     assert cur.Next(max_rows).is_eos()                          # EOS is sticky
-    got = run_both(op, gpu_ctx, ignore_order=(name == "group"), max_rows=max_rows)
+    got = run_both(op, gpu_ctx, ignore_order=name.startswith("group"), max_rows=max_rows)
     assert got.row_count() == seen
 
 
