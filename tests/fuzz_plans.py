@@ -14,7 +14,8 @@ NA = ss.NamedAttribute
 
 COLUMNS = [("a", ss.INT64, True), ("b", ss.INT64, False), ("k1", ss.INT32, True), ("k2", ss.INT32, False),
            ("u", ss.UINT32, False), ("w", ss.UINT64, True), ("d0", ss.DOUBLE, True), ("d1", ss.DOUBLE, False),
-           ("f", ss.FLOAT, False), ("t", ss.BOOL, True), ("s", ss.BOOL, False)]
+           ("f", ss.FLOAT, False), ("t", ss.BOOL, True), ("s", ss.BOOL, False), ("name", ss.STRING, True), ("day", ss.DATE, False)]
+WORDS = ["", "a", "ab", "abc", "b", "ba", "zebra", "Zebra", "alpha", "beta", "gamma", "delta", "x y", "x", "xyz"]
 INTS = [c for c in COLUMNS if c[1] in (ss.INT64, ss.INT32, ss.UINT32, ss.UINT64)]
 FLOATS = [c for c in COLUMNS if c[1] in (ss.DOUBLE, ss.FLOAT)]
 BOOLS = [c for c in COLUMNS if c[1] == ss.BOOL]
@@ -30,7 +31,8 @@ def make_view(n, seed):
         "k1": rng.integers(-100, 100, n).astype(np.int32), "k2": rng.integers(0, 7, n).astype(np.int32),
         "u": rng.integers(0, 1 << 32, n).astype(np.uint32), "w": rng.integers(0, 1 << 63, n).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64),
         "d0": rng.integers(-4000, 4000, n) * 0.25, "d1": rng.integers(-64, 64, n).astype(np.float64),
-        "f": (rng.integers(-64, 64, n) * 0.5).astype(np.float32), "t": rng.integers(0, 2, n).astype(bool), "s": rng.integers(0, 2, n).astype(bool)}
+        "f": (rng.integers(-64, 64, n) * 0.5).astype(np.float32), "t": rng.integers(0, 2, n).astype(bool), "s": rng.integers(0, 2, n).astype(bool),
+        "name": np.array([WORDS[i] for i in rng.integers(0, len(WORDS), n)], dtype=object), "day": rng.integers(-400, 400, n).astype(np.int32)}
     schema = ss.TupleSchema([ss.Attribute(name, t, ss.NULLABLE if nl else ss.NOT_NULLABLE) for (name, t, nl) in COLUMNS])
     return ss.View(schema, [ss.Column(data[name], nulls(nl)) for (name, _t, nl) in COLUMNS])
 
@@ -135,6 +137,16 @@ class Gen(object):
         if choice == 6:
             return self.pick([ss.IsOdd, ss.IsEven])(self.integer(depth - 1))
         if choice == 7:
+            r = self.rng.random()
+            if r < 0.3:     # STRING comparisons run on order-preserving dictionary codes
+                cmp = self.pick([ss.Less, ss.LessOrEqual, ss.Greater, ss.GreaterOrEqual, ss.Equal, ss.NotEqual])
+                return cmp(NA("name"), ss.ConstString(self.pick(WORDS + ["aa", "zz"])))
+            if r < 0.45:
+                return ss.In(NA("name"), [ss.ConstString(self.pick(WORDS + ["nope"])) for _ in range(int(self.rng.integers(1, 4)))])
+            if r < 0.6:     # DATE against DATE, and DATETIME through the explicit cast
+                if self.rng.random() < 0.5:
+                    return self.pick([ss.Less, ss.GreaterOrEqual, ss.Equal])(NA("day"), ss.ConstDate(int(self.rng.integers(-400, 400))))
+                return ss.Less(ss.CastTo(ss.DATETIME, NA("day")), ss.ConstDateTime(int(self.rng.integers(-400, 400)) * 86400000000 + 5))
             return ss.In(self.integer(depth - 1), [self.const_int() for _ in range(int(self.rng.integers(1, 5)))])
         return ss.If(self.boolean(depth - 1), self.boolean(depth - 1), self.boolean(depth - 1))
 
@@ -153,8 +165,12 @@ class Gen(object):
         return ss.Compute(e, child)
 
     def aggregate_plan(self, view, grouped):
-        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s"))
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("name")).Add(NA("day"))
         spec = ss.AggregationSpecification()
+        if self.rng.random() < 0.4:
+            spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST]), "name", "rname")
+        if self.rng.random() < 0.3:
+            spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.FIRST, ss.LAST]), "day", "rday")
         for i in range(int(self.rng.integers(1, 7))):
             name = "x%d" % i
             kind = int(self.rng.integers(0, 4))
@@ -178,18 +194,20 @@ class Gen(object):
         child = ss.Compute(e, child)
         if grouped:
             # [k1], [a], [k1, k2] ... do not pack into one 64-bit key word: the sort-based fallback
-            keys = self.pick([["k2"], ["k2", "s"], ["s"], ["k1"], ["k1", "k2"], ["a"], ["a", "k1", "s"]])
+            keys = self.pick([["k2"], ["k2", "s"], ["s"], ["k1"], ["k1", "k2"], ["a"], ["a", "k1", "s"], ["name"], ["day", "s"], ["name", "k2"]])
+            if "name" in keys:     # an aggregate's output may not reuse a key's name
+                spec.elements = [x for x in spec.elements if x[-1] != "rname"] or spec.elements
             return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child)
         return ss.ScalarAggregate(spec, child)
 
     def sort_plan(self, view):
-        e = ss.CompoundExpression().Add(NA("b")).Add(NA("k1")).Add(NA("d0")).Add(NA("t")).Add(NA("u"))
+        e = ss.CompoundExpression().Add(NA("b")).Add(NA("k1")).Add(NA("d0")).Add(NA("t")).Add(NA("u")).Add(NA("name")).Add(NA("day"))
         for i in range(int(self.rng.integers(0, 3))):
             e.AddAs("e%d" % i, self.any_expr(int(self.rng.integers(1, 4))))
         child = ss.ScanView(view)
         if self.rng.random() < 0.5:
             child = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), child)
-        names = ["b", "k1", "d0", "t", "u"]
+        names = ["b", "k1", "d0", "t", "u", "name", "day"]
         order = ss.SortOrder()
         for k in self.rng.permutation(len(names))[: int(self.rng.integers(1, 4))]:
             order.add(names[int(k)], self.pick([ss.ASCENDING, ss.DESCENDING]))
