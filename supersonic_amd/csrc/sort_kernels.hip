@@ -34,8 +34,10 @@ __device__ __forceinline__ u64 order_key(const void* col, u32 width, int kind, u
   else k = reinterpret_cast<const u8*>(col)[row];
   switch (kind) {
     case 1: k = width == 8 ? (k ^ 0x8000000000000000ull) : (u64)((u32)k ^ 0x80000000u); break;
-    case 2: { u32 b = (u32)k; b = (b & 0x80000000u) ? ~b : (b | 0x80000000u); k = b; } break;
-    case 3: k = (k & 0x8000000000000000ull) ? ~k : (k | 0x8000000000000000ull); break;
+    // -0.0 compares equal to +0.0 (ThreeWayCompare, types_infrastructure.h:238-246): one key for both, so
+    // that the stable sort leaves their relative order alone, as the reference's comparison sort does
+    case 2: { u32 b = (u32)k; if (b == 0x80000000u) b = 0u; b = (b & 0x80000000u) ? ~b : (b | 0x80000000u); k = b; } break;
+    case 3: if (k == 0x8000000000000000ull) k = 0ull; k = (k & 0x8000000000000000ull) ? ~k : (k | 0x8000000000000000ull); break;
     default: break;
   }
   return k;

@@ -689,3 +689,18 @@ def test_device_sharded_group_aggregate_single_rank(n, with_filter):
                           context="device sharded group aggregate")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_negative_zero_ties_keep_their_order(gpu_ctx, descending):
+    # -0.0 and +0.0 compare equal in the reference (ThreeWayCompare): a stable sort must not separate them
+    rng = np.random.default_rng(12)
+    n = 20011
+    pool = np.array([-0.0, 0.0, -1.5, 2.25, 0.0, -0.0, 7.0])
+    d = pool[rng.integers(0, len(pool), n)]
+    f = d.astype(np.float32)
+    schema = ss.TupleSchema([ss.Attribute("d", ss.DOUBLE), ss.Attribute("f", ss.FLOAT, ss.NULLABLE), ss.Attribute("id", ss.INT64)])
+    view = ss.View(schema, [d, ss.Column(f, rng.random(n) < 0.05), np.arange(n)])
+    order = ss.DESCENDING if descending else ss.ASCENDING
+    run_both(ss.Sort(ss.SortOrder().add("d", order), None, 0, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.Sort(ss.SortOrder().add("f", order), None, 0, ss.ScanView(view)), gpu_ctx)
