@@ -6,8 +6,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $REPO/bench.py --steps 20 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $R -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
+python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $R -- python $REPO/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
 done
