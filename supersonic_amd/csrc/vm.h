@@ -32,6 +32,9 @@
 #ifndef VM_WAVES_PER_EU
 #define VM_WAVES_PER_EU 4   /* occupancy target of the pipeline kernel (sets its VGPR budget) */
 #endif
+#ifndef VM_STAGE_PRIO
+#define VM_STAGE_PRIO 1     /* s_setprio level of a wave while it stages a tile (0 = same as the program) */
+#endif
 #define VM_COMPUTE_THREADS VM_THREADS
 #define VM_WG_THREADS VM_THREADS
 #define VM_WAVES (VM_THREADS / 64)       /* waves per workgroup */
