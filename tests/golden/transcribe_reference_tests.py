@@ -21,6 +21,7 @@ import json
 import os
 
 I32, I64, U32, U64, F32, F64, BOOL, DATE, STR = "INT32", "INT64", "UINT32", "UINT64", "FLOAT", "DOUBLE", "BOOL", "DATE", "STRING"
+DATETIME, BINARY = "DATETIME", "BINARY"
 INF, NAN = "inf", "nan"
 CASES = []
 
@@ -284,6 +285,76 @@ op_case("Group_TwoColumnsMultipleAggregations", GT + ":403-429", cols([I32, I32,
          [["SUM", "col2", "sum"], ["MIN", "col2", "min"], ["COUNT", "", "count"]], "INPUT"],
         [I32, I32, I32, I32, U64], [[2, 1, 7, 3, 2], [1, 2, -3, -3, 1], [1, 3, -5, -5, 1]], ordered=False)
 
+EMPTYP = ["CompoundSingleSourceProjector"]
+op_case("Group_CountWithNullableInputColumn", GT + ":135-149", cols([I32]), [[1], [None]],
+        ["GroupAggregate", EMPTYP, [["COUNT", "col0", "count"]], "INPUT"], [U64], [[1]], exp_nullable=[False])
+op_case("Group_CountAll", GT + ":151-165", cols([I32]), [[1], [None]],
+        ["GroupAggregate", EMPTYP, [["COUNT", "", "count"]], "INPUT"], [U64], [[2]], exp_nullable=[False])
+op_case("Group_AggregationWithOnlyNullInputs", GT + ":167-180", cols([I32]), [[None], [None]],
+        ["GroupAggregate", EMPTYP, [["SUM", "col0", "sum"]], "INPUT"], [I32], [[None]])
+op_case("Group_OutputTypeDifferentFromInputType", GT + ":182-197", cols([I32]), [[1], [3]],
+        ["GroupAggregate", EMPTYP, [["SUM", "col0", "sum", I64]], "INPUT"], [I64], [[4]], exp_names=["sum"], exp_nullable=[True])
+op_case("Group_MultipleAggregations", GT + ":199-218", cols([I32]), [[1], [2], [3]],
+        ["GroupAggregate", EMPTYP, [["SUM", "col0", "sum"], ["MAX", "col0", "max"], ["MIN", "col0", "min"]], "INPUT"],
+        [I32, I32, I32], [[6, 3, 1]], exp_names=["sum", "max", "min"])
+op_case("Group_GroupByWithoutAggregateFunctions_string", GT + ":430-447", cols([STR]), [["foo"], ["bar"], ["foo"], ["bar"]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [], "INPUT"], [STR], [["foo"], ["bar"]], ordered=False)
+# a GroupAggregate without key columns returns NO row for an empty input (a ScalarAggregate returns one)
+op_case("Group_AggregationOnEmptyInput", GT + ":449-460", cols([DATETIME]), [],
+        ["GroupAggregate", EMPTYP, [["MIN", "col0", "min"]], "INPUT"], [DATETIME], [])
+op_case("Group_AggregationOnEmptyInputWithGroupByColumn_string", GT + ":462-475", cols([STR, DATETIME]), [],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["MIN", "col1", "min"]], "INPUT"], [STR, DATETIME], [])
+op_case("Group_CountOnEmptyInput", GT + ":477-488", cols([DATETIME]), [],
+        ["GroupAggregate", EMPTYP, [["COUNT", "col0", "count"]], "INPUT"], [U64], [])
+op_case("Group_CountOnEmptyInputWithGroupByColumn_string", GT + ":490-503", cols([STR, DATETIME]), [],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["COUNT", "col1", "count"]], "INPUT"], [STR, U64], [])
+op_case("Group_AggregationInputColumnMissingError", GT + ":505-513", cols([I32]), [],
+        ["GroupAggregate", EMPTYP, [["SUM", "NotExistingCol", "sum"]], "INPUT"], None, [], expect_error=403)
+op_case("Group_AggregationResultColumnExistsError", GT + ":515-525", cols([I32, I32]), [],
+        ["GroupAggregate", EMPTYP, [["SUM", "col0", "result_col"], ["MIN", "col1", "result_col"]], "INPUT"], None, [], expect_error=404)
+op_case("Group_NoGroupByColumns", GT + ":702-727", cols([I32]), [[1], [1], [3], [3], [2], [3], [1]],
+        ["GroupAggregate", EMPTYP, [["SUM", "col0", "sum"], ["COUNT", "col0", "cnt"]], "INPUT"], [I32, U64], [[14, 7]])
+
+# ---- ColumnAggregator unit tests (supersonic/cursor/core/column_aggregator_test.cc), restated as GroupAggregate:
+# the test's result_index[] (which result row every input row updates) becomes the group key column "g"
+CA = "supersonic/cursor/core/column_aggregator_test.cc"
+
+
+def by_index(index_lists, value_lists):
+    return [[g, v] for idx, vals in zip(index_lists, value_lists) for g, v in zip(idx, vals)]
+
+
+IDX = [0, 1, 2, 3]
+op_case("ColumnAggregator_ComputeSimpleAggregation", CA + ":60-81", [["g", I32, False], ["v", I64, False]],
+        by_index([IDX, IDX], [[-5, 0, 4, 4], [-2, 3, 1, -1]]),
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["MIN", "v", "r"]], "INPUT"], [I32, I64],
+        [[0, -5], [1, 0], [2, 1], [3, -1]], ordered=False)
+op_case("ColumnAggregator_SumInt32StoredAsInt64", CA + ":83-117", [["g", I32, False], ["v", I32, True]],
+        by_index([IDX, IDX], [[-5, 0, 4, 4], [-2, 3, 1, -1]]),
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["SUM", "v", "r", I64]], "INPUT"], [I32, I64],
+        [[0, -7], [1, 3], [2, 5], [3, 3]], ordered=False)
+op_case("ColumnAggregator_SumUint32StoredAsInt64", CA + ":119-145", [["g", I32, False], ["v", U32, True]],
+        by_index([IDX, IDX], [[2, 3, 1, 4294967295], [5, 0, 4, 4]]),
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["SUM", "v", "r", I64]], "INPUT"], [I32, I64],
+        [[0, 7], [1, 3], [2, 5], [3, 4294967299]], ordered=False)
+op_case("ColumnAggregator_ComputeAggregationOfValuesWithNulls", CA + ":147-186", [["g", I32, False], ["v", I32, True]],
+        by_index([IDX, IDX], [[-2, None, 1, None], [None, None, 4, 4]]),
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["SUM", "v", "r"]], "INPUT"], [I32, I32],
+        [[0, -2], [1, None], [2, 5], [3, 4]], ordered=False)
+op_case("ColumnAggregator_ResultIndexRespected", CA + ":216-234", [["g", I32, False], ["v", I32, True]],
+        by_index([[2, 2, 2, 2]], [[1, 1, 1, 1]]),
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["SUM", "v", "r"]], "INPUT"], [I32, I32], [[2, 4]], ordered=False)
+op_case("ColumnAggregator_ComputeCount", CA + ":236-252", cols([I64]), [[-5], [0], [4], [4]],
+        ["ScalarAggregate", [["COUNT", "col0", "r", I64]], "INPUT"], [I64], [[4]], exp_nullable=[False])
+op_case("ColumnAggregator_ComputeCountWithoutInputColumn", CA + ":254-267", cols([I64]), [[-5], [0], [4], [4]],
+        ["ScalarAggregate", [["COUNT", "", "r", I64]], "INPUT"], [I64], [[4]], exp_nullable=[False])
+op_case("ColumnAggregator_ComputeCountOfValuesWithNulls", CA + ":269-290", cols([I32]), [[None], [0], [None], [4]],
+        ["ScalarAggregate", [["COUNT", "col0", "r", I32]], "INPUT"], [I32], [[2]], exp_nullable=[False])
+op_case("ColumnAggregator_NotSupportedAggregationDetected_string", CA + ":518-526", cols([STR]), [],
+        ["ScalarAggregate", [["SUM", "col0", "r"]], "INPUT"], None, [], expect_error=405)
+op_case("ColumnAggregator_NotSupportedCountOutputTypeDetected", CA + ":528-534", cols([I32]), [],
+        ["ScalarAggregate", [["COUNT", "col0", "r", DATETIME]], "INPUT"], None, [], expect_error=405)
+
 # ---- AggregateClusters (supersonic/cursor/core/aggregate_clusters_test.cc:28-150) ---------------
 CL = "supersonic/cursor/core/aggregate_clusters_test.cc"
 cl_rows = [[0, 13], [2, 4], [2, 5], [2, -4], [2, -6], [1, 3], [1, 4], [1, -3]]
@@ -294,6 +365,38 @@ op_case("Clusters_WithoutClusteredColumn", CL + ":105-121", cols([I32]), [[13], 
         ["AggregateClusters", ["CompoundSingleSourceProjector"], [["SUM", "col0", "sum"]], "INPUT"], [I32], [[23]])
 op_case("Clusters_EmptyInputWithClusteredColumn", CL + ":123-134", cols([I64, I32]), [],
         ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"], [I64, I32], [])
+
+op_case("Clusters_EmptyInputWithoutClusteredColumn_string", CL + ":139-150", cols([STR]), [],
+        ["AggregateClusters", ["CompoundSingleSourceProjector"], [["MAX", "col0", "max"]], "INPUT"], [STR], [])
+op_case("Clusters_MultiColumnAggregateClusters_string", CL + ":152-183", cols([STR, I32, STR, I32]),
+        [["a", 0, "a", 13], ["a", 2, "a", 4], ["a", 2, "a", 5], ["a", 2, "b", -4], ["a", 2, "b", -6], ["a", 1, "b", 3], ["a", 1, "b", 4],
+         ["a", 1, "bbbbbbbb", -3]],
+        ["AggregateClusters", ["Compound", ["ProjectNamedAttributeAs", "col0", "A"], ["ProjectNamedAttributeAs", "col1", "B"],
+                               ["ProjectNamedAttributeAs", "col2", "C"]],
+         [["SUM", "col1", "sum1"], ["SUM", "col3", "sum3"]], "INPUT"],
+        [STR, I32, STR, I32, I32], [["a", 0, "a", 0, 13], ["a", 2, "a", 4, 9], ["a", 2, "b", 4, -10], ["a", 1, "b", 2, 7], ["a", 1, "bbbbbbbb", 1, -3]],
+        exp_names=["A", "B", "C", "sum1", "sum3"])
+op_case("Clusters_BadGroupBy", CL + ":185-199", cols([I32]), [[13], [3], [7]],
+        ["AggregateClusters", ["ProjectNamedAttributeAs", "col1", "B"], [["MIN", "col0", "min"]], "INPUT"], None, [], expect_error=403)
+op_case("Clusters_ResultingColumnsNamesConflict", CL + ":221-232", cols([I32, I32]), [],
+        ["AggregateClusters", ["ProjectNamedAttributeAs", "col0", "A"], [["SUM", "col1", "A"]], "INPUT"], None, [], expect_error=404)
+
+# ---- ScalarAggregate on strings (aggregate_scalar_test.cc:37-51,91-104; the DISTINCT column is left out) ----
+op_case("ScalarAggregate_AggregateStrings_string", ST + ":33-45,91-104", cols([STR]),
+        [["f"], ["c"], ["a"], ["b"], ["g"], ["a"], ["d"], ["a"], [None], ["e"]],
+        ["ScalarAggregate", [["MAX", "col0", "max"], ["COUNT", "", "count(*)"], ["COUNT", "col0", "count"]], "INPUT"],
+        [STR, U64, U64], [["g", 10, 9]])
+
+# ---- Project (supersonic/cursor/core/project_test.cc) ----------------------------------------------
+PT = "supersonic/cursor/core/project_test.cc"
+op_case("Project_FirstColumnFromInput_string", PT + ":34-45", cols([I32, STR]), [[1, "foo"], [3, "bar"]],
+        ["Project", ["ProjectNamedAttribute", "col0"], "INPUT"], [I32], [[1], [3]])
+op_case("Project_SecondColumnFromInput_string", PT + ":47-58", cols([I32, STR]), [[1, "foo"], [3, "bar"]],
+        ["Project", ["ProjectNamedAttribute", "col1"], "INPUT"], [STR], [["foo"], ["bar"]])
+op_case("Project_EmptyInput_string", PT + ":60-65", cols([I32, STR]), [],
+        ["Project", ["ProjectNamedAttribute", "col1"], "INPUT"], [STR], [])
+op_case("Project_InvalidProjectorSpecification_string", PT + ":79-88", cols([I32, STR]), [[1, "foo"], [3, "bar"]],
+        ["Project", ["ProjectNamedAttribute", "incorrect_name"], "INPUT"], None, [], expect_error=403)
 
 # ---- Sort (supersonic/cursor/core/sort_test.cc:121-330; letters -> INT64 codes a=1, b=2, ...) ---
 SO = "supersonic/cursor/core/sort_test.cc"
@@ -335,6 +438,22 @@ op_case("Sort_TwoColumnsFirstMixed", SO + ":299-328", cols([I32, I64]),
         srows([(3, "z"), (None, "v"), (2, "z"), (3, None), (None, "w"), (3, "x"), (1, "x"), (None, "y")]),
         ["Sort", [["col0", "ASCENDING"], ["col1", "ASCENDING"]], None, "INPUT"], [I32, I64],
         srows([(None, "v"), (None, "w"), (None, "y"), (1, "x"), (2, "z"), (3, None), (3, "x"), (3, "z")]))
+
+mixed = [(3, "z"), (None, "v"), (2, "z"), (3, None), (None, "w"), (3, "x"), (1, "x"), (None, "y")]
+op_case("Sort_TwoColumnsFirstMixedDescending", SO + ":331-360", cols([I32, I64]), srows(mixed),
+        ["Sort", [["col0", "DESCENDING"], ["col1", "DESCENDING"]], None, "INPUT"], [I32, I64],
+        srows([(3, "z"), (3, "x"), (3, None), (2, "z"), (1, "x"), (None, "y"), (None, "w"), (None, "v")]))
+op_case("Sort_TwoColumnsFirstMixed_string", SO + ":299-328", cols([I32, STR]), [list(r) for r in mixed],
+        ["Sort", [["col0", "ASCENDING"], ["col1", "ASCENDING"]], None, "INPUT"], [I32, STR],
+        [[None, "v"], [None, "w"], [None, "y"], [1, "x"], [2, "z"], [3, None], [3, "x"], [3, "z"]])
+op_case("Sort_TwoColumnsFirstMixedDescending_string", SO + ":331-360", cols([I32, STR]), [list(r) for r in mixed],
+        ["Sort", [["col0", "DESCENDING"], ["col1", "DESCENDING"]], None, "INPUT"], [I32, STR],
+        [[3, "z"], [3, "x"], [3, None], [2, "z"], [1, "x"], [None, "y"], [None, "w"], [None, "v"]])
+# the sort key (position 2, DESCENDING) is not part of the result projection (position 1)
+op_case("Sort_Projections", SO + ":362-381", cols([I32, I32, I32]), [[3, 105, 210], [6, 111, 201], [2, 102, 203], [3, 104, 205]],
+        ["Sort", [["col2", "DESCENDING"]], ["ProjectAttributeAt", 1], "INPUT"], [I32], [[105], [104], [102], [111]])
+op_case("Filter_FilterOnDropped_string", "supersonic/cursor/core/filter_test.cc:316-329", cols([I32, STR]), [[1, "A"], [3, "B"]],
+        ["Filter", ["Equal", ["NamedAttribute", "col1"], ["ConstString", "A"]], ["ProjectNamedAttribute", "col0"], "INPUT"], [I32], [[1]])
 
 def bind_plan_case(name, source, expr, in_types, in_nullable, out_name, out_type, out_nullable, expect_error=None):
     n_in = len(in_types)

@@ -79,6 +79,11 @@ def build_projector(p):
     if p is None:
         return None
     head, args = p[0], p[1:]
+    if head == "Compound":      # (new CompoundSingleSourceProjector)->add(p1)->add(p2)...
+        c = ss.CompoundSingleSourceProjector()
+        for a in args:
+            c.add(build_projector(a))
+        return c
     return getattr(ss, head)(*args)
 
 
