@@ -119,6 +119,76 @@ expr_plan_case("StandardCast_uint64_to_uint32", "supersonic/expression/templated
                ["CastToType", "UINT32", ["AttributeAt", 0]], "UINT32",
                [[1234, 1234], [18446744073709551615, 4294967295], [0, 0]], nullable=False)
 
+expr_plan_case("ProjectingCast_int32_to_uint32", "supersonic/expression/templated/cast_expression_test.cc:289-294", [I32],
+               ["CastToType", "UINT32", ["AttributeAt", 0]], "UINT32", [[1, 1], [13, 13], [-1, 4294967295]], nullable=False)
+expr_plan_case("ProjectingCast_uint64_to_int64", "supersonic/expression/templated/cast_expression_test.cc:296-300", [U64],
+               ["CastToType", "INT64", ["AttributeAt", 0]], "INT64", [[1, 1], [18446744073709551597, -19], [1234567, 1234567]], nullable=False)
+expr_plan_case("NoOpCast_double", "supersonic/expression/templated/cast_expression_test.cc:303-309", [F64],
+               ["CastToType", "DOUBLE", ["AttributeAt", 0]], "DOUBLE", [[3.14, 3.14], [1.41, 1.41], [9.81, 9.81], [2.71, 2.71]], nullable=False)
+# ---- projecting_expressions_test.cc:60-183 over the fixture block (STRING, INT32, DOUBLE, INT32) -----------------
+PE = "supersonic/expression/core/projecting_expressions_test.cc"
+PROWS = [["1", 12, 5.1, 22], ["2", 13, 6.2, 23], ["3", 14, 7.3, 24], ["4", None, 8.4, 25], [None, 16, None, 26]]
+PTYPES = [STR, I32, F64, I32]
+for i in range(4):
+    CASES.append({"name": "Projecting_AttributeAtSelects_%d_string" % i, "source": PE + ":75-83", "kind": "expression",
+                  "input": {"schema": cols(PTYPES), "rows": PROWS}, "plan": ["Compute", ["AttributeAt", i], "INPUT"],
+                  "expected": {"types": [PTYPES[i]], "rows": [[r[i]] for r in PROWS], "names": ["col%d" % i], "nullable": [True]},
+                  "ordered": True, "expect_error": None})
+    CASES.append({"name": "Projecting_NamedAttributeSelects_%d_string" % i, "source": PE + ":85-93", "kind": "expression",
+                  "input": {"schema": cols(PTYPES), "rows": PROWS}, "plan": ["Compute", ["NamedAttribute", "col%d" % i], "INPUT"],
+                  "expected": {"types": [PTYPES[i]], "rows": [[r[i]] for r in PROWS], "names": ["col%d" % i], "nullable": [True]},
+                  "ordered": True, "expect_error": None})
+CASES.append({"name": "Projecting_Flat_string", "source": PE + ":156-165", "kind": "expression",
+              "input": {"schema": cols(PTYPES), "rows": PROWS},
+              "plan": ["Compute", ["CompoundExpression", ["Add", ["AttributeAt", 0]], ["Add", ["AttributeAt", 3]]], "INPUT"],
+              "expected": {"types": [STR, I32], "rows": [[r[0], r[3]] for r in PROWS], "names": ["col0", "col3"], "nullable": [True, True]},
+              "ordered": True, "expect_error": None})
+CASES.append({"name": "Projecting_Alias_string", "source": PE + ":174-183", "kind": "expression",
+              "input": {"schema": cols(PTYPES), "rows": PROWS}, "plan": ["Compute", ["Alias", "Some alias", ["AttributeAt", 0]], "INPUT"],
+              "expected": {"types": [STR], "rows": [[r[0]] for r in PROWS], "names": ["Some alias"], "nullable": [True]},
+              "ordered": True, "expect_error": None})
+CASES.append({"name": "Projecting_AliasFailsOnTooManyColumns_string", "source": PE + ":185-193", "kind": "binding",
+              "input": {"schema": cols(PTYPES), "rows": []},
+              "plan": ["Compute", ["Alias", "Some other alias", ["CompoundExpression", ["Add", ["AttributeAt", 0]], ["Add", ["AttributeAt", 1]]]], "INPUT"],
+              "expected": {"types": None, "rows": [], "names": None, "nullable": None}, "ordered": True, "expect_error": 401})
+
+# ---- vector_logic_test.cc:46-83: left[i] = (i % 3 == 0), right[i] = (i % 5 == 0) ----------------------------
+VL = "supersonic/expression/vector/vector_logic_test.cc"
+expr_case("VectorLogic_Or", VL + ":46-54", [BOOL, BOOL, BOOL], [[i % 3 == 0, i % 5 == 0, i % 3 == 0 or i % 5 == 0] for i in range(200)], "Or", nullable=False)
+expr_case("VectorLogic_And", VL + ":56-63", [BOOL, BOOL, BOOL], [[i % 3 == 0, i % 5 == 0, i % 15 == 0] for i in range(150)], "And", nullable=False)
+expr_case("VectorLogic_AndNot", VL + ":65-73", [BOOL, BOOL, BOOL], [[i % 3 == 0, i % 5 == 0, i % 3 != 0 and i % 5 == 0] for i in range(170)], "AndNot",
+          nullable=False)
+expr_case("VectorLogic_Not", VL + ":75-83", [BOOL, BOOL], [[i % 3 == 0, i % 3 != 0] for i in range(120)], "Not", nullable=False)
+
+# The TestCastBinding<from, to, is_implicit>(success) matrix (cast_expression_test.cc:63-287), the entries with
+# is_implicit == false (CastTo is the explicit cast; implicit ones only arise inside promotions).  Targets of
+# type BINARY / DATA_TYPE are outside the path and left out.
+CX = "supersonic/expression/templated/cast_expression_test.cc"
+EXPLICIT_CASTS = [
+    (U32, I32, True, ":80-95"), (U32, U32, True, ":80-95"), (U32, I64, True, ":80-95"), (U32, U64, True, ":80-95"), (U32, F32, True, ":80-95"),
+    (U32, F64, True, ":80-95"), (U32, DATE, False, ":80-95"), (U32, DATETIME, False, ":80-95"), (U32, STR, False, ":80-95"), (U32, BOOL, False, ":80-95"),
+    (I64, I32, True, ":97-121"), (I64, U32, True, ":97-121"), (I64, F32, True, ":97-121"), (I64, U64, True, ":97-121"), (I64, DATE, False, ":97-121"),
+    (I64, DATETIME, False, ":97-121"), (I64, STR, False, ":97-121"), (I64, BOOL, False, ":97-121"),
+    (U64, I32, True, ":123-147"), (U64, U32, True, ":123-147"), (U64, F32, True, ":123-147"), (U64, U64, True, ":123-147"), (U64, I64, True, ":123-147"),
+    (F32, I32, False, ":149-172"), (F32, U32, False, ":149-172"), (F32, I64, False, ":149-172"), (F32, U64, False, ":149-172"), (F32, F64, True, ":149-172"),
+    (F32, F32, True, ":149-172"),
+    (F64, U32, False, ":174-193"), (F64, U64, False, ":174-193"), (F64, F32, True, ":174-193"),
+    (DATE, DATE, True, ":195-213"), (DATE, DATETIME, True, ":195-213"), (DATE, I32, False, ":195-213"), (DATE, U32, False, ":195-213"),
+    (DATE, I64, False, ":195-213"), (DATE, U64, False, ":195-213"), (DATE, F32, False, ":195-213"), (DATE, F64, False, ":195-213"),
+    (DATE, STR, False, ":195-213"), (DATE, BOOL, False, ":195-213"),
+    (DATETIME, DATETIME, True, ":215-231"), (BOOL, BOOL, True, ":233-249"), (STR, STR, True, ":251-269"),
+    (STR, I32, False, ":251-269"), (STR, U32, False, ":251-269"), (STR, I64, False, ":251-269"), (STR, U64, False, ":251-269"), (STR, F32, False, ":251-269"),
+    (STR, F64, False, ":251-269"), (STR, DATE, False, ":251-269"), (STR, DATETIME, False, ":251-269"), (STR, BOOL, False, ":251-269"),
+]
+for (frm, to, ok, lines) in EXPLICIT_CASTS:
+    CASES.append({
+        "name": "CastBinding_%s_to_%s" % (frm, to), "source": CX + lines, "kind": "binding",
+        "input": {"schema": [["$0", frm, False]], "rows": []},
+        "plan": ["Compute", ["CastToType", to, ["AttributeAt", 0]], "INPUT"],
+        "expected": {"types": [to] if ok else None, "rows": [],
+                     "names": [("$0" if frm == to else "CAST_%s_TO_%s($0)" % (frm, to))] if ok else None, "nullable": [False] if ok else None},
+        "ordered": True, "expect_error": None if ok else 402})
+
 # ---- arithmetic (arithmetic_expressions_test.cc) ---------------------------------------------
 bind_case("NegateBinding_double", A + ":25-27", "Negate", [F64], [False], "(-$0)", F64, False)
 bind_case("NegateBinding_int32", A + ":25-28", "Negate", [I32], [False], "(-$0)", I32, False)
