@@ -130,7 +130,10 @@ enum {
  * factory functions (comparison_expressions.h): expressed with these pseudo
  * ids; the binder rewrites them exactly as the reference does
  * (comparison_bound_expressions.cc:832-848: a > b  ==  Less(b, a)). */
-enum { SSGPU_OP_GREATER = 100001, SSGPU_OP_GREATER_OR_EQUAL = 100002 };
+enum { SSGPU_OP_GREATER = 100001, SSGPU_OP_GREATER_OR_EQUAL = 100002,
+       /* NullingIf(cond, then, otherwise) (elementary_expressions.h:55-61): OPERATOR_IF whose NULL condition
+        * gives a NULL result instead of taking the OTHERWISE branch */
+       SSGPU_OP_NULLING_IF = 100003 };
 
 typedef struct ssgpu_expr {
   int32_t kind;      /* SSGPU_EXPR_* */

@@ -234,6 +234,7 @@ inline const Expression* In(const Expression* needle, ExpressionList* haystack) 
   return e;
 }
 inline const Expression* If(const Expression* c, const Expression* t, const Expression* e) { return internal::Op(204, c, t, e); }
+inline const Expression* NullingIf(const Expression* c, const Expression* t, const Expression* e) { return internal::Op(SSGPU_OP_NULLING_IF, c, t, e); }
 inline const Expression* IfNull(const Expression* a, const Expression* b) { return internal::Op(220, a, b); }
 inline const Expression* IsNull(const Expression* a) { return internal::Op(224, a); }
 inline const Expression* CastTo(DataType t, const Expression* a) { Expression* e = internal::Node(SSGPU_EXPR_CAST, 0, t); e->args.emplace_back(a); return e; }

@@ -50,7 +50,7 @@ enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DI
        OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
        OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
        OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
-       OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002 };
+       OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002, OP_NULLING_IF = 100003 };
 
 typedef struct { int code; char msg[512]; } orc_error;
 static void set_err(orc_error* e, int code, const char* fmt, const char* a, const char* b) {
@@ -557,14 +557,15 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       bnode* b = bnode_new(B_OP, op, t, r->nullable, nm); b->args[0] = l; b->args[1] = r; b->nargs = 2;
       return b;
     }
-    case OP_IF: {
+    case OP_IF: case OP_NULLING_IF: {
       /* BoundIfInternal, elementary_bound_expressions.cc:1084-1120 */
       if (a[0]->dtype != T_BOOL) { set_err(err, RC_TYPE_MISMATCH, "Expected BOOL in %s%s", a[0]->name, ""); return NULL; }
       int t = common_type(a[1]->dtype, a[2]->dtype, err); if (err->code) return NULL;
       bnode* x = make_cast(a[1], t, 1, err); bnode* y = make_cast(a[2], t, 1, err); if (err->code) return NULL;
       char nm[256]; snprintf(nm, sizeof(nm), "IF %s THEN %s ELSE %s", a[0]->name, x->name, y->name);
       /* plain IF: nullable iff THEN or OTHERWISE is (CreateIfSchema :1010-1025) */
-      bnode* b = bnode_new(B_OP, op, t, x->nullable || y->nullable, nm);
+      /* NullingIf: the condition's NULLs are viral as well (:1013-1016) */
+      bnode* b = bnode_new(B_OP, op, t, x->nullable || y->nullable || (op == OP_NULLING_IF && a[0]->nullable), nm);
       b->args[0] = a[0]; b->args[1] = x; b->args[2] = y; b->nargs = 3;
       return b;
     }
@@ -813,15 +814,17 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
       }
       b->nulls = y->nulls ? b->nullbuf : NULL; return;
     }
-    case OP_IF: {
+    case OP_IF: case OP_NULLING_IF: {
       bnode* z = b->args[2]; const int w = type_width(b->dtype); const uint8_t* cv = (const uint8_t*)x->data;
+      const int nulling = b->op == OP_NULLING_IF;
       /* non-nulling IF: THEN iff the condition is non-NULL TRUE, otherwise OTHERWISE; NULLs come
        * from the chosen branch only (elementary_bound_expressions.cc:893-1008) */
-      int any = y->nulls || z->nulls;
+      int any = y->nulls || z->nulls || (nulling && x->nulls);
       for (int64_t i = 0; i < n; ++i) {
-        int c = cv[i] != 0 && !(x->nulls && x->nulls[i]); bnode* src = c ? y : z;
+        const int cnull = x->nulls && x->nulls[i];
+        int c = cv[i] != 0 && !cnull; bnode* src = c ? y : z;
         memcpy((char*)b->buf + i * w, (const char*)src->data + i * w, (size_t)w);
-        b->nullbuf[i] = src->nulls ? src->nulls[i] : 0;
+        b->nullbuf[i] = (src->nulls ? src->nulls[i] : 0) || (nulling && cnull);   /* NullingIf: NULL condition, NULL result (:55-61) */
       }
       b->nulls = any ? b->nullbuf : NULL; return;
     }

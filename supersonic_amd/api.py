@@ -472,6 +472,7 @@ def In(needle, haystack):
 
 
 def If(c, t, e): return _op(204, c, t, e)
+def NullingIf(c, t, e): return _op(L.OP_NULLING_IF, c, t, e)   # a NULL condition gives NULL (elementary_expressions.h:55-61)
 def IfNull(a, b): return _op(220, a, b)
 def IsNull(a): return _op(224, a)
 def CastTo(data_type, a): return Expression(L.EXPR_CAST, dtype=data_type, args=[a])

@@ -720,7 +720,7 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
       *out = named;
       return Status::OK();
     }
-    case OP_IF: {
+    case OP_IF: case SSGPU_OP_NULLING_IF: {
       SS_RETURN_IF_ERROR(need(3));
       SS_RETURN_IF_ERROR(check_type(SSGPU_BOOL, args[0]));
       int t; SS_RETURN_IF_ERROR(common_type(args[1]->dtype, args[2]->dtype, &t));
@@ -729,7 +729,8 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
       SS_RETURN_IF_ERROR(make_cast(args[2], t, true, &ec));
       // plain (non-nulling) IF: a NULL condition takes the ELSE branch and does not make the
       // result NULL (elementary_bound_expressions.cc:893-904,1010-1025)
-      *out = make_op(op, t, tc->nullable || ec->nullable,
+      // NullingIf: NULLs of the condition are viral too (CreateIfSchema, :1010-1016)
+      *out = make_op(op, t, tc->nullable || ec->nullable || (op == SSGPU_OP_NULLING_IF && args[0]->nullable),
                      "IF " + args[0]->name + " THEN " + tc->name + " ELSE " + ec->name, {args[0], tc, ec}, depth);
       return Status::OK();
     }

@@ -402,6 +402,11 @@ Status Emitter::value(const BExprP& e, Val* out) {
           if (a[0].null < 0) { v.imm = true; v.bits = 0; } else { v.reg = a[0].null; }
           break;
         case OP_IF_NULL: {  // a NULL ? b : a
+          if (a[0].null < 0) {   // NULLABLE by schema but never NULL (e.g. a CASE whose chain collapsed): the value itself
+            v = a[0];
+            if (v.imm) { v.reg = materialize(v); v.imm = false; }
+            break;
+          }
           const uint16_t sop = v.width == 8 ? VM_SELECT_64 : v.width == 4 ? VM_SELECT_32 : VM_SELECT_8;
           Val x = a[1], y = a[0];
           if (x.imm && y.imm) { x.reg = materialize(x); x.imm = false; }
@@ -414,7 +419,7 @@ Status Emitter::value(const BExprP& e, Val* out) {
             LInstr& j = emit(VM_SELECT_8); j.dst = v.null; j.a = a[1].null; j.b_imm = true; j.imm = 0; j.imm_width = 1; j.c = a[0].null;
           }
         } break;
-        case OP_IF: {
+        case OP_IF: case SSGPU_OP_NULLING_IF: {
           const uint16_t sop = v.width == 8 ? VM_SELECT_64 : v.width == 4 ? VM_SELECT_32 : VM_SELECT_8;
           // choice = condition is non-NULL TRUE; a NULL condition takes the ELSE branch
           int cond = materialize(a[0]);
@@ -435,6 +440,7 @@ Status Emitter::value(const BExprP& e, Val* out) {
             if (a[1].null >= 0) j.a = a[1].null; else { j.a_imm = true; j.imm = 0; j.imm_width = 1; }
             if (a[2].null >= 0) j.b = a[2].null; else { j.b_imm = true; j.imm = 0; j.imm_width = 1; }
           }
+          if (e->op == SSGPU_OP_NULLING_IF) v.null = or_null(v.null, a[0].null);   // a NULL condition is a NULL result
         } break;
         default:
           return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "operator has no device lowering: " + e->name);

@@ -75,7 +75,7 @@ class Gen(object):
         if choice == 4:
             return self.pick([ss.CppDivideNulling, ss.ModulusNulling])(x, y)
         if choice == 5:
-            return ss.If(self.boolean(depth - 1), x, y)
+            return self.pick([ss.If, ss.NullingIf])(self.boolean(depth - 1), x, y)
         if choice == 6:
             return ss.IfNull(x, y)
         if choice == 7:
@@ -110,7 +110,7 @@ class Gen(object):
         if choice == 5:
             return ss.SqrtNulling(x)
         if choice == 6:
-            return ss.If(self.boolean(depth - 1), x, y)
+            return self.pick([ss.If, ss.NullingIf])(self.boolean(depth - 1), x, y)
         if choice == 7:
             return ss.IfNull(x, y)
         if choice == 8:

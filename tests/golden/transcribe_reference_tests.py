@@ -271,6 +271,32 @@ expr_case("IfWithAllNullable", E + ":687-701", [BOOL, I32, I32, I32],
           [[T, 1, 2, 1], [F, 1, 2, 2], [N, 1, 2, 2], [T, N, 2, N], [F, N, 2, 2], [N, N, 2, 2], [T, 1, N, 1], [F, 1, N, N],
            [N, 1, N, N], [T, N, N, N], [F, N, N, N], [N, N, N, N]], "If")
 
+bind_case("BasicNullingIf_binding", E + ":632-635", "NullingIf", [BOOL, I32, I64], [False, False, False],
+          "IF $0 THEN CAST_INT32_TO_INT64($1) ELSE $2", I64, False)
+expr_case("BasicNullingIf", E + ":637-641", [BOOL, I32, I64, I64], [[T, 1, 2, 1], [F, 3, 4, 4], [T, 1, 1, 1]], "NullingIf")
+expr_case("NullingIfWithNullCondition", E + ":651-655", [BOOL, I32, I32, I32], [[F, 1, 2, 2], [N, 1, 2, N], [T, 1, 2, 1]], "NullingIf")
+expr_case("NullingIfWithNullThen", E + ":665-669", [BOOL, DATE, DATE, DATE], [[T, 1, 2, 1], [T, N, 2, N], [F, N, 2, 2]], "NullingIf")
+expr_case("NullingIfWithNullOtherwise", E + ":679-683", [BOOL, BOOL, BOOL, BOOL], [[T, T, F, T], [T, T, N, T], [F, T, N, N]], "NullingIf")
+expr_case("NullingIfWithAllNullable", E + ":703-716", [BOOL, I32, I32, I32],
+          [[T, 1, 2, 1], [F, 1, 2, 2], [N, 1, 2, N], [T, N, 2, N], [F, N, 2, 2], [N, N, 2, N], [T, 1, N, 1], [F, 1, N, N],
+           [N, 1, N, N], [T, N, N, N], [F, N, N, N], [N, N, N, N]], "NullingIf")
+expr_case("XorWithoutNulls", E + ":412-419", [BOOL, BOOL, BOOL], [[T, T, F], [T, F, T], [F, T, T], [F, F, F]], "Xor", nullable=False)
+expr_case("IsNullNotNull_string", E + ":283-293", [STR, BOOL],
+          [["I am", F], ["You are", F], ["He/she/it is", F], ["We are", F], ["You are", F], ["They are", F], ["", F]], "IsNull", nullable=False)
+CASES.append({"name": "Cast_int32_to_double", "source": E + ":96-97", "kind": "binding", "input": {"schema": [["$0", I32, False]], "rows": []},
+              "plan": ["Compute", ["CastToType", "DOUBLE", ["AttributeAt", 0]], "INPUT"],
+              "expected": {"types": [F64], "rows": [], "names": ["CAST_INT32_TO_DOUBLE($0)"], "nullable": [False]}, "ordered": True, "expect_error": None})
+expr_plan_case("Cast_int32_to_double_values", E + ":99-103", [I32], ["CastToType", "DOUBLE", ["AttributeAt", 0]], "DOUBLE",
+               [[1, 1.0], [2, 2.0], [-1, -1.0]], nullable=False)
+# CalculateCommonType (elementary_expressions_test.cc:40-86), observed through IFNULL, which binds both arguments to it
+for (a_, b_, r_, ln) in [(F64, I32, F64, "40-46"), (F64, I64, F64, "40-46"), (F64, U32, F64, "40-46"), (F64, U64, F64, "40-46"), (F64, F32, F64, "40-46"),
+                         (F32, I32, F32, "48-54"), (F32, I64, F64, "48-54"), (F32, U32, F32, "48-54"), (F32, U64, F64, "48-54"), (F32, F64, F64, "48-54"),
+                         (I64, I32, I64, "56-62"), (I64, F32, F64, "56-62"), (I64, U32, I64, "56-62"), (I64, U64, I64, "56-62"), (I64, F64, F64, "56-62"),
+                         (I32, I64, I64, "64-70"), (I32, F32, F32, "64-70"), (I32, U32, I64, "64-70"), (I32, U64, I64, "64-70"), (I32, F64, F64, "64-70"),
+                         (U32, I64, I64, "72-78"), (U32, F32, F32, "72-78"), (U32, I32, I64, "72-78"), (U32, U64, U64, "72-78"), (U32, F64, F64, "72-78"),
+                         (U64, I64, I64, "80-86"), (U64, F32, F64, "80-86"), (U64, I32, I64, "80-86"), (U64, U32, U64, "80-86"), (U64, F64, F64, "80-86")]:
+    bind_case("CommonType_%s_%s" % (a_, b_), E + ":" + ln, "IfNull", [a_, b_], [True, False], None, r_, False)
+
 # ---- the Primer's column add (test/guide/primer.cc:205-221) -----------------------------------
 expr_case("Primer_ColumnAdd", "test/guide/primer.cc:205-221", [I32, I32, I32],
           [[a, b, c] for a, b, c in zip(range(8), [3, 4, 6, 8, 1, 2, 2, 9], [3, 5, 8, 11, 5, 7, 8, 16])], "Plus", nullable=False)

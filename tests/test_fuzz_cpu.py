@@ -1,6 +1,8 @@
 """Binder fuzz (CPU): for seeded random plans the device binder (ssgpu_plan_create on a bind-only
 context) must agree with the oracle's binder on success / failure, the return code of a failure, and the
 result schema (names, types, nullability) -- the reference's Bind() contract, without touching a GPU."""
+import os
+
 import pytest
 
 import supersonic_amd as ss
@@ -8,7 +10,7 @@ from oracle import oracle
 from fuzz_plans import Gen, make_view
 
 
-@pytest.mark.parametrize("seed", range(2000))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SS_FUZZ_SEEDS", "2000"))))
 def test_binder_agrees_with_oracle_on_random_plans(seed):
     view = make_view(3, seed)
     op, _ordered = Gen(seed).plan(view)

@@ -2,6 +2,8 @@
 path, under Compute / Filter / ScalarAggregate / GroupAggregate -- must produce the oracle's result
 bit for bit (fuzz_plans.py keeps to operators whose results are bit-defined).  1537 rows = three full
 512-row tiles and a partial one."""
+import os
+
 import pytest
 
 import supersonic_amd as ss
@@ -12,7 +14,7 @@ from fuzz_plans import Gen, make_view
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(2000))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SS_FUZZ_SEEDS", "2000"))))   # SS_FUZZ_SEEDS=20000 for a longer hunt
 def test_random_plan_matches_oracle(gpu_ctx, seed):
     view = make_view(1537, 1000 + seed)
     op, ordered = Gen(seed).plan(view)
