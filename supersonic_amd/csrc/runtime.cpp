@@ -1090,8 +1090,17 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   HIP_TRY(c, ex.total.ensure(8)); HIP_TRY(c, ex.total2.ensure(16));
   uint64_t* ka = ex.skeys_a.as<uint64_t>(); uint64_t* kb = ex.skeys_b.as<uint64_t>();
   uint32_t* ia = ex.sidx_a.as<uint32_t>(); uint32_t* ib = ex.sidx_b.as<uint32_t>();
+  // The major key's column can be read back from the sorted keys when its transform is a bijection (integer
+  // kinds, no NULLs): no gather for it -- and when it is the ONLY output column, no row ids at all.
+  const SortKey major = st.sort_keys.empty() ? SortKey{0, 0} : st.sort_keys[0];
+  const int major_kind = st.sort_keys.empty() ? 99 : sort_kind_of(st.in_schema[major.col].dtype);
+  const bool major_direct = !st.sort_keys.empty() && major_kind <= 1 && dtype_width(st.in_schema[major.col].dtype) >= 4 &&
+                            !(st.in_schema[major.col].nullable && in.cols[major.col].is_null);
+  bool keys_only = major_direct && st.sort_keys.size() == 1;
+  for (int col : st.sort_out_cols) keys_only = keys_only && col == major.col;
+  if (keys_only) ia = ib = nullptr;
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+  if (!keys_only) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
   auto one_pass = [&](uint32_t shift) -> int {
     HIP_TRY(c, ssgpu_launch_sort_hist(ka, shift, n, ex.shist.as<uint32_t>(), c->stream));
     HIP_TRY(c, ssgpu_launch_scan_counts(ex.shist.as<uint32_t>(), ex.soffs.as<uint32_t>(), (int)(nt * 256), ex.total.as<uint64_t>(), c->stream));
@@ -1129,6 +1138,11 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   }
   for (size_t i = 0; i < st.sort_out_cols.size(); ++i) {
     const int col = st.sort_out_cols[i];
+    if (major_direct && col == major.col && n > 0) {
+      HIP_TRY(c, ssgpu_launch_sort_unkey(ex.out[i].data.p, ka, ex.out[i].width, major_kind, major.order == SSGPU_DESCENDING, n, c->stream));
+      if (ex.out[i].nullable) HIP_TRY(c, hipMemsetAsync(ex.out[i].nulls.p, 0, n, c->stream));
+      continue;
+    }
     HIP_TRY(c, ssgpu_launch_sort_gather(ex.out[i].data.p, ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr,
                                         in.cols[col].data, in.cols[col].is_null, ex.out[i].width, ia, n, c->stream));
   }

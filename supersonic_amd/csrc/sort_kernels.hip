@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void ssgpu_sort_load_keys_kernel(u64* __restri
   for (int j = 0; j < LOAD_KEYS_PER_THREAD; ++j) {
     const u64 i = base + (u64)j * 256u;
     if (i >= n) break;
-    const u64 row = idx[i];
+    const u64 row = idx ? idx[i] : i;   // no row ids: the keys-only sort of a single column
     u64 k;
     if (null_pass) {
       const bool isnull = nulls && nulls[row];
@@ -108,6 +108,9 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_hist_kernel(const u64
 // first reordered by digit INSIDE LDS, then written out: a digit's keys of this tile form one
 // contiguous run in the output (4096 / 256 = 16 keys = 128 B on average), so the global writes
 // are coalesced instead of 64 random 8-byte stores per wave step.
+// HAS_IDX = false: keys only (a single-column sort whose output is the key column itself: no row ids
+// travel with the keys and no gather follows).
+template <bool HAS_IDX>
 __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
     const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
     u32 shift, u64 n, u32 n_tiles, const u32* __restrict__ offsets) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
   __shared__ u32 scanbuf[256];
   __shared__ u32 goff[256];          // global offset of digit d minus its tile-local start
   __shared__ u64 lk[SORT_TILE];
-  __shared__ u32 li[SORT_TILE];
+  __shared__ u32 li[HAS_IDX ? SORT_TILE : 1];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const u64 tile_base = (u64)blockIdx.x * SORT_TILE;
   const u64 wave_base = tile_base + (u64)wave * (SORT_TILE / 4);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
     const u64 i = wave_base + (u64)j * 64 + lane;
     const bool ok = i < n;
     k[j] = ok ? keys_in[i] : ~0ull;
-    id[j] = ok ? idx_in[i] : 0u;
+    id[j] = (HAS_IDX && ok) ? idx_in[i] : 0u;
     if (ok) atomicAdd(&wave_cnt[wave][(k[j] >> shift) & 0xFF], 1u);
   }
   __syncthreads();
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
       const u32 rank = (u32)__popcll(peers & lt);
       const u32 pos = wave_cnt[wave][d] + rank;
       lk[pos] = k[j];
-      li[pos] = id[j];
+      if (HAS_IDX) li[pos] = id[j];
     }
     // one lane per digit group advances the running counter (after every lane has read it)
     __builtin_amdgcn_wave_barrier();
@@ -183,9 +186,23 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
       const u64 key = lk[e];
       const u32 pos = goff[(u32)(key >> shift) & 0xFF] + e;
       keys_out[pos] = key;
-      idx_out[pos] = li[e];
+      if (HAS_IDX) idx_out[pos] = li[e];
     }
   }
+}
+
+// The sorted keys back to column values (integer kinds only: the transform is a bijection there): the key
+// column of the result needs no gather -- and nothing else at all when it is the only output column.
+__global__ __launch_bounds__(256) void ssgpu_sort_unkey_kernel(void* __restrict__ out, const u64* __restrict__ keys, u32 width, int kind,
+                                                               int descending, u64 n) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64 k = keys[i];
+  if (descending) k = ~k;
+  if (kind == 1) k = width == 8 ? (k ^ 0x8000000000000000ull) : (u64)((u32)k ^ 0x80000000u);
+  if (width == 8) reinterpret_cast<u64*>(out)[i] = k;
+  else if (width == 4) reinterpret_cast<u32*>(out)[i] = (u32)k;
+  else reinterpret_cast<u8*>(out)[i] = (u8)k;
 }
 
 // out[i] = col[idx[i]] for one column (and its NULL mask)
@@ -320,8 +337,14 @@ hipError_t ssgpu_launch_sort_hist(const uint64_t* keys, uint32_t shift, uint64_t
 hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out,
                                      uint32_t shift, uint64_t n, const uint32_t* offsets, hipStream_t s) {
   const uint32_t nt = ssgpu_sort_tiles(n);
-  if (nt) hipLaunchKernelGGL(ssgpu_sort_scatter_kernel, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out,
-                             idx_out, shift, (u64)n, nt, offsets);
+  if (nt && idx_in) hipLaunchKernelGGL(ssgpu_sort_scatter_kernel<true>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out,
+                                       idx_out, shift, (u64)n, nt, offsets);
+  else if (nt) hipLaunchKernelGGL(ssgpu_sort_scatter_kernel<false>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out,
+                                  idx_out, shift, (u64)n, nt, offsets);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_unkey(void* out, const uint64_t* keys, uint32_t width, int kind, int descending, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_unkey_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, out, (const u64*)keys, width, kind, descending, (u64)n);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_gather(void* out, uint8_t* out_nulls, const void* col, const uint8_t* nulls, uint32_t width,

@@ -704,3 +704,20 @@ def test_sort_negative_zero_ties_keep_their_order(gpu_ctx, descending):
     order = ss.DESCENDING if descending else ss.ASCENDING
     run_both(ss.Sort(ss.SortOrder().add("d", order), None, 0, ss.ScanView(view)), gpu_ctx)
     run_both(ss.Sort(ss.SortOrder().add("f", order), None, 0, ss.ScanView(view)), gpu_ctx)
+
+
+@pytest.mark.parametrize("n", [0, 1, 4097, 100003])
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_key_column_read_back_from_the_sorted_keys(gpu_ctx, n, descending):
+    # the major key's column comes from the sorted radix keys when that is lossless (integer, no NULLs): alone
+    # (keys-only sort, no row ids), next to payload columns, as the first of two keys, and not at all for a
+    # key with NULLs or a floating-point key
+    view = make_view(n, nullable=False)
+    order = ss.DESCENDING if descending else ss.ASCENDING
+    for key in ("d", "k2", "u"):
+        run_both(ss.Sort(ss.SortOrder().add(key, order), ss.ProjectNamedAttributes([key]), 0, ss.ScanView(view)), gpu_ctx)
+        run_both(ss.Sort(ss.SortOrder().add(key, order), ss.ProjectNamedAttributes(["a", key, "d0"]), 0, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.Sort(ss.SortOrder().add("k2", order).add("a", ss.ASCENDING), ss.ProjectNamedAttributes(["k2", "a", "c"]), 0, ss.ScanView(view)), gpu_ctx)
+    nullable = make_view(n, nullable=True)
+    run_both(ss.Sort(ss.SortOrder().add("d", order), ss.ProjectNamedAttributes(["d"]), 0, ss.ScanView(nullable)), gpu_ctx)
+    run_both(ss.Sort(ss.SortOrder().add("d1", order), ss.ProjectNamedAttributes(["d1"]), 0, ss.ScanView(view)), gpu_ctx)
