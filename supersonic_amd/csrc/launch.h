@@ -109,6 +109,9 @@ uint32_t ssgpu_sort_tiles(uint64_t n);
 hipError_t ssgpu_launch_sort_hist(const uint64_t* keys, uint32_t shift, uint64_t n, uint32_t* hist, hipStream_t s);
 hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out,
                                      uint32_t shift, uint64_t n, const uint32_t* offsets, hipStream_t s);
+// View-file loader: one piece = one column (or NULL-mask) segment of one file chunk inside a staged slab
+struct UnpackPiece { unsigned long long src_off; void* dst; unsigned long long bytes; };
+hipError_t ssgpu_launch_unpack(const char* slab, const UnpackPiece* pieces, unsigned int n_pieces, hipStream_t s);
 hipError_t ssgpu_launch_sort_unkey(void* out, const uint64_t* keys, uint32_t width, int kind, int descending, uint64_t n, hipStream_t s);
 hipError_t ssgpu_launch_sort_gather(void* out, uint8_t* out_nulls, const void* col, const uint8_t* nulls, uint32_t width,
                                     const uint32_t* idx, uint64_t n, hipStream_t s);

@@ -315,6 +315,29 @@ __global__ void ssgpu_dense_extract_kernel(const DenseExtractParams P) {
   }
 }
 
+// ---- View-file loader: scatter the pieces of a staged slab to their columns (one workgroup per piece) ----
+__global__ __launch_bounds__(256) void ssgpu_unpack_kernel(const char* __restrict__ slab, const UnpackPiece* __restrict__ pieces) {
+  const UnpackPiece pc = pieces[blockIdx.x];
+  const char* src = slab + pc.src_off;
+  char* dst = reinterpret_cast<char*>(pc.dst);
+  const u64 n = pc.bytes;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    const u64 n16 = n / 16;
+    for (u64 i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (u64 i = n16 * 16 + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  } else if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u) == 0) {   // the usual case: 8-byte chunk headers
+    const u64 n8 = n / 8;
+    for (u64 i = threadIdx.x; i < n8; i += 256) reinterpret_cast<u64*>(dst)[i] = reinterpret_cast<const u64*>(src)[i];
+    for (u64 i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  } else {
+    for (u64 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  }
+}
+hipError_t ssgpu_launch_unpack(const char* slab, const UnpackPiece* pieces, unsigned int n_pieces, hipStream_t s) {
+  if (n_pieces) hipLaunchKernelGGL(ssgpu_unpack_kernel, dim3(n_pieces), dim3(256), 0, s, slab, pieces);
+  return hipGetLastError();
+}
+
 // ---- launchers ------------------------------------------------------------------------------
 static inline int blocks_for(uint64_t n, int per) { return (int)((n + per - 1) / per); }
 
