@@ -206,6 +206,30 @@ inline const Expression* FloorToInt(const Expression* a) { return internal::Op(3
 inline const Expression* SqrtQuiet(const Expression* a) { return internal::Op(333, a); }
 inline const Expression* SqrtNulling(const Expression* a) { return internal::Op(334, a); }
 inline const Expression* SqrtSignaling(const Expression* a) { return internal::Op(335, a); }
+// libm family (expression/core/math_expressions.h): within a few ULP of the host libm
+inline const Expression* Exp(const Expression* a) { return internal::Op(320, a); }
+inline const Expression* LnQuiet(const Expression* a) { return internal::Op(325, a); }
+inline const Expression* LnNulling(const Expression* a) { return internal::Op(326, a); }
+inline const Expression* Log10Quiet(const Expression* a) { return internal::Op(329, a); }
+inline const Expression* Log10Nulling(const Expression* a) { return internal::Op(330, a); }
+inline const Expression* Log2Quiet(const Expression* a) { return internal::Op(357, a); }
+inline const Expression* Log2Nulling(const Expression* a) { return internal::Op(358, a); }
+inline const Expression* PowerQuiet(const Expression* a, const Expression* b) { return internal::Op(353, a, b); }
+inline const Expression* PowerNulling(const Expression* a, const Expression* b) { return internal::Op(354, a, b); }
+inline const Expression* PowerSignaling(const Expression* a, const Expression* b) { return internal::Op(355, a, b); }
+inline const Expression* Sin(const Expression* a) { return internal::Op(800, a); }
+inline const Expression* Cos(const Expression* a) { return internal::Op(804, a); }
+inline const Expression* Tan(const Expression* a) { return internal::Op(808, a); }
+inline const Expression* Asin(const Expression* a) { return internal::Op(812, a); }
+inline const Expression* Acos(const Expression* a) { return internal::Op(816, a); }
+inline const Expression* Atan(const Expression* a) { return internal::Op(820, a); }
+inline const Expression* Atan2(const Expression* x, const Expression* y) { return internal::Op(824, x, y); }
+inline const Expression* Sinh(const Expression* a) { return internal::Op(828, a); }
+inline const Expression* Cosh(const Expression* a) { return internal::Op(832, a); }
+inline const Expression* Tanh(const Expression* a) { return internal::Op(836, a); }
+inline const Expression* Asinh(const Expression* a) { return internal::Op(840, a); }
+inline const Expression* Acosh(const Expression* a) { return internal::Op(844, a); }
+inline const Expression* Atanh(const Expression* a) { return internal::Op(848, a); }
 inline const Expression* IsFinite(const Expression* a) { return internal::Op(148, a); }
 inline const Expression* IsInf(const Expression* a) { return internal::Op(152, a); }
 inline const Expression* IsNaN(const Expression* a) { return internal::Op(156, a); }

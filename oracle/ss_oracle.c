@@ -48,6 +48,10 @@ enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DI
        OP_BITWISE_XOR = 72, OP_SHIFT_LEFT = 76, OP_SHIFT_RIGHT = 80, OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116,
        OP_LESS_OR_EQUAL = 120, OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
        OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
+       OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
+       OP_POW_NULLING = 354, OP_POW_SIGNALING = 355, OP_LOG2_QUIET = 357, OP_LOG2_NULLING = 358, OP_SIN = 800, OP_COS = 804, OP_TAN = 808,
+       OP_ASIN = 812, OP_ACOS = 816, OP_ATAN = 820, OP_ATAN2 = 824, OP_SINH = 828, OP_COSH = 832, OP_TANH = 836, OP_ASINH = 840,
+       OP_ACOSH = 844, OP_ATANH = 848,
        OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
        OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
        OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002, OP_NULLING_IF = 100003 };
@@ -266,6 +270,22 @@ static int eval_cast(int from, int to, const void* A, void* D, int64_t n) {
     case 0: CASTROW(int32_t) case 1: CASTROW(uint32_t) case 2: CASTROW(int64_t)
     case 3: CASTROW(uint64_t) case 4: CASTROW(float) case 5: CASTROW(double)
   }
+  return 0;
+}
+
+/* the libm family: expression/core/math_evaluators.h:92-204 (one libm call per row) */
+static const char* libm1_name(int op) {
+  switch (op) { case OP_EXP: return "EXP"; case OP_LN_QUIET: case OP_LN_NULLING: return "LN"; case OP_LOG10_QUIET: case OP_LOG10_NULLING: return "LOG10";
+    case OP_LOG2_QUIET: case OP_LOG2_NULLING: return "LOG2"; case OP_SIN: return "SIN"; case OP_COS: return "COS"; case OP_TAN: return "TAN";
+    case OP_ASIN: return "ASIN"; case OP_ACOS: return "ACOS"; case OP_ATAN: return "ATAN"; case OP_SINH: return "SINH"; case OP_COSH: return "COSH";
+    case OP_TANH: return "TANH"; case OP_ASINH: return "ASINH"; case OP_ACOSH: return "ACOSH"; case OP_ATANH: return "ATANH"; }
+  return "?";
+}
+static double libm1(int op, double a) {
+  switch (op) { case OP_EXP: return exp(a); case OP_LN_QUIET: case OP_LN_NULLING: return log(a); case OP_LOG10_QUIET: case OP_LOG10_NULLING: return log10(a);
+    case OP_LOG2_QUIET: case OP_LOG2_NULLING: return log2(a); case OP_SIN: return sin(a); case OP_COS: return cos(a); case OP_TAN: return tan(a);
+    case OP_ASIN: return asin(a); case OP_ACOS: return acos(a); case OP_ATAN: return atan(a); case OP_SINH: return sinh(a); case OP_COSH: return cosh(a);
+    case OP_TANH: return tanh(a); case OP_ASINH: return asinh(a); case OP_ACOSH: return acosh(a); case OP_ATANH: return atanh(a); }
   return 0;
 }
 
@@ -527,6 +547,13 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       }
       return child;
     }
+    case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {
+      /* promoting binary expressions over DOUBLE (math_bound_expressions.cc:126-148,221-228) */
+      bnode* l = make_cast(a[0], T_DOUBLE, 1, err); bnode* r = make_cast(a[1], T_DOUBLE, 1, err); if (err->code) return NULL;
+      char nm[256]; snprintf(nm, sizeof(nm), "%s(%s, %s)", op == OP_ATAN2 ? "ATAN2" : "POW", l->name, r->name);
+      bnode* b = bnode_new(B_OP, op, T_DOUBLE, l->nullable || r->nullable || op == OP_POW_NULLING, nm); b->args[0] = l; b->args[1] = r; b->nargs = 2;
+      return op == OP_POW_SIGNALING ? b : fold(b, err);
+    }
     case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING:
     case OP_IS_FINITE: case OP_IS_INF: case OP_IS_NAN: case OP_IS_NORMAL: {
       bnode* c = make_cast(a[0], T_DOUBLE, 1, err); if (err->code) return NULL;
@@ -535,6 +562,16 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       char nm[256]; snprintf(nm, sizeof(nm), "%s(%s)", n, c->name);
       bnode* b = bnode_new(B_OP, op, is_sqrt ? T_DOUBLE : T_BOOL, c->nullable || op == OP_SQRT_NULLING, nm); b->args[0] = c; b->nargs = 1;
       return op == OP_SQRT_SIGNALING ? b : fold(b, err);
+    }
+    case OP_EXP: case OP_LN_QUIET: case OP_LN_NULLING: case OP_LOG10_QUIET: case OP_LOG10_NULLING: case OP_LOG2_QUIET: case OP_LOG2_NULLING:
+    case OP_SIN: case OP_COS: case OP_TAN: case OP_ASIN: case OP_ACOS: case OP_ATAN: case OP_SINH: case OP_COSH: case OP_TANH:
+    case OP_ASINH: case OP_ACOSH: case OP_ATANH: {
+      /* promoting unary expressions over DOUBLE (math_bound_expressions.cc:44-92,150-283) */
+      bnode* c = make_cast(a[0], T_DOUBLE, 1, err); if (err->code) return NULL;
+      const int nulling = op == OP_LN_NULLING || op == OP_LOG10_NULLING || op == OP_LOG2_NULLING;
+      char nm[256]; snprintf(nm, sizeof(nm), "%s(%s)", libm1_name(op), c->name);
+      bnode* b = bnode_new(B_OP, op, T_DOUBLE, c->nullable || nulling, nm); b->args[0] = c; b->nargs = 1;
+      return fold(b, err);
     }
     case OP_IS_ODD: case OP_IS_EVEN: {
       if (!is_integer(a[0]->dtype)) { set_err(err, RC_TYPE_MISMATCH, "IS_ODD / IS_EVEN need an integer argument%s%s", "", ""); return NULL; }
@@ -724,6 +761,20 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
       else { if (up) LOOP1(double, int64_t, (int64_t)ceil(a)) else LOOP1(double, int64_t, (int64_t)floor(a)) }
       b->nulls = x->nulls; return;
     }
+    case OP_EXP: case OP_LN_QUIET: case OP_LN_NULLING: case OP_LOG10_QUIET: case OP_LOG10_NULLING: case OP_LOG2_QUIET: case OP_LOG2_NULLING:
+    case OP_SIN: case OP_COS: case OP_TAN: case OP_ASIN: case OP_ACOS: case OP_ATAN: case OP_SINH: case OP_COSH: case OP_TANH:
+    case OP_ASINH: case OP_ACOSH: case OP_ATANH: {
+      const double* A = (const double*)x->data; double* D = (double*)b->buf;
+      for (int64_t i = 0; i < n; ++i) D[i] = libm1(b->op, A[i]);
+      b->nulls = x->nulls;
+      if (b->op == OP_LN_NULLING || b->op == OP_LOG10_NULLING || b->op == OP_LOG2_NULLING)   /* IsNonPositiveNuller, expression_traits.h:849-860 */
+        for (int64_t i = 0; i < n; ++i) {
+          if (!(A[i] <= 0)) continue;
+          if (b->nulls != b->nullbuf) { if (x->nulls) memcpy(b->nullbuf, x->nulls, (size_t)n); else memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; }
+          b->nullbuf[i] = 1;
+        }
+      return;
+    }
     case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING: {
       const double* A = (const double*)x->data; double* D = (double*)b->buf;
       for (int64_t i = 0; i < n; ++i) D[i] = sqrt(A[i]);
@@ -736,6 +787,21 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
             if (b->nulls != b->nullbuf) { if (x->nulls) memcpy(b->nullbuf, x->nulls, (size_t)n); else memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; }
             b->nullbuf[i] = 1;
           } else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative argument in %s%s", b->name, ""); return; }
+        }
+      return;
+    }
+    case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {
+      const double* A = (const double*)x->data; const double* B = (const double*)y->data; double* D = (double*)b->buf;
+      for (int64_t i = 0; i < n; ++i) D[i] = b->op == OP_ATAN2 ? atan2(A[i], B[i]) : pow(A[i], B[i]);
+      if (x->nulls || y->nulls) { or_nulls(b->nullbuf, x->nulls, y->nulls, n); b->nulls = b->nullbuf; } else b->nulls = NULL;
+      if (b->op == OP_POW_NULLING || b->op == OP_POW_SIGNALING)   /* FirstColumnNegativeAndSecondNonInteger, expression_traits.h:1329-1358 */
+        for (int64_t i = 0; i < n; ++i) {
+          if (!(A[i] < 0 && B[i] != trunc(B[i]))) continue;
+          const int already_null = b->nulls ? b->nulls[i] : 0;
+          if (b->op == OP_POW_NULLING) {
+            if (!b->nulls) { memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; }
+            b->nullbuf[i] = 1;
+          } else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative base with a non-integer exponent in %s%s", b->name, ""); return; }
         }
       return;
     }

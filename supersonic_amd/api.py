@@ -438,6 +438,36 @@ def FloorToInt(a): return _op(312, a)
 def SqrtQuiet(a): return _op(333, a)
 def SqrtNulling(a): return _op(334, a)
 def SqrtSignaling(a): return _op(335, a)
+# libm family (expression/core/math_expressions.h:30-140): results agree with the host libm to a few ULP
+def Exp(a): return _op(320, a)
+def LnQuiet(a): return _op(325, a)
+def LnNulling(a): return _op(326, a)
+def Log10Quiet(a): return _op(329, a)
+def Log10Nulling(a): return _op(330, a)
+def Log2Quiet(a): return _op(357, a)
+def Log2Nulling(a): return _op(358, a)
+def LogNulling(base, a): return DivideNulling(LnNulling(a), LnNulling(base))    # math_bound_expressions.cc:94-108
+def LogQuiet(base, a): return DivideQuiet(LnQuiet(a), LnQuiet(base))            # :110-124
+def PowerQuiet(a, b): return _op(353, a, b)
+def PowerNulling(a, b): return _op(354, a, b)
+def PowerSignaling(a, b): return _op(355, a, b)
+def Sin(a): return _op(800, a)
+def Cos(a): return _op(804, a)
+def Tan(a): return _op(808, a)
+def Cot(a): return DivideQuiet(ConstDouble(1.0), Tan(a))                        # :196-211
+def Asin(a): return _op(812, a)
+def Acos(a): return _op(816, a)
+def Atan(a): return _op(820, a)
+def Atan2(x, y): return _op(824, x, y)
+def Sinh(a): return _op(828, a)
+def Cosh(a): return _op(832, a)
+def Tanh(a): return _op(836, a)
+def Asinh(a): return _op(840, a)
+def Acosh(a): return _op(844, a)
+def Atanh(a): return _op(848, a)
+def ToDegrees(a): return Multiply(a, ConstDouble(180.0 / 3.141592653589793))     # :285-296
+def ToRadians(a): return Multiply(a, ConstDouble(3.141592653589793 / 180.0))     # :298-309
+def Pi(): return ConstDouble(3.141592653589793)
 def IsFinite(a): return _op(148, a)
 def IsInf(a): return _op(152, a)
 def IsNaN(a): return _op(156, a)

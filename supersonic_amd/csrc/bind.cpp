@@ -24,6 +24,10 @@ enum {
   OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116, OP_LESS_OR_EQUAL = 120,
   OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
   OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
+  OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
+  OP_POW_NULLING = 354, OP_POW_SIGNALING = 355, OP_LOG2_QUIET = 357, OP_LOG2_NULLING = 358, OP_SIN = 800, OP_COS = 804, OP_TAN = 808,
+  OP_ASIN = 812, OP_ACOS = 816, OP_ATAN = 820, OP_ATAN2 = 824, OP_SINH = 828, OP_COSH = 832, OP_TANH = 836, OP_ASINH = 840,
+  OP_ACOSH = 844, OP_ATANH = 848,
   OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
   OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST_QUIET = 265
 };
@@ -293,6 +297,9 @@ static bool fold_binary(int op, int t, uint64_t a, uint64_t b, int* out_type, ui
       case OP_ADD: r = x + y; break; case OP_SUBTRACT: r = x - y; break; case OP_MULTIPLY: r = x * y; break;
       case OP_DIVIDE_QUIET: case OP_DIVIDE_SIGNALING: r = x / y; break;
       case OP_DIVIDE_NULLING: if (y == 0) { *out_null = true; *out = 0; return true; } r = x / y; break;
+      case OP_ATAN2: r = atan2(x, y); break;
+      case OP_POW_QUIET: r = pow(x, y); break;
+      case OP_POW_NULLING: if (x < 0 && y != trunc(y)) { *out_null = true; *out = 0; return true; } r = pow(x, y); break;
       default: return false;
     }
     *out = to_bits(r); return true;
@@ -405,6 +412,25 @@ static bool try_fold(const BExprP& e, BExprP* out) {
         case OP_IS_NAN: *out = make_const(SSGPU_BOOL, std::isnan(d)); return true;
         case OP_IS_INF: *out = make_const(SSGPU_BOOL, std::isinf(d)); return true;
         case OP_IS_NORMAL: *out = make_const(SSGPU_BOOL, std::isnormal(d)); return true;
+        case OP_EXP: *out = make_const(e->dtype, to_bits(exp(d))); return true;
+        case OP_LN_QUIET: *out = make_const(e->dtype, to_bits(log(d))); return true;
+        case OP_LN_NULLING: *out = d <= 0 ? make_null(e->dtype) : make_const(e->dtype, to_bits(log(d))); return true;
+        case OP_LOG10_QUIET: *out = make_const(e->dtype, to_bits(log10(d))); return true;
+        case OP_LOG10_NULLING: *out = d <= 0 ? make_null(e->dtype) : make_const(e->dtype, to_bits(log10(d))); return true;
+        case OP_LOG2_QUIET: *out = make_const(e->dtype, to_bits(log2(d))); return true;
+        case OP_LOG2_NULLING: *out = d <= 0 ? make_null(e->dtype) : make_const(e->dtype, to_bits(log2(d))); return true;
+        case OP_SIN: *out = make_const(e->dtype, to_bits(sin(d))); return true;
+        case OP_COS: *out = make_const(e->dtype, to_bits(cos(d))); return true;
+        case OP_TAN: *out = make_const(e->dtype, to_bits(tan(d))); return true;
+        case OP_ASIN: *out = make_const(e->dtype, to_bits(asin(d))); return true;
+        case OP_ACOS: *out = make_const(e->dtype, to_bits(acos(d))); return true;
+        case OP_ATAN: *out = make_const(e->dtype, to_bits(atan(d))); return true;
+        case OP_SINH: *out = make_const(e->dtype, to_bits(sinh(d))); return true;
+        case OP_COSH: *out = make_const(e->dtype, to_bits(cosh(d))); return true;
+        case OP_TANH: *out = make_const(e->dtype, to_bits(tanh(d))); return true;
+        case OP_ASINH: *out = make_const(e->dtype, to_bits(asinh(d))); return true;
+        case OP_ACOSH: *out = make_const(e->dtype, to_bits(acosh(d))); return true;
+        case OP_ATANH: *out = make_const(e->dtype, to_bits(atanh(d))); return true;
         case OP_SQRT_QUIET: *out = make_const(e->dtype, to_bits(sqrt(d))); return true;
         case OP_SQRT_NULLING: *out = d < 0 ? make_null(e->dtype) : make_const(e->dtype, to_bits(sqrt(d))); return true;
         case OP_IS_ODD: case OP_IS_EVEN: {
@@ -609,6 +635,43 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
         default:  // RoundToInt binds as CEIL_TO_INT(ROUND(x)) (math_bound_expressions.cc:327-339)
           *out = unary(OP_CEIL_TO_INT, "CEIL_TO_INT", SSGPU_INT64, unary(OP_ROUND, "ROUND", t, args[0])); break;
       }
+      return Status::OK();
+    }
+    // libm family (math_bound_expressions.cc:44-92,126-283, expression_traits.h:718-1000,1329-1375): promoting
+    // unary / binary expressions over DOUBLE; LN / LOG10 / LOG2 NULLING are NULL for x <= 0, POW NULLING /
+    // SIGNALING for a negative base with a non-integer exponent
+    case OP_EXP: case OP_LN_QUIET: case OP_LN_NULLING: case OP_LOG10_QUIET: case OP_LOG10_NULLING: case OP_LOG2_QUIET: case OP_LOG2_NULLING:
+    case OP_SIN: case OP_COS: case OP_TAN: case OP_ASIN: case OP_ACOS: case OP_ATAN: case OP_SINH: case OP_COSH: case OP_TANH:
+    case OP_ASINH: case OP_ACOSH: case OP_ATANH: {
+      SS_RETURN_IF_ERROR(need(1));
+      if (!dtype_is_numeric(args[0]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("Cannot cast ") + dtype_name(args[0]->dtype) + " to DOUBLE");
+      BExprP c;
+      SS_RETURN_IF_ERROR(make_cast(args[0], SSGPU_DOUBLE, true, &c));
+      const char* nm = "?";
+      switch (op) {
+        case OP_EXP: nm = "EXP"; break; case OP_LN_QUIET: case OP_LN_NULLING: nm = "LN"; break;
+        case OP_LOG10_QUIET: case OP_LOG10_NULLING: nm = "LOG10"; break; case OP_LOG2_QUIET: case OP_LOG2_NULLING: nm = "LOG2"; break;
+        case OP_SIN: nm = "SIN"; break; case OP_COS: nm = "COS"; break; case OP_TAN: nm = "TAN"; break; case OP_ASIN: nm = "ASIN"; break;
+        case OP_ACOS: nm = "ACOS"; break; case OP_ATAN: nm = "ATAN"; break; case OP_SINH: nm = "SINH"; break; case OP_COSH: nm = "COSH"; break;
+        case OP_TANH: nm = "TANH"; break; case OP_ASINH: nm = "ASINH"; break; case OP_ACOSH: nm = "ACOSH"; break; default: nm = "ATANH"; break;
+      }
+      const bool nulling = op == OP_LN_NULLING || op == OP_LOG10_NULLING || op == OP_LOG2_NULLING;
+      *out = fold(make_op(op, SSGPU_DOUBLE, c->nullable || nulling, std::string(nm) + "(" + c->name + ")", {c}, depth));
+      if (nulling && (*out)->kind == BExpr::OP) (*out)->nullable = true;
+      return Status::OK();
+    }
+    case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {
+      SS_RETURN_IF_ERROR(need(2));
+      if (!dtype_is_numeric(args[0]->dtype) || !dtype_is_numeric(args[1]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("Cannot cast ") + dtype_name(args[0]->dtype) + " to DOUBLE");
+      BExprP l, r;
+      SS_RETURN_IF_ERROR(make_cast(args[0], SSGPU_DOUBLE, true, &l));
+      SS_RETURN_IF_ERROR(make_cast(args[1], SSGPU_DOUBLE, true, &r));
+      const std::string name = std::string(op == OP_ATAN2 ? "ATAN2" : "POW") + "(" + l->name + ", " + r->name + ")";
+      BExprP e = make_op(op, SSGPU_DOUBLE, l->nullable || r->nullable || op == OP_POW_NULLING, name, {l, r}, depth);
+      *out = op == OP_POW_SIGNALING ? e : fold(e);   // a constant failing POW_SIGNALING must still fail when evaluated
+      if (op == OP_POW_NULLING && (*out)->kind == BExpr::OP) (*out)->nullable = true;
       return Status::OK();
     }
     case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING:

@@ -115,6 +115,7 @@ struct Program {
   std::vector<LReg> regs;
   std::vector<StagedInput> staged;
   std::vector<JoinGather> gathers;   // rhs columns (and NULL masks) read by GATHER_* instructions
+  bool uses_math = false;            // has MATH1_F64 / MATH2_F64: runs in the MATH kernel variant
   uint32_t bytes_per_row = 0;   // LDS bytes per tile row (peak of live registers)
   uint32_t in_bytes_per_row = 0;  // of which: the staged input registers
   int n_slots = 0;

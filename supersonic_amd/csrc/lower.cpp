@@ -25,6 +25,10 @@ enum {
   OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
   OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36,
   OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
+  OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
+  OP_POW_NULLING = 354, OP_POW_SIGNALING = 355, OP_LOG2_QUIET = 357, OP_LOG2_NULLING = 358, OP_SIN = 800, OP_COS = 804, OP_TAN = 808,
+  OP_ASIN = 812, OP_ACOS = 816, OP_ATAN = 820, OP_ATAN2 = 824, OP_SINH = 828, OP_COSH = 832, OP_TANH = 836, OP_ASINH = 840,
+  OP_ACOSH = 844, OP_ATANH = 848,
   OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334,
   OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360, OP_AND = 40, OP_OR = 44,
   OP_AND_NOT = 48, OP_NOT = 52, OP_XOR = 56, OP_BITWISE_AND = 60, OP_BITWISE_OR = 64,
@@ -316,6 +320,54 @@ Status Emitter::value(const BExprP& e, Val* out) {
           Val odd; odd.width = 1; odd.reg = unop(mwidth(at) == 4 ? VM_ISODD_32 : VM_ISODD_64, a[0], 1);
           v.reg = e->op == OP_IS_ODD ? odd.reg : unop(VM_NOT_B8, odd, 1);
           v.null = a[0].null;
+        } break;
+        case OP_EXP: case OP_LN_QUIET: case OP_LN_NULLING: case OP_LOG10_QUIET: case OP_LOG10_NULLING: case OP_LOG2_QUIET: case OP_LOG2_NULLING:
+        case OP_SIN: case OP_COS: case OP_TAN: case OP_ASIN: case OP_ACOS: case OP_ATAN: case OP_SINH: case OP_COSH: case OP_TANH:
+        case OP_ASINH: case OP_ACOSH: case OP_ATANH: {
+          uint32_t fn = 0;
+          switch (e->op) {
+            case OP_EXP: fn = VM_MATH_EXP; break; case OP_LN_QUIET: case OP_LN_NULLING: fn = VM_MATH_LN; break;
+            case OP_LOG10_QUIET: case OP_LOG10_NULLING: fn = VM_MATH_LOG10; break; case OP_LOG2_QUIET: case OP_LOG2_NULLING: fn = VM_MATH_LOG2; break;
+            case OP_SIN: fn = VM_MATH_SIN; break; case OP_COS: fn = VM_MATH_COS; break; case OP_TAN: fn = VM_MATH_TAN; break;
+            case OP_ASIN: fn = VM_MATH_ASIN; break; case OP_ACOS: fn = VM_MATH_ACOS; break; case OP_ATAN: fn = VM_MATH_ATAN; break;
+            case OP_SINH: fn = VM_MATH_SINH; break; case OP_COSH: fn = VM_MATH_COSH; break; case OP_TANH: fn = VM_MATH_TANH; break;
+            case OP_ASINH: fn = VM_MATH_ASINH; break; case OP_ACOSH: fn = VM_MATH_ACOSH; break; default: fn = VM_MATH_ATANH; break;
+          }
+          int base_null = a[0].null;
+          if (e->op == OP_LN_NULLING || e->op == OP_LOG10_NULLING || e->op == OP_LOG2_NULLING) {
+            // IsNonPositiveNuller (expression_traits.h:849-860): x <= 0
+            Val zero; zero.imm = true; zero.bits = 0; zero.width = 8;
+            Val np; np.width = 1; np.reg = binop(VM_LE_F64, a[0], zero, 1);
+            if (base_null >= 0) { int r = new_reg(1); LInstr& i = emit(VM_NULL_OR); i.dst = r; i.a = base_null; i.b = np.reg; base_null = r; }
+            else base_null = np.reg;
+          }
+          const int x = materialize(a[0]);
+          v.reg = new_reg(8);
+          { LInstr& i = emit(VM_MATH1_F64); i.dst = v.reg; i.a = x; i.imm = fn; }
+          P->uses_math = true;
+          v.null = base_null;
+        } break;
+        case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {
+          int base_null = or_null(a[0].null, a[1].null);
+          if (e->op == OP_POW_NULLING || e->op == OP_POW_SIGNALING) {
+            // FirstColumnNegativeAndSecondNonInteger (expression_traits.h:1329-1358): base < 0 and exponent != trunc(exponent)
+            Val zero; zero.imm = true; zero.bits = 0; zero.width = 8;
+            Val neg; neg.width = 1; neg.reg = binop(VM_LT_F64, a[0], zero, 1);
+            Val tr; tr.width = 8; tr.reg = unop(VM_TRUNC_F64, a[1], 8);
+            Val frac; frac.width = 1; frac.reg = binop(VM_NE_F64, a[1], tr, 1);
+            Val bad; bad.width = 1; bad.reg = binop(VM_AND_B8, neg, frac, 1);
+            if (e->op == OP_POW_NULLING) {
+              if (base_null >= 0) { int r = new_reg(1); LInstr& i = emit(VM_NULL_OR); i.dst = r; i.a = base_null; i.b = bad.reg; base_null = r; }
+              else base_null = bad.reg;
+            } else {
+              LInstr& i = emit(VM_FAIL_TRUE_8); i.dst_is_reg = false; i.dst = 0; i.a = base_null; i.b = bad.reg; i.c = sel;
+            }
+          }
+          const int x = materialize(a[0]), y = materialize(a[1]);
+          v.reg = new_reg(8);
+          { LInstr& i = emit(VM_MATH2_F64); i.dst = v.reg; i.a = x; i.b = y; i.imm = e->op == OP_ATAN2 ? VM_MATH_ATAN2 : VM_MATH_POW; }
+          P->uses_math = true;
+          v.null = base_null;
         } break;
         case OP_SQRT_QUIET: case OP_SQRT_NULLING: case OP_SQRT_SIGNALING: {
           int base_null = a[0].null;

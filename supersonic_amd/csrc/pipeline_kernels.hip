@@ -406,7 +406,21 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
 // ---------------------------------------------------------------------------
 // One persistent 4-wave workgroup strides over the tiles.  Per tile: commit the prefetched
 // units to the LDS input registers, issue the loads of the next tile, run the program.
-template <int K>
+// libm functions of the MATH kernel variant (device libm: within a few ULP of the host's)
+__device__ __forceinline__ double vm_math1(u32 fn, double a) {
+  switch (fn) {
+    case VM_MATH_EXP: return exp(a);     case VM_MATH_LN: return log(a);       case VM_MATH_LOG10: return log10(a);
+    case VM_MATH_LOG2: return log2(a);   case VM_MATH_SIN: return sin(a);      case VM_MATH_COS: return cos(a);
+    case VM_MATH_TAN: return tan(a);     case VM_MATH_ASIN: return asin(a);    case VM_MATH_ACOS: return acos(a);
+    case VM_MATH_ATAN: return atan(a);   case VM_MATH_SINH: return sinh(a);    case VM_MATH_COSH: return cosh(a);
+    case VM_MATH_TANH: return tanh(a);   case VM_MATH_ASINH: return asinh(a);  case VM_MATH_ACOSH: return acosh(a);
+    default: return atanh(a);
+  }
+}
+
+// MATH = true adds the libm handlers (MATH1_F64 / MATH2_F64).  They live in their own instantiation so that
+// the kernel every other program runs is not touched by their code size and register demand.
+template <int K, bool MATH>
 __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline_kernel(const VmParams P) {
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -602,6 +616,27 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
         UNOP(ISNORMAL_F64, double, u8, (__builtin_isnormal(a) ? 1 : 0))
         UNOP(ISODD_32, i32, u8, ((a % 2) != 0 ? 1 : 0))
         UNOP(ISODD_64, i64, u8, ((a % 2) != 0 ? 1 : 0))
+        case VM_MATH1_F64: { CASE_FENCE;
+          if constexpr (MATH) {
+            const u32 fn = (u32)I.imm;
+            _Pragma("unroll 1") FOR_PAIRS {
+              auto va = lds_load2<double>(I.a, p);
+              lds_store2<double>(I.dst, p, vm_math1(fn, va.x), vm_math1(fn, va.y));
+            }
+          }
+        } break;
+        case VM_MATH2_F64: { CASE_FENCE;
+          if constexpr (MATH) {
+            const u32 fn = (u32)I.imm;
+            _Pragma("unroll 1") FOR_PAIRS {
+              auto va = lds_load2<double>(I.a, p);
+              auto vb = lds_load2<double>(I.b, p);
+              const double r0 = fn == VM_MATH_POW ? pow(va.x, vb.x) : atan2(va.x, vb.x);
+              const double r1 = fn == VM_MATH_POW ? pow(va.y, vb.y) : atan2(va.y, vb.y);
+              lds_store2<double>(I.dst, p, r0, r1);
+            }
+          }
+        } break;
         case VM_FAIL_TRUE_8: { CASE_FENCE;   // signaling math: flagged rows that are selected and not NULL
           bool bad = false;
           _Pragma("unroll") FOR_PAIRS {
@@ -2319,10 +2354,19 @@ __global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream) {
   dim3 g(grid), b(VM_WG_THREADS);  // 4 waves
   size_t lds = P.lds_bytes;
+  if (P.uses_math) {
+    switch (K) {
+      case 1: hipLaunchKernelGGL((ssgpu_pipeline_kernel<1, true>), g, b, lds, stream, P); break;
+      case 2: hipLaunchKernelGGL((ssgpu_pipeline_kernel<2, true>), g, b, lds, stream, P); break;
+      case 4: hipLaunchKernelGGL((ssgpu_pipeline_kernel<4, true>), g, b, lds, stream, P); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (K) {
-    case 1: hipLaunchKernelGGL(ssgpu_pipeline_kernel<1>, g, b, lds, stream, P); break;
-    case 2: hipLaunchKernelGGL(ssgpu_pipeline_kernel<2>, g, b, lds, stream, P); break;
-    case 4: hipLaunchKernelGGL(ssgpu_pipeline_kernel<4>, g, b, lds, stream, P); break;
+    case 1: hipLaunchKernelGGL((ssgpu_pipeline_kernel<1, false>), g, b, lds, stream, P); break;
+    case 2: hipLaunchKernelGGL((ssgpu_pipeline_kernel<2, false>), g, b, lds, stream, P); break;
+    case 4: hipLaunchKernelGGL((ssgpu_pipeline_kernel<4, false>), g, b, lds, stream, P); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -2387,9 +2431,12 @@ hipError_t ssgpu_part_agg_set_max_lds(int bytes) {
 }
 hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
   hipError_t e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_pipeline_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,

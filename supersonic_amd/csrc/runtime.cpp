@@ -29,6 +29,9 @@ using namespace ssgpu;
   } while (0)
 
 struct ssgpu_ctx {
+  // plans and blocks hold a reference: the context outlives them whatever order a garbage-collected host
+  // destroys the handles in (ssgpu_ctx_destroy only drops the owner's reference)
+  std::atomic<int> refs{1};
   int device = -1;
   hipStream_t stream = nullptr, copy_stream = nullptr;
   bool own_stream = false;
@@ -184,14 +187,15 @@ int ssgpu_ctx_create(int device_id, ssgpu_ctx** out) {
   return SSGPU_OK;
 }
 
-void ssgpu_ctx_destroy(ssgpu_ctx* c) {
-  if (!c) return;
+static void ctx_release(ssgpu_ctx* c) {
+  if (c->refs.fetch_sub(1) != 1) return;
   if (c->device >= 0) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   }
   delete c;
 }
+void ssgpu_ctx_destroy(ssgpu_ctx* c) { if (c) ctx_release(c); }
 
 const char* ssgpu_last_error(const ssgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 void* ssgpu_ctx_stream(ssgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -254,10 +258,11 @@ int ssgpu_block_create(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n, int64_
     if (b->data[i].ensure((size_t)cap * w) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
     if (a.nullable && b->nulls[i].ensure((size_t)cap) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
   }
+  c->refs.fetch_add(1);
   *out = b;
   return SSGPU_OK;
 }
-void ssgpu_block_destroy(ssgpu_block* b) { delete b; }
+void ssgpu_block_destroy(ssgpu_block* b) { if (!b) return; ssgpu_ctx* c = b->ctx; delete b; if (c) ctx_release(c); }
 
 // ---- View file format: cursor/infrastructure/file_io.cc ---------------------------------------
 static const int64_t kFileChunkRows = 8192;   // kMaxChunkRowCount, file_io.cc:70
@@ -440,6 +445,7 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   if (c->device >= 0) {
     (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end);
   }
+  c->refs.fetch_add(1);
   *out = p;
   return SSGPU_OK;
 }
@@ -455,7 +461,9 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
       if (p->ring1[i]) (void)hipEventDestroy(p->ring1[i]);
     }
   }
+  ssgpu_ctx* c = p->ctx;
   delete p;
+  if (c) ctx_release(c);
 }
 
 int32_t ssgpu_plan_attr_count(const ssgpu_plan* p) { return p ? (int32_t)p->result_schema.size() : 0; }
@@ -663,6 +671,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->n_instr = n_instr;
   P->n_staged = (int)prog.staged.size();
   P->n_outputs = prog.n_outputs;
+  P->uses_math = prog.uses_math ? 1u : 0u;
   P->n_slots = prog.n_slots;
   P->n_rows = in.rows;
   P->row_id_base = row_id_base;

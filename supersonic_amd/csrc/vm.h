@@ -23,6 +23,9 @@
 #include <stdint.h>
 
 #define VM_NONE 0xFFFFFFFFu
+/* functions of MATH1_F64 / MATH2_F64 (expression/core/math_evaluators.h:92-204: the libm calls of the reference) */
+enum { VM_MATH_EXP = 1, VM_MATH_LN, VM_MATH_LOG10, VM_MATH_LOG2, VM_MATH_SIN, VM_MATH_COS, VM_MATH_TAN, VM_MATH_ASIN, VM_MATH_ACOS,
+       VM_MATH_ATAN, VM_MATH_SINH, VM_MATH_COSH, VM_MATH_TANH, VM_MATH_ASINH, VM_MATH_ACOSH, VM_MATH_ATANH, VM_MATH_POW, VM_MATH_ATAN2 };
 #ifndef VM_THREADS
 #define VM_THREADS 256      /* threads per workgroup */
 #endif
@@ -95,6 +98,8 @@
   X(NULL_DIVZERO_32) X(NULL_DIVZERO_64) X(NULL_DIVZERO_F32) X(NULL_DIVZERO_F64)\
   X(FAIL_DIVZERO_32) X(FAIL_DIVZERO_64) X(FAIL_DIVZERO_F32) X(FAIL_DIVZERO_F64)\
   X(FILL_8) X(FILL_32) X(FILL_64) X(ROWID_64)                                  \
+  /* ---- libm family: dst = fn(a) / fn(a, b), fn = imm (VM_MATH_*); only in the MATH kernel variant */\
+  X(MATH1_F64) X(MATH2_F64)                                                    \
   X(SELECT_8) X(SELECT_32) X(SELECT_64) /* dst = c ? a : b  (IF / IFNULL) */   \
   X(SEL_FROM_PRED) /* dst = a(value) & !b(null)        filter.cc:180-196 */    \
   /* ---- scalar-aggregate sinks: dst = slot, a = value, b = null, c = sel -- */\
@@ -238,7 +243,7 @@ struct VmParams {
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */
   unsigned long long* debug_pc; /* optional [n_instr + 1]: cycles per instruction (wave 0 of every workgroup); last = staging */
   uint32_t debug_pc_lds_off;    /* LDS scratch of the same shape (accumulated there, flushed once) */
-  uint32_t pad_dbg;
+  uint32_t uses_math;           /* the program has MATH1_F64 / MATH2_F64 instructions: launch the MATH kernel variant */
   VmGroupTable group;
   VmJoin join[VM_MAX_JOINS];
   VmJoinCol join_cols[VM_MAX_JOIN_COLS];

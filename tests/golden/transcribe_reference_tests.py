@@ -152,6 +152,72 @@ CASES.append({"name": "Projecting_AliasFailsOnTooManyColumns_string", "source": 
               "plan": ["Compute", ["Alias", "Some other alias", ["CompoundExpression", ["Add", ["AttributeAt", 0]], ["Add", ["AttributeAt", 1]]]], "INPUT"],
               "expected": {"types": None, "rows": [], "names": None, "nullable": None}, "ordered": True, "expect_error": 401})
 
+# ---- the libm family (math_expressions_test.cc:32-95,123-135,362-672).  Where the reference's expectation is a libm
+# call (log(1000.), pow(3, -0.3) ...) the transcription makes the same call through Python's math module; the
+# device libm is held to max_ulp units in the last place of these values (exact for the oracle, which calls libm).
+import math  # noqa: E402
+MX = "supersonic/expression/core/math_expressions_test.cc"
+LIBM_ULP = 4
+
+
+def libm_case(name, lines, factory, types, rows):
+    expr_case(name, MX + lines, types, rows, factory, nullable=False)
+    CASES[-1]["max_ulp"] = LIBM_ULP
+
+
+for nm, fac, out_nullable in [("EXP", "Exp", False), ("LN", "LnNulling", True), ("LN", "LnQuiet", False), ("LOG10", "Log10Nulling", True),
+                              ("LOG10", "Log10Quiet", False), ("LOG2", "Log2Nulling", True), ("LOG2", "Log2Quiet", False), ("SIN", "Sin", False),
+                              ("COS", "Cos", False), ("TAN", "Tan", False), ("ASIN", "Asin", False), ("ACOS", "Acos", False), ("ATAN", "Atan", False),
+                              ("SINH", "Sinh", False), ("COSH", "Cosh", False), ("TANH", "Tanh", False), ("ASINH", "Asinh", False),
+                              ("ACOSH", "Acosh", False), ("ATANH", "Atanh", False)]:
+    bind_case("MathBinding_" + fac, MX + ":32-77", fac, [F64], [False], nm + "($0)", F64, out_nullable)
+bind_case("MathBinding_Cot", MX + ":63", "Cot", [F64], [False], "(CONST_DOUBLE /. TAN($0))", F64, False)
+bind_case("MathBinding_ToDegrees", MX + ":73", "ToDegrees", [F64], [False], "($0 * CONST_DOUBLE)", F64, False)
+bind_case("MathBinding_ToRadians", MX + ":74", "ToRadians", [F64], [False], "($0 * CONST_DOUBLE)", F64, False)
+bind_case("MathBinding_Atan2", MX + ":80-81", "Atan2", [F64, F64], [False, False], "ATAN2($0, $1)", F64, False)
+bind_case("MathBinding_LogQuiet", MX + ":84-85", "LogQuiet", [F64, F64], [False, False], "(LN($1) /. LN($0))", F64, False)
+bind_case("MathBinding_PowerSignaling", MX + ":86-87", "PowerSignaling", [F64, F64], [False, False], "POW($0, $1)", F64, False)
+bind_case("MathBinding_PowerQuiet", MX + ":88-89", "PowerQuiet", [F64, F64], [False, False], "POW($0, $1)", F64, False)
+bind_case("MathBinding_PowerNulling", MX + ":91-92", "PowerNulling", [F64, F64], [False, False], "POW($0, $1)", F64, True)
+bind_case("MathBinding_LogNulling", MX + ":93-94", "LogNulling", [F64, F64], [False, False], "(LN($1) /. LN($0))", F64, True)
+bind_case("MathBindingWithCast_Exp_float", MX + ":124-125", "Exp", [F32], [False], "EXP(CAST_FLOAT_TO_DOUBLE($0))", F64, False)
+bind_case("MathBindingWithCast_Sin_int32", MX + ":126-127", "Sin", [I32], [False], "SIN(CAST_INT32_TO_DOUBLE($0))", F64, False)
+bind_case("MathBindingWithCast_Cos_uint32", MX + ":128-129", "Cos", [U32], [False], "COS(CAST_UINT32_TO_DOUBLE($0))", F64, False)
+bind_case("MathBindingWithCast_Tan_uint64", MX + ":130-131", "Tan", [U64], [False], "TAN(CAST_UINT64_TO_DOUBLE($0))", F64, False)
+bind_case("MathBindingWithCast_Sin_int64", MX + ":132-133", "Sin", [I64], [False], "SIN(CAST_INT64_TO_DOUBLE($0))", F64, False)
+libm_case("LnNulling", ":362-370", "LnNulling", [F64, F64], [[1., 0.], [1000., math.log(1000.)], [math.exp(1), 1.], [0., None], [-1., None]])
+libm_case("LnQuiet", ":372-381", "LnQuiet", [F64, F64], [[1., 0.], [1000., math.log(1000.)], [0., "-inf"], [-1., NAN]])
+libm_case("Log10Nulling", ":383-390", "Log10Nulling", [F64, F64], [[1., 0.], [1000., 3.], [0., None], [-1., None]])
+libm_case("Log10Quiet", ":392-401", "Log10Quiet", [F64, F64], [[1., 0.], [1000., 3.], [0., "-inf"], [-1., NAN]])
+libm_case("Log2Nulling", ":403-411", "Log2Nulling", [F64, F64], [[1., 0.], [1000., math.log2(1000.)], [1024., 10.], [0., None], [-1., None]])
+libm_case("Log2Quiet", ":413-423", "Log2Quiet", [F64, F64], [[1., 0.], [1000., math.log2(1000.)], [1024., 10.], [0., "-inf"], [-1., NAN]])
+libm_case("Exp", ":425-431", "Exp", [F64, F64], [[0., 1.], [1000., INF], [-1., math.exp(-1.)]])
+libm_case("ExpWithIntInputType", ":433-438", "Exp", [I32, F64], [[-4, math.exp(-4.)], [4, math.exp(4.)]])
+libm_case("LogNulling", ":440-451", "LogNulling", [F64, I32, F64],
+          [[2., 4, 2.], [4., 4, 1.], [10., 2, math.log(2.) / math.log(10.)], [0., 2, None], [2., 0, None], [-1., 5, None], [5., -3, None], [-8., -8, None]])
+POW_ROWS = [[1., 0., 1.], [2., 2., 4.], [2.5, 2., 6.25], [4., 0.5, 2.], [-1., 2., 1.], [0., 0., 1.], [0., 0.5, 0.], [6.25, 0.5, 2.5], [0.5, -1., 2.],
+            [-1., -1., -1.], [3., -0.3, math.pow(3, -0.3)]]
+libm_case("PowerSignaling", ":475-489", "PowerSignaling", [F64, F64, F64], POW_ROWS)
+libm_case("PowerNulling", ":496-512", "PowerNulling", [F64, F64, F64], POW_ROWS + [[-1., 0.5, None], [-1., -0.5, None]])
+libm_case("PowerQuiet", ":514-532", "PowerQuiet", [F64, F64, F64], POW_ROWS + [[-1., 0.5, NAN], [-1., -0.5, NAN]])
+expr_case("PowerSignaling_fails", MX + ":491-494", [F64, F64, F64], [[-1., 0.5, None], [-1., -0.5, None]], "PowerSignaling", nullable=False, expect_error=104)
+libm_case("Sin", ":539-545", "Sin", [F64, F64], [[0., 0.], [math.acos(0), 1.], [1., math.sin(1)]])
+libm_case("Cos", ":547-553", "Cos", [F64, F64], [[0., 1.], [math.acos(-1), -1.], [1., math.cos(1)]])
+libm_case("Tan", ":555-561", "Tan", [F64, F64], [[0., 0.], [123., math.tan(123)], [1., math.tan(1)]])
+libm_case("Cot", ":563-569", "Cot", [F64, F64], [[1., 1. / math.tan(1.)], [2., 1. / math.tan(2.)], [3.14, 1. / math.tan(3.14)]])
+libm_case("Asin", ":571-577", "Asin", [F64, F64], [[0.5, math.asin(0.5)], [-0.5, math.asin(-0.5)], [0.14, math.asin(0.14)]])
+libm_case("Acos", ":579-585", "Acos", [F64, F64], [[0.5, math.acos(0.5)], [-0.5, math.acos(-0.5)], [0.14, math.acos(0.14)]])
+libm_case("Atan", ":587-593", "Atan", [F64, F64], [[1., math.atan(1.)], [2., math.atan(2.)], [3.14, math.atan(3.14)]])
+libm_case("Atan2", ":595-601", "Atan2", [F64, F64, F64], [[1., 1., math.atan2(1., 1.)], [2., 0., math.atan2(2., 0.)], [3.14, 0., math.atan2(3.14, 0.)]])
+libm_case("Sinh", ":603-609", "Sinh", [F64, F64], [[0., 0.], [1.3, math.sinh(1.3)], [2.1, math.sinh(2.1)]])
+libm_case("Cosh", ":611-617", "Cosh", [F64, F64], [[0., 1.], [1., math.cosh(1.)], [2., math.cosh(2.)]])
+libm_case("Tanh", ":619-625", "Tanh", [F64, F64], [[0., 0.], [123., math.tanh(123)], [1., math.tanh(1)]])
+libm_case("Asinh", ":627-633", "Asinh", [F64, F64], [[0.5, math.asinh(0.5)], [-0.5, math.asinh(-0.5)], [0.14, math.asinh(0.14)]])
+libm_case("Acosh", ":635-641", "Acosh", [F64, F64], [[0.5, NAN], [-0.5, NAN], [0.14, NAN]])
+libm_case("Atanh", ":643-649", "Atanh", [F64, F64], [[1., INF], [2., NAN], [3.14, NAN]])
+libm_case("ToDegrees", ":651-657", "ToDegrees", [F64, F64], [[0., 0.], [math.pi, 180.], [math.pi / 2., 90.]])
+libm_case("ToRadians", ":659-665", "ToRadians", [F64, F64], [[0., 0.], [180., math.pi], [90., math.pi / 2.]])
+
 # ---- vector_logic_test.cc:46-83: left[i] = (i % 3 == 0), right[i] = (i % 5 == 0) ----------------------------
 VL = "supersonic/expression/vector/vector_logic_test.cc"
 expr_case("VectorLogic_Or", VL + ":46-54", [BOOL, BOOL, BOOL], [[i % 3 == 0, i % 5 == 0, i % 3 == 0 or i % 5 == 0] for i in range(200)], "Or", nullable=False)

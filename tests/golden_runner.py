@@ -171,6 +171,11 @@ def check(case, schema, cols):
                 assert gv is None and wv is None, "row %d col %d: got %r want %r" % (r, c, gv, wv)
             elif isinstance(wv, float) and math.isnan(wv):
                 assert isinstance(gv, float) and math.isnan(gv), "row %d col %d: got %r want nan" % (r, c, gv)
+            elif case.get("max_ulp") and isinstance(gv, float):
+                # libm family: the reference's expectations are libm calls; the device libm agrees within a few ULP
+                from helpers import ulp_distance
+                d = float(ulp_distance(np.array([gv], dtype=np.float64), np.array([float(wv)], dtype=np.float64))[0])
+                assert d <= case["max_ulp"], "row %d col %d: got %r want %r (%g ULP)" % (r, c, gv, wv, d)
             elif isinstance(gv, float) or isinstance(wv, float):
                 # expected literals are written as in the reference's tests; compare in the column's type
                 t = cols[c][0].dtype.type

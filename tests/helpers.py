@@ -32,7 +32,18 @@ def sort_rows(cols):
     return [(d[order], None if z is None else z[order]) for d, z in cols]
 
 
-def assert_cols_equal(got, want, float_exact=True, context=""):
+def ulp_distance(g, w):
+    """Distance in units in the last place between two float64 arrays (0 for two NaNs or two equal infinities)."""
+    def key(a):
+        b = np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+        return np.where(b < 0, np.int64(-(2 ** 63)) - b, b)       # monotone integer image of the doubles
+    with np.errstate(over="ignore"):
+        d = np.abs(key(g) - key(w)).astype(np.float64)               # exact in int64 (values of like sign and magnitude)
+    both_nan = np.isnan(g) & np.isnan(w)
+    return np.where(both_nan, 0.0, np.where(np.isnan(g) != np.isnan(w), np.inf, d))
+
+
+def assert_cols_equal(got, want, float_exact=True, context="", max_ulp=0):
     assert len(got) == len(want), (context, len(got), len(want))
     for i, ((gd, gz), (wd, wz)) in enumerate(zip(got, want)):
         assert len(gd) == len(wd), "%s column %d: %d rows vs %d" % (context, i, len(gd), len(wd))
@@ -46,6 +57,11 @@ def assert_cols_equal(got, want, float_exact=True, context=""):
             bad = [j for j in range(len(g)) if g[j] != w[j]]
             assert not bad, "%s column %d: %d rows differ, first %s: got %s want %s" % (
                 context, i, len(bad), bad[:5], [g[j] for j in bad[:5]], [w[j] for j in bad[:5]])
+        elif max_ulp and g.dtype == np.float64:
+            d = ulp_distance(g, w)
+            bad = np.nonzero(d > max_ulp)[0]
+            assert len(bad) == 0, "%s column %d: %d rows beyond %d ULP, first %s: got %s want %s (ULP %s)" % (
+                context, i, len(bad), max_ulp, bad[:5], g[bad[:5]], w[bad[:5]], d[bad[:5]])
         elif float_exact or g.dtype.kind != "f":
             same = g.view(np.uint8).reshape(len(g), -1) == w.view(np.uint8).reshape(len(w), -1) if len(g) else np.ones((0, 1), bool)
             bad = np.nonzero(~same.all(axis=1))[0] if len(g) else []
@@ -55,7 +71,7 @@ def assert_cols_equal(got, want, float_exact=True, context=""):
             assert np.allclose(g, w, rtol=0, atol=0, equal_nan=True)
 
 
-def run_both(op, ctx, ignore_order=False, max_rows=1024):
+def run_both(op, ctx, ignore_order=False, max_rows=1024, max_ulp=0):
     cur = op.CreateCursor(ctx)
     got_view = ss.drain(cur, max_rows)
     oschema, want = oracle.run(op, max_rows)
@@ -63,5 +79,5 @@ def run_both(op, ctx, ignore_order=False, max_rows=1024):
     got = to_cols(got_view)
     if ignore_order:
         got, want = sort_rows(got), sort_rows(want)
-    assert_cols_equal(got, want, context=str(cur.schema()))
+    assert_cols_equal(got, want, context=str(cur.schema()), max_ulp=max_ulp)
     return got_view

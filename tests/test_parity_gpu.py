@@ -721,3 +721,49 @@ def test_sort_key_column_read_back_from_the_sorted_keys(gpu_ctx, n, descending):
     nullable = make_view(n, nullable=True)
     run_both(ss.Sort(ss.SortOrder().add("d", order), ss.ProjectNamedAttributes(["d"]), 0, ss.ScanView(nullable)), gpu_ctx)
     run_both(ss.Sort(ss.SortOrder().add("d1", order), ss.ProjectNamedAttributes(["d1"]), 0, ss.ScanView(view)), gpu_ctx)
+
+
+LIBM_ULP = 4   # device libm vs the host's (the reference calls glibc): tolerance of the libm family, DESIGN section 4
+
+
+@pytest.mark.parametrize("n", [0, 1, 513, 100003])
+def test_libm_family_within_a_few_ulp(gpu_ctx, n):
+    # EXP / LN / LOG10 / LOG2 / LOG / POW / trigonometric / hyperbolic functions (math_expressions.h:30-140): the NULL and
+    # failure rules are exact, the values agree with the host libm within LIBM_ULP units in the last place
+    rng = np.random.default_rng(21)
+    schema = ss.TupleSchema([ss.Attribute("x", ss.DOUBLE, ss.NULLABLE), ss.Attribute("u", ss.DOUBLE), ss.Attribute("p", ss.DOUBLE),
+                             ss.Attribute("k", ss.INT32), ss.Attribute("f", ss.FLOAT)])
+    x = rng.standard_normal(n) * 50.0
+    x[::7] = 0.0
+    view = ss.View(schema, [ss.Column(x, rng.random(n) < 0.1), rng.random(n) * 2.0 - 1.0, rng.integers(-6, 7, n) * 0.5,
+                            rng.integers(-5, 40, n).astype(np.int32), (rng.random(n) * 8.0).astype(np.float32)])
+    X, U, P_, K, F = NA("x"), NA("u"), NA("p"), NA("k"), NA("f")
+    groups = [
+        [("exp", ss.Exp(U)), ("exp_i", ss.Exp(K)), ("ln_n", ss.LnNulling(X)), ("ln_q", ss.LnQuiet(ss.Abs(X))), ("l10", ss.Log10Nulling(X)),
+         ("l2", ss.Log2Nulling(F)), ("l2q", ss.Log2Quiet(ss.Plus(F, ss.ConstDouble(1.0))))],
+        [("log_n", ss.LogNulling(ss.ConstDouble(10.0), X)), ("log_b", ss.LogNulling(F, K)), ("pow_n", ss.PowerNulling(X, P_)),
+         ("pow_q", ss.PowerQuiet(ss.Abs(X), U)), ("pow_i", ss.PowerNulling(K, ss.ConstInt32(3)))],
+        [("sin", ss.Sin(X)), ("cos", ss.Cos(X)), ("tan", ss.Tan(U)), ("cot", ss.Cot(ss.Plus(U, ss.ConstDouble(2.0)))), ("asin", ss.Asin(U)),
+         ("acos", ss.Acos(U)), ("atan", ss.Atan(X)), ("atan2", ss.Atan2(X, U))],
+        [("sinh", ss.Sinh(U)), ("cosh", ss.Cosh(U)), ("tanh", ss.Tanh(X)), ("asinh", ss.Asinh(X)), ("acosh", ss.Acosh(ss.Plus(ss.Abs(X), ss.ConstDouble(1.0)))),
+         ("atanh", ss.Atanh(ss.Multiply(U, ss.ConstDouble(0.99)))), ("deg", ss.ToDegrees(X)), ("rad", ss.ToRadians(K)), ("pi", ss.Multiply(ss.Pi(), U))],
+    ]
+    for g in groups:
+        e = ss.CompoundExpression()
+        for name, expr in g:
+            e.AddAs(name, expr)
+        run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx, max_ulp=LIBM_ULP)
+    # inside a filter and an aggregate (MIN / MAX / COUNT: order-independent)
+    spec = ss.AggregationSpecification().AddAggregation(ss.MAX, "y", "mx").AddAggregation(ss.MIN, "y", "mn").AddAggregation(ss.COUNT, "y", "c")
+    q = ss.ScalarAggregate(spec, ss.Compute(ss.CompoundExpression().AddAs("y", ss.LnNulling(X)),
+                                            ss.Filter(ss.Greater(ss.Sin(U), ss.ConstDouble(0.25)), ss.ProjectAllAttributes(), ss.ScanView(view))))
+    run_both(q, gpu_ctx, max_ulp=LIBM_ULP)
+
+
+def test_power_signaling_fails_on_a_negative_base_with_a_fractional_exponent(gpu_ctx):
+    schema = ss.TupleSchema([ss.Attribute("b", ss.DOUBLE), ss.Attribute("e", ss.DOUBLE)])
+    ok = ss.View(schema, [np.array([1.0, 2.0, -1.0, 0.5]), np.array([0.0, 2.0, 2.0, -1.0])])
+    run_both(ss.Compute(ss.PowerSignaling(NA("b"), NA("e")), ss.ScanView(ok)), gpu_ctx, max_ulp=LIBM_ULP)
+    bad = ss.View(schema, [np.array([1.0, -1.0]), np.array([0.5, 0.5])])
+    r = ss.Compute(ss.PowerSignaling(NA("b"), NA("e")), ss.ScanView(bad)).CreateCursor(gpu_ctx).Next(1024)
+    assert r.is_failure() and r.exception().return_code == 104
