@@ -165,7 +165,7 @@ class Gen(object):
         return ss.Compute(e, child)
 
     def aggregate_plan(self, view, grouped):
-        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("name")).Add(NA("day"))
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("name")).Add(NA("day")).Add(NA("a")).Add(NA("b")).Add(NA("k1")).Add(NA("w"))
         spec = ss.AggregationSpecification()
         if self.rng.random() < 0.4:
             spec.AddAggregation(self.pick([ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST]), "name", "rname")

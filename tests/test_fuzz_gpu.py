@@ -37,3 +37,21 @@ def test_random_plan_matches_oracle_many_tiles(gpu_ctx, seed):
     except oracle.OracleError:
         return
     run_both(op, gpu_ctx, ignore_order=not ordered)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3080))
+@pytest.mark.parametrize("partition", [0, 2])
+def test_random_high_cardinality_group_aggregate(seed, partition):
+    # ~50 k groups out of 70001 rows: the group table outgrows its first capacity (regrow + rerun) on the direct
+    # path, and the hash-partitioned execution (forced with group_partition = 2) runs with random aggregates
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", partition)
+    view = make_view(70001, seed)
+    g = Gen(seed)
+    op = g.aggregate_plan(view, True)
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(g.pick([["a", "b"], ["a", "k1"], ["w"]])), op.spec, None, op.child)
+    try:
+        oracle.run(op)
+    except oracle.OracleError:
+        return
+    run_both(op, ctx, ignore_order=True)
