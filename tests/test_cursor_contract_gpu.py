@@ -107,3 +107,19 @@ def test_repeated_runs_do_not_grow_device_memory(gpu_ctx):
         gpu_ctx.synchronize()
         free_after, _total = torch.cuda.mem_get_info(0)
         assert free_after >= free_before, (name, free_before, free_after)
+
+
+def test_recent_kernel_times_ring(gpu_ctx):
+    # ssgpu_plan_recent_kernel_ms: one (positive) duration per profiled run, oldest first, at most 256 kept
+    view = make_view(200003)
+    plan = ss.Plan(fpa_narrow(view), gpu_ctx)
+    assert plan.recent_kernel_ms() == []
+    for _ in range(5):
+        plan.run()
+    times = plan.recent_kernel_ms()
+    assert len(times) == 5 and all(t > 0.0 for t in times)
+    assert len(plan.recent_kernel_ms(3)) == 3
+    for _ in range(260):
+        plan.run()
+    assert len(plan.recent_kernel_ms(1000)) == 256
+    assert abs(plan.counters().dominant_ms - plan.recent_kernel_ms(1)[0]) < 1e-6
