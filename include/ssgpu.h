@@ -133,7 +133,10 @@ enum {
 enum { SSGPU_OP_GREATER = 100001, SSGPU_OP_GREATER_OR_EQUAL = 100002,
        /* NullingIf(cond, then, otherwise) (elementary_expressions.h:55-61): OPERATOR_IF whose NULL condition
         * gives a NULL result instead of taking the OTHERWISE branch */
-       SSGPU_OP_NULLING_IF = 100003 };
+       SSGPU_OP_NULLING_IF = 100003,
+       /* RoundWithPrecision(x, precision) (math_expressions.h): binds as OPERATOR_ROUND_WITH_MULTIPLIER(x,
+        * POW(10.0, precision)) after checking that the precision is an integer (math_bound_expressions.cc:341-382) */
+       SSGPU_OP_ROUND_WITH_PRECISION = 100004 };
 
 typedef struct ssgpu_expr {
   int32_t kind;      /* SSGPU_EXPR_* */

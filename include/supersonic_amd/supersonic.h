@@ -207,6 +207,7 @@ inline const Expression* SqrtQuiet(const Expression* a) { return internal::Op(33
 inline const Expression* SqrtNulling(const Expression* a) { return internal::Op(334, a); }
 inline const Expression* SqrtSignaling(const Expression* a) { return internal::Op(335, a); }
 // libm family (expression/core/math_expressions.h): within a few ULP of the host libm
+inline const Expression* RoundWithPrecision(const Expression* a, const Expression* precision) { return internal::Op(SSGPU_OP_ROUND_WITH_PRECISION, a, precision); }
 inline const Expression* Exp(const Expression* a) { return internal::Op(320, a); }
 inline const Expression* LnQuiet(const Expression* a) { return internal::Op(325, a); }
 inline const Expression* LnNulling(const Expression* a) { return internal::Op(326, a); }

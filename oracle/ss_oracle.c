@@ -54,7 +54,8 @@ enum { OP_ADD = 0, OP_MULTIPLY = 4, OP_SUBTRACT = 8, OP_DIVIDE_QUIET = 13, OP_DI
        OP_ACOSH = 844, OP_ATANH = 848,
        OP_SQRT_QUIET = 333, OP_SQRT_NULLING = 334, OP_SQRT_SIGNALING = 335, OP_CEIL = 342, OP_FLOOR = 346, OP_ABS = 360,
        OP_CASE = 200, OP_IF = 204, OP_IN = 208, OP_IF_NULL = 220, OP_IS_NULL = 224, OP_CAST = 265,
-       OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002, OP_NULLING_IF = 100003 };
+       OP_ROUND_WITH_MULTIPLIER = 364, OP_GREATER = 100001, OP_GREATER_OR_EQUAL = 100002, OP_NULLING_IF = 100003,
+       OP_ROUND_WITH_PRECISION = 100004 };
 
 typedef struct { int code; char msg[512]; } orc_error;
 static void set_err(orc_error* e, int code, const char* fmt, const char* a, const char* b) {
@@ -547,6 +548,19 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
       }
       return child;
     }
+    case OP_ROUND_WITH_PRECISION: {
+      /* BoundRoundWithPrecision, math_bound_expressions.cc:341-382: ROUND_WITH_MULTIPLIER(x, POW_QUIET(10.0, precision)) */
+      if (!is_integer(a[1]->dtype)) { set_err(err, RC_TYPE_MISMATCH, "Precision has to be an integer; is: %s%s", type_name(a[1]->dtype), ""); return NULL; }
+      bnode* x = make_cast(a[0], T_DOUBLE, 1, err); bnode* pr = make_cast(a[1], T_DOUBLE, 1, err); if (err->code) return NULL;
+      double ten_v = 10.0; uint64_t ten_bits; memcpy(&ten_bits, &ten_v, 8);
+      bnode* ten = make_const(T_DOUBLE, ten_bits);
+      char pn[256]; snprintf(pn, sizeof(pn), "POW(%s, %s)", ten->name, pr->name);
+      bnode* pw = bnode_new(B_OP, OP_POW_QUIET, T_DOUBLE, pr->nullable, pn); pw->args[0] = ten; pw->args[1] = pr; pw->nargs = 2;
+      pw = fold(pw, err);
+      char nm[256]; snprintf(nm, sizeof(nm), "ROUND_WITH_MULTIPLIER(%s, %s)", x->name, pw->name);
+      bnode* b = bnode_new(B_OP, OP_ROUND_WITH_MULTIPLIER, T_DOUBLE, x->nullable || pw->nullable, nm); b->args[0] = x; b->args[1] = pw; b->nargs = 2;
+      return fold(b, err);
+    }
     case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {
       /* promoting binary expressions over DOUBLE (math_bound_expressions.cc:126-148,221-228) */
       bnode* l = make_cast(a[0], T_DOUBLE, 1, err); bnode* r = make_cast(a[1], T_DOUBLE, 1, err); if (err->code) return NULL;
@@ -788,6 +802,12 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
             b->nullbuf[i] = 1;
           } else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative argument in %s%s", b->name, ""); return; }
         }
+      return;
+    }
+    case OP_ROUND_WITH_MULTIPLIER: {   /* operators::RoundWithMultiplier, math_evaluators.h:117-121 */
+      const double* A = (const double*)x->data; const double* B = (const double*)y->data; double* D = (double*)b->buf;
+      for (int64_t i = 0; i < n; ++i) D[i] = round(A[i] * B[i]) / B[i];
+      if (x->nulls || y->nulls) { or_nulls(b->nullbuf, x->nulls, y->nulls, n); b->nulls = b->nullbuf; } else b->nulls = NULL;
       return;
     }
     case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {

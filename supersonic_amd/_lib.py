@@ -33,7 +33,7 @@ ERROR_NO_DEVICE = 2000
 ERROR_HIP = 2001
 
 EXPR_ATTR_NAMED, EXPR_ATTR_AT, EXPR_CONST, EXPR_NULL, EXPR_OP, EXPR_ALIAS, EXPR_COMPOUND, EXPR_CAST = 1, 2, 3, 4, 5, 6, 7, 8
-OP_GREATER, OP_GREATER_OR_EQUAL, OP_NULLING_IF = 100001, 100002, 100003
+OP_GREATER, OP_GREATER_OR_EQUAL, OP_NULLING_IF, OP_ROUND_WITH_PRECISION = 100001, 100002, 100003, 100004
 PROJ_ALL, PROJ_NAMED, PROJ_AT, PROJ_NAMED_AS = 1, 2, 3, 4
 JOIN_INNER, JOIN_LEFT_OUTER = 0, 1
 KEYS_NOT_UNIQUE, KEYS_UNIQUE = 0, 1

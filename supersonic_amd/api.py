@@ -432,6 +432,7 @@ def Round(a): return _op(300, a)
 def Ceil(a): return _op(342, a)
 def Floor(a): return _op(346, a)
 def Trunc(a): return _op(304, a)
+def RoundWithPrecision(a, precision): return _op(L.OP_ROUND_WITH_PRECISION, a, precision)   # round(a * 10^p) / 10^p
 def RoundToInt(a): return _op(316, a)
 def CeilToInt(a): return _op(308, a)
 def FloorToInt(a): return _op(312, a)

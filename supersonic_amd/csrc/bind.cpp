@@ -24,7 +24,7 @@ enum {
   OP_BITWISE_ANDNOT = 84, OP_EQUAL = 100, OP_NOT_EQUAL = 104, OP_LESS = 116, OP_LESS_OR_EQUAL = 120,
   OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
   OP_ROUND = 300, OP_TRUNC = 304, OP_CEIL_TO_INT = 308, OP_FLOOR_TO_INT = 312, OP_ROUND_TO_INT = 316,
-  OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
+  OP_ROUND_WITH_MULTIPLIER = 364, OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
   OP_POW_NULLING = 354, OP_POW_SIGNALING = 355, OP_LOG2_QUIET = 357, OP_LOG2_NULLING = 358, OP_SIN = 800, OP_COS = 804, OP_TAN = 808,
   OP_ASIN = 812, OP_ACOS = 816, OP_ATAN = 820, OP_ATAN2 = 824, OP_SINH = 828, OP_COSH = 832, OP_TANH = 836, OP_ASINH = 840,
   OP_ACOSH = 844, OP_ATANH = 848,
@@ -298,6 +298,7 @@ static bool fold_binary(int op, int t, uint64_t a, uint64_t b, int* out_type, ui
       case OP_DIVIDE_QUIET: case OP_DIVIDE_SIGNALING: r = x / y; break;
       case OP_DIVIDE_NULLING: if (y == 0) { *out_null = true; *out = 0; return true; } r = x / y; break;
       case OP_ATAN2: r = atan2(x, y); break;
+      case OP_ROUND_WITH_MULTIPLIER: r = round(x * y) / y; break;   // operators::RoundWithMultiplier, math_evaluators.h:117-121
       case OP_POW_QUIET: r = pow(x, y); break;
       case OP_POW_NULLING: if (x < 0 && y != trunc(y)) { *out_null = true; *out = 0; return true; } r = pow(x, y); break;
       default: return false;
@@ -518,6 +519,8 @@ static Status bind_compare(int op, BExprP l, BExprP r, int depth, BExprP* out) {
   return Status::OK();
 }
 
+static ssgpu_expr x_expr_for(int op) { ssgpu_expr e; memset(&e, 0, sizeof(e)); e.kind = SSGPU_EXPR_OP; e.op = op; return e; }
+
 static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int depth, BExprP* out) {
   const int op = x.op;
   auto need = [&](size_t n) -> Status {
@@ -659,6 +662,21 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
       const bool nulling = op == OP_LN_NULLING || op == OP_LOG10_NULLING || op == OP_LOG2_NULLING;
       *out = fold(make_op(op, SSGPU_DOUBLE, c->nullable || nulling, std::string(nm) + "(" + c->name + ")", {c}, depth));
       if (nulling && (*out)->kind == BExpr::OP) (*out)->nullable = true;
+      return Status::OK();
+    }
+    case SSGPU_OP_ROUND_WITH_PRECISION: {
+      // BoundRoundWithPrecision (math_bound_expressions.cc:341-382): round(x * m) / m with m = POW_QUIET(10.0, precision)
+      SS_RETURN_IF_ERROR(need(2));
+      if (!dtype_is_integer(args[1]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("Wrong type of argument supplied. Precision has to be an integer; is: ") + dtype_name(args[1]->dtype));
+      if (!dtype_is_numeric(args[0]->dtype))
+        return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("Cannot cast ") + dtype_name(args[0]->dtype) + " to DOUBLE");
+      BExprP x, pw, ten = make_const(SSGPU_DOUBLE, to_bits(10.0));
+      SS_RETURN_IF_ERROR(make_cast(args[0], SSGPU_DOUBLE, true, &x));
+      ssgpu_expr px = x_expr_for(OP_POW_QUIET);
+      SS_RETURN_IF_ERROR(bind_operator(px, {ten, args[1]}, depth, &pw));
+      *out = fold(make_op(OP_ROUND_WITH_MULTIPLIER, SSGPU_DOUBLE, x->nullable || pw->nullable,
+                          "ROUND_WITH_MULTIPLIER(" + x->name + ", " + pw->name + ")", {x, pw}, depth));
       return Status::OK();
     }
     case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {

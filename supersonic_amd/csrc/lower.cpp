@@ -25,7 +25,7 @@ enum {
   OP_DIVIDE_SIGNALING = 15, OP_CPP_DIVIDE_NULLING = 18, OP_CPP_DIVIDE_SIGNALING = 19,
   OP_MODULUS_NULLING = 26, OP_MODULUS_SIGNALING = 27, OP_NEGATE = 36,
   OP_IS_ODD = 140, OP_IS_EVEN = 144, OP_IS_FINITE = 148, OP_IS_INF = 152, OP_IS_NAN = 156, OP_IS_NORMAL = 160,
-  OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
+  OP_ROUND_WITH_MULTIPLIER = 364, OP_EXP = 320, OP_LN_QUIET = 325, OP_LN_NULLING = 326, OP_LOG10_QUIET = 329, OP_LOG10_NULLING = 330, OP_POW_QUIET = 353,
   OP_POW_NULLING = 354, OP_POW_SIGNALING = 355, OP_LOG2_QUIET = 357, OP_LOG2_NULLING = 358, OP_SIN = 800, OP_COS = 804, OP_TAN = 808,
   OP_ASIN = 812, OP_ACOS = 816, OP_ATAN = 820, OP_ATAN2 = 824, OP_SINH = 828, OP_COSH = 832, OP_TANH = 836, OP_ASINH = 840,
   OP_ACOSH = 844, OP_ATANH = 848,
@@ -346,6 +346,12 @@ Status Emitter::value(const BExprP& e, Val* out) {
           { LInstr& i = emit(VM_MATH1_F64); i.dst = v.reg; i.a = x; i.imm = fn; }
           P->uses_math = true;
           v.null = base_null;
+        } break;
+        case OP_ROUND_WITH_MULTIPLIER: {   // round(x * m) / m: three correctly rounded IEEE operations (math_evaluators.h:117-121)
+          Val t; t.width = 8; t.reg = binop(VM_MUL_F64, a[0], a[1], 8);
+          Val r; r.width = 8; r.reg = unop(VM_ROUND_F64, t, 8);
+          v.reg = binop(VM_DIV_F64, r, a[1], 8);
+          v.null = or_null(a[0].null, a[1].null);
         } break;
         case OP_POW_QUIET: case OP_POW_NULLING: case OP_POW_SIGNALING: case OP_ATAN2: {
           int base_null = or_null(a[0].null, a[1].null);

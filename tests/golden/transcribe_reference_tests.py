@@ -185,6 +185,14 @@ bind_case("MathBindingWithCast_Sin_int32", MX + ":126-127", "Sin", [I32], [False
 bind_case("MathBindingWithCast_Cos_uint32", MX + ":128-129", "Cos", [U32], [False], "COS(CAST_UINT32_TO_DOUBLE($0))", F64, False)
 bind_case("MathBindingWithCast_Tan_uint64", MX + ":130-131", "Tan", [U64], [False], "TAN(CAST_UINT64_TO_DOUBLE($0))", F64, False)
 bind_case("MathBindingWithCast_Sin_int64", MX + ":132-133", "Sin", [I64], [False], "SIN(CAST_INT64_TO_DOUBLE($0))", F64, False)
+bind_case("RoundWithPrecisionBinding_float_int32", MX + ":97-103", "RoundWithPrecision", [F32, I32], [False, False],
+          "ROUND_WITH_MULTIPLIER(CAST_FLOAT_TO_DOUBLE($0), POW(CONST_DOUBLE, CAST_INT32_TO_DOUBLE($1)))", F64, False)
+bind_case("RoundWithPrecisionBinding_uint32_uint64", MX + ":105-110", "RoundWithPrecision", [U32, U64], [False, False],
+          "ROUND_WITH_MULTIPLIER(CAST_UINT32_TO_DOUBLE($0), POW(CONST_DOUBLE, CAST_UINT64_TO_DOUBLE($1)))", F64, False)
+bind_case("RoundWithPrecision_double_precision_fails", MX + ":112", "RoundWithPrecision", [F64, F64], [False, False], None, None, None, expect_error=402)
+libm_case("RoundWithPrecision", ":195-209", "RoundWithPrecision", [F64, I32, F64],
+          [[4., 0, 4.], [4., 2, 4.], [4., -1, 0.], [1024., -3, 1000.], [3.14, 1, 3.1], [3.141592, 4, 3.1416], [3.141592, 5, 3.14159], [-0.4, 0, -0.],
+           [-0.6, 0, -1.], [0.5, 0, 1.], [0.1, 20, 0.1]])
 libm_case("LnNulling", ":362-370", "LnNulling", [F64, F64], [[1., 0.], [1000., math.log(1000.)], [math.exp(1), 1.], [0., None], [-1., None]])
 libm_case("LnQuiet", ":372-381", "LnQuiet", [F64, F64], [[1., 0.], [1000., math.log(1000.)], [0., "-inf"], [-1., NAN]])
 libm_case("Log10Nulling", ":383-390", "Log10Nulling", [F64, F64], [[1., 0.], [1000., 3.], [0., None], [-1., None]])

@@ -767,3 +767,17 @@ def test_power_signaling_fails_on_a_negative_base_with_a_fractional_exponent(gpu
     bad = ss.View(schema, [np.array([1.0, -1.0]), np.array([0.5, 0.5])])
     r = ss.Compute(ss.PowerSignaling(NA("b"), NA("e")), ss.ScanView(bad)).CreateCursor(gpu_ctx).Next(1024)
     assert r.is_failure() and r.exception().return_code == 104
+
+
+@pytest.mark.parametrize("n", [0, 513, 100003])
+def test_round_with_precision(gpu_ctx, n):
+    # round(x * 10^p) / 10^p (math_bound_expressions.cc:341-382): a constant precision folds 10^p on the host, exactly as
+    # the reference does, and the rest is three IEEE operations -> bit-exact; a precision column goes through the device POW
+    rng = np.random.default_rng(5)
+    schema = ss.TupleSchema([ss.Attribute("x", ss.DOUBLE, ss.NULLABLE), ss.Attribute("p", ss.INT32), ss.Attribute("f", ss.FLOAT)])
+    view = ss.View(schema, [ss.Column(rng.standard_normal(n) * 1000.0, rng.random(n) < 0.1), rng.integers(-3, 6, n).astype(np.int32),
+                            (rng.random(n) * 100.0).astype(np.float32)])
+    e = (ss.CompoundExpression().AddAs("r2", ss.RoundWithPrecision(NA("x"), ss.ConstInt32(2))).AddAs("rm1", ss.RoundWithPrecision(NA("x"), ss.ConstInt64(-1)))
+         .AddAs("rf", ss.RoundWithPrecision(NA("f"), ss.ConstInt32(1))))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.Compute(ss.CompoundExpression().AddAs("rp", ss.RoundWithPrecision(NA("x"), NA("p"))), ss.ScanView(view)), gpu_ctx, max_ulp=LIBM_ULP)
