@@ -40,6 +40,15 @@ def q_min8(v):
     return ss.ScalarAggregate(spec, ss.ScanView(v))
 
 
+def q_fused4(v):
+    # all 8 columns staged by FOUR instructions (fused binary-operator sinks): what the interpreter costs per instruction
+    e = (ss.CompoundExpression().AddAs("s1", ss.Plus(NA("a"), NA("b"))).AddAs("s2", ss.Plus(NA("c"), NA("d")))
+         .AddAs("p1", ss.Multiply(NA("d0"), NA("d1"))).AddAs("p2", ss.Multiply(NA("d2"), NA("d3"))))
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "s1", "a1").AddAggregation(ss.SUM, "s2", "a2")
+            .AddAggregation(ss.SUM, "p1", "a3").AddAggregation(ss.SUM, "p2", "a4"))
+    return ss.ScalarAggregate(spec, ss.Compute(e, ss.ScanView(v)))
+
+
 def q_sum1(v):
     return ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "sa"), ss.ScanView(v))
 
@@ -129,7 +138,7 @@ def q_group2(v):
 
 
 QUERIES = {"sort": q_sort, "sort_key": q_sort_keyonly, "group2": q_group2, "add4": q_addn(4), "add16": q_addn(16), "sum4": q_sumn(4), "sum8": q_sumn(8),"wide": q_wide, "narrow": q_narrow, "stage8": q_stage8, "min8": q_min8, "sum1": q_sum1,
-           "filter_mat": q_filter_mat, "group": q_group, "group_small": q_group_small, "group_tiny": q_group_tiny, "join": q_join}
+           "fused4": q_fused4, "filter_mat": q_filter_mat, "group": q_group, "group_small": q_group_small, "group_tiny": q_group_tiny, "join": q_join}
 
 
 def main():
