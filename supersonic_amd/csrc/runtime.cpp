@@ -1332,10 +1332,14 @@ int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
 
 int check_error_flags(ssgpu_plan* p) {
   ssgpu_ctx* c = p->ctx;
-  for (auto& ex : p->exec) {
-    if (!ex.error_flag.p) continue;
-    uint32_t f = 0;
-    HIP_TRY(c, hipMemcpy(&f, ex.error_flag.p, 4, hipMemcpyDeviceToHost));
+  // The flags are written by kernels on c->stream, which is a non-blocking stream: a null-stream
+  // hipMemcpy is NOT ordered behind it and can read a flag before the run that sets (or clears) it.
+  std::vector<uint32_t> flags(p->exec.size(), 0);
+  for (size_t i = 0; i < p->exec.size(); ++i)
+    if (p->exec[i].error_flag.p)
+      HIP_TRY(c, hipMemcpyAsync(&flags[i], p->exec[i].error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t f : flags) {
     if (f) {
       c->err = f == 2 ? "Evaluation error: invalid argument of a signaling math expression (negative input of SQRT)"
                       : "Evaluation error: division by zero in a signaling expression";

@@ -94,7 +94,10 @@ def test_interrupt_from_another_thread_is_best_effort(gpu_ctx):
 
 
 def test_repeated_runs_do_not_grow_device_memory(gpu_ctx):
+    import os
     import torch
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("free device memory is shared with the other xdist workers' processes")
     view = make_view(200003, nullable=True)
     for name, op in operators(view).items():
         plan = ss.Plan(op, gpu_ctx)

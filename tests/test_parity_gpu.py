@@ -488,6 +488,27 @@ def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     run_both(op, gpu_ctx)
 
 
+def test_evaluation_error_is_ordered_behind_the_run(gpu_ctx):
+    # The error word is written by kernels on the context's (non-blocking) stream; reading it must be ordered
+    # behind the run that sets or clears it, also when that run is long and the only failing row is the last.
+    n = 12_000_000
+    a = np.arange(n, dtype=np.int64)
+    b_ok = np.ones(n, dtype=np.int64)
+    b_bad = b_ok.copy(); b_bad[-1] = 0
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64, ss.NOT_NULLABLE), ss.Attribute("b", ss.INT64, ss.NOT_NULLABLE)])
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "q", "s")
+    for _ in range(4):
+        for b, fails in ((b_bad, True), (b_ok, False)):
+            view = ss.View(schema, [a, b])
+            op = ss.ScalarAggregate(spec, ss.Compute(ss.CompoundExpression().AddAs("q", ss.DivideSignaling(NA("a"), NA("b"))),
+                                                     ss.ScanView(view)))
+            r = op.CreateCursor(gpu_ctx).Next(16)
+            if fails:
+                assert r.is_failure() and r.exception().return_code == 104
+            else:
+                assert not r.is_failure() and r.view().column(0).data[0] == float(n) * (n - 1) / 2
+
+
 def test_chained_stages(gpu_ctx):
     # Compute over a GroupAggregate result: two pipeline stages
     view = make_view(20000)
