@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- rows/sec of the fused Filter -> Project -> Aggregate path on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8(d) "Q-FPA-wide"): per GPU a device-resident
+Default workload (BASELINE.json configs[1], SURVEY.md 8(d) "Q-FPA-wide"): per GPU a device-resident
 100 M-row x 8-column Block (a,b,c,d INT64; d0..d3 DOUBLE) and the reference plan
 
     ScalarAggregate(SUM(s), COUNT(*), SUM(c), MIN(d), MAX(d0), SUM(d1), SUM(p))
@@ -9,17 +9,25 @@ Workload (BASELINE.json configs[1], SURVEY.md 8(d) "Q-FPA-wide"): per GPU a devi
       o Compute(a, a+b AS s, c, d, d0, d1, d2*d3 AS p)
       o ScanView(block)
 
-One "step" = one full pass of that plan over the block (inputs already in HBM).  With N > 1
-ranks every rank owns an independent row-range shard of the same size (weak scaling) and a
-step also all-reduces the partial aggregates over RCCL and finalises them.
+`--query group` is BASELINE configs[2] / configs[3] ("Q-GROUP-F"): Filter(a > 499) ->
+GroupAggregate(k1, k2; SUM / MIN / MAX x d0..d3), ~1e5 groups; with N > 1 ranks every rank aggregates
+its row-range shard and the partial tables meet in ONE RCCL all-gather followed by a merge plan
+(supersonic_amd.distributed.DeviceShardedGroupAggregate).
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (64 B/row x rows per
-launch) / average duration of the pipeline kernel measured with HIP events on the launch
-stream inside the library (ssgpu_plan_counters.dominant_ms).
+One "step" = one full pass of the plan over the resident rows (inputs already in HBM).  `--scaling
+weak` (default): --rows rows PER GPU; `--scaling strong`: --rows rows IN TOTAL, split into row ranges.
+`--gpus N` with N > 1 re-executes itself under `python -m torch.distributed.run` (one rank per GPU)
+unless it is already running under it (RANK / WORLD_SIZE set by the launcher).
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / average duration
+of the plan's kernels measured with HIP events on the launch stream inside the library.
+`--dry-run` (CPU, gloo, no kernels) exercises only the launch / collective / report plumbing and says
+so in the line (`"dry_run": true`, value 0): it is what the CPU test of the N > 1 path runs.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,9 +37,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 K_FILTER = 499
+N_GROUPS = 100000
 
 
-def build_plan(ss, view):
+# ---- the two workloads ------------------------------------------------------------------------
+def build_plan(ss, view, k_filter=K_FILTER):
     NA = ss.NamedAttribute
     compute = (ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))).Add(NA("c")).Add(NA("d"))
                .Add(NA("d0")).Add(NA("d1")).AddAs("p", ss.Multiply(NA("d2"), NA("d3"))))
@@ -39,7 +49,7 @@ def build_plan(ss, view):
             .AddAggregation(ss.SUM, "c", "sum_c").AddAggregation(ss.MIN, "d", "min_d")
             .AddAggregation(ss.MAX, "d0", "max_d0").AddAggregation(ss.SUM, "d1", "sum_d1")
             .AddAggregation(ss.SUM, "p", "sum_p"))
-    return ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(K_FILTER)), ss.ProjectAllAttributes(),
+    return ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(k_filter)), ss.ProjectAllAttributes(),
                                               ss.Compute(compute, ss.ScanView(view))))
 
 
@@ -48,20 +58,69 @@ def bench_schema(ss):
                           [ss.Attribute(n, ss.DOUBLE) for n in ("d0", "d1", "d2", "d3")])
 
 
-def gen_device_columns(torch, rows, seed, device):
+def group_schema(ss):
+    return ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("k1", ss.INT32), ss.Attribute("k2", ss.INT32)] +
+                          [ss.Attribute(n, ss.DOUBLE) for n in ("d0", "d1", "d2", "d3")])
+
+
+def group_spec(ss):
+    spec = ss.AggregationSpecification()
+    for c in ("d0", "d1", "d2", "d3"):
+        spec.AddAggregation(ss.SUM, c, "sum_" + c).AddAggregation(ss.MIN, c, "min_" + c).AddAggregation(ss.MAX, c, "max_" + c)
+    return spec
+
+
+def group_child(ss, view):
+    return ss.Filter(ss.Greater(ss.NamedAttribute("a"), ss.ConstInt64(K_FILTER)), ss.ProjectAllAttributes(), ss.ScanView(view))
+
+
+def build_group_plan(ss, view):
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), group_spec(ss), None, group_child(ss, view))
+
+
+def gen_device_columns(torch, rows, seed, device, row0=0):
     """Synthetic block of SURVEY 8(d): every partial DOUBLE sum is exact, so the result is
     bit-exact under any reduction order."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     a = torch.randint(0, 1000, (rows,), generator=g, device=device, dtype=torch.int64)
     b = torch.randint(0, 1000, (rows,), generator=g, device=device, dtype=torch.int64)
-    c = torch.arange(rows, device=device, dtype=torch.int64) % 100000
+    c = (torch.arange(rows, device=device, dtype=torch.int64) + row0) % 100000
     d = torch.randint(-(1 << 62), 1 << 62, (rows,), generator=g, device=device, dtype=torch.int64)
     d0 = torch.randint(-1000000, 1000001, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64)
     d1 = torch.randint(0, 4000, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64) * 0.25
     d2 = torch.randint(0, 64, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64)
     d3 = torch.randint(0, 64, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64)
     return [a, b, c, d, d0, d1, d2, d3]
+
+
+def gen_group_columns(torch, rows, seed, device):
+    """a | k1 = g / 317, k2 = g % 317 with g uniform in [0, 1e5) | d0..d3 as above."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    a = torch.randint(0, 1000, (rows,), generator=g, device=device, dtype=torch.int64)
+    grp = torch.randint(0, N_GROUPS, (rows,), generator=g, device=device, dtype=torch.int64)
+    k1 = (grp // 317).to(torch.int32)
+    k2 = (grp % 317).to(torch.int32)
+    del grp
+    d0 = torch.randint(-1000000, 1000001, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64)
+    d1 = torch.randint(0, 4000, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64) * 0.25
+    d2 = torch.randint(0, 64, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64)
+    d3 = torch.randint(0, 64, (rows,), generator=g, device=device, dtype=torch.int64).to(torch.float64)
+    return [a, k1, k2, d0, d1, d2, d3]
+
+
+def host_columns(np, query, n, seed=42):
+    rng = np.random.default_rng(seed)
+    if query == "group":
+        grp = rng.integers(0, N_GROUPS, n)
+        return [rng.integers(0, 1000, n), (grp // 317).astype(np.int32), (grp % 317).astype(np.int32),
+                rng.integers(-1000000, 1000001, n).astype(np.float64), rng.integers(0, 4000, n) * 0.25,
+                rng.integers(0, 64, n).astype(np.float64), rng.integers(0, 64, n).astype(np.float64)]
+    return [rng.integers(0, 1000, n), rng.integers(0, 1000, n), np.arange(n, dtype=np.int64) % 100000,
+            rng.integers(-(1 << 62), 1 << 62, n), rng.integers(-1000000, 1000001, n).astype(np.float64),
+            rng.integers(0, 4000, n) * 0.25, rng.integers(0, 64, n).astype(np.float64),
+            rng.integers(0, 64, n).astype(np.float64)]
 
 
 class _DevPtr(object):
@@ -77,7 +136,7 @@ def pmc_traffic(alg_bytes):
     counters cannot be read from inside the timed process, so the value is only reported
     when the committed pass measured the same workload (same algorithmic bytes)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             with open(path) as f:
                 j = json.load(f)
@@ -88,55 +147,236 @@ def pmc_traffic(alg_bytes):
     return None
 
 
-def cpu_baseline(ss, sample_rows):
-    """The oracle (CPU restatement of the reference's 1024-row pull model) on a bounded sample of
-    the same workload, 1 thread (the reference is single-threaded per plan)."""
+# ---- CPU baseline: the oracle (CPU restatement of the reference's 1024-row pull model) ----------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ss, query, sample_rows, budget_s=10.0):
+    """1 thread (the reference is single-threaded per plan) AND N threads over row-range shards of the same
+    sample (the ctypes calls into the C restatement release the GIL; the merge of N one-row / N partial
+    results is not timed: microseconds), plus BASELINE configs[0]'s exact shape (1 M rows x 4 INT64)."""
+    import threading
     import numpy as np
     from oracle import oracle
-    rng = np.random.default_rng(42)
     n = sample_rows
-    cols = [rng.integers(0, 1000, n), rng.integers(0, 1000, n), np.arange(n, dtype=np.int64) % 100000,
-            rng.integers(-(1 << 62), 1 << 62, n), rng.integers(-1000000, 1000001, n).astype(np.float64),
-            rng.integers(0, 4000, n) * 0.25, rng.integers(0, 64, n).astype(np.float64),
-            rng.integers(0, 64, n).astype(np.float64)]
-    view = ss.View(bench_schema(ss), cols)
-    op = build_plan(ss, view)
-    reps, elapsed = 0, 0.0
-    while elapsed < 12.0 and reps < 200:
+    schema = group_schema(ss) if query == "group" else bench_schema(ss)
+    make = (lambda v: build_group_plan(ss, v)) if query == "group" else (lambda v: build_plan(ss, v))
+    cols = host_columns(np, query, n)
+
+    def drain(op):
         cur = oracle.Cursor(op)
         t0 = time.perf_counter()
-        out_rows = cur.drain_discard()
-        elapsed += time.perf_counter() - t0
+        cur.drain_discard()
+        return time.perf_counter() - t0
+
+    op = make(ss.View(schema, cols))
+    reps, elapsed = 0, 0.0
+    while elapsed < budget_s and reps < 200:
+        elapsed += drain(op)
         reps += 1
-        assert out_rows == 1
-    return {"value": n * reps / elapsed, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": "%d rows x 8 cols (same plan, seed 42), %d passes, %.1f s of CPU; host has %d cores" % (
-                n, reps, elapsed, os.cpu_count() or 0)}
+    one = n * reps / elapsed
+    # N threads: one contiguous row range per thread
+    nproc = os.cpu_count() or 1
+    nthreads = max(1, min(nproc, 64))
+    bounds = [n * i // nthreads for i in range(nthreads + 1)]
+    ops = [make(ss.View(schema, [c[bounds[i]:bounds[i + 1]] for c in cols])) for i in range(nthreads)]
+    preps, pelapsed = 0, 0.0
+    while pelapsed < budget_s / 2 and preps < 200:
+        threads = [threading.Thread(target=drain, args=(o,)) for o in ops]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        pelapsed += time.perf_counter() - t0
+        preps += 1
+    out = {"value": one, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": "%d rows (same plan, seed 42), %d passes, %.1f s of CPU" % (n, reps, elapsed),
+           "threads": {"value": n * preps / pelapsed, "cores": nthreads,
+                       "sample": "%d row-range shards of the same sample, %d passes, %.1f s" % (nthreads, preps, pelapsed)},
+           "host": {"nproc": nproc, "model": _cpu_model()}}
+    # BASELINE configs[0]: Compute(a+b) -> Filter(a>K) -> Sum/Count on a 1 M-row x 4 INT64 table
+    rng = np.random.default_rng(42)
+    m = 1000000
+    s4 = ss.TupleSchema([ss.Attribute(x, ss.INT64) for x in ("a", "b", "c", "d")])
+    v4 = ss.View(s4, [rng.integers(0, 1000, m), rng.integers(0, 1000, m), np.arange(m, dtype=np.int64) % 100000, rng.integers(-(1 << 62), 1 << 62, m)])
+    NA = ss.NamedAttribute
+    op4 = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.COUNT, "a", "cnt"),
+                             ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(K_FILTER)), ss.ProjectAllAttributes(),
+                                       ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))), ss.ScanView(v4))))
+    r4, e4 = 0, 0.0
+    while e4 < 2.0 and r4 < 500:
+        e4 += drain(op4)
+        r4 += 1
+    out["config0"] = {"value": m * r4 / e4, "unit": "rows/s", "cores": 1,
+                      "sample": "1M rows x 4 INT64: Compute(a, a+b) -> Filter(a>499) -> SUM, COUNT; %d passes" % r4}
+    return out
 
 
-def main():
+# ---- launch plumbing ----------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(n):
+    """`bench.py --gpus N` started by hand: become N ranks (one per GPU) on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU")
-    ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--query", choices=["wide", "group"], default="wide")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also report 1 % / 99 % selectivity and the PCIe-inclusive rate (N = 1)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
     ap.add_argument("--no-events-in-loop", action="store_true",
                     help="do not record the per-kernel HIP events during the timed steps (kernel time from a separate loop)")
     ap.add_argument("--force-distributed", action="store_true",
-                    help="take the N > 1 code path (run_partial + RCCL all-reduce + finalize) even with one rank")
-    args = ap.parse_args()
+                    help="take the N > 1 code path (partial run + RCCL exchange + merge / finalize) even with one rank")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU / gloo, no kernels: only the launch, collective and report plumbing (tests)")
+    return ap.parse_args(argv)
+
+
+def metric_name(query):
+    return ("rows/sec filter->project->aggregate, 100M x 8 INT64/DOUBLE" if query == "wide"
+            else "rows/sec filter->group-aggregate (2 INT32 keys, 1e5 groups, SUM/MIN/MAX x 4 DOUBLE)")
+
+
+def dry_run(args, world, rank):
+    """The N > 1 plumbing without a GPU: same launch contract, same collective shape (an all-gather of a small
+    per-rank state + a fold), same barrier / max-over-ranks timing, same report -- no kernels, value 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1 or args.force_distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if "RANK" in os.environ:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    state = torch.full((56,), rank, dtype=torch.int64)
+    gathered = torch.empty(world * 56, dtype=torch.int64)   # gloo wants the flat form
+    collectives = 0
+
+    def step():
+        nonlocal collectives
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(gathered, state)
+            collectives += 1
+            gathered.view(world, 56).sum(0)
+
+    for _ in range(args.warmup):
+        step()
+    if dist.is_initialized():
+        dist.barrier()
+    collectives = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        assert gathered.view(world, 56)[:, 0].tolist() == list(range(world))
+    if rank == 0:
+        rows = args.rows if args.scaling == "weak" else args.rows // world
+        print(json.dumps({"metric": metric_name(args.query), "value": 0.0, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "int64/f64", "data": "none (dry run)", "dry_run": True,
+                          "config": {"workload": "dry run of --query %s: no kernels" % args.query, "rows_per_gpu": rows,
+                                     "collectives_per_step": collectives / max(args.steps, 1)}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extras(ss, torch, ctx, device, rows, cols, view):
+    """Secondary figures (N = 1): the headline plan at 1 % / 99 % selectivity, and the PCIe-inclusive rate of the
+    same plan over a pinned host block (staged on the copy stream, then run) -- never `value`."""
+    import ctypes as C
+    import numpy as np
+    out = {}
+    for name, k in (("selectivity_1pct", 989), ("selectivity_99pct", 9)):
+        plan = ss.Plan(build_plan(ss, view, k), ctx)
+        for _ in range(5):
+            plan.run(view)
+        ms = plan.recent_kernel_ms(256)[-3:]
+        out[name] = {"filter": "a > %d" % k, "kernel_ms": sum(ms) / len(ms), "rows_per_s": rows / (sum(ms) / len(ms) / 1e3)}
+        del plan
+    # PCIe-inclusive: 16 M rows x 8 columns (1 GB) from pinned host memory
+    n = min(rows, 16_000_000)
+    host = host_columns(np, "wide", n)
+    schema = bench_schema(ss)
+    lib = ctx.lib
+    blk = C.c_void_p()
+    from supersonic_amd import _lib as L
+    attrs = (L.Attr * 8)(*[L.Attr(schema.attribute(i).name().encode(), schema.attribute(i).type(), 0) for i in range(8)])
+    ctx.check(lib.ssgpu_block_create(ctx.handle, attrs, 8, n, C.byref(blk)))
+    pinned = []
+    for c in host:
+        p = C.c_void_p()
+        ctx.check(lib.ssgpu_host_alloc(ctx.handle, c.nbytes, C.byref(p)))
+        C.memmove(p, c.ctypes.data, c.nbytes)
+        pinned.append(p)
+    plan = ss.Plan(build_plan(ss, ss.DeviceView(schema, [(0, 0)] * 8, n)), ctx)
+    best = None
+    for _ in range(3):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for i, p in enumerate(pinned):
+            ctx.check(lib.ssgpu_block_upload(blk, i, p, None, 0, n))
+        res = C.c_void_p()
+        ctx.check(lib.ssgpu_plan_run_block(plan.handle, blk, C.byref(res)))
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["pcie_inclusive"] = {"rows": n, "bytes": n * 64, "seconds": best, "rows_per_s": n / best, "GB_per_s": n * 64 / best / 1e9,
+                             "note": "8 pinned host columns -> device block on the copy stream -> plan; best of 3"}
+    for p in pinned:
+        lib.ssgpu_host_free(ctx.handle, p)
+    lib.ssgpu_block_destroy(blk)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)          # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import torch
     import supersonic_amd as ss
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or args.force_distributed
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -162,17 +402,36 @@ def main():
     if args.grid_limit:
         ctx.set_option("grid_limit", args.grid_limit)
 
-    rows = args.rows
-    cols = gen_device_columns(torch, rows, 42 + rank, device)
+    # rows of this rank: a contiguous row range of the job
+    if args.scaling == "strong":
+        lo, hi = args.rows * rank // world, args.rows * (rank + 1) // world
+        rows, row_offset, total_rows_per_step = hi - lo, lo, args.rows
+    else:
+        rows, row_offset, total_rows_per_step = args.rows, rank * args.rows, args.rows * world
+    group = args.query == "group"
+    if group:
+        cols = gen_group_columns(torch, rows, 42 + rank, device)
+        schema = group_schema(ss)
+    else:
+        cols = gen_device_columns(torch, rows, 42 + rank, device, row_offset)
+        schema = bench_schema(ss)
     torch.cuda.synchronize(device)
-    view = ss.DeviceView(bench_schema(ss), [(t.data_ptr(), 0) for t in cols], rows)
-    plan = ss.Plan(build_plan(ss, view), ctx)
-    row_offset = rank * rows
+    view = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in cols], rows)
+    job = None
+    if group and distributed:
+        from supersonic_amd.distributed import DeviceShardedGroupAggregate
+        job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], group_spec(ss), group_child(ss, view))
+        plan = job.first
+    else:
+        plan = ss.Plan(build_group_plan(ss, view) if group else build_plan(ss, view), ctx)
 
     seg_tensors = None
 
     def step():
         nonlocal seg_tensors
+        if job is not None:
+            job.step()
+            return
         if not distributed:
             plan.run(view)
             return
@@ -197,20 +456,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # the library records HIP events around the pipeline kernel of every run on its launch stream and keeps
-    # the last 256 pairs: the timed steps stay fully asynchronous and their kernel durations are read afterwards
+    # the library records HIP events around the stage's kernels of every run on its launch stream and keeps
+    # the last 256 pairs: the timed steps stay asynchronous and their kernel durations are read afterwards
     ctx.set_option("profile", 0 if args.no_events_in_loop else 1)
-    ctx.set_option("profile_total", 0)      # only the pair around the pipeline kernel, not the whole-run pair
+    ctx.set_option("profile_total", 0)      # only the pair around the stage's kernels, not the whole-run pair
     for _ in range(args.warmup):
         step()
+    if job is not None:
+        while not job.check():               # set-up: the image capacity every rank agreed on holds every partial table
+            step()
     barrier()
     t0 = time.perf_counter()
-    dom_ms = []
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # the per-kernel clock: the HIP events the library recorded around the pipeline kernel of the TIMED
+    # the per-kernel clock: the HIP events the library recorded around the stage's kernels of the TIMED
     # steps (the most recent min(K, 256) of them); without them, a dedicated loop after the timed region
     kernel_ms = [] if args.no_events_in_loop else plan.recent_kernel_ms(256)[-args.steps:]
     if not kernel_ms:
@@ -220,37 +481,54 @@ def main():
             torch.cuda.synchronize(device)
             kernel_ms.append(plan.counters().dominant_ms)
     counters = plan.counters()
+    if job is not None and not job.check():
+        raise SystemExit("a partial group table outgrew the agreed image capacity inside the timed region")
 
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = plan.fetch()
+    result = (job.result()[0] if job is not None else plan).fetch()
     if rank == 0:
-        total_rows = rows * world * args.steps
-        value = total_rows / elapsed
+        value = total_rows_per_step * args.steps / elapsed
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
-        alg_bytes = counters.algorithmic_bytes  # 64 B/row x rows of one launch
+        alg_bytes = counters.algorithmic_bytes  # bytes/row of the staged input columns x rows of one launch
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        if group:
+            workload = ("Q-GROUP-F: GroupAggregate(k1,k2; SUM/MIN/MAX x d0..d3) o Filter(a>499) over a device-resident %d-row x 7-col "
+                        "block per GPU (~1e5 groups)" % rows)
+            par = ("row-range shards x%d: per-shard GroupAggregate, ONE RCCL all-gather of the packed partial tables, merge plan" % world
+                   if distributed else "single GPU")
+            kernel = "group stage (partition scatter + per-partition aggregation kernels)"
+            result_row = {"groups": result.row_count()}
+        else:
+            workload = ("Q-FPA-wide: SUM(a+b),COUNT(*),SUM(c),MIN(d),MAX(d0),SUM(d1),SUM(d2*d3) WHERE a>499 "
+                        "over a device-resident %d-row x 8-col block per GPU" % rows)
+            par = ("row-range shards x%d, one RCCL all-gather of the partial-aggregate state + one fold kernel per step" % world
+                   if distributed else "single GPU")
+            kernel = "ssgpu_pipeline_kernel"
+            result_row = [result.column(i).data[0].item() for i in range(result.column_count())]
         line = {
-            "metric": "rows/sec filter->project->aggregate, 100M x 8 INT64/DOUBLE",
+            "metric": metric_name(args.query),
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64/f64", "data": "synthetic",
-            "config": {"workload": "Q-FPA-wide: SUM(a+b),COUNT(*),SUM(c),MIN(d),MAX(d0),SUM(d1),SUM(d2*d3) WHERE a>499 "
-                                   "over a device-resident %d-row x 8-col block per GPU" % rows,
-                       "rows_per_gpu": rows, "parallelism": "row-range shards x%d, one RCCL all-gather of the partial-aggregate state + one fold kernel per step" % world
-                       if distributed else "single GPU",
+            "config": {"workload": workload, "rows_per_gpu": rows, "parallelism": par,
                        "tile_rows": counters.tile_rows, "grid": counters.grid, "lds_bytes": counters.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(alg_bytes),
-                         "kernel": "ssgpu_pipeline_kernel", "kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_row": alg_bytes / max(rows, 1)},
-            "result_row": [result.column(i).data[0].item() for i in range(result.column_count())],
+            "result_row": result_row,
         }
+        if job is not None:
+            line["config"]["collectives_per_step"] = job.collectives
+            line["config"]["image_capacity_rows"] = job.capacity
+        if world == 1 and args.extras and not group:
+            line["extras"] = extras(ss, torch, ctx, device, rows, cols, view)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ss, args.cpu_sample_rows)
+            line["cpu_baseline"] = cpu_baseline(ss, args.query, args.cpu_sample_rows or (4_000_000 if group else 16_000_000))
         # RCCL prints its version banner through C stdio (still buffered when stdout is a file):
         # drain it first so that the JSON line is the LAST line of stdout
         try:

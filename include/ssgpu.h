@@ -346,6 +346,31 @@ int32_t ssgpu_plan_partial_segments(ssgpu_plan* plan, ssgpu_partial_segment* out
 int ssgpu_plan_fold_partials(ssgpu_plan* plan, const void* images, int32_t n_images);
 int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
 
+/* ---- result images: the ONE-collective exchange of materialised results ----------------------
+ * Multi-GPU GroupAggregate over row-range shards (the reference documents the same
+ * external pattern -- aggregate per shard, shuffle, final aggregate -- at cursor/core/aggregate.h:236-242):
+ * every rank packs its partial group table into ONE contiguous device buffer of a size all ranks
+ * agree on (an "image": 64-byte header with the row count, then every column's data and NULL mask
+ * padded to `capacity_rows`), ONE all-gather moves the images, and ssgpu_images_unpack lays the
+ * n_images tables out as the contiguous columns of a (n_images * capacity_rows)-row View plus a
+ * trailing BOOL validity column (1 for real rows, 0 for padding) that the merge plan filters on.
+ * Row counts travel inside the images: nothing between the per-shard run and the merge run reads
+ * a device value on the host.  All three calls are asynchronous on the context's stream.
+ *   image_bytes / unpacked_bytes: sizes of one image and of the unpacked table;
+ *   offsets[4 * i + 0..3] for attribute i: data / NULL-mask offset inside an image, data / NULL-mask
+ *     offset inside the unpacked buffer (-1: not nullable); entry n_attrs (the validity column)
+ *     has only the unpacked data offset. `offsets` may be NULL.
+ * A table with more rows than capacity_rows is truncated and flagged in the header (word 2), and a
+ * run that hit an evaluation error (signaling division, SQRT ...) carries its error word (word 4);
+ * ssgpu_images_unpack leaves {largest row count seen, sum of row counts, any overflow, OR of the
+ * error words} as four int64 at the end of the unpacked buffer (unpacked_bytes - 32) for the
+ * caller's final check. */
+int ssgpu_plan_image_layout(const ssgpu_plan* plan, int64_t capacity_rows, int32_t n_images,
+                            int64_t* image_bytes, int64_t* unpacked_bytes, int64_t* offsets);
+int ssgpu_result_pack_image(ssgpu_result* r, int64_t capacity_rows, void* image);
+int ssgpu_images_unpack(ssgpu_plan* plan, const void* images, int32_t n_images, int64_t capacity_rows,
+                        void* unpacked, ssgpu_column* cols /* attr_count + 1 */);
+
 /* ---- result (ResultView / View) ------------------------------------------- */
 void ssgpu_result_destroy(ssgpu_result* r);
 int64_t ssgpu_result_row_count(ssgpu_result* r);

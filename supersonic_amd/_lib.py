@@ -134,6 +134,9 @@ SYMBOLS = [
     ("ssgpu_plan_partial_segments", C.c_int32, [P, C.POINTER(PartialSegment), C.c_int32]),
     ("ssgpu_plan_fold_partials", C.c_int, [P, P, C.c_int32]),
     ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
+    ("ssgpu_plan_image_layout", C.c_int, [P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("ssgpu_result_pack_image", C.c_int, [P, C.c_int64, P]),
+    ("ssgpu_images_unpack", C.c_int, [P, P, C.c_int32, C.c_int64, P, C.POINTER(Column)]),
     ("ssgpu_result_destroy", None, [P]),
     ("ssgpu_result_row_count", C.c_int64, [P]),
     ("ssgpu_result_column_count", C.c_int32, [P]),

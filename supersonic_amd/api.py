@@ -990,6 +990,32 @@ class Plan(object):
             ptrs.append((col.data or 0, col.is_null or 0))
         return DeviceView(self.result_schema, ptrs, rows)
 
+    # -- result images (ONE-collective exchange of materialised results, ssgpu.h) -----------
+    def image_layout(self, capacity_rows, n_images=1):
+        """(image_bytes, unpacked_bytes, offsets) -- offsets[i] = (image data, image NULL mask, unpacked data,
+        unpacked NULL mask) byte offsets of attribute i (-1 = none); the last entry is the validity column."""
+        n = self.result_schema.attribute_count()
+        ib, ub = C.c_int64(), C.c_int64()
+        offs = (C.c_int64 * (4 * (n + 1)))()
+        self.ctx.check(self.lib.ssgpu_plan_image_layout(self.handle, capacity_rows, n_images, C.byref(ib), C.byref(ub), offs))
+        return ib.value, ub.value, [tuple(offs[4 * i: 4 * i + 4]) for i in range(n + 1)]
+
+    def pack_image(self, capacity_rows, image_ptr, res=None):
+        """Pack the (device-resident) result into one image at the device pointer `image_ptr` (async)."""
+        self.ctx.check(self.lib.ssgpu_result_pack_image(res or self._result, capacity_rows, C.c_void_p(image_ptr)))
+
+    def unpack_images(self, images_ptr, n_images, capacity_rows, unpacked_ptr):
+        """n_images gathered images of THIS plan's result schema -> the columns of one
+        (n_images * capacity_rows)-row table at `unpacked_ptr` (async).  Returns a DeviceView whose
+        schema is the result schema plus a trailing NOT NULL BOOL column "__valid"."""
+        n = self.result_schema.attribute_count()
+        cols = (L.Column * (n + 1))()
+        self.ctx.check(self.lib.ssgpu_images_unpack(self.handle, C.c_void_p(images_ptr), n_images, capacity_rows,
+                                                    C.c_void_p(unpacked_ptr), cols))
+        attrs = [self.result_schema.attribute(i) for i in range(n)] + [Attribute("__valid", BOOL, NOT_NULLABLE)]
+        return DeviceView(TupleSchema(attrs), [(cols[i].data or 0, cols[i].is_null or 0) for i in range(n + 1)],
+                          n_images * capacity_rows)
+
     def counters(self):
         c = L.Counters()
         self.ctx.check(self.lib.ssgpu_plan_counters(self.handle, C.byref(c)))

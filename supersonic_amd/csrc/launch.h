@@ -125,4 +125,25 @@ hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const v
 hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
                                       const GroupAggOut* outs, uint32_t n_out, hipStream_t s);
 
+// result images (exchange_kernels.hip): one piece = one column's data or NULL mask
+struct ImagePiece { const void* src; unsigned long long image_off; unsigned long long unpacked_off; unsigned int width; unsigned int pad; };
+#define SSGPU_IMAGE_MAX_PIECES 92   /* kernel arguments stay under 4 KiB */
+#define SSGPU_IMAGE_HEADER 64
+struct ImagePackParams {
+  void* image;
+  const unsigned long long* rows_dev;   // device row count of the result, or null: rows_host
+  unsigned long long rows_host, capacity;
+  unsigned int n_pieces, n_flags;
+  const unsigned int* error_flags[8];   // evaluation-error words of the plan's stages (header word 4 = their OR)
+  ImagePiece pieces[SSGPU_IMAGE_MAX_PIECES];
+};
+struct ImageUnpackParams {
+  const void* images; void* unpacked;
+  unsigned long long image_bytes, capacity, valid_off, trailer_off;
+  unsigned int n_pieces, n_images;
+  ImagePiece pieces[SSGPU_IMAGE_MAX_PIECES];
+};
+hipError_t ssgpu_launch_pack_image(const ImagePackParams& P, hipStream_t s);
+hipError_t ssgpu_launch_unpack_images(const ImageUnpackParams& P, hipStream_t s);
+
 #endif  // SSGPU_LAUNCH_H_

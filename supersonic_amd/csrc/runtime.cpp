@@ -1588,3 +1588,106 @@ int ssgpu_plan_counters(ssgpu_plan* p, ssgpu_counters* out) {
 }
 
 }  // extern "C"
+
+// ---- result images (ssgpu.h "result images"): layout shared by pack, unpack and the host mirrors ----
+namespace {
+struct ImageLayout {
+  int64_t image_bytes = 0, unpacked_bytes = 0, valid_off = 0, trailer_off = 0;
+  std::vector<int64_t> img_data, img_null, unp_data, unp_null;   // per attribute; -1 = no NULL mask
+  std::vector<uint32_t> width;
+};
+int64_t align16(int64_t v) { return (v + 15) & ~int64_t(15); }
+bool image_layout(const Schema& schema, int64_t cap, int32_t n_images, ImageLayout* L) {
+  if (cap < 0 || n_images < 1 || schema.size() * 2 > SSGPU_IMAGE_MAX_PIECES) return false;
+  const size_t n = schema.size();
+  L->img_data.assign(n, -1); L->img_null.assign(n, -1); L->unp_data.assign(n, -1); L->unp_null.assign(n, -1); L->width.assign(n, 0);
+  int64_t io = SSGPU_IMAGE_HEADER, uo = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int w = dtype_width(schema[i].dtype);
+    if (w == 0) return false;
+    L->width[i] = (uint32_t)w;
+    L->img_data[i] = io; io = align16(io + cap * w);
+    L->unp_data[i] = uo; uo = align16(uo + (int64_t)n_images * cap * w);
+    if (schema[i].nullable) {
+      L->img_null[i] = io; io = align16(io + cap);
+      L->unp_null[i] = uo; uo = align16(uo + (int64_t)n_images * cap);
+    }
+  }
+  L->image_bytes = io;
+  L->valid_off = uo; uo = align16(uo + (int64_t)n_images * cap);
+  L->trailer_off = uo; uo += 32;
+  L->unpacked_bytes = uo;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int ssgpu_plan_image_layout(const ssgpu_plan* p, int64_t capacity_rows, int32_t n_images, int64_t* image_bytes,
+                            int64_t* unpacked_bytes, int64_t* offsets) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ImageLayout L;
+  if (!image_layout(p->result_schema, capacity_rows, n_images, &L)) {
+    p->ctx->err = "result images need fixed-width columns, at most 46 of them, and a non-negative capacity";
+    return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  }
+  if (image_bytes) *image_bytes = L.image_bytes;
+  if (unpacked_bytes) *unpacked_bytes = L.unpacked_bytes;
+  if (offsets) {
+    const size_t n = p->result_schema.size();
+    for (size_t i = 0; i < n; ++i) { offsets[4 * i] = L.img_data[i]; offsets[4 * i + 1] = L.img_null[i]; offsets[4 * i + 2] = L.unp_data[i]; offsets[4 * i + 3] = L.unp_null[i]; }
+    offsets[4 * n] = -1; offsets[4 * n + 1] = -1; offsets[4 * n + 2] = L.valid_off; offsets[4 * n + 3] = -1;
+  }
+  return SSGPU_OK;
+}
+
+int ssgpu_result_pack_image(ssgpu_result* r, int64_t capacity_rows, void* image) {
+  if (!r || !r->plan || r->plan->exec.empty() || !image) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
+  if (c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  ImageLayout L;
+  if (!image_layout(p->result_schema, capacity_rows, 1, &L)) { c->err = "result images need fixed-width columns and a non-negative capacity"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  StageExec& ex = p->exec.back();
+  ImagePackParams P; memset(&P, 0, sizeof(P));
+  P.image = image; P.capacity = (unsigned long long)capacity_rows;
+  if (ex.out_rows >= 0) P.rows_host = (unsigned long long)ex.out_rows; else P.rows_dev = ex.total.as<unsigned long long>();
+  for (auto& sx : p->exec) if (sx.error_flag.p && P.n_flags < 8) P.error_flags[P.n_flags++] = sx.error_flag.as<unsigned int>();
+  for (size_t i = 0; i < ex.out.size(); ++i) {
+    ImagePiece& d = P.pieces[P.n_pieces++];
+    d.src = ex.out[i].data.p; d.image_off = (unsigned long long)L.img_data[i]; d.width = L.width[i];
+    if (L.img_null[i] >= 0) {
+      ImagePiece& z = P.pieces[P.n_pieces++];
+      z.src = ex.out[i].nullable ? ex.out[i].nulls.p : nullptr; z.image_off = (unsigned long long)L.img_null[i]; z.width = 1;
+    }
+  }
+  HIP_TRY(c, ssgpu_launch_pack_image(P, c->stream));
+  return SSGPU_OK;
+}
+
+int ssgpu_images_unpack(ssgpu_plan* p, const void* images, int32_t n_images, int64_t capacity_rows, void* unpacked, ssgpu_column* cols) {
+  if (!p || !images || !unpacked || !cols) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  ImageLayout L;
+  if (!image_layout(p->result_schema, capacity_rows, n_images, &L)) { c->err = "result images need fixed-width columns and a non-negative capacity"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  ImageUnpackParams P; memset(&P, 0, sizeof(P));
+  P.images = images; P.unpacked = unpacked; P.image_bytes = (unsigned long long)L.image_bytes; P.capacity = (unsigned long long)capacity_rows;
+  P.valid_off = (unsigned long long)L.valid_off; P.trailer_off = (unsigned long long)L.trailer_off; P.n_images = (unsigned)n_images;
+  char* base = static_cast<char*>(unpacked);
+  const size_t n = p->result_schema.size();
+  for (size_t i = 0; i < n; ++i) {
+    ImagePiece& d = P.pieces[P.n_pieces++];
+    d.image_off = (unsigned long long)L.img_data[i]; d.unpacked_off = (unsigned long long)L.unp_data[i]; d.width = L.width[i];
+    cols[i].data = base + L.unp_data[i]; cols[i].is_null = nullptr;
+    if (L.img_null[i] >= 0) {
+      ImagePiece& z = P.pieces[P.n_pieces++];
+      z.image_off = (unsigned long long)L.img_null[i]; z.unpacked_off = (unsigned long long)L.unp_null[i]; z.width = 1;
+      cols[i].is_null = reinterpret_cast<const uint8_t*>(base + L.unp_null[i]);
+    }
+  }
+  cols[n].data = base + L.valid_off; cols[n].is_null = nullptr;
+  HIP_TRY(c, ssgpu_launch_unpack_images(P, c->stream));
+  return SSGPU_OK;
+}
+
+}  // extern "C"

@@ -83,9 +83,13 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
     return executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), everyone))
 
 
-def _merge_plan(group_by, merged_spec, counts, schema, everyone):
-    """The second, local GroupAggregate over the gathered partial tables (+ COUNT columns back to NOT NULL)."""
-    merged = ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), merged_spec, None, ss.ScanView(everyone))
+def _merge_plan(group_by, merged_spec, counts, schema, everyone, valid=None):
+    """The second, local GroupAggregate over the gathered partial tables (+ COUNT columns back to NOT NULL).
+    valid: name of a BOOL column of `everyone` marking the real rows (padding rows of fixed-size images are 0)."""
+    source = ss.ScanView(everyone)
+    if valid is not None:
+        source = ss.Filter(ss.NamedAttribute(valid), ss.ProjectAllAttributes(), source)
+    merged = ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), merged_spec, None, source)
     if counts:
         # SUM(...) is NULLABLE, COUNT is not: restore the schema of the single-process result
         e = ss.CompoundExpression()
@@ -328,58 +332,105 @@ def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_ran
     return final, final.result_device_view()
 
 
+class DeviceShardedGroupAggregate(object):
+    """GroupAggregate over row-range shards with ONE RCCL collective per step (BASELINE config #4).
+
+    Per step, all on the device and in stream order: the shard's GroupAggregate plan -> its partial
+    table packed into one image (`Plan.pack_image`, row count in the header) -> ONE
+    `all_gather_into_tensor` of the images -> `Plan.unpack_images` (contiguous columns + a validity
+    column) -> the merge plan (GroupAggregate of the merge functions under Filter(__valid)), which
+    was created once and is reused.  No device value is read on the host between the two plans'
+    own runs; `check()` reads the 32-byte trailer once, after the caller's last step.
+
+    The image capacity is agreed on at the first step (one extra all-reduce, set-up only) and
+    regrown by `check()` if a later shard outgrows it.  `collectives` counts the collectives the
+    most recent step issued (asserted to be 1 in the tests)."""
+
+    def __init__(self, ctx, group_by, spec, local_child, group=None, capacity_rows=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.ctx, self.group = ctx, group
+        self.world = dist.get_world_size(group)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.group_by = list(group_by)
+        self.merged_spec, self.counts = _merge_spec(spec)
+        self.first = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(self.group_by), spec, None, local_child), ctx)
+        schema = self.first.result_schema
+        for i in range(schema.attribute_count()):
+            if schema.attribute(i).type() == ss.STRING:
+                raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
+        self.capacity = int(capacity_rows)
+        self.merge = None
+        self.collectives = 0
+        self.setup_collectives = 0
+        # kernels and the collective are ordered by stream: the library launches on the ctx stream, RCCL on torch's
+        raw = ctx.stream()                                   # None / 0: the library launches on the legacy default stream
+        self._lib_stream = torch.cuda.ExternalStream(raw) if raw else torch.cuda.default_stream(self.device)
+
+    def _allocate(self):
+        torch = self.torch
+        self.image_bytes, self.unpacked_bytes, _offs = self.first.image_layout(self.capacity, self.world)
+        self.image = torch.empty(self.image_bytes, dtype=torch.uint8, device=self.device)
+        self.images = torch.empty(self.world * self.image_bytes, dtype=torch.uint8, device=self.device)
+        self.unpacked = torch.empty(self.unpacked_bytes, dtype=torch.uint8, device=self.device)
+        self.merge = None
+
+    def _agree_capacity(self):
+        """Set-up only: the largest partial table of any rank, with head room (one all-reduce, one host read)."""
+        torch = self.torch
+        rows = torch.tensor([self.first.lib.ssgpu_result_row_count(self.first._result)], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(rows, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.setup_collectives += 1
+        self.capacity = max(1024, (int(rows.item()) * 5 // 4 + 1023) // 1024 * 1024)
+
+    def step(self, view=None):
+        torch = self.torch
+        self.collectives = 0
+        self.first.run(view)
+        if not self.capacity:
+            self._agree_capacity()
+        if getattr(self, "_cap_alloc", None) != self.capacity:
+            self._allocate()
+            self._cap_alloc = self.capacity
+        self.first.pack_image(self.capacity, self.image.data_ptr())
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self._lib_stream)                      # the collective reads what the pack kernel wrote
+        self.dist.all_gather_into_tensor(self.images, self.image, group=self.group)
+        self.collectives += 1
+        self._lib_stream.wait_stream(cur)
+        everyone = self.first.unpack_images(self.images.data_ptr(), self.world, self.capacity, self.unpacked.data_ptr())
+        if self.merge is None:
+            self.merge = ss.Plan(_merge_plan(self.group_by, self.merged_spec, self.counts, self.first.result_schema, everyone,
+                                             valid="__valid"), self.ctx)
+        self.merge.run(everyone)
+        return self.merge
+
+    def check(self):
+        """After the last step: True if every image fitted; otherwise the capacity was regrown (all ranks
+        agree: they fold the same headers) and the step has to be repeated.  An evaluation error of any
+        shard's run surfaces here."""
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize(self.device)
+        t = self.unpacked[self.unpacked_bytes - 32:].view(self.torch.int64).tolist()
+        if t[3]:
+            raise ss.SupersonicException(ss.ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate")
+        if t[2]:
+            self.capacity = max(1024, (int(t[0]) * 5 // 4 + 1023) // 1024 * 1024)
+            return False
+        return True
+
+    def result(self):
+        return self.merge, self.merge.result_device_view()
+
+
 def device_sharded_group_aggregate(ctx, group_by, spec, local_child, group=None):
-    """sharded_group_aggregate with the partial group tables staying in HBM: the per-shard aggregate runs as a
-    device plan, its result buffers are wrapped as torch tensors (no copy), padded to the largest table and
-    exchanged with ONE RCCL all_gather per column buffer; the merge plan reads the gathered tables in place
-    (the padding rows are cut out by a compacting copy on the device).  BASELINE config #4.
-
-    Returns (plan, DeviceView): the full result on every rank, as device columns owned by `plan`."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    device = torch.device("cuda", torch.cuda.current_device())
-    merged_spec, counts = _merge_spec(spec)
-    first = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), spec, None, local_child), ctx)
-    first.run()
-    ctx.synchronize()
-    partial = first.result_device_view()
-    schema = partial.schema()
-    n_attrs = schema.attribute_count()
-    for i in range(n_attrs):
-        if schema.attribute(i).type() == ss.STRING:
-            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
-    rows = torch.tensor([partial.row_count()], dtype=torch.int64, device=device)
-    all_rows = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_rows, rows, group=group)
-    table_rows = [int(t.item()) for t in all_rows]
-    cap = max(max(table_rows), 1)
-    gathered, keep = [], []
-    for i in range(n_attrs):
-        w = np.dtype(ss.numpy_dtype(schema.attribute(i).type())).itemsize
-        ptrs = []
-        for which, width in ((0, w), (1, 1)):
-            if which == 1 and not schema.attribute(i).is_nullable():
-                ptrs.append(0)
-                continue
-            mine = torch.zeros(cap * width, dtype=torch.uint8, device=device)
-            src = partial._ptrs[i][which]
-            if src and partial.row_count():
-                mine[: partial.row_count() * width] = _bytes_over(torch, device, src, partial.row_count() * width)
-            everyone = torch.empty(world * cap * width, dtype=torch.uint8, device=device)
-            dist.all_gather_into_tensor(everyone, mine, group=group)
-            # drop the padding: the tables of all ranks back to back
-            packed = torch.cat([everyone[r * cap * width: r * cap * width + table_rows[r] * width] for r in range(world)]) if sum(table_rows) else everyone[:0]
-            if packed.numel() == 0:
-                packed = torch.zeros(max(width, 1), dtype=torch.uint8, device=device)
-            keep.append(packed)
-            ptrs.append(packed.data_ptr())
-        gathered.append((ptrs[0], ptrs[1]))
-    torch.cuda.synchronize()
-    everyone_view = ss.DeviceView(schema, gathered, sum(table_rows))
-    final = ss.Plan(_merge_plan(group_by, merged_spec, counts, schema, everyone_view), ctx)
-    final.run()
-    ctx.synchronize()
-    del keep
-    return final, final.result_device_view()
+    """One-shot form of DeviceShardedGroupAggregate: returns (plan, DeviceView) -- the full result on every
+    rank, as device columns owned by `plan`."""
+    job = DeviceShardedGroupAggregate(ctx, group_by, spec, local_child, group)
+    job.step()
+    while not job.check():
+        job.step()
+    plan, view = job.result()
+    plan._sharded_job = job     # the merge plan reads the job's buffers: keep them alive with it
+    return plan, view
