@@ -70,7 +70,12 @@ def group_spec(ss):
     return spec
 
 
+GROUP_FILTER = True     # --query group3 (BASELINE configs[2]: no Filter below the GroupAggregate) clears it
+
+
 def group_child(ss, view):
+    if not GROUP_FILTER:
+        return ss.ScanView(view)
     return ss.Filter(ss.Greater(ss.NamedAttribute("a"), ss.ConstInt64(K_FILTER)), ss.ProjectAllAttributes(), ss.ScanView(view))
 
 
@@ -243,7 +248,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling) or in total (strong scaling)")
-    ap.add_argument("--query", choices=["wide", "group"], default="wide")
+    ap.add_argument("--query", choices=["wide", "group", "group3"], default="wide",
+                    help="wide = configs[1] (headline); group = configs[3]'s per-GPU query (Filter -> GroupAggregate); group3 = configs[2] (GroupAggregate alone)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,6 +257,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
+    ap.add_argument("--opts", default="", help="extra context options (development): key=value,key=value")
     ap.add_argument("--no-events-in-loop", action="store_true",
                     help="do not record the per-kernel HIP events during the timed steps (kernel time from a separate loop)")
     ap.add_argument("--force-distributed", action="store_true",
@@ -366,6 +373,10 @@ def extras(ss, torch, ctx, device, rows, cols, view):
 
 def main():
     args = parse_args()
+    if args.query == "group3":
+        global GROUP_FILTER
+        GROUP_FILTER = False
+        args.query = "group"
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -401,6 +412,8 @@ def main():
         ctx.set_option("lds_target_bytes", args.lds_target)
     if args.grid_limit:
         ctx.set_option("grid_limit", args.grid_limit)
+    for kv in [x for x in args.opts.split(",") if x]:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     # rows of this rank: a contiguous row range of the job
     if args.scaling == "strong":
@@ -496,8 +509,8 @@ def main():
         alg_bytes = counters.algorithmic_bytes  # bytes/row of the staged input columns x rows of one launch
         achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         if group:
-            workload = ("Q-GROUP-F: GroupAggregate(k1,k2; SUM/MIN/MAX x d0..d3) o Filter(a>499) over a device-resident %d-row x 7-col "
-                        "block per GPU (~1e5 groups)" % rows)
+            workload = ("%s: GroupAggregate(k1,k2; SUM/MIN/MAX x d0..d3)%s over a device-resident %d-row x 7-col "
+                        "block per GPU (~1e5 groups)" % ("Q-GROUP-F" if GROUP_FILTER else "Q-GROUP", " o Filter(a>499)" if GROUP_FILTER else "", rows))
             par = ("row-range shards x%d: per-shard GroupAggregate, ONE RCCL all-gather of the packed partial tables, merge plan" % world
                    if distributed else "single GPU")
             kernel = "group stage (partition scatter + per-partition aggregation kernels)"

@@ -135,13 +135,14 @@ struct Stage {
   std::vector<uint64_t> group_acc_init;   // per-group accumulator identities
   std::vector<uint32_t> group_merge_op;   // VM_MERGE_* of every group accumulator
   int n_gaggs = 0;
-  // GROUP_AGG, partitioned execution (many groups): rows are first scattered into hash partitions
-  // (key + the distinct aggregate inputs), then one workgroup aggregates each partition in LDS
-  Program part_count;    // filters + key packing + PART_COUNT
-  Program part_scatter;  // filters + key packing + PART_RANK + one STOREC per partition column
-  std::vector<uint32_t> part_col_width;   // partition buffer columns: [0] = packed key (8), then values / NULL masks
-  struct PartAgg { int op; int val_col; int null_col; int has_cnt; };
-  std::vector<PartAgg> part_aggs;         // one per aggregate: GAGG opcode + its partition columns (-1 = none)
+  // GROUP_AGG, partitioned execution (many groups): ONE pass scatters a record per selected row (packed key +
+  // the distinct aggregate inputs, AoS) into its (hash partition, workgroup) segment, then one workgroup
+  // aggregates each partition in LDS
+  Program part_scatter;  // filters + key packing + PART_RANK + PART_REC_* per record field (pair)
+  uint32_t part_rec_bytes = 0;            // record size (multiple of 8); the packed key is bytes [0, 8)
+  struct PartAgg { int op; int val_off; int val_width; int null_off; int has_cnt; int word; };
+  std::vector<PartAgg> part_aggs;         // one per aggregate: GAGG opcode, byte offsets of its value / NULL flag in the
+                                          // record (-1 = none), first accumulator word in the group table
   std::vector<JoinSpec> joins;            // HashJoins fused into this stage's programs
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns

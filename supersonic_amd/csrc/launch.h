@@ -39,22 +39,23 @@ struct GroupExtractParams {
 
 // Partitioned GroupAggregate, second phase: one workgroup aggregates one hash partition in LDS
 // and dumps its table into slots [part * local_capacity, (part + 1) * local_capacity) of the
-// global table (no global atomics; the usual extraction kernels run on the result).
+// global table (no global atomics; the usual extraction kernels run on the result).  The partition's
+// records (rec_words x 8 bytes each, word 0 = packed key) sit in n_segs segments of seg_cap records:
+// segment (part, g) at record (part * n_segs + g) * seg_cap holds counts[part * n_segs + g] records.
 #define SSGPU_PART_THREADS 1024
 struct PartAggParams {
-  const void* cols[VM_MAX_OUTPUTS];   // partition columns; [0] = packed 64-bit keys
-  const unsigned int* offsets;        // scanned [partition][workgroup of the scatter pass] row offsets
-  const unsigned long long* total;    // selected rows in total
-  unsigned int n_tiles, n_parts;      // n_tiles = workgroups of the scatter pass
+  const unsigned long long* recs;
+  const unsigned int* counts;
+  unsigned int n_segs, seg_cap, rec_words, n_parts;
   unsigned int local_capacity;        // LDS table entries per partition
-  unsigned int n_gaggs;
-  unsigned int any_cnt;
-  unsigned int pad;
-  VmGroupTable G;                     // global table: capacity_mask + 1 == n_parts * local_capacity (any number)
-  int agg_op[VM_MAX_AGG_SLOTS];       // GAGG opcode per aggregate
-  int val_col[VM_MAX_AGG_SLOTS];      // partition column of the value (-1: COUNT)
-  int null_col[VM_MAX_AGG_SLOTS];     // partition column of the NULL mask (-1: never NULL)
-  int has_cnt[VM_MAX_AGG_SLOTS];
+  unsigned int n_gaggs;               // accumulator words per group
+  unsigned int n_aggs, any_cnt;
+  unsigned int debug, pad;            // development switches (perf attribution): 1 = no aggregation, 2 = no probe
+  VmGroupTable T;                     // global table: capacity_mask + 1 == n_parts * local_capacity (any number)
+  // one packed descriptor per aggregate: GAGG opcode (bits 0-15) | first accumulator word (16-23) | byte offset of
+  // the value in the record, 0xFF = none (24-31) | value width (32-39) | byte offset of the NULL flag, 0xFF = never
+  // NULL (40-47) | contribution count tracked (48)
+  unsigned long long desc[VM_MAX_AGG_SLOTS];
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
 hipError_t ssgpu_part_agg_set_max_lds(int bytes);

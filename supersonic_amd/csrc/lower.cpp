@@ -1004,11 +1004,17 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
   slotreg = em.new_reg(4);
   { LInstr& i = em.emit(VM_GRP_INSERT); i.dst = slotreg; i.a = keyreg; i.c = sel; }
   }
-  const uint64_t ng = plans.size();
+  // accumulator words of a group: one per aggregate, two (sum, compensation) for a DOUBLE sum -- every add's
+  // rounding error is captured exactly (TwoSum on the value the atomic returns) and accumulated next to it
+  auto is_dd = [](const AggPlan& ap) { return ap.aggregation == SSGPU_SUM && mtype(ap.out_type) == M_F64; };
+  uint64_t ng = 0;
+  for (auto& ap : plans) ng += is_dd(ap) ? 2 : 1;
   int rowid_reg = -1;
-  for (size_t j = 0; j < plans.size(); ++j) {
-    const AggPlan& ap = plans[j];
-    AggOut ao; ao.slot = (int)j; ao.slot_kind = 0; ao.result_nullable = ap.result_nullable; ao.has_cnt = false;
+  int word = 0;
+  for (size_t jj = 0; jj < plans.size(); ++jj) {
+    const AggPlan& ap = plans[jj];
+    const uint64_t j = (uint64_t)word;
+    AggOut ao; ao.slot = word; ao.slot_kind = 0; ao.result_nullable = ap.result_nullable; ao.has_cnt = false;
     uint64_t init = 0;
     if (ap.aggregation == SSGPU_COUNT) {
       int nullreg = -1;
@@ -1043,19 +1049,27 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
       i.imm = ((uint64_t)(ao.has_cnt ? 1 : 0) << 63) | (ng << 32) | j;
       ao.emit_kind = s.emit_kind;
     }
-    st->group_acc_init.push_back(init);
-    {
+    if (is_dd(ap)) {
+      st->group_acc_init.push_back(0x8000000000000000ull);   // -0.0: the identity of IEEE + (an all -0.0 group sums to -0.0)
+      st->group_acc_init.push_back(0);
+      st->group_merge_op.push_back(VM_MERGE_ADD_F64_HI);
+      st->group_merge_op.push_back(VM_MERGE_ADD_F64);
+      ao.emit_kind = EMIT_DD_F64;
+      word += 2;
+    } else {
+      st->group_acc_init.push_back(init);
       uint32_t mop = VM_MERGE_ADD_U64;
       if (ap.aggregation == SSGPU_MIN || ap.aggregation == SSGPU_FIRST) mop = VM_MERGE_MIN_U64;
       else if (ap.aggregation == SSGPU_MAX || ap.aggregation == SSGPU_LAST) mop = VM_MERGE_MAX_U64;
-      else if (ap.aggregation == SSGPU_SUM && (mtype(ap.out_type) == M_F32 || mtype(ap.out_type) == M_F64)) mop = VM_MERGE_ADD_F64;
+      else if (ap.aggregation == SSGPU_SUM && mtype(ap.out_type) == M_F32) mop = VM_MERGE_ADD_F64;
       st->group_merge_op.push_back(mop);
+      word += 1;
     }
     st->aggs.push_back(ao);
     Attr a; a.name = ap.out_name; a.dtype = ap.out_type; a.nullable = ap.result_nullable;
     st->out_schema.push_back(a);
   }
-  st->n_gaggs = (int)plans.size();
+  st->n_gaggs = (int)ng;
   allocate_registers(&st->main);
   st->algorithmic_bytes_per_row = staged_bytes(st->main);
   st->has_filter = !pipe.filters.empty();
@@ -1063,59 +1077,52 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
   return Status::OK();
 }
 
-// Partitioned execution of a hash GroupAggregate (many groups): two more programs over the same
-// pipe.  Both pack the key exactly like the direct program; the scatter program writes the key
-// and every distinct aggregate input (after its cast) to the row's slot of its hash partition.
+// Partitioned execution of a hash GroupAggregate (many groups): one more program over the same pipe.
+// It packs the key exactly like the direct program and writes ONE record per selected row -- the packed key
+// followed by every distinct aggregate input (after its cast) and NULL flag -- into the row's (hash
+// partition, workgroup) segment of the partition buffer.  Record layout: 8-byte fields (key first), then
+// 4-byte fields, then 1-byte fields, padded to a multiple of 8 bytes; adjacent 8-byte fields leave as one
+// 16-byte store.
 static Status build_partition_programs(const Pipe& pipe, const std::vector<int>& kpos, const std::vector<AggPlan>& plans, Stage* st) {
-  auto pack_key = [&](Emitter& em, int* keyreg_out) -> Status {
-    int keyreg = em.new_reg(8);
-    { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
-    for (size_t k = 0; k < kpos.size(); ++k) {
-      const BExprP& ke = pipe.cols[kpos[k]].expr;
-      Val v; SS_RETURN_IF_ERROR(em.value(ke, &v));
-      const GroupKeyField& f = st->group_keys[k];
-      int vr = em.materialize(v);
-      LInstr& i = em.emit(f.width == 8 ? VM_KEY_APPEND_64 : f.width == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
-      i.dst = keyreg; i.a = vr; i.b = v.null;
-      i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
-    }
-    *keyreg_out = keyreg;
-    return Status::OK();
-  };
-  {
-    Emitter em(&st->part_count, &pipe.joins);
-    SS_RETURN_IF_ERROR(emit_filters(em, pipe));
-    int keyreg; SS_RETURN_IF_ERROR(pack_key(em, &keyreg));
-    LInstr& i = em.emit(VM_PART_COUNT); i.dst_is_reg = false; i.dst = 0; i.a = keyreg; i.c = em.sel_by_depth.back();
-    allocate_registers(&st->part_count);
-  }
   Emitter em(&st->part_scatter, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
-  int keyreg; SS_RETURN_IF_ERROR(pack_key(em, &keyreg));
+  int keyreg = em.new_reg(8);
+  { LInstr& i = em.emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
+  for (size_t k = 0; k < kpos.size(); ++k) {
+    const BExprP& ke = pipe.cols[kpos[k]].expr;
+    Val v; SS_RETURN_IF_ERROR(em.value(ke, &v));
+    const GroupKeyField& f = st->group_keys[k];
+    int vr = em.materialize(v);
+    LInstr& i = em.emit(f.width == 8 ? VM_KEY_APPEND_64 : f.width == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
+    i.dst = keyreg; i.a = vr; i.b = v.null;
+    i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
+  }
   const int rank = em.new_reg(4);
   { LInstr& i = em.emit(VM_PART_RANK); i.dst = rank; i.a = keyreg; i.c = sel; }
-  st->part_col_width.clear(); st->part_aggs.clear();
-  std::map<int, int> col_of_reg;   // value / mask register -> partition column
-  auto store_reg = [&](int reg, uint32_t w) -> int {
-    auto it = col_of_reg.find(reg);
-    if (it != col_of_reg.end()) return it->second;
-    const int col = (int)st->part_col_width.size();
-    st->part_col_width.push_back(w);
-    LInstr& i = em.emit(w == 8 ? VM_STOREC_64 : w == 4 ? VM_STOREC_32 : VM_STOREC_8);
-    i.dst_is_reg = false; i.dst = col; i.a = reg; i.b = rank; i.c = sel;
-    col_of_reg[reg] = col;
-    return col;
+  struct Field { int reg; uint32_t width; int off; };
+  std::vector<Field> fields;
+  std::map<int, int> field_of_reg;   // value / mask register -> record field
+  auto add_field = [&](int reg, uint32_t w) -> int {
+    auto it = field_of_reg.find(reg);
+    if (it != field_of_reg.end()) return it->second;
+    fields.push_back(Field{reg, w, -1});
+    field_of_reg[reg] = (int)fields.size() - 1;
+    return (int)fields.size() - 1;
   };
-  store_reg(keyreg, 8);
+  add_field(keyreg, 8);
+  st->part_aggs.clear();
+  struct Ref { int val_field, null_field; };
+  std::vector<Ref> refs;
   int rowid_reg = -1;
   for (size_t j = 0; j < plans.size(); ++j) {
     const AggPlan& ap = plans[j];
-    Stage::PartAgg pa; pa.op = VM_GAGG_COUNT; pa.val_col = -1; pa.null_col = -1; pa.has_cnt = 0;
+    Stage::PartAgg pa; pa.op = VM_GAGG_COUNT; pa.val_off = -1; pa.val_width = 0; pa.null_off = -1; pa.has_cnt = 0; pa.word = st->aggs[j].slot;
+    Ref rf{-1, -1};
     if (ap.aggregation == SSGPU_COUNT) {
       if (ap.input_pos >= 0) {
         Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v));
-        if (v.null >= 0) pa.null_col = store_reg(v.null, 1);
+        if (v.null >= 0) rf.null_field = add_field(v.null, 1);
       }
     } else {
       const BExprP& src = pipe.cols[ap.input_pos].expr;
@@ -1126,19 +1133,43 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
         select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &sl, &init);
         if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
         pa.op = sl.op;
-        pa.val_col = store_reg(rowid_reg, 8);
+        rf.val_field = add_field(rowid_reg, 8); pa.val_width = 8;
       } else {
         if (!select_group_agg(ap.aggregation, ap.out_type, &sl, &init))
           return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
         pa.op = sl.op;
-        pa.val_col = store_reg(em.materialize(c), c.width);
+        rf.val_field = add_field(em.materialize(c), c.width); pa.val_width = (int)c.width;
       }
-      if (v.null >= 0) { pa.null_col = store_reg(v.null, 1); pa.has_cnt = 1; }
+      if (v.null >= 0) { rf.null_field = add_field(v.null, 1); pa.has_cnt = 1; }
     }
     st->part_aggs.push_back(pa);
+    refs.push_back(rf);
   }
-  if ((int)st->part_col_width.size() > VM_MAX_OUTPUTS) { st->part_count = Program(); st->part_scatter = Program(); return Status::OK(); }
-  st->part_scatter.n_outputs = (int)st->part_col_width.size();
+  uint32_t off = 0;
+  for (uint32_t w : {8u, 4u, 1u})
+    for (auto& f : fields) if (f.width == w) { f.off = (int)off; off += w; }
+  st->part_rec_bytes = (off + 7u) & ~7u;
+  if (st->part_rec_bytes > 128u) { st->part_scatter = Program(); st->part_aggs.clear(); return Status::OK(); }   // wider records: direct path only
+  for (size_t j = 0; j < refs.size(); ++j) {
+    if (refs[j].val_field >= 0) st->part_aggs[j].val_off = fields[refs[j].val_field].off;
+    if (refs[j].null_field >= 0) st->part_aggs[j].null_off = fields[refs[j].null_field].off;
+  }
+  const uint64_t rb = (uint64_t)st->part_rec_bytes << 16;
+  std::vector<const Field*> wide;
+  for (auto& f : fields) if (f.width == 8) wide.push_back(&f);
+  for (size_t q = 0; q < wide.size(); q += 2) {
+    if (q + 1 < wide.size()) {
+      LInstr& i = em.emit(VM_PART_REC_128); i.dst_is_reg = false; i.dst = 0; i.a = wide[q]->reg; i.d = wide[q + 1]->reg; i.b = rank; i.imm = (uint64_t)wide[q]->off | rb;
+    } else {
+      LInstr& i = em.emit(VM_PART_REC_64); i.dst_is_reg = false; i.dst = 0; i.a = wide[q]->reg; i.b = rank; i.imm = (uint64_t)wide[q]->off | rb;
+    }
+  }
+  for (auto& f : fields) {
+    if (f.width == 8) continue;
+    LInstr& i = em.emit(f.width == 4 ? VM_PART_REC_32 : VM_PART_REC_8); i.dst_is_reg = false; i.dst = 0; i.a = f.reg; i.b = rank; i.imm = (uint64_t)f.off | rb;
+  }
+  { LInstr& i = em.emit(VM_PART_FLUSH); i.dst_is_reg = false; i.dst = 0; i.imm = st->part_rec_bytes; }
+  st->part_scatter.n_outputs = 1;
   allocate_registers(&st->part_scatter);
   return Status::OK();
 }
@@ -1444,14 +1475,13 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
     stages->push_back(m);
   }
   for (auto& st : *stages)
-    for (const Program* pr : {&st.main, &st.count_pass, &st.part_count, &st.part_scatter})
+    for (const Program* pr : {&st.main, &st.count_pass, &st.part_scatter})
       if (pr->gathers.size() > VM_MAX_JOIN_COLS)
         return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many rhs columns gathered by the hash joins of one pipeline");
   *result_schema = stages->back().out_schema;
   for (size_t i = 0; i < stages->size(); ++i) {
     desc << "stage " << i << " kind=" << (*stages)[i].kind << "\n" << disassemble((*stages)[i].main);
     if (!(*stages)[i].count_pass.empty()) desc << " count pass:\n" << disassemble((*stages)[i].count_pass);
-    if (!(*stages)[i].part_count.empty()) desc << " partition count pass:\n" << disassemble((*stages)[i].part_count);
     if (!(*stages)[i].part_scatter.empty()) desc << " partition scatter pass:\n" << disassemble((*stages)[i].part_scatter);
   }
   *describe = desc.str();

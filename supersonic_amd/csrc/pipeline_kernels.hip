@@ -130,6 +130,15 @@ __device__ __forceinline__ DD wave_reduce_dd(DD v) {
 __device__ __forceinline__ u64 key_i64(i64 v) { return (u64)v ^ 0x8000000000000000ull; }
 __device__ __forceinline__ i64 unkey_i64(u64 k) { return (i64)(k ^ 0x8000000000000000ull); }
 
+// compensated atomic add: acc[0] += v with the add's exact rounding error accumulated in acc[1]
+__device__ __forceinline__ void dd_atomic_add(double* acc, double v) {
+  const double old = unsafeAtomicAdd(acc, v);
+  const double t = old + v;
+  const double bp = t - old;
+  const double err = (old - (t - bp)) + (v - bp);
+  if (err != 0.0) unsafeAtomicAdd(acc + 1, err);
+}
+
 // ---------------------------------------------------------------------------
 // row validity for sinks: row exists, passes the selection, value not NULL.
 // ---------------------------------------------------------------------------
@@ -382,7 +391,7 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
 
 #define GAGG_APPLY(LOADT, SL, E, ATOM)                                         \
       if ((SL) & VM_SLOT_LOCAL) {                                              \
-        const u32 li = ((SL) & ~VM_SLOT_LOCAL) * ng + s;                       \
+        const u32 li = ((SL) & ~VM_SLOT_LOCAL) * P.group.local_stride + s;     \
         u64* A = reinterpret_cast<u64*>(smem + P.group.local_acc_off) + li; LOADT e = (E); ATOM; \
         if (has_cnt) atomicAdd(reinterpret_cast<u32*>(smem + P.group.local_cnt_off) + li, 1u); \
       } else {                                                                 \
@@ -463,16 +472,15 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     const VmGroupTable& G = P.group;
     for (u32 e = (u32)t; e < G.local_capacity; e += VM_COMPUTE_THREADS)
       reinterpret_cast<u64*>(smem + G.local_keys_off)[e] = VM_KEY_EMPTY;
-    for (u32 i = (u32)t; i < G.local_capacity * G.n_gaggs; i += VM_COMPUTE_THREADS) {
-      reinterpret_cast<u64*>(smem + G.local_acc_off)[i] = G.acc_init[i % G.n_gaggs];
+    for (u32 i = (u32)t; i < G.local_capacity * G.local_stride; i += VM_COMPUTE_THREADS) {
+      reinterpret_cast<u64*>(smem + G.local_acc_off)[i] = G.acc_init[(i % G.local_stride) % G.n_gaggs];
       if (G.local_cnt_off != VM_NONE) reinterpret_cast<u32*>(smem + G.local_cnt_off)[i] = 0u;
     }
     if (t < 2) reinterpret_cast<u32*>(smem + P.scratch_lds_off + 128u)[t] = 0u;
   }
-  if (P.part_n) {  // partition passes: this workgroup's counters / scanned start offsets, [partition][workgroup]
+  if (P.part_n) {  // partition pass: rows this workgroup has written to each of its (partition, workgroup) segments
     u32* h = reinterpret_cast<u32*>(smem + P.part_lds_off);
-    for (u32 i = (u32)t; i < P.part_n; i += VM_COMPUTE_THREADS)
-      h[i] = P.tile_offsets ? P.tile_offsets[(u64)i * gridDim.x + blockIdx.x] : 0u;
+    for (u32 i = (u32)t; i < P.part_n; i += VM_COMPUTE_THREADS) h[i] = 0u;
   }
   PC_PROF(if (P.debug_pc) for (int i = t; i <= P.n_instr; i += VM_COMPUTE_THREADS) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[i] = 0ull;)
   __syncthreads();  // constant pool, accumulator records and group table visible to all waves
@@ -1752,28 +1760,108 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
           }
         } break;
         // ---- hash partitioning of the rows of a GroupAggregate with many groups ----------
-        // The partition counters live in LDS for the whole kernel (per WORKGROUP, not per tile: the
-        // persistent workgroup sees the same tiles in the count pass and in the scatter pass, so
-        // its scanned per-partition start offsets simply keep running) -- no barrier needed.
-        case VM_PART_COUNT: { CASE_FENCE;
-          u32* h = reinterpret_cast<u32*>(smem + P.part_lds_off);
+        // ONE pass: every selected row becomes a record (packed key + aggregate inputs) in the segment of its
+        // (hash partition, THIS workgroup) -- segments are private to a workgroup, so their fill counts live in LDS
+        // for the whole kernel and no global atomic or count pass is needed; a segment that runs full raises
+        // part_overflow and the host reruns with larger segments.
+        // Stores leave the L2 one transaction per line touched per instruction, whatever is written to the line
+        // later: a lane writing its own 40-byte record to its own segment costs three of them (measured: 54 % of the
+        // pass).  So the tile is counting-sorted by partition in LDS (PART_RANK), its records are assembled in that
+        // order in an LDS staging area (PART_REC_*), and PART_FLUSH copies the staging area out with consecutive
+        // lanes on consecutive words: a partition's records of the tile are one contiguous run in its segment.
+        // LDS behind part_lds_off: u32 fill[P] | tile count -> tile start [P] | run delta [P] | room [P] |
+        //                          u32 grec[tile_rows] (global record index by sorted position) | n | records
+        case VM_PART_RANK: { CASE_FENCE;
+          const u32 NP = P.part_n, cap = P.part_seg_cap, G = gridDim.x, wg = blockIdx.x;
+          u32* fill = reinterpret_cast<u32*>(smem + P.part_lds_off);
+          u32* th = fill + NP; u32* dl = th + NP; u32* room = dl + NP; u32* grec = room + NP;
+          u32* nsel = grec + (u32)(VM_TILE_UNIT * K);
+          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
+          for (u32 i = (u32)tp; i < NP; i += VM_COMPUTE_THREADS) th[i] = 0u;
+          WG_BARRIER();
+          u32 pb[2 * K], pr[2 * K];
           _Pragma("unroll") FOR_PAIRS {
             Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
             auto kk = lds_load2<u64>(I.a, p);
-            if (m.x) atomicAdd(&h[part_of(kk.x, P.part_n)], 1u);
-            if (m.y) atomicAdd(&h[part_of(kk.y, P.part_n)], 1u);
+            pb[2 * k] = part_of(kk.x, NP); pb[2 * k + 1] = part_of(kk.y, NP);
+            pr[2 * k] = m.x ? atomicAdd(&th[pb[2 * k]], 1u) : VM_NONE;
+            pr[2 * k + 1] = m.y ? atomicAdd(&th[pb[2 * k + 1]], 1u) : VM_NONE;
+          }
+          WG_BARRIER();
+          {  // exclusive scan of the tile histogram: thread tp owns partitions [tp * per, tp * per + per)
+            const u32 per = (NP + VM_COMPUTE_THREADS - 1u) / VM_COMPUTE_THREADS, i0 = (u32)tp * per;
+            u32 sum = 0;
+            for (u32 e = 0; e < per; ++e) sum += (i0 + e < NP) ? th[i0 + e] : 0u;
+            u32 inc = sum;
+            _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            if (lane == 63) scratch[wave] = inc;
+            WG_BARRIER();
+            u32 run = inc - sum;
+            for (int w = 0; w < wave; ++w) run += scratch[w];
+            if (tp == VM_COMPUTE_THREADS - 1) nsel[0] = run + sum;
+            bool over = false;
+            for (u32 e = 0; e < per; ++e) {
+              const u32 i = i0 + e;
+              if (i >= NP) break;
+              const u32 c = th[i], f = fill[i];
+              th[i] = run;                                   // first sorted position of partition i in this tile
+              dl[i] = (i * G + wg) * cap + f - run;          // global record index = dl[i] + sorted position
+              room[i] = cap - f;                             // records the segment still takes
+              const u32 take = c < cap - f ? c : cap - f;
+              over = over || take < c;
+              fill[i] = f + take;
+              run += c;
+            }
+            if (over) atomicExch(P.part_overflow, 1u);
+          }
+          WG_BARRIER();
+          _Pragma("unroll") FOR_PAIRS {
+            u32 s0 = VM_NONE, s1 = VM_NONE;
+            if (pr[2 * k] != VM_NONE) { const u32 sp = th[pb[2 * k]] + pr[2 * k]; const bool ok = pr[2 * k] < room[pb[2 * k]]; grec[sp] = ok ? dl[pb[2 * k]] + sp : VM_NONE; if (ok) s0 = sp; }
+            if (pr[2 * k + 1] != VM_NONE) { const u32 sp = th[pb[2 * k + 1]] + pr[2 * k + 1]; const bool ok = pr[2 * k + 1] < room[pb[2 * k + 1]]; grec[sp] = ok ? dl[pb[2 * k + 1]] + sp : VM_NONE; if (ok) s1 = sp; }
+            lds_store2<u32>(I.dst, p, s0, s1);
           }
         } break;
-        case VM_PART_RANK: { CASE_FENCE;    // destination row of every selected row inside its partition
-          u32* h = reinterpret_cast<u32*>(smem + P.part_lds_off);
+#define PART_REC_OP(OPNAME, T)                                                 \
+        case VM_##OPNAME: { CASE_FENCE;                                        \
+          char* stage = smem + P.part_lds_off + 16u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu); \
+          const u32 rb = (u32)((I.imm >> 16) & 0xFFFFu);                       \
+          _Pragma("unroll") FOR_PAIRS {                                        \
+            auto rk = lds_load2<u32>(I.b, p);                                  \
+            auto vv = fetch2<T>(I.a, I.a_mask, p);                             \
+            if (rk.x != VM_NONE) *reinterpret_cast<T*>(stage + rk.x * rb) = vv.x; \
+            if (rk.y != VM_NONE) *reinterpret_cast<T*>(stage + rk.y * rb) = vv.y; \
+          }                                                                    \
+        } break;
+        PART_REC_OP(PART_REC_8, u8)
+        PART_REC_OP(PART_REC_32, u32)
+        PART_REC_OP(PART_REC_64, u64)
+        case VM_PART_REC_128: { CASE_FENCE;   // two adjacent 8-byte fields
+          char* stage = smem + P.part_lds_off + 16u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu);
+          const u32 rb = (u32)((I.imm >> 16) & 0xFFFFu);
           _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
-            auto kk = lds_load2<u64>(I.a, p);
-            u32 r0 = 0, r1 = 0;
-            if (m.x) r0 = atomicAdd(&h[part_of(kk.x, P.part_n)], 1u);
-            if (m.y) r1 = atomicAdd(&h[part_of(kk.y, P.part_n)], 1u);
-            lds_store2<u32>(I.dst, p, r0, r1);
+            auto rk = lds_load2<u32>(I.b, p);
+            auto va = lds_load2<u64>(I.a, p);
+            auto vd = lds_load2<u64>(I.d, p);
+            if (rk.x != VM_NONE) { u64* d = reinterpret_cast<u64*>(stage + rk.x * rb); d[0] = va.x; d[1] = vd.x; }
+            if (rk.y != VM_NONE) { u64* d = reinterpret_cast<u64*>(stage + rk.y * rb); d[0] = va.y; d[1] = vd.y; }
           }
+        } break;
+        case VM_PART_FLUSH: { CASE_FENCE;     // the staged records of the tile -> their segments, 8 bytes per lane, lanes on consecutive words
+          const u32 NP = P.part_n;
+          const u32* grec = reinterpret_cast<const u32*>(smem + P.part_lds_off + 16u * NP);
+          const u32* nsel = grec + (u32)(VM_TILE_UNIT * K);
+          const u64* stage = reinterpret_cast<const u64*>(smem + P.part_lds_off + 16u * NP + 4u * (u32)(VM_TILE_UNIT * K) + 16u);
+          u64* out = reinterpret_cast<u64*>(P.outputs[0].dst);
+          const u32 wpr = (u32)I.imm >> 3;                   // words per record
+          WG_BARRIER();
+          const u32 words = nsel[0] * wpr;
+          for (u32 w = (u32)tp; w < words; w += VM_COMPUTE_THREADS) {
+            const u32 j = w / wpr, f = w - j * wpr;
+            const u32 g = grec[j];
+            if (g != VM_NONE) out[(u64)g * wpr + f] = stage[w];
+          }
+          WG_BARRIER();
         } break;
         STORE_OP(STORE_8, u8)
         STORE_OP(STORE_32, u32)
@@ -1831,11 +1919,11 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
             Valid2 m = valid_pair_(p, tile_valid, I.b, VM_NONE);
             auto sl = lds_load2<u32>(I.c, p);
             if (m.x && sl.x != 0xFFFFFFFFu) {
-              if (sl.x & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.x & ~VM_SLOT_LOCAL) * ng + s, 1ull);
+              if (sl.x & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.x & ~VM_SLOT_LOCAL) * P.group.local_stride + s, 1ull);
               else atomicAdd(&P.group.acc[(u64)sl.x * ng + s], 1ull);
             }
             if (m.y && sl.y != 0xFFFFFFFFu) {
-              if (sl.y & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.y & ~VM_SLOT_LOCAL) * ng + s, 1ull);
+              if (sl.y & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.y & ~VM_SLOT_LOCAL) * P.group.local_stride + s, 1ull);
               else atomicAdd(&P.group.acc[(u64)sl.y * ng + s], 1ull);
             }
           }
@@ -1844,7 +1932,9 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
         GAGG_ATOMIC(GAGG_SUM_U32, u32, atomicAdd(A, (u64)e))
         GAGG_ATOMIC(GAGG_SUM_I64, u64, atomicAdd(A, e))
         GAGG_ATOMIC(GAGG_SUM_F32, float, unsafeAtomicAdd(reinterpret_cast<double*>(A), (double)e))
-        GAGG_ATOMIC(GAGG_SUM_F64, double, unsafeAtomicAdd(reinterpret_cast<double*>(A), e))
+        // DOUBLE sums are compensated: the atomic returns the value it added to, so the rounding error of THIS add is
+        // known exactly (TwoSum) and is accumulated in the word behind the sum; result = sum + compensation
+        GAGG_ATOMIC(GAGG_SUM_F64, double, dd_atomic_add(reinterpret_cast<double*>(A), e))
         GAGG_ATOMIC(GAGG_MIN_I32, i32, atomicMin(A, key_i64((i64)e)))
         GAGG_ATOMIC(GAGG_MIN_U32, u32, atomicMin(A, (u64)e))
         GAGG_ATOMIC(GAGG_MIN_I64, i64, atomicMin(A, key_i64(e)))
@@ -1868,10 +1958,10 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     PC_PROF(if (P.debug_pc && P.n_instr > 0 && t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr - 1] += __builtin_amdgcn_s_memtime() - dbg_pc_last;)
   }
 
-  if (P.part_n && P.tile_counts && !P.tile_offsets) {  // count pass: publish this workgroup's partition histogram
+  if (P.part_n && P.tile_counts) {  // partition pass: publish the fill of this workgroup's segments
     __syncthreads();
     const u32* h = reinterpret_cast<const u32*>(smem + P.part_lds_off);
-    for (u32 i = (u32)t; i < P.part_n; i += VM_COMPUTE_THREADS) P.tile_counts[(u64)i * gridDim.x + blockIdx.x] = h[i];
+    for (u32 i = (u32)t; i < P.part_n; i += VM_COMPUTE_THREADS) P.tile_counts[(u64)i * gridDim.x + blockIdx.x] = h[i] < P.part_seg_cap ? h[i] : P.part_seg_cap;
   }
   if (P.group.local_capacity) {
     // merge the workgroup's table into the global one: one atomic per (group, aggregate)
@@ -1887,15 +1977,16 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
       const u32 gs = group_insert(G, key);
       if (gs == 0xFFFFFFFFu) continue;  // global table full: the host regrows and reruns
       for (u32 s = 0; s < ng; ++s) {
-        const u64 v = reinterpret_cast<const u64*>(smem + G.local_acc_off)[e * ng + s];
+        const u64 v = reinterpret_cast<const u64*>(smem + G.local_acc_off)[e * G.local_stride + s];
         u64* A = &G.acc[(u64)gs * ng + s];
         const u32 op = G.merge_op[s];
         if (op == VM_MERGE_ADD_U64) { if (v) atomicAdd(A, v); }
         else if (op == VM_MERGE_MIN_U64) atomicMin(A, v);
         else if (op == VM_MERGE_MAX_U64) atomicMax(A, v);
+        else if (op == VM_MERGE_ADD_F64_HI) dd_atomic_add(reinterpret_cast<double*>(A), u2d(v));
         else unsafeAtomicAdd(reinterpret_cast<double*>(A), u2d(v));
         if (G.local_cnt_off != VM_NONE) {
-          const u32 c = reinterpret_cast<const u32*>(smem + G.local_cnt_off)[e * ng + s];
+          const u32 c = reinterpret_cast<const u32*>(smem + G.local_cnt_off)[e * G.local_stride + s];
           if (c) atomicAdd(&G.cnt[(u64)gs * ng + s], c);
         }
       }
@@ -2185,7 +2276,7 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
         v0 = (v0 & 0x8000000000000000ull) ? (v0 & 0x7FFFFFFFFFFFFFFFull) : ~v0;
         emit_value(ao.data, row, EMIT_F32, v0, 0);
       } else {
-        emit_value(ao.data, row, ao.out_kind, v0, 0);
+        emit_value(ao.data, row, ao.out_kind, v0, ao.out_kind == EMIT_DD_F64 ? P.acc[(u64)slot * P.n_gaggs + ao.s + 1] : 0ull);
       }
       if (ao.is_null) ao.is_null[row] = c == 0;
     }
@@ -2194,97 +2285,195 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
 
 
 // ---------------------------------------------------------------------------
-// partitioned GroupAggregate, phase 2 (see PartAggParams in launch.h)
+// partitioned GroupAggregate, phase 2 (see PartAggParams in launch.h): one workgroup per hash partition
+// reads the partition's records (n_segs segments, one per workgroup of the scatter pass), aggregates them
+// in an LDS table and dumps the table into its own slot range of the global table -- no global atomic.
+// Everything the inner loop touches is LDS through address-space-3 pointers (ds_* instructions, not flat):
+// measured on this part, ds_add_f64 runs at 3 lanes / clock / CU, ds_min / max / add_u64 at 5.5, 32-bit
+// adds at 7 (tools/microbench/lds_atomics.hip) -- a 12-aggregate row costs about 3 clocks of atomics.
+// DOUBLE sums are compensated (the returning atomic gives the exact rounding error of every add).
+// The one key whose packed value equals the EMPTY sentinel lives in the reserved table entry C.
 // ---------------------------------------------------------------------------
-#define PART_ROWS 4   /* rows per thread per step: amortises the per-aggregate dispatch */
-#define PART_APPLY(OPNAME, LOADT, ATOM)                                               \
+#define PART_ROWS 2   /* records per lane per step */
+#define LDS_AS __attribute__((address_space(3)))
+template <int MAXW> struct RecVec { typedef u64 type __attribute__((ext_vector_type(MAXW))); };
+template <int MAXW> __device__ __forceinline__ u64 rec_word(const typename RecVec<MAXW>::type& r, u32 w) {
+  u64 v = r[0];
+#pragma unroll
+  for (int k = 1; k < MAXW; ++k) v = (w == (u32)k) ? r[k] : v;   // w is wave-uniform: scalar conditions, no register indexing
+  return v;
+}
+__device__ __forceinline__ u64 rec_field(u64 word, u32 off, u32 width) {
+  const u64 vmask = width >= 8 ? ~0ull : ((1ull << (width * 8u)) - 1ull);
+  return (word >> ((off & 7u) * 8u)) & vmask;
+}
+__device__ __forceinline__ void lds_dd_add(LDS_AS double* acc, double v) {
+  const double old = __hip_atomic_fetch_add(acc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const double t = old + v;
+  const double bp = t - old;
+  const double err = (old - (t - bp)) + (v - bp);
+  if (err != 0.0) __hip_atomic_fetch_add(acc + 1, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#define LDS_MIN(A, x) __hip_atomic_fetch_min((A), (u64)(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_MAX(A, x) __hip_atomic_fetch_max((A), (u64)(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_ADD(A, x) __hip_atomic_fetch_add((A), (u64)(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define PART_APPLY(OPNAME, EXPR)                                                      \
   case VM_##OPNAME: {                                                                 \
-    const LOADT* col = reinterpret_cast<const LOADT*>(P.cols[vc]);                    \
-    LOADT ev[PART_ROWS];                                                              \
-    _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) ev[j] = live[j] ? col[rr[j]] : (LOADT)0; \
-    _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) if (live[j]) { u64* A = AP[j]; LOADT e = ev[j]; ATOM; } \
+    _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) if (ok[j]) { LDS_AS u64* A = lacc + li[j] + word; const u64 raw = val[j]; EXPR; } \
   } break;
-
-__global__ __launch_bounds__(SSGPU_PART_THREADS) void ssgpu_part_agg_kernel(const PartAggParams P) {
-  const u32 t = threadIdx.x, part = blockIdx.x;
-  const u32 C = P.local_capacity, ng = P.n_gaggs;
-  u64* lkeys = reinterpret_cast<u64*>(smem + 0u);
-  u64* lacc = lkeys + C;
-  u32* lcnt = reinterpret_cast<u32*>(lacc + (size_t)C * ng);
-  for (u32 e = t; e < C; e += SSGPU_PART_THREADS) lkeys[e] = VM_KEY_EMPTY;
-  for (u32 i = t; i < C * ng; i += SSGPU_PART_THREADS) { lacc[i] = P.G.acc_init[i % ng]; if (P.any_cnt) lcnt[i] = 0u; }
+// exclusive scan of one value per thread over the workgroup (1024 threads); *total gets the sum
+__device__ __forceinline__ u32 part_block_scan(u32 v, LDS_AS u32* wsum, u32 t, u32* total) {
+  const u32 lane = t & 63u, wave = t >> 6;
+  u32 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if (lane >= (u32)d) inc += o; }
+  if (lane == 63u) wsum[wave] = inc;
   __syncthreads();
-  const u64 begin = P.offsets[(u64)part * P.n_tiles];
-  const u64 end = part + 1u < P.n_parts ? (u64)P.offsets[(u64)(part + 1u) * P.n_tiles] : *P.total;
-  const u64* keys = reinterpret_cast<const u64*>(P.cols[0]);
-  const u32 special = P.G.capacity_mask + 1u;   // global slot of the EMPTY-valued key
-  for (u64 r0 = begin; r0 < end; r0 += (u64)SSGPU_PART_THREADS * PART_ROWS) {
-    u64 rr[PART_ROWS]; bool live[PART_ROWS], spec[PART_ROWS]; u32 li[PART_ROWS]; u64 kk[PART_ROWS];
+  u32 pre = 0, tot = 0;
+#pragma unroll
+  for (u32 w = 0; w < SSGPU_PART_THREADS / 64; ++w) { const u32 x = wsum[w]; if (w < wave) pre += x; tot += x; }
+  if (total) *total = tot;
+  __syncthreads();
+  return pre + inc - v;
+}
+
+template <int MAXW>
+__global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_part_agg_kernel(const PartAggParams P) {
+  typedef typename RecVec<MAXW>::type Rec;
+  const u32 t = threadIdx.x, part = blockIdx.x;
+  const u32 C = P.local_capacity, ng = P.n_gaggs, W = P.rec_words, G = P.n_segs;
+  // an entry's accumulator words are `st` words apart, st odd: the lanes of a wave hit word k of 64 different entries,
+  // and with an even stride (16 words = 128 B) those addresses fall into two LDS banks -- a 32-way conflict on every
+  // atomic (measured: 5x slower)
+  const u32 st = ng | 1u;
+  // LDS carve-up (C + 1 table entries: entry C belongs to the EMPTY-valued key)
+  LDS_AS u64* const lkeys = (LDS_AS u64*)0u;
+  LDS_AS u64* const lacc = lkeys + (C + 1u);
+  LDS_AS u32* const lcnt = (LDS_AS u32*)(lacc + (size_t)(C + 1u) * st);
+  LDS_AS u32* const segoff = lcnt + (P.any_cnt ? (C + 1u) * st : 0u);   // [G + 1] first record of every segment in the flat order
+  LDS_AS u32* const wsum = segoff + G + 1u;                              // [16] scan scratch
+  for (u32 e = t; e <= C; e += SSGPU_PART_THREADS) lkeys[e] = VM_KEY_EMPTY;
+  for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (P.any_cnt) lcnt[i] = 0u; }
+  u32 total = 0;
+  {
+    const u32 n = t < G ? P.counts[(u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
+    const u32 ex = part_block_scan(n, wsum, t, &total);
+    if (t < G) segoff[t] = ex;
+    if (t == 0) segoff[G] = total;
+  }
+  __syncthreads();
+  const u64* const recs = P.recs + (u64)part * G * P.seg_cap * W;
+  const u32 seg_cap = P.seg_cap, n_aggs = P.n_aggs;
+  const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
+  u32 seg = 0;
+  for (u32 base = 0; base < total; base += SSGPU_PART_THREADS * PART_ROWS) {
+    Rec rec[PART_ROWS]; bool live[PART_ROWS]; u32 li[PART_ROWS];
 #pragma unroll
     for (int j = 0; j < PART_ROWS; ++j) {
-      rr[j] = r0 + (u64)j * SSGPU_PART_THREADS + t;
-      live[j] = rr[j] < end;
-      kk[j] = live[j] ? keys[rr[j]] : 0ull;
-    }
+      const u32 i = base + (u32)j * SSGPU_PART_THREADS + t;
+      live[j] = i < total;
+      if (live[j]) {
+        while (i >= segoff[seg + 1u]) ++seg;              // empty segments are stepped over
+        const u64* rp = recs + ((u64)seg * seg_cap + (i - segoff[seg])) * W;
 #pragma unroll
-    for (int j = 0; j < PART_ROWS; ++j) {
-      spec[j] = live[j] && kk[j] == VM_KEY_EMPTY;
-      li[j] = 0;
-      if (spec[j]) {
-        __hip_atomic_store(&P.G.keys[special], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (live[j]) {
-        const u32 i0 = __umulhi(hash_local(kk[j]), C);
-        const u64 c0 = __hip_atomic_load(&lkeys[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const u32 sl = group_probe_local(lkeys, C, 0u, kk[j], i0, c0);
-        if (sl == 0xFFFFFFFFu) { atomicExch(P.G.overflow, 1u); live[j] = false; }  // partition too large: the host re-partitions finer
-        li[j] = sl * ng;
+        for (int w = 0; w < MAXW; ++w) rec[j][w] = (u32)w < W ? rp[w] : 0ull;
+      } else {
+#pragma unroll
+        for (int w = 0; w < MAXW; ++w) rec[j][w] = 0ull;
       }
     }
-    for (u32 s = 0; s < ng; ++s) {
-      const int vc = P.val_col[s], nc = P.null_col[s];
-      const bool has_cnt = P.has_cnt[s] != 0;
-      bool lv[PART_ROWS]; u64* AP[PART_ROWS];
+#pragma unroll
+    for (int j = 0; j < PART_ROWS; ++j) {
+      li[j] = C * st;
+      const u64 key = rec[j][0];
+      if (P.debug & 2u) { li[j] = __umulhi(hash_local(key), C) * st; continue; }   // development: no probe
+      if (live[j]) {
+        if (key == VM_KEY_EMPTY) {
+          lkeys[C] = 0ull;                               // marks the reserved entry as used
+        } else {
+          u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
+          for (int probe = 0; probe < 16; ++probe) {
+            const u64 cur = __hip_atomic_load(lkeys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == key) { found = i; break; }
+            if (cur == VM_KEY_EMPTY) {
+              u64 expect = VM_KEY_EMPTY;
+              if (__hip_atomic_compare_exchange_strong(lkeys + i, &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || expect == key) { found = i; break; }
+            }
+            i = i + 1u == C ? 0u : i + 1u;
+          }
+          if (found == 0xFFFFFFFFu) { atomicExch(P.T.overflow, 1u); live[j] = false; }   // partition too large: the host re-partitions finer
+          else li[j] = found * st;
+        }
+      }
+    }
+    u32 last_off = 0xFFFFFFFFu; u64 val[PART_ROWS];
+#pragma unroll
+    for (int j = 0; j < PART_ROWS; ++j) val[j] = 0;
+    if (P.debug & 1u) {   // development: records loaded and probed, nothing aggregated
+#pragma unroll
+      for (int j = 0; j < PART_ROWS; ++j) if (live[j]) LDS_ADD(lacc + li[j], rec[j][1] ^ rec[j][(MAXW - 1) & 4]);
+      continue;
+    }
+    for (u32 s = 0; s < n_aggs; ++s) {
+      // the aggregate's descriptor comes out of a register (lane s of `mydesc`): a scalar memory load here would
+      // share its wait counter with the LDS atomics in flight and drain them once per aggregate
+      const u64 d = readlane64(mydesc, (int)s);
+      const u32 op = (u32)(d & 0xFFFFu), word = (u32)(d >> 16) & 0xFFu, voff = (u32)(d >> 24) & 0xFFu, vw = (u32)(d >> 32) & 0xFFu,
+                noff = (u32)(d >> 40) & 0xFFu;
+      const bool has_cnt = ((d >> 48) & 1ull) != 0;
+      if (voff != 0xFFu && voff != last_off) {   // MIN / MAX / SUM of one column share the fetched value
+        last_off = voff;
+#pragma unroll
+        for (int j = 0; j < PART_ROWS; ++j) val[j] = rec_field(rec_word<MAXW>(rec[j], voff >> 3), voff, vw);
+      }
+      bool ok[PART_ROWS];
 #pragma unroll
       for (int j = 0; j < PART_ROWS; ++j) {
-        lv[j] = live[j] && !(nc >= 0 && reinterpret_cast<const u8*>(P.cols[nc])[rr[j]]);   // NULL input: skipped
-        // the EMPTY-valued key aggregates straight into its reserved global slot (at most one group)
-        AP[j] = spec[j] ? &P.G.acc[(u64)special * ng + s] : &lacc[li[j] + s];
-        if (has_cnt && lv[j]) { if (spec[j]) atomicAdd(&P.G.cnt[(u64)special * ng + s], 1u); else atomicAdd(&lcnt[li[j] + s], 1u); }
+        ok[j] = live[j];
+        if (noff != 0xFFu) ok[j] = ok[j] && rec_field(rec_word<MAXW>(rec[j], noff >> 3), noff, 1) == 0;   // NULL input: skipped
+        if (has_cnt && ok[j]) __hip_atomic_fetch_add(lcnt + li[j] + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      {
-        bool* live = lv;   // PART_APPLY works on the rows whose input is not NULL
-        switch (P.agg_op[s]) {
-          case VM_GAGG_COUNT: { _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) if (live[j]) atomicAdd(AP[j], 1ull); } break;
-          PART_APPLY(GAGG_SUM_I32, i32, atomicAdd(A, (u64)(i64)e))
-          PART_APPLY(GAGG_SUM_U32, u32, atomicAdd(A, (u64)e))
-          PART_APPLY(GAGG_SUM_I64, u64, atomicAdd(A, e))
-          PART_APPLY(GAGG_SUM_F32, float, unsafeAtomicAdd(reinterpret_cast<double*>(A), (double)e))
-          PART_APPLY(GAGG_SUM_F64, double, unsafeAtomicAdd(reinterpret_cast<double*>(A), e))
-          PART_APPLY(GAGG_MIN_I32, i32, atomicMin(A, key_i64((i64)e)))
-          PART_APPLY(GAGG_MIN_U32, u32, atomicMin(A, (u64)e))
-          PART_APPLY(GAGG_MIN_I64, i64, atomicMin(A, key_i64(e)))
-          PART_APPLY(GAGG_MIN_U64, u64, atomicMin(A, e))
-          PART_APPLY(GAGG_MIN_B8, u8, atomicMin(A, (u64)(e != 0)))
-          PART_APPLY(GAGG_MAX_I32, i32, atomicMax(A, key_i64((i64)e)))
-          PART_APPLY(GAGG_MAX_U32, u32, atomicMax(A, (u64)e))
-          PART_APPLY(GAGG_MAX_I64, i64, atomicMax(A, key_i64(e)))
-          PART_APPLY(GAGG_MAX_U64, u64, atomicMax(A, e))
-          PART_APPLY(GAGG_MAX_B8, u8, atomicMax(A, (u64)(e != 0)))
-          PART_APPLY(GAGG_MIN_F32, float, if (e == e) atomicMin(A, FKEY(e)))
-          PART_APPLY(GAGG_MIN_F64, double, if (e == e) atomicMin(A, FKEY(e)))
-          PART_APPLY(GAGG_MAX_F32, float, if (e == e) atomicMax(A, FKEY(e)))
-          PART_APPLY(GAGG_MAX_F64, double, if (e == e) atomicMax(A, FKEY(e)))
-          default: break;
-        }
+      switch (op) {
+        PART_APPLY(GAGG_COUNT, LDS_ADD(A, 1ull))
+        PART_APPLY(GAGG_SUM_I32, LDS_ADD(A, (u64)(i64)(i32)(u32)raw))
+        PART_APPLY(GAGG_SUM_U32, LDS_ADD(A, (u64)(u32)raw))
+        PART_APPLY(GAGG_SUM_I64, LDS_ADD(A, raw))
+        PART_APPLY(GAGG_SUM_F32, __hip_atomic_fetch_add((LDS_AS double*)A, (double)__uint_as_float((u32)raw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+        PART_APPLY(GAGG_SUM_F64, lds_dd_add((LDS_AS double*)A, u2d(raw)))
+        PART_APPLY(GAGG_MIN_I32, LDS_MIN(A, key_i64((i64)(i32)(u32)raw)))
+        PART_APPLY(GAGG_MIN_U32, LDS_MIN(A, (u64)(u32)raw))
+        PART_APPLY(GAGG_MIN_I64, LDS_MIN(A, key_i64((i64)raw)))
+        PART_APPLY(GAGG_MIN_U64, LDS_MIN(A, raw))
+        PART_APPLY(GAGG_MIN_B8, LDS_MIN(A, (u64)((raw & 0xFFull) != 0)))
+        PART_APPLY(GAGG_MAX_I32, LDS_MAX(A, key_i64((i64)(i32)(u32)raw)))
+        PART_APPLY(GAGG_MAX_U32, LDS_MAX(A, (u64)(u32)raw))
+        PART_APPLY(GAGG_MAX_I64, LDS_MAX(A, key_i64((i64)raw)))
+        PART_APPLY(GAGG_MAX_U64, LDS_MAX(A, raw))
+        PART_APPLY(GAGG_MAX_B8, LDS_MAX(A, (u64)((raw & 0xFFull) != 0)))
+        PART_APPLY(GAGG_MIN_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MIN(A, FKEY(e)); })
+        PART_APPLY(GAGG_MIN_F64, { const double e = u2d(raw); if (e == e) LDS_MIN(A, FKEY(e)); })
+        PART_APPLY(GAGG_MAX_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MAX(A, FKEY(e)); })
+        PART_APPLY(GAGG_MAX_F64, { const double e = u2d(raw); if (e == e) LDS_MAX(A, FKEY(e)); })
+        default: break;
       }
     }
   }
   __syncthreads();
-  // dump: local entry e of partition `part` = global slot part * C + e (empty entries stay empty)
-  for (u32 e = t; e < C; e += SSGPU_PART_THREADS) P.G.keys[(u64)part * C + e] = lkeys[e];
+  // dump: local entry e of partition `part` = global slot part * C + e (empty entries stay empty); the reserved
+  // entry, if this partition saw the EMPTY-valued key, = the global table's reserved slot
+  for (u32 e = t; e < C; e += SSGPU_PART_THREADS) P.T.keys[(u64)part * C + e] = lkeys[e];
   for (u32 i = t; i < C * ng; i += SSGPU_PART_THREADS) {
-    P.G.acc[(u64)part * C * ng + i] = lacc[i];
-    if (P.any_cnt) P.G.cnt[(u64)part * C * ng + i] = lcnt[i];
+    const u32 l = (i / ng) * st + i % ng;
+    P.T.acc[(u64)part * C * ng + i] = lacc[l];
+    if (P.any_cnt) P.T.cnt[(u64)part * C * ng + i] = lcnt[l];
+  }
+  if (lkeys[C] != VM_KEY_EMPTY) {
+    const u64 special = (u64)P.T.capacity_mask + 1ull;
+    if (t == 0) P.T.keys[special] = 0ull;
+    for (u32 i = t; i < ng; i += SSGPU_PART_THREADS) {
+      P.T.acc[special * ng + i] = lacc[(size_t)C * st + i];
+      if (P.any_cnt) P.T.cnt[special * ng + i] = lcnt[(size_t)C * st + i];
+    }
   }
 }
 
@@ -2423,11 +2612,14 @@ hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipS
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(ssgpu_part_agg_kernel, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
+  if (P.rec_words <= 8) hipLaunchKernelGGL(ssgpu_part_agg_kernel<8>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
+  else hipLaunchKernelGGL(ssgpu_part_agg_kernel<16>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
   return hipGetLastError();
 }
 hipError_t ssgpu_part_agg_set_max_lds(int bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
   hipError_t e;

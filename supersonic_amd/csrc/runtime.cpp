@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <unistd.h>
 #include <thread>
@@ -43,6 +44,11 @@ struct ssgpu_ctx {
   int64_t group_capacity = 1 << 18;
   int64_t group_local = 1;       // 0: never use the LDS pre-aggregation table
   int64_t group_partition = 1;   // 0: never switch to the partitioned GroupAggregate; 2: always use it
+  int64_t part_n = 0;            // initial number of hash partitions (0 = 512)
+  int64_t part_wgs_per_cu = 0;   // resident workgroups per CU of the scatter pass (0 = wgs_per_cu)
+  int64_t part_lds_target = 0;   // LDS target of the scatter pass's tile (0 = lds_target_bytes)
+  int64_t part_agg_debug = 0;
+  int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
   int64_t profile = 1;           // record HIP events around kernels
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
@@ -97,11 +103,14 @@ struct StageExec {
   int group_sub = 1;            // sub-tables of the LDS table (spreads same-group rows of a wave)
   // partitioned execution (many groups)
   bool group_partitioned = false;
-  uint32_t part_n = 512;        // hash partitions (doubled when a partition overflows its LDS table)
-  DevBuf prog_pcount, prog_pscatter, part_hist, part_offs;
-  ProgramLayout lay_pcount{}, lay_pscatter{};
-  int n_instr_pcount = 0, n_instr_pscatter = 0;
-  std::vector<DevBuf> part_cols;
+  uint32_t part_n = 256;        // hash partitions (doubled when a partition overflows its LDS table)
+  bool part_n_chosen = false;
+  double part_groups_est = 0;   // group count estimated by the direct path's run feedback
+  uint32_t part_seg_growth = 1; // x4 whenever a (partition, workgroup) segment ran full
+  bool part_failed = false;     // the partitioned shape could not hold this input: stay on the direct path
+  DevBuf prog_pscatter, part_hist, part_recs;
+  ProgramLayout lay_pscatter{};
+  int n_instr_pscatter = 0;
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jrows, jmisc;
@@ -226,6 +235,11 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 3;
   else if (k == "group_local") c->group_local = value;
   else if (k == "group_partition") c->group_partition = value;
+  else if (k == "part_n") c->part_n = value;
+  else if (k == "part_wgs_per_cu") c->part_wgs_per_cu = value;
+  else if (k == "part_lds_target") c->part_lds_target = value;
+  else if (k == "part_agg_lds") c->part_agg_lds = value;
+  else if (k == "part_agg_debug") c->part_agg_debug = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -901,29 +915,35 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
 
 // GroupAggregate with many groups (run feedback: the workgroup-private LDS table of the direct
 // path is bypassed by most rows, i.e. the 24 G/s global atomic rate would bound the stage):
-//   1. PART_COUNT pass   per-tile histogram of hash partitions            (reads the key columns)
-//   2. scan              [partition][tile] offsets
-//   3. PART_RANK pass    key + distinct aggregate inputs scattered into their partition
-//   4. ssgpu_part_agg    one workgroup per partition aggregates it in LDS, no global atomics
-//   5. the usual extraction over the dumped tables
-int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
+//   1. scatter pass     ONE pipeline launch: every selected row becomes a record (packed key + the distinct
+//                       aggregate inputs) in the segment of its (hash partition, workgroup) -- segments are
+//                       over-allocated and private to a workgroup, so there is no count pass and no scan
+//   2. ssgpu_part_agg   one workgroup per partition aggregates its segments in LDS, no global atomics
+//   3. the usual extraction over the dumped tables
+// A segment that runs full (skewed keys) reruns with 4x larger segments; a partition with more groups than its
+// LDS table holds reruns with twice the partitions.  *fallback is set when neither can be satisfied.
+int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base, bool* fallback) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  *fallback = false;
   if (!ex.prog_pscatter.p) {
     LowerOptions o = c->opt;
+    if (c->part_lds_target > 0) o.lds_target_bytes = (int)c->part_lds_target;
     ex.lay_pscatter = layout_program(st.part_scatter, o);
-    o.tile_rows = VM_TILE_UNIT * ex.lay_pscatter.K;
-    ex.lay_pcount = layout_program(st.part_count, o);
-    if (ex.lay_pcount.K != ex.lay_pscatter.K) { c->err = "partition passes disagree on the tile size"; return SSGPU_ERROR_UNKNOWN; }
     int rc = upload_program(c, st.part_scatter, ex.lay_pscatter, &ex.prog_pscatter, &ex.n_instr_pscatter, &p->host_prog_scratch);
-    if (rc != SSGPU_OK) return rc;
-    rc = upload_program(c, st.part_count, ex.lay_pcount, &ex.prog_pcount, &ex.n_instr_pcount, &p->host_prog_scratch);
     if (rc != SSGPU_OK) return rc;
   }
   bool any_cnt = false;
   for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
-  const uint32_t entry = 8u + ng * 8u + (any_cnt ? ng * 4u : 0u);
-  const uint32_t C = std::max<uint32_t>(16u, (80u * 1024u) / entry);   // two 1024-thread workgroups per CU
+  const uint32_t W = st.part_rec_bytes / 8u;
+  // phase 2's LDS (two 1024-thread workgroups per CU): per table entry the key, the accumulator words and the
+  // contribution counts (C entries + the reserved one of the EMPTY-valued key), plus the segment offsets
+  const uint32_t stw = ng | 1u;   // accumulator words of an LDS entry are an odd number of words apart (bank conflicts, see the kernel)
+  const uint32_t entry = 8u + stw * 8u + (any_cnt ? stw * 4u : 0u);
+  const uint32_t fixed = entry + (1024u + 1u) * 4u + 64u + 64u;
+  const uint32_t budget = (c->part_agg_lds > 0 ? (uint32_t)c->part_agg_lds : 80u * 1024u);
+  if (fixed + 64u * entry > budget) { *fallback = true; return SSGPU_OK; }
+  const uint32_t C = (budget - fixed) / entry;
   HIP_TRY(c, ex.gpattern.ensure(ng * 8));
   if (!ex.pattern_ready) {
     std::vector<uint64_t> pattern(ng, 0);
@@ -936,80 +956,111 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     ex.pattern_ready = true;
   }
   HIP_TRY(c, ex.goverflow.ensure(16));
-  HIP_TRY(c, ex.total.ensure(8));
-  ex.part_cols.resize(st.part_col_width.size());
-  for (size_t i = 0; i < ex.part_cols.size(); ++i)
-    HIP_TRY(c, ex.part_cols[i].ensure((size_t)std::max<int64_t>(in.rows, 1) * st.part_col_width[i] + 16));
-  for (int attempt = 0; attempt < 6; ++attempt) {
+  if (!ex.part_n_chosen) {
+    // partitions: enough that a partition's groups load its table to about one half (the direct path's run feedback
+    // left an estimate of the group count); one partition per CU or more keeps phase 2's single wave of workgroups full
+    ex.part_n_chosen = true;
+    if (c->part_n > 0) ex.part_n = (uint32_t)c->part_n;
+    else {
+      uint32_t pn = 256;
+      while (ex.part_groups_est > 0.5 * (double)pn * (double)C && pn < 8192) pn *= 2;
+      ex.part_n = pn;
+    }
+  }
+  for (int attempt = 0; attempt < 8; ++attempt) {
     const uint32_t NP = ex.part_n;
     const uint32_t capacity = NP * C;
     const size_t slots = (size_t)capacity + 1;
+    VmParams Ps;
+    fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
+    apply_joins(p, ex, st.part_scatter, &Ps);
+    Ps.part_n = NP;
+    // behind the program's registers: four u32 arrays of NP entries, the tile's record index by sorted position, and
+    // the staging area where the tile's records are assembled in partition order (see VM_PART_RANK)
+    Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u;
+    Ps.lds_bytes = Ps.part_lds_off + NP * 16u + (uint32_t)Ps.tile_rows * 4u + 16u + (uint32_t)Ps.tile_rows * st.part_rec_bytes;
+    if (Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
+    ProgramLayout Ls = ex.lay_pscatter; Ls.lds_bytes = Ps.lds_bytes;
+    int grid;
+    {
+      const int64_t saved = c->wgs_per_cu;
+      if (c->part_wgs_per_cu > 0) c->wgs_per_cu = c->part_wgs_per_cu;
+      grid = std::min(grid_for(c, Ls, Ps.n_tiles), 1024);   // phase 2 scans a partition's segment counts with one thread each
+      c->wgs_per_cu = saved;
+    }
+    // records a (partition, workgroup) segment holds: the expected share of the INPUT rows (an upper bound of the
+    // selected ones) with head room for the spread of a uniform hash, times the growth factor of earlier overflows
+    const double expect = (double)std::max<int64_t>(in.rows, 1) / ((double)NP * (double)grid);
+    const uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
+    const uint64_t n_segs = (uint64_t)NP * (uint64_t)grid;
+    if (n_segs * seg_cap >= 0xFFFFFFFFull) { *fallback = true; return SSGPU_OK; }   // record indices are 32-bit
     HIP_TRY(c, ex.gkeys.ensure(slots * 8));
     HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
     HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
+    if (ex.part_recs.ensure(n_segs * seg_cap * st.part_rec_bytes + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
+    HIP_TRY(c, ex.part_hist.ensure(n_segs * 4));
     // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
     HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>() + capacity, VM_KEY_EMPTY, 1, c->stream));
     HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>() + (size_t)capacity * ng, ex.gpattern.as<uint64_t>(), ng, ng, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.gcnt.as<uint32_t>() + (size_t)capacity * ng, 0, ng * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
-    VmParams Pc, Ps;
-    fill_params(&Pc, st.part_count, ex.lay_pcount, ex.prog_pcount, ex.n_instr_pcount, in, row_id_base);
-    apply_joins(p, ex, st.part_count, &Pc);
-    fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
-    apply_joins(p, ex, st.part_scatter, &Ps);
-    Pc.part_n = Ps.part_n = NP;
-    Pc.part_lds_off = (Pc.lds_bytes + 15u) & ~15u; Pc.lds_bytes = Pc.part_lds_off + NP * 4u;
-    Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u; Ps.lds_bytes = Ps.part_lds_off + NP * 4u;
-    // both passes MUST run the same grid: the counters are per (partition, workgroup) and a
-    // persistent workgroup has to meet the same tiles in both
-    ProgramLayout Ls = ex.lay_pscatter; Ls.lds_bytes = std::max(Ps.lds_bytes, Pc.lds_bytes);
-    const int grid = grid_for(c, Ls, Ps.n_tiles);
-    const size_t cells = (size_t)NP * (size_t)grid;
-    HIP_TRY(c, ex.part_hist.ensure(cells * 4));
-    HIP_TRY(c, ex.part_offs.ensure(cells * 4));
-    Pc.error_flag = ex.error_flag.as<unsigned int>();
-    Pc.tile_counts = ex.part_hist.as<unsigned int>();
-    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    HIP_TRY(c, ssgpu_launch_pipeline(Pc, ex.lay_pcount.K, grid, c->stream));
-    HIP_TRY(c, ssgpu_launch_scan_counts(ex.part_hist.as<uint32_t>(), ex.part_offs.as<uint32_t>(), (int)cells, ex.total.as<uint64_t>(), c->stream));
     Ps.error_flag = ex.error_flag.as<unsigned int>();
-    Ps.tile_offsets = ex.part_offs.as<unsigned int>();
-    for (size_t i = 0; i < ex.part_cols.size(); ++i) { Ps.outputs[i].dst = ex.part_cols[i].p; Ps.outputs[i].width = st.part_col_width[i]; }
+    Ps.tile_counts = ex.part_hist.as<unsigned int>();
+    Ps.part_seg_cap = (uint32_t)seg_cap;
+    Ps.part_overflow = ex.goverflow.as<unsigned int>() + 1;
+    Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
+    { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
     HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
+    { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
     PartAggParams A;
     memset(&A, 0, sizeof(A));
-    for (size_t i = 0; i < ex.part_cols.size(); ++i) A.cols[i] = ex.part_cols[i].p;
-    A.offsets = ex.part_offs.as<unsigned int>();
-    A.total = ex.total.as<unsigned long long>();
-    A.n_tiles = (unsigned int)grid; A.n_parts = NP; A.local_capacity = C; A.n_gaggs = ng; A.any_cnt = any_cnt ? 1u : 0u;
-    A.G.keys = ex.gkeys.as<unsigned long long>(); A.G.acc = ex.gacc.as<unsigned long long>(); A.G.cnt = ex.gcnt.as<unsigned int>();
-    A.G.overflow = ex.goverflow.as<unsigned int>(); A.G.capacity_mask = capacity - 1u; A.G.n_gaggs = ng;
-    A.G.acc_init = ex.gpattern.as<unsigned long long>(); A.G.merge_op = ex.gmergeop.as<unsigned int>();
+    A.recs = ex.part_recs.as<unsigned long long>();
+    A.counts = ex.part_hist.as<unsigned int>();
+    A.n_segs = (unsigned int)grid; A.seg_cap = (unsigned int)seg_cap; A.rec_words = W; A.n_parts = NP;
+    A.debug = (unsigned int)c->part_agg_debug;
+    A.local_capacity = C; A.n_gaggs = ng; A.n_aggs = (unsigned int)st.part_aggs.size(); A.any_cnt = any_cnt ? 1u : 0u;
+    A.T.keys = ex.gkeys.as<unsigned long long>(); A.T.acc = ex.gacc.as<unsigned long long>(); A.T.cnt = ex.gcnt.as<unsigned int>();
+    A.T.overflow = ex.goverflow.as<unsigned int>(); A.T.capacity_mask = capacity - 1u; A.T.n_gaggs = ng;
+    A.T.acc_init = ex.gpattern.as<unsigned long long>(); A.T.merge_op = ex.gmergeop.as<unsigned int>();
     for (size_t j = 0; j < st.part_aggs.size(); ++j) {
-      A.agg_op[j] = st.part_aggs[j].op; A.val_col[j] = st.part_aggs[j].val_col;
-      A.null_col[j] = st.part_aggs[j].null_col; A.has_cnt[j] = st.part_aggs[j].has_cnt;
+      const Stage::PartAgg& a = st.part_aggs[j];
+      A.desc[j] = (uint64_t)(uint16_t)a.op | ((uint64_t)(uint8_t)a.word << 16) | ((uint64_t)(uint8_t)(a.val_off < 0 ? 0xFF : a.val_off) << 24) |
+                  ((uint64_t)(uint8_t)a.val_width << 32) | ((uint64_t)(uint8_t)(a.null_off < 0 ? 0xFF : a.null_off) << 40) | ((uint64_t)(a.has_cnt ? 1 : 0) << 48);
     }
-    HIP_TRY(c, ssgpu_launch_part_agg(A, C * entry, c->stream));
+    HIP_TRY(c, ssgpu_launch_part_agg(A, fixed + C * entry, c->stream));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
-    p->counters.n_launches += 8;
+    p->counters.n_launches += 6;
     p->counters.tile_rows = Ps.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)Ps.lds_bytes;
-    uint32_t fb[4] = {0, 0, 0, 0};
+    uint32_t fb[4] = {0, 0, 0, 0};   // [0] a partition outgrew its LDS table, [1] a segment ran full
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, overflow=%u\n", NP, C, fb[0]);
+    if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, grid %d, segments of %llu records (%u B), table overflow=%u segment overflow=%u\n",
+                                 NP, C, grid, (unsigned long long)seg_cap, st.part_rec_bytes, fb[0], fb[1]);
+    if (fb[1]) {   // skewed keys: larger segments (memory permitting), else the direct path
+      if (ex.part_seg_growth >= 64) { *fallback = true; return SSGPU_OK; }
+      ex.part_seg_growth *= 4;
+      continue;
+    }
     if (!fb[0]) return extract_groups(p, st, ex, capacity, ng, in, row_id_base);
     if (ex.part_n >= 8192) break;
     ex.part_n *= 2;   // a partition held more groups than its LDS table: partition finer and rerun
   }
-  c->err = "GroupAggregate: a hash partition does not fit the on-chip group table";
-  return SSGPU_ERROR_MEMORY_EXCEEDED;
+  *fallback = true;
+  return SSGPU_OK;
 }
 
 int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
-  if ((ex.group_partitioned || c->group_partition == 2) && !st.part_scatter.empty()) return run_group_agg_partitioned(p, si, in, row_id_base);
+  if ((ex.group_partitioned || c->group_partition == 2) && !st.part_scatter.empty()) {
+    bool fallback = false;
+    const int rc = run_group_agg_partitioned(p, si, in, row_id_base, &fallback);
+    if (rc != SSGPU_OK || !fallback) return rc;
+    // heavily skewed keys / too many groups per partition: the direct path (global table behind the LDS table) always works
+    ex.group_partitioned = false; ex.group_local = true; ex.part_failed = true;
+  }
   if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
   for (int attempt = 0; attempt < 8; ++attempt) {
     const size_t slots = (size_t)ex.capacity + 1;
@@ -1050,7 +1101,8 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     // entries as the LDS share of `group_wgs` resident workgroups per CU leaves room for
     bool any_cnt = false;
     for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
-    const uint32_t entry = 8u + ng * 8u + (any_cnt ? ng * 4u : 0u);
+    const uint32_t lstride = ng | 1u;   // odd word stride between LDS entries (bank conflicts, see VmGroupTable)
+    const uint32_t entry = 8u + lstride * 8u + (any_cnt ? lstride * 4u : 0u);
     const uint32_t base = (ex.lay.lds_bytes + 15u) & ~15u;
     auto local_capacity_for = [&](int wgs) -> uint32_t {
       const uint32_t share = (160u * 1024u) / (uint32_t)wgs;
@@ -1063,10 +1115,11 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     P.group.local_capacity = lcap;
     P.group.local_sub = lsub;
     P.group.local_sub_capacity = lcap / lsub;
+    P.group.local_stride = lstride;
     if (lcap) {
       P.group.local_keys_off = base;
       P.group.local_acc_off = base + lcap * 8u;
-      P.group.local_cnt_off = any_cnt ? base + lcap * 8u + lcap * ng * 8u : VM_NONE;
+      P.group.local_cnt_off = any_cnt ? base + lcap * 8u + lcap * lstride * 8u : VM_NONE;
       P.lds_bytes = base + lcap * entry;
     }
     int grid;
@@ -1112,7 +1165,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         for (int w = 4; w >= 1; --w) if ((double)local_capacity_for(w) * 0.9 >= groups) { best = w; break; }
         if (best > 0 && best != ex.group_wgs) ex.group_wgs = best;
         else if (best == 0 || (best == ex.group_wgs && (double)fb[1] * 4.0 >= rows)) {
-          if (c->group_partition && !st.part_scatter.empty() && in.rows >= (1 << 20)) ex.group_partitioned = true;
+          if (c->group_partition && !st.part_scatter.empty() && !ex.part_failed && in.rows >= (1 << 20)) { ex.group_partitioned = true; ex.part_groups_est = groups; }
           else if ((double)fb[1] * 2.0 >= rows) ex.group_local = false;
         }
       }

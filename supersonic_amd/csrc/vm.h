@@ -116,10 +116,14 @@ enum { VM_MATH_EXP = 1, VM_MATH_LN, VM_MATH_LOG10, VM_MATH_LOG2, VM_MATH_SIN, VM
   X(AGG_SUM_F64_ADD) X(AGG_SUM_F64_SUB) X(AGG_SUM_F64_MUL)                     \
   /* ---- materialising sinks ---------------------------------------------- */\
   X(SEL_COUNT)   /* a = sel: tile_counts[tile] = #selected        */           \
-  X(SEL_RANK) X(PART_COUNT) X(PART_RANK) X(JOIN_PROBE) X(IDX_VALID) X(GATHER_64) X(GATHER_32) X(GATHER_8) X(GATHER_NULL)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
+  X(SEL_RANK) X(PART_RANK) X(PART_REC_8) X(PART_REC_32) X(PART_REC_64) X(PART_REC_128) X(PART_FLUSH) X(JOIN_PROBE) X(IDX_VALID) X(GATHER_64) X(GATHER_32) X(GATHER_8) X(GATHER_NULL)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
   X(STORE_8) X(STORE_32) X(STORE_64)     /* dst = out col, a = reg, rows 1:1 */\
   X(STOREC_8) X(STOREC_32) X(STOREC_64)  /* + b = rank reg, c = sel (compact)*/\
   X(STORE_ROWID) /* dst = out col: int64 global row id of survivors, b,c */    \
+  /* PART_RANK: a = key(64), c = sel -> dst = u32 position of the row in the tile's partition-sorted order,    */\
+  /* VM_NONE for unselected rows; PART_REC_*: a (, d) = value reg(s), b = position reg, imm = byte offset      */\
+  /* inside the record | record bytes << 16 (AoS records in the LDS staging area); PART_FLUSH: imm = record    */\
+  /* bytes: staging area -> the rows' (hash partition, workgroup) segments of outputs[0]                       */\
   /* ---- group-aggregate sinks --------------------------------------------- */\
   X(KEY_ZERO)    /* dst(64) = 0 */                                             \
   X(KEY_APPEND_8) X(KEY_APPEND_32) X(KEY_APPEND_64)                            \
@@ -188,6 +192,9 @@ struct VmGroupTable {
   uint32_t local_keys_off;       /* LDS offsets: u64 keys[C], u64 acc[C][n], u32 cnt[C][n] */
   uint32_t local_acc_off;
   uint32_t local_cnt_off;        /* VM_NONE: no aggregate needs a contribution count */
+  uint32_t local_stride;         /* accumulator words between two LDS entries: n_gaggs made odd (an even stride puts word k of
+                                    every entry into a few LDS banks: 8- to 32-way conflicts on every atomic) */
+  uint32_t local_pad;
   uint32_t n_gaggs;
   const unsigned long long* acc_init;  /* [n_gaggs] identities                      */
   const unsigned int* merge_op;        /* [n_gaggs] VM_MERGE_*                       */
@@ -197,6 +204,7 @@ struct VmGroupTable {
 #define VM_MERGE_MIN_U64 1u
 #define VM_MERGE_MAX_U64 2u
 #define VM_MERGE_ADD_F64 3u
+#define VM_MERGE_ADD_F64_HI 4u /* high word of a compensated DOUBLE sum: the rounding error of the merge goes to word s + 1 */
 #define VM_SLOT_LOCAL 0x80000000u /* GRP_INSERT result: index into the LDS table */
 #define VM_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -235,9 +243,12 @@ struct VmParams {
   uint64_t slot_init1[VM_FAST_SLOTS];
   int32_t slot_kind[VM_FAST_SLOTS];   /* SlotKind of the fast slots */
   VmAccRec* wg_partials;        /* [grid][n_slots] */
-  unsigned int* tile_counts;    /* SEL_COUNT output / scanned offsets input; PART_*: [partition][workgroup] */
-  uint32_t part_n;              /* PART_COUNT / PART_RANK: number of hash partitions */
+  unsigned int* tile_counts;    /* SEL_COUNT output / scanned offsets input; PART_RANK: rows of segment [partition][workgroup] */
+  uint32_t part_n;              /* PART_RANK: number of hash partitions */
   uint32_t part_lds_off;        /* LDS offset of part_n u32 counters */
+  uint32_t part_seg_cap;        /* PART_RANK: records a (partition, workgroup) segment holds */
+  uint32_t part_pad;
+  unsigned int* part_overflow;  /* PART_RANK: set to 1 when a segment was full (the host reruns with larger segments) */
   const unsigned int* tile_offsets;
   unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */

@@ -267,6 +267,24 @@ def test_group_aggregate_partitioned_many_groups():
         assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="adaptive group run")
 
 
+def test_group_aggregate_partitioned_skewed_keys():
+    # one hot key takes 90 % of the rows: its (partition, workgroup) segments run full, the stage reruns with larger
+    # segments (x4 per attempt) and, if that is not enough, falls back to the direct path -- the rows never change
+    n = 300000
+    rng = np.random.default_rng(9)
+    key = np.where(rng.random(n) < 0.9, 77, rng.integers(0, 50000, n)).astype(np.int64)
+    val = rng.integers(-1000, 1000, n).astype(np.int64)
+    d = rng.integers(-4000, 4000, n) * 0.25
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64), ss.Attribute("d", ss.DOUBLE)])
+    view = ss.View(schema, [ss.Column(key), ss.Column(val), ss.Column(d)], n)
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "c").AddAggregation(ss.MIN, "v", "mn")
+            .AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MAX, "d", "mxd"))
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view))
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", 2)
+    run_both(op, ctx, ignore_order=True)
+
+
 def test_sharded_group_aggregate_merge_plan_on_device(gpu_ctx):
     # the multi-GPU GroupAggregate (per-shard aggregate -> all-gather -> merge aggregate) with the
     # device executor; one rank here, the world_size-2 exchange is covered on CPU (gloo)

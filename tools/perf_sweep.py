@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--debug", type=int, default=0)
     ap.add_argument("--wgs", type=int, default=0)
+    ap.add_argument("--opts", default="", help="extra context options: key=value,key=value")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cols = bench.gen_device_columns(torch, args.rows, 42, dev)
@@ -166,6 +167,8 @@ def main():
                     ctx.set_option("grid_limit", grid)
                     ctx.set_option("debug_timing", args.debug)
                     ctx.set_option("wgs_per_cu", args.wgs)
+                    for kv in [x for x in args.opts.split(",") if x]:
+                        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
                     try:
                         plan = ss.Plan(QUERIES[qn](view), ctx)
                         ms = []
