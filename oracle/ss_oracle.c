@@ -134,6 +134,7 @@ typedef struct bnode {
   char name[256];
   void* buf;          /* result data, ORC_BLOCK rows */
   uint8_t* nullbuf;   /* result is_null, ORC_BLOCK rows */
+  uint8_t* skipbuf;   /* skip vector handed to a child, ORC_BLOCK rows (allocated on first use) */
   const void* data;   /* evaluation result for the current block */
   const uint8_t* nulls;
 } bnode;
@@ -307,7 +308,7 @@ static int common_type(int t1, int t2, orc_error* err) {
   return -1;
 }
 
-static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err);
+static void eval_node(bnode* b, const orc_view* in, int64_t n, const uint8_t* skip, orc_error* err);
 static int all_const(bnode* b) {
   for (int i = 0; i < b->nargs; ++i) if (b->args[i]->kind != B_CONST && b->args[i]->kind != B_NULLCONST) return 0;
   return b->nargs > 0;
@@ -319,7 +320,7 @@ static bnode* fold(bnode* b, orc_error* err) {
   if ((b->kind != B_OP && b->kind != B_CAST) || !all_const(b)) return b;
   orc_view dummy; memset(&dummy, 0, sizeof(dummy)); dummy.rows = 1;
   orc_error local; memset(&local, 0, sizeof(local));
-  eval_node(b, &dummy, 1, &local);
+  eval_node(b, &dummy, 1, NULL, &local);
   if (local.code) { if (err && !err->code) *err = local; return b; }
   if (b->nulls && b->nulls[0]) return make_null(b->dtype);
   uint64_t bits = 0; memcpy(&bits, b->data, (size_t)type_width(b->dtype));
@@ -676,14 +677,101 @@ static void fill_const(bnode* b, int64_t n) {
   for (int64_t i = 0; i < n; ++i) memcpy((char*)b->buf + i * w, &b->bits, (size_t)w);
 }
 
-static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
+/* `skip` (NULL = no row skipped): rows the parent does not need.  The reference hands every child a skip vector --
+ * the branches of IF only see the rows that chose them (elementary_bound_expressions.cc:935-955), the right side of
+ * AND / OR / AND_NOT only the rows the left side has not decided (:279-318), a WHEN / THEN of CASE only the rows not
+ * yet written / matched (:640-690), and the children of every other operator share ONE vector that each ORs its NULLs
+ * into before the next child runs (abstract_bound_expressions.h:129-147) -- and a failing operator never fails on a
+ * skipped row (BinaryFailureChecker takes the skip vector as is_null).  Values are still computed on every row here
+ * (they are unspecified on skipped rows in the reference); only the failure checks look at `skip`. */
+static const uint8_t* child_skip(bnode* b, const uint8_t* skip, const uint8_t* extra, int negate_extra, int64_t n) {
+  if (!extra && !negate_extra) return skip;
+  if (!b->skipbuf) b->skipbuf = (uint8_t*)calloc(ORC_BLOCK, 1);
+  for (int64_t i = 0; i < n; ++i) {
+    const int e = extra ? extra[i] != 0 : 0;
+    b->skipbuf[i] = (uint8_t)((skip ? skip[i] != 0 : 0) || (negate_extra ? !e : e));
+  }
+  return b->skipbuf;
+}
+
+static void eval_node(bnode* b, const orc_view* in, int64_t n, const uint8_t* skip, orc_error* err) {
   switch (b->kind) {
     case B_INPUT: b->data = in->c[b->input_col].data; b->nulls = in->c[b->input_col].is_null; return;
     case B_CONST: fill_const(b, n); b->data = b->buf; b->nulls = NULL; return;  /* PostInit pre-fill */
     case B_NULLCONST: memset(b->buf, 0, (size_t)n * 8); memset(b->nullbuf, 1, (size_t)n); b->data = b->buf; b->nulls = b->nullbuf; return;
     default: break;
   }
-  for (int i = 0; i < b->nargs; ++i) { eval_node(b->args[i], in, n, err); if (err->code) return; }
+  if (b->kind == B_OP && (b->op == OP_IF || b->op == OP_NULLING_IF) && b->nargs == 3) {
+    eval_node(b->args[0], in, n, skip, err); if (err->code) return;
+    bnode* c = b->args[0];
+    uint8_t* choice = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));      /* condition TRUE and not NULL */
+    for (int64_t i = 0; i < n; ++i) choice[i] = (uint8_t)(((const uint8_t*)c->data)[i] != 0 && !(c->nulls && c->nulls[i]));
+    eval_node(b->args[1], in, n, child_skip(b, skip, choice, 1, n), err);
+    if (!err->code) {
+      if (b->op == OP_NULLING_IF && c->nulls) for (int64_t i = 0; i < n; ++i) choice[i] = (uint8_t)(choice[i] || c->nulls[i]);   /* a NULL condition skips both */
+      eval_node(b->args[2], in, n, child_skip(b, skip, choice, 0, n), err);
+    }
+    free(choice);
+    if (err->code) return;
+  } else if (b->kind == B_OP && (b->op == OP_AND || b->op == OP_OR || b->op == OP_AND_NOT) && b->nargs == 2) {
+    eval_node(b->args[0], in, n, skip, err); if (err->code) return;
+    bnode* l = b->args[0];
+    uint8_t* decided = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));     /* left not NULL and TRUE (OR, AND_NOT) / FALSE (AND) */
+    for (int64_t i = 0; i < n; ++i) {
+      const int lv = ((const uint8_t*)l->data)[i] != 0, ln = l->nulls && l->nulls[i];
+      decided[i] = (uint8_t)(!ln && (b->op == OP_AND ? !lv : lv));
+    }
+    eval_node(b->args[1], in, n, child_skip(b, skip, decided, 0, n), err);
+    free(decided);
+    if (err->code) return;
+  } else if (b->kind == B_OP && b->op == OP_IF_NULL && b->nargs == 2) {
+    /* the replacement is evaluated only where the first argument IS NULL (elementary_expressions_test.cc:377-394) */
+    eval_node(b->args[0], in, n, skip, err); if (err->code) return;
+    if (b->args[0]->nulls) eval_node(b->args[1], in, n, child_skip(b, skip, b->args[0]->nulls, 1, n), err);
+    else { uint8_t* all = (uint8_t*)malloc((size_t)(n > 0 ? n : 1)); memset(all, 1, (size_t)(n > 0 ? n : 1)); eval_node(b->args[1], in, n, all, err); free(all); }
+    if (err->code) return;
+  } else if (b->kind == B_OP && b->op == OP_CASE) {
+    /* CASE value, OTHERWISE, then (WHEN, THEN) pairs: a WHEN sees the rows no earlier WHEN matched, its THEN the rows it matched */
+    eval_node(b->args[0], in, n, skip, err); if (err->code) return;
+    bnode* cv = b->args[0]; const int tw = type_width(cv->dtype);
+    uint8_t* written = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+    uint8_t* match = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) written[i] = (uint8_t)((skip && skip[i]) || (cv->nulls && cv->nulls[i]));
+    for (int a = 2; a + 1 < b->nargs && !err->code; a += 2) {
+      bnode* wn = b->args[a];
+      eval_node(wn, in, n, child_skip(b, NULL, written, 0, n), err); if (err->code) break;
+      for (int64_t i = 0; i < n; ++i) {
+        int eq = 0;
+        if (!written[i] && !(wn->nulls && wn->nulls[i])) {
+          if (cv->dtype == T_DOUBLE) eq = ((const double*)cv->data)[i] == ((const double*)wn->data)[i];
+          else if (cv->dtype == T_FLOAT) eq = ((const float*)cv->data)[i] == ((const float*)wn->data)[i];
+          else eq = memcmp((const char*)cv->data + i * tw, (const char*)wn->data + i * tw, (size_t)tw) == 0;
+        }
+        match[i] = (uint8_t)eq;
+      }
+      eval_node(b->args[a + 1], in, n, child_skip(b, NULL, match, 1, n), err);
+      for (int64_t i = 0; i < n; ++i) written[i] = (uint8_t)(written[i] || match[i]);
+    }
+    if (!err->code) {   /* OTHERWISE: rows not written, plus the rows whose CASE value is NULL (but not the parent's skipped rows) */
+      for (int64_t i = 0; i < n; ++i) written[i] = (uint8_t)((skip && skip[i]) || (written[i] && !(cv->nulls && cv->nulls[i])));
+      eval_node(b->args[1], in, n, child_skip(b, NULL, written, 0, n), err);
+    }
+    free(written); free(match);
+    if (err->code) return;
+  } else {
+    /* one shared skip vector: every child adds its NULLs before the next one is evaluated */
+    const uint8_t* cur = skip; uint8_t* acc = NULL;
+    for (int i = 0; i < b->nargs; ++i) {
+      eval_node(b->args[i], in, n, cur, err);
+      if (err->code) { free(acc); return; }
+      if (b->args[i]->nulls && i + 1 < b->nargs) {
+        if (!acc) { acc = (uint8_t*)malloc((size_t)(n > 0 ? n : 1)); for (int64_t r = 0; r < n; ++r) acc[r] = (uint8_t)(cur ? cur[r] != 0 : 0); }
+        for (int64_t r = 0; r < n; ++r) acc[r] = (uint8_t)(acc[r] || b->args[i]->nulls[r]);
+        cur = acc;
+      }
+    }
+    free(acc);
+  }
   bnode* x = b->args[0]; bnode* y = b->nargs > 1 ? b->args[1] : NULL;
   b->data = b->buf; b->nulls = NULL;
   if (b->kind == B_CAST) {
@@ -800,7 +888,7 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
           if (b->op == OP_SQRT_NULLING) {
             if (b->nulls != b->nullbuf) { if (x->nulls) memcpy(b->nullbuf, x->nulls, (size_t)n); else memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; }
             b->nullbuf[i] = 1;
-          } else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative argument in %s%s", b->name, ""); return; }
+          } else if (!already_null && !(skip && skip[i])) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative argument in %s%s", b->name, ""); return; }
         }
       return;
     }
@@ -821,7 +909,7 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
           if (b->op == OP_POW_NULLING) {
             if (!b->nulls) { memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; }
             b->nullbuf[i] = 1;
-          } else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative base with a non-integer exponent in %s%s", b->name, ""); return; }
+          } else if (!already_null && !(skip && skip[i])) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: negative base with a non-integer exponent in %s%s", b->name, ""); return; }
         }
       return;
     }
@@ -848,8 +936,8 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
       /* BoundCaseExpression::DoEvaluate (elementary_bound_expressions.cc:595-760): the first WHEN
        * that is non-NULL and equal to a non-NULL CASE value selects its THEN; otherwise (no match,
        * or CASE value NULL) the OTHERWISE argument; the result is NULL iff the selected one is.
-       * (All arguments are evaluated on all rows here; the reference skips unselected rows, which
-       * only matters for failing sub-expressions.) */
+       * (Values are computed on all rows; which rows each argument may FAIL on is settled by the skip
+       * vectors eval_node handed them.) */
       const int w = type_width(b->dtype), tw = type_width(x->dtype);
       int any = 0;
       for (int a = 1; a < b->nargs; a += 2) if (b->args[a]->nulls) any = 1;
@@ -932,7 +1020,7 @@ static void eval_node(bnode* b, const orc_view* in, int64_t n, orc_error* err) {
       if (!zero) continue;
       int already_null = b->nulls ? b->nulls[i] : 0;
       if (nulling) { if (!b->nulls) { memset(b->nullbuf, 0, (size_t)n); b->nulls = b->nullbuf; } b->nullbuf[i] = 1; }
-      else if (!already_null) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: division by zero in %s%s", b->name, ""); return; }
+      else if (!already_null && !(skip && skip[i])) { set_err(err, RC_EVALUATION_ERROR, "Evaluation error: division by zero in %s%s", b->name, ""); return; }
     }
   }
 }
@@ -1358,7 +1446,7 @@ static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
       if (r <= 0) { if (r < 0) c->err = c->child->err; return r; }
       out->n = c->nouts; out->rows = in.rows;
       for (int i = 0; i < c->nouts; ++i) {
-        eval_node(c->outs[i], &in, in.rows, &c->err);
+        eval_node(c->outs[i], &in, in.rows, NULL, &c->err);
         if (c->err.code) return -1;
         out->c[i].data = c->outs[i]->data; out->c[i].is_null = c->outs[i]->nulls;
       }
@@ -1481,7 +1569,7 @@ static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
           if (r < 0) { c->err = c->child->err; return -1; }
           if (r == 0) { c->eos = 1; c->have_cur = 0; if (write_ptr) break; return 0; }
           /* PrepareInputRowIds, filter.cc:170-199: ids of rows whose predicate is non-NULL TRUE */
-          eval_node(c->pred, &c->cur, c->cur.rows, &c->err);
+          eval_node(c->pred, &c->cur, c->cur.rows, NULL, &c->err);
           if (c->err.code) return -1;
           const uint8_t* pv = (const uint8_t*)c->pred->data; const uint8_t* pn = c->pred->nulls;
           int64_t k = 0;

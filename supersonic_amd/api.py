@@ -890,8 +890,9 @@ class Plan(object):
             return cols, len(view._ptrs), view.row_count()
         # host View: stage into a device Block on the copy stream (pinned staging is the
         # caller's choice; numpy memory is pageable, which only makes the copy synchronous)
-        key = id(view)
-        if getattr(self, slot) is None or getattr(self, slot + "_key") != key:
+        # the staged block is reused only for the SAME view object (a strong reference is kept: the id of a freed
+        # temporary View is readily reused by the next one, which must not inherit its device data)
+        if getattr(self, slot) is None or getattr(self, slot + "_key") is not view:
             if getattr(self, slot) is not None:
                 self.lib.ssgpu_block_destroy(getattr(self, slot))
                 setattr(self, slot, None)
@@ -912,7 +913,7 @@ class Plan(object):
                         None if nulls is None else nulls.ctypes.data_as(C.c_void_p), 0, view.row_count()))
             self.lib.ssgpu_block_set_row_count(blk, view.row_count())
             self.ctx.synchronize()
-            setattr(self, slot, blk); setattr(self, slot + "_key", key)
+            setattr(self, slot, blk); setattr(self, slot + "_key", view)
         n = view.schema().attribute_count()
         cols = (L.Column * max(n, 1))()
         for i in range(n):

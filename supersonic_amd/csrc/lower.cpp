@@ -120,7 +120,7 @@ class Emitter {
   }
 
   Status value(const BExprP& e, Val* out);
-  bool has_value(const BExprP& e) { return memo_.count(key_of(e)) != 0; }
+  bool has_value(const BExprP& e) { return memo_.count(memo_key(e)) != 0; }
   Status cast_val(const Val& v, MT from, MT to, Val* out);
 
   // selection registers: sel_by_depth[d] = rows passing the first d filters (-1 = all)
@@ -143,6 +143,42 @@ class Emitter {
   const std::vector<JoinSpec>* joins_;
   std::map<int, int> join_idx_;
   std::string key_of(const BExprP& e);
+  // Guarded evaluation.  The reference evaluates a child under a skip vector: the THEN / OTHERWISE branches of IF
+  // only where they are chosen (elementary_bound_expressions.cc:935-955), the right side of AND / OR only where the
+  // left side has not decided (:279-318), a later argument of any operator only where the earlier ones are not NULL
+  // (children share one skip vector, abstract_bound_expressions.h:129-147) -- and a skipped row never raises an
+  // evaluation error (the failers take the skip vector as is_null).  Values may be computed everywhere; what has to
+  // respect the skip vector is the FAIL_* instructions.  guard_ = BOOL register, 1 = row evaluated (-1 = all).
+  int guard_ = -1;
+  std::map<const BExpr*, bool> can_fail_;
+  bool can_fail(const BExprP& e) {
+    auto it = can_fail_.find(e.get());
+    if (it != can_fail_.end()) return it->second;
+    bool f = e->kind == BExpr::OP && (e->op == OP_DIVIDE_SIGNALING || e->op == OP_CPP_DIVIDE_SIGNALING || e->op == OP_MODULUS_SIGNALING ||
+                                      e->op == OP_SQRT_SIGNALING || e->op == OP_POW_SIGNALING);
+    for (auto& a : e->args) f = f || can_fail(a);
+    can_fail_[e.get()] = f;
+    return f;
+  }
+  std::string memo_key(const BExprP& e) { return (guard_ >= 0 && can_fail(e)) ? key_of(e) + "@g" + std::to_string(guard_) : key_of(e); }
+  // guard AND mask / guard AND NOT mask (mask: BOOL register without NULLs)
+  int narrow_guard(int g, int mask, bool negate) {
+    int r = new_reg(1);
+    if (g < 0) {
+      if (!negate) return mask;
+      LInstr& i = emit(VM_NOT_B8); i.dst = r; i.a = mask;
+    } else {
+      LInstr& i = emit(negate ? VM_ANDNOT_B8 : VM_AND_B8); i.dst = r; i.a = mask; i.b = g;   // ANDNOT_B8(a, b) = !a && b
+    }
+    return r;
+  }
+  // the rows a FAIL_* instruction looks at: selected by the filters below AND evaluated (guard)
+  int fail_mask(int sel) {
+    if (guard_ < 0) return sel;
+    if (sel < 0) return guard_;
+    return narrow_guard(sel, guard_, false);
+  }
+  Status eval_args(const BExprP& e, std::vector<Val>* a);
   std::map<std::pair<int, bool>, int> staged_;
   std::map<std::string, Val> memo_;
   int all_null_ = -1;
@@ -226,8 +262,65 @@ Status Emitter::join_index(int join_id, int* reg) {
   return Status::OK();
 }
 
+// The arguments of an operator, evaluated in the reference's order and under the reference's skip vectors.
+Status Emitter::eval_args(const BExprP& e, std::vector<Val>* out) {
+  std::vector<Val>& a = *out;
+  a.resize(e->args.size());
+  const int saved = guard_;
+  auto restore = [&](const Status& s) { guard_ = saved; return s; };
+  if (a.empty()) return Status::OK();
+  Status st = value(e->args[0], &a[0]);
+  if (!st.ok()) return restore(st);
+  bool later_can_fail = false;
+  for (size_t i = 1; i < e->args.size(); ++i) later_can_fail = later_can_fail || can_fail(e->args[i]);
+  if (!later_can_fail) {
+    for (size_t i = 1; i < a.size(); ++i) { st = value(e->args[i], &a[i]); if (!st.ok()) return restore(st); }
+    return restore(Status::OK());
+  }
+  // "decided / chosen" mask of the first argument: BOOL value that is TRUE and not NULL
+  auto true_not_null = [&](const Val& v) -> int {
+    int r = materialize(v);
+    if (v.null < 0) return r;
+    int ch = new_reg(1);
+    LInstr& c = emit(VM_SEL_FROM_PRED); c.dst = ch; c.a = r; c.b = v.null;
+    return ch;
+  };
+  const int op = e->kind == BExpr::OP ? e->op : -1;
+  if (op == OP_IF || op == SSGPU_OP_NULLING_IF) {
+    const int choice = true_not_null(a[0]);
+    guard_ = narrow_guard(saved, choice, false);
+    st = value(e->args[1], &a[1]); if (!st.ok()) return restore(st);
+    guard_ = narrow_guard(saved, choice, true);
+    if (op == SSGPU_OP_NULLING_IF && a[0].null >= 0) guard_ = narrow_guard(guard_, a[0].null, true);   // a NULL condition skips both branches
+    st = value(e->args[2], &a[2]);
+    return restore(st);
+  }
+  if (op == OP_AND || op == OP_OR || op == OP_AND_NOT) {
+    // right side skipped where the left side decides: TRUE (OR, AND_NOT) / FALSE (AND) and not NULL
+    Val l = a[0];
+    if (op == OP_AND) { Val n; n.width = 1; n.reg = unop(VM_NOT_B8, l, 1); n.null = l.null; l = n; }
+    const int decided = true_not_null(l);
+    guard_ = narrow_guard(saved, decided, true);
+    st = value(e->args[1], &a[1]);
+    return restore(st);
+  }
+  if (op == OP_IF_NULL) {   // the replacement is evaluated only where the first argument IS NULL
+    if (a[0].null >= 0) guard_ = narrow_guard(saved, a[0].null, false);
+    else { Val never; never.imm = true; never.bits = 0; never.width = 1; guard_ = narrow_guard(saved, materialize(never), false); }
+    st = value(e->args[1], &a[1]);
+    return restore(st);
+  }
+  // every other operator: the children share one skip vector, each adds its NULLs before the next is evaluated
+  for (size_t i = 1; i < a.size(); ++i) {
+    if (a[i - 1].null >= 0 && can_fail(e->args[i])) guard_ = narrow_guard(guard_, a[i - 1].null, true);
+    st = value(e->args[i], &a[i]);
+    if (!st.ok()) return restore(st);
+  }
+  return restore(Status::OK());
+}
+
 Status Emitter::value(const BExprP& e, Val* out) {
-  const std::string key = key_of(e);
+  const std::string key = memo_key(e);
   auto it = memo_.find(key);
   if (it != memo_.end()) { *out = it->second; return Status::OK(); }
   const MT mt = mtype(e->dtype);
@@ -269,10 +362,10 @@ Status Emitter::value(const BExprP& e, Val* out) {
       SS_RETURN_IF_ERROR(cast_val(a, mtype(e->args[0]->dtype), mt, &v));
     } break;
     case BExpr::OP: {
-      std::vector<Val> a(e->args.size());
-      for (size_t i = 0; i < a.size(); ++i) SS_RETURN_IF_ERROR(value(e->args[i], &a[i]));
+      std::vector<Val> a;
+      SS_RETURN_IF_ERROR(eval_args(e, &a));
       const MT at = mtype(e->args[0]->dtype);
-      const int sel = sel_at(e->filter_depth);
+      const int sel = fail_mask(sel_at(e->filter_depth));
       switch (e->op) {
         case OP_ADD: v.reg = binop(pick(mt, VM_ADD_I32, VM_ADD_I32, VM_ADD_I64, VM_ADD_I64, VM_ADD_F32, VM_ADD_F64), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
         case OP_SUBTRACT: v.reg = binop(pick(mt, VM_SUB_I32, VM_SUB_I32, VM_SUB_I64, VM_SUB_I64, VM_SUB_F32, VM_SUB_F64), a[0], a[1], v.width); v.null = or_null(a[0].null, a[1].null); break;
@@ -1392,6 +1485,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         Stage st;
         if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
         else {
+          // GroupAggregateOptions::max_unique_keys_in_result folds every key beyond the limit into one extra last row
+          // (aggregate_groups.cc:326): depends on first-seen key order, which no device shape has -- refuse loudly
+          if (op.option0 != 0)
+            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "GroupAggregateOptions::max_unique_keys_in_result is not available on the device path");
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           bool too_wide = false;
           Status s = finish_group_agg(g, pipe, &st, false, &too_wide);

@@ -318,10 +318,15 @@ int ssgpu_block_create_from_file(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t
   // pass 1: chunk headers only (the payload size follows from the row count and the schema)
   int64_t total = 0; uint64_t rc = 0;
   std::vector<uint64_t> chunk_rows;
+  bool header_ok = true;
   while (fread(&rc, 8, 1, f) == 1) {
+    // a chunk never holds more than kMaxChunkRowCount rows (file_io.cc:70): anything else is a corrupt header, and
+    // trusting it would seek by a garbage (possibly negative) distance
+    if (rc > (uint64_t)kFileChunkRows) { header_ok = false; break; }
     if (fseek(f, (long)((int64_t)rc * row_bytes), SEEK_CUR) != 0) break;
     total += (int64_t)rc; chunk_rows.push_back(rc);
   }
+  if (!header_ok) { fclose(f); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; }
   { const long end = ftell(f); fseek(f, 0, SEEK_END); if (ftell(f) < end) { fclose(f); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; } }
   rewind(f);
   ssgpu_block* b = nullptr;
@@ -1383,6 +1388,8 @@ int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
   return SSGPU_OK;
 }
 
+int check_error_flags(ssgpu_plan* p);
+
 int check_error_flags(ssgpu_plan* p) {
   ssgpu_ctx* c = p->ctx;
   // The flags are written by kernels on c->stream, which is a non-blocking stream: a null-stream
@@ -1454,6 +1461,9 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       // next stage reads this stage's materialised result
       int64_t r = 0;
       rc = stage_rows(p, si, &r);
+      if (rc != SSGPU_OK) return rc;
+      // a stage that hit an evaluation error must not feed the next one (the hand-off already waits for the row count)
+      rc = check_error_flags(p);
       if (rc != SSGPU_OK) return rc;
       StageExec& ex = p->exec[si];
       in.cols.clear();
@@ -1591,6 +1601,9 @@ int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
   if (!r || !r->plan) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   StageExec& ex = r->plan->exec.back();
   if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  // device-resident consumers (the sharded sort / group aggregate) must not pass on the result of a run that hit a
+  // signaling division or SQRT error
+  { const int rc = check_error_flags(r->plan); if (rc != SSGPU_OK) return rc; }
   out->data = ex.out[i].data.p;
   out->is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
   return SSGPU_OK;

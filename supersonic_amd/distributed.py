@@ -112,7 +112,10 @@ _CONST_OF = {ss.INT32: ss.ConstInt32, ss.INT64: ss.ConstInt64, ss.UINT32: ss.Con
 
 
 def _choose_splitters(samples, world):
-    """world - 1 ascending splitters from the gathered, sorted sample of first-key values."""
+    """world - 1 ascending splitters from the gathered, sorted sample of first-key values (NaNs, which sort last in
+    numpy and compare false with everything, are never splitters)."""
+    if samples.dtype.kind == "f":
+        samples = samples[~np.isnan(samples)]
     if len(samples) == 0:
         return []
     return [samples[min(len(samples) - 1, (i + 1) * len(samples) // world)] for i in range(world - 1)]
@@ -127,9 +130,13 @@ def _range_predicate(key, dtype, nullable, splitters, d, world, descending):
     b = (world - 1 - d) if descending else d          # bucket index in ascending value order
     pred = None
     if splitters:
-        if b > 0:
-            pred = ss.Greater(ss.NamedAttribute(key), const(splitters[b - 1]))
-        if b < world - 1:
+        if b == world - 1:
+            # the last bucket is the complement of the others, not "key > splitter": every comparison with a NaN is
+            # false, so a NaN key would match no bucket and the row would vanish from the global result
+            pred = ss.Not(ss.LessOrEqual(ss.NamedAttribute(key), const(splitters[b - 1])))
+        else:
+            if b > 0:
+                pred = ss.Greater(ss.NamedAttribute(key), const(splitters[b - 1]))
             hi = ss.LessOrEqual(ss.NamedAttribute(key), const(splitters[b]))
             pred = hi if pred is None else ss.And(pred, hi)
     elif b != 0:

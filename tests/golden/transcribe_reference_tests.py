@@ -781,6 +781,72 @@ NU = "NOT_UNIQUE"
 join_case("HashJoin_1_InnerJoin_1_not_unique", HJ + ":140-150", "INNER", R1, R1, [[1, "a", 1, "a"]], NU)
 join_case("HashJoin_1_LeftOuterJoin_2_not_unique", HJ + ":176-187", "LEFT_OUTER", R1, R2, [[1, "a", None, None]], NU)
 join_case("HashJoin_12345_InnerJoin_654321_not_unique", HJ + ":189-203", "INNER", R12345, R654321, [[k, v, k, v] for k, v in R12345], NU)
+
+# ---- short circuit: which rows every child is evaluated on (skip vectors) ------------------------------------------
+# The reference's short-circuit tests (supersonic/testing/short_circuit_tester.h:37-62) give, per input row, the
+# skip vector each child of an operator must RECEIVE: a skipped child is not evaluated there, so a failing child
+# raises no evaluation error on that row.  Restated as data: for every row whose incoming skip flag is false and
+# every child k, the case wraps child k in an expression that fails (0 % 0, ModulusSignaling) on every row it is
+# evaluated on, and expects error 104 exactly when the table says the child is NOT skipped, else the table's result.
+# A BOOL child c becomes Or(Equal(0 % z, 1), c), an integer child Plus(0 % z, c): the failing part comes first, so it
+# sees the skip vector the child itself was handed (z = extra NOT NULL INT32 column of zeros, the last input).
+def short_circuit_cases(name, source, factory, child_types, out_type, table):
+    """table rows: [skip_in, child0, skip0, child1, skip1, ..., result] as in the reference's BlockBuilder."""
+    n = len(child_types)
+    for r, row in enumerate(table):
+        if row[0]:
+            continue            # rows the parent itself skips cannot be driven from outside an expression
+        vals = [row[1 + 2 * k] for k in range(n)]
+        skips = [row[2 + 2 * k] for k in range(n)]
+        for k in range(n):
+            zcol = ["AttributeAt", n]
+            boom = ["ModulusSignaling", ["ConstInt32", 0], zcol]
+            args = [["AttributeAt", i] for i in range(n)]
+            args[k] = (["Or", ["Equal", boom, ["ConstInt32", 1]], args[k]] if child_types[k] == BOOL else ["Plus", boom, args[k]])
+            CASES.append({
+                "name": "%s_row%d_child%d" % (name, r, k), "source": source, "kind": "expression",
+                "input": {"schema": [["col%d" % i, child_types[i], True] for i in range(n)] + [["z", I32, False]], "rows": [vals + [0]]},
+                "plan": ["Compute", [factory] + args, "INPUT"],
+                "expected": {"types": [out_type], "rows": [[row[-1]]], "names": None, "nullable": None},
+                "ordered": True, "expect_error": None if skips[k] else 104})
+
+
+T, F_ = True, False
+short_circuit_cases("ShortCircuit_And", E + ":444-461", "And", [BOOL, BOOL], BOOL, [
+    [F_, F_, F_, F_, T, F_], [F_, F_, F_, None, T, F_], [F_, T, F_, F_, F_, F_], [F_, T, F_, None, F_, None], [F_, None, F_, T, F_, None],
+    [F_, None, F_, F_, F_, F_], [F_, T, F_, T, F_, T], [T, F_, T, F_, T, None], [T, None, T, None, T, None], [T, T, T, T, T, None]])
+short_circuit_cases("ShortCircuit_Or", E + ":476-494", "Or", [BOOL, BOOL], BOOL, [
+    [F_, F_, F_, F_, F_, F_], [F_, F_, F_, None, F_, None], [F_, T, F_, F_, T, T], [F_, T, F_, None, T, T], [F_, None, F_, T, F_, T],
+    [F_, None, F_, None, F_, None], [F_, None, F_, F_, F_, None], [T, F_, T, F_, T, None], [T, F_, T, None, T, None], [T, None, T, F_, T, None],
+    [T, None, T, None, T, None]])
+short_circuit_cases("ShortCircuit_AndNot", E + ":518-536", "AndNot", [BOOL, BOOL], BOOL, [
+    [F_, F_, F_, T, F_, T], [F_, F_, F_, None, F_, None], [F_, T, F_, F_, T, F_], [F_, T, F_, None, T, F_], [F_, None, F_, F_, F_, F_],
+    [F_, None, F_, None, F_, None], [F_, None, F_, T, F_, None], [T, F_, T, F_, T, None], [T, F_, T, None, T, None], [T, None, T, F_, T, None],
+    [T, None, T, None, T, None]])
+short_circuit_cases("ShortCircuit_If", E + ":718-735", "If", [BOOL, I32, I32], I32, [
+    [F_, T, F_, 1, F_, 2, T, 1], [F_, T, F_, None, F_, 2, T, None], [F_, T, F_, 1, F_, None, T, 1], [F_, F_, F_, None, T, 2, F_, 2],
+    [F_, F_, F_, 1, T, None, F_, None], [F_, None, F_, 1, T, 2, F_, 2], [T, T, T, 1, T, 2, T, None], [T, F_, T, 1, T, 2, T, None],
+    [T, None, T, 1, T, 2, T, None]])
+short_circuit_cases("ShortCircuit_NullingIf", E + ":737-754", "NullingIf", [BOOL, I32, I32], I32, [
+    [F_, T, F_, 1, F_, 2, T, 1], [F_, T, F_, None, F_, 2, T, None], [F_, T, F_, 1, F_, None, T, 1], [F_, F_, F_, None, T, 2, F_, 2],
+    [F_, F_, F_, 1, T, None, F_, None], [F_, None, F_, 1, T, 2, T, None], [T, T, T, 1, T, 2, T, None], [T, F_, T, 1, T, 2, T, None],
+    [T, None, T, 1, T, 2, T, None]])
+# IfNull: the reference's table holds STRINGs ("One Ring To Rule Them All"); INT32 codes here, same NULL pattern
+short_circuit_cases("ShortCircuit_IfNull", E + ":377-394", "IfNull", [I32, I32], I32, [
+    [F_, 1, F_, 2, T, 1], [F_, 3, F_, 4, T, 3], [F_, 5, F_, None, T, 5], [F_, None, F_, 6, F_, 6], [F_, None, F_, None, F_, None],
+    [T, 1, T, 2, T, None], [T, 3, T, None, T, None], [T, None, T, 7, T, None], [T, None, T, None, T, None], [F_, None, F_, 5, F_, 5]])
+
+# CaseShortCircuit (case_expression_test.cc:195-253): A + CASE B WHEN C THEN 0 % D ELSE 0 % E -- which of the two
+# failing branches is evaluated, and that a NULL A skips the whole CASE
+CASE_SC = ["Plus", AT(0), ["CaseList", AT(1), ["ModulusSignaling", ["ConstInt32", 0], AT(4)], AT(2), ["ModulusSignaling", ["ConstInt32", 0], AT(3)]]]
+expr_plan_case("Case_ShortCircuit", C + ":229-245", [I32, I32, I32, I32, I32], CASE_SC, I32,
+               [[None, 1, 1, 0, 0, None], [None, 1, 2, 0, 0, None], [None, None, 2, 0, 0, None], [None, 1, None, 0, 0, None], [None, None, None, 0, 0, None],
+                [0, 1, 1, 1, 0, 0], [0, 1, 2, 0, 1, 0], [0, None, 1, 0, 1, 0], [0, None, None, 0, 1, 0], [0, 1, None, 0, 1, 0],
+                [0, 1, 1, None, 0, None], [0, 1, 2, 0, None, None], [0, None, 1, 0, None, None]])
+for _i, _row in enumerate([[0, 1, 1, 0, None], [0, 1, 2, None, 0], [0, None, None, None, 0]]):
+    expr_plan_case("Case_ShortCircuit_fails_%d" % _i, C + ":247-252", [I32, I32, I32, I32, I32], CASE_SC, I32, [_row + [None]])
+    CASES[-1]["expect_error"] = 104
+
 join_case("HashJoin_654321_LeftOuterJoin_12345_not_unique", HJ + ":222-238", "LEFT_OUTER", R654321, R12345,
           [[6, "f", None, None]] + [[k, v, k, v] for k, v in R654321[1:]], NU)
 R2b2b2c = [[2, "b"], [2, "b"], [2, "c"]]

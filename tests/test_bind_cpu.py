@@ -74,3 +74,17 @@ def test_bind_errors(bind_ctx):
     spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "t", "s")
     assert code(ss.ScalarAggregate(spec, scan())) == 405                                # column_aggregator.cc:549-556
     assert code(ss.Compute(ss.CastTo(ss.INT32, ss.Plus(NA("a"), ss.ConstDouble(1.0))), scan())) == 402   # float -> int cast
+
+
+def test_max_unique_keys_in_result_is_refused_at_bind():
+    # GroupAggregateOptions::max_unique_keys_in_result (aggregate_groups.cc:326) depends on first-seen key order:
+    # not available on the device path, and not silently ignored either
+    import numpy as np
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64)])
+    view = ss.View(schema, [np.arange(4), np.arange(4)])
+    opts = ss.GroupAggregateOptions()
+    opts.max_unique_keys_in_result = 2
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s"), opts, ss.ScanView(view))
+    with pytest.raises(ss.SupersonicException) as e:
+        ss.Plan(op, ss.Context(-1))
+    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED

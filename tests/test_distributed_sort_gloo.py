@@ -97,3 +97,24 @@ def test_range_predicates_partition_every_row_once():
                 _s, cols = oracle.run(ss.Filter(pred, ss.ProjectAllAttributes(), ss.ScanView(view)))
                 total += len(cols[0][0])
             assert total == 4000
+
+
+def test_range_predicates_keep_nan_keys():
+    # a DOUBLE first key with NaNs: every comparison with a NaN is false, so "key > lo AND key <= hi" buckets would match
+    # none of them and the rows would vanish from the global result; the last ascending bucket is the complement instead
+    rng = np.random.default_rng(4)
+    n = 3000
+    key = rng.integers(-50, 50, n) * 0.5
+    key[rng.random(n) < 0.05] = np.nan
+    schema = ss.TupleSchema([ss.Attribute("k", ss.DOUBLE, ss.NULLABLE), ss.Attribute("id", ss.INT64)])
+    view = ss.View(schema, [ss.Column(key, rng.random(n) < 0.1), np.arange(n)])
+    from supersonic_amd.distributed import _choose_splitters
+    assert not np.isnan(_choose_splitters(np.sort(key), 3)).any()       # NaNs (sorted last by numpy) are never splitters
+    for desc in (False, True):
+        for splitters in ([-3.5, 7.0], [2.0, 2.0]):
+            seen = np.zeros(n, int)
+            for d in range(3):
+                pred = _range_predicate("k", ss.DOUBLE, True, splitters, d, 3, desc)
+                _s, cols = oracle.run(ss.Filter(pred, ss.ProjectAllAttributes(), ss.ScanView(view)))
+                seen[cols[1][0]] += 1
+            assert (seen == 1).all()

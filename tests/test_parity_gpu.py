@@ -267,6 +267,56 @@ def test_group_aggregate_partitioned_many_groups():
         assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="adaptive group run")
 
 
+def test_plan_restages_every_new_host_view(gpu_ctx):
+    # one Plan run over a stream of temporary host Views (a per-batch loop): CPython reuses the id() of a freed View, so
+    # the staged device block must be keyed on the object itself -- never on its id
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64)])
+    op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "s"), ss.ScanView(ss.View(schema, [np.zeros(8, np.int64)])))
+    plan = ss.Plan(op, gpu_ctx)
+    for batch in range(20):
+        data = np.full(1000 + batch, batch, dtype=np.int64)
+        plan.run(ss.View(schema, [data]))               # the View is garbage as soon as run() returns
+        assert plan.fetch().column(0).data[0] == batch * (1000 + batch)
+
+
+def test_device_view_of_a_failed_run_reports_the_evaluation_error(gpu_ctx):
+    # result_device_view (what the sharded sort / group aggregate consume) must not hand out the buffers of a run that
+    # hit a signaling division
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
+    view = ss.View(schema, [np.arange(1, 2001), np.where(np.arange(2000) == 777, 0, 3)])
+    plan = ss.Plan(ss.Compute(ss.CompoundExpression().AddAs("q", ss.CppDivideSignaling(NA("a"), NA("b"))), ss.ScanView(view)), gpu_ctx)
+    plan.run()
+    with pytest.raises(ss.SupersonicException) as e:
+        plan.result_device_view()
+    assert e.value.return_code == ss.ERROR_EVALUATION_ERROR
+
+
+@pytest.mark.parametrize("nullable", [False, True])
+def test_guarded_signaling_operators_do_not_fail_on_rows_they_are_not_evaluated_on(gpu_ctx, nullable):
+    # the canonical guards: IF(b <> 0, a / b, x), (b <> 0) AND (a / b > 1), IFNULL, CASE, a NULL earlier argument --
+    # the reference evaluates the failing child under a skip vector (elementary_bound_expressions.cc:279-318,935-955)
+    rng = np.random.default_rng(3)
+    n = 5000
+    N = ss.NULLABLE if nullable else ss.NOT_NULLABLE
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64, N), ss.Attribute("b", ss.INT64), ss.Attribute("x", ss.DOUBLE, N)])
+    nl = (lambda: rng.random(n) < 0.2) if nullable else (lambda: None)
+    view = ss.View(schema, [ss.Column(rng.integers(-50, 50, n), nl()), rng.integers(0, 3, n), ss.Column(rng.integers(-9, 9, n) * 0.5, nl())])
+    nz = ss.NotEqual(NA("b"), ss.ConstInt64(0))
+    e = (ss.CompoundExpression()
+         .AddAs("g1", ss.If(nz, ss.CppDivideSignaling(NA("a"), NA("b")), ss.ConstInt64(-1)))
+         .AddAs("g2", ss.And(nz, ss.Greater(ss.DivideSignaling(NA("a"), NA("b")), ss.ConstDouble(1.0))))
+         .AddAs("g3", ss.Or(ss.Equal(NA("b"), ss.ConstInt64(0)), ss.Less(ss.ModulusSignaling(NA("a"), NA("b")), ss.ConstInt64(1))))
+         .AddAs("g4", ss.If(ss.GreaterOrEqual(NA("x"), ss.ConstDouble(0.0)), ss.SqrtSignaling(NA("x")), ss.ConstDouble(0.0)))
+         .AddAs("g5", ss.Case([NA("b"), ss.ConstInt64(7), ss.ConstInt64(1), ss.CppDivideSignaling(NA("a"), NA("b")),
+                               ss.ConstInt64(2), ss.ModulusSignaling(NA("a"), NA("b"))])))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
+    # and the unguarded forms still fail
+    for bad in (ss.CppDivideSignaling(NA("a"), NA("b")), ss.If(nz, ss.ConstInt64(1), ss.ModulusSignaling(ss.ConstInt64(5), NA("b")))):
+        with pytest.raises(ss.SupersonicException) as err:
+            ss.drain(ss.Compute(ss.CompoundExpression().AddAs("q", bad), ss.ScanView(view)).CreateCursor(gpu_ctx))
+        assert err.value.return_code == ss.ERROR_EVALUATION_ERROR
+
+
 def test_group_aggregate_partitioned_skewed_keys():
     # one hot key takes 90 % of the rows: its (partition, workgroup) segments run full, the stage reruns with larger
     # segments (x4 per attempt) and, if that is not enough, falls back to the direct path -- the rows never change
