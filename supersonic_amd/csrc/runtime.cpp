@@ -1436,6 +1436,8 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
     p->events_valid = false;
     if (c->profile_total) HIP_TRY(c, hipEventRecord(p->ev_begin, c->stream));
   }
+  // every stage's evaluation-error word starts clear: the flags of ALL stages are read at each hand-off and at fetch
+  for (auto& sx : p->exec) if (sx.error_flag.p) HIP_TRY(c, hipMemsetAsync(sx.error_flag.p, 0, sizeof(uint32_t), c->stream));
   int64_t alg_bytes = 0;
   for (size_t si = 0; si < p->stages.size(); ++si) {
     if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
