@@ -48,6 +48,8 @@ struct ssgpu_ctx {
   int64_t part_wgs_per_cu = 0;   // resident workgroups per CU of the scatter pass (0 = wgs_per_cu)
   int64_t part_lds_target = 0;   // LDS target of the scatter pass's tile (0 = lds_target_bytes)
   int64_t part_agg_debug = 0;
+  int64_t sort_records = 1;      // 0: always gather payload columns one by one
+  int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
   int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
   int64_t profile = 1;           // record HIP events around kernels
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
@@ -121,7 +123,8 @@ struct StageExec {
   DevBuf error_flag;
   DevBuf debug, debug_pc, total2;
   // sort / clusters
-  DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id;
+  DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs;
+  uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
   bool pattern_ready = false;
   // outputs
@@ -240,6 +243,8 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_lds_target") c->part_lds_target = value;
   else if (k == "part_agg_lds") c->part_agg_lds = value;
   else if (k == "part_agg_debug") c->part_agg_debug = value;
+  else if (k == "sort_records") c->sort_records = value;
+  else if (k == "sort_hybrid") c->sort_hybrid = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -1202,8 +1207,17 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   const uint32_t nt = ssgpu_sort_tiles(n);
   HIP_TRY(c, ex.skeys_a.ensure(std::max<uint64_t>(n, 1) * 8)); HIP_TRY(c, ex.skeys_b.ensure(std::max<uint64_t>(n, 1) * 8));
   HIP_TRY(c, ex.sidx_a.ensure(std::max<uint64_t>(n, 1) * 4)); HIP_TRY(c, ex.sidx_b.ensure(std::max<uint64_t>(n, 1) * 4));
-  HIP_TRY(c, ex.shist.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4)); HIP_TRY(c, ex.soffs.ensure((size_t)std::max<uint32_t>(nt, 1) * 256 * 4));
-  HIP_TRY(c, ex.total.ensure(8)); HIP_TRY(c, ex.total2.ensure(16));
+  HIP_TRY(c, ex.total2.ensure(16));
+  // one-sweep scratch: digit histograms + their scans, per-(tile, digit) status words (zeroed when (re)allocated: an
+  // all-zero word reads as "not ready" in every epoch), one tile ticket per pass, the "look-back gave up" flag
+  HIP_TRY(c, ex.shist.ensure(8 * 256 * 4)); HIP_TRY(c, ex.soffs.ensure(8 * 256 * 4));
+  {
+    const size_t need = (size_t)std::max<uint32_t>(nt, 1) * 256 * 8;
+    if (need > ex.sstatus.cap || !ex.sstatus.p) { HIP_TRY(c, ex.sstatus.ensure(need)); HIP_TRY(c, hipMemsetAsync(ex.sstatus.p, 0, ex.sstatus.cap, c->stream)); }
+  }
+  HIP_TRY(c, ex.sticket.ensure(64 * 4));
+  HIP_TRY(c, hipMemsetAsync(ex.sticket.p, 0, 64 * 4, c->stream));
+  uint32_t n_pass = 0;   // tickets [0, 61], "a tie run was too long" flag at [62], "look-back gave up" flag at [63]
   uint64_t* ka = ex.skeys_a.as<uint64_t>(); uint64_t* kb = ex.skeys_b.as<uint64_t>();
   uint32_t* ia = ex.sidx_a.as<uint32_t>(); uint32_t* ib = ex.sidx_b.as<uint32_t>();
   // The major key's column can be read back from the sorted keys when its transform is a bijection (integer
@@ -1216,37 +1230,99 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   for (int col : st.sort_out_cols) keys_only = keys_only && col == major.col;
   if (keys_only) ia = ib = nullptr;
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  // Payload: with three or more gathered columns the rows travel as fixed-stride records (ssgpu_sort_pack_kernel):
+  // the sorted order then fetches one record per row instead of one 64-byte sector per row PER COLUMN.
+  SortRecParams R; memset(&R, 0, sizeof(R));
+  bool use_records = false;
+  {
+    uint32_t off = 0, nf = 0, gathered = 0;
+    for (uint32_t wsel : {8u, 4u, 1u}) {
+      for (size_t i = 0; i < st.sort_out_cols.size(); ++i) {
+        const int col = st.sort_out_cols[i];
+        if (major_direct && col == major.col) continue;
+        if (ex.out[i].width == wsel && nf < SSGPU_SORT_MAX_FIELDS) {
+          R.fields[nf].src = in.cols[col].data; R.fields[nf].dst = ex.out[i].data.p; R.fields[nf].off = off; R.fields[nf].width = wsel; ++nf; off += wsel;
+          if (wsel == 8 || ex.out[i].width == wsel) ++gathered;
+        }
+        if (wsel == 1 && ex.out[i].nullable && nf < SSGPU_SORT_MAX_FIELDS) {   // NULL flags ride with the 1-byte fields
+          R.fields[nf].src = in.cols[col].is_null; R.fields[nf].dst = ex.out[i].nulls.p; R.fields[nf].off = off; R.fields[nf].width = 1; ++nf; off += 1;
+        }
+      }
+    }
+    uint32_t payload_cols = 0;
+    for (size_t i = 0; i < st.sort_out_cols.size(); ++i) if (!(major_direct && st.sort_out_cols[i] == major.col)) ++payload_cols;
+    R.stride = (off + 15u) & ~15u; R.n_fields = nf; R.n = n;
+    use_records = !keys_only && payload_cols >= 3 && R.stride <= 224u && nf < SSGPU_SORT_MAX_FIELDS && n > 0 && c->sort_records != 0;
+    (void)gathered;
+  }
+  if (use_records) {
+    HIP_TRY(c, ex.srecs.ensure((size_t)n * R.stride + 16));
+    R.recs = ex.srecs.p;
+    HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream));
+    p->counters.n_launches += 1;
+  }
   if (!keys_only) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
-  auto one_pass = [&](uint32_t shift) -> int {
-    HIP_TRY(c, ssgpu_launch_sort_hist(ka, shift, n, ex.shist.as<uint32_t>(), c->stream));
-    HIP_TRY(c, ssgpu_launch_scan_counts(ex.shist.as<uint32_t>(), ex.soffs.as<uint32_t>(), (int)(nt * 256), ex.total.as<uint64_t>(), c->stream));
-    HIP_TRY(c, ssgpu_launch_sort_scatter(ka, ia, kb, ib, shift, n, ex.soffs.as<uint32_t>(), c->stream));
-    std::swap(ka, kb); std::swap(ia, ib);
-    p->counters.n_launches += 3;
-    return SSGPU_OK;
-  };
   // least significant key first; each key: value digits, then the NULL-order bit on top
   for (int k = (int)st.sort_keys.size() - 1; k >= 0 && n > 0; --k) {
     const SortKey& sk = st.sort_keys[k];
     const int dtype = st.in_schema[sk.col].dtype;
     const uint32_t w = (uint32_t)dtype_width(dtype);
     const uint8_t* nulls = in.cols[sk.col].is_null;
-    // OR / AND of all transformed keys: digits on which every key agrees are skipped
+    // ONE read of the key column: transformed keys, OR / AND of all keys (digits on which every key agrees are
+    // skipped) and the histograms of all digits with their exclusive scans
     auto load_and_profile = [&](int kind, int null_pass, uint64_t* varying) -> int {
       const unsigned long long init[2] = {0ull, ~0ull};
       HIP_TRY(c, hipMemcpyAsync(ex.total2.p, init, 16, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, ssgpu_launch_sort_load_keys(ka, ia, in.cols[sk.col].data, nulls, w, kind, sk.order == SSGPU_DESCENDING, null_pass, n,
-                                             ex.total2.as<unsigned long long>(), c->stream));
+      HIP_TRY(c, hipMemsetAsync(ex.shist.p, 0, 8 * 256 * 4, c->stream));
+      HIP_TRY(c, ssgpu_launch_sort_load_keys_hist(ka, ia, in.cols[sk.col].data, nulls, w, kind, sk.order == SSGPU_DESCENDING, null_pass, n,
+                                                  ex.total2.as<unsigned long long>(), ex.shist.as<uint32_t>(), ex.soffs.as<uint32_t>(), c->stream));
       unsigned long long bits[2];
       HIP_TRY(c, hipMemcpyAsync(bits, ex.total2.p, 16, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       *varying = bits[0] ^ bits[1];
+      p->counters.n_launches += 2;
+      return SSGPU_OK;
+    };
+    auto one_pass = [&](uint32_t digit) -> int {
+      if (n_pass >= 62) { c->err = "Sort: too many radix passes in one stage"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+      HIP_TRY(c, ssgpu_launch_sort_onesweep(ka, ia, kb, ib, digit * 8, n, ex.soffs.as<uint32_t>() + digit * 256, ex.sstatus.as<unsigned long long>(),
+                                            ex.sticket.as<uint32_t>() + n_pass, ++ex.sort_epoch, ex.sticket.as<uint32_t>() + 63, c->stream));
+      ++n_pass;
+      std::swap(ka, kb); std::swap(ia, ib);
+      p->counters.n_launches += 1;
       return SSGPU_OK;
     };
     uint64_t varying = 0;
     rc = load_and_profile(sort_kind_of(dtype), 0, &varying); if (rc != SSGPU_OK) return rc;
-    for (uint32_t pass = 0; pass < w; ++pass)
-      if ((varying >> (pass * 8)) & 0xFFull) { rc = one_pass(pass * 8); if (rc != SSGPU_OK) return rc; }
+    // A wide key (all eight digits vary) that is the FIRST key processed (the rows are still in input order, which the
+    // stable tie-break relies on): sort by its high half and fix up the rare, short runs of equal high halves -- see
+    // ssgpu_sort_fix_ties_kernel -- instead of the four low-digit passes.
+    bool done = false;
+    if (c->sort_hybrid && w == 8 && k == (int)st.sort_keys.size() - 1 && (varying & 0xFFFFFFFFull) && !(nulls && st.in_schema[sk.col].nullable) &&
+        n >= (1u << 16)) {
+      bool high_busy = true;
+      for (uint32_t pass = 4; pass < 8; ++pass) high_busy = high_busy && ((varying >> (pass * 8)) & 0xFFull) != 0;
+      if (high_busy) {
+        for (uint32_t pass = 4; pass < 8; ++pass) { rc = one_pass(pass); if (rc != SSGPU_OK) return rc; }
+        uint32_t* flag = ex.sticket.as<uint32_t>() + 62;
+        HIP_TRY(c, ssgpu_launch_sort_fix_ties(ka, ia, n, 32, flag, c->stream));
+        uint32_t too_long = 0;
+        HIP_TRY(c, hipMemcpyAsync(&too_long, flag, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        p->counters.n_launches += 1;
+        if (!too_long) {
+          done = true;
+        } else {
+          // long runs of equal high halves: the plain LSD order over all digits, from scratch (the four passes used
+          // both buffers as targets: reload the row ids and the keys)
+          if (!keys_only) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+          uint64_t v2 = 0;
+          rc = load_and_profile(sort_kind_of(dtype), 0, &v2); if (rc != SSGPU_OK) return rc;
+        }
+      }
+    }
+    for (uint32_t pass = 0; pass < w && !done; ++pass)
+      if ((varying >> (pass * 8)) & 0xFFull) { rc = one_pass(pass); if (rc != SSGPU_OK) return rc; }
     if (nulls && st.in_schema[sk.col].nullable) {
       rc = load_and_profile(0, 1, &varying); if (rc != SSGPU_OK) return rc;
       if (varying & 1ull) { rc = one_pass(0); if (rc != SSGPU_OK) return rc; }
@@ -1259,10 +1335,18 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
       if (ex.out[i].nullable) HIP_TRY(c, hipMemsetAsync(ex.out[i].nulls.p, 0, n, c->stream));
       continue;
     }
+    if (use_records) continue;
     HIP_TRY(c, ssgpu_launch_sort_gather(ex.out[i].data.p, ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr,
                                         in.cols[col].data, in.cols[col].is_null, ex.out[i].width, ia, n, c->stream));
   }
+  if (use_records) { HIP_TRY(c, ssgpu_launch_sort_gather_rec(R, ia, c->stream)); p->counters.n_launches += 1; }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  if (n_pass) {   // the look-back never gives up on a healthy device; if it did, the order is wrong: fail loudly
+    uint32_t stuck = 0;
+    HIP_TRY(c, hipMemcpyAsync(&stuck, ex.sticket.as<uint32_t>() + 63, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stuck) { c->err = "Sort: a radix pass timed out waiting for a predecessor tile"; return SSGPU_ERROR_HIP; }
+  }
   ex.out_rows = in.rows;
   return SSGPU_OK;
 }

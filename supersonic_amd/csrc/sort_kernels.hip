@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
 #include "launch.h"
 
 typedef unsigned long long u64;
@@ -187,6 +188,259 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
       const u32 pos = goff[(u32)(key >> shift) & 0xFF] + e;
       keys_out[pos] = key;
       if (HAS_IDX) idx_out[pos] = li[e];
+    }
+  }
+}
+
+// ---- one-sweep LSD passes ------------------------------------------------------------------------------------------
+// (a) ONE read of the key column produces the transformed keys AND the global histograms of all eight digits
+//     (persistent workgroups, LDS histograms, one flush each) -- instead of one histogram kernel + a 3-launch scan per
+//     pass; (b) every scatter pass finds its tile's global offsets itself, by decoupled look-back over per-tile status
+//     words, so a pass is ONE kernel that reads and writes the (key, row id) pairs once.
+// Status word of (tile, digit): state (bits 63-62: 1 = this tile's count, 2 = inclusive prefix up to and including this
+// tile) | epoch (bits 61-32: status words of earlier passes / sorts carry another epoch and read as "not ready") | count
+// (bits 31-0).  One naturally aligned 8-byte word written by one relaxed agent-scope store and polled with relaxed
+// agent-scope loads: data and flag travel together, no fence (MI355X_MICROARCH.md, persistent kernels: handoff-1to1).
+// Tiles are numbered by a ticket taken at workgroup start, so every predecessor of a running tile is itself running or
+// done, whatever the dispatch order: the look-back cannot deadlock.
+__global__ __launch_bounds__(256) void ssgpu_sort_load_keys_hist_kernel(u64* __restrict__ keys, const u32* __restrict__ idx, const void* __restrict__ col,
+                                                 const u8* __restrict__ nulls, u32 width, int kind, int descending,
+                                                 int null_pass, u64 n, unsigned long long* __restrict__ bits, u32* __restrict__ hist8) {
+  __shared__ u32 h[8][256];
+  __shared__ u64 red[2][4];
+  const int t = threadIdx.x;
+  for (int d = 0; d < 8; ++d) h[d][t] = 0;
+  __syncthreads();
+  u64 vor = 0, vand = ~0ull;
+  for (u64 base = (u64)blockIdx.x * (256u * LOAD_KEYS_PER_THREAD); base < n; base += (u64)gridDim.x * (256u * LOAD_KEYS_PER_THREAD)) {
+#pragma unroll
+    for (int j = 0; j < LOAD_KEYS_PER_THREAD; ++j) {
+      const u64 i = base + (u64)j * 256u + t;
+      if (i >= n) break;
+      const u64 row = idx ? idx[i] : i;
+      u64 k;
+      if (null_pass) {
+        const bool isnull = nulls && nulls[row];
+        k = descending ? (isnull ? 1ull : 0ull) : (isnull ? 0ull : 1ull);
+      } else {
+        k = order_key(col, width, kind, row);
+        if (descending) k = ~k;
+        if (nulls && nulls[row]) k = 0;
+      }
+      keys[i] = k;
+      vor |= k; vand &= k;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) atomicAdd(&h[d][(k >> (8 * d)) & 0xFF], 1u);
+    }
+  }
+  for (int o = 32; o; o >>= 1) { vor |= __shfl_xor(vor, o); vand &= __shfl_xor(vand, o); }
+  const int lane = t & 63, wave = t >> 6;
+  if (lane == 0) { red[0][wave] = vor; red[1][wave] = vand; }
+  __syncthreads();
+  if (t == 0) {
+    atomicOr(&bits[0], red[0][0] | red[0][1] | red[0][2] | red[0][3]);
+    atomicAnd(&bits[1], red[1][0] & red[1][1] & red[1][2] & red[1][3]);
+  }
+  for (int d = 0; d < 8; ++d) if (h[d][t]) atomicAdd(&hist8[d * 256 + t], h[d][t]);
+}
+
+// exclusive scan of each digit's 256-bin histogram (one workgroup per digit)
+__global__ __launch_bounds__(256) void ssgpu_sort_scan_hist8_kernel(const u32* __restrict__ hist8, u32* __restrict__ base8) {
+  __shared__ u32 s[256];
+  const int t = threadIdx.x, d = blockIdx.x;
+  const u32 v = hist8[d * 256 + t];
+  s[t] = v;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const u32 x = t >= o ? s[t - o] : 0u;
+    __syncthreads();
+    s[t] += x;
+    __syncthreads();
+  }
+  base8[d * 256 + t] = s[t] - v;
+}
+
+#define ONESWEEP_AGG (1ull << 62)
+#define ONESWEEP_PREFIX (2ull << 62)
+template <bool HAS_IDX>
+__global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_onesweep_kernel(
+    const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
+    u32 shift, u64 n, const u32* __restrict__ digit_base, unsigned long long* __restrict__ status, u32* __restrict__ ticket,
+    u64 epoch, u32* __restrict__ stuck) {
+  __shared__ u32 wave_cnt[4][256];   // running tile-local positions per wave and digit
+  __shared__ u32 scanbuf[256];
+  __shared__ u32 goff[256];          // global offset of digit d minus its tile-local start
+  __shared__ u64 lk[SORT_TILE];
+  __shared__ u32 li[HAS_IDX ? SORT_TILE : 1];
+  __shared__ u32 tile_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) tile_s = atomicAdd(ticket, 1u);
+  for (int d = lane; d < 256; d += 64) wave_cnt[wave][d] = 0;
+  __syncthreads();
+  const u32 tile = tile_s;
+  const u64 tile_base = (u64)tile * SORT_TILE;
+  const u64 wave_base = tile_base + (u64)wave * (SORT_TILE / 4);
+  u64 k[SORT_ITEMS]; u32 id[SORT_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u64 i = wave_base + (u64)j * 64 + lane;
+    const bool ok = i < n;
+    k[j] = ok ? keys_in[i] : ~0ull;
+    id[j] = (HAS_IDX && ok) ? idx_in[i] : 0u;
+    if (ok) atomicAdd(&wave_cnt[wave][(k[j] >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  const u32 tot = wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
+  // publish this tile's count of digit t, then look back for the sum of all earlier tiles
+  const u64 tag = (epoch & 0x3FFFFFFFull) << 32;
+  unsigned long long* const mine = status + (u64)tile * 256 + t;
+  __hip_atomic_store(mine, ONESWEEP_AGG | tag | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32 prefix = 0;
+  for (u32 j = tile; j > 0;) {
+    --j;
+    const unsigned long long* const p = status + (u64)j * 256 + t;
+    u64 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 spins = 0;
+    while ((v >> 62) == 0 || (v & (0x3FFFFFFFull << 32)) != tag) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) { atomicExch(stuck, 1u); break; }      // never expected: give up rather than hang the device
+      v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    prefix += (u32)v;
+    if ((v >> 62) == 2) break;
+  }
+  __hip_atomic_store(mine, ONESWEEP_PREFIX | tag | (u64)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // exclusive scan of the tile's digit totals (thread t = digit t) -> tile-local run starts
+  scanbuf[t] = tot;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const u32 v = t >= o ? scanbuf[t - o] : 0u;
+    __syncthreads();
+    scanbuf[t] += v;
+    __syncthreads();
+  }
+  {
+    const u32 excl = scanbuf[t] - tot;
+    goff[t] = digit_base[t] + prefix - excl;
+    u32 run = excl;
+    for (int w = 0; w < 4; ++w) { const u32 c = wave_cnt[w][t]; wave_cnt[w][t] = run; run += c; }
+  }
+  const u32 valid = scanbuf[255];
+  __syncthreads();
+  // rank and place into LDS, 64 consecutive elements per step
+  const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u64 i = wave_base + (u64)j * 64 + lane;
+    const bool ok = i < n;
+    const u32 d = (u32)(k[j] >> shift) & 0xFF;
+    u64 peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const u64 bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    if (ok) {
+      const u32 rank = (u32)__popcll(peers & lt);
+      const u32 pos = wave_cnt[wave][d] + rank;
+      lk[pos] = k[j];
+      if (HAS_IDX) li[pos] = id[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (ok && (peers & lt) == 0) wave_cnt[wave][d] += (u32)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // coalesced write-out of the digit-ordered tile
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u32 e = (u32)j * SORT_THREADS + (u32)t;
+    if (e < valid) {
+      const u64 key = lk[e];
+      const u32 pos = goff[(u32)(key >> shift) & 0xFF] + e;
+      keys_out[pos] = key;
+      if (HAS_IDX) idx_out[pos] = li[e];
+    }
+  }
+}
+
+// ---- wide keys: sort by the high half, then fix up the ties ---------------------------------------------------------
+// A 64-bit key whose high 32 bits already separate almost all rows (100 M uniform keys: 1 % of the rows share their
+// high half with a neighbour, in runs of 2 or 3) does not need the four low-digit passes: after the stable passes over
+// the high digits the rows of one high half are adjacent and in input order, and sorting each such run by the low half
+// (stable insertion sort, in place, one thread per run) completes the order.  A run longer than SORT_TIE_RUN_MAX raises a
+// flag instead: the host then sorts all digits in LSD order as usual.
+#define SORT_TIE_RUN_MAX 64u
+template <bool HAS_IDX>
+__global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_kernel(u64* __restrict__ keys, u32* __restrict__ idx, u64 n, u32 hi_shift, u32* __restrict__ too_long) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 h = keys[i] >> hi_shift;
+  if (i > 0 && (keys[i - 1] >> hi_shift) == h) return;       // not the first row of its run
+  if (i + 1 >= n || (keys[i + 1] >> hi_shift) != h) return;  // a run of one
+  u32 len = 2;
+  while (i + len < n && len <= SORT_TIE_RUN_MAX && (keys[i + len] >> hi_shift) == h) ++len;
+  if (len > SORT_TIE_RUN_MAX) { if (*too_long == 0u) atomicExch(too_long, 1u); return; }   // the host sorts all digits instead
+  for (u32 a = 1; a < len; ++a) {                             // stable insertion sort of the run by the whole key
+    const u64 k = keys[i + a]; const u32 r = HAS_IDX ? idx[i + a] : 0u;
+    u32 b = a;
+    while (b > 0 && keys[i + b - 1] > k) { keys[i + b] = keys[i + b - 1]; if (HAS_IDX) idx[i + b] = idx[i + b - 1]; --b; }
+    keys[i + b] = k; if (HAS_IDX) idx[i + b] = r;
+  }
+}
+
+// ---- payload as records ---------------------------------------------------------------------------------------------
+// Gathering P payload columns one by one costs P random 8-byte reads per row, each of which moves a whole 64-byte sector
+// (13.8 of the 25.7 ms of the 8-column sort).  With three or more gathered columns the rows are first packed into
+// fixed-stride records (one coalesced pass) and the sorted order then fetches ONE record per row: every byte of every
+// sector read is used.  Both kernels transpose through LDS so that global accesses are 16 bytes per lane, consecutive
+// lanes on consecutive addresses.
+__global__ __launch_bounds__(256) void ssgpu_sort_pack_kernel(const SortRecParams P) {
+  extern __shared__ __attribute__((aligned(16))) char tile[];
+  const int t = threadIdx.x;
+  const u64 base = (u64)blockIdx.x * 256;
+  const u64 row = base + t;
+  const u32 S = P.stride;
+  if (row < P.n) {
+    for (u32 c = 0; c < P.n_fields; ++c) {
+      const SortRecField f = P.fields[c];
+      char* dst = tile + (u32)t * S + f.off;
+      if (f.width == 8) *reinterpret_cast<u64*>(dst) = reinterpret_cast<const u64*>(f.src)[row];
+      else if (f.width == 4) *reinterpret_cast<u32*>(dst) = reinterpret_cast<const u32*>(f.src)[row];
+      else *reinterpret_cast<u8*>(dst) = f.src ? reinterpret_cast<const u8*>(f.src)[row] : (u8)0;
+    }
+  }
+  __syncthreads();
+  const u64 rows_here = P.n - base < 256 ? P.n - base : 256;
+  const u32 chunks = (u32)(rows_here * S / 16);
+  uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<char*>(P.recs) + base * S);
+  for (u32 j = (u32)t; j < chunks; j += 256) out[j] = reinterpret_cast<const uint4*>(tile)[j];
+}
+
+__global__ __launch_bounds__(256) void ssgpu_sort_gather_rec_kernel(const SortRecParams P, const u32* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) char tile[];
+  __shared__ u32 rid[256];
+  const int t = threadIdx.x;
+  const u64 base = (u64)blockIdx.x * 256;
+  const u32 S = P.stride, cpr = S / 16;
+  const u64 rows_here = P.n - base < 256 ? P.n - base : 256;
+  if ((u64)t < rows_here) rid[t] = idx[base + t];
+  __syncthreads();
+  const u32 chunks = (u32)rows_here * cpr;
+  for (u32 j = (u32)t; j < chunks; j += 256) {
+    const u32 r = j / cpr, ch = j - r * cpr;
+    reinterpret_cast<uint4*>(tile)[j] = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.recs) + (u64)rid[r] * S)[ch];
+  }
+  __syncthreads();
+  if ((u64)t < rows_here) {
+    const u64 row = base + t;
+    for (u32 c = 0; c < P.n_fields; ++c) {
+      const SortRecField f = P.fields[c];
+      if (!f.dst) continue;
+      const char* src = tile + (u32)t * S + f.off;
+      if (f.width == 8) reinterpret_cast<u64*>(f.dst)[row] = *reinterpret_cast<const u64*>(src);
+      else if (f.width == 4) reinterpret_cast<u32*>(f.dst)[row] = *reinterpret_cast<const u32*>(src);
+      else reinterpret_cast<u8*>(f.dst)[row] = *reinterpret_cast<const u8*>(src);
     }
   }
 }
@@ -367,6 +621,36 @@ hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* id
                                        idx_out, shift, (u64)n, nt, offsets);
   else if (nt) hipLaunchKernelGGL(ssgpu_sort_scatter_kernel<false>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out,
                                   idx_out, shift, (u64)n, nt, offsets);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_load_keys_hist(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width, int kind,
+                                            int descending, int null_pass, uint64_t n, unsigned long long* bits, uint32_t* hist8, uint32_t* base8, hipStream_t s) {
+  if (!n) return hipSuccess;
+  const int grid = (int)std::min<uint64_t>(blocks_for(n, 256 * LOAD_KEYS_PER_THREAD), 2048);
+  hipLaunchKernelGGL(ssgpu_sort_load_keys_hist_kernel, dim3(grid), dim3(256), 0, s, (u64*)keys, idx, col, nulls, width, kind, descending, null_pass, (u64)n, bits, hist8);
+  hipLaunchKernelGGL(ssgpu_sort_scan_hist8_kernel, dim3(8), dim3(256), 0, s, (const u32*)hist8, base8);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_onesweep(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out, uint32_t shift, uint64_t n,
+                                      const uint32_t* digit_base, unsigned long long* status, uint32_t* ticket, uint64_t epoch, uint32_t* stuck, hipStream_t s) {
+  const uint32_t nt = ssgpu_sort_tiles(n);
+  if (nt && idx_in) hipLaunchKernelGGL(ssgpu_sort_onesweep_kernel<true>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
+                                       shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);
+  else if (nt) hipLaunchKernelGGL(ssgpu_sort_onesweep_kernel<false>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
+                                  shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_fix_ties(uint64_t* keys, uint32_t* idx, uint64_t n, uint32_t hi_shift, uint32_t* too_long, hipStream_t s) {
+  if (n && idx) hipLaunchKernelGGL(ssgpu_sort_fix_ties_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)keys, idx, (u64)n, hi_shift, too_long);
+  else if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)keys, idx, (u64)n, hi_shift, too_long);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s) {
+  if (P.n) hipLaunchKernelGGL(ssgpu_sort_pack_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, hipStream_t s) {
+  if (P.n) hipLaunchKernelGGL(ssgpu_sort_gather_rec_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P, idx);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_unkey(void* out, const uint64_t* keys, uint32_t width, int kind, int descending, uint64_t n, hipStream_t s) {

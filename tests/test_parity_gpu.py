@@ -267,6 +267,36 @@ def test_group_aggregate_partitioned_many_groups():
         assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="adaptive group run")
 
 
+@pytest.mark.parametrize("shape", ["uniform", "pairs", "long_runs", "sorted_high"])
+@pytest.mark.parametrize("payload", [0, 4])
+def test_sort_wide_keys_high_half_first(gpu_ctx, shape, payload):
+    # INT64 keys whose eight digits all vary: the sort orders them by the high half and fixes up runs of equal high halves
+    # by the low half ("pairs": many runs of 2-3), or -- when a run is long ("long_runs") -- falls back to all eight passes;
+    # either way the result is the stable order by the whole key, with 0 or 4 payload columns (records)
+    rng = np.random.default_rng(21)
+    n = 200003
+    lo = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    if shape == "uniform":
+        hi = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    elif shape == "pairs":
+        hi = rng.integers(0, 1 << 32, n // 2, dtype=np.uint64)[rng.integers(0, n // 2, n)]
+    elif shape == "long_runs":
+        hi = rng.integers(0, 1 << 32, 300, dtype=np.uint64)[rng.integers(0, 300, n)]
+    else:
+        hi = np.sort(rng.integers(0, 1 << 32, n // 3, dtype=np.uint64)[rng.integers(0, n // 3, n)])
+    key = ((hi << np.uint64(32)) | lo).view(np.int64)
+    key[::97] = key[5]                                   # exact duplicates: their input order must survive
+    cols = [ss.Column(key), ss.Column(np.arange(n, dtype=np.int64))] + [ss.Column(rng.integers(-9, 9, n) * 0.5) for _ in range(payload)]
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("id", ss.INT64)] + [ss.Attribute("p%d" % i, ss.DOUBLE) for i in range(payload)])
+    view = ss.View(schema, cols, n)
+    got = ss.drain(ss.Sort(ss.SortOrder().add("k", ss.ASCENDING), None, 0, ss.ScanView(view)).CreateCursor(gpu_ctx), 1 << 20)
+    order = np.argsort(key, kind="stable")
+    assert np.array_equal(got.column(0).data, key[order])
+    assert np.array_equal(got.column(1).data, order)
+    for i in range(payload):
+        assert np.array_equal(got.column(2 + i).data, cols[2 + i].data[order])
+
+
 def test_plan_restages_every_new_host_view(gpu_ctx):
     # one Plan run over a stream of temporary host Views (a per-batch loop): CPython reuses the id() of a freed View, so
     # the staged device block must be keyed on the object itself -- never on its id
