@@ -262,24 +262,25 @@ __global__ __launch_bounds__(256) void ssgpu_sort_scan_hist8_kernel(const u32* _
 
 #define ONESWEEP_AGG (1ull << 62)
 #define ONESWEEP_PREFIX (2ull << 62)
-template <bool HAS_IDX>
-__global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_onesweep_kernel(
+template <bool HAS_IDX, int THREADS>
+__global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
     const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
     u32 shift, u64 n, const u32* __restrict__ digit_base, unsigned long long* __restrict__ status, u32* __restrict__ ticket,
     u64 epoch, u32* __restrict__ stuck) {
-  __shared__ u32 wave_cnt[4][256];   // running tile-local positions per wave and digit
+  constexpr int NW = THREADS / 64, TILE = THREADS * SORT_ITEMS;
+  __shared__ u32 wave_cnt[NW][256];  // running tile-local positions per wave and digit
   __shared__ u32 scanbuf[256];
   __shared__ u32 goff[256];          // global offset of digit d minus its tile-local start
-  __shared__ u64 lk[SORT_TILE];
-  __shared__ u32 li[HAS_IDX ? SORT_TILE : 1];
+  __shared__ u64 lk[TILE];
+  __shared__ u32 li[HAS_IDX ? TILE : 1];
   __shared__ u32 tile_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) tile_s = atomicAdd(ticket, 1u);
   for (int d = lane; d < 256; d += 64) wave_cnt[wave][d] = 0;
   __syncthreads();
   const u32 tile = tile_s;
-  const u64 tile_base = (u64)tile * SORT_TILE;
-  const u64 wave_base = tile_base + (u64)wave * (SORT_TILE / 4);
+  const u64 tile_base = (u64)tile * TILE;
+  const u64 wave_base = tile_base + (u64)wave * (TILE / NW);
   u64 k[SORT_ITEMS]; u32 id[SORT_ITEMS];
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; ++j) {
@@ -290,43 +291,46 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_onesweep_kernel(
     if (ok) atomicAdd(&wave_cnt[wave][(k[j] >> shift) & 0xFF], 1u);
   }
   __syncthreads();
-  const u32 tot = wave_cnt[0][t] + wave_cnt[1][t] + wave_cnt[2][t] + wave_cnt[3][t];
-  // publish this tile's count of digit t, then look back for the sum of all earlier tiles
-  const u64 tag = (epoch & 0x3FFFFFFFull) << 32;
-  unsigned long long* const mine = status + (u64)tile * 256 + t;
-  __hip_atomic_store(mine, ONESWEEP_AGG | tag | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  u32 prefix = 0;
-  for (u32 j = tile; j > 0;) {
-    --j;
-    const unsigned long long* const p = status + (u64)j * 256 + t;
-    u64 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u32 spins = 0;
-    while ((v >> 62) == 0 || (v & (0x3FFFFFFFull << 32)) != tag) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 24)) { atomicExch(stuck, 1u); break; }      // never expected: give up rather than hang the device
-      v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32 tot = 0, prefix = 0;
+  if (t < 256) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += wave_cnt[w][t];
+    // publish this tile's count of digit t, then look back for the sum of all earlier tiles
+    const u64 tag = (epoch & 0x3FFFFFFFull) << 32;
+    unsigned long long* const mine = status + (u64)tile * 256 + t;
+    __hip_atomic_store(mine, ONESWEEP_AGG | tag | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (u32 j = tile; j > 0;) {
+      --j;
+      const unsigned long long* const p = status + (u64)j * 256 + t;
+      u64 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u32 spins = 0;
+      while ((v >> 62) == 0 || (v & (0x3FFFFFFFull << 32)) != tag) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { atomicExch(stuck, 1u); break; }      // never expected: give up rather than hang the device
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      prefix += (u32)v;
+      if ((v >> 62) == 2) break;
     }
-    prefix += (u32)v;
-    if ((v >> 62) == 2) break;
+    __hip_atomic_store(mine, ONESWEEP_PREFIX | tag | (u64)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scanbuf[t] = tot;
   }
-  __hip_atomic_store(mine, ONESWEEP_PREFIX | tag | (u64)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // exclusive scan of the tile's digit totals (thread t = digit t) -> tile-local run starts
-  scanbuf[t] = tot;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
-    const u32 v = t >= o ? scanbuf[t - o] : 0u;
+    const u32 v = (t < 256 && t >= o) ? scanbuf[t - o] : 0u;
     __syncthreads();
-    scanbuf[t] += v;
+    if (t < 256) scanbuf[t] += v;
     __syncthreads();
   }
-  {
+  if (t < 256) {
     const u32 excl = scanbuf[t] - tot;
     goff[t] = digit_base[t] + prefix - excl;
     u32 run = excl;
-    for (int w = 0; w < 4; ++w) { const u32 c = wave_cnt[w][t]; wave_cnt[w][t] = run; run += c; }
+    for (int w = 0; w < NW; ++w) { const u32 c = wave_cnt[w][t]; wave_cnt[w][t] = run; run += c; }
   }
-  const u32 valid = scanbuf[255];
   __syncthreads();
+  const u32 valid = scanbuf[255];
   // rank and place into LDS, 64 consecutive elements per step
   const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_onesweep_kernel(
   // coalesced write-out of the digit-ordered tile
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; ++j) {
-    const u32 e = (u32)j * SORT_THREADS + (u32)t;
+    const u32 e = (u32)j * THREADS + (u32)t;
     if (e < valid) {
       const u64 key = lk[e];
       const u32 pos = goff[(u32)(key >> shift) & 0xFF] + e;
@@ -631,13 +635,17 @@ hipError_t ssgpu_launch_sort_load_keys_hist(uint64_t* keys, const uint32_t* idx,
   hipLaunchKernelGGL(ssgpu_sort_scan_hist8_kernel, dim3(8), dim3(256), 0, s, (const u32*)hist8, base8);
   return hipGetLastError();
 }
+#ifndef SSGPU_ONESWEEP_THREADS
+#define SSGPU_ONESWEEP_THREADS 512      /* tile = 16 keys per thread: 8192 keys, a digit's run of a tile averages 256 bytes */
+#endif
+uint32_t ssgpu_onesweep_tiles(uint64_t n) { return (uint32_t)((n + (uint64_t)SSGPU_ONESWEEP_THREADS * SORT_ITEMS - 1) / ((uint64_t)SSGPU_ONESWEEP_THREADS * SORT_ITEMS)); }
 hipError_t ssgpu_launch_sort_onesweep(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out, uint32_t shift, uint64_t n,
                                       const uint32_t* digit_base, unsigned long long* status, uint32_t* ticket, uint64_t epoch, uint32_t* stuck, hipStream_t s) {
-  const uint32_t nt = ssgpu_sort_tiles(n);
-  if (nt && idx_in) hipLaunchKernelGGL(ssgpu_sort_onesweep_kernel<true>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
+  const uint32_t nt = ssgpu_onesweep_tiles(n);
+  if (nt && idx_in) hipLaunchKernelGGL((ssgpu_sort_onesweep_kernel<true, SSGPU_ONESWEEP_THREADS>), dim3(nt), dim3(SSGPU_ONESWEEP_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
                                        shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);
-  else if (nt) hipLaunchKernelGGL(ssgpu_sort_onesweep_kernel<false>, dim3(nt), dim3(SORT_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
-                                  shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);
+  else if (nt) hipLaunchKernelGGL((ssgpu_sort_onesweep_kernel<false, SSGPU_ONESWEEP_THREADS>), dim3(nt), dim3(SSGPU_ONESWEEP_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
+                                  shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);   // (1024-thread tiles for the keys-only form measured the same)
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_fix_ties(uint64_t* keys, uint32_t* idx, uint64_t n, uint32_t hi_shift, uint32_t* too_long, hipStream_t s) {
