@@ -1095,7 +1095,9 @@ static void block_grow(orc_block* b, int64_t cap) {
   b->cap = cap;
 }
 
-typedef struct agg_col { int aggregation, in_pos, in_type, out_type; } agg_col;
+/* distinct: only the first occurrence of every value of a group is aggregated -- DistinctAggregator keeps one hash set of
+ * the values seen per result row (cursor/core/column_aggregator.cc:308-376); here ONE set of (result row, value bits) pairs */
+typedef struct agg_col { int aggregation, in_pos, in_type, out_type; int distinct; uint64_t* dval; int64_t* drow; int64_t dcap, dcount; } agg_col;
 
 typedef struct orc_cursor {
   int kind; struct orc_cursor* child; orc_schema schema; orc_error err;
@@ -1152,7 +1154,9 @@ static int bind_aggs(orc_cursor* c, const orc_op* op, const orc_schema* in) {
     }
     g->in_type = g->in_pos >= 0 ? in->a[g->in_pos].type : T_UINT64;
     g->out_type = a->output_type >= 0 ? a->output_type : (a->aggregation == A_COUNT ? T_UINT64 : g->in_type);
-    if (a->distinct || a->aggregation == A_CONCAT) { set_err(&c->err, RC_NOT_IMPLEMENTED, "DISTINCT/CONCAT not restated%s%s", "", ""); return 0; }
+    if (a->aggregation == A_CONCAT) { set_err(&c->err, RC_NOT_IMPLEMENTED, "CONCAT not restated%s%s", "", ""); return 0; }
+    if (a->distinct && c->kind == C_CLUSTERS) { set_err(&c->err, RC_NOT_IMPLEMENTED, "DISTINCT inside AggregateClusters not restated%s%s", "", ""); return 0; }
+    g->distinct = a->distinct;
     if (a->aggregation == A_COUNT) { if (!is_integer(g->out_type)) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "COUNT output must be integer%s%s", "", ""); return 0; } }
     else {
       int ok = (is_numeric(g->in_type) && is_numeric(g->out_type)) ||
@@ -1290,13 +1294,38 @@ static int64_t load_as_i64(int t, const void* p, int64_t i) {
   return 0;
 }
 
+/* DISTINCT: 1 if (result row, value) was seen before, else remembers it (NULL inputs never get here: "NULL values do
+ * not count as distinct", column_aggregator.cc:326-329) */
+static int distinct_seen(agg_col* g, int64_t row, const void* in, int64_t i) {
+  const int w = type_width(g->in_type);
+  uint64_t bits = 0; memcpy(&bits, (const char*)in + i * w, (size_t)w);
+  if (g->in_type == T_DOUBLE && bits == 0x8000000000000000ull) bits = 0;      /* -0.0 == +0.0 */
+  if (g->in_type == T_FLOAT && bits == 0x80000000ull) bits = 0;
+  if ((g->dcount + 1) * 2 > g->dcap) {
+    const int64_t ncap = g->dcap ? g->dcap * 2 : 1024;
+    uint64_t* nv = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)ncap); int64_t* nr = (int64_t*)malloc(sizeof(int64_t) * (size_t)ncap);
+    for (int64_t q = 0; q < ncap; ++q) nr[q] = -1;
+    for (int64_t q = 0; q < g->dcap; ++q) if (g->drow[q] >= 0) {
+      uint64_t h = (g->dval[q] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)g->drow[q] * 0xC2B2AE3D27D4EB4Full); int64_t s2 = (int64_t)((h ^ (h >> 29)) & (uint64_t)(ncap - 1));
+      while (nr[s2] >= 0) s2 = (s2 + 1) & (ncap - 1);
+      nr[s2] = g->drow[q]; nv[s2] = g->dval[q];
+    }
+    free(g->dval); free(g->drow); g->dval = nv; g->drow = nr; g->dcap = ncap;
+  }
+  uint64_t h = (bits * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)row * 0xC2B2AE3D27D4EB4Full); int64_t s2 = (int64_t)((h ^ (h >> 29)) & (uint64_t)(g->dcap - 1));
+  while (g->drow[s2] >= 0) { if (g->drow[s2] == row && g->dval[s2] == bits) return 1; s2 = (s2 + 1) & (g->dcap - 1); }
+  g->drow[s2] = row; g->dval[s2] = bits; g->dcount++;
+  return 0;
+}
+
 /* one aggregate column over one view: acc[map[i]] op= v[i] */
-static void update_aggregation(const agg_col* g, const orc_view* v, const int64_t* map, void* res, uint8_t* res_null) {
+static void update_aggregation(agg_col* g, const orc_view* v, const int64_t* map, void* res, uint8_t* res_null) {
   const int64_t n = v->rows;
   if (g->aggregation == A_COUNT) {
     const uint8_t* nl = g->in_pos >= 0 ? v->c[g->in_pos].is_null : NULL;
     for (int64_t i = 0; i < n; ++i) {
       if (nl && nl[i]) continue;
+      if (g->distinct && distinct_seen(g, map[i], v->c[g->in_pos].data, i)) continue;
       if (type_width(g->out_type) == 8) ((uint64_t*)res)[map[i]] += 1; else ((uint32_t*)res)[map[i]] += 1;
     }
     return;
@@ -1306,6 +1335,7 @@ static void update_aggregation(const agg_col* g, const orc_view* v, const int64_
   for (int64_t i = 0; i < n; ++i) {
     if (nl && nl[i]) continue;
     const int64_t r = map[i];
+    if (g->distinct && distinct_seen(g, r, in, i)) continue;
     const int first = res_null[r];
     if (first) res_null[r] = 0;
 #define AGG_TYPED(TO, LOADER) { TO val = (TO)LOADER(g->in_type, in, i); TO* acc = (TO*)res + r; \

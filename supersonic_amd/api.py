@@ -579,6 +579,10 @@ class AggregationSpecification(object):
         self.elements.append((aggregation, 0, output_type, input_name, output_name))
         return self
 
+    def AddDistinctAggregationWithDefinedOutputType(self, aggregation, input_name, output_name, output_type):
+        self.elements.append((aggregation, 1, output_type, input_name, output_name))
+        return self
+
 
 class GroupAggregateOptions(object):
     def __init__(self):

@@ -146,6 +146,9 @@ struct Stage {
   std::vector<JoinSpec> joins;            // HashJoins fused into this stage's programs
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns
+  // DISTINCT aggregates (SCALAR_AGG / CLUSTERS over rows sorted by these columns: group keys + the distinct column): the
+  // runtime appends a BOOL input column that is 1 on the first row of every run of equal values of these columns
+  std::vector<int> distinct_cols;
   // JOIN_EXPAND: the previous stage materialised [lhs fields..., run start, run count]; every output
   // column is lhs field `col` (from_rhs = false) or column `col` of the auxiliary input
   struct JoinOut { bool from_rhs; int col; };

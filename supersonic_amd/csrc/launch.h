@@ -129,6 +129,8 @@ hipError_t ssgpu_launch_sort_gather(void* out, uint8_t* out_nulls, const void* c
                                     const uint32_t* idx, uint64_t n, hipStream_t s);
 hipError_t ssgpu_launch_cluster_count(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
                                       uint64_t n, uint32_t* tile_counts, hipStream_t s);
+hipError_t ssgpu_launch_cluster_flags(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
+                                      uint64_t n, uint8_t* flag, hipStream_t s);
 hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
                                        void* const* out_data, uint8_t* const* out_nulls, uint64_t n, const uint32_t* tile_offsets,
                                        uint32_t* seg_id, hipStream_t s);

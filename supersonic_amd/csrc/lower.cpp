@@ -780,6 +780,7 @@ struct AggPlan {
   int out_type = 0;
   std::string out_name;
   bool result_nullable = true;
+  bool distinct = false;   // only the first occurrence of every value of a group contributes (column_aggregator.cc:308-376)
 };
 
 static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schema& in, std::vector<AggPlan>* out) {
@@ -804,8 +805,8 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
       if (q.out_name == p.out_name)
         return Status::Error(SSGPU_ERROR_ATTRIBUTE_EXISTS,
                              "Incorrect aggregation specification. Aggregation output column name is non-unique: '" + p.out_name + "'.");
-    if (a.distinct)
-      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "DISTINCT aggregations are outside the device hot path");
+    // DISTINCT changes SUM and COUNT only: the MIN / MAX / FIRST / LAST of the distinct values are those of all values
+    p.distinct = a.distinct && (a.aggregation == SSGPU_SUM || a.aggregation == SSGPU_COUNT);
     if (a.aggregation == SSGPU_CONCAT)
       return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT (STRING) is outside the device hot path");
     // supported matrix (column_aggregator.cc:484-532)
@@ -943,27 +944,29 @@ static int64_t staged_bytes(const Program& p) {
   return b;
 }
 
-static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st) {
+// distinct_flag_input >= 0: index of a synthetic BOOL input column (appended by the runtime) that is 1 on the first row of
+// every run of equal (group keys, distinct column) in the -- sorted -- stage input; a DISTINCT aggregate treats every other
+// row like a NULL input
+static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const Pipe& pipe, Stage* st, int distinct_flag_input = -1) {
   st->kind = STAGE_SCALAR_AGG;
   st->in_schema = pipe.in_schema;
-  const Schema vs = schema_of(pipe.cols);
-  std::vector<AggPlan> plans;
-  SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, vs, &plans));
   if ((int)plans.size() > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
   st->joins = pipe.joins;
   Emitter em(&st->main, &pipe.joins);
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
+  int notfirst = -1;
+  if (distinct_flag_input >= 0) { Val f; f.width = 1; f.reg = em.staged(distinct_flag_input, false, 1); notfirst = em.unop(VM_NOT_B8, f, 1); }
   // COUNT(*) (or COUNT of a never-NULL column) under the same selection equals the contribution
   // count every non-COUNT aggregate of a never-NULL input already keeps: share it, no instruction
   int count_donor = -1;
   for (size_t j = 0; j < plans.size(); ++j)
-    if (plans[j].aggregation != SSGPU_COUNT && !pipe.cols[plans[j].input_pos].expr->nullable) { count_donor = (int)j; break; }
+    if (plans[j].aggregation != SSGPU_COUNT && !plans[j].distinct && !pipe.cols[plans[j].input_pos].expr->nullable) { count_donor = (int)j; break; }
   for (size_t j = 0; j < plans.size(); ++j) {
     const AggPlan& ap = plans[j];
     AggOut ao; ao.slot = (int)j; ao.has_cnt = true; ao.result_nullable = ap.result_nullable;
     if (ap.aggregation == SSGPU_COUNT) {
-      const bool never_null = ap.input_pos < 0 || !pipe.cols[ap.input_pos].expr->nullable;
+      const bool never_null = !ap.distinct && (ap.input_pos < 0 || !pipe.cols[ap.input_pos].expr->nullable);
       if (never_null && count_donor >= 0) {
         ao.slot = count_donor; ao.slot_kind = SLOT_COUNT;
         ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_CNT_U32 : EMIT_CNT_U64;
@@ -974,6 +977,7 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
       }
       int nullreg = -1;
       if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
+      if (ap.distinct) nullreg = em.or_null(nullreg, notfirst);
       LInstr& i = em.emit(VM_AGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = sel;
       ao.slot_kind = SLOT_COUNT;
       ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
@@ -984,7 +988,7 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
         return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
       // fused SUM(x op y): the binary node feeds only this aggregate -> no LDS round trip
       const MT smt = mtype(src->dtype);
-      const bool fusable = ap.aggregation == SSGPU_SUM && (int)j < VM_FAST_SLOTS && src->kind == BExpr::OP &&
+      const bool fusable = !ap.distinct && ap.aggregation == SSGPU_SUM && (int)j < VM_FAST_SLOTS && src->kind == BExpr::OP &&
                            src->dtype == ap.out_type && (smt == M_I64 || smt == M_U64 || smt == M_F64) &&
                            (src->op == OP_ADD || src->op == OP_SUBTRACT || src->op == OP_MULTIPLY) && !em.has_value(src);
       if (fusable) {
@@ -1005,7 +1009,8 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
         Val c;
         SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
         int vr = em.materialize(c);
-        LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = sel;
+        const int nullreg = ap.distinct ? em.or_null(v.null, notfirst) : v.null;
+        LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = sel;
       }
       ao.slot_kind = s.slot_kind; ao.emit_kind = s.emit_kind;
     }
@@ -1018,6 +1023,12 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
   st->algorithmic_bytes_per_row = staged_bytes(st->main);
   st->has_filter = !pipe.filters.empty();
   return Status::OK();
+}
+
+static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& pipe, Stage* st) {
+  std::vector<AggPlan> plans;
+  SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &plans));
+  return finish_scalar_agg_bound(plans, pipe, st);
 }
 
 struct AggPlan;
@@ -1047,7 +1058,8 @@ static Status bind_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& 
 // *too_wide is set (with an error status) when the hash aggregate cannot run as one fused pipeline
 // -- the packed key needs more than 64 bits, or FIRST/LAST reads a computed expression --
 // and lower_plan falls back to materialise + sort + clustered aggregation.
-static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* st, bool clustered = false, bool* too_wide = nullptr) {
+static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* st, bool clustered = false, bool* too_wide = nullptr,
+                               int distinct_flag_input = -1) {
   st->kind = clustered ? STAGE_CLUSTERS : STAGE_GROUP_AGG;
   st->in_schema = pipe.in_schema;
   const std::vector<int>& kpos = g.kpos; const std::vector<std::string>& knames = g.knames;
@@ -1057,6 +1069,8 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
   int slotreg = -1;
+  int notfirst = -1;   // DISTINCT aggregates (see finish_scalar_agg_bound)
+  if (distinct_flag_input >= 0) { Val f; f.width = 1; f.reg = em.staged(distinct_flag_input, false, 1); notfirst = em.unop(VM_NOT_B8, f, 1); }
   if (clustered) {
     for (size_t k = 0; k < kpos.size(); ++k) {
       const BExprP& ke = pipe.cols[kpos[k]].expr;
@@ -1112,6 +1126,7 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
     if (ap.aggregation == SSGPU_COUNT) {
       int nullreg = -1;
       if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
+      if (ap.distinct) nullreg = em.or_null(nullreg, notfirst);
       LInstr& i = em.emit(VM_GAGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = slotreg;
       i.imm = (ng << 32) | j;
       ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
@@ -1137,8 +1152,9 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
           return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
         vr = em.materialize(c);
       }
-      ao.has_cnt = v.null >= 0;
-      LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = v.null; i.c = slotreg;
+      const int nullreg = ap.distinct ? em.or_null(v.null, notfirst) : v.null;
+      ao.has_cnt = nullreg >= 0;
+      LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = slotreg;
       i.imm = ((uint64_t)(ao.has_cnt ? 1 : 0) << 63) | (ng << 32) | j;
       ao.emit_kind = s.emit_kind;
     }
@@ -1483,7 +1499,51 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
       } break;
       case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: {
         Stage st;
-        if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
+        // DISTINCT aggregates (SUM / COUNT of the distinct values of a group, column_aggregator.cc:308-376): materialise the
+        // keys and the aggregated columns, sort by (keys, distinct column), flag the first row of every (keys, value) run
+        // and aggregate with the flag standing in for "not NULL": a scalar aggregate over the sorted rows, or the
+        // clustered aggregation over the key runs.  One distinct column per specification.
+        bool any_distinct = false;
+        {
+          std::vector<AggPlan> probe;
+          SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &probe));
+          for (auto& ap : probe) any_distinct = any_distinct || ap.distinct;
+        }
+        if (any_distinct) {
+          if (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0)
+            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "GroupAggregateOptions::max_unique_keys_in_result is not available on the device path");
+          GroupBinding g;
+          if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
+          int dcol = -1;
+          for (auto& ap : g.plans) if (ap.distinct) {
+            if (dcol >= 0 && dcol != ap.input_pos) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "DISTINCT aggregations over more than one column in one specification");
+            dcol = ap.input_pos;
+          }
+          std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
+          auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
+          for (auto& k : g.kpos) k = slot_of(k);
+          for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+          dcol = slot_of(dcol);
+          Pipe pruned = pipe; pruned.cols.clear();
+          for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+          Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
+          stages->push_back(m);
+          Stage so; so.kind = STAGE_SORT; so.in_schema = m.out_schema; so.out_schema = m.out_schema;
+          std::vector<int> run_cols = g.kpos; run_cols.push_back(dcol);
+          for (int k : run_cols) {
+            if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length keys are outside the device hot path");
+            SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+          }
+          for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+          stages->push_back(so);
+          reset_pipe(&pipe, so.out_schema);
+          const int n_in = (int)so.out_schema.size();
+          if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st, n_in));
+          else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true, nullptr, n_in + 1));   // clustered: segment ids at n_in, the flag behind
+          st.distinct_cols = run_cols;
+          desc << "(materialise + sort + first-of-run flags) ";
+        } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
         else {
           // GroupAggregateOptions::max_unique_keys_in_result folds every key beyond the limit into one extra last row
           // (aggregate_groups.cc:326): depends on first-seen key order, which no device shape has -- refuse loudly

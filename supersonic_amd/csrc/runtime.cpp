@@ -123,7 +123,7 @@ struct StageExec {
   DevBuf error_flag;
   DevBuf debug, debug_pc, total2;
   // sort / clusters
-  DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs;
+  DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
   bool pattern_ready = false;
@@ -745,8 +745,28 @@ void fill_fast_slots(VmParams* P, const Stage& st) {
   }
 }
 
-int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base, bool stop_at_partial) {
+// DISTINCT aggregates: the BOOL column "first row of its (keys, value) run" over the sorted stage input
+int distinct_flags(ssgpu_ctx* c, const Stage& st, StageExec& ex, const InCols& in, ssgpu_column* out) {
+  const uint32_t nk = (uint32_t)st.distinct_cols.size();
+  if (nk > 16) { c->err = "DISTINCT aggregate under more than 15 group keys"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  const void* kdata[16] = {nullptr}; const uint8_t* knulls[16] = {nullptr}; uint32_t kwidth[16] = {0};
+  for (uint32_t k = 0; k < nk; ++k) {
+    const int col = st.distinct_cols[k];
+    kdata[k] = in.cols[col].data; knulls[k] = in.cols[col].is_null; kwidth[k] = (uint32_t)dtype_width(st.in_schema[col].dtype);
+  }
+  HIP_TRY(c, ex.dflag.ensure((size_t)std::max<int64_t>(in.rows, 1)));
+  HIP_TRY(c, ssgpu_launch_cluster_flags(kdata, knulls, kwidth, nk, (uint64_t)in.rows, ex.dflag.as<uint8_t>(), c->stream));
+  out->data = ex.dflag.p; out->is_null = nullptr;
+  return SSGPU_OK;
+}
+
+int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_base, bool stop_at_partial) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  InCols in = in0;
+  if (!st.distinct_cols.empty()) {
+    ssgpu_column f; const int rc = distinct_flags(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
+    in.cols.push_back(f);
+  }
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   apply_joins(p, ex, st.main, &P);
@@ -1389,6 +1409,10 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   InCols ext = in;
   ssgpu_column segcol; segcol.data = ex.seg_id.p; segcol.is_null = nullptr;
   ext.cols.push_back(segcol);
+  if (!st.distinct_cols.empty()) {
+    ssgpu_column f; const int frc = distinct_flags(c, st, ex, in, &f); if (frc != SSGPU_OK) return frc;
+    ext.cols.push_back(f);
+  }
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, ext, row_id_base);
   apply_joins(p, ex, st.main, &P);

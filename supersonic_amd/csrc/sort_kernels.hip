@@ -499,6 +499,12 @@ __device__ __forceinline__ bool cluster_boundary(const ClusterKeys& K, u64 i) {
   return false;
 }
 
+// DISTINCT aggregates: flag[i] = 1 on the first row of every run of equal (keys..., value) in the sorted input
+__global__ __launch_bounds__(256) void ssgpu_cluster_flags_kernel(const ClusterKeys K, u64 n, u8* __restrict__ flag) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = cluster_boundary(K, i) ? (u8)1 : (u8)0;
+}
+
 // pass 1: per-tile (512 rows) boundary counts
 __global__ __launch_bounds__(256) void ssgpu_cluster_count_kernel(const ClusterKeys K, u64 n, u32* __restrict__ tile_counts) {
   __shared__ u32 wsum[4];
@@ -676,6 +682,13 @@ hipError_t ssgpu_launch_cluster_count(const void* const* data, const uint8_t* co
   for (uint32_t k = 0; k < 16; ++k) { K.data[k] = k < nkeys ? data[k] : nullptr; K.nulls[k] = k < nkeys ? nulls[k] : nullptr; K.width[k] = k < nkeys ? width[k] : 0; }
   const int nt = blocks_for(n, 512);
   if (nt) hipLaunchKernelGGL(ssgpu_cluster_count_kernel, dim3(nt), dim3(256), 0, s, K, (u64)n, tile_counts);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_cluster_flags(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,
+                                      uint64_t n, uint8_t* flag, hipStream_t s) {
+  ClusterKeys K; K.n = nkeys;
+  for (uint32_t k = 0; k < 16; ++k) { K.data[k] = k < nkeys ? data[k] : nullptr; K.nulls[k] = k < nkeys ? nulls[k] : nullptr; K.width[k] = k < nkeys ? width[k] : 0; }
+  if (n) hipLaunchKernelGGL(ssgpu_cluster_flags_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, K, (u64)n, flag);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* const* nulls, const uint32_t* width, uint32_t nkeys,

@@ -419,20 +419,28 @@ op_case("Filter_FilterOnDropped", FT + ":318-332", cols([I32, I64]), two,
         ["Filter", ["Equal", ["NamedAttribute", "col1"], ["ConstInt64", 65]], ["ProjectNamedAttribute", "col0"], "INPUT"],
         [I32], [[1]], exp_names=["col0"])
 
-# ---- ScalarAggregate (supersonic/cursor/core/aggregate_scalar_test.cc:53-90; DISTINCT dropped) --
+# ---- ScalarAggregate (supersonic/cursor/core/aggregate_scalar_test.cc:53-90) ---------------------
+# An aggregation named X_DISTINCT is AddDistinctAggregation(X, ...).
 ST = "supersonic/cursor/core/aggregate_scalar_test.cc"
-spec4 = [["MAX", "col0", "max"], ["SUM", "col0", "sum"], ["COUNT", "", "count(*)"], ["COUNT", "col0", "count"]]
+spec5 = [["MAX", "col0", "max"], ["SUM", "col0", "sum"], ["COUNT", "", "count(*)"], ["COUNT", "col0", "count"],
+         ["COUNT_DISTINCT", "col0", "count distinct"]]
 op_case("ScalarAggregate_Integers", ST + ":53-70", cols([I32]), [[13], [3], [3], [None], [7]],
-        ["ScalarAggregate", spec4, "INPUT"], [I32, I32, U64, U64], [[13, 26, 5, 4]],
-        exp_names=["max", "sum", "count(*)", "count"], exp_nullable=[True, True, False, False])
+        ["ScalarAggregate", spec5, "INPUT"], [I32, I32, U64, U64, U64], [[13, 26, 5, 4, 3]],
+        exp_names=["max", "sum", "count(*)", "count", "count distinct"], exp_nullable=[True, True, False, False, False])
 op_case("ScalarAggregate_EmptyInput", ST + ":72-86", cols([I32]), [],
-        ["ScalarAggregate", spec4, "INPUT"], [I32, I32, U64, U64], [[None, None, 0, 0]])
+        ["ScalarAggregate", spec5, "INPUT"], [I32, I32, U64, U64, U64], [[None, None, 0, 0, 0]])
 
 # ---- GroupAggregate (supersonic/cursor/core/aggregate_groups_test.cc) --------------------------
 GT = "supersonic/cursor/core/aggregate_groups_test.cc"
 op_case("Group_SimpleAggregation", GT + ":102-117", cols([I32]), [[1], [3]],
         ["GroupAggregate", ["CompoundSingleSourceProjector"], [["SUM", "col0", "sum"]], "INPUT"],
         [I32], [[4]], exp_names=["sum"], exp_nullable=[True])
+op_case("Group_DistinctAggregation", GT + ":220-236", cols([I32]), [[3], [4], [4], [3]],
+        ["GroupAggregate", ["CompoundSingleSourceProjector"], [["SUM_DISTINCT", "col0", "sum"]], "INPUT"], [I32], [[7]])
+op_case("Group_DistinctCountAggregation", GT + ":238-255", cols([I32]), [[3], [4], [4], [3]],
+        ["GroupAggregate", ["CompoundSingleSourceProjector"], [["COUNT_DISTINCT", "col0", "count", I32]], "INPUT"], [I32], [[2]])
+op_case("Group_DistinctCountAggregationNeedsInputColumn", GT + ":257-270", cols([I32]), [[3]],
+        ["GroupAggregate", ["CompoundSingleSourceProjector"], [["COUNT_DISTINCT", "", "count", I32]], "INPUT"], None, [], expect_error=403)
 op_case("Group_CountWithInputColumn", GT + ":119-133", cols([I32]), [[1], [3]],
         ["GroupAggregate", ["CompoundSingleSourceProjector"], [["COUNT", "col0", "count"]], "INPUT"],
         [U64], [[2]], exp_nullable=[False])
@@ -551,11 +559,11 @@ op_case("Clusters_BadGroupBy", CL + ":185-199", cols([I32]), [[13], [3], [7]],
 op_case("Clusters_ResultingColumnsNamesConflict", CL + ":221-232", cols([I32, I32]), [],
         ["AggregateClusters", ["ProjectNamedAttributeAs", "col0", "A"], [["SUM", "col1", "A"]], "INPUT"], None, [], expect_error=404)
 
-# ---- ScalarAggregate on strings (aggregate_scalar_test.cc:37-51,91-104; the DISTINCT column is left out) ----
+# ---- ScalarAggregate on strings (aggregate_scalar_test.cc:37-51,91-104) ----
 op_case("ScalarAggregate_AggregateStrings_string", ST + ":33-45,91-104", cols([STR]),
         [["f"], ["c"], ["a"], ["b"], ["g"], ["a"], ["d"], ["a"], [None], ["e"]],
-        ["ScalarAggregate", [["MAX", "col0", "max"], ["COUNT", "", "count(*)"], ["COUNT", "col0", "count"]], "INPUT"],
-        [STR, U64, U64], [["g", 10, 9]])
+        ["ScalarAggregate", [["MAX", "col0", "max"], ["COUNT", "", "count(*)"], ["COUNT", "col0", "count"], ["COUNT_DISTINCT", "col0", "count distinct"]], "INPUT"],
+        [STR, U64, U64, U64], [["g", 10, 9, 7]])
 
 # ---- Project (supersonic/cursor/core/project_test.cc) ----------------------------------------------
 PT = "supersonic/cursor/core/project_test.cc"

@@ -90,10 +90,16 @@ def build_projector(p):
 def build_spec(spec):
     s = ss.AggregationSpecification()
     for item in spec:
-        if len(item) == 4:
-            s.AddAggregationWithDefinedOutputType(AGGS[item[0]], item[1], item[2], TYPES[item[3]])
+        distinct = item[0].endswith("_DISTINCT")          # AddDistinctAggregation(...)
+        agg = AGGS[item[0][: -len("_DISTINCT")] if distinct else item[0]]
+        if len(item) == 4 and distinct:
+            s.AddDistinctAggregationWithDefinedOutputType(agg, item[1], item[2], TYPES[item[3]])
+        elif len(item) == 4:
+            s.AddAggregationWithDefinedOutputType(agg, item[1], item[2], TYPES[item[3]])
+        elif distinct:
+            s.AddDistinctAggregation(agg, item[1], item[2])
         else:
-            s.AddAggregation(AGGS[item[0]], item[1], item[2])
+            s.AddAggregation(agg, item[1], item[2])
     return s
 
 

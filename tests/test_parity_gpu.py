@@ -297,6 +297,25 @@ def test_sort_wide_keys_high_half_first(gpu_ctx, shape, payload):
         assert np.array_equal(got.column(2 + i).data, cols[2 + i].data[order])
 
 
+@pytest.mark.parametrize("n", [0, 1, 1025, 60013])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_distinct_aggregates(gpu_ctx, n, nullable):
+    # SUM / COUNT of the DISTINCT values of a group (column_aggregator.cc:308-376), next to plain aggregates of the same and of
+    # other columns; MIN / MAX DISTINCT are the plain ones.  Device: materialise -> sort by (keys, column) -> first-of-run flags.
+    view = make_view(n, nullable=nullable)
+    spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "a", "cd").AddDistinctAggregation(ss.SUM, "a", "sd")
+            .AddAggregation(ss.SUM, "a", "s").AddAggregation(ss.COUNT, "a", "c").AddAggregation(ss.COUNT, "", "n")
+            .AddDistinctAggregation(ss.MAX, "d0", "mx").AddAggregation(ss.MIN, "d1", "mn"))
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "t"]), spec, None,
+                               ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx, ignore_order=True)
+    # a DISTINCT aggregate of a computed column, DOUBLE values (sums of small multiples of 0.5: exact in any order)
+    e = ss.CompoundExpression().Add(NA("k2")).AddAs("x", ss.Multiply(NA("d2"), ss.ConstDouble(0.5)))
+    spec2 = ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "x", "sx").AddDistinctAggregation(ss.COUNT, "x", "cx")
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec2, None, ss.Compute(e, ss.ScanView(view))), gpu_ctx, ignore_order=True)
+
+
 def test_plan_restages_every_new_host_view(gpu_ctx):
     # one Plan run over a stream of temporary host Views (a per-batch loop): CPython reuses the id() of a freed View, so
     # the staged device block must be keyed on the object itself -- never on its id
