@@ -27,6 +27,15 @@
  *   ssgpu_block_*          Block / Table (owning column storage)
  *                            base/infrastructure/block.h:412
  *                            cursor/infrastructure/table.h:49
+ *   ssgpu_expr_bind        Expression::DoBind(schema, allocator, max_row_count)
+ *                            supersonic/expression/base/expression.h:164-167
+ *   ssgpu_expr_evaluate    BoundExpressionTree::Evaluate(const View&)
+ *                            supersonic/expression/base/expression.h:116, expression.cc:57-76
+ *   ssgpu_allocator_*      BufferAllocator (Allocate / BestEffortAllocate / Reallocate / Available, Buffer dtor) and
+ *                          MemoryLimit (soft quota)    base/memory/memory.h:100-233,465-520
+ *   ssgpu_plan_set_memory_limit   Operation::SetBufferAllocator(MemoryLimit*)   cursor/base/operation.h:66-76
+ *   ssgpu_dict_*           STRING columns: StringPiece + Arena (base/memory/arena.h) become INT32 codes of an
+ *                          order-preserving dictionary (see "STRING columns" below)
  *   ssgpu_host_alloc/free  BufferAllocator::Allocate / Buffer dtor
  *                            base/memory/memory.h:100-233
  *
@@ -66,7 +75,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 3
+#define SSGPU_ABI_VERSION 4
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -257,6 +266,7 @@ typedef struct ssgpu_column {
 int ssgpu_ctx_create(int device_id, ssgpu_ctx** out);
 void ssgpu_ctx_destroy(ssgpu_ctx* ctx);
 const char* ssgpu_last_error(const ssgpu_ctx* ctx);
+int ssgpu_ctx_has_device(const ssgpu_ctx* ctx);   /* 0 for a bind-only context */
 int ssgpu_abi_version(void);
 /* The HIP stream (hipStream_t) all kernels of this ctx are launched on, and
  * the side stream used for host<->device staging of blocks. */
@@ -271,6 +281,39 @@ int ssgpu_ctx_set_option(ssgpu_ctx* ctx, const char* key, int64_t value);
 /* ---- pinned host memory (BufferAllocator seam, memory.h:100-233) -------- */
 int ssgpu_host_alloc(ssgpu_ctx* ctx, size_t bytes, void** out);
 void ssgpu_host_free(ssgpu_ctx* ctx, void* p);
+
+/* ---- BufferAllocator / MemoryLimit (base/memory/memory.h:100-233,465-520) -----------------------
+ * An allocator of DMA-able (pinned, 256-byte aligned) host memory with an optional soft quota, shaped like the
+ * reference's: Allocate(requested) = BestEffortAllocate(requested, requested); a request the quota cannot serve
+ * returns SSGPU_ERROR_MEMORY_EXCEEDED (102) and *out = NULL (the reference's callers turn a NULL Buffer into
+ * ERROR_MEMORY_EXCEEDED); zero-size requests succeed with a non-NULL pointer (memory.h:112-117).  quota < 0 =
+ * unlimited.  On a bind-only context (no device) the memory is ordinary aligned host memory.  Not thread-safe (as
+ * the reference's allocators other than ThreadSafe*). */
+typedef struct ssgpu_allocator ssgpu_allocator;
+int ssgpu_allocator_create(ssgpu_ctx* ctx, int64_t quota_bytes, ssgpu_allocator** out);
+void ssgpu_allocator_destroy(ssgpu_allocator* a);
+/* grants between `minimal` and `requested` bytes (as many as the quota leaves); *granted may be NULL */
+int ssgpu_allocator_allocate(ssgpu_allocator* a, size_t requested, size_t minimal, void** out, size_t* granted);
+/* BufferAllocator::Reallocate: contents preserved up to the smaller size; on failure the old buffer stays valid */
+int ssgpu_allocator_reallocate(ssgpu_allocator* a, void* p, size_t requested, size_t minimal, void** out, size_t* granted);
+void ssgpu_allocator_free(ssgpu_allocator* a, void* p);
+int64_t ssgpu_allocator_available(const ssgpu_allocator* a); /* bytes the quota still allows; INT64_MAX if unlimited */
+int64_t ssgpu_allocator_allocated(const ssgpu_allocator* a);
+
+/* ---- STRING columns: order-preserving dictionary ----------------------------------------------------
+ * STRING values cross the ABI as INT32 codes (see Conventions).  The dictionary is built here, behind the ABI, so
+ * that every host mirror (and every shard of a multi-GPU run that builds it over the same strings) gets the same
+ * codes: code = rank of the byte string in the reference's StringPiece order (memcmp, then length,
+ * types_infrastructure.h:238-246) among the DISTINCT strings given.  Strings are (pointer, length) pairs, as
+ * StringPiece; the dictionary copies the bytes (the Arena deep-copy rule, cursor/core/filter.cc:205-230). */
+typedef struct ssgpu_dict ssgpu_dict;
+int ssgpu_dict_create(const char* const* strings, const int32_t* lengths, int64_t n, ssgpu_dict** out);
+void ssgpu_dict_destroy(ssgpu_dict* d);
+int32_t ssgpu_dict_size(const ssgpu_dict* d);
+/* codes[i] = code of strings[i], or -1 if it is not in the dictionary (is_null rows, if given, get code 0) */
+int ssgpu_dict_encode(const ssgpu_dict* d, const char* const* strings, const int32_t* lengths, const uint8_t* is_null,
+                      int64_t n, int32_t* codes);
+int ssgpu_dict_decode(const ssgpu_dict* d, int32_t code, const char** bytes, int32_t* length);
 
 /* ---- device-resident Block ----------------------------------------------- */
 int ssgpu_block_create(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs,
@@ -308,6 +351,25 @@ const char* ssgpu_plan_describe(ssgpu_plan* plan);
 /* Debug/test hook: raw VM program of pipeline stage `stage` (see csrc/vm.h). */
 int ssgpu_plan_program(const ssgpu_plan* plan, int32_t stage, const void** instrs,
                        int32_t* n_instrs, int32_t* instr_bytes);
+
+/* Device memory a plan may hold (its stages' output, scratch and table buffers): a soft quota in the sense of
+ * MemoryLimit (memory.h:465).  A run that would need more fails with SSGPU_ERROR_MEMORY_EXCEEDED -- what a cursor
+ * of the reference does when its Operation was given a MemoryLimit allocator (operation.h:66-76,
+ * aggregate_groups.cc:372-402).  bytes < 0 = unlimited (default). */
+int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
+int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
+
+/* ---- standalone expression seam --------------------------------------------------------------------------
+ * Expression::Bind(schema, ...) -> BoundExpressionTree, BoundExpressionTree::Evaluate(view) -> result View
+ * (expression/base/expression.h:46-167, :116): the expression tree `root` (nodes as in ssgpu_plan_desc) is bound
+ * against `schema` exactly like a Compute over a scan (type promotion, names, nullability, bind errors); the bound
+ * tree is an ssgpu_plan whose schema (ssgpu_plan_attr) is the tree's result_schema.  max_row_count is the tree's
+ * row_capacity(): Evaluate over more rows fails with SSGPU_ERROR_TOO_MANY_ROWS (expression.cc:57-66); <= 0 means no
+ * bound (device buffers grow to the View).  Evaluate returns one result row per input row, in order. */
+int ssgpu_expr_bind(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs, const ssgpu_expr* exprs, int32_t n_exprs,
+                    const int32_t* expr_args, int32_t n_expr_args, int32_t root, int64_t max_row_count, ssgpu_plan** out);
+int64_t ssgpu_expr_row_capacity(const ssgpu_plan* bound);
+int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_cols, int64_t rows, ssgpu_result** out);
 
 /* ---- run ------------------------------------------------------------------ */
 /* cols: one entry per attribute of the plan's input schema, DEVICE pointers. */

@@ -101,9 +101,50 @@ class TupleSchema {
   std::vector<Attribute> attrs_;
 };
 
+// STRING cells of a View (supersonic/utils/stringpiece.h): a pointer + length, not owning the bytes.  Views handed to
+// ScanView / Evaluate hold arrays of these; across the C ABI they travel as INT32 codes of an order-preserving
+// dictionary (ssgpu_dict_*), and result Views point into the cursor's dictionary.
+class StringPiece {
+ public:
+  StringPiece() : data_(""), length_(0) {}
+  StringPiece(const char* s) : data_(s), length_(s ? strlen(s) : 0) {}            // NOLINT(runtime/explicit)
+  StringPiece(const std::string& s) : data_(s.data()), length_(s.size()) {}       // NOLINT(runtime/explicit)
+  StringPiece(const char* s, size_t n) : data_(s), length_(n) {}
+  const char* data() const { return data_; }
+  size_t size() const { return length_; }
+  size_t length() const { return length_; }
+  bool empty() const { return length_ == 0; }
+  std::string ToString() const { return std::string(data_, length_); }
+  int compare(const StringPiece& o) const {
+    const int r = memcmp(data_, o.data_, std::min(length_, o.length_));
+    return r != 0 ? r : (length_ < o.length_ ? -1 : (length_ > o.length_ ? 1 : 0));
+  }
+ private:
+  const char* data_;
+  size_t length_;
+};
+inline bool operator==(const StringPiece& a, const StringPiece& b) { return a.size() == b.size() && memcmp(a.data(), b.data(), a.size()) == 0; }
+inline bool operator!=(const StringPiece& a, const StringPiece& b) { return !(a == b); }
+inline bool operator<(const StringPiece& a, const StringPiece& b) { return a.compare(b) < 0; }
+
 inline size_t SizeOfDataType(DataType t) {
-  switch (t) { case INT32: case UINT32: case FLOAT: case DATE: return 4; case INT64: case UINT64: case DOUBLE: case DATETIME: return 8; case BOOL: return 1; default: return 0; }
+  switch (t) { case INT32: case UINT32: case FLOAT: case DATE: return 4; case INT64: case UINT64: case DOUBLE: case DATETIME: return 8; case BOOL: return 1;
+               case STRING: return sizeof(StringPiece); default: return 0; }
 }
+
+// ---- memory (base/memory/memory.h:100-233, 240, 465-520) over ssgpu_allocator_* -------------------------------
+class BufferAllocator;
+// Owns one block of a BufferAllocator; destroying it returns the block (memory.h:55-98).
+class Buffer {
+ public:
+  ~Buffer();
+  void* data() const { return data_; }
+  size_t size() const { return size_; }
+ private:
+  friend class BufferAllocator;
+  Buffer(void* data, size_t size, BufferAllocator* a) : data_(data), size_(size), allocator_(a) {}
+  void* data_; size_t size_; BufferAllocator* allocator_;
+};
 
 // ---- View (base/infrastructure/block.h:55-402): N (data, is_null) pairs + row count -----
 class Column {
@@ -134,6 +175,8 @@ class View {
 };
 
 // ---- expressions (expression/base/expression.h, core/*_expressions.h) --------------------
+class BoundExpressionTree;
+class BufferAllocator;
 class Expression {
  public:
   Expression(int kind, int op, int dtype, int64_t i64, double f64, const std::string& name) : kind(kind), op(op), dtype(dtype), i64(i64), f64(f64), name(name) {}
@@ -142,7 +185,10 @@ class Expression {
   int64_t i64;
   double f64;
   std::string name;
+  std::string sval;          // payload of a ConstString
   std::vector<std::unique_ptr<const Expression>> args;
+  // Expression::Bind(input_schema, allocator, max_row_count) (expression.h:158-160); defined below
+  FailureOrOwned<BoundExpressionTree> Bind(const TupleSchema& input_schema, BufferAllocator* allocator, rowcount_t max_row_count) const;
 };
 namespace internal {
 inline Expression* Node(int kind, int op = 0, int dtype = 0, int64_t i64 = 0, double f64 = 0, const std::string& name = "") { return new Expression(kind, op, dtype, i64, f64, name); }
@@ -160,6 +206,7 @@ inline const Expression* ConstUint32(uint32_t v) { return internal::Node(SSGPU_E
 inline const Expression* ConstUint64(uint64_t v) { return internal::Node(SSGPU_EXPR_CONST, 0, UINT64, static_cast<int64_t>(v)); }
 inline const Expression* ConstFloat(float v) { return internal::Node(SSGPU_EXPR_CONST, 0, FLOAT, 0, v); }
 inline const Expression* ConstDouble(double v) { return internal::Node(SSGPU_EXPR_CONST, 0, DOUBLE, 0, v); }
+inline const Expression* ConstString(const StringPiece& v) { Expression* e = internal::Node(SSGPU_EXPR_CONST, 0, STRING); e->sval = v.ToString(); return e; }
 inline const Expression* ConstBool(bool v) { return internal::Node(SSGPU_EXPR_CONST, 0, BOOL, v ? 1 : 0); }
 inline const Expression* Null(DataType t) { return internal::Node(SSGPU_EXPR_NULL, 0, t); }
 inline const Expression* Plus(const Expression* a, const Expression* b) { return internal::Op(0, a, b); }
@@ -338,6 +385,126 @@ struct Context {
 };
 }  // namespace internal
 
+// Pinned-host allocator with an optional soft quota.  Allocate / BestEffortAllocate return NULL when the quota (or the
+// host) cannot serve `minimal` -- callers turn that into ERROR_MEMORY_EXCEEDED, as the reference's do.
+class BufferAllocator {
+ public:
+  virtual ~BufferAllocator() { if (a_) ssgpu_allocator_destroy(a_); }
+  Buffer* Allocate(size_t requested) { return BestEffortAllocate(requested, requested); }
+  Buffer* BestEffortAllocate(size_t requested, size_t minimal) {
+    void* p = nullptr; size_t granted = 0;
+    if (ssgpu_allocator_allocate(a_, requested, minimal, &p, &granted) != SSGPU_OK) return nullptr;
+    return new Buffer(p, granted, this);
+  }
+  // On failure returns false and leaves the buffer as it was (memory.h:140-160).
+  bool Reallocate(size_t requested, Buffer* buffer) { return BestEffortReallocate(requested, requested, buffer); }
+  bool BestEffortReallocate(size_t requested, size_t minimal, Buffer* buffer) {
+    void* p = nullptr; size_t granted = 0;
+    if (ssgpu_allocator_reallocate(a_, buffer->data_, requested, minimal, &p, &granted) != SSGPU_OK) return false;
+    buffer->data_ = p; buffer->size_ = granted;
+    return true;
+  }
+  size_t Available() const { const int64_t v = ssgpu_allocator_available(a_); return v < 0 ? 0 : static_cast<size_t>(v); }
+  size_t GetUsage() const { return static_cast<size_t>(ssgpu_allocator_allocated(a_)); }
+  bool has_quota() const { return quota_ >= 0; }
+ protected:
+  explicit BufferAllocator(int64_t quota) : quota_(quota) { ssgpu_allocator_create(internal::Context::Get().ctx, quota, &a_); }
+ private:
+  friend class Buffer;
+  ssgpu_allocator* a_ = nullptr;
+  int64_t quota_;
+};
+inline Buffer::~Buffer() { ssgpu_allocator_free(allocator_->a_, data_); }
+
+class HeapBufferAllocator : public BufferAllocator {
+ public:
+  static HeapBufferAllocator* Get() { static HeapBufferAllocator a; return &a; }   // memory.h:240-250
+ private:
+  HeapBufferAllocator() : BufferAllocator(-1) {}
+};
+// MemoryLimit(quota): a soft quota; the delegate of the reference's constructor is always the pinned-host heap here.
+class MemoryLimit : public BufferAllocator {
+ public:
+  explicit MemoryLimit(size_t quota) : BufferAllocator(static_cast<int64_t>(quota)) {}
+  MemoryLimit(size_t quota, bool /*enforced*/, BufferAllocator* /*delegate*/) : BufferAllocator(static_cast<int64_t>(quota)) {}
+};
+
+namespace internal {
+// One order-preserving dictionary per cursor / evaluated View (ssgpu_dict_*): STRING cells <-> INT32 codes.
+struct Dictionary {
+  ssgpu_dict* d = nullptr;
+  ~Dictionary() { if (d) ssgpu_dict_destroy(d); }
+  int Build(const std::vector<StringPiece>& values) {
+    if (d) { ssgpu_dict_destroy(d); d = nullptr; }
+    std::vector<const char*> ptr; std::vector<int32_t> len;
+    for (auto& v : values) { ptr.push_back(v.data()); len.push_back(static_cast<int32_t>(v.size())); }
+    return ssgpu_dict_create(ptr.data(), len.data(), static_cast<int64_t>(values.size()), &d);
+  }
+  int Encode(const StringPiece* cells, const bool* is_null, rowcount_t n, std::vector<int32_t>* codes) const {
+    std::vector<const char*> ptr(static_cast<size_t>(n)); std::vector<int32_t> len(static_cast<size_t>(n));
+    for (rowcount_t i = 0; i < n; ++i) { ptr[i] = cells[i].data(); len[i] = static_cast<int32_t>(cells[i].size()); }
+    codes->assign(static_cast<size_t>(std::max<rowcount_t>(n, 1)), 0);
+    return ssgpu_dict_encode(d, ptr.data(), len.data(), reinterpret_cast<const uint8_t*>(is_null), n, codes->data());
+  }
+  StringPiece Decode(int32_t code) const {
+    const char* b = nullptr; int32_t n = 0;
+    return ssgpu_dict_decode(d, code, &b, &n) == SSGPU_OK ? StringPiece(b, static_cast<size_t>(n)) : StringPiece();
+  }
+  static void Collect(const View& v, std::vector<StringPiece>* out) {
+    for (int i = 0; i < v.schema().attribute_count(); ++i) {
+      if (v.schema().attribute(i).type() != STRING) continue;
+      const StringPiece* cells = v.column(i).typed_data<StringPiece>();
+      const bool* z = v.column(i).is_null();
+      for (rowcount_t r = 0; r < v.row_count(); ++r) if (!z || !z[r]) out->push_back(cells[r]);
+    }
+  }
+  static bool HasStrings(const TupleSchema& s) {
+    for (int i = 0; i < s.attribute_count(); ++i) if (s.attribute(i).type() == STRING) return true;
+    return false;
+  }
+};
+// host View -> device block (STRING columns as dictionary codes)
+inline int UploadView(ssgpu_ctx* ctx, const View* v, const Dictionary* dict, ssgpu_block** out) {
+  const TupleSchema& s = v->schema();
+  std::vector<ssgpu_attr> attrs;
+  for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
+  int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), std::max<rowcount_t>(v->row_count(), 1), out);
+  std::vector<int32_t> codes;
+  for (int i = 0; rc == SSGPU_OK && i < s.attribute_count() && v->row_count() > 0; ++i) {
+    const void* data = v->column(i).data();
+    if (s.attribute(i).type() == STRING) {
+      rc = dict && dict->d ? dict->Encode(v->column(i).typed_data<StringPiece>(), v->column(i).is_null(), v->row_count(), &codes) : SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+      data = codes.data();
+      if (rc != SSGPU_OK) break;
+    }
+    rc = ssgpu_block_upload(*out, i, data, reinterpret_cast<const uint8_t*>(v->column(i).is_null()), 0, v->row_count());
+    if (rc == SSGPU_OK && s.attribute(i).type() == STRING) rc = ssgpu_ctx_synchronize(ctx);   // `codes` is reused by the next column
+  }
+  if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(*out, v->row_count());
+  return rc;
+}
+// finished result -> host column pointers (STRING columns decoded into `cells`)
+inline int FetchResult(ssgpu_result* res, const TupleSchema& schema, const Dictionary* dict, rowcount_t* total,
+                       std::vector<const void*>* data, std::vector<const uint8_t*>* nulls, std::vector<std::vector<StringPiece>>* cells) {
+  *total = ssgpu_result_row_count(res);
+  if (*total < 0) return SSGPU_ERROR_HIP;
+  data->clear(); nulls->clear(); cells->assign(static_cast<size_t>(schema.attribute_count()), std::vector<StringPiece>());
+  for (int i = 0; i < schema.attribute_count(); ++i) {
+    const void* d = nullptr; const uint8_t* z = nullptr;
+    const int rc = ssgpu_result_column(res, i, &d, &z);
+    if (rc != SSGPU_OK) return rc;
+    if (schema.attribute(i).type() == STRING) {
+      std::vector<StringPiece>& c = (*cells)[static_cast<size_t>(i)];
+      c.resize(static_cast<size_t>(std::max<rowcount_t>(*total, 1)));
+      for (rowcount_t r = 0; r < *total; ++r) c[r] = (z && z[r]) || !dict ? StringPiece() : dict->Decode(static_cast<const int32_t*>(d)[r]);
+      d = c.data();
+    }
+    data->push_back(d); nulls->push_back(z);
+  }
+  return SSGPU_OK;
+}
+}  // namespace internal
+
 // ---- cursors (cursor/base/cursor.h:42-226) -----------------------------------------------------
 class ResultView {
  public:
@@ -371,16 +538,7 @@ class Cursor {
       ran_ = true;
       int rc = Stage(ctx);
       if (rc == SSGPU_OK) rc = ssgpu_plan_run_block(plan_, block_, &res_);
-      ssgpu_result* res = res_;
-      if (rc == SSGPU_OK) {
-        total_ = ssgpu_result_row_count(res);
-        if (total_ < 0) rc = SSGPU_ERROR_HIP;
-      }
-      for (int i = 0; rc == SSGPU_OK && i < schema_.attribute_count(); ++i) {
-        const void* d = nullptr; const uint8_t* z = nullptr;
-        rc = ssgpu_result_column(res, i, &d, &z);
-        host_data_.push_back(d); host_null_.push_back(z);
-      }
+      if (rc == SSGPU_OK) rc = internal::FetchResult(res_, schema_, &dict_, &total_, &host_data_, &host_null_, &cells_);
       if (rc != SSGPU_OK) { failed_ = true; return ResultView::Failure(new Exception(rc, ssgpu_last_error(ctx))); }
     }
     if (failed_) return ResultView::Failure(new Exception(ERROR_UNKNOWN_ERROR, "cursor already failed"));
@@ -399,32 +557,15 @@ class Cursor {
  private:
   friend class Operation;
   Cursor() {}
-  static int Upload(ssgpu_ctx* ctx, const View* v, ssgpu_block** out) {
-    const TupleSchema& s = v->schema();
-    std::vector<ssgpu_attr> attrs;
-    for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
-    int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), std::max<rowcount_t>(v->row_count(), 1), out);
-    for (int i = 0; rc == SSGPU_OK && i < s.attribute_count() && v->row_count() > 0; ++i)
-      rc = ssgpu_block_upload(*out, i, v->column(i).data(), reinterpret_cast<const uint8_t*>(v->column(i).is_null()), 0, v->row_count());
-    if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(*out, v->row_count());
-    return rc;
-  }
-  int Stage(ssgpu_ctx* ctx) {  // host View -> device block on the copy stream
+  int Stage(ssgpu_ctx* ctx) {  // host Views -> device blocks on the copy stream
     if (aux_) {                // rhs table of a HashJoin: the plan's auxiliary input
-      int rc = Upload(ctx, aux_, &aux_block_);
+      int rc = internal::UploadView(ctx, aux_, &dict_, &aux_block_);
       std::vector<ssgpu_column> cols(aux_->schema().attribute_count());
       for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(aux_block_, static_cast<int32_t>(i), &cols[i]);
       if (rc == SSGPU_OK) rc = ssgpu_plan_set_aux_input(plan_, cols.data(), static_cast<int32_t>(cols.size()), aux_->row_count());
       if (rc != SSGPU_OK) return rc;
     }
-    const TupleSchema& s = input_->schema();
-    std::vector<ssgpu_attr> attrs;
-    for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
-    int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), std::max<rowcount_t>(input_->row_count(), 1), &block_);
-    for (int i = 0; rc == SSGPU_OK && i < s.attribute_count() && input_->row_count() > 0; ++i)
-      rc = ssgpu_block_upload(block_, i, input_->column(i).data(), reinterpret_cast<const uint8_t*>(input_->column(i).is_null()), 0, input_->row_count());
-    if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(block_, input_->row_count());
-    return rc;
+    return internal::UploadView(ctx, input_, &dict_, &block_);
   }
   ssgpu_plan* plan_ = nullptr;
   ssgpu_block* block_ = nullptr;
@@ -432,10 +573,12 @@ class Cursor {
   const View* input_ = nullptr;
   const View* aux_ = nullptr;
   ssgpu_block* aux_block_ = nullptr;
+  internal::Dictionary dict_;   // STRING cells of the scanned Views and the plan's ConstStrings
   TupleSchema schema_;
   std::unique_ptr<View> view_;
   std::vector<const void*> host_data_;
   std::vector<const uint8_t*> host_null_;
+  std::vector<std::vector<StringPiece>> cells_;
   rowcount_t total_ = 0, pos_ = 0;
   bool ran_ = false, failed_ = false;
 };
@@ -448,6 +591,22 @@ class Operation {
   FailureOrOwned<Cursor> CreateCursor() const {
     Builder b;
     Emit(&b);
+    std::unique_ptr<Cursor> c(new Cursor);
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    // STRING: one order-preserving dictionary over the scanned Views' cells and the plan's ConstStrings
+    if (!b.string_consts.empty() || internal::Dictionary::HasStrings(b.scan->schema()) || (b.scan_aux && internal::Dictionary::HasStrings(b.scan_aux->schema()))) {
+      std::vector<StringPiece> values;
+      for (auto& sc : b.string_consts) values.push_back(StringPiece(*sc.second));
+      internal::Dictionary::Collect(*b.scan, &values);
+      if (b.scan_aux) internal::Dictionary::Collect(*b.scan_aux, &values);
+      int rc = c->dict_.Build(values);
+      for (size_t i = 0; rc == SSGPU_OK && i < b.string_consts.size(); ++i) {
+        StringPiece v(*b.string_consts[i].second); std::vector<int32_t> code;
+        rc = c->dict_.Encode(&v, nullptr, 1, &code);
+        b.exprs[static_cast<size_t>(b.string_consts[i].first)].i64 = code[0];
+      }
+      if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, "cannot build the STRING dictionary"));
+    }
     std::vector<ssgpu_attr> attrs;
     const TupleSchema& in = b.scan->schema();
     for (int i = 0; i < in.attribute_count(); ++i) attrs.push_back({in.attribute(i).name().c_str(), in.attribute(i).type(), in.attribute(i).nullability()});
@@ -465,11 +624,11 @@ class Operation {
       for (int i = 0; i < as.attribute_count(); ++i) aux_attrs.push_back({as.attribute(i).name().c_str(), as.attribute(i).type(), as.attribute(i).nullability()});
       d.aux_schema = aux_attrs.data(); d.n_aux_attrs = static_cast<int32_t>(aux_attrs.size());
     }
-    ssgpu_ctx* ctx = internal::Context::Get().ctx;
     ssgpu_plan* plan = nullptr;
     const int rc = ssgpu_plan_create(ctx, &d, &plan);
     if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, ssgpu_last_error(ctx)));
-    std::unique_ptr<Cursor> c(new Cursor);
+    // SetBufferAllocator(MemoryLimit): the plan's device buffers are charged to the allocator's remaining quota
+    if (const BufferAllocator* a = EffectiveAllocator()) if (a->has_quota()) ssgpu_plan_set_memory_limit(plan, static_cast<int64_t>(a->Available()));
     c->plan_ = plan; c->input_ = b.scan; c->aux_ = b.scan_aux;
     for (int i = 0; i < ssgpu_plan_attr_count(plan); ++i) {
       ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
@@ -478,8 +637,11 @@ class Operation {
     c->view_.reset(new View(c->schema_));
     return FailureOrOwned<Cursor>(c.release());
   }
-  // The reference's allocator seam (operation.h:66-76): device buffers are owned by the plan.
-  void SetBufferAllocator(void* /*allocator*/, bool /*cascade*/) {}
+  // The reference's allocator seam (operation.h:66-76).  Device buffers are owned by the plan; an allocator with a
+  // quota (MemoryLimit) bounds them, and a run that needs more fails with ERROR_MEMORY_EXCEEDED.  The allocator is not
+  // owned and must outlive the cursors.  One plan = one quota: the nearest allocator from the root applies.
+  void SetBufferAllocator(BufferAllocator* allocator, bool /*cascade_to_children*/) { allocator_ = allocator; }
+  virtual const BufferAllocator* EffectiveAllocator() const { return allocator_; }
 
   struct Builder {
     std::vector<ssgpu_op> ops; std::vector<ssgpu_expr> exprs; std::vector<int32_t> expr_args;
@@ -487,6 +649,7 @@ class Operation {
     const View* scan = nullptr;
     const View* scan_aux = nullptr;   // rhs table of a HashJoin (the plan's auxiliary input)
     bool aux = false;
+    std::vector<std::pair<int, const std::string*>> string_consts;   // (expr index, payload): codes are patched in later
     void ProjRange(const std::vector<SingleSourceProjector::Entry>& es, int32_t* first, int32_t* n) {
       *first = static_cast<int32_t>(projs.size()); *n = static_cast<int32_t>(es.size());
       for (auto& e : es) projs.push_back({e.kind, e.position, e.name.c_str(), e.alias.c_str(), e.source, 0});
@@ -499,6 +662,7 @@ class Operation {
       x.i64 = e->i64; x.f64 = e->f64; x.name = e->name.c_str();
       expr_args.insert(expr_args.end(), kids.begin(), kids.end());
       exprs.push_back(x);
+      if (e->kind == SSGPU_EXPR_CONST && e->dtype == STRING) string_consts.push_back({static_cast<int>(exprs.size()) - 1, &e->sval});
       return static_cast<int>(exprs.size()) - 1;
     }
     void Proj(const SingleSourceProjector* p, ssgpu_op* o) {
@@ -513,8 +677,133 @@ class Operation {
   };
   virtual int Emit(Builder* b) const = 0;
  protected:
+  BufferAllocator* allocator_ = nullptr;
   static ssgpu_op Blank(int kind, int child) { ssgpu_op o; memset(&o, 0, sizeof(o)); o.kind = kind; o.child = child; o.expr = -1; return o; }
 };
+
+// ---- BoundExpressionTree (expression/base/expression.h:96-145) over ssgpu_expr_bind / ssgpu_expr_evaluate ------------
+// FailureOrReference<const View> (base/exception/result.h): the View stays valid until the next Evaluate.
+class EvaluationResult {
+ public:
+  static EvaluationResult Success(const View* v) { EvaluationResult r; r.view_ = v; return r; }
+  static EvaluationResult Failure(Exception* e) { EvaluationResult r; r.exception_.reset(e); return r; }
+  bool is_failure() const { return exception_ != nullptr; }
+  bool is_success() const { return !is_failure(); }
+  const View& get() const { return *view_; }
+  const Exception& exception() const { return *exception_; }
+ private:
+  EvaluationResult() : view_(nullptr) {}
+  const View* view_;
+  std::shared_ptr<Exception> exception_;
+};
+
+class BoundExpressionTree {
+ public:
+  ~BoundExpressionTree() { Release(); }
+  const TupleSchema& result_schema() const { return schema_; }
+  rowcount_t row_capacity() const { return ssgpu_expr_row_capacity(plan_); }
+  // One result row per input row, in order.  ERROR_TOO_MANY_ROWS beyond row_capacity() (expression.cc:57-66);
+  // evaluation errors (signaling operators) come back as failures.
+  EvaluationResult Evaluate(const View& input) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    int rc = SSGPU_OK;
+    if (internal::Dictionary::HasStrings(input_schema_)) {   // the constants' codes depend on the View: one dictionary per View
+      std::vector<StringPiece> values;
+      internal::Dictionary::Collect(input, &values);
+      rc = Rebind(ctx, values);
+      if (rc != SSGPU_OK) return EvaluationResult::Failure(new Exception(rc, ssgpu_last_error(ctx)));
+    }
+    if (input.row_count() > row_capacity()) {
+      return EvaluationResult::Failure(new Exception(ERROR_TOO_MANY_ROWS, "Trying to evaluate an expression with more rows than its capacity"));
+    }
+    if (block_) { ssgpu_block_destroy(block_); block_ = nullptr; }
+    if (res_) { ssgpu_result_destroy(res_); res_ = nullptr; }
+    rc = internal::UploadView(ctx, &input, &dict_, &block_);
+    std::vector<ssgpu_column> cols(static_cast<size_t>(input_schema_.attribute_count()));
+    for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(block_, static_cast<int32_t>(i), &cols[i]);
+    if (rc == SSGPU_OK) rc = ssgpu_expr_evaluate(plan_, cols.data(), static_cast<int32_t>(cols.size()), input.row_count(), &res_);
+    rowcount_t total = 0;
+    if (rc == SSGPU_OK) rc = internal::FetchResult(res_, schema_, &dict_, &total, &host_data_, &host_null_, &cells_);
+    if (rc != SSGPU_OK) return EvaluationResult::Failure(new Exception(rc, ssgpu_last_error(ctx)));
+    for (int i = 0; i < schema_.attribute_count(); ++i)
+      view_->mutable_column(i)->Reset(host_data_[static_cast<size_t>(i)], reinterpret_cast<const bool*>(host_null_[static_cast<size_t>(i)]));
+    view_->set_row_count(total);
+    return EvaluationResult::Success(view_.get());
+  }
+
+ private:
+  friend class Expression;
+  BoundExpressionTree() {}
+  void Release() {
+    if (res_) ssgpu_result_destroy(res_);
+    if (block_) ssgpu_block_destroy(block_);
+    if (plan_) ssgpu_plan_destroy(plan_);
+    res_ = nullptr; block_ = nullptr; plan_ = nullptr;
+  }
+  // (re)binds the flattened tree against a dictionary of `values` + its own ConstStrings
+  int Rebind(ssgpu_ctx* ctx, std::vector<StringPiece> values) {
+    Release();
+    if (!string_consts_.empty() || !values.empty() || internal::Dictionary::HasStrings(input_schema_)) {
+      for (auto& sc : string_consts_) values.push_back(StringPiece(sc.second));
+      int rc = dict_.Build(values);
+      for (size_t i = 0; rc == SSGPU_OK && i < string_consts_.size(); ++i) {
+        StringPiece v(string_consts_[i].second); std::vector<int32_t> code;
+        rc = dict_.Encode(&v, nullptr, 1, &code);
+        exprs_[static_cast<size_t>(string_consts_[i].first)].i64 = code[0];
+      }
+      if (rc != SSGPU_OK) return rc;
+    }
+    std::vector<ssgpu_attr> attrs;
+    for (int i = 0; i < input_schema_.attribute_count(); ++i)
+      attrs.push_back({input_schema_.attribute(i).name().c_str(), input_schema_.attribute(i).type(), input_schema_.attribute(i).nullability()});
+    int rc = ssgpu_expr_bind(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), exprs_.data(), static_cast<int32_t>(exprs_.size()),
+                             expr_args_.data(), static_cast<int32_t>(expr_args_.size()), root_, max_row_count_, &plan_);
+    if (rc != SSGPU_OK) return rc;
+    if (memory_limit_ >= 0) ssgpu_plan_set_memory_limit(plan_, memory_limit_);
+    schema_ = TupleSchema();
+    for (int i = 0; i < ssgpu_plan_attr_count(plan_); ++i) {
+      ssgpu_attr a; ssgpu_plan_attr(plan_, i, &a);
+      schema_.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
+    }
+    view_.reset(new View(schema_));
+    return SSGPU_OK;
+  }
+  TupleSchema input_schema_, schema_;
+  std::vector<ssgpu_expr> exprs_;                 // the flattened tree; names point into names_
+  std::vector<int32_t> expr_args_;
+  std::vector<std::unique_ptr<std::string>> names_;
+  std::vector<std::pair<int, std::string>> string_consts_;
+  int32_t root_ = 0;
+  rowcount_t max_row_count_ = 0;
+  int64_t memory_limit_ = -1;
+  ssgpu_plan* plan_ = nullptr;
+  ssgpu_block* block_ = nullptr;
+  ssgpu_result* res_ = nullptr;
+  internal::Dictionary dict_;
+  std::unique_ptr<View> view_;
+  std::vector<const void*> host_data_;
+  std::vector<const uint8_t*> host_null_;
+  std::vector<std::vector<StringPiece>> cells_;
+};
+
+inline FailureOrOwned<BoundExpressionTree> Expression::Bind(const TupleSchema& input_schema, BufferAllocator* allocator, rowcount_t max_row_count) const {
+  std::unique_ptr<BoundExpressionTree> t(new BoundExpressionTree);
+  Operation::Builder b;
+  t->root_ = b.Expr(this);
+  t->exprs_ = b.exprs; t->expr_args_ = b.expr_args;
+  for (auto& x : t->exprs_) {            // the bound tree does not depend on this Expression's lifetime
+    t->names_.emplace_back(new std::string(x.name ? x.name : ""));
+    x.name = t->names_.back()->c_str();
+  }
+  for (auto& sc : b.string_consts) t->string_consts_.push_back({sc.first, *sc.second});
+  t->input_schema_ = input_schema;
+  t->max_row_count_ = max_row_count;
+  if (allocator && allocator->has_quota()) t->memory_limit_ = static_cast<int64_t>(allocator->Available());
+  ssgpu_ctx* ctx = internal::Context::Get().ctx;
+  const int rc = t->Rebind(ctx, std::vector<StringPiece>());
+  if (rc != SSGPU_OK) return FailureOrOwned<BoundExpressionTree>(new Exception(rc, ssgpu_last_error(ctx)));
+  return FailureOrOwned<BoundExpressionTree>(t.release());
+}
 
 namespace internal {
 class ScanViewOp : public Operation {
@@ -542,6 +831,7 @@ class UnaryOp : public Operation {
     o.option0 = opt_;
     return b->Op(o);
   }
+  const BufferAllocator* EffectiveAllocator() const override { return allocator_ ? allocator_ : child_->EffectiveAllocator(); }
  private:
   int kind_;
   std::unique_ptr<Operation> child_;
@@ -566,6 +856,7 @@ class HashJoinOp : public Operation {
     b->ProjRange(rp_->entries, &o.proj3_first, &o.proj3_n);
     return b->Op(o);
   }
+  const BufferAllocator* EffectiveAllocator() const override { return allocator_ ? allocator_ : lhs_->EffectiveAllocator(); }
  private:
   JoinType type_; KeyUniqueness uniq_;
   std::unique_ptr<const SingleSourceProjector> lk_, rk_;

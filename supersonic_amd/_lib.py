@@ -104,6 +104,24 @@ SYMBOLS = [
     ("ssgpu_ctx_create", C.c_int, [C.c_int, C.POINTER(P)]),
     ("ssgpu_ctx_destroy", None, [P]),
     ("ssgpu_last_error", C.c_char_p, [P]),
+    ("ssgpu_ctx_has_device", C.c_int, [P]),
+    ("ssgpu_allocator_create", C.c_int, [P, C.c_int64, C.POINTER(P)]),
+    ("ssgpu_allocator_destroy", None, [P]),
+    ("ssgpu_allocator_allocate", C.c_int, [P, C.c_size_t, C.c_size_t, C.POINTER(P), C.POINTER(C.c_size_t)]),
+    ("ssgpu_allocator_reallocate", C.c_int, [P, P, C.c_size_t, C.c_size_t, C.POINTER(P), C.POINTER(C.c_size_t)]),
+    ("ssgpu_allocator_free", None, [P, P]),
+    ("ssgpu_allocator_available", C.c_int64, [P]),
+    ("ssgpu_allocator_allocated", C.c_int64, [P]),
+    ("ssgpu_dict_create", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int64, C.POINTER(P)]),
+    ("ssgpu_dict_destroy", None, [P]),
+    ("ssgpu_dict_size", C.c_int32, [P]),
+    ("ssgpu_dict_encode", C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), P, C.c_int64, C.POINTER(C.c_int32)]),
+    ("ssgpu_dict_decode", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int32)]),
+    ("ssgpu_plan_set_memory_limit", C.c_int, [P, C.c_int64]),
+    ("ssgpu_plan_memory_in_use", C.c_int64, [P]),
+    ("ssgpu_expr_bind", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.POINTER(Expr), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64, C.POINTER(P)]),
+    ("ssgpu_expr_row_capacity", C.c_int64, [P]),
+    ("ssgpu_expr_evaluate", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_ctx_stream", P, [P]),
     ("ssgpu_ctx_copy_stream", P, [P]),
     ("ssgpu_ctx_set_stream", C.c_int, [P, P]),

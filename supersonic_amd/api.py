@@ -50,30 +50,82 @@ def _as_bytes(v):
 class StringDictionary(object):
     """STRING columns cross the C ABI as INT32 codes of ONE order-preserving dictionary per plan
     (include/ssgpu.h, "STRING columns"): sorted unique byte strings of every STRING column of the
-    scanned View and of every ConstString of the plan.  Python's bytes order is the reference's
-    StringPiece order (memcmp, then length), so comparisons, MIN/MAX, group keys and sort order of
-    the codes are those of the strings."""
+    scanned View and of every ConstString of the plan.  The dictionary itself lives behind the ABI
+    (ssgpu_dict_create/encode/decode): code order is the reference's StringPiece order (memcmp, then
+    length), so comparisons, MIN/MAX, group keys and sort order of the codes are those of the strings,
+    and the library owns a deep copy of the bytes (the reference's Arena rule)."""
 
     def __init__(self, strings):
-        self.values = sorted(set(strings))
-        self.code = {v: i for i, v in enumerate(self.values)}
+        self.lib = L.load()
+        vals = [_as_bytes(v) for v in strings]
+        self._arr, self._len = self._pack(vals)
+        h = C.c_void_p()
+        rc = self.lib.ssgpu_dict_create(self._arr, self._len, len(vals), C.byref(h))
+        if rc != L.OK:
+            raise SupersonicException(rc, "cannot build the STRING dictionary")
+        self.handle = h
+        del self._arr, self._len          # the library copied the bytes
+
+    @staticmethod
+    def _pack(vals):
+        arr = (C.c_char_p * max(len(vals), 1))()
+        lens = (C.c_int32 * max(len(vals), 1))()
+        for i, v in enumerate(vals):
+            arr[i] = v                    # c_char_p keeps the bytes object; the explicit length covers embedded NULs
+            lens[i] = len(v)
+        return arr, lens
+
+    def __len__(self):
+        return self.lib.ssgpu_dict_size(self.handle)
+
+    @property
+    def values(self):
+        return [self.value(i) for i in range(len(self))]
+
+    def value(self, code):
+        ptr, n = C.c_void_p(), C.c_int32()
+        if self.lib.ssgpu_dict_decode(self.handle, int(code), C.byref(ptr), C.byref(n)) != L.OK:
+            raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "STRING code %d outside the dictionary" % int(code))
+        return C.string_at(ptr, n.value)
+
+    def code_of(self, v):
+        return int(self.encode([v], None)[0])
 
     def encode(self, data, nulls):
-        out = np.zeros(len(data), np.int32)
-        for i, v in enumerate(data):
-            if nulls is not None and nulls[i]:
-                continue
-            try:
-                out[i] = self.code[_as_bytes(v)]
-            except KeyError:
-                raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "STRING value not in the plan's dictionary: the plan was created over another View")
+        n = len(data)
+        out = np.zeros(n, np.int32)
+        if n == 0:
+            return out
+        vals = [b"" if (nulls is not None and nulls[i]) else _as_bytes(v) for i, v in enumerate(data)]
+        arr, lens = self._pack(vals)
+        nn = None if nulls is None else np.ascontiguousarray(nulls, dtype=np.uint8)
+        rc = self.lib.ssgpu_dict_encode(self.handle, arr, lens, None if nn is None else nn.ctypes.data_as(C.c_void_p), n,
+                                        out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != L.OK:
+            raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "STRING value not in the plan's dictionary: the plan was created over another View")
         return out
 
     def decode(self, codes, nulls):
         out = np.empty(len(codes), dtype=object)
+        cache = {}
         for i, c in enumerate(codes):
-            out[i] = b"" if (nulls is not None and nulls[i]) else self.values[int(c)]
+            if nulls is not None and nulls[i]:
+                out[i] = b""
+                continue
+            c = int(c)
+            v = cache.get(c)
+            if v is None:
+                v = cache[c] = self.value(c)
+            out[i] = v
         return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ssgpu_dict_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class SupersonicException(Exception):
@@ -358,6 +410,11 @@ class Expression(object):
     def __init__(self, kind, op=0, dtype=0, args=(), i64=0, f64=0.0, name=None):
         self.kind, self.op, self.dtype, self.args, self.i64, self.f64, self.name = kind, op, dtype, list(args), i64, f64, name
 
+    def Bind(self, input_schema, allocator=None, max_row_count=0, context=None):
+        """Expression::Bind(input_schema, allocator, max_row_count) -> BoundExpressionTree
+        (expression/base/expression.h:158-160); bind errors raise SupersonicException (400-499)."""
+        return BoundExpressionTree(self, input_schema, allocator, max_row_count, context or Context.default())
+
 
 def NamedAttribute(name):
     return Expression(L.EXPR_ATTR_NAMED, name=name)
@@ -629,7 +686,7 @@ class _Builder(object):
         self.expr_args.extend(child)
         i64 = int(e.i64)
         if e.kind == L.EXPR_CONST and e.dtype == STRING:
-            i64 = self.strings.code[e.sval]          # dictionary code of the constant
+            i64 = self.strings.code_of(e.sval)       # dictionary code of the constant
         x = L.Expr(e.kind, e.op, e.dtype, first, len(child), 0, i64, float(e.f64), self.s(e.name))
         self.exprs.append(x)
         return len(self.exprs) - 1
@@ -666,8 +723,17 @@ class _Builder(object):
 
 
 class Operation(object):
+    buffer_allocator = None
+
     def _emit(self, b):
         raise NotImplementedError
+
+    def SetBufferAllocator(self, allocator, cascade_to_children=True):
+        """Operation::SetBufferAllocator (cursor/base/operation.h:66-76): the cursor created from this operation
+        allocates its device buffers against the allocator's quota (a MemoryLimit); running past it fails with
+        ERROR_MEMORY_EXCEEDED.  One plan = one device quota, so `cascade_to_children` has no separate meaning here."""
+        self.buffer_allocator = allocator
+        return self
 
     def CreateCursor(self, context=None):
         """Operation::CreateCursor (cursor/base/operation.h:62): binds the whole tree."""
@@ -825,6 +891,78 @@ def collect_strings(operation):
     return found
 
 
+def _find_allocator(operation):
+    """The allocator set on the nearest operation from the root (SetBufferAllocator cascades downwards)."""
+    o = operation
+    while o is not None:
+        if getattr(o, "buffer_allocator", None) is not None:
+            return o.buffer_allocator
+        o = getattr(o, "child", None)
+    return None
+
+
+class BufferAllocator(object):
+    """BufferAllocator over the C ABI's pinned-host allocator (base/memory/memory.h:100-233): Allocate /
+    BestEffortAllocate / Reallocate / Free / Available, with an optional soft quota (MemoryLimit, memory.h:465).
+    Buffers are pinned host memory when the context has a device (what the host<->device copies of a View want),
+    plain 256-byte aligned host memory on a bind-only context."""
+
+    def __init__(self, quota=None, context=None):
+        self.ctx = context or Context.default()
+        self.lib = self.ctx.lib
+        h = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_allocator_create(self.ctx.handle, -1 if quota is None else int(quota), C.byref(h)))
+        self.handle = h
+
+    def BestEffortAllocate(self, requested, minimal):
+        """-> (address, granted bytes) or None when `minimal` does not fit the quota (a NULL Buffer)."""
+        p, g = C.c_void_p(), C.c_size_t()
+        rc = self.lib.ssgpu_allocator_allocate(self.handle, int(requested), int(minimal), C.byref(p), C.byref(g))
+        if rc == L.ERROR_MEMORY_EXCEEDED:
+            return None
+        self.ctx.check(rc)
+        return (p.value, g.value)
+
+    def Allocate(self, requested):
+        return self.BestEffortAllocate(requested, requested)
+
+    def Reallocate(self, address, requested, minimal=None):
+        p, g = C.c_void_p(), C.c_size_t()
+        rc = self.lib.ssgpu_allocator_reallocate(self.handle, C.c_void_p(address), int(requested),
+                                                 int(requested if minimal is None else minimal), C.byref(p), C.byref(g))
+        if rc == L.ERROR_MEMORY_EXCEEDED:
+            return None
+        self.ctx.check(rc)
+        return (p.value, g.value)
+
+    def Free(self, address):
+        self.lib.ssgpu_allocator_free(self.handle, C.c_void_p(address))
+
+    def Available(self):
+        return self.lib.ssgpu_allocator_available(self.handle)
+
+    def GetUsage(self):
+        return self.lib.ssgpu_allocator_allocated(self.handle)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ssgpu_allocator_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def HeapBufferAllocator(context=None):
+    """HeapBufferAllocator::Get() (memory.h:240): no quota."""
+    return BufferAllocator(None, context)
+
+
+def MemoryLimit(quota, context=None):
+    """MemoryLimit(quota) (memory.h:465-520): a soft quota in bytes."""
+    return BufferAllocator(quota, context)
+
+
 class Plan(object):
     """A bound plan (ssgpu_plan): owns the device programs and result buffers."""
 
@@ -862,6 +1000,12 @@ class Plan(object):
         h = C.c_void_p()
         rc = self.lib.ssgpu_plan_create(context.handle, C.byref(d), C.byref(h))
         context.check(rc)
+        self._adopt(h)
+        alloc = _find_allocator(operation)
+        if alloc is not None:
+            self.set_buffer_allocator(alloc)
+
+    def _adopt(self, h):
         self.handle = h
         n = self.lib.ssgpu_plan_attr_count(h)
         out = []
@@ -877,6 +1021,17 @@ class Plan(object):
 
     def describe(self):
         return self.lib.ssgpu_plan_describe(self.handle).decode()
+
+    def set_memory_limit(self, nbytes):
+        """Soft quota on the device memory this plan holds (ssgpu_plan_set_memory_limit); None or < 0 = unlimited."""
+        self.ctx.check(self.lib.ssgpu_plan_set_memory_limit(self.handle, -1 if nbytes is None else int(nbytes)))
+
+    def set_buffer_allocator(self, allocator):
+        q = allocator.Available() if allocator is not None else None
+        self.set_memory_limit(None if (q is None or q >= (1 << 62)) else q)
+
+    def memory_in_use(self):
+        return self.lib.ssgpu_plan_memory_in_use(self.handle)
 
     def program(self, stage=0):
         """Raw VM instructions of a stage (debug hook used by tests/vm_emulator.py)."""
@@ -1035,17 +1190,86 @@ class Plan(object):
     def interrupt(self):
         self.lib.ssgpu_interrupt(self.handle)
 
+    def _release(self):
+        if getattr(self, "_aux_block", None):
+            self.lib.ssgpu_block_destroy(self._aux_block)
+        if getattr(self, "_block", None):
+            self.lib.ssgpu_block_destroy(self._block)
+        self._block = self._block_key = self._aux_block = self._aux_block_key = None
+        if getattr(self, "handle", None):
+            self.lib.ssgpu_plan_destroy(self.handle)
+            self.handle = None
+
     def __del__(self):
         try:
-            if getattr(self, "_aux_block", None):
-                self.lib.ssgpu_block_destroy(self._aux_block)
-            if getattr(self, "_block", None):
-                self.lib.ssgpu_block_destroy(self._block)
-            if getattr(self, "handle", None):
-                self.lib.ssgpu_plan_destroy(self.handle)
-                self.handle = None
+            self._release()
         except Exception:
             pass
+
+
+def _expr_strings(e, found):
+    if getattr(e, "sval", None) is not None:
+        found.append(e.sval)
+    for a in getattr(e, "args", ()):
+        _expr_strings(a, found)
+    return found
+
+
+class BoundExpressionTree(Plan):
+    """BoundExpressionTree (expression/base/expression.h:96-145) over ssgpu_expr_bind / ssgpu_expr_evaluate:
+    result_schema(), row_capacity(), Evaluate(view) -> ResultView."""
+
+    def __init__(self, expression, input_schema, allocator, max_row_count, context):
+        self.ctx, self.lib = context, context.lib
+        self.expression, self.input_schema = expression, input_schema
+        self.max_row_count = int(max_row_count or 0)
+        self.allocator = allocator
+        self.handle = None
+        self._block = self._block_key = self._aux_block = self._aux_block_key = None
+        self.aux_input = None
+        self._has_strings = any(input_schema.attribute(i).type() == STRING for i in range(input_schema.attribute_count()))
+        self._bind(_expr_strings(expression, []))
+
+    def _bind(self, strings):
+        """(Re)binds against a dictionary holding `strings`; a tree over STRING attributes is re-bound per View,
+        because the codes of its constants depend on the View's values (one dictionary per evaluated View)."""
+        if self.handle:
+            self._release()
+        b = _Builder()
+        b.strings = self.strings = StringDictionary(strings)
+        root = b.expr(self.expression)
+        schema = self.input_schema
+        attrs = _array(L.Attr, [L.Attr(b.s(schema.attribute(i).name()), schema.attribute(i).type(), schema.attribute(i).nullability())
+                                for i in range(schema.attribute_count())])
+        self._keep = (b, attrs, _array(L.Expr, b.exprs), _array(C.c_int32, b.expr_args))
+        h = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_expr_bind(self.ctx.handle, attrs, schema.attribute_count(), self._keep[2], len(b.exprs),
+                                                self._keep[3], len(b.expr_args), root, self.max_row_count, C.byref(h)))
+        self._adopt(h)
+        if self.allocator is not None:
+            self.set_buffer_allocator(self.allocator)
+
+    def row_capacity(self):
+        return self.lib.ssgpu_expr_row_capacity(self.handle)
+
+    def Evaluate(self, view):
+        """BoundExpressionTree::Evaluate(const View&) -> EvaluationResult (expression.cc:57-76): a ResultView holding
+        the result View or the failure (ERROR_TOO_MANY_ROWS beyond row_capacity(), evaluation errors 300-399)."""
+        try:
+            if self._has_strings and isinstance(view, View):
+                found = _expr_strings(self.expression, [])
+                for i in range(self.input_schema.attribute_count()):
+                    if self.input_schema.attribute(i).type() == STRING:
+                        col = view.column(i)
+                        found.extend(v for j, v in enumerate(col.data) if col.is_null is None or not col.is_null[j])
+                self._bind(found)
+            cols, n, rows = self._columns_for(view)
+            res = C.c_void_p()
+            self.ctx.check(self.lib.ssgpu_expr_evaluate(self.handle, cols, n, rows, C.byref(res)))
+            self._result = res
+            return ResultView(view=self.fetch(res))
+        except SupersonicException as e:
+            return ResultView(exception=e)
 
 
 class ResultView(object):

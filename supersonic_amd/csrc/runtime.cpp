@@ -24,7 +24,7 @@ using namespace ssgpu;
   do {                                                                               \
     hipError_t _e = (expr);                                                          \
     if (_e != hipSuccess) {                                                          \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                \
+      (ctx)->err = _e == hipErrorOutOfMemory ? std::string("Memory exceeded: ") + #expr : std::string(#expr) + ": " + hipGetErrorString(_e); \
       return _e == hipErrorOutOfMemory ? SSGPU_ERROR_MEMORY_EXCEEDED : SSGPU_ERROR_HIP; \
     }                                                                                \
   } while (0)
@@ -56,16 +56,27 @@ struct ssgpu_ctx {
   int64_t debug_timing = 0;
 };
 
+// Device memory a plan holds, against its soft quota (ssgpu_plan_set_memory_limit = MemoryLimit, memory.h:465): every
+// DevBuf (re)allocated while a plan runs is charged to that plan; a request beyond the quota fails like an allocation the
+// device cannot serve, which HIP_TRY turns into SSGPU_ERROR_MEMORY_EXCEEDED.
+struct MemQuota { int64_t limit = -1; int64_t used = 0; };
+static thread_local MemQuota* g_quota = nullptr;
+struct QuotaScope { MemQuota* saved; explicit QuotaScope(MemQuota* q) : saved(g_quota) { g_quota = q; } ~QuotaScope() { g_quota = saved; } };
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  MemQuota* q = nullptr;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); if (q) q->used -= (int64_t)cap; } p = nullptr; cap = 0; q = nullptr; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     size_t want = std::max<size_t>(bytes, 256);
+    MemQuota* Q = g_quota;
+    if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)cap : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
+    release();
     hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want; else p = nullptr;
+    if (e == hipSuccess) { cap = want; q = Q; if (q) q->used += (int64_t)want; } else p = nullptr;
     return e;
   }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -141,6 +152,8 @@ struct ssgpu_result {
 
 struct ssgpu_plan {
   ssgpu_ctx* ctx = nullptr;
+  MemQuota quota;               // declared before `exec`: outlives the buffers charged to it
+  int64_t expr_row_capacity = INT64_MAX;   // BoundExpressionTree::row_capacity() of a bound expression
   PlanDesc desc;
   std::vector<Stage> stages;
   std::vector<StageExec> exec;
@@ -209,6 +222,7 @@ static void ctx_release(ssgpu_ctx* c) {
 }
 void ssgpu_ctx_destroy(ssgpu_ctx* c) { if (c) ctx_release(c); }
 
+int ssgpu_ctx_has_device(const ssgpu_ctx* c) { return c && c->device >= 0 ? 1 : 0; }
 const char* ssgpu_last_error(const ssgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
 void* ssgpu_ctx_stream(ssgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 void* ssgpu_ctx_copy_stream(ssgpu_ctx* c) { return c ? (void*)c->copy_stream : nullptr; }
@@ -1523,6 +1537,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   if (n_cols != (int)p->desc.input_schema.size()) { c->err = "column count does not match the plan's input schema"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
   if (rows < 0) { c->err = "negative row count"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
+  QuotaScope quota_scope(&p->quota);
   HIP_TRY(c, hipSetDevice(c->device));
   // blocks are staged on the copy stream: kernels must wait for those copies
   memset(&p->counters, 0, sizeof(p->counters));
@@ -1599,6 +1614,39 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
   if (rc != SSGPU_OK) return rc;
   if (out) *out = &p->result;
   return SSGPU_OK;
+}
+
+int ssgpu_plan_set_memory_limit(ssgpu_plan* p, int64_t bytes) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  p->quota.limit = bytes < 0 ? -1 : bytes;
+  return SSGPU_OK;
+}
+int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* p) { return p ? p->quota.used : 0; }
+
+// Expression::Bind + BoundExpressionTree::Evaluate (expression/base/expression.h:46-167): the bound tree is a plan that
+// computes the expression over a scan of the schema it was bound against
+int ssgpu_expr_bind(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n_attrs, const ssgpu_expr* exprs, int32_t n_exprs,
+                    const int32_t* expr_args, int32_t n_expr_args, int32_t root, int64_t max_row_count, ssgpu_plan** out) {
+  if (!c || !schema || !exprs || !out || root < 0 || root >= n_exprs) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_op ops[2]; memset(ops, 0, sizeof(ops));
+  ops[0].kind = SSGPU_OP_SCAN; ops[0].child = -1; ops[0].expr = -1;
+  ops[1].kind = SSGPU_OP_COMPUTE; ops[1].child = 0; ops[1].expr = root;
+  ssgpu_plan_desc d; memset(&d, 0, sizeof(d));
+  d.input_schema = schema; d.n_attrs = n_attrs; d.ops = ops; d.n_ops = 2;
+  d.exprs = exprs; d.n_exprs = n_exprs; d.expr_args = expr_args; d.n_expr_args = n_expr_args;
+  int rc = ssgpu_plan_create(c, &d, out);
+  if (rc == SSGPU_OK) (*out)->expr_row_capacity = max_row_count > 0 ? max_row_count : INT64_MAX;
+  return rc;
+}
+int64_t ssgpu_expr_row_capacity(const ssgpu_plan* bound) { return bound ? bound->expr_row_capacity : 0; }
+int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_cols, int64_t rows, ssgpu_result** out) {
+  if (!bound) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  if (rows > bound->expr_row_capacity) {
+    bound->ctx->err = "Trying to evaluate an expression with number of rows: " + std::to_string(rows) +
+                      ", while the expression has capacity for less rows: " + std::to_string(bound->expr_row_capacity);
+    return SSGPU_ERROR_TOO_MANY_ROWS;
+  }
+  return ssgpu_plan_run(bound, cols, n_cols, rows, out);
 }
 
 int ssgpu_plan_run_block(ssgpu_plan* p, const ssgpu_block* b, ssgpu_result** out) {

@@ -231,11 +231,169 @@ static void TestRun(const Input& in) {
   }
 }
 
+
+// The seams around the hot path: BufferAllocator / MemoryLimit (base/memory/memory.h, memory_test.cc's quota cases),
+// Expression::Bind (expression.h:158-160) and the STRING dictionary at bind time.  No GPU needed.
+static void TestSeamsBind(const Input& in) {
+  {
+    MemoryLimit limit(1000);
+    std::unique_ptr<Buffer> a(limit.Allocate(600));
+    CHECK(a != nullptr);
+    if (a) { CHECK_EQ(a->size(), static_cast<size_t>(600)); memset(a->data(), 7, 600); }
+    CHECK_EQ(limit.Available(), static_cast<size_t>(400));
+    std::unique_ptr<Buffer> over(limit.Allocate(500));
+    CHECK(over == nullptr);                                   // NULL Buffer: what callers turn into ERROR_MEMORY_EXCEEDED
+    std::unique_ptr<Buffer> best(limit.BestEffortAllocate(500, 100));
+    CHECK(best != nullptr);
+    if (best) CHECK_EQ(best->size(), static_cast<size_t>(400));
+    CHECK(!limit.Reallocate(700, a.get()));                   // does not fit; the buffer is left as it was
+    CHECK_EQ(a->size(), static_cast<size_t>(600));
+    CHECK_EQ(static_cast<const char*>(a->data())[599], 7);
+    best.reset();
+    CHECK(limit.Reallocate(900, a.get()));
+    CHECK_EQ(a->size(), static_cast<size_t>(900));
+    CHECK_EQ(static_cast<const char*>(a->data())[599], 7);
+    a.reset();
+    CHECK_EQ(limit.GetUsage(), static_cast<size_t>(0));
+    std::unique_ptr<Buffer> zero(limit.Allocate(0));
+    CHECK(zero != nullptr && zero->data() != nullptr);         // memory.h:112-117
+    std::unique_ptr<Buffer> heap(HeapBufferAllocator::Get()->Allocate(1 << 20));
+    CHECK(heap != nullptr);
+  }
+  {
+    std::unique_ptr<const Expression> e(Plus(NamedAttribute("a"), NamedAttribute("d")));
+    FailureOrOwned<BoundExpressionTree> t = e->Bind(in.schema, HeapBufferAllocator::Get(), 100);
+    CHECK(t.is_success());
+    e.reset();                                                  // the bound tree does not need the Expression any more
+    if (t.is_success()) {
+      CHECK_EQ(t->result_schema().attribute_count(), 1);
+      CHECK_EQ(t->result_schema().attribute(0).type(), DOUBLE);
+      CHECK(t->result_schema().attribute(0).is_nullable());
+      CHECK_EQ(t->row_capacity(), static_cast<rowcount_t>(100));
+    }
+    std::unique_ptr<const Expression> bad(Plus(NamedAttribute("a"), NamedAttribute("zzz")));
+    FailureOrOwned<BoundExpressionTree> f = bad->Bind(in.schema, HeapBufferAllocator::Get(), 100);
+    CHECK(f.is_failure());
+    if (f.is_failure()) CHECK_EQ(f.exception().return_code(), ERROR_ATTRIBUTE_MISSING);
+  }
+  {  // STRING: constants and columns bind through the dictionary
+    TupleSchema s; s.add_attribute(Attribute("name", STRING, NULLABLE)); s.add_attribute(Attribute("v", INT32, NOT_NULLABLE));
+    StringPiece cells[3] = {"pear", "apple", "fig"}; int32_t v[3] = {1, 2, 3};
+    View view(s); view.mutable_column(0)->Reset(cells, nullptr); view.mutable_column(1)->Reset(v, nullptr); view.set_row_count(3);
+    std::unique_ptr<Operation> op(Filter(Less(NamedAttribute("name"), ConstString("grape")), ProjectAllAttributes(), ScanView(view)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) CHECK_EQ(c->schema().attribute(0).type(), STRING);
+    std::unique_ptr<Operation> mism(Filter(Less(NamedAttribute("name"), ConstInt32(1)), ProjectAllAttributes(), ScanView(view)));
+    CHECK(mism->CreateCursor().is_failure());
+    CHECK(StringPiece("ab") < StringPiece("abc"));
+    CHECK(StringPiece("b") != StringPiece("a"));
+  }
+}
+
+static void TestSeamsRun(const Input& in) {
+  {  // Bind once, Evaluate View after View (what ComputeCursor::Next does with its bound tree)
+    std::unique_ptr<const Expression> e((new CompoundExpression)->AddAs("s", Plus(NamedAttribute("a"), Multiply(NamedAttribute("b"), ConstInt64(3))))
+                                            ->AddAs("h", DivideNulling(NamedAttribute("d"), CastTo(DOUBLE, NamedAttribute("k")))));
+    FailureOrOwned<BoundExpressionTree> t = e->Bind(in.schema, HeapBufferAllocator::Get(), 2048);
+    CHECK(t.is_success());
+    if (t.is_failure()) return;
+    for (rowcount_t first = 0; first < Input::N; first += 2048) {
+      const rowcount_t n = std::min<rowcount_t>(2048, Input::N - first);
+      View slice(in.schema);
+      slice.mutable_column(0)->Reset(in.a.data() + first, nullptr);
+      slice.mutable_column(1)->Reset(in.b.data() + first, nullptr);
+      slice.mutable_column(2)->Reset(in.k.data() + first, nullptr);
+      slice.mutable_column(3)->Reset(in.d.data() + first, reinterpret_cast<const bool*>(in.d_null.data()) + first);
+      slice.set_row_count(n);
+      EvaluationResult r = t->Evaluate(slice);
+      if (r.is_failure()) { printf("evaluate failed: %s\n", r.exception().message().c_str()); ++g_fail; return; }
+      CHECK_EQ(r.get().row_count(), n);
+      bool ok = true;
+      for (rowcount_t i = 0; i < n && ok; ++i) {
+        const rowcount_t g = first + i;
+        ok = r.get().column(0).typed_data<int64_t>()[i] == in.a[g] + in.b[g] * 3;
+        const bool want_null = in.d_null[g] || in.k[g] == 0;
+        ok = ok && r.get().column(1).is_null()[i] == want_null;
+        if (!want_null) ok = ok && r.get().column(1).typed_data<double>()[i] == in.d[g] / in.k[g];
+      }
+      CHECK(ok);
+    }
+    EvaluationResult many = t->Evaluate(*in.view);             // 5000 rows > capacity 2048
+    CHECK(many.is_failure());
+    if (many.is_failure()) CHECK_EQ(many.exception().return_code(), ERROR_TOO_MANY_ROWS);
+  }
+  {  // STRING end to end: filter on a constant, group by a STRING key, MIN/MAX of strings
+    TupleSchema s; s.add_attribute(Attribute("name", STRING, NULLABLE)); s.add_attribute(Attribute("v", INT64, NOT_NULLABLE));
+    const char* words[6] = {"pear", "apple", "fig", "apple", "pear", "kiwi"};
+    std::vector<StringPiece> cells; std::vector<int64_t> v; std::vector<char> z;
+    for (int i = 0; i < 600; ++i) { cells.push_back(words[i % 6]); v.push_back(i); z.push_back(i % 50 == 49); }
+    View view(s); view.mutable_column(0)->Reset(cells.data(), reinterpret_cast<const bool*>(z.data())); view.mutable_column(1)->Reset(v.data(), nullptr); view.set_row_count(600);
+    std::unique_ptr<Operation> op(Sort((new SortOrder)->add(ProjectNamedAttribute("name"), ASCENDING), nullptr, 0,
+        GroupAggregate(ProjectNamedAttribute("name"), (new AggregationSpecification)->AddAggregation(SUM, "v", "sv")->AddAggregation(COUNT, "", "n"), nullptr,
+            Filter(NotEqual(NamedAttribute("name"), ConstString("fig")), ProjectAllAttributes(), ScanView(view)))));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) {
+      ResultView r = c->Next(Cursor::kDefaultRowCount);
+      if (r.is_failure()) { printf("string run failed: %s\n", r.exception().message().c_str()); ++g_fail; return; }
+      // NULL names fail the predicate (NULL != 'fig' is NULL); groups in StringPiece order
+      const char* want[3] = {"apple", "kiwi", "pear"};
+      CHECK_EQ(r.view().row_count(), static_cast<rowcount_t>(3));
+      for (int gi = 0; gi < 3 && r.view().row_count() == 3; ++gi) {
+        int64_t sum = 0; uint64_t cnt = 0;
+        for (int i = 0; i < 600; ++i) if (!z[i] && !strcmp(words[i % 6], want[gi])) { sum += v[i]; ++cnt; }
+        CHECK(r.view().column(0).typed_data<StringPiece>()[gi] == StringPiece(want[gi]));
+        CHECK_EQ(r.view().column(1).typed_data<int64_t>()[gi], sum);
+        CHECK_EQ(r.view().column(2).typed_data<uint64_t>()[gi], cnt);
+      }
+    }
+    std::unique_ptr<Operation> mm(ScalarAggregate((new AggregationSpecification)->AddAggregation(MIN, "name", "lo")->AddAggregation(MAX, "name", "hi"), ScanView(view)));
+    FailureOrOwned<Cursor> c2 = mm->CreateCursor();
+    CHECK(c2.is_success());
+    if (c2.is_success()) {
+      ResultView r = c2->Next(Cursor::kDefaultRowCount);
+      CHECK(r.has_data());
+      if (r.has_data()) {
+        CHECK(r.view().column(0).typed_data<StringPiece>()[0] == StringPiece("apple"));
+        CHECK(r.view().column(1).typed_data<StringPiece>()[0] == StringPiece("pear"));
+      }
+    }
+    // and through a bound expression: the dictionary is rebuilt per evaluated View
+    std::unique_ptr<const Expression> e(If(Less(NamedAttribute("name"), ConstString("g")), NamedAttribute("name"), ConstString("other")));
+    FailureOrOwned<BoundExpressionTree> t = e->Bind(s, HeapBufferAllocator::Get(), 1024);
+    CHECK(t.is_success());
+    if (t.is_success()) {
+      EvaluationResult r = t->Evaluate(view);
+      CHECK(r.is_success());
+      bool ok = r.is_success() && r.get().row_count() == 600;
+      for (int i = 0; ok && i < 600; ++i) {
+        if (z[i]) ok = r.get().column(0).typed_data<StringPiece>()[i] == StringPiece("other") || r.get().column(0).is_null() != nullptr;
+        else ok = r.get().column(0).typed_data<StringPiece>()[i] == (strcmp(words[i % 6], "g") < 0 ? StringPiece(words[i % 6]) : StringPiece("other"));
+      }
+      CHECK(ok);
+    }
+  }
+  {  // SetBufferAllocator(MemoryLimit): running past the quota is ERROR_MEMORY_EXCEEDED from Next() (aggregate_groups.cc:372-402)
+    MemoryLimit tiny(4096), roomy(static_cast<size_t>(1) << 30);
+    for (int pass = 0; pass < 2; ++pass) {
+      std::unique_ptr<Operation> op(GroupAggregate(ProjectNamedAttribute("k"), (new AggregationSpecification)->AddAggregation(SUM, "a", "sa"), nullptr, ScanView(*in.view)));
+      op->SetBufferAllocator(pass == 0 ? static_cast<BufferAllocator*>(&tiny) : &roomy, true);
+      FailureOrOwned<Cursor> c = op->CreateCursor();
+      CHECK(c.is_success());
+      ResultView r = c->Next(Cursor::kDefaultRowCount);
+      if (pass == 0) { CHECK(r.is_failure()); if (r.is_failure()) CHECK_EQ(r.exception().return_code(), ERROR_MEMORY_EXCEEDED); }
+      else { CHECK(r.has_data()); if (r.has_data()) CHECK_EQ(r.view().row_count(), static_cast<rowcount_t>(7)); }
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const bool run = argc > 1 && !strcmp(argv[1], "run");
   Input in;
   TestBind(in);
-  if (run) TestRun(in);
+  TestSeamsBind(in);
+  if (run) { TestRun(in); TestSeamsRun(in); }
   printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }
