@@ -108,10 +108,11 @@ static int schema_add(orc_schema* s, const char* name, int type, int nullable) {
 }
 
 /* =========================== expressions ====================================== */
+#define ORC_MAX_ARGS 128
 enum { E_NAMED = 1, E_AT = 2, E_CONST = 3, E_NULL = 4, E_OP = 5, E_ALIAS = 6, E_COMPOUND = 7, E_CAST = 8 };
 typedef struct orc_expr {
   int kind, op, dtype, nargs;
-  struct orc_expr* args[16];
+  struct orc_expr* args[ORC_MAX_ARGS];
   int64_t i64; double f64;
   char name[256];
 } orc_expr;
@@ -122,14 +123,18 @@ orc_expr* orc_expr_new(int kind, int op, int dtype, int64_t i64, double f64, con
   if (name) snprintf(e->name, sizeof(e->name), "%s", name);
   return e;
 }
-void orc_expr_add_arg(orc_expr* e, orc_expr* a) { if (e->nargs < 16) e->args[e->nargs++] = a; }
+/* more arguments than the checker holds must not pass for a shorter expression: abort (test infrastructure) */
+void orc_expr_add_arg(orc_expr* e, orc_expr* a) {
+  if (e->nargs >= ORC_MAX_ARGS) { fprintf(stderr, "ss_oracle: more than %d arguments\n", ORC_MAX_ARGS); abort(); }
+  e->args[e->nargs++] = a;
+}
 
 /* bound node: typed, owns a 1024-row result block
  * (BasicBoundExpression, expression/infrastructure/basic_bound_expression.h:49) */
 enum { B_INPUT, B_CONST, B_NULLCONST, B_OP, B_CAST };
 typedef struct bnode {
   int kind, op, dtype, nullable, input_col, nargs;
-  struct bnode* args[16];
+  struct bnode* args[ORC_MAX_ARGS];
   uint64_t bits;
   char name[256];
   void* buf;          /* result data, ORC_BLOCK rows */
@@ -400,7 +405,7 @@ static bnode* bind_compare(int op, bnode* l, bnode* r, orc_error* err) {
 
 /* CASE arg0 WHEN arg2 THEN arg3 ... ELSE arg1: BoundCase, elementary_bound_expressions.cc:1297-1356 */
 static bnode* bind_case(const orc_expr* e, const orc_schema* s, orc_error* err) {
-  bnode* a[16];
+  bnode* a[ORC_MAX_ARGS];
   const int n = e->nargs;
   if (n < 2) { set_err(err, RC_INVALID_ARGUMENT_VALUE, "Case expects at least 2 arguments (make sense from 4 arguments).%s%s", "", ""); return NULL; }
   if (n % 2 != 0) { set_err(err, RC_INVALID_ARGUMENT_VALUE, "Case expects odd number of arguments.%s%s", "", ""); return NULL; }
@@ -431,7 +436,7 @@ static bnode* bind_case(const orc_expr* e, const orc_schema* s, orc_error* err) 
 
 /* expr IN (value, ...): BoundInSet, comparison_bound_expressions.cc:759-813 (+ :642-700, :150-156) */
 static bnode* bind_in(const orc_expr* e, const orc_schema* s, orc_error* err) {
-  bnode* a[16];
+  bnode* a[ORC_MAX_ARGS];
   const int n = e->nargs;
   if (n < 1) { set_err(err, RC_INVALID_ARGUMENT_VALUE, "IN needs a needle%s%s", "", ""); return NULL; }
   for (int i = 0; i < n; ++i) { a[i] = bind_single(e->args[i], s, err); if (err->code) return NULL; }

@@ -128,7 +128,8 @@ struct Stage {
   Schema in_schema;     // schema of the stage input (plan input or previous stage's result)
   Schema out_schema;
   Program main;         // the pipeline program
-  Program count_pass;   // STAGE_MATERIALIZE with a filter: predicate + SEL_COUNT
+  Program count_pass;   // STAGE_MATERIALIZE with a filter, two-pass form: predicate + SEL_COUNT
+  bool single_pass = false;   // STAGE_MATERIALIZE with a filter: SEL_RANK_LB + STOREG (no count pass)
   bool has_filter = false;
   std::vector<AggOut> aggs;               // SCALAR_AGG / GROUP_AGG (out_schema order, after keys)
   std::vector<GroupKeyField> group_keys;  // GROUP_AGG
@@ -168,6 +169,7 @@ struct PlanDesc {
   std::vector<ssgpu_agg> aggs;
   std::vector<ssgpu_sortkey> sortkeys;
   std::vector<std::string> strings;  // storage for all names (stable addresses)
+  bool filter_single_pass = false;   // ctx option of the same name at plan creation (lower.cpp, finish_materialize)
 };
 Status copy_plan_desc(const ssgpu_plan_desc* d, PlanDesc* out);
 

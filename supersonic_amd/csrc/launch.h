@@ -86,6 +86,7 @@ hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream)
 hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream);
 
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream);
+int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K);
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
                                      VmAccRec* out, hipStream_t stream);

@@ -1283,12 +1283,25 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
   return Status::OK();
 }
 
+// A materialising stage.  With a filter, two forms exist:
+//  * two passes (default): a count pass (predicate + SEL_COUNT) and a device scan give every tile its first output
+//    row; the store pass ranks the survivors inside the tile (SEL_RANK) and each lane stores its own rows (STOREC);
+//  * one pass (ctx option filter_single_pass): SEL_RANK_LB counts the tile's survivors, learns the rows kept by all
+//    earlier tiles by decoupled look-back and the columns are gathered from LDS into consecutive output rows (STOREG).
+//    The gathers read rows other threads computed, so a batch of column values is evaluated first and a workgroup
+//    barrier (SEL_RANK_LB's own, or BARRIER for later batches) separates it from its stores; a second barrier keeps
+//    the next batch's temporaries from reusing registers that are still being gathered from.
+// Measured on MI355X (100 M rows x 8 columns, 50 %): 2.37 ms for the two passes against 3.2 ms for the single pass --
+// the look-back is a chain of n_tiles / grid cross-XCD round trips ("materialising Filter").
+static thread_local bool g_filter_single_pass = false;   // PlanDesc::filter_single_pass of the plan being lowered
 static Status finish_materialize(const Pipe& pipe, Stage* st) {
+  const bool single = g_filter_single_pass;
   st->kind = STAGE_MATERIALIZE;
   st->in_schema = pipe.in_schema;
   st->out_schema = schema_of(pipe.cols);
   st->has_filter = !pipe.filters.empty();
-  if (st->has_filter) {
+  st->single_pass = st->has_filter && single;
+  if (st->has_filter && !single) {
     Emitter ec(&st->count_pass, &pipe.joins);
     SS_RETURN_IF_ERROR(emit_filters(ec, pipe));
     LInstr& i = ec.emit(VM_SEL_COUNT); i.dst_is_reg = false; i.dst = 0; i.a = ec.sel_by_depth.back();
@@ -1299,28 +1312,54 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
   SS_RETURN_IF_ERROR(emit_filters(em, pipe));
   const int sel = em.sel_by_depth.back();
   int rank = -1;
-  if (st->has_filter) {
+  if (st->has_filter && !single) {
     rank = em.new_reg(4);
     LInstr& i = em.emit(VM_SEL_RANK); i.dst = rank; i.a = sel;
   }
   int out_index = 0;
+  struct Pending { Val v; bool nullable; };
+  std::vector<Pending> batch;
+  uint32_t batch_bytes = 0;
+  auto store = [&](const Val& x, uint32_t w) {
+    const uint16_t op = !st->has_filter ? (w == 8 ? VM_STORE_64 : w == 4 ? VM_STORE_32 : VM_STORE_8)
+                        : single        ? (w == 8 ? VM_STOREG_64 : w == 4 ? VM_STOREG_32 : VM_STOREG_8)
+                                        : (w == 8 ? VM_STOREC_64 : w == 4 ? VM_STOREC_32 : VM_STOREC_8);
+    LInstr& i = em.emit(op); i.dst_is_reg = false; i.dst = out_index++;
+    if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = (uint8_t)x.width; } else i.a = x.reg;
+    if (st->has_filter) { i.b = rank; if (!single) i.c = sel; }
+  };
+  auto flush = [&]() {
+    if (st->single_pass) {
+      if (rank < 0) { rank = em.new_reg(4); LInstr& i = em.emit(VM_SEL_RANK_LB); i.dst = rank; i.a = sel; }
+      else { LInstr& i = em.emit(VM_BARRIER); i.dst_is_reg = false; i.dst = 0; }
+    }
+    for (auto& pd : batch) {
+      store(pd.v, pd.v.width);
+      if (pd.nullable) {
+        Val nv; nv.width = 1;
+        if (pd.v.null >= 0) nv.reg = pd.v.null; else { nv.imm = true; nv.bits = 0; }
+        store(nv, 1);
+      }
+    }
+    batch.clear(); batch_bytes = 0;
+  };
+  const uint32_t kBatchBytes = 128;   // bytes per row of computed values kept live for one batch of gathers
   for (size_t c = 0; c < pipe.cols.size(); ++c) {
     const BExprP& e = pipe.cols[c].expr;
-    Val v; SS_RETURN_IF_ERROR(em.value(e, &v));
-    auto store = [&](const Val& x, uint32_t w) {
-      const uint16_t op = st->has_filter ? (w == 8 ? VM_STOREC_64 : w == 4 ? VM_STOREC_32 : VM_STOREC_8)
-                                         : (w == 8 ? VM_STORE_64 : w == 4 ? VM_STORE_32 : VM_STORE_8);
-      LInstr& i = em.emit(op); i.dst_is_reg = false; i.dst = out_index++;
-      if (x.imm) { i.a_imm = true; i.imm = x.bits; i.imm_width = (uint8_t)x.width; } else i.a = x.reg;
-      if (st->has_filter) { i.b = rank; i.c = sel; }
-    };
-    store(v, v.width);
-    if (e->nullable) {
-      Val nv; nv.width = 1;
-      if (v.null >= 0) nv.reg = v.null; else { nv.imm = true; nv.bits = 0; }
-      store(nv, 1);
+    if (st->single_pass && batch_bytes >= kBatchBytes) {
+      flush();
+      LInstr& i = em.emit(VM_BARRIER); i.dst_is_reg = false; i.dst = 0;
     }
+    const size_t before = st->main.code.size();
+    Val v; SS_RETURN_IF_ERROR(em.value(e, &v));
+    if (st->main.code.size() != before) batch_bytes += v.width + (e->nullable ? 1u : 0u);
+    batch.push_back(Pending{v, e->nullable});
+    if (!st->single_pass) flush();
     st->output_bytes_per_row += v.width + (e->nullable ? 1 : 0);
+  }
+  flush();
+  if (st->single_pass) {   // the next tile's staging overwrites the input registers: not before the last gather is done
+    LInstr& i = em.emit(VM_BARRIER); i.dst_is_reg = false; i.dst = 0;
   }
   if (out_index > VM_MAX_OUTPUTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many output columns for one pipeline");
   st->main.n_outputs = out_index;
@@ -1330,6 +1369,7 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
 }
 
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe) {
+  g_filter_single_pass = d.filter_single_pass;
   if (d.ops.empty()) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "empty plan");
   // chain from the root down to the scan
   std::vector<int> chain;

@@ -363,6 +363,22 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     }                                                                          \
   } break;
 
+// survivors of the tile -> output rows [base, base + cnt): lane g writes output row g, wave stores start on
+// 64-element boundaries of the OUTPUT column (full lines except at the tile's two ends)
+#define STOREG_OP(OPNAME, T)                                                   \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
+    const u32* sc = reinterpret_cast<const u32*>(smem + P.scratch_lds_off);    \
+    const u32 base = sc[40], end = base + sc[41];                              \
+    const u32* inv = reinterpret_cast<const u32*>(smem + I.b);                 \
+    for (u32 g = (base & ~63u) + (u32)tp; g < end; g += VM_COMPUTE_THREADS) {  \
+      if (g >= base) {                                                         \
+        const u32 src = inv[g - base];                                         \
+        out[g] = *reinterpret_cast<const T*>(smem + I.a + ((src * (u32)sizeof(T)) & I.a_mask)); \
+      }                                                                        \
+    }                                                                          \
+  } break;
+
 #define KEY_APPEND_OP(OPNAME, T, UT)                                           \
   case VM_##OPNAME: { CASE_FENCE;                                              \
     const u32 shift = (u32)(I.imm & 0xFF), bits = (u32)((I.imm >> 8) & 0xFF);  \
@@ -409,6 +425,39 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
       if (m.y) { GAGG_APPLY(LOADT, sl.y, vv.y, ATOM) }                         \
     }                                                                          \
   } break;
+
+// Decoupled look-back of the single-pass compaction (SEL_RANK_LB): publishes tile `tile`'s survivor count, adds up the
+// counts of the earlier tiles down to the first one that already knows its inclusive prefix, publishes this tile's own
+// inclusive prefix and returns the exclusive one.  Called by wave 0 of the workgroup, all 64 lanes (lane j looks at the
+// j-th tile back).  Kept out of line: inlined into the interpreter its spin loop changes the code the compiler makes
+// for every OTHER program (the 8-column headline ran 1.58 ms instead of 1.07 ms with this loop inlined, same box).
+__device__ __noinline__ u32 lookback_rows_before(unsigned long long* status, int tile, u32 run, u64 tag, unsigned int* ctrl, unsigned int* error_flag, int lane) {
+  unsigned long long* const mine = status + tile;
+  if (lane == 0) __hip_atomic_store(mine, (1ull << 62) | tag | (u64)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32 excl = 0, spins = 0;
+  for (int j0 = tile - 1; j0 >= 0;) {
+    const int j = j0 - lane;
+    u64 v = (2ull << 62) | tag;                      // before tile 0: an inclusive prefix of zero rows
+    if (j >= 0) v = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ready = (v >> 62) != 0 && (v & (0x3FFFFFFFull << 32)) == tag;
+    const u64 pending = __ballot(!ready), prefixes = __ballot(ready && (v >> 62) == 2);
+    // usable: every lane up to the first inclusive prefix (or all 64) has published
+    const u32 stop = prefixes ? (u32)__builtin_ctzll(prefixes) : 63u;
+    const u64 need = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
+    if (pending & need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22)) { if (lane == 0) { atomicExch(ctrl + 3, 1u); atomicExch(error_flag, 3u); } break; }   // never expected: give up rather than hang
+      continue;
+    }
+    u32 part = (u32)lane <= stop ? (u32)v : 0u;
+    for (int o = 32; o > 0; o >>= 1) part += (u32)__shfl_xor((int)part, o);
+    excl += part;
+    if (prefixes) break;
+    j0 -= 64;
+  }
+  if (lane == 0) __hip_atomic_store(mine, (2ull << 62) | tag | (u64)(excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
 
 // ---------------------------------------------------------------------------
 // the pipeline kernel: persistent workgroups stride over tiles
@@ -1661,15 +1710,26 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
 
         // ---- materialising sinks ----------------------------------------------
         case VM_SEL_COUNT: { CASE_FENCE;
-          u32 cnt = 0;
+          // one count per tile OF THE STORE PASS, which may be smaller than this pass's tile (count_sub_k 512-row
+          // units each; rows are ordered (k, wave, lane, j), so unit k of this tile is the k-th run of 512 rows)
+          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
           _Pragma("unroll") FOR_PAIRS {
             Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
-            cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            const u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            if (lane == 0) scratch[k * VM_WAVES + wave] = c;
           }
-          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
-          if (lane == 0) scratch[wave] = cnt;
           WG_BARRIER();
-          if (t == 0) { u32 sum = 0; for (int w = 0; w < VM_WAVES; ++w) sum += scratch[w]; P.tile_counts[tile] = sum; }
+          {
+            const int sub = P.count_sub_k > 0 ? P.count_sub_k : K;
+            const int per = K / sub;
+            if (t < per) {
+              u32 sum = 0;
+              for (int q = t * sub * VM_WAVES; q < (t + 1) * sub * VM_WAVES; ++q) sum += scratch[q];
+              const i64 idx = (i64)tile * per + t;
+              const i64 unit_rows = (i64)VM_TILE_UNIT * sub;
+              if (idx * unit_rows < P.n_rows || idx == 0) P.tile_counts[idx] = sum;
+            }
+          }
           WG_BARRIER();
         } break;
         case VM_SEL_RANK: { CASE_FENCE;
@@ -1691,6 +1751,43 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
             u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
             u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
             lds_store2<u32>(I.dst, p, r0, r0 + (m.x ? 1u : 0u));
+          }
+          WG_BARRIER();
+        } break;
+        case VM_SEL_RANK_LB: { CASE_FENCE;
+          // single-pass compaction.  (1) count the tile's survivors; (2) publish the count and look back over the
+          // earlier tiles' words for the number of rows they keep; (3) dst[i] = tile row of survivor i.
+          // Tiles are strided over the persistent workgroups, so the tiles one iteration works on are a contiguous window
+          // whose counts appear together; a tile only waits for tiles of the same or the previous iteration, which
+          // belong to workgroups that are resident (the host sizes the grid by the occupancy API for these programs).
+          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
+          _Pragma("unroll") FOR_PAIRS {
+            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
+            u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+            if (lane == 0) scratch[k * VM_WAVES + wave] = c;
+          }
+          WG_BARRIER();
+          u32 run = 0;
+          {
+            const u64 lt = (1ull << lane) - 1ull;
+            u32* inv = reinterpret_cast<u32*>(smem + I.dst);
+            _Pragma("unroll") FOR_PAIRS {
+              u32 mine = run;
+              for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
+              for (int w = 0; w < VM_WAVES; ++w) run += scratch[k * VM_WAVES + w];
+              Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
+              const u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
+              const u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
+              if (m.x) inv[r0] = 2u * (u32)p;
+              if (m.y) inv[r0 + (m.x ? 1u : 0u)] = 2u * (u32)p + 1u;
+            }
+          }
+          if (wave == 0) {
+            const u32 excl = lookback_rows_before(P.lb_status, tile, run, (P.lb_epoch & 0x3FFFFFFFull) << 32, P.lb_ctrl, P.error_flag, lane);
+            if (lane == 0) {
+              scratch[40] = excl; scratch[41] = run;
+              if (tile == P.n_tiles - 1) *reinterpret_cast<u64*>(P.lb_ctrl) = (u64)excl + run;
+            }
           }
           WG_BARRIER();
         } break;
@@ -1869,6 +1966,28 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
         STOREC_OP(STOREC_8, u8)
         STOREC_OP(STOREC_32, u32)
         STOREC_OP(STOREC_64, u64)
+        case VM_BARRIER: { CASE_FENCE; WG_BARRIER(); } break;
+        STOREG_OP(STOREG_32, u32)
+        STOREG_OP(STOREG_64, u64)
+        case VM_STOREG_8: { CASE_FENCE;      // four output rows per lane: one dword store where all four exist
+          u8* out = reinterpret_cast<u8*>(P.outputs[I.dst].dst);
+          const u32* sc = reinterpret_cast<const u32*>(smem + P.scratch_lds_off);
+          const u32 base = sc[40], end = base + sc[41];
+          const u32* inv = reinterpret_cast<const u32*>(smem + I.b);
+          for (u32 g = (base & ~255u) + 4u * (u32)tp; g < end; g += 4u * VM_COMPUTE_THREADS) {
+            u32 word = 0;
+            _Pragma("unroll") for (u32 j = 0; j < 4; ++j) {
+              const u32 gj = g + j;
+              if (gj >= base && gj < end) word |= (u32)*reinterpret_cast<const u8*>(smem + I.a + (inv[gj - base] & I.a_mask)) << (8u * j);
+            }
+            if (g >= base && g + 4u <= end && ((reinterpret_cast<uintptr_t>(out) & 3u) == 0)) {
+              *reinterpret_cast<u32*>(out + g) = word;
+            } else {
+              _Pragma("unroll") for (u32 j = 0; j < 4; ++j)
+                if (g + j >= base && g + j < end) out[g + j] = (u8)(word >> (8u * j));
+            }
+          }
+        } break;
         case VM_STORE_ROWID: { CASE_FENCE;
           i64* out = reinterpret_cast<i64*>(P.outputs[I.dst].dst);
           _Pragma("unroll") FOR_PAIRS {
@@ -2559,6 +2678,30 @@ hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+// workgroups of the pipeline kernel one CU can hold at once for this program (registers and LDS): programs whose tiles
+// wait for each other (SEL_RANK_LB) must not launch more workgroups than are resident together
+int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K) {
+  int n = 0;
+  hipError_t e = hipErrorInvalidValue;
+  const size_t lds = P.lds_bytes;
+  if (P.uses_math) {
+    switch (K) {
+      case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssgpu_pipeline_kernel<1, true>, VM_WG_THREADS, lds); break;
+      case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssgpu_pipeline_kernel<2, true>, VM_WG_THREADS, lds); break;
+      case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssgpu_pipeline_kernel<4, true>, VM_WG_THREADS, lds); break;
+      default: break;
+    }
+  } else {
+    switch (K) {
+      case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssgpu_pipeline_kernel<1, false>, VM_WG_THREADS, lds); break;
+      case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssgpu_pipeline_kernel<2, false>, VM_WG_THREADS, lds); break;
+      case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ssgpu_pipeline_kernel<4, false>, VM_WG_THREADS, lds); break;
+      default: break;
+    }
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+  return n < 1 ? 1 : n;
 }
 // NOT_UNIQUE hash join, expansion: output row o belongs to the lhs row i whose run [offsets[i],
 // offsets[i] + count[i]) contains it (binary search over the exclusive scan of the run counts) and to

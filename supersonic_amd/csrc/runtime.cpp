@@ -54,6 +54,7 @@ struct ssgpu_ctx {
   int64_t profile = 1;           // record HIP events around kernels
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
+  bool filter_single_pass = false;   // materialising Filter: one pass with decoupled look-back instead of count pass + scan + store pass (plans created after the option is set)
 };
 
 // Device memory a plan holds, against its soft quota (ssgpu_plan_set_memory_limit = MemoryLimit, memory.h:465): every
@@ -109,6 +110,9 @@ struct StageExec {
   DevBuf wg_partials, slot_recs, slot_kind, emit_descs, state;
   // filter compaction
   DevBuf tile_counts, tile_offsets, total;
+  DevBuf lb_status;             // single-pass form: one look-back word per tile
+  uint64_t lb_epoch = 0;        // stamp of the single-pass compaction status words (run_materialize)
+  int lb_resident_per_cu = 0;   // workgroups of this stage's program a CU holds at once (occupancy API)
   // group table
   DevBuf gkeys, gacc, gcnt, goverflow, gpattern, gmergeop;
   int group_wgs = 3;            // resident workgroups per CU of the group stage (adapted from run feedback)
@@ -265,6 +269,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   } else if (k == "profile") c->profile = value;
   else if (k == "profile_total") c->profile_total = value;
   else if (k == "debug_timing") c->debug_timing = value;
+  else if (k == "filter_single_pass") c->filter_single_pass = value != 0;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
 }
@@ -468,6 +473,7 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   ssgpu_plan* p = new ssgpu_plan;
   p->ctx = c;
   Status s = copy_plan_desc(d, &p->desc);
+  p->desc.filter_single_pass = c->filter_single_pass;
   if (s.ok()) s = lower_plan(p->desc, &p->stages, &p->result_schema, &p->describe);
   if (!s.ok()) { delete p; return fail(c, s); }
   for (auto& st : p->stages) {
@@ -555,8 +561,11 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
   if (!st.count_pass.empty()) {
-    LowerOptions o = c->opt; o.tile_rows = VM_TILE_UNIT * L.K;
+    // the count pass stages only the predicate's inputs: it takes the largest tile (fewer, longer tiles; its counts
+    // are still per tile of the store pass)
+    LowerOptions o = c->opt; o.tile_rows = VM_TILE_UNIT * 4;
     ex.lay_count = layout_program(st.count_pass, o);
+    if (ex.lay_count.K < L.K) { o.tile_rows = VM_TILE_UNIT * L.K; ex.lay_count = layout_program(st.count_pass, o); }
     rc = upload_program(c, st.count_pass, ex.lay_count, &ex.prog_count, &ex.n_instr_count, &p->host_prog_scratch);
     if (rc != SSGPU_OK) return rc;
   }
@@ -865,25 +874,52 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
     P.outputs[oi].dst = ex.out[i].data.p; P.outputs[oi].width = ex.out[i].width; ++oi;
     if (ex.out[i].nullable) { P.outputs[oi].dst = ex.out[i].nulls.p; P.outputs[oi].width = 1; ++oi; }
   }
-  const int grid = grid_for(c, ex.lay, P.n_tiles);
+  rc = attach_pc_profile(c, ex, &P);
+  if (rc != SSGPU_OK) return rc;
+  int grid = grid_for(c, ex.lay, P.n_tiles);
+  if (st.single_pass) {
+    // tiles wait for the counts of earlier tiles: every workgroup of the grid has to be resident at once
+    if (ex.lb_resident_per_cu == 0) ex.lb_resident_per_cu = ssgpu_pipeline_resident_per_cu(P, ex.lay.K);
+    grid = std::max(1, std::min(grid, c->cu_count * ex.lb_resident_per_cu));
+  }
   ex.grid = grid;
   p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
-  if (st.has_filter) {
+  if (st.has_filter && !st.single_pass) {
     const int nt = std::max(P.n_tiles, 1);
     HIP_TRY(c, ex.tile_counts.ensure((size_t)nt * sizeof(uint32_t)));
     HIP_TRY(c, ex.tile_offsets.ensure((size_t)nt * sizeof(uint32_t)));
-    HIP_TRY(c, ex.total.ensure(sizeof(uint64_t)));
+    HIP_TRY(c, ex.total.ensure(16));
     VmParams C;
     fill_params(&C, st.count_pass, ex.lay_count, ex.prog_count, ex.n_instr_count, in, row_id_base);
     apply_joins(p, ex, st.count_pass, &C);
     C.tile_counts = ex.tile_counts.as<unsigned int>();
+    C.count_sub_k = ex.lay.K;
     C.error_flag = P.error_flag;
     const int cgrid = grid_for(c, ex.lay_count, C.n_tiles);
-    HIP_TRY(c, ssgpu_launch_pipeline(C, ex.lay.K, cgrid, c->stream));
+    HIP_TRY(c, ssgpu_launch_pipeline(C, ex.lay_count.K, cgrid, c->stream));
     HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), P.n_tiles,
                                         ex.total.as<uint64_t>(), c->stream));
     P.tile_offsets = ex.tile_offsets.as<unsigned int>();
     p->counters.n_launches += 2;
+    ex.out_rows = -1;
+  } else if (st.has_filter) {
+    // single pass: tiles are ranked by decoupled look-back over lb_status (one word per
+    // tile, stamped with this run's epoch: words of earlier runs read as "not yet", so the buffer is zeroed only when
+    // it is (re)allocated or the 30-bit epoch wraps); ex.total = [survivors u64][ticket u32][gave-up flag u32]
+    const size_t nt = (size_t)std::max(P.n_tiles, 1);
+    const size_t had = ex.lb_status.cap;
+    HIP_TRY(c, ex.lb_status.ensure(nt * sizeof(uint64_t)));
+    ex.lb_epoch = (ex.lb_epoch + 1) & 0x3FFFFFFFull;
+    if (ex.lb_status.cap != had || ex.lb_epoch == 0) {
+      HIP_TRY(c, hipMemsetAsync(ex.lb_status.p, 0, ex.lb_status.cap, c->stream));
+      if (ex.lb_epoch == 0) ex.lb_epoch = 1;
+    }
+    HIP_TRY(c, ex.total.ensure(16));
+    HIP_TRY(c, hipMemsetAsync(ex.total.p, 0, 16, c->stream));
+    P.lb_status = ex.lb_status.as<unsigned long long>();
+    P.lb_ctrl = ex.total.as<unsigned int>();
+    P.lb_epoch = ex.lb_epoch;
+    p->counters.n_launches += 1;
     ex.out_rows = -1;
   } else {
     ex.out_rows = in.rows;
@@ -892,7 +928,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
   HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   p->counters.n_launches += 1;
-  return SSGPU_OK;
+  return print_pc_profile(c, ex, st.main, ex.n_instr_main);
 }
 
 // occupied slots of the global group table -> dense result rows in slot order
@@ -1522,6 +1558,7 @@ int check_error_flags(ssgpu_plan* p) {
       HIP_TRY(c, hipMemcpyAsync(&flags[i], p->exec[i].error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (uint32_t f : flags) {
+    if (f == 3) { c->err = "single-pass compaction: a tile waited for an earlier tile's row count for too long and gave up"; return SSGPU_ERROR_HIP; }
     if (f) {
       c->err = f == 2 ? "Evaluation error: invalid argument of a signaling math expression (negative input of SQRT)"
                       : "Evaluation error: division by zero in a signaling expression";

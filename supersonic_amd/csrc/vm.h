@@ -120,6 +120,13 @@ enum { VM_MATH_EXP = 1, VM_MATH_LN, VM_MATH_LOG10, VM_MATH_LOG2, VM_MATH_SIN, VM
   X(STORE_8) X(STORE_32) X(STORE_64)     /* dst = out col, a = reg, rows 1:1 */\
   X(STOREC_8) X(STOREC_32) X(STOREC_64)  /* + b = rank reg, c = sel (compact)*/\
   X(STORE_ROWID) /* dst = out col: int64 global row id of survivors, b,c */    \
+  /* single-pass compaction (decoupled look-back over the strided tiles, VmParams.lb_*):                         */\
+  /* SEL_RANK_LB: a = sel -> dst = u32 reg: tile row of the tile's i-th survivor; publishes the tile's count,    */\
+  /* resolves the rows kept by all earlier tiles (scratch words 32/33 = first output row / survivors)            */\
+  /* STOREG_*: dst = out col, a = value, b = the SEL_RANK_LB register: survivors gathered from LDS, lanes on     */\
+  /* consecutive output rows (coalesced, line-aligned stores)                                                    */\
+  X(SEL_RANK_LB) X(STOREG_8) X(STOREG_32) X(STOREG_64)                         \
+  X(BARRIER)     /* workgroup barrier: registers written so far may be read by other threads (STOREG) */ \
   /* PART_RANK: a = key(64), c = sel -> dst = u32 position of the row in the tile's partition-sorted order,    */\
   /* VM_NONE for unselected rows; PART_REC_*: a (, d) = value reg(s), b = position reg, imm = byte offset      */\
   /* inside the record | record bytes << 16 (AoS records in the LDS staging area); PART_FLUSH: imm = record    */\
@@ -237,7 +244,7 @@ struct VmParams {
   uint32_t imm_pool_lds_off; /* LDS offset of the constant pool: 16 B per instruction */
   uint32_t const_lds_off;    /* LDS offset of 2 x tile_rows bytes: all 0x01, then all 0x00 */
   uint32_t lds_bytes;
-  int32_t reserved1;
+  int32_t count_sub_k;    /* SEL_COUNT: 512-row units per counted tile (0 = this launch's K): the store pass's K */
   uint32_t reserved0;
   uint64_t slot_init0[VM_FAST_SLOTS]; /* per-lane identities of the fast slots */
   uint64_t slot_init1[VM_FAST_SLOTS];
@@ -250,6 +257,9 @@ struct VmParams {
   uint32_t part_pad;
   unsigned int* part_overflow;  /* PART_RANK: set to 1 when a segment was full (the host reruns with larger segments) */
   const unsigned int* tile_offsets;
+  unsigned long long* lb_status;  /* SEL_RANK_LB: one word per tile: state << 62 | epoch << 32 | rows (0 = not yet) */
+  unsigned int* lb_ctrl;          /* [0..1] u64 total survivors, [3] look-back gave up                              */
+  unsigned long long lb_epoch;    /* run stamp of lb_status words (stale words of earlier runs read as "not yet")    */
   unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */
   unsigned long long* debug_pc; /* optional [n_instr + 1]: cycles per instruction (wave 0 of every workgroup); last = staging */

@@ -16,8 +16,12 @@ def facade_bin():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     deps = [SRC, os.path.join(ROOT, "include", "ssgpu.h"), os.path.join(ROOT, "include", "supersonic_amd", "supersonic.h")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-o", OUT,
+        # pytest-xdist may hand this module's two tests to different workers: build under a private name and move the
+        # finished binary into place (a worker must never execute a half-written file)
+        tmp = "%s.%d.tmp" % (OUT, os.getpid())
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-o", tmp,
                                "-L" + LIBDIR, "-lssgpu", "-Wl,-rpath," + LIBDIR])
+        os.replace(tmp, OUT)
     return OUT
 
 

@@ -146,6 +146,49 @@ def test_filter_nullable_predicate_and_project(gpu_ctx, n):
     run_both(op, gpu_ctx)
 
 
+# The one-pass form of the materialising Filter (ctx option filter_single_pass: SEL_RANK_LB's decoupled look-back +
+# LDS-gathered coalesced stores) must give the same rows in the same order as the default count-pass form.
+@pytest.fixture(scope="module")
+def single_pass_ctx():
+    c = ss.Context(0)
+    c.set_option("filter_single_pass", 1)
+    return c
+
+
+@pytest.mark.parametrize("n", ROWS + [1000003])
+@pytest.mark.parametrize("k", [-1, 499, 989, 1000])
+def test_filter_materialize_single_pass(single_pass_ctx, n, k):
+    op = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(k)), ss.ProjectAllAttributes(), ss.ScanView(make_view(n)))
+    plan = ss.Plan(op, single_pass_ctx)
+    assert "SEL_RANK_LB" in plan.describe() and "SEL_COUNT" not in plan.describe()
+    run_both(op, single_pass_ctx)
+
+
+@pytest.mark.parametrize("n", [0, 65, 1025, 100003])
+def test_filter_single_pass_nullable_and_computed_columns(single_pass_ctx, n):
+    view = make_view(n, nullable=True)
+    pred = ss.And(ss.Greater(NA("a"), ss.ConstInt64(300)), NA("t"))
+    run_both(ss.Filter(pred, ss.ProjectNamedAttributes(["d", "k1", "a", "d0", "t"]), ss.ScanView(view)), single_pass_ctx)
+    # computed columns: more than one batch of gathers (BARRIER between batches)
+    e = ss.CompoundExpression()
+    for i in range(24):
+        e.AddAs("x%d" % i, ss.Plus(NA("b"), ss.ConstInt64(i)))
+    e.AddAs("h", ss.DivideNulling(NA("d0"), NA("d1"))).Add(NA("k1")).AddAs("five", ss.ConstInt32(5)).Add(NA("c"))
+    run_both(ss.Filter(ss.Less(NA("c"), ss.ConstInt64(40000)), ss.ProjectAllAttributes(), ss.Compute(e, ss.ScanView(view))), single_pass_ctx)
+
+
+def test_filter_single_pass_reuses_the_plan(single_pass_ctx):
+    # the look-back words carry a run stamp: a second run over other data must not see the first run's counts
+    views = [make_view(100003, seed=s) for s in (1, 2, 3)]
+    op = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(views[0]))
+    plan = ss.Plan(op, single_pass_ctx)
+    for v in views:
+        plan.run(v)
+        got = plan.fetch()
+        _, want = oracle_run(ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(v)))
+        assert_cols_equal(to_cols(got), want)
+
+
 def group_query(view, with_filter, keys=("k1", "k2")):
     spec = ss.AggregationSpecification()
     for col in ["d0", "d1", "d2", "d3"]:
