@@ -170,6 +170,7 @@ struct PlanDesc {
   std::vector<ssgpu_sortkey> sortkeys;
   std::vector<std::string> strings;  // storage for all names (stable addresses)
   bool filter_single_pass = false;   // ctx option of the same name at plan creation (lower.cpp, finish_materialize)
+  int part_rec_align = 0;            // ctx option: partition records padded to a multiple of this many bytes (0 = 8)
 };
 Status copy_plan_desc(const ssgpu_plan_desc* d, PlanDesc* out);
 

@@ -1032,6 +1032,7 @@ static Status finish_scalar_agg(const PlanDesc& d, const ssgpu_op& op, const Pip
 }
 
 struct AggPlan;
+static thread_local int g_part_rec_align = 0;   // PlanDesc::part_rec_align of the plan being lowered
 static Status build_partition_programs(const struct Pipe& pipe, const std::vector<int>& kpos, const std::vector<AggPlan>& plans, Stage* st);
 
 // clustered = AggregateClusters (aggregate_clusters.cc:338-520): the group id of a row is the
@@ -1258,6 +1259,7 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
   for (uint32_t w : {8u, 4u, 1u})
     for (auto& f : fields) if (f.width == w) { f.off = (int)off; off += w; }
   st->part_rec_bytes = (off + 7u) & ~7u;
+  if (g_part_rec_align > 8) st->part_rec_bytes = (st->part_rec_bytes + (uint32_t)g_part_rec_align - 1u) / (uint32_t)g_part_rec_align * (uint32_t)g_part_rec_align;
   if (st->part_rec_bytes > 128u) { st->part_scatter = Program(); st->part_aggs.clear(); return Status::OK(); }   // wider records: direct path only
   for (size_t j = 0; j < refs.size(); ++j) {
     if (refs[j].val_field >= 0) st->part_aggs[j].val_off = fields[refs[j].val_field].off;
@@ -1277,7 +1279,8 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     if (f.width == 8) continue;
     LInstr& i = em.emit(f.width == 4 ? VM_PART_REC_32 : VM_PART_REC_8); i.dst_is_reg = false; i.dst = 0; i.a = f.reg; i.b = rank; i.imm = (uint64_t)f.off | rb;
   }
-  { LInstr& i = em.emit(VM_PART_FLUSH); i.dst_is_reg = false; i.dst = 0; i.imm = st->part_rec_bytes; }
+  { const uint32_t wpr = st->part_rec_bytes / 8u;   // imm = words per record | (floor(2^32 / wpr) + 1) << 32
+    LInstr& i = em.emit(VM_PART_FLUSH); i.dst_is_reg = false; i.dst = 0; i.imm = (uint64_t)wpr | ((uint64_t)(uint32_t)(0x100000000ull / wpr + 1ull) << 32); }
   st->part_scatter.n_outputs = 1;
   allocate_registers(&st->part_scatter);
   return Status::OK();
@@ -1370,6 +1373,7 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
 
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe) {
   g_filter_single_pass = d.filter_single_pass;
+  g_part_rec_align = d.part_rec_align;
   if (d.ops.empty()) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_VALUE, "empty plan");
   // chain from the root down to the scan
   std::vector<int> chain;

@@ -206,6 +206,11 @@ __device__ __forceinline__ u32 hash_local(u64 key) {   // two 32-bit multiplies 
 }
 // hash partition of a key: decorrelated from the in-table home slot (both use the HIGH bits of
 // their hash through mulhi)
+// Segment (partition p, scatter workgroup wg) of the record buffer: partition-major, so that phase 2 reads one
+// contiguous region per partition.  (Workgroup-major -- the NP segments a scatter workgroup appends to adjacent, a few
+// MB -- made the scatter 6 % faster at 512 partitions but phase 2 read 768 regions 11.5 MB apart per partition and the
+// 1024-partition case ran 28 ms instead of 5.6 ms; A/B on one box.)
+#define SEG_INDEX(p, wg, NP, G) ((p) * (G) + (wg))
 __device__ __forceinline__ u32 part_of(u64 key, u32 n_parts) {
   u32 h = hash_local(key) * 0x2C1B3C6Du; h ^= h >> 16;
   return __umulhi(h * 0x297A2D39u, n_parts);
@@ -1869,59 +1874,57 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
         // LDS behind part_lds_off: u32 fill[P] | tile count -> tile start [P] | run delta [P] | room [P] |
         //                          u32 grec[tile_rows] (global record index by sorted position) | n | records
         case VM_PART_RANK: { CASE_FENCE;
+          // Every selected row takes the next free record of its (hash partition, this workgroup) segment -- one
+          // returning LDS atomic on the workgroup's fill counters, which live for the whole kernel -- and a place in
+          // the tile's staging area, where PART_REC_* assemble its record and from where PART_FLUSH copies it out.
+          // (An earlier form sorted the tile's rows by partition first: with >= 256 partitions and 512-row tiles a
+          // partition's run is one or two records, so the sort bought no coalescing and cost a histogram, a scan
+          // and three barriers over the partition count per tile -- a third of the pass.)
           const u32 NP = P.part_n, cap = P.part_seg_cap, G = gridDim.x, wg = blockIdx.x;
           u32* fill = reinterpret_cast<u32*>(smem + P.part_lds_off);
-          u32* th = fill + NP; u32* dl = th + NP; u32* room = dl + NP; u32* grec = room + NP;
+          u32* grec = fill + NP;
           u32* nsel = grec + (u32)(VM_TILE_UNIT * K);
           u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
-          for (u32 i = (u32)tp; i < NP; i += VM_COMPUTE_THREADS) th[i] = 0u;
-          WG_BARRIER();
-          u32 pb[2 * K], pr[2 * K];
+          const bool compact = I.c != VM_NONE;       // a selection: staged records are the survivors, in row order
+          if (compact) {
+            _Pragma("unroll") FOR_PAIRS {
+              Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
+              const u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
+              if (lane == 0) scratch[k * VM_WAVES + wave] = c;
+            }
+            WG_BARRIER();
+          }
+          bool over = false;
+          u32 run = 0;
+          const u64 lt = (1ull << lane) - 1ull;
           _Pragma("unroll") FOR_PAIRS {
             Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
             auto kk = lds_load2<u64>(I.a, p);
-            pb[2 * k] = part_of(kk.x, NP); pb[2 * k + 1] = part_of(kk.y, NP);
-            pr[2 * k] = m.x ? atomicAdd(&th[pb[2 * k]], 1u) : VM_NONE;
-            pr[2 * k + 1] = m.y ? atomicAdd(&th[pb[2 * k + 1]], 1u) : VM_NONE;
-          }
-          WG_BARRIER();
-          {  // exclusive scan of the tile histogram: thread tp owns partitions [tp * per, tp * per + per)
-            const u32 per = (NP + VM_COMPUTE_THREADS - 1u) / VM_COMPUTE_THREADS, i0 = (u32)tp * per;
-            u32 sum = 0;
-            for (u32 e = 0; e < per; ++e) sum += (i0 + e < NP) ? th[i0 + e] : 0u;
-            u32 inc = sum;
-            _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-            if (lane == 63) scratch[wave] = inc;
-            WG_BARRIER();
-            u32 run = inc - sum;
-            for (int w = 0; w < wave; ++w) run += scratch[w];
-            if (tp == VM_COMPUTE_THREADS - 1) nsel[0] = run + sum;
-            bool over = false;
-            for (u32 e = 0; e < per; ++e) {
-              const u32 i = i0 + e;
-              if (i >= NP) break;
-              const u32 c = th[i], f = fill[i];
-              th[i] = run;                                   // first sorted position of partition i in this tile
-              dl[i] = (i * G + wg) * cap + f - run;          // global record index = dl[i] + sorted position
-              room[i] = cap - f;                             // records the segment still takes
-              const u32 take = c < cap - f ? c : cap - f;
-              over = over || take < c;
-              fill[i] = f + take;
-              run += c;
+            u32 s0 = 2u * (u32)p, s1 = 2u * (u32)p + 1u;
+            if (compact) {
+              u32 mine = run;
+              for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
+              for (int w = 0; w < VM_WAVES; ++w) run += scratch[k * VM_WAVES + w];
+              const u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
+              s0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
+              s1 = s0 + (m.x ? 1u : 0u);
             }
-            if (over) atomicExch(P.part_overflow, 1u);
-          }
-          WG_BARRIER();
-          _Pragma("unroll") FOR_PAIRS {
-            u32 s0 = VM_NONE, s1 = VM_NONE;
-            if (pr[2 * k] != VM_NONE) { const u32 sp = th[pb[2 * k]] + pr[2 * k]; const bool ok = pr[2 * k] < room[pb[2 * k]]; grec[sp] = ok ? dl[pb[2 * k]] + sp : VM_NONE; if (ok) s0 = sp; }
-            if (pr[2 * k + 1] != VM_NONE) { const u32 sp = th[pb[2 * k + 1]] + pr[2 * k + 1]; const bool ok = pr[2 * k + 1] < room[pb[2 * k + 1]]; grec[sp] = ok ? dl[pb[2 * k + 1]] + sp : VM_NONE; if (ok) s1 = sp; }
+            if (m.x) {
+              const u32 pt = part_of(kk.x, NP), pos = atomicAdd(&fill[pt], 1u);
+              if (pos < cap) grec[s0] = SEG_INDEX(pt, wg, NP, G) * cap + pos; else { grec[s0] = VM_NONE; over = true; }
+            } else s0 = VM_NONE;
+            if (m.y) {
+              const u32 pt = part_of(kk.y, NP), pos = atomicAdd(&fill[pt], 1u);
+              if (pos < cap) grec[s1] = SEG_INDEX(pt, wg, NP, G) * cap + pos; else { grec[s1] = VM_NONE; over = true; }
+            } else s1 = VM_NONE;
             lds_store2<u32>(I.dst, p, s0, s1);
           }
+          if (over) atomicExch(P.part_overflow, 1u);
+          if (tp == 0) nsel[0] = compact ? run : tile_valid;
         } break;
 #define PART_REC_OP(OPNAME, T)                                                 \
         case VM_##OPNAME: { CASE_FENCE;                                        \
-          char* stage = smem + P.part_lds_off + 16u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu); \
+          char* stage = smem + P.part_lds_off + 4u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu); \
           const u32 rb = (u32)((I.imm >> 16) & 0xFFFFu);                       \
           _Pragma("unroll") FOR_PAIRS {                                        \
             auto rk = lds_load2<u32>(I.b, p);                                  \
@@ -1934,7 +1937,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
         PART_REC_OP(PART_REC_32, u32)
         PART_REC_OP(PART_REC_64, u64)
         case VM_PART_REC_128: { CASE_FENCE;   // two adjacent 8-byte fields
-          char* stage = smem + P.part_lds_off + 16u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu);
+          char* stage = smem + P.part_lds_off + 4u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu);
           const u32 rb = (u32)((I.imm >> 16) & 0xFFFFu);
           _Pragma("unroll") FOR_PAIRS {
             auto rk = lds_load2<u32>(I.b, p);
@@ -1946,17 +1949,22 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
         } break;
         case VM_PART_FLUSH: { CASE_FENCE;     // the staged records of the tile -> their segments, 8 bytes per lane, lanes on consecutive words
           const u32 NP = P.part_n;
-          const u32* grec = reinterpret_cast<const u32*>(smem + P.part_lds_off + 16u * NP);
+          const u32* grec = reinterpret_cast<const u32*>(smem + P.part_lds_off + 4u * NP);
           const u32* nsel = grec + (u32)(VM_TILE_UNIT * K);
-          const u64* stage = reinterpret_cast<const u64*>(smem + P.part_lds_off + 16u * NP + 4u * (u32)(VM_TILE_UNIT * K) + 16u);
+          const u64* stage = reinterpret_cast<const u64*>(smem + P.part_lds_off + 4u * NP + 4u * (u32)(VM_TILE_UNIT * K) + 16u);
           u64* out = reinterpret_cast<u64*>(P.outputs[0].dst);
-          const u32 wpr = (u32)I.imm >> 3;                   // words per record
+          const u32 wpr = (u32)I.imm & 0xFFFFu;              // words per record
+          const u32 rcp = (u32)(I.imm >> 32);                // floor(2^32 / wpr) + 1: word -> record without a division
           WG_BARRIER();
           const u32 words = nsel[0] * wpr;
-          for (u32 w = (u32)tp; w < words; w += VM_COMPUTE_THREADS) {
-            const u32 j = w / wpr, f = w - j * wpr;
-            const u32 g = grec[j];
-            if (g != VM_NONE) out[(u64)g * wpr + f] = stage[w];
+          for (u32 w0 = (u32)tp; w0 < words; w0 += 2u * VM_COMPUTE_THREADS) {
+            const u32 w1 = w0 + VM_COMPUTE_THREADS;
+            const u32 j0 = __umulhi(w0, rcp), j1 = __umulhi(w1, rcp);
+            const bool in1 = w1 < words;
+            const u32 g0 = grec[j0], g1 = in1 ? grec[j1] : VM_NONE;
+            const u64 v0 = stage[w0], v1 = in1 ? stage[w1] : 0ull;
+            if (g0 != VM_NONE) out[(u64)g0 * wpr + (w0 - j0 * wpr)] = v0;
+            if (g1 != VM_NONE) out[(u64)g1 * wpr + (w1 - j1 * wpr)] = v1;
           }
           WG_BARRIER();
         } break;
@@ -2481,7 +2489,8 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
     if (t == 0) segoff[G] = total;
   }
   __syncthreads();
-  const u64* const recs = P.recs + (u64)part * G * P.seg_cap * W;
+  const u64* const recs = P.recs + (u64)SEG_INDEX(part, 0u, P.n_parts, G) * P.seg_cap * W;
+  const u64 seg_step = (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
   const u32 seg_cap = P.seg_cap, n_aggs = P.n_aggs;
   const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
   u32 seg = 0;
@@ -2493,7 +2502,7 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
       live[j] = i < total;
       if (live[j]) {
         while (i >= segoff[seg + 1u]) ++seg;              // empty segments are stepped over
-        const u64* rp = recs + ((u64)seg * seg_cap + (i - segoff[seg])) * W;
+        const u64* rp = recs + ((u64)seg * seg_step + (i - segoff[seg])) * W;
 #pragma unroll
         for (int w = 0; w < MAXW; ++w) rec[j][w] = (u32)w < W ? rp[w] : 0ull;
       } else {
@@ -2511,7 +2520,7 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
           lkeys[C] = 0ull;                               // marks the reserved entry as used
         } else {
           u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
-          for (int probe = 0; probe < 16; ++probe) {
+          for (int probe = 0; probe < 16; ++probe) {    // a longer cluster = the table is too full: the host re-partitions finer
             const u64 cur = __hip_atomic_load(lkeys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (cur == key) { found = i; break; }
             if (cur == VM_KEY_EMPTY) {

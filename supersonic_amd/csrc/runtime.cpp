@@ -54,6 +54,7 @@ struct ssgpu_ctx {
   int64_t profile = 1;           // record HIP events around kernels
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
+  int64_t part_rec_align = 0;    // partition records padded to a multiple of this many bytes (plans created after the option is set)
   bool filter_single_pass = false;   // materialising Filter: one pass with decoupled look-back instead of count pass + scan + store pass (plans created after the option is set)
 };
 
@@ -270,6 +271,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "profile_total") c->profile_total = value;
   else if (k == "debug_timing") c->debug_timing = value;
   else if (k == "filter_single_pass") c->filter_single_pass = value != 0;
+  else if (k == "part_rec_align") c->part_rec_align = value;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
 }
@@ -474,6 +476,7 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   p->ctx = c;
   Status s = copy_plan_desc(d, &p->desc);
   p->desc.filter_single_pass = c->filter_single_pass;
+  p->desc.part_rec_align = (int)c->part_rec_align;
   if (s.ok()) s = lower_plan(p->desc, &p->stages, &p->result_schema, &p->describe);
   if (!s.ok()) { delete p; return fail(c, s); }
   for (auto& st : p->stages) {
@@ -1043,7 +1046,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (c->part_n > 0) ex.part_n = (uint32_t)c->part_n;
     else {
       uint32_t pn = 256;
-      while (ex.part_groups_est > 0.5 * (double)pn * (double)C && pn < 8192) pn *= 2;
+      while (ex.part_groups_est > 0.3 * (double)pn * (double)C && pn < 8192) pn *= 2;   // (the estimate is a lower bound: keep the load under one half)
       ex.part_n = pn;
     }
   }
@@ -1055,10 +1058,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
     apply_joins(p, ex, st.part_scatter, &Ps);
     Ps.part_n = NP;
-    // behind the program's registers: four u32 arrays of NP entries, the tile's record index by sorted position, and
-    // the staging area where the tile's records are assembled in partition order (see VM_PART_RANK)
+    // behind the program's registers: the workgroup's NP segment fill counters, the tile's record index by staging
+    // position, and the staging area where the tile's records are assembled (see VM_PART_RANK)
     Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u;
-    Ps.lds_bytes = Ps.part_lds_off + NP * 16u + (uint32_t)Ps.tile_rows * 4u + 16u + (uint32_t)Ps.tile_rows * st.part_rec_bytes;
+    Ps.lds_bytes = Ps.part_lds_off + NP * 4u + (uint32_t)Ps.tile_rows * 4u + 16u + (uint32_t)Ps.tile_rows * st.part_rec_bytes;
     if (Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
     ProgramLayout Ls = ex.lay_pscatter; Ls.lds_bytes = Ps.lds_bytes;
     int grid;
