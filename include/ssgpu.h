@@ -58,7 +58,30 @@
  *     on the codes are bit-exact restatements of the same operations on the strings
  *     (types_infrastructure.h:238-246); the bytes themselves never reach the device.
  *     Arithmetic, casts and SUM on STRING are bind errors exactly as in the reference.  The
- *     host mirrors own the dictionary (supersonic_amd/api.py: StringDictionary);
+ *     dictionary is ssgpu_dict_* below (the host mirrors build it through the ABI);
+ *   - floating aggregates, where results are not bit-defined by the reference's definition:
+ *       SUM over FLOAT / DOUBLE: the reference folds sequentially in input order
+ *       (aggregation_operators.h:173-186), so its result depends on the row order and is up to
+ *       thousands of ULP from the exact sum on ill-conditioned data.  Here scalar and grouped sums
+ *       are accumulated with compensation (double-double per lane, TwoSum-compensated atomics per
+ *       group) and rounded once: <= 1 ULP from the exact sum (measured 0 ULP against math.fsum,
+ *       tests/test_double_sum_gpu.py) and identical to the reference whenever every partial sum is
+ *       exactly representable;
+ *       MIN / MAX over FLOAT / DOUBLE: the reference's update is "if (val < result) result = val"
+ *       (aggregation_operators.h:200,221), which never replaces a NaN that came FIRST and never
+ *       takes a NaN that comes later: its result for a group containing NaN depends on whether the
+ *       NaN is the group's first non-NULL row.  DIVERGENCE: here NaN rows never contribute to
+ *       MIN / MAX, whatever their position (where every value is NaN a group's result is NaN and a
+ *       ScalarAggregate's is the identity, +inf for MIN and -inf for MAX) -- the result does
+ *       not depend on the row order.  -0.0 and +0.0 compare equal in the reference, so which of the
+ *       two a MIN / MAX returns is order-dependent there; here -0.0 < +0.0;
+ *       MIN / MAX from one integer type into another (AddAggregationWithDefinedOutputType): the
+ *       reference compares every value in its own type with the running result and stores the cast
+ *       (aggregation_operators.h:187-228), so MAX of INT32 {0, 1, -1} into UINT32 is 1
+ *       (aggregation_operators_test.cc:200-210) -- but a value the result type cannot hold makes its
+ *       result depend on the row order ({-1, 0, 1} gives 4294967295).  Here the extremum is taken in
+ *       the input's type and cast once: the same result whenever the values fit the result type, and
+ *       an order-independent one where they do not;
  *   - every *_create has a *_destroy; one ctx/plan is driven by one host
  *     thread at a time (as the reference); only ssgpu_interrupt is callable
  *     concurrently;

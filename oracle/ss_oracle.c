@@ -1299,6 +1299,19 @@ static int64_t load_as_i64(int t, const void* p, int64_t i) {
   return 0;
 }
 
+/* operators::Less across two column types (supersonic/base/infrastructure/operators.h:225-278): `a < b` after the usual
+ * arithmetic conversions, except that signed-vs-unsigned integers compare by value.  MIN / MAX compare every value IN ITS
+ * OWN TYPE with the running result and store the value cast to the result type (aggregation_operators.h:187-228:
+ * ThreeWayCompare<InputType, OutputType>), so a value the result type cannot hold makes the reference's result depend on
+ * the row order -- the sequential fold below is the reference's. */
+static int less_typed(int lt, const void* lp, int64_t li, int rt, const void* rp, int64_t ri) {
+  const int lk = arith_kind(lt), rk = arith_kind(rt);
+  if (lk == 4 || lk == 5 || rk == 4 || rk == 5) return load_as_double(lt, lp, li) < load_as_double(rt, rp, ri);   /* (float -> double is exact) */
+  const __int128 a = lk == 3 ? (__int128)((const uint64_t*)lp)[li] : (__int128)load_as_i64(lt, lp, li);
+  const __int128 b = rk == 3 ? (__int128)((const uint64_t*)rp)[ri] : (__int128)load_as_i64(rt, rp, ri);
+  return a < b;
+}
+
 /* DISTINCT: 1 if (result row, value) was seen before, else remembers it (NULL inputs never get here: "NULL values do
  * not count as distinct", column_aggregator.cc:326-329) */
 static int distinct_seen(agg_col* g, int64_t row, const void* in, int64_t i) {
@@ -1347,8 +1360,8 @@ static void update_aggregation(agg_col* g, const orc_view* v, const int64_t* map
       if (first) *acc = val; \
       else switch (g->aggregation) { \
         case A_SUM: *acc += val; break; \
-        case A_MIN: if (val < *acc) *acc = val; break;    /* "val < result" replaces; NaN never does */ \
-        case A_MAX: if (*acc < val) *acc = val; break; \
+        case A_MIN: if (less_typed(g->in_type, in, i, g->out_type, res, r)) *acc = val; break;  /* "val < result" replaces; NaN never does */ \
+        case A_MAX: if (less_typed(g->out_type, res, r, g->in_type, in, i)) *acc = val; break; \
         case A_FIRST: break; \
         case A_LAST: *acc = val; break; } }
     switch (ko) {

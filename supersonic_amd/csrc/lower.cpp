@@ -867,6 +867,22 @@ static bool select_scalar_agg(int aggregation, int out_type, AggSel* s) {
   }
   return false;
 }
+// MIN / MAX from one integer type into another (AddAggregationWithDefinedOutputType): the reference compares every value IN
+// ITS OWN TYPE with the running result (ThreeWayCompare<InputType, OutputType>, aggregation_operators.h:187-228;
+// aggregation_operators_test.cc:200-210 is the regression test: MAX of INT32 {1, -1} into UINT32 is 1) and stores the cast.
+// Here the extremum is found in the input's domain widened to 64 bits and truncated to the result type by the emit step
+// (the accumulator keys of all integer MIN / MAX are 64-bit): equal to the reference whenever the result type can hold the
+// values; where it cannot, the reference's result depends on the row order (include/ssgpu.h).
+static bool minmax_in_own_type(int aggregation, int in_type, int out_type, int* agg_type, int* emit_kind) {
+  if (aggregation != SSGPU_MIN && aggregation != SSGPU_MAX) return false;
+  const MT in = mtype(in_type), out = mtype(out_type);
+  auto integer = [](MT m) { return m == M_I32 || m == M_U32 || m == M_I64 || m == M_U64; };
+  if (in == out || !integer(in) || !integer(out) || in_type == SSGPU_STRING || out_type == SSGPU_STRING) return false;
+  const bool uns = in == M_U64;
+  *agg_type = uns ? SSGPU_UINT64 : SSGPU_INT64;
+  *emit_kind = mwidth(out) == 8 ? (uns ? EMIT_U64 : EMIT_I64KEY) : (uns ? EMIT_U32 : EMIT_I32KEY);
+  return true;
+}
 static bool select_group_agg(int aggregation, int out_type, AggSel* s, uint64_t* init) {
   const MT m = mtype(out_type);
   *init = 0;
@@ -1007,7 +1023,13 @@ static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const P
       } else {
         Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
         Val c;
-        SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+        int wide_type = 0, wide_emit = 0;
+        if (minmax_in_own_type(ap.aggregation, src->dtype, ap.out_type, &wide_type, &wide_emit)) {
+          select_scalar_agg(ap.aggregation, wide_type, &s); s.emit_kind = wide_emit;
+          SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(wide_type), &c));
+        } else {
+          SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+        }
         int vr = em.materialize(c);
         const int nullreg = ap.distinct ? em.or_null(v.null, notfirst) : v.null;
         LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = sel;
@@ -1134,7 +1156,9 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
     } else {
       const BExprP& src = pipe.cols[ap.input_pos].expr;
       Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
-      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+      int agg_type = ap.out_type, wide_emit = -1;
+      minmax_in_own_type(ap.aggregation, src->dtype, ap.out_type, &agg_type, &wide_emit);
+      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(agg_type), &c));
       AggSel s;
       int vr;
       if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
@@ -1149,8 +1173,9 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
         vr = rowid_reg;
         ao.gather_col = src->input_col;
       } else {
-        if (!select_group_agg(ap.aggregation, ap.out_type, &s, &init))
+        if (!select_group_agg(ap.aggregation, agg_type, &s, &init))
           return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
+        if (wide_emit >= 0) s.emit_kind = wide_emit;
         vr = em.materialize(c);
       }
       const int nullreg = ap.distinct ? em.or_null(v.null, notfirst) : v.null;
@@ -1237,7 +1262,9 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     } else {
       const BExprP& src = pipe.cols[ap.input_pos].expr;
       Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
-      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
+      int agg_type = ap.out_type, wide_emit = -1;
+      minmax_in_own_type(ap.aggregation, src->dtype, ap.out_type, &agg_type, &wide_emit);   // (the emit kind is the direct path's: same AggOut)
+      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(agg_type), &c));
       AggSel sl; uint64_t init = 0;
       if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
         select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &sl, &init);
@@ -1245,7 +1272,7 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
         pa.op = sl.op;
         rf.val_field = add_field(rowid_reg, 8); pa.val_width = 8;
       } else {
-        if (!select_group_agg(ap.aggregation, ap.out_type, &sl, &init))
+        if (!select_group_agg(ap.aggregation, agg_type, &sl, &init))
           return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
         pa.op = sl.op;
         rf.val_field = add_field(em.materialize(c), c.width); pa.val_width = (int)c.width;

@@ -870,6 +870,156 @@ R5k = [[k, v] for _ in range(1100) for k, v in R12345]
 join_case("HashJoin_12345_InnerJoin_5k_Rows", HJ + ":321-353", "INNER", R12345, R5k,
           [[k, v, k, v] for k, v in R12345 for _ in range(1100)], NU)
 
+
+# ---- the guide's GroupAggregate (test/guide/primer.cc:230-346: GroupedSums over key INT32, data DOUBLE) -----------
+op_case("Primer_GroupAggregateTest", "test/guide/primer.cc:294-346", [["key", I32, False], ["data", F64, False]],
+        [[k, d] for k, d in zip([1, 2, 3, 1, 2, 3, 1, 2], [1.5, 3.0, 3.0, 7.6, 5.5, 2.0, 1.6, 9.5])],
+        ["GroupAggregate", ["ProjectNamedAttribute", "key"], [["SUM", "data", "data_sums"]], "INPUT"],
+        [I32, F64], [[1, 1.5 + 7.6 + 1.6], [2, 3.0 + 5.5 + 9.5], [3, 3.0 + 2.0]], ordered=False, exp_names=["key", "data_sums"])
+
+# ---- test/guide/group_sort.cc: two-key grouping (STRING + BOOL keys, MIN / MAX), single-column sort --------------
+GS = "test/guide/group_sort.cc"
+EMP_SCHEMA = [["name", STR, False], ["age", I32, False], ["salary", I32, False], ["department", STR, False], ["full_time", BOOL, False]]
+EMP_PLAN = ["GroupAggregate", ["Compound", ["ProjectNamedAttributeAs", "full_time", "Works full time?"], ["ProjectAttributeAt", 3]],
+            [["MIN", "salary", "min_salary"], ["MAX", "age", "max_age"]], "INPUT"]
+
+
+def emp_expected(rows):
+    """TestResults() of the fixture (group_sort.cc:186-241): min salary / max age per (full_time, department)."""
+    acc = {}
+    for _name, age, sal, dept, ft in rows:
+        k = (ft, dept)
+        acc[k] = (min(acc[k][0], sal), max(acc[k][1], age)) if k in acc else (sal, age)
+    return [[k[0], k[1], v[0], v[1]] for k, v in acc.items()]
+
+
+_small = [[n, a, s, d, f] for n, a, s, d, f in zip(["John", "Darrel", "Greg", "Amanda", "Stacy"], [20, 25, 32, 31, 33], [1800, 3300, 4800, 3500, 1900],
+                                                   ["Accounting", "Sales", "Sales", "IT", "IT"], [False, True, False, True, False])]
+op_case("GroupSort_SmallGroupingTest", GS + ":251-283", EMP_SCHEMA, _small, EMP_PLAN, [BOOL, STR, I32, I32], emp_expected(_small),
+        ordered=False, exp_names=["Works full time?", "department", "min_salary", "max_age"])
+# LargeRandomGroupingTest draws from rand(); the same pools and value ranges from a fixed generator here
+_NAMES = ["John", "James", "Alan", "Judy", "Anne", "Ray", "Grace"]
+_DEPTS = ["IT", "Sales", "Legal", "Services", "Advertising", "Research", "Operations", "Compliance", "Public Relations", "Human Resources",
+          "Research", "Engineering", "Deployment", "Accounting", "Tech Support"]
+
+
+def _lcg(seed):
+    state = [seed]
+
+    def nxt():
+        state[0] = (state[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return state[0] >> 33
+    return nxt
+
+
+_r = _lcg(2012)
+_large = [[_NAMES[_r() % 7], 0, 0, _DEPTS[_r() % 15], False] for _ in range(2000)]
+for _row in _large:
+    _row[1] = _r() % 60 + 20
+    _row[2] = (_r() % 1900) * 10 + 1000
+    _row[4] = bool(_r() % 2)
+op_case("GroupSort_LargeRandomGroupingTest", GS + ":284-350", EMP_SCHEMA, _large, EMP_PLAN, [BOOL, STR, I32, I32], emp_expected(_large), ordered=False)
+
+GRADES = [[i, g] for i, g in zip(range(1, 9), [4.5, 4.2, 3.5, 4.8, 4.2, 3.9, 3.2, 4.8])]
+op_case("GroupSort_SmallSortingTest", GS + ":532-541", [["id", I32, False], ["grade", F64, False]], GRADES,
+        ["Sort", [["grade", "ASCENDING"]], None, "INPUT"], [I32, F64], sorted(GRADES, key=lambda r: r[1]), ordered=False)
+CASES[-1]["sorted_on"] = [1]     # the fixture checks order on the key and the multiset of rows (ties are unordered: sort.h:42)
+_r = _lcg(77)
+_grades = [[i + 1, 4.0 * (_r() % (1 << 31)) / float((1 << 31) - 1) + 1.0] for i in range(3000)]
+op_case("GroupSort_LargeSortingTest", GS + ":543-556", [["id", I32, False], ["grade", F64, False]], _grades,
+        ["Sort", [["grade", "ASCENDING"]], None, "INPUT"], [I32, F64], sorted(_grades, key=lambda r: r[1]), ordered=False)
+CASES[-1]["sorted_on"] = [1]
+
+# ---- test/smoke_test.cc:79-104: Plus over a two-row table, named attributes -----------------------------------------
+op_case("Smoke_ExpressionTest", "test/smoke_test.cc:79-104", [["a", I32, True], ["b", I32, True]], [[1, 2], [3, 5]],
+        ["Compute", ["Plus", ["NamedAttribute", "a"], ["NamedAttribute", "b"]], "INPUT"], [I32], [[3], [8]])
+
+# ---- vector_primitives_test.cc: the column primitives under the expressions (wrap-around adds :33-71; the typed fixtures
+# ---- :490-507,557-562 check every element against the C++ operator on random data -- restated with a fixed generator and
+# ---- the same per-element operator) ------------------------------------------------------------------------------------
+VP = "supersonic/expression/vector/vector_primitives_test.cc"
+IMAX, IMIN = 2147483647, -2147483648
+expr_case("VectorPrimitive_AddDirect", VP + ":33-51", [I32, I32, I32], [[1, 1, 2], [IMAX, IMIN, -1], [-5, 0, -5], [0, 0, 0], [IMAX, 1, IMIN]], "Plus", nullable=False)
+expr_case("VectorPrimitive_AddIndirect", VP + ":53-68", [I32, I32, I32], [[1, 1, 2], [IMAX, 0, IMAX], [-5, 0, -5], [0, IMIN, IMIN], [IMAX, 1, IMIN]], "Plus", nullable=False)
+
+
+def _wrap(v, t):
+    if t == I32:
+        return (v + (1 << 31)) % (1 << 32) - (1 << 31)
+    if t == U32:
+        return v % (1 << 32)
+    if t == I64:
+        return (v + (1 << 63)) % (1 << 64) - (1 << 63)
+    return v
+
+
+def _f32(x):
+    import struct
+    return struct.unpack("f", struct.pack("f", x))[0]
+
+
+_r = _lcg(424242)
+for _opn, _fac, _fn in (("ADD", "Plus", lambda a, b: a + b), ("SUBTRACT", "Minus", lambda a, b: a - b), ("MULTIPLY", "Multiply", lambda a, b: a * b)):
+    for _t in (I32, U32, I64, F64, F32):
+        _rows = []
+        for _ in range(64):
+            if _t in (F64, F32):
+                a, b = (_r() % 2000001 - 1000000) / 64.0, (_r() % 2000001 - 1000000) / 128.0     # exact in FLOAT too
+                if _t == F32:
+                    a, b = _f32(a), _f32(b)
+                    _rows.append([a, b, _f32(_fn(a, b))])
+                else:
+                    _rows.append([a, b, _fn(a, b)])
+            else:
+                bits = 64 if _t == I64 else 32
+                a = _wrap(_r() | (_r() << 31) | (_r() << 62), _t) if bits == 64 else _wrap(_r() | (_r() << 31), _t)
+                b = _wrap(_r() | (_r() << 31) | (_r() << 62), _t) if bits == 64 else _wrap(_r() | (_r() << 31), _t)
+                _rows.append([a, b, _wrap(_fn(a, b), _t)])
+        expr_case("VectorPrimitive_%s_%s" % (_opn, _t), VP + ":490-507", [_t, _t, _t], _rows, _fac, nullable=False)
+_rows = [[(_r() % 2000001 - 1000000) / 64.0, float(_r() % 1000 + 1)] for _ in range(64)]
+expr_case("VectorPrimitive_DIVIDE_SIGNALING_DOUBLE", VP + ":557", [F64, F64, F64], [[a, b, a / b] for a, b in _rows], "DivideSignaling", nullable=False)
+for _n, _fac, _fn in (("OR", "Or", lambda a, b: a or b), ("AND", "And", lambda a, b: a and b), ("AND_NOT", "AndNot", lambda a, b: (not a) and b)):
+    expr_case("VectorPrimitive_%s_BOOL" % _n, VP + ":560-562", [BOOL, BOOL, BOOL],
+              [[a, b, _fn(a, b)] for a in (False, True) for b in (False, True)], _fac, nullable=False)
+# integer division skips rows whose divisor is zero (RunDirectSkipRightZeroTest, :512-555): those rows are NULL in the nulling form
+_rows = [[_wrap(_r() | (_r() << 31), I32), (_r() % 7) - 3] for _ in range(50)]
+expr_case("VectorPrimitive_DIVIDE_INT32_SkipRightZero", VP + ":508-522", [I32, I32, I32],
+          [[a, b, None if b == 0 else _wrap(int(abs(a) // abs(b)) * (1 if (a < 0) == (b < 0) else -1), I32)] for a, b in _rows], "CppDivideNulling", nullable=False)
+
+# ---- binary_column_computers_test.cc:116-235: nullers and failers of the division family over a DOUBLE block; the skip vector of
+# ---- the fixture = the incoming NULLs of the left argument ---------------------------------------------------------------
+BC = "supersonic/expression/vector/binary_column_computers_test.cc"
+expr_case("BinaryComputers_BinaryTrivialNuller", BC + ":116-129", [F64, F64, F64], [[None if i % 2 == 0 else 1.0, 1.0, None if i % 2 == 0 else 1.0] for i in range(5)], "DivideSignaling")
+expr_case("BinaryComputers_BinaryNuller", BC + ":131-144", [F64, F64, F64],
+          [[None if i % 2 == 0 else 1.0, 0.0 if i < 2 else 1.0, None if (i % 2 == 0 or i < 2) else 1.0] for i in range(5)], "DivideNulling")
+expr_case("BinaryComputers_CheckAndNullFailureCount", BC + ":146-163", [F64, F64, F64], [[None if i % 2 == 0 else 1.0, 0.0, None] for i in range(5)], "DivideSignaling", expect_error=104)
+expr_case("BinaryComputers_CheckAndNull", BC + ":165-181", [F64, F64, F64],
+          [[None if i % 3 == 0 else 1.0, 0.0 if i % 2 == 0 else 1.0, None if (i % 2 == 0 or i % 3 == 0) else 1.0] for i in range(5)], "DivideNulling")
+expr_case("BinaryComputers_EvaluationFailure", BC + ":183-193", [F64, F64, F64], [[1.0, 0.0 if i == 3 else 1.0, None] for i in range(5)], "DivideSignaling", expect_error=104)
+expr_case("BinaryComputers_NonSelectiveCalculation", BC + ":195-213", [F64, F64, F64],
+          [[None if i > 3 else 1.0, float(i), None if (i == 0 or i > 3) else 1.0 / i] for i in range(5)], "DivideNulling")
+expr_case("BinaryComputers_SelectiveCalculation", BC + ":215-233", [F64, F64, F64], [[1.0, i + 1.0, 1.0 / (i + 1.0)] for i in range(5)], "CppDivideSignaling")
+
+# ---- aggregation_operators_test.cc: the per-value operators under the aggregates, restated as ScalarAggregate over a column whose
+# ---- first value is the operator's starting result -----------------------------------------------------------------------
+AO = "supersonic/base/infrastructure/aggregation_operators_test.cc"
+op_case("AggregationOperators_Sum_UINT32_to_INT64", AO + ":152-162", cols([U32]), [[1], [30]],
+        ["ScalarAggregate", [["SUM", "col0", "s", I64]], "INPUT"], [I64], [[31]])
+op_case("AggregationOperators_Max_FLOAT", AO + ":164-178", cols([F32]), [[0.0], [1.0], [0.5], ["-inf"]],
+        ["ScalarAggregate", [["MAX", "col0", "m"]], "INPUT"], [F32], [[1.0]])
+op_case("AggregationOperators_Max_FLOAT_inf", AO + ":164-178", cols([F32]), [[0.0], [1.0], [0.5], ["-inf"], ["inf"]],
+        ["ScalarAggregate", [["MAX", "col0", "m"]], "INPUT"], [F32], [["inf"]])
+op_case("AggregationOperators_MaxNoCastArguments", AO + ":200-210", cols([I32]), [[0], [1], [-1]],
+        ["ScalarAggregate", [["MAX", "col0", "m", U32]], "INPUT"], [U32], [[1]])
+op_case("AggregationOperators_MinForStrings", AO + ":212-227", cols([STR]), [["weasel"], ["zebra"], ["gnu"], ["hippopotamus"], ["antelope (a big one)"]],
+        ["ScalarAggregate", [["MIN", "col0", "m"]], "INPUT"], [STR], [["antelope (a big one)"]])
+op_case("AggregationOperators_MinForStrings_prefix", AO + ":212-224", cols([STR]), [["weasel"], ["zebra"], ["gnu"], ["hippopotamus"]],
+        ["ScalarAggregate", [["MIN", "col0", "m"]], "INPUT"], [STR], [["gnu"]])
+op_case("AggregationOperators_First", AO + ":275-285", cols([I32]), [[7], [1], [9]], ["ScalarAggregate", [["FIRST", "col0", "f"]], "INPUT"], [I32], [[7]])
+op_case("AggregationOperators_Last", AO + ":287-297", cols([I32]), [[7], [1], [9]], ["ScalarAggregate", [["LAST", "col0", "l"]], "INPUT"], [I32], [[9]])
+op_case("AggregationOperators_CrossTypeAssignment", AO + ":35-42", cols([I32]), [[1]],
+        ["ScalarAggregate", [["FIRST", "col0", "f", I64]], "INPUT"], [I64], [[1]])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
     with open(out, "w") as f:

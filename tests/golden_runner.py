@@ -169,6 +169,9 @@ def check(case, schema, cols):
         got.append(row)
     want = [[_value(v) for v in r] for r in exp["rows"]]
     assert len(got) == len(want), "row count %d != %d" % (len(got), len(want))
+    if case.get("sorted_on"):   # the guide's sort fixtures: non-decreasing on the key columns, ties in any order (sort.h:42)
+        for r in range(1, len(got)):
+            assert tuple(got[r - 1][c] for c in case["sorted_on"]) <= tuple(got[r][c] for c in case["sorted_on"]), "row %d out of order" % r
     if not case["ordered"]:
         got, want = sorted(got, key=_row_key), sorted(want, key=_row_key)
     for r, (g, w) in enumerate(zip(got, want)):

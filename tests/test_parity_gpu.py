@@ -998,3 +998,30 @@ def test_round_with_precision(gpu_ctx, n):
          .AddAs("rf", ss.RoundWithPrecision(NA("f"), ss.ConstInt32(1))))
     run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
     run_both(ss.Compute(ss.CompoundExpression().AddAs("rp", ss.RoundWithPrecision(NA("x"), NA("p"))), ss.ScanView(view)), gpu_ctx, max_ulp=LIBM_ULP)
+
+
+def test_float_min_max_ignore_nan_wherever_it_stands(gpu_ctx):
+    # include/ssgpu.h, "floating aggregates": the reference keeps a LEADING NaN and skips later ones
+    # (aggregation_operators.h:200,221: "if (val < result) result = val"); the device result does not depend on the
+    # row order -- NaN rows never contribute; a group of only NaN rows gives NaN (ScalarAggregate: +inf / -inf).
+    nan = float("nan")
+    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("x", ss.DOUBLE), ss.Attribute("f", ss.FLOAT, ss.NULLABLE)])
+    g = np.array([0, 0, 0, 1, 1, 1, 2, 2, 3], np.int32)
+    x = np.array([nan, 2.0, -1.0, 5.0, nan, 7.0, nan, nan, 4.0])
+    f = np.array([nan, 2.0, -1.0, 5.0, nan, 7.0, nan, nan, 4.0], np.float32)
+    fz = np.array([False, False, False, False, False, True, False, False, False])
+    view = ss.View(schema, [g, x, ss.Column(f, fz)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.MIN, "x", "lo").AddAggregation(ss.MAX, "x", "hi")
+            .AddAggregation(ss.MIN, "f", "flo").AddAggregation(ss.MAX, "f", "fhi"))
+    got = ss.drain(ss.Sort(ss.SortOrder().add("g", ss.ASCENDING), None, 0,
+                           ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(view))).CreateCursor(gpu_ctx))
+    lo, hi, flo, fhi = [got.column(i).data for i in (1, 2, 3, 4)]
+    assert list(lo[[0, 1, 3]]) == [-1.0, 5.0, 4.0] and list(hi[[0, 1, 3]]) == [2.0, 7.0, 4.0]
+    assert list(flo[[0, 1, 3]]) == [-1.0, 5.0, 4.0] and list(fhi[[0, 1, 3]]) == [2.0, 5.0, 4.0]
+    assert np.isnan(lo[2]) and np.isnan(hi[2]) and np.isnan(flo[2]) and np.isnan(fhi[2])
+    sc = ss.drain(ss.ScalarAggregate(spec, ss.ScanView(view)).CreateCursor(gpu_ctx))
+    assert [float(sc.column(i).data[0]) for i in range(4)] == [-1.0, 7.0, -1.0, 5.0]
+    only_nan = ss.View(schema, [g[6:8], x[6:8], ss.Column(f[6:8], fz[6:8])])
+    sc = ss.drain(ss.ScalarAggregate(spec, ss.ScanView(only_nan)).CreateCursor(gpu_ctx))
+    # no value at all contributes: the scalar accumulators keep their identities (the group tables' identities decode to NaN)
+    assert [float(sc.column(i).data[0]) for i in range(4)] == [float("inf"), float("-inf"), float("inf"), float("-inf")]
