@@ -966,11 +966,13 @@ def MemoryLimit(quota, context=None):
 class Plan(object):
     """A bound plan (ssgpu_plan): owns the device programs and result buffers."""
 
-    def __init__(self, operation, context):
+    def __init__(self, operation, context, extra_strings=None):
+        """extra_strings: further byte strings for the plan's dictionary -- what a sharded job passes so that every rank
+        builds the SAME dictionary (codes of STRING columns are then comparable across ranks)."""
         self.ctx = context
         self.lib = context.lib
         b = _Builder()
-        b.strings = self.strings = StringDictionary(collect_strings(operation))
+        b.strings = self.strings = StringDictionary(list(collect_strings(operation)) + [_as_bytes(v) for v in (extra_strings or [])])
         operation._emit(b)
         if b.scan is None:
             raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "plan has no ScanView")

@@ -38,6 +38,28 @@ def _merge_spec(spec):
     return merged, counts
 
 
+def job_strings(local_strings, group=None):
+    """Every byte string any rank's plan can meet, in one sorted list that is the same on all ranks: plans created with
+    it as `extra_strings` build identical order-preserving dictionaries, so the INT32 codes of STRING columns mean the
+    same thing on every rank and can cross shards like any other column (set-up only: one all_gather_object)."""
+    import torch.distributed as dist
+    mine = sorted(set(v.encode() if isinstance(v, str) else bytes(v) for v in local_strings))
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    return sorted(set().union(*[set(x) for x in everyone]))
+
+
+def _has_strings(schema):
+    return any(schema.attribute(i).type() == ss.STRING for i in range(schema.attribute_count()))
+
+
+def _gather_objects(values, group):
+    import torch.distributed as dist
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, list(values), group=group)
+    return everyone
+
+
 def _all_gather_view(view, group, device):
     """Concatenate every rank's View (same schema) in rank order."""
     import torch
@@ -53,6 +75,16 @@ def _all_gather_view(view, group, device):
     for i in range(view.column_count()):
         col = view.column(i)
         parts = []
+        if view.schema().attribute(i).type() == ss.STRING:   # host Views hold the byte strings themselves
+            chunks = _gather_objects([bytes(v) if v is not None else b"" for v in col.data], group)
+            data = np.empty(sum(counts), dtype=object)
+            data[:] = [v for chunk in chunks for v in chunk]
+            nulls = None
+            if view.schema().attribute(i).is_nullable():
+                zs = _gather_objects((col.is_null if col.is_null is not None else np.zeros(view.row_count(), bool)).tolist(), group)
+                nulls = np.array([z for chunk in zs for z in chunk], dtype=bool)
+            cols.append(ss.Column(data, nulls))
+            continue
         for arr, present in ((col.data, True), (col.is_null, col.is_null is not None)):
             # every rank must issue the same collectives: nullability comes from the schema
             if arr is None and not view.schema().attribute(i).is_nullable():
@@ -167,8 +199,19 @@ def _all_to_all_views(parts, schema, group, device):
     cols = []
     for i in range(schema.attribute_count()):
         np_dtype = parts[0].column(i).data.dtype
-        if np_dtype == object:
-            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
+        if schema.attribute(i).type() == ss.STRING:
+            # host Views hold the byte strings themselves: every rank publishes its per-destination lists and keeps its own
+            mine = [[bytes(v) if v is not None else b"" for v in p.column(i).data] for p in parts]
+            everyone = _gather_objects(mine, group)
+            data = np.empty(sum(recv), dtype=object)
+            data[:] = [v for src in range(world) for v in everyone[src][rank]]
+            nulls = None
+            if schema.attribute(i).is_nullable():
+                zmine = [(p.column(i).is_null if p.column(i).is_null is not None else np.zeros(p.row_count(), bool)).tolist() for p in parts]
+                zs = _gather_objects(zmine, group)
+                nulls = np.array([z for src in range(world) for z in zs[src][rank]], dtype=bool)
+            cols.append(ss.Column(data, nulls))
+            continue
         bufs = []
         for which in (0, 1):
             if which == 1 and not schema.attribute(i).is_nullable():
@@ -263,12 +306,15 @@ def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_ran
     device = torch.device("cuda", torch.cuda.current_device())
     schema = local_view.schema()
     n_attrs = schema.attribute_count()
-    widths = []
-    for i in range(n_attrs):
-        if schema.attribute(i).type() == ss.STRING:
-            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
-        widths.append(np.dtype(ss.numpy_dtype(schema.attribute(i).type())).itemsize)
-    first = ss.Plan(ss.Sort(sort_order, None, 0, ss.ScanView(local_view)), ctx)
+    widths = [4 if schema.attribute(i).type() == ss.STRING else np.dtype(ss.numpy_dtype(schema.attribute(i).type())).itemsize
+              for i in range(n_attrs)]
+    strings = None
+    if _has_strings(schema):
+        # STRING columns travel as the INT32 codes of ONE dictionary that every rank builds identically
+        if not isinstance(local_view, ss.View):
+            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns of a DeviceView carry their caller's dictionary: shard host Views")
+        strings = job_strings(ss.collect_strings(ss.ScanView(local_view)), group)
+    first = ss.Plan(ss.Sort(sort_order, None, 0, ss.ScanView(local_view)), ctx, strings)
     first.run()
     ctx.synchronize()
     local = first.result_device_view()
@@ -307,7 +353,7 @@ def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_ran
     parts = []
     for d in range(world):
         pl = ss.Plan(ss.Filter(_range_predicate(key, attr.type(), attr.is_nullable(), splitters, d, world, descending),
-                               ss.ProjectAllAttributes(), ss.ScanView(local)), ctx)
+                               ss.ProjectAllAttributes(), ss.ScanView(local)), ctx, strings)
         pl.run()
         parts.append((pl, pl.result_device_view()))
     ctx.synchronize()
@@ -332,7 +378,7 @@ def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_ran
             ptrs.append(t_out.data_ptr())
         arrived.append((ptrs[0], ptrs[1]))
     torch.cuda.synchronize()
-    final = ss.Plan(ss.Sort(sort_order, None, 0, ss.ScanView(ss.DeviceView(schema, arrived, sum(recv)))), ctx)
+    final = ss.Plan(ss.Sort(sort_order, None, 0, ss.ScanView(ss.DeviceView(schema, arrived, sum(recv)))), ctx, strings)
     final.run()
     ctx.synchronize()
     del keep, parts
@@ -362,11 +408,15 @@ class DeviceShardedGroupAggregate(object):
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.group_by = list(group_by)
         self.merged_spec, self.counts = _merge_spec(spec)
-        self.first = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(self.group_by), spec, None, local_child), ctx)
-        schema = self.first.result_schema
-        for i in range(schema.attribute_count()):
-            if schema.attribute(i).type() == ss.STRING:
-                raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "STRING columns cannot cross shards yet")
+        op = ss.GroupAggregate(ss.ProjectNamedAttributes(self.group_by), spec, None, local_child)
+        # STRING keys / MIN / MAX results travel as the INT32 codes of ONE dictionary that every rank builds identically
+        # (decided by the result schema, which is the same on all ranks: every rank issues the same collectives)
+        self.strings = None
+        probe = ss.Plan(op, ctx)
+        if _has_strings(probe.result_schema) or _has_strings(probe.input.schema()):
+            self.strings = job_strings(ss.collect_strings(op), group)
+            probe = ss.Plan(op, ctx, self.strings)
+        self.first = probe
         self.capacity = int(capacity_rows)
         self.merge = None
         self.collectives = 0
@@ -409,7 +459,7 @@ class DeviceShardedGroupAggregate(object):
         everyone = self.first.unpack_images(self.images.data_ptr(), self.world, self.capacity, self.unpacked.data_ptr())
         if self.merge is None:
             self.merge = ss.Plan(_merge_plan(self.group_by, self.merged_spec, self.counts, self.first.result_schema, everyone,
-                                             valid="__valid"), self.ctx)
+                                             valid="__valid"), self.ctx, self.strings)
         self.merge.run(everyone)
         return self.merge
 

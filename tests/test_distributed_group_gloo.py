@@ -94,3 +94,77 @@ def test_sharded_group_aggregate_over_gloo(n, with_filter, empty_rank):
     for _rank, schema, cols in results:           # every rank holds the full answer
         assert [tuple(x) for x in schema] == [tuple(x) for x in want_schema]
         assert_cols_equal(sort_rows(cols), sort_rows(want), context="sharded group aggregate")
+
+
+# ---- STRING keys and STRING MIN / MAX across shards: host Views carry the byte strings themselves ---------------------
+WORDS = [b"pear", b"apple", b"fig", b"kiwi", b"", b"apple pie", b"zebra\x00x"]
+
+
+def make_string_view(n, seed=5):
+    rng = np.random.default_rng(seed)
+    schema = ss.TupleSchema([ss.Attribute("name", ss.STRING, ss.NULLABLE), ss.Attribute("v", ss.INT64), ss.Attribute("tag", ss.STRING)])
+    names = np.empty(n, dtype=object); names[:] = [WORDS[i] for i in rng.integers(0, len(WORDS), n)]
+    tags = np.empty(n, dtype=object); tags[:] = [WORDS[i] for i in rng.integers(0, len(WORDS), n)]
+    return ss.View(schema, [ss.Column(names, rng.random(n) < 0.1), rng.integers(-50, 50, n), tags])
+
+
+def string_spec():
+    return (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "sv").AddAggregation(ss.MIN, "tag", "lo")
+            .AddAggregation(ss.MAX, "tag", "hi").AddAggregation(ss.COUNT, "", "n"))
+
+
+def string_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = make_string_view(n)
+    bounds = [0, n // 4, n]
+    out = sharded_group_aggregate(["name"], string_spec(), ss.ScanView(shard_of(full, bounds[rank], bounds[rank + 1])), oracle_executor)
+    q.put((rank, [(out.column(i).data, out.column(i).is_null) for i in range(out.column_count())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_group_aggregate_with_string_columns_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=string_worker, args=(r, 2, port, 5003, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _schema, want = oracle.run(ss.GroupAggregate(ss.ProjectNamedAttributes(["name"]), string_spec(), None, ss.ScanView(make_string_view(5003))))
+    for _rank, cols in results:
+        assert_cols_equal(sort_rows(cols), sort_rows(want), context="sharded group aggregate, STRING key")
+
+
+def test_job_strings_agree_across_ranks():
+    from supersonic_amd.distributed import job_strings
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=job_strings_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == sorted([b"", b"a", b"b", b"c", b"zz"])
+    # plans created with the job's strings give every rank the same order-preserving codes
+    d0 = ss.StringDictionary(got[0])
+    assert [d0.code_of(w) for w in got[0]] == list(range(len(got[0])))
+    assert job_strings is not None
+
+
+def job_strings_worker(rank, world, port, q):
+    from supersonic_amd.distributed import job_strings
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, job_strings([b"b", "a", b"zz"] if rank == 0 else [b"c", b"", b"a"])))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -118,3 +118,47 @@ def test_range_predicates_keep_nan_keys():
                 _s, cols = oracle.run(ss.Filter(pred, ss.ProjectAllAttributes(), ss.ScanView(view)))
                 seen[cols[1][0]] += 1
             assert (seen == 1).all()
+
+
+# ---- STRING payload columns cross the all-to-all (host Views carry the byte strings themselves) -----------------------
+def make_string_view(n, seed=9):
+    rng = np.random.default_rng(seed)
+    words = [b"pear", b"apple", b"fig", b"", b"kiwi\x00k", b"zebra"]
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("s", ss.STRING, ss.NULLABLE), ss.Attribute("id", ss.INT64)])
+    s = np.empty(n, dtype=object); s[:] = [words[i] for i in rng.integers(0, len(words), n)]
+    return ss.View(schema, [rng.integers(-50, 50, n), ss.Column(s, rng.random(n) < 0.15), np.arange(n)])
+
+
+def string_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = make_string_view(n)
+    bounds = [0, n // 3, n]
+    so = ss.SortOrder().add("k", ss.ASCENDING).add("s", ss.DESCENDING)
+    out = sharded_sort(so, ss.ScanView(shard_of(full, bounds[rank], bounds[rank + 1])), oracle_executor)
+    q.put((rank, [(out.column(i).data, out.column(i).is_null) for i in range(out.column_count())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sort_with_string_columns_over_gloo():
+    n = 4001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=string_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    so = ss.SortOrder().add("k", ss.ASCENDING).add("s", ss.DESCENDING)
+    _schema, want = oracle.run(ss.Sort(so, None, 0, ss.ScanView(make_string_view(n))))
+    got = []
+    for c in range(len(want)):
+        data = np.concatenate([results[r][c][0] for r in range(2)])
+        nulls = [results[r][c][1] for r in range(2)]
+        got.append((data, None if nulls[0] is None else np.concatenate(nulls)))
+    assert_cols_equal(got, want, context="sharded sort, STRING payload and second key")
