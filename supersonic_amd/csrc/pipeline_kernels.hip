@@ -1963,6 +1963,12 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
             const bool in1 = w1 < words;
             const u32 g0 = grec[j0], g1 = in1 ? grec[j1] : VM_NONE;
             const u64 v0 = stage[w0], v1 = in1 ? stage[w1] : 0ull;
+            if (P.part_pad) {   // development (ctx option part_scatter_debug): the same bytes written sequentially -- how much
+              const u64 seq = (u64)tile * (u32)(VM_TILE_UNIT * K) * wpr;   // of the pass is the scatter?  (3.08 -> 1.45 ms)
+              if (g0 != VM_NONE) out[seq + w0] = v0;
+              if (g1 != VM_NONE) out[seq + w1] = v1;
+              continue;
+            }
             if (g0 != VM_NONE) out[(u64)g0 * wpr + (w0 - j0 * wpr)] = v0;
             if (g1 != VM_NONE) out[(u64)g1 * wpr + (w1 - j1 * wpr)] = v1;
           }
@@ -2494,6 +2500,8 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   const u32 seg_cap = P.seg_cap, n_aggs = P.n_aggs;
   const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
   u32 seg = 0;
+  // (fetching step i + 1's records while step i is aggregated -- one record per lane per step, two sets in registers to stay
+  // under 64 VGPRs -- was tried: 2.95 ms instead of 1.85 ms for config #3; two records per lane and no prefetch it stays)
   for (u32 base = 0; base < total; base += SSGPU_PART_THREADS * PART_ROWS) {
     Rec rec[PART_ROWS]; bool live[PART_ROWS]; u32 li[PART_ROWS];
 #pragma unroll

@@ -50,6 +50,8 @@ struct ssgpu_ctx {
   int64_t part_agg_debug = 0;
   int64_t sort_records = 1;      // 0: always gather payload columns one by one
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
+  int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
+  int64_t sort_hi_digits = 4;    // high digits the hybrid sort passes over before fixing ties: 2..4, 0 = by row count
   int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
   int64_t profile = 1;           // record HIP events around kernels
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
@@ -262,8 +264,10 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_lds_target") c->part_lds_target = value;
   else if (k == "part_agg_lds") c->part_agg_lds = value;
   else if (k == "part_agg_debug") c->part_agg_debug = value;
+  else if (k == "part_scatter_debug") c->part_scatter_debug = value;
   else if (k == "sort_records") c->sort_records = value;
   else if (k == "sort_hybrid") c->sort_hybrid = value;
+  else if (k == "sort_hi_digits") c->sort_hi_digits = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -1091,6 +1095,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.error_flag = ex.error_flag.as<unsigned int>();
     Ps.tile_counts = ex.part_hist.as<unsigned int>();
     Ps.part_seg_cap = (uint32_t)seg_cap;
+    Ps.part_pad = (uint32_t)c->part_scatter_debug;
     Ps.part_overflow = ex.goverflow.as<unsigned int>() + 1;
     Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
     { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
@@ -1373,12 +1378,18 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     bool done = false;
     if (c->sort_hybrid && w == 8 && k == (int)st.sort_keys.size() - 1 && (varying & 0xFFFFFFFFull) && !(nulls && st.in_schema[sk.col].nullable) &&
         n >= (1u << 16)) {
+      // how many high digits: as few as keep the expected run of equal high parts short (n / 256^d <= 8 rows for
+      // uniform keys: 3 digits up to 134 M rows), never fewer than 2 nor more than 4
+      uint32_t hi_digits = 4;
+      if (c->sort_hi_digits >= 2 && c->sort_hi_digits <= 4) hi_digits = (uint32_t)c->sort_hi_digits;
+      else if (c->sort_hi_digits == 0) { hi_digits = 2; while (hi_digits < 4 && (double)n / std::pow(256.0, (double)hi_digits) > 8.0) ++hi_digits; }
+      const uint32_t first_pass = 8 - hi_digits;
       bool high_busy = true;
-      for (uint32_t pass = 4; pass < 8; ++pass) high_busy = high_busy && ((varying >> (pass * 8)) & 0xFFull) != 0;
+      for (uint32_t pass = first_pass; pass < 8; ++pass) high_busy = high_busy && ((varying >> (pass * 8)) & 0xFFull) != 0;
       if (high_busy) {
-        for (uint32_t pass = 4; pass < 8; ++pass) { rc = one_pass(pass); if (rc != SSGPU_OK) return rc; }
+        for (uint32_t pass = first_pass; pass < 8; ++pass) { rc = one_pass(pass); if (rc != SSGPU_OK) return rc; }
         uint32_t* flag = ex.sticket.as<uint32_t>() + 62;
-        HIP_TRY(c, ssgpu_launch_sort_fix_ties(ka, ia, n, 32, flag, c->stream));
+        HIP_TRY(c, ssgpu_launch_sort_fix_ties(ka, ia, n, first_pass * 8, flag, c->stream));
         uint32_t too_long = 0;
         HIP_TRY(c, hipMemcpyAsync(&too_long, flag, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
