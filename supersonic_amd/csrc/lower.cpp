@@ -223,6 +223,20 @@ Status Emitter::cast_val(const Val& v, MT from, MT to, Val* out) {
   else if (from == M_U64 && to == M_F64) op = VM_CAST_U64_F64;
   else if (from == M_F32 && to == M_F64) op = VM_CAST_F32_F64;
   else if (from == M_F64 && to == M_F32) op = VM_CAST_F64_F32;
+  else if ((from == M_F32 || from == M_F64) && (to64 || to32)) {
+    // C++ static_cast<integer>(floating) = truncation toward zero (what an aggregate into an integer result type stores,
+    // aggregation_operators.h:100-122): TRUNC, then the exact conversion of the integral value (x86 cvttsd2si for the
+    // out-of-range cases, like FLOOR_TO_INT), then the bits of the narrower type
+    Val t = v;
+    t.reg = unop(from == M_F32 ? VM_TRUNC_F32 : VM_TRUNC_F64, t, mwidth(from)); t.imm = false;
+    Val i64v = t;
+    i64v.reg = unop(from == M_F32 ? VM_FLOOR2I_F32 : VM_FLOOR2I_F64, t, 8); i64v.width = 8;
+    if (to64) { *out = i64v; out->null = v.null; return Status::OK(); }
+    Val n = i64v;
+    n.reg = unop(VM_CAST_I64_I32, i64v, 4); n.width = 4; n.null = v.null;
+    *out = n;
+    return Status::OK();
+  }
   else return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "cast not available on device");
   Val src = v;
   out->reg = unop(op, src, mwidth(to));
@@ -821,8 +835,12 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
         return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE,
                              std::string("Aggregation not supported. Aggregation function not defined for types ") +
                                  dtype_name(it) + " and " + dtype_name(p.out_type) + ".");
-      if (dtype_is_float(it) && dtype_is_integer(p.out_type))
-        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "floating input aggregated into an integer output is order-dependent; not on device");
+      // floating input into an integer result: MIN / MAX / FIRST / LAST store the truncated value, and because truncation is
+      // monotone the reference's fold (compare the floating value with the integer result, store the cast) gives
+      // min / max of the truncated values whatever the order.  SUM adds a floating value to an integer result and
+      // truncates after EVERY row: order-dependent, not restated on device.
+      if (dtype_is_float(it) && dtype_is_integer(p.out_type) && a.aggregation == SSGPU_SUM)
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output truncates after every row (order-dependent); not on device");
     }
     out->push_back(p);
   }

@@ -2749,22 +2749,54 @@ hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream)
 }
 // GroupAggregate FIRST / LAST: the group's accumulator holds the smallest / largest contributing
 // row id; the result is the input column's value at that row.
+// Value kinds: 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64, 6 one byte.  When the result type differs from the column's
+// (AddAggregationWithDefinedOutputType) the picked value is converted like the assignment the reference performs
+// (AssignmentOperator, aggregation_operators.h:100-122: a C++ conversion; floating -> integer truncates, cvttsd2si's
+// INT64_MIN for NaN / out of range).
 __global__ __launch_bounds__(256) void ssgpu_gather_rowid_kernel(void* __restrict__ dst, const u8* __restrict__ dst_null, const void* __restrict__ src,
-                                                                 u32 width, const u64* __restrict__ rowids, i64 row_id_base,
+                                                                 u32 width, int src_kind, int dst_kind, const u64* __restrict__ rowids, i64 row_id_base,
                                                                  const u64* __restrict__ n_rows_dev, u64 n_rows_max) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 n = n_rows_dev ? *n_rows_dev : n_rows_max;
   if (i >= n || i >= n_rows_max) return;
   const bool isnull = dst_null && dst_null[i];
   const u64 r = isnull ? 0ull : (u64)((i64)rowids[i] - row_id_base);
-  if (width == 8) reinterpret_cast<u64*>(dst)[i] = isnull ? 0ull : reinterpret_cast<const u64*>(src)[r];
-  else if (width == 4) reinterpret_cast<u32*>(dst)[i] = isnull ? 0u : reinterpret_cast<const u32*>(src)[r];
-  else reinterpret_cast<u8*>(dst)[i] = isnull ? (u8)0 : reinterpret_cast<const u8*>(src)[r];
+  if (src_kind == dst_kind) {
+    if (width == 8) reinterpret_cast<u64*>(dst)[i] = isnull ? 0ull : reinterpret_cast<const u64*>(src)[r];
+    else if (width == 4) reinterpret_cast<u32*>(dst)[i] = isnull ? 0u : reinterpret_cast<const u32*>(src)[r];
+    else reinterpret_cast<u8*>(dst)[i] = isnull ? (u8)0 : reinterpret_cast<const u8*>(src)[r];
+    return;
+  }
+  // widen to (i64 | u64 | f64), then narrow to the result type
+  i64 vi = 0; u64 vu = 0; double vf = 0.0; int fam = 0;     // 0 signed, 1 unsigned, 2 floating
+  if (!isnull) switch (src_kind) {
+    case 0: vi = reinterpret_cast<const i32*>(src)[r]; fam = 0; break;
+    case 1: vu = reinterpret_cast<const u32*>(src)[r]; fam = 1; break;
+    case 2: vi = reinterpret_cast<const i64*>(src)[r]; fam = 0; break;
+    case 3: vu = reinterpret_cast<const u64*>(src)[r]; fam = 1; break;
+    case 4: vf = (double)reinterpret_cast<const float*>(src)[r]; fam = 2; break;
+    case 5: vf = reinterpret_cast<const double*>(src)[r]; fam = 2; break;
+    default: vu = reinterpret_cast<const u8*>(src)[r]; fam = 1; break;
+  }
+  if (dst_kind == 4 || dst_kind == 5) {
+    const double d = fam == 2 ? vf : (fam == 1 ? (double)vu : (double)vi);
+    if (dst_kind == 5) reinterpret_cast<double*>(dst)[i] = d;
+    else reinterpret_cast<float*>(dst)[i] = fam == 2 ? (float)vf : (fam == 1 ? (float)vu : (float)vi);
+    return;
+  }
+  u64 bits;
+  if (fam == 2) {
+    const double tr = trunc(vf);
+    bits = (tr >= -9223372036854775808.0 && tr < 9223372036854775808.0) ? (u64)(i64)tr : 0x8000000000000000ull;   // NaN fails both tests
+  } else bits = fam == 1 ? vu : (u64)vi;
+  if (dst_kind == 2 || dst_kind == 3) reinterpret_cast<u64*>(dst)[i] = bits;
+  else if (dst_kind == 0 || dst_kind == 1) reinterpret_cast<u32*>(dst)[i] = (u32)bits;
+  else reinterpret_cast<u8*>(dst)[i] = (u8)bits;
 }
-hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, const uint64_t* rowids,
+hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, int src_kind, int dst_kind, const uint64_t* rowids,
                                      int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream) {
   if (n_rows_max) hipLaunchKernelGGL(ssgpu_gather_rowid_kernel, dim3((unsigned)((n_rows_max + 255) / 256)), dim3(256), 0, stream,
-                                     dst, dst_null, src, width, (const u64*)rowids, (i64)row_id_base, (const u64*)n_rows_dev, (u64)n_rows_max);
+                                     dst, dst_null, src, width, src_kind, dst_kind, (const u64*)rowids, (i64)row_id_base, (const u64*)n_rows_dev, (u64)n_rows_max);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream) {

@@ -947,8 +947,16 @@ static int gather_first_last(ssgpu_plan* p, Stage& st, StageExec& ex, size_t nk,
   for (size_t j = 0; j < st.aggs.size(); ++j) {
     const int col = st.aggs[j].gather_col;
     if (col < 0) continue;
+    auto kind_of = [](int dtype) {   // 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64, 6 one byte (the gather converts between them)
+      switch (dtype) {
+        case SSGPU_INT32: case SSGPU_DATE: case SSGPU_STRING: return 0; case SSGPU_UINT32: return 1;
+        case SSGPU_INT64: case SSGPU_DATETIME: return 2; case SSGPU_UINT64: return 3;
+        case SSGPU_FLOAT: return 4; case SSGPU_DOUBLE: return 5; default: return 6;
+      }
+    };
     HIP_TRY(c, ssgpu_launch_gather_rowid(ex.out[nk + j].data.p, ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr,
-                                         in.cols[col].data, ex.out[nk + j].width, ex.rowid_tmp[j].as<uint64_t>(), row_id_base,
+                                         in.cols[col].data, ex.out[nk + j].width, kind_of(st.in_schema[col].dtype), kind_of(st.out_schema[nk + j].dtype),
+                                         ex.rowid_tmp[j].as<uint64_t>(), row_id_base,
                                          n_rows_dev, n_rows_max, c->stream));
     p->counters.n_launches += 1;
   }

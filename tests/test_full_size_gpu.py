@@ -135,3 +135,44 @@ def test_sort_100m_config5_sortedness_checksum_idempotence(block):
     ctx.synchronize()
     (sd2, sc2), _n = device_columns(torch, device, plan2, ["<i8", "<i8"])
     assert torch.equal(sd2, sd) and torch.equal(sc2, sc)
+
+
+def test_sort_100m_all_eight_columns_rows_stay_together(block):
+    # the shape profiles/r02_sort_kernel_stats.csv times: Sort by d of the whole 8-column block (wide-key hybrid passes, the
+    # payload as packed records).  Properties: sorted on the key; every output row is an input row (a per-row fingerprint
+    # over all 8 columns has the same sum and the same xor before and after); `c` = row id % 100000 is unchanged as a multiset
+    torch, device, ctx, (a, b, c, d, d0, d1, d2, d3), view = block
+    plan = ss.Plan(ss.Sort(ss.SortOrder().add("d", ss.ASCENDING), None, 0, ss.ScanView(view)), ctx)
+    plan.run(view)
+    ctx.synchronize()
+    names = [plan.result_schema.attribute(i).name() for i in range(plan.result_schema.attribute_count())]
+    assert names == ["a", "b", "c", "d", "d0", "d1", "d2", "d3"]
+    outs, n = device_columns(torch, device, plan, ["<i8", "<i8", "<i8", "<i8", "<f8", "<f8", "<f8", "<f8"])
+    assert n == ROWS
+    sa, sb, sc, sd, s0, s1, s2, s3 = outs
+    assert bool((sd[1:] >= sd[:-1]).all().item())
+
+    def fingerprint(cols):
+        h = torch.zeros_like(cols[0])
+        for j, col in enumerate(cols):
+            v = col if col.dtype == torch.int64 else col.view(torch.int64)
+            h = (h * 1000003) ^ (v + (v >> 29) * (7919 + j))      # wrapping int64 arithmetic: order of the columns matters
+        return h
+    h_in, h_out = fingerprint([a, b, c, d, d0, d1, d2, d3]), fingerprint(outs)
+    assert int(h_in.sum().item()) == int(h_out.sum().item())
+    x_in, x_out = h_in[0].clone(), h_out[0].clone()
+    # xor-fold (torch has no xor reduction: fold by halves)
+    for h, name in ((h_in, "in"), (h_out, "out")):
+        t = h
+        while t.numel() > 1:
+            half = t.numel() // 2
+            rest = t[2 * half:]
+            t = t[:half] ^ t[half:2 * half]
+            if rest.numel():
+                t[0] ^= rest[0]
+        if name == "in":
+            x_in = t[0].item()
+        else:
+            x_out = t[0].item()
+    assert x_in == x_out
+    assert torch.equal(torch.bincount(sc, minlength=100000), torch.bincount(c, minlength=100000))

@@ -1064,3 +1064,28 @@ def test_float_min_max_ignore_nan_wherever_it_stands(gpu_ctx):
     sc = ss.drain(ss.ScalarAggregate(spec, ss.ScanView(only_nan)).CreateCursor(gpu_ctx))
     # no value at all contributes: the scalar accumulators keep their identities (the group tables' identities decode to NaN)
     assert [float(sc.column(i).data[0]) for i in range(4)] == [float("inf"), float("-inf"), float("inf"), float("-inf")]
+
+
+@pytest.mark.parametrize("n", [1, 65, 1025, 100003])
+def test_aggregates_into_other_result_types(gpu_ctx, n):
+    # AddAggregationWithDefinedOutputType across type families (column_aggregator.cc:484-532): floating inputs into integer
+    # results store the truncated value (MIN / MAX / FIRST / LAST; SUM is order-dependent there and not on device), integers
+    # into other integer types compare in their own type (aggregation_operators.h:187-228), FIRST / LAST cast the picked value
+    rng = np.random.default_rng(n)
+    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("x", ss.DOUBLE, ss.NULLABLE), ss.Attribute("f", ss.FLOAT),
+                             ss.Attribute("i", ss.INT32), ss.Attribute("u", ss.UINT32), ss.Attribute("w", ss.INT64, ss.NULLABLE)])
+    view = ss.View(schema, [rng.integers(0, 37, n).astype(np.int32), ss.Column(rng.normal(size=n) * 1000.0, rng.random(n) < 0.2),
+                            (rng.normal(size=n) * 100.0).astype(np.float32), rng.integers(0, 1 << 30, n).astype(np.int32),
+                            rng.integers(0, 1 << 31, n).astype(np.uint32), ss.Column(rng.integers(-(1 << 40), 1 << 40, n), rng.random(n) < 0.2)])
+    spec = ss.AggregationSpecification()
+    for agg, col, out, t in ((ss.MIN, "x", "mnx", ss.INT64), (ss.MAX, "x", "mxx", ss.INT32), (ss.MIN, "f", "mnf", ss.INT32), (ss.MAX, "f", "mxf", ss.INT64),
+                             (ss.MAX, "i", "mxi", ss.UINT32), (ss.MIN, "i", "mni", ss.INT64), (ss.MIN, "u", "mnu", ss.INT32), (ss.MAX, "u", "mxu", ss.UINT64),
+                             (ss.MAX, "w", "mxw", ss.DOUBLE), (ss.SUM, "i", "si", ss.INT64), (ss.SUM, "u", "su", ss.DOUBLE)):
+        spec.AddAggregationWithDefinedOutputType(agg, col, out, t)
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    fl = ss.AggregationSpecification()
+    for agg, col, out, t in ((ss.FIRST, "x", "fx", ss.INT64), (ss.LAST, "f", "lf", ss.INT64), (ss.FIRST, "i", "fi", ss.INT64), (ss.LAST, "w", "lw", ss.DOUBLE)):
+        fl.AddAggregationWithDefinedOutputType(agg, col, out, t)
+    run_both(ss.ScalarAggregate(fl, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), fl, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)

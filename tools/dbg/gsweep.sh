@@ -1,4 +1,3 @@
-for q in group3 group; do
-  echo "== $q"; bash tools/kstats.sh pa python bench.py --query $q --no-cpu-baseline --steps 10 --warmup 3 2>&1 | grep "part_agg\|pipeline_kernel\|value" | cut -c1-140
+for o in debug_timing=0 part_rec_align=64 part_rec_align=128; do
+  echo "== $o"; bash tools/kstats.sh pa python bench.py --query group3 --no-cpu-baseline --steps 10 --warmup 3 --opts $o 2>&1 | grep "part_agg\|pipeline_kernel" | cut -c1-140
 done
-timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_double_sum_gpu.py tests/test_full_size_gpu.py -x -q -m gpu -n 4 -k "group or sum" 2>&1 | tail -2
