@@ -174,6 +174,14 @@ class View {
   rowcount_t row_count_;
 };
 
+// Columns that already live in device memory (e.g. the unpacked partial tables of a sharded aggregate, another plan's
+// result): scanned with ScanDeviceView, never copied.  The caller keeps the memory alive while cursors use it.
+struct DeviceView {
+  TupleSchema schema;
+  std::vector<ssgpu_column> columns;   // one (data, is_null) pair of DEVICE pointers per attribute
+  rowcount_t row_count = 0;
+};
+
 // ---- expressions (expression/base/expression.h, core/*_expressions.h) --------------------
 class BoundExpressionTree;
 class BufferAllocator;
@@ -534,11 +542,10 @@ class Cursor {
 
   ResultView Next(rowcount_t max_row_count) {
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
-    if (!ran_) {
-      ran_ = true;
-      int rc = Stage(ctx);
-      if (rc == SSGPU_OK) rc = ssgpu_plan_run_block(plan_, block_, &res_);
+    if (!fetched_) {
+      int rc = RunOnDevice();
       if (rc == SSGPU_OK) rc = internal::FetchResult(res_, schema_, &dict_, &total_, &host_data_, &host_null_, &cells_);
+      fetched_ = true;
       if (rc != SSGPU_OK) { failed_ = true; return ResultView::Failure(new Exception(rc, ssgpu_last_error(ctx))); }
     }
     if (failed_) return ResultView::Failure(new Exception(ERROR_UNKNOWN_ERROR, "cursor already failed"));
@@ -554,10 +561,27 @@ class Cursor {
     return ResultView::Success(view_.get());
   }
 
+  // Runs the plan and leaves the result in device memory (Next() fetches it; sharded.h packs it into an image instead).
+  // Idempotent.  Returns a ReturnCode.
+  int RunOnDevice() {
+    if (ran_) return run_rc_;
+    ran_ = true;
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    int rc = Stage(ctx);
+    if (rc == SSGPU_OK) {
+      if (dev_) rc = ssgpu_plan_run(plan_, dev_->columns.data(), static_cast<int32_t>(dev_->columns.size()), dev_->row_count, &res_);
+      else rc = ssgpu_plan_run_block(plan_, block_, &res_);
+    }
+    return run_rc_ = rc;
+  }
+  ssgpu_plan* plan_handle() const { return plan_; }
+  ssgpu_result* result_handle() const { return res_; }
+
  private:
   friend class Operation;
   Cursor() {}
   int Stage(ssgpu_ctx* ctx) {  // host Views -> device blocks on the copy stream
+    if (dev_) return SSGPU_OK;   // device-resident input: nothing to stage
     if (aux_) {                // rhs table of a HashJoin: the plan's auxiliary input
       int rc = internal::UploadView(ctx, aux_, &dict_, &aux_block_);
       std::vector<ssgpu_column> cols(aux_->schema().attribute_count());
@@ -571,6 +595,7 @@ class Cursor {
   ssgpu_block* block_ = nullptr;
   ssgpu_result* res_ = nullptr;
   const View* input_ = nullptr;
+  const DeviceView* dev_ = nullptr;
   const View* aux_ = nullptr;
   ssgpu_block* aux_block_ = nullptr;
   internal::Dictionary dict_;   // STRING cells of the scanned Views and the plan's ConstStrings
@@ -580,7 +605,8 @@ class Cursor {
   std::vector<const uint8_t*> host_null_;
   std::vector<std::vector<StringPiece>> cells_;
   rowcount_t total_ = 0, pos_ = 0;
-  bool ran_ = false, failed_ = false;
+  bool ran_ = false, failed_ = false, fetched_ = false;
+  int run_rc_ = SSGPU_OK;
 };
 
 // ---- operations (cursor/base/operation.h:35-83 and the factories of supersonic.h) -------------
@@ -594,10 +620,11 @@ class Operation {
     std::unique_ptr<Cursor> c(new Cursor);
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
     // STRING: one order-preserving dictionary over the scanned Views' cells and the plan's ConstStrings
-    if (!b.string_consts.empty() || internal::Dictionary::HasStrings(b.scan->schema()) || (b.scan_aux && internal::Dictionary::HasStrings(b.scan_aux->schema()))) {
+    if (!b.scan && !b.scan_dev) return FailureOrOwned<Cursor>(new Exception(ERROR_INVALID_ARGUMENT_VALUE, "operation tree has no scan"));
+    if (!b.string_consts.empty() || (b.scan && internal::Dictionary::HasStrings(b.scan->schema())) || (b.scan_aux && internal::Dictionary::HasStrings(b.scan_aux->schema()))) {
       std::vector<StringPiece> values;
       for (auto& sc : b.string_consts) values.push_back(StringPiece(*sc.second));
-      internal::Dictionary::Collect(*b.scan, &values);
+      if (b.scan) internal::Dictionary::Collect(*b.scan, &values);
       if (b.scan_aux) internal::Dictionary::Collect(*b.scan_aux, &values);
       int rc = c->dict_.Build(values);
       for (size_t i = 0; rc == SSGPU_OK && i < b.string_consts.size(); ++i) {
@@ -608,7 +635,7 @@ class Operation {
       if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, "cannot build the STRING dictionary"));
     }
     std::vector<ssgpu_attr> attrs;
-    const TupleSchema& in = b.scan->schema();
+    const TupleSchema& in = b.scan ? b.scan->schema() : b.scan_dev->schema;
     for (int i = 0; i < in.attribute_count(); ++i) attrs.push_back({in.attribute(i).name().c_str(), in.attribute(i).type(), in.attribute(i).nullability()});
     ssgpu_plan_desc d; memset(&d, 0, sizeof(d));
     d.input_schema = attrs.data(); d.n_attrs = static_cast<int32_t>(attrs.size());
@@ -629,7 +656,7 @@ class Operation {
     if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, ssgpu_last_error(ctx)));
     // SetBufferAllocator(MemoryLimit): the plan's device buffers are charged to the allocator's remaining quota
     if (const BufferAllocator* a = EffectiveAllocator()) if (a->has_quota()) ssgpu_plan_set_memory_limit(plan, static_cast<int64_t>(a->Available()));
-    c->plan_ = plan; c->input_ = b.scan; c->aux_ = b.scan_aux;
+    c->plan_ = plan; c->input_ = b.scan; c->dev_ = b.scan_dev; c->aux_ = b.scan_aux;
     for (int i = 0; i < ssgpu_plan_attr_count(plan); ++i) {
       ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
       c->schema_.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
@@ -647,6 +674,7 @@ class Operation {
     std::vector<ssgpu_op> ops; std::vector<ssgpu_expr> exprs; std::vector<int32_t> expr_args;
     std::vector<ssgpu_proj> projs; std::vector<ssgpu_agg> aggs; std::vector<ssgpu_sortkey> sortkeys;
     const View* scan = nullptr;
+    const DeviceView* scan_dev = nullptr;   // device-resident input (ScanDeviceView)
     const View* scan_aux = nullptr;   // rhs table of a HashJoin (the plan's auxiliary input)
     bool aux = false;
     std::vector<std::pair<int, const std::string*>> string_consts;   // (expr index, payload): codes are patched in later
@@ -817,6 +845,13 @@ class ScanViewOp : public Operation {
  private:
   const View& view_;  // must outlive the operation (scan_view.h)
 };
+class ScanDeviceOp : public Operation {
+ public:
+  explicit ScanDeviceOp(const DeviceView& v) : view_(v) {}
+  int Emit(Builder* b) const override { b->scan_dev = &view_; return b->Op(Blank(SSGPU_OP_SCAN, -1)); }
+ private:
+  const DeviceView& view_;  // must outlive the operation and its cursors
+};
 class UnaryOp : public Operation {
  public:
   UnaryOp(int kind, Operation* child, const Expression* e, const SingleSourceProjector* p, const AggregationSpecification* a, const SortOrder* s, int64_t opt = 0)
@@ -872,6 +907,7 @@ inline Operation* HashJoin(JoinType join_type, const SingleSourceProjector* lhs_
 }
 
 inline Operation* ScanView(const View& view) { return new internal::ScanViewOp(view); }
+inline Operation* ScanDeviceView(const DeviceView& view) { return new internal::ScanDeviceOp(view); }
 inline Operation* Compute(const Expression* computation, Operation* child) { return new internal::UnaryOp(SSGPU_OP_COMPUTE, child, computation, nullptr, nullptr, nullptr); }
 inline Operation* Project(const SingleSourceProjector* projector, Operation* child) { return new internal::UnaryOp(SSGPU_OP_PROJECT, child, nullptr, projector, nullptr, nullptr); }
 inline Operation* Filter(const Expression* predicate, const SingleSourceProjector* projector, Operation* child) { return new internal::UnaryOp(SSGPU_OP_FILTER, child, predicate, projector, nullptr, nullptr); }

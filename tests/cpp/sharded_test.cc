@@ -1,0 +1,107 @@
+// A C++ host driving the sharded GroupAggregate (BASELINE config #4) through include/supersonic_amd/sharded.h: RCCL called
+// directly (ncclAllGather of the packed partial tables), no Python, no torch.  Runs with a 1-rank communicator on the
+// single-GPU test box -- the protocol (pack -> all-gather -> unpack -> merge) is the N-rank one -- and compares the merged
+// result with the plain single-process GroupAggregate.
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "supersonic_amd/sharded.h"
+
+using namespace supersonic;  // NOLINT
+
+static int g_fail = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+
+static AggregationSpecification* Spec() {
+  return (new AggregationSpecification)->AddAggregation(SUM, "v", "sv")->AddAggregation(MIN, "d", "mn")->AddAggregation(MAX, "d", "mx")
+      ->AddAggregation(COUNT, "v", "cv")->AddAggregation(COUNT, "", "n")->AddAggregation(FIRST, "d", "fd");
+}
+
+struct Row { int64_t sv; bool sv_null; double mn, mx; uint64_t cv, n; double fd; };
+
+static bool Drain(Cursor* c, std::map<int32_t, Row>* out) {
+  for (;;) {
+    ResultView r = c->Next(Cursor::kDefaultRowCount);
+    if (r.is_failure()) { printf("cursor failed: %s\n", r.exception().message().c_str()); return false; }
+    if (r.is_eos()) return true;
+    const View& v = r.view();
+    for (rowcount_t i = 0; i < v.row_count(); ++i) {
+      Row row;
+      row.sv_null = v.column(1).is_null() && v.column(1).is_null()[i];
+      row.sv = v.column(1).typed_data<int64_t>()[i];
+      row.mn = v.column(2).typed_data<double>()[i]; row.mx = v.column(3).typed_data<double>()[i];
+      row.cv = v.column(4).typed_data<uint64_t>()[i]; row.n = v.column(5).typed_data<uint64_t>()[i];
+      row.fd = v.column(6).typed_data<double>()[i];
+      (*out)[v.column(0).typed_data<int32_t>()[i]] = row;
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "build-only")) { printf("PASSED\n"); return 0; }
+  const int N = 60000;
+  std::vector<int32_t> k(N); std::vector<int64_t> a(N), v(N); std::vector<char> v_null(N); std::vector<double> d(N);
+  uint64_t s = 99;
+  for (int i = 0; i < N; ++i) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    k[i] = static_cast<int32_t>((s >> 40) % 257); a[i] = static_cast<int64_t>((s >> 20) % 1000);
+    v[i] = static_cast<int64_t>((s >> 33) % 2001) - 1000; v_null[i] = ((s >> 7) % 5) == 0;
+    d[i] = static_cast<double>((s >> 12) % 4096) * 0.25 - 300.0;
+  }
+  TupleSchema schema;
+  schema.add_attribute(Attribute("k", INT32, NOT_NULLABLE)); schema.add_attribute(Attribute("a", INT64, NOT_NULLABLE));
+  schema.add_attribute(Attribute("v", INT64, NULLABLE)); schema.add_attribute(Attribute("d", DOUBLE, NOT_NULLABLE));
+  View view(schema);
+  view.mutable_column(0)->Reset(k.data(), nullptr); view.mutable_column(1)->Reset(a.data(), nullptr);
+  view.mutable_column(2)->Reset(v.data(), reinterpret_cast<const bool*>(v_null.data())); view.mutable_column(3)->Reset(d.data(), nullptr);
+  view.set_row_count(N);
+
+  int dev = 0;
+  ncclComm_t comm;
+  if (ncclCommInitAll(&comm, 1, &dev) != ncclSuccess) { printf("FAIL: ncclCommInitAll\n"); return 1; }
+
+  auto shard = [&]() { return Filter(Greater(NamedAttribute("a"), ConstInt64(299)), ProjectAllAttributes(), ScanView(view)); };
+  std::map<int32_t, Row> got, want;
+  {
+    ShardedGroupAggregate job(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/1024);
+    FailureOrOwned<Cursor> c = job.Run();
+    CHECK(c.is_success());
+    if (c.is_failure()) { printf("sharded run failed: %s\n", c.exception().message().c_str()); return 1; }
+    CHECK(c->schema().attribute_count() == 7);
+    CHECK(c->schema().attribute(4).name() == "cv" && !c->schema().attribute(4).is_nullable());   // COUNT stays NOT NULL
+    CHECK(Drain(c.get(), &got));
+    CHECK(job.largest_table() == 257);
+    // a second step reuses the buffers
+    FailureOrOwned<Cursor> again = job.Run();
+    CHECK(again.is_success());
+  }
+  {
+    std::unique_ptr<Operation> plain(GroupAggregate(ProjectNamedAttribute("k"), Spec(), nullptr, shard()));
+    FailureOrOwned<Cursor> c = plain->CreateCursor();
+    CHECK(c.is_success());
+    CHECK(Drain(c.get(), &want));
+  }
+  CHECK(got.size() == want.size() && got.size() == 257);
+  for (auto& kv : want) {
+    auto it = got.find(kv.first);
+    CHECK(it != got.end());
+    if (it == got.end()) continue;
+    const Row& g = it->second; const Row& w = kv.second;
+    CHECK(g.sv_null == w.sv_null && (g.sv_null || g.sv == w.sv));
+    CHECK(g.mn == w.mn && g.mx == w.mx && g.cv == w.cv && g.n == w.n && g.fd == w.fd);
+  }
+  {  // a table that does not fit its image is reported, not truncated
+    ShardedGroupAggregate small(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/64);
+    FailureOrOwned<Cursor> c = small.Run();
+    CHECK(c.is_failure());
+    if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_MEMORY_EXCEEDED);
+    CHECK(small.largest_table() == 257);
+  }
+  ncclCommDestroy(comm);
+  printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -38,3 +38,32 @@ def test_facade_bind(facade_bin):
 @pytest.mark.gpu
 def test_facade_run(facade_bin):
     _run(facade_bin, "run")
+
+
+# ---- the C++ host's multi-GPU driver (include/supersonic_amd/sharded.h): RCCL linked directly ---------------------------
+SHARDED_SRC = os.path.join(ROOT, "tests", "cpp", "sharded_test.cc")
+SHARDED_OUT = os.path.join(ROOT, "tests", "cpp", "_build", "sharded_test")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+@pytest.fixture(scope="module")
+def sharded_bin():
+    os.makedirs(os.path.dirname(SHARDED_OUT), exist_ok=True)
+    deps = [SHARDED_SRC, os.path.join(ROOT, "include", "ssgpu.h"), os.path.join(ROOT, "include", "supersonic_amd", "supersonic.h"),
+            os.path.join(ROOT, "include", "supersonic_amd", "sharded.h")]
+    if not os.path.exists(SHARDED_OUT) or any(os.path.getmtime(d) > os.path.getmtime(SHARDED_OUT) for d in deps):
+        tmp = "%s.%d.tmp" % (SHARDED_OUT, os.getpid())
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROCM, "include"), SHARDED_SRC, "-o", tmp, "-L" + LIBDIR, "-lssgpu", "-Wl,-rpath," + LIBDIR,
+                               "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+        os.replace(tmp, SHARDED_OUT)
+    return SHARDED_OUT
+
+
+def test_sharded_driver_builds_against_rccl(sharded_bin):
+    _run(sharded_bin, "build-only")
+
+
+@pytest.mark.gpu
+def test_sharded_driver_runs_one_rank(sharded_bin):
+    _run(sharded_bin, "run")
