@@ -253,6 +253,8 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-specialize", action="store_true",
+                    help="run the interpreting pipeline kernel instead of the one specialised for the plan by runtime compilation")
     ap.add_argument("--extras", action="store_true", help="also report 1 % / 99 % selectivity and the PCIe-inclusive rate (N = 1)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--lds-target", type=int, default=0)
@@ -412,6 +414,10 @@ def main():
         ctx.set_option("lds_target_bytes", args.lds_target)
     if args.grid_limit:
         ctx.set_option("grid_limit", args.grid_limit)
+    # the plan's stages run kernels specialised for them (hiprtc, csrc/rtc.cpp: the interpreter's own handlers with the
+    # opcode dispatch folded away; compiled at the first, untimed run below).  Same work, bit-identical results -- the
+    # parity tests run both forms.
+    ctx.set_option("specialize", 0 if args.no_specialize else 1)
     for kv in [x for x in args.opts.split(",") if x]:
         ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
@@ -473,6 +479,8 @@ def main():
     # the last 256 pairs: the timed steps stay asynchronous and their kernel durations are read afterwards
     ctx.set_option("profile", 0 if args.no_events_in_loop else 1)
     ctx.set_option("profile_total", 0)      # only the pair around the stage's kernels, not the whole-run pair
+    step()                                   # set-up (not a warmup step): buffers are allocated and the stage kernels compiled
+    barrier()
     for _ in range(args.warmup):
         step()
     if job is not None:
@@ -528,7 +536,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64/f64", "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": rows, "parallelism": par,
-                       "tile_rows": counters.tile_rows, "grid": counters.grid, "lds_bytes": counters.lds_bytes},
+                       "tile_rows": counters.tile_rows, "grid": counters.grid, "lds_bytes": counters.lds_bytes,
+                       "specialized_stages": plan.specialized()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(alg_bytes),
                          "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,

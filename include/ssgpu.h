@@ -380,6 +380,12 @@ int ssgpu_plan_program(const ssgpu_plan* plan, int32_t stage, const void** instr
  * of the reference does when its Operation was given a MemoryLimit allocator (operation.h:66-76,
  * aggregate_groups.cc:372-402).  bytes < 0 = unlimited (default). */
 int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
+/* Context option "specialize" = 1 (set before the plan first runs): every stage's main program is compiled once more at
+ * run time (hiprtc) into a kernel specialised for it -- the same handlers with the opcode dispatch and operand offsets
+ * folded away -- and cached by program; a stage whose specialisation is not possible keeps the interpreting kernel
+ * (results are identical either way).  Returns how many stages of the plan run specialised kernels (0 before the
+ * first run); when a stage asked for it and did not get it, ssgpu_last_error() says why. */
+int32_t ssgpu_plan_specialized(const ssgpu_plan* plan);
 int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
 
 /* ---- standalone expression seam --------------------------------------------------------------------------

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("ssgpu_dict_encode", C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), P, C.c_int64, C.POINTER(C.c_int32)]),
     ("ssgpu_dict_decode", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int32)]),
     ("ssgpu_plan_set_memory_limit", C.c_int, [P, C.c_int64]),
+    ("ssgpu_plan_specialized", C.c_int32, [P]),
     ("ssgpu_plan_memory_in_use", C.c_int64, [P]),
     ("ssgpu_expr_bind", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.POINTER(Expr), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_expr_row_capacity", C.c_int64, [P]),

@@ -1035,6 +1035,10 @@ class Plan(object):
     def memory_in_use(self):
         return self.lib.ssgpu_plan_memory_in_use(self.handle)
 
+    def specialized(self):
+        """Stages of this plan that run kernels specialised by runtime compilation (context option "specialize")."""
+        return self.lib.ssgpu_plan_specialized(self.handle)
+
     def program(self, stage=0):
         """Raw VM instructions of a stage (debug hook used by tests/vm_emulator.py)."""
         ptr, n, nb = C.c_void_p(), C.c_int32(), C.c_int32()

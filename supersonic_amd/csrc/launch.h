@@ -2,8 +2,10 @@
 #ifndef SSGPU_LAUNCH_H_
 #define SSGPU_LAUNCH_H_
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#endif
 #include "vm.h"
 
 // scalar-aggregate slot combine rules (finish kernel) ------------------------
@@ -87,6 +89,12 @@ hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipS
 
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream);
 int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K);
+#ifndef __HIPCC_RTC__
+#include <string>
+// rtc.cpp: the pipeline kernel specialised for one finalised program (NULL + *why: keep the interpreter)
+void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, bool math, std::string* why);
+hipError_t ssgpu_launch_pipeline_rtc(void* fn, const VmParams& P, int grid, hipStream_t stream);
+#endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
                                      VmAccRec* out, hipStream_t stream);

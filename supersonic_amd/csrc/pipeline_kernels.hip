@@ -15,10 +15,15 @@
 //
 // Compile with -ffp-contract=off: the reference's IEEE + - * / are correctly
 // rounded single operations; FMA contraction would change results.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 #include "vm.h"
 #include "launch.h"
+#ifdef SSGPU_RTC_NINSTR
+#include "rtc_prog.h"   // static constexpr unsigned int kRtcProg[SSGPU_RTC_NINSTR + 1][8]: this plan's program (rtc.cpp)
+#endif
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -597,1497 +602,28 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     // space so every instruction is ONE scalar s_load_dwordx8, and fetch the next
     // instruction while the current one executes.
     __builtin_amdgcn_s_setprio(0);
+#ifdef SSGPU_RTC_NINSTR
+    // Per-plan specialisation (runtime compilation, rtc.cpp): the program is a compile-time constant, the loop is
+    // unrolled and every instruction's opcode switch, operand offsets and masks fold away -- what is left is the
+    // straight-line sequence of this plan's handlers.
+#define VM_PC_LOOP _Pragma("unroll") for (int pc = 0; pc < SSGPU_RTC_NINSTR; ++pc)
+#define VM_FETCH_NEXT(pc) u32x8{kRtcProg[pc][0], kRtcProg[pc][1], kRtcProg[pc][2], kRtcProg[pc][3], kRtcProg[pc][4], kRtcProg[pc][5], kRtcProg[pc][6], kRtcProg[pc][7]}
+    (void)prog;
+    u32x8 raw_next = VM_FETCH_NEXT(0);
+#else
+#define VM_PC_LOOP for (int pc = 0; pc < P.n_instr; ++pc)
+#define VM_FETCH_NEXT(pc) prog[pc]
     u32x8 raw_next = prog[0];
+#endif
     PC_PROF(u64 dbg_pc_last = 0;
     if (P.debug_pc) { dbg_pc_last = __builtin_amdgcn_s_memtime(); if (t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr] += dbg_pc_last - tw0; })
-    for (int pc = 0; pc < P.n_instr; ++pc) {
-      PC_PROF(if (P.debug_pc && pc > 0) {
-        const u64 now = __builtin_amdgcn_s_memtime();
-        if (t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[pc - 1] += now - dbg_pc_last;
-        dbg_pc_last = now;
-      })
-      // decode by dwords (a struct memcpy makes the compiler shuffle SGPR bytes)
-      // a_mask / b_mask: all-ones for a row register, 0 for the (stride-0) immediate
-      struct { u32 op, a_mask, b_mask, dst, a, b, c, d; u64 imm; } I;
-      I.op = raw_next[0] & 0xFFFFu;
-      I.a_mask = (u32)((int)(raw_next[0] << 15) >> 31); I.b_mask = (u32)((int)(raw_next[0] << 14) >> 31);
-      I.dst = raw_next[1]; I.a = raw_next[2]; I.b = raw_next[3]; I.c = raw_next[4]; I.d = raw_next[5];
-      I.imm = (u64)raw_next[6] | ((u64)raw_next[7] << 32);
-      raw_next = prog[pc + 1];  // the host pads the program with one trailing NOP
-      // launder the thread id once per instruction: without this LICM hoists every
-      // case's (t * width) address chain into the prologue (255 VGPRs, occupancy 1)
-      int tp = t;
-      asm volatile("" : "+v"(tp));
-      switch (I.op) {
-        case VM_NOP: break;
-        // ---- arithmetic ---------------------------------------------------
-        BINOP(ADD_I32, u32, u32, u32, a + b)
-        BINOP(ADD_I64, u64, u64, u64, a + b)
-        BINOP(ADD_F32, float, float, float, a + b)
-        BINOP(ADD_F64, double, double, double, a + b)
-        BINOP(SUB_I32, u32, u32, u32, a - b)
-        BINOP(SUB_I64, u64, u64, u64, a - b)
-        BINOP(SUB_F32, float, float, float, a - b)
-        BINOP(SUB_F64, double, double, double, a - b)
-        BINOP(MUL_I32, u32, u32, u32, a * b)
-        BINOP(MUL_I64, u64, u64, u64, a * b)
-        BINOP(MUL_F32, float, float, float, a * b)
-        BINOP(MUL_F64, double, double, double, a * b)
-        BINOP(DIV_F32, float, float, float, a / b)
-        BINOP(DIV_F64, double, double, double, a / b)
-        // integer division / modulus: rows with a zero divisor are NULL (nulling)
-        // or flagged (signaling) by a preceding *_DIVZERO_* instruction; compute 0
-        // there so no trap-like behaviour exists on device.
-        BINOP(CDIV_I32, i32, i32, i32, (b == 0 ? 0 : (b == -1 ? (i32)(0u - (u32)a) : a / b)))
-        BINOP(CDIV_I64, i64, i64, i64, (b == 0 ? 0 : (b == -1 ? (i64)(0ull - (u64)a) : a / b)))
-        BINOP(CDIV_U32, u32, u32, u32, (b == 0 ? 0u : a / b))
-        BINOP(CDIV_U64, u64, u64, u64, (b == 0 ? 0ull : a / b))
-        BINOP(MOD_I32, i32, i32, i32, (b == 0 || b == -1 ? 0 : a % b))
-        BINOP(MOD_I64, i64, i64, i64, (b == 0 || b == -1 ? 0 : a % b))
-        BINOP(MOD_U32, u32, u32, u32, (b == 0 ? 0u : a % b))
-        BINOP(MOD_U64, u64, u64, u64, (b == 0 ? 0ull : a % b))
-        UNOP(NEG_I32, u32, u32, 0u - a)
-        UNOP(NEG_I64, u64, u64, 0ull - a)
-        UNOP(NEG_F32, float, float, -a)
-        UNOP(NEG_F64, double, double, -a)
-        // ---- exact math: every one of these is a correctly rounded / exact IEEE operation, so the
-        // device result is bit-identical to the reference's libm call (math_evaluators.h:82-146)
-        UNOP(ABS_I32, i32, u32, (a < 0 ? 0u - (u32)a : (u32)a))
-        UNOP(ABS_I64, i64, u64, (a < 0 ? 0ull - (u64)a : (u64)a))
-        UNOP(ABS_F32, float, float, (a < 0 ? -a : a))
-        UNOP(ABS_F64, double, double, (a < 0 ? -a : a))
-        UNOP(ROUND_F32, float, float, roundf(a))
-        UNOP(ROUND_F64, double, double, round(a))
-        UNOP(CEIL_F32, float, float, ceilf(a))
-        UNOP(CEIL_F64, double, double, ceil(a))
-        UNOP(FLOOR_F32, float, float, floorf(a))
-        UNOP(FLOOR_F64, double, double, floor(a))
-        UNOP(TRUNC_F32, float, float, truncf(a))
-        UNOP(TRUNC_F64, double, double, trunc(a))
-        // static_cast<int64>(double) is undefined out of range; the reference runs on x86-64, whose
-        // cvttsd2si returns the "integer indefinite" value INT64_MIN for NaN and out-of-range inputs
-#define CVT_I64_X86(v) ({ const double v_ = (v); (v_ >= -9223372036854775808.0 && v_ < 9223372036854775808.0) ? (i64)v_ : (i64)0x8000000000000000ull; })
-        UNOP(CEIL2I_F32, float, i64, CVT_I64_X86(ceilf(a)))
-        UNOP(CEIL2I_F64, double, i64, CVT_I64_X86(ceil(a)))
-        UNOP(FLOOR2I_F32, float, i64, CVT_I64_X86(floorf(a)))
-        UNOP(FLOOR2I_F64, double, i64, CVT_I64_X86(floor(a)))
-        UNOP(SQRT_F64, double, double, __builtin_sqrt(a))
-        UNOP(ISFINITE_F64, double, u8, (__builtin_isfinite(a) ? 1 : 0))
-        UNOP(ISNAN_F64, double, u8, (a != a ? 1 : 0))
-        UNOP(ISINF_F64, double, u8, (__builtin_isinf(a) ? 1 : 0))
-        UNOP(ISNORMAL_F64, double, u8, (__builtin_isnormal(a) ? 1 : 0))
-        UNOP(ISODD_32, i32, u8, ((a % 2) != 0 ? 1 : 0))
-        UNOP(ISODD_64, i64, u8, ((a % 2) != 0 ? 1 : 0))
-        case VM_MATH1_F64: { CASE_FENCE;
-          if constexpr (MATH) {
-            const u32 fn = (u32)I.imm;
-            _Pragma("unroll 1") FOR_PAIRS {
-              auto va = lds_load2<double>(I.a, p);
-              lds_store2<double>(I.dst, p, vm_math1(fn, va.x), vm_math1(fn, va.y));
-            }
-          }
-        } break;
-        case VM_MATH2_F64: { CASE_FENCE;
-          if constexpr (MATH) {
-            const u32 fn = (u32)I.imm;
-            _Pragma("unroll 1") FOR_PAIRS {
-              auto va = lds_load2<double>(I.a, p);
-              auto vb = lds_load2<double>(I.b, p);
-              const double r0 = fn == VM_MATH_POW ? pow(va.x, vb.x) : atan2(va.x, vb.x);
-              const double r1 = fn == VM_MATH_POW ? pow(va.y, vb.y) : atan2(va.y, vb.y);
-              lds_store2<double>(I.dst, p, r0, r1);
-            }
-          }
-        } break;
-        case VM_FAIL_TRUE_8: { CASE_FENCE;   // signaling math: flagged rows that are selected and not NULL
-          bool bad = false;
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, I.a, I.c);
-            auto vb = lds_load2<u8>(I.b, p);
-            bad = bad || (m.x && vb.x) || (m.y && vb.y);
-          }
-          if (bad) atomicExch(P.error_flag, 2u);
-        } break;
-        // ---- bitwise --------------------------------------------------------
-        BINOP(BAND_32, u32, u32, u32, a & b)
-        BINOP(BAND_64, u64, u64, u64, a & b)
-        BINOP(BOR_32, u32, u32, u32, a | b)
-        BINOP(BOR_64, u64, u64, u64, a | b)
-        BINOP(BXOR_32, u32, u32, u32, a ^ b)
-        BINOP(BXOR_64, u64, u64, u64, a ^ b)
-        BINOP(BANDNOT_32, u32, u32, u32, (~a) & b)
-        BINOP(BANDNOT_64, u64, u64, u64, (~a) & b)
-        UNOP(BNOT_32, u32, u32, ~a)
-        UNOP(BNOT_64, u64, u64, ~a)
-        BINOP(SHL_I32, u32, u32, u32, a << (b & 31))
-        BINOP(SHL_I64, u64, u64, u64, a << (b & 63))
-        BINOP(SHR_I32, i32, u32, i32, a >> (b & 31))
-        BINOP(SHR_I64, i64, u64, i64, a >> (b & 63))
-        BINOP(SHR_U32, u32, u32, u32, a >> (b & 31))
-        BINOP(SHR_U64, u64, u64, u64, a >> (b & 63))
-        // ---- comparisons ----------------------------------------------------
-        BINOP(LT_I32, i32, i32, u8, a < b)
-        BINOP(LT_I64, i64, i64, u8, a < b)
-        BINOP(LT_U32, u32, u32, u8, a < b)
-        BINOP(LT_U64, u64, u64, u8, a < b)
-        BINOP(LT_F32, float, float, u8, a < b)
-        BINOP(LT_F64, double, double, u8, a < b)
-        BINOP(LT_B8, u8, u8, u8, a < b)
-        BINOP(LE_I32, i32, i32, u8, a <= b)
-        BINOP(LE_I64, i64, i64, u8, a <= b)
-        BINOP(LE_U32, u32, u32, u8, a <= b)
-        BINOP(LE_U64, u64, u64, u8, a <= b)
-        BINOP(LE_F32, float, float, u8, a <= b)
-        BINOP(LE_F64, double, double, u8, a <= b)
-        BINOP(LE_B8, u8, u8, u8, a <= b)
-        BINOP(EQ_32, u32, u32, u8, a == b)
-        BINOP(EQ_64, u64, u64, u8, a == b)
-        BINOP(EQ_F32, float, float, u8, a == b)
-        BINOP(EQ_F64, double, double, u8, a == b)
-        BINOP(EQ_B8, u8, u8, u8, a == b)
-        BINOP(NE_32, u32, u32, u8, a != b)
-        BINOP(NE_64, u64, u64, u8, a != b)
-        BINOP(NE_F32, float, float, u8, a != b)
-        BINOP(NE_F64, double, double, u8, a != b)
-        BINOP(NE_B8, u8, u8, u8, a != b)
-        BINOP(LT_I64_U64, i64, u64, u8, (a < 0) || ((u64)a < b))
-        BINOP(LT_U64_I64, u64, i64, u8, (b >= 0) && (a < (u64)b))
-        BINOP(LE_I64_U64, i64, u64, u8, (a < 0) || ((u64)a <= b))
-        BINOP(LE_U64_I64, u64, i64, u8, (b >= 0) && (a <= (u64)b))
-        BINOP(EQ_I64_U64, i64, u64, u8, (a >= 0) && ((u64)a == b))
-        BINOP(NE_I64_U64, i64, u64, u8, (a < 0) || ((u64)a != b))
-        // ---- casts -----------------------------------------------------------
-        UNOP(CAST_I32_I64, i32, i64, a)
-        UNOP(CAST_U32_I64, u32, i64, a)
-        UNOP(CAST_I64_I32, u64, u32, a)
-        UNOP(CAST_I32_F32, i32, float, a)
-        UNOP(CAST_I32_F64, i32, double, a)
-        UNOP(CAST_U32_F32, u32, float, a)
-        UNOP(CAST_U32_F64, u32, double, a)
-        UNOP(CAST_I64_F32, i64, float, a)
-        UNOP(CAST_I64_F64, i64, double, a)
-        UNOP(CAST_U64_F32, u64, float, a)
-        UNOP(CAST_U64_F64, u64, double, a)
-        UNOP(CAST_F32_F64, float, double, a)
-        UNOP(CAST_F64_F32, double, float, a)
-        UNOP(CAST_F32_I32, float, i32, a)
-        UNOP(CAST_F32_I64, float, i64, a)
-        UNOP(CAST_F32_U32, float, u32, a)
-        UNOP(CAST_F32_U64, float, u64, a)
-        UNOP(CAST_F64_I32, double, i32, a)
-        UNOP(CAST_F64_I64, double, i64, a)
-        UNOP(CAST_F64_U32, double, u32, a)
-        UNOP(CAST_F64_U64, double, u64, a)
-        UNOP(CAST_B8_I32, u8, i32, (a != 0))
-        UNOP(CAST_B8_I64, u8, i64, (a != 0))
-        UNOP(CAST_B8_F32, u8, float, (a != 0))
-        UNOP(CAST_B8_F64, u8, double, (a != 0))
-        UNOP(CAST_32_B8, u32, u8, (a != 0))
-        UNOP(CAST_64_B8, u64, u8, (a != 0))
-        UNOP(CAST_F32_B8, float, u8, (a != 0.0f))
-        UNOP(CAST_F64_B8, double, u8, (a != 0.0))
-        UNOP(COPY_8, u8, u8, a)
-        UNOP(COPY_32, u32, u32, a)
-        UNOP(COPY_64, u64, u64, a)
-        UNOP(FILL_8, u8, u8, a)
-        UNOP(FILL_32, u32, u32, a)
-        UNOP(FILL_64, u64, u64, a)
-        // ---- logic ------------------------------------------------------------
-        BINOP(AND_B8, u8, u8, u8, (a && b))
-        BINOP(OR_B8, u8, u8, u8, (a || b))
-        BINOP(XOR_B8, u8, u8, u8, ((a != 0) != (b != 0)))
-        BINOP(ANDNOT_B8, u8, u8, u8, (!a && b))
-        UNOP(NOT_B8, u8, u8, !a)
-        BINOP(NULL_OR, u8, u8, u8, (a || b))
-        // SQL three-valued AND / OR (elementary_bound_expressions.cc:343-404):
-        // operands a,b values; null masks at (imm & 0xFFFFFFFF) and (imm >> 32),
-        // VM_NONE when the side is not nullable.  dst = value, c = null out.
-        case VM_AND3:
-        case VM_OR3: { CASE_FENCE;
-          const u32 an_off = (u32)I.imm, bn_off = (u32)(I.imm >> 32);
-          const bool is_and = I.op == VM_AND3;
-          _Pragma("unroll") FOR_PAIRS {
-            auto va = lds_load2<u8>(I.a, p); auto vb = lds_load2<u8>(I.b, p);
-            Vec2<u8>::type an, bn; an.x = an.y = 0; bn.x = bn.y = 0;
-            if (an_off != VM_NONE) an = lds_load2<u8>(an_off, p);
-            if (bn_off != VM_NONE) bn = lds_load2<u8>(bn_off, p);
-            u8 v[2], z[2];
-            u8 aa[2] = {va.x, va.y}, bb[2] = {vb.x, vb.y}, na[2] = {an.x, an.y}, nb[2] = {bn.x, bn.y};
-            for (int j = 0; j < 2; ++j) {
-              bool A = aa[j] != 0, B = bb[j] != 0, NA = na[j] != 0, NB = nb[j] != 0;
-              if (is_and) {
-                bool decided_false = (!NA && !A) || (!NB && !B);
-                z[j] = (NA || NB) && !decided_false;
-                v[j] = !decided_false && A && B;
-              } else {
-                bool decided_true = (!NA && A) || (!NB && B);
-                z[j] = (NA || NB) && !decided_true;
-                v[j] = decided_true || (A || B);
-              }
-            }
-            lds_store2<u8>(I.dst, p, v[0], v[1]);
-            lds_store2<u8>(I.c, p, z[0], z[1]);
-          }
-        } break;
-        // dst(null mask) = a(null mask or NONE) | (b == 0)
-#define NULL_DIVZERO(OPNAME, T)                                                \
-        case VM_##OPNAME: { CASE_FENCE;                                        \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            auto vb = fetch2<T>(I.b, I.b_mask, p);                       \
-            Vec2<u8>::type z; z.x = z.y = 0;                                   \
-            if (I.a != VM_NONE) z = lds_load2<u8>(I.a, p);                     \
-            lds_store2<u8>(I.dst, p, (u8)(z.x || vb.x == (T)0), (u8)(z.y || vb.y == (T)0)); \
-          }                                                                    \
-        } break;
-        NULL_DIVZERO(NULL_DIVZERO_32, u32)
-        NULL_DIVZERO(NULL_DIVZERO_64, u64)
-        NULL_DIVZERO(NULL_DIVZERO_F32, float)
-        NULL_DIVZERO(NULL_DIVZERO_F64, double)
-        // signaling: a = null mask (or NONE), b = divisor, c = selection (or NONE)
-#define FAIL_DIVZERO(OPNAME, T)                                                \
-        case VM_##OPNAME: { CASE_FENCE;                                        \
-          bool bad = false;                                                    \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            Valid2 m = valid_pair_(p, tile_valid, I.a, I.c);        \
-            auto vb = fetch2<T>(I.b, I.b_mask, p);                       \
-            bad = bad || (m.x && vb.x == (T)0) || (m.y && vb.y == (T)0);       \
-          }                                                                    \
-          if (bad) atomicExch(P.error_flag, (u32)SSGPU_EVAL_ERROR_DIVZERO);    \
-        } break;
-#define SSGPU_EVAL_ERROR_DIVZERO 1
-        FAIL_DIVZERO(FAIL_DIVZERO_32, u32)
-        FAIL_DIVZERO(FAIL_DIVZERO_64, u64)
-        FAIL_DIVZERO(FAIL_DIVZERO_F32, float)
-        FAIL_DIVZERO(FAIL_DIVZERO_F64, double)
-#define SELECT_OP(OPNAME, T)                                                   \
-        case VM_##OPNAME: { CASE_FENCE;                                        \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            auto va = fetch2<T>(I.a, I.a_mask, p);                       \
-            auto vb = fetch2<T>(I.b, I.b_mask, p);                       \
-            auto vc = lds_load2<u8>(I.c, p);                                   \
-            lds_store2<T>(I.dst, p, vc.x ? va.x : vb.x, vc.y ? va.y : vb.y);   \
-          }                                                                    \
-        } break;
-        SELECT_OP(SELECT_8, u8)
-        SELECT_OP(SELECT_32, u32)
-        SELECT_OP(SELECT_64, u64)
-        case VM_SEL_FROM_PRED: { CASE_FENCE;  // keep iff predicate is non-NULL and TRUE (filter.cc:180-196)
-          _Pragma("unroll") FOR_PAIRS {
-            auto va = fetch2<u8>(I.a, I.a_mask, p);
-            u8 s0 = va.x != 0, s1 = va.y != 0;
-            if (I.b != VM_NONE) { auto z = lds_load2<u8>(I.b, p); s0 = s0 && !z.x; s1 = s1 && !z.y; }
-            if (I.c != VM_NONE) { auto q = lds_load2<u8>(I.c, p); s0 = s0 && q.x; s1 = s1 && q.y; }
-            lds_store2<u8>(I.dst, p, s0, s1);
-          }
-        } break;
-
-        // ---- scalar aggregate sinks -------------------------------------------
-        case VM_AGG_COUNT: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              ac += (u32)m.x + (u32)m.y;
-            }
-            FC[I.dst] = ac;
-          } else {
-            u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            if (lane == 0) { VmAccRec* A = acc_rec(P, I.dst, wave); A->v0 += cnt; A->cnt += cnt; }
-          }
-        } break;
-        case VM_AGG_SUM_I32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i32 e = vv.x; u64 x = acc, y = m.x ? (u64)((i64)e) : (u64)(0ull); acc = (x + y); }
-              { i32 e = vv.y; u64 x = acc, y = m.y ? (u64)((i64)e) : (u64)(0ull); acc = (x + y); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i32 e = vv.x; u64 x = local, y = m.x ? (u64)((i64)e) : (u64)(0ull); local = (x + y); }
-              { i32 e = vv.y; u64 x = local, y = m.y ? (u64)((i64)e) : (u64)(0ull); local = (x + y); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = (x + y); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_SUM_U32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u32 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = (x + y); }
-              { u32 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = (x + y); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); }
-              { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = (x + y); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_SUM_I64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = (x + y); }
-              { u64 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = (x + y); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = (x + y); }
-              { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = (x + y); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(x + y); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = (x + y); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_I32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i32 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              { i32 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (~0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
-              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_U32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u32 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              { u32 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (~0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
-              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_I64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i64 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              { i64 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (~0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
-              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_U64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              { u64 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (~0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
-              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_B8: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u8 e = vv.x; u64 x = acc, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              { u8 e = vv.y; u64 x = acc, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); acc = ((x < y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (~0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(~0ull); local = ((x < y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x < y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(~0ull), y = tot;
-              A->v0 = ((x < y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_I32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i32 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              { i32 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i32 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); }
-              { i32 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64((i64)e)) : (u64)(0ull); local = ((x > y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_U32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u32 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              { u32 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u32 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
-              { u32 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_I64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i64 e = vv.x; u64 x = acc, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              { i64 e = vv.y; u64 x = acc, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<i64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { i64 e = vv.x; u64 x = local, y = m.x ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); }
-              { i64 e = vv.y; u64 x = local, y = m.y ? (u64)(key_i64(e)) : (u64)(0ull); local = ((x > y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_U64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 e = vv.x; u64 x = acc, y = m.x ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              { u64 e = vv.y; u64 x = acc, y = m.y ? (u64)(e) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 e = vv.x; u64 x = local, y = m.x ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
-              { u64 e = vv.y; u64 x = local, y = m.y ? (u64)(e) : (u64)(0ull); local = ((x > y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_B8: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u8 e = vv.x; u64 x = acc, y = m.x ? (u64)((e != 0)) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              { u8 e = vv.y; u64 x = acc, y = m.y ? (u64)((e != 0)) : (u64)(0ull); acc = ((x > y ? x : y)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          } else {
-            u64 local = (0ull); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u8 e = vv.x; u64 x = local, y = m.x ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); }
-              { u8 e = vv.y; u64 x = local, y = m.y ? (u64)((e != 0)) : (u64)(0ull); local = ((x > y ? x : y)); }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)((x > y ? x : y)); });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              u64 x = A->cnt ? A->v0 : (u64)(0ull), y = tot;
-              A->v0 = ((x > y ? x : y)); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_F32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<float>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = acc, y = (double)vv.x; if (m.x && ((y < x))) acc = y; }
-              { double x = acc, y = (double)vv.y; if (m.y && ((y < x))) acc = y; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
-          } else {
-            double local = (__builtin_inf()); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<float>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; }
-              { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);
-              A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MIN_F64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<double>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = acc, y = (double)vv.x; if (m.x && ((y < x))) acc = y; }
-              { double x = acc, y = (double)vv.y; if (m.y && ((y < x))) acc = y; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
-          } else {
-            double local = (__builtin_inf()); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<double>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = local, y = (double)vv.x; if (m.x && ((y < x))) local = y; }
-              { double x = local, y = (double)vv.y; if (m.y && ((y < x))) local = y; }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((y < x)) ? ya : xa; });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              double x = A->cnt ? u2d(A->v0) : (double)(__builtin_inf()), y = u2d(tot);
-              A->v0 = d2u(((y < x)) ? y : x); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_F32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<float>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = acc, y = (double)vv.x; if (m.x && ((x < y))) acc = y; }
-              { double x = acc, y = (double)vv.y; if (m.y && ((x < y))) acc = y; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
-          } else {
-            double local = (-__builtin_inf()); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<float>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; }
-              { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);
-              A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_MAX_F64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<double>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = acc, y = (double)vv.x; if (m.x && ((x < y))) acc = y; }
-              { double x = acc, y = (double)vv.y; if (m.y && ((x < y))) acc = y; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(acc); FC[I.dst] = ac;
-          } else {
-            double local = (-__builtin_inf()); u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<double>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double x = local, y = (double)vv.x; if (m.x && ((x < y))) local = y; }
-              { double x = local, y = (double)vv.y; if (m.y && ((x < y))) local = y; }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return ((x < y)) ? ya : xa; });
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              double x = A->cnt ? u2d(A->v0) : (double)(-__builtin_inf()), y = u2d(tot);
-              A->v0 = d2u(((x < y)) ? y : x); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_SUM_F32:
-        case VM_AGG_SUM_F64: { CASE_FENCE;
-          // compensated (double-double) sum: bit-identical to the reference's sequential fold
-          // whenever every partial sum is exact, and within 1 ULP of the exact sum otherwise
-          const bool f32 = I.op == VM_AGG_SUM_F32;
-          if (I.dst < VM_FAST_SLOTS) {
-            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              double e0, e1;
-              if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; }
-              else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              if (m.x) local = dd_add_d(local, e0);
-              if (m.y) local = dd_add_d(local, e1);
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
-          } else {
-            DD local; local.hi = -0.0; local.lo = 0.0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              double e0, e1;
-              if (f32) { auto vv = lds_load2<float>(I.a, p); e0 = vv.x; e1 = vv.y; }
-              else     { auto vv = lds_load2<double>(I.a, p); e0 = vv.x; e1 = vv.y; }
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              if (m.x) local = dd_add_d(local, e0);
-              if (m.y) local = dd_add_d(local, e1);
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            DD tot = wave_reduce_dd(local);
-            if (lane == 0 && cnt) {
-              VmAccRec* A = acc_rec(P, I.dst, wave);
-              DD cur; cur.hi = A->cnt ? u2d(A->v0) : -0.0; cur.lo = A->cnt ? u2d(A->v1) : 0.0;
-              cur = dd_add(cur, tot);
-              A->v0 = d2u(cur.hi); A->v1 = d2u(cur.lo); A->cnt += cnt;
-            }
-          }
-        } break;
-        case VM_AGG_FIRST_8: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = ar, y = r0;     if (m.x && ((y < x))) { ar = y; av = (u64)vv.x; } }
-              { u64 x = ar, y = r0 + 1; if (m.y && ((y < x))) { ar = y; av = (u64)vv.y; } }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
-          } else {
-            u64 brow = (~0ull), bval = 0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } }
-              { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; });
-            u64 owner = __ballot(brow == trow);
-            if (cnt) {
-              int src = __ffsll((long long)owner) - 1;
-              u64 tval = readlane64(bval, src);
-              if (lane == 0) {
-                VmAccRec* A = acc_rec(P, I.dst, wave);
-                u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;
-                if ((y < x)) { A->v1 = trow; A->v0 = tval; }
-                A->cnt += cnt;
-              }
-            }
-          }
-        } break;
-        case VM_AGG_FIRST_32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = ar, y = r0;     if (m.x && ((y < x))) { ar = y; av = (u64)vv.x; } }
-              { u64 x = ar, y = r0 + 1; if (m.y && ((y < x))) { ar = y; av = (u64)vv.y; } }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
-          } else {
-            u64 brow = (~0ull), bval = 0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } }
-              { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; });
-            u64 owner = __ballot(brow == trow);
-            if (cnt) {
-              int src = __ffsll((long long)owner) - 1;
-              u64 tval = readlane64(bval, src);
-              if (lane == 0) {
-                VmAccRec* A = acc_rec(P, I.dst, wave);
-                u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;
-                if ((y < x)) { A->v1 = trow; A->v0 = tval; }
-                A->cnt += cnt;
-              }
-            }
-          }
-        } break;
-        case VM_AGG_FIRST_64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = ar, y = r0;     if (m.x && ((y < x))) { ar = y; av = (u64)vv.x; } }
-              { u64 x = ar, y = r0 + 1; if (m.y && ((y < x))) { ar = y; av = (u64)vv.y; } }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
-          } else {
-            u64 brow = (~0ull), bval = 0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = brow, y = r0;     if (m.x && ((y < x))) { brow = y; bval = (u64)vv.x; } }
-              { u64 x = brow, y = r0 + 1; if (m.y && ((y < x))) { brow = y; bval = (u64)vv.y; } }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y < x)) ? y : x; });
-            u64 owner = __ballot(brow == trow);
-            if (cnt) {
-              int src = __ffsll((long long)owner) - 1;
-              u64 tval = readlane64(bval, src);
-              if (lane == 0) {
-                VmAccRec* A = acc_rec(P, I.dst, wave);
-                u64 x = A->cnt ? A->v1 : (u64)(~0ull), y = trow;
-                if ((y < x)) { A->v1 = trow; A->v0 = tval; }
-                A->cnt += cnt;
-              }
-            }
-          }
-        } break;
-        case VM_AGG_LAST_8: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = ar, y = r0;     if (m.x && ((y >= x))) { ar = y; av = (u64)vv.x; } }
-              { u64 x = ar, y = r0 + 1; if (m.y && ((y >= x))) { ar = y; av = (u64)vv.y; } }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
-          } else {
-            u64 brow = (0ull), bval = 0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u8>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } }
-              { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; });
-            u64 owner = __ballot(brow == trow);
-            if (cnt) {
-              int src = __ffsll((long long)owner) - 1;
-              u64 tval = readlane64(bval, src);
-              if (lane == 0) {
-                VmAccRec* A = acc_rec(P, I.dst, wave);
-                u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;
-                if ((y >= x)) { A->v1 = trow; A->v0 = tval; }
-                A->cnt += cnt;
-              }
-            }
-          }
-        } break;
-        case VM_AGG_LAST_32: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = ar, y = r0;     if (m.x && ((y >= x))) { ar = y; av = (u64)vv.x; } }
-              { u64 x = ar, y = r0 + 1; if (m.y && ((y >= x))) { ar = y; av = (u64)vv.y; } }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
-          } else {
-            u64 brow = (0ull), bval = 0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u32>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } }
-              { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; });
-            u64 owner = __ballot(brow == trow);
-            if (cnt) {
-              int src = __ffsll((long long)owner) - 1;
-              u64 tval = readlane64(bval, src);
-              if (lane == 0) {
-                VmAccRec* A = acc_rec(P, I.dst, wave);
-                u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;
-                if ((y >= x)) { A->v1 = trow; A->v0 = tval; }
-                A->cnt += cnt;
-              }
-            }
-          }
-        } break;
-        case VM_AGG_LAST_64: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = ar, y = r0;     if (m.x && ((y >= x))) { ar = y; av = (u64)vv.x; } }
-              { u64 x = ar, y = r0 + 1; if (m.y && ((y >= x))) { ar = y; av = (u64)vv.y; } }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;
-          } else {
-            u64 brow = (0ull), bval = 0; u32 cnt = 0;
-            _Pragma("unroll") FOR_PAIRS {
-              auto vv = lds_load2<u64>(I.a, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-              { u64 x = brow, y = r0;     if (m.x && ((y >= x))) { brow = y; bval = (u64)vv.x; } }
-              { u64 x = brow, y = r0 + 1; if (m.y && ((y >= x))) { brow = y; bval = (u64)vv.y; } }
-              cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            }
-            u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return ((y >= x)) ? y : x; });
-            u64 owner = __ballot(brow == trow);
-            if (cnt) {
-              int src = __ffsll((long long)owner) - 1;
-              u64 tval = readlane64(bval, src);
-              if (lane == 0) {
-                VmAccRec* A = acc_rec(P, I.dst, wave);
-                u64 x = A->cnt ? A->v1 : (u64)(0ull), y = trow;
-                if ((y >= x)) { A->v1 = trow; A->v0 = tval; }
-                A->cnt += cnt;
-              }
-            }
-          }
-        } break;
-        case VM_AGG_SUM_I64_ADD: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<u64>(I.a, I.a_mask, p);
-              auto vd = fetch2<u64>(I.d, I.b_mask, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 a = va.x, b = vd.x; acc += m.x ? (a + b) : 0ull; }
-              { u64 a = va.y, b = vd.y; acc += m.y ? (a + b) : 0ull; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          }
-        } break;
-        case VM_AGG_SUM_I64_SUB: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<u64>(I.a, I.a_mask, p);
-              auto vd = fetch2<u64>(I.d, I.b_mask, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 a = va.x, b = vd.x; acc += m.x ? (a - b) : 0ull; }
-              { u64 a = va.y, b = vd.y; acc += m.y ? (a - b) : 0ull; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          }
-        } break;
-        case VM_AGG_SUM_I64_MUL: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {   // fused ops are only emitted for register-resident slots
-            u64 acc = F0[I.dst]; u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<u64>(I.a, I.a_mask, p);
-              auto vd = fetch2<u64>(I.d, I.b_mask, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { u64 a = va.x, b = vd.x; acc += m.x ? (a * b) : 0ull; }
-              { u64 a = va.y, b = vd.y; acc += m.y ? (a * b) : 0ull; }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = acc; FC[I.dst] = ac;
-          }
-        } break;
-        case VM_AGG_SUM_F64_ADD: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<double>(I.a, I.a_mask, p);
-              auto vd = fetch2<double>(I.d, I.b_mask, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a + b)); }
-              { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a + b)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
-          }
-        } break;
-        case VM_AGG_SUM_F64_SUB: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<double>(I.a, I.a_mask, p);
-              auto vd = fetch2<double>(I.d, I.b_mask, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a - b)); }
-              { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a - b)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
-          }
-        } break;
-        case VM_AGG_SUM_F64_MUL: { CASE_FENCE;
-          if (I.dst < VM_FAST_SLOTS) {
-            DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst];
-            _Pragma("unroll") FOR_PAIRS {
-              auto va = fetch2<double>(I.a, I.a_mask, p);
-              auto vd = fetch2<double>(I.d, I.b_mask, p);
-              Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);
-              { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (a * b)); }
-              { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (a * b)); }
-              ac += (u32)m.x + (u32)m.y;
-            }
-            F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;
-          }
-        } break;
-
-        // ---- materialising sinks ----------------------------------------------
-        case VM_SEL_COUNT: { CASE_FENCE;
-          // one count per tile OF THE STORE PASS, which may be smaller than this pass's tile (count_sub_k 512-row
-          // units each; rows are ordered (k, wave, lane, j), so unit k of this tile is the k-th run of 512 rows)
-          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
-            const u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            if (lane == 0) scratch[k * VM_WAVES + wave] = c;
-          }
-          WG_BARRIER();
-          {
-            const int sub = P.count_sub_k > 0 ? P.count_sub_k : K;
-            const int per = K / sub;
-            if (t < per) {
-              u32 sum = 0;
-              for (int q = t * sub * VM_WAVES; q < (t + 1) * sub * VM_WAVES; ++q) sum += scratch[q];
-              const i64 idx = (i64)tile * per + t;
-              const i64 unit_rows = (i64)VM_TILE_UNIT * sub;
-              if (idx * unit_rows < P.n_rows || idx == 0) P.tile_counts[idx] = sum;
-            }
-          }
-          WG_BARRIER();
-        } break;
-        case VM_SEL_RANK: { CASE_FENCE;
-          // order-preserving ranks: rows are ordered (k, wave, lane, j)
-          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
-            u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            if (lane == 0) scratch[k * VM_WAVES + wave] = c;
-          }
-          WG_BARRIER();
-          u32 base = P.tile_offsets[tile];
-          const u64 lt = (1ull << lane) - 1ull;
-          _Pragma("unroll") FOR_PAIRS {
-            u32 mine = base;
-            for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
-            for (int w = 0; w < VM_WAVES; ++w) base += scratch[k * VM_WAVES + w];
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
-            u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
-            u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
-            lds_store2<u32>(I.dst, p, r0, r0 + (m.x ? 1u : 0u));
-          }
-          WG_BARRIER();
-        } break;
-        case VM_SEL_RANK_LB: { CASE_FENCE;
-          // single-pass compaction.  (1) count the tile's survivors; (2) publish the count and look back over the
-          // earlier tiles' words for the number of rows they keep; (3) dst[i] = tile row of survivor i.
-          // Tiles are strided over the persistent workgroups, so the tiles one iteration works on are a contiguous window
-          // whose counts appear together; a tile only waits for tiles of the same or the previous iteration, which
-          // belong to workgroups that are resident (the host sizes the grid by the occupancy API for these programs).
-          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
-            u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-            if (lane == 0) scratch[k * VM_WAVES + wave] = c;
-          }
-          WG_BARRIER();
-          u32 run = 0;
-          {
-            const u64 lt = (1ull << lane) - 1ull;
-            u32* inv = reinterpret_cast<u32*>(smem + I.dst);
-            _Pragma("unroll") FOR_PAIRS {
-              u32 mine = run;
-              for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
-              for (int w = 0; w < VM_WAVES; ++w) run += scratch[k * VM_WAVES + w];
-              Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.a);
-              const u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
-              const u32 r0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
-              if (m.x) inv[r0] = 2u * (u32)p;
-              if (m.y) inv[r0 + (m.x ? 1u : 0u)] = 2u * (u32)p + 1u;
-            }
-          }
-          if (wave == 0) {
-            const u32 excl = lookback_rows_before(P.lb_status, tile, run, (P.lb_epoch & 0x3FFFFFFFull) << 32, P.lb_ctrl, P.error_flag, lane);
-            if (lane == 0) {
-              scratch[40] = excl; scratch[41] = run;
-              if (tile == P.n_tiles - 1) *reinterpret_cast<u64*>(P.lb_ctrl) = (u64)excl + run;
-            }
-          }
-          WG_BARRIER();
-        } break;
-        // ---- HashJoin probe + gathers (see VmJoin in vm.h) -------------------------------------
-        case VM_JOIN_PROBE: { CASE_FENCE;
-          const VmJoin J = P.join[I.imm & (VM_MAX_JOINS - 1)];
-          _Pragma("unroll") FOR_PAIRS {
-            auto kk = lds_load2<u64>(I.a, p);
-            u32 r[2];
-            const u64 key2[2] = {kk.x, kk.y};
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {
-              const u64 key = key2[j];
-              u32 found = VM_NONE;
-              if (key == VM_KEY_EMPTY) {
-                found = J.special[0];
-              } else {
-                u32 slot = hash64(key) & J.capacity_mask;
-                for (u32 probe = 0; probe <= J.capacity_mask; ++probe) {
-                  const u64 cur = J.keys[slot];
-                  if (cur == key) { found = J.rows[slot]; break; }
-                  if (cur == VM_KEY_EMPTY) break;
-                  slot = (slot + 1) & J.capacity_mask;
-                }
-              }
-              r[j] = found;
-            }
-            if (I.b != VM_NONE) {   // NULL key: no match
-              auto z = lds_load2<u8>(I.b, p);
-              if (z.x) r[0] = VM_NONE;
-              if (z.y) r[1] = VM_NONE;
-            }
-            lds_store2<u32>(I.dst, p, r[0], r[1]);
-          }
-        } break;
-        case VM_ROWID_64: { CASE_FENCE;      // global row id of every row of the tile
-          _Pragma("unroll") FOR_PAIRS {
-            const u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);
-            lds_store2<u64>(I.dst, p, r0, r0 + 1ull);
-          }
-        } break;
-        case VM_IDX_VALID: { CASE_FENCE;
-          _Pragma("unroll") FOR_PAIRS {
-            auto ix = lds_load2<u32>(I.a, p);
-            lds_store2<u8>(I.dst, p, (u8)(ix.x != VM_NONE), (u8)(ix.y != VM_NONE));
-          }
-        } break;
-#define GATHER_OP(OPNAME, T)                                                   \
-        case VM_##OPNAME: { CASE_FENCE;                                        \
-          const T* col = reinterpret_cast<const T*>(P.join_cols[I.imm].data);  \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            auto ix = lds_load2<u32>(I.a, p);                                  \
-            const T v0 = ix.x != VM_NONE ? col[ix.x] : (T)0;                   \
-            const T v1 = ix.y != VM_NONE ? col[ix.y] : (T)0;                   \
-            lds_store2<T>(I.dst, p, v0, v1);                                   \
-          }                                                                    \
-        } break;
-        GATHER_OP(GATHER_64, u64)
-        GATHER_OP(GATHER_32, u32)
-        GATHER_OP(GATHER_8, u8)
-        case VM_GATHER_NULL: { CASE_FENCE;   // NULL where nothing matched or the rhs value is NULL
-          const u8* nl = P.join_cols[I.imm].is_null;
-          _Pragma("unroll") FOR_PAIRS {
-            auto ix = lds_load2<u32>(I.a, p);
-            const u8 z0 = ix.x == VM_NONE ? (u8)1 : (nl ? (u8)(nl[ix.x] != 0) : (u8)0);
-            const u8 z1 = ix.y == VM_NONE ? (u8)1 : (nl ? (u8)(nl[ix.y] != 0) : (u8)0);
-            lds_store2<u8>(I.dst, p, z0, z1);
-          }
-        } break;
-        // ---- hash partitioning of the rows of a GroupAggregate with many groups ----------
-        // ONE pass: every selected row becomes a record (packed key + aggregate inputs) in the segment of its
-        // (hash partition, THIS workgroup) -- segments are private to a workgroup, so their fill counts live in LDS
-        // for the whole kernel and no global atomic or count pass is needed; a segment that runs full raises
-        // part_overflow and the host reruns with larger segments.
-        // Stores leave the L2 one transaction per line touched per instruction, whatever is written to the line
-        // later: a lane writing its own 40-byte record to its own segment costs three of them (measured: 54 % of the
-        // pass).  So the tile is counting-sorted by partition in LDS (PART_RANK), its records are assembled in that
-        // order in an LDS staging area (PART_REC_*), and PART_FLUSH copies the staging area out with consecutive
-        // lanes on consecutive words: a partition's records of the tile are one contiguous run in its segment.
-        // LDS behind part_lds_off: u32 fill[P] | tile count -> tile start [P] | run delta [P] | room [P] |
-        //                          u32 grec[tile_rows] (global record index by sorted position) | n | records
-        case VM_PART_RANK: { CASE_FENCE;
-          // Every selected row takes the next free record of its (hash partition, this workgroup) segment -- one
-          // returning LDS atomic on the workgroup's fill counters, which live for the whole kernel -- and a place in
-          // the tile's staging area, where PART_REC_* assemble its record and from where PART_FLUSH copies it out.
-          // (An earlier form sorted the tile's rows by partition first: with >= 256 partitions and 512-row tiles a
-          // partition's run is one or two records, so the sort bought no coalescing and cost a histogram, a scan
-          // and three barriers over the partition count per tile -- a third of the pass.)
-          const u32 NP = P.part_n, cap = P.part_seg_cap, G = gridDim.x, wg = blockIdx.x;
-          u32* fill = reinterpret_cast<u32*>(smem + P.part_lds_off);
-          u32* grec = fill + NP;
-          u32* nsel = grec + (u32)(VM_TILE_UNIT * K);
-          u32* scratch = reinterpret_cast<u32*>(smem + P.scratch_lds_off);
-          const bool compact = I.c != VM_NONE;       // a selection: staged records are the survivors, in row order
-          if (compact) {
-            _Pragma("unroll") FOR_PAIRS {
-              Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
-              const u32 c = (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));
-              if (lane == 0) scratch[k * VM_WAVES + wave] = c;
-            }
-            WG_BARRIER();
-          }
-          bool over = false;
-          u32 run = 0;
-          const u64 lt = (1ull << lane) - 1ull;
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
-            auto kk = lds_load2<u64>(I.a, p);
-            u32 s0 = 2u * (u32)p, s1 = 2u * (u32)p + 1u;
-            if (compact) {
-              u32 mine = run;
-              for (int w = 0; w < wave; ++w) mine += scratch[k * VM_WAVES + w];
-              for (int w = 0; w < VM_WAVES; ++w) run += scratch[k * VM_WAVES + w];
-              const u64 b0 = __ballot(m.x), b1 = __ballot(m.y);
-              s0 = mine + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
-              s1 = s0 + (m.x ? 1u : 0u);
-            }
-            if (m.x) {
-              const u32 pt = part_of(kk.x, NP), pos = atomicAdd(&fill[pt], 1u);
-              if (pos < cap) grec[s0] = SEG_INDEX(pt, wg, NP, G) * cap + pos; else { grec[s0] = VM_NONE; over = true; }
-            } else s0 = VM_NONE;
-            if (m.y) {
-              const u32 pt = part_of(kk.y, NP), pos = atomicAdd(&fill[pt], 1u);
-              if (pos < cap) grec[s1] = SEG_INDEX(pt, wg, NP, G) * cap + pos; else { grec[s1] = VM_NONE; over = true; }
-            } else s1 = VM_NONE;
-            lds_store2<u32>(I.dst, p, s0, s1);
-          }
-          if (over) atomicExch(P.part_overflow, 1u);
-          if (tp == 0) nsel[0] = compact ? run : tile_valid;
-        } break;
-#define PART_REC_OP(OPNAME, T)                                                 \
-        case VM_##OPNAME: { CASE_FENCE;                                        \
-          char* stage = smem + P.part_lds_off + 4u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu); \
-          const u32 rb = (u32)((I.imm >> 16) & 0xFFFFu);                       \
-          _Pragma("unroll") FOR_PAIRS {                                        \
-            auto rk = lds_load2<u32>(I.b, p);                                  \
-            auto vv = fetch2<T>(I.a, I.a_mask, p);                             \
-            if (rk.x != VM_NONE) *reinterpret_cast<T*>(stage + rk.x * rb) = vv.x; \
-            if (rk.y != VM_NONE) *reinterpret_cast<T*>(stage + rk.y * rb) = vv.y; \
-          }                                                                    \
-        } break;
-        PART_REC_OP(PART_REC_8, u8)
-        PART_REC_OP(PART_REC_32, u32)
-        PART_REC_OP(PART_REC_64, u64)
-        case VM_PART_REC_128: { CASE_FENCE;   // two adjacent 8-byte fields
-          char* stage = smem + P.part_lds_off + 4u * P.part_n + 4u * (u32)(VM_TILE_UNIT * K) + 16u + (u32)(I.imm & 0xFFFFu);
-          const u32 rb = (u32)((I.imm >> 16) & 0xFFFFu);
-          _Pragma("unroll") FOR_PAIRS {
-            auto rk = lds_load2<u32>(I.b, p);
-            auto va = lds_load2<u64>(I.a, p);
-            auto vd = lds_load2<u64>(I.d, p);
-            if (rk.x != VM_NONE) { u64* d = reinterpret_cast<u64*>(stage + rk.x * rb); d[0] = va.x; d[1] = vd.x; }
-            if (rk.y != VM_NONE) { u64* d = reinterpret_cast<u64*>(stage + rk.y * rb); d[0] = va.y; d[1] = vd.y; }
-          }
-        } break;
-        case VM_PART_FLUSH: { CASE_FENCE;     // the staged records of the tile -> their segments, 8 bytes per lane, lanes on consecutive words
-          const u32 NP = P.part_n;
-          const u32* grec = reinterpret_cast<const u32*>(smem + P.part_lds_off + 4u * NP);
-          const u32* nsel = grec + (u32)(VM_TILE_UNIT * K);
-          const u64* stage = reinterpret_cast<const u64*>(smem + P.part_lds_off + 4u * NP + 4u * (u32)(VM_TILE_UNIT * K) + 16u);
-          u64* out = reinterpret_cast<u64*>(P.outputs[0].dst);
-          const u32 wpr = (u32)I.imm & 0xFFFFu;              // words per record
-          const u32 rcp = (u32)(I.imm >> 32);                // floor(2^32 / wpr) + 1: word -> record without a division
-          WG_BARRIER();
-          const u32 words = nsel[0] * wpr;
-          for (u32 w0 = (u32)tp; w0 < words; w0 += 2u * VM_COMPUTE_THREADS) {
-            const u32 w1 = w0 + VM_COMPUTE_THREADS;
-            const u32 j0 = __umulhi(w0, rcp), j1 = __umulhi(w1, rcp);
-            const bool in1 = w1 < words;
-            const u32 g0 = grec[j0], g1 = in1 ? grec[j1] : VM_NONE;
-            const u64 v0 = stage[w0], v1 = in1 ? stage[w1] : 0ull;
-            if (P.part_pad) {   // development (ctx option part_scatter_debug): the same bytes written sequentially -- how much
-              const u64 seq = (u64)tile * (u32)(VM_TILE_UNIT * K) * wpr;   // of the pass is the scatter?  (3.08 -> 1.45 ms)
-              if (g0 != VM_NONE) out[seq + w0] = v0;
-              if (g1 != VM_NONE) out[seq + w1] = v1;
-              continue;
-            }
-            if (g0 != VM_NONE) out[(u64)g0 * wpr + (w0 - j0 * wpr)] = v0;
-            if (g1 != VM_NONE) out[(u64)g1 * wpr + (w1 - j1 * wpr)] = v1;
-          }
-          WG_BARRIER();
-        } break;
-        STORE_OP(STORE_8, u8)
-        STORE_OP(STORE_32, u32)
-        STORE_OP(STORE_64, u64)
-        STOREC_OP(STOREC_8, u8)
-        STOREC_OP(STOREC_32, u32)
-        STOREC_OP(STOREC_64, u64)
-        case VM_BARRIER: { CASE_FENCE; WG_BARRIER(); } break;
-        STOREG_OP(STOREG_32, u32)
-        STOREG_OP(STOREG_64, u64)
-        case VM_STOREG_8: { CASE_FENCE;      // four output rows per lane: one dword store where all four exist
-          u8* out = reinterpret_cast<u8*>(P.outputs[I.dst].dst);
-          const u32* sc = reinterpret_cast<const u32*>(smem + P.scratch_lds_off);
-          const u32 base = sc[40], end = base + sc[41];
-          const u32* inv = reinterpret_cast<const u32*>(smem + I.b);
-          for (u32 g = (base & ~255u) + 4u * (u32)tp; g < end; g += 4u * VM_COMPUTE_THREADS) {
-            u32 word = 0;
-            _Pragma("unroll") for (u32 j = 0; j < 4; ++j) {
-              const u32 gj = g + j;
-              if (gj >= base && gj < end) word |= (u32)*reinterpret_cast<const u8*>(smem + I.a + (inv[gj - base] & I.a_mask)) << (8u * j);
-            }
-            if (g >= base && g + 4u <= end && ((reinterpret_cast<uintptr_t>(out) & 3u) == 0)) {
-              *reinterpret_cast<u32*>(out + g) = word;
-            } else {
-              _Pragma("unroll") for (u32 j = 0; j < 4; ++j)
-                if (g + j >= base && g + j < end) out[g + j] = (u8)(word >> (8u * j));
-            }
-          }
-        } break;
-        case VM_STORE_ROWID: { CASE_FENCE;
-          i64* out = reinterpret_cast<i64*>(P.outputs[I.dst].dst);
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
-            auto rk = lds_load2<u32>(I.b, p);
-            i64 r0 = P.row_id_base + tile_base + 2 * (i64)p;
-            if (m.x) out[rk.x] = r0;
-            if (m.y) out[rk.y] = r0 + 1;
-          }
-        } break;
-
-        // ---- group aggregate sinks ----------------------------------------------
-        UNOP(KEY_ZERO, u64, u64, (a & 0ull))
-        KEY_APPEND_OP(KEY_APPEND_8, u8, u8)
-        KEY_APPEND_OP(KEY_APPEND_32, u32, u32)
-        KEY_APPEND_OP(KEY_APPEND_64, u64, u64)
-        case VM_GRP_INSERT: { CASE_FENCE;
-          const VmGroupTable& G = P.group;
-          const bool local = G.local_capacity != 0;
-          const u32 cap = G.local_sub_capacity, sub = ((u32)lane & (G.local_sub - 1u)) * cap;
-          u64* lkeys = reinterpret_cast<u64*>(smem + G.local_keys_off) + sub;
-          const u32 tag = VM_SLOT_LOCAL | sub;
-          u32 bypass = 0;
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);
-            auto kk = lds_load2<u64>(I.a, p);
-            u32 s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;
-            if (local) {
-              // both rows' home slots are read back to back, then resolved
-              const u32 i0 = __umulhi(hash_local(kk.x), cap), i1 = __umulhi(hash_local(kk.y), cap);
-              const u64 c0 = __hip_atomic_load(&lkeys[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              const u64 c1 = __hip_atomic_load(&lkeys[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (m.x && kk.x != VM_KEY_EMPTY) s0 = group_probe_local(lkeys, cap, tag, kk.x, i0, c0);
-              if (m.y && kk.y != VM_KEY_EMPTY) s1 = group_probe_local(lkeys, cap, tag, kk.y, i1, c1);
-            }
-            if (m.x && s0 == 0xFFFFFFFFu) { s0 = group_insert(G, kk.x); ++bypass; }
-            if (m.y && s1 == 0xFFFFFFFFu) { s1 = group_insert(G, kk.y); ++bypass; }
-            lds_store2<u32>(I.dst, p, s0, s1);
-          }
-          if (local && __ballot(bypass != 0)) {   // feedback for the host's table sizing
-            const u32 nb = (u32)wave_reduce_u64((u64)bypass, [](u64 x, u64 y) { return x + y; });
-            if (lane == 0) atomicAdd(reinterpret_cast<u32*>(smem + P.scratch_lds_off + 128u), nb);
-          }
-        } break;
-        case VM_GAGG_COUNT: { CASE_FENCE;
-          const u32 ng = (u32)(I.imm >> 32), s = (u32)I.imm;
-          _Pragma("unroll") FOR_PAIRS {
-            Valid2 m = valid_pair_(p, tile_valid, I.b, VM_NONE);
-            auto sl = lds_load2<u32>(I.c, p);
-            if (m.x && sl.x != 0xFFFFFFFFu) {
-              if (sl.x & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.x & ~VM_SLOT_LOCAL) * P.group.local_stride + s, 1ull);
-              else atomicAdd(&P.group.acc[(u64)sl.x * ng + s], 1ull);
-            }
-            if (m.y && sl.y != 0xFFFFFFFFu) {
-              if (sl.y & VM_SLOT_LOCAL) atomicAdd(reinterpret_cast<u64*>(smem + P.group.local_acc_off) + (sl.y & ~VM_SLOT_LOCAL) * P.group.local_stride + s, 1ull);
-              else atomicAdd(&P.group.acc[(u64)sl.y * ng + s], 1ull);
-            }
-          }
-        } break;
-        GAGG_ATOMIC(GAGG_SUM_I32, i32, atomicAdd(A, (u64)(i64)e))
-        GAGG_ATOMIC(GAGG_SUM_U32, u32, atomicAdd(A, (u64)e))
-        GAGG_ATOMIC(GAGG_SUM_I64, u64, atomicAdd(A, e))
-        GAGG_ATOMIC(GAGG_SUM_F32, float, unsafeAtomicAdd(reinterpret_cast<double*>(A), (double)e))
-        // DOUBLE sums are compensated: the atomic returns the value it added to, so the rounding error of THIS add is
-        // known exactly (TwoSum) and is accumulated in the word behind the sum; result = sum + compensation
-        GAGG_ATOMIC(GAGG_SUM_F64, double, dd_atomic_add(reinterpret_cast<double*>(A), e))
-        GAGG_ATOMIC(GAGG_MIN_I32, i32, atomicMin(A, key_i64((i64)e)))
-        GAGG_ATOMIC(GAGG_MIN_U32, u32, atomicMin(A, (u64)e))
-        GAGG_ATOMIC(GAGG_MIN_I64, i64, atomicMin(A, key_i64(e)))
-        GAGG_ATOMIC(GAGG_MIN_U64, u64, atomicMin(A, e))
-        GAGG_ATOMIC(GAGG_MIN_B8, u8, atomicMin(A, (u64)(e != 0)))
-        GAGG_ATOMIC(GAGG_MAX_I32, i32, atomicMax(A, key_i64((i64)e)))
-        GAGG_ATOMIC(GAGG_MAX_U32, u32, atomicMax(A, (u64)e))
-        GAGG_ATOMIC(GAGG_MAX_I64, i64, atomicMax(A, key_i64(e)))
-        GAGG_ATOMIC(GAGG_MAX_U64, u64, atomicMax(A, e))
-        GAGG_ATOMIC(GAGG_MAX_B8, u8, atomicMax(A, (u64)(e != 0)))
-        // floating MIN/MAX through the total-order key of the double (NaN rows skipped:
-        // "val < result" is false for NaN, aggregation_operators.h:200,221)
-#define FKEY(d) ({ u64 b_ = d2u((double)(d)); (b_ & 0x8000000000000000ull) ? ~b_ : (b_ | 0x8000000000000000ull); })
-        GAGG_ATOMIC(GAGG_MIN_F32, float, if (e == e) atomicMin(A, FKEY(e)))
-        GAGG_ATOMIC(GAGG_MIN_F64, double, if (e == e) atomicMin(A, FKEY(e)))
-        GAGG_ATOMIC(GAGG_MAX_F32, float, if (e == e) atomicMax(A, FKEY(e)))
-        GAGG_ATOMIC(GAGG_MAX_F64, double, if (e == e) atomicMax(A, FKEY(e)))
-        default: break;
-      }
+#ifdef SSGPU_RTC_NINSTR
+#include "rtc_steps.h"   // { constexpr int pc = k; #include "vm_body.inc" } for k = 0 .. SSGPU_RTC_NINSTR - 1 (rtc.cpp)
+#else
+    VM_PC_LOOP {
+#include "vm_body.inc"
     }
+#endif
     PC_PROF(if (P.debug_pc && P.n_instr > 0 && t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr - 1] += __builtin_amdgcn_s_memtime() - dbg_pc_last;)
   }
 
@@ -2178,6 +714,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
       P.wg_partials[((size_t)blockIdx.x * P.n_slots + s) * VM_WAVES + w] = *acc_rec(P, (u32)s, w);
 }
 
+#ifndef __HIPCC_RTC__   // runtime compilation (rtc.cpp) specialises the pipeline kernel only
 // ---------------------------------------------------------------------------
 // finish kernel: combine [grid][n_slots][4 waves] partial records per slot, in
 // (workgroup, wave) order, by the slot's rule.  One thread per slot.
@@ -2949,3 +1486,4 @@ hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, u
   hipLaunchKernelGGL(ssgpu_fill_pattern_u64_kernel, dim3(blocks), dim3(256), 0, stream, (u64*)p, (const u64*)pattern, plen, n);
   return hipGetLastError();
 }
+#endif  // __HIPCC_RTC__

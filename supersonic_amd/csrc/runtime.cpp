@@ -57,6 +57,9 @@ struct ssgpu_ctx {
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
   int64_t part_rec_align = 0;    // partition records padded to a multiple of this many bytes (plans created after the option is set)
+  int64_t specialize = -1;       // stages' main programs as kernels specialised by runtime compilation (rtc.cpp): 1 = from the
+                                 // first run, 0 = never, -1 = once a plan has run SPECIALIZE_AFTER_RUNS times (a plan that keeps
+                                 // running is worth the ~3 s compilation; a one-shot plan is not)
   bool filter_single_pass = false;   // materialising Filter: one pass with decoupled look-back instead of count pass + scan + store pass (plans created after the option is set)
 };
 
@@ -105,6 +108,10 @@ struct OutCol { DevBuf data, nulls; bool nullable = false; uint32_t width = 8; }
 struct StageExec {
   // device copies of the programs, finalised for tile_rows
   DevBuf prog_main, prog_count;
+  void* rtc_fn = nullptr;       // the main program's specialised kernel (rtc.cpp), NULL = interpreter
+  bool rtc_tried = false;
+  std::vector<VmInstr> host_prog_main;   // the finalised main program (what rtc.cpp compiles)
+  std::string rtc_why;          // why not, when specialisation was asked for and did not happen
   ProgramLayout lay{};
   ProgramLayout lay_count{};
   int n_instr_main = 0, n_instr_count = 0;
@@ -131,6 +138,7 @@ struct StageExec {
   DevBuf prog_pscatter, part_hist, part_recs;
   ProgramLayout lay_pscatter{};
   int n_instr_pscatter = 0;
+  void* rtc_fn_pscatter = nullptr; bool rtc_tried_pscatter = false; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jrows, jmisc;
@@ -170,6 +178,7 @@ struct ssgpu_plan {
   int64_t aux_rows = -1;
   std::string describe, describe_full;
   std::atomic<int> interrupted{0};
+  int64_t n_runs = 0;           // runs started (the auto mode of the runtime specialisation counts them)
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
   // the (dom0, dom1) pairs of the most recent profiled runs: ev_dom0 / ev_dom1 alias the current pair, so
   // a caller can time many asynchronous runs and read every kernel duration afterwards, without a sync in between
@@ -275,6 +284,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "profile_total") c->profile_total = value;
   else if (k == "debug_timing") c->debug_timing = value;
   else if (k == "filter_single_pass") c->filter_single_pass = value != 0;
+  else if (k == "specialize") c->specialize = value;
   else if (k == "part_rec_align") c->part_rec_align = value;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
@@ -557,16 +567,26 @@ int upload_program(ssgpu_ctx* c, const Program& prog, const ProgramLayout& L, De
   return SSGPU_OK;
 }
 
+static const int64_t SPECIALIZE_AFTER_RUNS = 8;
 int prepare_stage(ssgpu_plan* p, size_t si) {
   ssgpu_ctx* c = p->ctx;
   Stage& st = p->stages[si];
   StageExec& ex = p->exec[si];
   if (st.main.empty()) return SSGPU_OK;
   ProgramLayout L = layout_program(st.main, c->opt);
-  if (ex.prog_main.p && L.K == ex.lay.K) return SSGPU_OK;  // already prepared
+  auto maybe_specialize = [&]() {
+    if (ex.rtc_tried || c->specialize == 0 || (c->specialize < 0 && p->n_runs < SPECIALIZE_AFTER_RUNS)) return;
+    ex.rtc_tried = true;
+    if (ex.lay.lds_bytes > 64u * 1024u) ex.rtc_why = "the program's LDS exceeds what a module-loaded kernel may use without attributes";
+    else ex.rtc_fn = ssgpu_rtc_specialize(c->device, ex.host_prog_main.data(), ex.n_instr_main, ex.lay.K, st.main.uses_math, &ex.rtc_why);
+  };
+  if (ex.prog_main.p && L.K == ex.lay.K) { maybe_specialize(); return SSGPU_OK; }  // already prepared
   ex.lay = L;
   int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
+  ex.host_prog_main = p->host_prog_scratch;
+  ex.rtc_fn = nullptr; ex.rtc_why.clear(); ex.rtc_tried = false;
+  maybe_specialize();
   if (!st.count_pass.empty()) {
     // the count pass stages only the predicate's inputs: it takes the largest tile (fewer, longer tiles; its counts
     // are still per tile of the store pass)
@@ -718,6 +738,12 @@ int grid_for(ssgpu_ctx* c, const ProgramLayout& L, int n_tiles) {
   return (int)std::max<int64_t>(g, 1);
 }
 
+// the stage's main program: its specialised kernel when there is one (and the launch's LDS fits a module-loaded kernel)
+static hipError_t launch_main(ssgpu_ctx* c, StageExec& ex, const VmParams& P, int K, int grid) {
+  if (ex.rtc_fn && P.lds_bytes <= 64u * 1024u && !P.debug_pc) return ssgpu_launch_pipeline_rtc(ex.rtc_fn, P, grid, c->stream);
+  return ssgpu_launch_pipeline(P, K, grid, c->stream);
+}
+
 void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const DevBuf& dev_prog, int n_instr,
                  const InCols& in, int64_t row_id_base) {
   memset(P, 0, sizeof(*P));
@@ -823,7 +849,7 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
   HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
   { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+  HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
   HIP_TRY(c, ssgpu_launch_finish_slots(ex.wg_partials.as<VmAccRec>(), ns, grid * VM_WAVES, ex.slot_kind.as<int>(),
@@ -932,7 +958,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_b
     ex.out_rows = in.rows;
   }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+  HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   p->counters.n_launches += 1;
   return print_pc_profile(c, ex, st.main, ex.n_instr_main);
@@ -1027,6 +1053,13 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     ex.lay_pscatter = layout_program(st.part_scatter, o);
     int rc = upload_program(c, st.part_scatter, ex.lay_pscatter, &ex.prog_pscatter, &ex.n_instr_pscatter, &p->host_prog_scratch);
     if (rc != SSGPU_OK) return rc;
+    ex.host_prog_pscatter = p->host_prog_scratch;
+  }
+  if (!ex.rtc_tried_pscatter && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS))) {
+    ex.rtc_tried_pscatter = true;
+    std::string why;
+    ex.rtc_fn_pscatter = ssgpu_rtc_specialize(c->device, ex.host_prog_pscatter.data(), ex.n_instr_pscatter, ex.lay_pscatter.K, st.part_scatter.uses_math, &why);
+    if (!ex.rtc_fn_pscatter && ex.rtc_why.empty()) ex.rtc_why = "partition scatter: " + why;
   }
   bool any_cnt = false;
   for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
@@ -1108,7 +1141,8 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
     { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
+    if (ex.rtc_fn_pscatter && Ps.lds_bytes <= 64u * 1024u && !Ps.debug_pc) HIP_TRY(c, ssgpu_launch_pipeline_rtc(ex.rtc_fn_pscatter, Ps, grid, c->stream));
+    else HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
     { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
     PartAggParams A;
     memset(&A, 0, sizeof(A));
@@ -1230,7 +1264,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)P.lds_bytes;
     { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+    HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: wgs/CU=%d local entries=%u sub-tables=%u grid=%d lds=%u\n", ex.group_wgs, lcap, lsub, grid, P.lds_bytes);
@@ -1493,7 +1527,7 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   P.group.cnt = ex.gcnt.as<unsigned int>();
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, ssgpu_launch_pipeline(P, ex.lay.K, grid, c->stream));
+  HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   rc = ensure_rowid_tmp(c, st, ex, nseg);
   if (rc != SSGPU_OK) return rc;
@@ -1607,6 +1641,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
     c->err = "partial runs need a plan whose only stage is a ScalarAggregate"; return SSGPU_ERROR_NOT_IMPLEMENTED;
   }
   for (size_t si = 0; si < p->stages.size(); ++si) {
+    if (si == 0) ++p->n_runs;
     int rc = prepare_stage(p, si);
     if (rc != SSGPU_OK) return rc;
   }
@@ -1675,6 +1710,16 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
   return SSGPU_OK;
 }
 
+int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
+  if (!p) return 0;
+  int32_t n = 0;
+  for (auto& ex : p->exec) {
+    if (ex.rtc_fn) ++n;
+    if (ex.rtc_fn_pscatter) ++n;
+    else if (!ex.rtc_why.empty()) p->ctx->err = "stage runs on the interpreter: " + ex.rtc_why;
+  }
+  return n;
+}
 int ssgpu_plan_set_memory_limit(ssgpu_plan* p, int64_t bytes) {
   if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   p->quota.limit = bytes < 0 ? -1 : bytes;

@@ -20,7 +20,13 @@
 #ifndef SSGPU_VM_H_
 #define SSGPU_VM_H_
 
+#ifdef __HIPCC_RTC__   /* runtime compilation (rtc.cpp): no host headers */
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t; typedef unsigned long uintptr_t;
+typedef int hipError_t; typedef struct ihipStream_t* hipStream_t;
+#else
 #include <stdint.h>
+#endif
 
 #define VM_NONE 0xFFFFFFFFu
 /* functions of MATH1_F64 / MATH2_F64 (expression/core/math_evaluators.h:92-204: the libm calls of the reference) */

@@ -1089,3 +1089,50 @@ def test_aggregates_into_other_result_types(gpu_ctx, n):
         fl.AddAggregationWithDefinedOutputType(agg, col, out, t)
     run_both(ss.ScalarAggregate(fl, ss.ScanView(view)), gpu_ctx)
     run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), fl, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+
+
+# ---- runtime specialisation (context option "specialize", csrc/rtc.cpp): the same handlers compiled per plan with the
+# ---- opcode dispatch folded away must give bit-identical results ---------------------------------------------------------
+@pytest.fixture(scope="module")
+def specialized_ctx():
+    c = ss.Context(0)
+    c.set_option("specialize", 1)
+    return c
+
+
+def _run_specialized(op, ctx, expect_stages=1, **kw):
+    got = run_both(op, ctx, **kw)
+    plan = ss.Plan(op, ctx)
+    plan.run()
+    assert plan.specialized() >= expect_stages, ctx.last_error()
+    return got
+
+
+@pytest.mark.parametrize("n", [0, 1, 513, 2049, 100003])
+def test_specialized_scalar_aggregates(specialized_ctx, n):
+    _run_specialized(fpa_wide(make_view(n)), specialized_ctx)
+    _run_specialized(fpa_narrow(make_view(n)), specialized_ctx)
+    _run_specialized(fpa_wide(make_view(n, nullable=True)), specialized_ctx)
+
+
+@pytest.mark.parametrize("n", [1, 1025, 100003])
+def test_specialized_materialising_and_group_stages(specialized_ctx, n):
+    _run_specialized(compute_exprs(make_view(n, nullable=True)), specialized_ctx)
+    _run_specialized(ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(make_view(n))), specialized_ctx)
+    _run_specialized(group_query(make_view(n, nullable=True), True), specialized_ctx, ignore_order=True)
+
+
+def test_specialized_kernels_are_cached_and_report_errors(specialized_ctx):
+    import time
+    view = make_view(100003)
+    t0 = time.time(); p1 = ss.Plan(fpa_wide(view), specialized_ctx); p1.run(); specialized_ctx.synchronize(); first = time.time() - t0
+    t0 = time.time(); p2 = ss.Plan(fpa_wide(make_view(5000)), specialized_ctx); p2.run(); specialized_ctx.synchronize(); second = time.time() - t0
+    assert p1.specialized() == 1 and p2.specialized() == 1
+    assert second < max(first, 0.5)          # same program: no second compilation
+    # evaluation errors surface the same way from a specialised kernel
+    schema = ss.TupleSchema([ss.Attribute("b", ss.INT32)])
+    bad = ss.View(schema, [np.array([4, 0, 1], np.int32)])
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "q", "s")
+    op = ss.ScalarAggregate(spec, ss.Compute(ss.CompoundExpression().AddAs("q", ss.DivideSignaling(ss.ConstInt32(8), NA("b"))), ss.ScanView(bad)))
+    r = op.CreateCursor(specialized_ctx).Next()
+    assert r.is_failure() and r.exception().return_code == ss.ERROR_EVALUATION_ERROR
