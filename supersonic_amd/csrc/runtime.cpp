@@ -224,6 +224,8 @@ int ssgpu_ctx_create(int device_id, ssgpu_ctx** out) {
     (void)ssgpu_pipeline_set_max_lds(160 * 1024);
     (void)ssgpu_part_agg_set_max_lds(160 * 1024);
   }
+  // SSGPU_SPECIALIZE (development / test sweeps): the default of the `specialize` option for contexts of this process
+  if (const char* e = getenv("SSGPU_SPECIALIZE")) c->specialize = atoi(e);
   *out = c;
   return SSGPU_OK;
 }
