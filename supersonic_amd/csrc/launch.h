@@ -52,7 +52,10 @@ struct PartAggParams {
   unsigned int local_capacity;        // LDS table entries per partition
   unsigned int n_gaggs;               // accumulator words per group
   unsigned int n_aggs, any_cnt;
-  unsigned int debug, pad;            // development switches (perf attribution): 1 = no aggregation, 2 = no probe
+  unsigned int debug;                 // development switches (perf attribution): 1 = no aggregation, 2 = no probe
+  unsigned int slab_segs;             // 0: workgroup = hash partition (its table is dumped to its own slots of T).  > 0: ONE
+                                      // partition; workgroup j aggregates segments [j * slab_segs, (j + 1) * slab_segs) -- a slab of
+                                      // the rows -- in a table that holds EVERY group, and merges it into T with atomics
   VmGroupTable T;                     // global table: capacity_mask + 1 == n_parts * local_capacity (any number)
   // one packed descriptor per aggregate: GAGG opcode (bits 0-15) | first accumulator word (16-23) | byte offset of
   // the value in the record, 0xFF = none (24-31) | value width (32-39) | byte offset of the NULL flag, 0xFF = never

@@ -1011,7 +1011,10 @@ template <int MAXW>
 __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_part_agg_kernel(const PartAggParams P) {
   typedef typename RecVec<MAXW>::type Rec;
   const u32 t = threadIdx.x, part = blockIdx.x;
-  const u32 C = P.local_capacity, ng = P.n_gaggs, W = P.rec_words, G = P.n_segs;
+  const u32 C = P.local_capacity, ng = P.n_gaggs, W = P.rec_words;
+  // slab mode: this workgroup's segments are a run of the single partition's segments
+  const u32 seg0 = P.slab_segs ? part * P.slab_segs : 0u;
+  const u32 G = P.slab_segs ? (seg0 < P.n_segs ? (P.n_segs - seg0 < P.slab_segs ? P.n_segs - seg0 : P.slab_segs) : 0u) : P.n_segs;
   // an entry's accumulator words are `st` words apart, st odd: the lanes of a wave hit word k of 64 different entries,
   // and with an even stride (16 words = 128 B) those addresses fall into two LDS banks -- a 32-way conflict on every
   // atomic (measured: 5x slower)
@@ -1026,14 +1029,14 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (P.any_cnt) lcnt[i] = 0u; }
   u32 total = 0;
   {
-    const u32 n = t < G ? P.counts[(u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
+    const u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
     const u32 ex = part_block_scan(n, wsum, t, &total);
     if (t < G) segoff[t] = ex;
     if (t == 0) segoff[G] = total;
   }
   __syncthreads();
-  const u64* const recs = P.recs + (u64)SEG_INDEX(part, 0u, P.n_parts, G) * P.seg_cap * W;
-  const u64 seg_step = (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
+  const u64* const recs = P.recs + (P.slab_segs ? (u64)seg0 : (u64)SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap * W;
+  const u64 seg_step = P.slab_segs ? (u64)P.seg_cap : (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
   const u32 seg_cap = P.seg_cap, n_aggs = P.n_aggs;
   const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
   u32 seg = 0;
@@ -1065,7 +1068,8 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
           lkeys[C] = 0ull;                               // marks the reserved entry as used
         } else {
           u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
-          for (int probe = 0; probe < 16; ++probe) {    // a longer cluster = the table is too full: the host re-partitions finer
+          const int probe_limit = P.slab_segs ? (int)C : 16;   // hash partitions: a longer cluster = the table is too full, the host re-partitions finer
+          for (int probe = 0; probe < probe_limit; ++probe) {
             const u64 cur = __hip_atomic_load(lkeys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (cur == key) { found = i; break; }
             if (cur == VM_KEY_EMPTY) {
@@ -1132,6 +1136,30 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
     }
   }
   __syncthreads();
+  if (P.slab_segs) {
+    // slab mode: every workgroup saw (a slab of) all groups: merge the occupied entries into the global table, one
+    // atomic per (group, accumulator word) -- the direct path's end-of-kernel merge
+    for (u32 e = t; e <= C; e += SSGPU_PART_THREADS) {
+      const u64 key = lkeys[e];
+      if (key == VM_KEY_EMPTY) continue;
+      u32 gs;
+      if (e == C) { gs = P.T.capacity_mask + 1u; P.T.keys[gs] = 0ull; }   // the EMPTY-valued key's reserved slot
+      else gs = group_insert(P.T, key);
+      if (gs == 0xFFFFFFFFu) continue;                                     // global table full: flagged, the host regrows
+      for (u32 s = 0; s < ng; ++s) {
+        const u64 v = lacc[(size_t)e * st + s];
+        u64* A = &P.T.acc[(u64)gs * ng + s];
+        const u32 op = P.T.merge_op[s];
+        if (op == VM_MERGE_ADD_U64) { if (v) atomicAdd(A, v); }
+        else if (op == VM_MERGE_MIN_U64) atomicMin(A, v);
+        else if (op == VM_MERGE_MAX_U64) atomicMax(A, v);
+        else if (op == VM_MERGE_ADD_F64_HI) dd_atomic_add(reinterpret_cast<double*>(A), u2d(v));
+        else unsafeAtomicAdd(reinterpret_cast<double*>(A), u2d(v));
+        if (P.any_cnt) { const u32 c = lcnt[(size_t)e * st + s]; if (c) atomicAdd(&P.T.cnt[(u64)gs * ng + s], c); }
+      }
+    }
+    return;
+  }
   // dump: local entry e of partition `part` = global slot part * C + e (empty entries stay empty); the reserved
   // entry, if this partition saw the EMPTY-valued key, = the global table's reserved slot
   for (u32 e = t; e < C; e += SSGPU_PART_THREADS) P.T.keys[(u64)part * C + e] = lkeys[e];

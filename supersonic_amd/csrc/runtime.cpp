@@ -50,6 +50,7 @@ struct ssgpu_ctx {
   int64_t part_agg_debug = 0;
   int64_t sort_records = 1;      // 0: always gather payload columns one by one
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
+  int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_hi_digits = 4;    // high digits the hybrid sort passes over before fixing ties: 2..4, 0 = by row count
   int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
@@ -132,6 +133,8 @@ struct StageExec {
   bool group_partitioned = false;
   uint32_t part_n = 256;        // hash partitions (doubled when a partition overflows its LDS table)
   bool part_n_chosen = false;
+  bool part_slab_failed = false;
+  bool part_slab = false;       // partitioned path without hash partitions: every aggregation workgroup holds all groups (few groups)
   double part_groups_est = 0;   // group count estimated by the direct path's run feedback
   uint32_t part_seg_growth = 1; // x4 whenever a (partition, workgroup) segment ran full
   bool part_failed = false;     // the partitioned shape could not hold this input: stay on the direct path
@@ -275,6 +278,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_lds_target") c->part_lds_target = value;
   else if (k == "part_agg_lds") c->part_agg_lds = value;
   else if (k == "part_agg_debug") c->part_agg_debug = value;
+  else if (k == "group_slab") c->group_slab = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
   else if (k == "sort_records") c->sort_records = value;
   else if (k == "sort_hybrid") c->sort_hybrid = value;
@@ -1071,7 +1075,11 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
   const uint32_t stw = ng | 1u;   // accumulator words of an LDS entry are an odd number of words apart (bank conflicts, see the kernel)
   const uint32_t entry = 8u + stw * 8u + (any_cnt ? stw * 4u : 0u);
   const uint32_t fixed = entry + (1024u + 1u) * 4u + 64u + 64u;
-  const uint32_t budget = (c->part_agg_lds > 0 ? (uint32_t)c->part_agg_lds : 80u * 1024u);
+  // slab mode (few enough groups that ONE LDS table holds them all): no hash partitioning -- the scatter writes every
+  // workgroup's records sequentially, each aggregation workgroup (1024 threads, the whole LDS) takes a slab of them into a
+  // table of all groups and merges it into the global table.  Decided by run_group_agg from its group-count estimate.
+  if (c->group_slab == 2 && !ex.part_slab_failed) ex.part_slab = true;   // forced (tests)
+  const uint32_t budget = ex.part_slab ? 159u * 1024u : (c->part_agg_lds > 0 ? (uint32_t)c->part_agg_lds : 80u * 1024u);
   if (fixed + 64u * entry > budget) { *fallback = true; return SSGPU_OK; }
   const uint32_t C = (budget - fixed) / entry;
   HIP_TRY(c, ex.gpattern.ensure(ng * 8));
@@ -1098,8 +1106,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     }
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
-    const uint32_t NP = ex.part_n;
-    const uint32_t capacity = NP * C;
+    const bool slab = ex.part_slab;
+    const uint32_t NP = slab ? 1u : ex.part_n;
+    uint32_t capacity = NP * C;
+    if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
     const size_t slots = (size_t)capacity + 1;
     VmParams Ps;
     fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
@@ -1121,7 +1131,8 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     // records a (partition, workgroup) segment holds: the expected share of the INPUT rows (an upper bound of the
     // selected ones) with head room for the spread of a uniform hash, times the growth factor of earlier overflows
     const double expect = (double)std::max<int64_t>(in.rows, 1) / ((double)NP * (double)grid);
-    const uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
+    uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
+    if (slab) seg_cap = (uint64_t)((Ps.n_tiles + grid - 1) / grid) * (uint64_t)Ps.tile_rows;   // all rows a workgroup can see: never full
     const uint64_t n_segs = (uint64_t)NP * (uint64_t)grid;
     if (n_segs * seg_cap >= 0xFFFFFFFFull) { *fallback = true; return SSGPU_OK; }   // record indices are 32-bit
     HIP_TRY(c, ex.gkeys.ensure(slots * 8));
@@ -1129,10 +1140,16 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
     if (ex.part_recs.ensure(n_segs * seg_cap * st.part_rec_bytes + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
     HIP_TRY(c, ex.part_hist.ensure(n_segs * 4));
-    // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
-    HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>() + capacity, VM_KEY_EMPTY, 1, c->stream));
-    HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>() + (size_t)capacity * ng, ex.gpattern.as<uint64_t>(), ng, ng, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex.gcnt.as<uint32_t>() + (size_t)capacity * ng, 0, ng * 4, c->stream));
+    if (slab) {   // the aggregation workgroups merge into the table: all of it starts empty
+      HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>(), VM_KEY_EMPTY, slots, c->stream));
+      HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>(), ex.gpattern.as<uint64_t>(), ng, slots * ng, c->stream));
+      HIP_TRY(c, hipMemsetAsync(ex.gcnt.p, 0, slots * ng * 4, c->stream));
+    } else {
+      // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
+      HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>() + capacity, VM_KEY_EMPTY, 1, c->stream));
+      HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>() + (size_t)capacity * ng, ex.gpattern.as<uint64_t>(), ng, ng, c->stream));
+      HIP_TRY(c, hipMemsetAsync(ex.gcnt.as<uint32_t>() + (size_t)capacity * ng, 0, ng * 4, c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
     Ps.error_flag = ex.error_flag.as<unsigned int>();
@@ -1151,6 +1168,11 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     A.recs = ex.part_recs.as<unsigned long long>();
     A.counts = ex.part_hist.as<unsigned int>();
     A.n_segs = (unsigned int)grid; A.seg_cap = (unsigned int)seg_cap; A.rec_words = W; A.n_parts = NP;
+    if (slab) {   // one aggregation workgroup per CU, each over a run of the scatter workgroups' segments
+      const unsigned int wgs = (unsigned int)std::min<int>(grid, std::max(c->cu_count, 1));
+      A.slab_segs = ((unsigned int)grid + wgs - 1u) / wgs;
+      A.n_parts = ((unsigned int)grid + A.slab_segs - 1u) / A.slab_segs;
+    }
     A.debug = (unsigned int)c->part_agg_debug;
     A.local_capacity = C; A.n_gaggs = ng; A.n_aggs = (unsigned int)st.part_aggs.size(); A.any_cnt = any_cnt ? 1u : 0u;
     A.T.keys = ex.gkeys.as<unsigned long long>(); A.T.acc = ex.gacc.as<unsigned long long>(); A.T.cnt = ex.gcnt.as<unsigned int>();
@@ -1170,6 +1192,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, grid %d, segments of %llu records (%u B), table overflow=%u segment overflow=%u\n",
                                  NP, C, grid, (unsigned long long)seg_cap, st.part_rec_bytes, fb[0], fb[1]);
+    if (slab && (fb[0] || fb[1])) {   // more groups than one LDS table holds after all: hash partitions
+      ex.part_slab = false; ex.part_slab_failed = true;
+      return run_group_agg_partitioned(p, si, in, row_id_base, fallback);
+    }
     if (fb[1]) {   // skewed keys: larger segments (memory permitting), else the direct path
       if (ex.part_seg_growth >= 64) { *fallback = true; return SSGPU_OK; }
       ex.part_seg_growth *= 4;
@@ -1297,7 +1323,12 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         for (int w = 4; w >= 1; --w) if ((double)local_capacity_for(w) * 0.9 >= groups) { best = w; break; }
         if (best > 0 && best != ex.group_wgs) ex.group_wgs = best;
         else if (best == 0 || (best == ex.group_wgs && (double)fb[1] * 4.0 >= rows)) {
-          if (c->group_partition && !st.part_scatter.empty() && !ex.part_failed && in.rows >= (1 << 20)) { ex.group_partitioned = true; ex.part_groups_est = groups; }
+          if (c->group_partition && !st.part_scatter.empty() && !ex.part_failed && in.rows >= (1 << 20)) {
+            ex.group_partitioned = true; ex.part_groups_est = groups;
+            // few enough groups for ONE whole-LDS table (with head room for the estimate): slabs of rows instead of hash partitions
+            const uint32_t full = (159u * 1024u - (entry + 1025u * 4u + 128u)) / entry;
+            ex.part_slab = c->group_slab != 0 && groups * 1.08 <= (double)full;   // (a nearly full table probes longer; it still beats re-partitioning)
+          }
           else if ((double)fb[1] * 2.0 >= rows) ex.group_local = false;
         }
       }

@@ -1136,3 +1136,36 @@ def test_specialized_kernels_are_cached_and_report_errors(specialized_ctx):
     op = ss.ScalarAggregate(spec, ss.Compute(ss.CompoundExpression().AddAs("q", ss.DivideSignaling(ss.ConstInt32(8), NA("b"))), ss.ScanView(bad)))
     r = op.CreateCursor(specialized_ctx).Next()
     assert r.is_failure() and r.exception().return_code == ss.ERROR_EVALUATION_ERROR
+
+
+# ---- slab mode of the partitioned GroupAggregate: few enough groups for ONE whole-LDS table per aggregation workgroup;
+# ---- no hash partitions, the scatter writes records sequentially, tables are merged into the global one ------------------
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
+@pytest.mark.parametrize("with_filter", [False, True])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_group_aggregate_slab_mode(n, with_filter, nullable):
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", 2)
+    ctx.set_option("group_slab", 2)
+    keys = ("k1",) if nullable else ("k1", "k2")
+    run_both(group_query(make_view(n, nullable=nullable), with_filter, keys), ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), None, ss.ScanView(make_view(n, nullable=True))), ctx, ignore_order=True)
+
+
+def test_group_aggregate_slab_mode_falls_back_when_the_groups_do_not_fit():
+    # forced slab mode with far more groups than one LDS table holds (and the EMPTY-valued key): the table overflow sends the
+    # stage to the hash partitions
+    n = 200000
+    rng = np.random.default_rng(8)
+    key = rng.integers(0, 50000, n).astype(np.int64)
+    key[::777] = -1
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64), ss.Attribute("d", ss.DOUBLE)])
+    view = ss.View(schema, [key, rng.integers(-1000, 1000, n), rng.integers(-4000, 4000, n) * 0.25])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "c").AddAggregation(ss.MIN, "v", "mn")
+            .AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MAX, "d", "mx"))
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", 2)
+    ctx.set_option("group_slab", 2)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view)), ctx, ignore_order=True)
+    small = ss.View(schema, [key % 700, view.column(1).data, view.column(2).data])   # 700 groups (+ the EMPTY key's image): fits
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(small)), ctx, ignore_order=True)
