@@ -16,7 +16,7 @@ cp "$(find $S/stats -name '*domain_stats.csv' | head -1)" profiles/${R}_domain_s
 for q in group2 sort sort_key filter_mat group_small group_tiny join; do
   [ -f gpurun_out/prof_cfg/${q}_kernel_stats.csv ] && cp gpurun_out/prof_cfg/${q}_kernel_stats.csv profiles/${R}_${q}_kernel_stats.csv
 done
-for q in group3 group extras; do
+for q in group3 group extras interp; do
   [ -f gpurun_out/bench_$q.json ] && grep "^{" gpurun_out/bench_$q.json | tail -1 > profiles/${R}_bench_${q}_line.json
 done
 [ -f gpurun_out/double_sum_ulp.json ] && cp gpurun_out/double_sum_ulp.json profiles/${R}_double_sum_ulp.json
