@@ -95,7 +95,8 @@ int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K);
 #ifndef __HIPCC_RTC__
 #include <string>
 // rtc.cpp: the pipeline kernel specialised for one finalised program (NULL + *why: keep the interpreter)
-void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, bool math, std::string* why);
+void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, bool math, const uint32_t* staged_width, const uint32_t* staged_lds_off,
+                           int n_staged, std::string* why);
 hipError_t ssgpu_launch_pipeline_rtc(void* fn, const VmParams& P, int grid, hipStream_t stream);
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);

@@ -250,11 +250,21 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
 // Only FULL tiles go through the register file; the (single) partial tile at the end of the
 // input is staged in place by stage_partial_tile().
+// staged column s: element width and LDS offset of its register -- compile-time constants in a specialised build
+#if defined(SSGPU_RTC_NINSTR) && !defined(SSGPU_RTC_DYNAMIC_STAGING)
+#define STAGED_WIDTH(P, s) kRtcStagedWidth[s]
+#define STAGED_LDS_OFF(P, s) kRtcStagedOff[s]
+#define STAGED_COUNT(P) SSGPU_RTC_NSTAGED
+#else
+#define STAGED_WIDTH(P, s) (P).staged[s].width
+#define STAGED_LDS_OFF(P, s) (P).staged[s].lds_off
+#define STAGED_COUNT(P) (P).n_staged
+#endif
 template <int K>
 __device__ __forceinline__ void load_unit(const VmParams& P, int u, i64 tile_base, int t, u32x4& v) {
   const int s = u / K, k = u % K;
   const char* const src0 = reinterpret_cast<const char*>(P.staged[s].src);
-  const u32 w = P.staged[s].width;
+  const u32 w = STAGED_WIDTH(P, s);
   if (src0 == nullptr) return;  // nullable attribute whose View carries no is_null vector: stays 0
   const u32 p = (u32)(k * VM_COMPUTE_THREADS + t);
   if (w == 8) {
@@ -273,9 +283,9 @@ __device__ __forceinline__ void load_unit(const VmParams& P, int u, i64 tile_bas
 template <int K>
 __device__ __forceinline__ void commit_unit(const VmParams& P, int u, u32x4 v, int t) {
   const int s = u / K, k = u % K;
-  const u32 w = P.staged[s].width;
+  const u32 w = STAGED_WIDTH(P, s);
   const u32 p = (u32)(k * VM_COMPUTE_THREADS + t);
-  char* const dst = smem + P.staged[s].lds_off;
+  char* const dst = smem + STAGED_LDS_OFF(P, s);
   if (w == 8) *reinterpret_cast<u32x4*>(dst + p * 16u) = v;
   else if (w == 4) { u32x2 x = {v[0], v[1]}; *reinterpret_cast<u32x2*>(dst + p * 8u) = x; }
   else *reinterpret_cast<unsigned short*>(dst + p * 2u) = (unsigned short)v[0];
@@ -288,9 +298,9 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
   for (int u = u_begin; u < u_end; ++u) {
     const int s = u / K, k = u % K;
     const char* const src0 = reinterpret_cast<const char*>(P.staged[s].src);
-    const u32 w = P.staged[s].width;
+    const u32 w = STAGED_WIDTH(P, s);
     const u32 p = (u32)(k * VM_COMPUTE_THREADS + t), r0 = 2u * p;
-    char* const dst = smem + P.staged[s].lds_off;
+    char* const dst = smem + STAGED_LDS_OFF(P, s);
     const bool v0 = src0 != nullptr && r0 < tile_valid, v1 = src0 != nullptr && r0 + 1u < tile_valid;
     if (w == 8) {
       const u64* src = reinterpret_cast<const u64*>(src0) + tile_base + r0;
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   const int wave = t >> 6;
   const int tile_rows = VM_TILE_UNIT * K;
   const int n_my_tiles = P.n_tiles > (int)blockIdx.x ? (P.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int n_units = P.n_staged * K;
+  const int n_units = STAGED_COUNT(P) * K;
 
   // zero this workgroup's LDS aggregate records (slow slots; fast slots are written once)
   for (u32 o = (u32)t * 8u; o < (u32)P.n_slots * VM_ACC_STRIDE; o += VM_COMPUTE_THREADS * 8u)

@@ -573,6 +573,11 @@ int upload_program(ssgpu_ctx* c, const Program& prog, const ProgramLayout& L, De
   return SSGPU_OK;
 }
 
+// the staged columns of a program under a layout, as rtc.cpp bakes them into a specialised kernel (= what fill_params passes at run time)
+static void staged_table(const Program& prog, const ProgramLayout& L, std::vector<uint32_t>* width, std::vector<uint32_t>* off) {
+  width->clear(); off->clear();
+  for (auto& sgd : prog.staged) { width->push_back(prog.regs[sgd.reg].width); off->push_back(prog.regs[sgd.reg].row_off * (uint32_t)(VM_TILE_UNIT * L.K)); }
+}
 static const int64_t SPECIALIZE_AFTER_RUNS = 8;
 int prepare_stage(ssgpu_plan* p, size_t si) {
   ssgpu_ctx* c = p->ctx;
@@ -584,7 +589,10 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
     if (ex.rtc_tried || c->specialize == 0 || (c->specialize < 0 && p->n_runs < SPECIALIZE_AFTER_RUNS)) return;
     ex.rtc_tried = true;
     if (ex.lay.lds_bytes > 64u * 1024u) ex.rtc_why = "the program's LDS exceeds what a module-loaded kernel may use without attributes";
-    else ex.rtc_fn = ssgpu_rtc_specialize(c->device, ex.host_prog_main.data(), ex.n_instr_main, ex.lay.K, st.main.uses_math, &ex.rtc_why);
+    else {
+      std::vector<uint32_t> sw, so; staged_table(st.main, ex.lay, &sw, &so);
+      ex.rtc_fn = ssgpu_rtc_specialize(c->device, ex.host_prog_main.data(), ex.n_instr_main, ex.lay.K, st.main.uses_math, sw.data(), so.data(), (int)sw.size(), &ex.rtc_why);
+    }
   };
   if (ex.prog_main.p && L.K == ex.lay.K) { maybe_specialize(); return SSGPU_OK; }  // already prepared
   ex.lay = L;
@@ -1064,7 +1072,8 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
   if (!ex.rtc_tried_pscatter && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS))) {
     ex.rtc_tried_pscatter = true;
     std::string why;
-    ex.rtc_fn_pscatter = ssgpu_rtc_specialize(c->device, ex.host_prog_pscatter.data(), ex.n_instr_pscatter, ex.lay_pscatter.K, st.part_scatter.uses_math, &why);
+    std::vector<uint32_t> sw, so; staged_table(st.part_scatter, ex.lay_pscatter, &sw, &so);
+    ex.rtc_fn_pscatter = ssgpu_rtc_specialize(c->device, ex.host_prog_pscatter.data(), ex.n_instr_pscatter, ex.lay_pscatter.K, st.part_scatter.uses_math, sw.data(), so.data(), (int)sw.size(), &why);
     if (!ex.rtc_fn_pscatter && ex.rtc_why.empty()) ex.rtc_why = "partition scatter: " + why;
   }
   bool any_cnt = false;
