@@ -523,7 +523,7 @@ static bnode* bind_op(const orc_expr* e, const orc_schema* s, orc_error* err) {
         char cn[256]; snprintf(cn, sizeof(cn), "CAST_%s_TO_%s(%s)", type_name(t), type_name(st), c->name);
         bnode* k = bnode_new(B_CAST, OP_CAST, st, c->nullable, cn); k->args[0] = c; k->nargs = 1; c = fold(k, err);
       }
-      char nm[256]; snprintf(nm, sizeof(nm), "(-%s)", c->name);
+      char nm[256]; snprintf(nm, sizeof(nm), "(-%s)", a[0]->name);   /* the reinterpreting factory adds no CAST to the name (arithmetic_expressions_test.cc:28) */
       bnode* b = bnode_new(B_OP, op, st, c->nullable, nm); b->args[0] = c; b->nargs = 1;
       return fold(b, err);
     }

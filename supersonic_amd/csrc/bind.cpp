@@ -585,7 +585,9 @@ static Status bind_operator(const ssgpu_expr& x, std::vector<BExprP> args, int d
           e->args.push_back(c); c = e;
         }
       }
-      *out = fold(make_op(op, st, c->nullable, "(-" + c->name + ")", {c}, depth));
+      // the signed-type unary factory reinterprets an unsigned argument without a CAST node of its own: the name shows
+      // the argument itself (arithmetic_expressions_test.cc:28, arithmetic_bound_expressions_test.cc:26-29: "(-$0)" for UINT32)
+      *out = fold(make_op(op, st, c->nullable, "(-" + args[0]->name + ")", {c}, depth));
       return Status::OK();
     }
     case OP_BITWISE_NOT: {

@@ -266,7 +266,7 @@ for (frm, to, ok, lines) in EXPLICIT_CASTS:
 # ---- arithmetic (arithmetic_expressions_test.cc) ---------------------------------------------
 bind_case("NegateBinding_double", A + ":25-27", "Negate", [F64], [False], "(-$0)", F64, False)
 bind_case("NegateBinding_int32", A + ":25-28", "Negate", [I32], [False], "(-$0)", I32, False)
-bind_case("NegateBinding_uint32", A + ":25-29", "Negate", [U32], [False], "(-CAST_UINT32_TO_INT32($0))", I32, False)
+bind_case("NegateBinding_uint32", A + ":25-29", "Negate", [U32], [False], "(-$0)", I32, False)
 expr_case("Negate_float", A + ":34-40", [F32, F32], [[3., -3.], [0., -0.], [-3., 3.], [11.2, -11.2]], "Negate")
 expr_case("Negate_uint64", A + ":42-46", [U64, I64], [[0, 0], [4, -4], [12314, -12314]], "Negate")
 expr_case("Negate_uint32_null", A + ":48-52", [U32, I32], [[13, -13], [None, None], [0, 0]], "Negate")
@@ -1019,6 +1019,68 @@ op_case("AggregationOperators_First", AO + ":275-285", cols([I32]), [[7], [1], [
 op_case("AggregationOperators_Last", AO + ":287-297", cols([I32]), [[7], [1], [9]], ["ScalarAggregate", [["LAST", "col0", "l"]], "INPUT"], [I32], [[9]])
 op_case("AggregationOperators_CrossTypeAssignment", AO + ":35-42", cols([I32]), [[1]],
         ["ScalarAggregate", [["FIRST", "col0", "f", I64]], "INPUT"], [I64], [[1]])
+
+
+# ---- bound-expression factories: result names, promotions and bind failures (arithmetic_bound_expressions_test.cc,
+# ---- elementary_bound_expressions_test.cc, math_bound_expressions_test.cc; inputs are the fixture's NOT NULL $0, $1, ...
+# ---- unless TestBoundFactoryWithNulls says otherwise; expect_error -1 = TestBoundFactoryFailure: any bind failure) -------
+AB = "supersonic/expression/core/arithmetic_bound_expressions_test.cc"
+for _n, _f, _t, _name in (("Negate_INT32", "Negate", [I32], "(-$0)"), ("Negate_UINT32", "Negate", [U32], "(-$0)"),
+                          ("Plus", "Plus", [I32, I64], "(CAST_INT32_TO_INT64($0) + $1)"), ("Multiply", "Multiply", [I32, I64], "(CAST_INT32_TO_INT64($0) * $1)"),
+                          ("Minus", "Minus", [I32, I64], "(CAST_INT32_TO_INT64($0) - $1)"),
+                          ("DivideSignaling", "DivideSignaling", [U32, U64], "(CAST_UINT32_TO_DOUBLE($0) /. CAST_UINT64_TO_DOUBLE($1))"),
+                          ("DivideNulling", "DivideNulling", [U32, U64], "(CAST_UINT32_TO_DOUBLE($0) /. CAST_UINT64_TO_DOUBLE($1))"),
+                          ("DivideQuiet", "DivideQuiet", [U32, U64], "(CAST_UINT32_TO_DOUBLE($0) /. CAST_UINT64_TO_DOUBLE($1))"),
+                          ("CppDivideSignaling", "CppDivideSignaling", [U32, U64], "(CAST_UINT32_TO_UINT64($0) / $1)"),
+                          ("CppDivideNulling", "CppDivideNulling", [U32, U64], "(CAST_UINT32_TO_UINT64($0) / $1)"),
+                          ("ModulusSignaling", "ModulusSignaling", [U32, U64], "(CAST_UINT32_TO_UINT64($0) % $1)"),
+                          ("ModulusNulling", "ModulusNulling", [U32, U64], "(CAST_UINT32_TO_UINT64($0) % $1)")):
+    bind_case("ArithmeticBound_" + _n, AB + ":26-77", _f, _t, [False] * len(_t), _name, None, None)
+
+EBT = "supersonic/expression/core/elementary_bound_expressions_test.cc"
+bind_plan_case("ElementaryBound_CastTo_same", EBT + ":44-47", ["CastToType", I64, AT(0)], [I64], [False], "$0", I64, False)
+bind_plan_case("ElementaryBound_CastTo_widen", EBT + ":44-47", ["CastToType", I64, AT(0)], [I32], [False], "CAST_INT32_TO_INT64($0)", I64, False)
+bind_case("ElementaryBound_IfNull_not_nullable", EBT + ":82", "IfNull", [I32, I64], [False, False], "CAST_INT32_TO_INT64($0)", None, None)
+bind_case("ElementaryBound_IfNull_nullable_left", EBT + ":83-84", "IfNull", [I32, I32], [True, False], "IFNULL($0, $1)", None, None)
+bind_case("ElementaryBound_IfNull_nullable_right", EBT + ":85", "IfNull", [I32, I32], [False, True], "$0", None, None)
+for _i, (_t, _name) in enumerate((([BOOL, I32, BOOL, I32], "CASE($0, $1, $2, $3)"), ([STR, STR, STR, STR], "CASE($0, $1, $2, $3)"),
+                                  ([U32, STR, I32, STR, I64, STR, U64, STR],
+                                   "CASE(CAST_UINT32_TO_INT64($0), $1, CAST_INT32_TO_INT64($2), $3, $4, $5, CAST_UINT64_TO_INT64($6), $7)"),
+                                  ([U32, STR, I32, STR, I64, STR, U64, STR, F64, STR, F32, STR],
+                                   "CASE(CAST_UINT32_TO_DOUBLE($0), $1, CAST_INT32_TO_DOUBLE($2), $3, CAST_INT64_TO_DOUBLE($4), $5, CAST_UINT64_TO_DOUBLE($6), $7,"
+                                   " $8, $9, CAST_FLOAT_TO_DOUBLE($10), $11)"),
+                                  ([STR, U32, STR, I32, STR, I64, STR, U64, STR, F64, STR, F32],
+                                   "CASE($0, CAST_UINT32_TO_DOUBLE($1), $2, CAST_INT32_TO_DOUBLE($3), $4, CAST_INT64_TO_DOUBLE($5), $6, CAST_UINT64_TO_DOUBLE($7), $8, $9,"
+                                   " $10, CAST_FLOAT_TO_DOUBLE($11))"))):
+    bind_case("ElementaryBound_Case_%d" % _i, EBT + ":88-118", "CaseList", _t, [False] * len(_t), _name, None, None)
+for _i, _t in enumerate(([], [BOOL, I32, I64], [BOOL, I32, BOOL, I32, BOOL, STR], [BOOL, STR, BOOL, I32, BOOL, I32], [BOOL, STR, U32, STR])):
+    if _t:
+        bind_case("ElementaryBound_Case_fails_%d" % _i, EBT + ":119-137", "CaseList", _t, [False] * len(_t), None, None, None, expect_error=-1)
+for _n, _f in (("If", "If"), ("IfNulling", "NullingIf")):
+    bind_case("ElementaryBound_%s_INT64" % _n, EBT + ":168-187", _f, [BOOL, I32, I64], [False] * 3, "IF $0 THEN CAST_INT32_TO_INT64($1) ELSE $2", None, None)
+    bind_case("ElementaryBound_%s_FLOAT" % _n, EBT + ":168-187", _f, [BOOL, F32, U32], [False] * 3, "IF $0 THEN $1 ELSE CAST_UINT32_TO_FLOAT($2)", None, None)
+    bind_case("ElementaryBound_%s_condition_fails" % _n, EBT + ":168-187", _f, [I32, STR, STR], [False] * 3, None, None, None, expect_error=-1)
+    bind_case("ElementaryBound_%s_branches_fail" % _n, EBT + ":168-187", _f, [BOOL, U32, STR], [False] * 3, None, None, None, expect_error=-1)
+for _n, _f, _name in (("Or", "Or", "($0 OR $1)"), ("And", "And", "($0 AND $1)"), ("AndNot", "AndNot", "($0 !&& $1)"), ("Xor", "Xor", "($0 XOR $1)")):
+    bind_case("ElementaryBound_" + _n, EBT + ":190-210", _f, [BOOL, BOOL], [False, False], _name, None, None)
+bind_case("ElementaryBound_Not", EBT + ":190-192", "Not", [BOOL], [False], "(NOT $0)", None, None)
+bind_case("ElementaryBound_IsNull", EBT + ":214-216", "IsNull", [F32], [True], "ISNULL($0)", None, None)
+
+MB = "supersonic/expression/core/math_bound_expressions_test.cc"
+for _n, _f, _t, _name in (("Exp", "Exp", [F64], "EXP($0)"), ("Exp_INT32", "Exp", [I32], "EXP(CAST_INT32_TO_DOUBLE($0))"), ("LnNulling", "LnNulling", [F64], "LN($0)"),
+                          ("LnQuiet", "LnQuiet", [F64], "LN($0)"), ("Log10Nulling", "Log10Nulling", [F64], "LOG10($0)"), ("Log2Quiet", "Log2Quiet", [F64], "LOG2($0)"),
+                          ("LogNulling", "LogNulling", [F64, F64], "(LN($1) /. LN($0))"), ("PowerSignaling", "PowerSignaling", [F64, F64], "POW($0, $1)"),
+                          ("PowerNulling", "PowerNulling", [F64, F64], "POW($0, $1)"), ("PowerQuiet", "PowerQuiet", [F64, F64], "POW($0, $1)"),
+                          ("SqrtSignaling", "SqrtSignaling", [F64], "SQRT($0)"), ("SqrtNulling", "SqrtNulling", [F64], "SQRT($0)"), ("SqrtQuiet", "SqrtQuiet", [F64], "SQRT($0)"),
+                          ("Sin", "Sin", [F64], "SIN($0)"), ("Cos", "Cos", [F64], "COS($0)"), ("TanQuiet", "Tan", [F64], "TAN($0)"),
+                          ("Round", "Round", [F64], "ROUND($0)"), ("Round_INT32", "Round", [I32], "$0"),
+                          ("RoundToInt", "RoundToInt", [F64], "CEIL_TO_INT(ROUND($0))"), ("RoundToInt_UINT32", "RoundToInt", [U32], "$0"),
+                          ("Floor", "Floor", [F64], "FLOOR($0)"), ("Floor_INT32", "Floor", [I32], "$0"), ("FloorToInt", "FloorToInt", [F64], "FLOOR_TO_INT($0)"),
+                          ("FloorToInt_INT32", "FloorToInt", [I32], "$0"), ("Ceil", "Ceil", [F64], "CEIL($0)"), ("Ceil_INT32", "Ceil", [I32], "$0"),
+                          ("CeilToInt", "CeilToInt", [F64], "CEIL_TO_INT($0)"), ("CeilToInt_INT32", "CeilToInt", [I32], "$0"), ("Trunc", "Trunc", [F64], "TRUNC($0)"),
+                          ("Trunc_UINT64", "Trunc", [U64], "$0"), ("IsFinite", "IsFinite", [F64], "IS_FINITE($0)"), ("IsNormal", "IsNormal", [F64], "IS_NORMAL($0)"),
+                          ("IsNaN", "IsNaN", [F64], "IS_NAN($0)"), ("IsInf", "IsInf", [F64], "IS_INF($0)")):
+    bind_case("MathBound_" + _n, MB + ":27-149", _f, _t, [False] * len(_t), _name, None, None)
 
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")

@@ -18,7 +18,8 @@ def test_hip_path_reproduces_reference_golden_vector(gpu_ctx, case):
     if case["expect_error"]:
         with pytest.raises(ss.SupersonicException) as e:
             ss.drain(op.CreateCursor(gpu_ctx))
-        assert e.value.return_code == case["expect_error"]
+        # -1: the reference's test only requires the bind to FAIL (TestBoundFactoryFailure): any bind-time code (4xx)
+        assert (400 <= e.value.return_code < 500) if case["expect_error"] == -1 else e.value.return_code == case["expect_error"]
         return
     cur = op.CreateCursor(gpu_ctx)
     got = ss.drain(cur, 1024)
