@@ -1082,6 +1082,38 @@ for _n, _f, _t, _name in (("Exp", "Exp", [F64], "EXP($0)"), ("Exp_INT32", "Exp",
                           ("IsNaN", "IsNaN", [F64], "IS_NAN($0)"), ("IsInf", "IsInf", [F64], "IS_INF($0)")):
     bind_case("MathBound_" + _n, MB + ":27-149", _f, _t, [False] * len(_t), _name, None, None)
 
+
+# ---- comparison_bound_expressions_test.cc:35-65: names of the comparison factories (BINARY columns are outside the path) ----
+for _n, _f, _t, _name in (("Equal", "Equal", [I32, I64], "($0 == $1)"), ("NotEqual_string", "NotEqual", [STR, STR], "($0 <> $1)"),
+                          ("Greater_date", "Greater", [DATE, DATE], "($1 < $0)"), ("Greater_datetime", "Greater", [DATETIME, DATETIME], "($1 < $0)"),
+                          ("GreaterOrEqual_bool", "GreaterOrEqual", [BOOL, BOOL], "($1 <= $0)"),
+                          ("Less_int_double", "Less", [I32, F64], "(CAST_INT32_TO_DOUBLE($0) < $1)"), ("Less_double_int", "Less", [F64, I32], "($0 < CAST_INT32_TO_DOUBLE($1))"),
+                          ("LessOrEqual_float", "LessOrEqual", [F32, F32], "($0 <= $1)"), ("IsOdd", "IsOdd", [I32], "IS_ODD($0)"), ("IsEven", "IsEven", [U64], "IS_EVEN($0)")):
+    bind_case("ComparisonBound_" + _n, CB + ":35-65", _f, _t, [False] * len(_t), _name, BOOL, False)
+bind_plan_case("InSet_string", CB + ":117-119", IN4, [STR, STR, STR, STR], [False] * 4, "$0 IN ($1, $2, $3)", BOOL, False)
+IN3 = ["InList", ["AttributeAt", 0], ["AttributeAt", 1], ["AttributeAt", 2]]
+bind_plan_case("InSet_int_string_fails", CB + ":136", IN3, [I32, STR, I32], [False] * 3, None, None, None, expect_error=-1)
+bind_plan_case("InSet_string_int_fails", CB + ":137", IN3, [STR, STR, I32], [False] * 3, None, None, None, expect_error=-1)
+
+
+# ---- terminal_expressions_test.cc:57-66,101-127: NULL and constant terminals over a 5-row input ----------------------------
+TE = "supersonic/expression/infrastructure/terminal_expressions_test.cc"
+_five = [[i] for i in range(5)]
+op_case("Terminal_NullsAreNull", TE + ":57-66", [["x", I32, False]], _five, ["Compute", ["NullOf", F64], "INPUT"], [F64], [[None]] * 5,
+        exp_names=["NULL"], exp_nullable=[True])
+op_case("Terminal_ConstInt32", TE + ":101-113", [["x", I32, False]], _five, ["Compute", ["ConstInt32", 100], "INPUT"], [I32], [[100]] * 5,
+        exp_names=["CONST_INT32"], exp_nullable=[False])
+op_case("Terminal_ConstString", TE + ":115-127", [["x", I32, False]], _five, ["Compute", ["ConstString", "Supersonic"], "INPUT"], [STR], [["Supersonic"]] * 5,
+        exp_names=["CONST_STRING"], exp_nullable=[False])
+
+
+# ---- unary_column_computers_test.cc:107-177: NULL flow of unary computers (the fixture's skip vector = the input's NULLs) ----
+UC = "supersonic/expression/vector/unary_column_computers_test.cc"
+expr_case("UnaryComputers_EvaluationCopiesNulls", UC + ":107-118", [F64, F64], [[None if i % 3 != 0 else 2.0, None if i % 3 != 0 else -2.0] for i in range(4)], "Negate")
+expr_case("UnaryComputers_EvaluationIntroducesNulls", UC + ":136-147", [F64, F64], [[1.0 - i, None if i > 1 else (1.0 - i) ** 0.5] for i in range(4)], "SqrtNulling", nullable=False)
+expr_case("UnaryComputers_EvaluationWorksForSafe", UC + ":158-177", [F64, F64], [[4.0, 2.0], [9.0, 3.0], [-1.0, None]], "SqrtNulling", nullable=False)
+expr_case("UnaryComputers_SqrtNulling_keeps_input_nulls", UC + ":120-134", [F64, F64], [[None if i % 3 != 0 else 1.0 - i, None if (i % 3 != 0 or 1 - i < 0) else (1.0 - i) ** 0.5] for i in range(4)], "SqrtNulling")
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
     with open(out, "w") as f:
