@@ -317,7 +317,8 @@ int ssgpu_allocator_create(ssgpu_ctx* ctx, int64_t quota_bytes, ssgpu_allocator*
 void ssgpu_allocator_destroy(ssgpu_allocator* a);
 /* grants between `minimal` and `requested` bytes (as many as the quota leaves); *granted may be NULL */
 int ssgpu_allocator_allocate(ssgpu_allocator* a, size_t requested, size_t minimal, void** out, size_t* granted);
-/* BufferAllocator::Reallocate: contents preserved up to the smaller size; on failure the old buffer stays valid */
+/* BufferAllocator::Reallocate: contents preserved up to the smaller size; on failure the old buffer stays valid.  Like the
+ * reference's mediator the quota is checked as if the new buffer had to exist next to the old one (memory_test.cc:183-198) */
 int ssgpu_allocator_reallocate(ssgpu_allocator* a, void* p, size_t requested, size_t minimal, void** out, size_t* granted);
 void ssgpu_allocator_free(ssgpu_allocator* a, void* p);
 int64_t ssgpu_allocator_available(const ssgpu_allocator* a); /* bytes the quota still allows; INT64_MAX if unlimited */

@@ -80,7 +80,9 @@ int ssgpu_allocator_reallocate(ssgpu_allocator* a, void* p, size_t requested, si
   const size_t old = it->second;
   size_t grant = requested;
   if (a->quota >= 0) {
-    const int64_t avail = std::max<int64_t>(a->quota - a->used + (int64_t)old, 0);   // the old buffer's bytes come back
+    // conservative like the reference's mediator (memory.h, memory_test.cc:183-198: "realloc might degenerate to
+    // create-copy-free"): the whole new size has to fit NEXT TO the old buffer
+    const int64_t avail = std::max<int64_t>(a->quota - a->used, 0);
     if ((int64_t)grant > avail) grant = (size_t)avail;
     if (grant < minimal) { *out = nullptr; return SSGPU_ERROR_MEMORY_EXCEEDED; }       // the old buffer stays valid
   }

@@ -57,15 +57,59 @@ def test_allocator_reallocate_keeps_contents_and_old_buffer_on_failure(ctx):
     src = (C.c_ubyte * 1024).from_address(p)
     for i in range(1024):
         src[i] = i & 255
-    q, g2 = a.Reallocate(p, 3000)                    # the old bytes come back to the quota first
+    q, g2 = a.Reallocate(p, 3000)                    # 3000 fit next to the old 1024
     assert g2 == 3000 and a.GetUsage() == 3000
     assert bytes((C.c_ubyte * 1024).from_address(q)) == bytes(i & 255 for i in range(1024))
     assert a.Reallocate(q, 5000) is None             # does not fit ...
     assert a.GetUsage() == 3000                       # ... and the old buffer is still owned
     assert bytes((C.c_ubyte * 16).from_address(q)) == bytes(range(16))
-    r, g3 = a.Reallocate(q, 5000, 100)               # best effort
-    assert g3 == 4096
+    r, g3 = a.Reallocate(q, 5000, 100)               # best effort: what the quota leaves NEXT TO the old buffer
+    assert g3 == 1096 and a.GetUsage() == 1096
     a.Free(r)
+
+
+def test_allocator_follows_the_reference_memory_limit_tests(ctx):
+    # base/memory/memory_test.cc:176-181 AvailableInMemoryLimit
+    limit = ss.MemoryLimit(1000, ctx)
+    assert limit.Available() == 1000
+    p, _ = limit.Allocate(300)
+    assert limit.Available() == 700
+    # :183-198 ReallocShouldAdjustQuota: the mediator reserves the whole requested size while the old buffer is held
+    p, g = limit.Reallocate(p, 500)
+    assert g == 500 and limit.GetUsage() == 500 and limit.Available() == 500
+    assert limit.Reallocate(p, 700, 600) is None
+    assert limit.GetUsage() == 500 and limit.Available() == 500
+    limit.Free(p)
+    # :200-210 AllocatingEmptyAlwaysSucceeds
+    zero = ss.MemoryLimit(0, ctx)
+    assert zero.BestEffortAllocate(300, 10) is None
+    p2, g2 = zero.BestEffortAllocate(300, 0)
+    assert p2 and g2 == 0
+    p3, g3 = zero.Allocate(0)
+    assert p3 and g3 == 0
+    # :212-223 ReallocatingEmptyAlwaysSucceeds
+    lim = ss.MemoryLimit(300, ctx)
+    b, gb = lim.BestEffortAllocate(400, 300)
+    assert b and gb == 300
+    b, gb = lim.Reallocate(b, 100, 0)                # nothing is left next to the 300 bytes held: the buffer shrinks to 0
+    assert b and gb == 0
+    b, gb = lim.Reallocate(b, 0)
+    assert b and gb == 0
+    # :53-99 SharedQuotaAllocatorShouldAllocate (one allocator, the same arithmetic)
+    q = ss.MemoryLimit(1000, ctx)
+    b1, s1 = q.BestEffortAllocate(450, 100)
+    assert s1 == 450 and q.GetUsage() == 450 and q.Available() == 550
+    b2, s2 = q.BestEffortAllocate(350, 100)
+    assert s2 == 350 and q.GetUsage() == 800 and q.Available() == 200
+    b3, s3 = q.BestEffortAllocate(500, 100)
+    assert s3 == 200 and q.GetUsage() == 1000 and q.Available() == 0
+    assert q.BestEffortAllocate(500, 100) is None and q.Available() == 0
+    q.Free(b3); q.Free(b2)
+    assert q.GetUsage() == 450 and q.Available() == 550
+    q.Free(b1)
+    assert q.GetUsage() == 0 and q.Available() == 1000
+    b5, s5 = q.BestEffortAllocate(1200, 800)
+    assert s5 == 1000 and q.GetUsage() == 1000 and q.Available() == 0
 
 
 def test_allocator_rejects_bad_arguments(ctx):
