@@ -579,6 +579,7 @@ static void staged_table(const Program& prog, const ProgramLayout& L, std::vecto
   for (auto& sgd : prog.staged) { width->push_back(prog.regs[sgd.reg].width); off->push_back(prog.regs[sgd.reg].row_off * (uint32_t)(VM_TILE_UNIT * L.K)); }
 }
 static const int64_t SPECIALIZE_AFTER_RUNS = 8;
+static const int SPECIALIZE_AUTO_MAX_INSTR = 24;
 int prepare_stage(ssgpu_plan* p, size_t si) {
   ssgpu_ctx* c = p->ctx;
   Stage& st = p->stages[si];
@@ -588,6 +589,8 @@ int prepare_stage(ssgpu_plan* p, size_t si) {
   auto maybe_specialize = [&]() {
     if (ex.rtc_tried || c->specialize == 0 || (c->specialize < 0 && p->n_runs < SPECIALIZE_AFTER_RUNS)) return;
     ex.rtc_tried = true;
+    // compiling costs ~2 s + 0.4 s per instruction: the automatic mode leaves long programs to the interpreter
+    if (c->specialize < 0 && ex.n_instr_main > SPECIALIZE_AUTO_MAX_INSTR) { ex.rtc_why = "long program: set the specialize option to compile it"; return; }
     if (ex.lay.lds_bytes > 64u * 1024u) ex.rtc_why = "the program's LDS exceeds what a module-loaded kernel may use without attributes";
     else {
       std::vector<uint32_t> sw, so; staged_table(st.main, ex.lay, &sw, &so);
@@ -1069,7 +1072,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (rc != SSGPU_OK) return rc;
     ex.host_prog_pscatter = p->host_prog_scratch;
   }
-  if (!ex.rtc_tried_pscatter && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS))) {
+  if (!ex.rtc_tried_pscatter && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS && ex.n_instr_pscatter <= SPECIALIZE_AUTO_MAX_INSTR))) {
     ex.rtc_tried_pscatter = true;
     std::string why;
     std::vector<uint32_t> sw, so; staged_table(st.part_scatter, ex.lay_pscatter, &sw, &so);
