@@ -13,7 +13,11 @@
 //
 // Everything between the two plan runs is stream-ordered on ONE stream (the context's): no device value is read on the
 // host in between.  `supersonic_amd/distributed.py: DeviceShardedGroupAggregate` is the same protocol over
-// torch.distributed; this header is for hosts that link RCCL themselves.
+// torch.distributed; this header is for hosts that link RCCL themselves.  Like the reference's cursors, the mirror's
+// Cursor is single-shot, so Run() binds its two cursors anew on every call (cheap next to a shard's aggregation; the image
+// buffers are kept); a host that steps the same job thousands of times per second keeps the two ssgpu_plan handles and calls
+// ssgpu_plan_run on them, as distributed.py does.  STRING columns need one dictionary for the whole job
+// (distributed.py: job_strings) and are not handled here.
 #ifndef SUPERSONIC_AMD_SHARDED_H_
 #define SUPERSONIC_AMD_SHARDED_H_
 
