@@ -349,7 +349,16 @@ class FileOutput(object):
                 if schema.attribute(i).is_nullable():
                     nulls = col.is_null[off:off + rc] if col.is_null is not None else np.zeros(rc, np.bool_)
                     self._f.write(np.ascontiguousarray(nulls, dtype=np.bool_).tobytes())
-                self._f.write(np.ascontiguousarray(col.data[off:off + rc]).tobytes())
+                else:
+                    nulls = None
+                if schema.attribute(i).type() in (STRING, BINARY):
+                    # WriteVariableLengthData, file_io.cc:122-147: a uint64 length per row (0 for NULL and empty), then the
+                    # bytes of every non-NULL, non-empty value in one run
+                    vals = [b"" if (nulls is not None and nulls[j]) else _as_bytes(v) for j, v in enumerate(col.data[off:off + rc])]
+                    self._f.write(np.array([len(v) for v in vals], np.uint64).tobytes())
+                    self._f.write(b"".join(vals))
+                else:
+                    self._f.write(np.ascontiguousarray(col.data[off:off + rc]).tobytes())
         return view.row_count()
 
     def Finalize(self):
@@ -370,19 +379,35 @@ def read_view_file(schema, path):
             rc = int(np.frombuffer(head, np.uint64)[0])
             for i in range(schema.attribute_count()):
                 a = schema.attribute(i)
-                dt = np.dtype(_NP[a.type()])
+                dt = None if a.type() in (STRING, BINARY) else np.dtype(_NP[a.type()])
                 if a.is_nullable():
                     raw = f.read(rc)
                     if len(raw) != rc:
                         raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
                     nulls[i].append(np.frombuffer(raw, np.bool_))
+                if a.type() in (STRING, BINARY):
+                    # ReadVariableLengthData, file_io.cc:442-474: lengths, then one run of bytes cut by them
+                    raw = f.read(rc * 8)
+                    if len(raw) != rc * 8:
+                        raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                    lens = np.frombuffer(raw, np.uint64).astype(np.int64)
+                    total = int(lens.sum())
+                    blob = f.read(total)
+                    if len(blob) != total:
+                        raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                    ends = np.cumsum(lens)
+                    vals = np.empty(rc, dtype=object)
+                    for j in range(rc):
+                        vals[j] = blob[int(ends[j] - lens[j]):int(ends[j])]
+                    data[i].append(vals)
+                    continue
                 raw = f.read(rc * dt.itemsize)
                 if len(raw) != rc * dt.itemsize:
                     raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
                 data[i].append(np.frombuffer(raw, dt))
     cols = []
     for i in range(schema.attribute_count()):
-        dt = np.dtype(_NP[schema.attribute(i).type()])
+        dt = np.dtype(object if schema.attribute(i).type() in (STRING, BINARY) else _NP[schema.attribute(i).type()])
         d = np.concatenate(data[i]) if data[i] else np.zeros(0, dt)
         z = (np.concatenate(nulls[i]) if nulls[i] else np.zeros(0, np.bool_)) if schema.attribute(i).is_nullable() else None
         cols.append(Column(d, z))
@@ -392,8 +417,12 @@ def read_view_file(schema, path):
 def FileInput(schema, path, context=None):
     """FileInput(schema, file) drained straight into a device Block: chunks go through pinned
     staging buffers on the copy stream while the next chunk is read (ssgpu_block_create_from_file).
-    Returns a device-resident view usable with ScanView."""
+    Returns a device-resident view usable with ScanView.  A schema with STRING columns is read on the host instead
+    (the values have to meet the plan's dictionary before they can be codes in HBM): the returned host View goes
+    through ScanView's ordinary upload."""
     ctx = context or Context.default()
+    if any(schema.attribute(i).type() in (STRING, BINARY) for i in range(schema.attribute_count())):
+        return read_view_file(schema, path)
     attrs = (L.Attr * schema.attribute_count())()
     keep = []
     for i in range(schema.attribute_count()):
@@ -1119,6 +1148,12 @@ class Plan(object):
 
     def write_file(self, path, res=None):
         """FileOutput(path)->Write(result view): the finished result in the reference's file format."""
+        rs = self.result_schema
+        if any(rs.attribute(i).type() in (STRING, BINARY) for i in range(rs.attribute_count())):
+            out = FileOutput(path)          # variable-length values leave through the dictionary: fetched, then written
+            out.Write(self.fetch(res))
+            out.Finalize()
+            return
         self.ctx.check(self.lib.ssgpu_result_write_file(res or self._result, path.encode()))
 
     def fetch(self, res=None):

@@ -88,3 +88,68 @@ def test_file_to_device_block_to_query_to_file(gpu_ctx, tmp_path, n):
     copy = str(tmp_path / "copy.ssv")
     dev.write_file(copy)
     assert open(copy, "rb").read() == open(src, "rb").read()
+
+
+def schema_s():
+    return ss.TupleSchema([ss.Attribute("s", ss.STRING, ss.NULLABLE), ss.Attribute("k", ss.INT32), ss.Attribute("t", ss.STRING)])
+
+
+def test_variable_length_columns_match_hand_built_image(tmp_path):
+    # file_io.cc:22-27,122-147: [is_null bytes][uint64 length per row, 0 for NULL and empty][bytes of the rest in one run]
+    view = ss.View(schema_s(), [ss.Column(np.array([b"ab", b"ignored", b"", b"xyz"], dtype=object), np.array([False, True, False, False])),
+                                np.array([1, 2, 3, 4], np.int32), np.array([b"", b"q", b"\x00\x01", b"end"], dtype=object)])
+    path = str(tmp_path / "s.ssv")
+    out = ss.FileOutput(path); out.Write(view); out.Finalize()
+    image = (struct.pack("<Q", 4)
+             + bytes([0, 1, 0, 0]) + struct.pack("<4Q", 2, 0, 0, 3) + b"abxyz"
+             + struct.pack("<4i", 1, 2, 3, 4)
+             + struct.pack("<4Q", 0, 1, 2, 3) + b"q\x00\x01end")
+    assert open(path, "rb").read() == image
+    back = ss.read_view_file(schema_s(), path)
+    assert list(back.column(0).is_null) == [False, True, False, False]
+    assert list(back.column(0).data) == [b"ab", b"", b"", b"xyz"]            # a NULL row reads back as an empty piece
+    assert list(back.column(2).data) == [b"", b"q", b"\x00\x01", b"end"]
+    with open(str(tmp_path / "trunc.ssv"), "wb") as f:
+        f.write(image[:-2])
+    with pytest.raises(ss.SupersonicException):
+        ss.read_view_file(schema_s(), str(tmp_path / "trunc.ssv"))
+
+
+def test_variable_length_chunking(tmp_path):
+    n = 8192 + 100
+    rng = np.random.default_rng(2)
+    words = np.array([bytes(rng.integers(97, 123, rng.integers(0, 9)).astype(np.uint8)) for _ in range(n)], dtype=object)
+    view = ss.View(schema_s(), [ss.Column(words, rng.random(n) < 0.2), np.arange(n, dtype=np.int32), words[::-1].copy()])
+    path = str(tmp_path / "c.ssv")
+    out = ss.FileOutput(path); out.Write(view); out.Finalize()
+    back = ss.read_view_file(schema_s(), path)
+    nulls = view.column(0).is_null
+    assert list(back.column(0).is_null) == list(nulls)
+    assert [b"" if z else w for w, z in zip(words, nulls)] == list(back.column(0).data)
+    assert list(back.column(2).data) == list(words[::-1])
+    assert list(back.column(1).data) == list(range(n))
+
+
+@pytest.mark.gpu
+def test_string_file_to_query_to_file(gpu_ctx, tmp_path):
+    n = 20000
+    rng = np.random.default_rng(4)
+    pool = np.array([b"", b"a", b"ab", b"b", b"zz", b"a\x00", b"m" * 40], dtype=object)
+    view = ss.View(schema_s(), [ss.Column(pool[rng.integers(0, len(pool), n)], rng.random(n) < 0.1), rng.integers(-9, 9, n).astype(np.int32),
+                                pool[rng.integers(0, len(pool), n)]])
+    src = str(tmp_path / "in.ssv")
+    out = ss.FileOutput(src); out.Write(view); out.Finalize()
+    host = ss.FileInput(schema_s(), src, gpu_ctx)
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "k", "sk").AddAggregation(ss.MAX, "s", "ms").AddAggregation(ss.COUNT, "s", "c")
+
+    def query(v):
+        return ss.GroupAggregate(ss.ProjectNamedAttributes(["t"]), spec, None,
+                                 ss.Filter(ss.NotEqual(NA("t"), ss.ConstString("b")), ss.ProjectAllAttributes(), ss.ScanView(v)))
+    plan = ss.Plan(query(host), gpu_ctx)
+    plan.run()
+    dst = str(tmp_path / "out.ssv")
+    plan.write_file(dst)
+    got = ss.read_view_file(plan.result_schema, dst)
+    oschema, want = oracle.run(query(view), 1 << 20)
+    from helpers import sort_rows
+    assert_cols_equal(sort_rows(to_cols(got)), sort_rows(want), context="STRING file round trip")
