@@ -72,6 +72,33 @@ class FailureOrOwned {
   std::unique_ptr<Exception> exception_;
 };
 
+// FailureOr<T> / FailureOrVoid (utils/exception/failureor.h): a value or an owned Exception.
+template <typename T>
+class FailureOr {
+ public:
+  explicit FailureOr(const T& value) : value_(value) {}
+  explicit FailureOr(Exception* e) : value_(), exception_(e) {}
+  FailureOr(FailureOr&& o) = default;
+  bool is_failure() const { return exception_ != nullptr; }
+  bool is_success() const { return !is_failure(); }
+  const Exception& exception() const { return *exception_; }
+  const T& get() const { return value_; }
+ private:
+  T value_;
+  std::unique_ptr<Exception> exception_;
+};
+class FailureOrVoid {
+ public:
+  FailureOrVoid() {}
+  explicit FailureOrVoid(Exception* e) : exception_(e) {}
+  FailureOrVoid(FailureOrVoid&& o) = default;
+  bool is_failure() const { return exception_ != nullptr; }
+  bool is_success() const { return !is_failure(); }
+  const Exception& exception() const { return *exception_; }
+ private:
+  std::unique_ptr<Exception> exception_;
+};
+
 // ---- schema (base/infrastructure/tuple_schema.h:77,126) ---------------------------------
 class Attribute {
  public:
@@ -919,6 +946,108 @@ inline Operation* GroupAggregate(const SingleSourceProjector* group_by, const Ag
 inline Operation* AggregateClusters(const SingleSourceProjector* clustered_by, const AggregationSpecification* spec, Operation* child) { return new internal::UnaryOp(SSGPU_OP_AGGREGATE_CLUSTERS, child, nullptr, clustered_by, spec, nullptr); }
 inline Operation* Sort(const SortOrder* order, const SingleSourceProjector* result_projector, size_t memory_limit, Operation* child) {
   return new internal::UnaryOp(SSGPU_OP_SORT, child, nullptr, result_projector ? result_projector : ProjectAllAttributes(), nullptr, order, static_cast<int64_t>(memory_limit));
+}
+
+// ---- the View file format (cursor/infrastructure/file_io.h:58-72, file_io.cc:15-30) ---------------------------------
+// The reference hands its own File* to these; the mirror takes a path (the ABI reads with positional readers into pinned
+// slabs, which a File* abstraction cannot give it).  Chunks of <= 8192 rows: a uint64 row count, then per column the
+// is_null bytes (NULLABLE attributes) and the data -- raw for fixed-width types, a uint64 length per row (0 for NULL
+// and empty) followed by one run of bytes for STRING.
+
+// FileOutput(file, ownership) -> Sink (cursor.h Sink: Write(view) -> rows written, Finalize()).
+class Sink {
+ public:
+  virtual ~Sink() {}
+  virtual FailureOr<rowcount_t> Write(const View& data) = 0;
+  virtual FailureOrVoid Finalize() = 0;
+};
+
+namespace internal {
+class FileSink : public Sink {
+ public:
+  explicit FileSink(const std::string& path) : f_(fopen(path.c_str(), "wb")) {}
+  ~FileSink() override { if (f_) fclose(f_); }
+  FailureOr<rowcount_t> Write(const View& v) override {
+    static const rowcount_t kMaxChunkRowCount = 8192;   // file_io.cc:70
+    if (!f_) return FailureOr<rowcount_t>(new Exception(ERROR_UNKNOWN_ERROR, "FileOutput: the file is not open"));
+    bool ok = true;
+    auto put = [&](const void* p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, f_) == n); };
+    for (rowcount_t off = 0; off < v.row_count(); off += kMaxChunkRowCount) {
+      const uint64_t rc = std::min<rowcount_t>(kMaxChunkRowCount, v.row_count() - off);
+      put(&rc, 8);
+      for (int i = 0; i < v.column_count(); ++i) {
+        const Attribute& a = v.schema().attribute(i);
+        const bool* nulls = v.column(i).is_null();
+        if (a.is_nullable()) {
+          if (nulls) put(nulls + off, rc);
+          else { std::vector<char> zeros(rc, 0); put(zeros.data(), rc); }
+        }
+        if (a.type() == STRING || a.type() == BINARY) {
+          const StringPiece* cells = v.column(i).typed_data<StringPiece>() + off;
+          std::vector<uint64_t> lens(rc);
+          for (uint64_t r = 0; r < rc; ++r) lens[r] = (a.is_nullable() && nulls && nulls[off + r]) ? 0 : cells[r].size();
+          put(lens.data(), rc * 8);
+          for (uint64_t r = 0; r < rc; ++r) put(cells[r].data(), lens[r]);
+        } else {
+          put(static_cast<const char*>(v.column(i).data()) + off * SizeOfDataType(a.type()), rc * SizeOfDataType(a.type()));
+        }
+      }
+    }
+    if (!ok) return FailureOr<rowcount_t>(new Exception(ERROR_UNKNOWN_ERROR, "Error writing to the output file."));
+    return FailureOr<rowcount_t>(v.row_count());
+  }
+  FailureOrVoid Finalize() override {
+    const bool ok = !f_ || fclose(f_) == 0;
+    f_ = nullptr;
+    return ok ? FailureOrVoid() : FailureOrVoid(new Exception(ERROR_UNKNOWN_ERROR, "Error closing the output file."));
+  }
+ private:
+  FILE* f_;
+};
+}  // namespace internal
+
+inline Sink* FileOutput(const std::string& path) { return new internal::FileSink(path); }
+
+// A finished cursor's result straight from device memory into a file (fixed-width columns): FileOutput(...)->Write of
+// the whole result without the host View in between.
+inline FailureOrVoid WriteResultToFile(Cursor* cursor, const std::string& path) {
+  int rc = cursor->RunOnDevice();
+  if (rc == SSGPU_OK) rc = ssgpu_result_write_file(cursor->result_handle(), path.c_str());
+  return rc == SSGPU_OK ? FailureOrVoid() : FailureOrVoid(new Exception(rc, ssgpu_last_error(internal::Context::Get().ctx)));
+}
+
+// FileInput(schema, file, delete_when_done, allocator) drained into device memory: the columns of the whole file as a
+// DeviceView (scan it with ScanDeviceView).  Owns the device block.  Fixed-width columns only: STRING columns have to meet
+// a plan's dictionary on the host first (read them with the host tools, then ScanView).
+class DeviceTable {
+ public:
+  ~DeviceTable() { if (block_) ssgpu_block_destroy(block_); }
+  const DeviceView& view() const { return view_; }
+  rowcount_t row_count() const { return view_.row_count; }
+ private:
+  friend FailureOrOwned<DeviceTable> FileInput(const TupleSchema&, const std::string&, bool);
+  DeviceTable() {}
+  ssgpu_block* block_ = nullptr;
+  DeviceView view_;
+};
+
+inline FailureOrOwned<DeviceTable> FileInput(const TupleSchema& schema, const std::string& path, bool delete_when_done = false) {
+  ssgpu_ctx* ctx = internal::Context::Get().ctx;
+  std::vector<ssgpu_attr> attrs(schema.attribute_count());
+  for (int i = 0; i < schema.attribute_count(); ++i) {
+    attrs[i].name = schema.attribute(i).name().c_str();
+    attrs[i].dtype = schema.attribute(i).type();
+    attrs[i].nullable = schema.attribute(i).is_nullable() ? 1 : 0;
+  }
+  std::unique_ptr<DeviceTable> t(new DeviceTable);
+  int rc = ssgpu_block_create_from_file(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), path.c_str(), &t->block_);
+  if (rc != SSGPU_OK) return FailureOrOwned<DeviceTable>(new Exception(rc, ssgpu_last_error(ctx)));
+  t->view_.schema = schema;
+  t->view_.columns.resize(attrs.size());
+  for (size_t i = 0; i < attrs.size(); ++i) ssgpu_block_column(t->block_, static_cast<int32_t>(i), &t->view_.columns[i]);
+  t->view_.row_count = ssgpu_block_row_count(t->block_);
+  if (delete_when_done) remove(path.c_str());
+  return FailureOrOwned<DeviceTable>(t.release());
 }
 
 }  // namespace supersonic

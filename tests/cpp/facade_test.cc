@@ -391,11 +391,85 @@ static void TestSeamsRun(const Input& in) {
   }
 }
 
+// The View file format through the mirror: FileOutput's byte image (file_io.cc:15-30,122-147), then (GPU) FileInput ->
+// ScanDeviceView -> query -> WriteResultToFile.
+static std::string ReadAll(const std::string& path) {
+  std::string out; FILE* f = fopen(path.c_str(), "rb"); if (!f) return out;
+  char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+  fclose(f); return out;
+}
+static void TestFileFormat(bool run) {
+  char dir_template[] = "/tmp/ssgpu_facade_XXXXXX";
+  const std::string dir = mkdtemp(dir_template);
+  {  // a STRING column: lengths (0 for NULL and empty), then one run of bytes
+    TupleSchema schema;
+    schema.add_attribute(Attribute("s", STRING, NULLABLE));
+    schema.add_attribute(Attribute("k", INT32, NOT_NULLABLE));
+    const StringPiece cells[4] = {StringPiece("ab", 2), StringPiece("ignored", 7), StringPiece("", 0), StringPiece("xyz", 3)};
+    const bool nulls[4] = {false, true, false, false};
+    const int32_t k[4] = {1, 2, 3, 4};
+    View v(schema);
+    v.mutable_column(0)->Reset(cells, nulls); v.mutable_column(1)->Reset(k, nullptr); v.set_row_count(4);
+    std::unique_ptr<Sink> sink(FileOutput(dir + "/s.ssv"));
+    FailureOr<rowcount_t> w = sink->Write(v);
+    CHECK(w.is_success()); if (w.is_success()) CHECK_EQ(w.get(), static_cast<rowcount_t>(4));
+    CHECK(sink->Finalize().is_success());
+    std::string want;
+    const uint64_t rc = 4, lens[4] = {2, 0, 0, 3};
+    want.append(reinterpret_cast<const char*>(&rc), 8);
+    want.append(reinterpret_cast<const char*>(nulls), 4);
+    want.append(reinterpret_cast<const char*>(lens), 32);
+    want.append("abxyz");
+    want.append(reinterpret_cast<const char*>(k), 16);
+    CHECK(ReadAll(dir + "/s.ssv") == want);
+  }
+  const rowcount_t n = 20000;   // three chunks
+  TupleSchema schema;
+  schema.add_attribute(Attribute("k", INT32, NULLABLE));
+  schema.add_attribute(Attribute("v", INT64, NOT_NULLABLE));
+  std::vector<int32_t> k(n); std::vector<int64_t> val(n); std::vector<char> kn(n);
+  for (rowcount_t i = 0; i < n; ++i) { k[i] = static_cast<int32_t>(i % 5); val[i] = static_cast<int64_t>(i); kn[i] = (i % 11) == 0; }
+  View v(schema);
+  v.mutable_column(0)->Reset(k.data(), reinterpret_cast<const bool*>(kn.data())); v.mutable_column(1)->Reset(val.data(), nullptr); v.set_row_count(n);
+  {
+    std::unique_ptr<Sink> sink(FileOutput(dir + "/t.ssv"));
+    CHECK(sink->Write(v).is_success());
+    CHECK(sink->Finalize().is_success());
+    const std::string raw = ReadAll(dir + "/t.ssv");
+    CHECK_EQ(raw.size(), static_cast<size_t>(3 * 8 + n * (1 + 4 + 8)));
+    uint64_t first = 0; memcpy(&first, raw.data(), 8); CHECK_EQ(first, static_cast<uint64_t>(8192));
+  }
+  if (!run) return;
+  FailureOrOwned<DeviceTable> table = FileInput(schema, dir + "/t.ssv");
+  CHECK(table.is_success());
+  if (!table.is_success()) return;
+  CHECK_EQ(table->row_count(), n);
+  std::unique_ptr<Operation> op(GroupAggregate(ProjectNamedAttribute("k"), (new AggregationSpecification)->AddAggregation(SUM, "v", "sv"), nullptr,
+                                               ScanDeviceView(table->view())));
+  FailureOrOwned<Cursor> c = op->CreateCursor();
+  CHECK(c.is_success());
+  CHECK(WriteResultToFile(c.get(), dir + "/out.ssv").is_success());
+  FailureOrOwned<DeviceTable> back = FileInput(c->schema(), dir + "/out.ssv", true);
+  CHECK(back.is_success());
+  if (back.is_success()) CHECK_EQ(back->row_count(), static_cast<rowcount_t>(6));   // keys 0..4 and NULL
+  int64_t total = 0; rowcount_t rows = 0;
+  for (;;) {
+    ResultView r = c->Next(Cursor::kDefaultRowCount);
+    if (!r.has_data()) { CHECK(r.is_eos()); break; }
+    for (rowcount_t i = 0; i < r.view().row_count(); ++i) total += r.view().column(1).typed_data<int64_t>()[i];
+    rows += r.view().row_count();
+  }
+  CHECK_EQ(rows, static_cast<rowcount_t>(6));
+  CHECK_EQ(total, static_cast<int64_t>(n) * (n - 1) / 2);
+  CHECK(FileInput(schema, dir + "/missing.ssv").is_failure());
+}
+
 int main(int argc, char** argv) {
   const bool run = argc > 1 && !strcmp(argv[1], "run");
   Input in;
   TestBind(in);
   TestSeamsBind(in);
+  TestFileFormat(run);
   if (run) { TestRun(in); TestSeamsRun(in); }
   printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
   return g_fail ? 1 : 0;
