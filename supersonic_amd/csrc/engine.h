@@ -78,7 +78,7 @@ struct AggOut {        // one aggregate result column
   int gather_col = -1; // group FIRST/LAST: the slot holds a row id; the result is this stage-input column at that row
 };
 
-struct GroupKeyField { int out_col; uint32_t shift, bits, nullbit, width; };
+struct GroupKeyField { int out_col; uint32_t shift, bits, nullbit, width; uint32_t word = 0; /* hash-join keys of 65..128 bits: key word 0 / 1 */ };
 
 struct SortKey { int col; int order; };
 
@@ -89,8 +89,9 @@ struct JoinSpec {
   int type = 0;                          // SSGPU_JOIN_INNER / SSGPU_JOIN_LEFT_OUTER
   std::vector<BExprP> lhs_keys;          // over the stage input
   std::vector<int> rhs_key_cols;         // columns of the auxiliary input
-  std::vector<GroupKeyField> fields;     // packing of the 64-bit key (nullbit only for nullable lhs keys)
+  std::vector<GroupKeyField> fields;     // packing of the key: one 64-bit word, or two (`wide`, GroupKeyField::word)
   bool multi = false;                    // NOT_UNIQUE rhs keys: the index maps a key to a run of rhs rows
+  bool wide = false;                     // the packed key takes two 64-bit words (JOIN_PROBE_WIDE)
 };
 struct JoinGather { int join_id; int rhs_col; bool is_null_mask; };  // slot i of VmParams.join_cols
 enum { JOIN_GATHER_RUN_START = -1, JOIN_GATHER_RUN_COUNT = -2 };   // rhs_col of a multi join's per-key run arrays

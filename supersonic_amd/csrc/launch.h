@@ -84,6 +84,10 @@ struct JoinBuildParams {
   // rows and slot_of_row[i] is row i's slot (VM_NONE for a NULL key)
   unsigned int* counts;
   unsigned int* slot_of_row;
+  // keys of 65..128 packed bits: word[k] says which of the two key words field k belongs to, keys_hi holds the second
+  // word of every entry and `rows` (pre-filled with VM_NONE) is what an inserter claims (see ssgpu_join_build_kernel)
+  unsigned int word[8];
+  unsigned long long* keys_hi;
 };
 hipError_t ssgpu_launch_join_expand(const unsigned int* offsets, const unsigned int* run_start, const unsigned int* rows_sorted,
                                     unsigned long long n_lhs, unsigned long long n_out, unsigned int* lhs_idx, unsigned int* rhs_row, hipStream_t stream);

@@ -257,20 +257,24 @@ Status Emitter::join_index(int join_id, int* reg) {
   if (!joins_ || join_id < 0 || join_id >= (int)joins_->size()) return Status::Error(SSGPU_ERROR_UNKNOWN, "join reference outside its stage");
   const JoinSpec& js = (*joins_)[join_id];
   // pack the lhs key exactly as the index build packs the rhs key (JoinBuildParams)
-  int keyreg = new_reg(8);
+  int keyreg = new_reg(8), keyreg_hi = -1;
   { LInstr& i = emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
+  if (js.wide) {
+    keyreg_hi = new_reg(8);
+    LInstr& i = emit(VM_FILL_64); i.dst = keyreg_hi; i.a_imm = true; i.imm = 0; i.imm_width = 8;
+  }
   int any_null = -1;   // a NULL in any key column: the row matches nothing
   for (size_t k = 0; k < js.lhs_keys.size(); ++k) {
     Val v; SS_RETURN_IF_ERROR(value(js.lhs_keys[k], &v));
     const GroupKeyField& f = js.fields[k];
     int vr = materialize(v);
     LInstr& i = emit(f.width == 8 ? VM_KEY_APPEND_64 : f.width == 4 ? VM_KEY_APPEND_32 : VM_KEY_APPEND_8);
-    i.dst = keyreg; i.a = vr; i.b = -1;
+    i.dst = f.word ? keyreg_hi : keyreg; i.a = vr; i.b = -1;
     i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
     any_null = or_null(any_null, v.null);
   }
   const int idx = new_reg(4);
-  { LInstr& i = emit(VM_JOIN_PROBE); i.dst = idx; i.a = keyreg; i.b = any_null; i.imm = (uint64_t)join_id; }
+  { LInstr& i = emit(js.wide ? VM_JOIN_PROBE_WIDE : VM_JOIN_PROBE); i.dst = idx; i.a = keyreg; i.b = any_null; i.c = keyreg_hi; i.imm = (uint64_t)join_id; }
   join_idx_[join_id] = idx;
   *reg = idx;
   return Status::OK();
@@ -1493,18 +1497,21 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         SS_RETURN_IF_ERROR(bind_projector(d, op.proj2_first, op.proj2_n, rs, &rpos, &rnames));
         if (lpos.size() != rpos.size() || lpos.empty())
           return Status::Error(SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH, "hash join key selectors must pick the same, non-zero number of columns");
+        if (lpos.size() > 8) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash joins on more than 8 key columns are not on device");
         JoinSpec js; js.type = jtype; js.multi = multi;
-        uint32_t shift = 0;
+        uint32_t fill[2] = {0, 0};      // a key of 65..128 bits takes a second word; a field never straddles the two (first fit)
         for (size_t k = 0; k < lpos.size(); ++k) {
           const BExprP& le = pipe.cols[lpos[k]].expr;
           if (le->dtype != rs[rpos[k]].dtype)
             return Status::Error(SSGPU_ERROR_ATTRIBUTE_TYPE_MISMATCH, std::string("hash join key types differ: ") + dtype_name(le->dtype) + " vs " + dtype_name(rs[rpos[k]].dtype));
           const uint32_t w = (uint32_t)dtype_width(le->dtype);
           if (w == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join key type is outside the device hot path");
-          GroupKeyField f; f.out_col = (int)k; f.shift = shift; f.bits = w * 8; f.width = w;
+          const uint32_t word = fill[0] + w * 8 <= 64 ? 0u : 1u;
+          if (fill[word] + w * 8 > 64) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join keys that do not pack into two 64-bit words are not on device yet");
+          if (word) js.wide = true;
+          GroupKeyField f; f.out_col = (int)k; f.shift = fill[word]; f.bits = w * 8; f.width = w; f.word = word;
           f.nullbit = 0xFF;   // NULL keys never match: lhs NULLs are masked after the probe, rhs NULL rows are not indexed
-          shift += f.bits;
-          if (shift > 64) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash join keys wider than 64 packed bits are not on device yet");
+          fill[word] += f.bits;
           js.lhs_keys.push_back(le); js.rhs_key_cols.push_back(rpos[k]); js.fields.push_back(f);
         }
         const int join_id = (int)pipe.joins.size();

@@ -1191,9 +1191,52 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
 // ---------------------------------------------------------------------------
 // HashJoin index build (see JoinBuildParams in launch.h)
 // ---------------------------------------------------------------------------
+// The two key words of rhs row i (keys of 65..128 packed bits); false for a NULL key.
+__device__ __forceinline__ bool join_wide_key_of_row(const JoinBuildParams& P, u64 i, u64* lo, u64* hi) {
+  u64 w[2] = {0ull, 0ull};
+  for (u32 k = 0; k < P.n_keys; ++k) {
+    if (P.key_nulls[k] && P.key_nulls[k][i]) return false;
+    u64 v;
+    if (P.width[k] == 8) v = reinterpret_cast<const u64*>(P.key_data[k])[i];
+    else if (P.width[k] == 4) v = reinterpret_cast<const u32*>(P.key_data[k])[i];
+    else v = reinterpret_cast<const u8*>(P.key_data[k])[i];
+    const u64 vmask = P.bits[k] >= 64 ? ~0ull : ((1ull << P.bits[k]) - 1ull);
+    w[P.word[k] & 1u] |= (v & vmask) << P.shift[k];
+  }
+  *lo = w[0]; *hi = w[1];
+  return true;
+}
 __global__ __launch_bounds__(256) void ssgpu_join_build_kernel(const JoinBuildParams P) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   if (i >= P.n_rows) return;
+  if (P.keys_hi) {
+    // Two-word keys.  An inserter claims a slot by putting its ROW into rows[slot] (one 32-bit CAS); whoever meets a
+    // claimed slot compares its key with the claimant's, recomputed from the (immutable) key columns -- the key words the
+    // claimant stores into the table afterwards are only read by the probing kernel, so no ordering between the claim and
+    // those stores is needed, and there is no reserved key value.
+    u64 lo, hi;
+    if (!join_wide_key_of_row(P, i, &lo, &hi)) { if (P.slot_of_row) P.slot_of_row[i] = VM_NONE; return; }
+    const bool multi = P.counts != nullptr;
+    u32 slot = hash64(lo ^ hash64(hi)) & P.capacity_mask;
+    for (u32 probe = 0; probe <= P.capacity_mask; ++probe) {
+      const u32 old = atomicCAS(&P.rows[slot], VM_NONE, (u32)i);
+      if (old == VM_NONE) {
+        P.keys[slot] = lo; P.keys_hi[slot] = hi;
+        if (multi) { atomicAdd(&P.counts[slot], 1u); P.slot_of_row[i] = slot; }
+        return;
+      }
+      u64 olo, ohi;
+      (void)join_wide_key_of_row(P, old, &olo, &ohi);   // an indexed row: its key is not NULL
+      if (olo == lo && ohi == hi) {
+        if (multi) { atomicAdd(&P.counts[slot], 1u); P.slot_of_row[i] = slot; }
+        else atomicExch(&P.flags[0], 1u);                // duplicate key in a UNIQUE rhs
+        return;
+      }
+      slot = (slot + 1) & P.capacity_mask;
+    }
+    atomicExch(&P.flags[0], 2u);
+    return;
+  }
   u64 key = 0;
   for (u32 k = 0; k < P.n_keys; ++k) {
     if (P.key_nulls[k] && P.key_nulls[k][i]) { if (P.slot_of_row) P.slot_of_row[i] = VM_NONE; return; }   // NULL never equals anything: not indexed

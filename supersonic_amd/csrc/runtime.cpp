@@ -144,7 +144,7 @@ struct StageExec {
   void* rtc_fn_pscatter = nullptr; bool rtc_tried_pscatter = false; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
-  std::vector<DevBuf> jkeys, jrows, jmisc;
+  std::vector<DevBuf> jkeys, jkeys_hi, jrows, jmisc;
   std::vector<DevBuf> jcounts, jstarts, jslot_of_row, jrows_sorted;   // NOT_UNIQUE joins: key -> run of rhs rows
   DevBuf jx_offsets, jx_lhs_idx, jx_rhs_row;                           // JOIN_EXPAND scratch
   std::vector<VmJoin> vm_joins;
@@ -659,13 +659,17 @@ int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
   if (st.joins.empty()) return SSGPU_OK;
   if (p->aux_rows < 0) { c->err = "this plan joins against an auxiliary input: call ssgpu_plan_set_aux_input first"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   const size_t nj = st.joins.size();
-  ex.jkeys.resize(nj); ex.jrows.resize(nj); ex.jmisc.resize(nj); ex.vm_joins.resize(nj);
+  ex.jkeys.resize(nj); ex.jkeys_hi.resize(nj); ex.jrows.resize(nj); ex.jmisc.resize(nj); ex.vm_joins.resize(nj);
   for (size_t j = 0; j < nj; ++j) {
     const JoinSpec& js = st.joins[j];
     uint64_t cap = 16; while (cap < (uint64_t)std::max<int64_t>(p->aux_rows, 1) * 2) cap <<= 1;
     if (cap > (1ull << 31)) { c->err = "hash join rhs table too large"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
     HIP_TRY(c, ex.jkeys[j].ensure(cap * 8)); HIP_TRY(c, ex.jrows[j].ensure(cap * 4)); HIP_TRY(c, ex.jmisc[j].ensure(16));
     HIP_TRY(c, ssgpu_launch_fill_u64(ex.jkeys[j].as<uint64_t>(), VM_KEY_EMPTY, cap, c->stream));
+    if (js.wide) {   // two-word keys: a slot is free while rows[slot] == VM_NONE
+      HIP_TRY(c, ex.jkeys_hi[j].ensure(cap * 8));
+      HIP_TRY(c, ssgpu_launch_fill_u32(ex.jrows[j].as<unsigned int>(), VM_NONE, cap, c->stream));
+    }
     const uint32_t misc_init[4] = {VM_NONE, 0u, 0u, 0u};   // [0] special row, [1] flags
     HIP_TRY(c, hipMemcpyAsync(ex.jmisc[j].p, misc_init, 16, hipMemcpyHostToDevice, c->stream));
     JoinBuildParams B; memset(&B, 0, sizeof(B));
@@ -673,11 +677,12 @@ int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
     for (size_t k = 0; k < js.rhs_key_cols.size(); ++k) {
       const ssgpu_column& col = p->aux_cols[js.rhs_key_cols[k]];
       B.key_data[k] = col.data; B.key_nulls[k] = p->desc.aux_schema[js.rhs_key_cols[k]].nullable ? col.is_null : nullptr;
-      B.width[k] = js.fields[k].width; B.shift[k] = js.fields[k].shift; B.bits[k] = js.fields[k].bits;
+      B.width[k] = js.fields[k].width; B.shift[k] = js.fields[k].shift; B.bits[k] = js.fields[k].bits; B.word[k] = js.fields[k].word;
     }
     B.capacity_mask = (uint32_t)(cap - 1); B.n_rows = (unsigned long long)p->aux_rows;
     B.keys = ex.jkeys[j].as<unsigned long long>(); B.rows = ex.jrows[j].as<unsigned int>();
     B.special = ex.jmisc[j].as<unsigned int>(); B.flags = ex.jmisc[j].as<unsigned int>() + 1;
+    B.keys_hi = js.wide ? ex.jkeys_hi[j].as<unsigned long long>() : nullptr;
     if (js.multi) {
       const uint64_t nr = (uint64_t)std::max<int64_t>(p->aux_rows, 1);
       ex.jcounts.resize(nj); ex.jstarts.resize(nj); ex.jslot_of_row.resize(nj); ex.jrows_sorted.resize(nj);
@@ -704,7 +709,8 @@ int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
     if (misc[1]) { c->err = "hash join: the rhs keys were declared UNIQUE but a key occurs more than once"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
     VmJoin& J = ex.vm_joins[j];
     J.keys = ex.jkeys[j].as<unsigned long long>(); J.rows = ex.jrows[j].as<unsigned int>();
-    J.special = ex.jmisc[j].as<unsigned int>(); J.capacity_mask = (uint32_t)(cap - 1); J.pad = 0;
+    J.special = ex.jmisc[j].as<unsigned int>(); J.capacity_mask = (uint32_t)(cap - 1);
+    J.answer_slot = js.multi ? 1u : 0u; J.keys_hi = js.wide ? ex.jkeys_hi[j].as<unsigned long long>() : nullptr;
     p->counters.n_launches += 2;
   }
   return SSGPU_OK;

@@ -122,7 +122,7 @@ enum { VM_MATH_EXP = 1, VM_MATH_LN, VM_MATH_LOG10, VM_MATH_LOG2, VM_MATH_SIN, VM
   X(AGG_SUM_F64_ADD) X(AGG_SUM_F64_SUB) X(AGG_SUM_F64_MUL)                     \
   /* ---- materialising sinks ---------------------------------------------- */\
   X(SEL_COUNT)   /* a = sel: tile_counts[tile] = #selected        */           \
-  X(SEL_RANK) X(PART_RANK) X(PART_REC_8) X(PART_REC_32) X(PART_REC_64) X(PART_REC_128) X(PART_FLUSH) X(JOIN_PROBE) X(IDX_VALID) X(GATHER_64) X(GATHER_32) X(GATHER_8) X(GATHER_NULL)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
+  X(SEL_RANK) X(PART_RANK) X(PART_REC_8) X(PART_REC_32) X(PART_REC_64) X(PART_REC_128) X(PART_FLUSH) X(JOIN_PROBE) X(JOIN_PROBE_WIDE) X(IDX_VALID) X(GATHER_64) X(GATHER_32) X(GATHER_8) X(GATHER_NULL)    /* a = sel, dst = u32 rank reg (absolute out row) */          \
   X(STORE_8) X(STORE_32) X(STORE_64)     /* dst = out col, a = reg, rows 1:1 */\
   X(STOREC_8) X(STOREC_32) X(STOREC_64)  /* + b = rank reg, c = sel (compact)*/\
   X(STORE_ROWID) /* dst = out col: int64 global row id of survivors, b,c */    \
@@ -229,7 +229,8 @@ struct VmJoin {
   const unsigned int* rows;         /* rhs row of every entry */
   const unsigned int* special;      /* [0]: rhs row whose packed key equals VM_KEY_EMPTY, or VM_NONE */
   uint32_t capacity_mask;
-  uint32_t pad;
+  uint32_t answer_slot;             /* JOIN_PROBE_WIDE: 1 = answer with the key's slot (NOT_UNIQUE index), 0 = with rows[slot] */
+  const unsigned long long* keys_hi; /* JOIN_PROBE_WIDE: second word of every entry's key (rows[slot] == VM_NONE = free) */
 };
 struct VmJoinCol { const void* data; const unsigned char* is_null; };
 #define VM_MAX_JOINS 2

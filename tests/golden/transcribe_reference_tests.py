@@ -765,11 +765,11 @@ R12345 = [[1, "a"], [2, "b"], [3, "c"], [4, "d"], [5, "e"]]
 R654321 = [[6, "f"], [5, "e"], [4, "d"], [3, "c"], [2, "b"], [1, "a"]]
 
 
-def join_case(name, src, jtype, lrows, rrows, expected, uniqueness="UNIQUE"):
+def join_case(name, src, jtype, lrows, rrows, expected, uniqueness="UNIQUE", keys=(0,)):
     CASES.append({
         "name": name, "source": src, "kind": "operation",
         "input": {"schema": cols([I64, STR]), "rows": lrows}, "input2": {"schema": cols([I64, STR]), "rows": rrows},
-        "plan": ["HashJoin", jtype, [0], [0], ALLP, uniqueness, "INPUT", "INPUT2"],
+        "plan": ["HashJoin", jtype, list(keys), list(keys), ALLP, uniqueness, "INPUT", "INPUT2"],
         "expected": {"types": JT, "rows": expected, "names": JN, "nullable": None},
         "ordered": True, "expect_error": None})
 
@@ -789,6 +789,16 @@ NU = "NOT_UNIQUE"
 join_case("HashJoin_1_InnerJoin_1_not_unique", HJ + ":140-150", "INNER", R1, R1, [[1, "a", 1, "a"]], NU)
 join_case("HashJoin_1_LeftOuterJoin_2_not_unique", HJ + ":176-187", "LEFT_OUTER", R1, R2, [[1, "a", None, None]], NU)
 join_case("HashJoin_12345_InnerJoin_654321_not_unique", HJ + ":189-203", "INNER", R12345, R654321, [[k, v, k, v] for k, v in R12345], NU)
+
+# two-column (INT64, STRING) keys -- 96 packed bits -- in both uniqueness modes (TEST_P); a NULL in any key column matches nothing
+R1a1b2a2b = [[1, "a"], [1, "b"], [2, "a"], [2, "b"]]
+R1a1NNaNN = [[1, "a"], [1, None], [None, "a"], [None, None]]
+for U in ("UNIQUE", NU):
+    sfx = "" if U == "UNIQUE" else "_not_unique"
+    join_case("HashJoin_1a1b2a2b_InnerJoin_1a1b2a2b" + sfx, HJ + ":305-319", "INNER", R1a1b2a2b, R1a1b2a2b, [[k, v, k, v] for k, v in R1a1b2a2b], U, (0, 1))
+    join_case("HashJoin_1a1NNaNN_InnerJoin_1a1NNaNN" + sfx, HJ + ":355-366", "INNER", R1a1NNaNN, R1a1NNaNN, [[1, "a", 1, "a"]], U, (0, 1))
+    join_case("HashJoin_1a1NNaNN_LeftOuterJoin_1a1NNaNN" + sfx, HJ + ":368-382", "LEFT_OUTER", R1a1NNaNN, R1a1NNaNN,
+              [[1, "a", 1, "a"], [1, None, None, None], [None, "a", None, None], [None, None, None, None]], U, (0, 1))
 
 # ---- short circuit: which rows every child is evaluated on (skip vectors) ------------------------------------------
 # The reference's short-circuit tests (supersonic/testing/short_circuit_tester.h:37-62) give, per input row, the

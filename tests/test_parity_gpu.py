@@ -635,6 +635,56 @@ def test_hash_join_two_key_columns_and_errors(gpu_ctx):
     assert r.is_failure()
 
 
+@pytest.mark.parametrize("n,m", [(0, 5), (9, 0), (2049, 60), (30011, 700)])
+@pytest.mark.parametrize("join_type", [ss.INNER, ss.LEFT_OUTER])
+@pytest.mark.parametrize("uniq", [ss.UNIQUE, ss.NOT_UNIQUE])
+def test_hash_join_keys_of_two_words(gpu_ctx, n, m, join_type, uniq):
+    # keys that pack into 65..128 bits -- (INT64, STRING) as in hash_join_test.cc:305-382, (INT64, INT64), (INT32, INT64, BOOL):
+    # a two-word index whose slots are claimed by row (ssgpu_join_build_kernel)
+    rng = np.random.default_rng(n + m)
+    words = np.array([b"", b"a", b"ab", b"b", b"zz"], dtype=object)
+    rs = ss.TupleSchema([ss.Attribute("id", ss.INT64, ss.NULLABLE), ss.Attribute("tag", ss.STRING, ss.NULLABLE), ss.Attribute("id2", ss.INT64),
+                         ss.Attribute("flag", ss.BOOL), ss.Attribute("small", ss.INT32), ss.Attribute("w", ss.DOUBLE)])
+    ls = ss.TupleSchema([ss.Attribute("fk", ss.INT64, ss.NULLABLE), ss.Attribute("ftag", ss.STRING, ss.NULLABLE), ss.Attribute("fk2", ss.INT64),
+                         ss.Attribute("fflag", ss.BOOL), ss.Attribute("fsmall", ss.INT32), ss.Attribute("v", ss.INT64)])
+    # rhs: (id, tag), (id, id2) and (small, id2, flag) are unique when uniq == UNIQUE; values straddle 2^32 and include -1 / 0
+    base = (np.arange(m, dtype=np.int64) // 5) * ((1 << 33) + 7) - 1
+    if uniq == ss.NOT_UNIQUE:
+        base = base // 3
+    rview = ss.View(rs, [ss.Column(base, np.arange(m) % 19 == 4), ss.Column(words[np.arange(m) % 5], np.arange(m) % 23 == 7),
+                         (np.arange(m, dtype=np.int64) % 5) * -(1 << 40), (np.arange(m) % 2).astype(bool), (np.arange(m) // 10).astype(np.int32),
+                         rng.integers(-50, 50, m) * 0.5])
+    pick = rng.integers(0, max(m, 1), n)
+    hit = rng.random(n) < 0.7
+    def like(col, miss):
+        r = np.asarray(col)[pick] if m else np.zeros(n, dtype=np.asarray(miss).dtype)
+        return np.where(hit, r, miss) if m else np.full(n, miss)
+    lview = ss.View(ls, [ss.Column(like(rview.column(0).data, np.int64(12345)).astype(np.int64), rng.random(n) < 0.08),
+                         ss.Column(np.array(list(like(rview.column(1).data, b"q")), dtype=object) if n else np.zeros(0, dtype=object), rng.random(n) < 0.08),
+                         like(rview.column(2).data, np.int64(3)).astype(np.int64), like(rview.column(3).data, False).astype(bool),
+                         like(rview.column(4).data, np.int32(-7)).astype(np.int32), rng.integers(0, 1000, n)])
+    proj = (ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes("L.")).add(1, ss.ProjectNamedAttributes(["w", "tag", "id"])))
+    for lk, rk in ((["fk", "ftag"], ["id", "tag"]), (["fk", "fk2"], ["id", "id2"]), (["fsmall", "fk2", "fflag"], ["small", "id2", "flag"])):
+        op = ss.HashJoin(join_type, ss.ProjectNamedAttributes(lk), ss.ProjectNamedAttributes(rk), proj, uniq, ss.ScanView(lview), ss.ScanView(rview))
+        run_both(op, gpu_ctx)
+        spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "w", "sw").AddAggregation(ss.COUNT, "tag", "c").AddAggregation(ss.COUNT, "", "n")
+        run_both(ss.ScalarAggregate(spec, op), gpu_ctx)
+
+
+def test_hash_join_wide_key_errors(gpu_ctx):
+    s3 = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64), ss.Attribute("c", ss.INT64)])
+    v = ss.View(s3, [np.arange(4), np.arange(4), np.arange(4)])
+    proj = ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes("L.")).add(1, ss.ProjectAllAttributes("R."))
+    three = ss.HashJoin(ss.INNER, ss.ProjectNamedAttributes(["a", "b", "c"]), ss.ProjectNamedAttributes(["a", "b", "c"]), proj, ss.UNIQUE, ss.ScanView(v), ss.ScanView(v))
+    with pytest.raises(ss.SupersonicException) as e:      # three words: refused loudly, never computed elsewhere
+        three.CreateCursor(gpu_ctx)
+    assert e.value.return_code == 103          # ERROR_NOT_IMPLEMENTED
+    # duplicate two-word keys under a UNIQUE declaration are reported
+    d = ss.View(s3, [np.array([1, 1, 2, 2]), np.array([5, 5, 6, 7]), np.arange(4)])
+    dup = ss.HashJoin(ss.INNER, ss.ProjectNamedAttributes(["a", "b"]), ss.ProjectNamedAttributes(["a", "b"]), proj, ss.UNIQUE, ss.ScanView(v), ss.ScanView(d))
+    assert dup.CreateCursor(gpu_ctx).Next(1024).is_failure()
+
+
 def test_signaling_division_fails_only_on_selected_rows(gpu_ctx):
     n = 5000
     view = make_view(n)
