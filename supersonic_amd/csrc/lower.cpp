@@ -799,6 +799,7 @@ struct AggPlan {
   std::string out_name;
   bool result_nullable = true;
   bool distinct = false;   // only the first occurrence of every value of a group contributes (column_aggregator.cc:308-376)
+  int flag_pos = -1;       // DISTINCT over a second, third ... column: pipe column holding that column's first-of-run flag
 };
 
 static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schema& in, std::vector<AggPlan>* out) {
@@ -995,6 +996,19 @@ static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const P
   const int sel = em.sel_by_depth.back();
   int notfirst = -1;
   if (distinct_flag_input >= 0) { Val f; f.width = 1; f.reg = em.staged(distinct_flag_input, false, 1); notfirst = em.unop(VM_NOT_B8, f, 1); }
+  std::map<int, int> notfirst_of_col;   // materialised flag columns of further DISTINCT inputs (AggPlan::flag_pos)
+  auto notfirst_for = [&](const AggPlan& ap, int* out) -> Status {
+    *out = notfirst;
+    if (ap.flag_pos < 0) return Status::OK();
+    auto it = notfirst_of_col.find(ap.flag_pos);
+    if (it == notfirst_of_col.end()) {
+      Val f; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.flag_pos].expr, &f));
+      Val fm; fm.width = 1; fm.reg = em.materialize(f);
+      it = notfirst_of_col.emplace(ap.flag_pos, em.unop(VM_NOT_B8, fm, 1)).first;
+    }
+    *out = it->second;
+    return Status::OK();
+  };
   // COUNT(*) (or COUNT of a never-NULL column) under the same selection equals the contribution
   // count every non-COUNT aggregate of a never-NULL input already keeps: share it, no instruction
   int count_donor = -1;
@@ -1015,7 +1029,7 @@ static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const P
       }
       int nullreg = -1;
       if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
-      if (ap.distinct) nullreg = em.or_null(nullreg, notfirst);
+      if (ap.distinct) { int nf; SS_RETURN_IF_ERROR(notfirst_for(ap, &nf)); nullreg = em.or_null(nullreg, nf); }
       LInstr& i = em.emit(VM_AGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = sel;
       ao.slot_kind = SLOT_COUNT;
       ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
@@ -1053,7 +1067,8 @@ static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const P
           SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(ap.out_type), &c));
         }
         int vr = em.materialize(c);
-        const int nullreg = ap.distinct ? em.or_null(v.null, notfirst) : v.null;
+        int nullreg = v.null;
+        if (ap.distinct) { int nf; SS_RETURN_IF_ERROR(notfirst_for(ap, &nf)); nullreg = em.or_null(v.null, nf); }
         LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = sel;
       }
       ao.slot_kind = s.slot_kind; ao.emit_kind = s.emit_kind;
@@ -1116,6 +1131,19 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
   int slotreg = -1;
   int notfirst = -1;   // DISTINCT aggregates (see finish_scalar_agg_bound)
   if (distinct_flag_input >= 0) { Val f; f.width = 1; f.reg = em.staged(distinct_flag_input, false, 1); notfirst = em.unop(VM_NOT_B8, f, 1); }
+  std::map<int, int> notfirst_of_col;
+  auto notfirst_for = [&](const AggPlan& ap, int* out) -> Status {
+    *out = notfirst;
+    if (ap.flag_pos < 0) return Status::OK();
+    auto it = notfirst_of_col.find(ap.flag_pos);
+    if (it == notfirst_of_col.end()) {
+      Val f; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.flag_pos].expr, &f));
+      Val fm; fm.width = 1; fm.reg = em.materialize(f);
+      it = notfirst_of_col.emplace(ap.flag_pos, em.unop(VM_NOT_B8, fm, 1)).first;
+    }
+    *out = it->second;
+    return Status::OK();
+  };
   if (clustered) {
     for (size_t k = 0; k < kpos.size(); ++k) {
       const BExprP& ke = pipe.cols[kpos[k]].expr;
@@ -1171,7 +1199,7 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
     if (ap.aggregation == SSGPU_COUNT) {
       int nullreg = -1;
       if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
-      if (ap.distinct) nullreg = em.or_null(nullreg, notfirst);
+      if (ap.distinct) { int nf; SS_RETURN_IF_ERROR(notfirst_for(ap, &nf)); nullreg = em.or_null(nullreg, nf); }
       LInstr& i = em.emit(VM_GAGG_COUNT); i.dst_is_reg = false; i.dst = (int)j; i.b = nullreg; i.c = slotreg;
       i.imm = (ng << 32) | j;
       ao.emit_kind = dtype_width(ap.out_type) == 4 ? EMIT_U32 : EMIT_U64;
@@ -1200,7 +1228,8 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
         if (wide_emit >= 0) s.emit_kind = wide_emit;
         vr = em.materialize(c);
       }
-      const int nullreg = ap.distinct ? em.or_null(v.null, notfirst) : v.null;
+      int nullreg = v.null;
+      if (ap.distinct) { int nf; SS_RETURN_IF_ERROR(notfirst_for(ap, &nf)); nullreg = em.or_null(v.null, nf); }
       ao.has_cnt = nullreg >= 0;
       LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = slotreg;
       i.imm = ((uint64_t)(ao.has_cnt ? 1 : 0) << 63) | (ng << 32) | j;
@@ -1611,34 +1640,56 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           GroupBinding g;
           if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
-          int dcol = -1;
-          for (auto& ap : g.plans) if (ap.distinct) {
-            if (dcol >= 0 && dcol != ap.input_pos) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "DISTINCT aggregations over more than one column in one specification");
-            dcol = ap.input_pos;
-          }
           std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
           auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
           for (auto& k : g.kpos) k = slot_of(k);
           for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
-          dcol = slot_of(dcol);
+          std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
+          for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
           Pipe pruned = pipe; pruned.cols.clear();
           for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
-          Stage so; so.kind = STAGE_SORT; so.in_schema = m.out_schema; so.out_schema = m.out_schema;
-          std::vector<int> run_cols = g.kpos; run_cols.push_back(dcol);
-          for (int k : run_cols) {
-            if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length keys are outside the device hot path");
-            SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+          reset_pipe(&pipe, m.out_schema);
+          // sorts the pipe's rows by (keys, dcol); *run_cols = those columns
+          auto sort_by_run = [&](int dcol, std::vector<int>* run_cols) -> Status {
+            Stage so; so.kind = STAGE_SORT; so.in_schema = pipe.in_schema; so.out_schema = pipe.in_schema;
+            *run_cols = g.kpos; run_cols->push_back(dcol);
+            for (int k : *run_cols) {
+              if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length keys are outside the device hot path");
+              SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+            }
+            for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+            stages->push_back(so);
+            reset_pipe(&pipe, so.out_schema);
+            return Status::OK();
+          };
+          // Every DISTINCT column but the first gets its first-of-run flags as a stored BOOL column: the rows are sorted by
+          // (keys, that column), flagged (the synthetic input behind the stage's columns) and written back with the flag;
+          // the last sort -- by (keys, first DISTINCT column) -- carries those flags along as payload.
+          for (size_t e = 1; e < dcols.size(); ++e) {
+            std::vector<int> run_cols;
+            SS_RETURN_IF_ERROR(sort_by_run(dcols[e], &run_cols));
+            const int n_cols = (int)pipe.in_schema.size();
+            Pipe with_flag = pipe;
+            VCol fc; fc.name = "f" + std::to_string(e);
+            auto fe = std::make_shared<BExpr>();
+            fe->kind = BExpr::INPUT; fe->input_col = n_cols; fe->dtype = SSGPU_BOOL; fe->nullable = false; fe->name = fc.name;
+            fc.expr = fe;
+            with_flag.cols.push_back(fc);
+            Stage mf; SS_RETURN_IF_ERROR(finish_materialize(with_flag, &mf));
+            mf.distinct_cols = run_cols;
+            stages->push_back(mf);
+            reset_pipe(&pipe, mf.out_schema);
+            for (auto& ap : g.plans) if (ap.distinct && ap.input_pos == dcols[e]) ap.flag_pos = n_cols;
           }
-          for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
-          stages->push_back(so);
-          reset_pipe(&pipe, so.out_schema);
-          const int n_in = (int)so.out_schema.size();
+          std::vector<int> run_cols;
+          SS_RETURN_IF_ERROR(sort_by_run(dcols[0], &run_cols));
+          const int n_in = (int)pipe.in_schema.size();
           if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st, n_in));
           else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true, nullptr, n_in + 1));   // clustered: segment ids at n_in, the flag behind
           st.distinct_cols = run_cols;
-          desc << "(materialise + sort + first-of-run flags) ";
+          desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)) ";
         } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
         else {
           // GroupAggregateOptions::max_unique_keys_in_result folds every key beyond the limit into one extra last row

@@ -915,10 +915,15 @@ int emit_scalar_agg(ssgpu_plan* p, size_t si) {
   return SSGPU_OK;
 }
 
-int run_materialize(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
+int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
-  int rc = ensure_out_cols(c, st, ex, in.rows);
+  int rc = ensure_out_cols(c, st, ex, in0.rows);
   if (rc != SSGPU_OK) return rc;
+  InCols in = in0;
+  if (!st.distinct_cols.empty()) {   // a further DISTINCT column's first-of-run flags, stored with the rows (lower.cpp)
+    ssgpu_column f; rc = distinct_flags(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
+    in.cols.push_back(f);
+  }
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   apply_joins(p, ex, st.main, &P);

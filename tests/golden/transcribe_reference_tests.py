@@ -1124,6 +1124,60 @@ expr_case("UnaryComputers_EvaluationIntroducesNulls", UC + ":136-147", [F64, F64
 expr_case("UnaryComputers_EvaluationWorksForSafe", UC + ":158-177", [F64, F64], [[4.0, 2.0], [9.0, 3.0], [-1.0, None]], "SqrtNulling", nullable=False)
 expr_case("UnaryComputers_SqrtNulling_keeps_input_nulls", UC + ":120-134", [F64, F64], [[None if i % 3 != 0 else 1.0 - i, None if (i % 3 != 0 or 1 - i < 0) else (1.0 - i) ** 0.5] for i in range(4)], "SqrtNulling")
 
+# ---- hybrid_aggregate_test.cc: DISTINCT next to plain aggregations, and DISTINCT over two different columns.  The operation
+# under test there is HybridGroupAggregate, whose result contract is GroupAggregate's (aggregate.h: the hybrid form differs in
+# how it spills, not in what it returns); restated here on GroupAggregate, which is what the device path implements.
+HY = "supersonic/cursor/core/hybrid_aggregate_test.cc"
+op_case("Hybrid_NoGroupByColumns", HY + ":591-616", cols([I32]), [[1], [1], [3], [3], [2], [3], [1]],
+        ["GroupAggregate", ["CompoundSingleSourceProjector"], [["SUM", "col0", "sum"], ["COUNT", "col0", "cnt"], ["COUNT_DISTINCT", "col0", "dcnt"]], "INPUT"],
+        [I32, U64, U64], [[14, 7, 3]])
+op_case("Hybrid_Simple1", HY + ":618-650", cols([I32, I32]), [[1, 3], [1, 4], [3, -3], [2, 4], [3, -5]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"],
+         [["SUM", "col1", "sum"], ["SUM", "col0", "sum2"], ["COUNT", "col0", "cnt"], ["COUNT_DISTINCT", "col0", "dcnt"]], "INPUT"],
+        [I32, I32, I32, U64, U64], [[1, 7, 2, 2, 1], [2, 4, 2, 1, 1], [3, -8, 6, 2, 1]], ordered=False)
+op_case("Hybrid_DistinctAggregations_two_columns", HY + ":652-681", cols([I32, I32]), [[1, 3], [1, 4], [3, -1], [3, -2], [2, 4], [3, -3], [1, 3]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"],
+         [["SUM_DISTINCT", "col1", "sum"], ["COUNT_DISTINCT", "col1", "cnt"], ["COUNT_DISTINCT", "col0", "cnt2"]], "INPUT"],
+        [I32, I32, U64, U64], [[1, 7, 2, 1], [2, 4, 1, 1], [3, -6, 3, 1]], ordered=False)
+op_case("Hybrid_NonDistinctAndDistinctAggregations", HY + ":683-716", cols([I32, I32]),
+        [[1, 3], [1, 4], [3, -1], [3, -2], [2, 4], [3, -3], [1, 3], [1, None]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"],
+         [["SUM_DISTINCT", "col1", "sum"], ["COUNT_DISTINCT", "col1", "cnt"], ["SUM", "col1", "sum2"], ["COUNT", "col1", "cnt2"], ["COUNT", "", "cnt3"]], "INPUT"],
+        [I32, I32, U64, I32, U64, U64], [[1, 7, 2, 10, 3, 4], [2, 4, 1, 4, 1, 1], [3, -6, 3, -6, 3, 3]], ordered=False)
+
+# ---- base/infrastructure/operators_test.cc: Equal / Less across signed and unsigned integers (the operators behind the
+# comparison expressions and ThreeWayCompare).  Each EXPECT is restated as the comparison expression over two columns of
+# the operand types; the negative operands are the tests' static_cast<unsigned>(-5) values.
+OT = "supersonic/base/infrastructure/operators_test.cc"
+_INTS = [I32, U32, I64, U64]
+
+
+def _neg5(t):
+    return {I32: -5, I64: -5, U32: (1 << 32) - 5, U64: (1 << 64) - 5}[t]
+
+
+_eq_rows = {}
+for ta in _INTS:
+    for tb in _INTS:
+        rows = [[3, 3, True]]                                        # :41-59 eq(k*_3, k*_3)
+        if (ta in (I32, I64)) != (tb in (I32, I64)):                 # :61-69 a negative number never equals a huge unsigned one
+            rows.append([_neg5(ta), _neg5(tb), False])
+        expr_case("Operators_Equal_MixedNumerics_%s_%s" % (ta, tb), OT + ":40-72", [ta, tb, BOOL], rows, "Equal")
+expr_case("Operators_Equal_MixedNumerics_3_vs_5", OT + ":71", [I32, I64, BOOL], [[3, 5, False]], "Equal")
+expr_case("Operators_Equal_Bool", OT + ":74-80", [BOOL, BOOL, BOOL], [[False, False, True], [False, True, False], [True, False, False], [True, True, True]], "Equal")
+expr_case("Operators_Equal_String", OT + ":82-90", [STR, STR, BOOL], [["a", "a", True], ["a", "aa", False], ["aa", "a", False], ["aa", "aa", True]], "Equal")
+expr_case("Operators_Less_Trivial", OT + ":94-99", [I32, I32, BOOL], [[3, 5, True], [-5, 3, True], [5, -5, False]], "Less")
+for ts in (I32, I64):                                                # :101-124 signed vs unsigned, both ways
+    for tu in (U32, U64):
+        expr_case("Operators_Less_MixedNumerics_%s_%s" % (ts, tu), OT + ":101-124", [ts, tu, BOOL], [[-5, 5, True], [3, 5, True]], "Less")
+        expr_case("Operators_Less_MixedNumerics_%s_%s" % (tu, ts), OT + ":101-124", [tu, ts, BOOL], [[5, -5, False], [5, 3, False]], "Less")
+expr_case("Operators_Less_Bool", OT + ":126-132", [BOOL, BOOL, BOOL], [[False, False, False], [False, True, True], [True, False, False], [True, True, False]], "Less")
+expr_case("Operators_Less_String", OT + ":134-142", [STR, STR, BOOL], [["a", "a", False], ["a", "aa", True], ["aa", "a", False], ["aa", "aa", False]], "Less")
+_cmp3 = [[5, 3], [5, 5], [3, 5]]
+for _f, _want, _src in (("Greater", [True, False, False], ":146-151"), ("LessOrEqual", [False, True, True], ":153-158"),
+                        ("GreaterOrEqual", [True, True, False], ":160-165"), ("NotEqual", [True, False, True], ":167-172")):
+    expr_case("Operators_Complements_" + _f, OT + _src, [I32, I32, BOOL], [r + [w] for r, w in zip(_cmp3, _want)], _f)
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
     with open(out, "w") as f:

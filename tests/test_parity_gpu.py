@@ -359,6 +359,21 @@ def test_distinct_aggregates(gpu_ctx, n, nullable):
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec2, None, ss.Compute(e, ss.ScanView(view))), gpu_ctx, ignore_order=True)
 
 
+@pytest.mark.parametrize("n", [0, 3, 700, 40001])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_distinct_aggregates_over_several_columns(gpu_ctx, n, nullable):
+    # DISTINCT aggregations over two and three different columns of one specification (hybrid_aggregate_test.cc:652-720 has
+    # the two-column shape): every further column costs one more sort + flag pass whose flags ride along as payload
+    view = make_view(n, nullable=nullable)
+    spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "a", "cda").AddDistinctAggregation(ss.SUM, "k1", "sdk")
+            .AddAggregation(ss.SUM, "a", "s").AddDistinctAggregation(ss.SUM, "a", "sda").AddDistinctAggregation(ss.COUNT, "t", "cdt")
+            .AddAggregation(ss.COUNT, "", "n").AddDistinctAggregation(ss.COUNT, "k1", "cdk").AddAggregation(ss.MIN, "d1", "mn"))
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2", "t"]), spec, None,
+                               ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx, ignore_order=True)
+
+
 def test_plan_restages_every_new_host_view(gpu_ctx):
     # one Plan run over a stream of temporary host Views (a per-batch loop): CPython reuses the id() of a freed View, so
     # the staged device block must be keyed on the object itself -- never on its id
