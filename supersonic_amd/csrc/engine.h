@@ -92,6 +92,7 @@ struct JoinSpec {
   std::vector<GroupKeyField> fields;     // packing of the key: one 64-bit word, or two (`wide`, GroupKeyField::word)
   bool multi = false;                    // NOT_UNIQUE rhs keys: the index maps a key to a run of rhs rows
   bool wide = false;                     // the packed key takes two 64-bit words (JOIN_PROBE_WIDE)
+  int depth = 0;                         // number of Filters below the join: rows their selection dropped are not probed
 };
 struct JoinGather { int join_id; int rhs_col; bool is_null_mask; };  // slot i of VmParams.join_cols
 enum { JOIN_GATHER_RUN_START = -1, JOIN_GATHER_RUN_COUNT = -2 };   // rhs_col of a multi join's per-key run arrays

@@ -75,8 +75,8 @@ struct JoinBuildParams {
   unsigned int n_keys;
   unsigned int capacity_mask;
   unsigned long long n_rows;
-  unsigned long long* keys;     // capacity entries, pre-filled with VM_KEY_EMPTY
-  unsigned int* rows;
+  unsigned long long* keys;     // one-word keys: capacity {key, answer} pairs, pre-filled with VM_KEY_EMPTY; two-word keys: first words
+  unsigned int* rows;           // two-word keys only
   unsigned int* special;        // pre-filled with VM_NONE
   unsigned int* flags;          // pre-zeroed
   // NOT_UNIQUE keys (both null for a UNIQUE index): the table maps a key to its own slot, counts[slot]

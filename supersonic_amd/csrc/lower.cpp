@@ -139,6 +139,11 @@ class Emitter {
     return (int)P->gathers.size() - 1;
   }
 
+  // join_index: the stage's filter chain and whether later filters may be evaluated ahead of a probe (emit_filters sets both)
+  const std::vector<BExprP>* filters_ = nullptr;
+  bool hoist_ok_ = false;
+  bool may_fail(const BExprP& e) { return can_fail(e); }
+
  private:
   const std::vector<JoinSpec>* joins_;
   std::map<int, int> join_idx_;
@@ -150,6 +155,15 @@ class Emitter {
   // evaluation error (the failers take the skip vector as is_null).  Values may be computed everywhere; what has to
   // respect the skip vector is the FAIL_* instructions.  guard_ = BOOL register, 1 = row evaluated (-1 = all).
   int guard_ = -1;
+  std::map<const BExpr*, bool> reads_join_;
+  bool reads_join(const BExprP& e) {
+    auto it = reads_join_.find(e.get());
+    if (it != reads_join_.end()) return it->second;
+    bool f = e->kind == BExpr::JOINCOL || e->kind == BExpr::JOINMATCH || e->kind == BExpr::JOINSTART || e->kind == BExpr::JOINCNT;
+    for (auto& a : e->args) f = f || reads_join(a);
+    reads_join_[e.get()] = f;
+    return f;
+  }
   std::map<const BExpr*, bool> can_fail_;
   bool can_fail(const BExprP& e) {
     auto it = can_fail_.find(e.get());
@@ -257,13 +271,21 @@ Status Emitter::join_index(int join_id, int* reg) {
   if (!joins_ || join_id < 0 || join_id >= (int)joins_->size()) return Status::Error(SSGPU_ERROR_UNKNOWN, "join reference outside its stage");
   const JoinSpec& js = (*joins_)[join_id];
   // pack the lhs key exactly as the index build packs the rhs key (JoinBuildParams)
-  int keyreg = new_reg(8), keyreg_hi = -1;
+  int keyreg = -1, keyreg_hi = -1;
+  int any_null = -1;   // a NULL in any key column: the row matches nothing
+  // one 64-bit key column IS the packed key: no packing instructions
+  const bool direct = js.fields.size() == 1 && js.fields[0].width == 8 && js.fields[0].shift == 0 && !js.wide;
+  if (direct) {
+    Val v; SS_RETURN_IF_ERROR(value(js.lhs_keys[0], &v));
+    keyreg = materialize(v);
+    any_null = v.null;
+  } else {
+  keyreg = new_reg(8);
   { LInstr& i = emit(VM_FILL_64); i.dst = keyreg; i.a_imm = true; i.imm = 0; i.imm_width = 8; }
   if (js.wide) {
     keyreg_hi = new_reg(8);
     LInstr& i = emit(VM_FILL_64); i.dst = keyreg_hi; i.a_imm = true; i.imm = 0; i.imm_width = 8;
   }
-  int any_null = -1;   // a NULL in any key column: the row matches nothing
   for (size_t k = 0; k < js.lhs_keys.size(); ++k) {
     Val v; SS_RETURN_IF_ERROR(value(js.lhs_keys[k], &v));
     const GroupKeyField& f = js.fields[k];
@@ -273,8 +295,27 @@ Status Emitter::join_index(int join_id, int* reg) {
     i.imm = (uint64_t)f.shift | ((uint64_t)f.bits << 8) | ((uint64_t)f.nullbit << 16);
     any_null = or_null(any_null, v.null);
   }
+  }
+  // Rows the selection has already dropped are not probed: the selection at the join's depth and, when nothing in the stage
+  // can raise an evaluation error, the later filters that read no join column (a Filter written ABOVE the join on lhs
+  // columns: the probe and the rhs gathers are the expensive part of the row, the predicate is not).  Those rows look
+  // unmatched, which nothing observes: every consumer of the join's columns sits at or above the join's depth, and a
+  // hoisted filter drops its rows again at its own place in the chain.
+  int probe_sel = js.depth >= 0 && js.depth < (int)sel_by_depth.size() ? sel_by_depth[js.depth] : -1;
+  if (filters_ && hoist_ok_) {
+    for (size_t f = (size_t)std::max(js.depth, 0); f < filters_->size(); ++f) {
+      const BExprP& g = (*filters_)[f];
+      if (reads_join(g)) continue;
+      Val pv; SS_RETURN_IF_ERROR(value(g, &pv));
+      if (pv.imm) continue;
+      if (pv.null < 0 && probe_sel < 0) { probe_sel = pv.reg; continue; }
+      const int r = new_reg(1);
+      LInstr& i = emit(VM_SEL_FROM_PRED); i.dst = r; i.a = pv.reg; i.b = pv.null; i.c = probe_sel;
+      probe_sel = r;
+    }
+  }
   const int idx = new_reg(4);
-  { LInstr& i = emit(js.wide ? VM_JOIN_PROBE_WIDE : VM_JOIN_PROBE); i.dst = idx; i.a = keyreg; i.b = any_null; i.c = keyreg_hi; i.imm = (uint64_t)join_id; }
+  { LInstr& i = emit(js.wide ? VM_JOIN_PROBE_WIDE : VM_JOIN_PROBE); i.dst = idx; i.a = keyreg; i.b = any_null; i.c = keyreg_hi; i.d = probe_sel; i.imm = (uint64_t)join_id; }
   join_idx_[join_id] = idx;
   *reg = idx;
   return Status::OK();
@@ -958,6 +999,11 @@ static void reset_pipe(Pipe* p, const Schema& in) {
 
 // emit the filter chain; fills em.sel_by_depth
 static Status emit_filters(Emitter& em, const Pipe& pipe) {
+  em.filters_ = &pipe.filters;
+  em.hoist_ok_ = !pipe.joins.empty();
+  for (auto& f : pipe.filters) em.hoist_ok_ = em.hoist_ok_ && !em.may_fail(f);
+  for (auto& c : pipe.cols) em.hoist_ok_ = em.hoist_ok_ && !em.may_fail(c.expr);
+  for (auto& j : pipe.joins) for (auto& k : j.lhs_keys) em.hoist_ok_ = em.hoist_ok_ && !em.may_fail(k);
   for (size_t f = 0; f < pipe.filters.size(); ++f) {
     Val pv;
     SS_RETURN_IF_ERROR(em.value(pipe.filters[f], &pv));
@@ -1527,7 +1573,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         if (lpos.size() != rpos.size() || lpos.empty())
           return Status::Error(SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH, "hash join key selectors must pick the same, non-zero number of columns");
         if (lpos.size() > 8) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "hash joins on more than 8 key columns are not on device");
-        JoinSpec js; js.type = jtype; js.multi = multi;
+        JoinSpec js; js.type = jtype; js.multi = multi; js.depth = pipe.depth();
         uint32_t fill[2] = {0, 0};      // a key of 65..128 bits takes a second word; a field never straddles the two (first fit)
         for (size_t k = 0; k < lpos.size(); ++k) {
           const BExprP& le = pipe.cols[lpos[k]].expr;

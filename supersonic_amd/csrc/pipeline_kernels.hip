@@ -1255,17 +1255,18 @@ __global__ __launch_bounds__(256) void ssgpu_join_build_kernel(const JoinBuildPa
     } else if (atomicCAS(P.special, VM_NONE, (u32)i) != VM_NONE) atomicExch(&P.flags[0], 1u);
     return;
   }
+  // one-word keys: an entry is the pair {key, answer} in ONE 16-byte slot, so that the probe needs one load per slot
   u32 slot = hash64(key) & P.capacity_mask;
   for (u32 probe = 0; probe <= P.capacity_mask; ++probe) {
-    const u64 old = atomicCAS(&P.keys[slot], VM_KEY_EMPTY, key);
+    const u64 old = atomicCAS(&P.keys[2ull * slot], VM_KEY_EMPTY, key);
     if (multi) {
       if (old == VM_KEY_EMPTY || old == key) {
-        if (old == VM_KEY_EMPTY) P.rows[slot] = slot;   // the probe answers with the key's slot, not a row
+        if (old == VM_KEY_EMPTY) P.keys[2ull * slot + 1] = slot;   // the probe answers with the key's slot, not a row
         atomicAdd(&P.counts[slot], 1u); P.slot_of_row[i] = slot;
         return;
       }
     } else {
-      if (old == VM_KEY_EMPTY) { P.rows[slot] = (u32)i; return; }
+      if (old == VM_KEY_EMPTY) { P.keys[2ull * slot + 1] = i; return; }
       if (old == key) { atomicExch(&P.flags[0], 1u); return; }     // duplicate key in a UNIQUE rhs
     }
     slot = (slot + 1) & P.capacity_mask;

@@ -664,11 +664,13 @@ int build_joins(ssgpu_plan* p, Stage& st, StageExec& ex) {
     const JoinSpec& js = st.joins[j];
     uint64_t cap = 16; while (cap < (uint64_t)std::max<int64_t>(p->aux_rows, 1) * 2) cap <<= 1;
     if (cap > (1ull << 31)) { c->err = "hash join rhs table too large"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
-    HIP_TRY(c, ex.jkeys[j].ensure(cap * 8)); HIP_TRY(c, ex.jrows[j].ensure(cap * 4)); HIP_TRY(c, ex.jmisc[j].ensure(16));
-    HIP_TRY(c, ssgpu_launch_fill_u64(ex.jkeys[j].as<uint64_t>(), VM_KEY_EMPTY, cap, c->stream));
-    if (js.wide) {   // two-word keys: a slot is free while rows[slot] == VM_NONE
-      HIP_TRY(c, ex.jkeys_hi[j].ensure(cap * 8));
+    HIP_TRY(c, ex.jmisc[j].ensure(16));
+    if (js.wide) {   // two-word keys: keys / keys_hi / rows arrays; a slot is free while rows[slot] == VM_NONE
+      HIP_TRY(c, ex.jkeys[j].ensure(cap * 8)); HIP_TRY(c, ex.jkeys_hi[j].ensure(cap * 8)); HIP_TRY(c, ex.jrows[j].ensure(cap * 4));
       HIP_TRY(c, ssgpu_launch_fill_u32(ex.jrows[j].as<unsigned int>(), VM_NONE, cap, c->stream));
+    } else {         // one-word keys: {key, answer} pairs, free while key == VM_KEY_EMPTY
+      HIP_TRY(c, ex.jkeys[j].ensure(cap * 16));
+      HIP_TRY(c, ssgpu_launch_fill_u64(ex.jkeys[j].as<uint64_t>(), VM_KEY_EMPTY, cap * 2, c->stream));
     }
     const uint32_t misc_init[4] = {VM_NONE, 0u, 0u, 0u};   // [0] special row, [1] flags
     HIP_TRY(c, hipMemcpyAsync(ex.jmisc[j].p, misc_init, 16, hipMemcpyHostToDevice, c->stream));

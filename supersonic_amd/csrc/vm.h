@@ -225,8 +225,9 @@ struct VmGroupTable {
  * in an open-addressing index over the rhs table (imm = join number) and leaves the matched rhs
  * row (or VM_NONE) in a u32 register; GATHER_* (imm = slot of join_cols) fetch rhs values by it. */
 struct VmJoin {
-  const unsigned long long* keys;   /* capacity entries, VM_KEY_EMPTY = free */
-  const unsigned int* rows;         /* rhs row of every entry */
+  const unsigned long long* keys;   /* JOIN_PROBE: capacity {key, answer} pairs (16 bytes each), key == VM_KEY_EMPTY = free;
+                                       JOIN_PROBE_WIDE: the first key word of every entry */
+  const unsigned int* rows;         /* JOIN_PROBE_WIDE: rhs row of every entry, VM_NONE = free */
   const unsigned int* special;      /* [0]: rhs row whose packed key equals VM_KEY_EMPTY, or VM_NONE */
   uint32_t capacity_mask;
   uint32_t answer_slot;             /* JOIN_PROBE_WIDE: 1 = answer with the key's slot (NOT_UNIQUE index), 0 = with rows[slot] */

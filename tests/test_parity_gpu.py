@@ -686,6 +686,44 @@ def test_hash_join_keys_of_two_words(gpu_ctx, n, m, join_type, uniq):
         run_both(ss.ScalarAggregate(spec, op), gpu_ctx)
 
 
+@pytest.mark.parametrize("join_type", [ss.INNER, ss.LEFT_OUTER])
+def test_filters_above_a_join_are_evaluated_ahead_of_the_probe(gpu_ctx, join_type):
+    # a Filter written above the join that reads only lhs columns is evaluated first and its rows are not probed (lower.cpp:
+    # join_index) -- invisible in the result, also with NULL predicates, LEFT_OUTER NULL padding and filters on both sides
+    lview, rview = _join_views(30011, 300)
+    proj = (ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes("L.")).add(1, ss.ProjectNamedAttributes(["name", "w", "g"])))
+    join = lambda lhs: ss.HashJoin(join_type, ss.ProjectNamedAttribute("fk"), ss.ProjectNamedAttribute("id"), proj, ss.UNIQUE, lhs, ss.ScanView(rview))
+    below = ss.Filter(ss.Less(NA("a"), ss.ConstInt64(700)), ss.ProjectAllAttributes(), ss.ScanView(lview))
+    above = ss.Filter(ss.Greater(NA("L.fk"), ss.ConstInt64(10)), ss.ProjectAllAttributes(), join(below))           # NULLABLE predicate
+    run_both(above, gpu_ctx)
+    both = ss.Filter(ss.Or(ss.IsNull(NA("w")), ss.Less(NA("w"), ss.ConstDouble(20.0))), ss.ProjectAllAttributes(), above)   # reads the join: stays behind it
+    run_both(both, gpu_ctx)
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "w", "sw").AddAggregation(ss.COUNT, "name", "c").AddAggregation(ss.COUNT, "", "n")
+    run_both(ss.ScalarAggregate(spec, above), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), spec, None, both), gpu_ctx, ignore_order=True)
+
+
+def test_a_failing_expression_keeps_filters_behind_the_probe(gpu_ctx):
+    # The reference evaluates Compute(1000 / w) on EVERY joined row before the Filter above it sees them: a zero w on a row that
+    # filter would drop is still an evaluation error.  Probing fewer rows must not hide it.
+    ls = ss.TupleSchema([ss.Attribute("fk", ss.INT64), ss.Attribute("a", ss.INT64)])
+    rs = ss.TupleSchema([ss.Attribute("id", ss.INT64), ss.Attribute("w", ss.INT64)])
+    n = 5000
+    lview = ss.View(ls, [np.arange(n) % 50, np.arange(n)])
+    proj = ss.CompoundMultiSourceProjector().add(0, ss.ProjectAllAttributes()).add(1, ss.ProjectNamedAttributes(["w"]))
+
+    def query(w):
+        rview = ss.View(rs, [np.arange(50), w])
+        j = ss.HashJoin(ss.INNER, ss.ProjectNamedAttribute("fk"), ss.ProjectNamedAttribute("id"), proj, ss.UNIQUE, ss.ScanView(lview), ss.ScanView(rview))
+        e = ss.CompoundExpression().Add(NA("a")).AddAs("q", ss.DivideSignaling(ss.ConstInt64(1000), NA("w")))
+        return ss.Filter(ss.Less(NA("a"), ss.ConstInt64(10)), ss.ProjectAllAttributes(), ss.Compute(e, j))
+    ok = np.arange(50) + 1
+    run_both(query(ok), gpu_ctx)
+    bad = ok.copy(); bad[40] = 0           # fk == 40 first occurs at a == 40: a row the filter drops
+    r = query(bad).CreateCursor(gpu_ctx).Next(1024)
+    assert r.is_failure() and r.exception().return_code == 104
+
+
 def test_hash_join_wide_key_errors(gpu_ctx):
     s3 = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64), ss.Attribute("c", ss.INT64)])
     v = ss.View(s3, [np.arange(4), np.arange(4), np.arange(4)])
