@@ -137,7 +137,10 @@ struct SortRecField { const void* src; void* dst; unsigned int off, width; };   
 #define SSGPU_SORT_MAX_FIELDS 96
 struct SortRecParams { void* recs; unsigned long long n; unsigned int stride, n_fields; SortRecField fields[SSGPU_SORT_MAX_FIELDS]; };
 hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s);
-hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, hipStream_t s);
+hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s);
+hipError_t ssgpu_launch_sort_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, hipStream_t s);
+hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s);
+hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s);
 // View-file loader: one piece = one column (or NULL-mask) segment of one file chunk inside a staged slab
 struct UnpackPiece { unsigned long long src_off; void* dst; unsigned long long bytes; };
 hipError_t ssgpu_launch_unpack(const char* slab, const UnpackPiece* pieces, unsigned int n_pieces, hipStream_t s);

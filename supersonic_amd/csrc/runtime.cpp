@@ -52,6 +52,7 @@ struct ssgpu_ctx {
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
   int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
+  int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
   int64_t sort_hi_digits = 4;    // high digits the hybrid sort passes over before fixing ties: 2..4, 0 = by row count
   int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
   int64_t profile = 1;           // record HIP events around kernels
@@ -152,7 +153,7 @@ struct StageExec {
   DevBuf error_flag;
   DevBuf debug, debug_pc, total2;
   // sort / clusters
-  DevBuf skeys_a, skeys_b, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
+  DevBuf skeys_a, skeys_b, skeys_c, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
   bool pattern_ready = false;
@@ -283,6 +284,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "sort_records") c->sort_records = value;
   else if (k == "sort_hybrid") c->sort_hybrid = value;
   else if (k == "sort_hi_digits") c->sort_hi_digits = value;
+  else if (k == "sort_compact") c->sort_compact = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -1402,17 +1404,53 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   // kinds, no NULLs): no gather for it -- and when it is the ONLY output column, no row ids at all.
   const SortKey major = st.sort_keys.empty() ? SortKey{0, 0} : st.sort_keys[0];
   const int major_kind = st.sort_keys.empty() ? 99 : sort_kind_of(st.in_schema[major.col].dtype);
-  const bool major_direct = !st.sort_keys.empty() && major_kind <= 1 && dtype_width(st.in_schema[major.col].dtype) >= 4 &&
-                            !(st.in_schema[major.col].nullable && in.cols[major.col].is_null);
-  bool keys_only = major_direct && st.sort_keys.size() == 1;
+  const bool major_direct0 = !st.sort_keys.empty() && major_kind <= 1 && dtype_width(st.in_schema[major.col].dtype) >= 4 &&
+                             !(st.in_schema[major.col].nullable && in.cols[major.col].is_null);
+  bool major_direct = major_direct0;
+  bool keys_only = major_direct0 && st.sort_keys.size() == 1;
   for (int col : st.sort_out_cols) keys_only = keys_only && col == major.col;
   if (keys_only) ia = ib = nullptr;
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  // ONE read of a key column: transformed keys, OR / AND of all keys (digits on which every key agrees are skipped) and
+  // the histograms of all digits with their exclusive scans
+  auto load_key = [&](int k, int kind, int null_pass, const uint32_t* idx, uint64_t* varying) -> int {
+    const SortKey& sk = st.sort_keys[k];
+    const unsigned long long init[2] = {0ull, ~0ull};
+    HIP_TRY(c, hipMemcpyAsync(ex.total2.p, init, 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex.shist.p, 0, 8 * 256 * 4, c->stream));
+    HIP_TRY(c, ssgpu_launch_sort_load_keys_hist(ka, idx, in.cols[sk.col].data, in.cols[sk.col].is_null, (uint32_t)dtype_width(st.in_schema[sk.col].dtype), kind,
+                                                sk.order == SSGPU_DESCENDING, null_pass, n, ex.total2.as<unsigned long long>(), ex.shist.as<uint32_t>(),
+                                                ex.soffs.as<uint32_t>(), c->stream));
+    unsigned long long bits[2];
+    HIP_TRY(c, hipMemcpyAsync(bits, ex.total2.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *varying = bits[0] ^ bits[1];
+    p->counters.n_launches += 2;
+    return SSGPU_OK;
+  };
+  // The first key processed (the least significant one) is loaded before the payload layout is fixed: a wide key whose
+  // high half separates almost all rows is sorted as ONE word per row -- (high half << 32 | row id), see
+  // ssgpu_sort_compact_kernel -- which needs the key column inside the payload records (its low half is not in the
+  // sorted words) when it is also the major key.
+  const int k_first = (int)st.sort_keys.size() - 1;
+  bool first_loaded = false, compact = false;
+  uint64_t first_varying = 0;
+  if (k_first >= 0 && n >= (1u << 16) && !keys_only && c->sort_hybrid && c->sort_compact && c->sort_records && c->sort_hi_digits == 4) {
+    const SortKey& sk = st.sort_keys[k_first];
+    if (dtype_width(st.in_schema[sk.col].dtype) == 8 && !(in.cols[sk.col].is_null && st.in_schema[sk.col].nullable)) {
+      rc = load_key(k_first, sort_kind_of(st.in_schema[sk.col].dtype), 0, nullptr, &first_varying); if (rc != SSGPU_OK) return rc;
+      first_loaded = true;
+      compact = (first_varying & 0xFFFFFFFFull) != 0;
+      for (uint32_t pass = 4; pass < 8; ++pass) compact = compact && ((first_varying >> (pass * 8)) & 0xFFull) != 0;
+      if (compact && k_first == 0) major_direct = false;
+    }
+  }
   // Payload: with three or more gathered columns the rows travel as fixed-stride records (ssgpu_sort_pack_kernel):
   // the sorted order then fetches one record per row instead of one 64-byte sector per row PER COLUMN.
-  SortRecParams R; memset(&R, 0, sizeof(R));
+  SortRecParams R;
   bool use_records = false;
-  {
+  auto build_layout = [&]() {
+    memset(&R, 0, sizeof(R));
     uint32_t off = 0, nf = 0, gathered = 0;
     for (uint32_t wsel : {8u, 4u, 1u}) {
       for (size_t i = 0; i < st.sort_out_cols.size(); ++i) {
@@ -1432,14 +1470,17 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     R.stride = (off + 15u) & ~15u; R.n_fields = nf; R.n = n;
     use_records = !keys_only && payload_cols >= 3 && R.stride <= 224u && nf < SSGPU_SORT_MAX_FIELDS && n > 0 && c->sort_records != 0;
     (void)gathered;
-  }
+  };
+  build_layout();
+  if (compact && !use_records) { compact = false; major_direct = major_direct0; build_layout(); }   // the one-word form gathers through records
   if (use_records) {
     HIP_TRY(c, ex.srecs.ensure((size_t)n * R.stride + 16));
     R.recs = ex.srecs.p;
     HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream));
     p->counters.n_launches += 1;
   }
-  if (!keys_only) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+  if (!keys_only && !compact) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+  const uint64_t* compact_sorted = nullptr;   // the sorted (high half << 32 | row id) words when the record gather reads row ids from them
   // least significant key first; each key: value digits, then the NULL-order bit on top
   for (int k = (int)st.sort_keys.size() - 1; k >= 0 && n > 0; --k) {
     const SortKey& sk = st.sort_keys[k];
@@ -1448,19 +1489,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     const uint8_t* nulls = in.cols[sk.col].is_null;
     // ONE read of the key column: transformed keys, OR / AND of all keys (digits on which every key agrees are
     // skipped) and the histograms of all digits with their exclusive scans
-    auto load_and_profile = [&](int kind, int null_pass, uint64_t* varying) -> int {
-      const unsigned long long init[2] = {0ull, ~0ull};
-      HIP_TRY(c, hipMemcpyAsync(ex.total2.p, init, 16, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, hipMemsetAsync(ex.shist.p, 0, 8 * 256 * 4, c->stream));
-      HIP_TRY(c, ssgpu_launch_sort_load_keys_hist(ka, ia, in.cols[sk.col].data, nulls, w, kind, sk.order == SSGPU_DESCENDING, null_pass, n,
-                                                  ex.total2.as<unsigned long long>(), ex.shist.as<uint32_t>(), ex.soffs.as<uint32_t>(), c->stream));
-      unsigned long long bits[2];
-      HIP_TRY(c, hipMemcpyAsync(bits, ex.total2.p, 16, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      *varying = bits[0] ^ bits[1];
-      p->counters.n_launches += 2;
-      return SSGPU_OK;
-    };
+    auto load_and_profile = [&](int kind, int null_pass, uint64_t* varying) -> int { return load_key(k, kind, null_pass, ia, varying); };
     auto one_pass = [&](uint32_t digit) -> int {
       if (n_pass >= 62) { c->err = "Sort: too many radix passes in one stage"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
       HIP_TRY(c, ssgpu_launch_sort_onesweep(ka, ia, kb, ib, digit * 8, n, ex.soffs.as<uint32_t>() + digit * 256, ex.sstatus.as<unsigned long long>(),
@@ -1471,12 +1500,42 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
       return SSGPU_OK;
     };
     uint64_t varying = 0;
-    rc = load_and_profile(sort_kind_of(dtype), 0, &varying); if (rc != SSGPU_OK) return rc;
+    if (k == k_first && first_loaded) varying = first_varying;   // loaded above, in row order (what iota row ids would have read)
+    else { rc = load_and_profile(sort_kind_of(dtype), 0, &varying); if (rc != SSGPU_OK) return rc; }
     // A wide key (all eight digits vary) that is the FIRST key processed (the rows are still in input order, which the
     // stable tie-break relies on): sort by its high half and fix up the rare, short runs of equal high halves -- see
     // ssgpu_sort_fix_ties_kernel -- instead of the four low-digit passes.
-    bool done = false;
-    if (c->sort_hybrid && w == 8 && k == (int)st.sort_keys.size() - 1 && (varying & 0xFFFFFFFFull) && !(nulls && st.in_schema[sk.col].nullable) &&
+    bool done = false, tie_runs_too_long = false;
+    if (compact && k == k_first) {
+      // one word per row: the four high digits with the keys-only kernel, then the tie runs by the low halves
+      HIP_TRY(c, ex.skeys_c.ensure(std::max<uint64_t>(n, 1) * 8));
+      uint64_t* kc = kb; uint64_t* kd = ex.skeys_c.as<uint64_t>();
+      HIP_TRY(c, ssgpu_launch_sort_compact(kc, ka, n, c->stream));
+      for (uint32_t digit = 4; digit < 8; ++digit) {
+        if (n_pass >= 62) { c->err = "Sort: too many radix passes in one stage"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+        HIP_TRY(c, ssgpu_launch_sort_onesweep(kc, nullptr, kd, nullptr, digit * 8, n, ex.soffs.as<uint32_t>() + digit * 256, ex.sstatus.as<unsigned long long>(),
+                                              ex.sticket.as<uint32_t>() + n_pass, ++ex.sort_epoch, ex.sticket.as<uint32_t>() + 63, c->stream));
+        ++n_pass;
+        std::swap(kc, kd);
+      }
+      uint32_t* flag = ex.sticket.as<uint32_t>() + 62;
+      HIP_TRY(c, ssgpu_launch_sort_fix_ties_compact(kc, ka, n, flag, c->stream));
+      uint32_t too_long = 0;
+      HIP_TRY(c, hipMemcpyAsync(&too_long, flag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      p->counters.n_launches += 6;
+      if (!too_long) {
+        done = true;
+        if (k > 0) HIP_TRY(c, ssgpu_launch_sort_extract_idx(ia, kc, n, c->stream));   // more significant keys follow: they permute (key, row id) pairs
+        else compact_sorted = kc;
+      } else {
+        // long runs of equal high halves: the plain LSD order over all digits (the key array and the digit offsets are untouched)
+        HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));
+        HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+        compact = false; tie_runs_too_long = true;
+      }
+    }
+    if (!done && !tie_runs_too_long && c->sort_hybrid && w == 8 && k == (int)st.sort_keys.size() - 1 && (varying & 0xFFFFFFFFull) && !(nulls && st.in_schema[sk.col].nullable) &&
         n >= (1u << 16)) {
       // how many high digits: as few as keep the expected run of equal high parts short (n / 256^d <= 8 rows for
       // uniform keys: 3 digits up to 134 M rows), never fewer than 2 nor more than 4
@@ -1523,7 +1582,11 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     HIP_TRY(c, ssgpu_launch_sort_gather(ex.out[i].data.p, ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr,
                                         in.cols[col].data, in.cols[col].is_null, ex.out[i].width, ia, n, c->stream));
   }
-  if (use_records) { HIP_TRY(c, ssgpu_launch_sort_gather_rec(R, ia, c->stream)); p->counters.n_launches += 1; }
+  if (use_records) {
+    if (compact_sorted) HIP_TRY(c, ssgpu_launch_sort_gather_rec(R, reinterpret_cast<const uint32_t*>(compact_sorted), 2, c->stream));   // row id = low word
+    else HIP_TRY(c, ssgpu_launch_sort_gather_rec(R, ia, 1, c->stream));
+    p->counters.n_launches += 1;
+  }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   if (n_pass) {   // the look-back never gives up on a healthy device; if it did, the order is wrong: fail loudly
     uint32_t stuck = 0;

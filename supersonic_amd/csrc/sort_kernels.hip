@@ -393,6 +393,36 @@ __global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_kernel(u64* __restric
   }
 }
 
+// The same shortcut with the row id INSIDE the key word.  While only the high half is being sorted the low half is dead
+// weight: (high half << 32 | row id) is one 64-bit word per row instead of a key word plus a row-id word, so the four
+// passes run as the keys-only kernel (8 bytes per row in, 8 out, instead of 12 and 12).  The low halves are only needed
+// for the tie runs, which fetch them from the untouched key array by row id.
+__global__ __launch_bounds__(256) void ssgpu_sort_compact_kernel(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) kc[i] = (keys[i] & 0xFFFFFFFF00000000ull) | i;
+}
+__global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_compact_kernel(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n, u32* __restrict__ too_long) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u32 h = (u32)(kc[i] >> 32);
+  if (i > 0 && (u32)(kc[i - 1] >> 32) == h) return;       // not the first row of its run
+  if (i + 1 >= n || (u32)(kc[i + 1] >> 32) != h) return;  // a run of one
+  u32 len = 2;
+  while (i + len < n && len <= SORT_TIE_RUN_MAX && (u32)(kc[i + len] >> 32) == h) ++len;
+  if (len > SORT_TIE_RUN_MAX) { if (*too_long == 0u) atomicExch(too_long, 1u); return; }
+  for (u32 a = 1; a < len; ++a) {                          // stable insertion sort of the run by the low half of the key
+    const u64 k = kc[i + a];
+    const u32 lo = (u32)keys[(u32)k];
+    u32 b = a;
+    while (b > 0 && (u32)keys[(u32)kc[i + b - 1]] > lo) { kc[i + b] = kc[i + b - 1]; --b; }
+    kc[i + b] = k;
+  }
+}
+__global__ __launch_bounds__(256) void ssgpu_sort_extract_idx_kernel(u32* __restrict__ idx, const u64* __restrict__ kc, u64 n) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) idx[i] = (u32)kc[i];
+}
+
 // ---- payload as records ---------------------------------------------------------------------------------------------
 // Gathering P payload columns one by one costs P random 8-byte reads per row, each of which moves a whole 64-byte sector
 // (13.8 of the 25.7 ms of the 8-column sort).  With three or more gathered columns the rows are first packed into
@@ -421,14 +451,14 @@ __global__ __launch_bounds__(256) void ssgpu_sort_pack_kernel(const SortRecParam
   for (u32 j = (u32)t; j < chunks; j += 256) out[j] = reinterpret_cast<const uint4*>(tile)[j];
 }
 
-__global__ __launch_bounds__(256) void ssgpu_sort_gather_rec_kernel(const SortRecParams P, const u32* __restrict__ idx) {
+__global__ __launch_bounds__(256) void ssgpu_sort_gather_rec_kernel(const SortRecParams P, const u32* __restrict__ idx, u32 idx_stride) {
   extern __shared__ __attribute__((aligned(16))) char tile[];
   __shared__ u32 rid[256];
   const int t = threadIdx.x;
   const u64 base = (u64)blockIdx.x * 256;
   const u32 S = P.stride, cpr = S / 16;
   const u64 rows_here = P.n - base < 256 ? P.n - base : 256;
-  if ((u64)t < rows_here) rid[t] = idx[base + t];
+  if ((u64)t < rows_here) rid[t] = idx[(base + t) * idx_stride];   // stride 2: the low words of (high half << 32 | row id) keys
   __syncthreads();
   const u32 chunks = (u32)rows_here * cpr;
   for (u32 j = (u32)t; j < chunks; j += 256) {
@@ -663,8 +693,20 @@ hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s) {
   if (P.n) hipLaunchKernelGGL(ssgpu_sort_pack_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P);
   return hipGetLastError();
 }
-hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, hipStream_t s) {
-  if (P.n) hipLaunchKernelGGL(ssgpu_sort_gather_rec_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P, idx);
+hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s) {
+  if (P.n) hipLaunchKernelGGL(ssgpu_sort_gather_rec_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P, idx, idx_stride);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_compact_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_compact_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n, too_long);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_sort_extract_idx_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, idx, (const u64*)kc, (u64)n);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_unkey(void* out, const uint64_t* keys, uint32_t width, int kind, int descending, uint64_t n, hipStream_t s) {

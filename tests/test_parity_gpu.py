@@ -340,6 +340,51 @@ def test_sort_wide_keys_high_half_first(gpu_ctx, shape, payload):
         assert np.array_equal(got.column(2 + i).data, cols[2 + i].data[order])
 
 
+@pytest.mark.parametrize("shape", ["uniform", "pairs", "long_runs"])
+@pytest.mark.parametrize("kind", ["int_desc", "double", "minor_key"])
+def test_sort_wide_keys_as_one_word_per_row(gpu_ctx, shape, kind):
+    # the (high half << 32 | row id) form of the high-half-first sort (runtime.cpp: run_sort, `compact`): descending integer keys,
+    # DOUBLE keys (never read back from the sorted words) and a wide key that is the LEAST significant of two
+    rng = np.random.default_rng(33)
+    n = 150001
+    lo = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    if shape == "uniform":
+        hi = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    elif shape == "pairs":
+        hi = rng.integers(0, 1 << 32, n // 2, dtype=np.uint64)[rng.integers(0, n // 2, n)]
+    else:
+        hi = rng.integers(0, 1 << 32, 300, dtype=np.uint64)[rng.integers(0, 300, n)]
+    bits = (hi << np.uint64(32)) | lo
+    bits[::89] = bits[7]
+    payload = [rng.integers(-9, 9, n) * 0.5 for _ in range(3)]
+    rowid = np.arange(n, dtype=np.int64)
+    if kind == "double":
+        key = bits.view(np.float64).copy()
+        key[~np.isfinite(key)] = 1.5                      # NaN ordering is a separate test
+        kcol, ktype = key, ss.DOUBLE
+    else:
+        key = bits.view(np.int64)
+        kcol, ktype = key, ss.INT64
+    g = (np.arange(n) % 3).astype(np.int32)
+    schema = ss.TupleSchema([ss.Attribute("k", ktype), ss.Attribute("id", ss.INT64), ss.Attribute("g", ss.INT32)] + [ss.Attribute("p%d" % i, ss.DOUBLE) for i in range(3)])
+    view = ss.View(schema, [ss.Column(kcol), ss.Column(rowid), ss.Column(g)] + [ss.Column(x) for x in payload], n)
+    if kind == "int_desc":
+        order_spec = ss.SortOrder().add("k", ss.DESCENDING)
+        want = np.array(sorted(range(n), key=lambda i: (-int(key[i]), i)), dtype=np.int64)
+    elif kind == "double":
+        order_spec = ss.SortOrder().add("k", ss.ASCENDING)
+        want = np.argsort(key, kind="stable")
+    else:
+        order_spec = ss.SortOrder().add("g", ss.ASCENDING).add("k", ss.ASCENDING)
+        want = np.lexsort((rowid, key, g))
+    got = ss.drain(ss.Sort(order_spec, None, 0, ss.ScanView(view)).CreateCursor(gpu_ctx), 1 << 20)
+    assert np.array_equal(got.column(1).data, want)
+    assert np.array_equal(got.column(0).data.view(np.uint64), np.asarray(kcol)[want].view(np.uint64))
+    assert np.array_equal(got.column(2).data, g[want])
+    for i in range(3):
+        assert np.array_equal(got.column(3 + i).data, payload[i][want])
+
+
 @pytest.mark.parametrize("n", [0, 1, 1025, 60013])
 @pytest.mark.parametrize("nullable", [False, True])
 def test_distinct_aggregates(gpu_ctx, n, nullable):
