@@ -375,13 +375,12 @@ __global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
 // (stable insertion sort, in place, one thread per run) completes the order.  A run longer than SORT_TIE_RUN_MAX raises a
 // flag instead: the host then sorts all digits in LSD order as usual.
 #define SORT_TIE_RUN_MAX 64u
+// A thread looks at SORT_TIE_ROWS consecutive rows (two 16-byte loads and the two neighbours) and fixes the runs that START
+// among them: almost every row is a run of one, so the kernel is a streaming read of the keys.
+#define SORT_TIE_ROWS 4
 template <bool HAS_IDX>
-__global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_kernel(u64* __restrict__ keys, u32* __restrict__ idx, u64 n, u32 hi_shift, u32* __restrict__ too_long) {
-  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void sort_fix_run(u64* __restrict__ keys, u32* __restrict__ idx, u64 n, u32 hi_shift, u32* __restrict__ too_long, u64 i) {
   const u64 h = keys[i] >> hi_shift;
-  if (i > 0 && (keys[i - 1] >> hi_shift) == h) return;       // not the first row of its run
-  if (i + 1 >= n || (keys[i + 1] >> hi_shift) != h) return;  // a run of one
   u32 len = 2;
   while (i + len < n && len <= SORT_TIE_RUN_MAX && (keys[i + len] >> hi_shift) == h) ++len;
   if (len > SORT_TIE_RUN_MAX) { if (*too_long == 0u) atomicExch(too_long, 1u); return; }   // the host sorts all digits instead
@@ -390,6 +389,25 @@ __global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_kernel(u64* __restric
     u32 b = a;
     while (b > 0 && keys[i + b - 1] > k) { keys[i + b] = keys[i + b - 1]; if (HAS_IDX) idx[i + b] = idx[i + b - 1]; --b; }
     keys[i + b] = k; if (HAS_IDX) idx[i + b] = r;
+  }
+}
+template <bool HAS_IDX>
+__global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_kernel(u64* __restrict__ keys, u32* __restrict__ idx, u64 n, u32 hi_shift, u32* __restrict__ too_long) {
+  const u64 base = ((u64)blockIdx.x * 256 + threadIdx.x) * SORT_TIE_ROWS;
+  if (base >= n) return;
+  u64 h[SORT_TIE_ROWS + 2];   // high parts of rows base - 1 .. base + SORT_TIE_ROWS; have[] = the row exists (permuting a run never changes them)
+  bool have[SORT_TIE_ROWS + 2];
+#pragma unroll
+  for (int j = 0; j < SORT_TIE_ROWS + 2; ++j) {
+    const u64 r = base + (u64)j - 1;
+    have[j] = !(j == 0 && base == 0) && r < n;
+    h[j] = have[j] ? keys[r] >> hi_shift : 0ull;
+  }
+#pragma unroll
+  for (int j = 1; j <= SORT_TIE_ROWS; ++j) {
+    if (!have[j]) break;
+    const bool prev_same = have[j - 1] && h[j - 1] == h[j], next_same = have[j + 1] && h[j + 1] == h[j];
+    if (!prev_same && next_same) sort_fix_run<HAS_IDX>(keys, idx, n, hi_shift, too_long, base + (u64)j - 1);   // the first row of a run of two or more
   }
 }
 
@@ -401,12 +419,8 @@ __global__ __launch_bounds__(256) void ssgpu_sort_compact_kernel(u64* __restrict
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   if (i < n) kc[i] = (keys[i] & 0xFFFFFFFF00000000ull) | i;
 }
-__global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_compact_kernel(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n, u32* __restrict__ too_long) {
-  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void sort_fix_run_compact(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n, u32* __restrict__ too_long, u64 i) {
   const u32 h = (u32)(kc[i] >> 32);
-  if (i > 0 && (u32)(kc[i - 1] >> 32) == h) return;       // not the first row of its run
-  if (i + 1 >= n || (u32)(kc[i + 1] >> 32) != h) return;  // a run of one
   u32 len = 2;
   while (i + len < n && len <= SORT_TIE_RUN_MAX && (u32)(kc[i + len] >> 32) == h) ++len;
   if (len > SORT_TIE_RUN_MAX) { if (*too_long == 0u) atomicExch(too_long, 1u); return; }
@@ -416,6 +430,24 @@ __global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_compact_kernel(u64* _
     u32 b = a;
     while (b > 0 && (u32)keys[(u32)kc[i + b - 1]] > lo) { kc[i + b] = kc[i + b - 1]; --b; }
     kc[i + b] = k;
+  }
+}
+__global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_compact_kernel(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n, u32* __restrict__ too_long) {
+  const u64 base = ((u64)blockIdx.x * 256 + threadIdx.x) * SORT_TIE_ROWS;
+  if (base >= n) return;
+  u32 h[SORT_TIE_ROWS + 2];
+  bool have[SORT_TIE_ROWS + 2];
+#pragma unroll
+  for (int j = 0; j < SORT_TIE_ROWS + 2; ++j) {
+    const u64 r = base + (u64)j - 1;
+    have[j] = !(j == 0 && base == 0) && r < n;
+    h[j] = have[j] ? (u32)(kc[r] >> 32) : 0u;
+  }
+#pragma unroll
+  for (int j = 1; j <= SORT_TIE_ROWS; ++j) {
+    if (!have[j]) break;
+    const bool prev_same = have[j - 1] && h[j - 1] == h[j], next_same = have[j + 1] && h[j + 1] == h[j];
+    if (!prev_same && next_same) sort_fix_run_compact(kc, keys, n, too_long, base + (u64)j - 1);
   }
 }
 __global__ __launch_bounds__(256) void ssgpu_sort_extract_idx_kernel(u32* __restrict__ idx, const u64* __restrict__ kc, u64 n) {
@@ -685,8 +717,8 @@ hipError_t ssgpu_launch_sort_onesweep(const uint64_t* keys_in, const uint32_t* i
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_fix_ties(uint64_t* keys, uint32_t* idx, uint64_t n, uint32_t hi_shift, uint32_t* too_long, hipStream_t s) {
-  if (n && idx) hipLaunchKernelGGL(ssgpu_sort_fix_ties_kernel<true>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)keys, idx, (u64)n, hi_shift, too_long);
-  else if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_kernel<false>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)keys, idx, (u64)n, hi_shift, too_long);
+  if (n && idx) hipLaunchKernelGGL(ssgpu_sort_fix_ties_kernel<true>, dim3(blocks_for(n, 256 * SORT_TIE_ROWS)), dim3(256), 0, s, (u64*)keys, idx, (u64)n, hi_shift, too_long);
+  else if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_kernel<false>, dim3(blocks_for(n, 256 * SORT_TIE_ROWS)), dim3(256), 0, s, (u64*)keys, idx, (u64)n, hi_shift, too_long);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s) {
@@ -702,7 +734,7 @@ hipError_t ssgpu_launch_sort_compact(uint64_t* kc, const uint64_t* keys, uint64_
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_compact_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n, too_long);
+  if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_compact_kernel, dim3(blocks_for(n, 256 * SORT_TIE_ROWS)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n, too_long);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s) {
