@@ -371,6 +371,11 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     }                                                                          \
   } break;
 
+#ifdef SS_STOREC_NT   /* development A/B through SSGPU_RTC_FLAGS: compacted survivors written with nontemporal stores */
+#define STOREC_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define STOREC_ST(ptr, v) (*(ptr) = (v))
+#endif
 #define STOREC_OP(OPNAME, T)                                                   \
   case VM_##OPNAME: { CASE_FENCE;                                              \
     T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
@@ -378,8 +383,8 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
       Valid2 m = valid_pair_(p, tile_valid, VM_NONE, I.c);          \
       auto vv = fetch2<T>(I.a, I.a_mask, p);                             \
       auto rk = lds_load2<u32>(I.b, p);                                        \
-      if (m.x) out[rk.x] = vv.x;                                               \
-      if (m.y) out[rk.y] = vv.y;                                               \
+      if (m.x) STOREC_ST(out + rk.x, vv.x);                                    \
+      if (m.y) STOREC_ST(out + rk.y, vv.y);                                    \
     }                                                                          \
   } break;
 
