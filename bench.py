@@ -487,11 +487,18 @@ def main():
         while not job.check():               # set-up: the image capacity every rank agreed on holds every partial table
             step()
     barrier()
+    trace = [] if os.environ.get("SSGPU_BENCH_TRACE") else None    # development: host time of every step call
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if trace is not None:
+            trace.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if trace:
+        d = [(b - a) * 1e3 for a, b in zip([t0] + trace[:-1], trace)]
+        worst = sorted(range(len(d)), key=lambda i: -d[i])[:5]
+        sys.stderr.write("[bench trace] steps %d, median %.2f ms, slowest: %s\n" % (len(d), sorted(d)[len(d) // 2], ", ".join("#%d %.1f ms" % (i, d[i]) for i in worst)))
     # the per-kernel clock: the HIP events the library recorded around the stage's kernels of the TIMED
     # steps (the most recent min(K, 256) of them); without them, a dedicated loop after the timed region
     kernel_ms = [] if args.no_events_in_loop else plan.recent_kernel_ms(256)[-args.steps:]
