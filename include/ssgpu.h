@@ -298,7 +298,22 @@ void* ssgpu_ctx_copy_stream(ssgpu_ctx* ctx);
 /* Use a caller-owned stream (e.g. torch's current stream) for kernels. */
 int ssgpu_ctx_set_stream(ssgpu_ctx* ctx, void* hip_stream);
 int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
-/* Tuning knobs (0 = library default).  tile_rows must be a multiple of 512. */
+/* Tuning knobs; an unknown key is ERROR_INVALID_ARGUMENT_VALUE.  None of them changes a result.
+ *   shape of the tile VM:   tile_rows (0 = by the program's LDS need, else 512 / 1024 / 2048), lds_target_bytes, wgs_per_cu,
+ *                           grid_limit
+ *   runtime specialisation: specialize (1 = compile a plan's kernels at its first run, 0 = never, -1 = after 8 runs of a
+ *                           program of <= 24 instructions; ssgpu_plan_specialized reports what happened)
+ *   Filter:                 filter_single_pass (1 = decoupled look-back instead of count + store passes)
+ *   GroupAggregate:         group_capacity (initial table), group_local (0 = no LDS table in front of the global one),
+ *                           group_partition (0 never / 1 by run feedback / 2 always hash-partitioned), group_slab (0 never /
+ *                           1 by estimate / 2 always the one-table-per-CU form), part_n, part_wgs_per_cu, part_lds_target,
+ *                           part_agg_lds, part_rec_align
+ *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),
+ *                           sort_hi_digits (2..4, 0 = by row count), sort_compact (0 = (key, row id) pairs instead of one
+ *                           (high half | row id) word)
+ *   measurement:            profile, profile_total (HIP events around the stage kernels / the run: ssgpu_plan_counters,
+ *                           ssgpu_plan_recent_kernel_ms), debug_timing
+ *   development only (results may be WRONG): part_scatter_debug, part_agg_debug */
 int ssgpu_ctx_set_option(ssgpu_ctx* ctx, const char* key, int64_t value);
 
 /* ---- pinned host memory (BufferAllocator seam, memory.h:100-233) -------- */
