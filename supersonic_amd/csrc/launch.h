@@ -129,7 +129,8 @@ hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* id
                                      uint32_t shift, uint64_t n, const uint32_t* offsets, hipStream_t s);
 // one-sweep radix passes + record payload (sort_kernels.hip)
 hipError_t ssgpu_launch_sort_load_keys_hist(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width, int kind,
-                                            int descending, int null_pass, uint64_t n, unsigned long long* bits, uint32_t* hist8, uint32_t* base8, hipStream_t s);
+                                            int descending, int null_pass, uint64_t n, unsigned long long* bits, uint32_t* hist8, uint32_t* base8, hipStream_t s,
+                                            uint64_t* compact_out = nullptr);
 hipError_t ssgpu_launch_sort_onesweep(const uint64_t* keys_in, const uint32_t* idx_in, uint64_t* keys_out, uint32_t* idx_out, uint32_t shift, uint64_t n,
                                       const uint32_t* digit_base, unsigned long long* status, uint32_t* ticket, uint64_t epoch, uint32_t* stuck, hipStream_t s);
 hipError_t ssgpu_launch_sort_fix_ties(uint64_t* keys, uint32_t* idx, uint64_t n, uint32_t hi_shift, uint32_t* too_long, hipStream_t s);
@@ -138,7 +139,6 @@ struct SortRecField { const void* src; void* dst; unsigned int off, width; };   
 struct SortRecParams { void* recs; unsigned long long n; unsigned int stride, n_fields; SortRecField fields[SSGPU_SORT_MAX_FIELDS]; };
 hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s);
 hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s);
-hipError_t ssgpu_launch_sort_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, hipStream_t s);
 hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s);
 hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s);
 // View-file loader: one piece = one column (or NULL-mask) segment of one file chunk inside a staged slab

@@ -1413,14 +1413,14 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
   // ONE read of a key column: transformed keys, OR / AND of all keys (digits on which every key agrees are skipped) and
   // the histograms of all digits with their exclusive scans
-  auto load_key = [&](int k, int kind, int null_pass, const uint32_t* idx, uint64_t* varying) -> int {
+  auto load_key = [&](int k, int kind, int null_pass, const uint32_t* idx, uint64_t* varying, uint64_t* compact_out = nullptr) -> int {
     const SortKey& sk = st.sort_keys[k];
     const unsigned long long init[2] = {0ull, ~0ull};
     HIP_TRY(c, hipMemcpyAsync(ex.total2.p, init, 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(ex.shist.p, 0, 8 * 256 * 4, c->stream));
     HIP_TRY(c, ssgpu_launch_sort_load_keys_hist(ka, idx, in.cols[sk.col].data, in.cols[sk.col].is_null, (uint32_t)dtype_width(st.in_schema[sk.col].dtype), kind,
                                                 sk.order == SSGPU_DESCENDING, null_pass, n, ex.total2.as<unsigned long long>(), ex.shist.as<uint32_t>(),
-                                                ex.soffs.as<uint32_t>(), c->stream));
+                                                ex.soffs.as<uint32_t>(), c->stream, compact_out));
     unsigned long long bits[2];
     HIP_TRY(c, hipMemcpyAsync(bits, ex.total2.p, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1430,7 +1430,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   };
   // The first key processed (the least significant one) is loaded before the payload layout is fixed: a wide key whose
   // high half separates almost all rows is sorted as ONE word per row -- (high half << 32 | row id), see
-  // ssgpu_sort_compact_kernel -- which needs the key column inside the payload records (its low half is not in the
+  // ssgpu_sort_load_keys_hist_kernel's compact_out -- which needs the key column inside the payload records (its low half is not in the
   // sorted words) when it is also the major key.
   const int k_first = (int)st.sort_keys.size() - 1;
   bool first_loaded = false, compact = false;
@@ -1438,7 +1438,8 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   if (k_first >= 0 && n >= (1u << 16) && !keys_only && c->sort_hybrid && c->sort_compact && c->sort_records && c->sort_hi_digits == 4) {
     const SortKey& sk = st.sort_keys[k_first];
     if (dtype_width(st.in_schema[sk.col].dtype) == 8 && !(in.cols[sk.col].is_null && st.in_schema[sk.col].nullable)) {
-      rc = load_key(k_first, sort_kind_of(st.in_schema[sk.col].dtype), 0, nullptr, &first_varying); if (rc != SSGPU_OK) return rc;
+      // (the load also writes the one-word keys, into the second key buffer: cheaper than a pass of their own when they are used)
+      rc = load_key(k_first, sort_kind_of(st.in_schema[sk.col].dtype), 0, nullptr, &first_varying, kb); if (rc != SSGPU_OK) return rc;
       first_loaded = true;
       compact = (first_varying & 0xFFFFFFFFull) != 0;
       for (uint32_t pass = 4; pass < 8; ++pass) compact = compact && ((first_varying >> (pass * 8)) & 0xFFull) != 0;
@@ -1509,8 +1510,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     if (compact && k == k_first) {
       // one word per row: the four high digits with the keys-only kernel, then the tie runs by the low halves
       HIP_TRY(c, ex.skeys_c.ensure(std::max<uint64_t>(n, 1) * 8));
-      uint64_t* kc = kb; uint64_t* kd = ex.skeys_c.as<uint64_t>();
-      HIP_TRY(c, ssgpu_launch_sort_compact(kc, ka, n, c->stream));
+      uint64_t* kc = kb; uint64_t* kd = ex.skeys_c.as<uint64_t>();   // kb: written by the load above
       for (uint32_t digit = 4; digit < 8; ++digit) {
         if (n_pass >= 62) { c->err = "Sort: too many radix passes in one stage"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
         HIP_TRY(c, ssgpu_launch_sort_onesweep(kc, nullptr, kd, nullptr, digit * 8, n, ex.soffs.as<uint32_t>() + digit * 256, ex.sstatus.as<unsigned long long>(),

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(SORT_THREADS) void ssgpu_sort_scatter_kernel(
 // done, whatever the dispatch order: the look-back cannot deadlock.
 __global__ __launch_bounds__(256) void ssgpu_sort_load_keys_hist_kernel(u64* __restrict__ keys, const u32* __restrict__ idx, const void* __restrict__ col,
                                                  const u8* __restrict__ nulls, u32 width, int kind, int descending,
-                                                 int null_pass, u64 n, unsigned long long* __restrict__ bits, u32* __restrict__ hist8) {
+                                                 int null_pass, u64 n, unsigned long long* __restrict__ bits, u32* __restrict__ hist8,
+                                                 u64* __restrict__ compact_out) {
+  // compact_out (only with idx == NULL): also the one-word form (high half << 32 | row) of every key ("wide keys" below)
   __shared__ u32 h[8][256];
   __shared__ u64 red[2][4];
   const int t = threadIdx.x;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void ssgpu_sort_load_keys_hist_kernel(u64* __r
         if (nulls && nulls[row]) k = 0;
       }
       keys[i] = k;
+      if (compact_out) compact_out[i] = (k & 0xFFFFFFFF00000000ull) | i;
       vor |= k; vand &= k;
 #pragma unroll
       for (int d = 0; d < 8; ++d) atomicAdd(&h[d][(k >> (8 * d)) & 0xFF], 1u);
@@ -415,10 +418,7 @@ __global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_kernel(u64* __restric
 // weight: (high half << 32 | row id) is one 64-bit word per row instead of a key word plus a row-id word, so the four
 // passes run as the keys-only kernel (8 bytes per row in, 8 out, instead of 12 and 12).  The low halves are only needed
 // for the tie runs, which fetch them from the untouched key array by row id.
-__global__ __launch_bounds__(256) void ssgpu_sort_compact_kernel(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n) {
-  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) kc[i] = (keys[i] & 0xFFFFFFFF00000000ull) | i;
-}
+// (ssgpu_sort_load_keys_hist_kernel writes the one-word keys next to the full ones: compact_out.)
 __device__ __forceinline__ void sort_fix_run_compact(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n, u32* __restrict__ too_long, u64 i) {
   const u32 h = (u32)(kc[i] >> 32);
   u32 len = 2;
@@ -696,10 +696,11 @@ hipError_t ssgpu_launch_sort_scatter(const uint64_t* keys_in, const uint32_t* id
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_load_keys_hist(uint64_t* keys, const uint32_t* idx, const void* col, const uint8_t* nulls, uint32_t width, int kind,
-                                            int descending, int null_pass, uint64_t n, unsigned long long* bits, uint32_t* hist8, uint32_t* base8, hipStream_t s) {
+                                            int descending, int null_pass, uint64_t n, unsigned long long* bits, uint32_t* hist8, uint32_t* base8, hipStream_t s,
+                                            uint64_t* compact_out) {
   if (!n) return hipSuccess;
   const int grid = (int)std::min<uint64_t>(blocks_for(n, 256 * LOAD_KEYS_PER_THREAD), 2048);
-  hipLaunchKernelGGL(ssgpu_sort_load_keys_hist_kernel, dim3(grid), dim3(256), 0, s, (u64*)keys, idx, col, nulls, width, kind, descending, null_pass, (u64)n, bits, hist8);
+  hipLaunchKernelGGL(ssgpu_sort_load_keys_hist_kernel, dim3(grid), dim3(256), 0, s, (u64*)keys, idx, col, nulls, width, kind, descending, null_pass, (u64)n, bits, hist8, idx ? nullptr : (u64*)compact_out);
   hipLaunchKernelGGL(ssgpu_sort_scan_hist8_kernel, dim3(8), dim3(256), 0, s, (const u32*)hist8, base8);
   return hipGetLastError();
 }
@@ -727,10 +728,6 @@ hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s) {
 }
 hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s) {
   if (P.n) hipLaunchKernelGGL(ssgpu_sort_gather_rec_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P, idx, idx_stride);
-  return hipGetLastError();
-}
-hipError_t ssgpu_launch_sort_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(ssgpu_sort_compact_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s) {
