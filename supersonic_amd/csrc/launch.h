@@ -102,6 +102,9 @@ int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K);
 void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, bool math, const uint32_t* staged_width, const uint32_t* staged_lds_off,
                            int n_staged, std::string* why);
 hipError_t ssgpu_launch_pipeline_rtc(void* fn, const VmParams& P, int grid, hipStream_t stream);
+void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
+                                    unsigned int lds_bytes, std::string* why);
+hipError_t ssgpu_launch_part_agg_rtc(void* fn, const PartAggParams& P, hipStream_t stream);
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,

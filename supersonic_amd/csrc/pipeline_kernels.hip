@@ -501,6 +501,7 @@ __device__ __forceinline__ double vm_math1(u32 fn, double a) {
   }
 }
 
+#ifndef SSGPU_RTC_PART   // (the runtime compilation of the partition-aggregation kernel, below, leaves the pipeline kernel out)
 // MATH = true adds the libm handlers (MATH1_F64 / MATH2_F64).  They live in their own instantiation so that
 // the kernel every other program runs is not touched by their code size and register demand.
 template <int K, bool MATH>
@@ -728,8 +729,9 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     for (int w = 0; w < VM_WAVES; ++w)
       P.wg_partials[((size_t)blockIdx.x * P.n_slots + s) * VM_WAVES + w] = *acc_rec(P, (u32)s, w);
 }
+#endif  // SSGPU_RTC_PART
 
-#ifndef __HIPCC_RTC__   // runtime compilation (rtc.cpp) specialises the pipeline kernel only
+#ifndef __HIPCC_RTC__   // runtime compilation (rtc.cpp) specialises the pipeline kernel and, further down, ssgpu_part_agg_kernel
 // ---------------------------------------------------------------------------
 // finish kernel: combine [grid][n_slots][4 waves] partial records per slot, in
 // (workgroup, wave) order, by the slot's rule.  One thread per slot.
@@ -968,7 +970,9 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
   }
 }
 
+#endif  // __HIPCC_RTC__
 
+#if !defined(__HIPCC_RTC__) || defined(SSGPU_RTC_PART)
 // ---------------------------------------------------------------------------
 // partitioned GroupAggregate, phase 2 (see PartAggParams in launch.h): one workgroup per hash partition
 // reads the partition's records (n_segs segments, one per workgroup of the scatter pass), aggregates them
@@ -979,6 +983,29 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
 // DOUBLE sums are compensated (the returning atomic gives the exact rounding error of every add).
 // The one key whose packed value equals the EMPTY sentinel lives in the reserved table entry C.
 // ---------------------------------------------------------------------------
+// Specialised by runtime compilation (rtc.cpp: ssgpu_rtc_specialize_part_agg, -DSSGPU_RTC_PART): the aggregates'
+// descriptors, the record and accumulator widths and the LDS size are constants of rtc_part.h and the loop over the
+// aggregates is unrolled, so every field offset, opcode switch and record-word select below folds to the one instruction it
+// stands for -- the generic kernel spends ~50 vector instructions per aggregate and wave on that decoding.
+#ifdef SSGPU_RTC_PART
+#include "rtc_part.h"   // kPartNAggs, kPartDesc[], kPartW, kPartNg, kPartAnyCnt, kPartLdsBytes
+#define PART_NG(P) kPartNg
+#define PART_W(P) kPartW
+#define PART_ANY_CNT(P) (kPartAnyCnt != 0u)
+#define PART_NAGGS(P) kPartNAggs
+#define PART_AGG_LOOP _Pragma("unroll") for (u32 s = 0; s < kPartNAggs; ++s)
+#define PART_DESC(s) kPartDesc[s]
+#else
+#define PART_NG(P) (P).n_gaggs
+#define PART_W(P) (P).rec_words
+#define PART_ANY_CNT(P) ((P).any_cnt != 0u)
+#define PART_NAGGS(P) (P).n_aggs
+#define PART_AGG_LOOP for (u32 s = 0; s < n_aggs; ++s)
+#define PART_DESC(s) readlane64(mydesc, (int)(s))
+#endif
+#ifndef FKEY   /* (vm_body.inc defines the same for the pipeline kernel's GAGG handlers) */
+#define FKEY(d) ({ u64 b_ = d2u((double)(d)); (b_ & 0x8000000000000000ull) ? ~b_ : (b_ | 0x8000000000000000ull); })
+#endif
 #define PART_ROWS 2   /* records per lane per step */
 #define LDS_AS __attribute__((address_space(3)))
 template <int MAXW> struct RecVec { typedef u64 type __attribute__((ext_vector_type(MAXW))); };
@@ -1026,7 +1053,8 @@ template <int MAXW>
 __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_part_agg_kernel(const PartAggParams P) {
   typedef typename RecVec<MAXW>::type Rec;
   const u32 t = threadIdx.x, part = blockIdx.x;
-  const u32 C = P.local_capacity, ng = P.n_gaggs, W = P.rec_words;
+  const u32 C = P.local_capacity, ng = PART_NG(P), W = PART_W(P);
+  const bool any_cnt = PART_ANY_CNT(P);
   // slab mode: this workgroup's segments are a run of the single partition's segments
   const u32 seg0 = P.slab_segs ? part * P.slab_segs : 0u;
   const u32 G = P.slab_segs ? (seg0 < P.n_segs ? (P.n_segs - seg0 < P.slab_segs ? P.n_segs - seg0 : P.slab_segs) : 0u) : P.n_segs;
@@ -1035,13 +1063,19 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   // atomic (measured: 5x slower)
   const u32 st = ng | 1u;
   // LDS carve-up (C + 1 table entries: entry C belongs to the EMPTY-valued key)
+#ifdef SSGPU_RTC_PART
+  // a kernel loaded from a module cannot opt into more than 64 KiB of DYNAMIC LDS; its size is known here: static
+  __shared__ __attribute__((aligned(16))) char part_lds[kPartLdsBytes];
+  LDS_AS u64* const lkeys = (LDS_AS u64*)(LDS_AS char*)part_lds;
+#else
   LDS_AS u64* const lkeys = (LDS_AS u64*)0u;
+#endif
   LDS_AS u64* const lacc = lkeys + (C + 1u);
   LDS_AS u32* const lcnt = (LDS_AS u32*)(lacc + (size_t)(C + 1u) * st);
-  LDS_AS u32* const segoff = lcnt + (P.any_cnt ? (C + 1u) * st : 0u);   // [G + 1] first record of every segment in the flat order
+  LDS_AS u32* const segoff = lcnt + (any_cnt ? (C + 1u) * st : 0u);   // [G + 1] first record of every segment in the flat order
   LDS_AS u32* const wsum = segoff + G + 1u;                              // [16] scan scratch
   for (u32 e = t; e <= C; e += SSGPU_PART_THREADS) lkeys[e] = VM_KEY_EMPTY;
-  for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (P.any_cnt) lcnt[i] = 0u; }
+  for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (any_cnt) lcnt[i] = 0u; }
   u32 total = 0;
   {
     const u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
@@ -1052,8 +1086,9 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   __syncthreads();
   const u64* const recs = P.recs + (P.slab_segs ? (u64)seg0 : (u64)SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap * W;
   const u64 seg_step = P.slab_segs ? (u64)P.seg_cap : (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
-  const u32 seg_cap = P.seg_cap, n_aggs = P.n_aggs;
+  const u32 seg_cap = P.seg_cap, n_aggs = PART_NAGGS(P);
   const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
+  (void)mydesc; (void)n_aggs; (void)seg_cap;
   u32 seg = 0;
   // (fetching step i + 1's records while step i is aggregated -- one record per lane per step, two sets in registers to stay
   // under 64 VGPRs -- was tried: 2.95 ms instead of 1.85 ms for config #3; two records per lane and no prefetch it stays)
@@ -1106,10 +1141,10 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
       for (int j = 0; j < PART_ROWS; ++j) if (live[j]) LDS_ADD(lacc + li[j], rec[j][1] ^ rec[j][(MAXW - 1) & 4]);
       continue;
     }
-    for (u32 s = 0; s < n_aggs; ++s) {
+    PART_AGG_LOOP {
       // the aggregate's descriptor comes out of a register (lane s of `mydesc`): a scalar memory load here would
       // share its wait counter with the LDS atomics in flight and drain them once per aggregate
-      const u64 d = readlane64(mydesc, (int)s);
+      const u64 d = PART_DESC(s);
       const u32 op = (u32)(d & 0xFFFFu), word = (u32)(d >> 16) & 0xFFu, voff = (u32)(d >> 24) & 0xFFu, vw = (u32)(d >> 32) & 0xFFu,
                 noff = (u32)(d >> 40) & 0xFFu;
       const bool has_cnt = ((d >> 48) & 1ull) != 0;
@@ -1193,6 +1228,9 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   }
 }
 
+#endif  // !__HIPCC_RTC__ || SSGPU_RTC_PART
+
+#ifndef __HIPCC_RTC__
 // ---------------------------------------------------------------------------
 // HashJoin index build (see JoinBuildParams in launch.h)
 // ---------------------------------------------------------------------------

@@ -143,6 +143,7 @@ struct StageExec {
   ProgramLayout lay_pscatter{};
   int n_instr_pscatter = 0;
   void* rtc_fn_pscatter = nullptr; bool rtc_tried_pscatter = false; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
+  void* rtc_fn_part = nullptr; uint32_t rtc_part_lds = 0;   // ssgpu_part_agg_kernel specialised for this stage's aggregates and an LDS size (rtc.cpp)
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jkeys_hi, jrows, jmisc;
@@ -1210,7 +1211,15 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       A.desc[j] = (uint64_t)(uint16_t)a.op | ((uint64_t)(uint8_t)a.word << 16) | ((uint64_t)(uint8_t)(a.val_off < 0 ? 0xFF : a.val_off) << 24) |
                   ((uint64_t)(uint8_t)a.val_width << 32) | ((uint64_t)(uint8_t)(a.null_off < 0 ? 0xFF : a.null_off) << 40) | ((uint64_t)(a.has_cnt ? 1 : 0) << 48);
     }
-    HIP_TRY(c, ssgpu_launch_part_agg(A, fixed + C * entry, c->stream));
+    const uint32_t agg_lds = fixed + C * entry;
+    if (ex.rtc_part_lds != agg_lds && !A.debug && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS))) {
+      ex.rtc_part_lds = agg_lds;   // one attempt per LDS size (hash partitions and the slab form differ in it)
+      std::string why;
+      ex.rtc_fn_part = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why);
+      if (!ex.rtc_fn_part && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
+    }
+    if (ex.rtc_fn_part && ex.rtc_part_lds == agg_lds && !A.debug) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_fn_part, A, c->stream));
+    else HIP_TRY(c, ssgpu_launch_part_agg(A, agg_lds, c->stream));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     p->counters.n_launches += 6;
     p->counters.tile_rows = Ps.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)Ps.lds_bytes;
@@ -1837,6 +1846,7 @@ int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
   for (auto& ex : p->exec) {
     if (ex.rtc_fn) ++n;
     if (ex.rtc_fn_pscatter) ++n;
+    if (ex.rtc_fn_part) ++n;
     else if (!ex.rtc_why.empty()) p->ctx->err = "stage runs on the interpreter: " + ex.rtc_why;
   }
   return n;
