@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/prof_cfg
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for q in group2 sort sort_key filter_mat group_small group_tiny join; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$q -o $q -- python $REPO/tools/perf_sweep.py --queries $q --tiles 0 --reps 7 > $OUT/$q.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$q -o $q -- python $REPO/tools/perf_sweep.py --queries $q --tiles 0 --reps 7 --opts specialize=1 > $OUT/$q.log 2>&1
   f=$(find $OUT/$q -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] || { echo "$q: no kernel stats"; continue; }
   python - "$f" "$OUT/${q}_kernel_stats.csv" <<'PY'
