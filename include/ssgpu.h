@@ -399,8 +399,10 @@ int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
 /* Context option "specialize" = 1 (set before the plan first runs): every stage's main program is compiled once more at
  * run time (hiprtc) into a kernel specialised for it -- the same handlers with the opcode dispatch and operand offsets
  * folded away -- and cached by program; a stage whose specialisation is not possible keeps the interpreting kernel
- * (results are identical either way).  Returns how many stages of the plan run specialised kernels (0 before the
- * first run); when a stage asked for it and did not get it, ssgpu_last_error() says why. */
+ * (results are identical either way).  A partitioned GroupAggregate has up to three such kernels: the stage's program,
+ * its partition-scatter program and the partition-aggregation kernel (specialised for the aggregates' descriptors).
+ * Returns how many specialised kernels the plan runs (0 before the first run); when a stage asked for one and did not
+ * get it, ssgpu_last_error() says why. */
 int32_t ssgpu_plan_specialized(const ssgpu_plan* plan);
 int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
 
