@@ -1270,6 +1270,24 @@ def test_specialized_materialising_and_group_stages(specialized_ctx, n):
     _run_specialized(group_query(make_view(n, nullable=True), True), specialized_ctx, ignore_order=True)
 
 
+@pytest.mark.parametrize("slab", [0, 2])
+@pytest.mark.parametrize("n", [1025, 100003])
+def test_specialized_partition_aggregation_kernel(n, slab):
+    # the partitioned GroupAggregate's aggregation kernel compiled for the stage's aggregates (rtc.cpp:
+    # ssgpu_rtc_specialize_part_agg; static LDS of 80 KiB for hash partitions, 159 KiB for the slab form)
+    ctx = ss.Context(0)
+    for k, v in (("specialize", 1), ("group_partition", 2), ("group_slab", slab)):
+        ctx.set_option(k, v)
+    for nullable, keys in ((False, ("k1", "k2")), (True, ("k1",))):
+        op = group_query(make_view(n, nullable=nullable), True, keys)
+        run_both(op, ctx, ignore_order=True)
+        plan = ss.Plan(op, ctx)
+        plan.run()
+        assert plan.specialized() >= 2, ctx.last_error()      # the scatter program and the aggregation kernel
+    fl = ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), None, ss.ScanView(make_view(n, nullable=True)))
+    run_both(fl, ctx, ignore_order=True)
+
+
 def test_specialized_kernels_are_cached_and_report_errors(specialized_ctx):
     import time
     view = make_view(100003)
