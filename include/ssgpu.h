@@ -98,7 +98,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 4
+#define SSGPU_ABI_VERSION 5
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -301,8 +301,8 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
 /* Tuning knobs; an unknown key is ERROR_INVALID_ARGUMENT_VALUE.  None of them changes a result.
  *   shape of the tile VM:   tile_rows (0 = by the program's LDS need, else 512 / 1024 / 2048), lds_target_bytes, wgs_per_cu,
  *                           grid_limit
- *   runtime specialisation: specialize (1 = compile a plan's kernels at its first run, 0 = never, -1 = after 8 runs of a
- *                           program of <= 24 instructions; ssgpu_plan_specialized reports what happened)
+ *   runtime specialisation: specialize (1 = plans created afterwards run kernels compiled for them, see ssgpu_plan_specialize;
+ *                           0 = only plans that call ssgpu_plan_specialize; default 0)
  *   Filter:                 filter_single_pass (1 = decoupled look-back instead of count + store passes)
  *   GroupAggregate:         group_capacity (initial table), group_local (0 = no LDS table in front of the global one),
  *                           group_partition (0 never / 1 by run feedback / 2 always hash-partitioned), group_slab (0 never /
@@ -396,14 +396,34 @@ int ssgpu_plan_program(const ssgpu_plan* plan, int32_t stage, const void** instr
  * of the reference does when its Operation was given a MemoryLimit allocator (operation.h:66-76,
  * aggregate_groups.cc:372-402).  bytes < 0 = unlimited (default). */
 int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
-/* Context option "specialize" = 1 (set before the plan first runs): every stage's main program is compiled once more at
- * run time (hiprtc) into a kernel specialised for it -- the same handlers with the opcode dispatch and operand offsets
- * folded away -- and cached by program; a stage whose specialisation is not possible keeps the interpreting kernel
- * (results are identical either way).  A partitioned GroupAggregate has up to three such kernels: the stage's program,
- * its partition-scatter program and the partition-aggregation kernel (specialised for the aggregates' descriptors).
- * Returns how many specialised kernels the plan runs (0 before the first run); when a stage asked for one and did not
- * get it, ssgpu_last_error() says why. */
+/* Per-plan kernel specialisation by runtime compilation (hiprtc).  ssgpu_plan_specialize(plan) -- or the context option
+ * "specialize" = 1 at the time the plan is created -- makes the plan run kernels compiled for it: the same handlers as
+ * the interpreting kernel with the opcode dispatch and operand offsets folded away, cached by program and shared by all
+ * plans with the same program; results are identical either way.  WHEN code is compiled is explicit: inside
+ * ssgpu_plan_specialize for every stage whose launch shape is known without a run (scalar aggregates, materialising
+ * stages, clustered aggregation), otherwise at the first launch of a kernel shape (the plan's first run; a partitioned
+ * GroupAggregate has up to three kernels -- the stage's program, its partition-scatter program and the
+ * partition-aggregation kernel -- whose shape its first runs settle).  A plan that never asked never compiles: no run
+ * of it blocks on a compiler, and no code is loaded behind its back.  A compilation (~2 s + 0.4 s per VM instruction)
+ * does not hold any library lock: other plans run and compile meanwhile; two plans wanting the same kernel share one
+ * compilation.  The modules are reference-counted: ssgpu_plan_destroy drops the plan's references and the code object
+ * of a kernel no other plan uses is unloaded (ssgpu_memory_stats shows modules and code bytes currently loaded).
+ * A stage whose specialisation is not possible (no libhiprtc on the host, a compilation failure) keeps the
+ * interpreting kernel -- still the HIP path -- and ssgpu_plan_specialize_reason says why ("" if nothing was refused).
+ * ssgpu_plan_specialized: how many specialised kernels the plan currently holds. */
+int ssgpu_plan_specialize(ssgpu_plan* plan);
 int32_t ssgpu_plan_specialized(const ssgpu_plan* plan);
+const char* ssgpu_plan_specialize_reason(const ssgpu_plan* plan);
+/* What the library holds in this process, right now: device and pinned-host bytes of every live buffer (blocks, plans'
+ * scratch / tables / outputs, results), live plans / blocks / HIP events, and the specialised kernels' modules.  The
+ * per-process measure behind "repeated runs of a plan do not grow memory" (the reference watches its allocator the
+ * same way, testing/expression_test_helper.cc:213-245). */
+typedef struct ssgpu_memory_stats_t {
+  int64_t device_bytes, pinned_bytes;
+  int64_t live_plans, live_blocks, events;
+  int64_t rtc_modules, rtc_code_bytes, rtc_compilations;   /* loaded now / loaded now / hiprtc compilations so far */
+} ssgpu_memory_stats_t;
+int ssgpu_memory_stats(ssgpu_memory_stats_t* out);
 int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
 
 /* ---- standalone expression seam --------------------------------------------------------------------------

@@ -72,6 +72,11 @@ class Op(C.Structure):
                 ("proj2_first", C.c_int32), ("proj2_n", C.c_int32), ("proj3_first", C.c_int32), ("proj3_n", C.c_int32)]
 
 
+class MemoryStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("device_bytes", "pinned_bytes", "live_plans", "live_blocks", "events",
+                                          "rtc_modules", "rtc_code_bytes", "rtc_compilations")]
+
+
 class PlanDesc(C.Structure):
     _fields_ = [("input_schema", C.POINTER(Attr)), ("n_attrs", C.c_int32),
                 ("ops", C.POINTER(Op)), ("n_ops", C.c_int32),
@@ -119,6 +124,9 @@ SYMBOLS = [
     ("ssgpu_dict_decode", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int32)]),
     ("ssgpu_plan_set_memory_limit", C.c_int, [P, C.c_int64]),
     ("ssgpu_plan_specialized", C.c_int32, [P]),
+    ("ssgpu_plan_specialize", C.c_int, [P]),
+    ("ssgpu_plan_specialize_reason", C.c_char_p, [P]),
+    ("ssgpu_memory_stats", C.c_int, [C.POINTER(MemoryStats)]),
     ("ssgpu_plan_memory_in_use", C.c_int64, [P]),
     ("ssgpu_expr_bind", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.POINTER(Expr), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_expr_row_capacity", C.c_int64, [P]),

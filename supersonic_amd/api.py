@@ -189,6 +189,16 @@ class Context(object):
             pass
 
 
+def memory_stats():
+    """ssgpu_memory_stats: what the library holds in this process right now (device / pinned bytes, live plans, blocks and
+    events, loaded specialised-kernel modules), as a dict."""
+    st = L.MemoryStats()
+    rc = L.load().ssgpu_memory_stats(C.byref(st))
+    if rc != L.OK:
+        raise SupersonicException(rc, "ssgpu_memory_stats failed")
+    return {n: getattr(st, n) for n, _t in L.MemoryStats._fields_}
+
+
 # ---------------------------------------------------------------------------- schema
 class Attribute(object):
     def __init__(self, name, data_type, nullability=NOT_NULLABLE):
@@ -1065,8 +1075,17 @@ class Plan(object):
         return self.lib.ssgpu_plan_memory_in_use(self.handle)
 
     def specialized(self):
-        """Stages of this plan that run kernels specialised by runtime compilation (context option "specialize")."""
+        """Specialised kernels (runtime compilation, csrc/rtc.cpp) this plan currently holds."""
         return self.lib.ssgpu_plan_specialized(self.handle)
+
+    def specialize(self):
+        """ssgpu_plan_specialize: run kernels compiled for this plan; what can be compiled without a run is compiled now."""
+        self.ctx.check(self.lib.ssgpu_plan_specialize(self.handle))
+        return self
+
+    def specialize_reason(self):
+        """Why a stage that asked for a specialised kernel did not get one ("" if none was refused)."""
+        return (self.lib.ssgpu_plan_specialize_reason(self.handle) or b"").decode()
 
     def program(self, stage=0):
         """Raw VM instructions of a stage (debug hook used by tests/vm_emulator.py)."""

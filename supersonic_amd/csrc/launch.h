@@ -98,13 +98,19 @@ hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t
 int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K);
 #ifndef __HIPCC_RTC__
 #include <string>
-// rtc.cpp: the pipeline kernel specialised for one finalised program (NULL + *why: keep the interpreter)
+// rtc.cpp: kernels specialised by runtime compilation.  The specialize calls return a HANDLE to a cached, reference-counted
+// kernel (NULL + *why: keep the interpreter / the generic kernel); ssgpu_rtc_release drops the reference and the module
+// is unloaded with the last one.  static_lds > 0: the pipeline kernel's LDS is a static array of that size (launches of
+// more than 64 KiB of LDS, which a module-loaded kernel cannot get dynamically).
 void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, bool math, const uint32_t* staged_width, const uint32_t* staged_lds_off,
-                           int n_staged, std::string* why);
-hipError_t ssgpu_launch_pipeline_rtc(void* fn, const VmParams& P, int grid, hipStream_t stream);
+                           int n_staged, uint32_t static_lds, std::string* why);
+hipError_t ssgpu_launch_pipeline_rtc(void* handle, const VmParams& P, int grid, bool static_lds, hipStream_t stream);
 void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
                                     unsigned int lds_bytes, std::string* why);
-hipError_t ssgpu_launch_part_agg_rtc(void* fn, const PartAggParams& P, hipStream_t stream);
+hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
+void* ssgpu_rtc_function(void* handle);
+void ssgpu_rtc_release(void* handle);
+void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations);
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,

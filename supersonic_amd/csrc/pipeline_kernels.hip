@@ -506,6 +506,13 @@ __device__ __forceinline__ double vm_math1(u32 fn, double a) {
 // the kernel every other program runs is not touched by their code size and register demand.
 template <int K, bool MATH>
 __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline_kernel(const VmParams P) {
+#ifdef SSGPU_RTC_STATIC_LDS
+  // A module-loaded kernel cannot ask for more than 64 KiB of dynamic LDS: the specialised build of a launch that needs
+  // more declares its LDS statically (rtc.cpp).  It is the kernel's only LDS object, so it starts at LDS address 0 and
+  // every access below still goes through plain integer LDS addresses; the asm keeps the otherwise unreferenced array.
+  __shared__ __attribute__((aligned(16))) char rtc_static_lds[SSGPU_RTC_STATIC_LDS];
+  asm volatile("" ::"v"((u32)(size_t)(__attribute__((address_space(3))) char*)rtc_static_lds));
+#endif
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;

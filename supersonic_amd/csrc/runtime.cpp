@@ -59,9 +59,10 @@ struct ssgpu_ctx {
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
   int64_t part_rec_align = 0;    // partition records padded to a multiple of this many bytes (plans created after the option is set)
-  int64_t specialize = -1;       // stages' main programs as kernels specialised by runtime compilation (rtc.cpp): 1 = from the
-                                 // first run, 0 = never, -1 = once a plan has run SPECIALIZE_AFTER_RUNS times (a plan that keeps
-                                 // running is worth the ~3 s compilation; a one-shot plan is not)
+  int64_t specialize = 0;        // plans created on this context run kernels specialised for them by runtime compilation (rtc.cpp):
+                                 // 1 = yes, compiled when a kernel shape is first launched (the first run; a later run only if run
+                                 // feedback moves a GroupAggregate to another execution shape); 0 (and the legacy -1) = only plans
+                                 // that ask for it with ssgpu_plan_specialize.  Nothing is ever compiled at a hidden run count.
   bool filter_single_pass = false;   // materialising Filter: one pass with decoupled look-back instead of count pass + scan + store pass (plans created after the option is set)
 };
 
@@ -72,12 +73,16 @@ struct MemQuota { int64_t limit = -1; int64_t used = 0; };
 static thread_local MemQuota* g_quota = nullptr;
 struct QuotaScope { MemQuota* saved; explicit QuotaScope(MemQuota* q) : saved(g_quota) { g_quota = q; } ~QuotaScope() { g_quota = saved; } };
 
+// process-wide accounting of what the library holds (ssgpu_memory_stats): the per-process measure behind the
+// "repeated runs do not grow memory" contract (expression_test_helper.cc:213-245 watches its allocator the same way)
+static std::atomic<long long> g_dev_bytes{0}, g_pinned_bytes{0}, g_live_plans{0}, g_live_blocks{0}, g_events{0};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   MemQuota* q = nullptr;
   ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); if (q) q->used -= (int64_t)cap; } p = nullptr; cap = 0; q = nullptr; }
+  void release() { if (p) { (void)hipFree(p); g_dev_bytes.fetch_sub((long long)cap); if (q) q->used -= (int64_t)cap; } p = nullptr; cap = 0; q = nullptr; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
     size_t want = std::max<size_t>(bytes, 256);
@@ -85,7 +90,7 @@ struct DevBuf {
     if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)cap : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
     release();
     hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) { cap = want; q = Q; if (q) q->used += (int64_t)want; } else p = nullptr;
+    if (e == hipSuccess) { cap = want; q = Q; g_dev_bytes.fetch_add((long long)want); if (q) q->used += (int64_t)want; } else p = nullptr;
     return e;
   }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -94,13 +99,14 @@ struct DevBuf {
 struct PinnedBuf {
   void* p = nullptr;
   size_t cap = 0;
-  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  ~PinnedBuf() { drop(); }
+  void drop() { if (p) { (void)hipHostFree(p); g_pinned_bytes.fetch_sub((long long)cap); } p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    drop();
     size_t want = std::max<size_t>(bytes, 256);
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want; else p = nullptr;
+    if (e == hipSuccess) { cap = want; g_pinned_bytes.fetch_add((long long)want); } else p = nullptr;
     return e;
   }
 };
@@ -110,8 +116,13 @@ struct OutCol { DevBuf data, nulls; bool nullable = false; uint32_t width = 8; }
 struct StageExec {
   // device copies of the programs, finalised for tile_rows
   DevBuf prog_main, prog_count;
-  void* rtc_fn = nullptr;       // the main program's specialised kernel (rtc.cpp), NULL = interpreter
-  bool rtc_tried = false;
+  // A kernel specialised by runtime compilation (rtc.cpp): a reference to a cached module function.  `static_lds` is the
+  // LDS size it was compiled for when that exceeds what a module-loaded kernel may ask for dynamically (0 = dynamic).
+  struct RtcSlot {
+    void* h = nullptr; bool tried = false; uint32_t static_lds = 0;
+    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; }
+  };
+  RtcSlot rtc_main;             // the main program's specialised kernel, h == NULL: interpreter
   std::vector<VmInstr> host_prog_main;   // the finalised main program (what rtc.cpp compiles)
   std::string rtc_why;          // why not, when specialisation was asked for and did not happen
   ProgramLayout lay{};
@@ -142,8 +153,8 @@ struct StageExec {
   DevBuf prog_pscatter, part_hist, part_recs;
   ProgramLayout lay_pscatter{};
   int n_instr_pscatter = 0;
-  void* rtc_fn_pscatter = nullptr; bool rtc_tried_pscatter = false; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
-  void* rtc_fn_part = nullptr; uint32_t rtc_part_lds = 0;   // ssgpu_part_agg_kernel specialised for this stage's aggregates and an LDS size (rtc.cpp)
+  RtcSlot rtc_pscatter; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
+  RtcSlot rtc_part;             // ssgpu_part_agg_kernel specialised for this stage's aggregates and an LDS size (static_lds)
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jkeys_hi, jrows, jmisc;
@@ -183,7 +194,8 @@ struct ssgpu_plan {
   int64_t aux_rows = -1;
   std::string describe, describe_full;
   std::atomic<int> interrupted{0};
-  int64_t n_runs = 0;           // runs started (the auto mode of the runtime specialisation counts them)
+  int64_t n_runs = 0;           // runs started
+  bool specialize = false;      // this plan's kernels are specialised by runtime compilation (ctx option at creation, or ssgpu_plan_specialize)
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
   // the (dom0, dom1) pairs of the most recent profiled runs: ev_dom0 / ev_dom1 alias the current pair, so
   // a caller can time many asynchronous runs and read every kernel duration afterwards, without a sync in between
@@ -322,10 +334,11 @@ int ssgpu_block_create(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n, int64_
     if (a.nullable && b->nulls[i].ensure((size_t)cap) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
   }
   c->refs.fetch_add(1);
+  g_live_blocks.fetch_add(1);
   *out = b;
   return SSGPU_OK;
 }
-void ssgpu_block_destroy(ssgpu_block* b) { if (!b) return; ssgpu_ctx* c = b->ctx; delete b; if (c) ctx_release(c); }
+void ssgpu_block_destroy(ssgpu_block* b) { if (!b) return; ssgpu_ctx* c = b->ctx; delete b; g_live_blocks.fetch_sub(1); if (c) ctx_release(c); }
 
 // ---- View file format: cursor/infrastructure/file_io.cc ---------------------------------------
 static const int64_t kFileChunkRows = 8192;   // kMaxChunkRowCount, file_io.cc:70
@@ -512,10 +525,12 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   p->exec.resize(p->stages.size());
   for (auto& a : p->result_schema) p->attr_names.push_back(a.name);
   p->result.plan = p;
+  p->specialize = c->specialize > 0;
   if (c->device >= 0) {
-    (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end);
+    (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end); g_events.fetch_add(2);
   }
   c->refs.fetch_add(1);
+  g_live_plans.fetch_add(1);
   *out = p;
   return SSGPU_OK;
 }
@@ -524,14 +539,18 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   if (!p) return;
   if (p->ctx && p->ctx->device >= 0) {
     (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
-    if (p->ev_end) (void)hipEventDestroy(p->ev_end);
+    if (p->ev_begin) { (void)hipEventDestroy(p->ev_begin); g_events.fetch_sub(1); }
+    if (p->ev_end) { (void)hipEventDestroy(p->ev_end); g_events.fetch_sub(1); }
     for (int i = 0; i < ssgpu_plan::kEventRing; ++i) {
-      if (p->ring0[i]) (void)hipEventDestroy(p->ring0[i]);
-      if (p->ring1[i]) (void)hipEventDestroy(p->ring1[i]);
+      if (p->ring0[i]) { (void)hipEventDestroy(p->ring0[i]); g_events.fetch_sub(1); }
+      if (p->ring1[i]) { (void)hipEventDestroy(p->ring1[i]); g_events.fetch_sub(1); }
     }
   }
+  // the stream is drained: no launch of this plan's specialised kernels is in flight -- drop the references (the
+  // module of a kernel no other plan uses is unloaded, rtc.cpp)
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_part.drop(); }
   ssgpu_ctx* c = p->ctx;
+  g_live_plans.fetch_sub(1);
   delete p;
   if (c) ctx_release(c);
 }
@@ -581,32 +600,38 @@ static void staged_table(const Program& prog, const ProgramLayout& L, std::vecto
   width->clear(); off->clear();
   for (auto& sgd : prog.staged) { width->push_back(prog.regs[sgd.reg].width); off->push_back(prog.regs[sgd.reg].row_off * (uint32_t)(VM_TILE_UNIT * L.K)); }
 }
-static const int64_t SPECIALIZE_AFTER_RUNS = 8;
-static const int SPECIALIZE_AUTO_MAX_INSTR = 24;
+// The kernel specialised for `prog` (rtc.cpp) that a launch needing `lds_bytes` of LDS can use, compiled on first need when
+// the plan asked for specialisation; NULL = the interpreting kernel.  A launch beyond the 64 KiB of dynamic LDS a
+// module-loaded kernel may have gets a build whose LDS is a static array of exactly that size (one build per size: the
+// size fixes the occupancy, as it does for the interpreter).
+void* rtc_for(ssgpu_plan* p, StageExec& ex, StageExec::RtcSlot& slot, const Program& prog, const ProgramLayout& L, const std::vector<VmInstr>& host_prog,
+              int n_instr, uint32_t lds_bytes, const char* what) {
+  if (!p->specialize) return nullptr;
+  ssgpu_ctx* c = p->ctx;
+  const uint32_t need_static = lds_bytes > 64u * 1024u ? ((lds_bytes + 15u) & ~15u) : 0u;
+  if (slot.tried && slot.static_lds == need_static) return slot.h;
+  if (slot.h) { (void)hipStreamSynchronize(c->stream); slot.drop(); }   // launches of the kernel being replaced may still be in flight
+  slot.tried = true; slot.static_lds = need_static;
+  std::vector<uint32_t> sw, so; staged_table(prog, L, &sw, &so);
+  std::string why;
+  slot.h = ssgpu_rtc_specialize(c->device, host_prog.data(), n_instr, L.K, prog.uses_math, sw.data(), so.data(), (int)sw.size(), need_static, &why);
+  if (!slot.h && ex.rtc_why.empty()) ex.rtc_why = std::string(what) + why;
+  return slot.h;
+}
+
 int prepare_stage(ssgpu_plan* p, size_t si) {
   ssgpu_ctx* c = p->ctx;
   Stage& st = p->stages[si];
   StageExec& ex = p->exec[si];
   if (st.main.empty()) return SSGPU_OK;
   ProgramLayout L = layout_program(st.main, c->opt);
-  auto maybe_specialize = [&]() {
-    if (ex.rtc_tried || c->specialize == 0 || (c->specialize < 0 && p->n_runs < SPECIALIZE_AFTER_RUNS)) return;
-    ex.rtc_tried = true;
-    // compiling costs ~2 s + 0.4 s per instruction: the automatic mode leaves long programs to the interpreter
-    if (c->specialize < 0 && ex.n_instr_main > SPECIALIZE_AUTO_MAX_INSTR) { ex.rtc_why = "long program: set the specialize option to compile it"; return; }
-    if (ex.lay.lds_bytes > 64u * 1024u) ex.rtc_why = "the program's LDS exceeds what a module-loaded kernel may use without attributes";
-    else {
-      std::vector<uint32_t> sw, so; staged_table(st.main, ex.lay, &sw, &so);
-      ex.rtc_fn = ssgpu_rtc_specialize(c->device, ex.host_prog_main.data(), ex.n_instr_main, ex.lay.K, st.main.uses_math, sw.data(), so.data(), (int)sw.size(), &ex.rtc_why);
-    }
-  };
-  if (ex.prog_main.p && L.K == ex.lay.K) { maybe_specialize(); return SSGPU_OK; }  // already prepared
+  if (ex.prog_main.p && L.K == ex.lay.K) return SSGPU_OK;  // already prepared
   ex.lay = L;
   int rc = upload_program(c, st.main, L, &ex.prog_main, &ex.n_instr_main, &p->host_prog_scratch);
   if (rc != SSGPU_OK) return rc;
   ex.host_prog_main = p->host_prog_scratch;
-  ex.rtc_fn = nullptr; ex.rtc_why.clear(); ex.rtc_tried = false;
-  maybe_specialize();
+  if (ex.rtc_main.h) (void)hipStreamSynchronize(c->stream);
+  ex.rtc_main.drop(); ex.rtc_why.clear();   // another tile size is another program
   if (!st.count_pass.empty()) {
     // the count pass stages only the predicate's inputs: it takes the largest tile (fewer, longer tiles; its counts
     // are still per tile of the store pass)
@@ -766,9 +791,15 @@ int grid_for(ssgpu_ctx* c, const ProgramLayout& L, int n_tiles) {
   return (int)std::max<int64_t>(g, 1);
 }
 
-// the stage's main program: its specialised kernel when there is one (and the launch's LDS fits a module-loaded kernel)
-static hipError_t launch_main(ssgpu_ctx* c, StageExec& ex, const VmParams& P, int K, int grid) {
-  if (ex.rtc_fn && P.lds_bytes <= 64u * 1024u && !P.debug_pc) return ssgpu_launch_pipeline_rtc(ex.rtc_fn, P, grid, c->stream);
+// the stage's main program: its specialised kernel when the plan runs specialised kernels, else the interpreter.  (The
+// single-pass Filter keeps the interpreter: its grid is sized from THAT kernel's residency -- every workgroup must be
+// resident for the look-back to make progress -- and a specialised build may hold fewer per CU.)
+static hipError_t launch_main(ssgpu_plan* p, const Stage& st, StageExec& ex, const VmParams& P, int K, int grid) {
+  ssgpu_ctx* c = p->ctx;
+  if (p->specialize && !P.debug_pc && !st.single_pass) {
+    void* h = rtc_for(p, ex, ex.rtc_main, st.main, ex.lay, ex.host_prog_main, ex.n_instr_main, P.lds_bytes, "");
+    if (h) return ssgpu_launch_pipeline_rtc(h, P, grid, ex.rtc_main.static_lds != 0, c->stream);
+  }
   return ssgpu_launch_pipeline(P, K, grid, c->stream);
 }
 
@@ -877,7 +908,7 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
   HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
   { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
+  HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
   HIP_TRY(c, ssgpu_launch_finish_slots(ex.wg_partials.as<VmAccRec>(), ns, grid * VM_WAVES, ex.slot_kind.as<int>(),
@@ -991,7 +1022,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
     ex.out_rows = in.rows;
   }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
+  HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   p->counters.n_launches += 1;
   return print_pc_profile(c, ex, st.main, ex.n_instr_main);
@@ -1088,13 +1119,6 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (rc != SSGPU_OK) return rc;
     ex.host_prog_pscatter = p->host_prog_scratch;
   }
-  if (!ex.rtc_tried_pscatter && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS && ex.n_instr_pscatter <= SPECIALIZE_AUTO_MAX_INSTR))) {
-    ex.rtc_tried_pscatter = true;
-    std::string why;
-    std::vector<uint32_t> sw, so; staged_table(st.part_scatter, ex.lay_pscatter, &sw, &so);
-    ex.rtc_fn_pscatter = ssgpu_rtc_specialize(c->device, ex.host_prog_pscatter.data(), ex.n_instr_pscatter, ex.lay_pscatter.K, st.part_scatter.uses_math, sw.data(), so.data(), (int)sw.size(), &why);
-    if (!ex.rtc_fn_pscatter && ex.rtc_why.empty()) ex.rtc_why = "partition scatter: " + why;
-  }
   bool any_cnt = false;
   for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
   const uint32_t W = st.part_rec_bytes / 8u;
@@ -1188,8 +1212,11 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
     { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    if (ex.rtc_fn_pscatter && Ps.lds_bytes <= 64u * 1024u && !Ps.debug_pc) HIP_TRY(c, ssgpu_launch_pipeline_rtc(ex.rtc_fn_pscatter, Ps, grid, c->stream));
-    else HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
+    {
+      void* h = Ps.debug_pc ? nullptr : rtc_for(p, ex, ex.rtc_pscatter, st.part_scatter, ex.lay_pscatter, ex.host_prog_pscatter, ex.n_instr_pscatter, Ps.lds_bytes, "partition scatter: ");
+      if (h) HIP_TRY(c, ssgpu_launch_pipeline_rtc(h, Ps, grid, ex.rtc_pscatter.static_lds != 0, c->stream));
+      else HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
+    }
     { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
     PartAggParams A;
     memset(&A, 0, sizeof(A));
@@ -1212,13 +1239,15 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
                   ((uint64_t)(uint8_t)a.val_width << 32) | ((uint64_t)(uint8_t)(a.null_off < 0 ? 0xFF : a.null_off) << 40) | ((uint64_t)(a.has_cnt ? 1 : 0) << 48);
     }
     const uint32_t agg_lds = fixed + C * entry;
-    if (ex.rtc_part_lds != agg_lds && !A.debug && (c->specialize > 0 || (c->specialize < 0 && p->n_runs >= SPECIALIZE_AFTER_RUNS))) {
-      ex.rtc_part_lds = agg_lds;   // one attempt per LDS size (hash partitions and the slab form differ in it)
+    if (p->specialize && !A.debug && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds)) {
+      // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
+      if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
+      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds;
       std::string why;
-      ex.rtc_fn_part = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why);
-      if (!ex.rtc_fn_part && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
+      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why);
+      if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
-    if (ex.rtc_fn_part && ex.rtc_part_lds == agg_lds && !A.debug) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_fn_part, A, c->stream));
+    if (p->specialize && ex.rtc_part.h && ex.rtc_part.static_lds == agg_lds && !A.debug) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_part.h, A, c->stream));
     else HIP_TRY(c, ssgpu_launch_part_agg(A, agg_lds, c->stream));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     p->counters.n_launches += 6;
@@ -1328,7 +1357,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)P.lds_bytes;
     { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
+    HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: wgs/CU=%d local entries=%u sub-tables=%u grid=%d lds=%u\n", ex.group_wgs, lcap, lsub, grid, P.lds_bytes);
@@ -1657,7 +1686,7 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   P.group.cnt = ex.gcnt.as<unsigned int>();
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-  HIP_TRY(c, launch_main(c, ex, P, ex.lay.K, grid));
+  HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   rc = ensure_rowid_tmp(c, st, ex, nseg);
   if (rc != SSGPU_OK) return rc;
@@ -1777,7 +1806,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   }
   if (c->profile) {
     const int slot = (int)(p->profiled_runs % ssgpu_plan::kEventRing);
-    if (!p->ring0[slot]) { HIP_TRY(c, hipEventCreate(&p->ring0[slot])); HIP_TRY(c, hipEventCreate(&p->ring1[slot])); }
+    if (!p->ring0[slot]) { HIP_TRY(c, hipEventCreate(&p->ring0[slot])); HIP_TRY(c, hipEventCreate(&p->ring1[slot])); g_events.fetch_add(2); }
     p->ev_dom0 = p->ring0[slot]; p->ev_dom1 = p->ring1[slot];
     ++p->profiled_runs;
     p->events_valid = false;
@@ -1843,13 +1872,41 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
 int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
   if (!p) return 0;
   int32_t n = 0;
-  for (auto& ex : p->exec) {
-    if (ex.rtc_fn) ++n;
-    if (ex.rtc_fn_pscatter) ++n;
-    if (ex.rtc_fn_part) ++n;
-    else if (!ex.rtc_why.empty()) p->ctx->err = "stage runs on the interpreter: " + ex.rtc_why;
-  }
+  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0);
   return n;
+}
+const char* ssgpu_plan_specialize_reason(const ssgpu_plan* p) {
+  if (!p) return "";
+  for (auto& ex : p->exec) if (!ex.rtc_why.empty()) return ex.rtc_why.c_str();
+  return "";
+}
+// Ask for specialised kernels NOW: the deterministic compile point.  Stages whose launch shape is known without a run
+// (scalar aggregates, materialising stages, clustered aggregation) are compiled here; a GroupAggregate's kernels depend
+// on the execution shape its first runs settle on and are compiled when that shape is first launched.
+int ssgpu_plan_specialize(ssgpu_plan* p) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  p->specialize = true;
+  for (size_t si = 0; si < p->stages.size(); ++si) {
+    const int rc = prepare_stage(p, si);
+    if (rc != SSGPU_OK) return rc;
+    Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+    if (st.main.empty() || st.single_pass || st.kind == STAGE_GROUP_AGG) continue;
+    (void)rtc_for(p, ex, ex.rtc_main, st.main, ex.lay, ex.host_prog_main, ex.n_instr_main, ex.lay.lds_bytes, "");
+  }
+  return SSGPU_OK;
+}
+int ssgpu_memory_stats(ssgpu_memory_stats_t* out) {
+  if (!out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  memset(out, 0, sizeof(*out));
+  out->device_bytes = g_dev_bytes.load(); out->pinned_bytes = g_pinned_bytes.load();
+  out->live_plans = g_live_plans.load(); out->live_blocks = g_live_blocks.load(); out->events = g_events.load();
+  long long m = 0, b = 0, n = 0;
+  ssgpu_rtc_stats(&m, &b, &n);
+  out->rtc_modules = m; out->rtc_code_bytes = b; out->rtc_compilations = n;
+  return SSGPU_OK;
 }
 int ssgpu_plan_set_memory_limit(ssgpu_plan* p, int64_t bytes) {
   if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;

@@ -1252,7 +1252,7 @@ def _run_specialized(op, ctx, expect_stages=1, **kw):
     got = run_both(op, ctx, **kw)
     plan = ss.Plan(op, ctx)
     plan.run()
-    assert plan.specialized() >= expect_stages, ctx.last_error()
+    assert plan.specialized() >= expect_stages, plan.specialize_reason()
     return got
 
 
@@ -1283,9 +1283,29 @@ def test_specialized_partition_aggregation_kernel(n, slab):
         run_both(op, ctx, ignore_order=True)
         plan = ss.Plan(op, ctx)
         plan.run()
-        assert plan.specialized() >= 2, ctx.last_error()      # the scatter program and the aggregation kernel
+        assert plan.specialized() >= 2, plan.specialize_reason()      # the scatter program and the aggregation kernel
     fl = ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), None, ss.ScanView(make_view(n, nullable=True)))
     run_both(fl, ctx, ignore_order=True)
+
+
+def test_specialized_group_stage_beyond_64k_of_lds(specialized_ctx):
+    # a direct GroupAggregate whose LDS pre-aggregation table takes the launch past the 64 KiB of dynamic LDS a module-loaded
+    # kernel may have: the specialised build declares its LDS statically, at exactly the launch's size (rtc.cpp static_lds)
+    n = 300007
+    rng = np.random.default_rng(3)
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("v", ss.INT64), ss.Attribute("d", ss.DOUBLE, ss.NULLABLE)])
+    view = ss.View(schema, [rng.integers(0, 3000, n).astype(np.int32), rng.integers(-1000, 1000, n), ss.Column(rng.integers(-4000, 4000, n) * 0.25, rng.random(n) < 0.1)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "d", "c").AddAggregation(ss.MIN, "d", "mn")
+            .AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MAX, "v", "mx"))
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view))
+    plan = ss.Plan(op, specialized_ctx)
+    for _ in range(4):                       # the run feedback grows the LDS table (fewer workgroups per CU) over the first runs
+        plan.run()
+    assert plan.counters().lds_bytes > 64 * 1024, plan.counters().lds_bytes
+    assert plan.specialized() >= 1, plan.specialize_reason()
+    _schema, want = oracle_run(op)
+    got = plan.fetch()
+    assert_cols_equal(sort_rows(to_cols(got)), sort_rows(want))
 
 
 def test_specialized_kernels_are_cached_and_report_errors(specialized_ctx):
