@@ -53,6 +53,16 @@ def build_plan(ss, view, k_filter=K_FILTER):
                                               ss.Compute(compute, ss.ScanView(view))))
 
 
+def build_sort_plan(ss, view):
+    """BASELINE configs[4] / SURVEY 8(d) Q-SORT: Sort(d ASC) over the 8-column block, every column in the result."""
+    return ss.Sort(ss.SortOrder().add("d", ss.ASCENDING), ss.ProjectAllAttributes(), 0, ss.ScanView(view))
+
+
+def build_filter_mat_plan(ss, view, k_filter=K_FILTER):
+    """SURVEY 8(d) Q-FILTER-mat: Filter(a > K, ProjectAllAttributes), the survivors materialised."""
+    return ss.Filter(ss.Greater(ss.NamedAttribute("a"), ss.ConstInt64(k_filter)), ss.ProjectAllAttributes(), ss.ScanView(view))
+
+
 def bench_schema(ss):
     return ss.TupleSchema([ss.Attribute(n, ss.INT64) for n in ("a", "b", "c", "d")] +
                           [ss.Attribute(n, ss.DOUBLE) for n in ("d0", "d1", "d2", "d3")])
@@ -173,7 +183,8 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0):
     from oracle import oracle
     n = sample_rows
     schema = group_schema(ss) if query == "group" else bench_schema(ss)
-    make = (lambda v: build_group_plan(ss, v)) if query == "group" else (lambda v: build_plan(ss, v))
+    make = {"group": lambda v: build_group_plan(ss, v), "sort": lambda v: build_sort_plan(ss, v),
+            "filter_mat": lambda v: build_filter_mat_plan(ss, v)}.get(query, lambda v: build_plan(ss, v))
     cols = host_columns(np, query, n)
 
     def drain(op):
@@ -248,8 +259,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling) or in total (strong scaling)")
-    ap.add_argument("--query", choices=["wide", "group", "group3"], default="wide",
-                    help="wide = configs[1] (headline); group = configs[3]'s per-GPU query (Filter -> GroupAggregate); group3 = configs[2] (GroupAggregate alone)")
+    ap.add_argument("--query", choices=["wide", "group", "group3", "sort", "filter_mat"], default="wide",
+                    help="wide = configs[1] (headline); group = configs[3]'s per-GPU query (Filter -> GroupAggregate); group3 = configs[2] "
+                         "(GroupAggregate alone); sort = configs[4] (Sort(d) of the 8-column block); filter_mat = materialising Filter(a > 499)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -270,8 +282,10 @@ def parse_args(argv=None):
 
 
 def metric_name(query):
-    return ("rows/sec filter->project->aggregate, 100M x 8 INT64/DOUBLE" if query == "wide"
-            else "rows/sec filter->group-aggregate (2 INT32 keys, 1e5 groups, SUM/MIN/MAX x 4 DOUBLE)")
+    return {"wide": "rows/sec filter->project->aggregate, 100M x 8 INT64/DOUBLE",
+            "sort": "rows/sec Sort (ORDER BY 1 INT64 key), 100M x 8 INT64/DOUBLE",
+            "filter_mat": "rows/sec materialising Filter, 100M x 8 INT64/DOUBLE",
+            }.get(query, "rows/sec filter->group-aggregate (2 INT32 keys, 1e5 groups, SUM/MIN/MAX x 4 DOUBLE)")
 
 
 def dry_run(args, world, rank):
@@ -442,7 +456,10 @@ def main():
         job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], group_spec(ss), group_child(ss, view))
         plan = job.first
     else:
-        plan = ss.Plan(build_group_plan(ss, view) if group else build_plan(ss, view), ctx)
+        if (args.query in ("sort", "filter_mat")) and distributed:
+            raise SystemExit("--query %s is a single-GPU line (SURVEY 8(e): no single-exchange shape)" % args.query)
+        plan = ss.Plan(build_group_plan(ss, view) if group else build_sort_plan(ss, view) if args.query == "sort"
+                       else build_filter_mat_plan(ss, view) if args.query == "filter_mat" else build_plan(ss, view), ctx)
 
     seg_tensors = None
 
@@ -517,12 +534,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = (job.result()[0] if job is not None else plan).fetch()
+    if args.query in ("sort", "filter_mat"):
+        # the result is as large as the input: it stays in HBM; check it there (never copied to the host)
+        dv = plan.result_device_view()
+        out_rows = dv.row_count()
+        col = lambda i, ts: torch.as_tensor(_DevPtr(dv._ptrs[i][0], out_rows, ts), device=device)   # noqa: E731
+        if args.query == "sort":
+            key = col(3, "<i8")
+            checked = {"sorted": bool((key[1:] >= key[:-1]).all().item()) if out_rows > 1 else True,
+                       "key_sum_matches": int(key.sum().item()) == int(cols[3].sum().item()),
+                       "payload_sum_matches": int(col(0, "<i8").sum().item()) == int(cols[0].sum().item())}
+        else:
+            keep = cols[0] > K_FILTER
+            checked = {"rows_match": out_rows == int(keep.sum().item()),
+                       "first_column_matches": bool(torch.equal(col(0, "<i8"), cols[0][keep])),
+                       "last_column_matches": bool(torch.equal(col(7, "<f8"), cols[7][keep]))}
+            del keep
+        if not all(checked.values()):
+            raise SystemExit("bench.py --query %s: the device result failed its check: %r" % (args.query, checked))
+        result = None
+    else:
+        result = (job.result()[0] if job is not None else plan).fetch()
     if rank == 0:
         value = total_rows_per_step * args.steps / elapsed
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
         alg_bytes = counters.algorithmic_bytes  # bytes/row of the staged input columns x rows of one launch
-        achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         if group:
             workload = ("%s: GroupAggregate(k1,k2; SUM/MIN/MAX x d0..d3)%s over a device-resident %d-row x 7-col "
                         "block per GPU (~1e5 groups)" % ("Q-GROUP-F" if GROUP_FILTER else "Q-GROUP", " o Filter(a>499)" if GROUP_FILTER else "", rows))
@@ -530,6 +566,16 @@ def main():
                    if distributed else "single GPU")
             kernel = "group stage (partition scatter + per-partition aggregation kernels)"
             result_row = {"groups": result.row_count()}
+        elif args.query == "sort":
+            workload = "Q-SORT: Sort(d ASC, all 8 columns) of a device-resident %d-row x 8-col block" % rows
+            par, kernel = "single GPU", "sort stage (key load + histograms, radix passes, tie fix-up, record pack + gather)"
+            alg_bytes = 128 * rows               # every column read once and written once
+            result_row = dict(rows=out_rows, **checked)
+        elif args.query == "filter_mat":
+            workload = "Q-FILTER-mat: Filter(a>499, all 8 columns) of a device-resident %d-row x 8-col block, survivors materialised" % rows
+            par, kernel = "single GPU", "filter stage (count pass + scan + compacting store pass)"
+            alg_bytes = 64 * rows + 64 * out_rows   # 64 B/row read + 64 B per surviving row written
+            result_row = dict(rows=out_rows, **checked)
         else:
             workload = ("Q-FPA-wide: SUM(a+b),COUNT(*),SUM(c),MIN(d),MAX(d0),SUM(d1),SUM(d2*d3) WHERE a>499 "
                         "over a device-resident %d-row x 8-col block per GPU" % rows)
@@ -537,6 +583,7 @@ def main():
                    if distributed else "single GPU")
             kernel = "ssgpu_pipeline_kernel"
             result_row = [result.column(i).data[0].item() for i in range(result.column_count())]
+        achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         line = {
             "metric": metric_name(args.query),
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -554,10 +601,10 @@ def main():
         if job is not None:
             line["config"]["collectives_per_step"] = job.collectives
             line["config"]["image_capacity_rows"] = job.capacity
-        if world == 1 and args.extras and not group:
+        if world == 1 and args.extras and args.query == "wide":
             line["extras"] = extras(ss, torch, ctx, device, rows, cols, view)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ss, args.query, args.cpu_sample_rows or (4_000_000 if group else 16_000_000))
+            line["cpu_baseline"] = cpu_baseline(ss, args.query, args.cpu_sample_rows or {"wide": 16_000_000, "filter_mat": 16_000_000}.get(args.query, 4_000_000))
         # RCCL prints its version banner through C stdio (still buffered when stdout is a file):
         # drain it first so that the JSON line is the LAST line of stdout
         try:

@@ -426,6 +426,24 @@ typedef struct ssgpu_memory_stats_t {
 int ssgpu_memory_stats(ssgpu_memory_stats_t* out);
 int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
 
+/* What the last run of a plan's stage did -- the execution shape run feedback chose.  For tests and tuning: a parity
+ * test that claims to cover the partitioned GroupAggregate or the hybrid Sort asserts here that it ran. */
+typedef struct ssgpu_stage_info {
+  int32_t kind;             /* 1 scalar aggregate, 2 materialise, 3 group aggregate, 4 sort, 5 clustered aggregate, 6 join expansion */
+  int32_t group_shape;      /* group aggregate: 0 direct (LDS table + global table), 1 hash partitions, 2 slab */
+  int32_t part_n;           /* hash partitions of the partitioned shape */
+  int32_t part_seg_growth;  /* x4 per segment overflow (skewed keys) */
+  int32_t group_wgs_per_cu; /* direct shape: resident workgroups per CU the LDS table is sized for */
+  int32_t reruns;           /* attempts the last run needed beyond the first (regrown table, segments or partitions) */
+  int32_t sort_passes;      /* radix passes of the last run */
+  int32_t sort_mode;        /* 0 LSD over the varying digits, 1 high digits + tie fix-up, 2 one-word (high half | row id) keys;
+                               +16: tie runs were too long and all digits were sorted after all */
+  int32_t specialized;      /* bit 0 the stage's program, bit 1 the partition scatter, bit 2 the partition aggregation */
+  int32_t reserved[7];
+} ssgpu_stage_info;
+int32_t ssgpu_plan_stage_count(const ssgpu_plan* plan);
+int ssgpu_plan_stage_info(const ssgpu_plan* plan, int32_t stage, ssgpu_stage_info* out);
+
 /* ---- standalone expression seam --------------------------------------------------------------------------
  * Expression::Bind(schema, ...) -> BoundExpressionTree, BoundExpressionTree::Evaluate(view) -> result View
  * (expression/base/expression.h:46-167, :116): the expression tree `root` (nodes as in ssgpu_plan_desc) is bound

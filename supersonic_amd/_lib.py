@@ -77,6 +77,11 @@ class MemoryStats(C.Structure):
                                           "rtc_modules", "rtc_code_bytes", "rtc_compilations")]
 
 
+class StageInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "group_shape", "part_n", "part_seg_growth", "group_wgs_per_cu", "reruns",
+                                          "sort_passes", "sort_mode", "specialized")] + [("reserved", C.c_int32 * 7)]
+
+
 class PlanDesc(C.Structure):
     _fields_ = [("input_schema", C.POINTER(Attr)), ("n_attrs", C.c_int32),
                 ("ops", C.POINTER(Op)), ("n_ops", C.c_int32),
@@ -125,6 +130,8 @@ SYMBOLS = [
     ("ssgpu_plan_set_memory_limit", C.c_int, [P, C.c_int64]),
     ("ssgpu_plan_specialized", C.c_int32, [P]),
     ("ssgpu_plan_specialize", C.c_int, [P]),
+    ("ssgpu_plan_stage_count", C.c_int32, [P]),
+    ("ssgpu_plan_stage_info", C.c_int, [P, C.c_int32, C.POINTER(StageInfo)]),
     ("ssgpu_plan_specialize_reason", C.c_char_p, [P]),
     ("ssgpu_memory_stats", C.c_int, [C.POINTER(MemoryStats)]),
     ("ssgpu_plan_memory_in_use", C.c_int64, [P]),

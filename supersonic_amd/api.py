@@ -1078,6 +1078,15 @@ class Plan(object):
         """Specialised kernels (runtime compilation, csrc/rtc.cpp) this plan currently holds."""
         return self.lib.ssgpu_plan_specialized(self.handle)
 
+    def stage_info(self):
+        """ssgpu_plan_stage_info of every stage: what the last run did (execution shape, reruns, radix passes), as dicts."""
+        out = []
+        for i in range(self.lib.ssgpu_plan_stage_count(self.handle)):
+            st = L.StageInfo()
+            self.ctx.check(self.lib.ssgpu_plan_stage_info(self.handle, i, C.byref(st)))
+            out.append({n: getattr(st, n) for n, _t in L.StageInfo._fields_ if n != "reserved"})
+        return out
+
     def specialize(self):
         """ssgpu_plan_specialize: run kernels compiled for this plan; what can be compiled without a run is compiled now."""
         self.ctx.check(self.lib.ssgpu_plan_specialize(self.handle))

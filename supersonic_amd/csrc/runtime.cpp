@@ -88,6 +88,8 @@ struct DevBuf {
     size_t want = std::max<size_t>(bytes, 256);
     MemQuota* Q = g_quota;
     if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)cap : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
+    static const bool trace = getenv("SSGPU_TRACE") != nullptr;   // development: (re)allocations of large buffers are slow and must not sit in a steady state
+    if (trace && want >= (64u << 20)) fprintf(stderr, "[ssgpu trace] device buffer %zu -> %zu MiB\n", cap >> 20, want >> 20);
     release();
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) { cap = want; q = Q; g_dev_bytes.fetch_add((long long)want); if (q) q->used += (int64_t)want; } else p = nullptr;
@@ -173,6 +175,10 @@ struct StageExec {
   std::vector<OutCol> out;
   int64_t out_rows = -1;     // -1: read lazily from `total`
   int64_t out_capacity = 0;
+  // what the last run did (ssgpu_plan_stage_info)
+  int last_group_shape = 0;     // 0 direct, 1 hash partitions, 2 slab
+  int last_reruns = 0;          // attempts beyond the first (regrown table / segments / partitions)
+  int last_sort_passes = 0, last_sort_mode = 0;
 };
 
 struct ssgpu_result {
@@ -981,11 +987,13 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   }
   ex.grid = grid;
   p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
+  bool dom0_recorded = false;
   if (st.has_filter && !st.single_pass) {
     const int nt = std::max(P.n_tiles, 1);
     HIP_TRY(c, ex.tile_counts.ensure((size_t)nt * sizeof(uint32_t)));
     HIP_TRY(c, ex.tile_offsets.ensure((size_t)nt * sizeof(uint32_t)));
     HIP_TRY(c, ex.total.ensure(16));
+    if (c->profile) { HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream)); dom0_recorded = true; }   // the stage's kernels: count pass, scan, store pass
     VmParams C;
     fill_params(&C, st.count_pass, ex.lay_count, ex.prog_count, ex.n_instr_count, in, row_id_base);
     apply_joins(p, ex, st.count_pass, &C);
@@ -1021,7 +1029,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   } else {
     ex.out_rows = in.rows;
   }
-  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  if (c->profile && !dom0_recorded) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
   HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   p->counters.n_launches += 1;
@@ -1160,6 +1168,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
   for (int attempt = 0; attempt < 8; ++attempt) {
     const bool slab = ex.part_slab;
     const uint32_t NP = slab ? 1u : ex.part_n;
+    ex.last_group_shape = slab ? 2 : 1; if (attempt) ++ex.last_reruns;
     uint32_t capacity = NP * C;
     if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
     const size_t slots = (size_t)capacity + 1;
@@ -1258,7 +1267,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, grid %d, segments of %llu records (%u B), table overflow=%u segment overflow=%u\n",
                                  NP, C, grid, (unsigned long long)seg_cap, st.part_rec_bytes, fb[0], fb[1]);
     if (slab && (fb[0] || fb[1])) {   // more groups than one LDS table holds after all: hash partitions
-      ex.part_slab = false; ex.part_slab_failed = true;
+      ex.part_slab = false; ex.part_slab_failed = true; ++ex.last_reruns;
       return run_group_agg_partitioned(p, si, in, row_id_base, fallback);
     }
     if (fb[1]) {   // skewed keys: larger segments (memory permitting), else the direct path
@@ -1277,6 +1286,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
 int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  ex.last_reruns = 0;
   if ((ex.group_partitioned || c->group_partition == 2) && !st.part_scatter.empty()) {
     bool fallback = false;
     const int rc = run_group_agg_partitioned(p, si, in, row_id_base, &fallback);
@@ -1285,7 +1295,9 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     ex.group_partitioned = false; ex.group_local = true; ex.part_failed = true;
   }
   if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
+  ex.last_group_shape = 0;
   for (int attempt = 0; attempt < 8; ++attempt) {
+    if (attempt) ++ex.last_reruns;
     const size_t slots = (size_t)ex.capacity + 1;
     HIP_TRY(c, ex.gkeys.ensure(slots * 8));
     HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
@@ -1436,6 +1448,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   HIP_TRY(c, ex.sticket.ensure(64 * 4));
   HIP_TRY(c, hipMemsetAsync(ex.sticket.p, 0, 64 * 4, c->stream));
   uint32_t n_pass = 0;   // tickets [0, 61], "a tie run was too long" flag at [62], "look-back gave up" flag at [63]
+  int sort_mode = 0;     // 0 plain LSD passes, 1 high digits + tie fix-up, 2 one-word (high half | row id) keys; +16: tie runs too long, all digits after all
   uint64_t* ka = ex.skeys_a.as<uint64_t>(); uint64_t* kb = ex.skeys_b.as<uint64_t>();
   uint32_t* ia = ex.sidx_a.as<uint32_t>(); uint32_t* ib = ex.sidx_b.as<uint32_t>();
   // The major key's column can be read back from the sorted keys when its transform is a bijection (integer
@@ -1563,14 +1576,14 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       p->counters.n_launches += 6;
       if (!too_long) {
-        done = true;
+        done = true; sort_mode = 2;
         if (k > 0) HIP_TRY(c, ssgpu_launch_sort_extract_idx(ia, kc, n, c->stream));   // more significant keys follow: they permute (key, row id) pairs
         else compact_sorted = kc;
       } else {
         // long runs of equal high halves: the plain LSD order over all digits (the key array and the digit offsets are untouched)
         HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));
         HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
-        compact = false; tie_runs_too_long = true;
+        compact = false; tie_runs_too_long = true; sort_mode = 2 + 16;
       }
     }
     if (!done && !tie_runs_too_long && c->sort_hybrid && w == 8 && k == (int)st.sort_keys.size() - 1 && (varying & 0xFFFFFFFFull) && !(nulls && st.in_schema[sk.col].nullable) &&
@@ -1592,8 +1605,9 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         p->counters.n_launches += 1;
         if (!too_long) {
-          done = true;
+          done = true; sort_mode = 1;
         } else {
+          sort_mode = 1 + 16;
           // long runs of equal high halves: the plain LSD order over all digits, from scratch (the four passes used
           // both buffers as targets: reload the row ids and the keys)
           if (!keys_only) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
@@ -1626,6 +1640,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     p->counters.n_launches += 1;
   }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  ex.last_sort_passes = (int)n_pass; ex.last_sort_mode = sort_mode;
   if (n_pass) {   // the look-back never gives up on a healthy device; if it did, the order is wrong: fail loudly
     uint32_t stuck = 0;
     HIP_TRY(c, hipMemcpyAsync(&stuck, ex.sticket.as<uint32_t>() + 63, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1896,6 +1911,18 @@ int ssgpu_plan_specialize(ssgpu_plan* p) {
     if (st.main.empty() || st.single_pass || st.kind == STAGE_GROUP_AGG) continue;
     (void)rtc_for(p, ex, ex.rtc_main, st.main, ex.lay, ex.host_prog_main, ex.n_instr_main, ex.lay.lds_bytes, "");
   }
+  return SSGPU_OK;
+}
+int32_t ssgpu_plan_stage_count(const ssgpu_plan* p) { return p ? (int32_t)p->stages.size() : 0; }
+int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* out) {
+  if (!p || !out || stage < 0 || stage >= (int32_t)p->stages.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  const StageExec& ex = p->exec[stage];
+  memset(out, 0, sizeof(*out));
+  out->kind = (int32_t)p->stages[stage].kind;
+  out->group_shape = ex.last_group_shape; out->part_n = (int32_t)ex.part_n; out->part_seg_growth = (int32_t)ex.part_seg_growth;
+  out->group_wgs_per_cu = ex.group_wgs; out->reruns = ex.last_reruns;
+  out->sort_passes = ex.last_sort_passes; out->sort_mode = ex.last_sort_mode;
+  out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0);
   return SSGPU_OK;
 }
 int ssgpu_memory_stats(ssgpu_memory_stats_t* out) {

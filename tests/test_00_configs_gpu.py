@@ -1,0 +1,218 @@
+"""HIP path vs the CPU oracle at the SHAPES of BASELINE.json's configs, at sizes the oracle does in about a second.
+
+Collected first (file name), so that a driver run reaches every configuration's oracle comparison in its first minute:
+
+  #1 / #2  Compute(a+b) -> Filter(a>K) -> ScalarAggregate -- `bench.build_plan`, the headline plan, on the 8-column block
+  #3       GroupAggregate(k1, k2; SUM / MIN / MAX x d0..d3), random keys, 1e5 groups -- `bench.build_group_plan` exactly as
+           `bench.py --query group3` builds it, through every execution shape (direct, hash partitions with both specialised
+           kernels, slab), plus skewed keys that overflow segments (part_seg_growth) and partitions (part_n doubling)
+  #4       the row-range-sharded Filter -> GroupAggregate: `DeviceShardedGroupAggregate` (what `bench.py --query group
+           --force-distributed` steps) on a 1-rank RCCL group, pack / all-gather / unpack / merge, vs the oracle
+  #5       Sort(d ASC) over the 8-column block -- `bench.build_sort_plan`: one-word hybrid passes + tie fix-up + record
+           gather, and adversarial keys whose high halves collide (fallback to all eight digits)
+
+Reference shapes: supersonic/benchmark/examples/operation_example.cc:42-171.  Every comparison is bit-exact (the DOUBLE
+columns hold values whose partial sums are exact); `Plan.stage_info()` asserts that the shape a case names
+is the shape that ran."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import bench
+import supersonic_amd as ss
+from helpers import assert_cols_equal, schema_list, sort_rows, to_cols
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+N_ROWS = 2_000_000
+
+
+def make_ctx(**options):
+    ctx = ss.Context(0)
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    return ctx
+
+
+def check_plan(plan, want, context, ignore_order=False, runs=1, view=None):
+    infos = []
+    for i in range(runs):
+        plan.run(view) if view is not None else plan.run()
+        got = to_cols(plan.fetch())
+        w = want
+        if ignore_order:
+            got, w = sort_rows(got), sort_rows(want)
+        assert_cols_equal(got, w, context="%s (run %d)" % (context, i))
+        infos.append(plan.stage_info())
+    return infos
+
+
+# ---- configs #1 / #2: the headline plan ----------------------------------------------------------------------------
+@pytest.mark.parametrize("specialize", [0, 1])
+def test_config2_filter_project_aggregate_8_columns(specialize):
+    view = ss.View(bench.bench_schema(ss), bench.host_columns(np, "wide", N_ROWS))
+    op = bench.build_plan(ss, view)
+    oschema, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(specialize=specialize))
+    assert schema_list(plan.result_schema) == oschema
+    check_plan(plan, want, "config #2, specialize=%d" % specialize, runs=2)
+    assert plan.specialized() == specialize, plan.specialize_reason()
+
+
+def test_config1_cpu_reference_shape():
+    # configs[0]: Compute(a+b) -> Filter(a>K) -> Sum/Count on a 1 M-row x 4 INT64 table
+    rng = np.random.default_rng(42)
+    m = 1_000_000
+    s4 = ss.TupleSchema([ss.Attribute(x, ss.INT64) for x in ("a", "b", "c", "d")])
+    v4 = ss.View(s4, [rng.integers(0, 1000, m), rng.integers(0, 1000, m), np.arange(m, dtype=np.int64) % 100000, rng.integers(-(1 << 62), 1 << 62, m)])
+    NA = ss.NamedAttribute
+    op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.COUNT, "a", "cnt"),
+                            ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(bench.K_FILTER)), ss.ProjectAllAttributes(),
+                                      ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))), ss.ScanView(v4))))
+    _s, want = oracle.run(op)
+    check_plan(ss.Plan(op, make_ctx()), want, "config #1")
+
+
+# ---- config #3: GroupAggregate, 2 x INT32 keys, 1e5 groups, 12 DOUBLE aggregates ----------------------------------------
+def group3_op(view):
+    saved = bench.GROUP_FILTER
+    bench.GROUP_FILTER = False                        # what `--query group3` does
+    try:
+        return bench.build_group_plan(ss, view)
+    finally:
+        bench.GROUP_FILTER = saved
+
+
+@pytest.fixture(scope="module")
+def group3():
+    view = ss.View(bench.group_schema(ss), bench.host_columns(np, "group", N_ROWS))
+    op = group3_op(view)
+    oschema, want = oracle.run(op)
+    assert len(want[0][0]) == bench.N_GROUPS          # 2 M uniform draws hit every one of the 1e5 (k1, k2) pairs
+    return view, op, oschema, want
+
+
+def test_config3_group_aggregate_by_run_feedback(group3):
+    # the default policy: the first run takes the direct shape, its feedback (most rows bypass the LDS table) moves the
+    # plan to the hash partitions; every run of the walk gives the oracle's rows
+    _view, op, oschema, want = group3
+    plan = ss.Plan(op, make_ctx())
+    assert schema_list(plan.result_schema) == oschema
+    infos = check_plan(plan, want, "config #3 adaptive", ignore_order=True, runs=4)
+    shapes = [i[0]["group_shape"] for i in infos]
+    assert shapes[0] == 0 and shapes[-1] == 1, shapes
+
+
+def test_config3_partitioned_with_both_specialised_kernels(group3):
+    _view, op, _s, want = group3
+    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=1))
+    infos = check_plan(plan, want, "config #3 partitioned + specialised", ignore_order=True, runs=2)
+    assert infos[-1][0]["group_shape"] == 1 and infos[-1][0]["reruns"] == 0, infos
+    assert infos[-1][0]["specialized"] & 6 == 6, plan.specialize_reason()       # partition scatter and partition aggregation
+
+
+def test_config3_partitioned_interpreted_and_few_partitions_double(group3):
+    # 64 partitions x ~1000-entry tables cannot hold 1e5 groups: "partition finer and rerun" until they fit
+    _view, op, _s, want = group3
+    plan = ss.Plan(op, make_ctx(group_partition=2, part_n=64))
+    infos = check_plan(plan, want, "config #3, part_n doubling", ignore_order=True, runs=2)
+    assert infos[0][0]["reruns"] >= 1 and infos[0][0]["part_n"] > 64, infos
+    assert infos[1][0]["reruns"] == 0, infos                                    # the second run starts from what the first learnt
+
+
+@pytest.mark.parametrize("specialize", [0, 1])
+def test_config3_skewed_keys_overflow_their_segments(specialize):
+    # half of the rows carry ONE (k1, k2) pair: the (partition, workgroup) segments of that pair's partition run full, the
+    # stage reruns with 4x larger segments (part_seg_growth) -- same rows as the oracle, both kernel forms
+    cols = bench.host_columns(np, "group", N_ROWS, seed=7)
+    hot = np.random.default_rng(8).random(N_ROWS) < 0.5
+    cols[1] = np.where(hot, 123, cols[1]).astype(np.int32)
+    cols[2] = np.where(hot, 45, cols[2]).astype(np.int32)
+    op = group3_op(ss.View(bench.group_schema(ss), cols))
+    _s, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=specialize))
+    infos = check_plan(plan, want, "config #3 skewed", ignore_order=True, runs=2)
+    assert infos[0][0]["part_seg_growth"] > 1 or infos[0][0]["group_shape"] == 0, infos   # grew its segments (or, beyond x64, fell back to the direct shape)
+
+
+def test_config3_shape_with_few_groups_takes_the_slab_form():
+    # same 12 aggregates over ~1000 groups: ONE whole-LDS table per aggregation workgroup, no hash partitions
+    cols = bench.host_columns(np, "group", N_ROWS, seed=11)
+    g = np.random.default_rng(12).integers(0, 1000, N_ROWS)
+    cols[1], cols[2] = (g // 37).astype(np.int32), (g % 37).astype(np.int32)
+    op = group3_op(ss.View(bench.group_schema(ss), cols))
+    _s, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(specialize=1))
+    infos = check_plan(plan, want, "config #3 shape, 1000 groups", ignore_order=True, runs=4)
+    assert infos[-1][0]["group_shape"] in (0, 2), infos
+
+
+# ---- config #4: row-range-sharded Filter -> GroupAggregate, RCCL exchange of the partial tables ---------------------------
+def test_config4_sharded_filter_group_aggregate_one_rank():
+    import torch
+    import torch.distributed as dist
+    from supersonic_amd.distributed import DeviceShardedGroupAggregate
+    cols = bench.host_columns(np, "group", N_ROWS, seed=5)
+    view = ss.View(bench.group_schema(ss), cols)
+    want_op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), bench.group_spec(ss), None, bench.group_child(ss, view))
+    oschema, want = oracle.run(want_op)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = make_ctx(specialize=1)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], bench.group_spec(ss), bench.group_child(ss, view))
+        for _ in range(3):                       # bench.py's loop: step until the agreed image capacity holds every table
+            job.step()
+            while not job.check():
+                job.step()
+        assert job.collectives == 1              # ONE all-gather of the packed partial tables per step
+        plan = job.result()[0]
+        assert schema_list(plan.result_schema) == oschema
+        assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="config #4, one rank")
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- config #5: Sort(d ASC) of the 8-column block -----------------------------------------------------------------------
+def check_sort(cols, expect_mode, context, **options):
+    view = ss.View(bench.bench_schema(ss), cols)
+    op = bench.build_sort_plan(ss, view)
+    oschema, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(**options))
+    assert schema_list(plan.result_schema) == oschema
+    infos = check_plan(plan, want, context, runs=2)
+    assert infos[-1][0]["sort_mode"] in expect_mode, infos
+    return infos
+
+
+def unique_keys(cols):
+    # the reference's sort is not stable (sort.h:42): parity needs a key without duplicates
+    assert len(np.unique(cols[3])) == len(cols[3])
+    return cols
+
+
+def test_config5_sort_8_columns_one_word_passes_and_record_gather():
+    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2,), "config #5")
+    assert infos[-1][0]["sort_passes"] == 4, infos       # the four high digits; ties finished by ssgpu_sort_fix_ties_compact
+
+
+def test_config5_sort_colliding_high_halves_fall_back_to_all_digits():
+    # keys that agree in their high 32 bits in long runs: the tie runs are too long, every digit is sorted after all
+    cols = bench.host_columns(np, "wide", N_ROWS, seed=3)
+    rng = np.random.default_rng(4)
+    hi = rng.integers(-(1 << 30), 1 << 30, 997).astype(np.int64)              # ~2000 rows per high half
+    cols[3] = (hi[rng.integers(0, 997, N_ROWS)] << 32) | rng.permutation(N_ROWS).astype(np.int64)
+    infos = check_sort(unique_keys(cols), (2 + 16, 1 + 16), "config #5, colliding high halves")
+    assert infos[-1][0]["sort_passes"] >= 8, infos
+
+
+def test_config5_sort_pairs_form_and_column_gathers():
+    # the other payload forms of the same query: (key, row id) pairs through the hybrid passes, and column-by-column gathers
+    cols = unique_keys(bench.host_columns(np, "wide", N_ROWS, seed=9))
+    check_sort(cols, (1,), "config #5, (key, row id) pairs", sort_compact=0)
+    check_sort(cols, (0, 1), "config #5, column gathers", sort_records=0)
