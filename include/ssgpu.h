@@ -306,8 +306,9 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *   Filter:                 filter_single_pass (1 = decoupled look-back instead of count + store passes)
  *   GroupAggregate:         group_capacity (initial table), group_local (0 = no LDS table in front of the global one),
  *                           group_partition (0 never / 1 by run feedback / 2 always hash-partitioned), group_slab (0 never /
- *                           1 by estimate / 2 always the one-table-per-CU form), part_n, part_wgs_per_cu, part_lds_target,
- *                           part_agg_lds, part_rec_align
+ *                           1 by estimate / 2 always the one-table-per-CU form), part_plain (0 = the partition scatter always as
+ *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
+ *                           part_rec_align
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),
  *                           sort_hi_digits (2..4, 0 = by row count), sort_compact (0 = (key, row id) pairs instead of one
  *                           (high half | row id) word)
@@ -438,8 +439,10 @@ typedef struct ssgpu_stage_info {
   int32_t sort_passes;      /* radix passes of the last run */
   int32_t sort_mode;        /* 0 LSD over the varying digits, 1 high digits + tie fix-up, 2 one-word (high half | row id) keys;
                                +16: tie runs were too long and all digits were sorted after all */
-  int32_t specialized;      /* bit 0 the stage's program, bit 1 the partition scatter, bit 2 the partition aggregation */
-  int32_t reserved[7];
+  int32_t specialized;      /* bit 0 the stage's program, bit 1 the partition-scatter program, bit 2 the partition aggregation,
+                               bit 3 the plain partition scatter */
+  int32_t plain_scatter;    /* the partition scatter ran as its own kernel over (partition, XCD) segments, not as a VM program */
+  int32_t reserved[6];
 } ssgpu_stage_info;
 int32_t ssgpu_plan_stage_count(const ssgpu_plan* plan);
 int ssgpu_plan_stage_info(const ssgpu_plan* plan, int32_t stage, ssgpu_stage_info* out);

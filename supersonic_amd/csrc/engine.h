@@ -146,6 +146,16 @@ struct Stage {
   struct PartAgg { int op; int val_off; int val_width; int null_off; int has_cnt; int word; };
   std::vector<PartAgg> part_aggs;         // one per aggregate: GAGG opcode, byte offsets of its value / NULL flag in the
                                           // record (-1 = none), first accumulator word in the group table
+  // The same scatter as a kernel of its own (ssgpu_part_scatter_plain_kernel) when the stage is "plain": every group key and
+  // every aggregate input is an input column as it stands (no cast, no expression), every Filter below the aggregate is
+  // `column CMP constant`, and there is no join.  Record layout = part_scatter's, so phase 2 is the same kernel.
+  struct PlainScatter {
+    bool ok = false;
+    struct Key { int col; uint32_t width, shift, bits, nullbit; bool nullable; };
+    struct Field { int col; bool is_null_mask; uint32_t width, off; };
+    struct Pred { int col; int kind /* 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64 */; int cmp /* 0 <, 1 <=, 2 ==, 3 != */; bool col_on_left; bool nullable; uint64_t bits; };
+    std::vector<Key> keys; std::vector<Field> fields; std::vector<Pred> preds;
+  } plain;
   std::vector<JoinSpec> joins;            // HashJoins fused into this stage's programs
   std::vector<SortKey> sort_keys;         // SORT / CLUSTERS (columns of in_schema)
   std::vector<int> sort_out_cols;         // SORT: projected input columns

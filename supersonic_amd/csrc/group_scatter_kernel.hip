@@ -1,0 +1,220 @@
+// group_scatter_kernel.hip -- the partition scatter of a "plain" GroupAggregate stage as a kernel of its own.
+//
+// A translation unit of its own because it is compiled WITHOUT -structurizecfg-skip-uniform-regions (the tile VM's
+// kernels need that flag for their uniform opcode switch): this kernel's control flow is divergent by nature -- rows
+// that a predicate drops sit in random lanes -- and with the flag it produced wrong partitions as soon as a Filter
+// dropped rows (uniform loops nested in divergent regions were left unstructurized).
+//
+// Specialised by runtime compilation for plans that ask for it (rtc.cpp: ssgpu_rtc_specialize_pscat, -DSSGPU_RTC_PSCAT):
+// the key packing, the record's field list, the predicates, the record size and the LDS carve-up are constants of
+// rtc_pscat.h, every descriptor loop is unrolled and its kernel-argument reads fold away; only the column pointers stay
+// run-time values.
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#endif
+#include "vm.h"
+#include "launch.h"
+#ifdef SSGPU_RTC_PSCAT
+#include "rtc_pscat.h"   // kPsNKeys, kPsKey{Width,Shift,Bits,Nullbit}[], kPsNFields, kPsField{Width,Off}[], kPsNPreds, kPsPred{Kind,Cmp,ColLeft}[],
+                         // kPsRecWords, kPsRecInv, kPsNParts, kPsRows, kPsLdsBytes
+#define PS_NKEYS kPsNKeys
+#define PS_KEY_WIDTH(k) kPsKeyWidth[k]
+#define PS_KEY_SHIFT(k) kPsKeyShift[k]
+#define PS_KEY_BITS(k) kPsKeyBits[k]
+#define PS_KEY_NULLBIT(k) kPsKeyNullbit[k]
+#define PS_NFIELDS kPsNFields
+#define PS_FIELD_WIDTH(f) kPsFieldWidth[f]
+#define PS_FIELD_OFF(f) kPsFieldOff[f]
+#define PS_NPREDS kPsNPreds
+#define PS_PRED_KIND(q) kPsPredKind[q]
+#define PS_PRED_CMP(q) kPsPredCmp[q]
+#define PS_PRED_COL_LEFT(q) (kPsPredColLeft[q] != 0u)
+#define PS_REC_WORDS kPsRecWords
+#define PS_REC_INV kPsRecInv
+#define PS_NPARTS kPsNParts
+#define PS_UNROLL _Pragma("unroll")
+#else
+#define PS_NKEYS P.n_keys
+#define PS_KEY_WIDTH(k) P.keys[k].width
+#define PS_KEY_SHIFT(k) P.keys[k].shift
+#define PS_KEY_BITS(k) P.keys[k].bits
+#define PS_KEY_NULLBIT(k) P.keys[k].nullbit
+#define PS_NFIELDS P.n_fields
+#define PS_FIELD_WIDTH(f) P.fields[f].width
+#define PS_FIELD_OFF(f) P.fields[f].off
+#define PS_NPREDS P.n_preds
+#define PS_PRED_KIND(q) P.preds[q].kind
+#define PS_PRED_CMP(q) P.preds[q].cmp
+#define PS_PRED_COL_LEFT(q) (P.preds[q].col_on_left != 0u)
+#define PS_REC_WORDS P.rec_words
+#define PS_REC_INV P.rec_inv
+#define PS_NPARTS P.n_parts
+#define PS_UNROLL
+#endif
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int u32;
+typedef int i32;
+typedef unsigned char u8;
+__device__ __forceinline__ double u2d(u64 v) { return __longlong_as_double((i64)v); }
+// The hash partition of a packed key.  Any function of the key would be correct (phase 2 only needs equal keys in one
+// partition); this is pipeline_kernels.hip's part_of, whose high bits are decorrelated from the in-table home slot.
+__device__ __forceinline__ u32 hash_local(u64 key) {
+  u32 h = (u32)key ^ ((u32)(key >> 32) * 0x9E3779B1u);
+  h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+  return h;
+}
+__device__ __forceinline__ u32 part_of(u64 key, u32 n_parts) {
+  u32 h = hash_local(key) * 0x2C1B3C6Du; h ^= h >> 16;
+  return __umulhi(h * 0x297A2D39u, n_parts);
+}
+
+// ---------------------------------------------------------------------------
+// Partitioned GroupAggregate, phase 1 for plain stages (PlainScatterParams in launch.h; reference loop being replaced:
+// the per-row insert of cursor/core/aggregate_groups.cc:342-371 -> row_hash_set.cc:458-517).
+// Per tile of THREADS x R rows:  (1) every thread loads its rows' predicate and key columns, packs the key exactly as
+// KEY_APPEND_* do, and takes a rank inside its partition with one returning LDS atomic; the first 8-byte fields of the
+// record are fetched into registers meanwhile;  (2) one global atomic per (partition with rows, tile) reserves the tile's
+// run in the segment of (partition, this workgroup's XCD), while wave 0 scans the per-partition counts into staging
+// offsets;  (3) records are assembled in LDS in partition order;  (4) the staged words leave with consecutive lanes on
+// consecutive 8-byte words: a partition's run is one contiguous piece of its segment.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool pscat_pred(const void* data, const u8* nulls, u64 c, u32 kind, u32 cmp, bool col_on_left, u64 row) {
+  const bool is_null = nulls ? nulls[row] != 0 : false;    // a NULL predicate drops the row (filter.cc:170-199)
+  bool lt, gt, eq;   // column < constant, column > constant, column == constant
+  switch (kind) {
+    case 0: { const i32 v = reinterpret_cast<const i32*>(data)[row], k = (i32)(u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 1: { const u32 v = reinterpret_cast<const u32*>(data)[row], k = (u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 2: { const i64 v = reinterpret_cast<const i64*>(data)[row], k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 3: { const u64 v = reinterpret_cast<const u64*>(data)[row], k = c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 4: { const float v = reinterpret_cast<const float*>(data)[row], k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    default: { const double v = reinterpret_cast<const double*>(data)[row], k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
+  }
+  bool r;
+  switch (cmp) {
+    case 0: r = col_on_left ? lt : gt; break;                  // col < k   |  k < col   (a NaN compares false either way)
+    case 1: r = col_on_left ? (lt || eq) : (gt || eq); break;  // col <= k  |  k <= col
+    case 2: r = eq; break;
+    default: r = !eq; break;
+  }
+  return r && !is_null;
+}
+
+template <int R>
+__global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_kernel(const PlainScatterParams P) {
+  constexpr u32 THREADS = SSGPU_PSCAT_THREADS, T = THREADS * R, REGF = 6;
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const u32 NP = PS_NPARTS, cap = P.seg_cap, wpr = PS_REC_WORDS, rb = wpr * 8u;
+  const u32 xcd = blockIdx.x & (SSGPU_PSCAT_XCDS - 1u);
+  // LDS: per-partition counts of the tile | global base of the tile's run | staging
+  // offset of the run | global record index by staging position | the staged records
+#ifdef SSGPU_RTC_PSCAT
+  __shared__ __attribute__((aligned(16))) char pscat_lds[kPsLdsBytes];   // (a module-loaded kernel cannot ask for > 64 KiB of dynamic LDS)
+#else
+  extern __shared__ __attribute__((aligned(16))) char pscat_lds[];
+#endif
+  u32* const cnt = reinterpret_cast<u32*>(pscat_lds);
+  u32* const gbase = cnt + NP;
+  u32* const start = gbase + NP;
+  u32* const grec = start + NP + 2u;   // start[NP] = the tile's record count (+ one word of padding: the records stay 8-byte aligned)
+  char* const stage = reinterpret_cast<char*>(grec + T);
+  for (u32 i = t; i < NP; i += THREADS) cnt[i] = 0u;
+  __syncthreads();
+  const u64 n = P.n_rows, n_tiles = (n + T - 1) / T;
+  const u32 nf = PS_NFIELDS;
+  for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const u64 base = tile * T;
+    u64 key[R]; u64 fv[R][REGF]; u32 pt[R], pos[R]; bool ok[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const u64 row = base + (u64)j * THREADS + t;
+      ok[j] = row < n;
+      const u64 rowc = ok[j] ? row : 0ull;   // (every load below is unconditional: loops over descriptors stay out of divergent regions)
+      PS_UNROLL for (u32 q = 0; q < PS_NPREDS; ++q)
+        ok[j] = ok[j] & pscat_pred(P.preds[q].data, P.preds[q].nulls, P.preds[q].bits, PS_PRED_KIND(q), PS_PRED_CMP(q), PS_PRED_COL_LEFT(q), rowc);
+      key[j] = 0ull;
+      PS_UNROLL for (u32 k = 0; k < PS_NKEYS; ++k) {
+        const u32 kw = PS_KEY_WIDTH(k), kbits = PS_KEY_BITS(k), kshift = PS_KEY_SHIFT(k);
+        u64 a = kw == 8 ? reinterpret_cast<const u64*>(P.keys[k].data)[rowc] : kw == 4 ? (u64)reinterpret_cast<const u32*>(P.keys[k].data)[rowc]
+                                                                                       : (u64)reinterpret_cast<const u8*>(P.keys[k].data)[rowc];
+        a &= kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+        if (P.keys[k].nulls && P.keys[k].nulls[rowc]) a = 1ull << (PS_KEY_NULLBIT(k) - kshift);
+        key[j] |= a << kshift;
+      }
+#pragma unroll
+      for (u32 f = 0; f < REGF; ++f)   // the leading 8-byte fields travel through registers: their loads are in flight during the ranking
+        fv[j][f] = (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u && P.fields[f].src) ? reinterpret_cast<const u64*>(P.fields[f].src)[rowc] : 0ull;
+      pt[j] = part_of(key[j], NP);
+      pos[j] = 0u;
+      if (ok[j]) pos[j] = atomicAdd(&cnt[pt[j]], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {   // staging offsets: exclusive scan of the tile's per-partition counts
+      const u32 per = (NP + 63u) / 64u;
+      u32 s = 0;
+      for (u32 i = 0; i < per; ++i) { const u32 q = lane * per + i; if (q < NP) s += cnt[q]; }
+      u32 inc = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if (lane >= (u32)d) inc += o; }
+      u32 ex = inc - s;
+      for (u32 i = 0; i < per; ++i) { const u32 q = lane * per + i; if (q < NP) { start[q] = ex; ex += cnt[q]; } }
+      if (lane == 63u) start[NP] = ex;   // the tile's record count
+    } else {           // reserve every partition's run in its (partition, XCD) segment
+      for (u32 i = t - 64u; i < NP; i += THREADS - 64u) { const u32 c = cnt[i]; gbase[i] = c ? atomicAdd(&P.counts[i * SSGPU_PSCAT_XCDS + xcd], c) : 0u; }
+    }
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const u64 row = base + (u64)j * THREADS + t;
+      const u64 rowc = ok[j] ? row : 0ull;
+      const u32 s = ok[j] ? start[pt[j]] + pos[j] : 0u, g = gbase[pt[j]] + pos[j];
+      if (ok[j]) { if (g < cap) grec[s] = (pt[j] * SSGPU_PSCAT_XCDS + xcd) * cap + g; else { grec[s] = VM_NONE; over = true; } }
+      char* r = stage + (size_t)s * rb;
+      if (ok[j]) *reinterpret_cast<u64*>(r) = key[j];
+#pragma unroll
+      for (u32 f = 0; f < REGF; ++f) if (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u) { if (ok[j]) *reinterpret_cast<u64*>(r + PS_FIELD_OFF(f < nf ? f : 0u)) = fv[j][f]; }
+      PS_UNROLL for (u32 f = 0; f < nf; ++f) {
+        const u32 fw = PS_FIELD_WIDTH(f), fo = PS_FIELD_OFF(f);
+        const void* src = P.fields[f].src;
+        if (fw == 8u) { if (f >= REGF) { const u64 v = src ? reinterpret_cast<const u64*>(src)[rowc] : 0ull; if (ok[j]) *reinterpret_cast<u64*>(r + fo) = v; } }
+        else if (fw == 4u) { const u32 v = src ? reinterpret_cast<const u32*>(src)[rowc] : 0u; if (ok[j]) *reinterpret_cast<u32*>(r + fo) = v; }
+        else { const u8 v = src ? reinterpret_cast<const u8*>(src)[rowc] : (u8)0; if (ok[j]) *reinterpret_cast<u8*>(r + fo) = v; }
+      }
+    }
+    if (over) atomicExch(P.overflow, 1u);
+    for (u32 i = t; i < NP; i += THREADS) cnt[i] = 0u;   // (read last before the barrier above; next written after the one below)
+    __syncthreads();
+    const u32 words = start[NP] * wpr;
+    const u64* sw = reinterpret_cast<const u64*>(stage);
+    for (u32 w = t; w < words; w += THREADS) {
+      const u32 j = __umulhi(w, PS_REC_INV), f = w - j * wpr;
+      const u32 g = grec[j];
+      if (g != VM_NONE) P.recs[(u64)g * wpr + f] = sw[w];
+    }
+    // (no barrier here: the next tile's staging writes come after two more barriers, which every wave reaches only
+    //  after its part of this flush)
+  }
+}
+
+#ifndef __HIPCC_RTC__
+unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread) {
+  const unsigned int T = SSGPU_PSCAT_THREADS * (unsigned)rows_per_thread;
+  return (3u * n_parts + 2u + T) * 4u + 16u + T * rec_words * 8u;
+}
+hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const unsigned int lds2 = ssgpu_part_scatter_plain_lds(P.n_parts, P.rec_words, 2), lds1 = ssgpu_part_scatter_plain_lds(P.n_parts, P.rec_words, 1);
+  if (lds2 <= 156u * 1024u) hipLaunchKernelGGL(ssgpu_part_scatter_plain_kernel<2>, dim3((unsigned)grid), dim3(SSGPU_PSCAT_THREADS), lds2, stream, P);
+  else if (lds1 <= 156u * 1024u) hipLaunchKernelGGL(ssgpu_part_scatter_plain_kernel<1>, dim3((unsigned)grid), dim3(SSGPU_PSCAT_THREADS), lds1, stream, P);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+#endif  // !__HIPCC_RTC__

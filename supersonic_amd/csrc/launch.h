@@ -63,6 +63,31 @@ struct PartAggParams {
   unsigned long long desc[VM_MAX_AGG_SLOTS];
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
+
+// Partitioned GroupAggregate, first phase as a kernel of its own (not a tile-VM program) for "plain" stages: records are
+// assembled straight from the input columns.  One 1024-thread workgroup per CU takes tiles of 2048 (1024) rows, ranks
+// them by hash partition in LDS, stages the records in partition order and appends every partition's run of the tile to
+// the segment of (partition, XCD) with ONE global atomic -- the workgroups of an XCD share a segment, so the lines being
+// written at any time are few and complete inside that XCD's L2 instead of being evicted half-written (with one segment
+// per (partition, workgroup) the open lines exceed the L2 and the pass runs at the part's scattered-write rate).
+#define SSGPU_PSCAT_THREADS 1024
+#define SSGPU_PSCAT_XCDS 8
+#define SSGPU_PSCAT_MAX_KEYS 8
+#define SSGPU_PSCAT_MAX_FIELDS 24
+#define SSGPU_PSCAT_MAX_PREDS 4
+struct PlainScatterParams {
+  unsigned long long n_rows;
+  unsigned int n_parts, seg_cap, rec_words, rec_inv;   // rec_inv = floor(2^32 / rec_words) + 1
+  unsigned int n_keys, n_fields, n_preds, pad;
+  struct Key { const void* data; const unsigned char* nulls; unsigned int width, shift, bits, nullbit; } keys[SSGPU_PSCAT_MAX_KEYS];
+  struct Field { const void* src; unsigned int width, off; } fields[SSGPU_PSCAT_MAX_FIELDS];   // src NULL: an absent NULL mask (zeros)
+  struct Pred { const void* data; const unsigned char* nulls; unsigned int kind, cmp, col_on_left, pad; unsigned long long bits; } preds[SSGPU_PSCAT_MAX_PREDS];
+  unsigned long long* recs;     // n_parts * SSGPU_PSCAT_XCDS segments of seg_cap records
+  unsigned int* counts;         // [n_parts * SSGPU_PSCAT_XCDS] records appended to each segment; zero at launch
+  unsigned int* overflow;       // set when a segment ran full
+};
+hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid, hipStream_t stream);
+unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread);
 hipError_t ssgpu_part_agg_set_max_lds(int bytes);
 
 // HashJoin index over the rhs table: packed 64-bit key (same packing as the lhs KEY_APPEND
@@ -108,6 +133,8 @@ hipError_t ssgpu_launch_pipeline_rtc(void* handle, const VmParams& P, int grid, 
 void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
                                     unsigned int lds_bytes, std::string* why);
 hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
+void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int rows_per_thread, unsigned int lds_bytes, std::string* why);
+hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterParams& P, int grid, hipStream_t stream);
 void* ssgpu_rtc_function(void* handle);
 void ssgpu_rtc_release(void* handle);
 void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations);

@@ -1406,6 +1406,40 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
   { const uint32_t wpr = st->part_rec_bytes / 8u;   // imm = words per record | (floor(2^32 / wpr) + 1) << 32
     LInstr& i = em.emit(VM_PART_FLUSH); i.dst_is_reg = false; i.dst = 0; i.imm = (uint64_t)wpr | ((uint64_t)(uint32_t)(0x100000000ull / wpr + 1ull) << 32); }
   st->part_scatter.n_outputs = 1;
+  // ---- the plain form of the same pass (Stage::PlainScatter): sources of the record's fields, key columns, predicates ----
+  {
+    Stage::PlainScatter pl;
+    pl.ok = pipe.joins.empty() && kpos.size() <= 8 && fields.size() <= 24 && pipe.filters.size() <= 4;
+    std::map<int, std::pair<int, bool>> staged_of_reg;   // register -> (input column, is NULL mask)
+    for (auto& sgd : st->part_scatter.staged) staged_of_reg[sgd.reg] = std::make_pair(sgd.col, sgd.is_null_mask);
+    for (size_t k = 0; pl.ok && k < kpos.size(); ++k) {
+      const BExprP& ke = pipe.cols[kpos[k]].expr;
+      const GroupKeyField& f = st->group_keys[k];
+      if (ke->kind != BExpr::INPUT || (uint32_t)dtype_width(ke->dtype) != f.width) { pl.ok = false; break; }
+      pl.keys.push_back(Stage::PlainScatter::Key{ke->input_col, f.width, f.shift, f.bits, f.nullbit, f.nullbit != 0xFF});
+    }
+    for (size_t q = 1; pl.ok && q < fields.size(); ++q) {   // field 0 is the packed key
+      auto it = staged_of_reg.find(fields[q].reg);
+      if (it == staged_of_reg.end() || fields[q].off < 0) { pl.ok = false; break; }
+      const int col = it->second.first;
+      if (!it->second.second && (uint32_t)dtype_width(pipe.in_schema[col].dtype) != fields[q].width) { pl.ok = false; break; }
+      pl.fields.push_back(Stage::PlainScatter::Field{col, it->second.second, fields[q].width, (uint32_t)fields[q].off});
+    }
+    for (size_t q = 0; pl.ok && q < pipe.filters.size(); ++q) {
+      const BExprP& e = pipe.filters[q];
+      if (e->kind != BExpr::OP || e->args.size() != 2 || !(e->op == OP_LESS || e->op == OP_LESS_OR_EQUAL || e->op == OP_EQUAL || e->op == OP_NOT_EQUAL)) { pl.ok = false; break; }
+      const bool col_left = e->args[0]->kind == BExpr::INPUT && e->args[1]->kind == BExpr::CONST;
+      const bool col_right = e->args[1]->kind == BExpr::INPUT && e->args[0]->kind == BExpr::CONST;
+      if (!col_left && !col_right) { pl.ok = false; break; }
+      const BExprP& ce = e->args[col_left ? 0 : 1]; const BExprP& ke = e->args[col_left ? 1 : 0];
+      const MT m = mtype(ce->dtype);
+      if (m != mtype(ke->dtype) || !(m == M_I32 || m == M_U32 || m == M_I64 || m == M_U64 || m == M_F32 || m == M_F64)) { pl.ok = false; break; }
+      pl.preds.push_back(Stage::PlainScatter::Pred{ce->input_col, (int)m, e->op == OP_LESS ? 0 : e->op == OP_LESS_OR_EQUAL ? 1 : e->op == OP_EQUAL ? 2 : 3,
+                                                   col_left, ce->nullable, ke->bits});
+    }
+    if (!pl.ok) { pl.keys.clear(); pl.fields.clear(); pl.preds.clear(); }
+    st->plain = pl;
+  }
   allocate_registers(&st->part_scatter);
   return Status::OK();
 }
@@ -1833,6 +1867,16 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
     desc << "stage " << i << " kind=" << (*stages)[i].kind << "\n" << disassemble((*stages)[i].main);
     if (!(*stages)[i].count_pass.empty()) desc << " count pass:\n" << disassemble((*stages)[i].count_pass);
     if (!(*stages)[i].part_scatter.empty()) desc << " partition scatter pass:\n" << disassemble((*stages)[i].part_scatter);
+    if ((*stages)[i].plain.ok) {
+      const Stage::PlainScatter& pl = (*stages)[i].plain;
+      desc << " plain partition scatter: keys";
+      for (auto& k : pl.keys) desc << " col" << k.col << "(w" << k.width << " <<" << k.shift << (k.nullable ? " nullable" : "") << ")";
+      desc << " | fields";
+      for (auto& f : pl.fields) desc << " col" << f.col << (f.is_null_mask ? ".null" : "") << "(w" << f.width << ")@" << f.off;
+      desc << " | predicates";
+      for (auto& q : pl.preds) desc << " " << (q.col_on_left ? "col" : "const") << " cmp" << q.cmp << " " << (q.col_on_left ? "const" : "col") << " [col" << q.col << " kind " << q.kind << " bits " << q.bits << "]";
+      desc << "\n";
+    }
   }
   *describe = desc.str();
   return Status::OK();

@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (any_cnt) lcnt[i] = 0u; }
   u32 total = 0;
   {
-    const u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
+    u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
+    n = n < P.seg_cap ? n : P.seg_cap;   // (a segment that ran full: the plain scatter's counter keeps counting; the host reruns with larger segments)
     const u32 ex = part_block_scan(n, wsum, t, &total);
     if (t < G) segoff[t] = ex;
     if (t == 0) segoff[G] = total;
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
           lkeys[C] = 0ull;                               // marks the reserved entry as used
         } else {
           u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
-          const int probe_limit = P.slab_segs ? (int)C : 16;   // hash partitions: a longer cluster = the table is too full, the host re-partitions finer
+          const int probe_limit = P.slab_segs ? (int)C : 32;   // hash partitions: a longer cluster = the table is too full, the host re-partitions finer
           for (int probe = 0; probe < probe_limit; ++probe) {
             const u64 cur = __hip_atomic_load(lkeys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (cur == key) { found = i; break; }

@@ -51,6 +51,7 @@ struct ssgpu_ctx {
   int64_t sort_records = 1;      // 0: always gather payload columns one by one
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
   int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
+  int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
   int64_t sort_hi_digits = 4;    // high digits the hybrid sort passes over before fixing ties: 2..4, 0 = by row count
@@ -156,6 +157,7 @@ struct StageExec {
   ProgramLayout lay_pscatter{};
   int n_instr_pscatter = 0;
   RtcSlot rtc_pscatter; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
+  RtcSlot rtc_plain;            // ssgpu_part_scatter_plain_kernel specialised for this stage's record and a partition count (static_lds = its LDS size)
   RtcSlot rtc_part;             // ssgpu_part_agg_kernel specialised for this stage's aggregates and an LDS size (static_lds)
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
@@ -179,6 +181,7 @@ struct StageExec {
   int last_group_shape = 0;     // 0 direct, 1 hash partitions, 2 slab
   int last_reruns = 0;          // attempts beyond the first (regrown table / segments / partitions)
   int last_sort_passes = 0, last_sort_mode = 0;
+  bool last_plain_scatter = false;
 };
 
 struct ssgpu_result {
@@ -299,6 +302,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_agg_lds") c->part_agg_lds = value;
   else if (k == "part_agg_debug") c->part_agg_debug = value;
   else if (k == "group_slab") c->group_slab = value;
+  else if (k == "part_plain") c->part_plain = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
   else if (k == "sort_records") c->sort_records = value;
   else if (k == "sort_hybrid") c->sort_hybrid = value;
@@ -554,7 +558,7 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   }
   // the stream is drained: no launch of this plan's specialised kernels is in flight -- drop the references (the
   // module of a kernel no other plan uses is unloaded, rtc.cpp)
-  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_part.drop(); }
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); }
   ssgpu_ctx* c = p->ctx;
   g_live_plans.fetch_sub(1);
   delete p;
@@ -1161,7 +1165,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (c->part_n > 0) ex.part_n = (uint32_t)c->part_n;
     else {
       uint32_t pn = 256;
-      while (ex.part_groups_est > 0.3 * (double)pn * (double)C && pn < 8192) pn *= 2;   // (the estimate is a lower bound: keep the load under one half)
+      // (the estimate is a lower bound: keep the load under one half.  The plain scatter gets faster with fewer partitions --
+      //  fewer lines open per L2 -- and phase 2 does not mind a fuller table: it may load its tables a little more.)
+      const double load = st.plain.ok && c->part_plain ? 0.4 : 0.3;
+      while (ex.part_groups_est > load * (double)pn * (double)C && pn < 8192) pn *= 2;
       ex.part_n = pn;
     }
   }
@@ -1169,6 +1176,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     const bool slab = ex.part_slab;
     const uint32_t NP = slab ? 1u : ex.part_n;
     ex.last_group_shape = slab ? 2 : 1; if (attempt) ++ex.last_reruns;
+    ex.last_plain_scatter = false;
     uint32_t capacity = NP * C;
     if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
     const size_t slots = (size_t)capacity + 1;
@@ -1189,10 +1197,18 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       grid = std::min(grid_for(c, Ls, Ps.n_tiles), 1024);   // phase 2 scans a partition's segment counts with one thread each
       c->wgs_per_cu = saved;
     }
+    // plain stages: the scatter is a kernel of its own over (partition, XCD) segments (ssgpu_part_scatter_plain_kernel)
+    const uint32_t W0 = st.part_rec_bytes / 8u;
+    const bool plain = !slab && st.plain.ok && c->part_plain != 0 && !Ps.debug_pc && NP >= 2u && in.rows >= (1 << 16) &&
+                       ssgpu_part_scatter_plain_lds(NP, W0, 1) <= 156u * 1024u;
+    const int scatter_grid = grid;
+    if (plain) grid = SSGPU_PSCAT_XCDS;   // from here on `grid` is the number of segments per partition
+    ex.last_plain_scatter = plain;
     // records a (partition, workgroup) segment holds: the expected share of the INPUT rows (an upper bound of the
     // selected ones) with head room for the spread of a uniform hash, times the growth factor of earlier overflows
     const double expect = (double)std::max<int64_t>(in.rows, 1) / ((double)NP * (double)grid);
     uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
+    if (plain) seg_cap = (uint64_t)((expect * 1.3 + 8.0 * std::sqrt(expect) + 64.0) * (double)ex.part_seg_growth);   // (partitions differ by their group counts, too)
     if (slab) seg_cap = (uint64_t)((Ps.n_tiles + grid - 1) / grid) * (uint64_t)Ps.tile_rows;   // all rows a workgroup can see: never full
     const uint64_t n_segs = (uint64_t)NP * (uint64_t)grid;
     if (n_segs * seg_cap >= 0xFFFFFFFFull) { *fallback = true; return SSGPU_OK; }   // record indices are 32-bit
@@ -1219,14 +1235,53 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.part_pad = (uint32_t)c->part_scatter_debug;
     Ps.part_overflow = ex.goverflow.as<unsigned int>() + 1;
     Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
-    { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
+    if (!plain) { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    {
+    if (plain) {
+      PlainScatterParams S; memset(&S, 0, sizeof(S));
+      S.n_rows = (unsigned long long)in.rows; S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
+      S.n_keys = (uint32_t)st.plain.keys.size(); S.n_fields = (uint32_t)st.plain.fields.size(); S.n_preds = (uint32_t)st.plain.preds.size();
+      for (size_t k = 0; k < st.plain.keys.size(); ++k) {
+        const auto& K = st.plain.keys[k];
+        S.keys[k].data = in.cols[K.col].data; S.keys[k].nulls = K.nullable ? in.cols[K.col].is_null : nullptr;
+        S.keys[k].width = K.width; S.keys[k].shift = K.shift; S.keys[k].bits = K.bits; S.keys[k].nullbit = K.nullbit;
+      }
+      for (size_t f = 0; f < st.plain.fields.size(); ++f) {
+        const auto& F = st.plain.fields[f];
+        S.fields[f].src = F.is_null_mask ? (const void*)in.cols[F.col].is_null : in.cols[F.col].data; S.fields[f].width = F.width; S.fields[f].off = F.off;
+      }
+      for (size_t q = 0; q < st.plain.preds.size(); ++q) {
+        const auto& Q = st.plain.preds[q];
+        S.preds[q].data = in.cols[Q.col].data; S.preds[q].nulls = Q.nullable ? in.cols[Q.col].is_null : nullptr;
+        S.preds[q].kind = (uint32_t)Q.kind; S.preds[q].cmp = (uint32_t)Q.cmp; S.preds[q].col_on_left = Q.col_on_left ? 1u : 0u; S.preds[q].bits = Q.bits;
+      }
+      S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
+      HIP_TRY(c, hipMemsetAsync(ex.part_hist.p, 0, n_segs * 4, c->stream));
+      // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
+      const int pgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 1023) / 1024));
+      // the specialised build (plans that asked): one per (descriptor, partition count) -- the LDS carve-up is static in it
+      void* hs = nullptr;
+      if (p->specialize) {
+        const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
+        const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
+        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds)) {
+          if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
+          ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds;
+          std::string why;
+          ex.rtc_plain.h = ssgpu_rtc_specialize_pscat(c->device, S, R, lds, &why);
+          if (!ex.rtc_plain.h && ex.rtc_why.empty()) ex.rtc_why = "plain partition scatter: " + why;
+        }
+        hs = ex.rtc_plain.h;
+      }
+      if (hs) HIP_TRY(c, ssgpu_launch_part_scatter_plain_rtc(hs, S, pgrid, c->stream));
+      else HIP_TRY(c, ssgpu_launch_part_scatter_plain(S, pgrid, c->stream));
+      (void)scatter_grid;
+    } else {
       void* h = Ps.debug_pc ? nullptr : rtc_for(p, ex, ex.rtc_pscatter, st.part_scatter, ex.lay_pscatter, ex.host_prog_pscatter, ex.n_instr_pscatter, Ps.lds_bytes, "partition scatter: ");
       if (h) HIP_TRY(c, ssgpu_launch_pipeline_rtc(h, Ps, grid, ex.rtc_pscatter.static_lds != 0, c->stream));
       else HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
     }
-    { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
+    if (!plain) { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
     PartAggParams A;
     memset(&A, 0, sizeof(A));
     A.recs = ex.part_recs.as<unsigned long long>();
@@ -1295,7 +1350,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     ex.group_partitioned = false; ex.group_local = true; ex.part_failed = true;
   }
   if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
-  ex.last_group_shape = 0;
+  ex.last_group_shape = 0; ex.last_plain_scatter = false;
   for (int attempt = 0; attempt < 8; ++attempt) {
     if (attempt) ++ex.last_reruns;
     const size_t slots = (size_t)ex.capacity + 1;
@@ -1887,7 +1942,7 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
 int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
   if (!p) return 0;
   int32_t n = 0;
-  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0);
+  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_plain.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0);
   return n;
 }
 const char* ssgpu_plan_specialize_reason(const ssgpu_plan* p) {
@@ -1922,7 +1977,8 @@ int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* 
   out->group_shape = ex.last_group_shape; out->part_n = (int32_t)ex.part_n; out->part_seg_growth = (int32_t)ex.part_seg_growth;
   out->group_wgs_per_cu = ex.group_wgs; out->reruns = ex.last_reruns;
   out->sort_passes = ex.last_sort_passes; out->sort_mode = ex.last_sort_mode;
-  out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0);
+  out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0) + (ex.rtc_plain.h ? 8 : 0);
+  out->plain_scatter = ex.last_plain_scatter ? 1 : 0;
   return SSGPU_OK;
 }
 int ssgpu_memory_stats(ssgpu_memory_stats_t* out) {

@@ -105,25 +105,31 @@ def test_config3_group_aggregate_by_run_feedback(group3):
     assert shapes[0] == 0 and shapes[-1] == 1, shapes
 
 
-def test_config3_partitioned_with_both_specialised_kernels(group3):
+@pytest.mark.parametrize("part_plain", [1, 0])
+def test_config3_partitioned_with_specialised_kernels(group3, part_plain):
+    # part_plain=1 (default): the scatter is ssgpu_part_scatter_plain_kernel over (partition, XCD) segments -- config #3 is a
+    # "plain" stage (keys and aggregate inputs are input columns); part_plain=0: the scatter as a tile-VM program
     _view, op, _s, want = group3
-    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=1))
-    infos = check_plan(plan, want, "config #3 partitioned + specialised", ignore_order=True, runs=2)
+    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=1, part_plain=part_plain))
+    infos = check_plan(plan, want, "config #3 partitioned + specialised, part_plain=%d" % part_plain, ignore_order=True, runs=2)
     assert infos[-1][0]["group_shape"] == 1 and infos[-1][0]["reruns"] == 0, infos
-    assert infos[-1][0]["specialized"] & 6 == 6, plan.specialize_reason()       # partition scatter and partition aggregation
+    assert infos[-1][0]["plain_scatter"] == part_plain, infos
+    want_kernels = 12 if part_plain else 6       # partition aggregation + the plain scatter kernel / the partition-scatter program
+    assert infos[-1][0]["specialized"] & want_kernels == want_kernels, plan.specialize_reason()
 
 
-def test_config3_partitioned_interpreted_and_few_partitions_double(group3):
+@pytest.mark.parametrize("part_plain", [1, 0])
+def test_config3_partitioned_interpreted_and_few_partitions_double(group3, part_plain):
     # 64 partitions x ~1000-entry tables cannot hold 1e5 groups: "partition finer and rerun" until they fit
     _view, op, _s, want = group3
-    plan = ss.Plan(op, make_ctx(group_partition=2, part_n=64))
-    infos = check_plan(plan, want, "config #3, part_n doubling", ignore_order=True, runs=2)
+    plan = ss.Plan(op, make_ctx(group_partition=2, part_n=64, part_plain=part_plain))
+    infos = check_plan(plan, want, "config #3, part_n doubling, part_plain=%d" % part_plain, ignore_order=True, runs=2)
     assert infos[0][0]["reruns"] >= 1 and infos[0][0]["part_n"] > 64, infos
     assert infos[1][0]["reruns"] == 0, infos                                    # the second run starts from what the first learnt
 
 
-@pytest.mark.parametrize("specialize", [0, 1])
-def test_config3_skewed_keys_overflow_their_segments(specialize):
+@pytest.mark.parametrize("specialize,part_plain", [(0, 1), (1, 1), (0, 0)])
+def test_config3_skewed_keys_overflow_their_segments(specialize, part_plain):
     # half of the rows carry ONE (k1, k2) pair: the (partition, workgroup) segments of that pair's partition run full, the
     # stage reruns with 4x larger segments (part_seg_growth) -- same rows as the oracle, both kernel forms
     cols = bench.host_columns(np, "group", N_ROWS, seed=7)
@@ -132,7 +138,7 @@ def test_config3_skewed_keys_overflow_their_segments(specialize):
     cols[2] = np.where(hot, 45, cols[2]).astype(np.int32)
     op = group3_op(ss.View(bench.group_schema(ss), cols))
     _s, want = oracle.run(op)
-    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=specialize))
+    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=specialize, part_plain=part_plain))
     infos = check_plan(plan, want, "config #3 skewed", ignore_order=True, runs=2)
     assert infos[0][0]["part_seg_growth"] > 1 or infos[0][0]["group_shape"] == 0, infos   # grew its segments (or, beyond x64, fell back to the direct shape)
 
@@ -147,6 +153,19 @@ def test_config3_shape_with_few_groups_takes_the_slab_form():
     plan = ss.Plan(op, make_ctx(specialize=1))
     infos = check_plan(plan, want, "config #3 shape, 1000 groups", ignore_order=True, runs=4)
     assert infos[-1][0]["group_shape"] in (0, 2), infos
+
+
+@pytest.mark.parametrize("part_plain", [1, 0])
+def test_config4_per_gpu_query_filter_then_group_aggregate(part_plain):
+    # the per-GPU query of config #4 (`bench.py --query group`): Filter(a > 499) below the GroupAggregate; the plain scatter
+    # evaluates the predicate itself
+    view = ss.View(bench.group_schema(ss), bench.host_columns(np, "group", N_ROWS, seed=21))
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), bench.group_spec(ss), None, bench.group_child(ss, view))
+    _s, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(group_partition=2, part_plain=part_plain))
+    infos = check_plan(plan, want, "config #4 per-GPU query, part_plain=%d" % part_plain, ignore_order=True, runs=2)
+    assert infos[-1][0]["group_shape"] == 1 and infos[-1][0]["plain_scatter"] == part_plain, infos
+    assert infos[-1][0]["part_seg_growth"] == 1, infos      # half of the rows are dropped: no segment comes near its capacity
 
 
 # ---- config #4: row-range-sharded Filter -> GroupAggregate, RCCL exchange of the partial tables ---------------------------
