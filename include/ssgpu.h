@@ -115,6 +115,7 @@ enum { SSGPU_ASCENDING = 0, SSGPU_DESCENDING = 1 };
 enum {
   SSGPU_OK = 0,
   SSGPU_ERROR_UNKNOWN = 100,
+  SSGPU_ERROR_GENERAL_IO_ERROR = 101,   /* file_io.cc: every FileInput / FileOutput failure */
   SSGPU_ERROR_MEMORY_EXCEEDED = 102,
   SSGPU_ERROR_NOT_IMPLEMENTED = 103,
   SSGPU_ERROR_EVALUATION_ERROR = 104,
@@ -247,7 +248,7 @@ typedef struct ssgpu_op {
   int32_t sort_first;
   int32_t sort_n;
   int32_t child2;     /* HASH_JOIN: index of the rhs op (must precede); else unused */
-  int64_t option0;    /* GROUP: max_unique_keys_in_result (0 = unlimited);
+  int64_t option0;    /* GROUP: max_unique_keys_in_result (0 = no limit, n > 0 = limit n, -1 = limit 0; aggregate.h:160-205);
                          SORT: memory limit (ignored: no spill path);
                          SCAN: input index (0 = the plan input, 1 = the auxiliary input);
                          HASH_JOIN: JoinType | KeyUniqueness << 8             */

@@ -38,7 +38,7 @@ enum ColumnOrder { ASCENDING = 0, DESCENDING = 1 };
 enum JoinType { INNER = 0, LEFT_OUTER = 1 };          // supersonic.proto:108-113 (RIGHT/FULL_OUTER: not on device)
 enum KeyUniqueness { NOT_UNIQUE = 0, UNIQUE = 1 };    // supersonic.proto:115-118
 enum ReturnCode {
-  OK = 0, ERROR_UNKNOWN_ERROR = 100, ERROR_MEMORY_EXCEEDED = 102, ERROR_NOT_IMPLEMENTED = 103,
+  OK = 0, ERROR_UNKNOWN_ERROR = 100, ERROR_GENERAL_IO_ERROR = 101, ERROR_MEMORY_EXCEEDED = 102, ERROR_NOT_IMPLEMENTED = 103,
   ERROR_EVALUATION_ERROR = 104, ERROR_TOO_MANY_ROWS = 302, ERROR_ATTRIBUTE_COUNT_MISMATCH = 401,
   ERROR_ATTRIBUTE_TYPE_MISMATCH = 402, ERROR_ATTRIBUTE_MISSING = 403, ERROR_ATTRIBUTE_EXISTS = 404,
   ERROR_INVALID_ARGUMENT_TYPE = 405, ERROR_INVALID_ARGUMENT_VALUE = 407, INTERRUPTED = 1000
@@ -395,10 +395,21 @@ class AggregationSpecification {
   AggregationSpecification* AddAggregationWithDefinedOutputType(Aggregation a, const std::string& in, const std::string& out, DataType t) { elements.push_back({a, in, out, t, false}); return this; }
   std::vector<Element> elements;
 };
+// cursor/core/aggregate.h:160-205.  max_unique_keys_in_result: the result keeps the first (limit + 1) distinct keys in
+// first-seen order and every row with another key is aggregated into the last of those rows (row_hash_set.cc:500-511);
+// default kint64max = no limit.  Memory quota / estimated row count: no device counterpart (tables are sized by run feedback).
 class GroupAggregateOptions {
  public:
-  GroupAggregateOptions() : max_unique_keys_in_result(0) {}
-  int64_t max_unique_keys_in_result;
+  GroupAggregateOptions() : max_unique_keys_in_result_(INT64_MAX) {}
+  int64_t max_unique_keys_in_result() const { return max_unique_keys_in_result_; }
+  GroupAggregateOptions* set_max_unique_keys_in_result_(int64_t n) { max_unique_keys_in_result_ = n; return this; }
+  GroupAggregateOptions* set_memory_quota(size_t) { return this; }
+  GroupAggregateOptions* set_enforce_quota(bool) { return this; }
+  GroupAggregateOptions* set_estimated_result_row_count(int64_t) { return this; }
+  // ssgpu_op.option0: 0 = no limit, n > 0 = limit n, -1 = limit 0
+  int64_t option0() const { return max_unique_keys_in_result_ == INT64_MAX ? 0 : max_unique_keys_in_result_ == 0 ? -1 : max_unique_keys_in_result_; }
+ private:
+  int64_t max_unique_keys_in_result_;
 };
 class SortOrder {
  public:
@@ -941,7 +952,7 @@ inline Operation* Filter(const Expression* predicate, const SingleSourceProjecto
 inline Operation* ScalarAggregate(AggregationSpecification* spec, Operation* child) { return new internal::UnaryOp(SSGPU_OP_SCALAR_AGGREGATE, child, nullptr, nullptr, spec, nullptr); }
 inline Operation* GroupAggregate(const SingleSourceProjector* group_by, const AggregationSpecification* spec, GroupAggregateOptions* options, Operation* child) {
   std::unique_ptr<GroupAggregateOptions> own(options);
-  return new internal::UnaryOp(SSGPU_OP_GROUP_AGGREGATE, child, nullptr, group_by, spec, nullptr, options ? options->max_unique_keys_in_result : 0);
+  return new internal::UnaryOp(SSGPU_OP_GROUP_AGGREGATE, child, nullptr, group_by, spec, nullptr, options ? options->option0() : 0);
 }
 inline Operation* AggregateClusters(const SingleSourceProjector* clustered_by, const AggregationSpecification* spec, Operation* child) { return new internal::UnaryOp(SSGPU_OP_AGGREGATE_CLUSTERS, child, nullptr, clustered_by, spec, nullptr); }
 inline Operation* Sort(const SortOrder* order, const SingleSourceProjector* result_projector, size_t memory_limit, Operation* child) {
@@ -969,7 +980,7 @@ class FileSink : public Sink {
   ~FileSink() override { if (f_) fclose(f_); }
   FailureOr<rowcount_t> Write(const View& v) override {
     static const rowcount_t kMaxChunkRowCount = 8192;   // file_io.cc:70
-    if (!f_) return FailureOr<rowcount_t>(new Exception(ERROR_UNKNOWN_ERROR, "FileOutput: the file is not open"));
+    if (!f_) return FailureOr<rowcount_t>(new Exception(ERROR_GENERAL_IO_ERROR, "Writing view to the output file failed."));
     bool ok = true;
     auto put = [&](const void* p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, f_) == n); };
     for (rowcount_t off = 0; off < v.row_count(); off += kMaxChunkRowCount) {
@@ -993,13 +1004,13 @@ class FileSink : public Sink {
         }
       }
     }
-    if (!ok) return FailureOr<rowcount_t>(new Exception(ERROR_UNKNOWN_ERROR, "Error writing to the output file."));
+    if (!ok) return FailureOr<rowcount_t>(new Exception(ERROR_GENERAL_IO_ERROR, "Writing view to the output file failed."));
     return FailureOr<rowcount_t>(v.row_count());
   }
   FailureOrVoid Finalize() override {
     const bool ok = !f_ || fclose(f_) == 0;
     f_ = nullptr;
-    return ok ? FailureOrVoid() : FailureOrVoid(new Exception(ERROR_UNKNOWN_ERROR, "Error closing the output file."));
+    return ok ? FailureOrVoid() : FailureOrVoid(new Exception(ERROR_GENERAL_IO_ERROR, "Error closing the file."));
   }
  private:
   FILE* f_;

@@ -50,6 +50,7 @@ def lib():
         L.orc_op_add_proj.argtypes = [P, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_op_add_agg.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_op_add_sortkey.argtypes = [P, C.c_char_p, C.c_int]
+        L.orc_op_set_max_unique_keys.argtypes = [P, C.c_int64]
         L.orc_op_set_join.argtypes = [P, P, C.c_int]
         L.orc_op_add_proj_to.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_scan_add_column.argtypes = [P, C.c_char_p, C.c_int, C.c_int, P, P]
@@ -176,6 +177,10 @@ class _Tree(object):
         if kind == 8:
             for (name, order) in o.order.keys:
                 L.orc_op_add_sortkey(h, _enc(name), order)
+        if kind == 6 and getattr(o, "options", None) is not None:
+            limit = o.options.max_unique_keys_in_result        # GroupAggregateOptions (aggregate.h:160-205): kint64max = no limit
+            if limit < (1 << 63) - 1:
+                L.orc_op_set_max_unique_keys(h, int(limit))
         return h
 
 

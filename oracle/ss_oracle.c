@@ -1046,11 +1046,14 @@ typedef struct orc_op {
   /* hash join (cursor/core/hash_join.h:37-56): projs = lhs key selector */
   struct orc_op* child2; orc_proj projs2[ORC_MAX_COLS]; int nproj2; orc_proj projs3[ORC_MAX_COLS]; int nproj3;
   int join_type;
+  /* GroupAggregateOptions::max_unique_keys_in_result (cursor/core/aggregate.h:160-205): < 0 = no limit */
+  int64_t max_unique_keys;
 } orc_op;
 
 orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
-  orc_op* o = (orc_op*)calloc(1, sizeof(orc_op)); o->kind = kind; o->child = child; o->expr = expr; return o;
+  orc_op* o = (orc_op*)calloc(1, sizeof(orc_op)); o->kind = kind; o->child = child; o->expr = expr; o->max_unique_keys = -1; return o;
 }
+void orc_op_set_max_unique_keys(orc_op* o, int64_t limit) { o->max_unique_keys = limit; }
 void orc_op_add_proj(orc_op* o, int kind, int position, const char* name, const char* alias) {
   orc_proj* p = &o->projs[o->nproj++]; p->kind = kind; p->position = position;
   snprintf(p->name, sizeof(p->name), "%s", name ? name : ""); snprintf(p->alias, sizeof(p->alias), "%s", alias ? alias : "");
@@ -1112,7 +1115,7 @@ typedef struct orc_cursor {
   int64_t* ids; int64_t nids, read_ptr; orc_view cur; int have_cur, eos;
   orc_block block;                  /* result block (filter / aggregates / sort) */
   /* aggregates */ agg_col aggs[ORC_MAX_COLS]; int nagg; int done; int64_t out_rows, emit_pos;
-  /* group */ int64_t* bucket_head; int64_t* chain_next; uint64_t* row_hash; int64_t nbuckets;
+  /* group */ int64_t* bucket_head; int64_t* chain_next; uint64_t* row_hash; int64_t nbuckets; int64_t max_unique_keys;
   /* sort */ int sort_pos[16], sort_order[16], nsort; int64_t* perm; void* table;
   orc_view outv;
   /* hash join: rhs fully materialised, lhs streamed (hash_join.cc: LookupIndex + HashJoinCursor) */
@@ -1226,6 +1229,7 @@ orc_cursor* orc_create_cursor(const orc_op* op) {
       if (!bind_projector(op->projs, op->nproj, in, c->proj_pos, names, &c->nproj, &c->err)) return cursor_fail(c);
       for (int i = 0; i < c->nproj; ++i) schema_add(&c->schema, names[i], in->a[c->proj_pos[i]].type, in->a[c->proj_pos[i]].nullable);
       if (!bind_aggs(c, op, in)) return cursor_fail(c);
+      c->max_unique_keys = op->kind == C_GROUP_AGG ? op->max_unique_keys : -1;
       block_init(&c->block, &c->schema, 16);  /* kDefaultResultEstimatedGroupCount, aggregate.h:162 */
     } break;
     case C_HASH_JOIN: {
@@ -1418,6 +1422,9 @@ static int64_t group_insert(orc_cursor* c, const orc_view* v, int64_t i) {
   const uint64_t h = hash_row(c, v, i);
   for (int64_t g = c->bucket_head[h & (uint64_t)(c->nbuckets - 1)]; g >= 0; g = c->chain_next[g])
     if (c->row_hash[g] == h && key_equal(c, v, i, g)) return g;
+  /* row_hash_set.cc:500-511: a key that is not in the set is appended only while the set holds at most
+   * max_unique_keys_in_result rows; after that every unseen key is answered with the LAST row of the set */
+  if (c->max_unique_keys >= 0 && c->out_rows > c->max_unique_keys) return c->out_rows - 1;
   const int64_t g = c->out_rows;
   if (g >= c->block.cap) {  /* Aggregator grows x2 (aggregate_groups.cc:372-402) */
     const int64_t old = c->block.cap; block_grow(&c->block, old * 2);

@@ -18,6 +18,7 @@ ASCENDING, DESCENDING = 0, 1
 
 OK = 0
 ERROR_UNKNOWN = 100
+ERROR_GENERAL_IO_ERROR = 101
 ERROR_MEMORY_EXCEEDED = 102
 ERROR_NOT_IMPLEMENTED = 103
 ERROR_EVALUATION_ERROR = 104

@@ -25,7 +25,7 @@ import numpy as np
 from . import _lib as L
 from ._lib import (INT32, INT64, UINT32, UINT64, FLOAT, DOUBLE, BOOL, DATE, DATETIME, STRING, BINARY,  # noqa: F401
                    NOT_NULLABLE, NULLABLE, SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST, ASCENDING, DESCENDING,
-                   OK, ERROR_UNKNOWN, ERROR_MEMORY_EXCEEDED, ERROR_NOT_IMPLEMENTED, ERROR_EVALUATION_ERROR,
+                   OK, ERROR_UNKNOWN, ERROR_GENERAL_IO_ERROR, ERROR_MEMORY_EXCEEDED, ERROR_NOT_IMPLEMENTED, ERROR_EVALUATION_ERROR,
                    ERROR_TOO_MANY_ROWS, ERROR_ATTRIBUTE_COUNT_MISMATCH, ERROR_ATTRIBUTE_TYPE_MISMATCH,
                    ERROR_ATTRIBUTE_MISSING, ERROR_ATTRIBUTE_EXISTS, ERROR_INVALID_ARGUMENT_TYPE,
                    ERROR_INVALID_ARGUMENT_VALUE, INTERRUPTED, ERROR_NO_DEVICE, ERROR_HIP)
@@ -385,26 +385,31 @@ def read_view_file(schema, path):
             if not head:
                 break
             if len(head) != 8:
-                raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed.")
             rc = int(np.frombuffer(head, np.uint64)[0])
+            # FileInputCursor::Next, file_io.cc:398-409: a chunk holds 1 .. kMaxChunkRowCount rows; anything else is a corrupt header
+            if rc == 0:
+                raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed. Chunk of size 0.")
+            if rc > FILE_CHUNK_ROWS:
+                raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed. Input chunk too large.")
             for i in range(schema.attribute_count()):
                 a = schema.attribute(i)
                 dt = None if a.type() in (STRING, BINARY) else np.dtype(_NP[a.type()])
                 if a.is_nullable():
                     raw = f.read(rc)
                     if len(raw) != rc:
-                        raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                        raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed.")
                     nulls[i].append(np.frombuffer(raw, np.bool_))
                 if a.type() in (STRING, BINARY):
                     # ReadVariableLengthData, file_io.cc:442-474: lengths, then one run of bytes cut by them
                     raw = f.read(rc * 8)
                     if len(raw) != rc * 8:
-                        raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                        raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed.")
                     lens = np.frombuffer(raw, np.uint64).astype(np.int64)
                     total = int(lens.sum())
                     blob = f.read(total)
                     if len(blob) != total:
-                        raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                        raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed.")
                     ends = np.cumsum(lens)
                     vals = np.empty(rc, dtype=object)
                     for j in range(rc):
@@ -413,7 +418,7 @@ def read_view_file(schema, path):
                     continue
                 raw = f.read(rc * dt.itemsize)
                 if len(raw) != rc * dt.itemsize:
-                    raise SupersonicException(L.ERROR_UNKNOWN, "Reading cursor's data from the input file failed.")
+                    raise SupersonicException(L.ERROR_GENERAL_IO_ERROR, "Reading cursor's data from the input file failed.")
                 data[i].append(np.frombuffer(raw, dt))
     cols = []
     for i in range(schema.attribute_count()):
@@ -681,8 +686,23 @@ class AggregationSpecification(object):
 
 
 class GroupAggregateOptions(object):
+    """cursor/core/aggregate.h:160-205.  max_unique_keys_in_result: the result keeps the first (limit + 1) distinct keys in
+    first-seen order; every row whose key is not among them is aggregated into the LAST of those rows
+    (row_hash_set.cc:500-511).  Default kint64max = no limit.  The memory quota / estimated row count have no device
+    counterpart (tables are sized by run feedback)."""
+    NO_LIMIT = (1 << 63) - 1
+
     def __init__(self):
-        self.max_unique_keys_in_result = 0
+        self.max_unique_keys_in_result = self.NO_LIMIT
+
+    def set_max_unique_keys_in_result_(self, n):     # (the reference's spelling, trailing underscore included)
+        self.max_unique_keys_in_result = int(n)
+        return self
+
+    def _option0(self):
+        """ssgpu_op.option0: 0 = no limit, n > 0 = limit n, -1 = limit 0."""
+        n = self.max_unique_keys_in_result
+        return 0 if n >= self.NO_LIMIT else (-1 if n == 0 else n)
 
 
 class SortOrder(object):
@@ -839,7 +859,7 @@ class GroupAggregate(Operation):
         pf, pn = b.proj(self.group_by)
         af, an = b.aggspec(self.spec)
         return b.op(kind=L.OP_GROUP_AGGREGATE, child=c, proj_first=pf, proj_n=pn, agg_first=af, agg_n=an,
-                    option0=(self.options.max_unique_keys_in_result if self.options else 0))
+                    option0=(self.options._option0() if self.options else 0))
 
 
 class AggregateClusters(Operation):

@@ -66,7 +66,8 @@ enum StageKind {
   STAGE_GROUP_AGG = 3,    // pipeline -> device hash table -> group rows
   STAGE_SORT = 4,         // radix sort of the stage input by key columns
   STAGE_CLUSTERS = 5,     // segmented aggregate over pre-clustered keys
-  STAGE_JOIN_EXPAND = 6   // NOT_UNIQUE hash join: (lhs row, matching rhs row) pairs -> gathered columns
+  STAGE_JOIN_EXPAND = 6,  // NOT_UNIQUE hash join: (lhs row, matching rhs row) pairs -> gathered columns
+  STAGE_FOLD_TAIL = 7     // GroupAggregateOptions::max_unique_keys_in_result: rows beyond the limit folded into the last kept row
 };
 
 struct AggOut {        // one aggregate result column
@@ -166,6 +167,10 @@ struct Stage {
   // column is lhs field `col` (from_rhs = false) or column `col` of the auxiliary input
   struct JoinOut { bool from_rhs; int col; };
   std::vector<JoinOut> join_out;
+  // FOLD_TAIL (input: the group table sorted by first-seen row id, that id as the last column): rows [0, fold_limit] are
+  // kept, every later row is merged into row fold_limit with the column's merge function (0 keep = key columns, 1 SUM, 2 MIN, 3 MAX)
+  int64_t fold_limit = -1;
+  std::vector<int> fold_op;
   int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row
   int64_t output_bytes_per_row = 0;       // materialised output bytes per output row
 };

@@ -200,6 +200,67 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
 }
 
 #ifndef __HIPCC_RTC__
+// ---------------------------------------------------------------------------
+// max_unique_keys_in_result: the fold of the group table's tail (FoldTailColumn in launch.h; reference:
+// cursor/infrastructure/row_hash_set.cc:500-511 -- an unseen key beyond the limit is answered with the set's last row, so
+// its rows aggregate there).  The table arrives sorted by first-seen row id; column `blockIdx.x` of the result is its
+// rows [0, limit] with rows (limit, n_in) merged into row `limit`.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T fold_combine(T a, T b, u32 op) {
+  if (op == 1u) return (T)(a + b);
+  if (op == 2u) return b < a ? b : a;     // (a NaN never replaces: `val < result`, aggregation_operators.h:200,221)
+  return a < b ? b : a;
+}
+template <typename T>
+__device__ void fold_tail_column(const FoldTailColumn& C, u64 n_in, u64 limit, u64* lds_val, u32* lds_has) {
+  const u32 t = threadIdx.x, NT = blockDim.x;
+  const T* src = reinterpret_cast<const T*>(C.src);
+  T* dst = reinterpret_cast<T*>(C.dst);
+  const u64 keep = n_in < limit + 1ull ? n_in : limit + 1ull;
+  for (u64 i = t; i < keep; i += NT) { dst[i] = src[i]; if (C.dst_nulls) C.dst_nulls[i] = C.src_nulls ? C.src_nulls[i] : (u8)0; }
+  if (n_in <= limit + 1ull || C.op == 0u) return;
+  T acc = T(); u32 has = 0;
+  for (u64 i = limit + t; i < n_in; i += NT) {
+    if (C.src_nulls && C.src_nulls[i]) continue;
+    acc = has ? fold_combine<T>(acc, src[i], C.op) : src[i]; has = 1u;
+  }
+  u64 bits = 0; __builtin_memcpy(&bits, &acc, sizeof(T));
+  lds_val[t] = bits; lds_has[t] = has;
+  __syncthreads();
+  for (u32 d = NT >> 1; d > 0; d >>= 1) {
+    if (t < d && lds_has[t + d]) {
+      T b; __builtin_memcpy(&b, &lds_val[t + d], sizeof(T));
+      if (lds_has[t]) { T a; __builtin_memcpy(&a, &lds_val[t], sizeof(T)); a = fold_combine<T>(a, b, C.op); u64 w = 0; __builtin_memcpy(&w, &a, sizeof(T)); lds_val[t] = w; }
+      else { lds_val[t] = lds_val[t + d]; lds_has[t] = 1u; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    T r; __builtin_memcpy(&r, &lds_val[0], sizeof(T));
+    if (lds_has[0]) dst[limit] = r;
+    if (C.dst_nulls) C.dst_nulls[limit] = lds_has[0] ? (u8)0 : (u8)1;
+  }
+}
+__global__ __launch_bounds__(256) void ssgpu_fold_tail_kernel(const FoldTailColumn* cols, u64 n_in, u64 limit) {
+  __shared__ u64 lds_val[256];
+  __shared__ u32 lds_has[256];
+  const FoldTailColumn C = cols[blockIdx.x];
+  switch (C.kind) {
+    case 0: fold_tail_column<i32>(C, n_in, limit, lds_val, lds_has); break;
+    case 1: fold_tail_column<u32>(C, n_in, limit, lds_val, lds_has); break;
+    case 2: fold_tail_column<i64>(C, n_in, limit, lds_val, lds_has); break;
+    case 3: fold_tail_column<u64>(C, n_in, limit, lds_val, lds_has); break;
+    case 4: fold_tail_column<float>(C, n_in, limit, lds_val, lds_has); break;
+    case 5: fold_tail_column<double>(C, n_in, limit, lds_val, lds_has); break;
+    default: fold_tail_column<u8>(C, n_in, limit, lds_val, lds_has); break;
+  }
+}
+hipError_t ssgpu_launch_fold_tail(const FoldTailColumn* cols_dev, unsigned int n_cols, unsigned long long n_in, unsigned long long limit, hipStream_t stream) {
+  if (n_cols == 0) return hipSuccess;
+  hipLaunchKernelGGL(ssgpu_fold_tail_kernel, dim3(n_cols), dim3(256), 0, stream, cols_dev, (u64)n_in, (u64)limit);
+  return hipGetLastError();
+}
+
 unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread) {
   const unsigned int T = SSGPU_PSCAT_THREADS * (unsigned)rows_per_thread;
   return (3u * n_parts + 2u + T) * 4u + 16u + T * rec_words * 8u;

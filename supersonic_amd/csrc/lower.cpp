@@ -370,8 +370,13 @@ Status Emitter::eval_args(const BExprP& e, std::vector<Val>* out) {
     return restore(st);
   }
   // every other operator: the children share one skip vector, each adds its NULLs before the next is evaluated
+  // (the masks of EVERY earlier argument count: with three or more arguments one that cannot fail may sit between a
+  //  NULL-producing one and a signaling one -- pending masks are folded in before the first later argument that can fail)
+  size_t folded = 0;   // arguments [0, folded) have their NULL masks in guard_
   for (size_t i = 1; i < a.size(); ++i) {
-    if (a[i - 1].null >= 0 && can_fail(e->args[i])) guard_ = narrow_guard(guard_, a[i - 1].null, true);
+    if (can_fail(e->args[i]))
+      for (; folded < i; ++folded)
+        if (a[folded].null >= 0) guard_ = narrow_guard(guard_, a[folded].null, true);
     st = value(e->args[i], &a[i]);
     if (!st.ok()) return restore(st);
   }
@@ -833,6 +838,7 @@ static int lookup_pos(const Schema& s, const std::string& name) {
 }
 
 // ---- aggregate specification binding (aggregator.cc:63-186) --------------------------
+enum { AGG_FIRST_SEEN = 9001 };   // internal: the group's smallest global row id (UINT64, never NULL) -- first-seen order of the groups
 struct AggPlan {
   int aggregation = 0;
   int input_pos = -1;  // -1 for COUNT(*)
@@ -1242,7 +1248,14 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
     const uint64_t j = (uint64_t)word;
     AggOut ao; ao.slot = word; ao.slot_kind = 0; ao.result_nullable = ap.result_nullable; ao.has_cnt = false;
     uint64_t init = 0;
-    if (ap.aggregation == SSGPU_COUNT) {
+    if (ap.aggregation == AGG_FIRST_SEEN) {
+      if (clustered) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "first-seen group order needs the hash aggregate");
+      AggSel s; select_group_agg(SSGPU_MIN, SSGPU_UINT64, &s, &init);
+      if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
+      LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = rowid_reg; i.b = -1; i.c = slotreg;
+      i.imm = (ng << 32) | j;
+      ao.emit_kind = s.emit_kind;
+    } else if (ap.aggregation == SSGPU_COUNT) {
       int nullreg = -1;
       if (ap.input_pos >= 0) { Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v)); nullreg = v.null; }
       if (ap.distinct) { int nf; SS_RETURN_IF_ERROR(notfirst_for(ap, &nf)); nullreg = em.or_null(nullreg, nf); }
@@ -1291,7 +1304,7 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
     } else {
       st->group_acc_init.push_back(init);
       uint32_t mop = VM_MERGE_ADD_U64;
-      if (ap.aggregation == SSGPU_MIN || ap.aggregation == SSGPU_FIRST) mop = VM_MERGE_MIN_U64;
+      if (ap.aggregation == SSGPU_MIN || ap.aggregation == SSGPU_FIRST || ap.aggregation == AGG_FIRST_SEEN) mop = VM_MERGE_MIN_U64;
       else if (ap.aggregation == SSGPU_MAX || ap.aggregation == SSGPU_LAST) mop = VM_MERGE_MAX_U64;
       else if (ap.aggregation == SSGPU_SUM && mtype(ap.out_type) == M_F32) mop = VM_MERGE_ADD_F64;
       st->group_merge_op.push_back(mop);
@@ -1351,7 +1364,13 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     const AggPlan& ap = plans[j];
     Stage::PartAgg pa; pa.op = VM_GAGG_COUNT; pa.val_off = -1; pa.val_width = 0; pa.null_off = -1; pa.has_cnt = 0; pa.word = st->aggs[j].slot;
     Ref rf{-1, -1};
-    if (ap.aggregation == SSGPU_COUNT) {
+    if (ap.aggregation == AGG_FIRST_SEEN) {
+      AggSel sl; uint64_t init = 0;
+      select_group_agg(SSGPU_MIN, SSGPU_UINT64, &sl, &init);
+      if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
+      pa.op = sl.op;
+      rf.val_field = add_field(rowid_reg, 8); pa.val_width = 8;
+    } else if (ap.aggregation == SSGPU_COUNT) {
       if (ap.input_pos >= 0) {
         Val v; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.input_pos].expr, &v));
         if (v.null >= 0) rf.null_field = add_field(v.null, 1);
@@ -1720,6 +1739,11 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           GroupBinding g;
           if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
+          // FIRST / LAST follow the INPUT order (aggregation_operators.h:290-320); the DISTINCT shape aggregates rows that were
+          // sorted by (keys, distinct column), where "first" would mean "smallest distinct value": refused, not answered wrongly
+          for (auto& ap : g.plans)
+            if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST)
+              return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST / LAST next to a DISTINCT aggregate in one specification are not available on the device path");
           std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
           auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
           for (auto& k : g.kpos) k = slot_of(k);
@@ -1774,12 +1798,45 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         else {
           // GroupAggregateOptions::max_unique_keys_in_result folds every key beyond the limit into one extra last row
           // (aggregate_groups.cc:326): depends on first-seen key order, which no device shape has -- refuse loudly
-          if (op.option0 != 0)
-            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "GroupAggregateOptions::max_unique_keys_in_result is not available on the device path");
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          // GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205, row_hash_set.cc:500-511): the result keeps the
+          // first limit + 1 distinct keys in first-seen order and every row with another key is aggregated into the last of
+          // them.  Composed from existing stages: the hash aggregate with one hidden aggregate -- the group's smallest row id
+          // --, a sort of the group table by it (= first-seen order), and a fold of the rows beyond the limit into row `limit`
+          // with the aggregates' merge functions (SUM of sums, MIN of mins, MAX of maxes, SUM of counts).
+          const bool limited = op.option0 != 0;
+          const int64_t limit = op.option0 < 0 ? 0 : op.option0;
+          std::vector<int> fold_ops;
+          if (limited) {
+            if ((int)g.plans.size() + 1 > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
+            for (size_t k = 0; k < g.kpos.size(); ++k) fold_ops.push_back(0);
+            for (auto& ap : g.plans) {
+              if (ap.aggregation == SSGPU_SUM || ap.aggregation == SSGPU_COUNT) fold_ops.push_back(1);
+              else if (ap.aggregation == SSGPU_MIN) fold_ops.push_back(2);
+              else if (ap.aggregation == SSGPU_MAX) fold_ops.push_back(3);
+              else return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with FIRST / LAST / CONCAT aggregates is not available on the device path");
+            }
+            AggPlan hidden; hidden.aggregation = AGG_FIRST_SEEN; hidden.input_pos = -1; hidden.out_type = SSGPU_UINT64;
+            hidden.out_name = "$first_seen"; hidden.result_nullable = false;
+            g.plans.push_back(hidden);
+          }
           bool too_wide = false;
           Status s = finish_group_agg(g, pipe, &st, false, &too_wide);
           if (!s.ok() && !too_wide) return s;
+          if (too_wide && limited)
+            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with group keys wider than 64 packed bits is not available on the device path");
+          if (limited) {
+            stages->push_back(st);
+            Stage so; so.kind = STAGE_SORT; so.in_schema = st.out_schema; so.out_schema = st.out_schema;
+            SortKey sk; sk.col = (int)st.out_schema.size() - 1; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+            for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+            stages->push_back(so);
+            Stage ft; ft.kind = STAGE_FOLD_TAIL; ft.in_schema = so.out_schema; ft.fold_limit = limit; ft.fold_op = fold_ops;
+            ft.out_schema.assign(so.out_schema.begin(), so.out_schema.end() - 1);
+            for (auto& a : ft.out_schema) if (dtype_width(a.dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length columns are outside the device hot path");
+            st = ft;
+            desc << "(hash aggregate + first-seen order + fold beyond " << limit << " keys) ";
+          }
           if (too_wide) {
             // Keys that do not pack into one 64-bit word (e.g. a NULLABLE INT64 key, three INT32
             // keys), or FIRST/LAST of a computed expression (the value is fetched by row id from a

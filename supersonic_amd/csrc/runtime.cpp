@@ -390,16 +390,16 @@ int ssgpu_block_create_from_file(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t
   // pass 1: chunk headers only (the payload size follows from the row count and the schema)
   int64_t total = 0; uint64_t rc = 0;
   std::vector<uint64_t> chunk_rows;
-  bool header_ok = true;
+  bool header_ok = true; const char* header_why = "";
   while (fread(&rc, 8, 1, f) == 1) {
     // a chunk never holds more than kMaxChunkRowCount rows (file_io.cc:70): anything else is a corrupt header, and
     // trusting it would seek by a garbage (possibly negative) distance
-    if (rc > (uint64_t)kFileChunkRows) { header_ok = false; break; }
+    if (rc == 0 || rc > (uint64_t)kFileChunkRows) { header_ok = false; header_why = rc == 0 ? " Chunk of size 0." : " Input chunk too large."; break; }   // file_io.cc:398-409
     if (fseek(f, (long)((int64_t)rc * row_bytes), SEEK_CUR) != 0) break;
     total += (int64_t)rc; chunk_rows.push_back(rc);
   }
-  if (!header_ok) { fclose(f); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; }
-  { const long end = ftell(f); fseek(f, 0, SEEK_END); if (ftell(f) < end) { fclose(f); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; } }
+  if (!header_ok) { fclose(f); c->err = std::string("Reading cursor's data from the input file failed.") + header_why; return SSGPU_ERROR_GENERAL_IO_ERROR; }
+  { const long end = ftell(f); fseek(f, 0, SEEK_END); if (ftell(f) < end) { fclose(f); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_GENERAL_IO_ERROR; } }
   rewind(f);
   ssgpu_block* b = nullptr;
   int rcode = ssgpu_block_create(c, schema, n, std::max<int64_t>(total, 1), &b);
@@ -449,7 +449,7 @@ int ssgpu_block_create_from_file(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t
   fclose(f);
   if (ok) ok = hipStreamSynchronize(c->copy_stream) == hipSuccess;
   for (int i = 0; i < 2; ++i) if (done[i]) (void)hipEventDestroy(done[i]);
-  if (!ok || off != total) { ssgpu_block_destroy(b); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_UNKNOWN; }
+  if (!ok || off != total) { ssgpu_block_destroy(b); c->err = "Reading cursor's data from the input file failed."; return SSGPU_ERROR_GENERAL_IO_ERROR; }
   b->rows = total;
   *out = b;
   return SSGPU_OK;
@@ -458,7 +458,7 @@ int ssgpu_block_create_from_file(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t
 static int write_view_file(ssgpu_ctx* c, const char* path, int n, int64_t rows, const std::vector<const void*>& dev_data,
                            const std::vector<const uint8_t*>& dev_nulls, const std::vector<int>& width, const std::vector<bool>& nullable) {
   FILE* f = path ? fopen(path, "wb") : nullptr;
-  if (!f) { c->err = "Writing view to the output file failed."; return SSGPU_ERROR_UNKNOWN; }
+  if (!f) { c->err = "Writing view to the output file failed."; return SSGPU_ERROR_GENERAL_IO_ERROR; }
   std::vector<char> host;
   bool ok = true;
   for (int64_t off = 0; off < rows && ok; off += kFileChunkRows) {
@@ -476,7 +476,7 @@ static int write_view_file(ssgpu_ctx* c, const char* path, int n, int64_t rows, 
     }
   }
   ok = fclose(f) == 0 && ok;
-  if (!ok) { c->err = "Writing view to the output file failed."; return SSGPU_ERROR_UNKNOWN; }
+  if (!ok) { c->err = "Writing view to the output file failed."; return SSGPU_ERROR_GENERAL_IO_ERROR; }
   return SSGPU_OK;
 }
 
@@ -1819,6 +1819,37 @@ int run_join_expand(ssgpu_plan* p, size_t si, const InCols& in) {
   return SSGPU_OK;
 }
 
+// GroupAggregateOptions::max_unique_keys_in_result, last stage: the group table, sorted by first-seen row id (its last
+// column), keeps rows [0, limit] and has every later row merged into row `limit` (Stage::fold_op)
+int run_fold_tail(ssgpu_plan* p, size_t si, const InCols& in) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  const int64_t keep = std::min<int64_t>(in.rows, st.fold_limit + 1);
+  int rc = ensure_out_cols(c, st, ex, keep);
+  if (rc != SSGPU_OK) return rc;
+  auto kind_of = [](int dtype) {
+    switch (dtype) {
+      case SSGPU_INT32: case SSGPU_DATE: case SSGPU_STRING: return 0u; case SSGPU_UINT32: return 1u;
+      case SSGPU_INT64: case SSGPU_DATETIME: return 2u; case SSGPU_UINT64: return 3u;
+      case SSGPU_FLOAT: return 4u; case SSGPU_DOUBLE: return 5u; default: return 6u;
+    }
+  };
+  std::vector<FoldTailColumn> cols(st.out_schema.size());
+  for (size_t i = 0; i < cols.size(); ++i) {
+    cols[i].src = in.cols[i].data; cols[i].src_nulls = st.in_schema[i].nullable ? in.cols[i].is_null : nullptr;
+    cols[i].dst = ex.out[i].data.p; cols[i].dst_nulls = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
+    cols[i].op = (unsigned)st.fold_op[i]; cols[i].kind = kind_of(st.out_schema[i].dtype);
+  }
+  HIP_TRY(c, ex.emit_descs.ensure(std::max<size_t>(cols.size(), 1) * sizeof(FoldTailColumn)));
+  HIP_TRY(c, hipMemcpyAsync(ex.emit_descs.p, cols.data(), cols.size() * sizeof(FoldTailColumn), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // (`cols` is a host temporary)
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+  HIP_TRY(c, ssgpu_launch_fold_tail(ex.emit_descs.as<FoldTailColumn>(), (unsigned)cols.size(), (unsigned long long)in.rows, (unsigned long long)st.fold_limit, c->stream));
+  if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+  p->counters.n_launches += 1;
+  ex.out_rows = keep;
+  return SSGPU_OK;
+}
+
 int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
   ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[si];
   if (ex.out_rows < 0) {
@@ -1902,6 +1933,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       case STAGE_SORT: rc = run_sort(p, si, in); break;
       case STAGE_CLUSTERS: rc = run_clusters(p, si, in, row_id_base); break;
       case STAGE_JOIN_EXPAND: rc = run_join_expand(p, si, in); break;
+      case STAGE_FOLD_TAIL: rc = run_fold_tail(p, si, in); break;
       default: c->err = "stage kind not executable yet"; rc = SSGPU_ERROR_NOT_IMPLEMENTED; break;
     }
     if (rc != SSGPU_OK) return rc;

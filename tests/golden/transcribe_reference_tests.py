@@ -447,6 +447,12 @@ op_case("Group_CountWithInputColumn", GT + ":119-133", cols([I32]), [[1], [3]],
 op_case("Group_AggregationWithGroupBy", GT + ":272-295", cols([I32, I32], nullable=False), [[1, 3], [3, -3], [1, 4], [3, -5]],
         ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"],
         [I32, I32], [[1, 7], [3, -8]], ordered=False, exp_names=["col0", "sum"], exp_nullable=[False, True])
+# GroupAggregateOptions::max_unique_keys_in_result = 2 (CreateGroupAggregate's last argument): the first limit + 1 keys in
+# first-seen order keep a row, rows with any other key (5 here) aggregate into the last kept row (key 4)
+op_case("Group_AggregationWithGroupBy_UniqueRowLimit", GT + ":296-328", cols([I32, I32], nullable=False),
+        [[1, 3], [3, -3], [1, 4], [3, -5], [4, 5], [3, -1], [5, 1], [4, 3], [1, -2]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT", {"max_unique_keys_in_result": 2}],
+        [I32, I32], [[1, 5], [3, -9], [4, 9]], ordered=False, exp_names=["col0", "sum"], exp_nullable=[False, True])
 op_case("Group_GroupByNullableColumn", GT + ":330-354", cols([I32, I32]), [[3, -3], [None, 4], [3, -5], [None, 1]],
         ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT"],
         [I32, I32], [[3, -8], [None, 5]], ordered=False, exp_names=["col0", "sum"], exp_nullable=[True, True])

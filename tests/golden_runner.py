@@ -130,7 +130,10 @@ def build_plan(plan, view):
     if head == "ScalarAggregate":
         return ss.ScalarAggregate(build_spec(plan[1]), build_plan(plan[2], view))
     if head == "GroupAggregate":
-        return ss.GroupAggregate(build_projector(plan[1]), build_spec(plan[2]), None, build_plan(plan[3], view))
+        options = None
+        if len(plan) > 4 and plan[4]:
+            options = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(plan[4]["max_unique_keys_in_result"])
+        return ss.GroupAggregate(build_projector(plan[1]), build_spec(plan[2]), options, build_plan(plan[3], view))
     if head == "AggregateClusters":
         return ss.AggregateClusters(build_projector(plan[1]), build_spec(plan[2]), build_plan(plan[3], view))
     if head == "Sort":

@@ -77,15 +77,34 @@ def test_bind_errors(bind_ctx):
     assert code(ss.Compute(ss.CastTo(ss.INT32, ss.Plus(NA("a"), ss.ConstDouble(1.0))), scan())) == 402   # float -> int cast
 
 
-def test_max_unique_keys_in_result_is_refused_at_bind():
-    # GroupAggregateOptions::max_unique_keys_in_result (aggregate_groups.cc:326) depends on first-seen key order:
-    # not available on the device path, and not silently ignored either
+def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
+    # GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205, row_hash_set.cc:500-511): hash aggregate with a
+    # hidden first-seen row id, sort by it, fold of the rows beyond the limit -- the hidden column is not in the result schema;
+    # FIRST / LAST under a limit have no merge function on the device and are refused, not ignored
     import numpy as np
     schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64)])
     view = ss.View(schema, [np.arange(4), np.arange(4)])
-    opts = ss.GroupAggregateOptions()
-    opts.max_unique_keys_in_result = 2
+    opts = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2)
     op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s"), opts, ss.ScanView(view))
+    plan = ss.Plan(op, ss.Context(-1))
+    rs = plan.result_schema
+    assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "s"]
+    assert "fold beyond 2 keys" in plan.describe()
+    bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.FIRST, "v", "f"),
+                            ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
     with pytest.raises(ss.SupersonicException) as e:
-        ss.Plan(op, ss.Context(-1))
+        ss.Plan(bad, ss.Context(-1))
     assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+
+
+def test_first_last_next_to_distinct_is_refused():
+    # FIRST / LAST follow the input order (aggregation_operators.h:290-320); the DISTINCT shape aggregates rows sorted by
+    # (keys, distinct column), where they would answer with the smallest value's row: refused at bind, not answered wrongly
+    import numpy as np
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
+    view = ss.View(schema, [np.zeros(4, np.int32), np.arange(4), np.arange(4)])
+    spec = ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "s").AddAggregation(ss.FIRST, "b", "f")
+    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view)), ss.ScalarAggregate(spec, ss.ScanView(view))):
+        with pytest.raises(ss.SupersonicException) as e:
+            ss.Plan(op, ss.Context(-1))
+        assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED

@@ -153,3 +153,24 @@ def test_string_file_to_query_to_file(gpu_ctx, tmp_path):
     oschema, want = oracle.run(query(view), 1 << 20)
     from helpers import sort_rows
     assert_cols_equal(sort_rows(to_cols(got)), sort_rows(want), context="STRING file round trip")
+
+
+def test_corrupt_chunk_headers_are_io_errors(tmp_path):
+    # FileInputCursor::Next, file_io.cc:398-409: a chunk of 0 rows or of more than kMaxChunkRowCount rows is
+    # ERROR_GENERAL_IO_ERROR (101) with the reference's message -- never a giant read or a silent success
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64)])
+    for rows, text in ((0, "Chunk of size 0."), (8193, "Input chunk too large."), (1 << 60, "Input chunk too large.")):
+        path = str(tmp_path / ("bad_%d.view" % (rows % 100000)))
+        with open(path, "wb") as f:
+            f.write(np.array([rows], np.uint64).tobytes())
+            f.write(np.arange(16, dtype=np.int64).tobytes())
+        with pytest.raises(ss.SupersonicException) as e:
+            ss.read_view_file(schema, path)
+        assert e.value.return_code == ss.ERROR_GENERAL_IO_ERROR and text in str(e.value)
+    short = str(tmp_path / "short.view")
+    with open(short, "wb") as f:
+        f.write(np.array([4], np.uint64).tobytes())
+        f.write(np.arange(2, dtype=np.int64).tobytes())
+    with pytest.raises(ss.SupersonicException) as e:
+        ss.read_view_file(schema, short)
+    assert e.value.return_code == ss.ERROR_GENERAL_IO_ERROR

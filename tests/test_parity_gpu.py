@@ -1355,3 +1355,40 @@ def test_group_aggregate_slab_mode_falls_back_when_the_groups_do_not_fit():
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view)), ctx, ignore_order=True)
     small = ss.View(schema, [key % 700, view.column(1).data, view.column(2).data])   # 700 groups (+ the EMPTY key's image): fits
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(small)), ctx, ignore_order=True)
+
+
+# ---- GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205, row_hash_set.cc:500-511): the first limit + 1
+# ---- keys in first-seen order keep a row, every other key's rows aggregate into the last kept row.  The device composes it
+# ---- from a hash aggregate with a hidden first-seen row id, a sort by it and a fold of the tail: same rows, SAME ORDER ------
+@pytest.mark.parametrize("limit", [0, 1, 7, 500, 999, 1000, 5000])
+@pytest.mark.parametrize("n,partition", [(9, 1), (1025, 1), (100003, 1), (100003, 2)])
+def test_group_aggregate_max_unique_keys_in_result(n, partition, limit):
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", partition)
+    view = make_view(n, nullable=True)
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.COUNT, "d0", "c0").AddAggregation(ss.COUNT, "", "n")
+            .AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.SUM, "d1", "sd").AddAggregation(ss.MIN, "u", "mu")
+            .AddAggregation(ss.MAX, "f", "mf"))
+    opts = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit)
+    # (NULLABLE k1 + k2 would be 65 key bits: the wide-key shape is refused under a limit, see the next test)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, opts,
+                               ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx)   # ordered: first-seen order
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1"]), spec, opts, ss.ScanView(view)), ctx)                                   # a NULL key group among them
+    plain = make_view(n)                                # NOT NULL keys: two INT32 keys in one word
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit),
+                               ss.ScanView(plain)), ctx)
+
+
+def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
+    # aggregate_groups_test.cc:296-328 as written; what the composition cannot express is refused at bind, never ignored
+    schema = ss.TupleSchema([ss.Attribute("col0", ss.INT32), ss.Attribute("col1", ss.INT32)])
+    view = ss.View(schema, [np.array([1, 3, 1, 3, 4, 3, 5, 4, 1], np.int32), np.array([3, -3, 4, -5, 5, -1, 1, 3, -2], np.int32)])
+    opts = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2)
+    got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("col0"), ss.AggregationSpecification().AddAggregation(ss.SUM, "col1", "sum"), opts, ss.ScanView(view)), gpu_ctx)
+    assert got.column(0).data.tolist() == [1, 3, 4] and got.column(1).data.tolist() == [5, -9, 9]
+    wide = make_view(100, nullable=True)
+    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "s"), opts, ss.ScanView(wide)),
+               ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.LAST, "b", "l"), opts, ss.ScanView(wide))):
+        with pytest.raises(ss.SupersonicException) as e:
+            ss.Plan(op, gpu_ctx)
+        assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
