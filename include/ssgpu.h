@@ -109,7 +109,12 @@ enum {
 enum { SSGPU_NOT_NULLABLE = 0, SSGPU_NULLABLE = 1 };
 enum {
   SSGPU_SUM = 0, SSGPU_MIN = 1, SSGPU_MAX = 2, SSGPU_COUNT = 3,
-  SSGPU_CONCAT = 4, SSGPU_FIRST = 5, SSGPU_LAST = 6
+  SSGPU_CONCAT = 4, SSGPU_FIRST = 5, SSGPU_LAST = 6,
+  /* not a reference aggregation: the exact residual of the DOUBLE SUM of the same input column in the same GroupAggregate /
+   * AggregateClusters specification (which must precede it) -- the group's sum is accumulated in double-double, SUM emits
+   * s = fl(hi + lo) and SUM_RESIDUAL emits e with s + e == hi + lo exactly.  What a sharded run sends next to its partial
+   * sums so that the cross-shard total stays within 1 ULP of the exact sum (supersonic_amd/distributed.py). */
+  SSGPU_SUM_RESIDUAL = 100
 };
 enum { SSGPU_ASCENDING = 0, SSGPU_DESCENDING = 1 };
 enum {

@@ -35,7 +35,9 @@
 enum { T_INT32 = 1, T_INT64 = 2, T_UINT64 = 3, T_DATETIME = 4, T_DOUBLE = 5, T_BOOL = 6,
        T_UINT32 = 8, T_FLOAT = 9, T_DATE = 10, T_STRING = 0, T_BINARY = 7 };
 /* Aggregation values, supersonic.proto:86-94 */
-enum { A_SUM = 0, A_MIN = 1, A_MAX = 2, A_COUNT = 3, A_CONCAT = 4, A_FIRST = 5, A_LAST = 6 };
+enum { A_SUM = 0, A_MIN = 1, A_MAX = 2, A_COUNT = 3, A_CONCAT = 4, A_FIRST = 5, A_LAST = 6,
+       A_SUM_RESIDUAL = 100 /* not a reference aggregation (include/ssgpu.h): what the product's compensated DOUBLE sum did not fit in
+                               its rounded result; the reference's sequential fold has no such term -- here always 0.0 (NULL with its SUM) */ };
 /* ReturnCode values, supersonic.proto:40-82 */
 enum { RC_OK = 0, RC_NOT_IMPLEMENTED = 103, RC_EVALUATION_ERROR = 104, RC_COUNT_MISMATCH = 401,
        RC_TYPE_MISMATCH = 402, RC_ATTRIBUTE_MISSING = 403, RC_ATTRIBUTE_EXISTS = 404,
@@ -1357,6 +1359,7 @@ static void update_aggregation(agg_col* g, const orc_view* v, const int64_t* map
   for (int64_t i = 0; i < n; ++i) {
     if (nl && nl[i]) continue;
     const int64_t r = map[i];
+    if (g->aggregation == A_SUM_RESIDUAL) { res_null[r] = 0; ((double*)res)[r] = 0.0; continue; }
     if (g->distinct && distinct_seen(g, r, in, i)) continue;
     const int first = res_null[r];
     if (first) res_null[r] = 0;

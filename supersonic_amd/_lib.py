@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("SSGPU_LIB") or os.path.join(_HERE, "lib", "libssgpu.s
 INT32, INT64, UINT64, DATETIME, DOUBLE, BOOL, UINT32, FLOAT, DATE, STRING, BINARY = 1, 2, 3, 4, 5, 6, 8, 9, 10, 0, 7
 NOT_NULLABLE, NULLABLE = 0, 1
 SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6
+SUM_RESIDUAL = 100   # extension, see include/ssgpu.h
 ASCENDING, DESCENDING = 0, 1
 
 OK = 0

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _lib as L
 from ._lib import (INT32, INT64, UINT32, UINT64, FLOAT, DOUBLE, BOOL, DATE, DATETIME, STRING, BINARY,  # noqa: F401
-                   NOT_NULLABLE, NULLABLE, SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST, ASCENDING, DESCENDING,
+                   NOT_NULLABLE, NULLABLE, SUM, MIN, MAX, COUNT, CONCAT, FIRST, LAST, SUM_RESIDUAL, ASCENDING, DESCENDING,
                    OK, ERROR_UNKNOWN, ERROR_GENERAL_IO_ERROR, ERROR_MEMORY_EXCEEDED, ERROR_NOT_IMPLEMENTED, ERROR_EVALUATION_ERROR,
                    ERROR_TOO_MANY_ROWS, ERROR_ATTRIBUTE_COUNT_MISMATCH, ERROR_ATTRIBUTE_TYPE_MISMATCH,
                    ERROR_ATTRIBUTE_MISSING, ERROR_ATTRIBUTE_EXISTS, ERROR_INVALID_ARGUMENT_TYPE,

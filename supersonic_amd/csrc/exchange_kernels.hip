@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void ssgpu_pack_image_kernel(const ImagePackPa
   const u64 rows = rows_have < P.capacity ? rows_have : P.capacity;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     u64* h = reinterpret_cast<u64*>(P.image);
-    h[0] = rows; h[1] = P.capacity; h[2] = rows_have > P.capacity ? 1ull : 0ull; h[3] = rows_have;
+    u64 retry = 0;
+    for (u32 f = 0; f < P.n_retry; ++f) retry |= (u64)*P.retry_flags[f];
+    h[0] = rows; h[1] = P.capacity; h[2] = (rows_have > P.capacity || retry) ? 1ull : 0ull; h[3] = rows_have;
     u64 err = 0;
     for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)*P.error_flags[f];
     h[4] = err; h[5] = 0; h[6] = 0; h[7] = 0;

@@ -17,6 +17,7 @@ enum SlotKind {
 enum EmitKind {
   EMIT_U64 = 0, EMIT_I64KEY = 1, EMIT_U32 = 2, EMIT_I32KEY = 3, EMIT_F64 = 4, EMIT_F32 = 5,
   EMIT_DD_F64 = 6, EMIT_DD_F32 = 7, EMIT_U8 = 8,
+  EMIT_DDRES_F64 = 9, /* (hi, lo) accumulator pair -> the residual e of s = fl(hi + lo): s + e == hi + lo (SSGPU_SUM_RESIDUAL) */
   EMIT_CNT_U64 = 20, EMIT_CNT_U32 = 21, /* COUNT(*) = contribution count of another slot */
   EMIT_FKEY_F64 = 100, EMIT_FKEY_F32 = 101 /* group table: ordered-double key */
 };
@@ -210,6 +211,8 @@ struct ImagePackParams {
   unsigned long long rows_host, capacity;
   unsigned int n_pieces, n_flags;
   const unsigned int* error_flags[8];   // evaluation-error words of the plan's stages (header word 4 = their OR)
+  const unsigned int* retry_flags[4];   // table / segment overflow words not yet seen by the host (header word 2 |= any set)
+  unsigned int n_retry, pad2;
   ImagePiece pieces[SSGPU_IMAGE_MAX_PIECES];
 };
 struct ImageUnpackParams {

@@ -875,6 +875,14 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
     p.distinct = a.distinct && (a.aggregation == SSGPU_SUM || a.aggregation == SSGPU_COUNT);
     if (a.aggregation == SSGPU_CONCAT)
       return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT (STRING) is outside the device hot path");
+    if (a.aggregation == SSGPU_SUM_RESIDUAL) {   // extension (ssgpu.h): the exact residual of the DOUBLE SUM of the same column
+      bool found = false;
+      for (auto& q : *out) found = found || (q.aggregation == SSGPU_SUM && q.input_pos == p.input_pos && q.out_type == SSGPU_DOUBLE && !q.distinct);
+      if (a.distinct || in[p.input_pos].dtype != SSGPU_DOUBLE || p.out_type != SSGPU_DOUBLE || !found)
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "SUM_RESIDUAL follows the (non-DISTINCT) DOUBLE SUM of the same DOUBLE column in the same specification");
+      out->push_back(p);
+      continue;
+    }
     // supported matrix (column_aggregator.cc:484-532)
     if (a.aggregation == SSGPU_COUNT) {
       if (!dtype_is_integer(p.out_type))
@@ -1039,6 +1047,9 @@ static int64_t staged_bytes(const Program& p) {
 // every run of equal (group keys, distinct column) in the -- sorted -- stage input; a DISTINCT aggregate treats every other
 // row like a NULL input
 static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const Pipe& pipe, Stage* st, int distinct_flag_input = -1) {
+  for (auto& ap : plans)
+    if (ap.aggregation == SSGPU_SUM_RESIDUAL)
+      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM_RESIDUAL belongs to group aggregates (a sharded ScalarAggregate carries its double-double words in the partial state)");
   st->kind = STAGE_SCALAR_AGG;
   st->in_schema = pipe.in_schema;
   if ((int)plans.size() > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
@@ -1240,7 +1251,7 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
   // rounding error is captured exactly (TwoSum on the value the atomic returns) and accumulated next to it
   auto is_dd = [](const AggPlan& ap) { return ap.aggregation == SSGPU_SUM && mtype(ap.out_type) == M_F64; };
   uint64_t ng = 0;
-  for (auto& ap : plans) ng += is_dd(ap) ? 2 : 1;
+  for (auto& ap : plans) ng += ap.aggregation == SSGPU_SUM_RESIDUAL ? 0 : is_dd(ap) ? 2 : 1;
   int rowid_reg = -1;
   int word = 0;
   for (size_t jj = 0; jj < plans.size(); ++jj) {
@@ -1248,6 +1259,18 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
     const uint64_t j = (uint64_t)word;
     AggOut ao; ao.slot = word; ao.slot_kind = 0; ao.result_nullable = ap.result_nullable; ao.has_cnt = false;
     uint64_t init = 0;
+    if (ap.aggregation == SSGPU_SUM_RESIDUAL) {
+      // no accumulator of its own: the second view of the SUM's (sum, compensation) words
+      int src_j = -1;
+      for (size_t q = 0; q < jj; ++q)
+        if (plans[q].aggregation == SSGPU_SUM && plans[q].input_pos == ap.input_pos && plans[q].out_type == SSGPU_DOUBLE && !plans[q].distinct) src_j = (int)q;
+      if (src_j < 0) return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "SUM_RESIDUAL without its SUM");
+      ao = st->aggs[src_j]; ao.emit_kind = EMIT_DDRES_F64; ao.result_nullable = ap.result_nullable;
+      st->aggs.push_back(ao);
+      Attr a; a.name = ap.out_name; a.dtype = ap.out_type; a.nullable = ap.result_nullable;
+      st->out_schema.push_back(a);
+      continue;
+    }
     if (ap.aggregation == AGG_FIRST_SEEN) {
       if (clustered) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "first-seen group order needs the hash aggregate");
       AggSel s; select_group_agg(SSGPU_MIN, SSGPU_UINT64, &s, &init);
@@ -1364,6 +1387,7 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     const AggPlan& ap = plans[j];
     Stage::PartAgg pa; pa.op = VM_GAGG_COUNT; pa.val_off = -1; pa.val_width = 0; pa.null_off = -1; pa.has_cnt = 0; pa.word = st->aggs[j].slot;
     Ref rf{-1, -1};
+    if (ap.aggregation == SSGPU_SUM_RESIDUAL) continue;   // a second view of its SUM's accumulator words: nothing to accumulate
     if (ap.aggregation == AGG_FIRST_SEEN) {
       AggSel sl; uint64_t init = 0;
       select_group_agg(SSGPU_MIN, SSGPU_UINT64, &sl, &init);

@@ -851,6 +851,8 @@ __device__ __forceinline__ void emit_value(void* dst, size_t idx, int out_kind, 
     case EMIT_F32: reinterpret_cast<float*>(dst)[idx] = (float)u2d(v0); break;
     case EMIT_DD_F64: { double hi = u2d(v0), lo = u2d(v1);
       reinterpret_cast<double*>(dst)[idx] = (lo == 0.0) ? hi : hi + lo; } break;
+    case EMIT_DDRES_F64: { const double hi = u2d(v0), lo = u2d(v1), sm = hi + lo, bp = sm - hi;   // TwoSum: exact
+      reinterpret_cast<double*>(dst)[idx] = (lo == 0.0) ? 0.0 : (hi - (sm - bp)) + (lo - bp); } break;
     case EMIT_DD_F32: { double hi = u2d(v0), lo = u2d(v1);
       reinterpret_cast<float*>(dst)[idx] = (float)((lo == 0.0) ? hi : hi + lo); } break;
     case EMIT_U8: reinterpret_cast<u8*>(dst)[idx] = (u8)(v0 != 0); break;
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
         v0 = (v0 & 0x8000000000000000ull) ? (v0 & 0x7FFFFFFFFFFFFFFFull) : ~v0;
         emit_value(ao.data, row, EMIT_F32, v0, 0);
       } else {
-        emit_value(ao.data, row, ao.out_kind, v0, ao.out_kind == EMIT_DD_F64 ? P.acc[(u64)slot * P.n_gaggs + ao.s + 1] : 0ull);
+        emit_value(ao.data, row, ao.out_kind, v0, (ao.out_kind == EMIT_DD_F64 || ao.out_kind == EMIT_DDRES_F64) ? P.acc[(u64)slot * P.n_gaggs + ao.s + 1] : 0ull);
       }
       if (ao.is_null) ao.is_null[row] = c == 0;
     }

@@ -51,6 +51,7 @@ struct ssgpu_ctx {
   int64_t sort_records = 1;      // 0: always gather payload columns one by one
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
   int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
+  int64_t lazy_feedback = 1;     // 0: a GroupAggregate reads its overflow / feedback words back at the end of EVERY run (a stream synchronise per run)
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
@@ -182,6 +183,13 @@ struct StageExec {
   int last_reruns = 0;          // attempts beyond the first (regrown table / segments / partitions)
   int last_sort_passes = 0, last_sort_mode = 0;
   bool last_plain_scatter = false;
+  // Run feedback read lazily (steady state of a GroupAggregate that is the plan's last stage): the overflow / feedback
+  // words of the run are copied to pinned memory on the stream and looked at when the result is first touched or the
+  // plan runs again -- a run that did overflow after all is then repeated, synchronously, from the saved input columns.
+  PinnedBuf fb_host;
+  int fb_pending = 0;           // 0 none, 1 direct shape, 2 partitioned shape
+  int steady = 0;               // consecutive synchronous runs that neither overflowed nor changed the stage's shape
+  uint32_t steady_bypass = 0;   // direct shape: rows that bypassed the LDS table in the last synchronous run
 };
 
 struct ssgpu_result {
@@ -216,6 +224,8 @@ struct ssgpu_plan {
   std::vector<VmInstr> host_prog_scratch;
   bool partial_pending = false;
   int64_t last_rows = 0;
+  bool deferred = false;        // some stage's run feedback has not been looked at yet (settle_plan)
+  std::vector<ssgpu_column> last_cols; int64_t last_base = 0; bool last_partial = false;   // the last run's input (a deferred overflow repeats it)
   ssgpu_result result;
 };
 
@@ -303,6 +313,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_agg_debug") c->part_agg_debug = value;
   else if (k == "group_slab") c->group_slab = value;
   else if (k == "part_plain") c->part_plain = value;
+  else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
   else if (k == "sort_records") c->sort_records = value;
   else if (k == "sort_hybrid") c->sort_hybrid = value;
@@ -1316,9 +1327,16 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     p->counters.n_launches += 6;
     p->counters.tile_rows = Ps.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)Ps.lds_bytes;
-    uint32_t fb[4] = {0, 0, 0, 0};   // [0] a partition outgrew its LDS table, [1] a segment ran full
+    HIP_TRY(c, ex.fb_host.ensure(16));
+    uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // [0] a partition outgrew its LDS table, [1] a segment ran full
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
+    if (attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && si + 1 == p->stages.size()) {
+      // steady state: this shape held the last runs -- the flags are looked at lazily (settle_plan), no synchronise here
+      ex.fb_pending = 2; p->deferred = true;
+      return extract_groups(p, st, ex, capacity, ng, in, row_id_base);
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (attempt == 0 && !fb[0] && !fb[1]) ++ex.steady; else ex.steady = 0;
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, grid %d, segments of %llu records (%u B), table overflow=%u segment overflow=%u\n",
                                  NP, C, grid, (unsigned long long)seg_cap, st.part_rec_bytes, fb[0], fb[1]);
     if (slab && (fb[0] || fb[1])) {   // more groups than one LDS table holds after all: hash partitions
@@ -1347,7 +1365,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     const int rc = run_group_agg_partitioned(p, si, in, row_id_base, &fallback);
     if (rc != SSGPU_OK || !fallback) return rc;
     // heavily skewed keys / too many groups per partition: the direct path (global table behind the LDS table) always works
-    ex.group_partitioned = false; ex.group_local = true; ex.part_failed = true;
+    ex.group_partitioned = false; ex.group_local = true; ex.part_failed = true; ex.steady = 0;
   }
   if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
   ex.last_group_shape = 0; ex.last_plain_scatter = false;
@@ -1429,10 +1447,16 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: wgs/CU=%d local entries=%u sub-tables=%u grid=%d lds=%u\n", ex.group_wgs, lcap, lsub, grid, P.lds_bytes);
     p->counters.n_launches += 5;
-    uint32_t fb[4] = {0, 0, 0, 0};   // overflow flag, rows that bypassed the local table, max local occupancy
+    HIP_TRY(c, ex.fb_host.ensure(16));
+    uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // overflow flag, rows that bypassed the local table, max local occupancy
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
+    if (attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && si + 1 == p->stages.size()) {
+      ex.fb_pending = 1; p->deferred = true;   // steady state: looked at lazily (settle_plan)
+      break;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t overflow = fb[0];
+    const int shape_before[5] = {ex.group_wgs, ex.group_local ? 1 : 0, ex.group_partitioned ? 1 : 0, (int)ex.part_slab, ex.group_sub};
     if (lcap && !overflow) {
       // feedback for the next run of this plan: the largest residency whose table still holds
       // every group of a workgroup at <= 75% load; a table most rows bypass is switched off
@@ -1464,6 +1488,11 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
           else if ((double)fb[1] * 2.0 >= rows) ex.group_local = false;
         }
       }
+    }
+    {
+      const int shape_after[5] = {ex.group_wgs, ex.group_local ? 1 : 0, ex.group_partitioned ? 1 : 0, (int)ex.part_slab, ex.group_sub};
+      if (attempt == 0 && !overflow && memcmp(shape_before, shape_after, sizeof(shape_before)) == 0) { ++ex.steady; ex.steady_bypass = fb[1]; }
+      else ex.steady = 0;
     }
     if (!overflow) break;
     // table too small for this input: regrow x4 and run again (the reference grows its
@@ -1884,9 +1913,43 @@ int check_error_flags(ssgpu_plan* p) {
   return SSGPU_OK;
 }
 
+int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial);
+
+// Looks at run feedback that was left on the stream (StageExec::fb_pending).  A run that overflowed a table or a segment
+// after all produced an incomplete result: it is repeated here, synchronously (the stage is no longer "steady"), from the
+// columns the caller passed -- which it keeps alive until it has its result, as for every asynchronous run.
+int settle_plan(ssgpu_plan* p) {
+  if (!p->deferred) return SSGPU_OK;
+  ssgpu_ctx* c = p->ctx;
+  p->deferred = false;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  bool rerun = false;
+  for (auto& ex : p->exec) {
+    if (!ex.fb_pending) continue;
+    const uint32_t* fb = static_cast<const uint32_t*>(ex.fb_host.p);
+    const int kind = ex.fb_pending; ex.fb_pending = 0;
+    if (fb[0] || (kind == 2 && fb[1])) { rerun = true; ex.steady = 0; }
+    else if (kind == 1 && (uint64_t)fb[1] > 2ull * ex.steady_bypass + (uint64_t)(p->last_rows >> 6)) ex.steady = 0;   // the data moved: the next run adapts again
+  }
+  if (!rerun) return SSGPU_OK;
+  std::vector<ssgpu_column> cols = p->last_cols;
+  return run_plan(p, cols.data(), (int32_t)cols.size(), p->last_rows, p->last_base, p->last_partial);
+}
+
 int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial) {
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  if (p->deferred) {   // the previous run's feedback first: an overflow there puts the stage back into its adapting, synchronous form
+    p->deferred = false;   // (that run's result is being replaced by this run: nothing to repeat)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& ex : p->exec) {
+      if (!ex.fb_pending) continue;
+      const uint32_t* fb = static_cast<const uint32_t*>(ex.fb_host.p);
+      const int kind = ex.fb_pending; ex.fb_pending = 0;
+      if (fb[0] || (kind == 2 && fb[1])) ex.steady = 0;
+      else if (kind == 1 && (uint64_t)fb[1] > 2ull * ex.steady_bypass + (uint64_t)(p->last_rows >> 6)) ex.steady = 0;
+    }
+  }
   if (n_cols != (int)p->desc.input_schema.size()) { c->err = "column count does not match the plan's input schema"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
   if (rows < 0) { c->err = "negative row count"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
@@ -1955,6 +2018,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   if (c->profile && c->profile_total) { HIP_TRY(c, hipEventRecord(p->ev_end, c->stream)); p->events_valid = true; }
   p->counters.algorithmic_bytes = alg_bytes;
   p->last_rows = rows;
+  p->last_cols.assign(cols, cols + n_cols); p->last_base = row_id_base; p->last_partial = partial;
   p->partial_pending = partial;
   return SSGPU_OK;
 }
@@ -2141,7 +2205,9 @@ void ssgpu_result_destroy(ssgpu_result* r) { (void)r; /* owned by the plan: vali
 int ssgpu_result_write_file(ssgpu_result* r, const char* path) {
   if (!r || !r->plan || r->plan->exec.empty()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
-  int rc = check_error_flags(p);
+  int rc = settle_plan(p);
+  if (rc != SSGPU_OK) return rc;
+  rc = check_error_flags(p);
   if (rc != SSGPU_OK) return rc;
   const int64_t rows = ssgpu_result_row_count(r);
   if (rows < 0) return SSGPU_ERROR_HIP;
@@ -2155,6 +2221,7 @@ int ssgpu_result_write_file(ssgpu_result* r, const char* path) {
 
 int64_t ssgpu_result_row_count(ssgpu_result* r) {
   if (!r || !r->plan || r->plan->exec.empty()) return -1;
+  if (settle_plan(r->plan) != SSGPU_OK) return -1;
   int64_t rows = -1;
   if (stage_rows(r->plan, r->plan->exec.size() - 1, &rows) != SSGPU_OK) return -1;
   r->plan->counters.rows_out = rows;
@@ -2167,8 +2234,8 @@ int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
   StageExec& ex = r->plan->exec.back();
   if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   // device-resident consumers (the sharded sort / group aggregate) must not pass on the result of a run that hit a
-  // signaling division or SQRT error
-  { const int rc = check_error_flags(r->plan); if (rc != SSGPU_OK) return rc; }
+  // signaling division or SQRT error (or that overflowed a table: settled first)
+  { int rc = settle_plan(r->plan); if (rc != SSGPU_OK) return rc; rc = check_error_flags(r->plan); if (rc != SSGPU_OK) return rc; }
   out->data = ex.out[i].data.p;
   out->is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
   return SSGPU_OK;
@@ -2179,7 +2246,9 @@ int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data, const uin
   ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
   StageExec& ex = p->exec.back();
   if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
-  int rc = check_error_flags(p);
+  int rc = settle_plan(p);
+  if (rc != SSGPU_OK) return rc;
+  rc = check_error_flags(p);
   if (rc != SSGPU_OK) return rc;
   int64_t rows = ssgpu_result_row_count(r);
   if (rows < 0) return SSGPU_ERROR_HIP;
@@ -2283,6 +2352,12 @@ int ssgpu_result_pack_image(ssgpu_result* r, int64_t capacity_rows, void* image)
   P.image = image; P.capacity = (unsigned long long)capacity_rows;
   if (ex.out_rows >= 0) P.rows_host = (unsigned long long)ex.out_rows; else P.rows_dev = ex.total.as<unsigned long long>();
   for (auto& sx : p->exec) if (sx.error_flag.p && P.n_flags < 8) P.error_flags[P.n_flags++] = sx.error_flag.as<unsigned int>();
+  // a group stage whose overflow words have not been looked at yet (lazy feedback): they travel in the header, and a set
+  // word makes the receiver repeat the step -- by then the next run has settled the stage
+  for (auto& sx : p->exec) if (sx.fb_pending && sx.goverflow.p && P.n_retry + 2 <= 4) {
+    P.retry_flags[P.n_retry++] = sx.goverflow.as<unsigned int>();
+    if (sx.fb_pending == 2) P.retry_flags[P.n_retry++] = sx.goverflow.as<unsigned int>() + 1;
+  }
   for (size_t i = 0; i < ex.out.size(); ++i) {
     ImagePiece& d = P.pieces[P.n_pieces++];
     d.src = ex.out[i].data.p; d.image_off = (unsigned long long)L.img_data[i]; d.width = L.width[i];

@@ -636,9 +636,10 @@ __global__ void ssgpu_dense_extract_kernel(const DenseExtractParams P) {
   if (i >= P.n_rows) return;
   for (u32 q = 0; q < P.n_out; ++q) {
     const DenseAggOut o = P.out[q];
-    if (o.out_kind == EMIT_DD_F64) {   // compensated DOUBLE sum: (sum, compensation) in consecutive words
+    if (o.out_kind == EMIT_DD_F64 || o.out_kind == EMIT_DDRES_F64) {   // compensated DOUBLE sum: (sum, compensation) in consecutive words
       const double hi = __longlong_as_double((i64)P.acc[i * P.n_gaggs + o.s]), lo = __longlong_as_double((i64)P.acc[i * P.n_gaggs + o.s + 1]);
-      reinterpret_cast<double*>(o.data)[i] = lo == 0.0 ? hi : hi + lo;
+      const double sm = hi + lo, bp = sm - hi;
+      reinterpret_cast<double*>(o.data)[i] = o.out_kind == EMIT_DD_F64 ? (lo == 0.0 ? hi : sm) : (lo == 0.0 ? 0.0 : (hi - (sm - bp)) + (lo - bp));   // the sum / its exact residual (TwoSum)
     } else dense_emit(o.data, i, o.out_kind, P.acc[i * P.n_gaggs + o.s]);
     if (o.is_null) o.is_null[i] = o.has_cnt ? (P.cnt[i * P.n_gaggs + o.s] == 0) : 0;
   }

@@ -24,7 +24,27 @@ def device_executor(ctx):
     return run
 
 
-def _merge_spec(spec):
+RESIDUAL = "$res"    # suffix of the hidden column that carries a DOUBLE sum's residual across shards
+
+
+def _shard_spec(spec, input_schema):
+    """The specification a SHARD runs: `spec` plus, behind every DOUBLE SUM, the SUM_RESIDUAL of the same column
+    (include/ssgpu.h) -- the partial sum travels as the double-double pair (s, e), so that the cross-shard total is the
+    rounded sum of exact pairs instead of a sum of already rounded sums.  -> (shard spec, names of the sums that got one)."""
+    shard = ss.AggregationSpecification()
+    with_residual = []
+    for (aggregation, distinct, out_type, input_name, output_name) in spec.elements:
+        shard.elements.append((aggregation, distinct, out_type, input_name, output_name))
+        if aggregation != ss.SUM or distinct or input_schema is None:
+            continue
+        pos = input_schema.LookupAttributePosition(input_name)
+        if pos >= 0 and input_schema.attribute(pos).type() == ss.DOUBLE and out_type in (-1, ss.DOUBLE):
+            shard.elements.append((ss.SUM_RESIDUAL, 0, -1, input_name, output_name + RESIDUAL))
+            with_residual.append(output_name)
+    return shard, with_residual
+
+
+def _merge_spec(spec, with_residual=()):
     merged = ss.AggregationSpecification()
     counts = []
     for (aggregation, distinct, out_type, _input_name, output_name) in spec.elements:
@@ -35,7 +55,18 @@ def _merge_spec(spec):
             counts.append(output_name)
         else:
             merged.AddAggregation(aggregation, output_name, output_name)
+            if output_name in with_residual:
+                merged.AddAggregation(ss.SUM, output_name + RESIDUAL, output_name + RESIDUAL)
     return merged, counts
+
+
+def _schema_of(operation):
+    """Result schema of an operation tree (bound on a device-less context: binding needs no GPU); None if it does not bind
+    there -- the job then runs without residual columns, as before."""
+    try:
+        return ss.Plan(operation, ss.Context(-1)).result_schema
+    except ss.SupersonicException:
+        return None
 
 
 def job_strings(local_strings, group=None):
@@ -109,27 +140,36 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
     group_by: list of key attribute names; spec: AggregationSpecification; local_child: this rank's
     Operation (e.g. Filter(...ScanView(shard))).  Returns the same View on every rank (group order
     unspecified, as in the reference)."""
-    merged_spec, counts = _merge_spec(spec)
-    partial = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), spec, None, local_child))
+    shard_spec, with_residual = _shard_spec(spec, _schema_of(local_child))
+    merged_spec, counts = _merge_spec(spec, with_residual)
+    partial = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), shard_spec, None, local_child))
     everyone = _all_gather_view(partial, group, device)
     return executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), everyone))
 
 
 def _merge_plan(group_by, merged_spec, counts, schema, everyone, valid=None):
-    """The second, local GroupAggregate over the gathered partial tables (+ COUNT columns back to NOT NULL).
+    """The second, local GroupAggregate over the gathered partial tables (+ COUNT columns back to NOT NULL, and every DOUBLE
+    sum = its merged sum + its merged residual -- each of the two is itself accumulated in double-double -- with the
+    residual columns projected away).
     valid: name of a BOOL column of `everyone` marking the real rows (padding rows of fixed-size images are 0)."""
     source = ss.ScanView(everyone)
     if valid is not None:
         source = ss.Filter(ss.NamedAttribute(valid), ss.ProjectAllAttributes(), source)
     merged = ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), merged_spec, None, source)
-    if counts:
+    names = [schema.attribute(i).name() for i in range(schema.attribute_count())]
+    residuals = set(n for n in names if n.endswith(RESIDUAL))
+    if counts or residuals:
         # SUM(...) is NULLABLE, COUNT is not: restore the schema of the single-process result
         e = ss.CompoundExpression()
         for i in range(schema.attribute_count()):
             a = schema.attribute(i)
+            if a.name() in residuals:
+                continue
             if a.name() in counts:
                 zero = ss.ConstUint64(0) if a.type() == ss.UINT64 else ss.ConstUint32(0)
                 e.AddAs(a.name(), ss.IfNull(ss.NamedAttribute(a.name()), zero))
+            elif a.name() + RESIDUAL in residuals:
+                e.AddAs(a.name(), ss.Plus(ss.NamedAttribute(a.name()), ss.NamedAttribute(a.name() + RESIDUAL)))
             else:
                 e.Add(ss.NamedAttribute(a.name()))
         merged = ss.Compute(e, merged)
@@ -407,8 +447,9 @@ class DeviceShardedGroupAggregate(object):
         self.world = dist.get_world_size(group)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.group_by = list(group_by)
-        self.merged_spec, self.counts = _merge_spec(spec)
-        op = ss.GroupAggregate(ss.ProjectNamedAttributes(self.group_by), spec, None, local_child)
+        shard_spec, with_residual = _shard_spec(spec, _schema_of(local_child))
+        self.merged_spec, self.counts = _merge_spec(spec, with_residual)
+        op = ss.GroupAggregate(ss.ProjectNamedAttributes(self.group_by), shard_spec, None, local_child)
         # STRING keys / MIN / MAX results travel as the INT32 codes of ONE dictionary that every rank builds identically
         # (decided by the result schema, which is the same on all ranks: every rank issues the same collectives)
         self.strings = None

@@ -168,3 +168,31 @@ def job_strings_worker(rank, world, port, q):
     q.put((rank, job_strings([b"b", "a", b"zz"] if rank == 0 else [b"c", b"", b"a"])))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_shard_and_merge_specs_carry_double_sum_residuals():
+    # distributed.py: every DOUBLE SUM of the job travels as (SUM, SUM_RESIDUAL); other aggregates are unchanged and the
+    # merge plan's result has the original columns only (checked end to end on the GPU in test_double_sum_gpu.py)
+    import numpy as np
+    import supersonic_amd as ss
+    from supersonic_amd.distributed import _shard_spec, _merge_spec, RESIDUAL
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("d", ss.DOUBLE, ss.NULLABLE), ss.Attribute("i", ss.INT64), ss.Attribute("f", ss.FLOAT)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.SUM, "i", "si").AddAggregation(ss.MIN, "d", "mn")
+            .AddAggregation(ss.COUNT, "d", "c").AddAggregation(ss.SUM, "f", "sf"))
+    shard, with_residual = _shard_spec(spec, schema)
+    assert with_residual == ["sd"]
+    assert [(e[0], e[3], e[4]) for e in shard.elements] == [(ss.SUM, "d", "sd"), (ss.SUM_RESIDUAL, "d", "sd" + RESIDUAL), (ss.SUM, "i", "si"),
+                                                            (ss.MIN, "d", "mn"), (ss.COUNT, "d", "c"), (ss.SUM, "f", "sf")]
+    merged, counts = _merge_spec(spec, with_residual)
+    assert counts == ["c"]
+    assert [(e[0], e[3]) for e in merged.elements] == [(ss.SUM, "sd"), (ss.SUM, "sd" + RESIDUAL), (ss.SUM, "si"), (ss.MIN, "mn"), (ss.SUM, "c"), (ss.SUM, "sf")]
+    # binds (device-less context): a residual without its SUM, or over a non-DOUBLE column, is a bind error
+    view = ss.View(schema, [np.zeros(3, np.int32), ss.Column(np.zeros(3), np.zeros(3, bool)), np.zeros(3, np.int64), np.zeros(3, np.float32)])
+    ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), shard, None, ss.ScanView(view)), ss.Context(-1))
+    for bad in (ss.AggregationSpecification().AddAggregation(ss.SUM_RESIDUAL, "d", "r"),
+                ss.AggregationSpecification().AddAggregation(ss.SUM, "i", "s").AddAggregation(ss.SUM_RESIDUAL, "i", "r")):
+        try:
+            ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), bad, None, ss.ScanView(view)), ss.Context(-1))
+            raise AssertionError("bound")
+        except ss.SupersonicException as e:
+            assert e.return_code == ss.ERROR_INVALID_ARGUMENT_TYPE

@@ -86,3 +86,51 @@ def test_grouped_double_sum_is_within_one_ulp_of_the_exact_sum(groups, partition
     assert d.max() <= 1.0, (float(d.max()), int((d > 1).sum()))
     for k2, s2 in runs[1:]:                  # same bits whatever order the atomics arrived in
         assert np.array_equal(k2, keys) and s2.tobytes() == sums.tobytes()
+
+
+@pytest.mark.parametrize("groups,shards", [(7, 8), (1000, 8), (40000, 4)])
+def test_cross_shard_double_sum_keeps_the_ulp_bound(groups, shards):
+    """The sharded GroupAggregate (supersonic_amd/distributed.py) over row-range shards, as 8 GPUs would run it, on ONE GPU:
+    every shard's partial sum travels as the double-double pair (SUM, SUM_RESIDUAL), the merge adds the merged sums and the
+    merged residuals.  The total must stay within 1 ULP of the exact sum -- a sum of the shards' ROUNDED sums does not."""
+    from supersonic_amd.distributed import _shard_spec, _merge_spec, _merge_plan, RESIDUAL
+    n = 2000003
+    view, g, x = adversarial(n, groups, seed=9)
+    spec = ss.AggregationSpecification().AddAggregation(ss.SUM, "x", "s").AddAggregation(ss.COUNT, "", "n")
+    order = np.argsort(g, kind="stable")
+    gs, xs = g[order], x[order]
+    bounds = np.flatnonzero(np.r_[True, gs[1:] != gs[:-1], True])
+    exact = {int(gs[bounds[i]]): math.fsum(xs[bounds[i]:bounds[i + 1]].tolist()) for i in range(len(bounds) - 1)}
+    ctx = ss.Context(0)
+    shard_spec, with_residual = _shard_spec(spec, view.schema())
+    assert with_residual == ["s"]
+    merged_spec, counts = _merge_spec(spec, with_residual)
+    cuts = [n * i // shards for i in range(shards + 1)]
+    parts = []
+    for i in range(shards):
+        sv = ss.View(view.schema(), [g[cuts[i]:cuts[i + 1]], x[cuts[i]:cuts[i + 1]]])
+        parts.append(ss.drain(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), shard_spec, None, ss.ScanView(sv)).CreateCursor(ctx), 1 << 30))
+    schema = parts[0].schema()
+    assert [schema.attribute(i).name() for i in range(schema.attribute_count())] == ["g", "s", "s" + RESIDUAL, "n"]
+    everyone = ss.View(schema, [ss.Column(np.concatenate([p.column(i).data for p in parts]),
+                                          None if parts[0].column(i).is_null is None else np.concatenate([p.column(i).is_null for p in parts]))
+                                for i in range(schema.attribute_count())])
+    got = ss.drain(_merge_plan(["g"], merged_spec, counts, schema, everyone).CreateCursor(ctx), 1 << 30)
+    rs = got.schema()
+    assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["g", "s", "n"]          # the residual column does not leave the job
+    o = np.argsort(got.column(0).data)
+    keys, sums = got.column(0).data[o], got.column(1).data[o]
+    want = np.array([exact[int(k)] for k in keys])
+    d = ulp_distance(sums, want)
+    # the same merge WITHOUT the residuals: a sum of rounded partial sums
+    rounded = {}
+    for p in parts:
+        for k, s in zip(p.column(0).data.tolist(), p.column(1).data.tolist()):
+            rounded.setdefault(k, []).append(s)
+    d_rounded = ulp_distance(np.array([math.fsum(rounded[int(k)]) for k in keys]), want)
+    REPORT["cross_shard_%dgroups_%dshards" % (groups, shards)] = {
+        "hip_max_ulp_vs_exact": float(d.max()), "groups_off_by_one_ulp": int((d > 0).sum()),
+        "exactly_added_rounded_partials_max_ulp": float(d_rounded.max()), "groups": int(len(keys))}
+    save_report()
+    assert d.max() <= 1.0, (float(d.max()), int((d > 1).sum()))
+    assert int(got.column(2).data.sum()) == n

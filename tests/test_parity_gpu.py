@@ -1392,3 +1392,33 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(op, gpu_ctx)
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+
+
+# ---- lazy run feedback (runtime.cpp: settle_plan): in its steady state a GroupAggregate leaves its overflow words on the stream
+# ---- instead of synchronising at the end of every run; a run that overflows after all is repeated when its result is touched ---
+@pytest.mark.parametrize("partition", [1, 2])
+def test_group_aggregate_lazy_feedback_repeats_an_overflowing_run(partition):
+    rng = np.random.default_rng(11)
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64), ss.Attribute("d", ss.DOUBLE)])
+
+    def view_of(n, groups):
+        return ss.View(schema, [rng.integers(0, groups, n), rng.integers(-1000, 1000, n), rng.integers(-4000, 4000, n) * 0.25])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "c").AddAggregation(ss.MIN, "v", "mn")
+            .AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MAX, "d", "mx"))
+    few, many = view_of(300000, 3000), view_of(300000, 250000)
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", partition)
+    ctx.set_option("group_capacity", 8192)            # the direct shape's global table: 3000 groups fit, 250000 do not
+    op = lambda v: ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(v))   # noqa: E731
+    plan = ss.Plan(op(few), ctx)
+    _s, want_few = oracle_run(op(few))
+    for _ in range(6):                                # settles, then runs without a synchronise
+        plan.run(few)
+    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want_few), context="steady state")
+    plan.run(few)
+    plan.run(many)                                    # overflows its tables: noticed when the result is touched, and repeated
+    _s, want_many = oracle_run(op(many))
+    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want_many), context="overflow in the steady state")
+    assert plan.stage_info()[0]["reruns"] >= 1
+    plan.run(few)                                     # and back
+    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want_few), context="after the repeat")
