@@ -80,6 +80,7 @@ def group_spec(ss):
     return spec
 
 
+QUERY_NAME = "wide"     # the --query as given (group3 included): names the committed PMC pass of the workload
 GROUP_FILTER = True     # --query group3 (BASELINE configs[2]: no Filter below the GroupAggregate) clears it
 
 
@@ -145,17 +146,17 @@ class _DevPtr(object):
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def pmc_traffic(alg_bytes):
-    """HBM bytes per launch of the pipeline kernel from the committed PMC pass
-    (profiles/rNN_pmc.json, collected with rocprofv3 --pmc on this same command); PMC
-    counters cannot be read from inside the timed process, so the value is only reported
-    when the committed pass measured the same workload (same algorithmic bytes)."""
+def pmc_traffic(query, alg_bytes):
+    """HBM bytes per launch of the stage's kernels from the committed PMC passes (profiles/rNN_pmc_<query>.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE, one pass each, on this same command; FETCH_SIZE x 2 as calibrated on known byte counts,
+    tools/pmc_calibrate.sh).  PMC counters cannot be read from inside the timed process, so the value is only reported
+    when the committed pass measured the same workload (same query, same algorithmic bytes)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), reverse=True):
         try:
             with open(path) as f:
                 j = json.load(f)
-            if int(j.get("algorithmic_bytes_per_launch", -1)) == int(alg_bytes):
+            if j.get("query", "wide") == query and abs(int(j.get("algorithmic_bytes_per_launch", -1)) - int(alg_bytes)) <= int(alg_bytes) // 1000:
                 return float(j["traffic_bytes_per_launch"])
         except (OSError, ValueError, KeyError):
             continue
@@ -389,6 +390,8 @@ def extras(ss, torch, ctx, device, rows, cols, view):
 
 def main():
     args = parse_args()
+    global QUERY_NAME
+    QUERY_NAME = args.query
     if args.query == "group3":
         global GROUP_FILTER
         GROUP_FILTER = False
@@ -496,8 +499,19 @@ def main():
     # the last 256 pairs: the timed steps stay asynchronous and their kernel durations are read afterwards
     ctx.set_option("profile", 0 if args.no_events_in_loop else 1)
     ctx.set_option("profile_total", 0)      # only the pair around the stage's kernels, not the whole-run pair
-    step()                                   # set-up (not a warmup step): buffers are allocated and the stage kernels compiled
+    # set-up (not warm-up steps): buffers are allocated, the stage kernels compiled, and a GroupAggregate walks through its
+    # fed-back execution shapes -- until two consecutive steps compile nothing, allocate nothing and keep their shape
+    def settled_state():
+        st = ss.memory_stats()
+        return (st["device_bytes"], st["rtc_compilations"], json.dumps((job.first if job is not None else plan).stage_info(), sort_keys=True))
+    step()
     barrier()
+    for _ in range(8):
+        before = settled_state()
+        step()
+        barrier()
+        if settled_state() == before:
+            break
     for _ in range(args.warmup):
         step()
     if job is not None:
@@ -593,7 +607,7 @@ def main():
                        "tile_rows": counters.tile_rows, "grid": counters.grid, "lds_bytes": counters.lds_bytes,
                        "specialized_stages": plan.specialized()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(alg_bytes),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(QUERY_NAME, alg_bytes),
                          "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_row": alg_bytes / max(rows, 1)},
             "result_row": result_row,

@@ -68,13 +68,15 @@
  *       tests/test_double_sum_gpu.py) and identical to the reference whenever every partial sum is
  *       exactly representable;
  *       MIN / MAX over FLOAT / DOUBLE: the reference's update is "if (val < result) result = val"
- *       (aggregation_operators.h:200,221), which never replaces a NaN that came FIRST and never
- *       takes a NaN that comes later: its result for a group containing NaN depends on whether the
- *       NaN is the group's first non-NULL row.  DIVERGENCE: here NaN rows never contribute to
- *       MIN / MAX, whatever their position (where every value is NaN a group's result is NaN and a
- *       ScalarAggregate's is the identity, +inf for MIN and -inf for MAX) -- the result does
- *       not depend on the row order.  -0.0 and +0.0 compare equal in the reference, so which of the
- *       two a MIN / MAX returns is order-dependent there; here -0.0 < +0.0;
+ *       (aggregation_operators.h:200,221) after ASSIGNING a group's first non-NULL value: a NaN that
+ *       comes FIRST stays (nothing is less than NaN), a NaN that comes later is skipped.  Same here:
+ *       the kernels skip NaNs and flag the run when one reaches a floating MIN / MAX; such a run is
+ *       repeated ONCE, when its result is first touched, with the plan in its NaN-exact form (a
+ *       hidden FIRST of the column, result = IF(IS_NAN(first), first, min)), which the plan then
+ *       keeps -- data without NaNs never pays for it.  Not covered, and stated: aggregates next to a
+ *       DISTINCT aggregate, under max_unique_keys_in_result and across shards keep the
+ *       order-independent answer (NaNs skipped).  -0.0 and +0.0 compare equal in the reference, so
+ *       which of the two a MIN / MAX returns is order-dependent there; here -0.0 < +0.0;
  *       MIN / MAX from one integer type into another (AddAggregationWithDefinedOutputType): the
  *       reference compares every value in its own type with the running result and stores the cast
  *       (aggregation_operators.h:187-228), so MAX of INT32 {0, 1, -1} into UINT32 is 1

@@ -188,6 +188,10 @@ struct PlanDesc {
   std::vector<std::string> strings;  // storage for all names (stable addresses)
   bool filter_single_pass = false;   // ctx option of the same name at plan creation (lower.cpp, finish_materialize)
   int part_rec_align = 0;            // ctx option: partition records padded to a multiple of this many bytes (0 = 8)
+  // the reference keeps a NaN that is a group's FIRST non-NULL value as its floating MIN / MAX (aggregation_operators.h:189-228):
+  // in this form every such aggregate gets a hidden FIRST of the same column and the result is IF(IS_NAN(first), first, min).
+  // Set by the runtime when a run met a NaN in a floating MIN / MAX (SSGPU_FLAG_NAN_IN_MINMAX); plans start without it.
+  bool nan_exact = false;
 };
 Status copy_plan_desc(const ssgpu_plan_desc* d, PlanDesc* out);
 

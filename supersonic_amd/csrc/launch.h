@@ -62,6 +62,7 @@ struct PartAggParams {
   // the value in the record, 0xFF = none (24-31) | value width (32-39) | byte offset of the NULL flag, 0xFF = never
   // NULL (40-47) | contribution count tracked (48)
   unsigned long long desc[VM_MAX_AGG_SLOTS];
+  unsigned int* nan_flag;             // the stage's error word: SSGPU_FLAG_NAN_IN_MINMAX is set when a NaN reaches a floating MIN / MAX
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
 

@@ -1178,6 +1178,52 @@ static Status bind_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& 
   return Status::OK();
 }
 
+// ---- NaN-exact floating MIN / MAX (PlanDesc::nan_exact) ---------------------------------------------------------------
+// The reference's MIN / MAX assign a group's first non-NULL value and then replace it only when `val < result`
+// (aggregation_operators.h:189-228): a NaN that comes FIRST stays, later NaNs are skipped.  The kernels skip every NaN,
+// so in this form each floating MIN / MAX gets a hidden FIRST of the same column (the FIRST machinery already follows
+// input order) and the visible result becomes IF(IS_NAN(first), first, min).  NanFix: visible aggregate -> its hidden FIRST.
+struct NanFix { size_t agg; size_t first; };
+static void add_nan_exact_plans(bool enabled, const Schema& vs, std::vector<AggPlan>* plans, std::vector<NanFix>* fixes) {
+  if (!enabled) return;
+  const size_t n_user = plans->size();
+  for (size_t i = 0; i < n_user; ++i) {
+    const AggPlan ap = (*plans)[i];
+    if ((ap.aggregation != SSGPU_MIN && ap.aggregation != SSGPU_MAX) || ap.input_pos < 0) continue;
+    if (!dtype_is_float(vs[ap.input_pos].dtype) || !dtype_is_float(ap.out_type)) continue;
+    size_t first = 0;
+    for (size_t q = n_user; q < plans->size() && !first; ++q)
+      if ((*plans)[q].input_pos == ap.input_pos && (*plans)[q].out_type == ap.out_type) first = q;
+    if (!first) {
+      if ((int)plans->size() + 1 > VM_MAX_AGG_SLOTS) return;   // no slot left: the remaining aggregates keep the order-independent answer
+      AggPlan h; h.aggregation = SSGPU_FIRST; h.input_pos = ap.input_pos; h.out_type = ap.out_type;
+      h.out_name = "$first$" + std::to_string(plans->size()); h.result_nullable = true;
+      plans->push_back(h);
+      first = plans->size() - 1;
+    }
+    fixes->push_back(NanFix{i, first});
+  }
+}
+// the pipe over the aggregate's result: visible columns only, the fixed ones as IF(IS_NAN(first), first, min)
+static void apply_nan_fixes(const Schema& out_schema, size_t n_keys, size_t n_user, const std::vector<NanFix>& fixes, Pipe* pipe) {
+  std::vector<VCol> cols;
+  for (size_t c = 0; c < n_keys + n_user; ++c) {
+    VCol v = pipe->cols[c];
+    for (auto& f : fixes) {
+      if (n_keys + f.agg != c) continue;
+      const BExprP mn = pipe->cols[c].expr, fi = pipe->cols[n_keys + f.first].expr;
+      BExprP arg = fi;
+      if (fi->dtype != SSGPU_DOUBLE) { arg.reset(new BExpr); arg->kind = BExpr::CAST; arg->dtype = SSGPU_DOUBLE; arg->nullable = fi->nullable; arg->name = "CAST_TO_DOUBLE(" + fi->name + ")"; arg->args = {fi}; }
+      BExprP isnan(new BExpr); isnan->kind = BExpr::OP; isnan->op = OP_IS_NAN; isnan->dtype = SSGPU_BOOL; isnan->nullable = fi->nullable; isnan->name = "IS_NAN(" + fi->name + ")"; isnan->args = {arg};
+      BExprP sel(new BExpr); sel->kind = BExpr::OP; sel->op = OP_IF; sel->dtype = out_schema[c].dtype; sel->nullable = true;
+      sel->name = "IF(" + isnan->name + ", " + fi->name + ", " + mn->name + ")"; sel->args = {isnan, fi, mn};
+      v.expr = sel;
+    }
+    cols.push_back(v);
+  }
+  pipe->cols = cols;
+}
+
 // *too_wide is set (with an error status) when the hash aggregate cannot run as one fused pipeline
 // -- the packed key needs more than 64 bits, or FIRST/LAST reads a computed expression --
 // and lower_plan falls back to materialise + sort + clustered aggregation.
@@ -1747,6 +1793,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
       } break;
       case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: {
         Stage st;
+        std::vector<NanFix> nan_fixes; size_t n_user_aggs = 0, n_group_keys = 0;   // NaN-exact form (PlanDesc::nan_exact)
         // DISTINCT aggregates (SUM / COUNT of the distinct values of a group, column_aggregator.cc:308-376): materialise the
         // keys and the aggregated columns, sort by (keys, distinct column), flag the first row of every (keys, value) run
         // and aggregate with the flag standing in for "not NULL": a scalar aggregate over the sorted rows, or the
@@ -1818,8 +1865,13 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true, nullptr, n_in + 1));   // clustered: segment ids at n_in, the flag behind
           st.distinct_cols = run_cols;
           desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)) ";
-        } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg(d, op, pipe, &st));
-        else {
+        } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) {
+          std::vector<AggPlan> plans;
+          SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &plans));
+          n_user_aggs = plans.size();
+          add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &plans, &nan_fixes);
+          SS_RETURN_IF_ERROR(finish_scalar_agg_bound(plans, pipe, &st));
+        } else {
           // GroupAggregateOptions::max_unique_keys_in_result folds every key beyond the limit into one extra last row
           // (aggregate_groups.cc:326): depends on first-seen key order, which no device shape has -- refuse loudly
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
@@ -1830,6 +1882,8 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // with the aggregates' merge functions (SUM of sums, MIN of mins, MAX of maxes, SUM of counts).
           const bool limited = op.option0 != 0;
           const int64_t limit = op.option0 < 0 ? 0 : op.option0;
+          n_user_aggs = g.plans.size(); n_group_keys = g.kpos.size();
+          if (!limited) add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &g.plans, &nan_fixes);   // (under a key limit FIRST has no merge function)
           std::vector<int> fold_ops;
           if (limited) {
             if ((int)g.plans.size() + 1 > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
@@ -1893,6 +1947,11 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         stages->push_back(st);
         reset_pipe(&pipe, st.out_schema);
         pending = false;
+        if (!nan_fixes.empty()) {   // the visible result is computed from (min, hidden first): one more (tiny) pipeline over the aggregate's rows
+          apply_nan_fixes(st.out_schema, n_group_keys, n_user_aggs, nan_fixes, &pipe);
+          pending = true;
+          desc << "  (NaN-exact MIN / MAX: IF(IS_NAN(first), first, min))\n";
+        }
       } break;
       case SSGPU_OP_SORT: case SSGPU_OP_AGGREGATE_CLUSTERS: {
         // blocking operators over materialised rows: flush the pipeline first (a pipe that is
@@ -1907,6 +1966,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           reset_pipe(&pipe, m.out_schema);
         }
         Stage st;
+        std::vector<NanFix> c_fixes; size_t c_user_aggs = 0, c_keys = 0;
         st.in_schema = pipe.in_schema;
         if (op.kind == SSGPU_OP_SORT) {
           st.kind = STAGE_SORT;
@@ -1924,12 +1984,15 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           desc << "Sort -> [" << schema_to_string(st.out_schema) << "]\n";
         } else {
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          c_user_aggs = g.plans.size(); c_keys = g.kpos.size();
+          add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &g.plans, &c_fixes);
           SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
           desc << "AggregateClusters -> [" << schema_to_string(st.out_schema) << "]\n";
         }
         stages->push_back(st);
         reset_pipe(&pipe, st.out_schema);
         pending = false;
+        if (!c_fixes.empty()) { apply_nan_fixes(st.out_schema, c_keys, c_user_aggs, c_fixes, &pipe); pending = true; }
       } break;
       default:
         return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "operation kind " + std::to_string(op.kind) + " is outside the device hot path");

@@ -1187,10 +1187,10 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
         PART_APPLY(GAGG_MAX_I64, LDS_MAX(A, key_i64((i64)raw)))
         PART_APPLY(GAGG_MAX_U64, LDS_MAX(A, raw))
         PART_APPLY(GAGG_MAX_B8, LDS_MAX(A, (u64)((raw & 0xFFull) != 0)))
-        PART_APPLY(GAGG_MIN_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MIN(A, FKEY(e)); })
-        PART_APPLY(GAGG_MIN_F64, { const double e = u2d(raw); if (e == e) LDS_MIN(A, FKEY(e)); })
-        PART_APPLY(GAGG_MAX_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MAX(A, FKEY(e)); })
-        PART_APPLY(GAGG_MAX_F64, { const double e = u2d(raw); if (e == e) LDS_MAX(A, FKEY(e)); })
+        PART_APPLY(GAGG_MIN_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MIN(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
+        PART_APPLY(GAGG_MIN_F64, { const double e = u2d(raw); if (e == e) LDS_MIN(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
+        PART_APPLY(GAGG_MAX_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MAX(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
+        PART_APPLY(GAGG_MAX_F64, { const double e = u2d(raw); if (e == e) LDS_MAX(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
         default: break;
       }
     }

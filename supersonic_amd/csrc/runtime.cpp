@@ -225,6 +225,7 @@ struct ssgpu_plan {
   bool partial_pending = false;
   int64_t last_rows = 0;
   bool deferred = false;        // some stage's run feedback has not been looked at yet (settle_plan)
+  bool nan_seen = false;        // the last run met a NaN in a floating MIN / MAX (check_error_flags)
   std::vector<ssgpu_column> last_cols; int64_t last_base = 0; bool last_partial = false;   // the last run's input (a deferred overflow repeats it)
   ssgpu_result result;
 };
@@ -1308,6 +1309,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     A.T.keys = ex.gkeys.as<unsigned long long>(); A.T.acc = ex.gacc.as<unsigned long long>(); A.T.cnt = ex.gcnt.as<unsigned int>();
     A.T.overflow = ex.goverflow.as<unsigned int>(); A.T.capacity_mask = capacity - 1u; A.T.n_gaggs = ng;
     A.T.acc_init = ex.gpattern.as<unsigned long long>(); A.T.merge_op = ex.gmergeop.as<unsigned int>();
+    A.nan_flag = ex.error_flag.as<unsigned int>();
     for (size_t j = 0; j < st.part_aggs.size(); ++j) {
       const Stage::PartAgg& a = st.part_aggs[j];
       A.desc[j] = (uint64_t)(uint16_t)a.op | ((uint64_t)(uint8_t)a.word << 16) | ((uint64_t)(uint8_t)(a.val_off < 0 ? 0xFF : a.val_off) << 24) |
@@ -1902,6 +1904,10 @@ int check_error_flags(ssgpu_plan* p) {
     if (p->exec[i].error_flag.p)
       HIP_TRY(c, hipMemcpyAsync(&flags[i], p->exec[i].error_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t& f : flags) {
+    if (f & SSGPU_FLAG_NAN_IN_MINMAX) p->nan_seen = true;   // not an error: see fix_nan_minmax
+    f &= 0xFFu;
+  }
   for (uint32_t f : flags) {
     if (f == 3) { c->err = "single-pass compaction: a tile waited for an earlier tile's row count for too long and gave up"; return SSGPU_ERROR_HIP; }
     if (f) {
@@ -1936,9 +1942,38 @@ int settle_plan(ssgpu_plan* p) {
   return run_plan(p, cols.data(), (int32_t)cols.size(), p->last_rows, p->last_base, p->last_partial);
 }
 
+// Floating MIN / MAX and NaN.  The kernels skip NaN inputs, which is the reference's answer unless a NaN is a group's FIRST
+// non-NULL value -- then the reference's result is that NaN (aggregation_operators.h:189-228: the first value is assigned,
+// and "val < result" never replaces a NaN).  A run that met a NaN in such an aggregate (flagged by the kernels, seen by
+// check_error_flags) is therefore repeated once with the plan lowered in its NaN-exact form; the plan keeps that form.
+int fix_nan_minmax(ssgpu_plan* p) {
+  if (!p->nan_seen) return SSGPU_OK;
+  p->nan_seen = false;
+  if (p->desc.nan_exact || p->partial_pending) return SSGPU_OK;   // already exact (or a partial run: the shards' merge is not order-aware)
+  ssgpu_ctx* c = p->ctx;
+  p->desc.nan_exact = true;
+  std::vector<Stage> stages; Schema schema; std::string describe;
+  Status s = lower_plan(p->desc, &stages, &schema, &describe);
+  if (!s.ok()) { p->desc.nan_exact = false; return SSGPU_OK; }   // (a shape the exact form cannot take keeps the order-independent answer)
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); }
+  p->exec.clear();
+  p->stages = stages; p->describe = describe;
+  p->exec.resize(p->stages.size());
+  std::vector<ssgpu_column> cols = p->last_cols;
+  int rc = run_plan(p, cols.data(), (int32_t)cols.size(), p->last_rows, p->last_base, false);
+  if (rc != SSGPU_OK) return rc;
+  rc = settle_plan(p);
+  if (rc != SSGPU_OK) return rc;
+  rc = check_error_flags(p);
+  p->nan_seen = false;
+  return rc;
+}
+
 int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial) {
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  p->nan_seen = false;
   if (p->deferred) {   // the previous run's feedback first: an overflow there puts the stage back into its adapting, synchronous form
     p->deferred = false;   // (that run's result is being replaced by this run: nothing to repeat)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2208,6 +2243,7 @@ int ssgpu_result_write_file(ssgpu_result* r, const char* path) {
   int rc = settle_plan(p);
   if (rc != SSGPU_OK) return rc;
   rc = check_error_flags(p);
+  if (rc == SSGPU_OK) rc = fix_nan_minmax(p);
   if (rc != SSGPU_OK) return rc;
   const int64_t rows = ssgpu_result_row_count(r);
   if (rows < 0) return SSGPU_ERROR_HIP;
@@ -2231,11 +2267,11 @@ int32_t ssgpu_result_column_count(const ssgpu_result* r) { return r && r->plan ?
 
 int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
   if (!r || !r->plan) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
-  StageExec& ex = r->plan->exec.back();
-  if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   // device-resident consumers (the sharded sort / group aggregate) must not pass on the result of a run that hit a
   // signaling division or SQRT error (or that overflowed a table: settled first)
-  { int rc = settle_plan(r->plan); if (rc != SSGPU_OK) return rc; rc = check_error_flags(r->plan); if (rc != SSGPU_OK) return rc; }
+  { int rc = settle_plan(r->plan); if (rc != SSGPU_OK) return rc; rc = check_error_flags(r->plan); if (rc == SSGPU_OK) rc = fix_nan_minmax(r->plan); if (rc != SSGPU_OK) return rc; }
+  StageExec& ex = r->plan->exec.back();
+  if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   out->data = ex.out[i].data.p;
   out->is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
   return SSGPU_OK;
@@ -2244,12 +2280,13 @@ int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
 int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data, const uint8_t** is_null) {
   if (!r || !r->plan) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
-  StageExec& ex = p->exec.back();
-  if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   int rc = settle_plan(p);
   if (rc != SSGPU_OK) return rc;
   rc = check_error_flags(p);
+  if (rc == SSGPU_OK) rc = fix_nan_minmax(p);
   if (rc != SSGPU_OK) return rc;
+  StageExec& ex = p->exec.back();   // (the NaN-exact form replaces the plan's stages)
+  if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   int64_t rows = ssgpu_result_row_count(r);
   if (rows < 0) return SSGPU_ERROR_HIP;
   const size_t n = ex.out.size();

@@ -268,7 +268,7 @@ struct VmParams {
   unsigned long long* lb_status;  /* SEL_RANK_LB: one word per tile: state << 62 | epoch << 32 | rows (0 = not yet) */
   unsigned int* lb_ctrl;          /* [0..1] u64 total survivors, [3] look-back gave up                              */
   unsigned long long lb_epoch;    /* run stamp of lb_status words (stale words of earlier runs read as "not yet")    */
-  unsigned int* error_flag;     /* != 0: evaluation error (signaling ops)  */
+  unsigned int* error_flag;     /* low byte != 0: evaluation error (signaling ops); SSGPU_FLAG_NAN_IN_MINMAX: see below */
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */
   unsigned long long* debug_pc; /* optional [n_instr + 1]: cycles per instruction (wave 0 of every workgroup); last = staging */
   uint32_t debug_pc_lds_off;    /* LDS scratch of the same shape (accumulated there, flushed once) */
@@ -290,5 +290,10 @@ static inline const char* vm_op_name(uint16_t op) {
   return op < VM_OP_COUNT_ ? names[op] : "?";
 }
 #endif
+
+/* Bit of a stage's error word: a NaN reached a floating MIN / MAX.  The kernels skip NaNs (order-independent); the reference keeps
+ * a NaN that is the group's FIRST non-NULL value (aggregation_operators.h:189-228), so the host repeats such a run with the
+ * plan lowered in its NaN-exact form (lower.cpp: PlanDesc::nan_exact) -- data without NaNs never pays for it. */
+#define SSGPU_FLAG_NAN_IN_MINMAX 0x100u
 
 #endif  // SSGPU_VM_H_

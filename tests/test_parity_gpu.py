@@ -1187,31 +1187,51 @@ def test_round_with_precision(gpu_ctx, n):
     run_both(ss.Compute(ss.CompoundExpression().AddAs("rp", ss.RoundWithPrecision(NA("x"), NA("p"))), ss.ScanView(view)), gpu_ctx, max_ulp=LIBM_ULP)
 
 
-def test_float_min_max_ignore_nan_wherever_it_stands(gpu_ctx):
-    # include/ssgpu.h, "floating aggregates": the reference keeps a LEADING NaN and skips later ones
-    # (aggregation_operators.h:200,221: "if (val < result) result = val"); the device result does not depend on the
-    # row order -- NaN rows never contribute; a group of only NaN rows gives NaN (ScalarAggregate: +inf / -inf).
+@pytest.mark.parametrize("n", [9, 1025, 200003])
+@pytest.mark.parametrize("partition", [1, 2])
+def test_float_min_max_keep_a_leading_nan_like_the_reference(n, partition):
+    """aggregation_operators.h:189-228: a group's first non-NULL value is assigned, later values replace it only when
+    `val < result` -- so a NaN that comes FIRST stays (nothing compares less than NaN) and later NaNs are skipped.  The kernels
+    skip every NaN; a run that met one in a floating MIN / MAX is repeated in the plan's NaN-exact form (hidden FIRST of the
+    column, IF(IS_NAN(first), first, min)) -- bit-identical to the oracle, which restates the reference's fold."""
+    rng = np.random.default_rng(n)
     nan = float("nan")
-    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("x", ss.DOUBLE), ss.Attribute("f", ss.FLOAT, ss.NULLABLE)])
-    g = np.array([0, 0, 0, 1, 1, 1, 2, 2, 3], np.int32)
-    x = np.array([nan, 2.0, -1.0, 5.0, nan, 7.0, nan, nan, 4.0])
-    f = np.array([nan, 2.0, -1.0, 5.0, nan, 7.0, nan, nan, 4.0], np.float32)
-    fz = np.array([False, False, False, False, False, True, False, False, False])
-    view = ss.View(schema, [g, x, ss.Column(f, fz)])
-    spec = (ss.AggregationSpecification().AddAggregation(ss.MIN, "x", "lo").AddAggregation(ss.MAX, "x", "hi")
-            .AddAggregation(ss.MIN, "f", "flo").AddAggregation(ss.MAX, "f", "fhi"))
-    got = ss.drain(ss.Sort(ss.SortOrder().add("g", ss.ASCENDING), None, 0,
-                           ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(view))).CreateCursor(gpu_ctx))
-    lo, hi, flo, fhi = [got.column(i).data for i in (1, 2, 3, 4)]
-    assert list(lo[[0, 1, 3]]) == [-1.0, 5.0, 4.0] and list(hi[[0, 1, 3]]) == [2.0, 7.0, 4.0]
-    assert list(flo[[0, 1, 3]]) == [-1.0, 5.0, 4.0] and list(fhi[[0, 1, 3]]) == [2.0, 5.0, 4.0]
-    assert np.isnan(lo[2]) and np.isnan(hi[2]) and np.isnan(flo[2]) and np.isnan(fhi[2])
-    sc = ss.drain(ss.ScalarAggregate(spec, ss.ScanView(view)).CreateCursor(gpu_ctx))
-    assert [float(sc.column(i).data[0]) for i in range(4)] == [-1.0, 7.0, -1.0, 5.0]
-    only_nan = ss.View(schema, [g[6:8], x[6:8], ss.Column(f[6:8], fz[6:8])])
-    sc = ss.drain(ss.ScalarAggregate(spec, ss.ScanView(only_nan)).CreateCursor(gpu_ctx))
-    # no value at all contributes: the scalar accumulators keep their identities (the group tables' identities decode to NaN)
-    assert [float(sc.column(i).data[0]) for i in range(4)] == [float("inf"), float("-inf"), float("inf"), float("-inf")]
+    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("x", ss.DOUBLE), ss.Attribute("f", ss.FLOAT, ss.NULLABLE), ss.Attribute("v", ss.INT64)])
+    if n == 9:
+        g = np.array([0, 0, 0, 1, 1, 1, 2, 2, 3], np.int32)
+        x = np.array([nan, 2.0, -1.0, 5.0, nan, 7.0, nan, nan, 4.0])
+        f = x.astype(np.float32)
+        fz = np.array([False, False, False, False, False, True, True, False, False])
+    else:
+        g = rng.integers(0, 700, n).astype(np.int32)
+        x = rng.integers(-1000, 1000, n) * 0.5
+        x[rng.random(n) < 0.02] = nan                # many groups start with a NaN, many meet one later, many never do
+        f = x.astype(np.float32)
+        fz = rng.random(n) < 0.1
+    view = ss.View(schema, [g, x, ss.Column(f, fz), rng.integers(0, 100, n)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.MIN, "x", "lo").AddAggregation(ss.MAX, "x", "hi").AddAggregation(ss.SUM, "v", "sv")
+            .AddAggregation(ss.MIN, "f", "flo").AddAggregation(ss.MAX, "f", "fhi").AddAggregationWithDefinedOutputType(ss.MAX, "f", "fhd", ss.DOUBLE)
+            .AddAggregation(ss.COUNT, "f", "cf"))
+    ctx = ss.Context(0)
+    ctx.set_option("group_partition", partition)
+    group = ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(view))
+    got = run_both(group, ctx, ignore_order=True)
+    if n == 9:
+        lo = got.column(1).data[np.argsort(got.column(0).data)]
+        assert np.isnan(lo[0]) and lo[1] == 5.0 and np.isnan(lo[2]) and lo[3] == 4.0     # leading NaN kept, later NaN skipped, only-NaN group, no NaN
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), ctx)
+    run_both(ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("v"), ss.ConstInt64(49)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx)
+    order = np.argsort(g, kind="stable")
+    clustered = ss.View(schema, [g[order], x[order], ss.Column(f[order], fz[order]), view.column(3).data[order]])
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("g"), spec, ss.ScanView(clustered)), ctx)
+    # a plan keeps its exact form once it has needed it, and data without NaNs never pays for it
+    plan = ss.Plan(group, ctx)
+    plan.run(); plan.fetch()
+    assert "NaN-exact" in plan.describe()
+    clean = ss.View(schema, [g, np.nan_to_num(x), ss.Column(np.nan_to_num(f), fz), view.column(3).data])
+    plan2 = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(clean)), ctx)
+    plan2.run(); plan2.fetch()
+    assert "NaN-exact" not in plan2.describe()
 
 
 @pytest.mark.parametrize("n", [1, 65, 1025, 100003])
