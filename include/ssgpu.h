@@ -415,12 +415,15 @@ int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
  * partition-aggregation kernel -- whose shape its first runs settle).  A plan that never asked never compiles: no run
  * of it blocks on a compiler, and no code is loaded behind its back.  A compilation (~2 s + 0.4 s per VM instruction)
  * does not hold any library lock: other plans run and compile meanwhile; two plans wanting the same kernel share one
- * compilation.  The modules are reference-counted: ssgpu_plan_destroy drops the plan's references and the code object
- * of a kernel no other plan uses is unloaded (ssgpu_memory_stats shows modules and code bytes currently loaded).
+ * compilation.  The modules are reference-counted: ssgpu_plan_destroy drops the plan's references; a kernel without a user
+ * stays loaded while it is among the 8 most recently released ones (the next plan with the same program finds it instead
+ * of compiling for seconds) and is unloaded beyond that; ssgpu_specialized_kernels_trim(keep) unloads idle kernels down to
+ * `keep` at once (ssgpu_memory_stats shows modules and code bytes currently loaded).
  * A stage whose specialisation is not possible (no libhiprtc on the host, a compilation failure) keeps the
  * interpreting kernel -- still the HIP path -- and ssgpu_plan_specialize_reason says why ("" if nothing was refused).
  * ssgpu_plan_specialized: how many specialised kernels the plan currently holds. */
 int ssgpu_plan_specialize(ssgpu_plan* plan);
+void ssgpu_specialized_kernels_trim(int32_t keep);
 int32_t ssgpu_plan_specialized(const ssgpu_plan* plan);
 const char* ssgpu_plan_specialize_reason(const ssgpu_plan* plan);
 /* What the library holds in this process, right now: device and pinned-host bytes of every live buffer (blocks, plans'
@@ -526,6 +529,14 @@ int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
 int ssgpu_plan_image_layout(const ssgpu_plan* plan, int64_t capacity_rows, int32_t n_images,
                             int64_t* image_bytes, int64_t* unpacked_bytes, int64_t* offsets);
 int ssgpu_result_pack_image(ssgpu_result* r, int64_t capacity_rows, void* image);
+/* Key-range exchange (the form that scales): instead of sending its whole partial table to every rank, a shard routes
+ * every row to ONE of n_dest images by a hash of the row's first n_keys columns (the group keys; NULL keys hash as a flag)
+ * -- image d of `images` (n_dest consecutive images of ssgpu_plan_image_layout(plan, capacity_rows, 1) bytes) holds the
+ * rows whose key belongs to rank d.  One all-to-all of the equally sized images then gives every rank all partial rows
+ * of the groups it owns; it merges 1 / n_dest of the key space instead of everything (ssgpu_images_unpack + the merge
+ * plan as before).  The hash depends on the key bytes only: every rank agrees on a key's owner.  Headers as for
+ * ssgpu_result_pack_image (an image that is full is flagged; a set flag makes the receiver repeat the step). */
+int ssgpu_result_route_images(ssgpu_result* r, int32_t n_keys, int32_t n_dest, int64_t capacity_rows, void* images);
 int ssgpu_images_unpack(ssgpu_plan* plan, const void* images, int32_t n_images, int64_t capacity_rows,
                         void* unpacked, ssgpu_column* cols /* attr_count + 1 */);
 

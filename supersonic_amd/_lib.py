@@ -132,6 +132,7 @@ SYMBOLS = [
     ("ssgpu_plan_set_memory_limit", C.c_int, [P, C.c_int64]),
     ("ssgpu_plan_specialized", C.c_int32, [P]),
     ("ssgpu_plan_specialize", C.c_int, [P]),
+    ("ssgpu_specialized_kernels_trim", None, [C.c_int32]),
     ("ssgpu_plan_stage_count", C.c_int32, [P]),
     ("ssgpu_plan_stage_info", C.c_int, [P, C.c_int32, C.POINTER(StageInfo)]),
     ("ssgpu_plan_specialize_reason", C.c_char_p, [P]),
@@ -172,6 +173,7 @@ SYMBOLS = [
     ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
     ("ssgpu_plan_image_layout", C.c_int, [P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("ssgpu_result_pack_image", C.c_int, [P, C.c_int64, P]),
+    ("ssgpu_result_route_images", C.c_int, [P, C.c_int32, C.c_int32, C.c_int64, P]),
     ("ssgpu_images_unpack", C.c_int, [P, P, C.c_int32, C.c_int64, P, C.POINTER(Column)]),
     ("ssgpu_result_destroy", None, [P]),
     ("ssgpu_result_row_count", C.c_int64, [P]),

@@ -189,6 +189,11 @@ class Context(object):
             pass
 
 
+def specialized_kernels_trim(keep=0):
+    """Unload specialised kernels that no plan uses, down to `keep` of them (ssgpu_specialized_kernels_trim)."""
+    L.load().ssgpu_specialized_kernels_trim(int(keep))
+
+
 def memory_stats():
     """ssgpu_memory_stats: what the library holds in this process right now (device / pinned bytes, live plans, blocks and
     events, loaded specialised-kernel modules), as a dict."""
@@ -1252,6 +1257,11 @@ class Plan(object):
     def pack_image(self, capacity_rows, image_ptr, res=None):
         """Pack the (device-resident) result into one image at the device pointer `image_ptr` (async)."""
         self.ctx.check(self.lib.ssgpu_result_pack_image(res or self._result, capacity_rows, C.c_void_p(image_ptr)))
+
+    def route_images(self, n_keys, n_dest, capacity_rows, images_ptr, res=None):
+        """Key-range exchange: route the (device-resident) result's rows into n_dest images at `images_ptr` by a hash of their
+        first n_keys columns (async)."""
+        self.ctx.check(self.lib.ssgpu_result_route_images(res or self._result, n_keys, n_dest, capacity_rows, C.c_void_p(images_ptr)))
 
     def unpack_images(self, images_ptr, n_images, capacity_rows, unpacked_ptr):
         """n_images gathered images of THIS plan's result schema -> the columns of one

@@ -71,6 +71,71 @@ __global__ __launch_bounds__(256) void ssgpu_unpack_images_kernel(const ImageUnp
   copy_bytes(dst, image + pc.image_off, rows * pc.width, first, stride);
 }
 
+// ---- key-range exchange ------------------------------------------------------------------------------------------------
+// The all-gather form sends every partial table to every rank, which then merges ALL of them (world x redundant work, and
+// (world - 1) x the bytes on every link).  Here a shard's partial table is split by key instead: row -> image
+// hash(group keys) mod n_dest, one image per destination rank, ONE all-to-all of equally sized images, and every rank
+// merges only the groups it owns (1 / world of the key space).  The hash is a function of the key BYTES (NULL keys hash
+// as a flag, their value bytes ignored), so every rank routes a key to the same owner.  Rows of one source keep no
+// particular order inside an image (a group occurs once per source table: the merge does not depend on it).
+// Phase 1 (this kernel): destination and position of every row (one returning atomic on n_dest counters);
+// phase 2 (ssgpu_route_copy_kernel): the cells, column by column, coalesced reads.
+__device__ __forceinline__ u64 route_mix(u64 h, u64 x) { h ^= x; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; return h * 0xBF58476D1CE4E5B9ull; }
+__global__ __launch_bounds__(256) void ssgpu_route_rows_kernel(const ImagePackParams P, const ImageRoutePieces R, u32* __restrict__ dest_pos) {
+  const u64 rows = P.rows_dev ? *P.rows_dev : P.rows_host;
+  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < rows; r += (u64)gridDim.x * 256) {
+    u64 h = 0x243F6A8885A308D3ull;
+    for (u32 k = 0; k < R.n_keys; ++k) {
+      const ImagePiece pc = P.pieces[R.key_piece[k]];
+      const bool is_null = R.key_null_piece[k] >= 0 && P.pieces[R.key_null_piece[k]].src && reinterpret_cast<const u8*>(P.pieces[R.key_null_piece[k]].src)[r] != 0;
+      u64 v = 0;
+      if (!is_null) {
+        const char* c = reinterpret_cast<const char*>(pc.src) + r * pc.width;
+        v = pc.width == 8 ? *reinterpret_cast<const u64*>(c) : pc.width == 4 ? (u64)*reinterpret_cast<const u32*>(c) : (u64)*reinterpret_cast<const u8*>(c);
+      }
+      h = route_mix(h, v + (is_null ? 0x51ull : 0ull)) + k;
+    }
+    const u32 d = (u32)((h >> 32) % R.n_dest);
+    const u32 pos = atomicAdd(&R.counters[d], 1u);
+    dest_pos[2 * r] = d; dest_pos[2 * r + 1] = pos;
+  }
+}
+// grid = (blocks, pieces): piece p of row r -> image dest[r], row pos[r]; block (0, 0) writes the n_dest headers
+__global__ __launch_bounds__(256) void ssgpu_route_copy_kernel(const ImagePackParams P, const ImageRoutePieces R, const u32* __restrict__ dest_pos) {
+  const u64 rows = P.rows_dev ? *P.rows_dev : P.rows_host;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < R.n_dest) {
+    const u32 d = threadIdx.x;
+    u64* h = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.image) + (u64)d * R.image_bytes);
+    const u64 have = R.counters[d];
+    u64 retry = 0, err = 0;
+    for (u32 f = 0; f < P.n_retry; ++f) retry |= (u64)*P.retry_flags[f];
+    for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)*P.error_flags[f];
+    h[0] = have < P.capacity ? have : P.capacity; h[1] = P.capacity; h[2] = (have > P.capacity || retry) ? 1ull : 0ull; h[3] = have;
+    h[4] = err; h[5] = 0; h[6] = 0; h[7] = 0;
+  }
+  const ImagePiece pc = P.pieces[blockIdx.y];
+  const u32 w = pc.width;
+  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < rows; r += (u64)gridDim.x * 256) {
+    const u32 d = dest_pos[2 * r], pos = dest_pos[2 * r + 1];
+    if (pos >= P.capacity) continue;                     // this image is full: flagged in its header, the caller regrows and repeats
+    char* dst = reinterpret_cast<char*>(P.image) + (u64)d * R.image_bytes + pc.image_off + (u64)pos * w;
+    if (!pc.src) { for (u32 b = 0; b < w; ++b) dst[b] = 0; continue; }
+    const char* src = reinterpret_cast<const char*>(pc.src) + r * w;
+    if (w == 8) *reinterpret_cast<u64*>(dst) = *reinterpret_cast<const u64*>(src);
+    else if (w == 4) *reinterpret_cast<u32*>(dst) = *reinterpret_cast<const u32*>(src);
+    else *dst = *src;
+  }
+}
+hipError_t ssgpu_launch_route_images(const ImagePackParams& P, const ImageRoutePieces& R, hipStream_t s) {
+  // dest_pos scratch lives behind the counters (the caller sized it: n_dest + 2 * capacity_in words)
+  u32* dest_pos = R.counters + ((R.n_dest + 3u) & ~3u);
+  const u64 rows_max = P.rows_dev ? P.rows_host : P.rows_host;   // (rows_host carries the upper bound of the row count when rows_dev is given)
+  const unsigned bx = (unsigned)std::min<u64>(std::max<u64>((rows_max + 255) / 256, 1), 512);
+  hipLaunchKernelGGL(ssgpu_route_rows_kernel, dim3(bx), dim3(256), 0, s, P, R, dest_pos);
+  hipLaunchKernelGGL(ssgpu_route_copy_kernel, dim3(bx, std::max<u32>(P.n_pieces, 1)), dim3(256), 0, s, P, R, (const u32*)dest_pos);
+  return hipGetLastError();
+}
+
 hipError_t ssgpu_launch_pack_image(const ImagePackParams& P, hipStream_t s) {
   const unsigned bx = (unsigned)std::min<u64>(std::max<u64>((P.capacity * 8 + 4095) / 4096, 1), 256);
   hipLaunchKernelGGL(ssgpu_pack_image_kernel, dim3(bx, std::max<u32>(P.n_pieces, 1)), dim3(256), 0, s, P);

@@ -144,6 +144,7 @@ void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int ro
 hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterParams& P, int grid, hipStream_t stream);
 void* ssgpu_rtc_function(void* handle);
 void ssgpu_rtc_release(void* handle);
+void ssgpu_rtc_trim(int keep);   // unloads kernels without a user down to `keep` of them
 void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations);
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
@@ -223,6 +224,10 @@ struct ImageUnpackParams {
   ImagePiece pieces[SSGPU_IMAGE_MAX_PIECES];
 };
 hipError_t ssgpu_launch_pack_image(const ImagePackParams& P, hipStream_t s);
+// Key-range exchange: the result's rows routed into n_dest images by a hash of their first n_keys columns (the group keys),
+// image d at images + d * image_bytes.  counters: n_dest device words, zero at launch (rows appended to each image).
+struct ImageRoutePieces { unsigned int n_keys, n_dest; unsigned long long image_bytes; unsigned int* counters; unsigned int key_piece[16]; int key_null_piece[16]; };
+hipError_t ssgpu_launch_route_images(const ImagePackParams& P, const ImageRoutePieces& R, hipStream_t s);
 hipError_t ssgpu_launch_unpack_images(const ImageUnpackParams& P, hipStream_t s);
 
 #endif  // SSGPU_LAUNCH_H_

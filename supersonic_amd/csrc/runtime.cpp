@@ -171,6 +171,7 @@ struct StageExec {
   DevBuf debug, debug_pc, total2;
   // sort / clusters
   DevBuf skeys_a, skeys_b, skeys_c, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
+  DevBuf route_scratch;         // key-range exchange: per-destination counters + (destination, position) of every result row
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
   bool pattern_ready = false;
@@ -2112,6 +2113,7 @@ int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* 
   out->plain_scatter = ex.last_plain_scatter ? 1 : 0;
   return SSGPU_OK;
 }
+void ssgpu_specialized_kernels_trim(int32_t keep) { ssgpu_rtc_trim(keep); }
 int ssgpu_memory_stats(ssgpu_memory_stats_t* out) {
   if (!out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   memset(out, 0, sizeof(*out));
@@ -2404,6 +2406,44 @@ int ssgpu_result_pack_image(ssgpu_result* r, int64_t capacity_rows, void* image)
     }
   }
   HIP_TRY(c, ssgpu_launch_pack_image(P, c->stream));
+  return SSGPU_OK;
+}
+
+int ssgpu_result_route_images(ssgpu_result* r, int32_t n_keys, int32_t n_dest, int64_t capacity_rows, void* images) {
+  if (!r || !r->plan || r->plan->exec.empty() || !images || n_dest < 1 || n_dest > 256 || n_keys < 0 || n_keys > 16) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
+  if (c->device < 0) return SSGPU_ERROR_NO_DEVICE;
+  if (n_keys > (int32_t)p->result_schema.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ImageLayout L;
+  if (!image_layout(p->result_schema, capacity_rows, 1, &L)) { c->err = "result images need fixed-width columns and a non-negative capacity"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  StageExec& ex = p->exec.back();
+  ImagePackParams P; memset(&P, 0, sizeof(P));
+  ImageRoutePieces R; memset(&R, 0, sizeof(R));
+  P.image = images; P.capacity = (unsigned long long)capacity_rows;
+  const uint64_t rows_max = ex.out_rows >= 0 ? (uint64_t)ex.out_rows : (uint64_t)std::max<int64_t>(ex.out_capacity, 1);
+  P.rows_host = rows_max;   // the routing kernels' bound on the row count; the count itself is on the device when the stage left it there
+  if (ex.out_rows < 0) P.rows_dev = ex.total.as<unsigned long long>();
+  for (auto& sx : p->exec) if (sx.error_flag.p && P.n_flags < 8) P.error_flags[P.n_flags++] = sx.error_flag.as<unsigned int>();
+  for (auto& sx : p->exec) if (sx.fb_pending && sx.goverflow.p && P.n_retry + 2 <= 4) {
+    P.retry_flags[P.n_retry++] = sx.goverflow.as<unsigned int>();
+    if (sx.fb_pending == 2) P.retry_flags[P.n_retry++] = sx.goverflow.as<unsigned int>() + 1;
+  }
+  for (size_t i = 0; i < ex.out.size(); ++i) {
+    if ((int32_t)i < n_keys) { R.key_piece[i] = P.n_pieces; R.key_null_piece[i] = -1; }
+    ImagePiece& d = P.pieces[P.n_pieces++];
+    d.src = ex.out[i].data.p; d.image_off = (unsigned long long)L.img_data[i]; d.width = L.width[i];
+    if (L.img_null[i] >= 0) {
+      if ((int32_t)i < n_keys) R.key_null_piece[i] = (int)P.n_pieces;
+      ImagePiece& z = P.pieces[P.n_pieces++];
+      z.src = ex.out[i].nullable ? ex.out[i].nulls.p : nullptr; z.image_off = (unsigned long long)L.img_null[i]; z.width = 1;
+    }
+  }
+  R.n_keys = (unsigned)n_keys; R.n_dest = (unsigned)n_dest; R.image_bytes = (unsigned long long)L.image_bytes;
+  const size_t head = ((size_t)n_dest + 3u) & ~(size_t)3u;
+  HIP_TRY(c, ex.route_scratch.ensure((head + 2 * rows_max) * 4));
+  HIP_TRY(c, hipMemsetAsync(ex.route_scratch.p, 0, head * 4, c->stream));
+  R.counters = ex.route_scratch.as<unsigned int>();
+  HIP_TRY(c, ssgpu_launch_route_images(P, R, c->stream));
   return SSGPU_OK;
 }
 

@@ -134,17 +134,60 @@ def _all_gather_view(view, group, device):
     return ss.View(view.schema(), cols, sum(counts))
 
 
-def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, device="cpu"):
-    """GroupAggregate(group_by, spec, <all shards of local_child>) with one all-gather.
+def _owner_of_rows(view, n_keys, world):
+    """Owner rank of every row of a partial table: a hash of the key cells (NULL keys hash as a flag) modulo the world
+    size -- any function of the key values works as long as every rank computes the same one (host form of the key-range
+    exchange; the device form is ssgpu_result_route_images)."""
+    h = np.full(view.row_count(), 0x243F6A8885A308D3, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for k in range(n_keys):
+            col = view.column(k)
+            if col.data.dtype == object:
+                cells = np.array([int.from_bytes(bytes(v or b"")[:8].ljust(8, b"\0"), "little") ^ len(v or b"") for v in col.data], dtype=np.uint64)
+            else:
+                cells = np.zeros(view.row_count(), dtype=np.uint64)
+                raw = np.ascontiguousarray(col.data)
+                cells[:] = raw.view({1: np.uint8, 4: np.uint32, 8: np.uint64}[raw.dtype.itemsize])
+            if col.is_null is not None:
+                cells = np.where(col.is_null, np.uint64(0x51), cells)
+            h = (h ^ cells) * np.uint64(0x9E3779B97F4A7C15)
+            h ^= h >> np.uint64(29)
+    return ((h >> np.uint64(32)) % np.uint64(world)).astype(np.int64)
+
+
+def _take_rows(view, mask):
+    return ss.View(view.schema(), [ss.Column(view.column(i).data[mask], None if view.column(i).is_null is None else view.column(i).is_null[mask])
+                                   for i in range(view.column_count())], int(mask.sum()))
+
+
+def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, device="cpu", key_range=False):
+    """GroupAggregate(group_by, spec, <all shards of local_child>) with one exchange step.
 
     group_by: list of key attribute names; spec: AggregationSpecification; local_child: this rank's
     Operation (e.g. Filter(...ScanView(shard))).  Returns the same View on every rank (group order
-    unspecified, as in the reference)."""
+    unspecified, as in the reference).
+
+    key_range=False: every partial table goes to every rank (one all-gather) and every rank merges all of them.
+    key_range=True: a partial row goes only to the rank that owns its key (hash of the group keys modulo the world size:
+    one all-to-all), every rank merges 1 / world of the groups, and the finished slices are gathered -- the form whose
+    merge work and link traffic shrink with the number of ranks."""
+    import torch.distributed as dist
     shard_spec, with_residual = _shard_spec(spec, _schema_of(local_child))
     merged_spec, counts = _merge_spec(spec, with_residual)
     partial = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), shard_spec, None, local_child))
-    everyone = _all_gather_view(partial, group, device)
-    return executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), everyone))
+    if not key_range:
+        everyone = _all_gather_view(partial, group, device)
+        return executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), everyone))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    owner = _owner_of_rows(partial, len(group_by), world)
+    # the all-to-all, spelled with all-gathers of the per-destination slices (host form: any backend has all_gather)
+    mine = []
+    for d in range(world):
+        arrived = _all_gather_view(_take_rows(partial, owner == d), group, device)    # every rank receives destination d's rows ...
+        if d == rank:
+            mine = arrived                                                           # ... and keeps its own
+    merged = executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), mine))
+    return _all_gather_view(merged, group, device)
 
 
 def _merge_plan(group_by, merged_spec, counts, schema, everyone, valid=None):
@@ -439,11 +482,17 @@ class DeviceShardedGroupAggregate(object):
     regrown by `check()` if a later shard outgrows it.  `collectives` counts the collectives the
     most recent step issued (asserted to be 1 in the tests)."""
 
-    def __init__(self, ctx, group_by, spec, local_child, group=None, capacity_rows=0):
+    def __init__(self, ctx, group_by, spec, local_child, group=None, capacity_rows=0, exchange="all_gather"):
+        """exchange = "all_gather": every rank ends with the FULL result (every partial table goes everywhere, every rank
+        merges all of them).  exchange = "key_range": a partial row goes only to the owner of its key (ssgpu_result_route_images
+        + ONE all_to_all_single of equally sized images), every rank merges -- and ends with -- the groups it owns: merge
+        work and link traffic per rank shrink with the world size (`gather_result()` collects the full table when wanted)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.ctx, self.group = ctx, group
+        assert exchange in ("all_gather", "key_range")
+        self.exchange = exchange
         self.world = dist.get_world_size(group)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.group_by = list(group_by)
@@ -469,10 +518,17 @@ class DeviceShardedGroupAggregate(object):
     def _allocate(self):
         torch = self.torch
         self.image_bytes, self.unpacked_bytes, _offs = self.first.image_layout(self.capacity, self.world)
-        self.image = torch.empty(self.image_bytes, dtype=torch.uint8, device=self.device)
+        # all_gather: one image out, world images in; key_range: world images out (one per destination), world images in
+        n_out = self.world if self.exchange == "key_range" else 1
+        self.image = torch.empty(n_out * self.image_bytes, dtype=torch.uint8, device=self.device)
         self.images = torch.empty(self.world * self.image_bytes, dtype=torch.uint8, device=self.device)
         self.unpacked = torch.empty(self.unpacked_bytes, dtype=torch.uint8, device=self.device)
         self.merge = None
+
+    def _capacity_for(self, rows):
+        if self.exchange == "key_range":     # rows one destination receives from one source: its share of the keys, with head room for the hash's spread
+            return max(1024, (int(rows * 1.3 / self.world) + 2047) // 1024 * 1024)
+        return max(1024, (int(rows) * 5 // 4 + 1023) // 1024 * 1024)
 
     def _agree_capacity(self):
         """Set-up only: the largest partial table of any rank, with head room (one all-reduce, one host read)."""
@@ -480,7 +536,7 @@ class DeviceShardedGroupAggregate(object):
         rows = torch.tensor([self.first.lib.ssgpu_result_row_count(self.first._result)], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(rows, op=self.dist.ReduceOp.MAX, group=self.group)
         self.setup_collectives += 1
-        self.capacity = max(1024, (int(rows.item()) * 5 // 4 + 1023) // 1024 * 1024)
+        self.capacity = self._capacity_for(int(rows.item()))
 
     def step(self, view=None):
         torch = self.torch
@@ -491,10 +547,15 @@ class DeviceShardedGroupAggregate(object):
         if getattr(self, "_cap_alloc", None) != self.capacity:
             self._allocate()
             self._cap_alloc = self.capacity
-        self.first.pack_image(self.capacity, self.image.data_ptr())
         cur = torch.cuda.current_stream(self.device)
-        cur.wait_stream(self._lib_stream)                      # the collective reads what the pack kernel wrote
-        self.dist.all_gather_into_tensor(self.images, self.image, group=self.group)
+        if self.exchange == "key_range":
+            self.first.route_images(len(self.group_by), self.world, self.capacity, self.image.data_ptr())
+            cur.wait_stream(self._lib_stream)                  # the collective reads what the routing kernels wrote
+            self.dist.all_to_all_single(self.images, self.image, group=self.group)     # image d -> rank d, equal sizes
+        else:
+            self.first.pack_image(self.capacity, self.image.data_ptr())
+            cur.wait_stream(self._lib_stream)                  # the collective reads what the pack kernel wrote
+            self.dist.all_gather_into_tensor(self.images, self.image, group=self.group)
         self.collectives += 1
         self._lib_stream.wait_stream(cur)
         everyone = self.first.unpack_images(self.images.data_ptr(), self.world, self.capacity, self.unpacked.data_ptr())
@@ -513,13 +574,27 @@ class DeviceShardedGroupAggregate(object):
         t = self.unpacked[self.unpacked_bytes - 32:].view(self.torch.int64).tolist()
         if t[3]:
             raise ss.SupersonicException(ss.ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate")
+        if self.exchange == "key_range" and self.world > 1:
+            # every rank saw other images: the verdict and the new capacity have to be the same everywhere (one tiny
+            # all-reduce, after the timed steps only)
+            v = self.torch.tensor([int(t[2] != 0), int(t[0])], dtype=self.torch.int64, device=self.device)
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.setup_collectives += 1
+            t[2], t[0] = int(v[0].item()), int(v[1].item())
         if t[2]:
-            self.capacity = max(1024, (int(t[0]) * 5 // 4 + 1023) // 1024 * 1024)
+            self.capacity = max(self.capacity, (int(t[0]) * 5 // 4 + 1023) // 1024 * 1024) if self.exchange == "key_range" else \
+                max(1024, (int(t[0]) * 5 // 4 + 1023) // 1024 * 1024)
             return False
         return True
 
     def result(self):
+        """The merge plan and its result as device columns: the FULL table (all_gather) or this rank's groups (key_range)."""
         return self.merge, self.merge.result_device_view()
+
+    def gather_result(self):
+        """key_range: the full table on every rank -- the finished slices all-gathered through the host (not part of a step)."""
+        local = self.merge.fetch()
+        return local if self.exchange != "key_range" else _all_gather_view(local, self.group, self.device)
 
 
 def device_sharded_group_aggregate(ctx, group_by, spec, local_child, group=None):

@@ -154,8 +154,15 @@ def test_default_policy_never_compiles_and_modules_are_unloaded(gpu_ctx):
     assert ss.memory_stats()["rtc_modules"] == loaded["rtc_modules"]   # p2 still holds it
     del p2, b
     gc.collect()
-    assert ss.memory_stats()["rtc_modules"] == before["rtc_modules"]
-    assert ss.memory_stats()["rtc_code_bytes"] == before["rtc_code_bytes"]
+    # without a user the kernel stays loaded among the few most recently released ones (a cursor per query does not recompile) ...
+    assert ss.memory_stats()["rtc_modules"] <= before["rtc_modules"] + 8
+    p3 = ss.Plan(fpa_narrow(make_view(99)), gpu_ctx).specialize()
+    assert ss.memory_stats()["rtc_compilations"] == loaded["rtc_compilations"]       # found, not compiled again
+    del p3
+    gc.collect()
+    ss.specialized_kernels_trim(0)                                                    # ... and is unloaded on request, or when newer ones push it out
+    after = ss.memory_stats()
+    assert after["rtc_modules"] <= before["rtc_modules"] and after["rtc_code_bytes"] <= before["rtc_code_bytes"]
     del plan
 
 

@@ -58,14 +58,14 @@ def shard_of(full, lo, hi):
                                    for i in range(full.column_count())])
 
 
-def worker(rank, world, port, n, with_filter, empty_rank, q):
+def worker(rank, world, port, n, with_filter, empty_rank, q, key_range=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     full = make_view(n)
     bounds = [0, n, n] if empty_rank == 1 else ([0, 0, n] if empty_rank == 0 else [0, n // 3, n])
     shard = shard_of(full, bounds[rank], bounds[rank + 1])
-    out = sharded_group_aggregate(["k1", "k2"], spec(), child(shard, with_filter), oracle_executor)
+    out = sharded_group_aggregate(["k1", "k2"], spec(), child(shard, with_filter), oracle_executor, key_range=key_range)
     cols = [(out.column(i).data, out.column(i).is_null) for i in range(out.column_count())]
     schema = [(out.schema().attribute(i).name(), out.schema().attribute(i).type(), out.schema().attribute(i).is_nullable())
               for i in range(out.schema().attribute_count())]
@@ -78,12 +78,15 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+@pytest.mark.parametrize("key_range", [False, True])
 @pytest.mark.parametrize("n,with_filter,empty_rank", [(20001, False, None), (20001, True, None), (3000, True, 1), (3000, False, 0), (0, False, None)])
-def test_sharded_group_aggregate_over_gloo(n, with_filter, empty_rank):
+def test_sharded_group_aggregate_over_gloo(n, with_filter, empty_rank, key_range):
+    # key_range: a partial row travels only to the rank that owns its key (hash of the group keys modulo the world size), every
+    # rank merges its own slice of the groups and the finished slices are gathered -- same answer, 1 / world of the merge work
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, n, with_filter, empty_rank, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, n, with_filter, empty_rank, q, key_range)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(2)]
@@ -113,23 +116,24 @@ def string_spec():
             .AddAggregation(ss.MAX, "tag", "hi").AddAggregation(ss.COUNT, "", "n"))
 
 
-def string_worker(rank, world, port, n, q):
+def string_worker(rank, world, port, n, q, key_range=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     full = make_string_view(n)
     bounds = [0, n // 4, n]
-    out = sharded_group_aggregate(["name"], string_spec(), ss.ScanView(shard_of(full, bounds[rank], bounds[rank + 1])), oracle_executor)
+    out = sharded_group_aggregate(["name"], string_spec(), ss.ScanView(shard_of(full, bounds[rank], bounds[rank + 1])), oracle_executor, key_range=key_range)
     q.put((rank, [(out.column(i).data, out.column(i).is_null) for i in range(out.column_count())]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_group_aggregate_with_string_columns_over_gloo():
+@pytest.mark.parametrize("key_range", [False, True])
+def test_sharded_group_aggregate_with_string_columns_over_gloo(key_range):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=string_worker, args=(r, 2, port, 5003, q)) for r in range(2)]
+    procs = [ctx.Process(target=string_worker, args=(r, 2, port, 5003, q, key_range)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(2)]

@@ -1442,3 +1442,82 @@ def test_group_aggregate_lazy_feedback_repeats_an_overflowing_run(partition):
     assert plan.stage_info()[0]["reruns"] >= 1
     plan.run(few)                                     # and back
     assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want_few), context="after the repeat")
+
+
+# ---- key-range exchange of a sharded GroupAggregate (ssgpu_result_route_images, distributed.py exchange="key_range"):
+# ---- a partial row goes only to the rank that owns its key; every rank merges 1 / world of the groups ----------------------
+@pytest.mark.parametrize("n,world", [(100003, 3), (2000, 4), (0, 2)])
+def test_key_range_exchange_routes_every_group_to_one_owner(gpu_ctx, n, world):
+    """`world` ranks simulated on one GPU: every source shard routes its partial table into `world` images (one per owner),
+    owner d unpacks image d of every source and merges.  The owners' results are disjoint in their keys and together are the
+    oracle's GroupAggregate of the whole input -- DOUBLE sums as (SUM, SUM_RESIDUAL) pairs, COUNT kept NOT NULL, NULL keys."""
+    import torch
+    from supersonic_amd.distributed import _shard_spec, _merge_spec, _merge_plan
+    view = make_view(n, nullable=True)
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.SUM, "d1", "sd").AddAggregation(ss.MIN, "d0", "mn")
+            .AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.COUNT, "d0", "c0").AddAggregation(ss.COUNT, "", "n"))
+    keys = ["k1", "t"]                                           # a NULLABLE INT32 and a NULLABLE BOOL key
+    shard_spec, with_residual = _shard_spec(spec, view.schema())
+    merged_spec, counts = _merge_spec(spec, with_residual)
+    cuts = [n * i // world for i in range(world + 1)]
+    sources, cap = [], max(1024, int(n / world * 1.3 / world) + 2048)
+    dev = torch.device("cuda", 0)
+    image_bytes = None
+    for s in range(world):
+        sv = ss.View(view.schema(), [ss.Column(view.column(i).data[cuts[s]:cuts[s + 1]], None if view.column(i).is_null is None else view.column(i).is_null[cuts[s]:cuts[s + 1]])
+                                     for i in range(view.column_count())])
+        plan = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), shard_spec, None, ss.ScanView(sv)), gpu_ctx)
+        plan.run()
+        image_bytes, _ub, _offs = plan.image_layout(cap, 1)
+        out = torch.zeros(world * image_bytes, dtype=torch.uint8, device=dev)
+        plan.route_images(len(keys), world, cap, out.data_ptr())
+        gpu_ctx.synchronize()
+        sources.append((plan, out))
+    plan0 = sources[0][0]
+    _ib, unpacked_bytes, _offs = plan0.image_layout(cap, world)
+    owned, all_keys = [], []
+    for d in range(world):
+        arrived = torch.cat([out[d * image_bytes:(d + 1) * image_bytes] for (_p, out) in sources])      # what the all-to-all delivers to rank d
+        unpacked = torch.zeros(unpacked_bytes, dtype=torch.uint8, device=dev)
+        everyone = plan0.unpack_images(arrived.data_ptr(), world, cap, unpacked.data_ptr())
+        gpu_ctx.synchronize()
+        trailer = unpacked[unpacked_bytes - 32:].view(torch.int64).tolist()
+        assert trailer[2] == 0 and trailer[3] == 0, trailer                                             # no image overflowed, no evaluation error
+        got = ss.drain(_merge_plan(keys, merged_spec, counts, plan0.result_schema, everyone, valid="__valid").CreateCursor(gpu_ctx), 1 << 30)
+        owned.append(to_cols(got))
+        all_keys += list(zip(*[np.where(z, -7, dcol).tolist() if z is not None else dcol.tolist() for (dcol, z) in owned[-1][:2]]))
+    assert len(all_keys) == len(set(all_keys))                                                          # every group has exactly one owner
+    union = [(np.concatenate([o[i][0] for o in owned]), None if owned[0][i][1] is None else np.concatenate([o[i][1] for o in owned])) for i in range(len(owned[0]))]
+    oschema, want = oracle_run(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, ss.ScanView(view)))
+    assert_cols_equal(sort_rows(union), sort_rows(want), context="key-range exchange, %d owners" % world)
+    if n >= 100000:
+        assert min(len(o[0][0]) for o in owned) > 0                                                     # the hash spreads the groups
+
+
+@pytest.mark.parametrize("exchange", ["key_range", "all_gather"])
+def test_device_sharded_group_aggregate_exchange_forms_one_rank(exchange):
+    import socket
+    import torch
+    import torch.distributed as dist
+    from supersonic_amd.distributed import DeviceShardedGroupAggregate
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = ss.Context(0)
+        view = make_view(100003, nullable=True)
+        spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "sa").AddAggregation(ss.SUM, "d1", "sd").AddAggregation(ss.MIN, "d0", "mn")
+                .AddAggregation(ss.COUNT, "d0", "c").AddAggregation(ss.COUNT, "", "n"))
+        child = ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))
+        job = DeviceShardedGroupAggregate(ctx, ["k2", "t"], spec, child, exchange=exchange)
+        for _ in range(3):
+            job.step()
+            while not job.check():
+                job.step()
+        assert job.collectives == 1
+        got = job.gather_result()
+        schema, want = oracle_run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2", "t"]), spec, None, child))
+        assert_cols_equal(sort_rows(to_cols(got)), sort_rows(want), context="device sharded group aggregate, " + exchange)
+    finally:
+        dist.destroy_process_group()
