@@ -264,6 +264,9 @@ def parse_args(argv=None):
                     help="wide = configs[1] (headline); group = configs[3]'s per-GPU query (Filter -> GroupAggregate); group3 = configs[2] "
                          "(GroupAggregate alone); sort = configs[4] (Sort(d) of the 8-column block); filter_mat = materialising Filter(a > 499)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--exchange", choices=["all_gather", "key_range"], default="key_range",
+                    help="--query group on N > 1 ranks: all_gather = every partial table to every rank, every rank merges all of them; "
+                         "key_range = a partial row goes to the owner of its key (one all-to-all), every rank merges 1/N of the groups")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specialize", action="store_true",
@@ -456,7 +459,7 @@ def main():
     job = None
     if group and distributed:
         from supersonic_amd.distributed import DeviceShardedGroupAggregate
-        job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], group_spec(ss), group_child(ss, view))
+        job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], group_spec(ss), group_child(ss, view), exchange=args.exchange)
         plan = job.first
     else:
         if (args.query in ("sort", "filter_mat")) and distributed:
@@ -547,6 +550,13 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    groups_total = None
+    if group:
+        groups_total = (job.result()[0] if job is not None else plan).fetch().row_count()
+        if job is not None and args.exchange == "key_range" and world > 1:     # every rank holds the groups it owns: the table's size is their sum
+            g = torch.tensor([groups_total], device=device, dtype=torch.int64)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            groups_total = int(g.item())
 
     if args.query in ("sort", "filter_mat"):
         # the result is as large as the input: it stays in HBM; check it there (never copied to the host)
@@ -576,10 +586,11 @@ def main():
         if group:
             workload = ("%s: GroupAggregate(k1,k2; SUM/MIN/MAX x d0..d3)%s over a device-resident %d-row x 7-col "
                         "block per GPU (~1e5 groups)" % ("Q-GROUP-F" if GROUP_FILTER else "Q-GROUP", " o Filter(a>499)" if GROUP_FILTER else "", rows))
-            par = ("row-range shards x%d: per-shard GroupAggregate, ONE RCCL all-gather of the packed partial tables, merge plan" % world
+            par = ("row-range shards x%d: per-shard GroupAggregate, ONE RCCL %s of the packed partial tables, merge plan" % (
+                       world, "all-to-all by key range (every rank merges the groups it owns)" if args.exchange == "key_range" else "all-gather")
                    if distributed else "single GPU")
             kernel = "group stage (partition scatter + per-partition aggregation kernels)"
-            result_row = {"groups": result.row_count()}
+            result_row = {"groups": groups_total}
         elif args.query == "sort":
             workload = "Q-SORT: Sort(d ASC, all 8 columns) of a device-resident %d-row x 8-col block" % rows
             par, kernel = "single GPU", "sort stage (key load + histograms, radix passes, tie fix-up, record pack + gather)"
