@@ -363,6 +363,18 @@ int ssgpu_dict_encode(const ssgpu_dict* d, const char* const* strings, const int
                       int64_t n, int32_t* codes);
 int ssgpu_dict_decode(const ssgpu_dict* d, int32_t code, const char** bytes, int32_t* length);
 
+/* CONCAT aggregates (column_aggregator.cc:496-505) produce strings that are in no dictionary yet.  The device orders the
+ * values (materialise, stable sort by the group keys) and counts them; the strings are printed on the host -- PrintTyped
+ * forms: integers in decimal, BOOL as TRUE / FALSE, FLOAT / DOUBLE as SimpleFtoa / SimpleDtoa, STRING as is -- when the
+ * column is fetched, joined with ',' in input order, and become a dictionary OWNED BY THE RESULT:
+ * ssgpu_result_column_dict(result, col) is that dictionary for a CONCAT column (its INT32 cells are codes of it; valid
+ * until the plan runs again) and NULL for every other column (STRING cells of those are codes of the plan's dictionary).
+ * ssgpu_plan_set_dict hands the plan the dictionary its STRING columns were encoded with (borrowed; CONCAT of a STRING
+ * column prints through it).  Limits, refused at bind: DISTINCT CONCAT, DATE / DATETIME / BINARY inputs, a CONCAT result
+ * that feeds another operation, CONCAT under max_unique_keys_in_result or across shards. */
+int ssgpu_plan_set_dict(ssgpu_plan* plan, const ssgpu_dict* dict);
+const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t col);
+
 /* ---- device-resident Block ----------------------------------------------- */
 int ssgpu_block_create(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs,
                        int64_t row_capacity, ssgpu_block** out);

@@ -542,7 +542,16 @@ inline int FetchResult(ssgpu_result* res, const TupleSchema& schema, const Dicti
     if (schema.attribute(i).type() == STRING) {
       std::vector<StringPiece>& c = (*cells)[static_cast<size_t>(i)];
       c.resize(static_cast<size_t>(std::max<rowcount_t>(*total, 1)));
-      for (rowcount_t r = 0; r < *total; ++r) c[r] = (z && z[r]) || !dict ? StringPiece() : dict->Decode(static_cast<const int32_t*>(d)[r]);
+      // a CONCAT column's cells are codes of a dictionary the RESULT owns (its strings exist nowhere else); every other STRING
+      // column holds codes of the cursor's dictionary
+      if (const ssgpu_dict* own = ssgpu_result_column_dict(res, i)) {
+        for (rowcount_t r = 0; r < *total; ++r) {
+          const char* b = nullptr; int32_t n = 0;
+          c[r] = (z && z[r]) || ssgpu_dict_decode(own, static_cast<const int32_t*>(d)[r], &b, &n) != SSGPU_OK ? StringPiece() : StringPiece(b, static_cast<size_t>(n));
+        }
+      } else {
+        for (rowcount_t r = 0; r < *total; ++r) c[r] = (z && z[r]) || !dict ? StringPiece() : dict->Decode(static_cast<const int32_t*>(d)[r]);
+      }
       d = c.data();
     }
     data->push_back(d); nulls->push_back(z);
@@ -692,6 +701,7 @@ class Operation {
     ssgpu_plan* plan = nullptr;
     const int rc = ssgpu_plan_create(ctx, &d, &plan);
     if (rc != SSGPU_OK) return FailureOrOwned<Cursor>(new Exception(rc, ssgpu_last_error(ctx)));
+    if (c->dict_.d) ssgpu_plan_set_dict(plan, c->dict_.d);   // CONCAT prints STRING inputs through the cursor's dictionary
     // SetBufferAllocator(MemoryLimit): the plan's device buffers are charged to the allocator's remaining quota
     if (const BufferAllocator* a = EffectiveAllocator()) if (a->has_quota()) ssgpu_plan_set_memory_limit(plan, static_cast<int64_t>(a->Available()));
     c->plan_ = plan; c->input_ = b.scan; c->dev_ = b.scan_dev; c->aux_ = b.scan_aux;

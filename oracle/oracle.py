@@ -229,8 +229,98 @@ class Cursor(object):
         return lib().orc_drain(self.handle)
 
 
+A_CONCAT, T_BOOL, T_FLOAT, T_DOUBLE = 4, 6, 9, 5
+
+
+def _print_typed(t, v):
+    """PrintTyped (base/infrastructure/types_infrastructure.cc:45-80): decimal integers, TRUE / FALSE, SimpleFtoa / SimpleDtoa
+    (the shortest of %.6g / %.9g resp. %.15g / %.17g that reads back as the same value), STRING as is."""
+    if t == T_STRING:
+        return _bytes(v)
+    if t == T_BOOL:
+        return b"TRUE" if v else b"FALSE"
+    if t in (T_FLOAT, T_DOUBLE):
+        f = float(v)
+        if f != f:
+            return b"nan"
+        if f in (float("inf"), float("-inf")):
+            return b"inf" if f > 0 else b"-inf"
+        short, long_ = (6, 9) if t == T_FLOAT else (15, 17)
+        text = "%.*g" % (short, f)
+        back = np.float32(text) if t == T_FLOAT else float(text)
+        if back != (np.float32(f) if t == T_FLOAT else f):
+            text = "%.*g" % (long_, f)
+        return text.encode()
+    return str(int(v)).encode()
+
+
+def _run_with_concat(operation, max_rows):
+    """CONCAT aggregates (aggregation_operators.h:236-283, column_aggregator.cc:108-124,496-505): every non-NULL value of a
+    group, printed, in input order, joined with ','; a group without one is NULL.  The C restatement keeps STRINGs as
+    dictionary codes and cannot make new ones, so this part of the fold is restated here: the child's rows come from the C
+    restatement, the groups are formed in first-seen order (GroupAggregate), as key runs (AggregateClusters) or as the one
+    group of a ScalarAggregate -- the same orders the C restatement gives the other aggregates of the specification, which
+    it still computes."""
+    import copy
+    kind = KIND[type(operation).__name__]
+    cschema, crows = run(operation.child, max_rows)
+    names = [c[0] for c in cschema]
+    n = len(crows[0][0]) if crows else 0
+    keys = []
+    proj = getattr(operation, "group_by", None)
+    if proj is not None:
+        for (k, pos, name, _alias) in proj.entries:
+            if k == 1:              # ProjectAllAttributes
+                keys += list(range(len(names)))
+            else:
+                keys.append(pos if k == 3 else names.index(name))
+    def key_of(i):
+        return tuple((True, None) if (crows[k][1] is not None and crows[k][1][i]) else (False, crows[k][0][i].tobytes() if hasattr(crows[k][0][i], "tobytes") else crows[k][0][i]) for k in keys)
+    group_of, n_groups = np.zeros(n, dtype=np.int64), (1 if kind == 5 else 0)
+    if kind == 6:        # GroupAggregate: first-seen order (row_hash_set.cc:458-517)
+        seen = {}
+        for i in range(n):
+            group_of[i] = seen.setdefault(key_of(i), len(seen))
+        n_groups = len(seen)
+    elif kind == 7:      # AggregateClusters: a new group whenever the key changes (aggregate_clusters.cc:338-520)
+        prev = None
+        for i in range(n):
+            k = key_of(i)
+            if i == 0 or k != prev:
+                n_groups += 1
+            prev = k
+            group_of[i] = n_groups - 1
+    rest = copy.copy(operation)
+    rest.spec = copy.copy(operation.spec)
+    rest.spec.elements = [e for e in operation.spec.elements if e[0] != A_CONCAT]
+    rschema, rcols = run(rest, max_rows)
+    n_keys = len(rschema) - len(rest.spec.elements)
+    if kind != 5 and rcols:
+        assert len(rcols[0][0]) == n_groups
+    schema, cols, ri = list(rschema[:n_keys]), list(rcols[:n_keys]), n_keys
+    for (agg, _distinct, _otype, inp, outp) in operation.spec.elements:
+        if agg != A_CONCAT:
+            schema.append(rschema[ri]); cols.append(rcols[ri]); ri += 1
+            continue
+        c = names.index(inp)
+        text, has = [b""] * n_groups, np.zeros(n_groups, dtype=bool)
+        for i in range(n):
+            if crows[c][1] is not None and crows[c][1][i]:
+                continue
+            g = group_of[i]
+            text[g] = (text[g] + b"," if has[g] else b"") + _print_typed(cschema[c][1], crows[c][0][i])
+            has[g] = True
+        data = np.empty(n_groups, dtype=object)
+        data[:] = text
+        schema.append((outp, T_STRING, 1)); cols.append((data, ~has))
+    return schema, cols
+
+
 def run(operation, max_rows=1024):
     """Evaluate an operation tree on the CPU: (schema, [(data, is_null|None), ...])."""
+    spec = getattr(operation, "spec", None)
+    if spec is not None and any(e[0] == A_CONCAT for e in spec.elements):
+        return _run_with_concat(operation, max_rows)
     cur = Cursor(operation)
     parts = []
     while True:

@@ -1117,6 +1117,7 @@ typedef struct orc_cursor {
   int64_t* ids; int64_t nids, read_ptr; orc_view cur; int have_cur, eos;
   orc_block block;                  /* result block (filter / aggregates / sort) */
   /* aggregates */ agg_col aggs[ORC_MAX_COLS]; int nagg; int done; int64_t out_rows, emit_pos;
+  int has_concat;   /* the specification holds a CONCAT: bound here (schema), evaluated in oracle.py (new STRINGs) */
   /* group */ int64_t* bucket_head; int64_t* chain_next; uint64_t* row_hash; int64_t nbuckets; int64_t max_unique_keys;
   /* sort */ int sort_pos[16], sort_order[16], nsort; int64_t* perm; void* table;
   orc_view outv;
@@ -1164,7 +1165,17 @@ static int bind_aggs(orc_cursor* c, const orc_op* op, const orc_schema* in) {
     }
     g->in_type = g->in_pos >= 0 ? in->a[g->in_pos].type : T_UINT64;
     g->out_type = a->output_type >= 0 ? a->output_type : (a->aggregation == A_COUNT ? T_UINT64 : g->in_type);
-    if (a->aggregation == A_CONCAT) { set_err(&c->err, RC_NOT_IMPLEMENTED, "CONCAT not restated%s%s", "", ""); return 0; }
+    if (a->aggregation == A_CONCAT) {
+      /* column_aggregator.cc:496-505: CONCAT -> STRING over every printable type.  Bound here (name, STRING, NULLABLE); its
+       * values are new strings, which this restatement -- STRINGs are dictionary codes here -- cannot hold: oracle.py folds them */
+      if (a->output_type >= 0 && a->output_type != T_STRING) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "Aggregation not supported for types %s and %s.", type_name(g->in_type), type_name(a->output_type)); return 0; }
+      if (a->distinct || g->in_type == T_DATE || g->in_type == T_DATETIME || g->in_type == T_BINARY) { set_err(&c->err, RC_NOT_IMPLEMENTED, "CONCAT form not restated%s%s", "", ""); return 0; }
+      g->out_type = T_STRING; c->has_concat = 1;
+      if (!schema_add(&c->schema, a->output, T_STRING, 1)) {
+        set_err(&c->err, RC_ATTRIBUTE_EXISTS, "Incorrect aggregation specification. Aggregation output column name is non-unique: '%s'.%s", a->output, ""); return 0;
+      }
+      continue;
+    }
     if (a->distinct && c->kind == C_CLUSTERS) { set_err(&c->err, RC_NOT_IMPLEMENTED, "DISTINCT inside AggregateClusters not restated%s%s", "", ""); return 0; }
     g->distinct = a->distinct;
     if (a->aggregation == A_COUNT) { if (!is_integer(g->out_type)) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "COUNT output must be integer%s%s", "", ""); return 0; } }
@@ -1483,6 +1494,7 @@ static void view_from_block(const orc_cursor* c, const orc_block* b, int64_t off
 }
 
 static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
+  if (c->has_concat) { set_err(&c->err, RC_NOT_IMPLEMENTED, "a specification with CONCAT is evaluated by oracle.py (run), not pulled through this cursor%s%s", "", ""); return -1; }
   if (c->err.code) return -1;
   if (max_rows > ORC_BLOCK) max_rows = ORC_BLOCK;
   switch (c->kind) {

@@ -130,6 +130,8 @@ SYMBOLS = [
     ("ssgpu_dict_encode", C.c_int, [P, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), P, C.c_int64, C.POINTER(C.c_int32)]),
     ("ssgpu_dict_decode", C.c_int, [P, C.c_int32, C.POINTER(P), C.POINTER(C.c_int32)]),
     ("ssgpu_plan_set_memory_limit", C.c_int, [P, C.c_int64]),
+    ("ssgpu_plan_set_dict", C.c_int, [P, P]),
+    ("ssgpu_result_column_dict", P, [P, C.c_int32]),
     ("ssgpu_plan_specialized", C.c_int32, [P]),
     ("ssgpu_plan_specialize", C.c_int, [P]),
     ("ssgpu_specialized_kernels_trim", None, [C.c_int32]),

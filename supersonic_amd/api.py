@@ -1067,6 +1067,7 @@ class Plan(object):
         rc = self.lib.ssgpu_plan_create(context.handle, C.byref(d), C.byref(h))
         context.check(rc)
         self._adopt(h)
+        self.lib.ssgpu_plan_set_dict(h, self.strings.handle)      # CONCAT prints STRING inputs through the plan's dictionary
         alloc = _find_allocator(operation)
         if alloc is not None:
             self.set_buffer_allocator(alloc)
@@ -1226,7 +1227,19 @@ class Plan(object):
             if a.is_nullable():
                 nulls = (np.frombuffer(C.string_at(npn, rows), dtype=np.uint8).copy() != 0) if rows else np.zeros(0, bool)
             if a.type() == STRING:
-                data = self.strings.decode(data, nulls)
+                own = self.lib.ssgpu_result_column_dict(res, i)      # a CONCAT column: codes of the result's own dictionary
+                if own:
+                    dec = np.empty(len(data), dtype=object)
+                    ptr, n = C.c_void_p(), C.c_int32()
+                    for j, code in enumerate(data.tolist()):
+                        if nulls is not None and nulls[j]:
+                            dec[j] = b""
+                        else:
+                            self.ctx.check(self.lib.ssgpu_dict_decode(own, code, C.byref(ptr), C.byref(n)))
+                            dec[j] = C.string_at(ptr, n.value)
+                    data = dec
+                else:
+                    data = self.strings.decode(data, nulls)
             cols.append(Column(data, nulls))
         return View(self.result_schema, cols, rows)
 

@@ -171,6 +171,12 @@ struct Stage {
   // kept, every later row is merged into row fold_limit with the column's merge function (0 keep = key columns, 1 SUM, 2 MIN, 3 MAX)
   int64_t fold_limit = -1;
   std::vector<int> fold_op;
+  // CONCAT aggregates (column_aggregator.cc:496-505, aggregation_operators.h:236-283): a result of STRINGs that exist nowhere yet.
+  // The device counts the contributing (non-NULL) values in the column's place -- a UINT64 in out_schema -- and the host
+  // builds the strings when the column is fetched, from the stage's (materialised, for a group aggregate key-sorted) input:
+  // out_col of out_schema <- values of stage-input column src_col, in input order, joined with ','.
+  struct ConcatCol { int out_col; int src_col; int src_dtype; };
+  std::vector<ConcatCol> concat;
   int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row
   int64_t output_bytes_per_row = 0;       // materialised output bytes per output row
 };

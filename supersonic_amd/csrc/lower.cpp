@@ -873,8 +873,19 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
                              "Incorrect aggregation specification. Aggregation output column name is non-unique: '" + p.out_name + "'.");
     // DISTINCT changes SUM and COUNT only: the MIN / MAX / FIRST / LAST of the distinct values are those of all values
     p.distinct = a.distinct && (a.aggregation == SSGPU_SUM || a.aggregation == SSGPU_COUNT);
-    if (a.aggregation == SSGPU_CONCAT)
-      return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT (STRING) is outside the device hot path");
+    if (a.aggregation == SSGPU_CONCAT) {
+      // CONCAT -> STRING over every type with a PrintTyped form (column_aggregator.cc:496-505).  The values are ordered on the
+      // device and printed on the host (Stage::ConcatCol); DATE / DATETIME (strftime forms) and DISTINCT CONCAT are not restated.
+      const int it = in[p.input_pos].dtype;
+      if (a.output_type >= 0 && a.output_type != SSGPU_STRING)
+        return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, std::string("Aggregation not supported. Aggregation function not defined for types ") +
+                                                                    dtype_name(it) + " and " + dtype_name(a.output_type) + ".");
+      if (a.distinct || it == SSGPU_DATE || it == SSGPU_DATETIME || it == SSGPU_BINARY || dtype_width(it) == 0)
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT of DATE / DATETIME / BINARY values and DISTINCT CONCAT are outside the device path");
+      p.out_type = SSGPU_STRING; p.result_nullable = true; p.distinct = false;
+      out->push_back(p);
+      continue;
+    }
     if (a.aggregation == SSGPU_SUM_RESIDUAL) {   // extension (ssgpu.h): the exact residual of the DOUBLE SUM of the same column
       bool found = false;
       for (auto& q : *out) found = found || (q.aggregation == SSGPU_SUM && q.input_pos == p.input_pos && q.out_type == SSGPU_DOUBLE && !q.distinct);
@@ -1176,6 +1187,23 @@ static Status bind_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& 
   if ((int)g->plans.size() > VM_MAX_AGG_SLOTS || g->kpos.size() > 16)
     return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many keys/aggregations for one pipeline");
   return Status::OK();
+}
+
+// ---- CONCAT (Stage::ConcatCol) -----------------------------------------------------------------------------------------
+// In the aggregate's place the device counts the contributing values (COUNT(x) into UINT64); `pending` remembers which
+// result column becomes a STRING built on the host from which stage-input column.
+struct ConcatPlan { size_t agg; int input_pos; int dtype; };
+static void take_concat_plans(const Schema& vs, std::vector<AggPlan>* plans, std::vector<ConcatPlan>* pending) {
+  for (size_t i = 0; i < plans->size(); ++i) {
+    AggPlan& ap = (*plans)[i];
+    if (ap.aggregation != SSGPU_CONCAT) continue;
+    pending->push_back(ConcatPlan{i, ap.input_pos, vs[ap.input_pos].dtype});
+    ap.aggregation = SSGPU_COUNT; ap.out_type = SSGPU_UINT64; ap.result_nullable = false;
+  }
+}
+static bool has_concat(const std::vector<AggPlan>& plans) {
+  for (auto& ap : plans) if (ap.aggregation == SSGPU_CONCAT) return true;
+  return false;
 }
 
 // ---- NaN-exact floating MIN / MAX (PlanDesc::nan_exact) ---------------------------------------------------------------
@@ -1798,13 +1826,49 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         // keys and the aggregated columns, sort by (keys, distinct column), flag the first row of every (keys, value) run
         // and aggregate with the flag standing in for "not NULL": a scalar aggregate over the sorted rows, or the
         // clustered aggregation over the key runs.  One distinct column per specification.
-        bool any_distinct = false;
+        bool any_distinct = false, any_concat = false;
         {
           std::vector<AggPlan> probe;
           SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &probe));
           for (auto& ap : probe) any_distinct = any_distinct || ap.distinct;
+          any_concat = has_concat(probe);
         }
-        if (any_distinct) {
+        if (any_concat) {
+          // CONCAT (Stage::ConcatCol): the values have to reach the host in input order, group by group -- materialise the keys and
+          // the aggregated columns, (stable) sort by the keys, aggregate the key runs with the clustered kernel (CONCAT counted as
+          // COUNT(x)); the host prints the strings from the sorted rows and their segment ids when the column is fetched.
+          if (any_distinct) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate is not available on the device path");
+          if (ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
+          if (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT under max_unique_keys_in_result is not available on the device path");
+          GroupBinding g;
+          if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
+          std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
+          auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
+          for (auto& k : g.kpos) k = slot_of(k);
+          for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+          Pipe pruned = pipe; pruned.cols.clear();
+          for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+          Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
+          stages->push_back(m);
+          reset_pipe(&pipe, m.out_schema);
+          if (op.kind == SSGPU_OP_GROUP_AGGREGATE) {
+            Stage so; so.kind = STAGE_SORT; so.in_schema = m.out_schema; so.out_schema = m.out_schema;
+            for (int k : g.kpos) {
+              if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length group keys are outside the device hot path");
+              SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+            }
+            for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+            stages->push_back(so);
+            reset_pipe(&pipe, so.out_schema);
+          }
+          std::vector<ConcatPlan> concats;
+          take_concat_plans(schema_of(pipe.cols), &g.plans, &concats);
+          if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st));
+          else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
+          for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), cp.input_pos, cp.dtype});
+          desc << "(materialise" << (op.kind == SSGPU_OP_GROUP_AGGREGATE ? " + sort + clustered aggregation" : "") << "; CONCAT printed on the host) ";
+        } else if (any_distinct) {
           if (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0)
             return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "GroupAggregateOptions::max_unique_keys_in_result is not available on the device path");
           GroupBinding g;
@@ -1985,8 +2049,18 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         } else {
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           c_user_aggs = g.plans.size(); c_keys = g.kpos.size();
-          add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &g.plans, &c_fixes);
+          std::vector<ConcatPlan> concats;
+          if (has_concat(g.plans)) {
+            if (ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
+            for (auto& ap : g.plans)
+              if (ap.aggregation == SSGPU_CONCAT && pipe.cols[ap.input_pos].expr->kind != BExpr::INPUT)
+                return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT inside AggregateClusters needs a plain input column");
+            for (auto& ap : g.plans) if (ap.aggregation == SSGPU_CONCAT) ap.input_pos = ap.input_pos;   // (the stage input IS the pipe here: materialised above, or the plan input)
+            take_concat_plans(schema_of(pipe.cols), &g.plans, &concats);
+          }
+          add_nan_exact_plans(d.nan_exact && concats.empty(), schema_of(pipe.cols), &g.plans, &c_fixes);
           SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
+          for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), pipe.cols[cp.input_pos].expr->input_col, cp.dtype});
           desc << "AggregateClusters -> [" << schema_to_string(st.out_schema) << "]\n";
         }
         stages->push_back(st);
@@ -2007,6 +2081,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
       if (pr->gathers.size() > VM_MAX_JOIN_COLS)
         return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many rhs columns gathered by the hash joins of one pipeline");
   *result_schema = stages->back().out_schema;
+  for (auto& cc : stages->back().concat) { (*result_schema)[cc.out_col].dtype = SSGPU_STRING; (*result_schema)[cc.out_col].nullable = true; }   // (out_schema keeps the device's UINT64 count)
   for (size_t i = 0; i < stages->size(); ++i) {
     desc << "stage " << i << " kind=" << (*stages)[i].kind << "\n" << disassemble((*stages)[i].main);
     if (!(*stages)[i].count_pass.empty()) desc << " count pass:\n" << disassemble((*stages)[i].count_pass);

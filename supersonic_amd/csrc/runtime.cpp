@@ -197,6 +197,8 @@ struct ssgpu_result {
   ssgpu_plan* plan = nullptr;
   std::vector<PinnedBuf> host_data, host_nulls;
   std::vector<bool> fetched;
+  std::vector<ssgpu_dict*> concat_dicts;   // per column: the strings of a CONCAT result (codes of that column index it), else NULL
+  ~ssgpu_result() { for (ssgpu_dict* d : concat_dicts) if (d) ssgpu_dict_destroy(d); }
 };
 
 struct ssgpu_plan {
@@ -227,6 +229,7 @@ struct ssgpu_plan {
   int64_t last_rows = 0;
   bool deferred = false;        // some stage's run feedback has not been looked at yet (settle_plan)
   bool nan_seen = false;        // the last run met a NaN in a floating MIN / MAX (check_error_flags)
+  const ssgpu_dict* dict = nullptr;   // the plan's STRING dictionary (ssgpu_plan_set_dict): CONCAT prints STRING inputs through it
   std::vector<ssgpu_column> last_cols; int64_t last_base = 0; bool last_partial = false;   // the last run's input (a deferred overflow repeats it)
   ssgpu_result result;
 };
@@ -239,6 +242,12 @@ struct ssgpu_block {
 };
 
 static int fail(ssgpu_ctx* ctx, const Status& s) { if (ctx) ctx->err = s.msg; return s.code; }
+// the CONCAT description of result column `col` (Stage::ConcatCol), or NULL
+static const Stage::ConcatCol* concat_of(const ssgpu_plan* p, int32_t col) {
+  if (p->stages.empty()) return nullptr;
+  for (auto& cc : p->stages.back().concat) if (cc.out_col == col) return &cc;
+  return nullptr;
+}
 
 extern "C" {
 
@@ -1995,6 +2004,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   memset(&p->counters, 0, sizeof(p->counters));
   p->counters.rows_in = rows;
   p->result.fetched.assign(p->result.fetched.size(), false);
+  for (ssgpu_dict*& cd : p->result.concat_dicts) { if (cd) ssgpu_dict_destroy(cd); cd = nullptr; }
   InCols in; in.cols.assign(cols, cols + n_cols); in.rows = rows;
   if (partial && !(p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG)) {
     c->err = "partial runs need a plan whose only stage is a ScalarAggregate"; return SSGPU_ERROR_NOT_IMPLEMENTED;
@@ -2274,9 +2284,117 @@ int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
   { int rc = settle_plan(r->plan); if (rc != SSGPU_OK) return rc; rc = check_error_flags(r->plan); if (rc == SSGPU_OK) rc = fix_nan_minmax(r->plan); if (rc != SSGPU_OK) return rc; }
   StageExec& ex = r->plan->exec.back();
   if (i < 0 || i >= (int)ex.out.size()) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  if (concat_of(r->plan, i)) { r->plan->ctx->err = "a CONCAT column exists on the host only (ssgpu_result_column)"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
   out->data = ex.out[i].data.p;
   out->is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
   return SSGPU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// PrintTyped (base/infrastructure/types_infrastructure.cc:45-80): integers in decimal, BOOL as TRUE / FALSE, FLOAT / DOUBLE as
+// SimpleFtoa / SimpleDtoa (the shortest of %.6g / %.9g resp. %.15g / %.17g that reads back as the same value), STRING as is
+void print_typed(int dtype, const char* cell, const ssgpu_dict* dict, std::string* out) {
+  char buf[64];
+  switch (dtype) {
+    case SSGPU_INT32: { int32_t v; memcpy(&v, cell, 4); *out += std::to_string(v); } break;
+    case SSGPU_UINT32: { uint32_t v; memcpy(&v, cell, 4); *out += std::to_string(v); } break;
+    case SSGPU_INT64: { int64_t v; memcpy(&v, cell, 8); *out += std::to_string((long long)v); } break;
+    case SSGPU_UINT64: { uint64_t v; memcpy(&v, cell, 8); *out += std::to_string((unsigned long long)v); } break;
+    case SSGPU_BOOL: *out += *cell ? "TRUE" : "FALSE"; break;
+    case SSGPU_FLOAT: {
+      float v; memcpy(&v, cell, 4);
+      if (std::isnan(v)) { *out += "nan"; break; }
+      if (std::isinf(v)) { *out += v < 0 ? "-inf" : "inf"; break; }
+      snprintf(buf, sizeof(buf), "%.*g", 6, (double)v);
+      if (strtof(buf, nullptr) != v) snprintf(buf, sizeof(buf), "%.*g", 9, (double)v);
+      *out += buf;
+    } break;
+    case SSGPU_DOUBLE: {
+      double v; memcpy(&v, cell, 8);
+      if (std::isnan(v)) { *out += "nan"; break; }
+      if (std::isinf(v)) { *out += v < 0 ? "-inf" : "inf"; break; }
+      snprintf(buf, sizeof(buf), "%.*g", 15, v);
+      if (strtod(buf, nullptr) != v) snprintf(buf, sizeof(buf), "%.*g", 17, v);
+      *out += buf;
+    } break;
+    case SSGPU_STRING: {
+      int32_t code; memcpy(&code, cell, 4);
+      const char* bytes = nullptr; int32_t len = 0;
+      if (dict && ssgpu_dict_decode(dict, code, &bytes, &len) == SSGPU_OK) out->append(bytes, (size_t)len);
+    } break;
+    default: break;
+  }
+}
+
+// The STRINGs of a CONCAT column (Stage::ConcatCol): the stage's input rows -- materialised and, for a group aggregate, sorted
+// by the keys, so a group's rows are adjacent and in input order -- come to the host with their segment ids; every non-NULL
+// value is printed and appended to its group's string, ',' between values (aggregation_operators.h:236-283; the first value
+// is assigned, column_aggregator.cc:108-124).  A group without a non-NULL value is NULL.  The strings become a dictionary
+// of the result; the column holds its codes.
+int build_concat_column(ssgpu_result* r, int32_t col, const Stage::ConcatCol& cc, int64_t out_rows) {
+  ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
+  const size_t si = p->stages.size() - 1;
+  const Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  if (cc.src_dtype == SSGPU_STRING && !p->dict) { c->err = "CONCAT of a STRING column needs the plan's dictionary (ssgpu_plan_set_dict)"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  int64_t n = p->last_rows;
+  const void* dev_x = nullptr; const uint8_t* dev_z = nullptr;
+  if (si == 0) {
+    if (cc.src_col >= (int)p->last_cols.size()) return SSGPU_ERROR_UNKNOWN;
+    dev_x = p->last_cols[cc.src_col].data; dev_z = p->desc.input_schema[cc.src_col].nullable ? p->last_cols[cc.src_col].is_null : nullptr;
+  } else {
+    int rc = stage_rows(p, si - 1, &n); if (rc != SSGPU_OK) return rc;
+    StageExec& px = p->exec[si - 1];
+    dev_x = px.out[cc.src_col].data.p; dev_z = px.out[cc.src_col].nullable ? px.out[cc.src_col].nulls.as<uint8_t>() : nullptr;
+  }
+  const size_t w = (size_t)dtype_width(cc.src_dtype);
+  std::vector<char> x((size_t)n * w); std::vector<uint8_t> z; std::vector<uint32_t> seg;
+  if (n) HIP_TRY(c, hipMemcpyAsync(x.data(), dev_x, x.size(), hipMemcpyDeviceToHost, c->stream));
+  if (dev_z && n) { z.resize((size_t)n); HIP_TRY(c, hipMemcpyAsync(z.data(), dev_z, z.size(), hipMemcpyDeviceToHost, c->stream)); }
+  if (st.kind == STAGE_CLUSTERS && n) { seg.resize((size_t)n); HIP_TRY(c, hipMemcpyAsync(seg.data(), ex.seg_id.p, seg.size() * 4, hipMemcpyDeviceToHost, c->stream)); }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<std::string> text((size_t)out_rows); std::vector<uint8_t> has((size_t)out_rows, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    if (!z.empty() && z[(size_t)i]) continue;
+    const size_t g = seg.empty() ? 0 : seg[(size_t)i];
+    if (g >= (size_t)out_rows) continue;
+    if (has[g]) text[g] += ','; else has[g] = 1;
+    print_typed(cc.src_dtype, x.data() + (size_t)i * w, p->dict, &text[g]);
+  }
+  std::vector<const char*> ptrs; std::vector<int32_t> lens;
+  for (size_t g = 0; g < text.size(); ++g) if (has[g]) { ptrs.push_back(text[g].data()); lens.push_back((int32_t)text[g].size()); }
+  ssgpu_dict* dict = nullptr;
+  int rc = ssgpu_dict_create(ptrs.data(), lens.data(), (int64_t)ptrs.size(), &dict);
+  if (rc != SSGPU_OK) return rc;
+  ptrs.clear(); lens.clear();
+  for (size_t g = 0; g < text.size(); ++g) { ptrs.push_back(text[g].data()); lens.push_back((int32_t)text[g].size()); }
+  HIP_TRY(c, r->host_data[col].ensure((size_t)std::max<int64_t>(out_rows, 1) * 4)); HIP_TRY(c, r->host_nulls[col].ensure((size_t)std::max<int64_t>(out_rows, 1)));
+  std::vector<uint8_t> isnull((size_t)out_rows);
+  for (size_t g = 0; g < isnull.size(); ++g) isnull[g] = has[g] ? 0 : 1;
+  if (out_rows) {
+    rc = ssgpu_dict_encode(dict, ptrs.data(), lens.data(), isnull.data(), out_rows, static_cast<int32_t*>(r->host_data[col].p));
+    if (rc != SSGPU_OK) { ssgpu_dict_destroy(dict); return rc; }
+    memcpy(r->host_nulls[col].p, isnull.data(), isnull.size());
+  }
+  if (r->concat_dicts.size() < r->host_data.size()) r->concat_dicts.resize(r->host_data.size(), nullptr);
+  if (r->concat_dicts[col]) ssgpu_dict_destroy(r->concat_dicts[col]);
+  r->concat_dicts[col] = dict;
+  return SSGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ssgpu_plan_set_dict(ssgpu_plan* p, const ssgpu_dict* dict) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  p->dict = dict;
+  return SSGPU_OK;
+}
+const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t i) {
+  if (!r || !r->plan || !concat_of(r->plan, i)) return nullptr;
+  if ((size_t)i >= r->concat_dicts.size() || !r->concat_dicts[i]) { const void* d; const uint8_t* z; if (ssgpu_result_column(r, i, &d, &z) != SSGPU_OK) return nullptr; }
+  return (size_t)i < r->concat_dicts.size() ? r->concat_dicts[i] : nullptr;
 }
 
 int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data, const uint8_t** is_null) {
@@ -2293,6 +2411,16 @@ int ssgpu_result_column(ssgpu_result* r, int32_t i, const void** data, const uin
   if (rows < 0) return SSGPU_ERROR_HIP;
   const size_t n = ex.out.size();
   if (r->host_data.size() != n) { r->host_data = std::vector<PinnedBuf>(n); r->host_nulls = std::vector<PinnedBuf>(n); r->fetched.assign(n, false); }
+  if (!r->fetched[i] && concat_of(p, i)) {   // a CONCAT column: its strings are built here, from the stage's ordered input
+    rc = build_concat_column(r, i, *concat_of(p, i), rows);
+    if (rc != SSGPU_OK) return rc;
+    r->fetched[i] = true;
+  }
+  if (concat_of(p, i)) {
+    if (data) *data = r->host_data[i].p;
+    if (is_null) *is_null = (const uint8_t*)r->host_nulls[i].p;
+    return SSGPU_OK;
+  }
   if (!r->fetched[i]) {
     const size_t bytes = (size_t)rows * ex.out[i].width;
     HIP_TRY(c, r->host_data[i].ensure(bytes));

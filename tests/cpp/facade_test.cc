@@ -351,6 +351,33 @@ static void TestSeamsRun(const Input& in) {
         CHECK_EQ(r.view().column(2).typed_data<uint64_t>()[gi], cnt);
       }
     }
+    {  // CONCAT (column_aggregator_test.cc:365-412): printed values joined with ',' in input order; StringPiece cells of the result's own dictionary
+      TupleSchema cs; cs.add_attribute(Attribute("g", INT32, NOT_NULLABLE)); cs.add_attribute(Attribute("w", STRING, NULLABLE)); cs.add_attribute(Attribute("i", INT32, NOT_NULLABLE));
+      const char* ws[5] = {"baba", "baba", "dada", "aba", "wada"};
+      std::vector<int32_t> g = {0, 1, 0, 1, 0}, iv = {-5, 0, 345, 2, -2};
+      std::vector<StringPiece> wc; for (int k = 0; k < 5; ++k) wc.push_back(ws[k]);
+      std::vector<char> wz = {0, 0, 0, 1, 0};
+      View cv(cs); cv.mutable_column(0)->Reset(g.data(), nullptr); cv.mutable_column(1)->Reset(wc.data(), reinterpret_cast<const bool*>(wz.data()));
+      cv.mutable_column(2)->Reset(iv.data(), nullptr); cv.set_row_count(5);
+      std::unique_ptr<Operation> cop(GroupAggregate(ProjectNamedAttribute("g"),
+          (new AggregationSpecification)->AddAggregation(CONCAT, "w", "cw")->AddAggregation(CONCAT, "i", "ci")->AddAggregation(SUM, "i", "si"), nullptr, ScanView(cv)));
+      FailureOrOwned<Cursor> cc = cop->CreateCursor();
+      CHECK(cc.is_success());
+      if (cc.is_success()) {
+        CHECK_EQ(cc->schema().attribute(1).type(), STRING);
+        ResultView r = cc->Next(Cursor::kDefaultRowCount);
+        if (r.is_failure()) { printf("CONCAT run failed: %s\n", r.exception().message().c_str()); ++g_fail; }
+        else {
+          CHECK_EQ(r.view().row_count(), static_cast<rowcount_t>(2));
+          for (rowcount_t row = 0; row < r.view().row_count() && r.view().row_count() == 2; ++row) {
+            const bool g0 = r.view().column(0).typed_data<int32_t>()[row] == 0;
+            CHECK(r.view().column(1).typed_data<StringPiece>()[row] == StringPiece(g0 ? "baba,dada,wada" : "baba"));
+            CHECK(r.view().column(2).typed_data<StringPiece>()[row] == StringPiece(g0 ? "-5,345,-2" : "0,2"));
+            CHECK_EQ(r.view().column(3).typed_data<int32_t>()[row], g0 ? 338 : 2);
+          }
+        }
+      }
+    }
     std::unique_ptr<Operation> mm(ScalarAggregate((new AggregationSpecification)->AddAggregation(MIN, "name", "lo")->AddAggregation(MAX, "name", "hi"), ScanView(view)));
     FailureOrOwned<Cursor> c2 = mm->CreateCursor();
     CHECK(c2.is_success());

@@ -534,6 +534,21 @@ op_case("ColumnAggregator_ComputeCountWithoutInputColumn", CA + ":254-267", cols
         ["ScalarAggregate", [["COUNT", "", "r", I64]], "INPUT"], [I64], [[4]], exp_nullable=[False])
 op_case("ColumnAggregator_ComputeCountOfValuesWithNulls", CA + ":269-290", cols([I32]), [[None], [0], [None], [4]],
         ["ScalarAggregate", [["COUNT", "col0", "r", I32]], "INPUT"], [I32], [[2]], exp_nullable=[False])
+# CONCAT: the values of a group, printed, joined with ',' in input order (two UpdateAggregation calls = two input blocks)
+op_case("ColumnAggregator_ComputeConcatOfInts", CA + ":365-388", [["g", I32, False], ["v", I32, True]],
+        [[0, -5], [0, 0], [0, 345], [0, 2], [0, -2], [0, 3], [0, 1]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["CONCAT", "v", "r"]], "INPUT"], [I32, STR], [[0, "-5,0,345,2,-2,3,1"]], ordered=False)
+op_case("ColumnAggregator_ComputeConcatOfStrings_string", CA + ":390-412", [["g", I32, False], ["v", STR, True]],
+        [[0, "baba"], [0, "baba"], [0, "dada"], [0, "aba"], [0, "wada"]],
+        ["GroupAggregate", ["ProjectNamedAttribute", "g"], [["CONCAT", "v", "r"]], "INPUT"], [I32, STR], [[0, "baba,baba,dada,aba,wada"]], ordered=False)
+# aggregation_operators_test.cc:247-272 (ConcatStrings / ConcatInts): the operator appends ',' + value to what it has; the
+# first value of a group is assigned, not aggregated (column_aggregator.cc:108-124) -- together: "G,az,elle, is a kind of an antelope"
+op_case("AggregationOperators_ConcatStrings_string", "supersonic/base/infrastructure/aggregation_operators_test.cc:247-260", cols([STR]),
+        [["G"], ["az"], ["elle"], [" is a kind of an antelope"]],
+        ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["G,az,elle, is a kind of an antelope"]])
+op_case("AggregationOperators_ConcatInts", "supersonic/base/infrastructure/aggregation_operators_test.cc:262-272", cols([I32]),
+        [[-7], [None], [0]],
+        ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["-7,0"]])
 op_case("ColumnAggregator_NotSupportedAggregationDetected_string", CA + ":518-526", cols([STR]), [],
         ["ScalarAggregate", [["SUM", "col0", "r"]], "INPUT"], None, [], expect_error=405)
 op_case("ColumnAggregator_NotSupportedCountOutputTypeDetected", CA + ":528-534", cols([I32]), [],

@@ -11,7 +11,7 @@ import supersonic_amd as ss
 HERE = os.path.dirname(os.path.abspath(__file__))
 TYPES = {"INT32": ss.INT32, "INT64": ss.INT64, "UINT32": ss.UINT32, "UINT64": ss.UINT64, "FLOAT": ss.FLOAT,
          "DOUBLE": ss.DOUBLE, "BOOL": ss.BOOL, "DATE": ss.DATE, "DATETIME": ss.DATETIME, "STRING": ss.STRING}
-AGGS = {"SUM": ss.SUM, "MIN": ss.MIN, "MAX": ss.MAX, "COUNT": ss.COUNT, "FIRST": ss.FIRST, "LAST": ss.LAST}
+AGGS = {"SUM": ss.SUM, "MIN": ss.MIN, "MAX": ss.MAX, "COUNT": ss.COUNT, "FIRST": ss.FIRST, "LAST": ss.LAST, "CONCAT": ss.CONCAT}
 ORDERS = {"ASCENDING": ss.ASCENDING, "DESCENDING": ss.DESCENDING}
 
 

@@ -1521,3 +1521,42 @@ def test_device_sharded_group_aggregate_exchange_forms_one_rank(exchange):
         assert_cols_equal(sort_rows(to_cols(got)), sort_rows(want), context="device sharded group aggregate, " + exchange)
     finally:
         dist.destroy_process_group()
+
+
+# ---- CONCAT (column_aggregator.cc:496-505, aggregation_operators.h:236-283): the values of a group, printed (PrintTyped), joined
+# ---- with ',' in input order; NULL inputs skipped, a group without a value is NULL.  The device orders the rows (materialise +
+# ---- stable sort by the keys) and counts; the strings are printed on the host when the column is fetched ------------------------
+@pytest.mark.parametrize("n", [0, 1, 7, 1025, 30011])
+def test_concat_aggregate(gpu_ctx, n):
+    rng = np.random.default_rng(n + 1)
+    words = np.empty(n, dtype=object)
+    words[:] = [[b"baba", b"aba", b"", b"wada", b"x,y"][i] for i in rng.integers(0, 5, n)]
+    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("h", ss.INT64, ss.NULLABLE), ss.Attribute("i", ss.INT32, ss.NULLABLE), ss.Attribute("u", ss.UINT64),
+                             ss.Attribute("w", ss.STRING, ss.NULLABLE), ss.Attribute("d", ss.DOUBLE), ss.Attribute("f", ss.FLOAT), ss.Attribute("t", ss.BOOL, ss.NULLABLE),
+                             ss.Attribute("a", ss.INT64)])
+    dv = np.where(rng.random(n) < 0.2, rng.integers(-5, 5, n) * 0.5, rng.normal(size=n) * 10.0 ** rng.integers(-8, 12, n))
+    if n > 6:
+        dv[:6] = [float("nan"), float("inf"), float("-inf"), -0.0, 1.0 / 3.0, 1e22]
+    view = ss.View(schema, [rng.integers(0, 23, n).astype(np.int32), ss.Column(rng.integers(0, 3, n), rng.random(n) < 0.2),
+                            ss.Column(rng.integers(-(1 << 31), 1 << 31, n).astype(np.int32), rng.random(n) < 0.3),
+                            rng.integers(0, 1 << 63, n).astype(np.uint64) * np.uint64(2), ss.Column(words, rng.random(n) < 0.2), dv, dv.astype(np.float32),
+                            ss.Column(rng.integers(0, 2, n).astype(bool), rng.random(n) < 0.5), rng.integers(0, 1000, n)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.CONCAT, "i", "ci").AddAggregation(ss.SUM, "a", "sa").AddAggregation(ss.CONCAT, "w", "cw")
+            .AddAggregation(ss.CONCAT, "u", "cu").AddAggregation(ss.CONCAT, "d", "cd").AddAggregation(ss.CONCAT, "f", "cf").AddAggregation(ss.CONCAT, "t", "ct")
+            .AddAggregation(ss.COUNT, "i", "n").AddAggregation(ss.MIN, "w", "mw"))
+    flt = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(299)), ss.ProjectAllAttributes(), ss.ScanView(view))
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "h"]), spec, None, flt), gpu_ctx, ignore_order=True)      # a NULLABLE INT64 key among them
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.ScalarAggregate(spec, flt), gpu_ctx)
+    order = np.argsort(view.column(0).data, kind="stable")
+    clustered = ss.View(schema, [ss.Column(view.column(i).data[order], None if view.column(i).is_null is None else view.column(i).is_null[order]) for i in range(9)])
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("g"), spec, ss.ScanView(clustered)), gpu_ctx)
+    # a computed CONCAT input, and the refusals: DISTINCT CONCAT, a consumer above the CONCAT, a non-STRING result type
+    comp = ss.Compute(ss.CompoundExpression().Add(NA("g")).AddAs("s", ss.Plus(NA("a"), ss.ConstInt64(7))), ss.ScanView(view))
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "s", "cs"), None, comp), gpu_ctx, ignore_order=True)
+    for bad, code in ((ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddDistinctAggregation(ss.CONCAT, "i", "c"), None, ss.ScanView(view)), ss.ERROR_NOT_IMPLEMENTED),
+                      (ss.Sort(ss.SortOrder().add("g", ss.ASCENDING), None, 0, ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "i", "c"), None, ss.ScanView(view))), ss.ERROR_NOT_IMPLEMENTED),
+                      (ss.ScalarAggregate(ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.CONCAT, "i", "c", ss.INT64), ss.ScanView(view)), ss.ERROR_INVALID_ARGUMENT_TYPE)):
+        with pytest.raises(ss.SupersonicException) as e:
+            ss.Plan(bad, gpu_ctx)
+        assert e.value.return_code == code
