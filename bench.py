@@ -558,6 +558,23 @@ def main():
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             groups_total = int(g.item())
 
+    group_checked = None
+    if group and job is None:
+        # checksums of checksums against torch over the same device columns (every DOUBLE is a small multiple of 0.25: exact)
+        dv = plan.result_device_view()
+        out_rows = dv.row_count()
+        gcol = lambda i: torch.as_tensor(_DevPtr(dv._ptrs[i][0], out_rows, "<f8"), device=device)   # noqa: E731
+        keep = (cols[0] > K_FILTER) if GROUP_FILTER else None
+        sel = (lambda t: t[keep]) if keep is not None else (lambda t: t)                              # noqa: E731
+        gid = sel(cols[1].to(torch.int64) * 317 + cols[2])
+        group_checked = {"groups_match": out_rows == int((torch.bincount(gid, minlength=N_GROUPS) > 0).sum().item()),
+                         "sum_of_sums_d0": float(gcol(2).sum().item()) == float(sel(cols[3]).sum().item()),
+                         "sum_of_sums_d1": float(gcol(5).sum().item()) == float(sel(cols[4]).sum().item()),
+                         "min_of_mins_d2": float(gcol(9).min().item()) == float(sel(cols[5]).min().item()),
+                         "max_of_maxes_d3": float(gcol(13).max().item()) == float(sel(cols[6]).max().item())}
+        del gid, keep
+        if not all(group_checked.values()):
+            raise SystemExit("bench.py --query %s: the device result failed its check: %r" % (QUERY_NAME, group_checked))
     if args.query in ("sort", "filter_mat"):
         # the result is as large as the input: it stays in HBM; check it there (never copied to the host)
         dv = plan.result_device_view()
@@ -590,7 +607,7 @@ def main():
                        world, "all-to-all by key range (every rank merges the groups it owns)" if args.exchange == "key_range" else "all-gather")
                    if distributed else "single GPU")
             kernel = "group stage (partition scatter + per-partition aggregation kernels)"
-            result_row = {"groups": groups_total}
+            result_row = dict({"groups": groups_total}, **(group_checked or {}))
         elif args.query == "sort":
             workload = "Q-SORT: Sort(d ASC, all 8 columns) of a device-resident %d-row x 8-col block" % rows
             par, kernel = "single GPU", "sort stage (key load + histograms, radix passes, tie fix-up, record pack + gather)"

@@ -314,7 +314,8 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *   Filter:                 filter_single_pass (1 = decoupled look-back instead of count + store passes)
  *   GroupAggregate:         group_capacity (initial table), group_local (0 = no LDS table in front of the global one),
  *                           group_partition (0 never / 1 by run feedback / 2 always hash-partitioned), group_slab (0 never /
- *                           1 by estimate / 2 always the one-table-per-CU form), part_plain (0 = the partition scatter always as
+ *                           1 by estimate / 2 always the one-table-per-CU form), group_resident (0 = the one-table-per-CU form always
+ *                           through scatter + aggregation, never straight from the input columns), part_plain (0 = the partition scatter always as
  *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
  *                           part_rec_align
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),
@@ -454,7 +455,9 @@ int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
  * test that claims to cover the partitioned GroupAggregate or the hybrid Sort asserts here that it ran. */
 typedef struct ssgpu_stage_info {
   int32_t kind;             /* 1 scalar aggregate, 2 materialise, 3 group aggregate, 4 sort, 5 clustered aggregate, 6 join expansion */
-  int32_t group_shape;      /* group aggregate: 0 direct (LDS table + global table), 1 hash partitions, 2 slab */
+  int32_t group_shape;      /* group aggregate: 0 direct (LDS table + global table), 1 hash partitions, 2 slab (one LDS table of all groups per
+                               aggregation workgroup, records through memory), 3 resident (the same tables fed straight from the input
+                               columns of a plain stage: no scatter, no records) */
   int32_t part_n;           /* hash partitions of the partitioned shape */
   int32_t part_seg_growth;  /* x4 per segment overflow (skewed keys) */
   int32_t group_wgs_per_cu; /* direct shape: resident workgroups per CU the LDS table is sized for */
@@ -463,7 +466,7 @@ typedef struct ssgpu_stage_info {
   int32_t sort_mode;        /* 0 LSD over the varying digits, 1 high digits + tie fix-up, 2 one-word (high half | row id) keys;
                                +16: tie runs were too long and all digits were sorted after all */
   int32_t specialized;      /* bit 0 the stage's program, bit 1 the partition-scatter program, bit 2 the partition aggregation,
-                               bit 3 the plain partition scatter */
+                               bit 3 the plain partition scatter, bit 4 the resident group aggregation */
   int32_t plain_scatter;    /* the partition scatter ran as its own kernel over (partition, XCD) segments, not as a VM program */
   int32_t reserved[6];
 } ssgpu_stage_info;

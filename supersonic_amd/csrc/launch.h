@@ -96,6 +96,10 @@ struct FoldTailColumn { const void* src; const unsigned char* src_nulls; void* d
 hipError_t ssgpu_launch_fold_tail(const FoldTailColumn* cols_dev, unsigned int n_cols, unsigned long long n_in, unsigned long long limit, hipStream_t stream);
 unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread);
 hipError_t ssgpu_part_agg_set_max_lds(int bytes);
+// The LDS-resident form of a plain GroupAggregate stage (few groups: ONE LDS table holds them all): `grid` 1024-thread
+// workgroups read the input columns themselves (S: keys, fields, predicates; recs / counts unused), aggregate into a
+// table of all groups each and merge it into the global table (A as for the slab form, slab_segs != 0).  No scatter.
+hipError_t ssgpu_launch_group_resident(const PartAggParams& A, const PlainScatterParams& S, unsigned int lds_bytes, int grid, hipStream_t stream);
 
 // HashJoin index over the rhs table: packed 64-bit key (same packing as the lhs KEY_APPEND
 // instructions) -> rhs row.  Rows with a NULL key are not indexed (they can never match);
@@ -138,7 +142,8 @@ void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, 
                            int n_staged, uint32_t static_lds, std::string* why);
 hipError_t ssgpu_launch_pipeline_rtc(void* handle, const VmParams& P, int grid, bool static_lds, hipStream_t stream);
 void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
-                                    unsigned int lds_bytes, std::string* why);
+                                    unsigned int lds_bytes, std::string* why, const PlainScatterParams* source = nullptr);   // source: the resident form (reads the input columns)
+hipError_t ssgpu_launch_group_resident_rtc(void* handle, const PartAggParams& A, const PlainScatterParams& S, int grid, hipStream_t stream);
 hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
 void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int rows_per_thread, unsigned int lds_bytes, std::string* why);
 hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterParams& P, int grid, hipStream_t stream);

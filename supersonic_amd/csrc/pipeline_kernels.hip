@@ -1015,7 +1015,10 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
 #ifndef FKEY   /* (vm_body.inc defines the same for the pipeline kernel's GAGG handlers) */
 #define FKEY(d) ({ u64 b_ = d2u((double)(d)); (b_ & 0x8000000000000000ull) ? ~b_ : (b_ | 0x8000000000000000ull); })
 #endif
-#define PART_ROWS 2   /* records per lane per step */
+/* PART_ROWS: records per lane per step -- a constant of part_agg_body (2; the resident form, at one workgroup per CU, takes RESIDENT_ROWS) */
+#ifndef SSGPU_RESIDENT_ROWS
+#define SSGPU_RESIDENT_ROWS 4
+#endif
 #define LDS_AS __attribute__((address_space(3)))
 template <int MAXW> struct RecVec { typedef u64 type __attribute__((ext_vector_type(MAXW))); };
 template <int MAXW> __device__ __forceinline__ u64 rec_word(const typename RecVec<MAXW>::type& r, u32 w) {
@@ -1058,15 +1061,127 @@ __device__ __forceinline__ u32 part_block_scan(u32 v, LDS_AS u32* wsum, u32 t, u
   return pre + inc - v;
 }
 
-template <int MAXW>
-__global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_part_agg_kernel(const PartAggParams P) {
+// One predicate of a plain stage on one row (the same function as group_scatter_kernel.hip's pscat_pred).
+__device__ __forceinline__ bool plain_pred(const void* data, const u8* nulls, u64 c, u32 kind, u32 cmp, bool col_on_left, u64 row) {
+  const bool is_null = nulls ? nulls[row] != 0 : false;    // a NULL predicate drops the row (filter.cc:170-199)
+  bool lt, gt, eq;   // column < constant, column > constant, column == constant
+  switch (kind) {
+    case 0: { const i32 v = reinterpret_cast<const i32*>(data)[row], k = (i32)(u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 1: { const u32 v = reinterpret_cast<const u32*>(data)[row], k = (u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 2: { const i64 v = reinterpret_cast<const i64*>(data)[row], k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 3: { const u64 v = reinterpret_cast<const u64*>(data)[row], k = c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 4: { const float v = reinterpret_cast<const float*>(data)[row], k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    default: { const double v = reinterpret_cast<const double*>(data)[row], k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
+  }
+  bool r;
+  switch (cmp) {
+    case 0: r = col_on_left ? lt : gt; break;
+    case 1: r = col_on_left ? (lt || eq) : (gt || eq); break;
+    case 2: r = eq; break;
+    default: r = !eq; break;
+  }
+  return r && !is_null;
+}
+struct NoRowSource {};
+#ifdef SSGPU_RTC_PART_PLAIN   /* rtc_part.h of a resident-form build: the row source's descriptors are constants, too */
+#define RS_NKEYS kRsNKeys
+#define RS_KEY_WIDTH(k) kRsKeyWidth[k]
+#define RS_KEY_SHIFT(k) kRsKeyShift[k]
+#define RS_KEY_BITS(k) kRsKeyBits[k]
+#define RS_KEY_NULLBIT(k) kRsKeyNullbit[k]
+#define RS_NFIELDS kRsNFields
+#define RS_FIELD_WIDTH(f) kRsFieldWidth[f]
+#define RS_FIELD_OFF(f) kRsFieldOff[f]
+#define RS_NPREDS kRsNPreds
+#define RS_PRED_KIND(q) kRsPredKind[q]
+#define RS_PRED_CMP(q) kRsPredCmp[q]
+#define RS_PRED_COL_LEFT(q) (kRsPredColLeft[q] != 0u)
+#define RS_UNROLL _Pragma("unroll")
+#else
+#define RS_NKEYS S.n_keys
+#define RS_KEY_WIDTH(k) S.keys[k].width
+#define RS_KEY_SHIFT(k) S.keys[k].shift
+#define RS_KEY_BITS(k) S.keys[k].bits
+#define RS_KEY_NULLBIT(k) S.keys[k].nullbit
+#define RS_NFIELDS S.n_fields
+#define RS_FIELD_WIDTH(f) S.fields[f].width
+#define RS_FIELD_OFF(f) S.fields[f].off
+#define RS_NPREDS S.n_preds
+#define RS_PRED_KIND(q) S.preds[q].kind
+#define RS_PRED_CMP(q) S.preds[q].cmp
+#define RS_PRED_COL_LEFT(q) (S.preds[q].col_on_left != 0u)
+#define RS_UNROLL
+#endif
+__device__ __forceinline__ bool plain_pred_value(u64 raw, bool is_null, u64 c, u32 kind, u32 cmp, bool col_on_left) {
+  bool lt, gt, eq;
+  switch (kind) {
+    case 0: { const i32 v = (i32)(u32)raw, k = (i32)(u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 1: { const u32 v = (u32)raw, k = (u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 2: { const i64 v = (i64)raw, k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 3: { const u64 v = raw, k = c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 4: { const float v = __uint_as_float((u32)raw), k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    default: { const double v = u2d(raw), k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
+  }
+  bool r;
+  switch (cmp) {
+    case 0: r = col_on_left ? lt : gt; break;
+    case 1: r = col_on_left ? (lt || eq) : (gt || eq); break;
+    case 2: r = eq; break;
+    default: r = !eq; break;
+  }
+  return r && !is_null;
+}
+__device__ __forceinline__ u64 load_by_width(const void* p, u32 width, u64 row) {
+  return width == 8u ? reinterpret_cast<const u64*>(p)[row] : width == 4u ? (u64)reinterpret_cast<const u32*>(p)[row] : (u64)reinterpret_cast<const u8*>(p)[row];
+}
+#ifdef SSGPU_RTC_PART_PLAIN
+// The specialised resident kernel is software-pipelined: the column loads of step i + 1 are issued (into these registers:
+// every bound below is a constant of the build) before step i's LDS work starts and are first looked at one iteration
+// later.  At one 1024-thread workgroup per CU there are too few waves for the loads of some to hide behind the LDS
+// work of others: without this the two phases simply add up (measured: 0.9 ms of loads + 0.9 ms of LDS work = 1.8 ms).
+template <int ROWS> struct ResidentRaw {
+  u64 k[ROWS][kRsNKeys ? kRsNKeys : 1]; u32 kn[ROWS][kRsNKeys ? kRsNKeys : 1];
+  u64 f[ROWS][kRsNFields ? kRsNFields : 1];
+  u64 p[ROWS][kRsNPreds ? kRsNPreds : 1]; u32 pn[ROWS][kRsNPreds ? kRsNPreds : 1];
+  bool in[ROWS];
+};
+template <int ROWS>
+__device__ __forceinline__ void resident_issue(const PlainScatterParams& S, u64 base, u64 n_rows, u32 t, ResidentRaw<ROWS>& R) {
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) {
+    const u64 row = base + (u64)j * SSGPU_PART_THREADS + t;
+    R.in[j] = row < n_rows;
+    const u64 rowc = R.in[j] ? row : 0ull;       // unconditional loads on a row that exists
+#pragma unroll
+    for (u32 q = 0; q < kRsNPreds; ++q) {
+      R.p[j][q] = load_by_width(S.preds[q].data, (kRsPredKind[q] == 0u || kRsPredKind[q] == 1u || kRsPredKind[q] == 4u) ? 4u : 8u, rowc);
+      R.pn[j][q] = S.preds[q].nulls ? (u32)S.preds[q].nulls[rowc] : 0u;
+    }
+#pragma unroll
+    for (u32 k = 0; k < kRsNKeys; ++k) {
+      R.k[j][k] = load_by_width(S.keys[k].data, kRsKeyWidth[k], rowc);
+      R.kn[j][k] = S.keys[k].nulls ? (u32)S.keys[k].nulls[rowc] : 0u;
+    }
+#pragma unroll
+    for (u32 f = 0; f < kRsNFields; ++f) R.f[j][f] = S.fields[f].src ? load_by_width(S.fields[f].src, kRsFieldWidth[f], rowc) : 0ull;
+  }
+}
+#endif
+// PLAIN (the LDS-RESIDENT form of a plain stage, ssgpu_group_resident_kernel): there are no records in memory at all --
+// every workgroup holds a table of ALL groups (the slab form's table and end-of-kernel merge) and assembles its rows'
+// records in registers straight from the input columns, exactly as the plain scatter would have laid them out (key word,
+// then the field list of PlainScatterParams), so the aggregates' descriptors are the same.  40 bytes per row cross HBM
+// once instead of three times.
+template <int MAXW, bool PLAIN, typename SRC>
+__device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC& S) {
   typedef typename RecVec<MAXW>::type Rec;
+  constexpr int PART_ROWS = PLAIN ? SSGPU_RESIDENT_ROWS : 2;
   const u32 t = threadIdx.x, part = blockIdx.x;
   const u32 C = P.local_capacity, ng = PART_NG(P), W = PART_W(P);
   const bool any_cnt = PART_ANY_CNT(P);
   // slab mode: this workgroup's segments are a run of the single partition's segments
   const u32 seg0 = P.slab_segs ? part * P.slab_segs : 0u;
-  const u32 G = P.slab_segs ? (seg0 < P.n_segs ? (P.n_segs - seg0 < P.slab_segs ? P.n_segs - seg0 : P.slab_segs) : 0u) : P.n_segs;
+  const u32 G = PLAIN ? 0u : P.slab_segs ? (seg0 < P.n_segs ? (P.n_segs - seg0 < P.slab_segs ? P.n_segs - seg0 : P.slab_segs) : 0u) : P.n_segs;
   // an entry's accumulator words are `st` words apart, st odd: the lanes of a wave hit word k of 64 different entries,
   // and with an even stride (16 words = 128 B) those addresses fall into two LDS banks -- a 32-way conflict on every
   // atomic (measured: 5x slower)
@@ -1086,7 +1201,7 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
   for (u32 e = t; e <= C; e += SSGPU_PART_THREADS) lkeys[e] = VM_KEY_EMPTY;
   for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (any_cnt) lcnt[i] = 0u; }
   u32 total = 0;
-  {
+  if constexpr (!PLAIN) {
     u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
     n = n < P.seg_cap ? n : P.seg_cap;   // (a segment that ran full: the plain scatter's counter keeps counting; the host reruns with larger segments)
     const u32 ex = part_block_scan(n, wsum, t, &total);
@@ -1094,19 +1209,84 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
     if (t == 0) segoff[G] = total;
   }
   __syncthreads();
-  const u64* const recs = P.recs + (P.slab_segs ? (u64)seg0 : (u64)SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap * W;
-  const u64 seg_step = P.slab_segs ? (u64)P.seg_cap : (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
+  const u64* const recs = PLAIN ? nullptr : P.recs + (P.slab_segs ? (u64)seg0 : (u64)SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap * W;
+  const u64 seg_step = PLAIN ? 0ull : P.slab_segs ? (u64)P.seg_cap : (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
   const u32 seg_cap = P.seg_cap, n_aggs = PART_NAGGS(P);
   const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
   (void)mydesc; (void)n_aggs; (void)seg_cap;
   u32 seg = 0;
   // (fetching step i + 1's records while step i is aggregated -- one record per lane per step, two sets in registers to stay
   // under 64 VGPRs -- was tried: 2.95 ms instead of 1.85 ms for config #3; two records per lane and no prefetch it stays)
-  for (u32 base = 0; base < total; base += SSGPU_PART_THREADS * PART_ROWS) {
+  // (records: [0, total) of this workgroup's segments.  PLAIN: the rows of the input, tiles dealt round-robin to the workgroups)
+  u64 row_first = 0, row_limit = total, row_stride = SSGPU_PART_THREADS * PART_ROWS;
+  if constexpr (PLAIN) { row_first = (u64)part * (SSGPU_PART_THREADS * PART_ROWS); row_limit = S.n_rows; row_stride = (u64)gridDim.x * (SSGPU_PART_THREADS * PART_ROWS); }
+#ifdef SSGPU_RTC_PART_PLAIN
+  ResidentRaw<PART_ROWS> raw;
+  if constexpr (PLAIN) resident_issue<PART_ROWS>(S, row_first < row_limit ? row_first : 0ull, row_limit, t, raw);
+#endif
+  for (u64 base = row_first; base < row_limit; base += row_stride) {
     Rec rec[PART_ROWS]; bool live[PART_ROWS]; u32 li[PART_ROWS];
+    if constexpr (PLAIN) {
+#ifdef SSGPU_RTC_PART_PLAIN
+#pragma unroll
+      for (int j = 0; j < PART_ROWS; ++j) {         // the rows whose loads were issued one step ago
+        live[j] = raw.in[j];
+#pragma unroll
+        for (u32 q = 0; q < kRsNPreds; ++q)
+          live[j] = live[j] & plain_pred_value(raw.p[j][q], raw.pn[j][q] != 0u, S.preds[q].bits, kRsPredKind[q], kRsPredCmp[q], kRsPredColLeft[q] != 0u);
+        u64 key = 0ull;
+#pragma unroll
+        for (u32 k = 0; k < kRsNKeys; ++k) {
+          u64 a = raw.k[j][k] & (kRsKeyBits[k] >= 64u ? ~0ull : ((1ull << (kRsKeyBits[k] & 63u)) - 1ull));
+          if (raw.kn[j][k]) a = 1ull << ((kRsKeyNullbit[k] - kRsKeyShift[k]) & 63u);
+          key |= a << kRsKeyShift[k];
+        }
+#pragma unroll
+        for (int w = 1; w < MAXW; ++w) rec[j][w] = 0ull;
+        rec[j][0] = key;
+#pragma unroll
+        for (u32 f = 0; f < kRsNFields; ++f) rec[j][(kRsFieldOff[f] >> 3) < (u32)MAXW ? (kRsFieldOff[f] >> 3) : 0u] |= raw.f[j][f] << ((kRsFieldOff[f] & 7u) * 8u);
+      }
+      {   // next step's loads: in flight during this step's LDS work (past the end: the clamped row 0, discarded)
+        const u64 nb = base + row_stride;
+        resident_issue<PART_ROWS>(S, nb < row_limit ? nb : 0ull, nb < row_limit ? row_limit : 0ull, t, raw);
+      }
+#else
+#pragma unroll
+      for (int j = 0; j < PART_ROWS; ++j) {
+        const u64 row = base + (u64)j * SSGPU_PART_THREADS + t;
+        live[j] = row < row_limit;
+        const u64 rowc = live[j] ? row : 0ull;   // every load is unconditional (on a row that exists): the descriptor loops stay out of divergent regions
+        RS_UNROLL for (u32 q = 0; q < RS_NPREDS; ++q)
+          live[j] = live[j] & plain_pred(S.preds[q].data, S.preds[q].nulls, S.preds[q].bits, RS_PRED_KIND(q), RS_PRED_CMP(q), RS_PRED_COL_LEFT(q), rowc);
+        u64 key = 0ull;
+        RS_UNROLL for (u32 k = 0; k < RS_NKEYS; ++k) {
+          const u32 kw = RS_KEY_WIDTH(k), kbits = RS_KEY_BITS(k), kshift = RS_KEY_SHIFT(k);
+          u64 a = kw == 8 ? reinterpret_cast<const u64*>(S.keys[k].data)[rowc] : kw == 4 ? (u64)reinterpret_cast<const u32*>(S.keys[k].data)[rowc]
+                                                                                         : (u64)reinterpret_cast<const u8*>(S.keys[k].data)[rowc];
+          a &= kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+          if (S.keys[k].nulls && S.keys[k].nulls[rowc]) a = 1ull << (RS_KEY_NULLBIT(k) - kshift);
+          key |= a << kshift;
+        }
+#pragma unroll
+        for (int w = 1; w < MAXW; ++w) rec[j][w] = 0ull;
+        rec[j][0] = key;
+        RS_UNROLL for (u32 f = 0; f < RS_NFIELDS; ++f) {
+          const void* src = S.fields[f].src;
+          const u32 fw = RS_FIELD_WIDTH(f), fo = RS_FIELD_OFF(f);
+          if (!src) continue;                      // an absent NULL mask: zeros
+          const u64 v = fw == 8u ? reinterpret_cast<const u64*>(src)[rowc] : fw == 4u ? (u64)reinterpret_cast<const u32*>(src)[rowc] : (u64)reinterpret_cast<const u8*>(src)[rowc];
+          const u64 placed = v << ((fo & 7u) * 8u);
+          const u32 word = fo >> 3;              // (wave-uniform: scalar compares, no register indexing)
+#pragma unroll
+          for (int w = 1; w < MAXW; ++w) rec[j][w] |= (word == (u32)w) ? placed : 0ull;
+        }
+      }
+#endif
+    } else {
 #pragma unroll
     for (int j = 0; j < PART_ROWS; ++j) {
-      const u32 i = base + (u32)j * SSGPU_PART_THREADS + t;
+      const u32 i = (u32)base + (u32)j * SSGPU_PART_THREADS + t;
       live[j] = i < total;
       if (live[j]) {
         while (i >= segoff[seg + 1u]) ++seg;              // empty segments are stepped over
@@ -1117,6 +1297,7 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
 #pragma unroll
         for (int w = 0; w < MAXW; ++w) rec[j][w] = 0ull;
       }
+    }
     }
 #pragma unroll
     for (int j = 0; j < PART_ROWS; ++j) {
@@ -1176,7 +1357,19 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
         PART_APPLY(GAGG_SUM_U32, LDS_ADD(A, (u64)(u32)raw))
         PART_APPLY(GAGG_SUM_I64, LDS_ADD(A, raw))
         PART_APPLY(GAGG_SUM_F32, __hip_atomic_fetch_add((LDS_AS double*)A, (double)__uint_as_float((u32)raw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-        PART_APPLY(GAGG_SUM_F64, lds_dd_add((LDS_AS double*)A, u2d(raw)))
+        case VM_GAGG_SUM_F64: {
+          // compensated: the returning atomic gives the exact rounding error of the add.  All rows' adds are issued before
+          // the first returned value is looked at -- one LDS round trip per aggregate instead of one per row
+          double old[PART_ROWS];
+          _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) {
+            old[j] = 0.0;
+            if (ok[j]) old[j] = __hip_atomic_fetch_add((LDS_AS double*)(lacc + li[j] + word), u2d(val[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) {
+            const double v = u2d(val[j]), t2 = old[j] + v, bp = t2 - old[j], err = (old[j] - (t2 - bp)) + (v - bp);
+            if (ok[j] && err != 0.0) __hip_atomic_fetch_add((LDS_AS double*)(lacc + li[j] + word) + 1, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        } break;
         PART_APPLY(GAGG_MIN_I32, LDS_MIN(A, key_i64((i64)(i32)(u32)raw)))
         PART_APPLY(GAGG_MIN_U32, LDS_MIN(A, (u64)(u32)raw))
         PART_APPLY(GAGG_MIN_I64, LDS_MIN(A, key_i64((i64)raw)))
@@ -1236,6 +1429,15 @@ __global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_p
       if (P.any_cnt) P.T.cnt[special * ng + i] = lcnt[(size_t)C * st + i];
     }
   }
+}
+
+template <int MAXW>
+__global__ __launch_bounds__(SSGPU_PART_THREADS, MAXW <= 8 ? 8 : 4) void ssgpu_part_agg_kernel(const PartAggParams P) {
+  part_agg_body<MAXW, false, NoRowSource>(P, NoRowSource());
+}
+template <int MAXW>
+__global__ __launch_bounds__(SSGPU_PART_THREADS, 4) void ssgpu_group_resident_kernel(const PartAggParams P, const PlainScatterParams S) {
+  part_agg_body<MAXW, true, PlainScatterParams>(P, S);
 }
 
 #endif  // !__HIPCC_RTC__ || SSGPU_RTC_PART
@@ -1480,8 +1682,17 @@ hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes,
   else hipLaunchKernelGGL(ssgpu_part_agg_kernel<16>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
   return hipGetLastError();
 }
+hipError_t ssgpu_launch_group_resident(const PartAggParams& P, const PlainScatterParams& S, unsigned int lds_bytes, int grid, hipStream_t stream) {
+  if (P.rec_words <= 8) hipLaunchKernelGGL(ssgpu_group_resident_kernel<8>, dim3(grid), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P, S);
+  else hipLaunchKernelGGL(ssgpu_group_resident_kernel<16>, dim3(grid), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P, S);
+  return hipGetLastError();
+}
 hipError_t ssgpu_part_agg_set_max_lds(int bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_group_resident_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_group_resident_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

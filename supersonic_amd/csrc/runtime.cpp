@@ -51,6 +51,7 @@ struct ssgpu_ctx {
   int64_t sort_records = 1;      // 0: always gather payload columns one by one
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
   int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
+  int64_t group_resident = 1;    // 0: plain stages take the slab form through scatter + aggregation like every other stage (tests, A/B)
   int64_t lazy_feedback = 1;     // 0: a GroupAggregate reads its overflow / feedback words back at the end of EVERY run (a stream synchronise per run)
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
@@ -160,6 +161,7 @@ struct StageExec {
   RtcSlot rtc_pscatter; std::vector<VmInstr> host_prog_pscatter;   // its specialised kernel (rtc.cpp)
   RtcSlot rtc_plain;            // ssgpu_part_scatter_plain_kernel specialised for this stage's record and a partition count (static_lds = its LDS size)
   RtcSlot rtc_part;             // ssgpu_part_agg_kernel specialised for this stage's aggregates and an LDS size (static_lds)
+  RtcSlot rtc_resident;         // ssgpu_group_resident_kernel specialised for this stage's row source and aggregates
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jkeys_hi, jrows, jmisc;
@@ -323,6 +325,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_agg_lds") c->part_agg_lds = value;
   else if (k == "part_agg_debug") c->part_agg_debug = value;
   else if (k == "group_slab") c->group_slab = value;
+  else if (k == "group_resident") c->group_resident = value;
   else if (k == "part_plain") c->part_plain = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
@@ -580,7 +583,7 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   }
   // the stream is drained: no launch of this plan's specialised kernels is in flight -- drop the references (the
   // module of a kernel no other plan uses is unloaded, rtc.cpp)
-  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); }
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); }
   ssgpu_ctx* c = p->ctx;
   g_live_plans.fetch_sub(1);
   delete p;
@@ -1194,10 +1197,31 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       ex.part_n = pn;
     }
   }
+  auto fill_plain_source = [&](PlainScatterParams& S) {
+    memset(&S, 0, sizeof(S));
+    S.n_rows = (unsigned long long)in.rows;
+    S.n_keys = (uint32_t)st.plain.keys.size(); S.n_fields = (uint32_t)st.plain.fields.size(); S.n_preds = (uint32_t)st.plain.preds.size();
+    for (size_t k = 0; k < st.plain.keys.size(); ++k) {
+      const auto& K = st.plain.keys[k];
+      S.keys[k].data = in.cols[K.col].data; S.keys[k].nulls = K.nullable ? in.cols[K.col].is_null : nullptr;
+      S.keys[k].width = K.width; S.keys[k].shift = K.shift; S.keys[k].bits = K.bits; S.keys[k].nullbit = K.nullbit;
+    }
+    for (size_t f = 0; f < st.plain.fields.size(); ++f) {
+      const auto& F = st.plain.fields[f];
+      S.fields[f].src = F.is_null_mask ? (const void*)in.cols[F.col].is_null : in.cols[F.col].data; S.fields[f].width = F.width; S.fields[f].off = F.off;
+    }
+    for (size_t q = 0; q < st.plain.preds.size(); ++q) {
+      const auto& Q = st.plain.preds[q];
+      S.preds[q].data = in.cols[Q.col].data; S.preds[q].nulls = Q.nullable ? in.cols[Q.col].is_null : nullptr;
+      S.preds[q].kind = (uint32_t)Q.kind; S.preds[q].cmp = (uint32_t)Q.cmp; S.preds[q].col_on_left = Q.col_on_left ? 1u : 0u; S.preds[q].bits = Q.bits;
+    }
+  };
   for (int attempt = 0; attempt < 8; ++attempt) {
     const bool slab = ex.part_slab;
+    // plain stages, slab form: no scatter at all -- the aggregation workgroups read the input columns (ssgpu_group_resident_kernel)
+    const bool resident = slab && st.plain.ok && c->part_plain != 0 && c->group_resident != 0;
     const uint32_t NP = slab ? 1u : ex.part_n;
-    ex.last_group_shape = slab ? 2 : 1; if (attempt) ++ex.last_reruns;
+    ex.last_group_shape = resident ? 3 : slab ? 2 : 1; if (attempt) ++ex.last_reruns;
     ex.last_plain_scatter = false;
     uint32_t capacity = NP * C;
     if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
@@ -1210,7 +1234,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     // position, and the staging area where the tile's records are assembled (see VM_PART_RANK)
     Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u;
     Ps.lds_bytes = Ps.part_lds_off + NP * 4u + (uint32_t)Ps.tile_rows * 4u + 16u + (uint32_t)Ps.tile_rows * st.part_rec_bytes;
-    if (Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
+    if (!resident && Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
     ProgramLayout Ls = ex.lay_pscatter; Ls.lds_bytes = Ps.lds_bytes;
     int grid;
     {
@@ -1232,7 +1256,8 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
     if (plain) seg_cap = (uint64_t)((expect * 1.3 + 8.0 * std::sqrt(expect) + 64.0) * (double)ex.part_seg_growth);   // (partitions differ by their group counts, too)
     if (slab) seg_cap = (uint64_t)((Ps.n_tiles + grid - 1) / grid) * (uint64_t)Ps.tile_rows;   // all rows a workgroup can see: never full
-    const uint64_t n_segs = (uint64_t)NP * (uint64_t)grid;
+    if (resident) seg_cap = 1;                                                      // (no records are written)
+    const uint64_t n_segs = resident ? 1ull : (uint64_t)NP * (uint64_t)grid;
     if (n_segs * seg_cap >= 0xFFFFFFFFull) { *fallback = true; return SSGPU_OK; }   // record indices are 32-bit
     HIP_TRY(c, ex.gkeys.ensure(slots * 8));
     HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
@@ -1257,26 +1282,13 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.part_pad = (uint32_t)c->part_scatter_debug;
     Ps.part_overflow = ex.goverflow.as<unsigned int>() + 1;
     Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
-    if (!plain) { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
+    if (!plain && !resident) { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
-    if (plain) {
-      PlainScatterParams S; memset(&S, 0, sizeof(S));
-      S.n_rows = (unsigned long long)in.rows; S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
-      S.n_keys = (uint32_t)st.plain.keys.size(); S.n_fields = (uint32_t)st.plain.fields.size(); S.n_preds = (uint32_t)st.plain.preds.size();
-      for (size_t k = 0; k < st.plain.keys.size(); ++k) {
-        const auto& K = st.plain.keys[k];
-        S.keys[k].data = in.cols[K.col].data; S.keys[k].nulls = K.nullable ? in.cols[K.col].is_null : nullptr;
-        S.keys[k].width = K.width; S.keys[k].shift = K.shift; S.keys[k].bits = K.bits; S.keys[k].nullbit = K.nullbit;
-      }
-      for (size_t f = 0; f < st.plain.fields.size(); ++f) {
-        const auto& F = st.plain.fields[f];
-        S.fields[f].src = F.is_null_mask ? (const void*)in.cols[F.col].is_null : in.cols[F.col].data; S.fields[f].width = F.width; S.fields[f].off = F.off;
-      }
-      for (size_t q = 0; q < st.plain.preds.size(); ++q) {
-        const auto& Q = st.plain.preds[q];
-        S.preds[q].data = in.cols[Q.col].data; S.preds[q].nulls = Q.nullable ? in.cols[Q.col].is_null : nullptr;
-        S.preds[q].kind = (uint32_t)Q.kind; S.preds[q].cmp = (uint32_t)Q.cmp; S.preds[q].col_on_left = Q.col_on_left ? 1u : 0u; S.preds[q].bits = Q.bits;
-      }
+    if (resident) {
+      // nothing to scatter
+    } else if (plain) {
+      PlainScatterParams S; fill_plain_source(S);
+      S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
       S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
       HIP_TRY(c, hipMemsetAsync(ex.part_hist.p, 0, n_segs * 4, c->stream));
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
@@ -1303,7 +1315,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (h) HIP_TRY(c, ssgpu_launch_pipeline_rtc(h, Ps, grid, ex.rtc_pscatter.static_lds != 0, c->stream));
       else HIP_TRY(c, ssgpu_launch_pipeline(Ps, ex.lay_pscatter.K, grid, c->stream));
     }
-    if (!plain) { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
+    if (!plain && !resident) { int rc = print_pc_profile(c, ex, st.part_scatter, Ps.n_instr); if (rc != SSGPU_OK) return rc; }
     PartAggParams A;
     memset(&A, 0, sizeof(A));
     A.recs = ex.part_recs.as<unsigned long long>();
@@ -1326,7 +1338,24 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
                   ((uint64_t)(uint8_t)a.val_width << 32) | ((uint64_t)(uint8_t)(a.null_off < 0 ? 0xFF : a.null_off) << 40) | ((uint64_t)(a.has_cnt ? 1 : 0) << 48);
     }
     const uint32_t agg_lds = fixed + C * entry;
-    if (p->specialize && !A.debug && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds)) {
+    if (resident) {
+      PlainScatterParams S; fill_plain_source(S);
+      S.rec_words = W;
+      A.slab_segs = 1; A.n_segs = 0;
+      // one whole-LDS workgroup per CU; tiles of 2048 rows dealt round-robin
+      const int rgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
+      A.n_parts = (unsigned int)rgrid;
+      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds)) {
+        if (ex.rtc_resident.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_resident.drop(); }
+        ex.rtc_resident.tried = true; ex.rtc_resident.static_lds = agg_lds;
+        std::string why;
+        ex.rtc_resident.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, &S);
+        if (!ex.rtc_resident.h && ex.rtc_why.empty()) ex.rtc_why = "resident group aggregation: " + why;
+      }
+      if (p->specialize && ex.rtc_resident.h && ex.rtc_resident.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_resident.h, A, S, rgrid, c->stream));
+      else HIP_TRY(c, ssgpu_launch_group_resident(A, S, agg_lds, rgrid, c->stream));
+    } else
+    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds)) {
       // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
       if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
       ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds;
@@ -1334,7 +1363,8 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why);
       if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
-    if (p->specialize && ex.rtc_part.h && ex.rtc_part.static_lds == agg_lds && !A.debug) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_part.h, A, c->stream));
+    if (resident) { /* launched above */ }
+    else if (p->specialize && ex.rtc_part.h && ex.rtc_part.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_part.h, A, c->stream));
     else HIP_TRY(c, ssgpu_launch_part_agg(A, agg_lds, c->stream));
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     p->counters.n_launches += 6;
@@ -1966,7 +1996,7 @@ int fix_nan_minmax(ssgpu_plan* p) {
   Status s = lower_plan(p->desc, &stages, &schema, &describe);
   if (!s.ok()) { p->desc.nan_exact = false; return SSGPU_OK; }   // (a shape the exact form cannot take keeps the order-independent answer)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); }
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); }
   p->exec.clear();
   p->stages = stages; p->describe = describe;
   p->exec.resize(p->stages.size());
@@ -2084,7 +2114,7 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
 int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
   if (!p) return 0;
   int32_t n = 0;
-  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_plain.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0);
+  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_plain.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0) + (ex.rtc_resident.h ? 1 : 0);
   return n;
 }
 const char* ssgpu_plan_specialize_reason(const ssgpu_plan* p) {
@@ -2119,7 +2149,7 @@ int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* 
   out->group_shape = ex.last_group_shape; out->part_n = (int32_t)ex.part_n; out->part_seg_growth = (int32_t)ex.part_seg_growth;
   out->group_wgs_per_cu = ex.group_wgs; out->reruns = ex.last_reruns;
   out->sort_passes = ex.last_sort_passes; out->sort_mode = ex.last_sort_mode;
-  out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0) + (ex.rtc_plain.h ? 8 : 0);
+  out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0) + (ex.rtc_plain.h ? 8 : 0) + (ex.rtc_resident.h ? 16 : 0);
   out->plain_scatter = ex.last_plain_scatter ? 1 : 0;
   return SSGPU_OK;
 }

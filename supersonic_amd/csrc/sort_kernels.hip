@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256) void ssgpu_sort_scan_hist8_kernel(const u32* _
 
 #define ONESWEEP_AGG (1ull << 62)
 #define ONESWEEP_PREFIX (2ull << 62)
-template <bool HAS_IDX, int THREADS>
+#ifndef SSGPU_ONESWEEP_LOOKBACK
+#define SSGPU_ONESWEEP_LOOKBACK 4
+#endif
+template <bool HAS_IDX, int THREADS, int LB = SSGPU_ONESWEEP_LOOKBACK>
 __global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
     const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
     u32 shift, u64 n, const u32* __restrict__ digit_base, unsigned long long* __restrict__ status, u32* __restrict__ ticket,
@@ -302,18 +305,32 @@ __global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
     const u64 tag = (epoch & 0x3FFFFFFFull) << 32;
     unsigned long long* const mine = status + (u64)tile * 256 + t;
     __hip_atomic_store(mine, ONESWEEP_AGG | tag | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // LB predecessors per round trip: the walk is a chain of dependent agent-scope loads (the next address depends on
+    // whether this word already is a prefix), so its length in round trips, not its loads, is what a tile waits for
     for (u32 j = tile; j > 0;) {
-      --j;
-      const unsigned long long* const p = status + (u64)j * 256 + t;
-      u64 v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      u32 spins = 0;
-      while ((v >> 62) == 0 || (v & (0x3FFFFFFFull << 32)) != tag) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) { atomicExch(stuck, 1u); break; }      // never expected: give up rather than hang the device
-        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 nb = j < (u32)LB ? j : (u32)LB;
+      u64 v[LB];
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+        v[b] = (u32)b < nb ? __hip_atomic_load(status + (u64)(j - 1 - b) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      bool done = false;
+#pragma unroll
+      for (int b = 0; b < LB; ++b) {
+        if ((u32)b < nb && !done) {
+          const unsigned long long* const p = status + (u64)(j - 1 - b) * 256 + t;
+          u64 x = v[b];
+          u32 spins = 0;
+          while ((x >> 62) == 0 || (x & (0x3FFFFFFFull << 32)) != tag) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) { atomicExch(stuck, 1u); break; }      // never expected: give up rather than hang the device
+            x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          prefix += (u32)x;
+          done = (x >> 62) == 2;
+        }
       }
-      prefix += (u32)v;
-      if ((v >> 62) == 2) break;
+      if (done) break;
+      j -= nb;
     }
     __hip_atomic_store(mine, ONESWEEP_PREFIX | tag | (u64)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     scanbuf[t] = tot;
@@ -432,23 +449,32 @@ __device__ __forceinline__ void sort_fix_run_compact(u64* __restrict__ kc, const
     kc[i + b] = k;
   }
 }
+// A run costs its thread a chain of dependent random reads (the low halves live in the key array, by row id); with one
+// run per ~100 rows nearly every wave of a thread-per-4-rows kernel holds one and waits for it (0.6 ms for a 0.8 GB read).
+// Here a workgroup streams SORT_TIE_WG_ROWS rows (high halves through LDS, coalesced), lists the runs that START among
+// them, and then fixes them with as many lanes as there are runs: one latency chain per 2048 rows instead of per 256.
+#define SORT_TIE_WG_ROWS 2048
 __global__ __launch_bounds__(256) void ssgpu_sort_fix_ties_compact_kernel(u64* __restrict__ kc, const u64* __restrict__ keys, u64 n, u32* __restrict__ too_long) {
-  const u64 base = ((u64)blockIdx.x * 256 + threadIdx.x) * SORT_TIE_ROWS;
-  if (base >= n) return;
-  u32 h[SORT_TIE_ROWS + 2];
-  bool have[SORT_TIE_ROWS + 2];
-#pragma unroll
-  for (int j = 0; j < SORT_TIE_ROWS + 2; ++j) {
-    const u64 r = base + (u64)j - 1;
-    have[j] = !(j == 0 && base == 0) && r < n;
-    h[j] = have[j] ? (u32)(kc[r] >> 32) : 0u;
+  __shared__ u32 hs[SORT_TIE_WG_ROWS + 2];          // high halves of rows base - 1 .. base + SORT_TIE_WG_ROWS
+  __shared__ u32 runs[SORT_TIE_WG_ROWS / 2 + 1];    // a run holds at least two rows
+  __shared__ u32 n_runs;
+  const u64 base = (u64)blockIdx.x * SORT_TIE_WG_ROWS;
+  const u32 t = threadIdx.x;
+  if (t == 0) n_runs = 0;
+  for (u32 e = t; e < SORT_TIE_WG_ROWS + 2; e += 256) {
+    const u64 r = base + e;                          // row r - 1
+    hs[e] = (r >= 1 && r - 1 < n) ? (u32)(kc[r - 1] >> 32) : 0u;
   }
-#pragma unroll
-  for (int j = 1; j <= SORT_TIE_ROWS; ++j) {
-    if (!have[j]) break;
-    const bool prev_same = have[j - 1] && h[j - 1] == h[j], next_same = have[j + 1] && h[j + 1] == h[j];
-    if (!prev_same && next_same) sort_fix_run_compact(kc, keys, n, too_long, base + (u64)j - 1);
+  __syncthreads();
+  for (u32 e = t; e < SORT_TIE_WG_ROWS; e += 256) {
+    const u64 r = base + e;
+    if (r + 1 >= n) break;
+    const bool prev_same = r > 0 && hs[e] == hs[e + 1], next_same = hs[e + 2] == hs[e + 1];
+    if (!prev_same && next_same) runs[atomicAdd(&n_runs, 1u)] = e;       // the first row of a run of two or more
   }
+  __syncthreads();
+  const u32 nr = n_runs;
+  for (u32 q = t; q < nr; q += 256) sort_fix_run_compact(kc, keys, n, too_long, base + runs[q]);
 }
 __global__ __launch_bounds__(256) void ssgpu_sort_extract_idx_kernel(u32* __restrict__ idx, const u64* __restrict__ kc, u64 n) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -714,8 +740,11 @@ hipError_t ssgpu_launch_sort_onesweep(const uint64_t* keys_in, const uint32_t* i
   const uint32_t nt = ssgpu_onesweep_tiles(n);
   if (nt && idx_in) hipLaunchKernelGGL((ssgpu_sort_onesweep_kernel<true, SSGPU_ONESWEEP_THREADS>), dim3(nt), dim3(SSGPU_ONESWEEP_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
                                        shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);
-  else if (nt) hipLaunchKernelGGL((ssgpu_sort_onesweep_kernel<false, SSGPU_ONESWEEP_THREADS>), dim3(nt), dim3(SSGPU_ONESWEEP_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out,
-                                  shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck);   // (1024-thread tiles for the keys-only form measured the same)
+  else if (nt) {
+    static const int lb = getenv("SSGPU_SORT_LB") ? atoi(getenv("SSGPU_SORT_LB")) : SSGPU_ONESWEEP_LOOKBACK;   // EXPERIMENT
+#define LBCASE(N) case N: hipLaunchKernelGGL((ssgpu_sort_onesweep_kernel<false, SSGPU_ONESWEEP_THREADS, N>), dim3(nt), dim3(SSGPU_ONESWEEP_THREADS), 0, s, (const u64*)keys_in, idx_in, (u64*)keys_out, idx_out, shift, (u64)n, digit_base, status, ticket, (u64)epoch, stuck); break;
+    switch (lb) { LBCASE(1) LBCASE(2) LBCASE(8) LBCASE(16) default: LBCASE(4) }
+  }
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_fix_ties(uint64_t* keys, uint32_t* idx, uint64_t n, uint32_t hi_shift, uint32_t* too_long, hipStream_t s) {
@@ -732,7 +761,7 @@ hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* 
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_compact_kernel, dim3(blocks_for(n, 256 * SORT_TIE_ROWS)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n, too_long);
+  if (n) hipLaunchKernelGGL(ssgpu_sort_fix_ties_compact_kernel, dim3(blocks_for(n, SORT_TIE_WG_ROWS)), dim3(256), 0, s, (u64*)kc, (const u64*)keys, (u64)n, too_long);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s) {

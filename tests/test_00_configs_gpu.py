@@ -152,6 +152,9 @@ def test_config3_shape_with_few_groups_takes_the_slab_form():
     _s, want = oracle.run(op)
     plan = ss.Plan(op, make_ctx(specialize=1))
     infos = check_plan(plan, want, "config #3 shape, 1000 groups", ignore_order=True, runs=4)
+    assert infos[-1][0]["group_shape"] in (0, 3), infos                    # a plain stage: no scatter, the input columns are read in place
+    plan = ss.Plan(op, make_ctx(specialize=1, group_resident=0))
+    infos = check_plan(plan, want, "config #3 shape, 1000 groups, records through memory", ignore_order=True, runs=4)
     assert infos[-1][0]["group_shape"] in (0, 2), infos
 
 

@@ -115,6 +115,57 @@ def test_group_aggregate_100m_config3_checksums(block):
             assert int(cols[14][at].item()) == int(rows.sum().item())
 
 
+@pytest.mark.parametrize("with_filter", [False, True], ids=["config3", "config4_filter"])
+@pytest.mark.parametrize("keys", ["uniform", "skewed"])
+def test_group_aggregate_100m_random_keys_every_group_against_torch(block, keys, with_filter):
+    """Configs #3 / #4 at full size with keys in RANDOM row order (the hash-partitioned shape: the scatter, its segments and
+    the per-partition tables all work here, unlike the row-id keys above) and, for "skewed", half of the rows in 17 of the
+    1e5 groups (one group alone holds 30 %): segment overflow and the regrow / rerun path at 100 M rows.  Every group of
+    the result is compared with torch's scatter reductions over the same columns (all DOUBLE values are small multiples
+    of 0.25: the sums are exact in any order)."""
+    torch, device, ctx, _cols, _view = block
+    a, k1, k2, d0, d1, d2, d3 = bench.gen_group_columns(torch, ROWS, 77, device)
+    if keys == "skewed":
+        g = torch.Generator(device=device)
+        g.manual_seed(5)
+        u = torch.rand(ROWS, generator=g, device=device)
+        grp = k1.to(torch.int64) * 317 + k2
+        grp = torch.where(u < 0.3, torch.full_like(grp, 7), torch.where(u < 0.5, grp % 16, grp))
+        k1, k2 = (grp // 317).to(torch.int32), (grp % 317).to(torch.int32)
+        del u, grp
+    view = ss.DeviceView(bench.group_schema(ss), [(t.data_ptr(), 0) for t in (a, k1, k2, d0, d1, d2, d3)], ROWS)
+    spec = bench.group_spec(ss).AddAggregation(ss.COUNT, "", "cnt")
+    child = ss.ScanView(view)
+    if with_filter:
+        child = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(bench.K_FILTER)), ss.ProjectAllAttributes(), child)
+    plan = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, None, child), ctx)
+    # the same table from torch
+    keep = (a > bench.K_FILTER) if with_filter else torch.ones(ROWS, dtype=torch.bool, device=device)
+    gid = (k1.to(torch.int64) * 317 + k2)[keep]
+    want_cnt = torch.bincount(gid, minlength=bench.N_GROUPS)
+    want = []
+    for src in (d0, d1, d2, d3):
+        v = src[keep]
+        want.append((torch.zeros(bench.N_GROUPS, dtype=torch.float64, device=device).index_add_(0, gid, v),
+                     torch.full((bench.N_GROUPS,), float("inf"), dtype=torch.float64, device=device).scatter_reduce_(0, gid, v, "amin"),
+                     torch.full((bench.N_GROUPS,), float("-inf"), dtype=torch.float64, device=device).scatter_reduce_(0, gid, v, "amax")))
+        del v
+    present = want_cnt > 0
+    for _ in range(3):                  # the execution shape adapts to run feedback: check every shape it passes through
+        plan.run(view)
+        ctx.synchronize()
+        cols, n = device_columns(torch, device, plan, ["<i4", "<i4"] + ["<f8"] * 12 + ["<u8"])
+        assert n == int(present.sum().item())
+        key = cols[0].to(torch.int64) * 317 + cols[1].to(torch.int64)
+        order = torch.argsort(key)
+        assert torch.equal(key[order], present.nonzero().flatten())                            # every group exactly once
+        assert torch.equal(cols[14].to(torch.int64)[order], want_cnt[present])
+        for j in range(4):
+            for t in range(3):
+                assert torch.equal(cols[2 + 3 * j + t][order], want[j][t][present]), (j, t)
+    assert any(st["group_shape"] in (1, 2) for st in plan.stage_info())                       # partitioned or slab: not the direct table
+
+
 def test_sort_100m_config5_sortedness_checksum_idempotence(block):
     torch, device, ctx, (a, b, c, d, d0, d1, d2, d3), view = block
     op = ss.Sort(ss.SortOrder().add("d", ss.ASCENDING), ss.ProjectNamedAttributes(["d", "c"]), 0, ss.ScanView(view))

@@ -1296,7 +1296,7 @@ def test_specialized_partition_aggregation_kernel(n, slab):
     # the partitioned GroupAggregate's aggregation kernel compiled for the stage's aggregates (rtc.cpp:
     # ssgpu_rtc_specialize_part_agg; static LDS of 80 KiB for hash partitions, 159 KiB for the slab form)
     ctx = ss.Context(0)
-    for k, v in (("specialize", 1), ("group_partition", 2), ("group_slab", slab)):
+    for k, v in (("specialize", 1), ("group_partition", 2), ("group_slab", slab), ("group_resident", 0)):   # (records through memory: the kernels named above)
         ctx.set_option(k, v)
     for nullable, keys in ((False, ("k1", "k2")), (True, ("k1",))):
         op = group_query(make_view(n, nullable=nullable), True, keys)
@@ -1306,6 +1306,22 @@ def test_specialized_partition_aggregation_kernel(n, slab):
         assert plan.specialized() >= 2, plan.specialize_reason()      # the scatter program and the aggregation kernel
     fl = ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), None, ss.ScanView(make_view(n, nullable=True)))
     run_both(fl, ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("n", [1025, 100003])
+def test_specialized_resident_group_aggregation_kernel(n):
+    # the resident form compiled for the stage: the row source's key packing, field list and predicates and the aggregates'
+    # descriptors are all constants of the build (rtc.cpp: ssgpu_rtc_specialize_part_agg with a source)
+    ctx = ss.Context(0)
+    for k, v in (("specialize", 1), ("group_partition", 2), ("group_slab", 2)):
+        ctx.set_option(k, v)
+    for nullable, keys, with_filter in ((False, ("k1", "k2"), True), (True, ("k1",), False), (True, ("k1",), True)):
+        op = group_query(make_view(n, nullable=nullable), with_filter, keys)
+        run_both(op, ctx, ignore_order=True)
+        plan = ss.Plan(op, ctx)
+        plan.run()
+        info = plan.stage_info()[-1]
+        assert info["group_shape"] == 3 and info["specialized"] & 16, (info, plan.specialize_reason())
 
 
 def test_specialized_group_stage_beyond_64k_of_lds(specialized_ctx):
@@ -1346,15 +1362,24 @@ def test_specialized_kernels_are_cached_and_report_errors(specialized_ctx):
 
 # ---- slab mode of the partitioned GroupAggregate: few enough groups for ONE whole-LDS table per aggregation workgroup;
 # ---- no hash partitions, the scatter writes records sequentially, tables are merged into the global one ------------------
+# ---- plain stages (keys and aggregated values are input columns, predicates compare a column with a constant) take it
+# ---- without any scatter: the aggregation workgroups read the input columns themselves (group_shape 3, "resident")
+@pytest.mark.parametrize("resident", [1, 0])
 @pytest.mark.parametrize("n", [0, 1, 65, 1025, 100003])
 @pytest.mark.parametrize("with_filter", [False, True])
 @pytest.mark.parametrize("nullable", [False, True])
-def test_group_aggregate_slab_mode(n, with_filter, nullable):
+def test_group_aggregate_slab_mode(n, with_filter, nullable, resident):
     ctx = ss.Context(0)
     ctx.set_option("group_partition", 2)
     ctx.set_option("group_slab", 2)
+    ctx.set_option("group_resident", resident)
     keys = ("k1",) if nullable else ("k1", "k2")
-    run_both(group_query(make_view(n, nullable=nullable), with_filter, keys), ctx, ignore_order=True)
+    op = group_query(make_view(n, nullable=nullable), with_filter, keys)
+    run_both(op, ctx, ignore_order=True)
+    if n:
+        plan = ss.Plan(op, ctx)
+        plan.run()
+        assert plan.stage_info()[-1]["group_shape"] == (3 if resident else 2), plan.stage_info()
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), first_last_spec(), None, ss.ScanView(make_view(n, nullable=True))), ctx, ignore_order=True)
 
 
