@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
 #endif
 /* PART_ROWS: records per lane per step -- a constant of part_agg_body (2; the resident form, at one workgroup per CU, takes RESIDENT_ROWS) */
 #ifndef SSGPU_RESIDENT_ROWS
-#define SSGPU_RESIDENT_ROWS 4
+#define SSGPU_RESIDENT_ROWS 2   /* (4 and 8 measured the same: the kernel is bound by instruction issue, ~350 VALU instructions per row) */
 #endif
 #define LDS_AS __attribute__((address_space(3)))
 template <int MAXW> struct RecVec { typedef u64 type __attribute__((ext_vector_type(MAXW))); };
@@ -1220,11 +1220,16 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   // (records: [0, total) of this workgroup's segments.  PLAIN: the rows of the input, tiles dealt round-robin to the workgroups)
   u64 row_first = 0, row_limit = total, row_stride = SSGPU_PART_THREADS * PART_ROWS;
   if constexpr (PLAIN) { row_first = (u64)part * (SSGPU_PART_THREADS * PART_ROWS); row_limit = S.n_rows; row_stride = (u64)gridDim.x * (SSGPU_PART_THREADS * PART_ROWS); }
+  u64 trip_limit = row_limit;
 #ifdef SSGPU_RTC_PART_PLAIN
-  ResidentRaw<PART_ROWS> raw;
-  if constexpr (PLAIN) resident_issue<PART_ROWS>(S, row_first < row_limit ? row_first : 0ull, row_limit, t, raw);
+  // Trip k issues the loads of tile k and aggregates tile k - 1 (one more trip than tiles; the first aggregates nothing).
+  // There is deliberately no load ahead of the loop: loads pending on entry made the compiler wait, in every trip, for
+  // the first of the loads just issued (its wait-count bookkeeping merges the entry edge with the back edge) -- the
+  // pipeline then runs but hides nothing.
+  ResidentRaw<PART_ROWS> raw = {};
+  if constexpr (PLAIN) trip_limit = row_limit + row_stride;
 #endif
-  for (u64 base = row_first; base < row_limit; base += row_stride) {
+  for (u64 base = row_first; base < trip_limit; base += row_stride) {
     Rec rec[PART_ROWS]; bool live[PART_ROWS]; u32 li[PART_ROWS];
     if constexpr (PLAIN) {
 #ifdef SSGPU_RTC_PART_PLAIN
@@ -1247,9 +1252,12 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
 #pragma unroll
         for (u32 f = 0; f < kRsNFields; ++f) rec[j][(kRsFieldOff[f] >> 3) < (u32)MAXW ? (kRsFieldOff[f] >> 3) : 0u] |= raw.f[j][f] << ((kRsFieldOff[f] & 7u) * 8u);
       }
-      {   // next step's loads: in flight during this step's LDS work (past the end: the clamped row 0, discarded)
-        const u64 nb = base + row_stride;
+      {   // this tile's loads: in flight during the LDS work on the tile before it (past the end: the clamped row 0, discarded)
+        const u64 nb = base;
         resident_issue<PART_ROWS>(S, nb < row_limit ? nb : 0ull, nb < row_limit ? row_limit : 0ull, t, raw);
+        // the loads stay HERE: left alone, the compiler sinks them to their first use -- the top of the next trip -- and
+        // the pipeline is gone (seen in the ISA: 24 loads, then s_waitcnt vmcnt(22) straight away)
+        asm volatile("" ::: "memory");
       }
 #else
 #pragma unroll

