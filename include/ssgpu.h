@@ -315,7 +315,8 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *   GroupAggregate:         group_capacity (initial table), group_local (0 = no LDS table in front of the global one),
  *                           group_partition (0 never / 1 by run feedback / 2 always hash-partitioned), group_slab (0 never /
  *                           1 by estimate / 2 always the one-table-per-CU form), group_resident (0 = the one-table-per-CU form always
- *                           through scatter + aggregation, never straight from the input columns), part_plain (0 = the partition scatter always as
+ *                           through scatter + aggregation, never straight from the input columns), group_scout (0 = no scout run --
+ *                           the direct shape over a 1/64 prefix, result discarded -- ahead of a plan's first run over >= 8 M rows), part_plain (0 = the partition scatter always as
  *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
  *                           part_rec_align
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),

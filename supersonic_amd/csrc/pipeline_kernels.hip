@@ -1045,6 +1045,16 @@ __device__ __forceinline__ void lds_dd_add(LDS_AS double* acc, double v) {
   case VM_##OPNAME: {                                                                 \
     _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) if (ok[j]) { LDS_AS u64* A = lacc + li[j] + word; const u64 raw = val[j]; EXPR; } \
   } break;
+#define PART_APPLY_FLOAT(OPNAME, EDECL, LDSOP, NEUTRAL)                               \
+  case VM_##OPNAME: {                                                                 \
+    _Pragma("unroll") for (int j = 0; j < PART_ROWS; ++j) {                           \
+      const u64 raw = val[j]; EDECL;                                                  \
+      const bool isnan = !(e == e);                                                    \
+      const u64 k = isnan ? (u64)(NEUTRAL) : FKEY(e);                                  \
+      nan_acc |= (isnan && ok[j]) ? 1u : 0u;                                           \
+      if (ok[j]) { LDS_AS u64* A = lacc + li[j] + word; LDSOP(A, k); }                \
+    }                                                                                 \
+  } break;
 // exclusive scan of one value per thread over the workgroup (1024 threads); *total gets the sum
 __device__ __forceinline__ u32 part_block_scan(u32 v, LDS_AS u32* wsum, u32 t, u32* total) {
   const u32 lane = t & 63u, wave = t >> 6;
@@ -1221,6 +1231,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   u64 row_first = 0, row_limit = total, row_stride = SSGPU_PART_THREADS * PART_ROWS;
   if constexpr (PLAIN) { row_first = (u64)part * (SSGPU_PART_THREADS * PART_ROWS); row_limit = S.n_rows; row_stride = (u64)gridDim.x * (SSGPU_PART_THREADS * PART_ROWS); }
   u64 trip_limit = row_limit;
+  u32 nan_acc = 0;                 // this lane met a NaN in a floating MIN / MAX
 #ifdef SSGPU_RTC_PART_PLAIN
   // Trip k issues the loads of tile k and aggregates tile k - 1 (one more trip than tiles; the first aggregates nothing).
   // There is deliberately no load ahead of the loop: loads pending on entry made the compiler wait, in every trip, for
@@ -1388,14 +1399,18 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         PART_APPLY(GAGG_MAX_I64, LDS_MAX(A, key_i64((i64)raw)))
         PART_APPLY(GAGG_MAX_U64, LDS_MAX(A, raw))
         PART_APPLY(GAGG_MAX_B8, LDS_MAX(A, (u64)((raw & 0xFFull) != 0)))
-        PART_APPLY(GAGG_MIN_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MIN(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
-        PART_APPLY(GAGG_MIN_F64, { const double e = u2d(raw); if (e == e) LDS_MIN(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
-        PART_APPLY(GAGG_MAX_F32, { const float e = __uint_as_float((u32)raw); if (e == e) LDS_MAX(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
-        PART_APPLY(GAGG_MAX_F64, { const double e = u2d(raw); if (e == e) LDS_MAX(A, FKEY(e)); else if (P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX); })
+        // floating MIN / MAX: a NaN becomes the operation's neutral key and is remembered in a register (the stage's flag is
+        // raised once, after the loop) -- no branch per value; the key of a value is computed outside the `ok` region, so
+        // the MIN and the MAX of one column share it
+        PART_APPLY_FLOAT(GAGG_MIN_F32, const float e = __uint_as_float((u32)raw), LDS_MIN, ~0ull)
+        PART_APPLY_FLOAT(GAGG_MIN_F64, const double e = u2d(raw), LDS_MIN, ~0ull)
+        PART_APPLY_FLOAT(GAGG_MAX_F32, const float e = __uint_as_float((u32)raw), LDS_MAX, 0ull)
+        PART_APPLY_FLOAT(GAGG_MAX_F64, const double e = u2d(raw), LDS_MAX, 0ull)
         default: break;
       }
     }
   }
+  if (nan_acc && P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX);
   __syncthreads();
   if (P.slab_segs) {
     // slab mode: every workgroup saw (a slab of) all groups: merge the occupied entries into the global table, one

@@ -143,17 +143,34 @@ def test_group_aggregate_100m_random_keys_every_group_against_torch(block, keys,
     keep = (a > bench.K_FILTER) if with_filter else torch.ones(ROWS, dtype=torch.bool, device=device)
     gid = (k1.to(torch.int64) * 317 + k2)[keep]
     want_cnt = torch.bincount(gid, minlength=bench.N_GROUPS)
+    # (torch's scatter amin / amax -- and its DOUBLE index_add_ -- are compare-and-swap loops: with 30 % of the rows on ONE
+    #  element they take minutes.  The 17 hot groups of the skewed set are reduced with masks instead; the scatters see the
+    #  other rows only.)
+    hot = 17 if keys == "skewed" else 0
+    cold = gid >= hot
+    gid_cold = gid[cold]
     want = []
     for src in (d0, d1, d2, d3):
-        v = src[keep]
-        want.append((torch.zeros(bench.N_GROUPS, dtype=torch.float64, device=device).index_add_(0, gid, v),
-                     torch.full((bench.N_GROUPS,), float("inf"), dtype=torch.float64, device=device).scatter_reduce_(0, gid, v, "amin"),
-                     torch.full((bench.N_GROUPS,), float("-inf"), dtype=torch.float64, device=device).scatter_reduce_(0, gid, v, "amax")))
+        v = src[keep][cold]
+        want.append([torch.zeros(bench.N_GROUPS, dtype=torch.float64, device=device).index_add_(0, gid_cold, v),
+                     torch.full((bench.N_GROUPS,), float("inf"), dtype=torch.float64, device=device).scatter_reduce_(0, gid_cold, v, "amin"),
+                     torch.full((bench.N_GROUPS,), float("-inf"), dtype=torch.float64, device=device).scatter_reduce_(0, gid_cold, v, "amax")])
         del v
+    for g in range(hot):
+        rows_of_g = gid == g
+        if bool(rows_of_g.any().item()):
+            for j, src in enumerate((d0, d1, d2, d3)):
+                v = src[keep][rows_of_g]
+                want[j][0][g], want[j][1][g], want[j][2][g] = v.sum(), v.min(), v.max()
+                del v
+        del rows_of_g
+    del cold, gid_cold
     present = want_cnt > 0
+    shapes = []
     for _ in range(3):                  # the execution shape adapts to run feedback: check every shape it passes through
         plan.run(view)
         ctx.synchronize()
+        shapes.append([st["group_shape"] for st in plan.stage_info() if st["kind"] == 3][-1])
         cols, n = device_columns(torch, device, plan, ["<i4", "<i4"] + ["<f8"] * 12 + ["<u8"])
         assert n == int(present.sum().item())
         key = cols[0].to(torch.int64) * 317 + cols[1].to(torch.int64)
@@ -163,7 +180,10 @@ def test_group_aggregate_100m_random_keys_every_group_against_torch(block, keys,
         for j in range(4):
             for t in range(3):
                 assert torch.equal(cols[2 + 3 * j + t][order], want[j][t][present]), (j, t)
-    assert any(st["group_shape"] in (1, 2) for st in plan.stage_info())                       # partitioned or slab: not the direct table
+    # the scout run (a 1/64 prefix, direct shape, result discarded) sends already the FIRST run to the hash partitions:
+    # a cursor that is drained once never meets the 50 ms direct-shape run over 1e5 groups
+    if keys == "uniform":
+        assert shapes[0] == 1 and shapes[-1] == 1, shapes
 
 
 def test_sort_100m_config5_sortedness_checksum_idempotence(block):
