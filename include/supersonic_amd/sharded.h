@@ -11,6 +11,13 @@
 //   -> images laid out as contiguous columns + a validity flag  ssgpu_images_unpack
 //   -> merge GroupAggregate (SUM of sums, MIN of mins, ...)     an ordinary cursor over ScanDeviceView
 //
+// or, with Exchange KEY_RANGE (the form that scales: every rank merges 1 / world of the key space and ends with the groups
+// it owns, each link carries 1 / world of a table instead of all of it):
+//
+//   -> its partial table routed into `world` images by key      ssgpu_result_route_images
+//   -> ONE all-to-all of the images (grouped ncclSend / ncclRecv: image d goes to rank d)
+//   -> unpack + merge as above, over the rows this rank owns
+//
 // Everything between the two plan runs is stream-ordered on ONE stream (the context's): no device value is read on the
 // host in between.  `supersonic_amd/distributed.py: DeviceShardedGroupAggregate` is the same protocol over
 // torch.distributed; this header is for hosts that link RCCL themselves.  Like the reference's cursors, the mirror's
@@ -33,12 +40,15 @@ namespace supersonic {
 
 class ShardedGroupAggregate {
  public:
+  enum Exchange { ALL_GATHER, KEY_RANGE };
   // comm / world: the job's RCCL communicator and its size.  group_by: key attribute names.  spec and local_child
   // (this rank's shard: e.g. Filter(..., ScanView(shard))) are owned.  capacity_rows: rows an image holds -- at least
   // the largest partial table of any rank (a table that does not fit is reported by Run(), nothing is truncated silently).
+  // With KEY_RANGE an image holds the rows ONE destination receives from ONE source (about 1.3 / world of a partial table,
+  // the hash's spread included) and the result of Run() is this rank's share of the groups.
   ShardedGroupAggregate(ncclComm_t comm, int world, const std::vector<std::string>& group_by, AggregationSpecification* spec,
-                        Operation* local_child, rowcount_t capacity_rows)
-      : comm_(comm), world_(world), group_by_(group_by), capacity_(capacity_rows) {
+                        Operation* local_child, rowcount_t capacity_rows, Exchange exchange = ALL_GATHER)
+      : comm_(comm), world_(world), group_by_(group_by), capacity_(capacity_rows), exchange_(exchange) {
     // the merge functions of the aggregates (cf. distributed.py: _merge_spec)
     std::unique_ptr<AggregationSpecification> merged(new AggregationSpecification);
     for (auto& e : spec->elements) {
@@ -69,16 +79,28 @@ class ShardedGroupAggregate {
     if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
     if (image_bytes != image_bytes_ || unpacked_bytes != unpacked_bytes_) {
       Free();
-      if (hipMalloc(&image_, static_cast<size_t>(image_bytes)) != hipSuccess || hipMalloc(&images_, static_cast<size_t>(image_bytes) * world_) != hipSuccess ||
+      const size_t send_images = exchange_ == KEY_RANGE ? static_cast<size_t>(world_) : 1;     // key range: one image per destination
+      if (hipMalloc(&image_, static_cast<size_t>(image_bytes) * send_images) != hipSuccess || hipMalloc(&images_, static_cast<size_t>(image_bytes) * world_) != hipSuccess ||
           hipMalloc(&unpacked_, static_cast<size_t>(unpacked_bytes)) != hipSuccess)
         return Fail(ERROR_MEMORY_EXCEEDED, "cannot allocate the result images");
       image_bytes_ = image_bytes; unpacked_bytes_ = unpacked_bytes;
     }
     hipStream_t stream = static_cast<hipStream_t>(ssgpu_ctx_stream(ctx));   // NULL = the legacy default stream
-    rc = ssgpu_result_pack_image(shard->result_handle(), capacity_, image_);
-    if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-    if (ncclAllGather(image_, images_, static_cast<size_t>(image_bytes), ncclUint8, comm_, stream) != ncclSuccess)   // the ONE collective
-      return Fail(ERROR_UNKNOWN_ERROR, "ncclAllGather failed");
+    if (exchange_ == KEY_RANGE) {
+      rc = ssgpu_result_route_images(shard->result_handle(), static_cast<int32_t>(group_by_.size()), world_, capacity_, image_);
+      if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
+      bool ok = ncclGroupStart() == ncclSuccess;                     // the ONE collective: image d -> rank d
+      for (int r = 0; ok && r < world_; ++r)
+        ok = ncclSend(static_cast<const char*>(image_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess &&
+             ncclRecv(static_cast<char*>(images_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess;
+      ok = (ncclGroupEnd() == ncclSuccess) && ok;
+      if (!ok) return Fail(ERROR_UNKNOWN_ERROR, "the all-to-all of the result images (ncclSend / ncclRecv) failed");
+    } else {
+      rc = ssgpu_result_pack_image(shard->result_handle(), capacity_, image_);
+      if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
+      if (ncclAllGather(image_, images_, static_cast<size_t>(image_bytes), ncclUint8, comm_, stream) != ncclSuccess)   // the ONE collective
+        return Fail(ERROR_UNKNOWN_ERROR, "ncclAllGather failed");
+    }
     gathered_.schema = TupleSchema();
     for (int i = 0; i < n_attrs; ++i) {
       ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
@@ -135,6 +157,7 @@ class ShardedGroupAggregate {
   int world_;
   std::vector<std::string> group_by_, counts_;
   rowcount_t capacity_, largest_table_ = 0;
+  Exchange exchange_ = ALL_GATHER;
   std::string error_;
   std::unique_ptr<Operation> first_, merge_;
   std::unique_ptr<AggregationSpecification> merged_spec_;

@@ -1,5 +1,5 @@
 // A C++ host driving the sharded GroupAggregate (BASELINE config #4) through include/supersonic_amd/sharded.h: RCCL called
-// directly (ncclAllGather of the packed partial tables), no Python, no torch.  Runs with a 1-rank communicator on the
+// directly (ncclAllGather of the packed partial tables, or the key-range all-to-all of routed ones), no Python, no torch.  Runs with a 1-rank communicator on the
 // single-GPU test box -- the protocol (pack -> all-gather -> unpack -> merge) is the N-rank one -- and compares the merged
 // result with the plain single-process GroupAggregate.
 #include <stdio.h>
@@ -93,6 +93,28 @@ int main(int argc, char** argv) {
     const Row& g = it->second; const Row& w = kv.second;
     CHECK(g.sv_null == w.sv_null && (g.sv_null || g.sv == w.sv));
     CHECK(g.mn == w.mn && g.mx == w.mx && g.cv == w.cv && g.n == w.n && g.fd == w.fd);
+  }
+  {  // the key-range exchange: rows routed by key into one image per destination, one all-to-all (here: to itself), merge of the
+     // groups this rank owns -- with one rank, all of them
+    std::map<int32_t, Row> ranged;
+    ShardedGroupAggregate job(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/1024, ShardedGroupAggregate::KEY_RANGE);
+    FailureOrOwned<Cursor> c = job.Run();
+    CHECK(c.is_success());
+    if (c.is_failure()) { printf("key-range run failed: %s\n", c.exception().message().c_str()); return 1; }
+    CHECK(Drain(c.get(), &ranged));
+    CHECK(ranged.size() == want.size());
+    for (auto& kv : want) {
+      auto it = ranged.find(kv.first);
+      CHECK(it != ranged.end());
+      if (it == ranged.end()) continue;
+      const Row& g = it->second; const Row& w = kv.second;
+      CHECK(g.sv_null == w.sv_null && (g.sv_null || g.sv == w.sv));
+      CHECK(g.mn == w.mn && g.mx == w.mx && g.cv == w.cv && g.n == w.n && g.fd == w.fd);
+    }
+    ShardedGroupAggregate small(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/64, ShardedGroupAggregate::KEY_RANGE);
+    FailureOrOwned<Cursor> f = small.Run();
+    CHECK(f.is_failure());
+    if (f.is_failure()) CHECK(f.exception().return_code() == ERROR_MEMORY_EXCEEDED);
   }
   {  // a table that does not fit its image is reported, not truncated
     ShardedGroupAggregate small(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/64);

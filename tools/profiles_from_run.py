@@ -82,10 +82,28 @@ def main():
                  "traffic_bytes_per_launch": total, "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": total / alg if alg else None}
             with open(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q)), "w") as f:
                 json.dump(j, f, indent=1, sort_keys=True)
+        if traffic is None and os.path.exists(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q))):
+            # a collection without counter passes (tools/profile_refresh.sh): the committed counters of this round stand
+            traffic = json.load(open(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q))))["traffic_bytes_per_launch"]
         r = line["roofline"]
         summary.append("| %s | %.3f | %.3f | %.0f | %s | %s |" % (q, r["kernel_ms"], r["frac"], r["algorithmic_bytes_per_row"],
                        "%.2f" % (traffic / (r["algorithmic_bytes_per_row"] * line["config"]["rows_per_gpu"])) if traffic else "-",
                        "%.3f" % interp["roofline"]["kernel_ms"] if interp else "-"))
+    gs = os.path.join(SRC, "group_small")
+    if os.path.isdir(gs):
+        ks = os.path.join(gs, "kernel_stats.csv")
+        if os.path.exists(ks):
+            rows = list(csv.reader(open(ks)))
+            with open(os.path.join(DST, "%s_group_small_kernel_stats.csv" % ROUND), "w", newline="") as f:
+                csv.writer(f).writerows([rows[0]] + [r for r in rows[1:] if "ssgpu" in r[0]])
+        summary += ["", "GroupAggregate(a; SUM / MIN / MAX x d0..d3), 1000 groups, 100 M rows (`tools/perf_sweep.py --queries group_small`, 40 B/row):", ""]
+        for name, label in (("sweep_specialize1.txt", "resident form, specialised"), ("sweep_specialize0.txt", "resident form, generic kernel"),
+                            ("sweep_records_through_memory.txt", "slab form (group_resident=0), specialised")):
+            fp = os.path.join(gs, name)
+            if os.path.exists(fp):
+                for ln in open(fp).read().splitlines():
+                    if ln.startswith("group_small"):
+                        summary.append("* %s: `%s`" % (label, " ".join(ln.split())))
     with open(os.path.join(DST, ROUND + "_summary.md"), "w") as f:
         f.write("\n".join(summary) + "\n")
     print("\n".join(summary))
