@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
 DST = os.path.join(ROOT, "profiles")
-ROUND = "r03"
+ROUND = os.environ.get("SSGPU_PROFILE_TAG", "r03")   # r03b: the second collection of round 3 (tools/profile_refresh.sh, another box)
+PMC_ROUND = "r03"
 # the kernels of the timed stage, per query (substrings of rocprof's kernel names)
 STAGE = {"wide": ["ssgpu_pipeline_kernel", "ssgpu_finish_slots", "ssgpu_emit_scalar"],
          "group3": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill"],
@@ -36,7 +37,7 @@ def steady(values, launches_per_step):
 
 
 def main():
-    summary = ["# Round 3 profiles (MI355X, 100 M rows, `tools/profile_round3.sh`)", "",
+    summary = ["# Round 3 profiles (MI355X, 100 M rows, `tools/profile_round3.sh`%s)" % (" -- second collection, `tools/profile_refresh.sh`" if ROUND != "r03" else ""), "",
                "| query | kernel ms (bench line) | frac of 8 TB/s | algorithmic B/row | HBM traffic / algorithmic | interpreted kernel ms |", "|---|---|---|---|---|---|"]
     factors = {}
     cal = os.path.join(SRC, "pmc_calibration.json")
@@ -82,9 +83,9 @@ def main():
                  "traffic_bytes_per_launch": total, "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": total / alg if alg else None}
             with open(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q)), "w") as f:
                 json.dump(j, f, indent=1, sort_keys=True)
-        if traffic is None and os.path.exists(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q))):
+        if traffic is None and os.path.exists(os.path.join(DST, "%s_pmc_%s.json" % (PMC_ROUND, q))):
             # a collection without counter passes (tools/profile_refresh.sh): the committed counters of this round stand
-            traffic = json.load(open(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q))))["traffic_bytes_per_launch"]
+            traffic = json.load(open(os.path.join(DST, "%s_pmc_%s.json" % (PMC_ROUND, q))))["traffic_bytes_per_launch"]
         r = line["roofline"]
         summary.append("| %s | %.3f | %.3f | %.0f | %s | %s |" % (q, r["kernel_ms"], r["frac"], r["algorithmic_bytes_per_row"],
                        "%.2f" % (traffic / (r["algorithmic_bytes_per_row"] * line["config"]["rows_per_gpu"])) if traffic else "-",
