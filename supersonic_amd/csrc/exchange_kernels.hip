@@ -78,26 +78,46 @@ __global__ __launch_bounds__(256) void ssgpu_unpack_images_kernel(const ImageUnp
 // merges only the groups it owns (1 / world of the key space).  The hash is a function of the key BYTES (NULL keys hash
 // as a flag, their value bytes ignored), so every rank routes a key to the same owner.  Rows of one source keep no
 // particular order inside an image (a group occurs once per source table: the merge does not depend on it).
-// Phase 1 (this kernel): destination and position of every row (one returning atomic on n_dest counters);
+// Phase 1 (this kernel): destination and position of every row (one returning atomic per wave and destination on the n_dest counters);
 // phase 2 (ssgpu_route_copy_kernel): the cells, column by column, coalesced reads.
 __device__ __forceinline__ u64 route_mix(u64 h, u64 x) { h ^= x; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; return h * 0xBF58476D1CE4E5B9ull; }
 __global__ __launch_bounds__(256) void ssgpu_route_rows_kernel(const ImagePackParams P, const ImageRoutePieces R, u32* __restrict__ dest_pos) {
   const u64 rows = P.rows_dev ? *P.rows_dev : P.rows_host;
-  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < rows; r += (u64)gridDim.x * 256) {
-    u64 h = 0x243F6A8885A308D3ull;
-    for (u32 k = 0; k < R.n_keys; ++k) {
-      const ImagePiece pc = P.pieces[R.key_piece[k]];
-      const bool is_null = R.key_null_piece[k] >= 0 && P.pieces[R.key_null_piece[k]].src && reinterpret_cast<const u8*>(P.pieces[R.key_null_piece[k]].src)[r] != 0;
-      u64 v = 0;
-      if (!is_null) {
-        const char* c = reinterpret_cast<const char*>(pc.src) + r * pc.width;
-        v = pc.width == 8 ? *reinterpret_cast<const u64*>(c) : pc.width == 4 ? (u64)*reinterpret_cast<const u32*>(c) : (u64)*reinterpret_cast<const u8*>(c);
+  const u32 lane = threadIdx.x & 63u;
+  const u64 lanes_below = (1ull << lane) - 1ull;
+  for (u64 base = (u64)blockIdx.x * 256; base < rows; base += (u64)gridDim.x * 256) {
+    const u64 r = base + threadIdx.x;
+    const bool active = r < rows;
+    u32 d = 0;
+    if (active) {
+      u64 h = 0x243F6A8885A308D3ull;
+      for (u32 k = 0; k < R.n_keys; ++k) {
+        const ImagePiece pc = P.pieces[R.key_piece[k]];
+        const bool is_null = R.key_null_piece[k] >= 0 && P.pieces[R.key_null_piece[k]].src && reinterpret_cast<const u8*>(P.pieces[R.key_null_piece[k]].src)[r] != 0;
+        u64 v = 0;
+        if (!is_null) {
+          const char* c = reinterpret_cast<const char*>(pc.src) + r * pc.width;
+          v = pc.width == 8 ? *reinterpret_cast<const u64*>(c) : pc.width == 4 ? (u64)*reinterpret_cast<const u32*>(c) : (u64)*reinterpret_cast<const u8*>(c);
+        }
+        h = route_mix(h, v + (is_null ? 0x51ull : 0ull)) + k;
       }
-      h = route_mix(h, v + (is_null ? 0x51ull : 0ull)) + k;
+      d = (u32)((h >> 32) % R.n_dest);
     }
-    const u32 d = (u32)((h >> 32) % R.n_dest);
-    const u32 pos = atomicAdd(&R.counters[d], 1u);
-    dest_pos[2 * r] = d; dest_pos[2 * r + 1] = pos;
+    // one atomic per (wave, destination present in it), not one per row: with few destinations every row of the table hits
+    // the same handful of counters (measured on one rank, 1e5 rows on ONE counter: 1.2 ms of a 3.7 ms step)
+    u32 pos = 0;
+    u64 todo = __ballot(active);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const u32 k = (u32)__shfl((int)d, leader);
+      const u64 same = __ballot(active && d == k);
+      u32 first = 0;
+      if ((int)lane == leader) first = atomicAdd(&R.counters[k], (u32)__popcll(same));
+      first = (u32)__shfl((int)first, leader);
+      if (active && d == k) pos = first + (u32)__popcll(same & lanes_below);
+      todo &= ~same;
+    }
+    if (active) { dest_pos[2 * r] = d; dest_pos[2 * r + 1] = pos; }
   }
 }
 // grid = (blocks, pieces): piece p of row r -> image dest[r], row pos[r]; block (0, 0) writes the n_dest headers
