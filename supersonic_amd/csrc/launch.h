@@ -129,6 +129,15 @@ hipError_t ssgpu_launch_join_expand(const unsigned int* offsets, const unsigned 
                                     unsigned long long n_lhs, unsigned long long n_out, unsigned int* lhs_idx, unsigned int* rhs_row, hipStream_t stream);
 hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream);
 hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream);
+// one launch for all a GroupAggregate run clears: keys[n_keys] = EMPTY, acc[i] = pattern[i % ng] (n_acc words), cnt[n_cnt] = 0,
+// z[q][0 .. nz[q]) = 0 (32-bit words; unused: nz = 0)
+struct GroupInitParams {
+  unsigned long long* keys; unsigned long long n_keys;
+  unsigned long long* acc; const unsigned long long* pattern; unsigned int ng; unsigned long long n_acc;
+  unsigned int* cnt; unsigned long long n_cnt;
+  unsigned int* z[3]; unsigned long long nz[3];
+};
+hipError_t ssgpu_launch_group_init(const GroupInitParams& P, hipStream_t stream);
 
 hipError_t ssgpu_launch_pipeline(const VmParams& P, int K, int grid, hipStream_t stream);
 int ssgpu_pipeline_resident_per_cu(const VmParams& P, int K);

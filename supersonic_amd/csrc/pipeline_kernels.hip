@@ -1564,6 +1564,16 @@ __global__ void ssgpu_fill_u64_kernel(u64* __restrict__ p, u64 v, size_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 // acc init: per-slot pattern of n_gaggs identities
+// Everything a GroupAggregate run needs cleared, in ONE launch (keys -> EMPTY, accumulators -> their initial pattern,
+// contribution counts and up to three small word arrays -> 0): these were five or six tiny launches per run, and at the
+// shard sizes of a strong-scaling job (a 0.3 ms scan) the launches, not the kernels, are what a step waits for.
+__global__ __launch_bounds__(256) void ssgpu_group_init_kernel(const GroupInitParams P) {
+  const u64 first = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
+  for (u64 i = first; i < P.n_keys; i += stride) P.keys[i] = VM_KEY_EMPTY;
+  for (u64 i = first; i < P.n_acc; i += stride) P.acc[i] = P.pattern[i % P.ng];
+  for (u64 i = first; i < P.n_cnt; i += stride) P.cnt[i] = 0u;
+  for (int q = 0; q < 3; ++q) for (u64 i = first; i < P.nz[q]; i += stride) P.z[q][i] = 0u;
+}
 __global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __restrict__ pattern, u32 plen, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1848,6 +1858,12 @@ hipError_t ssgpu_launch_group_extract(const GroupExtractParams& P, hipStream_t s
 hipError_t ssgpu_launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t stream) {
   int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ssgpu_fill_u64_kernel, dim3(blocks), dim3(256), 0, stream, (u64*)p, (u64)v, n);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_group_init(const GroupInitParams& P, hipStream_t stream) {
+  const uint64_t n = std::max<uint64_t>(std::max<uint64_t>(P.n_keys, P.n_acc), std::max<uint64_t>(P.n_cnt, std::max<uint64_t>(P.nz[0], std::max<uint64_t>(P.nz[1], P.nz[2]))));
+  int blocks = (int)std::min<uint64_t>((n + 255) / 256, 4096); if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ssgpu_group_init_kernel, dim3(blocks), dim3(256), 0, stream, P);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, uint32_t plen, size_t n, hipStream_t stream) {

@@ -1268,18 +1268,23 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
     if (ex.part_recs.ensure(n_segs * seg_cap * st.part_rec_bytes + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
     HIP_TRY(c, ex.part_hist.ensure(n_segs * 4));
-    if (slab) {   // the aggregation workgroups merge into the table: all of it starts empty
-      HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>(), VM_KEY_EMPTY, slots, c->stream));
-      HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>(), ex.gpattern.as<uint64_t>(), ng, slots * ng, c->stream));
-      HIP_TRY(c, hipMemsetAsync(ex.gcnt.p, 0, slots * ng * 4, c->stream));
-    } else {
-      // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
-      HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>() + capacity, VM_KEY_EMPTY, 1, c->stream));
-      HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>() + (size_t)capacity * ng, ex.gpattern.as<uint64_t>(), ng, ng, c->stream));
-      HIP_TRY(c, hipMemsetAsync(ex.gcnt.as<uint32_t>() + (size_t)capacity * ng, 0, ng * 4, c->stream));
+    {
+      GroupInitParams I; memset(&I, 0, sizeof(I));
+      I.pattern = ex.gpattern.as<unsigned long long>(); I.ng = ng;
+      if (slab) {   // the aggregation workgroups merge into the table: all of it starts empty
+        I.keys = ex.gkeys.as<unsigned long long>(); I.n_keys = slots;
+        I.acc = ex.gacc.as<unsigned long long>(); I.n_acc = (unsigned long long)slots * ng;
+        I.cnt = ex.gcnt.as<unsigned int>(); I.n_cnt = (unsigned long long)slots * ng;
+      } else {      // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
+        I.keys = ex.gkeys.as<unsigned long long>() + capacity; I.n_keys = 1;
+        I.acc = ex.gacc.as<unsigned long long>() + (size_t)capacity * ng; I.n_acc = ng;
+        I.cnt = ex.gcnt.as<unsigned int>() + (size_t)capacity * ng; I.n_cnt = ng;
+      }
+      I.z[0] = ex.goverflow.as<unsigned int>(); I.nz[0] = 4;
+      I.z[1] = ex.error_flag.as<unsigned int>(); I.nz[1] = 1;
+      if (plain) { I.z[2] = ex.part_hist.as<unsigned int>(); I.nz[2] = n_segs; }     // the plain scatter's segment counters
+      HIP_TRY(c, ssgpu_launch_group_init(I, c->stream));
     }
-    HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 16, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
     Ps.error_flag = ex.error_flag.as<unsigned int>();
     Ps.tile_counts = ex.part_hist.as<unsigned int>();
     Ps.part_seg_cap = (uint32_t)seg_cap;
@@ -1294,7 +1299,6 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       PlainScatterParams S; fill_plain_source(S);
       S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
       S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
-      HIP_TRY(c, hipMemsetAsync(ex.part_hist.p, 0, n_segs * 4, c->stream));
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
       const int pgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 1023) / 1024));
       // the specialised build (plans that asked): one per (descriptor, partition count) -- the LDS carve-up is static in it
@@ -1464,11 +1468,15 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
       HIP_TRY(c, hipMemcpy(ex.gmergeop.p, mop.data(), ng * 4, hipMemcpyHostToDevice));
       ex.pattern_ready = true;
     }
-    HIP_TRY(c, ssgpu_launch_fill_u64(ex.gkeys.as<uint64_t>(), VM_KEY_EMPTY, slots, c->stream));
-    HIP_TRY(c, ssgpu_launch_fill_pattern_u64(ex.gacc.as<uint64_t>(), ex.gpattern.as<uint64_t>(), ng, slots * ng, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex.gcnt.p, 0, slots * ng * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex.goverflow.p, 0, 16, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, 4, c->stream));
+    {
+      GroupInitParams I; memset(&I, 0, sizeof(I));
+      I.keys = ex.gkeys.as<unsigned long long>(); I.n_keys = slots;
+      I.acc = ex.gacc.as<unsigned long long>(); I.pattern = ex.gpattern.as<unsigned long long>(); I.ng = ng; I.n_acc = (unsigned long long)slots * ng;
+      I.cnt = ex.gcnt.as<unsigned int>(); I.n_cnt = (unsigned long long)slots * ng;
+      I.z[0] = ex.goverflow.as<unsigned int>(); I.nz[0] = 4;
+      I.z[1] = ex.error_flag.as<unsigned int>(); I.nz[1] = 1;
+      HIP_TRY(c, ssgpu_launch_group_init(I, c->stream));
+    }
     VmParams P;
     fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
     apply_joins(p, ex, st.main, &P);
