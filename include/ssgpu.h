@@ -100,7 +100,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 5
+#define SSGPU_ABI_VERSION 6
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -318,7 +318,8 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *                           through scatter + aggregation, never straight from the input columns), group_scout (0 = no scout run --
  *                           the direct shape over a 1/64 prefix, result discarded -- ahead of a plan's first run over >= 8 M rows), part_plain (0 = the partition scatter always as
  *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
- *                           part_rec_align
+ *                           part_rec_align, lazy_feedback (0 = a GroupAggregate reads its overflow / feedback words at the end of EVERY run --
+ *                           one stream synchronise per run -- instead of leaving them to the next touch of the result; see ssgpu_plan_run)
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),
  *                           sort_hi_digits (2..4, 0 = by row count), sort_compact (0 = (key, row id) pairs instead of one
  *                           (high half | row id) word)
@@ -433,6 +434,11 @@ int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
  * stays loaded while it is among the 8 most recently released ones (the next plan with the same program finds it instead
  * of compiling for seconds) and is unloaded beyond that; ssgpu_specialized_kernels_trim(keep) unloads idle kernels down to
  * `keep` at once (ssgpu_memory_stats shows modules and code bytes currently loaded).
+ * Compiled code objects are also kept ON DISK (ABI 6), named by a hash of everything the compilation depended on (the
+ * library's kernel sources, the plan's program / descriptors, the compiler options, the architecture, the HIP runtime
+ * version): a second process loads them in milliseconds instead of compiling for seconds (ssgpu_memory_stats:
+ * rtc_disk_hits vs rtc_compilations).  Directory: $SSGPU_RTC_CACHE_DIR (empty string = no disk cache), else
+ * $XDG_CACHE_HOME/ssgpu/rtc, else $HOME/.cache/ssgpu/rtc; files are written atomically and checksummed.
  * A stage whose specialisation is not possible (no libhiprtc on the host, a compilation failure) keeps the
  * interpreting kernel -- still the HIP path -- and ssgpu_plan_specialize_reason says why ("" if nothing was refused).
  * ssgpu_plan_specialized: how many specialised kernels the plan currently holds. */
@@ -448,6 +454,7 @@ typedef struct ssgpu_memory_stats_t {
   int64_t device_bytes, pinned_bytes;
   int64_t live_plans, live_blocks, events;
   int64_t rtc_modules, rtc_code_bytes, rtc_compilations;   /* loaded now / loaded now / hiprtc compilations so far */
+  int64_t rtc_disk_hits;   /* specialised kernels loaded from the on-disk cache of code objects instead of being compiled (ABI 6) */
 } ssgpu_memory_stats_t;
 int ssgpu_memory_stats(ssgpu_memory_stats_t* out);
 int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
@@ -487,7 +494,16 @@ int64_t ssgpu_expr_row_capacity(const ssgpu_plan* bound);
 int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_cols, int64_t rows, ssgpu_result** out);
 
 /* ---- run ------------------------------------------------------------------ */
-/* cols: one entry per attribute of the plan's input schema, DEVICE pointers. */
+/* cols: one entry per attribute of the plan's input schema, DEVICE pointers.
+ * INPUT LIFETIME (ABI 6 spells it out): a run is asynchronous on the context's stream, and two things can make the library
+ * read the input columns AGAIN after ssgpu_plan_run has returned -- a GroupAggregate whose lazily read run feedback reports
+ * an overflow after all (the run is repeated), and a floating MIN / MAX that met a NaN (the run is repeated once in the
+ * plan's NaN-exact form).  Both happen when the result is first touched (ssgpu_result_row_count / _column /
+ * _device_column / _write_file) or when the plan runs again.  So: the columns passed to ssgpu_plan_run / _run_partial (and
+ * the block passed to ssgpu_plan_run_block, and the auxiliary input) must stay alive and UNMODIFIED until the result has
+ * been fetched or the plan has been run again or destroyed -- the same rule the reference states for ScanView ("the view
+ * must outlive the operation", cursor/core/scan_view.h).  A caller that cannot guarantee it sets the context option
+ * "lazy_feedback" = 0 (every run then settles before it returns) and fetches before it releases its input. */
 int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
                    int64_t rows, ssgpu_result** out);
 int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);

@@ -1,30 +1,34 @@
-// supersonic_amd/sharded.h -- a C++ host's multi-GPU driver for the sharded GroupAggregate (BASELINE config #4), written
-// directly against RCCL and the C ABI's result images (include/ssgpu.h, "result images").  One process (or thread) per
-// GPU; rows are range-sharded; no input row crosses xGMI.
+// supersonic_amd/sharded.h -- a C++ host's multi-GPU drivers for the sharded aggregates (BASELINE's metric at N > 1 and
+// config #4), written directly against RCCL and the C ABI (include/ssgpu.h: "partial aggregates", "result images").
+// One process (or thread) per GPU; rows are range-sharded; no input row crosses xGMI.
 //
 // The reference has no distributed code; the shape it documents for a sharded aggregation is
-// aggregate-per-shard -> shuffle -> final aggregate (supersonic/cursor/core/aggregate.h:236-242).  Here:
+// aggregate-per-shard -> shuffle -> final aggregate (supersonic/cursor/core/aggregate.h:236-242).
 //
+// ShardedScalarAggregate (the headline query, Filter -> Compute -> ScalarAggregate):
+//   the shard's rows up to the partial-aggregate state           ssgpu_plan_run_partial
+//   -> ONE ncclAllGather of the state (a few hundred bytes)       RCCL over xGMI
+//   -> ONE kernel folds the `world` states and emits the row      ssgpu_plan_fold_partials + ssgpu_plan_finalize
+//
+// ShardedGroupAggregate:
 //   per-shard GroupAggregate (the caller's pipeline)            RunOnDevice()
 //   -> its partial table packed into ONE device image           ssgpu_result_pack_image
 //   -> ONE ncclAllGather of the images                          RCCL over xGMI
 //   -> images laid out as contiguous columns + a validity flag  ssgpu_images_unpack
 //   -> merge GroupAggregate (SUM of sums, MIN of mins, ...)     an ordinary cursor over ScanDeviceView
-//
 // or, with Exchange KEY_RANGE (the form that scales: every rank merges 1 / world of the key space and ends with the groups
 // it owns, each link carries 1 / world of a table instead of all of it):
-//
 //   -> its partial table routed into `world` images by key      ssgpu_result_route_images
 //   -> ONE all-to-all of the images (grouped ncclSend / ncclRecv: image d goes to rank d)
 //   -> unpack + merge as above, over the rows this rank owns
 //
 // Everything between the two plan runs is stream-ordered on ONE stream (the context's): no device value is read on the
-// host in between.  `supersonic_amd/distributed.py: DeviceShardedGroupAggregate` is the same protocol over
-// torch.distributed; this header is for hosts that link RCCL themselves.  Like the reference's cursors, the mirror's
-// Cursor is single-shot, so Run() binds its two cursors anew on every call (cheap next to a shard's aggregation; the image
-// buffers are kept); a host that steps the same job thousands of times per second keeps the two ssgpu_plan handles and calls
-// ssgpu_plan_run on them, as distributed.py does.  STRING columns need one dictionary for the whole job
-// (distributed.py: job_strings) and are not handled here.
+// host in between.  Both plans are bound ONCE and re-run on every Run() (DeviceCursor::Rewind): a step costs no binding,
+// no allocation and no compilation.  DOUBLE sums cross shards as exact (SUM, SSGPU_SUM_RESIDUAL) pairs -- each group's
+// double-double accumulator leaves its shard unrounded -- so the cross-shard total stays within 1 ULP of the exact sum
+// (adding the shards' ROUNDED sums is hundreds to thousands of ULP off on ill-conditioned data, profiles/r03_double_sum_ulp.json).
+// `supersonic_amd/distributed.py` is the same protocol over torch.distributed.  STRING columns need one dictionary for the
+// whole job (distributed.py: job_strings) and are not handled here.
 #ifndef SUPERSONIC_AMD_SHARDED_H_
 #define SUPERSONIC_AMD_SHARDED_H_
 
@@ -38,6 +42,79 @@
 
 namespace supersonic {
 
+namespace internal {
+// A cursor over a plan somebody else keeps (the sharded drivers re-run their plans every step and hand out the result of
+// the LAST step): forwards to it, owns nothing.
+class BorrowedCursor : public Cursor {
+ public:
+  explicit BorrowedCursor(DeviceCursor* c) : c_(c) {}
+  const TupleSchema& schema() const override { return c_->schema(); }
+  ResultView Next(rowcount_t max_row_count) override { return c_->Next(max_row_count); }
+  void Interrupt() override { c_->Interrupt(); }
+  void AppendDebugDescription(string* target) const override { c_->AppendDebugDescription(target); }
+  CursorId GetCursorId() const override { return c_->GetCursorId(); }
+  DeviceCursor* device_cursor() const { return c_; }
+ private:
+  DeviceCursor* c_;
+};
+inline FailureOrOwned<Cursor> FailCursor(int code, const std::string& message) { return FailureOrOwned<Cursor>(new Exception(code, message)); }
+}  // namespace internal
+
+// The headline query at N > 1: `ScalarAggregate(spec, child)` over the concatenation of every rank's `local_child`.
+class ShardedScalarAggregate {
+ public:
+  // comm / world: the job's RCCL communicator and its size.  spec and local_child (this rank's shard, e.g.
+  // Filter(..., Compute(..., ScanView(shard)))) are owned.
+  ShardedScalarAggregate(ncclComm_t comm, int world, AggregationSpecification* spec, Operation* local_child)
+      : comm_(comm), world_(world), op_(ScalarAggregate(spec, local_child)) {}
+  ~ShardedScalarAggregate() { if (gathered_) (void)hipFree(gathered_); }
+
+  // One step over this rank's rows, which are rows [global_row_offset, ...) of the job (FIRST / LAST follow the global row
+  // order).  The returned cursor serves the ONE result row -- the same on every rank -- until the next Run().
+  FailureOrOwned<Cursor> Run(int64_t global_row_offset) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    if (!cursor_) {
+      FailureOrOwned<Cursor> c = op_->CreateCursor();
+      if (c.is_failure()) return c;
+      cursor_.reset(c.release());
+    }
+    internal::DeviceCursor* dc = internal::AsDeviceCursor(cursor_.get());
+    dc->Rewind();
+    int rc = dc->RunPartialOnDevice(global_row_offset);
+    if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+    // the partial-aggregate state: 8 arrays of n_slots 64-bit words, contiguous in segment order
+    ssgpu_partial_segment segs[16];
+    const int32_t n = ssgpu_plan_partial_segments(dc->plan_handle(), segs, 16);
+    if (n <= 0) return internal::FailCursor(ERROR_NOT_IMPLEMENTED, "the plan exposes no partial-aggregate state");
+    size_t words = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      if (static_cast<const char*>(segs[i].device_ptr) != static_cast<const char*>(segs[0].device_ptr) + words * 8)
+        return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the partial-aggregate state is not contiguous");
+      words += static_cast<size_t>(segs[i].count);
+    }
+    if (words * 8 * static_cast<size_t>(world_) > gathered_bytes_) {
+      if (gathered_) (void)hipFree(gathered_);
+      gathered_ = nullptr; gathered_bytes_ = 0;
+      if (hipMalloc(&gathered_, words * 8 * static_cast<size_t>(world_)) != hipSuccess) return internal::FailCursor(ERROR_MEMORY_EXCEEDED, "cannot allocate the gathered states");
+      gathered_bytes_ = words * 8 * static_cast<size_t>(world_);
+    }
+    hipStream_t stream = static_cast<hipStream_t>(ssgpu_ctx_stream(ctx));
+    if (ncclAllGather(segs[0].device_ptr, gathered_, words * 8, ncclUint8, comm_, stream) != ncclSuccess)   // the ONE collective
+      return internal::FailCursor(ERROR_UNKNOWN_ERROR, "ncclAllGather of the partial-aggregate states failed");
+    rc = dc->FinalizePartial(gathered_, world_);
+    if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+    return FailureOrOwned<Cursor>(new internal::BorrowedCursor(dc));
+  }
+
+ private:
+  ncclComm_t comm_;
+  int world_;
+  std::unique_ptr<Operation> op_;
+  std::unique_ptr<Cursor> cursor_;     // bound once, re-run every step
+  void* gathered_ = nullptr;
+  size_t gathered_bytes_ = 0;
+};
+
 class ShardedGroupAggregate {
  public:
   enum Exchange { ALL_GATHER, KEY_RANGE };
@@ -49,120 +126,208 @@ class ShardedGroupAggregate {
   ShardedGroupAggregate(ncclComm_t comm, int world, const std::vector<std::string>& group_by, AggregationSpecification* spec,
                         Operation* local_child, rowcount_t capacity_rows, Exchange exchange = ALL_GATHER)
       : comm_(comm), world_(world), group_by_(group_by), capacity_(capacity_rows), exchange_(exchange) {
-    // the merge functions of the aggregates (cf. distributed.py: _merge_spec)
-    std::unique_ptr<AggregationSpecification> merged(new AggregationSpecification);
-    for (auto& e : spec->elements) {
-      if (e.distinct || e.aggregation == CONCAT) { error_ = "aggregation cannot be merged across shards"; break; }
+    Init(spec, std::vector<Operation*>(1, local_child));
+  }
+  // Several shards resident on ONE device, no communicator: their images meet in this process as if they were further
+  // ranks (a table larger than one block aggregated block by block -- and the way the N-rank arithmetic, e.g. the 1-ULP
+  // property of cross-shard DOUBLE sums, is tested on a single GPU).  Same protocol, the collective left out.
+  ShardedGroupAggregate(const std::vector<std::string>& group_by, AggregationSpecification* spec, const std::vector<Operation*>& local_children,
+                        rowcount_t capacity_rows, Exchange exchange = ALL_GATHER)
+      : comm_(nullptr), world_(1), group_by_(group_by), capacity_(capacity_rows), exchange_(exchange) {
+    Init(spec, local_children);
+  }
+  ~ShardedGroupAggregate() { shard_cursors_.clear(); merge_cursor_.reset(); Free(); }
+
+ private:
+  void Init(AggregationSpecification* spec, const std::vector<Operation*>& local_children) {
+    std::unique_ptr<AggregationSpecification> own_spec(spec);
+    std::vector<std::unique_ptr<Operation>> own_children;
+    for (Operation* c : local_children) own_children.emplace_back(c);
+    if (own_children.empty()) { error_code_ = ERROR_INVALID_ARGUMENT_VALUE; error_ = "no local shard"; return; }
+    // the input's types decide which sums travel as (SUM, SUM_RESIDUAL) pairs: bind the child once to learn them
+    TupleSchema child_schema;
+    {
+      FailureOrOwned<Cursor> probe = own_children[0]->CreateCursor();
+      if (probe.is_failure()) { error_code_ = probe.exception().return_code(); error_ = probe.exception().message(); return; }
+      child_schema = probe->schema();
+    }
+    // the shard's specification (+ residuals) and the merge functions of the aggregates (cf. distributed.py: _shard_spec, _merge_spec)
+    std::unique_ptr<AggregationSpecification> shard(new AggregationSpecification), merged(new AggregationSpecification);
+    for (auto& e : own_spec->elements) {
+      if (e.distinct || e.aggregation == CONCAT) { error_code_ = ERROR_NOT_IMPLEMENTED; error_ = "aggregation cannot be merged across shards"; return; }
+      shard->elements.push_back(e);
       const Aggregation m = e.aggregation == COUNT ? SUM : e.aggregation;
       merged->AddAggregation(m, e.output, e.output);
       if (e.aggregation == COUNT) counts_.push_back(e.output);
+      const int pos = child_schema.LookupAttributePosition(e.input);
+      if (e.aggregation == SUM && pos >= 0 && child_schema.attribute(pos).type() == DOUBLE && (e.output_type < 0 || e.output_type == DOUBLE)) {
+        shard->AddAggregation(static_cast<Aggregation>(SSGPU_SUM_RESIDUAL), e.input, e.output + kResidual);
+        merged->AddAggregation(SUM, e.output + kResidual, e.output + kResidual);
+        residuals_.push_back(e.output);
+      }
     }
     merged_spec_ = std::move(merged);
-    CompoundSingleSourceProjector* keys = new CompoundSingleSourceProjector;
-    for (auto& k : group_by) keys->add(ProjectNamedAttribute(k));
-    first_.reset(GroupAggregate(keys, spec, nullptr, local_child));
+    for (auto& child : own_children) {
+      CompoundSingleSourceProjector* keys = new CompoundSingleSourceProjector;
+      for (auto& k : group_by_) keys->add(ProjectNamedAttribute(k));
+      first_.emplace_back(GroupAggregate(keys, new AggregationSpecification(*shard), nullptr, child.release()));
+    }
   }
-  ~ShardedGroupAggregate() { Free(); }
 
-  // One step.  On success the returned cursor serves the full result (the same on every rank).
+ public:
+  // One step.  On success the returned cursor serves the result of THIS step -- the full table (ALL_GATHER: the same on every
+  // rank) or this rank's groups (KEY_RANGE) -- until the next Run().  On failure every rank fails: the verdict (a table
+  // that did not fit, an evaluation error in any shard) is agreed on with one small all-reduce where the ranks saw
+  // different images (KEY_RANGE), so no rank proceeds with a result the others rejected.
   FailureOrOwned<Cursor> Run() {
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
-    if (!error_.empty()) return Fail(ERROR_NOT_IMPLEMENTED, error_);
-    FailureOrOwned<Cursor> shard = first_->CreateCursor();
-    if (shard.is_failure()) return Fail(shard.exception().return_code(), shard.exception().message());
-    int rc = shard->RunOnDevice();
-    if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-    ssgpu_plan* plan = shard->plan_handle();
-    const int n_attrs = ssgpu_plan_attr_count(plan);
-    int64_t image_bytes = 0, unpacked_bytes = 0;
-    rc = ssgpu_plan_image_layout(plan, capacity_, world_, &image_bytes, &unpacked_bytes, nullptr);
-    if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-    if (image_bytes != image_bytes_ || unpacked_bytes != unpacked_bytes_) {
-      Free();
-      const size_t send_images = exchange_ == KEY_RANGE ? static_cast<size_t>(world_) : 1;     // key range: one image per destination
-      if (hipMalloc(&image_, static_cast<size_t>(image_bytes) * send_images) != hipSuccess || hipMalloc(&images_, static_cast<size_t>(image_bytes) * world_) != hipSuccess ||
-          hipMalloc(&unpacked_, static_cast<size_t>(unpacked_bytes)) != hipSuccess)
-        return Fail(ERROR_MEMORY_EXCEEDED, "cannot allocate the result images");
-      image_bytes_ = image_bytes; unpacked_bytes_ = unpacked_bytes;
+    if (!error_.empty()) return internal::FailCursor(error_code_, error_);
+    while (shard_cursors_.size() < first_.size()) {
+      FailureOrOwned<Cursor> shard = first_[shard_cursors_.size()]->CreateCursor();
+      if (shard.is_failure()) return shard;
+      shard_cursors_.emplace_back(shard.release());
     }
+    const int n_local = static_cast<int>(shard_cursors_.size());
+    const int n_images = comm_ ? world_ : n_local;                          // images that meet in this process's merge
     hipStream_t stream = static_cast<hipStream_t>(ssgpu_ctx_stream(ctx));   // NULL = the legacy default stream
-    if (exchange_ == KEY_RANGE) {
-      rc = ssgpu_result_route_images(shard->result_handle(), static_cast<int32_t>(group_by_.size()), world_, capacity_, image_);
-      if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-      bool ok = ncclGroupStart() == ncclSuccess;                     // the ONE collective: image d -> rank d
-      for (int r = 0; ok && r < world_; ++r)
-        ok = ncclSend(static_cast<const char*>(image_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess &&
-             ncclRecv(static_cast<char*>(images_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess;
-      ok = (ncclGroupEnd() == ncclSuccess) && ok;
-      if (!ok) return Fail(ERROR_UNKNOWN_ERROR, "the all-to-all of the result images (ncclSend / ncclRecv) failed");
-    } else {
-      rc = ssgpu_result_pack_image(shard->result_handle(), capacity_, image_);
-      if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-      if (ncclAllGather(image_, images_, static_cast<size_t>(image_bytes), ncclUint8, comm_, stream) != ncclSuccess)   // the ONE collective
-        return Fail(ERROR_UNKNOWN_ERROR, "ncclAllGather failed");
-    }
-    gathered_.schema = TupleSchema();
-    for (int i = 0; i < n_attrs; ++i) {
-      ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
-      gathered_.schema.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
-    }
-    gathered_.schema.add_attribute(Attribute("__valid", BOOL, NOT_NULLABLE));
-    gathered_.columns.assign(static_cast<size_t>(n_attrs) + 1, ssgpu_column());
-    rc = ssgpu_images_unpack(plan, images_, world_, capacity_, unpacked_, gathered_.columns.data());
-    if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-    gathered_.row_count = static_cast<rowcount_t>(world_) * capacity_;
-    // the merge: GroupAggregate of the merge functions over the real rows (+ COUNT columns back to NOT NULL)
-    CompoundSingleSourceProjector* keys = new CompoundSingleSourceProjector;
-    for (auto& k : group_by_) keys->add(ProjectNamedAttribute(k));
-    std::unique_ptr<AggregationSpecification> ms(new AggregationSpecification(*merged_spec_));
-    Operation* merge = GroupAggregate(keys, ms.release(), nullptr,
-                                      Filter(NamedAttribute("__valid"), ProjectAllAttributes(), ScanDeviceView(gathered_)));
-    if (!counts_.empty()) {
-      CompoundExpression* e = new CompoundExpression;
-      for (int i = 0; i < n_attrs; ++i) {
-        const Attribute& a = gathered_.schema.attribute(i);
-        bool is_count = false;
-        for (auto& cname : counts_) is_count = is_count || cname == a.name();
-        if (is_count) e->AddAs(a.name(), IfNull(NamedAttribute(a.name()), a.type() == UINT64 ? ConstUint64(0) : ConstUint32(0)));
-        else e->Add(NamedAttribute(a.name()));
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      int rc = SSGPU_OK;
+      for (int l = 0; l < n_local; ++l) {
+        internal::DeviceCursor* sc = internal::AsDeviceCursor(shard_cursors_[static_cast<size_t>(l)].get());
+        sc->Rewind();
+        rc = sc->RunOnDevice();
+        if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
       }
-      merge = Compute(e, merge);
+      internal::DeviceCursor* shard = internal::AsDeviceCursor(shard_cursors_[0].get());
+      ssgpu_plan* plan = shard->plan_handle();
+      const int n_attrs = ssgpu_plan_attr_count(plan);
+      int64_t image_bytes = 0, unpacked_bytes = 0;
+      rc = ssgpu_plan_image_layout(plan, static_cast<int64_t>(capacity_), n_images, &image_bytes, &unpacked_bytes, nullptr);
+      if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+      if (image_bytes != image_bytes_ || unpacked_bytes != unpacked_bytes_) {
+        merge_cursor_.reset(); merge_.reset();                       // (they scan the buffers that are about to move)
+        Free();
+        const size_t send_images = exchange_ == KEY_RANGE ? static_cast<size_t>(world_) : 1;     // key range: one image per destination
+        if (hipMalloc(&image_, static_cast<size_t>(image_bytes) * send_images) != hipSuccess || hipMalloc(&images_, static_cast<size_t>(image_bytes) * n_images) != hipSuccess ||
+            hipMalloc(&unpacked_, static_cast<size_t>(unpacked_bytes)) != hipSuccess || hipMalloc(&verdict_dev_, 4 * sizeof(int64_t)) != hipSuccess)
+          return internal::FailCursor(ERROR_MEMORY_EXCEEDED, "cannot allocate the result images");
+        image_bytes_ = image_bytes; unpacked_bytes_ = unpacked_bytes;
+      }
+      if (!comm_) {
+        // shards of one device: every shard's image straight into its slot of the gathered buffer (with KEY_RANGE the one
+        // destination is this process: routing with n_dest = 1 is the packing, in another row order)
+        for (int l = 0; l < n_local && rc == SSGPU_OK; ++l) {
+          internal::DeviceCursor* sc = internal::AsDeviceCursor(shard_cursors_[static_cast<size_t>(l)].get());
+          char* slot = static_cast<char*>(images_) + static_cast<size_t>(l) * image_bytes;
+          rc = exchange_ == KEY_RANGE ? ssgpu_result_route_images(sc->result_handle(), static_cast<int32_t>(group_by_.size()), 1, static_cast<int64_t>(capacity_), slot)
+                                      : ssgpu_result_pack_image(sc->result_handle(), static_cast<int64_t>(capacity_), slot);
+        }
+        if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+      } else if (exchange_ == KEY_RANGE) {
+        rc = ssgpu_result_route_images(shard->result_handle(), static_cast<int32_t>(group_by_.size()), world_, static_cast<int64_t>(capacity_), image_);
+        if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+        bool ok = ncclGroupStart() == ncclSuccess;                     // the ONE collective: image d -> rank d
+        for (int r = 0; ok && r < world_; ++r)
+          ok = ncclSend(static_cast<const char*>(image_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess &&
+               ncclRecv(static_cast<char*>(images_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess;
+        ok = (ncclGroupEnd() == ncclSuccess) && ok;
+        if (!ok) return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the all-to-all of the result images (ncclSend / ncclRecv) failed");
+      } else {
+        rc = ssgpu_result_pack_image(shard->result_handle(), static_cast<int64_t>(capacity_), image_);
+        if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+        if (ncclAllGather(image_, images_, static_cast<size_t>(image_bytes), ncclUint8, comm_, stream) != ncclSuccess)   // the ONE collective
+          return internal::FailCursor(ERROR_UNKNOWN_ERROR, "ncclAllGather failed");
+      }
+      if (!merge_cursor_) {
+        gathered_.schema = TupleSchema();
+        for (int i = 0; i < n_attrs; ++i) {
+          ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
+          gathered_.schema.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
+        }
+        gathered_.schema.add_attribute(Attribute("__valid", BOOL, NOT_NULLABLE));
+        gathered_.columns.assign(static_cast<size_t>(n_attrs) + 1, ssgpu_column());
+      }
+      rc = ssgpu_images_unpack(plan, images_, n_images, static_cast<int64_t>(capacity_), unpacked_, gathered_.columns.data());
+      if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+      gathered_.row_count = static_cast<rowcount_t>(n_images) * capacity_;
+      if (!merge_cursor_) {
+        // the merge, bound once: GroupAggregate of the merge functions over the real rows; COUNT columns back to NOT NULL,
+        // every DOUBLE sum = its merged sum + its merged residual (each accumulated in double-double), residuals projected away
+        CompoundSingleSourceProjector* keys = new CompoundSingleSourceProjector;
+        for (auto& k : group_by_) keys->add(ProjectNamedAttribute(k));
+        std::unique_ptr<AggregationSpecification> ms(new AggregationSpecification(*merged_spec_));
+        Operation* merge = GroupAggregate(keys, ms.release(), nullptr, Filter(NamedAttribute("__valid"), ProjectAllAttributes(), ScanDeviceView(gathered_)));
+        if (!counts_.empty() || !residuals_.empty()) {
+          CompoundExpression* e = new CompoundExpression;
+          for (int i = 0; i < n_attrs; ++i) {
+            const Attribute& a = gathered_.schema.attribute(i);
+            if (a.name().size() > strlen(kResidual) && a.name().compare(a.name().size() - strlen(kResidual), strlen(kResidual), kResidual) == 0) continue;
+            if (Has(counts_, a.name())) e->AddAs(a.name(), IfNull(NamedAttribute(a.name()), a.type() == UINT64 ? ConstUint64(0) : ConstUint32(0)));
+            else if (Has(residuals_, a.name())) e->AddAs(a.name(), Plus(NamedAttribute(a.name()), NamedAttribute(a.name() + kResidual)));
+            else e->Add(NamedAttribute(a.name()));
+          }
+          merge = Compute(e, merge);
+        }
+        merge_.reset(merge);
+        FailureOrOwned<Cursor> mc = merge_->CreateCursor();
+        if (mc.is_failure()) return mc;
+        merge_cursor_.reset(mc.release());
+      }
+      internal::DeviceCursor* merge = internal::AsDeviceCursor(merge_cursor_.get());
+      merge->Rewind();
+      rc = merge->RunOnDevice();
+      if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+      // the final check, once per step and after everything was enqueued: did every table fit, did any shard fail?
+      // trailer = {largest table, sum of row counts, any image flagged (full, or its shard has to repeat the step), OR of error words}
+      int64_t trailer[4] = {0, 0, 0, 0};
+      const char* trailer_dev = static_cast<const char*>(unpacked_) + unpacked_bytes_ - 32;
+      if (comm_ && exchange_ == KEY_RANGE && world_ > 1) {
+        // every rank unpacked DIFFERENT images: agree on the verdict (MAX over ranks of every word) before anybody decides
+        if (hipMemcpyAsync(verdict_dev_, trailer_dev, 32, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+            ncclAllReduce(verdict_dev_, verdict_dev_, 4, ncclInt64, ncclMax, comm_, stream) != ncclSuccess)
+          return internal::FailCursor(ERROR_UNKNOWN_ERROR, "cannot agree on the step's verdict (ncclAllReduce)");
+        trailer_dev = static_cast<const char*>(verdict_dev_);
+      }
+      if (hipMemcpyAsync(trailer, trailer_dev, 32, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+        return internal::FailCursor(ERROR_UNKNOWN_ERROR, "cannot read the images' trailer");
+      largest_table_ = static_cast<rowcount_t>(trailer[0]);
+      if (trailer[3]) return internal::FailCursor(ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate");
+      if (trailer[2]) {
+        // flagged without a table that is too large: a shard's lazily read run feedback asked for the step to be repeated
+        // (ssgpu.h, ssgpu_result_route_images) -- every rank sees the same verdict, so every rank repeats
+        if (largest_table_ <= capacity_ && attempt + 1 < 3) continue;
+        return internal::FailCursor(ERROR_MEMORY_EXCEEDED, "a shard's partial table has more rows than capacity_rows (largest_table() tells how many)");
+      }
+      return FailureOrOwned<Cursor>(new internal::BorrowedCursor(merge));
     }
-    merge_.reset(merge);
-    FailureOrOwned<Cursor> result = merge_->CreateCursor();
-    if (result.is_failure()) return result;
-    rc = result->RunOnDevice();
-    if (rc != SSGPU_OK) return Fail(rc, ssgpu_last_error(ctx));
-    // the final check, once per step and after everything was enqueued: did every table fit, did any shard fail?
-    int64_t trailer[4] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(trailer, static_cast<const char*>(unpacked_) + unpacked_bytes_ - 32, 32, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess)
-      return Fail(ERROR_UNKNOWN_ERROR, "cannot read the images' trailer");
-    largest_table_ = trailer[0];
-    if (trailer[3]) return Fail(ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate");
-    if (trailer[2]) return Fail(ERROR_MEMORY_EXCEEDED, "a shard's partial table has more rows than capacity_rows (largest_table() tells how many)");
-    return result;
+    return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the step kept asking to be repeated");
   }
-  rowcount_t largest_table() const { return largest_table_; }   // rows of the largest partial table seen by the last Run()
+  rowcount_t largest_table() const { return largest_table_; }   // rows of the largest partial table (KEY_RANGE: image) seen by the last Run()
 
  private:
-  static FailureOrOwned<Cursor> Fail(int code, const std::string& message) { return FailureOrOwned<Cursor>(new Exception(code, message)); }
+  static constexpr const char* kResidual = "$res";   // suffix of the hidden column that carries a DOUBLE sum's residual across shards
+  static bool Has(const std::vector<std::string>& v, const std::string& x) { for (auto& e : v) if (e == x) return true; return false; }
   void Free() {
     if (image_) (void)hipFree(image_);
     if (images_) (void)hipFree(images_);
     if (unpacked_) (void)hipFree(unpacked_);
-    image_ = images_ = unpacked_ = nullptr; image_bytes_ = unpacked_bytes_ = 0;
+    if (verdict_dev_) (void)hipFree(verdict_dev_);
+    image_ = images_ = unpacked_ = verdict_dev_ = nullptr; image_bytes_ = unpacked_bytes_ = 0;
   }
   ncclComm_t comm_;
   int world_;
-  std::vector<std::string> group_by_, counts_;
+  std::vector<std::string> group_by_, counts_, residuals_;
   rowcount_t capacity_, largest_table_ = 0;
   Exchange exchange_ = ALL_GATHER;
   std::string error_;
-  std::unique_ptr<Operation> first_, merge_;
+  int error_code_ = OK;
+  std::vector<std::unique_ptr<Operation>> first_;          // one per local shard (one, unless the shards of one device are simulated ranks)
+  std::unique_ptr<Operation> merge_;
+  std::vector<std::unique_ptr<Cursor>> shard_cursors_;     // bound once, re-run every step (declared after the operations: destroyed first)
+  std::unique_ptr<Cursor> merge_cursor_;
   std::unique_ptr<AggregationSpecification> merged_spec_;
   DeviceView gathered_;
-  void* image_ = nullptr; void* images_ = nullptr; void* unpacked_ = nullptr;
+  void* image_ = nullptr; void* images_ = nullptr; void* unpacked_ = nullptr; void* verdict_dev_ = nullptr;
   int64_t image_bytes_ = 0, unpacked_bytes_ = 0;
 };
 

@@ -23,12 +23,33 @@
 #include <utility>
 #include <vector>
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <deque>
+
 #include "../ssgpu.h"
+
+// The reference's integral types (supersonic/utils/integral_types.h:22-43) live in the global namespace, and user code
+// written against supersonic/supersonic.h uses them unqualified (test/guide/primer.cc: `int32 a[8]`, `const int32* result`).
+#ifndef SUPERSONIC_AMD_NO_GLOBAL_INTEGRAL_TYPES
+typedef signed char int8;
+typedef short int16;
+typedef int int32;
+typedef long long int64;
+typedef unsigned char uint8;
+typedef unsigned short uint16;
+typedef unsigned int uint32;
+typedef unsigned long long uint64;
+#endif
 
 namespace supersonic {
 
-typedef int64_t rowcount_t;
-typedef int64_t rowid_t;
+using std::string;
+
+// base/infrastructure/types.h:252-256: row counts are UNSIGNED (so Next(-1) asks for "as many rows as you have"), row ids signed
+typedef unsigned long long rowcount_t;
+typedef long long rowid_t;
 
 // ---- enums: numeric values of supersonic/proto/supersonic.proto ------------------------
 enum DataType { INT32 = 1, INT64 = 2, UINT64 = 3, DATETIME = 4, DOUBLE = 5, BOOL = 6, UINT32 = 8, FLOAT = 9, DATE = 10, STRING = 0, BINARY = 7 };
@@ -50,6 +71,9 @@ class Exception {
   Exception(int code, const std::string& message) : code_(code), message_(message) {}
   ReturnCode return_code() const { return static_cast<ReturnCode>(code_); }
   const std::string& message() const { return message_; }
+  // exception.h: the message with its code (there are no stack frames to print on this side of the C ABI)
+  std::string ToString() const { return "Exception " + std::to_string(code_) + ": " + message_; }
+  std::string PrintStackTrace() const { return ToString(); }
  private:
   int code_;
   std::string message_;
@@ -67,6 +91,8 @@ class FailureOrOwned {
   T* get() const { return value_.get(); }
   T* release() { return value_.release(); }
   T* operator->() const { return value_.get(); }
+  T& operator*() const { return *value_; }
+  Exception* release_exception() { return exception_.release(); }
  private:
   std::unique_ptr<T> value_;
   std::unique_ptr<Exception> exception_;
@@ -83,6 +109,7 @@ class FailureOr {
   bool is_success() const { return !is_failure(); }
   const Exception& exception() const { return *exception_; }
   const T& get() const { return value_; }
+  Exception* release_exception() { return exception_.release(); }
  private:
   T value_;
   std::unique_ptr<Exception> exception_;
@@ -95,9 +122,19 @@ class FailureOrVoid {
   bool is_failure() const { return exception_ != nullptr; }
   bool is_success() const { return !is_failure(); }
   const Exception& exception() const { return *exception_; }
+  Exception* release_exception() { return exception_.release(); }
  private:
   std::unique_ptr<Exception> exception_;
 };
+
+// SucceedOrDie (utils/exception/failureor.h:442-466): "turn exceptions into runtime crashes" -- the adapters user code wraps
+// around CreateCursor() / Bind() when a failure is a programming error (test/guide/primer.cc:286-291).
+namespace internal {
+inline void Die(const Exception& e) { fprintf(stderr, "SucceedOrDie: %s\n", e.PrintStackTrace().c_str()); abort(); }
+}  // namespace internal
+inline void SucceedOrDie(FailureOrVoid result) { if (result.is_failure()) internal::Die(result.exception()); }
+template <typename T> T SucceedOrDie(FailureOr<T> result) { if (result.is_failure()) internal::Die(result.exception()); return result.get(); }
+template <typename T> T* SucceedOrDie(FailureOrOwned<T> result) { if (result.is_failure()) internal::Die(result.exception()); return result.release(); }   // ownership passes to the caller
 
 // ---- schema (base/infrastructure/tuple_schema.h:77,126) ---------------------------------
 class Attribute {
@@ -173,31 +210,98 @@ class Buffer {
   void* data_; size_t size_; BufferAllocator* allocator_;
 };
 
+// ---- TypeTraits / variant pointers (base/infrastructure/types.h:300-420, variant_pointer.h:87-139, bit_pointers.h) -------
+template <DataType type> struct TypeTraits;
+template <> struct TypeTraits<INT32> { typedef int32 cpp_type; };
+template <> struct TypeTraits<INT64> { typedef int64 cpp_type; };
+template <> struct TypeTraits<UINT32> { typedef uint32 cpp_type; };
+template <> struct TypeTraits<UINT64> { typedef uint64 cpp_type; };
+template <> struct TypeTraits<FLOAT> { typedef float cpp_type; };
+template <> struct TypeTraits<DOUBLE> { typedef double cpp_type; };
+template <> struct TypeTraits<BOOL> { typedef bool cpp_type; };
+template <> struct TypeTraits<DATE> { typedef int32 cpp_type; };
+template <> struct TypeTraits<DATETIME> { typedef int64 cpp_type; };
+template <> struct TypeTraits<STRING> { typedef StringPiece cpp_type; };
+template <> struct TypeTraits<BINARY> { typedef StringPiece cpp_type; };
+
+typedef const bool* bool_const_ptr;   // one byte per row (bit_pointers.h:529-533, the non-bit-packed build)
+typedef bool* bool_ptr;
+
+class VariantConstPointer {
+ public:
+  VariantConstPointer() : pointer_(nullptr) {}
+  VariantConstPointer(const void* pointer) : pointer_(pointer) {}   // NOLINT(runtime/explicit): as the reference
+  template <DataType type> const typename TypeTraits<type>::cpp_type* as() const { return static_cast<const typename TypeTraits<type>::cpp_type*>(pointer_); }
+  const StringPiece* as_variable_length() const { return static_cast<const StringPiece*>(pointer_); }
+  const void* raw() const { return pointer_; }
+  bool is_null() const { return pointer_ == nullptr; }
+  VariantConstPointer offset(int64 rows, DataType type) const { return VariantConstPointer(static_cast<const char*>(pointer_) + rows * static_cast<int64>(SizeOfDataType(type))); }
+ private:
+  friend bool operator==(VariantConstPointer a, VariantConstPointer b);
+  const void* pointer_;
+};
+inline bool operator==(VariantConstPointer a, VariantConstPointer b) { return a.pointer_ == b.pointer_; }
+
 // ---- View (base/infrastructure/block.h:55-402): N (data, is_null) pairs + row count -----
 class Column {
  public:
-  Column() : data_(nullptr), is_null_(nullptr) {}
-  void Reset(const void* data, const bool* is_null) { data_ = data; is_null_ = is_null; }
-  const void* data() const { return data_; }
-  const bool* is_null() const { return is_null_; }   // nullptr => no NULLs
-  template <typename T> const T* typed_data() const { return static_cast<const T*>(data_); }
+  const Attribute& attribute() const { return *attribute_; }
+  VariantConstPointer data() const { return data_; }
+  VariantConstPointer data_plus_offset(rowid_t offset) const { return data_.offset(offset, attribute_->type()); }
+  bool_const_ptr is_null() const { return is_null_; }   // nullptr => no NULLs
+  bool_const_ptr is_null_plus_offset(rowcount_t offset) const { return is_null_ ? is_null_ + offset : nullptr; }
+  // typed_data<INT32>() as in the reference (block.h:90-96) ...
+  template <DataType type> const typename TypeTraits<type>::cpp_type* typed_data() const { return data_.as<type>(); }
+  // ... and by C++ type, for generic code on this side
+  template <typename T> const T* typed_data() const { return static_cast<const T*>(data_.raw()); }
+  const StringPiece* variable_length_data() const { return data_.as_variable_length(); }
+  void Reset(VariantConstPointer data, bool_const_ptr is_null) { data_ = data; is_null_ = is_null; }
+  void ResetFrom(const Column& other) { Reset(other.data(), other.is_null()); }
+  void ResetFromPlusOffset(const Column& other, rowcount_t offset) { Reset(other.data_plus_offset(static_cast<rowid_t>(offset)), other.is_null_plus_offset(offset)); }
+  void ResetIsNull(bool_const_ptr is_null) { if (attribute_->is_nullable()) is_null_ = is_null; }
  private:
-  const void* data_;
-  const bool* is_null_;
+  friend class View;
+  Column() : attribute_(nullptr), is_null_(nullptr) {}
+  const Attribute* attribute_;   // points into the owning View's schema
+  VariantConstPointer data_;
+  bool_const_ptr is_null_;
 };
 
 class View {
  public:
-  explicit View(const TupleSchema& schema) : schema_(schema), columns_(schema.attribute_count()), row_count_(0) {}
+  explicit View(const TupleSchema& schema) : schema_(schema), columns_(new Column[Count(schema)]), row_count_(0) { Init(); }
+  View(const View& other) : schema_(other.schema()), columns_(new Column[Count(other.schema())]), row_count_(0) { Init(); ResetFrom(other); }
+  View(const View& other, rowcount_t offset, rowcount_t row_count) : schema_(other.schema()), columns_(new Column[Count(other.schema())]), row_count_(0) {
+    Init(); ResetFromSubRange(other, offset, row_count);
+  }
+  View(const Column& column, rowcount_t row_count)
+      : schema_(TupleSchema::Singleton(column.attribute().name(), column.attribute().type(), column.attribute().nullability())), columns_(new Column[1]), row_count_(row_count) {
+    Init(); mutable_column(0)->ResetFrom(column);
+  }
   const TupleSchema& schema() const { return schema_; }
   int column_count() const { return schema_.attribute_count(); }
   const Column& column(int i) const { return columns_[i]; }
   Column* mutable_column(int i) { return &columns_[i]; }
   rowcount_t row_count() const { return row_count_; }
   void set_row_count(rowcount_t n) { row_count_ = n; }
+  void ResetFrom(const View& other) {
+    for (int i = 0; i < column_count(); ++i) mutable_column(i)->ResetFrom(other.column(i));
+    set_row_count(other.row_count());
+  }
+  void ResetFromSubRange(const View& other, rowcount_t offset, rowcount_t row_count) {
+    for (int i = 0; i < column_count(); ++i) mutable_column(i)->ResetFromPlusOffset(other.column(i), offset);
+    set_row_count(row_count);
+  }
+  void Advance(rowcount_t offset) {
+    for (int i = 0; i < column_count(); ++i) { Column* c = mutable_column(i); c->ResetFromPlusOffset(*c, offset); }
+    row_count_ -= (row_count_ < offset ? row_count_ : offset);
+  }
  private:
-  TupleSchema schema_;
-  std::vector<Column> columns_;
+  static size_t Count(const TupleSchema& s) { return static_cast<size_t>(s.attribute_count() > 0 ? s.attribute_count() : 1); }
+  void Init() { for (int i = 0; i < schema_.attribute_count(); ++i) columns_[i].attribute_ = &schema_.attribute(i); }
+  View& operator=(const View& other);   // not assignable, as the reference's (block.h:396)
+  const TupleSchema schema_;
+  std::unique_ptr<Column[]> columns_;
   rowcount_t row_count_;
 };
 
@@ -490,7 +594,7 @@ struct Dictionary {
     std::vector<const char*> ptr(static_cast<size_t>(n)); std::vector<int32_t> len(static_cast<size_t>(n));
     for (rowcount_t i = 0; i < n; ++i) { ptr[i] = cells[i].data(); len[i] = static_cast<int32_t>(cells[i].size()); }
     codes->assign(static_cast<size_t>(std::max<rowcount_t>(n, 1)), 0);
-    return ssgpu_dict_encode(d, ptr.data(), len.data(), reinterpret_cast<const uint8_t*>(is_null), n, codes->data());
+    return ssgpu_dict_encode(d, ptr.data(), len.data(), reinterpret_cast<const uint8_t*>(is_null), static_cast<int64_t>(n), codes->data());
   }
   StringPiece Decode(int32_t code) const {
     const char* b = nullptr; int32_t n = 0;
@@ -514,26 +618,27 @@ inline int UploadView(ssgpu_ctx* ctx, const View* v, const Dictionary* dict, ssg
   const TupleSchema& s = v->schema();
   std::vector<ssgpu_attr> attrs;
   for (int i = 0; i < s.attribute_count(); ++i) attrs.push_back({s.attribute(i).name().c_str(), s.attribute(i).type(), s.attribute(i).nullability()});
-  int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), std::max<rowcount_t>(v->row_count(), 1), out);
+  int rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), static_cast<int64_t>(std::max<rowcount_t>(v->row_count(), 1)), out);
   std::vector<int32_t> codes;
   for (int i = 0; rc == SSGPU_OK && i < s.attribute_count() && v->row_count() > 0; ++i) {
-    const void* data = v->column(i).data();
+    const void* data = v->column(i).data().raw();
     if (s.attribute(i).type() == STRING) {
       rc = dict && dict->d ? dict->Encode(v->column(i).typed_data<StringPiece>(), v->column(i).is_null(), v->row_count(), &codes) : SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
       data = codes.data();
       if (rc != SSGPU_OK) break;
     }
-    rc = ssgpu_block_upload(*out, i, data, reinterpret_cast<const uint8_t*>(v->column(i).is_null()), 0, v->row_count());
+    rc = ssgpu_block_upload(*out, i, data, reinterpret_cast<const uint8_t*>(v->column(i).is_null()), 0, static_cast<int64_t>(v->row_count()));
     if (rc == SSGPU_OK && s.attribute(i).type() == STRING) rc = ssgpu_ctx_synchronize(ctx);   // `codes` is reused by the next column
   }
-  if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(*out, v->row_count());
+  if (rc == SSGPU_OK) rc = ssgpu_block_set_row_count(*out, static_cast<int64_t>(v->row_count()));
   return rc;
 }
 // finished result -> host column pointers (STRING columns decoded into `cells`)
 inline int FetchResult(ssgpu_result* res, const TupleSchema& schema, const Dictionary* dict, rowcount_t* total,
                        std::vector<const void*>* data, std::vector<const uint8_t*>* nulls, std::vector<std::vector<StringPiece>>* cells) {
-  *total = ssgpu_result_row_count(res);
-  if (*total < 0) return SSGPU_ERROR_HIP;
+  const int64_t fetched_rows = ssgpu_result_row_count(res);
+  if (fetched_rows < 0) return SSGPU_ERROR_HIP;
+  *total = static_cast<rowcount_t>(fetched_rows);
   data->clear(); nulls->clear(); cells->assign(static_cast<size_t>(schema.attribute_count()), std::vector<StringPiece>());
   for (int i = 0; i < schema.attribute_count(); ++i) {
     const void* d = nullptr; const uint8_t* z = nullptr;
@@ -564,30 +669,73 @@ inline int FetchResult(ssgpu_result* res, const TupleSchema& schema, const Dicti
 class ResultView {
  public:
   static ResultView Success(const View* v) { ResultView r; r.view_ = v; return r; }
-  static ResultView EOS() { ResultView r; r.eos_ = true; return r; }
+  static ResultView EOS() { ResultView r; r.status_ = kEos; return r; }
+  static ResultView BOS() { ResultView r; r.status_ = kBos; return r; }
+  static ResultView WaitingOnBarrier() { ResultView r; r.status_ = kBarrier; return r; }
   static ResultView Failure(Exception* e) { ResultView r; r.exception_.reset(e); return r; }
   bool has_data() const { return view_ != nullptr; }
-  bool is_eos() const { return eos_; }
+  bool is_done() const { return is_eos() || is_failure(); }
+  bool is_eos() const { return status_ == kEos; }
+  bool is_bos() const { return status_ == kBos; }
+  bool is_waiting_on_barrier() const { return status_ == kBarrier; }
   bool is_failure() const { return exception_ != nullptr; }
   const View& view() const { return *view_; }
   const Exception& exception() const { return *exception_; }
+  // ownership of the exception passes to the caller (a copy: the ResultView itself stays copyable, cursor.h:120)
+  Exception* release_exception() { Exception* e = exception_ ? new Exception(*exception_) : nullptr; exception_.reset(); return e; }
  private:
-  ResultView() : view_(nullptr), eos_(false) {}
+  enum Status { kData, kEos, kBos, kBarrier };
+  ResultView() : view_(nullptr), status_(kData) {}
   const View* view_;
-  bool eos_;
+  Status status_;
   std::shared_ptr<Exception> exception_;
 };
+inline const View& SucceedOrDie(ResultView result_view) {   // cursor.h:124-127
+  if (result_view.is_failure()) internal::Die(result_view.exception());
+  return result_view.view();
+}
+
+// cursor/proto/cursors.proto:13-67 (the ids of the cursors this path has)
+enum CursorId { FILE_INPUT = 3, VIEW = 7, AGGREGATE_CLUSTERS = 8, COMPUTE = 15, FILTER = 16, GROUP_AGGREGATE = 18, HASH_JOIN = 19, PROJECT = 26,
+                SCALAR_AGGREGATE = 29, SORT = 30, UNKNOWN_ID = 42 };
+class CursorTransformer;
 
 class Operation;
 
+// The reference's pure interface (cursor/base/cursor.h:131-226): user code holds Cursor*, calls schema() / Next() /
+// Interrupt(), and may implement its own cursors against it.
 class Cursor {
  public:
   static const rowcount_t kDefaultRowCount = 1024;  // cursor.h:133
-  ~Cursor() { if (res_) ssgpu_result_destroy(res_); if (aux_block_) ssgpu_block_destroy(aux_block_); if (block_) ssgpu_block_destroy(block_); if (plan_) ssgpu_plan_destroy(plan_); }
-  const TupleSchema& schema() const { return schema_; }
-  void Interrupt() { ssgpu_interrupt(plan_); }   // thread-safe, non-blocking (cursor.h:150-186)
+  virtual ~Cursor() {}
+  virtual const TupleSchema& schema() const = 0;
+  int column_count() const { return schema().attribute_count(); }
+  // between one and max_row_count rows, EOS, or an Exception; Next(-1) = "as many as you have" (rowcount_t is unsigned)
+  virtual ResultView Next(rowcount_t max_row_count) = 0;
+  virtual void Interrupt() = 0;                                     // thread-safe, non-blocking (cursor.h:150-186)
+  virtual void AppendDebugDescription(string* target) const = 0;
+  virtual bool IsWaitingOnBarrierSupported() const { return false; }
+  virtual void ApplyToChildren(CursorTransformer* /*transformer*/) {}   // a device cursor is one fused pipeline: no child cursors to visit
+  virtual CursorId GetCursorId() const { return UNKNOWN_ID; }
+  string DebugDescription() const { string d; AppendDebugDescription(&d); return d; }
+ protected:
+  Cursor() {}
+ private:
+  Cursor(const Cursor&);
+  Cursor& operator=(const Cursor&);
+};
 
-  ResultView Next(rowcount_t max_row_count) {
+namespace internal {
+// What Operation::CreateCursor() returns: the whole bound operation tree as ONE device plan (ssgpu_plan).
+class DeviceCursor : public Cursor {
+ public:
+  ~DeviceCursor() override { if (res_) ssgpu_result_destroy(res_); if (aux_block_) ssgpu_block_destroy(aux_block_); if (block_) ssgpu_block_destroy(block_); if (plan_) ssgpu_plan_destroy(plan_); }
+  const TupleSchema& schema() const override { return schema_; }
+  void Interrupt() override { ssgpu_interrupt(plan_); }
+  void AppendDebugDescription(string* target) const override { target->append(description_); }
+  CursorId GetCursorId() const override { return id_; }
+
+  ResultView Next(rowcount_t max_row_count) override {
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
     if (!fetched_) {
       int rc = RunOnDevice();
@@ -597,6 +745,7 @@ class Cursor {
     }
     if (failed_) return ResultView::Failure(new Exception(ERROR_UNKNOWN_ERROR, "cursor already failed"));
     if (pos_ >= total_) return ResultView::EOS();
+    if (max_row_count == 0) max_row_count = 1;   // (the contract is "between one and max_row_count rows")
     const rowcount_t n = std::min<rowcount_t>(max_row_count, total_ - pos_);
     for (int i = 0; i < schema_.attribute_count(); ++i) {
       const size_t w = SizeOfDataType(schema_.attribute(i).type());
@@ -616,7 +765,7 @@ class Cursor {
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
     int rc = Stage(ctx);
     if (rc == SSGPU_OK) {
-      if (dev_) rc = ssgpu_plan_run(plan_, dev_->columns.data(), static_cast<int32_t>(dev_->columns.size()), dev_->row_count, &res_);
+      if (dev_) rc = ssgpu_plan_run(plan_, dev_->columns.data(), static_cast<int32_t>(dev_->columns.size()), static_cast<int64_t>(dev_->row_count), &res_);
       else rc = ssgpu_plan_run_block(plan_, block_, &res_);
     }
     return run_rc_ = rc;
@@ -624,16 +773,50 @@ class Cursor {
   ssgpu_plan* plan_handle() const { return plan_; }
   ssgpu_result* result_handle() const { return res_; }
 
+  // A device cursor can run its plan AGAIN (the reference's cursors are single-shot; a sharded job steps the same plans
+  // thousands of times and must not rebind them): forget the previous result, keep plan, buffers and staged input.
+  // restage = true uploads the host View again (its contents changed); device-resident inputs are never copied.
+  void Rewind(bool restage = false) {
+    ran_ = false; fetched_ = false; failed_ = false; pos_ = 0; total_ = 0; run_rc_ = SSGPU_OK;
+    if (restage) { if (block_) { ssgpu_block_destroy(block_); block_ = nullptr; } if (aux_block_) { ssgpu_block_destroy(aux_block_); aux_block_ = nullptr; } }
+  }
+  // Multi-GPU scalar aggregates (ssgpu.h: partial aggregates): run the shard's rows up to the partial-aggregate state ...
+  int RunPartialOnDevice(int64_t global_row_offset) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    int rc = Stage(ctx);
+    if (rc != SSGPU_OK) return rc;
+    std::vector<ssgpu_column> cols;
+    int64_t rows = 0;
+    if (dev_) { cols = dev_->columns; rows = static_cast<int64_t>(dev_->row_count); }
+    else {
+      cols.resize(static_cast<size_t>(input_->schema().attribute_count()));
+      for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(block_, static_cast<int32_t>(i), &cols[i]);
+      rows = ssgpu_block_row_count(block_);
+      // the block was staged on the copy stream: the run must wait for it (ssgpu_plan_run_block does this for full runs)
+      if (rc == SSGPU_OK) rc = ssgpu_ctx_synchronize(ctx);
+    }
+    if (rc == SSGPU_OK) rc = ssgpu_plan_run_partial(plan_, cols.data(), static_cast<int32_t>(cols.size()), rows, global_row_offset);
+    return rc;
+  }
+  // ... and, after the caller has gathered every rank's state (n_images consecutive copies, device memory), fold and emit.
+  int FinalizePartial(const void* gathered_state, int32_t n_images) {
+    int rc = ssgpu_plan_fold_partials(plan_, gathered_state, n_images);
+    if (rc == SSGPU_OK) rc = ssgpu_plan_finalize(plan_, &res_);
+    ran_ = true; run_rc_ = rc; fetched_ = false; failed_ = false; pos_ = 0;
+    return rc;
+  }
+
  private:
-  friend class Operation;
-  Cursor() {}
+  friend class BasicOperation;
+  DeviceCursor() {}
   int Stage(ssgpu_ctx* ctx) {  // host Views -> device blocks on the copy stream
     if (dev_) return SSGPU_OK;   // device-resident input: nothing to stage
+    if (block_) return SSGPU_OK;   // staged by an earlier run of this cursor (Rewind)
     if (aux_) {                // rhs table of a HashJoin: the plan's auxiliary input
       int rc = internal::UploadView(ctx, aux_, &dict_, &aux_block_);
       std::vector<ssgpu_column> cols(aux_->schema().attribute_count());
       for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(aux_block_, static_cast<int32_t>(i), &cols[i]);
-      if (rc == SSGPU_OK) rc = ssgpu_plan_set_aux_input(plan_, cols.data(), static_cast<int32_t>(cols.size()), aux_->row_count());
+      if (rc == SSGPU_OK) rc = ssgpu_plan_set_aux_input(plan_, cols.data(), static_cast<int32_t>(cols.size()), static_cast<int64_t>(aux_->row_count()));
       if (rc != SSGPU_OK) return rc;
     }
     return internal::UploadView(ctx, input_, &dict_, &block_);
@@ -654,17 +837,43 @@ class Cursor {
   rowcount_t total_ = 0, pos_ = 0;
   bool ran_ = false, failed_ = false, fetched_ = false;
   int run_rc_ = SSGPU_OK;
+  CursorId id_ = UNKNOWN_ID;
+  string description_;
 };
+// The device side of a cursor this library made (sharded.h, WriteResultToFile); NULL for a foreign Cursor implementation.
+inline DeviceCursor* AsDeviceCursor(Cursor* c) { return dynamic_cast<DeviceCursor*>(c); }
+}  // namespace internal
 
 // ---- operations (cursor/base/operation.h:35-83 and the factories of supersonic.h) -------------
+// The reference's pure interface (cursor/base/operation.h:35-83).
 class Operation {
  public:
   virtual ~Operation() {}
+  // The allocator is not owned and must outlive the operation's cursors; NULL resets it to "unset".
+  virtual void SetBufferAllocator(BufferAllocator* buffer_allocator, bool cascade_to_children) = 0;
+  virtual void SetBufferAllocatorWhereUnset(BufferAllocator* buffer_allocator, bool cascade_to_children) = 0;
+  // Binds the whole tree; the Operation must outlive the cursors it returns (operation.h:59).
+  virtual FailureOrOwned<Cursor> CreateCursor() const = 0;
+  virtual void AppendDebugDescription(string* const target) const = 0;
+  string DebugDescription() const { string result; AppendDebugDescription(&result); return result; }
+ protected:
+  Operation() {}
+ private:
+  Operation(const Operation&);
+  Operation& operator=(const Operation&);
+};
+
+namespace internal {
+// Every operation the factories below make: a node of the symbolic tree that CreateCursor() flattens into ONE
+// ssgpu_plan_desc (the device runs the fused tree; there are no per-operation cursors).
+class BasicOperation : public Operation {
+ public:
   // Binds the whole tree (Expression::Bind, projector/aggregation binding) and lowers it.
-  FailureOrOwned<Cursor> CreateCursor() const {
+  FailureOrOwned<Cursor> CreateCursor() const override {
     Builder b;
     Emit(&b);
-    std::unique_ptr<Cursor> c(new Cursor);
+    if (!b.error.empty()) return FailureOrOwned<Cursor>(new Exception(ERROR_NOT_IMPLEMENTED, b.error));
+    std::unique_ptr<DeviceCursor> c(new DeviceCursor);
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
     // STRING: one order-preserving dictionary over the scanned Views' cells and the plan's ConstStrings
     if (!b.scan && !b.scan_dev) return FailureOrOwned<Cursor>(new Exception(ERROR_INVALID_ARGUMENT_VALUE, "operation tree has no scan"));
@@ -710,13 +919,31 @@ class Operation {
       c->schema_.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
     }
     c->view_.reset(new View(c->schema_));
+    c->id_ = cursor_id(); AppendDebugDescription(&c->description_);
     return FailureOrOwned<Cursor>(c.release());
   }
-  // The reference's allocator seam (operation.h:66-76).  Device buffers are owned by the plan; an allocator with a
+  // The reference's allocator seam (operation.h:48-58).  Device buffers are owned by the plan; an allocator with a
   // quota (MemoryLimit) bounds them, and a run that needs more fails with ERROR_MEMORY_EXCEEDED.  The allocator is not
   // owned and must outlive the cursors.  One plan = one quota: the nearest allocator from the root applies.
-  void SetBufferAllocator(BufferAllocator* allocator, bool /*cascade_to_children*/) { allocator_ = allocator; }
+  void SetBufferAllocator(BufferAllocator* allocator, bool cascade_to_children) override {
+    allocator_ = allocator;
+    if (cascade_to_children) for (Operation* child : children()) child->SetBufferAllocator(allocator, true);
+  }
+  void SetBufferAllocatorWhereUnset(BufferAllocator* allocator, bool cascade_to_children) override {
+    if (!allocator_) allocator_ = allocator;
+    if (cascade_to_children) for (Operation* child : children()) child->SetBufferAllocatorWhereUnset(allocator, true);
+  }
+  void AppendDebugDescription(string* const target) const override {
+    target->append(name());
+    target->append("(");
+    bool first = true;
+    for (Operation* child : children()) { if (!first) target->append(", "); first = false; child->AppendDebugDescription(target); }
+    target->append(")");
+  }
   virtual const BufferAllocator* EffectiveAllocator() const { return allocator_; }
+  virtual std::vector<Operation*> children() const { return std::vector<Operation*>(); }
+  virtual const char* name() const = 0;
+  virtual CursorId cursor_id() const { return UNKNOWN_ID; }
 
   struct Builder {
     std::vector<ssgpu_op> ops; std::vector<ssgpu_expr> exprs; std::vector<int32_t> expr_args;
@@ -725,6 +952,7 @@ class Operation {
     const DeviceView* scan_dev = nullptr;   // device-resident input (ScanDeviceView)
     const View* scan_aux = nullptr;   // rhs table of a HashJoin (the plan's auxiliary input)
     bool aux = false;
+    std::string error;                // a child that is not one of this library's operations cannot join the fused plan
     std::vector<std::pair<int, const std::string*>> string_consts;   // (expr index, payload): codes are patched in later
     void ProjRange(const std::vector<SingleSourceProjector::Entry>& es, int32_t* first, int32_t* n) {
       *first = static_cast<int32_t>(projs.size()); *n = static_cast<int32_t>(es.size());
@@ -752,10 +980,21 @@ class Operation {
     int Op(ssgpu_op o) { ops.push_back(o); return static_cast<int>(ops.size()) - 1; }
   };
   virtual int Emit(Builder* b) const = 0;
+  // a child's node index; a foreign Operation (not made by these factories) has no device form
+  static int EmitChild(const Operation* child, Builder* b) {
+    const BasicOperation* c = dynamic_cast<const BasicOperation*>(child);
+    if (!c) { if (b->error.empty()) b->error = "an operation of the tree is not a device operation of this library: " + (child ? child->DebugDescription() : string("NULL")); return -1; }
+    return c->Emit(b);
+  }
+  static const BufferAllocator* AllocatorOf(const Operation* child) {
+    const BasicOperation* c = dynamic_cast<const BasicOperation*>(child);
+    return c ? c->EffectiveAllocator() : nullptr;
+  }
  protected:
   BufferAllocator* allocator_ = nullptr;
   static ssgpu_op Blank(int kind, int child) { ssgpu_op o; memset(&o, 0, sizeof(o)); o.kind = kind; o.child = child; o.expr = -1; return o; }
 };
+}  // namespace internal
 
 // ---- BoundExpressionTree (expression/base/expression.h:96-145) over ssgpu_expr_bind / ssgpu_expr_evaluate ------------
 // FailureOrReference<const View> (base/exception/result.h): the View stays valid until the next Evaluate.
@@ -777,7 +1016,7 @@ class BoundExpressionTree {
  public:
   ~BoundExpressionTree() { Release(); }
   const TupleSchema& result_schema() const { return schema_; }
-  rowcount_t row_capacity() const { return ssgpu_expr_row_capacity(plan_); }
+  rowcount_t row_capacity() const { return static_cast<rowcount_t>(ssgpu_expr_row_capacity(plan_)); }
   // One result row per input row, in order.  ERROR_TOO_MANY_ROWS beyond row_capacity() (expression.cc:57-66);
   // evaluation errors (signaling operators) come back as failures.
   EvaluationResult Evaluate(const View& input) {
@@ -797,7 +1036,7 @@ class BoundExpressionTree {
     rc = internal::UploadView(ctx, &input, &dict_, &block_);
     std::vector<ssgpu_column> cols(static_cast<size_t>(input_schema_.attribute_count()));
     for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(block_, static_cast<int32_t>(i), &cols[i]);
-    if (rc == SSGPU_OK) rc = ssgpu_expr_evaluate(plan_, cols.data(), static_cast<int32_t>(cols.size()), input.row_count(), &res_);
+    if (rc == SSGPU_OK) rc = ssgpu_expr_evaluate(plan_, cols.data(), static_cast<int32_t>(cols.size()), static_cast<int64_t>(input.row_count()), &res_);
     rowcount_t total = 0;
     if (rc == SSGPU_OK) rc = internal::FetchResult(res_, schema_, &dict_, &total, &host_data_, &host_null_, &cells_);
     if (rc != SSGPU_OK) return EvaluationResult::Failure(new Exception(rc, ssgpu_last_error(ctx)));
@@ -833,7 +1072,7 @@ class BoundExpressionTree {
     for (int i = 0; i < input_schema_.attribute_count(); ++i)
       attrs.push_back({input_schema_.attribute(i).name().c_str(), input_schema_.attribute(i).type(), input_schema_.attribute(i).nullability()});
     int rc = ssgpu_expr_bind(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), exprs_.data(), static_cast<int32_t>(exprs_.size()),
-                             expr_args_.data(), static_cast<int32_t>(expr_args_.size()), root_, max_row_count_, &plan_);
+                             expr_args_.data(), static_cast<int32_t>(expr_args_.size()), root_, static_cast<int64_t>(max_row_count_), &plan_);
     if (rc != SSGPU_OK) return rc;
     if (memory_limit_ >= 0) ssgpu_plan_set_memory_limit(plan_, memory_limit_);
     schema_ = TupleSchema();
@@ -864,7 +1103,7 @@ class BoundExpressionTree {
 
 inline FailureOrOwned<BoundExpressionTree> Expression::Bind(const TupleSchema& input_schema, BufferAllocator* allocator, rowcount_t max_row_count) const {
   std::unique_ptr<BoundExpressionTree> t(new BoundExpressionTree);
-  Operation::Builder b;
+  internal::BasicOperation::Builder b;
   t->root_ = b.Expr(this);
   t->exprs_ = b.exprs; t->expr_args_ = b.expr_args;
   for (auto& x : t->exprs_) {            // the bound tree does not depend on this Expression's lifetime
@@ -882,9 +1121,11 @@ inline FailureOrOwned<BoundExpressionTree> Expression::Bind(const TupleSchema& i
 }
 
 namespace internal {
-class ScanViewOp : public Operation {
+class ScanViewOp : public BasicOperation {
  public:
   explicit ScanViewOp(const View& v) : view_(v) {}
+  const char* name() const override { return "ScanView"; }
+  CursorId cursor_id() const override { return VIEW; }
   int Emit(Builder* b) const override {
     ssgpu_op o = Blank(SSGPU_OP_SCAN, -1);
     if (b->aux) { b->scan_aux = &view_; o.option0 = 1; } else { b->scan = &view_; }
@@ -893,19 +1134,32 @@ class ScanViewOp : public Operation {
  private:
   const View& view_;  // must outlive the operation (scan_view.h)
 };
-class ScanDeviceOp : public Operation {
+class ScanDeviceOp : public BasicOperation {
  public:
   explicit ScanDeviceOp(const DeviceView& v) : view_(v) {}
+  const char* name() const override { return "ScanDeviceView"; }
+  CursorId cursor_id() const override { return VIEW; }
   int Emit(Builder* b) const override { b->scan_dev = &view_; return b->Op(Blank(SSGPU_OP_SCAN, -1)); }
  private:
   const DeviceView& view_;  // must outlive the operation and its cursors
 };
-class UnaryOp : public Operation {
+class UnaryOp : public BasicOperation {
  public:
   UnaryOp(int kind, Operation* child, const Expression* e, const SingleSourceProjector* p, const AggregationSpecification* a, const SortOrder* s, int64_t opt = 0)
       : kind_(kind), child_(child), expr_(e), proj_(p), aggs_(a), sort_(s), opt_(opt) {}
+  std::vector<Operation*> children() const override { return std::vector<Operation*>(1, child_.get()); }
+  const char* name() const override {
+    switch (kind_) { case SSGPU_OP_COMPUTE: return "Compute"; case SSGPU_OP_FILTER: return "Filter"; case SSGPU_OP_PROJECT: return "Project";
+                     case SSGPU_OP_SCALAR_AGGREGATE: return "ScalarAggregate"; case SSGPU_OP_GROUP_AGGREGATE: return "GroupAggregate";
+                     case SSGPU_OP_AGGREGATE_CLUSTERS: return "AggregateClusters"; case SSGPU_OP_SORT: return "Sort"; default: return "Operation"; }
+  }
+  CursorId cursor_id() const override {
+    switch (kind_) { case SSGPU_OP_COMPUTE: return COMPUTE; case SSGPU_OP_FILTER: return FILTER; case SSGPU_OP_PROJECT: return PROJECT;
+                     case SSGPU_OP_SCALAR_AGGREGATE: return SCALAR_AGGREGATE; case SSGPU_OP_GROUP_AGGREGATE: return GROUP_AGGREGATE;
+                     case SSGPU_OP_AGGREGATE_CLUSTERS: return AGGREGATE_CLUSTERS; case SSGPU_OP_SORT: return SORT; default: return UNKNOWN_ID; }
+  }
   int Emit(Builder* b) const override {
-    ssgpu_op o = Blank(kind_, child_->Emit(b));
+    ssgpu_op o = Blank(kind_, EmitChild(child_.get(), b));
     if (expr_) o.expr = b->Expr(expr_.get());
     if (proj_) b->Proj(proj_.get(), &o);
     if (aggs_) b->Aggs(aggs_.get(), &o);
@@ -914,7 +1168,7 @@ class UnaryOp : public Operation {
     o.option0 = opt_;
     return b->Op(o);
   }
-  const BufferAllocator* EffectiveAllocator() const override { return allocator_ ? allocator_ : child_->EffectiveAllocator(); }
+  const BufferAllocator* EffectiveAllocator() const override { return allocator_ ? allocator_ : AllocatorOf(child_.get()); }
  private:
   int kind_;
   std::unique_ptr<Operation> child_;
@@ -925,13 +1179,16 @@ class UnaryOp : public Operation {
   int64_t opt_;
 };
 // HashJoinOperation (cursor/core/hash_join.h:37-56): INNER / LEFT_OUTER, UNIQUE rhs keys, rhs = ScanView(table)
-class HashJoinOp : public Operation {
+class HashJoinOp : public BasicOperation {
  public:
   HashJoinOp(JoinType t, const SingleSourceProjector* lk, const SingleSourceProjector* rk, const MultiSourceProjector* rp,
              KeyUniqueness u, Operation* lhs, Operation* rhs) : type_(t), uniq_(u), lk_(lk), rk_(rk), rp_(rp), lhs_(lhs), rhs_(rhs) {}
+  std::vector<Operation*> children() const override { std::vector<Operation*> c; c.push_back(lhs_.get()); c.push_back(rhs_.get()); return c; }
+  const char* name() const override { return "HashJoin"; }
+  CursorId cursor_id() const override { return HASH_JOIN; }
   int Emit(Builder* b) const override {
-    const int l = lhs_->Emit(b);
-    b->aux = true; const int r = rhs_->Emit(b); b->aux = false;
+    const int l = EmitChild(lhs_.get(), b);
+    b->aux = true; const int r = EmitChild(rhs_.get(), b); b->aux = false;
     ssgpu_op o = Blank(SSGPU_OP_HASH_JOIN, l);
     o.child2 = r; o.option0 = static_cast<int64_t>(type_) | (static_cast<int64_t>(uniq_) << 8);
     b->ProjRange(lk_->entries, &o.proj_first, &o.proj_n);
@@ -939,7 +1196,7 @@ class HashJoinOp : public Operation {
     b->ProjRange(rp_->entries, &o.proj3_first, &o.proj3_n);
     return b->Op(o);
   }
-  const BufferAllocator* EffectiveAllocator() const override { return allocator_ ? allocator_ : lhs_->EffectiveAllocator(); }
+  const BufferAllocator* EffectiveAllocator() const override { return allocator_ ? allocator_ : AllocatorOf(lhs_.get()); }
  private:
   JoinType type_; KeyUniqueness uniq_;
   std::unique_ptr<const SingleSourceProjector> lk_, rk_;
@@ -968,6 +1225,171 @@ inline Operation* AggregateClusters(const SingleSourceProjector* clustered_by, c
 inline Operation* Sort(const SortOrder* order, const SingleSourceProjector* result_projector, size_t memory_limit, Operation* child) {
   return new internal::UnaryOp(SSGPU_OP_SORT, child, nullptr, result_projector ? result_projector : ProjectAllAttributes(), nullptr, order, static_cast<int64_t>(memory_limit));
 }
+
+// ---- Arena (base/memory/arena.h): owns the bytes of variable-length values ----------------------------------------------
+// StringPiece cells of a View do not own their bytes; user code parks them in an Arena that lives as long as the View
+// (test/guide/group_sort.cc:129,273).  The two size arguments of the reference (initial / maximal buffer) have no
+// meaning for this implementation and are accepted for source compatibility.
+class Arena {
+ public:
+  Arena(size_t /*initial_buffer_size*/, size_t /*max_buffer_size*/) {}
+  Arena(BufferAllocator* /*allocator*/, size_t /*initial_buffer_size*/, size_t /*max_buffer_size*/) {}
+  // copies the bytes, returns where they now live (NULL only if memory runs out)
+  const char* AddStringPieceContent(const StringPiece& value) { chunks_.emplace_back(value.data(), value.size()); bytes_ += value.size(); return chunks_.back().data(); }
+  void Reset() { chunks_.clear(); bytes_ = 0; }
+  size_t memory_footprint() const { return bytes_; }
+ private:
+  std::deque<std::string> chunks_;
+  size_t bytes_ = 0;
+};
+
+// ---- Table / TableRowWriter (cursor/infrastructure/table.h:49-290) --------------------------------------------------------
+// An Operation that owns a growable block of rows on the HOST and scans it: the container user code fills row by row
+// (TableRowWriter) or view by view (AppendView) and then hands to an operation tree like any other child.  Column
+// buffers come from the BufferAllocator given (pinned host memory: the scan's upload is a DMA), variable-length values
+// are deep-copied into the Table's own arena (the reference's rule, table.cc / view_copier.h).
+class Table : public internal::BasicOperation {
+ public:
+  Table(const TupleSchema& schema, BufferAllocator* buffer_allocator)
+      : alloc_(buffer_allocator ? buffer_allocator : HeapBufferAllocator::Get()), view_(schema), arena_(0, 0),
+        data_(static_cast<size_t>(schema.attribute_count())), nulls_(static_cast<size_t>(schema.attribute_count())), capacity_(0) {}
+  ~Table() override {}
+  const char* name() const override { return "Table"; }
+  CursorId cursor_id() const override { return VIEW; }
+  int Emit(Builder* b) const override {   // = ScanView(view())
+    ssgpu_op o = Blank(SSGPU_OP_SCAN, -1);
+    if (b->aux) { b->scan_aux = &view_; o.option0 = 1; } else { b->scan = &view_; }
+    return b->Op(o);
+  }
+  const View& view() const { return view_; }
+  const TupleSchema& schema() const { return view_.schema(); }
+  rowcount_t row_count() const { return view_.row_count(); }
+  rowcount_t row_capacity() const { return capacity_; }
+  void Clear() { view_.set_row_count(0); arena_.Reset(); }
+  // Capacity for at least `needed_capacity` rows; false (and the old capacity) if the allocator refuses.
+  bool ReserveRowCapacity(rowcount_t needed_capacity) {
+    if (needed_capacity <= capacity_) return true;
+    rowcount_t cap = capacity_ ? capacity_ : 16;
+    while (cap < needed_capacity) cap *= 2;
+    return SetRowCapacity(cap);
+  }
+  bool SetRowCapacity(rowcount_t row_capacity) {
+    if (row_capacity < row_count()) return false;
+    // allocate all new buffers first: on failure nothing has changed
+    std::vector<std::unique_ptr<Buffer>> nd(data_.size()), nn(nulls_.size());
+    for (int i = 0; i < schema().attribute_count(); ++i) {
+      const size_t w = SizeOfDataType(schema().attribute(i).type());
+      nd[static_cast<size_t>(i)].reset(alloc_->Allocate(static_cast<size_t>(row_capacity) * w));
+      if (!nd[static_cast<size_t>(i)]) return false;
+      if (schema().attribute(i).is_nullable()) {
+        nn[static_cast<size_t>(i)].reset(alloc_->Allocate(static_cast<size_t>(row_capacity)));
+        if (!nn[static_cast<size_t>(i)]) return false;
+      }
+    }
+    for (int i = 0; i < schema().attribute_count(); ++i) {
+      const size_t k = static_cast<size_t>(i), w = SizeOfDataType(schema().attribute(i).type());
+      if (row_count()) memcpy(nd[k]->data(), data_[k]->data(), static_cast<size_t>(row_count()) * w);
+      if (nn[k]) { memset(nn[k]->data(), 0, static_cast<size_t>(row_capacity)); if (row_count()) memcpy(nn[k]->data(), nulls_[k]->data(), static_cast<size_t>(row_count())); }
+      data_[k] = std::move(nd[k]); nulls_[k] = std::move(nn[k]);
+      view_.mutable_column(i)->Reset(data_[k]->data(), nulls_[k] ? static_cast<const bool*>(nulls_[k]->data()) : nullptr);
+    }
+    capacity_ = row_capacity;
+    return true;
+  }
+  // A new row (its cells unset: the caller Sets / SetNulls every one of them); its index, or -1 when out of memory.
+  rowid_t AddRow() {
+    if (!ReserveRowCapacity(row_count() + 1)) return -1;
+    view_.set_row_count(row_count() + 1);
+    return static_cast<rowid_t>(row_count() - 1);
+  }
+  template <DataType type> bool Set(int col_index, rowid_t row_index, const typename TypeTraits<type>::cpp_type& value) {
+    typedef typename TypeTraits<type>::cpp_type T;
+    if (schema().attribute(col_index).type() != type) return false;
+    const size_t k = static_cast<size_t>(col_index);
+    static_cast<T*>(data_[k]->data())[row_index] = Keep(value);
+    if (nulls_[k]) static_cast<bool*>(nulls_[k]->data())[row_index] = false;
+    return true;
+  }
+  void SetNull(int col_index, rowid_t row_index) {
+    const size_t k = static_cast<size_t>(col_index);
+    if (nulls_[k]) static_cast<bool*>(nulls_[k]->data())[row_index] = true;
+  }
+  // Appends (deep-copies) the rows of a View with this Table's schema; returns the number of rows appended.
+  rowcount_t AppendView(const View& view) {
+    const rowcount_t n = view.row_count(), at = row_count();
+    if (n == 0 || !ReserveRowCapacity(at + n)) return 0;
+    for (int i = 0; i < schema().attribute_count(); ++i) {
+      const size_t k = static_cast<size_t>(i), w = SizeOfDataType(schema().attribute(i).type());
+      const bool* z = view.column(i).is_null();
+      if (schema().attribute(i).type() == STRING || schema().attribute(i).type() == BINARY) {
+        const StringPiece* src = view.column(i).variable_length_data();
+        StringPiece* dst = static_cast<StringPiece*>(data_[k]->data()) + at;
+        for (rowcount_t r = 0; r < n; ++r) dst[r] = (z && z[r]) ? StringPiece() : Keep(src[r]);
+      } else {
+        memcpy(static_cast<char*>(data_[k]->data()) + at * w, view.column(i).data().raw(), static_cast<size_t>(n) * w);
+      }
+      if (nulls_[k]) { bool* dz = static_cast<bool*>(nulls_[k]->data()) + at; for (rowcount_t r = 0; r < n; ++r) dz[r] = z ? z[r] : false; }
+    }
+    view_.set_row_count(at + n);
+    return n;
+  }
+  bool CopyFrom(const Table& other) { Clear(); return AppendView(other.view()) == other.view().row_count(); }
+ private:
+  template <typename T> const T& Keep(const T& v) { return v; }
+  StringPiece Keep(const StringPiece& v) { return StringPiece(arena_.AddStringPieceContent(v), v.size()); }   // deep copy
+  BufferAllocator* alloc_;
+  View view_;
+  Arena arena_;
+  std::vector<std::unique_ptr<Buffer>> data_, nulls_;
+  rowcount_t capacity_;
+};
+
+// table.h:212-290: `writer.AddRow().Int32(1).String("x").Null()` ... `writer.CheckSuccess()`
+class TableRowWriter {
+ public:
+  explicit TableRowWriter(Table* table) : table_(table), col_index_(table->schema().attribute_count()), row_index_(-1), failed_(false) {}
+  TableRowWriter& AddRow() {
+    if (success()) {
+      if (col_index_ != table_->schema().attribute_count()) { failed_ = true; return *this; }   // the previous row is not complete
+      row_index_ = table_->AddRow();
+      failed_ = row_index_ < 0;
+      col_index_ = 0;
+    }
+    return *this;
+  }
+  TableRowWriter& Int32(int32 value) { return Set<INT32>(value); }
+  TableRowWriter& Int64(int64 value) { return Set<INT64>(value); }
+  TableRowWriter& Uint32(uint32 value) { return Set<UINT32>(value); }
+  TableRowWriter& Uint64(uint64 value) { return Set<UINT64>(value); }
+  TableRowWriter& Float(float value) { return Set<FLOAT>(value); }
+  TableRowWriter& Double(double value) { return Set<DOUBLE>(value); }
+  TableRowWriter& Bool(bool value) { return Set<BOOL>(value); }
+  TableRowWriter& Date(int32 value) { return Set<DATE>(value); }
+  TableRowWriter& Datetime(int64 value) { return Set<DATETIME>(value); }
+  TableRowWriter& String(const StringPiece& value) { return Set<STRING>(value); }
+  TableRowWriter& Null() {
+    if (success()) { if (col_index_ >= table_->schema().attribute_count()) failed_ = true; else table_->SetNull(col_index_++, row_index_); }
+    return *this;
+  }
+  TableRowWriter& AllFurtherNull() {
+    if (success()) while (col_index_ < table_->schema().attribute_count()) table_->SetNull(col_index_++, row_index_);
+    return *this;
+  }
+  template <DataType type> TableRowWriter& Set(const typename TypeTraits<type>::cpp_type& value) {
+    if (success()) failed_ = col_index_ >= table_->schema().attribute_count() || !table_->Set<type>(col_index_++, row_index_, value);
+    return *this;
+  }
+  bool success() const { return !failed_; }
+  void CheckSuccess() const {
+    if (!success()) { fprintf(stderr, "TableRowWriter failed at row %lld, column %d\n", static_cast<long long>(row_index_), col_index_); abort(); }
+  }
+  const TupleSchema& schema() const { return table_->schema(); }
+ private:
+  Table* table_;
+  int col_index_;
+  rowid_t row_index_;
+  bool failed_;
+};
 
 // ---- the View file format (cursor/infrastructure/file_io.h:58-72, file_io.cc:15-30) ---------------------------------
 // The reference hands its own File* to these; the mirror takes a path (the ABI reads with positional readers into pinned
@@ -1010,7 +1432,7 @@ class FileSink : public Sink {
           put(lens.data(), rc * 8);
           for (uint64_t r = 0; r < rc; ++r) put(cells[r].data(), lens[r]);
         } else {
-          put(static_cast<const char*>(v.column(i).data()) + off * SizeOfDataType(a.type()), rc * SizeOfDataType(a.type()));
+          put(static_cast<const char*>(v.column(i).data().raw()) + off * SizeOfDataType(a.type()), rc * SizeOfDataType(a.type()));
         }
       }
     }
@@ -1032,8 +1454,10 @@ inline Sink* FileOutput(const std::string& path) { return new internal::FileSink
 // A finished cursor's result straight from device memory into a file (fixed-width columns): FileOutput(...)->Write of
 // the whole result without the host View in between.
 inline FailureOrVoid WriteResultToFile(Cursor* cursor, const std::string& path) {
-  int rc = cursor->RunOnDevice();
-  if (rc == SSGPU_OK) rc = ssgpu_result_write_file(cursor->result_handle(), path.c_str());
+  internal::DeviceCursor* dc = internal::AsDeviceCursor(cursor);
+  if (!dc) return FailureOrVoid(new Exception(ERROR_NOT_IMPLEMENTED, "WriteResultToFile needs a cursor made by this library's operations"));
+  int rc = dc->RunOnDevice();
+  if (rc == SSGPU_OK) rc = ssgpu_result_write_file(dc->result_handle(), path.c_str());
   return rc == SSGPU_OK ? FailureOrVoid() : FailureOrVoid(new Exception(rc, ssgpu_last_error(internal::Context::Get().ctx)));
 }
 

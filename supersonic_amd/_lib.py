@@ -76,7 +76,7 @@ class Op(C.Structure):
 
 class MemoryStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("device_bytes", "pinned_bytes", "live_plans", "live_blocks", "events",
-                                          "rtc_modules", "rtc_code_bytes", "rtc_compilations")]
+                                          "rtc_modules", "rtc_code_bytes", "rtc_compilations", "rtc_disk_hits")]
 
 
 class StageInfo(C.Structure):

@@ -1432,7 +1432,10 @@ class Cursor(object):
         total = self._result.row_count()
         if self._pos >= total:
             return ResultView(eos=True)
-        n = min(int(max_row_count), total - self._pos)
+        # rowcount_t is an UNSIGNED 64-bit integer in the reference (base/infrastructure/types.h:252-256): Next(-1), the guide's
+        # "as many rows as you have" (test/guide/primer.cc:321), is Next(2**64 - 1); 0 still returns at least one row
+        want = int(max_row_count) & 0xFFFFFFFFFFFFFFFF
+        n = min(max(want, 1), total - self._pos)
         lo, hi = self._pos, self._pos + n
         self._pos = hi
         cols = [Column(c.data[lo:hi], None if c.is_null is None else c.is_null[lo:hi]) for c in self._result._cols]

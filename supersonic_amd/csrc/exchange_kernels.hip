@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ssgpu_pack_image_kernel(const ImagePackPa
     for (u32 f = 0; f < P.n_retry; ++f) retry |= (u64)*P.retry_flags[f];
     h[0] = rows; h[1] = P.capacity; h[2] = (rows_have > P.capacity || retry) ? 1ull : 0ull; h[3] = rows_have;
     u64 err = 0;
-    for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)*P.error_flags[f];
+    for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)(*P.error_flags[f] & 0xFFu);   // evaluation errors only: the NaN-in-MIN/MAX bit is no error (across shards NaNs are skipped, ssgpu.h)
     h[4] = err; h[5] = 0; h[6] = 0; h[7] = 0;
   }
   const ImagePiece pc = P.pieces[blockIdx.y];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ssgpu_route_copy_kernel(const ImagePackPa
     const u64 have = R.counters[d];
     u64 retry = 0, err = 0;
     for (u32 f = 0; f < P.n_retry; ++f) retry |= (u64)*P.retry_flags[f];
-    for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)*P.error_flags[f];
+    for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)(*P.error_flags[f] & 0xFFu);   // (as in ssgpu_pack_image_kernel)
     h[0] = have < P.capacity ? have : P.capacity; h[1] = P.capacity; h[2] = (have > P.capacity || retry) ? 1ull : 0ull; h[3] = have;
     h[4] = err; h[5] = 0; h[6] = 0; h[7] = 0;
   }

@@ -159,7 +159,7 @@ hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterP
 void* ssgpu_rtc_function(void* handle);
 void ssgpu_rtc_release(void* handle);
 void ssgpu_rtc_trim(int keep);   // unloads kernels without a user down to `keep` of them
-void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations);
+void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations, long long* disk_hits);
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,

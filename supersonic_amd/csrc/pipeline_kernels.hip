@@ -357,6 +357,149 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
 // the wave reduction happens once, at the end of the kernel.  Further slots fall back to a
 // per-tile wave reduction into LDS records.
 
+// The scalar aggregate sinks of vm_body.inc, one text per handler SHAPE (instantiated there per value type).
+// AGG_U64: values that combine in a 64-bit unsigned domain -- integers as order-preserving keys, BOOL as 0 / 1.
+//   CONV: the row's value `e` (of type T) as u64; IDENT: the identity of COMBINE; COMBINE: (x, y) -> u64.
+#define AGG_U64_STEP(ACC, E, M, T, CONV, IDENT, COMBINE)                       \
+        { T e = (E); u64 x = ACC, y = (M) ? (u64)(CONV) : (u64)(IDENT); ACC = (COMBINE); }
+#define AGG_U64(OPNAME, T, CONV, IDENT, COMBINE)                               \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    if (I.dst < VM_FAST_SLOTS) {                                               \
+      u64 acc = F0[I.dst]; u32 ac = FC[I.dst];                                 \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto vv = lds_load2<T>(I.a, p);                                        \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        AGG_U64_STEP(acc, vv.x, m.x, T, CONV, IDENT, COMBINE)                  \
+        AGG_U64_STEP(acc, vv.y, m.y, T, CONV, IDENT, COMBINE)                  \
+        ac += (u32)m.x + (u32)m.y;                                             \
+      }                                                                        \
+      F0[I.dst] = acc; FC[I.dst] = ac;                                         \
+    } else {                                                                   \
+      u64 local = (IDENT); u32 cnt = 0;                                        \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto vv = lds_load2<T>(I.a, p);                                        \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        AGG_U64_STEP(local, vv.x, m.x, T, CONV, IDENT, COMBINE)                \
+        AGG_U64_STEP(local, vv.y, m.y, T, CONV, IDENT, COMBINE)                \
+        cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));    \
+      }                                                                        \
+      u64 tot = wave_reduce_u64(local, [](u64 x, u64 y) { return (u64)(COMBINE); }); \
+      if (lane == 0 && cnt) {                                                  \
+        VmAccRec* A = acc_rec(P, I.dst, wave);                                 \
+        u64 x = A->cnt ? A->v0 : (u64)(IDENT), y = tot;                        \
+        A->v0 = (COMBINE); A->cnt += cnt;                                      \
+      }                                                                        \
+    }                                                                          \
+  } break;
+
+// floating MIN / MAX in the double domain.  BETTER: "y replaces x".  A NaN never replaces anything (every comparison with
+// it is false); that one was met is remembered per lane for the whole kernel (vm_nan_seen: a lane mask in two SGPRs) and
+// reported once, at the end of the kernel -- no branch and no atomic per tile.
+#define AGG_FMM_STEP(ACC, E, M, BETTER)                                        \
+        { double x = ACC, y = (double)(E); vm_nan_seen |= (M) && (y != y); if ((M) && (BETTER)) ACC = y; }
+#define AGG_FMINMAX(OPNAME, T, IDENT, BETTER)                                  \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    if (I.dst < VM_FAST_SLOTS) {                                               \
+      double acc = u2d(F0[I.dst]); u32 ac = FC[I.dst];                         \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto vv = lds_load2<T>(I.a, p);                                        \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        AGG_FMM_STEP(acc, vv.x, m.x, BETTER)                                   \
+        AGG_FMM_STEP(acc, vv.y, m.y, BETTER)                                   \
+        ac += (u32)m.x + (u32)m.y;                                             \
+      }                                                                        \
+      F0[I.dst] = d2u(acc); FC[I.dst] = ac;                                    \
+    } else {                                                                   \
+      double local = (IDENT); u32 cnt = 0;                                     \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto vv = lds_load2<T>(I.a, p);                                        \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        AGG_FMM_STEP(local, vv.x, m.x, BETTER)                                 \
+        AGG_FMM_STEP(local, vv.y, m.y, BETTER)                                 \
+        cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));    \
+      }                                                                        \
+      u64 tot = wave_reduce_u64(d2u(local), [](u64 xa, u64 ya) { double x = u2d(xa), y = u2d(ya); return (BETTER) ? ya : xa; }); \
+      if (lane == 0 && cnt) {                                                  \
+        VmAccRec* A = acc_rec(P, I.dst, wave);                                 \
+        double x = A->cnt ? u2d(A->v0) : (double)(IDENT), y = u2d(tot);        \
+        A->v0 = d2u((BETTER) ? y : x); A->cnt += cnt;                          \
+      }                                                                        \
+    }                                                                          \
+  } break;
+
+// FIRST / LAST: (value, global row id) pairs; BETTER: "row id y replaces row id x"; IDENT: the row id that never wins.
+#define AGG_FL_STEP(ROW, VAL, R, E, M, BETTER)                                 \
+        { u64 x = ROW, y = (R); if ((M) && (BETTER)) { ROW = y; VAL = (u64)(E); } }
+#define AGG_FIRSTLAST(OPNAME, T, IDENT, BETTER)                                \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    if (I.dst < VM_FAST_SLOTS) {                                               \
+      u64 av = F0[I.dst], ar = F1[I.dst]; u32 ac = FC[I.dst];                  \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto vv = lds_load2<T>(I.a, p);                                        \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);                \
+        AGG_FL_STEP(ar, av, r0, vv.x, m.x, BETTER)                             \
+        AGG_FL_STEP(ar, av, r0 + 1, vv.y, m.y, BETTER)                         \
+        ac += (u32)m.x + (u32)m.y;                                             \
+      }                                                                        \
+      F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;                          \
+    } else {                                                                   \
+      u64 brow = (IDENT), bval = 0; u32 cnt = 0;                               \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto vv = lds_load2<T>(I.a, p);                                        \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);                \
+        AGG_FL_STEP(brow, bval, r0, vv.x, m.x, BETTER)                         \
+        AGG_FL_STEP(brow, bval, r0 + 1, vv.y, m.y, BETTER)                     \
+        cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));    \
+      }                                                                        \
+      u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return (BETTER) ? y : x; }); \
+      u64 owner = __ballot(brow == trow);                                      \
+      if (cnt) {                                                               \
+        int src = __ffsll((long long)owner) - 1;                               \
+        u64 tval = readlane64(bval, src);                                      \
+        if (lane == 0) {                                                       \
+          VmAccRec* A = acc_rec(P, I.dst, wave);                               \
+          u64 x = A->cnt ? A->v1 : (u64)(IDENT), y = trow;                     \
+          if (BETTER) { A->v1 = trow; A->v0 = tval; }                          \
+          A->cnt += cnt;                                                       \
+        }                                                                      \
+      }                                                                        \
+    }                                                                          \
+  } break;
+
+// SUM(a OP b) with the binary operator fused into the sink (lower.cpp emits these for register-resident slots only)
+#define AGG_FUSED_I64(OPNAME, EXPR)                                            \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    if (I.dst < VM_FAST_SLOTS) {                                               \
+      u64 acc = F0[I.dst]; u32 ac = FC[I.dst];                                 \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto va = fetch2<u64>(I.a, I.a_mask, p);                               \
+        auto vd = fetch2<u64>(I.d, I.b_mask, p);                               \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        { u64 a = va.x, b = vd.x; acc += m.x ? (EXPR) : 0ull; }                \
+        { u64 a = va.y, b = vd.y; acc += m.y ? (EXPR) : 0ull; }                \
+        ac += (u32)m.x + (u32)m.y;                                             \
+      }                                                                        \
+      F0[I.dst] = acc; FC[I.dst] = ac;                                         \
+    }                                                                          \
+  } break;
+#define AGG_FUSED_F64(OPNAME, EXPR)                                            \
+  case VM_##OPNAME: { CASE_FENCE;                                              \
+    if (I.dst < VM_FAST_SLOTS) {                                               \
+      DD local; local.hi = u2d(F0[I.dst]); local.lo = u2d(F1[I.dst]); u32 ac = FC[I.dst]; \
+      _Pragma("unroll") FOR_PAIRS {                                            \
+        auto va = fetch2<double>(I.a, I.a_mask, p);                            \
+        auto vd = fetch2<double>(I.d, I.b_mask, p);                            \
+        Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
+        { double a = va.x, b = vd.x; if (m.x) local = dd_add_d(local, (EXPR)); } \
+        { double a = va.y, b = vd.y; if (m.y) local = dd_add_d(local, (EXPR)); } \
+        ac += (u32)m.x + (u32)m.y;                                             \
+      }                                                                        \
+      F0[I.dst] = d2u(local.hi); F1[I.dst] = d2u(local.lo); FC[I.dst] = ac;    \
+    }                                                                          \
+  } break;
+
 #define STORE_OP(OPNAME, T)                                                    \
   case VM_##OPNAME: { CASE_FENCE;                                              \
     T* out = reinterpret_cast<T*>(P.outputs[I.dst].dst);                       \
@@ -529,6 +672,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   u64xS F0, F1; u32xS FC;
 #pragma unroll
   for (int s = 0; s < VM_FAST_SLOTS; ++s) { F0[s] = P.slot_init0[s]; F1[s] = P.slot_init1[s]; FC[s] = 0; }
+  bool vm_nan_seen = false;   // this lane met a NaN in a floating MIN / MAX (AGG_FMINMAX): reported once, after the tile loop
   // constant LDS arrays: tile_rows x 0x01 (absent selection) then tile_rows x 0x00 (absent NULL mask)
   for (u32 o = (u32)t * 8u; o < 2u * (u32)tile_rows; o += VM_COMPUTE_THREADS * 8u)
     *reinterpret_cast<u64*>(smem + P.const_lds_off + o) = o < (u32)tile_rows ? 0x0101010101010101ull : 0ull;
@@ -650,6 +794,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     PC_PROF(if (P.debug_pc && P.n_instr > 0 && t == 0) reinterpret_cast<u64*>(smem + P.debug_pc_lds_off)[P.n_instr - 1] += __builtin_amdgcn_s_memtime() - dbg_pc_last;)
   }
 
+  if (vm_nan_seen && P.error_flag) atomicOr(P.error_flag, SSGPU_FLAG_NAN_IN_MINMAX);
   if (P.part_n && P.tile_counts) {  // partition pass: publish the fill of this workgroup's segments
     __syncthreads();
     const u32* h = reinterpret_cast<const u32*>(smem + P.part_lds_off);

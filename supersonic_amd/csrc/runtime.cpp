@@ -125,8 +125,8 @@ struct StageExec {
   // A kernel specialised by runtime compilation (rtc.cpp): a reference to a cached module function.  `static_lds` is the
   // LDS size it was compiled for when that exceeds what a module-loaded kernel may ask for dynamically (0 = dynamic).
   struct RtcSlot {
-    void* h = nullptr; bool tried = false; uint32_t static_lds = 0;
-    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; }
+    void* h = nullptr; bool tried = false; uint32_t static_lds = 0, tag = 0;   // tag: what else the kernel was compiled for (partition count, rows per thread)
+    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; tag = 0; }
   };
   RtcSlot rtc_main;             // the main program's specialised kernel, h == NULL: interpreter
   std::vector<VmInstr> host_prog_main;   // the finalised main program (what rtc.cpp compiles)
@@ -1306,9 +1306,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (p->specialize) {
         const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
         const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
-        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds)) {
+        const uint32_t tag = NP * 4u + (uint32_t)R;
+        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag)) {
           if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
-          ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds;
+          ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds; ex.rtc_plain.tag = tag;
           std::string why;
           ex.rtc_plain.h = ssgpu_rtc_specialize_pscat(c->device, S, R, lds, &why);
           if (!ex.rtc_plain.h && ex.rtc_why.empty()) ex.rtc_why = "plain partition scatter: " + why;
@@ -1535,7 +1536,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     HIP_TRY(c, ex.fb_host.ensure(16));
     uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // overflow flag, rows that bypassed the local table, max local occupancy
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
-    if (attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && si + 1 == p->stages.size()) {
+    if (!scout && attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && si + 1 == p->stages.size()) {   // (a scout run exists for its feedback: always read)
       ex.fb_pending = 1; p->deferred = true;   // steady state: looked at lazily (settle_plan)
       break;
     }
@@ -2242,9 +2243,9 @@ int ssgpu_memory_stats(ssgpu_memory_stats_t* out) {
   memset(out, 0, sizeof(*out));
   out->device_bytes = g_dev_bytes.load(); out->pinned_bytes = g_pinned_bytes.load();
   out->live_plans = g_live_plans.load(); out->live_blocks = g_live_blocks.load(); out->events = g_events.load();
-  long long m = 0, b = 0, n = 0;
-  ssgpu_rtc_stats(&m, &b, &n);
-  out->rtc_modules = m; out->rtc_code_bytes = b; out->rtc_compilations = n;
+  long long m = 0, b = 0, n = 0, d = 0;
+  ssgpu_rtc_stats(&m, &b, &n, &d);
+  out->rtc_modules = m; out->rtc_code_bytes = b; out->rtc_compilations = n; out->rtc_disk_hits = d;
   return SSGPU_OK;
 }
 int ssgpu_plan_set_memory_limit(ssgpu_plan* p, int64_t bytes) {

@@ -114,7 +114,7 @@ static void TestRun(const Input& in) {
       sum += in.a[i] + in.b[i] * 3; ++cnt;
       if (!in.d_null[i]) { any = true; mn = fmin(mn, in.d[i]); }
     }
-    CHECK_EQ(r.view().row_count(), 1);
+    CHECK_EQ(r.view().row_count(), 1u);
     CHECK_EQ(r.view().column(0).typed_data<int64_t>()[0], sum);
     CHECK_EQ(r.view().column(1).typed_data<uint64_t>()[0], cnt);
     CHECK(any && r.view().column(2).typed_data<double>()[0] == mn);
@@ -152,8 +152,8 @@ static void TestRun(const Input& in) {
     if (r.is_failure()) { printf("run failed: %s\n", r.exception().message().c_str()); ++g_fail; return; }
     int64_t sa[7] = {0}; uint64_t cd[7] = {0};
     for (int i = 0; i < Input::N; ++i) { sa[in.k[i]] += in.a[i]; cd[in.k[i]] += !in.d_null[i]; }
-    CHECK_EQ(r.view().row_count(), 7);
-    for (int g = 0; g < 7 && g < r.view().row_count(); ++g) {
+    CHECK_EQ(r.view().row_count(), 7u);
+    for (int g = 0; g < 7 && static_cast<supersonic::rowcount_t>(g) < r.view().row_count(); ++g) {
       CHECK_EQ(r.view().column(0).typed_data<int32_t>()[g], g);
       CHECK_EQ(r.view().column(1).typed_data<int64_t>()[g], sa[g]);
       CHECK_EQ(r.view().column(2).typed_data<uint64_t>()[g], cd[g]);
@@ -487,7 +487,7 @@ static void TestFileFormat(bool run) {
     rows += r.view().row_count();
   }
   CHECK_EQ(rows, static_cast<rowcount_t>(6));
-  CHECK_EQ(total, static_cast<int64_t>(n) * (n - 1) / 2);
+  CHECK_EQ(total, static_cast<int64_t>(n) * static_cast<int64_t>(n - 1) / 2);
   CHECK(FileInput(schema, dir + "/missing.ssv").is_failure());
 }
 

@@ -75,9 +75,13 @@ int main(int argc, char** argv) {
     CHECK(c->schema().attribute(4).name() == "cv" && !c->schema().attribute(4).is_nullable());   // COUNT stays NOT NULL
     CHECK(Drain(c.get(), &got));
     CHECK(job.largest_table() == 257);
-    // a second step reuses the buffers
+    // a second step re-runs the SAME two plans (bound once) and reuses the buffers: same result
     FailureOrOwned<Cursor> again = job.Run();
     CHECK(again.is_success());
+    std::map<int32_t, Row> second;
+    if (again.is_success()) CHECK(Drain(again.get(), &second));
+    CHECK(second.size() == got.size());
+    for (auto& kv : got) { auto it = second.find(kv.first); CHECK(it != second.end() && it->second.sv == kv.second.sv && it->second.mx == kv.second.mx && it->second.n == kv.second.n); }
   }
   {
     std::unique_ptr<Operation> plain(GroupAggregate(ProjectNamedAttribute("k"), Spec(), nullptr, shard()));
@@ -122,6 +126,74 @@ int main(int argc, char** argv) {
     CHECK(c.is_failure());
     if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_MEMORY_EXCEEDED);
     CHECK(small.largest_table() == 257);
+  }
+  {  // DOUBLE sums across shards stay exact where the exact sum is representable (<= 1 ULP in general): two shards of ONE device
+     // meet in this process like two ranks.  Group g: shard 0 holds 1e16 and 101 ones (its exact sum 1e16 + 101 is not a
+     // double: the ROUNDED partial is 1e16 + 100 or + 102), shard 1 holds -1e16 and 100 ones.  Exact total: 201.  Adding the
+     // shards' rounded sums gives 200 or 202; the (SUM, SUM_RESIDUAL) pairs give 201.
+    const int G = 300, PER0 = 102, PER1 = 101;
+    std::vector<int32_t> k0, k1; std::vector<double> x0, x1;
+    for (int g = 0; g < G; ++g) {
+      for (int i = 0; i < PER0; ++i) { k0.push_back(g); x0.push_back(i == 0 ? 1e16 : 1.0); }
+      for (int i = 0; i < PER1; ++i) { k1.push_back(g); x1.push_back(i == 0 ? -1e16 : 1.0); }
+    }
+    TupleSchema s2;
+    s2.add_attribute(Attribute("k", INT32, NOT_NULLABLE)); s2.add_attribute(Attribute("x", DOUBLE, NOT_NULLABLE));
+    View v0(s2), v1(s2);
+    v0.mutable_column(0)->Reset(k0.data(), nullptr); v0.mutable_column(1)->Reset(x0.data(), nullptr); v0.set_row_count(k0.size());
+    v1.mutable_column(0)->Reset(k1.data(), nullptr); v1.mutable_column(1)->Reset(x1.data(), nullptr); v1.set_row_count(k1.size());
+    for (int form = 0; form < 2; ++form) {
+      std::vector<Operation*> shards;
+      shards.push_back(ScanView(v0)); shards.push_back(ScanView(v1));
+      ShardedGroupAggregate job({"k"}, (new AggregationSpecification)->AddAggregation(SUM, "x", "sx")->AddAggregation(COUNT, "", "n"), shards, 512,
+                                form ? ShardedGroupAggregate::KEY_RANGE : ShardedGroupAggregate::ALL_GATHER);
+      FailureOrOwned<Cursor> c = job.Run();
+      CHECK(c.is_success());
+      if (c.is_failure()) { printf("two-shard run failed: %s\n", c.exception().message().c_str()); return 1; }
+      CHECK(c->schema().attribute_count() == 3);                       // the residual column is projected away
+      int groups = 0, exact = 0;
+      for (;;) {
+        ResultView r = c->Next(-1);
+        if (!r.has_data()) { CHECK(r.is_eos()); break; }
+        for (rowcount_t i = 0; i < r.view().row_count(); ++i, ++groups) {
+          if (r.view().column(1).typed_data<DOUBLE>()[i] == 201.0) ++exact;
+          CHECK(r.view().column(2).typed_data<UINT64>()[i] == static_cast<uint64>(PER0 + PER1));
+        }
+      }
+      CHECK(groups == G);
+      CHECK(exact == G);                                                // every cross-shard sum is the exact one
+      if (exact != G) printf("cross-shard DOUBLE sums: %d of %d exact (form %d)\n", exact, G, form);
+    }
+  }
+  {  // the headline's shape at N > 1: ShardedScalarAggregate (partial run -> ONE all-gather of the state -> fold + emit) on the
+     // one-rank communicator, against the plain single-process cursor; stepped twice on the same bound plan
+    auto scalar_child = [&]() {
+      return Filter(Greater(NamedAttribute("a"), ConstInt64(299)), ProjectAllAttributes(),
+                    Compute((new CompoundExpression)->Add(NamedAttribute("a"))->AddAs("s", Plus(NamedAttribute("a"), NamedAttribute("v")))->Add(NamedAttribute("d")), ScanView(view)));
+    };
+    auto scalar_spec = []() {
+      return (new AggregationSpecification)->AddAggregation(SUM, "s", "sum_s")->AddAggregation(COUNT, "", "cnt")->AddAggregation(MIN, "d", "min_d")
+          ->AddAggregation(SUM, "d", "sum_d")->AddAggregation(LAST, "d", "last_d");
+    };
+    std::unique_ptr<Operation> plain(ScalarAggregate(scalar_spec(), scalar_child()));
+    std::unique_ptr<Cursor> pc(SucceedOrDie(plain->CreateCursor()));
+    ResultView want_row = pc->Next(-1);
+    CHECK(want_row.has_data() && want_row.view().row_count() == 1u);
+    ShardedScalarAggregate job(comm, 1, scalar_spec(), scalar_child());
+    for (int step = 0; step < 2 && want_row.has_data(); ++step) {
+      FailureOrOwned<Cursor> c = job.Run(/*global_row_offset=*/0);
+      CHECK(c.is_success());
+      if (c.is_failure()) { printf("sharded scalar run failed: %s\n", c.exception().message().c_str()); break; }
+      ResultView got_row = c->Next(-1);
+      CHECK(got_row.has_data() && got_row.view().row_count() == 1u && got_row.view().column_count() == 5);
+      if (!got_row.has_data()) break;
+      CHECK(got_row.view().column(0).typed_data<INT64>()[0] == want_row.view().column(0).typed_data<INT64>()[0]);
+      CHECK(got_row.view().column(1).typed_data<UINT64>()[0] == want_row.view().column(1).typed_data<UINT64>()[0]);
+      CHECK(got_row.view().column(2).typed_data<DOUBLE>()[0] == want_row.view().column(2).typed_data<DOUBLE>()[0]);
+      CHECK(got_row.view().column(3).typed_data<DOUBLE>()[0] == want_row.view().column(3).typed_data<DOUBLE>()[0]);
+      CHECK(got_row.view().column(4).typed_data<DOUBLE>()[0] == want_row.view().column(4).typed_data<DOUBLE>()[0]);
+      CHECK(c->Next(-1).is_eos());
+    }
   }
   ncclCommDestroy(comm);
   printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);

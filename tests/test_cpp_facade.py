@@ -40,6 +40,37 @@ def test_facade_run(facade_bin):
     _run(facade_bin, "run")
 
 
+# ---- reference-style user code against the reference's include path: tests/cpp/guide_test.cc includes ONLY
+# "supersonic/supersonic.h" and is built with -I<repo>/include (C++14, as plain as a user's build line gets) -------------
+GUIDE_SRC = os.path.join(ROOT, "tests", "cpp", "guide_test.cc")
+GUIDE_OUT = os.path.join(ROOT, "tests", "cpp", "_build", "guide_test")
+
+
+@pytest.fixture(scope="module")
+def guide_bin():
+    os.makedirs(os.path.dirname(GUIDE_OUT), exist_ok=True)
+    deps = [GUIDE_SRC, os.path.join(ROOT, "include", "ssgpu.h"), os.path.join(ROOT, "include", "supersonic_amd", "supersonic.h"),
+            os.path.join(ROOT, "include", "supersonic", "supersonic.h")]
+    if not os.path.exists(GUIDE_OUT) or any(os.path.getmtime(d) > os.path.getmtime(GUIDE_OUT) for d in deps):
+        tmp = "%s.%d.tmp" % (GUIDE_OUT, os.getpid())
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), GUIDE_SRC, "-o", tmp,
+                               "-L" + LIBDIR, "-lssgpu", "-Wl,-rpath," + LIBDIR])
+        os.replace(tmp, GUIDE_OUT)
+    return GUIDE_OUT
+
+
+def test_guide_style_program_builds_and_binds(guide_bin):
+    with open(GUIDE_SRC) as f:
+        includes = [line.strip() for line in f if line.startswith("#include \"")]
+    assert includes == ['#include "supersonic/supersonic.h"']        # the reference's umbrella header, nothing of this repository's own
+    _run(guide_bin, "bind")
+
+
+@pytest.mark.gpu
+def test_guide_style_program_runs(guide_bin):
+    _run(guide_bin, "run")
+
+
 # ---- the C++ host's multi-GPU driver (include/supersonic_amd/sharded.h): RCCL linked directly ---------------------------
 SHARDED_SRC = os.path.join(ROOT, "tests", "cpp", "sharded_test.cc")
 SHARDED_OUT = os.path.join(ROOT, "tests", "cpp", "_build", "sharded_test")

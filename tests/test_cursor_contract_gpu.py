@@ -60,6 +60,23 @@ def test_output_block_sizes(gpu_ctx, name, max_rows):
     assert got.row_count() == seen
 
 
+@pytest.mark.parametrize("name", ["scalar", "filter", "group", "sort"])
+def test_next_minus_one_returns_everything_that_is_left(gpu_ctx, name):
+    """rowcount_t is unsigned in the reference (types.h:252-256): the guide's `cursor->Next(-1)` (primer.cc:321,
+    group_sort.cc:223) asks for as many rows as the cursor has -- never a view of -1 rows, never a cursor walking backwards."""
+    op = operators(make_view(30011, nullable=True))[name]
+    want = run_both(op, gpu_ctx, ignore_order=name.startswith("group"))
+    cur = op.CreateCursor(gpu_ctx)
+    first = cur.Next(7) if want.row_count() > 7 else None          # part of the result first, then "the rest"
+    r = cur.Next(-1)
+    assert not r.is_failure(), r.exception()
+    taken = first.view().row_count() if first is not None else 0
+    assert r.view().row_count() == want.row_count() - taken and r.view().row_count() >= 1
+    assert cur.Next(-1).is_eos()
+    zero = op.CreateCursor(gpu_ctx).Next(0)                          # "between one and max_row_count rows"
+    assert not zero.is_failure() and zero.view().row_count() == 1
+
+
 def test_interrupt_before_next_and_reuse(gpu_ctx):
     op = operators(make_view(30011))["sort"]
     cur = op.CreateCursor(gpu_ctx)
