@@ -146,6 +146,20 @@ class _DevPtr(object):
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+def pmc_source(query, alg_bytes):
+    """The committed PMC pass `pmc_traffic` reads for this workload (its path relative to the repository), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            if j.get("query", "wide") == query and abs(int(j.get("algorithmic_bytes_per_launch", -1)) - int(alg_bytes)) <= int(alg_bytes) // 1000:
+                return os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def pmc_traffic(query, alg_bytes):
     """HBM bytes per launch of the stage's kernels from the committed PMC passes (profiles/rNN_pmc_<query>.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE, one pass each, on this same command; FETCH_SIZE x 2 as calibrated on known byte counts,
@@ -161,6 +175,95 @@ def pmc_traffic(query, alg_bytes):
         except (OSError, ValueError, KeyError):
             continue
     return None
+
+
+# ---- the other BASELINE configs, measured in the same process after the headline's timed region ------------------------------
+def check_group_result(torch, plan, cols, device, with_filter):
+    """checksums of checksums against torch over the same device columns (every DOUBLE is a small multiple of 0.25: exact)"""
+    dv = plan.result_device_view()
+    out_rows = dv.row_count()
+    gcol = lambda i: torch.as_tensor(_DevPtr(dv._ptrs[i][0], out_rows, "<f8"), device=device)   # noqa: E731
+    keep = (cols[0] > K_FILTER) if with_filter else None
+    sel = (lambda t: t[keep]) if keep is not None else (lambda t: t)                              # noqa: E731
+    gid = sel(cols[1].to(torch.int64) * 317 + cols[2])
+    return {"groups_match": out_rows == int((torch.bincount(gid, minlength=N_GROUPS) > 0).sum().item()),
+            "sum_of_sums_d0": float(gcol(2).sum().item()) == float(sel(cols[3]).sum().item()),
+            "sum_of_sums_d1": float(gcol(5).sum().item()) == float(sel(cols[4]).sum().item()),
+            "min_of_mins_d2": float(gcol(9).min().item()) == float(sel(cols[5]).min().item()),
+            "max_of_maxes_d3": float(gcol(13).max().item()) == float(sel(cols[6]).max().item())}, out_rows
+
+
+def check_rows_result(torch, plan, cols, device, query):
+    """Sort / materialising Filter: the result is as large as the input -- it stays in HBM and is checked there"""
+    dv = plan.result_device_view()
+    out_rows = dv.row_count()
+    col = lambda i, ts: torch.as_tensor(_DevPtr(dv._ptrs[i][0], out_rows, ts), device=device)   # noqa: E731
+    if query == "sort":
+        key = col(3, "<i8")
+        return {"sorted": bool((key[1:] >= key[:-1]).all().item()) if out_rows > 1 else True,
+                "key_sum_matches": int(key.sum().item()) == int(cols[3].sum().item()),
+                "payload_sum_matches": int(col(0, "<i8").sum().item()) == int(cols[0].sum().item())}, out_rows
+    keep = cols[0] > K_FILTER
+    return {"rows_match": out_rows == int(keep.sum().item()),
+            "first_column_matches": bool(torch.equal(col(0, "<i8"), cols[0][keep])),
+            "last_column_matches": bool(torch.equal(col(7, "<f8"), cols[7][keep]))}, out_rows
+
+
+def measure_config(ss, torch, ctx, device, query, rows, steps, wide_cols=None):
+    """One of the BASELINE configs next to the headline (group3 = configs[2], group = configs[3]'s per-GPU query, sort =
+    configs[4], filter_mat = SURVEY 8(d) Q-FILTER-mat) on this GPU: set-up until the plan's shape has settled, `steps` timed
+    steps, the stage's kernel time from the library's HIP events, the result checked on the device."""
+    global GROUP_FILTER
+    saved_filter = GROUP_FILTER
+    group = query in ("group", "group3")
+    GROUP_FILTER = query == "group"
+    try:
+        if group:
+            cols, schema = gen_group_columns(torch, rows, 42, device), group_schema(ss)
+        else:
+            cols, schema = (wide_cols if wide_cols is not None else gen_device_columns(torch, rows, 42, device)), bench_schema(ss)
+        torch.cuda.synchronize(device)
+        view = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in cols], rows)
+        plan = ss.Plan(build_group_plan(ss, view) if group else build_sort_plan(ss, view) if query == "sort" else build_filter_mat_plan(ss, view), ctx)
+
+        def settled():
+            st = ss.memory_stats()
+            return (st["device_bytes"], st["rtc_compilations"], st["rtc_disk_hits"], json.dumps(plan.stage_info(), sort_keys=True))
+        plan.run(view)
+        torch.cuda.synchronize(device)
+        for _ in range(8):
+            before = settled()
+            plan.run(view)
+            torch.cuda.synchronize(device)
+            if settled() == before:
+                break
+        for _ in range(3):
+            plan.run(view)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan.run(view)
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        kernel_ms = plan.recent_kernel_ms(256)[-steps:]
+        if group:
+            checked, out_rows = check_group_result(torch, plan, cols, device, GROUP_FILTER)
+            alg = plan.counters().algorithmic_bytes
+        else:
+            checked, out_rows = check_rows_result(torch, plan, cols, device, query)
+            alg = 128 * rows if query == "sort" else 64 * rows + 64 * out_rows
+        kms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        out = {"rows": rows, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kms, "rows_per_s": rows * steps / elapsed,
+               "algorithmic_bytes_per_row": alg / max(rows, 1), "frac": (alg / (kms / 1e3) / 1e9 / HBM_PEAK_GBS) if kms > 0 else 0.0,
+               "result_rows": out_rows, "checked": bool(all(checked.values())), "specialized_stages": plan.specialized(),
+               "traffic_source": pmc_source(query, alg)}
+        if not out["checked"]:
+            out["failed_checks"] = [k for k, v in checked.items() if not v]
+        del plan, view, cols
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        GROUP_FILTER = saved_filter
 
 
 # ---- CPU baseline: the oracle (CPU restatement of the reference's 1024-row pull model) ----------
@@ -272,6 +375,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-specialize", action="store_true",
                     help="run the interpreting pipeline kernel instead of the one specialised for the plan by runtime compilation")
     ap.add_argument("--extras", action="store_true", help="also report 1 % / 99 % selectivity and the PCIe-inclusive rate (N = 1)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1, --query wide: do not measure the other BASELINE configs (group3, group, sort, filter_mat) after the headline's timed region")
+    ap.add_argument("--config-steps", type=int, default=30, help="timed steps of each of those configs")
+    ap.add_argument("--no-regimes", action="store_true",
+                    help="distributed runs: report only the regime --scaling names, not both (weak: --rows per GPU; strong: --rows in total)")
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
@@ -331,13 +439,28 @@ def dry_run(args, world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         assert gathered.view(world, 56)[:, 0].tolist() == list(range(world))
+    # the second regime of a weak run (see main): the same loop once more, timed the same way
+    regimes = None
+    if dist.is_initialized() and args.scaling == "weak" and not args.no_regimes:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regimes = {"weak": {"rows_per_gpu": args.rows, "rows_total": args.rows * world, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "value": 0.0},
+                   "strong": {"rows_total": args.rows // world * world, "rows_per_gpu": args.rows // world, "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3, "value": 0.0}}
+        collectives //= 2
     if rank == 0:
         rows = args.rows if args.scaling == "weak" else args.rows // world
-        print(json.dumps({"metric": metric_name(args.query), "value": 0.0, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
-                          "scaling": args.scaling, "vs_baseline": None, "dtype": "int64/f64", "data": "none (dry run)", "dry_run": True,
-                          "config": {"workload": "dry run of --query %s: no kernels" % args.query, "rows_per_gpu": rows,
-                                     "collectives_per_step": collectives / max(args.steps, 1)}}), flush=True)
+        line = {"metric": metric_name(args.query), "value": 0.0, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                "scaling": args.scaling, "vs_baseline": None, "dtype": "int64/f64", "data": "none (dry run)", "dry_run": True,
+                "config": {"workload": "dry run of --query %s: no kernels" % args.query, "rows_per_gpu": rows,
+                           "collectives_per_step": collectives / max(args.steps, 1)}}
+        if regimes is not None:
+            line["regimes"] = regimes
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -469,10 +592,10 @@ def main():
 
     seg_tensors = None
 
-    def step():
+    def step(view=view, row_offset=row_offset):
         nonlocal seg_tensors
         if job is not None:
-            job.step()
+            job.step(view)
             return
         if not distributed:
             plan.run(view)
@@ -488,10 +611,9 @@ def main():
             seg_tensors = (state, gathered)
         state, gathered = seg_tensors
         # ONE collective over RCCL / xGMI (all-gather of the tiny state), then ONE kernel folds the
-        # `world` images segment by segment with each segment's operator (ssgpu_plan_fold_partials)
+        # `world` images segment by segment with each segment's operator and emits the row (ssgpu_plan_fold_finalize)
         dist.all_gather_into_tensor(gathered, state)
-        plan.fold_partials(gathered.data_ptr(), world)
-        plan.finalize()
+        plan.fold_finalize(gathered.data_ptr(), world)
 
     def barrier():
         if distributed:
@@ -550,6 +672,50 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # Both scaling regimes in ONE line: the timed region above is the regime --scaling names; the other one runs
+    # here over the same resident columns -- strong scaling of a weak run = the job of --rows rows IN TOTAL, every rank taking
+    # the first rows / N of its columns -- with the same barrier + max-over-ranks clock.  The single-GPU time of the same
+    # plan over all --rows rows, measured on this very box, gives the efficiency without a second launch of the benchmark.
+    regimes = None
+    if distributed and not args.no_regimes and args.scaling == "weak":
+        def timed(fn, k):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / k * 1e3
+        k = max(10, min(args.steps, 100))
+        regimes = {"weak": {"rows_per_gpu": rows, "rows_total": rows * world, "ms_per_step": elapsed / args.steps * 1e3, "value": total_rows_per_step * args.steps / elapsed}}
+        # the one-GPU reference: the same plan (the shard plan of a GroupAggregate job) over all --rows rows, no exchange
+        single = (lambda: job.first.run(view)) if job is not None else (lambda: plan.run(view))
+        for _ in range(3):
+            single()
+        n1_ms = timed(single, k)
+        regimes["weak"]["n1_ms_per_step"] = n1_ms
+        regimes["weak"]["efficiency_vs_n1"] = n1_ms / regimes["weak"]["ms_per_step"]
+        share = rows // world
+        if share > 0:
+            sview = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in cols], share)
+            strong_step = lambda: step(sview, rank * share)   # noqa: E731
+            for _ in range(5):
+                strong_step()
+            if job is not None:
+                while not job.check():
+                    strong_step()
+            ms = timed(strong_step, k)
+            regimes["strong"] = {"rows_total": share * world, "rows_per_gpu": share, "ms_per_step": ms, "value": share * world / (ms / 1e3),
+                                 "n1_ms_per_step": n1_ms, "efficiency_vs_n1": n1_ms / (world * ms) if world > 1 else None,
+                                 "note": "every rank takes the first rows / N of its resident columns: a job of --rows rows in total"}
+            for _ in range(3):                     # leave the plans' results as the primary regime left them (the checks below read them)
+                step()
+            if job is not None:
+                job.check()
+            barrier()
     groups_total = None
     if group:
         groups_total = (job.result()[0] if job is not None else plan).fetch().row_count()
@@ -560,37 +726,11 @@ def main():
 
     group_checked = None
     if group and job is None:
-        # checksums of checksums against torch over the same device columns (every DOUBLE is a small multiple of 0.25: exact)
-        dv = plan.result_device_view()
-        out_rows = dv.row_count()
-        gcol = lambda i: torch.as_tensor(_DevPtr(dv._ptrs[i][0], out_rows, "<f8"), device=device)   # noqa: E731
-        keep = (cols[0] > K_FILTER) if GROUP_FILTER else None
-        sel = (lambda t: t[keep]) if keep is not None else (lambda t: t)                              # noqa: E731
-        gid = sel(cols[1].to(torch.int64) * 317 + cols[2])
-        group_checked = {"groups_match": out_rows == int((torch.bincount(gid, minlength=N_GROUPS) > 0).sum().item()),
-                         "sum_of_sums_d0": float(gcol(2).sum().item()) == float(sel(cols[3]).sum().item()),
-                         "sum_of_sums_d1": float(gcol(5).sum().item()) == float(sel(cols[4]).sum().item()),
-                         "min_of_mins_d2": float(gcol(9).min().item()) == float(sel(cols[5]).min().item()),
-                         "max_of_maxes_d3": float(gcol(13).max().item()) == float(sel(cols[6]).max().item())}
-        del gid, keep
+        group_checked, _rows = check_group_result(torch, plan, cols, device, GROUP_FILTER)
         if not all(group_checked.values()):
             raise SystemExit("bench.py --query %s: the device result failed its check: %r" % (QUERY_NAME, group_checked))
     if args.query in ("sort", "filter_mat"):
-        # the result is as large as the input: it stays in HBM; check it there (never copied to the host)
-        dv = plan.result_device_view()
-        out_rows = dv.row_count()
-        col = lambda i, ts: torch.as_tensor(_DevPtr(dv._ptrs[i][0], out_rows, ts), device=device)   # noqa: E731
-        if args.query == "sort":
-            key = col(3, "<i8")
-            checked = {"sorted": bool((key[1:] >= key[:-1]).all().item()) if out_rows > 1 else True,
-                       "key_sum_matches": int(key.sum().item()) == int(cols[3].sum().item()),
-                       "payload_sum_matches": int(col(0, "<i8").sum().item()) == int(cols[0].sum().item())}
-        else:
-            keep = cols[0] > K_FILTER
-            checked = {"rows_match": out_rows == int(keep.sum().item()),
-                       "first_column_matches": bool(torch.equal(col(0, "<i8"), cols[0][keep])),
-                       "last_column_matches": bool(torch.equal(col(7, "<f8"), cols[7][keep]))}
-            del keep
+        checked, out_rows = check_rows_result(torch, plan, cols, device, args.query)
         if not all(checked.values()):
             raise SystemExit("bench.py --query %s: the device result failed its check: %r" % (args.query, checked))
         result = None
@@ -636,6 +776,7 @@ def main():
                        "specialized_stages": plan.specialized()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(QUERY_NAME, alg_bytes),
+                         "traffic_source": pmc_source(QUERY_NAME, alg_bytes),    # `traffic` is read from this committed PMC pass, not counted in this run
                          "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_row": alg_bytes / max(rows, 1)},
             "result_row": result_row,
@@ -643,6 +784,17 @@ def main():
         if job is not None:
             line["config"]["collectives_per_step"] = job.collectives
             line["config"]["image_capacity_rows"] = job.capacity
+        if regimes is not None:
+            line["regimes"] = regimes
+        if world == 1 and not distributed and args.query == "wide" and QUERY_NAME == "wide" and not args.no_configs:
+            # the other BASELINE configs on the SAME box, after the headline's timed region (its value, ms_per_step and roofline are
+            # untouched): config #3 (group3), config #4's per-GPU query (group), config #5 (sort), the materialising Filter
+            line["configs"] = {}
+            for q in ("group3", "group", "sort", "filter_mat"):
+                try:
+                    line["configs"][q] = measure_config(ss, torch, ctx, device, q, rows, args.config_steps, wide_cols=cols)
+                except Exception as e:   # noqa: BLE001 -- the headline line must survive a failing extra
+                    line["configs"][q] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.extras and args.query == "wide":
             line["extras"] = extras(ss, torch, ctx, device, rows, cols, view)
         if world == 1 and not args.no_cpu_baseline:

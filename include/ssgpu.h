@@ -320,9 +320,11 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
  *                           part_rec_align, lazy_feedback (0 = a GroupAggregate reads its overflow / feedback words at the end of EVERY run --
  *                           one stream synchronise per run -- instead of leaving them to the next touch of the result; see ssgpu_plan_run)
+ *   stage hand-off:         async_handoff (0 = the row count of every intermediate result is read on the host before the next stage is launched;
+ *                           default 1: a filter-less Compute / Project stage takes it from the device, no stream synchronise in between)
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),
  *                           sort_hi_digits (2..4, 0 = by row count), sort_compact (0 = (key, row id) pairs instead of one
- *                           (high half | row id) word)
+ *                           (high half | row id) word), sort_bucketed (0 = payload records packed in row order, never partitioned by the key's top digit)
  *   measurement:            profile, profile_total (HIP events around the stage kernels / the run: ssgpu_plan_counters,
  *                           ssgpu_plan_recent_kernel_ms), debug_timing
  *   development only (results may be WRONG): part_scatter_debug, part_agg_debug */
@@ -472,7 +474,7 @@ typedef struct ssgpu_stage_info {
   int32_t reruns;           /* attempts the last run needed beyond the first (regrown table, segments or partitions) */
   int32_t sort_passes;      /* radix passes of the last run */
   int32_t sort_mode;        /* 0 LSD over the varying digits, 1 high digits + tie fix-up, 2 one-word (high half | row id) keys;
-                               +16: tie runs were too long and all digits were sorted after all */
+                               +16: tie runs were too long and all digits were sorted after all; +32: payload records in key-bucket order */
   int32_t specialized;      /* bit 0 the stage's program, bit 1 the partition-scatter program, bit 2 the partition aggregation,
                                bit 3 the plain partition scatter, bit 4 the resident group aggregation */
   int32_t plain_scatter;    /* the partition scatter ran as its own kernel over (partition, XCD) segments, not as a VM program */
@@ -538,6 +540,10 @@ int32_t ssgpu_plan_partial_segments(ssgpu_plan* plan, ssgpu_partial_segment* out
  * an element-wise all-reduce cannot express). */
 int ssgpu_plan_fold_partials(ssgpu_plan* plan, const void* images, int32_t n_images);
 int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
+/* ssgpu_plan_fold_partials + ssgpu_plan_finalize as ONE kernel launch (ABI 6): what follows the collective of a sharded scalar
+ * aggregate is a few hundred bytes of work -- three dependent launches of it cost a measurable part of a step at the shard
+ * sizes of an 8-GPU job (12.5 M rows: 0.13 ms of scan).  Same result as the two calls. */
+int ssgpu_plan_fold_finalize(ssgpu_plan* plan, const void* images, int32_t n_images, ssgpu_result** out);
 
 /* ---- result images: the ONE-collective exchange of materialised results ----------------------
  * Multi-GPU GroupAggregate over row-range shards (the reference documents the same

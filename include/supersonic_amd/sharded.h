@@ -8,7 +8,7 @@
 // ShardedScalarAggregate (the headline query, Filter -> Compute -> ScalarAggregate):
 //   the shard's rows up to the partial-aggregate state           ssgpu_plan_run_partial
 //   -> ONE ncclAllGather of the state (a few hundred bytes)       RCCL over xGMI
-//   -> ONE kernel folds the `world` states and emits the row      ssgpu_plan_fold_partials + ssgpu_plan_finalize
+//   -> ONE kernel folds the `world` states and emits the row      ssgpu_plan_fold_finalize
 //
 // ShardedGroupAggregate:
 //   per-shard GroupAggregate (the caller's pipeline)            RunOnDevice()

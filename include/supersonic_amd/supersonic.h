@@ -800,8 +800,7 @@ class DeviceCursor : public Cursor {
   }
   // ... and, after the caller has gathered every rank's state (n_images consecutive copies, device memory), fold and emit.
   int FinalizePartial(const void* gathered_state, int32_t n_images) {
-    int rc = ssgpu_plan_fold_partials(plan_, gathered_state, n_images);
-    if (rc == SSGPU_OK) rc = ssgpu_plan_finalize(plan_, &res_);
+    int rc = ssgpu_plan_fold_finalize(plan_, gathered_state, n_images, &res_);   // fold + state -> slots + emit: one launch
     ran_ = true; run_rc_ = rc; fetched_ = false; failed_ = false; pos_ = 0;
     return rc;
   }

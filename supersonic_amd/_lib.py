@@ -173,6 +173,7 @@ SYMBOLS = [
     ("ssgpu_plan_partial_segments", C.c_int32, [P, C.POINTER(PartialSegment), C.c_int32]),
     ("ssgpu_plan_fold_partials", C.c_int, [P, P, C.c_int32]),
     ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
+    ("ssgpu_plan_fold_finalize", C.c_int, [P, P, C.c_int32, C.POINTER(P)]),
     ("ssgpu_plan_image_layout", C.c_int, [P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("ssgpu_result_pack_image", C.c_int, [P, C.c_int64, P]),
     ("ssgpu_result_route_images", C.c_int, [P, C.c_int32, C.c_int32, C.c_int64, P]),

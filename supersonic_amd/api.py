@@ -1200,6 +1200,14 @@ class Plan(object):
         self._result = res
         return res
 
+    def fold_finalize(self, images_ptr, n_images):
+        """fold_partials + finalize as ONE kernel launch (ssgpu_plan_fold_finalize): the step of a sharded scalar aggregate
+        after its collective."""
+        res = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_plan_fold_finalize(self.handle, C.c_void_p(images_ptr), n_images, C.byref(res)))
+        self._result = res
+        return res
+
     def write_file(self, path, res=None):
         """FileOutput(path)->Write(result view): the finished result in the reference's file format."""
         rs = self.result_schema

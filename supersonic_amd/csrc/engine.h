@@ -154,7 +154,7 @@ struct Stage {
     bool ok = false;
     struct Key { int col; uint32_t width, shift, bits, nullbit; bool nullable; };
     struct Field { int col; bool is_null_mask; uint32_t width, off; };
-    struct Pred { int col; int kind /* 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64 */; int cmp /* 0 <, 1 <=, 2 ==, 3 != */; bool col_on_left; bool nullable; uint64_t bits; };
+    struct Pred { int col; int kind /* 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64, 6 one byte (BOOL) */; int cmp /* 0 <, 1 <=, 2 ==, 3 != */; bool col_on_left; bool nullable; uint64_t bits; };
     std::vector<Key> keys; std::vector<Field> fields; std::vector<Pred> preds;
   } plain;
   std::vector<JoinSpec> joins;            // HashJoins fused into this stage's programs

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void ssgpu_route_copy_kernel(const ImagePackPa
     for (u32 f = 0; f < P.n_flags; ++f) err |= (u64)(*P.error_flags[f] & 0xFFu);   // (as in ssgpu_pack_image_kernel)
     h[0] = have < P.capacity ? have : P.capacity; h[1] = P.capacity; h[2] = (have > P.capacity || retry) ? 1ull : 0ull; h[3] = have;
     h[4] = err; h[5] = 0; h[6] = 0; h[7] = 0;
+    R.counters[d] = 0u;   // nobody else reads the counters in this launch: left clear for the next routing (no per-step fill launch)
   }
   const ImagePiece pc = P.pieces[blockIdx.y];
   const u32 w = pc.width;
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(256) void ssgpu_route_copy_kernel(const ImagePackPa
   }
 }
 hipError_t ssgpu_launch_route_images(const ImagePackParams& P, const ImageRoutePieces& R, hipStream_t s) {
-  // dest_pos scratch lives behind the counters (the caller sized it: n_dest + 2 * capacity_in words)
-  u32* dest_pos = R.counters + ((R.n_dest + 3u) & ~3u);
+  // dest_pos scratch lives behind the counters (the caller sized it: 256 + 2 * capacity_in words)
+  u32* dest_pos = R.counters + 256;   // (n_dest <= 256: a fixed head, so that the counters a routing leaves clear stay clear whatever the next n_dest)
   const u64 rows_max = P.rows_dev ? P.rows_host : P.rows_host;   // (rows_host carries the upper bound of the row count when rows_dev is given)
   const unsigned bx = (unsigned)std::min<u64>(std::max<u64>((rows_max + 255) / 256, 1), 512);
   hipLaunchKernelGGL(ssgpu_route_rows_kernel, dim3(bx), dim3(256), 0, s, P, R, dest_pos);

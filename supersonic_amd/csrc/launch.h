@@ -35,6 +35,7 @@ struct GroupExtractParams {
   uint32_t n_gaggs;
   uint32_t n_keys;
   uint32_t n_aggs_out;
+  uint32_t extra_slots;   /* occupied-or-empty slots behind the special one: capacity + 1 .. capacity + extra_slots (the heavy hitters' dense slots) */
   const unsigned int* tile_offsets;
   GroupKeyOut keys_out[16];
   GroupAggOut aggs_out[VM_MAX_AGG_SLOTS];
@@ -63,6 +64,10 @@ struct PartAggParams {
   // NULL (40-47) | contribution count tracked (48)
   unsigned long long desc[VM_MAX_AGG_SLOTS];
   unsigned int* nan_flag;             // the stage's error word: SSGPU_FLAG_NAN_IN_MINMAX is set when a NaN reaches a floating MIN / MAX
+  // Heavy hitters (resident form only): the table is seeded with the row source's hot_keys and takes NO other key -- rows of
+  // every other key are skipped (they go through the partition scatter, which in turn skips the hot ones) -- and entry e is
+  // merged into global slot hot_base + e (dense slots behind the partitions' ranges) instead of a hashed slot.
+  unsigned int hot_only, hot_base;
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
 
@@ -77,6 +82,8 @@ hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes,
 #define SSGPU_PSCAT_MAX_KEYS 8
 #define SSGPU_PSCAT_MAX_FIELDS 24
 #define SSGPU_PSCAT_MAX_PREDS 4
+#define SSGPU_HOT_MAX 16     /* heavy-hitter keys a stage handles apart from the hash partitions */
+#define SSGPU_HOT_SLOTS 64   /* entries of the heavy hitters' LDS table = dense global slots reserved for them */
 struct PlainScatterParams {
   unsigned long long n_rows;
   unsigned int n_parts, seg_cap, rec_words, rec_inv;   // rec_inv = floor(2^32 / rec_words) + 1
@@ -87,7 +94,14 @@ struct PlainScatterParams {
   unsigned long long* recs;     // n_parts * SSGPU_PSCAT_XCDS segments of seg_cap records
   unsigned int* counts;         // [n_parts * SSGPU_PSCAT_XCDS] records appended to each segment; zero at launch
   unsigned int* overflow;       // set when a segment ran full
+  // heavy hitters: rows whose packed key is one of these are NOT scattered (ssgpu_group_resident_kernel, hot_only, aggregates them)
+  unsigned int n_hot, hot_pad;
+  unsigned long long hot_keys[SSGPU_HOT_MAX];
 };
+// Heavy-hitter detection: one workgroup counts the packed keys of `n_sample` rows taken at a regular stride (predicates
+// applied) and reports the keys seen at least `min_count` times -- at most SSGPU_HOT_MAX, the most frequent ones.
+// out[0] = number of keys, out[1 + 2 i] = key i, out[2 + 2 i] = its count in the sample.
+hipError_t ssgpu_launch_hot_keys(const PlainScatterParams& S, unsigned long long n_sample, unsigned int min_count, unsigned long long* out, hipStream_t stream);
 hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid, hipStream_t stream);
 // GroupAggregateOptions::max_unique_keys_in_result, last step (group_scatter_kernel.hip): one workgroup per column copies rows
 // [0, min(n_in, limit + 1)) and merges every row beyond `limit` into row `limit` (op: 0 keep, 1 sum, 2 min, 3 max; kind:
@@ -135,7 +149,7 @@ struct GroupInitParams {
   unsigned long long* keys; unsigned long long n_keys;
   unsigned long long* acc; const unsigned long long* pattern; unsigned int ng; unsigned long long n_acc;
   unsigned int* cnt; unsigned long long n_cnt;
-  unsigned int* z[3]; unsigned long long nz[3];
+  unsigned int* z[4]; unsigned long long nz[4];
 };
 hipError_t ssgpu_launch_group_init(const GroupInitParams& P, hipStream_t stream);
 
@@ -163,15 +177,19 @@ void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compi
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
-                                     VmAccRec* out, hipStream_t stream);
+                                     VmAccRec* out, uint64_t* state /* NULL, or the reducible state of a partial run */, hipStream_t stream);
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state,
                                        hipStream_t stream);
 hipError_t ssgpu_launch_fold_state(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, hipStream_t stream);
+hipError_t ssgpu_launch_fold_emit(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs,
+                                  const EmitDesc* descs, int n_out, hipStream_t stream);
 hipError_t ssgpu_launch_state_to_slots(const uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs,
                                        hipStream_t stream);
 hipError_t ssgpu_launch_emit_scalar(const VmAccRec* recs, const EmitDesc* descs, int n_out, hipStream_t stream);
 hipError_t ssgpu_launch_scan_counts(const uint32_t* in, uint32_t* out, int n, uint64_t* total, hipStream_t stream);
 hipError_t ssgpu_launch_group_count(const GroupExtractParams& P, uint32_t* tile_counts, hipStream_t stream);
+// count + scan + extract in one launch (decoupled look-back over ticket-ordered 512-slot tiles); ctrl = [rows u64][ticket u32][gave-up u32], zero at launch
+hipError_t ssgpu_launch_group_extract_lb(const GroupExtractParams& P, unsigned long long* status, uint64_t epoch, unsigned int* ctrl, unsigned int* error_flag, hipStream_t stream);
 hipError_t ssgpu_launch_group_extract(const GroupExtractParams& P, hipStream_t stream);
 hipError_t ssgpu_launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t stream);
 hipError_t ssgpu_launch_fill_pattern_u64(uint64_t* p, const uint64_t* pattern, uint32_t plen, size_t n,
@@ -197,6 +215,10 @@ struct SortRecField { const void* src; void* dst; unsigned int off, width; };   
 struct SortRecParams { void* recs; unsigned long long n; unsigned int stride, n_fields; SortRecField fields[SSGPU_SORT_MAX_FIELDS]; };
 hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s);
 hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s);
+// the pack pass as a stable partition of the records by the key's top digit (see ssgpu_sort_partition_pack_kernel)
+uint32_t ssgpu_sort_partition_rows(uint32_t stride);
+hipError_t ssgpu_launch_sort_partition_pack(const SortRecParams& P, const uint64_t* keys, uint64_t* words, uint64_t* keys_part, const uint32_t* digit_base,
+                                            unsigned long long* status, uint32_t* ticket, uint64_t epoch, uint32_t* stuck, hipStream_t s);
 hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s);
 hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s);
 // View-file loader: one piece = one column (or NULL-mask) segment of one file chunk inside a staged slab

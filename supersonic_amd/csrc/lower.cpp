@@ -1544,6 +1544,10 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     }
     for (size_t q = 0; pl.ok && q < pipe.filters.size(); ++q) {
       const BExprP& e = pipe.filters[q];
+      if (e->kind == BExpr::INPUT && mtype(e->dtype) == M_B8) {   // a BOOL column as the predicate itself (e.g. the validity column of unpacked result images): column != FALSE
+        pl.preds.push_back(Stage::PlainScatter::Pred{e->input_col, (int)M_B8, 3, true, e->nullable, 0});
+        continue;
+      }
       if (e->kind != BExpr::OP || e->args.size() != 2 || !(e->op == OP_LESS || e->op == OP_LESS_OR_EQUAL || e->op == OP_EQUAL || e->op == OP_NOT_EQUAL)) { pl.ok = false; break; }
       const bool col_left = e->args[0]->kind == BExpr::INPUT && e->args[1]->kind == BExpr::CONST;
       const bool col_right = e->args[1]->kind == BExpr::INPUT && e->args[0]->kind == BExpr::CONST;

@@ -506,9 +506,9 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
     _Pragma("unroll") FOR_PAIRS {                                              \
       i64 r0 = tile_base + 2 * (i64)p;                                         \
       auto vv = fetch2<T>(I.a, I.a_mask, p);                             \
-      if (r0 + 1 < P.n_rows) {                                                 \
+      if (r0 + 1 < vm_n_rows) {                                                \
         *reinterpret_cast<typename Vec2<T>::type*>(out + r0) = vv;             \
-      } else if (r0 < P.n_rows) {                                              \
+      } else if (r0 < vm_n_rows) {                                             \
         out[r0] = vv.x;                                                        \
       }                                                                        \
     }                                                                          \
@@ -660,7 +660,15 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   const int lane = t & 63;
   const int wave = t >> 6;
   const int tile_rows = VM_TILE_UNIT * K;
-  const int n_my_tiles = P.n_tiles > (int)blockIdx.x ? (P.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  // the input's row count: a kernel argument, or -- for a stage that runs straight behind the stage that produces its input,
+  // without the host reading the count in between -- a device word written by that stage (the argument is then an upper bound)
+  i64 vm_n_rows = P.n_rows; int vm_n_tiles = P.n_tiles;
+  if (P.n_rows_dev) {
+    const u64 have = *P.n_rows_dev;
+    vm_n_rows = have < (u64)P.n_rows ? (i64)have : P.n_rows;
+    vm_n_tiles = (int)((vm_n_rows + tile_rows - 1) / tile_rows);
+  }
+  const int n_my_tiles = vm_n_tiles > (int)blockIdx.x ? (vm_n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int n_units = STAGED_COUNT(P) * K;
 
   // zero this workgroup's LDS aggregate records (slow slots; fast slots are written once)
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   const int n_pf = n_units < VM_PF_UNITS ? n_units : VM_PF_UNITS;
   {
     const i64 tb = (i64)blockIdx.x * tile_rows;
-    if (n_my_tiles > 0 && tb + tile_rows <= P.n_rows) {
+    if (n_my_tiles > 0 && tb + tile_rows <= vm_n_rows) {
 #pragma unroll
       for (int u = 0; u < VM_PF_UNITS; ++u)
         if (u < n_pf) load_unit<K>(P, u, tb, t, pf[u]);
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   for (int it = 0; it < n_my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const i64 tile_base = (i64)tile * tile_rows;
-    const u32 tile_valid = (u32)((P.n_rows - tile_base) < (i64)tile_rows ? (P.n_rows - tile_base) : (i64)tile_rows);
+    const u32 tile_valid = (u32)((vm_n_rows - tile_base) < (i64)tile_rows ? (vm_n_rows - tile_base) : (i64)tile_rows);
     const u64 tw0 = (P.debug || P.debug_pc) ? __builtin_amdgcn_s_memtime() : 0;
     // A wave that is about to commit its tile and put the next tile's loads in flight is issued ahead of
     // waves in the middle of their program: the sooner the loads leave, the more of HBM's latency they hide
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     // ... and put the next tile's loads in flight before the program runs over this one
     {
       const i64 tb = tile_base + (i64)gridDim.x * tile_rows;
-      if (it + 1 < n_my_tiles && tb + tile_rows <= P.n_rows) {
+      if (it + 1 < n_my_tiles && tb + tile_rows <= vm_n_rows) {
         // launder the thread id: otherwise the per-unit lane offsets are hoisted out of the
         // tile loop as 64-bit VGPR pairs and spilled (scratch reloads between the loads)
         int tl = t;
@@ -912,9 +920,51 @@ __device__ __forceinline__ void combine_rec(int kind, VmAccRec& acc, const VmAcc
 // One workgroup per slot: thread t folds records t, t+256, ... in order, then a fixed
 // LDS tree folds the 256 thread results.  The shape is fixed, so results are reproducible
 // run to run (and exact whenever the partial sums are exact).
+// Reducible-state <-> slot records for the multi-GPU exchange.  The state is
+// eight u64 arrays of n_slots elements: [sum_i64 | cnt | dd_hi | dd_lo | min_u64 |
+// max_u64 | min_f64 | max_f64], each combined across ranks by one element-wise
+// all-reduce (sum / sum / sum / sum / min / max / min / max).
+__device__ __forceinline__ void slot_to_state(const VmAccRec r, int kind, int s, int n_slots, u64* __restrict__ state) {
+  u64* sum_i = state; u64* cnt = state + n_slots; u64* hi = state + 2 * n_slots; u64* lo = state + 3 * n_slots;
+  u64* mn = state + 4 * n_slots; u64* mx = state + 5 * n_slots;
+  u64* mnf = state + 6 * n_slots; u64* mxf = state + 7 * n_slots;
+  const bool fl = kind == SLOT_FIRST || kind == SLOT_LAST;   // value in the sum array, row id in the min / max array
+  sum_i[s] = (kind == SLOT_SUM_INT || kind == SLOT_COUNT || fl) ? r.v0 : 0;
+  cnt[s] = r.cnt;
+  hi[s] = kind == SLOT_SUM_DD ? r.v0 : d2u(0.0);
+  lo[s] = kind == SLOT_SUM_DD ? r.v1 : d2u(0.0);
+  // signed-order view so that an int64 all-reduce min/max is order-correct for u64 keys
+  mn[s] = (kind == SLOT_MIN_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : (kind == SLOT_FIRST && r.cnt) ? (r.v1 ^ 0x8000000000000000ull) : 0x7FFFFFFFFFFFFFFFull;
+  mx[s] = (kind == SLOT_MAX_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : (kind == SLOT_LAST && r.cnt) ? (r.v1 ^ 0x8000000000000000ull) : 0x8000000000000000ull;
+  mnf[s] = (kind == SLOT_MIN_F64 && r.cnt) ? r.v0 : d2u(__builtin_inf());
+  mxf[s] = (kind == SLOT_MAX_F64 && r.cnt) ? r.v0 : d2u(-__builtin_inf());
+}
+__device__ __forceinline__ VmAccRec state_to_slot(const u64* __restrict__ state, int kind, int s, int n_slots) {
+  VmAccRec r; r.v0 = 0; r.v1 = 0; r.pad = 0;
+  r.cnt = state[n_slots + s];
+  switch (kind) {
+    case SLOT_COUNT: case SLOT_SUM_INT: r.v0 = state[s]; break;
+    case SLOT_SUM_DD: {
+      // the ranks' hi and lo parts were summed independently; renormalise
+      DD a; a.hi = u2d(state[2 * n_slots + s]); a.lo = 0.0;
+      a = dd_add_d(a, u2d(state[3 * n_slots + s]));
+      r.v0 = d2u(a.hi); r.v1 = d2u(a.lo);
+    } break;
+    case SLOT_MIN_U64: r.v0 = state[4 * n_slots + s] ^ 0x8000000000000000ull; break;
+    case SLOT_MAX_U64: r.v0 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
+    case SLOT_MIN_F64: r.v0 = state[6 * n_slots + s]; break;
+    case SLOT_MAX_F64: r.v0 = state[7 * n_slots + s]; break;
+    case SLOT_FIRST: r.v0 = state[s]; r.v1 = state[4 * n_slots + s] ^ 0x8000000000000000ull; break;
+    case SLOT_LAST: r.v0 = state[s]; r.v1 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
+    default: break;
+  }
+  return r;
+}
+
+// `state` (may be NULL): a partial run (multi-GPU) leaves the slot's reducible state next to its record -- one launch less.
 __global__ __launch_bounds__(256) void ssgpu_finish_slots_kernel(const VmAccRec* __restrict__ partials, int n_slots,
                                                                  int n_parts, const int* __restrict__ slot_kind,
-                                                                 VmAccRec* __restrict__ out) {
+                                                                 VmAccRec* __restrict__ out, u64* __restrict__ state) {
   __shared__ VmAccRec tree[256];
   const int s = blockIdx.x, t = threadIdx.x;
   const int kind = slot_kind[s];
@@ -930,57 +980,20 @@ __global__ __launch_bounds__(256) void ssgpu_finish_slots_kernel(const VmAccRec*
     if (t < stride) { VmAccRec a = tree[t]; combine_rec(kind, a, tree[t + stride]); tree[t] = a; }
     __syncthreads();
   }
-  if (t == 0) out[s] = tree[0];
+  if (t == 0) { out[s] = tree[0]; if (state) slot_to_state(tree[0], kind, s, n_slots, state); }
 }
 
-// Reducible-state <-> slot records for the multi-GPU exchange.  The state is
-// eight u64 arrays of n_slots elements: [sum_i64 | cnt | dd_hi | dd_lo | min_u64 |
-// max_u64 | min_f64 | max_f64], each combined across ranks by one element-wise
-// all-reduce (sum / sum / sum / sum / min / max / min / max).
 __global__ void ssgpu_slots_to_state_kernel(const VmAccRec* __restrict__ recs, int n_slots,
                                             const int* __restrict__ slot_kind, u64* __restrict__ state) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
-  const VmAccRec r = recs[s];
-  const int kind = slot_kind[s];
-  u64* sum_i = state; u64* cnt = state + n_slots; u64* hi = state + 2 * n_slots; u64* lo = state + 3 * n_slots;
-  u64* mn = state + 4 * n_slots; u64* mx = state + 5 * n_slots;
-  u64* mnf = state + 6 * n_slots; u64* mxf = state + 7 * n_slots;
-  const bool fl = kind == SLOT_FIRST || kind == SLOT_LAST;   // value in the sum array, row id in the min / max array
-  sum_i[s] = (kind == SLOT_SUM_INT || kind == SLOT_COUNT || fl) ? r.v0 : 0;
-  cnt[s] = r.cnt;
-  hi[s] = kind == SLOT_SUM_DD ? r.v0 : d2u(0.0);
-  lo[s] = kind == SLOT_SUM_DD ? r.v1 : d2u(0.0);
-  // signed-order view so that an int64 all-reduce min/max is order-correct for u64 keys
-  mn[s] = (kind == SLOT_MIN_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : (kind == SLOT_FIRST && r.cnt) ? (r.v1 ^ 0x8000000000000000ull) : 0x7FFFFFFFFFFFFFFFull;
-  mx[s] = (kind == SLOT_MAX_U64 && r.cnt) ? (r.v0 ^ 0x8000000000000000ull) : (kind == SLOT_LAST && r.cnt) ? (r.v1 ^ 0x8000000000000000ull) : 0x8000000000000000ull;
-  mnf[s] = (kind == SLOT_MIN_F64 && r.cnt) ? r.v0 : d2u(__builtin_inf());
-  mxf[s] = (kind == SLOT_MAX_F64 && r.cnt) ? r.v0 : d2u(-__builtin_inf());
+  slot_to_state(recs[s], slot_kind[s], s, n_slots, state);
 }
 __global__ void ssgpu_state_to_slots_kernel(const u64* __restrict__ state, int n_slots,
                                             const int* __restrict__ slot_kind, VmAccRec* __restrict__ recs) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
-  const int kind = slot_kind[s];
-  VmAccRec r; r.v0 = 0; r.v1 = 0; r.pad = 0;
-  r.cnt = state[n_slots + s];
-  switch (kind) {
-    case SLOT_COUNT: case SLOT_SUM_INT: r.v0 = state[s]; break;
-    case SLOT_SUM_DD: {
-      // the all-reduce summed hi and lo parts independently; renormalise
-      DD a; a.hi = u2d(state[2 * n_slots + s]); a.lo = 0.0;
-      a = dd_add_d(a, u2d(state[3 * n_slots + s]));
-      r.v0 = d2u(a.hi); r.v1 = d2u(a.lo);
-    } break;
-    case SLOT_MIN_U64: r.v0 = state[4 * n_slots + s] ^ 0x8000000000000000ull; break;
-    case SLOT_MAX_U64: r.v0 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
-    case SLOT_MIN_F64: r.v0 = state[6 * n_slots + s]; break;
-    case SLOT_MAX_F64: r.v0 = state[7 * n_slots + s]; break;
-    case SLOT_FIRST: r.v0 = state[s]; r.v1 = state[4 * n_slots + s] ^ 0x8000000000000000ull; break;
-    case SLOT_LAST: r.v0 = state[s]; r.v1 = state[5 * n_slots + s] ^ 0x8000000000000000ull; break;
-    default: break;
-  }
-  recs[s] = r;
+  recs[s] = state_to_slot(state, slot_kind[s], s, n_slots);
 }
 
 // Emit one aggregate result column element from its final slot record.
@@ -1006,17 +1019,19 @@ __device__ __forceinline__ void emit_value(void* dst, size_t idx, int out_kind, 
 }
 
 
-__global__ void ssgpu_emit_scalar_kernel(const VmAccRec* __restrict__ recs, const EmitDesc* __restrict__ descs,
-                                         int n_out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
-  const EmitDesc d = descs[i];
-  const VmAccRec r = recs[d.slot];
+__device__ __forceinline__ void emit_scalar_one(const EmitDesc d, const VmAccRec r) {
   if (d.out_kind == EMIT_CNT_U64 || d.out_kind == EMIT_CNT_U32)   // COUNT(*) sharing another slot's row count
     emit_value(d.data, 0, d.out_kind == EMIT_CNT_U64 ? EMIT_U64 : EMIT_U32, r.cnt, 0);
   else
     emit_value(d.data, 0, d.out_kind, r.v0, r.v1);
   if (d.is_null) d.is_null[0] = r.cnt == 0;
+}
+__global__ void ssgpu_emit_scalar_kernel(const VmAccRec* __restrict__ recs, const EmitDesc* __restrict__ descs,
+                                         int n_out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const EmitDesc d = descs[i];
+  emit_scalar_one(d, recs[d.slot]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1059,7 +1074,7 @@ __global__ __launch_bounds__(1024) void ssgpu_scan_counts_kernel(const u32* __re
 // deterministic by a count / scan / scatter over 512-slot tiles).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool group_slot_occupied(const GroupExtractParams& P, u32 slot) {
-  if (slot > P.capacity) return false;
+  if (slot > P.capacity + P.extra_slots) return false;
   // the special slot `capacity` owns the key whose value equals the EMPTY sentinel
   return P.keys[slot] != VM_KEY_EMPTY;  // the special slot holds 0 once its key was seen
 }
@@ -1076,6 +1091,43 @@ __global__ __launch_bounds__(256) void ssgpu_group_count_kernel(const GroupExtra
   if (t == 0) tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// One occupied slot of the table -> result row `row` (keys unpacked, aggregates emitted)
+__device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, u32 slot, u32 row);
+// count + scan + extract in ONE launch: tiles of 512 slots take a ticket, publish their occupied-slot count and look back
+// over the earlier tickets for their first result row (decoupled look-back, the status words stamped with the run's epoch
+// so that the buffer is never cleared).  Same row order as the three-kernel form (slot order).  ctrl = [rows u64][ticket u32]
+// [gave-up u32], zero at launch.  A GroupAggregate run used to end with three dependent small launches; at the row counts
+// of a sharded step (1e5 groups: 513 tiles) they cost more than the work.
+__global__ __launch_bounds__(256) void ssgpu_group_extract_lb_kernel(const GroupExtractParams P, unsigned long long* __restrict__ status, u64 tag,
+                                                                     unsigned int* __restrict__ ctrl, unsigned int* __restrict__ error_flag) {
+  __shared__ u32 wsum[4];
+  __shared__ u32 s_tile, s_base;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_tile = atomicAdd(ctrl + 2, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  const u32 s0 = tile * 512u + (u32)t * 2u;
+  const bool o0 = group_slot_occupied(P, s0), o1 = group_slot_occupied(P, s0 + 1);
+  const u64 b0 = __ballot(o0), b1 = __ballot(o1);
+  if (lane == 0) wsum[wave] = (u32)__popcll(b0) + (u32)__popcll(b1);
+  __syncthreads();
+  if (wave == 0) {
+    const u32 run = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const u32 excl = lookback_rows_before(status, (int)tile, run, tag, ctrl, error_flag, lane);
+    if (lane == 0) {
+      s_base = excl;
+      if (tile == gridDim.x - 1u) *reinterpret_cast<u64*>(ctrl) = (u64)excl + run;
+    }
+  }
+  __syncthreads();
+  u32 base = s_base;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const u64 lt = (1ull << lane) - 1ull;
+  const u32 r0 = base + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
+  if (o0) group_extract_slot(P, s0, r0);
+  if (o1) group_extract_slot(P, s0 + 1, r0 + (o0 ? 1u : 0u));
+}
+
 __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExtractParams P) {
   __shared__ u32 wsum[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1089,11 +1141,11 @@ __global__ __launch_bounds__(256) void ssgpu_group_extract_kernel(const GroupExt
   for (int w = 0; w < wave; ++w) base += wsum[w];
   const u64 lt = (1ull << lane) - 1ull;
   u32 r0 = base + (u32)__popcll(b0 & lt) + (u32)__popcll(b1 & lt);
-  u32 rr[2] = {r0, r0 + (o0 ? 1u : 0u)};
-  bool oo[2] = {o0, o1};
-  for (int j = 0; j < 2; ++j) {
-    if (!oo[j]) continue;
-    const u32 slot = s0 + j; const u32 row = rr[j];
+  if (o0) group_extract_slot(P, s0, r0);
+  if (o1) group_extract_slot(P, s0 + 1, r0 + (o0 ? 1u : 0u));
+}
+__device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, u32 slot, u32 row) {
+  {
     const u64 key = slot == P.capacity ? VM_KEY_EMPTY : P.keys[slot];
     for (u32 q = 0; q < P.n_keys; ++q) {
       const GroupKeyOut ko = P.keys_out[q];
@@ -1226,6 +1278,7 @@ __device__ __forceinline__ bool plain_pred(const void* data, const u8* nulls, u6
     case 2: { const i64 v = reinterpret_cast<const i64*>(data)[row], k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
     case 3: { const u64 v = reinterpret_cast<const u64*>(data)[row], k = c; lt = v < k; gt = v > k; eq = v == k; } break;
     case 4: { const float v = reinterpret_cast<const float*>(data)[row], k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    case 6: { const u8 v = reinterpret_cast<const u8*>(data)[row], k = (u8)c; lt = v < k; gt = v > k; eq = v == k; } break;   // a BOOL column as the predicate: (column != FALSE)
     default: { const double v = reinterpret_cast<const double*>(data)[row], k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
   }
   bool r;
@@ -1275,6 +1328,7 @@ __device__ __forceinline__ bool plain_pred_value(u64 raw, bool is_null, u64 c, u
     case 2: { const i64 v = (i64)raw, k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
     case 3: { const u64 v = raw, k = c; lt = v < k; gt = v > k; eq = v == k; } break;
     case 4: { const float v = __uint_as_float((u32)raw), k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    case 6: { const u8 v = (u8)raw, k = (u8)c; lt = v < k; gt = v > k; eq = v == k; } break;
     default: { const double v = u2d(raw), k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
   }
   bool r;
@@ -1309,7 +1363,7 @@ __device__ __forceinline__ void resident_issue(const PlainScatterParams& S, u64 
     const u64 rowc = R.in[j] ? row : 0ull;       // unconditional loads on a row that exists
 #pragma unroll
     for (u32 q = 0; q < kRsNPreds; ++q) {
-      R.p[j][q] = load_by_width(S.preds[q].data, (kRsPredKind[q] == 0u || kRsPredKind[q] == 1u || kRsPredKind[q] == 4u) ? 4u : 8u, rowc);
+      R.p[j][q] = load_by_width(S.preds[q].data, kRsPredKind[q] == 6u ? 1u : (kRsPredKind[q] == 0u || kRsPredKind[q] == 1u || kRsPredKind[q] == 4u) ? 4u : 8u, rowc);
       R.pn[j][q] = S.preds[q].nulls ? (u32)S.preds[q].nulls[rowc] : 0u;
     }
 #pragma unroll
@@ -1355,6 +1409,18 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   LDS_AS u32* const wsum = segoff + G + 1u;                              // [16] scan scratch
   for (u32 e = t; e <= C; e += SSGPU_PART_THREADS) lkeys[e] = VM_KEY_EMPTY;
   for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (any_cnt) lcnt[i] = 0u; }
+  if constexpr (PLAIN) {
+    if (P.hot_only) {   // heavy hitters: the table holds the hot keys and nothing else.  One thread seeds it, so every workgroup's copy is identical
+      __syncthreads();
+      if (t == 0)
+        for (u32 h = 0; h < S.n_hot; ++h) {
+          const u64 key = S.hot_keys[h];
+          u32 i = __umulhi(hash_local(key), C);
+          while (lkeys[i] != VM_KEY_EMPTY && lkeys[i] != key) i = i + 1u == C ? 0u : i + 1u;
+          lkeys[i] = key;
+        }
+    }
+  }
   u32 total = 0;
   if constexpr (!PLAIN) {
     u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)
@@ -1469,7 +1535,18 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
       const u64 key = rec[j][0];
       if (P.debug & 2u) { li[j] = __umulhi(hash_local(key), C) * st; continue; }   // development: no probe
       if (live[j]) {
-        if (key == VM_KEY_EMPTY) {
+        if (PLAIN && P.hot_only) {
+          // only the seeded keys have an entry: an EMPTY entry on the probe path means "not a heavy hitter" -- the row belongs to the scatter
+          u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
+          if (key != VM_KEY_EMPTY)
+            for (u32 probe = 0; probe < C; ++probe) {
+              const u64 cur = lkeys[i];
+              if (cur == key) { found = i; break; }
+              if (cur == VM_KEY_EMPTY) break;
+              i = i + 1u == C ? 0u : i + 1u;
+            }
+          if (found == 0xFFFFFFFFu) live[j] = false; else li[j] = found * st;
+        } else if (key == VM_KEY_EMPTY) {
           lkeys[C] = 0ull;                               // marks the reserved entry as used
         } else {
           u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
@@ -1564,7 +1641,8 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
       const u64 key = lkeys[e];
       if (key == VM_KEY_EMPTY) continue;
       u32 gs;
-      if (e == C) { gs = P.T.capacity_mask + 1u; P.T.keys[gs] = 0ull; }   // the EMPTY-valued key's reserved slot
+      if (P.hot_only) { if (e == C) continue; gs = P.hot_base + e; P.T.keys[gs] = key; }   // heavy hitters: entry e = dense slot hot_base + e (every workgroup stores the same key)
+      else if (e == C) { gs = P.T.capacity_mask + 1u; P.T.keys[gs] = 0ull; }   // the EMPTY-valued key's reserved slot
       else gs = group_insert(P.T, key);
       if (gs == 0xFFFFFFFFu) continue;                                     // global table full: flagged, the host regrows
       for (u32 s = 0; s < ng; ++s) {
@@ -1717,7 +1795,7 @@ __global__ __launch_bounds__(256) void ssgpu_group_init_kernel(const GroupInitPa
   for (u64 i = first; i < P.n_keys; i += stride) P.keys[i] = VM_KEY_EMPTY;
   for (u64 i = first; i < P.n_acc; i += stride) P.acc[i] = P.pattern[i % P.ng];
   for (u64 i = first; i < P.n_cnt; i += stride) P.cnt[i] = 0u;
-  for (int q = 0; q < 3; ++q) for (u64 i = first; i < P.nz[q]; i += stride) P.z[q][i] = 0u;
+  for (int q = 0; q < 4; ++q) for (u64 i = first; i < P.nz[q]; i += stride) P.z[q][i] = 0u;
 }
 __global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __restrict__ pattern, u32 plen, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1885,8 +1963,8 @@ hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
   return e;
 }
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
-                                     VmAccRec* out, hipStream_t stream) {
-  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(n_slots), dim3(256), 0, stream, partials, n_slots, n_parts, slot_kind, out);
+                                     VmAccRec* out, uint64_t* state, hipStream_t stream) {
+  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(n_slots), dim3(256), 0, stream, partials, n_slots, n_parts, slot_kind, out, (u64*)state);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state, hipStream_t stream) {
@@ -1899,12 +1977,18 @@ hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const 
 // counts), double sum (double-double hi / lo), signed min / max (integer extrema and row ids in
 // their sign-corrected domain), double min / max.  FIRST / LAST slots take the value of the image
 // that holds the smallest / largest contributing row id.
+__device__ __forceinline__ void fold_state_slot(const u64* __restrict__ images, int n_images, u64* __restrict__ state, int n_slots, int kind, int s);
 __global__ __launch_bounds__(64) void ssgpu_fold_state_kernel(const u64* __restrict__ images, int n_images, u64* __restrict__ state,
                                                               int n_slots, const int* __restrict__ slot_kind) {
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= n_slots) return;
+  fold_state_slot(images, n_images, state, n_slots, slot_kind[s], s);
+}
+// fold (as above) + state -> slot records + the result row, in ONE launch of one workgroup (ssgpu_plan_fold_finalize): what
+// follows the collective of a sharded scalar aggregate is a few hundred bytes of work, and three dependent launches of it
+// cost more than the 12.5 M-row scan of an 8-GPU shard is allowed to lose
+__device__ __forceinline__ void fold_state_slot(const u64* __restrict__ images, int n_images, u64* __restrict__ state, int n_slots, int kind, int s) {
   const size_t total = (size_t)SSGPU_STATE_ARRAYS * n_slots;
-  const int kind = slot_kind[s];
   u64 a[SSGPU_STATE_ARRAYS];
   for (int k = 0; k < SSGPU_STATE_ARRAYS; ++k) a[k] = images[(size_t)k * n_slots + s];
   for (int r = 1; r < n_images; ++r) {
@@ -1922,6 +2006,22 @@ __global__ __launch_bounds__(64) void ssgpu_fold_state_kernel(const u64* __restr
     a[7] = u2d(v[7]) > u2d(a[7]) ? v[7] : a[7];
   }
   for (int k = 0; k < SSGPU_STATE_ARRAYS; ++k) state[(size_t)k * n_slots + s] = a[k];
+}
+__global__ __launch_bounds__(256) void ssgpu_fold_emit_kernel(const u64* __restrict__ images, int n_images, u64* __restrict__ state, int n_slots,
+                                                              const int* __restrict__ slot_kind, VmAccRec* __restrict__ recs,
+                                                              const EmitDesc* __restrict__ descs, int n_out) {
+  for (int s = threadIdx.x; s < n_slots; s += 256) {
+    fold_state_slot(images, n_images, state, n_slots, slot_kind[s], s);
+    recs[s] = state_to_slot(state, slot_kind[s], s, n_slots);   // (reads back only what this thread has just written)
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_out; i += 256) { const EmitDesc d = descs[i]; emit_scalar_one(d, recs[d.slot]); }
+}
+hipError_t ssgpu_launch_fold_emit(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, VmAccRec* recs,
+                                  const EmitDesc* descs, int n_out, hipStream_t stream) {
+  hipLaunchKernelGGL(ssgpu_fold_emit_kernel, dim3(1), dim3(256), 0, stream, (const u64*)images, n_images, (u64*)state, n_slots, slot_kind, recs, descs, n_out);
+  return hipGetLastError();
 }
 hipError_t ssgpu_launch_fold_state(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, hipStream_t stream) {
   if (n_slots > 0) hipLaunchKernelGGL(ssgpu_fold_state_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, stream, (const u64*)images, n_images, (u64*)state, n_slots, slot_kind);
@@ -1995,6 +2095,11 @@ hipError_t ssgpu_launch_group_count(const GroupExtractParams& P, uint32_t* tile_
   hipLaunchKernelGGL(ssgpu_group_count_kernel, dim3(blocks), dim3(256), 0, stream, P, tile_counts);
   return hipGetLastError();
 }
+hipError_t ssgpu_launch_group_extract_lb(const GroupExtractParams& P, unsigned long long* status, uint64_t epoch, unsigned int* ctrl, unsigned int* error_flag, hipStream_t stream) {
+  int blocks = (int)(((size_t)P.capacity + 1 + P.extra_slots + 511) / 512);
+  hipLaunchKernelGGL(ssgpu_group_extract_lb_kernel, dim3(blocks), dim3(256), 0, stream, P, status, (u64)((epoch & 0x3FFFFFFFull) << 32), ctrl, error_flag);
+  return hipGetLastError();
+}
 hipError_t ssgpu_launch_group_extract(const GroupExtractParams& P, hipStream_t stream) {
   int blocks = (int)(((size_t)P.capacity + 1 + 511) / 512);
   hipLaunchKernelGGL(ssgpu_group_extract_kernel, dim3(blocks), dim3(256), 0, stream, P);
@@ -2006,7 +2111,7 @@ hipError_t ssgpu_launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t 
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_group_init(const GroupInitParams& P, hipStream_t stream) {
-  const uint64_t n = std::max<uint64_t>(std::max<uint64_t>(P.n_keys, P.n_acc), std::max<uint64_t>(P.n_cnt, std::max<uint64_t>(P.nz[0], std::max<uint64_t>(P.nz[1], P.nz[2]))));
+  const uint64_t n = std::max<uint64_t>(std::max<uint64_t>(P.n_keys, P.n_acc), std::max<uint64_t>(P.n_cnt, std::max<uint64_t>(std::max<uint64_t>(P.nz[0], P.nz[3]), std::max<uint64_t>(P.nz[1], P.nz[2]))));
   int blocks = (int)std::min<uint64_t>((n + 255) / 256, 4096); if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ssgpu_group_init_kernel, dim3(blocks), dim3(256), 0, stream, P);
   return hipGetLastError();

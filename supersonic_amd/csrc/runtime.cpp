@@ -53,10 +53,12 @@ struct ssgpu_ctx {
   int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
   int64_t group_scout = 1;       // 0: no scout run ahead of the first large GroupAggregate run (see run_group_agg)
   int64_t group_resident = 1;    // 0: plain stages take the slab form through scatter + aggregation like every other stage (tests, A/B)
+  int64_t async_handoff = 1;     // 0: every stage hand-off reads the row count on the host (a stream synchronise), even where the next stage could take it from the device
   int64_t lazy_feedback = 1;     // 0: a GroupAggregate reads its overflow / feedback words back at the end of EVERY run (a stream synchronise per run)
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
+  int64_t sort_bucketed = 1;     // 0: payload records always packed in row order (no partition by the key's top digit)
   int64_t sort_hi_digits = 4;    // high digits the hybrid sort passes over before fixing ties: 2..4, 0 = by row count
   int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
   int64_t profile = 1;           // record HIP events around kernels
@@ -140,6 +142,7 @@ struct StageExec {
   // filter compaction
   DevBuf tile_counts, tile_offsets, total;
   DevBuf lb_status;             // single-pass form: one look-back word per tile
+  DevBuf xstatus; uint64_t x_epoch = 0;   // group extraction (one launch, decoupled look-back): one status word per 512-slot tile, stamped with the run's epoch
   uint64_t lb_epoch = 0;        // stamp of the single-pass compaction status words (run_materialize)
   int lb_resident_per_cu = 0;   // workgroups of this stage's program a CU holds at once (occupancy API)
   // group table
@@ -165,6 +168,10 @@ struct StageExec {
   RtcSlot rtc_plain;            // ssgpu_part_scatter_plain_kernel specialised for this stage's record and a partition count (static_lds = its LDS size)
   RtcSlot rtc_part;             // ssgpu_part_agg_kernel specialised for this stage's aggregates and an LDS size (static_lds)
   RtcSlot rtc_resident;         // ssgpu_group_resident_kernel specialised for this stage's row source and aggregates
+  RtcSlot rtc_hot;              // the same kernel for the heavy hitters' small table (hot_only)
+  uint32_t hot_n = 0; uint64_t hot_keys[SSGPU_HOT_MAX] = {0};   // heavy-hitter keys found when a partition segment overflowed (kept for the plan's later runs)
+  bool hot_tried = false;       // the sample has been looked at for this plan
+  DevBuf hot_out;
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jkeys_hi, jrows, jmisc;
@@ -176,6 +183,7 @@ struct StageExec {
   DevBuf debug, debug_pc, total2;
   // sort / clusters
   DevBuf skeys_a, skeys_b, skeys_c, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
+  DevBuf skeys_p, pstatus;      // bucket-ordered records (ssgpu_sort_partition_pack_kernel): the keys by record position, its look-back status words
   DevBuf route_scratch;         // key-range exchange: per-destination counters + (destination, position) of every result row
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
@@ -183,6 +191,7 @@ struct StageExec {
   // outputs
   std::vector<OutCol> out;
   int64_t out_rows = -1;     // -1: read lazily from `total`
+  const void* out_rows_dev = nullptr;   // ... or, when set, from this device word of an EARLIER stage (a filter-less stage fed through a device-side row count)
   int64_t out_capacity = 0;
   // what the last run did (ssgpu_plan_stage_info)
   int last_group_shape = 0;     // 0 direct, 1 hash partitions, 2 slab
@@ -194,6 +203,7 @@ struct StageExec {
   // plan runs again -- a run that did overflow after all is then repeated, synchronously, from the saved input columns.
   PinnedBuf fb_host;
   int fb_pending = 0;           // 0 none, 1 direct shape, 2 partitioned shape
+  hipEvent_t fb_event = nullptr;   // recorded behind the copy of the feedback words (record_feedback)
   int steady = 0;               // consecutive synchronous runs that neither overflowed nor changed the stage's shape
   uint32_t steady_bypass = 0;   // direct shape: rows that bypassed the LDS table in the last synchronous run
 };
@@ -332,11 +342,13 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "group_scout") c->group_scout = value;
   else if (k == "part_plain") c->part_plain = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
+  else if (k == "async_handoff") c->async_handoff = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
   else if (k == "sort_records") c->sort_records = value;
   else if (k == "sort_hybrid") c->sort_hybrid = value;
   else if (k == "sort_hi_digits") c->sort_hi_digits = value;
   else if (k == "sort_compact") c->sort_compact = value;
+  else if (k == "sort_bucketed") c->sort_bucketed = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -587,7 +599,8 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   }
   // the stream is drained: no launch of this plan's specialised kernels is in flight -- drop the references (the
   // module of a kernel no other plan uses is unloaded, rtc.cpp)
-  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); }
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); ex.rtc_hot.drop(); }
+  for (auto& ex : p->exec) if (ex.fb_event) { (void)hipEventDestroy(ex.fb_event); ex.fb_event = nullptr; g_events.fetch_sub(1); }
   ssgpu_ctx* c = p->ctx;
   g_live_plans.fetch_sub(1);
   delete p;
@@ -620,7 +633,8 @@ void ssgpu_interrupt(ssgpu_plan* p) { if (p) p->interrupted.store(1, std::memory
 // ---- execution helpers -------------------------------------------------------------
 namespace {
 
-struct InCols { std::vector<ssgpu_column> cols; int64_t rows = 0; };
+struct InCols { std::vector<ssgpu_column> cols; int64_t rows = 0;
+                const unsigned long long* rows_dev = nullptr; };   // rows_dev: the row count lives on the device (a stage hand-off without a host round trip); `rows` is then an upper bound
 
 int upload_program(ssgpu_ctx* c, const Program& prog, const ProgramLayout& L, DevBuf* dev, int* n_instr, std::vector<VmInstr>* scratch) {
   finalize_program(prog, L, scratch);
@@ -852,6 +866,7 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
   P->uses_math = prog.uses_math ? 1u : 0u;
   P->n_slots = prog.n_slots;
   P->n_rows = in.rows;
+  P->n_rows_dev = in.rows_dev;
   P->row_id_base = row_id_base;
   P->tile_rows = VM_TILE_UNIT * L.K;
   P->n_tiles = (int)((in.rows + P->tile_rows - 1) / P->tile_rows);
@@ -944,14 +959,15 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
     HIP_TRY(c, ex.debug.ensure((size_t)grid * 4 * 8));
     P.debug = ex.debug.as<unsigned long long>();
   }
-  HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
+  // (the stage's error word was cleared by run_plan)
   { int rc = attach_pc_profile(c, ex, &P); if (rc != SSGPU_OK) return rc; }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
   HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
+  // a partial run (multi-GPU) leaves the reducible state next to the slot records, in the same launch
   HIP_TRY(c, ssgpu_launch_finish_slots(ex.wg_partials.as<VmAccRec>(), ns, grid * VM_WAVES, ex.slot_kind.as<int>(),
-                                       ex.slot_recs.as<VmAccRec>(), c->stream));
+                                       ex.slot_recs.as<VmAccRec>(), stop_at_partial ? ex.state.as<uint64_t>() : nullptr, c->stream));
   p->counters.n_launches += 2;
   p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
   if (c->debug_timing) {
@@ -962,29 +978,35 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
     fprintf(stderr, "[ssgpu debug] grid=%d tiles/wg=%.1f cycles/wg=%.0f wait=%.1f%% cycles/tile=%.0f (wait %.0f)\n", grid, tiles / grid,
             tot / grid, 100.0 * wait / tot, tot / tiles, wait / tiles);
   }
-  if (stop_at_partial) {
-    HIP_TRY(c, ssgpu_launch_slots_to_state(ex.slot_recs.as<VmAccRec>(), ns, ex.slot_kind.as<int>(), ex.state.as<uint64_t>(), c->stream));
-    p->counters.n_launches += 1;
+  return SSGPU_OK;
+}
+
+// the one-row result's output buffers and their emit descriptors (uploaded once: the buffers never move)
+int prepare_scalar_emit(ssgpu_plan* p, size_t si, int* n_out) {
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  int rc = ensure_out_cols(c, st, ex, 1);
+  if (rc != SSGPU_OK) return rc;
+  *n_out = (int)st.aggs.size();
+  if (!ex.emit_ready) {
+    std::vector<EmitDesc> descs;
+    for (size_t i = 0; i < st.aggs.size(); ++i) {
+      EmitDesc d; d.data = ex.out[i].data.p; d.is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
+      d.slot = st.aggs[i].slot; d.out_kind = st.aggs[i].emit_kind;
+      descs.push_back(d);
+    }
+    HIP_TRY(c, ex.emit_descs.ensure(std::max<size_t>(descs.size(), 1) * sizeof(EmitDesc)));
+    HIP_TRY(c, hipMemcpy(ex.emit_descs.p, descs.data(), descs.size() * sizeof(EmitDesc), hipMemcpyHostToDevice));
+    ex.emit_ready = true;
   }
   return SSGPU_OK;
 }
 
 int emit_scalar_agg(ssgpu_plan* p, size_t si) {
-  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
-  int rc = ensure_out_cols(c, st, ex, 1);
+  ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[si];
+  int n_out = 0;
+  const int rc = prepare_scalar_emit(p, si, &n_out);
   if (rc != SSGPU_OK) return rc;
-  std::vector<EmitDesc> descs;
-  for (size_t i = 0; i < st.aggs.size(); ++i) {
-    EmitDesc d; d.data = ex.out[i].data.p; d.is_null = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
-    d.slot = st.aggs[i].slot; d.out_kind = st.aggs[i].emit_kind;
-    descs.push_back(d);
-  }
-  if (!ex.emit_ready) {  // output buffers of a 1-row result never move: upload once
-    HIP_TRY(c, ex.emit_descs.ensure(descs.size() * sizeof(EmitDesc)));
-    HIP_TRY(c, hipMemcpy(ex.emit_descs.p, descs.data(), descs.size() * sizeof(EmitDesc), hipMemcpyHostToDevice));
-    ex.emit_ready = true;
-  }
-  HIP_TRY(c, ssgpu_launch_emit_scalar(ex.slot_recs.as<VmAccRec>(), ex.emit_descs.as<EmitDesc>(), (int)descs.size(), c->stream));
+  HIP_TRY(c, ssgpu_launch_emit_scalar(ex.slot_recs.as<VmAccRec>(), ex.emit_descs.as<EmitDesc>(), n_out, c->stream));
   p->counters.n_launches += 1;
   ex.out_rows = 1;
   return SSGPU_OK;
@@ -994,6 +1016,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   int rc = ensure_out_cols(c, st, ex, in0.rows);
   if (rc != SSGPU_OK) return rc;
+  ex.out_rows_dev = nullptr;
   InCols in = in0;
   if (!st.distinct_cols.empty()) {   // a further DISTINCT column's first-of-run flags, stored with the rows (lower.cpp)
     ssgpu_column f; rc = distinct_flags(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
@@ -1002,8 +1025,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   apply_joins(p, ex, st.main, &P);
-  P.error_flag = ex.error_flag.as<unsigned int>();
-  HIP_TRY(c, hipMemsetAsync(ex.error_flag.p, 0, sizeof(uint32_t), c->stream));
+  P.error_flag = ex.error_flag.as<unsigned int>();   // (cleared by run_plan)
   // output table: data column then (if nullable) its null mask, in out_schema order
   int oi = 0;
   for (size_t i = 0; i < ex.out.size(); ++i) {
@@ -1059,6 +1081,8 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
     P.lb_epoch = ex.lb_epoch;
     p->counters.n_launches += 1;
     ex.out_rows = -1;
+  } else if (in.rows_dev) {
+    ex.out_rows = -1; ex.out_rows_dev = in.rows_dev;   // as many rows as came in: the same device word
   } else {
     ex.out_rows = in.rows;
   }
@@ -1106,15 +1130,21 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
   const int ntile = (int)((slots + 511) / 512);
   int rc = ensure_out_cols(c, st, ex, (int64_t)slots);
   if (rc != SSGPU_OK) return rc;
-  HIP_TRY(c, ex.tile_counts.ensure((size_t)ntile * 4));
-  HIP_TRY(c, ex.tile_offsets.ensure((size_t)ntile * 4));
-  HIP_TRY(c, ex.total.ensure(8));
+  HIP_TRY(c, ex.total.ensure(16));   // [rows u64][ticket u32][gave-up u32]: cleared by the run's ssgpu_group_init launch
+  {
+    const size_t had = ex.xstatus.cap;
+    HIP_TRY(c, ex.xstatus.ensure((size_t)ntile * 8));
+    ex.x_epoch = (ex.x_epoch + 1) & 0x3FFFFFFFull;
+    if (ex.xstatus.cap != had || ex.x_epoch == 0) {   // words of earlier runs read as "not yet": cleared only when (re)allocated or the epoch wraps
+      HIP_TRY(c, hipMemsetAsync(ex.xstatus.p, 0, ex.xstatus.cap, c->stream));
+      if (ex.x_epoch == 0) ex.x_epoch = 1;
+    }
+  }
   GroupExtractParams G;
   memset(&G, 0, sizeof(G));
   G.keys = ex.gkeys.as<unsigned long long>();
   G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
   G.capacity = capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size();
-  G.tile_offsets = ex.tile_offsets.as<unsigned int>();
   for (size_t k = 0; k < st.group_keys.size(); ++k) {
     const GroupKeyField& f = st.group_keys[k];
     G.keys_out[k].data = ex.out[k].data.p;
@@ -1129,10 +1159,9 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
     G.aggs_out[j].is_null = ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr;
     G.aggs_out[j].s = st.aggs[j].slot; G.aggs_out[j].out_kind = st.aggs[j].emit_kind; G.aggs_out[j].has_cnt = st.aggs[j].has_cnt ? 1 : 0;
   }
-  HIP_TRY(c, ssgpu_launch_group_count(G, ex.tile_counts.as<uint32_t>(), c->stream));
-  HIP_TRY(c, ssgpu_launch_scan_counts(ex.tile_counts.as<uint32_t>(), ex.tile_offsets.as<uint32_t>(), ntile, ex.total.as<uint64_t>(), c->stream));
-  HIP_TRY(c, ssgpu_launch_group_extract(G, c->stream));
-  p->counters.n_launches += 3;
+  // count + scan + extract as ONE launch (ticket-ordered tiles, decoupled look-back): same rows, same (slot) order
+  HIP_TRY(c, ssgpu_launch_group_extract_lb(G, ex.xstatus.as<unsigned long long>(), ex.x_epoch, ex.total.as<unsigned int>(), ex.error_flag.as<unsigned int>(), c->stream));
+  p->counters.n_launches += 1;
   rc = gather_first_last(p, st, ex, nk, in, row_id_base, ex.total.as<uint64_t>(), slots);
   if (rc != SSGPU_OK) return rc;
   ex.out_rows = -1;
@@ -1148,6 +1177,25 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
 //   3. the usual extraction over the dumped tables
 // A segment that runs full (skewed keys) reruns with 4x larger segments; a partition with more groups than its
 // LDS table holds reruns with twice the partitions.  *fallback is set when neither can be satisfied.
+// Lazy run feedback (StageExec::fb_pending) needs nobody between this stage and the end of the run to wait for the host:
+// the stage is the plan's last one, or every later stage is a filter-less materialising stage that takes its row count from
+// the device (run_plan's hand-off) -- e.g. the merge plan of a sharded job: GroupAggregate -> Compute.
+static bool tail_runs_without_host(const ssgpu_plan* p, size_t si) {
+  if (!p->ctx->async_handoff && si + 1 < p->stages.size()) return false;
+  for (size_t k = si + 1; k < p->stages.size(); ++k) {
+    const Stage& nx = p->stages[k];
+    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && nx.joins.empty())) return false;
+  }
+  return true;
+}
+// the feedback words are copied to pinned memory on the stream; this event says when THAT copy is done (looking at them then
+// does not have to wait for everything queued behind it: the next run of a stepping job starts while the step before is
+// still in flight)
+static int record_feedback(ssgpu_ctx* c, StageExec& ex) {
+  if (!ex.fb_event) { HIP_TRY(c, hipEventCreateWithFlags(&ex.fb_event, hipEventDisableTiming)); g_events.fetch_add(1); }
+  HIP_TRY(c, hipEventRecord(ex.fb_event, c->stream));
+  return SSGPU_OK;
+}
 int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base, bool* fallback) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
@@ -1187,6 +1235,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     ex.pattern_ready = true;
   }
   HIP_TRY(c, ex.goverflow.ensure(16));
+  HIP_TRY(c, ex.total.ensure(16));
   if (!ex.part_n_chosen) {
     // partitions: enough that a partition's groups load its table to about one half (the direct path's run feedback
     // left an estimate of the group count); one partition per CU or more keeps phase 2's single wave of workgroups full
@@ -1229,7 +1278,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     ex.last_plain_scatter = false;
     uint32_t capacity = NP * C;
     if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
-    const size_t slots = (size_t)capacity + 1;
+    // heavy hitters (found when a segment overflowed, below): their groups live in SSGPU_HOT_SLOTS dense slots behind the special one
+    const bool hot = !slab && ex.hot_n > 0 && st.plain.ok && c->part_plain != 0;
+    const uint32_t extra = hot ? SSGPU_HOT_SLOTS : 0u;
+    const size_t slots = (size_t)capacity + 1 + extra;
     VmParams Ps;
     fill_params(&Ps, st.part_scatter, ex.lay_pscatter, ex.prog_pscatter, ex.n_instr_pscatter, in, row_id_base);
     apply_joins(p, ex, st.part_scatter, &Ps);
@@ -1275,14 +1327,15 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
         I.keys = ex.gkeys.as<unsigned long long>(); I.n_keys = slots;
         I.acc = ex.gacc.as<unsigned long long>(); I.n_acc = (unsigned long long)slots * ng;
         I.cnt = ex.gcnt.as<unsigned int>(); I.n_cnt = (unsigned long long)slots * ng;
-      } else {      // only the reserved slot of the EMPTY-valued key needs initialising: phase 2 writes every other slot
-        I.keys = ex.gkeys.as<unsigned long long>() + capacity; I.n_keys = 1;
-        I.acc = ex.gacc.as<unsigned long long>() + (size_t)capacity * ng; I.n_acc = ng;
-        I.cnt = ex.gcnt.as<unsigned int>() + (size_t)capacity * ng; I.n_cnt = ng;
+      } else {      // only the reserved slot of the EMPTY-valued key (and the heavy hitters' slots behind it) need initialising: phase 2 writes every other slot
+        I.keys = ex.gkeys.as<unsigned long long>() + capacity; I.n_keys = 1 + extra;
+        I.acc = ex.gacc.as<unsigned long long>() + (size_t)capacity * ng; I.n_acc = (unsigned long long)(1 + extra) * ng;
+        I.cnt = ex.gcnt.as<unsigned int>() + (size_t)capacity * ng; I.n_cnt = (unsigned long long)(1 + extra) * ng;
       }
       I.z[0] = ex.goverflow.as<unsigned int>(); I.nz[0] = 4;
       I.z[1] = ex.error_flag.as<unsigned int>(); I.nz[1] = 1;
       if (plain) { I.z[2] = ex.part_hist.as<unsigned int>(); I.nz[2] = n_segs; }     // the plain scatter's segment counters
+      I.z[3] = ex.total.as<unsigned int>(); I.nz[3] = 4;                             // the extraction's row count, ticket and gave-up flag
       HIP_TRY(c, ssgpu_launch_group_init(I, c->stream));
     }
     Ps.error_flag = ex.error_flag.as<unsigned int>();
@@ -1297,6 +1350,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       // nothing to scatter
     } else if (plain) {
       PlainScatterParams S; fill_plain_source(S);
+      if (hot) { S.n_hot = ex.hot_n; for (uint32_t h = 0; h < ex.hot_n; ++h) S.hot_keys[h] = ex.hot_keys[h]; }   // their rows are aggregated by the resident kernel below
       S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
       S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
@@ -1381,8 +1435,9 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, ex.fb_host.ensure(16));
     uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // [0] a partition outgrew its LDS table, [1] a segment ran full
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
-    if (attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && si + 1 == p->stages.size()) {
+    if (attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && tail_runs_without_host(p, si)) {
       // steady state: this shape held the last runs -- the flags are looked at lazily (settle_plan), no synchronise here
+      { const int rc = record_feedback(c, ex); if (rc != SSGPU_OK) return rc; }
       ex.fb_pending = 2; p->deferred = true;
       return extract_groups(p, st, ex, capacity, ng, in, row_id_base);
     }
@@ -1458,6 +1513,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
     HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
     HIP_TRY(c, ex.goverflow.ensure(16));
+    HIP_TRY(c, ex.total.ensure(16));
     HIP_TRY(c, ex.gpattern.ensure(ng * 8));
     HIP_TRY(c, ex.gmergeop.ensure(ng * 4));
     if (!ex.pattern_ready) {
@@ -1476,6 +1532,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
       I.cnt = ex.gcnt.as<unsigned int>(); I.n_cnt = (unsigned long long)slots * ng;
       I.z[0] = ex.goverflow.as<unsigned int>(); I.nz[0] = 4;
       I.z[1] = ex.error_flag.as<unsigned int>(); I.nz[1] = 1;
+      I.z[3] = ex.total.as<unsigned int>(); I.nz[3] = 4;   // the extraction's row count, ticket and gave-up flag
       HIP_TRY(c, ssgpu_launch_group_init(I, c->stream));
     }
     VmParams P;
@@ -1536,7 +1593,8 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     HIP_TRY(c, ex.fb_host.ensure(16));
     uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // overflow flag, rows that bypassed the local table, max local occupancy
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
-    if (!scout && attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && si + 1 == p->stages.size()) {   // (a scout run exists for its feedback: always read)
+    if (!scout && attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && tail_runs_without_host(p, si)) {   // (a scout run exists for its feedback: always read)
+      { const int rc = record_feedback(c, ex); if (rc != SSGPU_OK) return rc; }
       ex.fb_pending = 1; p->deferred = true;   // steady state: looked at lazily (settle_plan)
       break;
     }
@@ -1565,7 +1623,9 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         for (int w = 4; w >= 1; --w) if ((double)local_capacity_for(w) * 0.9 >= groups) { best = w; break; }
         if (best > 0 && best != ex.group_wgs) ex.group_wgs = best;
         else if (best == 0 || (best == ex.group_wgs && (double)fb[1] * 4.0 >= rows)) {
-          if (c->group_partition && !st.part_scatter.empty() && !ex.part_failed && in.rows >= (1 << 20)) {
+          // (a plain stage's scatter is its own kernel, worth it from 64 K rows: the merge of a sharded job's partial tables --
+          //  1e5 rows, every one its own group -- takes 150 us through the global atomics and 25 us through partitions)
+          if (c->group_partition && !st.part_scatter.empty() && !ex.part_failed && in.rows >= (st.plain.ok && c->part_plain ? (1 << 16) : (1 << 20))) {
             ex.group_partitioned = true; ex.part_groups_est = groups;
             // few enough groups for ONE whole-LDS table (with head room for the estimate): slabs of rows instead of hash partitions
             const uint32_t full = (159u * 1024u - (entry + 1025u * 4u + 128u)) / entry;
@@ -1591,7 +1651,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         const int ntile = (int)((nslots + 511) / 512);
         HIP_TRY(c, ex.tile_counts.ensure((size_t)ntile * 4));
         HIP_TRY(c, ex.tile_offsets.ensure((size_t)ntile * 4));
-        HIP_TRY(c, ex.total.ensure(8));
+        HIP_TRY(c, ex.total.ensure(16));
         GroupExtractParams G;
         memset(&G, 0, sizeof(G));
         G.keys = ex.gkeys.as<unsigned long long>(); G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
@@ -1735,10 +1795,25 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   };
   build_layout();
   if (compact && !use_records) { compact = false; major_direct = major_direct0; build_layout(); }   // the one-word form gathers through records
+  // One sort key, sorted as one-word keys: the pack pass is also a stable partition of the records by the key's top digit, and the
+  // sorted words carry record POSITIONS instead of row ids -- the final gather then reads inside one bucket (1 / 256 of the
+  // table) at a time, on chip, instead of all over it (sort_kernels.hip: ssgpu_sort_partition_pack_kernel).
+  bool bucketed = false;
   if (use_records) {
     HIP_TRY(c, ex.srecs.ensure((size_t)n * R.stride + 16));
     R.recs = ex.srecs.p;
-    HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream));
+    const uint32_t tile_rows = ssgpu_sort_partition_rows(R.stride);
+    bucketed = compact && k_first == 0 && tile_rows != 0 && c->sort_bucketed != 0 && n >= (1u << 20) && ((first_varying >> 56) & 0xFFull) != 0;
+    if (bucketed) {
+      HIP_TRY(c, ex.skeys_p.ensure(std::max<uint64_t>(n, 1) * 8));
+      const size_t need = (size_t)((n + tile_rows - 1) / tile_rows) * 256 * 8;
+      if (need > ex.pstatus.cap || !ex.pstatus.p) { HIP_TRY(c, ex.pstatus.ensure(need)); HIP_TRY(c, hipMemsetAsync(ex.pstatus.p, 0, ex.pstatus.cap, c->stream)); }
+      HIP_TRY(c, ssgpu_launch_sort_partition_pack(R, ka, kb, ex.skeys_p.as<uint64_t>(), ex.soffs.as<uint32_t>() + 7 * 256, ex.pstatus.as<unsigned long long>(),
+                                                  ex.sticket.as<uint32_t>() + n_pass, ++ex.sort_epoch, ex.sticket.as<uint32_t>() + 63, c->stream));
+      ++n_pass;
+    } else {
+      HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream));
+    }
     p->counters.n_launches += 1;
   }
   if (!keys_only && !compact) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
@@ -1780,7 +1855,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
         std::swap(kc, kd);
       }
       uint32_t* flag = ex.sticket.as<uint32_t>() + 62;
-      HIP_TRY(c, ssgpu_launch_sort_fix_ties_compact(kc, ka, n, flag, c->stream));
+      HIP_TRY(c, ssgpu_launch_sort_fix_ties_compact(kc, bucketed ? ex.skeys_p.as<uint64_t>() : ka, n, flag, c->stream));   // (low halves by row id, or by record position)
       uint32_t too_long = 0;
       HIP_TRY(c, hipMemcpyAsync(&too_long, flag, 4, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1793,6 +1868,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
         // long runs of equal high halves: the plain LSD order over all digits (the key array and the digit offsets are untouched)
         HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));
         HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
+        if (bucketed) { HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream)); bucketed = false; }   // the plain order gathers by ROW id: records back in row order
         compact = false; tie_runs_too_long = true; sort_mode = 2 + 16;
       }
     }
@@ -1850,7 +1926,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     p->counters.n_launches += 1;
   }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
-  ex.last_sort_passes = (int)n_pass; ex.last_sort_mode = sort_mode;
+  ex.last_sort_passes = (int)n_pass; ex.last_sort_mode = sort_mode + (bucketed ? 32 : 0);
   if (n_pass) {   // the look-back never gives up on a healthy device; if it did, the order is wrong: fail loudly
     uint32_t stuck = 0;
     HIP_TRY(c, hipMemcpyAsync(&stuck, ex.sticket.as<uint32_t>() + 63, 4, hipMemcpyDeviceToHost, c->stream));
@@ -2005,11 +2081,12 @@ int run_fold_tail(ssgpu_plan* p, size_t si, const InCols& in) {
   return SSGPU_OK;
 }
 
+static const void* rows_word(const StageExec& ex) { return ex.out_rows_dev ? ex.out_rows_dev : ex.total.p; }
 int stage_rows(ssgpu_plan* p, size_t si, int64_t* rows) {
   ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[si];
   if (ex.out_rows < 0) {
     uint64_t total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&total, ex.total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&total, rows_word(ex), 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     ex.out_rows = (int64_t)total;
   }
@@ -2080,7 +2157,8 @@ int fix_nan_minmax(ssgpu_plan* p) {
   Status s = lower_plan(p->desc, &stages, &schema, &describe);
   if (!s.ok()) { p->desc.nan_exact = false; return SSGPU_OK; }   // (a shape the exact form cannot take keeps the order-independent answer)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); }
+  for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); ex.rtc_hot.drop(); }
+  for (auto& ex : p->exec) if (ex.fb_event) { (void)hipEventDestroy(ex.fb_event); ex.fb_event = nullptr; g_events.fetch_sub(1); }
   p->exec.clear();
   p->stages = stages; p->describe = describe;
   p->exec.resize(p->stages.size());
@@ -2100,9 +2178,10 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   p->nan_seen = false;
   if (p->deferred) {   // the previous run's feedback first: an overflow there puts the stage back into its adapting, synchronous form
     p->deferred = false;   // (that run's result is being replaced by this run: nothing to repeat)
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& ex : p->exec) {
       if (!ex.fb_pending) continue;
+      // only the copy of the words has to be done -- not the work queued behind it (a stepping job keeps the stream busy)
+      if (ex.fb_event) HIP_TRY(c, hipEventSynchronize(ex.fb_event)); else HIP_TRY(c, hipStreamSynchronize(c->stream));
       const uint32_t* fb = static_cast<const uint32_t*>(ex.fb_host.p);
       const int kind = ex.fb_pending; ex.fb_pending = 0;
       if (fb[0] || (kind == 2 && fb[1])) ex.steady = 0;
@@ -2137,7 +2216,10 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
     if (c->profile_total) HIP_TRY(c, hipEventRecord(p->ev_begin, c->stream));
   }
   // every stage's evaluation-error word starts clear: the flags of ALL stages are read at each hand-off and at fetch
-  for (auto& sx : p->exec) if (sx.error_flag.p) HIP_TRY(c, hipMemsetAsync(sx.error_flag.p, 0, sizeof(uint32_t), c->stream));
+  // (a GroupAggregate that is the plan's FIRST stage clears its word in its own init launch -- one fill launch less per run; later
+  //  stages' words are read at the hand-offs before those stages run, so they are cleared here)
+  for (size_t si = 0; si < p->exec.size(); ++si)
+    if (p->exec[si].error_flag.p && !(si == 0 && p->stages[si].kind == STAGE_GROUP_AGG)) HIP_TRY(c, hipMemsetAsync(p->exec[si].error_flag.p, 0, sizeof(uint32_t), c->stream));
   int64_t alg_bytes = 0;
   for (size_t si = 0; si < p->stages.size(); ++si) {
     if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
@@ -2162,13 +2244,27 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
     if (rc != SSGPU_OK) return rc;
     if (si + 1 < p->stages.size()) {
       // next stage reads this stage's materialised result
-      int64_t r = 0;
-      rc = stage_rows(p, si, &r);
-      if (rc != SSGPU_OK) return rc;
-      // a stage that hit an evaluation error must not feed the next one (the hand-off already waits for the row count)
-      rc = check_error_flags(p);
-      if (rc != SSGPU_OK) return rc;
       StageExec& ex = p->exec[si];
+      const Stage& nx = p->stages[si + 1];
+      // A filter-less materialising stage (Compute / Project over a blocking stage's result, e.g. the COUNT -> NOT NULL and
+      // sum + residual columns of a sharded merge) takes the row count FROM THE DEVICE: no stream synchronise between the two
+      // stages, the kernel reads the count where the producer left it and runs over the buffers' capacity at most.  Every
+      // stage's error word is still looked at when the result is touched (check_error_flags); rows beyond the count are
+      // never computed, so a signaling operator cannot fail on them.
+      const bool device_rows = c->async_handoff != 0 && !c->debug_timing && ex.out_rows < 0 && ex.out_capacity > 0 && nx.kind == STAGE_MATERIALIZE &&
+                               !nx.has_filter && nx.distinct_cols.empty() && nx.joins.empty();
+      int64_t r = 0;
+      in.rows_dev = nullptr;
+      if (device_rows) {
+        r = ex.out_capacity;
+        in.rows_dev = static_cast<const unsigned long long*>(rows_word(ex));
+      } else {
+        rc = stage_rows(p, si, &r);
+        if (rc != SSGPU_OK) return rc;
+        // a stage that hit an evaluation error must not feed the next one (the hand-off already waits for the row count)
+        rc = check_error_flags(p);
+        if (rc != SSGPU_OK) return rc;
+      }
       in.cols.clear();
       for (auto& oc : ex.out) { ssgpu_column col; col.data = oc.data.p; col.is_null = oc.nullable ? oc.nulls.as<uint8_t>() : nullptr; in.cols.push_back(col); }
       in.rows = r;
@@ -2198,7 +2294,7 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
 int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
   if (!p) return 0;
   int32_t n = 0;
-  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_plain.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0) + (ex.rtc_resident.h ? 1 : 0);
+  for (auto& ex : p->exec) n += (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 1 : 0) + (ex.rtc_plain.h ? 1 : 0) + (ex.rtc_part.h ? 1 : 0) + (ex.rtc_resident.h ? 1 : 0) + (ex.rtc_hot.h ? 1 : 0);
   return n;
 }
 const char* ssgpu_plan_specialize_reason(const ssgpu_plan* p) {
@@ -2345,6 +2441,23 @@ int ssgpu_plan_fold_partials(ssgpu_plan* p, const void* images, int32_t n_images
   StageExec& ex = p->exec[0];
   const int ns = p->stages[0].main.n_slots;
   HIP_TRY(c, ssgpu_launch_fold_state(static_cast<const uint64_t*>(images), n_images, ex.state.as<uint64_t>(), ns, ex.slot_kind.as<int>(), c->stream));
+  return SSGPU_OK;
+}
+
+int ssgpu_plan_fold_finalize(ssgpu_plan* p, const void* images, int32_t n_images, ssgpu_result** out) {
+  if (!p || !p->partial_pending || p->stages.empty() || !images || n_images < 1) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  StageExec& ex = p->exec[0];
+  const int ns = p->stages[0].main.n_slots;
+  int n_out = 0;
+  const int rc = prepare_scalar_emit(p, 0, &n_out);
+  if (rc != SSGPU_OK) return rc;
+  HIP_TRY(c, ssgpu_launch_fold_emit(static_cast<const uint64_t*>(images), n_images, ex.state.as<uint64_t>(), ns, ex.slot_kind.as<int>(),
+                                    ex.slot_recs.as<VmAccRec>(), ex.emit_descs.as<EmitDesc>(), n_out, c->stream));
+  p->counters.n_launches += 1;
+  ex.out_rows = 1;
+  p->partial_pending = false;
+  if (out) *out = &p->result;
   return SSGPU_OK;
 }
 
@@ -2631,7 +2744,7 @@ int ssgpu_result_pack_image(ssgpu_result* r, int64_t capacity_rows, void* image)
   StageExec& ex = p->exec.back();
   ImagePackParams P; memset(&P, 0, sizeof(P));
   P.image = image; P.capacity = (unsigned long long)capacity_rows;
-  if (ex.out_rows >= 0) P.rows_host = (unsigned long long)ex.out_rows; else P.rows_dev = ex.total.as<unsigned long long>();
+  if (ex.out_rows >= 0) P.rows_host = (unsigned long long)ex.out_rows; else P.rows_dev = static_cast<const unsigned long long*>(rows_word(ex));
   for (auto& sx : p->exec) if (sx.error_flag.p && P.n_flags < 8) P.error_flags[P.n_flags++] = sx.error_flag.as<unsigned int>();
   // a group stage whose overflow words have not been looked at yet (lazy feedback): they travel in the header, and a set
   // word makes the receiver repeat the step -- by then the next run has settled the stage
@@ -2664,7 +2777,7 @@ int ssgpu_result_route_images(ssgpu_result* r, int32_t n_keys, int32_t n_dest, i
   P.image = images; P.capacity = (unsigned long long)capacity_rows;
   const uint64_t rows_max = ex.out_rows >= 0 ? (uint64_t)ex.out_rows : (uint64_t)std::max<int64_t>(ex.out_capacity, 1);
   P.rows_host = rows_max;   // the routing kernels' bound on the row count; the count itself is on the device when the stage left it there
-  if (ex.out_rows < 0) P.rows_dev = ex.total.as<unsigned long long>();
+  if (ex.out_rows < 0) P.rows_dev = static_cast<const unsigned long long*>(rows_word(ex));
   for (auto& sx : p->exec) if (sx.error_flag.p && P.n_flags < 8) P.error_flags[P.n_flags++] = sx.error_flag.as<unsigned int>();
   for (auto& sx : p->exec) if (sx.fb_pending && sx.goverflow.p && P.n_retry + 2 <= 4) {
     P.retry_flags[P.n_retry++] = sx.goverflow.as<unsigned int>();
@@ -2681,9 +2794,12 @@ int ssgpu_result_route_images(ssgpu_result* r, int32_t n_keys, int32_t n_dest, i
     }
   }
   R.n_keys = (unsigned)n_keys; R.n_dest = (unsigned)n_dest; R.image_bytes = (unsigned long long)L.image_bytes;
-  const size_t head = ((size_t)n_dest + 3u) & ~(size_t)3u;
-  HIP_TRY(c, ex.route_scratch.ensure((head + 2 * rows_max) * 4));
-  HIP_TRY(c, hipMemsetAsync(ex.route_scratch.p, 0, head * 4, c->stream));
+  {
+    // the per-destination counters are left clear by the routing's own last kernel: filled only when the buffer is new
+    const void* had = ex.route_scratch.p; const size_t had_cap = ex.route_scratch.cap;
+    HIP_TRY(c, ex.route_scratch.ensure((256 + 2 * rows_max) * 4));
+    if (ex.route_scratch.p != had || ex.route_scratch.cap != had_cap) HIP_TRY(c, hipMemsetAsync(ex.route_scratch.p, 0, 256 * 4, c->stream));
+  }
   R.counters = ex.route_scratch.as<unsigned int>();
   HIP_TRY(c, ssgpu_launch_route_images(P, R, c->stream));
   return SSGPU_OK;

@@ -268,6 +268,7 @@ struct VmParams {
   unsigned long long* lb_status;  /* SEL_RANK_LB: one word per tile: state << 62 | epoch << 32 | rows (0 = not yet) */
   unsigned int* lb_ctrl;          /* [0..1] u64 total survivors, [3] look-back gave up                              */
   unsigned long long lb_epoch;    /* run stamp of lb_status words (stale words of earlier runs read as "not yet")    */
+  const unsigned long long* n_rows_dev;  /* optional: the input's row count lives on the DEVICE (a stage fed by a stage whose row count no host has read yet); n_rows / n_tiles are then upper bounds */
   unsigned int* error_flag;     /* low byte != 0: evaluation error (signaling ops); SSGPU_FLAG_NAN_IN_MINMAX: see below */
   unsigned long long* debug;    /* optional [grid][4]: total cycles, barrier-wait cycles, tiles */
   unsigned long long* debug_pc; /* optional [n_instr + 1]: cycles per instruction (wave 0 of every workgroup); last = staging */

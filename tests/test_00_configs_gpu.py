@@ -219,8 +219,28 @@ def unique_keys(cols):
 
 
 def test_config5_sort_8_columns_one_word_passes_and_record_gather():
-    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2,), "config #5")
-    assert infos[-1][0]["sort_passes"] == 4, infos       # the four high digits; ties finished by ssgpu_sort_fix_ties_compact
+    # the default form: one-word keys, the records packed in key-BUCKET order (mode 2 + 32: the pack pass partitions them by the
+    # key's top digit, the sorted words carry record positions), four radix passes + the partitioning pass
+    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2 + 32,), "config #5")
+    assert infos[-1][0]["sort_passes"] == 5, infos       # the partition-pack pass + the four high digits; ties finished by ssgpu_sort_fix_ties_compact
+    # the same with the records packed in row order (round 3's form)
+    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2,), "config #5, records in row order", sort_bucketed=0)
+    assert infos[-1][0]["sort_passes"] == 4, infos
+
+
+def test_config5_sort_bucketed_records_ragged_sizes_and_skewed_top_digits():
+    # the bucket-ordered pack at sizes that end inside a tile, with top digits that are all equal but one (one huge bucket) and
+    # with negative / positive keys (the top digit's sign flip), NULLABLE payload columns riding in the records
+    rng = np.random.default_rng(21)
+    for n, shape in ((1 << 20, "uniform"), ((1 << 20) + 777, "one_bucket"), (1500001, "two_buckets")):
+        cols = bench.host_columns(np, "wide", n, seed=13)
+        if shape == "one_bucket":
+            cols[3] = (np.int64(5) << 56) | (rng.permutation(n).astype(np.int64) << 33) | 1      # one top digit, distinct high halves
+            cols[3][0] = -7                                                   # (a second top digit: the digit has to vary for this form)
+        elif shape == "two_buckets":
+            cols[3] = np.where(np.arange(n) % 3 == 0, -1 - rng.permutation(n).astype(np.int64) * 1000003, rng.permutation(n).astype(np.int64) * 1000003)
+        infos = check_sort(unique_keys(cols), (2 + 32,), "config #5 bucketed, %s, %d rows" % (shape, n))
+        assert infos[-1][0]["sort_passes"] == 5, infos
 
 
 def test_config5_sort_colliding_high_halves_fall_back_to_all_digits():

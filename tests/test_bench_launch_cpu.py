@@ -31,6 +31,12 @@ def test_bench_gpus_2_launches_two_ranks(query, scaling):
     assert line["steps"] == 5 and line["warmup"] == 2
     assert line["config"]["collectives_per_step"] == 1
     assert line["config"]["rows_per_gpu"] == (1000 if scaling == "weak" else 500)
+    if scaling == "weak":
+        # a weak run reports BOTH regimes in its one line: --rows per GPU (the timed region) and --rows in total (strong)
+        assert line["regimes"]["weak"]["rows_total"] == 2000 and line["regimes"]["strong"]["rows_total"] == 1000
+        assert line["regimes"]["strong"]["rows_per_gpu"] == 500 and line["regimes"]["strong"]["ms_per_step"] > 0
+    else:
+        assert "regimes" not in line
 
 
 def test_bench_default_is_one_gpu():

@@ -952,8 +952,9 @@ def test_device_sharded_sort_single_rank_exchange(descending):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("n,shards", [(100003, 3), (2000, 4), (5, 3)])
-def test_partial_state_fold_across_shards(gpu_ctx, n, shards):
+def test_partial_state_fold_across_shards(gpu_ctx, n, shards, fused):
     # the N > 1 ScalarAggregate protocol on one GPU: every shard runs ssgpu_plan_run_partial with its global row
     # offset, the shards' partial states are laid out as an all-gather would (consecutive images), folded with
     # ssgpu_plan_fold_partials and finalised -- the result must be the single-plan answer (FIRST / LAST included)
@@ -982,8 +983,11 @@ def test_partial_state_fold_across_shards(gpu_ctx, n, shards):
         plans.append(plan)
     gathered = torch.cat(images)
     torch.cuda.synchronize()
-    plans[0].fold_partials(gathered.data_ptr(), shards)
-    plans[0].finalize()
+    if fused:                                               # ssgpu_plan_fold_finalize: the same two steps as one launch
+        plans[0].fold_finalize(gathered.data_ptr(), shards)
+    else:
+        plans[0].fold_partials(gathered.data_ptr(), shards)
+        plans[0].finalize()
     got = plans[0].fetch()
     _schema, want = oracle_run(query(view))
     assert_cols_equal([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())], want, context="folded partial state")
@@ -1017,6 +1021,47 @@ def test_device_sharded_group_aggregate_single_rank(n, with_filter):
         assert [(gs.attribute(i).name(), gs.attribute(i).type(), gs.attribute(i).is_nullable()) for i in range(gs.attribute_count())] == [tuple(x) for x in schema]
         assert_cols_equal(sort_rows([(got.column(i).data, got.column(i).is_null) for i in range(got.column_count())]), sort_rows(want),
                           context="device sharded group aggregate")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["all_gather", "key_range"])
+def test_device_sharded_group_aggregate_skips_nans_in_float_min_max(exchange):
+    # A NaN in a floating MIN / MAX column sets the stage's NaN bit next to its evaluation-error code (SSGPU_FLAG_NAN_IN_MINMAX).
+    # The bit is no error: it must not travel in the image headers as one (round 3's headers carried the raw word and a
+    # sharded job with a NaN anywhere failed with ERROR_EVALUATION_ERROR).  Across shards NaNs are skipped (ssgpu.h); with no
+    # NaN as a group's first value that is the reference's answer too, so the oracle is the check.  Merge large enough for
+    # the partitioned merge shape as well (>= 64 K rows of images).
+    import socket
+    import torch
+    import torch.distributed as dist
+    from supersonic_amd.distributed import DeviceShardedGroupAggregate
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = ss.Context(0)
+        rng = np.random.default_rng(77)
+        n = 400003
+        k = rng.integers(0, 90000, n).astype(np.int32)
+        x = rng.integers(-1000, 1000, n) * 0.5
+        first_of_group = np.zeros(n, bool)
+        first_of_group[np.unique(k, return_index=True)[1]] = True
+        x[(rng.random(n) < 0.05) & ~first_of_group] = np.nan          # NaNs, never as a group's first value
+        f = x.astype(np.float32)
+        schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("x", ss.DOUBLE), ss.Attribute("f", ss.FLOAT)])
+        view = ss.View(schema, [k, x, f])
+        spec = (ss.AggregationSpecification().AddAggregation(ss.MIN, "x", "mn").AddAggregation(ss.MAX, "x", "mx").AddAggregation(ss.MAX, "f", "mf")
+                .AddAggregation(ss.COUNT, "", "n"))
+        job = DeviceShardedGroupAggregate(ctx, ["k"], spec, ss.ScanView(view), exchange=exchange)
+        for _ in range(4):                                                  # the steady (lazily checked) steps too
+            job.step()
+            while not job.check():                                          # raises on an (alleged) evaluation error
+                job.step()
+        got = job.result()[0].fetch()
+        _schema, want = oracle_run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(view)))
+        assert_cols_equal(sort_rows(to_cols(got)), sort_rows(want), context="sharded MIN / MAX over a column with NaNs (%s)" % exchange)
     finally:
         dist.destroy_process_group()
 

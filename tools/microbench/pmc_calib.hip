@@ -86,6 +86,12 @@ int main(int argc, char** argv) {
       CHECK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(calib_gather_rec64, dim3(8192), dim3(256), 0, 0, (const uint4*)buf, rec64, small64 - 1, out); CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
       printf("gather_rec64       4 MiB window: %8.3f ms  %6.2f G records/s\n", time_ms(e0, e1), rec64 / time_ms(e0, e1) / 1e6);
     }
+    // where the rate changes: the same 64 M record reads over windows from one XCD's L2 (4 MiB) through the Infinity Cache (256 MiB) to DRAM
+    for (u64 mib = 2; mib <= 4096; mib *= 2) {
+      const u64 wrec = (mib << 20) / 64;
+      CHECK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(calib_gather_rec64, dim3(8192), dim3(256), 0, 0, (const uint4*)buf, rec64, wrec - 1, out); CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+      printf("window_sweep rec64 %5llu MiB: %8.3f ms  %6.2f G records/s\n", mib, time_ms(e0, e1), rec64 / time_ms(e0, e1) / 1e6);
+    }
     CHECK(hipDeviceSynchronize());
     printf("done\n");
     return 0;
