@@ -324,7 +324,7 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *                           default 1: a filter-less Compute / Project stage takes it from the device, no stream synchronise in between)
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),
  *                           sort_hi_digits (2..4, 0 = by row count), sort_compact (0 = (key, row id) pairs instead of one
- *                           (high half | row id) word), sort_bucketed (0 = payload records packed in row order, never partitioned by the key's top digit)
+ *                           (high half | row id) word)
  *   measurement:            profile, profile_total (HIP events around the stage kernels / the run: ssgpu_plan_counters,
  *                           ssgpu_plan_recent_kernel_ms), debug_timing
  *   development only (results may be WRONG): part_scatter_debug, part_agg_debug */
@@ -474,11 +474,12 @@ typedef struct ssgpu_stage_info {
   int32_t reruns;           /* attempts the last run needed beyond the first (regrown table, segments or partitions) */
   int32_t sort_passes;      /* radix passes of the last run */
   int32_t sort_mode;        /* 0 LSD over the varying digits, 1 high digits + tie fix-up, 2 one-word (high half | row id) keys;
-                               +16: tie runs were too long and all digits were sorted after all; +32: payload records in key-bucket order */
+                               +16: tie runs were too long and all digits were sorted after all */
   int32_t specialized;      /* bit 0 the stage's program, bit 1 the partition-scatter program, bit 2 the partition aggregation,
                                bit 3 the plain partition scatter, bit 4 the resident group aggregation */
   int32_t plain_scatter;    /* the partition scatter ran as its own kernel over (partition, XCD) segments, not as a VM program */
-  int32_t reserved[6];
+  int32_t hot_keys;         /* heavy-hitter keys the stage aggregates apart from the hash partitions (found when a segment overflowed; ABI 6) */
+  int32_t reserved[5];
 } ssgpu_stage_info;
 int32_t ssgpu_plan_stage_count(const ssgpu_plan* plan);
 int ssgpu_plan_stage_info(const ssgpu_plan* plan, int32_t stage, ssgpu_stage_info* out);

@@ -81,7 +81,7 @@ class MemoryStats(C.Structure):
 
 class StageInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "group_shape", "part_n", "part_seg_growth", "group_wgs_per_cu", "reruns",
-                                          "sort_passes", "sort_mode", "specialized", "plain_scatter")] + [("reserved", C.c_int32 * 6)]
+                                          "sort_passes", "sort_mode", "specialized", "plain_scatter", "hot_keys")] + [("reserved", C.c_int32 * 5)]
 
 
 class PlanDesc(C.Structure):

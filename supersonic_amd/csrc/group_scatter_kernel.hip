@@ -122,6 +122,16 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
   u32* const grec = start + NP + 2u;   // start[NP] = the tile's record count (+ one word of padding: the records stay 8-byte aligned)
   char* const stage = reinterpret_cast<char*>(grec + T);
   for (u32 i = t; i < NP; i += THREADS) cnt[i] = 0u;
+  // the heavy hitters' keys as a small open-addressing set (<= SSGPU_HOT_MAX keys in SSGPU_HOT_SLOTS slots)
+  __shared__ u64 hot_tab[SSGPU_HOT_SLOTS];
+  if (t < SSGPU_HOT_SLOTS) hot_tab[t] = VM_KEY_EMPTY;
+  __syncthreads();
+  if (t == 0)
+    for (u32 h = 0; h < P.n_hot; ++h) {
+      u32 i = hash_local(P.hot_keys[h]) & (SSGPU_HOT_SLOTS - 1u);
+      while (hot_tab[i] != VM_KEY_EMPTY && hot_tab[i] != P.hot_keys[h]) i = (i + 1u) & (SSGPU_HOT_SLOTS - 1u);
+      hot_tab[i] = P.hot_keys[h];
+    }
   __syncthreads();
   const u64 n = P.n_rows, n_tiles = (n + T - 1) / T;
   const u32 nf = PS_NFIELDS;
@@ -148,7 +158,15 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
       for (u32 f = 0; f < REGF; ++f)   // the leading 8-byte fields travel through registers: their loads are in flight during the ranking
         fv[j][f] = (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u && P.fields[f].src) ? reinterpret_cast<const u64*>(P.fields[f].src)[rowc] : 0ull;
       // heavy hitters are aggregated by the resident kernel (hot_only), not scattered: one key must not fill a partition's segments
-      for (u32 h = 0; h < P.n_hot; ++h) ok[j] = ok[j] & (key[j] != P.hot_keys[h]);
+      if (P.n_hot) {   // (uniform)
+        u32 i = hash_local(key[j]) & (SSGPU_HOT_SLOTS - 1u);
+        for (u32 probe = 0; probe < SSGPU_HOT_SLOTS; ++probe) {
+          const u64 cur = hot_tab[i];
+          if (cur == key[j]) { ok[j] = false; break; }
+          if (cur == VM_KEY_EMPTY) break;
+          i = (i + 1u) & (SSGPU_HOT_SLOTS - 1u);
+        }
+      }
       pt[j] = part_of(key[j], NP);
       pos[j] = 0u;
       if (ok[j]) pos[j] = atomicAdd(&cnt[pt[j]], 1u);
@@ -342,8 +360,9 @@ unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec
 hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (the kernel also has 512 bytes of static LDS -- the heavy hitters' key set: the dynamic part may take the rest of the 160 KiB)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     attr_done = true;
   }
   const unsigned int lds2 = ssgpu_part_scatter_plain_lds(P.n_parts, P.rec_words, 2), lds1 = ssgpu_part_scatter_plain_lds(P.n_parts, P.rec_words, 1);

@@ -82,7 +82,7 @@ hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes,
 #define SSGPU_PSCAT_MAX_KEYS 8
 #define SSGPU_PSCAT_MAX_FIELDS 24
 #define SSGPU_PSCAT_MAX_PREDS 4
-#define SSGPU_HOT_MAX 16     /* heavy-hitter keys a stage handles apart from the hash partitions */
+#define SSGPU_HOT_MAX 32     /* heavy-hitter keys a stage handles apart from the hash partitions */
 #define SSGPU_HOT_SLOTS 64   /* entries of the heavy hitters' LDS table = dense global slots reserved for them */
 struct PlainScatterParams {
   unsigned long long n_rows;
@@ -215,10 +215,6 @@ struct SortRecField { const void* src; void* dst; unsigned int off, width; };   
 struct SortRecParams { void* recs; unsigned long long n; unsigned int stride, n_fields; SortRecField fields[SSGPU_SORT_MAX_FIELDS]; };
 hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s);
 hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s);
-// the pack pass as a stable partition of the records by the key's top digit (see ssgpu_sort_partition_pack_kernel)
-uint32_t ssgpu_sort_partition_rows(uint32_t stride);
-hipError_t ssgpu_launch_sort_partition_pack(const SortRecParams& P, const uint64_t* keys, uint64_t* words, uint64_t* keys_part, const uint32_t* digit_base,
-                                            unsigned long long* status, uint32_t* ticket, uint64_t epoch, uint32_t* stuck, hipStream_t s);
 hipError_t ssgpu_launch_sort_fix_ties_compact(uint64_t* kc, const uint64_t* keys, uint64_t n, uint32_t* too_long, hipStream_t s);
 hipError_t ssgpu_launch_sort_extract_idx(uint32_t* idx, const uint64_t* kc, uint64_t n, hipStream_t s);
 // View-file loader: one piece = one column (or NULL-mask) segment of one file chunk inside a staged slab

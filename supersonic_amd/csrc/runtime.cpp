@@ -58,7 +58,6 @@ struct ssgpu_ctx {
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
-  int64_t sort_bucketed = 1;     // 0: payload records always packed in row order (no partition by the key's top digit)
   int64_t sort_hi_digits = 4;    // high digits the hybrid sort passes over before fixing ties: 2..4, 0 = by row count
   int64_t part_agg_lds = 0;      // LDS bytes of phase 2's workgroup (0 = 80 KiB: two workgroups per CU)
   int64_t profile = 1;           // record HIP events around kernels
@@ -183,7 +182,6 @@ struct StageExec {
   DevBuf debug, debug_pc, total2;
   // sort / clusters
   DevBuf skeys_a, skeys_b, skeys_c, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
-  DevBuf skeys_p, pstatus;      // bucket-ordered records (ssgpu_sort_partition_pack_kernel): the keys by record position, its look-back status words
   DevBuf route_scratch;         // key-range exchange: per-destination counters + (destination, position) of every result row
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
@@ -348,7 +346,6 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "sort_hybrid") c->sort_hybrid = value;
   else if (k == "sort_hi_digits") c->sort_hi_digits = value;
   else if (k == "sort_compact") c->sort_compact = value;
-  else if (k == "sort_bucketed") c->sort_bucketed = value;
   else if (k == "group_capacity") {
     int64_t cap = 1; while (cap < value) cap <<= 1;
     c->group_capacity = cap;
@@ -1124,9 +1121,9 @@ static int ensure_rowid_tmp(ssgpu_ctx* c, Stage& st, StageExec& ex, uint64_t row
   return SSGPU_OK;
 }
 
-int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, uint32_t ng, const InCols& in, int64_t row_id_base) {
+int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, uint32_t ng, const InCols& in, int64_t row_id_base, uint32_t extra_slots = 0) {
   ssgpu_ctx* c = p->ctx;
-  const size_t slots = (size_t)capacity + 1;
+  const size_t slots = (size_t)capacity + 1 + extra_slots;
   const int ntile = (int)((slots + 511) / 512);
   int rc = ensure_out_cols(c, st, ex, (int64_t)slots);
   if (rc != SSGPU_OK) return rc;
@@ -1144,7 +1141,7 @@ int extract_groups(ssgpu_plan* p, Stage& st, StageExec& ex, uint32_t capacity, u
   memset(&G, 0, sizeof(G));
   G.keys = ex.gkeys.as<unsigned long long>();
   G.acc = ex.gacc.as<unsigned long long>(); G.cnt = ex.gcnt.as<unsigned int>();
-  G.capacity = capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size();
+  G.capacity = capacity; G.n_gaggs = ng; G.n_keys = (uint32_t)st.group_keys.size(); G.n_aggs_out = (uint32_t)st.aggs.size(); G.extra_slots = extra_slots;
   for (size_t k = 0; k < st.group_keys.size(); ++k) {
     const GroupKeyField& f = st.group_keys[k];
     G.keys_out[k].data = ex.out[k].data.p;
@@ -1346,6 +1343,40 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.outputs[0].dst = ex.part_recs.p; Ps.outputs[0].width = st.part_rec_bytes;
     if (!plain && !resident) { int rc = attach_pc_profile(c, ex, &Ps); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+    if (hot && plain) {
+      // The heavy hitters' rows: aggregated by the resident kernel in its hot_only form -- every workgroup holds a small table
+      // seeded with the hot keys, reads the input columns, skips every row of another key, and merges its entries into the
+      // dense slots capacity + 1 + e.  The scatter below skips exactly these rows.
+      PlainScatterParams S; fill_plain_source(S);
+      S.rec_words = W;
+      S.n_hot = ex.hot_n; for (uint32_t h = 0; h < ex.hot_n; ++h) S.hot_keys[h] = ex.hot_keys[h];
+      PartAggParams H; memset(&H, 0, sizeof(H));
+      H.rec_words = W; H.slab_segs = 1; H.n_segs = 0; H.seg_cap = 1;
+      H.local_capacity = SSGPU_HOT_SLOTS; H.n_gaggs = ng; H.n_aggs = (unsigned int)st.part_aggs.size(); H.any_cnt = any_cnt ? 1u : 0u;
+      H.T.keys = ex.gkeys.as<unsigned long long>(); H.T.acc = ex.gacc.as<unsigned long long>(); H.T.cnt = ex.gcnt.as<unsigned int>();
+      H.T.overflow = ex.goverflow.as<unsigned int>() + 2; H.T.capacity_mask = capacity - 1u; H.T.n_gaggs = ng;
+      H.T.acc_init = ex.gpattern.as<unsigned long long>(); H.T.merge_op = ex.gmergeop.as<unsigned int>();
+      H.nan_flag = ex.error_flag.as<unsigned int>();
+      H.hot_only = 1u; H.hot_base = capacity + 1u;
+      for (size_t j = 0; j < st.part_aggs.size(); ++j) {
+        const Stage::PartAgg& a = st.part_aggs[j];
+        H.desc[j] = (uint64_t)(uint16_t)a.op | ((uint64_t)(uint8_t)a.word << 16) | ((uint64_t)(uint8_t)(a.val_off < 0 ? 0xFF : a.val_off) << 24) |
+                    ((uint64_t)(uint8_t)a.val_width << 32) | ((uint64_t)(uint8_t)(a.null_off < 0 ? 0xFF : a.null_off) << 40) | ((uint64_t)(a.has_cnt ? 1 : 0) << 48);
+      }
+      const uint32_t hot_lds = fixed + SSGPU_HOT_SLOTS * entry;
+      const int hgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
+      H.n_parts = (unsigned int)hgrid;
+      if (p->specialize && !(ex.rtc_hot.tried && ex.rtc_hot.static_lds == hot_lds)) {
+        if (ex.rtc_hot.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_hot.drop(); }
+        ex.rtc_hot.tried = true; ex.rtc_hot.static_lds = hot_lds;
+        std::string why;
+        ex.rtc_hot.h = ssgpu_rtc_specialize_part_agg(c->device, H.desc, (int)H.n_aggs, W, ng, any_cnt, hot_lds, &why, &S);
+        if (!ex.rtc_hot.h && ex.rtc_why.empty()) ex.rtc_why = "heavy-hitter aggregation: " + why;
+      }
+      if (p->specialize && ex.rtc_hot.h && ex.rtc_hot.static_lds == hot_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_hot.h, H, S, hgrid, c->stream));
+      else HIP_TRY(c, ssgpu_launch_group_resident(H, S, hot_lds, hgrid, c->stream));
+      p->counters.n_launches += 1;
+    }
     if (resident) {
       // nothing to scatter
     } else if (plain) {
@@ -1439,7 +1470,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       // steady state: this shape held the last runs -- the flags are looked at lazily (settle_plan), no synchronise here
       { const int rc = record_feedback(c, ex); if (rc != SSGPU_OK) return rc; }
       ex.fb_pending = 2; p->deferred = true;
-      return extract_groups(p, st, ex, capacity, ng, in, row_id_base);
+      return extract_groups(p, st, ex, capacity, ng, in, row_id_base, extra);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (attempt == 0 && !fb[0] && !fb[1]) ++ex.steady; else ex.steady = 0;
@@ -1451,6 +1482,25 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     }
     if (fb[1]) {   // skewed keys: larger segments (memory permitting), else the direct path
       if (ex.part_seg_growth >= 64) { *fallback = true; return SSGPU_OK; }
+      if (plain && !ex.hot_tried) {
+        // Skewed keys?  Look at a sample of the rows before making every segment larger: a few keys that hold a large share of
+        // the rows (each would fill ONE partition) are taken out of the partitions altogether and aggregated on their own
+        // (ssgpu_hot_keys_kernel -> hot_only resident pass + a scatter that skips them), and the rest fits the segments as sized.
+        ex.hot_tried = true;
+        PlainScatterParams S; fill_plain_source(S);
+        HIP_TRY(c, ex.hot_out.ensure((1 + 2 * SSGPU_HOT_MAX) * 8));
+        const uint64_t n_sample = (uint64_t)std::min<int64_t>(in.rows, (int64_t)1 << 18);
+        // "hot": at least a quarter of a partition's expected share of the sample
+        const uint32_t min_count = (uint32_t)std::max<uint64_t>(n_sample / (4ull * NP), 16);
+        HIP_TRY(c, ssgpu_launch_hot_keys(S, n_sample, min_count, ex.hot_out.as<unsigned long long>(), c->stream));
+        uint64_t found[1 + 2 * SSGPU_HOT_MAX];
+        HIP_TRY(c, hipMemcpyAsync(found, ex.hot_out.p, sizeof(found), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        ex.hot_n = (uint32_t)std::min<uint64_t>(found[0], SSGPU_HOT_MAX);
+        for (uint32_t h = 0; h < ex.hot_n; ++h) ex.hot_keys[h] = found[1 + 2 * h];
+        if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: %u heavy-hitter key(s) in a sample of %llu rows (threshold %u)\n", ex.hot_n, (unsigned long long)n_sample, min_count);
+        if (ex.hot_n > 0) continue;   // again, with the heavy hitters handled apart
+      }
       if (plain) {
         // the plain scatter's segment counters kept counting past the end: the fullest one says what this input needs.
         // One step to that size -- or, when such segments would not fit in a quarter of the free memory (one group holds
@@ -1472,7 +1522,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       ex.part_seg_growth *= 4;
       continue;
     }
-    if (!fb[0]) return extract_groups(p, st, ex, capacity, ng, in, row_id_base);
+    if (!fb[0]) return extract_groups(p, st, ex, capacity, ng, in, row_id_base, extra);
     if (ex.part_n >= 8192) break;
     ex.part_n *= 2;   // a partition held more groups than its LDS table: partition finer and rerun
   }
@@ -1795,25 +1845,10 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
   };
   build_layout();
   if (compact && !use_records) { compact = false; major_direct = major_direct0; build_layout(); }   // the one-word form gathers through records
-  // One sort key, sorted as one-word keys: the pack pass is also a stable partition of the records by the key's top digit, and the
-  // sorted words carry record POSITIONS instead of row ids -- the final gather then reads inside one bucket (1 / 256 of the
-  // table) at a time, on chip, instead of all over it (sort_kernels.hip: ssgpu_sort_partition_pack_kernel).
-  bool bucketed = false;
   if (use_records) {
     HIP_TRY(c, ex.srecs.ensure((size_t)n * R.stride + 16));
     R.recs = ex.srecs.p;
-    const uint32_t tile_rows = ssgpu_sort_partition_rows(R.stride);
-    bucketed = compact && k_first == 0 && tile_rows != 0 && c->sort_bucketed != 0 && n >= (1u << 20) && ((first_varying >> 56) & 0xFFull) != 0;
-    if (bucketed) {
-      HIP_TRY(c, ex.skeys_p.ensure(std::max<uint64_t>(n, 1) * 8));
-      const size_t need = (size_t)((n + tile_rows - 1) / tile_rows) * 256 * 8;
-      if (need > ex.pstatus.cap || !ex.pstatus.p) { HIP_TRY(c, ex.pstatus.ensure(need)); HIP_TRY(c, hipMemsetAsync(ex.pstatus.p, 0, ex.pstatus.cap, c->stream)); }
-      HIP_TRY(c, ssgpu_launch_sort_partition_pack(R, ka, kb, ex.skeys_p.as<uint64_t>(), ex.soffs.as<uint32_t>() + 7 * 256, ex.pstatus.as<unsigned long long>(),
-                                                  ex.sticket.as<uint32_t>() + n_pass, ++ex.sort_epoch, ex.sticket.as<uint32_t>() + 63, c->stream));
-      ++n_pass;
-    } else {
-      HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream));
-    }
+    HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream));
     p->counters.n_launches += 1;
   }
   if (!keys_only && !compact) HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
@@ -1855,7 +1890,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
         std::swap(kc, kd);
       }
       uint32_t* flag = ex.sticket.as<uint32_t>() + 62;
-      HIP_TRY(c, ssgpu_launch_sort_fix_ties_compact(kc, bucketed ? ex.skeys_p.as<uint64_t>() : ka, n, flag, c->stream));   // (low halves by row id, or by record position)
+      HIP_TRY(c, ssgpu_launch_sort_fix_ties_compact(kc, ka, n, flag, c->stream));
       uint32_t too_long = 0;
       HIP_TRY(c, hipMemcpyAsync(&too_long, flag, 4, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1868,7 +1903,6 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
         // long runs of equal high halves: the plain LSD order over all digits (the key array and the digit offsets are untouched)
         HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));
         HIP_TRY(c, ssgpu_launch_sort_iota(ia, n, c->stream));
-        if (bucketed) { HIP_TRY(c, ssgpu_launch_sort_pack(R, c->stream)); bucketed = false; }   // the plain order gathers by ROW id: records back in row order
         compact = false; tie_runs_too_long = true; sort_mode = 2 + 16;
       }
     }
@@ -1926,7 +1960,7 @@ int run_sort(ssgpu_plan* p, size_t si, const InCols& in) {
     p->counters.n_launches += 1;
   }
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
-  ex.last_sort_passes = (int)n_pass; ex.last_sort_mode = sort_mode + (bucketed ? 32 : 0);
+  ex.last_sort_passes = (int)n_pass; ex.last_sort_mode = sort_mode;
   if (n_pass) {   // the look-back never gives up on a healthy device; if it did, the order is wrong: fail loudly
     uint32_t stuck = 0;
     HIP_TRY(c, hipMemcpyAsync(&stuck, ex.sticket.as<uint32_t>() + 63, 4, hipMemcpyDeviceToHost, c->stream));
@@ -2331,6 +2365,7 @@ int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* 
   out->sort_passes = ex.last_sort_passes; out->sort_mode = ex.last_sort_mode;
   out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0) + (ex.rtc_plain.h ? 8 : 0) + (ex.rtc_resident.h ? 16 : 0);
   out->plain_scatter = ex.last_plain_scatter ? 1 : 0;
+  out->hot_keys = (int32_t)ex.hot_n;
   return SSGPU_OK;
 }
 void ssgpu_specialized_kernels_trim(int32_t keep) { ssgpu_rtc_trim(keep); }

@@ -509,156 +509,6 @@ __global__ __launch_bounds__(256) void ssgpu_sort_pack_kernel(const SortRecParam
   for (u32 j = (u32)t; j < chunks; j += 256) out[j] = reinterpret_cast<const uint4*>(tile)[j];
 }
 
-// ---- payload records in KEY-BUCKET order (round 4) ----------------------------------------------------------------------
-// The record gather at the end of the sort is 100 M random 64-byte reads.  Measured (tools/microbench/pmc_calib.hip, window
-// sweep): such reads run at 47 G records/s when they spread over more than ~128 MiB (DRAM), and at 230 - 300 G records/s when
-// the rows a wave of workgroups asks for sit within <= 32 MiB (they are then served on chip, by the Infinity Cache).  So the
-// records are not packed in ROW order any more: this kernel is the pack pass AND a stable partition of the records by the
-// key's top digit (256 buckets) -- the one-sweep scheme of the radix passes (ticket-ordered tiles, per-digit status words,
-// decoupled look-back) with the whole record as payload, staged in LDS in bucket order so that a bucket's run of a tile
-// leaves as one contiguous piece.  Every row's sorted word becomes (high half << 32 | POSITION of its record) instead of
-// (high half << 32 | row id); the radix passes and the tie fix-up do not care, and the final gather of an output row reads a
-// record of the bucket that output row belongs to -- 1 / 256 of the table (25 MB for 100 M x 64 B), not all of it.
-// keys: the transformed 64-bit keys in row order (ssgpu_sort_load_keys_hist_kernel); words: the one-word keys, low half
-// rewritten here; keys_part[pos]: the full key of the record at `pos` (the tie fix-up reads low halves by position).
-template <int CPR, int ROWS>
-__global__ __launch_bounds__(256) void ssgpu_sort_partition_pack_kernel(const SortRecParams P, const u64* __restrict__ keys, u64* __restrict__ words,
-                                                                        u64* __restrict__ keys_part, const u32* __restrict__ digit_base,
-                                                                        unsigned long long* __restrict__ status, u32* __restrict__ ticket, u64 epoch,
-                                                                        u32* __restrict__ stuck) {
-  constexpr int NW = 4, TR = 256 * ROWS, S = 16 * CPR;
-  extern __shared__ __attribute__((aligned(16))) char stage[];   // TR records in bucket order
-  __shared__ u32 wave_cnt[NW][256];
-  __shared__ u32 scanbuf[256];
-  __shared__ u32 goff[256];
-  __shared__ u64 lkey[TR];
-  __shared__ u32 tile_s;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) tile_s = atomicAdd(ticket, 1u);
-  for (int d = lane; d < 256; d += 64) wave_cnt[wave][d] = 0;
-  __syncthreads();
-  const u32 tile = tile_s;
-  const u64 tile_base = (u64)tile * TR;
-  const u64 wave_base = tile_base + (u64)wave * (TR / NW);
-  u64 k[ROWS];
-#pragma unroll
-  for (int j = 0; j < ROWS; ++j) {
-    const u64 i = wave_base + (u64)j * 64 + lane;
-    const bool ok = i < P.n;
-    k[j] = ok ? keys[i] : ~0ull;
-    if (ok) atomicAdd(&wave_cnt[wave][(u32)(k[j] >> 56)], 1u);
-  }
-  __syncthreads();
-  u32 tot = 0, prefix = 0;
-  {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) tot += wave_cnt[w][t];
-    const u64 tag = (epoch & 0x3FFFFFFFull) << 32;
-    unsigned long long* const mine = status + (u64)tile * 256 + t;
-    __hip_atomic_store(mine, ONESWEEP_AGG | tag | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (u32 j = tile; j > 0; --j) {
-      const unsigned long long* const p = status + (u64)(j - 1) * 256 + t;
-      u64 x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      u32 spins = 0;
-      while ((x >> 62) == 0 || (x & (0x3FFFFFFFull << 32)) != tag) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) { atomicExch(stuck, 1u); break; }      // never expected: give up rather than hang the device
-        x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      prefix += (u32)x;
-      if ((x >> 62) == 2) break;
-    }
-    __hip_atomic_store(mine, ONESWEEP_PREFIX | tag | (u64)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    scanbuf[t] = tot;
-  }
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    const u32 v = t >= o ? scanbuf[t - o] : 0u;
-    __syncthreads();
-    scanbuf[t] += v;
-    __syncthreads();
-  }
-  {
-    const u32 excl = scanbuf[t] - tot;
-    goff[t] = digit_base[t] + prefix - excl;      // record position of local position e with digit t: goff[t] + e
-    u32 run = excl;
-    for (int w = 0; w < NW; ++w) { const u32 c = wave_cnt[w][t]; wave_cnt[w][t] = run; run += c; }
-  }
-  __syncthreads();
-  const u32 valid = scanbuf[255];
-  // stable rank of every row inside the tile (row order = (wave, step, lane) order, as in the radix passes)
-  const u64 lt = (1ull << lane) - 1ull;
-  u32 lp[ROWS];
-#pragma unroll
-  for (int j = 0; j < ROWS; ++j) {
-    const u64 i = wave_base + (u64)j * 64 + lane;
-    const bool ok = i < P.n;
-    const u32 d = (u32)(k[j] >> 56);
-    u64 peers = __ballot(ok);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const u64 bal = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? bal : ~bal;
-    }
-    lp[j] = 0;
-    if (ok) {
-      lp[j] = wave_cnt[wave][d] + (u32)__popcll(peers & lt);
-      lkey[lp[j]] = k[j];
-      words[i] = (k[j] & 0xFFFFFFFF00000000ull) | (u64)(goff[d] + lp[j]);   // the row's sorted word now names its record's position
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (ok && (peers & lt) == 0) wave_cnt[wave][d] += (u32)__popcll(peers);
-    __builtin_amdgcn_wave_barrier();
-  }
-  // the rows' fields, straight from the columns into their records' places in LDS: eight fields x ROWS rows of loads in flight
-  for (u32 c0 = 0; c0 < P.n_fields; c0 += 8) {
-    u64 v[8][ROWS];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (c0 + q < P.n_fields) {                  // (uniform)
-        const SortRecField f = P.fields[c0 + q];
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) {
-          const u64 i = wave_base + (u64)j * 64 + lane;
-          const u64 ic = i < P.n ? i : 0ull;
-          v[q][j] = !f.src ? 0ull : f.width == 8 ? reinterpret_cast<const u64*>(f.src)[ic] : f.width == 4 ? (u64)reinterpret_cast<const u32*>(f.src)[ic]
-                                                                                                    : (u64)reinterpret_cast<const u8*>(f.src)[ic];
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (c0 + q < P.n_fields) {
-        const SortRecField f = P.fields[c0 + q];
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) {
-          const u64 i = wave_base + (u64)j * 64 + lane;
-          if (i >= P.n) continue;
-          char* dst = stage + lp[j] * (u32)S + f.off;
-          if (f.width == 8) *reinterpret_cast<u64*>(dst) = v[q][j];
-          else if (f.width == 4) *reinterpret_cast<u32*>(dst) = (u32)v[q][j];
-          else *reinterpret_cast<u8*>(dst) = (u8)v[q][j];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // write-out: local position e -> record goff[digit(e)] + e; a bucket's run of the tile is contiguous
-#pragma unroll
-  for (int i = 0; i < ROWS * CPR; ++i) {
-    const u32 j = (u32)t + 256u * (u32)i, e = j / (u32)CPR, ch = j % (u32)CPR;
-    if (e < valid) {
-      const u64 pos = (u64)goff[(u32)(lkey[e] >> 56)] + e;
-      reinterpret_cast<uint4*>(P.recs)[pos * CPR + ch] = reinterpret_cast<const uint4*>(stage)[j];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const u32 e = (u32)t + 256u * (u32)i;
-    if (e < valid) keys_part[(u64)goff[(u32)(lkey[e] >> 56)] + e] = lkey[e];
-  }
-}
-
 // The same gather for records of CPR x 16 bytes, written for what bounds it: every row is one random 16 x CPR-byte read, and
 // a random read is a DRAM round trip.  The generic kernel below loops `load -> wait -> LDS store` once per 16-byte chunk (the
 // compiler keeps the wait inside the loop: the trip count is a run-time value), i.e. CPR dependent round trips per thread;
@@ -666,6 +516,10 @@ __global__ __launch_bounds__(256) void ssgpu_sort_partition_pack_kernel(const So
 // (round 4): random 64-byte reads issued this way run at 43 G records/s over a 4 GiB window; the counters say one 64-byte
 // request per record (FETCH_SIZE is exact for them -- it is halved only for 128-byte streaming requests).
 // The output columns are written with nontemporal stores: nothing reads them again before the kernel ends.
+// (Round 4 also tried packing the records in key-BUCKET order -- a stable one-sweep partition of whole records by the key's top
+//  digit instead of the row-order pack, so that this gather reads inside a 25 MB bucket (on chip: 230 G records/s) instead of
+//  all over 6.4 GB.  Measured, same box: the gather 3.45 -> 2.95 ms (it is at copy speed: 13 GB move either way), the
+//  partitioning pack 4.59 ms against 2.25 ms -- 11.4 vs 9.5 ms for the sort.  Removed; profiles/r04_sort_bucketed_experiment.json.)
 template <int CPR>
 __global__ __launch_bounds__(256) void ssgpu_sort_gather_rec_fast_kernel(const SortRecParams P, const u32* __restrict__ idx, u32 idx_stride) {
   extern __shared__ __attribute__((aligned(16))) char tile[];
@@ -939,27 +793,6 @@ hipError_t ssgpu_launch_sort_fix_ties(uint64_t* keys, uint32_t* idx, uint64_t n,
 }
 hipError_t ssgpu_launch_sort_pack(const SortRecParams& P, hipStream_t s) {
   if (P.n) hipLaunchKernelGGL(ssgpu_sort_pack_kernel, dim3(blocks_for(P.n, 256)), dim3(256), 256 * P.stride, s, P);
-  return hipGetLastError();
-}
-// rows per tile of the bucket-ordered pack (64 KiB of staged records at most; 0: the record is too wide for it)
-uint32_t ssgpu_sort_partition_rows(uint32_t stride) {
-  const uint32_t cpr = stride % 16u == 0 ? stride / 16u : 0u;
-  return cpr == 0 || cpr > 8 ? 0u : cpr <= 4 ? 1024u : 512u;
-}
-hipError_t ssgpu_launch_sort_partition_pack(const SortRecParams& P, const uint64_t* keys, uint64_t* words, uint64_t* keys_part, const uint32_t* digit_base,
-                                            unsigned long long* status, uint32_t* ticket, uint64_t epoch, uint32_t* stuck, hipStream_t s) {
-  const uint32_t tr = ssgpu_sort_partition_rows(P.stride);
-  if (!P.n || !tr) return hipGetLastError();
-  const dim3 g(blocks_for(P.n, tr)), b(256);
-  const size_t lds = (size_t)tr * P.stride;
-  // up to 64 KiB of staged records next to 14 KiB of static LDS: above the default dynamic-LDS limit of a kernel
-#define PP(CPR, ROWS) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_sort_partition_pack_kernel<CPR, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; } } \
-  hipLaunchKernelGGL((ssgpu_sort_partition_pack_kernel<CPR, ROWS>), g, b, lds, s, P, (const u64*)keys, (u64*)words, (u64*)keys_part, digit_base, status, ticket, (u64)epoch, stuck)
-  switch (P.stride / 16u) {
-    case 1: PP(1, 4); break; case 2: PP(2, 4); break; case 3: PP(3, 4); break; case 4: PP(4, 4); break;
-    case 5: PP(5, 2); break; case 6: PP(6, 2); break; case 7: PP(7, 2); break; default: PP(8, 2); break;
-  }
-#undef PP
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_sort_gather_rec(const SortRecParams& P, const uint32_t* idx, uint32_t idx_stride, hipStream_t s) {

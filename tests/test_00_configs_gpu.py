@@ -140,7 +140,30 @@ def test_config3_skewed_keys_overflow_their_segments(specialize, part_plain):
     _s, want = oracle.run(op)
     plan = ss.Plan(op, make_ctx(group_partition=2, specialize=specialize, part_plain=part_plain))
     infos = check_plan(plan, want, "config #3 skewed", ignore_order=True, runs=2)
-    assert infos[0][0]["part_seg_growth"] > 1 or infos[0][0]["group_shape"] == 0, infos   # grew its segments (or, beyond x64, fell back to the direct shape)
+    if part_plain:
+        # the plain scatter looks at a sample of the rows when a segment overflows: the one hot pair is aggregated apart from the
+        # partitions (hot_only resident pass), the segments stay as sized and the stage stays in the partitioned shape
+        assert infos[0][0]["hot_keys"] >= 1 and infos[-1][0]["group_shape"] == 1 and infos[-1][0]["part_seg_growth"] == 1, infos
+        assert infos[-1][0]["reruns"] == 0, infos                                         # the second run knows the hot key already
+    else:
+        assert infos[0][0]["part_seg_growth"] > 1 or infos[0][0]["group_shape"] == 0, infos   # grew its segments (or, beyond x64, fell back to the direct shape)
+
+
+def test_config3_many_heavy_hitters_next_to_uniform_keys():
+    # 20 keys hold 60 % of the rows between them (3 % each) and the EMPTY-sentinel-free rest is uniform: all of them are found
+    # in the sample and aggregated apart; a NULLABLE value column and a Filter ride along (the hot pass applies both)
+    cols = bench.host_columns(np, "group", N_ROWS, seed=17)
+    rng = np.random.default_rng(18)
+    u = rng.random(N_ROWS)
+    hot_g = rng.integers(0, 100000, 20)
+    g = np.where(u < 0.6, hot_g[(u * 1e6).astype(np.int64) % 20], cols[1].astype(np.int64) * 317 + cols[2])
+    cols[1], cols[2] = (g // 317).astype(np.int32), (g % 317).astype(np.int32)
+    view = ss.View(bench.group_schema(ss), cols)
+    for op in (group3_op(view), ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), bench.group_spec(ss), None, bench.group_child(ss, view))):
+        _s, want = oracle.run(op)
+        plan = ss.Plan(op, make_ctx(group_partition=2, specialize=1))
+        infos = check_plan(plan, want, "config #3, 20 heavy hitters", ignore_order=True, runs=3)
+        assert infos[0][0]["hot_keys"] >= 15 and infos[-1][0]["group_shape"] == 1 and infos[-1][0]["part_seg_growth"] == 1, infos
 
 
 def test_config3_shape_with_few_groups_takes_the_slab_form():
@@ -219,28 +242,22 @@ def unique_keys(cols):
 
 
 def test_config5_sort_8_columns_one_word_passes_and_record_gather():
-    # the default form: one-word keys, the records packed in key-BUCKET order (mode 2 + 32: the pack pass partitions them by the
-    # key's top digit, the sorted words carry record positions), four radix passes + the partitioning pass
-    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2 + 32,), "config #5")
-    assert infos[-1][0]["sort_passes"] == 5, infos       # the partition-pack pass + the four high digits; ties finished by ssgpu_sort_fix_ties_compact
-    # the same with the records packed in row order (round 3's form)
-    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2,), "config #5, records in row order", sort_bucketed=0)
-    assert infos[-1][0]["sort_passes"] == 4, infos
+    infos = check_sort(unique_keys(bench.host_columns(np, "wide", N_ROWS)), (2,), "config #5")
+    assert infos[-1][0]["sort_passes"] == 4, infos       # the four high digits; ties finished by ssgpu_sort_fix_ties_compact
 
 
-def test_config5_sort_bucketed_records_ragged_sizes_and_skewed_top_digits():
-    # the bucket-ordered pack at sizes that end inside a tile, with top digits that are all equal but one (one huge bucket) and
-    # with negative / positive keys (the top digit's sign flip), NULLABLE payload columns riding in the records
+def test_config5_sort_ragged_sizes_one_top_digit_and_mixed_signs():
+    # sizes that end inside a tile; keys with ONE top digit (distinct high halves below it) and keys of both signs
     rng = np.random.default_rng(21)
-    for n, shape in ((1 << 20, "uniform"), ((1 << 20) + 777, "one_bucket"), (1500001, "two_buckets")):
+    for n, shape in ((1 << 20, "uniform"), ((1 << 20) + 777, "one_top_digit"), (1500001, "both_signs")):
         cols = bench.host_columns(np, "wide", n, seed=13)
-        if shape == "one_bucket":
-            cols[3] = (np.int64(5) << 56) | (rng.permutation(n).astype(np.int64) << 33) | 1      # one top digit, distinct high halves
-            cols[3][0] = -7                                                   # (a second top digit: the digit has to vary for this form)
-        elif shape == "two_buckets":
+        if shape == "one_top_digit":
+            cols[3] = (np.int64(5) << 56) | (rng.permutation(n).astype(np.int64) << 33) | 1
+            cols[3][0] = -7
+        elif shape == "both_signs":
             cols[3] = np.where(np.arange(n) % 3 == 0, -1 - rng.permutation(n).astype(np.int64) * 1000003, rng.permutation(n).astype(np.int64) * 1000003)
-        infos = check_sort(unique_keys(cols), (2 + 32,), "config #5 bucketed, %s, %d rows" % (shape, n))
-        assert infos[-1][0]["sort_passes"] == 5, infos
+        # (whatever form the keys send the sort to -- the both-signs keys have few distinct high halves: long tie runs, all digits)
+        check_sort(unique_keys(cols), (2, 1, 0, 2 + 16, 1 + 16), "config #5, %s, %d rows" % (shape, n))
 
 
 def test_config5_sort_colliding_high_halves_fall_back_to_all_digits():
