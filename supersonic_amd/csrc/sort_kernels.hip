@@ -12,6 +12,7 @@
 // AggregateClusters (cursor/core/aggregate_clusters.cc:97-122,286-315): cluster boundary
 // flags + exclusive scan give every row its output row ("segment id").
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
@@ -268,6 +269,11 @@ __global__ __launch_bounds__(256) void ssgpu_sort_scan_hist8_kernel(const u32* _
 #ifndef SSGPU_ONESWEEP_LOOKBACK
 #define SSGPU_ONESWEEP_LOOKBACK 4      /* measured per pass, 100 M one-word keys: 1: 0.73 ms, 2: 0.70, 4: 0.68, 8: 0.71, 16: 0.74 */
 #endif
+// Where a pass's time goes (round 4, 100 M one-word keys, parts of the kernel switched off one at a time, same box; 0.79 ms whole):
+//   key loads alone 0.19 | + histogram 0.17 | + look-back 0.14 | + ranking 0.13 | + write-out 0.19 ms -- the phases add up (two
+//   512-thread workgroups per CU overlap little), and with histogram and ranking fused (below) the pass without its look-back
+//   drops from 0.65 to 0.56 ms while the whole pass stays at 0.77: the chain of tiles waiting for their predecessors' counts sets
+//   the pace (profiles/r04_sort_onesweep_attribution.json).
 template <bool HAS_IDX, int THREADS, int LB = SSGPU_ONESWEEP_LOOKBACK>
 __global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
     const u64* __restrict__ keys_in, const u32* __restrict__ idx_in, u64* __restrict__ keys_out, u32* __restrict__ idx_out,
@@ -294,7 +300,32 @@ __global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
     const bool ok = i < n;
     k[j] = ok ? keys_in[i] : ~0ull;
     id[j] = (HAS_IDX && ok) ? idx_in[i] : 0u;
-    if (ok) atomicAdd(&wave_cnt[wave][(k[j] >> shift) & 0xFF], 1u);
+  }
+  // Histogram AND stable rank in one sweep over the wave's keys (round 4; it used to be one LDS atomic per key here and, after the
+  // scan, a second sweep with the same eight ballots per key plus a read-modify-write of the running digit position per step --
+  // measured with parts switched off: 0.17 + 0.13 of a 0.79 ms pass).  Per step of 64 keys: the lanes that share a digit find each
+  // other by ballots, the lowest of them (the leader) adds the group's size to the wave's counter of that digit with ONE returning
+  // LDS atomic -- different leaders hit different counters -- and what it gets back is the number of keys with that digit in the
+  // wave's EARLIER steps; every lane's rank among the wave's keys of its digit is that number plus the lanes of its group below it.
+  // When the sweep ends the counters hold the histogram, and placing a key later is one add.
+  const u64 lt = (1ull << lane) - 1ull;
+  u32 off[SORT_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; ++j) {
+    const u64 i = wave_base + (u64)j * 64 + lane;
+    const bool ok = i < n;
+    const u32 d = (u32)(k[j] >> shift) & 0xFF;
+    u64 peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const u64 bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const int leader = ok ? __ffsll((long long)peers) - 1 : lane;
+    u32 before = 0;
+    if (ok && lane == leader) before = atomicAdd(&wave_cnt[wave][d], (u32)__popcll(peers));
+    before = (u32)__shfl((int)before, leader);
+    off[j] = before + (u32)__popcll(peers & lt);
   }
   __syncthreads();
   u32 tot = 0, prefix = 0;
@@ -351,28 +382,15 @@ __global__ __launch_bounds__(THREADS) void ssgpu_sort_onesweep_kernel(
   }
   __syncthreads();
   const u32 valid = scanbuf[255];
-  // rank and place into LDS, 64 consecutive elements per step
-  const u64 lt = (1ull << lane) - 1ull;
+  // place into LDS in digit order: the wave's first position of the digit (wave_cnt, set above) + the key's rank among the wave's keys of it
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; ++j) {
     const u64 i = wave_base + (u64)j * 64 + lane;
-    const bool ok = i < n;
-    const u32 d = (u32)(k[j] >> shift) & 0xFF;
-    u64 peers = __ballot(ok);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const u64 bal = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? bal : ~bal;
-    }
-    if (ok) {
-      const u32 rank = (u32)__popcll(peers & lt);
-      const u32 pos = wave_cnt[wave][d] + rank;
+    if (i < n) {
+      const u32 pos = wave_cnt[wave][(u32)(k[j] >> shift) & 0xFF] + off[j];
       lk[pos] = k[j];
       if (HAS_IDX) li[pos] = id[j];
     }
-    __builtin_amdgcn_wave_barrier();
-    if (ok && (peers & lt) == 0) wave_cnt[wave][d] += (u32)__popcll(peers);
-    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   // coalesced write-out of the digit-ordered tile
