@@ -3,6 +3,7 @@
 block sizes {1, 2, 5, 20, 10001, "everything"}, Interrupt() is best-effort and leaves the plan
 usable (cursor.h:150-186), and repeated runs of a plan do not grow device memory
 (expression_test_helper.cc:213-245, the "memory stability" run)."""
+import os
 import threading
 
 import numpy as np
@@ -197,3 +198,57 @@ def test_recent_kernel_times_ring(gpu_ctx):
         plan.run()
     assert len(plan.recent_kernel_ms(1000)) == 256
     assert abs(plan.counters().dominant_ms - plan.recent_kernel_ms(1)[0]) < 1e-6
+
+
+_CACHE_CHILD = r"""
+import json, sys
+import numpy as np
+import supersonic_amd as ss
+ctx = ss.Context(0)
+rng = np.random.default_rng(3)
+n = 50021
+schema = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64), ss.Attribute("d", ss.DOUBLE)])
+view = ss.View(schema, [rng.integers(0, 1000, n), rng.integers(0, 1000, n), rng.integers(0, 4000, n) * 0.25])
+NA = ss.NamedAttribute
+op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.COUNT, "", "n"),
+                        ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(),
+                                  ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))).Add(NA("d")), ss.ScanView(view))))
+plan = ss.Plan(op, ctx).specialize()
+plan.run()
+got = plan.fetch()
+st = ss.memory_stats()
+print(json.dumps({"specialized": plan.specialized(), "compilations": st["rtc_compilations"], "disk_hits": st["rtc_disk_hits"],
+                  "row": [got.column(i).data[0].item() for i in range(got.column_count())]}))
+"""
+
+
+def test_specialised_kernels_survive_the_process(tmp_path):
+    """The on-disk cache of code objects (rtc.cpp): the second PROCESS that wants the same kernel loads it instead of compiling
+    for seconds; a damaged cache file is ignored and replaced; SSGPU_RTC_CACHE_DIR= (empty) switches the cache off."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def child(cache_dir):
+        env = dict(os.environ, SSGPU_RTC_CACHE_DIR=cache_dir, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _CACHE_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    cache = str(tmp_path / "rtc")
+    first = child(cache)
+    assert first["specialized"] == 1 and first["compilations"] >= 1 and first["disk_hits"] == 0, first
+    files = [f for f in os.listdir(cache) if f.endswith(".co")]
+    assert len(files) == first["compilations"], (files, first)
+    second = child(cache)
+    assert second["specialized"] == 1 and second["compilations"] == 0 and second["disk_hits"] >= 1, second      # loaded, not compiled
+    assert second["row"] == first["row"]
+    path = os.path.join(cache, files[0])
+    with open(path, "r+b") as f:                                    # a torn file: checksum fails -> compiled again, file replaced
+        f.truncate(os.path.getsize(path) // 2)
+    third = child(cache)
+    assert third["specialized"] == 1 and third["compilations"] >= 1 and third["row"] == first["row"], third
+    assert child(cache)["compilations"] == 0                        # ... and the replacement is good
+    off = child("")
+    assert off["compilations"] >= 1 and off["disk_hits"] == 0, off   # no disk cache at all

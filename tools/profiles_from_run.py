@@ -10,14 +10,14 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("SSGPU_PROFILE_SRC", "prof_r03"))
 DST = os.path.join(ROOT, "profiles")
 ROUND = os.environ.get("SSGPU_PROFILE_TAG", "r03")   # r03b: the second collection of round 3 (tools/profile_refresh.sh, another box)
-PMC_ROUND = "r03"
+PMC_ROUND = os.environ.get("SSGPU_PROFILE_PMC_TAG", "r03")
 # the kernels of the timed stage, per query (substrings of rocprof's kernel names)
 STAGE = {"wide": ["ssgpu_pipeline_kernel", "ssgpu_finish_slots", "ssgpu_emit_scalar"],
-         "group3": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill"],
-         "group": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill"],
+         "group3": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill", "ssgpu_group_init"],
+         "group": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill", "ssgpu_group_init"],
          "sort": ["ssgpu_sort_"], "filter_mat": ["ssgpu_pipeline_kernel", "ssgpu_scan_counts"]}
 
 
@@ -37,7 +37,7 @@ def steady(values, launches_per_step):
 
 
 def main():
-    summary = ["# Round 3 profiles (MI355X, 100 M rows, `tools/profile_round3.sh`%s)" % (" -- second collection, `tools/profile_refresh.sh`" if ROUND != "r03" else ""), "",
+    summary = ["# %s profiles (MI355X, 100 M rows, `tools/profile_round%s.sh`%s)" % (ROUND, ROUND[2] if len(ROUND) > 2 else "3", " -- second collection, `tools/profile_refresh.sh`" if ROUND == "r03b" else ""), "",
                "| query | kernel ms (bench line) | frac of 8 TB/s | algorithmic B/row | HBM traffic / algorithmic | interpreted kernel ms |", "|---|---|---|---|---|---|"]
     factors = {}
     cal = os.path.join(SRC, "pmc_calibration.json")
@@ -74,12 +74,17 @@ def main():
                 fk = steady(fetch.get(k, [0.0]), n_per_step) * n_per_step
                 wk = steady(write.get(k, [0.0]), n_per_step) * n_per_step
                 per_kernel[k] = {"FETCH_SIZE_KiB_per_step": fk, "WRITE_SIZE_KiB_per_step": wk, "launches_per_step": n_per_step}
-                total += fk * 1024 * 2 + wk * 1024
+                # FETCH_SIZE tallies every request at 64 bytes: 128-byte streaming requests are under-counted by 2, the record gather's
+                # random 64-byte requests are counted in full (profiles/r04_pmc_gather_calibration.json)
+                ff = 1.0 if "sort_gather_rec" in k else 2.0
+                per_kernel[k]["fetch_factor"] = ff
+                total += fk * 1024 * ff + wk * 1024
             alg = line["roofline"]["algorithmic_bytes_per_row"] * line["config"]["rows_per_gpu"]
             traffic = total
             j = {"round": ROUND, "query": q, "command": "python bench.py --query %s --steps 5 --warmup 2 --no-cpu-baseline" % q,
-                 "kernels": per_kernel, "correction": "FETCH_SIZE x 2 (gfx950: the counter tallies 128-byte requests at 64 bytes; measured 2.000 for 4 / 8 / 16 B-per-lane "
-                                                      "reads and 40-byte records), WRITE_SIZE x 1 (measured 1.000): profiles/%s_pmc_calibration.json" % ROUND,
+                 "kernels": per_kernel, "correction": "FETCH_SIZE x 2 for streaming kernels (gfx950: the counter tallies 128-byte requests at 64 bytes; measured 2.000 for 4 / 8 / 16 B-per-lane "
+                                                      "reads and 40-byte records), x 1 for the Sort's record gather (random 64-byte reads are 64-byte requests: measured 1.000, "
+                                                      "profiles/r04_pmc_gather_calibration.json), WRITE_SIZE x 1 (measured 1.000)",
                  "traffic_bytes_per_launch": total, "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": total / alg if alg else None}
             with open(os.path.join(DST, "%s_pmc_%s.json" % (ROUND, q)), "w") as f:
                 json.dump(j, f, indent=1, sort_keys=True)
