@@ -169,7 +169,8 @@ struct StageExec {
   RtcSlot rtc_resident;         // ssgpu_group_resident_kernel specialised for this stage's row source and aggregates
   RtcSlot rtc_hot;              // the same kernel for the heavy hitters' small table (hot_only)
   uint32_t hot_n = 0; uint64_t hot_keys[SSGPU_HOT_MAX] = {0};   // heavy-hitter keys found when a partition segment overflowed (kept for the plan's later runs)
-  bool hot_tried = false;       // the sample has been looked at for this plan
+  int64_t hot_sampled_run = -1; // the run (ssgpu_plan::n_runs) whose overflow last made the host look at a sample: once per run, so that a plan that meets
+                                // other data later (other hot keys) finds them again
   DevBuf hot_out;
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
@@ -1482,11 +1483,11 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     }
     if (fb[1]) {   // skewed keys: larger segments (memory permitting), else the direct path
       if (ex.part_seg_growth >= 64) { *fallback = true; return SSGPU_OK; }
-      if (plain && !ex.hot_tried) {
+      if (plain && ex.hot_sampled_run != p->n_runs) {
         // Skewed keys?  Look at a sample of the rows before making every segment larger: a few keys that hold a large share of
         // the rows (each would fill ONE partition) are taken out of the partitions altogether and aggregated on their own
         // (ssgpu_hot_keys_kernel -> hot_only resident pass + a scatter that skips them), and the rest fits the segments as sized.
-        ex.hot_tried = true;
+        ex.hot_sampled_run = p->n_runs;
         PlainScatterParams S; fill_plain_source(S);
         HIP_TRY(c, ex.hot_out.ensure((1 + 2 * SSGPU_HOT_MAX) * 8));
         const uint64_t n_sample = (uint64_t)std::min<int64_t>(in.rows, (int64_t)1 << 18);
@@ -1499,7 +1500,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
         ex.hot_n = (uint32_t)std::min<uint64_t>(found[0], SSGPU_HOT_MAX);
         for (uint32_t h = 0; h < ex.hot_n; ++h) ex.hot_keys[h] = found[1 + 2 * h];
         if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: %u heavy-hitter key(s) in a sample of %llu rows (threshold %u)\n", ex.hot_n, (unsigned long long)n_sample, min_count);
-        if (ex.hot_n > 0) continue;   // again, with the heavy hitters handled apart
+        if (ex.hot_n > 0) continue;   // again, with the heavy hitters (of THIS input: an earlier run's list is replaced) handled apart
       }
       if (plain) {
         // the plain scatter's segment counters kept counting past the end: the fullest one says what this input needs.
