@@ -47,7 +47,7 @@ std::string schema_to_string(const Schema& s);
 struct BExpr;
 typedef std::shared_ptr<BExpr> BExprP;
 struct BExpr {
-  enum Kind { INPUT, CONST, NULLCONST, OP, CAST, JOINCOL, JOINMATCH, JOINSTART, JOINCNT } kind = INPUT;
+  enum Kind { INPUT, CONST, NULLCONST, OP, CAST, JOINCOL, JOINMATCH, JOINSTART, JOINCNT, ROWID /* the row's index in the plan's input (UINT64) */ } kind = INPUT;
   int op = 0;          // reference OperatorId for OP
   int dtype = SSGPU_INT64;
   bool nullable = false;
@@ -168,9 +168,10 @@ struct Stage {
   struct JoinOut { bool from_rhs; int col; };
   std::vector<JoinOut> join_out;
   // FOLD_TAIL (input: the group table sorted by first-seen row id, that id as the last column): rows [0, fold_limit] are
-  // kept, every later row is merged into row fold_limit with the column's merge function (0 keep = key columns, 1 SUM, 2 MIN, 3 MAX)
+  // kept, every later row is merged into row fold_limit with the column's merge function (0 keep = key columns, 1 SUM, 2 MIN, 3 MAX,
+  // 4 / 5 = FIRST / LAST: the value of the merged row whose UINT64 column fold_by[i] -- a row id -- is smallest / largest)
   int64_t fold_limit = -1;
-  std::vector<int> fold_op;
+  std::vector<int> fold_op, fold_by;
   // CONCAT aggregates (column_aggregator.cc:496-505, aggregation_operators.h:236-283): a result of STRINGs that exist nowhere yet.
   // The device counts the contributing (non-NULL) values in the column's place -- a UINT64 in out_schema -- and the host
   // builds the strings when the column is fetched, from the stage's (materialised, for a group aggregate key-sorted) input:

@@ -240,6 +240,31 @@ __device__ void fold_tail_column(const FoldTailColumn& C, u64 n_in, u64 limit, u
   const u64 keep = n_in < limit + 1ull ? n_in : limit + 1ull;
   for (u64 i = t; i < keep; i += NT) { dst[i] = src[i]; if (C.dst_nulls) C.dst_nulls[i] = C.src_nulls ? C.src_nulls[i] : (u8)0; }
   if (n_in <= limit + 1ull || C.op == 0u) return;
+  if (C.op >= 4u) {
+    // FIRST / LAST: the smallest / largest row id of the merged rows (ids of different groups differ), then its row's value
+    const bool first = C.op == 4u;
+    u64 best = first ? ~0ull : 0ull; u32 has = 0;
+    for (u64 i = limit + t; i < n_in; i += NT) {
+      if (C.by_nulls && C.by_nulls[i]) continue;
+      const u64 r = C.by[i];
+      best = has ? (first ? (r < best ? r : best) : (r > best ? r : best)) : r; has = 1u;
+    }
+    lds_val[t] = best; lds_has[t] = has;
+    __syncthreads();
+    for (u32 d = NT >> 1; d > 0; d >>= 1) {
+      if (t < d && lds_has[t + d]) {
+        const u64 b = lds_val[t + d];
+        if (lds_has[t]) { const u64 a = lds_val[t]; lds_val[t] = first ? (b < a ? b : a) : (b > a ? b : a); }
+        else { lds_val[t] = b; lds_has[t] = 1u; }
+      }
+      __syncthreads();
+    }
+    const u64 pick = lds_val[0]; const u32 any = lds_has[0];
+    if (!any) { if (t == 0 && C.dst_nulls) C.dst_nulls[limit] = (u8)1; return; }
+    for (u64 i = limit + t; i < n_in; i += NT)
+      if (!(C.by_nulls && C.by_nulls[i]) && C.by[i] == pick) { dst[limit] = src[i]; if (C.dst_nulls) C.dst_nulls[limit] = C.src_nulls ? C.src_nulls[i] : (u8)0; }
+    return;
+  }
   T acc = T(); u32 has = 0;
   for (u64 i = limit + t; i < n_in; i += NT) {
     if (C.src_nulls && C.src_nulls[i]) continue;

@@ -106,7 +106,10 @@ hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid
 // GroupAggregateOptions::max_unique_keys_in_result, last step (group_scatter_kernel.hip): one workgroup per column copies rows
 // [0, min(n_in, limit + 1)) and merges every row beyond `limit` into row `limit` (op: 0 keep, 1 sum, 2 min, 3 max; kind:
 // 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64, 6 one byte), NULL partial results skipped
-struct FoldTailColumn { const void* src; const unsigned char* src_nulls; void* dst; unsigned char* dst_nulls; unsigned int op, kind; };
+struct FoldTailColumn {
+  const void* src; const unsigned char* src_nulls; void* dst; unsigned char* dst_nulls; unsigned int op, kind;
+  const unsigned long long* by; const unsigned char* by_nulls;   // op 4 / 5 (FIRST / LAST): the row-id column the value is picked by
+};
 hipError_t ssgpu_launch_fold_tail(const FoldTailColumn* cols_dev, unsigned int n_cols, unsigned long long n_in, unsigned long long limit, hipStream_t stream);
 unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread);
 hipError_t ssgpu_part_agg_set_max_lds(int bytes);

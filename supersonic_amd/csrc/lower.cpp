@@ -208,6 +208,7 @@ std::string Emitter::key_of(const BExprP& e) {
     case BExpr::JOINMATCH: s << "M" << e->join_id; break;
     case BExpr::JOINSTART: s << "JS" << e->join_id; break;
     case BExpr::JOINCNT: s << "JC" << e->join_id; break;
+    case BExpr::ROWID: s << "R"; break;
     default:
       s << (e->kind == BExpr::CAST ? "K" : "O") << e->op << ":" << e->dtype << ":" << e->filter_depth << "(";
       for (auto& a : e->args) s << key_of(a) << ",";
@@ -399,6 +400,7 @@ Status Emitter::value(const BExprP& e, Val* out) {
       break;
     case BExpr::CONST: v.imm = true; v.bits = e->bits; break;
     case BExpr::NULLCONST: v.imm = true; v.bits = 0; v.null = const_null_reg(); break;
+    case BExpr::ROWID: { v.reg = new_reg(8); LInstr& i = emit(VM_ROWID_64); i.dst = v.reg; } break;
     case BExpr::JOINMATCH: {
       int idx; SS_RETURN_IF_ERROR(join_index(e->join_id, &idx));
       v.reg = new_reg(1);
@@ -847,6 +849,8 @@ struct AggPlan {
   bool result_nullable = true;
   bool distinct = false;   // only the first occurrence of every value of a group contributes (column_aggregator.cc:308-376)
   int flag_pos = -1;       // DISTINCT over a second, third ... column: pipe column holding that column's first-of-run flag
+  bool rowid_only = false; // FIRST / LAST that yields the chosen row's id (UINT64) instead of its value: the arg-min / arg-max
+                           // column the fold of a key limit picks values by
 };
 
 static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schema& in, std::vector<AggPlan>* out) {
@@ -1364,20 +1368,21 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
       Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
       int agg_type = ap.out_type, wide_emit = -1;
       minmax_in_own_type(ap.aggregation, src->dtype, ap.out_type, &agg_type, &wide_emit);
-      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(agg_type), &c));
+      Val c = v;
+      if (!ap.rowid_only) SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(agg_type), &c));
       AggSel s;
       int vr;
       if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
         // FIRST / LAST (aggregation_operators.h:290-320): MIN / MAX of the contributing row ids;
         // the value is fetched from the input column after extraction (runtime: gather_rowid)
-        if (src->kind != BExpr::INPUT || dtype_width(src->dtype) == 0) {
+        if (!ap.rowid_only && (src->kind != BExpr::INPUT || dtype_width(src->dtype) == 0)) {
           if (too_wide && dtype_width(src->dtype) != 0) *too_wide = true;   // computed input: materialise it first
           return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST/LAST inside GroupAggregate need a plain input column on device");
         }
         select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &s, &init);
         if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
         vr = rowid_reg;
-        ao.gather_col = src->input_col;
+        if (!ap.rowid_only) ao.gather_col = src->input_col;
       } else {
         if (!select_group_agg(ap.aggregation, agg_type, &s, &init))
           return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, "aggregation not supported for this type");
@@ -1478,7 +1483,8 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
       Val v; SS_RETURN_IF_ERROR(em.value(src, &v));
       int agg_type = ap.out_type, wide_emit = -1;
       minmax_in_own_type(ap.aggregation, src->dtype, ap.out_type, &agg_type, &wide_emit);   // (the emit kind is the direct path's: same AggOut)
-      Val c; SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(agg_type), &c));
+      Val c = v;
+      if (!ap.rowid_only) SS_RETURN_IF_ERROR(em.cast_val(v, mtype(src->dtype), mtype(agg_type), &c));
       AggSel sl; uint64_t init = 0;
       if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
         select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &sl, &init);
@@ -1952,16 +1958,30 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           const int64_t limit = op.option0 < 0 ? 0 : op.option0;
           n_user_aggs = g.plans.size(); n_group_keys = g.kpos.size();
           if (!limited) add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &g.plans, &nan_fixes);   // (under a key limit FIRST has no merge function)
-          std::vector<int> fold_ops;
+          std::vector<int> fold_ops, fold_by;
           if (limited) {
-            if ((int)g.plans.size() + 1 > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
-            for (size_t k = 0; k < g.kpos.size(); ++k) fold_ops.push_back(0);
+            // FIRST / LAST under the limit: the folded row's value is the one at the smallest / largest contributing row id
+            // over all the groups it absorbs (NULL inputs never contribute, aggregation_operators.h:290-320) -- every
+            // FIRST / LAST gets a hidden twin that yields that row id, and the fold picks the value by it.
+            const size_t n_user = g.plans.size();
+            std::vector<AggPlan> twins;
+            for (size_t k = 0; k < g.kpos.size(); ++k) { fold_ops.push_back(0); fold_by.push_back(-1); }
             for (auto& ap : g.plans) {
+              int by = -1;
               if (ap.aggregation == SSGPU_SUM || ap.aggregation == SSGPU_COUNT) fold_ops.push_back(1);
               else if (ap.aggregation == SSGPU_MIN) fold_ops.push_back(2);
               else if (ap.aggregation == SSGPU_MAX) fold_ops.push_back(3);
-              else return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with FIRST / LAST / CONCAT aggregates is not available on the device path");
+              else if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) {
+                fold_ops.push_back(ap.aggregation == SSGPU_FIRST ? 4 : 5);
+                AggPlan t = ap; t.rowid_only = true; t.out_type = SSGPU_UINT64; t.out_name = "$row_of_" + std::to_string(twins.size());
+                by = (int)(g.kpos.size() + n_user + twins.size());
+                twins.push_back(t);
+              }
+              else return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with CONCAT aggregates is not available on the device path");
+              fold_by.push_back(by);
             }
+            for (auto& t : twins) g.plans.push_back(t);
+            if ((int)g.plans.size() + 1 > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
             AggPlan hidden; hidden.aggregation = AGG_FIRST_SEEN; hidden.input_pos = -1; hidden.out_type = SSGPU_UINT64;
             hidden.out_name = "$first_seen"; hidden.result_nullable = false;
             g.plans.push_back(hidden);
@@ -1969,20 +1989,27 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           bool too_wide = false;
           Status s = finish_group_agg(g, pipe, &st, false, &too_wide);
           if (!s.ok() && !too_wide) return s;
-          if (too_wide && limited)
-            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with group keys wider than 64 packed bits is not available on the device path");
-          if (limited) {
+          if (too_wide && limited) {
+            // keys wider than one 64-bit word under a limit: the sorted shape below, its first-seen id = MIN of the input row id
+            // stored as one more materialised column.  (FIRST / LAST twins would need that id masked by another column's NULLs.)
+            if (fold_ops.size() != g.kpos.size() + n_user_aggs || std::count_if(fold_ops.begin(), fold_ops.end(), [](int o) { return o >= 4; }) != 0)
+              return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with FIRST / LAST in the sorted shape (group keys wider than 64 packed bits, FIRST / LAST of a computed value) is not available on the device path");
+            g.plans.resize(n_user_aggs);
+          }
+          auto append_limit_tail = [&]() -> Status {
             stages->push_back(st);
             Stage so; so.kind = STAGE_SORT; so.in_schema = st.out_schema; so.out_schema = st.out_schema;
             SortKey sk; sk.col = (int)st.out_schema.size() - 1; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
             for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
             stages->push_back(so);
-            Stage ft; ft.kind = STAGE_FOLD_TAIL; ft.in_schema = so.out_schema; ft.fold_limit = limit; ft.fold_op = fold_ops;
-            ft.out_schema.assign(so.out_schema.begin(), so.out_schema.end() - 1);
+            Stage ft; ft.kind = STAGE_FOLD_TAIL; ft.in_schema = so.out_schema; ft.fold_limit = limit; ft.fold_op = fold_ops; ft.fold_by = fold_by;
+            ft.out_schema.assign(so.out_schema.begin(), so.out_schema.begin() + (long)fold_ops.size());   // (the row-id twins and the first-seen id end here)
             for (auto& a : ft.out_schema) if (dtype_width(a.dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length columns are outside the device hot path");
             st = ft;
-            desc << "(hash aggregate + first-seen order + fold beyond " << limit << " keys) ";
-          }
+            desc << "(" << (too_wide ? "" : "hash aggregate + ") << "first-seen order + fold beyond " << limit << " keys) ";
+            return Status::OK();
+          };
+          if (limited && !too_wide) SS_RETURN_IF_ERROR(append_limit_tail());
           if (too_wide) {
             // Keys that do not pack into one 64-bit word (e.g. a NULLABLE INT64 key, three INT32
             // keys), or FIRST/LAST of a computed expression (the value is fetched by row id from a
@@ -1996,6 +2023,14 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             for (auto& ap : gm.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
             Pipe pruned = pipe; pruned.cols.clear();
             for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+            if (limited) {
+              VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
+              rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
+              pruned.cols.push_back(rc);
+              AggPlan hidden; hidden.aggregation = SSGPU_MIN; hidden.input_pos = (int)pruned.cols.size() - 1; hidden.out_type = SSGPU_UINT64;
+              hidden.out_name = "$first_seen"; hidden.result_nullable = false;
+              gm.plans.push_back(hidden);
+            }
             Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
             stages->push_back(m);
             Stage so; so.kind = STAGE_SORT; so.in_schema = m.out_schema; so.out_schema = m.out_schema;
@@ -2009,6 +2044,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             st = Stage();
             SS_RETURN_IF_ERROR(finish_group_agg(gm, pipe, &st, true));
             desc << "(materialise + sort + clustered aggregation) ";
+            if (limited) SS_RETURN_IF_ERROR(append_limit_tail());
           }
         }
         desc << (op.kind == SSGPU_OP_SCALAR_AGGREGATE ? "ScalarAggregate" : "GroupAggregate") << " -> [" << schema_to_string(st.out_schema) << "]\n";

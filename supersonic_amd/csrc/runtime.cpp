@@ -2104,6 +2104,9 @@ int run_fold_tail(ssgpu_plan* p, size_t si, const InCols& in) {
     cols[i].src = in.cols[i].data; cols[i].src_nulls = st.in_schema[i].nullable ? in.cols[i].is_null : nullptr;
     cols[i].dst = ex.out[i].data.p; cols[i].dst_nulls = ex.out[i].nullable ? ex.out[i].nulls.as<uint8_t>() : nullptr;
     cols[i].op = (unsigned)st.fold_op[i]; cols[i].kind = kind_of(st.out_schema[i].dtype);
+    const int by = i < st.fold_by.size() ? st.fold_by[i] : -1;
+    cols[i].by = by >= 0 ? (const unsigned long long*)in.cols[by].data : nullptr;
+    cols[i].by_nulls = by >= 0 && st.in_schema[by].nullable ? in.cols[by].is_null : nullptr;
   }
   HIP_TRY(c, ex.emit_descs.ensure(std::max<size_t>(cols.size(), 1) * sizeof(FoldTailColumn)));
   HIP_TRY(c, hipMemcpyAsync(ex.emit_descs.p, cols.data(), cols.size() * sizeof(FoldTailColumn), hipMemcpyHostToDevice, c->stream));

@@ -80,7 +80,7 @@ def test_bind_errors(bind_ctx):
 def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     # GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205, row_hash_set.cc:500-511): hash aggregate with a
     # hidden first-seen row id, sort by it, fold of the rows beyond the limit -- the hidden column is not in the result schema;
-    # FIRST / LAST under a limit have no merge function on the device and are refused, not ignored
+    # FIRST / LAST under a limit fold by a hidden row-id twin each (also not in the result schema); CONCAT under a limit is refused
     import numpy as np
     schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64)])
     view = ss.View(schema, [np.arange(4), np.arange(4)])
@@ -90,7 +90,11 @@ def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     rs = plan.result_schema
     assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "s"]
     assert "fold beyond 2 keys" in plan.describe()
-    bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.FIRST, "v", "f"),
+    fl = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.FIRST, "v", "f").AddAggregation(ss.LAST, "v", "l"),
+                           ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
+    rs = ss.Plan(fl, ss.Context(-1)).result_schema
+    assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "f", "l"]
+    bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f"),
                             ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
     with pytest.raises(ss.SupersonicException) as e:
         ss.Plan(bad, ss.Context(-1))

@@ -1458,12 +1458,20 @@ def test_group_aggregate_max_unique_keys_in_result(n, partition, limit):
     view = make_view(n, nullable=True)
     spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.COUNT, "d0", "c0").AddAggregation(ss.COUNT, "", "n")
             .AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.SUM, "d1", "sd").AddAggregation(ss.MIN, "u", "mu")
-            .AddAggregation(ss.MAX, "f", "mf"))
+            .AddAggregation(ss.MAX, "f", "mf")
+            # FIRST / LAST under the limit: the folded row answers with the value at the smallest / largest row id over every group
+            # it absorbs (NULL inputs do not count: d0 / d / t are NULLABLE in the first two views)
+            .AddAggregation(ss.FIRST, "d0", "fd").AddAggregation(ss.LAST, "d", "ld").AddAggregation(ss.LAST, "f", "lf").AddAggregation(ss.FIRST, "t", "ft"))
     opts = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit)
-    # (NULLABLE k1 + k2 would be 65 key bits: the wide-key shape is refused under a limit, see the next test)
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, opts,
                                ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx)   # ordered: first-seen order
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1"]), spec, opts, ss.ScanView(view)), ctx)                                   # a NULL key group among them
+    # NULLABLE k1 + k2 = 65 key bits: materialise (+ the input row id) -> sort by the keys -> clustered aggregation with MIN(row id)
+    # as the first-seen order -> the same sort + fold.  (FIRST / LAST there are refused: next test.)
+    spec_wide = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.COUNT, "d0", "c0").AddAggregation(ss.COUNT, "", "n")
+                 .AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.SUM, "d1", "sd").AddAggregation(ss.MAX, "f", "mf"))
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec_wide, opts,
+                               ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(299)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx)
     plain = make_view(n)                                # NOT NULL keys: two INT32 keys in one word
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit),
                                ss.ScanView(plain)), ctx)
@@ -1477,8 +1485,9 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
     got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("col0"), ss.AggregationSpecification().AddAggregation(ss.SUM, "col1", "sum"), opts, ss.ScanView(view)), gpu_ctx)
     assert got.column(0).data.tolist() == [1, 3, 4] and got.column(1).data.tolist() == [5, -9, 9]
     wide = make_view(100, nullable=True)
-    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "s"), opts, ss.ScanView(wide)),
-               ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.LAST, "b", "l"), opts, ss.ScanView(wide))):
+    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), ss.AggregationSpecification().AddAggregation(ss.LAST, "b", "s"), opts, ss.ScanView(wide)),
+               ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "b", "s"), opts, ss.ScanView(wide)),
+               ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l"), opts, ss.ScanView(wide))):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(op, gpu_ctx)
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_parity_gpu.py -x -q -k "max_unique" -n 4 2>&1 | tail -15
