@@ -77,6 +77,7 @@ struct AggOut {        // one aggregate result column
   bool has_cnt;        // group: contribution count tracked (nullable input)
   bool result_nullable;
   int gather_col = -1; // group FIRST/LAST: the slot holds a row id; the result is this stage-input column at that row
+  bool gather_low32 = false;   // ... the row id is the slot's low half (its high half ordered the rows: AggPlan::order_pos)
 };
 
 struct GroupKeyField { int out_col; uint32_t shift, bits, nullbit, width; uint32_t word = 0; /* hash-join keys of 65..128 bits: key word 0 / 1 */ };

@@ -234,7 +234,7 @@ hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* c
                                        void* const* out_data, uint8_t* const* out_nulls, uint64_t n, const uint32_t* tile_offsets,
                                        uint32_t* seg_id, hipStream_t s);
 hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, int src_kind, int dst_kind, const uint64_t* rowids,
-                                     int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream);
+                                     uint64_t rowid_mask /* bits of a rowids word that ARE the row id */, int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream);
 hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
                                       const GroupAggOut* outs, uint32_t n_out, hipStream_t s);
 

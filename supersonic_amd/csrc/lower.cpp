@@ -849,6 +849,8 @@ struct AggPlan {
   bool result_nullable = true;
   bool distinct = false;   // only the first occurrence of every value of a group contributes (column_aggregator.cc:308-376)
   int flag_pos = -1;       // DISTINCT over a second, third ... column: pipe column holding that column's first-of-run flag
+  int order_pos = -1;      // FIRST / LAST over rows that were re-ordered on the way (the DISTINCT shape): pipe column holding the
+                           // row's id in the ORIGINAL order -- the aggregate picks by it, not by the row's position here
   bool rowid_only = false; // FIRST / LAST that yields the chosen row's id (UINT64) instead of its value: the arg-min / arg-max
                            // column the fold of a key limit picks values by
 };
@@ -1382,6 +1384,17 @@ static Status finish_group_agg(const GroupBinding& g, const Pipe& pipe, Stage* s
         select_group_agg(ap.aggregation == SSGPU_FIRST ? SSGPU_MIN : SSGPU_MAX, SSGPU_UINT64, &s, &init);
         if (rowid_reg < 0) { rowid_reg = em.new_reg(8); LInstr& r = em.emit(VM_ROWID_64); r.dst = rowid_reg; }
         vr = rowid_reg;
+        if (ap.order_pos >= 0) {
+          // MIN / MAX of (original row id << 32 | position here): the extremum's low half is where the value is fetched
+          // (both are below 2^32: the Sort stage in front refuses more rows)
+          Val ov; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.order_pos].expr, &ov));
+          const int packed = em.new_reg(8);
+          { LInstr& z = em.emit(VM_FILL_64); z.dst = packed; z.a_imm = true; z.imm = 0; z.imm_width = 8; }
+          { LInstr& k = em.emit(VM_KEY_APPEND_64); k.dst = packed; k.a = em.materialize(ov); k.b = -1; k.imm = 32ull | (32ull << 8); }
+          { LInstr& k = em.emit(VM_KEY_APPEND_64); k.dst = packed; k.a = rowid_reg; k.b = -1; k.imm = 0ull | (32ull << 8); }
+          vr = packed;
+          ao.gather_low32 = true;
+        }
         if (!ap.rowid_only) ao.gather_col = src->input_col;
       } else {
         if (!select_group_agg(ap.aggregation, agg_type, &s, &init))
@@ -1886,9 +1899,12 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
           // FIRST / LAST follow the INPUT order (aggregation_operators.h:290-320); the DISTINCT shape aggregates rows that were
           // sorted by (keys, distinct column), where "first" would mean "smallest distinct value": refused, not answered wrongly
-          for (auto& ap : g.plans)
-            if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST)
-              return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST / LAST next to a DISTINCT aggregate in one specification are not available on the device path");
+          // In a GroupAggregate they pick by the row's ORIGINAL id instead, stored as one more column and carried through the sorts
+          // (AggPlan::order_pos); the scalar sinks pick by position only: refused there, not answered wrongly.
+          bool first_last = false;
+          for (auto& ap : g.plans) first_last = first_last || ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST;
+          if (first_last && op.kind == SSGPU_OP_SCALAR_AGGREGATE)
+            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST / LAST next to a DISTINCT aggregate in one ScalarAggregate are not available on the device path");
           std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
           auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
           for (auto& k : g.kpos) k = slot_of(k);
@@ -1897,6 +1913,12 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
           Pipe pruned = pipe; pruned.cols.clear();
           for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+          if (first_last) {
+            VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
+            rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
+            pruned.cols.push_back(rc);
+            for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = (int)pruned.cols.size() - 1;
+          }
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
           reset_pipe(&pipe, m.out_schema);

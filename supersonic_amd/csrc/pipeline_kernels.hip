@@ -1884,13 +1884,13 @@ hipError_t ssgpu_launch_join_build(const JoinBuildParams& P, hipStream_t stream)
 // (AssignmentOperator, aggregation_operators.h:100-122: a C++ conversion; floating -> integer truncates, cvttsd2si's
 // INT64_MIN for NaN / out of range).
 __global__ __launch_bounds__(256) void ssgpu_gather_rowid_kernel(void* __restrict__ dst, const u8* __restrict__ dst_null, const void* __restrict__ src,
-                                                                 u32 width, int src_kind, int dst_kind, const u64* __restrict__ rowids, i64 row_id_base,
+                                                                 u32 width, int src_kind, int dst_kind, const u64* __restrict__ rowids, u64 rowid_mask, i64 row_id_base,
                                                                  const u64* __restrict__ n_rows_dev, u64 n_rows_max) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 n = n_rows_dev ? *n_rows_dev : n_rows_max;
   if (i >= n || i >= n_rows_max) return;
   const bool isnull = dst_null && dst_null[i];
-  const u64 r = isnull ? 0ull : (u64)((i64)rowids[i] - row_id_base);
+  const u64 r = isnull ? 0ull : (u64)((i64)(rowids[i] & rowid_mask) - row_id_base);
   if (src_kind == dst_kind) {
     if (width == 8) reinterpret_cast<u64*>(dst)[i] = isnull ? 0ull : reinterpret_cast<const u64*>(src)[r];
     else if (width == 4) reinterpret_cast<u32*>(dst)[i] = isnull ? 0u : reinterpret_cast<const u32*>(src)[r];
@@ -1923,10 +1923,10 @@ __global__ __launch_bounds__(256) void ssgpu_gather_rowid_kernel(void* __restric
   else if (dst_kind == 0 || dst_kind == 1) reinterpret_cast<u32*>(dst)[i] = (u32)bits;
   else reinterpret_cast<u8*>(dst)[i] = (u8)bits;
 }
-hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, int src_kind, int dst_kind, const uint64_t* rowids,
+hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, int src_kind, int dst_kind, const uint64_t* rowids, uint64_t rowid_mask,
                                      int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream) {
   if (n_rows_max) hipLaunchKernelGGL(ssgpu_gather_rowid_kernel, dim3((unsigned)((n_rows_max + 255) / 256)), dim3(256), 0, stream,
-                                     dst, dst_null, src, width, src_kind, dst_kind, (const u64*)rowids, (i64)row_id_base, (const u64*)n_rows_dev, (u64)n_rows_max);
+                                     dst, dst_null, src, width, src_kind, dst_kind, (const u64*)rowids, (u64)rowid_mask, (i64)row_id_base, (const u64*)n_rows_dev, (u64)n_rows_max);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipStream_t stream) {

@@ -1109,7 +1109,7 @@ static int gather_first_last(ssgpu_plan* p, Stage& st, StageExec& ex, size_t nk,
     };
     HIP_TRY(c, ssgpu_launch_gather_rowid(ex.out[nk + j].data.p, ex.out[nk + j].nullable ? ex.out[nk + j].nulls.as<uint8_t>() : nullptr,
                                          in.cols[col].data, ex.out[nk + j].width, kind_of(st.in_schema[col].dtype), kind_of(st.out_schema[nk + j].dtype),
-                                         ex.rowid_tmp[j].as<uint64_t>(), row_id_base,
+                                         ex.rowid_tmp[j].as<uint64_t>(), st.aggs[j].gather_low32 ? 0xFFFFFFFFull : ~0ull, row_id_base,
                                          n_rows_dev, n_rows_max, c->stream));
     p->counters.n_launches += 1;
   }

@@ -419,6 +419,24 @@ def test_distinct_aggregates_over_several_columns(gpu_ctx, n, nullable):
                                ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx, ignore_order=True)
 
 
+@pytest.mark.parametrize("n", [0, 5, 1025, 60013])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_first_last_next_to_distinct_aggregates(gpu_ctx, n, nullable):
+    # FIRST / LAST follow the INPUT order (aggregation_operators.h:290-320) although the DISTINCT shape re-orders the rows by
+    # (keys, distinct column): the input row id is stored as one more column, carried through the sorts, and the clustered
+    # aggregate picks by (row id << 32 | position).  One and two DISTINCT columns; NULL inputs never count; with a filter.
+    view = make_view(n, nullable=nullable)
+    spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "sd").AddAggregation(ss.FIRST, "d0", "fd").AddAggregation(ss.LAST, "d", "ld")
+            .AddAggregation(ss.FIRST, "b", "fb").AddAggregation(ss.LAST, "t", "lt").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.LAST, "a", "la"))
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    spec.AddDistinctAggregation(ss.COUNT, "k1", "cdk")
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2", "t"]), spec, None,
+                               ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx, ignore_order=True)
+    with pytest.raises(ss.SupersonicException) as e:                 # the scalar sinks pick by position only
+        ss.Plan(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+
+
 def test_plan_restages_every_new_host_view(gpu_ctx):
     # one Plan run over a stream of temporary host Views (a per-batch loop): CPython reuses the id() of a freed View, so
     # the staged device block must be keyed on the object itself -- never on its id
