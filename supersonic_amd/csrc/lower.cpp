@@ -1149,7 +1149,12 @@ static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const P
         int vr = em.materialize(c);
         int nullreg = v.null;
         if (ap.distinct) { int nf; SS_RETURN_IF_ERROR(notfirst_for(ap, &nf)); nullreg = em.or_null(v.null, nf); }
-        LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = sel;
+        int order_reg = -1;   // FIRST / LAST over re-ordered rows: the column that holds the original order (AggPlan::order_pos)
+        if (ap.order_pos >= 0 && (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST)) {
+          Val ov; SS_RETURN_IF_ERROR(em.value(pipe.cols[ap.order_pos].expr, &ov));
+          order_reg = em.materialize(ov);
+        }
+        LInstr& i = em.emit(s.op); i.dst_is_reg = false; i.dst = (int)j; i.a = vr; i.b = nullreg; i.c = sel; i.d = order_reg;
       }
       ao.slot_kind = s.slot_kind; ao.emit_kind = s.emit_kind;
     }
@@ -1899,12 +1904,9 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
           // FIRST / LAST follow the INPUT order (aggregation_operators.h:290-320); the DISTINCT shape aggregates rows that were
           // sorted by (keys, distinct column), where "first" would mean "smallest distinct value": refused, not answered wrongly
-          // In a GroupAggregate they pick by the row's ORIGINAL id instead, stored as one more column and carried through the sorts
-          // (AggPlan::order_pos); the scalar sinks pick by position only: refused there, not answered wrongly.
+          // They pick by the row's ORIGINAL id instead, stored as one more column and carried through the sorts (AggPlan::order_pos).
           bool first_last = false;
           for (auto& ap : g.plans) first_last = first_last || ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST;
-          if (first_last && op.kind == SSGPU_OP_SCALAR_AGGREGATE)
-            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "FIRST / LAST next to a DISTINCT aggregate in one ScalarAggregate are not available on the device path");
           std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
           auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
           for (auto& k : g.kpos) k = slot_of(k);

@@ -437,9 +437,10 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
       _Pragma("unroll") FOR_PAIRS {                                            \
         auto vv = lds_load2<T>(I.a, p);                                        \
         Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
-        u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);                \
+        u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p), r1 = r0 + 1;  \
+        if (I.d != VM_NONE) { auto oo = lds_load2<u64>(I.d, p); r0 = oo.x; r1 = oo.y; } /* the order is a column's (rows re-ordered on the way) */ \
         AGG_FL_STEP(ar, av, r0, vv.x, m.x, BETTER)                             \
-        AGG_FL_STEP(ar, av, r0 + 1, vv.y, m.y, BETTER)                         \
+        AGG_FL_STEP(ar, av, r1, vv.y, m.y, BETTER)                             \
         ac += (u32)m.x + (u32)m.y;                                             \
       }                                                                        \
       F0[I.dst] = av; F1[I.dst] = ar; FC[I.dst] = ac;                          \
@@ -448,9 +449,10 @@ __device__ __forceinline__ void stage_units_direct(const VmParams& P, int u_begi
       _Pragma("unroll") FOR_PAIRS {                                            \
         auto vv = lds_load2<T>(I.a, p);                                        \
         Valid2 m = valid_pair_(p, tile_valid, I.b, I.c);                       \
-        u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p);                \
+        u64 r0 = (u64)(P.row_id_base + tile_base + 2 * (i64)p), r1 = r0 + 1;  \
+        if (I.d != VM_NONE) { auto oo = lds_load2<u64>(I.d, p); r0 = oo.x; r1 = oo.y; } \
         AGG_FL_STEP(brow, bval, r0, vv.x, m.x, BETTER)                         \
-        AGG_FL_STEP(brow, bval, r0 + 1, vv.y, m.y, BETTER)                     \
+        AGG_FL_STEP(brow, bval, r1, vv.y, m.y, BETTER)                         \
         cnt += (u32)__popcll(__ballot(m.x)) + (u32)__popcll(__ballot(m.y));    \
       }                                                                        \
       u64 trow = wave_reduce_u64(brow, [](u64 x, u64 y) { return (BETTER) ? y : x; }); \

@@ -101,10 +101,9 @@ def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
 
 
-def test_first_last_next_to_distinct_binds_for_groups_and_is_refused_for_scalars():
+def test_first_last_next_to_distinct_pick_by_the_stored_row_id():
     # FIRST / LAST follow the input order (aggregation_operators.h:290-320); the DISTINCT shape aggregates rows sorted by
-    # (keys, distinct column).  GroupAggregate: the input row id rides along as a column and the aggregate picks by it;
-    # ScalarAggregate: the scalar sinks pick by position -- refused at bind, not answered wrongly
+    # (keys, distinct column): the input row id rides along as a column and the aggregates pick by it
     import numpy as np
     schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
     view = ss.View(schema, [np.zeros(4, np.int32), np.arange(4), np.arange(4)])
@@ -113,6 +112,6 @@ def test_first_last_next_to_distinct_binds_for_groups_and_is_refused_for_scalars
     rs = plan.result_schema
     assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "s", "f"]
     assert "ROWID_64" in plan.describe() and "KEY_APPEND_64" in plan.describe()
-    with pytest.raises(ss.SupersonicException) as e:
-        ss.Plan(ss.ScalarAggregate(spec, ss.ScanView(view)), ss.Context(-1))
-    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+    scalar = ss.Plan(ss.ScalarAggregate(spec, ss.ScanView(view)), ss.Context(-1))
+    first = [ln for ln in scalar.describe().splitlines() if "AGG_FIRST_64" in ln]
+    assert "ROWID_64" in scalar.describe() and len(first) == 1 and "d=r" in first[0], scalar.describe()

@@ -424,7 +424,8 @@ def test_distinct_aggregates_over_several_columns(gpu_ctx, n, nullable):
 def test_first_last_next_to_distinct_aggregates(gpu_ctx, n, nullable):
     # FIRST / LAST follow the INPUT order (aggregation_operators.h:290-320) although the DISTINCT shape re-orders the rows by
     # (keys, distinct column): the input row id is stored as one more column, carried through the sorts, and the clustered
-    # aggregate picks by (row id << 32 | position).  One and two DISTINCT columns; NULL inputs never count; with a filter.
+    # aggregate picks by (row id << 32 | position), the scalar sinks by the row id.  One and two DISTINCT columns; NULL inputs never
+    # count; with a filter.
     view = make_view(n, nullable=nullable)
     spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "sd").AddAggregation(ss.FIRST, "d0", "fd").AddAggregation(ss.LAST, "d", "ld")
             .AddAggregation(ss.FIRST, "b", "fb").AddAggregation(ss.LAST, "t", "lt").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.LAST, "a", "la"))
@@ -432,9 +433,8 @@ def test_first_last_next_to_distinct_aggregates(gpu_ctx, n, nullable):
     spec.AddDistinctAggregation(ss.COUNT, "k1", "cdk")
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2", "t"]), spec, None,
                                ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx, ignore_order=True)
-    with pytest.raises(ss.SupersonicException) as e:                 # the scalar sinks pick by position only
-        ss.Plan(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
-    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)    # the scalar sinks take their order from that column too
+    run_both(ss.ScalarAggregate(spec, ss.Filter(ss.Less(NA("b"), ss.ConstInt64(300)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx)
 
 
 def test_plan_restages_every_new_host_view(gpu_ctx):
@@ -1351,6 +1351,19 @@ def test_specialized_materialising_and_group_stages(specialized_ctx, n):
     _run_specialized(compute_exprs(make_view(n, nullable=True)), specialized_ctx)
     _run_specialized(ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(make_view(n))), specialized_ctx)
     _run_specialized(group_query(make_view(n, nullable=True), True), specialized_ctx, ignore_order=True)
+
+
+def test_specialized_first_last_by_a_stored_row_id(specialized_ctx):
+    # the round-4 forms of FIRST / LAST -- order taken from a stored row-id column next to DISTINCT aggregates, row-id twins
+    # under a key limit -- through the per-plan compiled kernels
+    view = make_view(30011, nullable=True)
+    spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "sd").AddAggregation(ss.FIRST, "d0", "fd").AddAggregation(ss.LAST, "d", "ld")
+            .AddAggregation(ss.COUNT, "", "n"))
+    _run_specialized(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, None, ss.ScanView(view)), specialized_ctx, ignore_order=True)
+    _run_specialized(ss.ScalarAggregate(spec, ss.ScanView(view)), specialized_ctx)
+    plain = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.FIRST, "d0", "fd").AddAggregation(ss.LAST, "d", "ld"))
+    _run_specialized(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), plain, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(7), ss.ScanView(view)),
+                     specialized_ctx)
 
 
 @pytest.mark.parametrize("slab", [0, 2])
