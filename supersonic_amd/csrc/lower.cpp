@@ -2014,11 +2014,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           Status s = finish_group_agg(g, pipe, &st, false, &too_wide);
           if (!s.ok() && !too_wide) return s;
           if (too_wide && limited) {
-            // keys wider than one 64-bit word under a limit: the sorted shape below, its first-seen id = MIN of the input row id
-            // stored as one more materialised column.  (FIRST / LAST twins would need that id masked by another column's NULLs.)
-            if (fold_ops.size() != g.kpos.size() + n_user_aggs || std::count_if(fold_ops.begin(), fold_ops.end(), [](int o) { return o >= 4; }) != 0)
-              return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result with FIRST / LAST in the sorted shape (group keys wider than 64 packed bits, FIRST / LAST of a computed value) is not available on the device path");
-            g.plans.resize(n_user_aggs);
+            // keys wider than one 64-bit word (or FIRST / LAST of a computed value) under a limit: the sorted shape below, its
+            // first-seen id = MIN of the input row id stored as one more materialised column; the FIRST / LAST twins order by
+            // that column too (AggPlan::order_pos: `row id << 32 | position`, which folds like the plain row id)
+            g.plans.pop_back();   // (AGG_FIRST_SEEN: the hash aggregate's form)
           }
           auto append_limit_tail = [&]() -> Status {
             stages->push_back(st);
@@ -2051,6 +2050,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
               VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
               rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
               pruned.cols.push_back(rc);
+              for (auto& ap : gm.plans) if (ap.rowid_only) ap.order_pos = (int)pruned.cols.size() - 1;
               AggPlan hidden; hidden.aggregation = SSGPU_MIN; hidden.input_pos = (int)pruned.cols.size() - 1; hidden.out_type = SSGPU_UINT64;
               hidden.out_name = "$first_seen"; hidden.result_nullable = false;
               gm.plans.push_back(hidden);

@@ -1498,11 +1498,13 @@ def test_group_aggregate_max_unique_keys_in_result(n, partition, limit):
                                ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx)   # ordered: first-seen order
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1"]), spec, opts, ss.ScanView(view)), ctx)                                   # a NULL key group among them
     # NULLABLE k1 + k2 = 65 key bits: materialise (+ the input row id) -> sort by the keys -> clustered aggregation with MIN(row id)
-    # as the first-seen order -> the same sort + fold.  (FIRST / LAST there are refused: next test.)
-    spec_wide = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.COUNT, "d0", "c0").AddAggregation(ss.COUNT, "", "n")
-                 .AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.SUM, "d1", "sd").AddAggregation(ss.MAX, "f", "mf"))
-    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec_wide, opts,
+    # as the first-seen order -> the same sort + fold; the FIRST / LAST twins order by that stored row id too
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, opts,
                                ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(299)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx)
+    # FIRST / LAST of a computed value take the sorted shape as well (the value is fetched from a stored column)
+    e = ss.CompoundExpression().Add(NA("k2")).AddAs("x", ss.Plus(NA("a"), NA("b"))).Add(NA("d0"))
+    spec_x = ss.AggregationSpecification().AddAggregation(ss.FIRST, "x", "fx").AddAggregation(ss.LAST, "x", "lx").AddAggregation(ss.SUM, "d0", "s")
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec_x, opts, ss.Compute(e, ss.ScanView(view))), ctx)
     plain = make_view(n)                                # NOT NULL keys: two INT32 keys in one word
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit),
                                ss.ScanView(plain)), ctx)
@@ -1516,8 +1518,7 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
     got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("col0"), ss.AggregationSpecification().AddAggregation(ss.SUM, "col1", "sum"), opts, ss.ScanView(view)), gpu_ctx)
     assert got.column(0).data.tolist() == [1, 3, 4] and got.column(1).data.tolist() == [5, -9, 9]
     wide = make_view(100, nullable=True)
-    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), ss.AggregationSpecification().AddAggregation(ss.LAST, "b", "s"), opts, ss.ScanView(wide)),
-               ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "b", "s"), opts, ss.ScanView(wide)),
+    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "b", "s"), opts, ss.ScanView(wide)),
                ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l"), opts, ss.ScanView(wide))):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(op, gpu_ctx)
