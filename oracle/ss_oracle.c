@@ -1176,7 +1176,12 @@ static int bind_aggs(orc_cursor* c, const orc_op* op, const orc_schema* in) {
       }
       continue;
     }
-    if (a->distinct && c->kind == C_CLUSTERS) { set_err(&c->err, RC_NOT_IMPLEMENTED, "DISTINCT inside AggregateClusters not restated%s%s", "", ""); return 0; }
+    /* DISTINCT inside AggregateClusters: Aggregator::Create builds the same DistinctAggregator columns for every aggregating
+     * cursor (cursor/core/aggregator.cc:88-101); AggregateClustersCursor::ProcessInput resets key set and aggregator together
+     * and aggregates every cluster it emits inside ONE call (the unfinished last cluster is dropped and reprocessed,
+     * aggregate_clusters.cc:436-520), so the (result row, value) sets below -- result row = the cluster's number -- see exactly
+     * one cluster's rows.  The reference has no test vector for this combination: pinned only through its parts (the DISTINCT
+     * vectors of GroupAggregate, the cluster vectors of AggregateClusters). */
     g->distinct = a->distinct;
     if (a->aggregation == A_COUNT) { if (!is_integer(g->out_type)) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "COUNT output must be integer%s%s", "", ""); return 0; } }
     else {

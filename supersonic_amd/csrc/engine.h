@@ -164,6 +164,9 @@ struct Stage {
   // DISTINCT aggregates (SCALAR_AGG / CLUSTERS over rows sorted by these columns: group keys + the distinct column): the
   // runtime appends a BOOL input column that is 1 on the first row of every run of equal values of these columns
   std::vector<int> distinct_cols;
+  // MATERIALIZE: the stage's last (synthetic) input column holds, for every input row, the number of its cluster -- runs of equal
+  // values of these input columns (the AggregateClusters boundary scan), computed in front of the stage's program
+  std::vector<int> segment_cols;
   // JOIN_EXPAND: the previous stage materialised [lhs fields..., run start, run count]; every output
   // column is lhs field `col` (from_rhs = false) or column `col` of the auxiliary input
   struct JoinOut { bool from_rhs; int col; };

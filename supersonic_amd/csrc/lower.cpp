@@ -1674,6 +1674,51 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
   return Status::OK();
 }
 
+// The DISTINCT shape behind its first materialise (`pipe` = the identity over that stage's rows).  Every DISTINCT column but the
+// first gets its first-of-run flags as a stored BOOL column: the rows are sorted by (sort_keys, that column), flagged (the
+// synthetic input behind the stage's columns) and written back with the flag; the last sort -- by (sort_keys, first DISTINCT
+// column) -- carries those flags along as payload; then the aggregation over the sorted rows: scalar, or clustered by g->kpos.
+static Status lower_distinct_sorts(std::vector<Stage>* stages, Pipe* pipe_io, GroupBinding* g_io, const std::vector<int>& sort_keys,
+                                   const std::vector<int>& dcols, bool scalar, Stage* st_out) {
+  Pipe& pipe = *pipe_io; GroupBinding& g = *g_io; Stage& st = *st_out;
+  // sorts the pipe's rows by (sort_keys, dcol); *run_cols = those columns
+  auto sort_by_run = [&](int dcol, std::vector<int>* run_cols) -> Status {
+    Stage so; so.kind = STAGE_SORT; so.in_schema = pipe.in_schema; so.out_schema = pipe.in_schema;
+    *run_cols = sort_keys; run_cols->push_back(dcol);
+    for (int k : *run_cols) {
+      if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length keys are outside the device hot path");
+      SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+    }
+    for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+    stages->push_back(so);
+    reset_pipe(&pipe, so.out_schema);
+    return Status::OK();
+  };
+  for (size_t e = 1; e < dcols.size(); ++e) {
+    std::vector<int> run_cols;
+    SS_RETURN_IF_ERROR(sort_by_run(dcols[e], &run_cols));
+    const int n_cols = (int)pipe.in_schema.size();
+    Pipe with_flag = pipe;
+    VCol fc; fc.name = "f" + std::to_string(e);
+    auto fe = std::make_shared<BExpr>();
+    fe->kind = BExpr::INPUT; fe->input_col = n_cols; fe->dtype = SSGPU_BOOL; fe->nullable = false; fe->name = fc.name;
+    fc.expr = fe;
+    with_flag.cols.push_back(fc);
+    Stage mf; SS_RETURN_IF_ERROR(finish_materialize(with_flag, &mf));
+    mf.distinct_cols = run_cols;
+    stages->push_back(mf);
+    reset_pipe(&pipe, mf.out_schema);
+    for (auto& ap : g.plans) if (ap.distinct && ap.input_pos == dcols[e]) ap.flag_pos = n_cols;
+  }
+  std::vector<int> run_cols;
+  SS_RETURN_IF_ERROR(sort_by_run(dcols[0], &run_cols));
+  const int n_in = (int)pipe.in_schema.size();
+  if (scalar) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st, n_in));
+  else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true, nullptr, n_in + 1));   // clustered: segment ids at n_in, the flag behind
+  st.distinct_cols = run_cols;
+  return Status::OK();
+}
+
 Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_schema, std::string* describe) {
   g_filter_single_pass = d.filter_single_pass;
   g_part_rec_align = d.part_rec_align;
@@ -1924,44 +1969,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
           reset_pipe(&pipe, m.out_schema);
-          // sorts the pipe's rows by (keys, dcol); *run_cols = those columns
-          auto sort_by_run = [&](int dcol, std::vector<int>* run_cols) -> Status {
-            Stage so; so.kind = STAGE_SORT; so.in_schema = pipe.in_schema; so.out_schema = pipe.in_schema;
-            *run_cols = g.kpos; run_cols->push_back(dcol);
-            for (int k : *run_cols) {
-              if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length keys are outside the device hot path");
-              SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
-            }
-            for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
-            stages->push_back(so);
-            reset_pipe(&pipe, so.out_schema);
-            return Status::OK();
-          };
-          // Every DISTINCT column but the first gets its first-of-run flags as a stored BOOL column: the rows are sorted by
-          // (keys, that column), flagged (the synthetic input behind the stage's columns) and written back with the flag;
-          // the last sort -- by (keys, first DISTINCT column) -- carries those flags along as payload.
-          for (size_t e = 1; e < dcols.size(); ++e) {
-            std::vector<int> run_cols;
-            SS_RETURN_IF_ERROR(sort_by_run(dcols[e], &run_cols));
-            const int n_cols = (int)pipe.in_schema.size();
-            Pipe with_flag = pipe;
-            VCol fc; fc.name = "f" + std::to_string(e);
-            auto fe = std::make_shared<BExpr>();
-            fe->kind = BExpr::INPUT; fe->input_col = n_cols; fe->dtype = SSGPU_BOOL; fe->nullable = false; fe->name = fc.name;
-            fc.expr = fe;
-            with_flag.cols.push_back(fc);
-            Stage mf; SS_RETURN_IF_ERROR(finish_materialize(with_flag, &mf));
-            mf.distinct_cols = run_cols;
-            stages->push_back(mf);
-            reset_pipe(&pipe, mf.out_schema);
-            for (auto& ap : g.plans) if (ap.distinct && ap.input_pos == dcols[e]) ap.flag_pos = n_cols;
-          }
-          std::vector<int> run_cols;
-          SS_RETURN_IF_ERROR(sort_by_run(dcols[0], &run_cols));
-          const int n_in = (int)pipe.in_schema.size();
-          if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st, n_in));
-          else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true, nullptr, n_in + 1));   // clustered: segment ids at n_in, the flag behind
-          st.distinct_cols = run_cols;
+          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, g.kpos, dcols, op.kind == SSGPU_OP_SCALAR_AGGREGATE, &st));
           desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)) ";
         } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) {
           std::vector<AggPlan> plans;
@@ -2121,6 +2129,54 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
                 return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT inside AggregateClusters needs a plain input column");
             for (auto& ap : g.plans) if (ap.aggregation == SSGPU_CONCAT) ap.input_pos = ap.input_pos;   // (the stage input IS the pipe here: materialised above, or the plan input)
             take_concat_plans(schema_of(pipe.cols), &g.plans, &concats);
+          }
+          bool any_distinct = false, first_last = false;
+          for (auto& ap : g.plans) {
+            any_distinct = any_distinct || ap.distinct;
+            first_last = first_last || ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST;
+          }
+          if (any_distinct) {
+            // DISTINCT aggregates of clusters (Aggregator::Create serves AggregateClusters too, aggregator.cc:88-101): the DISTINCT
+            // shape of the GroupAggregate with the cluster's NUMBER as the sort key.  The rows are stored once more together with
+            // their segment id (the boundary scan over the key columns, run in front of this stage: Stage::segment_cols), sorted
+            // by (segment id, DISTINCT column), flagged and aggregated as clusters of (segment id, keys...) -- equal keys of
+            // different clusters stay apart and the clusters keep their input order; the segment id is projected away behind.
+            if (!concats.empty()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate inside AggregateClusters is not available on the device path");
+            std::vector<int> key_inputs;
+            for (int k : g.kpos) {
+              if (pipe.cols[k].expr->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "clustered keys must be plain input columns");
+              key_inputs.push_back(pipe.cols[k].expr->input_col);
+            }
+            std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
+            auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
+            for (auto& k : g.kpos) k = slot_of(k);
+            for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+            std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
+            for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
+            Pipe pruned = pipe; pruned.cols.clear();
+            for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+            { VCol sc; sc.name = "$segment"; sc.expr = std::make_shared<BExpr>();
+              sc.expr->kind = BExpr::INPUT; sc.expr->input_col = (int)pipe.in_schema.size(); sc.expr->dtype = SSGPU_UINT32; sc.expr->nullable = false; sc.expr->name = sc.name;
+              pruned.cols.push_back(sc); }
+            const int seg_pos = (int)pruned.cols.size() - 1;
+            if (first_last) {
+              VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
+              rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
+              pruned.cols.push_back(rc);
+              for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = (int)pruned.cols.size() - 1;
+            }
+            Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
+            m.segment_cols = key_inputs;
+            stages->push_back(m);
+            reset_pipe(&pipe, m.out_schema);
+            g.kpos.insert(g.kpos.begin(), seg_pos); g.knames.insert(g.knames.begin(), "$segment");
+            SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, std::vector<int>{seg_pos}, dcols, false, &st));
+            desc << "(materialise with segment ids + " << dcols.size() << " x (sort + first-of-run flags)) AggregateClusters -> [" << schema_to_string(st.out_schema) << "] minus its first column\n";
+            stages->push_back(st);
+            reset_pipe(&pipe, st.out_schema);
+            pipe.cols.erase(pipe.cols.begin());   // (the segment id)
+            pending = true;
+            break;
           }
           add_nan_exact_plans(d.nan_exact && concats.empty(), schema_of(pipe.cols), &g.plans, &c_fixes);
           SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));

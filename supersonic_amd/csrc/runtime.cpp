@@ -183,6 +183,7 @@ struct StageExec {
   DevBuf debug, debug_pc, total2;
   // sort / clusters
   DevBuf skeys_a, skeys_b, skeys_c, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
+  DevBuf seg_counts, seg_offsets, seg_total;   // segment_ids() of a MATERIALIZE stage (its own: the stage's filter passes use tile_counts / total)
   DevBuf route_scratch;         // key-range exchange: per-destination counters + (destination, position) of every result row
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
@@ -1010,6 +1011,29 @@ int emit_scalar_agg(ssgpu_plan* p, size_t si) {
   return SSGPU_OK;
 }
 
+// Stage::segment_cols: the cluster number of every input row (the boundary count + scan + assign passes of run_clusters,
+// without the key write-out) as one more input column
+int segment_ids(ssgpu_ctx* c, const Stage& st, StageExec& ex, const InCols& in, ssgpu_column* out) {
+  const uint32_t nk = (uint32_t)st.segment_cols.size();
+  if (nk > 16) { c->err = "AggregateClusters with more than 16 keys"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  const void* kdata[16] = {nullptr}; const uint8_t* knulls[16] = {nullptr}; uint32_t kwidth[16] = {0};
+  void* okdata[16] = {nullptr}; uint8_t* oknulls[16] = {nullptr};
+  for (uint32_t k = 0; k < nk; ++k) {
+    const int col = st.segment_cols[k];
+    kdata[k] = in.cols[col].data; knulls[k] = st.in_schema[col].nullable ? in.cols[col].is_null : nullptr; kwidth[k] = (uint32_t)dtype_width(st.in_schema[col].dtype);
+  }
+  const uint64_t n = (uint64_t)in.rows;
+  const int ntile = (int)((n + 511) / 512);
+  HIP_TRY(c, ex.seg_counts.ensure((size_t)std::max(ntile, 1) * 4)); HIP_TRY(c, ex.seg_offsets.ensure((size_t)std::max(ntile, 1) * 4));
+  HIP_TRY(c, ex.seg_total.ensure(8)); HIP_TRY(c, ex.seg_id.ensure(std::max<uint64_t>(n, 1) * 4));
+  HIP_TRY(c, hipMemsetAsync(ex.seg_total.p, 0, 8, c->stream));
+  HIP_TRY(c, ssgpu_launch_cluster_count(kdata, knulls, kwidth, nk, n, ex.seg_counts.as<uint32_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_scan_counts(ex.seg_counts.as<uint32_t>(), ex.seg_offsets.as<uint32_t>(), ntile, ex.seg_total.as<uint64_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_cluster_assign(kdata, knulls, kwidth, nk, okdata, oknulls, n, ex.seg_offsets.as<uint32_t>(), ex.seg_id.as<uint32_t>(), c->stream));
+  out->data = ex.seg_id.p; out->is_null = nullptr;
+  return SSGPU_OK;
+}
+
 int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   int rc = ensure_out_cols(c, st, ex, in0.rows);
@@ -1018,6 +1042,10 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   InCols in = in0;
   if (!st.distinct_cols.empty()) {   // a further DISTINCT column's first-of-run flags, stored with the rows (lower.cpp)
     ssgpu_column f; rc = distinct_flags(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
+    in.cols.push_back(f);
+  }
+  if (!st.segment_cols.empty()) {    // DISTINCT aggregates of clusters: the rows are stored with their cluster's number
+    ssgpu_column f; rc = segment_ids(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
     in.cols.push_back(f);
   }
   VmParams P;
@@ -1182,7 +1210,7 @@ static bool tail_runs_without_host(const ssgpu_plan* p, size_t si) {
   if (!p->ctx->async_handoff && si + 1 < p->stages.size()) return false;
   for (size_t k = si + 1; k < p->stages.size(); ++k) {
     const Stage& nx = p->stages[k];
-    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && nx.joins.empty())) return false;
+    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && nx.segment_cols.empty() && nx.joins.empty())) return false;
   }
   return true;
 }
@@ -2290,7 +2318,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       // stage's error word is still looked at when the result is touched (check_error_flags); rows beyond the count are
       // never computed, so a signaling operator cannot fail on them.
       const bool device_rows = c->async_handoff != 0 && !c->debug_timing && ex.out_rows < 0 && ex.out_capacity > 0 && nx.kind == STAGE_MATERIALIZE &&
-                               !nx.has_filter && nx.distinct_cols.empty() && nx.joins.empty();
+                               !nx.has_filter && nx.distinct_cols.empty() && nx.segment_cols.empty() && nx.joins.empty();
       int64_t r = 0;
       in.rows_dev = nullptr;
       if (device_rows) {

@@ -688,6 +688,7 @@ __global__ __launch_bounds__(256) void ssgpu_cluster_assign_kernel(const Cluster
     seg_id[r] = ss[j];
     if (!ff[j]) continue;
     for (u32 k = 0; k < K.n; ++k) {
+      if (!O.data[k]) continue;   // (segment ids only: Stage::segment_cols)
       const bool isnull = K.nulls[k] && K.nulls[k][r];
       const u32 w = K.width[k];
       if (w == 8) reinterpret_cast<u64*>(O.data[k])[ss[j]] = isnull ? 0ull : reinterpret_cast<const u64*>(K.data[k])[r];

@@ -115,3 +115,21 @@ def test_first_last_next_to_distinct_pick_by_the_stored_row_id():
     scalar = ss.Plan(ss.ScalarAggregate(spec, ss.ScanView(view)), ss.Context(-1))
     first = [ln for ln in scalar.describe().splitlines() if "AGG_FIRST_64" in ln]
     assert "ROWID_64" in scalar.describe() and len(first) == 1 and "d=r" in first[0], scalar.describe()
+
+
+def test_distinct_inside_aggregate_clusters_binds_with_a_segment_id_column():
+    # materialise (keys, inputs, the cluster's number from the boundary scan) -> sort by (number, DISTINCT column) -> flags ->
+    # clusters of (number, keys); the number is projected away behind the aggregate
+    import numpy as np
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
+    view = ss.View(schema, [np.zeros(4, np.int32), np.arange(4), np.arange(4)])
+    spec = ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "s").AddAggregation(ss.MAX, "b", "m")
+    plan = ss.Plan(ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), spec, ss.ScanView(view)), ss.Context(-1))
+    rs = plan.result_schema
+    assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "s", "m"]
+    assert "segment ids" in plan.describe()
+    bad = ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "s").AddAggregation(ss.CONCAT, "b", "c"),
+                               ss.ScanView(view))
+    with pytest.raises(ss.SupersonicException) as e:
+        ss.Plan(bad, ss.Context(-1))
+    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED

@@ -912,6 +912,33 @@ def test_aggregate_clusters(gpu_ctx, n, nullable):
     run_both(ss.AggregateClusters(ss.ProjectNamedAttributes(["k", "k2"]), spec, ss.ScanView(view)), gpu_ctx)
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 513, 10001, 100003])
+@pytest.mark.parametrize("nullable", [False, True])
+def test_aggregate_clusters_with_distinct_aggregates(gpu_ctx, n, nullable):
+    # DISTINCT aggregates of clusters (Aggregator::Create, aggregator.cc:88-101, serves AggregateClusters as every aggregating
+    # cursor; a cluster is always aggregated inside one ProcessInput call, aggregate_clusters.cc:436-520): the DISTINCT shape with
+    # the cluster's number as the sort key -- equal keys of different clusters stay apart, the clusters keep their input order.
+    # Long runs (many repeats of few values), one and two DISTINCT columns, FIRST / LAST next to them, below a Filter / Compute.
+    rng = np.random.default_rng(12)
+    N = ss.NULLABLE if nullable else ss.NOT_NULLABLE
+    key = np.cumsum(rng.integers(0, 40, n) == 0) % 7 if n else np.zeros(0, np.int64)      # runs of ~40 rows; 7 keys that come back
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64, N), ss.Attribute("v", ss.INT64, N), ss.Attribute("w", ss.INT32), ss.Attribute("d", ss.DOUBLE)])
+    knull = (key % 5 == 0) if nullable else None
+    vnull = (rng.random(n) < 0.2) if nullable else None
+    view = ss.View(schema, [ss.Column(key, knull), ss.Column(rng.integers(-6, 6, n), vnull), rng.integers(0, 5, n).astype(np.int32), rng.integers(0, 8, n) * 0.5])
+    spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "v", "sdv").AddDistinctAggregation(ss.COUNT, "v", "cdv").AddAggregation(ss.SUM, "v", "sv")
+            .AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.MAX, "d", "mx"))
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), spec, ss.ScanView(view)), gpu_ctx)
+    spec.AddDistinctAggregation(ss.COUNT, "w", "cdw").AddDistinctAggregation(ss.SUM, "d", "sdd").AddAggregation(ss.FIRST, "v", "fv").AddAggregation(ss.LAST, "d", "ld")
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), spec, ss.ScanView(view)), gpu_ctx)
+    # below a Filter and a Compute (the pipeline is flushed first), and a consumer above (the segment id is projected away)
+    e = ss.CompoundExpression().Add(NA("k")).Add(NA("v")).AddAs("w", ss.Plus(NA("w"), ss.ConstInt32(1))).Add(NA("d"))
+    child = ss.Compute(e, ss.Filter(ss.Less(NA("d"), ss.ConstDouble(3.0)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    agg = ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), spec, child)
+    run_both(agg, gpu_ctx)
+    run_both(ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "sdv", "t").AddAggregation(ss.COUNT, "k", "c").AddAggregation(ss.SUM, "cdw", "u"), agg), gpu_ctx)
+
+
 @pytest.mark.parametrize("n", [0, 1, 1025, 100003])
 def test_date_and_datetime(gpu_ctx, n):
     # DATE (days, INT32) / DATETIME (microseconds, INT64): the DATE -> DATETIME cast multiplies by the
