@@ -200,6 +200,42 @@ class Gen(object):
             return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child)
         return ss.ScalarAggregate(spec, child)
 
+    def ordered_aggregate_plan(self, view):
+        """Aggregates whose device shapes carry an explicit order along (round 4): DISTINCT next to FIRST / LAST, key limits with
+        FIRST / LAST and wide keys, DISTINCT inside AggregateClusters.  Returns (operation, result order is defined)."""
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("k1")).Add(NA("a")).Add(NA("b")).Add(NA("u")).Add(NA("t")).Add(NA("day")).Add(NA("name"))
+        shape = self.pick(["scalar", "group", "group", "limit", "limit", "clusters", "clusters"])
+        spec = ss.AggregationSpecification()
+        inputs = ["a", "b", "k1", "u", "t", "day", "k2"]
+        for i in range(int(self.rng.integers(0, 3))):
+            e.AddAs("x%d" % i, self.integer(int(self.rng.integers(0, 3))))
+            inputs.append("x%d" % i)
+        any_distinct = False
+        for i in range(int(self.rng.integers(1, 7))):
+            name = self.pick(inputs)
+            agg = self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST, ss.FIRST, ss.LAST])
+            if name in ("t", "day", "name") and agg == ss.SUM:
+                agg = ss.COUNT
+            distinct = shape != "limit" and agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < 0.45
+            any_distinct = any_distinct or distinct
+            (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
+        if shape in ("scalar", "group", "clusters") and not any_distinct:
+            spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1", "u"]), "rd")
+        child = ss.ScanView(view)
+        if self.rng.random() < 0.5:
+            child = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), child)
+        child = ss.Compute(e, child)
+        if shape == "scalar":
+            return ss.ScalarAggregate(spec, child), True
+        keys = self.pick([["k2"], ["k2", "s"], ["s"], ["k1"], ["k1", "k2"], ["a", "s"], ["day", "s"], ["name", "k2"]])
+        if shape == "clusters":
+            # (runs of equal keys are short in random rows; ["s"] and ["k2"] give runs of 2 .. 7 rows here and there)
+            return ss.AggregateClusters(ss.ProjectNamedAttributes(self.pick([["s"], ["k2"], ["k2", "s"], ["t"]])), spec, child), True
+        if shape == "limit":
+            return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec,
+                                     ss.GroupAggregateOptions().set_max_unique_keys_in_result_(int(self.rng.integers(0, 9))), child), True
+        return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child), False
+
     def sort_plan(self, view):
         e = ss.CompoundExpression().Add(NA("b")).Add(NA("k1")).Add(NA("d0")).Add(NA("t")).Add(NA("u")).Add(NA("name")).Add(NA("day"))
         for i in range(int(self.rng.integers(0, 3))):

@@ -55,3 +55,19 @@ def test_random_high_cardinality_group_aggregate(seed, partition):
     except oracle.OracleError:
         return
     run_both(op, ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("n", [1537, 20011])
+@pytest.mark.parametrize("seed", range(4000, 4250))
+def test_random_ordered_aggregates(gpu_ctx, seed, n):
+    # the round-4 shapes: DISTINCT next to FIRST / LAST (scalar, grouped, clustered), key limits with FIRST / LAST and keys of any
+    # width, DISTINCT inside AggregateClusters -- every one carries the input order along as a stored column
+    view = make_view(n, seed)
+    op, ordered = Gen(seed).ordered_aggregate_plan(view)
+    try:
+        oracle.run(op)
+    except oracle.OracleError:
+        with pytest.raises(ss.SupersonicException):
+            ss.Plan(op, gpu_ctx)
+        return
+    run_both(op, gpu_ctx, ignore_order=not ordered)
