@@ -67,6 +67,11 @@
  *       group) and rounded once: <= 1 ULP from the exact sum (measured 0 ULP against math.fsum,
  *       tests/test_double_sum_gpu.py) and identical to the reference whenever every partial sum is
  *       exactly representable;
+ *       SUM of a FLOAT / DOUBLE input into an INTEGER result (AddAggregationWithDefinedOutputType): `*result += val`
+ *       adds in the floating type and truncates back after every row -- there the order IS the definition, and the
+ *       rows are folded one after the other in input order (materialise -> one thread per group / cluster / the one
+ *       wavefront of a ScalarAggregate): bit-identical to the reference, and slow by construction.  Refused next to
+ *       DISTINCT / CONCAT aggregates, under max_unique_keys_in_result and across shards;
  *       MIN / MAX over FLOAT / DOUBLE: the reference's update is "if (val < result) result = val"
  *       (aggregation_operators.h:200,221) after ASSIGNING a group's first non-NULL value: a NaN that
  *       comes FIRST stays (nothing is less than NaN), a NaN that comes later is skipped.  Same here:

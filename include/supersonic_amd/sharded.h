@@ -160,6 +160,11 @@ class ShardedGroupAggregate {
       merged->AddAggregation(m, e.output, e.output);
       if (e.aggregation == COUNT) counts_.push_back(e.output);
       const int pos = child_schema.LookupAttributePosition(e.input);
+      if (e.aggregation == SUM && pos >= 0 && (child_schema.attribute(pos).type() == DOUBLE || child_schema.attribute(pos).type() == FLOAT) &&
+          (e.output_type == INT32 || e.output_type == UINT32 || e.output_type == INT64 || e.output_type == UINT64)) {
+        // (the reference adds and truncates row after row, aggregation_operators.h:173-185: a shard's result is not a partial sum)
+        error_code_ = ERROR_NOT_IMPLEMENTED; error_ = "SUM of a floating input into an integer output cannot be merged across shards"; return;
+      }
       if (e.aggregation == SUM && pos >= 0 && child_schema.attribute(pos).type() == DOUBLE && (e.output_type < 0 || e.output_type == DOUBLE)) {
         shard->AddAggregation(static_cast<Aggregation>(SSGPU_SUM_RESIDUAL), e.input, e.output + kResidual);
         merged->AddAggregation(SUM, e.output + kResidual, e.output + kResidual);

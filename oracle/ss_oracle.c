@@ -1387,6 +1387,23 @@ static void update_aggregation(agg_col* g, const orc_view* v, const int64_t* map
         case A_MAX: if (less_typed(g->out_type, res, r, g->in_type, in, i)) *acc = val; break; \
         case A_FIRST: break; \
         case A_LAST: *acc = val; break; } }
+    if (g->aggregation == A_SUM && ko <= 3 && (arith_kind(g->in_type) == 4 || arith_kind(g->in_type) == 5)) {
+      /* SUM of a floating input into an integer result (AddAggregationWithDefinedOutputType; column_aggregator.cc:484-532 lists
+       * the pair): AggregationOperator<SUM>, aggregation_operators.h:173-185, is `*result += val` -- C++ adds in the floating
+       * type (FLOAT stays float) and converts back to the integer after EVERY row; the first value is assigned
+       * (column_aggregator.cc:170-175).  Order-dependent: this loop IS the reference's order.  Floating -> integer goes
+       * through int64_t like every other such store here (in range it is the plain C conversion). */
+#define SEQ_SUM(TO, F) { TO* acc = (TO*)res + r; const F v = ((const F*)in)[i]; \
+        if (first) *acc = (TO)(int64_t)v; else *acc = (TO)(int64_t)((F)*acc + v); }
+      if (arith_kind(g->in_type) == 4) switch (ko) {
+        case 0: SEQ_SUM(int32_t, float) break; case 1: SEQ_SUM(uint32_t, float) break;
+        case 2: SEQ_SUM(int64_t, float) break; default: SEQ_SUM(uint64_t, float) break; }
+      else switch (ko) {
+        case 0: SEQ_SUM(int32_t, double) break; case 1: SEQ_SUM(uint32_t, double) break;
+        case 2: SEQ_SUM(int64_t, double) break; default: SEQ_SUM(uint64_t, double) break; }
+#undef SEQ_SUM
+      continue;
+    }
     switch (ko) {
       case 0: AGG_TYPED(int32_t, load_as_i64) break;
       case 1: AGG_TYPED(uint32_t, load_as_i64) break;

@@ -167,6 +167,11 @@ struct Stage {
   // MATERIALIZE: the stage's last (synthetic) input column holds, for every input row, the number of its cluster -- runs of equal
   // values of these input columns (the AggregateClusters boundary scan), computed in front of the stage's program
   std::vector<int> segment_cols;
+  // SCALAR_AGG / CLUSTERS: SUM of a floating input column into an integer result -- the reference adds and truncates row after
+  // row (aggregation_operators.h:173-185), so the stage's program only counts the column (the result's slot) and the runtime
+  // folds the rows in their order afterwards (ssgpu_launch_seq_sum) into result column `out_col`
+  struct SeqSum { int out_col; int in_col; };
+  std::vector<SeqSum> seq_sums;
   // JOIN_EXPAND: the previous stage materialised [lhs fields..., run start, run count]; every output
   // column is lhs field `col` (from_rhs = false) or column `col` of the auxiliary input
   struct JoinOut { bool from_rhs; int col; };

@@ -235,6 +235,10 @@ hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* c
                                        uint32_t* seg_id, hipStream_t s);
 hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const void* src, uint32_t width, int src_kind, int dst_kind, const uint64_t* rowids,
                                      uint64_t rowid_mask /* bits of a rowids word that ARE the row id */, int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream);
+// SUM of a floating column into an integer result, row after row in the rows' order (sort_kernels.hip: SeqSumParams); one result
+// per segment of seg_id (nullptr: one segment of all n rows); kinds 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64
+hipError_t ssgpu_launch_seq_sum(const void* src, const uint8_t* src_nulls, int src_kind, const uint32_t* seg_id, uint64_t n,
+                                void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s);
 hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
                                       const GroupAggOut* outs, uint32_t n_out, hipStream_t s);
 

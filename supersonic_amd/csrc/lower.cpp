@@ -851,6 +851,7 @@ struct AggPlan {
   int flag_pos = -1;       // DISTINCT over a second, third ... column: pipe column holding that column's first-of-run flag
   int order_pos = -1;      // FIRST / LAST over rows that were re-ordered on the way (the DISTINCT shape): pipe column holding the
                            // row's id in the ORIGINAL order -- the aggregate picks by it, not by the row's position here
+  bool sequential = false; // SUM of a floating input into an integer result: folded row after row in the input order (Stage::seq_sums)
   bool rowid_only = false; // FIRST / LAST that yields the chosen row's id (UINT64) instead of its value: the arg-min / arg-max
                            // column the fold of a key limit picks values by
 };
@@ -915,9 +916,11 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
       // floating input into an integer result: MIN / MAX / FIRST / LAST store the truncated value, and because truncation is
       // monotone the reference's fold (compare the floating value with the integer result, store the cast) gives
       // min / max of the truncated values whatever the order.  SUM adds a floating value to an integer result and
-      // truncates after EVERY row: order-dependent, not restated on device.
-      if (dtype_is_float(it) && dtype_is_integer(p.out_type) && a.aggregation == SSGPU_SUM)
-        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output truncates after every row (order-dependent); not on device");
+      // truncates after EVERY row: order-dependent -- the rows are folded one after the other in the input order (take_sequential).
+      if (dtype_is_float(it) && dtype_is_integer(p.out_type) && a.aggregation == SSGPU_SUM) {
+        if (a.distinct) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM DISTINCT of a floating input into an integer output is not available on the device path");
+        p.sequential = true;
+      }
     }
     out->push_back(p);
   }
@@ -1063,6 +1066,22 @@ static int64_t staged_bytes(const Program& p) {
 // distinct_flag_input >= 0: index of a synthetic BOOL input column (appended by the runtime) that is 1 on the first row of
 // every run of equal (group keys, distinct column) in the -- sorted -- stage input; a DISTINCT aggregate treats every other
 // row like a NULL input
+static bool has_sequential(const std::vector<AggPlan>& plans) { for (auto& ap : plans) if (ap.sequential) return true; return false; }
+// Sequential sums (AggPlan::sequential) leave the stage's program: each becomes COUNT(column) -- its slot, its result type -- and
+// an entry of Stage::seq_sums; the runtime overwrites the count with the row-after-row fold.  `pipe` must be the identity
+// over stored columns (the callers materialise first), `first_out` = the result column of plans[0].
+static Status take_sequential(std::vector<AggPlan>* plans, const Pipe& pipe, size_t first_out, std::vector<Stage::SeqSum>* out) {
+  for (size_t j = 0; j < plans->size(); ++j) {
+    AggPlan& ap = (*plans)[j];
+    if (!ap.sequential) continue;
+    const BExprP& src = pipe.cols[ap.input_pos].expr;
+    if (src->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating value into an integer output needs a stored input column");
+    out->push_back(Stage::SeqSum{(int)(first_out + j), src->input_col});
+    ap.aggregation = SSGPU_COUNT; ap.sequential = false;
+  }
+  return Status::OK();
+}
+
 static Status finish_scalar_agg_bound(const std::vector<AggPlan>& plans, const Pipe& pipe, Stage* st, int distinct_flag_input = -1) {
   for (auto& ap : plans)
     if (ap.aggregation == SSGPU_SUM_RESIDUAL)
@@ -1905,6 +1924,9 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &probe));
           for (auto& ap : probe) any_distinct = any_distinct || ap.distinct;
           any_concat = has_concat(probe);
+          // (a sum folded row after row needs the rows in input order and a result row of its own: none of the composed shapes)
+          if (has_sequential(probe) && (any_distinct || any_concat || (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0)))
+            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to DISTINCT / CONCAT aggregates or under max_unique_keys_in_result is not available on the device path");
         }
         if (any_concat) {
           // CONCAT (Stage::ConcatCol): the values have to reach the host in input order, group by group -- materialise the keys and
@@ -1975,8 +1997,23 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           std::vector<AggPlan> plans;
           SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &plans));
           n_user_aggs = plans.size();
+          std::vector<Stage::SeqSum> seqs;
+          if (has_sequential(plans)) {
+            // the row-after-row sums read stored columns in input order: the aggregated columns are materialised first
+            std::vector<int> used;
+            auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
+            for (auto& ap : plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+            Pipe pruned = pipe; pruned.cols.clear();
+            for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+            Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
+            stages->push_back(m);
+            reset_pipe(&pipe, m.out_schema);
+            SS_RETURN_IF_ERROR(take_sequential(&plans, pipe, 0, &seqs));
+            desc << "(materialise; floating sums into integers folded row after row) ";
+          }
           add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &plans, &nan_fixes);
           SS_RETURN_IF_ERROR(finish_scalar_agg_bound(plans, pipe, &st));
+          st.seq_sums = seqs;
         } else {
           // GroupAggregateOptions::max_unique_keys_in_result folds every key beyond the limit into one extra last row
           // (aggregate_groups.cc:326): depends on first-seen key order, which no device shape has -- refuse loudly
@@ -2018,8 +2055,8 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             hidden.out_name = "$first_seen"; hidden.result_nullable = false;
             g.plans.push_back(hidden);
           }
-          bool too_wide = false;
-          Status s = finish_group_agg(g, pipe, &st, false, &too_wide);
+          bool too_wide = has_sequential(g.plans);   // (row-after-row sums: the sorted shape keeps the input order inside a group)
+          Status s = too_wide ? Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "sorted shape") : finish_group_agg(g, pipe, &st, false, &too_wide);
           if (!s.ok() && !too_wide) return s;
           if (too_wide && limited) {
             // keys wider than one 64-bit word (or FIRST / LAST of a computed value) under a limit: the sorted shape below, its
@@ -2074,7 +2111,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             stages->push_back(so);
             reset_pipe(&pipe, so.out_schema);
             st = Stage();
+            std::vector<Stage::SeqSum> seqs;
+            SS_RETURN_IF_ERROR(take_sequential(&gm.plans, pipe, gm.kpos.size(), &seqs));
             SS_RETURN_IF_ERROR(finish_group_agg(gm, pipe, &st, true));
+            st.seq_sums = seqs;
             desc << "(materialise + sort + clustered aggregation) ";
             if (limited) SS_RETURN_IF_ERROR(append_limit_tail());
           }
@@ -2142,6 +2182,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             // by (segment id, DISTINCT column), flagged and aggregated as clusters of (segment id, keys...) -- equal keys of
             // different clusters stay apart and the clusters keep their input order; the segment id is projected away behind.
             if (!concats.empty()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate inside AggregateClusters is not available on the device path");
+            if (has_sequential(g.plans)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to a DISTINCT aggregate is not available on the device path");
             std::vector<int> key_inputs;
             for (int k : g.kpos) {
               if (pipe.cols[k].expr->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "clustered keys must be plain input columns");
@@ -2178,8 +2219,11 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             pending = true;
             break;
           }
+          std::vector<Stage::SeqSum> seqs;
+          SS_RETURN_IF_ERROR(take_sequential(&g.plans, pipe, g.kpos.size(), &seqs));
           add_nan_exact_plans(d.nan_exact && concats.empty(), schema_of(pipe.cols), &g.plans, &c_fixes);
           SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
+          st.seq_sums = seqs;
           for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), pipe.cols[cp.input_pos].expr->input_col, cp.dtype});
           desc << "AggregateClusters -> [" << schema_to_string(st.out_schema) << "]\n";
         }

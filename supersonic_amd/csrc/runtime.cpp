@@ -980,6 +980,25 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
   return SSGPU_OK;
 }
 
+// Stage::seq_sums: SUM of a floating column into an integer result, folded row after row over the stage's input (its segments
+// for a clustered stage, all rows for a scalar one); overwrites the COUNT the stage's program left in the result column
+static int run_seq_sums(ssgpu_plan* p, Stage& st, StageExec& ex, const InCols& in, const uint32_t* seg_id) {
+  ssgpu_ctx* c = p->ctx;
+  auto kind_of = [](int dtype) {
+    switch (dtype) {
+      case SSGPU_INT32: return 0; case SSGPU_UINT32: return 1; case SSGPU_INT64: return 2; case SSGPU_UINT64: return 3;
+      case SSGPU_FLOAT: return 4; default: return 5;
+    }
+  };
+  for (auto& q : st.seq_sums) {
+    HIP_TRY(c, ssgpu_launch_seq_sum(in.cols[q.in_col].data, st.in_schema[q.in_col].nullable ? in.cols[q.in_col].is_null : nullptr, kind_of(st.in_schema[q.in_col].dtype),
+                                    seg_id, (uint64_t)in.rows, ex.out[q.out_col].data.p, ex.out[q.out_col].nullable ? ex.out[q.out_col].nulls.as<uint8_t>() : nullptr,
+                                    kind_of(st.out_schema[q.out_col].dtype), c->stream));
+    p->counters.n_launches += 1;
+  }
+  return SSGPU_OK;
+}
+
 // the one-row result's output buffers and their emit descriptors (uploaded once: the buffers never move)
 int prepare_scalar_emit(ssgpu_plan* p, size_t si, int* n_out) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
@@ -2062,6 +2081,7 @@ int run_clusters(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base
   }
   HIP_TRY(c, ssgpu_launch_dense_extract(ex.gacc.as<uint64_t>(), ex.gcnt.as<uint32_t>(), ng, nseg, outs.data(), (uint32_t)outs.size(), c->stream));
   rc = gather_first_last(p, st, ex, nk, in, row_id_base, nullptr, nseg);
+  if (rc == SSGPU_OK && !st.seq_sums.empty()) rc = run_seq_sums(p, st, ex, in, ex.seg_id.as<uint32_t>());
   if (rc != SSGPU_OK) return rc;
   p->counters.n_launches += 6;
   ex.out_rows = (int64_t)nseg;
@@ -2298,6 +2318,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       case STAGE_SCALAR_AGG:
         rc = run_scalar_agg(p, si, in, row_id_base, partial);
         if (rc == SSGPU_OK && !partial) rc = emit_scalar_agg(p, si);
+        if (rc == SSGPU_OK && !partial && !st.seq_sums.empty()) rc = run_seq_sums(p, st, p->exec[si], in, nullptr);
         break;
       case STAGE_MATERIALIZE: rc = run_materialize(p, si, in, row_id_base); break;
       case STAGE_GROUP_AGG: rc = run_group_agg(p, si, in, row_id_base); break;

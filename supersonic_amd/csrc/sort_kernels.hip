@@ -699,6 +699,85 @@ __global__ __launch_bounds__(256) void ssgpu_cluster_assign_kernel(const Cluster
   }
 }
 
+// ---- SUM of a floating input into an integer result (AddAggregationWithDefinedOutputType) --------------------------------
+// aggregation_operators.h:173-185: `*result += val` with an integer result and a floating value adds in the floating type and
+// truncates back after EVERY row (the first non-NULL value is assigned: column_aggregator.cc:170-175), so the result depends
+// on the row order -- no parallel reduction has it.  The rows arrive in the reference's order within a segment (the input
+// order: the stable sort of the sorted shape, or the clusters themselves) and one thread folds each segment, row after row.
+// Conversions as everywhere on the path: floating -> integer truncates, out of range / NaN gives INT64_MIN's bits
+// (cvttsd2si), the low bytes are stored for the narrower types.
+struct SeqSumParams {
+  const void* src; const u8* src_nulls; const u32* seg_id;   // seg_id == nullptr: all rows are one segment (ScalarAggregate)
+  void* dst; u8* dst_nulls; u64 n; int src_kind, dst_kind;   // kinds: 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64
+};
+template <typename F> __device__ __forceinline__ u64 seq_to_bits(F x) {
+  const double tr = trunc((double)x);
+  return (tr >= -9223372036854775808.0 && tr < 9223372036854775808.0) ? (u64)(i64)tr : 0x8000000000000000ull;
+}
+template <typename F> __device__ __forceinline__ F seq_from_bits(u64 bits, int dst_kind) {
+  switch (dst_kind) {
+    case 0: return (F)(int)(u32)bits;
+    case 1: return (F)(u32)bits;
+    case 2: return (F)(i64)bits;
+    default: return (F)bits;
+  }
+}
+__device__ __forceinline__ void seq_store(const SeqSumParams& P, u64 seg, u64 bits, bool any) {
+  if (P.dst_kind == 2 || P.dst_kind == 3) reinterpret_cast<u64*>(P.dst)[seg] = any ? bits : 0ull;
+  else reinterpret_cast<u32*>(P.dst)[seg] = any ? (u32)bits : 0u;
+  if (P.dst_nulls) P.dst_nulls[seg] = any ? (u8)0 : (u8)1;
+}
+template <typename F>
+__device__ __forceinline__ void seq_step(const SeqSumParams& P, F v, u64& bits, bool& any) {
+  if (!any) { bits = seq_to_bits<F>(v); any = true; }
+  else bits = seq_to_bits<F>(seq_from_bits<F>(bits, P.dst_kind) + v);
+  if (P.dst_kind == 0 || P.dst_kind == 1) bits = (u64)(u32)bits;      // (the result lives in its own width between the rows)
+}
+template <typename F>
+__global__ __launch_bounds__(256) void ssgpu_seq_sum_segments_kernel(const SeqSumParams P) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.n) return;
+  const u32 seg = P.seg_id[i];
+  if (i != 0 && P.seg_id[i - 1] == seg) return;        // not a segment's first row
+  u64 bits = 0; bool any = false;
+  for (u64 r = i; r < P.n && P.seg_id[r] == seg; ++r) {
+    if (P.src_nulls && P.src_nulls[r]) continue;
+    seq_step<F>(P, reinterpret_cast<const F*>(P.src)[r], bits, any);
+  }
+  seq_store(P, seg, bits, any);
+}
+// one segment (ScalarAggregate): ONE wavefront loads 64 rows at a time, coalesced, and lane 0 folds them in row order
+template <typename F>
+__global__ __launch_bounds__(64) void ssgpu_seq_sum_all_kernel(const SeqSumParams P) {
+  const int lane = threadIdx.x;
+  u64 bits = 0; bool any = false;
+  for (u64 base = 0; base < P.n; base += 64) {
+    const u64 r = base + (u64)lane;
+    F v = F(0); bool ok = false;
+    if (r < P.n) { ok = !(P.src_nulls && P.src_nulls[r]); if (ok) v = reinterpret_cast<const F*>(P.src)[r]; }
+    const u64 okmask = __ballot(ok);
+    if (okmask == 0ull) continue;
+    for (int l = 0; l < 64; ++l) {
+      const F x = __shfl(v, l);
+      if ((okmask >> l) & 1ull) seq_step<F>(P, x, bits, any);
+    }
+  }
+  if (lane == 0) seq_store(P, 0, bits, any);
+}
+hipError_t ssgpu_launch_seq_sum(const void* src, const uint8_t* src_nulls, int src_kind, const uint32_t* seg_id, uint64_t n,
+                                void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s) {
+  SeqSumParams P; P.src = src; P.src_nulls = src_nulls; P.seg_id = seg_id; P.dst = dst; P.dst_nulls = dst_nulls; P.n = n; P.src_kind = src_kind; P.dst_kind = dst_kind;
+  if (seg_id) {
+    if (!n) return hipSuccess;
+    if (src_kind == 4) hipLaunchKernelGGL(ssgpu_seq_sum_segments_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(ssgpu_seq_sum_segments_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);
+  } else {
+    if (src_kind == 4) hipLaunchKernelGGL(ssgpu_seq_sum_all_kernel<float>, dim3(1), dim3(64), 0, s, P);
+    else hipLaunchKernelGGL(ssgpu_seq_sum_all_kernel<double>, dim3(1), dim3(64), 0, s, P);
+  }
+  return hipGetLastError();
+}
+
 // dense extraction of per-segment aggregates (same record layout as the group table)
 struct DenseAggOut { void* data; u8* is_null; int s; int out_kind; int has_cnt; int pad; };
 struct DenseExtractParams { const u64* acc; const u32* cnt; u32 n_gaggs; u32 n_out; u64 n_rows; DenseAggOut out[VM_MAX_AGG_SLOTS]; };

@@ -38,6 +38,9 @@ def _shard_spec(spec, input_schema):
         if aggregation != ss.SUM or distinct or input_schema is None:
             continue
         pos = input_schema.LookupAttributePosition(input_name)
+        if pos >= 0 and input_schema.attribute(pos).type() in (ss.FLOAT, ss.DOUBLE) and out_type in (ss.INT32, ss.UINT32, ss.INT64, ss.UINT64):
+            # the reference adds and truncates row after row (aggregation_operators.h:173-185): a shard's result is not a partial sum
+            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output cannot be merged across shards")
         if pos >= 0 and input_schema.attribute(pos).type() == ss.DOUBLE and out_type in (-1, ss.DOUBLE):
             shard.elements.append((ss.SUM_RESIDUAL, 0, -1, input_name, output_name + RESIDUAL))
             with_residual.append(output_name)

@@ -200,3 +200,17 @@ def test_shard_and_merge_specs_carry_double_sum_residuals():
             raise AssertionError("bound")
         except ss.SupersonicException as e:
             assert e.return_code == ss.ERROR_INVALID_ARGUMENT_TYPE
+
+
+def test_sum_of_floating_values_into_an_integer_is_not_merged_across_shards():
+    # aggregation_operators.h:173-185: the reference adds and truncates row after row, so a shard's result is not a partial sum of
+    # the job's -- refused when the job is set up (on one GPU the rows are folded in order: test_parity_gpu.py)
+    import pytest
+    import supersonic_amd as ss
+    from supersonic_amd.distributed import _shard_spec
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("d", ss.DOUBLE, ss.NULLABLE), ss.Attribute("f", ss.FLOAT)])
+    for col, t in (("d", ss.INT64), ("f", ss.INT32), ("d", ss.UINT64)):
+        with pytest.raises(ss.SupersonicException) as e:
+            _shard_spec(ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, col, "s", t), schema)
+        assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+    _shard_spec(ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.MAX, "d", "m", ss.INT64), schema)   # (MIN / MAX truncate monotonically: merged)

@@ -1327,7 +1327,7 @@ def test_float_min_max_keep_a_leading_nan_like_the_reference(n, partition):
 @pytest.mark.parametrize("n", [1, 65, 1025, 100003])
 def test_aggregates_into_other_result_types(gpu_ctx, n):
     # AddAggregationWithDefinedOutputType across type families (column_aggregator.cc:484-532): floating inputs into integer
-    # results store the truncated value (MIN / MAX / FIRST / LAST; SUM is order-dependent there and not on device), integers
+    # results store the truncated value (MIN / MAX / FIRST / LAST; SUM is order-dependent there: next test), integers
     # into other integer types compare in their own type (aggregation_operators.h:187-228), FIRST / LAST cast the picked value
     rng = np.random.default_rng(n)
     schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("x", ss.DOUBLE, ss.NULLABLE), ss.Attribute("f", ss.FLOAT),
@@ -1347,6 +1347,51 @@ def test_aggregates_into_other_result_types(gpu_ctx, n):
         fl.AddAggregationWithDefinedOutputType(agg, col, out, t)
     run_both(ss.ScalarAggregate(fl, ss.ScanView(view)), gpu_ctx)
     run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), fl, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 65, 1025, 30011])
+def test_sum_of_floating_values_into_integer_results(gpu_ctx, n):
+    # AggregationOperator<SUM> is `*result += val` (aggregation_operators.h:173-185): with an integer result and a floating
+    # value C++ adds in the floating type and truncates back after EVERY row -- 0.6 + 0.6 + 0.6 is 0, not 1 -- so the result
+    # depends on the row order and the device folds the rows one after the other in input order (the sorted shape for a
+    # GroupAggregate, the clusters themselves, all rows for a ScalarAggregate).  Mixed signs, fractions, NULLs, FLOAT stays float.
+    rng = np.random.default_rng(100 + n)
+    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("x", ss.DOUBLE, ss.NULLABLE), ss.Attribute("f", ss.FLOAT),
+                             ss.Attribute("p", ss.DOUBLE), ss.Attribute("i", ss.INT64), ss.Attribute("run", ss.INT32)])
+    view = ss.View(schema, [rng.integers(0, 37, n).astype(np.int32), ss.Column(rng.normal(size=n) * 10.0, rng.random(n) < 0.2),
+                            (rng.normal(size=n) * 100.0).astype(np.float32), rng.random(n) * 3.0, rng.integers(-50, 50, n),
+                            (np.arange(n) // 7 % 5).astype(np.int32)])
+    spec = ss.AggregationSpecification()
+    for col, out, t in (("x", "sx64", ss.INT64), ("x", "sx32", ss.INT32), ("f", "sf64", ss.INT64), ("f", "sf32", ss.INT32), ("p", "spu64", ss.UINT64), ("p", "spu32", ss.UINT32)):
+        spec.AddAggregationWithDefinedOutputType(ss.SUM, col, out, t)
+    spec.AddAggregation(ss.SUM, "i", "si").AddAggregation(ss.COUNT, "x", "cx").AddAggregation(ss.MAX, "p", "mp").AddAggregation(ss.FIRST, "x", "fx")
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("run"), spec, ss.ScanView(view)), gpu_ctx)
+    # below a Filter and a Compute: the folded column is a computed one, and the rows that pass keep their order
+    e = ss.CompoundExpression().Add(NA("g")).AddAs("x", ss.Multiply(NA("x"), ss.ConstDouble(1.5))).Add(NA("f")).Add(NA("p")).Add(NA("i")).Add(NA("run"))
+    child = ss.Compute(e, ss.Filter(ss.Less(NA("i"), ss.ConstInt64(25)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    run_both(ss.ScalarAggregate(spec, child), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "run"]), spec, None, child), gpu_ctx, ignore_order=True)
+    # what stays refused: next to DISTINCT aggregates, under a key limit (their shapes re-order or re-combine the rows)
+    for bad in (ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64)
+                                  .AddDistinctAggregation(ss.COUNT, "i", "c"), None, ss.ScanView(view)),
+                ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64),
+                                  ss.GroupAggregateOptions().set_max_unique_keys_in_result_(3), ss.ScanView(view))):
+        with pytest.raises(ss.SupersonicException) as err:
+            ss.Plan(bad, gpu_ctx)
+        assert err.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+
+
+def test_sum_of_floating_values_into_integer_results_reference_arithmetic(gpu_ctx):
+    # the C++ rule by hand: 0.6 three times is 0 (each step truncates); 2.5, -0.75, 0.5 -> 2, (2 - 0.75 = 1.25) 1, (1.5) 1;
+    # FLOAT adds in float: 16777216 + 1.0f stays 16777216
+    schema = ss.TupleSchema([ss.Attribute("a", ss.DOUBLE), ss.Attribute("b", ss.DOUBLE), ss.Attribute("c", ss.FLOAT)])
+    view = ss.View(schema, [np.array([0.6, 0.6, 0.6]), np.array([2.5, -0.75, 0.5]), np.array([16777216.0, 1.0, 1.0], np.float32)])
+    spec = (ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "a", "sa", ss.INT64)
+            .AddAggregationWithDefinedOutputType(ss.SUM, "b", "sb", ss.INT32).AddAggregationWithDefinedOutputType(ss.SUM, "c", "sc", ss.INT64))
+    got = run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    assert [int(got.column(i).data[0]) for i in range(3)] == [0, 1, 16777216]
 
 
 # ---- runtime specialisation (context option "specialize", csrc/rtc.cpp): the same handlers compiled per plan with the
