@@ -236,6 +236,30 @@ class Gen(object):
                                      ss.GroupAggregateOptions().set_max_unique_keys_in_result_(int(self.rng.integers(0, 9))), child), True
         return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child), False
 
+    def sequential_sum_plan(self, view):
+        """SUM of FLOAT / DOUBLE inputs into integer results (folded row after row in input order) next to ordinary aggregates,
+        as ScalarAggregate / GroupAggregate / AggregateClusters.  Returns (operation, result order is defined)."""
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("k1")).Add(NA("a")).Add(NA("b")).Add(NA("d0")).Add(NA("d1")).Add(NA("f")).Add(NA("t"))
+        inputs = ["d0", "d1", "f"]
+        if self.rng.random() < 0.5:
+            e.AddAs("y", ss.Plus(self.floating(int(self.rng.integers(0, 3))), ss.ConstDouble(0.0)))
+            inputs.append("y")
+        spec = ss.AggregationSpecification()
+        for i in range(int(self.rng.integers(1, 4))):
+            spec.AddAggregationWithDefinedOutputType(ss.SUM, self.pick(inputs), "q%d" % i, self.pick([ss.INT64, ss.INT32, ss.INT64]))
+        for i in range(int(self.rng.integers(0, 4))):
+            spec.AddAggregation(self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST]), self.pick(["a", "b", "k1", "t"]), "r%d" % i)
+        child = ss.ScanView(view)
+        if self.rng.random() < 0.5:
+            child = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), child)
+        child = ss.Compute(e, child)
+        shape = self.pick(["scalar", "group", "group", "clusters"])
+        if shape == "scalar":
+            return ss.ScalarAggregate(spec, child), True
+        if shape == "clusters":
+            return ss.AggregateClusters(ss.ProjectNamedAttributes(self.pick([["s"], ["k2"], ["k2", "s"], ["t"]])), spec, child), True
+        return ss.GroupAggregate(ss.ProjectNamedAttributes(self.pick([["k2"], ["k2", "s"], ["k1"], ["k1", "k2"], ["a", "s"]])), spec, None, child), False
+
     def sort_plan(self, view):
         e = ss.CompoundExpression().Add(NA("b")).Add(NA("k1")).Add(NA("d0")).Add(NA("t")).Add(NA("u")).Add(NA("name")).Add(NA("day"))
         for i in range(int(self.rng.integers(0, 3))):

@@ -71,3 +71,18 @@ def test_random_ordered_aggregates(gpu_ctx, seed, n):
             ss.Plan(op, gpu_ctx)
         return
     run_both(op, gpu_ctx, ignore_order=not ordered)
+
+
+@pytest.mark.parametrize("n", [1537, 20011])
+@pytest.mark.parametrize("seed", range(5000, 5150))
+def test_random_sequential_sums(gpu_ctx, seed, n):
+    # SUM of floating inputs into integer results: the reference's row-after-row arithmetic, bit for bit
+    view = make_view(n, seed)
+    op, ordered = Gen(seed).sequential_sum_plan(view)
+    try:
+        oracle.run(op)
+    except oracle.OracleError:
+        with pytest.raises(ss.SupersonicException):
+            ss.Plan(op, gpu_ctx)
+        return
+    run_both(op, gpu_ctx, ignore_order=not ordered)
