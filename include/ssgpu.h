@@ -446,6 +446,12 @@ int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
  * version): a second process loads them in milliseconds instead of compiling for seconds (ssgpu_memory_stats:
  * rtc_disk_hits vs rtc_compilations).  Directory: $SSGPU_RTC_CACHE_DIR (empty string = no disk cache), else
  * $XDG_CACHE_HOME/ssgpu/rtc, else $HOME/.cache/ssgpu/rtc; files are written atomically and checksummed.
+ * THE DEFAULT POLICY (context option "specialize" = 2; process-wide default: environment SSGPU_SPECIALIZE): a plan runs the
+ * compiled kernel of a stage where one EXISTS -- loaded in this process, or in the on-disk cache from any earlier process --
+ * and the interpreting kernel where none does; it never compiles.  So a service whose plans were specialised once (option 1,
+ * ssgpu_plan_specialize, or a warm-up run) gets the compiled kernels by default from then on, and a plan that meets an empty
+ * cache still blocks on no compiler.  ssgpu_plan_specialize on such a plan compiles what it did not find.  "specialize" = 0:
+ * the interpreting kernels only (unless the plan asks).
  * A stage whose specialisation is not possible (no libhiprtc on the host, a compilation failure) keeps the
  * interpreting kernel -- still the HIP path -- and ssgpu_plan_specialize_reason says why ("" if nothing was refused).
  * ssgpu_plan_specialized: how many specialised kernels the plan currently holds. */

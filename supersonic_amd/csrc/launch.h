@@ -175,6 +175,7 @@ void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int ro
 hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterParams& P, int grid, hipStream_t stream);
 void* ssgpu_rtc_function(void* handle);
 void ssgpu_rtc_release(void* handle);
+void ssgpu_rtc_cached_only(bool on);   // the calling thread's requests from now on: find a kernel (memory, disk) or fail -- never compile
 void ssgpu_rtc_trim(int keep);   // unloads kernels without a user down to `keep` of them
 void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations, long long* disk_hits);
 #endif

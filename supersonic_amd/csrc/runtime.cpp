@@ -64,10 +64,13 @@ struct ssgpu_ctx {
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
   int64_t part_rec_align = 0;    // partition records padded to a multiple of this many bytes (plans created after the option is set)
-  int64_t specialize = 0;        // plans created on this context run kernels specialised for them by runtime compilation (rtc.cpp):
+  int64_t specialize = 2;        // plans created on this context run kernels specialised for them by runtime compilation (rtc.cpp):
                                  // 1 = yes, compiled when a kernel shape is first launched (the first run; a later run only if run
-                                 // feedback moves a GroupAggregate to another execution shape); 0 (and the legacy -1) = only plans
-                                 // that ask for it with ssgpu_plan_specialize.  Nothing is ever compiled at a hidden run count.
+                                 // feedback moves a GroupAggregate to another execution shape); 2 (the default) = where such a kernel
+                                 // EXISTS already -- loaded in this process or stored in the on-disk cache by any earlier one -- and
+                                 // never compiled: a plan costs no compiler time unless it asks (1, or ssgpu_plan_specialize), and a
+                                 // service that asked once runs the compiled kernels from then on; 0 (and the legacy -1) = only
+                                 // plans that ask for it with ssgpu_plan_specialize.  Nothing is ever compiled at a hidden run count.
   bool filter_single_pass = false;   // materialising Filter: one pass with decoupled look-back instead of count pass + scan + store pass (plans created after the option is set)
 };
 
@@ -231,6 +234,7 @@ struct ssgpu_plan {
   std::atomic<int> interrupted{0};
   int64_t n_runs = 0;           // runs started
   bool specialize = false;      // this plan's kernels are specialised by runtime compilation (ctx option at creation, or ssgpu_plan_specialize)
+  bool cached_only = false;     // ... but only where the kernel exists already (option specialize = 2): this plan never compiles
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
   // the (dom0, dom1) pairs of the most recent profiled runs: ev_dom0 / ev_dom1 alias the current pair, so
   // a caller can time many asynchronous runs and read every kernel duration afterwards, without a sync in between
@@ -576,6 +580,7 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   for (auto& a : p->result_schema) p->attr_names.push_back(a.name);
   p->result.plan = p;
   p->specialize = c->specialize > 0;
+  p->cached_only = c->specialize == 2;
   if (c->device >= 0) {
     (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end); g_events.fetch_add(2);
   }
@@ -2261,6 +2266,7 @@ int fix_nan_minmax(ssgpu_plan* p) {
 int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial) {
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  ssgpu_rtc_cached_only(p->cached_only);   // (this thread's kernel requests during the run)
   p->nan_seen = false;
   if (p->deferred) {   // the previous run's feedback first: an overflow there puts the stage back into its adapting, synchronous form
     p->deferred = false;   // (that run's result is being replaced by this run: nothing to repeat)
@@ -2398,6 +2404,14 @@ int ssgpu_plan_specialize(ssgpu_plan* p) {
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
   HIP_TRY(c, hipSetDevice(c->device));
   p->specialize = true;
+  if (p->cached_only) {          // kernels this plan looked for and did not find are compiled from now on
+    p->cached_only = false;
+    for (auto& ex : p->exec) {
+      for (StageExec::RtcSlot* sl : {&ex.rtc_main, &ex.rtc_pscatter, &ex.rtc_plain, &ex.rtc_part, &ex.rtc_resident, &ex.rtc_hot}) if (!sl->h) sl->tried = false;
+      ex.rtc_why.clear();
+    }
+  }
+  ssgpu_rtc_cached_only(false);
   for (size_t si = 0; si < p->stages.size(); ++si) {
     const int rc = prepare_stage(p, si);
     if (rc != SSGPU_OK) return rc;

@@ -9,6 +9,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library's default policy is "run a stage's compiled kernel where one exists (this process, the on-disk cache), never
+# compile" (ssgpu.h: specialize = 2).  The suite pins the interpreting kernels for every context that does not ask -- which
+# kernel a default plan runs must not depend on what an earlier test or an earlier suite run left in the cache; the compiled
+# kernels are exercised by the tests that set the option (1 or 2) themselves.
+os.environ.setdefault("SSGPU_SPECIALIZE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     # build the in-tree artefacts if they are missing (no-op when already built)

@@ -184,6 +184,38 @@ def test_default_policy_never_compiles_and_modules_are_unloaded(gpu_ctx):
     del plan
 
 
+def test_default_policy_uses_compiled_kernels_where_they_exist_and_never_compiles():
+    """Context option specialize = 2 (the library's default; the suite pins 0 through SSGPU_SPECIALIZE): a plan finds a kernel
+    another plan compiled, never compiles itself, says why a stage stayed with the interpreting kernel, and compiles once asked."""
+    import time
+    from helpers import to_cols, assert_cols_equal
+    view = make_view(30011)
+    fresh = int(time.time() * 1000) % 1000003 + 1000        # a constant no earlier run has compiled: the program is new to every cache
+    op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.MIN, "c", "mc").AddAggregation(ss.COUNT, "", "n"),
+                            ss.Filter(ss.Less(ss.NamedAttribute("a"), ss.ConstInt64(fresh)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    found_only = ss.Context(0)
+    found_only.set_option("specialize", 2)
+    compiling = ss.Context(0)
+    compiling.set_option("specialize", 1)
+    before = ss.memory_stats()["rtc_compilations"]
+    a = ss.Plan(op, found_only)
+    a.run()
+    want = to_cols(a.fetch())
+    assert a.specialized() == 0 and "not in the kernel cache" in a.specialize_reason() and ss.memory_stats()["rtc_compilations"] == before
+    b = ss.Plan(op, compiling)
+    b.run()
+    assert b.specialized() == 1 and ss.memory_stats()["rtc_compilations"] == before + 1
+    c = ss.Plan(op, found_only)            # the same program: found in this process
+    c.run()
+    assert c.specialized() == 1 and ss.memory_stats()["rtc_compilations"] == before + 1
+    assert_cols_equal(to_cols(c.fetch()), want)
+    assert_cols_equal(to_cols(b.fetch()), want)
+    a.specialize()                          # the plan that had missed it asks: found now, still no second compilation
+    a.run()
+    assert a.specialized() == 1 and ss.memory_stats()["rtc_compilations"] == before + 1
+    assert_cols_equal(to_cols(a.fetch()), want)
+
+
 def test_recent_kernel_times_ring(gpu_ctx):
     # ssgpu_plan_recent_kernel_ms: one (positive) duration per profiled run, oldest first, at most 256 kept
     view = make_view(200003)
@@ -213,7 +245,13 @@ NA = ss.NamedAttribute
 op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "sum_s").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.COUNT, "", "n"),
                         ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(),
                                   ss.Compute(ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))).Add(NA("d")), ss.ScanView(view))))
-plan = ss.Plan(op, ctx).specialize()
+policy = sys.argv[1] if len(sys.argv) > 1 else "ask"
+if policy == "ask":
+    plan = ss.Plan(op, ctx).specialize()
+else:                                   # the context's policy decides ("default": the library's own default, no option set)
+    if policy != "default":
+        ctx.set_option("specialize", int(policy))
+    plan = ss.Plan(op, ctx)
 plan.run()
 got = plan.fetch()
 st = ss.memory_stats()
@@ -230,20 +268,29 @@ def test_specialised_kernels_survive_the_process(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-    def child(cache_dir):
+    def child(cache_dir, policy="ask"):
         env = dict(os.environ, SSGPU_RTC_CACHE_DIR=cache_dir, PYTHONPATH=root)
-        out = subprocess.run([sys.executable, "-c", _CACHE_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+        env.pop("SSGPU_SPECIALIZE", None)          # (conftest pins 0 for the suite: the children see the library's own default)
+        out = subprocess.run([sys.executable, "-c", _CACHE_CHILD, policy], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
         assert out.returncode == 0, out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
     cache = str(tmp_path / "rtc")
+    # the default policy (specialize = 2): compiled kernels where they exist, never a compilation
+    cold = child(cache, "default")
+    assert cold["specialized"] == 0 and cold["compilations"] == 0 and cold["disk_hits"] == 0, cold
     first = child(cache)
     assert first["specialized"] == 1 and first["compilations"] >= 1 and first["disk_hits"] == 0, first
     files = [f for f in os.listdir(cache) if f.endswith(".co")]
     assert len(files) == first["compilations"], (files, first)
     second = child(cache)
     assert second["specialized"] == 1 and second["compilations"] == 0 and second["disk_hits"] >= 1, second      # loaded, not compiled
-    assert second["row"] == first["row"]
+    assert second["row"] == first["row"] == cold["row"]
+    for policy in ("default", "2"):             # ... and a plan that never asked finds it, too
+        warm = child(cache, policy)
+        assert warm["specialized"] == 1 and warm["compilations"] == 0 and warm["disk_hits"] >= 1 and warm["row"] == first["row"], (policy, warm)
+    never = child(cache, "0")
+    assert never["specialized"] == 0 and never["compilations"] == 0 and never["disk_hits"] == 0 and never["row"] == first["row"], never
     path = os.path.join(cache, files[0])
     with open(path, "r+b") as f:                                    # a torn file: checksum fails -> compiled again, file replaced
         f.truncate(os.path.getsize(path) // 2)
