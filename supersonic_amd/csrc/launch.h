@@ -47,6 +47,10 @@ struct GroupExtractParams {
 // records (rec_words x 8 bytes each, word 0 = packed key) sit in n_segs segments of seg_cap records:
 // segment (part, g) at record (part * n_segs + g) * seg_cap holds counts[part * n_segs + g] records.
 #define SSGPU_PART_THREADS 1024
+// widest partition record, in 8-byte words: 8- and 16-word kernels serve the scans; the 20-word build exists for the merge of
+// sharded partial tables (key + 16 value columns = 17 words), whose rows all belong to different groups -- through the global
+// table that is one atomic per value, in partitions' LDS tables a tenth of it.  Records beyond 16 words take the plain scatter only.
+#define SSGPU_PART_MAX_WORDS 20
 struct PartAggParams {
   const unsigned long long* recs;
   const unsigned int* counts;

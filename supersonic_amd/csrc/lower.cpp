@@ -1544,7 +1544,7 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     for (auto& f : fields) if (f.width == w) { f.off = (int)off; off += w; }
   st->part_rec_bytes = (off + 7u) & ~7u;
   if (g_part_rec_align > 8) st->part_rec_bytes = (st->part_rec_bytes + (uint32_t)g_part_rec_align - 1u) / (uint32_t)g_part_rec_align * (uint32_t)g_part_rec_align;
-  if (st->part_rec_bytes > 128u) { st->part_scatter = Program(); st->part_aggs.clear(); return Status::OK(); }   // wider records: direct path only
+  if (st->part_rec_bytes > SSGPU_PART_MAX_WORDS * 8u) { st->part_scatter = Program(); st->part_aggs.clear(); return Status::OK(); }   // wider records: direct path only
   for (size_t j = 0; j < refs.size(); ++j) {
     if (refs[j].val_field >= 0) st->part_aggs[j].val_off = fields[refs[j].val_field].off;
     if (refs[j].null_field >= 0) st->part_aggs[j].null_off = fields[refs[j].null_field].off;
@@ -1604,6 +1604,8 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
     if (!pl.ok) { pl.keys.clear(); pl.fields.clear(); pl.preds.clear(); }
     st->plain = pl;
   }
+  // records beyond 16 words exist in the plain form only (the scatter as its own kernel; the VM's record tile would not fit the LDS)
+  if (st->part_rec_bytes > 128u && !st->plain.ok) { st->part_scatter = Program(); st->part_aggs.clear(); return Status::OK(); }
   allocate_registers(&st->part_scatter);
   return Status::OK();
 }

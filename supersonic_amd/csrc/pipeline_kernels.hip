@@ -1937,7 +1937,9 @@ hipError_t ssgpu_launch_fill_u32(unsigned int* p, unsigned int v, size_t n, hipS
 }
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream) {
   if (P.rec_words <= 8) hipLaunchKernelGGL(ssgpu_part_agg_kernel<8>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
-  else hipLaunchKernelGGL(ssgpu_part_agg_kernel<16>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
+  else if (P.rec_words <= 16) hipLaunchKernelGGL(ssgpu_part_agg_kernel<16>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
+  else if (P.rec_words <= SSGPU_PART_MAX_WORDS) hipLaunchKernelGGL(ssgpu_part_agg_kernel<SSGPU_PART_MAX_WORDS>, dim3(P.n_parts), dim3(SSGPU_PART_THREADS), lds_bytes, stream, P);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_group_resident(const PartAggParams& P, const PlainScatterParams& S, unsigned int lds_bytes, int grid, hipStream_t stream) {
@@ -1951,6 +1953,8 @@ hipError_t ssgpu_part_agg_set_max_lds(int bytes) {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_group_resident_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_group_resident_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel<SSGPU_PART_MAX_WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(ssgpu_part_agg_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

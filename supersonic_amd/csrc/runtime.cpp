@@ -29,6 +29,7 @@ using namespace ssgpu;
     }                                                                                \
   } while (0)
 
+static bool trace_on() { static const bool on = getenv("SSGPU_TRACE") != nullptr; return on; }   // development: shape decisions and fallbacks on stderr
 struct ssgpu_ctx {
   // plans and blocks hold a reference: the context outlives them whatever order a garbage-collected host
   // destroys the handles in (ssgpu_ctx_destroy only drops the owner's reference)
@@ -1329,7 +1330,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     uint32_t capacity = NP * C;
     if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
     // heavy hitters (found when a segment overflowed, below): their groups live in SSGPU_HOT_SLOTS dense slots behind the special one
-    const bool hot = !slab && ex.hot_n > 0 && st.plain.ok && c->part_plain != 0;
+    const bool hot = !slab && ex.hot_n > 0 && st.plain.ok && c->part_plain != 0 && st.part_rec_bytes <= 128u;
     const uint32_t extra = hot ? SSGPU_HOT_SLOTS : 0u;
     const size_t slots = (size_t)capacity + 1 + extra;
     VmParams Ps;
@@ -1340,7 +1341,13 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     // position, and the staging area where the tile's records are assembled (see VM_PART_RANK)
     Ps.part_lds_off = (Ps.lds_bytes + 15u) & ~15u;
     Ps.lds_bytes = Ps.part_lds_off + NP * 4u + (uint32_t)Ps.tile_rows * 4u + 16u + (uint32_t)Ps.tile_rows * st.part_rec_bytes;
-    if (!resident && Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
+    // plain stages: the scatter is a kernel of its own over (partition, XCD) segments (ssgpu_part_scatter_plain_kernel)
+    const uint32_t W0 = st.part_rec_bytes / 8u;
+    const bool plain = !slab && st.plain.ok && c->part_plain != 0 && !Ps.debug_pc && NP >= 2u && in.rows >= (1 << 16) &&
+                       ssgpu_part_scatter_plain_lds(NP, W0, 1) <= 156u * 1024u;
+    if (W0 > 16u && !plain) { if (trace_on()) fprintf(stderr, "[ssgpu trace] wide records (%u words) without the plain scatter: slab %d plain.ok %d NP %u rows %lld lds %u\n", W0, (int)slab, (int)st.plain.ok, NP, (long long)in.rows, ssgpu_part_scatter_plain_lds(NP, W0, 1)); *fallback = true; return SSGPU_OK; }     // (17 .. 20-word records: the plain scatter + ssgpu_part_agg_kernel<20> only)
+    if (!resident && !plain && Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
+    if (plain && Ps.lds_bytes > 160u * 1024u) Ps.lds_bytes = 160u * 1024u;   // (the VM form's LDS is not used: only its tile shape sizes the grid below)
     ProgramLayout Ls = ex.lay_pscatter; Ls.lds_bytes = Ps.lds_bytes;
     int grid;
     {
@@ -1349,10 +1356,6 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       grid = std::min(grid_for(c, Ls, Ps.n_tiles), 1024);   // phase 2 scans a partition's segment counts with one thread each
       c->wgs_per_cu = saved;
     }
-    // plain stages: the scatter is a kernel of its own over (partition, XCD) segments (ssgpu_part_scatter_plain_kernel)
-    const uint32_t W0 = st.part_rec_bytes / 8u;
-    const bool plain = !slab && st.plain.ok && c->part_plain != 0 && !Ps.debug_pc && NP >= 2u && in.rows >= (1 << 16) &&
-                       ssgpu_part_scatter_plain_lds(NP, W0, 1) <= 156u * 1024u;
     const int scatter_grid = grid;
     if (plain) grid = SSGPU_PSCAT_XCDS;   // from here on `grid` is the number of segments per partition
     ex.last_plain_scatter = plain;
@@ -1703,7 +1706,14 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t overflow = fb[0];
+    if (trace_on()) fprintf(stderr, "[ssgpu trace] group run: rows %lld lcap %u overflow %u misses %u occupancy %u grid %d tiles %lld tile_rows %d steady %d scout %d\n", (long long)in.rows, lcap, overflow, fb[1], fb[2], grid, (long long)P.n_tiles, (int)P.tile_rows, ex.steady, (int)scout);
     const int shape_before[5] = {ex.group_wgs, ex.group_local ? 1 : 0, ex.group_partitioned ? 1 : 0, (int)ex.part_slab, ex.group_sub};
+    if (!lcap && !overflow && !scout && c->group_partition && !st.part_scatter.empty() && !ex.part_failed && st.plain.ok && c->part_plain != 0 && in.rows >= (1 << 16)) {
+      // No table on chip at all (an entry of this stage's many aggregates is too wide for one): every row is an entry's worth of
+      // global atomics -- the merge of a sharded job's partial tables: 1e5 rows x 16 values, 0.10 ms.  Partitions' LDS tables take
+      // the same rows in a fraction of that; nothing is known about the group count, so they are sized for one group per row.
+      ex.group_partitioned = true; ex.part_groups_est = (double)in.rows; ex.part_slab = false;
+    }
     if (lcap && !overflow) {
       // feedback for the next run of this plan: the largest residency whose table still holds
       // every group of a workgroup at <= 75% load; a table most rows bypass is switched off
@@ -1714,6 +1724,17 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         ex.group_wgs = best;
         // (splitting the table into per-lane-group sub-tables was measured: 1.5 -> 2.1 ms on an
         //  8-group query; same-address LDS atomics are not the bottleneck, so group_sub stays 1)
+        // No row missed its table -- but a table that ends up holding (nearly) one group per row the workgroup saw has reduced
+        // nothing: every row goes on to the global table as an entry's worth of atomics (the merge of a sharded job's partial
+        // tables: 1e5 rows, every one its own group, 0.10 ms of atomics).  Partitions' LDS tables do that merge on chip.
+        const double rows_per_wg = (double)((P.n_tiles + grid - 1) / grid) * (double)P.tile_rows;
+        if ((double)fb[2] * 2.0 >= rows_per_wg && c->group_partition && !st.part_scatter.empty() && !ex.part_failed && st.plain.ok && c->part_plain != 0 &&
+            in.rows >= (1 << 16)) {
+          const double groups_est = std::min((double)in.rows, (double)fb[2] * (double)grid);
+          const uint32_t full = (159u * 1024u - (entry + 1025u * 4u + 128u)) / entry;
+          ex.group_partitioned = true; ex.part_groups_est = groups_est;
+          ex.part_slab = c->group_slab != 0 && groups_est * 1.08 <= (double)full;
+        }
       } else {
         // some rows missed the (full) table.  With G >> C uniformly hit groups a fraction C/G of
         // the rows finds its group in the table, so G ~= C * rows / (rows - bypassed): size the
@@ -1724,6 +1745,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         const double groups = std::max<double>((double)std::max(fb[2], lcap) * rows / hit, (double)fb[2]);
         int best = 0;
         for (int w = 4; w >= 1; --w) if ((double)local_capacity_for(w) * 0.9 >= groups) { best = w; break; }
+        if (trace_on()) fprintf(stderr, "[ssgpu trace] group feedback: rows %lld misses %u groups %u est %.0f best %d wgs %d part_scatter %d part_failed %d partitioned %d\n", (long long)in.rows, fb[1], fb[2], groups, best, ex.group_wgs, (int)!st.part_scatter.empty(), (int)ex.part_failed, (int)ex.group_partitioned);
         if (best > 0 && best != ex.group_wgs) ex.group_wgs = best;
         else if (best == 0 || (best == ex.group_wgs && (double)fb[1] * 4.0 >= rows)) {
           // (a plain stage's scatter is its own kernel, worth it from 64 K rows: the merge of a sharded job's partial tables --

@@ -47,6 +47,40 @@ def _shard_spec(spec, input_schema):
     return shard, with_residual
 
 
+def _never_null(shard_spec, input_schema):
+    """Result columns of a shard's table that are never NULL although their type says NULLABLE: SUM / MIN / MAX / FIRST / LAST
+    (and a sum's residual) of a NOT NULL input column -- a group of a partial table has at least one row.  The merge plan reads
+    them as NOT NULL columns: its aggregates then keep no contribution counts (half the atomics of a merge whose rows all
+    belong to different groups); the merged results are NULLABLE again by the aggregates' own typing."""
+    names = set()
+    if input_schema is None:
+        return names
+    for (aggregation, distinct, _out_type, input_name, output_name) in shard_spec.elements:
+        if distinct or aggregation in (ss.COUNT, ss.CONCAT):
+            continue
+        pos = input_schema.LookupAttributePosition(input_name)
+        if pos >= 0 and not input_schema.attribute(pos).is_nullable():
+            names.add(output_name)
+    return names
+
+
+def _declare_not_null(view, names):
+    """`view` (a DeviceView) with the columns `names` declared NOT NULL (their NULL masks are all zero: _never_null)."""
+    if not names:
+        return view
+    schema = view.schema()
+    attrs, ptrs = [], []
+    for i in range(schema.attribute_count()):
+        a = schema.attribute(i)
+        if a.name() in names and a.is_nullable():
+            attrs.append(ss.Attribute(a.name(), a.type(), ss.NOT_NULLABLE))
+            ptrs.append((view._ptrs[i][0], 0))
+        else:
+            attrs.append(a)
+            ptrs.append(view._ptrs[i])
+    return ss.DeviceView(ss.TupleSchema(attrs), ptrs, view.row_count())
+
+
 def _merge_spec(spec, with_residual=()):
     merged = ss.AggregationSpecification()
     counts = []
@@ -499,8 +533,10 @@ class DeviceShardedGroupAggregate(object):
         self.world = dist.get_world_size(group)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.group_by = list(group_by)
-        shard_spec, with_residual = _shard_spec(spec, _schema_of(local_child))
+        child_schema = _schema_of(local_child)
+        shard_spec, with_residual = _shard_spec(spec, child_schema)
         self.merged_spec, self.counts = _merge_spec(spec, with_residual)
+        self.never_null = _never_null(shard_spec, child_schema)
         op = ss.GroupAggregate(ss.ProjectNamedAttributes(self.group_by), shard_spec, None, local_child)
         # STRING keys / MIN / MAX results travel as the INT32 codes of ONE dictionary that every rank builds identically
         # (decided by the result schema, which is the same on all ranks: every rank issues the same collectives)
@@ -561,7 +597,7 @@ class DeviceShardedGroupAggregate(object):
             self.dist.all_gather_into_tensor(self.images, self.image, group=self.group)
         self.collectives += 1
         self._lib_stream.wait_stream(cur)
-        everyone = self.first.unpack_images(self.images.data_ptr(), self.world, self.capacity, self.unpacked.data_ptr())
+        everyone = _declare_not_null(self.first.unpack_images(self.images.data_ptr(), self.world, self.capacity, self.unpacked.data_ptr()), self.never_null)
         if self.merge is None:
             self.merge = ss.Plan(_merge_plan(self.group_by, self.merged_spec, self.counts, self.first.result_schema, everyone,
                                              valid="__valid"), self.ctx, self.strings)

@@ -1653,6 +1653,7 @@ def test_key_range_exchange_routes_every_group_to_one_owner(gpu_ctx, n, world):
         plan.run()
         image_bytes, _ub, _offs = plan.image_layout(cap, 1)
         out = torch.zeros(world * image_bytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()            # (torch fills on ITS stream; the library's kernels run on the context's)
         plan.route_images(len(keys), world, cap, out.data_ptr())
         gpu_ctx.synchronize()
         sources.append((plan, out))
@@ -1662,6 +1663,7 @@ def test_key_range_exchange_routes_every_group_to_one_owner(gpu_ctx, n, world):
     for d in range(world):
         arrived = torch.cat([out[d * image_bytes:(d + 1) * image_bytes] for (_p, out) in sources])      # what the all-to-all delivers to rank d
         unpacked = torch.zeros(unpacked_bytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()            # (the concatenation above has to be complete before another stream reads it)
         everyone = plan0.unpack_images(arrived.data_ptr(), world, cap, unpacked.data_ptr())
         gpu_ctx.synchronize()
         trailer = unpacked[unpacked_bytes - 32:].view(torch.int64).tolist()
