@@ -160,6 +160,10 @@ class ShardedGroupAggregate {
       merged->AddAggregation(m, e.output, e.output);
       if (e.aggregation == COUNT) counts_.push_back(e.output);
       const int pos = child_schema.LookupAttributePosition(e.input);
+      // SUM / MIN / MAX / FIRST / LAST of a NOT NULL input are never NULL in a partial table (a group has a row): the merge reads
+      // them as NOT NULL columns and keeps no contribution counts for them (cf. distributed.py: _never_null)
+      const bool never_null = e.aggregation != COUNT && pos >= 0 && !child_schema.attribute(pos).is_nullable();
+      if (never_null) never_null_.push_back(e.output);
       if (e.aggregation == SUM && pos >= 0 && (child_schema.attribute(pos).type() == DOUBLE || child_schema.attribute(pos).type() == FLOAT) &&
           (e.output_type == INT32 || e.output_type == UINT32 || e.output_type == INT64 || e.output_type == UINT64)) {
         // (the reference adds and truncates row after row, aggregation_operators.h:173-185: a shard's result is not a partial sum)
@@ -169,6 +173,7 @@ class ShardedGroupAggregate {
         shard->AddAggregation(static_cast<Aggregation>(SSGPU_SUM_RESIDUAL), e.input, e.output + kResidual);
         merged->AddAggregation(SUM, e.output + kResidual, e.output + kResidual);
         residuals_.push_back(e.output);
+        if (never_null) never_null_.push_back(e.output + kResidual);
       }
     }
     merged_spec_ = std::move(merged);
@@ -247,7 +252,7 @@ class ShardedGroupAggregate {
         gathered_.schema = TupleSchema();
         for (int i = 0; i < n_attrs; ++i) {
           ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
-          gathered_.schema.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));
+          gathered_.schema.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), Has(never_null_, a.name) ? NOT_NULLABLE : static_cast<Nullability>(a.nullable)));
         }
         gathered_.schema.add_attribute(Attribute("__valid", BOOL, NOT_NULLABLE));
         gathered_.columns.assign(static_cast<size_t>(n_attrs) + 1, ssgpu_column());
@@ -321,7 +326,7 @@ class ShardedGroupAggregate {
   }
   ncclComm_t comm_;
   int world_;
-  std::vector<std::string> group_by_, counts_, residuals_;
+  std::vector<std::string> group_by_, counts_, residuals_, never_null_;
   rowcount_t capacity_, largest_table_ = 0;
   Exchange exchange_ = ALL_GATHER;
   std::string error_;
