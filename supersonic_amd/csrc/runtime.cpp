@@ -1711,8 +1711,9 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     if (!lcap && !overflow && !scout && c->group_partition && !st.part_scatter.empty() && !ex.part_failed && st.plain.ok && c->part_plain != 0 && in.rows >= (1 << 16)) {
       // No table on chip at all (an entry of this stage's many aggregates is too wide for one): every row is an entry's worth of
       // global atomics -- the merge of a sharded job's partial tables: 1e5 rows x 16 values, 0.10 ms.  Partitions' LDS tables take
-      // the same rows in a fraction of that; nothing is known about the group count, so they are sized for one group per row.
-      ex.group_partitioned = true; ex.part_groups_est = (double)in.rows; ex.part_slab = false;
+      // the same rows in a fraction of that; nothing is known about the group count, so they are sized for one group per row
+      // -- an upper bound, which may load the tables to twice the usual share (0.8): half the bound goes in as the estimate.
+      ex.group_partitioned = true; ex.part_groups_est = (double)in.rows * 0.5; ex.part_slab = false;
     }
     if (lcap && !overflow) {
       // feedback for the next run of this plan: the largest residency whose table still holds
