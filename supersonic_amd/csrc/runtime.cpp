@@ -1790,8 +1790,10 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
         // most prefix rows brought a new group: the groups grow with the rows -- scale to the whole input (an upper bound)
         est = (double)seen * 8.0 >= (double)in.rows ? (double)seen * ((double)ex.scout_full_rows / (double)std::max<int64_t>(in.rows, 1)) : (double)seen;
       }
-      if (lcap && c->group_partition && !ex.part_failed) {
-        if (est > (double)local_capacity_for(1) * 0.75) {
+      // (a stage without a table on chip -- entries too wide -- has only the partitions to go to, and only in the plain form)
+      const bool only_partitions = !lcap && st.plain.ok && c->part_plain != 0 && !st.part_scatter.empty();
+      if ((lcap || only_partitions) && c->group_partition && !ex.part_failed) {
+        if (est > (lcap ? (double)local_capacity_for(1) * 0.75 : 0.0)) {
           uint32_t full = 0;
           { const uint32_t stw = ng | 1u, pentry = 8u + stw * 8u + (any_cnt ? stw * 4u : 0u); full = (159u * 1024u - (pentry + 1025u * 4u + 128u)) / pentry; }
           ex.group_partitioned = true; ex.part_groups_est = est;

@@ -1425,6 +1425,36 @@ def test_specialized_materialising_and_group_stages(specialized_ctx, n):
     _run_specialized(group_query(make_view(n, nullable=True), True), specialized_ctx, ignore_order=True)
 
 
+@pytest.mark.parametrize("specialize", [0, 1])
+@pytest.mark.parametrize("groups", [100000, 900, 7])
+def test_group_aggregate_with_records_of_more_than_16_words(groups, specialize):
+    # 18 aggregates of NOT NULL columns = a 19-word partition record (round 4: ssgpu_part_agg_kernel<20>, plain scatter only) and an
+    # LDS entry too wide for a table inside the pipeline kernel: the direct shape would send every row to the global table.  The
+    # first run has nothing to go by (no table on chip, no feedback) and sizes partitions for its row count; every group count
+    # has to come out right, whichever shape the later runs settle on.
+    n = 300007
+    ctx = ss.Context(0)
+    ctx.set_option("specialize", specialize)
+    view = make_view(n)
+    keyed = ss.View(view.schema(), [view.column(i) if i != 2 else ss.Column(np.arange(n) * 7919 % groups, None) for i in range(view.column_count())])
+    spec = ss.AggregationSpecification()
+    for col in ("a", "b", "d"):
+        spec.AddAggregation(ss.SUM, col, "s_" + col).AddAggregation(ss.MIN, col, "mn_" + col).AddAggregation(ss.MAX, col, "mx_" + col)
+    for col in ("d1", "d2", "d3", "u"):
+        spec.AddAggregation(ss.MIN, col, "mn_" + col).AddAggregation(ss.MAX, col, "mx_" + col)
+    spec.AddAggregation(ss.COUNT, "", "n")
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["c"]), spec, None, ss.ScanView(keyed))
+    _s, want = oracle_run(op)
+    plan = ss.Plan(op, ctx)
+    shapes = []
+    for _ in range(4):
+        plan.run(keyed)
+        assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="%d groups" % groups)
+        shapes.append([st["group_shape"] for st in plan.stage_info() if st["kind"] == 3][-1])
+    if groups > 7:                                   # (7 groups sit in the pipeline kernel's own LDS table: the direct shape is the right one)
+        assert shapes[-1] in (1, 2, 3), shapes       # partitions, or one table for all groups: not the per-row global atomics again
+
+
 def test_specialized_first_last_by_a_stored_row_id(specialized_ctx):
     # the round-4 forms of FIRST / LAST -- order taken from a stored row-id column next to DISTINCT aggregates, row-id twins
     # under a key limit -- through the per-plan compiled kernels
