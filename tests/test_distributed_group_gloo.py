@@ -214,3 +214,26 @@ def test_sum_of_floating_values_into_an_integer_is_not_merged_across_shards():
             _shard_spec(ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, col, "s", t), schema)
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
     _shard_spec(ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.MAX, "d", "m", ss.INT64), schema)   # (MIN / MAX truncate monotonically: merged)
+
+
+def test_never_null_partial_columns_are_declared_not_null_for_the_merge():
+    # distributed.py: SUM / MIN / MAX / FIRST / LAST (and a sum's residual) of a NOT NULL input are never NULL in a shard's table
+    # -- the merge plan reads them as NOT NULL columns (no contribution counts); COUNT, DISTINCT and NULLABLE inputs are left alone
+    import supersonic_amd as ss
+    from supersonic_amd.distributed import _shard_spec, _never_null, _declare_not_null, RESIDUAL
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("d", ss.DOUBLE), ss.Attribute("n", ss.DOUBLE, ss.NULLABLE), ss.Attribute("i", ss.INT64)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MIN, "n", "mn").AddAggregation(ss.COUNT, "i", "c")
+            .AddAggregation(ss.LAST, "i", "li").AddAggregation(ss.MAX, "d", "mx"))
+    shard, _with_residual = _shard_spec(spec, schema)
+    names = _never_null(shard, schema)
+    assert names == {"sd", "sd" + RESIDUAL, "li", "mx"}
+    assert _never_null(shard, None) == set()
+    result = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("sd", ss.DOUBLE, ss.NULLABLE), ss.Attribute("sd" + RESIDUAL, ss.DOUBLE, ss.NULLABLE),
+                             ss.Attribute("mn", ss.DOUBLE, ss.NULLABLE), ss.Attribute("c", ss.UINT64), ss.Attribute("li", ss.INT64, ss.NULLABLE),
+                             ss.Attribute("mx", ss.DOUBLE, ss.NULLABLE), ss.Attribute("__valid", ss.BOOL)])
+    view = ss.DeviceView(result, [(1000 + 16 * i, 2000 + 16 * i) for i in range(8)], 5)
+    out = _declare_not_null(view, names)
+    got = [(out.schema().attribute(i).name(), out.schema().attribute(i).is_nullable(), out._ptrs[i]) for i in range(8)]
+    assert got == [("k", False, (1000, 2000)), ("sd", False, (1016, 0)), ("sd" + RESIDUAL, False, (1032, 0)), ("mn", True, (1048, 2048)),
+                   ("c", False, (1064, 2064)), ("li", False, (1080, 0)), ("mx", False, (1096, 0)), ("__valid", False, (1112, 2112))]
+    assert out.row_count() == 5 and _declare_not_null(view, set()) is view
