@@ -1627,6 +1627,61 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
 
 
+@pytest.mark.parametrize("specialize", [0, 1])
+def test_merge_of_four_partial_tables_through_wide_partitions(specialize):
+    """Four shards' partial tables (config #4's 12 aggregates + 4 residuals: a 17-word record) gathered on one GPU and merged the way a
+    rank of a 4-GPU job merges them: the never-NULL partial columns declared NOT NULL (no contribution counts), the merge stage
+    without a table on chip and therefore -- from its second run on -- through 20-word partition records, where every group now
+    meets its four partial rows.  Every run's result is the oracle's GroupAggregate of the whole input; DOUBLE sums exact."""
+    import torch
+    from supersonic_amd.distributed import _shard_spec, _merge_spec, _merge_plan, _never_null, _declare_not_null
+    ctx = ss.Context(0)
+    ctx.set_option("specialize", specialize)
+    n, world, groups = 480000, 4, 60000
+    rng = np.random.default_rng(5)
+    schema = ss.TupleSchema([ss.Attribute("k1", ss.INT32), ss.Attribute("k2", ss.INT32)] + [ss.Attribute("d%d" % i, ss.DOUBLE) for i in range(4)])
+    g = rng.integers(0, groups, n)
+    view = ss.View(schema, [(g // 300).astype(np.int32), (g % 300).astype(np.int32)] + [rng.integers(-4000, 4000, n) * 0.25 for _ in range(4)])
+    spec = ss.AggregationSpecification()
+    for i in range(4):
+        spec.AddAggregation(ss.SUM, "d%d" % i, "s%d" % i).AddAggregation(ss.MIN, "d%d" % i, "mn%d" % i).AddAggregation(ss.MAX, "d%d" % i, "mx%d" % i)
+    keys = ["k1", "k2"]
+    shard_spec, with_residual = _shard_spec(spec, schema)
+    merged_spec, counts = _merge_spec(spec, with_residual)
+    never_null = _never_null(shard_spec, schema)
+    assert len(never_null) == 16
+    cap, dev = 65536, torch.device("cuda", 0)
+    plans, images, image_bytes = [], [], None
+    for s in range(world):
+        lo, hi = n * s // world, n * (s + 1) // world
+        sv = ss.View(schema, [ss.Column(view.column(i).data[lo:hi], None) for i in range(view.column_count())])
+        plan = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), shard_spec, None, ss.ScanView(sv)), ctx)
+        plan.run()
+        image_bytes, _ub, _offs = plan.image_layout(cap, 1)
+        out = torch.zeros(image_bytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        plan.pack_image(cap, out.data_ptr())
+        ctx.synchronize()
+        plans.append(plan)
+        images.append(out)
+    _ib, unpacked_bytes, _offs = plans[0].image_layout(cap, world)
+    gathered = torch.cat(images)
+    unpacked = torch.zeros(unpacked_bytes, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    everyone = _declare_not_null(plans[0].unpack_images(gathered.data_ptr(), world, cap, unpacked.data_ptr()), never_null)
+    ctx.synchronize()
+    trailer = unpacked[unpacked_bytes - 32:].view(torch.int64).tolist()
+    assert trailer[2] == 0 and trailer[3] == 0, trailer
+    merge = ss.Plan(_merge_plan(keys, merged_spec, counts, plans[0].result_schema, everyone, valid="__valid"), ctx)
+    _s, want = oracle_run(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, ss.ScanView(view)))
+    shapes = []
+    for _ in range(4):
+        merge.run(everyone)
+        assert_cols_equal(sort_rows(to_cols(merge.fetch())), sort_rows(want), context="merged partial tables")
+        shapes.append([st["group_shape"] for st in merge.stage_info() if st["kind"] == 3][-1])
+    assert shapes[0] == 0 and shapes[-1] == 1, shapes          # direct once (nothing known), partitions from then on
+
+
 # ---- lazy run feedback (runtime.cpp: settle_plan): in its steady state a GroupAggregate leaves its overflow words on the stream
 # ---- instead of synchronising at the end of every run; a run that overflows after all is repeated when its result is touched ---
 @pytest.mark.parametrize("partition", [1, 2])

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_parity_gpu.py -q -x -k "more_than_16_words" 2>&1 | tail -15
+python -m pytest tests/test_parity_gpu.py -q -x -k "four_partial_tables" 2>&1 | tail -15
