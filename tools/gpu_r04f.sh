@@ -6,7 +6,7 @@ cd $REPO; export TMPDIR=/tmp
 ( timeout 600 python -m pytest tests/test_00_configs_gpu.py tests/test_full_size_gpu.py tests/test_parity_gpu.py -m gpu -x -q -n 4 -k "sort or Sort" ) > $OUT/sort_tests.log 2>&1; tail -3 $OUT/sort_tests.log
 cd /tmp
 for d in 0 1 4; do
-  SSGPU_ONESWEEP_DEBUG=$d timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d$d -o t -- python $REPO/tools/dbg/sort_only.py > $OUT/d$d.log 2>&1
+  SSGPU_ONESWEEP_DEBUG=$d timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d$d -o t -- python $REPO/tools/sort_only.py > $OUT/d$d.log 2>&1
 done
 python3 - <<'PY'
 import csv, os

@@ -1,6 +1,6 @@
 """Development aid: config #5's Sort a few times, product only (no result check: used with kernel parts switched off)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import bench
 import supersonic_amd as ss
