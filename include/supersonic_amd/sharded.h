@@ -28,7 +28,7 @@
 // double-double accumulator leaves its shard unrounded -- so the cross-shard total stays within 1 ULP of the exact sum
 // (adding the shards' ROUNDED sums is hundreds to thousands of ULP off on ill-conditioned data, profiles/r03_double_sum_ulp.json).
 // `supersonic_amd/distributed.py` is the same protocol over torch.distributed.  STRING columns need one dictionary for the
-// whole job (distributed.py: job_strings) and are not handled here.
+// whole job (distributed.py: job_strings); this driver builds none and refuses STRING keys / STRING results (ERROR_NOT_IMPLEMENTED).
 #ifndef SUPERSONIC_AMD_SHARDED_H_
 #define SUPERSONIC_AMD_SHARDED_H_
 
@@ -151,6 +151,14 @@ class ShardedGroupAggregate {
       if (probe.is_failure()) { error_code_ = probe.exception().return_code(); error_ = probe.exception().message(); return; }
       child_schema = probe->schema();
     }
+    // STRING values cross shards as the INT32 codes of a dictionary, and every plan builds its own from the strings it meets: a
+    // job needs ONE dictionary for all its plans (distributed.py: job_strings, an all-gather of the ranks' strings at set-up).
+    // This driver does not build one -- it refuses STRING keys and STRING results instead of merging codes of different
+    // dictionaries (COUNT of a STRING column is a number and is fine).
+    auto is_string = [&](const std::string& name) { const int pos = child_schema.LookupAttributePosition(name); return pos >= 0 && child_schema.attribute(pos).type() == STRING; };
+    for (auto& k : group_by_) if (is_string(k)) { error_code_ = ERROR_NOT_IMPLEMENTED; error_ = "STRING group keys need one dictionary for the whole job: not available in this driver"; return; }
+    for (auto& e : own_spec->elements)
+      if (e.aggregation != COUNT && is_string(e.input)) { error_code_ = ERROR_NOT_IMPLEMENTED; error_ = "STRING aggregate results need one dictionary for the whole job: not available in this driver"; return; }
     // the shard's specification (+ residuals) and the merge functions of the aggregates (cf. distributed.py: _shard_spec, _merge_spec)
     std::unique_ptr<AggregationSpecification> shard(new AggregationSpecification), merged(new AggregationSpecification);
     for (auto& e : own_spec->elements) {

@@ -195,6 +195,40 @@ int main(int argc, char** argv) {
       CHECK(c->Next(-1).is_eos());
     }
   }
+  {
+    // what the driver refuses, loudly: STRING keys / STRING results (every plan has its own dictionary: the codes of different shards
+    // must not be merged) and the row-after-row SUM of floating values into an integer (a shard's result is not a partial sum)
+    StringPiece names[4] = {"pear", "apple", "fig", "apple"}; int64_t vals[4] = {1, 2, 3, 4}; double ds[4] = {0.6, 0.6, 0.6, 2.5};
+    TupleSchema ss;
+    ss.add_attribute(Attribute("name", STRING, NOT_NULLABLE)); ss.add_attribute(Attribute("v", INT64, NOT_NULLABLE)); ss.add_attribute(Attribute("x", DOUBLE, NOT_NULLABLE));
+    View sv(ss);
+    sv.mutable_column(0)->Reset(names, nullptr); sv.mutable_column(1)->Reset(vals, nullptr); sv.mutable_column(2)->Reset(ds, nullptr);
+    sv.set_row_count(4);
+    {
+      ShardedGroupAggregate job(comm, 1, {"name"}, (new AggregationSpecification)->AddAggregation(SUM, "v", "s"), ScanView(sv), 1024);
+      FailureOrOwned<Cursor> c = job.Run();
+      CHECK(c.is_failure());
+      if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_NOT_IMPLEMENTED);
+    }
+    {
+      ShardedGroupAggregate job(comm, 1, {"v"}, (new AggregationSpecification)->AddAggregation(MIN, "name", "m"), ScanView(sv), 1024);
+      FailureOrOwned<Cursor> c = job.Run();
+      CHECK(c.is_failure());
+      if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_NOT_IMPLEMENTED);
+    }
+    {
+      ShardedGroupAggregate job(comm, 1, {"v"}, (new AggregationSpecification)->AddAggregationWithDefinedOutputType(SUM, "x", "s", INT64), ScanView(sv), 1024);
+      FailureOrOwned<Cursor> c = job.Run();
+      CHECK(c.is_failure());
+      if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_NOT_IMPLEMENTED);
+    }
+    {   // (COUNT of a STRING column is a number: merged)
+      ShardedGroupAggregate job(comm, 1, {"v"}, (new AggregationSpecification)->AddAggregation(COUNT, "name", "c"), ScanView(sv), 1024);
+      FailureOrOwned<Cursor> c = job.Run();
+      CHECK(c.is_success());
+      if (c.is_success()) { ResultView r = c->Next(-1); CHECK(r.has_data() && r.view().row_count() == 4u); }
+    }
+  }
   ncclCommDestroy(comm);
   printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
   return g_fail ? 1 : 0;
