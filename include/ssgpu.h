@@ -532,7 +532,11 @@ void ssgpu_interrupt(ssgpu_plan* plan);
  * stop before finalisation and expose element-wise reducible partial buffers.
  * Segment `i` is `count` elements of `dtype` to be combined across ranks with
  * `reduce` (0 = sum, 1 = min, 2 = max); the caller all-reduces each segment in
- * place (RCCL) and then calls ssgpu_plan_finalize. */
+ * place (RCCL) and then calls ssgpu_plan_finalize.
+ * STRING results (MIN / MAX / FIRST / LAST of a STRING column) are codes of the plan's dictionary: states -- and result
+ * images, below -- of different plans may only be combined when the plans were created with the SAME dictionary (every
+ * rank passing the job's strings: ssgpu_dict_*; distributed.py: job_strings).  The host drivers that do not build one
+ * refuse STRING results (include/supersonic_amd/sharded.h). */
 typedef struct ssgpu_partial_segment {
   void* device_ptr;
   int64_t count;

@@ -76,6 +76,11 @@ class ShardedScalarAggregate {
     if (!cursor_) {
       FailureOrOwned<Cursor> c = op_->CreateCursor();
       if (c.is_failure()) return c;
+      // a STRING result (MIN / MAX / FIRST / LAST of a STRING column) is a code of THIS plan's dictionary: the ranks' states must
+      // not be folded (one dictionary for the whole job is not built here; cf. ShardedGroupAggregate)
+      for (int i = 0; i < c->schema().attribute_count(); ++i)
+        if (c->schema().attribute(i).type() == STRING)
+          return internal::FailCursor(ERROR_NOT_IMPLEMENTED, "STRING aggregate results need one dictionary for the whole job: not available in this driver");
       cursor_.reset(c.release());
     }
     internal::DeviceCursor* dc = internal::AsDeviceCursor(cursor_.get());

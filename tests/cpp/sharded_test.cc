@@ -222,6 +222,12 @@ int main(int argc, char** argv) {
       CHECK(c.is_failure());
       if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_NOT_IMPLEMENTED);
     }
+    {
+      ShardedScalarAggregate job(comm, 1, (new AggregationSpecification)->AddAggregation(MAX, "name", "m"), ScanView(sv));
+      FailureOrOwned<Cursor> c = job.Run(0);
+      CHECK(c.is_failure());
+      if (c.is_failure()) CHECK(c.exception().return_code() == ERROR_NOT_IMPLEMENTED);
+    }
     {   // (COUNT of a STRING column is a number: merged)
       ShardedGroupAggregate job(comm, 1, {"v"}, (new AggregationSpecification)->AddAggregation(COUNT, "name", "c"), ScanView(sv), 1024);
       FailureOrOwned<Cursor> c = job.Run();
