@@ -1695,6 +1695,25 @@ static Status finish_materialize(const Pipe& pipe, Stage* st) {
   return Status::OK();
 }
 
+// The columns an aggregate reads -- keys first, then the aggregated inputs, each once, in first-use order -- as a pipe of their own
+// (what the composed shapes materialise before they sort): *kpos and the plans' input_pos are rewritten to positions in it.
+static Pipe prune_to_used(const Pipe& pipe, std::vector<int>* kpos, std::vector<AggPlan>* plans) {
+  std::vector<int> used;
+  auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
+  if (kpos) for (auto& k : *kpos) k = slot_of(k);
+  for (auto& ap : *plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+  Pipe pruned = pipe; pruned.cols.clear();
+  for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+  return pruned;
+}
+// One more column of such a pipe: the row's index in the plan's input ("$row", UINT64, NOT NULL).  -> its position
+static int add_row_id_column(Pipe* pruned) {
+  VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
+  rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
+  pruned->cols.push_back(rc);
+  return (int)pruned->cols.size() - 1;
+}
+
 // The DISTINCT shape behind its first materialise (`pipe` = the identity over that stage's rows).  Every DISTINCT column but the
 // first gets its first-of-run flags as a stored BOOL column: the rows are sorted by (sort_keys, that column), flagged (the
 // synthetic input behind the stage's columns) and written back with the flag; the last sort -- by (sort_keys, first DISTINCT
@@ -1940,12 +1959,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           GroupBinding g;
           if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
-          std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
-          auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
-          for (auto& k : g.kpos) k = slot_of(k);
-          for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
-          Pipe pruned = pipe; pruned.cols.clear();
-          for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+          Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
           reset_pipe(&pipe, m.out_schema);
@@ -1976,19 +1990,12 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // They pick by the row's ORIGINAL id instead, stored as one more column and carried through the sorts (AggPlan::order_pos).
           bool first_last = false;
           for (auto& ap : g.plans) first_last = first_last || ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST;
-          std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
-          auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
-          for (auto& k : g.kpos) k = slot_of(k);
-          for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+          Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
           std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
           for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
-          Pipe pruned = pipe; pruned.cols.clear();
-          for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
           if (first_last) {
-            VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
-            rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
-            pruned.cols.push_back(rc);
-            for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = (int)pruned.cols.size() - 1;
+            const int row_pos = add_row_id_column(&pruned);
+            for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
           }
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
@@ -2002,11 +2009,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           std::vector<Stage::SeqSum> seqs;
           if (has_sequential(plans)) {
             // the row-after-row sums read stored columns in input order: the aggregated columns are materialised first
-            std::vector<int> used;
-            auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
-            for (auto& ap : plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
-            Pipe pruned = pipe; pruned.cols.clear();
-            for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+            Pipe pruned = prune_to_used(pipe, nullptr, &plans);
             Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
             stages->push_back(m);
             reset_pipe(&pipe, m.out_schema);
@@ -2086,19 +2089,12 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             // stored column): materialise the keys and the aggregated columns, radix-sort the rows by the
             // keys and aggregate the now contiguous groups with the clustered kernel.  Group order
             // is unspecified in the reference (hash order, aggregate_groups.cc:332-433).
-            std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
-            auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
             GroupBinding gm = g;
-            for (auto& k : gm.kpos) k = slot_of(k);
-            for (auto& ap : gm.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
-            Pipe pruned = pipe; pruned.cols.clear();
-            for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
+            Pipe pruned = prune_to_used(pipe, &gm.kpos, &gm.plans);
             if (limited) {
-              VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
-              rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
-              pruned.cols.push_back(rc);
-              for (auto& ap : gm.plans) if (ap.rowid_only) ap.order_pos = (int)pruned.cols.size() - 1;
-              AggPlan hidden; hidden.aggregation = SSGPU_MIN; hidden.input_pos = (int)pruned.cols.size() - 1; hidden.out_type = SSGPU_UINT64;
+              const int row_pos = add_row_id_column(&pruned);
+              for (auto& ap : gm.plans) if (ap.rowid_only) ap.order_pos = row_pos;
+              AggPlan hidden; hidden.aggregation = SSGPU_MIN; hidden.input_pos = row_pos; hidden.out_type = SSGPU_UINT64;
               hidden.out_name = "$first_seen"; hidden.result_nullable = false;
               gm.plans.push_back(hidden);
             }
@@ -2190,23 +2186,16 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
               if (pipe.cols[k].expr->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "clustered keys must be plain input columns");
               key_inputs.push_back(pipe.cols[k].expr->input_col);
             }
-            std::vector<int> used;   // pipe columns the aggregate reads, in first-use order
-            auto slot_of = [&](int pos) { for (size_t i = 0; i < used.size(); ++i) if (used[i] == pos) return (int)i; used.push_back(pos); return (int)used.size() - 1; };
-            for (auto& k : g.kpos) k = slot_of(k);
-            for (auto& ap : g.plans) if (ap.input_pos >= 0) ap.input_pos = slot_of(ap.input_pos);
+            Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
             std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
             for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
-            Pipe pruned = pipe; pruned.cols.clear();
-            for (size_t i = 0; i < used.size(); ++i) { VCol c = pipe.cols[used[i]]; c.name = "c" + std::to_string(i); pruned.cols.push_back(c); }
             { VCol sc; sc.name = "$segment"; sc.expr = std::make_shared<BExpr>();
               sc.expr->kind = BExpr::INPUT; sc.expr->input_col = (int)pipe.in_schema.size(); sc.expr->dtype = SSGPU_UINT32; sc.expr->nullable = false; sc.expr->name = sc.name;
               pruned.cols.push_back(sc); }
             const int seg_pos = (int)pruned.cols.size() - 1;
             if (first_last) {
-              VCol rc; rc.name = "$row"; rc.expr = std::make_shared<BExpr>();
-              rc.expr->kind = BExpr::ROWID; rc.expr->dtype = SSGPU_UINT64; rc.expr->nullable = false; rc.expr->name = rc.name;
-              pruned.cols.push_back(rc);
-              for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = (int)pruned.cols.size() - 1;
+              const int row_pos = add_row_id_column(&pruned);
+              for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             }
             Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
             m.segment_cols = key_inputs;
