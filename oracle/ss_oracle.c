@@ -1391,7 +1391,7 @@ static void update_aggregation(agg_col* g, const orc_view* v, const int64_t* map
       /* SUM of a floating input into an integer result (AddAggregationWithDefinedOutputType; column_aggregator.cc:484-532 lists
        * the pair): AggregationOperator<SUM>, aggregation_operators.h:173-185, is `*result += val` -- C++ adds in the floating
        * type (FLOAT stays float) and converts back to the integer after EVERY row; the first value is assigned
-       * (column_aggregator.cc:170-175).  Order-dependent: this loop IS the reference's order.  Floating -> integer goes
+       * (column_aggregator.cc:154-166).  Order-dependent: this loop IS the reference's order.  Floating -> integer goes
        * through int64_t like every other such store here (in range it is the plain C conversion). */
 #define SEQ_SUM(TO, F) { TO* acc = (TO*)res + r; const F v = ((const F*)in)[i]; \
         if (first) *acc = (TO)(int64_t)v; else *acc = (TO)(int64_t)((F)*acc + v); }

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void ssgpu_cluster_assign_kernel(const Cluster
 
 // ---- SUM of a floating input into an integer result (AddAggregationWithDefinedOutputType) --------------------------------
 // aggregation_operators.h:173-185: `*result += val` with an integer result and a floating value adds in the floating type and
-// truncates back after EVERY row (the first non-NULL value is assigned: column_aggregator.cc:170-175), so the result depends
+// truncates back after EVERY row (the first non-NULL value is assigned: column_aggregator.cc:154-166), so the result depends
 // on the row order -- no parallel reduction has it.  The rows arrive in the reference's order within a segment (the input
 // order: the stable sort of the sorted shape, or the clusters themselves) and one thread folds each segment, row after row.
 // Conversions as everywhere on the path: floating -> integer truncates, out of range / NaN gives INT64_MIN's bits
