@@ -53,6 +53,7 @@ struct ssgpu_ctx {
   int64_t sort_hybrid = 1;       // 0: never take the high-half-first shortcut for wide keys
   int64_t group_slab = 1;        // 0: never take the slab form of the partitioned GroupAggregate
   int64_t group_scout = 1;       // 0: no scout run ahead of the first large GroupAggregate run (see run_group_agg)
+  int64_t group_scout_rows = 8 << 20;   // ... "large": inputs of at least this many rows (a smaller value helps first runs and costs steady ones: see run_group_agg)
   int64_t group_resident = 1;    // 0: plain stages take the slab form through scatter + aggregation like every other stage (tests, A/B)
   int64_t async_handoff = 1;     // 0: every stage hand-off reads the row count on the host (a stream synchronise), even where the next stage could take it from the device
   int64_t lazy_feedback = 1;     // 0: a GroupAggregate reads its overflow / feedback words back at the end of EVERY run (a stream synchronise per run)
@@ -345,6 +346,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "group_slab") c->group_slab = value;
   else if (k == "group_resident") c->group_resident = value;
   else if (k == "group_scout") c->group_scout = value;
+  else if (k == "group_scout_rows") c->group_scout_rows = value;
   else if (k == "part_plain") c->part_plain = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "async_handoff") c->async_handoff = value;
@@ -1593,12 +1595,17 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
   // The execution shape follows run feedback, and the shape a plan starts in (the direct one) is the wrong one for a large
   // input with many groups: 54 ms for BASELINE config #3, whose steady shape takes 3.  A cursor that is drained once never
   // sees the steady shape -- so the first large run is preceded by a scout: the direct shape over a 1/64 prefix of the
-  // rows (>= 1 M), only for its feedback (group-count estimate -> direct / partitioned / one-table form).  Its result is
-  // thrown away; a prefix that is not representative (input sorted by key) just leaves the old behaviour.
-  if (!scout && !ex.scouted && c->group_scout != 0 && c->group_partition == 1 && !ex.group_partitioned && !st.part_scatter.empty() && in.rows >= (int64_t)(8 << 20)) {
+  // rows (>= 1 M; an eighth of a smaller input, >= 128 K), only for its feedback (group-count estimate -> direct / partitioned /
+  // one-table form).  Its result is thrown away; a prefix that is not representative (input sorted by key) just leaves the old
+  // behaviour.  "Large" = group_scout_rows, 8 M rows.  With 1 M the first runs of 2 - 6 M-row inputs get 30 - 60 % faster (they
+  // take the direct shape otherwise: 1.5 - 4.8 ms), but a prefix of an eighth over-estimates the group count of such inputs up
+  // to eightfold and the plan then keeps too many partitions (or the one-table form where partitions are faster): steady runs
+  // 1.5 - 3 x slower (profiles/r04_first_run.json).  A plan that is run once may set it lower; the default favours the plan that is run again.
+  if (!scout && !ex.scouted && c->group_scout != 0 && c->group_partition == 1 && !ex.group_partitioned && !st.part_scatter.empty() &&
+      in.rows >= std::max<int64_t>(c->group_scout_rows, (int64_t)1 << 18)) {
     ex.scouted = true; ex.scout_full_rows = in.rows;
     InCols prefix = in;
-    prefix.rows = std::max<int64_t>(in.rows / 64, (int64_t)1 << 20);
+    prefix.rows = in.rows >= ((int64_t)8 << 20) ? std::max<int64_t>(in.rows / 64, (int64_t)1 << 20) : std::max<int64_t>(in.rows / 8, (int64_t)1 << 17);
     const int rc = run_group_agg(p, si, prefix, row_id_base, true);
     if (rc != SSGPU_OK) return rc;
     ex.steady = 0;

@@ -95,14 +95,24 @@ def group3():
 
 
 def test_config3_group_aggregate_by_run_feedback(group3):
-    # the default policy: the first run takes the direct shape, its feedback (most rows bypass the LDS table) moves the
-    # plan to the hash partitions; every run of the walk gives the oracle's rows
+    # without a scout run (inputs below group_scout_rows = 8 M rows get none; group_scout = 0 says so explicitly): the
+    # first run takes the direct shape, its feedback (most rows bypass the LDS table) moves the plan to the hash partitions;
+    # every run of the walk gives the oracle's rows
     _view, op, oschema, want = group3
-    plan = ss.Plan(op, make_ctx())
+    plan = ss.Plan(op, make_ctx(group_scout=0))
     assert schema_list(plan.result_schema) == oschema
     infos = check_plan(plan, want, "config #3 adaptive", ignore_order=True, runs=4)
     shapes = [i[0]["group_shape"] for i in infos]
     assert shapes[0] == 0 and shapes[-1] == 1, shapes
+
+
+def test_config3_first_run_after_a_scout_is_partitioned(group3):
+    # group_scout_rows = 1 M (default 8 M): a scout run over a prefix (an eighth of this 2 M-row input) estimates the group count,
+    # and already the FIRST run -- the only one of a cursor that is drained once -- takes the hash partitions
+    _view, op, _s, want = group3
+    plan = ss.Plan(op, make_ctx(group_scout_rows=1 << 20))
+    infos = check_plan(plan, want, "config #3 after a scout", ignore_order=True, runs=3)
+    assert [i[0]["group_shape"] for i in infos] == [1, 1, 1], infos
 
 
 @pytest.mark.parametrize("part_plain", [1, 0])
