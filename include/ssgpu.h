@@ -321,7 +321,8 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *                           group_partition (0 never / 1 by run feedback / 2 always hash-partitioned), group_slab (0 never /
  *                           1 by estimate / 2 always the one-table-per-CU form), group_resident (0 = the one-table-per-CU form always
  *                           through scatter + aggregation, never straight from the input columns), group_scout (0 = no scout run --
- *                           the direct shape over a 1/64 prefix, result discarded -- ahead of a plan's first run over >= 8 M rows), part_plain (0 = the partition scatter always as
+ *                           the direct shape over a 1/64 prefix, result discarded -- ahead of a plan's first run over >= group_scout_rows rows; group_scout_rows: 8 M by default, a plan that is run ONCE over fewer rows may lower it --
+ *                           an eighth of a smaller input is scouted --, trading a faster first run for a coarser group-count estimate), part_plain (0 = the partition scatter always as
  *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
  *                           part_rec_align, lazy_feedback (0 = a GroupAggregate reads its overflow / feedback words at the end of EVERY run --
  *                           one stream synchronise per run -- instead of leaving them to the next touch of the result; see ssgpu_plan_run)
