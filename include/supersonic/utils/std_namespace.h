@@ -1,0 +1,6 @@
+// supersonic/utils/std_namespace.h -- the reference's include path for this header (/root/reference/supersonic/utils/std_namespace.h).  The MI355X-native mirror
+// keeps the whole builder API of the path in one header; this file only makes the reference's #include line resolve.
+#ifndef SSGPU_FWD_SUPERSONIC_UTILS_STD_NAMESPACE_H_
+#define SSGPU_FWD_SUPERSONIC_UTILS_STD_NAMESPACE_H_
+#include "../../supersonic_amd/supersonic.h"
+#endif  // SSGPU_FWD_SUPERSONIC_UTILS_STD_NAMESPACE_H_

@@ -27,6 +27,9 @@
 #include <stdlib.h>
 
 #include <deque>
+#include <map>
+#include <ostream>
+#include <set>
 
 #include "../ssgpu.h"
 
@@ -43,9 +46,68 @@ typedef unsigned int uint32;
 typedef unsigned long long uint64;
 #endif
 
+// The reference keeps StringPiece, `string` and its map helpers in the GLOBAL namespace (supersonic/utils/strings/stringpiece.h,
+// supersonic/utils/map_util.h), and its guides use them unqualified (test/guide/group_sort.cc:170-209: `const StringPiece*`,
+// `string names_str[...]`, `ContainsKey(max_age, key)`); `supersonic::StringPiece` names the same class.
+using std::string;
+
+// STRING cells of a View (supersonic/utils/strings/stringpiece.h): a pointer + length, not owning the bytes.  Views handed to
+// ScanView / Evaluate hold arrays of these; across the C ABI they travel as INT32 codes of an order-preserving
+// dictionary (ssgpu_dict_*), and result Views point into the cursor's dictionary.
+class StringPiece {
+ public:
+  StringPiece() : data_(""), length_(0) {}
+  StringPiece(const char* s) : data_(s), length_(s ? strlen(s) : 0) {}            // NOLINT(runtime/explicit)
+  StringPiece(const std::string& s) : data_(s.data()), length_(s.size()) {}       // NOLINT(runtime/explicit)
+  StringPiece(const char* s, size_t n) : data_(s), length_(n) {}
+  const char* data() const { return data_; }
+  size_t size() const { return length_; }
+  size_t length() const { return length_; }
+  bool empty() const { return length_ == 0; }
+  std::string ToString() const { return std::string(data_, length_); }
+  int compare(const StringPiece& o) const {
+    const int r = memcmp(data_, o.data_, std::min(length_, o.length_));
+    return r != 0 ? r : (length_ < o.length_ ? -1 : (length_ > o.length_ ? 1 : 0));
+  }
+ private:
+  const char* data_;
+  size_t length_;
+};
+inline bool operator==(const StringPiece& a, const StringPiece& b) { return a.size() == b.size() && memcmp(a.data(), b.data(), a.size()) == 0; }
+inline bool operator!=(const StringPiece& a, const StringPiece& b) { return !(a == b); }
+inline bool operator<(const StringPiece& a, const StringPiece& b) { return a.compare(b) < 0; }
+
+inline std::ostream& operator<<(std::ostream& o, const StringPiece& piece) { o.write(piece.data(), static_cast<std::streamsize>(piece.size())); return o; }
+
+// supersonic/utils/map_util.h:100-330 (the helpers user code of this path calls)
+template <class Collection, class Key> bool ContainsKey(const Collection& collection, const Key& key) { return collection.find(key) != collection.end(); }
+template <class Collection, class Key, class Value> bool ContainsKeyValuePair(const Collection& collection, const Key& key, const Value& value) {
+  auto range = collection.equal_range(key);
+  for (auto it = range.first; it != range.second; ++it) if (it->second == value) return true;
+  return false;
+}
+template <class Collection> const typename Collection::value_type::second_type* FindOrNull(const Collection& collection, const typename Collection::value_type::first_type& key) {
+  auto it = collection.find(key);
+  return it == collection.end() ? nullptr : &it->second;
+}
+template <class Collection> const typename Collection::value_type::second_type& FindWithDefault(const Collection& collection, const typename Collection::value_type::first_type& key,
+                                                                                                const typename Collection::value_type::second_type& value) {
+  auto it = collection.find(key);
+  return it == collection.end() ? value : it->second;
+}
+template <class Collection> bool InsertIfNotPresent(Collection* const collection, const typename Collection::value_type::first_type& key, const typename Collection::value_type::second_type& value) {
+  return collection->insert(typename Collection::value_type(key, value)).second;
+}
+template <class Collection> bool InsertOrUpdate(Collection* const collection, const typename Collection::value_type::first_type& key, const typename Collection::value_type::second_type& value) {
+  auto ret = collection->insert(typename Collection::value_type(key, value));
+  if (!ret.second) { ret.first->second = value; return false; }
+  return true;
+}
+
 namespace supersonic {
 
 using std::string;
+using ::StringPiece;
 
 // base/infrastructure/types.h:252-256: row counts are UNSIGNED (so Next(-1) asks for "as many rows as you have"), row ids signed
 typedef unsigned long long rowcount_t;
@@ -164,32 +226,6 @@ class TupleSchema {
  private:
   std::vector<Attribute> attrs_;
 };
-
-// STRING cells of a View (supersonic/utils/stringpiece.h): a pointer + length, not owning the bytes.  Views handed to
-// ScanView / Evaluate hold arrays of these; across the C ABI they travel as INT32 codes of an order-preserving
-// dictionary (ssgpu_dict_*), and result Views point into the cursor's dictionary.
-class StringPiece {
- public:
-  StringPiece() : data_(""), length_(0) {}
-  StringPiece(const char* s) : data_(s), length_(s ? strlen(s) : 0) {}            // NOLINT(runtime/explicit)
-  StringPiece(const std::string& s) : data_(s.data()), length_(s.size()) {}       // NOLINT(runtime/explicit)
-  StringPiece(const char* s, size_t n) : data_(s), length_(n) {}
-  const char* data() const { return data_; }
-  size_t size() const { return length_; }
-  size_t length() const { return length_; }
-  bool empty() const { return length_ == 0; }
-  std::string ToString() const { return std::string(data_, length_); }
-  int compare(const StringPiece& o) const {
-    const int r = memcmp(data_, o.data_, std::min(length_, o.length_));
-    return r != 0 ? r : (length_ < o.length_ ? -1 : (length_ > o.length_ ? 1 : 0));
-  }
- private:
-  const char* data_;
-  size_t length_;
-};
-inline bool operator==(const StringPiece& a, const StringPiece& b) { return a.size() == b.size() && memcmp(a.data(), b.data(), a.size()) == 0; }
-inline bool operator!=(const StringPiece& a, const StringPiece& b) { return !(a == b); }
-inline bool operator<(const StringPiece& a, const StringPiece& b) { return a.compare(b) < 0; }
 
 inline size_t SizeOfDataType(DataType t) {
   switch (t) { case INT32: case UINT32: case FLOAT: case DATE: return 4; case INT64: case UINT64: case DOUBLE: case DATETIME: return 8; case BOOL: return 1;
@@ -1240,6 +1276,148 @@ class Arena {
  private:
   std::deque<std::string> chunks_;
   size_t bytes_ = 0;
+};
+
+// ---- Block / OwnedColumn (base/infrastructure/block.h:196-286, 412-491; allocation rule block.cc:20-60) ---------------------
+// A Block OWNS host columns: per column one buffer of `row_capacity << log2(width)` bytes from the BufferAllocator (pinned
+// host memory here, so a Block's view is DMA-able when it is scanned), one byte per row of NULL mask for NULLABLE
+// attributes, and an Arena for the bytes of variable-length values.  It has a row capacity and no row count
+// (view().row_count() IS the capacity).  User code of the path fills Blocks through ViewCopier (test/guide/group_sort.cc:437-
+// 461, join.cc:351-372) or through mutable_column(i)->mutable_typed_data<T>().
+class Block;
+class OwnedColumn {
+ public:
+  const Column& content() const { return *column_; }
+  void* mutable_data() { return data_ ? data_->data() : nullptr; }
+  void* mutable_data_plus_offset(rowcount_t offset) { return static_cast<char*>(mutable_data()) + offset * SizeOfDataType(column_->attribute().type()); }
+  template <DataType type> typename TypeTraits<type>::cpp_type* mutable_typed_data() { return static_cast<typename TypeTraits<type>::cpp_type*>(mutable_data()); }
+  template <DataType type> typename TypeTraits<type>::cpp_type* mutable_weakly_typed_data() { return static_cast<typename TypeTraits<type>::cpp_type*>(mutable_data()); }
+  StringPiece* mutable_variable_length_data() { return static_cast<StringPiece*>(mutable_data()); }
+  bool_ptr mutable_is_null() { return is_nullable() && nulls_ ? static_cast<bool*>(nulls_->data()) : nullptr; }   // NULL for NOT_NULLABLE attributes
+  bool_ptr mutable_is_null_plus_offset(rowcount_t offset) { bool_ptr z = mutable_is_null(); return z ? z + offset : nullptr; }
+  Arena* arena() { return arena_.get(); }                       // variable-length columns only
+  // block.cc:20-45: both buffers are (re)allocated, old content is kept up to the smaller capacity
+  bool Reallocate(rowcount_t row_capacity, BufferAllocator* allocator) {
+    const size_t width = SizeOfDataType(column_->attribute().type());
+    if (!Grow(&data_, static_cast<size_t>(row_capacity) * width, allocator)) return false;
+    if (is_nullable() && !Grow(&nulls_, static_cast<size_t>(row_capacity), allocator)) return false;
+    column_->Reset(data_->data(), is_nullable() ? static_cast<const bool*>(nulls_->data()) : nullptr);
+    return true;
+  }
+ private:
+  friend class Block;
+  OwnedColumn() : column_(nullptr) {}
+  void Init(BufferAllocator* allocator, Column* column) {
+    column_ = column;
+    const DataType t = column->attribute().type();
+    if (t == STRING || t == BINARY) arena_.reset(new Arena(allocator, 0, static_cast<size_t>(-1)));
+  }
+  bool is_nullable() const { return column_->attribute().is_nullable(); }
+  static bool Grow(std::unique_ptr<Buffer>* b, size_t bytes, BufferAllocator* allocator) {
+    if (!*b) { b->reset(allocator->Allocate(bytes)); return *b != nullptr; }   // (zero-size requests succeed with non-NULL data, memory.h:112-117)
+    return allocator->Reallocate(bytes, b->get());
+  }
+  Column* column_;                 // the owning Block's view column
+  std::unique_ptr<Buffer> data_, nulls_;
+  std::unique_ptr<Arena> arena_;
+  OwnedColumn(const OwnedColumn&);
+  OwnedColumn& operator=(const OwnedColumn&);
+};
+
+class Block {
+ public:
+  Block(const TupleSchema& schema, BufferAllocator* allocator)
+      : allocator_(allocator), columns_(new OwnedColumn[static_cast<size_t>(schema.attribute_count() > 0 ? schema.attribute_count() : 1)]), view_(schema) {
+    for (int i = 0; i < schema.attribute_count(); ++i) columns_[i].Init(allocator, view_.mutable_column(i));
+  }
+  // true iff every column got its buffers; on failure the capacity is not raised (block.cc:47-60)
+  bool Reallocate(rowcount_t new_row_capacity) {
+    if (new_row_capacity < view_.row_count()) view_.set_row_count(new_row_capacity);
+    for (int i = 0; i < column_count(); ++i) if (!columns_[i].Reallocate(new_row_capacity, allocator_)) return false;
+    view_.set_row_count(new_row_capacity);
+    return true;
+  }
+  void ResetArenas() { for (int i = 0; i < column_count(); ++i) if (columns_[i].arena()) columns_[i].arena()->Reset(); }
+  OwnedColumn* mutable_column(int column_index) { return &columns_[column_index]; }
+  const View& view() const { return view_; }
+  BufferAllocator* allocator() { return allocator_; }
+  const TupleSchema& schema() const { return view_.schema(); }
+  int column_count() const { return schema().attribute_count(); }
+  rowcount_t row_capacity() const { return view_.row_count(); }
+  const Column& column(size_t column_index) const { return view_.column(static_cast<int>(column_index)); }
+  bool_const_ptr is_null(size_t column_index) const { return column(column_index).is_null(); }
+ private:
+  BufferAllocator* const allocator_;
+  std::unique_ptr<OwnedColumn[]> columns_;
+  View view_;
+  Block(const Block&);
+  Block& operator=(const Block&);
+};
+
+// ---- ViewCopier / SelectiveViewCopier (base/infrastructure/view_copier.h:49-158, copy_column.cc:112-240) -------------------
+// Copy `row_count` rows of a View into a Block at `output_offset`; with a selector, input row `input_row_ids[i]` goes to
+// output row `output_offset + i` and a negative id makes a NULL row (the outer join's missing side, copy_column.cc:199-240).
+// deep_copy = variable-length values are copied into the output column's arena (otherwise the cells keep pointing at the
+// source's bytes).  Returns the number of rows copied: fewer than asked only when an arena runs out of memory.
+enum RowSelectorType { NO_SELECTOR = 0, INPUT_SELECTOR = 1 };
+class BaseViewCopier {
+ protected:
+  BaseViewCopier(const TupleSchema& source_schema, const TupleSchema& result_schema, bool deep_copy) : source_schema_(source_schema), result_schema_(result_schema), deep_copy_(deep_copy) {}
+  rowcount_t Copy(const rowcount_t row_count, const View& input_view, const rowid_t* input_row_ids, const rowcount_t output_offset, Block* output_block) const {
+    for (int c = 0; c < result_schema_.attribute_count(); ++c) {
+      const Column& in = input_view.column(c);
+      OwnedColumn* out = output_block->mutable_column(c);
+      const DataType type = result_schema_.attribute(c).type();
+      const size_t width = SizeOfDataType(type);
+      const bool variable = type == STRING || type == BINARY;
+      bool_const_ptr in_null = in.is_null();
+      bool_ptr out_null = out->mutable_is_null_plus_offset(output_offset);
+      const char* src = static_cast<const char*>(in.data().raw());
+      char* dst = static_cast<char*>(out->mutable_data_plus_offset(output_offset));
+      if (!input_row_ids && !variable) {   // a run of whole rows: one copy per buffer
+        if (row_count) memcpy(dst, src, static_cast<size_t>(row_count) * width);
+        if (out_null) { if (in_null) memcpy(out_null, in_null, static_cast<size_t>(row_count)); else if (row_count) memset(out_null, 0, static_cast<size_t>(row_count)); }
+        continue;
+      }
+      for (rowcount_t i = 0; i < row_count; ++i) {
+        const rowid_t r = input_row_ids ? input_row_ids[i] : static_cast<rowid_t>(i);
+        const bool is_null = r < 0 || (in_null && in_null[r]);
+        if (out_null) out_null[i] = is_null;
+        if (is_null) { if (variable) reinterpret_cast<StringPiece*>(dst)[i] = StringPiece(); continue; }
+        if (variable) {
+          const StringPiece& cell = reinterpret_cast<const StringPiece*>(src)[r];
+          if (deep_copy_) {
+            const char* kept = out->arena()->AddStringPieceContent(cell);
+            if (kept == nullptr) return i;
+            reinterpret_cast<StringPiece*>(dst)[i] = StringPiece(kept, cell.size());
+          } else {
+            reinterpret_cast<StringPiece*>(dst)[i] = cell;
+          }
+        } else {
+          memcpy(dst + i * width, src + static_cast<size_t>(r) * width, width);
+        }
+      }
+    }
+    return row_count;
+  }
+ private:
+  TupleSchema source_schema_, result_schema_;
+  bool deep_copy_;
+};
+class ViewCopier : public BaseViewCopier {
+ public:
+  ViewCopier(const TupleSchema& schema, bool deep_copy) : BaseViewCopier(schema, schema, deep_copy) {}
+  rowcount_t Copy(const rowcount_t row_count, const View& input_view, const rowcount_t output_offset, Block* output_block) const {
+    return BaseViewCopier::Copy(row_count, input_view, nullptr, output_offset, output_block);
+  }
+};
+class SelectiveViewCopier : public BaseViewCopier {
+ public:
+  SelectiveViewCopier(const TupleSchema& schema, bool deep_copy) : BaseViewCopier(schema, schema, deep_copy) {}
+  SelectiveViewCopier(const TupleSchema& source_schema, const TupleSchema& result_schema, bool deep_copy) : BaseViewCopier(source_schema, result_schema, deep_copy) {}
+  rowcount_t Copy(const rowcount_t row_count, const View& input_view, const rowid_t* input_row_ids, const rowcount_t output_offset, Block* output_block) const {
+    return BaseViewCopier::Copy(row_count, input_view, input_row_ids, output_offset, output_block);
+  }
 };
 
 // ---- Table / TableRowWriter (cursor/infrastructure/table.h:49-290) --------------------------------------------------------

@@ -162,8 +162,8 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
         u32 i = hash_local(key[j]) & (SSGPU_HOT_SLOTS - 1u);
         for (u32 probe = 0; probe < SSGPU_HOT_SLOTS; ++probe) {
           const u64 cur = hot_tab[i];
+          if (cur == VM_KEY_EMPTY) break;      // (first: a row whose packed key IS the EMPTY value is never a heavy hitter -- it must not match a free slot)
           if (cur == key[j]) { ok[j] = false; break; }
-          if (cur == VM_KEY_EMPTY) break;
           i = (i + 1u) & (SSGPU_HOT_SLOTS - 1u);
         }
       }

@@ -1413,6 +1413,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   for (u32 i = t; i < (C + 1u) * st; i += SSGPU_PART_THREADS) { lacc[i] = P.T.acc_init[(i % st) % ng]; if (any_cnt) lcnt[i] = 0u; }
   if constexpr (PLAIN) {
     if (P.hot_only) {   // heavy hitters: the table holds the hot keys and nothing else.  One thread seeds it, so every workgroup's copy is identical
+      if (t < 2u) wsum[t] = 0u;   // which entries a row of THIS run reached (a plan keeps its hot keys across runs; other data may not hold them)
       __syncthreads();
       if (t == 0)
         for (u32 h = 0; h < S.n_hot; ++h) {
@@ -1445,6 +1446,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   if constexpr (PLAIN) { row_first = (u64)part * (SSGPU_PART_THREADS * PART_ROWS); row_limit = S.n_rows; row_stride = (u64)gridDim.x * (SSGPU_PART_THREADS * PART_ROWS); }
   u64 trip_limit = row_limit;
   u32 nan_acc = 0;                 // this lane met a NaN in a floating MIN / MAX
+  u64 touched = 0;                 // hot_only: the seeded entries this lane's rows reached (local_capacity = SSGPU_HOT_SLOTS = 64)
 #ifdef SSGPU_RTC_PART_PLAIN
   // Trip k issues the loads of tile k and aggregates tile k - 1 (one more trip than tiles; the first aggregates nothing).
   // There is deliberately no load ahead of the loop: loads pending on entry made the compiler wait, in every trip, for
@@ -1547,7 +1549,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
               if (cur == VM_KEY_EMPTY) break;
               i = i + 1u == C ? 0u : i + 1u;
             }
-          if (found == 0xFFFFFFFFu) live[j] = false; else li[j] = found * st;
+          if (found == 0xFFFFFFFFu) live[j] = false; else { li[j] = found * st; touched |= 1ull << (found & 63u); }
         } else if (key == VM_KEY_EMPTY) {
           lkeys[C] = 0ull;                               // marks the reserved entry as used
         } else {
@@ -1635,6 +1637,12 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
     }
   }
   if (nan_acc && P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX);
+  if constexpr (PLAIN) {
+    if (P.hot_only && touched) {
+      if ((u32)touched) __hip_atomic_fetch_or(wsum, (u32)touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((u32)(touched >> 32)) __hip_atomic_fetch_or(wsum + 1, (u32)(touched >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
   __syncthreads();
   if (P.slab_segs) {
     // slab mode: every workgroup saw (a slab of) all groups: merge the occupied entries into the global table, one
@@ -1643,7 +1651,11 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
       const u64 key = lkeys[e];
       if (key == VM_KEY_EMPTY) continue;
       u32 gs;
-      if (P.hot_only) { if (e == C) continue; gs = P.hot_base + e; P.T.keys[gs] = key; }   // heavy hitters: entry e = dense slot hot_base + e (every workgroup stores the same key)
+      if (P.hot_only) {   // heavy hitters: entry e = dense slot hot_base + e (every workgroup that saw a row of the key stores the same key).
+        // A seeded key that no row of this run carries publishes nothing: the extraction would emit it as a group of zero rows
+        if (e == C || !((wsum[(e >> 5) & 1u] >> (e & 31u)) & 1u)) continue;
+        gs = P.hot_base + e; P.T.keys[gs] = key;
+      }
       else if (e == C) { gs = P.T.capacity_mask + 1u; P.T.keys[gs] = 0ull; }   // the EMPTY-valued key's reserved slot
       else gs = group_insert(P.T, key);
       if (gs == 0xFFFFFFFFu) continue;                                     // global table full: flagged, the host regrows

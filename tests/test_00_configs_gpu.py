@@ -176,6 +176,45 @@ def test_config3_many_heavy_hitters_next_to_uniform_keys():
         assert infos[0][0]["hot_keys"] >= 15 and infos[-1][0]["group_shape"] == 1 and infos[-1][0]["part_seg_growth"] == 1, infos
 
 
+@pytest.mark.parametrize("specialize", [0, 1])
+def test_config3_hot_keys_of_an_earlier_run_leave_no_phantom_group(specialize):
+    # a plan keeps the heavy-hitter keys it found; run again over data WITHOUT those keys (a stepping shard, a reused plan)
+    # a seeded entry no row reached must not come back as a group of zero rows
+    cols = bench.host_columns(np, "group", N_ROWS, seed=31)
+    hot = np.random.default_rng(32).random(N_ROWS) < 0.5
+    cols[1] = np.where(hot, 123, cols[1]).astype(np.int32)
+    cols[2] = np.where(hot, 45, cols[2]).astype(np.int32)
+    view = ss.View(bench.group_schema(ss), cols)
+    op = group3_op(view)
+    _s, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=specialize))
+    infos = check_plan(plan, want, "skewed, first data", ignore_order=True, runs=2)
+    assert infos[-1][0]["hot_keys"] >= 1, infos
+    cold = bench.host_columns(np, "group", N_ROWS, seed=33)
+    gone = (cold[1] == 123) & (cold[2] == 45)
+    cold[1] = np.where(gone, 7, cold[1]).astype(np.int32)            # the hot pair does not occur at all
+    view2 = ss.View(bench.group_schema(ss), cold)
+    _s, want2 = oracle.run(group3_op(view2))
+    infos = check_plan(plan, want2, "same plan, data without its hot key", ignore_order=True, runs=2, view=view2)
+    assert infos[-1][0]["hot_keys"] >= 1, infos                         # the hot pass still ran (and published nothing)
+
+
+@pytest.mark.parametrize("specialize", [0, 1])
+def test_heavy_hitters_next_to_the_key_whose_packed_value_is_all_ones(specialize):
+    # two NOT NULL INT32 keys that are both -1 pack into the EMPTY value of the tables (it has a reserved slot); with heavy
+    # hitters active the scatter's hot-set probe must not take a free slot of its table for that key
+    cols = bench.host_columns(np, "group", N_ROWS, seed=41)
+    u = np.random.default_rng(42).random(N_ROWS)
+    cols[1] = np.where(u < 0.5, 123, np.where(u < 0.502, -1, cols[1])).astype(np.int32)
+    cols[2] = np.where(u < 0.5, 45, np.where(u < 0.502, -1, cols[2])).astype(np.int32)
+    view = ss.View(bench.group_schema(ss), cols)
+    op = group3_op(view)
+    _s, want = oracle.run(op)
+    plan = ss.Plan(op, make_ctx(group_partition=2, specialize=specialize))
+    infos = check_plan(plan, want, "skewed keys + the all-ones key", ignore_order=True, runs=3)
+    assert infos[-1][0]["hot_keys"] >= 1 and infos[-1][0]["group_shape"] == 1, infos
+
+
 def test_config3_shape_with_few_groups_takes_the_slab_form():
     # same 12 aggregates over ~1000 groups: ONE whole-LDS table per aggregation workgroup, no hash partitions
     cols = bench.host_columns(np, "group", N_ROWS, seed=11)

@@ -2,6 +2,7 @@
 builder API (supersonic/supersonic.h) driven from C++ exactly as its guide tests do."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -69,6 +70,37 @@ def test_guide_style_program_builds_and_binds(guide_bin):
 @pytest.mark.gpu
 def test_guide_style_program_runs(guide_bin):
     _run(guide_bin, "run")
+
+
+# ---- the reference's OWN guide programs, unchanged: /root/reference/test/guide/{primer,group_sort}.cc are compiled where they
+# lie (nothing is copied) against -I<repo>/include and linked with libssgpu; the binaries are built in the build container
+# (also by __graft_entry__.build()) and travel to the GPU box as built artefacts, where they RUN: every TEST of the guide --
+# bound a + b, Compute, Filter, grouped aggregates with STRING + BOOL keys, Sort drained 1024 rows at a time into a Block
+# through ViewCopier -- must pass against the MI355X library ------------------------------------------------------------
+sys.path.insert(0, os.path.join(ROOT, "tests", "cpp"))
+import build_ref_guides  # noqa: E402
+
+
+@pytest.mark.parametrize("name", build_ref_guides.GUIDES)
+def test_reference_guide_compiles_and_links_unchanged(name):
+    if not os.path.exists(build_ref_guides.source(name)):
+        pytest.skip("no reference checkout here (the GPU box): the binary built in the build container is what runs")
+    out = build_ref_guides.build(name)
+    assert out and os.access(out, os.X_OK)
+    # and under -Wall -Werror as a pure syntax check of the facade's surface the guide touches
+    # (-Wno-sign-compare: the guide itself compares an int loop index with an unsigned count, group_sort.cc:550)
+    subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Werror", "-Wno-sign-compare", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "cpp", "minigtest"), build_ref_guides.source(name)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", build_ref_guides.GUIDES)
+def test_reference_guide_runs_green(name):
+    out = build_ref_guides.build(name) or build_ref_guides.binary(name)
+    if not os.path.exists(out):
+        pytest.skip("tests/cpp/_build/ref_guide_%s was not built (no reference checkout where this tree was built)" % name)
+    p = subprocess.run([out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0 and "[  PASSED  ]" in p.stdout and "FAILED" not in p.stdout, p.stdout[-4000:]
 
 
 # ---- the C++ host's multi-GPU driver (include/supersonic_amd/sharded.h): RCCL linked directly ---------------------------
