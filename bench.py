@@ -367,9 +367,11 @@ def parse_args(argv=None):
                     help="wide = configs[1] (headline); group = configs[3]'s per-GPU query (Filter -> GroupAggregate); group3 = configs[2] "
                          "(GroupAggregate alone); sort = configs[4] (Sort(d) of the 8-column block); filter_mat = materialising Filter(a > 499)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--exchange", choices=["all_gather", "key_range"], default="key_range",
-                    help="--query group on N > 1 ranks: all_gather = every partial table to every rank, every rank merges all of them; "
-                         "key_range = a partial row goes to the owner of its key (one all-to-all), every rank merges 1/N of the groups")
+    ap.add_argument("--exchange", choices=["all_gather", "key_range", "dense"], default="dense",
+                    help="--query group on N > 1 ranks: dense = dense-slot tables (SURVEY 8(e)): the ranks agree on the key ranges once, a step is "
+                         "shard scan -> ONE all-to-all of slot slices -> element-wise fold + extraction, no merge plan; all_gather = every "
+                         "packed partial table to every rank, every rank merges all of them; key_range = a partial row goes to the owner of "
+                         "its key (one all-to-all), every rank merges 1/N of the groups")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specialize", action="store_true",
@@ -581,8 +583,20 @@ def main():
     view = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in cols], rows)
     job = None
     if group and distributed:
-        from supersonic_amd.distributed import DeviceShardedGroupAggregate
-        job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], group_spec(ss), group_child(ss, view), exchange=args.exchange)
+        from supersonic_amd.distributed import DenseShardedGroupAggregate, DeviceShardedGroupAggregate, PlanDenseBackend
+        if args.exchange == "dense":
+            # ONE plan per rank -- the job's own GroupAggregate -- whose table slot of a group is the keys' mixed-radix number on every rank
+            backend = PlanDenseBackend(ctx, ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), group_spec(ss), None, group_child(ss, view)))
+            job = DenseShardedGroupAggregate(backend)
+            try:
+                job.setup(view)
+                job.first, job.capacity = backend.plan, None
+                job.result = lambda: (backend.plan, None)
+            except ss.SupersonicException as e:      # the same verdict on every rank (same plan, same agreed ranges): the image exchange
+                sys.stderr.write("[bench] dense slots do not fit this job (%s): key-range exchange\n" % e)
+                args.exchange, job = "key_range", None
+        if job is None:
+            job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], group_spec(ss), group_child(ss, view), exchange=args.exchange)
         plan = job.first
     else:
         if (args.query in ("sort", "filter_mat")) and distributed:
@@ -719,7 +733,7 @@ def main():
     groups_total = None
     if group:
         groups_total = (job.result()[0] if job is not None else plan).fetch().row_count()
-        if job is not None and args.exchange == "key_range" and world > 1:     # every rank holds the groups it owns: the table's size is their sum
+        if job is not None and args.exchange in ("key_range", "dense") and world > 1:     # every rank holds the groups it owns: the table's size is their sum
             g = torch.tensor([groups_total], device=device, dtype=torch.int64)
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             groups_total = int(g.item())
@@ -743,7 +757,9 @@ def main():
         if group:
             workload = ("%s: GroupAggregate(k1,k2; SUM/MIN/MAX x d0..d3)%s over a device-resident %d-row x 7-col "
                         "block per GPU (~1e5 groups)" % ("Q-GROUP-F" if GROUP_FILTER else "Q-GROUP", " o Filter(a>499)" if GROUP_FILTER else "", rows))
-            par = ("row-range shards x%d: per-shard GroupAggregate, ONE RCCL %s of the packed partial tables, merge plan" % (
+            par = ("row-range shards x%d: per-shard GroupAggregate into a dense-slot table, ONE RCCL all-to-all of slot slices, element-wise fold (no merge plan)" % world
+                   if distributed and args.exchange == "dense" else
+                   "row-range shards x%d: per-shard GroupAggregate, ONE RCCL %s of the packed partial tables, merge plan" % (
                        world, "all-to-all by key range (every rank merges the groups it owns)" if args.exchange == "key_range" else "all-gather")
                    if distributed else "single GPU")
             kernel = "group stage (partition scatter + per-partition aggregation kernels)"
@@ -784,6 +800,9 @@ def main():
         if job is not None:
             line["config"]["collectives_per_step"] = job.collectives
             line["config"]["image_capacity_rows"] = job.capacity
+            line["config"]["exchange"] = args.exchange
+            if args.exchange == "dense":
+                line["config"]["dense_layout"] = job.layout
         if regimes is not None:
             line["regimes"] = regimes
         if world == 1 and not distributed and args.query == "wide" and QUERY_NAME == "wide" and not args.no_configs:

@@ -105,7 +105,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 6
+#define SSGPU_ABI_VERSION 7
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -491,7 +491,9 @@ typedef struct ssgpu_stage_info {
                                bit 3 the plain partition scatter, bit 4 the resident group aggregation */
   int32_t plain_scatter;    /* the partition scatter ran as its own kernel over (partition, XCD) segments, not as a VM program */
   int32_t hot_keys;         /* heavy-hitter keys the stage aggregates apart from the hash partitions (found when a segment overflowed; ABI 6) */
-  int32_t reserved[5];
+  int32_t dense_slots;      /* > 0: the group tables are indexed by the key columns' value ranges (dense slots, ABI 7) -- this many slots; group_shape
+                               then says how they are filled: 1 partitions of slot ranges, 3 one table fed from the input columns */
+  int32_t reserved[4];
 } ssgpu_stage_info;
 int32_t ssgpu_plan_stage_count(const ssgpu_plan* plan);
 int ssgpu_plan_stage_info(const ssgpu_plan* plan, int32_t stage, ssgpu_stage_info* out);
@@ -529,8 +531,9 @@ int ssgpu_plan_set_aux_input(ssgpu_plan* plan, const ssgpu_column* cols, int32_t
 void ssgpu_interrupt(ssgpu_plan* plan);
 
 /* Multi-GPU partial aggregates (row-range shards).  For plans
- * whose root is a ScalarAggregate (or a dense-slot GroupAggregate) the run can
- * stop before finalisation and expose element-wise reducible partial buffers.
+ * whose root is a ScalarAggregate the run can stop before finalisation and expose
+ * element-wise reducible partial buffers (a GroupAggregate with dense slots has
+ * its own, table-shaped form: ssgpu_plan_run_dense below).
  * Segment `i` is `count` elements of `dtype` to be combined across ranks with
  * `reduce` (0 = sum, 1 = min, 2 = max); the caller all-reduces each segment in
  * place (RCCL) and then calls ssgpu_plan_finalize.
@@ -556,6 +559,49 @@ int32_t ssgpu_plan_partial_segments(ssgpu_plan* plan, ssgpu_partial_segment* out
  * aggregates (their value travels with the smallest / largest contributing global row id, which
  * an element-wise all-reduce cannot express). */
 int ssgpu_plan_fold_partials(ssgpu_plan* plan, const void* images, int32_t n_images);
+
+/* ---- dense-slot GroupAggregate across ranks (ABI 7; SURVEY 8(e): "slot = dense key index") ----------------------------------
+ * A GroupAggregate whose group keys are input columns with small value ranges (integers, BOOL, DATE / DATETIME, STRING codes)
+ * and whose aggregate inputs are input columns (under Filters of the form `column CMP constant`) can index its table by
+ * the keys' mixed-radix number instead of a hash: slot = sum_k (value_k - lo_k) * stride_k.  A single process does this on
+ * its own (context option "group_dense", default 1: one pass over the key columns finds the ranges on a plan's first large
+ * run; ssgpu_stage_info.dense_slots says it happened).  Across ranks it makes every shard's partial table THE SAME ARRAY, so
+ * the exchange is one all-to-all of contiguous slot slices and one element-wise fold -- no merge plan, no routing, no
+ * packed images, and DOUBLE sums cross as their raw (hi, lo) accumulators (rounded once, after the fold):
+ *
+ *   set-up   every rank: ssgpu_plan_key_ranges over its shard; the ranks agree on the union (min of lo, max of hi: any
+ *            host-side exchange) and each calls ssgpu_plan_set_dense with the SAME ranges and n_chunks = number of ranks.
+ *   step     ssgpu_plan_run_dense(shard columns, table)   table: n_chunks * chunk_bytes of device memory; chunk r = the slots
+ *                                                         rank r owns (64-byte header + keys + accumulators + counts)
+ *            ONE all-to-all of the chunks (chunk r of every rank -> rank r)
+ *            ssgpu_plan_fold_dense(received chunks, n)    folds the n images of the owned slot range and extracts them: the
+ *                                                         result holds the groups this rank owns (every group on one rank)
+ *   check    ssgpu_plan_dense_flags (after any number of steps; it synchronises): what the headers of the LAST fold carried
+ *            -- bit 1 a record segment ran full on some rank (ssgpu_plan_dense_grow on every rank, repeat the step), bit 2 a
+ *            key outside the ranges (agree on new ranges, ssgpu_plan_set_dense again, repeat), error: the OR of the ranks'
+ *            evaluation-error words.  Every rank sees the same flags: a failing rank still sends its (flagged) chunks, so no
+ *            rank returns early from a step while others wait in the collective.
+ *
+ * ssgpu_plan_key_ranges / _set_dense return SSGPU_ERROR_NOT_IMPLEMENTED for a plan this form cannot take (not a single
+ * plain GroupAggregate stage; floating keys; FIRST / LAST aggregates, whose values live in the shard that saw the row) and
+ * ssgpu_plan_set_dense returns SSGPU_ERROR_INVALID_ARGUMENT_VALUE for ranges whose table would be too large
+ * (> 2^21 slots): the caller then uses the image exchange (result images, below).  lo / hi are in an order-preserving
+ * unsigned domain (signed key columns: value XOR 2^63 after sign extension); lo[k] > hi[k] = "no value of key k seen". */
+typedef struct ssgpu_dense_layout {
+  int64_t slots;        /* product of the key spans */
+  int32_t n_parts;      /* partitions a shard aggregates in (a multiple of n_chunks) */
+  int32_t part_cap;     /* table entries per partition */
+  int64_t chunk_slots;  /* regular slots of a chunk = (n_parts / n_chunks) * part_cap; one special slot follows them */
+  int64_t chunk_bytes;  /* 64-byte header + (chunk_slots + 1) * (8 + 8 n_gaggs [+ 4 n_gaggs]) bytes, rounded to 64 */
+  int32_t n_gaggs;      /* accumulator words per group */
+  int32_t has_counts;   /* contribution counts are kept (some aggregate input is nullable) */
+} ssgpu_dense_layout;
+int ssgpu_plan_key_ranges(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int32_t* n_keys, uint64_t* lo, uint64_t* hi);
+int ssgpu_plan_set_dense(ssgpu_plan* plan, int32_t n_keys, const uint64_t* lo, const uint64_t* hi, int32_t n_chunks, ssgpu_dense_layout* out);
+int ssgpu_plan_run_dense(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows, void* table);
+int ssgpu_plan_fold_dense(ssgpu_plan* plan, const void* chunks, int32_t n_chunks, ssgpu_result** out);
+int ssgpu_plan_dense_flags(ssgpu_plan* plan, uint32_t* flags, uint32_t* error);
+int ssgpu_plan_dense_grow(ssgpu_plan* plan);
 int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
 /* ssgpu_plan_fold_partials + ssgpu_plan_finalize as ONE kernel launch (ABI 6): what follows the collective of a sharded scalar
  * aggregate is a few hundred bytes of work -- three dependent launches of it cost a measurable part of a step at the shard

@@ -860,8 +860,9 @@ class DeviceCursor : public Cursor {
   ssgpu_block* block_ = nullptr;
   ssgpu_result* res_ = nullptr;
   const View* input_ = nullptr;
-  const DeviceView* dev_ = nullptr;
+  const DeviceView* dev_ = nullptr;   // (this library's own device-resident input: shared with the caller, who may step it -- sharded.h)
   const View* aux_ = nullptr;
+  std::unique_ptr<View> input_own_, aux_own_;   // the cursor's copies of the scanned host Views
   ssgpu_block* aux_block_ = nullptr;
   internal::Dictionary dict_;   // STRING cells of the scanned Views and the plan's ConstStrings
   TupleSchema schema_;
@@ -948,7 +949,12 @@ class BasicOperation : public Operation {
     if (c->dict_.d) ssgpu_plan_set_dict(plan, c->dict_.d);   // CONCAT prints STRING inputs through the cursor's dictionary
     // SetBufferAllocator(MemoryLimit): the plan's device buffers are charged to the allocator's remaining quota
     if (const BufferAllocator* a = EffectiveAllocator()) if (a->has_quota()) ssgpu_plan_set_memory_limit(plan, static_cast<int64_t>(a->Available()));
-    c->plan_ = plan; c->input_ = b.scan; c->dev_ = b.scan_dev; c->aux_ = b.scan_aux;
+    // A cursor is self-contained, as the reference's (view_cursor.cc:69-73: the cursor holds its own copy of the View): the
+    // Operation tree and the scanned View OBJECTS may die once the cursor exists -- test/guide/primer.cc:225-290 returns a cursor
+    // from a function whose View and Operation are locals -- only the arrays the View points at must stay.
+    c->plan_ = plan; c->dev_ = b.scan_dev;
+    if (b.scan) { c->input_own_.reset(new View(*b.scan)); c->input_ = c->input_own_.get(); }
+    if (b.scan_aux) { c->aux_own_.reset(new View(*b.scan_aux)); c->aux_ = c->aux_own_.get(); }
     for (int i = 0; i < ssgpu_plan_attr_count(plan); ++i) {
       ssgpu_attr a; ssgpu_plan_attr(plan, i, &a);
       c->schema_.add_attribute(Attribute(a.name, static_cast<DataType>(a.dtype), static_cast<Nullability>(a.nullable)));

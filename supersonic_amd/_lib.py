@@ -81,7 +81,7 @@ class MemoryStats(C.Structure):
 
 class StageInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "group_shape", "part_n", "part_seg_growth", "group_wgs_per_cu", "reruns",
-                                          "sort_passes", "sort_mode", "specialized", "plain_scatter", "hot_keys")] + [("reserved", C.c_int32 * 5)]
+                                          "sort_passes", "sort_mode", "specialized", "plain_scatter", "hot_keys", "dense_slots")] + [("reserved", C.c_int32 * 4)]
 
 
 class PlanDesc(C.Structure):
@@ -101,6 +101,11 @@ class Column(C.Structure):
 
 class PartialSegment(C.Structure):
     _fields_ = [("device_ptr", C.c_void_p), ("count", C.c_int64), ("dtype", C.c_int32), ("reduce", C.c_int32)]
+
+
+class DenseLayout(C.Structure):
+    _fields_ = [("slots", C.c_int64), ("n_parts", C.c_int32), ("part_cap", C.c_int32), ("chunk_slots", C.c_int64), ("chunk_bytes", C.c_int64),
+                ("n_gaggs", C.c_int32), ("has_counts", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -172,6 +177,12 @@ SYMBOLS = [
     ("ssgpu_plan_run_partial", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64]),
     ("ssgpu_plan_partial_segments", C.c_int32, [P, C.POINTER(PartialSegment), C.c_int32]),
     ("ssgpu_plan_fold_partials", C.c_int, [P, P, C.c_int32]),
+    ("ssgpu_plan_key_ranges", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("ssgpu_plan_set_dense", C.c_int, [P, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, C.POINTER(DenseLayout)]),
+    ("ssgpu_plan_run_dense", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, P]),
+    ("ssgpu_plan_fold_dense", C.c_int, [P, P, C.c_int32, C.POINTER(P)]),
+    ("ssgpu_plan_dense_flags", C.c_int, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("ssgpu_plan_dense_grow", C.c_int, [P]),
     ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
     ("ssgpu_plan_fold_finalize", C.c_int, [P, P, C.c_int32, C.POINTER(P)]),
     ("ssgpu_plan_image_layout", C.c_int, [P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

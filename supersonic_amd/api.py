@@ -1190,6 +1190,49 @@ class Plan(object):
         k = self.lib.ssgpu_plan_partial_segments(self.handle, segs, 16)
         return [(segs[i].device_ptr, segs[i].count, segs[i].dtype, segs[i].reduce) for i in range(k)]
 
+    # ---- dense-slot GroupAggregate across ranks (ssgpu.h: ssgpu_plan_key_ranges ... ssgpu_plan_dense_grow) ----------------
+    def key_ranges(self, view):
+        """Value ranges of the group keys over `view` (united with what this plan has seen before): [(lo, hi)] in the order-
+        preserving unsigned domain of ssgpu.h (lo > hi: no value).  NOT_IMPLEMENTED for plans the dense form cannot take."""
+        cols, n, rows = self._columns_for(view)
+        nk = C.c_int32(0)
+        lo = (C.c_uint64 * 8)()
+        hi = (C.c_uint64 * 8)()
+        self.ctx.check(self.lib.ssgpu_plan_key_ranges(self.handle, cols, n, rows, C.byref(nk), lo, hi))
+        return [(int(lo[k]), int(hi[k])) for k in range(nk.value)]
+
+    def set_dense(self, ranges, n_chunks):
+        """Lay the group table out for these key ranges, in n_chunks slot ranges (one per rank); returns the layout."""
+        n = len(ranges)
+        lo = (C.c_uint64 * max(n, 1))(*[r[0] for r in ranges])
+        hi = (C.c_uint64 * max(n, 1))(*[r[1] for r in ranges])
+        lay = L.DenseLayout()
+        self.ctx.check(self.lib.ssgpu_plan_set_dense(self.handle, n, lo, hi, n_chunks, C.byref(lay)))
+        return {f: getattr(lay, f) for f, _t in L.DenseLayout._fields_}
+
+    def run_dense(self, view, table_ptr):
+        """This shard's partial table into the caller's chunked device buffer (n_chunks * chunk_bytes); nothing is read back."""
+        cols, n, rows = self._columns_for(view)
+        self.ctx.check(self.lib.ssgpu_plan_run_dense(self.handle, cols, n, rows, C.c_void_p(table_ptr)))
+
+    def fold_dense(self, chunks_ptr, n_chunks):
+        """Fold the n_chunks images of the slot range this rank owns (what the all-to-all delivered) and extract its groups."""
+        res = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_plan_fold_dense(self.handle, C.c_void_p(chunks_ptr), n_chunks, C.byref(res)))
+        self._result = res
+        return res
+
+    def dense_flags(self):
+        """(flags, error) the last fold's chunk headers carried; synchronises.  flags: 2 = a record segment ran full, 4 = a key
+        outside the ranges -- on SOME rank; every rank reads the same words."""
+        f = C.c_uint32(0)
+        e = C.c_uint32(0)
+        self.ctx.check(self.lib.ssgpu_plan_dense_flags(self.handle, C.byref(f), C.byref(e)))
+        return f.value, e.value
+
+    def dense_grow(self):
+        self.ctx.check(self.lib.ssgpu_plan_dense_grow(self.handle))
+
     def fold_partials(self, images_ptr, n_images):
         """Fold n_images all-gathered images of the partial state (device pointer) into this plan's state."""
         self.ctx.check(self.lib.ssgpu_plan_fold_partials(self.handle, C.c_void_p(images_ptr), n_images))

@@ -153,7 +153,7 @@ struct Stage {
   // `column CMP constant`, and there is no join.  Record layout = part_scatter's, so phase 2 is the same kernel.
   struct PlainScatter {
     bool ok = false;
-    struct Key { int col; uint32_t width, shift, bits, nullbit; bool nullable; };
+    struct Key { int col; uint32_t width, shift, bits, nullbit; bool nullable; int dtype = 0; };
     struct Field { int col; bool is_null_mask; uint32_t width, off; };
     struct Pred { int col; int kind /* 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64, 6 one byte (BOOL) */; int cmp /* 0 <, 1 <=, 2 ==, 3 != */; bool col_on_left; bool nullable; uint64_t bits; };
     std::vector<Key> keys; std::vector<Field> fields; std::vector<Pred> preds;

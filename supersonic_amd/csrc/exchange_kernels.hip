@@ -167,3 +167,90 @@ hipError_t ssgpu_launch_unpack_images(const ImageUnpackParams& P, hipStream_t s)
   hipLaunchKernelGGL(ssgpu_unpack_images_kernel, dim3(bx, P.n_pieces + 1, std::max<u32>(P.n_images, 1)), dim3(256), 0, s, P);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Dense-slot tables across ranks (DenseKeyMap / DenseFoldParams in launch.h; SURVEY 8(e): partial tables that share a
+// deterministic slot function combine element by element).  After ONE all-to-all of equally shaped table chunks a rank
+// holds n_chunks images of the slot range it owns; this kernel folds them, word by word with the word's merge function,
+// into the table the usual extraction reads.  DOUBLE sums cross as their raw (hi, lo) accumulator pairs and are added in
+// double-double, so a group's sum is rounded once, at the extraction -- whatever the number of shards (the reference is
+// single-process: cursor/core/aggregate_groups.cc:332-433 keeps one accumulator per group; this is its N-way restatement).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double u2d_x(u64 v) { return __longlong_as_double((long long)v); }
+__device__ __forceinline__ u64 d2u_x(double v) { return (u64)__double_as_longlong(v); }
+__global__ __launch_bounds__(256) void ssgpu_dense_fold_kernel(const DenseFoldParams P) {
+  const u64 n_slots = (u64)P.slots + 1ull, ng = P.n_gaggs, n_words = n_slots * ng;
+  const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      u32 flags = 0, err = 0;
+      for (u32 c = 0; c < P.n_chunks; ++c) {
+        const u32* h = reinterpret_cast<const u32*>(static_cast<const char*>(P.chunks) + (u64)c * P.chunk_bytes);
+        flags |= h[0]; err |= h[1];
+      }
+      P.flags_out[0] = flags; P.flags_out[1] = err;   // (what THIS fold's headers carried)
+    }
+    for (int q = 0; q < 2; ++q) for (u32 w = threadIdx.x; w < P.n_clear[q]; w += 256u) P.clear[q][w] = 0u;
+  }
+  if (i >= n_words) return;
+  const u64 slot = i / ng; const u32 w = (u32)(i - slot * ng);
+  const u64 keys_off = SSGPU_DENSE_HEADER, acc_off = keys_off + n_slots * 8ull, cnt_off = acc_off + n_words * 8ull;
+  const u32 op = P.merge_op[w];
+  if (w == 0) {
+    u64 key = ~0ull;   // VM_KEY_EMPTY
+    for (u32 c = 0; c < P.n_chunks; ++c) {
+      const u64 k = reinterpret_cast<const u64*>(static_cast<const char*>(P.chunks) + (u64)c * P.chunk_bytes + keys_off)[slot];
+      if (k != ~0ull) key = k;
+    }
+    P.keys[slot] = key;
+  }
+  if (P.any_cnt) {
+    u32 n = 0;
+    for (u32 c = 0; c < P.n_chunks; ++c) n += reinterpret_cast<const u32*>(static_cast<const char*>(P.chunks) + (u64)c * P.chunk_bytes + cnt_off)[i];
+    P.cnt[i] = n;
+  }
+  if (op == 3u /* VM_MERGE_ADD_F64 */ && w > 0 && P.merge_op[w - 1] == 4u /* VM_MERGE_ADD_F64_HI */) return;   // the low word of a pair: written with its high word
+  const u64* a0 = reinterpret_cast<const u64*>(static_cast<const char*>(P.chunks) + acc_off);
+  u64 v = a0[i];
+  if (op == 4u) {
+    double hi = u2d_x(v), lo = u2d_x(a0[i + 1]);
+    for (u32 c = 1; c < P.n_chunks; ++c) {
+      const u64* a = reinterpret_cast<const u64*>(static_cast<const char*>(P.chunks) + (u64)c * P.chunk_bytes + acc_off);
+      const double bh = u2d_x(a[i]), bl = u2d_x(a[i + 1]);
+      const double s = hi + bh, bb = s - hi;
+      double e = (hi - (s - bb)) + (bh - bb);     // TwoSum: s + e == hi + bh exactly
+      e += lo + bl;
+      const double h2 = s + e;
+      lo = e - (h2 - s); hi = h2;
+    }
+    P.acc[i] = d2u_x(hi); P.acc[i + 1] = d2u_x(lo);
+    return;
+  }
+  for (u32 c = 1; c < P.n_chunks; ++c) {
+    const u64 b = reinterpret_cast<const u64*>(static_cast<const char*>(P.chunks) + (u64)c * P.chunk_bytes + acc_off)[i];
+    if (op == 0u) v += b;
+    else if (op == 1u) v = b < v ? b : v;
+    else if (op == 2u) v = b > v ? b : v;
+    else v = d2u_x(u2d_x(v) + u2d_x(b));
+  }
+  P.acc[i] = v;
+}
+hipError_t ssgpu_launch_dense_fold(const DenseFoldParams& P, hipStream_t stream) {
+  const u64 n_words = ((u64)P.slots + 1ull) * P.n_gaggs;
+  const unsigned int blocks = (unsigned int)std::max<u64>((n_words + 255) / 256, 1);
+  hipLaunchKernelGGL(ssgpu_dense_fold_kernel, dim3(blocks), dim3(256), 0, stream, P);
+  return hipGetLastError();
+}
+// the header of every chunk of a freshly filled table buffer: the run's overflow / domain-miss flags and its evaluation-error word
+__global__ void ssgpu_dense_headers_kernel(char* chunks, u32 n_chunks, u64 chunk_bytes, const u32* __restrict__ overflow4, const u32* __restrict__ error_flag) {
+  const u32 flags = (overflow4[0] ? 1u : 0u) | (overflow4[1] ? 2u : 0u) | (overflow4[3] ? 4u : 0u);
+  const u32 err = error_flag ? *error_flag : 0u;
+  for (u32 c = threadIdx.x; c < n_chunks; c += blockDim.x) {
+    u32* h = reinterpret_cast<u32*>(chunks + (u64)c * chunk_bytes);
+    h[0] = flags; h[1] = err;
+  }
+}
+hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsigned long long chunk_bytes, const unsigned int* overflow4, const unsigned int* error_flag, hipStream_t stream) {
+  hipLaunchKernelGGL(ssgpu_dense_headers_kernel, dim3(1), dim3(64), 0, stream, static_cast<char*>(chunks), n_chunks, (u64)chunk_bytes, overflow4, error_flag);
+  return hipGetLastError();
+}

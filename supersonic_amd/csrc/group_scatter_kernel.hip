@@ -33,6 +33,7 @@
 #define PS_REC_WORDS kPsRecWords
 #define PS_REC_INV kPsRecInv
 #define PS_NPARTS kPsNParts
+#define PS_DENSE (kPsDense != 0u)
 #define PS_UNROLL _Pragma("unroll")
 #else
 #define PS_NKEYS P.n_keys
@@ -50,6 +51,7 @@
 #define PS_REC_WORDS P.rec_words
 #define PS_REC_INV P.rec_inv
 #define PS_NPARTS P.n_parts
+#define PS_DENSE (P.dense.on != 0u)
 #define PS_UNROLL
 #endif
 
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
   const u32 nf = PS_NFIELDS;
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * T;
-    u64 key[R]; u64 fv[R][REGF]; u32 pt[R], pos[R]; bool ok[R];
+    u64 key[R]; u64 fv[R][REGF]; u32 pt[R], pos[R]; bool ok[R]; bool miss = false;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const u64 row = base + (u64)j * THREADS + t;
@@ -167,6 +169,14 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
           i = (i + 1u) & (SSGPU_HOT_SLOTS - 1u);
         }
       }
+      if (PS_DENSE) {   // (uniform) dense slots: the record carries the group's dense index, partition = index % NP
+        u32 idx;
+        const bool in = ssgpu_dense_index(P.dense, key[j], &idx);
+        if (ok[j] && !in) miss = true;
+        ok[j] = ok[j] && in;
+        (void)ssgpu_dense_entry(P.dense, idx, &pt[j]);
+        key[j] = (u64)idx;
+      } else
       pt[j] = part_of(key[j], NP);
       pos[j] = 0u;
       if (ok[j]) pos[j] = atomicAdd(&cnt[pt[j]], 1u);
@@ -206,12 +216,13 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
       }
     }
     if (over) atomicExch(P.overflow, 1u);
+    if (miss) atomicExch(P.overflow + 2, 1u);   // a key outside the dense ranges: the host widens them and repeats the run
     for (u32 i = t; i < NP; i += THREADS) cnt[i] = 0u;   // (read last before the barrier above; next written after the one below)
     __syncthreads();
     const u32 words = start[NP] * wpr;
     const u64* sw = reinterpret_cast<const u64*>(stage);
     for (u32 w = t; w < words; w += THREADS) {
-      const u32 j = __umulhi(w, PS_REC_INV), f = w - j * wpr;
+      const u32 j = wpr == 1u ? w : __umulhi(w, PS_REC_INV), f = w - j * wpr;   // (one-word records -- the key alone, COUNT(*) queries: 2^32 / 1 + 1 does not fit rec_inv)
       const u32 g = grec[j];
       if (g != VM_NONE) P.recs[(u64)g * wpr + f] = sw[w];
     }
@@ -375,6 +386,55 @@ __global__ __launch_bounds__(1024) void ssgpu_hot_keys_kernel(const PlainScatter
 }
 hipError_t ssgpu_launch_hot_keys(const PlainScatterParams& S, unsigned long long n_sample, unsigned int min_count, unsigned long long* out, hipStream_t stream) {
   hipLaunchKernelGGL(ssgpu_hot_keys_kernel, dim3(1), dim3(1024), 0, stream, S, (u64)n_sample, min_count, (u64*)out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Value ranges of the key columns (DenseKeyMap in launch.h): one streaming read of the key columns, min / max in an
+// order-preserving unsigned domain (signed columns: sign bit flipped), wave reduction, one atomic per wave and word.
+// out = [min x n_keys][max x n_keys][non-NULL rows x n_keys], initialised by the launcher.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ssgpu_key_domain_kernel(const PlainScatterParams P, const u32 signed_mask, u64* __restrict__ out) {
+  const u64 n = P.n_rows;
+  const u32 nk = P.n_keys;
+  u64 lo[SSGPU_PSCAT_MAX_KEYS], hi[SSGPU_PSCAT_MAX_KEYS], cnt[SSGPU_PSCAT_MAX_KEYS];
+#pragma unroll
+  for (u32 k = 0; k < SSGPU_PSCAT_MAX_KEYS; ++k) { lo[k] = ~0ull; hi[k] = 0ull; cnt[k] = 0ull; }
+  for (u64 row = (u64)blockIdx.x * 1024u + threadIdx.x; row < n; row += (u64)gridDim.x * 1024u) {
+#pragma unroll
+    for (u32 k = 0; k < SSGPU_PSCAT_MAX_KEYS; ++k) {
+      if (k >= nk) break;
+      const u32 kw = P.keys[k].width;
+      const bool sgn = (signed_mask >> k) & 1u;
+      u64 a = kw == 8 ? reinterpret_cast<const u64*>(P.keys[k].data)[row]
+            : kw == 4 ? (sgn ? (u64)(i64)reinterpret_cast<const i32*>(P.keys[k].data)[row] : (u64)reinterpret_cast<const u32*>(P.keys[k].data)[row])
+                      : (u64)reinterpret_cast<const u8*>(P.keys[k].data)[row];
+      if (sgn) a ^= 0x8000000000000000ull;
+      const bool is_null = P.keys[k].nulls && P.keys[k].nulls[row];
+      if (!is_null) { lo[k] = a < lo[k] ? a : lo[k]; hi[k] = a > hi[k] ? a : hi[k]; cnt[k] += 1ull; }
+    }
+  }
+  const u32 lane = threadIdx.x & 63u;
+#pragma unroll
+  for (u32 k = 0; k < SSGPU_PSCAT_MAX_KEYS; ++k) {
+    if (k >= nk) break;
+    u64 l = lo[k], h = hi[k], c = cnt[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const u64 ol = __shfl_xor(l, d), oh = __shfl_xor(h, d), oc = __shfl_xor(c, d);
+      l = ol < l ? ol : l; h = oh > h ? oh : h; c += oc;
+    }
+    if (lane == 0 && c) { atomicMin(&out[k], l); atomicMax(&out[nk + k], h); atomicAdd(&out[2u * nk + k], c); }
+  }
+}
+hipError_t ssgpu_launch_key_domain(const PlainScatterParams& S, const unsigned int* is_signed, unsigned long long* out, int grid, hipStream_t stream) {
+  unsigned int mask = 0;
+  for (unsigned int k = 0; k < S.n_keys; ++k) if (is_signed[k]) mask |= 1u << k;
+  hipError_t e = hipMemsetAsync(out, 0xFF, (size_t)S.n_keys * 8, stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(out + S.n_keys, 0, (size_t)S.n_keys * 16, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ssgpu_key_domain_kernel, dim3((unsigned)(grid > 0 ? grid : 1)), dim3(1024), 0, stream, S, mask, (u64*)out);
   return hipGetLastError();
 }
 

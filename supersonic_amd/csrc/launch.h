@@ -47,6 +47,24 @@ struct GroupExtractParams {
 // records (rec_words x 8 bytes each, word 0 = packed key) sit in n_segs segments of seg_cap records:
 // segment (part, g) at record (part * n_segs + g) * seg_cap holds counts[part * n_segs + g] records.
 #define SSGPU_PART_THREADS 1024
+// Dense slots ("slot = dense key index"): when the value ranges of a plain stage's key columns are small, a group's
+// table slot is a mixed-radix number over them -- idx = sum_k off_k * stride_k, off_k = value - lo_k (the last of a NULLABLE
+// key's span_k offsets is its NULL) -- instead of a hash of the packed key.  No key is stored or compared while rows are
+// aggregated (a record carries idx where the hashed form carries the packed key), partition = idx % n_parts and LDS entry
+// = idx / n_parts are exact, every table of a job -- every run, every shard -- has the SAME slot for a group, so partial
+// tables of different ranks combine element by element.  The packed key is rebuilt from idx when a table is dumped.
+// A row outside the ranges raises the stage's domain-miss flag (the host widens the ranges and repeats the run).
+#define SSGPU_DENSE_MAX_SLOTS (1u << 21)
+struct DenseKeyMap {
+  unsigned int on, n_keys;
+  unsigned int n_parts, parts_inv;    // parts_inv = floor(2^32 / n_parts) + 1
+  unsigned int chunk_parts;           // partitions per table chunk: partition p dumps into chunk p / chunk_parts (1 chunk: all of them)
+  unsigned int part_cap;              // table entries of a partition (index / n_parts < part_cap)
+  unsigned int chunk_slots;           // regular slots of a chunk (chunk_parts * part_cap); its special slot follows them
+  unsigned int pad0;
+  unsigned long long chunk_stride;    // bytes from a chunk's keys / accumulators / counts to the next chunk's
+  struct Key { unsigned long long lo; unsigned int span, stride, shift, bits, nullbit, pad; } keys[8];
+};
 // widest partition record, in 8-byte words: 8- and 16-word kernels serve the scans; the 20-word build exists for the merge of
 // sharded partial tables (key + 16 value columns = 17 words), whose rows all belong to different groups -- through the global
 // table that is one atomic per value, in partitions' LDS tables a tenth of it.  Records beyond 16 words take the plain scatter only.
@@ -72,8 +90,47 @@ struct PartAggParams {
   // every other key are skipped (they go through the partition scatter, which in turn skips the hot ones) -- and entry e is
   // merged into global slot hot_base + e (dense slots behind the partitions' ranges) instead of a hashed slot.
   unsigned int hot_only, hot_base;
+  DenseKeyMap dense;                  // dense.on: word 0 of a record is the group's dense index, not its packed key
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+// packed key -> dense index; false: the key lies outside the ranges (idx then addresses slot 0 and must not be used)
+__device__ __forceinline__ bool ssgpu_dense_index(const DenseKeyMap& D, unsigned long long key, unsigned int* idx) {
+  unsigned int i = 0; bool in = true;
+  for (unsigned int k = 0; k < D.n_keys; ++k) {
+    const DenseKeyMap::Key K = D.keys[k];
+    const unsigned long long mask = K.bits >= 64u ? ~0ull : ((1ull << K.bits) - 1ull);
+    unsigned long long off = ((key >> K.shift) - K.lo) & mask;     // value - lo modulo 2^bits: the offset inside the range, in either signedness
+    const bool nullable = K.nullbit != 0xFFu;
+    const bool is_null = nullable && ((key >> K.nullbit) & 1ull);
+    const unsigned int values = nullable ? K.span - 1u : K.span;
+    if (is_null) off = K.span - 1u;
+    else if (off >= values) { in = false; off = 0; }
+    i += (unsigned int)off * K.stride;
+  }
+  *idx = i;
+  return in;
+}
+__device__ __forceinline__ unsigned long long ssgpu_dense_key_of(const DenseKeyMap& D, unsigned int idx) {
+  unsigned long long key = 0ull;
+  for (unsigned int k = 0; k < D.n_keys; ++k) {
+    const DenseKeyMap::Key K = D.keys[k];
+    const unsigned long long mask = K.bits >= 64u ? ~0ull : ((1ull << K.bits) - 1ull);
+    const unsigned int off = (idx / K.stride) % K.span;
+    if (K.nullbit != 0xFFu && off == K.span - 1u) key |= 1ull << K.nullbit;
+    else key |= ((K.lo + off) & mask) << K.shift;
+  }
+  return key;
+}
+// idx -> (partition, entry): partition = idx % n_parts, entry = idx / n_parts
+__device__ __forceinline__ unsigned int ssgpu_dense_entry(const DenseKeyMap& D, unsigned int idx, unsigned int* part) {
+  if (D.n_parts == 1u) { *part = 0u; return idx; }   // (one table of all slots; 2^32 / 1 + 1 does not fit parts_inv)
+  unsigned int q = __umulhi(idx, D.parts_inv);
+  if (q * D.n_parts > idx) --q;
+  *part = idx - q * D.n_parts;
+  return q;
+}
+#endif
 
 // Partitioned GroupAggregate, first phase as a kernel of its own (not a tile-VM program) for "plain" stages: records are
 // assembled straight from the input columns.  One 1024-thread workgroup per CU takes tiles of 2048 (1024) rows, ranks
@@ -101,7 +158,27 @@ struct PlainScatterParams {
   // heavy hitters: rows whose packed key is one of these are NOT scattered (ssgpu_group_resident_kernel, hot_only, aggregates them)
   unsigned int n_hot, hot_pad;
   unsigned long long hot_keys[SSGPU_HOT_MAX];
+  DenseKeyMap dense;            // dense.on: partition and record key word are the group's dense index (overflow[2] = a row outside the ranges)
 };
+// Value ranges of a plain stage's key columns over ALL rows (predicates not applied: a superset is as good), for DenseKeyMap:
+// out[k] = smallest value of key k, out[n_keys + k] = largest -- in an order-preserving UNSIGNED domain (a signed column's,
+// is_signed[k], values with their sign bit flipped) -- out[2 n_keys + k] = its rows that are not NULL (0: no value at all).
+// out must hold 3 * n_keys words; the launcher initialises them.
+hipError_t ssgpu_launch_key_domain(const PlainScatterParams& S, const unsigned int* is_signed, unsigned long long* out, int grid, hipStream_t stream);
+// Sharded dense tables (ssgpu_plan_run_dense / ssgpu_plan_fold_dense): every chunk of a table buffer starts with a 64-byte header
+// -- [0] flags of the run that filled it (bit 0 table overflow, bit 1 segment overflow, bit 2 a row outside the key ranges),
+// [1] the stage's evaluation-error word -- then keys[slots + 1], acc[(slots + 1) * ng], cnt[(slots + 1) * ng] (when counts are kept).
+#define SSGPU_DENSE_HEADER 64
+struct DenseFoldParams {
+  const void* chunks; unsigned int n_chunks, n_gaggs, any_cnt, slots;   // n_chunks images of ONE slot range (slots regular slots + the special one)
+  unsigned long long chunk_bytes;
+  unsigned long long* keys; unsigned long long* acc; unsigned int* cnt;   // the folded table (slots + 1 entries)
+  const unsigned int* merge_op;
+  unsigned int* flags_out;      // [0] |= the chunks' flags, [1] |= their error words
+  unsigned int* clear[2]; unsigned int n_clear[2];   // words this launch also zeroes (the extraction's control words)
+};
+hipError_t ssgpu_launch_dense_fold(const DenseFoldParams& P, hipStream_t stream);
+hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsigned long long chunk_bytes, const unsigned int* overflow4, const unsigned int* error_flag, hipStream_t stream);
 // Heavy-hitter detection: one workgroup counts the packed keys of `n_sample` rows taken at a regular stride (predicates
 // applied) and reports the keys seen at least `min_count` times -- at most SSGPU_HOT_MAX, the most frequent ones.
 // out[0] = number of keys, out[1 + 2 i] = key i, out[2 + 2 i] = its count in the sample.
@@ -157,6 +234,7 @@ struct GroupInitParams {
   unsigned long long* acc; const unsigned long long* pattern; unsigned int ng; unsigned long long n_acc;
   unsigned int* cnt; unsigned long long n_cnt;
   unsigned int* z[4]; unsigned long long nz[4];
+  unsigned int n_rep, pad; unsigned long long rep_stride;   // keys / acc / cnt ranges repeated n_rep MORE times, rep_stride bytes apart (the chunks of a dense table buffer)
 };
 hipError_t ssgpu_launch_group_init(const GroupInitParams& P, hipStream_t stream);
 
@@ -172,7 +250,8 @@ void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, 
                            int n_staged, uint32_t static_lds, std::string* why);
 hipError_t ssgpu_launch_pipeline_rtc(void* handle, const VmParams& P, int grid, bool static_lds, hipStream_t stream);
 void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
-                                    unsigned int lds_bytes, std::string* why, const PlainScatterParams* source = nullptr);   // source: the resident form (reads the input columns)
+                                    unsigned int lds_bytes, std::string* why, const PlainScatterParams* source = nullptr,   // source: the resident form (reads the input columns)
+                                    bool dense = false);                                                                    // dense: records carry dense indices (DenseKeyMap), no probe
 hipError_t ssgpu_launch_group_resident_rtc(void* handle, const PartAggParams& A, const PlainScatterParams& S, int grid, hipStream_t stream);
 hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
 void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int rows_per_thread, unsigned int lds_bytes, std::string* why);

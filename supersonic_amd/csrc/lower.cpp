@@ -1576,7 +1576,7 @@ static Status build_partition_programs(const Pipe& pipe, const std::vector<int>&
       const BExprP& ke = pipe.cols[kpos[k]].expr;
       const GroupKeyField& f = st->group_keys[k];
       if (ke->kind != BExpr::INPUT || (uint32_t)dtype_width(ke->dtype) != f.width) { pl.ok = false; break; }
-      pl.keys.push_back(Stage::PlainScatter::Key{ke->input_col, f.width, f.shift, f.bits, f.nullbit, f.nullbit != 0xFF});
+      pl.keys.push_back(Stage::PlainScatter::Key{ke->input_col, f.width, f.shift, f.bits, f.nullbit, f.nullbit != 0xFF, (int)ke->dtype});
     }
     for (size_t q = 1; pl.ok && q < fields.size(); ++q) {   // field 0 is the packed key
       auto it = staged_of_reg.find(fields[q].reg);

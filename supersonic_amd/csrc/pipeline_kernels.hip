@@ -1203,6 +1203,7 @@ __device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, 
 #define PART_NAGGS(P) kPartNAggs
 #define PART_AGG_LOOP _Pragma("unroll") for (u32 s = 0; s < kPartNAggs; ++s)
 #define PART_DESC(s) kPartDesc[s]
+#define PART_DENSE(P) (kPartDense != 0u)
 #else
 #define PART_NG(P) (P).n_gaggs
 #define PART_W(P) (P).rec_words
@@ -1210,6 +1211,7 @@ __device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, 
 #define PART_NAGGS(P) (P).n_aggs
 #define PART_AGG_LOOP for (u32 s = 0; s < n_aggs; ++s)
 #define PART_DESC(s) readlane64(mydesc, (int)(s))
+#define PART_DENSE(P) ((P).dense.on != 0u)
 #endif
 #ifndef FKEY   /* (vm_body.inc defines the same for the pipeline kernel's GAGG handlers) */
 #define FKEY(d) ({ u64 b_ = d2u((double)(d)); (b_ & 0x8000000000000000ull) ? ~b_ : (b_ | 0x8000000000000000ull); })
@@ -1447,6 +1449,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   u64 trip_limit = row_limit;
   u32 nan_acc = 0;                 // this lane met a NaN in a floating MIN / MAX
   u64 touched = 0;                 // hot_only: the seeded entries this lane's rows reached (local_capacity = SSGPU_HOT_SLOTS = 64)
+  bool miss = false;               // dense slots: a row whose key lies outside the ranges
 #ifdef SSGPU_RTC_PART_PLAIN
   // Trip k issues the loads of tile k and aggregates tile k - 1 (one more trip than tiles; the first aggregates nothing).
   // There is deliberately no load ahead of the loop: loads pending on entry made the compiler wait, in every trip, for
@@ -1533,13 +1536,31 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
       }
     }
     }
+    if constexpr (PLAIN) {
+      if (PART_DENSE(P)) {   // dense slots: the packed key becomes the group's dense index (outside every divergent region: a uniform loop over the keys)
+#pragma unroll
+        for (int j = 0; j < PART_ROWS; ++j) {
+          u32 idx;
+          const bool in = ssgpu_dense_index(P.dense, rec[j][0], &idx);
+          miss = miss || (live[j] && !in);
+          live[j] = live[j] && in;
+          rec[j][0] = (u64)idx;
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < PART_ROWS; ++j) {
       li[j] = C * st;
       const u64 key = rec[j][0];
       if (P.debug & 2u) { li[j] = __umulhi(hash_local(key), C) * st; continue; }   // development: no probe
       if (live[j]) {
-        if (PLAIN && P.hot_only) {
+        if (PART_DENSE(P)) {
+          // no probe: the entry IS the index (one table of all slots) or index / partitions; the key word only marks the entry used
+          u32 pp;
+          const u32 e = P.slab_segs ? (u32)key : ssgpu_dense_entry(P.dense, (u32)key, &pp);
+          li[j] = e * st;
+          lkeys[e] = 0ull;
+        } else if (PLAIN && P.hot_only) {
           // only the seeded keys have an entry: an EMPTY entry on the probe path means "not a heavy hitter" -- the row belongs to the scatter
           u32 i = __umulhi(hash_local(key), C), found = 0xFFFFFFFFu;
           if (key != VM_KEY_EMPTY)
@@ -1637,6 +1658,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
     }
   }
   if (nan_acc && P.nan_flag) atomicOr(P.nan_flag, SSGPU_FLAG_NAN_IN_MINMAX);
+  if (miss) atomicExch(P.T.overflow + 3, 1u);   // the host widens the ranges and repeats the run
   if constexpr (PLAIN) {
     if (P.hot_only && touched) {
       if ((u32)touched) __hip_atomic_fetch_or(wsum, (u32)touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1647,6 +1669,36 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   if (P.slab_segs) {
     // slab mode: every workgroup saw (a slab of) all groups: merge the occupied entries into the global table, one
     // atomic per (group, accumulator word) -- the direct path's end-of-kernel merge
+    if (PART_DENSE(P)) {
+      // one table of all dense slots: entry e = index e.  Its global slot follows the job-wide layout (partition = index % n_parts,
+      // chunk = partition / chunk_parts), so every table of the job is the same array; the packed key is rebuilt from the index
+      for (u32 e0 = 0; e0 < C; e0 += SSGPU_PART_THREADS) {
+        const u32 e = e0 + t, ec = e < C ? e : 0u;
+        const u64 packed = ssgpu_dense_key_of(P.dense, ec);       // (uniform loops: outside the divergent part)
+        u32 pp; const u32 q = ssgpu_dense_entry(P.dense, ec, &pp);
+        const u32 chunk = pp / P.dense.chunk_parts;
+        const bool used = e < C && lkeys[ec] != VM_KEY_EMPTY;
+        if (used) {
+          const u32 gs = packed == VM_KEY_EMPTY ? P.dense.chunk_slots : (pp - chunk * P.dense.chunk_parts) * P.dense.part_cap + q;
+          u64* const keys_c = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.T.keys) + (u64)chunk * P.dense.chunk_stride);
+          u64* const acc_c = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.T.acc) + (u64)chunk * P.dense.chunk_stride);
+          u32* const cnt_c = reinterpret_cast<u32*>(reinterpret_cast<char*>(P.T.cnt) + (u64)chunk * P.dense.chunk_stride);
+          keys_c[gs] = packed == VM_KEY_EMPTY ? 0ull : packed;
+          for (u32 s = 0; s < ng; ++s) {
+            const u64 v = lacc[(size_t)e * st + s];
+            u64* A = &acc_c[(u64)gs * ng + s];
+            const u32 op = P.T.merge_op[s];
+            if (op == VM_MERGE_ADD_U64) { if (v) atomicAdd(A, v); }
+            else if (op == VM_MERGE_MIN_U64) atomicMin(A, v);
+            else if (op == VM_MERGE_MAX_U64) atomicMax(A, v);
+            else if (op == VM_MERGE_ADD_F64_HI) dd_atomic_add(reinterpret_cast<double*>(A), u2d(v));
+            else unsafeAtomicAdd(reinterpret_cast<double*>(A), u2d(v));
+            if (P.any_cnt) { const u32 c = lcnt[(size_t)e * st + s]; if (c) atomicAdd(&cnt_c[(u64)gs * ng + s], c); }
+          }
+        }
+      }
+      return;
+    }
     for (u32 e = t; e <= C; e += SSGPU_PART_THREADS) {
       const u64 key = lkeys[e];
       if (key == VM_KEY_EMPTY) continue;
@@ -1669,6 +1721,43 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         else if (op == VM_MERGE_ADD_F64_HI) dd_atomic_add(reinterpret_cast<double*>(A), u2d(v));
         else unsafeAtomicAdd(reinterpret_cast<double*>(A), u2d(v));
         if (P.any_cnt) { const u32 c = lcnt[(size_t)e * st + s]; if (c) atomicAdd(&P.T.cnt[(u64)gs * ng + s], c); }
+      }
+    }
+    return;
+  }
+  if (PART_DENSE(P)) {
+    // dense slots: entry e of partition `part` is index e * n_parts + part; it lands in slot (part % chunk_parts) * C + e of chunk
+    // part / chunk_parts with its packed key rebuilt (an index whose packed key is the EMPTY value goes to the chunk's special slot)
+    const u32 chunk = part / P.dense.chunk_parts, pin = part - chunk * P.dense.chunk_parts;
+    u64* const keys_c = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.T.keys) + (u64)chunk * P.dense.chunk_stride);
+    u64* const acc_c = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.T.acc) + (u64)chunk * P.dense.chunk_stride);
+    u32* const cnt_c = reinterpret_cast<u32*>(reinterpret_cast<char*>(P.T.cnt) + (u64)chunk * P.dense.chunk_stride);
+    LDS_AS u32* const s_special = wsum + 2;   // (scan scratch, free by now) the entry whose packed key is the EMPTY value, if it was used
+    if (t == 0) *s_special = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 e0 = 0; e0 < C; e0 += SSGPU_PART_THREADS) {
+      const u32 e = e0 + t, ec = e < C ? e : 0u;
+      const u64 packed = ssgpu_dense_key_of(P.dense, ec * P.dense.n_parts + part);
+      if (e < C) {
+        const bool used = lkeys[e] != VM_KEY_EMPTY;
+        const bool special = used && packed == VM_KEY_EMPTY;
+        if (special) *s_special = e;
+        keys_c[(u64)pin * C + e] = (used && !special) ? packed : VM_KEY_EMPTY;
+      }
+    }
+    for (u32 i = t; i < C * ng; i += SSGPU_PART_THREADS) {
+      const u32 l = (i / ng) * st + i % ng;
+      acc_c[(u64)pin * C * ng + i] = lacc[l];
+      if (P.any_cnt) cnt_c[(u64)pin * C * ng + i] = lcnt[l];
+    }
+    __syncthreads();
+    const u32 se = *s_special;
+    if (se != 0xFFFFFFFFu) {
+      const u64 sp = (u64)P.dense.chunk_slots;
+      if (t == 0) keys_c[sp] = 0ull;
+      for (u32 i = t; i < ng; i += SSGPU_PART_THREADS) {
+        acc_c[sp * ng + i] = lacc[(size_t)se * st + i];
+        if (P.any_cnt) cnt_c[sp * ng + i] = lcnt[(size_t)se * st + i];
       }
     }
     return;
@@ -1806,9 +1895,14 @@ __global__ void ssgpu_fill_u64_kernel(u64* __restrict__ p, u64 v, size_t n) {
 // shard sizes of a strong-scaling job (a 0.3 ms scan) the launches, not the kernels, are what a step waits for.
 __global__ __launch_bounds__(256) void ssgpu_group_init_kernel(const GroupInitParams P) {
   const u64 first = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
-  for (u64 i = first; i < P.n_keys; i += stride) P.keys[i] = VM_KEY_EMPTY;
-  for (u64 i = first; i < P.n_acc; i += stride) P.acc[i] = P.pattern[i % P.ng];
-  for (u64 i = first; i < P.n_cnt; i += stride) P.cnt[i] = 0u;
+  for (u32 r = 0; r <= P.n_rep; ++r) {   // (the chunks of a dense table buffer: the same three ranges, rep_stride bytes apart)
+    u64* const keys = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.keys) + (u64)r * P.rep_stride);
+    u64* const acc = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.acc) + (u64)r * P.rep_stride);
+    u32* const cnt = reinterpret_cast<u32*>(reinterpret_cast<char*>(P.cnt) + (u64)r * P.rep_stride);
+    for (u64 i = first; i < P.n_keys; i += stride) keys[i] = VM_KEY_EMPTY;
+    for (u64 i = first; i < P.n_acc; i += stride) acc[i] = P.pattern[i % P.ng];
+    for (u64 i = first; i < P.n_cnt; i += stride) cnt[i] = 0u;
+  }
   for (int q = 0; q < 4; ++q) for (u64 i = first; i < P.nz[q]; i += stride) P.z[q][i] = 0u;
 }
 __global__ void ssgpu_fill_pattern_u64_kernel(u64* __restrict__ p, const u64* __restrict__ pattern, u32 plen, size_t n) {

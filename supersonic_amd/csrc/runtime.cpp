@@ -55,6 +55,9 @@ struct ssgpu_ctx {
   int64_t group_scout = 1;       // 0: no scout run ahead of the first large GroupAggregate run (see run_group_agg)
   int64_t group_scout_rows = 8 << 20;   // ... "large": inputs of at least this many rows (a smaller value helps first runs and costs steady ones: see run_group_agg)
   int64_t group_resident = 1;    // 0: plain stages take the slab form through scatter + aggregation like every other stage (tests, A/B)
+  int64_t group_dense = 1;       // 0: never index group tables by the keys' value ranges (dense slots, see DenseState); SSGPU_GROUP_DENSE sets the process default
+  int64_t dense_parts = 0;       // partitions of the dense partitioned shape (0 = as many as keep the tables within 80 KiB, at least 512)
+  int64_t dense_min_rows = 1 << 16;   // inputs below this many rows never look for dense ranges (tests lower it to reach the dense kernels with small inputs)
   int64_t async_handoff = 1;     // 0: every stage hand-off reads the row count on the host (a stream synchronise), even where the next stage could take it from the device
   int64_t lazy_feedback = 1;     // 0: a GroupAggregate reads its overflow / feedback words back at the end of EVERY run (a stream synchronise per run)
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
@@ -177,6 +180,22 @@ struct StageExec {
   int64_t hot_sampled_run = -1; // the run (ssgpu_plan::n_runs) whose overflow last made the host look at a sample: once per run, so that a plan that meets
                                 // other data later (other hot keys) finds them again
   DevBuf hot_out;
+  // Dense slots (launch.h: DenseKeyMap): a plain stage whose key columns span small value ranges indexes its tables by the keys'
+  // mixed-radix number instead of hashing them.  The ranges come from one pass over the key columns (the stage's first large
+  // run, or ssgpu_plan_key_ranges) and are kept: a later row outside them raises the domain-miss flag, the ranges are widened
+  // to the union and the run is repeated.  `fixed`: the caller set them (a sharded job's ranks must all use the same ones).
+  struct DenseState {
+    bool on = false, failed = false, checked = false, fixed = false, resident = false;
+    uint32_t n_keys = 0, n_chunks = 1;
+    uint64_t lo[8] = {0}, hi[8] = {0};   // order-preserving unsigned domain (signed columns: sign bit flipped); lo > hi: no value seen
+    uint32_t span[8] = {0}, stride[8] = {0};
+    uint64_t slots = 0;                  // product of the spans
+    uint32_t np = 0, cap = 0;            // partitions (a multiple of n_chunks), table entries per partition: np * cap >= slots
+    uint64_t chunk_bytes = 0;            // header + keys + acc + cnt of (np / n_chunks) * cap + 1 slots, rounded to 64
+    int64_t widened = 0;                 // times a run met a key outside the ranges
+  } dense;
+  DevBuf dense_dom, dense_flags;
+  void* dense_table = nullptr;           // ssgpu_plan_run_dense: the caller's table buffer (n_chunks * chunk_bytes) for THIS run
   std::vector<DevBuf> rowid_tmp;   // FIRST / LAST in GroupAggregate: extracted row ids per aggregate
   // hash joins fused into this stage: index (keys, rows, [special, flags]) per join
   std::vector<DevBuf> jkeys, jkeys_hi, jrows, jmisc;
@@ -294,6 +313,7 @@ int ssgpu_ctx_create(int device_id, ssgpu_ctx** out) {
   }
   // SSGPU_SPECIALIZE (development / test sweeps): the default of the `specialize` option for contexts of this process
   if (const char* e = getenv("SSGPU_SPECIALIZE")) c->specialize = atoi(e);
+  if (const char* e = getenv("SSGPU_GROUP_DENSE")) c->group_dense = atoi(e);
   *out = c;
   return SSGPU_OK;
 }
@@ -345,6 +365,9 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "part_agg_debug") c->part_agg_debug = value;
   else if (k == "group_slab") c->group_slab = value;
   else if (k == "group_resident") c->group_resident = value;
+  else if (k == "group_dense") c->group_dense = value;
+  else if (k == "dense_parts") c->dense_parts = value;
+  else if (k == "dense_min_rows") c->dense_min_rows = value;
   else if (k == "group_scout") c->group_scout = value;
   else if (k == "group_scout_rows") c->group_scout_rows = value;
   else if (k == "part_plain") c->part_plain = value;
@@ -1249,6 +1272,114 @@ static int record_feedback(ssgpu_ctx* c, StageExec& ex) {
   HIP_TRY(c, hipEventRecord(ex.fb_event, c->stream));
   return SSGPU_OK;
 }
+
+// ---- dense slots (launch.h: DenseKeyMap; StageExec::DenseState) -----------------------------------------------------------
+static bool dense_signed(int dtype) { return dtype == SSGPU_INT32 || dtype == SSGPU_INT64 || dtype == SSGPU_DATE || dtype == SSGPU_DATETIME || dtype == SSGPU_STRING; }
+static bool dense_eligible(const ssgpu_ctx* c, const Stage& st) {
+  if (!c->group_dense || !c->group_partition || !st.plain.ok || c->part_plain == 0 || st.part_scatter.empty() || st.plain.keys.empty()) return false;
+  for (auto& k : st.plain.keys)
+    switch (k.dtype) {
+      case SSGPU_INT32: case SSGPU_UINT32: case SSGPU_INT64: case SSGPU_UINT64: case SSGPU_BOOL: case SSGPU_DATE: case SSGPU_DATETIME: case SSGPU_STRING: break;
+      default: return false;   // floating keys: bit patterns, not ranges
+    }
+  return true;
+}
+static void dense_entry_bytes(const Stage& st, uint32_t* entry, uint32_t* fixed, uint32_t* slot_bytes) {
+  const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  bool any_cnt = false;
+  for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
+  const uint32_t stw = ng | 1u;
+  *entry = 8u + stw * 8u + (any_cnt ? stw * 4u : 0u);
+  *fixed = *entry + (1024u + 1u) * 4u + 64u + 64u;
+  *slot_bytes = 8u + ng * 8u + (any_cnt ? ng * 4u : 0u);
+}
+// One pass over the key columns: value ranges (order-preserving unsigned domain) united into the stage's DenseState.
+static int dense_find_ranges(ssgpu_plan* p, const Stage& st, StageExec& ex, const InCols& in) {
+  ssgpu_ctx* c = p->ctx;
+  const uint32_t nk = (uint32_t)st.plain.keys.size();
+  auto& D = ex.dense;
+  if (D.n_keys != nk) { D.n_keys = nk; for (uint32_t k = 0; k < 8; ++k) { D.lo[k] = ~0ull; D.hi[k] = 0ull; } }
+  if (in.rows <= 0) return SSGPU_OK;
+  PlainScatterParams S; memset(&S, 0, sizeof(S));
+  S.n_rows = (unsigned long long)in.rows; S.n_keys = nk;
+  unsigned int is_signed[8] = {0};
+  for (uint32_t k = 0; k < nk; ++k) {
+    const auto& K = st.plain.keys[k];
+    S.keys[k].data = in.cols[K.col].data; S.keys[k].nulls = K.nullable ? in.cols[K.col].is_null : nullptr;
+    S.keys[k].width = K.width; S.keys[k].shift = K.shift; S.keys[k].bits = K.bits; S.keys[k].nullbit = K.nullbit;
+    is_signed[k] = dense_signed(K.dtype) ? 1u : 0u;
+  }
+  HIP_TRY(c, ex.dense_dom.ensure(3 * 8 * 8));
+  const int grid = (int)std::min<int64_t>((int64_t)std::max(c->cu_count, 1) * 2, std::max<int64_t>(1, (in.rows + 4095) / 4096));
+  HIP_TRY(c, ssgpu_launch_key_domain(S, is_signed, ex.dense_dom.as<unsigned long long>(), grid, c->stream));
+  uint64_t out[24];
+  HIP_TRY(c, hipMemcpyAsync(out, ex.dense_dom.p, (size_t)nk * 24, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  p->counters.n_launches += 1;
+  for (uint32_t k = 0; k < nk; ++k) {
+    if (!out[2 * nk + k]) continue;   // no value of this key here
+    D.lo[k] = std::min(D.lo[k], out[k]); D.hi[k] = std::max(D.hi[k], out[nk + k]);
+  }
+  return SSGPU_OK;
+}
+// Spans, strides, slot count and table geometry from the ranges.  false: no usable table (ranges too wide for the row count or
+// for SSGPU_DENSE_MAX_SLOTS).  tabled: the table goes to a caller's chunked buffer (sharded job): always the partitioned shape.
+static bool dense_configure(const ssgpu_ctx* c, const Stage& st, StageExec& ex, uint32_t n_chunks, bool tabled, int64_t rows_hint) {
+  auto& D = ex.dense;
+  const uint32_t nk = (uint32_t)st.plain.keys.size();
+  if (nk == 0 || nk > 8 || n_chunks == 0) return false;
+  uint64_t slots = 1;
+  for (uint32_t k = 0; k < nk; ++k) {
+    const uint64_t values = D.hi[k] >= D.lo[k] ? D.hi[k] - D.lo[k] : ~0ull;   // (minus one)
+    if (D.hi[k] >= D.lo[k] && values >= (uint64_t)SSGPU_DENSE_MAX_SLOTS) return false;
+    uint64_t span = (D.hi[k] >= D.lo[k] ? values + 1 : 0) + (st.plain.keys[k].nullable ? 1 : 0);
+    if (span == 0) span = 1;
+    D.span[k] = (uint32_t)span;
+    slots *= span;
+    if (slots > (uint64_t)SSGPU_DENSE_MAX_SLOTS) return false;
+  }
+  // the table's work (clearing, dumping, extracting D slots) must stay small next to the scan
+  if (rows_hint > 0 && slots > (uint64_t)std::max<int64_t>(rows_hint / 4, 4096)) return false;
+  uint32_t stride = 1;
+  for (int k = (int)nk - 1; k >= 0; --k) { D.stride[k] = stride; stride *= D.span[k]; }
+  D.slots = slots; D.n_chunks = n_chunks;
+  uint32_t entry, fixed, slot_bytes;
+  dense_entry_bytes(st, &entry, &fixed, &slot_bytes);
+  const uint32_t budget80 = c->part_agg_lds > 0 ? (uint32_t)c->part_agg_lds : 80u * 1024u;
+  if (fixed + 64u * entry > budget80) return false;
+  const uint32_t cmax = (budget80 - fixed) / entry, cfull = (159u * 1024u - fixed) / entry;
+  D.resident = !tabled && n_chunks == 1 && slots <= cfull && c->group_slab != 0 && c->group_resident != 0;
+  if (D.resident) { D.np = 1; D.cap = (uint32_t)slots; }
+  else {
+    uint64_t np = (slots + cmax - 1) / cmax;
+    const uint64_t want = c->dense_parts > 0 ? (uint64_t)c->dense_parts : 512ull;
+    np = std::max(np, std::min<uint64_t>(want, std::max<uint64_t>(slots / 64, 1)));   // (at least 64 entries per partition)
+    np = std::max<uint64_t>(np, 2);
+    np = (np + n_chunks - 1) / n_chunks * n_chunks;
+    if (np > 4096) return false;
+    D.np = (uint32_t)np; D.cap = (uint32_t)((slots + np - 1) / np);
+  }
+  const uint64_t chunk_slots = (uint64_t)(D.np / n_chunks) * D.cap;
+  D.chunk_bytes = (SSGPU_DENSE_HEADER + (chunk_slots + 1) * slot_bytes + 63ull) & ~63ull;
+  return true;
+}
+static DenseKeyMap dense_map(const Stage& st, const StageExec& ex, bool tabled) {
+  DenseKeyMap M; memset(&M, 0, sizeof(M));
+  const auto& D = ex.dense;
+  M.on = 1u; M.n_keys = (unsigned int)st.plain.keys.size();
+  M.n_parts = D.np; M.parts_inv = (unsigned int)(0x100000000ull / D.np + 1ull);
+  M.chunk_parts = tabled ? D.np / D.n_chunks : D.np;   // (a run into the plan's own table: one chunk, whatever a sharded job configured)
+  M.part_cap = D.cap; M.chunk_slots = M.chunk_parts * D.cap;
+  M.chunk_stride = tabled ? D.chunk_bytes : 0ull;
+  for (size_t k = 0; k < st.plain.keys.size(); ++k) {
+    const auto& K = st.plain.keys[k];
+    const uint64_t lo_ord = D.hi[k] >= D.lo[k] ? D.lo[k] : (dense_signed(K.dtype) ? 0x8000000000000000ull : 0ull);
+    M.keys[k].lo = dense_signed(K.dtype) ? lo_ord ^ 0x8000000000000000ull : lo_ord;   // back to the column's own bit pattern
+    M.keys[k].span = D.span[k]; M.keys[k].stride = D.stride[k]; M.keys[k].shift = K.shift; M.keys[k].bits = K.bits; M.keys[k].nullbit = K.nullbit;
+  }
+  return M;
+}
+
 int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_base, bool* fallback) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
@@ -1273,9 +1404,15 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
   // workgroup's records sequentially, each aggregation workgroup (1024 threads, the whole LDS) takes a slab of them into a
   // table of all groups and merges it into the global table.  Decided by run_group_agg from its group-count estimate.
   if (c->group_slab == 2 && !ex.part_slab_failed) ex.part_slab = true;   // forced (tests)
+  // dense slots: the geometry was fixed with the key ranges (dense_configure) -- one table of all slots fed from the input columns
+  // (resident), or np partitions of cap entries each
+  const bool dense = ex.dense.on;
+  const bool tabled = dense && ex.dense_table != nullptr;   // the table goes to the caller's chunked buffer (ssgpu_plan_run_dense)
+  if (dense) { ex.part_slab = ex.dense.resident; ex.part_n = ex.dense.np; ex.part_n_chosen = true; }
   const uint32_t budget = ex.part_slab ? 159u * 1024u : (c->part_agg_lds > 0 ? (uint32_t)c->part_agg_lds : 80u * 1024u);
   if (fixed + 64u * entry > budget) { *fallback = true; return SSGPU_OK; }
-  const uint32_t C = (budget - fixed) / entry;
+  uint32_t C = (budget - fixed) / entry;
+  if (dense) { if (ex.dense.cap > C) { if (trace_on()) fprintf(stderr, "[ssgpu trace] dense: cap %u > C %u\n", ex.dense.cap, C); *fallback = true; return SSGPU_OK; } C = std::max(ex.dense.cap, 1u); }
   HIP_TRY(c, ex.gpattern.ensure(ng * 8));
   if (!ex.pattern_ready) {
     std::vector<uint64_t> pattern(ng, 0);
@@ -1330,9 +1467,9 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     ex.last_group_shape = resident ? 3 : slab ? 2 : 1; if (attempt) ++ex.last_reruns;
     ex.last_plain_scatter = false;
     uint32_t capacity = NP * C;
-    if (slab) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
+    if (slab && !dense) { capacity = 1024; while (capacity < 4u * C) capacity *= 2; }   // the merge inserts by hash: a power of two, never full
     // heavy hitters (found when a segment overflowed, below): their groups live in SSGPU_HOT_SLOTS dense slots behind the special one
-    const bool hot = !slab && ex.hot_n > 0 && st.plain.ok && c->part_plain != 0 && st.part_rec_bytes <= 128u;
+    const bool hot = !slab && !dense && ex.hot_n > 0 && st.plain.ok && c->part_plain != 0 && st.part_rec_bytes <= 128u;
     const uint32_t extra = hot ? SSGPU_HOT_SLOTS : 0u;
     const size_t slots = (size_t)capacity + 1 + extra;
     VmParams Ps;
@@ -1345,8 +1482,9 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     Ps.lds_bytes = Ps.part_lds_off + NP * 4u + (uint32_t)Ps.tile_rows * 4u + 16u + (uint32_t)Ps.tile_rows * st.part_rec_bytes;
     // plain stages: the scatter is a kernel of its own over (partition, XCD) segments (ssgpu_part_scatter_plain_kernel)
     const uint32_t W0 = st.part_rec_bytes / 8u;
-    const bool plain = !slab && st.plain.ok && c->part_plain != 0 && !Ps.debug_pc && NP >= 2u && in.rows >= (1 << 16) &&
+    const bool plain = !slab && st.plain.ok && c->part_plain != 0 && !Ps.debug_pc && NP >= 2u && (dense || in.rows >= (1 << 16)) &&
                        ssgpu_part_scatter_plain_lds(NP, W0, 1) <= 156u * 1024u;
+    if (dense && !plain && !resident) { if (trace_on()) fprintf(stderr, "[ssgpu trace] dense: neither the plain scatter nor the resident kernel can run (NP %u)\n", NP); *fallback = true; return SSGPU_OK; }   // (dense slots exist in the plain scatter and the resident kernel only)
     if (W0 > 16u && !plain) { if (trace_on()) fprintf(stderr, "[ssgpu trace] wide records (%u words) without the plain scatter: slab %d plain.ok %d NP %u rows %lld lds %u\n", W0, (int)slab, (int)st.plain.ok, NP, (long long)in.rows, ssgpu_part_scatter_plain_lds(NP, W0, 1)); *fallback = true; return SSGPU_OK; }     // (17 .. 20-word records: the plain scatter + ssgpu_part_agg_kernel<20> only)
     if (!resident && !plain && Ps.lds_bytes > 160u * 1024u) { *fallback = true; return SSGPU_OK; }
     if (plain && Ps.lds_bytes > 160u * 1024u) Ps.lds_bytes = 160u * 1024u;   // (the VM form's LDS is not used: only its tile shape sizes the grid below)
@@ -1365,27 +1503,53 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     // selected ones) with head room for the spread of a uniform hash, times the growth factor of earlier overflows
     const double expect = (double)std::max<int64_t>(in.rows, 1) / ((double)NP * (double)grid);
     uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
-    if (plain) seg_cap = (uint64_t)((expect * 1.3 + 8.0 * std::sqrt(expect) + 64.0) * (double)ex.part_seg_growth);   // (partitions differ by their group counts, too)
+    if (plain) {
+      // the plain scatter deals tiles of 2048 (1024) rows round-robin to one workgroup per CU, and a workgroup appends to the segments of
+      // ITS XCD: with few tiles the XCDs' shares differ by whole tiles (one tile: every row in XCD 0's segments)
+      const uint64_t T = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2048u : 1024u;
+      const uint64_t tiles = ((uint64_t)std::max<int64_t>(in.rows, 1) + T - 1) / T;
+      const uint64_t pg = (uint64_t)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 1023) / 1024));
+      const uint64_t xcds = std::min<uint64_t>(std::min<uint64_t>(SSGPU_PSCAT_XCDS, pg), tiles);
+      const double per_xcd = (double)std::min<uint64_t>((uint64_t)std::max<int64_t>(in.rows, 1), (tiles + xcds - 1) / xcds * T);
+      const double expect_x = per_xcd / (double)NP;
+      seg_cap = (uint64_t)((expect_x * 1.3 + 8.0 * std::sqrt(expect_x) + 64.0) * (double)ex.part_seg_growth);   // (partitions differ by their group counts, too)
+    }
     if (slab) seg_cap = (uint64_t)((Ps.n_tiles + grid - 1) / grid) * (uint64_t)Ps.tile_rows;   // all rows a workgroup can see: never full
     if (resident) seg_cap = 1;                                                      // (no records are written)
     const uint64_t n_segs = resident ? 1ull : (uint64_t)NP * (uint64_t)grid;
     if (n_segs * seg_cap >= 0xFFFFFFFFull) { *fallback = true; return SSGPU_OK; }   // record indices are 32-bit
-    HIP_TRY(c, ex.gkeys.ensure(slots * 8));
-    HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
-    HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
+    unsigned long long* tkeys; unsigned long long* tacc; unsigned int* tcnt;   // the global table of this run
+    DenseKeyMap dmap; memset(&dmap, 0, sizeof(dmap));
+    if (dense) dmap = dense_map(st, ex, tabled);
+    if (tabled) {
+      char* base = static_cast<char*>(ex.dense_table);
+      tkeys = reinterpret_cast<unsigned long long*>(base + SSGPU_DENSE_HEADER);
+      tacc = tkeys + ((size_t)dmap.chunk_slots + 1);
+      tcnt = reinterpret_cast<unsigned int*>(tacc + ((size_t)dmap.chunk_slots + 1) * ng);
+    } else {
+      HIP_TRY(c, ex.gkeys.ensure(slots * 8));
+      HIP_TRY(c, ex.gacc.ensure(slots * ng * 8));
+      HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
+      tkeys = ex.gkeys.as<unsigned long long>(); tacc = ex.gacc.as<unsigned long long>(); tcnt = ex.gcnt.as<unsigned int>();
+    }
     if (ex.part_recs.ensure(n_segs * seg_cap * st.part_rec_bytes + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
     HIP_TRY(c, ex.part_hist.ensure(n_segs * 4));
     {
       GroupInitParams I; memset(&I, 0, sizeof(I));
       I.pattern = ex.gpattern.as<unsigned long long>(); I.ng = ng;
       if (slab) {   // the aggregation workgroups merge into the table: all of it starts empty
-        I.keys = ex.gkeys.as<unsigned long long>(); I.n_keys = slots;
-        I.acc = ex.gacc.as<unsigned long long>(); I.n_acc = (unsigned long long)slots * ng;
-        I.cnt = ex.gcnt.as<unsigned int>(); I.n_cnt = (unsigned long long)slots * ng;
+        I.keys = tkeys; I.n_keys = slots;
+        I.acc = tacc; I.n_acc = (unsigned long long)slots * ng;
+        I.cnt = tcnt; I.n_cnt = (unsigned long long)slots * ng;
+      } else if (tabled) {   // the special slot of every chunk (phase 2 writes every regular slot of every chunk)
+        I.keys = tkeys + dmap.chunk_slots; I.n_keys = 1;
+        I.acc = tacc + (size_t)dmap.chunk_slots * ng; I.n_acc = ng;
+        I.cnt = tcnt + (size_t)dmap.chunk_slots * ng; I.n_cnt = any_cnt ? ng : 0;
+        I.n_rep = ex.dense.n_chunks - 1u; I.rep_stride = ex.dense.chunk_bytes;
       } else {      // only the reserved slot of the EMPTY-valued key (and the heavy hitters' slots behind it) need initialising: phase 2 writes every other slot
-        I.keys = ex.gkeys.as<unsigned long long>() + capacity; I.n_keys = 1 + extra;
-        I.acc = ex.gacc.as<unsigned long long>() + (size_t)capacity * ng; I.n_acc = (unsigned long long)(1 + extra) * ng;
-        I.cnt = ex.gcnt.as<unsigned int>() + (size_t)capacity * ng; I.n_cnt = (unsigned long long)(1 + extra) * ng;
+        I.keys = tkeys + capacity; I.n_keys = 1 + extra;
+        I.acc = tacc + (size_t)capacity * ng; I.n_acc = (unsigned long long)(1 + extra) * ng;
+        I.cnt = tcnt + (size_t)capacity * ng; I.n_cnt = (unsigned long long)(1 + extra) * ng;
       }
       I.z[0] = ex.goverflow.as<unsigned int>(); I.nz[0] = 4;
       I.z[1] = ex.error_flag.as<unsigned int>(); I.nz[1] = 1;
@@ -1440,6 +1604,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     } else if (plain) {
       PlainScatterParams S; fill_plain_source(S);
       if (hot) { S.n_hot = ex.hot_n; for (uint32_t h = 0; h < ex.hot_n; ++h) S.hot_keys[h] = ex.hot_keys[h]; }   // their rows are aggregated by the resident kernel below
+      S.dense = dmap;
       S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
       S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
@@ -1449,7 +1614,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (p->specialize) {
         const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
         const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
-        const uint32_t tag = NP * 4u + (uint32_t)R;
+        const uint32_t tag = NP * 8u + (uint32_t)R * 2u + (dense ? 1u : 0u);
         if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag)) {
           if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
           ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds; ex.rtc_plain.tag = tag;
@@ -1480,7 +1645,8 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     }
     A.debug = (unsigned int)c->part_agg_debug;
     A.local_capacity = C; A.n_gaggs = ng; A.n_aggs = (unsigned int)st.part_aggs.size(); A.any_cnt = any_cnt ? 1u : 0u;
-    A.T.keys = ex.gkeys.as<unsigned long long>(); A.T.acc = ex.gacc.as<unsigned long long>(); A.T.cnt = ex.gcnt.as<unsigned int>();
+    A.T.keys = tkeys; A.T.acc = tacc; A.T.cnt = tcnt;
+    A.dense = dmap;
     A.T.overflow = ex.goverflow.as<unsigned int>(); A.T.capacity_mask = capacity - 1u; A.T.n_gaggs = ng;
     A.T.acc_init = ex.gpattern.as<unsigned long long>(); A.T.merge_op = ex.gmergeop.as<unsigned int>();
     A.nan_flag = ex.error_flag.as<unsigned int>();
@@ -1492,27 +1658,27 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     const uint32_t agg_lds = fixed + C * entry;
     if (resident) {
       PlainScatterParams S; fill_plain_source(S);
-      S.rec_words = W;
+      S.rec_words = W; S.dense = dmap;
       A.slab_segs = 1; A.n_segs = 0;
       // one whole-LDS workgroup per CU; tiles of 2048 rows dealt round-robin
       const int rgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
       A.n_parts = (unsigned int)rgrid;
-      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds)) {
+      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds && ex.rtc_resident.tag == (dense ? 1u : 0u))) {
         if (ex.rtc_resident.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_resident.drop(); }
-        ex.rtc_resident.tried = true; ex.rtc_resident.static_lds = agg_lds;
+        ex.rtc_resident.tried = true; ex.rtc_resident.static_lds = agg_lds; ex.rtc_resident.tag = dense ? 1u : 0u;
         std::string why;
-        ex.rtc_resident.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, &S);
+        ex.rtc_resident.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, &S, dense);
         if (!ex.rtc_resident.h && ex.rtc_why.empty()) ex.rtc_why = "resident group aggregation: " + why;
       }
       if (p->specialize && ex.rtc_resident.h && ex.rtc_resident.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_resident.h, A, S, rgrid, c->stream));
       else HIP_TRY(c, ssgpu_launch_group_resident(A, S, agg_lds, rgrid, c->stream));
     } else
-    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds)) {
+    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u))) {
       // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
       if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
-      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds;
+      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = dense ? 1u : 0u;
       std::string why;
-      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why);
+      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, nullptr, dense);
       if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
     if (resident) { /* launched above */ }
@@ -1521,6 +1687,14 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     p->counters.n_launches += 6;
     p->counters.tile_rows = Ps.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)Ps.lds_bytes;
+    if (tabled) {
+      // a sharded job's partial table: its flags (segment overflow, a key outside the ranges, the evaluation-error word) travel in the
+      // chunks' headers to every rank, which all see them after the exchange (ssgpu_plan_fold_dense); nothing is read back here
+      HIP_TRY(c, ssgpu_launch_dense_headers(ex.dense_table, ex.dense.n_chunks, ex.dense.chunk_bytes, ex.goverflow.as<unsigned int>(), ex.error_flag.as<unsigned int>(), c->stream));
+      p->counters.n_launches += 1;
+      ex.out_rows = 0;
+      return SSGPU_OK;
+    }
     HIP_TRY(c, ex.fb_host.ensure(16));
     uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // [0] a partition outgrew its LDS table, [1] a segment ran full
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
@@ -1531,7 +1705,19 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       return extract_groups(p, st, ex, capacity, ng, in, row_id_base, extra);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (attempt == 0 && !fb[0] && !fb[1]) ++ex.steady; else ex.steady = 0;
+    if (attempt == 0 && !fb[0] && !fb[1] && !fb[3]) ++ex.steady; else ex.steady = 0;
+    if (dense && trace_on()) fprintf(stderr, "[ssgpu trace] dense run: rows %lld slots %llu np %u cap %u resident %d plain %d seg_cap %llu fb %u %u %u %u\n", (long long)in.rows, (unsigned long long)ex.dense.slots, NP, C, (int)resident, (int)plain, (unsigned long long)seg_cap, fb[0], fb[1], fb[2], fb[3]);
+    if (dense && fb[3]) {
+      // a key outside the ranges the table was laid out for: look at THIS input's ranges, widen to the union, lay the table out again
+      ++ex.dense.widened; ++ex.last_reruns;
+      bool ok = !ex.dense.fixed && ex.dense.widened <= 8;
+      if (ok) { const int rc = dense_find_ranges(p, st, ex, in); if (rc != SSGPU_OK) return rc; ok = dense_configure(c, st, ex, 1, false, in.rows); }
+      if (!ok) { ex.dense.on = false; ex.dense.failed = !ex.dense.fixed; *fallback = true; if (ex.dense.fixed) { c->err = "a group key lies outside the dense ranges this plan was given (ssgpu_plan_set_dense)"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; } return SSGPU_OK; }
+      return run_group_agg_partitioned(p, si, in, row_id_base, fallback);
+    }
+    if (dense && fb[0]) { ex.dense.on = false; ex.dense.failed = true; *fallback = true; return SSGPU_OK; }
+    // (dense && fb[1]: rows pile up on a few slots -- a key's NULLs, a popular value.  The segments grow to what this input needs, below,
+    //  up to x16; beyond that the hashed shapes take over, which aggregate heavy hitters apart)
     if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: partitioned, %u partitions x %u entries, grid %d, segments of %llu records (%u B), table overflow=%u segment overflow=%u\n",
                                  NP, C, grid, (unsigned long long)seg_cap, st.part_rec_bytes, fb[0], fb[1]);
     if (slab && (fb[0] || fb[1])) {   // more groups than one LDS table holds after all: hash partitions
@@ -1540,7 +1726,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     }
     if (fb[1]) {   // skewed keys: larger segments (memory permitting), else the direct path
       if (ex.part_seg_growth >= 64) { *fallback = true; return SSGPU_OK; }
-      if (plain && ex.hot_sampled_run != p->n_runs) {
+      if (plain && !dense && ex.hot_sampled_run != p->n_runs) {
         // Skewed keys?  Look at a sample of the rows before making every segment larger: a few keys that hold a large share of
         // the rows (each would fill ONE partition) are taken out of the partitions altogether and aggregated on their own
         // (ssgpu_hot_keys_kernel -> hot_only resident pass + a scatter that skips them), and the rest fits the segments as sized.
@@ -1573,7 +1759,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const double need = (double)n_segs * ((double)seg_cap / (double)ex.part_seg_growth * (double)growth) * (double)st.part_rec_bytes;
-        if ((double)seg_cap / (double)ex.part_seg_growth * (double)growth < (double)fullest * 1.1 || need > ((double)free_b + (double)ex.part_recs.cap) * 0.25) { *fallback = true; return SSGPU_OK; }
+        if ((double)seg_cap / (double)ex.part_seg_growth * (double)growth < (double)fullest * 1.1 || need > ((double)free_b + (double)ex.part_recs.cap) * 0.25 || (dense && growth > 16u)) {
+          if (dense) { ex.dense.on = false; ex.dense.failed = true; ex.part_seg_growth = 1; }
+          *fallback = true; return SSGPU_OK;
+        }
         ex.part_seg_growth = std::max(growth, ex.part_seg_growth * 4u);
         continue;
       }
@@ -1601,6 +1790,23 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
   // take the direct shape otherwise: 1.5 - 4.8 ms), but a prefix of an eighth over-estimates the group count of such inputs up
   // to eightfold and the plan then keeps too many partitions (or the one-table form where partitions are faster): steady runs
   // 1.5 - 3 x slower (profiles/r04_first_run.json).  A plan that is run once may set it lower; the default favours the plan that is run again.
+  // Dense slots first: a plain stage whose key columns span small value ranges indexes its tables by the keys themselves -- no
+  // hashing, no probe, no group-count estimate (the ranges bound it), the same slot for a group in every run and on every rank.
+  // The ranges cost one pass over the key columns, once per plan (again only when a later input leaves them).
+  if (!scout && !ex.dense.on && !ex.dense.failed && !ex.dense.checked && !ex.dense.fixed && in.rows >= std::max<int64_t>(c->dense_min_rows, 1) && dense_eligible(c, st)) {
+    ex.dense.checked = true;
+    { const int rc = dense_find_ranges(p, st, ex, in); if (rc != SSGPU_OK) return rc; }
+    if (dense_configure(c, st, ex, 1, false, in.rows)) ex.dense.on = true; else ex.dense.failed = true;
+    if (c->debug_timing) fprintf(stderr, "[ssgpu debug] group stage: key ranges span %llu dense slots -> %s\n", (unsigned long long)ex.dense.slots, ex.dense.on ? (ex.dense.resident ? "dense, one table" : "dense partitions") : "hashed");
+  }
+  if (!scout && ex.dense.on) {
+    bool not_dense = false;
+    const int rc = run_group_agg_partitioned(p, si, in, row_id_base, &not_dense);
+    if (rc != SSGPU_OK || !not_dense) return rc;
+    // the ranges did not make a usable table after all (keys too unevenly spread, a segment that would not fit): the hashed shapes
+    ex.dense.on = false; if (!ex.dense.fixed) ex.dense.failed = true;
+    ex.part_n_chosen = false; ex.part_slab = false; ex.steady = 0;
+  }
   if (!scout && !ex.scouted && c->group_scout != 0 && c->group_partition == 1 && !ex.group_partitioned && !st.part_scatter.empty() &&
       in.rows >= std::max<int64_t>(c->group_scout_rows, (int64_t)1 << 18)) {
     ex.scouted = true; ex.scout_full_rows = in.rows;
@@ -2258,7 +2464,7 @@ int settle_plan(ssgpu_plan* p) {
     if (!ex.fb_pending) continue;
     const uint32_t* fb = static_cast<const uint32_t*>(ex.fb_host.p);
     const int kind = ex.fb_pending; ex.fb_pending = 0;
-    if (fb[0] || (kind == 2 && fb[1])) { rerun = true; ex.steady = 0; }
+    if (fb[0] || (kind == 2 && (fb[1] || fb[3]))) { rerun = true; ex.steady = 0; }
     else if (kind == 1 && (uint64_t)fb[1] > 2ull * ex.steady_bypass + (uint64_t)(p->last_rows >> 6)) ex.steady = 0;   // the data moved: the next run adapts again
   }
   if (!rerun) return SSGPU_OK;
@@ -2308,7 +2514,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       if (ex.fb_event) HIP_TRY(c, hipEventSynchronize(ex.fb_event)); else HIP_TRY(c, hipStreamSynchronize(c->stream));
       const uint32_t* fb = static_cast<const uint32_t*>(ex.fb_host.p);
       const int kind = ex.fb_pending; ex.fb_pending = 0;
-      if (fb[0] || (kind == 2 && fb[1])) ex.steady = 0;
+      if (fb[0] || (kind == 2 && (fb[1] || fb[3]))) ex.steady = 0;
       else if (kind == 1 && (uint64_t)fb[1] > 2ull * ex.steady_bypass + (uint64_t)(p->last_rows >> 6)) ex.steady = 0;
     }
   }
@@ -2465,6 +2671,7 @@ int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* 
   out->specialized = (ex.rtc_main.h ? 1 : 0) + (ex.rtc_pscatter.h ? 2 : 0) + (ex.rtc_part.h ? 4 : 0) + (ex.rtc_plain.h ? 8 : 0) + (ex.rtc_resident.h ? 16 : 0);
   out->plain_scatter = ex.last_plain_scatter ? 1 : 0;
   out->hot_keys = (int32_t)ex.hot_n;
+  out->dense_slots = ex.dense.on ? (int32_t)ex.dense.slots : 0;
   return SSGPU_OK;
 }
 void ssgpu_specialized_kernels_trim(int32_t keep) { ssgpu_rtc_trim(keep); }
@@ -2538,6 +2745,130 @@ int ssgpu_plan_set_aux_input(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_
 int ssgpu_plan_run_partial(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t base) {
   if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   return run_plan(p, cols, n_cols, rows, base, true);
+}
+
+// ---- dense-slot GroupAggregate across ranks (ssgpu.h) -----------------------------------------------------------------------
+static int dense_stage_of(ssgpu_plan* p, bool need_device) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (need_device && (!c || c->device < 0)) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  if (p->stages.size() != 1 || p->stages[0].kind != STAGE_GROUP_AGG || !dense_eligible(c, p->stages[0])) {
+    c->err = "dense slots need a plan that is ONE plain GroupAggregate stage over integer-like key columns"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+  }
+  for (auto& a : p->stages[0].aggs) if (a.gather_col >= 0) { c->err = "FIRST / LAST aggregates take their values from the shard that saw the row: not in the dense exchange"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  return SSGPU_OK;
+}
+int ssgpu_plan_key_ranges(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int32_t* n_keys, uint64_t* lo, uint64_t* hi) {
+  int rc = dense_stage_of(p, true);
+  if (rc != SSGPU_OK) return rc;
+  ssgpu_ctx* c = p->ctx;
+  if (n_cols != (int)p->desc.input_schema.size() || rows < 0 || !n_keys || !lo || !hi) { c->err = "key ranges: bad arguments"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  InCols in; in.cols.assign(cols, cols + n_cols); in.rows = rows;
+  StageExec& ex = p->exec[0];
+  rc = dense_find_ranges(p, p->stages[0], ex, in);
+  if (rc != SSGPU_OK) return rc;
+  *n_keys = (int32_t)ex.dense.n_keys;
+  for (uint32_t k = 0; k < ex.dense.n_keys; ++k) { lo[k] = ex.dense.lo[k]; hi[k] = ex.dense.hi[k]; }
+  return SSGPU_OK;
+}
+int ssgpu_plan_set_dense(ssgpu_plan* p, int32_t n_keys, const uint64_t* lo, const uint64_t* hi, int32_t n_chunks, ssgpu_dense_layout* out) {
+  int rc = dense_stage_of(p, false);
+  if (rc != SSGPU_OK) return rc;
+  ssgpu_ctx* c = p->ctx; const Stage& st = p->stages[0]; StageExec& ex = p->exec[0];
+  if (n_keys != (int32_t)st.plain.keys.size() || !lo || !hi || n_chunks < 1) { c->err = "dense ranges: one (lo, hi) pair per group key and at least one chunk"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  ex.dense.n_keys = (uint32_t)n_keys;
+  for (int32_t k = 0; k < n_keys; ++k) { ex.dense.lo[k] = lo[k]; ex.dense.hi[k] = hi[k]; }
+  if (!dense_configure(c, st, ex, (uint32_t)n_chunks, true, 0)) {
+    ex.dense.on = false; ex.dense.fixed = false;
+    c->err = "dense ranges: the table of these ranges would exceed 2^21 slots (or 4096 partitions)"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  }
+  ex.dense.on = true; ex.dense.fixed = true; ex.dense.failed = false; ex.dense.widened = 0;
+  ex.part_seg_growth = std::max(ex.part_seg_growth, 1u);
+  if (out) {
+    uint32_t entry, fixed, slot_bytes;
+    dense_entry_bytes(st, &entry, &fixed, &slot_bytes);
+    memset(out, 0, sizeof(*out));
+    out->slots = (int64_t)ex.dense.slots; out->n_parts = (int32_t)ex.dense.np; out->part_cap = (int32_t)ex.dense.cap;
+    out->chunk_slots = (int64_t)(ex.dense.np / ex.dense.n_chunks) * ex.dense.cap; out->chunk_bytes = (int64_t)ex.dense.chunk_bytes;
+    out->n_gaggs = std::max(st.n_gaggs, 1); out->has_counts = slot_bytes > 8u + (uint32_t)out->n_gaggs * 8u ? 1 : 0;
+  }
+  return SSGPU_OK;
+}
+int ssgpu_plan_run_dense(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, void* table) {
+  int rc = dense_stage_of(p, true);
+  if (rc != SSGPU_OK) return rc;
+  StageExec& ex = p->exec[0];
+  if (!ex.dense.on || !ex.dense.fixed || !table) { p->ctx->err = "ssgpu_plan_run_dense: set the ranges first (ssgpu_plan_set_dense) and pass a table buffer"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  ex.dense_table = table;
+  rc = run_plan(p, cols, n_cols, rows, 0, false);
+  ex.dense_table = nullptr;
+  if (rc == SSGPU_OK && !ex.dense.on) { p->ctx->err = "the dense table could not be laid out for this input (a partition's segments would not fit)"; rc = SSGPU_ERROR_MEMORY_EXCEEDED; ex.dense.on = true; }
+  return rc;
+}
+int ssgpu_plan_fold_dense(ssgpu_plan* p, const void* chunks, int32_t n_chunks, ssgpu_result** out) {
+  int rc = dense_stage_of(p, true);
+  if (rc != SSGPU_OK) return rc;
+  ssgpu_ctx* c = p->ctx; Stage& st = p->stages[0]; StageExec& ex = p->exec[0];
+  if (!ex.dense.on || !ex.dense.fixed || !chunks || n_chunks < 1) { c->err = "ssgpu_plan_fold_dense: set the ranges first (ssgpu_plan_set_dense)"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  QuotaScope quota_scope(&p->quota);
+  HIP_TRY(c, hipSetDevice(c->device));
+  rc = prepare_stage(p, 0);
+  if (rc != SSGPU_OK) return rc;
+  const uint32_t ng = (uint32_t)std::max(st.n_gaggs, 1);
+  bool any_cnt = false;
+  for (auto& a : st.aggs) any_cnt = any_cnt || a.has_cnt;
+  const uint32_t slots = (ex.dense.np / ex.dense.n_chunks) * ex.dense.cap;
+  HIP_TRY(c, ex.gkeys.ensure(((size_t)slots + 1) * 8));
+  HIP_TRY(c, ex.gacc.ensure(((size_t)slots + 1) * ng * 8));
+  HIP_TRY(c, ex.gcnt.ensure(((size_t)slots + 1) * ng * 4));
+  HIP_TRY(c, ex.total.ensure(16));
+  HIP_TRY(c, ex.dense_flags.ensure(16));
+  HIP_TRY(c, ex.gmergeop.ensure(ng * 4));
+  HIP_TRY(c, ex.gpattern.ensure(ng * 8));
+  if (!ex.pattern_ready) {
+    std::vector<uint64_t> pattern(ng, 0);
+    std::vector<uint32_t> mop(ng, VM_MERGE_ADD_U64);
+    for (size_t i = 0; i < st.group_acc_init.size(); ++i) pattern[i] = st.group_acc_init[i];
+    for (size_t i = 0; i < st.group_merge_op.size(); ++i) mop[i] = st.group_merge_op[i];
+    HIP_TRY(c, hipMemcpy(ex.gpattern.p, pattern.data(), ng * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(ex.gmergeop.p, mop.data(), ng * 4, hipMemcpyHostToDevice));
+    ex.pattern_ready = true;
+  }
+  DenseFoldParams F; memset(&F, 0, sizeof(F));
+  F.chunks = chunks; F.n_chunks = (unsigned int)n_chunks; F.n_gaggs = ng; F.any_cnt = any_cnt ? 1u : 0u; F.slots = slots; F.chunk_bytes = ex.dense.chunk_bytes;
+  F.keys = ex.gkeys.as<unsigned long long>(); F.acc = ex.gacc.as<unsigned long long>(); F.cnt = ex.gcnt.as<unsigned int>();
+  F.merge_op = ex.gmergeop.as<unsigned int>(); F.flags_out = ex.dense_flags.as<unsigned int>();
+  F.clear[0] = ex.total.as<unsigned int>(); F.n_clear[0] = 4;   // the extraction's row count, ticket and gave-up flag
+  HIP_TRY(c, ssgpu_launch_dense_fold(F, c->stream));
+  p->counters.n_launches += 1;
+  p->result.fetched.assign(p->result.fetched.size(), false);
+  InCols none;
+  rc = extract_groups(p, st, ex, slots, ng, none, 0);
+  if (rc != SSGPU_OK) return rc;
+  if (out) *out = &p->result;
+  return SSGPU_OK;
+}
+int ssgpu_plan_dense_flags(ssgpu_plan* p, uint32_t* flags, uint32_t* error) {
+  int rc = dense_stage_of(p, true);
+  if (rc != SSGPU_OK) return rc;
+  ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[0];
+  uint32_t w[2] = {0, 0};
+  if (ex.dense_flags.p) {
+    HIP_TRY(c, hipMemcpyAsync(w, ex.dense_flags.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (flags) *flags = w[0];
+  if (error) *error = w[1] & 0xFFu;   // (the NaN-in-MIN/MAX bit is not an error: the fold skips NaNs like every order-independent shape)
+  return SSGPU_OK;
+}
+int ssgpu_plan_dense_grow(ssgpu_plan* p) {
+  int rc = dense_stage_of(p, false);
+  if (rc != SSGPU_OK) return rc;
+  StageExec& ex = p->exec[0];
+  if (ex.part_seg_growth >= 64u) { p->ctx->err = "a partition's record segments cannot grow any further (one group holds most of the rows)"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+  ex.part_seg_growth *= 4u;
+  return SSGPU_OK;
 }
 
 int32_t ssgpu_plan_partial_segments(ssgpu_plan* p, ssgpu_partial_segment* out, int32_t max_segments) {

@@ -636,6 +636,128 @@ class DeviceShardedGroupAggregate(object):
         return local if self.exchange != "key_range" else _all_gather_view(local, self.group, self.device)
 
 
+class PlanDenseBackend(object):
+    """The device side of DenseShardedGroupAggregate: ONE plan -- the job's GroupAggregate itself, no shard / merge pair --
+    run through ssgpu_plan_run_dense / ssgpu_plan_fold_dense, buffers as torch tensors on the plan's device."""
+
+    def __init__(self, ctx, op, strings=None):
+        import torch
+        self.torch = torch
+        ctx.set_option("group_dense", 1)
+        self.ctx = ctx
+        self.plan = ss.Plan(op, ctx, strings) if strings is not None else ss.Plan(op, ctx)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        raw = ctx.stream()
+        self._lib_stream = torch.cuda.ExternalStream(raw) if raw else torch.cuda.default_stream(self.device)
+
+    def key_ranges(self, view):
+        return self.plan.key_ranges(view)
+
+    def set_dense(self, ranges, n_chunks):
+        return self.plan.set_dense(ranges, n_chunks)
+
+    def alloc(self, nbytes):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+
+    def run_dense(self, view, table):
+        self.plan.run_dense(view, table.data_ptr())
+
+    def before_collective(self):      # the collective (torch's stream) reads what the library's stream wrote
+        self.torch.cuda.current_stream(self.device).wait_stream(self._lib_stream)
+
+    def after_collective(self):
+        self._lib_stream.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    def fold_dense(self, chunks, n_chunks):
+        self.plan.fold_dense(chunks.data_ptr(), n_chunks)
+
+    def dense_flags(self):
+        return self.plan.dense_flags()
+
+    def dense_grow(self):
+        self.plan.dense_grow()
+
+    def local_result(self):
+        return self.plan.fetch()
+
+
+class DenseShardedGroupAggregate(object):
+    """GroupAggregate over row-range shards through DENSE SLOTS (include/ssgpu.h "dense-slot GroupAggregate
+    across ranks"): the ranks agree once on the value ranges of the group keys; from then on every rank's partial table is
+    the same array -- slot = the keys' mixed-radix number -- and a step is
+
+        shard scan into the table (chunk r = the slots rank r owns)  ->  ONE all_to_all_single of the chunks  ->
+        element-wise fold of the world images of the owned slot range + extraction
+
+    No merge plan, no routing, no packing; DOUBLE sums cross as raw (hi, lo) accumulator pairs and are rounded once.  Every
+    rank ends with the groups it owns (`gather_result()` collects the table).  What can go wrong in a step travels in the
+    chunks' headers, which reach EVERY rank: a rank whose shard overflowed a segment, met a key outside the ranges or hit an
+    evaluation error still sends its chunks, flagged -- nobody leaves a step early, and `check()` gives every rank the same
+    verdict without a further collective: False = repeat the step (segments were enlarged / the ranks agreed on wider ranges).
+    `backend`: PlanDenseBackend on a GPU; the CPU tests pass a host restatement of the table with the same interface.
+    Raises SupersonicException(NOT_IMPLEMENTED / INVALID_ARGUMENT_VALUE) from `setup()` when the plan or the ranges do not
+    take this form -- identically on every rank (same plan, same agreed ranges) -- and the caller uses the image exchange."""
+
+    def __init__(self, backend, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend, self.group = backend, group
+        self.world = dist.get_world_size(group)
+        self.layout = None
+        self.collectives = 0
+        self.setup_collectives = 0
+        self.ranges = None
+        self._view = None
+
+    def setup(self, view):
+        """Set-up (and again when a step met a key outside the ranges): every rank's key ranges, united -- one all_gather_object."""
+        mine = self.backend.key_ranges(view)
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, [list(r) for r in mine], group=self.group)
+        self.setup_collectives += 1
+        ranges = [(min(r[k][0] for r in everyone), max(r[k][1] for r in everyone)) for k in range(len(mine))]
+        if self.ranges is not None:            # never narrower than before: a plan that alternates between inputs settles
+            ranges = [(min(a[0], b[0]), max(a[1], b[1])) for a, b in zip(ranges, self.ranges)]
+        self.ranges = ranges
+        self.layout = self.backend.set_dense(ranges, self.world)
+        nbytes = self.world * int(self.layout["chunk_bytes"])
+        self.table = self.backend.alloc(nbytes)
+        self.chunks = self.backend.alloc(nbytes)
+
+    def step(self, view=None):
+        self._view = view
+        self.collectives = 0
+        if self.layout is None:
+            self.setup(view)
+        self.backend.run_dense(view, self.table)
+        self.backend.before_collective()
+        self.dist.all_to_all_single(self.chunks, self.table, group=self.group)     # chunk r of every rank -> rank r
+        self.collectives += 1
+        self.backend.after_collective()
+        self.backend.fold_dense(self.chunks, self.world)
+        return self.backend
+
+    def check(self):
+        flags, error = self.backend.dense_flags()      # the OR over every rank's headers: the same words on every rank
+        if error:
+            raise ss.SupersonicException(ss.ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate")
+        if flags & 4:                                   # some rank met a key outside the ranges: agree on wider ones
+            self.setup(self._view)
+            return False
+        if flags & 2:                                   # some rank's record segments ran full: every rank enlarges its own
+            self.backend.dense_grow()
+            return False
+        if flags & 1:
+            raise ss.SupersonicException(ss.ERROR_MEMORY_EXCEEDED, "a dense partition outgrew its table")
+        return True
+
+    def gather_result(self):
+        """The full table on every rank: the owners' finished slices concatenated in rank order (not part of a step)."""
+        local = self.backend.local_result()
+        device = getattr(self.backend, "device", None)
+        return _all_gather_view(local, self.group, device if device is not None else "cpu")
+
+
 def device_sharded_group_aggregate(ctx, group_by, spec, local_child, group=None):
     """One-shot form of DeviceShardedGroupAggregate: returns (plan, DeviceView) -- the full result on every
     rank, as device columns owned by `plan`."""

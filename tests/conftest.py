@@ -14,6 +14,11 @@ if ROOT not in sys.path:
 # kernel a default plan runs must not depend on what an earlier test or an earlier suite run left in the cache; the compiled
 # kernels are exercised by the tests that set the option (1 or 2) themselves.
 os.environ.setdefault("SSGPU_SPECIALIZE", "0")
+# Dense slots (ssgpu.h: group_dense, default 1) change which execution shape a plain GroupAggregate takes.  The suite's older
+# tests were written against the hashed shapes and assert them through stage_info: they keep running against those (option 0
+# as this process's default); the dense shapes have their own tests, which set the option themselves (tests/test_dense_gpu.py,
+# the dense cases of tests/test_00_configs_gpu.py, the dense sweep of the fuzz generator).
+os.environ.setdefault("SSGPU_GROUP_DENSE", "0")
 
 
 def pytest_configure(config):

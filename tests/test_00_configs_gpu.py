@@ -272,6 +272,100 @@ def test_config4_sharded_filter_group_aggregate_one_rank():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("specialize", [0, 1])
+def test_config4_dense_slot_exchange_on_one_rank(specialize):
+    # config #4 through DENSE SLOTS (what `bench.py --query group --gpus N` steps by default): the ranks agree on
+    # the key ranges, a step is shard scan into a slot-indexed table -> ONE all_to_all_single of slot slices -> element-wise
+    # fold + extraction on the plan itself -- no merge plan.  One rank, RCCL to itself; vs the oracle on the whole input
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from supersonic_amd.distributed import DenseShardedGroupAggregate, PlanDenseBackend
+    cols = bench.host_columns(np, "group", N_ROWS, seed=5)
+    view = ss.View(bench.group_schema(ss), cols)
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), bench.group_spec(ss), None, bench.group_child(ss, view))
+    oschema, want = oracle.run(op)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = make_ctx(specialize=specialize)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        backend = PlanDenseBackend(ctx, op)
+        job = DenseShardedGroupAggregate(backend)
+        for _ in range(3):
+            job.step(view)
+            while not job.check():
+                job.step(view)
+        assert job.collectives == 1 and job.setup_collectives == 1, (job.collectives, job.setup_collectives)
+        assert job.layout["slots"] == 316 * 317 and job.layout["n_parts"] % job.world == 0, job.layout
+        assert schema_list(backend.plan.result_schema) == oschema
+        assert_cols_equal(sort_rows(to_cols(backend.plan.fetch())), sort_rows(want), context="config #4, dense exchange, one rank")
+        info = backend.plan.stage_info()[0]
+        assert info["dense_slots"] == 316 * 317 and info["group_shape"] == 1, info
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_dense_tables_of_several_shards_fold_into_disjoint_owners(world):
+    # `world` ranks simulated on one GPU, no process group: every rank's plan runs its shard into a chunked table (chunk r = the
+    # slots rank r owns), the all-to-all is done by hand (chunk r of every table -> owner r), every owner folds its `world` images
+    # and extracts.  Owners are disjoint and together they are the oracle's result over the whole input; DOUBLE sums cross as raw
+    # (hi, lo) accumulators; a NULLABLE key, a NULLABLE aggregate input (contribution counts travel) and a Filter ride along
+    torch = pytest.importorskip("torch")
+    n = 600_000
+    rng = np.random.default_rng(17 + world)
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32, ss.NULLABLE), ss.Attribute("t", ss.BOOL), ss.Attribute("a", ss.INT64),
+                             ss.Attribute("v", ss.INT64), ss.Attribute("d", ss.DOUBLE, ss.NULLABLE), ss.Attribute("x", ss.DOUBLE)])
+    data = [ss.Column(rng.integers(-700, 9000, n).astype(np.int32), rng.random(n) < 0.05), rng.integers(0, 2, n).astype(bool), rng.integers(0, 1000, n),
+            rng.integers(-1000, 1000, n), ss.Column(rng.integers(-4000, 4000, n) * 0.25, rng.random(n) < 0.2), rng.uniform(-1.0, 1.0, n)]
+    whole = ss.View(schema, data)
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "c").AddAggregation(ss.MIN, "v", "mn")
+            .AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MAX, "d", "mx").AddAggregation(ss.COUNT, "d", "cd"))
+
+    def op_of(view):
+        return ss.GroupAggregate(ss.ProjectNamedAttributes(["k", "t"]), spec, None,
+                                 ss.Filter(ss.Greater(ss.NamedAttribute("a"), ss.ConstInt64(299)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    _s, want = oracle.run(op_of(whole))
+    bounds = [n * r // world for r in range(world + 1)]
+    bounds[1] = bounds[1] // 3                       # ragged shards (and with world = 8 a small one)
+    shards = [ss.View(schema, [ss.Column(c.data[bounds[r]:bounds[r + 1]], None if c.is_null is None else c.is_null[bounds[r]:bounds[r + 1]])
+                               for c in (whole.column(i) for i in range(6))]) for r in range(world)]
+    ctx = make_ctx(group_dense=1)
+    plans = [ss.Plan(op_of(sh), ctx) for sh in shards]
+    ranges = [p.key_ranges(sh) for p, sh in zip(plans, shards)]
+    union = [(min(r[k][0] for r in ranges), max(r[k][1] for r in ranges)) for k in range(2)]
+    layouts = [p.set_dense(union, world) for p in plans]
+    assert all(lay == layouts[0] for lay in layouts) and layouts[0]["n_parts"] % world == 0, layouts
+    cb = layouts[0]["chunk_bytes"]
+    tables = [torch.zeros(world * cb, dtype=torch.uint8, device="cuda") for _ in range(world)]
+    for attempt in range(4):
+        for p, sh, t in zip(plans, shards, tables):
+            p.run_dense(sh, t.data_ptr())
+        ctx.synchronize()
+        got_rows, flags = [], []
+        for owner in range(world):
+            images = torch.cat([t[owner * cb:(owner + 1) * cb] for t in tables])     # what all_to_all_single delivers to `owner`
+            torch.cuda.synchronize()
+            plans[owner].fold_dense(images.data_ptr(), world)
+            flags.append(plans[owner].dense_flags())
+            got_rows.append(to_cols(plans[owner].fetch()))
+        assert all(f == flags[0] for f in flags), flags          # every owner saw every rank's header: the same verdict everywhere
+        if flags[0] == (0, 0):
+            break
+        # a twentieth of the rows carry the NULL key (two slots): their partition outgrows segments sized for an even spread on
+        # the larger shards -- every rank enlarges its segments and the step is repeated (DenseShardedGroupAggregate.check)
+        assert flags[0] == (2, 0) and attempt < 2, (attempt, flags)
+        for p in plans:
+            p.dense_grow()
+    merged = [(np.concatenate([g[i][0] for g in got_rows]), None if got_rows[0][i][1] is None else np.concatenate([g[i][1] for g in got_rows])) for i in range(len(want))]
+    # every group on exactly one owner: the concatenation has the oracle's row count and its rows
+    exact = [i for i in range(len(want)) if i != 5]                                        # (column 5 = SUM(d): multiples of 0.25, exact too)
+    assert_cols_equal(sort_rows(merged), sort_rows(want), context="dense tables of %d shards" % world)
+    assert len(exact) == len(want) - 1
+
+
 # ---- config #5: Sort(d ASC) of the 8-column block -----------------------------------------------------------------------
 def check_sort(cols, expect_mode, context, **options):
     view = ss.View(bench.bench_schema(ss), cols)

@@ -209,6 +209,23 @@ def test_group_aggregate(gpu_ctx, n, with_filter, nullable):
     run_both(group_query(make_view(n, nullable=nullable), with_filter, keys), gpu_ctx, ignore_order=True)
 
 
+@pytest.mark.parametrize("part_plain", [1, 0])
+@pytest.mark.parametrize("dense", [0, 1])
+def test_group_aggregate_count_only_has_one_word_records(part_plain, dense):
+    # COUNT(*) alone: a partition record is the key word and nothing else -- the word -> record division by multiplication
+    # (floor(2^32 / words) + 1) has no 32-bit form for ONE word (found by the dense fuzz: groups merged into each other)
+    n = 100003
+    view = make_view(n, nullable=True)
+    ctx = ss.Context(0)
+    for k, v in (("group_partition", 2), ("part_plain", part_plain), ("group_dense", dense), ("group_resident", 0), ("group_slab", 0)):
+        ctx.set_option(k, v)
+    for keys in (["k1"], ["k2", "t"]):
+        spec = ss.AggregationSpecification().AddAggregation(ss.COUNT, "", "rows")
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, ss.ScanView(view)), ctx, ignore_order=True)
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None,
+                                   ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))), ctx, ignore_order=True)
+
+
 @pytest.mark.parametrize("n", [0, 1000, 100003])
 def test_group_aggregate_int64_key(gpu_ctx, n):
     view = make_view(n)
