@@ -278,7 +278,31 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(ss, query, sample_rows, budget_s=10.0):
+def _physical_cores():
+    """(physical cores, logical CPUs) of this host: distinct (physical id, core id) pairs of /proc/cpuinfo."""
+    logical = os.cpu_count() or 1
+    try:
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        if cores:
+            return len(cores), logical
+    except OSError:
+        pass
+    return logical, logical
+
+
+def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True):
     """1 thread (the reference is single-threaded per plan) AND N threads over row-range shards of the same
     sample (the ctypes calls into the C restatement release the GIL; the merge of N one-row / N partial
     results is not timed: microseconds), plus BASELINE configs[0]'s exact shape (1 M rows x 4 INT64)."""
@@ -304,8 +328,8 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0):
         reps += 1
     one = n * reps / elapsed
     # N threads: one contiguous row range per thread
-    nproc = os.cpu_count() or 1
-    nthreads = max(1, min(nproc, 64))
+    physical, nproc = _physical_cores()
+    nthreads = max(1, min(physical, 256))        # one thread per PHYSICAL core (SMT siblings add little to a streaming loop)
     bounds = [n * i // nthreads for i in range(nthreads + 1)]
     ops = [make(ss.View(schema, [c[bounds[i]:bounds[i + 1]] for c in cols])) for i in range(nthreads)]
     preps, pelapsed = 0, 0.0
@@ -322,7 +346,9 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0):
            "sample": "%d rows (same plan, seed 42), %d passes, %.1f s of CPU" % (n, reps, elapsed),
            "threads": {"value": n * preps / pelapsed, "cores": nthreads,
                        "sample": "%d row-range shards of the same sample, %d passes, %.1f s" % (nthreads, preps, pelapsed)},
-           "host": {"nproc": nproc, "model": _cpu_model()}}
+           "host": {"nproc": nproc, "physical_cores": physical, "model": _cpu_model()}}
+    if not with_config0:
+        return out
     # BASELINE configs[0]: Compute(a+b) -> Filter(a>K) -> Sum/Count on a 1 M-row x 4 INT64 table
     rng = np.random.default_rng(42)
     m = 1000000
@@ -339,6 +365,17 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0):
     out["config0"] = {"value": m * r4 / e4, "unit": "rows/s", "cores": 1,
                       "sample": "1M rows x 4 INT64: Compute(a, a+b) -> Filter(a>499) -> SUM, COUNT; %d passes" % r4}
     return out
+
+
+def config_cpu_baseline(ss, q):
+    """cpu_baseline of one of the extra configs (group3 / group / sort / filter_mat): 2 M-row sample, about 3 s of CPU."""
+    global GROUP_FILTER
+    saved = GROUP_FILTER
+    GROUP_FILTER = q == "group"
+    try:
+        return cpu_baseline(ss, "group" if q in ("group", "group3") else q, 2_000_000, budget_s=2.0, with_config0=False)
+    finally:
+        GROUP_FILTER = saved
 
 
 # ---- launch plumbing ----------------------------------------------------------------------------
@@ -563,6 +600,9 @@ def main():
     # opcode dispatch folded away; compiled at the first, untimed run below).  Same work, bit-identical results -- the
     # parity tests run both forms.
     ctx.set_option("specialize", 0 if args.no_specialize else 1)
+    # timed steps are enqueued back to back and never wait for the host: the opt-in of ssgpu.h's INPUT LIFETIME rule (the
+    # default settles every run before ssgpu_plan_run returns); the resident columns outlive every step
+    ctx.set_option("lazy_feedback", 1)
     for kv in [x for x in args.opts.split(",") if x]:
         ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
@@ -793,6 +833,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(QUERY_NAME, alg_bytes),
                          "traffic_source": pmc_source(QUERY_NAME, alg_bytes),    # `traffic` is read from this committed PMC pass, not counted in this run
+                         "traffic_measured": False,                               # (PMC counters need rocprofv3 around the process: tools/profile_round5.sh)
                          "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_row": alg_bytes / max(rows, 1)},
             "result_row": result_row,
@@ -812,8 +853,10 @@ def main():
             for q in ("group3", "group", "sort", "filter_mat"):
                 try:
                     line["configs"][q] = measure_config(ss, torch, ctx, device, q, rows, args.config_steps, wide_cols=cols)
+                    if not args.no_cpu_baseline:       # the oracle on the same query, a bounded sample (about 3 s of CPU each)
+                        line["configs"][q]["cpu_baseline"] = config_cpu_baseline(ss, q)
                 except Exception as e:   # noqa: BLE001 -- the headline line must survive a failing extra
-                    line["configs"][q] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    line["configs"][q] = dict(line["configs"].get(q) or {}, error="%s: %s" % (type(e).__name__, e))
         if world == 1 and args.extras and args.query == "wide":
             line["extras"] = extras(ss, torch, ctx, device, rows, cols, view)
         if world == 1 and not args.no_cpu_baseline:

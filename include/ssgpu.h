@@ -512,15 +512,20 @@ int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_c
 
 /* ---- run ------------------------------------------------------------------ */
 /* cols: one entry per attribute of the plan's input schema, DEVICE pointers.
- * INPUT LIFETIME (ABI 6 spells it out): a run is asynchronous on the context's stream, and two things can make the library
- * read the input columns AGAIN after ssgpu_plan_run has returned -- a GroupAggregate whose lazily read run feedback reports
- * an overflow after all (the run is repeated), and a floating MIN / MAX that met a NaN (the run is repeated once in the
- * plan's NaN-exact form).  Both happen when the result is first touched (ssgpu_result_row_count / _column /
- * _device_column / _write_file) or when the plan runs again.  So: the columns passed to ssgpu_plan_run / _run_partial (and
- * the block passed to ssgpu_plan_run_block, and the auxiliary input) must stay alive and UNMODIFIED until the result has
- * been fetched or the plan has been run again or destroyed -- the same rule the reference states for ScanView ("the view
- * must outlive the operation", cursor/core/scan_view.h).  A caller that cannot guarantee it sets the context option
- * "lazy_feedback" = 0 (every run then settles before it returns) and fetches before it releases its input. */
+ * INPUT LIFETIME.  By default (ABI 7; context option "lazy_feedback" = 0) ssgpu_plan_run returns with every decision made that
+ * could send the library back to the input columns: a GroupAggregate's overflow / feedback words have been read, a floating
+ * MIN / MAX that met a NaN has been repeated in the plan's NaN-exact form.  The run itself is still asynchronous work on the
+ * context's stream in general, so the rule is the reference's for ScanView ("the view must outlive the operation",
+ * cursor/core/scan_view.h) shortened to the run: the columns passed to ssgpu_plan_run (the block passed to
+ * ssgpu_plan_run_block, the auxiliary input) must stay alive and unmodified until ssgpu_plan_run has returned AND the stream
+ * has been synchronised (ssgpu_ctx_synchronize, or any result access) -- after that they may be freed or overwritten, and
+ * the result is still fetched correctly (tests/test_cursor_contract_gpu.py::test_input_may_be_overwritten_after_a_synchronised_run).
+ * "lazy_feedback" = 1 is the opt-in for callers that step a plan without ever waiting for the host (a sharded job's
+ * steps: supersonic_amd/distributed.py, include/supersonic_amd/sharded.h, bench.py): a GroupAggregate in its steady state
+ * then leaves its feedback words on the stream, and a run that overflowed after all -- or met a NaN -- is repeated FROM THE
+ * INPUT COLUMNS when its result is first touched (ssgpu_result_row_count / _column / _device_column / _write_file) or when
+ * the plan runs again.  Such a caller keeps the columns of ssgpu_plan_run / _run_partial alive and unmodified until the
+ * result has been fetched or the plan has been run again or destroyed. */
 int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
                    int64_t rows, ssgpu_result** out);
 int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);
@@ -579,8 +584,10 @@ int ssgpu_plan_fold_partials(ssgpu_plan* plan, const void* images, int32_t n_ima
  *   check    ssgpu_plan_dense_flags (after any number of steps; it synchronises): what the headers of the LAST fold carried
  *            -- bit 1 a record segment ran full on some rank (ssgpu_plan_dense_grow on every rank, repeat the step), bit 2 a
  *            key outside the ranges (agree on new ranges, ssgpu_plan_set_dense again, repeat), error: the OR of the ranks'
- *            evaluation-error words.  Every rank sees the same flags: a failing rank still sends its (flagged) chunks, so no
- *            rank returns early from a step while others wait in the collective.
+ *            evaluation-error words.  Every rank sees the same flags: a rank whose ssgpu_plan_run_dense FAILED (memory quota,
+ *            interrupt, ...) calls ssgpu_plan_dense_fail(table, code) instead and still takes part in the all-to-all -- its
+ *            chunks arrive flagged (bit 3, the return code in bits 8..23 of `flags`), every rank raises the same error, and
+ *            nobody waits in the collective for a rank that has already returned.
  *
  * ssgpu_plan_key_ranges / _set_dense return SSGPU_ERROR_NOT_IMPLEMENTED for a plan this form cannot take (not a single
  * plain GroupAggregate stage; floating keys; FIRST / LAST aggregates, whose values live in the shard that saw the row) and
@@ -602,6 +609,7 @@ int ssgpu_plan_run_dense(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_c
 int ssgpu_plan_fold_dense(ssgpu_plan* plan, const void* chunks, int32_t n_chunks, ssgpu_result** out);
 int ssgpu_plan_dense_flags(ssgpu_plan* plan, uint32_t* flags, uint32_t* error);
 int ssgpu_plan_dense_grow(ssgpu_plan* plan);
+int ssgpu_plan_dense_fail(ssgpu_plan* plan, void* table, int32_t code);
 int ssgpu_plan_finalize(ssgpu_plan* plan, ssgpu_result** out);
 /* ssgpu_plan_fold_partials + ssgpu_plan_finalize as ONE kernel launch (ABI 6): what follows the collective of a sharded scalar
  * aggregate is a few hundred bytes of work -- three dependent launches of it cost a measurable part of a step at the shard

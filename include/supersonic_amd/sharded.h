@@ -149,6 +149,9 @@ class ShardedGroupAggregate {
     std::vector<std::unique_ptr<Operation>> own_children;
     for (Operation* c : local_children) own_children.emplace_back(c);
     if (own_children.empty()) { error_code_ = ERROR_INVALID_ARGUMENT_VALUE; error_ = "no local shard"; return; }
+    // a sharded job steps its plans without waiting for the host and keeps its shards' columns alive: the opt-in of ssgpu.h's
+    // "lazy_feedback" (the default settles every run before it returns)
+    ssgpu_ctx_set_option(internal::Context::Get().ctx, "lazy_feedback", 1);
     // the input's types decide which sums travel as (SUM, SUM_RESIDUAL) pairs: bind the child once to learn them
     TupleSchema child_schema;
     {
@@ -213,13 +216,22 @@ class ShardedGroupAggregate {
     const int n_local = static_cast<int>(shard_cursors_.size());
     const int n_images = comm_ ? world_ : n_local;                          // images that meet in this process's merge
     hipStream_t stream = static_cast<hipStream_t>(ssgpu_ctx_stream(ctx));   // NULL = the legacy default stream
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
       int rc = SSGPU_OK;
+      // A rank whose shard run fails (memory quota, interrupt, an input that does not bind like the others') must NOT return here
+      // while the other ranks enter the collective below -- they would wait in ncclAllGather / ncclSend forever.  It sends an
+      // EMPTY image flagged with its return code instead (header word 5), and every rank fails the step with that code once
+      // the trailer has been read.  (Without a communicator there is nobody to wait: fail at once.)
+      int local_fail = SSGPU_OK; std::string local_fail_msg;
       for (int l = 0; l < n_local; ++l) {
         internal::DeviceCursor* sc = internal::AsDeviceCursor(shard_cursors_[static_cast<size_t>(l)].get());
         sc->Rewind();
         rc = sc->RunOnDevice();
-        if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+        if (rc != SSGPU_OK) {
+          if (!comm_) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+          local_fail = rc; local_fail_msg = ssgpu_last_error(ctx);
+          break;
+        }
       }
       internal::DeviceCursor* shard = internal::AsDeviceCursor(shard_cursors_[0].get());
       ssgpu_plan* plan = shard->plan_handle();
@@ -247,8 +259,11 @@ class ShardedGroupAggregate {
         }
         if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
       } else if (exchange_ == KEY_RANGE) {
-        rc = ssgpu_result_route_images(shard->result_handle(), static_cast<int32_t>(group_by_.size()), world_, static_cast<int64_t>(capacity_), image_);
-        if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+        rc = local_fail == SSGPU_OK ? ssgpu_result_route_images(shard->result_handle(), static_cast<int32_t>(group_by_.size()), world_, static_cast<int64_t>(capacity_), image_) : local_fail;
+        if (rc != SSGPU_OK) {
+          if (local_fail == SSGPU_OK) { local_fail = rc; local_fail_msg = ssgpu_last_error(ctx); }
+          if (!FlagFailedImages(world_, image_bytes, local_fail, stream)) return internal::FailCursor(ERROR_UNKNOWN_ERROR, "cannot flag the images of a failed shard run");
+        }
         bool ok = ncclGroupStart() == ncclSuccess;                     // the ONE collective: image d -> rank d
         for (int r = 0; ok && r < world_; ++r)
           ok = ncclSend(static_cast<const char*>(image_) + static_cast<size_t>(r) * image_bytes, static_cast<size_t>(image_bytes), ncclUint8, r, comm_, stream) == ncclSuccess &&
@@ -256,7 +271,12 @@ class ShardedGroupAggregate {
         ok = (ncclGroupEnd() == ncclSuccess) && ok;
         if (!ok) return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the all-to-all of the result images (ncclSend / ncclRecv) failed");
       } else {
-        rc = ssgpu_result_pack_image(shard->result_handle(), static_cast<int64_t>(capacity_), image_);
+        rc = local_fail == SSGPU_OK ? ssgpu_result_pack_image(shard->result_handle(), static_cast<int64_t>(capacity_), image_) : local_fail;
+        if (rc != SSGPU_OK) {
+          if (local_fail == SSGPU_OK) { local_fail = rc; local_fail_msg = ssgpu_last_error(ctx); }
+          if (!FlagFailedImages(1, image_bytes, local_fail, stream)) return internal::FailCursor(ERROR_UNKNOWN_ERROR, "cannot flag the image of a failed shard run");
+          rc = SSGPU_OK;
+        }
         if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
         if (ncclAllGather(image_, images_, static_cast<size_t>(image_bytes), ncclUint8, comm_, stream) != ncclSuccess)   // the ONE collective
           return internal::FailCursor(ERROR_UNKNOWN_ERROR, "ncclAllGather failed");
@@ -314,12 +334,19 @@ class ShardedGroupAggregate {
       if (hipMemcpyAsync(trailer, trailer_dev, 32, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
         return internal::FailCursor(ERROR_UNKNOWN_ERROR, "cannot read the images' trailer");
       largest_table_ = static_cast<rowcount_t>(trailer[0]);
-      if (trailer[3]) return internal::FailCursor(ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate");
+      // (every rank reads the same trailer -- after the all-reduce above where they unpacked different images -- so every rank
+      //  takes the same branch below: nobody proceeds with a result the others rejected, nobody repeats alone)
+      if (trailer[3] >> 8) {
+        const int code = static_cast<int>(trailer[3] >> 8);
+        return internal::FailCursor(code, local_fail != SSGPU_OK ? local_fail_msg : "the GroupAggregate of another rank's shard failed");
+      }
+      if (trailer[3] & 0xFF) return internal::FailCursor(ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate");
       if (trailer[2]) {
-        // flagged without a table that is too large: a shard's lazily read run feedback asked for the step to be repeated
-        // (ssgpu.h, ssgpu_result_route_images) -- every rank sees the same verdict, so every rank repeats
-        if (largest_table_ <= capacity_ && attempt + 1 < 3) continue;
-        return internal::FailCursor(ERROR_MEMORY_EXCEEDED, "a shard's partial table has more rows than capacity_rows (largest_table() tells how many)");
+        if (attempt + 1 >= 6) break;
+        // a table that outgrew the images: larger images (as distributed.py's check() does) and the step again; flagged without
+        // one: a shard's lazily read run feedback asked for the step to be repeated (ssgpu.h, ssgpu_result_route_images)
+        if (largest_table_ > capacity_) capacity_ = (largest_table_ * 5 / 4 + 1023) / 1024 * 1024;
+        continue;
       }
       return FailureOrOwned<Cursor>(new internal::BorrowedCursor(merge));
     }
@@ -330,6 +357,14 @@ class ShardedGroupAggregate {
  private:
   static constexpr const char* kResidual = "$res";   // suffix of the hidden column that carries a DOUBLE sum's residual across shards
   static bool Has(const std::vector<std::string>& v, const std::string& x) { for (auto& e : v) if (e == x) return true; return false; }
+  // header (64 bytes: rows, capacity, flagged, rows wanted, evaluation errors, FAILURE CODE, 0, 0) of n empty images of a failed run
+  bool FlagFailedImages(int n, int64_t image_bytes, int code, hipStream_t stream) {
+    fail_header_[0] = 0; fail_header_[1] = static_cast<int64_t>(capacity_); fail_header_[2] = 0; fail_header_[3] = 0; fail_header_[4] = 0;
+    fail_header_[5] = code; fail_header_[6] = 0; fail_header_[7] = 0;
+    for (int d = 0; d < n; ++d)
+      if (hipMemcpyAsync(static_cast<char*>(image_) + static_cast<size_t>(d) * image_bytes, fail_header_, sizeof(fail_header_), hipMemcpyHostToDevice, stream) != hipSuccess) return false;
+    return hipStreamSynchronize(stream) == hipSuccess;     // (fail_header_ is pageable host memory: the copies are done before it changes)
+  }
   void Free() {
     if (image_) (void)hipFree(image_);
     if (images_) (void)hipFree(images_);
@@ -352,6 +387,7 @@ class ShardedGroupAggregate {
   DeviceView gathered_;
   void* image_ = nullptr; void* images_ = nullptr; void* unpacked_ = nullptr; void* verdict_dev_ = nullptr;
   int64_t image_bytes_ = 0, unpacked_bytes_ = 0;
+  int64_t fail_header_[8] = {0};
 };
 
 }  // namespace supersonic

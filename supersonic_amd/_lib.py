@@ -183,6 +183,7 @@ SYMBOLS = [
     ("ssgpu_plan_fold_dense", C.c_int, [P, P, C.c_int32, C.POINTER(P)]),
     ("ssgpu_plan_dense_flags", C.c_int, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("ssgpu_plan_dense_grow", C.c_int, [P]),
+    ("ssgpu_plan_dense_fail", C.c_int, [P, P, C.c_int32]),
     ("ssgpu_plan_finalize", C.c_int, [P, C.POINTER(P)]),
     ("ssgpu_plan_fold_finalize", C.c_int, [P, P, C.c_int32, C.POINTER(P)]),
     ("ssgpu_plan_image_layout", C.c_int, [P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -1233,6 +1233,11 @@ class Plan(object):
     def dense_grow(self):
         self.ctx.check(self.lib.ssgpu_plan_dense_grow(self.handle))
 
+    def dense_fail(self, table_ptr, code):
+        """This rank's run failed with `code`: flag every chunk of its table, so that the step's collective still happens and every
+        rank learns of the failure from the headers."""
+        self.ctx.check(self.lib.ssgpu_plan_dense_fail(self.handle, C.c_void_p(table_ptr), int(code)))
+
     def fold_partials(self, images_ptr, n_images):
         """Fold n_images all-gathered images of the partial state (device pointer) into this plan's state."""
         self.ctx.check(self.lib.ssgpu_plan_fold_partials(self.handle, C.c_void_p(images_ptr), n_images))

@@ -56,13 +56,14 @@ __global__ __launch_bounds__(256) void ssgpu_unpack_images_kernel(const ImageUnp
     u8* valid = reinterpret_cast<u8*>(P.unpacked) + P.valid_off + (u64)r * P.capacity;
     for (u64 i = first; i < P.capacity; i += stride) valid[i] = i < rows ? (u8)1 : (u8)0;
     if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-      u64 mx = 0, sum = 0, over = 0, err = 0;
+      u64 mx = 0, sum = 0, over = 0, err = 0, failed = 0;
       for (u32 q = 0; q < P.n_images; ++q) {
         const u64* hq = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(P.images) + (u64)q * P.image_bytes);
         mx = hq[3] > mx ? hq[3] : mx; sum += hq[0]; over |= hq[2]; err |= hq[4];
+        failed = hq[5] > failed ? hq[5] : failed;     // a rank whose shard run FAILED (quota, interrupt ...) still sends an (empty) image: its return code
       }
       u64* t = reinterpret_cast<u64*>(reinterpret_cast<char*>(P.unpacked) + P.trailer_off);
-      t[0] = mx; t[1] = sum; t[2] = over; t[3] = err;
+      t[0] = mx; t[1] = sum; t[2] = over; t[3] = (err & 0xFFull) | (failed << 8);
     }
     return;
   }
@@ -183,12 +184,13 @@ __global__ __launch_bounds__(256) void ssgpu_dense_fold_kernel(const DenseFoldPa
   const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
-      u32 flags = 0, err = 0;
+      u32 flags = 0, err = 0, failed = 0;
       for (u32 c = 0; c < P.n_chunks; ++c) {
         const u32* h = reinterpret_cast<const u32*>(static_cast<const char*>(P.chunks) + (u64)c * P.chunk_bytes);
-        flags |= h[0]; err |= h[1];
+        flags |= h[0] & 0xFFu; err |= h[1];
+        failed = (h[0] >> 8) > failed ? (h[0] >> 8) : failed;   // bits 8..: the return code of a rank whose shard run failed (bit 3 set)
       }
-      P.flags_out[0] = flags; P.flags_out[1] = err;   // (what THIS fold's headers carried)
+      P.flags_out[0] = flags | (failed << 8); P.flags_out[1] = err;   // (what THIS fold's headers carried)
     }
     for (int q = 0; q < 2; ++q) for (u32 w = threadIdx.x; w < P.n_clear[q]; w += 256u) P.clear[q][w] = 0u;
   }
@@ -242,15 +244,15 @@ hipError_t ssgpu_launch_dense_fold(const DenseFoldParams& P, hipStream_t stream)
   return hipGetLastError();
 }
 // the header of every chunk of a freshly filled table buffer: the run's overflow / domain-miss flags and its evaluation-error word
-__global__ void ssgpu_dense_headers_kernel(char* chunks, u32 n_chunks, u64 chunk_bytes, const u32* __restrict__ overflow4, const u32* __restrict__ error_flag) {
-  const u32 flags = (overflow4[0] ? 1u : 0u) | (overflow4[1] ? 2u : 0u) | (overflow4[3] ? 4u : 0u);
-  const u32 err = error_flag ? *error_flag : 0u;
+__global__ void ssgpu_dense_headers_kernel(char* chunks, u32 n_chunks, u64 chunk_bytes, const u32* __restrict__ overflow4, const u32* __restrict__ error_flag, u32 forced) {
+  const u32 flags = forced ? forced : (overflow4[0] ? 1u : 0u) | (overflow4[1] ? 2u : 0u) | (overflow4[3] ? 4u : 0u);
+  const u32 err = !forced && error_flag ? *error_flag : 0u;
   for (u32 c = threadIdx.x; c < n_chunks; c += blockDim.x) {
     u32* h = reinterpret_cast<u32*>(chunks + (u64)c * chunk_bytes);
     h[0] = flags; h[1] = err;
   }
 }
-hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsigned long long chunk_bytes, const unsigned int* overflow4, const unsigned int* error_flag, hipStream_t stream) {
-  hipLaunchKernelGGL(ssgpu_dense_headers_kernel, dim3(1), dim3(64), 0, stream, static_cast<char*>(chunks), n_chunks, (u64)chunk_bytes, overflow4, error_flag);
+hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsigned long long chunk_bytes, const unsigned int* overflow4, const unsigned int* error_flag, hipStream_t stream, unsigned int forced_flags) {
+  hipLaunchKernelGGL(ssgpu_dense_headers_kernel, dim3(1), dim3(64), 0, stream, static_cast<char*>(chunks), n_chunks, (u64)chunk_bytes, overflow4, error_flag, forced_flags);
   return hipGetLastError();
 }

@@ -178,7 +178,9 @@ struct DenseFoldParams {
   unsigned int* clear[2]; unsigned int n_clear[2];   // words this launch also zeroes (the extraction's control words)
 };
 hipError_t ssgpu_launch_dense_fold(const DenseFoldParams& P, hipStream_t stream);
-hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsigned long long chunk_bytes, const unsigned int* overflow4, const unsigned int* error_flag, hipStream_t stream);
+// forced_flags != 0: every header gets exactly these flags (a rank whose run failed: 8 | return code << 8) and a zero error word
+hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsigned long long chunk_bytes, const unsigned int* overflow4, const unsigned int* error_flag, hipStream_t stream,
+                                      unsigned int forced_flags = 0);
 // Heavy-hitter detection: one workgroup counts the packed keys of `n_sample` rows taken at a regular stride (predicates
 // applied) and reports the keys seen at least `min_count` times -- at most SSGPU_HOT_MAX, the most frequent ones.
 // out[0] = number of keys, out[1 + 2 i] = key i, out[2 + 2 i] = its count in the sample.

@@ -56,10 +56,14 @@ struct ssgpu_ctx {
   int64_t group_scout_rows = 8 << 20;   // ... "large": inputs of at least this many rows (a smaller value helps first runs and costs steady ones: see run_group_agg)
   int64_t group_resident = 1;    // 0: plain stages take the slab form through scatter + aggregation like every other stage (tests, A/B)
   int64_t group_dense = 1;       // 0: never index group tables by the keys' value ranges (dense slots, see DenseState); SSGPU_GROUP_DENSE sets the process default
-  int64_t dense_parts = 0;       // partitions of the dense partitioned shape (0 = as many as keep the tables within 80 KiB, at least 512)
+  int64_t dense_parts = 0;       // partitions of the dense partitioned shape (0 = 256, more -- the next power of two -- when the tables would outgrow 80 KiB)
   int64_t dense_min_rows = 1 << 16;   // inputs below this many rows never look for dense ranges (tests lower it to reach the dense kernels with small inputs)
   int64_t async_handoff = 1;     // 0: every stage hand-off reads the row count on the host (a stream synchronise), even where the next stage could take it from the device
-  int64_t lazy_feedback = 1;     // 0: a GroupAggregate reads its overflow / feedback words back at the end of EVERY run (a stream synchronise per run)
+  int64_t lazy_feedback = 0;     // 1: a GroupAggregate in its steady state leaves its overflow / feedback words on the stream instead of reading them back
+                                 // at the end of every run, and a run may be REPEATED from the caller's input columns when its result is first touched
+                                 // (an overflow seen late, a NaN in a floating MIN / MAX).  Off by default (round 5): ssgpu_plan_run returns with every
+                                 // such decision made -- the input may be released or overwritten once the run has been synchronised.  Callers that
+                                 // step a plan without touching the host opt in (distributed.py, sharded.h, bench.py) and keep their input alive.
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
@@ -1351,9 +1355,14 @@ static bool dense_configure(const ssgpu_ctx* c, const Stage& st, StageExec& ex, 
   D.resident = !tabled && n_chunks == 1 && slots <= cfull && c->group_slab != 0 && c->group_resident != 0;
   if (D.resident) { D.np = 1; D.cap = (uint32_t)slots; }
   else {
-    uint64_t np = (slots + cmax - 1) / cmax;
-    const uint64_t want = c->dense_parts > 0 ? (uint64_t)c->dense_parts : 512ull;
-    np = std::max(np, std::min<uint64_t>(want, std::max<uint64_t>(slots / 64, 1)));   // (at least 64 entries per partition)
+    // partitions: 256 (one aggregation workgroup per CU) unless the tables would not fit 80 KiB of LDS, then the next power of
+    // two -- measured on config #3's 100 172 slots, 100 M rows: 192 partitions 2.85 ms, 256 2.57, 384 2.95, 512 2.68, 1024 2.96
+    // (profiles/r05_dense_parts.json; fewer partitions = fewer open output lines in the scatter, powers of two beat the others)
+    const uint64_t np_min = (slots + cmax - 1) / cmax;
+    uint64_t np;
+    if (c->dense_parts > 0) np = std::max<uint64_t>((uint64_t)c->dense_parts, np_min);
+    else { np = 256; while (np < np_min) np *= 2; }
+    np = std::min(np, std::max<uint64_t>(np_min, std::max<uint64_t>(slots / 64, 1)));   // (at least 64 entries per partition where the slots allow)
     np = std::max<uint64_t>(np, 2);
     np = (np + n_chunks - 1) / n_chunks * n_chunks;
     if (np > 4096) return false;
@@ -2618,6 +2627,17 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
   if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   int rc = run_plan(p, cols, n_cols, rows, 0, false);
   if (rc != SSGPU_OK) return rc;
+  if (!p->ctx->lazy_feedback) {
+    // the safe mode (default): everything that could make the library read the input columns again is decided HERE, while the
+    // caller still holds them -- run feedback is never deferred in this mode, and the NaN-exact repeat of a floating MIN / MAX
+    // happens now instead of when the result is first touched.  (An evaluation error still surfaces where it always did: when
+    // the result is touched -- its flag stays set until the next run.)
+    rc = settle_plan(p);
+    if (rc != SSGPU_OK) return rc;
+    (void)check_error_flags(p);      // synchronises; sets nan_seen
+    rc = fix_nan_minmax(p);
+    if (rc != SSGPU_OK) return rc;
+  }
   if (out) *out = &p->result;
   return SSGPU_OK;
 }
@@ -2860,6 +2880,18 @@ int ssgpu_plan_dense_flags(ssgpu_plan* p, uint32_t* flags, uint32_t* error) {
   }
   if (flags) *flags = w[0];
   if (error) *error = w[1] & 0xFFu;   // (the NaN-in-MIN/MAX bit is not an error: the fold skips NaNs like every order-independent shape)
+  return SSGPU_OK;
+}
+// A rank whose shard run failed (memory quota, interrupt, anything ssgpu_plan_run_dense returned) must still take part in the
+// step's collective, or the other ranks wait in it forever: it sends its table with every chunk header flagged "failed" +
+// the return code, and every rank's ssgpu_plan_dense_flags reports it after the fold.
+int ssgpu_plan_dense_fail(ssgpu_plan* p, void* table, int32_t code) {
+  int rc = dense_stage_of(p, true);
+  if (rc != SSGPU_OK) return rc;
+  ssgpu_ctx* c = p->ctx; StageExec& ex = p->exec[0];
+  if (!ex.dense.fixed || !table || code <= 0) { c->err = "ssgpu_plan_dense_fail: no table layout (ssgpu_plan_set_dense), or no failure code"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, ssgpu_launch_dense_headers(table, ex.dense.n_chunks, ex.dense.chunk_bytes, nullptr, nullptr, c->stream, 8u | ((uint32_t)code << 8)));
   return SSGPU_OK;
 }
 int ssgpu_plan_dense_grow(ssgpu_plan* p) {

@@ -528,6 +528,7 @@ class DeviceShardedGroupAggregate(object):
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.ctx, self.group = ctx, group
+        ctx.set_option("lazy_feedback", 1)       # a step never waits for the host; the job keeps its shard's columns alive (ssgpu.h: INPUT LIFETIME)
         assert exchange in ("all_gather", "key_range")
         self.exchange = exchange
         self.world = dist.get_world_size(group)
@@ -569,31 +570,48 @@ class DeviceShardedGroupAggregate(object):
             return max(1024, (int(rows * 1.3 / self.world) + 2047) // 1024 * 1024)
         return max(1024, (int(rows) * 5 // 4 + 1023) // 1024 * 1024)
 
-    def _agree_capacity(self):
+    def _agree_capacity(self, failed=0):
         """Set-up only: the largest partial table of any rank, with head room (one all-reduce, one host read)."""
         torch = self.torch
-        rows = torch.tensor([self.first.lib.ssgpu_result_row_count(self.first._result)], dtype=torch.int64, device=self.device)
+        rows = torch.tensor([0 if failed else self.first.lib.ssgpu_result_row_count(self.first._result)], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(rows, op=self.dist.ReduceOp.MAX, group=self.group)
         self.setup_collectives += 1
         self.capacity = self._capacity_for(int(rows.item()))
 
+    def _failed_images(self, code):
+        """This rank's shard run failed: its images leave EMPTY and flagged with the return code (header word 5), so that the
+        step's collective still happens and every rank's check() raises -- a rank that returned here would leave the others
+        waiting in the all-to-all / all-gather forever."""
+        torch = self.torch
+        header = torch.tensor([0, self.capacity, 0, 0, 0, int(code), 0, 0], dtype=torch.int64).view(torch.uint8).to(self.device)
+        n_out = self.world if self.exchange == "key_range" else 1
+        for d in range(n_out):
+            self.image[d * self.image_bytes:d * self.image_bytes + 64].copy_(header)
+
     def step(self, view=None):
         torch = self.torch
         self.collectives = 0
-        self.first.run(view)
+        failed = 0
+        try:
+            self.first.run(view)
+        except ss.SupersonicException as e:
+            failed = e.return_code if e.return_code > 0 else ss.ERROR_UNKNOWN
         if not self.capacity:
-            self._agree_capacity()
+            self._agree_capacity(failed)
         if getattr(self, "_cap_alloc", None) != self.capacity:
             self._allocate()
             self._cap_alloc = self.capacity
         cur = torch.cuda.current_stream(self.device)
-        if self.exchange == "key_range":
+        if failed:
+            self._failed_images(failed)
+        elif self.exchange == "key_range":
             self.first.route_images(len(self.group_by), self.world, self.capacity, self.image.data_ptr())
-            cur.wait_stream(self._lib_stream)                  # the collective reads what the routing kernels wrote
-            self.dist.all_to_all_single(self.images, self.image, group=self.group)     # image d -> rank d, equal sizes
         else:
             self.first.pack_image(self.capacity, self.image.data_ptr())
-            cur.wait_stream(self._lib_stream)                  # the collective reads what the pack kernel wrote
+        cur.wait_stream(self._lib_stream)                  # the collective reads what the routing / pack kernels wrote
+        if self.exchange == "key_range":
+            self.dist.all_to_all_single(self.images, self.image, group=self.group)     # image d -> rank d, equal sizes
+        else:
             self.dist.all_gather_into_tensor(self.images, self.image, group=self.group)
         self.collectives += 1
         self._lib_stream.wait_stream(cur)
@@ -611,7 +629,14 @@ class DeviceShardedGroupAggregate(object):
         self.ctx.synchronize()
         self.torch.cuda.synchronize(self.device)
         t = self.unpacked[self.unpacked_bytes - 32:].view(self.torch.int64).tolist()
-        if t[3]:
+        if self.exchange == "key_range" and self.world > 1:   # every rank unpacked other images: the failure / error word as well as the capacity verdict below
+            w = self.torch.tensor([int(t[3])], dtype=self.torch.int64, device=self.device)
+            self.dist.all_reduce(w, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.setup_collectives += 1
+            t[3] = int(w.item())
+        if t[3] >> 8:
+            raise ss.SupersonicException(t[3] >> 8, "the GroupAggregate of a rank's shard failed (return code %d)" % (t[3] >> 8))
+        if t[3] & 0xFF:
             raise ss.SupersonicException(ss.ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate")
         if self.exchange == "key_range" and self.world > 1:
             # every rank saw other images: the verdict and the new capacity have to be the same everywhere (one tiny
@@ -677,6 +702,9 @@ class PlanDenseBackend(object):
     def dense_grow(self):
         self.plan.dense_grow()
 
+    def dense_fail(self, table, code):
+        self.plan.dense_fail(table.data_ptr(), code)
+
     def local_result(self):
         return self.plan.fetch()
 
@@ -729,7 +757,12 @@ class DenseShardedGroupAggregate(object):
         self.collectives = 0
         if self.layout is None:
             self.setup(view)
-        self.backend.run_dense(view, self.table)
+        try:
+            self.backend.run_dense(view, self.table)
+        except ss.SupersonicException as e:
+            # this rank's shard failed (memory quota, interrupt ...): it still takes part in the collective -- its chunks leave flagged
+            # with the code, every rank's check() raises it; returning here would leave the other ranks waiting in the all-to-all
+            self.backend.dense_fail(self.table, e.return_code if e.return_code > 0 else ss.ERROR_UNKNOWN)
         self.backend.before_collective()
         self.dist.all_to_all_single(self.chunks, self.table, group=self.group)     # chunk r of every rank -> rank r
         self.collectives += 1
@@ -739,6 +772,8 @@ class DenseShardedGroupAggregate(object):
 
     def check(self):
         flags, error = self.backend.dense_flags()      # the OR over every rank's headers: the same words on every rank
+        if flags & 8:
+            raise ss.SupersonicException(flags >> 8, "the GroupAggregate of a rank's shard failed (return code %d)" % (flags >> 8))
         if error:
             raise ss.SupersonicException(ss.ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate")
         if flags & 4:                                   # some rank met a key outside the ranges: agree on wider ones

@@ -366,6 +366,50 @@ def test_dense_tables_of_several_shards_fold_into_disjoint_owners(world):
     assert len(exact) == len(want) - 1
 
 
+@pytest.mark.parametrize("exchange", ["dense", "key_range", "all_gather"])
+def test_config4_a_failing_shard_run_still_joins_the_collective_and_fails_the_step(exchange):
+    # a rank whose shard run fails BEFORE the step's collective (here: an interrupt; a memory quota is the same path) must not
+    # return while the others wait in it: it sends flagged, empty chunks / images, and every rank's check() raises the code.
+    # One rank, RCCL to itself: the step completes (no hang, the collective ran) and check() raises INTERRUPTED; the next step works.
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from supersonic_amd.distributed import DenseShardedGroupAggregate, DeviceShardedGroupAggregate, PlanDenseBackend
+    cols = bench.host_columns(np, "group", 300_000, seed=5)
+    view = ss.View(bench.group_schema(ss), cols)
+    op = ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), bench.group_spec(ss), None, bench.group_child(ss, view))
+    _s, want = oracle.run(op)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = make_ctx()
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        if exchange == "dense":
+            backend = PlanDenseBackend(ctx, op)
+            job = DenseShardedGroupAggregate(backend)
+            plan_of = lambda: backend.plan                                 # noqa: E731
+        else:
+            job = DeviceShardedGroupAggregate(ctx, ["k1", "k2"], bench.group_spec(ss), bench.group_child(ss, view), exchange=exchange)
+            plan_of = lambda: job.result()[0]                              # noqa: E731
+
+        def good_step():
+            job.step(view)
+            while not job.check():
+                job.step(view)
+            assert_cols_equal(sort_rows(to_cols(plan_of().fetch())), sort_rows(want), context="%s exchange" % exchange)
+        good_step()
+        (backend.plan if exchange == "dense" else job.first).interrupt()    # the next run of the shard plan returns INTERRUPTED
+        job.step(view)                                                      # ... and the step still reaches (and leaves) its collective
+        assert job.collectives == 1
+        with pytest.raises(ss.SupersonicException) as e:
+            job.check()
+        assert e.value.return_code == ss.INTERRUPTED, e.value
+        good_step()                                                         # the job is usable afterwards
+    finally:
+        dist.destroy_process_group()
+
+
 # ---- config #5: Sort(d ASC) of the 8-column block -----------------------------------------------------------------------
 def check_sort(cols, expect_mode, context, **options):
     view = ss.View(bench.bench_schema(ss), cols)

@@ -299,3 +299,46 @@ def test_specialised_kernels_survive_the_process(tmp_path):
     assert child(cache)["compilations"] == 0                        # ... and the replacement is good
     off = child("")
     assert off["compilations"] >= 1 and off["disk_hits"] == 0, off   # no disk cache at all
+
+
+# ---- INPUT LIFETIME (include/ssgpu.h, ABI 7): under the defaults a run is settled when ssgpu_plan_run returns -- run feedback read,
+# ---- a NaN-exact repeat done -- so the input may be overwritten once the stream has been synchronised, and the result is still right.
+# ---- (With "lazy_feedback" = 1, the sharded drivers' opt-in, the same sequence may repeat a run from the overwritten columns.) ----------
+def test_input_may_be_overwritten_after_a_synchronised_run():
+    torch = pytest.importorskip("torch")
+    from oracle import oracle
+    from helpers import assert_cols_equal, sort_rows, to_cols
+    n = 300000
+    rng = np.random.default_rng(11)
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64), ss.Attribute("d", ss.DOUBLE)])
+
+    def host(groups, nan_first=False):
+        d = rng.integers(-4000, 4000, n) * 0.25
+        if nan_first:
+            d[:5000] = np.nan                      # leading NaNs: the reference keeps a group's first value when it is a NaN
+        return [rng.integers(0, groups, n), rng.integers(-1000, 1000, n), d]
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "c").AddAggregation(ss.MIN, "d", "mn")
+            .AddAggregation(ss.MAX, "d", "mx"))
+    few, many, nans = host(3000), host(250000), host(3000, nan_first=True)
+    dev = torch.device("cuda", 0)
+    tensors = [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c in few]
+    view = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in tensors], n)
+    ctx = ss.Context(0)                               # defaults: lazy_feedback = 0
+    ctx.set_option("group_capacity", 8192)            # 3000 groups fit the direct shape's table, 250000 overflow it (a repeated run)
+    ctx.set_option("group_dense", 0)
+    op = lambda cols: ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(ss.View(schema, cols)))   # noqa: E731
+    plan = ss.Plan(op(few), ctx)                      # (bound over a host View of the same schema; every run below takes the device columns)
+    torch.cuda.synchronize()
+    for _ in range(4):                                # into the steady state (where the lazy mode would stop reading feedback back)
+        plan.run(view)
+    for cols in (many, nans, few):
+        for t, c in zip(tensors, cols):
+            t.copy_(torch.from_numpy(np.ascontiguousarray(c)))
+        torch.cuda.synchronize()
+        plan.run(view)
+        ctx.synchronize()
+        for t in tensors:                             # the caller is done with its input: overwritten before the result is touched
+            t.zero_()
+        torch.cuda.synchronize()
+        _s, want = oracle.run(op(cols))
+        assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="input overwritten after run + synchronise")

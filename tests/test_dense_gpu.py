@@ -144,7 +144,9 @@ def test_negative_keys_null_keys_and_the_all_ones_key(specialize):
             assert infos[0]["reruns"] >= 1 and infos[-1]["part_seg_growth"] > 1, infos
 
 
-def test_ranges_are_widened_when_a_later_input_leaves_them():
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_ranges_are_widened_when_a_later_input_leaves_them(lazy):
+    # lazy = 1 (the sharded drivers' opt-in): the miss of a steady-state run is seen when the result is touched, and the run repeated
     n = 200_000
     rng = np.random.default_rng(7)
     first = keyed_view({"a": (ss.INT32, rng.integers(0, 100, n).astype(np.int32))}, n, seed=8)
@@ -152,7 +154,7 @@ def test_ranges_are_widened_when_a_later_input_leaves_them():
     op = keyed_op(first, ["a"])
     _s, want1 = oracle.run(op)
     _s, want2 = oracle.run(keyed_op(later, ["a"]))
-    plan = ss.Plan(op, dense_ctx())
+    plan = ss.Plan(op, dense_ctx(lazy_feedback=lazy))
     i1 = run_plan(plan, want1, "first ranges", runs=3)          # (the third run is past the lazy-feedback threshold: the miss of the next is seen late)
     assert i1[-1]["dense_slots"] == 100, i1
     i2 = run_plan(plan, want2, "wider ranges", runs=2, view=later)

@@ -1712,6 +1712,7 @@ def test_group_aggregate_lazy_feedback_repeats_an_overflowing_run(partition):
             .AddAggregation(ss.SUM, "d", "sd").AddAggregation(ss.MAX, "d", "mx"))
     few, many = view_of(300000, 3000), view_of(300000, 250000)
     ctx = ss.Context(0)
+    ctx.set_option("lazy_feedback", 1)                # (opt-in since round 5: the default settles every run before it returns)
     ctx.set_option("group_partition", partition)
     ctx.set_option("group_capacity", 8192)            # the direct shape's global table: 3000 groups fit, 250000 do not
     op = lambda v: ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), spec, None, ss.ScanView(v))   # noqa: E731
