@@ -332,16 +332,23 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True):
     nthreads = max(1, min(physical, 256))        # one thread per PHYSICAL core (SMT siblings add little to a streaming loop)
     bounds = [n * i // nthreads for i in range(nthreads + 1)]
     ops = [make(ss.View(schema, [c[bounds[i]:bounds[i + 1]] for c in cols])) for i in range(nthreads)]
+    # every thread drains its shard `inner` times per start: starting 128 Python threads costs milliseconds, a pass over a 1 / 128 share
+    # of the sample about as much -- a pass per start would time the thread starts (round 5's first 128-thread figure read 206 M rows/s)
+    inner = max(1, int(0.1 / max(elapsed / reps / nthreads, 1e-6)))
+
+    def drain_many(op):
+        for _ in range(inner):
+            drain(op)
     preps, pelapsed = 0, 0.0
-    while pelapsed < budget_s / 2 and preps < 200:
-        threads = [threading.Thread(target=drain, args=(o,)) for o in ops]
+    while pelapsed < budget_s / 2 and preps < 200 * inner:
+        threads = [threading.Thread(target=drain_many, args=(o,)) for o in ops]
         t0 = time.perf_counter()
         for t in threads:
             t.start()
         for t in threads:
             t.join()
         pelapsed += time.perf_counter() - t0
-        preps += 1
+        preps += inner
     out = {"value": one, "unit": "rows/s", "cores": 1, "kind": "port",
            "sample": "%d rows (same plan, seed 42), %d passes, %.1f s of CPU" % (n, reps, elapsed),
            "threads": {"value": n * preps / pelapsed, "cores": nthreads,

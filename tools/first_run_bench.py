@@ -25,6 +25,6 @@ for rows in (1 << 18, 1 << 20, 1 << 21, 1 << 22, 6_000_000, 1 << 23, 1 << 24):
     for _ in range(6):
         t = time.perf_counter(); plan.run(view); ctx.synchronize(); times.append((time.perf_counter() - t) * 1e3)
     info = [st for st in plan.stage_info() if st["kind"] == 3][-1]
-    out.append({"rows": rows, "first_run_ms": round(times[0], 3), "second_ms": round(times[1], 3), "steady_ms": round(min(times[2:]), 3), "steady_shape": info["group_shape"]})
+    out.append({"rows": rows, "first_run_ms": round(times[0], 3), "second_ms": round(times[1], 3), "steady_ms": round(min(times[2:]), 3), "steady_shape": info["group_shape"], "dense_slots": info["dense_slots"]})
     print(out[-1], flush=True)
 print(json.dumps({"groups": groups, "runs": out}))
