@@ -1199,6 +1199,169 @@ for _f, _want, _src in (("Greater", [True, False, False], ":146-151"), ("LessOrE
                         ("GreaterOrEqual", [True, True, False], ":160-165"), ("NotEqual", [True, False, True], ":167-172")):
     expr_case("Operators_Complements_" + _f, OT + _src, [I32, I32, BOOL], [r + [w] for r, w in zip(_cmp3, _want)], _f)
 
+
+# =====================================================================================================================================
+# DERIVED cases (kind "derived"): combinations the reference's own tests hold no vector of.  The expected rows are worked out BY HAND
+# from the cited reference lines -- each case carries its derivation -- not taken from the oracle or the device: a misreading shared by
+# oracle and kernels (written by the same hand) would show here as a disagreement with the derivation.
+# =====================================================================================================================================
+def derived_case(name, source, derivation, schema, rows, plan, exp_types, exp_rows, ordered=True):
+    CASES.append({"name": name, "source": source, "kind": "derived", "derivation": derivation,
+                  "input": {"schema": schema, "rows": rows}, "plan": plan,
+                  "expected": {"types": exp_types, "rows": exp_rows, "names": None, "nullable": None},
+                  "ordered": ordered, "expect_error": None})
+
+
+AGG = "supersonic/cursor/core/aggregator.cc:88-101"
+CLC = "supersonic/cursor/core/aggregate_clusters.cc:436-520"
+DST = "supersonic/cursor/core/column_aggregator.cc:308-376"
+RHS = "supersonic/cursor/infrastructure/row_hash_set.cc:500-511"
+AOP = "supersonic/base/infrastructure/aggregation_operators.h:290-320"
+D_CLUSTER = ("Aggregator::Init makes a DistinctAggregator for every aggregation with is_distinct, whatever cursor owns the Aggregator (" + AGG + "); "
+             "AggregateClusters numbers the clusters of a block 0, 1, 2 ... as result indices and a cluster is a run of ADJACENT equal keys (" + CLC + "); "
+             "DistinctAggregator keeps one value set PER RESULT INDEX, skips NULL inputs and feeds the inner aggregator only the first occurrence of a value (" + DST + "). ")
+
+# ---- A: DISTINCT aggregates inside AggregateClusters --------------------------------------------------------------------------------
+derived_case("Derived_Clusters_DistinctPerCluster", AGG + "; " + CLC + "; " + DST,
+             D_CLUSTER + "Keys 1,1,1,2,2,1 = three clusters (the last 1 is not adjacent to the first run).  Cluster 0 holds 5,5,7: distinct {5,7} -> SUM 12, "
+             "COUNT 2; plain COUNT 3, SUM 17.  Cluster 1 holds 5,NULL: distinct {5} -> 5, 1; COUNT 1, SUM 5.  Cluster 2 holds 5 -> 5, 1, 1, 5 "
+             "(its set is its own: the 5 of cluster 0 does not hide it).",
+             cols([I32, I32]), [[1, 5], [1, 5], [1, 7], [2, 5], [2, None], [1, 5]],
+             ["AggregateClusters", ["ProjectNamedAttribute", "col0"],
+              [["SUM_DISTINCT", "col1", "sd"], ["COUNT_DISTINCT", "col1", "cd"], ["COUNT", "col1", "c"], ["SUM", "col1", "s"]], "INPUT"],
+             [I32, I32, U64, U64, I32], [[1, 12, 2, 3, 17], [2, 5, 1, 1, 5], [1, 5, 1, 1, 5]])
+derived_case("Derived_Clusters_DistinctAllNullCluster", AGG + "; " + DST,
+             D_CLUSTER + "A cluster whose values are all NULL never calls the inner aggregator: SUM DISTINCT stays NULL (the aggregate's initial state, "
+             "column_aggregator.cc:108-124), COUNT DISTINCT 0.  The next cluster (9,9) gives 9 and 1.",
+             cols([I32, I32]), [[4, None], [4, None], [6, 9], [6, 9]],
+             ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM_DISTINCT", "col1", "sd"], ["COUNT_DISTINCT", "col1", "cd"]], "INPUT"],
+             [I32, I32, U64], [[4, None, 0], [6, 9, 1]])
+derived_case("Derived_Clusters_DistinctWithoutClusteredColumn", AGG + "; " + CLC + "; " + DST,
+             D_CLUSTER + "No clustering column: the whole input is one cluster (aggregate_clusters_test.cc:105-121).  Values 3,1,3,NULL,1 -> set {3,1}: "
+             "SUM DISTINCT 4, COUNT DISTINCT 2, MAX DISTINCT 3 (MAX of the distinct values is the MAX), COUNT(*) 5.",
+             cols([I32]), [[3], [1], [3], [None], [1]],
+             ["AggregateClusters", ["CompoundSingleSourceProjector"],
+              [["SUM_DISTINCT", "col0", "sd"], ["COUNT_DISTINCT", "col0", "cd"], ["MAX_DISTINCT", "col0", "mx"], ["COUNT", "", "n"]], "INPUT"],
+             [I32, U64, I32, U64], [[4, 2, 3, 5]])
+derived_case("Derived_Clusters_TwoDistinctColumns", AGG + "; " + DST,
+             D_CLUSTER + "Each DISTINCT aggregation has its own DistinctAggregator, so two columns keep independent sets.  Cluster 1: a = 1,1 -> {1}: COUNT 1; "
+             "b = 9,8 -> {9,8}: COUNT 2, SUM 17.  Cluster 2: a = 1,2,2 -> {1,2}: COUNT 2, SUM 3; b = 9,9,9 -> {9}: COUNT 1, SUM 9.",
+             cols([I32, I32, I32]), [[1, 1, 9], [1, 1, 8], [2, 1, 9], [2, 2, 9], [2, 2, 9]],
+             ["AggregateClusters", ["ProjectNamedAttribute", "col0"],
+              [["COUNT_DISTINCT", "col1", "ca"], ["SUM_DISTINCT", "col1", "sa"], ["COUNT_DISTINCT", "col2", "cb"], ["SUM_DISTINCT", "col2", "sb"]], "INPUT"],
+             [I32, U64, I32, U64, I32], [[1, 1, 1, 2, 17], [2, 2, 3, 1, 9]])
+derived_case("Derived_Clusters_DistinctDoubles", AGG + "; " + DST,
+             D_CLUSTER + "DOUBLE values compare by value in the set: 0.5,0.5,0.25 -> {0.5,0.25}: SUM DISTINCT 0.75 (exact), COUNT DISTINCT 2; cluster 8: -1.5 alone.",
+             cols([I32, F64]), [[7, 0.5], [7, 0.5], [7, 0.25], [8, -1.5]],
+             ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM_DISTINCT", "col1", "sd"], ["COUNT_DISTINCT", "col1", "cd"]], "INPUT"],
+             [I32, F64, U64], [[7, 0.75, 2], [8, -1.5, 1]])
+_big = [[i // 1500, i % 7] for i in range(3000)]
+derived_case("Derived_Clusters_DistinctAcrossInputBlocks", CLC + "; " + DST,
+             D_CLUSTER + "Two clusters of 1500 rows: longer than the 1024-row blocks the cursor pulls, so each cluster meets the aggregator in more than one "
+             "ProcessInput call; the trailing partial cluster of a block is re-processed with the next one (aggregate_clusters.cc:470-520), so its set still "
+             "sees every value once.  Values i mod 7: every cluster holds 0..6 -> COUNT DISTINCT 7, SUM DISTINCT 21; COUNT(*) 1500 each.",
+             cols([I32, I32]), _big,
+             ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["COUNT_DISTINCT", "col1", "cd"], ["SUM_DISTINCT", "col1", "sd"], ["COUNT", "", "n"]], "INPUT"],
+             [I32, U64, I32, U64], [[0, 7, 21, 1500], [1, 7, 21, 1500]])
+
+# ---- B: FIRST / LAST next to DISTINCT aggregates -------------------------------------------------------------------------------------
+D_FL = ("FIRST assigns a group's first non-NULL value and never changes it, LAST assigns every non-NULL value (" + AOP + "; NULL inputs are skipped by "
+        "ColumnAggregatorImpl::UpdateAggregation, column_aggregator.cc:108-124): both follow the INPUT order, whatever the DISTINCT aggregates next to them do (" + DST + "). ")
+derived_case("Derived_Group_FirstLastNextToDistinct", AOP + "; " + DST,
+             D_FL + "Group 1 = rows 0,2,4: v = NULL,7,9 -> FIRST 7, LAST 9; w = 3,5,3 -> {3,5}: COUNT DISTINCT 2, SUM DISTINCT 8.  Group 2 = rows 1,3: v = 4,4 -> "
+             "FIRST 4, LAST 4; w = 3,NULL -> {3}: 1, 3.",
+             cols([I32, I32, I32]), [[1, None, 3], [2, 4, 3], [1, 7, 5], [2, 4, None], [1, 9, 3]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"],
+              [["FIRST", "col1", "f"], ["LAST", "col1", "l"], ["COUNT_DISTINCT", "col2", "cd"], ["SUM_DISTINCT", "col2", "sd"]], "INPUT"],
+             [I32, I32, I32, U64, I32], [[1, 7, 9, 2, 8], [2, 4, 4, 1, 3]], ordered=False)
+derived_case("Derived_Scalar_FirstLastNextToDistinct", AOP + "; " + DST,
+             D_FL + "One group of NULL,2,2,5,NULL: FIRST 2, LAST 5, set {2,5}: COUNT DISTINCT 2, SUM DISTINCT 7; COUNT 3.",
+             cols([I32]), [[None], [2], [2], [5], [None]],
+             ["ScalarAggregate", [["FIRST", "col0", "f"], ["LAST", "col0", "l"], ["COUNT_DISTINCT", "col0", "cd"], ["SUM_DISTINCT", "col0", "sd"], ["COUNT", "col0", "c"]], "INPUT"],
+             [I32, I32, U64, I32, U64], [[2, 5, 2, 7, 3]])
+derived_case("Derived_Group_FirstLastOfAnAllNullGroupNextToDistinct", AOP + "; " + DST,
+             D_FL + "Group 5 has only NULL values of v: FIRST and LAST stay NULL; its w = 1,1 -> COUNT DISTINCT 1.  Group 6: v = 8 -> FIRST = LAST = 8; w = 2,1 -> 2.",
+             cols([I32, I32, I32]), [[5, None, 1], [6, 8, 2], [5, None, 1], [6, None, 1]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["FIRST", "col1", "f"], ["LAST", "col1", "l"], ["COUNT_DISTINCT", "col2", "cd"]], "INPUT"],
+             [I32, I32, I32, U64], [[5, None, None, 1], [6, 8, 8, 2]], ordered=False)
+derived_case("Derived_Group_LastFollowsInputOrderNotValueOrder", AOP + "; " + DST,
+             D_FL + "The DISTINCT aggregate's value order must not leak into LAST: group 1's v arrives as 9,1,5 -> FIRST 9, LAST 5 (not the largest, not the smallest); "
+             "SUM DISTINCT of v = 15; group 2: v = 2,2 -> FIRST 2, LAST 2, SUM DISTINCT 2.",
+             cols([I32, I32]), [[1, 9], [2, 2], [1, 1], [1, 5], [2, 2]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["FIRST", "col1", "f"], ["LAST", "col1", "l"], ["SUM_DISTINCT", "col1", "sd"]], "INPUT"],
+             [I32, I32, I32, I32], [[1, 9, 5, 15], [2, 2, 2, 2]], ordered=False)
+
+# ---- C: max_unique_keys_in_result with FIRST / LAST and with keys wider than 64 bits -----------------------------------------------------
+D_LIM = ("RowHashSet::Insert appends an unseen key while the index holds <= max_unique_keys_in_result rows and answers every LATER unseen key with the index's "
+         "last row (" + RHS + "): rows 0 .. limit are the first limit + 1 keys in first-seen order, and row `limit` also receives every row of every other key, "
+         "in input order.  The result keeps the index's order (aggregate_groups.cc:404-433). ")
+_lim_keys = [7, 8, 9, 8, 10, 7]
+derived_case("Derived_Limit_FirstLastOfTheFoldedRow", RHS + "; " + AOP,
+             D_LIM + D_FL + "Limit 1: 7 -> row 0, 8 -> row 1 (the index held 1 <= 1 rows), 9 -> unseen, index holds 2 > 1 -> row 1; 8 -> row 1; 10 -> row 1; 7 -> row 0.  "
+             "Row 0 = inputs 0,5: SUM 1 + 6 = 7, FIRST 1, LAST 6, COUNT 2.  Row 1 = inputs 1,2,3,4 (values 2,3,4,5): SUM 14, FIRST 2, LAST 5 -- the LAST of "
+             "row 1 comes from key 10 -- COUNT 4.",
+             cols([I32, I32], nullable=False), [[k, v] for k, v in zip(_lim_keys, [1, 2, 3, 4, 5, 6])],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s"], ["FIRST", "col1", "f"], ["LAST", "col1", "l"], ["COUNT", "", "n"]], "INPUT",
+              {"max_unique_keys_in_result": 1}],
+             [I32, I32, I32, I32, U64], [[7, 7, 1, 6, 2], [8, 14, 2, 5, 4]])
+derived_case("Derived_Limit_FirstLastSkipNullsOfTheFoldedRow", RHS + "; " + AOP,
+             D_LIM + D_FL + "Same keys, values 1,NULL,3,NULL,NULL,6.  Row 1 = inputs 1..4 = NULL,3,NULL,NULL: its own key 8 only brings NULLs, the one value 3 comes "
+             "from key 9: FIRST 3, LAST 3, COUNT(v) 1, SUM 3.  Row 0: 1 and 6.",
+             cols([I32, I32]), [[k, v] for k, v in zip(_lim_keys, [1, None, 3, None, None, 6])],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["FIRST", "col1", "f"], ["LAST", "col1", "l"], ["COUNT", "col1", "c"], ["SUM", "col1", "s"]], "INPUT",
+              {"max_unique_keys_in_result": 1}],
+             [I32, I32, I32, U64, I32], [[7, 1, 6, 2, 7], [8, 3, 3, 1, 3]])
+derived_case("Derived_Limit_ZeroKeepsOneRow", RHS,
+             D_LIM + "Limit 0: the first key is appended (the index held 0 <= 0 rows), every other key folds into it: ONE row, key 7, SUM 21, MIN 1, MAX 6, COUNT 6, "
+             "FIRST 1, LAST 6.",
+             cols([I32, I32], nullable=False), [[k, v] for k, v in zip(_lim_keys, [1, 2, 3, 4, 5, 6])],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"],
+              [["SUM", "col1", "s"], ["MIN", "col1", "mn"], ["MAX", "col1", "mx"], ["COUNT", "", "n"], ["FIRST", "col1", "f"], ["LAST", "col1", "l"]], "INPUT",
+              {"max_unique_keys_in_result": 0}],
+             [I32, I32, I32, I32, U64, I32, I32], [[7, 21, 1, 6, 6, 1, 6]])
+derived_case("Derived_Limit_NotReachedChangesNothing", RHS,
+             D_LIM + "Limit 5 with four distinct keys: nothing folds.  First-seen order 7, 8, 9, 10: SUMs 7, 6, 3, 5; LASTs 6, 4, 3, 5.",
+             cols([I32, I32], nullable=False), [[k, v] for k, v in zip(_lim_keys, [1, 2, 3, 4, 5, 6])],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s"], ["LAST", "col1", "l"]], "INPUT", {"max_unique_keys_in_result": 5}],
+             [I32, I32, I32], [[7, 7, 6], [8, 6, 4], [9, 3, 3], [10, 5, 5]])
+derived_case("Derived_Limit_WideKeys", RHS + "; " + AOP,
+             D_LIM + D_FL + "Two INT64 keys (128 packed bits: the device's sorted shape).  Limit 1: (1,1) -> row 0; (1,2) -> row 1; (2,1) unseen, index holds 2 -> row 1; "
+             "(1,2) -> row 1; (1,1) -> row 0.  Row 0: 10 + 50 = 60, FIRST 10, LAST 50.  Row 1: 20 + 30 + 40 = 90, FIRST 20, LAST 40, and it keeps the key (1,2).",
+             cols([I64, I64, I32], nullable=False), [[1, 1, 10], [1, 2, 20], [2, 1, 30], [1, 2, 40], [1, 1, 50]],
+             ["GroupAggregate", ["ProjectNamedAttributes", ["col0", "col1"]], [["SUM", "col2", "s"], ["FIRST", "col2", "f"], ["LAST", "col2", "l"]], "INPUT",
+              {"max_unique_keys_in_result": 1}],
+             [I64, I64, I32, I32, I32], [[1, 1, 60, 10, 50], [1, 2, 90, 20, 40]])
+derived_case("Derived_Limit_NullKeyIsAKey", RHS + "; supersonic/cursor/infrastructure/row_hash_set.cc:143-210",
+             D_LIM + "NULL keys compare equal to each other (RowComparator, row_hash_set.cc:143-210), so NULL is one key like any other.  Limit 1: NULL -> row 0, "
+             "5 -> row 1, NULL -> row 0, 6 -> folds into row 1.  Row 0 (key NULL): 1 + 3 = 4; row 1 (key 5): 2 + 4 = 6, LAST 4.",
+             cols([I32, I32]), [[None, 1], [5, 2], [None, 3], [6, 4]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s"], ["LAST", "col1", "l"], ["COUNT", "", "n"]], "INPUT",
+              {"max_unique_keys_in_result": 1}],
+             [I32, I32, I32, U64], [[None, 4, 3, 2], [5, 6, 4, 2]])
+derived_case("Derived_Limit_WideKeysMinMaxCount", RHS,
+             D_LIM + "Three INT32 keys (96 packed bits).  Limit 2: (1,1,1) -> 0, (2,2,2) -> 1, (3,3,3) -> 2, (4,4,4) -> folds into row 2, (2,2,2) -> 1, (5,5,5) -> row 2.  "
+             "Row 2 = values 30, 40, 60: MIN 30, MAX 60, COUNT 3, SUM 130; row 1 = 20, 50.",
+             cols([I32, I32, I32, I32], nullable=False), [[1, 1, 1, 10], [2, 2, 2, 20], [3, 3, 3, 30], [4, 4, 4, 40], [2, 2, 2, 50], [5, 5, 5, 60]],
+             ["GroupAggregate", ["ProjectNamedAttributes", ["col0", "col1", "col2"]],
+              [["MIN", "col3", "mn"], ["MAX", "col3", "mx"], ["COUNT", "", "n"], ["SUM", "col3", "s"]], "INPUT", {"max_unique_keys_in_result": 2}],
+             [I32, I32, I32, I32, I32, U64, I32], [[1, 1, 1, 10, 10, 1, 10], [2, 2, 2, 20, 50, 2, 70], [3, 3, 3, 30, 60, 3, 130]])
+
+# ---- D: SUM of a floating input into an integer result (the reference's row-after-row arithmetic) --------------------------------------------
+D_SEQ = ("AddAggregationWithDefinedOutputType(SUM, DOUBLE column, INT result): AggregationOperator<SUM>::Update is `*result += val` on an integer result and a "
+         "floating val (supersonic/base/infrastructure/aggregation_operators.h:173-185): C++ converts *result to the floating type, adds, and truncates the sum "
+         "back toward zero -- after EVERY row; the first value is assigned (truncated). ")
+derived_case("Derived_SumOfDoublesIntoInt32TruncatesEveryRow", "supersonic/base/infrastructure/aggregation_operators.h:173-185",
+             D_SEQ + "0.6, 0.6, 0.6, 0.6: assigned 0 (trunc 0.6), then 0 + 0.6 = 0.6 -> 0, again 0, again 0: result 0, where a sum first, truncate last reading gives 2.  "
+             "1.5, 1.5: assigned 1, then 1 + 1.5 = 2.5 -> 2.  -0.9, -0.9, -0.3: assigned 0 (trunc toward zero), 0 - 0.9 -> 0, 0 - 0.3 -> 0.",
+             cols([I32, F64]), [[1, 0.6], [1, 0.6], [1, 0.6], [1, 0.6], [2, 1.5], [2, 1.5], [3, -0.9], [3, -0.9], [3, -0.3]],
+             ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s", I32]], "INPUT"],
+             [I32, I32], [[1, 0], [2, 2], [3, 0]])
+derived_case("Derived_SumOfDoublesIntoInt64OrderMatters", "supersonic/base/infrastructure/aggregation_operators.h:173-185",
+             D_SEQ + "2.75, 0.5, 0.5: assigned 2, 2 + 0.5 = 2.5 -> 2, 2 + 0.5 -> 2: result 2 (the real sum 3.75 would truncate to 3).  NULLs are skipped: "
+             "NULL, 7.9, NULL, 0.2 -> assigned 7, 7 + 0.2 = 7.2 -> 7.",
+             cols([F64]), [[2.75], [0.5], [0.5]],
+             ["ScalarAggregate", [["SUM", "col0", "s", I64]], "INPUT"], [I64], [[2]])
+
 if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
     with open(out, "w") as f:
