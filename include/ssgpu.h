@@ -70,15 +70,18 @@
  *       SUM of a FLOAT / DOUBLE input into an INTEGER result (AddAggregationWithDefinedOutputType): `*result += val`
  *       adds in the floating type and truncates back after every row -- there the order IS the definition, and the
  *       rows are folded one after the other in input order (materialise -> one thread per group / cluster / the one
- *       wavefront of a ScalarAggregate): bit-identical to the reference, and slow by construction.  Refused next to
- *       DISTINCT / CONCAT aggregates, under max_unique_keys_in_result and across shards;
+ *       wavefront of a ScalarAggregate): bit-identical to the reference, and slow by construction -- 10 - 20 ns per row of the
+ *       longest segment, i.e. 1 - 2 s for a ScalarAggregate over 1e8 rows, where every other aggregate of the path takes a
+ *       millisecond.  The one-segment fold runs in launches of 2^21 rows and looks at ssgpu_interrupt between them.  Refused next
+ *       to DISTINCT / CONCAT aggregates, under max_unique_keys_in_result and across shards;
  *       MIN / MAX over FLOAT / DOUBLE: the reference's update is "if (val < result) result = val"
  *       (aggregation_operators.h:200,221) after ASSIGNING a group's first non-NULL value: a NaN that
  *       comes FIRST stays (nothing is less than NaN), a NaN that comes later is skipped.  Same here:
  *       the kernels skip NaNs and flag the run when one reaches a floating MIN / MAX; such a run is
- *       repeated ONCE, when its result is first touched, with the plan in its NaN-exact form (a
+ *       repeated ONCE with the plan in its NaN-exact form (a
  *       hidden FIRST of the column, result = IF(IS_NAN(first), first, min)), which the plan then
- *       keeps -- data without NaNs never pays for it.  Not covered, and stated: aggregates next to a
+ *       keeps -- data without NaNs never pays for it.  (The repeat happens inside ssgpu_plan_run under the default
+ *       "lazy_feedback" = 0, when the result is first touched under 1: see INPUT LIFETIME below.)  Not covered, and stated: aggregates next to a
  *       DISTINCT aggregate, under max_unique_keys_in_result and across shards keep the
  *       order-independent answer (NaNs skipped).  -0.0 and +0.0 compare equal in the reference, so
  *       which of the two a MIN / MAX returns is order-dependent there; here -0.0 < +0.0;

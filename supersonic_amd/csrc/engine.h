@@ -167,6 +167,7 @@ struct Stage {
   // MATERIALIZE: the stage's last (synthetic) input column holds, for every input row, the number of its cluster -- runs of equal
   // values of these input columns (the AggregateClusters boundary scan), computed in front of the stage's program
   std::vector<int> segment_cols;
+  bool has_segment = false;               // ... the stage HAS that synthetic column (segment_cols may be empty: AggregateClusters without a clustering column = one cluster)
   // SCALAR_AGG / CLUSTERS: SUM of a floating input column into an integer result -- the reference adds and truncates row after
   // row (aggregation_operators.h:173-185), so the stage's program only counts the column (the result's slot) and the runtime
   // folds the rows in their order afterwards (ssgpu_launch_seq_sum) into result column `out_col`

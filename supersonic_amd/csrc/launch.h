@@ -323,8 +323,10 @@ hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const v
                                      uint64_t rowid_mask /* bits of a rowids word that ARE the row id */, int64_t row_id_base, const uint64_t* n_rows_dev, uint64_t n_rows_max, hipStream_t stream);
 // SUM of a floating column into an integer result, row after row in the rows' order (sort_kernels.hip: SeqSumParams); one result
 // per segment of seg_id (nullptr: one segment of all n rows); kinds 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64
+// (one segment only) first / state / resume: rows [first, n) continue the fold from state[0..1] -- the host cuts a long fold into
+// launches and looks at the plan's interrupt flag between them
 hipError_t ssgpu_launch_seq_sum(const void* src, const uint8_t* src_nulls, int src_kind, const uint32_t* seg_id, uint64_t n,
-                                void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s);
+                                void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s, uint64_t first = 0, uint64_t* state = nullptr, int resume = 0);
 hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
                                       const GroupAggOut* outs, uint32_t n_out, hipStream_t s);
 

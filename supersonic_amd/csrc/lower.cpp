@@ -2198,7 +2198,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
               for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             }
             Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
-            m.segment_cols = key_inputs;
+            m.segment_cols = key_inputs; m.has_segment = true;
             stages->push_back(m);
             reset_pipe(&pipe, m.out_schema);
             g.kpos.insert(g.kpos.begin(), seg_pos); g.knames.insert(g.knames.begin(), "$segment");

@@ -1017,6 +1017,7 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
 
 // Stage::seq_sums: SUM of a floating column into an integer result, folded row after row over the stage's input (its segments
 // for a clustered stage, all rows for a scalar one); overwrites the COUNT the stage's program left in the result column
+static const int64_t kSeqSumPiece = 1 << 21;   // rows one launch of the one-segment sequential fold takes (20 - 40 ms)
 static int run_seq_sums(ssgpu_plan* p, Stage& st, StageExec& ex, const InCols& in, const uint32_t* seg_id) {
   ssgpu_ctx* c = p->ctx;
   auto kind_of = [](int dtype) {
@@ -1026,10 +1027,29 @@ static int run_seq_sums(ssgpu_plan* p, Stage& st, StageExec& ex, const InCols& i
     }
   };
   for (auto& q : st.seq_sums) {
-    HIP_TRY(c, ssgpu_launch_seq_sum(in.cols[q.in_col].data, st.in_schema[q.in_col].nullable ? in.cols[q.in_col].is_null : nullptr, kind_of(st.in_schema[q.in_col].dtype),
-                                    seg_id, (uint64_t)in.rows, ex.out[q.out_col].data.p, ex.out[q.out_col].nullable ? ex.out[q.out_col].nulls.as<uint8_t>() : nullptr,
-                                    kind_of(st.out_schema[q.out_col].dtype), c->stream));
-    p->counters.n_launches += 1;
+    const void* src = in.cols[q.in_col].data;
+    const uint8_t* src_nulls = st.in_schema[q.in_col].nullable ? in.cols[q.in_col].is_null : nullptr;
+    uint8_t* dst_nulls = ex.out[q.out_col].nullable ? ex.out[q.out_col].nulls.as<uint8_t>() : nullptr;
+    const int sk = kind_of(st.in_schema[q.in_col].dtype), dk = kind_of(st.out_schema[q.out_col].dtype);
+    if (seg_id || in.rows <= kSeqSumPiece) {
+      HIP_TRY(c, ssgpu_launch_seq_sum(src, src_nulls, sk, seg_id, (uint64_t)in.rows, ex.out[q.out_col].data.p, dst_nulls, dk, c->stream));
+      p->counters.n_launches += 1;
+      continue;
+    }
+    // ONE segment of many rows (a ScalarAggregate): a single wavefront folds it, 10 - 20 ns per row -- seconds at 1e8 rows.  The fold
+    // runs in pieces of kSeqSumPiece rows whose state stays on the device, and the host looks at the plan's interrupt flag
+    // between them (Cursor::Interrupt, cursor.h:150-186: best effort, but not "after the next minute")
+    HIP_TRY(c, ex.total2.ensure(16));
+    for (int64_t first = 0; first < in.rows; first += kSeqSumPiece) {
+      const int64_t end = std::min<int64_t>(in.rows, first + kSeqSumPiece);
+      HIP_TRY(c, ssgpu_launch_seq_sum(src, src_nulls, sk, nullptr, (uint64_t)end, ex.out[q.out_col].data.p, dst_nulls, dk, c->stream,
+                                      (uint64_t)first, ex.total2.as<uint64_t>(), first > 0 ? 1 : 0));
+      p->counters.n_launches += 1;
+      if (end < in.rows) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
+      }
+    }
   }
   return SSGPU_OK;
 }
@@ -1098,7 +1118,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
     ssgpu_column f; rc = distinct_flags(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
     in.cols.push_back(f);
   }
-  if (!st.segment_cols.empty()) {    // DISTINCT aggregates of clusters: the rows are stored with their cluster's number
+  if (st.has_segment) {    // DISTINCT aggregates of clusters: the rows are stored with their cluster's number
     ssgpu_column f; rc = segment_ids(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
     in.cols.push_back(f);
   }
@@ -1264,7 +1284,7 @@ static bool tail_runs_without_host(const ssgpu_plan* p, size_t si) {
   if (!p->ctx->async_handoff && si + 1 < p->stages.size()) return false;
   for (size_t k = si + 1; k < p->stages.size(); ++k) {
     const Stage& nx = p->stages[k];
-    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && nx.segment_cols.empty() && nx.joins.empty())) return false;
+    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && !nx.has_segment && nx.joins.empty())) return false;
   }
   return true;
 }
@@ -2592,7 +2612,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       // stage's error word is still looked at when the result is touched (check_error_flags); rows beyond the count are
       // never computed, so a signaling operator cannot fail on them.
       const bool device_rows = c->async_handoff != 0 && !c->debug_timing && ex.out_rows < 0 && ex.out_capacity > 0 && nx.kind == STAGE_MATERIALIZE &&
-                               !nx.has_filter && nx.distinct_cols.empty() && nx.segment_cols.empty() && nx.joins.empty();
+                               !nx.has_filter && nx.distinct_cols.empty() && !nx.has_segment && nx.joins.empty();
       int64_t r = 0;
       in.rows_dev = nullptr;
       if (device_rows) {

@@ -709,6 +709,9 @@ __global__ __launch_bounds__(256) void ssgpu_cluster_assign_kernel(const Cluster
 struct SeqSumParams {
   const void* src; const u8* src_nulls; const u32* seg_id;   // seg_id == nullptr: all rows are one segment (ScalarAggregate)
   void* dst; u8* dst_nulls; u64 n; int src_kind, dst_kind;   // kinds: 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64
+  // the one-segment fold in pieces (so that a host can look at its interrupt flag between them): rows [first, n) of this launch continue
+  // from state[0] = the running result's bits, state[1] = "a value was seen" when resume != 0, and leave them there
+  u64 first; u64* state; int resume, pad;
 };
 template <typename F> __device__ __forceinline__ u64 seq_to_bits(F x) {
   const double tr = trunc((double)x);
@@ -751,7 +754,8 @@ template <typename F>
 __global__ __launch_bounds__(64) void ssgpu_seq_sum_all_kernel(const SeqSumParams P) {
   const int lane = threadIdx.x;
   u64 bits = 0; bool any = false;
-  for (u64 base = 0; base < P.n; base += 64) {
+  if (P.resume && P.state) { bits = P.state[0]; any = P.state[1] != 0ull; }
+  for (u64 base = P.first; base < P.n; base += 64) {
     const u64 r = base + (u64)lane;
     F v = F(0); bool ok = false;
     if (r < P.n) { ok = !(P.src_nulls && P.src_nulls[r]); if (ok) v = reinterpret_cast<const F*>(P.src)[r]; }
@@ -762,11 +766,12 @@ __global__ __launch_bounds__(64) void ssgpu_seq_sum_all_kernel(const SeqSumParam
       if ((okmask >> l) & 1ull) seq_step<F>(P, x, bits, any);
     }
   }
-  if (lane == 0) seq_store(P, 0, bits, any);
+  if (lane == 0) { seq_store(P, 0, bits, any); if (P.state) { P.state[0] = bits; P.state[1] = any ? 1ull : 0ull; } }
 }
 hipError_t ssgpu_launch_seq_sum(const void* src, const uint8_t* src_nulls, int src_kind, const uint32_t* seg_id, uint64_t n,
-                                void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s) {
+                                void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s, uint64_t first, uint64_t* state, int resume) {
   SeqSumParams P; P.src = src; P.src_nulls = src_nulls; P.seg_id = seg_id; P.dst = dst; P.dst_nulls = dst_nulls; P.n = n; P.src_kind = src_kind; P.dst_kind = dst_kind;
+  P.first = first; P.state = reinterpret_cast<u64*>(state); P.resume = resume; P.pad = 0;
   if (seg_id) {
     if (!n) return hipSuccess;
     if (src_kind == 4) hipLaunchKernelGGL(ssgpu_seq_sum_segments_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P);

@@ -342,3 +342,41 @@ def test_input_may_be_overwritten_after_a_synchronised_run():
         torch.cuda.synchronize()
         _s, want = oracle.run(op(cols))
         assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="input overwritten after run + synchronise")
+
+
+# ---- two contexts driven from two host threads at the same time (each context and its plans by ONE thread, as the reference's
+# ---- cursors: cursor.h:131-148): the library's thread-local state (memory quota scope, kernel-cache policy, lowering scratch) and its
+# ---- process-wide caches (compiled kernels, memory statistics) must not leak from one thread's plans into the other's ------------------
+def test_two_contexts_from_two_threads_do_not_disturb_each_other():
+    from oracle import oracle
+    from helpers import assert_cols_equal, sort_rows, to_cols
+    errors = []
+
+    def worker(seed, specialize, quota):
+        try:
+            ctx = ss.Context(0)
+            ctx.set_option("specialize", specialize)
+            for round_no in range(6):
+                view = make_view(60001 + 1000 * round_no, seed=seed + round_no, nullable=bool(round_no % 2))
+                ops = [fpa_narrow(view), group_query(view, bool(round_no % 2), ("k1",) if round_no % 2 else ("k1", "k2"))]
+                for op in ops:
+                    plan = ss.Plan(op, ctx)
+                    if quota and round_no == 3 and op is ops[1]:
+                        plan.set_memory_limit(4096)                       # this thread's plan runs out of quota; the other thread's never does
+                        with pytest.raises(ss.SupersonicException) as e:
+                            plan.run()
+                            plan.fetch()
+                        assert e.value.return_code == ss.ERROR_MEMORY_EXCEEDED
+                        continue
+                    plan.run()
+                    _s, want = oracle.run(op)
+                    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="thread %d round %d" % (seed, round_no))
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((seed, repr(e)))
+    threads = [threading.Thread(target=worker, args=(100, 1, True)), threading.Thread(target=worker, args=(200, 0, False)),
+               threading.Thread(target=worker, args=(300, 1, False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors

@@ -954,6 +954,10 @@ def test_aggregate_clusters_with_distinct_aggregates(gpu_ctx, n, nullable):
     agg = ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), spec, child)
     run_both(agg, gpu_ctx)
     run_both(ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "sdv", "t").AddAggregation(ss.COUNT, "k", "c").AddAggregation(ss.SUM, "cdw", "u"), agg), gpu_ctx)
+    # WITHOUT a clustering column the whole input is one cluster (aggregate_clusters_test.cc:105-121): the stage still stores a
+    # segment number -- of zero key columns (round 5: the derived golden case of this shape met an unset column pointer)
+    run_both(ss.AggregateClusters(ss.CompoundSingleSourceProjector(), spec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.AggregateClusters(ss.CompoundSingleSourceProjector(), spec, child), gpu_ctx)
 
 
 @pytest.mark.parametrize("n", [0, 1, 1025, 100003])
@@ -1409,6 +1413,41 @@ def test_sum_of_floating_values_into_integer_results_reference_arithmetic(gpu_ct
             .AddAggregationWithDefinedOutputType(ss.SUM, "b", "sb", ss.INT32).AddAggregationWithDefinedOutputType(ss.SUM, "c", "sc", ss.INT64))
     got = run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
     assert [int(got.column(i).data[0]) for i in range(3)] == [0, 1, 16777216]
+
+
+def test_sum_of_floating_values_into_an_integer_runs_in_pieces_and_can_be_interrupted():
+    # ONE segment of 5 M rows: the fold runs in launches of 2^21 rows whose state stays on the device (same bits as one launch:
+    # the oracle folds all rows in one loop) and looks at the plan's interrupt flag between them
+    import threading
+    import time
+    n = 5_000_001
+    rng = np.random.default_rng(77)
+    schema = ss.TupleSchema([ss.Attribute("x", ss.DOUBLE, ss.NULLABLE), ss.Attribute("f", ss.FLOAT)])
+    view = ss.View(schema, [ss.Column(rng.normal(size=n) * 10.0, rng.random(n) < 0.1), (rng.normal(size=n) * 3.0).astype(np.float32)])
+    spec = (ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "sx", ss.INT64)
+            .AddAggregationWithDefinedOutputType(ss.SUM, "f", "sf", ss.INT32).AddAggregation(ss.COUNT, "x", "cx"))
+    op = ss.ScalarAggregate(spec, ss.ScanView(view))
+    ctx = ss.Context(0)
+    run_both(op, ctx)
+    plan = ss.Plan(op, ctx)
+    plan.run()                                     # (buffers, upload)
+    t0 = time.perf_counter()
+    plan.run()
+    ctx.synchronize()
+    whole = time.perf_counter() - t0
+    timer = threading.Timer(whole * 0.2, plan.interrupt)          # Cursor::Interrupt from another thread, a fifth of the way in
+    timer.start()
+    t0 = time.perf_counter()
+    with pytest.raises(ss.SupersonicException) as err:
+        plan.run()
+    took = time.perf_counter() - t0
+    timer.join()
+    assert err.value.return_code == ss.INTERRUPTED
+    assert took < whole * 0.9, (took, whole)       # it stopped at a piece boundary, not after the whole fold
+    plan.run()                                     # and the plan is usable afterwards
+    got = plan.fetch()
+    _s, want = oracle_run(op)
+    assert [int(got.column(i).data[0]) for i in range(3)] == [int(want[i][0][0]) for i in range(3)]
 
 
 # ---- runtime specialisation (context option "specialize", csrc/rtc.cpp): the same handlers compiled per plan with the
