@@ -122,7 +122,13 @@ class ShardedScalarAggregate {
 
 class ShardedGroupAggregate {
  public:
-  enum Exchange { ALL_GATHER, KEY_RANGE };
+  // DENSE (ssgpu.h "dense-slot GroupAggregate across ranks"): the ranks agree once on the value ranges of the group keys
+  // (two small ncclAllReduce at set-up); from then on every rank's partial table is the same slot-indexed array and a step is
+  // shard scan -> ONE all-to-all of slot slices -> element-wise fold + extraction on the SAME plan -- no merge plan, no packing,
+  // DOUBLE sums cross as raw (hi, lo) accumulators.  Every rank ends with the groups it owns (as KEY_RANGE).  Plans it does not
+  // fit (FIRST / LAST, floating keys, key ranges beyond 2^21 slots) fail Run() with the library's code, identically on every
+  // rank: the caller constructs the job with KEY_RANGE instead.  capacity_rows is not used.
+  enum Exchange { ALL_GATHER, KEY_RANGE, DENSE };
   // comm / world: the job's RCCL communicator and its size.  group_by: key attribute names.  spec and local_child
   // (this rank's shard: e.g. Filter(..., ScanView(shard))) are owned.  capacity_rows: rows an image holds -- at least
   // the largest partial table of any rank (a table that does not fit is reported by Run(), nothing is truncated silently).
@@ -152,6 +158,7 @@ class ShardedGroupAggregate {
     // a sharded job steps its plans without waiting for the host and keeps its shards' columns alive: the opt-in of ssgpu.h's
     // "lazy_feedback" (the default settles every run before it returns)
     ssgpu_ctx_set_option(internal::Context::Get().ctx, "lazy_feedback", 1);
+    if (exchange_ == DENSE) ssgpu_ctx_set_option(internal::Context::Get().ctx, "group_dense", 1);
     // the input's types decide which sums travel as (SUM, SUM_RESIDUAL) pairs: bind the child once to learn them
     TupleSchema child_schema;
     {
@@ -196,7 +203,8 @@ class ShardedGroupAggregate {
     for (auto& child : own_children) {
       CompoundSingleSourceProjector* keys = new CompoundSingleSourceProjector;
       for (auto& k : group_by_) keys->add(ProjectNamedAttribute(k));
-      first_.emplace_back(GroupAggregate(keys, new AggregationSpecification(*shard), nullptr, child.release()));
+      // (DENSE: the job's own aggregation -- its accumulators travel raw, there is no merge plan to feed with residual columns)
+      first_.emplace_back(GroupAggregate(keys, new AggregationSpecification(exchange_ == DENSE ? *own_spec : *shard), nullptr, child.release()));
     }
   }
 
@@ -216,6 +224,7 @@ class ShardedGroupAggregate {
     const int n_local = static_cast<int>(shard_cursors_.size());
     const int n_images = comm_ ? world_ : n_local;                          // images that meet in this process's merge
     hipStream_t stream = static_cast<hipStream_t>(ssgpu_ctx_stream(ctx));   // NULL = the legacy default stream
+    if (exchange_ == DENSE) return RunDense(ctx, stream);
     for (int attempt = 0; attempt < 6; ++attempt) {
       int rc = SSGPU_OK;
       // A rank whose shard run fails (memory quota, interrupt, an input that does not bind like the others') must NOT return here
@@ -353,6 +362,82 @@ class ShardedGroupAggregate {
     return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the step kept asking to be repeated");
   }
   rowcount_t largest_table() const { return largest_table_; }   // rows of the largest partial table (KEY_RANGE: image) seen by the last Run()
+  int64_t dense_slots() const { return dense_layout_.slots; }     // DENSE: slots of the job-wide table (0 before the first Run())
+
+ private:
+  // ---- the DENSE exchange ---------------------------------------------------------------------------------------------------------
+  // the ranks' key ranges united: lo = min, hi = max over the ranks (order-preserving unsigned domain, ssgpu.h)
+  bool AgreeRanges(int32_t n_keys, uint64_t* lo, uint64_t* hi, hipStream_t stream) {
+    if (!comm_ || world_ == 1) return true;
+    const size_t bytes = static_cast<size_t>(n_keys) * 8;
+    if (!ranges_dev_ && hipMalloc(&ranges_dev_, 2 * 8 * 8) != hipSuccess) return false;
+    char* d = static_cast<char*>(ranges_dev_);
+    return hipMemcpyAsync(d, lo, bytes, hipMemcpyHostToDevice, stream) == hipSuccess && hipMemcpyAsync(d + 64, hi, bytes, hipMemcpyHostToDevice, stream) == hipSuccess &&
+           ncclAllReduce(d, d, static_cast<size_t>(n_keys), ncclUint64, ncclMin, comm_, stream) == ncclSuccess &&
+           ncclAllReduce(d + 64, d + 64, static_cast<size_t>(n_keys), ncclUint64, ncclMax, comm_, stream) == ncclSuccess &&
+           hipMemcpyAsync(lo, d, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess && hipMemcpyAsync(hi, d + 64, bytes, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+           hipStreamSynchronize(stream) == hipSuccess;
+  }
+  FailureOrOwned<Cursor> SetUpDense(internal::DeviceCursor* shard, hipStream_t stream) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    int32_t n_keys = 0; uint64_t lo[8], hi[8];
+    int rc = shard->DenseKeyRanges(&n_keys, lo, hi);
+    // (refusals are decided by the plan's shape -- the same on every rank -- before any collective: no rank is left waiting)
+    if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+    if (dense_ready_) for (int32_t k = 0; k < n_keys; ++k) { lo[k] = std::min(lo[k], dense_lo_[k]); hi[k] = std::max(hi[k], dense_hi_[k]); }   // never narrower
+    if (!AgreeRanges(n_keys, lo, hi, stream)) return internal::FailCursor(ERROR_UNKNOWN_ERROR, "cannot agree on the key ranges (ncclAllReduce)");
+    rc = shard->SetDense(n_keys, lo, hi, comm_ ? world_ : 1, &dense_layout_);
+    if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+    for (int32_t k = 0; k < n_keys; ++k) { dense_lo_[k] = lo[k]; dense_hi_[k] = hi[k]; }
+    const size_t bytes = static_cast<size_t>(dense_layout_.chunk_bytes) * static_cast<size_t>(comm_ ? world_ : 1);
+    if (bytes != dense_bytes_) {
+      if (table_) (void)hipFree(table_);
+      if (chunks_) (void)hipFree(chunks_);
+      table_ = chunks_ = nullptr;
+      if (hipMalloc(&table_, bytes) != hipSuccess || hipMalloc(&chunks_, bytes) != hipSuccess) return internal::FailCursor(ERROR_MEMORY_EXCEEDED, "cannot allocate the dense table buffers");
+      dense_bytes_ = bytes;
+    }
+    dense_ready_ = true;
+    return FailureOrOwned<Cursor>(static_cast<Cursor*>(nullptr));
+  }
+  FailureOrOwned<Cursor> RunDense(ssgpu_ctx* ctx, hipStream_t stream) {
+    if (shard_cursors_.size() != 1) return internal::FailCursor(ERROR_NOT_IMPLEMENTED, "the DENSE exchange takes one shard per process");
+    internal::DeviceCursor* shard = internal::AsDeviceCursor(shard_cursors_[0].get());
+    const int n = comm_ ? world_ : 1;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      if (!dense_ready_) { FailureOrOwned<Cursor> s = SetUpDense(shard, stream); if (s.is_failure()) return s; }
+      shard->Rewind();
+      int rc = shard->RunDense(table_);
+      if (rc != SSGPU_OK) {
+        // this rank's run failed: it still joins the all-to-all -- with flagged chunks -- and every rank fails the step below
+        const std::string msg = ssgpu_last_error(ctx);
+        if (ssgpu_plan_dense_fail(shard->plan_handle(), table_, rc) != SSGPU_OK) return internal::FailCursor(rc, msg);
+        local_fail_msg_ = msg;
+      }
+      if (comm_) {
+        bool ok = ncclGroupStart() == ncclSuccess;                     // the ONE collective: chunk r -> rank r
+        for (int r = 0; ok && r < world_; ++r)
+          ok = ncclSend(static_cast<const char*>(table_) + static_cast<size_t>(r) * dense_layout_.chunk_bytes, static_cast<size_t>(dense_layout_.chunk_bytes), ncclUint8, r, comm_, stream) == ncclSuccess &&
+               ncclRecv(static_cast<char*>(chunks_) + static_cast<size_t>(r) * dense_layout_.chunk_bytes, static_cast<size_t>(dense_layout_.chunk_bytes), ncclUint8, r, comm_, stream) == ncclSuccess;
+        ok = (ncclGroupEnd() == ncclSuccess) && ok;
+        if (!ok) return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the all-to-all of the dense table chunks (ncclSend / ncclRecv) failed");
+      }
+      rc = shard->FoldDense(comm_ ? chunks_ : table_, n);
+      if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+      // the verdict every rank reads from the headers it received: the same words everywhere, so the same branch everywhere
+      uint32_t flags = 0, error = 0;
+      rc = ssgpu_plan_dense_flags(shard->plan_handle(), &flags, &error);
+      if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx));
+      if (flags & 8u) return internal::FailCursor(static_cast<int>(flags >> 8), local_fail_msg_.empty() ? "the GroupAggregate of another rank's shard failed" : local_fail_msg_);
+      if (error) return internal::FailCursor(ERROR_EVALUATION_ERROR, "Evaluation error in a shard's GroupAggregate");
+      if (flags & 4u) { dense_ready_ = false; continue; }       // a key outside the ranges on some rank: agree on wider ones
+      if (flags & 2u) { rc = ssgpu_plan_dense_grow(shard->plan_handle()); if (rc != SSGPU_OK) return internal::FailCursor(rc, ssgpu_last_error(ctx)); continue; }
+      if (flags & 1u) return internal::FailCursor(ERROR_MEMORY_EXCEEDED, "a dense partition outgrew its table");
+      return FailureOrOwned<Cursor>(new internal::BorrowedCursor(shard));
+    }
+    return internal::FailCursor(ERROR_UNKNOWN_ERROR, "the dense step kept asking to be repeated");
+  }
+ public:
 
  private:
   static constexpr const char* kResidual = "$res";   // suffix of the hidden column that carries a DOUBLE sum's residual across shards
@@ -370,6 +455,10 @@ class ShardedGroupAggregate {
     if (images_) (void)hipFree(images_);
     if (unpacked_) (void)hipFree(unpacked_);
     if (verdict_dev_) (void)hipFree(verdict_dev_);
+    if (table_) (void)hipFree(table_);
+    if (chunks_) (void)hipFree(chunks_);
+    if (ranges_dev_) (void)hipFree(ranges_dev_);
+    table_ = chunks_ = ranges_dev_ = nullptr; dense_bytes_ = 0;
     image_ = images_ = unpacked_ = verdict_dev_ = nullptr; image_bytes_ = unpacked_bytes_ = 0;
   }
   ncclComm_t comm_;
@@ -388,6 +477,13 @@ class ShardedGroupAggregate {
   void* image_ = nullptr; void* images_ = nullptr; void* unpacked_ = nullptr; void* verdict_dev_ = nullptr;
   int64_t image_bytes_ = 0, unpacked_bytes_ = 0;
   int64_t fail_header_[8] = {0};
+  // DENSE
+  bool dense_ready_ = false;
+  ssgpu_dense_layout dense_layout_ = {};
+  uint64_t dense_lo_[8] = {0}, dense_hi_[8] = {0};
+  void* table_ = nullptr; void* chunks_ = nullptr; void* ranges_dev_ = nullptr;
+  size_t dense_bytes_ = 0;
+  std::string local_fail_msg_;
 };
 
 }  // namespace supersonic

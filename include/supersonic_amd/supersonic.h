@@ -834,6 +834,28 @@ class DeviceCursor : public Cursor {
     if (rc == SSGPU_OK) rc = ssgpu_plan_run_partial(plan_, cols.data(), static_cast<int32_t>(cols.size()), rows, global_row_offset);
     return rc;
   }
+  // Dense-slot GroupAggregate across ranks (ssgpu.h "dense-slot GroupAggregate across ranks"; sharded.h: ShardedGroupAggregate DENSE):
+  // the shard's key ranges, the job-wide table layout, a run into the caller's chunked table, the fold of the received chunks.
+  int DenseKeyRanges(int32_t* n_keys, uint64_t* lo, uint64_t* hi) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    std::vector<ssgpu_column> cols; int64_t rows = 0;
+    int rc = StagedColumns(ctx, &cols, &rows);
+    if (rc == SSGPU_OK) rc = ssgpu_plan_key_ranges(plan_, cols.data(), static_cast<int32_t>(cols.size()), rows, n_keys, lo, hi);
+    return rc;
+  }
+  int SetDense(int32_t n_keys, const uint64_t* lo, const uint64_t* hi, int32_t n_chunks, ssgpu_dense_layout* layout) { return ssgpu_plan_set_dense(plan_, n_keys, lo, hi, n_chunks, layout); }
+  int RunDense(void* table) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    std::vector<ssgpu_column> cols; int64_t rows = 0;
+    int rc = StagedColumns(ctx, &cols, &rows);
+    if (rc == SSGPU_OK) rc = ssgpu_plan_run_dense(plan_, cols.data(), static_cast<int32_t>(cols.size()), rows, table);
+    return rc;
+  }
+  int FoldDense(const void* chunks, int32_t n_chunks) {
+    const int rc = ssgpu_plan_fold_dense(plan_, chunks, n_chunks, &res_);
+    ran_ = true; run_rc_ = rc; fetched_ = false; failed_ = false; pos_ = 0;
+    return rc;
+  }
   // ... and, after the caller has gathered every rank's state (n_images consecutive copies, device memory), fold and emit.
   int FinalizePartial(const void* gathered_state, int32_t n_images) {
     int rc = ssgpu_plan_fold_finalize(plan_, gathered_state, n_images, &res_);   // fold + state -> slots + emit: one launch
@@ -844,6 +866,17 @@ class DeviceCursor : public Cursor {
  private:
   friend class BasicOperation;
   DeviceCursor() {}
+  // the plan's input as device columns: the caller's device-resident view, or the host View staged into a block (and waited for)
+  int StagedColumns(ssgpu_ctx* ctx, std::vector<ssgpu_column>* cols, int64_t* rows) {
+    int rc = Stage(ctx);
+    if (rc != SSGPU_OK) return rc;
+    if (dev_) { *cols = dev_->columns; *rows = static_cast<int64_t>(dev_->row_count); return SSGPU_OK; }
+    cols->resize(static_cast<size_t>(input_->schema().attribute_count()));
+    for (size_t i = 0; rc == SSGPU_OK && i < cols->size(); ++i) rc = ssgpu_block_column(block_, static_cast<int32_t>(i), &(*cols)[i]);
+    *rows = ssgpu_block_row_count(block_);
+    if (rc == SSGPU_OK) rc = ssgpu_ctx_synchronize(ctx);   // the block was staged on the copy stream
+    return rc;
+  }
   int Stage(ssgpu_ctx* ctx) {  // host Views -> device blocks on the copy stream
     if (dev_) return SSGPU_OK;   // device-resident input: nothing to stage
     if (block_) return SSGPU_OK;   // staged by an earlier run of this cursor (Rewind)

@@ -123,6 +123,41 @@ int main(int argc, char** argv) {
     std::map<int32_t, Row> regrown;
     if (f.is_success()) { CHECK(Drain(f.get(), &regrown)); CHECK(regrown.size() == want.size()); }
   }
+  {  // the DENSE exchange: key ranges agreed at set-up, then shard scan -> ONE all-to-all of slot slices (here: to itself)
+     // -> element-wise fold + extraction on the same plan; no merge plan.  FIRST / LAST are not in this form (their values live in the
+     // shard that saw the row): the job is refused before any collective, identically on every rank
+    auto spec_dense = []() { return (new AggregationSpecification)->AddAggregation(SUM, "v", "sv")->AddAggregation(MIN, "d", "mn")->AddAggregation(MAX, "d", "mx")
+                                 ->AddAggregation(COUNT, "v", "cv")->AddAggregation(COUNT, "", "n")->AddAggregation(SUM, "d", "fd"); };
+    ShardedGroupAggregate job(comm, 1, {"k"}, spec_dense(), shard(), /*capacity_rows=*/0, ShardedGroupAggregate::DENSE);
+    std::map<int32_t, Row> dense, dense2, plain_rows;
+    FailureOrOwned<Cursor> c = job.Run();
+    CHECK(c.is_success());
+    if (c.is_failure()) { printf("dense run failed: %s\n", c.exception().message().c_str()); return 1; }
+    CHECK(Drain(c.get(), &dense));
+    CHECK(job.dense_slots() == 257);
+    FailureOrOwned<Cursor> again = job.Run();            // a second step: the same plan, the same buffers
+    CHECK(again.is_success());
+    if (again.is_success()) CHECK(Drain(again.get(), &dense2));
+    std::unique_ptr<Operation> plain(GroupAggregate(ProjectNamedAttribute("k"), spec_dense(), nullptr, shard()));
+    FailureOrOwned<Cursor> pc = plain->CreateCursor();
+    CHECK(pc.is_success());
+    CHECK(Drain(pc.get(), &plain_rows));
+    CHECK(dense.size() == plain_rows.size() && dense.size() == 257 && dense2.size() == 257);
+    for (auto& kv : plain_rows) {
+      for (auto* got_rows : {&dense, &dense2}) {
+        auto it = got_rows->find(kv.first);
+        CHECK(it != got_rows->end());
+        if (it == got_rows->end()) continue;
+        const Row& g = it->second; const Row& w = kv.second;
+        CHECK(g.sv_null == w.sv_null && (g.sv_null || g.sv == w.sv));
+        CHECK(g.mn == w.mn && g.mx == w.mx && g.cv == w.cv && g.n == w.n && g.fd == w.fd);
+      }
+    }
+    ShardedGroupAggregate refused(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/0, ShardedGroupAggregate::DENSE);   // Spec() has a FIRST
+    FailureOrOwned<Cursor> r = refused.Run();
+    CHECK(r.is_failure());
+    if (r.is_failure()) CHECK(r.exception().return_code() == ERROR_NOT_IMPLEMENTED);
+  }
   {  // the same with the all-gather exchange
     ShardedGroupAggregate small(comm, 1, {"k"}, Spec(), shard(), /*capacity_rows=*/64);
     FailureOrOwned<Cursor> c = small.Run();
