@@ -7,6 +7,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
@@ -94,12 +96,50 @@ struct QuotaScope { MemQuota* saved; explicit QuotaScope(MemQuota* q) : saved(g_
 // "repeated runs do not grow memory" contract (expression_test_helper.cc:213-245 watches its allocator the same way)
 static std::atomic<long long> g_dev_bytes{0}, g_pinned_bytes{0}, g_live_plans{0}, g_live_blocks{0}, g_events{0};
 
+// A small pool of device blocks between plans.  The reference's usage model is a cursor per query, drained once
+// (test/guide/group_sort.cc:166,223): every query's first -- and only -- run would pay a hipMalloc per buffer (two dozen for a
+// GroupAggregate, each 50 - 300 us: more than the kernels of a million-row input).  Blocks of a DESTROYED plan (its stream has been
+// drained: nothing in flight can touch them) are parked here instead of freed, and the next plan's DevBuf::ensure takes one that
+// fits (within 2x; small blocks by 4 KiB class) before it asks the driver.  Bounded: SSGPU_POOL_MB (default 4096, 0 = off) and
+// 4096 blocks; what is parked still counts as held by the library (ssgpu_memory_stats.device_bytes).
+struct DevPool {
+  std::mutex m;
+  std::multimap<size_t, std::pair<void*, int>> blocks;   // capacity -> (pointer, device)
+  size_t bytes = 0;
+  size_t limit() { static const size_t v = [] { const char* e = getenv("SSGPU_POOL_MB"); return (size_t)(e ? atoll(e) : 4096) << 20; }(); return v; }
+  bool park(void* p, size_t cap) {
+    int dev = 0;
+    if (limit() == 0 || hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(m);
+    if (bytes + cap > limit() || blocks.size() >= 4096) return false;
+    blocks.emplace(cap, std::make_pair(p, dev)); bytes += cap;
+    return true;
+  }
+  void* take(size_t want, size_t* cap) {
+    int dev = 0;
+    if (limit() == 0 || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const size_t most = want <= 4096 ? 4096 : want * 2;
+    std::lock_guard<std::mutex> lock(m);
+    for (auto it = blocks.lower_bound(want); it != blocks.end() && it->first <= most; ++it)
+      if (it->second.second == dev) { void* p = it->second.first; *cap = it->first; bytes -= it->first; blocks.erase(it); return p; }
+    return nullptr;
+  }
+};
+static DevPool g_pool;
+static thread_local bool tls_park_released = false;   // set while a plan whose stream has been drained is being destroyed
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   MemQuota* q = nullptr;
   ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); g_dev_bytes.fetch_sub((long long)cap); if (q) q->used -= (int64_t)cap; } p = nullptr; cap = 0; q = nullptr; }
+  void release() {
+    if (p) {
+      if (q) q->used -= (int64_t)cap;
+      if (!(tls_park_released && g_pool.park(p, cap))) { (void)hipFree(p); g_dev_bytes.fetch_sub((long long)cap); }
+    }
+    p = nullptr; cap = 0; q = nullptr;
+  }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
     size_t want = std::max<size_t>(bytes, 256);
@@ -108,6 +148,9 @@ struct DevBuf {
     static const bool trace = getenv("SSGPU_TRACE") != nullptr;   // development: (re)allocations of large buffers are slow and must not sit in a steady state
     if (trace && want >= (64u << 20)) fprintf(stderr, "[ssgpu trace] device buffer %zu -> %zu MiB\n", cap >> 20, want >> 20);
     release();
+    size_t pooled_cap = 0;
+    // (a plan under a quota allocates exactly what it asks for; a pooled block is still counted in g_dev_bytes)
+    if (void* pooled = (Q && Q->limit >= 0) ? nullptr : g_pool.take(want, &pooled_cap)) { p = pooled; cap = pooled_cap; q = Q; if (q) q->used += (int64_t)cap; return hipSuccess; }
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) { cap = want; q = Q; g_dev_bytes.fetch_add((long long)want); if (q) q->used += (int64_t)want; } else p = nullptr;
     return e;
@@ -637,7 +680,9 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   for (auto& ex : p->exec) if (ex.fb_event) { (void)hipEventDestroy(ex.fb_event); ex.fb_event = nullptr; g_events.fetch_sub(1); }
   ssgpu_ctx* c = p->ctx;
   g_live_plans.fetch_sub(1);
+  tls_park_released = c && c->device >= 0;   // the stream was drained above: the plan's device blocks may go to the pool (DevPool)
   delete p;
+  tls_park_released = false;
   if (c) ctx_release(c);
 }
 

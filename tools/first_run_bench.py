@@ -1,6 +1,6 @@
 """What a cursor that is drained ONCE pays: the first run of config #3's GroupAggregate (2 x INT32 keys, 12 DOUBLE aggregates) at sizes
 below and above the scout's threshold, against the plan's steady state.  Usage: python tools/first_run_bench.py [groups]"""
-import os, sys, time, json
+import gc, os, sys, time, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import bench
@@ -19,7 +19,8 @@ for rows in (1 << 18, 1 << 20, 1 << 21, 1 << 22, 6_000_000, 1 << 23, 1 << 24):
     torch.cuda.synchronize()
     ctx = ss.Context(0)
     ctx.set_option("specialize", 0)
-    warm = ss.Plan(op, ctx); warm.run(view); ctx.synchronize()          # (buffers of the context's pool, module load)
+    warm = ss.Plan(op, ctx); warm.run(view); ctx.synchronize()          # (module load; an earlier query of the same service)
+    del warm; gc.collect()                                              # ... whose cursor is gone: its device blocks wait in the library's pool
     plan = ss.Plan(op, ctx)
     times = []
     for _ in range(6):
