@@ -264,6 +264,8 @@ typedef struct ssgpu_op {
   int32_t sort_n;
   int32_t child2;     /* HASH_JOIN: index of the rhs op (must precede); else unused */
   int64_t option0;    /* GROUP: max_unique_keys_in_result (0 = no limit, n > 0 = limit n, -1 = limit 0; aggregate.h:160-205);
+                         DISTINCT aggregates under it keep ONE seen-value set per result row, the folded last row included
+                         (column_aggregator.cc:308-376); CONCAT under it is refused;
                          SORT: memory limit (ignored: no spill path);
                          SCAN: input index (0 = the plan input, 1 = the auxiliary input);
                          HASH_JOIN: JoinType | KeyUniqueness << 8             */

@@ -167,6 +167,10 @@ struct Stage {
   // MATERIALIZE: the stage's last (synthetic) input column holds, for every input row, the number of its cluster -- runs of equal
   // values of these input columns (the AggregateClusters boundary scan), computed in front of the stage's program
   std::vector<int> segment_cols;
+  // MATERIALIZE, DISTINCT aggregates under max_unique_keys_in_result: the input rows are sorted by the group keys segment_cols (stable) and
+  // carry their input row id in column rank_rowid_col; two synthetic input columns follow the stage's columns -- the row's RESULT ROW
+  // (first-seen rank of its key, clamped to rank_limit: row_hash_set.cc:500-511) as UINT32, and a BOOL that says its own key keeps a row
+  bool has_rank = false; int64_t rank_limit = 0; int rank_rowid_col = -1;
   bool has_segment = false;               // ... the stage HAS that synthetic column (segment_cols may be empty: AggregateClusters without a clustering column = one cluster)
   // SCALAR_AGG / CLUSTERS: SUM of a floating input column into an integer result -- the reference adds and truncates row after
   // row (aggregation_operators.h:173-185), so the stage's program only counts the column (the result's slot) and the runtime

@@ -327,6 +327,10 @@ hipError_t ssgpu_launch_gather_rowid(void* dst, const uint8_t* dst_null, const v
 // launches and looks at the plan's interrupt flag between them
 hipError_t ssgpu_launch_seq_sum(const void* src, const uint8_t* src_nulls, int src_kind, const uint32_t* seg_id, uint64_t n,
                                 void* dst, uint8_t* dst_nulls, int dst_kind, hipStream_t s, uint64_t first = 0, uint64_t* state = nullptr, int resume = 0);
+// first-seen ranks of key clusters (sort_kernels.hip): DISTINCT aggregates under max_unique_keys_in_result
+hipError_t ssgpu_launch_seg_first(const uint32_t* seg_id, const uint64_t* rowid, uint64_t n, uint32_t* first, hipStream_t s);
+hipError_t ssgpu_launch_rank_scatter(const uint32_t* sorted, uint64_t n_seg, uint32_t* rank, hipStream_t s);
+hipError_t ssgpu_launch_rank_rows(const uint32_t* seg_id, const uint32_t* rank, uint64_t n, uint32_t limit, uint32_t* out_rank, uint8_t* out_own, hipStream_t s);
 hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
                                       const GroupAggOut* outs, uint32_t n_out, hipStream_t s);
 

@@ -1979,9 +1979,76 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
           for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), cp.input_pos, cp.dtype});
           desc << "(materialise" << (op.kind == SSGPU_OP_GROUP_AGGREGATE ? " + sort + clustered aggregation" : "") << "; CONCAT printed on the host) ";
+        } else if (any_distinct && op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0) {
+          // DISTINCT aggregates under GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205).  The reference keeps one
+          // set of seen values per RESULT ROW (column_aggregator.cc:308-376 indexes its sets by the row the RowHashSet answered),
+          // and under the limit that row is min(first-seen rank of the key, limit) (row_hash_set.cc:500-511) -- so the rows beyond the
+          // limit share ONE set, and no merge of per-key results can give its answer.  The result row is computed for every INPUT
+          // row instead and stands in for the key: materialise (keys, aggregated columns, row id) -> stable sort by the keys ->
+          // store the rows once more with `$rank` (Stage::has_rank: cluster numbers, every cluster's first row id, the clusters'
+          // order by it, clamped) and with every key masked to NULL outside the groups that keep a row of their own -> the
+          // DISTINCT shape with `$rank` as its one key; the visible keys are FIRST(masked key) by row id; `$rank` is dropped behind.
+          const int64_t limit = op.option0 < 0 ? 0 : op.option0;
+          if (limit >= (1ll << 31)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result beyond 2^31 keys next to a DISTINCT aggregate");
+          GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
+          const size_t n_keys = g.kpos.size();
+          Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
+          const int row_pos = add_row_id_column(&pruned);
+          Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
+          stages->push_back(m);
+          Stage so; so.kind = STAGE_SORT; so.in_schema = m.out_schema; so.out_schema = m.out_schema;
+          for (int k : g.kpos) {
+            if (dtype_width(so.in_schema[k].dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length group keys are outside the device hot path");
+            SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; so.sort_keys.push_back(sk);
+          }
+          for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
+          stages->push_back(so);
+          reset_pipe(&pipe, so.out_schema);
+          const int n_stored = (int)pipe.cols.size();
+          auto synthetic = [&](const char* name, int input_col, int dtype) {
+            VCol sc; sc.name = name; sc.expr = std::make_shared<BExpr>();
+            sc.expr->kind = BExpr::INPUT; sc.expr->input_col = input_col; sc.expr->dtype = dtype; sc.expr->nullable = false; sc.expr->name = name;
+            pipe.cols.push_back(sc);
+            return (int)pipe.cols.size() - 1;
+          };
+          const int rank_pos = synthetic("$rank", n_stored, SSGPU_UINT32);
+          const int own_pos = synthetic("$own", n_stored + 1, SSGPU_BOOL);
+          std::vector<int> masked_pos;
+          for (size_t k = 0; k < n_keys; ++k) {
+            const BExprP key = pipe.cols[g.kpos[k]].expr;
+            BExprP none(new BExpr); none->kind = BExpr::NULLCONST; none->dtype = key->dtype; none->nullable = true; none->name = "NULL";
+            VCol v; v.name = "$key" + std::to_string(k); v.expr = std::make_shared<BExpr>();
+            v.expr->kind = BExpr::OP; v.expr->op = OP_IF; v.expr->dtype = key->dtype; v.expr->nullable = true;
+            v.expr->name = "IF($own, " + key->name + ", NULL)"; v.expr->args = {pipe.cols[own_pos].expr, key, none};
+            pipe.cols.push_back(v);
+            masked_pos.push_back((int)pipe.cols.size() - 1);
+          }
+          Stage mr; SS_RETURN_IF_ERROR(finish_materialize(pipe, &mr));
+          mr.has_rank = true; mr.rank_limit = limit; mr.rank_rowid_col = row_pos; mr.segment_cols = g.kpos;
+          stages->push_back(mr);
+          reset_pipe(&pipe, mr.out_schema);
+          GroupBinding gr;
+          gr.kpos = {rank_pos}; gr.knames = {"$rank"};
+          for (size_t k = 0; k < n_keys; ++k) {
+            AggPlan kp; kp.aggregation = SSGPU_FIRST; kp.input_pos = masked_pos[k]; kp.out_type = mr.out_schema[masked_pos[k]].dtype;
+            kp.out_name = g.knames[k]; kp.result_nullable = so.out_schema[g.kpos[k]].nullable; kp.order_pos = row_pos;
+            gr.plans.push_back(kp);
+          }
+          std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
+          for (auto& ap : g.plans) {
+            if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
+            if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
+            gr.plans.push_back(ap);
+          }
+          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &gr, std::vector<int>{rank_pos}, dcols, false, &st));
+          desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit << " + " << dcols.size()
+               << " x (sort + first-of-run flags)) GroupAggregate -> [" << schema_to_string(st.out_schema) << "] minus its first column\n";
+          stages->push_back(st);
+          reset_pipe(&pipe, st.out_schema);
+          pipe.cols.erase(pipe.cols.begin());   // ($rank)
+          pending = true;
+          break;
         } else if (any_distinct) {
-          if (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0)
-            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "GroupAggregateOptions::max_unique_keys_in_result is not available on the device path");
           GroupBinding g;
           if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));

@@ -254,6 +254,7 @@ struct StageExec {
   DevBuf debug, debug_pc, total2;
   // sort / clusters
   DevBuf skeys_a, skeys_b, skeys_c, sidx_a, sidx_b, shist, soffs, seg_id, sstatus, sticket, srecs, dflag;
+  DevBuf rank_first, rank_of_seg, rank_row, rank_own;   // Stage::has_rank (rank_columns)
   DevBuf seg_counts, seg_offsets, seg_total;   // segment_ids() of a MATERIALIZE stage (its own: the stage's filter passes use tile_counts / total)
   DevBuf route_scratch;         // key-range exchange: per-destination counters + (destination, position) of every result row
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
@@ -1153,6 +1154,35 @@ int segment_ids(ssgpu_ctx* c, const Stage& st, StageExec& ex, const InCols& in, 
   return SSGPU_OK;
 }
 
+// Stage::has_rank: the RESULT ROW of every input row under GroupAggregateOptions::max_unique_keys_in_result, and whether the row's own
+// key keeps a result row.  The rows are sorted by the keys: cluster numbers (segment_ids) -> every cluster's first input row id
+// -> the clusters ordered by it (their first-seen rank: the order RowHashSet::Insert numbers new keys in, row_hash_set.cc:458-517) -> per
+// row min(rank, limit).  One host round trip (the cluster count); launches and an LSD sort over the CLUSTERS, not the rows.
+int rank_columns(ssgpu_plan* p, const Stage& st, StageExec& ex, const InCols& in, ssgpu_column* rank_out, ssgpu_column* own_out) {
+  ssgpu_ctx* c = p->ctx;
+  if (in.rows >= (1ll << 32)) { c->err = "DISTINCT aggregates under max_unique_keys_in_result: more than 2^32 input rows"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  ssgpu_column seg;
+  int rc = segment_ids(c, st, ex, in, &seg);
+  if (rc != SSGPU_OK) return rc;
+  const uint64_t n = (uint64_t)in.rows;
+  uint64_t n_seg = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n_seg, ex.seg_total.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, ex.rank_first.ensure(std::max<uint64_t>(n_seg, 1) * 4)); HIP_TRY(c, ex.rank_of_seg.ensure(std::max<uint64_t>(n_seg, 1) * 4));
+  HIP_TRY(c, ex.rank_row.ensure(std::max<uint64_t>(n, 1) * 4)); HIP_TRY(c, ex.rank_own.ensure(std::max<uint64_t>(n, 1)));
+  HIP_TRY(c, ssgpu_launch_seg_first(ex.seg_id.as<uint32_t>(), (const uint64_t*)in.cols[st.rank_rowid_col].data, n, ex.rank_first.as<uint32_t>(), c->stream));
+  uint32_t* sorted = nullptr;
+  rc = sort_rows_by_u32(p, ex, ex.rank_first.as<uint32_t>(), n_seg, &sorted);
+  if (rc != SSGPU_OK) return rc;
+  HIP_TRY(c, ssgpu_launch_rank_scatter(sorted, n_seg, ex.rank_of_seg.as<uint32_t>(), c->stream));
+  HIP_TRY(c, ssgpu_launch_rank_rows(ex.seg_id.as<uint32_t>(), ex.rank_of_seg.as<uint32_t>(), n, (uint32_t)st.rank_limit, ex.rank_row.as<uint32_t>(),
+                                    ex.rank_own.as<uint8_t>(), c->stream));
+  p->counters.n_launches += 3;
+  rank_out->data = ex.rank_row.p; rank_out->is_null = nullptr;
+  own_out->data = ex.rank_own.p; own_out->is_null = nullptr;
+  return SSGPU_OK;
+}
+
 int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_base) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   int rc = ensure_out_cols(c, st, ex, in0.rows);
@@ -1166,6 +1196,10 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   if (st.has_segment) {    // DISTINCT aggregates of clusters: the rows are stored with their cluster's number
     ssgpu_column f; rc = segment_ids(c, st, ex, in0, &f); if (rc != SSGPU_OK) return rc;
     in.cols.push_back(f);
+  }
+  if (st.has_rank) {       // DISTINCT aggregates under a key limit: the rows are stored with their result row
+    ssgpu_column r, o; rc = rank_columns(p, st, ex, in0, &r, &o); if (rc != SSGPU_OK) return rc;
+    in.cols.push_back(r); in.cols.push_back(o);
   }
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
@@ -1329,7 +1363,7 @@ static bool tail_runs_without_host(const ssgpu_plan* p, size_t si) {
   if (!p->ctx->async_handoff && si + 1 < p->stages.size()) return false;
   for (size_t k = si + 1; k < p->stages.size(); ++k) {
     const Stage& nx = p->stages[k];
-    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && !nx.has_segment && nx.joins.empty())) return false;
+    if (!(nx.kind == STAGE_MATERIALIZE && !nx.has_filter && nx.distinct_cols.empty() && !nx.has_segment && !nx.has_rank && nx.joins.empty())) return false;
   }
   return true;
 }
@@ -2657,7 +2691,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
       // stage's error word is still looked at when the result is touched (check_error_flags); rows beyond the count are
       // never computed, so a signaling operator cannot fail on them.
       const bool device_rows = c->async_handoff != 0 && !c->debug_timing && ex.out_rows < 0 && ex.out_capacity > 0 && nx.kind == STAGE_MATERIALIZE &&
-                               !nx.has_filter && nx.distinct_cols.empty() && !nx.has_segment && nx.joins.empty();
+                               !nx.has_filter && nx.distinct_cols.empty() && !nx.has_segment && !nx.has_rank && nx.joins.empty();
       int64_t r = 0;
       in.rows_dev = nullptr;
       if (device_rows) {

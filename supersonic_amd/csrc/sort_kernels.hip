@@ -958,6 +958,39 @@ hipError_t ssgpu_launch_cluster_assign(const void* const* data, const uint8_t* c
   if (nt) hipLaunchKernelGGL(ssgpu_cluster_assign_kernel, dim3(nt), dim3(256), 0, s, K, O, (u64)n, tile_offsets, seg_id);
   return hipGetLastError();
 }
+// ---- first-seen ranks of key clusters (DISTINCT aggregates under max_unique_keys_in_result; runtime.cpp: rank_columns) ---------------
+// The rows arrive sorted by their group keys (stable: input order inside a cluster) with their input row id as a column.  A key's
+// place in the reference's RowHashSet is its FIRST-SEEN order (row_hash_set.cc:458-517): the rank of its cluster's first row id
+// among all clusters' first row ids.  (1) the first row id of every cluster, (2) [host: sort the clusters by it] rank of every
+// cluster, (3) per row: its result row = min(rank, limit) and whether its own group keeps a row of its own (rank <= limit).
+__global__ void ssgpu_seg_first_kernel(const u32* __restrict__ seg_id, const u64* __restrict__ rowid, u64 n, u32* __restrict__ first) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0 || seg_id[i] != seg_id[i - 1]) first[seg_id[i]] = (u32)rowid[i];
+}
+__global__ void ssgpu_rank_scatter_kernel(const u32* __restrict__ sorted, u64 n_seg, u32* __restrict__ rank) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_seg) rank[sorted[j]] = (u32)j;
+}
+__global__ void ssgpu_rank_rows_kernel(const u32* __restrict__ seg_id, const u32* __restrict__ rank, u64 n, u32 limit, u32* __restrict__ out_rank, u8* __restrict__ out_own) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 r = rank[seg_id[i]];
+  out_rank[i] = r < limit ? r : limit;
+  out_own[i] = r <= limit ? (u8)1 : (u8)0;
+}
+hipError_t ssgpu_launch_seg_first(const uint32_t* seg_id, const uint64_t* rowid, uint64_t n, uint32_t* first, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_seg_first_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, seg_id, (const u64*)rowid, (u64)n, first);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_rank_scatter(const uint32_t* sorted, uint64_t n_seg, uint32_t* rank, hipStream_t s) {
+  if (n_seg) hipLaunchKernelGGL(ssgpu_rank_scatter_kernel, dim3(blocks_for(n_seg, 256)), dim3(256), 0, s, sorted, (u64)n_seg, rank);
+  return hipGetLastError();
+}
+hipError_t ssgpu_launch_rank_rows(const uint32_t* seg_id, const uint32_t* rank, uint64_t n, uint32_t limit, uint32_t* out_rank, uint8_t* out_own, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(ssgpu_rank_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, seg_id, rank, (u64)n, limit, out_rank, (u8*)out_own);
+  return hipGetLastError();
+}
 hipError_t ssgpu_launch_dense_extract(const uint64_t* acc, const uint32_t* cnt, uint32_t n_gaggs, uint64_t n_rows,
                                       const GroupAggOut* outs, uint32_t n_out, hipStream_t s) {
   DenseExtractParams P; memset(&P, 0, sizeof(P));

@@ -236,6 +236,35 @@ class Gen(object):
                                      ss.GroupAggregateOptions().set_max_unique_keys_in_result_(int(self.rng.integers(0, 9))), child), True
         return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child), False
 
+    def distinct_limit_plan(self, view):
+        """DISTINCT aggregates under GroupAggregateOptions::max_unique_keys_in_result (round 5): the seen-value sets belong to the RESULT
+        rows, so the rows folded into the last one share a set.  Keys of every width, FIRST / LAST and plain aggregates next to
+        them, limits around and beyond the number of groups.  Returns (operation, True): first-seen order is defined."""
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("k1")).Add(NA("a")).Add(NA("b")).Add(NA("u")).Add(NA("t")).Add(NA("day")).Add(NA("name"))
+        spec = ss.AggregationSpecification()
+        inputs = ["a", "b", "k1", "u", "t", "day", "k2", "s"]
+        for i in range(int(self.rng.integers(0, 3))):
+            e.AddAs("x%d" % i, self.integer(int(self.rng.integers(0, 3))))
+            inputs.append("x%d" % i)
+        n_distinct = 0
+        for i in range(int(self.rng.integers(1, 6))):
+            name = self.pick(inputs)
+            agg = self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.COUNT, ss.FIRST, ss.LAST])
+            if name in ("t", "day") and agg == ss.SUM:
+                agg = ss.COUNT
+            distinct = agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < 0.6
+            n_distinct += distinct
+            (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
+        if not n_distinct:
+            spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1", "u", "s"]), "rd")
+        child = ss.ScanView(view)
+        if self.rng.random() < 0.5:
+            child = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), child)
+        child = ss.Compute(e, child)
+        keys = self.pick([["k2"], ["k2", "s"], ["s"], ["k1"], ["k1", "k2"], ["a", "s"], ["day", "s"], ["name", "k2"], ["t"]])
+        limit = int(self.pick([0, 1, 2, 3, 5, 8, 40, 300, 5000, 100000]))
+        return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit), child), True
+
     def sequential_sum_plan(self, view):
         """SUM of FLOAT / DOUBLE inputs into integer results (folded row after row in input order) next to ordinary aggregates,
         as ScalarAggregate / GroupAggregate / AggregateClusters.  Returns (operation, result order is defined)."""

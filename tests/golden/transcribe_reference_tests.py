@@ -1346,6 +1346,32 @@ derived_case("Derived_Limit_WideKeysMinMaxCount", RHS,
               [["MIN", "col3", "mn"], ["MAX", "col3", "mx"], ["COUNT", "", "n"], ["SUM", "col3", "s"]], "INPUT", {"max_unique_keys_in_result": 2}],
              [I32, I32, I32, I32, I32, U64, I32], [[1, 1, 1, 10, 10, 1, 10], [2, 2, 2, 20, 50, 2, 70], [3, 3, 3, 30, 60, 3, 130]])
 
+# ---- C2: DISTINCT aggregates under max_unique_keys_in_result: one seen-value set per RESULT row ------------------------------------------------
+D_LIMD = (D_LIM + "DistinctAggregator::UpdateAggregation looks a row's value up in distinct_values_[result_index_map[i]] (" + DST + "): the set belongs to the RESULT "
+          "ROW the hash set answered, so every key folded into row `limit` shares that row's one set; NULL inputs are skipped. ")
+derived_case("Derived_Limit_DistinctSharesTheFoldedRowsSet", RHS + "; " + DST,
+             D_LIMD + "Keys 1,2,3,4,3,5,4,1,2 under limit 2: rows 0, 1 = keys 1, 2; row 2 = key 3 and, folded, 4 and 5.  Row 2 sees 7 (key 3), 7 (key 4: already in "
+             "the row's set), 8 (key 3), 8 (key 5: seen), 9 (key 4): distinct {7, 8, 9} -> COUNT 3, SUM 24 -- per-key answers would add up to 2 + 2 + 1 = 5 and 46; plain "
+             "COUNT(*) 5.  Row 0: 5, 5 -> {5}: 1, 5, 2 rows.  Row 1: 6, 1 -> 2, 7, 2 rows.",
+             cols([I32, I64], nullable=False), [[1, 5], [2, 6], [3, 7], [4, 7], [3, 8], [5, 8], [4, 9], [1, 5], [2, 1]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["COUNT_DISTINCT", "col1", "c"], ["SUM_DISTINCT", "col1", "s"], ["COUNT", "", "n"]], "INPUT",
+              {"max_unique_keys_in_result": 2}],
+             [I32, U64, I64, U64], [[1, 1, 5, 2], [2, 2, 7, 2], [3, 3, 24, 5]])
+derived_case("Derived_Limit_DistinctZeroLimitIsAScalarDistinct", RHS + "; " + DST,
+             D_LIMD + "Limit 0: every row lands in row 0, whose key is the first one seen (9).  Values 4, NULL, 4, 6, NULL, 6, 5: distinct {4, 6, 5} -> COUNT 3, SUM 15; "
+             "COUNT(v) 5; LAST 5 (NULLs never count).",
+             cols([I32, I32]), [[9, 4], [8, None], [7, 4], [9, 6], [None, None], [6, 6], [8, 5]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["COUNT_DISTINCT", "col1", "c"], ["SUM_DISTINCT", "col1", "s"], ["COUNT", "col1", "n"], ["LAST", "col1", "l"]],
+              "INPUT", {"max_unique_keys_in_result": 0}],
+             [I32, U64, I32, U64, I32], [[9, 3, 15, 5, 5]])
+derived_case("Derived_Limit_DistinctNullKeyOwnsTheFoldedRow", RHS + "; " + DST + "; supersonic/cursor/infrastructure/row_hash_set.cc:143-210",
+             D_LIMD + "NULL is a key (RowComparator, row_hash_set.cc:143-210).  Keys 5, NULL, 6, NULL, 7 under limit 1: row 0 = key 5; row 1 = key NULL (the index held 1 <= 1 "
+             "rows), and 6, 7 fold into it -- the row shows the key NULL.  Row 1 sees 2, 3, 2, 3: distinct {2, 3} -> COUNT 2, SUM 5, FIRST 2; row 0: {1} -> 1, 1, 1.",
+             cols([I32, I32]), [[5, 1], [None, 2], [6, 3], [None, 2], [7, 3]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["COUNT_DISTINCT", "col1", "c"], ["SUM_DISTINCT", "col1", "s"], ["FIRST", "col1", "f"]], "INPUT",
+              {"max_unique_keys_in_result": 1}],
+             [I32, U64, I32, I32], [[5, 1, 1, 1], [None, 2, 5, 2]])
+
 # ---- D: SUM of a floating input into an integer result (the reference's row-after-row arithmetic) --------------------------------------------
 D_SEQ = ("AddAggregationWithDefinedOutputType(SUM, DOUBLE column, INT result): AggregationOperator<SUM>::Update is `*result += val` on an integer result and a "
          "floating val (supersonic/base/infrastructure/aggregation_operators.h:173-185): C++ converts *result to the floating type, adds, and truncates the sum "

@@ -94,6 +94,13 @@ def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
                            ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
     rs = ss.Plan(fl, ss.Context(-1)).result_schema
     assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "f", "l"]
+    # DISTINCT under a limit: the rows are re-keyed by their result row ($rank, hidden) -- one seen-value set per result row
+    ds = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "v", "c").AddAggregation(ss.LAST, "v", "l"),
+                           ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
+    dplan = ss.Plan(ds, ss.Context(-1))
+    rs = dplan.result_schema
+    assert [(rs.attribute(i).name(), rs.attribute(i).is_nullable()) for i in range(rs.attribute_count())] == [("k", False), ("c", False), ("l", True)]
+    assert "result row of every input row under the limit 2" in dplan.describe()
     bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f"),
                             ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
     with pytest.raises(ss.SupersonicException) as e:

@@ -32,6 +32,27 @@ def test_binder_agrees_with_oracle_on_random_plans(seed):
     assert got == [tuple(x) for x in want_schema]
 
 
+@pytest.mark.parametrize("seed", range(6000, 6200))
+def test_binder_agrees_with_oracle_on_distinct_aggregates_under_a_key_limit(seed):
+    view = make_view(3, seed)
+    op, _ordered = Gen(seed).distinct_limit_plan(view)
+    want_schema = want_err = None
+    try:
+        want_schema, _cols = oracle.run(op)
+    except oracle.OracleError as e:
+        want_err = e.return_code
+    try:
+        plan = ss.Plan(op, ss.Context(-1))
+    except ss.SupersonicException as e:
+        assert want_err is not None, "device binder failed (%s) where the oracle binds" % e
+        assert e.return_code == want_err
+        return
+    assert want_err is None, "device binder accepted a plan the oracle rejects with %s" % want_err
+    rs = plan.result_schema
+    got = [(rs.attribute(i).name(), rs.attribute(i).type(), rs.attribute(i).is_nullable()) for i in range(rs.attribute_count())]
+    assert got == [tuple(x) for x in want_schema]
+
+
 @pytest.mark.parametrize("seed", range(4000, 4250))
 def test_binder_agrees_with_oracle_on_random_ordered_aggregates(seed):
     # DISTINCT next to FIRST / LAST, key limits, DISTINCT inside AggregateClusters: the binder refuses nothing the oracle binds

@@ -74,6 +74,22 @@ def test_random_ordered_aggregates(gpu_ctx, seed, n):
 
 
 @pytest.mark.parametrize("n", [1537, 20011])
+@pytest.mark.parametrize("seed", range(6000, 6200))
+def test_random_distinct_aggregates_under_a_key_limit(gpu_ctx, seed, n):
+    # DISTINCT under max_unique_keys_in_result: one seen-value set per RESULT row (column_aggregator.cc:308-376 over the row index
+    # row_hash_set.cc:500-511 answers) -- the device stores every input row's result row and aggregates by it
+    view = make_view(n, seed)
+    op, ordered = Gen(seed).distinct_limit_plan(view)
+    try:
+        oracle.run(op)
+    except oracle.OracleError:
+        with pytest.raises(ss.SupersonicException):
+            ss.Plan(op, gpu_ctx)
+        return
+    run_both(op, gpu_ctx, ignore_order=not ordered)
+
+
+@pytest.mark.parametrize("n", [1537, 20011])
 @pytest.mark.parametrize("seed", range(5000, 5150))
 def test_random_sequential_sums(gpu_ctx, seed, n):
     # SUM of floating inputs into integer results: the reference's row-after-row arithmetic, bit for bit

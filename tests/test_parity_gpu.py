@@ -1676,11 +1676,42 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
     got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("col0"), ss.AggregationSpecification().AddAggregation(ss.SUM, "col1", "sum"), opts, ss.ScanView(view)), gpu_ctx)
     assert got.column(0).data.tolist() == [1, 3, 4] and got.column(1).data.tolist() == [5, -9, 9]
     wide = make_view(100, nullable=True)
-    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "b", "s"), opts, ss.ScanView(wide)),
-               ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l"), opts, ss.ScanView(wide))):
+    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l"), opts, ss.ScanView(wide)),):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(op, gpu_ctx)
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+
+
+@pytest.mark.parametrize("limit", [0, 1, 2, 7, 299, 300, 5000])
+@pytest.mark.parametrize("n", [9, 1025, 100003])
+def test_group_aggregate_distinct_under_max_unique_keys_in_result(gpu_ctx, n, limit):
+    """DISTINCT aggregates under a key limit.  The reference's DISTINCT aggregator keeps one set of seen values per RESULT ROW
+    (column_aggregator.cc:308-376), and beyond the limit every new key is answered with the last row (row_hash_set.cc:500-511): the
+    folded row's COUNT(DISTINCT x) counts the distinct x over ALL its rows -- not a sum of per-key counts.  The device stores each
+    input row's result row (first-seen rank of its key, clamped) and aggregates by it; same rows in the SAME (first-seen) order."""
+    view = make_view(n, nullable=True)
+    spec = (ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "b", "cb").AddDistinctAggregation(ss.SUM, "b", "sb")
+            .AddDistinctAggregation(ss.COUNT, "d0", "c0").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.SUM, "a", "sa")
+            .AddDistinctAggregation(ss.SUM, "u", "su").AddAggregation(ss.MIN, "d0", "mn").AddAggregation(ss.MAX, "f", "mf")
+            .AddAggregation(ss.FIRST, "d0", "fd").AddAggregation(ss.LAST, "t", "lt"))
+    opts = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), spec, opts, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1"]), spec, opts,                                  # a NULL key group among them
+                               ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(299)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, opts, ss.ScanView(view)), gpu_ctx)   # 65 key bits
+    plain = make_view(n)
+    got = run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, opts, ss.ScanView(plain)), gpu_ctx)   # NOT NULL keys stay NOT NULL
+    assert not got.schema().attribute(0).is_nullable() and not got.schema().attribute(1).is_nullable()
+
+
+def test_distinct_under_key_limit_shares_one_set_beyond_the_limit(gpu_ctx):
+    # keys 1, 2 keep their rows; 3, 4, 5 fold into the row of key 3: its distinct values of v are {7, 8, 9} -- 3, not 2 + 2 + 1
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("v", ss.INT64)])
+    view = ss.View(schema, [np.array([1, 2, 3, 4, 3, 5, 4, 1, 2], np.int32), np.array([5, 6, 7, 7, 8, 8, 9, 5, 1], np.int64)])
+    spec = ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "v", "c").AddDistinctAggregation(ss.SUM, "v", "s").AddAggregation(ss.COUNT, "", "n")
+    got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("k"), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view)), gpu_ctx)
+    assert got.column(0).data.tolist() == [1, 2, 3]
+    assert got.column(1).data.tolist() == [1, 2, 3] and got.column(2).data.tolist() == [5, 7, 24] and got.column(3).data.tolist() == [2, 2, 5]
 
 
 @pytest.mark.parametrize("specialize", [0, 1])
