@@ -265,7 +265,7 @@ typedef struct ssgpu_op {
   int32_t child2;     /* HASH_JOIN: index of the rhs op (must precede); else unused */
   int64_t option0;    /* GROUP: max_unique_keys_in_result (0 = no limit, n > 0 = limit n, -1 = limit 0; aggregate.h:160-205);
                          DISTINCT aggregates under it keep ONE seen-value set per result row, the folded last row included
-                         (column_aggregator.cc:308-376); CONCAT under it is refused;
+                         (column_aggregator.cc:308-376), and CONCAT joins a result row's values in input order over all its keys;
                          SORT: memory limit (ignored: no spill path);
                          SCAN: input index (0 = the plan input, 1 = the auxiliary input);
                          HASH_JOIN: JoinType | KeyUniqueness << 8             */
@@ -387,7 +387,7 @@ int ssgpu_dict_decode(const ssgpu_dict* d, int32_t code, const char** bytes, int
  * until the plan runs again) and NULL for every other column (STRING cells of those are codes of the plan's dictionary).
  * ssgpu_plan_set_dict hands the plan the dictionary its STRING columns were encoded with (borrowed; CONCAT of a STRING
  * column prints through it).  Limits, refused at bind: DISTINCT CONCAT, DATE / DATETIME / BINARY inputs, a CONCAT result
- * that feeds another operation, CONCAT under max_unique_keys_in_result or across shards. */
+ * that feeds another operation, CONCAT next to a DISTINCT aggregate or across shards. */
 int ssgpu_plan_set_dict(ssgpu_plan* plan, const ssgpu_dict* dict);
 const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t col);
 

@@ -279,8 +279,17 @@ def _run_with_concat(operation, max_rows):
     group_of, n_groups = np.zeros(n, dtype=np.int64), (1 if kind == 5 else 0)
     if kind == 6:        # GroupAggregate: first-seen order (row_hash_set.cc:458-517)
         seen = {}
+        limit = getattr(getattr(operation, "options", None), "max_unique_keys_in_result", None)
         for i in range(n):
-            group_of[i] = seen.setdefault(key_of(i), len(seen))
+            k = key_of(i)
+            if k not in seen:
+                # GroupAggregateOptions::max_unique_keys_in_result (row_hash_set.cc:500-511): an unseen key is appended while the index
+                # holds <= limit rows; later unseen keys are answered with the index's last row and NOT remembered
+                if limit is not None and len(seen) > limit:
+                    group_of[i] = len(seen) - 1
+                    continue
+                seen[k] = len(seen)
+            group_of[i] = seen[k]
         n_groups = len(seen)
     elif kind == 7:      # AggregateClusters: a new group whenever the key changes (aggregate_clusters.cc:338-520)
         prev = None

@@ -1949,13 +1949,13 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           if (has_sequential(probe) && (any_distinct || any_concat || (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0)))
             return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to DISTINCT / CONCAT aggregates or under max_unique_keys_in_result is not available on the device path");
         }
-        if (any_concat) {
+        const bool limited_group = op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0;
+        if (any_concat && !(limited_group && !any_distinct)) {
           // CONCAT (Stage::ConcatCol): the values have to reach the host in input order, group by group -- materialise the keys and
           // the aggregated columns, (stable) sort by the keys, aggregate the key runs with the clustered kernel (CONCAT counted as
           // COUNT(x)); the host prints the strings from the sorted rows and their segment ids when the column is fetched.
           if (any_distinct) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate is not available on the device path");
           if (ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
-          if (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT under max_unique_keys_in_result is not available on the device path");
           GroupBinding g;
           if (op.kind == SSGPU_OP_GROUP_AGGREGATE) SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           else SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &g.plans));
@@ -1979,7 +1979,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
           for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), cp.input_pos, cp.dtype});
           desc << "(materialise" << (op.kind == SSGPU_OP_GROUP_AGGREGATE ? " + sort + clustered aggregation" : "") << "; CONCAT printed on the host) ";
-        } else if (any_distinct && op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0) {
+        } else if ((any_distinct || any_concat) && limited_group) {
           // DISTINCT aggregates under GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205).  The reference keeps one
           // set of seen values per RESULT ROW (column_aggregator.cc:308-376 indexes its sets by the row the RowHashSet answered),
           // and under the limit that row is min(first-seen rank of the key, limit) (row_hash_set.cc:500-511) -- so the rows beyond the
@@ -1988,6 +1988,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // store the rows once more with `$rank` (Stage::has_rank: cluster numbers, every cluster's first row id, the clusters'
           // order by it, clamped) and with every key masked to NULL outside the groups that keep a row of their own -> the
           // DISTINCT shape with `$rank` as its one key; the visible keys are FIRST(masked key) by row id; `$rank` is dropped behind.
+          // CONCAT under the limit takes the same road: a result row's string joins the values of ALL its rows in input order
+          // (column_aggregator.cc:108-124 over the same result index), so the stored rows are sorted by ($rank, row id) and aggregated
+          // as clusters of `$rank`; the host prints from that stage's input (Stage::ConcatCol::stage) behind the projection.
+          if (any_concat && ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
           const int64_t limit = op.option0 < 0 ? 0 : op.option0;
           if (limit >= (1ll << 31)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result beyond 2^31 keys next to a DISTINCT aggregate");
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
@@ -2039,6 +2043,28 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
             if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             gr.plans.push_back(ap);
+          }
+          if (any_concat) {
+            Stage s2; s2.kind = STAGE_SORT; s2.in_schema = mr.out_schema; s2.out_schema = mr.out_schema;
+            for (int k : {rank_pos, row_pos}) { SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; s2.sort_keys.push_back(sk); }
+            for (size_t i = 0; i < s2.in_schema.size(); ++i) s2.sort_out_cols.push_back((int)i);
+            stages->push_back(s2);
+            reset_pipe(&pipe, s2.out_schema);
+            std::vector<ConcatPlan> concats;
+            take_concat_plans(schema_of(pipe.cols), &gr.plans, &concats);
+            SS_RETURN_IF_ERROR(finish_group_agg(gr, pipe, &st, true));
+            stages->push_back(st);
+            const int cluster_stage = (int)stages->size() - 1;
+            reset_pipe(&pipe, st.out_schema);
+            pipe.cols.erase(pipe.cols.begin());   // ($rank)
+            Stage fm; SS_RETURN_IF_ERROR(finish_materialize(pipe, &fm));
+            for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)cp.agg; cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.stage = cluster_stage; fm.concat.push_back(cc); }
+            desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit
+                 << " + sort by (result row, row id) + clustered aggregation; CONCAT printed on the host) GroupAggregate -> [" << schema_to_string(fm.out_schema) << "]\n";
+            stages->push_back(fm);
+            reset_pipe(&pipe, fm.out_schema);
+            pending = false;
+            break;
           }
           SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &gr, std::vector<int>{rank_pos}, dcols, false, &st));
           desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit << " + " << dcols.size()

@@ -3158,7 +3158,7 @@ void print_typed(int dtype, const char* cell, const ssgpu_dict* dict, std::strin
 // of the result; the column holds its codes.
 int build_concat_column(ssgpu_result* r, int32_t col, const Stage::ConcatCol& cc, int64_t out_rows) {
   ssgpu_plan* p = r->plan; ssgpu_ctx* c = p->ctx;
-  const size_t si = p->stages.size() - 1;
+  const size_t si = cc.stage >= 0 ? (size_t)cc.stage : p->stages.size() - 1;
   const Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   if (cc.src_dtype == SSGPU_STRING && !p->dict) { c->err = "CONCAT of a STRING column needs the plan's dictionary (ssgpu_plan_set_dict)"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   int64_t n = p->last_rows;

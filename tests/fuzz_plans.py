@@ -247,15 +247,19 @@ class Gen(object):
             e.AddAs("x%d" % i, self.integer(int(self.rng.integers(0, 3))))
             inputs.append("x%d" % i)
         n_distinct = 0
+        concat = self.rng.random() < 0.3      # CONCAT under the limit instead (CONCAT next to DISTINCT is refused on the device path)
         for i in range(int(self.rng.integers(1, 6))):
             name = self.pick(inputs)
             agg = self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.COUNT, ss.FIRST, ss.LAST])
             if name in ("t", "day") and agg == ss.SUM:
                 agg = ss.COUNT
-            distinct = agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < 0.6
+            distinct = not concat and agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < 0.6
             n_distinct += distinct
             (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
-        if not n_distinct:
+        if concat:
+            for j in range(int(self.rng.integers(1, 3))):
+                spec.AddAggregation(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name"]), "rc%d" % j)
+        elif not n_distinct:
             spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1", "u", "s"]), "rd")
         child = ss.ScanView(view)
         if self.rng.random() < 0.5:

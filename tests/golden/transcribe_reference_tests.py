@@ -1372,6 +1372,14 @@ derived_case("Derived_Limit_DistinctNullKeyOwnsTheFoldedRow", RHS + "; " + DST +
               {"max_unique_keys_in_result": 1}],
              [I32, U64, I32, I32], [[5, 1, 1, 1], [None, 2, 5, 2]])
 
+derived_case("Derived_Limit_ConcatJoinsTheFoldedRowsValuesInInputOrder", RHS + "; supersonic/cursor/core/column_aggregator.cc:108-124",
+             D_LIM + "CONCAT appends a row's printed value to the string of its RESULT row (column_aggregator.cc:108-124 walks result_index_map like every other "
+             "aggregator; NULL inputs are skipped, ',' between values).  Keys 1,2,3,4,3,5,4,1,2 under limit 2: row 2 = keys 3, 4, 5 = inputs 2,3,4,5,6 = 7, 7, 8, NULL, 9 "
+             "-> '7,7,8,9' in INPUT order (not key after key); row 0 = '5,5'; row 1 = '6,1'.",
+             cols([I32, I64]), [[1, 5], [2, 6], [3, 7], [4, 7], [3, 8], [5, None], [4, 9], [1, 5], [2, 1]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["CONCAT", "col1", "c"], ["COUNT", "", "n"]], "INPUT", {"max_unique_keys_in_result": 2}],
+             [I32, STR, U64], [[1, "5,5", 2], [2, "6,1", 2], [3, "7,7,8,9", 5]])
+
 # ---- D: SUM of a floating input into an integer result (the reference's row-after-row arithmetic) --------------------------------------------
 D_SEQ = ("AddAggregationWithDefinedOutputType(SUM, DOUBLE column, INT result): AggregationOperator<SUM>::Update is `*result += val` on an integer result and a "
          "floating val (supersonic/base/infrastructure/aggregation_operators.h:173-185): C++ converts *result to the floating type, adds, and truncates the sum "

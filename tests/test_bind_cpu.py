@@ -80,7 +80,7 @@ def test_bind_errors(bind_ctx):
 def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     # GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205, row_hash_set.cc:500-511): hash aggregate with a
     # hidden first-seen row id, sort by it, fold of the rows beyond the limit -- the hidden column is not in the result schema;
-    # FIRST / LAST under a limit fold by a hidden row-id twin each (also not in the result schema); CONCAT under a limit is refused
+    # FIRST / LAST under a limit fold by a hidden row-id twin each (also not in the result schema); DISTINCT and CONCAT under a limit re-key the rows by their result row; CONCAT next to DISTINCT is refused
     import numpy as np
     schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64)])
     view = ss.View(schema, [np.arange(4), np.arange(4)])
@@ -101,7 +101,13 @@ def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     rs = dplan.result_schema
     assert [(rs.attribute(i).name(), rs.attribute(i).is_nullable()) for i in range(rs.attribute_count())] == [("k", False), ("c", False), ("l", True)]
     assert "result row of every input row under the limit 2" in dplan.describe()
-    bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f"),
+    cc = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f"),
+                           ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
+    cplan = ss.Plan(cc, ss.Context(-1))
+    rs = cplan.result_schema
+    assert [(rs.attribute(i).name(), rs.attribute(i).type()) for i in range(rs.attribute_count())] == [("k", ss.INT64), ("f", ss.STRING)]
+    assert "sort by (result row, row id)" in cplan.describe()
+    bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f").AddDistinctAggregation(ss.SUM, "v", "s"),
                             ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
     with pytest.raises(ss.SupersonicException) as e:
         ss.Plan(bad, ss.Context(-1))

@@ -1676,7 +1676,8 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
     got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("col0"), ss.AggregationSpecification().AddAggregation(ss.SUM, "col1", "sum"), opts, ss.ScanView(view)), gpu_ctx)
     assert got.column(0).data.tolist() == [1, 3, 4] and got.column(1).data.tolist() == [5, -9, 9]
     wide = make_view(100, nullable=True)
-    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l"), opts, ss.ScanView(wide)),):
+    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l").AddDistinctAggregation(ss.SUM, "b", "s"),
+                                 opts, ss.ScanView(wide)),):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(op, gpu_ctx)
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
@@ -1702,6 +1703,13 @@ def test_group_aggregate_distinct_under_max_unique_keys_in_result(gpu_ctx, n, li
     plain = make_view(n)
     got = run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, opts, ss.ScanView(plain)), gpu_ctx)   # NOT NULL keys stay NOT NULL
     assert not got.schema().attribute(0).is_nullable() and not got.schema().attribute(1).is_nullable()
+    # CONCAT under the limit: the folded row's string joins the values of all its keys in INPUT order
+    cspec = (ss.AggregationSpecification().AddAggregation(ss.CONCAT, "d0", "cd").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.CONCAT, "k1", "ck")
+             .AddAggregation(ss.SUM, "a", "sa").AddAggregation(ss.FIRST, "t", "ft").AddAggregation(ss.LAST, "d0", "ld"))
+    if n <= 1025:
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), cspec, opts, ss.ScanView(view)), gpu_ctx)
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), cspec, opts,
+                                   ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(299)), ss.ProjectAllAttributes(), ss.ScanView(view))), gpu_ctx)
 
 
 def test_distinct_under_key_limit_shares_one_set_beyond_the_limit(gpu_ctx):
