@@ -307,16 +307,28 @@ def _run_with_concat(operation, max_rows):
     if kind != 5 and rcols:
         assert len(rcols[0][0]) == n_groups
     schema, cols, ri = list(rschema[:n_keys]), list(rcols[:n_keys]), n_keys
-    for (agg, _distinct, _otype, inp, outp) in operation.spec.elements:
+    for (agg, distinct, _otype, inp, outp) in operation.spec.elements:
         if agg != A_CONCAT:
             schema.append(rschema[ri]); cols.append(rcols[ri]); ri += 1
             continue
         c = names.index(inp)
         text, has = [b""] * n_groups, np.zeros(n_groups, dtype=bool)
+        seen = set()
         for i in range(n):
             if crows[c][1] is not None and crows[c][1][i]:
                 continue
             g = group_of[i]
+            if distinct:
+                # DISTINCT CONCAT: the DistinctAggregator in front of the CONCAT (column_aggregator.cc:308-376) keeps one set of seen
+                # values per result row and passes a value on at its first occurrence only; values compare as in the C restatement's
+                # distinct_seen(): by their bits, -0.0 as +0.0
+                v = crows[c][0][i]
+                if cschema[c][1] in (T_FLOAT, T_DOUBLE) and v == 0:
+                    v = type(v)(0.0)
+                k = (int(g), v.tobytes() if hasattr(v, "tobytes") else v)
+                if k in seen:
+                    continue
+                seen.add(k)
             text[g] = (text[g] + b"," if has[g] else b"") + _print_typed(cschema[c][1], crows[c][0][i])
             has[g] = True
         data = np.empty(n_groups, dtype=object)

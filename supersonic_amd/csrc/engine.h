@@ -190,7 +190,11 @@ struct Stage {
   // The device counts the contributing (non-NULL) values in the column's place -- a UINT64 in out_schema -- and the host
   // builds the strings when the column is fetched, from the stage's (materialised, for a group aggregate key-sorted) input:
   // out_col of out_schema <- values of stage-input column src_col, in input order, joined with ','.
-  struct ConcatCol { int out_col; int src_col; int src_dtype; int stage = -1; /* the CLUSTERS stage whose ordered input and segment ids hold the values (-1: this, the last stage) */ };
+  struct ConcatCol {
+    int out_col; int src_col; int src_dtype;
+    int stage = -1;          // the CLUSTERS stage whose ordered input and segment ids hold the values (-1: this, the last stage)
+    bool distinct = false;   // DISTINCT CONCAT: a result row prints every value once, at its first occurrence (column_aggregator.cc:308-376)
+  };
   std::vector<ConcatCol> concat;
   int64_t algorithmic_bytes_per_row = 0;  // staged input bytes per input row
   int64_t output_bytes_per_row = 0;       // materialised output bytes per output row

@@ -852,6 +852,7 @@ struct AggPlan {
   int order_pos = -1;      // FIRST / LAST over rows that were re-ordered on the way (the DISTINCT shape): pipe column holding the
                            // row's id in the ORIGINAL order -- the aggregate picks by it, not by the row's position here
   bool sequential = false; // SUM of a floating input into an integer result: folded row after row in the input order (Stage::seq_sums)
+  bool concat_distinct = false;  // DISTINCT CONCAT: the host prints a value once per result row (Stage::ConcatCol::distinct)
   bool rowid_only = false; // FIRST / LAST that yields the chosen row's id (UINT64) instead of its value: the arg-min / arg-max
                            // column the fold of a key limit picks values by
 };
@@ -882,14 +883,15 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
     p.distinct = a.distinct && (a.aggregation == SSGPU_SUM || a.aggregation == SSGPU_COUNT);
     if (a.aggregation == SSGPU_CONCAT) {
       // CONCAT -> STRING over every type with a PrintTyped form (column_aggregator.cc:496-505).  The values are ordered on the
-      // device and printed on the host (Stage::ConcatCol); DATE / DATETIME (strftime forms) and DISTINCT CONCAT are not restated.
+      // device and printed on the host (Stage::ConcatCol); DATE / DATETIME (strftime forms) are not restated.  DISTINCT CONCAT prints
+      // a value at its first occurrence in the result row only (the DistinctAggregator in front of the CONCAT, :308-376).
       const int it = in[p.input_pos].dtype;
       if (a.output_type >= 0 && a.output_type != SSGPU_STRING)
         return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, std::string("Aggregation not supported. Aggregation function not defined for types ") +
                                                                     dtype_name(it) + " and " + dtype_name(a.output_type) + ".");
-      if (a.distinct || it == SSGPU_DATE || it == SSGPU_DATETIME || it == SSGPU_BINARY || dtype_width(it) == 0)
-        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT of DATE / DATETIME / BINARY values and DISTINCT CONCAT are outside the device path");
-      p.out_type = SSGPU_STRING; p.result_nullable = true; p.distinct = false;
+      if (it == SSGPU_DATE || it == SSGPU_DATETIME || it == SSGPU_BINARY || dtype_width(it) == 0)
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT of DATE / DATETIME / BINARY values is outside the device path");
+      p.out_type = SSGPU_STRING; p.result_nullable = true; p.distinct = false; p.concat_distinct = a.distinct != 0;
       out->push_back(p);
       continue;
     }
@@ -1222,12 +1224,12 @@ static Status bind_group_agg(const PlanDesc& d, const ssgpu_op& op, const Pipe& 
 // ---- CONCAT (Stage::ConcatCol) -----------------------------------------------------------------------------------------
 // In the aggregate's place the device counts the contributing values (COUNT(x) into UINT64); `pending` remembers which
 // result column becomes a STRING built on the host from which stage-input column.
-struct ConcatPlan { size_t agg; int input_pos; int dtype; };
+struct ConcatPlan { size_t agg; int input_pos; int dtype; bool distinct; };
 static void take_concat_plans(const Schema& vs, std::vector<AggPlan>* plans, std::vector<ConcatPlan>* pending) {
   for (size_t i = 0; i < plans->size(); ++i) {
     AggPlan& ap = (*plans)[i];
     if (ap.aggregation != SSGPU_CONCAT) continue;
-    pending->push_back(ConcatPlan{i, ap.input_pos, vs[ap.input_pos].dtype});
+    pending->push_back(ConcatPlan{i, ap.input_pos, vs[ap.input_pos].dtype, ap.concat_distinct});
     ap.aggregation = SSGPU_COUNT; ap.out_type = SSGPU_UINT64; ap.result_nullable = false;
   }
 }
@@ -1977,7 +1979,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           take_concat_plans(schema_of(pipe.cols), &g.plans, &concats);
           if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st));
           else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
-          for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), cp.input_pos, cp.dtype});
+          for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)(g.kpos.size() + cp.agg); cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.distinct = cp.distinct; st.concat.push_back(cc); }
           desc << "(materialise" << (op.kind == SSGPU_OP_GROUP_AGGREGATE ? " + sort + clustered aggregation" : "") << "; CONCAT printed on the host) ";
         } else if ((any_distinct || any_concat) && limited_group) {
           // DISTINCT aggregates under GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205).  The reference keeps one
@@ -2058,7 +2060,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             reset_pipe(&pipe, st.out_schema);
             pipe.cols.erase(pipe.cols.begin());   // ($rank)
             Stage fm; SS_RETURN_IF_ERROR(finish_materialize(pipe, &fm));
-            for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)cp.agg; cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.stage = cluster_stage; fm.concat.push_back(cc); }
+            for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)cp.agg; cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.stage = cluster_stage; cc.distinct = cp.distinct; fm.concat.push_back(cc); }
             desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit
                  << " + sort by (result row, row id) + clustered aggregation; CONCAT printed on the host) GroupAggregate -> [" << schema_to_string(fm.out_schema) << "]\n";
             stages->push_back(fm);
@@ -2308,7 +2310,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           add_nan_exact_plans(d.nan_exact && concats.empty(), schema_of(pipe.cols), &g.plans, &c_fixes);
           SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
           st.seq_sums = seqs;
-          for (auto& cp : concats) st.concat.push_back(Stage::ConcatCol{(int)(g.kpos.size() + cp.agg), pipe.cols[cp.input_pos].expr->input_col, cp.dtype});
+          for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)(g.kpos.size() + cp.agg); cc.src_col = pipe.cols[cp.input_pos].expr->input_col; cc.src_dtype = cp.dtype; cc.distinct = cp.distinct; st.concat.push_back(cc); }
           desc << "AggregateClusters -> [" << schema_to_string(st.out_schema) << "]\n";
         }
         stages->push_back(st);

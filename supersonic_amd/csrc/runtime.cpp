@@ -16,6 +16,7 @@
 #include <string>
 #include <unistd.h>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "engine.h"
@@ -3178,10 +3179,21 @@ int build_concat_column(ssgpu_result* r, int32_t col, const Stage::ConcatCol& cc
   if (st.kind == STAGE_CLUSTERS && n) { seg.resize((size_t)n); HIP_TRY(c, hipMemcpyAsync(seg.data(), ex.seg_id.p, seg.size() * 4, hipMemcpyDeviceToHost, c->stream)); }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   std::vector<std::string> text((size_t)out_rows); std::vector<uint8_t> has((size_t)out_rows, 0);
+  // DISTINCT CONCAT: the DistinctAggregator in front of the CONCAT lets a value through at its first occurrence in the result row
+  // (column_aggregator.cc:308-376: one set per result index; NULLs never count).  Values compare as the device's other DISTINCT
+  // aggregates compare them: by their bits, -0.0 as +0.0.  A group's rows are adjacent here, so ONE set, emptied at every new group.
+  std::unordered_set<uint64_t> seen; size_t seen_group = (size_t)-1;
   for (int64_t i = 0; i < n; ++i) {
     if (!z.empty() && z[(size_t)i]) continue;
     const size_t g = seg.empty() ? 0 : seg[(size_t)i];
     if (g >= (size_t)out_rows) continue;
+    if (cc.distinct) {
+      if (g != seen_group) { seen.clear(); seen_group = g; }
+      uint64_t bits = 0; memcpy(&bits, x.data() + (size_t)i * w, w);
+      if (cc.src_dtype == SSGPU_DOUBLE && bits == 0x8000000000000000ull) bits = 0;
+      if (cc.src_dtype == SSGPU_FLOAT && bits == 0x80000000ull) bits = 0;
+      if (!seen.insert(bits).second) continue;
+    }
     if (has[g]) text[g] += ','; else has[g] = 1;
     print_typed(cc.src_dtype, x.data() + (size_t)i * w, p->dict, &text[g]);
   }

@@ -258,7 +258,7 @@ class Gen(object):
             (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
         if concat:
             for j in range(int(self.rng.integers(1, 3))):
-                spec.AddAggregation(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name"]), "rc%d" % j)
+                (spec.AddDistinctAggregation if self.rng.random() < 0.4 else spec.AddAggregation)(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name"]), "rc%d" % j)
         elif not n_distinct:
             spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1", "u", "s"]), "rd")
         child = ss.ScanView(view)

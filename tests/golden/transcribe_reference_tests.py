@@ -1380,6 +1380,14 @@ derived_case("Derived_Limit_ConcatJoinsTheFoldedRowsValuesInInputOrder", RHS + "
              ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["CONCAT", "col1", "c"], ["COUNT", "", "n"]], "INPUT", {"max_unique_keys_in_result": 2}],
              [I32, STR, U64], [[1, "5,5", 2], [2, "6,1", 2], [3, "7,7,8,9", 5]])
 
+derived_case("Derived_DistinctConcatPrintsFirstOccurrences", DST + "; supersonic/cursor/core/column_aggregator.cc:108-124,568-590",
+             "CreateDistinctAggregator wraps the CONCAT column aggregator in a DistinctAggregator (column_aggregator.cc:568-590), which hands it only the rows whose value "
+             "is not yet in the set of their result index (" + DST + "), NULLs never; the CONCAT then appends those, ',' between values, in input order.  Group 1 "
+             "sees 5, 7, 5, NULL, 7, 9 -> '5,7,9' (plain CONCAT next to it: '5,7,5,7,9'); group 2 sees 5, 5 -> '5' (its set is its own); group 3 only NULL -> NULL.",
+             cols([I32, I32]), [[1, 5], [2, 5], [1, 7], [1, 5], [3, None], [1, None], [2, 5], [1, 7], [1, 9]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["CONCAT_DISTINCT", "col1", "d"], ["CONCAT", "col1", "c"]], "INPUT"],
+             [I32, STR, STR], [[1, "5,7,9", "5,7,5,7,9"], [2, "5", "5,5"], [3, None, None]])
+
 # ---- D: SUM of a floating input into an integer result (the reference's row-after-row arithmetic) --------------------------------------------
 D_SEQ = ("AddAggregationWithDefinedOutputType(SUM, DOUBLE column, INT result): AggregationOperator<SUM>::Update is `*result += val` on an integer result and a "
          "floating val (supersonic/base/infrastructure/aggregation_operators.h:173-185): C++ converts *result to the floating type, adds, and truncates the sum "

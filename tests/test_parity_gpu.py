@@ -1917,11 +1917,20 @@ def test_concat_aggregate(gpu_ctx, n):
     order = np.argsort(view.column(0).data, kind="stable")
     clustered = ss.View(schema, [ss.Column(view.column(i).data[order], None if view.column(i).is_null is None else view.column(i).is_null[order]) for i in range(9)])
     run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("g"), spec, ss.ScanView(clustered)), gpu_ctx)
-    # a computed CONCAT input, and the refusals: DISTINCT CONCAT, a consumer above the CONCAT, a non-STRING result type
+    # DISTINCT CONCAT: a result row prints every value once, at its first occurrence (the DistinctAggregator in front of the CONCAT,
+    # column_aggregator.cc:308-376); h has three values, t two, w five, d / f repeat their small halves and hold -0.0 next to 0.0
+    dspec = (ss.AggregationSpecification().AddDistinctAggregation(ss.CONCAT, "h", "ch").AddAggregation(ss.CONCAT, "h", "ah").AddDistinctAggregation(ss.CONCAT, "w", "cw")
+             .AddDistinctAggregation(ss.CONCAT, "t", "ct").AddDistinctAggregation(ss.CONCAT, "d", "cd").AddDistinctAggregation(ss.CONCAT, "f", "cf")
+             .AddAggregation(ss.COUNT, "h", "n").AddDistinctAggregation(ss.CONCAT, "i", "ci"))
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), dspec, None, flt), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "h"]), dspec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), dspec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(5), ss.ScanView(view)), gpu_ctx)
+    run_both(ss.ScalarAggregate(dspec, flt), gpu_ctx)
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("g"), dspec, ss.ScanView(clustered)), gpu_ctx)
+    # a computed CONCAT input, and the refusals: a consumer above the CONCAT, a non-STRING result type
     comp = ss.Compute(ss.CompoundExpression().Add(NA("g")).AddAs("s", ss.Plus(NA("a"), ss.ConstInt64(7))), ss.ScanView(view))
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "s", "cs"), None, comp), gpu_ctx, ignore_order=True)
-    for bad, code in ((ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddDistinctAggregation(ss.CONCAT, "i", "c"), None, ss.ScanView(view)), ss.ERROR_NOT_IMPLEMENTED),
-                      (ss.Sort(ss.SortOrder().add("g", ss.ASCENDING), None, 0, ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "i", "c"), None, ss.ScanView(view))), ss.ERROR_NOT_IMPLEMENTED),
+    for bad, code in ((ss.Sort(ss.SortOrder().add("g", ss.ASCENDING), None, 0, ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "i", "c"), None, ss.ScanView(view))), ss.ERROR_NOT_IMPLEMENTED),
                       (ss.ScalarAggregate(ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.CONCAT, "i", "c", ss.INT64), ss.ScanView(view)), ss.ERROR_INVALID_ARGUMENT_TYPE)):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(bad, gpu_ctx)
