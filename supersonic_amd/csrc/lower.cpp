@@ -1941,18 +1941,20 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         // keys and the aggregated columns, sort by (keys, distinct column), flag the first row of every (keys, value) run
         // and aggregate with the flag standing in for "not NULL": a scalar aggregate over the sorted rows, or the
         // clustered aggregation over the key runs.  One distinct column per specification.
-        bool any_distinct = false, any_concat = false;
+        bool any_distinct = false, any_concat = false, any_seq = false;
         {
           std::vector<AggPlan> probe;
           SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &probe));
           for (auto& ap : probe) any_distinct = any_distinct || ap.distinct;
           any_concat = has_concat(probe);
-          // (a sum folded row after row needs the rows in input order and a result row of its own: none of the composed shapes)
-          if (has_sequential(probe) && (any_distinct || any_concat || (op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0)))
-            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to DISTINCT / CONCAT aggregates or under max_unique_keys_in_result is not available on the device path");
+          // (a sum folded row after row needs a result row's rows in input order: the CONCAT shape and the key limit's result-row
+          // shape keep it, the DISTINCT shape sorts by the values)
+          any_seq = has_sequential(probe);
+          if (any_seq && any_distinct)
+            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to a DISTINCT aggregate is not available on the device path");
         }
         const bool limited_group = op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0;
-        if (any_concat && !(limited_group && !any_distinct)) {
+        if (any_concat && !limited_group) {
           // CONCAT (Stage::ConcatCol): the values have to reach the host in input order, group by group -- materialise the keys and
           // the aggregated columns, (stable) sort by the keys, aggregate the key runs with the clustered kernel (CONCAT counted as
           // COUNT(x)); the host prints the strings from the sorted rows and their segment ids when the column is fetched.
@@ -1977,11 +1979,14 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           }
           std::vector<ConcatPlan> concats;
           take_concat_plans(schema_of(pipe.cols), &g.plans, &concats);
+          std::vector<Stage::SeqSum> seqs;   // (a group's rows are adjacent and in input order here: row-after-row sums fold them as they lie)
+          SS_RETURN_IF_ERROR(take_sequential(&g.plans, pipe, g.kpos.size(), &seqs));
           if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st));
           else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
+          st.seq_sums = seqs;
           for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)(g.kpos.size() + cp.agg); cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.distinct = cp.distinct; st.concat.push_back(cc); }
           desc << "(materialise" << (op.kind == SSGPU_OP_GROUP_AGGREGATE ? " + sort + clustered aggregation" : "") << "; CONCAT printed on the host) ";
-        } else if ((any_distinct || any_concat) && limited_group) {
+        } else if ((any_distinct || any_concat || any_seq) && limited_group) {
           // DISTINCT aggregates under GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205).  The reference keeps one
           // set of seen values per RESULT ROW (column_aggregator.cc:308-376 indexes its sets by the row the RowHashSet answered),
           // and under the limit that row is min(first-seen rank of the key, limit) (row_hash_set.cc:500-511) -- so the rows beyond the
@@ -1993,6 +1998,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // CONCAT under the limit takes the same road: a result row's string joins the values of ALL its rows in input order
           // (column_aggregator.cc:108-124 over the same result index), so the stored rows are sorted by ($rank, row id) and aggregated
           // as clusters of `$rank`; the host prints from that stage's input (Stage::ConcatCol::stage) behind the projection.
+          if (any_concat && any_distinct) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate is not available on the device path");
           if (any_concat && ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
           const int64_t limit = op.option0 < 0 ? 0 : op.option0;
           if (limit >= (1ll << 31)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result beyond 2^31 keys next to a DISTINCT aggregate");
@@ -2046,7 +2052,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             gr.plans.push_back(ap);
           }
-          if (any_concat) {
+          if (any_concat || any_seq) {   // (a result row's rows in input order: CONCAT prints them, a row-after-row SUM folds them)
             Stage s2; s2.kind = STAGE_SORT; s2.in_schema = mr.out_schema; s2.out_schema = mr.out_schema;
             for (int k : {rank_pos, row_pos}) { SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; s2.sort_keys.push_back(sk); }
             for (size_t i = 0; i < s2.in_schema.size(); ++i) s2.sort_out_cols.push_back((int)i);
@@ -2054,7 +2060,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             reset_pipe(&pipe, s2.out_schema);
             std::vector<ConcatPlan> concats;
             take_concat_plans(schema_of(pipe.cols), &gr.plans, &concats);
+            std::vector<Stage::SeqSum> seqs;
+            SS_RETURN_IF_ERROR(take_sequential(&gr.plans, pipe, 1, &seqs));
             SS_RETURN_IF_ERROR(finish_group_agg(gr, pipe, &st, true));
+            st.seq_sums = seqs;
             stages->push_back(st);
             const int cluster_stage = (int)stages->size() - 1;
             reset_pipe(&pipe, st.out_schema);
@@ -2062,7 +2071,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             Stage fm; SS_RETURN_IF_ERROR(finish_materialize(pipe, &fm));
             for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)cp.agg; cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.stage = cluster_stage; cc.distinct = cp.distinct; fm.concat.push_back(cc); }
             desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit
-                 << " + sort by (result row, row id) + clustered aggregation; CONCAT printed on the host) GroupAggregate -> [" << schema_to_string(fm.out_schema) << "]\n";
+                 << " + sort by (result row, row id) + clustered aggregation" << (concats.empty() ? "" : "; CONCAT printed on the host") << ") GroupAggregate -> [" << schema_to_string(fm.out_schema) << "]\n";
             stages->push_back(fm);
             reset_pipe(&pipe, fm.out_schema);
             pending = false;

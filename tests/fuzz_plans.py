@@ -240,7 +240,7 @@ class Gen(object):
         """DISTINCT aggregates under GroupAggregateOptions::max_unique_keys_in_result (round 5): the seen-value sets belong to the RESULT
         rows, so the rows folded into the last one share a set.  Keys of every width, FIRST / LAST and plain aggregates next to
         them, limits around and beyond the number of groups.  Returns (operation, True): first-seen order is defined."""
-        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("k1")).Add(NA("a")).Add(NA("b")).Add(NA("u")).Add(NA("t")).Add(NA("day")).Add(NA("name"))
+        e = ss.CompoundExpression().Add(NA("k2")).Add(NA("s")).Add(NA("k1")).Add(NA("a")).Add(NA("b")).Add(NA("u")).Add(NA("t")).Add(NA("day")).Add(NA("name")).Add(NA("d0"))
         spec = ss.AggregationSpecification()
         inputs = ["a", "b", "k1", "u", "t", "day", "k2", "s"]
         for i in range(int(self.rng.integers(0, 3))):
@@ -256,10 +256,15 @@ class Gen(object):
             distinct = not concat and agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < 0.6
             n_distinct += distinct
             (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
+        if concat or self.rng.random() < 0.15:     # a row-after-row SUM (floating input, integer result) rides the (result row, row id) order as well
+            spec.AddAggregationWithDefinedOutputType(ss.SUM, "d0", "rq", self.pick([ss.INT64, ss.INT32]))
+            n_distinct = n_distinct if concat else -1
+        if n_distinct < 0:
+            spec.elements = [x for x in spec.elements if not x[1]]     # (next to DISTINCT it stays refused)
         if concat:
             for j in range(int(self.rng.integers(1, 3))):
                 (spec.AddDistinctAggregation if self.rng.random() < 0.4 else spec.AddAggregation)(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name"]), "rc%d" % j)
-        elif not n_distinct:
+        elif n_distinct == 0:
             spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1", "u", "s"]), "rd")
         child = ss.ScanView(view)
         if self.rng.random() < 0.5:

@@ -1398,6 +1398,13 @@ derived_case("Derived_SumOfDoublesIntoInt32TruncatesEveryRow", "supersonic/base/
              cols([I32, F64]), [[1, 0.6], [1, 0.6], [1, 0.6], [1, 0.6], [2, 1.5], [2, 1.5], [3, -0.9], [3, -0.9], [3, -0.3]],
              ["AggregateClusters", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s", I32]], "INPUT"],
              [I32, I32], [[1, 0], [2, 2], [3, 0]])
+derived_case("Derived_Limit_SumOfDoublesIntoInt64FoldsTheFoldedRowInInputOrder", RHS + "; supersonic/base/infrastructure/aggregation_operators.h:173-185",
+             D_LIM + D_SEQ + "Keys 1, 2, 3, 2 under limit 1: row 0 = key 1 = 5.5 -> 5.  Row 1 = key 2 and, folded, key 3 = inputs 1, 2, 3 IN INPUT ORDER: 1.6 -> "
+             "assigned 1; 1 - 1.9 = -0.9 -> 0; 0 + 1.6 = 1.6 -> 1: result 1.  (Key after key -- 1.6, 1.6, then -1.9 -- would give 1, 2.6 -> 2, 0.1 -> 0.)  CONCAT next to it "
+             "joins the same rows in the same order.",
+             cols([I32, F64], nullable=False), [[1, 5.5], [2, 1.6], [3, -1.9], [2, 1.6]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s", I64], ["CONCAT", "col1", "c"]], "INPUT", {"max_unique_keys_in_result": 1}],
+             [I32, I64, STR], [[1, 5, "5.5"], [2, 1, "1.6,-1.9,1.6"]])
 derived_case("Derived_SumOfDoublesIntoInt64OrderMatters", "supersonic/base/infrastructure/aggregation_operators.h:173-185",
              D_SEQ + "2.75, 0.5, 0.5: assigned 2, 2 + 0.5 = 2.5 -> 2, 2 + 0.5 -> 2: result 2 (the real sum 3.75 would truncate to 3).  NULLs are skipped: "
              "NULL, 7.9, NULL, 0.2 -> assigned 7, 7 + 0.2 = 7.2 -> 7.",

@@ -1394,11 +1394,25 @@ def test_sum_of_floating_values_into_integer_results(gpu_ctx, n):
     child = ss.Compute(e, ss.Filter(ss.Less(NA("i"), ss.ConstInt64(25)), ss.ProjectAllAttributes(), ss.ScanView(view)))
     run_both(ss.ScalarAggregate(spec, child), gpu_ctx)
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "run"]), spec, None, child), gpu_ctx, ignore_order=True)
-    # what stays refused: next to DISTINCT aggregates, under a key limit (their shapes re-order or re-combine the rows)
+    # under a key limit: the folded row's rows come from several keys and are folded in INPUT order (the rows sorted by (result row, row id))
+    for limit in (0, 3, 36, 100):
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(limit), ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "run"]), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(5), child), gpu_ctx)
+    # next to CONCAT (its shape keeps a group's rows adjacent and in input order), with and without a limit
+    cspec = ss.AggregationSpecification().AddAggregation(ss.CONCAT, "i", "ci")
+    for col, out, t in (("x", "sx64", ss.INT64), ("f", "sf32", ss.INT32), ("p", "spu64", ss.UINT64)):
+        cspec.AddAggregationWithDefinedOutputType(ss.SUM, col, out, t)
+    cspec.AddAggregation(ss.LAST, "x", "lx")
+    if n <= 1025:
+        run_both(ss.ScalarAggregate(cspec, ss.ScanView(view)), gpu_ctx)
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), cspec, None, child), gpu_ctx, ignore_order=True)
+        run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), cspec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(4), ss.ScanView(view)), gpu_ctx)
+        run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("run"), cspec, ss.ScanView(view)), gpu_ctx)
+    # what stays refused: next to DISTINCT aggregates (their shape sorts a group's rows by the values)
     for bad in (ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64)
                                   .AddDistinctAggregation(ss.COUNT, "i", "c"), None, ss.ScanView(view)),
-                ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64),
-                                  ss.GroupAggregateOptions().set_max_unique_keys_in_result_(3), ss.ScanView(view))):
+                ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64)
+                                  .AddDistinctAggregation(ss.COUNT, "i", "c"), ss.GroupAggregateOptions().set_max_unique_keys_in_result_(3), ss.ScanView(view))):
         with pytest.raises(ss.SupersonicException) as err:
             ss.Plan(bad, gpu_ctx)
         assert err.value.return_code == ss.ERROR_NOT_IMPLEMENTED
