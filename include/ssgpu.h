@@ -388,7 +388,8 @@ int ssgpu_dict_decode(const ssgpu_dict* d, int32_t code, const char** bytes, int
  * until the plan runs again) and NULL for every other column (STRING cells of those are codes of the plan's dictionary).
  * ssgpu_plan_set_dict hands the plan the dictionary its STRING columns were encoded with (borrowed; CONCAT of a STRING
  * column prints through it).  DISTINCT CONCAT prints a value once per result row, at its first
- * occurrence.  Limits, refused at bind: DATE / DATETIME / BINARY inputs, a CONCAT result
+ * occurrence.  DATE / DATETIME print as the reference's strftime forms ("%Y/%m/%d", "%Y/%m/%d-%H:%M:%S" of gmtime,
+ * types_infrastructure.cc:92-114).  Limits, refused at bind: BINARY inputs, a CONCAT result
  * that feeds another operation, CONCAT next to a DISTINCT aggregate or across shards. */
 int ssgpu_plan_set_dict(ssgpu_plan* plan, const ssgpu_dict* dict);
 const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t col);

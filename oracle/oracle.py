@@ -229,7 +229,18 @@ class Cursor(object):
         return lib().orc_drain(self.handle)
 
 
-A_CONCAT, T_BOOL, T_FLOAT, T_DOUBLE = 4, 6, 9, 5
+A_CONCAT, T_BOOL, T_FLOAT, T_DOUBLE, T_DATE, T_DATETIME = 4, 6, 9, 5, 10, 4
+
+
+def _civil(days):
+    """(year, month, day) of a day count since 1970-01-01 in the proleptic Gregorian calendar (what gmtime gives, any year)."""
+    z = days + 719468                                   # days since 0000-03-01; 400 years = 146097 days
+    era, doe = divmod(z, 146097)
+    yoe = (doe - doe // 1460 + doe // 36524 - doe // 146096) // 365
+    doy = doe - (365 * yoe + yoe // 4 - yoe // 100)
+    mp = (5 * doy + 2) // 153
+    month = mp + 3 if mp < 10 else mp - 9
+    return yoe + era * 400 + (1 if month <= 2 else 0), month, doy - (153 * mp + 2) // 5 + 1
 
 
 def _print_typed(t, v):
@@ -239,6 +250,20 @@ def _print_typed(t, v):
         return _bytes(v)
     if t == T_BOOL:
         return b"TRUE" if v else b"FALSE"
+    if t in (T_DATE, T_DATETIME):
+        # PrintTyped<DATE> / <DATETIME> (types_infrastructure.cc:36-39,92-114): strftime("%Y/%m/%d" / "%Y/%m/%d-%H:%M:%S") of gmtime;
+        # DATE's `value * (24 * 3600)` is an int32 product (wraps beyond +-24855 days: undefined in the reference), DATETIME drops
+        # the microseconds toward zero; glibc's %Y prints the year unpadded
+        if t == T_DATE:
+            secs = ((int(v) * 86400 + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)
+        else:
+            secs = abs(int(v)) // 1000000 * (1 if int(v) >= 0 else -1)
+        days, sod = divmod(secs, 86400)
+        y, m, d = _civil(days)
+        text = "%d/%02d/%02d" % (y, m, d)
+        if t == T_DATETIME:
+            text += "-%02d:%02d:%02d" % (sod // 3600, sod // 60 % 60, sod % 60)
+        return text.encode()
     if t in (T_FLOAT, T_DOUBLE):
         f = float(v)
         if f != f:

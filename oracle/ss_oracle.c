@@ -1169,7 +1169,7 @@ static int bind_aggs(orc_cursor* c, const orc_op* op, const orc_schema* in) {
       /* column_aggregator.cc:496-505: CONCAT -> STRING over every printable type.  Bound here (name, STRING, NULLABLE); its
        * values are new strings, which this restatement -- STRINGs are dictionary codes here -- cannot hold: oracle.py folds them */
       if (a->output_type >= 0 && a->output_type != T_STRING) { set_err(&c->err, RC_INVALID_ARGUMENT_TYPE, "Aggregation not supported for types %s and %s.", type_name(g->in_type), type_name(a->output_type)); return 0; }
-      if (g->in_type == T_DATE || g->in_type == T_DATETIME || g->in_type == T_BINARY) { set_err(&c->err, RC_NOT_IMPLEMENTED, "CONCAT form not restated%s%s", "", ""); return 0; }
+      if (g->in_type == T_BINARY) { set_err(&c->err, RC_NOT_IMPLEMENTED, "CONCAT form not restated%s%s", "", ""); return 0; }
       /* (DISTINCT CONCAT: the DistinctAggregator in front of it, column_aggregator.cc:568-590 -- folded by oracle.py as well) */
       g->out_type = T_STRING; c->has_concat = 1;
       if (!schema_add(&c->schema, a->output, T_STRING, 1)) {

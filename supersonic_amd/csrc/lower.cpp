@@ -883,14 +883,14 @@ static Status bind_aggregations(const PlanDesc& d, int first, int n, const Schem
     p.distinct = a.distinct && (a.aggregation == SSGPU_SUM || a.aggregation == SSGPU_COUNT);
     if (a.aggregation == SSGPU_CONCAT) {
       // CONCAT -> STRING over every type with a PrintTyped form (column_aggregator.cc:496-505).  The values are ordered on the
-      // device and printed on the host (Stage::ConcatCol); DATE / DATETIME (strftime forms) are not restated.  DISTINCT CONCAT prints
+      // device and printed on the host (Stage::ConcatCol: DATE / DATETIME in the reference's strftime forms).  DISTINCT CONCAT prints
       // a value at its first occurrence in the result row only (the DistinctAggregator in front of the CONCAT, :308-376).
       const int it = in[p.input_pos].dtype;
       if (a.output_type >= 0 && a.output_type != SSGPU_STRING)
         return Status::Error(SSGPU_ERROR_INVALID_ARGUMENT_TYPE, std::string("Aggregation not supported. Aggregation function not defined for types ") +
                                                                     dtype_name(it) + " and " + dtype_name(a.output_type) + ".");
-      if (it == SSGPU_DATE || it == SSGPU_DATETIME || it == SSGPU_BINARY || dtype_width(it) == 0)
-        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT of DATE / DATETIME / BINARY values is outside the device path");
+      if (it == SSGPU_BINARY || dtype_width(it) == 0)
+        return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT of BINARY values is outside the device path");
       p.out_type = SSGPU_STRING; p.result_nullable = true; p.distinct = false; p.concat_distinct = a.distinct != 0;
       out->push_back(p);
       continue;

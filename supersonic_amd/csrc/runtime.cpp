@@ -3117,11 +3117,38 @@ int ssgpu_result_device_column(ssgpu_result* r, int32_t i, ssgpu_column* out) {
 }  // extern "C"
 
 namespace {
-// PrintTyped (base/infrastructure/types_infrastructure.cc:45-80): integers in decimal, BOOL as TRUE / FALSE, FLOAT / DOUBLE as
+// the calendar date of a day count since 1970-01-01 (proleptic Gregorian calendar, any year: 400-year eras of 146097 days)
+static void civil_from_days(int64_t z, int64_t* year, unsigned* month, unsigned* day) {
+  z += 719468;                                            // days since 0000-03-01
+  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  const unsigned doe = (unsigned)(z - era * 146097);      // day of the era [0, 146096]
+  const unsigned yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const unsigned doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const unsigned mp = (5 * doy + 2) / 153;                // month counted from March
+  *day = doy - (153 * mp + 2) / 5 + 1;
+  *month = mp < 10 ? mp + 3 : mp - 9;
+  *year = (int64_t)yoe + era * 400 + (*month <= 2 ? 1 : 0);
+}
+// PrintTyped<DATE / DATETIME> (types_infrastructure.cc:36-39,92-114): strftime of gmtime, "%Y/%m/%d" resp. "%Y/%m/%d-%H:%M:%S" (glibc's %Y:
+// the year as it is, no padding, '-' for years before 0); microseconds are dropped (`value / 1000000`, toward zero)
+static void print_time(int64_t seconds, bool with_time, std::string* out) {
+  int64_t days = seconds / 86400, sod = seconds % 86400;
+  if (sod < 0) { sod += 86400; days -= 1; }
+  int64_t y; unsigned m, d; civil_from_days(days, &y, &m, &d);
+  char buf[64];
+  if (with_time) snprintf(buf, sizeof(buf), "%lld/%02u/%02u-%02d:%02d:%02d", (long long)y, m, d, (int)(sod / 3600), (int)(sod / 60 % 60), (int)(sod % 60));
+  else snprintf(buf, sizeof(buf), "%lld/%02u/%02u", (long long)y, m, d);
+  *out += buf;
+}
+// PrintTyped (base/infrastructure/types_infrastructure.cc:45-114): integers in decimal, BOOL as TRUE / FALSE, FLOAT / DOUBLE as
 // SimpleFtoa / SimpleDtoa (the shortest of %.6g / %.9g resp. %.15g / %.17g that reads back as the same value), STRING as is
 void print_typed(int dtype, const char* cell, const ssgpu_dict* dict, std::string* out) {
   char buf[64];
   switch (dtype) {
+    // DATE: `const time_t time = value * (24 * 3600)` is an int32 product in the reference (:105): it leaves the int range beyond
+    // +-24855 days (the years 1901 .. 2038) -- undefined there, the wrapped product here
+    case SSGPU_DATE: { int32_t v; memcpy(&v, cell, 4); print_time((int64_t)(int32_t)((uint32_t)v * 86400u), false, out); } break;
+    case SSGPU_DATETIME: { int64_t v; memcpy(&v, cell, 8); print_time(v / 1000000, true, out); } break;
     case SSGPU_INT32: { int32_t v; memcpy(&v, cell, 4); *out += std::to_string(v); } break;
     case SSGPU_UINT32: { uint32_t v; memcpy(&v, cell, 4); *out += std::to_string(v); } break;
     case SSGPU_INT64: { int64_t v; memcpy(&v, cell, 8); *out += std::to_string((long long)v); } break;

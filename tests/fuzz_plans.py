@@ -263,7 +263,7 @@ class Gen(object):
             spec.elements = [x for x in spec.elements if not x[1]]     # (next to DISTINCT it stays refused)
         if concat:
             for j in range(int(self.rng.integers(1, 3))):
-                (spec.AddDistinctAggregation if self.rng.random() < 0.4 else spec.AddAggregation)(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name"]), "rc%d" % j)
+                (spec.AddDistinctAggregation if self.rng.random() < 0.4 else spec.AddAggregation)(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name", "day"]), "rc%d" % j)
         elif n_distinct == 0:
             spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1", "u", "s"]), "rd")
         child = ss.ScanView(view)

@@ -549,6 +549,14 @@ op_case("AggregationOperators_ConcatStrings_string", "supersonic/base/infrastruc
 op_case("AggregationOperators_ConcatInts", "supersonic/base/infrastructure/aggregation_operators_test.cc:262-272", cols([I32]),
         [[-7], [None], [0]],
         ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["-7,0"]])
+# PrintTyped<DATE> / <DATETIME> (types_infrastructure_test.cc:85-89: 1 day prints as 1970/01/02[-00:00:00]) reached through CONCAT, whose values
+# PrintTyped prints (column_aggregator.cc:510-513 lists CONCAT over DATE and DATETIME); NULLs skipped, ',' between values
+op_case("TypesInfrastructure_PrintDateThroughConcat", "supersonic/base/infrastructure/types_infrastructure_test.cc:89; supersonic/base/infrastructure/types_infrastructure.cc:104-114",
+        cols([DATE]), [[1], [None], [0], [11016], [-1]],
+        ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["1970/01/02,1970/01/01,2000/02/29,1969/12/31"]])
+op_case("TypesInfrastructure_PrintDateTimeThroughConcat", "supersonic/base/infrastructure/types_infrastructure_test.cc:85; supersonic/base/infrastructure/types_infrastructure.cc:92-102",
+        cols([DATETIME]), [[24 * 60 * 60 * 1000000], [0], [951782400 * 1000000 + 3661 * 1000000 + 999999], [-1000000]],
+        ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["1970/01/02-00:00:00,1970/01/01-00:00:00,2000/02/29-01:01:01,1969/12/31-23:59:59"]])
 op_case("ColumnAggregator_NotSupportedAggregationDetected_string", CA + ":518-526", cols([STR]), [],
         ["ScalarAggregate", [["SUM", "col0", "r"]], "INPUT"], None, [], expect_error=405)
 op_case("ColumnAggregator_NotSupportedCountOutputTypeDetected", CA + ":528-534", cols([I32]), [],

@@ -1906,6 +1906,23 @@ def test_device_sharded_group_aggregate_exchange_forms_one_rank(exchange):
 # ---- CONCAT (column_aggregator.cc:496-505, aggregation_operators.h:236-283): the values of a group, printed (PrintTyped), joined
 # ---- with ',' in input order; NULL inputs skipped, a group without a value is NULL.  The device orders the rows (materialise +
 # ---- stable sort by the keys) and counts; the strings are printed on the host when the column is fetched ------------------------
+@pytest.mark.parametrize("n", [1, 9, 2049])
+def test_concat_of_dates_and_datetimes(gpu_ctx, n):
+    # PrintTyped<DATE> / <DATETIME> (types_infrastructure.cc:92-114): gmtime + strftime "%Y/%m/%d[-%H:%M:%S]", microseconds dropped toward
+    # zero; years before 1000 unpadded, before 0 with '-'.  DATEs inside +-24855 days (beyond that the reference's int32 product is undefined)
+    rng = np.random.default_rng(n)
+    schema = ss.TupleSchema([ss.Attribute("g", ss.INT32), ss.Attribute("day", ss.DATE, ss.NULLABLE), ss.Attribute("ts", ss.DATETIME, ss.NULLABLE)])
+    days = rng.integers(-24855, 24856, n).astype(np.int32)
+    ts = np.where(rng.random(n) < 0.5, rng.integers(-(1 << 62), 1 << 62, n), rng.integers(-4 * 10 ** 15, 4 * 10 ** 15, n))
+    ts[:1] = -62135596800 * 1000000 - 1              # the last second of the year 0
+    view = ss.View(schema, [rng.integers(0, 5, n).astype(np.int32), ss.Column(days, rng.random(n) < 0.2), ss.Column(ts, rng.random(n) < 0.2)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.CONCAT, "day", "cd").AddAggregation(ss.CONCAT, "ts", "ct").AddDistinctAggregation(ss.CONCAT, "day", "dd")
+            .AddAggregation(ss.MAX, "day", "md").AddAggregation(ss.MIN, "ts", "mt"))
+    run_both(ss.ScalarAggregate(spec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), spec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view)), gpu_ctx)
+
+
 @pytest.mark.parametrize("n", [0, 1, 7, 1025, 30011])
 def test_concat_aggregate(gpu_ctx, n):
     rng = np.random.default_rng(n + 1)
