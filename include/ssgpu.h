@@ -73,8 +73,9 @@
  *       wavefront of a ScalarAggregate): bit-identical to the reference, and slow by construction -- 10 - 20 ns per row of the
  *       longest segment, i.e. 1 - 2 s for a ScalarAggregate over 1e8 rows, where every other aggregate of the path takes a
  *       millisecond.  The one-segment fold runs in launches of 2^21 rows and looks at ssgpu_interrupt between them.  Under
- *       max_unique_keys_in_result the folded row's rows are folded in input order across its keys.  Refused next
- *       to DISTINCT aggregates (their shape sorts a group's rows by the values) and across shards;
+ *       max_unique_keys_in_result the folded row's rows are folded in input order across its keys; next to DISTINCT
+ *       aggregates (whose shape sorts a group's rows by the values) the rows are sorted back by their input row id first.
+ *       Refused across shards;
  *       MIN / MAX over FLOAT / DOUBLE: the reference's update is "if (val < result) result = val"
  *       (aggregation_operators.h:200,221) after ASSIGNING a group's first non-NULL value: a NaN that
  *       comes FIRST stays (nothing is less than NaN), a NaN that comes later is skipped.  Same here:

@@ -1720,8 +1720,11 @@ static int add_row_id_column(Pipe* pruned) {
 // first gets its first-of-run flags as a stored BOOL column: the rows are sorted by (sort_keys, that column), flagged (the
 // synthetic input behind the stage's columns) and written back with the flag; the last sort -- by (sort_keys, first DISTINCT
 // column) -- carries those flags along as payload; then the aggregation over the sorted rows: scalar, or clustered by g->kpos.
+// restore_row_pos >= 0 (the pipe column holding the input row id): the specification also holds a sum folded row after row, which
+// needs every group's rows in INPUT order -- then EVERY DISTINCT column gets stored flags, a last sort by (sort_keys, row id)
+// puts the rows back, and the aggregation reads the flags as columns; the row-after-row sums leave the program (take_sequential).
 static Status lower_distinct_sorts(std::vector<Stage>* stages, Pipe* pipe_io, GroupBinding* g_io, const std::vector<int>& sort_keys,
-                                   const std::vector<int>& dcols, bool scalar, Stage* st_out) {
+                                   const std::vector<int>& dcols, bool scalar, Stage* st_out, int restore_row_pos = -1) {
   Pipe& pipe = *pipe_io; GroupBinding& g = *g_io; Stage& st = *st_out;
   // sorts the pipe's rows by (sort_keys, dcol); *run_cols = those columns
   auto sort_by_run = [&](int dcol, std::vector<int>* run_cols) -> Status {
@@ -1736,7 +1739,7 @@ static Status lower_distinct_sorts(std::vector<Stage>* stages, Pipe* pipe_io, Gr
     reset_pipe(&pipe, so.out_schema);
     return Status::OK();
   };
-  for (size_t e = 1; e < dcols.size(); ++e) {
+  for (size_t e = restore_row_pos >= 0 ? 0 : 1; e < dcols.size(); ++e) {
     std::vector<int> run_cols;
     SS_RETURN_IF_ERROR(sort_by_run(dcols[e], &run_cols));
     const int n_cols = (int)pipe.in_schema.size();
@@ -1753,6 +1756,15 @@ static Status lower_distinct_sorts(std::vector<Stage>* stages, Pipe* pipe_io, Gr
     for (auto& ap : g.plans) if (ap.distinct && ap.input_pos == dcols[e]) ap.flag_pos = n_cols;
   }
   std::vector<int> run_cols;
+  if (restore_row_pos >= 0) {
+    SS_RETURN_IF_ERROR(sort_by_run(restore_row_pos, &run_cols));
+    std::vector<Stage::SeqSum> seqs;
+    SS_RETURN_IF_ERROR(take_sequential(&g.plans, pipe, scalar ? 0 : g.kpos.size(), &seqs));
+    if (scalar) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st));
+    else SS_RETURN_IF_ERROR(finish_group_agg(g, pipe, &st, true));
+    st.seq_sums = seqs;
+    return Status::OK();
+  }
   SS_RETURN_IF_ERROR(sort_by_run(dcols[0], &run_cols));
   const int n_in = (int)pipe.in_schema.size();
   if (scalar) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st, n_in));
@@ -1950,8 +1962,6 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // (a sum folded row after row needs a result row's rows in input order: the CONCAT shape and the key limit's result-row
           // shape keep it, the DISTINCT shape sorts by the values)
           any_seq = has_sequential(probe);
-          if (any_seq && any_distinct)
-            return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to a DISTINCT aggregate is not available on the device path");
         }
         const bool limited_group = op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0;
         if (any_concat && !limited_group) {
@@ -2052,7 +2062,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             gr.plans.push_back(ap);
           }
-          if (any_concat || any_seq) {   // (a result row's rows in input order: CONCAT prints them, a row-after-row SUM folds them)
+          if (any_concat || (any_seq && !any_distinct)) {   // (a result row's rows in input order: CONCAT prints them, a row-after-row SUM folds them)
             Stage s2; s2.kind = STAGE_SORT; s2.in_schema = mr.out_schema; s2.out_schema = mr.out_schema;
             for (int k : {rank_pos, row_pos}) { SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; s2.sort_keys.push_back(sk); }
             for (size_t i = 0; i < s2.in_schema.size(); ++i) s2.sort_out_cols.push_back((int)i);
@@ -2077,7 +2087,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             pending = false;
             break;
           }
-          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &gr, std::vector<int>{rank_pos}, dcols, false, &st));
+          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &gr, std::vector<int>{rank_pos}, dcols, false, &st, any_seq ? row_pos : -1));
           desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit << " + " << dcols.size()
                << " x (sort + first-of-run flags)) GroupAggregate -> [" << schema_to_string(st.out_schema) << "] minus its first column\n";
           stages->push_back(st);
@@ -2097,15 +2107,16 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
           std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
           for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
-          if (first_last) {
-            const int row_pos = add_row_id_column(&pruned);
+          int row_pos = -1;
+          if (first_last || any_seq) {
+            row_pos = add_row_id_column(&pruned);
             for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
           }
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
           reset_pipe(&pipe, m.out_schema);
-          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, g.kpos, dcols, op.kind == SSGPU_OP_SCALAR_AGGREGATE, &st));
-          desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)) ";
+          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, g.kpos, dcols, op.kind == SSGPU_OP_SCALAR_AGGREGATE, &st, any_seq ? row_pos : -1));
+          desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)" << (any_seq ? " + sort back into input order" : "") << ") ";
         } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) {
           std::vector<AggPlan> plans;
           SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &plans));
@@ -2284,7 +2295,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             // by (segment id, DISTINCT column), flagged and aggregated as clusters of (segment id, keys...) -- equal keys of
             // different clusters stay apart and the clusters keep their input order; the segment id is projected away behind.
             if (!concats.empty()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate inside AggregateClusters is not available on the device path");
-            if (has_sequential(g.plans)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "SUM of a floating input into an integer output next to a DISTINCT aggregate is not available on the device path");
+            const bool c_seq = has_sequential(g.plans);
             std::vector<int> key_inputs;
             for (int k : g.kpos) {
               if (pipe.cols[k].expr->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "clustered keys must be plain input columns");
@@ -2297,8 +2308,9 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
               sc.expr->kind = BExpr::INPUT; sc.expr->input_col = (int)pipe.in_schema.size(); sc.expr->dtype = SSGPU_UINT32; sc.expr->nullable = false; sc.expr->name = sc.name;
               pruned.cols.push_back(sc); }
             const int seg_pos = (int)pruned.cols.size() - 1;
-            if (first_last) {
-              const int row_pos = add_row_id_column(&pruned);
+            int row_pos = -1;
+            if (first_last || c_seq) {
+              row_pos = add_row_id_column(&pruned);
               for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             }
             Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
@@ -2306,7 +2318,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             stages->push_back(m);
             reset_pipe(&pipe, m.out_schema);
             g.kpos.insert(g.kpos.begin(), seg_pos); g.knames.insert(g.knames.begin(), "$segment");
-            SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, std::vector<int>{seg_pos}, dcols, false, &st));
+            SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, std::vector<int>{seg_pos}, dcols, false, &st, c_seq ? row_pos : -1));
             desc << "(materialise with segment ids + " << dcols.size() << " x (sort + first-of-run flags)) AggregateClusters -> [" << schema_to_string(st.out_schema) << "] minus its first column\n";
             stages->push_back(st);
             reset_pipe(&pipe, st.out_schema);

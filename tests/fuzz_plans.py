@@ -258,9 +258,6 @@ class Gen(object):
             (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
         if concat or self.rng.random() < 0.15:     # a row-after-row SUM (floating input, integer result) rides the (result row, row id) order as well
             spec.AddAggregationWithDefinedOutputType(ss.SUM, "d0", "rq", self.pick([ss.INT64, ss.INT32]))
-            n_distinct = n_distinct if concat else -1
-        if n_distinct < 0:
-            spec.elements = [x for x in spec.elements if not x[1]]     # (next to DISTINCT it stays refused)
         if concat:
             for j in range(int(self.rng.integers(1, 3))):
                 (spec.AddDistinctAggregation if self.rng.random() < 0.4 else spec.AddAggregation)(ss.CONCAT, self.pick(["a", "b", "k1", "u", "s", "k2", "name", "day"]), "rc%d" % j)
@@ -287,6 +284,8 @@ class Gen(object):
             spec.AddAggregationWithDefinedOutputType(ss.SUM, self.pick(inputs), "q%d" % i, self.pick([ss.INT64, ss.INT32, ss.INT64]))
         for i in range(int(self.rng.integers(0, 4))):
             spec.AddAggregation(self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.FIRST, ss.LAST]), self.pick(["a", "b", "k1", "t"]), "r%d" % i)
+        for i in range(int(self.pick([0, 0, 1, 2]))):     # DISTINCT aggregates next to them: the rows are sorted back into input order
+            spec.AddDistinctAggregation(self.pick([ss.SUM, ss.COUNT]), self.pick(["a", "b", "k1"]), "rd%d" % i)
         child = ss.ScanView(view)
         if self.rng.random() < 0.5:
             child = ss.Filter(self.boolean(int(self.rng.integers(1, 3))), ss.ProjectAllAttributes(), child)

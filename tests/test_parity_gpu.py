@@ -1408,14 +1408,17 @@ def test_sum_of_floating_values_into_integer_results(gpu_ctx, n):
         run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), cspec, None, child), gpu_ctx, ignore_order=True)
         run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), cspec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(4), ss.ScanView(view)), gpu_ctx)
         run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("run"), cspec, ss.ScanView(view)), gpu_ctx)
-    # what stays refused: next to DISTINCT aggregates (their shape sorts a group's rows by the values)
-    for bad in (ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64)
-                                  .AddDistinctAggregation(ss.COUNT, "i", "c"), None, ss.ScanView(view)),
-                ss.GroupAggregate(ss.ProjectNamedAttribute("g"), ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "x", "s", ss.INT64)
-                                  .AddDistinctAggregation(ss.COUNT, "i", "c"), ss.GroupAggregateOptions().set_max_unique_keys_in_result_(3), ss.ScanView(view))):
-        with pytest.raises(ss.SupersonicException) as err:
-            ss.Plan(bad, gpu_ctx)
-        assert err.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+    # next to DISTINCT aggregates: their shape sorts a group's rows by the values -- every DISTINCT column's flags are stored and a last
+    # sort by (keys, row id) puts the rows back into input order before the fold
+    dspec = ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "i", "ci")
+    for col, out, t in (("x", "sx64", ss.INT64), ("f", "sf32", ss.INT32), ("p", "spu64", ss.UINT64)):
+        dspec.AddAggregationWithDefinedOutputType(ss.SUM, col, out, t)
+    dspec.AddDistinctAggregation(ss.SUM, "i", "si").AddDistinctAggregation(ss.COUNT, "g", "cg").AddAggregation(ss.LAST, "x", "lx").AddAggregation(ss.COUNT, "", "n")
+    run_both(ss.ScalarAggregate(dspec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), dspec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "run"]), dspec, None, child), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("g"), dspec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(3), ss.ScanView(view)), gpu_ctx)
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("run"), dspec, ss.ScanView(view)), gpu_ctx)
 
 
 def test_sum_of_floating_values_into_integer_results_reference_arithmetic(gpu_ctx):
