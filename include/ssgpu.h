@@ -391,7 +391,7 @@ int ssgpu_dict_decode(const ssgpu_dict* d, int32_t code, const char** bytes, int
  * column prints through it).  DISTINCT CONCAT prints a value once per result row, at its first
  * occurrence.  DATE / DATETIME print as the reference's strftime forms ("%Y/%m/%d", "%Y/%m/%d-%H:%M:%S" of gmtime,
  * types_infrastructure.cc:92-114).  Limits, refused at bind: BINARY inputs, a CONCAT result
- * that feeds another operation, CONCAT next to a DISTINCT aggregate or across shards. */
+ * that feeds another operation, CONCAT across shards.  (Next to DISTINCT aggregates the rows are sorted back into input order first.) */
 int ssgpu_plan_set_dict(ssgpu_plan* plan, const ssgpu_dict* dict);
 const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t col);
 

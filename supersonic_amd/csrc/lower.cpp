@@ -1723,8 +1723,10 @@ static int add_row_id_column(Pipe* pruned) {
 // restore_row_pos >= 0 (the pipe column holding the input row id): the specification also holds a sum folded row after row, which
 // needs every group's rows in INPUT order -- then EVERY DISTINCT column gets stored flags, a last sort by (sort_keys, row id)
 // puts the rows back, and the aggregation reads the flags as columns; the row-after-row sums leave the program (take_sequential).
+// CONCAT aggregates ride the same order: they become COUNTs here and *concats says which (the caller attaches Stage::ConcatCol).
 static Status lower_distinct_sorts(std::vector<Stage>* stages, Pipe* pipe_io, GroupBinding* g_io, const std::vector<int>& sort_keys,
-                                   const std::vector<int>& dcols, bool scalar, Stage* st_out, int restore_row_pos = -1) {
+                                   const std::vector<int>& dcols, bool scalar, Stage* st_out, int restore_row_pos = -1,
+                                   std::vector<ConcatPlan>* concats = nullptr) {
   Pipe& pipe = *pipe_io; GroupBinding& g = *g_io; Stage& st = *st_out;
   // sorts the pipe's rows by (sort_keys, dcol); *run_cols = those columns
   auto sort_by_run = [&](int dcol, std::vector<int>* run_cols) -> Status {
@@ -1758,6 +1760,7 @@ static Status lower_distinct_sorts(std::vector<Stage>* stages, Pipe* pipe_io, Gr
   std::vector<int> run_cols;
   if (restore_row_pos >= 0) {
     SS_RETURN_IF_ERROR(sort_by_run(restore_row_pos, &run_cols));
+    if (concats) take_concat_plans(schema_of(pipe.cols), &g.plans, concats);
     std::vector<Stage::SeqSum> seqs;
     SS_RETURN_IF_ERROR(take_sequential(&g.plans, pipe, scalar ? 0 : g.kpos.size(), &seqs));
     if (scalar) SS_RETURN_IF_ERROR(finish_scalar_agg_bound(g.plans, pipe, &st));
@@ -1795,6 +1798,26 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
   Pipe pipe;
   reset_pipe(&pipe, d.input_schema);
   bool pending = true;  // pipe has operations not yet flushed into a stage
+  // A clustered aggregation keyed by a hidden first column ($rank, $segment): the stage, then the projection that drops the column.
+  // CONCAT columns belong to the LAST stage (the host prints them when the result is fetched), which is that projection: they point
+  // back at the aggregation's stage (Stage::ConcatCol::stage), whose ordered input and segment ids hold the values.
+  auto drop_hidden_key = [&](const Stage& agg, size_t n_stage_keys, const std::vector<ConcatPlan>& concats) -> Status {
+    stages->push_back(agg);
+    const int agg_stage = (int)stages->size() - 1;
+    reset_pipe(&pipe, agg.out_schema);
+    pipe.cols.erase(pipe.cols.begin());
+    pending = true;
+    if (concats.empty()) return Status::OK();
+    Stage fm; SS_RETURN_IF_ERROR(finish_materialize(pipe, &fm));
+    for (auto& cp : concats) {
+      Stage::ConcatCol cc; cc.out_col = (int)(n_stage_keys - 1 + cp.agg); cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.stage = agg_stage; cc.distinct = cp.distinct;
+      fm.concat.push_back(cc);
+    }
+    stages->push_back(fm);
+    reset_pipe(&pipe, fm.out_schema);
+    pending = false;
+    return Status::OK();
+  };
   for (size_t ci = 1; ci < chain.size(); ++ci) {
     const ssgpu_op& op = d.ops[chain[ci]];
     const Schema vs = schema_of(pipe.cols);
@@ -1964,7 +1987,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           any_seq = has_sequential(probe);
         }
         const bool limited_group = op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0;
-        if (any_concat && !limited_group) {
+        if (any_concat && !limited_group && !any_distinct) {
           // CONCAT (Stage::ConcatCol): the values have to reach the host in input order, group by group -- materialise the keys and
           // the aggregated columns, (stable) sort by the keys, aggregate the key runs with the clustered kernel (CONCAT counted as
           // COUNT(x)); the host prints the strings from the sorted rows and their segment ids when the column is fetched.
@@ -2008,7 +2031,6 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // CONCAT under the limit takes the same road: a result row's string joins the values of ALL its rows in input order
           // (column_aggregator.cc:108-124 over the same result index), so the stored rows are sorted by ($rank, row id) and aggregated
           // as clusters of `$rank`; the host prints from that stage's input (Stage::ConcatCol::stage) behind the projection.
-          if (any_concat && any_distinct) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate is not available on the device path");
           if (any_concat && ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
           const int64_t limit = op.option0 < 0 ? 0 : op.option0;
           if (limit >= (1ll << 31)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result beyond 2^31 keys next to a DISTINCT aggregate");
@@ -2062,7 +2084,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
             gr.plans.push_back(ap);
           }
-          if (any_concat || (any_seq && !any_distinct)) {   // (a result row's rows in input order: CONCAT prints them, a row-after-row SUM folds them)
+          if ((any_concat || any_seq) && !any_distinct) {   // (a result row's rows in input order: CONCAT prints them, a row-after-row SUM folds them)
             Stage s2; s2.kind = STAGE_SORT; s2.in_schema = mr.out_schema; s2.out_schema = mr.out_schema;
             for (int k : {rank_pos, row_pos}) { SortKey sk; sk.col = k; sk.order = SSGPU_ASCENDING; s2.sort_keys.push_back(sk); }
             for (size_t i = 0; i < s2.in_schema.size(); ++i) s2.sort_out_cols.push_back((int)i);
@@ -2087,13 +2109,12 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             pending = false;
             break;
           }
-          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &gr, std::vector<int>{rank_pos}, dcols, false, &st, any_seq ? row_pos : -1));
+          std::vector<ConcatPlan> concats;
+          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &gr, std::vector<int>{rank_pos}, dcols, false, &st, any_seq || any_concat ? row_pos : -1, &concats));
           desc << "(materialise + sort by the keys + result row of every input row under the limit " << limit << " + " << dcols.size()
-               << " x (sort + first-of-run flags)) GroupAggregate -> [" << schema_to_string(st.out_schema) << "] minus its first column\n";
-          stages->push_back(st);
-          reset_pipe(&pipe, st.out_schema);
-          pipe.cols.erase(pipe.cols.begin());   // ($rank)
-          pending = true;
+               << " x (sort + first-of-run flags)" << (any_seq || any_concat ? " + sort back into input order" : "") << ") GroupAggregate -> ["
+               << schema_to_string(st.out_schema) << "] minus its first column\n";
+          SS_RETURN_IF_ERROR(drop_hidden_key(st, gr.kpos.size(), concats));
           break;
         } else if (any_distinct) {
           GroupBinding g;
@@ -2107,16 +2128,23 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
           std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
           for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
+          // CONCAT next to DISTINCT: the values have to reach the host group by group in input order -- the restored order of the
+          // row-after-row sums serves it (every DISTINCT column's flags stored, a last sort by (keys, row id))
+          if (any_concat && ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
+          const bool restore = any_seq || any_concat;
           int row_pos = -1;
-          if (first_last || any_seq) {
+          if (first_last || restore) {
             row_pos = add_row_id_column(&pruned);
             for (auto& ap : g.plans) if (ap.aggregation == SSGPU_FIRST || ap.aggregation == SSGPU_LAST) ap.order_pos = row_pos;
           }
           Stage m; SS_RETURN_IF_ERROR(finish_materialize(pruned, &m));
           stages->push_back(m);
           reset_pipe(&pipe, m.out_schema);
-          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, g.kpos, dcols, op.kind == SSGPU_OP_SCALAR_AGGREGATE, &st, any_seq ? row_pos : -1));
-          desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)" << (any_seq ? " + sort back into input order" : "") << ") ";
+          std::vector<ConcatPlan> concats;
+          SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, g.kpos, dcols, op.kind == SSGPU_OP_SCALAR_AGGREGATE, &st, restore ? row_pos : -1, &concats));
+          for (auto& cp : concats) { Stage::ConcatCol cc; cc.out_col = (int)(g.kpos.size() + cp.agg); cc.src_col = cp.input_pos; cc.src_dtype = cp.dtype; cc.distinct = cp.distinct; st.concat.push_back(cc); }
+          desc << "(materialise + " << dcols.size() << " x (sort + first-of-run flags)" << (restore ? " + sort back into input order" : "")
+               << (concats.empty() ? "" : "; CONCAT printed on the host") << ") ";
         } else if (op.kind == SSGPU_OP_SCALAR_AGGREGATE) {
           std::vector<AggPlan> plans;
           SS_RETURN_IF_ERROR(bind_aggregations(d, op.agg_first, op.agg_n, schema_of(pipe.cols), &plans));
@@ -2294,14 +2322,14 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             // their segment id (the boundary scan over the key columns, run in front of this stage: Stage::segment_cols), sorted
             // by (segment id, DISTINCT column), flagged and aggregated as clusters of (segment id, keys...) -- equal keys of
             // different clusters stay apart and the clusters keep their input order; the segment id is projected away behind.
-            if (!concats.empty()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "CONCAT next to a DISTINCT aggregate inside AggregateClusters is not available on the device path");
-            const bool c_seq = has_sequential(g.plans);
+            const bool c_seq = has_sequential(g.plans) || !concats.empty();   // (both need a cluster's rows back in input order)
             std::vector<int> key_inputs;
             for (int k : g.kpos) {
               if (pipe.cols[k].expr->kind != BExpr::INPUT) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "clustered keys must be plain input columns");
               key_inputs.push_back(pipe.cols[k].expr->input_col);
             }
             Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);
+            for (auto& cp : concats) cp.input_pos = g.plans[cp.agg].input_pos;   // (the CONCAT columns -- COUNTs by now -- moved with the pruning)
             std::vector<int> dcols;  // the DISTINCT input columns, in first-use order
             for (auto& ap : g.plans) if (ap.distinct && std::find(dcols.begin(), dcols.end(), ap.input_pos) == dcols.end()) dcols.push_back(ap.input_pos);
             { VCol sc; sc.name = "$segment"; sc.expr = std::make_shared<BExpr>();
@@ -2320,10 +2348,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             g.kpos.insert(g.kpos.begin(), seg_pos); g.knames.insert(g.knames.begin(), "$segment");
             SS_RETURN_IF_ERROR(lower_distinct_sorts(stages, &pipe, &g, std::vector<int>{seg_pos}, dcols, false, &st, c_seq ? row_pos : -1));
             desc << "(materialise with segment ids + " << dcols.size() << " x (sort + first-of-run flags)) AggregateClusters -> [" << schema_to_string(st.out_schema) << "] minus its first column\n";
-            stages->push_back(st);
-            reset_pipe(&pipe, st.out_schema);
-            pipe.cols.erase(pipe.cols.begin());   // (the segment id)
-            pending = true;
+            SS_RETURN_IF_ERROR(drop_hidden_key(st, g.kpos.size(), concats));
             break;
           }
           std::vector<Stage::SeqSum> seqs;

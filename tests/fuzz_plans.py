@@ -247,13 +247,13 @@ class Gen(object):
             e.AddAs("x%d" % i, self.integer(int(self.rng.integers(0, 3))))
             inputs.append("x%d" % i)
         n_distinct = 0
-        concat = self.rng.random() < 0.3      # CONCAT under the limit instead (CONCAT next to DISTINCT is refused on the device path)
+        concat = self.rng.random() < 0.3      # CONCAT under the limit as well, alone or next to DISTINCT aggregates
         for i in range(int(self.rng.integers(1, 6))):
             name = self.pick(inputs)
             agg = self.pick([ss.SUM, ss.MIN, ss.MAX, ss.COUNT, ss.COUNT, ss.FIRST, ss.LAST])
             if name in ("t", "day") and agg == ss.SUM:
                 agg = ss.COUNT
-            distinct = not concat and agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < 0.6
+            distinct = agg in (ss.SUM, ss.COUNT, ss.MIN, ss.MAX) and self.rng.random() < (0.3 if concat else 0.6)
             n_distinct += distinct
             (spec.AddDistinctAggregation if distinct else spec.AddAggregation)(agg, name, "r%d" % i)
         if concat or self.rng.random() < 0.15:     # a row-after-row SUM (floating input, integer result) rides the (result row, row id) order as well

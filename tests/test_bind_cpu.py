@@ -80,7 +80,7 @@ def test_bind_errors(bind_ctx):
 def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     # GroupAggregateOptions::max_unique_keys_in_result (aggregate.h:160-205, row_hash_set.cc:500-511): hash aggregate with a
     # hidden first-seen row id, sort by it, fold of the rows beyond the limit -- the hidden column is not in the result schema;
-    # FIRST / LAST under a limit fold by a hidden row-id twin each (also not in the result schema); DISTINCT and CONCAT under a limit re-key the rows by their result row; CONCAT next to DISTINCT is refused
+    # FIRST / LAST under a limit fold by a hidden row-id twin each (also not in the result schema); DISTINCT and CONCAT under a limit re-key the rows by their result row; a CONCAT result below another operation is refused
     import numpy as np
     schema = ss.TupleSchema([ss.Attribute("k", ss.INT64), ss.Attribute("v", ss.INT64)])
     view = ss.View(schema, [np.arange(4), np.arange(4)])
@@ -107,8 +107,9 @@ def test_max_unique_keys_in_result_binds_as_aggregate_sort_fold():
     rs = cplan.result_schema
     assert [(rs.attribute(i).name(), rs.attribute(i).type()) for i in range(rs.attribute_count())] == [("k", ss.INT64), ("f", ss.STRING)]
     assert "sort by (result row, row id)" in cplan.describe()
-    bad = ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f").AddDistinctAggregation(ss.SUM, "v", "s"),
-                            ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view))
+    bad = ss.Sort(ss.SortOrder().add("k", ss.ASCENDING), None, 0,
+                  ss.GroupAggregate(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "v", "f").AddDistinctAggregation(ss.SUM, "v", "s"),
+                                    ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2), ss.ScanView(view)))
     with pytest.raises(ss.SupersonicException) as e:
         ss.Plan(bad, ss.Context(-1))
     assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
@@ -141,8 +142,8 @@ def test_distinct_inside_aggregate_clusters_binds_with_a_segment_id_column():
     rs = plan.result_schema
     assert [rs.attribute(i).name() for i in range(rs.attribute_count())] == ["k", "s", "m"]
     assert "segment ids" in plan.describe()
-    bad = ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "s").AddAggregation(ss.CONCAT, "b", "c"),
-                               ss.ScanView(view))
-    with pytest.raises(ss.SupersonicException) as e:
-        ss.Plan(bad, ss.Context(-1))
-    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+    # CONCAT next to it: the rows are sorted back into input order, the strings come from the aggregation's stage behind the projection
+    both = ss.AggregateClusters(ss.ProjectNamedAttributes(["k"]), ss.AggregationSpecification().AddDistinctAggregation(ss.SUM, "a", "s").AddAggregation(ss.CONCAT, "b", "c"),
+                                ss.ScanView(view))
+    rs = ss.Plan(both, ss.Context(-1)).result_schema
+    assert [(rs.attribute(i).name(), rs.attribute(i).type()) for i in range(rs.attribute_count())] == [("k", ss.INT32), ("s", ss.INT64), ("c", ss.STRING)]

@@ -1692,9 +1692,11 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
     opts = ss.GroupAggregateOptions().set_max_unique_keys_in_result_(2)
     got = run_both(ss.GroupAggregate(ss.ProjectNamedAttribute("col0"), ss.AggregationSpecification().AddAggregation(ss.SUM, "col1", "sum"), opts, ss.ScanView(view)), gpu_ctx)
     assert got.column(0).data.tolist() == [1, 3, 4] and got.column(1).data.tolist() == [5, -9, 9]
+    # what the composition cannot express: a CONCAT result below another operation (its strings exist on the host only)
     wide = make_view(100, nullable=True)
-    for op in (ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l").AddDistinctAggregation(ss.SUM, "b", "s"),
-                                 opts, ss.ScanView(wide)),):
+    for op in (ss.Sort(ss.SortOrder().add("k2", ss.ASCENDING), None, 0,
+                       ss.GroupAggregate(ss.ProjectNamedAttributes(["k2"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "b", "l").AddDistinctAggregation(ss.SUM, "b", "s"),
+                                         opts, ss.ScanView(wide))),):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(op, gpu_ctx)
         assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
@@ -1961,6 +1963,14 @@ def test_concat_aggregate(gpu_ctx, n):
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), dspec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(5), ss.ScanView(view)), gpu_ctx)
     run_both(ss.ScalarAggregate(dspec, flt), gpu_ctx)
     run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("g"), dspec, ss.ScanView(clustered)), gpu_ctx)
+    # CONCAT next to DISTINCT aggregates: the DISTINCT shape's rows are sorted back into input order (stored flags) before the host reads them
+    mspec = (ss.AggregationSpecification().AddAggregation(ss.CONCAT, "i", "ci").AddDistinctAggregation(ss.COUNT, "h", "dh").AddDistinctAggregation(ss.CONCAT, "w", "cw")
+             .AddDistinctAggregation(ss.SUM, "a", "da").AddAggregation(ss.FIRST, "i", "fi").AddAggregation(ss.COUNT, "", "n"))
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), mspec, None, flt), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g", "h"]), mspec, None, ss.ScanView(view)), gpu_ctx, ignore_order=True)
+    run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), mspec, ss.GroupAggregateOptions().set_max_unique_keys_in_result_(5), ss.ScanView(view)), gpu_ctx)
+    run_both(ss.ScalarAggregate(mspec, ss.ScanView(view)), gpu_ctx)
+    run_both(ss.AggregateClusters(ss.ProjectNamedAttribute("g"), mspec, ss.ScanView(clustered)), gpu_ctx)
     # a computed CONCAT input, and the refusals: a consumer above the CONCAT, a non-STRING result type
     comp = ss.Compute(ss.CompoundExpression().Add(NA("g")).AddAs("s", ss.Plus(NA("a"), ss.ConstInt64(7))), ss.ScanView(view))
     run_both(ss.GroupAggregate(ss.ProjectNamedAttributes(["g"]), ss.AggregationSpecification().AddAggregation(ss.CONCAT, "s", "cs"), None, comp), gpu_ctx, ignore_order=True)
