@@ -75,7 +75,7 @@
  *       millisecond.  The one-segment fold runs in launches of 2^21 rows and looks at ssgpu_interrupt between them.  Under
  *       max_unique_keys_in_result the folded row's rows are folded in input order across its keys; next to DISTINCT
  *       aggregates (whose shape sorts a group's rows by the values) the rows are sorted back by their input row id first.
- *       Refused across shards;
+ *       Across shards the rows themselves travel (supersonic_amd.distributed.sharded_group_aggregate); the fused drivers refuse;
  *       MIN / MAX over FLOAT / DOUBLE: the reference's update is "if (val < result) result = val"
  *       (aggregation_operators.h:200,221) after ASSIGNING a group's first non-NULL value: a NaN that
  *       comes FIRST stays (nothing is less than NaN), a NaN that comes later is skipped.  Same here:
@@ -391,7 +391,7 @@ int ssgpu_dict_decode(const ssgpu_dict* d, int32_t code, const char** bytes, int
  * column prints through it).  DISTINCT CONCAT prints a value once per result row, at its first
  * occurrence.  DATE / DATETIME print as the reference's strftime forms ("%Y/%m/%d", "%Y/%m/%d-%H:%M:%S" of gmtime,
  * types_infrastructure.cc:92-114).  Limits, refused at bind: BINARY inputs, a CONCAT result
- * that feeds another operation, CONCAT across shards.  (Next to DISTINCT aggregates the rows are sorted back into input order first.) */
+ * that feeds another operation.  (Across shards the rows travel: sharded_group_aggregate.  Next to DISTINCT aggregates the rows are sorted back into input order first.) */
 int ssgpu_plan_set_dict(ssgpu_plan* plan, const ssgpu_dict* dict);
 const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t col);
 

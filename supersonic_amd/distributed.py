@@ -86,7 +86,7 @@ def _merge_spec(spec, with_residual=()):
     counts = []
     for (aggregation, distinct, out_type, _input_name, output_name) in spec.elements:
         if distinct or aggregation == ss.CONCAT:   # FIRST / LAST merge as themselves: partial tables are gathered in rank (= row) order
-            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "aggregation cannot be merged across shards")
+            raise ss.SupersonicException(ss.ERROR_NOT_IMPLEMENTED, "aggregation cannot be merged across shards as a partial result (sharded_group_aggregate sends the distinct pairs / the rows instead)")
         if aggregation == ss.COUNT:
             merged.AddAggregation(ss.SUM, output_name, output_name)   # COUNT merges as SUM of the partial counts
             counts.append(output_name)
@@ -209,12 +209,28 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
     one all-to-all), every rank merges 1 / world of the groups, and the finished slices are gathered -- the form whose
     merge work and link traffic shrink with the number of ranks."""
     import torch.distributed as dist
-    shard_spec, with_residual = _shard_spec(spec, _schema_of(local_child))
-    merged_spec, counts = _merge_spec(spec, with_residual)
-    partial = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), shard_spec, None, local_child))
+    child_schema = _schema_of(local_child)
+    mode = _exchange_mode(spec, child_schema)
+    if mode == "rows":
+        # CONCAT and the row-after-row SUM need a group's VALUES in input order, not a partial result: the shards send the rows
+        # themselves -- keys and aggregated columns -- and the owner runs the specification as written over them (rank order =
+        # row order of the job, kept by the gather; the answer, DOUBLE sums included, is the single-process one)
+        used = list(group_by) + [n for n in dict.fromkeys(e[3] for e in spec.elements if e[3]) if n not in group_by]
+        partial = executor(ss.Project(ss.ProjectNamedAttributes(used), local_child))
+        merge = lambda rows: ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), spec, None, ss.ScanView(rows))   # noqa: E731
+    else:
+        plain = ss.AggregationSpecification()
+        plain.elements = [e for e in spec.elements if not e[1]]
+        shard_spec, with_residual = _shard_spec(plain, child_schema)
+        if mode == "distinct":
+            partial, merge = _distinct_blocks(group_by, spec, plain, shard_spec, with_residual, local_child, executor)
+        else:
+            merged_spec, counts = _merge_spec(spec, with_residual)
+            partial = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(list(group_by)), shard_spec, None, local_child))
+            schema = partial.schema()
+            merge = lambda rows: _merge_plan(group_by, merged_spec, counts, schema, rows)   # noqa: E731
     if not key_range:
-        everyone = _all_gather_view(partial, group, device)
-        return executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), everyone))
+        return executor(merge(_all_gather_view(partial, group, device)))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     owner = _owner_of_rows(partial, len(group_by), world)
     # the all-to-all, spelled with all-gathers of the per-destination slices (host form: any backend has all_gather)
@@ -223,8 +239,97 @@ def sharded_group_aggregate(group_by, spec, local_child, executor, group=None, d
         arrived = _all_gather_view(_take_rows(partial, owner == d), group, device)    # every rank receives destination d's rows ...
         if d == rank:
             mine = arrived                                                           # ... and keeps its own
-    merged = executor(_merge_plan(group_by, merged_spec, counts, partial.schema(), mine))
-    return _all_gather_view(merged, group, device)
+    return _all_gather_view(executor(merge(mine)), group, device)
+
+
+def _exchange_mode(spec, child_schema):
+    """What the shards of a GroupAggregate send: "partial" tables (every aggregate merges: SUM of sums ...), partial tables next to
+    the "distinct" (keys, value) pairs of every DISTINCT aggregate, or -- for CONCAT and the row-after-row SUM of a floating input
+    into an integer result (aggregation_operators.h:173-185) -- the "rows" themselves."""
+    mode = "partial"
+    for (aggregation, distinct, out_type, input_name, _output_name) in spec.elements:
+        if aggregation == ss.CONCAT:
+            return "rows"
+        if aggregation == ss.SUM and child_schema is not None and out_type in (ss.INT32, ss.UINT32, ss.INT64, ss.UINT64):
+            pos = child_schema.LookupAttributePosition(input_name)
+            if pos >= 0 and child_schema.attribute(pos).type() in (ss.FLOAT, ss.DOUBLE):
+                return "rows"
+        if distinct:
+            mode = "distinct"
+    return mode
+
+
+DISTINCT_OF = "$distinct:"   # prefix of the union table's column that carries a DISTINCT aggregate's input values
+
+
+def _distinct_blocks(group_by, spec, plain, shard_spec, with_residual, local_child, executor):
+    """DISTINCT aggregates across shards.  The distinct values of a group over the whole job are the distinct values of the shards'
+    distinct values: every shard sends, next to its partial table of the other aggregates, the (keys, value) pairs of each DISTINCT
+    input (a GroupAggregate by keys + value), all stacked into ONE table -- a block's rows are NULL in the other blocks' columns,
+    and every merging aggregate skips NULLs -- so one exchange and one merge plan serve: SUM of sums ... over the partial columns,
+    the DISTINCT aggregates as written over the pair columns.  -> (this rank's stacked table, rows -> merge plan)."""
+    keys = list(group_by)
+    blocks = []      # (view, {union column name: column name in the view})
+    if plain.elements:
+        part = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), shard_spec, None, local_child))
+        blocks.append((part, {part.schema().attribute(i).name(): part.schema().attribute(i).name() for i in range(part.schema().attribute_count())}))
+    inputs = list(dict.fromkeys(e[3] for e in spec.elements if e[1]))
+    for name in inputs:
+        by = keys + ([name] if name not in keys else [])
+        pairs = executor(ss.GroupAggregate(ss.ProjectNamedAttributes(by), ss.AggregationSpecification().AddAggregation(ss.COUNT, "", "$n"), None, local_child))
+        cols = {k: k for k in keys}
+        cols[DISTINCT_OF + name] = name
+        blocks.append((pairs, cols))
+    # the stacked table: keys, the partial table's columns, one column per DISTINCT input; every non-key column NULLABLE
+    attrs, seen = [], set()
+    for view, cols in blocks:
+        for union_name, local_name in cols.items():
+            if union_name in seen:
+                continue
+            seen.add(union_name)
+            a = view.schema().attribute(view.schema().LookupAttributePosition(local_name))
+            attrs.append(ss.Attribute(union_name, a.type(), a.nullability() if union_name in keys else ss.NULLABLE))
+    total = sum(view.row_count() for view, _ in blocks)
+    columns = []
+    for a in attrs:
+        is_string = a.type() == ss.STRING
+        data = np.empty(total, dtype=object) if is_string else np.zeros(total, dtype=ss.numpy_dtype(a.type()))
+        if is_string:
+            data[:] = [b""] * total
+        nulls = np.zeros(total, dtype=bool) if a.is_nullable() else None
+        at = 0
+        for view, cols in blocks:
+            n = view.row_count()
+            if a.name() in cols:
+                col = view.column(view.schema().LookupAttributePosition(cols[a.name()]))
+                data[at:at + n] = col.data
+                if col.is_null is not None:
+                    nulls[at:at + n] = col.is_null
+            else:
+                nulls[at:at + n] = True
+            at += n
+        columns.append(ss.Column(data, nulls))
+    stacked = ss.View(ss.TupleSchema(attrs), columns, total)
+    merged_spec, counts = ss.AggregationSpecification(), []
+    for (aggregation, distinct, out_type, input_name, output_name) in spec.elements:
+        if distinct:
+            merged_spec.elements.append((aggregation, 1, out_type, DISTINCT_OF + input_name, output_name))
+        elif aggregation == ss.COUNT:
+            merged_spec.AddAggregation(ss.SUM, output_name, output_name)
+            counts.append(output_name)
+        else:
+            merged_spec.AddAggregation(aggregation, output_name, output_name)
+            if output_name in with_residual:
+                merged_spec.AddAggregation(ss.SUM, output_name + RESIDUAL, output_name + RESIDUAL)
+    # the columns of the merged GroupAggregate, in its order, for _merge_plan's projection (COUNT back to NOT NULL, sum + residual)
+    single = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, local_child), ss.Context(-1)).result_schema
+    out_attrs = []
+    for i in range(single.attribute_count()):
+        out_attrs.append(single.attribute(i))
+        if single.attribute(i).name() in with_residual:
+            out_attrs.append(ss.Attribute(single.attribute(i).name() + RESIDUAL, ss.DOUBLE, ss.NULLABLE))
+    out_schema = ss.TupleSchema(out_attrs)
+    return stacked, (lambda rows: _merge_plan(group_by, merged_spec, counts, out_schema, rows))
 
 
 def _merge_plan(group_by, merged_spec, counts, schema, everyone, valid=None):

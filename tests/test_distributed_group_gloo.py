@@ -237,3 +237,54 @@ def test_never_null_partial_columns_are_declared_not_null_for_the_merge():
     assert got == [("k", False, (1000, 2000)), ("sd", False, (1016, 0)), ("sd" + RESIDUAL, False, (1032, 0)), ("mn", True, (1048, 2048)),
                    ("c", False, (1064, 2064)), ("li", False, (1080, 0)), ("mx", False, (1096, 0)), ("__valid", False, (1112, 2112))]
     assert out.row_count() == 5 and _declare_not_null(view, set()) is view
+
+
+# ---- DISTINCT, CONCAT and the row-after-row SUM across shards: what a shard's result is NOT a partial result of --------------------
+def _hard_spec(kind):
+    spec = ss.AggregationSpecification()
+    if kind == "distinct":          # the shards send their distinct (keys, value) pairs next to the partial table
+        return (spec.AddDistinctAggregation(ss.COUNT, "v", "cdv").AddAggregation(ss.SUM, "d", "sd").AddDistinctAggregation(ss.SUM, "v", "sdv")
+                .AddAggregation(ss.COUNT, "", "n").AddDistinctAggregation(ss.COUNT, "a", "cda").AddAggregation(ss.LAST, "v", "lv").AddDistinctAggregation(ss.COUNT, "k2", "cdk"))
+    if kind == "distinct_only":
+        return spec.AddDistinctAggregation(ss.SUM, "v", "sdv")
+    if kind == "concat":            # the shards send the rows themselves
+        return spec.AddAggregation(ss.CONCAT, "v", "cv").AddAggregation(ss.SUM, "d", "sd").AddDistinctAggregation(ss.COUNT, "a", "cda").AddAggregation(ss.COUNT, "", "n")
+    return spec.AddAggregationWithDefinedOutputType(ss.SUM, "d", "sq", ss.INT64).AddAggregation(ss.MAX, "v", "mv").AddAggregation(ss.FIRST, "a", "fa")
+
+
+def hard_worker(rank, world, port, n, kind, q, key_range):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = make_view(n)
+    bounds = [0, n // 3, n]
+    out = sharded_group_aggregate(["k1", "k2"], _hard_spec(kind), child(shard_of(full, bounds[rank], bounds[rank + 1]), True), oracle_executor, key_range=key_range)
+    cols = [(out.column(i).data, out.column(i).is_null) for i in range(out.column_count())]
+    schema = [(out.schema().attribute(i).name(), out.schema().attribute(i).type(), out.schema().attribute(i).is_nullable())
+              for i in range(out.schema().attribute_count())]
+    q.put((rank, schema, cols))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("key_range", [False, True])
+@pytest.mark.parametrize("kind", ["distinct", "distinct_only", "concat", "sequential"])
+@pytest.mark.parametrize("n", [6001, 0])
+def test_sharded_group_aggregate_of_unmergeable_aggregates_over_gloo(n, kind, key_range):
+    """COUNT(DISTINCT v) of a group is not the sum of the shards' counts, a CONCAT not a concatenation of partial strings in any
+    order, `*result += val` into an integer not a sum of truncated sums: the first travels as distinct (keys, value) pairs stacked under
+    the partial table, the other two as the rows themselves.  Every rank ends with the oracle's answer for the WHOLE input."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=hard_worker, args=(r, 2, port, n, kind, q, key_range)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want_schema, want = oracle.run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), _hard_spec(kind), None, child(make_view(n), True)))
+    for _rank, schema, cols in results:
+        assert [tuple(x) for x in schema] == [tuple(x) for x in want_schema]
+        assert_cols_equal(sort_rows(cols), sort_rows(want), context="sharded %s" % kind)

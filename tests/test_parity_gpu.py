@@ -540,6 +540,18 @@ def test_sharded_group_aggregate_merge_plan_on_device(gpu_ctx):
         out = sharded_group_aggregate(["k1", "k2"], spec, child, device_executor(gpu_ctx))
         _schema, want = oracle.run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), spec, None, child))
         assert_cols_equal(sort_rows(to_cols(out)), sort_rows(want), context="sharded group aggregate on device")
+        # what is not a partial result: DISTINCT aggregates travel as distinct (keys, value) pairs stacked under the partial table,
+        # CONCAT and the row-after-row SUM as the rows themselves -- the shard plans and the merge plans run on the device here
+        hard = [ss.AggregationSpecification().AddDistinctAggregation(ss.COUNT, "b", "cb").AddAggregation(ss.SUM, "d0", "s0").AddDistinctAggregation(ss.SUM, "u", "su")
+                .AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.LAST, "t", "lt"),
+                ss.AggregationSpecification().AddAggregation(ss.CONCAT, "t", "ct").AddAggregation(ss.SUM, "d0", "s0").AddDistinctAggregation(ss.COUNT, "b", "cb"),
+                ss.AggregationSpecification().AddAggregationWithDefinedOutputType(ss.SUM, "d1", "q", ss.INT64).AddAggregation(ss.MAX, "b", "mb")]
+        small = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(make_view(4000, nullable=True)))
+        for hspec in hard:
+            for key_range in (False, True):
+                out = sharded_group_aggregate(["k1", "k2"], hspec, small, device_executor(gpu_ctx), key_range=key_range)
+                _schema, want = oracle.run(ss.GroupAggregate(ss.ProjectNamedAttributes(["k1", "k2"]), hspec, None, small))
+                assert_cols_equal(sort_rows(to_cols(out)), sort_rows(want), context="sharded hard aggregates on device")
     finally:
         dist.destroy_process_group()
 
