@@ -456,12 +456,19 @@ int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
  * version): a second process loads them in milliseconds instead of compiling for seconds (ssgpu_memory_stats:
  * rtc_disk_hits vs rtc_compilations).  Directory: $SSGPU_RTC_CACHE_DIR (empty string = no disk cache), else
  * $XDG_CACHE_HOME/ssgpu/rtc, else $HOME/.cache/ssgpu/rtc; files are written atomically and checksummed.
- * THE DEFAULT POLICY (context option "specialize" = 2; process-wide default: environment SSGPU_SPECIALIZE): a plan runs the
- * compiled kernel of a stage where one EXISTS -- loaded in this process, or in the on-disk cache from any earlier process --
- * and the interpreting kernel where none does; it never compiles.  So a service whose plans were specialised once (option 1,
- * ssgpu_plan_specialize, or a warm-up run) gets the compiled kernels by default from then on, and a plan that meets an empty
- * cache still blocks on no compiler.  ssgpu_plan_specialize on such a plan compiles what it did not find.  "specialize" = 0:
- * the interpreting kernels only (unless the plan asks).
+ * "specialize" = 2: a plan runs the compiled kernel of a stage where one EXISTS -- loaded in this process, or in the on-disk
+ * cache from any earlier process -- and the interpreting kernel where none does; it never compiles.
+ * THE DEFAULT POLICY ("specialize" = 3; process-wide default: environment SSGPU_SPECIALIZE): like 2, and a kernel that is
+ * MISSING when a run over at least "specialize_min_rows" (default 2^22) input rows wants it is compiled IN THE BACKGROUND by the
+ * library's one worker thread.  No run ever waits for a compiler: that run and the next ones use the interpreting kernel; the
+ * plan asks again (at most every 20 ms) and switches when the kernel is there -- ssgpu_plan_specialized counts it from then on,
+ * ssgpu_plan_specialize_reason says "being compiled ..." until then -- and every later plan and, through the disk cache, every
+ * later process finds it at once.  A cold process therefore runs its first seconds interpreted (the headline query: 0.70 of the
+ * roofline instead of 0.80) and a service reaches the compiled kernels without anybody calling ssgpu_plan_specialize.  Small
+ * runs never start a compilation.  The worker compiles one kernel at a time, oldest request first; at process exit queued
+ * requests are dropped and a compilation in flight is waited for (seconds).  ssgpu_plan_specialize on a plan of policy 2 / 3
+ * compiles what it did not find -- now, waiting (for the worker too, if it is at that kernel).  "specialize" = 0: the
+ * interpreting kernels only (unless the plan asks).
  * A stage whose specialisation is not possible (no libhiprtc on the host, a compilation failure) keeps the
  * interpreting kernel -- still the HIP path -- and ssgpu_plan_specialize_reason says why ("" if nothing was refused).
  * ssgpu_plan_specialized: how many specialised kernels the plan currently holds. */

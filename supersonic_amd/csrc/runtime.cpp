@@ -76,13 +76,16 @@ struct ssgpu_ctx {
   int64_t profile_total = 1;     // ... and around the whole run (kernel_ms); 0 keeps only the dominant kernel's pair
   int64_t debug_timing = 0;
   int64_t part_rec_align = 0;    // partition records padded to a multiple of this many bytes (plans created after the option is set)
-  int64_t specialize = 2;        // plans created on this context run kernels specialised for them by runtime compilation (rtc.cpp):
+  int64_t specialize = 3;        // plans created on this context run kernels specialised for them by runtime compilation (rtc.cpp):
                                  // 1 = yes, compiled when a kernel shape is first launched (the first run; a later run only if run
-                                 // feedback moves a GroupAggregate to another execution shape); 2 (the default) = where such a kernel
-                                 // EXISTS already -- loaded in this process or stored in the on-disk cache by any earlier one -- and
-                                 // never compiled: a plan costs no compiler time unless it asks (1, or ssgpu_plan_specialize), and a
-                                 // service that asked once runs the compiled kernels from then on; 0 (and the legacy -1) = only
-                                 // plans that ask for it with ssgpu_plan_specialize.  Nothing is ever compiled at a hidden run count.
+                                 // feedback moves a GroupAggregate to another execution shape) -- the run WAITS for the compiler;
+                                 // 2 = where such a kernel EXISTS already -- loaded in this process or stored in the on-disk cache
+                                 // by any earlier one -- and never compiled; 3 (the default) = like 2, and a kernel that is missing
+                                 // when a run over >= specialize_min_rows rows wants it is compiled by the library's one worker
+                                 // thread: no run ever waits for the compiler, the plan's later runs (and, through the disk cache,
+                                 // later processes) pick the kernel up; 0 (and the legacy -1) = only plans that ask for it with
+                                 // ssgpu_plan_specialize.
+  int64_t specialize_min_rows = 1 << 22;   // option 3: runs over fewer input rows never start a compilation (their kernels take microseconds)
   bool filter_single_pass = false;   // materialising Filter: one pass with decoupled look-back instead of count pass + scan + store pass (plans created after the option is set)
 };
 
@@ -183,7 +186,18 @@ struct StageExec {
   // LDS size it was compiled for when that exceeds what a module-loaded kernel may ask for dynamically (0 = dynamic).
   struct RtcSlot {
     void* h = nullptr; bool tried = false; uint32_t static_lds = 0, tag = 0;   // tag: what else the kernel was compiled for (partition count, rows per thread)
-    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; tag = 0; }
+    // the kernel was being compiled when the slot asked (rtc.cpp: background compilation, or another plan's): the slot asks again --
+    // not at every launch, the request rebuilds the kernel's key -- until it has it
+    bool pending = false; std::chrono::steady_clock::time_point next_poll{};
+    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; tag = 0; pending = false; }
+    bool ask_again() {
+      if (!pending) return false;
+      const auto now = std::chrono::steady_clock::now();
+      if (now < next_poll) return false;
+      next_poll = now + std::chrono::milliseconds(20);
+      return true;
+    }
+    void asked() { pending = !h && ssgpu_rtc_pending(); if (pending) next_poll = std::chrono::steady_clock::now() + std::chrono::milliseconds(20); }
   };
   RtcSlot rtc_main;             // the main program's specialised kernel, h == NULL: interpreter
   std::vector<VmInstr> host_prog_main;   // the finalised main program (what rtc.cpp compiles)
@@ -304,7 +318,9 @@ struct ssgpu_plan {
   std::atomic<int> interrupted{0};
   int64_t n_runs = 0;           // runs started
   bool specialize = false;      // this plan's kernels are specialised by runtime compilation (ctx option at creation, or ssgpu_plan_specialize)
-  bool cached_only = false;     // ... but only where the kernel exists already (option specialize = 2): this plan never compiles
+  bool cached_only = false;     // ... but only where the kernel exists already (option specialize = 2 / 3): no run of this plan waits for the compiler
+  bool background = false;      // ... and what is missing is left to the worker thread (option 3) when a run of >= background_min_rows rows wants it
+  int64_t background_min_rows = 0;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
   // the (dom0, dom1) pairs of the most recent profiled runs: ev_dom0 / ev_dom1 alias the current pair, so
   // a caller can time many asynchronous runs and read every kernel duration afterwards, without a sync in between
@@ -435,6 +451,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "debug_timing") c->debug_timing = value;
   else if (k == "filter_single_pass") c->filter_single_pass = value != 0;
   else if (k == "specialize") c->specialize = value;
+  else if (k == "specialize_min_rows") c->specialize_min_rows = value < 0 ? 0 : value;
   else if (k == "part_rec_align") c->part_rec_align = value;
   else { c->err = "unknown option " + k; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   return SSGPU_OK;
@@ -655,7 +672,8 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   for (auto& a : p->result_schema) p->attr_names.push_back(a.name);
   p->result.plan = p;
   p->specialize = c->specialize > 0;
-  p->cached_only = c->specialize == 2;
+  p->cached_only = c->specialize == 2 || c->specialize == 3;
+  p->background = c->specialize == 3; p->background_min_rows = c->specialize_min_rows;
   if (c->device >= 0) {
     (void)hipEventCreate(&p->ev_begin); (void)hipEventCreate(&p->ev_end); g_events.fetch_add(2);
   }
@@ -743,13 +761,16 @@ void* rtc_for(ssgpu_plan* p, StageExec& ex, StageExec::RtcSlot& slot, const Prog
   if (!p->specialize) return nullptr;
   ssgpu_ctx* c = p->ctx;
   const uint32_t need_static = lds_bytes > 64u * 1024u ? ((lds_bytes + 15u) & ~15u) : 0u;
-  if (slot.tried && slot.static_lds == need_static) return slot.h;
+  if (slot.tried && slot.static_lds == need_static && !slot.ask_again()) return slot.h;
   if (slot.h) { (void)hipStreamSynchronize(c->stream); slot.drop(); }   // launches of the kernel being replaced may still be in flight
+  const bool was_pending = slot.pending;
   slot.tried = true; slot.static_lds = need_static;
   std::vector<uint32_t> sw, so; staged_table(prog, L, &sw, &so);
   std::string why;
   slot.h = ssgpu_rtc_specialize(c->device, host_prog.data(), n_instr, L.K, prog.uses_math, sw.data(), so.data(), (int)sw.size(), need_static, &why);
+  slot.asked();
   if (!slot.h && ex.rtc_why.empty()) ex.rtc_why = std::string(what) + why;
+  if (slot.h && was_pending) ex.rtc_why.clear();
   return slot.h;
 }
 
@@ -1697,11 +1718,12 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       const uint32_t hot_lds = fixed + SSGPU_HOT_SLOTS * entry;
       const int hgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
       H.n_parts = (unsigned int)hgrid;
-      if (p->specialize && !(ex.rtc_hot.tried && ex.rtc_hot.static_lds == hot_lds)) {
+      if (p->specialize && !(ex.rtc_hot.tried && ex.rtc_hot.static_lds == hot_lds && !ex.rtc_hot.ask_again())) {
         if (ex.rtc_hot.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_hot.drop(); }
         ex.rtc_hot.tried = true; ex.rtc_hot.static_lds = hot_lds;
         std::string why;
         ex.rtc_hot.h = ssgpu_rtc_specialize_part_agg(c->device, H.desc, (int)H.n_aggs, W, ng, any_cnt, hot_lds, &why, &S);
+        ex.rtc_hot.asked();
         if (!ex.rtc_hot.h && ex.rtc_why.empty()) ex.rtc_why = "heavy-hitter aggregation: " + why;
       }
       if (p->specialize && ex.rtc_hot.h && ex.rtc_hot.static_lds == hot_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_hot.h, H, S, hgrid, c->stream));
@@ -1724,11 +1746,12 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
         const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
         const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
         const uint32_t tag = NP * 8u + (uint32_t)R * 2u + (dense ? 1u : 0u);
-        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag)) {
+        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag && !ex.rtc_plain.ask_again())) {
           if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
           ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds; ex.rtc_plain.tag = tag;
           std::string why;
           ex.rtc_plain.h = ssgpu_rtc_specialize_pscat(c->device, S, R, lds, &why);
+          ex.rtc_plain.asked();
           if (!ex.rtc_plain.h && ex.rtc_why.empty()) ex.rtc_why = "plain partition scatter: " + why;
         }
         hs = ex.rtc_plain.h;
@@ -1772,22 +1795,24 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       // one whole-LDS workgroup per CU; tiles of 2048 rows dealt round-robin
       const int rgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
       A.n_parts = (unsigned int)rgrid;
-      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds && ex.rtc_resident.tag == (dense ? 1u : 0u))) {
+      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds && ex.rtc_resident.tag == (dense ? 1u : 0u) && !ex.rtc_resident.ask_again())) {
         if (ex.rtc_resident.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_resident.drop(); }
         ex.rtc_resident.tried = true; ex.rtc_resident.static_lds = agg_lds; ex.rtc_resident.tag = dense ? 1u : 0u;
         std::string why;
         ex.rtc_resident.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, &S, dense);
+        ex.rtc_resident.asked();
         if (!ex.rtc_resident.h && ex.rtc_why.empty()) ex.rtc_why = "resident group aggregation: " + why;
       }
       if (p->specialize && ex.rtc_resident.h && ex.rtc_resident.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_resident.h, A, S, rgrid, c->stream));
       else HIP_TRY(c, ssgpu_launch_group_resident(A, S, agg_lds, rgrid, c->stream));
     } else
-    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u))) {
+    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) && !ex.rtc_part.ask_again())) {
       // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
       if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
       ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = dense ? 1u : 0u;
       std::string why;
       ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, nullptr, dense);
+      ex.rtc_part.asked();
       if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
     if (resident) { /* launched above */ }
@@ -2613,7 +2638,7 @@ int fix_nan_minmax(ssgpu_plan* p) {
 int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial) {
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
-  ssgpu_rtc_cached_only(p->cached_only);   // (this thread's kernel requests during the run)
+  ssgpu_rtc_mode(!p->cached_only ? 0 : p->background && rows >= p->background_min_rows ? 2 : 1);   // (this thread's kernel requests during the run)
   p->nan_seen = false;
   if (p->deferred) {   // the previous run's feedback first: an overflow there puts the stage back into its adapting, synchronous form
     p->deferred = false;   // (that run's result is being replaced by this run: nothing to repeat)
@@ -2750,7 +2775,13 @@ int32_t ssgpu_plan_specialized(const ssgpu_plan* p) {
 }
 const char* ssgpu_plan_specialize_reason(const ssgpu_plan* p) {
   if (!p) return "";
-  for (auto& ex : p->exec) if (!ex.rtc_why.empty()) return ex.rtc_why.c_str();
+  for (auto& ex : p->exec) {
+    if (ex.rtc_why.empty()) continue;
+    // "being compiled": true while one of the stage's slots is still waiting for its kernel
+    if (ex.rtc_why.find("being compiled") != std::string::npos && !(ex.rtc_main.pending || ex.rtc_pscatter.pending || ex.rtc_plain.pending || ex.rtc_part.pending ||
+                                                                    ex.rtc_resident.pending || ex.rtc_hot.pending)) continue;
+    return ex.rtc_why.c_str();
+  }
   return "";
 }
 // Ask for specialised kernels NOW: the deterministic compile point.  Stages whose launch shape is known without a run
@@ -2762,8 +2793,8 @@ int ssgpu_plan_specialize(ssgpu_plan* p) {
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
   HIP_TRY(c, hipSetDevice(c->device));
   p->specialize = true;
-  if (p->cached_only) {          // kernels this plan looked for and did not find are compiled from now on
-    p->cached_only = false;
+  if (p->cached_only) {          // kernels this plan looked for and did not find are compiled from now on (one the worker is at: waited for)
+    p->cached_only = false; p->background = false;
     for (auto& ex : p->exec) {
       for (StageExec::RtcSlot* sl : {&ex.rtc_main, &ex.rtc_pscatter, &ex.rtc_plain, &ex.rtc_part, &ex.rtc_resident, &ex.rtc_hot}) if (!sl->h) sl->tried = false;
       ex.rtc_why.clear();

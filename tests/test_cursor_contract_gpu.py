@@ -184,8 +184,54 @@ def test_default_policy_never_compiles_and_modules_are_unloaded(gpu_ctx):
     del plan
 
 
+def test_background_compilation_never_blocks_a_run_and_arrives_later():
+    """Context option specialize = 3 (the library's default; the suite pins 0 through SSGPU_SPECIALIZE): a kernel that is in no cache is
+    compiled by the library's worker thread when a run over >= specialize_min_rows rows wants it.  The run that asked -- and the ones
+    after it -- use the interpreting kernel and do not wait; the plan picks the kernel up when it is there; results are the same
+    before and after; smaller runs never start a compilation."""
+    import time
+    from helpers import to_cols, assert_cols_equal
+    view = make_view(30011)
+    fresh = int(time.time() * 1000) % 1000003 + 2000003      # a constant no earlier run has compiled: the program is new to every cache
+    op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.MAX, "c", "mc").AddAggregation(ss.COUNT, "", "n"),
+                            ss.Filter(ss.Less(ss.NamedAttribute("a"), ss.ConstInt64(fresh)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    ctx = ss.Context(0)
+    ctx.set_option("specialize", 3)
+    before = ss.memory_stats()["rtc_compilations"]
+    small = ss.Plan(op, ctx)                       # 30011 rows < the default threshold of 2^22: nothing is compiled for it
+    small.run()
+    want = to_cols(small.fetch())
+    assert small.specialized() == 0 and "not in the kernel cache" in small.specialize_reason()
+    ctx.set_option("specialize_min_rows", 1000)
+    plan = ss.Plan(op, ctx)
+    t0 = time.time()
+    plan.run()
+    first_run_s = time.time() - t0
+    assert plan.specialized() == 0 and "being compiled in the background" in plan.specialize_reason(), plan.specialize_reason()
+    assert first_run_s < 1.0, first_run_s          # (a compilation takes seconds: the run did not wait for one)
+    assert_cols_equal(to_cols(plan.fetch()), want)
+    interpreted_runs = 0
+    deadline = time.time() + 180
+    while plan.specialized() == 0 and time.time() < deadline:
+        plan.run()                                 # interpreted meanwhile, same answer
+        interpreted_runs += 1
+        assert_cols_equal(to_cols(plan.fetch()), want)
+        time.sleep(0.2)
+    assert plan.specialized() == 1 and plan.specialize_reason() == "", (plan.specialize_reason(), interpreted_runs)
+    assert interpreted_runs >= 1 and ss.memory_stats()["rtc_compilations"] == before + 1
+    plan.run()
+    assert_cols_equal(to_cols(plan.fetch()), want)
+    again = ss.Plan(op, ctx)                       # the next plan with this program: found at once
+    again.run()
+    assert again.specialized() == 1 and ss.memory_stats()["rtc_compilations"] == before + 1
+    small.specialize()                             # the plan that missed it below the threshold asks: found, no second compilation
+    small.run()
+    assert small.specialized() == 1 and ss.memory_stats()["rtc_compilations"] == before + 1
+    assert_cols_equal(to_cols(small.fetch()), want)
+
+
 def test_default_policy_uses_compiled_kernels_where_they_exist_and_never_compiles():
-    """Context option specialize = 2 (the library's default; the suite pins 0 through SSGPU_SPECIALIZE): a plan finds a kernel
+    """Context option specialize = 2: a plan finds a kernel
     another plan compiled, never compiles itself, says why a stage stayed with the interpreting kernel, and compiles once asked."""
     import time
     from helpers import to_cols, assert_cols_equal
@@ -249,7 +295,10 @@ policy = sys.argv[1] if len(sys.argv) > 1 else "ask"
 if policy == "ask":
     plan = ss.Plan(op, ctx).specialize()
 else:                                   # the context's policy decides ("default": the library's own default, no option set)
-    if policy != "default":
+    if policy == "background":
+        ctx.set_option("specialize", 3)
+        ctx.set_option("specialize_min_rows", 1)
+    elif policy != "default":
         ctx.set_option("specialize", int(policy))
     plan = ss.Plan(op, ctx)
 plan.run()
@@ -276,9 +325,17 @@ def test_specialised_kernels_survive_the_process(tmp_path):
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
     cache = str(tmp_path / "rtc")
-    # the default policy (specialize = 2): compiled kernels where they exist, never a compilation
+    # the default policy (specialize = 3) below its row threshold: compiled kernels where they exist, never a compilation
     cold = child(cache, "default")
     assert cold["specialized"] == 0 and cold["compilations"] == 0 and cold["disk_hits"] == 0, cold
+    # a process that ENDS while the worker compiles for it waits for that compilation (seconds), exits cleanly, and leaves the code object
+    # to the next process
+    bg_cache = str(tmp_path / "rtc_bg")
+    leaving = child(bg_cache, "background")
+    assert leaving["specialized"] == 0 and leaving["disk_hits"] == 0 and leaving["row"] == cold["row"], leaving
+    assert len([f for f in os.listdir(bg_cache) if f.endswith(".co")]) == 1
+    heir = child(bg_cache, "background")
+    assert heir["specialized"] == 1 and heir["compilations"] == 0 and heir["disk_hits"] >= 1 and heir["row"] == cold["row"], heir
     first = child(cache)
     assert first["specialized"] == 1 and first["compilations"] >= 1 and first["disk_hits"] == 0, first
     files = [f for f in os.listdir(cache) if f.endswith(".co")]
