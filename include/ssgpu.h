@@ -110,7 +110,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 7
+#define SSGPU_ABI_VERSION 8
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -545,6 +545,19 @@ int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_c
 int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
                    int64_t rows, ssgpu_result** out);
 int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);
+/* CHUNKED STAGING of a host-resident input (ABI 8).  ssgpu_plan_run / _run_block want the whole input in device memory, and a
+ * block's uploads are waited for before the first kernel starts: copy and kernel run one after the other, and an input larger than
+ * the device's memory cannot run at all -- where the reference drains its child 1024 rows at a time (aggregate_scalar.cc:53-68).
+ * ssgpu_plan_run_host takes HOST columns (`data` / `is_null` are host pointers; pinned memory -- ssgpu_host_alloc -- for the
+ * copies to be asynchronous) of any length and moves them through two alternating sets of device columns of `chunk_rows` rows
+ * (<= 0: 2^24): chunk k + 1 is copied on the copy stream while the plan reads chunk k; every chunk leaves the partial state of
+ * the multi-GPU form, and ONE launch folds the states in row order and emits the row.  Device memory: 2 * chunk_rows rows.
+ * Same result as ssgpu_plan_run over the whole input (FIRST / LAST follow the global row order; floating sums are folded chunk
+ * by chunk in double-double like the shards of a multi-GPU job; a leading NaN of a floating MIN / MAX is skipped as across
+ * shards).  For plans whose only stage is a ScalarAggregate (over Filter / Compute / Project) -- the path's headline shape;
+ * SSGPU_ERROR_NOT_IMPLEMENTED otherwise.  The host columns must stay alive and unmodified until the call has returned AND the
+ * context's streams have drained (ssgpu_ctx_synchronize, or fetching the result). */
+int ssgpu_plan_run_host(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows, int64_t chunk_rows, ssgpu_result** out);
 /* The auxiliary input of a HASH_JOIN plan (rhs: DEVICE columns of the dimension table).  Stays
  * bound until replaced; the join index is rebuilt from it at the start of every run. */
 int ssgpu_plan_set_aux_input(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows);

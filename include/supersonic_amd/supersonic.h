@@ -565,11 +565,19 @@ class SortOrder {
 namespace internal {
 struct Context {
   ssgpu_ctx* ctx = nullptr;
+  // > 0: a ScalarAggregate over a host View of more rows than this is staged in chunks of this many rows (ssgpu_plan_run_host: the
+  // copy of chunk k + 1 overlaps the kernel over chunk k; inputs larger than device memory run) -- SetHostStagingChunkRows below
+  rowcount_t host_chunk_rows = 0;
   Context() { if (ssgpu_ctx_create(0, &ctx) != SSGPU_OK) ssgpu_ctx_create(-1, &ctx); }  // bind-only without a GPU
   ~Context() { ssgpu_ctx_destroy(ctx); }
   static Context& Get() { static Context c; return c; }
 };
 }  // namespace internal
+
+// Extension of this library (no counterpart in the reference, whose cursors stream by construction): ScalarAggregates over host
+// Views of more than `rows` rows are staged through the device in chunks of `rows` rows instead of being uploaded whole
+// (0 = off, the default).  Takes effect for cursors created afterwards.
+inline void SetHostStagingChunkRows(rowcount_t rows) { internal::Context::Get().host_chunk_rows = rows; }
 
 // Pinned-host allocator with an optional soft quota.  Allocate / BestEffortAllocate return NULL when the quota (or the
 // host) cannot serve `minimal` -- callers turn that into ERROR_MEMORY_EXCEEDED, as the reference's do.
@@ -799,6 +807,18 @@ class DeviceCursor : public Cursor {
     if (ran_) return run_rc_;
     ran_ = true;
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    const rowcount_t chunk = internal::Context::Get().host_chunk_rows;
+    if (!dev_ && !block_ && !aux_ && chunk > 0 && input_->row_count() > chunk && !internal::Dictionary::HasStrings(input_->schema())) {
+      // chunked staging straight from the scanned View (the reference drains its child block by block: aggregate_scalar.cc:53-68)
+      std::vector<ssgpu_column> cols(static_cast<size_t>(input_->schema().attribute_count()));
+      for (size_t i = 0; i < cols.size(); ++i) {
+        cols[i].data = input_->column(static_cast<int>(i)).data().raw();
+        cols[i].is_null = reinterpret_cast<const uint8_t*>(input_->column(static_cast<int>(i)).is_null());
+      }
+      int rc = ssgpu_plan_run_host(plan_, cols.data(), static_cast<int32_t>(cols.size()), static_cast<int64_t>(input_->row_count()), static_cast<int64_t>(chunk), &res_);
+      if (rc == SSGPU_OK) rc = ssgpu_ctx_synchronize(ctx);   // (the View's memory is the caller's: nothing may read it after Next)
+      if (rc != SSGPU_ERROR_NOT_IMPLEMENTED) return run_rc_ = rc;   // (not a single ScalarAggregate stage: the block path below)
+    }
     int rc = Stage(ctx);
     if (rc == SSGPU_OK) {
       if (dev_) rc = ssgpu_plan_run(plan_, dev_->columns.data(), static_cast<int32_t>(dev_->columns.size()), static_cast<int64_t>(dev_->row_count), &res_);

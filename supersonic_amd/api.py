@@ -1183,6 +1183,35 @@ class Plan(object):
         self._result = res
         return res
 
+    def run_host(self, view=None, chunk_rows=0):
+        """Chunked staging (ssgpu_plan_run_host): the HOST columns of `view` (default: the plan's input) travel through two alternating
+        sets of device columns of chunk_rows rows, chunk k + 1 being copied while chunk k is read -- inputs larger than device
+        memory run, and the copy overlaps the kernels (pinned numpy memory, e.g. torch's pin_memory, for the copies to be
+        asynchronous).  For plans whose only stage is a ScalarAggregate; NOT_IMPLEMENTED otherwise."""
+        view = view if view is not None else self.input
+        if isinstance(view, DeviceView):
+            raise SupersonicException(ERROR_INVALID_ARGUMENT_VALUE, "run_host takes a host View (device columns: run)")
+        schema = view.schema()
+        n = schema.attribute_count()
+        cols = (L.Column * max(n, 1))()
+        keep = []                                # the arrays whose memory the asynchronous copies read
+        for i in range(n):
+            col = view.column(i)
+            nulls = col.is_null
+            data = col.data
+            if schema.attribute(i).type() == STRING:
+                data = self.strings.encode(data, nulls)
+            data = np.ascontiguousarray(data, dtype=np.int32 if schema.attribute(i).type() == STRING else _NP[schema.attribute(i).type()])
+            nulls = None if nulls is None else np.ascontiguousarray(nulls, dtype=np.bool_)
+            keep.append((data, nulls))
+            cols[i].data = data.ctypes.data
+            cols[i].is_null = None if nulls is None else nulls.ctypes.data
+        res = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_plan_run_host(self.handle, cols, n, view.row_count(), int(chunk_rows), C.byref(res)))
+        self.ctx.synchronize()                   # (the host arrays may go once the streams have drained)
+        self._result = res
+        return res
+
     def run_partial(self, view, global_row_offset=0):
         cols, n, rows = self._columns_for(view)
         self.ctx.check(self.lib.ssgpu_plan_run_partial(self.handle, cols, n, rows, global_row_offset))

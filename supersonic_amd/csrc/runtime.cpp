@@ -336,6 +336,10 @@ struct ssgpu_plan {
   bool nan_seen = false;        // the last run met a NaN in a floating MIN / MAX (check_error_flags)
   const ssgpu_dict* dict = nullptr;   // the plan's STRING dictionary (ssgpu_plan_set_dict): CONCAT prints STRING inputs through it
   std::vector<ssgpu_column> last_cols; int64_t last_base = 0; bool last_partial = false;   // the last run's input (a deferred overflow repeats it)
+  // ssgpu_plan_run_host: two alternating sets of device columns the host rows are staged through, and the chunks' partial states
+  std::vector<DevBuf> host_stage_data[2], host_stage_nulls[2];
+  DevBuf host_states;
+  bool keep_error_flags = false;   // ... whose runs after the first leave the error words alone: an evaluation error of ANY chunk fails the run
   ssgpu_result result;
 };
 
@@ -2683,7 +2687,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   // (a GroupAggregate that is the plan's FIRST stage clears its word in its own init launch -- one fill launch less per run; later
   //  stages' words are read at the hand-offs before those stages run, so they are cleared here)
   for (size_t si = 0; si < p->exec.size(); ++si)
-    if (p->exec[si].error_flag.p && !(si == 0 && p->stages[si].kind == STAGE_GROUP_AGG)) HIP_TRY(c, hipMemsetAsync(p->exec[si].error_flag.p, 0, sizeof(uint32_t), c->stream));
+    if (p->exec[si].error_flag.p && !p->keep_error_flags && !(si == 0 && p->stages[si].kind == STAGE_GROUP_AGG)) HIP_TRY(c, hipMemsetAsync(p->exec[si].error_flag.p, 0, sizeof(uint32_t), c->stream));
   int64_t alg_bytes = 0;
   for (size_t si = 0; si < p->stages.size(); ++si) {
     if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
@@ -2882,6 +2886,79 @@ int ssgpu_plan_run_block(ssgpu_plan* p, const ssgpu_block* b, ssgpu_result** out
   std::vector<ssgpu_column> cols(b->schema.size());
   for (size_t i = 0; i < cols.size(); ++i) ssgpu_block_column(b, (int32_t)i, &cols[i]);
   return ssgpu_plan_run(p, cols.data(), (int32_t)cols.size(), b->rows, out);
+}
+
+// Chunked staging of a HOST input (ssgpu.h).  Chunk k + 1 is copied on the copy stream while the plan's kernel reads chunk k on the
+// compute stream; a staging set is written again only after the run that read it has finished (events, no host wait); every chunk
+// leaves its partial state (the multi-GPU form: run_plan(partial)), and ONE launch folds the states in chunk (= row) order and emits.
+int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows, int64_t chunk_rows, ssgpu_result** out) {
+  if (!p || (!host_cols && n_cols)) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  if (!(p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG)) {
+    c->err = "chunked staging serves plans whose only stage is a ScalarAggregate (over Filter / Compute / Project); other plans take device columns (ssgpu_block_upload + ssgpu_plan_run_block)";
+    return SSGPU_ERROR_NOT_IMPLEMENTED;
+  }
+  if (n_cols != (int)p->desc.input_schema.size() || rows < 0) { c->err = "ssgpu_plan_run_host: column count / row count do not fit the plan's input"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (chunk_rows <= 0) chunk_rows = 1 << 24;
+  const int64_t n_chunks = std::max<int64_t>(1, (rows + chunk_rows - 1) / chunk_rows);
+  const Schema& schema = p->desc.input_schema;
+  for (int b = 0; b < 2; ++b) { p->host_stage_data[b].resize((size_t)n_cols); p->host_stage_nulls[b].resize((size_t)n_cols); }
+  for (int32_t i = 0; i < n_cols; ++i) {
+    if (dtype_width(schema[i].dtype) == 0) { c->err = "ssgpu_plan_run_host: variable-length columns travel as dictionary codes (INT32)"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    if (!host_cols[i].data && rows) { c->err = "ssgpu_plan_run_host: a column without data"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  }
+  const size_t state_bytes = (size_t)SSGPU_STATE_ARRAYS * (size_t)std::max(p->stages[0].main.n_slots, 1) * 8;
+  HIP_TRY(c, p->host_states.ensure((size_t)n_chunks * state_bytes));
+  hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  auto drop_events = [&]() { for (int b = 0; b < 2; ++b) { if (uploaded[b]) (void)hipEventDestroy(uploaded[b]); if (consumed[b]) (void)hipEventDestroy(consumed[b]); } };
+  for (int b = 0; b < 2; ++b)
+    if (hipEventCreateWithFlags(&uploaded[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming) != hipSuccess) {
+      drop_events(); c->err = "hipEventCreate failed"; return SSGPU_ERROR_HIP;
+    }
+  const int64_t cap = std::min<int64_t>(chunk_rows, std::max<int64_t>(rows, 1));
+  auto upload = [&](int64_t k) -> int {     // chunk k into staging set k & 1, on the copy stream
+    const int b = (int)(k & 1);
+    const int64_t lo = k * chunk_rows, n = std::min<int64_t>(chunk_rows, rows - lo);
+    if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, consumed[b], 0));   // (the run over chunk k - 2 read this set)
+    for (int32_t i = 0; i < n_cols; ++i) {
+      const size_t w = (size_t)dtype_width(schema[i].dtype);
+      HIP_TRY(c, p->host_stage_data[b][(size_t)i].ensure((size_t)cap * w));
+      if (n > 0) HIP_TRY(c, hipMemcpyAsync(p->host_stage_data[b][(size_t)i].p, static_cast<const char*>(host_cols[i].data) + (size_t)lo * w, (size_t)n * w, hipMemcpyHostToDevice, c->copy_stream));
+      if (!schema[i].nullable) continue;
+      HIP_TRY(c, p->host_stage_nulls[b][(size_t)i].ensure((size_t)cap));
+      if (n <= 0) continue;
+      if (host_cols[i].is_null) HIP_TRY(c, hipMemcpyAsync(p->host_stage_nulls[b][(size_t)i].p, host_cols[i].is_null + lo, (size_t)n, hipMemcpyHostToDevice, c->copy_stream));
+      else HIP_TRY(c, hipMemsetAsync(p->host_stage_nulls[b][(size_t)i].p, 0, (size_t)n, c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(uploaded[b], c->copy_stream));
+    return SSGPU_OK;
+  };
+  int rc = upload(0);
+  std::vector<ssgpu_column> dev((size_t)n_cols);
+  for (int64_t k = 0; rc == SSGPU_OK && k < n_chunks; ++k) {
+    const int b = (int)(k & 1);
+    const int64_t lo = k * chunk_rows, n = std::max<int64_t>(0, std::min<int64_t>(chunk_rows, rows - lo));
+    if (k + 1 < n_chunks) { rc = upload(k + 1); if (rc != SSGPU_OK) break; }     // (queued BEFORE this chunk's run: the copy overlaps the kernel)
+    if (hipStreamWaitEvent(c->stream, uploaded[b], 0) != hipSuccess) { c->err = "hipStreamWaitEvent failed"; rc = SSGPU_ERROR_HIP; break; }
+    for (int32_t i = 0; i < n_cols; ++i) {
+      dev[(size_t)i].data = p->host_stage_data[b][(size_t)i].p;
+      dev[(size_t)i].is_null = schema[i].nullable ? p->host_stage_nulls[b][(size_t)i].as<uint8_t>() : nullptr;
+    }
+    p->keep_error_flags = k > 0;
+    rc = run_plan(p, dev.data(), n_cols, n, lo, true);
+    p->keep_error_flags = false;
+    if (rc != SSGPU_OK) break;
+    if (hipMemcpyAsync(p->host_states.as<char>() + (size_t)k * state_bytes, p->exec[0].state.p, state_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipEventRecord(consumed[b], c->stream) != hipSuccess) { c->err = "ssgpu_plan_run_host: queueing a chunk failed"; rc = SSGPU_ERROR_HIP; break; }
+  }
+  if (rc != SSGPU_OK) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream); drop_events(); return rc; }
+  drop_events();
+  rc = ssgpu_plan_fold_finalize(p, p->host_states.p, (int32_t)n_chunks, out);
+  if (rc != SSGPU_OK) return rc;
+  p->last_cols.clear(); p->last_rows = rows;     // (nothing of this run can be repeated from device columns: they were staging sets)
+  return settle_plan(p) == SSGPU_OK ? check_error_flags(p) : SSGPU_ERROR_HIP;
 }
 
 int ssgpu_plan_set_aux_input(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows) {

@@ -491,13 +491,50 @@ static void TestFileFormat(bool run) {
   CHECK(FileInput(schema, dir + "/missing.ssv").is_failure());
 }
 
+// Chunked staging (SetHostStagingChunkRows): a ScalarAggregate over a host View larger than the chunk is fed to the device chunk by
+// chunk -- the copy of one overlapping the kernel over the one before -- and gives the row the whole-block path gives
+static void TestHostStaging() {
+  const rowcount_t n = 100003;
+  TupleSchema schema;
+  schema.add_attribute(Attribute("a", INT64, NOT_NULLABLE));
+  schema.add_attribute(Attribute("x", DOUBLE, NULLABLE));
+  std::vector<int64_t> a(n); std::vector<double> x(n); std::vector<char> xn(n);
+  for (rowcount_t i = 0; i < n; ++i) { a[i] = static_cast<int64_t>((i * 7919) % 1000); x[i] = 0.25 * static_cast<double>(i % 4001) - 300.0; xn[i] = (i % 13) == 0; }
+  View v(schema);
+  v.mutable_column(0)->Reset(a.data(), nullptr); v.mutable_column(1)->Reset(x.data(), reinterpret_cast<const bool*>(xn.data())); v.set_row_count(n);
+  auto make = [&]() {
+    return ScalarAggregate((new AggregationSpecification)->AddAggregation(SUM, "a", "sa")->AddAggregation(COUNT, "x", "cx")->AddAggregation(MIN, "x", "mn")
+                               ->AddAggregation(SUM, "x", "sx")->AddAggregation(LAST, "x", "lx")->AddAggregation(FIRST, "a", "fa"),
+                           Filter(Greater(NamedAttribute("a"), ConstInt64(499)), ProjectAllAttributes(), ScanView(v)));
+  };
+  int64_t sa[2] = {0, 0}, fa[2] = {0, 0}; uint64_t cx[2] = {0, 0}; double mn[2] = {0, 0}, sx[2] = {0, 0}, lx[2] = {0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    SetHostStagingChunkRows(pass == 0 ? 0 : 4096);     // whole block, then 25 chunks
+    std::unique_ptr<Operation> op(make());
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (!c.is_success()) continue;
+    ResultView r = c->Next(Cursor::kDefaultRowCount);
+    CHECK(r.has_data());
+    if (!r.has_data()) continue;
+    CHECK_EQ(r.view().row_count(), static_cast<rowcount_t>(1));
+    sa[pass] = r.view().column(0).typed_data<int64_t>()[0]; cx[pass] = r.view().column(1).typed_data<uint64_t>()[0];
+    mn[pass] = r.view().column(2).typed_data<double>()[0]; sx[pass] = r.view().column(3).typed_data<double>()[0];
+    lx[pass] = r.view().column(4).typed_data<double>()[0]; fa[pass] = r.view().column(5).typed_data<int64_t>()[0];
+  }
+  SetHostStagingChunkRows(0);
+  CHECK_EQ(sa[0], sa[1]); CHECK_EQ(cx[0], cx[1]); CHECK(mn[0] == mn[1]); CHECK(sx[0] == sx[1]); CHECK(lx[0] == lx[1]); CHECK_EQ(fa[0], fa[1]);
+  int64_t want_sa = 0; for (rowcount_t i = 0; i < n; ++i) if (a[i] > 499) want_sa += a[i];
+  CHECK_EQ(sa[1], want_sa);
+}
+
 int main(int argc, char** argv) {
   const bool run = argc > 1 && !strcmp(argv[1], "run");
   Input in;
   TestBind(in);
   TestSeamsBind(in);
   TestFileFormat(run);
-  if (run) { TestRun(in); TestSeamsRun(in); }
+  if (run) { TestRun(in); TestSeamsRun(in); TestHostStaging(); }
   printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -437,3 +437,48 @@ def test_two_contexts_from_two_threads_do_not_disturb_each_other():
     for t in threads:
         t.join(600)
     assert not errors, errors
+
+
+# ---- chunked staging of a host-resident input (ssgpu_plan_run_host) ------------------------------------------------------------------
+@pytest.mark.parametrize("nullable", [False, True])
+@pytest.mark.parametrize("n,chunk", [(0, 1000), (1, 1000), (999, 1000), (1000, 1000), (1001, 1000), (70001, 4096), (70001, 1 << 20), (300007, 50000), (300007, 0)])
+def test_chunked_staging_of_a_host_input_gives_the_single_run_answer(gpu_ctx, n, chunk, nullable):
+    """The rows travel through two alternating sets of device columns, chunk k + 1 copied while chunk k is read; every chunk leaves a
+    partial state and one launch folds them in row order.  Same row as the oracle's -- FIRST / LAST by global row order, counts,
+    integer and (exactly representable) floating sums, MIN / MAX, under a Filter and a Compute -- whatever the chunking."""
+    from helpers import to_cols, assert_cols_equal
+    from oracle import oracle
+    view = make_view(n, nullable=nullable)
+    NA = ss.NamedAttribute
+    e = (ss.CompoundExpression().Add(NA("a")).AddAs("s", ss.Plus(NA("a"), NA("b"))).Add(NA("d")).Add(NA("d0")).Add(NA("d1")).Add(NA("u")).Add(NA("t")).Add(NA("k1")))
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "s", "ss").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.COUNT, "d0", "c0")
+            .AddAggregation(ss.MIN, "d", "mn").AddAggregation(ss.MAX, "d0", "mx").AddAggregation(ss.SUM, "d1", "s1").AddAggregation(ss.FIRST, "d0", "f0")
+            .AddAggregation(ss.LAST, "u", "lu").AddAggregation(ss.LAST, "t", "lt").AddAggregation(ss.FIRST, "k1", "fk"))
+    op = ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.Compute(e, ss.ScanView(view))))
+    _schema, want = oracle.run(op)
+    plan = ss.Plan(op, gpu_ctx)
+    for _ in range(2):                       # (the staging sets are reused by the second call)
+        plan.run_host(chunk_rows=chunk)
+        assert_cols_equal(to_cols(plan.fetch()), want, context="chunked staging n=%d chunk=%d" % (n, chunk))
+    plan.run()                               # and the ordinary form still runs on the same plan
+    assert_cols_equal(to_cols(plan.fetch()), want)
+
+
+def test_chunked_staging_reports_an_evaluation_error_of_any_chunk_and_refuses_other_plans(gpu_ctx):
+    NA = ss.NamedAttribute
+    n = 10000
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
+    b = np.ones(n, dtype=np.int64)
+    b[137] = 0                               # the FIRST chunk divides by zero; the later chunks must not wipe the flag
+    view = ss.View(schema, [np.arange(n), b])
+    op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "q", "sq"),
+                            ss.Compute(ss.CompoundExpression().AddAs("q", ss.DivideSignaling(NA("a"), NA("b"))), ss.ScanView(view)))
+    plan = ss.Plan(op, gpu_ctx)
+    with pytest.raises(ss.SupersonicException) as e:
+        plan.run_host(chunk_rows=1000)
+        plan.fetch()
+    assert e.value.return_code == ss.ERROR_EVALUATION_ERROR
+    group = ss.Plan(ss.GroupAggregate(ss.ProjectNamedAttribute("b"), ss.AggregationSpecification().AddAggregation(ss.SUM, "a", "s"), None, ss.ScanView(view)), gpu_ctx)
+    with pytest.raises(ss.SupersonicException) as e:
+        group.run_host(chunk_rows=1000)
+    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
