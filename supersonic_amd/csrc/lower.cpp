@@ -2032,8 +2032,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // (column_aggregator.cc:108-124 over the same result index), so the stored rows are sorted by ($rank, row id) and aggregated
           // as clusters of `$rank`; the host prints from that stage's input (Stage::ConcatCol::stage) behind the projection.
           if (any_concat && ci + 1 != chain.size()) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a CONCAT result cannot feed another operation on the device path (its strings are built on the host)");
-          const int64_t limit = op.option0 < 0 ? 0 : op.option0;
-          if (limit >= (1ll << 31)) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "max_unique_keys_in_result beyond 2^31 keys next to a DISTINCT aggregate");
+          const int64_t limit = op.option0 < 0 ? 0 : op.option0;     // (ranks are below 2^32 - 1: the stage clamps a larger limit to "never folds")
           GroupBinding g; SS_RETURN_IF_ERROR(bind_group_agg(d, op, pipe, &g));
           const size_t n_keys = g.kpos.size();
           Pipe pruned = prune_to_used(pipe, &g.kpos, &g.plans);

@@ -339,6 +339,7 @@ struct ssgpu_plan {
   // ssgpu_plan_run_host: two alternating sets of device columns the host rows are staged through, and the chunks' partial states
   std::vector<DevBuf> host_stage_data[2], host_stage_nulls[2];
   DevBuf host_states;
+  int64_t run_row_end = 0;         // row_id_base + rows of the run in progress: one past the largest row id a stage can meet
   bool keep_error_flags = false;   // ... whose runs after the first leave the error words alone: an evaluation error of ANY chunk fails the run
   ssgpu_result result;
 };
@@ -1186,7 +1187,8 @@ int segment_ids(ssgpu_ctx* c, const Stage& st, StageExec& ex, const InCols& in, 
 // row min(rank, limit).  One host round trip (the cluster count); launches and an LSD sort over the CLUSTERS, not the rows.
 int rank_columns(ssgpu_plan* p, const Stage& st, StageExec& ex, const InCols& in, ssgpu_column* rank_out, ssgpu_column* own_out) {
   ssgpu_ctx* c = p->ctx;
-  if (in.rows >= (1ll << 32)) { c->err = "DISTINCT aggregates under max_unique_keys_in_result: more than 2^32 input rows"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  // (the clusters are ordered by the 32-bit image of their first row id: every row id of this run has to fit)
+  if (p->run_row_end >= (1ll << 32) - 1) { c->err = "DISTINCT / CONCAT aggregates under max_unique_keys_in_result: row ids beyond 2^32"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
   ssgpu_column seg;
   int rc = segment_ids(c, st, ex, in, &seg);
   if (rc != SSGPU_OK) return rc;
@@ -1201,7 +1203,7 @@ int rank_columns(ssgpu_plan* p, const Stage& st, StageExec& ex, const InCols& in
   rc = sort_rows_by_u32(p, ex, ex.rank_first.as<uint32_t>(), n_seg, &sorted);
   if (rc != SSGPU_OK) return rc;
   HIP_TRY(c, ssgpu_launch_rank_scatter(sorted, n_seg, ex.rank_of_seg.as<uint32_t>(), c->stream));
-  HIP_TRY(c, ssgpu_launch_rank_rows(ex.seg_id.as<uint32_t>(), ex.rank_of_seg.as<uint32_t>(), n, (uint32_t)st.rank_limit, ex.rank_row.as<uint32_t>(),
+  HIP_TRY(c, ssgpu_launch_rank_rows(ex.seg_id.as<uint32_t>(), ex.rank_of_seg.as<uint32_t>(), n, (uint32_t)std::min<int64_t>(st.rank_limit, 0xFFFFFFFFll), ex.rank_row.as<uint32_t>(),
                                     ex.rank_own.as<uint8_t>(), c->stream));
   p->counters.n_launches += 3;
   rank_out->data = ex.rank_row.p; rank_out->is_null = nullptr;
@@ -2643,6 +2645,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
   ssgpu_rtc_mode(!p->cached_only ? 0 : p->background && rows >= p->background_min_rows ? 2 : 1);   // (this thread's kernel requests during the run)
+  p->run_row_end = row_id_base + rows;
   p->nan_seen = false;
   if (p->deferred) {   // the previous run's feedback first: an overflow there puts the stage back into its adapting, synchronous form
     p->deferred = false;   // (that run's result is being replaced by this run: nothing to repeat)
