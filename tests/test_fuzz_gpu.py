@@ -58,7 +58,7 @@ def test_random_high_cardinality_group_aggregate(seed, partition):
 
 
 @pytest.mark.parametrize("n", [1537, 20011])
-@pytest.mark.parametrize("seed", range(4000, 4250))
+@pytest.mark.parametrize("seed", range(4000, 4000 + int(os.environ.get("SS_FUZZ_ORDERED_SEEDS", "250"))))
 def test_random_ordered_aggregates(gpu_ctx, seed, n):
     # the round-4 shapes: DISTINCT next to FIRST / LAST (scalar, grouped, clustered), key limits with FIRST / LAST and keys of any
     # width, DISTINCT inside AggregateClusters -- every one carries the input order along as a stored column
@@ -74,7 +74,7 @@ def test_random_ordered_aggregates(gpu_ctx, seed, n):
 
 
 @pytest.mark.parametrize("n", [1537, 20011])
-@pytest.mark.parametrize("seed", range(6000, 6200))
+@pytest.mark.parametrize("seed", range(6000, 6000 + int(os.environ.get("SS_FUZZ_LIMIT_SEEDS", "200"))))   # SS_FUZZ_LIMIT_SEEDS=3000 for a longer hunt
 def test_random_distinct_aggregates_under_a_key_limit(gpu_ctx, seed, n):
     # DISTINCT under max_unique_keys_in_result: one seen-value set per RESULT row (column_aggregator.cc:308-376 over the row index
     # row_hash_set.cc:500-511 answers) -- the device stores every input row's result row and aggregates by it
@@ -90,7 +90,7 @@ def test_random_distinct_aggregates_under_a_key_limit(gpu_ctx, seed, n):
 
 
 @pytest.mark.parametrize("n", [1537, 20011])
-@pytest.mark.parametrize("seed", range(5000, 5150))
+@pytest.mark.parametrize("seed", range(5000, 5000 + int(os.environ.get("SS_FUZZ_SEQ_SEEDS", "150"))))
 def test_random_sequential_sums(gpu_ctx, seed, n):
     # SUM of floating inputs into integer results: the reference's row-after-row arithmetic, bit for bit
     view = make_view(n, seed)
