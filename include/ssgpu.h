@@ -558,6 +558,18 @@ int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_resul
  * SSGPU_ERROR_NOT_IMPLEMENTED otherwise.  The host columns must stay alive and unmodified until the call has returned AND the
  * context's streams have drained (ssgpu_ctx_synchronize, or fetching the result). */
 int ssgpu_plan_run_host(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows, int64_t chunk_rows, ssgpu_result** out);
+/* The PUSH form of the same, for a caller that meets its input the way the reference's cursors do -- a child's Next() handing out
+ * Views of <= 1024 rows that are only valid until the next Next() (cursor.h:131-148, aggregate_scalar.cc:53-68):
+ *     ssgpu_plan_stream_begin(plan, chunk_rows)            (<= 0: 2^22 rows per staging set)
+ *     ssgpu_plan_stream_push(plan, host_cols, n, rows)     any number of times, any number of rows; the rows are COPIED into a pinned
+ *                                                          staging set before the call returns (the caller's memory is free again);
+ *                                                          a full set is sent to the device and the plan runs over it while the
+ *                                                          caller fills the other one
+ *     ssgpu_plan_stream_finish(plan, &result)              the partly filled set, the fold of the chunks' states, the result row
+ * Same plans, same result as ssgpu_plan_run_host.  A failed push / finish ends the stream; begin on an open stream drops it. */
+int ssgpu_plan_stream_begin(ssgpu_plan* plan, int64_t chunk_rows);
+int ssgpu_plan_stream_push(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows);
+int ssgpu_plan_stream_finish(ssgpu_plan* plan, ssgpu_result** out);
 /* The auxiliary input of a HASH_JOIN plan (rhs: DEVICE columns of the dimension table).  Stays
  * bound until replaced; the join index is rebuilt from it at the start of every run. */
 int ssgpu_plan_set_aux_input(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows);

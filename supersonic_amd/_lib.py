@@ -173,6 +173,9 @@ SYMBOLS = [
     ("ssgpu_plan_run", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_plan_run_block", C.c_int, [P, P, C.POINTER(P)]),
     ("ssgpu_plan_run_host", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64, C.POINTER(P)]),
+    ("ssgpu_plan_stream_begin", C.c_int, [P, C.c_int64]),
+    ("ssgpu_plan_stream_push", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64]),
+    ("ssgpu_plan_stream_finish", C.c_int, [P, C.POINTER(P)]),
     ("ssgpu_plan_set_aux_input", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64]),
     ("ssgpu_interrupt", None, [P]),
     ("ssgpu_plan_run_partial", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64]),

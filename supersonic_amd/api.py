@@ -1212,6 +1212,31 @@ class Plan(object):
         self._result = res
         return res
 
+    def stream(self, views, chunk_rows=0):
+        """The push form of chunked staging (ssgpu_plan_stream_begin / _push / _finish): `views` is an iterable of host Views with the
+        plan's input schema -- the blocks a child cursor hands out -- each of which may be overwritten as soon as the next is asked for."""
+        self.ctx.check(self.lib.ssgpu_plan_stream_begin(self.handle, int(chunk_rows)))
+        for view in views:
+            schema = view.schema()
+            n = schema.attribute_count()
+            cols = (L.Column * max(n, 1))()
+            keep = []
+            for i in range(n):
+                col = view.column(i)
+                data, nulls = col.data, col.is_null
+                if schema.attribute(i).type() == STRING:
+                    data = self.strings.encode(data, nulls)
+                data = np.ascontiguousarray(data, dtype=np.int32 if schema.attribute(i).type() == STRING else _NP[schema.attribute(i).type()])
+                nulls = None if nulls is None else np.ascontiguousarray(nulls, dtype=np.bool_)
+                keep.append((data, nulls))
+                cols[i].data = data.ctypes.data
+                cols[i].is_null = None if nulls is None else nulls.ctypes.data
+            self.ctx.check(self.lib.ssgpu_plan_stream_push(self.handle, cols, n, view.row_count()))
+        res = C.c_void_p()
+        self.ctx.check(self.lib.ssgpu_plan_stream_finish(self.handle, C.byref(res)))
+        self._result = res
+        return res
+
     def run_partial(self, view, global_row_offset=0):
         cols, n, rows = self._columns_for(view)
         self.ctx.check(self.lib.ssgpu_plan_run_partial(self.handle, cols, n, rows, global_row_offset))

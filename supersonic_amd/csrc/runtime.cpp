@@ -339,6 +339,22 @@ struct ssgpu_plan {
   // ssgpu_plan_run_host: two alternating sets of device columns the host rows are staged through, and the chunks' partial states
   std::vector<DevBuf> host_stage_data[2], host_stage_nulls[2];
   DevBuf host_states;
+  // ssgpu_plan_stream_*: the same staging sets fed from a pinned pair the pushed rows are copied into (the caller's Views are only valid
+  // until its child's next Next)
+  struct HostStream {
+    bool open = false; int rc = SSGPU_OK;
+    int64_t chunk_rows = 0, fill = 0, pushed = 0, chunks = 0; int cur = 0;
+    std::vector<PinnedBuf> pin_data[2], pin_nulls[2];
+    hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    bool in_flight[2] = {false, false};
+    void drop_events() {
+      for (int b = 0; b < 2; ++b) {
+        if (uploaded[b]) (void)hipEventDestroy(uploaded[b]);
+        if (consumed[b]) (void)hipEventDestroy(consumed[b]);
+        uploaded[b] = consumed[b] = nullptr; in_flight[b] = false;
+      }
+    }
+  } host_stream;
   int64_t run_row_end = 0;         // row_id_base + rows of the run in progress: one past the largest row id a stage can meet
   bool keep_error_flags = false;   // ... whose runs after the first leave the error words alone: an evaluation error of ANY chunk fails the run
   ssgpu_result result;
@@ -692,6 +708,7 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   if (!p) return;
   if (p->ctx && p->ctx->device >= 0) {
     (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->host_stream.open) { (void)hipStreamSynchronize(p->ctx->copy_stream); p->host_stream.drop_events(); p->host_stream.open = false; }   // (a stream nobody finished)
     if (p->ev_begin) { (void)hipEventDestroy(p->ev_begin); g_events.fetch_sub(1); }
     if (p->ev_end) { (void)hipEventDestroy(p->ev_end); g_events.fetch_sub(1); }
     for (int i = 0; i < ssgpu_plan::kEventRing; ++i) {
@@ -2961,6 +2978,119 @@ int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_
   rc = ssgpu_plan_fold_finalize(p, p->host_states.p, (int32_t)n_chunks, out);
   if (rc != SSGPU_OK) return rc;
   p->last_cols.clear(); p->last_rows = rows;     // (nothing of this run can be repeated from device columns: they were staging sets)
+  return settle_plan(p) == SSGPU_OK ? check_error_flags(p) : SSGPU_ERROR_HIP;
+}
+
+// ---- the push form of chunked staging: begin / push / push ... / finish (ssgpu.h) --------------------------------------------------------
+static int stream_abort(ssgpu_plan* p, int rc) {
+  ssgpu_ctx* c = p->ctx;
+  (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream);
+  p->host_stream.drop_events(); p->host_stream.open = false; p->host_stream.rc = rc; p->keep_error_flags = false;
+  return rc;
+}
+// the filled part of pinned set b -> device set b -> one partial run -> its state appended to host_states
+static int stream_flush(ssgpu_plan* p, int b, int64_t n) {
+  ssgpu_ctx* c = p->ctx; ssgpu_plan::HostStream& hs = p->host_stream;
+  const Schema& schema = p->desc.input_schema;
+  const int32_t n_cols = (int32_t)schema.size();
+  if (hs.in_flight[b]) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, hs.consumed[b], 0));   // (the run that read device set b)
+  for (int32_t i = 0; i < n_cols; ++i) {
+    const size_t w = (size_t)dtype_width(schema[i].dtype);
+    HIP_TRY(c, p->host_stage_data[b][(size_t)i].ensure((size_t)hs.chunk_rows * w));
+    if (n > 0) HIP_TRY(c, hipMemcpyAsync(p->host_stage_data[b][(size_t)i].p, hs.pin_data[b][(size_t)i].p, (size_t)n * w, hipMemcpyHostToDevice, c->copy_stream));
+    if (!schema[i].nullable) continue;
+    HIP_TRY(c, p->host_stage_nulls[b][(size_t)i].ensure((size_t)hs.chunk_rows));
+    if (n > 0) HIP_TRY(c, hipMemcpyAsync(p->host_stage_nulls[b][(size_t)i].p, hs.pin_nulls[b][(size_t)i].p, (size_t)n, hipMemcpyHostToDevice, c->copy_stream));
+  }
+  HIP_TRY(c, hipEventRecord(hs.uploaded[b], c->copy_stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, hs.uploaded[b], 0));
+  std::vector<ssgpu_column> dev((size_t)n_cols);
+  for (int32_t i = 0; i < n_cols; ++i) {
+    dev[(size_t)i].data = p->host_stage_data[b][(size_t)i].p;
+    dev[(size_t)i].is_null = schema[i].nullable ? p->host_stage_nulls[b][(size_t)i].as<uint8_t>() : nullptr;
+  }
+  p->keep_error_flags = hs.chunks > 0;
+  const int rc = run_plan(p, dev.data(), n_cols, n, hs.pushed - n, true);
+  p->keep_error_flags = false;
+  if (rc != SSGPU_OK) return rc;
+  const size_t state_bytes = (size_t)SSGPU_STATE_ARRAYS * (size_t)std::max(p->stages[0].main.n_slots, 1) * 8;
+  if ((size_t)(hs.chunks + 1) * state_bytes > p->host_states.cap) {     // the states so far move into a larger buffer (they are a few hundred bytes each)
+    DevBuf bigger;
+    HIP_TRY(c, bigger.ensure(std::max<size_t>((size_t)(hs.chunks + 1) * state_bytes * 2, 64 * state_bytes)));
+    if (hs.chunks) HIP_TRY(c, hipMemcpyAsync(bigger.p, p->host_states.p, (size_t)hs.chunks * state_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::swap(bigger.p, p->host_states.p); std::swap(bigger.cap, p->host_states.cap);
+  }
+  HIP_TRY(c, hipMemcpyAsync(p->host_states.as<char>() + (size_t)hs.chunks * state_bytes, p->exec[0].state.p, state_bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(hs.consumed[b], c->stream));
+  hs.in_flight[b] = true;
+  ++hs.chunks;
+  return SSGPU_OK;
+}
+int ssgpu_plan_stream_begin(ssgpu_plan* p, int64_t chunk_rows) {
+  if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  if (!(p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG)) {
+    c->err = "chunked staging serves plans whose only stage is a ScalarAggregate (over Filter / Compute / Project); other plans take device columns (ssgpu_block_upload + ssgpu_plan_run_block)";
+    return SSGPU_ERROR_NOT_IMPLEMENTED;
+  }
+  const Schema& schema = p->desc.input_schema;
+  for (auto& a : schema) if (dtype_width(a.dtype) == 0) { c->err = "ssgpu_plan_stream_begin: variable-length columns travel as dictionary codes (INT32)"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  ssgpu_plan::HostStream& hs = p->host_stream;
+  if (hs.open) (void)stream_abort(p, SSGPU_OK);     // (an unfinished stream is dropped)
+  hs.chunk_rows = chunk_rows > 0 ? chunk_rows : (1 << 22); hs.fill = 0; hs.pushed = 0; hs.chunks = 0; hs.cur = 0; hs.rc = SSGPU_OK;
+  for (int b = 0; b < 2; ++b) {
+    p->host_stage_data[b].resize(schema.size()); p->host_stage_nulls[b].resize(schema.size());
+    hs.pin_data[b].resize(schema.size()); hs.pin_nulls[b].resize(schema.size());
+    for (size_t i = 0; i < schema.size(); ++i) {
+      HIP_TRY(c, hs.pin_data[b][i].ensure((size_t)hs.chunk_rows * (size_t)dtype_width(schema[i].dtype)));
+      if (schema[i].nullable) HIP_TRY(c, hs.pin_nulls[b][i].ensure((size_t)hs.chunk_rows));
+    }
+    if (hipEventCreateWithFlags(&hs.uploaded[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&hs.consumed[b], hipEventDisableTiming) != hipSuccess) {
+      hs.drop_events(); c->err = "hipEventCreate failed"; return SSGPU_ERROR_HIP;
+    }
+  }
+  hs.open = true;
+  return SSGPU_OK;
+}
+int ssgpu_plan_stream_push(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows) {
+  if (!p || !p->host_stream.open) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx; ssgpu_plan::HostStream& hs = p->host_stream;
+  const Schema& schema = p->desc.input_schema;
+  if (n_cols != (int32_t)schema.size() || rows < 0 || (!host_cols && rows)) { c->err = "ssgpu_plan_stream_push: column count / row count do not fit the plan's input"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  for (int64_t done = 0; done < rows;) {
+    if (hs.fill == 0 && hs.in_flight[hs.cur]) HIP_TRY(c, hipEventSynchronize(hs.uploaded[hs.cur]));   // (the copy that last read this pinned set)
+    const int64_t n = std::min<int64_t>(rows - done, hs.chunk_rows - hs.fill);
+    for (int32_t i = 0; i < n_cols; ++i) {
+      const size_t w = (size_t)dtype_width(schema[i].dtype);
+      memcpy(static_cast<char*>(hs.pin_data[hs.cur][(size_t)i].p) + (size_t)hs.fill * w, static_cast<const char*>(host_cols[i].data) + (size_t)done * w, (size_t)n * w);
+      if (!schema[i].nullable) continue;
+      if (host_cols[i].is_null) memcpy(static_cast<char*>(hs.pin_nulls[hs.cur][(size_t)i].p) + hs.fill, host_cols[i].is_null + done, (size_t)n);
+      else memset(static_cast<char*>(hs.pin_nulls[hs.cur][(size_t)i].p) + hs.fill, 0, (size_t)n);
+    }
+    hs.fill += n; hs.pushed += n; done += n;
+    if (hs.fill == hs.chunk_rows) {
+      const int rc = stream_flush(p, hs.cur, hs.fill);
+      if (rc != SSGPU_OK) return stream_abort(p, rc);
+      hs.cur ^= 1; hs.fill = 0;
+    }
+  }
+  return SSGPU_OK;
+}
+int ssgpu_plan_stream_finish(ssgpu_plan* p, ssgpu_result** out) {
+  if (!p || !p->host_stream.open) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_plan::HostStream& hs = p->host_stream;
+  if (hs.fill > 0 || hs.chunks == 0) {     // the last, partly filled set (or no row at all: the one row of an empty input)
+    const int rc = stream_flush(p, hs.cur, hs.fill);
+    if (rc != SSGPU_OK) return stream_abort(p, rc);
+  }
+  const int64_t n_chunks = hs.chunks, rows = hs.pushed;
+  hs.drop_events(); hs.open = false;
+  int rc = ssgpu_plan_fold_finalize(p, p->host_states.p, (int32_t)n_chunks, out);
+  if (rc != SSGPU_OK) return rc;
+  p->last_cols.clear(); p->last_rows = rows;
   return settle_plan(p) == SSGPU_OK ? check_error_flags(p) : SSGPU_ERROR_HIP;
 }
 

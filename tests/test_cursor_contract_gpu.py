@@ -482,3 +482,39 @@ def test_chunked_staging_reports_an_evaluation_error_of_any_chunk_and_refuses_ot
     with pytest.raises(ss.SupersonicException) as e:
         group.run_host(chunk_rows=1000)
     assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
+
+
+@pytest.mark.parametrize("n,block,chunk", [(0, 1024, 4096), (1, 1024, 4096), (70001, 1024, 4096), (70001, 1000, 4096), (70001, 8192, 1000), (300007, 1024, 1 << 16), (300007, 77777, 0)])
+def test_push_form_of_chunked_staging_takes_the_blocks_of_a_child_cursor(gpu_ctx, n, block, chunk):
+    """ssgpu_plan_stream_begin / _push / _finish: the input arrives as the reference's cursors hand it out -- blocks of <= 1024 rows in ONE
+    buffer that the next block overwrites (cursor.h:131-148) -- is copied into pinned staging sets, and a full set runs on the device while
+    the other one fills.  Same row as the oracle's over the whole input."""
+    from helpers import to_cols, assert_cols_equal
+    from oracle import oracle
+    view = make_view(n, nullable=True)
+    NA = ss.NamedAttribute
+    spec = (ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "sb").AddAggregation(ss.COUNT, "", "n").AddAggregation(ss.COUNT, "d0", "c0")
+            .AddAggregation(ss.MIN, "d", "mn").AddAggregation(ss.MAX, "d0", "mx").AddAggregation(ss.SUM, "d1", "s1").AddAggregation(ss.FIRST, "d0", "f0")
+            .AddAggregation(ss.LAST, "u", "lu").AddAggregation(ss.LAST, "t", "lt"))
+    op = ss.ScalarAggregate(spec, ss.Filter(ss.Greater(NA("b"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    _schema, want = oracle.run(op)
+    schema = view.schema()
+    # the child's ONE output block: every Next() overwrites it
+    buf = [(np.zeros(block, dtype=view.column(i).data.dtype), None if view.column(i).is_null is None else np.zeros(block, dtype=bool)) for i in range(view.column_count())]
+
+    def blocks():
+        for lo in range(0, n, block):
+            m = min(block, n - lo)
+            for i, (d, z) in enumerate(buf):
+                d[:m] = view.column(i).data[lo:lo + m]
+                if z is not None:
+                    z[:m] = view.column(i).is_null[lo:lo + m]
+            yield ss.View(schema, [ss.Column(d[:m], None if z is None else z[:m]) for (d, z) in buf], m)
+            for d, _z in buf:
+                d[:m] = 0                    # (the memory is the child's again)
+    plan = ss.Plan(op, gpu_ctx)
+    for _ in range(2):
+        plan.stream(blocks(), chunk_rows=chunk)
+        assert_cols_equal(to_cols(plan.fetch()), want, context="push staging n=%d block=%d chunk=%d" % (n, block, chunk))
+    plan.run()
+    assert_cols_equal(to_cols(plan.fetch()), want)
