@@ -27,6 +27,51 @@ def device_executor(ctx):
 RESIDUAL = "$res"    # suffix of the hidden column that carries a DOUBLE sum's residual across shards
 
 
+class _HostBounce(object):
+    """torch.distributed for DEVICE tensors over a backend that only moves host memory (gloo): every collective of the device
+    drivers goes device -> host -> collective -> device.  It exists for ONE purpose: several ranks on ONE GPU (RCCL refuses two
+    ranks of a device), so that the drivers' kernels -- pack / route / unpack, the dense fold -- meet images that a second real
+    process produced (tests/test_two_ranks_one_gpu.py).  A job on RCCL never comes here."""
+
+    def __init__(self, dist):
+        self._dist = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def __getattr__(self, name):
+        return getattr(self._dist, name)
+
+    def all_reduce(self, tensor, op=None, group=None):
+        host = tensor.cpu()
+        self._dist.all_reduce(host, op=op, group=group)
+        tensor.copy_(host)
+
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None, group=None):
+        host = output.cpu()
+        self._dist.all_to_all_single(host, input.cpu(), output_split_sizes, input_split_sizes, group=group)
+        output.copy_(host)
+
+    def all_gather_into_tensor(self, output, input, group=None):
+        world = self._dist.get_world_size(group)
+        parts = [input.cpu().clone() for _ in range(world)]
+        self._dist.all_gather(parts, input.cpu(), group=group)
+        import torch
+        output.copy_(torch.cat([p.reshape(-1) for p in parts]).view(output.dtype).reshape(output.shape))
+
+    def all_gather(self, outputs, input, group=None):
+        if not input.is_cuda:
+            return self._dist.all_gather(outputs, input, group=group)
+        parts = [o.cpu() for o in outputs]
+        self._dist.all_gather(parts, input.cpu(), group=group)
+        for o, p in zip(outputs, parts):
+            o.copy_(p)
+
+
+def _dist_for(group):
+    """torch.distributed as the device drivers use it: itself on RCCL, through host copies on gloo (_HostBounce)."""
+    import torch.distributed as dist
+    return _HostBounce(dist) if dist.get_backend(group) == "gloo" else dist
+
+
 def _shard_spec(spec, input_schema):
     """The specification a SHARD runs: `spec` plus, behind every DOUBLE SUM, the SUM_RESIDUAL of the same column
     (include/ssgpu.h) -- the partial sum travels as the double-double pair (s, e), so that the cross-shard total is the
@@ -133,6 +178,8 @@ def _all_gather_view(view, group, device):
     import torch
     import torch.distributed as dist
 
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"                     # (host Views through a host backend: no bounce over the device)
     world = dist.get_world_size(group)
     rows = torch.tensor([view.row_count()], dtype=torch.int64, device=device)
     all_rows = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
@@ -524,7 +571,7 @@ def device_sharded_sort(ctx, sort_order, local_view, group=None, samples_per_ran
     local_view: this rank's shard (host View or DeviceView).  Returns (plan, DeviceView): the rank's
     slice of the global order as device columns owned by `plan` (fetch with plan.fetch())."""
     import torch
-    import torch.distributed as dist
+    dist = _dist_for(group)
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -631,7 +678,7 @@ class DeviceShardedGroupAggregate(object):
         work and link traffic per rank shrink with the world size (`gather_result()` collects the full table when wanted)."""
         import torch
         import torch.distributed as dist
-        self.torch, self.dist = torch, dist
+        self.torch, self.dist = torch, _dist_for(group)
         self.ctx, self.group = ctx, group
         ctx.set_option("lazy_feedback", 1)       # a step never waits for the host; the job keeps its shard's columns alive (ssgpu.h: INPUT LIFETIME)
         assert exchange in ("all_gather", "key_range")
@@ -833,7 +880,7 @@ class DenseShardedGroupAggregate(object):
 
     def __init__(self, backend, group=None):
         import torch.distributed as dist
-        self.dist = dist
+        self.dist = _dist_for(group)      # (host tensors of the CPU tests pass through it unchanged)
         self.backend, self.group = backend, group
         self.world = dist.get_world_size(group)
         self.layout = None
