@@ -148,3 +148,30 @@ def test_two_processes_share_the_gpu_and_exchange_real_images(world):
     merged = [np.concatenate([results[r]["sort"][i][0] for r in range(world)]) for i in range(6)]
     assert np.array_equal(merged[4], want_sorted[4][0]) and np.array_equal(merged[0], want_sorted[0][0])
     assert sorted(merged[1].tolist()) == sorted(want_sorted[1][0].tolist())
+
+
+@pytest.mark.parametrize("query,extra", [("wide", []), ("group", []), ("group", ["--exchange", "key_range"]), ("wide", ["--scaling", "strong"])])
+def test_bench_py_takes_its_multi_rank_path_with_two_ranks_on_one_gpu(query, extra):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with SSGPU_BENCH_SHARE_GPU=1: both
+    ranks on device 0, collectives over gloo through the host.  The timings mean nothing; the line must come out, carry both regimes and
+    -- for the GroupAggregate -- the checked group count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SSGPU_BENCH_SHARE_GPU="1")
+    env.pop("SSGPU_SPECIALIZE", None); env.pop("SSGPU_GROUP_DENSE", None)      # (the library's own defaults, as in the driver's run)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "1000000", "--query", query, "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                   # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "development_mode" in line["config"]
+    assert "roofline" in line and line["roofline"]["kernel_ms"] > 0
+    if query == "group":
+        assert line["result_row"]["groups"] > 90000 and line["config"]["collectives_per_step"] == 1
+    if "--scaling" not in extra:
+        assert set(line["regimes"]) == {"weak", "strong"}
