@@ -1715,7 +1715,7 @@ def test_group_aggregate_max_unique_keys_reference_vector_and_refusals(gpu_ctx):
 
 
 @pytest.mark.parametrize("limit", [0, 1, 2, 7, 299, 300, 5000, 10 ** 12])
-@pytest.mark.parametrize("n", [9, 1025, 100003])
+@pytest.mark.parametrize("n", [0, 1, 9, 1025, 100003])
 def test_group_aggregate_distinct_under_max_unique_keys_in_result(gpu_ctx, n, limit):
     """DISTINCT aggregates under a key limit.  The reference's DISTINCT aggregator keeps one set of seen values per RESULT ROW
     (column_aggregator.cc:308-376), and beyond the limit every new key is answered with the last row (row_hash_set.cc:500-511): the
