@@ -455,7 +455,8 @@ int ssgpu_plan_set_memory_limit(ssgpu_plan* plan, int64_t bytes);
  * library's kernel sources, the plan's program / descriptors, the compiler options, the architecture, the HIP runtime
  * version): a second process loads them in milliseconds instead of compiling for seconds (ssgpu_memory_stats:
  * rtc_disk_hits vs rtc_compilations).  Directory: $SSGPU_RTC_CACHE_DIR (empty string = no disk cache), else
- * $XDG_CACHE_HOME/ssgpu/rtc, else $HOME/.cache/ssgpu/rtc; files are written atomically and checksummed.
+ * $XDG_CACHE_HOME/ssgpu/rtc, else $HOME/.cache/ssgpu/rtc; files are written atomically and checksummed.  The directory is bounded:
+ * after a store the least recently used code objects go until it is below 3/4 of $SSGPU_RTC_CACHE_MAX_MB (default 512; <= 0: no limit).
  * "specialize" = 2: a plan runs the compiled kernel of a stage where one EXISTS -- loaded in this process, or in the on-disk
  * cache from any earlier process -- and the interpreting kernel where none does; it never compiles.
  * THE DEFAULT POLICY ("specialize" = 3; process-wide default: environment SSGPU_SPECIALIZE): like 2, and a kernel that is

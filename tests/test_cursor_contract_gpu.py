@@ -358,6 +358,56 @@ def test_specialised_kernels_survive_the_process(tmp_path):
     assert off["compilations"] >= 1 and off["disk_hits"] == 0, off   # no disk cache at all
 
 
+_TRIM_CHILD = r"""
+import sys
+import numpy as np
+import supersonic_amd as ss
+ctx = ss.Context(0)
+ctx.set_option("specialize", 1)
+n = 5003
+schema = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
+view = ss.View(schema, [np.arange(n), np.arange(n)])
+for k in sys.argv[1:]:
+    op = ss.ScalarAggregate(ss.AggregationSpecification().AddAggregation(ss.SUM, "b", "s"),
+                            ss.Filter(ss.Less(ss.NamedAttribute("a"), ss.ConstInt64(int(k))), ss.ProjectAllAttributes(), ss.ScanView(view)))
+    plan = ss.Plan(op, ctx)
+    plan.run()
+    assert plan.specialized() == 1, plan.specialize_reason()
+print("rtc_disk_hits", ss.memory_stats()["rtc_disk_hits"])
+"""
+
+
+def test_the_disk_cache_of_code_objects_is_bounded(tmp_path):
+    """$SSGPU_RTC_CACHE_MAX_MB: after a store, the least recently USED code objects go until the directory is below 3/4 of the limit (a
+    load counts as a use); the newest file always stays; <= 0 switches the limit off."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = str(tmp_path / "rtc")
+
+    def child(limit_mb, *constants):
+        env = dict(os.environ, SSGPU_RTC_CACHE_DIR=cache, SSGPU_RTC_CACHE_MAX_MB=str(limit_mb), PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _TRIM_CHILD] + [str(c) for c in constants], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return int([l for l in out.stdout.splitlines() if l.startswith("rtc_disk_hits")][-1].split()[1])
+
+    def files():
+        return sorted(f for f in os.listdir(cache) if f.endswith(".co"))
+    child(0, 11, 12, 13, 14)                       # no limit: four kernels, four files
+    four = files()
+    assert len(four) == 4
+    size = max(os.path.getsize(os.path.join(cache, f)) for f in four)
+    time.sleep(0.05)
+    assert child(0, 12) == 1                       # kernel 12 is USED again (loaded from its file): it becomes the most recent of the four
+    used = max(four, key=lambda f: os.stat(os.path.join(cache, f)).st_atime_ns)
+    limit_mb = 3.5 * size / (1024.0 * 1024.0)      # room for three and a half files: storing a fifth trims down to 3/4 of that = two files
+    child(limit_mb, 15)
+    left = files()
+    assert len(left) == 2 and used in left, (left, used, four)
+    assert len(set(left) - set(four)) == 1         # ... and the one just stored
+
+
 # ---- INPUT LIFETIME (include/ssgpu.h, ABI 7): under the defaults a run is settled when ssgpu_plan_run returns -- run feedback read,
 # ---- a NaN-exact repeat done -- so the input may be overwritten once the stream has been synchronised, and the result is still right.
 # ---- (With "lazy_feedback" = 1, the sharded drivers' opt-in, the same sequence may repeat a run from the overwritten columns.) ----------
