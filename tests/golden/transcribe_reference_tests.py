@@ -1413,6 +1413,22 @@ derived_case("Derived_Limit_SumOfDoublesIntoInt64FoldsTheFoldedRowInInputOrder",
              cols([I32, F64], nullable=False), [[1, 5.5], [2, 1.6], [3, -1.9], [2, 1.6]],
              ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s", I64], ["CONCAT", "col1", "c"]], "INPUT", {"max_unique_keys_in_result": 1}],
              [I32, I64, STR], [[1, 5, "5.5"], [2, 1, "1.6,-1.9,1.6"]])
+derived_case("Derived_SumOfDoublesIntoInt64NextToDistinctKeepsInputOrder", "supersonic/base/infrastructure/aggregation_operators.h:173-185; " + DST,
+             D_SEQ + "Every aggregation of a specification is fed the same rows in the same (input) order -- a DISTINCT aggregate next to the sum changes nothing for "
+             "the sum (" + DST + " filters the rows of ITS aggregator only).  Group 1 holds 2.5, -0.75, 0.5 in this order: assigned 2; 2 - 0.75 = 1.25 -> 1; 1 + 0.5 = 1.5 -> 1: "
+             "result 1 (folded in VALUE order -- -0.75, 0.5, 2.5, the order a DISTINCT implementation may sort into -- it would be 0, 0, 2: result 2).  COUNT DISTINCT 3, SUM "
+             "DISTINCT 2.25.  Group 2 holds 0.5, 0.5: SUM 0, COUNT DISTINCT 1, SUM DISTINCT 0.5.",
+             cols([I32, F64], nullable=False), [[1, 2.5], [2, 0.5], [1, -0.75], [1, 0.5], [2, 0.5]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "s", I64], ["COUNT_DISTINCT", "col1", "c"], ["SUM_DISTINCT", "col1", "d"]], "INPUT"],
+             [I32, I64, U64, F64], [[1, 1, 3, 2.25], [2, 0, 1, 0.5]], ordered=False)
+derived_case("Derived_ConcatNextToDistinctKeepsInputOrder", "supersonic/cursor/core/column_aggregator.cc:108-124; " + DST,
+             "CONCAT appends the printed values of its result row in input order (column_aggregator.cc:108-124); the DistinctAggregator next to it keeps its own set and "
+             "filters only its own aggregator's rows (" + DST + ").  Group 7 holds 9, 3, 9, NULL, 3, 1: CONCAT '9,3,9,3,1' (input order, repeats kept, NULL skipped) next to COUNT "
+             "DISTINCT 3 and SUM DISTINCT 13; DISTINCT CONCAT of the same column '9,3,1'.  Group 8 holds NULL only: both strings NULL, COUNT DISTINCT 0, SUM DISTINCT NULL.",
+             cols([I32, I32]), [[7, 9], [7, 3], [8, None], [7, 9], [7, None], [7, 3], [7, 1]],
+             ["GroupAggregate", ["ProjectNamedAttribute", "col0"],
+              [["CONCAT", "col1", "c"], ["COUNT_DISTINCT", "col1", "n"], ["SUM_DISTINCT", "col1", "s"], ["CONCAT_DISTINCT", "col1", "dc"]], "INPUT"],
+             [I32, STR, U64, I32, STR], [[7, "9,3,9,3,1", 3, 13, "9,3,1"], [8, None, 0, None, None]], ordered=False)
 derived_case("Derived_SumOfDoublesIntoInt64OrderMatters", "supersonic/base/infrastructure/aggregation_operators.h:173-185",
              D_SEQ + "2.75, 0.5, 0.5: assigned 2, 2 + 0.5 = 2.5 -> 2, 2 + 0.5 -> 2: result 2 (the real sum 3.75 would truncate to 3).  NULLs are skipped: "
              "NULL, 7.9, NULL, 0.2 -> assigned 7, 7 + 0.2 = 7.2 -> 7.",
