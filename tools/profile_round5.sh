@@ -14,11 +14,11 @@ for q in wide group3 group sort filter_mat; do
   mkdir -p $OUT/$q
   extra="--no-cpu-baseline"; [ $q = wide ] && extra=""
   python $REPO/bench.py --query $q $extra > $OUT/$q/line.json 2> $OUT/$q/line.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$q/stats -o k -- python $REPO/bench.py --query $q --steps 50 --warmup 5 --no-cpu-baseline --no-configs > $OUT/$q/stats.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$q/stats -o k -- python $REPO/bench.py --query $q --steps 50 --warmup 5 --no-cpu-baseline --no-configs > $OUT/$q/stats.log 2>&1
   f=$(find $OUT/$q/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/$q/kernel_stats.csv
   rm -rf $OUT/$q/stats
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $OUT/$q/pmc_$c -o p -- python $REPO/bench.py --query $q --steps 5 --warmup 2 --no-cpu-baseline --no-configs > $OUT/$q/pmc_$c.log 2>&1
+    timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/$q/pmc_$c -o p -- python $REPO/bench.py --query $q --steps 5 --warmup 2 --no-cpu-baseline --no-configs > $OUT/$q/pmc_$c.log 2>&1
     f=$(find $OUT/$q/pmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/$q/$c.csv
     rm -rf $OUT/$q/pmc_$c
   done
@@ -39,7 +39,7 @@ done
 for ex in key_range all_gather; do
   python $REPO/bench.py --query group --force-distributed --exchange $ex --rows 12500000 --warmup 60 --no-cpu-baseline --opts group_dense=0 2> /dev/null | grep "^{" > $OUT/dist1/group_12m5_rows_dist1_$ex.json
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dist1/stats_group -o k -- python $REPO/bench.py --query group --force-distributed --exchange dense --rows 12500000 --steps 100 --warmup 10 --no-cpu-baseline --no-regimes > $OUT/dist1/stats_group.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dist1/stats_group -o k -- python $REPO/bench.py --query group --force-distributed --exchange dense --rows 12500000 --steps 100 --warmup 10 --no-cpu-baseline --no-regimes > $OUT/dist1/stats_group.log 2>&1
 f=$(find $OUT/dist1/stats_group -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/dist1/group_12m5_rows_dist1_dense_kernel_stats.csv
 rm -rf $OUT/dist1/stats_group
 python $REPO/tools/first_run_bench.py > $OUT/first_run.json 2> $OUT/first_run.err
