@@ -1174,6 +1174,27 @@ op_case("Hybrid_NonDistinctAndDistinctAggregations", HY + ":683-716", cols([I32,
          [["SUM_DISTINCT", "col1", "sum"], ["COUNT_DISTINCT", "col1", "cnt"], ["SUM", "col1", "sum2"], ["COUNT", "col1", "cnt2"], ["COUNT", "", "cnt3"]], "INPUT"],
         [I32, I32, U64, I32, U64, U64], [[1, 7, 2, 10, 3, 4], [2, 4, 1, 4, 1, 1], [3, -6, 3, -6, 3, 3]], ordered=False)
 
+_hy_rows1 = [[1], [1], [3], [3], [2], [3], [1]]
+_hy_spec = [["SUM", "col0", "sum"], ["COUNT", "col0", "cnt"], ["COUNT_DISTINCT", "col0", "dcnt"]]
+op_case("Hybrid_GroupByColumnPosition1", HY + ":894-919", cols([I32, I32]), [[r[0], 0] for r in _hy_rows1],
+        ["GroupAggregate", ["ProjectAttributeAt", 1], _hy_spec, "INPUT"], [I32, I32, U64, U64], [[0, 14, 7, 3]], exp_names=["col1", "sum", "cnt", "dcnt"])
+op_case("Hybrid_GroupByAllColumns", HY + ":921-948", cols([I32]), _hy_rows1,
+        ["GroupAggregate", ["ProjectAllAttributes"], _hy_spec, "INPUT"], [I32, I32, U64, U64], [[1, 3, 3, 1], [2, 2, 1, 1], [3, 9, 3, 1]], ordered=False)
+op_case("Hybrid_GroupByColumnRenamed", HY + ":950-977", cols([I32, I32]), [[r[0], 0] for r in _hy_rows1],
+        ["GroupAggregate", ["ProjectNamedAttributeAs", "col1", "key"], _hy_spec, "INPUT"], [I32, I32, U64, U64], [[0, 14, 7, 3]],
+        exp_names=["key", "sum", "cnt", "dcnt"])
+
+# ---- base/infrastructure/projector_test.cc: the projectors the operations take, bound against a schema (restated as a Project over two rows)
+PJ = "supersonic/base/infrastructure/projector_test.cc"
+_pj_schema = [["schema 0 attribute 0", I64, True], ["schema 0 attribute 1", STR, True]]
+_pj_rows = [[7, "x"], [None, None]]
+op_case("Projector_AllAttributes", PJ + ":68-75", _pj_schema, _pj_rows, ["Project", ["ProjectAllAttributes"], "INPUT"], [I64, STR], _pj_rows,
+        exp_names=["schema 0 attribute 0", "schema 0 attribute 1"], exp_nullable=[True, True])
+op_case("Projector_AllAttributesWithPrefix", PJ + ":76-85", _pj_schema, _pj_rows, ["Project", ["ProjectAllAttributes", "prefix "], "INPUT"], [I64, STR], _pj_rows,
+        exp_names=["prefix schema 0 attribute 0", "prefix schema 0 attribute 1"], exp_nullable=[True, True])
+op_case("Projector_AttributeAtPosition", PJ + ":87-99", _pj_schema, _pj_rows, ["Project", ["ProjectAttributeAt", 1], "INPUT"], [STR], [["x"], [None]],
+        exp_names=["schema 0 attribute 1"], exp_nullable=[True])
+
 # ---- base/infrastructure/operators_test.cc: Equal / Less across signed and unsigned integers (the operators behind the
 # comparison expressions and ThreeWayCompare).  Each EXPECT is restated as the comparison expression over two columns of
 # the operand types; the negative operands are the tests' static_cast<unsigned>(-5) values.
