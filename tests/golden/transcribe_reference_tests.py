@@ -549,14 +549,20 @@ op_case("AggregationOperators_ConcatStrings_string", "supersonic/base/infrastruc
 op_case("AggregationOperators_ConcatInts", "supersonic/base/infrastructure/aggregation_operators_test.cc:262-272", cols([I32]),
         [[-7], [None], [0]],
         ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["-7,0"]])
-# PrintTyped<DATE> / <DATETIME> (types_infrastructure_test.cc:85-89: 1 day prints as 1970/01/02[-00:00:00]) reached through CONCAT, whose values
-# PrintTyped prints (column_aggregator.cc:510-513 lists CONCAT over DATE and DATETIME); NULLs skipped, ',' between values
-op_case("TypesInfrastructure_PrintDateThroughConcat", "supersonic/base/infrastructure/types_infrastructure_test.cc:89; supersonic/base/infrastructure/types_infrastructure.cc:104-114",
-        cols([DATE]), [[1], [None], [0], [11016], [-1]],
-        ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["1970/01/02,1970/01/01,2000/02/29,1969/12/31"]])
-op_case("TypesInfrastructure_PrintDateTimeThroughConcat", "supersonic/base/infrastructure/types_infrastructure_test.cc:85; supersonic/base/infrastructure/types_infrastructure.cc:92-102",
-        cols([DATETIME]), [[24 * 60 * 60 * 1000000], [0], [951782400 * 1000000 + 3661 * 1000000 + 999999], [-1000000]],
-        ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [["1970/01/02-00:00:00,1970/01/01-00:00:00,2000/02/29-01:01:01,1969/12/31-23:59:59"]])
+# PrintTyped (types_infrastructure_test.cc:53-90, PrinterTest.ShouldPrintNormalValues): every TestPrinter<type>(value, text) of the types CONCAT
+# accepts (column_aggregator.cc:496-515), reached through CONCAT, whose values PrintTyped prints; ',' between the values of one type
+TI = "supersonic/base/infrastructure/types_infrastructure_test.cc"
+for _t, _vals, _text, _lines in (
+        (I32, [316, -5], "316,-5", ":56-57"), (U32, [2316, 4294967291], "2316,4294967291", ":59-60"),
+        (I64, [334153124625418816, -334153124625418816], "334153124625418816,-334153124625418816", ":62-63"),
+        (U64, [334153124625418816, 18112590949084132800], "334153124625418816,18112590949084132800", ":65-66"),
+        (F32, [1.18, -1.18, 0.0, -1.244e24, -1.43e5], "1.18,-1.18,0,-1.244e+24,-143000", ":68-72"),
+        (F64, [1.18, -1.18, 0.0, -1.244e24, -1.43e5], "1.18,-1.18,0,-1.244e+24,-143000", ":74-78"),
+        (BOOL, [True, False], "TRUE,FALSE", ":80-81"),
+        (DATETIME, [1260189023 * 1000000, -24 * 60 * 60 * 1000000, 24 * 60 * 60 * 1000000], "2009/12/07-12:30:23,1969/12/31-00:00:00,1970/01/02-00:00:00", ":83-85"),
+        (DATE, [14585, -1, 1], "2009/12/07,1969/12/31,1970/01/02", ":87-89")):
+    op_case("TypesInfrastructure_Print_%s_ThroughConcat" % _t, TI + _lines, cols([_t]), [[v] for v in _vals] + [[None]],
+            ["ScalarAggregate", [["CONCAT", "col0", "r"]], "INPUT"], [STR], [[_text]])
 op_case("ColumnAggregator_NotSupportedAggregationDetected_string", CA + ":518-526", cols([STR]), [],
         ["ScalarAggregate", [["SUM", "col0", "r"]], "INPUT"], None, [], expect_error=405)
 op_case("ColumnAggregator_NotSupportedCountOutputTypeDetected", CA + ":528-534", cols([I32]), [],
