@@ -302,11 +302,52 @@ def _physical_cores():
     return logical, logical
 
 
-def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True):
-    """1 thread (the reference is single-threaded per plan) AND N threads over row-range shards of the same
-    sample (the ctypes calls into the C restatement release the GIL; the merge of N one-row / N partial
-    results is not timed: microseconds), plus BASELINE configs[0]'s exact shape (1 M rows x 4 INT64)."""
-    import threading
+def _pin_cpus():
+    """One logical CPU per PHYSICAL core this process may run on (first sibling of every (physical id, core id) of /proc/cpuinfo,
+    intersected with the affinity mask): where the N-thread baseline pins its threads."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = set(range(os.cpu_count() or 1))
+    first, cpu, phys, core = {}, None, None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in list(f) + [""]:
+                if line.startswith("processor"):
+                    cpu = int(line.split(":", 1)[1])
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if cpu is not None and cpu in allowed:
+                        first.setdefault((phys, core) if phys is not None and core is not None else ("cpu", cpu), cpu)
+                    cpu = phys = core = None
+    except OSError:
+        pass
+    return sorted(first.values()) or sorted(allowed)
+
+
+def _mem_available():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    return int(line.split()[1]) * 1024
+    except (OSError, ValueError):
+        pass
+    return 8 << 30
+
+
+def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True, rows_per_thread=1_000_000):
+    """The oracle (the CPU restatement of the reference's 1024-row pull model) on this host's cores, through its C harness
+    (oracle/ss_oracle.c orc_bench_threads: pthreads, barrier-to-barrier wall time, nothing of Python inside the timed region):
+      * 1 thread over `sample_rows` rows (the reference is single-threaded per plan);
+      * one thread per PHYSICAL core, pinned, each over its own contiguous `rows_per_thread` rows that IT first touched
+        (NUMA-local), the same plan per shard and -- GroupAggregate -- a final merge of the partial tables by key-hash ranges,
+        which is timed and charged to every pass; Sort: N sorted runs, the merge of the runs is NOT included (an upper bound);
+      * the same threads' plain read bandwidth over the same columns, the ceiling the N-thread figure is read against;
+    plus BASELINE configs[0]'s exact shape (1 M rows x 4 INT64)."""
     import numpy as np
     from oracle import oracle
     n = sample_rows
@@ -314,6 +355,7 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True):
     make = {"group": lambda v: build_group_plan(ss, v), "sort": lambda v: build_sort_plan(ss, v),
             "filter_mat": lambda v: build_filter_mat_plan(ss, v)}.get(query, lambda v: build_plan(ss, v))
     cols = host_columns(np, query, n)
+    row_bytes = sum(c.dtype.itemsize for c in cols)
 
     def drain(op):
         cur = oracle.Cursor(op)
@@ -321,38 +363,45 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True):
         cur.drain_discard()
         return time.perf_counter() - t0
 
-    op = make(ss.View(schema, cols))
-    reps, elapsed = 0, 0.0
-    while elapsed < budget_s and reps < 200:
-        elapsed += drain(op)
-        reps += 1
-    one = n * reps / elapsed
-    # N threads: one contiguous row range per thread
-    physical, nproc = _physical_cores()
-    nthreads = max(1, min(physical, 256))        # one thread per PHYSICAL core (SMT siblings add little to a streaming loop)
-    bounds = [n * i // nthreads for i in range(nthreads + 1)]
-    ops = [make(ss.View(schema, [c[bounds[i]:bounds[i + 1]] for c in cols])) for i in range(nthreads)]
-    # every thread drains its shard `inner` times per start: starting 128 Python threads costs milliseconds, a pass over a 1 / 128 share
-    # of the sample about as much -- a pass per start would time the thread starts (round 5's first 128-thread figure read 206 M rows/s)
-    inner = max(1, int(0.1 / max(elapsed / reps / nthreads, 1e-6)))
+    def timed(bench, threads, cpus, budget):
+        """passes sized from one untimed-for-the-report pass so that the measured run takes about `budget` seconds"""
+        first = bench.run(threads, 1, cpus)
+        per_pass = max(first["seconds"], 1e-6)
+        passes = max(1, min(2000, int(budget / per_pass)))
+        r = bench.run(threads, passes, cpus)
+        r["passes"] = passes
+        return r
 
-    def drain_many(op):
-        for _ in range(inner):
-            drain(op)
-    preps, pelapsed = 0, 0.0
-    while pelapsed < budget_s / 2 and preps < 200 * inner:
-        threads = [threading.Thread(target=drain_many, args=(o,)) for o in ops]
-        t0 = time.perf_counter()
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        pelapsed += time.perf_counter() - t0
-        preps += inner
-    out = {"value": one, "unit": "rows/s", "cores": 1, "kind": "port",
-           "sample": "%d rows (same plan, seed 42), %d passes, %.1f s of CPU" % (n, reps, elapsed),
-           "threads": {"value": n * preps / pelapsed, "cores": nthreads,
-                       "sample": "%d row-range shards of the same sample, %d passes, %.1f s" % (nthreads, preps, pelapsed)},
+    op = make(ss.View(schema, cols))
+    pin = _pin_cpus()
+    one_bench = oracle.ThreadedBench(op)
+    r1 = timed(one_bench, 1, pin[:1], budget_s)
+    one = n * r1["passes"] / r1["seconds"]
+    # N threads: one contiguous row range per thread, filled by the thread itself from the 1-thread sample
+    physical, nproc = _physical_cores()
+    nthreads = max(1, min(len(pin), physical, 256))
+    per = int(min(rows_per_thread, n, max(65536, _mem_available() // 4 // max(nthreads * row_bytes, 1))))
+    total = per * nthreads
+    big = [np.empty(total, dtype=c.dtype) for c in cols]          # untouched pages: first written by the thread that reads them
+    big_op = make(ss.View(schema, big))
+    nbench = oracle.ThreadedBench(big_op, sample=op)
+    rn = timed(nbench, nthreads, pin, budget_s / 2)
+    per_pass = rn["seconds"] / rn["passes"] + (rn["merge_seconds"] or 0.0)
+    stream = nbench.stream_read(nthreads, max(1, int(1.0 / max(total * row_bytes / 200e9, 1e-3))), pin)
+    threads = {"value": total / per_pass, "cores": nthreads, "gb_per_s": total * row_bytes / per_pass / 1e9,
+               "host_read_gb_per_s": stream / 1e9, "pinned": True,
+               "sample": "%d pinned threads x %d rows each (copies of the 1-thread sample, first touched by their thread), %d passes, %.1f s"
+                         % (nthreads, per, rn["passes"], rn["seconds"])}
+    if rn["merge_seconds"] is not None:
+        threads["merge_ms"] = rn["merge_seconds"] * 1e3
+        threads["sample"] += "; + the merge of the %d partial tables (%d groups) by key-hash ranges, %.1f ms, charged to every pass" % (
+            nthreads, rn["merged_groups"], rn["merge_seconds"] * 1e3)
+    elif query == "sort":
+        threads["sample"] += "; %d sorted runs -- the merge of the runs is NOT included (an upper bound for the CPU)" % nthreads
+    del big, big_op, nbench
+    out = {"value": one, "unit": "rows/s", "cores": 1, "kind": "port", "gb_per_s": one * row_bytes / 1e9,
+           "sample": "%d rows (same plan, seed 42), %d passes, %.1f s of CPU" % (n, r1["passes"], r1["seconds"]),
+           "threads": threads,
            "host": {"nproc": nproc, "physical_cores": physical, "model": _cpu_model()}}
     if not with_config0:
         return out

@@ -71,6 +71,10 @@ def lib():
         L.orc_next.argtypes = [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(P), C.POINTER(P)]
         L.orc_drain.restype = C.c_int64
         L.orc_drain.argtypes = [P]
+        L.orc_bench_threads.restype = C.c_int
+        L.orc_bench_threads.argtypes = [P, P, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double)]
+        L.orc_bench_stream_read.restype = C.c_double
+        L.orc_bench_stream_read.argtypes = [P, C.c_int, C.c_int, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -227,6 +231,40 @@ class Cursor(object):
 
     def drain_discard(self):
         return lib().orc_drain(self.handle)
+
+
+class ThreadedBench(object):
+    """bench.py's N-thread CPU baseline (ss_oracle.c "bench harness"): `nthreads` pthreads, pinned to `cpus` (one id per thread,
+    or None), each draining a fresh cursor of `operation` over its own contiguous row range of the plan's ScanView `passes`
+    times; for GroupAggregate plans the partial tables are merged afterwards (every thread owns a hash range of the keys).
+    `sample`: a plan of the same shape over a small view -- every thread fills ITS rows of the big view with copies of it
+    before the clock starts (first touch by the thread that will read them: NUMA-local pages)."""
+
+    def __init__(self, operation, sample=None):
+        self.tree, self.sample_tree = _Tree(), _Tree()
+        self.handle = self.tree.op(operation)
+        self.sample = self.sample_tree.op(sample) if sample is not None else None
+
+    @staticmethod
+    def _cpus(cpus, nthreads):
+        if cpus is None:
+            return None
+        assert len(cpus) >= nthreads
+        return (C.c_int * nthreads)(*[int(c) for c in cpus[:nthreads]])
+
+    def run(self, nthreads, passes, cpus=None, merge=True):
+        """-> dict(seconds, merge_seconds (None if this plan has no merge step / it is not supported), merged_groups,
+        merged_checksum, result_rows)"""
+        out = (C.c_double * 5)()
+        rc = lib().orc_bench_threads(self.handle, self.sample, int(nthreads), int(passes), self._cpus(cpus, nthreads), 1 if merge else 0, out)
+        if rc == -1:
+            raise OracleError(-1, "a cursor of the threaded CPU baseline failed")
+        return {"seconds": out[0], "merge_seconds": out[1] if out[1] > 0 else None, "merged_groups": int(out[2]),
+                "merged_checksum": out[3], "result_rows": int(out[4])}
+
+    def stream_read(self, nthreads, passes, cpus=None):
+        """bytes/s of a plain summing read of the ScanView's columns by the same threads"""
+        return lib().orc_bench_stream_read(self.handle, int(nthreads), int(passes), self._cpus(cpus, nthreads))
 
 
 A_CONCAT, T_BOOL, T_FLOAT, T_DOUBLE, T_DATE, T_DATETIME = 4, 6, 9, 5, 10, 4

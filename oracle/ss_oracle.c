@@ -146,12 +146,28 @@ typedef struct bnode {
   const uint8_t* nulls;
 } bnode;
 
+/* Bound nodes of the cursors one thread creates while `tl_nodes` is set are remembered there, so that orc_cursor_free can
+ * release them (the bench harness below creates thousands of cursors; the tests never free theirs). */
+typedef struct { bnode** node; uint8_t* owns_bufs; int64_t n, cap; } node_list;
+static __thread node_list* tl_nodes = NULL;
+static void track_node(bnode* b, int owns_bufs) {
+  node_list* l = tl_nodes;
+  if (!l) return;
+  if (l->n == l->cap) {
+    l->cap = l->cap ? l->cap * 2 : 64;
+    l->node = (bnode**)realloc(l->node, sizeof(bnode*) * (size_t)l->cap);
+    l->owns_bufs = (uint8_t*)realloc(l->owns_bufs, (size_t)l->cap);
+  }
+  l->node[l->n] = b; l->owns_bufs[l->n] = (uint8_t)owns_bufs; ++l->n;
+}
+
 static bnode* bnode_new(int kind, int op, int dtype, int nullable, const char* name) {
   bnode* b = (bnode*)calloc(1, sizeof(bnode));
   b->kind = kind; b->op = op; b->dtype = dtype; b->nullable = nullable;
   snprintf(b->name, sizeof(b->name), "%s", name ? name : "");
   b->buf = calloc(ORC_BLOCK, 8);
   b->nullbuf = (uint8_t*)calloc(ORC_BLOCK, 1);
+  track_node(b, 1);
   return b;
 }
 
@@ -652,6 +668,7 @@ static bnode* bind_expr(const orc_expr* e, const orc_schema* s, bnode** multi, i
     case E_ALIAS: {
       bnode* c = bind_single(e->args[0], s, err); if (err->code) return NULL;
       b = (bnode*)malloc(sizeof(bnode)); *b = *c;   /* same computation, new name */
+      track_node(b, 0);
       snprintf(b->name, sizeof(b->name), "%s", e->name);
     } break;
     case E_COMPOUND:
@@ -1796,4 +1813,261 @@ int64_t orc_drain(orc_cursor* c) {
   orc_view v; int r; int64_t total = 0;
   while ((r = cursor_next(c, ORC_BLOCK, &v)) > 0) total += v.rows;
   return r < 0 ? -1 : total;
+}
+
+/* ==== bench.py's CPU baseline harness ====================================================================================
+ * Not part of the restatement: the N-thread form of the CPU baseline SURVEY 8(d) asks for -- "N threads over row-range
+ * shards with a final merge" -- done where it costs nothing extra: pthreads pinned to the CPUs the caller names, every thread
+ * first-touches its own shard of the input (NUMA-local pages), a barrier, `passes` drains of a fresh cursor over the shard
+ * per thread, a barrier, and for GroupAggregate plans the merge of the N partial tables (every thread owns the groups whose
+ * key hash is its number).  Wall time is taken between the barriers by the calling thread. */
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
+
+static void block_free(orc_block* b) {
+  for (int i = 0; i < b->n; ++i) { free(b->data[i]); free(b->nulls[i]); }
+  memset(b, 0, sizeof(*b));
+}
+
+/* releases a cursor tree; bound nodes only if the creating thread tracked them (tl_nodes) */
+static void cursor_free(orc_cursor* c) {
+  if (!c) return;
+  cursor_free(c->child); cursor_free(c->rhs);
+  block_free(&c->block); block_free(&c->rhs_rows);
+  free(c->ids); free(c->bucket_head); free(c->chain_next); free(c->row_hash); free(c->perm); free(c->match);
+  if (c->table) { block_free((orc_block*)c->table); free(c->table); }
+  for (int j = 0; j < c->nagg; ++j) { free(c->aggs[j].dval); free(c->aggs[j].drow); }
+  free(c);
+}
+static void nodes_free(node_list* l) {
+  for (int64_t i = 0; i < l->n; ++i) {
+    bnode* b = l->node[i];
+    if (l->owns_bufs[i]) { free(b->buf); free(b->nullbuf); }
+    /* (an alias shares its source's result buffers -- copied at bind time, before any skip vector existed: skipbuf is its own) */
+    free(b->skipbuf);
+    free(b);
+  }
+  l->n = 0;
+}
+
+typedef struct {
+  const orc_op* op; const orc_op* sample;     /* sample: a plan whose ScanView holds `sample rows` of the same schema, or NULL */
+  int nthreads, passes, tid, cpu, merge;
+  int64_t lo, hi;                              /* this thread's row range of op's ScanView */
+  pthread_barrier_t* bar;
+  orc_cursor* last;                            /* the last pass's cursor (kept for the merge) */
+  int64_t result_rows; int failed;
+  struct bench_thread_s* all;
+  /* merge output */ int64_t merged_groups; double merged_checksum;
+} bench_thread_base;
+typedef struct bench_thread_s { bench_thread_base b; } bench_thread;
+
+static const orc_op* scan_of(const orc_op* op) { while (op && op->kind != C_SCAN) op = op->child; return op; }
+static orc_cursor* scan_cursor_of(orc_cursor* c) { while (c && c->kind != C_SCAN) c = c->child; return c; }
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* merge of partial GroupAggregate tables: thread t inserts the rows of EVERY partial table whose key hash % nthreads == t
+ * into its own chained table and folds the aggregates with each column's own function (SUM / COUNT add, MIN / MAX compare;
+ * NULL = no value yet) -- the key-range all-to-all of a sharded hash aggregate, on shared memory. */
+static int merge_supported(const orc_cursor* c) {
+  if (c->kind != C_GROUP_AGG || c->max_unique_keys >= 0) return 0;
+  for (int j = 0; j < c->nagg; ++j) {
+    const int a = c->aggs[j].aggregation;
+    if (c->aggs[j].distinct || !(a == A_SUM || a == A_MIN || a == A_MAX || a == A_COUNT)) return 0;
+    if (arith_kind(c->aggs[j].out_type) > 5) return 0;
+  }
+  return 1;
+}
+static uint64_t hash_block_row(const orc_cursor* c, const orc_block* b, int64_t i) {
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+  for (int k = 0; k < c->nproj; ++k) {
+    uint64_t x = 0;
+    if (b->nulls[k][i]) x = 0xdeadbeefcafef00dull; else memcpy(&x, (const char*)b->data[k] + i * b->width[k], (size_t)b->width[k]);
+    h = mix64(h ^ x) + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1);
+  }
+  return h;
+}
+static void merge_partials(bench_thread* me) {
+  bench_thread* all = me->b.all; const int nt = me->b.nthreads;
+  const orc_cursor* c0 = all[0].b.last; const int nk = c0->nproj, na = c0->nagg;
+  orc_block out; block_init(&out, &c0->schema, 1024);
+  int64_t nb = 2048, n = 0; int64_t* head = (int64_t*)malloc(sizeof(int64_t) * (size_t)nb);
+  int64_t* next = (int64_t*)malloc(sizeof(int64_t) * (size_t)out.cap); uint64_t* hs = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)out.cap);
+  for (int64_t i = 0; i < nb; ++i) head[i] = -1;
+  for (int p = 0; p < nt; ++p) {
+    const orc_cursor* c = all[p].b.last; const orc_block* b = &c->block;
+    for (int64_t r = 0; r < c->out_rows; ++r) {
+      const uint64_t h = c->row_hash[r];      /* (the hash the shard's own table computed for the row: hash_row == hash_block_row) */
+      if ((int)((h >> 32) % (uint64_t)nt) != me->b.tid) continue;
+      int64_t g = head[h & (uint64_t)(nb - 1)];
+      for (; g >= 0; g = next[g]) {
+        if (hs[g] != h) continue;
+        int same = 1;
+        for (int k = 0; k < nk && same; ++k) {
+          if (out.nulls[k][g] != b->nulls[k][r]) same = 0;
+          else if (!b->nulls[k][r] && memcmp((char*)out.data[k] + g * out.width[k], (char*)b->data[k] + r * b->width[k], (size_t)out.width[k])) same = 0;
+        }
+        if (same) break;
+      }
+      if (g < 0) {
+        if (n == out.cap) {
+          block_grow(&out, out.cap * 2);
+          next = (int64_t*)realloc(next, sizeof(int64_t) * (size_t)out.cap); hs = (uint64_t*)realloc(hs, sizeof(uint64_t) * (size_t)out.cap);
+        }
+        g = n++;
+        for (int k = 0; k < nk + na; ++k) { memcpy((char*)out.data[k] + g * out.width[k], (char*)b->data[k] + r * b->width[k], (size_t)out.width[k]); out.nulls[k][g] = b->nulls[k][r]; }
+        hs[g] = h;
+        if (n * 4 > nb * 3) {
+          nb *= 2; free(head); head = (int64_t*)malloc(sizeof(int64_t) * (size_t)nb);
+          for (int64_t i = 0; i < nb; ++i) head[i] = -1;
+          for (int64_t q = 0; q < n; ++q) { const int64_t s = (int64_t)(hs[q] & (uint64_t)(nb - 1)); next[q] = head[s]; head[s] = q; }
+        } else { const int64_t s = (int64_t)(h & (uint64_t)(nb - 1)); next[g] = head[s]; head[s] = g; }
+        continue;
+      }
+      for (int j = 0; j < na; ++j) {
+        const int col = nk + j, a = c->aggs[j].aggregation;
+        if (b->nulls[col][r]) continue;
+        if (out.nulls[col][g]) { memcpy((char*)out.data[col] + g * out.width[col], (char*)b->data[col] + r * b->width[col], (size_t)out.width[col]); out.nulls[col][g] = 0; continue; }
+#define MERGE(T) { T* d = (T*)out.data[col] + g; const T v = ((const T*)b->data[col])[r]; \
+          if (a == A_SUM || a == A_COUNT) *d = (T)(*d + v); else if (a == A_MIN) { if (v < *d) *d = v; } else { if (v > *d) *d = v; } }
+        switch (arith_kind(c->aggs[j].out_type)) {
+          case 0: MERGE(int32_t) break; case 1: MERGE(uint32_t) break; case 2: MERGE(int64_t) break;
+          case 3: MERGE(uint64_t) break; case 4: MERGE(float) break; default: MERGE(double) break; }
+#undef MERGE
+      }
+    }
+  }
+  me->b.merged_groups = n;
+  /* a checksum the caller compares with the one-thread result: the sum of the first aggregate column (as double) */
+  double sum = 0;
+  if (na > 0) for (int64_t g = 0; g < n; ++g) if (!out.nulls[nk][g]) {
+    switch (arith_kind(c0->aggs[0].out_type)) {
+      case 0: sum += (double)((int32_t*)out.data[nk])[g]; break; case 1: sum += (double)((uint32_t*)out.data[nk])[g]; break;
+      case 2: sum += (double)((int64_t*)out.data[nk])[g]; break; case 3: sum += (double)((uint64_t*)out.data[nk])[g]; break;
+      case 4: sum += (double)((float*)out.data[nk])[g]; break; default: sum += ((double*)out.data[nk])[g]; break; }
+  }
+  me->b.merged_checksum = sum;
+  block_free(&out); free(head); free(next); free(hs);
+}
+
+static void* bench_thread_main(void* arg) {
+  bench_thread* me = (bench_thread*)arg;
+  if (me->b.cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(me->b.cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+  const orc_op* scan = scan_of(me->b.op);
+  /* first touch: this thread writes its own rows (copies of the sample, continued at the shard's own offset into it) */
+  if (me->b.sample) {
+    const orc_op* ss = scan_of(me->b.sample); const int64_t sn = ss->scan_view.rows;
+    for (int k = 0; k < scan->scan_view.n && sn > 0; ++k) {
+      const int w = type_width(scan->scan_schema.a[k].type);
+      for (int64_t r = me->b.lo; r < me->b.hi; ) {
+        const int64_t off = r % sn; int64_t n = sn - off; if (n > me->b.hi - r) n = me->b.hi - r;
+        memcpy((char*)scan->scan_view.c[k].data + r * w, (const char*)ss->scan_view.c[k].data + off * w, (size_t)n * (size_t)w);
+        if (scan->scan_view.c[k].is_null && ss->scan_view.c[k].is_null) memcpy((uint8_t*)scan->scan_view.c[k].is_null + r, ss->scan_view.c[k].is_null + off, (size_t)n);
+        r += n;
+      }
+    }
+  }
+  node_list nodes; memset(&nodes, 0, sizeof(nodes));
+  tl_nodes = &nodes;
+  pthread_barrier_wait(me->b.bar);                 /* ---- timed region starts (the caller reads the clock after this barrier) */
+  for (int p = 0; p < me->b.passes; ++p) {
+    if (me->b.last) { cursor_free(me->b.last); nodes_free(&nodes); }
+    orc_cursor* c = orc_create_cursor(me->b.op);
+    orc_cursor* sc = scan_cursor_of(c);
+    if (c->err.code || !sc) { me->b.failed = 1; me->b.last = c; break; }
+    for (int k = 0; k < sc->scan.n; ++k) {          /* this thread's contiguous row range of the ScanView */
+      const int w = type_width(sc->schema.a[k].type);
+      sc->scan.c[k].data = (const char*)sc->scan.c[k].data + me->b.lo * w;
+      if (sc->scan.c[k].is_null) sc->scan.c[k].is_null += me->b.lo;
+    }
+    sc->scan.rows = me->b.hi - me->b.lo;
+    me->b.result_rows = orc_drain(c);
+    if (me->b.result_rows < 0) me->b.failed = 1;
+    me->b.last = c;
+  }
+  pthread_barrier_wait(me->b.bar);                 /* ---- all shards done */
+  if (me->b.merge) { merge_partials(me); pthread_barrier_wait(me->b.bar); }   /* ---- merged */
+  tl_nodes = NULL; nodes_free(&nodes); free(nodes.node); free(nodes.owns_bufs);
+  return NULL;
+}
+
+/* out[0] = seconds of the passes (all threads, barrier to barrier), out[1] = seconds of the merge (0 if none), out[2] = groups
+ * after the merge, out[3] = checksum after the merge, out[4] = result rows of the last pass summed over the threads.
+ * cpus: one CPU id per thread to pin to, or NULL.  merge: 1 = merge partial GroupAggregate tables when the plan allows it.
+ * Returns 0, or -1 if a cursor failed, -2 if the merge was asked for and is not possible for this plan (out[1] = -1). */
+int orc_bench_threads(const orc_op* op, const orc_op* sample, int nthreads, int passes, const int* cpus, int merge, double* out) {
+  const orc_op* scan = scan_of(op);
+  if (!scan || nthreads < 1 || passes < 1) return -1;
+  const int64_t rows = scan->scan_view.rows;
+  bench_thread* th = (bench_thread*)calloc((size_t)nthreads, sizeof(bench_thread));
+  pthread_t* ids = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1);
+  int can_merge = 0;
+  if (merge) { orc_cursor* probe = orc_create_cursor(op); can_merge = !probe->err.code && merge_supported(probe); }
+  for (int t = 0; t < nthreads; ++t) {
+    th[t].b.op = op; th[t].b.sample = sample; th[t].b.nthreads = nthreads; th[t].b.passes = passes; th[t].b.tid = t;
+    th[t].b.cpu = cpus ? cpus[t] : -1; th[t].b.merge = can_merge; th[t].b.bar = &bar; th[t].b.all = th;
+    th[t].b.lo = rows * t / nthreads; th[t].b.hi = rows * (t + 1) / nthreads;
+    pthread_create(&ids[t], NULL, bench_thread_main, &th[t]);
+  }
+  pthread_barrier_wait(&bar); const double t0 = now_s();
+  pthread_barrier_wait(&bar); const double t1 = now_s();
+  double t2 = t1;
+  if (can_merge) { pthread_barrier_wait(&bar); t2 = now_s(); }
+  int failed = 0; double groups = 0, checksum = 0, result_rows = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    pthread_join(ids[t], NULL);
+    failed |= th[t].b.failed; groups += (double)th[t].b.merged_groups; checksum += th[t].b.merged_checksum; result_rows += (double)th[t].b.result_rows;
+    cursor_free(th[t].b.last);
+  }
+  pthread_barrier_destroy(&bar); free(th); free(ids);
+  out[0] = t1 - t0; out[1] = can_merge ? t2 - t1 : (merge ? -1.0 : 0.0); out[2] = groups; out[3] = checksum; out[4] = result_rows;
+  return failed ? -1 : (merge && !can_merge ? -2 : 0);
+}
+
+/* the host's streaming READ bandwidth with the same threads over the same columns (sum of 64-bit words, every column of the
+ * ScanView once per pass): the ceiling the N-thread figure is read against.  Returns bytes per second. */
+typedef struct { const orc_op* scan; int64_t lo, hi; int passes, cpu; pthread_barrier_t* bar; uint64_t sink; } stream_thread;
+static void* stream_thread_main(void* arg) {
+  stream_thread* me = (stream_thread*)arg;
+  if (me->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(me->cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+  pthread_barrier_wait(me->bar);
+  uint64_t acc = 0;
+  for (int p = 0; p < me->passes; ++p)
+    for (int k = 0; k < me->scan->scan_view.n; ++k) {
+      const int w = type_width(me->scan->scan_schema.a[k].type);
+      const uint64_t* d = (const uint64_t*)((const char*)me->scan->scan_view.c[k].data + me->lo * w);
+      const int64_t words = (me->hi - me->lo) * w / 8;
+      uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      int64_t i = 0;
+      for (; i + 4 <= words; i += 4) { a0 += d[i]; a1 += d[i + 1]; a2 += d[i + 2]; a3 += d[i + 3]; }
+      for (; i < words; ++i) a0 += d[i];
+      acc += a0 + a1 + a2 + a3;
+    }
+  me->sink = acc;
+  pthread_barrier_wait(me->bar);
+  return NULL;
+}
+double orc_bench_stream_read(const orc_op* op, int nthreads, int passes, const int* cpus) {
+  const orc_op* scan = scan_of(op);
+  if (!scan || nthreads < 1 || passes < 1) return 0.0;
+  const int64_t rows = scan->scan_view.rows;
+  stream_thread* th = (stream_thread*)calloc((size_t)nthreads, sizeof(stream_thread));
+  pthread_t* ids = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+  pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1);
+  int64_t bytes_per_row = 0;
+  for (int k = 0; k < scan->scan_view.n; ++k) bytes_per_row += type_width(scan->scan_schema.a[k].type);
+  for (int t = 0; t < nthreads; ++t) {
+    th[t].scan = scan; th[t].lo = rows * t / nthreads; th[t].hi = rows * (t + 1) / nthreads; th[t].passes = passes;
+    th[t].cpu = cpus ? cpus[t] : -1; th[t].bar = &bar;
+    pthread_create(&ids[t], NULL, stream_thread_main, &th[t]);
+  }
+  pthread_barrier_wait(&bar); const double t0 = now_s();
+  pthread_barrier_wait(&bar); const double t1 = now_s();
+  uint64_t sink = 0;
+  for (int t = 0; t < nthreads; ++t) { pthread_join(ids[t], NULL); sink += th[t].sink; }
+  pthread_barrier_destroy(&bar); free(th); free(ids);
+  return (double)bytes_per_row * (double)rows * (double)passes / ((t1 - t0) > 0 ? (t1 - t0) : 1e-9) + (sink == 0x123456789abcdefull ? 1e-30 : 0.0);
 }

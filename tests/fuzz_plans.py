@@ -337,3 +337,31 @@ class Gen(object):
         if r < 0.9:
             return self.sort_plan(view), True
         return self.join_plan(view), True
+
+
+# ---- random PLAIN GroupAggregates (tests/test_dense_gpu.py, tests/fuzz_worker.py "plain_group"): keys and aggregate inputs are
+# ---- input columns, Filters are `column CMP constant` -- the stages that take the dense-slot shapes
+def random_plain_group(seed, view):
+    rng = np.random.default_rng(90000 + seed)
+
+    def pick(xs):
+        return xs[int(rng.integers(0, len(xs)))]
+    keys = pick([["k2"], ["k2", "s"], ["s"], ["k1"], ["k1", "k2"], ["t", "k2"], ["day"], ["day", "s"], ["name"], ["name", "k2"], ["s", "day"], ["t"], ["k1", "s", "t"]])
+    spec = ss.AggregationSpecification()
+    inputs = [c for c in ("a", "b", "k1", "k2", "u", "w", "d1", "f", "t", "s", "day", "name", "d0") if c not in keys]
+    for i in range(int(rng.integers(1, 7))):
+        col = pick(inputs)
+        aggs = [ss.MIN, ss.MAX, ss.COUNT]
+        if col in ("a", "b", "k1", "k2", "u", "w", "d1", "d0"):
+            aggs.append(ss.SUM)            # (d0 / d1 hold multiples of 0.25: every partial sum is exact)
+        # (FIRST / LAST order by a row id the stage computes: not a plain stage -- the hashed tests cover them)
+        spec.AddAggregation(pick(aggs), col, "r%d" % i)
+    if rng.random() < 0.5:
+        spec.AddAggregation(ss.COUNT, "", "rows")
+    child = ss.ScanView(view)
+    for _ in range(int(rng.integers(0, 3))):
+        col, const = pick([("b", ss.ConstInt64(int(rng.integers(-60, 60)))), ("k2", ss.ConstInt32(int(rng.integers(0, 7)))), ("a", ss.ConstInt64(int(rng.integers(-1000, 1000)))),
+                           ("d1", ss.ConstDouble(float(rng.integers(-64, 64)))), ("u", ss.ConstUint32(int(rng.integers(0, 1 << 32))))])
+        cmp = pick([ss.Less, ss.LessOrEqual, ss.Greater, ss.GreaterOrEqual, ss.Equal, ss.NotEqual])
+        child = ss.Filter(cmp(ss.NamedAttribute(col), const) if rng.random() < 0.7 else cmp(const, ss.NamedAttribute(col)), ss.ProjectAllAttributes(), child)
+    return ss.GroupAggregate(ss.ProjectNamedAttributes(keys), spec, None, child)

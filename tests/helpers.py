@@ -71,9 +71,18 @@ def assert_cols_equal(got, want, float_exact=True, context="", max_ulp=0):
             assert np.allclose(g, w, rtol=0, atol=0, equal_nan=True)
 
 
-def run_both(op, ctx, ignore_order=False, max_rows=1024, max_ulp=0):
+def run_both(op, ctx, ignore_order=False, max_rows=1024, max_ulp=0, stats=None):
+    """stats: a dict that collects which kernels the device run used (plans that held a specialised kernel, GroupAggregate
+    stages that ran in a dense-slot shape) -- how tests/test_fuzz_shipped_gpu.py shows what it tested."""
     cur = op.CreateCursor(ctx)
     got_view = ss.drain(cur, max_rows)
+    if stats is not None:
+        stats["plans"] = stats.get("plans", 0) + 1
+        stats["specialized_plans"] = stats.get("specialized_plans", 0) + (1 if cur.plan.specialized() > 0 else 0)
+        info = cur.plan.stage_info()
+        groups = [st for st in info if st["kind"] == 3]
+        stats["group_stages"] = stats.get("group_stages", 0) + len(groups)
+        stats["dense_stages"] = stats.get("dense_stages", 0) + sum(1 for st in groups if st["dense_slots"] > 0)
     oschema, want = oracle.run(op, max_rows)
     assert schema_list(cur.schema()) == oschema, (schema_list(cur.schema()), oschema)
     got = to_cols(got_view)
