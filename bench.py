@@ -177,6 +177,63 @@ def pmc_traffic(query, alg_bytes):
     return None
 
 
+# ---- HBM traffic of THIS run's command, counted by rocprofv3 around child runs of it ------------------------------------------
+PMC_STAGE = {"wide": ["ssgpu_pipeline_kernel", "ssgpu_finish_slots", "ssgpu_emit_scalar"],
+             "group3": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill", "ssgpu_group_init"],
+             "group": ["ssgpu_part_scatter_plain", "ssgpu_part_agg", "ssgpu_group_extract", "ssgpu_group_count", "ssgpu_scan_counts", "ssgpu_fill", "ssgpu_group_init"],
+             "sort": ["ssgpu_sort_"], "filter_mat": ["ssgpu_pipeline_kernel", "ssgpu_scan_counts"]}
+
+
+def measure_traffic(query, rows, alg_bytes, timeout_s=240):
+    """HBM bytes per step of the stage's kernels, counted for THIS command on THIS box: two child runs of bench.py under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE -- one counter per pass and no trace domain next to it, as the guide's
+    HBM section prescribes), 3 timed steps each, the per-kernel averages of the steady-state launches summed.  Unit and gfx950
+    correction as calibrated on known byte counts (profiles/r04_pmc_calibration.json, r04_pmc_gather_calibration.json): both
+    counters are KiB; FETCH_SIZE tallies 128-byte streaming requests at 64 bytes (x 2) except for the Sort's record gather,
+    whose random 64-byte reads are counted in full.  Returns (bytes per step, per-kernel dict) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    counts = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="ssgpu_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", SSGPU_BENCH_CHILD="1")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--query", query, "--rows", str(rows), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-configs", "--no-traffic"]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s, text=True)
+        except (OSError, subprocess.TimeoutExpired) as e:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, "%s pass: %s" % (counter, e)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, "%s pass: rc %d, %d counter files: %s" % (counter, p.returncode, len(files), p.stdout[-300:])
+        acc = collections.defaultdict(list)
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] == counter and any(sub in row["Kernel_Name"] for sub in PMC_STAGE[query]):
+                    acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        counts[counter] = acc
+    per_kernel, total = {}, 0.0
+    for k in sorted(set(counts["FETCH_SIZE"]) | set(counts["WRITE_SIZE"])):
+        n_per_step = 4 if "onesweep" in k else 1
+        tail = lambda v: (sum(v[-3 * n_per_step:]) / max(len(v[-3 * n_per_step:]), 1)) * n_per_step if v else 0.0   # noqa: E731
+        fk, wk = tail(counts["FETCH_SIZE"].get(k)), tail(counts["WRITE_SIZE"].get(k))
+        ff = 1.0 if "sort_gather_rec" in k else 2.0
+        per_kernel[k] = {"FETCH_SIZE_KiB_per_step": fk, "WRITE_SIZE_KiB_per_step": wk, "fetch_factor": ff, "launches_per_step": n_per_step}
+        total += (fk * ff + wk) * 1024.0
+    if total <= 0:
+        return None, "no counter rows for the stage's kernels"
+    return total, per_kernel
+
+
 # ---- the other BASELINE configs, measured in the same process after the headline's timed region ------------------------------
 def check_group_result(torch, plan, cols, device, with_filter):
     """checksums of checksums against torch over the same device columns (every DOUBLE is a small multiple of 0.25: exact)"""
@@ -467,6 +524,8 @@ def parse_args(argv=None):
                          "its key (one all-to-all), every rank merges 1/N of the groups")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = 16 M (wide) / 4 M (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not count HBM traffic with rocprofv3 --pmc child runs (roofline.traffic is then read from the committed pass)")
     ap.add_argument("--no-specialize", action="store_true",
                     help="run the interpreting pipeline kernel instead of the one specialised for the plan by runtime compilation")
     ap.add_argument("--extras", action="store_true", help="also report 1 % / 99 % selectivity and the PCIe-inclusive rate (N = 1)")
@@ -925,6 +984,39 @@ def main():
                     line["configs"][q] = dict(line["configs"].get(q) or {}, error="%s: %s" % (type(e).__name__, e))
         if world == 1 and args.extras and args.query == "wide":
             line["extras"] = extras(ss, torch, ctx, device, rows, cols, view)
+        if world == 1 and not distributed and args.query == "wide" and QUERY_NAME == "wide" and not os.environ.get("SSGPU_BENCH_CHILD"):
+            # the same plan under the LIBRARY'S DEFAULT options (a context nobody tuned: specialize = 3 -- the compiled kernel where one
+            # exists, here the one the headline compiled --, lazy_feedback = 0 -- every run settled before ssgpu_plan_run returns):
+            # what a caller who sets nothing gets, next to the tuned headline (round-5 advice)
+            try:
+                dctx = ss.Context(local_rank)
+                dctx.set_stream(stream.cuda_stream)
+                dplan = ss.Plan(build_plan(ss, view), dctx)
+                for _ in range(5):
+                    dplan.run(view)
+                torch.cuda.synchronize(device)
+                k = max(10, min(args.steps, 50))
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    dplan.run(view)
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                line["default_options"] = {"ms_per_step": dt / k * 1e3, "value": rows * k / dt, "steps": k, "specialized_stages": dplan.specialized(),
+                                           "options": "library defaults: specialize = 3 (compiled kernel where one exists, never waits for the compiler), "
+                                                      "lazy_feedback = 0 (every run settled before it returns)"}
+                del dplan, dctx
+            except Exception as e:   # noqa: BLE001
+                line["default_options"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if (world == 1 and not distributed and not args.no_traffic and not os.environ.get("SSGPU_BENCH_CHILD")
+                and not any(k.startswith("ROCP") for k in os.environ)):      # (not when this process itself runs under rocprofv3)
+            # this command's own counters (the timed region is over; the children are separate processes on the same GPU)
+            measured, detail = measure_traffic(QUERY_NAME, rows, alg_bytes)
+            if measured is not None:
+                line["roofline"].update({"traffic": measured, "traffic_measured": True, "traffic_over_algorithmic": measured / max(alg_bytes, 1),
+                                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around child runs of this command (3 steps each), "
+                                                           "FETCH_SIZE x 2 for streaming reads (gfx950), counters in KiB", "traffic_kernels": detail})
+            else:
+                line["roofline"]["traffic_note"] = "not counted in this run (%s): read from the committed pass" % detail
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ss, args.query, args.cpu_sample_rows or {"wide": 16_000_000, "filter_mat": 16_000_000}.get(args.query, 4_000_000))
         # RCCL prints its version banner through C stdio (still buffered when stdout is a file):

@@ -110,7 +110,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 8
+#define SSGPU_ABI_VERSION 9
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -488,6 +488,12 @@ typedef struct ssgpu_memory_stats_t {
   int64_t rtc_disk_hits;   /* specialised kernels loaded from the on-disk cache of code objects instead of being compiled (ABI 6) */
 } ssgpu_memory_stats_t;
 int ssgpu_memory_stats(ssgpu_memory_stats_t* out);
+/* Device blocks of destroyed plans wait in a bounded per-process pool (SSGPU_POOL_MB, default 4 GiB; still counted in
+ * device_bytes) for the next plan of the same device.  The library gives them back to the driver by itself when an allocation
+ * fails for lack of memory and when the process's last device context is destroyed; ssgpu_pool_trim does it on request
+ * (device < 0: every device) and returns the bytes freed (ABI 9).  The reference's counterpart is MemoryLimit / the soft
+ * quota's release on cursor destruction (base/memory/memory.h:420-520). */
+int64_t ssgpu_pool_trim(int32_t device);
 int64_t ssgpu_plan_memory_in_use(const ssgpu_plan* plan);
 
 /* What the last run of a plan's stage did -- the execution shape run feedback chose.  For tests and tuning: a parity
@@ -542,7 +548,10 @@ int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_c
  * then leaves its feedback words on the stream, and a run that overflowed after all -- or met a NaN -- is repeated FROM THE
  * INPUT COLUMNS when its result is first touched (ssgpu_result_row_count / _column / _device_column / _write_file) or when
  * the plan runs again.  Such a caller keeps the columns of ssgpu_plan_run / _run_partial alive and unmodified until the
- * result has been fetched or the plan has been run again or destroyed. */
+ * result has been fetched or the plan has been run again or destroyed.  The option is a property of the PLAN: a plan takes the
+ * context's value when it is created, and ssgpu_plan_set_option(plan, "lazy_feedback", v) changes it for that plan alone (ABI 9) --
+ * which is what the sharded drivers do, so that other plans of a shared context keep the default contract. */
+int ssgpu_plan_set_option(ssgpu_plan* plan, const char* key, int64_t value);
 int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
                    int64_t rows, ssgpu_result** out);
 int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);

@@ -155,9 +155,8 @@ class ShardedGroupAggregate {
     std::vector<std::unique_ptr<Operation>> own_children;
     for (Operation* c : local_children) own_children.emplace_back(c);
     if (own_children.empty()) { error_code_ = ERROR_INVALID_ARGUMENT_VALUE; error_ = "no local shard"; return; }
-    // a sharded job steps its plans without waiting for the host and keeps its shards' columns alive: the opt-in of ssgpu.h's
-    // "lazy_feedback" (the default settles every run before it returns)
-    ssgpu_ctx_set_option(internal::Context::Get().ctx, "lazy_feedback", 1);
+    // (a sharded job steps its plans without waiting for the host and keeps its shards' columns alive: its OWN plans opt in to
+    // ssgpu.h's "lazy_feedback" when their cursors are made -- Run() -- and other plans of the shared context keep the default)
     if (exchange_ == DENSE) ssgpu_ctx_set_option(internal::Context::Get().ctx, "group_dense", 1);
     // the input's types decide which sums travel as (SUM, SUM_RESIDUAL) pairs: bind the child once to learn them
     TupleSchema child_schema;
@@ -219,6 +218,7 @@ class ShardedGroupAggregate {
     while (shard_cursors_.size() < first_.size()) {
       FailureOrOwned<Cursor> shard = first_[shard_cursors_.size()]->CreateCursor();
       if (shard.is_failure()) return shard;
+      if (internal::DeviceCursor* dc = internal::AsDeviceCursor(shard.get())) ssgpu_plan_set_option(dc->plan_handle(), "lazy_feedback", 1);
       shard_cursors_.emplace_back(shard.release());
     }
     const int n_local = static_cast<int>(shard_cursors_.size());
@@ -323,6 +323,7 @@ class ShardedGroupAggregate {
         merge_.reset(merge);
         FailureOrOwned<Cursor> mc = merge_->CreateCursor();
         if (mc.is_failure()) return mc;
+        if (internal::DeviceCursor* dc = internal::AsDeviceCursor(mc.get())) ssgpu_plan_set_option(dc->plan_handle(), "lazy_feedback", 1);
         merge_cursor_.reset(mc.release());
       }
       internal::DeviceCursor* merge = internal::AsDeviceCursor(merge_cursor_.get());

@@ -1067,12 +1067,16 @@ typedef struct orc_op {
   int join_type;
   /* GroupAggregateOptions::max_unique_keys_in_result (cursor/core/aggregate.h:160-205): < 0 = no limit */
   int64_t max_unique_keys;
+  /* BestEffortGroupAggregate (cursor/core/aggregate.h:230-250): > 0 = the result block holds this many groups; the cursor emits
+   * what it aggregated when the next unseen key does not fit and starts anew at that row (aggregate_groups.cc:332-433) */
+  int64_t best_effort_groups;
 } orc_op;
 
 orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
   orc_op* o = (orc_op*)calloc(1, sizeof(orc_op)); o->kind = kind; o->child = child; o->expr = expr; o->max_unique_keys = -1; return o;
 }
 void orc_op_set_max_unique_keys(orc_op* o, int64_t limit) { o->max_unique_keys = limit; }
+void orc_op_set_best_effort(orc_op* o, int64_t groups) { o->best_effort_groups = groups < 1 ? 1 : groups; }
 void orc_op_add_proj(orc_op* o, int kind, int position, const char* name, const char* alias) {
   orc_proj* p = &o->projs[o->nproj++]; p->kind = kind; p->position = position;
   snprintf(p->name, sizeof(p->name), "%s", name ? name : ""); snprintf(p->alias, sizeof(p->alias), "%s", alias ? alias : "");
@@ -1136,6 +1140,7 @@ typedef struct orc_cursor {
   /* aggregates */ agg_col aggs[ORC_MAX_COLS]; int nagg; int done; int64_t out_rows, emit_pos;
   int has_concat;   /* the specification holds a CONCAT: bound here (schema), evaluated in oracle.py (new STRINGs) */
   /* group */ int64_t* bucket_head; int64_t* chain_next; uint64_t* row_hash; int64_t nbuckets; int64_t max_unique_keys;
+  int64_t best_effort_groups;   /* > 0: BestEffortGroupAggregate with a result block of this many rows (pending input: cur / read_ptr / eos) */
   /* sort */ int sort_pos[16], sort_order[16], nsort; int64_t* perm; void* table;
   orc_view outv;
   /* hash join: rhs fully materialised, lhs streamed (hash_join.cc: LookupIndex + HashJoinCursor) */
@@ -1266,6 +1271,7 @@ orc_cursor* orc_create_cursor(const orc_op* op) {
       for (int i = 0; i < c->nproj; ++i) schema_add(&c->schema, names[i], in->a[c->proj_pos[i]].type, in->a[c->proj_pos[i]].nullable);
       if (!bind_aggs(c, op, in)) return cursor_fail(c);
       c->max_unique_keys = op->kind == C_GROUP_AGG ? op->max_unique_keys : -1;
+      c->best_effort_groups = op->kind == C_GROUP_AGG ? op->best_effort_groups : 0;
       block_init(&c->block, &c->schema, 16);  /* kDefaultResultEstimatedGroupCount, aggregate.h:162 */
     } break;
     case C_HASH_JOIN: {
@@ -1706,6 +1712,66 @@ static int cursor_next(orc_cursor* c, int64_t max_rows, orc_view* out) {
       return 1;
     }
     case C_GROUP_AGG: {
+      if (c->best_effort_groups > 0) {
+        /* BestEffortGroupAggregate: GroupAggregateCursor::Next / ProcessInput with best_effort_ (aggregate_groups.cc:211-222,
+         * 332-433).  The reference aggregates input until its key set / result block cannot take another key (an allocator
+         * verdict: deterministic under GuaranteeMemory, aggregate_groups.cc:160-163), emits what it has, and when that has
+         * been read resets key set and aggregator (:333-345) and goes on with the input rows it had not consumed
+         * (child_.truncate, :362).  Restated with the result block's row capacity as the verdict: a view aggregates the
+         * longest run of input rows, starting where the last one stopped, that holds at most `best_effort_groups` keys. */
+        for (;;) {
+          if (c->done && c->emit_pos < c->out_rows) {
+            int64_t n = c->out_rows - c->emit_pos; if (n > max_rows) n = max_rows;
+            view_from_block(c, &c->block, c->emit_pos, n, out);
+            c->emit_pos += n; return 1;
+          }
+          if (c->done && c->eos && !(c->have_cur && c->read_ptr < c->cur.rows)) return 0;
+          /* ProcessInput */
+          if (!c->chain_next) {
+            c->chain_next = (int64_t*)malloc(sizeof(int64_t) * (size_t)c->block.cap);
+            c->row_hash = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)c->block.cap);
+          }
+          c->nbuckets = 32; c->out_rows = 0; group_rehash(c, c->nbuckets);
+          reset_agg_rows(c, c->nproj, 0, c->block.cap);
+          for (int j = 0; j < c->nagg; ++j) { agg_col* g = &c->aggs[j]; if (g->distinct && g->dcap) { for (int64_t q = 0; q < g->dcap; ++q) g->drow[q] = -1; g->dcount = 0; } }
+          int full = 0; int64_t consumed = 0;
+          while (!full) {
+            if (!(c->have_cur && c->read_ptr < c->cur.rows)) {
+              if (c->eos) break;
+              int r = cursor_next(c->child, ORC_BLOCK, &c->cur);
+              if (r < 0) { c->err = c->child->err; return -1; }
+              if (r == 0) { c->eos = 1; c->have_cur = 0; break; }
+              c->have_cur = 1; c->read_ptr = 0;
+            }
+            /* the rest of the pending block, as a view of its own */
+            orc_view in = c->cur; in.rows = c->cur.rows - c->read_ptr;
+            for (int k = 0; k < in.n; ++k) {
+              const int w = type_width(c->child->schema.a[k].type);
+              in.c[k].data = (const char*)c->cur.c[k].data + c->read_ptr * w;
+              if (in.c[k].is_null) in.c[k].is_null = c->cur.c[k].is_null + c->read_ptr;
+            }
+            int64_t map[ORC_BLOCK]; int64_t take = 0;
+            const int64_t saved_limit = c->max_unique_keys; c->max_unique_keys = -1;
+            for (; take < in.rows; ++take) {
+              const int64_t before = c->out_rows;
+              if (before >= c->best_effort_groups) {
+                /* would this row need a new group?  look it up without inserting */
+                const uint64_t h = hash_row(c, &in, take); int64_t g = c->bucket_head[h & (uint64_t)(c->nbuckets - 1)];
+                for (; g >= 0; g = c->chain_next[g]) if (c->row_hash[g] == h && key_equal(c, &in, take, g)) break;
+                if (g < 0) { full = 1; break; }
+                map[take] = g; continue;
+              }
+              map[take] = group_insert(c, &in, take);
+            }
+            c->max_unique_keys = saved_limit;
+            in.rows = take;
+            for (int j = 0; j < c->nagg; ++j) update_aggregation(&c->aggs[j], &in, map, c->block.data[c->nproj + j], c->block.nulls[c->nproj + j]);
+            c->read_ptr += take; consumed += take;
+          }
+          c->done = 1; c->emit_pos = 0;
+          if (c->out_rows == 0) return 0;      /* (no input rows at all) */
+        }
+      }
       /* GroupAggregateCursor::ProcessInput, cursor/core/aggregate_groups.cc:332-433: consume
        * ALL input, then iterate the result (keys || aggregates, first-seen order) */
       if (!c->done) {

@@ -144,6 +144,8 @@ SYMBOLS = [
     ("ssgpu_plan_stage_info", C.c_int, [P, C.c_int32, C.POINTER(StageInfo)]),
     ("ssgpu_plan_specialize_reason", C.c_char_p, [P]),
     ("ssgpu_memory_stats", C.c_int, [C.POINTER(MemoryStats)]),
+    ("ssgpu_pool_trim", C.c_int64, [C.c_int32]),
+    ("ssgpu_plan_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("ssgpu_plan_memory_in_use", C.c_int64, [P]),
     ("ssgpu_expr_bind", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.POINTER(Expr), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_expr_row_capacity", C.c_int64, [P]),

@@ -194,6 +194,11 @@ def specialized_kernels_trim(keep=0):
     L.load().ssgpu_specialized_kernels_trim(int(keep))
 
 
+def pool_trim(device=-1):
+    """ssgpu_pool_trim: free the device blocks the library keeps between plans (all devices by default); returns bytes freed."""
+    return L.load().ssgpu_pool_trim(int(device))
+
+
 def memory_stats():
     """ssgpu_memory_stats: what the library holds in this process right now (device / pinned bytes, live plans, blocks and
     events, loaded specialised-kernel modules), as a dict."""
@@ -1088,6 +1093,11 @@ class Plan(object):
 
     def describe(self):
         return self.lib.ssgpu_plan_describe(self.handle).decode()
+
+    def set_option(self, key, value):
+        """ssgpu_plan_set_option: an option of this plan alone ("lazy_feedback")."""
+        self.ctx.check(self.lib.ssgpu_plan_set_option(self.handle, key.encode(), int(value)))
+        return self
 
     def set_memory_limit(self, nbytes):
         """Soft quota on the device memory this plan holds (ssgpu_plan_set_memory_limit); None or < 0 = unlimited."""

@@ -262,6 +262,7 @@ void* ssgpu_rtc_function(void* handle);
 void ssgpu_rtc_release(void* handle);
 void ssgpu_rtc_cached_only(bool on);   // the calling thread's requests from now on: find a kernel (memory, disk) or fail -- never compile
 void ssgpu_rtc_mode(int mode);         // ... in general: 0 compile what is missing now, 1 never compile, 2 leave what is missing to the worker thread
+int ssgpu_rtc_current_mode();         // the calling thread's mode (a slot remembers the mode it missed under: a stronger one asks again)
 bool ssgpu_rtc_pending();              // the calling thread's last request came back empty-handed because its kernel is being compiled
 void ssgpu_rtc_trim(int keep);   // unloads kernels without a user down to `keep` of them
 void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compilations, long long* disk_hits);

@@ -111,9 +111,13 @@ struct DevPool {
   std::multimap<size_t, std::pair<void*, int>> blocks;   // capacity -> (pointer, device)
   size_t bytes = 0;
   size_t limit() { static const size_t v = [] { const char* e = getenv("SSGPU_POOL_MB"); return (size_t)(e ? atoll(e) : 4096) << 20; }(); return v; }
+  // The device of a parked block is the device of the POINTER (hipPointerGetAttributes), never the calling thread's current
+  // device: ssgpu_plan_destroy may run while another context's device is current (round-5 advice).
   bool park(void* p, size_t cap) {
-    int dev = 0;
-    if (limit() == 0 || hipGetDevice(&dev) != hipSuccess) return false;
+    if (limit() == 0) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int dev = attr.device;
     std::lock_guard<std::mutex> lock(m);
     if (bytes + cap > limit() || blocks.size() >= 4096) return false;
     blocks.emplace(cap, std::make_pair(p, dev)); bytes += cap;
@@ -128,8 +132,28 @@ struct DevPool {
       if (it->second.second == dev) { void* p = it->second.first; *cap = it->first; bytes -= it->first; blocks.erase(it); return p; }
     return nullptr;
   }
+  // frees every parked block (dev < 0) or those of one device; returns the bytes given back to the driver
+  size_t trim(int dev);
+  size_t parked(int dev) {
+    std::lock_guard<std::mutex> lock(m);
+    size_t n = 0;
+    for (auto& b : blocks) if (dev < 0 || b.second.second == dev) n += b.first;
+    return n;
+  }
 };
 static DevPool g_pool;
+size_t DevPool::trim(int dev) {
+  std::vector<std::pair<void*, size_t>> out;
+  {
+    std::lock_guard<std::mutex> lock(m);
+    for (auto it = blocks.begin(); it != blocks.end();)
+      if (dev < 0 || it->second.second == dev) { out.emplace_back(it->second.first, it->first); bytes -= it->first; it = blocks.erase(it); } else ++it;
+  }
+  size_t freed = 0;
+  for (auto& b : out) { (void)hipFree(b.first); g_dev_bytes.fetch_sub((long long)b.second); freed += b.second; }
+  return freed;
+}
+static std::atomic<int> g_device_contexts{0};          // contexts with a device alive in this process: the last one to go empties the pool
 static thread_local bool tls_park_released = false;   // set while a plan whose stream has been drained is being destroyed
 
 struct DevBuf {
@@ -156,6 +180,12 @@ struct DevBuf {
     // (a plan under a quota allocates exactly what it asks for; a pooled block is still counted in g_dev_bytes)
     if (void* pooled = (Q && Q->limit >= 0) ? nullptr : g_pool.take(want, &pooled_cap)) { p = pooled; cap = pooled_cap; q = Q; if (q) q->used += (int64_t)cap; return hipSuccess; }
     hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory) {
+      // the driver is out of memory while blocks of destroyed plans sit in the pool: give those back and ask once more
+      (void)hipGetLastError();
+      int dev = -1;
+      if (hipGetDevice(&dev) == hipSuccess && g_pool.trim(dev) > 0) e = hipMalloc(&p, want);
+    }
     if (e == hipSuccess) { cap = want; q = Q; g_dev_bytes.fetch_add((long long)want); if (q) q->used += (int64_t)want; } else p = nullptr;
     return e;
   }
@@ -186,10 +216,15 @@ struct StageExec {
   // LDS size it was compiled for when that exceeds what a module-loaded kernel may ask for dynamically (0 = dynamic).
   struct RtcSlot {
     void* h = nullptr; bool tried = false; uint32_t static_lds = 0, tag = 0;   // tag: what else the kernel was compiled for (partition count, rows per thread)
+    // the request mode (rtc.cpp: 0 compile now, 1 caches only, 2 leave it to the worker) the slot came back empty-handed under: a
+    // small first run of a specialize = 3 plan asks in mode 1 and misses -- a later LARGE run (mode 2) must ask again, or the plan
+    // would stay on the interpreter for its lifetime (round-5 advice)
+    int missed_mode = -1;
+    bool stronger_mode_now() const { if (h || missed_mode < 0) return false; const int m = ssgpu_rtc_current_mode(); return missed_mode == 1 && m != 1; }
     // the kernel was being compiled when the slot asked (rtc.cpp: background compilation, or another plan's): the slot asks again --
     // not at every launch, the request rebuilds the kernel's key -- until it has it
     bool pending = false; std::chrono::steady_clock::time_point next_poll{};
-    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; tag = 0; pending = false; }
+    void drop() { if (h) ssgpu_rtc_release(h); h = nullptr; tried = false; static_lds = 0; tag = 0; pending = false; missed_mode = -1; }
     bool ask_again() {
       if (!pending) return false;
       const auto now = std::chrono::steady_clock::now();
@@ -197,7 +232,7 @@ struct StageExec {
       next_poll = now + std::chrono::milliseconds(20);
       return true;
     }
-    void asked() { pending = !h && ssgpu_rtc_pending(); if (pending) next_poll = std::chrono::steady_clock::now() + std::chrono::milliseconds(20); }
+    void asked() { pending = !h && ssgpu_rtc_pending(); missed_mode = h ? -1 : ssgpu_rtc_current_mode(); if (pending) next_poll = std::chrono::steady_clock::now() + std::chrono::milliseconds(20); }
   };
   RtcSlot rtc_main;             // the main program's specialised kernel, h == NULL: interpreter
   std::vector<VmInstr> host_prog_main;   // the finalised main program (what rtc.cpp compiles)
@@ -319,6 +354,7 @@ struct ssgpu_plan {
   int64_t n_runs = 0;           // runs started
   bool specialize = false;      // this plan's kernels are specialised by runtime compilation (ctx option at creation, or ssgpu_plan_specialize)
   bool cached_only = false;     // ... but only where the kernel exists already (option specialize = 2 / 3): no run of this plan waits for the compiler
+  bool lazy_feedback = false;   // the context's option at the time the plan was made, or ssgpu_plan_set_option: THIS plan's steady-state runs leave their feedback on the stream
   bool background = false;      // ... and what is missing is left to the worker thread (option 3) when a run of >= background_min_rows rows wants it
   int64_t background_min_rows = 0;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
@@ -394,6 +430,7 @@ int ssgpu_ctx_create(int device_id, ssgpu_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SSGPU_ERROR_HIP; }
     c->own_stream = true;
+    g_device_contexts.fetch_add(1);
     (void)ssgpu_pipeline_set_max_lds(160 * 1024);
     (void)ssgpu_part_agg_set_max_lds(160 * 1024);
   }
@@ -409,9 +446,12 @@ static void ctx_release(ssgpu_ctx* c) {
   if (c->device >= 0) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (g_device_contexts.fetch_sub(1) == 1) (void)g_pool.trim(-1);   // nobody is left to take a parked block
   }
   delete c;
 }
+// Gives the device blocks the library keeps between plans (DevPool) back to the driver; device < 0 = every device.
+int64_t ssgpu_pool_trim(int32_t device) { return (int64_t)g_pool.trim(device); }
 void ssgpu_ctx_destroy(ssgpu_ctx* c) { if (c) ctx_release(c); }
 
 int ssgpu_ctx_has_device(const ssgpu_ctx* c) { return c && c->device >= 0 ? 1 : 0; }
@@ -693,6 +733,7 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   for (auto& a : p->result_schema) p->attr_names.push_back(a.name);
   p->result.plan = p;
   p->specialize = c->specialize > 0;
+  p->lazy_feedback = c->lazy_feedback != 0;
   p->cached_only = c->specialize == 2 || c->specialize == 3;
   p->background = c->specialize == 3; p->background_min_rows = c->specialize_min_rows;
   if (c->device >= 0) {
@@ -702,6 +743,16 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
   g_live_plans.fetch_add(1);
   *out = p;
   return SSGPU_OK;
+}
+
+// Options of ONE plan (ABI 9).  "lazy_feedback": what the context option of that name gives every plan created under it, for this
+// plan only -- the sharded drivers opt their own plans in without changing the contract of other plans on a shared context.
+int ssgpu_plan_set_option(ssgpu_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  const std::string k = key;
+  if (k == "lazy_feedback") { p->lazy_feedback = value != 0; return SSGPU_OK; }
+  if (p->ctx) p->ctx->err = "unknown plan option '" + k + "'";
+  return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
 }
 
 void ssgpu_plan_destroy(ssgpu_plan* p) {
@@ -722,6 +773,7 @@ void ssgpu_plan_destroy(ssgpu_plan* p) {
   for (auto& ex : p->exec) if (ex.fb_event) { (void)hipEventDestroy(ex.fb_event); ex.fb_event = nullptr; g_events.fetch_sub(1); }
   ssgpu_ctx* c = p->ctx;
   g_live_plans.fetch_sub(1);
+  if (c && c->device >= 0) (void)hipSetDevice(c->device);   // frees and parks below belong to the plan's device, whatever is current
   tls_park_released = c && c->device >= 0;   // the stream was drained above: the plan's device blocks may go to the pool (DevPool)
   delete p;
   tls_park_released = false;
@@ -783,7 +835,7 @@ void* rtc_for(ssgpu_plan* p, StageExec& ex, StageExec::RtcSlot& slot, const Prog
   if (!p->specialize) return nullptr;
   ssgpu_ctx* c = p->ctx;
   const uint32_t need_static = lds_bytes > 64u * 1024u ? ((lds_bytes + 15u) & ~15u) : 0u;
-  if (slot.tried && slot.static_lds == need_static && !slot.ask_again()) return slot.h;
+  if (slot.tried && slot.static_lds == need_static && !slot.ask_again() && !slot.stronger_mode_now()) return slot.h;
   if (slot.h) { (void)hipStreamSynchronize(c->stream); slot.drop(); }   // launches of the kernel being replaced may still be in flight
   const bool was_pending = slot.pending;
   slot.tried = true; slot.static_lds = need_static;
@@ -1741,7 +1793,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       const uint32_t hot_lds = fixed + SSGPU_HOT_SLOTS * entry;
       const int hgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
       H.n_parts = (unsigned int)hgrid;
-      if (p->specialize && !(ex.rtc_hot.tried && ex.rtc_hot.static_lds == hot_lds && !ex.rtc_hot.ask_again())) {
+      if (p->specialize && !(ex.rtc_hot.tried && ex.rtc_hot.static_lds == hot_lds && !ex.rtc_hot.ask_again() && !ex.rtc_hot.stronger_mode_now())) {
         if (ex.rtc_hot.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_hot.drop(); }
         ex.rtc_hot.tried = true; ex.rtc_hot.static_lds = hot_lds;
         std::string why;
@@ -1769,7 +1821,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
         const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
         const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
         const uint32_t tag = NP * 8u + (uint32_t)R * 2u + (dense ? 1u : 0u);
-        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag && !ex.rtc_plain.ask_again())) {
+        if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag && !ex.rtc_plain.ask_again() && !ex.rtc_plain.stronger_mode_now())) {
           if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
           ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds; ex.rtc_plain.tag = tag;
           std::string why;
@@ -1818,7 +1870,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       // one whole-LDS workgroup per CU; tiles of 2048 rows dealt round-robin
       const int rgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 2047) / 2048));
       A.n_parts = (unsigned int)rgrid;
-      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds && ex.rtc_resident.tag == (dense ? 1u : 0u) && !ex.rtc_resident.ask_again())) {
+      if (p->specialize && !(ex.rtc_resident.tried && ex.rtc_resident.static_lds == agg_lds && ex.rtc_resident.tag == (dense ? 1u : 0u) && !ex.rtc_resident.ask_again() && !ex.rtc_resident.stronger_mode_now())) {
         if (ex.rtc_resident.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_resident.drop(); }
         ex.rtc_resident.tried = true; ex.rtc_resident.static_lds = agg_lds; ex.rtc_resident.tag = dense ? 1u : 0u;
         std::string why;
@@ -1829,7 +1881,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (p->specialize && ex.rtc_resident.h && ex.rtc_resident.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_resident.h, A, S, rgrid, c->stream));
       else HIP_TRY(c, ssgpu_launch_group_resident(A, S, agg_lds, rgrid, c->stream));
     } else
-    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) && !ex.rtc_part.ask_again())) {
+    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) && !ex.rtc_part.ask_again() && !ex.rtc_part.stronger_mode_now())) {
       // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
       if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
       ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = dense ? 1u : 0u;
@@ -1855,7 +1907,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     HIP_TRY(c, ex.fb_host.ensure(16));
     uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // [0] a partition outgrew its LDS table, [1] a segment ran full
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
-    if (attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && tail_runs_without_host(p, si)) {
+    if (attempt == 0 && ex.steady >= 2 && p->lazy_feedback && !c->debug_timing && tail_runs_without_host(p, si)) {
       // steady state: this shape held the last runs -- the flags are looked at lazily (settle_plan), no synchronise here
       { const int rc = record_feedback(c, ex); if (rc != SSGPU_OK) return rc; }
       ex.fb_pending = 2; p->deferred = true;
@@ -1915,6 +1967,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
         while (growth < 64u && (double)seg_cap / (double)ex.part_seg_growth * (double)growth < (double)fullest * 1.1) growth *= 4u;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
+        free_b += g_pool.parked(c->device);        // parked blocks are given back when an allocation needs them (DevBuf::ensure)
         const double need = (double)n_segs * ((double)seg_cap / (double)ex.part_seg_growth * (double)growth) * (double)st.part_rec_bytes;
         if ((double)seg_cap / (double)ex.part_seg_growth * (double)growth < (double)fullest * 1.1 || need > ((double)free_b + (double)ex.part_recs.cap) * 0.25 || (dense && growth > 16u)) {
           if (dense) { ex.dense.on = false; ex.dense.failed = true; ex.part_seg_growth = 1; }
@@ -2069,7 +2122,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     HIP_TRY(c, ex.fb_host.ensure(16));
     uint32_t* fb = static_cast<uint32_t*>(ex.fb_host.p);   // overflow flag, rows that bypassed the local table, max local occupancy
     HIP_TRY(c, hipMemcpyAsync(fb, ex.goverflow.p, 16, hipMemcpyDeviceToHost, c->stream));
-    if (!scout && attempt == 0 && ex.steady >= 2 && c->lazy_feedback && !c->debug_timing && tail_runs_without_host(p, si)) {   // (a scout run exists for its feedback: always read)
+    if (!scout && attempt == 0 && ex.steady >= 2 && p->lazy_feedback && !c->debug_timing && tail_runs_without_host(p, si)) {   // (a scout run exists for its feedback: always read)
       { const int rc = record_feedback(c, ex); if (rc != SSGPU_OK) return rc; }
       ex.fb_pending = 1; p->deferred = true;   // steady state: looked at lazily (settle_plan)
       break;
@@ -2776,7 +2829,7 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
   if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   int rc = run_plan(p, cols, n_cols, rows, 0, false);
   if (rc != SSGPU_OK) return rc;
-  if (!p->ctx->lazy_feedback) {
+  if (!p->lazy_feedback) {
     // the safe mode (default): everything that could make the library read the input columns again is decided HERE, while the
     // caller still holds them -- run feedback is never deferred in this mode, and the NaN-exact repeat of a floating MIN / MAX
     // happens now instead of when the result is first touched.  (An evaluation error still surfaces where it always did: when
@@ -3019,7 +3072,7 @@ static int stream_flush(ssgpu_plan* p, int b, int64_t n) {
     HIP_TRY(c, bigger.ensure(std::max<size_t>((size_t)(hs.chunks + 1) * state_bytes * 2, 64 * state_bytes)));
     if (hs.chunks) HIP_TRY(c, hipMemcpyAsync(bigger.p, p->host_states.p, (size_t)hs.chunks * state_bytes, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::swap(bigger.p, p->host_states.p); std::swap(bigger.cap, p->host_states.cap);
+    std::swap(bigger.p, p->host_states.p); std::swap(bigger.cap, p->host_states.cap); std::swap(bigger.q, p->host_states.q);
   }
   HIP_TRY(c, hipMemcpyAsync(p->host_states.as<char>() + (size_t)hs.chunks * state_bytes, p->exec[0].state.p, state_bytes, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(hs.consumed[b], c->stream));

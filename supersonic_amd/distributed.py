@@ -680,7 +680,6 @@ class DeviceShardedGroupAggregate(object):
         import torch.distributed as dist
         self.torch, self.dist = torch, _dist_for(group)
         self.ctx, self.group = ctx, group
-        ctx.set_option("lazy_feedback", 1)       # a step never waits for the host; the job keeps its shard's columns alive (ssgpu.h: INPUT LIFETIME)
         assert exchange in ("all_gather", "key_range")
         self.exchange = exchange
         self.world = dist.get_world_size(group)
@@ -699,6 +698,9 @@ class DeviceShardedGroupAggregate(object):
             self.strings = job_strings(ss.collect_strings(op), group)
             probe = ss.Plan(op, ctx, self.strings)
         self.first = probe
+        # a step never waits for the host; the job keeps its shard's columns alive (ssgpu.h: INPUT LIFETIME) -- an option of the job's
+        # OWN plans: other plans on the (possibly shared) context keep the default contract
+        self.first.set_option("lazy_feedback", 1)
         self.capacity = int(capacity_rows)
         self.merge = None
         self.collectives = 0
@@ -771,6 +773,7 @@ class DeviceShardedGroupAggregate(object):
         if self.merge is None:
             self.merge = ss.Plan(_merge_plan(self.group_by, self.merged_spec, self.counts, self.first.result_schema, everyone,
                                              valid="__valid"), self.ctx, self.strings)
+            self.merge.set_option("lazy_feedback", 1)
         self.merge.run(everyone)
         return self.merge
 
@@ -823,6 +826,7 @@ class PlanDenseBackend(object):
         ctx.set_option("group_dense", 1)
         self.ctx = ctx
         self.plan = ss.Plan(op, ctx, strings) if strings is not None else ss.Plan(op, ctx)
+        self.plan.set_option("lazy_feedback", 1)      # (the job keeps its shard's columns alive between steps)
         self.device = torch.device("cuda", torch.cuda.current_device())
         raw = ctx.stream()
         self._lib_stream = torch.cuda.ExternalStream(raw) if raw else torch.cuda.default_stream(self.device)

@@ -42,6 +42,21 @@ def build(name, force=False):
     return out
 
 
+def expected():
+    """Guide binaries the build container said it built (tests/cpp/_build/EXPECTED, written by mark_expected)."""
+    try:
+        with open(os.path.join(OUT_DIR, "EXPECTED")) as f:
+            return [ln.strip() for ln in f if ln.strip()]
+    except OSError:
+        return []
+
+
+def mark_expected(names):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, "EXPECTED"), "w") as f:
+        f.write("".join(n + "\n" for n in names))
+
+
 if __name__ == "__main__":
     for g in GUIDES:
         print(g, "->", build(g, force="--force" in sys.argv))

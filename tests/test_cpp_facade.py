@@ -96,11 +96,24 @@ def test_reference_guide_compiles_and_links_unchanged(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", build_ref_guides.GUIDES)
 def test_reference_guide_runs_green(name):
+    """The binary is built where a reference checkout exists (the build container, __graft_entry__.build()) and travels to the GPU box
+    with the other built artefacts.  build() leaves tests/cpp/_build/EXPECTED next to it: where that file (or SSGPU_EXPECT_REF_GUIDES=1)
+    says the binaries were built, a missing one FAILS -- a skip here would read as a pass.  What ran is appended to
+    gpurun_out/ref_guides_ran.txt (copied into profiles/ with the round's other evidence)."""
     out = build_ref_guides.build(name) or build_ref_guides.binary(name)
+    expected = os.environ.get("SSGPU_EXPECT_REF_GUIDES") == "1" or name in build_ref_guides.expected()
     if not os.path.exists(out):
+        assert not expected, "tests/cpp/_build/ref_guide_%s is expected (tests/cpp/_build/EXPECTED / SSGPU_EXPECT_REF_GUIDES) and missing" % name
         pytest.skip("tests/cpp/_build/ref_guide_%s was not built (no reference checkout where this tree was built)" % name)
     p = subprocess.run([out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
     assert p.returncode == 0 and "[  PASSED  ]" in p.stdout and "FAILED" not in p.stdout, p.stdout[-4000:]
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "ref_guides_ran.txt"), "a") as f:
+            passed = [ln.strip() for ln in p.stdout.splitlines() if "[       OK ]" in ln]
+            f.write("ref_guide_%s: rc 0, %d TESTs OK: %s\n" % (name, len(passed), "; ".join(passed)))
+    except OSError:
+        pass
 
 
 # ---- the C++ host's multi-GPU driver (include/supersonic_amd/sharded.h): RCCL linked directly ---------------------------

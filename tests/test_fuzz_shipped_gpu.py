@@ -32,13 +32,22 @@ LEGS = [
     ("specialized/general", "plan", 0, 2000, 1537, 1000, SPEC),
     ("specialized/many-tiles", "plan", 2000, 200, 70001, 0, SPEC),
     ("specialized/ordered", "ordered_aggregate_plan", 4000, 250, 1537, 0, SPEC),
-    ("specialized/key-limit", "distinct_limit_plan", 6000, 200, 1537, 0, SPEC),
-    ("specialized/row-after-row", "sequential_sum_plan", 5000, 150, 1537, 0, SPEC),
     ("dense/plain-groups", "plain_group", 0, 2000, 0, 0, DENSE),
     ("dense/general", "plan", 0, 2000, 1537, 1000, DENSE),
     ("dense+specialized/plain-groups", "plain_group", 2000, 400, 0, 0, BOTH),
     ("dense+specialized/many-tiles", "plan", 2000, 200, 70001, 0, BOTH),
 ]
+
+
+# the multi-stage shapes (three to four compiled kernels per plan): part of the full corpus (SS_FUZZ_SHIPPED_FULL=1; the round's full
+# run is profiles/r06_fuzz_shipped_full.json: 20 minutes with 48 workers), not of the default suite, which has to fit the driver's
+# time limit next to the other 5000 tests
+FULL_LEGS = [
+    ("specialized/key-limit", "distinct_limit_plan", 6000, 200, 1537, 0, SPEC),
+    ("specialized/row-after-row", "sequential_sum_plan", 5000, 150, 1537, 0, SPEC),
+]
+if os.environ.get("SS_FUZZ_SHIPPED_FULL") == "1":
+    LEGS = LEGS + FULL_LEGS
 
 
 def jobs():
