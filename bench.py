@@ -385,6 +385,28 @@ def _pin_cpus():
     return sorted(first.values()) or sorted(allowed)
 
 
+def _cpu_quota():
+    """CPUs' worth of time this process's cgroup may use (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), or None if unlimited: threads
+    beyond it are throttled, not run -- the GPU boxes of this pool report 256 CPUs and schedule about 16."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return max(1, int(round(int(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0 and period > 0:
+            return max(1, int(round(quota / float(period))))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _mem_available():
     try:
         with open("/proc/meminfo") as f:
@@ -436,7 +458,10 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True, rows_
     one = n * r1["passes"] / r1["seconds"]
     # N threads: one contiguous row range per thread, filled by the thread itself from the 1-thread sample
     physical, nproc = _physical_cores()
-    nthreads = max(1, min(len(pin), physical, 256))
+    quota = _cpu_quota()
+    nthreads = max(1, min(len(pin), physical, 256, quota or 256))     # one thread per physical core the cgroup actually schedules
+    if nthreads < len(pin):                                             # spread the threads over the sockets / CCDs (memory channels)
+        pin = [pin[i * len(pin) // nthreads] for i in range(nthreads)]
     per = int(min(rows_per_thread, n, max(65536, _mem_available() // 4 // max(nthreads * row_bytes, 1))))
     total = per * nthreads
     big = [np.empty(total, dtype=c.dtype) for c in cols]          # untouched pages: first written by the thread that reads them
@@ -459,7 +484,7 @@ def cpu_baseline(ss, query, sample_rows, budget_s=10.0, with_config0=True, rows_
     out = {"value": one, "unit": "rows/s", "cores": 1, "kind": "port", "gb_per_s": one * row_bytes / 1e9,
            "sample": "%d rows (same plan, seed 42), %d passes, %.1f s of CPU" % (n, r1["passes"], r1["seconds"]),
            "threads": threads,
-           "host": {"nproc": nproc, "physical_cores": physical, "model": _cpu_model()}}
+           "host": {"nproc": nproc, "physical_cores": physical, "cpu_quota_cores": quota, "model": _cpu_model()}}
     if not with_config0:
         return out
     # BASELINE configs[0]: Compute(a+b) -> Filter(a>K) -> Sum/Count on a 1 M-row x 4 INT64 table
@@ -538,6 +563,9 @@ def parse_args(argv=None):
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
     ap.add_argument("--opts", default="", help="extra context options (development): key=value,key=value")
+    ap.add_argument("--stagger", type=int, default=-1,
+                    help="development (A/B of HBM channel phase): place the input columns in ONE allocation, column i at i x (2 MiB-rounded size + this many "
+                         "bytes); -1 = one allocation per column as torch makes them")
     ap.add_argument("--no-events-in-loop", action="store_true",
                     help="do not record the per-kernel HIP events during the timed steps (kernel time from a separate loop)")
     ap.add_argument("--force-distributed", action="store_true",
@@ -743,6 +771,18 @@ def main():
     else:
         cols = gen_device_columns(torch, rows, 42 + rank, device, row_offset)
         schema = bench_schema(ss)
+    if args.stagger >= 0:
+        pitch = [((t.numel() * t.element_size() + (2 << 20) - 1) // (2 << 20)) * (2 << 20) + args.stagger for t in cols]
+        arena = torch.empty(sum(pitch) + (2 << 20), dtype=torch.uint8, device=device)
+        base = (-arena.data_ptr()) % (2 << 20)
+        placed, off = [], base
+        for t, pch in zip(cols, pitch):
+            nb = t.numel() * t.element_size()
+            dst = arena[off:off + nb].view(t.dtype)
+            dst.copy_(t)
+            placed.append(dst)
+            off += pch
+        cols = placed
     torch.cuda.synchronize(device)
     view = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in cols], rows)
     job = None

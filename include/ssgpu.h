@@ -243,6 +243,9 @@ enum {
   SSGPU_OP_GROUP_AGGREGATE = 6,    /* GroupAggregate(keys, spec, opts, child) aggregate.h:224 */
   SSGPU_OP_AGGREGATE_CLUSTERS = 7, /* AggregateClusters(keys, spec, child) aggregate.h:285 */
   SSGPU_OP_SORT = 8,               /* Sort(order, proj, mem_limit, child) sort.h:83 */
+  SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE = 10, /* BestEffortGroupAggregate(keys, spec, opts, child) aggregate.h:246-250; option0 =
+                                      GroupAggregateOptions::memory_quota in bytes (0 = none): the result block holds quota / bytes of a
+                                      result row groups; run with ssgpu_plan_run_best_effort (ABI 9) */
   SSGPU_OP_HASH_JOIN = 9           /* HashJoinOperation(type, lhs keys, rhs keys, result projector,
                                       uniqueness, lhs, rhs) hash_join.h:37-56.  `child` = lhs chain,
                                       `child2` = the rhs op, which must be a SCAN of the auxiliary
@@ -552,6 +555,20 @@ int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_c
  * context's value when it is created, and ssgpu_plan_set_option(plan, "lazy_feedback", v) changes it for that plan alone (ABI 9) --
  * which is what the sharded drivers do, so that other plans of a shared context keep the default contract. */
 int ssgpu_plan_set_option(ssgpu_plan* plan, const char* key, int64_t value);
+/* BestEffortGroupAggregate (cursor/core/aggregate.h:230-250; GroupAggregateCursor::Next / ProcessInput with best_effort_,
+ * aggregate_groups.cc:211-222,332-433), for a plan whose root is SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE (ABI 9).  ONE call is one
+ * ProcessInput: the GroupAggregate over the LONGEST run of input rows that starts at start_row and holds at most `capacity`
+ * distinct keys (capacity = option0 bytes / bytes of one result row -- widths + 1 per NULLABLE column, block.cc:20-36 --, at least 1;
+ * option0 = 0: no bound) -- the reference's verdict "the result block is full" is its allocator's, deterministic under
+ * GuaranteeMemory (:160-163); here it is the block's row capacity.  The rows of the result are key-unique; *next_row is where
+ * the next call starts, == rows when the input is exhausted.  The cursor contract on top (both host mirrors): every Next()
+ * returns rows of ONE such result, so "rows are key-unique on the group-by key within each returned view" holds, and an input
+ * of any size never raises ERROR_MEMORY_EXCEEDED -- a run that does not fit the plan's memory limit is repeated over half the
+ * input window with the capacity lowered to match; only a single row that does not fit fails (:405-412).
+ * Not available (bind-time ERROR_NOT_IMPLEMENTED): DISTINCT / CONCAT aggregates, floating SUMs into integers, and a
+ * BestEffortGroupAggregate below another operation. */
+int ssgpu_plan_run_best_effort(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t start_row,
+                               int64_t* next_row, ssgpu_result** out);
 int ssgpu_plan_run(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols,
                    int64_t rows, ssgpu_result** out);
 int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_result** out);

@@ -540,16 +540,20 @@ class AggregationSpecification {
 // default kint64max = no limit.  Memory quota / estimated row count: no device counterpart (tables are sized by run feedback).
 class GroupAggregateOptions {
  public:
-  GroupAggregateOptions() : max_unique_keys_in_result_(INT64_MAX) {}
+  GroupAggregateOptions() : max_unique_keys_in_result_(INT64_MAX), memory_quota_(0) {}
   int64_t max_unique_keys_in_result() const { return max_unique_keys_in_result_; }
   GroupAggregateOptions* set_max_unique_keys_in_result_(int64_t n) { max_unique_keys_in_result_ = n; return this; }
-  GroupAggregateOptions* set_memory_quota(size_t) { return this; }
+  // aggregate.h:170-175.  BestEffortGroupAggregate: the result block of a view holds quota / (bytes of a result row) groups
+  // (ssgpu.h ssgpu_plan_run_best_effort); GroupAggregate tables are sized by run feedback and ignore it.  0 / never set = no quota.
+  GroupAggregateOptions* set_memory_quota(size_t bytes) { memory_quota_ = bytes > (size_t(1) << 62) ? 0 : static_cast<int64_t>(bytes); return this; }
+  int64_t memory_quota() const { return memory_quota_; }
   GroupAggregateOptions* set_enforce_quota(bool) { return this; }
   GroupAggregateOptions* set_estimated_result_row_count(int64_t) { return this; }
   // ssgpu_op.option0: 0 = no limit, n > 0 = limit n, -1 = limit 0
   int64_t option0() const { return max_unique_keys_in_result_ == INT64_MAX ? 0 : max_unique_keys_in_result_ == 0 ? -1 : max_unique_keys_in_result_; }
  private:
   int64_t max_unique_keys_in_result_;
+  int64_t memory_quota_;
 };
 class SortOrder {
  public:
@@ -740,7 +744,7 @@ inline const View& SucceedOrDie(ResultView result_view) {   // cursor.h:124-127
 }
 
 // cursor/proto/cursors.proto:13-67 (the ids of the cursors this path has)
-enum CursorId { FILE_INPUT = 3, VIEW = 7, AGGREGATE_CLUSTERS = 8, COMPUTE = 15, FILTER = 16, GROUP_AGGREGATE = 18, HASH_JOIN = 19, PROJECT = 26,
+enum CursorId { FILE_INPUT = 3, VIEW = 7, AGGREGATE_CLUSTERS = 8, BEST_EFFORT_GROUP_AGGREGATE = 10, COMPUTE = 15, FILTER = 16, GROUP_AGGREGATE = 18, HASH_JOIN = 19, PROJECT = 26,
                 SCALAR_AGGREGATE = 29, SORT = 30, UNKNOWN_ID = 42 };
 class CursorTransformer;
 
@@ -781,7 +785,19 @@ class DeviceCursor : public Cursor {
 
   ResultView Next(rowcount_t max_row_count) override {
     ssgpu_ctx* ctx = internal::Context::Get().ctx;
-    if (!fetched_) {
+    if (id_ == BEST_EFFORT_GROUP_AGGREGATE) {
+      // GroupAggregateCursor::Next with best_effort_ (aggregate_groups.cc:211-222): serve the current result; when it has been read and
+      // the input is not exhausted, ProcessInput again (ssgpu_plan_run_best_effort).  A view never mixes rows of two results.
+      while (!failed_ && (!fetched_ || pos_ >= total_)) {
+        if (fetched_ && be_next_row_ >= be_rows_) return ResultView::EOS();
+        std::vector<ssgpu_column> cols;
+        int rc = StagedColumns(ctx, &cols, &be_rows_);
+        if (rc == SSGPU_OK) rc = ssgpu_plan_run_best_effort(plan_, cols.data(), static_cast<int32_t>(cols.size()), be_rows_, be_next_row_, &be_next_row_, &res_);
+        if (rc == SSGPU_OK) rc = internal::FetchResult(res_, schema_, &dict_, &total_, &host_data_, &host_null_, &cells_);
+        fetched_ = true; ran_ = true; run_rc_ = rc; pos_ = 0;
+        if (rc != SSGPU_OK) { failed_ = true; return ResultView::Failure(new Exception(rc, ssgpu_last_error(ctx))); }
+      }
+    } else if (!fetched_) {
       int rc = RunOnDevice();
       if (rc == SSGPU_OK) rc = internal::FetchResult(res_, schema_, &dict_, &total_, &host_data_, &host_null_, &cells_);
       fetched_ = true;
@@ -833,7 +849,7 @@ class DeviceCursor : public Cursor {
   // thousands of times and must not rebind them): forget the previous result, keep plan, buffers and staged input.
   // restage = true uploads the host View again (its contents changed); device-resident inputs are never copied.
   void Rewind(bool restage = false) {
-    ran_ = false; fetched_ = false; failed_ = false; pos_ = 0; total_ = 0; run_rc_ = SSGPU_OK;
+    ran_ = false; fetched_ = false; failed_ = false; pos_ = 0; total_ = 0; run_rc_ = SSGPU_OK; be_next_row_ = 0;
     if (restage) { if (block_) { ssgpu_block_destroy(block_); block_ = nullptr; } if (aux_block_) { ssgpu_block_destroy(aux_block_); aux_block_ = nullptr; } }
   }
   // Multi-GPU scalar aggregates (ssgpu.h: partial aggregates): run the shard's rows up to the partial-aggregate state ...
@@ -924,6 +940,7 @@ class DeviceCursor : public Cursor {
   std::vector<const uint8_t*> host_null_;
   std::vector<std::vector<StringPiece>> cells_;
   rowcount_t total_ = 0, pos_ = 0;
+  int64_t be_next_row_ = 0, be_rows_ = 0;   // BestEffortGroupAggregate: where the next view starts / the input's row count
   bool ran_ = false, failed_ = false, fetched_ = false;
   int run_rc_ = SSGPU_OK;
   CursorId id_ = UNKNOWN_ID;
@@ -1245,11 +1262,13 @@ class UnaryOp : public BasicOperation {
   const char* name() const override {
     switch (kind_) { case SSGPU_OP_COMPUTE: return "Compute"; case SSGPU_OP_FILTER: return "Filter"; case SSGPU_OP_PROJECT: return "Project";
                      case SSGPU_OP_SCALAR_AGGREGATE: return "ScalarAggregate"; case SSGPU_OP_GROUP_AGGREGATE: return "GroupAggregate";
+                     case SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE: return "BestEffortGroupAggregate";
                      case SSGPU_OP_AGGREGATE_CLUSTERS: return "AggregateClusters"; case SSGPU_OP_SORT: return "Sort"; default: return "Operation"; }
   }
   CursorId cursor_id() const override {
     switch (kind_) { case SSGPU_OP_COMPUTE: return COMPUTE; case SSGPU_OP_FILTER: return FILTER; case SSGPU_OP_PROJECT: return PROJECT;
                      case SSGPU_OP_SCALAR_AGGREGATE: return SCALAR_AGGREGATE; case SSGPU_OP_GROUP_AGGREGATE: return GROUP_AGGREGATE;
+                     case SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE: return BEST_EFFORT_GROUP_AGGREGATE;
                      case SSGPU_OP_AGGREGATE_CLUSTERS: return AGGREGATE_CLUSTERS; case SSGPU_OP_SORT: return SORT; default: return UNKNOWN_ID; }
   }
   int Emit(Builder* b) const override {
@@ -1314,6 +1333,14 @@ inline Operation* ScalarAggregate(AggregationSpecification* spec, Operation* chi
 inline Operation* GroupAggregate(const SingleSourceProjector* group_by, const AggregationSpecification* spec, GroupAggregateOptions* options, Operation* child) {
   std::unique_ptr<GroupAggregateOptions> own(options);
   return new internal::UnaryOp(SSGPU_OP_GROUP_AGGREGATE, child, nullptr, group_by, spec, nullptr, options ? options->option0() : 0);
+}
+// aggregate.h:230-250: groups and aggregates as many input rows as the result block holds, returns them, and starts anew with the
+// input it had not consumed -- rows are key-unique within each returned view, not across views; an input of any size is processed
+// (ERROR_MEMORY_EXCEEDED is not returned because the input is large).  options->memory_quota bounds the block; without one the
+// result is GroupAggregate's.  Takes ownership of its arguments like GroupAggregate.
+inline Operation* BestEffortGroupAggregate(const SingleSourceProjector* group_by, const AggregationSpecification* spec, GroupAggregateOptions* options, Operation* child) {
+  std::unique_ptr<GroupAggregateOptions> own(options);
+  return new internal::UnaryOp(SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE, child, nullptr, group_by, spec, nullptr, options ? options->memory_quota() : 0);
 }
 inline Operation* AggregateClusters(const SingleSourceProjector* clustered_by, const AggregationSpecification* spec, Operation* child) { return new internal::UnaryOp(SSGPU_OP_AGGREGATE_CLUSTERS, child, nullptr, clustered_by, spec, nullptr); }
 inline Operation* Sort(const SortOrder* order, const SingleSourceProjector* result_projector, size_t memory_limit, Operation* child) {

@@ -19,7 +19,7 @@ _NP = {1: np.int32, 2: np.int64, 8: np.uint32, 3: np.uint64, 9: np.float32, 5: n
        10: np.int32, 4: np.int64, 0: np.int32}   # 0 = STRING: dictionary codes inside the C restatement
 T_STRING = 0
 
-KIND = {"ScanView": 1, "Compute": 2, "Filter": 3, "Project": 4, "ScalarAggregate": 5, "GroupAggregate": 6,
+KIND = {"ScanView": 1, "Compute": 2, "Filter": 3, "Project": 4, "ScalarAggregate": 5, "GroupAggregate": 6, "BestEffortGroupAggregate": 6,
         "AggregateClusters": 7, "Sort": 8, "HashJoinOperation": 9}
 
 
@@ -51,6 +51,7 @@ def lib():
         L.orc_op_add_agg.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_op_add_sortkey.argtypes = [P, C.c_char_p, C.c_int]
         L.orc_op_set_max_unique_keys.argtypes = [P, C.c_int64]
+        L.orc_op_set_best_effort_quota.argtypes = [P, C.c_int64]
         L.orc_op_set_join.argtypes = [P, P, C.c_int]
         L.orc_op_add_proj_to.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_scan_add_column.argtypes = [P, C.c_char_p, C.c_int, C.c_int, P, P]
@@ -181,7 +182,10 @@ class _Tree(object):
         if kind == 8:
             for (name, order) in o.order.keys:
                 L.orc_op_add_sortkey(h, _enc(name), order)
-        if kind == 6 and getattr(o, "options", None) is not None:
+        if type(o).__name__ == "BestEffortGroupAggregate":      # aggregate.h:230-250; options.memory_quota bounds the result block
+            quota = getattr(getattr(o, "options", None), "memory_quota", None)
+            L.orc_op_set_best_effort_quota(h, int(quota) if quota is not None else 0)
+        elif kind == 6 and getattr(o, "options", None) is not None:
             limit = o.options.max_unique_keys_in_result        # GroupAggregateOptions (aggregate.h:160-205): kint64max = no limit
             if limit < (1 << 63) - 1:
                 L.orc_op_set_max_unique_keys(h, int(limit))

@@ -1070,6 +1070,7 @@ typedef struct orc_op {
   /* BestEffortGroupAggregate (cursor/core/aggregate.h:230-250): > 0 = the result block holds this many groups; the cursor emits
    * what it aggregated when the next unseen key does not fit and starts anew at that row (aggregate_groups.cc:332-433) */
   int64_t best_effort_groups;
+  int64_t best_effort_quota;    /* ... or GroupAggregateOptions::memory_quota in bytes (0 = none): groups = quota / bytes of a result row */
 } orc_op;
 
 orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
@@ -1077,6 +1078,10 @@ orc_op* orc_op_new(int kind, orc_op* child, orc_expr* expr) {
 }
 void orc_op_set_max_unique_keys(orc_op* o, int64_t limit) { o->max_unique_keys = limit; }
 void orc_op_set_best_effort(orc_op* o, int64_t groups) { o->best_effort_groups = groups < 1 ? 1 : groups; }
+/* BestEffortGroupAggregate under GroupAggregateOptions::set_memory_quota(bytes) (aggregate.h:170-175; 0 = no quota): the result block
+ * holds quota / (bytes of one result row: every column's width + 1 byte of is_null where NULLABLE, block.cc:20-36) rows, at least 1
+ * -- aggregate_groups_test.cc:601-626: INT32 key + INT32 SUM, both NULLABLE = 10 bytes, quota 20 => 2 groups per view */
+void orc_op_set_best_effort_quota(orc_op* o, int64_t bytes) { o->best_effort_groups = INT64_MAX; o->best_effort_quota = bytes < 0 ? 0 : bytes; }
 void orc_op_add_proj(orc_op* o, int kind, int position, const char* name, const char* alias) {
   orc_proj* p = &o->projs[o->nproj++]; p->kind = kind; p->position = position;
   snprintf(p->name, sizeof(p->name), "%s", name ? name : ""); snprintf(p->alias, sizeof(p->alias), "%s", alias ? alias : "");
@@ -1272,6 +1277,12 @@ orc_cursor* orc_create_cursor(const orc_op* op) {
       if (!bind_aggs(c, op, in)) return cursor_fail(c);
       c->max_unique_keys = op->kind == C_GROUP_AGG ? op->max_unique_keys : -1;
       c->best_effort_groups = op->kind == C_GROUP_AGG ? op->best_effort_groups : 0;
+      if (c->best_effort_groups > 0 && op->best_effort_quota > 0) {
+        int64_t row_bytes = 0;
+        for (int i = 0; i < c->schema.n; ++i) row_bytes += type_width(c->schema.a[i].type) + (c->schema.a[i].nullable ? 1 : 0);
+        c->best_effort_groups = op->best_effort_quota / (row_bytes > 0 ? row_bytes : 1);
+        if (c->best_effort_groups < 1) c->best_effort_groups = 1;
+      }
       block_init(&c->block, &c->schema, 16);  /* kDefaultResultEstimatedGroupCount, aggregate.h:162 */
     } break;
     case C_HASH_JOIN: {

@@ -40,6 +40,7 @@ PROJ_ALL, PROJ_NAMED, PROJ_AT, PROJ_NAMED_AS = 1, 2, 3, 4
 JOIN_INNER, JOIN_LEFT_OUTER = 0, 1
 KEYS_NOT_UNIQUE, KEYS_UNIQUE = 0, 1
 OP_SCAN, OP_COMPUTE, OP_FILTER, OP_PROJECT, OP_SCALAR_AGGREGATE, OP_GROUP_AGGREGATE, OP_AGGREGATE_CLUSTERS, OP_SORT = 1, 2, 3, 4, 5, 6, 7, 8
+OP_BEST_EFFORT_GROUP_AGGREGATE = 10
 OP_HASH_JOIN = 9
 
 
@@ -146,6 +147,7 @@ SYMBOLS = [
     ("ssgpu_memory_stats", C.c_int, [C.POINTER(MemoryStats)]),
     ("ssgpu_pool_trim", C.c_int64, [C.c_int32]),
     ("ssgpu_plan_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("ssgpu_plan_run_best_effort", C.c_int, [C.c_void_p, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
     ("ssgpu_plan_memory_in_use", C.c_int64, [P]),
     ("ssgpu_expr_bind", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.POINTER(Expr), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_expr_row_capacity", C.c_int64, [P]),
@@ -242,6 +244,8 @@ def load():
         _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
+            if os.environ.get("SSGPU_LIB") and not hasattr(lib, name):
+                continue             # (a build-variant experiment with an OLDER library, tools/ab/: entry points it lacks are not bound)
             fn = getattr(lib, name)  # AttributeError if the library does not export the ABI
             fn.restype = res
             fn.argtypes = args

@@ -704,9 +704,22 @@ class GroupAggregateOptions(object):
 
     def __init__(self):
         self.max_unique_keys_in_result = self.NO_LIMIT
+        self.memory_quota = None          # bytes; None = no quota (the reference's default: numeric_limits<size_t>::max())
 
     def set_max_unique_keys_in_result_(self, n):     # (the reference's spelling, trailing underscore included)
         self.max_unique_keys_in_result = int(n)
+        return self
+
+    def set_memory_quota(self, nbytes):
+        """aggregate.h:170-175.  BestEffortGroupAggregate: the result block of a view holds quota / (bytes of a result row) groups;
+        GroupAggregate tables are sized by run feedback and ignore it."""
+        self.memory_quota = int(nbytes)
+        return self
+
+    def set_enforce_quota(self, _flag):
+        return self
+
+    def set_estimated_result_row_count(self, _n):
         return self
 
     def _option0(self):
@@ -870,6 +883,23 @@ class GroupAggregate(Operation):
         af, an = b.aggspec(self.spec)
         return b.op(kind=L.OP_GROUP_AGGREGATE, child=c, proj_first=pf, proj_n=pn, agg_first=af, agg_n=an,
                     option0=(self.options._option0() if self.options else 0))
+
+
+class BestEffortGroupAggregate(Operation):
+    """cursor/core/aggregate.h:230-250: groups and aggregates as many input rows as the result block holds, returns them, and starts
+    anew with the input it had not consumed -- rows are key-unique within each returned view, not across views; an input of any
+    size is processed (no ERROR_MEMORY_EXCEEDED).  options.memory_quota bounds the block (include/ssgpu.h
+    ssgpu_plan_run_best_effort); without one the result is the GroupAggregate's."""
+
+    def __init__(self, group_by, aggregation, options, child):
+        self.group_by, self.spec, self.options, self.child = group_by, aggregation, options, child
+
+    def _emit(self, b):
+        c = self.child._emit(b)
+        pf, pn = b.proj(self.group_by)
+        af, an = b.aggspec(self.spec)
+        quota = self.options.memory_quota if (self.options is not None and self.options.memory_quota is not None) else 0
+        return b.op(kind=L.OP_BEST_EFFORT_GROUP_AGGREGATE, child=c, proj_first=pf, proj_n=pn, agg_first=af, agg_n=an, option0=max(0, min(int(quota), (1 << 62))))
 
 
 class AggregateClusters(Operation):
@@ -1192,6 +1222,16 @@ class Plan(object):
         self.ctx.check(self.lib.ssgpu_plan_run(self.handle, cols, n, rows, C.byref(res)))
         self._result = res
         return res
+
+    def run_best_effort(self, start_row=0, view=None):
+        """ssgpu_plan_run_best_effort: one view of a BestEffortGroupAggregate -- the aggregate over the longest run of input rows from
+        start_row on whose keys fit the result block.  Returns the row the next view starts at (== the input's row count: done)."""
+        self._bind_aux()
+        cols, n, rows = self._columns_for(view if view is not None else self.input)
+        res, nxt = C.c_void_p(), C.c_int64()
+        self.ctx.check(self.lib.ssgpu_plan_run_best_effort(self.handle, cols, n, rows, int(start_row), C.byref(nxt), C.byref(res)))
+        self._result = res
+        return nxt.value
 
     def run_host(self, view=None, chunk_rows=0):
         """Chunked staging (ssgpu_plan_run_host): the HOST columns of `view` (default: the plan's input) travel through two alternating
@@ -1534,6 +1574,8 @@ class Cursor(object):
         self._result = None
         self._pos = 0
         self._interrupted = False
+        self._best_effort = isinstance(operation, BestEffortGroupAggregate)
+        self._next_row, self._input_rows = 0, 0
 
     def schema(self):
         return self.plan.result_schema
@@ -1543,7 +1585,22 @@ class Cursor(object):
         self.plan.interrupt()
 
     def Next(self, max_row_count=kDefaultRowCount):
-        if self._result is None:
+        if self._best_effort:
+            # GroupAggregateCursor::Next with best_effort_ (aggregate_groups.cc:211-222): serve the current result; when it has been
+            # read and the input is not exhausted, ProcessInput again.  A view never mixes rows of two results.
+            while self._result is None or self._pos >= self._result.row_count():
+                if self._result is not None and self._next_row >= self._input_rows:
+                    return ResultView(eos=True)
+                try:
+                    self._next_row = self.plan.run_best_effort(self._next_row)
+                    self._result = self.plan.fetch()
+                    self._input_rows = self.plan.input.row_count()
+                    self._pos = 0
+                except SupersonicException as e:
+                    return ResultView(exception=e)
+                if self._result.row_count() == 0 and self._next_row >= self._input_rows:
+                    return ResultView(eos=True)
+        elif self._result is None:
             try:
                 self.plan.run()
                 self._result = self.plan.fetch()

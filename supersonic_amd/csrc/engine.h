@@ -185,6 +185,7 @@ struct Stage {
   // kept, every later row is merged into row fold_limit with the column's merge function (0 keep = key columns, 1 SUM, 2 MIN, 3 MAX,
   // 4 / 5 = FIRST / LAST: the value of the merged row whose UINT64 column fold_by[i] -- a row id -- is smallest / largest)
   int64_t fold_limit = -1;
+  bool fold_cut = false;   // BestEffortGroupAggregate: rows [0, capacity) are KEPT as they are, nothing is merged; the first-seen id of row `capacity` is the next view's first input row
   std::vector<int> fold_op, fold_by;
   // CONCAT aggregates (column_aggregator.cc:496-505, aggregation_operators.h:236-283): a result of STRINGs that exist nowhere yet.
   // The device counts the contributing (non-NULL) values in the column's place -- a UINT64 in out_schema -- and the host

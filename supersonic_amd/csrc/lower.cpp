@@ -1969,7 +1969,12 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
         pipe.cols = nc; pending = true;
         desc << (jtype == SSGPU_JOIN_INNER ? "HashJoin INNER" : "HashJoin LEFT_OUTER") << " -> [" << schema_to_string(schema_of(pipe.cols)) << "]\n";
       } break;
-      case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: {
+      case SSGPU_OP_SCALAR_AGGREGATE: case SSGPU_OP_GROUP_AGGREGATE: case SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE: {
+        // BestEffortGroupAggregate (aggregate.h:230-250, aggregate_groups.cc:332-433): a GroupAggregate whose table holds a bounded
+        // number of groups.  Lowered as the hash aggregate with the hidden first-seen row id, the table sorted by it (= first-seen
+        // order) and a CUT: the first `capacity` rows are the view, and the first-seen id of row `capacity` -- the first input row
+        // whose key found no room -- is where ssgpu_plan_run_best_effort aggregates again from (runtime.cpp).
+        const bool best_effort = op.kind == SSGPU_OP_BEST_EFFORT_GROUP_AGGREGATE;
         Stage st;
         std::vector<NanFix> nan_fixes; size_t n_user_aggs = 0, n_group_keys = 0;   // NaN-exact form (PlanDesc::nan_exact)
         // DISTINCT aggregates (SUM / COUNT of the distinct values of a group, column_aggregator.cc:308-376): materialise the
@@ -1987,6 +1992,10 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           any_seq = has_sequential(probe);
         }
         const bool limited_group = op.kind == SSGPU_OP_GROUP_AGGREGATE && op.option0 != 0;
+        if (best_effort && ci + 1 != chain.size())
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "a BestEffortGroupAggregate below another operation is not available on the device path (its views are handed out one run at a time)");
+        if (best_effort && (any_distinct || any_concat || any_seq))
+          return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "BestEffortGroupAggregate with DISTINCT / CONCAT aggregates or a floating SUM into an integer is not available on the device path");
         if (any_concat && !limited_group && !any_distinct) {
           // CONCAT (Stage::ConcatCol): the values have to reach the host in input order, group by group -- materialise the keys and
           // the aggregated columns, (stable) sort by the keys, aggregate the key runs with the clustered kernel (CONCAT counted as
@@ -2170,12 +2179,18 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
           // them.  Composed from existing stages: the hash aggregate with one hidden aggregate -- the group's smallest row id
           // --, a sort of the group table by it (= first-seen order), and a fold of the rows beyond the limit into row `limit`
           // with the aggregates' merge functions (SUM of sums, MIN of mins, MAX of maxes, SUM of counts).
-          const bool limited = op.option0 != 0;
+          const bool limited = best_effort || op.option0 != 0;     // (both forms need the first-seen row id and the table sorted by it)
           const int64_t limit = op.option0 < 0 ? 0 : op.option0;
           n_user_aggs = g.plans.size(); n_group_keys = g.kpos.size();
-          if (!limited) add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &g.plans, &nan_fixes);   // (under a key limit FIRST has no merge function)
+          if (!limited || best_effort) add_nan_exact_plans(d.nan_exact, schema_of(pipe.cols), &g.plans, &nan_fixes);   // (under a key limit FIRST has no merge function; a cut merges nothing)
           std::vector<int> fold_ops, fold_by;
-          if (limited) {
+          if (best_effort) {
+            for (size_t k = 0; k < g.kpos.size() + g.plans.size(); ++k) { fold_ops.push_back(0); fold_by.push_back(-1); }   // every column is kept as it is
+            if ((int)g.plans.size() + 1 > VM_MAX_AGG_SLOTS) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "too many aggregations for one pipeline");
+            AggPlan hidden; hidden.aggregation = AGG_FIRST_SEEN; hidden.input_pos = -1; hidden.out_type = SSGPU_UINT64;
+            hidden.out_name = "$first_seen"; hidden.result_nullable = false;
+            g.plans.push_back(hidden);
+          } else if (limited) {
             // FIRST / LAST under the limit: the folded row's value is the one at the smallest / largest contributing row id
             // over all the groups it absorbs (NULL inputs never contribute, aggregation_operators.h:290-320) -- every
             // FIRST / LAST gets a hidden twin that yields that row id, and the fold picks the value by it.
@@ -2218,10 +2233,19 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             for (size_t i = 0; i < so.in_schema.size(); ++i) so.sort_out_cols.push_back((int)i);
             stages->push_back(so);
             Stage ft; ft.kind = STAGE_FOLD_TAIL; ft.in_schema = so.out_schema; ft.fold_limit = limit; ft.fold_op = fold_ops; ft.fold_by = fold_by;
+            ft.fold_cut = best_effort;
+            if (best_effort) {
+              // GroupAggregateOptions::memory_quota in bytes (option0; 0 = none) -> the rows the result block holds: every visible column's
+              // width + its byte of is_null where NULLABLE (block.cc:20-36); aggregate_groups_test.cc:601-626: 20 bytes / (4+1 + 4+1) = 2
+              int64_t row_bytes = 0;
+              for (size_t i = 0; i < fold_ops.size(); ++i) row_bytes += dtype_width(so.out_schema[i].dtype) + (so.out_schema[i].nullable ? 1 : 0);
+              ft.fold_limit = op.option0 > 0 ? std::max<int64_t>(1, op.option0 / std::max<int64_t>(row_bytes, 1)) : 0;   // (0 = no bound; nothing is merged)
+            }
             ft.out_schema.assign(so.out_schema.begin(), so.out_schema.begin() + (long)fold_ops.size());   // (the row-id twins and the first-seen id end here)
             for (auto& a : ft.out_schema) if (dtype_width(a.dtype) == 0) return Status::Error(SSGPU_ERROR_NOT_IMPLEMENTED, "variable-length columns are outside the device hot path");
             st = ft;
-            desc << "(" << (too_wide ? "" : "hash aggregate + ") << "first-seen order + fold beyond " << limit << " keys) ";
+            if (best_effort) desc << "(" << (too_wide ? "" : "hash aggregate + ") << "first-seen order + cut at " << ft.fold_limit << " groups) ";
+            else desc << "(" << (too_wide ? "" : "hash aggregate + ") << "first-seen order + fold beyond " << limit << " keys) ";
             return Status::OK();
           };
           if (limited && !too_wide) SS_RETURN_IF_ERROR(append_limit_tail());
@@ -2259,7 +2283,7 @@ Status lower_plan(const PlanDesc& d, std::vector<Stage>* stages, Schema* result_
             if (limited) SS_RETURN_IF_ERROR(append_limit_tail());
           }
         }
-        desc << (op.kind == SSGPU_OP_SCALAR_AGGREGATE ? "ScalarAggregate" : "GroupAggregate") << " -> [" << schema_to_string(st.out_schema) << "]\n";
+        desc << (op.kind == SSGPU_OP_SCALAR_AGGREGATE ? "ScalarAggregate" : best_effort ? "BestEffortGroupAggregate" : "GroupAggregate") << " -> [" << schema_to_string(st.out_schema) << "]\n";
         stages->push_back(st);
         reset_pipe(&pipe, st.out_schema);
         pending = false;

@@ -670,7 +670,13 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
     vm_n_rows = have < (u64)P.n_rows ? (i64)have : P.n_rows;
     vm_n_tiles = (int)((vm_n_rows + tile_rows - 1) / tile_rows);
   }
-  const int n_my_tiles = vm_n_tiles > (int)blockIdx.x ? (vm_n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  // Which tile a workgroup takes first; round `it` of the tile loop takes tile first + it * grid.  Workgroups are dealt to the 8 XCDs
+  // round-robin (block b runs on XCD b % 8), so with first = b the 8 tiles around any row position belong to 8 different L2s.  A
+  // stage that WRITES compacted rows (the materialising Filter's store pass) then has both halves of the output line two
+  // neighbouring tiles share in two L2s, and each writes a partial line.  VM_FLAG_XCD_CHUNKS hands every XCD a contiguous eighth
+  // of each round's tiles: neighbours share an L2 (and the line is merged there) except at the 7 chunk borders.
+  const int vm_first_tile = ((P.flags & VM_FLAG_XCD_CHUNKS) && (gridDim.x & 7u) == 0u) ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int n_my_tiles = vm_n_tiles > vm_first_tile ? (vm_n_tiles - vm_first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int n_units = STAGED_COUNT(P) * K;
 
   // zero this workgroup's LDS aggregate records (slow slots; fast slots are written once)
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   for (int u = 0; u < VM_PF_UNITS; ++u) pf[u] = u32x4{0u, 0u, 0u, 0u};
   const int n_pf = n_units < VM_PF_UNITS ? n_units : VM_PF_UNITS;
   {
-    const i64 tb = (i64)blockIdx.x * tile_rows;
+    const i64 tb = (i64)vm_first_tile * tile_rows;
     if (n_my_tiles > 0 && tb + tile_rows <= vm_n_rows) {
 #pragma unroll
       for (int u = 0; u < VM_PF_UNITS; ++u)
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(VM_WG_THREADS, VM_WAVES_PER_EU) void ssgpu_pipeline
   const u64 dbg_t0 = P.debug ? __builtin_amdgcn_s_memtime() : 0;
   const ProgPtr prog = prog0;
   for (int it = 0; it < n_my_tiles; ++it) {
-    const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+    const int tile = vm_first_tile + it * (int)gridDim.x;
     const i64 tile_base = (i64)tile * tile_rows;
     const u32 tile_valid = (u32)((vm_n_rows - tile_base) < (i64)tile_rows ? (vm_n_rows - tile_base) : (i64)tile_rows);
     const u64 tw0 = (P.debug || P.debug_pc) ? __builtin_amdgcn_s_memtime() : 0;

@@ -44,6 +44,9 @@ struct ssgpu_ctx {
   std::string err;
   LowerOptions opt;
   int64_t grid_limit = 0;        // 0 = CUs * residency
+  int64_t out_stagger = 0;       // bytes between the channel phases of a stage's output columns (ensure_out_cols); 0 = every column at the base of its own allocation
+  int64_t tile_map = 1;          // which tile a workgroup of a pipeline launch takes: 0 = its block index (neighbouring tiles on different XCDs), 1 = XCD-contiguous
+                                 // chunks for launches that WRITE compacted / materialised rows (vm.h VM_FLAG_XCD_CHUNKS: lines two tiles share merge in one L2), 2 = for every launch
   int64_t wgs_per_cu = 3;        // resident 4-wave workgroups per CU (<= 4 at the kernel's 128-VGPR budget; 3 streams best)
   int64_t group_capacity = 1 << 18;
   int64_t group_local = 1;       // 0: never use the LDS pre-aggregation table
@@ -158,18 +161,35 @@ static thread_local bool tls_park_released = false;   // set while a plan whose 
 
 struct DevBuf {
   void* p = nullptr;
-  size_t cap = 0;
+  size_t cap = 0;         // bytes usable at p
+  size_t shift = 0;       // p sits this many bytes into its allocation (set before ensure): how the output columns of a stage get
+                          // bases of different HBM channel phase (ssgpu_ctx option out_stagger; profiles/r06_filter_ab.txt)
+  size_t held = 0;        // the shift p was allocated with
   MemQuota* q = nullptr;
   ~DevBuf() { release(); }
   void release() {
     if (p) {
-      if (q) q->used -= (int64_t)cap;
-      if (!(tls_park_released && g_pool.park(p, cap))) { (void)hipFree(p); g_dev_bytes.fetch_sub((long long)cap); }
+      void* base = static_cast<char*>(p) - held; const size_t full = cap + held;
+      if (q) q->used -= (int64_t)full;
+      if (!(tls_park_released && g_pool.park(base, full))) { (void)hipFree(base); g_dev_bytes.fetch_sub((long long)full); }
     }
-    p = nullptr; cap = 0; q = nullptr;
+    p = nullptr; cap = 0; held = 0; q = nullptr;
   }
   hipError_t ensure(size_t bytes) {
-    if (bytes <= cap && p) return hipSuccess;
+    if (bytes <= cap && p && held == shift) return hipSuccess;
+    if (shift) {      // (shifted buffers are few and large: allocated exactly, never taken from the pool)
+      const size_t want = std::max<size_t>(bytes, 256) + shift;
+      MemQuota* Q = g_quota;
+      if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)(cap + held) : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
+      release();
+      void* base = nullptr;
+      hipError_t e = hipMalloc(&base, want);
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); int dev = -1; if (hipGetDevice(&dev) == hipSuccess && g_pool.trim(dev) > 0) e = hipMalloc(&base, want); }
+      if (e != hipSuccess) return e;
+      p = static_cast<char*>(base) + shift; cap = want - shift; held = shift; q = Q;
+      g_dev_bytes.fetch_add((long long)want); if (q) q->used += (int64_t)want;
+      return hipSuccess;
+    }
     size_t want = std::max<size_t>(bytes, 256);
     MemQuota* Q = g_quota;
     if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)cap : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
@@ -354,6 +374,9 @@ struct ssgpu_plan {
   int64_t n_runs = 0;           // runs started
   bool specialize = false;      // this plan's kernels are specialised by runtime compilation (ctx option at creation, or ssgpu_plan_specialize)
   bool cached_only = false;     // ... but only where the kernel exists already (option specialize = 2 / 3): no run of this plan waits for the compiler
+  // BestEffortGroupAggregate (a stage with Stage::fold_cut): the row the last run's table had no room for (-1: every key fitted), the
+  // capacity in force (a failed allocation lowers it below the operation's), the input window the next view starts with
+  bool best_effort = false; int64_t be_cut = -1, be_capacity = 0, be_window = 0, be_base = 0;
   bool lazy_feedback = false;   // the context's option at the time the plan was made, or ssgpu_plan_set_option: THIS plan's steady-state runs leave their feedback on the stream
   bool background = false;      // ... and what is missing is left to the worker thread (option 3) when a run of >= background_min_rows rows wants it
   int64_t background_min_rows = 0;
@@ -482,6 +505,8 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   } else if (k == "lds_target_bytes") c->opt.lds_target_bytes = (int)value;
   else if (k == "grid_limit") c->grid_limit = value;
   else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 3;
+  else if (k == "tile_map") c->tile_map = value;
+  else if (k == "out_stagger") c->out_stagger = value < 0 ? 0 : value;
   else if (k == "group_local") c->group_local = value;
   else if (k == "group_partition") c->group_partition = value;
   else if (k == "part_n") c->part_n = value;
@@ -730,6 +755,7 @@ int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) 
     }
   }
   p->exec.resize(p->stages.size());
+  for (auto& st : p->stages) if (st.kind == STAGE_FOLD_TAIL && st.fold_cut) { p->best_effort = true; p->be_capacity = st.fold_limit > 0 ? st.fold_limit : INT64_MAX; }
   for (auto& a : p->result_schema) p->attr_names.push_back(a.name);
   p->result.plan = p;
   p->specialize = c->specialize > 0;
@@ -1065,6 +1091,10 @@ int ensure_out_cols(ssgpu_ctx* c, const Stage& st, StageExec& ex, int64_t rows) 
     OutCol& oc = ex.out[i];
     oc.width = (uint32_t)dtype_width(st.out_schema[i].dtype);
     oc.nullable = st.out_schema[i].nullable;
+    // output columns of one stage are written in lockstep (every workgroup stores the same row range of all of them at once): bases
+    // that are congruent modulo the HBM channel interleave put those stores on the same channels.  Column i starts i x out_stagger
+    // bytes into its allocation (large outputs only; default 4352 = 4 KiB + 256 B, profiles/r06_stagger_sweep.txt)
+    oc.data.shift = (c->out_stagger > 0 && rows >= (1 << 20)) ? (size_t)c->out_stagger * i : 0;
     HIP_TRY(c, oc.data.ensure((size_t)std::max<int64_t>(rows, 1) * oc.width + 16));
     if (oc.nullable) HIP_TRY(c, oc.nulls.ensure((size_t)std::max<int64_t>(rows, 1) + 16));
   }
@@ -1115,6 +1145,7 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
   VmParams P;
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   apply_joins(p, ex, st.main, &P);
+  if (c->tile_map >= 2) P.flags |= VM_FLAG_XCD_CHUNKS;
   fill_fast_slots(&P, st);
   const int grid = grid_for(c, ex.lay, P.n_tiles);
   ex.grid = grid;
@@ -1302,6 +1333,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
   fill_params(&P, st.main, ex.lay, ex.prog_main, ex.n_instr_main, in, row_id_base);
   apply_joins(p, ex, st.main, &P);
   P.error_flag = ex.error_flag.as<unsigned int>();   // (cleared by run_plan)
+  if (c->tile_map >= 1) P.flags |= VM_FLAG_XCD_CHUNKS;   // this launch writes rows: neighbouring tiles' shared output lines meet in one L2
   // output table: data column then (if nullable) its null mask, in out_schema order
   int oi = 0;
   for (size_t i = 0; i < ex.out.size(); ++i) {
@@ -1330,6 +1362,7 @@ int run_materialize(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_
     apply_joins(p, ex, st.count_pass, &C);
     C.tile_counts = ex.tile_counts.as<unsigned int>();
     C.count_sub_k = ex.lay.K;
+    if (c->tile_map >= 2) C.flags |= VM_FLAG_XCD_CHUNKS;
     C.error_flag = P.error_flag;
     const int cgrid = grid_for(c, ex.lay_count, C.n_tiles);
     HIP_TRY(c, ssgpu_launch_pipeline(C, ex.lay_count.K, cgrid, c->stream));
@@ -2590,6 +2623,32 @@ int run_join_expand(ssgpu_plan* p, size_t si, const InCols& in) {
 // column), keeps rows [0, limit] and has every later row merged into row `limit` (Stage::fold_op)
 int run_fold_tail(ssgpu_plan* p, size_t si, const InCols& in) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
+  if (st.fold_cut) {
+    // BestEffortGroupAggregate: the first `capacity` groups in first-seen order ARE the view -- copied as they are -- and the
+    // first-seen row id of the next group, the first input row whose key found no room (aggregate_groups.cc:362: the reference
+    // truncates its input view there), is where the next view starts (ssgpu_plan_run_best_effort)
+    const int64_t keep = std::min<int64_t>(in.rows, p->be_capacity);
+    int rc = ensure_out_cols(c, st, ex, keep);
+    if (rc != SSGPU_OK) return rc;
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom0, c->stream));
+    for (size_t i = 0; i < st.out_schema.size() && keep > 0; ++i) {
+      HIP_TRY(c, hipMemcpyAsync(ex.out[i].data.p, in.cols[i].data, (size_t)keep * ex.out[i].width, hipMemcpyDeviceToDevice, c->stream));
+      if (ex.out[i].nullable) {
+        if (st.in_schema[i].nullable && in.cols[i].is_null) HIP_TRY(c, hipMemcpyAsync(ex.out[i].nulls.p, in.cols[i].is_null, (size_t)keep, hipMemcpyDeviceToDevice, c->stream));
+        else HIP_TRY(c, hipMemsetAsync(ex.out[i].nulls.p, 0, (size_t)keep, c->stream));
+      }
+    }
+    if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
+    p->be_cut = -1;
+    if (in.rows > keep) {
+      unsigned long long next = 0;
+      HIP_TRY(c, hipMemcpyAsync(&next, static_cast<const unsigned long long*>(in.cols[st.in_schema.size() - 1].data) + keep, 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      p->be_cut = (int64_t)next + p->be_base;
+    }
+    ex.out_rows = keep;
+    return SSGPU_OK;
+  }
   const int64_t keep = std::min<int64_t>(in.rows, st.fold_limit + 1);
   int rc = ensure_out_cols(c, st, ex, keep);
   if (rc != SSGPU_OK) return rc;
@@ -2839,6 +2898,69 @@ int ssgpu_plan_run(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int6
     (void)check_error_flags(p);      // synchronises; sets nan_seen
     rc = fix_nan_minmax(p);
     if (rc != SSGPU_OK) return rc;
+  }
+  if (out) *out = &p->result;
+  return SSGPU_OK;
+}
+
+// BestEffortGroupAggregate (cursor/core/aggregate.h:230-250; GroupAggregateCursor::Next / ProcessInput with best_effort_,
+// aggregate_groups.cc:211-222,332-433).  One call = one ProcessInput: the plan's GroupAggregate over the LONGEST run of input rows
+// that starts at `start_row` and holds at most `capacity` distinct keys (the operation's option0; the reference's verdict comes from
+// its allocator, deterministic under GuaranteeMemory -- here the result block's row capacity).  The result is key-unique; *next_row
+// is where the next call starts (== rows: the input is exhausted).  How: the aggregate runs over a window of input rows with the
+// hidden first-seen row id; if more than `capacity` keys turn up, the first-seen id of key number `capacity` IS the end of the run,
+// and the aggregate runs again over exactly [start_row, end).  A window in which every key fitted and that is not the end of the
+// input is widened (x 4).  ERROR_MEMORY_EXCEEDED is never the answer to a large input: a run that does not fit the plan's memory
+// limit is repeated over half the window with the capacity lowered to match (the reference emits what it has and starts anew,
+// :375-393); only a single row that does not fit fails (:405-412).
+int ssgpu_plan_run_best_effort(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t start_row, int64_t* next_row, ssgpu_result** out) {
+  if (!p || !next_row) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = p->ctx;
+  if (!p->best_effort) { if (c) c->err = "ssgpu_plan_run_best_effort needs a plan whose root is a BestEffortGroupAggregate"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  if (n_cols != (int)p->desc.input_schema.size()) { c->err = "column count does not match the plan's input schema"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
+  if (start_row < 0 || start_row > rows) { c->err = "start_row outside the input"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  std::vector<ssgpu_column> win((size_t)n_cols);
+  auto window = [&](int64_t s) {
+    for (int i = 0; i < n_cols; ++i) {
+      const size_t w = (size_t)dtype_width(p->desc.input_schema[i].dtype);
+      win[i].data = cols[i].data ? static_cast<const char*>(cols[i].data) + (size_t)s * w : nullptr;
+      win[i].is_null = cols[i].is_null ? cols[i].is_null + s : nullptr;
+    }
+  };
+  auto run_range = [&](int64_t s, int64_t n) -> int {
+    window(s);
+    p->be_base = s;      // (row ids count from the window's first row -- FIRST / LAST fetch their values by them --; the cut stage adds the base back)
+    int rc = run_plan(p, win.data(), n_cols, n, 0, false);
+    if (rc != SSGPU_OK) return rc;
+    rc = settle_plan(p);
+    if (rc != SSGPU_OK) return rc;
+    rc = check_error_flags(p);
+    if (rc != SSGPU_OK) return rc;
+    return fix_nan_minmax(p);
+  };
+  const int64_t left = rows - start_row;
+  int64_t W = p->be_window > 0 ? p->be_window : std::max<int64_t>(1 << 16, p->be_capacity < (INT64_MAX >> 4) ? p->be_capacity * 8 : INT64_MAX);
+  for (;;) {
+    W = std::max<int64_t>(1, std::min(W, left));
+    if (left == 0) W = 0;
+    int rc = run_range(start_row, W);
+    if (rc == SSGPU_ERROR_MEMORY_EXCEEDED && W > 1) {
+      // what fits is emitted and the aggregation starts anew: half the window, and no more groups than that many rows can hold
+      W = std::max<int64_t>(1, W / 2); p->be_window = W; p->be_capacity = std::min(p->be_capacity, W);
+      continue;
+    }
+    if (rc != SSGPU_OK) return rc;
+    if (p->be_cut >= 0) {
+      const int64_t end = p->be_cut;
+      if (end <= start_row || end > start_row + W) { c->err = "best-effort cut outside the window"; return SSGPU_ERROR_HIP; }
+      rc = run_range(start_row, end - start_row);
+      if (rc != SSGPU_OK) return rc;
+      if (p->be_cut >= 0) { c->err = "best-effort run over its own cut still overflows"; return SSGPU_ERROR_HIP; }
+      *next_row = end;
+      break;
+    }
+    if (W >= left) { *next_row = rows; break; }
+    W = W > (INT64_MAX >> 2) ? INT64_MAX : W * 4; p->be_window = W;      // every key of the window fitted: the run goes on
   }
   if (out) *out = &p->result;
   return SSGPU_OK;

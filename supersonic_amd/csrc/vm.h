@@ -253,7 +253,7 @@ struct VmParams {
   uint32_t const_lds_off;    /* LDS offset of 2 x tile_rows bytes: all 0x01, then all 0x00 */
   uint32_t lds_bytes;
   int32_t count_sub_k;    /* SEL_COUNT: 512-row units per counted tile (0 = this launch's K): the store pass's K */
-  uint32_t reserved0;
+  uint32_t flags;         /* VM_FLAG_*: bit 0 = tiles handed out in XCD-contiguous chunks (see vm_first_tile) */
   uint64_t slot_init0[VM_FAST_SLOTS]; /* per-lane identities of the fast slots */
   uint64_t slot_init1[VM_FAST_SLOTS];
   int32_t slot_kind[VM_FAST_SLOTS];   /* SlotKind of the fast slots */
@@ -280,6 +280,8 @@ struct VmParams {
   VmStagedCol staged[VM_MAX_STAGED];
   VmOutCol outputs[VM_MAX_OUTPUTS];
 };
+
+#define VM_FLAG_XCD_CHUNKS 1u
 
 #ifndef __HIPCC__
 static inline const char* vm_op_name(uint16_t op) {

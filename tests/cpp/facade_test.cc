@@ -221,6 +221,36 @@ static void TestRun(const Input& in) {
       CHECK_EQ(at, want_a.size());
     }
   }
+  {  // BestEffortGroupAggregate: the reference's own vector (aggregate_groups_test.cc:601-626): "at 20 bytes quota, the buffer is filled
+     // after processing 3 rows" -- views {1: 7, 3: -3} and {2: 4, 3: -5}, each key-unique, no ERROR_MEMORY_EXCEEDED
+    std::vector<int32_t> key = {1, 1, 3, 2, 3}, val = {3, 4, -3, 4, -5};
+    TupleSchema ts;
+    ts.add_attribute(Attribute("col0", INT32, NULLABLE));
+    ts.add_attribute(Attribute("col1", INT32, NULLABLE));
+    View rows(ts);
+    rows.mutable_column(0)->Reset(key.data(), nullptr);
+    rows.mutable_column(1)->Reset(val.data(), nullptr);
+    rows.set_row_count(5);
+    std::unique_ptr<Operation> op(BestEffortGroupAggregate(ProjectNamedAttribute("col0"), (new AggregationSpecification)->AddAggregation(SUM, "col1", "sum"),
+                                                           (new GroupAggregateOptions)->set_memory_quota(20)->set_estimated_result_row_count(2), ScanView(rows)));
+    FailureOrOwned<Cursor> c = op->CreateCursor();
+    CHECK(c.is_success());
+    if (c.is_success()) {
+      CHECK_EQ(c->GetCursorId(), BEST_EFFORT_GROUP_AGGREGATE);
+      const int32_t want[2][2][2] = {{{1, 7}, {3, -3}}, {{2, 4}, {3, -5}}};
+      for (int v = 0; v < 2; ++v) {
+        ResultView r = c->Next(Cursor::kDefaultRowCount);
+        CHECK(r.has_data());
+        if (!r.has_data()) break;
+        CHECK_EQ(r.view().row_count(), static_cast<rowcount_t>(2));
+        for (int j = 0; j < 2 && r.view().row_count() == 2; ++j) {
+          CHECK_EQ(r.view().column(0).typed_data<int32_t>()[j], want[v][j][0]);
+          CHECK_EQ(r.view().column(1).typed_data<int32_t>()[j], want[v][j][1]);
+        }
+      }
+      CHECK(c->Next(Cursor::kDefaultRowCount).is_eos());
+    }
+  }
   {  // signaling division by zero surfaces as ERROR_EVALUATION_ERROR from Next()
     std::unique_ptr<Operation> op(Compute(DivideSignaling(NamedAttribute("a"), Minus(NamedAttribute("b"), NamedAttribute("b"))), ScanView(*in.view)));
     FailureOrOwned<Cursor> c = op->CreateCursor();

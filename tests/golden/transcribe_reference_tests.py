@@ -496,6 +496,16 @@ op_case("Group_AggregationInputColumnMissingError", GT + ":505-513", cols([I32])
         ["GroupAggregate", EMPTYP, [["SUM", "NotExistingCol", "sum"]], "INPUT"], None, [], expect_error=403)
 op_case("Group_AggregationResultColumnExistsError", GT + ":515-525", cols([I32, I32]), [],
         ["GroupAggregate", EMPTYP, [["SUM", "col0", "result_col"], ["MIN", "col1", "result_col"]], "INPUT"], None, [], expect_error=404)
+# BestEffortGroupAggregate (aggregate.h:230-250): "At 20 bytes quota, the buffer is filled after processing 3 rows" -- the block holds
+# 20 / (INT32 + is_null + INT32 + is_null) = 2 groups, key 2 (row 3) finds no room: {1: 3 + 4, 3: -3} is returned, the aggregation starts
+# anew at row 3.  The reference compares with SetIgnoreRowOrder(true)
+op_case("Group_BestEffortGroupAggregate", GT + ":601-626", cols([I32, I32]), [[1, 3], [1, 4], [3, -3], [2, 4], [3, -5]],
+        ["BestEffortGroupAggregate", ["ProjectNamedAttribute", "col0"], [["SUM", "col1", "sum"]], "INPUT",
+         {"memory_quota": 20, "estimated_result_row_count": 2}],
+        [I32, I32], [[1, 7], [3, -3], [2, 4], [3, -5]], ordered=False, exp_names=["col0", "sum"], exp_nullable=[True, True])
+op_case("Group_BestEffortGroupAggregateWithoutGroupByColumns", GT + ":628-647", cols([I32]), [[1], [2], [3]],
+        ["BestEffortGroupAggregate", EMPTYP, [["SUM", "col0", "sum"]], "INPUT", {"memory_quota": 100, "estimated_result_row_count": 2}],
+        [I32], [[6]], exp_names=["sum"])
 op_case("Group_NoGroupByColumns", GT + ":702-727", cols([I32]), [[1], [1], [3], [3], [2], [3], [1]],
         ["GroupAggregate", EMPTYP, [["SUM", "col0", "sum"], ["COUNT", "col0", "cnt"]], "INPUT"], [I32, U64], [[14, 7]])
 

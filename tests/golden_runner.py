@@ -129,6 +129,15 @@ def build_plan(plan, view):
         return ss.Project(build_projector(plan[1]), build_plan(plan[2], view))
     if head == "ScalarAggregate":
         return ss.ScalarAggregate(build_spec(plan[1]), build_plan(plan[2], view))
+    if head == "BestEffortGroupAggregate":
+        options = None
+        if len(plan) > 4 and plan[4]:
+            options = ss.GroupAggregateOptions()
+            if "memory_quota" in plan[4]:
+                options.set_memory_quota(plan[4]["memory_quota"])
+            if "estimated_result_row_count" in plan[4]:
+                options.set_estimated_result_row_count(plan[4]["estimated_result_row_count"])
+        return ss.BestEffortGroupAggregate(build_projector(plan[1]), build_spec(plan[2]), options, build_plan(plan[3], view))
     if head == "GroupAggregate":
         options = None
         if len(plan) > 4 and plan[4]:

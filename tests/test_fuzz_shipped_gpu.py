@@ -61,6 +61,17 @@ def jobs():
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup schedules (the GPU boxes report 256 CPUs and run about 16): more workers than that only
+    take turns (measured: 12 and 96 workers finish the same corpus in the same time)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else max(1, int(round(int(quota) / float(period))))
+    except (OSError, ValueError):
+        return None
+
+
 def run_job(job):
     env = dict(os.environ)
     env.pop("SSGPU_SPECIALIZE", None)
@@ -76,7 +87,7 @@ def run_job(job):
 @pytest.fixture(scope="module")
 def corpus():
     work = jobs()
-    workers = int(os.environ.get("SS_FUZZ_WORKERS", "0")) or max(4, min(48, (os.cpu_count() or 8) // 4))
+    workers = int(os.environ.get("SS_FUZZ_WORKERS", "0")) or max(4, min(48, cpu_quota() or (os.cpu_count() or 8) // 4))
     with concurrent.futures.ThreadPoolExecutor(workers) as pool:
         results = list(pool.map(run_job, [j for _leg, j in work]))
     legs = {}
