@@ -80,6 +80,7 @@ def group_spec(ss):
     return spec
 
 
+LAYOUT = "library"      # --layout: where the resident columns live (a Block the library lays out / one torch allocation per column)
 QUERY_NAME = "wide"     # the --query as given (group3 included): names the committed PMC pass of the workload
 GROUP_FILTER = True     # --query group3 (BASELINE configs[2]: no Filter below the GroupAggregate) clears it
 
@@ -137,6 +138,21 @@ def host_columns(np, query, n, seed=42):
             rng.integers(-(1 << 62), 1 << 62, n), rng.integers(-1000000, 1000001, n).astype(np.float64),
             rng.integers(0, 4000, n) * 0.25, rng.integers(0, 64, n).astype(np.float64),
             rng.integers(0, 64, n).astype(np.float64)]
+
+
+def place_in_library_block(ss, torch, ctx, schema, cols, rows, device):
+    """The resident input as a device Block the LIBRARY lays out (ssgpu_block_create: one arena, column bases skewed against HBM
+    channel conflicts -- include/ssgpu.h "device-resident Block"): the synthetic columns are generated by torch and copied
+    into the block's columns once, before any timing.  -> (block, torch tensors over the block's columns)."""
+    blk = ss.DeviceBlock(schema, rows, ctx)
+    placed = []
+    for i, t in enumerate(cols):
+        ts = {torch.int64: "<i8", torch.float64: "<f8", torch.int32: "<i4"}[t.dtype]
+        dst = torch.as_tensor(_DevPtr(blk.column_ptr(i), rows, ts), device=device)
+        dst.copy_(t)
+        placed.append(dst)
+    torch.cuda.synchronize(device)
+    return blk, placed
 
 
 class _DevPtr(object):
@@ -280,6 +296,9 @@ def measure_config(ss, torch, ctx, device, query, rows, steps, wide_cols=None):
         else:
             cols, schema = (wide_cols if wide_cols is not None else gen_device_columns(torch, rows, 42, device)), bench_schema(ss)
         torch.cuda.synchronize(device)
+        blk = None
+        if group and LAYOUT == "library":
+            blk, cols = place_in_library_block(ss, torch, ctx, schema, cols, rows, device)
         view = ss.DeviceView(schema, [(t.data_ptr(), 0) for t in cols], rows)
         plan = ss.Plan(build_group_plan(ss, view) if group else build_sort_plan(ss, view) if query == "sort" else build_filter_mat_plan(ss, view), ctx)
 
@@ -316,7 +335,7 @@ def measure_config(ss, torch, ctx, device, query, rows, steps, wide_cols=None):
                "traffic_source": pmc_source(query, alg)}
         if not out["checked"]:
             out["failed_checks"] = [k for k, v in checked.items() if not v]
-        del plan, view, cols
+        del plan, view, cols, blk
         torch.cuda.empty_cache()
         return out
     finally:
@@ -563,6 +582,9 @@ def parse_args(argv=None):
     ap.add_argument("--lds-target", type=int, default=0)
     ap.add_argument("--grid-limit", type=int, default=0)
     ap.add_argument("--opts", default="", help="extra context options (development): key=value,key=value")
+    ap.add_argument("--layout", choices=["library", "torch"], default="library",
+                    help="library = the resident columns live in a device Block the library lays out (ssgpu_block_create: one arena, skewed column "
+                         "bases); torch = one torch allocation per column, handed over as a DeviceView (what rounds 1-5 measured)")
     ap.add_argument("--stagger", type=int, default=-1,
                     help="development (A/B of HBM channel phase): place the input columns in ONE allocation, column i at i x (2 MiB-rounded size + this many "
                          "bytes); -1 = one allocation per column as torch makes them")
@@ -698,8 +720,9 @@ def extras(ss, torch, ctx, device, rows, cols, view):
 
 def main():
     args = parse_args()
-    global QUERY_NAME
+    global QUERY_NAME, LAYOUT
     QUERY_NAME = args.query
+    LAYOUT = args.layout
     if args.query == "group3":
         global GROUP_FILTER
         GROUP_FILTER = False
@@ -771,6 +794,10 @@ def main():
     else:
         cols = gen_device_columns(torch, rows, 42 + rank, device, row_offset)
         schema = bench_schema(ss)
+    input_block = None
+    if args.stagger < 0 and args.layout == "library":
+        input_block, cols = place_in_library_block(ss, torch, ctx, schema, cols, rows, device)
+        torch.cuda.empty_cache()
     if args.stagger >= 0:
         pitch = [((t.numel() * t.element_size() + (2 << 20) - 1) // (2 << 20)) * (2 << 20) + args.stagger for t in cols]
         arena = torch.empty(sum(pitch) + (2 << 20), dtype=torch.uint8, device=device)
@@ -991,6 +1018,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64/f64", "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": rows, "parallelism": par,
+                       "input_layout": ("arena, column pitch 2 MiB-rounded + %d B (--stagger)" % args.stagger if args.stagger >= 0 else
+                                        "device Block laid out by the library (ssgpu_block_create: one arena, column bases skewed by 512 B)" if args.layout == "library"
+                                        else "one torch allocation per column"),
                        "tile_rows": counters.tile_rows, "grid": counters.grid, "lds_bytes": counters.lds_bytes,
                        "specialized_stages": plan.specialized()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -323,6 +323,46 @@ class DeviceView(object):
         return self._rows
 
 
+class DeviceBlock(object):
+    """A device-resident Block the LIBRARY lays out (ssgpu_block_create: one arena, column bases skewed against HBM channel
+    conflicts -- include/ssgpu.h "device-resident Block") for columns that are produced on the device: `column_ptr(i)` is where
+    the caller writes column i (row_capacity x width bytes; `null_ptr(i)` its NULL mask or 0), `view()` the DeviceView plans scan."""
+
+    def __init__(self, schema, row_capacity, context):
+        self.schema, self.ctx, self.rows = schema, context, int(row_capacity)
+        attrs = [L.Attr(schema.attribute(i).name().encode(), schema.attribute(i).type(), schema.attribute(i).nullability())
+                 for i in range(schema.attribute_count())]
+        self._attrs = _array(L.Attr, attrs)
+        h = C.c_void_p()
+        context.check(context.lib.ssgpu_block_create(context.handle, self._attrs, len(attrs), self.rows, C.byref(h)))
+        self.handle = h
+        context.check(context.lib.ssgpu_block_set_row_count(h, self.rows))
+        self._ptrs = []
+        for i in range(len(attrs)):
+            col = L.Column()
+            context.check(context.lib.ssgpu_block_column(h, i, C.byref(col)))
+            self._ptrs.append((col.data or 0, col.is_null or 0))
+
+    def column_ptr(self, i):
+        return self._ptrs[i][0]
+
+    def null_ptr(self, i):
+        return self._ptrs[i][1]
+
+    def view(self, rows=None):
+        v = DeviceView(self.schema, self._ptrs, self.rows if rows is None else int(rows))
+        v._owner = self          # (the block lives as long as a view of it)
+        return v
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.ctx.lib.ssgpu_block_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class BlockView(DeviceView):
     """A DeviceView over an owned device Block (kept alive with the view)."""
 

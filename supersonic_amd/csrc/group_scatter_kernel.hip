@@ -34,6 +34,8 @@
 #define PS_REC_INV kPsRecInv
 #define PS_NPARTS kPsNParts
 #define PS_DENSE (kPsDense != 0u)
+#define PS_SPLIT (kPsSplit != 0u)
+#define PS_PAY_INV kPsPayInv
 #define PS_UNROLL _Pragma("unroll")
 #else
 #define PS_NKEYS P.n_keys
@@ -52,8 +54,22 @@
 #define PS_REC_INV P.rec_inv
 #define PS_NPARTS P.n_parts
 #define PS_DENSE (P.dense.on != 0u)
+#define PS_SPLIT (P.split != 0u)
+#define PS_PAY_INV P.pay_inv
 #define PS_UNROLL
 #endif
+// Input columns are read once and never again: non-temporal loads keep them from pushing the half-written record lines out of the
+// XCD's L2 (the lines of the (partition, XCD) segments complete there; one evicted early is written to HBM twice).
+#ifndef PS_NT
+#define PS_NT 1
+#endif
+template <typename T> __device__ __forceinline__ T ps_ld(const T* p) {
+#if PS_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -87,13 +103,13 @@ __device__ __forceinline__ bool pscat_pred(const void* data, const u8* nulls, u6
   const bool is_null = nulls ? nulls[row] != 0 : false;    // a NULL predicate drops the row (filter.cc:170-199)
   bool lt, gt, eq;   // column < constant, column > constant, column == constant
   switch (kind) {
-    case 0: { const i32 v = reinterpret_cast<const i32*>(data)[row], k = (i32)(u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
-    case 1: { const u32 v = reinterpret_cast<const u32*>(data)[row], k = (u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
-    case 2: { const i64 v = reinterpret_cast<const i64*>(data)[row], k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
-    case 3: { const u64 v = reinterpret_cast<const u64*>(data)[row], k = c; lt = v < k; gt = v > k; eq = v == k; } break;
-    case 4: { const float v = reinterpret_cast<const float*>(data)[row], k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
-    case 6: { const u8 v = reinterpret_cast<const u8*>(data)[row], k = (u8)c; lt = v < k; gt = v > k; eq = v == k; } break;   // a BOOL column as the predicate: (column != FALSE)
-    default: { const double v = reinterpret_cast<const double*>(data)[row], k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
+    case 0: { const i32 v = ps_ld(reinterpret_cast<const i32*>(data) + row), k = (i32)(u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 1: { const u32 v = ps_ld(reinterpret_cast<const u32*>(data) + row), k = (u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 2: { const i64 v = ps_ld(reinterpret_cast<const i64*>(data) + row), k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 3: { const u64 v = ps_ld(reinterpret_cast<const u64*>(data) + row), k = c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 4: { const float v = ps_ld(reinterpret_cast<const float*>(data) + row), k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    case 6: { const u8 v = ps_ld(reinterpret_cast<const u8*>(data) + row), k = (u8)c; lt = v < k; gt = v > k; eq = v == k; } break;   // a BOOL column as the predicate: (column != FALSE)
+    default: { const double v = ps_ld(reinterpret_cast<const double*>(data) + row), k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
   }
   bool r;
   switch (cmp) {
@@ -150,15 +166,15 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
       key[j] = 0ull;
       PS_UNROLL for (u32 k = 0; k < PS_NKEYS; ++k) {
         const u32 kw = PS_KEY_WIDTH(k), kbits = PS_KEY_BITS(k), kshift = PS_KEY_SHIFT(k);
-        u64 a = kw == 8 ? reinterpret_cast<const u64*>(P.keys[k].data)[rowc] : kw == 4 ? (u64)reinterpret_cast<const u32*>(P.keys[k].data)[rowc]
-                                                                                       : (u64)reinterpret_cast<const u8*>(P.keys[k].data)[rowc];
+        u64 a = kw == 8 ? ps_ld(reinterpret_cast<const u64*>(P.keys[k].data) + rowc) : kw == 4 ? (u64)ps_ld(reinterpret_cast<const u32*>(P.keys[k].data) + rowc)
+                                                                                       : (u64)ps_ld(reinterpret_cast<const u8*>(P.keys[k].data) + rowc);
         a &= kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
         if (P.keys[k].nulls && P.keys[k].nulls[rowc]) a = 1ull << (PS_KEY_NULLBIT(k) - kshift);
         key[j] |= a << kshift;
       }
 #pragma unroll
       for (u32 f = 0; f < REGF; ++f)   // the leading 8-byte fields travel through registers: their loads are in flight during the ranking
-        fv[j][f] = (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u && P.fields[f].src) ? reinterpret_cast<const u64*>(P.fields[f].src)[rowc] : 0ull;
+        fv[j][f] = (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u && P.fields[f].src) ? ps_ld(reinterpret_cast<const u64*>(P.fields[f].src) + rowc) : 0ull;
       // heavy hitters are aggregated by the resident kernel (hot_only), not scattered: one key must not fill a partition's segments
       if (P.n_hot) {   // (uniform)
         u32 i = hash_local(key[j]) & (SSGPU_HOT_SLOTS - 1u);
@@ -174,8 +190,8 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
         const bool in = ssgpu_dense_index(P.dense, key[j], &idx);
         if (ok[j] && !in) miss = true;
         ok[j] = ok[j] && in;
-        (void)ssgpu_dense_entry(P.dense, idx, &pt[j]);
-        key[j] = (u64)idx;
+        const u32 entry = ssgpu_dense_entry(P.dense, idx, &pt[j]);
+        key[j] = PS_SPLIT ? (u64)entry : (u64)idx;   // (split records: the partition's table entry, 16 bits in an array of its own)
       } else
       pt[j] = part_of(key[j], NP);
       pos[j] = 0u;
@@ -210,17 +226,33 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
       PS_UNROLL for (u32 f = 0; f < nf; ++f) {
         const u32 fw = PS_FIELD_WIDTH(f), fo = PS_FIELD_OFF(f);
         const void* src = P.fields[f].src;
-        if (fw == 8u) { if (f >= REGF) { const u64 v = src ? reinterpret_cast<const u64*>(src)[rowc] : 0ull; if (ok[j]) *reinterpret_cast<u64*>(r + fo) = v; } }
-        else if (fw == 4u) { const u32 v = src ? reinterpret_cast<const u32*>(src)[rowc] : 0u; if (ok[j]) *reinterpret_cast<u32*>(r + fo) = v; }
-        else { const u8 v = src ? reinterpret_cast<const u8*>(src)[rowc] : (u8)0; if (ok[j]) *reinterpret_cast<u8*>(r + fo) = v; }
+        if (fw == 8u) { if (f >= REGF) { const u64 v = src ? ps_ld(reinterpret_cast<const u64*>(src) + rowc) : 0ull; if (ok[j]) *reinterpret_cast<u64*>(r + fo) = v; } }
+        else if (fw == 4u) { const u32 v = src ? ps_ld(reinterpret_cast<const u32*>(src) + rowc) : 0u; if (ok[j]) *reinterpret_cast<u32*>(r + fo) = v; }
+        else { const u8 v = src ? ps_ld(reinterpret_cast<const u8*>(src) + rowc) : (u8)0; if (ok[j]) *reinterpret_cast<u8*>(r + fo) = v; }
       }
     }
     if (over) atomicExch(P.overflow, 1u);
     if (miss) atomicExch(P.overflow + 2, 1u);   // a key outside the dense ranges: the host widens them and repeats the run
     for (u32 i = t; i < NP; i += THREADS) cnt[i] = 0u;   // (read last before the barrier above; next written after the one below)
     __syncthreads();
-    const u32 words = start[NP] * wpr;
     const u64* sw = reinterpret_cast<const u64*>(stage);
+    if (PS_SPLIT) {
+      // split records (dense slots): the payload words of a record -- everything behind its key word -- go to the segment's record
+      // array, (wpr - 1) words each, and the key word, which here is the entry of the partition's table (< 2^16), to the segment's
+      // array of 16-bit entries: 34 bytes per row for four DOUBLE inputs where the whole record took 40
+      const u32 pw = wpr - 1u, nrec = start[NP], pwords = nrec * pw;
+      for (u32 w = t; w < pwords; w += THREADS) {
+        const u32 j = pw == 1u ? w : __umulhi(w, PS_PAY_INV), f = w - j * pw;
+        const u32 g = grec[j];
+        if (g != VM_NONE) P.recs[(u64)g * pw + f] = sw[j * wpr + 1u + f];
+      }
+      for (u32 j = t; j < nrec; j += THREADS) {
+        const u32 g = grec[j];
+        if (g != VM_NONE) P.recs_entry[g] = (unsigned short)sw[j * wpr];
+      }
+      continue;   // (as below: no barrier needed before the next tile)
+    }
+    const u32 words = start[NP] * wpr;
     for (u32 w = t; w < words; w += THREADS) {
       const u32 j = wpr == 1u ? w : __umulhi(w, PS_REC_INV), f = w - j * wpr;   // (one-word records -- the key alone, COUNT(*) queries: 2^32 / 1 + 1 does not fit rec_inv)
       const u32 g = grec[j];

@@ -91,6 +91,10 @@ struct PartAggParams {
   // merged into global slot hot_base + e (dense slots behind the partitions' ranges) instead of a hashed slot.
   unsigned int hot_only, hot_base;
   DenseKeyMap dense;                  // dense.on: word 0 of a record is the group's dense index, not its packed key
+  // split records (PlainScatterParams::split): `recs` holds (rec_words - 1) payload words per record, word 0 -- the entry of this
+  // partition's table the record belongs to -- comes from recs_entry
+  const unsigned short* recs_entry;
+  unsigned int split, pad2;
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
@@ -148,11 +152,14 @@ __device__ __forceinline__ unsigned int ssgpu_dense_entry(const DenseKeyMap& D, 
 struct PlainScatterParams {
   unsigned long long n_rows;
   unsigned int n_parts, seg_cap, rec_words, rec_inv;   // rec_inv = floor(2^32 / rec_words) + 1
-  unsigned int n_keys, n_fields, n_preds, pad;
+  unsigned int n_keys, n_fields, n_preds;
+  unsigned int split;           // dense slots only: records leave as (rec_words - 1) payload words in `recs` + a 16-bit table entry in `recs_entry`
   struct Key { const void* data; const unsigned char* nulls; unsigned int width, shift, bits, nullbit; } keys[SSGPU_PSCAT_MAX_KEYS];
   struct Field { const void* src; unsigned int width, off; } fields[SSGPU_PSCAT_MAX_FIELDS];   // src NULL: an absent NULL mask (zeros)
   struct Pred { const void* data; const unsigned char* nulls; unsigned int kind, cmp, col_on_left, pad; unsigned long long bits; } preds[SSGPU_PSCAT_MAX_PREDS];
   unsigned long long* recs;     // n_parts * SSGPU_PSCAT_XCDS segments of seg_cap records
+  unsigned short* recs_entry;   // split: the same segments' table entries, one per record
+  unsigned int pay_inv, pad1;   // split: floor(2^32 / (rec_words - 1)) + 1
   unsigned int* counts;         // [n_parts * SSGPU_PSCAT_XCDS] records appended to each segment; zero at launch
   unsigned int* overflow;       // set when a segment ran full
   // heavy hitters: rows whose packed key is one of these are NOT scattered (ssgpu_group_resident_kernel, hot_only, aggregates them)
@@ -253,7 +260,8 @@ void* ssgpu_rtc_specialize(int device, const VmInstr* prog, int n_instr, int K, 
 hipError_t ssgpu_launch_pipeline_rtc(void* handle, const VmParams& P, int grid, bool static_lds, hipStream_t stream);
 void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
                                     unsigned int lds_bytes, std::string* why, const PlainScatterParams* source = nullptr,   // source: the resident form (reads the input columns)
-                                    bool dense = false);                                                                    // dense: records carry dense indices (DenseKeyMap), no probe
+                                    bool dense = false,                                                                     // dense: records carry dense indices (DenseKeyMap), no probe
+                                    bool split = false);                                                                    // split: records arrive as payload words + 16-bit table entries
 hipError_t ssgpu_launch_group_resident_rtc(void* handle, const PartAggParams& A, const PlainScatterParams& S, int grid, hipStream_t stream);
 hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
 void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int rows_per_thread, unsigned int lds_bytes, std::string* why);

@@ -1210,6 +1210,7 @@ __device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, 
 #define PART_AGG_LOOP _Pragma("unroll") for (u32 s = 0; s < kPartNAggs; ++s)
 #define PART_DESC(s) kPartDesc[s]
 #define PART_DENSE(P) (kPartDense != 0u)
+#define PART_SPLIT(P) (kPartSplit != 0u)
 #else
 #define PART_NG(P) (P).n_gaggs
 #define PART_W(P) (P).rec_words
@@ -1218,6 +1219,7 @@ __device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, 
 #define PART_AGG_LOOP for (u32 s = 0; s < n_aggs; ++s)
 #define PART_DESC(s) readlane64(mydesc, (int)(s))
 #define PART_DENSE(P) ((P).dense.on != 0u)
+#define PART_SPLIT(P) ((P).split != 0u)
 #endif
 #ifndef FKEY   /* (vm_body.inc defines the same for the pipeline kernel's GAGG handlers) */
 #define FKEY(d) ({ u64 b_ = d2u((double)(d)); (b_ & 0x8000000000000000ull) ? ~b_ : (b_ | 0x8000000000000000ull); })
@@ -1441,7 +1443,11 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
     if (t == 0) segoff[G] = total;
   }
   __syncthreads();
-  const u64* const recs = PLAIN ? nullptr : P.recs + (P.slab_segs ? (u64)seg0 : (u64)SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap * W;
+  // split records (dense partitions): W - 1 payload words per record in `recs`, the table entry (word 0) in a 16-bit array of its own
+  const bool split = !PLAIN && PART_SPLIT(P);
+  const u32 RW = split ? W - 1u : W;
+  const u64* const recs = PLAIN ? nullptr : P.recs + (P.slab_segs ? (u64)seg0 : (u64)SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap * RW;
+  const unsigned short* const rentry = split ? P.recs_entry + (u64)SEG_INDEX(part, 0u, P.n_parts, G) * P.seg_cap : nullptr;
   const u64 seg_step = PLAIN ? 0ull : P.slab_segs ? (u64)P.seg_cap : (u64)(SEG_INDEX(part, 1u, P.n_parts, G) - SEG_INDEX(part, 0u, P.n_parts, G)) * P.seg_cap;   // records between this partition's consecutive segments
   const u32 seg_cap = P.seg_cap, n_aggs = PART_NAGGS(P);
   const u64 mydesc = (t & 63u) < n_aggs ? P.desc[t & 63u] : 0ull;   // lane s of every wave holds aggregate s's descriptor
@@ -1533,9 +1539,19 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
       live[j] = i < total;
       if (live[j]) {
         while (i >= segoff[seg + 1u]) ++seg;              // empty segments are stepped over
-        const u64* rp = recs + ((u64)seg * seg_step + (i - segoff[seg])) * W;
+        const u64 ri = (u64)seg * seg_step + (i - segoff[seg]);
+        if (split) {
+          // (RW even -- a specialised build knows it: the payload is 16-byte aligned and leaves as dwordx4 loads)
+          const u64* rp = recs + ri * RW;
+          if (!(RW & 1u)) rp = reinterpret_cast<const u64*>(__builtin_assume_aligned(rp, 16));
+          rec[j][0] = (u64)__builtin_nontemporal_load(rentry + ri);
+#pragma unroll
+          for (int w = 1; w < MAXW; ++w) rec[j][w] = (u32)w < W ? __builtin_nontemporal_load(rp + (w - 1)) : 0ull;
+        } else {
+        const u64* rp = recs + ri * W;
 #pragma unroll
         for (int w = 0; w < MAXW; ++w) rec[j][w] = (u32)w < W ? rp[w] : 0ull;
+        }
       } else {
 #pragma unroll
         for (int w = 0; w < MAXW; ++w) rec[j][w] = 0ull;
@@ -1563,7 +1579,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         if (PART_DENSE(P)) {
           // no probe: the entry IS the index (one table of all slots) or index / partitions; the key word only marks the entry used
           u32 pp;
-          const u32 e = P.slab_segs ? (u32)key : ssgpu_dense_entry(P.dense, (u32)key, &pp);
+          const u32 e = (P.slab_segs || split) ? (u32)key : ssgpu_dense_entry(P.dense, (u32)key, &pp);
           li[j] = e * st;
           lkeys[e] = 0ull;
         } else if (PLAIN && P.hot_only) {

@@ -44,7 +44,7 @@ struct ssgpu_ctx {
   std::string err;
   LowerOptions opt;
   int64_t grid_limit = 0;        // 0 = CUs * residency
-  int64_t out_stagger = 0;       // bytes between the channel phases of a stage's output columns (ensure_out_cols); 0 = every column at the base of its own allocation
+  int64_t out_arena = 1;         // 1: a stage's large result is one allocation with skewed column bases (ensure_out_cols), 0: a buffer per column
   int64_t tile_map = 1;          // which tile a workgroup of a pipeline launch takes: 0 = its block index (neighbouring tiles on different XCDs), 1 = XCD-contiguous
                                  // chunks for launches that WRITE compacted / materialised rows (vm.h VM_FLAG_XCD_CHUNKS: lines two tiles share merge in one L2), 2 = for every launch
   int64_t wgs_per_cu = 3;        // resident 4-wave workgroups per CU (<= 4 at the kernel's 128-VGPR budget; 3 streams best)
@@ -70,6 +70,7 @@ struct ssgpu_ctx {
                                  // (an overflow seen late, a NaN in a floating MIN / MAX).  Off by default (round 5): ssgpu_plan_run returns with every
                                  // such decision made -- the input may be released or overwritten once the run has been synchronised.  Callers that
                                  // step a plan without touching the host opt in (distributed.py, sharded.h, bench.py) and keep their input alive.
+  int64_t part_split = 1;        // dense partitions: records leave the plain scatter as payload words + 16-bit table entries (0: whole records, index word included)
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
@@ -161,35 +162,21 @@ static thread_local bool tls_park_released = false;   // set while a plan whose 
 
 struct DevBuf {
   void* p = nullptr;
-  size_t cap = 0;         // bytes usable at p
-  size_t shift = 0;       // p sits this many bytes into its allocation (set before ensure): how the output columns of a stage get
-                          // bases of different HBM channel phase (ssgpu_ctx option out_stagger; profiles/r06_filter_ab.txt)
-  size_t held = 0;        // the shift p was allocated with
+  size_t cap = 0;
+  bool view = false;      // p points into somebody else's allocation (a block's arena): never freed, never regrown here
   MemQuota* q = nullptr;
   ~DevBuf() { release(); }
   void release() {
-    if (p) {
-      void* base = static_cast<char*>(p) - held; const size_t full = cap + held;
-      if (q) q->used -= (int64_t)full;
-      if (!(tls_park_released && g_pool.park(base, full))) { (void)hipFree(base); g_dev_bytes.fetch_sub((long long)full); }
+    if (p && !view) {
+      if (q) q->used -= (int64_t)cap;
+      if (!(tls_park_released && g_pool.park(p, cap))) { (void)hipFree(p); g_dev_bytes.fetch_sub((long long)cap); }
     }
-    p = nullptr; cap = 0; held = 0; q = nullptr;
+    p = nullptr; cap = 0; q = nullptr; view = false;
   }
+  void set_view(void* ptr, size_t bytes) { release(); p = ptr; cap = bytes; view = true; }
   hipError_t ensure(size_t bytes) {
-    if (bytes <= cap && p && held == shift) return hipSuccess;
-    if (shift) {      // (shifted buffers are few and large: allocated exactly, never taken from the pool)
-      const size_t want = std::max<size_t>(bytes, 256) + shift;
-      MemQuota* Q = g_quota;
-      if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)(cap + held) : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
-      release();
-      void* base = nullptr;
-      hipError_t e = hipMalloc(&base, want);
-      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); int dev = -1; if (hipGetDevice(&dev) == hipSuccess && g_pool.trim(dev) > 0) e = hipMalloc(&base, want); }
-      if (e != hipSuccess) return e;
-      p = static_cast<char*>(base) + shift; cap = want - shift; held = shift; q = Q;
-      g_dev_bytes.fetch_add((long long)want); if (q) q->used += (int64_t)want;
-      return hipSuccess;
-    }
+    if (bytes <= cap && p) return hipSuccess;
+    if (view) return hipErrorInvalidValue;    // (a view has the size its owner gave it)
     size_t want = std::max<size_t>(bytes, 256);
     MemQuota* Q = g_quota;
     if (Q && Q->limit >= 0 && Q->used - (q == Q ? (int64_t)cap : 0) + (int64_t)want > Q->limit) return hipErrorOutOfMemory;
@@ -227,7 +214,7 @@ struct PinnedBuf {
   }
 };
 
-struct OutCol { DevBuf data, nulls; bool nullable = false; uint32_t width = 8; };
+struct OutCol { DevBuf data, nulls; bool nullable = false; uint32_t width = 8; };   // (views into StageExec::out_arena for large results)
 
 struct StageExec {
   // device copies of the programs, finalised for tile_rows
@@ -330,7 +317,9 @@ struct StageExec {
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
   bool pattern_ready = false;
+  bool last_split_records = false;   // the last partitioned run wrote split records (payload + 16-bit entries)
   // outputs
+  DevBuf out_arena;          // large results: ONE allocation, `out` holds views into it (ensure_out_cols)
   std::vector<OutCol> out;
   int64_t out_rows = -1;     // -1: read lazily from `total`
   const void* out_rows_dev = nullptr;   // ... or, when set, from this device word of an EARLIER stage (a filter-less stage fed through a device-side row count)
@@ -377,6 +366,7 @@ struct ssgpu_plan {
   // BestEffortGroupAggregate (a stage with Stage::fold_cut): the row the last run's table had no room for (-1: every key fitted), the
   // capacity in force (a failed allocation lowers it below the operation's), the input window the next view starts with
   bool best_effort = false; int64_t be_cut = -1, be_capacity = 0, be_window = 0, be_base = 0;
+  uint32_t group_capacity_hint = 0;   // first capacity of a direct-shape group table when the plan knows better than the context's default (best effort under a memory limit)
   bool lazy_feedback = false;   // the context's option at the time the plan was made, or ssgpu_plan_set_option: THIS plan's steady-state runs leave their feedback on the stream
   bool background = false;      // ... and what is missing is left to the worker thread (option 3) when a run of >= background_min_rows rows wants it
   int64_t background_min_rows = 0;
@@ -423,8 +413,15 @@ struct ssgpu_block {
   ssgpu_ctx* ctx = nullptr;
   Schema schema;
   int64_t capacity = 0, rows = 0;
+  // Large blocks are ONE allocation: column i's data starts i x (its 2 MiB-rounded size + kBlockColumnSkew) into it, the NULL masks
+  // follow.  A pipeline reads the same rows of all its columns at the same time; columns allocated one by one start at bases that are
+  // congruent modulo every power of two the allocator aligns to, which puts those reads on the same HBM channels.  Measured on the
+  // headline query (8 columns x 800 MB): one allocation per column 0.81 of 8 TB/s, one arena 0.83, arena + 512 B of skew per column
+  // 0.865; the materialising Filter 2.33 -> 2.02 -> 1.93 ms (profiles/r06_stagger_sweep.txt).  `data` / `nulls` are views into it.
+  DevBuf arena;
   std::vector<DevBuf> data, nulls;
 };
+static const size_t kBlockColumnSkew = 512, kBlockArenaMin = 32u << 20;
 
 static int fail(ssgpu_ctx* ctx, const Status& s) { if (ctx) ctx->err = s.msg; return s.code; }
 // the CONCAT description of result column `col` (Stage::ConcatCol), or NULL
@@ -506,7 +503,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "grid_limit") c->grid_limit = value;
   else if (k == "wgs_per_cu") c->wgs_per_cu = value > 0 ? value : 3;
   else if (k == "tile_map") c->tile_map = value;
-  else if (k == "out_stagger") c->out_stagger = value < 0 ? 0 : value;
+  else if (k == "out_arena") c->out_arena = value;
   else if (k == "group_local") c->group_local = value;
   else if (k == "group_partition") c->group_partition = value;
   else if (k == "part_n") c->part_n = value;
@@ -522,6 +519,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "group_scout") c->group_scout = value;
   else if (k == "group_scout_rows") c->group_scout_rows = value;
   else if (k == "part_plain") c->part_plain = value;
+  else if (k == "part_split") c->part_split = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "async_handoff") c->async_handoff = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
@@ -556,14 +554,28 @@ int ssgpu_block_create(ssgpu_ctx* c, const ssgpu_attr* schema, int32_t n, int64_
   ssgpu_block* b = new ssgpu_block;
   b->ctx = c; b->capacity = cap; b->rows = 0;
   b->data.resize(n); b->nulls.resize(n);
+  size_t total = 0;
   for (int i = 0; i < n; ++i) {
     Attr a; a.name = schema[i].name ? schema[i].name : ""; a.dtype = schema[i].dtype; a.nullable = schema[i].nullable != 0;
     int w = dtype_width(a.dtype);
     if (w == 0) { delete b; c->err = "variable-length columns are outside the device hot path"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
     b->schema.push_back(a);
-    // rows << log2(size) bytes per column + rows bytes of null mask (block.cc:20-36)
-    if (b->data[i].ensure((size_t)cap * w) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
-    if (a.nullable && b->nulls[i].ensure((size_t)cap) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+    total += (size_t)cap * w + (a.nullable ? (size_t)cap : 0);
+  }
+  // rows << log2(size) bytes per column + rows bytes of null mask (block.cc:20-36)
+  if (total >= kBlockArenaMin) {
+    auto pitch = [](size_t bytes) { return ((bytes + (2u << 20) - 1) / (2u << 20)) * (2u << 20) + kBlockColumnSkew; };
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) need += pitch((size_t)cap * dtype_width(b->schema[i].dtype)) + (b->schema[i].nullable ? pitch((size_t)cap) : 0);
+    if (b->arena.ensure(need) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) { const size_t bytes = (size_t)cap * dtype_width(b->schema[i].dtype); b->data[i].set_view(b->arena.as<char>() + off, bytes); off += pitch(bytes); }
+    for (int i = 0; i < n; ++i) if (b->schema[i].nullable) { b->nulls[i].set_view(b->arena.as<char>() + off, (size_t)cap); off += pitch((size_t)cap); }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      if (b->data[i].ensure((size_t)cap * dtype_width(b->schema[i].dtype)) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+      if (b->schema[i].nullable && b->nulls[i].ensure((size_t)cap) != hipSuccess) { delete b; c->err = "device allocation failed"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+    }
   }
   c->refs.fetch_add(1);
   g_live_blocks.fetch_add(1);
@@ -738,11 +750,16 @@ int ssgpu_block_column(const ssgpu_block* b, int32_t col, ssgpu_column* out) {
 }
 
 // ---- plans ------------------------------------------------------------------------
+// finishes a plan whose description is already in p->desc (ssgpu_plan_create; the head / tail plans of chunked execution)
+static int plan_finish_create(ssgpu_ctx* c, ssgpu_plan* p, Status s, ssgpu_plan** out);
 int ssgpu_plan_create(ssgpu_ctx* c, const ssgpu_plan_desc* d, ssgpu_plan** out) {
   if (!c || !d || !out) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_plan* p = new ssgpu_plan;
   p->ctx = c;
-  Status s = copy_plan_desc(d, &p->desc);
+  return plan_finish_create(c, p, copy_plan_desc(d, &p->desc), out);
+}
+static int plan_finish_create(ssgpu_ctx* c, ssgpu_plan* p, Status s, ssgpu_plan** out) {
+  p->ctx = c;
   p->desc.filter_single_pass = c->filter_single_pass;
   p->desc.part_rec_align = (int)c->part_rec_align;
   if (s.ok()) s = lower_plan(p->desc, &p->stages, &p->result_schema, &p->describe);
@@ -1087,14 +1104,38 @@ void fill_params(VmParams* P, const Program& prog, const ProgramLayout& L, const
 
 int ensure_out_cols(ssgpu_ctx* c, const Stage& st, StageExec& ex, int64_t rows) {
   ex.out.resize(st.out_schema.size());
+  size_t total = 0;
   for (size_t i = 0; i < st.out_schema.size(); ++i) {
     OutCol& oc = ex.out[i];
     oc.width = (uint32_t)dtype_width(st.out_schema[i].dtype);
     oc.nullable = st.out_schema[i].nullable;
-    // output columns of one stage are written in lockstep (every workgroup stores the same row range of all of them at once): bases
-    // that are congruent modulo the HBM channel interleave put those stores on the same channels.  Column i starts i x out_stagger
-    // bytes into its allocation (large outputs only; default 4352 = 4 KiB + 256 B, profiles/r06_stagger_sweep.txt)
-    oc.data.shift = (c->out_stagger > 0 && rows >= (1 << 20)) ? (size_t)c->out_stagger * i : 0;
+    total += (size_t)std::max<int64_t>(rows, 1) * (oc.width + (oc.nullable ? 1u : 0u));
+  }
+  if (c->out_arena && total >= kBlockArenaMin && st.out_schema.size() > 1) {
+    // a large materialised result is laid out like a device block (ssgpu_block: one allocation, column bases skewed): its columns
+    // are written in lockstep by the store pass / the sort's gather, and read in lockstep by the stage that follows
+    auto pitch = [](size_t bytes) { return ((bytes + (2u << 20) - 1) / (2u << 20)) * (2u << 20) + kBlockColumnSkew; };
+    bool fits = ex.out_arena.p != nullptr;
+    for (size_t i = 0; i < ex.out.size() && fits; ++i)
+      fits = ex.out[i].data.view && ex.out[i].data.cap >= (size_t)std::max<int64_t>(rows, 1) * ex.out[i].width + 16 &&
+             (!ex.out[i].nullable || (ex.out[i].nulls.view && ex.out[i].nulls.cap >= (size_t)std::max<int64_t>(rows, 1) + 16));
+    if (!fits) {
+      size_t need = 0;
+      for (auto& oc : ex.out) need += pitch((size_t)rows * oc.width + 16) + (oc.nullable ? pitch((size_t)rows + 16) : 0);
+      for (auto& oc : ex.out) { oc.data.release(); oc.nulls.release(); }
+      ex.out_arena.release();
+      HIP_TRY(c, ex.out_arena.ensure(need));
+      size_t off = 0;
+      for (auto& oc : ex.out) { const size_t bytes = (size_t)rows * oc.width + 16; oc.data.set_view(ex.out_arena.as<char>() + off, bytes); off += pitch(bytes); }
+      for (auto& oc : ex.out) if (oc.nullable) { oc.nulls.set_view(ex.out_arena.as<char>() + off, (size_t)rows + 16); off += pitch((size_t)rows + 16); }
+    }
+    ex.out_capacity = rows;
+    return SSGPU_OK;
+  }
+  for (size_t i = 0; i < st.out_schema.size(); ++i) {
+    OutCol& oc = ex.out[i];
+    if (oc.data.view) oc.data.release();      // (a result that shrank below the arena's threshold: back to buffers of its own)
+    if (oc.nulls.view) oc.nulls.release();
     HIP_TRY(c, oc.data.ensure((size_t)std::max<int64_t>(rows, 1) * oc.width + 16));
     if (oc.nullable) HIP_TRY(c, oc.nulls.ensure((size_t)std::max<int64_t>(rows, 1) + 16));
   }
@@ -1770,7 +1811,12 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       HIP_TRY(c, ex.gcnt.ensure(slots * ng * 4));
       tkeys = ex.gkeys.as<unsigned long long>(); tacc = ex.gacc.as<unsigned long long>(); tcnt = ex.gcnt.as<unsigned int>();
     }
-    if (ex.part_recs.ensure(n_segs * seg_cap * st.part_rec_bytes + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
+    // split records: a dense partition's record needs no key -- its table entry (index / partitions < 2^16) travels in a 16-bit array
+    // next to the payload words: 34 bytes per row written and read back where a whole record with its index word took 40
+    const bool split = dense && plain && !resident && c->part_split != 0 && W0 >= 2u && C <= 65536u;
+    const size_t payload_bytes = split ? ((n_segs * seg_cap * (size_t)(W0 - 1u) * 8 + 255) & ~(size_t)255) : n_segs * seg_cap * (size_t)st.part_rec_bytes;
+    if (ex.part_recs.ensure(payload_bytes + (split ? n_segs * seg_cap * 2 : 0) + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
+    ex.last_split_records = split;
     HIP_TRY(c, ex.part_hist.ensure(n_segs * 4));
     {
       GroupInitParams I; memset(&I, 0, sizeof(I));
@@ -1846,6 +1892,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       S.dense = dmap;
       S.n_parts = NP; S.seg_cap = (uint32_t)seg_cap; S.rec_words = W0; S.rec_inv = (uint32_t)(0x100000000ull / W0 + 1ull);
       S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
+      if (split) { S.split = 1u; S.recs_entry = reinterpret_cast<unsigned short*>(ex.part_recs.as<char>() + payload_bytes); S.pay_inv = W0 > 2u ? (uint32_t)(0x100000000ull / (W0 - 1u) + 1ull) : 0u; }
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
       const int pgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 1023) / 1024));
       // the specialised build (plans that asked): one per (descriptor, partition count) -- the LDS carve-up is static in it
@@ -1853,7 +1900,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (p->specialize) {
         const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
         const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
-        const uint32_t tag = NP * 8u + (uint32_t)R * 2u + (dense ? 1u : 0u);
+        const uint32_t tag = NP * 16u + (uint32_t)R * 4u + (split ? 2u : 0u) + (dense ? 1u : 0u);
         if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag && !ex.rtc_plain.ask_again() && !ex.rtc_plain.stronger_mode_now())) {
           if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
           ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds; ex.rtc_plain.tag = tag;
@@ -1876,6 +1923,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     PartAggParams A;
     memset(&A, 0, sizeof(A));
     A.recs = ex.part_recs.as<unsigned long long>();
+    if (split) { A.split = 1u; A.recs_entry = reinterpret_cast<const unsigned short*>(ex.part_recs.as<char>() + payload_bytes); }
     A.counts = ex.part_hist.as<unsigned int>();
     A.n_segs = (unsigned int)grid; A.seg_cap = (unsigned int)seg_cap; A.rec_words = W; A.n_parts = NP;
     if (slab) {   // one aggregation workgroup per CU, each over a run of the scatter workgroups' segments
@@ -1914,12 +1962,12 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (p->specialize && ex.rtc_resident.h && ex.rtc_resident.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_resident.h, A, S, rgrid, c->stream));
       else HIP_TRY(c, ssgpu_launch_group_resident(A, S, agg_lds, rgrid, c->stream));
     } else
-    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) && !ex.rtc_part.ask_again() && !ex.rtc_part.stronger_mode_now())) {
+    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) + (split ? 2u : 0u) && !ex.rtc_part.ask_again() && !ex.rtc_part.stronger_mode_now())) {
       // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
       if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
-      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = dense ? 1u : 0u;
+      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = (dense ? 1u : 0u) + (split ? 2u : 0u);
       std::string why;
-      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, nullptr, dense);
+      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, nullptr, dense, split);
       ex.rtc_part.asked();
       if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
@@ -2066,7 +2114,7 @@ int run_group_agg(ssgpu_plan* p, size_t si, const InCols& in, int64_t row_id_bas
     // heavily skewed keys / too many groups per partition: the direct path (global table behind the LDS table) always works
     ex.group_partitioned = false; ex.group_local = true; ex.part_failed = true; ex.steady = 0;
   }
-  if (ex.capacity == 0) ex.capacity = (uint32_t)c->group_capacity;
+  if (ex.capacity == 0) ex.capacity = p->group_capacity_hint ? p->group_capacity_hint : (uint32_t)c->group_capacity;
   ex.last_group_shape = 0; ex.last_plain_scatter = false;
   for (int attempt = 0; attempt < 8; ++attempt) {
     if (attempt) ++ex.last_reruns;
@@ -2947,6 +2995,14 @@ int ssgpu_plan_run_best_effort(ssgpu_plan* p, const ssgpu_column* cols, int32_t 
     if (rc == SSGPU_ERROR_MEMORY_EXCEEDED && W > 1) {
       // what fits is emitted and the aggregation starts anew: half the window, and no more groups than that many rows can hold
       W = std::max<int64_t>(1, W / 2); p->be_window = W; p->be_capacity = std::min(p->be_capacity, W);
+      // the stages start over with buffers sized for the smaller window: what they hold was sized for the run that did not fit
+      // (tables only grow while a plan lives), and a direct-shape table starts at 4 slots per possible group instead of the context's default
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (auto& ex : p->exec) { ex.rtc_main.drop(); ex.rtc_pscatter.drop(); ex.rtc_plain.drop(); ex.rtc_part.drop(); ex.rtc_resident.drop(); ex.rtc_hot.drop(); }
+      for (auto& ex : p->exec) if (ex.fb_event) { (void)hipEventDestroy(ex.fb_event); ex.fb_event = nullptr; g_events.fetch_sub(1); }
+      p->exec.clear(); p->exec.resize(p->stages.size());
+      p->deferred = false;
+      { uint32_t cap = 1024; while ((int64_t)cap < 4 * W && cap < (1u << 30)) cap *= 2; p->group_capacity_hint = cap; }
       continue;
     }
     if (rc != SSGPU_OK) return rc;
