@@ -526,7 +526,9 @@ typedef struct ssgpu_stage_info {
   int32_t hot_keys;         /* heavy-hitter keys the stage aggregates apart from the hash partitions (found when a segment overflowed; ABI 6) */
   int32_t dense_slots;      /* > 0: the group tables are indexed by the key columns' value ranges (dense slots, ABI 7) -- this many slots; group_shape
                                then says how they are filled: 1 partitions of slot ranges, 3 one table fed from the input columns */
-  int32_t reserved[4];
+  int32_t split_records;    /* dense partitions: the last run's records left the scatter as payload words + 16-bit table entries (no index word) */
+  int32_t row_ranges;       /* dense partitions: row ranges the last run took its input in -- range k is aggregated on a side stream while range k + 1 is scattered (1: one range, no overlap) */
+  int32_t reserved[2];
 } ssgpu_stage_info;
 int32_t ssgpu_plan_stage_count(const ssgpu_plan* plan);
 int ssgpu_plan_stage_info(const ssgpu_plan* plan, int32_t stage, ssgpu_stage_info* out);

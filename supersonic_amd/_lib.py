@@ -82,7 +82,7 @@ class MemoryStats(C.Structure):
 
 class StageInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "group_shape", "part_n", "part_seg_growth", "group_wgs_per_cu", "reruns",
-                                          "sort_passes", "sort_mode", "specialized", "plain_scatter", "hot_keys", "dense_slots")] + [("reserved", C.c_int32 * 4)]
+                                          "sort_passes", "sort_mode", "specialized", "plain_scatter", "hot_keys", "dense_slots", "split_records", "row_ranges")] + [("reserved", C.c_int32 * 2)]
 
 
 class PlanDesc(C.Structure):

@@ -58,10 +58,10 @@
 #define PS_PAY_INV P.pay_inv
 #define PS_UNROLL
 #endif
-// Input columns are read once and never again: non-temporal loads keep them from pushing the half-written record lines out of the
-// XCD's L2 (the lines of the (partition, XCD) segments complete there; one evicted early is written to HBM twice).
+// Input columns are read once and never again; non-temporal loads (-DPS_NT=1) were meant to keep them from pushing the half-written
+// record lines out of the XCD's L2.  Measured (profiles/r06_split_ab.txt): config #3 2.60 -> 2.73 ms, config #4 unchanged: off.
 #ifndef PS_NT
-#define PS_NT 1
+#define PS_NT 0
 #endif
 template <typename T> __device__ __forceinline__ T ps_ld(const T* p) {
 #if PS_NT
@@ -121,9 +121,36 @@ __device__ __forceinline__ bool pscat_pred(const void* data, const u8* nulls, u6
   return r && !is_null;
 }
 
-template <int R>
-__global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_kernel(const PlainScatterParams P) {
-  constexpr u32 THREADS = SSGPU_PSCAT_THREADS, T = THREADS * R, REGF = 6;
+#ifdef SSGPU_RTC_PSCAT
+// the same predicate on a value that is already in a register (the pipelined form loads a tile's columns one tile ahead)
+__device__ __forceinline__ bool pscat_pred_value(u64 raw, bool is_null, u64 c, u32 kind, u32 cmp, bool col_on_left) {
+  bool lt, gt, eq;
+  switch (kind) {
+    case 0: { const i32 v = (i32)(u32)raw, k = (i32)(u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 1: { const u32 v = (u32)raw, k = (u32)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 2: { const i64 v = (i64)raw, k = (i64)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 3: { const u64 v = raw, k = c; lt = v < k; gt = v > k; eq = v == k; } break;
+    case 4: { const float v = __uint_as_float((u32)raw), k = __uint_as_float((u32)c); lt = v < k; gt = v > k; eq = v == k; } break;
+    case 6: { const u8 v = (u8)raw, k = (u8)c; lt = v < k; gt = v > k; eq = v == k; } break;
+    default: { const double v = u2d(raw), k = u2d(c); lt = v < k; gt = v > k; eq = v == k; } break;
+  }
+  bool r;
+  switch (cmp) {
+    case 0: r = col_on_left ? lt : gt; break;
+    case 1: r = col_on_left ? (lt || eq) : (gt || eq); break;
+    case 2: r = eq; break;
+    default: r = !eq; break;
+  }
+  return r && !is_null;
+}
+__device__ __forceinline__ u64 pscat_load_width(const void* p, u32 width, u64 row) {
+  return width == 8u ? ps_ld(reinterpret_cast<const u64*>(p) + row) : width == 4u ? (u64)ps_ld(reinterpret_cast<const u32*>(p) + row) : (u64)ps_ld(reinterpret_cast<const u8*>(p) + row);
+}
+#endif
+
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void ssgpu_part_scatter_plain_kernel(const PlainScatterParams P) {
+  constexpr u32 THREADS = NT, T = THREADS * R, REGF = 6;
   const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const u32 NP = PS_NPARTS, cap = P.seg_cap, wpr = PS_REC_WORDS, rb = wpr * 8u;
   const u32 xcd = blockIdx.x & (SSGPU_PSCAT_XCDS - 1u);
@@ -153,6 +180,172 @@ __global__ __launch_bounds__(SSGPU_PSCAT_THREADS) void ssgpu_part_scatter_plain_
   __syncthreads();
   const u64 n = P.n_rows, n_tiles = (n + T - 1) / T;
   const u32 nf = PS_NFIELDS;
+#ifdef SSGPU_RTC_PSCAT
+  if constexpr (kPsPipe != 0u) {
+    // The software-pipelined form (specialised builds; profiles/r06_pscat_pipe.txt).  A tile's work is a chain of latencies -- column
+    // loads, ranking, one returning global atomic per partition, staging, flush -- and with ONE workgroup per CU (the staging area
+    // takes most of the LDS) nothing overlaps them: measured, a tile of 2048 rows takes 10 us whatever its size, half of it waiting.
+    // Here tile k + 1's columns are loaded and ranked, and its runs reserved, while tile k is staged and flushed:
+    //   [A] gbase <- the reservations issued one trip ago | barrier | stage(k), rank(k + 1) <- the columns loaded one trip ago
+    //   [B] barrier | scan + reserve(k + 1) (atomics issued, not waited for), load(k + 2), flush(k)
+    // Two counter arrays alternate (rank(k + 1) runs while tile k's counts are being cleared); two barriers per tile instead of three.
+    constexpr u32 NK = kPsNKeys ? kPsNKeys : 1u, NQ = kPsNPreds ? kPsNPreds : 1u, RES = THREADS - 64u, NGB = (kPsNParts + RES - 1u) / RES;
+    u32* const cnt_a = cnt; u32* const cnt_b = reinterpret_cast<u32*>(stage + (size_t)T * rb);
+    for (u32 i = t; i < NP; i += THREADS) cnt_b[i] = 0u;
+    struct Raw { u64 k[R][NK]; u32 kn[R][NK]; u64 p[R][NQ]; u32 pn[R][NQ]; u64 f[R][REGF]; bool in[R]; };
+    struct St { u64 key[R]; u32 pt[R], pos[R]; bool ok[R]; u64 fv[R][REGF]; };
+    auto issue = [&](u64 tile, Raw& W) {
+      const u64 base = tile * T;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const u64 row = base + (u64)j * THREADS + t;
+        W.in[j] = tile < n_tiles && row < n;
+        const u64 rowc = W.in[j] ? row : 0ull;     // (unconditional loads, on a row that exists)
+#pragma unroll
+        for (u32 q = 0; q < kPsNPreds; ++q) {
+          W.p[j][q] = pscat_load_width(P.preds[q].data, kPsPredKind[q] == 6u ? 1u : (kPsPredKind[q] == 0u || kPsPredKind[q] == 1u || kPsPredKind[q] == 4u) ? 4u : 8u, rowc);
+          W.pn[j][q] = P.preds[q].nulls ? (u32)P.preds[q].nulls[rowc] : 0u;
+        }
+#pragma unroll
+        for (u32 k = 0; k < kPsNKeys; ++k) {
+          W.k[j][k] = pscat_load_width(P.keys[k].data, kPsKeyWidth[k], rowc);
+          W.kn[j][k] = P.keys[k].nulls ? (u32)P.keys[k].nulls[rowc] : 0u;
+        }
+#pragma unroll
+        for (u32 f = 0; f < REGF; ++f)
+          W.f[j][f] = (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u && P.fields[f].src) ? ps_ld(reinterpret_cast<const u64*>(P.fields[f].src) + rowc) : 0ull;
+      }
+    };
+    bool miss = false, over = false;
+    auto rank = [&](const Raw& W, St& S, u32* c) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        bool ok = W.in[j];
+#pragma unroll
+        for (u32 q = 0; q < kPsNPreds; ++q) ok = ok & pscat_pred_value(W.p[j][q], W.pn[j][q] != 0u, P.preds[q].bits, kPsPredKind[q], kPsPredCmp[q], kPsPredColLeft[q] != 0u);
+        u64 key = 0ull;
+#pragma unroll
+        for (u32 k = 0; k < kPsNKeys; ++k) {
+          u64 a = W.k[j][k] & (kPsKeyBits[k] >= 64u ? ~0ull : ((1ull << (kPsKeyBits[k] & 63u)) - 1ull));
+          if (W.kn[j][k]) a = 1ull << ((kPsKeyNullbit[k] - kPsKeyShift[k]) & 63u);
+          key |= a << kPsKeyShift[k];
+        }
+        if (P.n_hot) {   // (uniform) heavy hitters are aggregated apart
+          u32 i = hash_local(key) & (SSGPU_HOT_SLOTS - 1u);
+          for (u32 probe = 0; probe < SSGPU_HOT_SLOTS; ++probe) {
+            const u64 cur = hot_tab[i];
+            if (cur == VM_KEY_EMPTY) break;
+            if (cur == key) { ok = false; break; }
+            i = (i + 1u) & (SSGPU_HOT_SLOTS - 1u);
+          }
+        }
+        u32 pt;
+        if (PS_DENSE) {
+          u32 idx;
+          const bool in = ssgpu_dense_index(P.dense, key, &idx);
+          if (ok && !in) miss = true;
+          ok = ok && in;
+          const u32 entry = ssgpu_dense_entry(P.dense, idx, &pt);
+          key = PS_SPLIT ? (u64)entry : (u64)idx;
+        } else pt = part_of(key, NP);
+        S.key[j] = key; S.pt[j] = pt; S.ok[j] = ok; S.pos[j] = 0u;
+        if (ok) S.pos[j] = atomicAdd(&c[pt], 1u);
+#pragma unroll
+        for (u32 f = 0; f < REGF; ++f) S.fv[j][f] = W.f[j][f];
+      }
+    };
+    u32 gb[NGB];
+    auto scan_reserve = [&](const u32* c) {
+      if (wave == 0) {   // staging offsets: exclusive scan of the tile's per-partition counts
+        const u32 per = (NP + 63u) / 64u;
+        u32 s0 = 0;
+        for (u32 i = 0; i < per; ++i) { const u32 q = lane * per + i; if (q < NP) s0 += c[q]; }
+        u32 inc = s0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if (lane >= (u32)d) inc += o; }
+        u32 ex = inc - s0;
+        for (u32 i = 0; i < per; ++i) { const u32 q = lane * per + i; if (q < NP) { start[q] = ex; ex += c[q]; } }
+        if (lane == 63u) start[NP] = ex;
+      } else {           // every partition's run in its (partition, XCD) segment: the atomics leave now, their answers are looked at one trip later
+#pragma unroll
+        for (u32 g = 0; g < NGB; ++g) {
+          const u32 i = t - 64u + g * RES;
+          gb[g] = 0u;
+          if (i < NP) { const u32 cc = c[i]; if (cc) gb[g] = atomicAdd(&P.counts[i * SSGPU_PSCAT_XCDS + xcd], cc); }
+        }
+      }
+    };
+    Raw raw; St cur;
+    const u64 tile0 = blockIdx.x, step = gridDim.x;
+    issue(tile0, raw);
+    rank(raw, cur, cnt_a);
+    __syncthreads();
+    scan_reserve(cnt_a);
+    issue(tile0 + step, raw);
+    u32 par = 0u;
+    for (u64 tile = tile0; tile < n_tiles; tile += step) {
+      if (wave != 0) {
+#pragma unroll
+        for (u32 g = 0; g < NGB; ++g) { const u32 i = t - 64u + g * RES; if (i < NP) gbase[i] = gb[g]; }
+      }
+      __syncthreads();                                                   // [A]
+      const u32 nrec = start[NP];
+      u32* const c_cur = par ? cnt_b : cnt_a; u32* const c_nxt = par ? cnt_a : cnt_b;
+      for (u32 i = t; i < NP; i += THREADS) c_cur[i] = 0u;              // (this tile's counts: scanned and reserved one trip ago)
+      const u64 base = tile * T;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const u64 row = base + (u64)j * THREADS + t;
+        const bool ok = cur.ok[j];
+        const u64 rowc = ok ? row : 0ull;
+        const u32 pt = cur.pt[j];
+        const u32 s1 = ok ? start[pt] + cur.pos[j] : 0u, g = gbase[pt] + cur.pos[j];
+        if (ok) { if (g < cap) grec[s1] = (pt * SSGPU_PSCAT_XCDS + xcd) * cap + g; else { grec[s1] = VM_NONE; over = true; } }
+        char* r = stage + (size_t)s1 * rb;
+        if (ok) *reinterpret_cast<u64*>(r) = cur.key[j];
+#pragma unroll
+        for (u32 f = 0; f < REGF; ++f) if (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u) { if (ok) *reinterpret_cast<u64*>(r + PS_FIELD_OFF(f < nf ? f : 0u)) = cur.fv[j][f]; }
+#pragma unroll
+        for (u32 f = 0; f < nf; ++f) {
+          const u32 fw = PS_FIELD_WIDTH(f), fo = PS_FIELD_OFF(f);
+          const void* src = P.fields[f].src;
+          if (fw == 8u) { if (f >= REGF) { const u64 v = src ? ps_ld(reinterpret_cast<const u64*>(src) + rowc) : 0ull; if (ok) *reinterpret_cast<u64*>(r + fo) = v; } }
+          else if (fw == 4u) { const u32 v = src ? ps_ld(reinterpret_cast<const u32*>(src) + rowc) : 0u; if (ok) *reinterpret_cast<u32*>(r + fo) = v; }
+          else { const u8 v = src ? ps_ld(reinterpret_cast<const u8*>(src) + rowc) : (u8)0; if (ok) *reinterpret_cast<u8*>(r + fo) = v; }
+        }
+      }
+      St nxt;
+      rank(raw, nxt, c_nxt);                                    // (tile + step: its columns were requested one trip ago; past the end: no row counts)
+      __syncthreads();                                                   // [B]
+      scan_reserve(c_nxt);
+      issue(tile + 2u * step, raw);
+      const u64* sw = reinterpret_cast<const u64*>(stage);
+      if (PS_SPLIT) {
+        const u32 pw = wpr - 1u, pwords = nrec * pw;
+        for (u32 w = t; w < pwords; w += THREADS) {
+          const u32 j = pw == 1u ? w : __umulhi(w, PS_PAY_INV), f = w - j * pw;
+          const u32 g = grec[j];
+          if (g != VM_NONE) P.recs[(u64)g * pw + f] = sw[j * wpr + 1u + f];
+        }
+        for (u32 j = t; j < nrec; j += THREADS) {
+          const u32 g = grec[j];
+          if (g != VM_NONE) P.recs_entry[g] = (unsigned short)sw[j * wpr];
+        }
+      } else {
+        const u32 words = nrec * wpr;
+        for (u32 w = t; w < words; w += THREADS) {
+          const u32 j = wpr == 1u ? w : __umulhi(w, PS_REC_INV), f = w - j * wpr;
+          const u32 g = grec[j];
+          if (g != VM_NONE) P.recs[(u64)g * wpr + f] = sw[w];
+        }
+      }
+      cur = nxt; par ^= 1u;
+    }
+    if (over) atomicExch(P.overflow, 1u);
+    if (miss) atomicExch(P.overflow + 2, 1u);
+    return;
+  }
+#endif
   for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const u64 base = tile * T;
     u64 key[R]; u64 fv[R][REGF]; u32 pt[R], pos[R]; bool ok[R]; bool miss = false;
@@ -480,22 +673,42 @@ hipError_t ssgpu_launch_key_domain(const PlainScatterParams& S, const unsigned i
   return hipGetLastError();
 }
 
-unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread) {
-  const unsigned int T = SSGPU_PSCAT_THREADS * (unsigned)rows_per_thread;
-  return (3u * n_parts + 2u + T) * 4u + 16u + T * rec_words * 8u;
+unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread, int threads) {
+  const unsigned int T = (unsigned)threads * (unsigned)rows_per_thread;
+  return (3u * n_parts + 2u + T) * 4u + 16u + T * rec_words * 8u + n_parts * 4u;   // (+ the pipelined form's second counter array, behind the staging area)
 }
-hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid, hipStream_t stream) {
+// The launch shape of the plain scatter: 1024 threads x 2 rows (1 when the staging area of 2048 records does not fit the LDS), one
+// workgroup per CU -- or what the caller asks for (development options pscat_threads / pscat_rows / pscat_wgs): 512-thread
+// workgroups of 2 - 4 rows per thread, several per CU, overlap one workgroup's load and reservation latencies with another's flush.
+PscatGeom ssgpu_part_scatter_plain_geom(unsigned int n_parts, unsigned int rec_words, int threads, int rows, int wgs_per_cu) {
+  PscatGeom g; g.pipe = 0u; g.threads = threads == 512 ? 512u : 1024u; g.wgs_per_cu = wgs_per_cu > 0 ? (unsigned)wgs_per_cu : 1u;
+  const unsigned int max_rows = g.threads == 512u ? 6u : 3u;
+  g.rows = rows > 0 ? (unsigned)rows : 2u;
+  if (g.rows > max_rows) g.rows = max_rows;
+  if (g.threads == 512u && g.rows < 2u) g.rows = 2u;
+  const unsigned int budget = (156u * 1024u) / g.wgs_per_cu;     // (every resident workgroup needs its staging area)
+  const unsigned int min_rows = g.threads == 512u ? 2u : 1u;
+  while (g.rows > min_rows && ssgpu_part_scatter_plain_lds(n_parts, rec_words, (int)g.rows, (int)g.threads) > budget) --g.rows;
+  g.lds = ssgpu_part_scatter_plain_lds(n_parts, rec_words, (int)g.rows, (int)g.threads);
+  if (g.lds > 156u * 1024u && g.threads == 512u) { g.threads = 1024u; g.rows = 1u; g.lds = ssgpu_part_scatter_plain_lds(n_parts, rec_words, 1, 1024); }
+  return g;
+}
+template <int R, int NT> static hipError_t pscat_launch(const PlainScatterParams& P, unsigned int lds, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  if (!attr_done) {
-    // (the kernel also has 512 bytes of static LDS -- the heavy hitters' key set: the dynamic part may take the rest of the 160 KiB)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    attr_done = true;
-  }
-  const unsigned int lds2 = ssgpu_part_scatter_plain_lds(P.n_parts, P.rec_words, 2), lds1 = ssgpu_part_scatter_plain_lds(P.n_parts, P.rec_words, 1);
-  if (lds2 <= 156u * 1024u) hipLaunchKernelGGL(ssgpu_part_scatter_plain_kernel<2>, dim3((unsigned)grid), dim3(SSGPU_PSCAT_THREADS), lds2, stream, P);
-  else if (lds1 <= 156u * 1024u) hipLaunchKernelGGL(ssgpu_part_scatter_plain_kernel<1>, dim3((unsigned)grid), dim3(SSGPU_PSCAT_THREADS), lds1, stream, P);
-  else return hipErrorInvalidValue;
+  // (the kernel also has 512 bytes of static LDS -- the heavy hitters' key set: the dynamic part may take the rest of the 160 KiB)
+  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ssgpu_part_scatter_plain_kernel<R, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr_done = true; }
+  hipLaunchKernelGGL((ssgpu_part_scatter_plain_kernel<R, NT>), dim3((unsigned)grid), dim3(NT), lds, stream, P);
   return hipGetLastError();
+}
+hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, const PscatGeom& g, int grid, hipStream_t stream) {
+  if (g.lds > 156u * 1024u) return hipErrorInvalidValue;
+  if (g.threads == 1024u && g.rows == 2u) return pscat_launch<2, 1024>(P, g.lds, grid, stream);
+  if (g.threads == 1024u && g.rows == 1u) return pscat_launch<1, 1024>(P, g.lds, grid, stream);
+  if (g.threads == 512u && g.rows == 2u) return pscat_launch<2, 512>(P, g.lds, grid, stream);
+  if (g.threads == 512u && g.rows == 3u) return pscat_launch<3, 512>(P, g.lds, grid, stream);
+  if (g.threads == 512u && g.rows == 4u) return pscat_launch<4, 512>(P, g.lds, grid, stream);
+  if (g.threads == 512u && g.rows == 6u) return pscat_launch<6, 512>(P, g.lds, grid, stream);
+  if (g.threads == 1024u && g.rows == 3u) return pscat_launch<3, 1024>(P, g.lds, grid, stream);
+  return hipErrorInvalidValue;
 }
 #endif  // !__HIPCC_RTC__

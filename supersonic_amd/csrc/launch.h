@@ -94,7 +94,10 @@ struct PartAggParams {
   // split records (PlainScatterParams::split): `recs` holds (rec_words - 1) payload words per record, word 0 -- the entry of this
   // partition's table the record belongs to -- comes from recs_entry
   const unsigned short* recs_entry;
-  unsigned int split, pad2;
+  unsigned int split;
+  // dense partitions, the input taken in several row ranges (the aggregation of range k runs beside the scatter of range k + 1): the
+  // partition's table starts from what the launch before it dumped into T instead of from the empty table
+  unsigned int accumulate;
 };
 hipError_t ssgpu_launch_part_agg(const PartAggParams& P, unsigned int lds_bytes, hipStream_t stream);
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
@@ -192,7 +195,9 @@ hipError_t ssgpu_launch_dense_headers(void* chunks, unsigned int n_chunks, unsig
 // applied) and reports the keys seen at least `min_count` times -- at most SSGPU_HOT_MAX, the most frequent ones.
 // out[0] = number of keys, out[1 + 2 i] = key i, out[2 + 2 i] = its count in the sample.
 hipError_t ssgpu_launch_hot_keys(const PlainScatterParams& S, unsigned long long n_sample, unsigned int min_count, unsigned long long* out, hipStream_t stream);
-hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, int grid, hipStream_t stream);
+struct PscatGeom { unsigned int threads, rows, wgs_per_cu, lds, pipe; };   // workgroup size, rows per thread (tile = threads x rows), resident workgroups per CU the LDS is sized for, LDS bytes, software-pipelined form (specialised builds)
+PscatGeom ssgpu_part_scatter_plain_geom(unsigned int n_parts, unsigned int rec_words, int threads, int rows, int wgs_per_cu);   // 0 = the default of each (1024 threads, 2 rows if they fit, 1 workgroup per CU)
+hipError_t ssgpu_launch_part_scatter_plain(const PlainScatterParams& P, const PscatGeom& g, int grid, hipStream_t stream);
 // GroupAggregateOptions::max_unique_keys_in_result, last step (group_scatter_kernel.hip): one workgroup per column copies rows
 // [0, min(n_in, limit + 1)) and merges every row beyond `limit` into row `limit` (op: 0 keep, 1 sum, 2 min, 3 max; kind:
 // 0 i32, 1 u32, 2 i64, 3 u64, 4 f32, 5 f64, 6 one byte), NULL partial results skipped
@@ -201,7 +206,7 @@ struct FoldTailColumn {
   const unsigned long long* by; const unsigned char* by_nulls;   // op 4 / 5 (FIRST / LAST): the row-id column the value is picked by
 };
 hipError_t ssgpu_launch_fold_tail(const FoldTailColumn* cols_dev, unsigned int n_cols, unsigned long long n_in, unsigned long long limit, hipStream_t stream);
-unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread);
+unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread, int threads = SSGPU_PSCAT_THREADS);
 hipError_t ssgpu_part_agg_set_max_lds(int bytes);
 // The LDS-resident form of a plain GroupAggregate stage (few groups: ONE LDS table holds them all): `grid` 1024-thread
 // workgroups read the input columns themselves (S: keys, fields, predicates; recs / counts unused), aggregate into a
@@ -264,8 +269,8 @@ void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, 
                                     bool split = false);                                                                    // split: records arrive as payload words + 16-bit table entries
 hipError_t ssgpu_launch_group_resident_rtc(void* handle, const PartAggParams& A, const PlainScatterParams& S, int grid, hipStream_t stream);
 hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
-void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, int rows_per_thread, unsigned int lds_bytes, std::string* why);
-hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterParams& P, int grid, hipStream_t stream);
+void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, const PscatGeom& g, std::string* why);
+hipError_t ssgpu_launch_part_scatter_plain_rtc(void* handle, const PlainScatterParams& P, const PscatGeom& g, int grid, hipStream_t stream);
 void* ssgpu_rtc_function(void* handle);
 void ssgpu_rtc_release(void* handle);
 void ssgpu_rtc_cached_only(bool on);   // the calling thread's requests from now on: find a kernel (memory, disk) or fail -- never compile

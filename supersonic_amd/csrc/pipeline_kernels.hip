@@ -1434,6 +1434,38 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         }
     }
   }
+  if constexpr (!PLAIN) {
+    if (P.accumulate && PART_DENSE(P) && !P.slab_segs) {
+      // the table an earlier launch dumped for this partition (same layout as the dump at the end of this function), read back: the
+      // rows of this launch are one more range of the same input
+      __syncthreads();
+      const u32 chunk = part / P.dense.chunk_parts, pin = part - chunk * P.dense.chunk_parts;
+      const u64* const keys_c = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(P.T.keys) + (u64)chunk * P.dense.chunk_stride);
+      const u64* const acc_c = reinterpret_cast<const u64*>(reinterpret_cast<const char*>(P.T.acc) + (u64)chunk * P.dense.chunk_stride);
+      const u32* const cnt_c = reinterpret_cast<const u32*>(reinterpret_cast<const char*>(P.T.cnt) + (u64)chunk * P.dense.chunk_stride);
+      const u64 sp = (u64)P.dense.chunk_slots;
+      const bool special_used = keys_c[sp] != VM_KEY_EMPTY;
+      for (u32 e0 = 0; e0 < C; e0 += SSGPU_PART_THREADS) {
+        const u32 e = e0 + t, ec = e < C ? e : 0u;
+        const u64 packed = ssgpu_dense_key_of(P.dense, ec * P.dense.n_parts + part);   // (uniform loop over the keys: outside the divergent part)
+        if (e < C) {
+          const bool from_special = packed == VM_KEY_EMPTY && special_used;
+          if (from_special) {
+            lkeys[e] = 0ull;
+            for (u32 s = 0; s < ng; ++s) { lacc[(size_t)e * st + s] = acc_c[sp * ng + s]; if (any_cnt) lcnt[(size_t)e * st + s] = cnt_c[sp * ng + s]; }
+          } else if (keys_c[(u64)pin * C + e] != VM_KEY_EMPTY) lkeys[e] = 0ull;
+        }
+      }
+      __syncthreads();
+      for (u32 i = t; i < C * ng; i += SSGPU_PART_THREADS) {
+        const u32 e = i / ng, l = e * st + i % ng;
+        if (lkeys[e] != VM_KEY_EMPTY && !(special_used && ssgpu_dense_key_of(P.dense, e * P.dense.n_parts + part) == VM_KEY_EMPTY)) {
+          lacc[l] = acc_c[(u64)pin * C * ng + i];
+          if (any_cnt) lcnt[l] = cnt_c[(u64)pin * C * ng + i];
+        }
+      }
+    }
+  }
   u32 total = 0;
   if constexpr (!PLAIN) {
     u32 n = t < G ? P.counts[P.slab_segs ? (u64)(seg0 + t) : (u64)part * G + t] : 0u;    // G <= 1024 (the host caps the scatter grid)

@@ -18,6 +18,7 @@
 #include <thread>
 #include <unordered_set>
 #include <vector>
+#include <functional>
 
 #include "engine.h"
 
@@ -39,6 +40,8 @@ struct ssgpu_ctx {
   std::atomic<int> refs{1};
   int device = -1;
   hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipStream_t side_stream = nullptr;      // created on first use: the aggregation of one row range of a dense GroupAggregate runs here, beside the scatter of the next
+  hipEvent_t side_ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool own_stream = false;
   int cu_count = 0;
   std::string err;
@@ -70,7 +73,11 @@ struct ssgpu_ctx {
                                  // (an overflow seen late, a NaN in a floating MIN / MAX).  Off by default (round 5): ssgpu_plan_run returns with every
                                  // such decision made -- the input may be released or overwritten once the run has been synchronised.  Callers that
                                  // step a plan without touching the host opt in (distributed.py, sharded.h, bench.py) and keep their input alive.
-  int64_t part_split = 1;        // dense partitions: records leave the plain scatter as payload words + 16-bit table entries (0: whole records, index word included)
+  int64_t part_overlap_rows = 1 << 23;   // ... inputs of at least this many rows
+  int64_t part_overlap = 1;      // dense partitions over >= 2^23 rows: > 1: the input is taken in this many row ranges, range k aggregated (side stream) while range k + 1 is scattered. Measured slower (the two kernels share the memory system: profiles/r06_overlap_ab.txt): off
+  int64_t pscat_pipe = 1;        // specialised plain scatter: the software-pipelined form (tile k + 1 loaded, ranked and reserved while tile k is staged and flushed)
+  int64_t pscat_threads = 0, pscat_rows = 0, pscat_wgs = 0;   // launch shape of the plain scatter (0: 1024 threads x 2 rows, one workgroup per CU; ssgpu_part_scatter_plain_geom)
+  int64_t part_split = 0;        // dense partitions: records leave the plain scatter as payload words + 16-bit table entries (0: whole records, index word included)
   int64_t part_plain = 1;        // 0: never run the partition scatter as its own kernel (plain stages), always as the VM program
   int64_t part_scatter_debug = 0;   // development: 1 = the scatter writes its records sequentially (wrong results)
   int64_t sort_compact = 1;      // 0: never sort (high half << 32 | row id) words instead of (key, row id) pairs
@@ -317,6 +324,7 @@ struct StageExec {
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
   bool pattern_ready = false;
+  int last_row_ranges = 1;           // row ranges the last dense-partition run took its input in (scatter of one beside the aggregation of the one before)
   bool last_split_records = false;   // the last partitioned run wrote split records (payload + 16-bit entries)
   // outputs
   DevBuf out_arena;          // large results: ONE allocation, `out` holds views into it (ensure_out_cols)
@@ -365,7 +373,7 @@ struct ssgpu_plan {
   bool cached_only = false;     // ... but only where the kernel exists already (option specialize = 2 / 3): no run of this plan waits for the compiler
   // BestEffortGroupAggregate (a stage with Stage::fold_cut): the row the last run's table had no room for (-1: every key fitted), the
   // capacity in force (a failed allocation lowers it below the operation's), the input window the next view starts with
-  bool best_effort = false; int64_t be_cut = -1, be_capacity = 0, be_window = 0, be_base = 0;
+  bool best_effort = false; int64_t be_cut = -1, be_capacity = 0, be_window = 0, be_base = 0, be_window_fail = 0;
   uint32_t group_capacity_hint = 0;   // first capacity of a direct-shape group table when the plan knows better than the context's default (best effort under a memory limit)
   bool lazy_feedback = false;   // the context's option at the time the plan was made, or ssgpu_plan_set_option: THIS plan's steady-state runs leave their feedback on the stream
   bool background = false;      // ... and what is missing is left to the worker thread (option 3) when a run of >= background_min_rows rows wants it
@@ -466,6 +474,8 @@ static void ctx_release(ssgpu_ctx* c) {
   if (c->device >= 0) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    for (hipEvent_t& e : c->side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (g_device_contexts.fetch_sub(1) == 1) (void)g_pool.trim(-1);   // nobody is left to take a parked block
   }
   delete c;
@@ -520,6 +530,12 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "group_scout_rows") c->group_scout_rows = value;
   else if (k == "part_plain") c->part_plain = value;
   else if (k == "part_split") c->part_split = value;
+  else if (k == "pscat_threads") c->pscat_threads = value;
+  else if (k == "pscat_rows") c->pscat_rows = value;
+  else if (k == "pscat_wgs") c->pscat_wgs = value;
+  else if (k == "pscat_pipe") c->pscat_pipe = value;
+  else if (k == "part_overlap") c->part_overlap = value;
+  else if (k == "part_overlap_rows") c->part_overlap_rows = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "async_handoff") c->async_handoff = value;
   else if (k == "part_scatter_debug") c->part_scatter_debug = value;
@@ -1780,22 +1796,29 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     ex.last_plain_scatter = plain;
     // records a (partition, workgroup) segment holds: the expected share of the INPUT rows (an upper bound of the
     // selected ones) with head room for the spread of a uniform hash, times the growth factor of earlier overflows
-    const double expect = (double)std::max<int64_t>(in.rows, 1) / ((double)NP * (double)grid);
+    // Row ranges (dense partitions of a large input): the scatter is bound by memory and latency, the aggregation by LDS atomics, and
+    // each needs about half a CU's LDS -- so the input is taken in KR ranges, and while range k + 1 is scattered (this stream) range k
+    // is aggregated (side stream) into the same tables, each launch starting from what the one before it dumped (PartAggParams::accumulate).
+    // Every range has its own segments; `range_rows` is what the segments are sized for.
+    const uint32_t KR = (dense && plain && !resident && !slab && c->part_split == 0 && c->part_overlap > 1 && in.rows >= std::max<int64_t>(c->part_overlap_rows, 1)) ? (uint32_t)std::min<int64_t>(c->part_overlap, 8) : 1u;
+    const int64_t range_rows = (in.rows + KR - 1) / KR;
+    const double expect = (double)std::max<int64_t>(range_rows, 1) / ((double)NP * (double)grid);
     uint64_t seg_cap = (uint64_t)((expect * 1.25 + 8.0 * std::sqrt(expect) + 32.0) * (double)ex.part_seg_growth);
     if (plain) {
       // the plain scatter deals tiles of 2048 (1024) rows round-robin to one workgroup per CU, and a workgroup appends to the segments of
       // ITS XCD: with few tiles the XCDs' shares differ by whole tiles (one tile: every row in XCD 0's segments)
-      const uint64_t T = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2048u : 1024u;
-      const uint64_t tiles = ((uint64_t)std::max<int64_t>(in.rows, 1) + T - 1) / T;
-      const uint64_t pg = (uint64_t)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 1023) / 1024));
+      const PscatGeom geom = ssgpu_part_scatter_plain_geom(NP, W0, (int)c->pscat_threads, (int)c->pscat_rows, (int)c->pscat_wgs);
+      const uint64_t T = (uint64_t)geom.threads * geom.rows;
+      const uint64_t tiles = ((uint64_t)std::max<int64_t>(range_rows, 1) + T - 1) / T;
+      const uint64_t pg = (uint64_t)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (range_rows + 1023) / 1024));
       const uint64_t xcds = std::min<uint64_t>(std::min<uint64_t>(SSGPU_PSCAT_XCDS, pg), tiles);
-      const double per_xcd = (double)std::min<uint64_t>((uint64_t)std::max<int64_t>(in.rows, 1), (tiles + xcds - 1) / xcds * T);
+      const double per_xcd = (double)std::min<uint64_t>((uint64_t)std::max<int64_t>(range_rows, 1), (tiles + xcds - 1) / xcds * T);
       const double expect_x = per_xcd / (double)NP;
       seg_cap = (uint64_t)((expect_x * 1.3 + 8.0 * std::sqrt(expect_x) + 64.0) * (double)ex.part_seg_growth);   // (partitions differ by their group counts, too)
     }
     if (slab) seg_cap = (uint64_t)((Ps.n_tiles + grid - 1) / grid) * (uint64_t)Ps.tile_rows;   // all rows a workgroup can see: never full
     if (resident) seg_cap = 1;                                                      // (no records are written)
-    const uint64_t n_segs = resident ? 1ull : (uint64_t)NP * (uint64_t)grid;
+    const uint64_t n_segs = resident ? 1ull : (uint64_t)NP * (uint64_t)grid;     // (of ONE row range)
     if (n_segs * seg_cap >= 0xFFFFFFFFull) { *fallback = true; return SSGPU_OK; }   // record indices are 32-bit
     unsigned long long* tkeys; unsigned long long* tacc; unsigned int* tcnt;   // the global table of this run
     DenseKeyMap dmap; memset(&dmap, 0, sizeof(dmap));
@@ -1815,9 +1838,10 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
     // next to the payload words: 34 bytes per row written and read back where a whole record with its index word took 40
     const bool split = dense && plain && !resident && c->part_split != 0 && W0 >= 2u && C <= 65536u;
     const size_t payload_bytes = split ? ((n_segs * seg_cap * (size_t)(W0 - 1u) * 8 + 255) & ~(size_t)255) : n_segs * seg_cap * (size_t)st.part_rec_bytes;
-    if (ex.part_recs.ensure(payload_bytes + (split ? n_segs * seg_cap * 2 : 0) + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
-    ex.last_split_records = split;
-    HIP_TRY(c, ex.part_hist.ensure(n_segs * 4));
+    const size_t range_rec_bytes = (payload_bytes + 255) & ~(size_t)255;     // (KR > 1 implies whole records: one range's segments)
+    if (ex.part_recs.ensure((KR > 1 ? range_rec_bytes * KR : payload_bytes + (split ? n_segs * seg_cap * 2 : 0)) + 16) != hipSuccess) { (void)hipGetLastError(); *fallback = true; return SSGPU_OK; }
+    ex.last_split_records = split; ex.last_row_ranges = (int)KR;
+    HIP_TRY(c, ex.part_hist.ensure(n_segs * KR * 4));
     {
       GroupInitParams I; memset(&I, 0, sizeof(I));
       I.pattern = ex.gpattern.as<unsigned long long>(); I.ng = ng;
@@ -1837,7 +1861,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       }
       I.z[0] = ex.goverflow.as<unsigned int>(); I.nz[0] = 4;
       I.z[1] = ex.error_flag.as<unsigned int>(); I.nz[1] = 1;
-      if (plain) { I.z[2] = ex.part_hist.as<unsigned int>(); I.nz[2] = n_segs; }     // the plain scatter's segment counters
+      if (plain) { I.z[2] = ex.part_hist.as<unsigned int>(); I.nz[2] = n_segs * KR; }     // the plain scatter's segment counters
       I.z[3] = ex.total.as<unsigned int>(); I.nz[3] = 4;                             // the extraction's row count, ticket and gave-up flag
       HIP_TRY(c, ssgpu_launch_group_init(I, c->stream));
     }
@@ -1884,6 +1908,7 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       else HIP_TRY(c, ssgpu_launch_group_resident(H, S, hot_lds, hgrid, c->stream));
       p->counters.n_launches += 1;
     }
+    std::function<int(uint32_t)> scatter_range;
     if (resident) {
       // nothing to scatter
     } else if (plain) {
@@ -1894,25 +1919,43 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       S.recs = ex.part_recs.as<unsigned long long>(); S.counts = ex.part_hist.as<unsigned int>(); S.overflow = ex.goverflow.as<unsigned int>() + 1;
       if (split) { S.split = 1u; S.recs_entry = reinterpret_cast<unsigned short*>(ex.part_recs.as<char>() + payload_bytes); S.pay_inv = W0 > 2u ? (uint32_t)(0x100000000ull / (W0 - 1u) + 1ull) : 0u; }
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
-      const int pgrid = (int)std::min<int64_t>(std::max(c->cu_count, 1), std::max<int64_t>(1, (in.rows + 1023) / 1024));
+      PscatGeom geom = ssgpu_part_scatter_plain_geom(NP, W0, (int)c->pscat_threads, (int)c->pscat_rows, (int)c->pscat_wgs);
+      geom.pipe = c->pscat_pipe != 0 ? 1u : 0u;
+      const int pgrid = (int)std::min<int64_t>((int64_t)std::max(c->cu_count, 1) * geom.wgs_per_cu, std::max<int64_t>(1, (in.rows + 1023) / 1024));
       // the specialised build (plans that asked): one per (descriptor, partition count) -- the LDS carve-up is static in it
       void* hs = nullptr;
       if (p->specialize) {
-        const int R = ssgpu_part_scatter_plain_lds(NP, W0, 2) <= 156u * 1024u ? 2 : 1;
-        const uint32_t lds = ssgpu_part_scatter_plain_lds(NP, W0, R);
-        const uint32_t tag = NP * 16u + (uint32_t)R * 4u + (split ? 2u : 0u) + (dense ? 1u : 0u);
+        const uint32_t lds = geom.lds;
+        const uint32_t tag = NP * 128u + (geom.pipe ? 64u : 0u) + (geom.threads == 512u ? 32u : 0u) + geom.rows * 4u + (split ? 2u : 0u) + (dense ? 1u : 0u);
         if (!(ex.rtc_plain.tried && ex.rtc_plain.static_lds == lds && ex.rtc_plain.tag == tag && !ex.rtc_plain.ask_again() && !ex.rtc_plain.stronger_mode_now())) {
           if (ex.rtc_plain.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_plain.drop(); }
           ex.rtc_plain.tried = true; ex.rtc_plain.static_lds = lds; ex.rtc_plain.tag = tag;
           std::string why;
-          ex.rtc_plain.h = ssgpu_rtc_specialize_pscat(c->device, S, R, lds, &why);
+          ex.rtc_plain.h = ssgpu_rtc_specialize_pscat(c->device, S, geom, &why);
           ex.rtc_plain.asked();
           if (!ex.rtc_plain.h && ex.rtc_why.empty()) ex.rtc_why = "plain partition scatter: " + why;
         }
         hs = ex.rtc_plain.h;
       }
-      if (hs) HIP_TRY(c, ssgpu_launch_part_scatter_plain_rtc(hs, S, pgrid, c->stream));
-      else HIP_TRY(c, ssgpu_launch_part_scatter_plain(S, pgrid, c->stream));
+      // range k of the input: the same descriptors over the rows [k * range_rows, ...), into range k's segments
+      scatter_range = [&, S, geom, pgrid, hs](uint32_t k) -> int {
+        PlainScatterParams R = S;
+        if (KR > 1) {
+          const uint64_t lo = (uint64_t)k * (uint64_t)range_rows;
+          R.n_rows = (unsigned long long)std::max<int64_t>(0, std::min<int64_t>(range_rows, in.rows - (int64_t)lo));
+          auto pred_width = [](uint32_t kind) { return kind == 6u ? 1u : (kind == 0u || kind == 1u || kind == 4u) ? 4u : 8u; };
+          for (uint32_t i = 0; i < R.n_keys; ++i) { R.keys[i].data = static_cast<const char*>(R.keys[i].data) + lo * R.keys[i].width; if (R.keys[i].nulls) R.keys[i].nulls += lo; }
+          for (uint32_t i = 0; i < R.n_fields; ++i) if (R.fields[i].src) R.fields[i].src = static_cast<const char*>(R.fields[i].src) + lo * R.fields[i].width;
+          for (uint32_t i = 0; i < R.n_preds; ++i) { R.preds[i].data = static_cast<const char*>(R.preds[i].data) + lo * pred_width(R.preds[i].kind); if (R.preds[i].nulls) R.preds[i].nulls += lo; }
+          R.recs = reinterpret_cast<unsigned long long*>(ex.part_recs.as<char>() + (size_t)k * range_rec_bytes);
+          R.counts = ex.part_hist.as<unsigned int>() + (size_t)k * n_segs;
+        }
+        const int g = (int)std::min<int64_t>(pgrid, std::max<int64_t>(1, ((int64_t)R.n_rows + 1023) / 1024));
+        if (hs) HIP_TRY(c, ssgpu_launch_part_scatter_plain_rtc(hs, R, geom, g, c->stream));
+        else HIP_TRY(c, ssgpu_launch_part_scatter_plain(R, geom, g, c->stream));
+        return SSGPU_OK;
+      };
+      if (KR == 1) { const int rc = scatter_range(0); if (rc != SSGPU_OK) return rc; }
       (void)scatter_grid;
     } else {
       void* h = Ps.debug_pc ? nullptr : rtc_for(p, ex, ex.rtc_pscatter, st.part_scatter, ex.lay_pscatter, ex.host_prog_pscatter, ex.n_instr_pscatter, Ps.lds_bytes, "partition scatter: ");
@@ -1971,9 +2014,30 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       ex.rtc_part.asked();
       if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
+    auto agg_launch = [&](const PartAggParams& AA, hipStream_t on) -> int {
+      if (p->specialize && ex.rtc_part.h && ex.rtc_part.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_part.h, AA, on));
+      else HIP_TRY(c, ssgpu_launch_part_agg(AA, agg_lds, on));
+      return SSGPU_OK;
+    };
     if (resident) { /* launched above */ }
-    else if (p->specialize && ex.rtc_part.h && ex.rtc_part.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_part_agg_rtc(ex.rtc_part.h, A, c->stream));
-    else HIP_TRY(c, ssgpu_launch_part_agg(A, agg_lds, c->stream));
+    else if (KR > 1) {
+      if (!c->side_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+      for (uint32_t k = 0; k <= KR; ++k) if (!c->side_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->side_ev[k], hipEventDisableTiming));
+      for (uint32_t k = 0; k < KR; ++k) {
+        { const int rc = scatter_range(k); if (rc != SSGPU_OK) return rc; }
+        HIP_TRY(c, hipEventRecord(c->side_ev[k], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_ev[k], 0));
+        PartAggParams AK = A;
+        AK.recs = reinterpret_cast<const unsigned long long*>(ex.part_recs.as<char>() + (size_t)k * range_rec_bytes);
+        AK.counts = ex.part_hist.as<unsigned int>() + (size_t)k * n_segs;
+        AK.accumulate = k ? 1u : 0u;
+        { const int rc = agg_launch(AK, c->side_stream); if (rc != SSGPU_OK) return rc; }
+      }
+      HIP_TRY(c, hipEventRecord(c->side_ev[KR], c->side_stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_ev[KR], 0));     // (the extraction, and whatever the caller queues next, follow the last aggregation)
+      p->counters.n_launches += 2 * (KR - 1);
+    }
+    else { const int rc = agg_launch(A, c->stream); if (rc != SSGPU_OK) return rc; }
     if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
     p->counters.n_launches += 6;
     p->counters.tile_rows = Ps.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)Ps.lds_bytes;
@@ -2994,6 +3058,7 @@ int ssgpu_plan_run_best_effort(ssgpu_plan* p, const ssgpu_column* cols, int32_t 
     int rc = run_range(start_row, W);
     if (rc == SSGPU_ERROR_MEMORY_EXCEEDED && W > 1) {
       // what fits is emitted and the aggregation starts anew: half the window, and no more groups than that many rows can hold
+      p->be_window_fail = W;       // (no later window of this plan is widened to this size again)
       W = std::max<int64_t>(1, W / 2); p->be_window = W; p->be_capacity = std::min(p->be_capacity, W);
       // the stages start over with buffers sized for the smaller window: what they hold was sized for the run that did not fit
       // (tables only grow while a plan lives), and a direct-shape table starts at 4 slots per possible group instead of the context's default
@@ -3016,7 +3081,12 @@ int ssgpu_plan_run_best_effort(ssgpu_plan* p, const ssgpu_column* cols, int32_t 
       break;
     }
     if (W >= left) { *next_row = rows; break; }
-    W = W > (INT64_MAX >> 2) ? INT64_MAX : W * 4; p->be_window = W;      // every key of the window fitted: the run goes on
+    // every key of the window fitted: the run goes on over a wider one -- unless a window of that size has already failed to fit the
+    // memory limit: then this window is the view (widening and halving would alternate for ever)
+    int64_t wider = W > (INT64_MAX >> 2) ? INT64_MAX : W * 4;
+    if (p->be_window_fail > 0 && wider >= p->be_window_fail) wider = std::max(W, p->be_window_fail / 2);
+    if (wider <= W) { *next_row = start_row + W; break; }
+    W = wider; p->be_window = W;
   }
   if (out) *out = &p->result;
   return SSGPU_OK;
@@ -3078,6 +3148,8 @@ int ssgpu_plan_stage_info(const ssgpu_plan* p, int32_t stage, ssgpu_stage_info* 
   out->plain_scatter = ex.last_plain_scatter ? 1 : 0;
   out->hot_keys = (int32_t)ex.hot_n;
   out->dense_slots = ex.dense.on ? (int32_t)ex.dense.slots : 0;
+  out->split_records = (ex.dense.on && ex.last_group_shape == 1 && ex.last_split_records) ? 1 : 0;
+  out->row_ranges = (ex.dense.on && ex.last_group_shape == 1) ? ex.last_row_ranges : 1;
   return SSGPU_OK;
 }
 void ssgpu_specialized_kernels_trim(int32_t keep) { ssgpu_rtc_trim(keep); }

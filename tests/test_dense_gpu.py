@@ -53,13 +53,16 @@ def group3_op(view, with_filter):
 # ---- BASELINE configs #3 / #4 in the dense shape: what `bench.py --query group3 / group` runs by default -----------------------
 @pytest.mark.parametrize("with_filter", [False, True])
 @pytest.mark.parametrize("specialize", [0, 1])
-def test_config3_and_4_take_dense_partitions_from_the_first_run(specialize, with_filter):
+@pytest.mark.parametrize("split", [1, 0])
+def test_config3_and_4_take_dense_partitions_from_the_first_run(specialize, with_filter, split):
+    # split = 1 (the default): the records cross HBM as payload words + 16-bit table entries; 0: whole records, index word first
     n = 2_000_000
     view = ss.View(bench.group_schema(ss), bench.host_columns(np, "group", n))
     op = group3_op(view, with_filter)
     _s, want = oracle.run(op)
-    plan = ss.Plan(op, dense_ctx(specialize=specialize))
+    plan = ss.Plan(op, dense_ctx(specialize=specialize, part_split=split))
     infos = run_plan(plan, want, "config #%d, dense" % (4 if with_filter else 3), runs=3)
+    assert [i["split_records"] for i in infos] == [split] * 3, infos
     # k1 = g // 317 in [0, 315], k2 = g % 317 in [0, 316]: 316 x 317 slots; no scout, no direct first run, no rerun
     assert [i["dense_slots"] for i in infos] == [316 * 317] * 3 and [i["group_shape"] for i in infos] == [1, 1, 1], infos
     assert [i["reruns"] for i in infos] == [0, 0, 0] and infos[0]["plain_scatter"] == 1, infos
@@ -83,14 +86,42 @@ def test_few_groups_take_one_dense_table_fed_from_the_columns(specialize):
             assert infos[-1]["specialized"] & 16, plan.specialize_reason()
 
 
+@pytest.mark.parametrize("ranges", [2, 3, 8])
+@pytest.mark.parametrize("nullable", [False, True])
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_dense_partitions_over_row_ranges(ranges, nullable, with_filter):
+    """Large inputs take the dense partitions in row ranges: range k is aggregated (side stream, the table read back from what the launch
+    before it dumped) while range k + 1 is scattered.  Forced here on a small input; three runs of one plan (the tables are reused)."""
+    n = 300007
+    ctx = dense_ctx(dense_min_rows=1, dense_parts=7, group_resident=0, part_overlap=ranges, part_overlap_rows=1)
+    keys = ("k1",) if nullable else ("k1", "k2")
+    op = group_query(make_view(n, nullable=nullable), with_filter, keys)
+    _s, want = oracle.run(op)
+    plan = ss.Plan(op, ctx)
+    infos = run_plan(plan, want, "dense partitions, %d row ranges" % ranges, runs=3)
+    assert [i["row_ranges"] for i in infos] == [ranges] * 3 and infos[-1]["group_shape"] == 1, infos
+
+
+def test_config3_over_row_ranges_specialized():
+    n = 2_000_000
+    view = ss.View(bench.group_schema(ss), bench.host_columns(np, "group", n))
+    for with_filter in (False, True):
+        op = group3_op(view, with_filter)
+        _s, want = oracle.run(op)
+        plan = ss.Plan(op, dense_ctx(specialize=1, part_overlap=4, part_overlap_rows=1))
+        infos = run_plan(plan, want, "config #%d, dense, 4 row ranges" % (4 if with_filter else 3), runs=3)
+        assert [i["row_ranges"] for i in infos] == [4] * 3, infos
+
+
 # ---- every row count / NULL / Filter case of the hashed GroupAggregate tests, in the dense shape (dense_min_rows = 1) --------------
 @pytest.mark.parametrize("n", [1, 65, 1025, 100003])
 @pytest.mark.parametrize("with_filter", [False, True])
 @pytest.mark.parametrize("nullable", [False, True])
-@pytest.mark.parametrize("parts", [0, 7])
+@pytest.mark.parametrize("parts", [0, 7, -7])
 def test_dense_group_aggregate_small_inputs(n, with_filter, nullable, parts):
-    # parts = 7: forces the partitioned dense shape with an odd partition count where the ranges would fit one table
-    ctx = dense_ctx(dense_min_rows=1, dense_parts=parts, group_resident=0 if parts else 1)
+    # parts = 7: forces the partitioned dense shape with an odd partition count where the ranges would fit one table (-7: the same with whole records)
+    split, parts = (0, -parts) if parts < 0 else (1, parts)
+    ctx = dense_ctx(dense_min_rows=1, dense_parts=parts, group_resident=0 if parts else 1, part_split=split)
     keys = ("k1",) if nullable else ("k1", "k2")
     op = group_query(make_view(n, nullable=nullable), with_filter, keys)
     run_both(op, ctx, ignore_order=True)
