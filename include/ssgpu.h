@@ -110,7 +110,7 @@
 extern "C" {
 #endif
 
-#define SSGPU_ABI_VERSION 9
+#define SSGPU_ABI_VERSION 10
 
 /* ---- reference enum values (supersonic/proto/supersonic.proto) ---------- */
 enum {
@@ -590,9 +590,21 @@ int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_resul
  * the multi-GPU form, and ONE launch folds the states in row order and emits the row.  Device memory: 2 * chunk_rows rows.
  * Same result as ssgpu_plan_run over the whole input (FIRST / LAST follow the global row order; floating sums are folded chunk
  * by chunk in double-double like the shards of a multi-GPU job; a leading NaN of a floating MIN / MAX is skipped as across
- * shards).  For plans whose only stage is a ScalarAggregate (over Filter / Compute / Project) -- the path's headline shape;
- * SSGPU_ERROR_NOT_IMPLEMENTED otherwise.  The host columns must stay alive and unmodified until the call has returned AND the
- * context's streams have drained (ssgpu_ctx_synchronize, or fetching the result). */
+ * shards).  The host columns must stay alive and unmodified until the call has returned AND the context's streams have drained
+ * (ssgpu_ctx_synchronize, or fetching the result).
+ * Which plans (ABI 10; ssgpu_plan_chunked_form tells, also on a bind-only context):
+ *   1  ONE ScalarAggregate stage (over Filter / Compute / Project) -- the path's headline shape: the state fold described above;
+ *   2  plans of row-local operations only (Filter / Compute / Project / HashJoin against the auxiliary input; filter.cc:96-128 pulls
+ *      its child the same way): every chunk runs the plan, its result rows are appended on the device; the rows keep the input's order;
+ *   3  plans whose first blocking operation on the input's path is a GroupAggregate without a key limit, over row-local operations
+ *      (aggregate_groups.cc:212-282 ProcessInput): every chunk runs the plan UP TO AND INCLUDING the GroupAggregate -- in whatever
+ *      shape its run feedback picks, DOUBLE sums with their SSGPU_SUM_RESIDUAL -- and leaves a partial table; the partial tables are
+ *      appended, and at the end ONE second plan runs over them: GroupAggregate of the merge functions (COUNT merges as SUM, FIRST /
+ *      LAST in chunk = row order) -> Compute restoring the first one's schema -> the operations above it (Sort, Compute, ...).
+ *      DISTINCT / CONCAT aggregates and the row-after-row SUM of a floating column into an integer are not partial results, and a NaN
+ *      reaching a floating MIN / MAX is order-dependent in the reference: SSGPU_ERROR_NOT_IMPLEMENTED (bind time resp. the chunk that
+ *      meets it) -- those run over device columns.  Device memory: the staging sets + (groups met per chunk) x chunks partial rows.
+ * Everything else (Sort / AggregateClusters / key-limited GroupAggregate as the first blocking operation): SSGPU_ERROR_NOT_IMPLEMENTED. */
 int ssgpu_plan_run_host(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows, int64_t chunk_rows, ssgpu_result** out);
 /* The PUSH form of the same, for a caller that meets its input the way the reference's cursors do -- a child's Next() handing out
  * Views of <= 1024 rows that are only valid until the next Next() (cursor.h:131-148, aggregate_scalar.cc:53-68):
@@ -606,6 +618,10 @@ int ssgpu_plan_run_host(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t
 int ssgpu_plan_stream_begin(ssgpu_plan* plan, int64_t chunk_rows);
 int ssgpu_plan_stream_push(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows);
 int ssgpu_plan_stream_finish(ssgpu_plan* plan, ssgpu_result** out);
+/* The chunked form (1 / 2 / 3 above) ssgpu_plan_run_host / _stream_* would take for this plan, or its refusal's return code; for form 3
+ * `head` / `tail` (may be NULL) receive the descriptions (as ssgpu_plan_describe gives them) of the per-chunk plan and of the merging
+ * plan, valid while the plan lives.  Needs no device. */
+int ssgpu_plan_chunked_form(ssgpu_plan* plan, int32_t* kind, const char** head, const char** tail);
 /* The auxiliary input of a HASH_JOIN plan (rhs: DEVICE columns of the dimension table).  Stays
  * bound until replaced; the join index is rebuilt from it at the start of every run. */
 int ssgpu_plan_set_aux_input(ssgpu_plan* plan, const ssgpu_column* cols, int32_t n_cols, int64_t rows);

@@ -569,7 +569,7 @@ class SortOrder {
 namespace internal {
 struct Context {
   ssgpu_ctx* ctx = nullptr;
-  // > 0: a ScalarAggregate over a host View of more rows than this is staged in chunks of this many rows (ssgpu_plan_run_host: the
+  // > 0: a plan with a chunked form (ssgpu.h "CHUNKED STAGING": ScalarAggregate / row-local / GroupAggregate-first) over a host View of more rows than this is staged in chunks of this many rows (ssgpu_plan_run_host: the
   // copy of chunk k + 1 overlaps the kernel over chunk k; inputs larger than device memory run) -- SetHostStagingChunkRows below
   rowcount_t host_chunk_rows = 0;
   Context() { if (ssgpu_ctx_create(0, &ctx) != SSGPU_OK) ssgpu_ctx_create(-1, &ctx); }  // bind-only without a GPU
@@ -833,7 +833,7 @@ class DeviceCursor : public Cursor {
       }
       int rc = ssgpu_plan_run_host(plan_, cols.data(), static_cast<int32_t>(cols.size()), static_cast<int64_t>(input_->row_count()), static_cast<int64_t>(chunk), &res_);
       if (rc == SSGPU_OK) rc = ssgpu_ctx_synchronize(ctx);   // (the View's memory is the caller's: nothing may read it after Next)
-      if (rc != SSGPU_ERROR_NOT_IMPLEMENTED) return run_rc_ = rc;   // (not a single ScalarAggregate stage: the block path below)
+      if (rc != SSGPU_ERROR_NOT_IMPLEMENTED) return run_rc_ = rc;   // (no chunked form for this plan, or a chunk met what only a whole-input run answers: the block path below)
     }
     int rc = Stage(ctx);
     if (rc == SSGPU_OK) {

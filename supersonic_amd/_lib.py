@@ -180,6 +180,7 @@ SYMBOLS = [
     ("ssgpu_plan_stream_begin", C.c_int, [P, C.c_int64]),
     ("ssgpu_plan_stream_push", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64]),
     ("ssgpu_plan_stream_finish", C.c_int, [P, C.POINTER(P)]),
+    ("ssgpu_plan_chunked_form", C.c_int, [P, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
     ("ssgpu_plan_set_aux_input", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64]),
     ("ssgpu_interrupt", None, [P]),
     ("ssgpu_plan_run_partial", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.c_int64]),

@@ -1277,7 +1277,8 @@ class Plan(object):
         """Chunked staging (ssgpu_plan_run_host): the HOST columns of `view` (default: the plan's input) travel through two alternating
         sets of device columns of chunk_rows rows, chunk k + 1 being copied while chunk k is read -- inputs larger than device
         memory run, and the copy overlaps the kernels (pinned numpy memory, e.g. torch's pin_memory, for the copies to be
-        asynchronous).  For plans whose only stage is a ScalarAggregate; NOT_IMPLEMENTED otherwise."""
+        asynchronous).  ScalarAggregate plans, row-local plans (Filter / Compute / Project / HashJoin) and plans whose first blocking
+        operation is a GroupAggregate of mergeable aggregates (include/ssgpu.h, "CHUNKED STAGING"); NOT_IMPLEMENTED otherwise."""
         view = view if view is not None else self.input
         if isinstance(view, DeviceView):
             raise SupersonicException(ERROR_INVALID_ARGUMENT_VALUE, "run_host takes a host View (device columns: run)")
@@ -1301,6 +1302,13 @@ class Plan(object):
         self.ctx.synchronize()                   # (the host arrays may go once the streams have drained)
         self._result = res
         return res
+
+    def chunked_form(self):
+        """ssgpu_plan_chunked_form: how run_host / stream would take this plan -- (1, ...) ScalarAggregate state fold, (2, ...) row-local plan,
+        results appended, (3, per-chunk plan, merging plan) GroupAggregate partial tables + one merge; raises what they would raise."""
+        kind, head, tail = C.c_int32(0), C.c_char_p(), C.c_char_p()
+        self.ctx.check(self.lib.ssgpu_plan_chunked_form(self.handle, C.byref(kind), C.byref(head), C.byref(tail)))
+        return kind.value, (head.value or b"").decode(), (tail.value or b"").decode()
 
     def stream(self, views, chunk_rows=0):
         """The push form of chunked staging (ssgpu_plan_stream_begin / _push / _finish): `views` is an iterable of host Views with the
@@ -1409,6 +1417,13 @@ class Plan(object):
             out.Finalize()
             return
         self.ctx.check(self.lib.ssgpu_result_write_file(res or self._result, path.encode()))
+
+    def result_row_count(self, res=None):
+        """ssgpu_result_row_count of the last run's result (waits for the run; nothing is copied)."""
+        rows = self.lib.ssgpu_result_row_count(res or self._result)
+        if rows < 0:
+            raise SupersonicException(L.ERROR_HIP, self.ctx.last_error())
+        return int(rows)
 
     def fetch(self, res=None):
         """Copy the result to host: a View over numpy arrays."""

@@ -18,6 +18,7 @@
 #include <thread>
 #include <unordered_set>
 #include <vector>
+#include <deque>
 #include <functional>
 
 #include "engine.h"
@@ -401,6 +402,7 @@ struct ssgpu_plan {
   struct HostStream {
     bool open = false; int rc = SSGPU_OK;
     int64_t chunk_rows = 0, fill = 0, pushed = 0, chunks = 0; int cur = 0;
+    int kind = 1;                 // ssgpu_plan::StreamJob::kind of the open stream (1: ScalarAggregate states)
     std::vector<PinnedBuf> pin_data[2], pin_nulls[2];
     hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     bool in_flight[2] = {false, false};
@@ -412,6 +414,18 @@ struct ssgpu_plan {
       }
     }
   } host_stream;
+  // Chunked execution of plans that are not one ScalarAggregate stage (ssgpu_plan_run_host / ssgpu_plan_stream_*; stream_job_* below):
+  // kind 2 = every stage is row-local (Filter / Compute / Project / HashJoin): each chunk runs the plan itself and its result rows are
+  // appended; kind 3 = the first blocking operation on the input's path is a GroupAggregate of mergeable aggregates: `head` (the plan up to
+  // and including it, DOUBLE sums with their residuals) runs over every chunk, the partial tables are appended, and `tail` -- a
+  // GroupAggregate of the merge functions over them, the single-run schema restored, then the operations above -- runs once at the end.
+  struct StreamJob {
+    int kind = 0;
+    ssgpu_plan* head = nullptr; ssgpu_plan* tail = nullptr;     // kind 3: owned; kind 2: head == the plan itself
+    std::vector<DevBuf> acc_data, acc_nulls;                    // the appended rows, one buffer per result column of `head`
+    int64_t acc_rows = 0, acc_cap = 0;
+  };
+  StreamJob* stream_job = nullptr;
   int64_t run_row_end = 0;         // row_id_base + rows of the run in progress: one past the largest row id a stage can meet
   bool keep_error_flags = false;   // ... whose runs after the first leave the error words alone: an evaluation error of ANY chunk fails the run
   ssgpu_result result;
@@ -816,6 +830,13 @@ int ssgpu_plan_set_option(ssgpu_plan* p, const char* key, int64_t value) {
 
 void ssgpu_plan_destroy(ssgpu_plan* p) {
   if (!p) return;
+  if (p->stream_job) {
+    ssgpu_plan::StreamJob* j = p->stream_job; p->stream_job = nullptr;
+    if (p->ctx && p->ctx->device >= 0) (void)hipStreamSynchronize(p->ctx->stream);
+    if (j->tail) ssgpu_plan_destroy(j->tail);
+    if (j->head && j->head != p) ssgpu_plan_destroy(j->head);
+    delete j;
+  }
   if (p->ctx && p->ctx->device >= 0) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->host_stream.open) { (void)hipStreamSynchronize(p->ctx->copy_stream); p->host_stream.drop_events(); p->host_stream.open = false; }   // (a stream nobody finished)
@@ -3211,6 +3232,304 @@ int ssgpu_plan_run_block(ssgpu_plan* p, const ssgpu_block* b, ssgpu_result** out
   return ssgpu_plan_run(p, cols.data(), (int32_t)cols.size(), b->rows, out);
 }
 
+
+// ---- chunked execution beyond the ScalarAggregate shape (ssgpu_plan::StreamJob) ------------------------------------------------
+// The reference pulls 1024-row blocks from any child for every operation (aggregate_groups.cc:212,282 ProcessInput, filter.cc:96-128);
+// here a HOST input of any size crosses PCIe in chunks while the device works on the chunk before it.
+static void stream_job_reset_out(ssgpu_plan* q) {     // the last stage's result buffers: views of an accumulation are dropped, a fresh run allocates its own
+  if (q->exec.empty()) return;
+  StageExec& ex = q->exec.back();
+  bool any_view = false;
+  for (auto& oc : ex.out) any_view = any_view || oc.data.view || oc.nulls.view;
+  if (!any_view || ex.out_arena.p) return;            // (views into the stage's own arena stay)
+  for (auto& oc : ex.out) { oc.data.release(); oc.nulls.release(); }
+  ex.out_capacity = 0; ex.out_rows = 0;
+}
+static int lookup_name(const Schema& s, const char* name) {
+  for (size_t i = 0; i < s.size(); ++i) if (s[i].name == (name ? name : "")) return (int)i;
+  return -1;
+}
+// kind 3: the derived plans.  iB = the GroupAggregate in p->desc.ops
+static int stream_job_build_group(ssgpu_plan* p, int iB, ssgpu_plan** head_out, ssgpu_plan** tail_out) {
+  ssgpu_ctx* c = p->ctx; const PlanDesc& D = p->desc;
+  std::vector<ssgpu_attr> in_attrs, aux_attrs;
+  for (auto& a : D.input_schema) in_attrs.push_back(ssgpu_attr{a.name.c_str(), a.dtype, a.nullable ? 1 : 0});
+  for (auto& a : D.aux_schema) aux_attrs.push_back(ssgpu_attr{a.name.c_str(), a.dtype, a.nullable ? 1 : 0});
+  ssgpu_plan_desc base; memset(&base, 0, sizeof(base));
+  base.input_schema = in_attrs.data(); base.n_attrs = (int32_t)in_attrs.size();
+  base.ops = D.ops.data(); base.n_ops = (int32_t)D.ops.size();
+  base.exprs = D.exprs.data(); base.n_exprs = (int32_t)D.exprs.size();
+  base.expr_args = D.expr_args.data(); base.n_expr_args = (int32_t)D.expr_args.size();
+  base.projs = D.projs.data(); base.n_projs = (int32_t)D.projs.size();
+  base.aggs = D.aggs.data(); base.n_aggs = (int32_t)D.aggs.size();
+  base.sortkeys = D.sortkeys.data(); base.n_sortkeys = (int32_t)D.sortkeys.size();
+  base.aux_schema = aux_attrs.empty() ? nullptr : aux_attrs.data(); base.n_aux_attrs = (int32_t)aux_attrs.size();
+  const ssgpu_op B = D.ops[(size_t)iB];
+  // the schema the GroupAggregate reads: the plan cut below it, bound
+  Schema child_schema;
+  {
+    ssgpu_plan_desc d1 = base; d1.n_ops = B.child + 1;
+    ssgpu_plan* child = nullptr;
+    const int rc = ssgpu_plan_create(c, &d1, &child);
+    if (rc != SSGPU_OK) return rc;
+    child_schema = child->result_schema;
+    ssgpu_plan_destroy(child);
+  }
+  // head: the plan up to and including the GroupAggregate; behind every DOUBLE sum its residual (SSGPU_SUM_RESIDUAL: the partial sum
+  // travels as the exact pair (s, e), as between shards -- supersonic_amd/distributed.py _shard_spec)
+  std::deque<std::string> names;
+  std::vector<ssgpu_agg> haggs(D.aggs.begin(), D.aggs.end());
+  const size_t hfirst = haggs.size();
+  enum { COL_RESIDUAL = 1000 };
+  std::vector<int> col_fn;                      // per aggregate column of the head's result: its aggregation, or COL_RESIDUAL
+  for (int j = 0; j < B.agg_n; ++j) {
+    const ssgpu_agg a = D.aggs[(size_t)(B.agg_first + j)];
+    if (a.distinct || a.aggregation == SSGPU_CONCAT || a.aggregation == SSGPU_SUM_RESIDUAL) {
+      c->err = "chunked execution: DISTINCT / CONCAT aggregates are not partial results (their GroupAggregate takes device columns: ssgpu_plan_run)"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+    }
+    const int pos = lookup_name(child_schema, a.input);
+    const int in_type = pos >= 0 ? child_schema[(size_t)pos].dtype : -1;
+    const bool int_out = a.output_type == SSGPU_INT32 || a.output_type == SSGPU_UINT32 || a.output_type == SSGPU_INT64 || a.output_type == SSGPU_UINT64;
+    if (a.aggregation == SSGPU_SUM && (in_type == SSGPU_FLOAT || in_type == SSGPU_DOUBLE) && int_out) {
+      // the reference adds and truncates row after row (aggregation_operators.h:173-185): a chunk's result is not a partial sum
+      c->err = "chunked execution: SUM of a floating input into an integer result is a row-after-row fold, not a partial result"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+    }
+    haggs.push_back(a); col_fn.push_back(a.aggregation);
+    if (a.aggregation == SSGPU_SUM && in_type == SSGPU_DOUBLE && (a.output_type == -1 || a.output_type == SSGPU_DOUBLE)) {
+      names.push_back(std::string(a.output ? a.output : "") + "$res");
+      ssgpu_agg r; memset(&r, 0, sizeof(r));
+      r.aggregation = SSGPU_SUM_RESIDUAL; r.output_type = -1; r.input = a.input; r.output = names.back().c_str();
+      haggs.push_back(r); col_fn.push_back(COL_RESIDUAL);
+    }
+  }
+  std::vector<ssgpu_op> hops(D.ops.begin(), D.ops.begin() + iB + 1);
+  hops[(size_t)iB].agg_first = (int32_t)hfirst; hops[(size_t)iB].agg_n = (int32_t)(haggs.size() - hfirst);
+  ssgpu_plan* head = nullptr;
+  {
+    ssgpu_plan_desc dh = base; dh.ops = hops.data(); dh.n_ops = iB + 1; dh.aggs = haggs.data(); dh.n_aggs = (int32_t)haggs.size();
+    const int rc = ssgpu_plan_create(c, &dh, &head);
+    if (rc != SSGPU_OK) return rc;
+  }
+  // tail: Scan(partial tables) -> GroupAggregate(the merge functions: COUNT merges as SUM) -> Compute(COUNT back to NOT NULL, every
+  // DOUBLE sum = merged sum + merged residual, residuals projected away: the GroupAggregate's own schema) -> the operations above
+  const Schema& hs = head->result_schema;
+  const size_t nk = hs.size() - col_fn.size();
+  std::vector<ssgpu_attr> t_in;
+  for (auto& a : hs) t_in.push_back(ssgpu_attr{a.name.c_str(), a.dtype, a.nullable ? 1 : 0});
+  std::vector<ssgpu_expr> texprs(D.exprs.begin(), D.exprs.end());
+  std::vector<int32_t> targs(D.expr_args.begin(), D.expr_args.end());
+  std::vector<ssgpu_proj> tprojs(D.projs.begin(), D.projs.end());
+  std::vector<ssgpu_agg> taggs(D.aggs.begin(), D.aggs.end());
+  const int32_t kp_first = (int32_t)tprojs.size();
+  for (size_t k = 0; k < nk; ++k) { ssgpu_proj pr; memset(&pr, 0, sizeof(pr)); pr.kind = SSGPU_PROJ_AT; pr.position = (int32_t)k; pr.name = ""; pr.alias = ""; tprojs.push_back(pr); }
+  const int32_t ma_first = (int32_t)taggs.size();
+  for (size_t j = 0; j < col_fn.size(); ++j) {
+    ssgpu_agg m; memset(&m, 0, sizeof(m));
+    m.aggregation = (col_fn[j] == SSGPU_COUNT || col_fn[j] == COL_RESIDUAL) ? SSGPU_SUM : col_fn[j];
+    m.output_type = -1; m.input = hs[nk + j].name.c_str(); m.output = hs[nk + j].name.c_str();
+    taggs.push_back(m);
+  }
+  auto add_expr = [&](int kind, int op, int dtype, const char* name, std::initializer_list<int32_t> kids, int64_t i64 = 0) -> int32_t {
+    ssgpu_expr e; memset(&e, 0, sizeof(e));
+    e.kind = kind; e.op = op; e.dtype = dtype; e.first_arg = (int32_t)targs.size(); e.nargs = (int32_t)kids.size(); e.i64 = i64; e.name = name ? name : "";
+    for (int32_t k : kids) targs.push_back(k);
+    texprs.push_back(e);
+    return (int32_t)texprs.size() - 1;
+  };
+  std::vector<int32_t> outs;
+  for (size_t k = 0; k < nk; ++k) outs.push_back(add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, hs[k].name.c_str(), {}));
+  for (size_t j = 0; j < col_fn.size(); ++j) {
+    const char* nm = hs[nk + j].name.c_str();
+    if (col_fn[j] == COL_RESIDUAL) continue;
+    const int32_t self = add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, nm, {});
+    if (col_fn[j] == SSGPU_COUNT) {
+      const int32_t zero = add_expr(SSGPU_EXPR_CONST, 0, hs[nk + j].dtype, "", {}, 0);
+      const int32_t ifnull = add_expr(SSGPU_EXPR_OP, 220 /* OPERATOR_IFNULL */, 0, "", {self, zero});
+      outs.push_back(add_expr(SSGPU_EXPR_ALIAS, 0, 0, nm, {ifnull}));
+    } else if (j + 1 < col_fn.size() && col_fn[j + 1] == COL_RESIDUAL) {
+      const int32_t res = add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, hs[nk + j + 1].name.c_str(), {});
+      const int32_t sum = add_expr(SSGPU_EXPR_OP, 0 /* OPERATOR_ADD */, 0, "", {self, res});
+      outs.push_back(add_expr(SSGPU_EXPR_ALIAS, 0, 0, nm, {sum}));
+    } else outs.push_back(self);
+  }
+  int32_t root;
+  { ssgpu_expr e; memset(&e, 0, sizeof(e)); e.kind = SSGPU_EXPR_COMPOUND; e.first_arg = (int32_t)targs.size(); e.nargs = (int32_t)outs.size(); e.name = "";
+    for (int32_t k : outs) targs.push_back(k);
+    texprs.push_back(e); root = (int32_t)texprs.size() - 1; }
+  std::vector<ssgpu_op> tops;
+  { ssgpu_op o; memset(&o, 0, sizeof(o)); o.kind = SSGPU_OP_SCAN; o.child = -1; o.expr = -1; o.child2 = -1; tops.push_back(o); }
+  { ssgpu_op o; memset(&o, 0, sizeof(o)); o.kind = SSGPU_OP_GROUP_AGGREGATE; o.child = 0; o.expr = -1; o.child2 = -1; o.proj_first = kp_first; o.proj_n = (int32_t)nk; o.agg_first = ma_first; o.agg_n = (int32_t)col_fn.size(); tops.push_back(o); }
+  { ssgpu_op o; memset(&o, 0, sizeof(o)); o.kind = SSGPU_OP_COMPUTE; o.child = 1; o.expr = root; o.child2 = -1; tops.push_back(o); }
+  std::vector<int32_t> remap(D.ops.size(), -1);
+  remap[(size_t)iB] = 2;
+  bool tail_has_aux = false;
+  for (size_t j = (size_t)iB + 1; j < D.ops.size(); ++j) {
+    ssgpu_op o = D.ops[j];
+    auto ref = [&](int32_t k) -> int32_t {
+      if (k < 0) return k;
+      if (remap[(size_t)k] >= 0) return remap[(size_t)k];
+      const ssgpu_op& r = D.ops[(size_t)k];
+      if (r.kind == SSGPU_OP_SCAN && r.option0 == 1) { tops.push_back(r); tail_has_aux = true; remap[(size_t)k] = (int32_t)tops.size() - 1; return remap[(size_t)k]; }
+      return -2;
+    };
+    o.child = ref(o.child); if (o.kind == SSGPU_OP_HASH_JOIN) o.child2 = ref(o.child2);
+    if (o.child == -2 || o.child2 == -2) { ssgpu_plan_destroy(head); c->err = "chunked execution: the operations above the GroupAggregate read more than its result"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    tops.push_back(o); remap[j] = (int32_t)tops.size() - 1;
+  }
+  ssgpu_plan* tail = nullptr;
+  {
+    ssgpu_plan_desc dt; memset(&dt, 0, sizeof(dt));
+    dt.input_schema = t_in.data(); dt.n_attrs = (int32_t)t_in.size();
+    dt.ops = tops.data(); dt.n_ops = (int32_t)tops.size();
+    dt.exprs = texprs.data(); dt.n_exprs = (int32_t)texprs.size();
+    dt.expr_args = targs.data(); dt.n_expr_args = (int32_t)targs.size();
+    dt.projs = tprojs.data(); dt.n_projs = (int32_t)tprojs.size();
+    dt.aggs = taggs.data(); dt.n_aggs = (int32_t)taggs.size();
+    dt.sortkeys = D.sortkeys.data(); dt.n_sortkeys = (int32_t)D.sortkeys.size();
+    if (tail_has_aux) { dt.aux_schema = aux_attrs.data(); dt.n_aux_attrs = (int32_t)aux_attrs.size(); }
+    const int rc = ssgpu_plan_create(c, &dt, &tail);
+    if (rc != SSGPU_OK) { ssgpu_plan_destroy(head); return rc; }
+  }
+  if (tail->result_schema.size() != p->result_schema.size()) { ssgpu_plan_destroy(head); ssgpu_plan_destroy(tail); c->err = "chunked execution: the merged plan's schema differs from the plan's"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+  for (size_t i = 0; i < p->result_schema.size(); ++i)
+    if (tail->result_schema[i].dtype != p->result_schema[i].dtype || tail->result_schema[i].name != p->result_schema[i].name) {
+      ssgpu_plan_destroy(head); ssgpu_plan_destroy(tail); c->err = "chunked execution: the merged plan's schema differs from the plan's (column '" + p->result_schema[i].name + "')"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+    }
+  *head_out = head; *tail_out = tail;
+  return SSGPU_OK;
+}
+// Which chunked form serves the plan (and the derived plans of kind 3, made once per plan): 1 = ScalarAggregate state fold (the caller's own code)
+static int stream_job_prepare(ssgpu_plan* p, int* kind_out, bool for_run = true) {
+  ssgpu_ctx* c = p->ctx;
+  if (p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG) { *kind_out = 1; return SSGPU_OK; }
+  if (!p->stream_job) {
+    int kind = 0, iB = -1;
+    bool row_local = !p->stages.empty();
+    for (auto& st : p->stages)
+      row_local = row_local && ((st.kind == STAGE_MATERIALIZE && st.distinct_cols.empty() && !st.has_segment && !st.has_rank && st.concat.empty()) || st.kind == STAGE_JOIN_EXPAND);
+    if (row_local) kind = 2;
+    else {
+      // the path from the root down to the scan of the plan's input; its lowest operation that is not row-local
+      std::vector<int> path;
+      for (int i = (int)p->desc.ops.size() - 1; i >= 0; i = p->desc.ops[(size_t)i].child) path.push_back(i);
+      for (size_t k = path.size(); k-- > 0;) {
+        const ssgpu_op& o = p->desc.ops[(size_t)path[k]];
+        if (o.kind == SSGPU_OP_SCAN || o.kind == SSGPU_OP_COMPUTE || o.kind == SSGPU_OP_FILTER || o.kind == SSGPU_OP_PROJECT || o.kind == SSGPU_OP_HASH_JOIN) continue;
+        if (o.kind == SSGPU_OP_GROUP_AGGREGATE && o.option0 == 0) { kind = 3; iB = path[k]; }
+        break;
+      }
+    }
+    if (!kind) {
+      c->err = "chunked staging serves plans of row-local operations (Filter / Compute / Project / HashJoin), ScalarAggregates over them, and plans whose "
+               "first blocking operation is a GroupAggregate without a key limit; other plans take device columns (ssgpu_block_upload + ssgpu_plan_run_block)";
+      return SSGPU_ERROR_NOT_IMPLEMENTED;
+    }
+    ssgpu_plan* head = p; ssgpu_plan* tail = nullptr;
+    if (kind == 3) { const int rc = stream_job_build_group(p, iB, &head, &tail); if (rc != SSGPU_OK) return rc; }
+    p->stream_job = new ssgpu_plan::StreamJob;
+    p->stream_job->kind = kind; p->stream_job->head = head; p->stream_job->tail = tail;
+  }
+  *kind_out = p->stream_job->kind;
+  if (!for_run) return SSGPU_OK;
+  ssgpu_plan::StreamJob& J = *p->stream_job;
+  J.acc_rows = 0;
+  for (ssgpu_plan* q : {J.head, J.tail}) {
+    if (!q || q == p) continue;
+    q->aux_cols = p->aux_cols; q->aux_rows = p->aux_rows; q->dict = p->dict; q->quota.limit = p->quota.limit;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  stream_job_reset_out(J.head);
+  *kind_out = J.kind;
+  return SSGPU_OK;
+}
+// one staged chunk (device columns, `n` rows, the chunk's first row id `base`) through the head plan; its result rows join the accumulation
+static int stream_job_chunk(ssgpu_plan* p, const ssgpu_column* dev, int32_t n_cols, int64_t n, int64_t base) {
+  ssgpu_ctx* c = p->ctx; ssgpu_plan::StreamJob& J = *p->stream_job; ssgpu_plan* h = J.head;
+  int rc = run_plan(h, dev, n_cols, n, base, false);
+  if (rc == SSGPU_OK) rc = settle_plan(h);
+  if (rc == SSGPU_OK) rc = check_error_flags(h);
+  if (rc != SSGPU_OK) { if (h != p && h->ctx == c) {} return rc; }
+  if (h->nan_seen && J.kind == 3) {
+    // a NaN met by a floating MIN / MAX: the reference keeps it when it is the group's FIRST value (aggregation_operators.h:189-228), which
+    // per-chunk partial results cannot tell apart from a later one
+    h->nan_seen = false;
+    c->err = "chunked execution: a NaN reached a floating MIN / MAX of the GroupAggregate (order-dependent in the reference); run the plan over device columns"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+  }
+  if (J.kind == 2) { rc = fix_nan_minmax(h); if (rc != SSGPU_OK) return rc; }
+  int64_t rows = 0;
+  rc = stage_rows(h, h->exec.size() - 1, &rows);
+  if (rc != SSGPU_OK) return rc;
+  StageExec& ex = h->exec.back();
+  const size_t nc = ex.out.size();
+  if (J.acc_data.size() != nc) {
+    if (!J.acc_data.empty()) { c->err = "chunked execution: result shape changed"; return SSGPU_ERROR_HIP; }
+    J.acc_data = std::vector<DevBuf>(nc); J.acc_nulls = std::vector<DevBuf>(nc); J.acc_cap = 0;
+  }
+  if (J.acc_rows + rows > J.acc_cap) {      // grow: twice what is needed, the rows so far move over
+    QuotaScope quota_scope(&p->quota);
+    const int64_t cap = std::max<int64_t>((J.acc_rows + rows) * 2, 1 << 16);
+    for (size_t i = 0; i < nc; ++i) {
+      DevBuf bigger;
+      if (bigger.ensure((size_t)cap * ex.out[i].width + 16) != hipSuccess) { (void)hipGetLastError(); c->err = "chunked execution: the accumulated result does not fit the device"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+      if (J.acc_rows) HIP_TRY(c, hipMemcpyAsync(bigger.p, J.acc_data[i].p, (size_t)J.acc_rows * ex.out[i].width, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      std::swap(bigger.p, J.acc_data[i].p); std::swap(bigger.cap, J.acc_data[i].cap); std::swap(bigger.q, J.acc_data[i].q);
+      if (!ex.out[i].nullable) continue;
+      DevBuf bn;
+      if (bn.ensure((size_t)cap + 16) != hipSuccess) { (void)hipGetLastError(); c->err = "chunked execution: the accumulated result does not fit the device"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
+      if (J.acc_rows) HIP_TRY(c, hipMemcpyAsync(bn.p, J.acc_nulls[i].p, (size_t)J.acc_rows, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      std::swap(bn.p, J.acc_nulls[i].p); std::swap(bn.cap, J.acc_nulls[i].cap); std::swap(bn.q, J.acc_nulls[i].q);
+    }
+    J.acc_cap = cap;
+  }
+  for (size_t i = 0; i < nc && rows > 0; ++i) {
+    HIP_TRY(c, hipMemcpyAsync(J.acc_data[i].as<char>() + (size_t)J.acc_rows * ex.out[i].width, ex.out[i].data.p, (size_t)rows * ex.out[i].width, hipMemcpyDeviceToDevice, c->stream));
+    if (ex.out[i].nullable) HIP_TRY(c, hipMemcpyAsync(J.acc_nulls[i].as<char>() + J.acc_rows, ex.out[i].nulls.p, (size_t)rows, hipMemcpyDeviceToDevice, c->stream));
+  }
+  J.acc_rows += rows;
+  return SSGPU_OK;
+}
+// the end of the input: kind 2 -- the accumulation IS the result (installed as the last stage's columns); kind 3 -- the tail plan over it
+static int stream_job_finish(ssgpu_plan* p, ssgpu_result** out) {
+  ssgpu_ctx* c = p->ctx; ssgpu_plan::StreamJob& J = *p->stream_job;
+  if (J.kind == 3) {
+    std::vector<ssgpu_column> cols(J.acc_data.size());
+    StageExec& hx = J.head->exec.back();
+    for (size_t i = 0; i < cols.size(); ++i) { cols[i].data = J.acc_data[i].p; cols[i].is_null = hx.out[i].nullable ? J.acc_nulls[i].as<uint8_t>() : nullptr; }
+    int rc = run_plan(J.tail, cols.data(), (int32_t)cols.size(), J.acc_rows, 0, false);
+    if (rc == SSGPU_OK) rc = settle_plan(J.tail);
+    if (rc == SSGPU_OK) rc = check_error_flags(J.tail);
+    if (rc == SSGPU_OK) rc = fix_nan_minmax(J.tail);
+    if (rc != SSGPU_OK) return rc;
+    if (out) *out = &J.tail->result;
+    return SSGPU_OK;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  StageExec& ex = p->exec.back();
+  for (size_t i = 0; i < ex.out.size(); ++i) {
+    ex.out[i].data.release(); ex.out[i].nulls.release();
+    ex.out[i].data.set_view(J.acc_data[i].p, J.acc_data[i].cap);
+    if (ex.out[i].nullable) ex.out[i].nulls.set_view(J.acc_nulls[i].p, J.acc_nulls[i].cap);
+  }
+  ex.out_arena.release();
+  ex.out_rows = J.acc_rows; ex.out_rows_dev = nullptr; ex.out_capacity = J.acc_cap;
+  p->result.fetched.assign(p->result.fetched.size(), false);
+  if (out) *out = &p->result;
+  return SSGPU_OK;
+}
+
+int ssgpu_plan_chunked_form(ssgpu_plan* p, int32_t* kind, const char** head, const char** tail) {
+  if (!p || !kind) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  int k = 0;
+  const int rc = stream_job_prepare(p, &k, false);
+  if (rc != SSGPU_OK) return rc;
+  *kind = k;
+  if (head) *head = (k == 3 && p->stream_job) ? p->stream_job->head->describe.c_str() : p->describe.c_str();
+  if (tail) *tail = (k == 3 && p->stream_job) ? p->stream_job->tail->describe.c_str() : "";
+  return SSGPU_OK;
+}
+
 // Chunked staging of a HOST input (ssgpu.h).  Chunk k + 1 is copied on the copy stream while the plan's kernel reads chunk k on the
 // compute stream; a staging set is written again only after the run that read it has finished (events, no host wait); every chunk
 // leaves its partial state (the multi-GPU form: run_plan(partial)), and ONE launch folds the states in chunk (= row) order and emits.
@@ -3218,12 +3537,10 @@ int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_
   if (!p || (!host_cols && n_cols)) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
-  if (!(p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG)) {
-    c->err = "chunked staging serves plans whose only stage is a ScalarAggregate (over Filter / Compute / Project); other plans take device columns (ssgpu_block_upload + ssgpu_plan_run_block)";
-    return SSGPU_ERROR_NOT_IMPLEMENTED;
-  }
   if (n_cols != (int)p->desc.input_schema.size() || rows < 0) { c->err = "ssgpu_plan_run_host: column count / row count do not fit the plan's input"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   HIP_TRY(c, hipSetDevice(c->device));
+  int job_kind = 0;
+  { const int jrc = stream_job_prepare(p, &job_kind); if (jrc != SSGPU_OK) return jrc; }
   if (chunk_rows <= 0) chunk_rows = 1 << 24;
   const int64_t n_chunks = std::max<int64_t>(1, (rows + chunk_rows - 1) / chunk_rows);
   const Schema& schema = p->desc.input_schema;
@@ -3232,8 +3549,8 @@ int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_
     if (dtype_width(schema[i].dtype) == 0) { c->err = "ssgpu_plan_run_host: variable-length columns travel as dictionary codes (INT32)"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
     if (!host_cols[i].data && rows) { c->err = "ssgpu_plan_run_host: a column without data"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
   }
-  const size_t state_bytes = (size_t)SSGPU_STATE_ARRAYS * (size_t)std::max(p->stages[0].main.n_slots, 1) * 8;
-  HIP_TRY(c, p->host_states.ensure((size_t)n_chunks * state_bytes));
+  const size_t state_bytes = job_kind == 1 ? (size_t)SSGPU_STATE_ARRAYS * (size_t)std::max(p->stages[0].main.n_slots, 1) * 8 : 0;
+  if (job_kind == 1) HIP_TRY(c, p->host_states.ensure((size_t)n_chunks * state_bytes));
   hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   auto drop_events = [&]() { for (int b = 0; b < 2; ++b) { if (uploaded[b]) (void)hipEventDestroy(uploaded[b]); if (consumed[b]) (void)hipEventDestroy(consumed[b]); } };
   for (int b = 0; b < 2; ++b)
@@ -3269,6 +3586,12 @@ int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_
       dev[(size_t)i].data = p->host_stage_data[b][(size_t)i].p;
       dev[(size_t)i].is_null = schema[i].nullable ? p->host_stage_nulls[b][(size_t)i].as<uint8_t>() : nullptr;
     }
+    if (job_kind != 1) {     // the chunk through the head plan, its result rows appended (stream_job_chunk)
+      rc = stream_job_chunk(p, dev.data(), n_cols, n, lo);
+      if (rc != SSGPU_OK) break;
+      if (hipEventRecord(consumed[b], c->stream) != hipSuccess) { c->err = "ssgpu_plan_run_host: queueing a chunk failed"; rc = SSGPU_ERROR_HIP; break; }
+      continue;
+    }
     p->keep_error_flags = k > 0;
     rc = run_plan(p, dev.data(), n_cols, n, lo, true);
     p->keep_error_flags = false;
@@ -3278,6 +3601,12 @@ int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_
   }
   if (rc != SSGPU_OK) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream); drop_events(); return rc; }
   drop_events();
+  if (job_kind != 1) {
+    rc = stream_job_finish(p, out);
+    if (rc != SSGPU_OK) return rc;
+    p->last_cols.clear(); p->last_rows = rows;
+    return SSGPU_OK;
+  }
   rc = ssgpu_plan_fold_finalize(p, p->host_states.p, (int32_t)n_chunks, out);
   if (rc != SSGPU_OK) return rc;
   p->last_cols.clear(); p->last_rows = rows;     // (nothing of this run can be repeated from device columns: they were staging sets)
@@ -3312,6 +3641,14 @@ static int stream_flush(ssgpu_plan* p, int b, int64_t n) {
     dev[(size_t)i].data = p->host_stage_data[b][(size_t)i].p;
     dev[(size_t)i].is_null = schema[i].nullable ? p->host_stage_nulls[b][(size_t)i].as<uint8_t>() : nullptr;
   }
+  if (hs.kind != 1) {
+    const int jrc = stream_job_chunk(p, dev.data(), n_cols, n, hs.pushed - n);
+    if (jrc != SSGPU_OK) return jrc;
+    HIP_TRY(c, hipEventRecord(hs.consumed[b], c->stream));
+    hs.in_flight[b] = true;
+    ++hs.chunks;
+    return SSGPU_OK;
+  }
   p->keep_error_flags = hs.chunks > 0;
   const int rc = run_plan(p, dev.data(), n_cols, n, hs.pushed - n, true);
   p->keep_error_flags = false;
@@ -3334,15 +3671,12 @@ int ssgpu_plan_stream_begin(ssgpu_plan* p, int64_t chunk_rows) {
   if (!p) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
   ssgpu_ctx* c = p->ctx;
   if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
-  if (!(p->stages.size() == 1 && p->stages[0].kind == STAGE_SCALAR_AGG)) {
-    c->err = "chunked staging serves plans whose only stage is a ScalarAggregate (over Filter / Compute / Project); other plans take device columns (ssgpu_block_upload + ssgpu_plan_run_block)";
-    return SSGPU_ERROR_NOT_IMPLEMENTED;
-  }
   const Schema& schema = p->desc.input_schema;
   for (auto& a : schema) if (dtype_width(a.dtype) == 0) { c->err = "ssgpu_plan_stream_begin: variable-length columns travel as dictionary codes (INT32)"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
   HIP_TRY(c, hipSetDevice(c->device));
   ssgpu_plan::HostStream& hs = p->host_stream;
   if (hs.open) (void)stream_abort(p, SSGPU_OK);     // (an unfinished stream is dropped)
+  { int kind = 0; const int jrc = stream_job_prepare(p, &kind); if (jrc != SSGPU_OK) return jrc; hs.kind = kind; }
   hs.chunk_rows = chunk_rows > 0 ? chunk_rows : (1 << 22); hs.fill = 0; hs.pushed = 0; hs.chunks = 0; hs.cur = 0; hs.rc = SSGPU_OK;
   for (int b = 0; b < 2; ++b) {
     p->host_stage_data[b].resize(schema.size()); p->host_stage_nulls[b].resize(schema.size());
@@ -3391,6 +3725,12 @@ int ssgpu_plan_stream_finish(ssgpu_plan* p, ssgpu_result** out) {
   }
   const int64_t n_chunks = hs.chunks, rows = hs.pushed;
   hs.drop_events(); hs.open = false;
+  if (hs.kind != 1) {
+    const int jrc = stream_job_finish(p, out);
+    if (jrc != SSGPU_OK) return jrc;
+    p->last_cols.clear(); p->last_rows = rows;
+    return SSGPU_OK;
+  }
   int rc = ssgpu_plan_fold_finalize(p, p->host_states.p, (int32_t)n_chunks, out);
   if (rc != SSGPU_OK) return rc;
   p->last_cols.clear(); p->last_rows = rows;

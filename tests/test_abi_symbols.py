@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_bind_only_context():
     lib = _lib.load()
-    assert lib.ssgpu_abi_version() == 9
+    assert lib.ssgpu_abi_version() == 10
     h = ctypes.c_void_p()
     assert lib.ssgpu_ctx_create(-1, ctypes.byref(h)) == 0
     assert lib.ssgpu_ctx_synchronize(h) == _lib.ERROR_NO_DEVICE

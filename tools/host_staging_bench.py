@@ -66,6 +66,46 @@ def main():
         row = row or this
         best = min(times[1:])
         out["runs"][label] = {"seconds": best, "GB_per_s": n * 64 / best / 1e9, "rows_per_s": n / best, "same_row": this == row}
+    # ---- the other chunked forms (ssgpu.h "CHUNKED STAGING" 2 and 3): a materialising Filter over the same block, and BASELINE configs[2]'s
+    # GroupAggregate (2 x INT32 keys, 1e5 groups, 12 DOUBLE aggregates) over a pinned host block of its own
+    def timed(op, label_prefix, row_bytes, same):
+        runs = {}
+        first = None
+        for label, chunk in (("upload_then_run", None), ("chunked_2^22", 1 << 22), ("chunked_2^24", 1 << 24)):
+            plan = ss.Plan(op, ctx)
+            times = []
+            for _rep in range(3):
+                plan._block_key = None
+                t0 = time.perf_counter()
+                if chunk is None:
+                    plan.run()
+                else:
+                    plan.run_host(chunk_rows=chunk)
+                ctx.synchronize()
+                rows_out = plan.result_row_count()
+                times.append(time.perf_counter() - t0)
+            digest = same(plan)
+            first = first if first is not None else digest
+            best = min(times[1:])
+            runs[label] = {"seconds": best, "GB_per_s": n * row_bytes / best / 1e9, "rows_per_s": n / best, "rows_out": rows_out, "same_result": digest == first}
+            del plan
+        return runs
+    fop = ss.Filter(ss.Greater(NA("a"), ss.ConstInt64(499)), ss.ProjectAllAttributes(), ss.ScanView(view))
+    out["filter_mat"] = {"bytes": n * 64, "runs": timed(fop, "filter", 64, lambda plan: plan.result_row_count())}
+    import bench
+    gcols = []
+    for arr in bench.host_columns(np, "group", n):
+        pinned = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
+        gcols.append(pinned)
+    gview = ss.View(bench.group_schema(ss), [t.numpy() for t in gcols])
+    bench.GROUP_FILTER = False
+    gop = bench.build_group_plan(ss, gview)
+
+    def group_digest(plan):
+        got = plan.fetch()
+        order = np.lexsort((got.column(1).data, got.column(0).data))
+        return (got.row_count(), float(got.column(2).data[order][:1000].sum()), float(got.column(5).data[order][-1000:].sum()))
+    out["group3"] = {"bytes": n * 48, "runs": timed(gop, "group3", 48, group_digest)}
     print(json.dumps(out))
 
 
