@@ -675,7 +675,7 @@ hipError_t ssgpu_launch_key_domain(const PlainScatterParams& S, const unsigned i
 
 unsigned int ssgpu_part_scatter_plain_lds(unsigned int n_parts, unsigned int rec_words, int rows_per_thread, int threads) {
   const unsigned int T = (unsigned)threads * (unsigned)rows_per_thread;
-  return (3u * n_parts + 2u + T) * 4u + 16u + T * rec_words * 8u + n_parts * 4u;   // (+ the pipelined form's second counter array, behind the staging area)
+  return (3u * n_parts + 2u + T) * 4u + 16u + T * rec_words * 8u;   // (the pipelined form's second counter array -- n_parts more words behind the staging area -- is added by the caller that asks for it)
 }
 // The launch shape of the plain scatter: 1024 threads x 2 rows (1 when the staging area of 2048 records does not fit the LDS), one
 // workgroup per CU -- or what the caller asks for (development options pscat_threads / pscat_rows / pscat_wgs): 512-thread

@@ -282,7 +282,8 @@ void ssgpu_rtc_stats(long long* modules, long long* code_bytes, long long* compi
 #endif
 hipError_t ssgpu_pipeline_set_max_lds(int bytes);
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
-                                     VmAccRec* out, uint64_t* state /* NULL, or the reducible state of a partial run */, hipStream_t stream);
+                                     VmAccRec* out, uint64_t* state /* NULL, or the reducible state of a partial run */, hipStream_t stream,
+                                     const EmitDesc* descs = nullptr, int n_out = 0 /* descs: the result columns are emitted by the same launch */);
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state,
                                        hipStream_t stream);
 hipError_t ssgpu_launch_fold_state(const uint64_t* images, int n_images, uint64_t* state, int n_slots, const int* slot_kind, hipStream_t stream);

@@ -970,9 +970,13 @@ __device__ __forceinline__ VmAccRec state_to_slot(const u64* __restrict__ state,
 }
 
 // `state` (may be NULL): a partial run (multi-GPU) leaves the slot's reducible state next to its record -- one launch less.
+__device__ __forceinline__ void emit_scalar_one(const EmitDesc d, const VmAccRec r);
+// descs != NULL: the workgroup of slot s also emits the result columns that read it (one launch less per ScalarAggregate run: the
+// emit kernel used to follow as a launch of its own)
 __global__ __launch_bounds__(256) void ssgpu_finish_slots_kernel(const VmAccRec* __restrict__ partials, int n_slots,
                                                                  int n_parts, const int* __restrict__ slot_kind,
-                                                                 VmAccRec* __restrict__ out, u64* __restrict__ state) {
+                                                                 VmAccRec* __restrict__ out, u64* __restrict__ state,
+                                                                 const EmitDesc* __restrict__ descs, int n_out) {
   __shared__ VmAccRec tree[256];
   const int s = blockIdx.x, t = threadIdx.x;
   const int kind = slot_kind[s];
@@ -989,6 +993,8 @@ __global__ __launch_bounds__(256) void ssgpu_finish_slots_kernel(const VmAccRec*
     __syncthreads();
   }
   if (t == 0) { out[s] = tree[0]; if (state) slot_to_state(tree[0], kind, s, n_slots, state); }
+  if (descs)
+    for (int i = t; i < n_out; i += 256) { const EmitDesc d = descs[i]; if (d.slot == s) emit_scalar_one(d, tree[0]); }
 }
 
 __global__ void ssgpu_slots_to_state_kernel(const VmAccRec* __restrict__ recs, int n_slots,
@@ -2129,8 +2135,8 @@ hipError_t ssgpu_pipeline_set_max_lds(int bytes) {
   return e;
 }
 hipError_t ssgpu_launch_finish_slots(const VmAccRec* partials, int n_slots, int n_parts, const int* slot_kind,
-                                     VmAccRec* out, uint64_t* state, hipStream_t stream) {
-  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(n_slots), dim3(256), 0, stream, partials, n_slots, n_parts, slot_kind, out, (u64*)state);
+                                     VmAccRec* out, uint64_t* state, hipStream_t stream, const EmitDesc* descs, int n_out) {
+  hipLaunchKernelGGL(ssgpu_finish_slots_kernel, dim3(n_slots), dim3(256), 0, stream, partials, n_slots, n_parts, slot_kind, out, (u64*)state, descs, n_out);
   return hipGetLastError();
 }
 hipError_t ssgpu_launch_slots_to_state(const VmAccRec* recs, int n_slots, const int* slot_kind, uint64_t* state, hipStream_t stream) {

@@ -74,6 +74,7 @@ struct ssgpu_ctx {
                                  // (an overflow seen late, a NaN in a floating MIN / MAX).  Off by default (round 5): ssgpu_plan_run returns with every
                                  // such decision made -- the input may be released or overwritten once the run has been synchronised.  Callers that
                                  // step a plan without touching the host opt in (distributed.py, sharded.h, bench.py) and keep their input alive.
+  int64_t fuse_emit = 1;         // ScalarAggregate: the finish launch also emits the result row (0: a launch of its own, as until round 6)
   int64_t part_overlap_rows = 1 << 23;   // ... inputs of at least this many rows
   int64_t part_overlap = 1;      // dense partitions over >= 2^23 rows: > 1: the input is taken in this many row ranges, range k aggregated (side stream) while range k + 1 is scattered. Measured slower (the two kernels share the memory system: profiles/r06_overlap_ab.txt): off
   int64_t pscat_pipe = 1;        // specialised plain scatter: the software-pipelined form (tile k + 1 loaded, ranked and reserved while tile k is staged and flushed)
@@ -324,6 +325,7 @@ struct StageExec {
   DevBuf route_scratch;         // key-range exchange: per-destination counters + (destination, position) of every result row
   uint64_t sort_epoch = 0;      // one-sweep status words of earlier passes carry an older epoch
   bool emit_ready = false;
+  bool emitted_with_finish = false;  // this run's finish launch also emitted the result row
   bool pattern_ready = false;
   int last_row_ranges = 1;           // row ranges the last dense-partition run took its input in (scatter of one beside the aggregation of the one before)
   bool last_split_records = false;   // the last partitioned run wrote split records (payload + 16-bit entries)
@@ -549,6 +551,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "pscat_wgs") c->pscat_wgs = value;
   else if (k == "pscat_pipe") c->pscat_pipe = value;
   else if (k == "part_overlap") c->part_overlap = value;
+  else if (k == "fuse_emit") c->fuse_emit = value;
   else if (k == "part_overlap_rows") c->part_overlap_rows = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "async_handoff") c->async_handoff = value;
@@ -1213,6 +1216,7 @@ int distinct_flags(ssgpu_ctx* c, const Stage& st, StageExec& ex, const InCols& i
   return SSGPU_OK;
 }
 
+int prepare_scalar_emit(ssgpu_plan* p, size_t si, int* n_out);
 int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_base, bool stop_at_partial) {
   ssgpu_ctx* c = p->ctx; Stage& st = p->stages[si]; StageExec& ex = p->exec[si];
   InCols in = in0;
@@ -1250,9 +1254,14 @@ int run_scalar_agg(ssgpu_plan* p, size_t si, const InCols& in0, int64_t row_id_b
   HIP_TRY(c, launch_main(p, st, ex, P, ex.lay.K, grid));
   if (c->profile) HIP_TRY(c, hipEventRecord(p->ev_dom1, c->stream));
   { int rc = print_pc_profile(c, ex, st.main, P.n_instr); if (rc != SSGPU_OK) return rc; }
-  // a partial run (multi-GPU) leaves the reducible state next to the slot records, in the same launch
+  // a partial run (multi-GPU) leaves the reducible state next to the slot records, in the same launch; a whole run emits its result
+  // row in it (emit_scalar_agg then has nothing left to launch)
+  int n_emit = 0;
+  ex.emitted_with_finish = false;
+  if (!stop_at_partial && c->fuse_emit) { const int rc = prepare_scalar_emit(p, si, &n_emit); if (rc != SSGPU_OK) return rc; ex.emitted_with_finish = true; }
   HIP_TRY(c, ssgpu_launch_finish_slots(ex.wg_partials.as<VmAccRec>(), ns, grid * VM_WAVES, ex.slot_kind.as<int>(),
-                                       ex.slot_recs.as<VmAccRec>(), stop_at_partial ? ex.state.as<uint64_t>() : nullptr, c->stream));
+                                       ex.slot_recs.as<VmAccRec>(), stop_at_partial ? ex.state.as<uint64_t>() : nullptr, c->stream,
+                                       ex.emitted_with_finish ? ex.emit_descs.as<EmitDesc>() : nullptr, n_emit));
   p->counters.n_launches += 2;
   p->counters.tile_rows = P.tile_rows; p->counters.grid = grid; p->counters.lds_bytes = (int32_t)ex.lay.lds_bytes;
   if (c->debug_timing) {
@@ -1330,6 +1339,7 @@ int emit_scalar_agg(ssgpu_plan* p, size_t si) {
   int n_out = 0;
   const int rc = prepare_scalar_emit(p, si, &n_out);
   if (rc != SSGPU_OK) return rc;
+  if (ex.emitted_with_finish) { ex.emitted_with_finish = false; ex.out_rows = 1; return SSGPU_OK; }   // (the finish launch of this run wrote the row)
   HIP_TRY(c, ssgpu_launch_emit_scalar(ex.slot_recs.as<VmAccRec>(), ex.emit_descs.as<EmitDesc>(), n_out, c->stream));
   p->counters.n_launches += 1;
   ex.out_rows = 1;
@@ -1941,7 +1951,9 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (split) { S.split = 1u; S.recs_entry = reinterpret_cast<unsigned short*>(ex.part_recs.as<char>() + payload_bytes); S.pay_inv = W0 > 2u ? (uint32_t)(0x100000000ull / (W0 - 1u) + 1ull) : 0u; }
       // one fat workgroup per CU: every workgroup more multiplies the open lines and the per-tile atomics
       PscatGeom geom = ssgpu_part_scatter_plain_geom(NP, W0, (int)c->pscat_threads, (int)c->pscat_rows, (int)c->pscat_wgs);
-      geom.pipe = c->pscat_pipe != 0 ? 1u : 0u;
+      // (the pipelined form -- specialised builds -- keeps a second array of per-partition counters behind the staging area)
+      geom.pipe = (c->pscat_pipe != 0 && p->specialize && geom.lds + NP * 4u <= 156u * 1024u) ? 1u : 0u;
+      if (geom.pipe) geom.lds += NP * 4u;
       const int pgrid = (int)std::min<int64_t>((int64_t)std::max(c->cu_count, 1) * geom.wgs_per_cu, std::max<int64_t>(1, (in.rows + 1023) / 1024));
       // the specialised build (plans that asked): one per (descriptor, partition count) -- the LDS carve-up is static in it
       void* hs = nullptr;
