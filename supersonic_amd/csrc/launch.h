@@ -266,7 +266,8 @@ hipError_t ssgpu_launch_pipeline_rtc(void* handle, const VmParams& P, int grid, 
 void* ssgpu_rtc_specialize_part_agg(int device, const unsigned long long* desc, int n_aggs, unsigned int rec_words, unsigned int n_gaggs, bool any_cnt,
                                     unsigned int lds_bytes, std::string* why, const PlainScatterParams* source = nullptr,   // source: the resident form (reads the input columns)
                                     bool dense = false,                                                                     // dense: records carry dense indices (DenseKeyMap), no probe
-                                    bool split = false);                                                                    // split: records arrive as payload words + 16-bit table entries
+                                    bool split = false,                                                                     // split: records arrive as payload words + 16-bit table entries
+                                    bool prefetch = false);                                                                 // prefetch: the record form loads a trip ahead (narrow records)
 hipError_t ssgpu_launch_group_resident_rtc(void* handle, const PartAggParams& A, const PlainScatterParams& S, int grid, hipStream_t stream);
 hipError_t ssgpu_launch_part_agg_rtc(void* handle, const PartAggParams& P, hipStream_t stream);
 void* ssgpu_rtc_specialize_pscat(int device, const PlainScatterParams& S, const PscatGeom& g, std::string* why);

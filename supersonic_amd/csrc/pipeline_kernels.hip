@@ -1234,6 +1234,9 @@ __device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, 
 #ifndef SSGPU_RESIDENT_ROWS
 #define SSGPU_RESIDENT_ROWS 2   /* (4 and 8 measured the same: the kernel is bound by instruction issue, ~350 VALU instructions per row) */
 #endif
+#ifndef SSGPU_PART_ROWS
+#define SSGPU_PART_ROWS 2       /* records per lane per step of the record form (4: measured the same, profiles/r06_part_rows.txt) */
+#endif
 #define LDS_AS __attribute__((address_space(3)))
 template <int MAXW> struct RecVec { typedef u64 type __attribute__((ext_vector_type(MAXW))); };
 template <int MAXW> __device__ __forceinline__ u64 rec_word(const typename RecVec<MAXW>::type& r, u32 w) {
@@ -1402,7 +1405,7 @@ __device__ __forceinline__ void resident_issue(const PlainScatterParams& S, u64 
 template <int MAXW, bool PLAIN, typename SRC>
 __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC& S) {
   typedef typename RecVec<MAXW>::type Rec;
-  constexpr int PART_ROWS = PLAIN ? SSGPU_RESIDENT_ROWS : 2;
+  constexpr int PART_ROWS = PLAIN ? SSGPU_RESIDENT_ROWS : SSGPU_PART_ROWS;
   const u32 t = threadIdx.x, part = blockIdx.x;
   const u32 C = P.local_capacity, ng = PART_NG(P), W = PART_W(P);
   const bool any_cnt = PART_ANY_CNT(P);
@@ -1508,6 +1511,18 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
   ResidentRaw<PART_ROWS> raw = {};
   if constexpr (PLAIN) trip_limit = row_limit + row_stride;
 #endif
+  // The record form, specialised builds with narrow records (two sets of a record's words fit the 64-VGPR budget): the same pipeline --
+  // trip k issues the loads of records [k] and aggregates records [k - 1].  The kernel is bound by these loads (4 GB at 5 TB/s for
+  // config #3 with every wave alternating between loading and LDS atomics); see the note above about no load ahead of the loop.
+#if defined(SSGPU_RTC_PART) && !defined(SSGPU_PART_NO_PREFETCH)
+  constexpr bool kPrefetch = !PLAIN && kPartW <= 6u && kPartPrefetch != 0u;
+#else
+  constexpr bool kPrefetch = false;
+#endif
+  Rec pre[PART_ROWS]; bool pre_live[PART_ROWS];
+#pragma unroll
+  for (int j = 0; j < PART_ROWS; ++j) { pre_live[j] = false; _Pragma("unroll") for (int w = 0; w < MAXW; ++w) pre[j][w] = 0ull; }
+  if constexpr (kPrefetch) trip_limit = row_limit + row_stride;
   for (u64 base = row_first; base < trip_limit; base += row_stride) {
     Rec rec[PART_ROWS]; bool live[PART_ROWS]; u32 li[PART_ROWS];
     if constexpr (PLAIN) {
@@ -1570,6 +1585,22 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         }
       }
 #endif
+    } else if constexpr (kPrefetch) {
+#pragma unroll
+    for (int j = 0; j < PART_ROWS; ++j) { live[j] = pre_live[j]; rec[j] = pre[j]; }       // the records whose loads were issued one trip ago
+#pragma unroll
+    for (int j = 0; j < PART_ROWS; ++j) {
+      const u64 i64 = base + (u64)j * SSGPU_PART_THREADS + t;
+      pre_live[j] = i64 < (u64)total;
+      const u32 i = pre_live[j] ? (u32)i64 : 0u;
+      if (pre_live[j]) {
+        while (i >= segoff[seg + 1u]) ++seg;
+        const u64* rp = recs + ((u64)seg * seg_step + (i - segoff[seg])) * W;
+#pragma unroll
+        for (int w = 0; w < MAXW; ++w) pre[j][w] = (u32)w < W ? rp[w] : 0ull;
+      }
+    }
+    asm volatile("" ::: "memory");     // (the loads stay here: left alone the compiler sinks them to their first use, the top of the next trip)
     } else {
 #pragma unroll
     for (int j = 0; j < PART_ROWS; ++j) {

@@ -74,6 +74,7 @@ struct ssgpu_ctx {
                                  // (an overflow seen late, a NaN in a floating MIN / MAX).  Off by default (round 5): ssgpu_plan_run returns with every
                                  // such decision made -- the input may be released or overwritten once the run has been synchronised.  Callers that
                                  // step a plan without touching the host opt in (distributed.py, sharded.h, bench.py) and keep their input alive.
+  int64_t part_prefetch = 1;     // specialised partition aggregation, records of <= 6 words: the loads of trip k + 1 are issued before trip k's LDS atomics
   int64_t fuse_emit = 1;         // ScalarAggregate: the finish launch also emits the result row (0: a launch of its own, as until round 6)
   int64_t part_overlap_rows = 1 << 23;   // ... inputs of at least this many rows
   int64_t part_overlap = 1;      // dense partitions over >= 2^23 rows: > 1: the input is taken in this many row ranges, range k aggregated (side stream) while range k + 1 is scattered. Measured slower (the two kernels share the memory system: profiles/r06_overlap_ab.txt): off
@@ -552,6 +553,7 @@ int ssgpu_ctx_set_option(ssgpu_ctx* c, const char* key, int64_t value) {
   else if (k == "pscat_pipe") c->pscat_pipe = value;
   else if (k == "part_overlap") c->part_overlap = value;
   else if (k == "fuse_emit") c->fuse_emit = value;
+  else if (k == "part_prefetch") c->part_prefetch = value;
   else if (k == "part_overlap_rows") c->part_overlap_rows = value;
   else if (k == "lazy_feedback") c->lazy_feedback = value;
   else if (k == "async_handoff") c->async_handoff = value;
@@ -2038,12 +2040,12 @@ int run_group_agg_partitioned(ssgpu_plan* p, size_t si, const InCols& in, int64_
       if (p->specialize && ex.rtc_resident.h && ex.rtc_resident.static_lds == agg_lds) HIP_TRY(c, ssgpu_launch_group_resident_rtc(ex.rtc_resident.h, A, S, rgrid, c->stream));
       else HIP_TRY(c, ssgpu_launch_group_resident(A, S, agg_lds, rgrid, c->stream));
     } else
-    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) + (split ? 2u : 0u) && !ex.rtc_part.ask_again() && !ex.rtc_part.stronger_mode_now())) {
+    if (p->specialize && !(ex.rtc_part.tried && ex.rtc_part.static_lds == agg_lds && ex.rtc_part.tag == (dense ? 1u : 0u) + (split ? 2u : 0u) + (c->part_prefetch ? 4u : 0u) && !ex.rtc_part.ask_again() && !ex.rtc_part.stronger_mode_now())) {
       // one kernel per LDS size (hash partitions and the slab form differ in it): compiled when that shape is first run
       if (ex.rtc_part.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); ex.rtc_part.drop(); }
-      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = (dense ? 1u : 0u) + (split ? 2u : 0u);
+      ex.rtc_part.tried = true; ex.rtc_part.static_lds = agg_lds; ex.rtc_part.tag = (dense ? 1u : 0u) + (split ? 2u : 0u) + (c->part_prefetch ? 4u : 0u);
       std::string why;
-      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, nullptr, dense, split);
+      ex.rtc_part.h = ssgpu_rtc_specialize_part_agg(c->device, A.desc, (int)A.n_aggs, W, ng, any_cnt, agg_lds, &why, nullptr, dense, split, c->part_prefetch != 0);
       ex.rtc_part.asked();
       if (!ex.rtc_part.h && ex.rtc_why.empty()) ex.rtc_why = "partition aggregation: " + why;
     }
