@@ -544,6 +544,14 @@ int ssgpu_expr_bind(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs, c
                     const int32_t* expr_args, int32_t n_expr_args, int32_t root, int64_t max_row_count, ssgpu_plan** out);
 int64_t ssgpu_expr_row_capacity(const ssgpu_plan* bound);
 int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_cols, int64_t rows, ssgpu_result** out);
+/* The node-level form, BoundExpression::DoEvaluate(const View& input, const BoolView& skip_vectors) (expression.h:46-92): `skip` holds
+ * one DEVICE byte vector of `rows` bytes per result attribute (n_skip == the bound tree's attribute count; a NULL entry = nothing is
+ * skipped), in and out as in the reference: a row whose byte is set on entry is not evaluated -- its result is NULL and a signalling
+ * operator (DivideSignaling, SqrtSignaling ...) does not fail on it -- and on return the vector holds the result column's NULLs,
+ * entry skips included.  The tree is re-bound once, on first use, as IF($skip_i, NULL, e_i) per attribute (guarded evaluation IS the
+ * skip-vector contract).  Nested compound expressions and variable-length results: SSGPU_ERROR_NOT_IMPLEMENTED (ABI 10). */
+int ssgpu_expr_evaluate_skip(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_cols, int64_t rows, uint8_t* const* skip, int32_t n_skip,
+                             ssgpu_result** out);
 
 /* ---- run ------------------------------------------------------------------ */
 /* cols: one entry per attribute of the plan's input schema, DEVICE pointers.

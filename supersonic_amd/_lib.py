@@ -152,6 +152,7 @@ SYMBOLS = [
     ("ssgpu_expr_bind", C.c_int, [P, C.POINTER(Attr), C.c_int32, C.POINTER(Expr), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int64, C.POINTER(P)]),
     ("ssgpu_expr_row_capacity", C.c_int64, [P]),
     ("ssgpu_expr_evaluate", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(P)]),
+    ("ssgpu_expr_evaluate_skip", C.c_int, [P, C.POINTER(Column), C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(P)]),
     ("ssgpu_ctx_stream", P, [P]),
     ("ssgpu_ctx_copy_stream", P, [P]),
     ("ssgpu_ctx_set_stream", C.c_int, [P, P]),

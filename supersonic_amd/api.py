@@ -1599,6 +1599,54 @@ class BoundExpressionTree(Plan):
             return ResultView(exception=e)
 
 
+    def DoEvaluate(self, view, skip_vectors):
+        """BoundExpression::DoEvaluate(const View& input, const BoolView& skip_vectors) (expression/base/expression.h:46-92) over
+        ssgpu_expr_evaluate_skip: one skip vector per result attribute -- a numpy bool array (uploaded; updated IN PLACE with the result's
+        NULLs on return), a device pointer (int; the library writes the NULLs back to it), or None (nothing skipped).  A row whose skip byte
+        is set is not evaluated: NULL result, no failure from a signalling operator."""
+        try:
+            n_out = self.result_schema.attribute_count()
+            if len(skip_vectors) != n_out:
+                raise SupersonicException(L.ERROR_ATTRIBUTE_COUNT_MISMATCH, "one skip vector per result attribute")
+            cols, n, rows = self._columns_for(view)
+            host = [i for i, v in enumerate(skip_vectors) if isinstance(v, np.ndarray)]
+            ptrs = (C.c_void_p * max(n_out, 1))()
+            blk = None
+            if host:
+                attrs = _array(L.Attr, [L.Attr(("s%d" % i).encode(), BOOL, NOT_NULLABLE) for i in host])
+                blk = C.c_void_p()
+                self.ctx.check(self.lib.ssgpu_block_create(self.ctx.handle, attrs, len(host), max(rows, 1), C.byref(blk)))
+                for k, i in enumerate(host):
+                    arr = np.ascontiguousarray(skip_vectors[i], dtype=np.bool_)
+                    if len(arr) != rows:
+                        raise SupersonicException(L.ERROR_INVALID_ARGUMENT_VALUE, "a skip vector has one byte per input row")
+                    if rows:
+                        self.ctx.check(self.lib.ssgpu_block_upload(blk, k, arr.ctypes.data_as(C.c_void_p), None, 0, rows))
+                    col = L.Column()
+                    self.ctx.check(self.lib.ssgpu_block_column(blk, k, C.byref(col)))
+                    ptrs[i] = col.data
+                self.ctx.synchronize()
+            for i, v in enumerate(skip_vectors):
+                if v is not None and not isinstance(v, np.ndarray):
+                    ptrs[i] = int(v)
+            try:
+                res = C.c_void_p()
+                self.ctx.check(self.lib.ssgpu_expr_evaluate_skip(self.handle, cols, n, rows, ptrs, n_out, C.byref(res)))
+                self._result = res
+                out = self.fetch(res)
+            finally:
+                if blk is not None:
+                    self.ctx.synchronize()
+                    self.lib.ssgpu_block_destroy(blk)
+            for i in host:
+                z = out.column(i).is_null
+                if z is not None:
+                    skip_vectors[i][:] = z
+            return ResultView(view=out)
+        except SupersonicException as e:
+            return ResultView(exception=e)
+
+
 class ResultView(object):
     """cursor/base/cursor.h:42-122."""
 

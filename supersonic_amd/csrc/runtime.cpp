@@ -429,6 +429,7 @@ struct ssgpu_plan {
     int64_t acc_rows = 0, acc_cap = 0;
   };
   StreamJob* stream_job = nullptr;
+  ssgpu_plan* skip_plan = nullptr;   // a bound expression's node-level form (ssgpu_expr_evaluate_skip): the same tree under IF($skip_i, NULL, e_i), made on first use
   int64_t run_row_end = 0;         // row_id_base + rows of the run in progress: one past the largest row id a stage can meet
   bool keep_error_flags = false;   // ... whose runs after the first leave the error words alone: an evaluation error of ANY chunk fails the run
   ssgpu_result result;
@@ -835,6 +836,7 @@ int ssgpu_plan_set_option(ssgpu_plan* p, const char* key, int64_t value) {
 
 void ssgpu_plan_destroy(ssgpu_plan* p) {
   if (!p) return;
+  if (p->skip_plan) { ssgpu_plan* q = p->skip_plan; p->skip_plan = nullptr; ssgpu_plan_destroy(q); }
   if (p->stream_job) {
     ssgpu_plan::StreamJob* j = p->stream_job; p->stream_job = nullptr;
     if (p->ctx && p->ctx->device >= 0) (void)hipStreamSynchronize(p->ctx->stream);
@@ -3229,6 +3231,89 @@ int ssgpu_expr_evaluate(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_c
     return SSGPU_ERROR_TOO_MANY_ROWS;
   }
   return ssgpu_plan_run(bound, cols, n_cols, rows, out);
+}
+
+// BoundExpression::DoEvaluate(const View& input, const BoolView& skip_vectors) (expression/base/expression.h:46-92; how the reference's
+// operations call into a bound node: bound_expression_factory.cc:44-107 hands every child the rows it may skip).  One skip vector per
+// result attribute, in and out: a row whose skip byte is set on entry is not evaluated -- its result is NULL and no failing operator
+// fails on it -- and on return the vector holds the result's NULLs (entry skips included).  Here: the tree re-bound once as
+// Compute(IF($skip_i, NULL, e_i) AS name_i) over the input plus one BOOL column per result attribute -- IF evaluates its branches
+// guardedly (lower.cpp), which is exactly the skip-vector contract -- and the result's NULL masks copied back into the caller's vectors.
+int ssgpu_expr_evaluate_skip(ssgpu_plan* bound, const ssgpu_column* cols, int32_t n_cols, int64_t rows, uint8_t* const* skip, int32_t n_skip, ssgpu_result** out) {
+  if (!bound || !skip) return SSGPU_ERROR_INVALID_ARGUMENT_VALUE;
+  ssgpu_ctx* c = bound->ctx;
+  const PlanDesc& D = bound->desc;
+  const int n_out = (int)bound->result_schema.size();
+  if (n_skip != n_out) { c->err = "skip vectors: one per result attribute (" + std::to_string(n_out) + ")"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
+  if (D.ops.size() != 2 || D.ops[1].kind != SSGPU_OP_COMPUTE) { c->err = "ssgpu_expr_evaluate_skip needs a tree bound by ssgpu_expr_bind"; return SSGPU_ERROR_INVALID_ARGUMENT_VALUE; }
+  if (rows > bound->expr_row_capacity) {
+    c->err = "Trying to evaluate an expression with number of rows: " + std::to_string(rows) + ", while the expression has capacity for less rows: " + std::to_string(bound->expr_row_capacity);
+    return SSGPU_ERROR_TOO_MANY_ROWS;
+  }
+  if (!bound->skip_plan) {
+    const ssgpu_expr& root = D.exprs[(size_t)D.ops[1].expr];
+    std::vector<int32_t> kids;
+    if (root.kind == SSGPU_EXPR_COMPOUND) for (int i = 0; i < root.nargs; ++i) kids.push_back(D.expr_args[(size_t)(root.first_arg + i)]);
+    else kids.push_back(D.ops[1].expr);
+    if ((int)kids.size() != n_out) { c->err = "skip vectors: a nested compound expression has no node-level form"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+    std::deque<std::string> names;
+    std::vector<ssgpu_attr> attrs;
+    for (auto& a : D.input_schema) attrs.push_back(ssgpu_attr{a.name.c_str(), a.dtype, a.nullable ? 1 : 0});
+    for (int i = 0; i < n_out; ++i) { names.push_back("$skip" + std::to_string(i)); attrs.push_back(ssgpu_attr{names.back().c_str(), SSGPU_BOOL, 0}); }
+    std::vector<ssgpu_expr> exprs(D.exprs.begin(), D.exprs.end());
+    std::vector<int32_t> args(D.expr_args.begin(), D.expr_args.end());
+    auto add = [&](int kind, int op, int dtype, const char* name, std::initializer_list<int32_t> kk) -> int32_t {
+      ssgpu_expr e; memset(&e, 0, sizeof(e));
+      e.kind = kind; e.op = op; e.dtype = dtype; e.first_arg = (int32_t)args.size(); e.nargs = (int32_t)kk.size(); e.name = name ? name : "";
+      for (int32_t k : kk) args.push_back(k);
+      exprs.push_back(e);
+      return (int32_t)exprs.size() - 1;
+    };
+    std::vector<int32_t> outs;
+    for (int i = 0; i < n_out; ++i) {
+      int32_t inner = kids[(size_t)i];
+      if (exprs[(size_t)inner].kind == SSGPU_EXPR_ALIAS && exprs[(size_t)inner].nargs == 1) inner = args[(size_t)exprs[(size_t)inner].first_arg];
+      const int dtype = bound->result_schema[(size_t)i].dtype;
+      if (dtype_width(dtype) == 0) { c->err = "skip vectors: variable-length results have no node-level form"; return SSGPU_ERROR_NOT_IMPLEMENTED; }
+      const int32_t cond = add(SSGPU_EXPR_ATTR_NAMED, 0, 0, names[(size_t)i].c_str(), {});
+      const int32_t null = add(SSGPU_EXPR_NULL, 0, dtype, "", {});
+      const int32_t sel = add(SSGPU_EXPR_OP, 204 /* OPERATOR_IF */, 0, "", {cond, null, inner});
+      outs.push_back(add(SSGPU_EXPR_ALIAS, 0, 0, bound->result_schema[(size_t)i].name.c_str(), {sel}));
+    }
+    int32_t new_root;
+    { ssgpu_expr e; memset(&e, 0, sizeof(e)); e.kind = SSGPU_EXPR_COMPOUND; e.first_arg = (int32_t)args.size(); e.nargs = (int32_t)outs.size(); e.name = "";
+      for (int32_t k : outs) args.push_back(k);
+      exprs.push_back(e); new_root = (int32_t)exprs.size() - 1; }
+    ssgpu_plan* q = nullptr;
+    const int rc = ssgpu_expr_bind(c, attrs.data(), (int32_t)attrs.size(), exprs.data(), (int32_t)exprs.size(), args.data(), (int32_t)args.size(), new_root,
+                                   bound->expr_row_capacity == INT64_MAX ? 0 : bound->expr_row_capacity, &q);
+    if (rc != SSGPU_OK) return rc;
+    bound->skip_plan = q;
+  }
+  ssgpu_plan* q = bound->skip_plan;
+  q->dict = bound->dict; q->quota.limit = bound->quota.limit;
+  if (n_cols != (int)D.input_schema.size()) { c->err = "column count does not match the plan's input schema"; return SSGPU_ERROR_ATTRIBUTE_COUNT_MISMATCH; }
+  if (!c || c->device < 0) { if (c) c->err = "no gfx950 device bound to this context (bind-only context)"; return SSGPU_ERROR_NO_DEVICE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // a vector the caller does not have (NULL) skips nothing: a zeroed one of the library's own
+  HIP_TRY(c, q->host_states.ensure((size_t)std::max<int64_t>(rows, 1)));
+  bool need_zero = false;
+  for (int i = 0; i < n_out; ++i) need_zero = need_zero || !skip[i];
+  if (need_zero) HIP_TRY(c, hipMemsetAsync(q->host_states.p, 0, (size_t)std::max<int64_t>(rows, 1), c->stream));
+  std::vector<ssgpu_column> all(cols, cols + n_cols);
+  for (int i = 0; i < n_out; ++i) { ssgpu_column k; k.data = skip[i] ? (const void*)skip[i] : (const void*)q->host_states.p; k.is_null = nullptr; all.push_back(k); }
+  ssgpu_result* res = nullptr;
+  int rc = ssgpu_plan_run(q, all.data(), (int32_t)all.size(), rows, &res);
+  if (rc != SSGPU_OK) return rc;
+  for (int i = 0; i < n_out && rows > 0; ++i) {
+    if (!skip[i]) continue;
+    ssgpu_column col;
+    rc = ssgpu_result_device_column(res, i, &col);
+    if (rc != SSGPU_OK) return rc;
+    if (col.is_null) HIP_TRY(c, hipMemcpyAsync(skip[i], col.is_null, (size_t)rows, hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (out) *out = res;
+  return SSGPU_OK;
 }
 
 int ssgpu_plan_run_block(ssgpu_plan* p, const ssgpu_block* b, ssgpu_result** out) {

@@ -49,6 +49,58 @@ def test_evaluate_matches_oracle(gpu_ctx, name, n):
     assert_cols_equal(to_cols(r.view()), want, context=name)
 
 
+# ---- the node-level form: DoEvaluate(view, skip_vectors) (expression.h:46-92) --------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 65, 1025, 50001])
+def test_do_evaluate_honours_and_returns_skip_vectors(gpu_ctx, n):
+    """One in / out skip vector per result attribute: a skipped row is NULL in the result whatever its inputs; on return the vector holds
+    the result's NULLs (the skips of the call included).  Checked against the oracle's Compute over the same View with the skipped rows'
+    results nulled; an attribute without a vector (None) is evaluated everywhere."""
+    view = table(n)
+    rng = np.random.default_rng(n + 7)
+    expr = EXPRESSIONS["compound"]
+    bound = expr().Bind(view.schema(), None, max(n, 1), gpu_ctx)
+    skip = [rng.random(n) < 0.3, None, rng.random(n) < 0.5]
+    given = [None if v is None else v.copy() for v in skip]
+    r = bound.DoEvaluate(view, skip)
+    assert r.has_data(), r.exception()
+    _schema, want = oracle.run(ss.Compute(expr(), ss.ScanView(view)), 1 << 20)
+    got = to_cols(r.view())
+    for i, (data, nulls) in enumerate(want):
+        wn = np.zeros(n, dtype=bool) if nulls is None else np.asarray(nulls, dtype=bool).copy()
+        if given[i] is not None:
+            wn |= given[i]
+        gn = np.zeros(n, dtype=bool) if got[i][1] is None else np.asarray(got[i][1], dtype=bool)
+        assert np.array_equal(gn, wn), "attribute %d: NULLs" % i
+        keep = ~wn
+        assert np.array_equal(np.asarray(got[i][0])[keep], np.asarray(data)[keep]), "attribute %d: values" % i
+        if skip[i] is not None:
+            assert np.array_equal(skip[i], wn), "attribute %d: the vector on return" % i
+
+
+def test_do_evaluate_does_not_fail_on_skipped_rows(gpu_ctx):
+    """A signalling division by zero fails the evaluation (expression.cc:57-76) -- unless every offending row is skipped."""
+    n = 5000
+    schema = ss.TupleSchema([ss.Attribute("a", ss.INT64), ss.Attribute("b", ss.INT64)])
+    b = np.ones(n, dtype=np.int64)
+    bad = np.zeros(n, dtype=bool)
+    bad[[7, 1234, 4999]] = True
+    b[bad] = 0
+    view = ss.View(schema, [np.arange(n, dtype=np.int64), b])
+    bound = ss.DivideSignaling(NA("a"), NA("b")).Bind(schema, None, n, gpu_ctx)
+    r = bound.Evaluate(view)
+    assert r.is_failure() and r.exception().return_code == L.ERROR_EVALUATION_ERROR
+    skip = [bad.copy()]
+    r = bound.DoEvaluate(view, skip)
+    assert r.has_data(), r.exception()
+    data, nulls = to_cols(r.view())[0]
+    assert np.array_equal(np.asarray(nulls, dtype=bool), bad)
+    assert np.array_equal(np.asarray(data)[~bad], np.arange(n)[~bad])
+    r = bound.DoEvaluate(view, [np.zeros(n, dtype=bool)])         # nothing skipped: the failure is back
+    assert r.is_failure() and r.exception().return_code == L.ERROR_EVALUATION_ERROR
+    r = bound.DoEvaluate(view, [None, None])                       # one vector per attribute
+    assert r.is_failure() and r.exception().return_code == L.ERROR_ATTRIBUTE_COUNT_MISMATCH
+
+
 def test_evaluate_reuses_the_bound_tree_over_many_views(gpu_ctx):
     # a bound tree is evaluated block after block (what ComputeCursor::Next does, compute.cc:74-90)
     bound = EXPRESSIONS["compound"]().Bind(table(1).schema(), None, 4096, gpu_ctx)
