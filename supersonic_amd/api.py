@@ -1425,8 +1425,9 @@ class Plan(object):
             raise SupersonicException(L.ERROR_HIP, self.ctx.last_error())
         return int(rows)
 
-    def fetch(self, res=None):
-        """Copy the result to host: a View over numpy arrays."""
+    def fetch(self, res=None, nulls_of_result=False):
+        """Copy the result to host: a View over numpy arrays.  nulls_of_result: a column has a NULL mask when the RESULT has one (a
+        result of another plan with this plan's columns: DoEvaluate's skip form makes every column NULLABLE)."""
         res = res or self._result
         rows = self.lib.ssgpu_result_row_count(res)
         if rows < 0:
@@ -1439,7 +1440,7 @@ class Plan(object):
             dt = np.dtype(np.int32 if a.type() == STRING else _NP[a.type()])
             data = np.frombuffer(C.string_at(dp, rows * dt.itemsize), dtype=dt).copy() if rows else np.zeros(0, dt)
             nulls = None
-            if a.is_nullable():
+            if a.is_nullable() or (nulls_of_result and npn.value):
                 nulls = (np.frombuffer(C.string_at(npn, rows), dtype=np.uint8).copy() != 0) if rows else np.zeros(0, bool)
             if a.type() == STRING:
                 own = self.lib.ssgpu_result_column_dict(res, i)      # a CONCAT column: codes of the result's own dictionary
@@ -1633,7 +1634,7 @@ class BoundExpressionTree(Plan):
                 res = C.c_void_p()
                 self.ctx.check(self.lib.ssgpu_expr_evaluate_skip(self.handle, cols, n, rows, ptrs, n_out, C.byref(res)))
                 self._result = res
-                out = self.fetch(res)
+                out = self.fetch(res, nulls_of_result=True)
             finally:
                 if blk is not None:
                     self.ctx.synchronize()
