@@ -3544,10 +3544,11 @@ static int stream_job_prepare(ssgpu_plan* p, int* kind_out, bool for_run = true)
 // one staged chunk (device columns, `n` rows, the chunk's first row id `base`) through the head plan; its result rows join the accumulation
 static int stream_job_chunk(ssgpu_plan* p, const ssgpu_column* dev, int32_t n_cols, int64_t n, int64_t base) {
   ssgpu_ctx* c = p->ctx; ssgpu_plan::StreamJob& J = *p->stream_job; ssgpu_plan* h = J.head;
+  if (h != p && p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }   // (Cursor::Interrupt reaches the plan the caller holds; the derived plans run on its behalf)
   int rc = run_plan(h, dev, n_cols, n, base, false);
   if (rc == SSGPU_OK) rc = settle_plan(h);
   if (rc == SSGPU_OK) rc = check_error_flags(h);
-  if (rc != SSGPU_OK) { if (h != p && h->ctx == c) {} return rc; }
+  if (rc != SSGPU_OK) return rc;
   if (h->nan_seen && J.kind == 3) {
     // a NaN met by a floating MIN / MAX: the reference keeps it when it is the group's FIRST value (aggregation_operators.h:189-228), which
     // per-chunk partial results cannot tell apart from a later one
@@ -3593,6 +3594,7 @@ static int stream_job_chunk(ssgpu_plan* p, const ssgpu_column* dev, int32_t n_co
 static int stream_job_finish(ssgpu_plan* p, ssgpu_result** out) {
   ssgpu_ctx* c = p->ctx; ssgpu_plan::StreamJob& J = *p->stream_job;
   if (J.kind == 3) {
+    if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
     std::vector<ssgpu_column> cols(J.acc_data.size());
     StageExec& hx = J.head->exec.back();
     for (size_t i = 0; i < cols.size(); ++i) { cols[i].data = J.acc_data[i].p; cols[i].is_null = hx.out[i].nullable ? J.acc_nulls[i].as<uint8_t>() : nullptr; }
