@@ -189,6 +189,7 @@ __global__ __launch_bounds__(NT) void ssgpu_part_scatter_plain_kernel(const Plai
     //   [A] gbase <- the reservations issued one trip ago | barrier | stage(k), rank(k + 1) <- the columns loaded one trip ago
     //   [B] barrier | scan + reserve(k + 1) (atomics issued, not waited for), load(k + 2), flush(k)
     // Two counter arrays alternate (rank(k + 1) runs while tile k's counts are being cleared); two barriers per tile instead of three.
+    if (n == 0) return;     // (the loads below are unconditional on a row that exists: row 0)
     constexpr u32 NK = kPsNKeys ? kPsNKeys : 1u, NQ = kPsNPreds ? kPsNPreds : 1u, RES = THREADS - 64u, NGB = (kPsNParts + RES - 1u) / RES;
     u32* const cnt_a = cnt; u32* const cnt_b = reinterpret_cast<u32*>(stage + (size_t)T * rb);
     for (u32 i = t; i < NP; i += THREADS) cnt_b[i] = 0u;

@@ -1234,6 +1234,14 @@ __device__ __forceinline__ void group_extract_slot(const GroupExtractParams& P, 
 #ifndef SSGPU_RESIDENT_ROWS
 #define SSGPU_RESIDENT_ROWS 2   /* (4 and 8 measured the same: the kernel is bound by instruction issue, ~350 VALU instructions per row) */
 #endif
+#ifndef SSGPU_PART_NT
+#define SSGPU_PART_NT 0         /* 1: partition records are read with non-temporal loads (read once; A/B through SSGPU_RTC_FLAGS) */
+#endif
+#if SSGPU_PART_NT
+#define PART_LD(p) __builtin_nontemporal_load(p)
+#else
+#define PART_LD(p) (*(p))
+#endif
 #ifndef SSGPU_PART_ROWS
 #define SSGPU_PART_ROWS 2       /* records per lane per step of the record form (4: measured the same, profiles/r06_part_rows.txt) */
 #endif
@@ -1597,7 +1605,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         while (i >= segoff[seg + 1u]) ++seg;
         const u64* rp = recs + ((u64)seg * seg_step + (i - segoff[seg])) * W;
 #pragma unroll
-        for (int w = 0; w < MAXW; ++w) pre[j][w] = (u32)w < W ? rp[w] : 0ull;
+        for (int w = 0; w < MAXW; ++w) pre[j][w] = (u32)w < W ? PART_LD(rp + w) : 0ull;
       }
     }
     asm volatile("" ::: "memory");     // (the loads stay here: left alone the compiler sinks them to their first use, the top of the next trip)
@@ -1619,7 +1627,7 @@ __device__ __forceinline__ void part_agg_body(const PartAggParams& P, const SRC&
         } else {
         const u64* rp = recs + ri * W;
 #pragma unroll
-        for (int w = 0; w < MAXW; ++w) rec[j][w] = (u32)w < W ? rp[w] : 0ull;
+        for (int w = 0; w < MAXW; ++w) rec[j][w] = (u32)w < W ? PART_LD(rp + w) : 0ull;
         }
       } else {
 #pragma unroll
