@@ -336,6 +336,14 @@ int ssgpu_ctx_synchronize(ssgpu_ctx* ctx);
  *                           a VM program, never as its own kernel), part_n, part_wgs_per_cu, part_lds_target, part_agg_lds,
  *                           part_rec_align, lazy_feedback (0 = a GroupAggregate reads its overflow / feedback words at the end of EVERY run --
  *                           one stream synchronise per run -- instead of leaving them to the next touch of the result; see ssgpu_plan_run)
+ *                           plain partition scatter (ABI 10): pscat_pipe (0 = the tile-after-tile loop instead of the software pipeline of the
+ *                           specialised build), pscat_threads / pscat_rows / pscat_wgs (launch shape: 512 / 1024 threads, rows per thread,
+ *                           workgroups per CU; 0 = 1024 x 2 x 1), part_split (1 = dense partitions' records as payload words + 16-bit table
+ *                           entries), part_prefetch (0 = the partition aggregation loads its records in the trip that uses them),
+ *                           part_overlap / part_overlap_rows (> 1: a dense run over at least that many rows takes its input in that many
+ *                           row ranges, range k aggregated on a side stream beside the scatter of range k + 1; measured slower, default 1)
+ *   ScalarAggregate:        fuse_emit (0 = the result row is emitted by a launch of its own instead of the finish launch)
+ *   results:                out_arena (0 = one allocation per column of a stage's large result instead of one arena with skewed bases)
  *   stage hand-off:         async_handoff (0 = the row count of every intermediate result is read on the host before the next stage is launched;
  *                           default 1: a filter-less Compute / Project stage takes it from the device, no stream synchronise in between)
  *   Sort:                   sort_records (0 = gather payload column by column), sort_hybrid (0 = all eight digits),

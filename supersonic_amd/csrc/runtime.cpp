@@ -427,6 +427,8 @@ struct ssgpu_plan {
     ssgpu_plan* head = nullptr; ssgpu_plan* tail = nullptr;     // kind 3: owned; kind 2: head == the plan itself
     std::vector<DevBuf> acc_data, acc_nulls;                    // the appended rows, one buffer per result column of `head`
     int64_t acc_rows = 0, acc_cap = 0;
+    int64_t rows_hint = 0;      // ssgpu_plan_run_host, kind 2: the input's row count -- what a row-local plan returns at most; the first allocation
+                                // of the accumulation takes it (when a quarter of the free device memory holds it) instead of growing by doubling
   };
   StreamJob* stream_job = nullptr;
   ssgpu_plan* skip_plan = nullptr;   // a bound expression's node-level form (ssgpu_expr_evaluate_skip): the same tree under IF($skip_i, NULL, e_i), made on first use
@@ -3567,7 +3569,13 @@ static int stream_job_chunk(ssgpu_plan* p, const ssgpu_column* dev, int32_t n_co
   }
   if (J.acc_rows + rows > J.acc_cap) {      // grow: twice what is needed, the rows so far move over
     QuotaScope quota_scope(&p->quota);
-    const int64_t cap = std::max<int64_t>((J.acc_rows + rows) * 2, 1 << 16);
+    int64_t cap = std::max<int64_t>((J.acc_rows + rows) * 2, 1 << 16);
+    if (J.kind == 2 && J.rows_hint > cap) {
+      size_t row_bytes = 0, free_b = 0, total_b = 0;
+      for (size_t i = 0; i < nc; ++i) row_bytes += ex.out[i].width + (ex.out[i].nullable ? 1u : 0u);
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)J.rows_hint * row_bytes <= free_b / 4) cap = J.rows_hint;
+      else (void)hipGetLastError();
+    }
     for (size_t i = 0; i < nc; ++i) {
       DevBuf bigger;
       if (bigger.ensure((size_t)cap * ex.out[i].width + 16) != hipSuccess) { (void)hipGetLastError(); c->err = "chunked execution: the accumulated result does not fit the device"; return SSGPU_ERROR_MEMORY_EXCEEDED; }
@@ -3642,6 +3650,7 @@ int ssgpu_plan_run_host(ssgpu_plan* p, const ssgpu_column* host_cols, int32_t n_
   HIP_TRY(c, hipSetDevice(c->device));
   int job_kind = 0;
   { const int jrc = stream_job_prepare(p, &job_kind); if (jrc != SSGPU_OK) return jrc; }
+  if (p->stream_job) p->stream_job->rows_hint = rows;
   if (chunk_rows <= 0) chunk_rows = 1 << 24;
   const int64_t n_chunks = std::max<int64_t>(1, (rows + chunk_rows - 1) / chunk_rows);
   const Schema& schema = p->desc.input_schema;
@@ -3778,6 +3787,7 @@ int ssgpu_plan_stream_begin(ssgpu_plan* p, int64_t chunk_rows) {
   ssgpu_plan::HostStream& hs = p->host_stream;
   if (hs.open) (void)stream_abort(p, SSGPU_OK);     // (an unfinished stream is dropped)
   { int kind = 0; const int jrc = stream_job_prepare(p, &kind); if (jrc != SSGPU_OK) return jrc; hs.kind = kind; }
+  if (p->stream_job) p->stream_job->rows_hint = 0;      // (a pushed stream's length is not known)
   hs.chunk_rows = chunk_rows > 0 ? chunk_rows : (1 << 22); hs.fill = 0; hs.pushed = 0; hs.chunks = 0; hs.cur = 0; hs.rc = SSGPU_OK;
   for (int b = 0; b < 2; ++b) {
     p->host_stage_data[b].resize(schema.size()); p->host_stage_nulls[b].resize(schema.size());
