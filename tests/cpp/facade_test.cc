@@ -558,13 +558,74 @@ static void TestHostStaging() {
   CHECK_EQ(sa[1], want_sa);
 }
 
+// The other chunked forms through the facade (ssgpu.h "CHUNKED STAGING" 2 and 3): a materialising Filter appends every chunk's rows, a
+// GroupAggregate leaves a partial table per chunk and is merged once -- both must give what the whole-block path gives
+static void TestHostStagingOtherForms() {
+  const rowcount_t n = 120007;
+  TupleSchema schema;
+  schema.add_attribute(Attribute("k", INT32, NOT_NULLABLE));
+  schema.add_attribute(Attribute("a", INT64, NOT_NULLABLE));
+  schema.add_attribute(Attribute("x", DOUBLE, NULLABLE));
+  std::vector<int32_t> k(n); std::vector<int64_t> a(n); std::vector<double> x(n); std::vector<char> xn(n);
+  for (rowcount_t i = 0; i < n; ++i) { k[i] = static_cast<int32_t>((i * 31) % 977); a[i] = static_cast<int64_t>((i * 7919) % 1000); x[i] = 0.25 * static_cast<double>(i % 4001) - 300.0; xn[i] = (i % 11) == 0; }
+  View v(schema);
+  v.mutable_column(0)->Reset(k.data(), nullptr); v.mutable_column(1)->Reset(a.data(), nullptr);
+  v.mutable_column(2)->Reset(x.data(), reinterpret_cast<const bool*>(xn.data())); v.set_row_count(n);
+  // form 3: per key SUM(a), COUNT(x), SUM(x), MAX(x) -- summed over the keys (the result's row order is unspecified)
+  int64_t sum_a[2] = {0, 0}; uint64_t cnt_x[2] = {0, 0}; double sum_x[2] = {0, 0}, max_x[2] = {0, 0}; rowcount_t groups[2] = {0, 0};
+  // form 2: the rows of Filter(a > 499), in input order -- a running checksum that depends on the order
+  uint64_t checksum[2] = {0, 0}; rowcount_t kept[2] = {0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    SetHostStagingChunkRows(pass == 0 ? 0 : 5000);
+    {
+      std::unique_ptr<Operation> op(GroupAggregate(ProjectNamedAttribute("k"),
+                                                   (new AggregationSpecification)->AddAggregation(SUM, "a", "sa")->AddAggregation(COUNT, "x", "cx")
+                                                       ->AddAggregation(SUM, "x", "sx")->AddAggregation(MAX, "x", "mx"),
+                                                   nullptr, Filter(Greater(NamedAttribute("a"), ConstInt64(99)), ProjectAllAttributes(), ScanView(v))));
+      FailureOrOwned<Cursor> c = op->CreateCursor();
+      CHECK(c.is_success());
+      if (c.is_success())
+        for (;;) {
+          ResultView r = c->Next(Cursor::kDefaultRowCount);
+          if (!r.has_data()) { CHECK(r.is_eos()); break; }
+          for (rowcount_t i = 0; i < r.view().row_count(); ++i) {
+            sum_a[pass] += r.view().column(1).typed_data<int64_t>()[i]; cnt_x[pass] += r.view().column(2).typed_data<uint64_t>()[i];
+            if (!r.view().column(3).is_null() || !r.view().column(3).is_null()[i]) sum_x[pass] += r.view().column(3).typed_data<double>()[i];
+            if (!r.view().column(4).is_null() || !r.view().column(4).is_null()[i]) max_x[pass] = std::max(max_x[pass], r.view().column(4).typed_data<double>()[i]);
+          }
+          groups[pass] += r.view().row_count();
+        }
+    }
+    {
+      std::unique_ptr<Operation> op(Filter(Greater(NamedAttribute("a"), ConstInt64(499)), ProjectAllAttributes(), ScanView(v)));
+      FailureOrOwned<Cursor> c = op->CreateCursor();
+      CHECK(c.is_success());
+      if (c.is_success())
+        for (;;) {
+          ResultView r = c->Next(Cursor::kDefaultRowCount);
+          if (!r.has_data()) { CHECK(r.is_eos()); break; }
+          for (rowcount_t i = 0; i < r.view().row_count(); ++i)
+            checksum[pass] = checksum[pass] * 1000003ull + static_cast<uint64_t>(r.view().column(0).typed_data<int32_t>()[i]) * 31ull + static_cast<uint64_t>(r.view().column(1).typed_data<int64_t>()[i]);
+          kept[pass] += r.view().row_count();
+        }
+    }
+  }
+  SetHostStagingChunkRows(0);
+  CHECK_EQ(groups[0], static_cast<rowcount_t>(977)); CHECK_EQ(groups[1], groups[0]);
+  CHECK_EQ(sum_a[0], sum_a[1]); CHECK_EQ(cnt_x[0], cnt_x[1]); CHECK(sum_x[0] == sum_x[1]); CHECK(max_x[0] == max_x[1]);
+  CHECK_EQ(kept[0], kept[1]); CHECK_EQ(checksum[0], checksum[1]);
+  int64_t want = 0; rowcount_t want_kept = 0;
+  for (rowcount_t i = 0; i < n; ++i) { if (a[i] > 99) want += a[i]; if (a[i] > 499) ++want_kept; }
+  CHECK_EQ(sum_a[1], want); CHECK_EQ(kept[1], want_kept);
+}
+
 int main(int argc, char** argv) {
   const bool run = argc > 1 && !strcmp(argv[1], "run");
   Input in;
   TestBind(in);
   TestSeamsBind(in);
   TestFileFormat(run);
-  if (run) { TestRun(in); TestSeamsRun(in); TestHostStaging(); }
+  if (run) { TestRun(in); TestSeamsRun(in); TestHostStaging(); TestHostStagingOtherForms(); }
   printf(g_fail ? "FAILED (%d)\n" : "PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }
