@@ -411,14 +411,16 @@ const ssgpu_dict* ssgpu_result_column_dict(ssgpu_result* r, int32_t col);
  * more is ONE device allocation, column i's data starting i x (its 2 MiB-rounded size + 512 bytes) into it and the NULL masks
  * behind the data.  A pipeline reads the same rows of all its columns at once; columns that are allocated one by one start at
  * bases congruent modulo every power of two the allocator aligns to, and those reads meet on the same HBM channels.  Measured on
- * the 8-column headline query: one allocation per column 0.81 of 8 TB/s, one arena 0.83, arena + 512 B of skew 0.865; the
- * materialising Filter 2.33 -> 1.93 ms (profiles/r06_stagger_sweep.txt).  Callers that bring their own device columns
+ * the 8-column headline query, same box, alternating: one allocation per column 0.786 of 8 TB/s, the arena 0.816 - 0.820
+ * (profiles/r06_layout_ab.txt).  Callers that bring their own device columns
  * (ssgpu_plan_run) get what their layout gives; ssgpu_block_create + ssgpu_block_column is how to get this one. */
 int ssgpu_block_create(ssgpu_ctx* ctx, const ssgpu_attr* schema, int32_t n_attrs,
                        int64_t row_capacity, ssgpu_block** out);
 void ssgpu_block_destroy(ssgpu_block* b);
 /* Async H2D on the copy stream; `is_null` may be NULL for NOT_NULLABLE columns.
- * Source should be pinned (ssgpu_host_alloc) for the copy to overlap. */
+ * Source should be pinned (ssgpu_host_alloc) for the copy to overlap.  The next run of ANY plan of the context (ssgpu_plan_run with
+ * ssgpu_block_column's pointers, ssgpu_expr_evaluate, ssgpu_plan_run_block ...) is ordered behind the uploads issued before it: the
+ * caller needs no synchronise between upload and run (ABI 10; until then only ssgpu_plan_run_block waited for them). */
 int ssgpu_block_upload(ssgpu_block* b, int32_t col, const void* host_data,
                        const uint8_t* host_is_null, int64_t row_offset, int64_t rows);
 int ssgpu_block_set_row_count(ssgpu_block* b, int64_t rows);

@@ -1282,6 +1282,7 @@ class Plan(object):
         view = view if view is not None else self.input
         if isinstance(view, DeviceView):
             raise SupersonicException(ERROR_INVALID_ARGUMENT_VALUE, "run_host takes a host View (device columns: run)")
+        self._bind_aux()                         # (a HashJoin's rhs table: device-resident, bound as for run)
         schema = view.schema()
         n = schema.attribute_count()
         cols = (L.Column * max(n, 1))()
@@ -1313,6 +1314,7 @@ class Plan(object):
     def stream(self, views, chunk_rows=0):
         """The push form of chunked staging (ssgpu_plan_stream_begin / _push / _finish): `views` is an iterable of host Views with the
         plan's input schema -- the blocks a child cursor hands out -- each of which may be overwritten as soon as the next is asked for."""
+        self._bind_aux()
         self.ctx.check(self.lib.ssgpu_plan_stream_begin(self.handle, int(chunk_rows)))
         for view in views:
             schema = view.schema()

@@ -41,6 +41,11 @@ struct ssgpu_ctx {
   std::atomic<int> refs{1};
   int device = -1;
   hipStream_t stream = nullptr, copy_stream = nullptr;
+  // ssgpu_block_upload copies on the copy stream; a run that reads the block through raw column pointers (ssgpu_plan_run / ssgpu_expr_evaluate
+  // with ssgpu_block_column's answers, instead of ssgpu_plan_run_block) used to race with those copies -- seen as a wrong Evaluate result
+  // of the C++ facade on a loaded GPU.  Every upload raises the flag; the next run of ANY plan of the context orders its stream behind the copies.
+  std::atomic<bool> copy_pending{false};
+  hipEvent_t copy_ev = nullptr;
   hipStream_t side_stream = nullptr;      // created on first use: the aggregation of one row range of a dense GroupAggregate runs here, beside the scatter of the next
   hipEvent_t side_ev[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool own_stream = false;
@@ -444,8 +449,9 @@ struct ssgpu_block {
   // Large blocks are ONE allocation: column i's data starts i x (its 2 MiB-rounded size + kBlockColumnSkew) into it, the NULL masks
   // follow.  A pipeline reads the same rows of all its columns at the same time; columns allocated one by one start at bases that are
   // congruent modulo every power of two the allocator aligns to, which puts those reads on the same HBM channels.  Measured on the
-  // headline query (8 columns x 800 MB): one allocation per column 0.81 of 8 TB/s, one arena 0.83, arena + 512 B of skew per column
-  // 0.865; the materialising Filter 2.33 -> 2.02 -> 1.93 ms (profiles/r06_stagger_sweep.txt).  `data` / `nulls` are views into it.
+  // headline query (8 columns x 800 MB), same box, alternating: one allocation per column 0.786 of 8 TB/s, this layout 0.816 - 0.820
+  // (profiles/r06_layout_ab.txt; the single-process skew sweep r06_stagger_sweep.txt is within process-to-process noise).  `data` /
+  // `nulls` are views into it.
   DevBuf arena;
   std::vector<DevBuf> data, nulls;
 };
@@ -495,6 +501,7 @@ static void ctx_release(ssgpu_ctx* c) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->copy_ev) { (void)hipEventDestroy(c->copy_ev); c->copy_ev = nullptr; }
     for (hipEvent_t& e : c->side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (g_device_contexts.fetch_sub(1) == 1) (void)g_pool.trim(-1);   // nobody is left to take a parked block
   }
@@ -773,6 +780,7 @@ int ssgpu_block_upload(ssgpu_block* b, int32_t col, const void* hd, const uint8_
     else HIP_TRY(c, hipMemsetAsync((char*)b->nulls[col].p + off, 0, (size_t)rows, c->copy_stream));
   }
   if (off + rows > b->rows) b->rows = off + rows;
+  c->copy_pending.store(true, std::memory_order_release);
   return SSGPU_OK;
 }
 int ssgpu_block_set_row_count(ssgpu_block* b, int64_t rows) {
@@ -2869,6 +2877,14 @@ int check_error_flags(ssgpu_plan* p) {
   return SSGPU_OK;
 }
 
+// block uploads since the last run (ssgpu_ctx::copy_pending): whatever is launched on the compute stream from here on comes after them
+static int order_after_uploads(ssgpu_ctx* c) {
+  if (!c->copy_pending.exchange(false, std::memory_order_acq_rel)) return SSGPU_OK;
+  if (!c->copy_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->copy_ev, c->copy_stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
+  return SSGPU_OK;
+}
 int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t rows, int64_t row_id_base, bool partial);
 
 // Looks at run feedback that was left on the stream (StageExec::fb_pending).  A run that overflowed a table or a segment
@@ -2944,6 +2960,7 @@ int run_plan(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_cols, int64_t ro
   if (p->interrupted.exchange(0)) { c->err = "interrupted"; return SSGPU_INTERRUPTED; }
   QuotaScope quota_scope(&p->quota);
   HIP_TRY(c, hipSetDevice(c->device));
+  { const int orc = order_after_uploads(c); if (orc != SSGPU_OK) return orc; }
   // blocks are staged on the copy stream: kernels must wait for those copies
   memset(&p->counters, 0, sizeof(p->counters));
   p->counters.rows_in = rows;
@@ -3881,6 +3898,8 @@ int ssgpu_plan_key_ranges(ssgpu_plan* p, const ssgpu_column* cols, int32_t n_col
   HIP_TRY(c, hipSetDevice(c->device));
   InCols in; in.cols.assign(cols, cols + n_cols); in.rows = rows;
   StageExec& ex = p->exec[0];
+  rc = order_after_uploads(c);
+  if (rc != SSGPU_OK) return rc;
   rc = dense_find_ranges(p, p->stages[0], ex, in);
   if (rc != SSGPU_OK) return rc;
   *n_keys = (int32_t)ex.dense.n_keys;
