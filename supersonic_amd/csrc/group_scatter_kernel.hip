@@ -121,6 +121,14 @@ __device__ __forceinline__ bool pscat_pred(const void* data, const u8* nulls, u6
   return r && !is_null;
 }
 
+#ifndef PS_PAIR_LOADS
+#define PS_PAIR_LOADS 0     /* 1: the pipelined form with two rows per thread loads pairs of consecutive rows (A/B: profiles/r06_pair_loads.txt) */
+#endif
+#if PS_PAIR_LOADS
+#define PS_ROW(base, j, t) ((R) == 2 ? (base) + 2ull * (t) + (u64)(j) : (base) + (u64)(j) * THREADS + (t))
+#else
+#define PS_ROW(base, j, t) ((base) + (u64)(j) * THREADS + (t))
+#endif
 #ifdef SSGPU_RTC_PSCAT
 // the same predicate on a value that is already in a register (the pipelined form loads a tile's columns one tile ahead)
 __device__ __forceinline__ bool pscat_pred_value(u64 raw, bool is_null, u64 c, u32 kind, u32 cmp, bool col_on_left) {
@@ -197,9 +205,43 @@ __global__ __launch_bounds__(NT) void ssgpu_part_scatter_plain_kernel(const Plai
     struct St { u64 key[R]; u32 pt[R], pos[R]; bool ok[R]; u64 fv[R][REGF]; };
     auto issue = [&](u64 tile, Raw& W) {
       const u64 base = tile * T;
+#if PS_PAIR_LOADS
+      // (-DPS_PAIR_LOADS=1, two rows per thread) a thread takes two CONSECUTIVE rows of the tile, so that an 8-byte column leaves
+      // memory as 16 bytes per lane and a 4-byte one as 8; which rows of a tile a thread holds is immaterial to everything downstream
+      if constexpr (R == 2) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+        const u64 row0 = base + 2ull * t;
+        const bool both = tile < n_tiles && row0 + 1ull < n;
+        if (both) {
+          W.in[0] = W.in[1] = true;
+#pragma unroll
+          for (u32 q = 0; q < kPsNPreds; ++q) {
+            const u32 pw = kPsPredKind[q] == 6u ? 1u : (kPsPredKind[q] == 0u || kPsPredKind[q] == 1u || kPsPredKind[q] == 4u) ? 4u : 8u;
+            if (pw == 8u) { const u64x2 v = *reinterpret_cast<const u64x2*>(reinterpret_cast<const u64*>(P.preds[q].data) + row0); W.p[0][q] = v.x; W.p[1][q] = v.y; }
+            else if (pw == 4u) { const u32x2 v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const u32*>(P.preds[q].data) + row0); W.p[0][q] = v.x; W.p[1][q] = v.y; }
+            else { W.p[0][q] = reinterpret_cast<const u8*>(P.preds[q].data)[row0]; W.p[1][q] = reinterpret_cast<const u8*>(P.preds[q].data)[row0 + 1]; }
+            W.pn[0][q] = P.preds[q].nulls ? (u32)P.preds[q].nulls[row0] : 0u; W.pn[1][q] = P.preds[q].nulls ? (u32)P.preds[q].nulls[row0 + 1] : 0u;
+          }
+#pragma unroll
+          for (u32 k = 0; k < kPsNKeys; ++k) {
+            if (kPsKeyWidth[k] == 8u) { const u64x2 v = *reinterpret_cast<const u64x2*>(reinterpret_cast<const u64*>(P.keys[k].data) + row0); W.k[0][k] = v.x; W.k[1][k] = v.y; }
+            else if (kPsKeyWidth[k] == 4u) { const u32x2 v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const u32*>(P.keys[k].data) + row0); W.k[0][k] = v.x; W.k[1][k] = v.y; }
+            else { W.k[0][k] = reinterpret_cast<const u8*>(P.keys[k].data)[row0]; W.k[1][k] = reinterpret_cast<const u8*>(P.keys[k].data)[row0 + 1]; }
+            W.kn[0][k] = P.keys[k].nulls ? (u32)P.keys[k].nulls[row0] : 0u; W.kn[1][k] = P.keys[k].nulls ? (u32)P.keys[k].nulls[row0 + 1] : 0u;
+          }
+#pragma unroll
+          for (u32 f = 0; f < REGF; ++f) {
+            if (f < nf && PS_FIELD_WIDTH(f < nf ? f : 0u) == 8u && P.fields[f].src) { const u64x2 v = *reinterpret_cast<const u64x2*>(reinterpret_cast<const u64*>(P.fields[f].src) + row0); W.f[0][f] = v.x; W.f[1][f] = v.y; }
+            else { W.f[0][f] = 0ull; W.f[1][f] = 0ull; }
+          }
+          return;
+        }
+      }
+#endif
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const u64 row = base + (u64)j * THREADS + t;
+        const u64 row = PS_ROW(base, j, t);
         W.in[j] = tile < n_tiles && row < n;
         const u64 rowc = W.in[j] ? row : 0ull;     // (unconditional loads, on a row that exists)
 #pragma unroll
@@ -296,7 +338,7 @@ __global__ __launch_bounds__(NT) void ssgpu_part_scatter_plain_kernel(const Plai
       const u64 base = tile * T;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const u64 row = base + (u64)j * THREADS + t;
+        const u64 row = PS_ROW(base, j, t);
         const bool ok = cur.ok[j];
         const u64 rowc = ok ? row : 0ull;
         const u32 pt = cur.pt[j];
