@@ -619,9 +619,10 @@ int ssgpu_plan_run_block(ssgpu_plan* plan, const ssgpu_block* block, ssgpu_resul
  *      shape its run feedback picks, DOUBLE sums with their SSGPU_SUM_RESIDUAL -- and leaves a partial table; the partial tables are
  *      appended, and at the end ONE second plan runs over them: GroupAggregate of the merge functions (COUNT merges as SUM, FIRST /
  *      LAST in chunk = row order) -> Compute restoring the first one's schema -> the operations above it (Sort, Compute, ...).
- *      DISTINCT / CONCAT aggregates and the row-after-row SUM of a floating column into an integer are not partial results, and a NaN
- *      reaching a floating MIN / MAX is order-dependent in the reference: SSGPU_ERROR_NOT_IMPLEMENTED (bind time resp. the chunk that
- *      meets it) -- those run over device columns.  Device memory: the staging sets + (groups met per chunk) x chunks partial rows.
+ *      A floating MIN / MAX keeps a NaN that is the group's FIRST value (aggregation_operators.h:189-228): the first value travels as a
+ *      hidden FIRST next to the NaN-skipping partial result and the merged one is IF(IS_NAN(first), first, min).  DISTINCT / CONCAT
+ *      aggregates and the row-after-row SUM of a floating column into an integer are not partial results: SSGPU_ERROR_NOT_IMPLEMENTED
+ *      at bind time -- those run over device columns.  Device memory: the staging sets + (groups met per chunk) x chunks partial rows.
  * Everything else (Sort / AggregateClusters / key-limited GroupAggregate as the first blocking operation): SSGPU_ERROR_NOT_IMPLEMENTED. */
 int ssgpu_plan_run_host(ssgpu_plan* plan, const ssgpu_column* host_cols, int32_t n_cols, int64_t rows, int64_t chunk_rows, ssgpu_result** out);
 /* The PUSH form of the same, for a caller that meets its input the way the reference's cursors do -- a child's Next() handing out

@@ -816,6 +816,12 @@ static int plan_finish_create(ssgpu_ctx* c, ssgpu_plan* p, Status s, ssgpu_plan*
     if (!st.main.empty() && layout_program(st.main, o).lds_bytes > 160u * 1024u) {
       delete p; c->err = "expression needs more than 160 KiB of LDS per tile"; return SSGPU_ERROR_NOT_IMPLEMENTED;
     }
+    // ... and the columns (and NULL masks) a program stages must fit the kernel's argument block.  (Until round 6 nothing looked: a Compute
+    // over 26 NULLABLE columns -- 52 staged arrays against 48 slots -- wrote past VmParams::staged and returned wrong first / last columns.)
+    for (const Program* pr : {&st.main, &st.count_pass, &st.part_scatter})
+      if (pr->staged.size() > (size_t)VM_MAX_STAGED) {
+        delete p; c->err = "a pipeline reads more than " + std::to_string(VM_MAX_STAGED) + " input arrays (columns + NULL masks)"; return SSGPU_ERROR_NOT_IMPLEMENTED;
+      }
   }
   p->exec.resize(p->stages.size());
   for (auto& st : p->stages) if (st.kind == STAGE_FOLD_TAIL && st.fold_cut) { p->best_effort = true; p->be_capacity = st.fold_limit > 0 ? st.fold_limit : INT64_MAX; }
@@ -3398,7 +3404,7 @@ static int stream_job_build_group(ssgpu_plan* p, int iB, ssgpu_plan** head_out, 
   std::deque<std::string> names;
   std::vector<ssgpu_agg> haggs(D.aggs.begin(), D.aggs.end());
   const size_t hfirst = haggs.size();
-  enum { COL_RESIDUAL = 1000 };
+  enum { COL_RESIDUAL = 1000, COL_FIRST = 1001 };
   std::vector<int> col_fn;                      // per aggregate column of the head's result: its aggregation, or COL_RESIDUAL
   for (int j = 0; j < B.agg_n; ++j) {
     const ssgpu_agg a = D.aggs[(size_t)(B.agg_first + j)];
@@ -3413,6 +3419,15 @@ static int stream_job_build_group(ssgpu_plan* p, int iB, ssgpu_plan** head_out, 
       c->err = "chunked execution: SUM of a floating input into an integer result is a row-after-row fold, not a partial result"; return SSGPU_ERROR_NOT_IMPLEMENTED;
     }
     haggs.push_back(a); col_fn.push_back(a.aggregation);
+    if ((a.aggregation == SSGPU_MIN || a.aggregation == SSGPU_MAX) && (in_type == SSGPU_FLOAT || in_type == SSGPU_DOUBLE)) {
+      // a NaN that is a group's FIRST value stays its MIN / MAX in the reference (aggregation_operators.h:189-228); the kernels skip NaNs,
+      // so the group's first value travels next to the partial result and the merged one becomes IF(IS_NAN(first), first, min) -- the
+      // plan's own NaN-exact form (lower.cpp), spelled out over the chunks
+      names.push_back(std::string(a.output ? a.output : "") + "$first");
+      ssgpu_agg r; memset(&r, 0, sizeof(r));
+      r.aggregation = SSGPU_FIRST; r.output_type = -1; r.input = a.input; r.output = names.back().c_str();
+      haggs.push_back(r); col_fn.push_back(COL_FIRST);
+    }
     if (a.aggregation == SSGPU_SUM && in_type == SSGPU_DOUBLE && (a.output_type == -1 || a.output_type == SSGPU_DOUBLE)) {
       names.push_back(std::string(a.output ? a.output : "") + "$res");
       ssgpu_agg r; memset(&r, 0, sizeof(r));
@@ -3443,7 +3458,7 @@ static int stream_job_build_group(ssgpu_plan* p, int iB, ssgpu_plan** head_out, 
   const int32_t ma_first = (int32_t)taggs.size();
   for (size_t j = 0; j < col_fn.size(); ++j) {
     ssgpu_agg m; memset(&m, 0, sizeof(m));
-    m.aggregation = (col_fn[j] == SSGPU_COUNT || col_fn[j] == COL_RESIDUAL) ? SSGPU_SUM : col_fn[j];
+    m.aggregation = (col_fn[j] == SSGPU_COUNT || col_fn[j] == COL_RESIDUAL) ? SSGPU_SUM : col_fn[j] == COL_FIRST ? SSGPU_FIRST : col_fn[j];
     m.output_type = -1; m.input = hs[nk + j].name.c_str(); m.output = hs[nk + j].name.c_str();
     taggs.push_back(m);
   }
@@ -3458,8 +3473,16 @@ static int stream_job_build_group(ssgpu_plan* p, int iB, ssgpu_plan** head_out, 
   for (size_t k = 0; k < nk; ++k) outs.push_back(add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, hs[k].name.c_str(), {}));
   for (size_t j = 0; j < col_fn.size(); ++j) {
     const char* nm = hs[nk + j].name.c_str();
-    if (col_fn[j] == COL_RESIDUAL) continue;
+    if (col_fn[j] == COL_RESIDUAL || col_fn[j] == COL_FIRST) continue;
     const int32_t self = add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, nm, {});
+    if (j + 1 < col_fn.size() && col_fn[j + 1] == COL_FIRST) {
+      const char* fn = hs[nk + j + 1].name.c_str();
+      const int32_t f1 = add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, fn, {}), f2 = add_expr(SSGPU_EXPR_ATTR_NAMED, 0, 0, fn, {});
+      const int32_t isnan = add_expr(SSGPU_EXPR_OP, 156 /* OPERATOR_IS_NAN */, 0, "", {f1});
+      const int32_t pick = add_expr(SSGPU_EXPR_OP, 204 /* OPERATOR_IF */, 0, "", {isnan, f2, self});
+      outs.push_back(add_expr(SSGPU_EXPR_ALIAS, 0, 0, nm, {pick}));
+      continue;
+    }
     if (col_fn[j] == SSGPU_COUNT) {
       const int32_t zero = add_expr(SSGPU_EXPR_CONST, 0, hs[nk + j].dtype, "", {}, 0);
       const int32_t ifnull = add_expr(SSGPU_EXPR_OP, 220 /* OPERATOR_IFNULL */, 0, "", {self, zero});
@@ -3568,12 +3591,7 @@ static int stream_job_chunk(ssgpu_plan* p, const ssgpu_column* dev, int32_t n_co
   if (rc == SSGPU_OK) rc = settle_plan(h);
   if (rc == SSGPU_OK) rc = check_error_flags(h);
   if (rc != SSGPU_OK) return rc;
-  if (h->nan_seen && J.kind == 3) {
-    // a NaN met by a floating MIN / MAX: the reference keeps it when it is the group's FIRST value (aggregation_operators.h:189-228), which
-    // per-chunk partial results cannot tell apart from a later one
-    h->nan_seen = false;
-    c->err = "chunked execution: a NaN reached a floating MIN / MAX of the GroupAggregate (order-dependent in the reference); run the plan over device columns"; return SSGPU_ERROR_NOT_IMPLEMENTED;
-  }
+  if (J.kind == 3) h->nan_seen = false;   // (NaNs a floating MIN / MAX skipped: the group's FIRST value travels next to it and the tail decides -- stream_job_build_group)
   if (J.kind == 2) { rc = fix_nan_minmax(h); if (rc != SSGPU_OK) return rc; }
   int64_t rows = 0;
   rc = stage_rows(h, h->exec.size() - 1, &rows);

@@ -49,7 +49,7 @@ enum { VM_MATH_EXP = 1, VM_MATH_LN, VM_MATH_LOG10, VM_MATH_LOG2, VM_MATH_SIN, VM
 #define VM_WAVES (VM_THREADS / 64)       /* waves per workgroup */
 #define VM_TILE_UNIT (2 * VM_THREADS)    /* rows of a K = 1 tile: one row pair per thread */
 #define VM_FAST_SLOTS 8     /* aggregate slots with per-lane register accumulators */
-#define VM_MAX_STAGED 48
+#define VM_MAX_STAGED 80     /* input arrays (columns + NULL masks) one pipeline stages; ssgpu_plan_create refuses more.  VmParams stays under the 4 KiB kernel-argument block */
 #define VM_MAX_OUTPUTS 64
 #define VM_MAX_AGG_SLOTS 64
 #define VM_ACC_STRIDE (VM_WAVES * 32) /* bytes of LDS per aggregate slot: one 32 B record per wave */

@@ -147,3 +147,22 @@ def test_distinct_inside_aggregate_clusters_binds_with_a_segment_id_column():
                                 ss.ScanView(view))
     rs = ss.Plan(both, ss.Context(-1)).result_schema
     assert [(rs.attribute(i).name(), rs.attribute(i).type()) for i in range(rs.attribute_count())] == [("k", ss.INT32), ("s", ss.INT64), ("c", ss.STRING)]
+
+
+def test_a_pipeline_over_more_input_arrays_than_the_kernel_takes_is_refused():
+    """VM_MAX_STAGED (csrc/vm.h) input arrays -- columns and NULL masks -- per pipeline; beyond them ssgpu_plan_create says so instead of
+    writing past the kernel's argument block."""
+    import numpy as np
+    ctx = ss.Context(-1)
+
+    def compute_over(n_in):
+        schema = ss.TupleSchema([ss.Attribute("c%d" % i, ss.INT32, ss.NULLABLE) for i in range(n_in)])     # (narrow columns: the LDS bound comes later)
+        view = ss.View(schema, [ss.Column(np.zeros(3, dtype=np.int32), np.zeros(3, dtype=bool)) for _ in range(n_in)])
+        e = ss.CompoundExpression()
+        for i in range(0, n_in - 1, 2):
+            e.AddAs("s%d" % i, ss.Plus(ss.NamedAttribute("c%d" % i), ss.NamedAttribute("c%d" % (i + 1))))
+        return ss.Plan(ss.Compute(e, ss.ScanView(view)), ctx)
+    compute_over(40)                           # 80 arrays: fits
+    with pytest.raises(ss.SupersonicException) as err:
+        compute_over(42)                       # 84
+    assert err.value.return_code == ss.ERROR_NOT_IMPLEMENTED and "input arrays" in str(err.value)

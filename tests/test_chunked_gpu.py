@@ -166,20 +166,40 @@ def test_config3_plan_over_host_chunks(gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_a_nan_in_a_floating_min_max_is_refused_by_the_chunk_that_meets_it(gpu_ctx):
-    n = 5000
-    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("x", ss.DOUBLE)])
-    x = np.arange(n, dtype=np.float64)
-    x[3100] = np.nan
-    view = ss.View(schema, [np.arange(n, dtype=np.int32) % 7, x])
-    op = ss.GroupAggregate(ss.ProjectNamedAttribute("k"), ss.AggregationSpecification().AddAggregation(ss.MIN, "x", "m"), None, ss.ScanView(view))
-    plan = ss.Plan(op, gpu_ctx)
-    with pytest.raises(ss.SupersonicException) as e:
-        plan.run_host(chunk_rows=1000)
-    assert e.value.return_code == ss.ERROR_NOT_IMPLEMENTED
-    plan.run()                               # over device columns the reference's order-dependent answer is reproduced
+@pytest.mark.parametrize("dtype", ["double", "float"])
+@pytest.mark.parametrize("chunk", [1000, 777, 5000, 0])
+def test_a_nan_that_is_a_groups_first_value_stays_its_min_and_max_across_chunks(gpu_ctx, dtype, chunk):
+    """aggregation_operators.h:189-228: the first non-NULL value is assigned, and `val < result` never replaces a NaN -- so a group whose
+    FIRST value is a NaN keeps it, a NaN met later is skipped.  Per-chunk partial results skip NaNs; the group's first value travels next
+    to them (a hidden FIRST) and the merged result is IF(IS_NAN(first), first, min): the oracle's rows whatever the chunking -- groups
+    that start with a NaN (in the first chunk and in a later one), meet one later, hold nothing but NaNs, or nothing but NULLs."""
+    n, groups = 5000, 9
+    np_t, ss_t = (np.float64, ss.DOUBLE) if dtype == "double" else (np.float32, ss.FLOAT)
+    rng = np.random.default_rng(17)
+    k = (np.arange(n) % groups).astype(np.int32)
+    x = (rng.integers(-1000, 1000, n) * 0.5).astype(np_t)
+    nulls = rng.random(n) < 0.1
+    first_row = {g: int(np.flatnonzero(k == g)[0]) for g in range(groups)}
+    x[first_row[0]] = np.nan; nulls[first_row[0]] = False                    # group 0: starts with a NaN (chunk 0)
+    x[first_row[1]] = np.nan; nulls[first_row[1]] = True                     # group 1: its first row is NULL (the NaN under it does not count) ...
+    x[np.flatnonzero(k == 1)[1]] = np.nan; nulls[np.flatnonzero(k == 1)[1]] = False   # ... and its first non-NULL value is a NaN
+    x[np.flatnonzero(k == 2)[300]] = np.nan; nulls[np.flatnonzero(k == 2)[300]] = False   # group 2: a NaN in a later chunk, not first
+    x[k == 3] = np.nan; nulls[k == 3] = False                                # group 3: nothing but NaNs
+    nulls[k == 4] = True                                                     # group 4: nothing but NULLs
+    g5 = np.flatnonzero(k == 5); nulls[g5[:200]] = True; x[g5[200]] = np.nan; nulls[g5[200]] = False   # group 5: NULLs through the first chunks, then a NaN first
+    schema = ss.TupleSchema([ss.Attribute("k", ss.INT32), ss.Attribute("x", ss_t, ss.NULLABLE)])
+    view = ss.View(schema, [k, ss.Column(x, nulls)])
+    spec = (ss.AggregationSpecification().AddAggregation(ss.MIN, "x", "mn").AddAggregation(ss.MAX, "x", "mx").AddAggregation(ss.COUNT, "x", "c")
+            .AddAggregation(ss.FIRST, "x", "f"))
+    op = ss.GroupAggregate(ss.ProjectNamedAttribute("k"), spec, None, ss.ScanView(view))
     _schema, want = oracle.run(op)
-    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want))
+    plan = ss.Plan(op, gpu_ctx)
+    kind, head, tail = plan.chunked_form()
+    assert kind == 3 and "mn$first" in head and "mx$first" in head, (head, tail)
+    plan.run_host(chunk_rows=chunk)
+    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="NaN-first groups, chunk %d" % chunk)
+    plan.run()
+    assert_cols_equal(sort_rows(to_cols(plan.fetch())), sort_rows(want), context="NaN-first groups, one run")
 
 
 # ---- which plans (no device needed) ------------------------------------------------------------------------------------------------------

@@ -1991,3 +1991,18 @@ def test_concat_aggregate(gpu_ctx, n):
         with pytest.raises(ss.SupersonicException) as e:
             ss.Plan(bad, gpu_ctx)
         assert e.value.return_code == code
+
+
+# ---- wide schemas: every staged array (column or NULL mask) takes a slot of the kernel's argument block ---------------------------------
+@pytest.mark.parametrize("n_in,dtype", [(24, "f8"), (26, "f8"), (32, "f8"), (40, "i4")])
+def test_compute_over_many_nullable_columns(gpu_ctx, n_in, dtype):
+    """26 NULLABLE DOUBLE columns are 52 staged arrays: until round 6 VmParams::staged held 48 and nothing checked -- the first and the last
+    result columns came back wrong (found through the chunked GroupAggregate's merging plan, which reads 26 such columns)."""
+    n = 5003
+    rng = np.random.default_rng(n_in)
+    schema = ss.TupleSchema([ss.Attribute("c%d" % i, ss.DOUBLE if dtype == "f8" else ss.INT32, ss.NULLABLE) for i in range(n_in)])
+    view = ss.View(schema, [ss.Column(rng.integers(-1000, 1000, n).astype(dtype), rng.random(n) < 0.1) for _ in range(n_in)])
+    e = ss.CompoundExpression()
+    for i in range(0, n_in - 1, 2):
+        e.AddAs("s%d" % i, ss.Plus(NA("c%d" % i), NA("c%d" % (i + 1))))
+    run_both(ss.Compute(e, ss.ScanView(view)), gpu_ctx)
