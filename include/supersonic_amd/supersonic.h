@@ -1123,6 +1123,22 @@ class EvaluationResult {
   std::shared_ptr<Exception> exception_;
 };
 
+// One bool array per column, all of one length (base/infrastructure/bit_pointers.h:541-582): the skip vectors of DoEvaluate.
+class BoolView {
+ public:
+  explicit BoolView(size_t column_count) : columns_(column_count, nullptr), rows_(0) {}
+  explicit BoolView(bool_ptr data) : columns_(1, data), rows_(0) {}
+  int column_count() const { return static_cast<int>(columns_.size()); }
+  rowcount_t row_count() const { return rows_; }
+  bool_ptr column(int i) const { return columns_[static_cast<size_t>(i)]; }
+  void ResetColumn(int i, bool_ptr data) { columns_[static_cast<size_t>(i)] = data; }
+  void set_row_count(rowcount_t rows) { rows_ = rows; }
+
+ private:
+  std::vector<bool_ptr> columns_;
+  rowcount_t rows_;
+};
+
 class BoundExpressionTree {
  public:
   ~BoundExpressionTree() { Release(); }
@@ -1155,6 +1171,56 @@ class BoundExpressionTree {
       view_->mutable_column(i)->Reset(host_data_[static_cast<size_t>(i)], reinterpret_cast<const bool*>(host_null_[static_cast<size_t>(i)]));
     view_->set_row_count(total);
     return EvaluationResult::Success(view_.get());
+  }
+  // BoundExpression::DoEvaluate(const View& input, const BoolView& skip_vectors) (expression/base/expression.h:46-92): one skip vector per
+  // result attribute, in and out -- a row whose byte is set is not evaluated (NULL result, no failure of a signalling operator on it); on
+  // return the vector holds the result's NULLs.  A column of the BoolView that is NULL skips nothing (ssgpu_expr_evaluate_skip).
+  EvaluationResult DoEvaluate(const View& input, const BoolView& skip_vectors) {
+    ssgpu_ctx* ctx = internal::Context::Get().ctx;
+    if (internal::Dictionary::HasStrings(input_schema_))
+      return EvaluationResult::Failure(new Exception(ERROR_NOT_IMPLEMENTED, "DoEvaluate over STRING attributes: the dictionary is per View (Evaluate)"));
+    if (skip_vectors.column_count() != schema_.attribute_count())
+      return EvaluationResult::Failure(new Exception(ERROR_ATTRIBUTE_COUNT_MISMATCH, "one skip vector per result attribute"));
+    if (input.row_count() > row_capacity())
+      return EvaluationResult::Failure(new Exception(ERROR_TOO_MANY_ROWS, "Trying to evaluate an expression with more rows than its capacity"));
+    if (block_) { ssgpu_block_destroy(block_); block_ = nullptr; }
+    if (res_) { ssgpu_result_destroy(res_); res_ = nullptr; }
+    const rowcount_t n = input.row_count();
+    int rc = internal::UploadView(ctx, &input, &dict_, &block_);
+    // the caller's vectors as a device block of BOOL columns (only the ones it has)
+    std::vector<int> have;
+    for (int i = 0; i < skip_vectors.column_count(); ++i) if (skip_vectors.column(i)) have.push_back(i);
+    ssgpu_block* sblock = nullptr;
+    std::vector<std::string> names;
+    std::vector<ssgpu_attr> attrs;
+    for (size_t k = 0; k < have.size(); ++k) names.push_back("s" + std::to_string(k));
+    for (size_t k = 0; k < have.size(); ++k) attrs.push_back({names[k].c_str(), BOOL, NOT_NULLABLE});
+    if (rc == SSGPU_OK && !have.empty()) rc = ssgpu_block_create(ctx, attrs.data(), static_cast<int32_t>(attrs.size()), static_cast<int64_t>(std::max<rowcount_t>(n, 1)), &sblock);
+    std::vector<uint8_t*> skip(static_cast<size_t>(skip_vectors.column_count()), nullptr);
+    for (size_t k = 0; rc == SSGPU_OK && k < have.size(); ++k) {
+      if (n > 0) rc = ssgpu_block_upload(sblock, static_cast<int32_t>(k), skip_vectors.column(have[k]), nullptr, 0, static_cast<int64_t>(n));
+      ssgpu_column col;
+      if (rc == SSGPU_OK) rc = ssgpu_block_column(sblock, static_cast<int32_t>(k), &col);
+      if (rc == SSGPU_OK) skip[static_cast<size_t>(have[k])] = static_cast<uint8_t*>(const_cast<void*>(col.data));
+    }
+    std::vector<ssgpu_column> cols(static_cast<size_t>(input_schema_.attribute_count()));
+    for (size_t i = 0; rc == SSGPU_OK && i < cols.size(); ++i) rc = ssgpu_block_column(block_, static_cast<int32_t>(i), &cols[i]);
+    ssgpu_result* res = nullptr;     // (owned by the bound tree's skip form inside the library: not destroyed here)
+    if (rc == SSGPU_OK) rc = ssgpu_expr_evaluate_skip(plan_, cols.data(), static_cast<int32_t>(cols.size()), static_cast<int64_t>(n), skip.data(), static_cast<int32_t>(skip.size()), &res);
+    rowcount_t total = 0;
+    TupleSchema nullable_schema;     // every attribute of the skip form's result is NULLABLE
+    for (int i = 0; i < schema_.attribute_count(); ++i) nullable_schema.add_attribute(Attribute(schema_.attribute(i).name(), schema_.attribute(i).type(), NULLABLE));
+    if (rc == SSGPU_OK) rc = internal::FetchResult(res, nullable_schema, &dict_, &total, &host_data_, &host_null_, &cells_);
+    if (sblock) { if (rc == SSGPU_OK) rc = ssgpu_ctx_synchronize(ctx); else (void)ssgpu_ctx_synchronize(ctx); ssgpu_block_destroy(sblock); }
+    if (rc != SSGPU_OK) return EvaluationResult::Failure(new Exception(rc, ssgpu_last_error(ctx)));
+    if (!skip_view_ || skip_view_->schema().attribute_count() != nullable_schema.attribute_count()) skip_view_.reset(new View(nullable_schema));
+    for (int i = 0; i < nullable_schema.attribute_count(); ++i) {
+      skip_view_->mutable_column(i)->Reset(host_data_[static_cast<size_t>(i)], reinterpret_cast<const bool*>(host_null_[static_cast<size_t>(i)]));
+      if (skip_vectors.column(i) && host_null_[static_cast<size_t>(i)])
+        for (rowcount_t r = 0; r < total; ++r) skip_vectors.column(i)[r] = host_null_[static_cast<size_t>(i)][r] != 0;
+    }
+    skip_view_->set_row_count(total);
+    return EvaluationResult::Success(skip_view_.get());
   }
 
  private:
@@ -1207,6 +1273,7 @@ class BoundExpressionTree {
   ssgpu_result* res_ = nullptr;
   internal::Dictionary dict_;
   std::unique_ptr<View> view_;
+  std::unique_ptr<View> skip_view_;   // DoEvaluate's result: the same attributes, all NULLABLE
   std::vector<const void*> host_data_;
   std::vector<const uint8_t*> host_null_;
   std::vector<std::vector<StringPiece>> cells_;

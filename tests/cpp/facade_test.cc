@@ -352,6 +352,30 @@ static void TestSeamsRun(const Input& in) {
       }
       CHECK(ok);
     }
+    {  // the node-level form: skip vectors in and out (expression.h:46-92)
+      const rowcount_t n = 2000;
+      View slice(in.schema);
+      slice.mutable_column(0)->Reset(in.a.data(), nullptr); slice.mutable_column(1)->Reset(in.b.data(), nullptr);
+      slice.mutable_column(2)->Reset(in.k.data(), nullptr); slice.mutable_column(3)->Reset(in.d.data(), reinterpret_cast<const bool*>(in.d_null.data()));
+      slice.set_row_count(n);
+      std::vector<char> skip0(n), skip1(n);
+      for (rowcount_t i = 0; i < n; ++i) { skip0[i] = (i % 3) == 0; skip1[i] = (i % 5) == 0; }
+      BoolView skips(2);
+      skips.ResetColumn(0, reinterpret_cast<bool*>(skip0.data())); skips.ResetColumn(1, reinterpret_cast<bool*>(skip1.data()));
+      skips.set_row_count(n);
+      EvaluationResult r = t->DoEvaluate(slice, skips);
+      CHECK(r.is_success());
+      if (r.is_success()) {
+        bool ok = r.get().row_count() == n;
+        for (rowcount_t i = 0; i < n && ok; ++i) {
+          const bool s0 = (i % 3) == 0, want1 = (i % 5) == 0 || in.d_null[i] || in.k[i] == 0;
+          ok = r.get().column(0).is_null()[i] == s0 && (s0 || r.get().column(0).typed_data<int64_t>()[i] == in.a[i] + in.b[i] * 3);
+          ok = ok && r.get().column(1).is_null()[i] == want1 && (want1 || r.get().column(1).typed_data<double>()[i] == in.d[i] / in.k[i]);
+          ok = ok && (skip0[i] != 0) == s0 && (skip1[i] != 0) == want1;      // the vectors on return: the result's NULLs
+        }
+        CHECK(ok);
+      }
+    }
     EvaluationResult many = t->Evaluate(*in.view);             // 5000 rows > capacity 2048
     CHECK(many.is_failure());
     if (many.is_failure()) CHECK_EQ(many.exception().return_code(), ERROR_TOO_MANY_ROWS);
