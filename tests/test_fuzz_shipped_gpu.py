@@ -20,7 +20,9 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+# (the corpus runs inside a module fixture: ten minutes of hiprtc on the GPU boxes' 16 cores -- far beyond pytest.ini's per-test timeout,
+#  which exists for hangs, not for this)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(3600)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCALE = float(os.environ.get("SS_FUZZ_SHIPPED_SCALE", "1"))     # 0.1 for a quick look, 10 for a hunt
 
